@@ -1,0 +1,345 @@
+/*
+ * casim.h — C ABI of libcasim: the MI355X-native scale-up simulation engine.
+ *
+ * This header is the drop-in boundary for ONE path of the Cluster Autoscaler
+ * (all `CA/` paths are relative to /root/reference/cluster-autoscaler/, `V/` to its
+ * vendor/k8s.io/):
+ *
+ *   estimator.Estimator.Estimate              CA/estimator/estimator.go:53-56
+ *     -> BinpackingNodeEstimator.Estimate     CA/estimator/binpacking_estimator.go:102-161
+ *   ClusterSnapshot.CheckPredicates           CA/simulator/clustersnapshot/clustersnapshot.go:96
+ *     (batched, as used by SchedulablePodGroups CA/core/scaleup/orchestrator/orchestrator.go:535-570)
+ *   expander.Filter.BestOptions               CA/expander/expander.go:59-62
+ *
+ * A cgo shim binds exactly these entry points:
+ *   - the ENCODER  (casim_enc_*): turns pod / node-template objects (strings) into the flat
+ *     integer + bitmask tables the device consumes.  It replaces the per-call string work
+ *     inside the scheduler Filter plugins (V/kubernetes/pkg/scheduler/framework/plugins/...).
+ *   - the ENGINE   (casim_ctx_*, casim_problem_*): uploads the tables to HBM and runs the
+ *     hand-written HIP kernels for gfx950.
+ *
+ * Conventions: every function returns int32 status (0 = ok, <0 = internal error, never
+ * throws / aborts across the ABI) unless it returns a handle (NULL on failure; see
+ * casim_last_error).  All buffers are caller-owned, read-only for the callee unless named
+ * `out`.  No torch / C++ types appear in any signature.
+ */
+#ifndef CASIM_H_
+#define CASIM_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CASIM_ABI_VERSION 1
+
+/* Resource lanes.  Lane 0 = cpu in millicores (Quantity.MilliValue), lane 1 = memory bytes,
+ * lane 2 = ephemeral-storage bytes, lanes 3.. = scalar / extended resources (Quantity.Value),
+ * mirroring framework.Resource  V/kubernetes/pkg/scheduler/framework/types.go:989-998. */
+#define CASIM_MAX_RES 8
+#define CASIM_RES_CPU 0
+#define CASIM_RES_MEM 1
+#define CASIM_RES_EPHEMERAL 2
+
+/* ---- status codes ------------------------------------------------------------------- */
+#define CASIM_OK 0
+#define CASIM_ERR_INVALID (-1)      /* bad argument / inconsistent table sizes            */
+#define CASIM_ERR_HIP (-2)          /* a HIP runtime call failed (see casim_last_error)   */
+#define CASIM_ERR_NO_DEVICE (-3)    /* no gfx950 device visible: the engine NEVER falls   */
+                                    /* back to a CPU path                                  */
+#define CASIM_ERR_NOMEM (-4)
+/* per node-group status written to casim_results.status                                  */
+#define CASIM_NG_OK 0
+#define CASIM_NG_UNSUPPORTED 1      /* a PEG of this group needs a predicate outside the   */
+                                    /* encoded subset: the shim must delegate this group   */
+                                    /* to the Go estimator (SURVEY §8b "error convention") */
+
+/* ---- PEG flags (casim_pegs.flags) -------------------------------------------------------- */
+#define CASIM_PEG_TOLERATES_UNSCHEDULABLE 0x1u /* tolerates node.kubernetes.io/unschedulable:NoSchedule
+                                                  V/.../nodeunschedulable/node_unschedulable.go:142-160 */
+#define CASIM_PEG_SELF_EXCL_NODE 0x2u  /* at most one pod of this PEG per node: hostname
+                                          self-anti-affinity or a host port it conflicts with itself */
+#define CASIM_PEG_SELF_EXCL_ZONE 0x4u  /* at most one pod of this PEG per node group: required
+                                          anti-affinity to itself on a non-hostname topology key
+                                          (all nodes of a group clone one template)   */
+#define CASIM_PEG_FASTPATH_OK 0x8u     /* shouldUseFastPath  CA/estimator/binpacking_estimator.go:411 */
+#define CASIM_PEG_FASTPATH_AA_SELF 0x10u /* numNodesByAntiAffinity = len(pods)  :444-450      */
+#define CASIM_PEG_UNSUPPORTED 0x20u    /* needs fallback (affinity, topology spread, DRA, ...)   */
+
+/* ---- group flags (casim_groups.flags) ---------------------------------------------------- */
+#define CASIM_NG_UNSCHEDULABLE 0x1u    /* template node.Spec.Unschedulable                       */
+
+/* ---- expander kinds (casim_best_option) -------------------------------------------------- */
+#define CASIM_EXPANDER_LEAST_NODES 0   /* CA/expander/leastnodes/leastnodes.go:35-61 */
+#define CASIM_EXPANDER_LEAST_WASTE 1   /* CA/expander/waste/waste.go:37-73           */
+#define CASIM_EXPANDER_MOST_PODS 2     /* CA/expander/mostpods/mostpods.go:33-53     */
+
+/*
+ * PEG table: one record per PodEquivalenceGroup (CA/estimator/estimator.go:37-48), structure of
+ * arrays.  G records, R resource lanes, mask widths in 64-bit words.
+ */
+typedef struct casim_pegs {
+    int32_t n_pegs;           /* G */
+    int32_t n_res;            /* R, 1..CASIM_MAX_RES */
+    int32_t w_taint;          /* words per toleration mask (taint dictionary)          */
+    int32_t w_label;          /* words per nodeSelector mask (label-requirement dictionary) */
+    int32_t w_excl;           /* words per node-local exclusion mask (ports + hostname anti-affinity) */
+    int32_t w_zone;           /* words per group-wide exclusion mask (non-hostname anti-affinity)      */
+    const int64_t* req;       /* [G][R] pod request per lane  (fit.go:321-331 computePodResourceRequest) */
+    const int32_t* count;     /* [G]    len(peg.Pods)                                   */
+    const uint32_t* flags;    /* [G]    CASIM_PEG_*                                     */
+    const uint64_t* tol_mask; /* [G][w_taint] bit t set: some toleration tolerates taint t (toleration.go:52-77) */
+    const uint64_t* sel_mask; /* [G][w_label] bit l set: the PEG requires label requirement l (nodeaffinity.go:306-333) */
+    const uint64_t* excl_block; /* [G][w_excl] node bits that forbid this PEG on a node  */
+    const uint64_t* excl_mark;  /* [G][w_excl] node bits this PEG sets once it is on a node */
+    const uint64_t* zone_block; /* [G][w_zone] group bits that forbid this PEG in the group */
+    const uint64_t* zone_mark;  /* [G][w_zone] group bits this PEG sets once placed in the group */
+    const double* fp_cpu;     /* [G] first container cpu request, AsApproximateFloat64 (binpacking_estimator.go:451-455); may be NULL if fastpath unused */
+    const double* fp_mem;     /* [G] first container memory request, AsApproximateFloat64 (:456-458) */
+} casim_pegs;
+
+/*
+ * Node-group table: one record per candidate node group = one Estimate() call
+ * (CA/core/scaleup/orchestrator/orchestrator.go:409-413).  NG records.
+ * The schedulable PEG subset of each group (SchedulablePodGroups, orchestrator.go:535) is a CSR
+ * list; pass peg_offsets == NULL to let the engine compute it on the device (feasibility kernel).
+ */
+typedef struct casim_groups {
+    int32_t n_groups;             /* NG */
+    const int64_t* alloc;         /* [NG][R] node.Status.Allocatable per lane (types.go:527-537 SetNode)  */
+    const int64_t* init_req;      /* [NG][R] requested by pods preloaded on the template (DaemonSets; node_info_utils.go:111-118) */
+    const int32_t* allowed_pods;  /* [NG] Allocatable.AllowedPodNumber                                   */
+    const int32_t* init_pods;     /* [NG] pods preloaded on the template                                 */
+    const uint32_t* flags;        /* [NG] CASIM_NG_*                                                     */
+    const uint64_t* taint_mask;   /* [NG][w_taint] NoSchedule/NoExecute taints of the template (helper/taint.go:23-27) */
+    const uint64_t* label_mask;   /* [NG][w_label] label requirements the template satisfies            */
+    const uint64_t* init_excl;    /* [NG][w_excl] node bits already set on a fresh node (ports of preloaded pods, ...) */
+    const uint64_t* init_zone;    /* [NG][w_zone] group bits already set (matching pods in the existing cluster) */
+    const uint64_t* zone_valid;   /* [NG][w_zone] group bits whose topology key exists on the template: only these
+                                     are ever marked (a term on a key the node lacks never matches, filtering.go:155-163) */
+    const int32_t* max_nodes;     /* [NG] limiter result after getMinLimit: <0 forbid, 0 unlimited, >0 cap (threshold_based_limiter.go:34-69) */
+    const int32_t* existing_nodes;/* [NG] E: nodes already in the snapshot; they occupy list positions 0..E-1 */
+    const int32_t* last_index;    /* [NG] lastIndexOrderMapping.lastIndex on entry (scheduling_opts.go:39-63) */
+    const double* cap_cpu;        /* [NG] node.Status.Capacity cpu  AsApproximateFloat64 (fastpath chooser); may be NULL */
+    const double* cap_mem;        /* [NG] node.Status.Capacity mem  AsApproximateFloat64; may be NULL    */
+    const int64_t* waste_cpu;     /* [NG] node.Status.Capacity cpu MilliValue (least-waste, waste.go:85-90); may be NULL */
+    const int64_t* waste_mem;     /* [NG] node.Status.Capacity memory Value; may be NULL                 */
+    const int32_t* peg_offsets;   /* [NG+1] CSR offsets into peg_index, or NULL = compute on device      */
+    const int32_t* peg_index;     /* [peg_offsets[NG]] PEG ids, in the order they reach Estimate()       */
+} casim_groups;
+
+typedef struct casim_options {
+    int32_t fastpath;             /* --fastpath-binpacking-enabled (flags.go:203), default 0 */
+    int32_t reserved[7];
+} casim_options;
+
+/*
+ * Results of one batch.  All arrays caller-allocated.  `order`/`placed` use the same CSR
+ * offsets as the input (or the offsets returned by casim_problem_csr when computed on device):
+ * for group i, sorted position k:  order[off[i]+k] = PEG id processed k-th
+ * (DecreasingPodOrderer + fastpath move), placed[off[i]+k] = how many of its pods were
+ * scheduled — always a prefix of the PEG.  The shim rebuilds
+ * Estimate()'s []*Pod as concat_k PEG[order[k]].Pods[0:placed[k]].
+ */
+typedef struct casim_results {
+    int32_t* node_count;      /* [NG] len(newNodesWithPods)  binpacking_estimator.go:160 */
+    int32_t* pods_scheduled;  /* [NG] len(scheduledPods)                                  */
+    int32_t* nodes_added;     /* [NG] nodes added to the snapshot (incl. empty ones)      */
+    int32_t* limiter_nodes;   /* [NG] thresholdBasedEstimationLimiter.nodes at exit       */
+    int32_t* last_index_out;  /* [NG] lastIndex at exit                                   */
+    int32_t* status;          /* [NG] CASIM_NG_*                                          */
+    int64_t* req_cpu_sum;     /* [NG] sum of lane-0 requests of scheduled pods (least-waste) */
+    int64_t* req_mem_sum;     /* [NG] sum of lane-1 requests of scheduled pods            */
+    int32_t* order;           /* [nnz]                                                    */
+    int32_t* placed;          /* [nnz]                                                    */
+} casim_results;
+
+/* ======================================================================================
+ * ENGINE
+ * ==================================================================================== */
+typedef struct casim_ctx casim_ctx;
+typedef struct casim_problem casim_problem;
+
+/* ABI version of the loaded library. */
+int32_t casim_abi_version(void);
+/* Human-readable message of the last failure on the calling thread ("" if none). */
+const char* casim_last_error(void);
+
+/*
+ * Create an engine context bound to HIP device `device`.  `stream` is an optional
+ * hipStream_t (passed as void*) on which every kernel and copy of this context is enqueued;
+ * NULL = the context creates its own stream.  Safe to call from any OS thread (cgo): every
+ * entry point re-binds the device on entry (SURVEY §8b "threading").
+ * Returns NULL (casim_last_error explains) if no gfx950 device is visible — there is no
+ * CPU fallback in this library.
+ */
+casim_ctx* casim_ctx_create(int32_t device, void* stream);
+void casim_ctx_destroy(casim_ctx* ctx);
+/* Number of HIP devices visible (0 when none / no driver). */
+int32_t casim_device_count(void);
+
+/*
+ * Upload one batch (PEG table + node-group table) to HBM and size the device scratch.
+ * The returned problem stays resident until destroyed; it can be run many times.
+ */
+casim_problem* casim_problem_create(casim_ctx* ctx, const casim_pegs* pegs,
+                                    const casim_groups* groups, const casim_options* opts);
+void casim_problem_destroy(casim_problem* p);
+
+/*
+ * Enqueue the whole hot path for the resident batch on the context's stream:
+ *   [feasibility + CSR compaction, if peg_offsets was NULL] -> order -> pack.
+ * Asynchronous; results stay in HBM until casim_problem_fetch.
+ * Replaces the NG loop of prepareScaleUp (orchestrator.go:1049-1068).
+ */
+int32_t casim_problem_run(casim_problem* p);
+
+/* Block until the stream is idle, then copy the results to the caller's buffers. */
+int32_t casim_problem_fetch(casim_problem* p, casim_results* out);
+
+/* Number of (group, PEG) pairs (nnz) and the CSR offsets actually used by the last run
+ * (needed when the engine computed the schedulable subsets).  offsets_out has NG+1 slots or
+ * is NULL.  Synchronises the stream. */
+int32_t casim_problem_csr(casim_problem* p, int32_t* nnz_out, int32_t* offsets_out);
+
+/* upload + run + fetch in one call: the form the Go Estimate() wrapper uses once per loop. */
+int32_t casim_estimate_batch(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups,
+                             const casim_options* opts, casim_results* out);
+
+/*
+ * Batched CheckPredicates(exemplar, fresh template node): bit (i, g) of
+ * out_bits[i * ceil(G/64) + g/64] is set iff PEG g passes every encoded Filter on an empty
+ * node of group i (Appendix A `fits`).  Replaces the G x NG RunFiltersOnNode calls of
+ * SchedulablePodGroups (orchestrator.go:552).  Synchronous.
+ */
+int32_t casim_feasibility(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups,
+                          uint64_t* out_bits);
+
+/*
+ * Dense per-pod x per-node predicate matrix on resident data (the streaming form of the
+ * same kernel; rows = PEG records expanded by `count`, columns = groups expanded by
+ * `repeat` nodes).  Used for roofline measurement and as the device-side building block of
+ * filter-out-schedulable.  out_bits may be NULL (result left in HBM).
+ * Layout: [ceil(n_cols/64)][n_rows] uint64 (column-block major so that the wave's stores
+ * coalesce).  Asynchronous unless out_bits != NULL.
+ */
+int32_t casim_problem_dense_check(casim_problem* p, int32_t col_repeat, uint64_t* out_bits,
+                                  int64_t* n_rows_out, int64_t* n_cols_out);
+
+/*
+ * Expander reduce on the device results of the last run: applies the filter chain `kinds`
+ * (each CASIM_EXPANDER_*) in order to the options with node_count > 0 and pods_scheduled > 0
+ * (orchestrator.go:1057-1063), as chainStrategy.BestOption does (factory/chain.go:36-45).
+ * best_ng_out   = lowest-index group of the surviving set (deterministic stand-in for the
+ *                 random fallback, random.go:49-56), -1 if no option;
+ * n_best_out    = size of the surviving set (so a shim can apply its own random pick);
+ * best_set_out  = [NG] 1 for surviving groups, may be NULL;
+ * key_out       = packed sortable int64 key of the winner (smaller = better, group index in
+ *                 the low 20 bits) for a cross-GPU min all-reduce; may be NULL.
+ * key_out       = [2] int64: [0] packed key (metric << 20 | global group id, exact for the integer
+ *                 metrics), [1] the full 63-bit order-preserving metric (two-step reduce for least-waste);
+ * dev_key_out   = optional DEVICE pointer (void*) to 2 int64 receiving the same pair, so that an RCCL
+ *                 all-reduce can consume it without a host round trip; may be NULL.
+ * group_id_base = added to the local group index inside the key (rank offset when the
+ *                 groups are sharded across GPUs).
+ * Synchronous unless every host out pointer is NULL.
+ */
+int32_t casim_best_option(casim_problem* p, const int32_t* kinds, int32_t n_kinds,
+                          int32_t group_id_base, int32_t* best_ng_out, int32_t* n_best_out,
+                          uint8_t* best_set_out, int64_t* key_out, void* dev_key_out);
+
+/* Measurement helpers (used by bench.py): run `iters` times, bracketed by HIP events on the
+ * context's stream; returns the mean per-run milliseconds of the whole pipeline and of the
+ * named kernel classes.  kernel_ms_out: [0]=feasibility+csr [1]=order [2]=pack (may be NULL). */
+int32_t casim_problem_time(casim_problem* p, int32_t iters, float* total_ms_out,
+                           float* kernel_ms_out);
+/* Same for the dense check kernel alone. */
+int32_t casim_problem_time_dense(casim_problem* p, int32_t col_repeat, int32_t iters,
+                                 float* ms_out, int64_t* n_rows_out, int64_t* n_cols_out);
+/* Device-to-device copy bandwidth probe (GB/s) used as the "achievable HBM" reference. */
+int32_t casim_copy_bandwidth(casim_ctx* ctx, int64_t bytes, int32_t iters, double* gbps_out);
+
+/* ======================================================================================
+ * ENCODER  (host side, C++ inside; replaces the string work of the Filter plugins)
+ * ==================================================================================== */
+typedef struct casim_encoder casim_encoder;
+
+typedef struct casim_encoder_options {
+    int32_t n_res;                 /* R: lanes every object carries (>= 2)                     */
+    int32_t enable_taint_comparison_ops; /* TaintTolerationComparisonOperators gate (toleration.go:66-72); default 0 */
+    int32_t reserved[6];
+} casim_encoder_options;
+
+casim_encoder* casim_enc_create(const casim_encoder_options* opts);
+void casim_enc_destroy(casim_encoder* e);
+
+/* ---- node-group templates ------------------------------------------------------------ */
+/* Adds a node group; returns its index (>= 0) or <0.  alloc = Allocatable lanes, capacity_* =
+ * node.Status.Capacity (least-waste / fastpath chooser). */
+int32_t casim_enc_add_group(casim_encoder* e, const char* template_name, const int64_t* alloc,
+                            int32_t allowed_pods, int64_t capacity_cpu_milli,
+                            int64_t capacity_mem_bytes, int32_t unschedulable);
+int32_t casim_enc_group_add_label(casim_encoder* e, int32_t group, const char* key, const char* value);
+int32_t casim_enc_group_add_taint(casim_encoder* e, int32_t group, const char* key, const char* value,
+                                  const char* effect);
+/* override Capacity.{Cpu,Memory}().AsApproximateFloat64() (default: milli * 1e-3, bytes) */
+int32_t casim_enc_group_set_fastpath_capacity(casim_encoder* e, int32_t group, double cpu, double mem);
+/* limiter inputs: result of StartEstimation's getMinLimit fold (the shim runs the
+ * reference's own thresholds), E and lastIndex. */
+int32_t casim_enc_group_set_limits(casim_encoder* e, int32_t group, int32_t max_nodes,
+                                   int32_t existing_nodes, int32_t last_index);
+/* A pod preloaded on the template (DaemonSet pod): `pod` is a pod spec id from
+ * casim_enc_add_pod_spec. */
+int32_t casim_enc_group_add_preloaded_pod(casim_encoder* e, int32_t group, int32_t pod_spec);
+/* Restrict the group to an explicit PEG list (order = order the PEGs reach Estimate).  If never
+ * called for any group, the engine derives the schedulable subsets on the device. */
+int32_t casim_enc_group_set_pegs(casim_encoder* e, int32_t group, const int32_t* pegs, int32_t n);
+
+/* ---- pod specs and PEGs -------------------------------------------------------------- */
+/* A pod spec = the scheduling-relevant part of one exemplar pod.  Returns its id. */
+int32_t casim_enc_add_pod_spec(casim_encoder* e, const char* namespace_, const int64_t* req);
+int32_t casim_enc_pod_add_label(casim_encoder* e, int32_t pod, const char* key, const char* value);
+/* op: "", "Equal", "Exists", "Lt", "Gt";  effect: "", "NoSchedule", "NoExecute", "PreferNoSchedule" */
+int32_t casim_enc_pod_add_toleration(casim_encoder* e, int32_t pod, const char* key, const char* op,
+                                     const char* value, const char* effect);
+int32_t casim_enc_pod_add_node_selector(casim_encoder* e, int32_t pod, const char* key, const char* value);
+/* One requirement of the (single) required node-affinity term; op in In/NotIn/Exists/
+ * DoesNotExist/Gt/Lt; values = n_values C strings. */
+int32_t casim_enc_pod_add_node_affinity_req(casim_encoder* e, int32_t pod, const char* key,
+                                            const char* op, const char* const* values, int32_t n_values);
+/* protocol "" = TCP, ip "" = 0.0.0.0  (V/kube-scheduler/framework/types.go:633-640 sanitize) */
+int32_t casim_enc_pod_add_host_port(casim_encoder* e, int32_t pod, const char* ip, const char* protocol,
+                                    int32_t port);
+/* Required pod anti-affinity term: topology key, explicit namespaces (n = 0 => the pod's own
+ * namespace, types.go getNamespacesFromPodAffinityTerm), and a label selector given as
+ * requirements (matchLabels k=v is op "In" with one value).  Returns the term id. */
+int32_t casim_enc_pod_add_anti_affinity_term(casim_encoder* e, int32_t pod, const char* topology_key,
+                                             const char* const* namespaces, int32_t n_namespaces);
+int32_t casim_enc_term_add_requirement(casim_encoder* e, int32_t pod, int32_t term, const char* key,
+                                       const char* op, const char* const* values, int32_t n_values);
+/* first-container requests as float64 for the fastpath chooser */
+int32_t casim_enc_pod_set_fastpath_requests(casim_encoder* e, int32_t pod, double cpu, double mem);
+/* Mark the spec as carrying a predicate outside the encoded subset (required pod affinity,
+ * topology spread, volumes, DRA claims, multi-term node affinity, namespaceSelector...). */
+int32_t casim_enc_pod_mark_unsupported(casim_encoder* e, int32_t pod, const char* why);
+/* A PodEquivalenceGroup: `count` pods sharing pod spec `pod`.  Returns the PEG id. */
+int32_t casim_enc_add_peg(casim_encoder* e, int32_t pod_spec, int32_t count);
+
+/* Pods already running in the cluster that may interact with anti-affinity on non-hostname
+ * topology keys: (pod spec, label set of the node it runs on given as a group-like label
+ * list).  v0 accepts them only to detect interactions; see DESIGN.md. */
+int32_t casim_enc_add_existing_pod(casim_encoder* e, int32_t pod_spec, const char* const* node_label_keys,
+                                   const char* const* node_label_values, int32_t n_labels);
+
+/* Build the dictionaries and the flat tables.  After finalize the views below stay valid
+ * until the encoder is destroyed. */
+int32_t casim_enc_finalize(casim_encoder* e);
+int32_t casim_enc_tables(const casim_encoder* e, casim_pegs* pegs_out, casim_groups* groups_out);
+/* Dictionary sizes (bits in use) for reporting: taints, label requirements, node bits, zone bits */
+int32_t casim_enc_dict_sizes(const casim_encoder* e, int32_t sizes_out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CASIM_H_ */

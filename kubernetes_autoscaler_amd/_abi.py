@@ -1,0 +1,123 @@
+"""ctypes mirror of include/casim.h (struct layouts and function prototypes only — loading the
+shared library happens in _ffi.py).  Kept separate so that the test-only wave emulator
+(tests/emu/libcasim_emu.so), which consumes the same structs, can reuse the layouts."""
+import ctypes as C
+
+ABI_VERSION = 1
+MAX_RES = 8
+
+OK = 0
+ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_NOMEM = -1, -2, -3, -4
+NG_OK, NG_UNSUPPORTED = 0, 1
+
+PEG_TOLERATES_UNSCHEDULABLE = 0x1
+PEG_SELF_EXCL_NODE = 0x2
+PEG_SELF_EXCL_ZONE = 0x4
+PEG_FASTPATH_OK = 0x8
+PEG_FASTPATH_AA_SELF = 0x10
+PEG_UNSUPPORTED = 0x20
+NGF_UNSCHEDULABLE = 0x1
+
+EXPANDER_LEAST_NODES, EXPANDER_LEAST_WASTE, EXPANDER_MOST_PODS = 0, 1, 2
+
+i32p = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+u8p = C.POINTER(C.c_uint8)
+f64p = C.POINTER(C.c_double)
+
+
+class Pegs(C.Structure):
+    _fields_ = [
+        ("n_pegs", C.c_int32), ("n_res", C.c_int32), ("w_taint", C.c_int32), ("w_label", C.c_int32),
+        ("w_excl", C.c_int32), ("w_zone", C.c_int32),
+        ("req", i64p), ("count", i32p), ("flags", u32p),
+        ("tol_mask", u64p), ("sel_mask", u64p), ("excl_block", u64p), ("excl_mark", u64p),
+        ("zone_block", u64p), ("zone_mark", u64p), ("fp_cpu", f64p), ("fp_mem", f64p),
+    ]
+
+
+class Groups(C.Structure):
+    _fields_ = [
+        ("n_groups", C.c_int32),
+        ("alloc", i64p), ("init_req", i64p), ("allowed_pods", i32p), ("init_pods", i32p), ("flags", u32p),
+        ("taint_mask", u64p), ("label_mask", u64p), ("init_excl", u64p), ("init_zone", u64p), ("zone_valid", u64p),
+        ("max_nodes", i32p), ("existing_nodes", i32p), ("last_index", i32p),
+        ("cap_cpu", f64p), ("cap_mem", f64p), ("waste_cpu", i64p), ("waste_mem", i64p),
+        ("peg_offsets", i32p), ("peg_index", i32p),
+    ]
+
+
+class Options(C.Structure):
+    _fields_ = [("fastpath", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class Results(C.Structure):
+    _fields_ = [
+        ("node_count", i32p), ("pods_scheduled", i32p), ("nodes_added", i32p), ("limiter_nodes", i32p),
+        ("last_index_out", i32p), ("status", i32p), ("req_cpu_sum", i64p), ("req_mem_sum", i64p),
+        ("order", i32p), ("placed", i32p),
+    ]
+
+
+class EncoderOptions(C.Structure):
+    _fields_ = [("n_res", C.c_int32), ("enable_taint_comparison_ops", C.c_int32), ("reserved", C.c_int32 * 6)]
+
+
+cstr = C.c_char_p
+cstrp = C.POINTER(C.c_char_p)
+
+# name -> (restype, argtypes): every symbol include/casim.h declares
+PROTOTYPES = {
+    "casim_abi_version": (C.c_int32, []),
+    "casim_last_error": (C.c_char_p, []),
+    "casim_ctx_create": (C.c_void_p, [C.c_int32, C.c_void_p]),
+    "casim_ctx_destroy": (None, [C.c_void_p]),
+    "casim_device_count": (C.c_int32, []),
+    "casim_problem_create": (C.c_void_p, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(Options)]),
+    "casim_problem_destroy": (None, [C.c_void_p]),
+    "casim_problem_run": (C.c_int32, [C.c_void_p]),
+    "casim_problem_fetch": (C.c_int32, [C.c_void_p, C.POINTER(Results)]),
+    "casim_problem_csr": (C.c_int32, [C.c_void_p, i32p, i32p]),
+    "casim_estimate_batch": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(Options), C.POINTER(Results)]),
+    "casim_feasibility": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), u64p]),
+    "casim_problem_dense_check": (C.c_int32, [C.c_void_p, C.c_int32, u64p, i64p, i64p]),
+    "casim_best_option": (C.c_int32, [C.c_void_p, i32p, C.c_int32, C.c_int32, i32p, i32p, u8p, i64p, C.c_void_p]),
+    "casim_problem_time": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "casim_problem_time_dense": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float), i64p, i64p]),
+    "casim_copy_bandwidth": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, f64p]),
+    "casim_enc_create": (C.c_void_p, [C.POINTER(EncoderOptions)]),
+    "casim_enc_destroy": (None, [C.c_void_p]),
+    "casim_enc_add_group": (C.c_int32, [C.c_void_p, cstr, i64p, C.c_int32, C.c_int64, C.c_int64, C.c_int32]),
+    "casim_enc_group_add_label": (C.c_int32, [C.c_void_p, C.c_int32, cstr, cstr]),
+    "casim_enc_group_add_taint": (C.c_int32, [C.c_void_p, C.c_int32, cstr, cstr, cstr]),
+    "casim_enc_group_set_fastpath_capacity": (C.c_int32, [C.c_void_p, C.c_int32, C.c_double, C.c_double]),
+    "casim_enc_group_set_limits": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "casim_enc_group_add_preloaded_pod": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
+    "casim_enc_group_set_pegs": (C.c_int32, [C.c_void_p, C.c_int32, i32p, C.c_int32]),
+    "casim_enc_add_pod_spec": (C.c_int32, [C.c_void_p, cstr, i64p]),
+    "casim_enc_pod_add_label": (C.c_int32, [C.c_void_p, C.c_int32, cstr, cstr]),
+    "casim_enc_pod_add_toleration": (C.c_int32, [C.c_void_p, C.c_int32, cstr, cstr, cstr, cstr]),
+    "casim_enc_pod_add_node_selector": (C.c_int32, [C.c_void_p, C.c_int32, cstr, cstr]),
+    "casim_enc_pod_add_node_affinity_req": (C.c_int32, [C.c_void_p, C.c_int32, cstr, cstr, cstrp, C.c_int32]),
+    "casim_enc_pod_add_host_port": (C.c_int32, [C.c_void_p, C.c_int32, cstr, cstr, C.c_int32]),
+    "casim_enc_pod_add_anti_affinity_term": (C.c_int32, [C.c_void_p, C.c_int32, cstr, cstrp, C.c_int32]),
+    "casim_enc_term_add_requirement": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, cstr, cstr, cstrp, C.c_int32]),
+    "casim_enc_pod_set_fastpath_requests": (C.c_int32, [C.c_void_p, C.c_int32, C.c_double, C.c_double]),
+    "casim_enc_pod_mark_unsupported": (C.c_int32, [C.c_void_p, C.c_int32, cstr]),
+    "casim_enc_add_peg": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
+    "casim_enc_add_existing_pod": (C.c_int32, [C.c_void_p, C.c_int32, cstrp, cstrp, C.c_int32]),
+    "casim_enc_finalize": (C.c_int32, [C.c_void_p]),
+    "casim_enc_tables": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups)]),
+    "casim_enc_dict_sizes": (C.c_int32, [C.c_void_p, i32p]),
+}
+
+
+def bind(lib):
+    """Attach prototypes; raises AttributeError if the library misses a declared symbol."""
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib

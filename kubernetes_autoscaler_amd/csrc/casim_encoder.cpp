@@ -1,0 +1,585 @@
+// casim_encoder.cpp — host encoder (SURVEY Appendix C "H1"): dictionary-encodes the string side of
+// the scheduler Filter plugins once per scale-up loop so that the device only sees integers
+// and bitmasks.  Pure host C++, no HIP.  C ABI in include/casim.h (casim_enc_*).
+//
+// What is evaluated HERE, once per (PEG, dictionary entry), instead of per pod x node in Go:
+//   Toleration.ToleratesTaint          V/api/core/v1/toleration.go:52-114
+//   labels.Requirement.Matches         V/apimachinery/pkg/labels/selector.go:247-292
+//   RequiredNodeAffinity.Match         V/component-helpers/scheduling/corev1/nodeaffinity/nodeaffinity.go:323-333
+//   HostPortInfo.CheckConflict         V/kube-scheduler/framework/types.go:602-640
+//   AffinityTerm.Matches               V/kube-scheduler/framework/types.go:390-395
+//   shouldUseFastPath / labelSelectorMatches  CA/estimator/binpacking_estimator.go:399-425,444-450
+#include <errno.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <set>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/casim.h"
+
+namespace {
+
+const char* kHostname = "kubernetes.io/hostname";
+const char* kUnschedulableTaint = "node.kubernetes.io/unschedulable";
+
+enum ReqOp { kIn, kNotIn, kExists, kDoesNotExist, kGt, kLt, kBadOp };
+enum TolOp { kTolEqual, kTolExists, kTolLt, kTolGt, kTolBad };
+
+std::string S(const char* s) { return s ? std::string(s) : std::string(); }
+
+struct Requirement { std::string key; ReqOp op; std::vector<std::string> values; };
+struct Toleration { std::string key; TolOp op; std::string value, effect; };
+struct Taint { std::string key, value, effect; bool operator<(const Taint& o) const { return std::tie(key, value, effect) < std::tie(o.key, o.value, o.effect); } };
+struct Port { std::string ip, proto; int32_t port; bool operator<(const Port& o) const { return std::tie(ip, proto, port) < std::tie(o.ip, o.proto, o.port); } };
+struct Term { std::string topology_key; std::vector<std::string> namespaces; std::vector<Requirement> selector; };
+typedef std::map<std::string, std::string> Labels;
+
+struct PodSpec {
+    std::string ns;
+    int64_t req[CASIM_MAX_RES];
+    Labels labels;
+    std::vector<Toleration> tolerations;
+    std::vector<std::pair<std::string, std::string>> node_selector;
+    std::vector<Requirement> node_affinity;
+    std::vector<Port> ports;
+    std::vector<Term> anti;
+    double fp_cpu = 0, fp_mem = 0;
+    bool unsupported = false;
+    std::string why;
+};
+struct Group {
+    std::string name;
+    int64_t alloc[CASIM_MAX_RES];
+    int32_t allowed = 0;
+    int64_t cap_cpu = 0, cap_mem = 0;
+    double fp_cap_cpu = 0, fp_cap_mem = 0;
+    bool unschedulable = false;
+    Labels labels;
+    std::vector<Taint> taints;
+    int32_t max_nodes = 0, existing = 0, last_index = 0;
+    std::vector<int32_t> preloaded;
+    bool has_pegs = false;
+    std::vector<int32_t> pegs;
+};
+struct Peg { int32_t spec; int32_t count; };
+struct ExistingPod { int32_t spec; Labels node_labels; };
+
+bool parse_int64(const std::string& s, int64_t* out) {  // strconv.ParseInt(s, 10, 64)
+    if (s.empty()) return false;
+    size_t i = (s[0] == '+' || s[0] == '-') ? 1 : 0;
+    if (i == s.size()) return false;
+    for (size_t j = i; j < s.size(); ++j) if (s[j] < '0' || s[j] > '9') return false;
+    errno = 0;
+    long long v = strtoll(s.c_str(), nullptr, 10);
+    if (errno == ERANGE) return false;
+    *out = v;
+    return true;
+}
+ReqOp parse_req_op(const char* op) {
+    const std::string o = S(op);
+    if (o == "In") return kIn;
+    if (o == "NotIn") return kNotIn;
+    if (o == "Exists") return kExists;
+    if (o == "DoesNotExist") return kDoesNotExist;
+    if (o == "Gt") return kGt;
+    if (o == "Lt") return kLt;
+    return kBadOp;
+}
+TolOp parse_tol_op(const char* op) {
+    const std::string o = S(op);
+    if (o.empty() || o == "Equal") return kTolEqual;  // empty operator means Equal
+    if (o == "Exists") return kTolExists;
+    if (o == "Lt") return kTolLt;
+    if (o == "Gt") return kTolGt;
+    return kTolBad;
+}
+bool requirement_matches(const Requirement& r, const Labels& ls) {
+    auto it = ls.find(r.key);
+    const bool exists = it != ls.end();
+    switch (r.op) {
+    case kIn: if (!exists) return false; for (auto& v : r.values) if (v == it->second) return true; return false;
+    case kNotIn: if (!exists) return true; for (auto& v : r.values) if (v == it->second) return false; return true;
+    case kExists: return exists;
+    case kDoesNotExist: return !exists;
+    case kGt: case kLt: {
+        if (!exists) return false;
+        int64_t lv, rv;
+        if (!parse_int64(it->second, &lv)) return false;
+        if (r.values.size() != 1 || !parse_int64(r.values[0], &rv)) return false;
+        return (r.op == kGt && lv > rv) || (r.op == kLt && lv < rv);
+    }
+    default: return false;
+    }
+}
+bool selector_matches(const std::vector<Requirement>& sel, const Labels& ls) {
+    for (auto& r : sel) if (!requirement_matches(r, ls)) return false;
+    return true;
+}
+bool term_matches(const Term& t, const PodSpec& target) {
+    bool ns_ok = false;
+    for (auto& n : t.namespaces) if (n == target.ns) { ns_ok = true; break; }
+    return ns_ok && selector_matches(t.selector, target.labels);
+}
+bool tolerates(const Toleration& t, const Taint& tn, bool cmp_ops) {
+    if (!t.effect.empty() && t.effect != tn.effect) return false;
+    if (!t.key.empty() && t.key != tn.key) return false;
+    switch (t.op) {
+    case kTolEqual: return t.value == tn.value;
+    case kTolExists: return true;
+    case kTolLt: case kTolGt: {
+        if (!cmp_ops) return false;
+        int64_t tv, nv;
+        if (t.value.empty() || t.value[0] == '+' || !parse_int64(t.value, &tv)) return false;  // IsDecimalInteger
+        if (tn.value.empty() || tn.value[0] == '+' || !parse_int64(tn.value, &nv)) return false;
+        return t.op == kTolLt ? nv < tv : nv > tv;
+    }
+    default: return false;
+    }
+}
+Port sanitize(Port p) {
+    if (p.ip.empty()) p.ip = "0.0.0.0";
+    if (p.proto.empty()) p.proto = "TCP";
+    return p;
+}
+bool ports_conflict(const Port& want, const Port& used) {  // CheckConflict(want) against one used entry
+    if (want.port <= 0 || used.port <= 0) return false;
+    if (want.proto != used.proto || want.port != used.port) return false;
+    return want.ip == "0.0.0.0" || used.ip == "0.0.0.0" || want.ip == used.ip;
+}
+std::string req_signature(const Requirement& r) {
+    std::string s = std::to_string((int)r.op) + "\x1f" + r.key;
+    for (auto& v : r.values) { s += "\x1f"; s += v; }
+    return s;
+}
+
+struct BitAlloc {
+    int n = 0;
+    int next() { return n++; }
+    int words() const { return (n + 63) / 64; }
+};
+inline void set_bit(std::vector<uint64_t>& m, size_t row, int W, int bit) { m[row * (size_t)W + (size_t)(bit >> 6)] |= 1ull << (bit & 63); }
+
+}  // namespace
+
+struct casim_encoder {
+    casim_encoder_options opt;
+    std::vector<PodSpec> specs;
+    std::vector<Group> groups;
+    std::vector<Peg> pegs;
+    std::vector<ExistingPod> existing;
+    bool finalized = false;
+    // flat tables
+    int Wt = 0, Wl = 0, Wx = 0, Wz = 0;
+    std::vector<int64_t> req, alloc, init_req, waste_cpu, waste_mem;
+    std::vector<int32_t> count, allowed, init_pods, max_nodes, existing_nodes, last_index, peg_off, peg_idx;
+    std::vector<uint32_t> pflags, gflags;
+    std::vector<uint64_t> tol, sel, xblock, xmark, zblock, zmark, taint, label, init_excl, init_zone, zone_valid;
+    std::vector<double> fp_cpu, fp_mem, cap_cpu, cap_mem;
+    int dict[4] = {0, 0, 0, 0};
+};
+
+extern "C" {
+
+casim_encoder* casim_enc_create(const casim_encoder_options* opts) {
+    if (!opts || opts->n_res < 2 || opts->n_res > CASIM_MAX_RES) return nullptr;
+    casim_encoder* e = new (std::nothrow) casim_encoder();
+    if (e) e->opt = *opts;
+    return e;
+}
+void casim_enc_destroy(casim_encoder* e) { delete e; }
+
+#define ENC_CHECK(e) if (!(e) || (e)->finalized) return CASIM_ERR_INVALID
+#define POD_CHECK(e, p) ENC_CHECK(e); if ((p) < 0 || (size_t)(p) >= (e)->specs.size()) return CASIM_ERR_INVALID
+#define GRP_CHECK(e, g) ENC_CHECK(e); if ((g) < 0 || (size_t)(g) >= (e)->groups.size()) return CASIM_ERR_INVALID
+
+int32_t casim_enc_add_group(casim_encoder* e, const char* template_name, const int64_t* alloc, int32_t allowed_pods,
+                            int64_t capacity_cpu_milli, int64_t capacity_mem_bytes, int32_t unschedulable) {
+    ENC_CHECK(e);
+    if (!alloc) return CASIM_ERR_INVALID;
+    Group g;
+    g.name = S(template_name);
+    for (int r = 0; r < CASIM_MAX_RES; ++r) g.alloc[r] = r < e->opt.n_res ? alloc[r] : 0;
+    g.allowed = allowed_pods; g.cap_cpu = capacity_cpu_milli; g.cap_mem = capacity_mem_bytes; g.unschedulable = unschedulable != 0;
+    // Capacity.Cpu().AsApproximateFloat64() for a milli quantity = float64(milli) * 10^-3 (quantity.go:468-483)
+    g.fp_cap_cpu = (double)capacity_cpu_milli * 1e-3; g.fp_cap_mem = (double)capacity_mem_bytes;
+    e->groups.push_back(g);
+    return (int32_t)e->groups.size() - 1;
+}
+int32_t casim_enc_group_set_fastpath_capacity(casim_encoder* e, int32_t group, double cpu, double mem) {
+    GRP_CHECK(e, group); e->groups[group].fp_cap_cpu = cpu; e->groups[group].fp_cap_mem = mem; return CASIM_OK;
+}
+int32_t casim_enc_group_add_label(casim_encoder* e, int32_t group, const char* key, const char* value) {
+    GRP_CHECK(e, group); e->groups[group].labels[S(key)] = S(value); return CASIM_OK;
+}
+int32_t casim_enc_group_add_taint(casim_encoder* e, int32_t group, const char* key, const char* value, const char* effect) {
+    GRP_CHECK(e, group); e->groups[group].taints.push_back(Taint{S(key), S(value), S(effect)}); return CASIM_OK;
+}
+int32_t casim_enc_group_set_limits(casim_encoder* e, int32_t group, int32_t max_nodes, int32_t existing_nodes, int32_t last_index) {
+    GRP_CHECK(e, group);
+    if (existing_nodes < 0 || last_index < 0) return CASIM_ERR_INVALID;
+    e->groups[group].max_nodes = max_nodes; e->groups[group].existing = existing_nodes; e->groups[group].last_index = last_index;
+    return CASIM_OK;
+}
+int32_t casim_enc_group_add_preloaded_pod(casim_encoder* e, int32_t group, int32_t pod_spec) {
+    GRP_CHECK(e, group); POD_CHECK(e, pod_spec); e->groups[group].preloaded.push_back(pod_spec); return CASIM_OK;
+}
+int32_t casim_enc_group_set_pegs(casim_encoder* e, int32_t group, const int32_t* pegs, int32_t n) {
+    GRP_CHECK(e, group);
+    if (n < 0 || (n > 0 && !pegs)) return CASIM_ERR_INVALID;
+    e->groups[group].has_pegs = true;
+    e->groups[group].pegs.assign(pegs, pegs + n);
+    return CASIM_OK;
+}
+int32_t casim_enc_add_pod_spec(casim_encoder* e, const char* namespace_, const int64_t* req) {
+    ENC_CHECK(e);
+    if (!req) return CASIM_ERR_INVALID;
+    PodSpec p;
+    p.ns = S(namespace_);
+    for (int r = 0; r < CASIM_MAX_RES; ++r) p.req[r] = r < e->opt.n_res ? req[r] : 0;
+    e->specs.push_back(p);
+    return (int32_t)e->specs.size() - 1;
+}
+int32_t casim_enc_pod_add_label(casim_encoder* e, int32_t pod, const char* key, const char* value) {
+    POD_CHECK(e, pod); e->specs[pod].labels[S(key)] = S(value); return CASIM_OK;
+}
+int32_t casim_enc_pod_add_toleration(casim_encoder* e, int32_t pod, const char* key, const char* op, const char* value, const char* effect) {
+    POD_CHECK(e, pod); e->specs[pod].tolerations.push_back(Toleration{S(key), parse_tol_op(op), S(value), S(effect)}); return CASIM_OK;
+}
+int32_t casim_enc_pod_add_node_selector(casim_encoder* e, int32_t pod, const char* key, const char* value) {
+    POD_CHECK(e, pod); e->specs[pod].node_selector.push_back({S(key), S(value)}); return CASIM_OK;
+}
+static Requirement make_req(const char* key, const char* op, const char* const* values, int32_t n) {
+    Requirement r; r.key = S(key); r.op = parse_req_op(op);
+    for (int i = 0; i < n; ++i) r.values.push_back(S(values[i]));
+    return r;
+}
+int32_t casim_enc_pod_add_node_affinity_req(casim_encoder* e, int32_t pod, const char* key, const char* op, const char* const* values, int32_t n_values) {
+    POD_CHECK(e, pod);
+    if (n_values < 0 || (n_values > 0 && !values)) return CASIM_ERR_INVALID;
+    e->specs[pod].node_affinity.push_back(make_req(key, op, values, n_values)); return CASIM_OK;
+}
+int32_t casim_enc_pod_add_host_port(casim_encoder* e, int32_t pod, const char* ip, const char* protocol, int32_t port) {
+    POD_CHECK(e, pod); e->specs[pod].ports.push_back(Port{S(ip), S(protocol), port}); return CASIM_OK;
+}
+int32_t casim_enc_pod_add_anti_affinity_term(casim_encoder* e, int32_t pod, const char* topology_key, const char* const* namespaces, int32_t n_namespaces) {
+    POD_CHECK(e, pod);
+    if (n_namespaces < 0 || (n_namespaces > 0 && !namespaces)) return CASIM_ERR_INVALID;
+    Term t; t.topology_key = S(topology_key);
+    if (n_namespaces == 0) t.namespaces.push_back(e->specs[pod].ns);  // getNamespacesFromPodAffinityTerm
+    for (int i = 0; i < n_namespaces; ++i) t.namespaces.push_back(S(namespaces[i]));
+    e->specs[pod].anti.push_back(t);
+    return (int32_t)e->specs[pod].anti.size() - 1;
+}
+int32_t casim_enc_term_add_requirement(casim_encoder* e, int32_t pod, int32_t term, const char* key, const char* op, const char* const* values, int32_t n_values) {
+    POD_CHECK(e, pod);
+    if (term < 0 || (size_t)term >= e->specs[pod].anti.size()) return CASIM_ERR_INVALID;
+    if (n_values < 0 || (n_values > 0 && !values)) return CASIM_ERR_INVALID;
+    e->specs[pod].anti[term].selector.push_back(make_req(key, op, values, n_values)); return CASIM_OK;
+}
+int32_t casim_enc_pod_set_fastpath_requests(casim_encoder* e, int32_t pod, double cpu, double mem) {
+    POD_CHECK(e, pod); e->specs[pod].fp_cpu = cpu; e->specs[pod].fp_mem = mem; return CASIM_OK;
+}
+int32_t casim_enc_pod_mark_unsupported(casim_encoder* e, int32_t pod, const char* why) {
+    POD_CHECK(e, pod); e->specs[pod].unsupported = true; e->specs[pod].why = S(why); return CASIM_OK;
+}
+int32_t casim_enc_add_peg(casim_encoder* e, int32_t pod_spec, int32_t count) {
+    POD_CHECK(e, pod_spec);
+    if (count < 0) return CASIM_ERR_INVALID;
+    e->pegs.push_back(Peg{pod_spec, count});
+    return (int32_t)e->pegs.size() - 1;
+}
+int32_t casim_enc_add_existing_pod(casim_encoder* e, int32_t pod_spec, const char* const* keys, const char* const* values, int32_t n) {
+    POD_CHECK(e, pod_spec);
+    if (n < 0 || (n > 0 && (!keys || !values))) return CASIM_ERR_INVALID;
+    ExistingPod x; x.spec = pod_spec;
+    for (int i = 0; i < n; ++i) x.node_labels[S(keys[i])] = S(values[i]);
+    e->existing.push_back(x);
+    return CASIM_OK;
+}
+
+int32_t casim_enc_finalize(casim_encoder* e) {
+    ENC_CHECK(e);
+    const int R = e->opt.n_res;
+    const size_t G = e->pegs.size(), NG = e->groups.size(), NS = e->specs.size();
+    const bool cmp_ops = e->opt.enable_taint_comparison_ops != 0;
+    for (auto& g : e->groups)
+        if (g.has_pegs) for (int32_t pg : g.pegs) if (pg < 0 || (size_t)pg >= G) return CASIM_ERR_INVALID;
+
+    // ---- dictionaries ------------------------------------------------------------------
+    // (1) taints that reject scheduling (NoSchedule / NoExecute)
+    std::map<Taint, int> taint_id;
+    for (auto& g : e->groups)
+        for (auto& t : g.taints)
+            if ((t.effect == "NoSchedule" || t.effect == "NoExecute") && !taint_id.count(t)) { const int id = (int)taint_id.size(); taint_id[t] = id; }
+    e->Wt = ((int)taint_id.size() + 63) / 64;
+    // (2) label requirements used by some PEG spec (nodeSelector pair == In{value})
+    std::map<std::string, int> lreq_id;
+    std::vector<Requirement> lreqs;
+    std::vector<std::vector<int>> spec_lreqs(NS);
+    std::vector<bool> spec_used(NS, false);
+    for (auto& pg : e->pegs) spec_used[(size_t)pg.spec] = true;
+    for (size_t s = 0; s < NS; ++s) {
+        if (!spec_used[s]) continue;
+        PodSpec& p = e->specs[s];
+        std::vector<Requirement> all = p.node_affinity;
+        for (auto& kv : p.node_selector) { Requirement r; r.key = kv.first; r.op = kIn; r.values = {kv.second}; all.push_back(r); }
+        for (auto& r : all) {
+            // every simulated node gets its own hostname label (node_info_utils.go:130): not a template property
+            if (r.key == kHostname) { p.unsupported = true; p.why = "node selector on kubernetes.io/hostname"; continue; }
+            const std::string sig = req_signature(r);
+            auto it = lreq_id.find(sig);
+            int id;
+            if (it == lreq_id.end()) { id = (int)lreqs.size(); lreq_id[sig] = id; lreqs.push_back(r); } else id = it->second;
+            spec_lreqs[s].push_back(id);
+        }
+    }
+    e->Wl = ((int)lreqs.size() + 63) / 64;
+
+    // (3) node-local exclusion bits: host ports and hostname anti-affinity across DIFFERENT units.
+    // Units: every PEG, plus every spec preloaded on some template.
+    BitAlloc xbits;
+    std::vector<uint32_t> pflags(G, 0);
+    // ports
+    std::map<Port, int> port_bit;                       // sanitized used port -> bit (only when shared)
+    {
+        std::map<Port, std::set<int>> users;            // port -> units using it (unit = PEG id, or -1-spec for preloaded)
+        for (size_t i = 0; i < G; ++i)
+            for (auto& p : e->specs[(size_t)e->pegs[i].spec].ports) if (p.port > 0) users[sanitize(p)].insert((int)i);
+        for (auto& g : e->groups)
+            for (int32_t s : g.preloaded)
+                for (auto& p : e->specs[(size_t)s].ports) if (p.port > 0) users[sanitize(p)].insert(-1 - s);
+        // a used port needs a bit when some OTHER unit wants a conflicting port
+        for (auto& a : users) {
+            bool shared = false;
+            for (auto& b : users) {
+                if (!ports_conflict(b.first, a.first)) continue;
+                for (int ub : b.second) for (int ua : a.second) if (ua != ub) shared = true;
+                if (shared) break;
+            }
+            if (shared) port_bit[a.first] = xbits.next();
+        }
+    }
+    // hostname anti-affinity between different units
+    std::vector<int> peg_occ_bit(G, -1);                 // occupancy bit of a PEG (set when someone else conflicts with it)
+    std::map<int32_t, int> pre_occ_bit;                  // preloaded spec -> bit
+    std::vector<std::vector<int>> peg_blockers(G);       // bits that block PEG i at node level
+    auto host_conflict = [&](const PodSpec& a, const PodSpec& b) {
+        for (auto& t : a.anti) if (t.topology_key == kHostname && term_matches(t, b)) return true;
+        for (auto& t : b.anti) if (t.topology_key == kHostname && term_matches(t, a)) return true;
+        return false;
+    };
+    {
+        std::vector<size_t> with_terms;  // PEGs whose spec has hostname terms
+        for (size_t i = 0; i < G; ++i)
+            for (auto& t : e->specs[(size_t)e->pegs[i].spec].anti) if (t.topology_key == kHostname) { with_terms.push_back(i); break; }
+        for (size_t i : with_terms) {
+            const PodSpec& a = e->specs[(size_t)e->pegs[i].spec];
+            for (size_t j = 0; j < G; ++j) {
+                const PodSpec& b = e->specs[(size_t)e->pegs[j].spec];
+                bool hit = false;
+                for (auto& t : a.anti) if (t.topology_key == kHostname && term_matches(t, b)) { hit = true; break; }
+                if (!hit) continue;
+                if (i == j) { pflags[i] |= CASIM_PEG_SELF_EXCL_NODE; continue; }
+                if (peg_occ_bit[i] < 0) peg_occ_bit[i] = xbits.next();
+                if (peg_occ_bit[j] < 0) peg_occ_bit[j] = xbits.next();
+                peg_blockers[i].push_back(peg_occ_bit[j]);
+                peg_blockers[j].push_back(peg_occ_bit[i]);
+            }
+        }
+        for (auto& g : e->groups)
+            for (int32_t s : g.preloaded)
+                for (size_t i = 0; i < G; ++i)
+                    if (host_conflict(e->specs[(size_t)s], e->specs[(size_t)e->pegs[i].spec])) {
+                        if (!pre_occ_bit.count(s)) pre_occ_bit[s] = xbits.next();
+                        peg_blockers[i].push_back(pre_occ_bit[s]);
+                    }
+    }
+    e->Wx = xbits.words();
+
+    // (4) group-wide exclusion bits: anti-affinity on non-hostname topology keys.  All nodes of a group
+    // clone one template, so a domain == the whole group when the template carries the key.
+    BitAlloc zbits;
+    std::map<std::pair<int, std::string>, int> occ_z;     // (PEG, topology key) -> occupancy bit
+    std::vector<std::vector<int>> z_block(G), z_mark(G);
+    std::map<int, std::string> zbit_key;                  // bit -> topology key ("" = always valid)
+    std::vector<int> static_zbit(G, -1);                  // per-PEG "blocked by the existing cluster" bit
+    {
+        auto occ = [&](int pg, const std::string& tk) {
+            auto k = std::make_pair(pg, tk);
+            auto it = occ_z.find(k);
+            if (it != occ_z.end()) return it->second;
+            const int b = zbits.next(); occ_z[k] = b; zbit_key[b] = tk; z_mark[(size_t)pg].push_back(b);
+            return b;
+        };
+        for (size_t i = 0; i < G; ++i) {
+            const PodSpec& a = e->specs[(size_t)e->pegs[i].spec];
+            for (auto& t : a.anti) {
+                if (t.topology_key == kHostname) continue;
+                for (size_t j = 0; j < G; ++j) {
+                    if (!term_matches(t, e->specs[(size_t)e->pegs[j].spec])) continue;
+                    // i must not join a domain holding j; j must not join a domain holding i
+                    z_block[i].push_back(occ((int)j, t.topology_key));
+                    z_block[j].push_back(occ((int)i, t.topology_key));
+                }
+            }
+        }
+    }
+    // existing cluster pods: static (PEG, group) blocks
+    std::vector<std::vector<bool>> existing_block(G, std::vector<bool>(NG, false));
+    for (size_t i = 0; i < G; ++i) {
+        const PodSpec& a = e->specs[(size_t)e->pegs[i].spec];
+        for (auto& x : e->existing) {
+            const PodSpec& b = e->specs[(size_t)x.spec];
+            for (size_t gi = 0; gi < NG; ++gi) {
+                const Group& g = e->groups[gi];
+                auto same_domain = [&](const std::string& tk) {
+                    if (tk == kHostname) return false;  // new nodes never share a hostname with an existing node
+                    auto a1 = g.labels.find(tk); auto b1 = x.node_labels.find(tk);
+                    return a1 != g.labels.end() && b1 != x.node_labels.end() && a1->second == b1->second;
+                };
+                bool blk = false;
+                for (auto& t : a.anti) if (same_domain(t.topology_key) && term_matches(t, b)) blk = true;
+                for (auto& t : b.anti) if (same_domain(t.topology_key) && term_matches(t, a)) blk = true;
+                if (blk) existing_block[i][gi] = true;
+            }
+        }
+        for (size_t gi = 0; gi < NG; ++gi) {  // pods preloaded on the template share every non-hostname domain with its clones
+            const Group& g = e->groups[gi];
+            for (int32_t s : g.preloaded) {
+                const PodSpec& b = e->specs[(size_t)s];
+                for (auto& t : a.anti) if (t.topology_key != kHostname && g.labels.count(t.topology_key) && term_matches(t, b)) existing_block[i][gi] = true;
+                for (auto& t : b.anti) if (t.topology_key != kHostname && g.labels.count(t.topology_key) && term_matches(t, a)) existing_block[i][gi] = true;
+            }
+        }
+        bool any = false;
+        for (size_t gi = 0; gi < NG; ++gi) any = any || existing_block[i][gi];
+        if (any) { static_zbit[i] = zbits.next(); zbit_key[static_zbit[i]] = ""; z_block[i].push_back(static_zbit[i]); }
+    }
+    e->Wz = zbits.words();
+
+    // ---- flat PEG table ------------------------------------------------------------------
+    const int Wt = e->Wt, Wl = e->Wl, Wx = e->Wx, Wz = e->Wz;
+    e->req.assign(G * (size_t)R, 0); e->count.assign(G, 0); e->pflags.assign(G, 0);
+    e->tol.assign(G * (size_t)Wt, 0); e->sel.assign(G * (size_t)Wl, 0);
+    e->xblock.assign(G * (size_t)Wx, 0); e->xmark.assign(G * (size_t)Wx, 0);
+    e->zblock.assign(G * (size_t)Wz, 0); e->zmark.assign(G * (size_t)Wz, 0);
+    e->fp_cpu.assign(G, 0.0); e->fp_mem.assign(G, 0.0);
+    const Taint unsched{kUnschedulableTaint, "", "NoSchedule"};
+    for (size_t i = 0; i < G; ++i) {
+        const PodSpec& p = e->specs[(size_t)e->pegs[i].spec];
+        for (int r = 0; r < R; ++r) e->req[i * (size_t)R + (size_t)r] = p.req[r];
+        e->count[i] = e->pegs[i].count;
+        uint32_t f = pflags[i];
+        for (auto& t : p.tolerations) if (tolerates(t, unsched, cmp_ops)) { f |= CASIM_PEG_TOLERATES_UNSCHEDULABLE; break; }
+        for (auto& kv : taint_id) {
+            bool ok = false;
+            for (auto& t : p.tolerations) if (tolerates(t, kv.first, cmp_ops)) { ok = true; break; }
+            if (ok) set_bit(e->tol, i, Wt, kv.second);
+        }
+        for (int id : spec_lreqs[(size_t)e->pegs[i].spec]) set_bit(e->sel, i, Wl, id);
+        // ports: any host port conflicts with a second copy of the same pod
+        bool has_port = false;
+        for (auto& pt : p.ports) {
+            if (pt.port <= 0) continue;
+            has_port = true;
+            const Port sp = sanitize(pt);
+            auto own = port_bit.find(sp);
+            if (own != port_bit.end()) set_bit(e->xmark, i, Wx, own->second);
+            for (auto& pb : port_bit) if (ports_conflict(sp, pb.first)) set_bit(e->xblock, i, Wx, pb.second);
+        }
+        if (has_port) f |= CASIM_PEG_SELF_EXCL_NODE;
+        if (peg_occ_bit[i] >= 0) set_bit(e->xmark, i, Wx, peg_occ_bit[i]);
+        for (int b : peg_blockers[i]) set_bit(e->xblock, i, Wx, b);
+        for (int b : z_block[i]) set_bit(e->zblock, i, Wz, b);
+        for (int b : z_mark[i]) set_bit(e->zmark, i, Wz, b);
+        // fastpath eligibility: no topology spread (unsupported anyway) and no non-hostname anti-affinity
+        bool fp_ok = !p.unsupported;
+        for (auto& t : p.anti) if (t.topology_key != kHostname) fp_ok = false;
+        if (fp_ok) f |= CASIM_PEG_FASTPATH_OK;
+        for (auto& t : p.anti)
+            if (t.topology_key == kHostname && selector_matches(t.selector, p.labels)) { f |= CASIM_PEG_FASTPATH_AA_SELF; break; }
+        if (p.unsupported) f |= CASIM_PEG_UNSUPPORTED;
+        e->pflags[i] = f;
+        e->fp_cpu[i] = p.fp_cpu; e->fp_mem[i] = p.fp_mem;
+    }
+
+    // ---- flat group table ------------------------------------------------------------------
+    e->alloc.assign(NG * (size_t)R, 0); e->init_req.assign(NG * (size_t)R, 0);
+    e->allowed.assign(NG, 0); e->init_pods.assign(NG, 0); e->gflags.assign(NG, 0);
+    e->taint.assign(NG * (size_t)Wt, 0); e->label.assign(NG * (size_t)Wl, 0);
+    e->init_excl.assign(NG * (size_t)Wx, 0); e->init_zone.assign(NG * (size_t)Wz, 0); e->zone_valid.assign(NG * (size_t)Wz, 0);
+    e->max_nodes.assign(NG, 0); e->existing_nodes.assign(NG, 0); e->last_index.assign(NG, 0);
+    e->cap_cpu.assign(NG, 0.0); e->cap_mem.assign(NG, 0.0); e->waste_cpu.assign(NG, 0); e->waste_mem.assign(NG, 0);
+    bool any_explicit = false;
+    for (size_t gi = 0; gi < NG; ++gi) {
+        const Group& g = e->groups[gi];
+        for (int r = 0; r < R; ++r) e->alloc[gi * (size_t)R + (size_t)r] = g.alloc[r];
+        e->allowed[gi] = g.allowed;
+        e->gflags[gi] = g.unschedulable ? CASIM_NG_UNSCHEDULABLE : 0;
+        e->max_nodes[gi] = g.max_nodes; e->existing_nodes[gi] = g.existing; e->last_index[gi] = g.last_index;
+        e->cap_cpu[gi] = g.fp_cap_cpu; e->cap_mem[gi] = g.fp_cap_mem;
+        e->waste_cpu[gi] = g.cap_cpu; e->waste_mem[gi] = g.cap_mem;
+        for (auto& t : g.taints) { auto it = taint_id.find(t); if (it != taint_id.end()) set_bit(e->taint, gi, Wt, it->second); }
+        for (size_t l = 0; l < lreqs.size(); ++l) if (requirement_matches(lreqs[l], g.labels)) set_bit(e->label, gi, Wl, (int)l);
+        for (int32_t s : g.preloaded) {
+            const PodSpec& p = e->specs[(size_t)s];
+            for (int r = 0; r < R; ++r) e->init_req[gi * (size_t)R + (size_t)r] += p.req[r];
+            e->init_pods[gi] += 1;
+            for (auto& pt : p.ports) {
+                if (pt.port <= 0) continue;
+                auto it = port_bit.find(sanitize(pt));
+                if (it != port_bit.end()) set_bit(e->init_excl, gi, Wx, it->second);
+            }
+            auto ob = pre_occ_bit.find(s);
+            if (ob != pre_occ_bit.end()) set_bit(e->init_excl, gi, Wx, ob->second);
+        }
+        for (auto& zk : zbit_key) {
+            if (zk.second.empty() || g.labels.count(zk.second)) set_bit(e->zone_valid, gi, Wz, zk.first);
+        }
+        for (size_t i = 0; i < G; ++i) if (existing_block[i][gi]) set_bit(e->init_zone, gi, Wz, static_zbit[i]);
+        any_explicit = any_explicit || g.has_pegs;
+    }
+    e->peg_off.clear(); e->peg_idx.clear();
+    if (any_explicit) {
+        e->peg_off.push_back(0);
+        for (auto& g : e->groups) {
+            for (int32_t pg : g.pegs) e->peg_idx.push_back(pg);
+            e->peg_off.push_back((int32_t)e->peg_idx.size());
+        }
+        if (e->peg_idx.empty()) e->peg_idx.push_back(0);  // keep a valid pointer
+    }
+    e->dict[0] = (int)taint_id.size(); e->dict[1] = (int)lreqs.size(); e->dict[2] = xbits.n; e->dict[3] = zbits.n;
+    e->finalized = true;
+    return CASIM_OK;
+}
+
+int32_t casim_enc_tables(const casim_encoder* e, casim_pegs* p, casim_groups* g) {
+    if (!e || !e->finalized || !p || !g) return CASIM_ERR_INVALID;
+    memset(p, 0, sizeof *p); memset(g, 0, sizeof *g);
+    p->n_pegs = (int32_t)e->pegs.size(); p->n_res = e->opt.n_res;
+    p->w_taint = e->Wt; p->w_label = e->Wl; p->w_excl = e->Wx; p->w_zone = e->Wz;
+    p->req = e->req.data(); p->count = e->count.data(); p->flags = e->pflags.data();
+    p->tol_mask = e->tol.data(); p->sel_mask = e->sel.data();
+    p->excl_block = e->xblock.data(); p->excl_mark = e->xmark.data();
+    p->zone_block = e->zblock.data(); p->zone_mark = e->zmark.data();
+    p->fp_cpu = e->fp_cpu.data(); p->fp_mem = e->fp_mem.data();
+    g->n_groups = (int32_t)e->groups.size();
+    g->alloc = e->alloc.data(); g->init_req = e->init_req.data(); g->allowed_pods = e->allowed.data(); g->init_pods = e->init_pods.data();
+    g->flags = e->gflags.data(); g->taint_mask = e->taint.data(); g->label_mask = e->label.data();
+    g->init_excl = e->init_excl.data(); g->init_zone = e->init_zone.data(); g->zone_valid = e->zone_valid.data();
+    g->max_nodes = e->max_nodes.data(); g->existing_nodes = e->existing_nodes.data(); g->last_index = e->last_index.data();
+    g->cap_cpu = e->cap_cpu.data(); g->cap_mem = e->cap_mem.data(); g->waste_cpu = e->waste_cpu.data(); g->waste_mem = e->waste_mem.data();
+    if (!e->peg_off.empty()) { g->peg_offsets = e->peg_off.data(); g->peg_index = e->peg_idx.data(); }
+    return CASIM_OK;
+}
+int32_t casim_enc_dict_sizes(const casim_encoder* e, int32_t sizes_out[4]) {
+    if (!e || !e->finalized || !sizes_out) return CASIM_ERR_INVALID;
+    for (int i = 0; i < 4; ++i) sizes_out[i] = e->dict[i];
+    return CASIM_OK;
+}
+
+}  // extern "C"

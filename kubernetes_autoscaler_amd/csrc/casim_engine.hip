@@ -1,0 +1,383 @@
+// casim_engine.hip — the product runtime: HIP backend for casim_pipeline.h + the C ABI of
+// include/casim.h (casim_ctx_*, casim_problem_*, ...).  gfx950 only; no CPU fallback: every
+// entry point fails with CASIM_ERR_NO_DEVICE when no HIP device is visible.
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "casim_pipeline.h"
+
+namespace {
+
+thread_local std::string g_err;
+int32_t set_err(int32_t code, const std::string& m) { g_err = m; return code; }
+
+struct HipBackend {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    size_t lds = 64 * 1024;
+    hipError_t last = hipSuccess;
+    std::string msg;
+
+    void check(hipError_t e, const char* what) {
+        if (e != hipSuccess && last == hipSuccess) { last = e; msg = std::string(what) + ": " + hipGetErrorString(e); }
+    }
+    void bind() { check(hipSetDevice(device), "hipSetDevice"); }
+    void* alloc(size_t b) { void* p = nullptr; check(hipMalloc(&p, b), "hipMalloc"); return p; }
+    void free(void* p) { if (p) (void)hipFree(p); }
+    void h2d(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D"); }
+    void d2h(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H"); }
+    void zero(void* d, size_t n) { if (n) check(hipMemsetAsync(d, 0, n, stream), "hipMemsetAsync"); }
+    void sync() { check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
+    size_t lds_budget() const { return lds; }
+    bool ok() const { return last == hipSuccess; }
+    const char* error() const { return msg.c_str(); }
+    void clear() { last = hipSuccess; msg.clear(); }
+
+    template <class K, class... A>
+    void launch(K kernel, int gx, int gy, int block, size_t smem, A... args) {
+        if (gx <= 0 || gy <= 0) return;
+        if (smem > 64 * 1024) {
+            // MI355X: 160 KiB LDS per CU; anything above the 64 KiB default needs the opt-in
+            check(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem), "hipFuncSetAttribute(LDS)");
+        }
+        hipLaunchKernelGGL(kernel, dim3((unsigned)gx, (unsigned)gy, 1), dim3((unsigned)block, 1, 1), smem, stream, args...);
+        check(hipGetLastError(), "kernel launch");
+    }
+};
+
+typedef casim::ProblemT<HipBackend> HipProblem;
+
+}  // namespace
+
+struct casim_ctx {
+    HipBackend bk;
+};
+struct casim_problem {
+    casim_ctx* ctx;
+    HipProblem* prob;
+    // dense-check scratch
+    uint64_t* d_dense = nullptr; size_t dense_bytes = 0;
+    int32_t* d_row_peg = nullptr; int64_t dense_rows = 0;
+};
+
+// ------------------------------------------------------------------------------------------
+// dense per-pod x per-node predicate kernel (streaming form of fits(); roofline probe and
+// building block of filter-out-schedulable)
+// ------------------------------------------------------------------------------------------
+namespace casim {
+
+// Column record staged in LDS: everything a column (= one simulated / existing node) contributes.
+struct DenseCol {
+    int64_t freepos[CASIM_KMAX_RES];  // max(free, 0): req <= freepos <=> (req == 0 || req <= free)   (fit.go:699-752)
+    uint64_t taint, label, excl, zone; // first word of each mask (dense probe supports W <= 1 per kind)
+    uint32_t flags;                    // bit0 unschedulable, bit1 no pod slot left
+    uint32_t pad;
+};
+
+// grid = (ceil(P/256), ceil(ncols/64/kColBlocksPerWG)); block = 256 threads = 256 rows (pods).
+// Each thread keeps its pod record in registers, walks 64 columns from LDS (broadcast reads) and
+// emits one uint64; the wave's 64 stores are contiguous (layout [col_block][row]).
+constexpr int kDenseColBlocks = 8;
+__global__ __launch_bounds__(256) void dense_check_kernel(DevTables t, const int32_t* __restrict__ row_peg, int64_t n_rows,
+                                                          int col_repeat, int64_t n_cols, uint64_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    DenseCol* cols = (DenseCol*)smem_raw;  // [64]
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = row < n_rows;
+    const int g = live ? row_peg[row] : 0;
+    int64_t req[CASIM_KMAX_RES];
+#pragma unroll
+    for (int r = 0; r < CASIM_KMAX_RES; ++r) req[r] = (live && r < t.R) ? t.req[(int64_t)g * t.R + r] : 0;
+    const uint64_t tol = t.Wt ? t.tol[(int64_t)g * t.Wt] : 0ull, sel = t.Wl ? t.sel[(int64_t)g * t.Wl] : 0ull;
+    const uint64_t xb = t.Wx ? t.xblock[(int64_t)g * t.Wx] : 0ull, zb = t.Wz ? t.zblock[(int64_t)g * t.Wz] : 0ull;
+    const uint32_t pf = live ? t.pflags[g] : CASIM_PEG_UNSUPPORTED;
+    const int64_t n_cb = (n_cols + 63) / 64;
+    for (int cbi = 0; cbi < kDenseColBlocks; ++cbi) {
+        const int64_t cb = (int64_t)blockIdx.y * kDenseColBlocks + cbi;
+        if (cb >= n_cb) break;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int64_t col = cb * 64 + threadIdx.x;
+            DenseCol c; memset(&c, 0, sizeof c);
+            if (col < n_cols) {
+                const int ng = (int)(col / col_repeat);
+                for (int r = 0; r < CASIM_KMAX_RES; ++r) {
+                    const int64_t f = r < t.R ? t.alloc[(int64_t)ng * t.R + r] - t.init_req[(int64_t)ng * t.R + r] : 0;
+                    c.freepos[r] = f > 0 ? f : 0;
+                }
+                c.taint = t.Wt ? t.taint[(int64_t)ng * t.Wt] : 0ull; c.label = t.Wl ? t.label[(int64_t)ng * t.Wl] : 0ull;
+                c.excl = t.Wx ? t.init_excl[(int64_t)ng * t.Wx] : 0ull; c.zone = t.Wz ? t.init_zone[(int64_t)ng * t.Wz] : 0ull;
+                c.flags = ((t.gflags[ng] & CASIM_NG_UNSCHEDULABLE) ? 1u : 0u) | ((t.allowed[ng] - t.init_pods[ng] < 1) ? 2u : 0u);
+            } else c.flags = 2u;
+            cols[threadIdx.x] = c;
+        }
+        __syncthreads();
+        uint64_t bits = 0;
+        if (!(pf & CASIM_PEG_UNSUPPORTED)) {
+#pragma unroll 4
+            for (int j = 0; j < 64; ++j) {
+                const DenseCol& c = cols[j];
+                bool ok = !(c.flags & 2u) && (!(c.flags & 1u) || (pf & CASIM_PEG_TOLERATES_UNSCHEDULABLE));
+                ok = ok && !(c.taint & ~tol) && !(sel & ~c.label) && !(xb & c.excl) && !(zb & c.zone);
+#pragma unroll
+                for (int r = 0; r < CASIM_KMAX_RES; ++r) ok = ok && (req[r] <= c.freepos[r]);
+                bits |= (uint64_t)ok << j;
+            }
+        }
+        if (live) out[cb * n_rows + row] = bits;
+    }
+}
+
+__global__ void expand_rows_kernel(const int32_t* __restrict__ count, int G, const int64_t* __restrict__ row_off, int32_t* __restrict__ row_peg) {
+    // one block per PEG writes its run of row -> PEG ids
+    const int g = blockIdx.x;
+    if (g >= G) return;
+    const int64_t a = row_off[g], n = count[g];
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) row_peg[a + i] = g;
+}
+
+__global__ void copy_probe_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+}  // namespace casim
+
+extern "C" {
+
+int32_t casim_abi_version(void) { return CASIM_ABI_VERSION; }
+const char* casim_last_error(void) { return g_err.c_str(); }
+
+int32_t casim_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+casim_ctx* casim_ctx_create(int32_t device, void* stream) {
+    g_err.clear();
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { set_err(CASIM_ERR_NO_DEVICE, "no HIP device visible: libcasim has no CPU path"); return nullptr; }
+    if (device < 0 || device >= n) { set_err(CASIM_ERR_INVALID, "device index out of range"); return nullptr; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_err(CASIM_ERR_HIP, "hipGetDeviceProperties failed"); return nullptr; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_err(CASIM_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", libcasim is built for gfx950 only");
+        return nullptr;
+    }
+    casim_ctx* c = new (std::nothrow) casim_ctx();
+    if (!c) { set_err(CASIM_ERR_NOMEM, "out of memory"); return nullptr; }
+    c->bk.device = device;
+    c->bk.bind();
+    if (stream) c->bk.stream = (hipStream_t)stream;
+    else { c->bk.check(hipStreamCreateWithFlags(&c->bk.stream, hipStreamNonBlocking), "hipStreamCreate"); c->bk.own_stream = true; }
+    // usable dynamic LDS per workgroup: 160 KiB on MI355X (keep a little headroom)
+    int optin = 0;
+    if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && optin > 0) c->bk.lds = (size_t)optin;
+    if (c->bk.lds > 160 * 1024) c->bk.lds = 160 * 1024;
+    if (!c->bk.ok()) { set_err(CASIM_ERR_HIP, c->bk.msg); delete c; return nullptr; }
+    return c;
+}
+void casim_ctx_destroy(casim_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->bk.device);
+    if (ctx->bk.own_stream && ctx->bk.stream) (void)hipStreamDestroy(ctx->bk.stream);
+    delete ctx;
+}
+
+casim_problem* casim_problem_create(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts) {
+    g_err.clear();
+    if (!ctx) { set_err(CASIM_ERR_INVALID, "null context"); return nullptr; }
+    ctx->bk.bind(); ctx->bk.clear();
+    casim_problem* p = new (std::nothrow) casim_problem();
+    if (!p) { set_err(CASIM_ERR_NOMEM, "out of memory"); return nullptr; }
+    p->ctx = ctx;
+    p->prob = new (std::nothrow) HipProblem(ctx->bk);
+    if (!p->prob) { delete p; set_err(CASIM_ERR_NOMEM, "out of memory"); return nullptr; }
+    const int32_t rc = p->prob->init(pegs, groups, opts);
+    if (rc != CASIM_OK) { set_err(rc, p->prob->error()); delete p->prob; delete p; return nullptr; }
+    return p;
+}
+void casim_problem_destroy(casim_problem* p) {
+    if (!p) return;
+    p->ctx->bk.bind();
+    (void)hipStreamSynchronize(p->ctx->bk.stream);
+    if (p->d_dense) (void)hipFree(p->d_dense);
+    if (p->d_row_peg) (void)hipFree(p->d_row_peg);
+    delete p->prob;
+    delete p;
+}
+
+#define PROB_ENTER(p)                                                            \
+    g_err.clear();                                                               \
+    if (!(p) || !(p)->prob) return set_err(CASIM_ERR_INVALID, "null problem");   \
+    (p)->ctx->bk.bind(); (p)->ctx->bk.clear()
+#define PROB_RET(p, rc) do { const int32_t _rc = (rc); if (_rc != CASIM_OK) set_err(_rc, (p)->prob->error()); return _rc; } while (0)
+
+int32_t casim_problem_run(casim_problem* p) { PROB_ENTER(p); PROB_RET(p, p->prob->run()); }
+int32_t casim_problem_fetch(casim_problem* p, casim_results* out) { PROB_ENTER(p); PROB_RET(p, p->prob->fetch(out)); }
+int32_t casim_problem_csr(casim_problem* p, int32_t* nnz_out, int32_t* offsets_out) { PROB_ENTER(p); PROB_RET(p, p->prob->csr(nnz_out, offsets_out)); }
+
+int32_t casim_estimate_batch(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts, casim_results* out) {
+    casim_problem* p = casim_problem_create(ctx, pegs, groups, opts);
+    if (!p) return g_err.empty() ? CASIM_ERR_INVALID : (casim_device_count() > 0 ? CASIM_ERR_INVALID : CASIM_ERR_NO_DEVICE);
+    int32_t rc = casim_problem_run(p);
+    if (rc == CASIM_OK) rc = casim_problem_fetch(p, out);
+    const std::string keep = g_err;
+    casim_problem_destroy(p);
+    g_err = keep;
+    return rc;
+}
+
+int32_t casim_feasibility(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups, uint64_t* out_bits) {
+    g_err.clear();
+    if (!ctx || !groups || !out_bits) return set_err(CASIM_ERR_INVALID, "null argument");
+    casim_groups g = *groups;
+    g.peg_offsets = nullptr; g.peg_index = nullptr;
+    casim_problem* p = casim_problem_create(ctx, pegs, &g, nullptr);
+    if (!p) return CASIM_ERR_INVALID;
+    int32_t rc = p->prob->run_feasibility();
+    if (rc == CASIM_OK) rc = p->prob->fetch_bits(out_bits);
+    if (rc != CASIM_OK) set_err(rc, p->prob->error());
+    const std::string keep = g_err;
+    casim_problem_destroy(p);
+    g_err = keep;
+    return rc;
+}
+
+int32_t casim_best_option(casim_problem* p, const int32_t* kinds, int32_t n_kinds, int32_t group_id_base, int32_t* best_ng_out,
+                          int32_t* n_best_out, uint8_t* best_set_out, int64_t* key_out, void* dev_key_out) {
+    PROB_ENTER(p);
+    PROB_RET(p, p->prob->best_option(kinds, n_kinds, group_id_base, best_ng_out, n_best_out, best_set_out, key_out, dev_key_out));
+}
+
+// ---- measurement -----------------------------------------------------------------------------
+int32_t casim_problem_time(casim_problem* p, int32_t iters, float* total_ms_out, float* kernel_ms_out) {
+    PROB_ENTER(p);
+    if (iters <= 0) return set_err(CASIM_ERR_INVALID, "iters must be > 0");
+    HipBackend& bk = p->ctx->bk;
+    hipEvent_t ev[4];
+    for (auto& e : ev) bk.check(hipEventCreate(&e), "hipEventCreate");
+    double tot = 0, kf = 0, ko = 0, kp = 0;
+    for (int i = 0; i < iters; ++i) {
+        bk.check(hipEventRecord(ev[0], bk.stream), "hipEventRecord");
+        p->prob->run_feasibility();
+        bk.check(hipEventRecord(ev[1], bk.stream), "hipEventRecord");
+        p->prob->run_order();
+        bk.check(hipEventRecord(ev[2], bk.stream), "hipEventRecord");
+        p->prob->run_pack();
+        bk.check(hipEventRecord(ev[3], bk.stream), "hipEventRecord");
+        bk.check(hipEventSynchronize(ev[3]), "hipEventSynchronize");
+        float a = 0, b = 0, c = 0, d = 0;
+        (void)hipEventElapsedTime(&a, ev[0], ev[3]); (void)hipEventElapsedTime(&b, ev[0], ev[1]);
+        (void)hipEventElapsedTime(&c, ev[1], ev[2]); (void)hipEventElapsedTime(&d, ev[2], ev[3]);
+        tot += a; kf += b; ko += c; kp += d;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    if (total_ms_out) *total_ms_out = (float)(tot / iters);
+    if (kernel_ms_out) { kernel_ms_out[0] = (float)(kf / iters); kernel_ms_out[1] = (float)(ko / iters); kernel_ms_out[2] = (float)(kp / iters); }
+    // mark as run so that fetch works after a timing loop
+    const int32_t rc = p->prob->run();
+    PROB_RET(p, rc != CASIM_OK ? rc : (bk.ok() ? CASIM_OK : CASIM_ERR_HIP));
+}
+
+static int32_t dense_prepare(casim_problem* p, int32_t col_repeat, int64_t* n_rows, int64_t* n_cols) {
+    HipBackend& bk = p->ctx->bk;
+    const DevTables& t = p->prob->tables();
+    if (col_repeat <= 0) return CASIM_ERR_INVALID;
+    if (t.Wt > 1 || t.Wl > 1 || t.Wx > 1 || t.Wz > 1) return CASIM_ERR_INVALID;  // dense probe: one word per mask kind
+    if (!p->d_row_peg) {
+        std::vector<int32_t> cnt((size_t)t.G);
+        bk.d2h(cnt.data(), t.count, 4 * (size_t)t.G); bk.sync();
+        std::vector<int64_t> off((size_t)t.G + 1, 0);
+        for (int i = 0; i < t.G; ++i) off[(size_t)i + 1] = off[(size_t)i] + cnt[(size_t)i];
+        p->dense_rows = off[(size_t)t.G];
+        int64_t* d_off = (int64_t*)bk.alloc(8 * ((size_t)t.G + 1));
+        bk.h2d(d_off, off.data(), 8 * ((size_t)t.G + 1));
+        p->d_row_peg = (int32_t*)bk.alloc(4 * (size_t)(p->dense_rows > 0 ? p->dense_rows : 1));
+        if (t.G > 0) bk.launch(casim::expand_rows_kernel, t.G, 1, 256, (size_t)0, t.count, t.G, (const int64_t*)d_off, p->d_row_peg);
+        bk.sync();
+        bk.free(d_off);
+    }
+    *n_rows = p->dense_rows;
+    *n_cols = (int64_t)t.NG * col_repeat;
+    const size_t need = (size_t)((*n_cols + 63) / 64) * (size_t)(*n_rows) * 8;
+    if (need > p->dense_bytes) {
+        if (p->d_dense) bk.free(p->d_dense);
+        p->d_dense = (uint64_t*)bk.alloc(need > 0 ? need : 8);
+        p->dense_bytes = need;
+    }
+    return bk.ok() ? CASIM_OK : CASIM_ERR_HIP;
+}
+static void dense_launch(casim_problem* p, int32_t col_repeat, int64_t n_rows, int64_t n_cols) {
+    HipBackend& bk = p->ctx->bk;
+    const int64_t n_cb = (n_cols + 63) / 64;
+    if (n_rows <= 0 || n_cb <= 0) return;
+    bk.launch(casim::dense_check_kernel, (int)((n_rows + 255) / 256), (int)((n_cb + casim::kDenseColBlocks - 1) / casim::kDenseColBlocks), 256,
+              sizeof(casim::DenseCol) * 64, p->prob->tables(), (const int32_t*)p->d_row_peg, n_rows, (int)col_repeat, n_cols, p->d_dense);
+}
+
+int32_t casim_problem_dense_check(casim_problem* p, int32_t col_repeat, uint64_t* out_bits, int64_t* n_rows_out, int64_t* n_cols_out) {
+    PROB_ENTER(p);
+    int64_t nr = 0, nc = 0;
+    int32_t rc = dense_prepare(p, col_repeat, &nr, &nc);
+    if (rc != CASIM_OK) return set_err(rc, p->ctx->bk.ok() ? "dense check: unsupported table shape (mask wider than one word?)" : p->ctx->bk.msg);
+    dense_launch(p, col_repeat, nr, nc);
+    if (n_rows_out) *n_rows_out = nr;
+    if (n_cols_out) *n_cols_out = nc;
+    if (out_bits) { p->ctx->bk.d2h(out_bits, p->d_dense, (size_t)((nc + 63) / 64) * (size_t)nr * 8); p->ctx->bk.sync(); }
+    return p->ctx->bk.ok() ? CASIM_OK : set_err(CASIM_ERR_HIP, p->ctx->bk.msg);
+}
+int32_t casim_problem_time_dense(casim_problem* p, int32_t col_repeat, int32_t iters, float* ms_out, int64_t* n_rows_out, int64_t* n_cols_out) {
+    PROB_ENTER(p);
+    if (iters <= 0) return set_err(CASIM_ERR_INVALID, "iters must be > 0");
+    int64_t nr = 0, nc = 0;
+    int32_t rc = dense_prepare(p, col_repeat, &nr, &nc);
+    if (rc != CASIM_OK) return set_err(rc, "dense check: unsupported table shape");
+    HipBackend& bk = p->ctx->bk;
+    hipEvent_t a, b;
+    bk.check(hipEventCreate(&a), "hipEventCreate"); bk.check(hipEventCreate(&b), "hipEventCreate");
+    dense_launch(p, col_repeat, nr, nc);  // warm-up
+    bk.check(hipEventRecord(a, bk.stream), "hipEventRecord");
+    for (int i = 0; i < iters; ++i) dense_launch(p, col_repeat, nr, nc);
+    bk.check(hipEventRecord(b, bk.stream), "hipEventRecord");
+    bk.check(hipEventSynchronize(b), "hipEventSynchronize");
+    float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    if (ms_out) *ms_out = ms / iters;
+    if (n_rows_out) *n_rows_out = nr;
+    if (n_cols_out) *n_cols_out = nc;
+    return bk.ok() ? CASIM_OK : set_err(CASIM_ERR_HIP, bk.msg);
+}
+
+int32_t casim_copy_bandwidth(casim_ctx* ctx, int64_t bytes, int32_t iters, double* gbps_out) {
+    g_err.clear();
+    if (!ctx || bytes < 4096 || iters <= 0 || !gbps_out) return set_err(CASIM_ERR_INVALID, "bad argument");
+    HipBackend& bk = ctx->bk; bk.bind(); bk.clear();
+    const int64_t n = bytes / 16;
+    uint4* a = (uint4*)bk.alloc((size_t)n * 16); uint4* b = (uint4*)bk.alloc((size_t)n * 16);
+    if (!bk.ok()) { bk.free(a); bk.free(b); return set_err(CASIM_ERR_HIP, bk.msg); }
+    bk.zero(a, (size_t)n * 16);
+    hipEvent_t e0, e1;
+    bk.check(hipEventCreate(&e0), "hipEventCreate"); bk.check(hipEventCreate(&e1), "hipEventCreate");
+    bk.launch(casim::copy_probe_kernel, 2048, 1, 256, (size_t)0, (const uint4*)a, b, n);
+    bk.check(hipEventRecord(e0, bk.stream), "hipEventRecord");
+    for (int i = 0; i < iters; ++i) bk.launch(casim::copy_probe_kernel, 2048, 1, 256, (size_t)0, (const uint4*)a, b, n);
+    bk.check(hipEventRecord(e1, bk.stream), "hipEventRecord");
+    bk.check(hipEventSynchronize(e1), "hipEventSynchronize");
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    bk.free(a); bk.free(b);
+    *gbps_out = ms > 0 ? (2.0 * (double)n * 16.0 * iters) / (ms * 1e-3) / 1e9 : 0.0;
+    return bk.ok() ? CASIM_OK : set_err(CASIM_ERR_HIP, bk.msg);
+}
+
+}  // extern "C"

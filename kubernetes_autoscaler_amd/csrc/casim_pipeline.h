@@ -1,0 +1,303 @@
+// casim_pipeline.h — host orchestration of one batch (upload, scratch sizing, launch sequence,
+// fetch), written once against a small Backend concept:
+//
+//   struct Backend {
+//     void*  alloc(size_t bytes);            // device memory (HBM)
+//     void   free(void* p);
+//     void   h2d(void* dst, const void* src, size_t bytes);   // async on the backend's stream
+//     void   d2h(void* dst, const void* src, size_t bytes);
+//     void   zero(void* dst, size_t bytes);
+//     void   sync();
+//     size_t lds_budget() const;             // dynamic LDS bytes one workgroup may ask for
+//     template <class K, class... A> void launch(K kernel, int gx, int gy, int block, size_t smem, A... args);
+//     bool   ok() const;  const char* error() const;
+//   };
+//
+// The product backend (casim_engine.hip) is the HIP runtime on a gfx950 device; tests/emu
+// provides a host backend that runs the same kernels under the wave emulator.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "casim_kernels.h"
+
+namespace casim {
+
+inline int64_t round_up64(int64_t v) { return (v + 63) & ~63ll; }
+
+template <class BK>
+class ProblemT {
+public:
+    explicit ProblemT(BK& bk) : bk_(bk) {}
+    ~ProblemT() { release(); }
+    ProblemT(const ProblemT&) = delete;
+    ProblemT& operator=(const ProblemT&) = delete;
+
+    // ---- upload -----------------------------------------------------------------------
+    int32_t init(const casim_pegs* p, const casim_groups* g, const casim_options* o) {
+        if (!p || !g) return fail(CASIM_ERR_INVALID, "null table");
+        if (p->n_pegs < 0 || g->n_groups < 0) return fail(CASIM_ERR_INVALID, "negative size");
+        if (p->n_res < 2 || p->n_res > CASIM_KMAX_RES) return fail(CASIM_ERR_INVALID, "n_res must be in [2, 8]");
+        if (p->w_taint < 0 || p->w_label < 0 || p->w_excl < 0 || p->w_zone < 0) return fail(CASIM_ERR_INVALID, "negative mask width");
+        G_ = p->n_pegs; NG_ = g->n_groups;
+        memset(&dt_, 0, sizeof dt_); memset(&dr_, 0, sizeof dr_); memset(&ps_, 0, sizeof ps_); memset(&os_, 0, sizeof os_);
+        dt_.G = G_; dt_.R = p->n_res; dt_.Wt = p->w_taint; dt_.Wl = p->w_label; dt_.Wx = p->w_excl; dt_.Wz = p->w_zone;
+        dt_.NG = NG_; dt_.fastpath = o ? o->fastpath : 0;
+        const int R = dt_.R;
+        const size_t G = (size_t)G_, NG = (size_t)NG_;
+        if (G > 0 && (!p->req || !p->count || !p->flags)) return fail(CASIM_ERR_INVALID, "PEG table has null columns");
+        if (NG > 0 && (!g->alloc || !g->init_req || !g->allowed_pods || !g->init_pods || !g->flags || !g->max_nodes ||
+                       !g->existing_nodes || !g->last_index))
+            return fail(CASIM_ERR_INVALID, "group table has null columns");
+        if (G > 0 && ((dt_.Wt && !p->tol_mask) || (dt_.Wl && !p->sel_mask) || (dt_.Wx && (!p->excl_block || !p->excl_mark)) ||
+                      (dt_.Wz && (!p->zone_block || !p->zone_mark))))
+            return fail(CASIM_ERR_INVALID, "PEG mask column missing");
+        if (NG > 0 && ((dt_.Wt && !g->taint_mask) || (dt_.Wl && !g->label_mask) || (dt_.Wx && !g->init_excl) || (dt_.Wz && (!g->init_zone || !g->zone_valid))))
+            return fail(CASIM_ERR_INVALID, "group mask column missing");
+        if (dt_.fastpath && (!p->fp_cpu || !p->fp_mem || !g->cap_cpu || !g->cap_mem))
+            return fail(CASIM_ERR_INVALID, "fastpath needs fp_cpu/fp_mem/cap_cpu/cap_mem");
+
+        dt_.req = up(p->req, G * R); dt_.count = up(p->count, G); dt_.pflags = up(p->flags, G);
+        dt_.tol = up(p->tol_mask, G * dt_.Wt); dt_.sel = up(p->sel_mask, G * dt_.Wl);
+        dt_.xblock = up(p->excl_block, G * dt_.Wx); dt_.xmark = up(p->excl_mark, G * dt_.Wx);
+        dt_.zblock = up(p->zone_block, G * dt_.Wz); dt_.zmark = up(p->zone_mark, G * dt_.Wz);
+        dt_.fp_cpu = p->fp_cpu ? up(p->fp_cpu, G) : nullptr; dt_.fp_mem = p->fp_mem ? up(p->fp_mem, G) : nullptr;
+        dt_.alloc = up(g->alloc, NG * R); dt_.init_req = up(g->init_req, NG * R);
+        dt_.allowed = up(g->allowed_pods, NG); dt_.init_pods = up(g->init_pods, NG); dt_.gflags = up(g->flags, NG);
+        dt_.taint = up(g->taint_mask, NG * dt_.Wt); dt_.label = up(g->label_mask, NG * dt_.Wl);
+        dt_.init_excl = up(g->init_excl, NG * dt_.Wx); dt_.init_zone = up(g->init_zone, NG * dt_.Wz); dt_.zone_valid = up(g->zone_valid, NG * dt_.Wz);
+        dt_.max_nodes = up(g->max_nodes, NG); dt_.existing = up(g->existing_nodes, NG); dt_.last_index = up(g->last_index, NG);
+        dt_.cap_cpu = g->cap_cpu ? up(g->cap_cpu, NG) : nullptr; dt_.cap_mem = g->cap_mem ? up(g->cap_mem, NG) : nullptr;
+        dt_.waste_cpu = g->waste_cpu ? up(g->waste_cpu, NG) : nullptr; dt_.waste_mem = g->waste_mem ? up(g->waste_mem, NG) : nullptr;
+
+        // ---- schedulable subsets ----
+        csr_on_device_ = g->peg_offsets == nullptr;
+        std::vector<int64_t> pods_of_group(NG, 0);  // sum of max(count, 1) over the group's PEGs (node bound)
+        std::vector<int32_t> pegs_of_group(NG, 0);
+        if (!csr_on_device_) {
+            if (NG > 0 && g->peg_offsets[0] != 0) return fail(CASIM_ERR_INVALID, "peg_offsets[0] != 0");
+            nnz_cap_ = NG > 0 ? g->peg_offsets[NG] : 0;
+            for (size_t i = 0; i < NG; ++i) {
+                const int32_t a = g->peg_offsets[i], b = g->peg_offsets[i + 1];
+                if (b < a) return fail(CASIM_ERR_INVALID, "peg_offsets not monotone");
+                pegs_of_group[i] = b - a;
+                for (int32_t k = a; k < b; ++k) {
+                    const int32_t pg = g->peg_index[k];
+                    if (pg < 0 || pg >= G_) return fail(CASIM_ERR_INVALID, "peg_index out of range");
+                    if (p->count[pg] < 0) return fail(CASIM_ERR_INVALID, "negative PEG count");
+                    pods_of_group[i] += p->count[pg] > 1 ? p->count[pg] : 1;
+                }
+            }
+            h_off_.assign(g->peg_offsets, g->peg_offsets + NG + 1);
+            dt_.peg_off = up(g->peg_offsets, NG + 1);
+            dt_.peg_idx = up(g->peg_index, (size_t)nnz_cap_);
+        } else {
+            const int64_t cap = (int64_t)G_ * (int64_t)NG_;
+            if (cap > 0x7fffffffll) return fail(CASIM_ERR_INVALID, "G x NG too large for device-side CSR");
+            nnz_cap_ = (int32_t)cap;
+            int64_t all = 0;
+            for (size_t i = 0; i < G; ++i) { if (p->count[i] < 0) return fail(CASIM_ERR_INVALID, "negative PEG count"); all += p->count[i] > 1 ? p->count[i] : 1; }
+            for (size_t i = 0; i < NG; ++i) { pods_of_group[i] = all; pegs_of_group[i] = G_; }
+            Wg_ = (G_ + 63) / 64;
+            d_bits_ = (uint64_t*)dalloc(sizeof(uint64_t) * NG * (size_t)Wg_);
+            d_counts_ = (int32_t*)dalloc(sizeof(int32_t) * (NG + 1));
+            d_off_ = (int32_t*)dalloc(sizeof(int32_t) * (NG + 1));
+            d_idx_ = (int32_t*)dalloc(sizeof(int32_t) * (size_t)nnz_cap_);
+            dt_.peg_off = d_off_; dt_.peg_idx = d_idx_;
+        }
+
+        // ---- packer state geometry ----
+        std::vector<int32_t> cap(NG);
+        std::vector<int64_t> soff(NG);
+        int64_t total = 0, worst = 0;
+        for (size_t i = 0; i < NG; ++i) {
+            int64_t n = g->max_nodes[i] > 0 ? (int64_t)g->max_nodes[i] : (g->max_nodes[i] < 0 ? 0 : pods_of_group[i]);
+            if (g->max_nodes[i] > 0 && pods_of_group[i] < n) n = pods_of_group[i];  // never more nodes than pods (+ empty ones)
+            n = round_up64(n + 1);
+            if (n > 0x3fffffffll) return fail(CASIM_ERR_INVALID, "node bound too large");
+            cap[i] = (int32_t)n;
+            const int64_t bytes = casim_pack_state_bytes(R, dt_.Wx, dt_.Wz, n);
+            soff[i] = total; total += (bytes + 255) & ~255ll;
+            worst = bytes > worst ? bytes : worst;
+        }
+        pack_smem_ = (size_t)worst;
+        pack_lds_ = worst <= (int64_t)bk_.lds_budget();
+        ps_.node_cap = up(cap.data(), NG);
+        if (!pack_lds_) {
+            ps_.state_off = up(soff.data(), NG);
+            ps_.gstate = (char*)dalloc((size_t)total);
+        }
+        // ---- order scratch geometry ----
+        std::vector<int64_t> ooff(NG);
+        int64_t ototal = 0, oworst = 0;
+        for (size_t i = 0; i < NG; ++i) {
+            int64_t npad = 1;
+            while (npad < pegs_of_group[i]) npad <<= 1;
+            const int64_t bytes = npad * 12 + 8 + 8 * kOrderThreads;
+            ooff[i] = ototal; ototal += (bytes + 255) & ~255ll;
+            oworst = bytes > oworst ? bytes : oworst;
+        }
+        order_smem_ = (size_t)oworst;
+        order_lds_ = oworst <= (int64_t)bk_.lds_budget();
+        if (!order_lds_) {
+            os_.off = up(ooff.data(), NG);
+            os_.gbuf = (char*)dalloc((size_t)ototal);
+        }
+        // ---- results ----
+        dr_.node_count = (int32_t*)dalloc(4 * NG); dr_.pods = (int32_t*)dalloc(4 * NG); dr_.nodes_added = (int32_t*)dalloc(4 * NG);
+        dr_.limiter_nodes = (int32_t*)dalloc(4 * NG); dr_.last_index_out = (int32_t*)dalloc(4 * NG); dr_.status = (int32_t*)dalloc(4 * NG);
+        dr_.cpu_sum = (int64_t*)dalloc(8 * NG); dr_.mem_sum = (int64_t*)dalloc(8 * NG);
+        dr_.order = (int32_t*)dalloc(4 * (size_t)nnz_cap_); dr_.placed = (int32_t*)dalloc(4 * (size_t)nnz_cap_);
+        dr_.fast_last = (uint8_t*)dalloc(NG);
+        d_opt_set_ = (uint8_t*)dalloc(NG);
+        d_opt_out_ = (int32_t*)dalloc(16);
+        d_opt_key_ = (int64_t*)dalloc(16);
+        if (!bk_.ok()) return fail(CASIM_ERR_HIP, bk_.error());
+        ready_ = true;
+        return CASIM_OK;
+    }
+
+    // ---- launch sequence ----------------------------------------------------------------
+    int32_t run_feasibility() {
+        if (!csr_on_device_ || NG_ == 0) return CASIM_OK;
+        if (G_ > 0) bk_.launch(feas_kernel, (G_ + 255) / 256, NG_, 256, (size_t)0, dt_, d_bits_, Wg_);
+        bk_.launch(csr_count_kernel, NG_, 1, 256, (size_t)64, (const uint64_t*)d_bits_, Wg_, d_counts_);
+        bk_.launch(csr_scan_kernel, 1, 1, 64, (size_t)0, (const int32_t*)d_counts_, NG_, d_off_);
+        bk_.launch(csr_fill_kernel, NG_, 1, 64, (size_t)0, (const uint64_t*)d_bits_, Wg_, (const int32_t*)d_off_, d_idx_);
+        return CASIM_OK;
+    }
+    int32_t run_order() {
+        if (NG_ == 0) return CASIM_OK;
+        if (order_lds_) bk_.launch(order_kernel<true>, NG_, 1, kOrderThreads, order_smem_, dt_, dr_, os_);
+        else bk_.launch(order_kernel<false>, NG_, 1, kOrderThreads, (size_t)0, dt_, dr_, os_);
+        return CASIM_OK;
+    }
+    int32_t run_pack() {
+        if (NG_ == 0) return CASIM_OK;
+        if (pack_lds_) bk_.launch(pack_kernel<true>, NG_, 1, 64, pack_smem_, dt_, dr_, ps_);
+        else bk_.launch(pack_kernel<false>, NG_, 1, 64, (size_t)0, dt_, dr_, ps_);
+        return CASIM_OK;
+    }
+    int32_t run() {
+        if (!ready_) return fail(CASIM_ERR_INVALID, "problem not initialised");
+        run_feasibility(); run_order(); run_pack();
+        ran_ = true;
+        return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
+    }
+
+    int32_t csr(int32_t* nnz_out, int32_t* offsets_out) {
+        if (!ready_) return fail(CASIM_ERR_INVALID, "problem not initialised");
+        if (csr_on_device_) {
+            if (!ran_) return fail(CASIM_ERR_INVALID, "run the problem first");
+            h_off_.resize((size_t)NG_ + 1);
+            bk_.d2h(h_off_.data(), d_off_, 4 * ((size_t)NG_ + 1));
+            bk_.sync();
+        }
+        if (nnz_out) *nnz_out = NG_ > 0 ? h_off_[(size_t)NG_] : 0;
+        if (offsets_out && NG_ >= 0) for (int i = 0; i <= NG_; ++i) offsets_out[i] = h_off_.empty() ? 0 : h_off_[(size_t)i];
+        return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
+    }
+
+    int32_t fetch(casim_results* out) {
+        if (!ready_ || !ran_) return fail(CASIM_ERR_INVALID, "nothing to fetch: run the problem first");
+        if (!out) return fail(CASIM_ERR_INVALID, "null results");
+        int32_t nnz = 0;
+        const int32_t rc = csr(&nnz, nullptr);
+        if (rc != CASIM_OK) return rc;
+        const size_t NG = (size_t)NG_;
+        if (out->node_count) bk_.d2h(out->node_count, dr_.node_count, 4 * NG);
+        if (out->pods_scheduled) bk_.d2h(out->pods_scheduled, dr_.pods, 4 * NG);
+        if (out->nodes_added) bk_.d2h(out->nodes_added, dr_.nodes_added, 4 * NG);
+        if (out->limiter_nodes) bk_.d2h(out->limiter_nodes, dr_.limiter_nodes, 4 * NG);
+        if (out->last_index_out) bk_.d2h(out->last_index_out, dr_.last_index_out, 4 * NG);
+        if (out->status) bk_.d2h(out->status, dr_.status, 4 * NG);
+        if (out->req_cpu_sum) bk_.d2h(out->req_cpu_sum, dr_.cpu_sum, 8 * NG);
+        if (out->req_mem_sum) bk_.d2h(out->req_mem_sum, dr_.mem_sum, 8 * NG);
+        if (out->order) bk_.d2h(out->order, dr_.order, 4 * (size_t)nnz);
+        if (out->placed) bk_.d2h(out->placed, dr_.placed, 4 * (size_t)nnz);
+        bk_.sync();
+        return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
+    }
+
+    // bit-matrix [NG][ceil(G/64)] of the last run_feasibility()
+    int32_t fetch_bits(uint64_t* out_bits) {
+        if (!csr_on_device_) return fail(CASIM_ERR_INVALID, "feasibility was not computed on the device");
+        bk_.d2h(out_bits, d_bits_, sizeof(uint64_t) * (size_t)NG_ * (size_t)Wg_);
+        bk_.sync();
+        return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
+    }
+
+    int32_t best_option(const int32_t* kinds, int32_t n_kinds, int32_t group_id_base, int32_t* best_ng_out, int32_t* n_best_out,
+                        uint8_t* best_set_out, int64_t* key_out, void* dev_key_out) {
+        if (!ready_ || !ran_) return fail(CASIM_ERR_INVALID, "run the problem first");
+        if (n_kinds < 0 || n_kinds > 8 || (n_kinds > 0 && !kinds)) return fail(CASIM_ERR_INVALID, "bad expander chain");
+        OptionArgs a; memset(&a, 0, sizeof a);
+        a.node_count = dr_.node_count; a.pods = dr_.pods; a.status = dr_.status; a.cpu_sum = dr_.cpu_sum; a.mem_sum = dr_.mem_sum;
+        a.waste_cpu = dt_.waste_cpu; a.waste_mem = dt_.waste_mem; a.NG = NG_; a.n_kinds = n_kinds; a.group_id_base = group_id_base;
+        for (int i = 0; i < n_kinds; ++i) {
+            a.kinds[i] = kinds[i];
+            if (kinds[i] < 0 || kinds[i] > 2) return fail(CASIM_ERR_INVALID, "unknown expander kind");
+            if (kinds[i] == CASIM_EXPANDER_LEAST_WASTE && (!dt_.waste_cpu || !dt_.waste_mem)) return fail(CASIM_ERR_INVALID, "least-waste needs waste_cpu/waste_mem");
+        }
+        a.best_set = d_opt_set_; a.out = d_opt_out_; a.key_out = dev_key_out ? (int64_t*)dev_key_out : d_opt_key_;
+        bk_.launch(option_kernel, 1, 1, 256, (size_t)(8 * 256), a);
+        if (best_ng_out || n_best_out || best_set_out || key_out) {
+            int32_t o[2] = {-1, 0};
+            bk_.d2h(o, d_opt_out_, 8);
+            if (best_set_out) bk_.d2h(best_set_out, d_opt_set_, (size_t)NG_);
+            int64_t kk[2] = {0, 0};
+            if (key_out) bk_.d2h(kk, a.key_out, 16);
+            bk_.sync();
+            if (best_ng_out) *best_ng_out = o[0];
+            if (n_best_out) *n_best_out = o[1];
+            if (key_out) { key_out[0] = kk[0]; key_out[1] = kk[1]; }
+        }
+        return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
+    }
+
+    const std::string& error() const { return err_; }
+    BK& backend() { return bk_; }
+    const DevTables& tables() const { return dt_; }
+    int groups() const { return NG_; }
+    int pegs() const { return G_; }
+    bool csr_on_device() const { return csr_on_device_; }
+    bool pack_in_lds() const { return pack_lds_; }
+    static constexpr int kOrderThreads = 256;
+
+private:
+    template <class T>
+    const T* up(const T* src, size_t n) {
+        if (n == 0 || !src) return nullptr;
+        T* d = (T*)dalloc(sizeof(T) * n);
+        if (d) bk_.h2d(d, src, sizeof(T) * n);
+        return d;
+    }
+    void* dalloc(size_t bytes) {
+        if (bytes == 0) bytes = 8;
+        void* p = bk_.alloc(bytes);
+        if (p) allocs_.push_back(p);
+        return p;
+    }
+    void release() {
+        for (void* p : allocs_) bk_.free(p);
+        allocs_.clear();
+    }
+    int32_t fail(int32_t code, const char* msg) { err_ = msg ? msg : ""; return code; }
+
+    BK& bk_;
+    DevTables dt_; DevResults dr_; PackScratch ps_; OrderScratch os_;
+    int G_ = 0, NG_ = 0, Wg_ = 0;
+    int32_t nnz_cap_ = 0;
+    bool csr_on_device_ = false, pack_lds_ = true, order_lds_ = true, ready_ = false, ran_ = false;
+    size_t pack_smem_ = 0, order_smem_ = 0;
+    uint64_t* d_bits_ = nullptr; int32_t* d_counts_ = nullptr; int32_t* d_off_ = nullptr; int32_t* d_idx_ = nullptr;
+    uint8_t* d_opt_set_ = nullptr; int32_t* d_opt_out_ = nullptr; int64_t* d_opt_key_ = nullptr;
+    std::vector<int32_t> h_off_;
+    std::vector<void*> allocs_;
+    std::string err_;
+};
+
+}  // namespace casim

@@ -1,0 +1,76 @@
+// casim_types.h — plain-old-data argument blocks shared by the host runtime and the kernels.
+#pragma once
+#include <stdint.h>
+
+#define CASIM_KMAX_RES 8
+
+// Device-resident copy of casim_pegs + casim_groups (include/casim.h), structure of arrays.
+struct DevTables {
+    int32_t G, R, Wt, Wl, Wx, Wz, NG;
+    int32_t fastpath;
+    // PEG table
+    const int64_t* req;      // [G][R]
+    const int32_t* count;    // [G]
+    const uint32_t* pflags;  // [G]
+    const uint64_t* tol;     // [G][Wt]
+    const uint64_t* sel;     // [G][Wl]
+    const uint64_t* xblock;  // [G][Wx]
+    const uint64_t* xmark;   // [G][Wx]
+    const uint64_t* zblock;  // [G][Wz]
+    const uint64_t* zmark;   // [G][Wz]
+    const double* fp_cpu;    // [G] or null
+    const double* fp_mem;    // [G] or null
+    // node-group table
+    const int64_t* alloc;     // [NG][R]
+    const int64_t* init_req;  // [NG][R]
+    const int32_t* allowed;   // [NG]
+    const int32_t* init_pods; // [NG]
+    const uint32_t* gflags;   // [NG]
+    const uint64_t* taint;    // [NG][Wt]
+    const uint64_t* label;    // [NG][Wl]
+    const uint64_t* init_excl;// [NG][Wx]
+    const uint64_t* init_zone;// [NG][Wz]
+    const uint64_t* zone_valid;// [NG][Wz]
+    const int32_t* max_nodes; // [NG]
+    const int32_t* existing;  // [NG]
+    const int32_t* last_index;// [NG]
+    const double* cap_cpu;    // [NG] or null
+    const double* cap_mem;    // [NG] or null
+    const int64_t* waste_cpu; // [NG] or null
+    const int64_t* waste_mem; // [NG] or null
+    // schedulable subsets (CSR), device memory
+    const int32_t* peg_off;   // [NG+1]
+    const int32_t* peg_idx;   // [nnz]
+};
+
+struct DevResults {
+    int32_t* node_count;
+    int32_t* pods;
+    int32_t* nodes_added;
+    int32_t* limiter_nodes;
+    int32_t* last_index_out;
+    int32_t* status;
+    int64_t* cpu_sum;
+    int64_t* mem_sum;
+    int32_t* order;      // [nnz]
+    int32_t* placed;     // [nnz]
+    uint8_t* fast_last;  // [NG] 1 => fastpath applies to the last PEG of the sorted list
+};
+
+// Per-group scratch geometry of the packer: simulated-node state lives in LDS when every
+// group of the launch fits, else in an HBM scratch slab.
+struct PackScratch {
+    const int32_t* node_cap;   // [NG] node slots reserved for the group (multiple of 64)
+    const int64_t* state_off;  // [NG] byte offset into gstate (global variant)
+    char* gstate;              // HBM slab (global variant) or null
+};
+
+struct OrderScratch {
+    const int64_t* off;  // [NG] byte offset into gbuf (global variant)
+    char* gbuf;
+};
+
+// bytes of packer state per simulated node (8-byte fields first)
+static inline int64_t casim_pack_state_bytes(int R, int Wx, int Wz, int64_t cap) {
+    return cap * (8ll * R + 8ll * Wx + 12ll) + 64ll * 8ll * (Wz > 0 ? Wz : 1);
+}

@@ -1,0 +1,150 @@
+"""Python driver of the C++ host encoder (casim_enc_* in include/casim.h).
+
+It walks pod / node-template objects exactly the way the cgo shim of INTEGRATION.md does and
+returns flat tables (ctypes views owned by the C++ encoder)."""
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+from . import _abi
+from ._ffi import check, lib
+from .objects import NodeInfo, Pod, PodEquivalenceGroup, RES_CPU, RES_EPHEMERAL, RES_MEMORY
+
+DEFAULT_LANES = (RES_CPU, RES_MEMORY)
+
+
+def _b(s: str) -> bytes:
+    return (s or "").encode("utf-8")
+
+
+def _strs(values: Sequence[str]):
+    arr = (C.c_char_p * max(len(values), 1))()
+    for i, v in enumerate(values):
+        arr[i] = _b(v)
+    return arr
+
+
+class Encoder:
+    """One encoder instance == one scale-up loop's worth of PEGs and node groups."""
+
+    def __init__(self, lanes: Sequence[str] = DEFAULT_LANES, enable_taint_comparison_ops: bool = False):
+        if len(lanes) < 2 or len(lanes) > _abi.MAX_RES or lanes[0] != RES_CPU or lanes[1] != RES_MEMORY:
+            raise ValueError("lanes must start with ('cpu', 'memory') and have 2..8 entries")
+        self.lanes = tuple(lanes)
+        opts = _abi.EncoderOptions(n_res=len(lanes), enable_taint_comparison_ops=int(enable_taint_comparison_ops))
+        self._h = lib.casim_enc_create(C.byref(opts))
+        if not self._h:
+            raise MemoryError("casim_enc_create failed")
+        self._spec_of: Dict[int, int] = {}      # id(pod object) -> spec id (PEGs repeat one pointer)
+        self._keep: List[object] = []
+        self.finalized = False
+        self.n_pegs = 0
+        self.n_groups = 0
+
+    def close(self):
+        if self._h:
+            lib.casim_enc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- pods ---------------------------------------------------------------------------
+    def _lane_vector(self, res: Dict[str, int]):
+        vec = (C.c_int64 * _abi.MAX_RES)()
+        for i, name in enumerate(self.lanes):
+            vec[i] = int(res.get(name, 0))
+        return vec
+
+    def add_pod_spec(self, pod: Pod) -> int:
+        key = id(pod)
+        if key in self._spec_of:
+            return self._spec_of[key]
+        self._keep.append(pod)
+        h = self._h
+        unknown = [r for r, v in pod.requests.items() if r not in self.lanes and v]
+        s = lib.casim_enc_add_pod_spec(h, _b(pod.namespace), self._lane_vector(pod.requests))
+        if s < 0:
+            check(s, "casim_enc_add_pod_spec")
+        for k, v in pod.labels.items():
+            check(lib.casim_enc_pod_add_label(h, s, _b(k), _b(v)))
+        for t in pod.tolerations:
+            check(lib.casim_enc_pod_add_toleration(h, s, _b(t.key), _b(t.operator), _b(t.value), _b(t.effect)))
+        for k, v in pod.node_selector.items():
+            check(lib.casim_enc_pod_add_node_selector(h, s, _b(k), _b(v)))
+        for r in pod.node_affinity:
+            check(lib.casim_enc_pod_add_node_affinity_req(h, s, _b(r.key), _b(r.operator), _strs(r.values), len(r.values)))
+        for p in pod.host_ports:
+            check(lib.casim_enc_pod_add_host_port(h, s, _b(p.host_ip), _b(p.protocol), int(p.host_port)))
+        for term in pod.anti_affinity:
+            t = lib.casim_enc_pod_add_anti_affinity_term(h, s, _b(term.topology_key), _strs(term.namespaces), len(term.namespaces))
+            if t < 0:
+                check(t, "casim_enc_pod_add_anti_affinity_term")
+            for r in term.requirements():
+                check(lib.casim_enc_term_add_requirement(h, s, t, _b(r.key), _b(r.operator), _strs(r.values), len(r.values)))
+        cpu, mem = pod.fastpath_requests()
+        check(lib.casim_enc_pod_set_fastpath_requests(h, s, cpu, mem))
+        if pod.topology_spread:
+            check(lib.casim_enc_pod_mark_unsupported(h, s, b"topologySpreadConstraints"))
+        if pod.unsupported_reason:
+            check(lib.casim_enc_pod_mark_unsupported(h, s, _b(pod.unsupported_reason)))
+        if unknown:
+            check(lib.casim_enc_pod_mark_unsupported(h, s, _b("resource not in lanes: " + ",".join(unknown))))
+        self._spec_of[key] = s
+        return s
+
+    def add_peg(self, peg: PodEquivalenceGroup) -> int:
+        ex = peg.exemplar()
+        if ex is None:
+            # an empty group still occupies a slot of the orderer (score 0, Exemplar() == nil)
+            ex = Pod(name="<empty>")
+        s = self.add_pod_spec(ex)
+        g = lib.casim_enc_add_peg(self._h, s, len(peg.pods))
+        if g < 0:
+            check(g, "casim_enc_add_peg")
+        self.n_pegs += 1
+        return g
+
+    # ---- node groups -----------------------------------------------------------------------
+    def add_group(self, template: NodeInfo, max_nodes: int = 0, existing_nodes: int = 0, last_index: int = 0,
+                  pegs: Optional[Sequence[int]] = None) -> int:
+        node = template.node
+        unknown = [r for r in node.allocatable if r not in self.lanes and r != "pods"]
+        del unknown  # extra node resources nobody requests are irrelevant to the Filters
+        g = lib.casim_enc_add_group(self._h, _b(node.name), self._lane_vector(node.allocatable), node.allowed_pods(),
+                                    int(node.capacity.get(RES_CPU, 0)), int(node.capacity.get(RES_MEMORY, 0)),
+                                    int(node.unschedulable))
+        if g < 0:
+            check(g, "casim_enc_add_group")
+        for k, v in node.labels.items():
+            check(lib.casim_enc_group_add_label(self._h, g, _b(k), _b(v)))
+        for t in node.taints:
+            check(lib.casim_enc_group_add_taint(self._h, g, _b(t.key), _b(t.value), _b(t.effect)))
+        check(lib.casim_enc_group_set_limits(self._h, g, int(max_nodes), int(existing_nodes), int(last_index)))
+        for p in template.pods:
+            check(lib.casim_enc_group_add_preloaded_pod(self._h, g, self.add_pod_spec(p)))
+        if pegs is not None:
+            arr = (C.c_int32 * max(len(pegs), 1))(*pegs)
+            check(lib.casim_enc_group_set_pegs(self._h, g, arr, len(pegs)))
+        self.n_groups += 1
+        return g
+
+    def add_existing_pod(self, pod: Pod, node_labels: Dict[str, str]):
+        ks, vs = list(node_labels.keys()), list(node_labels.values())
+        check(lib.casim_enc_add_existing_pod(self._h, self.add_pod_spec(pod), _strs(ks), _strs(vs), len(ks)))
+
+    # ---- tables ----------------------------------------------------------------------------
+    def finalize(self):
+        check(lib.casim_enc_finalize(self._h), "casim_enc_finalize")
+        self.finalized = True
+        self.pegs = _abi.Pegs()
+        self.groups = _abi.Groups()
+        check(lib.casim_enc_tables(self._h, C.byref(self.pegs), C.byref(self.groups)))
+        return self.pegs, self.groups
+
+    def dict_sizes(self):
+        out = (C.c_int32 * 4)()
+        check(lib.casim_enc_dict_sizes(self._h, out))
+        return {"taints": out[0], "label_requirements": out[1], "node_bits": out[2], "zone_bits": out[3]}

@@ -1,0 +1,182 @@
+"""Python binding of the ENGINE half of include/casim.h: contexts, resident problems, results.
+
+Every call goes through the C ABI into the HIP kernels of libcasim.so.  Nothing here computes a
+result on the host; without an MI355X `Context()` raises NoDeviceError."""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+from ._ffi import CasimError, NoDeviceError, check, last_error, lib  # noqa: F401
+
+
+def _ptr(a: np.ndarray, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+@dataclass
+class BatchResult:
+    """Results of one batch: one entry per node group (= one Estimate() call)."""
+    offsets: np.ndarray          # [NG+1] CSR offsets of order/placed
+    node_count: np.ndarray       # len(newNodesWithPods)
+    pods_scheduled: np.ndarray
+    nodes_added: np.ndarray
+    limiter_nodes: np.ndarray
+    last_index_out: np.ndarray
+    status: np.ndarray
+    req_cpu_sum: np.ndarray
+    req_mem_sum: np.ndarray
+    order: np.ndarray            # [nnz] PEG id processed k-th within its group
+    placed: np.ndarray           # [nnz] pods of that PEG that were scheduled (a prefix)
+
+    def group(self, i: int):
+        a, b = int(self.offsets[i]), int(self.offsets[i + 1])
+        return self.order[a:b], self.placed[a:b]
+
+
+def alloc_results(n_groups: int, nnz: int):
+    ng = max(n_groups, 1)
+    arrs = dict(
+        node_count=np.zeros(ng, np.int32), pods_scheduled=np.zeros(ng, np.int32), nodes_added=np.zeros(ng, np.int32),
+        limiter_nodes=np.zeros(ng, np.int32), last_index_out=np.zeros(ng, np.int32), status=np.zeros(ng, np.int32),
+        req_cpu_sum=np.zeros(ng, np.int64), req_mem_sum=np.zeros(ng, np.int64),
+        order=np.zeros(max(nnz, 1), np.int32), placed=np.zeros(max(nnz, 1), np.int32))
+    st = _abi.Results(
+        node_count=_ptr(arrs["node_count"], C.c_int32), pods_scheduled=_ptr(arrs["pods_scheduled"], C.c_int32),
+        nodes_added=_ptr(arrs["nodes_added"], C.c_int32), limiter_nodes=_ptr(arrs["limiter_nodes"], C.c_int32),
+        last_index_out=_ptr(arrs["last_index_out"], C.c_int32), status=_ptr(arrs["status"], C.c_int32),
+        req_cpu_sum=_ptr(arrs["req_cpu_sum"], C.c_int64), req_mem_sum=_ptr(arrs["req_mem_sum"], C.c_int64),
+        order=_ptr(arrs["order"], C.c_int32), placed=_ptr(arrs["placed"], C.c_int32))
+    return st, arrs
+
+
+def finish_results(arrs, n_groups: int, nnz: int, offsets: np.ndarray) -> BatchResult:
+    out = {k: (v[:nnz] if k in ("order", "placed") else v[:n_groups]) for k, v in arrs.items()}
+    return BatchResult(offsets=offsets, **out)
+
+
+def device_count() -> int:
+    return int(lib.casim_device_count())
+
+
+class Context:
+    """casim_ctx: one HIP device + one stream.  `stream` may be a raw hipStream_t (int), e.g.
+    torch.cuda.current_stream().cuda_stream, so that torch events bracket the kernels."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self._h = lib.casim_ctx_create(int(device), C.c_void_p(stream) if stream else None)
+        if not self._h:
+            msg = last_error()
+            if device_count() == 0:
+                raise NoDeviceError(_abi.ERR_NO_DEVICE, msg or "no HIP device visible")
+            raise CasimError(_abi.ERR_HIP, msg)
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib.casim_ctx_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def copy_bandwidth_gbps(self, nbytes: int = 1 << 30, iters: int = 10) -> float:
+        out = C.c_double(0)
+        check(lib.casim_copy_bandwidth(self._h, nbytes, iters, C.byref(out)), "casim_copy_bandwidth")
+        return out.value
+
+    def feasibility(self, pegs: _abi.Pegs, groups: _abi.Groups) -> np.ndarray:
+        """bit-matrix [NG][ceil(G/64)]: PEG g passes every encoded Filter on a fresh node of group i."""
+        wg = (pegs.n_pegs + 63) // 64
+        bits = np.zeros((max(groups.n_groups, 1), max(wg, 1)), np.uint64)
+        check(lib.casim_feasibility(self._h, C.byref(pegs), C.byref(groups), _ptr(bits, C.c_uint64)), "casim_feasibility")
+        return bits[:groups.n_groups, :wg]
+
+
+class Problem:
+    """casim_problem: a batch resident in HBM; run() enqueues feasibility -> order -> pack."""
+
+    def __init__(self, ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, fastpath: bool = False):
+        self.ctx = ctx
+        self.n_groups = groups.n_groups
+        self.n_pegs = pegs.n_pegs
+        opts = _abi.Options(fastpath=int(fastpath))
+        self._h = lib.casim_problem_create(ctx._h, C.byref(pegs), C.byref(groups), C.byref(opts))
+        if not self._h:
+            raise CasimError(_abi.ERR_INVALID, last_error())
+
+    def close(self):
+        if self._h:
+            lib.casim_problem_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def run(self):
+        check(lib.casim_problem_run(self._h), "casim_problem_run")
+
+    def csr(self):
+        nnz = C.c_int32(0)
+        off = np.zeros(self.n_groups + 1, np.int32)
+        check(lib.casim_problem_csr(self._h, C.byref(nnz), _ptr(off, C.c_int32)), "casim_problem_csr")
+        return int(nnz.value), off
+
+    def fetch(self) -> BatchResult:
+        nnz, off = self.csr()
+        st, arrs = alloc_results(self.n_groups, nnz)
+        check(lib.casim_problem_fetch(self._h, C.byref(st)), "casim_problem_fetch")
+        return finish_results(arrs, self.n_groups, nnz, off)
+
+    def best_option(self, kinds: Sequence[int], group_id_base: int = 0, dev_key_ptr: Optional[int] = None):
+        ks = (C.c_int32 * max(len(kinds), 1))(*kinds)
+        best, nbest = C.c_int32(-1), C.c_int32(0)
+        bset = np.zeros(max(self.n_groups, 1), np.uint8)
+        key = np.zeros(2, np.int64)
+        check(lib.casim_best_option(self._h, ks, len(kinds), int(group_id_base), C.byref(best), C.byref(nbest),
+                                    _ptr(bset, C.c_uint8), _ptr(key, C.c_int64),
+                                    C.c_void_p(dev_key_ptr) if dev_key_ptr else None), "casim_best_option")
+        return int(best.value), int(nbest.value), bset[:self.n_groups], key
+
+    def best_option_device(self, kinds: Sequence[int], group_id_base: int, dev_key_ptr: int):
+        """Asynchronous form: only writes the 2-int64 key into device memory (for the RCCL reduce)."""
+        ks = (C.c_int32 * max(len(kinds), 1))(*kinds)
+        check(lib.casim_best_option(self._h, ks, len(kinds), int(group_id_base), None, None, None, None,
+                                    C.c_void_p(dev_key_ptr)), "casim_best_option")
+
+    def time(self, iters: int = 10):
+        tot = C.c_float(0)
+        ks = (C.c_float * 3)()
+        check(lib.casim_problem_time(self._h, int(iters), C.byref(tot), ks), "casim_problem_time")
+        return float(tot.value), {"feasibility_csr_ms": ks[0], "order_ms": ks[1], "pack_ms": ks[2]}
+
+    def dense_check(self, col_repeat: int, fetch: bool = True):
+        nr, nc = C.c_int64(0), C.c_int64(0)
+        if not fetch:
+            check(lib.casim_problem_dense_check(self._h, int(col_repeat), None, C.byref(nr), C.byref(nc)), "dense_check")
+            return None, int(nr.value), int(nc.value)
+        # two calls: first learns the shape (asynchronous launch), second copies
+        check(lib.casim_problem_dense_check(self._h, int(col_repeat), None, C.byref(nr), C.byref(nc)), "dense_check")
+        bits = np.zeros(((nc.value + 63) // 64, max(nr.value, 1)), np.uint64)
+        check(lib.casim_problem_dense_check(self._h, int(col_repeat), _ptr(bits, C.c_uint64), C.byref(nr), C.byref(nc)), "dense_check")
+        return bits[:, :nr.value], int(nr.value), int(nc.value)
+
+    def time_dense(self, col_repeat: int, iters: int = 10):
+        ms = C.c_float(0)
+        nr, nc = C.c_int64(0), C.c_int64(0)
+        check(lib.casim_problem_time_dense(self._h, int(col_repeat), int(iters), C.byref(ms), C.byref(nr), C.byref(nc)), "time_dense")
+        return float(ms.value), int(nr.value), int(nc.value)
+
+
+def estimate_batch(ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, fastpath: bool = False) -> BatchResult:
+    with Problem(ctx, pegs, groups, fastpath) as p:
+        p.run()
+        return p.fetch()

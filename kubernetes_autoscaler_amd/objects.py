@@ -1,0 +1,201 @@
+"""Host-side object model mirroring the slice of the Kubernetes API the scale-up simulation reads.
+
+Names follow the reference so that tests read like the reference's tests:
+  Pod / Node / Taint / Toleration ...            k8s.io/api/core/v1
+  NodeInfo                                       CA/simulator/framework/infos.go:57
+  PodEquivalenceGroup                            CA/estimator/estimator.go:37-48
+  build_test_pod / build_test_node / ...         CA/utils/test/test_utils.go:38,367
+  make_node                                      CA/estimator/binpacking_estimator_test.go:44-64
+(`CA/` = /root/reference/cluster-autoscaler/.)
+
+Quantities are plain integers: cpu in millicores (Quantity.MilliValue), everything else in base
+units (Quantity.Value)."""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+MiB = 1024 * 1024
+GiB = 1024 * MiB
+
+LABEL_HOSTNAME = "kubernetes.io/hostname"
+LABEL_ZONE = "topology.kubernetes.io/zone"
+
+RES_CPU, RES_MEMORY, RES_EPHEMERAL = "cpu", "memory", "ephemeral-storage"
+
+
+@dataclass
+class Toleration:
+    key: str = ""
+    operator: str = ""      # "" == Equal (toleration.go:62)
+    value: str = ""
+    effect: str = ""
+
+
+@dataclass
+class Taint:
+    key: str
+    value: str = ""
+    effect: str = "NoSchedule"
+
+
+@dataclass
+class Requirement:
+    """labels.Requirement / v1.NodeSelectorRequirement / metav1.LabelSelectorRequirement."""
+    key: str
+    operator: str            # In, NotIn, Exists, DoesNotExist, Gt, Lt
+    values: Sequence[str] = ()
+
+
+@dataclass
+class PodAffinityTerm:
+    """v1.PodAffinityTerm restricted to what the encoder supports (no namespaceSelector)."""
+    topology_key: str
+    match_labels: Dict[str, str] = field(default_factory=dict)
+    match_expressions: List[Requirement] = field(default_factory=list)
+    namespaces: Sequence[str] = ()
+
+    def requirements(self) -> List[Requirement]:
+        reqs = [Requirement(k, "In", (v,)) for k, v in sorted(self.match_labels.items())]
+        return reqs + list(self.match_expressions)
+
+
+@dataclass
+class ContainerPort:
+    host_port: int
+    host_ip: str = ""
+    protocol: str = ""
+
+
+@dataclass
+class Pod:
+    name: str
+    namespace: str = "default"
+    labels: Dict[str, str] = field(default_factory=dict)
+    # total pod requests per resource name (resource.PodRequests); cpu in millicores
+    requests: Dict[str, int] = field(default_factory=dict)
+    tolerations: List[Toleration] = field(default_factory=list)
+    node_selector: Dict[str, str] = field(default_factory=dict)
+    node_affinity: List[Requirement] = field(default_factory=list)   # ONE required term, ANDed
+    host_ports: List[ContainerPort] = field(default_factory=list)
+    anti_affinity: List[PodAffinityTerm] = field(default_factory=list)
+    # first container's requests as AsApproximateFloat64 for the fastpath chooser; None = derive
+    fastpath_cpu: Optional[float] = None
+    fastpath_mem: Optional[float] = None
+    has_containers: bool = True
+    topology_spread: bool = False          # outside the encoded subset -> fallback
+    unsupported_reason: str = ""           # anything else outside the encoded subset
+
+    def fastpath_requests(self):
+        """Containers[0].Resources.Requests.{Cpu,Memory}().AsApproximateFloat64()
+        (binpacking_estimator.go:451-458).  A NewMilliQuantity(v) is float64(v) * 10**-3,
+        a NewQuantity(v) is float64(v)  (quantity.go:468-483)."""
+        if not self.has_containers:
+            return 0.0, 0.0
+        cpu = self.fastpath_cpu if self.fastpath_cpu is not None else float(self.requests.get(RES_CPU, 0)) * 1e-3
+        mem = self.fastpath_mem if self.fastpath_mem is not None else float(self.requests.get(RES_MEMORY, 0))
+        return cpu, mem
+
+
+@dataclass
+class Node:
+    name: str
+    labels: Dict[str, str] = field(default_factory=dict)
+    taints: List[Taint] = field(default_factory=list)
+    allocatable: Dict[str, int] = field(default_factory=dict)   # incl. "pods"
+    capacity: Dict[str, int] = field(default_factory=dict)
+    unschedulable: bool = False
+
+    def allowed_pods(self) -> int:
+        return int(self.allocatable.get("pods", 0))
+
+
+@dataclass
+class NodeInfo:
+    """framework.NodeInfo: a node plus the pods already on it (DaemonSet pods for a template)."""
+    node: Node
+    pods: List[Pod] = field(default_factory=list)
+
+
+@dataclass
+class PodEquivalenceGroup:
+    pods: List[Pod] = field(default_factory=list)
+
+    def exemplar(self) -> Optional[Pod]:
+        return self.pods[0] if self.pods else None
+
+
+# ---------------------------------------------------------------------------------------------
+# builders mirroring CA/utils/test/test_utils.go and the estimator tests
+# ---------------------------------------------------------------------------------------------
+def build_test_pod(name: str, cpu: int, mem: int, *options) -> Pod:
+    """BuildTestPod(name, cpuMilli, memBytes, opts...)  test_utils.go:38-70."""
+    pod = Pod(name=name, namespace="default")
+    if cpu >= 0:
+        pod.requests[RES_CPU] = cpu
+    if mem >= 0:
+        pod.requests[RES_MEMORY] = mem
+    for opt in options:
+        opt(pod)
+    return pod
+
+
+def with_namespace(ns):
+    def f(pod): pod.namespace = ns
+    return f
+
+
+def with_labels(labels):
+    def f(pod): pod.labels = dict(labels)
+    return f
+
+
+def with_host_port(port):
+    """WithHostPort  test_utils.go:152-163."""
+    def f(pod):
+        if port > 0:
+            pod.host_ports = [ContainerPort(host_port=port)]
+    return f
+
+
+def with_max_skew(max_skew, key, min_domains):
+    """WithMaxSkew  test_utils.go:165-184 — topology spread is outside the encoded subset."""
+    def f(pod):
+        if max_skew > 0:
+            pod.topology_spread = True
+    return f
+
+
+def with_pod_hostname_anti_affinity(labels):
+    """WithPodHostnameAntiAffinity  test_utils.go:223-240."""
+    def f(pod): pod.anti_affinity = [PodAffinityTerm(topology_key=LABEL_HOSTNAME, match_labels=dict(labels))]
+    return f
+
+
+def with_node_selector(sel):
+    def f(pod): pod.node_selector = dict(sel)
+    return f
+
+
+def with_tolerations(tols):
+    def f(pod): pod.tolerations = list(tols)
+    return f
+
+
+def build_test_node(name: str, cpu_milli: int, mem: int, pods: int = 100) -> Node:
+    """BuildTestNode  test_utils.go:367-400: pods capacity 100, allocatable == capacity."""
+    cap = {"pods": pods}
+    if cpu_milli >= 0:
+        cap[RES_CPU] = cpu_milli
+    if mem >= 0:
+        cap[RES_MEMORY] = mem
+    return Node(name=name, labels={}, capacity=dict(cap), allocatable=dict(cap))
+
+
+def make_node(cpu: int, mem_mib: int, pod_count: int, name: str, zone: str) -> Node:
+    """makeNode  binpacking_estimator_test.go:44-64 (memory given in MiB)."""
+    cap = {RES_CPU: cpu, RES_MEMORY: mem_mib * MiB, "pods": pod_count}
+    return Node(name=name, labels={LABEL_HOSTNAME: name, LABEL_ZONE: zone}, capacity=dict(cap), allocatable=dict(cap))
+
+
+def make_pod_equivalence_group(pod: Pod, count: int) -> PodEquivalenceGroup:
+    """makePodEquivalenceGroup  binpacking_estimator_test.go:34-42 (one pointer repeated)."""
+    return PodEquivalenceGroup(pods=[pod] * count)

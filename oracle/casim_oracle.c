@@ -1,0 +1,940 @@
+/*
+ * casim_oracle.c — CPU ORACLE (test infrastructure, NOT product code). See casim_oracle.h.
+ *
+ * Restates, object level and pod by pod, the reference path
+ *   BinpackingNodeEstimator.Estimate -> PredicateSnapshot.SchedulePod* ->
+ *   SchedulerPluginRunner.RunFilters* -> scheduler Filter plugins.
+ * Each function cites the reference file:line it follows (`CA/` =
+ * /root/reference/cluster-autoscaler/, `V/` = its vendor/k8s.io/).
+ *
+ * Deliberately naive: per-pod loops, per-node Filter runs, string-keyed maps rebuilt per pod —
+ * the same asymptotic work the Go code does, so that timing it gives a "port"
+ * CPU baseline.  Strings are interned to integer ids at insertion (id equality == string
+ * equality); numeric Gt/Lt comparisons go back to the strings.
+ */
+#include "casim_oracle.h"
+
+#include <errno.h>
+#include <limits.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------- */
+/* small utilities                                                                        */
+/* ------------------------------------------------------------------------------------- */
+#define VEC(T) struct { T* v; int n, cap; }
+#define VEC_PUSH(vec, item)                                                        \
+    do {                                                                           \
+        if ((vec).n == (vec).cap) {                                                \
+            (vec).cap = (vec).cap ? (vec).cap * 2 : 4;                             \
+            (vec).v = realloc((vec).v, sizeof(*(vec).v) * (size_t)(vec).cap);      \
+        }                                                                          \
+        (vec).v[(vec).n++] = (item);                                               \
+    } while (0)
+#define VEC_FREE(vec) do { free((vec).v); (vec).v = NULL; (vec).n = (vec).cap = 0; } while (0)
+
+typedef VEC(int) ivec;
+
+/* string interning */
+typedef struct { char** s; int n, cap; int* table; int tcap; } strtab;
+
+static unsigned long hash_str(const char* s) {
+    unsigned long h = 1469598103934665603UL;
+    for (; *s; ++s) { h ^= (unsigned char)*s; h *= 1099511628211UL; }
+    return h;
+}
+static void strtab_rehash(strtab* t, int tcap) {
+    free(t->table);
+    t->tcap = tcap;
+    t->table = malloc(sizeof(int) * (size_t)tcap);
+    for (int i = 0; i < tcap; ++i) t->table[i] = -1;
+    for (int i = 0; i < t->n; ++i) {
+        unsigned long h = hash_str(t->s[i]) % (unsigned long)tcap;
+        while (t->table[h] >= 0) h = (h + 1) % (unsigned long)tcap;
+        t->table[h] = i;
+    }
+}
+static int intern(strtab* t, const char* s) {
+    if (!s) s = "";
+    if (t->tcap == 0) strtab_rehash(t, 64);
+    unsigned long h = hash_str(s) % (unsigned long)t->tcap;
+    while (t->table[h] >= 0) {
+        if (strcmp(t->s[t->table[h]], s) == 0) return t->table[h];
+        h = (h + 1) % (unsigned long)t->tcap;
+    }
+    if (t->n == t->cap) { t->cap = t->cap ? t->cap * 2 : 32; t->s = realloc(t->s, sizeof(char*) * (size_t)t->cap); }
+    t->s[t->n] = strdup(s);
+    t->table[h] = t->n++;
+    if (t->n * 2 > t->tcap) strtab_rehash(t, t->tcap * 2);
+    return t->n - 1;
+}
+
+/* ------------------------------------------------------------------------------------- */
+/* object model                                                                           */
+/* ------------------------------------------------------------------------------------- */
+enum { OP_IN, OP_NOTIN, OP_EXISTS, OP_DOESNOTEXIST, OP_GT, OP_LT, OP_BAD };
+enum { TOL_EQUAL, TOL_EXISTS, TOL_LT, TOL_GT, TOL_BAD };
+
+typedef struct { int key, value; } kv;
+typedef struct { int key, value, effect; } taint;
+typedef struct { int key, op, value, effect; } toleration;
+typedef struct { int key, op; ivec values; } requirement;
+typedef VEC(requirement) reqvec;
+typedef struct { int ip, proto, port; } hostport;
+typedef struct { int topology_key; ivec namespaces; reqvec selector; } aff_term;
+
+typedef struct {
+    int ns;
+    int64_t req[ORC_MAX_RES];
+    VEC(kv) labels;
+    VEC(toleration) tolerations;
+    VEC(kv) node_selector;
+    reqvec node_affinity; /* single required term, ANDed requirements */
+    int has_node_affinity;
+    VEC(hostport) ports;
+    VEC(aff_term) anti_terms;
+    double fp_cpu, fp_mem;
+    int fp_has_requests;
+    int has_topology_spread;
+} podspec;
+
+typedef struct {
+    int name;
+    VEC(kv) labels;
+    VEC(taint) taints;
+    int unschedulable;
+    int64_t alloc[ORC_MAX_RES];
+    int allowed_pods;
+    int64_t cap_cpu_milli, cap_mem;
+    double fp_cap_cpu, fp_cap_mem; /* Capacity.{Cpu,Memory}().AsApproximateFloat64() */
+    /* NodeInfo aggregates  V/kubernetes/pkg/scheduler/framework/types.go:166-214 */
+    int64_t requested[ORC_MAX_RES];
+    ivec pods;          /* pod spec ids, in AddPod order */
+    VEC(hostport) used_ports;
+    int n_pods_with_aa; /* len(PodsWithRequiredAntiAffinity) */
+    int is_new;         /* created by this Estimate (estimationState.newNodeNames) */
+    int new_pods;       /* pods placed by this Estimate (newNodesWithPods) */
+} node;
+
+struct orc {
+    int n_res;
+    strtab st;
+    VEC(podspec) pods;
+    VEC(node) nodes;     /* node objects (templates / existing) */
+    VEC(node) snap;      /* the cluster snapshot list, insertion order */
+    int taint_cmp_ops;
+    int id_hostname, id_noschedule, id_noexecute, id_allip, id_tcp, id_empty, id_unsched_key;
+    int64_t filter_runs;
+};
+
+/* ------------------------------------------------------------------------------------- */
+/* construction                                                                           */
+/* ------------------------------------------------------------------------------------- */
+orc* orc_new(int n_res) {
+    if (n_res < 2 || n_res > ORC_MAX_RES) return NULL;
+    orc* o = calloc(1, sizeof(orc));
+    o->n_res = n_res;
+    o->id_empty = intern(&o->st, "");
+    o->id_hostname = intern(&o->st, "kubernetes.io/hostname");
+    o->id_noschedule = intern(&o->st, "NoSchedule");
+    o->id_noexecute = intern(&o->st, "NoExecute");
+    o->id_allip = intern(&o->st, "0.0.0.0");
+    o->id_tcp = intern(&o->st, "TCP");
+    o->id_unsched_key = intern(&o->st, "node.kubernetes.io/unschedulable");
+    return o;
+}
+
+static void free_reqvec(reqvec* r) {
+    for (int i = 0; i < r->n; ++i) VEC_FREE(r->v[i].values);
+    VEC_FREE(*r);
+}
+static void node_free(node* n) {
+    VEC_FREE(n->labels); VEC_FREE(n->taints); VEC_FREE(n->pods); VEC_FREE(n->used_ports);
+}
+void orc_free(orc* o) {
+    if (!o) return;
+    for (int i = 0; i < o->pods.n; ++i) {
+        podspec* p = &o->pods.v[i];
+        VEC_FREE(p->labels); VEC_FREE(p->tolerations); VEC_FREE(p->node_selector);
+        free_reqvec(&p->node_affinity); VEC_FREE(p->ports);
+        for (int t = 0; t < p->anti_terms.n; ++t) { VEC_FREE(p->anti_terms.v[t].namespaces); free_reqvec(&p->anti_terms.v[t].selector); }
+        VEC_FREE(p->anti_terms);
+    }
+    VEC_FREE(o->pods);
+    for (int i = 0; i < o->nodes.n; ++i) node_free(&o->nodes.v[i]);
+    VEC_FREE(o->nodes);
+    for (int i = 0; i < o->snap.n; ++i) node_free(&o->snap.v[i]);
+    VEC_FREE(o->snap);
+    for (int i = 0; i < o->st.n; ++i) free(o->st.s[i]);
+    free(o->st.s); free(o->st.table);
+    free(o);
+}
+void orc_set_taint_comparison_ops(orc* o, int enabled) { o->taint_cmp_ops = enabled; }
+
+int orc_pod(orc* o, const char* ns, const int64_t* req) {
+    podspec p; memset(&p, 0, sizeof p);
+    p.ns = intern(&o->st, ns);
+    for (int r = 0; r < o->n_res; ++r) p.req[r] = req[r];
+    VEC_PUSH(o->pods, p);
+    return o->pods.n - 1;
+}
+#define PODCHK(o, pod) if ((pod) < 0 || (pod) >= (o)->pods.n) return -1
+#define NODECHK(o, nd) if ((nd) < 0 || (nd) >= (o)->nodes.n) return -1
+
+int orc_pod_label(orc* o, int pod, const char* key, const char* value) {
+    PODCHK(o, pod);
+    int k = intern(&o->st, key), v = intern(&o->st, value);
+    podspec* p = &o->pods.v[pod];
+    for (int i = 0; i < p->labels.n; ++i) if (p->labels.v[i].key == k) { p->labels.v[i].value = v; return 0; }
+    kv e = {k, v}; VEC_PUSH(p->labels, e); return 0;
+}
+static int parse_tol_op(const char* op) {
+    if (!op || !*op || strcmp(op, "Equal") == 0) return TOL_EQUAL; /* empty operator means Equal, toleration.go:62 */
+    if (strcmp(op, "Exists") == 0) return TOL_EXISTS;
+    if (strcmp(op, "Lt") == 0) return TOL_LT;
+    if (strcmp(op, "Gt") == 0) return TOL_GT;
+    return TOL_BAD;
+}
+int orc_pod_toleration(orc* o, int pod, const char* key, const char* op, const char* value, const char* effect) {
+    PODCHK(o, pod);
+    toleration t = {intern(&o->st, key), parse_tol_op(op), intern(&o->st, value), intern(&o->st, effect)};
+    VEC_PUSH(o->pods.v[pod].tolerations, t); return 0;
+}
+int orc_pod_node_selector(orc* o, int pod, const char* key, const char* value) {
+    PODCHK(o, pod);
+    kv e = {intern(&o->st, key), intern(&o->st, value)};
+    VEC_PUSH(o->pods.v[pod].node_selector, e); return 0;
+}
+static int parse_req_op(const char* op) {
+    if (!op) return OP_BAD;
+    if (!strcmp(op, "In")) return OP_IN;
+    if (!strcmp(op, "NotIn")) return OP_NOTIN;
+    if (!strcmp(op, "Exists")) return OP_EXISTS;
+    if (!strcmp(op, "DoesNotExist")) return OP_DOESNOTEXIST;
+    if (!strcmp(op, "Gt")) return OP_GT;
+    if (!strcmp(op, "Lt")) return OP_LT;
+    return OP_BAD;
+}
+static requirement make_req(orc* o, const char* key, const char* op, const char* const* values, int n) {
+    requirement r; memset(&r, 0, sizeof r);
+    r.key = intern(&o->st, key); r.op = parse_req_op(op);
+    for (int i = 0; i < n; ++i) VEC_PUSH(r.values, intern(&o->st, values[i]));
+    return r;
+}
+int orc_pod_node_affinity_req(orc* o, int pod, const char* key, const char* op, const char* const* values, int n) {
+    PODCHK(o, pod);
+    requirement r = make_req(o, key, op, values, n);
+    VEC_PUSH(o->pods.v[pod].node_affinity, r);
+    o->pods.v[pod].has_node_affinity = 1; return 0;
+}
+int orc_pod_host_port(orc* o, int pod, const char* ip, const char* protocol, int port) {
+    PODCHK(o, pod);
+    hostport h = {intern(&o->st, ip), intern(&o->st, protocol), port};
+    VEC_PUSH(o->pods.v[pod].ports, h); return 0;
+}
+int orc_pod_anti_affinity_term(orc* o, int pod, const char* topology_key, const char* const* namespaces, int n) {
+    PODCHK(o, pod);
+    aff_term t; memset(&t, 0, sizeof t);
+    t.topology_key = intern(&o->st, topology_key);
+    /* getNamespacesFromPodAffinityTerm  V/kubernetes/pkg/scheduler/framework/types.go (newAffinityTerm):
+     * no namespaces and no namespaceSelector => the pod's own namespace */
+    if (n == 0) VEC_PUSH(t.namespaces, o->pods.v[pod].ns);
+    for (int i = 0; i < n; ++i) VEC_PUSH(t.namespaces, intern(&o->st, namespaces[i]));
+    VEC_PUSH(o->pods.v[pod].anti_terms, t);
+    return o->pods.v[pod].anti_terms.n - 1;
+}
+int orc_term_requirement(orc* o, int pod, int term, const char* key, const char* op, const char* const* values, int n) {
+    PODCHK(o, pod);
+    if (term < 0 || term >= o->pods.v[pod].anti_terms.n) return -1;
+    requirement r = make_req(o, key, op, values, n);
+    VEC_PUSH(o->pods.v[pod].anti_terms.v[term].selector, r); return 0;
+}
+int orc_pod_fastpath_requests(orc* o, int pod, double cpu, double mem) {
+    PODCHK(o, pod);
+    o->pods.v[pod].fp_cpu = cpu; o->pods.v[pod].fp_mem = mem; o->pods.v[pod].fp_has_requests = 1; return 0;
+}
+int orc_pod_has_topology_spread(orc* o, int pod, int flag) { PODCHK(o, pod); o->pods.v[pod].has_topology_spread = flag; return 0; }
+
+int orc_node(orc* o, const char* name, const int64_t* alloc, int allowed_pods, int64_t cap_cpu_milli, int64_t cap_mem, int unschedulable) {
+    node n; memset(&n, 0, sizeof n);
+    n.name = intern(&o->st, name);
+    for (int r = 0; r < o->n_res; ++r) n.alloc[r] = alloc[r];
+    n.allowed_pods = allowed_pods; n.cap_cpu_milli = cap_cpu_milli; n.cap_mem = cap_mem;
+    /* AsApproximateFloat64 of NewMilliQuantity(v): float64(v) * math.Pow10(-3)
+     * (V/apimachinery/pkg/api/resource/quantity.go:468-483); override with orc_node_fastpath_capacity */
+    n.fp_cap_cpu = (double)cap_cpu_milli * 1e-3; n.fp_cap_mem = (double)cap_mem;
+    n.unschedulable = unschedulable;
+    VEC_PUSH(o->nodes, n);
+    return o->nodes.n - 1;
+}
+static void node_set_label(node* n, int k, int v) {
+    for (int i = 0; i < n->labels.n; ++i) if (n->labels.v[i].key == k) { n->labels.v[i].value = v; return; }
+    kv e = {k, v}; VEC_PUSH(n->labels, e);
+}
+int orc_node_fastpath_capacity(orc* o, int nd, double cpu, double mem) {
+    NODECHK(o, nd); o->nodes.v[nd].fp_cap_cpu = cpu; o->nodes.v[nd].fp_cap_mem = mem; return 0;
+}
+int orc_node_label(orc* o, int nd, const char* key, const char* value) {
+    NODECHK(o, nd); node_set_label(&o->nodes.v[nd], intern(&o->st, key), intern(&o->st, value)); return 0;
+}
+int orc_node_taint(orc* o, int nd, const char* key, const char* value, const char* effect) {
+    NODECHK(o, nd);
+    taint t = {intern(&o->st, key), intern(&o->st, value), intern(&o->st, effect)};
+    VEC_PUSH(o->nodes.v[nd].taints, t); return 0;
+}
+
+/* HostPortInfo.sanitize  V/kube-scheduler/framework/types.go:633-640 */
+static void port_sanitize(const orc* o, hostport* h) {
+    if (h->ip == o->id_empty) h->ip = o->id_allip;
+    if (h->proto == o->id_empty) h->proto = o->id_tcp;
+}
+/* HostPortInfo.Add  V/kube-scheduler/framework/types.go:552-571 */
+static void ports_add(const orc* o, node* n, hostport h) {
+    if (h.port <= 0) return;
+    port_sanitize(o, &h);
+    for (int i = 0; i < n->used_ports.n; ++i) {
+        hostport* u = &n->used_ports.v[i];
+        if (u->ip == h.ip && u->proto == h.proto && u->port == h.port) return;
+    }
+    VEC_PUSH(n->used_ports, h);
+}
+/* NodeInfo.AddPodInfo / update(+1)  V/kubernetes/pkg/scheduler/framework/types.go:361-371,439-463 */
+static void node_add_pod(const orc* o, node* n, int pod) {
+    const podspec* p = &o->pods.v[pod];
+    VEC_PUSH(n->pods, pod);
+    if (p->anti_terms.n > 0) n->n_pods_with_aa++;
+    for (int r = 0; r < o->n_res; ++r) n->requested[r] += p->req[r]; /* Resource.Add :1028-1049 */
+    for (int i = 0; i < p->ports.n; ++i) ports_add(o, n, p->ports.v[i]);
+}
+int orc_node_add_pod(orc* o, int nd, int pod) { NODECHK(o, nd); PODCHK(o, pod); node_add_pod(o, &o->nodes.v[nd], pod); return 0; }
+
+static node node_clone(const node* s) {
+    node d = *s;
+    memset(&d.labels, 0, sizeof d.labels); memset(&d.taints, 0, sizeof d.taints);
+    memset(&d.pods, 0, sizeof d.pods); memset(&d.used_ports, 0, sizeof d.used_ports);
+    for (int i = 0; i < s->labels.n; ++i) VEC_PUSH(d.labels, s->labels.v[i]);
+    for (int i = 0; i < s->taints.n; ++i) VEC_PUSH(d.taints, s->taints.v[i]);
+    for (int i = 0; i < s->pods.n; ++i) VEC_PUSH(d.pods, s->pods.v[i]);
+    for (int i = 0; i < s->used_ports.n; ++i) VEC_PUSH(d.used_ports, s->used_ports.v[i]);
+    return d;
+}
+int orc_snapshot_add(orc* o, int nd) {
+    NODECHK(o, nd);
+    node c = node_clone(&o->nodes.v[nd]);
+    VEC_PUSH(o->snap, c);
+    return o->snap.n - 1;
+}
+
+/* ------------------------------------------------------------------------------------- */
+/* label requirement / selector matching                                                   */
+/* ------------------------------------------------------------------------------------- */
+static int labels_lookup(const kv* labels, int n, int key, int* value_out) {
+    for (int i = 0; i < n; ++i) if (labels[i].key == key) { *value_out = labels[i].value; return 1; }
+    return 0;
+}
+/* strconv.ParseInt(s, 10, 64) */
+static int parse_int64(const char* s, int64_t* out) {
+    if (!s || !*s) return 0;
+    const char* p = s;
+    if (*p == '+' || *p == '-') ++p;
+    if (!*p) return 0;
+    for (const char* q = p; *q; ++q) if (*q < '0' || *q > '9') return 0;
+    errno = 0;
+    long long v = strtoll(s, NULL, 10);
+    if (errno == ERANGE) return 0;
+    *out = v; return 1;
+}
+/* Requirement.Matches  V/apimachinery/pkg/labels/selector.go:247-292 */
+static int requirement_matches(const orc* o, const requirement* r, const kv* labels, int n) {
+    int val = 0, exists = labels_lookup(labels, n, r->key, &val);
+    switch (r->op) {
+    case OP_IN:
+        if (!exists) return 0;
+        for (int i = 0; i < r->values.n; ++i) if (r->values.v[i] == val) return 1;
+        return 0;
+    case OP_NOTIN:
+        if (!exists) return 1;
+        for (int i = 0; i < r->values.n; ++i) if (r->values.v[i] == val) return 0;
+        return 1;
+    case OP_EXISTS: return exists;
+    case OP_DOESNOTEXIST: return !exists;
+    case OP_GT: case OP_LT: {
+        if (!exists) return 0;
+        int64_t lv, rv;
+        if (!parse_int64(o->st.s[val], &lv)) return 0;
+        if (r->values.n != 1) return 0;
+        if (!parse_int64(o->st.s[r->values.v[0]], &rv)) return 0;
+        return (r->op == OP_GT && lv > rv) || (r->op == OP_LT && lv < rv);
+    }
+    default: return 0;
+    }
+}
+/* internalSelector.Matches: every requirement must match (selector.go:386-393) */
+static int selector_matches(const orc* o, const reqvec* sel, const kv* labels, int n) {
+    for (int i = 0; i < sel->n; ++i) if (!requirement_matches(o, &sel->v[i], labels, n)) return 0;
+    return 1;
+}
+/* AffinityTerm.Matches  V/kube-scheduler/framework/types.go:390-395 (namespaceSelector: none => matches nothing) */
+static int term_matches_pod(const orc* o, const aff_term* t, const podspec* p) {
+    int ns_ok = 0;
+    for (int i = 0; i < t->namespaces.n; ++i) if (t->namespaces.v[i] == p->ns) { ns_ok = 1; break; }
+    if (!ns_ok) return 0;
+    return selector_matches(o, &t->selector, p->labels.v, p->labels.n);
+}
+
+/* ------------------------------------------------------------------------------------- */
+/* Filter plugins                                                                          */
+/* ------------------------------------------------------------------------------------- */
+static const char* PL_UNSCHED = "NodeUnschedulable";
+static const char* PL_TAINT = "TaintToleration";
+static const char* PL_AFFINITY = "NodeAffinity";
+static const char* PL_PORTS = "NodePorts";
+static const char* PL_FIT = "NodeResourcesFit";
+static const char* PL_IPA = "InterPodAffinity";
+
+/* Toleration.ToleratesTaint  V/api/core/v1/toleration.go:52-77 */
+static int tolerates_taint(const orc* o, const toleration* t, const taint* tn) {
+    if (t->effect != o->id_empty && t->effect != tn->effect) return 0;
+    if (t->key != o->id_empty && t->key != tn->key) return 0;
+    switch (t->op) {
+    case TOL_EQUAL: return t->value == tn->value;
+    case TOL_EXISTS: return 1;
+    case TOL_LT: case TOL_GT: {
+        if (!o->taint_cmp_ops) return 0;
+        /* compareNumericValues  toleration.go:80-114 (IsDecimalInteger rejects signs other than '-') */
+        int64_t tv, nv;
+        if (!parse_int64(o->st.s[t->value], &tv) || o->st.s[t->value][0] == '+') return 0;
+        if (!parse_int64(o->st.s[tn->value], &nv) || o->st.s[tn->value][0] == '+') return 0;
+        return t->op == TOL_LT ? (nv < tv) : (nv > tv);
+    }
+    default: return 0;
+    }
+}
+/* TaintToleration.Filter  V/kubernetes/pkg/scheduler/framework/plugins/tainttoleration/taint_toleration.go:119-132
+ * FindMatchingUntoleratedTaint  V/component-helpers/scheduling/corev1/helpers.go:79-87
+ * DoNotScheduleTaintsFilterFunc V/kubernetes/pkg/scheduler/framework/plugins/helper/taint.go:23-27 */
+static int filter_taints(const orc* o, const podspec* p, const node* n) {
+    for (int i = 0; i < n->taints.n; ++i) {
+        const taint* tn = &n->taints.v[i];
+        if (tn->effect != o->id_noschedule && tn->effect != o->id_noexecute) continue;
+        int tolerated = 0;
+        for (int j = 0; j < p->tolerations.n && !tolerated; ++j) tolerated = tolerates_taint(o, &p->tolerations.v[j], tn);
+        if (!tolerated) return 0;
+    }
+    return 1;
+}
+/* NodeUnschedulable.Filter  V/.../nodeunschedulable/node_unschedulable.go:142-160: unschedulable nodes
+ * pass only if the pod tolerates node.kubernetes.io/unschedulable:NoSchedule */
+static int filter_unschedulable(const orc* o, const podspec* p, const node* n) {
+    if (!n->unschedulable) return 1;
+    taint tn = {o->id_unsched_key, o->id_empty, o->id_noschedule};
+    for (int j = 0; j < p->tolerations.n; ++j) if (tolerates_taint(o, &p->tolerations.v[j], &tn)) return 1;
+    return 0;
+}
+/* NodeAffinity.Filter  V/.../nodeaffinity/node_affinity.go:218-240;  RequiredNodeAffinity.Match
+ * V/component-helpers/scheduling/corev1/nodeaffinity/nodeaffinity.go:323-333 */
+static int filter_node_affinity(const orc* o, const podspec* p, const node* n) {
+    for (int i = 0; i < p->node_selector.n; ++i) { /* labels.SelectorFromSet: all key==value */
+        int val;
+        if (!labels_lookup(n->labels.v, n->labels.n, p->node_selector.v[i].key, &val)) return 0;
+        if (val != p->node_selector.v[i].value) return 0;
+    }
+    if (p->has_node_affinity && !selector_matches(o, &p->node_affinity, n->labels.v, n->labels.n)) return 0;
+    return 1;
+}
+/* HostPortInfo.CheckConflict  V/kube-scheduler/framework/types.go:602-631 */
+static int ports_conflict(const orc* o, const node* n, hostport h) {
+    if (h.port <= 0) return 0;
+    port_sanitize(o, &h);
+    for (int i = 0; i < n->used_ports.n; ++i) {
+        const hostport* u = &n->used_ports.v[i];
+        if (u->proto != h.proto || u->port != h.port) continue;
+        if (h.ip == o->id_allip) return 1;                  /* 0.0.0.0 checks every IP */
+        if (u->ip == o->id_allip || u->ip == h.ip) return 1; /* else 0.0.0.0 and the same IP */
+    }
+    return 0;
+}
+/* NodePorts.Filter / fitsPorts  V/.../nodeports/node_ports.go:162-190 */
+static int filter_ports(const orc* o, const podspec* p, const node* n) {
+    for (int i = 0; i < p->ports.n; ++i) if (ports_conflict(o, n, p->ports.v[i])) return 0;
+    return 1;
+}
+/* fitsRequest  V/.../noderesources/fit.go:678-765.  *reason gets the FIRST insufficient resource */
+static int filter_fit(const orc* o, const podspec* p, const node* n, const char** reason) {
+    int ok = 1;
+    if (n->pods.n + 1 > n->allowed_pods) { ok = 0; if (reason && !*reason) *reason = "Too many pods"; }
+    int all_zero = 1;
+    for (int r = 0; r < o->n_res; ++r) if (p->req[r] != 0) all_zero = 0;
+    if (all_zero) return ok;
+    static const char* names[ORC_MAX_RES] = {"Insufficient cpu", "Insufficient memory", "Insufficient ephemeral-storage",
+        "Insufficient scalar-0", "Insufficient scalar-1", "Insufficient scalar-2", "Insufficient scalar-3", "Insufficient scalar-4"};
+    for (int r = 0; r < o->n_res; ++r) {
+        if (p->req[r] > 0 && p->req[r] > n->alloc[r] - n->requested[r]) { ok = 0; if (reason && !*reason) *reason = names[r]; }
+    }
+    return ok;
+}
+
+/* InterPodAffinity pre-filter state: topologyToMatchedTermCount maps
+ * V/.../interpodaffinity/filtering.go:59-76,204-309 */
+typedef struct { int key, value; int64_t count; } tpcount;
+typedef VEC(tpcount) tpmap;
+static void tpmap_add(tpmap* m, int key, int value, int64_t c) {
+    for (int i = 0; i < m->n; ++i) if (m->v[i].key == key && m->v[i].value == value) { m->v[i].count += c; return; }
+    tpcount e = {key, value, c}; VEC_PUSH(*m, e);
+}
+static int64_t tpmap_get(const tpmap* m, int key, int value) {
+    for (int i = 0; i < m->n; ++i) if (m->v[i].key == key && m->v[i].value == value) return m->v[i].count;
+    return 0;
+}
+typedef struct { tpmap existing_anti; tpmap incoming_anti; int skip; } ipa_state;
+
+/* InterPodAffinity.PreFilter  filtering.go:274-309 (required pod AFFINITY terms are out of
+ * the encoded subset; specs carrying them are never sent down this path) */
+static void ipa_prefilter(const orc* o, const podspec* p, ipa_state* s) {
+    memset(s, 0, sizeof *s);
+    /* getExistingAntiAffinityCounts :204-231 — nodes from HavePodsWithRequiredAntiAffinityList */
+    for (int i = 0; i < o->snap.n; ++i) {
+        const node* n = &o->snap.v[i];
+        if (n->n_pods_with_aa == 0) continue;
+        for (int j = 0; j < n->pods.n; ++j) {
+            const podspec* ep = &o->pods.v[n->pods.v[j]];
+            for (int t = 0; t < ep->anti_terms.n; ++t) {
+                const aff_term* term = &ep->anti_terms.v[t];
+                if (!term_matches_pod(o, term, p)) continue;
+                int val;
+                if (labels_lookup(n->labels.v, n->labels.n, term->topology_key, &val)) tpmap_add(&s->existing_anti, term->topology_key, val, 1);
+            }
+        }
+    }
+    /* getIncomingAffinityAntiAffinityCounts :234-272 — every node, every pod */
+    if (p->anti_terms.n > 0) {
+        for (int i = 0; i < o->snap.n; ++i) {
+            const node* n = &o->snap.v[i];
+            for (int j = 0; j < n->pods.n; ++j) {
+                const podspec* ep = &o->pods.v[n->pods.v[j]];
+                for (int t = 0; t < p->anti_terms.n; ++t) {
+                    const aff_term* term = &p->anti_terms.v[t];
+                    if (!term_matches_pod(o, term, ep)) continue;
+                    int val;
+                    if (labels_lookup(n->labels.v, n->labels.n, term->topology_key, &val)) tpmap_add(&s->incoming_anti, term->topology_key, val, 1);
+                }
+            }
+        }
+    }
+    /* :300-305 Skip when nothing can interact */
+    s->skip = (s->existing_anti.n == 0 && p->anti_terms.n == 0);
+}
+static void ipa_free(ipa_state* s) { VEC_FREE(s->existing_anti); VEC_FREE(s->incoming_anti); }
+/* InterPodAffinity.Filter  filtering.go:412-432 with satisfyPodAntiAffinity :367-380 and
+ * satisfyExistingPodsAntiAffinity :352-364 */
+static int filter_ipa(const podspec* p, const node* n, const ipa_state* s) {
+    if (s->skip) return 1;
+    if (s->incoming_anti.n > 0) {
+        for (int t = 0; t < p->anti_terms.n; ++t) {
+            int val;
+            if (labels_lookup(n->labels.v, n->labels.n, p->anti_terms.v[t].topology_key, &val))
+                if (tpmap_get(&s->incoming_anti, p->anti_terms.v[t].topology_key, val) > 0) return 0;
+        }
+    }
+    if (s->existing_anti.n > 0) {
+        for (int i = 0; i < n->labels.n; ++i)
+            if (tpmap_get(&s->existing_anti, n->labels.v[i].key, n->labels.v[i].value) > 0) return 0;
+    }
+    return 1;
+}
+
+/* frameworkImpl.RunFilterPlugins in default profile order
+ * V/kubernetes/pkg/scheduler/framework/runtime/framework.go:1093-1126,
+ * V/kubernetes/pkg/scheduler/apis/config/v1/default_plugins.go:34-51: first failing Filter wins */
+static int run_filter_plugins(orc* o, const podspec* p, const node* n, const ipa_state* s,
+                              const char** plugin, const char** reason) {
+    o->filter_runs++;
+    const char* dummy = NULL;
+    if (!reason) reason = &dummy;
+    *reason = NULL;
+    const char* failed = NULL;
+    if (!filter_unschedulable(o, p, n)) { failed = PL_UNSCHED; *reason = "node(s) were unschedulable"; }
+    /* NodeName: pending pods have empty spec.nodeName => pass (node_name.go:79-86) */
+    else if (!filter_taints(o, p, n)) { failed = PL_TAINT; *reason = "node(s) had untolerated taint(s)"; }
+    else if ((p->node_selector.n > 0 || p->has_node_affinity) && !filter_node_affinity(o, p, n)) {
+        failed = PL_AFFINITY; *reason = "node(s) didn't match Pod's node affinity/selector";
+    } else if (p->ports.n > 0 && !filter_ports(o, p, n)) {
+        failed = PL_PORTS; *reason = "node(s) didn't have free ports for the requested pod ports";
+    } else if (!filter_fit(o, p, n, reason)) { failed = PL_FIT; }
+    else if (!filter_ipa(p, n, s)) { failed = PL_IPA; *reason = "node(s) didn't satisfy anti-affinity rules"; }
+    if (failed) { if (plugin) *plugin = failed; return 0; }
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------- */
+/* SchedulerPluginRunner                                                                   */
+/* ------------------------------------------------------------------------------------- */
+/* lastIndexOrderMapping.At  CA/simulator/clustersnapshot/scheduling_opts.go:54-59 */
+int orc_last_index_at(int i, int offset, int last_index, int n) {
+    if (n == 0) return -1;
+    return (i + offset + last_index) % n;
+}
+
+/* RunFiltersUntilPassingNode  CA/simulator/clustersnapshot/predicate/plugin_runner.go:54-143,
+ * parallelism 1.  accept_new_only mirrors Estimate's IsNodeAcceptable (binpacking_estimator.go:172-174). */
+static int run_filters_until_passing(orc* o, int pod, int accept_new_only, int* last_index) {
+    const podspec* p = &o->pods.v[pod];
+    ipa_state st; ipa_prefilter(o, p, &st);
+    int n = o->snap.n, found = -1;
+    for (int i = 0; i < n; ++i) {
+        int idx = orc_last_index_at(i, 1, *last_index, n);
+        if (idx < 0) break;
+        const node* nd = &o->snap.v[idx];
+        if (nd->unschedulable) continue;                    /* :108-110 */
+        if (accept_new_only && !nd->is_new) continue;       /* :114 */
+        if (run_filter_plugins(o, p, nd, &st, NULL, NULL)) { found = idx; break; }
+    }
+    ipa_free(&st);
+    if (found >= 0) *last_index = found;                    /* MarkMatch :138 */
+    return found;
+}
+/* RunFiltersOnNode  plugin_runner.go:146-181 */
+static int run_filters_on_node(orc* o, int pod, int idx, const char** plugin, const char** reason) {
+    const podspec* p = &o->pods.v[pod];
+    ipa_state st; ipa_prefilter(o, p, &st);
+    int ok = run_filter_plugins(o, p, &o->snap.v[idx], &st, plugin, reason);
+    ipa_free(&st);
+    return ok;
+}
+int orc_run_filters_on_snapshot_node(orc* o, int index, int pod, const char** plugin_out, const char** reason_out) {
+    if (index < 0 || index >= o->snap.n) return -1;
+    PODCHK(o, pod);
+    return run_filters_on_node(o, pod, index, plugin_out, reason_out);
+}
+int orc_run_filters_until_passing(orc* o, int pod, int* last_index) {
+    PODCHK(o, pod);
+    return run_filters_until_passing(o, pod, 0, last_index);
+}
+
+/* ------------------------------------------------------------------------------------- */
+/* limiter + thresholds                                                                    */
+/* ------------------------------------------------------------------------------------- */
+/* getMinLimit  CA/estimator/threshold_based_limiter.go:45-53 */
+int64_t orc_get_min_limit(int64_t base, int64_t target) {
+    if (base < 0 || target < 0) return -1;
+    if ((base == 0 || base > target) && target > 0) return target;
+    return base;
+}
+/* StartEstimation :34-43 (duration part disabled: oracle runs with maxDuration 0) */
+void orc_limiter_start(orc_limiter* l, int n, const int* node_limits) {
+    l->nodes = 0; l->max_nodes = 0;
+    for (int i = 0; i < n; ++i) l->max_nodes = (int)orc_get_min_limit(l->max_nodes, node_limits[i]);
+}
+/* PermissionToAddNode :57-69 */
+int orc_limiter_permission(orc_limiter* l) {
+    if (l->max_nodes < 0 || (l->max_nodes > 0 && l->nodes >= l->max_nodes)) return 0;
+    l->nodes++;
+    return 1;
+}
+/* sngCapacityThreshold  CA/estimator/sng_capacity_threshold.go:34-59 */
+int orc_sng_capacity_limit(int has_context, int n, const int* max_size, const int* target_size) {
+    if (!has_context) return 0;
+    int total = 0;
+    for (int i = 0; i < n; ++i) { int c = max_size[i] - target_size[i]; if (c > 0) total += c; }
+    if (total <= 0) return -1;
+    return total;
+}
+/* clusterCapacityThreshold  CA/estimator/cluster_capacity_threshold.go:33-41 */
+int orc_cluster_capacity_limit(int has_context, int cluster_max, int current_nodes) {
+    if (!has_context || cluster_max == 0) return 0;
+    if (cluster_max < 0 || cluster_max <= current_nodes) return -1;
+    return cluster_max - current_nodes;
+}
+
+/* ------------------------------------------------------------------------------------- */
+/* orderer + fastpath chooser                                                              */
+/* ------------------------------------------------------------------------------------- */
+/* calculatePodScore  CA/estimator/decreasing_pod_orderer.go:64-88 */
+double orc_pod_score(int64_t cpu_req, int64_t mem_req, int64_t cpu_alloc, int64_t mem_alloc) {
+    double score = 0;
+    if (cpu_alloc > 0) score += (double)cpu_req / (double)cpu_alloc;
+    if (mem_alloc > 0) score += (double)mem_req / (double)mem_alloc;
+    return score;
+}
+/* Order :46-62; ties keep input order (canonical rule, see header) */
+void orc_order(int n, const int64_t* cpu_req, const int64_t* mem_req, const uint8_t* has_exemplar,
+               int64_t cpu_alloc, int64_t mem_alloc, int32_t* order_out) {
+    double* score = malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; ++i) {
+        score[i] = (has_exemplar && !has_exemplar[i]) ? 0.0 : orc_pod_score(cpu_req[i], mem_req[i], cpu_alloc, mem_alloc);
+        order_out[i] = i;
+    }
+    for (int i = 1; i < n; ++i) { /* stable insertion sort, descending */
+        int32_t x = order_out[i]; int j = i - 1;
+        while (j >= 0 && score[order_out[j]] < score[x]) { order_out[j + 1] = order_out[j]; --j; }
+        order_out[j + 1] = x;
+    }
+    free(score);
+}
+/* determineBestPEGToFastpath  CA/estimator/binpacking_estimator.go:433-473 */
+int orc_best_fastpath_peg(int n, const int32_t* count, const double* cpu_req, const double* mem_req,
+                          const uint8_t* aa_self_hostname, const uint8_t* fastpath_ok,
+                          const uint8_t* has_requests, double cap_cpu, double cap_mem) {
+    int max_saved = 0, best = -1;
+    for (int i = 0; i < n; ++i) {
+        if (count[i] == 0) continue; /* Exemplar() == nil */
+        int by_aa = aa_self_hostname[i] ? count[i] : 0, by_cpu = 0, by_mem = 0;
+        if (has_requests[i]) {
+            by_cpu = (int)ceil((double)count[i] * cpu_req[i] / cap_cpu);
+            by_mem = (int)ceil((double)count[i] * mem_req[i] / cap_mem);
+        }
+        int nodes = by_aa; if (by_cpu > nodes) nodes = by_cpu; if (by_mem > nodes) nodes = by_mem;
+        int saved = 0;
+        if (nodes > 0) saved = count[i] - count[i] / nodes;
+        if (saved >= max_saved && fastpath_ok[i]) { best = i; max_saved = saved; }
+    }
+    return best;
+}
+
+/* ------------------------------------------------------------------------------------- */
+/* Estimate                                                                                */
+/* ------------------------------------------------------------------------------------- */
+typedef struct {
+    orc* o;
+    int template_node;
+    int new_index;          /* estimationState.newNodeNameIndex */
+    int last_node;          /* snapshot index of lastNodeName, -1 = "" */
+    orc_limiter limiter;
+    int last_index;         /* runner.defaultNodeOrdering.lastIndex */
+    int fake_nodes;         /* fastpath fake nodes with pods */
+    int scheduled;
+    int64_t cpu_sum, mem_sum;
+} est_state;
+
+/* labelSelectorMatches(term.LabelSelector, exemplar.Labels) && key == hostname
+ * binpacking_estimator.go:444-450 */
+static int peg_aa_self_hostname(const orc* o, const podspec* p) {
+    for (int t = 0; t < p->anti_terms.n; ++t) {
+        const aff_term* term = &p->anti_terms.v[t];
+        if (term->topology_key == o->id_hostname && selector_matches(o, &term->selector, p->labels.v, p->labels.n)) return 1;
+    }
+    return 0;
+}
+/* shouldUseFastPath :411-425 / hasNonHostnamePodAntiAffinity :399-409 */
+static int peg_fastpath_ok(const orc* o, const podspec* p) {
+    if (p->has_topology_spread) return 0;
+    for (int t = 0; t < p->anti_terms.n; ++t) if (p->anti_terms.v[t].topology_key != o->id_hostname) return 0;
+    return 1;
+}
+
+/* addNewNodeToSnapshot :326-342 + SanitizedNodeInfo CA/simulator/node_info_utils.go:93-137 */
+static void add_new_node(est_state* s) {
+    orc* o = s->o;
+    const node* tmpl = &o->nodes.v[s->template_node];
+    node nn = node_clone(tmpl); /* DeepCopy; preloaded pods are copied with it (:111-118) */
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s-e-%d", o->st.s[tmpl->name], s->new_index);
+    nn.name = intern(&o->st, buf);
+    node_set_label(&nn, o->id_hostname, nn.name); /* :130 */
+    nn.is_new = 1; nn.new_pods = 0;
+    VEC_PUSH(o->snap, nn);
+    s->new_index++;
+    s->last_node = o->snap.n - 1;
+}
+/* SchedulePod success path: createPodInfo + StorePodInfo  predicate_snapshot.go:281-286,
+ * then estimationState.trackScheduledPod  binpacking_estimator.go:58-61 */
+static void commit(est_state* s, int pod, int node_idx) {
+    orc* o = s->o;
+    node_add_pod(o, &o->snap.v[node_idx], pod);
+    o->snap.v[node_idx].new_pods++;
+    s->scheduled++;
+    s->cpu_sum += o->pods.v[pod].req[0];
+    s->mem_sum += o->pods.v[pod].req[1];
+}
+
+/* tryToScheduleOnExistingNodes :163-186; returns index of first unscheduled pod */
+static int try_existing(est_state* s, int pod, int count) {
+    int index;
+    for (index = 0; index < count; ++index) {
+        int nd = run_filters_until_passing(s->o, pod, 1, &s->last_index);
+        if (nd < 0) break;
+        commit(s, pod, nd);
+    }
+    return index;
+}
+/* tryToScheduleOnNewNodes :190-269; returns newNodesAvailable; *placed += pods scheduled.
+ * (the hostname-topology-spread retry :212-227 is outside the encoded subset) */
+static int try_new_nodes(est_state* s, int pod, int count, int* placed) {
+    orc* o = s->o;
+    for (int i = 0; i < count; ++i) {
+        int found = 0;
+        if (s->last_node >= 0) {
+            if (run_filters_on_node(o, pod, s->last_node, NULL, NULL)) { found = 1; commit(s, pod, s->last_node); (*placed)++; }
+        }
+        if (!found) {
+            if (s->last_node >= 0 && o->snap.v[s->last_node].new_pods == 0) return 1; /* :234-236 */
+            if (!orc_limiter_permission(&s->limiter)) return 0;                       /* :244-246 */
+            add_new_node(s);                                                            /* :249 */
+            if (!run_filters_on_node(o, pod, s->last_node, NULL, NULL)) break;         /* :257-263 */
+            commit(s, pod, s->last_node); (*placed)++;
+        }
+    }
+    return 1;
+}
+/* tryFastPath :274-324 */
+static int try_fast_path(est_state* s, int pod, int count, int* placed) {
+    orc* o = s->o;
+    if (count == 0) return 1;
+    if (!orc_limiter_permission(&s->limiter)) return 0;
+    add_new_node(s);
+    int i = 0;
+    for (; i < count; ++i) {
+        if (!run_filters_on_node(o, pod, s->last_node, NULL, NULL)) break;
+        commit(s, pod, s->last_node); (*placed)++;
+    }
+    int per_node = i;
+    if (per_node == 0) return 1;
+    int size = count / per_node;
+    if (per_node * size < count) size++;
+    for (int j = 1; j < size; ++j) {
+        if (!orc_limiter_permission(&s->limiter)) return 0;
+        int k = per_node < count - i ? per_node : count - i;
+        /* trackScheduledPod(pods[i+k], fakeNodeName): counted, not simulated */
+        s->fake_nodes++;
+        s->scheduled += k; *placed += k;
+        s->cpu_sum += (int64_t)k * o->pods.v[pod].req[0];
+        s->mem_sum += (int64_t)k * o->pods.v[pod].req[1];
+        i += k;
+    }
+    return 1;
+}
+
+int orc_estimate(orc* o, int template_node, int n_pegs, const int32_t* peg_pod, const int32_t* peg_count,
+                 int max_nodes, int last_index, int fastpath, orc_estimate_result* out) {
+    NODECHK(o, template_node);
+    for (int i = 0; i < n_pegs; ++i) { PODCHK(o, peg_pod[i]); if (peg_count[i] < 0) return -1; }
+    const node* tmpl = &o->nodes.v[template_node];
+    o->filter_runs = 0;
+
+    est_state s; memset(&s, 0, sizeof s);
+    s.o = o; s.template_node = template_node; s.last_node = -1; s.last_index = last_index;
+    /* limiter.StartEstimation :109 with one static threshold (maxNodes, duration 0) */
+    orc_limiter_start(&s.limiter, 1, &max_nodes);
+
+    /* podOrderer.Order :112 */
+    int64_t* cpu = malloc(sizeof(int64_t) * (size_t)(n_pegs + 1));
+    int64_t* mem = malloc(sizeof(int64_t) * (size_t)(n_pegs + 1));
+    uint8_t* has = malloc((size_t)(n_pegs + 1));
+    for (int i = 0; i < n_pegs; ++i) { cpu[i] = o->pods.v[peg_pod[i]].req[0]; mem[i] = o->pods.v[peg_pod[i]].req[1]; has[i] = peg_count[i] > 0; }
+    orc_order(n_pegs, cpu, mem, has, tmpl->alloc[0], tmpl->alloc[1], out->order);
+
+    /* fastpath: move the best PEG last :114-124 */
+    int use_fast_last = 0;
+    if (fastpath && n_pegs > 0) {
+        int32_t* cnt = malloc(sizeof(int32_t) * (size_t)n_pegs);
+        double* fc = malloc(sizeof(double) * (size_t)n_pegs); double* fm = malloc(sizeof(double) * (size_t)n_pegs);
+        uint8_t* aa = malloc((size_t)n_pegs); uint8_t* ok = malloc((size_t)n_pegs); uint8_t* hr = malloc((size_t)n_pegs);
+        for (int k = 0; k < n_pegs; ++k) {
+            const podspec* p = &o->pods.v[peg_pod[out->order[k]]];
+            cnt[k] = peg_count[out->order[k]]; fc[k] = p->fp_cpu; fm[k] = p->fp_mem; hr[k] = (uint8_t)p->fp_has_requests;
+            aa[k] = (uint8_t)peg_aa_self_hostname(o, p); ok[k] = (uint8_t)peg_fastpath_ok(o, p);
+        }
+        /* Capacity.Cpu().AsApproximateFloat64(): milli value * 10^-3 (quantity.go:468-483) */
+        int best = orc_best_fastpath_peg(n_pegs, cnt, fc, fm, aa, ok, hr, tmpl->fp_cap_cpu, tmpl->fp_cap_mem);
+        if (best != -1) {
+            int32_t b = out->order[best];
+            for (int k = best; k + 1 < n_pegs; ++k) out->order[k] = out->order[k + 1];
+            out->order[n_pegs - 1] = b;
+            use_fast_last = 1;
+        }
+        free(cnt); free(fc); free(fm); free(aa); free(ok); free(hr);
+    }
+    free(cpu); free(mem); free(has);
+
+    /* clusterSnapshot.Fork :126 */
+    int fork_len = o->snap.n;
+
+    int more = 1;
+    for (int k = 0; k < n_pegs; ++k) {
+        int pg = out->order[k], pod = peg_pod[pg], count = peg_count[pg];
+        int done = try_existing(&s, pod, count);             /* :137 */
+        int placed = done;
+        if (more) {
+            if (k == n_pegs - 1 && use_fast_last) more = try_fast_path(&s, pod, count - done, &placed);   /* :146 */
+            else more = try_new_nodes(&s, pod, count - done, &placed);                                    /* :148 */
+        }
+        out->placed[k] = placed;
+    }
+
+    int with_pods = 0, added = 0;
+    for (int i = fork_len; i < o->snap.n; ++i) {
+        if (out->node_pods && added < out->node_pods_cap) out->node_pods[added] = o->snap.v[i].new_pods;
+        added++;
+        if (o->snap.v[i].new_pods > 0) with_pods++;
+    }
+    out->node_count = with_pods + s.fake_nodes;  /* len(newNodesWithPods) :160 */
+    out->pods_scheduled = s.scheduled;
+    out->nodes_added = added;
+    out->limiter_nodes = s.limiter.nodes;
+    out->last_index_out = s.last_index;
+    out->internal_error = 0;
+    out->req_cpu_sum = s.cpu_sum; out->req_mem_sum = s.mem_sum;
+    out->filter_runs = o->filter_runs;
+
+    /* clusterSnapshot.Revert :127-129 */
+    for (int i = fork_len; i < o->snap.n; ++i) node_free(&o->snap.v[i]);
+    o->snap.n = fork_len;
+    return 0;
+}
+
+/* SchedulablePodGroups' CheckPredicates  CA/core/scaleup/orchestrator/orchestrator.go:542-552:
+ * Fork; AddNodeInfo(template itself); CheckPredicates(exemplar, template name); Revert */
+int orc_check_predicates(orc* o, int template_node, int pod, const char** plugin_out, const char** reason_out) {
+    NODECHK(o, template_node); PODCHK(o, pod);
+    node c = node_clone(&o->nodes.v[template_node]);
+    VEC_PUSH(o->snap, c);
+    int ok = run_filters_on_node(o, pod, o->snap.n - 1, plugin_out, reason_out);
+    node_free(&o->snap.v[o->snap.n - 1]);
+    o->snap.n--;
+    return ok;
+}
+
+/* ------------------------------------------------------------------------------------- */
+/* expander filters                                                                        */
+/* ------------------------------------------------------------------------------------- */
+/* leastnodes.BestOptions  CA/expander/leastnodes/leastnodes.go:35-61 */
+int orc_least_nodes(int n, const int32_t* node_count, uint8_t* sel) {
+    int least = INT_MAX, cnt = 0;
+    memset(sel, 0, (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (node_count[i] == 0) continue;
+        if (node_count[i] == least) { sel[i] = 1; cnt++; continue; }
+        if (node_count[i] < least) { least = node_count[i]; memset(sel, 0, (size_t)n); sel[i] = 1; cnt = 1; }
+    }
+    return cnt;
+}
+/* mostpods.BestOptions  CA/expander/mostpods/mostpods.go:33-53 */
+int orc_most_pods(int n, const int32_t* pod_count, uint8_t* sel) {
+    int maxp = 0, cnt = 0;
+    memset(sel, 0, (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (pod_count[i] == maxp) { sel[i] = 1; cnt++; continue; }
+        if (pod_count[i] > maxp) { maxp = pod_count[i]; memset(sel, 0, (size_t)n); sel[i] = 1; cnt = 1; }
+    }
+    return cnt;
+}
+/* leastwaste.BestOptions  CA/expander/waste/waste.go:37-73 (statement order kept: the
+ * equality append runs BEFORE the "nil or smaller" replacement) */
+int orc_least_waste(int n, const int32_t* node_count, const int64_t* req_cpu, const int64_t* req_mem,
+                    const int64_t* node_cpu, const int64_t* node_mem, const uint8_t* has_node_info, uint8_t* sel) {
+    double least = 0; int have = 0, cnt = 0;
+    memset(sel, 0, (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (has_node_info && !has_node_info[i]) continue;
+        int64_t avail_cpu = node_cpu[i] * (int64_t)node_count[i];
+        int64_t avail_mem = node_mem[i] * (int64_t)node_count[i];
+        double wasted_cpu = (double)(avail_cpu - req_cpu[i]) / (double)avail_cpu;
+        double wasted_mem = (double)(avail_mem - req_mem[i]) / (double)avail_mem;
+        double score = wasted_cpu + wasted_mem;
+        if (score == least) { sel[i] = 1; cnt++; have = 1; }
+        if (!have || score < least) { least = score; memset(sel, 0, (size_t)n); sel[i] = 1; cnt = 1; have = 1; }
+    }
+    return cnt;
+}

@@ -1,0 +1,205 @@
+// casim_emu.cpp — cooperative-fiber wave64 emulator (TEST INFRASTRUCTURE ONLY). See casim_emu.h.
+#include "casim_emu.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+
+#include <vector>
+
+namespace casim_emu {
+namespace {
+
+constexpr size_t kStack = 256 * 1024;
+
+struct Fiber {
+    ucontext_t uc;
+    FiberCtx ctx;
+    char* stack = nullptr;
+    bool done = false;
+};
+
+struct WaveState {
+    int size = 0;        // lanes in this wave
+    int arrived = 0;
+    uint64_t gen = 0;
+    uint64_t slot[64];
+    uint64_t result = 0;
+};
+
+struct Block {
+    std::vector<Fiber> fibers;
+    std::vector<WaveState> waves;
+    int n = 0;
+    int cur = 0;
+    int arrived = 0;
+    uint64_t gen = 0;
+    int live = 0;
+    uint64_t events = 0;  // bumped by every completed collective / finished fiber (deadlock detection)
+    ucontext_t sched;
+    const std::function<void()>* body = nullptr;
+    std::vector<char> smem;
+};
+
+Block* g_blk = nullptr;
+
+void yield_fiber() {
+    Block& b = *g_blk;
+    Fiber& f = b.fibers[b.cur];
+    swapcontext(&f.uc, &b.sched);
+}
+
+void trampoline() {
+    Block& b = *g_blk;
+    (*b.body)();
+    b.fibers[b.cur].done = true;
+    b.live--;
+    b.events++;
+    swapcontext(&b.fibers[b.cur].uc, &b.sched);
+}
+
+WaveState& my_wave() { return g_blk->waves[g_blk->fibers[g_blk->cur].ctx.tid >> 6]; }
+int my_lane() { return g_blk->fibers[g_blk->cur].ctx.tid & 63; }
+
+// two-phase wave collective: everyone deposits, last arriver combines, everyone reads
+template <class Combine>
+uint64_t wave_collective(uint64_t v, Combine combine) {
+    WaveState& w = my_wave();
+    const int lane = my_lane();
+    w.slot[lane] = v;
+    const uint64_t g = w.gen;
+    if (++w.arrived == w.size) {
+        w.result = combine(w);
+        w.arrived = 0;
+        w.gen++;
+        g_blk->events++;
+    } else {
+        while (w.gen == g) yield_fiber();
+    }
+    return w.result;
+}
+
+}  // namespace
+
+FiberCtx& cur() { return g_blk->fibers[g_blk->cur].ctx; }
+char* dyn_smem() { return g_blk->smem.data(); }
+
+void block_sync() {
+    Block& b = *g_blk;
+    const uint64_t g = b.gen;
+    if (++b.arrived == b.n) {
+        b.arrived = 0;
+        b.gen++;
+        b.events++;
+    } else {
+        while (b.gen == g) yield_fiber();
+    }
+}
+
+uint64_t wave_ballot(bool p) {
+    return wave_collective(p ? 1 : 0, [](WaveState& w) {
+        uint64_t m = 0;
+        for (int i = 0; i < w.size; ++i) m |= (w.slot[i] & 1ull) << i;
+        return m;
+    });
+}
+
+uint64_t wave_xchg_u64(uint64_t v, int src_lane) {
+    // the exchanged vector must survive until every lane has read its source: snapshot per generation
+    WaveState& w = my_wave();
+    const int lane = my_lane();
+    static thread_local uint64_t snap[64][64];  // [wave % 64][lane]
+    const int widx = (g_blk->fibers[g_blk->cur].ctx.tid >> 6) & 63;
+    w.slot[lane] = v;
+    const uint64_t g = w.gen;
+    if (++w.arrived == w.size) {
+        for (int i = 0; i < 64; ++i) snap[widx][i] = i < w.size ? w.slot[i] : 0;
+        w.arrived = 0;
+        w.gen++;
+        g_blk->events++;
+    } else {
+        while (w.gen == g) yield_fiber();
+    }
+    // second rendezvous so that nobody overwrites snap before all lanes have read it
+    const uint64_t out = snap[widx][src_lane & 63];
+    const uint64_t g2 = w.gen;
+    if (++w.arrived == w.size) {
+        w.arrived = 0;
+        w.gen++;
+        g_blk->events++;
+    } else {
+        while (w.gen == g2) yield_fiber();
+    }
+    return out;
+}
+
+uint64_t wave_sum_u64(uint64_t v) {
+    return wave_collective(v, [](WaveState& w) {
+        uint64_t s = 0;
+        for (int i = 0; i < w.size; ++i) s += w.slot[i];
+        return s;
+    });
+}
+uint64_t wave_max_u64(uint64_t v) {
+    return wave_collective(v, [](WaveState& w) {
+        uint64_t s = 0;
+        for (int i = 0; i < w.size; ++i) s = w.slot[i] > s ? w.slot[i] : s;
+        return s;
+    });
+}
+
+void launch(int gx, int gy, int block, size_t smem, const std::function<void()>& body) {
+    Block blk;
+    blk.n = block;
+    blk.fibers.resize((size_t)block);
+    blk.waves.resize((size_t)(block + 63) / 64);
+    blk.smem.assign(smem + 64, 0);
+    blk.body = &body;
+    for (int i = 0; i < block; ++i) blk.fibers[(size_t)i].stack = (char*)malloc(kStack);
+    Block* prev = g_blk;
+    g_blk = &blk;
+    for (int by = 0; by < gy; ++by) {
+        for (int bx = 0; bx < gx; ++bx) {
+            blk.arrived = 0; blk.gen = 0; blk.live = block;
+            for (size_t w = 0; w < blk.waves.size(); ++w) {
+                blk.waves[w].arrived = 0; blk.waves[w].gen = 0;
+                const int left = block - (int)w * 64;
+                blk.waves[w].size = left < 64 ? left : 64;
+            }
+            // LDS content is undefined at kernel start: poison it so that reads of unwritten LDS show up
+            memset(blk.smem.data(), 0xA5, blk.smem.size());
+            for (int i = 0; i < block; ++i) {
+                Fiber& f = blk.fibers[(size_t)i];
+                f.ctx = FiberCtx{i, bx, by, block, gx};
+                f.done = false;
+                getcontext(&f.uc);
+                f.uc.uc_stack.ss_sp = f.stack;
+                f.uc.uc_stack.ss_size = kStack;
+                f.uc.uc_link = nullptr;
+                makecontext(&f.uc, (void (*)())trampoline, 0);
+            }
+            long spins = 0;
+            while (blk.live > 0) {
+                bool progressed = false;
+                for (int i = 0; i < block; ++i) {
+                    if (blk.fibers[(size_t)i].done) continue;
+                    blk.cur = i;
+                    const uint64_t ev_before = blk.events;
+                    swapcontext(&blk.sched, &blk.fibers[(size_t)i].uc);
+                    progressed |= blk.events != ev_before;
+                }
+                // a block whose threads wait forever (divergent collective) would spin here
+                if (!progressed && ++spins > 1000) {
+                    fprintf(stderr, "casim_emu: deadlock in block (%d,%d): a collective was not reached by all lanes\n", bx, by);
+                    abort();
+                }
+                if (progressed) spins = 0;
+            }
+        }
+    }
+    g_blk = prev;
+    for (int i = 0; i < block; ++i) free(blk.fibers[(size_t)i].stack);
+}
+
+}  // namespace casim_emu

@@ -1,0 +1,66 @@
+// casim_emu_api.cpp — host backend for casim_pipeline.h running the product kernels under the
+// wave emulator (TEST INFRASTRUCTURE ONLY; built by tests/emu/Makefile into
+// tests/emu/libcasim_emu.so; never part of libcasim.so).
+#define CASIM_HOST_EMU 1
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "casim_emu.h"
+#include "../../kubernetes_autoscaler_amd/csrc/casim_pipeline.h"
+
+namespace {
+struct EmuBackend {
+    size_t lds = 160 * 1024;
+    void* alloc(size_t b) { return calloc(1, b); }
+    void free(void* p) { ::free(p); }
+    void h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
+    void d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
+    void zero(void* d, size_t n) { memset(d, 0, n); }
+    void sync() {}
+    size_t lds_budget() const { return lds; }
+    bool ok() const { return true; }
+    const char* error() const { return ""; }
+    template <class K, class... A>
+    void launch(K kernel, int gx, int gy, int block, size_t smem, A... args) {
+        casim_emu::launch(gx, gy, block, smem, [&]() { kernel(args...); });
+    }
+};
+thread_local std::string g_err;
+}  // namespace
+
+extern "C" {
+
+const char* emu_last_error() { return g_err.c_str(); }
+
+// lds_budget_bytes <= 0 keeps the default (160 KiB); a tiny value forces the HBM-scratch variants.
+int32_t emu_estimate_batch(const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts,
+                           casim_results* out, int64_t lds_budget_bytes, int32_t* nnz_out, int32_t* offsets_out,
+                           const int32_t* kinds, int32_t n_kinds, int32_t group_id_base, int32_t* best_out /*[2]*/,
+                           uint8_t* best_set_out, int64_t* key_out /*[2]*/) {
+    EmuBackend bk;
+    if (lds_budget_bytes > 0) bk.lds = (size_t)lds_budget_bytes;
+    casim::ProblemT<EmuBackend> p(bk);
+    int32_t rc = p.init(pegs, groups, opts);
+    if (rc == CASIM_OK) rc = p.run();
+    if (rc == CASIM_OK) rc = p.fetch(out);
+    if (rc == CASIM_OK && (nnz_out || offsets_out)) rc = p.csr(nnz_out, offsets_out);
+    if (rc == CASIM_OK && n_kinds >= 0 && best_out)
+        rc = p.best_option(kinds, n_kinds, group_id_base, &best_out[0], &best_out[1], best_set_out, key_out, nullptr);
+    if (rc != CASIM_OK) g_err = p.error();
+    return rc;
+}
+
+int32_t emu_feasibility(const casim_pegs* pegs, const casim_groups* groups, uint64_t* out_bits) {
+    EmuBackend bk;
+    casim::ProblemT<EmuBackend> p(bk);
+    casim_groups g = *groups;
+    g.peg_offsets = nullptr; g.peg_index = nullptr;
+    int32_t rc = p.init(pegs, &g, nullptr);
+    if (rc == CASIM_OK) rc = p.run_feasibility();
+    if (rc == CASIM_OK) rc = p.fetch_bits(out_bits);
+    if (rc != CASIM_OK) g_err = p.error();
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,232 @@
+"""ctypes driver of the CPU oracle (oracle/libcasim_oracle.so).  TEST INFRASTRUCTURE: imported only by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg — never by the product package."""
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Sequence
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "libcasim_oracle.so")
+MAX_RES = 8
+
+i32p = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
+u8p = C.POINTER(C.c_uint8)
+f64p = C.POINTER(C.c_double)
+cstr = C.c_char_p
+cstrp = C.POINTER(C.c_char_p)
+
+
+class EstimateResult(C.Structure):
+    _fields_ = [
+        ("node_count", C.c_int32), ("pods_scheduled", C.c_int32), ("nodes_added", C.c_int32),
+        ("limiter_nodes", C.c_int32), ("last_index_out", C.c_int32), ("internal_error", C.c_int32),
+        ("req_cpu_sum", C.c_int64), ("req_mem_sum", C.c_int64), ("filter_runs", C.c_int64),
+        ("order", i32p), ("placed", i32p), ("node_pods", i32p), ("node_pods_cap", C.c_int32),
+    ]
+
+
+class Limiter(C.Structure):
+    _fields_ = [("max_nodes", C.c_int), ("nodes", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            import subprocess
+            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+        L = C.CDLL(LIB)
+        P = C.c_void_p
+        sigs = {
+            "orc_new": (P, [C.c_int]), "orc_free": (None, [P]),
+            "orc_pod": (C.c_int, [P, cstr, i64p]), "orc_pod_label": (C.c_int, [P, C.c_int, cstr, cstr]),
+            "orc_pod_toleration": (C.c_int, [P, C.c_int, cstr, cstr, cstr, cstr]),
+            "orc_pod_node_selector": (C.c_int, [P, C.c_int, cstr, cstr]),
+            "orc_pod_node_affinity_req": (C.c_int, [P, C.c_int, cstr, cstr, cstrp, C.c_int]),
+            "orc_pod_host_port": (C.c_int, [P, C.c_int, cstr, cstr, C.c_int]),
+            "orc_pod_anti_affinity_term": (C.c_int, [P, C.c_int, cstr, cstrp, C.c_int]),
+            "orc_term_requirement": (C.c_int, [P, C.c_int, C.c_int, cstr, cstr, cstrp, C.c_int]),
+            "orc_pod_fastpath_requests": (C.c_int, [P, C.c_int, C.c_double, C.c_double]),
+            "orc_pod_has_topology_spread": (C.c_int, [P, C.c_int, C.c_int]),
+            "orc_node": (C.c_int, [P, cstr, i64p, C.c_int, C.c_int64, C.c_int64, C.c_int]),
+            "orc_node_fastpath_capacity": (C.c_int, [P, C.c_int, C.c_double, C.c_double]),
+            "orc_node_label": (C.c_int, [P, C.c_int, cstr, cstr]),
+            "orc_node_taint": (C.c_int, [P, C.c_int, cstr, cstr, cstr]),
+            "orc_node_add_pod": (C.c_int, [P, C.c_int, C.c_int]),
+            "orc_snapshot_add": (C.c_int, [P, C.c_int]),
+            "orc_set_taint_comparison_ops": (None, [P, C.c_int]),
+            "orc_estimate": (C.c_int, [P, C.c_int, C.c_int, i32p, i32p, C.c_int, C.c_int, C.c_int, C.POINTER(EstimateResult)]),
+            "orc_check_predicates": (C.c_int, [P, C.c_int, C.c_int, cstrp, cstrp]),
+            "orc_run_filters_on_snapshot_node": (C.c_int, [P, C.c_int, C.c_int, cstrp, cstrp]),
+            "orc_run_filters_until_passing": (C.c_int, [P, C.c_int, C.POINTER(C.c_int)]),
+            "orc_get_min_limit": (C.c_int64, [C.c_int64, C.c_int64]),
+            "orc_sng_capacity_limit": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+            "orc_cluster_capacity_limit": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+            "orc_limiter_start": (None, [C.POINTER(Limiter), C.c_int, C.POINTER(C.c_int)]),
+            "orc_limiter_permission": (C.c_int, [C.POINTER(Limiter)]),
+            "orc_last_index_at": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+            "orc_pod_score": (C.c_double, [C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
+            "orc_order": (None, [C.c_int, i64p, i64p, u8p, C.c_int64, C.c_int64, i32p]),
+            "orc_best_fastpath_peg": (C.c_int, [C.c_int, i32p, f64p, f64p, u8p, u8p, u8p, C.c_double, C.c_double]),
+            "orc_least_nodes": (C.c_int, [C.c_int, i32p, u8p]),
+            "orc_most_pods": (C.c_int, [C.c_int, i32p, u8p]),
+            "orc_least_waste": (C.c_int, [C.c_int, i32p, i64p, i64p, i64p, i64p, u8p, u8p]),
+        }
+        for name, (res, args) in sigs.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _b(s):
+    return (s or "").encode("utf-8")
+
+
+def _strs(values):
+    arr = (C.c_char_p * max(len(values), 1))()
+    for i, v in enumerate(values):
+        arr[i] = _b(v)
+    return arr
+
+
+@dataclass
+class OracleEstimate:
+    node_count: int
+    pods_scheduled: int
+    nodes_added: int
+    limiter_nodes: int
+    last_index_out: int
+    req_cpu_sum: int
+    req_mem_sum: int
+    filter_runs: int
+    order: np.ndarray      # input PEG index processed k-th
+    placed: np.ndarray     # pods scheduled of that PEG
+    node_pods: np.ndarray  # pods per simulated node
+
+
+class OracleScenario:
+    """A cluster snapshot + pod specs + node templates inside the oracle."""
+
+    def __init__(self, lanes: Sequence[str] = ("cpu", "memory"), taint_comparison_ops: bool = False):
+        self.L = lib()
+        self.lanes = tuple(lanes)
+        self.h = self.L.orc_new(len(self.lanes))
+        assert self.h
+        if taint_comparison_ops:
+            self.L.orc_set_taint_comparison_ops(self.h, 1)
+        self._pod_ids: Dict[int, int] = {}
+        self._keep: List[object] = []
+
+    def close(self):
+        if self.h:
+            self.L.orc_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _vec(self, res):
+        v = (C.c_int64 * MAX_RES)()
+        for i, name in enumerate(self.lanes):
+            v[i] = int(res.get(name, 0))
+        return v
+
+    def pod(self, pod) -> int:
+        key = id(pod)
+        if key in self._pod_ids:
+            return self._pod_ids[key]
+        self._keep.append(pod)
+        L, h = self.L, self.h
+        p = L.orc_pod(h, _b(pod.namespace), self._vec(pod.requests))
+        assert p >= 0
+        for k, v in pod.labels.items():
+            L.orc_pod_label(h, p, _b(k), _b(v))
+        for t in pod.tolerations:
+            L.orc_pod_toleration(h, p, _b(t.key), _b(t.operator), _b(t.value), _b(t.effect))
+        for k, v in pod.node_selector.items():
+            L.orc_pod_node_selector(h, p, _b(k), _b(v))
+        for r in pod.node_affinity:
+            L.orc_pod_node_affinity_req(h, p, _b(r.key), _b(r.operator), _strs(r.values), len(r.values))
+        for hp in pod.host_ports:
+            L.orc_pod_host_port(h, p, _b(hp.host_ip), _b(hp.protocol), int(hp.host_port))
+        for term in pod.anti_affinity:
+            t = L.orc_pod_anti_affinity_term(h, p, _b(term.topology_key), _strs(term.namespaces), len(term.namespaces))
+            for r in term.requirements():
+                L.orc_term_requirement(h, p, t, _b(r.key), _b(r.operator), _strs(r.values), len(r.values))
+        if pod.has_containers:
+            cpu, mem = pod.fastpath_requests()
+            L.orc_pod_fastpath_requests(h, p, cpu, mem)
+        if pod.topology_spread:
+            L.orc_pod_has_topology_spread(h, p, 1)
+        self._pod_ids[key] = p
+        return p
+
+    def node(self, info) -> int:
+        """info: NodeInfo (node + preloaded pods)"""
+        L, h = self.L, self.h
+        nd = info.node
+        n = L.orc_node(h, _b(nd.name), self._vec(nd.allocatable), nd.allowed_pods(), int(nd.capacity.get("cpu", 0)),
+                       int(nd.capacity.get("memory", 0)), int(nd.unschedulable))
+        assert n >= 0
+        for k, v in nd.labels.items():
+            L.orc_node_label(h, n, _b(k), _b(v))
+        for t in nd.taints:
+            L.orc_node_taint(h, n, _b(t.key), _b(t.value), _b(t.effect))
+        for p in info.pods:
+            L.orc_node_add_pod(h, n, self.pod(p))
+        return n
+
+    def add_existing(self, info) -> int:
+        """AddNodeInfo into the cluster snapshot (list order = insertion order)."""
+        return self.L.orc_snapshot_add(self.h, self.node(info))
+
+    def estimate(self, template_node: int, pegs, max_nodes: int = 0, last_index: int = 0, fastpath: bool = False,
+                 node_pods_cap: int = 0) -> OracleEstimate:
+        n = len(pegs)
+        pod_ids = (C.c_int32 * max(n, 1))()
+        counts = (C.c_int32 * max(n, 1))()
+        from kubernetes_autoscaler_amd.objects import Pod
+        for i, g in enumerate(pegs):
+            ex = g.exemplar()
+            if ex is None:
+                ex = Pod(name="<empty>")
+                self._keep.append(ex)
+            pod_ids[i] = self.pod(ex)
+            counts[i] = len(g.pods)
+        order = np.zeros(max(n, 1), np.int32)
+        placed = np.zeros(max(n, 1), np.int32)
+        cap = node_pods_cap or 1
+        node_pods = np.zeros(cap, np.int32)
+        res = EstimateResult(order=order.ctypes.data_as(i32p), placed=placed.ctypes.data_as(i32p),
+                             node_pods=node_pods.ctypes.data_as(i32p) if node_pods_cap else None, node_pods_cap=node_pods_cap)
+        rc = self.L.orc_estimate(self.h, template_node, n, pod_ids, counts, int(max_nodes), int(last_index), int(fastpath), C.byref(res))
+        assert rc == 0, rc
+        return OracleEstimate(res.node_count, res.pods_scheduled, res.nodes_added, res.limiter_nodes, res.last_index_out,
+                              res.req_cpu_sum, res.req_mem_sum, res.filter_runs, order[:n].copy(), placed[:n].copy(),
+                              node_pods[:min(res.nodes_added, node_pods_cap)].copy())
+
+    def check_predicates(self, template_node: int, pod):
+        plug, reason = C.c_char_p(), C.c_char_p()
+        ok = self.L.orc_check_predicates(self.h, template_node, self.pod(pod), C.byref(plug), C.byref(reason))
+        return bool(ok), (plug.value or b"").decode(), (reason.value or b"").decode()
+
+    def run_filters_on_node(self, snapshot_index: int, pod):
+        plug, reason = C.c_char_p(), C.c_char_p()
+        ok = self.L.orc_run_filters_on_snapshot_node(self.h, snapshot_index, self.pod(pod), C.byref(plug), C.byref(reason))
+        return bool(ok), (plug.value or b"").decode(), (reason.value or b"").decode()
+
+    def run_filters_until_passing(self, pod, last_index: int = 0):
+        li = C.c_int(last_index)
+        idx = self.L.orc_run_filters_until_passing(self.h, self.pod(pod), C.byref(li))
+        return idx, li.value

@@ -1,0 +1,218 @@
+"""Pins the CPU oracle (oracle/casim_oracle.c) against the reference's own known-answer tests
+(tests/golden/reference_vectors.json).  CPU only."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from kubernetes_autoscaler_amd.objects import (MiB, NodeInfo, Pod, Taint, build_test_node, build_test_pod, make_node,
+                                               make_pod_equivalence_group, with_host_port, with_labels, with_max_skew,
+                                               with_namespace)
+from oracle_driver import Limiter, OracleScenario, lib
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")))
+
+
+def _estimate_case(case, fastpath, setup, template_pods=None):
+    s = OracleScenario()
+    ex = setup["existing_node"]
+    s.add_existing(NodeInfo(make_node(ex["cpu"], ex["mem_mib"], ex["pods"], ex["name"], ex["zone"])))
+    t = setup["template"]
+    tmpl = s.node(NodeInfo(make_node(case["millicores"], case["memory_mib"], template_pods or t["pods"], t["name"], t["zone"])))
+    pegs = []
+    for g in case["pegs"]:
+        opts = [with_namespace(setup["namespace"]), with_labels(setup["labels"])]
+        if g.get("host_port"):
+            opts.append(with_host_port(g["host_port"]))
+        pegs.append(make_pod_equivalence_group(build_test_pod("estimatee", g["cpu"], g["mem"], *opts), g["count"]))
+    return s.estimate(tmpl, pegs, max_nodes=case["max_nodes"], fastpath=fastpath)
+
+
+@pytest.mark.parametrize("case", GOLD["binpacking_estimate"]["cases"], ids=lambda c: c["name"])
+def test_binpacking_estimate(case):
+    setup = GOLD["binpacking_estimate"]["setup"]
+    r = _estimate_case(case, False, setup)
+    assert (r.node_count, r.pods_scheduled) == (case["expect_nodes"], case["expect_pods"])
+    if "expect_placed_by_input_peg" in case:
+        by_input = [0] * len(case["pegs"])
+        for k, pg in enumerate(r.order):
+            by_input[pg] = int(r.placed[k])
+        assert by_input == case["expect_placed_by_input_peg"]
+        assert list(r.order) == [1, 0]  # the high-resource group is processed first
+    if case["check_fastpath"]:
+        # "the result should be consistent with fastpath and non-fastpath" (:246-251)
+        f = _estimate_case(case, True, setup)
+        assert (f.node_count, f.pods_scheduled) == (r.node_count, r.pods_scheduled)
+
+
+def test_benchmark_binpacking_estimate():
+    b = GOLD["binpacking_estimate"]["benchmark"]
+    r = _estimate_case(b, False, GOLD["binpacking_estimate"]["setup"], template_pods=b["template_pods"])
+    assert (r.node_count, r.pods_scheduled) == (b["expect_nodes"], b["expect_pods"])
+    assert list(r.order) == [1, 0] and list(r.placed) == [1000, 50000]
+
+
+@pytest.mark.parametrize("case", GOLD["fastpath_chooser"]["cases"], ids=lambda c: c["name"])
+def test_fastpath_chooser(case):
+    L = lib()
+    n = len(case["pegs"])
+    node = GOLD["fastpath_chooser"]["node"]
+    count = (C.c_int32 * n)(*[g["count"] for g in case["pegs"]])
+    pods = []
+    for g in case["pegs"]:
+        if g.get("no_containers"):
+            pods.append(Pod(name="x", has_containers=False))
+        else:
+            pods.append(build_test_pod("x", g["cpu"], g["mem"], with_max_skew(2, "kubernetes.io/hostname", 1) if g.get("topology_spread") else (lambda p: None)))
+    cpu = (C.c_double * n)(*[p.fastpath_requests()[0] for p in pods])
+    mem = (C.c_double * n)(*[p.fastpath_requests()[1] for p in pods])
+    aa = (C.c_uint8 * n)(*[0] * n)
+    ok = (C.c_uint8 * n)(*[0 if p.topology_spread else 1 for p in pods])
+    hr = (C.c_uint8 * n)(*[1 if p.has_containers else 0 for p in pods])
+    got = L.orc_best_fastpath_peg(n, count, cpu, mem, aa, ok, hr, float(node["cpu"]) * 1e-3, float(node["mem_mib"] * MiB))
+    assert got == case["expect"]
+
+
+@pytest.mark.parametrize("case", GOLD["pod_orderer"]["cases"], ids=lambda c: c["name"])
+def test_pod_orderer(case):
+    L = lib()
+    G = GOLD["pod_orderer"]
+    names = case["input"]
+    n = len(names)
+    cpu = (C.c_int64 * max(n, 1))(*[G["pods"][x]["cpu"] for x in names])
+    mem = (C.c_int64 * max(n, 1))(*[G["pods"][x]["mem"] for x in names])
+    has = (C.c_uint8 * max(n, 1))(*[1] * n)
+    order = (C.c_int32 * max(n, 1))()
+    L.orc_order(n, cpu, mem, has, G["node"]["cpu"], G["node"]["mem_mib"] * MiB, order)
+    assert [names[order[i]] for i in range(n)] == case["expect"]
+
+
+@pytest.mark.parametrize("case", GOLD["limiter"]["cases"], ids=lambda c: c["name"])
+def test_limiter(case):
+    L = lib()
+    lim = Limiter()
+    dyn = case.get("dynamic_threshold_start")
+
+    def start():
+        nonlocal dyn
+        if dyn is not None:
+            dyn += 1  # dynamicThreshold.NodeLimit increments on every StartEstimation (:47-50)
+            ths = [dyn]
+        else:
+            ths = case["thresholds"]
+        arr = (C.c_int * max(len(ths), 1))(*ths)
+        L.orc_limiter_start(C.byref(lim), len(ths), arr)
+
+    start()
+    for op in case["ops"]:
+        if op == "reset":
+            start()
+        else:
+            assert bool(L.orc_limiter_permission(C.byref(lim))) == (op == "allow")
+    assert lim.nodes == case["expect_nodes"]
+
+
+def test_min_limit():
+    L = lib()
+    for base, target, want in GOLD["min_limit"]["cases"]:
+        assert L.orc_get_min_limit(base, target) == want
+
+
+@pytest.mark.parametrize("case", GOLD["sng_capacity_threshold"]["cases"], ids=lambda c: c["name"])
+def test_sng_capacity_threshold(case):
+    L = lib()
+    groups = [case["current"]] + case["similar"]
+    mx = (C.c_int * len(groups))(*[g[0] for g in groups])
+    tg = (C.c_int * len(groups))(*[g[1] for g in groups])
+    assert L.orc_sng_capacity_limit(1, len(groups), mx, tg) == case["want"]
+
+
+def test_cluster_capacity_threshold():
+    L = lib()
+    for mx, cur, want in GOLD["cluster_capacity_threshold"]["cases"]:
+        assert L.orc_cluster_capacity_limit(1, mx, cur) == want
+    assert L.orc_cluster_capacity_limit(0, 10, 5) == 0  # nil context (:34)
+
+
+def test_last_index_order_mapping():
+    L = lib()
+    n = GOLD["last_index_order_mapping"]["n"]
+    for c in GOLD["last_index_order_mapping"]["cases"]:
+        assert [L.orc_last_index_at(i, c["offset"], c["last_match"], n) for i in range(n)] == c["want"]
+    assert L.orc_last_index_at(0, 1, 0, 0) == -1
+
+
+@pytest.mark.parametrize("case", GOLD["run_filters_on_node"]["cases"], ids=lambda c: c["name"])
+def test_run_filters_on_node(case):
+    G = GOLD["run_filters_on_node"]
+    pods = {k: build_test_pod(k, v[0], v[1]) for k, v in G["pods"].items()}
+    s = OracleScenario()
+    nd = G["node"]
+    idx = s.add_existing(NodeInfo(build_test_node(nd["name"], nd["cpu"], nd["mem"]), [pods[x] for x in case["scheduled"]]))
+    ok, plugin, reason = s.run_filters_on_node(idx, pods[case["test"]])
+    assert ok == case["ok"]
+    if not ok:
+        assert plugin == case["plugin"] and reason == case["reason"]
+
+
+@pytest.mark.parametrize("case", GOLD["run_filters_until_passing_node"]["cases"], ids=lambda c: c["name"])
+def test_run_filters_until_passing_node(case):
+    G = GOLD["run_filters_until_passing_node"]
+    # any insertion order must give a node of the expected set (the reference ranges over a Go map)
+    for perm in ([0, 1], [1, 0]):
+        for last_index in (0, 1):
+            s = OracleScenario()
+            names = []
+            for i in perm:
+                nd = G["nodes"][i]
+                s.add_existing(NodeInfo(build_test_node(nd["name"], nd["cpu"], nd["mem"])))
+                names.append(nd["name"])
+            idx, li = s.run_filters_until_passing(build_test_pod("p", case["pod"][0], case["pod"][1]), last_index)
+            if case.get("expect_error"):
+                assert idx == -1 and li == last_index
+            else:
+                assert names[idx] in case["expect_nodes"] and li == idx
+
+
+def test_taints():
+    G = GOLD["taints"]
+    nd = build_test_node(G["node"]["name"], G["node"]["cpu"], G["node"]["mem"])
+    nd.taints = [Taint(*t) for t in G["node"]["taints"]]
+    s = OracleScenario()
+    idx = s.add_existing(NodeInfo(nd))
+    ok, plugin, reason = s.run_filters_on_node(idx, build_test_pod("p1", 0, 0))
+    assert (ok, plugin, reason) == (G["expect"]["ok"], G["expect"]["plugin"], G["expect"]["reason"])
+
+
+def _sel(n, fn, *arrs):
+    sel = (C.c_uint8 * max(n, 1))()
+    cnt = fn(n, *arrs, sel)
+    got = [i for i in range(n) if sel[i]]
+    assert cnt == len(got)
+    return got
+
+
+def test_least_nodes_and_most_pods():
+    L = lib()
+    for c in GOLD["least_nodes"]["cases"]:
+        n = len(c["counts"])
+        assert _sel(n, L.orc_least_nodes, (C.c_int32 * max(n, 1))(*c["counts"])) == c["want"]
+    for c in GOLD["most_pods"]["cases"]:
+        n = len(c["pods"])
+        assert _sel(n, L.orc_most_pods, (C.c_int32 * max(n, 1))(*c["pods"])) == c["want"]
+
+
+def test_least_waste():
+    L = lib()
+    G = GOLD["least_waste"]
+    for c in G["cases"]:
+        n = len(c["options"])
+        nc = (C.c_int32 * n)(*[1] * n)
+        rc = (C.c_int64 * n)(*[o["pods"] * G["cpu_per_pod"] for o in c["options"]])
+        rm = (C.c_int64 * n)(*[o["pods"] * G["mem_per_pod"] for o in c["options"]])
+        ncpu = (C.c_int64 * n)(*[o["node"][0] for o in c["options"]])
+        nmem = (C.c_int64 * n)(*[o["node"][1] for o in c["options"]])
+        has = (C.c_uint8 * n)(*[1] * n)
+        assert _sel(n, L.orc_least_waste, nc, rc, rm, ncpu, nmem, has) == c["want"]
