@@ -1,6 +1,6 @@
 """ctypes mirror of include/casim.h (struct layouts and function prototypes only — loading the
-shared library happens in _ffi.py).  Kept separate so that the test-only wave emulator
-(tests/emu/libcasim_emu.so), which consumes the same structs, can reuse the layouts."""
+shared library happens in _ffi.py).  Kept separate so that test harnesses that consume the same
+structs can reuse the layouts without loading the product library."""
 import ctypes as C
 
 ABI_VERSION = 1

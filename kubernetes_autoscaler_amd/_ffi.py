@@ -28,7 +28,7 @@ def _load():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C kubernetes_autoscaler_amd/csrc` (hipcc --offload-arch=gfx950). "
             "kubernetes_autoscaler_amd has no pure-Python / CPU fallback.")
-    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    lib = ctypes.CDLL(LIB_PATH)  # RTLD_LOCAL: the library keeps its symbols to itself
     _abi.bind(lib)
     if lib.casim_abi_version() != _abi.ABI_VERSION:
         raise ImportError(f"libcasim ABI {lib.casim_abi_version()} != expected {_abi.ABI_VERSION}: rebuild")

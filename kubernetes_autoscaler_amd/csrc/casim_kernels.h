@@ -334,6 +334,7 @@ CS_GLOBAL void pack_kernel(DevTables t, DevResults res, PackScratch ps) {
     const int32_t maxn = t.max_nodes[ng];
     const int32_t E = t.existing[ng];
     const bool fast_last = t.fastpath && res.fast_last[ng];
+    const bool group_unschedulable = (t.gflags[ng] & CASIM_NG_UNSCHEDULABLE) != 0;
     const uint64_t* zvalid = t.zone_valid + (int64_t)ng * Wz;
     for (int w = 0; w < Wz; ++w) c.szone[w * 64 + lane] = t.init_zone[(int64_t)ng * Wz + w];
 
@@ -366,12 +367,15 @@ CS_GLOBAL void pack_kernel(DevTables t, DevResults res, PackScratch ps) {
         }
 
         int32_t placed = 0;
+        uint32_t on_last = 0;  // pods of THIS PEG that a2 put on the newest node (self-exclusion has no node bit)
 
         // ---- a2: tryToScheduleOnExistingNodes (:163-186), closed form over the cyclic node order ----
         // k identical pods visit the nodes round-robin from lastIndex+1 (MarkMatch moves the start
         // to the matched node); after t full rounds node j holds min(c_j, t) pods  (SURVEY N3).
         const uint32_t keff = (uint32_t)(zselfx ? (cnt > 0 ? 1 : 0) : cnt);
-        if (M > 0 && keff > 0 && static_ok && !zblocked) {
+        // RunFiltersUntilPassingNode skips Spec.Unschedulable nodes before any Filter runs, tolerated or not
+        // (plugin_runner.go:108-110); every simulated node clones the template's flag.
+        if (M > 0 && keff > 0 && static_ok && !zblocked && !group_unschedulable) {
             const int S = (M + 63) >> 6;
             const uint32_t cap1 = keff + 1;
             uint32_t tot = 0, cmax = 0;
@@ -414,6 +418,7 @@ CS_GLOBAL void pack_kernel(DevTables t, DevResults res, PackScratch ps) {
                 }
                 const int32_t target = Rr > 0 ? (int32_t)Rr - 1 : Tot - 1;
                 int32_t basec = 0, new_last = last_index;
+                uint32_t x_mine_last = 0;
                 for (int s = 0; s < S; ++s) {
                     const int m = s * 64 + lane;
                     const uint32_t cj = (uint32_t)c.sctmp[m];
@@ -426,8 +431,10 @@ CS_GLOBAL void pack_kernel(DevTables t, DevResults res, PackScratch ps) {
                     const uint64_t hit = cs::ballot(cand && rot == target);
                     if (hit) new_last = E + s * 64 + cs::ffs64(hit);
                     if (x > 0) node_commit(c, t, m, x, req, xmark);
+                    if (m == M - 1) x_mine_last = x;
                     basec += cs::popc64(b);
                 }
+                on_last = (uint32_t)cs::readlane_u64(x_mine_last, (M - 1) & 63);
                 last_index = new_last;
                 for (int w = 0; w < Wz; ++w) c.szone[w * 64 + lane] |= zmark[w] & zvalid[w];
             }
@@ -493,7 +500,8 @@ CS_GLOBAL void pack_kernel(DevTables t, DevResults res, PackScratch ps) {
                 if (M > 0) {
                     const int lm = M - 1, owner = lm & 63;
                     uint32_t cl = 0;
-                    if (!blocked && lane == owner) cl = node_capacity(c, t, lm, req, xblock, (uint32_t)rem, selfx || zselfx);
+                    if (!blocked && !(selfx && on_last > 0) && lane == owner)
+                        cl = node_capacity(c, t, lm, req, xblock, (uint32_t)rem, selfx || zselfx);
                     cl = (uint32_t)cs::readlane_u64(cl, owner);
                     if (cl > 0) {
                         if (lane == owner) node_commit(c, t, lm, cl, req, xmark);

@@ -1,0 +1,274 @@
+"""Seeded synthetic scale-up workloads: BASELINE.md §3 configs C0..C4 plus a feature-mix fuzzer.
+
+PRNG = splitmix64, seed 0xCA5CADE0 + config id.  All request values are exact
+integers (no fractional milli), so Quantity rounding never engages.  Generators return plain
+objects (kubernetes_autoscaler_amd.objects); nothing here touches the device or any checker."""
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+from .objects import (GiB, LABEL_HOSTNAME, LABEL_ZONE, MiB, ContainerPort, Node, NodeInfo, Pod, PodAffinityTerm,
+                      PodEquivalenceGroup, Taint, Toleration)
+
+SEED_BASE = 0xCA5CADE0
+MASK = (1 << 64) - 1
+
+
+class SplitMix64:
+    def __init__(self, seed: int):
+        self.s = seed & MASK
+
+    def next(self) -> int:
+        self.s = (self.s + 0x9E3779B97F4A7C15) & MASK
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK
+        return z ^ (z >> 31)
+
+    def below(self, n: int) -> int:
+        return self.next() % n
+
+    def pick(self, seq):
+        return seq[self.below(len(seq))]
+
+    def chance(self, num: int, den: int) -> bool:
+        return self.below(den) < num
+
+    def sample(self, seq, k: int):
+        pool = list(seq)
+        out = []
+        for _ in range(min(k, len(pool))):
+            out.append(pool.pop(self.below(len(pool))))
+        return out
+
+
+@dataclass
+class GroupPlan:
+    template: NodeInfo
+    max_nodes: int = 0
+    last_index: int = 0
+    pegs: Optional[Sequence[int]] = None
+
+
+@dataclass
+class Workload:
+    name: str
+    pegs: List[PodEquivalenceGroup]
+    groups: List[GroupPlan]
+    existing: List[NodeInfo] = field(default_factory=list)
+    lanes: Sequence[str] = ("cpu", "memory")
+
+    @property
+    def n_pods(self) -> int:
+        return sum(len(p.pods) for p in self.pegs)
+
+    def checks(self, pegs_per_group=None) -> int:
+        """pods x nodes predicate checks of one simulation: sum_NG P_NG * Ncap_NG."""
+        total = 0
+        for gi, g in enumerate(self.groups):
+            ids = pegs_per_group[gi] if pegs_per_group is not None else (g.pegs if g.pegs is not None else range(len(self.pegs)))
+            total += sum(len(self.pegs[i].pods) for i in ids) * max(g.max_nodes, 0)
+        return total
+
+
+def _node(name, cpu_m, mem, pods, labels=None, taints=None) -> Node:
+    cap = {"cpu": cpu_m, "memory": mem, "pods": pods}
+    lab = {LABEL_HOSTNAME: name}
+    lab.update(labels or {})
+    return Node(name=name, labels=lab, taints=list(taints or []), capacity=dict(cap), allocatable=dict(cap))
+
+
+def _peg(name, cpu_m, mem, count, **kw) -> PodEquivalenceGroup:
+    pod = Pod(name=name, namespace=kw.pop("namespace", "default"), labels=kw.pop("labels", {"app": name}),
+              requests={"cpu": cpu_m, "memory": mem}, **kw)
+    return PodEquivalenceGroup(pods=[pod] * count)
+
+
+def _score(cpu, mem, acpu, amem):
+    return float(cpu) / float(acpu) + float(mem) / float(amem)
+
+
+def _distinct_scores(rng, n, shapes, draw):
+    """Draw n (cpu, mem) pairs whose orderer score is pairwise distinct on EVERY template shape
+    (Go's sort.Slice is unstable; distinct scores make the reference order well defined)."""
+    out, seen = [], [set() for _ in shapes]
+    while len(out) < n:
+        cpu, mem = draw(rng)
+        keys = [_score(cpu, mem, a, b) for a, b in shapes]
+        if any(k in s for k, s in zip(keys, seen)):
+            continue
+        for k, s in zip(keys, seen):
+            s.add(k)
+        out.append((cpu, mem))
+    return out
+
+
+def config_c0() -> Workload:
+    """100 pods x 10 identical nodes, CPU+mem only (plumbing)."""
+    tmpl = NodeInfo(_node("c0-template", 4000, 16 * GiB, 110))
+    shapes = [(1500, 2 * GiB), (1000, 1 * GiB), (500, 4 * GiB), (250, 512 * MiB)]
+    pegs = [_peg(f"c0-peg{i}", c, m, 25) for i, (c, m) in enumerate(shapes)]
+    return Workload("C0", pegs, [GroupPlan(tmpl, max_nodes=10)])
+
+
+def _draw_c1(rng):
+    return 50 * (1 + rng.below(80)), 64 * MiB * (1 + rng.below(256))
+
+
+def config_c1(seed_offset: int = 0, n_pegs: int = 200, pods_per_peg: int = 50, cap: int = 256) -> Workload:
+    """10k pods x 256 candidate nodes, CPU+mem only: 1 group, 32 cores / 128 GiB / 110 pods."""
+    rng = SplitMix64(SEED_BASE + 1 + (seed_offset << 8))
+    acpu, amem = 32000, 128 * GiB
+    tmpl = NodeInfo(_node("c1-template", acpu, amem, 110))
+    pairs = _distinct_scores(rng, n_pegs, [(acpu, amem)], _draw_c1)
+    pegs = [_peg(f"c1-peg{i}", c, m, pods_per_peg) for i, (c, m) in enumerate(pairs)]
+    return Workload("C1", pegs, [GroupPlan(tmpl, max_nodes=cap)])
+
+
+TAINT_KEYS = [f"dedicated-{i}" for i in range(8)]
+LABEL_KEYS = [f"pool-{i}" for i in range(8)]
+SHAPES = [8, 16, 32, 64, 96]
+
+
+def _c2_groups(rng, n_groups, cap, with_taints=True):
+    groups = []
+    for gi in range(n_groups):
+        cores = SHAPES[gi % len(SHAPES)]
+        labels = {LABEL_ZONE: f"zone-{gi % 3}", "shape": f"c{cores}"}
+        for k in rng.sample(LABEL_KEYS, 4 + rng.below(5)):
+            labels[k] = f"v{rng.below(4)}"
+        taints = []
+        if with_taints:
+            for k in rng.sample(TAINT_KEYS, rng.below(3)):
+                taints.append(Taint(k, f"t{rng.below(2)}", rng.pick(["NoSchedule", "NoExecute"])))
+        node = _node(f"ng{gi}-template", cores * 1000, cores * 4 * GiB, 110, labels, taints)
+        groups.append(GroupPlan(NodeInfo(node), max_nodes=cap[gi] if isinstance(cap, list) else cap))
+    return groups
+
+
+def _c2_pegs(rng, n_pegs, pods_per_peg, groups, prefix, with_tolerations=True, with_selectors=True):
+    shapes = sorted({(g.template.node.allocatable["cpu"], g.template.node.allocatable["memory"]) for g in groups})
+    pairs = _distinct_scores(rng, n_pegs, shapes, lambda r: (50 * (1 + r.below(80)), 64 * MiB * (1 + r.below(256))))
+    pegs = []
+    for i, (c, m) in enumerate(pairs):
+        tols, sel = [], {}
+        if with_tolerations:
+            for k in rng.sample(TAINT_KEYS, 2 + rng.below(5)):
+                if rng.chance(1, 2):
+                    tols.append(Toleration(key=k, operator="Exists"))
+                else:
+                    tols.append(Toleration(key=k, operator="Equal", value=f"t{rng.below(2)}", effect=rng.pick(["", "NoSchedule", "NoExecute"])))
+        if with_selectors and rng.chance(1, 2):
+            for k in rng.sample(LABEL_KEYS, 1 + rng.below(2)):
+                sel[k] = f"v{rng.below(4)}"
+        pegs.append(_peg(f"{prefix}-peg{i}", c, m, pods_per_peg, tolerations=tols, node_selector=sel))
+    return pegs
+
+
+def config_c2(seed_offset: int = 0, n_groups: int = 20, n_pegs: int = 400, pods_per_peg: int = 25, cap: int = 50) -> Workload:
+    """10k pods x 1k nodes across 20 node groups with taints/tolerations + nodeSelector."""
+    rng = SplitMix64(SEED_BASE + 2 + (seed_offset << 8))
+    groups = _c2_groups(rng, n_groups, cap)
+    pegs = _c2_pegs(rng, n_pegs, pods_per_peg, groups, "c2")
+    return Workload("C2", pegs, groups)
+
+
+def config_c3(seed_offset: int = 0, n_groups: int = 64, n_pegs: int = 1000, pods_per_peg: int = 50) -> Workload:
+    """50k pods x 4k nodes, 64 node groups (caps 62-63, sum 4000): sharded over the GPUs of one node."""
+    rng = SplitMix64(SEED_BASE + 3 + (seed_offset << 8))
+    total = (4000 * n_groups) // 64
+    caps = [total // n_groups + (1 if i < total % n_groups else 0) for i in range(n_groups)]
+    groups = _c2_groups(rng, n_groups, caps)
+    pegs = _c2_pegs(rng, n_pegs, pods_per_peg, groups, "c3")
+    return Workload("C3", pegs, groups)
+
+
+def config_c4(seed_offset: int = 0, n_groups: int = 20, n_pegs: int = 400, pods_per_peg: int = 25, cap: int = 50) -> Workload:
+    """10k pods x 1k nodes with pod anti-affinity: 50 % of the PEGs self-anti-affine on hostname,
+    10 % anti-affine to another PEG's label."""
+    rng = SplitMix64(SEED_BASE + 4 + (seed_offset << 8))
+    groups = _c2_groups(rng, n_groups, cap, with_taints=False)
+    pegs = _c2_pegs(rng, n_pegs, pods_per_peg, groups, "c4", with_tolerations=False)
+    for i, pg in enumerate(pegs):
+        pod = pg.pods[0]
+        r = rng.below(10)
+        if r < 5:
+            pod.anti_affinity = [PodAffinityTerm(LABEL_HOSTNAME, match_labels={"app": pod.labels["app"]})]
+        elif r == 5:
+            other = pegs[rng.below(len(pegs))].pods[0]
+            pod.anti_affinity = [PodAffinityTerm(LABEL_HOSTNAME, match_labels={"app": other.labels["app"]})]
+    return Workload("C4", pegs, groups)
+
+
+CONFIGS = {"C0": config_c0, "C1": config_c1, "C2": config_c2, "C3": config_c3, "C4": config_c4}
+
+
+def batch_of(make, n: int, **kw) -> Workload:
+    """n independent simulations of one config (distinct seeds) concatenated into one batch: every
+    group only sees the PEGs of its own simulation."""
+    pegs, groups, name = [], [], None
+    for b in range(n):
+        w = make(seed_offset=b, **kw) if make is not config_c0 else make()
+        name = w.name
+        base = len(pegs)
+        pegs.extend(w.pegs)
+        for g in w.groups:
+            ids = g.pegs if g.pegs is not None else range(len(w.pegs))
+            groups.append(GroupPlan(g.template, g.max_nodes, g.last_index, [base + i for i in ids]))
+    return Workload(f"{name}x{n}", pegs, groups)
+
+
+# ---------------------------------------------------------------------------------------------
+# feature-mix fuzzer (tests): small scenarios touching every encoded predicate and every exit
+# of the packer; scores may tie here (the canonical tie rule = input order is part of parity)
+# ---------------------------------------------------------------------------------------------
+def fuzz(seed: int, max_groups: int = 4, max_pegs: int = 12, rich: bool = True) -> Workload:
+    rng = SplitMix64(0xF0220000 + seed)
+    n_groups = 1 + rng.below(max_groups)
+    n_pegs = 1 + rng.below(max_pegs)
+    n_existing = rng.below(4)
+    ports = [5555, 8080, 9090]
+    groups = []
+    for gi in range(n_groups):
+        cpu = rng.pick([1000, 2000, 4000, 8000])
+        mem = rng.pick([1, 2, 8, 64]) * GiB
+        labels = {LABEL_ZONE: f"zone-{rng.below(2)}"} if rng.chance(3, 4) else {}
+        for k in rng.sample(LABEL_KEYS[:4], rng.below(4)):
+            labels[k] = f"v{rng.below(2)}"
+        taints = [Taint(k, f"t{rng.below(2)}", rng.pick(["NoSchedule", "NoExecute", "PreferNoSchedule"]))
+                  for k in rng.sample(TAINT_KEYS[:3], rng.below(3))] if rich else []
+        node = _node(f"fz{seed}-ng{gi}", cpu, mem, rng.pick([3, 10, 110]), labels, taints)
+        if rich and rng.chance(1, 12):
+            node.unschedulable = True
+        pre = []
+        if rich and rng.chance(1, 3):
+            ds = Pod(name=f"ds{gi}", namespace="kube-system", labels={"app": "ds"}, requests={"cpu": 100, "memory": 64 * MiB})
+            if rng.chance(1, 2):
+                ds.host_ports = [ContainerPort(rng.pick(ports))]
+            pre.append(ds)
+        groups.append(GroupPlan(NodeInfo(node, pre), max_nodes=rng.pick([0, 0, 1, 3, 7, 64, -1]), last_index=rng.below(6)))
+    pegs = []
+    for i in range(n_pegs):
+        cpu = rng.pick([0, 50, 100, 250, 500, 1000, 1500, 3000])
+        mem = rng.pick([0, 64 * MiB, 256 * MiB, 1 * GiB, 3 * GiB])
+        count = rng.pick([1, 1, 2, 3, 7, 20, 64, 130])
+        kw = {}
+        if rich:
+            if rng.chance(1, 2):
+                kw["tolerations"] = [Toleration(key=k, operator=rng.pick(["Exists", "Equal", ""]), value=f"t{rng.below(2)}",
+                                                effect=rng.pick(["", "NoSchedule", "NoExecute"])) for k in rng.sample(TAINT_KEYS[:3], 1 + rng.below(3))]
+                if rng.chance(1, 6):
+                    kw["tolerations"].append(Toleration(operator="Exists"))  # tolerates everything
+            if rng.chance(1, 4):
+                kw["node_selector"] = {k: f"v{rng.below(2)}" for k in rng.sample(LABEL_KEYS[:4], 1)}
+            if rng.chance(1, 5):
+                kw["host_ports"] = [ContainerPort(rng.pick(ports), host_ip=rng.pick(["", "", "10.0.0.1"]), protocol=rng.pick(["", "TCP", "UDP"]))]
+        app = f"app{rng.below(max(2, n_pegs // 2))}"
+        pg = _peg(f"fz{seed}-peg{i}", cpu, mem, count, labels={"app": app}, **kw)
+        pod = pg.pods[0]
+        if rich and rng.chance(1, 3):
+            target = rng.pick([app, f"app{rng.below(max(2, n_pegs // 2))}"])
+            key = LABEL_HOSTNAME if rng.chance(3, 4) else LABEL_ZONE
+            pod.anti_affinity = [PodAffinityTerm(key, match_labels={"app": target})]
+        pegs.append(pg)
+    existing = [NodeInfo(_node(f"fz{seed}-old{i}", 1000, 1 * GiB, 10, {LABEL_ZONE: f"zone-{rng.below(2)}"})) for i in range(n_existing)]
+    return Workload(f"fuzz{seed}", pegs, groups, existing)

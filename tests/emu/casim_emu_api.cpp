@@ -29,12 +29,13 @@ struct EmuBackend {
 thread_local std::string g_err;
 }  // namespace
 
+#define EMU_API __attribute__((visibility("default")))
 extern "C" {
 
-const char* emu_last_error() { return g_err.c_str(); }
+EMU_API const char* emu_last_error() { return g_err.c_str(); }
 
 // lds_budget_bytes <= 0 keeps the default (160 KiB); a tiny value forces the HBM-scratch variants.
-int32_t emu_estimate_batch(const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts,
+EMU_API int32_t emu_estimate_batch(const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts,
                            casim_results* out, int64_t lds_budget_bytes, int32_t* nnz_out, int32_t* offsets_out,
                            const int32_t* kinds, int32_t n_kinds, int32_t group_id_base, int32_t* best_out /*[2]*/,
                            uint8_t* best_set_out, int64_t* key_out /*[2]*/) {
@@ -51,7 +52,7 @@ int32_t emu_estimate_batch(const casim_pegs* pegs, const casim_groups* groups, c
     return rc;
 }
 
-int32_t emu_feasibility(const casim_pegs* pegs, const casim_groups* groups, uint64_t* out_bits) {
+EMU_API int32_t emu_feasibility(const casim_pegs* pegs, const casim_groups* groups, uint64_t* out_bits) {
     EmuBackend bk;
     casim::ProblemT<EmuBackend> p(bk);
     casim_groups g = *groups;

@@ -1,0 +1,153 @@
+"""Shared test harness: runs one scale-up scenario through
+  (a) the CPU oracle (pod by pod, object level),
+  (b) the product encoder + the product kernels under the wave emulator (CPU tests), or
+  (c) the product encoder + libcasim on a real MI355X (-m gpu tests),
+and compares them bit for bit."""
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from kubernetes_autoscaler_amd import _abi
+from kubernetes_autoscaler_amd.encoder import Encoder
+from kubernetes_autoscaler_amd.engine import BatchResult, alloc_results, finish_results
+from kubernetes_autoscaler_amd.objects import Node, NodeInfo, PodEquivalenceGroup, build_test_node
+from oracle_driver import OracleEstimate, OracleScenario
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "libcasim_emu.so")
+
+
+@dataclass
+class GroupSpec:
+    template: NodeInfo
+    max_nodes: int = 0
+    last_index: int = 0
+    pegs: Optional[Sequence[int]] = None   # indices into Scenario.pegs; None = all / device-side feasibility
+
+
+@dataclass
+class Scenario:
+    pegs: List[PodEquivalenceGroup]
+    groups: List[GroupSpec]
+    existing: List[NodeInfo] = field(default_factory=list)   # nodes already in the cluster snapshot
+    lanes: Sequence[str] = ("cpu", "memory")
+    fastpath: bool = False
+    device_csr: bool = False    # let the engine derive the schedulable subsets (feasibility kernel)
+
+
+# ---------------------------------------------------------------------------------------------
+def run_oracle(sc: Scenario):
+    """Per group: OracleEstimate plus the list of global PEG ids it was given."""
+    s = OracleScenario(lanes=sc.lanes)
+    for info in sc.existing:
+        s.add_existing(info)
+    out = []
+    for g in sc.groups:
+        tmpl = s.node(g.template)
+        if g.pegs is None and sc.device_csr:
+            ids = [i for i, pg in enumerate(sc.pegs) if pg.exemplar() is not None and s.check_predicates(tmpl, pg.exemplar())[0]]
+        else:
+            ids = list(range(len(sc.pegs))) if g.pegs is None else list(g.pegs)
+        est = s.estimate(tmpl, [sc.pegs[i] for i in ids], max_nodes=g.max_nodes, last_index=g.last_index, fastpath=sc.fastpath,
+                         node_pods_cap=0)
+        out.append((est, ids))
+    s.close()
+    return out
+
+
+def encode(sc: Scenario) -> Encoder:
+    enc = Encoder(lanes=sc.lanes)
+    for pg in sc.pegs:
+        enc.add_peg(pg)
+    for info in sc.existing:
+        for p in info.pods:
+            enc.add_existing_pod(p, info.node.labels)
+    for g in sc.groups:
+        pegs = None
+        if not sc.device_csr:
+            pegs = list(range(len(sc.pegs))) if g.pegs is None else list(g.pegs)
+        enc.add_group(g.template, max_nodes=g.max_nodes, existing_nodes=len(sc.existing), last_index=g.last_index, pegs=pegs)
+    enc.finalize()
+    return enc
+
+
+_emu = None
+
+
+def emu_lib():
+    global _emu
+    if _emu is None:
+        L = C.CDLL(EMU_LIB)
+        L.emu_estimate_batch.restype = C.c_int32
+        L.emu_estimate_batch.argtypes = [C.POINTER(_abi.Pegs), C.POINTER(_abi.Groups), C.POINTER(_abi.Options), C.POINTER(_abi.Results),
+                                         C.c_int64, _abi.i32p, _abi.i32p, _abi.i32p, C.c_int32, C.c_int32, _abi.i32p, _abi.u8p, _abi.i64p]
+        L.emu_feasibility.restype = C.c_int32
+        L.emu_feasibility.argtypes = [C.POINTER(_abi.Pegs), C.POINTER(_abi.Groups), _abi.u64p]
+        L.emu_last_error.restype = C.c_char_p
+        _emu = L
+    return _emu
+
+
+def run_emu(enc: Encoder, fastpath=False, lds_budget=0, kinds=None, group_id_base=0):
+    """Product kernels under the wave emulator.  Returns (BatchResult, best) where best is
+    None or (best_index, n_best, best_set, key)."""
+    L = emu_lib()
+    pegs, groups = enc.pegs, enc.groups
+    ng, G = groups.n_groups, pegs.n_pegs
+    nnz_cap = G * ng if not groups.peg_offsets else groups.peg_offsets[ng]
+    st, arrs = alloc_results(ng, nnz_cap)
+    opts = _abi.Options(fastpath=int(fastpath))
+    nnz = C.c_int32(0)
+    off = np.zeros(ng + 1, np.int32)
+    best = (C.c_int32 * 2)(-1, 0)
+    bset = np.zeros(max(ng, 1), np.uint8)
+    key = np.zeros(2, np.int64)
+    ks = (C.c_int32 * 8)(*(kinds or []))
+    rc = L.emu_estimate_batch(C.byref(pegs), C.byref(groups), C.byref(opts), C.byref(st), int(lds_budget), C.byref(nnz),
+                              off.ctypes.data_as(_abi.i32p), ks, len(kinds) if kinds is not None else -1, group_id_base,
+                              best if kinds is not None else None, bset.ctypes.data_as(_abi.u8p), key.ctypes.data_as(_abi.i64p))
+    assert rc == 0, (rc, L.emu_last_error())
+    res = finish_results(arrs, ng, int(nnz.value), off)
+    return res, ((best[0], best[1], bset[:ng].copy(), key.copy()) if kinds is not None else None)
+
+
+def run_emu_feasibility(enc: Encoder) -> np.ndarray:
+    L = emu_lib()
+    wg = (enc.pegs.n_pegs + 63) // 64
+    bits = np.zeros((max(enc.groups.n_groups, 1), max(wg, 1)), np.uint64)
+    rc = L.emu_feasibility(C.byref(enc.pegs), C.byref(enc.groups), bits.ctypes.data_as(_abi.u64p))
+    assert rc == 0, (rc, L.emu_last_error())
+    return bits[:enc.groups.n_groups, :wg]
+
+
+def run_gpu(enc: Encoder, ctx, fastpath=False, kinds=None, group_id_base=0):
+    from kubernetes_autoscaler_amd.engine import Problem
+    with Problem(ctx, enc.pegs, enc.groups, fastpath) as p:
+        p.run()
+        res = p.fetch()
+        best = p.best_option(kinds, group_id_base) if kinds is not None else None
+    return res, best
+
+
+# ---------------------------------------------------------------------------------------------
+def assert_matches_oracle(res: BatchResult, oracle, what=""):
+    """Bit-exact comparison of one batch against the per-group oracle results."""
+    assert len(oracle) == len(res.node_count), what
+    for i, (est, ids) in enumerate(oracle):
+        tag = f"{what} group {i}"
+        order, placed = res.group(i)
+        assert int(res.status[i]) == 0, tag
+        assert list(order) == [ids[k] for k in est.order], f"{tag}: PEG order"
+        assert list(placed) == list(est.placed), f"{tag}: placed per PEG\n got {list(placed)}\n want {list(est.placed)}"
+        got = (int(res.node_count[i]), int(res.pods_scheduled[i]), int(res.nodes_added[i]), int(res.limiter_nodes[i]),
+               int(res.last_index_out[i]), int(res.req_cpu_sum[i]), int(res.req_mem_sum[i]))
+        want = (est.node_count, est.pods_scheduled, est.nodes_added, est.limiter_nodes, est.last_index_out, est.req_cpu_sum,
+                est.req_mem_sum)
+        assert got == want, f"{tag}: (nodes, pods, added, limiter, lastIndex, cpu, mem) got {got} want {want}"
+
+
+def dummy_existing(n: int) -> List[NodeInfo]:
+    return [NodeInfo(build_test_node(f"existing-{i}", 100, 100 * 1024 * 1024, pods=10)) for i in range(n)]

@@ -1,0 +1,71 @@
+"""CPU tests of the drop-in boundary: libcasim.so loads, exports every symbol include/casim.h declares,
+and FAILS LOUDLY (no CPU fallback) when no MI355X is visible."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import kubernetes_autoscaler_amd as kaa
+from kubernetes_autoscaler_amd import _abi, _ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "casim.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(casim_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(_abi.PROTOTYPES)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_ffi.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.casim_abi_version() == _abi.ABI_VERSION
+
+
+def test_library_is_built_for_gfx950_only():
+    blob = open(_ffi.LIB_PATH, "rb").read()
+    archs = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", blob))
+    assert archs == {b"gfx950"}, archs
+
+
+def test_struct_layouts_match_the_header():
+    # sizes computed by hand from include/casim.h (LP64): ints first, then pointers
+    assert ctypes.sizeof(_abi.Pegs) == 6 * 4 + 11 * 8
+    assert ctypes.sizeof(_abi.Groups) == 8 + 19 * 8
+    assert ctypes.sizeof(_abi.Results) == 10 * 8
+    assert ctypes.sizeof(_abi.Options) == 32 and ctypes.sizeof(_abi.EncoderOptions) == 32
+
+
+@pytest.mark.skipif(kaa.device_count() > 0, reason="a GPU is visible")
+def test_engine_fails_loudly_without_a_gpu():
+    with pytest.raises(kaa.NoDeviceError):
+        kaa.Context(0)
+    assert "no CPU path" in _ffi.last_error() or "no HIP device" in _ffi.last_error()
+
+
+def test_product_package_never_touches_the_oracle():
+    """No import / include / link of anything under oracle/ or tests/emu from the product package
+    (the CASIM_HOST_EMU branch of casim_device.h is only ever compiled by tests/emu/Makefile)."""
+    pkg = os.path.join(ROOT, "kubernetes_autoscaler_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            path = os.path.join(dirpath, f)
+            if f.endswith(".py"):
+                text = open(path).read()
+                assert not re.search(r"oracle|libcasim_emu|emu_driver", text), path
+            elif f == "Makefile":
+                text = open(path).read()
+                assert "oracle" not in text and "emu" not in text and "CASIM_HOST_EMU" not in text, path
+            elif f.endswith((".h", ".hip", ".cpp")):
+                for line in open(path, errors="replace"):
+                    if line.lstrip().startswith("#include") and "casim_emu.h" not in line:
+                        assert "oracle" not in line and "emu" not in line, (path, line)
+    blob = open(_ffi.LIB_PATH, "rb").read()
+    assert b"orc_estimate" not in blob and b"casim_emu" not in blob
