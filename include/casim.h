@@ -237,10 +237,12 @@ int32_t casim_problem_dense_check(casim_problem* p, int32_t col_repeat, uint64_t
  * best_set_out  = [NG] 1 for surviving groups, may be NULL;
  * key_out       = packed sortable int64 key of the winner (smaller = better, group index in
  *                 the low 20 bits) for a cross-GPU min all-reduce; may be NULL.
- * key_out       = [2] int64: [0] packed key (metric << 20 | global group id, exact for the integer
- *                 metrics), [1] the full 63-bit order-preserving metric (two-step reduce for least-waste);
- * dev_key_out   = optional DEVICE pointer (void*) to 2 int64 receiving the same pair, so that an RCCL
- *                 all-reduce can consume it without a host round trip; may be NULL.
+ * key_out       = [10] int64 key block of the winner, smaller = better: [0] packed
+ *                 (first filter's metric << 20 | global group id; one all-reduce(min) is exact for the
+ *                 integer metrics), [1..8] the winner's metric under each filter (order-preserving
+ *                 int64; the chain is the lexicographic min over (m_1..m_k, id)), [9] global group id;
+ * dev_key_out   = optional DEVICE pointer (void*) to 10 int64 receiving the same block, so that an
+ *                 RCCL collective can consume it without a host round trip; may be NULL.
  * group_id_base = added to the local group index inside the key (rank offset when the
  *                 groups are sharded across GPUs).
  * Synchronous unless every host out pointer is NULL.

@@ -587,7 +587,7 @@ struct OptionArgs {
     int32_t group_id_base;
     uint8_t* best_set;      // [NG] out
     int32_t* out;           // [2]: best index (local), survivors
-    int64_t* key_out;       // [1]: packed key of the winner
+    int64_t* key_out;       // [10]: key block of the winner (see option_kernel)
 };
 
 CS_DEVICE uint64_t option_metric(const OptionArgs& a, int kind, int i) {
@@ -611,12 +611,10 @@ CS_GLOBAL void option_kernel(OptionArgs a) {
     for (int i = tid; i < a.NG; i += nt)
         a.best_set[i] = (a.status[i] == CASIM_NG_OK && a.node_count[i] > 0 && a.pods[i] > 0) ? 1 : 0;
     cs::sync();
-    uint64_t last_metric = 0;
     for (int f = 0; f < a.n_kinds; ++f) {
         uint64_t mine = ~0ull;
-        uint32_t cnt = 0;
         for (int i = tid; i < a.NG; i += nt)
-            if (a.best_set[i]) { const uint64_t m = option_metric(a, a.kinds[f], i); mine = m < mine ? m : mine; cnt++; }
+            if (a.best_set[i]) { const uint64_t m = option_metric(a, a.kinds[f], i); mine = m < mine ? m : mine; }
         red[tid] = mine;
         cs::sync();
         for (int s = nt >> 1; s > 0; s >>= 1) {
@@ -625,7 +623,6 @@ CS_GLOBAL void option_kernel(OptionArgs a) {
         }
         const uint64_t best = red[0];
         cs::sync();
-        last_metric = best;
         for (int i = tid; i < a.NG; i += nt)
             if (a.best_set[i] && option_metric(a, a.kinds[f], i) != best) a.best_set[i] = 0;
         cs::sync();
@@ -653,15 +650,25 @@ CS_GLOBAL void option_kernel(OptionArgs a) {
     if (tid == 0) {
         a.out[0] = bi == ~0ull ? -1 : (int32_t)bi;
         a.out[1] = (int32_t)red[0];
-        // key: top 43 bits of the last metric | 20-bit global group id; exact for integer metrics
-        // (< 2^43); for least-waste the two-step reduce in distributed.py uses the full metric.
-        int64_t key = 0x7fffffffffffffffll;
+        // key block (10 x int64, smaller = better) for the cross-GPU reduce:
+        //   [0]      packed (first filter's metric << 20 | global group id): one all-reduce(min) is exact
+        //            for the integer metrics (least-nodes / most-pods, < 2^43)
+        //   [1..8]   the winner's metric under each filter of the chain, order-preserving int64
+        //            (the chain == lexicographic min over (m_1, .., m_k, id))
+        //   [9]      global group id of the winner
+        const int64_t none = 0x7fffffffffffffffll;
+        for (int i = 0; i < 10; ++i) a.key_out[i] = none;
         if (bi != ~0ull) {
-            const uint64_t m = last_metric > 0x7ffffffffffull ? 0x7ffffffffffull : last_metric;
-            key = (int64_t)((m << 20) | (uint64_t)((a.group_id_base + (int32_t)bi) & 0xfffff));
+            for (int f = 0; f < a.n_kinds; ++f)
+                a.key_out[1 + f] = (int64_t)(option_metric(a, a.kinds[f], (int)bi) ^ 0x8000000000000000ull);
+            const int64_t gid = (int64_t)a.group_id_base + (int64_t)bi;
+            a.key_out[9] = gid;
+            if (a.n_kinds > 0) {
+                uint64_t m = option_metric(a, a.kinds[0], (int)bi);
+                if (m > 0x7ffffffffffull) m = 0x7ffffffffffull;
+                a.key_out[0] = (int64_t)((m << 20) | (uint64_t)(gid & 0xfffff));
+            } else a.key_out[0] = gid;
         }
-        a.key_out[0] = key;
-        a.key_out[1] = bi == ~0ull ? 0x7fffffffffffffffll : (int64_t)(last_metric >> 1);  // full metric (order-preserving, 63 bits)
     }
 }
 

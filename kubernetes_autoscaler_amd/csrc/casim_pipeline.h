@@ -154,7 +154,7 @@ public:
         dr_.fast_last = (uint8_t*)dalloc(NG);
         d_opt_set_ = (uint8_t*)dalloc(NG);
         d_opt_out_ = (int32_t*)dalloc(16);
-        d_opt_key_ = (int64_t*)dalloc(16);
+        d_opt_key_ = (int64_t*)dalloc(80);
         if (!bk_.ok()) return fail(CASIM_ERR_HIP, bk_.error());
         ready_ = true;
         return CASIM_OK;
@@ -248,12 +248,12 @@ public:
             int32_t o[2] = {-1, 0};
             bk_.d2h(o, d_opt_out_, 8);
             if (best_set_out) bk_.d2h(best_set_out, d_opt_set_, (size_t)NG_);
-            int64_t kk[2] = {0, 0};
-            if (key_out) bk_.d2h(kk, a.key_out, 16);
+            int64_t kk[10] = {0};
+            if (key_out) bk_.d2h(kk, a.key_out, 80);
             bk_.sync();
             if (best_ng_out) *best_ng_out = o[0];
             if (n_best_out) *n_best_out = o[1];
-            if (key_out) { key_out[0] = kk[0]; key_out[1] = kk[1]; }
+            if (key_out) for (int i = 0; i < 10; ++i) key_out[i] = kk[i];
         }
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
     }

@@ -140,14 +140,14 @@ class Problem:
         ks = (C.c_int32 * max(len(kinds), 1))(*kinds)
         best, nbest = C.c_int32(-1), C.c_int32(0)
         bset = np.zeros(max(self.n_groups, 1), np.uint8)
-        key = np.zeros(2, np.int64)
+        key = np.zeros(10, np.int64)
         check(lib.casim_best_option(self._h, ks, len(kinds), int(group_id_base), C.byref(best), C.byref(nbest),
                                     _ptr(bset, C.c_uint8), _ptr(key, C.c_int64),
                                     C.c_void_p(dev_key_ptr) if dev_key_ptr else None), "casim_best_option")
         return int(best.value), int(nbest.value), bset[:self.n_groups], key
 
     def best_option_device(self, kinds: Sequence[int], group_id_base: int, dev_key_ptr: int):
-        """Asynchronous form: only writes the 2-int64 key into device memory (for the RCCL reduce)."""
+        """Asynchronous form: only writes the 10-int64 key block into device memory (for the RCCL reduce)."""
         ks = (C.c_int32 * max(len(kinds), 1))(*kinds)
         check(lib.casim_best_option(self._h, ks, len(kinds), int(group_id_base), None, None, None, None,
                                     C.c_void_p(dev_key_ptr)), "casim_best_option")

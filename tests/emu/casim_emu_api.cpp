@@ -38,7 +38,7 @@ EMU_API const char* emu_last_error() { return g_err.c_str(); }
 EMU_API int32_t emu_estimate_batch(const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts,
                            casim_results* out, int64_t lds_budget_bytes, int32_t* nnz_out, int32_t* offsets_out,
                            const int32_t* kinds, int32_t n_kinds, int32_t group_id_base, int32_t* best_out /*[2]*/,
-                           uint8_t* best_set_out, int64_t* key_out /*[2]*/) {
+                           uint8_t* best_set_out, int64_t* key_out /*[10]*/) {
     EmuBackend bk;
     if (lds_budget_bytes > 0) bk.lds = (size_t)lds_budget_bytes;
     casim::ProblemT<EmuBackend> p(bk);

@@ -104,7 +104,7 @@ def run_emu(enc: Encoder, fastpath=False, lds_budget=0, kinds=None, group_id_bas
     off = np.zeros(ng + 1, np.int32)
     best = (C.c_int32 * 2)(-1, 0)
     bset = np.zeros(max(ng, 1), np.uint8)
-    key = np.zeros(2, np.int64)
+    key = np.zeros(10, np.int64)
     ks = (C.c_int32 * 8)(*(kinds or []))
     rc = L.emu_estimate_batch(C.byref(pegs), C.byref(groups), C.byref(opts), C.byref(st), int(lds_budget), C.byref(nnz),
                               off.ctypes.data_as(_abi.i32p), ks, len(kinds) if kinds is not None else -1, group_id_base,
