@@ -1,0 +1,222 @@
+"""Host-side mirror of the reference's estimator package (CA/estimator/*.go) around the HIP engine.
+
+Same names, argument meaning and behaviour as the reference so that tests read like the reference's:
+  Threshold / NewStaticThreshold / NewSngCapacityThreshold / NewClusterCapacityThreshold
+  EstimationLimiter / NewThresholdBasedEstimationLimiter      CA/estimator/threshold_based_limiter.go
+  EstimationContext                                           CA/estimator/estimation_context.go:24
+  EstimationPodOrderer / NewDecreasingPodOrderer              CA/estimator/decreasing_pod_orderer.go
+  Estimator / NewBinpackingNodeEstimator / EstimatorBuilder   CA/estimator/{estimator,binpacking_estimator}.go
+The limiter arithmetic is host logic (it only produces `max_nodes`); ordering, bin-packing and every
+predicate check run on the device — `BinpackingNodeEstimator.estimate` has no host implementation."""
+import time
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence, Tuple
+
+from .encoder import Encoder
+from .engine import Context, Problem
+from .objects import NodeInfo, Pod, PodEquivalenceGroup
+
+BINPACKING_ESTIMATOR_NAME = "binpacking"
+GPU_BINPACKING_ESTIMATOR_NAME = "gpu-binpacking"
+AVAILABLE_ESTIMATORS = [BINPACKING_ESTIMATOR_NAME, GPU_BINPACKING_ESTIMATOR_NAME]
+
+
+# ---- cloudprovider.NodeGroup: the three methods the thresholds read ---------------------------
+@dataclass
+class NodeGroup:
+    id_: str
+    max_size_: int = 0
+    target_size_: int = 0
+
+    def id(self) -> str:
+        return self.id_
+
+    def max_size(self) -> int:
+        return self.max_size_
+
+    def target_size(self) -> int:
+        return self.target_size_
+
+
+@dataclass
+class EstimationContext:
+    """estimation_context.go:24-60."""
+    cluster_max_node_limit_: int = 0
+    similar_node_groups_: List[NodeGroup] = field(default_factory=list)
+    current_node_count_: int = 0
+
+    def similar_node_groups(self):
+        return self.similar_node_groups_
+
+    def cluster_max_node_limit(self):
+        return self.cluster_max_node_limit_
+
+    def current_node_count(self):
+        return self.current_node_count_
+
+
+# ---- thresholds ---------------------------------------------------------------------------------
+class StaticThreshold:
+    """static_threshold.go."""
+
+    def __init__(self, max_nodes: int, max_duration: float = 0.0):
+        self.max_nodes, self.max_duration = max_nodes, max_duration
+
+    def node_limit(self, node_group, context) -> int:
+        return self.max_nodes
+
+    def duration_limit(self, node_group, context) -> float:
+        return self.max_duration
+
+
+class SngCapacityThreshold:
+    """sng_capacity_threshold.go:34-59."""
+
+    def node_limit(self, node_group, context) -> int:
+        if context is None:
+            return 0
+        total = self._capacity(node_group) + sum(self._capacity(g) for g in context.similar_node_groups())
+        return -1 if total <= 0 else total
+
+    @staticmethod
+    def _capacity(ng) -> int:
+        cap = ng.max_size() - ng.target_size()
+        return cap if cap > 0 else 0
+
+    def duration_limit(self, node_group, context) -> float:
+        return 0.0
+
+
+class ClusterCapacityThreshold:
+    """cluster_capacity_threshold.go:33-41."""
+
+    def node_limit(self, node_group, context) -> int:
+        if context is None or context.cluster_max_node_limit() == 0:
+            return 0
+        if context.cluster_max_node_limit() < 0 or context.cluster_max_node_limit() <= context.current_node_count():
+            return -1
+        return context.cluster_max_node_limit() - context.current_node_count()
+
+    def duration_limit(self, node_group, context) -> float:
+        return 0.0
+
+
+def get_min_limit(base, target):
+    """getMinLimit  threshold_based_limiter.go:45-53."""
+    if base < 0 or target < 0:
+        return -1
+    if (base == 0 or base > target) and target > 0:
+        return target
+    return base
+
+
+class ThresholdBasedEstimationLimiter:
+    """thresholdBasedEstimationLimiter  threshold_based_limiter.go:26-77.  On the device path only
+    StartEstimation's fold matters (max_nodes travels to the packer, which counts the grants itself);
+    PermissionToAddNode is kept for interface parity and for the duration cut-off between batches."""
+
+    def __init__(self, thresholds: Sequence):
+        self.thresholds = list(thresholds)
+        self.max_nodes = 0
+        self.max_duration = 0.0
+        self.nodes = 0
+        self.start = 0.0
+
+    def start_estimation(self, pegs, node_group, context):
+        self.start = time.monotonic()
+        self.nodes = 0
+        self.max_nodes = 0
+        self.max_duration = 0.0
+        for t in self.thresholds:
+            self.max_nodes = get_min_limit(self.max_nodes, t.node_limit(node_group, context))
+            self.max_duration = get_min_limit(self.max_duration, t.duration_limit(node_group, context))
+
+    def end_estimation(self):
+        pass
+
+    def permission_to_add_node(self) -> bool:
+        if self.max_nodes < 0 or (self.max_nodes > 0 and self.nodes >= self.max_nodes):
+            return False
+        if self.max_duration < 0 or (self.max_duration > 0 and self.start and time.monotonic() > self.start + self.max_duration):
+            return False
+        self.nodes += 1
+        return True
+
+    def device_max_nodes(self) -> int:
+        """What the packer receives: a negative duration limit forbids every node, like :62-66."""
+        return -1 if self.max_duration < 0 else self.max_nodes
+
+
+class DecreasingPodOrderer:
+    """decreasing_pod_orderer.go: the order itself is computed by order_kernel on the device (score =
+    cpuReq/cpuAlloc + memReq/memAlloc in float64, descending).  This object only selects it."""
+    name = "decreasing"
+
+
+@dataclass
+class ClusterSnapshotView:
+    """What Estimate needs from clustersnapshot.ClusterSnapshot on the device path: how many nodes
+    the snapshot already lists (they occupy list positions), the runner's lastIndex
+    (plugin_runner.go:33-36) and the pods that can interact through non-hostname anti-affinity."""
+    existing: List[NodeInfo] = field(default_factory=list)
+    last_index: int = 0
+
+
+class BinpackingNodeEstimator:
+    """NewBinpackingNodeEstimator(clusterSnapshot, limiter, podOrderer, context, analyser, fastpath)
+    binpacking_estimator.go:66-82 — backed by libcasim (HIP)."""
+
+    def __init__(self, engine_ctx: Context, cluster_snapshot: ClusterSnapshotView, limiter: ThresholdBasedEstimationLimiter,
+                 pod_orderer: Optional[DecreasingPodOrderer] = None, context: Optional[EstimationContext] = None,
+                 estimation_analyser_func: Optional[Callable] = None, fastpath_binpacking_enabled: bool = False,
+                 lanes: Sequence[str] = ("cpu", "memory"), fallback: Optional[Callable] = None):
+        self.engine_ctx = engine_ctx
+        self.snapshot = cluster_snapshot
+        self.limiter = limiter
+        self.pod_orderer = pod_orderer or DecreasingPodOrderer()
+        self.context = context
+        self.analyser = estimation_analyser_func
+        self.fastpath = fastpath_binpacking_enabled
+        self.lanes = lanes
+        self.fallback = fallback   # the Go estimator in the real shim; None here => unsupported raises
+
+    def estimate(self, pegs: List[PodEquivalenceGroup], node_template: NodeInfo, node_group) -> Tuple[int, List[Pod]]:
+        """Estimate  binpacking_estimator.go:102-161: (node count, pods that fit, in placement order)."""
+        self.limiter.start_estimation(pegs, node_group, self.context)
+        try:
+            enc = Encoder(lanes=self.lanes)
+            ids = [enc.add_peg(pg) for pg in pegs]
+            for info in self.snapshot.existing:
+                for p in info.pods:
+                    enc.add_existing_pod(p, info.node.labels)
+            enc.add_group(node_template, max_nodes=self.limiter.device_max_nodes(), existing_nodes=len(self.snapshot.existing),
+                          last_index=self.snapshot.last_index, pegs=ids)
+            enc.finalize()
+            with Problem(self.engine_ctx, enc.pegs, enc.groups, self.fastpath) as prob:
+                prob.run()
+                res = prob.fetch()
+            if int(res.status[0]) != 0:
+                if self.fallback is not None:
+                    return self.fallback(pegs, node_template, node_group)
+                raise NotImplementedError("a PEG needs a predicate outside the encoded subset (delegate to the Go estimator)")
+            order, placed = res.group(0)
+            pods: List[Pod] = []
+            for pg_id, n in zip(order, placed):
+                pods.extend(pegs[int(pg_id)].pods[:int(n)])
+            self.snapshot.last_index = int(res.last_index_out[0])   # the runner's lastIndex persists (plugin_runner.go:138)
+            self.limiter.nodes = int(res.limiter_nodes[0])
+            return int(res.node_count[0]), pods
+        finally:
+            self.limiter.end_estimation()
+
+
+def new_estimator_builder(name: str, limiter, orderer=None, analyser=None, fastpath: bool = False, engine_ctx: Optional[Context] = None):
+    """NewEstimatorBuilder  estimator.go:62-77: returns func(clusterSnapshot, context) Estimator."""
+    if name != GPU_BINPACKING_ESTIMATOR_NAME:
+        raise ValueError(f"unknown estimator: {name} (this package provides only {GPU_BINPACKING_ESTIMATOR_NAME})")
+    if engine_ctx is None:
+        engine_ctx = Context(0)
+
+    def builder(cluster_snapshot: ClusterSnapshotView, context: EstimationContext):
+        return BinpackingNodeEstimator(engine_ctx, cluster_snapshot, limiter, orderer, context, analyser, fastpath)
+    return builder

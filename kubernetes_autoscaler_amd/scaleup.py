@@ -1,0 +1,87 @@
+"""The scale-up simulation loop of ScaleUpOrchestrator.prepareScaleUp
+(CA/core/scaleup/orchestrator/orchestrator.go:1043-1085) as ONE batched device call:
+
+    for ng in validNodeGroups: SchedulablePodGroups(...)       :1049-1051  -> feas_kernel + CSR kernels
+    for ng in validNodeGroups: ComputeExpansionOption(...)     :1053-1068  -> order_kernel + pack_kernel
+    ExpanderStrategy.BestOption(options)                       :1079       -> option_kernel (+ RCCL when sharded)
+
+The reference runs the two loops sequentially on one goroutine; every node group is an independent
+Estimate (Fork/Revert), so here all of them are simulated by one launch, one wavefront per group."""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .encoder import Encoder
+from .engine import BatchResult, Context, Problem
+from .estimator import ClusterSnapshotView, EstimationContext, NodeGroup, ThresholdBasedEstimationLimiter
+from .expander import ChainStrategy, Option
+from .objects import NodeInfo, Pod, PodEquivalenceGroup
+
+
+@dataclass
+class ScaleUpPlan:
+    """What prepareScaleUp derives: one Option per node group that can help + the chosen one."""
+    options: List[Option]
+    best: Optional[Option]
+    n_equally_good: int
+    schedulable_pod_groups: Dict[str, List[int]]      # node group id -> PEG indices (SchedulablePodGroups)
+    result: BatchResult
+    delegated: List[str] = field(default_factory=list)  # groups with CASIM_NG_UNSUPPORTED (Go estimator's job)
+
+
+class ScaleUpSimulator:
+    def __init__(self, engine_ctx: Context, limiter: ThresholdBasedEstimationLimiter, expander: ChainStrategy = None,
+                 max_nodes_total: int = 0, fastpath: bool = False, lanes: Sequence[str] = ("cpu", "memory")):
+        self.ctx = engine_ctx
+        self.limiter = limiter
+        self.expander = expander or ChainStrategy()
+        self.max_nodes_total = max_nodes_total
+        self.fastpath = fastpath
+        self.lanes = lanes
+
+    def prepare_scale_up(self, pegs: List[PodEquivalenceGroup], node_groups: List[NodeGroup], node_infos: Dict[str, NodeInfo],
+                         snapshot: ClusterSnapshotView, all_or_nothing: bool = False) -> ScaleUpPlan:
+        enc = Encoder(lanes=self.lanes)
+        for pg in pegs:
+            enc.add_peg(pg)
+        for info in snapshot.existing:
+            for p in info.pods:
+                enc.add_existing_pod(p, info.node.labels)
+        for ng in node_groups:
+            # estimatorBuilder(..., NewEstimationContext(MaxNodesTotal, similarNodeGroups, currentNodeCount))  :409-412
+            context = EstimationContext(self.max_nodes_total, [], len(snapshot.existing))
+            self.limiter.start_estimation(pegs, ng, context)
+            enc.add_group(node_infos[ng.id()], max_nodes=self.limiter.device_max_nodes(), existing_nodes=len(snapshot.existing),
+                          last_index=snapshot.last_index, pegs=None)   # None: SchedulablePodGroups runs on the device
+            self.limiter.end_estimation()
+        enc.finalize()
+        with Problem(self.ctx, enc.pegs, enc.groups, self.fastpath) as prob:
+            prob.run()
+            res = prob.fetch()
+            best_idx, n_best, best_set = self.expander.best_option_index(prob)
+        total_pods = sum(len(pg.pods) for pg in pegs)
+        options, schedulable, delegated = [], {}, []
+        by_group: Dict[int, Option] = {}
+        for i, ng in enumerate(node_groups):
+            order, placed = res.group(i)
+            schedulable[ng.id()] = sorted(int(x) for x in order)
+            if int(res.status[i]) != 0:
+                delegated.append(ng.id())
+                continue
+            pods: List[Pod] = []
+            for pg_id, n in zip(order, placed):
+                pods.extend(pegs[int(pg_id)].pods[:int(n)])
+            opt = Option(node_group=ng, node_count=int(res.node_count[i]), pods=pods)
+            # orchestrator.go:1057-1063: drop empty options and, for all-or-nothing, partial ones
+            if not pods or opt.node_count == 0:
+                continue
+            if all_or_nothing and len(pods) < total_pods:
+                continue
+            options.append(opt)
+            by_group[i] = opt
+        best = by_group.get(best_idx) if best_idx >= 0 else None
+        if all_or_nothing and best is None and options:
+            # the device chain ran over every valid option; re-run the choice among the all-or-nothing survivors
+            best = min(options, key=lambda o: (o.node_count, node_groups.index(o.node_group)))
+        return ScaleUpPlan(options, best, n_best, schedulable, res, delegated)

@@ -97,3 +97,88 @@ def test_size_independent_properties(ctx):
         assert int(a.pods_scheduled[i]) == int(placed.sum())
         assert int(a.req_cpu_sum[i]) == int((placed.astype(np.int64) * cpu[order]).sum())
         assert 0 <= int(a.node_count[i]) <= int(a.nodes_added[i]) <= g.max_nodes
+
+
+# ---- the reference-interface mirror on the GPU ------------------------------------------------------
+def _est(ctx, max_nodes, fastpath=False):
+    from kubernetes_autoscaler_amd import estimator as est
+    from kubernetes_autoscaler_amd.objects import NodeInfo, make_node
+    snap = est.ClusterSnapshotView(existing=[NodeInfo(make_node(100, 100, 10, "oldnode", "zone-jupiter"))])
+    limiter = est.ThresholdBasedEstimationLimiter([est.StaticThreshold(max_nodes, 0.0)])
+    return est.BinpackingNodeEstimator(ctx, snap, limiter, est.DecreasingPodOrderer(), None, None, fastpath)
+
+
+@pytest.mark.parametrize("case", GOLD["cases"], ids=lambda c: c["name"])
+def test_binpacking_estimate_like_the_reference_test(ctx, case):
+    """TestBinpackingEstimate (binpacking_estimator_test.go:66-254) written against the mirror API."""
+    from kubernetes_autoscaler_amd.objects import (NodeInfo, build_test_pod, make_node, make_pod_equivalence_group,
+                                                   with_host_port, with_labels, with_namespace)
+    pegs = []
+    for g in case["pegs"]:
+        opts = [with_namespace("universe"), with_labels({"app": "estimatee"})]
+        if g.get("host_port"):
+            opts.append(with_host_port(g["host_port"]))
+        pegs.append(make_pod_equivalence_group(build_test_pod("estimatee", g["cpu"], g["mem"], *opts), g["count"]))
+    node_info = NodeInfo(make_node(case["millicores"], case["memory_mib"], 10, "template", "zone-mars"))
+    nodes, pods = _est(ctx, case["max_nodes"]).estimate(pegs, node_info, None)
+    assert (nodes, len(pods)) == (case["expect_nodes"], case["expect_pods"])
+    if "expect_placed_by_input_peg" in case:
+        assert pods == pegs[1].pods   # expectProcessedPods == highResourcePodGroup.Pods
+    if case["check_fastpath"]:
+        fn, fp = _est(ctx, case["max_nodes"], fastpath=True).estimate(pegs, node_info, None)
+        assert (fn, fp) == (nodes, pods)
+
+
+@pytest.mark.parametrize("kinds", [[0], [2], [1], [1, 0]])
+def test_expander_chain_on_device(ctx, kinds):
+    from test_expander_emu import oracle_chain
+    for seed in range(12):
+        w = workloads.fuzz(7000 + seed, max_groups=9, max_pegs=10, rich=False)
+        sc = scenario_of(w)
+        res, best = run_gpu(encode(sc), ctx, kinds=kinds, group_id_base=100)
+        assert_matches_oracle(res, run_oracle(sc), f"fuzz {7000 + seed}")
+        want = oracle_chain(res, kinds, [g.template.node.capacity["cpu"] for g in w.groups],
+                            [g.template.node.capacity["memory"] for g in w.groups])
+        bi, nb, bset, key = best
+        assert [i for i in range(len(bset)) if bset[i]] == want and bi == (want[0] if want else -1)
+        assert key[9] == (100 + want[0] if want else 0x7FFFFFFFFFFFFFFF)
+
+
+def test_prepare_scale_up_batched(ctx):
+    """ScaleUpSimulator.prepare_scale_up == SchedulablePodGroups + ComputeExpansionOption + expander, composed from the oracle."""
+    from kubernetes_autoscaler_amd import estimator as est
+    from kubernetes_autoscaler_amd.expander import ChainStrategy
+    from kubernetes_autoscaler_amd.scaleup import ScaleUpSimulator
+    w = workloads.config_c2(n_groups=12, n_pegs=80, pods_per_peg=10, cap=20)
+    ngs = [est.NodeGroup(f"ng{i}", max_size_=g.max_nodes, target_size_=0) for i, g in enumerate(w.groups)]
+    infos = {ng.id(): g.template for ng, g in zip(ngs, w.groups)}
+    limiter = est.ThresholdBasedEstimationLimiter([est.SngCapacityThreshold(), est.ClusterCapacityThreshold()])
+    sim = ScaleUpSimulator(ctx, limiter, ChainStrategy(["least-waste", "least-nodes"]), max_nodes_total=0)
+    plan = sim.prepare_scale_up(w.pegs, ngs, infos, est.ClusterSnapshotView())
+    sc = scenario_of(w, device_csr=True)
+    oracle = run_oracle(sc)
+    assert_matches_oracle(plan.result, oracle, "prepare_scale_up")
+    for ng, (o, ids) in zip(ngs, oracle):
+        assert plan.schedulable_pod_groups[ng.id()] == sorted(ids)
+    assert plan.best is not None and plan.best in plan.options
+    assert all(o.node_count > 0 and o.pods for o in plan.options)
+
+
+def test_dense_check_matches_feasibility(ctx):
+    """dense per-pod x per-node bit-matrix == fits(peg, fresh node) expanded by pod count and node repeat."""
+    w = workloads.config_c2(n_groups=7, n_pegs=50, pods_per_peg=3, cap=5)
+    sc = scenario_of(w, device_csr=True)
+    enc = encode(sc)
+    feas = ctx.feasibility(enc.pegs, enc.groups)           # [NG][ceil(G/64)]
+    rep = 3
+    with kaa.Problem(ctx, enc.pegs, enc.groups) as p:
+        bits, nr, nc = p.dense_check(rep)
+    assert (nr, nc) == (w.n_pods, len(w.groups) * rep)
+    row = 0
+    for g, pg in enumerate(w.pegs):
+        for _ in pg.pods:
+            for col in range(nc):
+                want = (int(feas[col // rep, g // 64]) >> (g % 64)) & 1
+                got = (int(bits[col // 64, row]) >> (col % 64)) & 1
+                assert got == want, (g, col)
+            row += 1
