@@ -30,16 +30,20 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s a
 
 
 def build_batch(workloads, Encoder, B, seed_base, n_pegs, pods_per_peg, cap):
+    """B independent C1 simulations (seeds seed_base .. seed_base+B-1) in one encoder: the PEGs go in
+    through the bulk ABI entry (same (cpu, mem) pairs as workloads.config_c1(seed))."""
+    import numpy as np
     enc = Encoder()
     checks = 0
     pegs_total = 0
+    tmpl = workloads.config_c1(seed_offset=0, n_pegs=1, pods_per_peg=1, cap=cap).groups[0].template
+    counts = np.full(n_pegs, pods_per_peg, np.int32)
     for b in range(B):
-        w = workloads.config_c1(seed_offset=seed_base + b, n_pegs=n_pegs, pods_per_peg=pods_per_peg, cap=cap)
-        ids = [enc.add_peg(pg) for pg in w.pegs]
-        g = w.groups[0]
-        enc.add_group(g.template, max_nodes=g.max_nodes, existing_nodes=0, last_index=0, pegs=ids)
-        checks += w.checks()
-        pegs_total += len(ids)
+        pairs = np.array(workloads.c1_pairs(seed_base + b, n_pegs), dtype=np.int64)
+        ids = enc.add_resource_pegs(pairs, counts)
+        enc.add_group(tmpl, max_nodes=cap, existing_nodes=0, last_index=0, pegs=list(ids))
+        checks += n_pegs * pods_per_peg * cap
+        pegs_total += n_pegs
     enc.finalize()
     return enc, checks, pegs_total
 

@@ -131,7 +131,8 @@ typedef struct casim_groups {
 
 typedef struct casim_options {
     int32_t fastpath;             /* --fastpath-binpacking-enabled (flags.go:203), default 0 */
-    int32_t reserved[7];
+    int32_t force_generic_packer; /* 1 = never use the register-resident int32 packer (testing / A-B) */
+    int32_t reserved[6];
 } casim_options;
 
 /*
@@ -327,6 +328,12 @@ int32_t casim_enc_pod_set_fastpath_requests(casim_encoder* e, int32_t pod, doubl
 int32_t casim_enc_pod_mark_unsupported(casim_encoder* e, int32_t pod, const char* why);
 /* A PodEquivalenceGroup: `count` pods sharing pod spec `pod`.  Returns the PEG id. */
 int32_t casim_enc_add_peg(casim_encoder* e, int32_t pod_spec, int32_t count);
+
+/* Bulk form for resource-only PEGs (no labels, tolerations, selectors, ports or affinity): one cgo
+ * crossing for n PEGs.  req = [n][n_res] lanes, count = [n]; ids_out (may be NULL) receives the
+ * PEG ids.  Returns the id of the first PEG added or <0. */
+int32_t casim_enc_add_resource_pegs(casim_encoder* e, const char* namespace_, int32_t n, const int64_t* req,
+                                    const int32_t* count, int32_t* ids_out);
 
 /* Pods already running in the cluster that may interact with anti-affinity on non-hostname
  * topology keys: (pod spec, label set of the node it runs on given as a group-like label

@@ -50,7 +50,7 @@ class Groups(C.Structure):
 
 
 class Options(C.Structure):
-    _fields_ = [("fastpath", C.c_int32), ("reserved", C.c_int32 * 7)]
+    _fields_ = [("fastpath", C.c_int32), ("force_generic_packer", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class Results(C.Structure):
@@ -107,6 +107,7 @@ PROTOTYPES = {
     "casim_enc_pod_set_fastpath_requests": (C.c_int32, [C.c_void_p, C.c_int32, C.c_double, C.c_double]),
     "casim_enc_pod_mark_unsupported": (C.c_int32, [C.c_void_p, C.c_int32, cstr]),
     "casim_enc_add_peg": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
+    "casim_enc_add_resource_pegs": (C.c_int32, [C.c_void_p, cstr, C.c_int32, i64p, i32p, i32p]),
     "casim_enc_add_existing_pod": (C.c_int32, [C.c_void_p, C.c_int32, cstrp, cstrp, C.c_int32]),
     "casim_enc_finalize": (C.c_int32, [C.c_void_p]),
     "casim_enc_tables": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups)]),

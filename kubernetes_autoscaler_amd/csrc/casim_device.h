@@ -34,6 +34,7 @@ CS_DEVICE uint64_t readlane_u64(uint64_t v, int l) { return casim_emu::wave_xchg
 CS_DEVICE uint32_t wave_sum_u32(uint32_t v) { return (uint32_t)casim_emu::wave_sum_u64(v); }
 CS_DEVICE uint64_t wave_sum_u64(uint64_t v) { return casim_emu::wave_sum_u64(v); }
 CS_DEVICE uint32_t wave_max_u32(uint32_t v) { return (uint32_t)casim_emu::wave_max_u64(v); }
+CS_DEVICE uint32_t bcast_u32(uint32_t v, int uniform_lane) { return (uint32_t)casim_emu::wave_xchg_u64(v, uniform_lane); }
 CS_DEVICE int popc64(uint64_t v) { return __builtin_popcountll(v); }
 CS_DEVICE int ffs64(uint64_t v) { return v ? __builtin_ctzll(v) : -1; }
 CS_DEVICE int fls64(uint64_t v) { return v ? 63 - __builtin_clzll(v) : -1; }
@@ -68,28 +69,43 @@ CS_DEVICE uint64_t readlane_u64(uint64_t v, int l) {
     hi = (uint32_t)__shfl((int)hi, l, 64);
     return ((uint64_t)hi << 32) | lo;
 }
-CS_DEVICE uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
-    return v;
+// Wave64 reductions on the VALU with DPP (data-parallel primitives): 6 dependent VALU ops instead of
+// 6 ds_bpermute round trips through the LDS crossbar (each ~100 cycles of latency on the packer's
+// critical path — r01a profile).  Pattern: butterfly inside each row of 16 lanes (quad_perm, row_ror),
+// then row_bcast:15 into rows 1/3 and row_bcast:31 into rows 2/3; lane 63 holds the result.
+template <int CTRL, int ROW_MASK>
+CS_DEVICE uint32_t dpp_u32(uint32_t old, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
 }
-CS_DEVICE uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, off, 64);
-        uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), off, 64);
-        v += ((uint64_t)hi << 32) | lo;
-    }
-    return v;
+CS_DEVICE uint32_t wave_sum_u32(uint32_t v) {
+    v += dpp_u32<0xB1, 0xF>(0u, v);    // quad_perm [1,0,3,2]
+    v += dpp_u32<0x4E, 0xF>(0u, v);    // quad_perm [2,3,0,1]
+    v += dpp_u32<0x124, 0xF>(0u, v);   // row_ror:4
+    v += dpp_u32<0x128, 0xF>(0u, v);   // row_ror:8  -> every lane holds its row's sum
+    v += dpp_u32<0x142, 0xA>(0u, v);   // row_bcast:15 -> rows 1 and 3
+    v += dpp_u32<0x143, 0xC>(0u, v);   // row_bcast:31 -> rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 CS_DEVICE uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
+    uint32_t o;
+    o = dpp_u32<0xB1, 0xF>(0u, v); v = o > v ? o : v;
+    o = dpp_u32<0x4E, 0xF>(0u, v); v = o > v ? o : v;
+    o = dpp_u32<0x124, 0xF>(0u, v); v = o > v ? o : v;
+    o = dpp_u32<0x128, 0xF>(0u, v); v = o > v ? o : v;
+    o = dpp_u32<0x142, 0xA>(0u, v); v = o > v ? o : v;
+    o = dpp_u32<0x143, 0xC>(0u, v); v = o > v ? o : v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// exact 64-bit sum of 32-bit lane values: two 32-bit DPP reductions on the 16-bit halves
+CS_DEVICE uint64_t wave_sum_u64(uint64_t v) {
+    const uint32_t lo = wave_sum_u32((uint32_t)v & 0xffffu);
+    const uint32_t mid = wave_sum_u32(((uint32_t)v >> 16) & 0xffffu);
+    const uint32_t h0 = wave_sum_u32((uint32_t)(v >> 32) & 0xffffu);
+    const uint32_t h1 = wave_sum_u32((uint32_t)(v >> 48));
+    return (uint64_t)lo + ((uint64_t)mid << 16) + ((uint64_t)h0 << 32) + ((uint64_t)h1 << 48);
+}
+// value of a wave-UNIFORM lane index: v_readlane_b32 (scalar result, no LDS crossbar)
+CS_DEVICE uint32_t bcast_u32(uint32_t v, int uniform_lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, uniform_lane); }
 CS_DEVICE int popc64(uint64_t v) { return __popcll(v); }
 CS_DEVICE int ffs64(uint64_t v) { return v ? (int)__builtin_ctzll(v) : -1; }
 CS_DEVICE int fls64(uint64_t v) { return v ? 63 - (int)__builtin_clzll(v) : -1; }
@@ -104,6 +120,15 @@ CS_DEVICE int mbcnt(uint64_t mask) {
     int l = lane();
     uint64_t below = l == 0 ? 0ull : (~0ull >> (64 - l));
     return popc64(mask & below);
+}
+// exact sum of 64 uint32 lane values as a uint64: two 32-bit reductions on the 16-bit halves
+CS_DEVICE uint64_t wave_sum_u32_wide(uint32_t v) {
+    const uint32_t lo = wave_sum_u32(v & 0xffffu);
+    const uint32_t hi = wave_sum_u32(v >> 16);
+    return (uint64_t)lo + ((uint64_t)hi << 16);
+}
+CS_DEVICE uint64_t bcast_u64(uint64_t v, int uniform_lane) {
+    return ((uint64_t)bcast_u32((uint32_t)(v >> 32), uniform_lane) << 32) | bcast_u32((uint32_t)v, uniform_lane);
 }
 // bits [0, n) set; n may be <= 0 or >= 64
 CS_DEVICE uint64_t low_mask(int n) { return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1)); }

@@ -292,6 +292,25 @@ int32_t casim_enc_add_peg(casim_encoder* e, int32_t pod_spec, int32_t count) {
     e->pegs.push_back(Peg{pod_spec, count});
     return (int32_t)e->pegs.size() - 1;
 }
+int32_t casim_enc_add_resource_pegs(casim_encoder* e, const char* namespace_, int32_t n, const int64_t* req, const int32_t* count,
+                                    int32_t* ids_out) {
+    ENC_CHECK(e);
+    if (n < 0 || (n > 0 && (!req || !count))) return CASIM_ERR_INVALID;
+    const int R = e->opt.n_res;
+    const int32_t first = (int32_t)e->pegs.size();
+    for (int32_t i = 0; i < n; ++i) {  // (no exact reserve(): repeated bulk calls would re-copy every spec each time)
+        if (count[i] < 0) return CASIM_ERR_INVALID;
+        PodSpec p;
+        p.ns = S(namespace_);
+        for (int r = 0; r < CASIM_MAX_RES; ++r) p.req[r] = r < R ? req[(size_t)i * (size_t)R + (size_t)r] : 0;
+        // Containers[0].Resources.Requests as float64 (binpacking_estimator.go:451-458): milli * 10^-3, bytes
+        p.fp_cpu = (double)p.req[0] * 1e-3; p.fp_mem = (double)p.req[1];
+        e->specs.push_back(p);
+        e->pegs.push_back(Peg{(int32_t)e->specs.size() - 1, count[i]});
+        if (ids_out) ids_out[i] = first + i;
+    }
+    return first;
+}
 int32_t casim_enc_add_existing_pod(casim_encoder* e, int32_t pod_spec, const char* const* keys, const char* const* values, int32_t n) {
     POD_CHECK(e, pod_spec);
     if (n < 0 || (n > 0 && (!keys || !values))) return CASIM_ERR_INVALID;
@@ -390,13 +409,21 @@ int32_t casim_enc_finalize(casim_encoder* e) {
                 peg_blockers[j].push_back(peg_occ_bit[i]);
             }
         }
-        for (auto& g : e->groups)
-            for (int32_t s : g.preloaded)
-                for (size_t i = 0; i < G; ++i)
-                    if (host_conflict(e->specs[(size_t)s], e->specs[(size_t)e->pegs[i].spec])) {
-                        if (!pre_occ_bit.count(s)) pre_occ_bit[s] = xbits.next();
-                        peg_blockers[i].push_back(pre_occ_bit[s]);
-                    }
+        std::set<int32_t> pre_specs;  // distinct specs preloaded on some template
+        for (auto& g : e->groups) for (int32_t s : g.preloaded) pre_specs.insert(s);
+        for (int32_t s : pre_specs) {
+            bool s_has_terms = false;
+            for (auto& t : e->specs[(size_t)s].anti) if (t.topology_key == kHostname) s_has_terms = true;
+            auto visit = [&](size_t i) {
+                if (host_conflict(e->specs[(size_t)s], e->specs[(size_t)e->pegs[i].spec])) {
+                    if (!pre_occ_bit.count(s)) pre_occ_bit[s] = xbits.next();
+                    peg_blockers[i].push_back(pre_occ_bit[s]);
+                }
+            };
+            // only a pod that carries hostname terms can conflict with a term-less one
+            if (s_has_terms) for (size_t i = 0; i < G; ++i) visit(i);
+            else for (size_t i : with_terms) visit(i);
+        }
     }
     e->Wx = xbits.words();
 
@@ -428,36 +455,45 @@ int32_t casim_enc_finalize(casim_encoder* e) {
             }
         }
     }
-    // existing cluster pods: static (PEG, group) blocks
-    std::vector<std::vector<bool>> existing_block(G, std::vector<bool>(NG, false));
-    for (size_t i = 0; i < G; ++i) {
-        const PodSpec& a = e->specs[(size_t)e->pegs[i].spec];
-        for (auto& x : e->existing) {
-            const PodSpec& b = e->specs[(size_t)x.spec];
+    // existing cluster pods and pods preloaded on a template: static (PEG, group) blocks through
+    // non-hostname topology keys.  Sparse: only PEGs / pods that carry such terms can interact.
+    std::vector<std::vector<uint32_t>> existing_block(G);   // PEG -> groups where it is blocked
+    {
+        auto has_zone_terms = [&](const PodSpec& p) {
+            for (auto& t : p.anti) if (t.topology_key != kHostname) return true;
+            return false;
+        };
+        bool others_have_terms = false;
+        for (auto& x : e->existing) others_have_terms = others_have_terms || has_zone_terms(e->specs[(size_t)x.spec]);
+        for (auto& g : e->groups) for (int32_t s : g.preloaded) others_have_terms = others_have_terms || has_zone_terms(e->specs[(size_t)s]);
+        const bool any_others = !e->existing.empty();
+        bool any_preloaded = false;
+        for (auto& g : e->groups) any_preloaded = any_preloaded || !g.preloaded.empty();
+        for (size_t i = 0; i < G && (any_others || any_preloaded); ++i) {
+            const PodSpec& a = e->specs[(size_t)e->pegs[i].spec];
+            if (!others_have_terms && !has_zone_terms(a)) continue;
             for (size_t gi = 0; gi < NG; ++gi) {
                 const Group& g = e->groups[gi];
-                auto same_domain = [&](const std::string& tk) {
-                    if (tk == kHostname) return false;  // new nodes never share a hostname with an existing node
-                    auto a1 = g.labels.find(tk); auto b1 = x.node_labels.find(tk);
-                    return a1 != g.labels.end() && b1 != x.node_labels.end() && a1->second == b1->second;
-                };
                 bool blk = false;
-                for (auto& t : a.anti) if (same_domain(t.topology_key) && term_matches(t, b)) blk = true;
-                for (auto& t : b.anti) if (same_domain(t.topology_key) && term_matches(t, a)) blk = true;
-                if (blk) existing_block[i][gi] = true;
+                for (auto& x : e->existing) {
+                    const PodSpec& b = e->specs[(size_t)x.spec];
+                    auto same_domain = [&](const std::string& tk) {
+                        if (tk == kHostname) return false;  // new nodes never share a hostname with an existing node
+                        auto a1 = g.labels.find(tk); auto b1 = x.node_labels.find(tk);
+                        return a1 != g.labels.end() && b1 != x.node_labels.end() && a1->second == b1->second;
+                    };
+                    for (auto& t : a.anti) if (same_domain(t.topology_key) && term_matches(t, b)) blk = true;
+                    for (auto& t : b.anti) if (same_domain(t.topology_key) && term_matches(t, a)) blk = true;
+                }
+                for (int32_t s2 : g.preloaded) {  // preloaded pods share every non-hostname domain with the template's clones
+                    const PodSpec& b = e->specs[(size_t)s2];
+                    for (auto& t : a.anti) if (t.topology_key != kHostname && g.labels.count(t.topology_key) && term_matches(t, b)) blk = true;
+                    for (auto& t : b.anti) if (t.topology_key != kHostname && g.labels.count(t.topology_key) && term_matches(t, a)) blk = true;
+                }
+                if (blk) existing_block[i].push_back((uint32_t)gi);
             }
+            if (!existing_block[i].empty()) { static_zbit[i] = zbits.next(); zbit_key[static_zbit[i]] = ""; z_block[i].push_back(static_zbit[i]); }
         }
-        for (size_t gi = 0; gi < NG; ++gi) {  // pods preloaded on the template share every non-hostname domain with its clones
-            const Group& g = e->groups[gi];
-            for (int32_t s : g.preloaded) {
-                const PodSpec& b = e->specs[(size_t)s];
-                for (auto& t : a.anti) if (t.topology_key != kHostname && g.labels.count(t.topology_key) && term_matches(t, b)) existing_block[i][gi] = true;
-                for (auto& t : b.anti) if (t.topology_key != kHostname && g.labels.count(t.topology_key) && term_matches(t, a)) existing_block[i][gi] = true;
-            }
-        }
-        bool any = false;
-        for (size_t gi = 0; gi < NG; ++gi) any = any || existing_block[i][gi];
-        if (any) { static_zbit[i] = zbits.next(); zbit_key[static_zbit[i]] = ""; z_block[i].push_back(static_zbit[i]); }
     }
     e->Wz = zbits.words();
 
@@ -540,9 +576,9 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         for (auto& zk : zbit_key) {
             if (zk.second.empty() || g.labels.count(zk.second)) set_bit(e->zone_valid, gi, Wz, zk.first);
         }
-        for (size_t i = 0; i < G; ++i) if (existing_block[i][gi]) set_bit(e->init_zone, gi, Wz, static_zbit[i]);
         any_explicit = any_explicit || g.has_pegs;
     }
+    for (size_t i = 0; i < G; ++i) for (uint32_t gi : existing_block[i]) set_bit(e->init_zone, gi, Wz, static_zbit[i]);
     e->peg_off.clear(); e->peg_idx.clear();
     if (any_explicit) {
         e->peg_off.push_back(0);

@@ -49,7 +49,12 @@ CS_DEVICE bool static_filters_pass(const DevTables& t, int g, int ng) {
 // How many pods with request `req` fit into (free, slots), clamped to `clampk`.
 // fitsRequest: pod count first, then every lane with req > 0 needs req <= alloc - requested
 // (fit.go:681-765); k pods fit iff k <= slots and k*req <= free for each such lane.
-CS_DEVICE uint32_t capacity_of(const int64_t* fr, int stride, int32_t slots, int R, const int64_t* req, uint32_t clampk) {
+// `rq` (optional) = 1.0 / (double)req[r], precomputed once per PEG: the quotient is then ONE f64
+// multiply + an exact +-1 fix-up instead of a ~100-instruction emulated 64-bit division.
+// Exactness: f < 2^53 converts exactly; the quotient d < c <= 2^31, so the estimate's absolute error
+// is < 2^-20 and trunc() is within +-1 of floor(f/q); the remainder test restores the exact floor.
+CS_DEVICE uint32_t capacity_of(const int64_t* fr, int stride, int32_t slots, int R, const int64_t* req, uint32_t clampk,
+                               const double* rq = nullptr) {
     if (slots <= 0) return 0;
     uint32_t c = (uint32_t)slots < clampk ? (uint32_t)slots : clampk;
     for (int r = 0; r < CASIM_KMAX_RES; ++r) {
@@ -61,7 +66,14 @@ CS_DEVICE uint32_t capacity_of(const int64_t* fr, int stride, int32_t slots, int
             // division only when the running bound does not already fit: c*q <= f  => floor(f/q) >= c
             const unsigned __int128 cq = (unsigned __int128)c * (uint64_t)q;
             if (cq > (unsigned __int128)(uint64_t)f) {
-                const uint64_t d = (uint64_t)f / (uint64_t)q;
+                uint64_t d;
+                if (rq && f < (1ll << 53)) {
+                    uint32_t e = (uint32_t)((double)f * rq[r]);
+                    const int64_t rem = f - (int64_t)((uint64_t)e * (uint64_t)q);
+                    if (rem < 0) e -= 1;
+                    else if (rem >= q) e += 1;
+                    d = e;
+                } else d = (uint64_t)f / (uint64_t)q;
                 c = (uint32_t)d;  // d < c here
             }
         }
@@ -250,14 +262,23 @@ CS_GLOBAL void order_kernel(DevTables t, DevResults res, OrderScratch os) {
             if (i == Gn - 1) src = best;
             else if (i >= best) src = i + 1;
         }
-        res.order[off + i] = t.peg_idx[off + pos[src]];
+        // Emit the PEG record in PROCESSING order (structure of arrays): the packer then streams its
+        // group's records with coalesced loads, 64 records per wave-load, and never chases indices.
+        // The template-level Filters (taints, nodeSelector / affinity, unschedulable) are constant per
+        // (PEG, group): evaluate them once here and hand them over as one flag bit.
+        const int g = t.peg_idx[off + pos[src]];
+        res.order[off + i] = g;
+        res.s_count[off + i] = t.count[g];
+        res.s_flags[off + i] = (t.pflags[g] & ~CASIM_KFLAG_STATIC_OK) | (static_filters_pass(t, g, ng) ? CASIM_KFLAG_STATIC_OK : 0u);
+        for (int r = 0; r < t.R; ++r) res.s_req[(int64_t)(off + i) * t.R + r] = t.req[(int64_t)g * t.R + r];
     }
     if (tid == 0) res.fast_last[ng] = best >= 0 ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------
-// K_pack: one wavefront = one Estimate()
+// K_pack: one wavefront = one Estimate()  -> casim_pack.h (included at the end of this file)
 // ------------------------------------------------------------------------------------------
+#if 0  // round-1 first version (LDS state, shuffle reductions); kept until casim_pack.h has soaked
 struct PackCtx {
     int64_t* sfree;   // [R][cap]
     uint64_t* sexcl;  // [Wx][cap]
@@ -572,6 +593,8 @@ CS_GLOBAL void pack_kernel(DevTables t, DevResults res, PackScratch ps) {
     }
 }
 
+#endif  // round-1 first version of pack_kernel
+
 // ------------------------------------------------------------------------------------------
 // K_option: expander filter chain over the groups of one launch
 // ------------------------------------------------------------------------------------------
@@ -673,3 +696,5 @@ CS_GLOBAL void option_kernel(OptionArgs a) {
 }
 
 }  // namespace casim
+
+#include "casim_pack.h"

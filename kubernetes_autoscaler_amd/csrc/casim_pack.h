@@ -1,0 +1,609 @@
+// casim_pack.h — K_pack: one wavefront simulates one BinpackingNodeEstimator.Estimate()
+// (CA/estimator/binpacking_estimator.go:102-342; `CA/` = /root/reference/cluster-autoscaler/).
+//
+// Reference semantics, restated as closed forms over a PodEquivalenceGroup of k identical pods:
+//   a2  tryToScheduleOnExistingNodes (:163-186): pods visit the simulated nodes round-robin in the
+//       cyclic order that starts right after lastIndex (scheduling_opts.go:54-59; MarkMatch moves the
+//       start to the matched node, plugin_runner.go:138).  With per-node capacities c_j, after t full
+//       rounds node j holds min(c_j, t) pods: find the largest T with
+//       S(T) = sum_j min(c_j, T) <= k by bisection on wave sums, hand the remaining k - S(T) pods to
+//       the first nodes (rotated order) with c_j > T, and read the new lastIndex off the last one.
+//   a3  tryToScheduleOnNewNodes (:190-269): next-fit on the newest node, then ceil(r / c_new) fresh
+//       nodes, gated by the limiter (threshold_based_limiter.go:57-69), with the three exits of
+//       SURVEY N2 (empty newest node / limiter refusal / pod does not fit a fresh node).
+//   a4  tryFastPath (:274-324): one simulated node + arithmetic for the rest (last PEG only).
+// Filters: NodeResourcesFit (fit.go:678-765) as integer compares in capacity_of(); TaintToleration /
+// NodeAffinity / NodeUnschedulable folded into one precomputed flag by order_kernel; NodePorts and
+// InterPodAffinity (anti-affinity) as node-local / group-wide exclusion bits.
+//
+// Mapping to the wave: simulated node m is owned by lane (m & 63), slot (m >> 6).  Node state is
+// lane-private, so the kernel needs no barrier; all cross-lane traffic is ballots, v_mbcnt, v_readlane
+// and DPP reductions.  Two node stores share ONE algorithm body:
+//   RegStore<R, NPT>  node state in VGPRs as int32 (lanes pre-divided by their gcd on the host — exact,
+//                     see casim_pipeline.h), up to 64*NPT nodes, no exclusion bits: the fast path
+//   MemStore<kLds>    int64 state in LDS (or an HBM slab), any R / node count / exclusion masks
+// PEG records arrive in processing order (written by order_kernel): 64 records per coalesced
+// wave-load, one per lane, broadcast field by field with v_readlane.
+#pragma once
+#include "casim_device.h"
+#include "casim_types.h"
+
+namespace casim {
+
+template <class L, int RMAX>
+struct PegView {
+    L req[RMAX];
+    double rq[RMAX];  // 1 / req: quotient estimate of capacity_of
+    const uint64_t* xblock;
+    const uint64_t* xmark;
+};
+template <class L, int RMAX>
+struct FreshNode {
+    L free[RMAX];  // alloc - requested by pods preloaded on the template
+    int32_t slots;           // allowed pods - preloaded pods
+    const uint64_t* excl;    // node bits already set on a fresh node
+};
+
+// How many pods with request `req` fit into (free, slots), clamped to `clampk`
+// (fitsRequest, fit.go:681-765: pod count first, then every lane with req > 0 needs req <= free).
+// Quotients use one f64 multiply by the PEG's precomputed reciprocal + an exact +-1 fix-up (see
+// capacity_of in casim_kernels.h for the error bound); int64 lanes above 2^53 fall back to a division.
+template <class L, int RMAX>
+CS_DEVICE uint32_t capacity_lanes(const L* fr, int32_t slots, int R, const PegView<L, RMAX>& pv, uint32_t clampk) {
+    if (slots <= 0) return 0;
+    uint32_t c = (uint32_t)slots < clampk ? (uint32_t)slots : clampk;
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+        if (r < R) {
+            const L q = pv.req[r];
+            if (q > 0) {
+                const L f = fr[r];
+                if (f < q) return 0;
+                bool need;
+                if constexpr (sizeof(L) == 4) need = (uint64_t)c * (uint64_t)(uint32_t)q > (uint64_t)(uint32_t)f;
+                else need = (unsigned __int128)c * (uint64_t)q > (unsigned __int128)(uint64_t)f;
+                if (need) {  // floor(f / q) < c
+                    uint32_t e;
+                    if (sizeof(L) == 4 || (int64_t)f < (1ll << 53)) {
+                        e = (uint32_t)((double)f * pv.rq[r]);
+                        const int64_t rem = (int64_t)f - (int64_t)((uint64_t)e * (uint64_t)q);
+                        if (rem < 0) e -= 1;
+                        else if (rem >= (int64_t)q) e += 1;
+                    } else e = (uint32_t)((uint64_t)f / (uint64_t)q);
+                    c = e;
+                }
+            }
+        }
+    }
+    return c;
+}
+
+// ---- node store: int64 state in LDS / HBM -------------------------------------------------------
+template <bool kLds>
+struct MemStore {
+    using Lane = int64_t;
+    static constexpr int kNPT = 0;          // 0 = runtime slot count
+    static constexpr int kRMax = CASIM_KMAX_RES;
+    static constexpr bool kHasExcl = true;
+    using Peg = PegView<int64_t, CASIM_KMAX_RES>;
+    using Fresh = FreshNode<int64_t, CASIM_KMAX_RES>;
+    int R, Wx, cap;
+    int64_t* sfree;   // [R][cap]
+    uint64_t* sexcl;  // [Wx][cap]
+    int32_t* sslots;  // [cap]
+    int32_t* snpods;  // [cap]
+    int32_t* sctmp;   // [cap]
+
+    CS_DEVICE uint32_t capacity(int, int m, const Peg& pv, uint32_t clampk, bool selfx) const {
+        for (int w = 0; w < Wx; ++w)
+            if (sexcl[(int64_t)w * cap + m] & pv.xblock[w]) return 0;  // NodePorts / hostname anti-affinity
+        Lane fr[CASIM_KMAX_RES];
+#pragma unroll
+        for (int r = 0; r < CASIM_KMAX_RES; ++r) fr[r] = r < R ? sfree[(int64_t)r * cap + m] : 0;
+        uint32_t k = capacity_lanes<Lane, CASIM_KMAX_RES>(fr, sslots[m], R, pv, clampk);
+        if (selfx && k > 1) k = 1;
+        return k;
+    }
+    // place x pods on node m (NodeInfo.AddPodInfo / update, types.go:361-371,439-463)
+    CS_DEVICE void commit(int, int m, uint32_t x, const Peg& pv) {
+        for (int r = 0; r < R; ++r) sfree[(int64_t)r * cap + m] -= (int64_t)x * pv.req[r];
+        sslots[m] -= (int32_t)x;
+        snpods[m] += (int32_t)x;
+        for (int w = 0; w < Wx; ++w) sexcl[(int64_t)w * cap + m] |= pv.xmark[w];
+    }
+    CS_DEVICE void create(int, int m, uint32_t x, const Peg& pv, const Fresh& fn) {
+        for (int r = 0; r < R; ++r) sfree[(int64_t)r * cap + m] = fn.free[r] - (int64_t)x * pv.req[r];
+        sslots[m] = fn.slots - (int32_t)x;
+        snpods[m] = (int32_t)x;
+        for (int w = 0; w < Wx; ++w) sexcl[(int64_t)w * cap + m] = fn.excl[w] | (x > 0 ? pv.xmark[w] : 0ull);
+    }
+    CS_DEVICE uint32_t get_c(int, int m) const { return (uint32_t)sctmp[m]; }
+    CS_DEVICE void set_c(int, int m, uint32_t v) { sctmp[m] = (int32_t)v; }
+    CS_DEVICE int32_t npods(int, int m) const { return snpods[m]; }
+    // summary pruning is a register-store feature
+    CS_DEVICE bool may_fit(const Peg&) const { return true; }
+    CS_DEVICE void tighten(int, int) {}
+    CS_DEVICE void note_create(const Fresh&) {}
+    CS_DEVICE void note_change() {}
+};
+
+// ---- node store: int32 state in VGPRs (fast path) ---------------------------------------------------
+template <int R_, int NPT_>
+struct RegStore {
+    using Lane = int32_t;
+    static constexpr int kNPT = NPT_;
+    static constexpr int kRMax = R_;
+    static constexpr bool kHasExcl = false;
+    using Peg = PegView<int32_t, R_>;
+    using Fresh = FreshNode<int32_t, R_>;
+    int32_t fr[NPT_][R_];
+    int32_t slots[NPT_];
+    int32_t pods[NPT_];
+    uint32_t c[NPT_];
+
+    CS_DEVICE uint32_t capacity(int s, int, const Peg& pv, uint32_t clampk, bool selfx) const {
+        uint32_t k = capacity_lanes<Lane, R_>(fr[s], slots[s], R_, pv, clampk);
+        if (selfx && k > 1) k = 1;
+        return k;
+    }
+    CS_DEVICE void commit(int s, int, uint32_t x, const Peg& pv) {
+#pragma unroll
+        for (int r = 0; r < R_; ++r) fr[s][r] -= (int32_t)x * pv.req[r];
+        slots[s] -= (int32_t)x;
+        pods[s] += (int32_t)x;
+    }
+    CS_DEVICE void create(int s, int, uint32_t x, const Peg& pv, const Fresh& fn) {
+#pragma unroll
+        for (int r = 0; r < R_; ++r) fr[s][r] = fn.free[r] - (int32_t)x * pv.req[r];
+        slots[s] = fn.slots - (int32_t)x;
+        pods[s] = (int32_t)x;
+    }
+    CS_DEVICE uint32_t get_c(int s, int) const { return c[s]; }
+    CS_DEVICE void set_c(int s, int, uint32_t v) { c[s] = v; }
+    CS_DEVICE int32_t npods(int s, int) const { return pods[s]; }
+
+    // Summary pruning.  bound_free[r] / bound_slots are wave-uniform UPPER bounds of max_j free_j[r] and
+    // max_j slots_j over all simulated nodes.  Placements only lower the true maxima, so a stale bound stays
+    // valid; a new node raises it to the fresh values.  A PEG with req[r] > bound_free[r] for some lane
+    // (or no slot anywhere) fits nowhere: its a2 sweep is skipped (it would compute c_j = 0 for every node).
+    int32_t bound_free[R_];
+    int32_t bound_slots;
+    bool dirty;
+    CS_DEVICE void reset_bounds() {
+#pragma unroll
+        for (int r = 0; r < R_; ++r) bound_free[r] = (int32_t)0x80000000;
+        bound_slots = (int32_t)0x80000000;
+        dirty = false;
+    }
+    CS_DEVICE bool may_fit(const Peg& pv) const {
+        bool ok = bound_slots >= 1;
+#pragma unroll
+        for (int r = 0; r < R_; ++r) ok = ok && !(pv.req[r] > 0 && pv.req[r] > bound_free[r]);
+        return ok;
+    }
+    CS_DEVICE void note_create(const Fresh& fn) {
+#pragma unroll
+        for (int r = 0; r < R_; ++r) bound_free[r] = fn.free[r] > bound_free[r] ? fn.free[r] : bound_free[r];
+        bound_slots = fn.slots > bound_slots ? fn.slots : bound_slots;
+        dirty = true;
+    }
+    CS_DEVICE void note_change() { dirty = true; }
+    // recompute the exact maxima (R_+1 DPP reductions); called when a sweep found nothing although the bounds passed
+    CS_DEVICE void tighten(int M, int lane) {
+        if (!dirty) return;
+        int32_t lf[R_];
+        int32_t ls = (int32_t)0x80000000;
+#pragma unroll
+        for (int r = 0; r < R_; ++r) lf[r] = (int32_t)0x80000000;
+#pragma unroll
+        for (int s = 0; s < NPT_; ++s) {
+            if (s * 64 + lane < M) {
+#pragma unroll
+                for (int r = 0; r < R_; ++r) lf[r] = fr[s][r] > lf[r] ? fr[s][r] : lf[r];
+                ls = slots[s] > ls ? slots[s] : ls;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R_; ++r) bound_free[r] = (int32_t)(cs::wave_max_u32((uint32_t)lf[r] ^ 0x80000000u) ^ 0x80000000u);
+        bound_slots = (int32_t)(cs::wave_max_u32((uint32_t)ls ^ 0x80000000u) ^ 0x80000000u);
+        dirty = false;
+    }
+};
+
+// slot loops: fully unrolled for the register store (static VGPR indices), runtime for the memory store
+template <class Store, class F>
+CS_DEVICE void for_slots(int S, F&& f) {
+    if constexpr (Store::kNPT > 0) {
+#pragma unroll
+        for (int s = 0; s < Store::kNPT; ++s)
+            if (s < S) f(s);
+    } else {
+        for (int s = 0; s < S; ++s) f(s);
+    }
+}
+template <class Store, class F>
+CS_DEVICE void with_slot(int ls, F&& f) {
+    if constexpr (Store::kNPT > 0) {
+#pragma unroll
+        for (int s = 0; s < Store::kNPT; ++s)
+            if (s == ls) f(s);
+    } else {
+        f(ls);
+    }
+}
+
+// PEG-record source of the 64-record chunk loaded by the wave (processing order)
+struct PegChunk {
+    int32_t cnt;
+    uint32_t flags;
+    int32_t g;
+};
+
+// The algorithm body, shared by every store.
+//   ReqLoader(kk, r) -> request lane r of sorted record kk (int64 original or int32 gcd-scaled)
+template <class Store, class ReqLoader>
+CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, const typename Store::Fresh& fn,
+                         uint64_t* szone /*[Wz][64] per-lane copies or null*/, ReqLoader load_req, const int64_t* sum_scale) {
+    using L = typename Store::Lane;
+    constexpr int RM = Store::kRMax;
+    const int ng = cs::bid();
+    const int lane = cs::lane();
+    const int R = t.R;
+    const int Wx = Store::kHasExcl ? t.Wx : 0;
+    const int Wz = Store::kHasExcl ? t.Wz : 0;
+    const int off = t.peg_off[ng];
+    const int Gn = t.peg_off[ng + 1] - off;
+
+    const int32_t maxn = t.max_nodes[ng];
+    const int32_t E = t.existing[ng];
+    const bool fast_last = t.fastpath && res.fast_last[ng];
+    const bool group_unschedulable = (t.gflags[ng] & CASIM_NG_UNSCHEDULABLE) != 0;
+    const uint64_t* zvalid = t.zone_valid + (int64_t)ng * Wz;
+    for (int w = 0; w < Wz; ++w) szone[w * 64 + lane] = t.init_zone[(int64_t)ng * Wz + w];
+
+    int32_t M = 0;                         // simulated nodes so far (estimationState.newNodeNameIndex)
+    int32_t last_index = t.last_index[ng]; // lastIndexOrderMapping.lastIndex
+    int32_t granted = 0;                   // limiter.nodes
+    bool more = true;                      // newNodesAvailable
+    int32_t fakes = 0;                     // fastpath fake nodes
+    int32_t total_placed = 0;
+    int64_t sum0 = 0, sum1 = 0;            // sum of placed * req lane 0 / 1 (in store units)
+
+    for (int k0 = 0; k0 < Gn; k0 += 64) {
+        // ---- one coalesced wave-load: PEG record k0+lane of this group, in processing order ----
+        const int kk = k0 + lane;
+        const bool have = kk < Gn;
+        const int32_t my_cnt = have ? res.s_count[off + kk] : 0;
+        const uint32_t my_flags = have ? res.s_flags[off + kk] : 0u;
+        const int32_t my_g = have ? res.order[off + kk] : 0;
+        L my_req[RM];
+#pragma unroll
+        for (int r = 0; r < RM; ++r) my_req[r] = (have && r < R) ? load_req(off + kk, r) : (L)0;
+        int32_t my_placed = 0;
+        const int nk = Gn - k0 < 64 ? Gn - k0 : 64;
+
+        for (int j = 0; j < nk; ++j) {
+            const int k = k0 + j;
+            const int32_t cnt = (int32_t)cs::bcast_u32((uint32_t)my_cnt, j);
+            const uint32_t pf = cs::bcast_u32(my_flags, j);
+            typename Store::Peg pv;
+#pragma unroll
+            for (int r = 0; r < RM; ++r) {
+                if (r < R) {
+                    if constexpr (sizeof(L) == 4) pv.req[r] = (L)cs::bcast_u32((uint32_t)my_req[r], j);
+                    else pv.req[r] = (L)cs::bcast_u64((uint64_t)my_req[r], j);
+                } else pv.req[r] = 0;
+                pv.rq[r] = pv.req[r] > 0 ? 1.0 / (double)pv.req[r] : 0.0;
+            }
+            const bool selfx = (pf & CASIM_PEG_SELF_EXCL_NODE) != 0;
+            bool zselfx = (pf & CASIM_PEG_SELF_EXCL_ZONE) != 0;
+            const bool static_ok = (pf & CASIM_KFLAG_STATIC_OK) != 0;
+            pv.xblock = nullptr; pv.xmark = nullptr;
+            const uint64_t *zblock = nullptr, *zmark = nullptr;
+            if (Wx > 0 || Wz > 0) {
+                const int g = (int)cs::bcast_u32((uint32_t)my_g, j);
+                pv.xblock = t.xblock + (int64_t)g * Wx; pv.xmark = t.xmark + (int64_t)g * Wx;
+                zblock = t.zblock + (int64_t)g * Wz; zmark = t.zmark + (int64_t)g * Wz;
+            }
+            bool zblocked = false;
+            for (int w = 0; w < Wz; ++w) {
+                zblocked |= (szone[w * 64 + lane] & zblock[w]) != 0;
+                zselfx |= (zblock[w] & zmark[w] & zvalid[w]) != 0;  // the PEG excludes itself group-wide
+            }
+
+            int32_t placed = 0;
+            uint32_t on_last = 0;  // pods of THIS PEG that a2 put on the newest node (self-exclusion has no node bit)
+
+            // ---- a2: closed form of the cyclic first-fit over the simulated nodes ----
+            // RunFiltersUntilPassingNode skips Spec.Unschedulable nodes before any Filter runs, tolerated or
+            // not (plugin_runner.go:108-110); every simulated node clones the template's flag.
+            const uint32_t keff = (uint32_t)(zselfx ? (cnt > 0 ? 1 : 0) : cnt);
+            if (M > 0 && keff > 0 && static_ok && !zblocked && !group_unschedulable) {
+                const int S = (M + 63) >> 6;
+                const uint64_t cap1 = (uint64_t)keff + 1;
+                // exact wave sum of per-lane values <= cap1: one 32-bit DPP reduction when 64 * cap1 < 2^32
+                auto wsum = [&](uint64_t v) -> uint64_t {
+                    if (v > cap1) v = cap1;
+                    return cap1 <= (1ull << 25) ? (uint64_t)cs::wave_sum_u32((uint32_t)v) : cs::wave_sum_u32_wide((uint32_t)v);
+                };
+                // pass A: capacities c_j; n1 = nodes that take at least one pod (ballots only, no reduction)
+                uint64_t lane_sum = 0;
+                uint32_t lane_max = 0;
+                int32_t n1 = 0;
+                if (st.may_fit(pv)) {  // summary pruning: no node can take this PEG (stale-but-safe bounds)
+                    for_slots<Store>(S, [&](int s) {
+                        const int m = s * 64 + lane;
+                        uint32_t cj = 0;
+                        if (m < M) cj = st.capacity(s, m, pv, keff, selfx);
+                        st.set_c(s, m, cj);
+                        lane_sum += cj;
+                        lane_max = cj > lane_max ? cj : lane_max;
+                        n1 += cs::popc64(cs::ballot(cj > 0));
+                    });
+                    if (n1 == 0) st.tighten(M, lane);  // the bounds were too loose: make them exact again
+                }
+                if (n1 > 0) {
+                    uint32_t T, Rr;
+                    if ((uint32_t)n1 > keff) {
+                        // S(1) = n1 > k: not even one full round — the k pods go to the first k fitting nodes
+                        T = 0; Rr = keff; placed = (int32_t)keff;
+                    } else {
+                        const uint64_t tot = wsum(lane_sum);
+                        const uint32_t cmax = cs::wave_max_u32(lane_max);
+                        if (tot <= keff) { T = cmax; Rr = 0; placed = (int32_t)tot; }  // every node saturates
+                        else {
+                            uint32_t lo = 1, hi = cmax; uint64_t slo = (uint64_t)n1;  // S(lo) <= keff < S(hi)
+                            while (hi - lo > 1) {
+                                const uint32_t mid = lo + ((hi - lo) >> 1);
+                                uint64_t ls = 0;
+                                for_slots<Store>(S, [&](int s) {
+                                    const uint32_t cj = st.get_c(s, s * 64 + lane);
+                                    ls += cj < mid ? cj : mid;
+                                });
+                                const uint64_t sm = wsum(ls);
+                                if (sm <= keff) { lo = mid; slo = sm; } else hi = mid;
+                            }
+                            T = lo; Rr = keff - (uint32_t)slo; placed = (int32_t)keff;
+                        }
+                    }
+                    const uint32_t Tf = Rr > 0 ? T + 1 : T;  // last round: candidates have c >= Tf
+                    // rotated order starts at list position (lastIndex + 1) % n; positions < E are the
+                    // pre-existing cluster nodes (never acceptable)
+                    const int32_t n = E + M;
+                    const int32_t o = (int32_t)(((int64_t)last_index + 1) % n);
+                    const int32_t m0 = o > E ? o - E : 0;
+                    int32_t A = 0, Tot = 0;
+                    for_slots<Store>(S, [&](int s) {
+                        const uint64_t b = cs::ballot(st.get_c(s, s * 64 + lane) >= Tf);
+                        Tot += cs::popc64(b);
+                        A += cs::popc64(b & cs::low_mask(m0 - s * 64));
+                    });
+                    const int32_t target = Rr > 0 ? (int32_t)Rr - 1 : Tot - 1;
+                    int32_t basec = 0, new_last = last_index;
+                    uint32_t x_mine_last = 0;
+                    for_slots<Store>(S, [&](int s) {
+                        const int m = s * 64 + lane;
+                        const uint32_t cj = st.get_c(s, m);
+                        const bool cand = cj >= Tf;
+                        const uint64_t b = cs::ballot(cand);
+                        const int32_t pex = basec + cs::mbcnt(b);
+                        const int32_t rot = m >= m0 ? pex - A : (Tot - A) + pex;
+                        uint32_t x = cj < T ? cj : T;
+                        if (Rr > 0 && cand && rot < (int32_t)Rr) x += 1;
+                        const uint64_t hit = cs::ballot(cand && rot == target);
+                        if (hit) new_last = E + s * 64 + cs::ffs64(hit);
+                        if (x > 0) st.commit(s, m, x, pv);
+                        if (m == M - 1) x_mine_last = x;
+                        basec += cs::popc64(b);
+                    });
+                    on_last = cs::bcast_u32(x_mine_last, (M - 1) & 63);
+                    last_index = new_last;
+                    st.note_change();
+                    for (int w = 0; w < Wz; ++w) szone[w * 64 + lane] |= zmark[w] & zvalid[w];
+                }
+            }
+
+            // ---- a3 / a4: tryToScheduleOnNewNodes (:190-269) or tryFastPath (:274-324) ----
+            int32_t rem = cnt - placed;
+            if (rem > 0 && more) {
+                zblocked = false;
+                for (int w = 0; w < Wz; ++w) zblocked |= (szone[w * 64 + lane] & zblock[w]) != 0;
+                bool blocked = !static_ok || zblocked;
+                // capacity of a FRESH node for this PEG
+                uint32_t cfresh = 0;
+                {
+                    bool xb = false;
+                    for (int w = 0; w < Wx; ++w) xb |= (fn.excl[w] & pv.xblock[w]) != 0;
+                    if (!xb) cfresh = capacity_lanes<L, RM>(fn.free, fn.slots, R, pv, (uint32_t)rem);
+                    if ((selfx || zselfx) && cfresh > 1) cfresh = 1;
+                }
+                // the lane that owns node m writes its fresh state + x pods: node first+i gets
+                // min(per, pods_total - i*per) pods
+                auto create_nodes = [&](int32_t first, int32_t nadd, uint32_t per, int32_t pods_total) {
+                    st.note_create(fn);
+                    const int s_lo = first >> 6, s_hi = (first + nadd - 1) >> 6;
+                    for_slots<Store>(s_hi + 1, [&](int s) {
+                        const int32_t m = s * 64 + lane;
+                        if (s >= s_lo && m >= first && m < first + nadd) {
+                            const int32_t i = m - first;
+                            const int64_t left = (int64_t)pods_total - (int64_t)i * per;
+                            const uint32_t x = left <= 0 ? 0u : (left < (int64_t)per ? (uint32_t)left : per);
+                            st.create(s, m, x, pv, fn);
+                        }
+                    });
+                };
+                auto permission_left = [&]() -> int64_t {  // nodes the limiter would still grant
+                    if (maxn < 0) return 0;
+                    if (maxn == 0) return 0x7fffffffll;
+                    return maxn > granted ? (int64_t)(maxn - granted) : 0;
+                };
+                bool marked = false;
+
+                if (fast_last && k == Gn - 1) {
+                    // tryFastPath: one simulated node, the rest by arithmetic
+                    if (permission_left() <= 0) more = false;
+                    else {
+                        granted++;
+                        const uint32_t per = blocked ? 0u : (cfresh < (uint32_t)rem ? cfresh : (uint32_t)rem);
+                        create_nodes(M, 1, per, (int32_t)per);
+                        M++;
+                        if (per > 0) {
+                            marked = true;
+                            placed += (int32_t)per;
+                            const int32_t size = (int32_t)(((int64_t)rem + per - 1) / per);  // scaleUpSize
+                            const int64_t left = permission_left();
+                            const int32_t want = size - 1;
+                            const int32_t nf = want < left ? want : (int32_t)left;
+                            const int64_t fp = (int64_t)nf * per;
+                            placed += (int32_t)(nf == want ? (int64_t)rem - per : fp);
+                            fakes += nf; granted += nf;
+                            if (nf < want) more = false;
+                        }
+                    }
+                } else {
+                    // next-fit on the newest node (:198-209)
+                    if (M > 0) {
+                        const int lm = M - 1, owner = lm & 63;
+                        uint32_t cl = 0;
+                        if (!blocked && !(selfx && on_last > 0) && lane == owner)
+                            with_slot<Store>(lm >> 6, [&](int s) { cl = st.capacity(s, lm, pv, (uint32_t)rem, selfx || zselfx); });
+                        cl = cs::bcast_u32(cl, owner);
+                        if (cl > 0) {
+                            if (lane == owner) with_slot<Store>(lm >> 6, [&](int s) { st.commit(s, lm, cl, pv); });
+                            placed += (int32_t)cl; rem -= (int32_t)cl; marked = true;
+                            st.note_change();
+                            if (zselfx) blocked = true;
+                        }
+                    }
+                    bool stop = rem == 0;
+                    if (!stop && M > 0) {
+                        // newest node still empty and the pod does not fit it: a new one would not help (:234-236)
+                        const int lm = M - 1, owner = lm & 63;
+                        uint32_t np_l = 0;
+                        if (lane == owner) with_slot<Store>(lm >> 6, [&](int s) { np_l = (uint32_t)st.npods(s, lm); });
+                        if (cs::bcast_u32(np_l, owner) == 0) stop = true;
+                    }
+                    while (!stop) {
+                        const uint32_t cn = blocked ? 0u : cfresh;
+                        if (cn == 0 || zselfx) {
+                            if (permission_left() <= 0) { more = false; break; }       // :244-246
+                            granted++;
+                            const uint32_t x = cn < (uint32_t)rem ? cn : (uint32_t)rem;  // 0 or 1
+                            create_nodes(M, 1, x, (int32_t)x);
+                            M++;
+                            if (x == 0) break;                                          // :257-263 node stays, PEG abandoned
+                            placed += (int32_t)x; rem -= (int32_t)x; marked = true;
+                            blocked = true;                                             // zselfx: the group now holds one
+                            if (rem == 0) break;
+                        } else {
+                            const int64_t need = ((int64_t)rem + cn - 1) / cn;
+                            const int64_t left = permission_left();
+                            const int32_t nadd = (int32_t)(need < left ? need : left);
+                            const int64_t fit = (int64_t)nadd * cn;
+                            const int32_t pl = (int32_t)(fit < rem ? fit : rem);
+                            if (nadd > 0) {
+                                create_nodes(M, nadd, cn, pl);
+                                M += nadd; granted += nadd; placed += pl; rem -= pl; marked = true;
+                            }
+                            if (need > left) more = false;
+                            break;
+                        }
+                    }
+                }
+                if (marked)
+                    for (int w = 0; w < Wz; ++w) szone[w * 64 + lane] |= zmark[w] & zvalid[w];
+            }
+
+            if (lane == j) my_placed = placed;
+            total_placed += placed;
+            sum0 += (int64_t)placed * (int64_t)pv.req[0];
+            sum1 += (int64_t)placed * (int64_t)pv.req[1];
+        }
+        if (have) res.placed[off + kk] = my_placed;  // one coalesced wave-store per 64 PEGs
+    }
+
+    // len(newNodesWithPods) (:160)
+    int32_t with_pods = 0;
+    for_slots<Store>((M + 63) >> 6, [&](int s) {
+        const int m = s * 64 + lane;
+        with_pods += cs::popc64(cs::ballot(m < M && st.npods(s, m) > 0));
+    });
+    if (lane == 0) {
+        res.node_count[ng] = with_pods + fakes;
+        res.pods[ng] = total_placed;
+        res.nodes_added[ng] = M;
+        res.limiter_nodes[ng] = granted;
+        res.last_index_out[ng] = last_index;
+        res.status[ng] = CASIM_NG_OK;
+        res.cpu_sum[ng] = sum0 * (sum_scale ? sum_scale[0] : 1);
+        res.mem_sum[ng] = sum1 * (sum_scale ? sum_scale[1] : 1);
+    }
+}
+
+// a group carrying a PEG outside the encoded predicate subset is delegated (status only)
+CS_DEVICE bool pack_unsupported(const DevTables& t, const DevResults& res) {
+    const int ng = cs::bid(), lane = cs::lane();
+    const int off = t.peg_off[ng], Gn = t.peg_off[ng + 1] - off;
+    bool bad = false;
+    for (int i = lane; i < Gn; i += 64) bad |= (res.s_flags[off + i] & CASIM_PEG_UNSUPPORTED) != 0;
+    if (!cs::ballot(bad)) return false;
+    for (int i = lane; i < Gn; i += 64) res.placed[off + i] = 0;
+    if (lane == 0) {
+        res.node_count[ng] = 0; res.pods[ng] = 0; res.nodes_added[ng] = 0; res.limiter_nodes[ng] = 0;
+        res.last_index_out[ng] = t.last_index[ng]; res.status[ng] = CASIM_NG_UNSUPPORTED;
+        res.cpu_sum[ng] = 0; res.mem_sum[ng] = 0;
+    }
+    return true;
+}
+
+// ---- generic kernel: int64 state in LDS (kLds) or an HBM slab ------------------------------------
+template <bool kLds>
+CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void pack_kernel(DevTables t, DevResults res, PackScratch ps) {
+    if (pack_unsupported(t, res)) return;
+    const int ng = cs::bid();
+    const int R = t.R, Wx = t.Wx, Wz = t.Wz;
+    MemStore<kLds> st;
+    st.R = R; st.Wx = Wx; st.cap = ps.node_cap[ng];
+    char* base = kLds ? cs::dyn_smem() : ps.gstate + ps.state_off[ng];
+    st.sfree = (int64_t*)base;
+    st.sexcl = (uint64_t*)(st.sfree + (int64_t)R * st.cap);
+    uint64_t* szone = st.sexcl + (int64_t)Wx * st.cap;
+    st.sslots = (int32_t*)(szone + 64 * (Wz > 0 ? Wz : 1));
+    st.snpods = st.sslots + st.cap;
+    st.sctmp = st.snpods + st.cap;
+    FreshNode<int64_t, CASIM_KMAX_RES> fn;
+    for (int r = 0; r < CASIM_KMAX_RES; ++r) fn.free[r] = r < R ? t.alloc[(int64_t)ng * R + r] - t.init_req[(int64_t)ng * R + r] : 0;
+    fn.slots = t.allowed[ng] - t.init_pods[ng];
+    fn.excl = t.init_excl + (int64_t)ng * Wx;
+    const int64_t* s_req = res.s_req;
+    pack_body(t, res, st, fn, szone, [=](int idx, int r) -> int64_t { return s_req[(int64_t)idx * R + r]; }, nullptr);
+}
+
+// ---- fast kernel: int32 gcd-scaled lanes, node state in VGPRs, no exclusion masks ----------------
+// Launched only when the host proved the batch eligible (casim_pipeline.h): Wx == Wz == 0, R <= R_,
+// every scaled value < 2^31 and every group's node bound <= 64 * NPT_.
+template <int R_, int NPT_>
+CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void pack_fast_kernel(DevTables t, DevResults res, FastScratch fs) {
+    if (pack_unsupported(t, res)) return;
+    const int ng = cs::bid();
+    RegStore<R_, NPT_> st;
+#pragma unroll
+    for (int s = 0; s < NPT_; ++s) {
+#pragma unroll
+        for (int r = 0; r < R_; ++r) st.fr[s][r] = 0;
+        st.slots[s] = 0; st.pods[s] = 0; st.c[s] = 0;
+    }
+    st.reset_bounds();
+    FreshNode<int32_t, R_> fn;
+#pragma unroll
+    for (int r = 0; r < R_; ++r) fn.free[r] = r < t.R ? fs.fresh32[(int64_t)ng * t.R + r] : 0;
+    fn.slots = t.allowed[ng] - t.init_pods[ng];
+    fn.excl = nullptr;
+    const int32_t* req32 = fs.req32;
+    const int32_t* order = res.order;
+    const int R = t.R;
+    pack_body(t, res, st, fn, (uint64_t*)nullptr,
+              [=](int idx, int r) -> int32_t { return req32[(int64_t)order[idx] * R + r]; }, fs.scale);
+}
+
+}  // namespace casim

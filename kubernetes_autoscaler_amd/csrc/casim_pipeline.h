@@ -116,7 +116,7 @@ public:
         for (size_t i = 0; i < NG; ++i) {
             int64_t n = g->max_nodes[i] > 0 ? (int64_t)g->max_nodes[i] : (g->max_nodes[i] < 0 ? 0 : pods_of_group[i]);
             if (g->max_nodes[i] > 0 && pods_of_group[i] < n) n = pods_of_group[i];  // never more nodes than pods (+ empty ones)
-            n = round_up64(n + 1);
+            n = round_up64(n > 0 ? n : 1);  // both terms bound the nodes ever added (limiter grants / one node per pod)
             if (n > 0x3fffffffll) return fail(CASIM_ERR_INVALID, "node bound too large");
             cap[i] = (int32_t)n;
             const int64_t bytes = casim_pack_state_bytes(R, dt_.Wx, dt_.Wz, n);
@@ -125,6 +125,42 @@ public:
         }
         pack_smem_ = (size_t)worst;
         pack_lds_ = worst <= (int64_t)bk_.lds_budget();
+        // ---- fast packer eligibility: no exclusion masks, <= 4 lanes, <= 1024 nodes per group and every
+        // lane value representable as int32 after dividing the lane by the gcd of all its values ----
+        fast_npt_ = 0;
+        {
+            int32_t maxcap = 0;
+            for (size_t i = 0; i < NG; ++i) maxcap = cap[i] > maxcap ? cap[i] : maxcap;
+            bool ok = o ? o->force_generic_packer == 0 : true;
+            ok = ok && dt_.Wx == 0 && dt_.Wz == 0 && R <= 4 && maxcap <= 64 * 16 && NG > 0;
+            std::vector<int64_t> scale((size_t)R, 0);
+            auto gcd64 = [](int64_t a, int64_t b) { if (a < 0) a = -a; if (b < 0) b = -b; while (b) { const int64_t x = a % b; a = b; b = x; } return a; };
+            if (ok) {
+                for (size_t i = 0; i < G; ++i) for (int r = 0; r < R; ++r) scale[(size_t)r] = gcd64(scale[(size_t)r], p->req[i * R + r]);
+                for (size_t i = 0; i < NG; ++i) for (int r = 0; r < R; ++r) {
+                    scale[(size_t)r] = gcd64(scale[(size_t)r], g->alloc[i * R + r]);
+                    scale[(size_t)r] = gcd64(scale[(size_t)r], g->init_req[i * R + r]);
+                }
+                for (int r = 0; r < R; ++r) if (scale[(size_t)r] == 0) scale[(size_t)r] = 1;
+                const int64_t lim = 0x7fffffffll;
+                auto fits32 = [&](int64_t v, int r) { const int64_t s = v / scale[(size_t)r]; return s <= lim && s >= -lim; };
+                for (size_t i = 0; i < G && ok; ++i) for (int r = 0; r < R; ++r) ok = ok && p->req[i * R + r] >= 0 && fits32(p->req[i * R + r], r);
+                for (size_t i = 0; i < NG && ok; ++i) for (int r = 0; r < R; ++r)
+                    ok = ok && fits32(g->alloc[i * R + r], r) && fits32(g->init_req[i * R + r], r) && fits32(g->alloc[i * R + r] - g->init_req[i * R + r], r);
+            }
+            if (ok) {
+                std::vector<int32_t> req32(G * (size_t)R), fresh32(NG * (size_t)R);
+                for (size_t i = 0; i < G; ++i) for (int r = 0; r < R; ++r) req32[i * R + r] = (int32_t)(p->req[i * R + r] / scale[(size_t)r]);
+                for (size_t i = 0; i < NG; ++i) for (int r = 0; r < R; ++r)
+                    fresh32[i * R + r] = (int32_t)((g->alloc[i * R + r] - g->init_req[i * R + r]) / scale[(size_t)r]);
+                fs_.req32 = up(req32.data(), req32.size());
+                fs_.fresh32 = up(fresh32.data(), fresh32.size());
+                fs_.scale = up(scale.data(), scale.size());
+                bk_.sync();  // the staging vectors die at the end of this scope
+                fast_npt_ = maxcap <= 64 ? 1 : (maxcap <= 256 ? 4 : 16);
+                fast_r_ = R <= 2 ? 2 : 4;
+            }
+        }
         ps_.node_cap = up(cap.data(), NG);
         if (!pack_lds_) {
             ps_.state_off = up(soff.data(), NG);
@@ -152,9 +188,12 @@ public:
         dr_.cpu_sum = (int64_t*)dalloc(8 * NG); dr_.mem_sum = (int64_t*)dalloc(8 * NG);
         dr_.order = (int32_t*)dalloc(4 * (size_t)nnz_cap_); dr_.placed = (int32_t*)dalloc(4 * (size_t)nnz_cap_);
         dr_.fast_last = (uint8_t*)dalloc(NG);
+        dr_.s_count = (int32_t*)dalloc(4 * (size_t)nnz_cap_); dr_.s_flags = (uint32_t*)dalloc(4 * (size_t)nnz_cap_);
+        dr_.s_req = (int64_t*)dalloc(8 * (size_t)nnz_cap_ * (size_t)R);
         d_opt_set_ = (uint8_t*)dalloc(NG);
         d_opt_out_ = (int32_t*)dalloc(16);
         d_opt_key_ = (int64_t*)dalloc(80);
+        bk_.sync();  // every staging buffer (caller tables, local vectors) may be released after init()
         if (!bk_.ok()) return fail(CASIM_ERR_HIP, bk_.error());
         ready_ = true;
         return CASIM_OK;
@@ -177,6 +216,19 @@ public:
     }
     int32_t run_pack() {
         if (NG_ == 0) return CASIM_OK;
+        if (fast_npt_ > 0) {
+            // register-resident int32 packer (no LDS): pick the instantiation by lanes and node bound
+            if (fast_r_ == 2) {
+                if (fast_npt_ == 1) bk_.launch(pack_fast_kernel<2, 1>, NG_, 1, 64, (size_t)0, dt_, dr_, fs_);
+                else if (fast_npt_ == 4) bk_.launch(pack_fast_kernel<2, 4>, NG_, 1, 64, (size_t)0, dt_, dr_, fs_);
+                else bk_.launch(pack_fast_kernel<2, 16>, NG_, 1, 64, (size_t)0, dt_, dr_, fs_);
+            } else {
+                if (fast_npt_ == 1) bk_.launch(pack_fast_kernel<4, 1>, NG_, 1, 64, (size_t)0, dt_, dr_, fs_);
+                else if (fast_npt_ == 4) bk_.launch(pack_fast_kernel<4, 4>, NG_, 1, 64, (size_t)0, dt_, dr_, fs_);
+                else bk_.launch(pack_fast_kernel<4, 16>, NG_, 1, 64, (size_t)0, dt_, dr_, fs_);
+            }
+            return CASIM_OK;
+        }
         if (pack_lds_) bk_.launch(pack_kernel<true>, NG_, 1, 64, pack_smem_, dt_, dr_, ps_);
         else bk_.launch(pack_kernel<false>, NG_, 1, 64, (size_t)0, dt_, dr_, ps_);
         return CASIM_OK;
@@ -265,6 +317,7 @@ public:
     int pegs() const { return G_; }
     bool csr_on_device() const { return csr_on_device_; }
     bool pack_in_lds() const { return pack_lds_; }
+    int fast_npt() const { return fast_npt_; }   // > 0: the register-resident packer handles this batch
     static constexpr int kOrderThreads = 256;
 
 private:
@@ -288,8 +341,8 @@ private:
     int32_t fail(int32_t code, const char* msg) { err_ = msg ? msg : ""; return code; }
 
     BK& bk_;
-    DevTables dt_; DevResults dr_; PackScratch ps_; OrderScratch os_;
-    int G_ = 0, NG_ = 0, Wg_ = 0;
+    DevTables dt_; DevResults dr_; PackScratch ps_; OrderScratch os_; FastScratch fs_ = {nullptr, nullptr, nullptr};
+    int G_ = 0, NG_ = 0, Wg_ = 0, fast_npt_ = 0, fast_r_ = 0;
     int32_t nnz_cap_ = 0;
     bool csr_on_device_ = false, pack_lds_ = true, order_lds_ = true, ready_ = false, ran_ = false;
     size_t pack_smem_ = 0, order_smem_ = 0;

@@ -55,7 +55,14 @@ struct DevResults {
     int32_t* order;      // [nnz]
     int32_t* placed;     // [nnz]
     uint8_t* fast_last;  // [NG] 1 => fastpath applies to the last PEG of the sorted list
+    // PEG records in processing order, written by order_kernel, streamed by pack_kernel
+    int32_t* s_count;    // [nnz]
+    uint32_t* s_flags;   // [nnz] CASIM_PEG_* | CASIM_KFLAG_STATIC_OK
+    int64_t* s_req;      // [nnz][R]
 };
+
+// kernel-internal flag bit (not part of the ABI): the template-level Filters pass for (PEG, group)
+#define CASIM_KFLAG_STATIC_OK 0x80000000u
 
 // Per-group scratch geometry of the packer: simulated-node state lives in LDS when every
 // group of the launch fits, else in an HBM scratch slab.
@@ -63,6 +70,14 @@ struct PackScratch {
     const int32_t* node_cap;   // [NG] node slots reserved for the group (multiple of 64)
     const int64_t* state_off;  // [NG] byte offset into gstate (global variant)
     char* gstate;              // HBM slab (global variant) or null
+};
+
+// Inputs of the register-resident fast packer: every resource lane divided by the gcd of all its
+// values (requests, allocatable, preloaded requests) — exact, and small enough for int32.
+struct FastScratch {
+    const int32_t* req32;    // [G][R]  req / scale
+    const int32_t* fresh32;  // [NG][R] (alloc - init_req) / scale
+    const int64_t* scale;    // [R]     gcd per lane (>= 1)
 };
 
 struct OrderScratch {

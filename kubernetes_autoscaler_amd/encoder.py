@@ -107,6 +107,22 @@ class Encoder:
         self.n_pegs += 1
         return g
 
+    def add_resource_pegs(self, requests, counts, namespace: str = "default"):
+        """Bulk form (casim_enc_add_resource_pegs): `requests` is an [n][R] integer array of lanes,
+        `counts` an [n] array.  Returns the PEG ids (a contiguous range)."""
+        import numpy as np
+        req = np.ascontiguousarray(requests, dtype=np.int64)
+        cnt = np.ascontiguousarray(counts, dtype=np.int32)
+        if req.ndim != 2 or req.shape[1] != len(self.lanes) or cnt.shape[0] != req.shape[0]:
+            raise ValueError("requests must be [n][len(lanes)] and counts [n]")
+        n = int(req.shape[0])
+        first = lib.casim_enc_add_resource_pegs(self._h, _b(namespace), n, req.ctypes.data_as(_abi.i64p),
+                                                cnt.ctypes.data_as(_abi.i32p), None)
+        if first < 0:
+            check(first, "casim_enc_add_resource_pegs")
+        self.n_pegs += n
+        return range(first, first + n)
+
     # ---- node groups -----------------------------------------------------------------------
     def add_group(self, template: NodeInfo, max_nodes: int = 0, existing_nodes: int = 0, last_index: int = 0,
                   pegs: Optional[Sequence[int]] = None) -> int:

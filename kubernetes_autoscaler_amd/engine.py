@@ -101,11 +101,11 @@ class Context:
 class Problem:
     """casim_problem: a batch resident in HBM; run() enqueues feasibility -> order -> pack."""
 
-    def __init__(self, ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, fastpath: bool = False):
+    def __init__(self, ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, fastpath: bool = False, force_generic_packer: bool = False):
         self.ctx = ctx
         self.n_groups = groups.n_groups
         self.n_pegs = pegs.n_pegs
-        opts = _abi.Options(fastpath=int(fastpath))
+        opts = _abi.Options(fastpath=int(fastpath), force_generic_packer=int(force_generic_packer))
         self._h = lib.casim_problem_create(ctx._h, C.byref(pegs), C.byref(groups), C.byref(opts))
         if not self._h:
             raise CasimError(_abi.ERR_INVALID, last_error())

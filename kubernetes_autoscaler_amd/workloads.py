@@ -114,12 +114,20 @@ def _draw_c1(rng):
     return 50 * (1 + rng.below(80)), 64 * MiB * (1 + rng.below(256))
 
 
+C1_ALLOC = (32000, 128 * GiB)
+
+
+def c1_pairs(seed_offset: int = 0, n_pegs: int = 200):
+    """The (cpu milli, memory bytes) request pairs of one C1 simulation (same stream as config_c1)."""
+    rng = SplitMix64(SEED_BASE + 1 + (seed_offset << 8))
+    return _distinct_scores(rng, n_pegs, [C1_ALLOC], _draw_c1)
+
+
 def config_c1(seed_offset: int = 0, n_pegs: int = 200, pods_per_peg: int = 50, cap: int = 256) -> Workload:
     """10k pods x 256 candidate nodes, CPU+mem only: 1 group, 32 cores / 128 GiB / 110 pods."""
-    rng = SplitMix64(SEED_BASE + 1 + (seed_offset << 8))
-    acpu, amem = 32000, 128 * GiB
+    acpu, amem = C1_ALLOC
     tmpl = NodeInfo(_node("c1-template", acpu, amem, 110))
-    pairs = _distinct_scores(rng, n_pegs, [(acpu, amem)], _draw_c1)
+    pairs = c1_pairs(seed_offset, n_pegs)
     pegs = [_peg(f"c1-peg{i}", c, m, pods_per_peg) for i, (c, m) in enumerate(pairs)]
     return Workload("C1", pegs, [GroupPlan(tmpl, max_nodes=cap)])
 

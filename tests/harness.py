@@ -91,7 +91,7 @@ def emu_lib():
     return _emu
 
 
-def run_emu(enc: Encoder, fastpath=False, lds_budget=0, kinds=None, group_id_base=0):
+def run_emu(enc: Encoder, fastpath=False, lds_budget=0, kinds=None, group_id_base=0, generic=False):
     """Product kernels under the wave emulator.  Returns (BatchResult, best) where best is
     None or (best_index, n_best, best_set, key)."""
     L = emu_lib()
@@ -99,7 +99,7 @@ def run_emu(enc: Encoder, fastpath=False, lds_budget=0, kinds=None, group_id_bas
     ng, G = groups.n_groups, pegs.n_pegs
     nnz_cap = G * ng if not groups.peg_offsets else groups.peg_offsets[ng]
     st, arrs = alloc_results(ng, nnz_cap)
-    opts = _abi.Options(fastpath=int(fastpath))
+    opts = _abi.Options(fastpath=int(fastpath), force_generic_packer=int(generic))
     nnz = C.c_int32(0)
     off = np.zeros(ng + 1, np.int32)
     best = (C.c_int32 * 2)(-1, 0)
@@ -123,9 +123,9 @@ def run_emu_feasibility(enc: Encoder) -> np.ndarray:
     return bits[:enc.groups.n_groups, :wg]
 
 
-def run_gpu(enc: Encoder, ctx, fastpath=False, kinds=None, group_id_base=0):
+def run_gpu(enc: Encoder, ctx, fastpath=False, kinds=None, group_id_base=0, generic=False):
     from kubernetes_autoscaler_amd.engine import Problem
-    with Problem(ctx, enc.pegs, enc.groups, fastpath) as p:
+    with Problem(ctx, enc.pegs, enc.groups, fastpath, generic) as p:
         p.run()
         res = p.fetch()
         best = p.best_option(kinds, group_id_base) if kinds is not None else None

@@ -80,3 +80,27 @@ def test_builders_match_the_reference_helpers():
     assert objects.build_test_node("n", 1000, 2000000).allocatable["pods"] == 100
     assert len(objects.make_pod_equivalence_group(p, 7).pods) == 7
     assert p.fastpath_requests() == (350 * 1e-3, 1000.0)
+
+
+def test_bulk_resource_pegs_equal_object_path():
+    """casim_enc_add_resource_pegs (one ABI crossing) must build the same tables as pod objects."""
+    import numpy as np
+    from kubernetes_autoscaler_amd import Encoder, workloads
+    w = workloads.config_c1(seed_offset=3, n_pegs=40, pods_per_peg=7, cap=32)
+    a = Encoder()
+    ids = [a.add_peg(pg) for pg in w.pegs]
+    a.add_group(w.groups[0].template, max_nodes=32, pegs=ids)
+    a.finalize()
+    b = Encoder()
+    ids_b = b.add_resource_pegs(np.array(workloads.c1_pairs(3, 40), dtype=np.int64), np.full(40, 7, np.int32))
+    b.add_group(w.groups[0].template, max_nodes=32, pegs=list(ids_b))
+    b.finalize()
+    assert list(ids_b) == ids
+    for f in ("n_pegs", "n_res", "w_taint", "w_label", "w_excl", "w_zone"):
+        assert getattr(a.pegs, f) == getattr(b.pegs, f)
+    n = a.pegs.n_pegs
+    assert [a.pegs.req[i] for i in range(2 * n)] == [b.pegs.req[i] for i in range(2 * n)]
+    assert [a.pegs.count[i] for i in range(n)] == [b.pegs.count[i] for i in range(n)]
+    assert [a.pegs.flags[i] for i in range(n)] == [b.pegs.flags[i] for i in range(n)]
+    assert [a.pegs.fp_cpu[i] for i in range(n)] == [b.pegs.fp_cpu[i] for i in range(n)]
+    assert [a.pegs.fp_mem[i] for i in range(n)] == [b.pegs.fp_mem[i] for i in range(n)]
