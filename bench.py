@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=2048, help="independent C1 simulations per GPU per step")
+    ap.add_argument("--batch", type=int, default=16384, help="independent C1 simulations per GPU per step")
     ap.add_argument("--pegs", type=int, default=200)
     ap.add_argument("--pods-per-peg", type=int, default=50)
     ap.add_argument("--cap", type=int, default=256)

@@ -8,7 +8,7 @@ import os
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcasim.so")
+LIB_PATH = os.environ.get("CASIM_LIB_PATH") or os.path.join(_HERE, "libcasim.so")   # override: profiling builds only
 
 
 class CasimError(RuntimeError):

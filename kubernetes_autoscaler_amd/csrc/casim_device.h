@@ -39,6 +39,7 @@ CS_DEVICE int popc64(uint64_t v) { return __builtin_popcountll(v); }
 CS_DEVICE int ffs64(uint64_t v) { return v ? __builtin_ctzll(v) : -1; }
 CS_DEVICE int fls64(uint64_t v) { return v ? 63 - __builtin_clzll(v) : -1; }
 CS_DEVICE uint64_t double_bits(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
+CS_DEVICE double bits_double(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
 }  // namespace cs
 
 #else
@@ -110,6 +111,7 @@ CS_DEVICE int popc64(uint64_t v) { return __popcll(v); }
 CS_DEVICE int ffs64(uint64_t v) { return v ? (int)__builtin_ctzll(v) : -1; }
 CS_DEVICE int fls64(uint64_t v) { return v ? 63 - (int)__builtin_clzll(v) : -1; }
 CS_DEVICE uint64_t double_bits(double d) { return (uint64_t)__double_as_longlong(d); }
+CS_DEVICE double bits_double(uint64_t u) { return __longlong_as_double((long long)u); }
 }  // namespace cs
 #endif
 

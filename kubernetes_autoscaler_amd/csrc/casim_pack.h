@@ -28,6 +28,17 @@
 #include "casim_device.h"
 #include "casim_types.h"
 
+// Optional phase timing (s_memtime ticks per phase, per group) for tools/prof_pack.sh builds only.
+#if defined(CASIM_PACK_PROF) && !defined(CASIM_HOST_EMU)
+#define CASIM_PROF_DECL uint64_t prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t prof_last = __builtin_amdgcn_s_memtime()
+#define CASIM_PROF(i) do { const uint64_t _n = __builtin_amdgcn_s_memtime(); prof_acc[i] += _n - prof_last; prof_last = _n; } while (0)
+#define CASIM_PROF_STORE(p) do { if ((p) && cs::lane() == 0) for (int _i = 0; _i < 8; ++_i) (p)[(int64_t)cs::bid() * 8 + _i] = (int64_t)prof_acc[_i]; } while (0)
+#else
+#define CASIM_PROF_DECL
+#define CASIM_PROF(i)
+#define CASIM_PROF_STORE(p) (void)(p)
+#endif
+
 namespace casim {
 
 template <class L, int RMAX>
@@ -50,6 +61,25 @@ struct FreshNode {
 // capacity_of in casim_kernels.h for the error bound); int64 lanes above 2^53 fall back to a division.
 template <class L, int RMAX>
 CS_DEVICE uint32_t capacity_lanes(const L* fr, int32_t slots, int R, const PegView<L, RMAX>& pv, uint32_t clampk) {
+    if constexpr (sizeof(L) == 4) {
+        // int32 lanes: straight-line code (selects, no lane-divergent branch) so that the slots of one
+        // sweep interleave; the only branches are on the wave-uniform request.
+        uint32_t c = slots > 0 ? ((uint32_t)slots < clampk ? (uint32_t)slots : clampk) : 0u;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const L q = pv.req[r];
+            if (r < R && q > 0) {  // wave-uniform
+                const L f = fr[r];
+                const bool fits = f >= q;
+                const uint32_t fpos = fits ? (uint32_t)f : 0u;
+                uint32_t e = (uint32_t)((double)fpos * pv.rq[r]);  // f < 2^31, e <= f: exact up to +-1
+                const int64_t rem = (int64_t)fpos - (int64_t)((uint64_t)e * (uint64_t)(uint32_t)q);
+                e = rem < 0 ? e - 1 : (rem >= (int64_t)q ? e + 1 : e);
+                c = e < c ? e : c;   // fits == false gives e == 0
+            }
+        }
+        return c;
+    }
     if (slots <= 0) return 0;
     uint32_t c = (uint32_t)slots < clampk ? (uint32_t)slots : clampk;
 #pragma unroll
@@ -145,6 +175,51 @@ struct RegStore {
         uint32_t k = capacity_lanes<Lane, R_>(fr[s], slots[s], R_, pv, clampk);
         if (selfx && k > 1) k = 1;
         return k;
+    }
+    // Pass A for ALL slots at once: resource lane outermost (its branch is wave-uniform), slots innermost,
+    // so the NPT_ independent quotient chains (cvt -> f64 mul -> cvt -> fix-up) interleave instead of
+    // running back to back.  Slots beyond M hold zeros (slots == 0), hence c == 0 without a mask.
+    CS_DEVICE void capacity_all(const Peg& pv, uint32_t clampk, bool selfx) {
+#pragma unroll
+        for (int s = 0; s < NPT_; ++s) c[s] = slots[s] > 0 ? ((uint32_t)slots[s] < clampk ? (uint32_t)slots[s] : clampk) : 0u;
+#pragma unroll
+        for (int r = 0; r < R_; ++r) {
+            const int32_t q = pv.req[r];
+            if (q > 0) {  // wave-uniform
+                const double rq = pv.rq[r];
+                // stage-wise over the slots (explicit software interleave of the independent chains)
+                uint32_t fpos[NPT_], e[NPT_];
+                double d[NPT_];
+#pragma unroll
+                for (int s = 0; s < NPT_; ++s) fpos[s] = fr[s][r] >= q ? (uint32_t)fr[s][r] : 0u;
+#pragma unroll
+                for (int s = 0; s < NPT_; ++s) d[s] = (double)fpos[s];
+#pragma unroll
+                for (int s = 0; s < NPT_; ++s) d[s] *= rq;
+#pragma unroll
+                for (int s = 0; s < NPT_; ++s) e[s] = (uint32_t)d[s];
+                if (q < (1 << 30)) {
+                    // remainder in wrapping 32-bit arithmetic: the true value lies in (-q, 2q), |.| < 2^31
+                    int32_t rem[NPT_];
+#pragma unroll
+                    for (int s = 0; s < NPT_; ++s) rem[s] = (int32_t)(fpos[s] - e[s] * (uint32_t)q);
+#pragma unroll
+                    for (int s = 0; s < NPT_; ++s) e[s] = rem[s] < 0 ? e[s] - 1 : (rem[s] >= q ? e[s] + 1 : e[s]);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < NPT_; ++s) {
+                        const int64_t rem = (int64_t)fpos[s] - (int64_t)((uint64_t)e[s] * (uint64_t)(uint32_t)q);
+                        e[s] = rem < 0 ? e[s] - 1 : (rem >= (int64_t)q ? e[s] + 1 : e[s]);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < NPT_; ++s) c[s] = e[s] < c[s] ? e[s] : c[s];
+            }
+        }
+        if (selfx) {
+#pragma unroll
+            for (int s = 0; s < NPT_; ++s) c[s] = c[s] > 1 ? 1u : c[s];
+        }
     }
     CS_DEVICE void commit(int s, int, uint32_t x, const Peg& pv) {
 #pragma unroll
@@ -243,7 +318,8 @@ struct PegChunk {
 //   ReqLoader(kk, r) -> request lane r of sorted record kk (int64 original or int32 gcd-scaled)
 template <class Store, class ReqLoader>
 CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, const typename Store::Fresh& fn,
-                         uint64_t* szone /*[Wz][64] per-lane copies or null*/, ReqLoader load_req, const int64_t* sum_scale) {
+                         uint64_t* szone /*[Wz][64] per-lane copies or null*/, ReqLoader load_req, const int64_t* sum_scale,
+                         int64_t* prof_out = nullptr) {
     using L = typename Store::Lane;
     constexpr int RM = Store::kRMax;
     const int ng = cs::bid();
@@ -269,7 +345,9 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     int32_t total_placed = 0;
     int64_t sum0 = 0, sum1 = 0;            // sum of placed * req lane 0 / 1 (in store units)
 
+    CASIM_PROF_DECL;
     for (int k0 = 0; k0 < Gn; k0 += 64) {
+        CASIM_PROF(0);  // chunk load / store, loop overhead
         // ---- one coalesced wave-load: PEG record k0+lane of this group, in processing order ----
         const int kk = k0 + lane;
         const bool have = kk < Gn;
@@ -279,6 +357,11 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
         L my_req[RM];
 #pragma unroll
         for (int r = 0; r < RM; ++r) my_req[r] = (have && r < R) ? load_req(off + kk, r) : (L)0;
+        // 1 / req for capacity_lanes' quotient estimate: computed by the record's own lane, i.e. 64 PEGs'
+        // worth of f64 divisions per wave instruction instead of one uniform division per PEG
+        double my_rq[RM];
+#pragma unroll
+        for (int r = 0; r < RM; ++r) my_rq[r] = my_req[r] > 0 ? 1.0 / (double)my_req[r] : 0.0;
         int32_t my_placed = 0;
         const int nk = Gn - k0 < 64 ? Gn - k0 : 64;
 
@@ -293,7 +376,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     if constexpr (sizeof(L) == 4) pv.req[r] = (L)cs::bcast_u32((uint32_t)my_req[r], j);
                     else pv.req[r] = (L)cs::bcast_u64((uint64_t)my_req[r], j);
                 } else pv.req[r] = 0;
-                pv.rq[r] = pv.req[r] > 0 ? 1.0 / (double)pv.req[r] : 0.0;
+                pv.rq[r] = cs::bits_double(cs::bcast_u64(cs::double_bits(my_rq[r]), j));
             }
             const bool selfx = (pf & CASIM_PEG_SELF_EXCL_NODE) != 0;
             bool zselfx = (pf & CASIM_PEG_SELF_EXCL_ZONE) != 0;
@@ -311,6 +394,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 zselfx |= (zblock[w] & zmark[w] & zvalid[w]) != 0;  // the PEG excludes itself group-wide
             }
 
+            CASIM_PROF(1);  // record broadcast + reciprocals
             int32_t placed = 0;
             uint32_t on_last = 0;  // pods of THIS PEG that a2 put on the newest node (self-exclusion has no node bit)
 
@@ -331,17 +415,28 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 uint32_t lane_max = 0;
                 int32_t n1 = 0;
                 if (st.may_fit(pv)) {  // summary pruning: no node can take this PEG (stale-but-safe bounds)
-                    for_slots<Store>(S, [&](int s) {
-                        const int m = s * 64 + lane;
-                        uint32_t cj = 0;
-                        if (m < M) cj = st.capacity(s, m, pv, keff, selfx);
-                        st.set_c(s, m, cj);
-                        lane_sum += cj;
-                        lane_max = cj > lane_max ? cj : lane_max;
-                        n1 += cs::popc64(cs::ballot(cj > 0));
-                    });
+                    if constexpr (Store::kNPT > 0) {
+                        st.capacity_all(pv, keff, selfx);  // every slot, interleaved (nodes >= M are all-zero)
+                        for_slots<Store>(S, [&](int s) {
+                            const uint32_t cj = st.get_c(s, s * 64 + lane);
+                            lane_sum += cj;
+                            lane_max = cj > lane_max ? cj : lane_max;
+                            n1 += cs::popc64(cs::ballot(cj > 0));
+                        });
+                    } else {
+                        for_slots<Store>(S, [&](int s) {
+                            const int m = s * 64 + lane;
+                            uint32_t cj = 0;
+                            if (m < M) cj = st.capacity(s, m, pv, keff, selfx);
+                            st.set_c(s, m, cj);
+                            lane_sum += cj;
+                            lane_max = cj > lane_max ? cj : lane_max;
+                            n1 += cs::popc64(cs::ballot(cj > 0));
+                        });
+                    }
                     if (n1 == 0) st.tighten(M, lane);  // the bounds were too loose: make them exact again
                 }
+                CASIM_PROF(2);  // a2 pass A (capacities)
                 if (n1 > 0) {
                     uint32_t T, Rr;
                     if ((uint32_t)n1 > keff) {
@@ -366,6 +461,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                             T = lo; Rr = keff - (uint32_t)slo; placed = (int32_t)keff;
                         }
                     }
+                    CASIM_PROF(3);  // a2 reductions + bisection
                     const uint32_t Tf = Rr > 0 ? T + 1 : T;  // last round: candidates have c >= Tf
                     // rotated order starts at list position (lastIndex + 1) % n; positions < E are the
                     // pre-existing cluster nodes (never acceptable)
@@ -403,6 +499,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 }
             }
 
+            CASIM_PROF(4);  // a2 passes B + C (rotated rank, commit)
             // ---- a3 / a4: tryToScheduleOnNewNodes (:190-269) or tryFastPath (:274-324) ----
             int32_t rem = cnt - placed;
             if (rem > 0 && more) {
@@ -450,7 +547,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         if (per > 0) {
                             marked = true;
                             placed += (int32_t)per;
-                            const int32_t size = (int32_t)(((int64_t)rem + per - 1) / per);  // scaleUpSize
+                            const int32_t size = (int32_t)(((uint32_t)rem + per - 1u) / per);  // scaleUpSize
                             const int64_t left = permission_left();
                             const int32_t want = size - 1;
                             const int32_t nf = want < left ? want : (int32_t)left;
@@ -496,7 +593,9 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                             blocked = true;                                             // zselfx: the group now holds one
                             if (rem == 0) break;
                         } else {
-                            const int64_t need = ((int64_t)rem + cn - 1) / cn;
+                            // rem <= 2^31 - 1 and cn <= rem: 32-bit unsigned arithmetic is exact (an emulated
+                            // 64-bit division here cost more than the whole node creation)
+                            const int64_t need = (int64_t)(((uint32_t)rem + cn - 1u) / cn);
                             const int64_t left = permission_left();
                             const int32_t nadd = (int32_t)(need < left ? need : left);
                             const int64_t fit = (int64_t)nadd * cn;
@@ -514,6 +613,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     for (int w = 0; w < Wz; ++w) szone[w * 64 + lane] |= zmark[w] & zvalid[w];
             }
 
+            CASIM_PROF(5);  // a3 / a4
             if (lane == j) my_placed = placed;
             total_placed += placed;
             sum0 += (int64_t)placed * (int64_t)pv.req[0];
@@ -522,6 +622,8 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
         if (have) res.placed[off + kk] = my_placed;  // one coalesced wave-store per 64 PEGs
     }
 
+    CASIM_PROF(0);
+    CASIM_PROF_STORE(prof_out);
     // len(newNodesWithPods) (:160)
     int32_t with_pods = 0;
     for_slots<Store>((M + 63) >> 6, [&](int s) {
@@ -583,6 +685,8 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void pack_kernel(DevTables t, DevResults res, 
 // Launched only when the host proved the batch eligible (casim_pipeline.h): Wx == Wz == 0, R <= R_,
 // every scaled value < 2^31 and every group's node bound <= 64 * NPT_.
 template <int R_, int NPT_>
+// launch bounds (64, 1): let the register allocator take what it needs — forcing 5 waves/SIMD (<= 96
+// VGPRs) spilled ~200 B/lane to scratch and halved the throughput on MI355X (r01 measurement)
 CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void pack_fast_kernel(DevTables t, DevResults res, FastScratch fs) {
     if (pack_unsupported(t, res)) return;
     const int ng = cs::bid();
@@ -603,7 +707,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void pack_fast_kernel(DevTables t, DevResults 
     const int32_t* order = res.order;
     const int R = t.R;
     pack_body(t, res, st, fn, (uint64_t*)nullptr,
-              [=](int idx, int r) -> int32_t { return req32[(int64_t)order[idx] * R + r]; }, fs.scale);
+              [=](int idx, int r) -> int32_t { return req32[(int64_t)order[idx] * R + r]; }, fs.scale, fs.prof);
 }
 
 }  // namespace casim

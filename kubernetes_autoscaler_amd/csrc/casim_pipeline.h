@@ -17,6 +17,8 @@
 // provides a host backend that runs the same kernels under the wave emulator.
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -157,6 +159,7 @@ public:
                 fs_.fresh32 = up(fresh32.data(), fresh32.size());
                 fs_.scale = up(scale.data(), scale.size());
                 bk_.sync();  // the staging vectors die at the end of this scope
+                if (getenv("CASIM_PACK_PROF_DUMP")) { fs_.prof = (int64_t*)dalloc(8 * 8 * NG); bk_.zero(fs_.prof, 8 * 8 * NG); }
                 fast_npt_ = maxcap <= 64 ? 1 : (maxcap <= 256 ? 4 : 16);
                 fast_r_ = R <= 2 ? 2 : 4;
             }
@@ -226,6 +229,13 @@ public:
                 if (fast_npt_ == 1) bk_.launch(pack_fast_kernel<4, 1>, NG_, 1, 64, (size_t)0, dt_, dr_, fs_);
                 else if (fast_npt_ == 4) bk_.launch(pack_fast_kernel<4, 4>, NG_, 1, 64, (size_t)0, dt_, dr_, fs_);
                 else bk_.launch(pack_fast_kernel<4, 16>, NG_, 1, 64, (size_t)0, dt_, dr_, fs_);
+            }
+            if (fs_.prof) {  // profiling builds: mean ticks per phase over the groups
+                std::vector<int64_t> h((size_t)NG_ * 8);
+                bk_.d2h(h.data(), fs_.prof, h.size() * 8); bk_.sync();
+                double m[8] = {0};
+                for (int i = 0; i < NG_; ++i) for (int j = 0; j < 8; ++j) m[j] += (double)h[(size_t)i * 8 + j] / NG_;
+                fprintf(stderr, "[pack prof] ticks/group: loop %.0f bcast %.0f passA %.0f reduce %.0f passBC %.0f a3 %.0f\n", m[0], m[1], m[2], m[3], m[4], m[5]);
             }
             return CASIM_OK;
         }
@@ -341,7 +351,7 @@ private:
     int32_t fail(int32_t code, const char* msg) { err_ = msg ? msg : ""; return code; }
 
     BK& bk_;
-    DevTables dt_; DevResults dr_; PackScratch ps_; OrderScratch os_; FastScratch fs_ = {nullptr, nullptr, nullptr};
+    DevTables dt_; DevResults dr_; PackScratch ps_; OrderScratch os_; FastScratch fs_ = {nullptr, nullptr, nullptr, nullptr};
     int G_ = 0, NG_ = 0, Wg_ = 0, fast_npt_ = 0, fast_r_ = 0;
     int32_t nnz_cap_ = 0;
     bool csr_on_device_ = false, pack_lds_ = true, order_lds_ = true, ready_ = false, ran_ = false;

@@ -78,6 +78,7 @@ struct FastScratch {
     const int32_t* req32;    // [G][R]  req / scale
     const int32_t* fresh32;  // [NG][R] (alloc - init_req) / scale
     const int64_t* scale;    // [R]     gcd per lane (>= 1)
+    int64_t* prof;           // [NG][8] phase ticks (CASIM_PACK_PROF builds) or null
 };
 
 struct OrderScratch {
