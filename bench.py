@@ -48,15 +48,17 @@ def build_batch(workloads, Encoder, B, seed_base, n_pegs, pods_per_peg, cap):
     return enc, checks, pegs_total
 
 
-def algorithmic_bytes_pack(pegs, groups, nnz):
-    """sum_NG (G_NG * Bp) + NG * Bn + sum_NG (8 + 8 * G_NG).
-    Bp = PEG record the packer reads (req lanes, count, flags, masks, order entry),
-    Bn = node-group record, results = counters + order/placed per PEG."""
+def algorithmic_bytes_pack(pegs, groups, nnz, fast):
+    """sum_NG (G_NG * Bp) + NG * Bn + sum_NG (8 + 8 * G_NG), with the record sizes of the
+    packer that actually runs.  Bp = PEG record read per (group, PEG): request lanes + count + flags +
+    order entry (+ masks); Bn = node-group record; written: placed per PEG + 40 B of counters per group.
+    The register-resident packer reads gcd-scaled int32 lanes (4 B each), the generic one int64."""
     R = pegs.n_res
+    lane_bytes = 4 if fast else 8
     wsum = pegs.w_taint + pegs.w_label + 2 * pegs.w_excl + 2 * pegs.w_zone
-    Bp = 8 * R + 4 + 4 + 8 * wsum + 4
-    Bn = 8 * 2 * R + 4 * 6 + 8 * (pegs.w_taint + pegs.w_label + pegs.w_excl + 2 * pegs.w_zone)
-    return nnz * Bp + groups.n_groups * Bn + groups.n_groups * 8 + 8 * nnz, Bp, Bn
+    Bp = lane_bytes * R + 4 + 4 + 4 + 8 * wsum
+    Bn = lane_bytes * R + 4 * 6 + 8 * (pegs.w_excl + 2 * pegs.w_zone)
+    return nnz * Bp + groups.n_groups * Bn + groups.n_groups * 40 + 4 * nnz, Bp, Bn
 
 
 def cpu_baseline(workloads, seed_base, n_pegs, pods_per_peg, cap, budget_s=12.0, max_sims=4096):
@@ -169,9 +171,10 @@ def main():
         # dominant kernel: per-kernel HIP-event timing on the launch stream (libcasim: casim_problem_time)
         total_ms, kms = prob.time(iters=max(5, min(args.steps, 20)))
         nnz, _ = prob.csr()
-        bytes_pack, Bp, Bn = algorithmic_bytes_pack(enc.pegs, enc.groups, nnz)
+        info = prob.info()
+        bytes_pack, Bp, Bn = algorithmic_bytes_pack(enc.pegs, enc.groups, nnz, info["fast_packer_slots_per_lane"] > 0)
         achieved = bytes_pack / (kms["pack_ms"] * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "pack_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        roofline = {"bound": "hbm", "kernel": "pack_fast_kernel<%d,%d>" % (info["fast_packer_lanes"], info["fast_packer_slots_per_lane"]) if info["fast_packer_slots_per_lane"] else "pack_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                     "algorithmic_bytes_per_launch": bytes_pack, "bytes_per_peg_record": Bp, "bytes_per_group_record": Bn,
                     "kernel_ms": kms["pack_ms"],
@@ -195,8 +198,11 @@ def main():
         # streaming form of the same predicates: dense per-pod x per-node check (HBM-facing kernel)
         if not args.no_dense:
             try:
+                # bounded probe: 256 simulations' pods x (256 groups x 16 nodes) = 2.56 M x 4096 -> 1.3 GB of bits
                 rep = 16
-                ms, nr, nc = prob.time_dense(rep, iters=5)
+                encd, _, _ = build_batch(workloads, kaa.Encoder, 256, 1 << 21, args.pegs, args.pods_per_peg, args.cap)
+                with kaa.Problem(ctx, encd.pegs, encd.groups) as pd:
+                    ms, nr, nc = pd.time_dense(rep, iters=5)
                 R = enc.pegs.n_res
                 bp = 8 * R + 4 + 4 + 8 * 4
                 bn = 8 * 2 * R + 8 + 8 * 4

@@ -204,6 +204,12 @@ int32_t casim_problem_fetch(casim_problem* p, casim_results* out);
  * is NULL.  Synchronises the stream. */
 int32_t casim_problem_csr(casim_problem* p, int32_t* nnz_out, int32_t* offsets_out);
 
+/* How the resident batch will be executed (for reports): info_out[0] = node slots per lane of the
+ * register-resident int32 packer (0 = generic int64 packer), [1] = its lane count, [2] = 1 if the
+ * generic packer keeps node state in LDS (0 = HBM slab), [3] = 1 if the schedulable subsets are
+ * derived on the device, [4..7] reserved (0). */
+int32_t casim_problem_info(casim_problem* p, int32_t info_out[8]);
+
 /* upload + run + fetch in one call: the form the Go Estimate() wrapper uses once per loop. */
 int32_t casim_estimate_batch(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups,
                              const casim_options* opts, casim_results* out);

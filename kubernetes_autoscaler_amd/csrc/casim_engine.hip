@@ -38,7 +38,7 @@ struct HipBackend {
     size_t lds_budget() const { return lds; }
     bool ok() const { return last == hipSuccess; }
     const char* error() const { return msg.c_str(); }
-    void clear() { last = hipSuccess; msg.clear(); }
+    void clear() { last = hipSuccess; msg.clear(); (void)hipGetLastError(); }  // also drop HIP's sticky last error
 
     template <class K, class... A>
     void launch(K kernel, int gx, int gy, int block, size_t smem, A... args) {
@@ -85,6 +85,7 @@ struct DenseCol {
 // Each thread keeps its pod record in registers, walks 64 columns from LDS (broadcast reads) and
 // emits one uint64; the wave's 64 stores are contiguous (layout [col_block][row]).
 constexpr int kDenseColBlocks = 8;
+template <int RD>  // resource lanes actually compared (2, 4 or 8): the inner loop is RD 64-bit compares per column
 __global__ __launch_bounds__(256) void dense_check_kernel(DevTables t, const int32_t* __restrict__ row_peg, int64_t n_rows,
                                                           int col_repeat, int64_t n_cols, uint64_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -92,9 +93,9 @@ __global__ __launch_bounds__(256) void dense_check_kernel(DevTables t, const int
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = row < n_rows;
     const int g = live ? row_peg[row] : 0;
-    int64_t req[CASIM_KMAX_RES];
+    int64_t req[RD];
 #pragma unroll
-    for (int r = 0; r < CASIM_KMAX_RES; ++r) req[r] = (live && r < t.R) ? t.req[(int64_t)g * t.R + r] : 0;
+    for (int r = 0; r < RD; ++r) req[r] = (live && r < t.R) ? t.req[(int64_t)g * t.R + r] : 0;
     const uint64_t tol = t.Wt ? t.tol[(int64_t)g * t.Wt] : 0ull, sel = t.Wl ? t.sel[(int64_t)g * t.Wl] : 0ull;
     const uint64_t xb = t.Wx ? t.xblock[(int64_t)g * t.Wx] : 0ull, zb = t.Wz ? t.zblock[(int64_t)g * t.Wz] : 0ull;
     const uint32_t pf = live ? t.pflags[g] : CASIM_PEG_UNSUPPORTED;
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void dense_check_kernel(DevTables t, const int
                 bool ok = !(c.flags & 2u) && (!(c.flags & 1u) || (pf & CASIM_PEG_TOLERATES_UNSCHEDULABLE));
                 ok = ok && !(c.taint & ~tol) && !(sel & ~c.label) && !(xb & c.excl) && !(zb & c.zone);
 #pragma unroll
-                for (int r = 0; r < CASIM_KMAX_RES; ++r) ok = ok && (req[r] <= c.freepos[r]);
+                for (int r = 0; r < RD; ++r) ok = ok && (req[r] <= c.freepos[r]);
                 bits |= (uint64_t)ok << j;
             }
         }
@@ -224,6 +225,14 @@ void casim_problem_destroy(casim_problem* p) {
 
 int32_t casim_problem_run(casim_problem* p) { PROB_ENTER(p); PROB_RET(p, p->prob->run()); }
 int32_t casim_problem_fetch(casim_problem* p, casim_results* out) { PROB_ENTER(p); PROB_RET(p, p->prob->fetch(out)); }
+int32_t casim_problem_info(casim_problem* p, int32_t info_out[8]) {
+    g_err.clear();
+    if (!p || !p->prob || !info_out) return set_err(CASIM_ERR_INVALID, "null argument");
+    for (int i = 0; i < 8; ++i) info_out[i] = 0;
+    info_out[0] = p->prob->fast_npt(); info_out[1] = p->prob->fast_lanes();
+    info_out[2] = p->prob->pack_in_lds() ? 1 : 0; info_out[3] = p->prob->csr_on_device() ? 1 : 0;
+    return CASIM_OK;
+}
 int32_t casim_problem_csr(casim_problem* p, int32_t* nnz_out, int32_t* offsets_out) { PROB_ENTER(p); PROB_RET(p, p->prob->csr(nnz_out, offsets_out)); }
 
 int32_t casim_estimate_batch(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts, casim_results* out) {
@@ -321,8 +330,11 @@ static void dense_launch(casim_problem* p, int32_t col_repeat, int64_t n_rows, i
     HipBackend& bk = p->ctx->bk;
     const int64_t n_cb = (n_cols + 63) / 64;
     if (n_rows <= 0 || n_cb <= 0) return;
-    bk.launch(casim::dense_check_kernel, (int)((n_rows + 255) / 256), (int)((n_cb + casim::kDenseColBlocks - 1) / casim::kDenseColBlocks), 256,
-              sizeof(casim::DenseCol) * 64, p->prob->tables(), (const int32_t*)p->d_row_peg, n_rows, (int)col_repeat, n_cols, p->d_dense);
+    const int gx = (int)((n_rows + 255) / 256), gy = (int)((n_cb + casim::kDenseColBlocks - 1) / casim::kDenseColBlocks);
+    const DevTables& t = p->prob->tables();
+    if (t.R <= 2) bk.launch(casim::dense_check_kernel<2>, gx, gy, 256, sizeof(casim::DenseCol) * 64, t, (const int32_t*)p->d_row_peg, n_rows, (int)col_repeat, n_cols, p->d_dense);
+    else if (t.R <= 4) bk.launch(casim::dense_check_kernel<4>, gx, gy, 256, sizeof(casim::DenseCol) * 64, t, (const int32_t*)p->d_row_peg, n_rows, (int)col_repeat, n_cols, p->d_dense);
+    else bk.launch(casim::dense_check_kernel<8>, gx, gy, 256, sizeof(casim::DenseCol) * 64, t, (const int32_t*)p->d_row_peg, n_rows, (int)col_repeat, n_cols, p->d_dense);
 }
 
 int32_t casim_problem_dense_check(casim_problem* p, int32_t col_repeat, uint64_t* out_bits, int64_t* n_rows_out, int64_t* n_cols_out) {

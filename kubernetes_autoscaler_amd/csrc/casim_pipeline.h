@@ -327,7 +327,8 @@ public:
     int pegs() const { return G_; }
     bool csr_on_device() const { return csr_on_device_; }
     bool pack_in_lds() const { return pack_lds_; }
-    int fast_npt() const { return fast_npt_; }   // > 0: the register-resident packer handles this batch
+    int fast_npt() const { return fast_npt_; }
+    int fast_lanes() const { return fast_npt_ > 0 ? fast_r_ : 0; }   // > 0: the register-resident packer handles this batch
     static constexpr int kOrderThreads = 256;
 
 private:

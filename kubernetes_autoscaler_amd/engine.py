@@ -124,6 +124,12 @@ class Problem:
     def run(self):
         check(lib.casim_problem_run(self._h), "casim_problem_run")
 
+    def info(self):
+        out = (C.c_int32 * 8)()
+        check(lib.casim_problem_info(self._h, out), "casim_problem_info")
+        return {"fast_packer_slots_per_lane": out[0], "fast_packer_lanes": out[1], "generic_state_in_lds": bool(out[2]),
+                "csr_on_device": bool(out[3])}
+
     def csr(self):
         nnz = C.c_int32(0)
         off = np.zeros(self.n_groups + 1, np.int32)
