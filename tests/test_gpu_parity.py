@@ -182,3 +182,26 @@ def test_dense_check_matches_feasibility(ctx):
                 got = (int(bits[col // 64, row]) >> (col % 64)) & 1
                 assert got == want, (g, col)
             row += 1
+
+
+# ---- edge cases of the boundary on the GPU ------------------------------------------------------------
+from test_edge_cases_emu import CASES as EDGE_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("name,sc", EDGE_CASES, ids=[c[0] for c in EDGE_CASES])
+def test_edge_case(ctx, name, sc):
+    res, _ = run_gpu(encode(sc), ctx)
+    assert_matches_oracle(res, run_oracle(sc), name)
+
+
+def test_generic_packer_equals_register_packer(ctx):
+    """force_generic_packer: the int64 LDS packer and the int32 register packer agree bit for bit."""
+    for name in ("C0", "C1", "C2"):
+        w = workloads.CONFIGS[name]()
+        sc = scenario_of(w)
+        enc = encode(sc)
+        a, _ = run_gpu(enc, ctx)
+        b, _ = run_gpu(enc, ctx, generic=True)
+        for f in ("node_count", "pods_scheduled", "nodes_added", "limiter_nodes", "last_index_out", "req_cpu_sum", "req_mem_sum", "order", "placed"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), (name, f)
+        assert_matches_oracle(b, run_oracle(sc), name)
