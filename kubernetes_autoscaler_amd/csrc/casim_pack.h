@@ -176,50 +176,44 @@ struct RegStore {
         if (selfx && k > 1) k = 1;
         return k;
     }
-    // Pass A for ALL slots at once: resource lane outermost (its branch is wave-uniform), slots innermost,
-    // so the NPT_ independent quotient chains (cvt -> f64 mul -> cvt -> fix-up) interleave instead of
-    // running back to back.  Slots beyond M hold zeros (slots == 0), hence c == 0 without a mask.
-    CS_DEVICE void capacity_all(const Peg& pv, uint32_t clampk, bool selfx) {
+    // Pass A for all slots.  Per slot: a cheap fit mask first (pod slot left and req <= free on every
+    // requested lane: a handful of compares); only slots where SOME node fits (wave-uniform ballot) pay for
+    // the quotient chain (cvt -> f64 mul by the PEG's reciprocal -> cvt -> exact +-1 fix-up).  In the
+    // steady state of a scale-up most PEGs fit nowhere or on a few nodes, so most slots stop at the mask.
+    // Slots beyond M hold zeros (slots == 0): no extra guard.  Returns n1 = nodes taking >= 1 pod.
+    CS_DEVICE int32_t capacity_all(const Peg& pv, uint32_t clampk, bool selfx) {
+        int32_t n1 = 0;
 #pragma unroll
-        for (int s = 0; s < NPT_; ++s) c[s] = slots[s] > 0 ? ((uint32_t)slots[s] < clampk ? (uint32_t)slots[s] : clampk) : 0u;
+        for (int s = 0; s < NPT_; ++s) {
+            bool fit = slots[s] > 0;
 #pragma unroll
-        for (int r = 0; r < R_; ++r) {
-            const int32_t q = pv.req[r];
-            if (q > 0) {  // wave-uniform
-                const double rq = pv.rq[r];
-                // stage-wise over the slots (explicit software interleave of the independent chains)
-                uint32_t fpos[NPT_], e[NPT_];
-                double d[NPT_];
+            for (int r = 0; r < R_; ++r) fit = fit && (pv.req[r] <= 0 || fr[s][r] >= pv.req[r]);
+            const uint64_t fb = cs::ballot(fit);
+            uint32_t k = 0;
+            if (fb) {  // wave-uniform
+                n1 += cs::popc64(fb);
+                k = fit ? ((uint32_t)slots[s] < clampk ? (uint32_t)slots[s] : clampk) : 0u;
 #pragma unroll
-                for (int s = 0; s < NPT_; ++s) fpos[s] = fr[s][r] >= q ? (uint32_t)fr[s][r] : 0u;
-#pragma unroll
-                for (int s = 0; s < NPT_; ++s) d[s] = (double)fpos[s];
-#pragma unroll
-                for (int s = 0; s < NPT_; ++s) d[s] *= rq;
-#pragma unroll
-                for (int s = 0; s < NPT_; ++s) e[s] = (uint32_t)d[s];
-                if (q < (1 << 30)) {
-                    // remainder in wrapping 32-bit arithmetic: the true value lies in (-q, 2q), |.| < 2^31
-                    int32_t rem[NPT_];
-#pragma unroll
-                    for (int s = 0; s < NPT_; ++s) rem[s] = (int32_t)(fpos[s] - e[s] * (uint32_t)q);
-#pragma unroll
-                    for (int s = 0; s < NPT_; ++s) e[s] = rem[s] < 0 ? e[s] - 1 : (rem[s] >= q ? e[s] + 1 : e[s]);
-                } else {
-#pragma unroll
-                    for (int s = 0; s < NPT_; ++s) {
-                        const int64_t rem = (int64_t)fpos[s] - (int64_t)((uint64_t)e[s] * (uint64_t)(uint32_t)q);
-                        e[s] = rem < 0 ? e[s] - 1 : (rem >= (int64_t)q ? e[s] + 1 : e[s]);
+                for (int r = 0; r < R_; ++r) {
+                    const int32_t q = pv.req[r];
+                    if (q > 0) {  // wave-uniform
+                        const uint32_t fpos = fit ? (uint32_t)fr[s][r] : 0u;
+                        uint32_t e = (uint32_t)((double)fpos * pv.rq[r]);
+                        if (q < (1 << 30)) {  // remainder in wrapping 32-bit arithmetic: it lies in (-q, 2q)
+                            const int32_t rem = (int32_t)(fpos - e * (uint32_t)q);
+                            e = rem < 0 ? e - 1 : (rem >= q ? e + 1 : e);
+                        } else {
+                            const int64_t rem = (int64_t)fpos - (int64_t)((uint64_t)e * (uint64_t)(uint32_t)q);
+                            e = rem < 0 ? e - 1 : (rem >= (int64_t)q ? e + 1 : e);
+                        }
+                        k = e < k ? e : k;
                     }
                 }
-#pragma unroll
-                for (int s = 0; s < NPT_; ++s) c[s] = e[s] < c[s] ? e[s] : c[s];
+                if (selfx) k = k > 1 ? 1u : k;
             }
+            c[s] = k;
         }
-        if (selfx) {
-#pragma unroll
-            for (int s = 0; s < NPT_; ++s) c[s] = c[s] > 1 ? 1u : c[s];
-        }
+        return n1;
     }
     CS_DEVICE void commit(int s, int, uint32_t x, const Peg& pv) {
 #pragma unroll
@@ -416,21 +410,13 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 int32_t n1 = 0;
                 if (st.may_fit(pv)) {  // summary pruning: no node can take this PEG (stale-but-safe bounds)
                     if constexpr (Store::kNPT > 0) {
-                        st.capacity_all(pv, keff, selfx);  // every slot, interleaved (nodes >= M are all-zero)
-                        for_slots<Store>(S, [&](int s) {
-                            const uint32_t cj = st.get_c(s, s * 64 + lane);
-                            lane_sum += cj;
-                            lane_max = cj > lane_max ? cj : lane_max;
-                            n1 += cs::popc64(cs::ballot(cj > 0));
-                        });
+                        n1 = st.capacity_all(pv, keff, selfx);  // every slot (nodes >= M are all-zero)
                     } else {
                         for_slots<Store>(S, [&](int s) {
                             const int m = s * 64 + lane;
                             uint32_t cj = 0;
                             if (m < M) cj = st.capacity(s, m, pv, keff, selfx);
                             st.set_c(s, m, cj);
-                            lane_sum += cj;
-                            lane_max = cj > lane_max ? cj : lane_max;
                             n1 += cs::popc64(cs::ballot(cj > 0));
                         });
                     }
@@ -443,6 +429,12 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         // S(1) = n1 > k: not even one full round — the k pods go to the first k fitting nodes
                         T = 0; Rr = keff; placed = (int32_t)keff;
                     } else {
+                        // sum and max of the capacities are only needed when the pods complete >= 1 round
+                        for_slots<Store>(S, [&](int s) {
+                            const uint32_t cj = st.get_c(s, s * 64 + lane);
+                            lane_sum += cj;
+                            lane_max = cj > lane_max ? cj : lane_max;
+                        });
                         const uint64_t tot = wsum(lane_sum);
                         const uint32_t cmax = cs::wave_max_u32(lane_max);
                         if (tot <= keff) { T = cmax; Rr = 0; placed = (int32_t)tot; }  // every node saturates
