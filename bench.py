@@ -124,10 +124,17 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: kubernetes_autoscaler_amd has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # CASIM_BENCH_SELFTEST=1: exercise the N > 1 control flow on a 1-GPU box (every rank on cuda:0, gloo
+    # for the collectives).  Numbers from this mode are meaningless; the driver never sets it.
+    selftest = os.environ.get("CASIM_BENCH_SELFTEST") == "1"
+    dev_index = 0 if selftest else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if selftest:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
 
     B = args.batch
     t0 = time.time()
@@ -135,9 +142,9 @@ def main():
     t_encode = time.time() - t0
 
     stream = torch.cuda.current_stream().cuda_stream
-    ctx = kaa.Context(local_rank, stream=stream)
+    ctx = kaa.Context(dev_index, stream=stream)
     prob = kaa.Problem(ctx, enc.pegs, enc.groups)
-    key = torch.full((10,), 0x7FFFFFFFFFFFFFFF, dtype=torch.int64, device=f"cuda:{local_rank}")
+    key = torch.full((10,), 0x7FFFFFFFFFFFFFFF, dtype=torch.int64, device=f"cuda:{dev_index}")
     kinds = [_abi.EXPANDER_LEAST_NODES]
     base = rank * B
 
@@ -160,7 +167,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t_start
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if selftest else f"cuda:{dev_index}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

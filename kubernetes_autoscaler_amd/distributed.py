@@ -27,11 +27,18 @@ def shard_groups(groups: Sequence, rank: int, world: int) -> List:
     return list(groups[lo:hi])
 
 
+def _for_backend(t: torch.Tensor) -> torch.Tensor:
+    """gloo (CPU tests / the bench's self-test mode) reduces host tensors; RCCL reduces in place on the device."""
+    if dist.is_initialized() and dist.get_backend() == "gloo" and t.is_cuda:
+        return t.cpu()
+    return t
+
+
 def reduce_best_min(key_block: torch.Tensor) -> int:
     """Single-filter chains on an integer metric (least-nodes / most-pods): ONE all-reduce(min) on the
     packed key (metric << 20 | global group id) is exact and already breaks ties towards the lowest
     group id.  Returns the global group id or -1."""
-    k = key_block[0:1].clone()
+    k = _for_backend(key_block[0:1].clone())
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(k, op=dist.ReduceOp.MIN)
     v = int(k.item())
@@ -44,8 +51,9 @@ def reduce_best_gather(key_block: torch.Tensor, n_kinds: int) -> int:
     filter chain computes over the union of all options."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world > 1:
-        out = torch.empty(world * KEY_WORDS, dtype=torch.int64, device=key_block.device)
-        dist.all_gather_into_tensor(out, key_block.contiguous())
+        kb = _for_backend(key_block.contiguous())
+        out = torch.empty(world * KEY_WORDS, dtype=torch.int64, device=kb.device)
+        dist.all_gather_into_tensor(out, kb)
         blocks = out.view(world, KEY_WORDS)
     else:
         blocks = key_block.view(1, KEY_WORDS)
