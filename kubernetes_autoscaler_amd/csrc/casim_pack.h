@@ -39,6 +39,13 @@
 #define CASIM_PROF_STORE(p) (void)(p)
 #endif
 
+// Waves per SIMD the register allocator of the 256-node fast packer must leave room for.  Measured on
+// MI355X (r01, C1 x 16384): natural allocation 148 VGPRs = 3 waves/SIMD -> 8.2 M sims/s; 4 waves
+// (128 VGPRs, 68 B/lane of scratch) -> 9.2 M; 5 waves (96 VGPRs, 204 B/lane) -> 4.0 M.
+#ifndef CASIM_FAST_WAVES
+#define CASIM_FAST_WAVES 4
+#endif
+
 namespace casim {
 
 template <class L, int RMAX>
@@ -679,7 +686,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void pack_kernel(DevTables t, DevResults res, 
 template <int R_, int NPT_>
 // launch bounds (64, 1): let the register allocator take what it needs — forcing 5 waves/SIMD (<= 96
 // VGPRs) spilled ~200 B/lane to scratch and halved the throughput on MI355X (r01 measurement)
-CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void pack_fast_kernel(DevTables t, DevResults res, FastScratch fs) {
+CS_GLOBAL CS_LAUNCH_BOUNDS(64, (NPT_ == 4 ? CASIM_FAST_WAVES : 1)) void pack_fast_kernel(DevTables t, DevResults res, FastScratch fs) {
     if (pack_unsupported(t, res)) return;
     const int ng = cs::bid();
     RegStore<R_, NPT_> st;
