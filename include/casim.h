@@ -258,6 +258,38 @@ int32_t casim_best_option(casim_problem* p, const int32_t* kinds, int32_t n_kind
                           int32_t group_id_base, int32_t* best_ng_out, int32_t* n_best_out,
                           uint8_t* best_set_out, int64_t* key_out, void* dev_key_out);
 
+/*
+ * HintingSimulator.TrySchedulePods (CA/simulator/scheduling/hinting_simulator.go:53-135) — the
+ * filter-out-schedulable pass (CA/core/podlistprocessor/filter_out_schedulable.go:48-103): pending pods,
+ * one by one in the caller's (priority) order, against the nodes ALREADY in the cluster snapshot.
+ *   classes  = one casim_pegs record per distinct pending-pod spec (count is ignored);
+ *   nodes    = one casim_groups record per existing node: alloc, init_req / init_pods / init_excl = what its
+ *              running pods hold (encode them as preloaded pods), taint / label masks of THAT node,
+ *              CASIM_NG_UNSCHEDULABLE; the limiter / CSR fields are ignored.  The encoder must run with
+ *              explicit_self_exclusion = 1.
+ * Per pod: the hinted node first (tryScheduleUsingHints :86-110: RunFiltersOnNode, no lastIndex update), else
+ * the first passing node in cyclic order from lastIndex + 1 among acceptable, schedulable nodes
+ * (RunFiltersUntilPassingNode, plugin_runner.go:54-143), with the SimilarPodsScheduling memo (:115-118,
+ * applied to every class: a class that fit nowhere cannot fit later, state only fills up).
+ * Returns CASIM_OK, <0 on error, or CASIM_NG_UNSUPPORTED (> 0) when a class needs a predicate outside the
+ * encoded subset or a group-wide (non-hostname) exclusion: the shim then runs the Go simulator.
+ */
+typedef struct casim_pod_sequence {
+    int32_t n_pods;                  /* P */
+    const int32_t* pod_class;        /* [P] class (PEG id) of each pending pod, processing order          */
+    const int32_t* hint_node;        /* [P] node index hinted for the pod (hints.go) or -1; may be NULL    */
+    const uint8_t* node_acceptable;  /* [N] SchedulingOptions.IsNodeAcceptable; may be NULL (= all)        */
+    int32_t break_on_failure;        /* stop at the first pod that fits nowhere                            */
+    int32_t last_index;              /* lastIndexOrderMapping.lastIndex on entry                           */
+} casim_pod_sequence;
+
+int32_t casim_try_schedule_pods(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes,
+                                const casim_pod_sequence* seq, int32_t* node_out /*[P], -1 = stays pending*/,
+                                int32_t* last_index_out, int32_t* n_scheduled_out);
+/* Same on resident data, `iters` times, HIP-event timed (bench / profiles). */
+int32_t casim_time_try_schedule_pods(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes,
+                                     const casim_pod_sequence* seq, int32_t iters, float* ms_out);
+
 /* Measurement helpers (used by bench.py): run `iters` times, bracketed by HIP events on the
  * context's stream; returns the mean per-run milliseconds of the whole pipeline and of the
  * named kernel classes.  kernel_ms_out: [0]=feasibility+csr [1]=order [2]=pack (may be NULL). */
@@ -277,7 +309,9 @@ typedef struct casim_encoder casim_encoder;
 typedef struct casim_encoder_options {
     int32_t n_res;                 /* R: lanes every object carries (>= 2)                     */
     int32_t enable_taint_comparison_ops; /* TaintTolerationComparisonOperators gate (toleration.go:66-72); default 0 */
-    int32_t reserved[6];
+    int32_t explicit_self_exclusion;     /* 1 = self-conflicts (own host port, hostname self-anti-affinity) also get
+                                            node bits; required by casim_try_schedule_pods (pod-by-pod placement) */
+    int32_t reserved[5];
 } casim_encoder_options;
 
 casim_encoder* casim_enc_create(const casim_encoder_options* opts);

@@ -62,7 +62,13 @@ class Results(C.Structure):
 
 
 class EncoderOptions(C.Structure):
-    _fields_ = [("n_res", C.c_int32), ("enable_taint_comparison_ops", C.c_int32), ("reserved", C.c_int32 * 6)]
+    _fields_ = [("n_res", C.c_int32), ("enable_taint_comparison_ops", C.c_int32), ("explicit_self_exclusion", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
+
+
+class PodSequence(C.Structure):
+    _fields_ = [("n_pods", C.c_int32), ("pod_class", i32p), ("hint_node", i32p), ("node_acceptable", u8p),
+                ("break_on_failure", C.c_int32), ("last_index", C.c_int32)]
 
 
 cstr = C.c_char_p
@@ -87,6 +93,9 @@ PROTOTYPES = {
     "casim_best_option": (C.c_int32, [C.c_void_p, i32p, C.c_int32, C.c_int32, i32p, i32p, u8p, i64p, C.c_void_p]),
     "casim_problem_time": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "casim_problem_time_dense": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float), i64p, i64p]),
+    "casim_try_schedule_pods": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(PodSequence), i32p, i32p, i32p]),
+    "casim_time_try_schedule_pods": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(PodSequence), C.c_int32,
+                                                 C.POINTER(C.c_float)]),
     "casim_copy_bandwidth": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, f64p]),
     "casim_enc_create": (C.c_void_p, [C.POINTER(EncoderOptions)]),
     "casim_enc_destroy": (None, [C.c_void_p]),

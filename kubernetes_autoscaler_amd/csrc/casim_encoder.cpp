@@ -348,7 +348,8 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         for (auto& kv : p.node_selector) { Requirement r; r.key = kv.first; r.op = kIn; r.values = {kv.second}; all.push_back(r); }
         for (auto& r : all) {
             // every simulated node gets its own hostname label (node_info_utils.go:130): not a template property
-            if (r.key == kHostname) { p.unsupported = true; p.why = "node selector on kubernetes.io/hostname"; continue; }
+            // (per-node consumers pass real nodes: there the label is an ordinary one)
+            if (r.key == kHostname && !e->opt.explicit_self_exclusion) { p.unsupported = true; p.why = "node selector on kubernetes.io/hostname"; continue; }
             const std::string sig = req_signature(r);
             auto it = lreq_id.find(sig);
             int id;
@@ -379,7 +380,9 @@ int32_t casim_enc_finalize(casim_encoder* e) {
                 for (int ub : b.second) for (int ua : a.second) if (ua != ub) shared = true;
                 if (shared) break;
             }
-            if (shared) port_bit[a.first] = xbits.next();
+            // explicit_self_exclusion (per-pod consumers such as casim_try_schedule_pods): every used port
+            // gets a node bit, so that "this class already sits on the node" is remembered by the node
+            if (shared || e->opt.explicit_self_exclusion) port_bit[a.first] = xbits.next();
         }
     }
     // hostname anti-affinity between different units
@@ -402,7 +405,14 @@ int32_t casim_enc_finalize(casim_encoder* e) {
                 bool hit = false;
                 for (auto& t : a.anti) if (t.topology_key == kHostname && term_matches(t, b)) { hit = true; break; }
                 if (!hit) continue;
-                if (i == j) { pflags[i] |= CASIM_PEG_SELF_EXCL_NODE; continue; }
+                if (i == j) {
+                    pflags[i] |= CASIM_PEG_SELF_EXCL_NODE;
+                    if (e->opt.explicit_self_exclusion) {  // self-conflict as a real node bit (see above)
+                        if (peg_occ_bit[i] < 0) peg_occ_bit[i] = xbits.next();
+                        peg_blockers[i].push_back(peg_occ_bit[i]);
+                    }
+                    continue;
+                }
                 if (peg_occ_bit[i] < 0) peg_occ_bit[i] = xbits.next();
                 if (peg_occ_bit[j] < 0) peg_occ_bit[j] = xbits.next();
                 peg_blockers[i].push_back(peg_occ_bit[j]);
@@ -426,6 +436,19 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         }
     }
     e->Wx = xbits.words();
+    // Hostname terms assume that every node carries its own kubernetes.io/hostname value (true for the
+    // template clones of an Estimate, node_info_utils.go:130).  Per-node consumers pass real nodes: when one of
+    // them lacks the label its pods are in no hostname domain at all, which the node bits cannot express.
+    if (e->opt.explicit_self_exclusion) {
+        bool all_named = true;
+        for (auto& g : e->groups) if (!g.labels.count(kHostname)) all_named = false;
+        if (!all_named)
+            for (size_t i = 0; i < G; ++i)
+                if (!peg_blockers[i].empty() || peg_occ_bit[i] >= 0) {  // so far both hold hostname bits only
+                    PodSpec& p = e->specs[(size_t)e->pegs[i].spec];
+                    p.unsupported = true; p.why = "hostname anti-affinity with a node that has no kubernetes.io/hostname label";
+                }
+    }
 
     // (4) group-wide exclusion bits: anti-affinity on non-hostname topology keys.  All nodes of a group
     // clone one template, so a domain == the whole group when the template carries the key.

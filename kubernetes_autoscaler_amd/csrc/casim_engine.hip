@@ -370,6 +370,42 @@ int32_t casim_problem_time_dense(casim_problem* p, int32_t col_repeat, int32_t i
     return bk.ok() ? CASIM_OK : set_err(CASIM_ERR_HIP, bk.msg);
 }
 
+// ---- filter-out-schedulable ---------------------------------------------------
+int32_t casim_try_schedule_pods(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes, const casim_pod_sequence* seq,
+                                int32_t* node_out, int32_t* last_index_out, int32_t* n_scheduled_out) {
+    g_err.clear();
+    if (!ctx) return set_err(CASIM_ERR_INVALID, "null context");
+    HipBackend& bk = ctx->bk; bk.bind(); bk.clear();
+    casim::SchedulerT<HipBackend> s(bk);
+    int32_t rc = s.init(classes, nodes, seq);
+    if (rc == CASIM_OK) rc = s.run();
+    if (rc == CASIM_OK) rc = s.fetch(node_out, last_index_out, n_scheduled_out);
+    if (rc < 0) set_err(rc, s.error());
+    return rc;
+}
+
+int32_t casim_time_try_schedule_pods(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes,
+                                     const casim_pod_sequence* seq, int32_t iters, float* ms_out) {
+    g_err.clear();
+    if (!ctx || iters <= 0 || !ms_out) return set_err(CASIM_ERR_INVALID, "bad argument");
+    HipBackend& bk = ctx->bk; bk.bind(); bk.clear();
+    casim::SchedulerT<HipBackend> s(bk);
+    int32_t rc = s.init(classes, nodes, seq);
+    if (rc != CASIM_OK) { if (rc < 0) set_err(rc, s.error()); return rc; }
+    rc = s.run();  // warm-up (also the LDS opt-in)
+    hipEvent_t e0, e1;
+    bk.check(hipEventCreate(&e0), "hipEventCreate"); bk.check(hipEventCreate(&e1), "hipEventCreate");
+    bk.check(hipEventRecord(e0, bk.stream), "hipEventRecord");
+    for (int i = 0; i < iters && rc == CASIM_OK; ++i) rc = s.run();
+    bk.check(hipEventRecord(e1, bk.stream), "hipEventRecord");
+    bk.check(hipEventSynchronize(e1), "hipEventSynchronize");
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_out = ms;
+    if (rc < 0) return set_err(rc, s.error());
+    return bk.ok() ? CASIM_OK : set_err(CASIM_ERR_HIP, bk.msg);
+}
+
 int32_t casim_copy_bandwidth(casim_ctx* ctx, int64_t bytes, int32_t iters, double* gbps_out) {
     g_err.clear();
     if (!ctx || bytes < 4096 || iters <= 0 || !gbps_out) return set_err(CASIM_ERR_INVALID, "bad argument");

@@ -278,322 +278,6 @@ CS_GLOBAL void order_kernel(DevTables t, DevResults res, OrderScratch os) {
 // ------------------------------------------------------------------------------------------
 // K_pack: one wavefront = one Estimate()  -> casim_pack.h (included at the end of this file)
 // ------------------------------------------------------------------------------------------
-#if 0  // round-1 first version (LDS state, shuffle reductions); kept until casim_pack.h has soaked
-struct PackCtx {
-    int64_t* sfree;   // [R][cap]
-    uint64_t* sexcl;  // [Wx][cap]
-    int32_t* sslots;  // [cap]
-    int32_t* snpods;  // [cap]
-    int32_t* sctmp;   // [cap]
-    uint64_t* szone;  // [Wz][64] one private copy per lane
-    int cap;
-};
-
-CS_DEVICE uint32_t node_capacity(const PackCtx& c, const DevTables& t, int m, const int64_t* req, const uint64_t* xblock,
-                                 uint32_t clampk, bool selfx) {
-    for (int w = 0; w < t.Wx; ++w)
-        if (c.sexcl[(int64_t)w * c.cap + m] & xblock[w]) return 0;  // NodePorts / hostname anti-affinity
-    uint32_t k = capacity_of(c.sfree + m, c.cap, c.sslots[m], t.R, req, clampk);
-    if (selfx && k > 1) k = 1;
-    return k;
-}
-// place x pods of the PEG on node m (NodeInfo.AddPodInfo / update, types.go:361-371,439-463)
-CS_DEVICE void node_commit(const PackCtx& c, const DevTables& t, int m, uint32_t x, const int64_t* req, const uint64_t* xmark) {
-    for (int r = 0; r < CASIM_KMAX_RES; ++r) {
-        if (r >= t.R) break;
-        c.sfree[(int64_t)r * c.cap + m] -= (int64_t)x * req[r];
-    }
-    c.sslots[m] -= (int32_t)x;
-    c.snpods[m] += (int32_t)x;
-    for (int w = 0; w < t.Wx; ++w) c.sexcl[(int64_t)w * c.cap + m] |= xmark[w];
-}
-CS_DEVICE uint32_t sat_add(uint32_t a, uint32_t b, uint32_t cap1) {  // min(a + b, cap1), a,b <= 2^31
-    const uint32_t s = a + b;
-    return s > cap1 ? cap1 : s;
-}
-
-template <bool kLds>
-CS_GLOBAL void pack_kernel(DevTables t, DevResults res, PackScratch ps) {
-    const int ng = cs::bid();
-    const int lane = cs::lane();
-    const int R = t.R, Wx = t.Wx, Wz = t.Wz;
-    const int off = t.peg_off[ng];
-    const int Gn = t.peg_off[ng + 1] - off;
-
-    PackCtx c;
-    c.cap = ps.node_cap[ng];
-    {
-        char* base = kLds ? cs::dyn_smem() : ps.gstate + ps.state_off[ng];
-        c.sfree = (int64_t*)base;
-        c.sexcl = (uint64_t*)(c.sfree + (int64_t)R * c.cap);
-        c.szone = c.sexcl + (int64_t)Wx * c.cap;
-        c.sslots = (int32_t*)(c.szone + 64 * (Wz > 0 ? Wz : 1));
-        c.snpods = c.sslots + c.cap;
-        c.sctmp = c.snpods + c.cap;
-    }
-
-    // a group carrying a PEG outside the encoded predicate subset is delegated (status only)
-    {
-        bool bad = false;
-        for (int i = lane; i < Gn; i += 64) bad |= (t.pflags[t.peg_idx[off + i]] & CASIM_PEG_UNSUPPORTED) != 0;
-        if (cs::ballot(bad)) {
-            for (int i = lane; i < Gn; i += 64) res.placed[off + i] = 0;
-            if (lane == 0) {
-                res.node_count[ng] = 0; res.pods[ng] = 0; res.nodes_added[ng] = 0; res.limiter_nodes[ng] = 0;
-                res.last_index_out[ng] = t.last_index[ng]; res.status[ng] = CASIM_NG_UNSUPPORTED;
-                res.cpu_sum[ng] = 0; res.mem_sum[ng] = 0;
-            }
-            return;
-        }
-    }
-
-    // group constants (wave-uniform)
-    int64_t ffree[CASIM_KMAX_RES];  // free vector of a fresh node: alloc - requested-by-preloaded-pods
-    for (int r = 0; r < CASIM_KMAX_RES; ++r) ffree[r] = r < R ? t.alloc[(int64_t)ng * R + r] - t.init_req[(int64_t)ng * R + r] : 0;
-    const int32_t fslots = t.allowed[ng] - t.init_pods[ng];
-    const uint64_t* fexcl = t.init_excl + (int64_t)ng * Wx;
-    const int32_t maxn = t.max_nodes[ng];
-    const int32_t E = t.existing[ng];
-    const bool fast_last = t.fastpath && res.fast_last[ng];
-    const bool group_unschedulable = (t.gflags[ng] & CASIM_NG_UNSCHEDULABLE) != 0;
-    const uint64_t* zvalid = t.zone_valid + (int64_t)ng * Wz;
-    for (int w = 0; w < Wz; ++w) c.szone[w * 64 + lane] = t.init_zone[(int64_t)ng * Wz + w];
-
-    int32_t M = 0;                        // simulated nodes so far (estimationState.newNodeNameIndex)
-    int32_t last_index = t.last_index[ng];// lastIndexOrderMapping.lastIndex
-    int32_t granted = 0;                  // limiter.nodes
-    bool more = true;                     // newNodesAvailable
-    int32_t fakes = 0;                    // fastpath fake nodes
-    int32_t total_placed = 0;
-    int64_t cpu_sum = 0, mem_sum = 0;
-
-    for (int k = 0; k < Gn; ++k) {
-        const int g = res.order[off + k];
-        const int32_t cnt = t.count[g];
-        const uint32_t pf = t.pflags[g];
-        const bool selfx = (pf & CASIM_PEG_SELF_EXCL_NODE) != 0;
-        bool zselfx = (pf & CASIM_PEG_SELF_EXCL_ZONE) != 0;
-        int64_t req[CASIM_KMAX_RES];
-        for (int r = 0; r < CASIM_KMAX_RES; ++r) req[r] = r < R ? t.req[(int64_t)g * R + r] : 0;
-        const uint64_t* xblock = t.xblock + (int64_t)g * Wx;
-        const uint64_t* xmark = t.xmark + (int64_t)g * Wx;
-        const uint64_t* zblock = t.zblock + (int64_t)g * Wz;
-        const uint64_t* zmark = t.zmark + (int64_t)g * Wz;
-        const bool static_ok = static_filters_pass(t, g, ng);
-
-        bool zblocked = false;
-        for (int w = 0; w < Wz; ++w) {
-            zblocked |= (c.szone[w * 64 + lane] & zblock[w]) != 0;
-            zselfx |= (zblock[w] & zmark[w] & zvalid[w]) != 0;  // the PEG excludes itself group-wide
-        }
-
-        int32_t placed = 0;
-        uint32_t on_last = 0;  // pods of THIS PEG that a2 put on the newest node (self-exclusion has no node bit)
-
-        // ---- a2: tryToScheduleOnExistingNodes (:163-186), closed form over the cyclic node order ----
-        // k identical pods visit the nodes round-robin from lastIndex+1 (MarkMatch moves the start
-        // to the matched node); after t full rounds node j holds min(c_j, t) pods  (SURVEY N3).
-        const uint32_t keff = (uint32_t)(zselfx ? (cnt > 0 ? 1 : 0) : cnt);
-        // RunFiltersUntilPassingNode skips Spec.Unschedulable nodes before any Filter runs, tolerated or not
-        // (plugin_runner.go:108-110); every simulated node clones the template's flag.
-        if (M > 0 && keff > 0 && static_ok && !zblocked && !group_unschedulable) {
-            const int S = (M + 63) >> 6;
-            const uint32_t cap1 = keff + 1;
-            uint32_t tot = 0, cmax = 0;
-            for (int s = 0; s < S; ++s) {
-                const int m = s * 64 + lane;
-                uint32_t cj = 0;
-                if (m < M) cj = node_capacity(c, t, m, req, xblock, keff, selfx);
-                c.sctmp[m] = (int32_t)cj;
-                tot = sat_add(tot, cs::wave_sum_u32(cj), cap1);
-                const uint32_t mx = cs::wave_max_u32(cj);
-                cmax = mx > cmax ? mx : cmax;
-            }
-            if (tot > 0) {
-                uint32_t T, Rr;
-                if (tot <= keff) { T = cmax; Rr = 0; placed = (int32_t)tot; }
-                else {
-                    uint32_t lo = 0, hi = cmax, slo = 0;  // S(lo) <= keff < S(hi)
-                    while (hi - lo > 1) {
-                        const uint32_t mid = lo + ((hi - lo) >> 1);
-                        uint32_t sm = 0;
-                        for (int s = 0; s < S; ++s) {
-                            const uint32_t cj = (uint32_t)c.sctmp[s * 64 + lane];
-                            sm = sat_add(sm, cs::wave_sum_u32(cj < mid ? cj : mid), cap1);
-                        }
-                        if (sm <= keff) { lo = mid; slo = sm; } else hi = mid;
-                    }
-                    T = lo; Rr = keff - slo; placed = (int32_t)keff;
-                }
-                const uint32_t Tf = Rr > 0 ? T + 1 : T;  // last round: candidates have c >= Tf
-                // rotated order starts at list position (lastIndex + 1) % n; positions < E are the
-                // pre-existing cluster nodes (never acceptable)
-                const int32_t n = E + M;
-                const int32_t o = (int32_t)(((int64_t)last_index + 1) % n);
-                const int32_t m0 = o > E ? o - E : 0;
-                int32_t A = 0, Tot = 0;
-                for (int s = 0; s < S; ++s) {
-                    const uint64_t b = cs::ballot((uint32_t)c.sctmp[s * 64 + lane] >= Tf);
-                    Tot += cs::popc64(b);
-                    A += cs::popc64(b & cs::low_mask(m0 - s * 64));
-                }
-                const int32_t target = Rr > 0 ? (int32_t)Rr - 1 : Tot - 1;
-                int32_t basec = 0, new_last = last_index;
-                uint32_t x_mine_last = 0;
-                for (int s = 0; s < S; ++s) {
-                    const int m = s * 64 + lane;
-                    const uint32_t cj = (uint32_t)c.sctmp[m];
-                    const bool cand = cj >= Tf;
-                    const uint64_t b = cs::ballot(cand);
-                    const int32_t pex = basec + cs::mbcnt(b);
-                    const int32_t rot = m >= m0 ? pex - A : (Tot - A) + pex;
-                    uint32_t x = cj < T ? cj : T;
-                    if (Rr > 0 && cand && rot < (int32_t)Rr) x += 1;
-                    const uint64_t hit = cs::ballot(cand && rot == target);
-                    if (hit) new_last = E + s * 64 + cs::ffs64(hit);
-                    if (x > 0) node_commit(c, t, m, x, req, xmark);
-                    if (m == M - 1) x_mine_last = x;
-                    basec += cs::popc64(b);
-                }
-                on_last = (uint32_t)cs::readlane_u64(x_mine_last, (M - 1) & 63);
-                last_index = new_last;
-                for (int w = 0; w < Wz; ++w) c.szone[w * 64 + lane] |= zmark[w] & zvalid[w];
-            }
-        }
-
-        // ---- a3 / a4: tryToScheduleOnNewNodes (:190-269) or tryFastPath (:274-324) ----
-        int32_t rem = cnt - placed;
-        if (rem > 0 && more) {
-            zblocked = false;
-            for (int w = 0; w < Wz; ++w) zblocked |= (c.szone[w * 64 + lane] & zblock[w]) != 0;
-            bool blocked = !static_ok || zblocked;
-            // capacity of a FRESH node for this PEG
-            uint32_t cfresh = 0;
-            {
-                bool xb = false;
-                for (int w = 0; w < Wx; ++w) xb |= (fexcl[w] & xblock[w]) != 0;
-                if (!xb) cfresh = capacity_of(ffree, 1, fslots, R, req, (uint32_t)rem);
-                if ((selfx || zselfx) && cfresh > 1) cfresh = 1;
-            }
-            // lane that owns node m writes its fresh state + x pods
-            auto create_nodes = [&](int32_t first, int32_t nadd, uint32_t per, int32_t pods_total) {
-                // node first+i gets min(per, pods_total - i*per) pods
-                for (int32_t m = first + ((lane - first) & 63); m < first + nadd; m += 64) {
-                    const int32_t i = m - first;
-                    int64_t left = (int64_t)pods_total - (int64_t)i * per;
-                    const uint32_t x = left <= 0 ? 0u : (left < (int64_t)per ? (uint32_t)left : per);
-                    for (int r = 0; r < CASIM_KMAX_RES; ++r) { if (r >= R) break; c.sfree[(int64_t)r * c.cap + m] = ffree[r] - (int64_t)x * req[r]; }
-                    c.sslots[m] = fslots - (int32_t)x;
-                    c.snpods[m] = (int32_t)x;
-                    for (int w = 0; w < Wx; ++w) c.sexcl[(int64_t)w * c.cap + m] = fexcl[w] | (x > 0 ? xmark[w] : 0ull);
-                }
-            };
-            auto permission_left = [&]() -> int64_t {  // nodes the limiter would still grant
-                if (maxn < 0) return 0;
-                if (maxn == 0) return 0x7fffffffll;
-                return maxn > granted ? (int64_t)(maxn - granted) : 0;
-            };
-            bool marked = false;
-
-            if (fast_last && k == Gn - 1) {
-                // tryFastPath: one simulated node, the rest by arithmetic
-                if (permission_left() <= 0) more = false;
-                else {
-                    granted++;
-                    const uint32_t per = blocked ? 0u : (cfresh < (uint32_t)rem ? cfresh : (uint32_t)rem);
-                    create_nodes(M, 1, per, (int32_t)per);
-                    M++;
-                    if (per > 0) {
-                        marked = true;
-                        placed += (int32_t)per;
-                        const int32_t size = (int32_t)(((int64_t)rem + per - 1) / per);  // scaleUpSize
-                        const int64_t left = permission_left();
-                        const int32_t want = size - 1;
-                        const int32_t nf = want < left ? want : (int32_t)left;
-                        const int64_t fp = (int64_t)nf * per;
-                        placed += (int32_t)(nf == want ? (int64_t)rem - per : fp);
-                        fakes += nf; granted += nf;
-                        if (nf < want) more = false;
-                    }
-                }
-            } else {
-                // next-fit on the newest node (:198-209)
-                if (M > 0) {
-                    const int lm = M - 1, owner = lm & 63;
-                    uint32_t cl = 0;
-                    if (!blocked && !(selfx && on_last > 0) && lane == owner)
-                        cl = node_capacity(c, t, lm, req, xblock, (uint32_t)rem, selfx || zselfx);
-                    cl = (uint32_t)cs::readlane_u64(cl, owner);
-                    if (cl > 0) {
-                        if (lane == owner) node_commit(c, t, lm, cl, req, xmark);
-                        placed += (int32_t)cl; rem -= (int32_t)cl; marked = true;
-                        if (zselfx) blocked = true;
-                    }
-                }
-                bool stop = rem == 0;
-                if (!stop && M > 0) {
-                    // newest node still empty and the pod does not fit it: a new one would not help (:234-236)
-                    const int lm = M - 1, owner = lm & 63;
-                    int32_t np = lane == owner ? c.snpods[lm] : 0;
-                    np = (int32_t)cs::readlane_u64((uint32_t)np, owner);
-                    if (np == 0) stop = true;
-                }
-                while (!stop) {
-                    const uint32_t cn = blocked ? 0u : cfresh;
-                    if (cn == 0 || zselfx) {
-                        if (permission_left() <= 0) { more = false; break; }       // :244-246
-                        granted++;
-                        const uint32_t x = cn < (uint32_t)rem ? cn : (uint32_t)rem;  // 0 or 1
-                        create_nodes(M, 1, x, (int32_t)x);
-                        M++;
-                        if (x == 0) break;                                          // :257-263 node stays, PEG abandoned
-                        placed += (int32_t)x; rem -= (int32_t)x; marked = true;
-                        blocked = true;                                             // zselfx: the group now holds one
-                        if (rem == 0) break;
-                    } else {
-                        const int64_t need = ((int64_t)rem + cn - 1) / cn;
-                        const int64_t left = permission_left();
-                        const int32_t nadd = (int32_t)(need < left ? need : left);
-                        const int64_t fit = (int64_t)nadd * cn;
-                        const int32_t pl = (int32_t)(fit < rem ? fit : rem);
-                        if (nadd > 0) {
-                            create_nodes(M, nadd, cn, pl);
-                            M += nadd; granted += nadd; placed += pl; rem -= pl; marked = true;
-                        }
-                        if (need > left) more = false;
-                        break;
-                    }
-                }
-            }
-            if (marked)
-                for (int w = 0; w < Wz; ++w) c.szone[w * 64 + lane] |= zmark[w] & zvalid[w];
-        }
-
-        if (lane == 0) res.placed[off + k] = placed;
-        total_placed += placed;
-        cpu_sum += (int64_t)placed * req[0];
-        mem_sum += (int64_t)placed * (R > 1 ? req[1] : 0);
-    }
-
-    // len(newNodesWithPods) (:160)
-    int32_t with_pods = 0;
-    for (int s = 0; s < ((M + 63) >> 6); ++s) {
-        const int m = s * 64 + lane;
-        with_pods += cs::popc64(cs::ballot(m < M && c.snpods[m] > 0));
-    }
-    if (lane == 0) {
-        res.node_count[ng] = with_pods + fakes;
-        res.pods[ng] = total_placed;
-        res.nodes_added[ng] = M;
-        res.limiter_nodes[ng] = granted;
-        res.last_index_out[ng] = last_index;
-        res.status[ng] = CASIM_NG_OK;
-        res.cpu_sum[ng] = cpu_sum;
-        res.mem_sum[ng] = mem_sum;
-    }
-}
-
-#endif  // round-1 first version of pack_kernel
 
 // ------------------------------------------------------------------------------------------
 // K_option: expander filter chain over the groups of one launch

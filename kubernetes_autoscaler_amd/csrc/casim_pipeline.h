@@ -365,3 +365,5 @@ private:
 };
 
 }  // namespace casim
+
+#include "casim_sched.h"

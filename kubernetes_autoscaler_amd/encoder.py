@@ -26,11 +26,13 @@ def _strs(values: Sequence[str]):
 class Encoder:
     """One encoder instance == one scale-up loop's worth of PEGs and node groups."""
 
-    def __init__(self, lanes: Sequence[str] = DEFAULT_LANES, enable_taint_comparison_ops: bool = False):
+    def __init__(self, lanes: Sequence[str] = DEFAULT_LANES, enable_taint_comparison_ops: bool = False,
+                 explicit_self_exclusion: bool = False):
         if len(lanes) < 2 or len(lanes) > _abi.MAX_RES or lanes[0] != RES_CPU or lanes[1] != RES_MEMORY:
             raise ValueError("lanes must start with ('cpu', 'memory') and have 2..8 entries")
         self.lanes = tuple(lanes)
-        opts = _abi.EncoderOptions(n_res=len(lanes), enable_taint_comparison_ops=int(enable_taint_comparison_ops))
+        opts = _abi.EncoderOptions(n_res=len(lanes), enable_taint_comparison_ops=int(enable_taint_comparison_ops),
+                                   explicit_self_exclusion=int(explicit_self_exclusion))
         self._h = lib.casim_enc_create(C.byref(opts))
         if not self._h:
             raise MemoryError("casim_enc_create failed")

@@ -57,6 +57,20 @@ def finish_results(arrs, n_groups: int, nnz: int, offsets: np.ndarray) -> BatchR
     return BatchResult(offsets=offsets, **out)
 
 
+def make_pod_sequence(pod_class, hint_node=None, node_acceptable=None, break_on_failure: bool = False, last_index: int = 0):
+    """casim_pod_sequence over numpy arrays; returns (struct, arrays to keep alive)."""
+    pc = np.ascontiguousarray(pod_class, np.int32)
+    hn = None if hint_node is None else np.ascontiguousarray(hint_node, np.int32)
+    na = None if node_acceptable is None else np.ascontiguousarray(node_acceptable, np.uint8)
+    if hn is not None and hn.shape != pc.shape:
+        raise ValueError("hint_node must have one entry per pod")
+    seq = _abi.PodSequence(n_pods=int(pc.shape[0]), pod_class=_ptr(pc, C.c_int32) if pc.size else None,
+                           hint_node=_ptr(hn, C.c_int32) if hn is not None and hn.size else None,
+                           node_acceptable=_ptr(na, C.c_uint8) if na is not None and na.size else None,
+                           break_on_failure=int(bool(break_on_failure)), last_index=int(last_index))
+    return seq, (pc, hn, na)
+
+
 def device_count() -> int:
     return int(lib.casim_device_count())
 
@@ -96,6 +110,28 @@ class Context:
         bits = np.zeros((max(groups.n_groups, 1), max(wg, 1)), np.uint64)
         check(lib.casim_feasibility(self._h, C.byref(pegs), C.byref(groups), _ptr(bits, C.c_uint64)), "casim_feasibility")
         return bits[:groups.n_groups, :wg]
+
+
+    def try_schedule_pods(self, classes: _abi.Pegs, nodes: _abi.Groups, pod_class, hint_node=None, node_acceptable=None,
+                          break_on_failure: bool = False, last_index: int = 0, time_iters: int = 0):
+        """HintingSimulator.TrySchedulePods on the device (casim_try_schedule_pods).
+        Returns (status, node_out[P], last_index, n_scheduled); status NG_UNSUPPORTED => delegate to the Go path.
+        With time_iters > 0 returns the HIP-event time in ms of one resident pass instead."""
+        seq, keep = make_pod_sequence(pod_class, hint_node, node_acceptable, break_on_failure, last_index)
+        if time_iters > 0:
+            ms = C.c_float(0)
+            rc = lib.casim_time_try_schedule_pods(self._h, C.byref(classes), C.byref(nodes), C.byref(seq), int(time_iters), C.byref(ms))
+            if rc < 0:
+                check(rc, "casim_time_try_schedule_pods")
+            return rc, ms.value / time_iters
+        node_out = np.full(max(seq.n_pods, 1), -1, np.int32)
+        li, ns = C.c_int32(0), C.c_int32(0)
+        rc = lib.casim_try_schedule_pods(self._h, C.byref(classes), C.byref(nodes), C.byref(seq), _ptr(node_out, C.c_int32),
+                                         C.byref(li), C.byref(ns))
+        if rc < 0:
+            check(rc, "casim_try_schedule_pods")
+        del keep
+        return rc, node_out[:seq.n_pods], li.value, ns.value
 
 
 class Problem:

@@ -83,6 +83,24 @@ class Pod:
     has_containers: bool = True
     topology_spread: bool = False          # outside the encoded subset -> fallback
     unsupported_reason: str = ""           # anything else outside the encoded subset
+    # identity / ownership: only the filter-out-schedulable pass reads these (hints.go, similar_pods.go)
+    uid: str = ""
+    controller_uid: str = ""               # drain.ControllerRef(pod).UID, "" = no controller
+    daemonset: bool = False                # pod_utils.IsDaemonSetPod
+    priority: int = 0                      # corev1helpers.PodPriority
+
+    def spec_key(self):
+        """Hashable scheduling-relevant spec + labels: two pods with equal keys are interchangeable for every
+        encoded Filter (what SimilarPodsSchedulingInfo.Match compares, similar_pods.go:48-50)."""
+        return (self.namespace, tuple(sorted(self.labels.items())), tuple(sorted(self.requests.items())),
+                tuple((t.key, t.operator, t.value, t.effect) for t in self.tolerations),
+                tuple(sorted(self.node_selector.items())),
+                tuple((r.key, r.operator, tuple(r.values)) for r in self.node_affinity),
+                tuple((h.host_port, h.host_ip, h.protocol) for h in self.host_ports),
+                tuple((t.topology_key, tuple(sorted(t.match_labels.items())),
+                       tuple((r.key, r.operator, tuple(r.values)) for r in t.match_expressions), tuple(t.namespaces))
+                      for t in self.anti_affinity),
+                self.topology_spread, self.unsupported_reason, self.has_containers)
 
     def fastpath_requests(self):
         """Containers[0].Resources.Requests.{Cpu,Memory}().AsApproximateFloat64()

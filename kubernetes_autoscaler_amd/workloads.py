@@ -7,7 +7,7 @@ from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
 from .objects import (GiB, LABEL_HOSTNAME, LABEL_ZONE, MiB, ContainerPort, Node, NodeInfo, Pod, PodAffinityTerm,
-                      PodEquivalenceGroup, Taint, Toleration)
+                      PodEquivalenceGroup, Taint, Toleration, build_test_node, build_test_pod)
 
 SEED_BASE = 0xCA5CADE0
 MASK = (1 << 64) - 1
@@ -280,3 +280,112 @@ def fuzz(seed: int, max_groups: int = 4, max_pegs: int = 12, rich: bool = True) 
         pegs.append(pg)
     existing = [NodeInfo(_node(f"fz{seed}-old{i}", 1000, 1 * GiB, 10, {LABEL_ZONE: f"zone-{rng.below(2)}"})) for i in range(n_existing)]
     return Workload(f"fuzz{seed}", pegs, groups, existing)
+
+
+# ---------------------------------------------------------------------------------------------
+# filter-out-schedulable workloads: pending pods against the nodes already in the cluster
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class PendingWorkload:
+    name: str
+    nodes: List[NodeInfo]
+    pods: List[Pod]
+    hints: Optional[List[int]] = None        # node index per pod or -1
+    acceptable: Optional[List[int]] = None   # per node
+    break_on_failure: bool = False
+    last_index: int = 0
+
+
+def filter_out_schedulable_benchmark(n_nodes: int, n_scheduled: int, n_pending: int) -> PendingWorkload:
+    """BenchmarkFilterOutSchedulable (CA/core/podlistprocessor/filter_out_schedulable_test.go:212-300): nodes
+    2000m / 200000 B, scheduled pods 1000m / 200000 B assigned round-robin, pending pods 1000m / 2000000 B (memory
+    never fits: every pending pod stays pending — the reference runs pods x nodes Filters, its worst case)."""
+    nodes = [NodeInfo(build_test_node(f"n-{i}", 2000, 200000)) for i in range(n_nodes)]
+    for i in range(n_scheduled):
+        nodes[i % n_nodes].pods.append(build_test_pod(f"s-{i}", 1000, 200000))
+    pods = [build_test_pod(f"p-{i}", 1000, 2000000) for i in range(n_pending)]
+    return PendingWorkload(f"fos_{n_nodes}n_{n_scheduled}s_{n_pending}p", nodes, pods)
+
+
+def pending_scale(n_nodes: int, n_pending: int, n_classes: int = 32, seed: int = 1) -> PendingWorkload:
+    """A packing-heavy variant: heterogeneous half-full nodes, `n_classes` controller specs whose pods mostly DO fit."""
+    rng = SplitMix64(0x5C4ED000 + seed)
+    nodes = []
+    for i in range(n_nodes):
+        cpu = rng.pick([4000, 8000, 16000, 32000])
+        mem = rng.pick([16, 32, 64, 128]) * GiB
+        info = NodeInfo(_node(f"n-{i}", cpu, mem, 110, {LABEL_ZONE: f"zone-{i % 3}", "pool": f"p{rng.below(4)}"}))
+        for j in range(rng.below(6)):
+            info.pods.append(Pod(name=f"r-{i}-{j}", labels={"app": "running"}, requests={"cpu": rng.pick([250, 500, 1000]), "memory": rng.pick([1, 2, 4]) * GiB}))
+        nodes.append(info)
+    specs = []
+    for c in range(n_classes):
+        kw = {}
+        if rng.chance(1, 4):
+            kw["node_selector"] = {"pool": f"p{rng.below(4)}"}
+        specs.append(dict(labels={"app": f"c{c}"}, requests={"cpu": rng.pick([100, 250, 500, 1000, 2000]), "memory": rng.pick([128 * MiB, 512 * MiB, 1 * GiB, 4 * GiB])},
+                          controller_uid=f"rs-{c}", **kw))
+    pods = []
+    while len(pods) < n_pending:
+        c = rng.below(n_classes)
+        for _ in range(min(rng.pick([1, 3, 10, 40, 200]), n_pending - len(pods))):
+            pods.append(Pod(name=f"p-{len(pods)}", **{k: (dict(v) if isinstance(v, dict) else v) for k, v in specs[c].items()}))
+    return PendingWorkload(f"pending_{n_nodes}n_{n_pending}p_{n_classes}c", nodes, pods)
+
+
+def fuzz_pending(seed: int, max_nodes: int = 40, max_pods: int = 120) -> PendingWorkload:
+    """Random small filter-out-schedulable scenario inside the encoded predicate subset (hostname anti-affinity,
+    host ports, taints, selectors, unschedulable / unacceptable nodes, hints, runs of identical pods)."""
+    rng = SplitMix64(0xF1F1000 + seed)
+    n_nodes = 1 + rng.below(max_nodes) if not rng.chance(1, 8) else 60 + rng.below(140)
+    ports = [5555, 8080, 9090]
+    apps = [f"app{i}" for i in range(4)]
+    nodes = []
+    for i in range(n_nodes):
+        labels = {k: f"v{rng.below(2)}" for k in rng.sample(LABEL_KEYS[:3], rng.below(3))}
+        taints = [Taint(k, f"t{rng.below(2)}", rng.pick(["NoSchedule", "NoExecute", "PreferNoSchedule"]))
+                  for k in rng.sample(TAINT_KEYS[:2], rng.below(2))] if rng.chance(1, 3) else []
+        node = _node(f"fp{seed}-n{i}", rng.pick([500, 1000, 2000, 4000]), rng.pick([1, 2, 8]) * GiB, rng.pick([2, 5, 110]), labels, taints)
+        if rng.chance(1, 10):
+            node.unschedulable = True
+        info = NodeInfo(node)
+        for j in range(rng.below(3)):
+            p = Pod(name=f"run{i}-{j}", labels={"app": rng.pick(apps)}, requests={"cpu": rng.pick([0, 100, 300]), "memory": rng.pick([0, 128 * MiB, 512 * MiB])})
+            if rng.chance(1, 5):
+                p.host_ports = [ContainerPort(rng.pick(ports))]
+            if rng.chance(1, 6):
+                p.anti_affinity = [PodAffinityTerm(LABEL_HOSTNAME, match_labels={"app": rng.pick(apps)})]
+            info.pods.append(p)
+        nodes.append(info)
+    n_specs = 1 + rng.below(6)
+    specs = []
+    for c in range(n_specs):
+        kw = dict(labels={"app": rng.pick(apps)}, requests={"cpu": rng.pick([0, 50, 100, 250, 500, 1000]), "memory": rng.pick([0, 64 * MiB, 256 * MiB, 1 * GiB])})
+        if rng.chance(1, 3):
+            kw["tolerations"] = [Toleration(key=k, operator=rng.pick(["Exists", "Equal", ""]), value=f"t{rng.below(2)}",
+                                            effect=rng.pick(["", "NoSchedule", "NoExecute"])) for k in rng.sample(TAINT_KEYS[:2], 1 + rng.below(2))]
+            if rng.chance(1, 4):
+                kw["tolerations"].append(Toleration(operator="Exists"))
+        if rng.chance(1, 4):
+            kw["node_selector"] = {k: f"v{rng.below(2)}" for k in rng.sample(LABEL_KEYS[:3], 1)}
+        if rng.chance(1, 5):
+            kw["host_ports"] = [ContainerPort(rng.pick(ports), host_ip=rng.pick(["", "", "10.0.0.1"]), protocol=rng.pick(["", "TCP", "UDP"]))]
+        if rng.chance(1, 4):
+            kw["anti_affinity"] = [PodAffinityTerm(LABEL_HOSTNAME, match_labels={"app": rng.pick(apps)})]
+        if rng.chance(1, 2):
+            kw["controller_uid"] = f"ctrl-{c}"
+        specs.append(kw)
+    n_pods = 1 + rng.below(max_pods)
+    pods, hints = [], []
+    while len(pods) < n_pods:
+        c = rng.below(n_specs)
+        for _ in range(min(rng.pick([1, 1, 2, 5, 20, 70]), n_pods - len(pods))):
+            kw = specs[c]
+            pods.append(Pod(name=f"pend{len(pods)}", labels=dict(kw["labels"]), requests=dict(kw["requests"]),
+                            tolerations=list(kw.get("tolerations", [])), node_selector=dict(kw.get("node_selector", {})),
+                            host_ports=list(kw.get("host_ports", [])), anti_affinity=list(kw.get("anti_affinity", [])),
+                            controller_uid=kw.get("controller_uid", "")))
+            hints.append(rng.below(n_nodes) if rng.chance(1, 5) else -1)
+    acceptable = [0 if rng.chance(1, 6) else 1 for _ in range(n_nodes)] if rng.chance(1, 3) else None
+    return PendingWorkload(f"fuzz_pending{seed}", nodes, pods, hints if rng.chance(2, 3) else None, acceptable,
+                           break_on_failure=rng.chance(1, 5), last_index=rng.below(n_nodes + 2))

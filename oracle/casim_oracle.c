@@ -897,6 +897,70 @@ int orc_check_predicates(orc* o, int template_node, int pod, const char** plugin
 }
 
 /* ------------------------------------------------------------------------------------- */
+/* HintingSimulator.TrySchedulePods  (filter-out-schedulable)                              */
+/* ------------------------------------------------------------------------------------- */
+int orc_snapshot_size(const orc* o) { return o->snap.n; }
+
+/* SimilarPodsScheduling  CA/simulator/scheduling/similar_pods.go:50-97: per controller at most 10
+ * remembered (spec, labels) entries; here an entry is a pod spec id */
+typedef struct { int key; int specs[10]; int n; } similar_entry;
+
+/* TrySchedulePods  CA/simulator/scheduling/hinting_simulator.go:53-82 with
+ * tryScheduleUsingHints :86-110 and trySchedule :114-135 */
+int orc_try_schedule_pods(orc* o, int n_pods, const int32_t* pod, const int32_t* hint, const int32_t* similar_key,
+                          const uint8_t* acceptable, int break_on_failure, int* last_index, int32_t* node_out) {
+    VEC(similar_entry) memo; memset(&memo, 0, sizeof memo);
+    int scheduled = 0;
+    for (int i = 0; i < n_pods; ++i) node_out[i] = -1;
+    for (int i = 0; i < n_pods; ++i) {
+        const int p = pod[i];
+        if (p < 0 || p >= o->pods.n) { VEC_FREE(memo); return -1; }
+        int node_idx = -1;
+        /* tryScheduleUsingHints: hinted node still in the cluster, acceptable, and SchedulePod passes */
+        if (hint && hint[i] >= 0 && hint[i] < o->snap.n && (!acceptable || acceptable[hint[i]])) {
+            if (run_filters_on_node(o, p, hint[i], NULL, NULL)) node_idx = hint[i];
+        }
+        if (node_idx < 0) {
+            /* trySchedule: similar pod already found unschedulable? */
+            int similar_unschedulable = 0;
+            const int key = similar_key ? similar_key[i] : -1;
+            similar_entry* ent = NULL;
+            if (key >= 0) {
+                for (int m = 0; m < memo.n; ++m) if (memo.v[m].key == key) { ent = &memo.v[m]; break; }
+                if (ent) for (int s = 0; s < ent->n; ++s) if (ent->specs[s] == p) similar_unschedulable = 1;
+            }
+            if (!similar_unschedulable) {
+                /* SchedulePodOnAnyNodeMatching(pod, opts): every acceptable node, cyclic from lastIndex + 1 */
+                const podspec* ps = &o->pods.v[p];
+                ipa_state st; ipa_prefilter(o, ps, &st);
+                const int n = o->snap.n;
+                for (int k = 0; k < n; ++k) {
+                    const int idx = orc_last_index_at(k, 1, *last_index, n);
+                    if (idx < 0) break;
+                    const node* nd = &o->snap.v[idx];
+                    if (nd->unschedulable) continue;
+                    if (acceptable && !acceptable[idx]) continue;
+                    if (run_filter_plugins(o, ps, nd, &st, NULL, NULL)) { node_idx = idx; break; }
+                }
+                ipa_free(&st);
+                if (node_idx >= 0) *last_index = node_idx;
+                else if (key >= 0) { /* SetUnschedulable :80-97 */
+                    if (!ent) { similar_entry e; memset(&e, 0, sizeof e); e.key = key; VEC_PUSH(memo, e); ent = &memo.v[memo.n - 1]; }
+                    if (ent->n < 10) ent->specs[ent->n++] = p;
+                }
+            }
+        }
+        if (node_idx >= 0) {
+            node_add_pod(o, &o->snap.v[node_idx], p);   /* SchedulePod commits the pod to the snapshot */
+            node_out[i] = node_idx;
+            scheduled++;
+        } else if (break_on_failure) break;
+    }
+    VEC_FREE(memo);
+    return scheduled;
+}
+
+/* ------------------------------------------------------------------------------------- */
 /* expander filters                                                                        */
 /* ------------------------------------------------------------------------------------- */
 /* leastnodes.BestOptions  CA/expander/leastnodes/leastnodes.go:35-61 */

@@ -97,6 +97,21 @@ int orc_run_filters_on_snapshot_node(orc* o, int index, int pod, const char** pl
  * (plugin_runner.go:54-143); returns the matched list index or -1; updates *last_index. */
 int orc_run_filters_until_passing(orc* o, int pod, int* last_index);
 
+/* ---- HintingSimulator.TrySchedulePods  (CA/simulator/scheduling/hinting_simulator.go:53-135) ----
+ * Pending pods against the nodes ALREADY in the snapshot (filter-out-schedulable).
+ * pod[i]          pod spec of the i-th pending pod (processing order)
+ * hint[i]         snapshot index of the hinted node or -1                     (hints.go)
+ * similar_key[i]  >= 0: controller-equivalence key for SimilarPodsScheduling, -1: no controller
+ * acceptable      [snapshot size] IsNodeAcceptable per node, or NULL = every node
+ * node_out[i]     snapshot index the pod was scheduled on, -1 if it stays pending
+ * Pods are committed to the snapshot (the caller forks; see orc_snapshot_truncate). Returns the
+ * number of scheduled pods. */
+int orc_try_schedule_pods(orc* o, int n_pods, const int32_t* pod, const int32_t* hint, const int32_t* similar_key,
+                          const uint8_t* acceptable, int break_on_failure, int* last_index, int32_t* node_out);
+/* number of nodes in the snapshot; drop nodes added after `n` (Revert) — pods committed to older
+ * nodes stay, so tests build a fresh scenario per case */
+int orc_snapshot_size(const orc* o);
+
 /* ---- pieces with their own reference unit tests ----------------------------------------- */
 /* getMinLimit (threshold_based_limiter.go:45-53) */
 int64_t orc_get_min_limit(int64_t base, int64_t target);

@@ -64,4 +64,19 @@ EMU_API int32_t emu_feasibility(const casim_pegs* pegs, const casim_groups* grou
     return rc;
 }
 
+// lds_budget_bytes: as above (a tiny value forces the HBM-slab variant of K_sched)
+EMU_API int32_t emu_try_schedule_pods(const casim_pegs* classes, const casim_groups* nodes, const casim_pod_sequence* seq,
+                                      int64_t lds_budget_bytes, int32_t* node_out, int32_t* last_index_out, int32_t* n_scheduled_out,
+                                      int32_t* info_out /*[2]: runs, state in LDS*/) {
+    EmuBackend bk;
+    if (lds_budget_bytes > 0) bk.lds = (size_t)lds_budget_bytes;
+    casim::SchedulerT<EmuBackend> s(bk);
+    int32_t rc = s.init(classes, nodes, seq);
+    if (rc == CASIM_OK) rc = s.run();
+    if (rc == CASIM_OK) rc = s.fetch(node_out, last_index_out, n_scheduled_out);
+    if (info_out) { info_out[0] = s.runs(); info_out[1] = s.in_lds() ? 1 : 0; }
+    if (rc < 0) g_err = s.error();
+    return rc;
+}
+
 }  // extern "C"

@@ -151,3 +151,72 @@ def assert_matches_oracle(res: BatchResult, oracle, what=""):
 
 def dummy_existing(n: int) -> List[NodeInfo]:
     return [NodeInfo(build_test_node(f"existing-{i}", 100, 100 * 1024 * 1024, pods=10)) for i in range(n)]
+
+
+# ---------------------------------------------------------------------------------------------
+# filter-out-schedulable: TrySchedulePods on oracle / emulator / GPU
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class SchedCase:
+    nodes: List[NodeInfo]                       # the cluster snapshot, list order
+    pods: list                                  # pending pods, processing order
+    hints: Optional[Sequence[int]] = None       # node index per pod or -1
+    acceptable: Optional[Sequence[int]] = None  # per node
+    break_on_failure: bool = False
+    last_index: int = 0
+    lanes: Sequence[str] = ("cpu", "memory")
+
+
+def sched_oracle(case: SchedCase):
+    """(node_out, last_index, n_scheduled) from the object-level oracle; SimilarPods keyed by controller_uid."""
+    s = OracleScenario(lanes=case.lanes)
+    for info in case.nodes:
+        s.add_existing(info)
+    keys = {}
+    sk = [(-1 if not p.controller_uid or p.daemonset else keys.setdefault(p.controller_uid, len(keys))) for p in case.pods]
+    out = s.try_schedule_pods(case.pods, case.hints, sk, case.acceptable, case.break_on_failure, case.last_index)
+    s.close()
+    return out
+
+
+def sched_encode(case: SchedCase):
+    from kubernetes_autoscaler_amd.scheduling import encode_pending_pods
+    return encode_pending_pods(case.nodes, case.pods, case.lanes)
+
+
+def sched_emu(case: SchedCase, lds_budget=0):
+    """Product encoder + K_sched under the wave emulator: (status, node_out, last_index, n_scheduled, info)."""
+    from kubernetes_autoscaler_amd.engine import make_pod_sequence
+    L = emu_lib()
+    if not hasattr(L, "_sched_ready"):
+        L.emu_try_schedule_pods.restype = C.c_int32
+        L.emu_try_schedule_pods.argtypes = [C.POINTER(_abi.Pegs), C.POINTER(_abi.Groups), C.POINTER(_abi.PodSequence), C.c_int64,
+                                            _abi.i32p, _abi.i32p, _abi.i32p, _abi.i32p]
+        L._sched_ready = True
+    enc, pod_class = sched_encode(case)
+    seq, keep = make_pod_sequence(pod_class, case.hints, case.acceptable, case.break_on_failure, case.last_index)
+    node_out = np.full(max(len(case.pods), 1), -1, np.int32)
+    li, ns = C.c_int32(0), C.c_int32(0)
+    info = (C.c_int32 * 2)(0, 0)
+    rc = L.emu_try_schedule_pods(C.byref(enc.pegs), C.byref(enc.groups), C.byref(seq), int(lds_budget),
+                                 node_out.ctypes.data_as(_abi.i32p), C.byref(li), C.byref(ns), info)
+    assert rc >= 0, (rc, L.emu_last_error())
+    del keep
+    enc.close()
+    return rc, node_out[:len(case.pods)].copy(), li.value, ns.value, (info[0], info[1])
+
+
+def sched_gpu(case: SchedCase, ctx):
+    enc, pod_class = sched_encode(case)
+    rc, node_out, li, ns = ctx.try_schedule_pods(enc.pegs, enc.groups, pod_class, case.hints, case.acceptable,
+                                                 case.break_on_failure, case.last_index)
+    enc.close()
+    return rc, node_out.copy(), li, ns
+
+
+def assert_sched_matches(got, want, what=""):
+    rc, node_out, li, ns = got[0], got[1], got[2], got[3]
+    w_out, w_li, w_ns = want
+    assert rc == 0, f"{what}: status {rc}"
+    assert list(node_out) == list(w_out), f"{what}: node per pod\n got {list(node_out)}\n want {list(w_out)}"
+    assert (li, ns) == (w_li, w_ns), f"{what}: (lastIndex, scheduled) got {(li, ns)} want {(w_li, w_ns)}"

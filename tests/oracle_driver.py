@@ -65,6 +65,8 @@ def lib():
             "orc_check_predicates": (C.c_int, [P, C.c_int, C.c_int, cstrp, cstrp]),
             "orc_run_filters_on_snapshot_node": (C.c_int, [P, C.c_int, C.c_int, cstrp, cstrp]),
             "orc_run_filters_until_passing": (C.c_int, [P, C.c_int, C.POINTER(C.c_int)]),
+            "orc_try_schedule_pods": (C.c_int, [P, C.c_int, i32p, i32p, i32p, u8p, C.c_int, C.POINTER(C.c_int), i32p]),
+            "orc_snapshot_size": (C.c_int, [P]),
             "orc_get_min_limit": (C.c_int64, [C.c_int64, C.c_int64]),
             "orc_sng_capacity_limit": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
             "orc_cluster_capacity_limit": (C.c_int, [C.c_int, C.c_int, C.c_int]),
@@ -230,3 +232,20 @@ class OracleScenario:
         li = C.c_int(last_index)
         idx = self.L.orc_run_filters_until_passing(self.h, self.pod(pod), C.byref(li))
         return idx, li.value
+
+    def try_schedule_pods(self, pods, hints=None, similar_keys=None, acceptable=None, break_on_failure: bool = False,
+                          last_index: int = 0):
+        """HintingSimulator.TrySchedulePods against the snapshot built with add_existing(); pods are committed.
+        Returns (node_out[P], last_index, n_scheduled)."""
+        n = len(pods)
+        ids = np.array([self.pod(p) for p in pods], np.int32) if n else np.zeros(1, np.int32)
+        hn = np.full(max(n, 1), -1, np.int32) if hints is None else np.ascontiguousarray(hints, np.int32)
+        sk = np.full(max(n, 1), -1, np.int32) if similar_keys is None else np.ascontiguousarray(similar_keys, np.int32)
+        acc = None if acceptable is None else np.ascontiguousarray(acceptable, np.uint8)
+        out = np.full(max(n, 1), -1, np.int32)
+        li = C.c_int(last_index)
+        ns = self.L.orc_try_schedule_pods(self.h, n, ids.ctypes.data_as(i32p), hn.ctypes.data_as(i32p), sk.ctypes.data_as(i32p),
+                                          acc.ctypes.data_as(u8p) if acc is not None else None, int(break_on_failure), C.byref(li),
+                                          out.ctypes.data_as(i32p))
+        assert ns >= 0, ns
+        return out[:n].copy(), li.value, ns

@@ -1,0 +1,100 @@
+"""-m gpu: SURVEY §8 row f1 (filter-out-schedulable) on a real MI355X through the C ABI
+(casim_try_schedule_pods), against the CPU oracle — bit-exact node per pending pod."""
+import numpy as np
+import pytest
+
+import kubernetes_autoscaler_amd as kaa
+from harness import SchedCase, assert_sched_matches, sched_gpu, sched_oracle
+from kubernetes_autoscaler_amd.objects import NodeInfo, build_test_node, build_test_pod
+from kubernetes_autoscaler_amd.scheduling import FilterOutSchedulablePodListProcessor, HintingSimulator, UnsupportedPredicate
+from kubernetes_autoscaler_amd.workloads import _node, filter_out_schedulable_benchmark, fuzz_pending, pending_scale
+from test_oracle_golden import GOLD, golden_hinted_cases, golden_sched_case
+from test_sched_emu import case_of
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = kaa.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("case", GOLD["try_schedule_pods"]["cases"], ids=lambda c: c["name"])
+def test_golden_try_schedule_pods(ctx, case):
+    sc, names = golden_sched_case(case)
+    got = sched_gpu(sc, ctx)
+    assert {p.name: names[m] for p, m in zip(sc.pods, got[1]) if m >= 0} == case["want"]
+    assert_sched_matches(got, sched_oracle(sc), case["name"])
+
+
+@pytest.mark.parametrize("case", GOLD["pod_schedules_on_hinted_node"]["cases"], ids=lambda c: c["name"])
+def test_golden_pod_schedules_on_hinted_node(ctx, case):
+    for sc, want in golden_hinted_cases(case):
+        rc, node_out, last_index, n_sched = sched_gpu(sc, ctx)
+        assert rc == 0 and list(node_out) == want and n_sched == len(want) and last_index == 0
+
+
+def test_fuzz(ctx):
+    for seed in range(300):
+        w = fuzz_pending(seed)
+        sc = case_of(w)
+        assert_sched_matches(sched_gpu(sc, ctx), sched_oracle(sc), w.name)
+
+
+@pytest.mark.parametrize("shape", [(1, 30, 1000), (10, 300, 1000), (100, 3000, 1000), (200, 200, 60000), (1000, 1000, 12000)],
+                         ids=lambda s: f"{s[0]}n_{s[1]}s_{s[2]}p")
+def test_benchmark_filter_out_schedulable_shapes(ctx, shape):
+    """BenchmarkFilterOutSchedulable's grid at full size: every pending pod stays pending.  The oracle runs the
+    pods x nodes Filters only for the shapes it finishes in seconds; the property holds for all."""
+    w = filter_out_schedulable_benchmark(*shape)
+    sc = case_of(w)
+    rc, node_out, li, ns = sched_gpu(sc, ctx)
+    assert rc == 0 and ns == 0 and li == 0 and (node_out == -1).all() and len(node_out) == shape[2]
+    if shape[0] * shape[2] <= 200000:
+        assert_sched_matches((rc, node_out, li, ns), sched_oracle(sc), w.name)
+
+
+def test_packing_at_scale(ctx):
+    """2000 heterogeneous nodes (state in LDS or HBM), 20000 pending pods that mostly fit."""
+    w = pending_scale(2000, 20000, n_classes=32, seed=7)
+    sc = case_of(w)
+    got = sched_gpu(sc, ctx)
+    want = sched_oracle(sc)
+    assert want[2] > 10000
+    assert_sched_matches(got, want, w.name)
+    # size-independent properties: no node over-committed, pods of one spec placed in run order
+    node_out = got[1]
+    cpu = np.zeros(len(w.nodes), np.int64)
+    for p, m in zip(w.pods, node_out):
+        if m >= 0:
+            cpu[m] += p.requests["cpu"]
+    for i, info in enumerate(w.nodes):
+        used = sum(q.requests.get("cpu", 0) for q in info.pods)
+        assert used + cpu[i] <= info.node.allocatable["cpu"]
+
+
+def test_host_mirror_processor_keeps_hints(ctx):
+    """FilterOutSchedulablePodListProcessor.Process twice: the second loop iteration finds every pod on its hinted
+    node (hints survive DropOldHints once)."""
+    nodes = [NodeInfo(_node(f"n{i}", 2000, 8 << 30, 110)) for i in range(5)]
+    pods = [build_test_pod(f"p{i}", 600, 1 << 20) for i in range(17)]
+    for i, p in enumerate(pods):
+        p.priority = i % 3
+    proc = FilterOutSchedulablePodListProcessor(ctx)
+    left = proc.process(nodes, list(pods))
+    assert len(left) == 17 - 15  # 3 pods of 600m per 2000m node
+    assert all(p.priority == 0 for p in left)  # highest priority first
+    sim = proc.scheduling_simulator
+    first = {k: v for k, v in sim.hints.old.items()}
+    assert len(first) == 15
+    statuses, _ = sim.try_schedule_pods(nodes, [p for p in pods if p not in left])
+    assert {f"{s.pod.namespace}/{s.pod.name}": s.node_name for s in statuses} == first
+
+
+def test_host_mirror_delegates_unsupported(ctx):
+    from kubernetes_autoscaler_amd.objects import Pod
+    sim = HintingSimulator(ctx)
+    with pytest.raises(UnsupportedPredicate):
+        sim.try_schedule_pods([NodeInfo(build_test_node("n", 1000, 1000))], [Pod(name="s", requests={"cpu": 1}, topology_spread=True)])

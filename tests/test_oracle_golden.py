@@ -216,3 +216,49 @@ def test_least_waste():
         nmem = (C.c_int64 * n)(*[o["node"][1] for o in c["options"]])
         has = (C.c_uint8 * n)(*[1] * n)
         assert _sel(n, L.orc_least_waste, nc, rc, rm, ncpu, nmem, has) == c["want"]
+
+
+# ---- filter-out-schedulable: HintingSimulator.TrySchedulePods ------------------------
+def golden_sched_case(case):
+    """SchedCase of one TestTrySchedulePods row."""
+    from harness import SchedCase
+    names = [n["name"] for n in case["nodes"]]
+    infos = []
+    for n in case["nodes"]:
+        infos.append(NodeInfo(build_test_node(n["name"], n["cpu"], n["mem"]),
+                              [build_test_pod(p["name"], p["cpu"], p["mem"]) for p in case["scheduled"] if p["node"] == n["name"]]))
+    pods = [build_test_pod(n, c, m) for n, c, m in case["new_pods"]]
+    hints = [names.index(case.get("hints", {}).get(p.name)) if case.get("hints", {}).get(p.name) in names else -1 for p in pods]
+    acc = [1 if n in case["acceptable"] else 0 for n in names] if "acceptable" in case else None
+    return SchedCase(nodes=infos, pods=pods, hints=hints, acceptable=acc), names
+
+
+@pytest.mark.parametrize("case", GOLD["try_schedule_pods"]["cases"], ids=lambda c: c["name"])
+def test_try_schedule_pods(case):
+    from harness import sched_oracle
+    sc, names = golden_sched_case(case)
+    node_out, _, n_sched = sched_oracle(sc)
+    got = {p.name: names[m] for p, m in zip(sc.pods, node_out) if m >= 0}
+    assert got == case["want"] and n_sched == len(case["want"])
+
+
+def golden_hinted_cases(case):
+    """every rotation of the pod order of one TestPodSchedulesOnHintedNode row (the reference iterates a Go map)"""
+    from harness import SchedCase
+    G = GOLD["pod_schedules_on_hinted_node"]
+    names = case["nodes"]
+    items = list(case["pod_nodes"].items())
+    for rot in range(len(items)):
+        order = items[rot:] + items[:rot]
+        infos = [NodeInfo(build_test_node(n, G["node_cpu"], G["node_mem"])) for n in names]
+        pods = [build_test_pod(p, G["pod_cpu"], G["pod_mem"]) for p, _ in order]
+        yield SchedCase(nodes=infos, pods=pods, hints=[names.index(n) for _, n in order]), [names.index(n) for _, n in order]
+
+
+@pytest.mark.parametrize("case", GOLD["pod_schedules_on_hinted_node"]["cases"], ids=lambda c: c["name"])
+def test_pod_schedules_on_hinted_node(case):
+    from harness import sched_oracle
+    for sc, want in golden_hinted_cases(case):
+        node_out, last_index, n_sched = sched_oracle(sc)
+        assert list(node_out) == want and n_sched == len(want)
+        assert last_index == 0  # hinted placements do not move lastIndex

@@ -1,0 +1,111 @@
+"""SURVEY §8 row f1 (filter-out-schedulable): the product encoder + K_sched_static / K_sched under the wave
+emulator against the object-level CPU oracle, bit for bit (node of every pending pod, lastIndex, count).
+CPU only; the same cases run on the MI355X in test_gpu_parity.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from harness import SchedCase, assert_sched_matches, sched_emu, sched_oracle
+from kubernetes_autoscaler_amd import _abi
+from kubernetes_autoscaler_amd.objects import (LABEL_ZONE, ContainerPort, NodeInfo, Pod, PodAffinityTerm, build_test_node,
+                                               build_test_pod, with_host_port, with_pod_hostname_anti_affinity)
+from kubernetes_autoscaler_amd.workloads import _node, filter_out_schedulable_benchmark, fuzz_pending, pending_scale
+from test_oracle_golden import GOLD, golden_hinted_cases, golden_sched_case
+
+
+def case_of(w) -> SchedCase:
+    return SchedCase(nodes=w.nodes, pods=w.pods, hints=w.hints, acceptable=w.acceptable, break_on_failure=w.break_on_failure,
+                     last_index=w.last_index)
+
+
+def check(case: SchedCase, what="", lds_budgets=(0, 64)):
+    want = sched_oracle(case)
+    for lds in lds_budgets:  # 0 = node state in LDS, 64 B = forced HBM slab
+        got = sched_emu(case, lds_budget=lds)
+        assert not case.pods or not case.nodes or got[4][1] == (1 if lds == 0 else 0)
+        assert_sched_matches(got, want, f"{what} lds={lds}")
+    return want
+
+
+@pytest.mark.parametrize("case", GOLD["try_schedule_pods"]["cases"], ids=lambda c: c["name"])
+def test_golden_try_schedule_pods(case):
+    sc, names = golden_sched_case(case)
+    _, node_out, _, n_sched, _ = sched_emu(sc)
+    got = {p.name: names[m] for p, m in zip(sc.pods, node_out) if m >= 0}
+    assert got == case["want"] and n_sched == len(case["want"])
+    check(sc, case["name"])
+
+
+@pytest.mark.parametrize("case", GOLD["pod_schedules_on_hinted_node"]["cases"], ids=lambda c: c["name"])
+def test_golden_pod_schedules_on_hinted_node(case):
+    for sc, want in golden_hinted_cases(case):
+        _, node_out, last_index, n_sched, _ = sched_emu(sc)
+        assert list(node_out) == want and n_sched == len(want) and last_index == 0
+
+
+@pytest.mark.parametrize("seed", range(400))
+def test_fuzz(seed):
+    w = fuzz_pending(seed)
+    check(case_of(w), w.name)
+
+
+def test_benchmark_small_shapes():
+    # BenchmarkFilterOutSchedulable "nothing" / "small" / "medium": nothing fits, every pod stays pending
+    for n, s, p in ((1, 30, 1000), (10, 300, 1000), (100, 3000, 1000)):
+        w = filter_out_schedulable_benchmark(n, s, p)
+        node_out, li, ns = check(case_of(w), w.name, lds_budgets=(0,))
+        assert ns == 0 and li == 0 and (node_out == -1).all()
+
+
+def test_packing_many_slots():
+    # > 64 nodes (several slots per lane), runs longer than one round
+    w = pending_scale(300, 2500, n_classes=12, seed=3)
+    node_out, _, ns = check(case_of(w), w.name)
+    assert ns > 1000
+
+
+def test_round_robin_order_inside_a_run():
+    # 3 nodes with capacities 3 / 1 / 2 for the pod, lastIndex = 1 -> rotated order n2, n0, n1 per round
+    nodes = [NodeInfo(build_test_node("n0", 3000, 10**9)), NodeInfo(build_test_node("n1", 1000, 10**9)), NodeInfo(build_test_node("n2", 2000, 10**9))]
+    pods = [build_test_pod(f"p{i}", 1000, 1) for i in range(8)]
+    node_out, li, ns = check(SchedCase(nodes=nodes, pods=pods, last_index=1))
+    assert list(node_out) == [2, 0, 1, 2, 0, 0, -1, -1] and ns == 6 and li == 0
+
+
+def test_self_exclusion_across_runs():
+    # a host-port class split into two runs by another class: the second run must see the first run's pods
+    nodes = [NodeInfo(_node(f"n{i}", 4000, 10**9, 100)) for i in range(3)]
+    a = [build_test_pod(f"a{i}", 100, 1, with_host_port(8080)) for i in range(4)]
+    b = [build_test_pod("b0", 100, 1)]
+    aa = [build_test_pod(f"h{i}", 100, 1, with_pod_hostname_anti_affinity({"app": "h"})) for i in range(5)]
+    for p in aa:
+        p.labels = {"app": "h"}
+    pods = a[:2] + b + a[2:] + aa[:2] + b + aa[2:]
+    node_out, _, ns = check(SchedCase(nodes=nodes, pods=pods))
+    assert ns == 3 + 2 + 3
+
+
+def test_unsupported_predicates_are_delegated():
+    nodes = [NodeInfo(build_test_node("n0", 4000, 10**9))]
+    nodes[0].node.labels[LABEL_ZONE] = "z"
+    zone = Pod(name="z", labels={"app": "z"}, requests={"cpu": 1}, anti_affinity=[PodAffinityTerm(LABEL_ZONE, match_labels={"app": "z"})])
+    assert sched_emu(SchedCase(nodes=nodes, pods=[zone]))[0] == _abi.NG_UNSUPPORTED
+    spread = Pod(name="s", requests={"cpu": 1}, topology_spread=True)
+    assert sched_emu(SchedCase(nodes=nodes, pods=[build_test_pod("ok", 1, 1), spread]))[0] == _abi.NG_UNSUPPORTED
+    # hostname anti-affinity against a node without the hostname label cannot be expressed by node bits
+    named = NodeInfo(_node("named", 4000, 10**9, 100))
+    bare = NodeInfo(build_test_node("bare", 4000, 10**9))  # BuildTestNode sets no labels at all
+    h = build_test_pod("h", 1, 1, with_pod_hostname_anti_affinity({"app": "h"}))
+    h.labels = {"app": "h"}
+    assert sched_emu(SchedCase(nodes=[named, bare], pods=[h]))[0] == _abi.NG_UNSUPPORTED
+    assert sched_emu(SchedCase(nodes=[named], pods=[h]))[0] == 0
+
+
+def test_empty_inputs():
+    nodes = [NodeInfo(build_test_node("n0", 1000, 1000))]
+    rc, node_out, li, ns, _ = sched_emu(SchedCase(nodes=nodes, pods=[], last_index=5))
+    assert (rc, len(node_out), li, ns) == (0, 0, 5, 0)
+    rc, node_out, li, ns, _ = sched_emu(SchedCase(nodes=[], pods=[build_test_pod("p", 1, 1)], last_index=0))
+    assert (rc, list(node_out), ns) == (0, [-1], 0)
