@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""SURVEY §8 row f1 measurement: HintingSimulator.TrySchedulePods (filter-out-schedulable) on the MI355X
+(resident tables, HIP-event time of fill + K_sched_static + K_sched) next to the CPU oracle on the same inputs,
+for BenchmarkFilterOutSchedulable's grid (filter_out_schedulable_test.go:212-300) and packing-heavy variants."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import kubernetes_autoscaler_amd as kaa  # noqa: E402
+from kubernetes_autoscaler_amd import workloads  # noqa: E402
+from kubernetes_autoscaler_amd.scheduling import encode_pending_pods  # noqa: E402
+from harness import SchedCase, assert_sched_matches, sched_oracle  # noqa: E402
+
+ORACLE_CHECK_LIMIT = float(os.environ.get("CASIM_ORACLE_CHECK_LIMIT", 6e7))  # pods x nodes the oracle is asked to walk
+
+ctx = kaa.Context(0)
+cases = [workloads.filter_out_schedulable_benchmark(*s) for s in ((1, 30, 1000), (10, 300, 1000), (100, 3000, 1000), (200, 200, 60000), (1000, 1000, 12000))]
+cases += [workloads.pending_scale(1000, 12000, 32, 1), workloads.pending_scale(5000, 50000, 64, 2), workloads.pending_scale(15000, 150000, 128, 3)]
+for w in cases:
+    t0 = time.perf_counter(); enc, pod_class = encode_pending_pods(w.nodes, w.pods); t_enc = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rc, node_out, li, ns = ctx.try_schedule_pods(enc.pegs, enc.groups, pod_class, w.hints, w.acceptable, w.break_on_failure, w.last_index)
+    t_call = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rc, node_out, li, ns = ctx.try_schedule_pods(enc.pegs, enc.groups, pod_class, w.hints, w.acceptable, w.break_on_failure, w.last_index)
+    t_call2 = time.perf_counter() - t0
+    _, ms = ctx.try_schedule_pods(enc.pegs, enc.groups, pod_class, w.hints, w.acceptable, w.break_on_failure, w.last_index, time_iters=20)
+    rec = {"workload": w.name, "nodes": len(w.nodes), "pending": len(w.pods), "classes": int(enc.pegs.n_pegs), "scheduled": int(ns),
+           "gpu_kernels_ms": ms, "gpu_call_ms_cold": t_call * 1e3, "gpu_call_ms": t_call2 * 1e3, "encode_ms": t_enc * 1e3,
+           "pods_per_s_kernels": len(w.pods) / (ms * 1e-3)}
+    if len(w.nodes) * len(w.pods) <= ORACLE_CHECK_LIMIT:
+        sc = SchedCase(nodes=w.nodes, pods=w.pods, hints=w.hints, acceptable=w.acceptable, break_on_failure=w.break_on_failure, last_index=w.last_index)
+        t0 = time.perf_counter(); want = sched_oracle(sc); t_orc = time.perf_counter() - t0
+        assert_sched_matches((rc, node_out, li, ns), want, w.name)
+        rec.update(oracle_ms=t_orc * 1e3, parity="bit-exact")
+    print(json.dumps(rec), flush=True)
+    enc.close()
+ctx.close()
