@@ -18,6 +18,7 @@
 #include <string.h>
 #define CS_GLOBAL
 #define CS_DEVICE inline
+#define CS_HOST_DEVICE inline
 #define CS_RESTRICT
 #define CS_LAUNCH_BOUNDS(t, w)
 #include "casim_emu.h"  // tests/emu (add -Itests/emu); test infrastructure only
@@ -49,6 +50,7 @@ CS_DEVICE double bits_double(uint64_t u) { double d; memcpy(&d, &u, 8); return d
 #include <hip/hip_runtime.h>
 #define CS_GLOBAL __global__
 #define CS_DEVICE __device__ __forceinline__
+#define CS_HOST_DEVICE __host__ __device__ inline
 #define CS_RESTRICT __restrict__
 #define CS_LAUNCH_BOUNDS(t, w) __launch_bounds__(t, w)
 namespace cs {

@@ -10,12 +10,16 @@
 //   K_sched_static  grid (ceil(N/64), C): one wave = 64 nodes x one pod class; the state-independent
 //                   Filters (TaintToleration, NodeAffinity / nodeSelector, NodeUnschedulable) as one
 //                   ballot word per (class, 64 nodes).  Fully parallel, streams the mask tables once.
-//   K_sched         ONE wavefront; node m lives in lane (m & 63), slot (m >> 6), state (free resources,
-//                   free pod slots, node-local exclusion bits) in LDS or an HBM slab.  The host folds
-//                   consecutive pods of one class without hints into a run (class, k); a run is the
-//                   closed form of k consecutive cyclic first-fits (the a2 form of casim_pack.h: after t
-//                   full rounds node j holds min(c_j, t) pods; bisection on S(T) = sum_j min(c_j, T)),
-//                   plus a per-round pass that names the node of every pod of the run.
+//   K_sched         ONE workgroup of T = 64..1024 threads (the pass is one sequential process); node m is owned by
+//                   thread m % T, chunk m / T, its state (free resources, free pod slots, node-local exclusion
+//                   bits) lives in LDS, or in an HBM slab when the cluster outgrows 160 KB.  The host folds
+//                   consecutive pods of one class without hints into a run (class, k).  A run walks the nodes in
+//                   cyclic order, T at a time: every fitting node takes one pod (block-wide rank = LDS prefix of
+//                   the per-wave ballot counts) and the walk stops as soon as the k pods are placed — like the
+//                   reference, a pod that fits nearby never looks at the rest of the cluster.  Only when the whole
+//                   cluster was walked and pods are left do rounds 2.. run, in the closed form of casim_pack.h's
+//                   a2 (after t more rounds node j holds min(c'_j, t) more pods; bisection on
+//                   S(t) = sum_j min(c'_j, t) with block-wide sums), one walk per round naming the node of every pod.
 //
 // SimilarPodsScheduling (similar_pods.go:38-98) only memoises "a pod with this spec found no node"; the
 // snapshot only fills up during the pass, so a class that failed once fails again whether or not the
@@ -44,10 +48,6 @@ struct SchedArgs {
     char* gstate;               // HBM slab (global variant) or null
 };
 
-inline int64_t casim_sched_state_bytes(int R, int Wx, int64_t cap, int memo_classes) {
-    return cap * (8ll * R + 8ll * Wx + 12ll) + 2ll * 8ll * (cap / 64) + 4ll * ((memo_classes + 31) / 32) + 64;
-}
-
 CS_GLOBAL void fill_i32_kernel(int32_t* p, int64_t n, int32_t v) {
     const int64_t i = (int64_t)cs::bid() * cs::nthreads() + cs::tid();
     if (i < n) p[i] = v;
@@ -63,27 +63,96 @@ CS_GLOBAL void sched_static_kernel(DevTables t, uint64_t* CS_RESTRICT fbits, int
     if (cs::lane() == 0) fbits[(int64_t)c * S + cs::bid()] = b;
 }
 
+// Workgroup-wide collectives of K_sched: every value they return is identical in all waves of the block.
+// Double-buffered LDS cells: a cell is rewritten two collectives later, i.e. after a barrier that every wave
+// reaches only once it has read the previous content.
+struct BlockCtl {
+    uint64_t* red;    // [2][16]
+    uint32_t* tab;    // [2][16]
+    uint32_t* slot;   // [2]
+    int W, wave, lane;
+    int ph_red, ph_tab, ph_slot;
+
+    // per-wave counts -> (block total, sum over the waves before mine)
+    CS_DEVICE void count_prefix(uint32_t wave_count, uint32_t& total, uint32_t& before) {
+        if (W == 1) { total = wave_count; before = 0; return; }
+        uint32_t* tb = tab + ph_tab * 16;
+        if (lane == 0) tb[wave] = wave_count;
+        cs::sync();
+        const uint32_t v = lane < W ? tb[lane] : 0u;
+        total = cs::wave_sum_u32(v);
+        before = cs::wave_sum_u32(lane < wave ? v : 0u);
+        ph_tab ^= 1;
+    }
+    CS_DEVICE uint64_t sum(uint64_t lane_value) {
+        const uint64_t w = cs::wave_sum_u64(lane_value);
+        if (W == 1) return w;
+        uint64_t* rb = red + ph_red * 16;
+        if (lane == 0) rb[wave] = w;
+        cs::sync();
+        const uint64_t r = cs::wave_sum_u64(lane < W ? rb[lane] : 0ull);
+        ph_red ^= 1;
+        return r;
+    }
+    CS_DEVICE uint32_t max(uint32_t lane_value) {
+        const uint32_t w = cs::wave_max_u32(lane_value);
+        if (W == 1) return w;
+        uint64_t* rb = red + ph_red * 16;
+        if (lane == 0) rb[wave] = w;
+        cs::sync();
+        const uint32_t r = cs::wave_max_u32(lane < W ? (uint32_t)rb[lane] : 0u);
+        ph_red ^= 1;
+        return r;
+    }
+    // value of the (at most one) thread with `mine`; `fallback` when no thread has it
+    CS_DEVICE uint32_t pick(bool mine, uint32_t v, uint32_t fallback) {
+        uint32_t* s = slot + ph_slot;
+        if (cs::tid() == 0) *s = fallback;
+        cs::sync();
+        if (mine) *s = v;
+        cs::sync();
+        const uint32_t r = *s;
+        ph_slot ^= 1;
+        return r;
+    }
+};
+
+CS_HOST_DEVICE int64_t casim_sched_ctrl_bytes(int memo_classes) {
+    return 2 * 16 * 8 + 2 * 16 * 4 + 16 + ((4ll * ((memo_classes + 31) / 32) + 7) & ~7ll);
+}
+inline int64_t casim_sched_state_bytes(int R, int Wx, int64_t cap) {
+    return cap * (8ll * R + 8ll * Wx + 12ll) + 2ll * 8ll * (cap / 64);
+}
+
+// One workgroup of T = 64..1024 threads; node m is owned by thread (m % T), chunk (m / T).
 template <bool kLds>
-CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void sched_kernel(DevTables t, SchedArgs a) {
+CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) {
     using Store = MemStore<kLds>;
-    const int lane = cs::lane();
+    const int tid = cs::tid(), lane = cs::lane(), wave = tid >> 6;
+    const int T = cs::nthreads();
     const int R = t.R, Wx = t.Wx, N = a.N;
-    const int S = a.cap >> 6;
+    const int Q = a.cap / T;  // chunks
+    char* smem = cs::dyn_smem();
+    BlockCtl bc;
+    bc.red = (uint64_t*)smem;
+    bc.tab = (uint32_t*)(bc.red + 32);
+    bc.slot = bc.tab + 32;
+    bc.W = T >> 6; bc.wave = wave; bc.lane = lane; bc.ph_red = bc.ph_tab = bc.ph_slot = 0;
+    uint32_t* memo = bc.slot + 4;  // [ceil(memo_classes / 32)] class found no node
     Store st;
     st.R = R; st.Wx = Wx; st.cap = a.cap;
-    char* base = kLds ? cs::dyn_smem() : a.gstate;
+    char* base = kLds ? smem + casim_sched_ctrl_bytes(a.memo_classes) : a.gstate;
     st.sfree = (int64_t*)base;
     st.sexcl = (uint64_t*)(st.sfree + (int64_t)R * st.cap);
-    uint64_t* scanb = st.sexcl + (int64_t)Wx * st.cap;  // [S] acceptable && !Spec.Unschedulable
-    uint64_t* accb = scanb + S;                          // [S] acceptable
-    st.sslots = (int32_t*)(accb + S);
+    uint64_t* scanb = st.sexcl + (int64_t)Wx * st.cap;  // [cap / 64] acceptable && !Spec.Unschedulable
+    uint64_t* accb = scanb + (a.cap >> 6);               // [cap / 64] acceptable
+    st.sslots = (int32_t*)(accb + (a.cap >> 6));
     st.snpods = st.sslots + st.cap;
     st.sctmp = st.snpods + st.cap;
-    uint32_t* memo = (uint32_t*)(st.sctmp + st.cap);     // [ceil(memo_classes / 32)] class found no node
 
     // ---- prologue: node state = what the running pods of each node hold (NodeInfo.Requested, types.go) ----
-    for (int s = 0; s < S; ++s) {
-        const int m = s * 64 + lane;
+    for (int q = 0; q < Q; ++q) {
+        const int m = q * T + tid;
         const bool live = m < N;
         for (int r = 0; r < R; ++r) st.sfree[(int64_t)r * st.cap + m] = live ? t.alloc[(int64_t)m * R + r] - t.init_req[(int64_t)m * R + r] : 0;
         for (int w = 0; w < Wx; ++w) st.sexcl[(int64_t)w * st.cap + m] = live ? t.init_excl[(int64_t)m * Wx + w] : 0ull;
@@ -92,11 +161,11 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void sched_kernel(DevTables t, SchedArgs a) {
         st.sctmp[m] = 0;
         const bool acc = live && (a.acceptable == nullptr || a.acceptable[m] != 0);
         const uint64_t ab = cs::ballot(acc);
-        const uint64_t sb = cs::ballot(acc && !(t.gflags[m < N ? m : 0] & CASIM_NG_UNSCHEDULABLE));
-        if (lane == 0) { accb[s] = ab; scanb[s] = sb; }
+        const uint64_t sb = cs::ballot(acc && !(t.gflags[live ? m : 0] & CASIM_NG_UNSCHEDULABLE));
+        if (lane == 0) { accb[m >> 6] = ab; scanb[m >> 6] = sb; }
     }
-    for (int i = lane; i < (a.memo_classes + 31) / 32; i += 64) memo[i] = 0u;
-    if (kLds) cs::sync();
+    for (int i = tid; i < (a.memo_classes + 31) / 32; i += T) memo[i] = 0u;
+    cs::sync();
 
     int32_t last_index = a.last_index;
     int32_t scheduled = 0;
@@ -128,133 +197,161 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void sched_kernel(DevTables t, SchedArgs a) {
             pv.xmark = t.xmark + (int64_t)c * Wx;
             bool selfx = (t.pflags[c] & CASIM_PEG_SELF_EXCL_NODE) != 0;
             for (int w = 0; w < Wx; ++w) selfx |= (pv.xblock[w] & pv.xmark[w]) != 0;
-            const uint64_t* fb = a.fbits + (int64_t)c * S;
+            const uint64_t* fb = a.fbits + (int64_t)c * (a.cap >> 6);
             int32_t placed = 0;
 
             // ---- tryScheduleUsingHints (:86-110): RunFiltersOnNode on the hinted node, no lastIndex update ----
             if (hint >= 0 && hint < N) {
-                const int hs = hint >> 6, owner = hint & 63;
-                uint32_t ch = 0;
-                if (((fb[hs] & accb[hs]) >> owner) & 1ull) {
-                    if (lane == owner) ch = st.capacity(hs, hint, pv, 1u, false);
-                    ch = cs::bcast_u32(ch, owner);
-                }
-                if (ch > 0) {
-                    if (lane == owner) st.commit(hs, hint, 1u, pv);
-                    if (lane == 0) a.node_out[first] = hint;
-                    placed = 1;
+                if (((fb[hint >> 6] & accb[hint >> 6]) >> (hint & 63)) & 1ull) {
+                    const bool owner = tid == hint % T;
+                    uint32_t ch = 0;
+                    if (owner) ch = st.capacity(0, hint, pv, 1u, false);
+                    if (bc.pick(owner, ch, 0u) > 0) {
+                        if (owner) { st.commit(0, hint, 1u, pv); a.node_out[first] = hint; }
+                        placed = 1;
+                    }
                 }
             }
 
-            // ---- trySchedule (:114-135): memo, then the closed form of `cnt - placed` cyclic first-fits ----
+            // ---- trySchedule (:114-135): memo, then `cnt - placed` consecutive cyclic first-fits in closed form ----
             const uint32_t keff = (uint32_t)(cnt - placed);
             const bool memo_hit = c < a.memo_classes && ((memo[c >> 5] >> (c & 31)) & 1u);
             if (keff > 0 && !memo_hit) {
-                const uint64_t cap1 = (uint64_t)keff + 1;
-                auto wsum = [&](uint64_t v) -> uint64_t {
-                    if (v > cap1) v = cap1;
-                    return cap1 <= (1ull << 25) ? (uint64_t)cs::wave_sum_u32((uint32_t)v) : cs::wave_sum_u32_wide((uint32_t)v);
+                // The cyclic order starts at m0 = (lastIndex + 1) % N.  Pieces of T nodes in that order: chunk q0 from
+                // m0 on, the following chunks (wrapping), and last the part of chunk q0 below m0.
+                int32_t m0 = (int32_t)(((int64_t)last_index + 1) % N);
+                if (m0 < 0) m0 += N;
+                const int q0 = m0 / T;
+                const bool wrap_piece = (m0 % T) != 0;
+                const int P = Q + (wrap_piece ? 1 : 0);
+                auto piece_node = [&](int p, int& m, bool& valid) {
+                    int q = p < Q ? q0 + p : q0;
+                    if (q >= Q) q -= Q;
+                    m = q * T + tid;
+                    valid = m < N && (p != 0 || m >= m0) && (p != Q || m < m0);
                 };
-                // pass A: capacities c_j of the schedulable, acceptable, statically passing nodes
-                int32_t n1 = 0;
-                for (int s = 0; s < S; ++s) {
-                    const int m = s * 64 + lane;
-                    const uint64_t elig = fb[s] & scanb[s];  // wave-uniform
+                // Round 1, fused with the capacity pass: walking the pieces in cyclic order, every fitting node takes one
+                // pod until the run is exhausted — then the walk stops early (the reference would not look further
+                // either); c' = c - 1 is what later rounds may still use.
+                uint32_t cum = 0;
+                int32_t pod_base = first + placed;
+                uint32_t last_owner_val = 0;
+                bool last_mine = false;
+                for (int p = 0; p < P; ++p) {
+                    int m; bool valid;
+                    piece_node(p, m, valid);
                     uint32_t cj = 0;
-                    if (elig) {
-                        if ((elig >> lane) & 1ull) cj = st.capacity(s, m, pv, keff, selfx);
-                        n1 += cs::popc64(cs::ballot(cj > 0));
+                    if (valid && (((fb[m >> 6] & scanb[m >> 6]) >> lane) & 1ull)) cj = st.capacity(0, m, pv, keff, selfx);
+                    const bool fit = cj > 0;
+                    const uint64_t b = cs::ballot(fit);
+                    uint32_t tot_p, before;
+                    bc.count_prefix((uint32_t)cs::popc64(b), tot_p, before);
+                    const uint32_t rank = cum + before + (uint32_t)cs::mbcnt(b);
+                    const bool gets = fit && rank < keff;
+                    if (gets) { a.node_out[pod_base + (int32_t)rank] = m; st.commit(0, m, 1u, pv); }
+                    if (valid) st.set_c(0, m, gets ? cj - 1u : 0u);
+                    if (tot_p > 0) {  // every thread re-evaluates: only the owner in the LAST placing piece stays flagged
+                        const uint32_t upto = cum + tot_p < keff ? cum + tot_p : keff;
+                        last_mine = gets && rank == upto - 1u;
+                        if (last_mine) last_owner_val = (uint32_t)m;
                     }
-                    st.set_c(s, m, cj);
+                    cum += tot_p;
+                    if (cum >= keff) break;
                 }
-                if (n1 > 0) {
-                    uint32_t T, Rr;
-                    int32_t got;
-                    if ((uint32_t)n1 > keff) { T = 0; Rr = keff; got = (int32_t)keff; }
-                    else {
-                        uint64_t lane_sum = 0;
-                        uint32_t lane_max = 0;
-                        for (int s = 0; s < S; ++s) {
-                            const uint32_t cj = st.get_c(s, s * 64 + lane);
-                            lane_sum += cj;
-                            lane_max = cj > lane_max ? cj : lane_max;
-                        }
-                        const uint64_t tot = wsum(lane_sum);
-                        const uint32_t cmax = cs::wave_max_u32(lane_max);
-                        if (tot <= keff) { T = cmax; Rr = 0; got = (int32_t)tot; }
+                if (cum > 0) {
+                    // MarkMatch (plugin_runner.go:138): lastIndex = node of the last pod placed so far
+                    last_index = (int32_t)bc.pick(last_mine, last_owner_val, (uint32_t)last_index);
+                    placed += (int32_t)(cum < keff ? cum : keff);
+                }
+                if (cum > 0 && cum < keff) {
+                    // ---- the whole cluster was walked and pods are left: rounds 2.. over c' in closed form ----
+                    const uint32_t rem = keff - cum;
+                    pod_base += (int32_t)cum;
+                    uint64_t lane_sum = 0;
+                    uint32_t lane_max = 0;
+                    for (int q = 0; q < Q; ++q) {
+                        const int m = q * T + tid;
+                        const uint32_t cj = m < N ? st.get_c(0, m) : 0u;
+                        lane_sum += cj;
+                        lane_max = cj > lane_max ? cj : lane_max;
+                    }
+                    const uint64_t tot = bc.sum(lane_sum);
+                    if (tot > 0) {
+                        const uint32_t cmax = bc.max(lane_max);
+                        uint32_t Tn, Rr;
+                        int32_t got;
+                        if (tot <= rem) { Tn = cmax; Rr = 0; got = (int32_t)tot; }
                         else {
-                            uint32_t lo = 1, hi = cmax; uint64_t slo = (uint64_t)n1;  // S(lo) <= keff < S(hi)
+                            // largest Tn with S(Tn) = sum_j min(c'_j, Tn) <= rem; S(0) = 0 <= rem < S(cmax) = tot
+                            uint32_t lo = 0, hi = cmax; uint64_t slo = 0;
                             while (hi - lo > 1) {
                                 const uint32_t mid = lo + ((hi - lo) >> 1);
                                 uint64_t ls = 0;
-                                for (int s = 0; s < S; ++s) {
-                                    const uint32_t cj = st.get_c(s, s * 64 + lane);
+                                for (int q = 0; q < Q; ++q) {
+                                    const int m = q * T + tid;
+                                    const uint32_t cj = m < N ? st.get_c(0, m) : 0u;
                                     ls += cj < mid ? cj : mid;
                                 }
-                                const uint64_t sm = wsum(ls);
-                                if (sm <= keff) { lo = mid; slo = sm; } else hi = mid;
+                                const uint64_t sm = bc.sum(ls);
+                                if (sm <= rem) { lo = mid; slo = sm; } else hi = mid;
                             }
-                            T = lo; Rr = keff - (uint32_t)slo; got = (int32_t)keff;
+                            Tn = lo; Rr = rem - (uint32_t)slo; got = (int32_t)rem;
                         }
-                    }
-                    const uint32_t Tf = Rr > 0 ? T + 1 : T;
-                    const int32_t m0 = (int32_t)(((int64_t)last_index + 1) % N);  // rotated order starts here
-                    // one pass per round t: the nodes with c_j >= t, in rotated order, take the round's pods
-                    // (pod index = pods of earlier rounds + rotated rank); the last round also commits
-                    int32_t pod_base = first + placed;
-                    int32_t new_last = last_index;
-                    for (uint32_t tr = 1; tr <= Tf; ++tr) {
-                        const bool partial = Rr > 0 && tr == Tf;
-                        const bool lastr = tr == Tf;
-                        int32_t A = 0, Tot = 0;
-                        for (int s = 0; s < S; ++s) {
-                            const uint64_t b = cs::ballot(st.get_c(s, s * 64 + lane) >= tr);
-                            Tot += cs::popc64(b);
-                            A += cs::popc64(b & cs::low_mask(m0 - s * 64));
-                        }
-                        const int32_t take = partial ? (int32_t)Rr : Tot;
-                        int32_t basec = 0;
-                        for (int s = 0; s < S; ++s) {
-                            const int m = s * 64 + lane;
-                            const uint32_t cj = st.get_c(s, m);
-                            const bool cand = cj >= tr;
-                            const uint64_t b = cs::ballot(cand);
-                            if (b || lastr) {  // wave-uniform
-                                const int32_t pex = basec + cs::mbcnt(b);
-                                const int32_t rot = m >= m0 ? pex - A : (Tot - A) + pex;
-                                const bool gets = cand && rot < take;
-                                if (gets) a.node_out[pod_base + rot] = m;
+                        const uint32_t Tf = Rr > 0 ? Tn + 1 : Tn;
+                        // one walk per round: the nodes with c' >= tr, in cyclic order, take the round's pods (pod index =
+                        // pods of earlier rounds + rank); the last walk also commits
+                        last_mine = false;
+                        for (uint32_t tr = 1; tr <= Tf; ++tr) {
+                            const bool partial = Rr > 0 && tr == Tf;
+                            const bool lastr = tr == Tf;
+                            uint32_t cumr = 0;
+                            for (int p = 0; p < P; ++p) {
+                                int m; bool valid;
+                                piece_node(p, m, valid);
+                                const uint32_t cj = valid ? st.get_c(0, m) : 0u;
+                                const bool cand = cj >= tr;
+                                const uint64_t b = cs::ballot(cand);
+                                uint32_t tot_p, before;
+                                bc.count_prefix((uint32_t)cs::popc64(b), tot_p, before);
+                                const uint32_t rank = cumr + before + (uint32_t)cs::mbcnt(b);
+                                const bool gets = cand && (!partial || rank < Rr);
+                                if (gets) a.node_out[pod_base + (int32_t)rank] = m;
                                 if (lastr) {
-                                    const uint64_t hit = cs::ballot(gets && rot == take - 1);
-                                    if (hit) new_last = s * 64 + cs::ffs64(hit);
-                                    const uint32_t x = (cj < T ? cj : T) + ((partial && gets) ? 1u : 0u);
-                                    if (x > 0) st.commit(s, m, x, pv);
+                                    if (tot_p > 0 && (!partial || cumr < Rr)) {  // this piece takes pods of the last round
+                                        uint32_t upto = cumr + tot_p;
+                                        if (partial && upto > Rr) upto = Rr;
+                                        last_mine = gets && rank == upto - 1u;
+                                        if (last_mine) last_owner_val = (uint32_t)m;
+                                    }
+                                    const uint32_t x = (cj < Tn ? cj : Tn) + ((partial && gets) ? 1u : 0u);
+                                    if (x > 0) st.commit(0, m, x, pv);
                                 }
-                                basec += cs::popc64(b);
+                                cumr += tot_p;
                             }
+                            pod_base += (int32_t)(partial ? Rr : cumr);
                         }
-                        pod_base += take;
+                        last_index = (int32_t)bc.pick(last_mine, last_owner_val, (uint32_t)last_index);
+                        placed += got;
                     }
-                    last_index = new_last;
-                    placed += got;
                 }
             }
             scheduled += placed;
             if (placed < cnt) {
                 // SetUnschedulable (:127); breakOnFailure (:79-81)
-                if (c < a.memo_classes && lane == 0) memo[c >> 5] |= 1u << (c & 31);
-                if (kLds) cs::sync();
+                if (c < a.memo_classes && tid == 0) memo[c >> 5] |= 1u << (c & 31);
+                cs::sync();
                 if (a.break_on_failure) stop = true;
             }
         }
     }
-    if (lane == 0) {
+    if (tid == 0) {
         a.out[0] = last_index;
         a.out[1] = scheduled;
         a.out[2] = runs_done;
         a.out[3] = 0;
     }
 }
+
 
 // ---- host side: one TrySchedulePods call ------------------------------------------------------------
 template <class BK>
@@ -316,7 +413,9 @@ public:
         dt_.taint = up(g->taint_mask, N * dt_.Wt); dt_.label = up(g->label_mask, N * dt_.Wl);
         dt_.init_excl = up(g->init_excl, N * dt_.Wx);
 
-        cap_ = (int32_t)round_up64_((int64_t)N_);
+        // one workgroup: 64..1024 threads, node m -> thread m % T, chunk m / T
+        threads_ = (int)(round_up64_((int64_t)N_) < 1024 ? round_up64_((int64_t)N_) : 1024);
+        cap_ = (int32_t)(((int64_t)N_ + threads_ - 1) / threads_ * threads_);
         S_ = cap_ >> 6;
         a_.N = N_; a_.C = C_; a_.n_runs = n_runs_; a_.break_on_failure = q->break_on_failure ? 1 : 0;
         // lastIndex of a list that shrank since the last loop: any value is a valid cyclic origin
@@ -329,9 +428,9 @@ public:
         a_.fbits = d_fbits_;
         a_.node_out = (int32_t*)dalloc(4 * P);
         a_.out = (int32_t*)dalloc(16);
-        const int64_t bytes = casim_sched_state_bytes(R, dt_.Wx, cap_, a_.memo_classes);
-        smem_ = (size_t)bytes;
-        lds_ = bytes <= (int64_t)bk_.lds_budget();
+        const int64_t ctrl = casim_sched_ctrl_bytes(a_.memo_classes), bytes = casim_sched_state_bytes(R, dt_.Wx, cap_);
+        lds_ = ctrl + bytes <= (int64_t)bk_.lds_budget();
+        smem_ = (size_t)(lds_ ? ctrl + bytes : ctrl);
         if (!lds_) a_.gstate = (char*)dalloc((size_t)bytes);
         bk_.sync();  // the run tables above are locals: the uploads must have left them
         if (!bk_.ok()) return fail(CASIM_ERR_HIP, bk_.error());
@@ -344,8 +443,8 @@ public:
         if (!ready_) return fail(CASIM_ERR_INVALID, "scheduler not initialised");
         bk_.launch(fill_i32_kernel, (P_ + 255) / 256, 1, 256, (size_t)0, a_.node_out, (int64_t)P_, (int32_t)-1);
         if (C_ > 0) bk_.launch(sched_static_kernel, S_, C_, 64, (size_t)0, dt_, d_fbits_, S_);
-        if (lds_) bk_.launch(sched_kernel<true>, 1, 1, 64, smem_, dt_, a_);
-        else bk_.launch(sched_kernel<false>, 1, 1, 64, (size_t)0, dt_, a_);
+        if (lds_) bk_.launch(sched_kernel<true>, 1, 1, threads_, smem_, dt_, a_);
+        else bk_.launch(sched_kernel<false>, 1, 1, threads_, smem_, dt_, a_);
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
     }
 
@@ -367,6 +466,7 @@ public:
 
     const std::string& error() const { return err_; }
     int runs() const { return n_runs_; }
+    int threads() const { return threads_; }
     bool in_lds() const { return lds_; }
 
 private:
@@ -388,7 +488,7 @@ private:
 
     BK& bk_;
     DevTables dt_; SchedArgs a_;
-    int C_ = 0, N_ = 0, P_ = 0, S_ = 0;
+    int C_ = 0, N_ = 0, P_ = 0, S_ = 0, threads_ = 64;
     int32_t cap_ = 0, n_runs_ = 0, last_index_ = 0;
     bool ready_ = false, trivial_ = false, lds_ = true;
     size_t smem_ = 0;

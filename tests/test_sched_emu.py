@@ -109,3 +109,39 @@ def test_empty_inputs():
     assert (rc, len(node_out), li, ns) == (0, 0, 5, 0)
     rc, node_out, li, ns, _ = sched_emu(SchedCase(nodes=[], pods=[build_test_pod("p", 1, 1)], last_index=0))
     assert (rc, list(node_out), ns) == (0, [-1], 0)
+
+
+def _pool_cluster(n_nodes, every, cpu=4000):
+    nodes = []
+    for i in range(n_nodes):
+        nd = _node(f"n{i}", cpu if i % 3 else cpu // 2, 10**9, 110, {"pool": "a" if i % every == 0 else "b"})
+        nodes.append(NodeInfo(nd))
+    return nodes
+
+
+def _pool_pods(prefix, n, cpu, pool=None):
+    return [Pod(name=f"{prefix}{i}", labels={"app": prefix}, requests={"cpu": cpu, "memory": 1}, node_selector={"pool": pool} if pool else {},
+                controller_uid=prefix) for i in range(n)]
+
+
+@pytest.mark.parametrize("last_index", [0, 63, 1023, 1100, 2047, 2499])
+def test_several_chunks_of_1024_nodes(last_index):
+    """N > 1024: chunks of T = 1024 nodes, cyclic origin inside a chunk (wrap piece), rounds 2.. across chunks."""
+    nodes = _pool_cluster(2500, 29)
+    pods = (_pool_pods("x", 200, 500, "a")       # 87 eligible nodes: rounds with a partial last round
+            + _pool_pods("y", 3, 1500)           # three single first-fits right after the origin
+            + _pool_pods("x", 700, 500, "a")     # saturates pool a, the rest stays pending (memo afterwards)
+            + _pool_pods("z", 1500, 1000)        # fewer pods than fitting nodes: stops early
+            + _pool_pods("x", 5, 500, "a"))      # memo hit
+    hints = [-1] * len(pods)
+    hints[201] = 2400
+    hints[950] = 7
+    want = check(SchedCase(nodes=nodes, pods=pods, hints=hints, last_index=last_index), f"li={last_index}", lds_budgets=(0, 64))
+    assert want[2] > 1900
+
+
+def test_fuzz_large_clusters():
+    for seed in range(6):
+        w = pending_scale(1100 + 400 * seed, 1500, n_classes=10, seed=40 + seed)
+        w.last_index = 37 * seed * seed
+        check(case_of(w), w.name, lds_budgets=(0,) if seed % 2 else (64,))
