@@ -179,6 +179,15 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
         const int32_t my_count = have ? a.run_count[kk] : 0;
         const int32_t my_hint = have ? a.run_hint[kk] : -1;
         const int32_t my_first = have ? a.run_first[kk] : 0;
+        // the class record of run kk rides along in its lane: one round trip to HBM per 64 runs, not one per run
+        int64_t my_req[CASIM_KMAX_RES];
+        double my_rq[CASIM_KMAX_RES];
+#pragma unroll
+        for (int r = 0; r < CASIM_KMAX_RES; ++r) {
+            my_req[r] = (have && r < R) ? t.req[(int64_t)my_class * R + r] : 0;
+            my_rq[r] = my_req[r] > 0 ? 1.0 / (double)my_req[r] : 0.0;
+        }
+        const uint32_t my_flags = have ? t.pflags[my_class] : 0u;
         const int nk = a.n_runs - k0 < 64 ? a.n_runs - k0 : 64;
         for (int j = 0; j < nk && !stop; ++j) {
             const int c = (int)cs::bcast_u32((uint32_t)my_class, j);
@@ -190,12 +199,12 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
             typename Store::Peg pv;
 #pragma unroll
             for (int r = 0; r < CASIM_KMAX_RES; ++r) {
-                pv.req[r] = r < R ? t.req[(int64_t)c * R + r] : 0;
-                pv.rq[r] = pv.req[r] > 0 ? 1.0 / (double)pv.req[r] : 0.0;
+                pv.req[r] = r < R ? (int64_t)cs::bcast_u64((uint64_t)my_req[r], j) : 0;
+                pv.rq[r] = r < R ? cs::bits_double(cs::bcast_u64(cs::double_bits(my_rq[r]), j)) : 0.0;
             }
             pv.xblock = t.xblock + (int64_t)c * Wx;
             pv.xmark = t.xmark + (int64_t)c * Wx;
-            bool selfx = (t.pflags[c] & CASIM_PEG_SELF_EXCL_NODE) != 0;
+            bool selfx = (cs::bcast_u32(my_flags, j) & CASIM_PEG_SELF_EXCL_NODE) != 0;
             for (int w = 0; w < Wx; ++w) selfx |= (pv.xblock[w] & pv.xmark[w]) != 0;
             const uint64_t* fb = a.fbits + (int64_t)c * (a.cap >> 6);
             int32_t placed = 0;
