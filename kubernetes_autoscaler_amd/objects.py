@@ -88,6 +88,8 @@ class Pod:
     controller_uid: str = ""               # drain.ControllerRef(pod).UID, "" = no controller
     daemonset: bool = False                # pod_utils.IsDaemonSetPod
     priority: int = 0                      # corev1helpers.PodPriority
+    # digest of the spec fields the model does not carry (volumes after sanitization, ...): only equality matters
+    spec_extra: str = ""
 
     def spec_key(self):
         """Hashable scheduling-relevant spec + labels: two pods with equal keys are interchangeable for every
@@ -100,7 +102,7 @@ class Pod:
                 tuple((t.topology_key, tuple(sorted(t.match_labels.items())),
                        tuple((r.key, r.operator, tuple(r.values)) for r in t.match_expressions), tuple(t.namespaces))
                       for t in self.anti_affinity),
-                self.topology_spread, self.unsupported_reason, self.has_containers)
+                self.topology_spread, self.unsupported_reason, self.has_containers, self.spec_extra)
 
     def fastpath_requests(self):
         """Containers[0].Resources.Requests.{Cpu,Memory}().AsApproximateFloat64()

@@ -98,3 +98,31 @@ def test_host_mirror_delegates_unsupported(ctx):
     sim = HintingSimulator(ctx)
     with pytest.raises(UnsupportedPredicate):
         sim.try_schedule_pods([NodeInfo(build_test_node("n", 1000, 1000))], [Pod(name="s", requests={"cpu": 1}, topology_spread=True)])
+
+
+def test_schedulable_pod_groups_matrix(ctx):
+    """BuildPodGroups on the host + the PEG x node-group matrix in one device call == CheckPredicates
+    of every group exemplar on every template (oracle)."""
+    from kubernetes_autoscaler_amd import workloads
+    from kubernetes_autoscaler_amd.equivalence import build_pod_groups, schedulable_pod_groups
+    from oracle_driver import OracleScenario
+    for seed in range(40):
+        w = workloads.fuzz(7000 + seed, max_groups=6, max_pegs=24)
+        pods = []
+        for i, pg in enumerate(w.pegs):
+            for k in range(min(len(pg.pods), 3)):
+                p = pg.pods[0]
+                q = type(p)(**{**p.__dict__, "name": f"{p.name}-{k}", "controller_uid": f"ctrl{i % 5}"})
+                pods.append(q)
+        groups = build_pod_groups(pods)
+        assert sum(len(g.pods) for g in groups) == len(pods)
+        templates = {g.template.node.name: g.template for g in w.groups}
+        if any(g.pods[0].anti_affinity and g.pods[0].anti_affinity[0].topology_key != "kubernetes.io/hostname" for g in groups):
+            continue  # zone terms need the existing-cluster context of a full scenario
+        ok = schedulable_pod_groups(ctx, groups, templates)
+        s = OracleScenario()
+        for i, (name, tmpl) in enumerate(templates.items()):
+            t = s.node(tmpl)
+            for j, g in enumerate(groups):
+                assert bool(ok[i, j]) == s.check_predicates(t, g.pods[0])[0], (seed, name, j)
+        s.close()

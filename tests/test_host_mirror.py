@@ -104,3 +104,56 @@ def test_bulk_resource_pegs_equal_object_path():
     assert [a.pegs.flags[i] for i in range(n)] == [b.pegs.flags[i] for i in range(n)]
     assert [a.pegs.fp_cpu[i] for i in range(n)] == [b.pegs.fp_cpu[i] for i in range(n)]
     assert [a.pegs.fp_mem[i] for i in range(n)] == [b.pegs.fp_mem[i] for i in range(n)]
+
+
+# ---- equivalence groups (core/scaleup/equivalence/groups_test.go) ----------------------------
+def _gold():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")))["equivalence_groups"]
+
+
+def test_group_schedulable_pods_for_node():
+    from kubernetes_autoscaler_amd.equivalence import build_pod_groups, group_pods_by_scheduling_properties
+    from kubernetes_autoscaler_amd.objects import build_test_pod
+    G = _gold()["group_schedulable_pods_for_node"]
+    pods = []
+    for p in G["pods"]:
+        pod = build_test_pod(p["name"], p["cpu"], p["mem"])
+        pod.controller_uid = p.get("controller", "")
+        pod.spec_extra = p.get("spec_extra", "")
+        pods.append(pod)
+    groups = group_pods_by_scheduling_properties(pods)
+    assert sorted(sorted(q.name for q in g) for g in groups) == sorted(sorted(g) for g in G["want_groups"])
+    assert [len(g.pods) for g in build_pod_groups(pods)] == [len(g) for g in groups]
+
+
+def test_equivalence_group_size_limiting():
+    from kubernetes_autoscaler_amd.equivalence import group_pods_by_scheduling_properties
+    from kubernetes_autoscaler_amd.objects import build_test_pod
+    G = _gold()["size_limiting"]
+    pods = []
+    for i in range(G["n_pods"]):
+        p = build_test_pod(f"p{i}", G["cpu"], G["mem"])
+        p.controller_uid = G["controller"]
+        p.labels = {"uniqueLabel": f"l{i}"}
+        pods.append(p)
+    assert [len(g) for g in group_pods_by_scheduling_properties(pods)] == G["want_group_sizes"]
+    # the 11th distinct spec is not cached: a twin of it still opens its own group, a twin of the 1st joins it
+    twin_last = build_test_pod("twin-last", G["cpu"], G["mem"]); twin_last.controller_uid = G["controller"]; twin_last.labels = {"uniqueLabel": "l10"}
+    twin_first = build_test_pod("twin-first", G["cpu"], G["mem"]); twin_first.controller_uid = G["controller"]; twin_first.labels = {"uniqueLabel": "l0"}
+    sizes = [len(g) for g in group_pods_by_scheduling_properties(pods + [twin_last, twin_first])]
+    assert sizes == [2] + [1] * 11
+
+
+def test_equivalence_group_ignores_daemonsets():
+    from kubernetes_autoscaler_amd.equivalence import group_pods_by_scheduling_properties
+    from kubernetes_autoscaler_amd.objects import build_test_pod
+    G = _gold()["ignores_daemonsets"]
+    pods = []
+    for i in range(G["n_pods"]):
+        p = build_test_pod(f"p{i + 1}", G["cpu"], G["mem"])
+        p.controller_uid = G["controller"]
+        p.daemonset = True
+        pods.append(p)
+    assert len(group_pods_by_scheduling_properties(pods)) == G["want_groups"]
