@@ -59,6 +59,16 @@ class PodAffinityTerm:
 
 
 @dataclass
+class TopologySpreadConstraint:
+    """DoNotSchedule topologySpreadConstraint.  The device path delegates pods that carry one
+    (CASIM_PEG_UNSUPPORTED); the fields exist so that the shim / tests can hand them to the checker."""
+    max_skew: int
+    topology_key: str
+    min_domains: int = 0                   # 0 = nil (treated as 1)
+    match_labels: Dict[str, str] = field(default_factory=dict)
+
+
+@dataclass
 class ContainerPort:
     host_port: int
     host_ip: str = ""
@@ -82,6 +92,7 @@ class Pod:
     fastpath_mem: Optional[float] = None
     has_containers: bool = True
     topology_spread: bool = False          # outside the encoded subset -> fallback
+    spread_constraints: List[TopologySpreadConstraint] = field(default_factory=list)
     unsupported_reason: str = ""           # anything else outside the encoded subset
     # identity / ownership: only the filter-out-schedulable pass reads these (hints.go, similar_pods.go)
     uid: str = ""
@@ -102,7 +113,9 @@ class Pod:
                 tuple((t.topology_key, tuple(sorted(t.match_labels.items())),
                        tuple((r.key, r.operator, tuple(r.values)) for r in t.match_expressions), tuple(t.namespaces))
                       for t in self.anti_affinity),
-                self.topology_spread, self.unsupported_reason, self.has_containers, self.spec_extra)
+                self.topology_spread, tuple((c.max_skew, c.topology_key, c.min_domains, tuple(sorted(c.match_labels.items())))
+                                            for c in self.spread_constraints),
+                self.unsupported_reason, self.has_containers, self.spec_extra)
 
     def fastpath_requests(self):
         """Containers[0].Resources.Requests.{Cpu,Memory}().AsApproximateFloat64()
@@ -181,6 +194,7 @@ def with_max_skew(max_skew, key, min_domains):
     def f(pod):
         if max_skew > 0:
             pod.topology_spread = True
+            pod.spread_constraints = [TopologySpreadConstraint(max_skew, key, min_domains, {"app": "estimatee"})]
     return f
 
 

@@ -84,6 +84,9 @@ typedef struct { int key, op; ivec values; } requirement;
 typedef VEC(requirement) reqvec;
 typedef struct { int ip, proto, port; } hostport;
 typedef struct { int topology_key; ivec namespaces; reqvec selector; } aff_term;
+/* topologySpreadConstraint  V/.../podtopologyspread/common.go:34-41 (DoNotSchedule constraints only; nodeAffinityPolicy
+ * Honor and nodeTaintsPolicy Ignore, the defaults :108-110) */
+typedef struct { int max_skew, topology_key, min_domains; reqvec selector; int selector_set; } spread_constraint;
 
 typedef struct {
     int ns;
@@ -98,6 +101,7 @@ typedef struct {
     double fp_cpu, fp_mem;
     int fp_has_requests;
     int has_topology_spread;
+    VEC(spread_constraint) spread;
 } podspec;
 
 typedef struct {
@@ -127,6 +131,7 @@ struct orc {
     int taint_cmp_ops;
     int id_hostname, id_noschedule, id_noexecute, id_allip, id_tcp, id_empty, id_unsched_key;
     int64_t filter_runs;
+    const char* last_fail_reason; /* reason of the last failing Filter run (SchedulingError.FailingPredicateReasons) */
 };
 
 /* ------------------------------------------------------------------------------------- */
@@ -161,6 +166,8 @@ void orc_free(orc* o) {
         free_reqvec(&p->node_affinity); VEC_FREE(p->ports);
         for (int t = 0; t < p->anti_terms.n; ++t) { VEC_FREE(p->anti_terms.v[t].namespaces); free_reqvec(&p->anti_terms.v[t].selector); }
         VEC_FREE(p->anti_terms);
+        for (int c = 0; c < p->spread.n; ++c) free_reqvec(&p->spread.v[c].selector);
+        VEC_FREE(p->spread);
     }
     VEC_FREE(o->pods);
     for (int i = 0; i < o->nodes.n; ++i) node_free(&o->nodes.v[i]);
@@ -256,6 +263,25 @@ int orc_pod_fastpath_requests(orc* o, int pod, double cpu, double mem) {
     o->pods.v[pod].fp_cpu = cpu; o->pods.v[pod].fp_mem = mem; o->pods.v[pod].fp_has_requests = 1; return 0;
 }
 int orc_pod_has_topology_spread(orc* o, int pod, int flag) { PODCHK(o, pod); o->pods.v[pod].has_topology_spread = flag; return 0; }
+/* a DoNotSchedule topologySpreadConstraint; min_domains <= 0 means nil (treated as 1, common.go:107) */
+int orc_pod_spread_constraint(orc* o, int pod, int max_skew, const char* topology_key, int min_domains) {
+    PODCHK(o, pod);
+    spread_constraint c; memset(&c, 0, sizeof c);
+    c.max_skew = max_skew; c.topology_key = intern(&o->st, topology_key); c.min_domains = min_domains > 0 ? min_domains : 1;
+    VEC_PUSH(o->pods.v[pod].spread, c);
+    o->pods.v[pod].has_topology_spread = 1;
+    return o->pods.v[pod].spread.n - 1;
+}
+/* one requirement of the constraint's labelSelector (matchLabels pair == In{value}); a constraint without any
+ * requirement has an EMPTY selector, which counts nothing (countPodsMatchSelector, common.go:144-147) */
+int orc_spread_requirement(orc* o, int pod, int constraint, const char* key, const char* op, const char* const* values, int n) {
+    PODCHK(o, pod);
+    if (constraint < 0 || constraint >= o->pods.v[pod].spread.n) return -1;
+    requirement r = make_req(o, key, op, values, n);
+    VEC_PUSH(o->pods.v[pod].spread.v[constraint].selector, r);
+    o->pods.v[pod].spread.v[constraint].selector_set = 1;
+    return 0;
+}
 
 int orc_node(orc* o, const char* name, const int64_t* alloc, int allowed_pods, int64_t cap_cpu_milli, int64_t cap_mem, int unschedulable) {
     node n; memset(&n, 0, sizeof n);
@@ -393,6 +419,10 @@ static const char* PL_AFFINITY = "NodeAffinity";
 static const char* PL_PORTS = "NodePorts";
 static const char* PL_FIT = "NodeResourcesFit";
 static const char* PL_IPA = "InterPodAffinity";
+static const char* PL_PTS = "PodTopologySpread";
+/* podtopologyspread/plugin.go: ErrReasonConstraintsNotMatch / ErrReasonNodeLabelNotMatch */
+static const char* REASON_PTS_CONSTRAINTS = "node(s) didn't match pod topology spread constraints";
+static const char* REASON_PTS_LABEL = "node(s) didn't match pod topology spread constraints (missing required label)";
 
 /* Toleration.ToleratesTaint  V/api/core/v1/toleration.go:52-77 */
 static int tolerates_taint(const orc* o, const toleration* t, const taint* tn) {
@@ -545,10 +575,57 @@ static int filter_ipa(const podspec* p, const node* n, const ipa_state* s) {
     return 1;
 }
 
+/* PodTopologySpread.PreFilter = calPreFilterState  V/.../podtopologyspread/filtering.go:236-316 with the
+ * NodeInclusionPolicy feature on (default): a node contributes to constraint i when it carries EVERY topology key
+ * of the pod's constraints and matches the pod's required node affinity / selector (policy Honor); its matching
+ * pods (same namespace, selector) are added to the domain of its topology value — a domain exists even at count 0. */
+typedef struct { tpmap* counts; int n; } pts_state;
+static int filter_node_affinity(const orc* o, const podspec* p, const node* n);
+static void pts_prefilter(const orc* o, const podspec* p, pts_state* s) {
+    s->n = p->spread.n; s->counts = NULL;
+    if (s->n == 0) return;
+    s->counts = calloc((size_t)s->n, sizeof(tpmap));
+    for (int i = 0; i < o->snap.n; ++i) {
+        const node* n = &o->snap.v[i];
+        int all = 1;
+        for (int c = 0; c < s->n; ++c) { int val; if (!labels_lookup(n->labels.v, n->labels.n, p->spread.v[c].topology_key, &val)) all = 0; }
+        if (!all) continue;                                           /* nodeLabelsMatchSpreadConstraints :268 */
+        if (!filter_node_affinity(o, p, n)) continue;                 /* matchNodeInclusionPolicies, Honor */
+        for (int c = 0; c < s->n; ++c) {
+            const spread_constraint* sc = &p->spread.v[c];
+            int val = 0; labels_lookup(n->labels.v, n->labels.n, sc->topology_key, &val);
+            int64_t count = 0;
+            if (sc->selector_set)                                     /* countPodsMatchSelector common.go:143-158 */
+                for (int j = 0; j < n->pods.n; ++j) {
+                    const podspec* ep = &o->pods.v[n->pods.v[j]];
+                    if (ep->ns == p->ns && selector_matches(o, &sc->selector, ep->labels.v, ep->labels.n)) count++;
+                }
+            tpmap_add(&s->counts[c], sc->topology_key, val, count);
+        }
+    }
+}
+static void pts_free(pts_state* s) { for (int c = 0; c < s->n; ++c) VEC_FREE(s->counts[c]); free(s->counts); }
+/* PodTopologySpread.Filter  filtering.go:319-366: matchNum + selfMatch - globalMin <= maxSkew per constraint;
+ * minMatchNum :54-68 (fewer domains than minDomains => global minimum 0). Returns 0 ok, 1 constraints, 2 label. */
+static int filter_pts(const orc* o, const podspec* p, const node* n, const pts_state* s) {
+    for (int c = 0; c < s->n; ++c) {
+        const spread_constraint* sc = &p->spread.v[c];
+        int val;
+        if (!labels_lookup(n->labels.v, n->labels.n, sc->topology_key, &val)) return 2;
+        int64_t min = INT32_MAX;                                      /* newCriticalPaths: MaxInt32 */
+        for (int i = 0; i < s->counts[c].n; ++i) if (s->counts[c].v[i].count < min) min = s->counts[c].v[i].count;
+        if (s->counts[c].n < sc->min_domains) min = 0;
+        int self = sc->selector_set && selector_matches(o, &sc->selector, p->labels.v, p->labels.n) ? 1 : 0;
+        int64_t match = tpmap_get(&s->counts[c], sc->topology_key, val);
+        if (match + self - min > sc->max_skew) return 1;
+    }
+    return 0;
+}
+
 /* frameworkImpl.RunFilterPlugins in default profile order
  * V/kubernetes/pkg/scheduler/framework/runtime/framework.go:1093-1126,
  * V/kubernetes/pkg/scheduler/apis/config/v1/default_plugins.go:34-51: first failing Filter wins */
-static int run_filter_plugins(orc* o, const podspec* p, const node* n, const ipa_state* s,
+static int run_filter_plugins(orc* o, const podspec* p, const node* n, const ipa_state* s, const pts_state* ts,
                               const char** plugin, const char** reason) {
     o->filter_runs++;
     const char* dummy = NULL;
@@ -563,7 +640,12 @@ static int run_filter_plugins(orc* o, const podspec* p, const node* n, const ipa
     } else if (p->ports.n > 0 && !filter_ports(o, p, n)) {
         failed = PL_PORTS; *reason = "node(s) didn't have free ports for the requested pod ports";
     } else if (!filter_fit(o, p, n, reason)) { failed = PL_FIT; }
-    else if (!filter_ipa(p, n, s)) { failed = PL_IPA; *reason = "node(s) didn't satisfy anti-affinity rules"; }
+    else {
+        const int pts = ts ? filter_pts(o, p, n, ts) : 0;
+        if (pts) { failed = PL_PTS; *reason = pts == 1 ? REASON_PTS_CONSTRAINTS : REASON_PTS_LABEL; }
+        else if (!filter_ipa(p, n, s)) { failed = PL_IPA; *reason = "node(s) didn't satisfy anti-affinity rules"; }
+    }
+    o->last_fail_reason = failed ? *reason : NULL;
     if (failed) { if (plugin) *plugin = failed; return 0; }
     return 1;
 }
@@ -579,9 +661,10 @@ int orc_last_index_at(int i, int offset, int last_index, int n) {
 
 /* RunFiltersUntilPassingNode  CA/simulator/clustersnapshot/predicate/plugin_runner.go:54-143,
  * parallelism 1.  accept_new_only mirrors Estimate's IsNodeAcceptable (binpacking_estimator.go:172-174). */
-static int run_filters_until_passing(orc* o, int pod, int accept_new_only, int* last_index) {
+static int run_filters_until_passing_ex(orc* o, int pod, int accept_new_only, int skip_idx, int* last_index) {
     const podspec* p = &o->pods.v[pod];
     ipa_state st; ipa_prefilter(o, p, &st);
+    pts_state ts; pts_prefilter(o, p, &ts);
     int n = o->snap.n, found = -1;
     for (int i = 0; i < n; ++i) {
         int idx = orc_last_index_at(i, 1, *last_index, n);
@@ -589,18 +672,23 @@ static int run_filters_until_passing(orc* o, int pod, int accept_new_only, int* 
         const node* nd = &o->snap.v[idx];
         if (nd->unschedulable) continue;                    /* :108-110 */
         if (accept_new_only && !nd->is_new) continue;       /* :114 */
-        if (run_filter_plugins(o, p, nd, &st, NULL, NULL)) { found = idx; break; }
+        if (idx == skip_idx) continue;
+        if (run_filter_plugins(o, p, nd, &st, &ts, NULL, NULL)) { found = idx; break; }
     }
-    ipa_free(&st);
+    ipa_free(&st); pts_free(&ts);
     if (found >= 0) *last_index = found;                    /* MarkMatch :138 */
     return found;
+}
+static int run_filters_until_passing(orc* o, int pod, int accept_new_only, int* last_index) {
+    return run_filters_until_passing_ex(o, pod, accept_new_only, -1, last_index);
 }
 /* RunFiltersOnNode  plugin_runner.go:146-181 */
 static int run_filters_on_node(orc* o, int pod, int idx, const char** plugin, const char** reason) {
     const podspec* p = &o->pods.v[pod];
     ipa_state st; ipa_prefilter(o, p, &st);
-    int ok = run_filter_plugins(o, p, &o->snap.v[idx], &st, plugin, reason);
-    ipa_free(&st);
+    pts_state ts; pts_prefilter(o, p, &ts);
+    int ok = run_filter_plugins(o, p, &o->snap.v[idx], &st, &ts, plugin, reason);
+    ipa_free(&st); pts_free(&ts);
     return ok;
 }
 int orc_run_filters_on_snapshot_node(orc* o, int index, int pod, const char** plugin_out, const char** reason_out) {
@@ -696,6 +784,7 @@ int orc_best_fastpath_peg(int n, const int32_t* count, const double* cpu_req, co
 /* ------------------------------------------------------------------------------------- */
 /* Estimate                                                                                */
 /* ------------------------------------------------------------------------------------- */
+typedef struct { int idx; node copy; } saved_node;
 typedef struct {
     orc* o;
     int template_node;
@@ -704,6 +793,8 @@ typedef struct {
     orc_limiter limiter;
     int last_index;         /* runner.defaultNodeOrdering.lastIndex */
     int fake_nodes;         /* fastpath fake nodes with pods */
+    int fork_len;           /* snapshot length at Fork */
+    VEC(saved_node) saved;  /* forked-snapshot nodes that received pods (hostname-spread retry only) */
     int scheduled;
     int64_t cpu_sum, mem_sum;
 } est_state;
@@ -742,6 +833,11 @@ static void add_new_node(est_state* s) {
  * then estimationState.trackScheduledPod  binpacking_estimator.go:58-61 */
 static void commit(est_state* s, int pod, int node_idx) {
     orc* o = s->o;
+    if (node_idx < s->fork_len && o->snap.v[node_idx].new_pods == 0) {
+        /* first pod of this Estimate on a node of the forked snapshot: keep the pre-fork NodeInfo for Revert */
+        saved_node sv; sv.idx = node_idx; sv.copy = node_clone(&o->snap.v[node_idx]);
+        VEC_PUSH(s->saved, sv);
+    }
     node_add_pod(o, &o->snap.v[node_idx], pod);
     o->snap.v[node_idx].new_pods++;
     s->scheduled++;
@@ -761,12 +857,23 @@ static int try_existing(est_state* s, int pod, int count) {
 }
 /* tryToScheduleOnNewNodes :190-269; returns newNodesAvailable; *placed += pods scheduled.
  * (the hostname-topology-spread retry :212-227 is outside the encoded subset) */
+static int pod_uses_hostname_spread(const orc* o, const podspec* p) {  /* isPodUsingHostNameTopologyKey :358-369 */
+    for (int c = 0; c < p->spread.n; ++c) if (p->spread.v[c].topology_key == o->id_hostname) return 1;
+    return 0;
+}
 static int try_new_nodes(est_state* s, int pod, int count, int* placed) {
     orc* o = s->o;
     for (int i = 0; i < count; ++i) {
         int found = 0;
         if (s->last_node >= 0) {
-            if (run_filters_on_node(o, pod, s->last_node, NULL, NULL)) { found = 1; commit(s, pod, s->last_node); (*placed)++; }
+            const char* reason = NULL;
+            if (run_filters_on_node(o, pod, s->last_node, NULL, &reason)) { found = 1; commit(s, pod, s->last_node); (*placed)++; }
+            else if (pod_uses_hostname_spread(o, &o->pods.v[pod]) && reason == REASON_PTS_CONSTRAINTS) {
+                /* :212-227 the last node is full for the hostname spread: any OTHER node of the snapshot — new or
+                 * already in the cluster — may take the pod (IsNodeAcceptable only excludes lastNodeName) */
+                int nd = run_filters_until_passing_ex(o, pod, 0, s->last_node, &s->last_index);
+                if (nd >= 0) { found = 1; commit(s, pod, nd); (*placed)++; }
+            }
         }
         if (!found) {
             if (s->last_node >= 0 && o->snap.v[s->last_node].new_pods == 0) return 1; /* :234-236 */
@@ -850,6 +957,7 @@ int orc_estimate(orc* o, int template_node, int n_pegs, const int32_t* peg_pod, 
 
     /* clusterSnapshot.Fork :126 */
     int fork_len = o->snap.n;
+    s.fork_len = fork_len;
 
     int more = 1;
     for (int k = 0; k < n_pegs; ++k) {
@@ -869,6 +977,8 @@ int orc_estimate(orc* o, int template_node, int n_pegs, const int32_t* peg_pod, 
         added++;
         if (o->snap.v[i].new_pods > 0) with_pods++;
     }
+    /* trackScheduledPod (:58-61) also records a node of the forked snapshot that took a pod in the retry above */
+    with_pods += s.saved.n;
     out->node_count = with_pods + s.fake_nodes;  /* len(newNodesWithPods) :160 */
     out->pods_scheduled = s.scheduled;
     out->nodes_added = added;
@@ -881,6 +991,11 @@ int orc_estimate(orc* o, int template_node, int n_pegs, const int32_t* peg_pod, 
     /* clusterSnapshot.Revert :127-129 */
     for (int i = fork_len; i < o->snap.n; ++i) node_free(&o->snap.v[i]);
     o->snap.n = fork_len;
+    for (int i = 0; i < s.saved.n; ++i) {
+        node_free(&o->snap.v[s.saved.v[i].idx]);
+        o->snap.v[s.saved.v[i].idx] = s.saved.v[i].copy;
+    }
+    VEC_FREE(s.saved);
     return 0;
 }
 
@@ -933,6 +1048,7 @@ int orc_try_schedule_pods(orc* o, int n_pods, const int32_t* pod, const int32_t*
                 /* SchedulePodOnAnyNodeMatching(pod, opts): every acceptable node, cyclic from lastIndex + 1 */
                 const podspec* ps = &o->pods.v[p];
                 ipa_state st; ipa_prefilter(o, ps, &st);
+                pts_state ts; pts_prefilter(o, ps, &ts);
                 const int n = o->snap.n;
                 for (int k = 0; k < n; ++k) {
                     const int idx = orc_last_index_at(k, 1, *last_index, n);
@@ -940,9 +1056,9 @@ int orc_try_schedule_pods(orc* o, int n_pods, const int32_t* pod, const int32_t*
                     const node* nd = &o->snap.v[idx];
                     if (nd->unschedulable) continue;
                     if (acceptable && !acceptable[idx]) continue;
-                    if (run_filter_plugins(o, ps, nd, &st, NULL, NULL)) { node_idx = idx; break; }
+                    if (run_filter_plugins(o, ps, nd, &st, &ts, NULL, NULL)) { node_idx = idx; break; }
                 }
-                ipa_free(&st);
+                ipa_free(&st); pts_free(&ts);
                 if (node_idx >= 0) *last_index = node_idx;
                 else if (key >= 0) { /* SetUnschedulable :80-97 */
                     if (!ent) { similar_entry e; memset(&e, 0, sizeof e); e.key = key; VEC_PUSH(memo, e); ent = &memo.v[memo.n - 1]; }

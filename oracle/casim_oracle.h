@@ -8,8 +8,9 @@
  *
  * Parity pin: the reference itself cannot run here (no Go toolchain), so this
  * oracle is pinned against the reference's own known-answer tests, transcribed as data in
- * tests/golden/reference_vectors.json (TestBinpackingEstimate rows 1-5,
- * BenchmarkBinpackingEstimate 2595/51000, TestDetermineBestPodEquivalenceGroupToFastpath,
+ * tests/golden/reference_vectors.json (TestBinpackingEstimate rows 1-8 — the three
+ * PodTopologySpread rows included —, BenchmarkBinpackingEstimate 2595/51000, TestTrySchedulePods,
+ * TestPodSchedulesOnHintedNode, TestDetermineBestPodEquivalenceGroupToFastpath,
  * TestPodPriorityProcessor, TestThresholdBasedLimiter, TestMinLimit, TestSngCapacityThreshold,
  * TestNewClusterCapacityThreshold, TestLastIndexOrderMapping, TestRunFiltersOnNode,
  * TestRunFilterUntilPassingNode, TestDebugInfo taints, TestLeastNodes, TestLeastWaste).
@@ -53,6 +54,12 @@ int orc_term_requirement(orc* o, int pod, int term, const char* key, const char*
                          const char* const* values, int n_values);
 int orc_pod_fastpath_requests(orc* o, int pod, double cpu, double mem);
 int orc_pod_has_topology_spread(orc* o, int pod, int flag); /* only feeds shouldUseFastPath */
+/* DoNotSchedule topologySpreadConstraint (PodTopologySpread Filter, V/.../podtopologyspread/filtering.go);
+ * min_domains <= 0 = nil.  The product delegates such pods (CASIM_PEG_UNSUPPORTED); the oracle evaluates them so
+ * that it is pinned on TestBinpackingEstimate's topology-spread rows too. */
+int orc_pod_spread_constraint(orc* o, int pod, int max_skew, const char* topology_key, int min_domains);
+int orc_spread_requirement(orc* o, int pod, int constraint, const char* key, const char* op,
+                           const char* const* values, int n_values);
 
 /* ---- node objects (a template or a node of the existing cluster) ---------------------- */
 int orc_node(orc* o, const char* name, const int64_t* alloc, int allowed_pods,

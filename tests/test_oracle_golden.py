@@ -26,11 +26,14 @@ def _estimate_case(case, fastpath, setup, template_pods=None):
         opts = [with_namespace(setup["namespace"]), with_labels(setup["labels"])]
         if g.get("host_port"):
             opts.append(with_host_port(g["host_port"]))
+        if g.get("max_skew"):
+            opts.append(with_max_skew(*g["max_skew"]))
         pegs.append(make_pod_equivalence_group(build_test_pod("estimatee", g["cpu"], g["mem"], *opts), g["count"]))
     return s.estimate(tmpl, pegs, max_nodes=case["max_nodes"], fastpath=fastpath)
 
 
-@pytest.mark.parametrize("case", GOLD["binpacking_estimate"]["cases"], ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", GOLD["binpacking_estimate"]["cases"] + GOLD["binpacking_estimate"]["topology_spread_cases"],
+                         ids=lambda c: c["name"])
 def test_binpacking_estimate(case):
     setup = GOLD["binpacking_estimate"]["setup"]
     r = _estimate_case(case, False, setup)
