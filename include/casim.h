@@ -290,6 +290,40 @@ int32_t casim_try_schedule_pods(casim_ctx* ctx, const casim_pegs* classes, const
 int32_t casim_time_try_schedule_pods(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes,
                                      const casim_pod_sequence* seq, int32_t iters, float* ms_out);
 
+/*
+ * Scale-down removal simulation: the Planner.categorizeNodes loop
+ * (CA/core/scaledown/planner/planner.go:300-330) around RemovalSimulator.SimulateNodeRemoval
+ * (CA/simulator/cluster.go:131-265).  classes / nodes as for casim_try_schedule_pods (the nodes carry ALL their
+ * running pods, the candidates' own pods included).  Per candidate, in order: the node becomes an unacceptable
+ * ghost, its pods (GetPodsToMove's list, drainability and PDB rules stay on the host) go through TrySchedulePods
+ * with breakOnFailure on the acceptable destinations; all placed => removable and, with `persist` (the planner's
+ * NewRemovalSimulator(..., true)), the moves are committed, the node leaves the list (lastIndex positions shift
+ * like the reference's list) and the destination set; otherwise the simulation is reverted.  lastIndex is never
+ * reverted (it lives in the plugin runner).
+ * The call stops in front of a candidate that received pods from an earlier committed removal — its pod list is no
+ * longer the one the caller computed: *n_processed_out < K, the caller applies the results so far and re-submits
+ * the rest (GetPodsToMove runs again on the host, with its updated PDB tracker).
+ * removable_out[k]: 1 removable, 0 no place to move the pods, 2 not evaluated.  node_out[i]: destination of pod i
+ * in its candidate's simulation (also for a failed one: the reference keeps those hints), -1 not placed.
+ */
+typedef struct casim_removal_candidates {
+    int32_t n_candidates;            /* K */
+    const int32_t* cand_node;        /* [K] node index, planner order, distinct */
+    const int32_t* pod_offsets;      /* [K+1] pods to move of candidate k: [pod_offsets[k], pod_offsets[k+1]) */
+    const int32_t* pod_class;        /* [total] */
+    const int32_t* hint_node;        /* [total] or NULL */
+    const uint8_t* destination;      /* [N] podDestinations membership; NULL = every node */
+    int32_t persist;                 /* canPersist */
+    int32_t max_removable;           /* stop after this many removable nodes (unneededNodesLimit); 0 = no limit */
+    int32_t last_index;
+} casim_removal_candidates;
+
+int32_t casim_simulate_node_removals(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes,
+                                     const casim_removal_candidates* cand, uint8_t* removable_out /*[K]*/,
+                                     int32_t* node_out /*[total]*/, int32_t* last_index_out, int32_t* n_processed_out);
+int32_t casim_time_node_removals(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes,
+                                 const casim_removal_candidates* cand, int32_t iters, float* ms_out);
+
 /* Measurement helpers (used by bench.py): run `iters` times, bracketed by HIP events on the
  * context's stream; returns the mean per-run milliseconds of the whole pipeline and of the
  * named kernel classes.  kernel_ms_out: [0]=feasibility+csr [1]=order [2]=pack (may be NULL). */

@@ -71,6 +71,11 @@ class PodSequence(C.Structure):
                 ("break_on_failure", C.c_int32), ("last_index", C.c_int32)]
 
 
+class RemovalCandidates(C.Structure):
+    _fields_ = [("n_candidates", C.c_int32), ("cand_node", i32p), ("pod_offsets", i32p), ("pod_class", i32p), ("hint_node", i32p),
+                ("destination", u8p), ("persist", C.c_int32), ("max_removable", C.c_int32), ("last_index", C.c_int32)]
+
+
 cstr = C.c_char_p
 cstrp = C.POINTER(C.c_char_p)
 
@@ -96,6 +101,10 @@ PROTOTYPES = {
     "casim_try_schedule_pods": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(PodSequence), i32p, i32p, i32p]),
     "casim_time_try_schedule_pods": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(PodSequence), C.c_int32,
                                                  C.POINTER(C.c_float)]),
+    "casim_simulate_node_removals": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(RemovalCandidates), u8p, i32p,
+                                                 i32p, i32p]),
+    "casim_time_node_removals": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(RemovalCandidates), C.c_int32,
+                                             C.POINTER(C.c_float)]),
     "casim_copy_bandwidth": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, f64p]),
     "casim_enc_create": (C.c_void_p, [C.POINTER(EncoderOptions)]),
     "casim_enc_destroy": (None, [C.c_void_p]),

@@ -34,6 +34,7 @@ struct HipBackend {
     void h2d(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D"); }
     void d2h(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H"); }
     void zero(void* d, size_t n) { if (n) check(hipMemsetAsync(d, 0, n, stream), "hipMemsetAsync"); }
+    void fill8(void* d, int v, size_t n) { if (n) check(hipMemsetAsync(d, v, n, stream), "hipMemsetAsync"); }
     void sync() { check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
     size_t lds_budget() const { return lds; }
     bool ok() const { return last == hipSuccess; }
@@ -382,6 +383,42 @@ int32_t casim_try_schedule_pods(casim_ctx* ctx, const casim_pegs* classes, const
     if (rc == CASIM_OK) rc = s.fetch(node_out, last_index_out, n_scheduled_out);
     if (rc < 0) set_err(rc, s.error());
     return rc;
+}
+
+// ---- scale-down removal simulation ----------------------------------------------
+int32_t casim_simulate_node_removals(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes,
+                                     const casim_removal_candidates* cand, uint8_t* removable_out, int32_t* node_out,
+                                     int32_t* last_index_out, int32_t* n_processed_out) {
+    g_err.clear();
+    if (!ctx) return set_err(CASIM_ERR_INVALID, "null context");
+    HipBackend& bk = ctx->bk; bk.bind(); bk.clear();
+    casim::SchedulerT<HipBackend> s(bk);
+    int32_t rc = s.init_removals(classes, nodes, cand);
+    if (rc == CASIM_OK) rc = s.run();
+    if (rc == CASIM_OK) rc = s.fetch_removals(removable_out, node_out, last_index_out, n_processed_out);
+    if (rc < 0) set_err(rc, s.error());
+    return rc;
+}
+int32_t casim_time_node_removals(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes,
+                                 const casim_removal_candidates* cand, int32_t iters, float* ms_out) {
+    g_err.clear();
+    if (!ctx || iters <= 0 || !ms_out) return set_err(CASIM_ERR_INVALID, "bad argument");
+    HipBackend& bk = ctx->bk; bk.bind(); bk.clear();
+    casim::SchedulerT<HipBackend> s(bk);
+    int32_t rc = s.init_removals(classes, nodes, cand);
+    if (rc != CASIM_OK) { if (rc < 0) set_err(rc, s.error()); return rc; }
+    rc = s.run();
+    hipEvent_t e0, e1;
+    bk.check(hipEventCreate(&e0), "hipEventCreate"); bk.check(hipEventCreate(&e1), "hipEventCreate");
+    bk.check(hipEventRecord(e0, bk.stream), "hipEventRecord");
+    for (int i = 0; i < iters && rc == CASIM_OK; ++i) rc = s.run();
+    bk.check(hipEventRecord(e1, bk.stream), "hipEventRecord");
+    bk.check(hipEventSynchronize(e1), "hipEventSynchronize");
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_out = ms;
+    if (rc < 0) return set_err(rc, s.error());
+    return bk.ok() ? CASIM_OK : set_err(CASIM_ERR_HIP, bk.msg);
 }
 
 int32_t casim_time_try_schedule_pods(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes,

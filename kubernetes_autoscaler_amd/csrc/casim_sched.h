@@ -44,8 +44,16 @@ struct SchedArgs {
     const uint8_t* acceptable;  // [N] or null
     const uint64_t* fbits;      // [C][cap / 64] from sched_static_kernel
     int32_t* node_out;          // [P], pre-filled with -1
-    int32_t* out;               // [4]: lastIndex, pods scheduled, runs processed, 0
+    int32_t* out;               // [4]: lastIndex, pods scheduled, runs processed, candidates processed
     char* gstate;               // HBM slab (global variant) or null
+    // ---- removal simulation: n_cand > 0 turns every candidate's runs into one transaction ----
+    int32_t n_cand, persist, max_removable;
+    const int32_t* cand_node;     // [K] node whose removal is simulated
+    const int32_t* cand_run_off;  // [K+1] runs of candidate k
+    const int32_t* cand_pod_off;  // [K+1] pods of candidate k in node_out
+    uint8_t* removable_out;       // [K] 1 removable / 0 no place (pre-filled with 2 = not evaluated)
+    uint8_t* arrived;             // [cap] node received pods of a committed removal (zeroed)
+    char* committed;              // HBM: last committed sfree / sexcl / sslots (same layout as the working copy)
 };
 
 CS_GLOBAL void fill_i32_kernel(int32_t* p, int64_t n, int32_t v) {
@@ -117,8 +125,9 @@ struct BlockCtl {
     }
 };
 
-CS_HOST_DEVICE int64_t casim_sched_ctrl_bytes(int memo_classes) {
-    return 2 * 16 * 8 + 2 * 16 * 4 + 16 + ((4ll * ((memo_classes + 31) / 32) + 7) & ~7ll);
+// LDS control block: collective cells, the memo bits and (transactions only) the alive words + their rank prefix
+CS_HOST_DEVICE int64_t casim_sched_ctrl_bytes(int memo_classes, int alive_words) {
+    return 2 * 16 * 8 + 2 * 16 * 4 + 16 + ((4ll * ((memo_classes + 31) / 32) + 7) & ~7ll) + 12ll * alive_words + (alive_words & 1 ? 4 : 0);
 }
 inline int64_t casim_sched_state_bytes(int R, int Wx, int64_t cap) {
     return cap * (8ll * R + 8ll * Wx + 12ll) + 2ll * 8ll * (cap / 64);
@@ -139,9 +148,15 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
     bc.slot = bc.tab + 32;
     bc.W = T >> 6; bc.wave = wave; bc.lane = lane; bc.ph_red = bc.ph_tab = bc.ph_slot = 0;
     uint32_t* memo = bc.slot + 4;  // [ceil(memo_classes / 32)] class found no node
+    // transactions: which nodes are still in the snapshot list, and how many live nodes precede each 64-node word
+    // (lastIndex is a POSITION in the reference's node list, which shrinks when a removal is committed)
+    const bool txn = a.n_cand > 0;
+    const int nw = txn ? a.cap >> 6 : 0;
+    uint64_t* alive = (uint64_t*)((char*)memo + ((4ll * ((a.memo_classes + 31) / 32) + 7) & ~7ll));  // [nw]
+    uint32_t* wpre = (uint32_t*)(alive + nw);                                                           // [nw]
     Store st;
     st.R = R; st.Wx = Wx; st.cap = a.cap;
-    char* base = kLds ? smem + casim_sched_ctrl_bytes(a.memo_classes) : a.gstate;
+    char* base = kLds ? smem + casim_sched_ctrl_bytes(a.memo_classes, nw) : a.gstate;
     st.sfree = (int64_t*)base;
     st.sexcl = (uint64_t*)(st.sfree + (int64_t)R * st.cap);
     uint64_t* scanb = st.sexcl + (int64_t)Wx * st.cap;  // [cap / 64] acceptable && !Spec.Unschedulable
@@ -149,6 +164,10 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
     st.sslots = (int32_t*)(accb + (a.cap >> 6));
     st.snpods = st.sslots + st.cap;
     st.sctmp = st.snpods + st.cap;
+    // committed copy (transactions): what Revert() restores
+    int64_t* cfree = (int64_t*)a.committed;
+    uint64_t* cexcl = (uint64_t*)(cfree + (int64_t)R * st.cap);
+    int32_t* cslots = (int32_t*)(cexcl + (int64_t)Wx * st.cap);
 
     // ---- prologue: node state = what the running pods of each node hold (NodeInfo.Requested, types.go) ----
     for (int q = 0; q < Q; ++q) {
@@ -163,6 +182,13 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
         const uint64_t ab = cs::ballot(acc);
         const uint64_t sb = cs::ballot(acc && !(t.gflags[live ? m : 0] & CASIM_NG_UNSCHEDULABLE));
         if (lane == 0) { accb[m >> 6] = ab; scanb[m >> 6] = sb; }
+        if (txn) {
+            for (int r = 0; r < R; ++r) cfree[(int64_t)r * st.cap + m] = st.sfree[(int64_t)r * st.cap + m];
+            for (int w = 0; w < Wx; ++w) cexcl[(int64_t)w * st.cap + m] = st.sexcl[(int64_t)w * st.cap + m];
+            cslots[m] = st.sslots[m];
+            const uint64_t lb = cs::ballot(live);
+            if (lane == 0) { alive[m >> 6] = lb; wpre[m >> 6] = (uint32_t)((m >> 6) << 6) < (uint32_t)N ? (uint32_t)((m >> 6) << 6) : (uint32_t)N; }
+        }
     }
     for (int i = tid; i < (a.memo_classes + 31) / 32; i += T) memo[i] = 0u;
     cs::sync();
@@ -170,11 +196,52 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
     int32_t last_index = a.last_index;
     int32_t scheduled = 0;
     int32_t runs_done = 0;
+    int32_t n_alive = N;       // len(nodeInfosList)
+    int32_t removed = 0, cand_done = 0;
+    bool any_dead = false;
     bool stop = false;
+    // position of node m in the current node list / node at position p
+    auto rank_of = [&](int m) -> int32_t {
+        if (!any_dead) return m;
+        return (int32_t)wpre[m >> 6] + cs::popc64(alive[m >> 6] & cs::low_mask(m & 63));
+    };
+    auto node_at = [&](int32_t pos) -> int32_t {
+        if (!any_dead) return pos;
+        bool mine = false; uint32_t w_mine = 0;
+        for (int w = tid; w < nw; w += T) {
+            const int32_t lo = (int32_t)wpre[w], cntw = cs::popc64(alive[w]);
+            if (pos >= lo && pos < lo + cntw) { mine = true; w_mine = (uint32_t)w; }
+        }
+        const uint32_t w = bc.pick(mine, w_mine, 0u);
+        uint64_t b = alive[w];
+        for (int32_t i = (int32_t)wpre[w]; i < pos; ++i) b &= b - 1;   // drop the live nodes in front
+        return (int32_t)(w << 6) + cs::ffs64(b);
+    };
 
-    for (int k0 = 0; k0 < a.n_runs && !stop; k0 += 64) {
+    const int n_tx = txn ? a.n_cand : 1;
+    for (int kc = 0; kc < n_tx; ++kc) {
+    int run_lo = 0, run_hi = a.n_runs, Y = -1;
+    bool break_on_failure = a.break_on_failure != 0, failed = false;
+    if (txn) {
+        // ---- SimulateNodeRemoval (cluster.go:131-172) of candidate kc, planner order (planner.go:300-330) ----
+        if (a.max_removable > 0 && removed >= a.max_removable) break;
+        Y = a.cand_node[kc];
+        if (a.arrived[Y]) break;   // its pod list changed under the caller's feet: the caller re-submits from here
+        cand_done = kc + 1;
+        run_lo = a.cand_run_off[kc]; run_hi = a.cand_run_off[kc + 1];
+        break_on_failure = true;
+        if (!((alive[Y >> 6] >> (Y & 63)) & 1ull)) {   // NoNodeInfo (:139-147)
+            if (tid == 0) a.removable_out[kc] = 0;
+            continue;
+        }
+        // Fork; the candidate turns into a pod-less tainted ghost that keeps its list position (:243-265)
+        cs::sync();
+        if (tid == 0) { accb[Y >> 6] &= ~(1ull << (Y & 63)); scanb[Y >> 6] &= ~(1ull << (Y & 63)); }
+        cs::sync();
+    }
+    for (int k0 = run_lo; k0 < run_hi && !stop && !failed; k0 += 64) {
         const int kk = k0 + lane;
-        const bool have = kk < a.n_runs;
+        const bool have = kk < run_hi;
         const int32_t my_class = have ? a.run_class[kk] : 0;
         const int32_t my_count = have ? a.run_count[kk] : 0;
         const int32_t my_hint = have ? a.run_hint[kk] : -1;
@@ -188,8 +255,8 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
             my_rq[r] = my_req[r] > 0 ? 1.0 / (double)my_req[r] : 0.0;
         }
         const uint32_t my_flags = have ? t.pflags[my_class] : 0u;
-        const int nk = a.n_runs - k0 < 64 ? a.n_runs - k0 : 64;
-        for (int j = 0; j < nk && !stop; ++j) {
+        const int nk = run_hi - k0 < 64 ? run_hi - k0 : 64;
+        for (int j = 0; j < nk && !stop && !failed; ++j) {
             const int c = (int)cs::bcast_u32((uint32_t)my_class, j);
             const int32_t cnt = (int32_t)cs::bcast_u32((uint32_t)my_count, j);
             const int32_t hint = (int32_t)cs::bcast_u32((uint32_t)my_hint, j);
@@ -228,8 +295,9 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
             if (keff > 0 && !memo_hit) {
                 // The cyclic order starts at m0 = (lastIndex + 1) % N.  Pieces of T nodes in that order: chunk q0 from
                 // m0 on, the following chunks (wrapping), and last the part of chunk q0 below m0.
-                int32_t m0 = (int32_t)(((int64_t)last_index + 1) % N);
-                if (m0 < 0) m0 += N;
+                int32_t p0 = (int32_t)(((int64_t)last_index + 1) % n_alive);
+                if (p0 < 0) p0 += n_alive;
+                const int32_t m0 = node_at(p0);
                 const int q0 = m0 / T;
                 const bool wrap_piece = (m0 % T) != 0;
                 const int P = Q + (wrap_piece ? 1 : 0);
@@ -262,7 +330,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                     if (tot_p > 0) {  // every thread re-evaluates: only the owner in the LAST placing piece stays flagged
                         const uint32_t upto = cum + tot_p < keff ? cum + tot_p : keff;
                         last_mine = gets && rank == upto - 1u;
-                        if (last_mine) last_owner_val = (uint32_t)m;
+                        if (last_mine) last_owner_val = (uint32_t)rank_of(m);
                     }
                     cum += tot_p;
                     if (cum >= keff) break;
@@ -330,7 +398,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                                         uint32_t upto = cumr + tot_p;
                                         if (partial && upto > Rr) upto = Rr;
                                         last_mine = gets && rank == upto - 1u;
-                                        if (last_mine) last_owner_val = (uint32_t)m;
+                                        if (last_mine) last_owner_val = (uint32_t)rank_of(m);
                                     }
                                     const uint32_t x = (cj < Tn ? cj : Tn) + ((partial && gets) ? 1u : 0u);
                                     if (x > 0) st.commit(0, m, x, pv);
@@ -349,15 +417,58 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                 // SetUnschedulable (:127); breakOnFailure (:79-81)
                 if (c < a.memo_classes && tid == 0) memo[c >> 5] |= 1u << (c & 31);
                 cs::sync();
-                if (a.break_on_failure) stop = true;
+                if (break_on_failure) { if (txn) failed = true; else stop = true; }
             }
         }
     }
+    if (txn) {
+        // every pod found a place <=> the node is removable (findPlaceFor :219-224)
+        const bool ok = !failed;
+        const int p_lo = a.cand_pod_off[kc], p_hi = a.cand_pod_off[kc + 1];
+        cs::sync();
+        if (ok && a.persist) {
+            // Commit (withForkedSnapshot :174-188): the touched nodes become the new committed state, the ghost leaves
+            // the list (:230) and the destination set (planner.go:318)
+            for (int i = p_lo + tid; i < p_hi; i += T) {
+                const int m = a.node_out[i];
+                for (int r = 0; r < R; ++r) cfree[(int64_t)r * st.cap + m] = st.sfree[(int64_t)r * st.cap + m];
+                for (int w = 0; w < Wx; ++w) cexcl[(int64_t)w * st.cap + m] = st.sexcl[(int64_t)w * st.cap + m];
+                cslots[m] = st.sslots[m];
+                a.arrived[m] = 1;
+            }
+            if (tid == 0) {
+                alive[Y >> 6] &= ~(1ull << (Y & 63));
+                uint32_t acc = 0;
+                for (int w = 0; w < nw; ++w) { wpre[w] = acc; acc += (uint32_t)cs::popc64(alive[w]); }
+            }
+            n_alive--; any_dead = true;
+        } else {
+            // Revert: touched nodes get their committed state back, the candidate its pods and its place
+            for (int i = p_lo + tid; i < p_hi; i += T) {
+                const int m = a.node_out[i];
+                if (m < 0) continue;
+                for (int r = 0; r < R; ++r) st.sfree[(int64_t)r * st.cap + m] = cfree[(int64_t)r * st.cap + m];
+                for (int w = 0; w < Wx; ++w) st.sexcl[(int64_t)w * st.cap + m] = cexcl[(int64_t)w * st.cap + m];
+                st.sslots[m] = cslots[m];
+            }
+            if (tid == 0) {
+                const bool acc = a.acceptable == nullptr || a.acceptable[Y] != 0;
+                if (acc) {
+                    accb[Y >> 6] |= 1ull << (Y & 63);
+                    if (!(t.gflags[Y] & CASIM_NG_UNSCHEDULABLE)) scanb[Y >> 6] |= 1ull << (Y & 63);
+                }
+            }
+        }
+        if (ok) removed++;
+        if (tid == 0) a.removable_out[kc] = ok ? 1 : 0;
+        cs::sync();
+    }
+    }  // transactions
     if (tid == 0) {
         a.out[0] = last_index;
         a.out[1] = scheduled;
         a.out[2] = runs_done;
-        a.out[3] = 0;
+        a.out[3] = cand_done;
     }
 }
 
@@ -372,7 +483,25 @@ public:
     SchedulerT& operator=(const SchedulerT&) = delete;
 
     // returns CASIM_OK, CASIM_NG_UNSUPPORTED (> 0) or an error code (< 0)
-    int32_t init(const casim_pegs* p, const casim_groups* g, const casim_pod_sequence* q) {
+    // removal simulation: the pods of all candidates form the sequence, every candidate is one transaction
+    int32_t init_removals(const casim_pegs* p, const casim_groups* g, const casim_removal_candidates* rc) {
+        if (!rc) return fail(CASIM_ERR_INVALID, "null candidates");
+        if (rc->n_candidates < 0) return fail(CASIM_ERR_INVALID, "negative size");
+        if (rc->n_candidates > 0 && (!rc->cand_node || !rc->pod_offsets)) return fail(CASIM_ERR_INVALID, "candidate table has null columns");
+        const int K = rc->n_candidates;
+        if (K > 0 && rc->pod_offsets[0] != 0) return fail(CASIM_ERR_INVALID, "pod_offsets[0] != 0");
+        for (int k = 0; k < K; ++k) {
+            if (rc->pod_offsets[k + 1] < rc->pod_offsets[k]) return fail(CASIM_ERR_INVALID, "pod_offsets not monotone");
+            if (!g || rc->cand_node[k] < 0 || rc->cand_node[k] >= g->n_groups) return fail(CASIM_ERR_INVALID, "candidate node out of range");
+        }
+        casim_pod_sequence q; memset(&q, 0, sizeof q);
+        q.n_pods = K > 0 ? rc->pod_offsets[K] : 0;
+        q.pod_class = rc->pod_class; q.hint_node = rc->hint_node; q.node_acceptable = rc->destination;
+        q.break_on_failure = 1; q.last_index = rc->last_index;
+        return init(p, g, &q, rc);
+    }
+
+    int32_t init(const casim_pegs* p, const casim_groups* g, const casim_pod_sequence* q, const casim_removal_candidates* cand = nullptr) {
         if (!p || !g || !q) return fail(CASIM_ERR_INVALID, "null table");
         if (p->n_pegs < 0 || g->n_groups < 0 || q->n_pods < 0) return fail(CASIM_ERR_INVALID, "negative size");
         if (p->n_res < 2 || p->n_res > CASIM_KMAX_RES) return fail(CASIM_ERR_INVALID, "n_res must be in [2, 8]");
@@ -391,9 +520,13 @@ public:
         if (N > 0x3fffffc0ull) return fail(CASIM_ERR_INVALID, "too many nodes");
 
         // ---- runs: consecutive pods of one class without a hint; predicates outside the subset -> delegate ----
-        std::vector<int32_t> rc, rn, rh, rf;
+        std::vector<int32_t> rc, rn, rh, rf, cro;
         std::vector<uint8_t> used(C, 0);
+        K_ = cand ? cand->n_candidates : 0;
+        int next_cand = 0;
         for (size_t i = 0; i < P; ++i) {
+            bool boundary = false;  // a run never spans two candidates
+            while (cand && next_cand < K_ && (size_t)cand->pod_offsets[next_cand] <= i) { cro.push_back((int32_t)rc.size()); next_cand++; boundary = true; }
             const int32_t c = q->pod_class[i];
             if (c < 0 || c >= C_) return fail(CASIM_ERR_INVALID, "pod_class out of range");
             int32_t h = q->hint_node ? q->hint_node[i] : -1;
@@ -405,11 +538,12 @@ public:
                 for (int w = 0; w < p->w_zone; ++w)
                     if (p->zone_block[(size_t)c * p->w_zone + w] | p->zone_mark[(size_t)c * p->w_zone + w]) return CASIM_NG_UNSUPPORTED;
             }
-            if (h < 0 && !rc.empty() && rc.back() == c && rh.back() < 0 && rn.back() < 0x7fffffff) rn.back()++;
+            if (!boundary && h < 0 && !rc.empty() && rc.back() == c && rh.back() < 0 && rn.back() < 0x7fffffff) rn.back()++;
             else { rc.push_back(c); rn.push_back(1); rh.push_back(h); rf.push_back((int32_t)i); }
         }
         n_runs_ = (int32_t)rc.size();
-        if (N_ == 0 || P_ == 0) { trivial_ = true; last_index_ = q->last_index; return CASIM_OK; }
+        while (cand && (int)cro.size() <= K_) cro.push_back(n_runs_);  // candidates without pods + the end marker
+        if (N_ == 0 || (P_ == 0 && K_ == 0)) { trivial_ = true; last_index_ = q->last_index; return CASIM_OK; }
 
         memset(&dt_, 0, sizeof dt_); memset(&a_, 0, sizeof a_);
         dt_.G = C_; dt_.NG = N_; dt_.R = p->n_res; dt_.Wt = p->w_taint; dt_.Wl = p->w_label; dt_.Wx = p->w_excl; dt_.Wz = 0;
@@ -437,7 +571,18 @@ public:
         a_.fbits = d_fbits_;
         a_.node_out = (int32_t*)dalloc(4 * P);
         a_.out = (int32_t*)dalloc(16);
-        const int64_t ctrl = casim_sched_ctrl_bytes(a_.memo_classes), bytes = casim_sched_state_bytes(R, dt_.Wx, cap_);
+        if (K_ > 0) {
+            a_.memo_classes = 0;  // breakOnFailure ends a simulation at the first miss: the memo is never consulted
+            a_.n_cand = K_; a_.persist = cand->persist ? 1 : 0; a_.max_removable = cand->max_removable > 0 ? cand->max_removable : 0;
+            a_.cand_node = up(cand->cand_node, (size_t)K_);
+            a_.cand_run_off = up(cro.data(), cro.size());
+            a_.cand_pod_off = up(cand->pod_offsets, (size_t)K_ + 1);
+            a_.removable_out = (uint8_t*)dalloc((size_t)K_);
+            a_.arrived = (uint8_t*)dalloc((size_t)cap_);
+            a_.committed = (char*)dalloc((size_t)cap_ * (8u * (size_t)R + 8u * (size_t)dt_.Wx + 4u));
+        }
+        const int alive_words = K_ > 0 ? S_ : 0;
+        const int64_t ctrl = casim_sched_ctrl_bytes(a_.memo_classes, alive_words), bytes = casim_sched_state_bytes(R, dt_.Wx, cap_);
         lds_ = ctrl + bytes <= (int64_t)bk_.lds_budget();
         smem_ = (size_t)(lds_ ? ctrl + bytes : ctrl);
         if (!lds_) a_.gstate = (char*)dalloc((size_t)bytes);
@@ -450,7 +595,8 @@ public:
     int32_t run() {
         if (trivial_) return CASIM_OK;
         if (!ready_) return fail(CASIM_ERR_INVALID, "scheduler not initialised");
-        bk_.launch(fill_i32_kernel, (P_ + 255) / 256, 1, 256, (size_t)0, a_.node_out, (int64_t)P_, (int32_t)-1);
+        if (P_ > 0) bk_.launch(fill_i32_kernel, (P_ + 255) / 256, 1, 256, (size_t)0, a_.node_out, (int64_t)P_, (int32_t)-1);
+        if (K_ > 0) { bk_.fill8(a_.removable_out, 2, (size_t)K_); bk_.zero(a_.arrived, (size_t)cap_); }
         if (C_ > 0) bk_.launch(sched_static_kernel, S_, C_, 64, (size_t)0, dt_, d_fbits_, S_);
         if (lds_) bk_.launch(sched_kernel<true>, 1, 1, threads_, smem_, dt_, a_);
         else bk_.launch(sched_kernel<false>, 1, 1, threads_, smem_, dt_, a_);
@@ -470,6 +616,25 @@ public:
         bk_.sync();
         if (last_index_out) *last_index_out = o[0];
         if (n_scheduled_out) *n_scheduled_out = o[1];
+        return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
+    }
+
+    // removal simulation results: removable[K] (1 / 0 / 2 = not evaluated), candidates with a final answer
+    int32_t fetch_removals(uint8_t* removable_out, int32_t* node_out, int32_t* last_index_out, int32_t* n_processed_out) {
+        if (trivial_) {
+            for (int k = 0; k < K_; ++k) if (removable_out) removable_out[k] = 2;
+            for (int i = 0; i < P_; ++i) if (node_out) node_out[i] = -1;
+            if (last_index_out) *last_index_out = last_index_;
+            if (n_processed_out) *n_processed_out = 0;
+            return CASIM_OK;
+        }
+        int32_t o[4] = {0, 0, 0, 0};
+        if (node_out && P_ > 0) bk_.d2h(node_out, a_.node_out, 4 * (size_t)P_);
+        if (removable_out && K_ > 0) bk_.d2h(removable_out, a_.removable_out, (size_t)K_);
+        bk_.d2h(o, a_.out, 16);
+        bk_.sync();
+        if (last_index_out) *last_index_out = o[0];
+        if (n_processed_out) *n_processed_out = o[3];
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
     }
 
@@ -497,7 +662,7 @@ private:
 
     BK& bk_;
     DevTables dt_; SchedArgs a_;
-    int C_ = 0, N_ = 0, P_ = 0, S_ = 0, threads_ = 64;
+    int C_ = 0, N_ = 0, P_ = 0, S_ = 0, K_ = 0, threads_ = 64;
     int32_t cap_ = 0, n_runs_ = 0, last_index_ = 0;
     bool ready_ = false, trivial_ = false, lds_ = true;
     size_t smem_ = 0;

@@ -71,6 +71,24 @@ def make_pod_sequence(pod_class, hint_node=None, node_acceptable=None, break_on_
     return seq, (pc, hn, na)
 
 
+def make_removal_candidates(cand_node, pod_offsets, pod_class, hint_node=None, destination=None, persist=True, max_removable=0,
+                            last_index=0):
+    """casim_removal_candidates over numpy arrays; returns (struct, arrays to keep alive)."""
+    cn = np.ascontiguousarray(cand_node, np.int32)
+    po = np.ascontiguousarray(pod_offsets, np.int32)
+    pc = np.ascontiguousarray(pod_class, np.int32)
+    hn = None if hint_node is None else np.ascontiguousarray(hint_node, np.int32)
+    ds = None if destination is None else np.ascontiguousarray(destination, np.uint8)
+    if po.shape[0] != cn.shape[0] + 1:
+        raise ValueError("pod_offsets must have one more entry than cand_node")
+    st = _abi.RemovalCandidates(n_candidates=int(cn.shape[0]), cand_node=_ptr(cn, C.c_int32) if cn.size else None,
+                                pod_offsets=_ptr(po, C.c_int32), pod_class=_ptr(pc, C.c_int32) if pc.size else None,
+                                hint_node=_ptr(hn, C.c_int32) if hn is not None and hn.size else None,
+                                destination=_ptr(ds, C.c_uint8) if ds is not None and ds.size else None,
+                                persist=int(bool(persist)), max_removable=int(max_removable), last_index=int(last_index))
+    return st, (cn, po, pc, hn, ds)
+
+
 def device_count() -> int:
     return int(lib.casim_device_count())
 
@@ -132,6 +150,31 @@ class Context:
             check(rc, "casim_try_schedule_pods")
         del keep
         return rc, node_out[:seq.n_pods], li.value, ns.value
+
+
+    def simulate_node_removals(self, classes: _abi.Pegs, nodes: _abi.Groups, cand_node, pod_offsets, pod_class, hint_node=None,
+                               destination=None, persist: bool = True, max_removable: int = 0, last_index: int = 0,
+                               time_iters: int = 0):
+        """Planner.categorizeNodes loop around SimulateNodeRemoval on the device (casim_simulate_node_removals).
+        Returns (status, removable[K], node_out[total], last_index, n_processed); with time_iters > 0 the HIP-event
+        time in ms of one resident pass instead."""
+        rc_struct, keep = make_removal_candidates(cand_node, pod_offsets, pod_class, hint_node, destination, persist, max_removable, last_index)
+        if time_iters > 0:
+            ms = C.c_float(0)
+            rc = lib.casim_time_node_removals(self._h, C.byref(classes), C.byref(nodes), C.byref(rc_struct), int(time_iters), C.byref(ms))
+            if rc < 0:
+                check(rc, "casim_time_node_removals")
+            return rc, ms.value / time_iters
+        K, total = rc_struct.n_candidates, int(keep[1][-1]) if len(keep[1]) else 0
+        removable = np.full(max(K, 1), 2, np.uint8)
+        node_out = np.full(max(total, 1), -1, np.int32)
+        li, npr = C.c_int32(0), C.c_int32(0)
+        rc = lib.casim_simulate_node_removals(self._h, C.byref(classes), C.byref(nodes), C.byref(rc_struct), _ptr(removable, C.c_uint8),
+                                              _ptr(node_out, C.c_int32), C.byref(li), C.byref(npr))
+        if rc < 0:
+            check(rc, "casim_simulate_node_removals")
+        del keep
+        return rc, removable[:K], node_out[:total], li.value, npr.value
 
 
 class Problem:

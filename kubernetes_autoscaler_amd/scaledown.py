@@ -1,0 +1,155 @@
+"""Host-side mirror of the scale-down removal simulation:
+
+    Planner.categorizeNodes loop                 CA/core/scaledown/planner/planner.go:286-336
+    RemovalSimulator.SimulateNodeRemoval         CA/simulator/cluster.go:131-172
+    findPlaceFor / replaceWithTaintedGhostNode   CA/simulator/cluster.go:190-265
+    GetPodsToMove (host policy, stays host)      CA/simulator/drain.go:49-86
+
+The per-candidate Fork -> unschedule -> TrySchedulePods(breakOnFailure) -> Commit/Revert chain runs on the device as
+ONE call over all candidates (casim_simulate_node_removals -> K_sched with transactions).  What stays here is what
+the reference also keeps outside the scheduler simulation: which pods of a node have to move (drainability rules,
+PDBs), the hint map, and the snapshot objects.  When an earlier removal moved pods onto a later candidate, that
+candidate's pod list is no longer the one that was submitted; the device stops in front of it and this loop
+re-submits the rest from the updated snapshot — exactly the point where the reference calls GetPodsToMove again."""
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+from .encoder import Encoder
+from .engine import Context
+from .objects import NodeInfo, Pod, PodEquivalenceGroup
+from .scheduling import Hints, UnsupportedPredicate, hint_key_from_pod
+
+# simulator.UnremovableReason (cluster.go:78-103), the two this path produces
+NO_PLACE_TO_MOVE_PODS = "NoPlaceToMovePods"
+BLOCKED_BY_POD = "BlockedByPod"
+
+
+@dataclass
+class NodeToBeRemoved:
+    """simulator.NodeToBeRemoved (cluster.go:42-54)."""
+    node: object
+    pods_to_reschedule: List[Pod]
+    daemon_set_pods: List[Pod] = field(default_factory=list)
+
+
+@dataclass
+class UnremovableNode:
+    """simulator.UnremovableNode (cluster.go:56-63)."""
+    node: object
+    reason: str
+
+
+def default_pods_to_move(info: NodeInfo) -> Optional[List[Pod]]:
+    """GetPodsToMove with rules that let everything drain: every non-DaemonSet pod moves (drain.go:64-84).
+    Return None for a node blocked by a pod (BlockDrain)."""
+    return [p for p in info.pods if not p.daemonset]
+
+
+class RemovalSimulator:
+    """simulator.NewRemovalSimulator(listers, clusterSnapshot, deleteOptions, drainabilityRules, persist)."""
+
+    def __init__(self, ctx: Context, snapshot: List[NodeInfo], persist_successful_simulations: bool = True,
+                 pods_to_move: Callable[[NodeInfo], Optional[List[Pod]]] = default_pods_to_move, lanes=None):
+        self.ctx = ctx
+        self.snapshot = snapshot            # list order == the order lastIndex refers to; mutated when persisting
+        self.can_persist = persist_successful_simulations
+        self.pods_to_move = pods_to_move
+        self.lanes = lanes
+        self.hints = Hints()
+        self.last_index = 0
+        self.device_calls = 0
+
+    def drop_old_hints(self):
+        self.hints.drop_old()
+
+    # ---- one device call over `names` (prefix semantics) ----------------------------------------------------
+    def _submit(self, names: Sequence[str], lists: List[List[Pod]], destinations: Dict[str, bool], max_removable: int):
+        enc = Encoder(explicit_self_exclusion=True) if self.lanes is None else Encoder(lanes=self.lanes, explicit_self_exclusion=True)
+        class_of: Dict[tuple, int] = {}
+        pod_class: List[int] = []
+        hint: List[int] = []
+        off = [0]
+        pos = {info.node.name: i for i, info in enumerate(self.snapshot)}
+        for lst in lists:
+            for p in lst:
+                k = p.spec_key()
+                c = class_of.get(k)
+                if c is None:
+                    c = enc.add_peg(PodEquivalenceGroup(pods=[p]))
+                    class_of[k] = c
+                pod_class.append(c)
+                h = self.hints.get(hint_key_from_pod(p))
+                hint.append(pos.get(h, -1) if h is not None else -1)
+            off.append(len(pod_class))
+        for info in self.snapshot:
+            enc.add_group(info, pegs=[])
+        enc.finalize()
+        dest = np.array([1 if destinations.get(info.node.name, False) else 0 for info in self.snapshot], np.uint8)
+        self.device_calls += 1
+        out = self.ctx.simulate_node_removals(enc.pegs, enc.groups, [pos[n] for n in names], off, pod_class, hint, dest,
+                                              persist=self.can_persist, max_removable=max_removable, last_index=self.last_index)
+        enc.close()
+        if out[0] == _abi.NG_UNSUPPORTED:
+            raise UnsupportedPredicate("pods to move need a predicate outside the encoded subset")
+        return out, off
+
+    def simulate_node_removals(self, candidates: Sequence[str], destinations: Dict[str, bool], max_removable: int = 0):
+        """The categorizeNodes loop (planner.go:300-330): SimulateNodeRemoval per candidate in order, successful
+        simulations persisted when `can_persist`, the removed node dropped from `destinations` (:318).
+        Returns (removable: List[NodeToBeRemoved], unremovable: List[UnremovableNode], skipped: names not evaluated)."""
+        removable: List[NodeToBeRemoved] = []
+        unremovable: List[UnremovableNode] = []
+        todo = list(candidates)
+        while todo:
+            if max_removable > 0 and len(removable) >= max_removable:
+                break
+            by_name = {info.node.name: info for info in self.snapshot}
+            # GetPodsToMove on the CURRENT snapshot; blocked / vanished nodes never reach the device
+            names, lists = [], []
+            for n in todo:
+                info = by_name.get(n)
+                lst = self.pods_to_move(info) if info is not None else None
+                names.append(n)
+                lists.append(lst)
+            # the device takes the longest prefix whose nodes are all simulatable
+            cut = next((i for i, lst in enumerate(lists) if lst is None), len(names))
+            if cut == 0:
+                n = todo.pop(0)
+                if n in by_name:
+                    unremovable.append(UnremovableNode(by_name[n].node, BLOCKED_BY_POD))
+                continue
+            left = (max_removable - len(removable)) if max_removable > 0 else 0
+            infos = list(self.snapshot)   # node indices of this call refer to this list
+            (status, rem, node_out, last_index, n_done), off = self._submit(names[:cut], lists[:cut], destinations, left)
+            self.last_index = last_index
+            if n_done == 0:
+                raise RuntimeError("device made no progress")  # cannot happen: a rebuilt list has no unseen arrivals
+            moves = []
+            for k in range(n_done):
+                if int(rem[k]) == 2:   # not evaluated: the removable limit was reached inside the call
+                    n_done = k
+                    break
+                info, pods = by_name[names[k]], lists[k]
+                dests = [int(node_out[i]) for i in range(off[k], off[k + 1])]
+                for p, m in zip(pods, dests):
+                    if m >= 0:  # hints.Set on every placement, reverted simulation or not (hinting_simulator.go:108,133)
+                        self.hints.set(hint_key_from_pod(p), infos[m].node.name)
+                if int(rem[k]) == 1:
+                    removable.append(NodeToBeRemoved(info.node, list(pods), [p for p in info.pods if p.daemonset]))
+                    if self.can_persist:
+                        moves.append((info, pods, dests))
+                        destinations.pop(names[k], None)   # planner.go:318 (the planner always persists)
+                else:
+                    unremovable.append(UnremovableNode(info.node, NO_PLACE_TO_MOVE_PODS))
+            # Commit: the snapshot is only rewritten between device calls, so the indices above stayed valid
+            for info, pods, dests in moves:
+                for p, m in zip(pods, dests):
+                    infos[m].pods.append(p)       # the pod now runs on its destination (arrival order)
+                self.snapshot.remove(info)         # RemoveNodeInfo: later list positions shift by one
+            if n_done == 0:
+                break
+            todo = todo[n_done:]
+        return removable, unremovable, todo

@@ -389,3 +389,100 @@ def fuzz_pending(seed: int, max_nodes: int = 40, max_pods: int = 120) -> Pending
     acceptable = [0 if rng.chance(1, 6) else 1 for _ in range(n_nodes)] if rng.chance(1, 3) else None
     return PendingWorkload(f"fuzz_pending{seed}", nodes, pods, hints if rng.chance(2, 3) else None, acceptable,
                            break_on_failure=rng.chance(1, 5), last_index=rng.below(n_nodes + 2))
+
+
+# ---------------------------------------------------------------------------------------------
+# scale-down workloads: which nodes can go once their pods are packed elsewhere
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class RemovalWorkload:
+    name: str
+    nodes: List[NodeInfo]
+    candidates: List[int]                       # node indices, planner order
+    destination: Optional[List[int]] = None
+    hints: Optional[dict] = None                # id(pod) -> node index
+    persist: bool = True
+    max_removable: int = 0
+    last_index: int = 0
+
+
+def fuzz_removals(seed: int, max_nodes: int = 30) -> RemovalWorkload:
+    """Random small cluster with under-used nodes; candidates in a random order."""
+    rng = SplitMix64(0xD0D0000 + seed)
+    n_nodes = 2 + rng.below(max_nodes) if not rng.chance(1, 10) else 70 + rng.below(120)
+    ports = [5555, 8080]
+    apps = [f"app{i}" for i in range(4)]
+    n_specs = 1 + rng.below(5)
+    specs = []
+    for c in range(n_specs):
+        kw = dict(labels={"app": rng.pick(apps)}, requests={"cpu": rng.pick([50, 100, 250, 500, 1000]), "memory": rng.pick([64 * MiB, 256 * MiB, 1 * GiB])})
+        if rng.chance(1, 6):
+            kw["host_ports"] = [ContainerPort(rng.pick(ports))]
+        if rng.chance(1, 6):
+            kw["anti_affinity"] = [PodAffinityTerm(LABEL_HOSTNAME, match_labels={"app": rng.pick(apps)})]
+        if rng.chance(1, 5):
+            kw["node_selector"] = {"pool": f"p{rng.below(2)}"}
+        if rng.chance(1, 5):
+            kw["tolerations"] = [Toleration(key="dedicated", operator="Exists")]
+        specs.append(kw)
+    nodes = []
+    for i in range(n_nodes):
+        taints = [Taint("dedicated", "x", "NoSchedule")] if rng.chance(1, 8) else []
+        node = _node(f"sd{seed}-n{i}", rng.pick([1000, 2000, 4000]), rng.pick([2, 4, 8]) * GiB, rng.pick([4, 8, 110]), {"pool": f"p{rng.below(2)}"}, taints)
+        if rng.chance(1, 15):
+            node.unschedulable = True
+        info = NodeInfo(node)
+        # fill greedily with random specs that fit the node on their own terms (the snapshot is a legal cluster state)
+        cpu = mem = 0
+        used_ports, apps_here = set(), []
+        for _ in range(rng.below(5)):
+            kw = specs[rng.below(n_specs)]
+            rq = kw["requests"]
+            if cpu + rq["cpu"] > node.allocatable["cpu"] or mem + rq["memory"] > node.allocatable["memory"] or len(info.pods) >= node.allocatable["pods"]:
+                continue
+            pp = tuple(h.host_port for h in kw.get("host_ports", []))
+            if any(x in used_ports for x in pp):
+                continue
+            aa = kw.get("anti_affinity", [])
+            if any(t.match_labels["app"] in apps_here for t in aa):
+                continue
+            if any(q.anti_affinity and q.anti_affinity[0].match_labels["app"] == kw["labels"]["app"] for q in info.pods):
+                continue
+            if "node_selector" in kw and kw["node_selector"]["pool"] != node.labels["pool"]:
+                continue
+            if taints and "tolerations" not in kw:
+                continue
+            info.pods.append(Pod(name=f"r{i}-{len(info.pods)}", labels=dict(kw["labels"]), requests=dict(rq), host_ports=list(kw.get("host_ports", [])),
+                                 anti_affinity=list(aa), node_selector=dict(kw.get("node_selector", {})), tolerations=list(kw.get("tolerations", [])),
+                                 controller_uid=f"rs-{specs.index(kw)}"))
+            cpu += rq["cpu"]; mem += rq["memory"]; used_ports.update(pp); apps_here.append(kw["labels"]["app"])
+        if rng.chance(1, 6):
+            info.pods.append(Pod(name=f"ds{i}", namespace="kube-system", labels={"app": "ds"}, requests={"cpu": 50, "memory": 32 * MiB}, daemonset=True))
+        nodes.append(info)
+    order = rng.sample(list(range(n_nodes)), 1 + rng.below(n_nodes))
+    destination = [0 if rng.chance(1, 8) else 1 for _ in range(n_nodes)] if rng.chance(1, 3) else None
+    hints = {}
+    if rng.chance(1, 2):
+        for c in order:
+            for p in nodes[c].pods:
+                if not p.daemonset and rng.chance(1, 4):
+                    hints[id(p)] = rng.below(n_nodes)
+    return RemovalWorkload(f"fuzz_removals{seed}", nodes, order, destination, hints or None, persist=not rng.chance(1, 5),
+                           max_removable=rng.pick([0, 0, 0, 1, 3]), last_index=rng.below(n_nodes + 1))
+
+
+def removal_scale(n_nodes: int, pods_per_node: int = 12, frac_candidates: float = 0.3, seed: int = 1) -> RemovalWorkload:
+    """An under-used cluster: every node ~35 % full with controller pods; the emptiest nodes are candidates
+    (utilization order, like the planner's eligibility + sorting processors)."""
+    rng = SplitMix64(0x5CA1E000 + seed)
+    nodes = []
+    for i in range(n_nodes):
+        info = NodeInfo(_node(f"n-{i}", 16000, 64 * GiB, 110, {LABEL_ZONE: f"zone-{i % 3}"}))
+        for j in range(rng.below(pods_per_node + 1)):
+            c = rng.below(24)
+            info.pods.append(Pod(name=f"p-{i}-{j}", labels={"app": f"c{c}"}, requests={"cpu": 250 * (1 + c % 4), "memory": (1 + c % 3) * GiB},
+                                 controller_uid=f"rs-{c}"))
+        nodes.append(info)
+    util = sorted(range(n_nodes), key=lambda i: (sum(p.requests["cpu"] for p in nodes[i].pods), i))
+    cands = util[:max(1, int(n_nodes * frac_candidates))]
+    return RemovalWorkload(f"removal_{n_nodes}n", nodes, cands)

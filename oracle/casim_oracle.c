@@ -118,6 +118,7 @@ typedef struct {
     ivec pods;          /* pod spec ids, in AddPod order */
     VEC(hostport) used_ports;
     int n_pods_with_aa; /* len(PodsWithRequiredAntiAffinity) */
+    int orig_id;        /* position at orc_snapshot_add time (stable id across removals) */
     int is_new;         /* created by this Estimate (estimationState.newNodeNames) */
     int new_pods;       /* pods placed by this Estimate (newNodesWithPods) */
 } node;
@@ -132,6 +133,10 @@ struct orc {
     int id_hostname, id_noschedule, id_noexecute, id_allip, id_tcp, id_empty, id_unsched_key;
     int64_t filter_runs;
     const char* last_fail_reason; /* reason of the last failing Filter run (SchedulingError.FailingPredicateReasons) */
+    /* Fork()/Revert() support for callers that commit pods to snapshot nodes: pre-images of touched nodes */
+    int snap_added;     /* nodes ever added to the snapshot (source of orig_id) */
+    int undo_on;
+    struct { int n, cap; struct undo_rec { int orig_id; node copy; }* v; } undo;
 };
 
 /* ------------------------------------------------------------------------------------- */
@@ -349,6 +354,7 @@ static node node_clone(const node* s) {
 int orc_snapshot_add(orc* o, int nd) {
     NODECHK(o, nd);
     node c = node_clone(&o->nodes.v[nd]);
+    c.orig_id = o->snap_added++;
     VEC_PUSH(o->snap, c);
     return o->snap.n - 1;
 }
@@ -1016,6 +1022,17 @@ int orc_check_predicates(orc* o, int template_node, int pod, const char** plugin
 /* ------------------------------------------------------------------------------------- */
 int orc_snapshot_size(const orc* o) { return o->snap.n; }
 
+/* pre-image of a snapshot node about to be modified inside a forked region (see orc_simulate_node_removals) */
+static void undo_touch(orc* o, int idx) {
+    if (!o->undo_on) return;
+    const int id = o->snap.v[idx].orig_id;
+    for (int i = 0; i < o->undo.n; ++i) if (o->undo.v[i].orig_id == id) return;
+    if (o->undo.n == o->undo.cap) { o->undo.cap = o->undo.cap ? o->undo.cap * 2 : 16; o->undo.v = realloc(o->undo.v, sizeof(*o->undo.v) * (size_t)o->undo.cap); }
+    o->undo.v[o->undo.n].orig_id = id;
+    o->undo.v[o->undo.n].copy = node_clone(&o->snap.v[idx]);
+    o->undo.n++;
+}
+
 /* SimilarPodsScheduling  CA/simulator/scheduling/similar_pods.go:50-97: per controller at most 10
  * remembered (spec, labels) entries; here an entry is a pod spec id */
 typedef struct { int key; int specs[10]; int n; } similar_entry;
@@ -1067,6 +1084,7 @@ int orc_try_schedule_pods(orc* o, int n_pods, const int32_t* pod, const int32_t*
             }
         }
         if (node_idx >= 0) {
+            undo_touch(o, node_idx);
             node_add_pod(o, &o->snap.v[node_idx], p);   /* SchedulePod commits the pod to the snapshot */
             node_out[i] = node_idx;
             scheduled++;
@@ -1074,6 +1092,110 @@ int orc_try_schedule_pods(orc* o, int n_pods, const int32_t* pod, const int32_t*
     }
     VEC_FREE(memo);
     return scheduled;
+}
+
+/* ------------------------------------------------------------------------------------- */
+/* scale-down: RemovalSimulator.SimulateNodeRemoval in planner order         */
+/* ------------------------------------------------------------------------------------- */
+static int snap_pos_of(const orc* o, int orig_id) {
+    for (int i = 0; i < o->snap.n; ++i) if (o->snap.v[i].orig_id == orig_id) return i;
+    return -1;
+}
+/* Planner.categorizeNodes loop  CA/core/scaledown/planner/planner.go:300-330 around
+ * RemovalSimulator.SimulateNodeRemoval  CA/simulator/cluster.go:131-172 and findPlaceFor :190-231:
+ *   per candidate, in order: Fork; the candidate becomes a pod-less tainted ghost (replaceWithTaintedGhostNode
+ *   :243-265; canonical list order: the ghost keeps the candidate's list position); TrySchedulePods(its pods,
+ *   breakOnFailure = true, acceptable = destination && not the candidate); all pods placed => removable:
+ *   with `persist` the moves are committed, the ghost leaves the list (RemoveNodeInfo :230) and the node
+ *   leaves the destination set (planner.go:318); otherwise Revert.  lastIndex lives in the plugin runner and is
+ *   never reverted.
+ * Node ids are positions at orc_snapshot_add time.  pods / hints: per candidate pod_offsets[k]..pod_offsets[k+1].
+ * dynamic_lists = 1: pods that an earlier removal moved onto a later candidate are appended to that candidate's
+ *   list (what GetPodsToMove sees in the committed snapshot); 0: the loop stops in front of such a candidate
+ *   (*n_processed < K) — the protocol of casim_simulate_node_removals, whose caller re-submits the rest.
+ * removable_out[k]: 1 removable, 0 no place, 2 not evaluated.  node_out[i]: node the i-th listed pod was placed
+ * on in ITS candidate's simulation (-1: not placed).  final_node_out[i] (may be NULL): where the pod is at the end
+ * (its candidate id if it never moved for good). */
+int orc_simulate_node_removals(orc* o, int K, const int32_t* cand_node, const int32_t* pod_offsets, const int32_t* pod,
+                               const int32_t* hint, const uint8_t* destination, int persist, int max_removable,
+                               int dynamic_lists, int* last_index, uint8_t* removable_out, int32_t* node_out,
+                               int32_t* final_node_out, int* n_processed) {
+    const int N0 = o->snap_added;
+    const int total = pod_offsets[K];
+    uint8_t* dest = malloc((size_t)(N0 > 0 ? N0 : 1));
+    for (int i = 0; i < N0; ++i) dest[i] = destination ? destination[i] : 1;
+    for (int k = 0; k < K; ++k) removable_out[k] = 2;
+    for (int i = 0; i < total; ++i) node_out[i] = -1;
+    int32_t* where = malloc(sizeof(int32_t) * (size_t)(total > 0 ? total : 1));   /* current node (orig id) of every listed pod */
+    for (int k = 0; k < K; ++k) for (int i = pod_offsets[k]; i < pod_offsets[k + 1]; ++i) where[i] = cand_node[k];
+    int removed = 0, k = 0;
+    for (; k < K; ++k) {
+        if (max_removable > 0 && removed >= max_removable) break;         /* planner.go:306-310 */
+        const int Y = cand_node[k];
+        const int ypos = snap_pos_of(o, Y);
+        if (ypos < 0) { removable_out[k] = 0; continue; }                  /* NoNodeInfo :139-147 */
+        /* the candidate's list: its own pods, then pods moved onto it earlier */
+        VEC(int) list; memset(&list, 0, sizeof list);
+        for (int i = pod_offsets[k]; i < pod_offsets[k + 1]; ++i) VEC_PUSH(list, i);
+        int arrived = 0;
+        for (int i = 0; i < total; ++i) if (where[i] == Y && !(i >= pod_offsets[k] && i < pod_offsets[k + 1])) arrived++;
+        if (arrived && !dynamic_lists) { VEC_FREE(list); break; }
+        if (arrived) {
+            /* arrival order == order of the committed moves: earlier candidates first, list order inside */
+            for (int kk = 0; kk < k; ++kk) for (int i = pod_offsets[kk]; i < pod_offsets[kk + 1]; ++i) if (where[i] == Y) VEC_PUSH(list, i);
+        }
+        /* Fork */
+        o->undo_on = 1; o->undo.n = 0;
+        node saved_y = o->snap.v[ypos];                                    /* moved, restored or freed below */
+        node ghost = node_clone(&saved_y);
+        ghost.pods.n = 0; ghost.used_ports.n = 0; ghost.n_pods_with_aa = 0;
+        memset(ghost.requested, 0, sizeof ghost.requested);
+        { taint t = {intern(&o->st, "ToBeDeletedByClusterAutoscaler"), intern(&o->st, "0"), o->id_noschedule}; VEC_PUSH(ghost.taints, t); }
+        o->snap.v[ypos] = ghost;
+        const int n = o->snap.n, np = list.n;
+        int32_t* pp = malloc(sizeof(int32_t) * (size_t)(np > 0 ? np : 1));
+        int32_t* hh = malloc(sizeof(int32_t) * (size_t)(np > 0 ? np : 1));
+        int32_t* oo = malloc(sizeof(int32_t) * (size_t)(np > 0 ? np : 1));
+        uint8_t* acc = malloc((size_t)n);
+        for (int i = 0; i < n; ++i) acc[i] = (uint8_t)(i != ypos && dest[o->snap.v[i].orig_id]);   /* isCandidateNode :191-193 */
+        for (int i = 0; i < np; ++i) {
+            pp[i] = pod[list.v[i]];
+            /* hints of the caller refer to original pods; a pod that was moved carries the hint of its last move = the
+             * node it sits on = the candidate itself, which is not acceptable */
+            const int h = (hint && where[list.v[i]] == cand_node[k] && list.v[i] >= pod_offsets[k] && list.v[i] < pod_offsets[k + 1]) ? hint[list.v[i]] : -1;
+            hh[i] = h >= 0 ? snap_pos_of(o, h) : -1;
+        }
+        const int placed = orc_try_schedule_pods(o, np, pp, hh, NULL, acc, 1, last_index, oo);
+        const int ok = placed == np;
+        for (int i = 0; i < np; ++i)
+            if (list.v[i] >= pod_offsets[k] && list.v[i] < pod_offsets[k + 1]) node_out[list.v[i]] = oo[i] >= 0 ? o->snap.v[oo[i]].orig_id : -1;
+        o->undo_on = 0;
+        if (ok && persist) {
+            for (int i = 0; i < np; ++i) where[list.v[i]] = o->snap.v[oo[i]].orig_id;
+            for (int i = 0; i < o->undo.n; ++i) node_free(&o->undo.v[i].copy);
+            node_free(&saved_y); node_free(&o->snap.v[ypos]);
+            for (int i = ypos; i + 1 < o->snap.n; ++i) o->snap.v[i] = o->snap.v[i + 1];   /* RemoveNodeInfo */
+            o->snap.n--;
+            dest[Y] = 0;
+            removed++;
+        } else {
+            for (int i = 0; i < o->undo.n; ++i) {                          /* Revert */
+                const int pos = snap_pos_of(o, o->undo.v[i].orig_id);
+                node_free(&o->snap.v[pos]);
+                o->snap.v[pos] = o->undo.v[i].copy;
+            }
+            node_free(&o->snap.v[ypos]);
+            o->snap.v[ypos] = saved_y;
+            if (ok) removed++;
+        }
+        o->undo.n = 0;
+        removable_out[k] = (uint8_t)(ok ? 1 : 0);
+        free(pp); free(hh); free(oo); free(acc); VEC_FREE(list);
+    }
+    if (final_node_out) for (int i = 0; i < total; ++i) final_node_out[i] = where[i];
+    *n_processed = k;
+    free(dest); free(where);
+    return removed;
 }
 
 /* ------------------------------------------------------------------------------------- */

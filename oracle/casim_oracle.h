@@ -119,6 +119,14 @@ int orc_try_schedule_pods(orc* o, int n_pods, const int32_t* pod, const int32_t*
  * nodes stay, so tests build a fresh scenario per case */
 int orc_snapshot_size(const orc* o);
 
+/* ---- scale-down: Planner.categorizeNodes loop around RemovalSimulator.SimulateNodeRemoval (SURVEY §8 f4;
+ * CA/core/scaledown/planner/planner.go:300-330, CA/simulator/cluster.go:131-265).  See the .c file for the
+ * argument meaning.  Node ids = positions at orc_snapshot_add time.  Returns the number of removable nodes. */
+int orc_simulate_node_removals(orc* o, int n_candidates, const int32_t* cand_node, const int32_t* pod_offsets,
+                               const int32_t* pod, const int32_t* hint, const uint8_t* destination, int persist,
+                               int max_removable, int dynamic_lists, int* last_index, uint8_t* removable_out,
+                               int32_t* node_out, int32_t* final_node_out, int* n_processed);
+
 /* ---- pieces with their own reference unit tests ----------------------------------------- */
 /* getMinLimit (threshold_based_limiter.go:45-53) */
 int64_t orc_get_min_limit(int64_t base, int64_t target);

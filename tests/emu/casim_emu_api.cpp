@@ -17,6 +17,7 @@ struct EmuBackend {
     void h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     void d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     void zero(void* d, size_t n) { memset(d, 0, n); }
+    void fill8(void* d, int v, size_t n) { memset(d, v, n); }
     void sync() {}
     size_t lds_budget() const { return lds; }
     bool ok() const { return true; }
@@ -75,6 +76,19 @@ EMU_API int32_t emu_try_schedule_pods(const casim_pegs* classes, const casim_gro
     if (rc == CASIM_OK) rc = s.run();
     if (rc == CASIM_OK) rc = s.fetch(node_out, last_index_out, n_scheduled_out);
     if (info_out) { info_out[0] = s.runs(); info_out[1] = s.in_lds() ? 1 : 0; }
+    if (rc < 0) g_err = s.error();
+    return rc;
+}
+
+EMU_API int32_t emu_simulate_node_removals(const casim_pegs* classes, const casim_groups* nodes, const casim_removal_candidates* cand,
+                                           int64_t lds_budget_bytes, uint8_t* removable_out, int32_t* node_out, int32_t* last_index_out,
+                                           int32_t* n_processed_out) {
+    EmuBackend bk;
+    if (lds_budget_bytes > 0) bk.lds = (size_t)lds_budget_bytes;
+    casim::SchedulerT<EmuBackend> s(bk);
+    int32_t rc = s.init_removals(classes, nodes, cand);
+    if (rc == CASIM_OK) rc = s.run();
+    if (rc == CASIM_OK) rc = s.fetch_removals(removable_out, node_out, last_index_out, n_processed_out);
     if (rc < 0) g_err = s.error();
     return rc;
 }

@@ -220,3 +220,105 @@ def assert_sched_matches(got, want, what=""):
     assert rc == 0, f"{what}: status {rc}"
     assert list(node_out) == list(w_out), f"{what}: node per pod\n got {list(node_out)}\n want {list(w_out)}"
     assert (li, ns) == (w_li, w_ns), f"{what}: (lastIndex, scheduled) got {(li, ns)} want {(w_li, w_ns)}"
+
+
+# ---------------------------------------------------------------------------------------------
+# scale-down removal simulation
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class RemovalCase:
+    nodes: List[NodeInfo]                          # the cluster snapshot, list order; pods = everything running there
+    candidates: List[int]                          # node indices, planner order
+    destination: Optional[Sequence[int]] = None    # per node
+    hints: Optional[dict] = None                   # id(pod) -> node index
+    persist: bool = True
+    max_removable: int = 0
+    last_index: int = 0
+    lanes: Sequence[str] = ("cpu", "memory")
+
+    def pod_lists(self):
+        return [[p for p in self.nodes[c].pods if not p.daemonset] for c in self.candidates]
+
+    def flat_hints(self):
+        if not self.hints:
+            return None
+        return [self.hints.get(id(p), -1) for lst in self.pod_lists() for p in lst]
+
+
+def removal_oracle(case: RemovalCase, dynamic_lists=False):
+    s = OracleScenario(lanes=case.lanes)
+    for info in case.nodes:
+        s.add_existing(info)
+    out = s.simulate_node_removals(case.candidates, case.pod_lists(), case.flat_hints(), case.destination, case.persist,
+                                   case.max_removable, dynamic_lists, case.last_index)
+    s.close()
+    return out
+
+
+def removal_encode(case: RemovalCase):
+    """Classes of the pods to move + one node record per snapshot node (all its pods preloaded)."""
+    enc = Encoder(lanes=case.lanes, explicit_self_exclusion=True)
+    class_of, pod_class, off = {}, [], [0]
+    for lst in case.pod_lists():
+        for p in lst:
+            k = p.spec_key()
+            if k not in class_of:
+                class_of[k] = enc.add_peg(PodEquivalenceGroup(pods=[p]))
+            pod_class.append(class_of[k])
+        off.append(len(pod_class))
+    for info in case.nodes:
+        enc.add_group(info, pegs=[])
+    enc.finalize()
+    return enc, np.array(pod_class, np.int32), np.array(off, np.int32)
+
+
+def emu_simulate_node_removals(classes, nodes, cand_node, pod_offsets, pod_class, hint_node=None, destination=None, persist=True,
+                               max_removable=0, last_index=0, lds_budget=0):
+    from kubernetes_autoscaler_amd.engine import make_removal_candidates
+    L = emu_lib()
+    if not hasattr(L, "_removal_ready"):
+        L.emu_simulate_node_removals.restype = C.c_int32
+        L.emu_simulate_node_removals.argtypes = [C.POINTER(_abi.Pegs), C.POINTER(_abi.Groups), C.POINTER(_abi.RemovalCandidates), C.c_int64,
+                                                 _abi.u8p, _abi.i32p, _abi.i32p, _abi.i32p]
+        L._removal_ready = True
+    st, keep = make_removal_candidates(cand_node, pod_offsets, pod_class, hint_node, destination, persist, max_removable, last_index)
+    K, total = st.n_candidates, int(keep[1][-1])
+    removable = np.full(max(K, 1), 2, np.uint8)
+    node_out = np.full(max(total, 1), -1, np.int32)
+    li, npr = C.c_int32(0), C.c_int32(0)
+    rc = L.emu_simulate_node_removals(C.byref(classes), C.byref(nodes), C.byref(st), int(lds_budget), removable.ctypes.data_as(_abi.u8p),
+                                      node_out.ctypes.data_as(_abi.i32p), C.byref(li), C.byref(npr))
+    assert rc >= 0, (rc, L.emu_last_error())
+    del keep
+    return rc, removable[:K].copy(), node_out[:total].copy(), li.value, npr.value
+
+
+class EmuContext:
+    """Stands in for engine.Context in CPU tests of the host mirrors: same method, product kernels under the emulator."""
+
+    def __init__(self, lds_budget=0):
+        self.lds_budget = lds_budget
+
+    def simulate_node_removals(self, classes, nodes, cand_node, pod_offsets, pod_class, hint_node=None, destination=None,
+                               persist=True, max_removable=0, last_index=0):
+        return emu_simulate_node_removals(classes, nodes, cand_node, pod_offsets, pod_class, hint_node, destination, persist,
+                                          max_removable, last_index, self.lds_budget)
+
+
+def removal_device(case: RemovalCase, ctx):
+    """ctx: engine.Context (MI355X) or EmuContext."""
+    enc, pod_class, off = removal_encode(case)
+    out = ctx.simulate_node_removals(enc.pegs, enc.groups, case.candidates, off, pod_class, case.flat_hints(), case.destination,
+                                     persist=case.persist, max_removable=case.max_removable, last_index=case.last_index)
+    enc.close()
+    return out
+
+
+def assert_removal_matches(got, want, what=""):
+    rc, rem, node_out, li, npr = got
+    w_rem, w_out, _, w_li, w_npr = want
+    assert rc == 0, f"{what}: status {rc}"
+    assert npr == w_npr, f"{what}: candidates processed got {npr} want {w_npr}"
+    assert list(rem) == list(w_rem), f"{what}: removable\n got {list(rem)}\n want {list(w_rem)}"
+    assert list(node_out) == list(w_out), f"{what}: destinations\n got {list(node_out)}\n want {list(w_out)}"
+    assert li == w_li, f"{what}: lastIndex got {li} want {w_li}"

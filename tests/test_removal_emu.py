@@ -1,0 +1,105 @@
+"""SURVEY §8 row f4 (scale-down removal simulation): product encoder + K_sched transactions under the wave emulator
+against the object-level CPU oracle — removable flag per candidate, destination of every moved pod, lastIndex, and the
+number of candidates the call could decide.  CPU only; the same cases run on the MI355X in test_gpu_sched.py."""
+import numpy as np
+import pytest
+
+from harness import EmuContext, RemovalCase, assert_removal_matches, removal_device, removal_oracle
+from kubernetes_autoscaler_amd.objects import NodeInfo, Pod, build_test_pod
+from kubernetes_autoscaler_amd.scaledown import NO_PLACE_TO_MOVE_PODS, RemovalSimulator
+from kubernetes_autoscaler_amd.workloads import _node, fuzz_removals, removal_scale
+
+
+def case_of(w) -> RemovalCase:
+    return RemovalCase(nodes=w.nodes, candidates=w.candidates, destination=w.destination, hints=w.hints, persist=w.persist,
+                       max_removable=w.max_removable, last_index=w.last_index)
+
+
+def check(case, what="", lds=(0, 64)):
+    want = removal_oracle(case)
+    for b in lds:
+        assert_removal_matches(removal_device(case, EmuContext(b)), want, f"{what} lds={b}")
+    return want
+
+
+@pytest.mark.parametrize("seed", range(300))
+def test_fuzz(seed):
+    w = fuzz_removals(seed)
+    check(case_of(w), w.name)
+
+
+def test_simple_chain():
+    # three nodes of 1000m: n0 {400}, n1 {400}, n2 {300}; candidates n0, n1, n2 in that order, everything persists
+    nodes = [NodeInfo(_node(f"n{i}", 1000, 10**9, 10)) for i in range(3)]
+    for i, cpu in enumerate((400, 400, 300)):
+        nodes[i].pods.append(build_test_pod(f"p{i}", cpu, 1))
+    rem, node_out, final, li, npr = check(RemovalCase(nodes=nodes, candidates=[0, 1, 2]))
+    # n0's pod goes to n1 (first node after lastIndex 0); n1 then carries an arrival: the call stops in front of it
+    assert list(rem) == [1, 2, 2] and list(node_out) == [1, -1, -1] and npr == 1
+
+
+def test_reverted_simulation_leaves_no_trace():
+    # candidate n0 has two pods, only one fits elsewhere: reverted; candidate n2's pod then still sees n1 untouched
+    nodes = [NodeInfo(_node(f"n{i}", 1000, 10**9, 10)) for i in range(3)]
+    nodes[0].pods += [build_test_pod("a", 600, 1), build_test_pod("b", 600, 1)]
+    nodes[1].pods += [build_test_pod("c", 300, 1)]
+    nodes[2].pods += [build_test_pod("d", 700, 1)]
+    rem, node_out, final, li, npr = check(RemovalCase(nodes=nodes, candidates=[0, 2], destination=[1, 1, 0]))
+    assert list(rem) == [0, 1] and list(node_out) == [1, -1, 1] and npr == 2
+
+
+def test_list_positions_shift_after_a_removal():
+    # after n1 is removed the list is [n0, n2, n3]: lastIndex keeps counting positions, not node ids
+    nodes = [NodeInfo(_node(f"n{i}", 1000, 10**9, 10)) for i in range(4)]
+    nodes[1].pods.append(build_test_pod("x", 100, 1))
+    nodes[3].pods.append(build_test_pod("y", 100, 1))
+    for li in range(5):
+        check(RemovalCase(nodes=nodes, candidates=[1, 3], last_index=li), f"li={li}")
+
+
+def test_empty_nodes_are_removable():
+    nodes = [NodeInfo(_node(f"n{i}", 1000, 10**9, 10)) for i in range(5)]
+    rem, node_out, final, li, npr = check(RemovalCase(nodes=nodes, candidates=[4, 0, 2, 1, 3], last_index=2))
+    assert list(rem) == [1] * 5 and npr == 5 and li == 2
+
+
+def test_max_removable_and_not_persisting():
+    w = removal_scale(40, pods_per_node=4, frac_candidates=0.5, seed=3)
+    for persist in (True, False):
+        for limit in (0, 1, 4):
+            check(RemovalCase(nodes=w.nodes, candidates=w.candidates, persist=persist, max_removable=limit), f"persist={persist} limit={limit}")
+
+
+def test_large_cluster_several_chunks():
+    w = removal_scale(1300, pods_per_node=3, frac_candidates=0.05, seed=5)
+    want = check(case_of(w), w.name, lds=(0,))
+    assert want[4] >= 1
+
+
+# ---- host mirror: the planner loop re-submits when a candidate received pods -----------------------------------
+@pytest.mark.parametrize("seed", range(60))
+def test_mirror_chained_calls_equal_the_reference_loop(seed):
+    """RemovalSimulator.simulate_node_removals (several device calls, GetPodsToMove re-run in between) == the oracle
+    walking the whole candidate list with arrived pods appended (what the reference's committed snapshot shows)."""
+    w = fuzz_removals(1000 + seed)
+    if not w.persist:
+        w.persist = True
+    nodes = [NodeInfo(info.node, list(info.pods)) for info in w.nodes]
+    case = RemovalCase(nodes=w.nodes, candidates=w.candidates, destination=w.destination, hints=None, persist=True,
+                       max_removable=w.max_removable, last_index=w.last_index)
+    rem, node_out, final, li, npr = removal_oracle(case, dynamic_lists=True)
+    sim = RemovalSimulator(EmuContext(), nodes, persist_successful_simulations=True)
+    sim.last_index = w.last_index
+    dest = {info.node.name: (w.destination is None or bool(w.destination[i])) for i, info in enumerate(w.nodes)}
+    removable, unremovable, skipped = sim.simulate_node_removals([w.nodes[c].node.name for c in w.candidates], dest, w.max_removable)
+    want_removable = [w.nodes[c].node.name for k, c in enumerate(w.candidates) if rem[k] == 1]
+    want_unremovable = [w.nodes[c].node.name for k, c in enumerate(w.candidates) if rem[k] == 0]
+    assert [r.node.name for r in removable] == want_removable
+    assert [u.node.name for u in unremovable] == want_unremovable and all(u.reason == NO_PLACE_TO_MOVE_PODS for u in unremovable)
+    assert len(skipped) == len(w.candidates) - npr
+    assert sim.last_index == li
+    # where every pod that was ever listed sits at the end
+    where = {id(p): info.node.name for info in nodes for p in info.pods}
+    flat = [p for lst in case.pod_lists() for p in lst]
+    for p, f in zip(flat, final):
+        assert where[id(p)] == w.nodes[f].node.name, (p.name, f)
