@@ -300,11 +300,13 @@ int32_t casim_time_try_schedule_pods(casim_ctx* ctx, const casim_pegs* classes, 
  * NewRemovalSimulator(..., true)), the moves are committed, the node leaves the list (lastIndex positions shift
  * like the reference's list) and the destination set; otherwise the simulation is reverted.  lastIndex is never
  * reverted (it lives in the plugin runner).
- * The call stops in front of a candidate that received pods from an earlier committed removal — its pod list is no
- * longer the one the caller computed: *n_processed_out < K, the caller applies the results so far and re-submits
- * the rest (GetPodsToMove runs again on the host, with its updated PDB tracker).
- * removable_out[k]: 1 removable, 0 no place to move the pods, 2 not evaluated.  node_out[i]: destination of pod i
- * in its candidate's simulation (also for a failed one: the reference keeps those hints), -1 not placed.
+ * A candidate that received pods from an earlier committed removal lists them again after its own pods, in arrival
+ * order — what GetPodsToMove sees in the committed snapshot.  Those "ext" pods are reported in the ext_* arrays
+ * (which candidate's simulation, which pod, where it went).  The call stops in front of such a candidate
+ * (n_processed < K; the caller applies the results so far and re-submits the rest) when one of the arrived pods
+ * is marked pod_sticky (the host has to re-run its drainability / PDB rules for it) or the ext arrays are full.
+ * removable[k]: 1 removable, 0 no place to move the pods, 2 not evaluated.  node_out[i]: destination of pod i in
+ * its own candidate's simulation (also for a failed one: the reference keeps those hints), -1 not placed.
  */
 typedef struct casim_removal_candidates {
     int32_t n_candidates;            /* K */
@@ -313,14 +315,26 @@ typedef struct casim_removal_candidates {
     const int32_t* pod_class;        /* [total] */
     const int32_t* hint_node;        /* [total] or NULL */
     const uint8_t* destination;      /* [N] podDestinations membership; NULL = every node */
+    const uint8_t* pod_sticky;       /* [total] or NULL: 1 = may not move a second time without the host */
     int32_t persist;                 /* canPersist */
     int32_t max_removable;           /* stop after this many removable nodes (unneededNodesLimit); 0 = no limit */
     int32_t last_index;
+    int32_t ext_capacity;            /* entries of the ext_* result arrays; 0 = stop at the first candidate with arrivals */
 } casim_removal_candidates;
 
+typedef struct casim_removal_results {
+    uint8_t* removable;              /* [K] */
+    int32_t* node_out;               /* [total] */
+    int32_t* ext_candidate;          /* [ext_capacity] candidate whose simulation listed the pod again */
+    int32_t* ext_pod;                /* [ext_capacity] flat index of that pod */
+    int32_t* ext_node;               /* [ext_capacity] its destination in that simulation, -1 not placed */
+    int32_t n_ext;                   /* out: ext entries written */
+    int32_t last_index;              /* out */
+    int32_t n_processed;             /* out: candidates [0, n_processed) have their final answer */
+} casim_removal_results;
+
 int32_t casim_simulate_node_removals(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes,
-                                     const casim_removal_candidates* cand, uint8_t* removable_out /*[K]*/,
-                                     int32_t* node_out /*[total]*/, int32_t* last_index_out, int32_t* n_processed_out);
+                                     const casim_removal_candidates* cand, casim_removal_results* out);
 int32_t casim_time_node_removals(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes,
                                  const casim_removal_candidates* cand, int32_t iters, float* ms_out);
 

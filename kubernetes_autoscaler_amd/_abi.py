@@ -73,7 +73,13 @@ class PodSequence(C.Structure):
 
 class RemovalCandidates(C.Structure):
     _fields_ = [("n_candidates", C.c_int32), ("cand_node", i32p), ("pod_offsets", i32p), ("pod_class", i32p), ("hint_node", i32p),
-                ("destination", u8p), ("persist", C.c_int32), ("max_removable", C.c_int32), ("last_index", C.c_int32)]
+                ("destination", u8p), ("pod_sticky", u8p), ("persist", C.c_int32), ("max_removable", C.c_int32),
+                ("last_index", C.c_int32), ("ext_capacity", C.c_int32)]
+
+
+class RemovalResults(C.Structure):
+    _fields_ = [("removable", u8p), ("node_out", i32p), ("ext_candidate", i32p), ("ext_pod", i32p), ("ext_node", i32p),
+                ("n_ext", C.c_int32), ("last_index", C.c_int32), ("n_processed", C.c_int32)]
 
 
 cstr = C.c_char_p
@@ -101,8 +107,8 @@ PROTOTYPES = {
     "casim_try_schedule_pods": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(PodSequence), i32p, i32p, i32p]),
     "casim_time_try_schedule_pods": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(PodSequence), C.c_int32,
                                                  C.POINTER(C.c_float)]),
-    "casim_simulate_node_removals": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(RemovalCandidates), u8p, i32p,
-                                                 i32p, i32p]),
+    "casim_simulate_node_removals": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(RemovalCandidates),
+                                                 C.POINTER(RemovalResults)]),
     "casim_time_node_removals": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(RemovalCandidates), C.c_int32,
                                              C.POINTER(C.c_float)]),
     "casim_copy_bandwidth": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, f64p]),

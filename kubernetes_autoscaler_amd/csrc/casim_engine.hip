@@ -387,15 +387,14 @@ int32_t casim_try_schedule_pods(casim_ctx* ctx, const casim_pegs* classes, const
 
 // ---- scale-down removal simulation ----------------------------------------------
 int32_t casim_simulate_node_removals(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes,
-                                     const casim_removal_candidates* cand, uint8_t* removable_out, int32_t* node_out,
-                                     int32_t* last_index_out, int32_t* n_processed_out) {
+                                     const casim_removal_candidates* cand, casim_removal_results* out) {
     g_err.clear();
     if (!ctx) return set_err(CASIM_ERR_INVALID, "null context");
     HipBackend& bk = ctx->bk; bk.bind(); bk.clear();
     casim::SchedulerT<HipBackend> s(bk);
     int32_t rc = s.init_removals(classes, nodes, cand);
     if (rc == CASIM_OK) rc = s.run();
-    if (rc == CASIM_OK) rc = s.fetch_removals(removable_out, node_out, last_index_out, n_processed_out);
+    if (rc == CASIM_OK) rc = s.fetch_removals(out);
     if (rc < 0) set_err(rc, s.error());
     return rc;
 }

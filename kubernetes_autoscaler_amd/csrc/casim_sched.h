@@ -44,7 +44,7 @@ struct SchedArgs {
     const uint8_t* acceptable;  // [N] or null
     const uint64_t* fbits;      // [C][cap / 64] from sched_static_kernel
     int32_t* node_out;          // [P], pre-filled with -1
-    int32_t* out;               // [4]: lastIndex, pods scheduled, runs processed, candidates processed
+    int32_t* out;               // [8]: lastIndex, pods scheduled, runs processed, candidates processed, ext pods
     char* gstate;               // HBM slab (global variant) or null
     // ---- removal simulation: n_cand > 0 turns every candidate's runs into one transaction ----
     int32_t n_cand, persist, max_removable;
@@ -54,6 +54,14 @@ struct SchedArgs {
     uint8_t* removable_out;       // [K] 1 removable / 0 no place (pre-filled with 2 = not evaluated)
     uint8_t* arrived;             // [cap] node received pods of a committed removal (zeroed)
     char* committed;              // HBM: last committed sfree / sexcl / sslots (same layout as the working copy)
+    // pods that a committed removal moved onto a later candidate are listed again by that candidate ("ext" pods)
+    int32_t P, ext_cap;           // pods in the caller's flat list; room for ext pods (node_out has P + ext_cap entries)
+    const int32_t* pod_class;     // [P] class of every listed pod
+    const uint8_t* pod_sticky;    // [P] or null: the host must look at this pod again before it moves a second time
+    int32_t* ext_ref;             // [ext_cap] out: flat index of the pod
+    int32_t* ext_cand;            // [ext_cap] out: candidate whose simulation lists it again
+    int32_t* log_ref;             // [P + ext_cap] committed moves in commit order: pod,
+    int32_t* log_dest;            //               destination
 };
 
 CS_GLOBAL void fill_i32_kernel(int32_t* p, int64_t n, int32_t v) {
@@ -198,6 +206,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
     int32_t runs_done = 0;
     int32_t n_alive = N;       // len(nodeInfosList)
     int32_t removed = 0, cand_done = 0;
+    int32_t log_n = 0, ext_n = 0;   // committed moves so far / ext pods listed so far
     bool any_dead = false;
     bool stop = false;
     // position of node m in the current node list / node at position p
@@ -220,13 +229,36 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
 
     const int n_tx = txn ? a.n_cand : 1;
     for (int kc = 0; kc < n_tx; ++kc) {
-    int run_lo = 0, run_hi = a.n_runs, Y = -1;
+    int run_lo = 0, run_hi = a.n_runs, Y = -1, e_lo = 0, e_hi = 0;
     bool break_on_failure = a.break_on_failure != 0, failed = false;
     if (txn) {
         // ---- SimulateNodeRemoval (cluster.go:131-172) of candidate kc, planner order (planner.go:300-330) ----
         if (a.max_removable > 0 && removed >= a.max_removable) break;
         Y = a.cand_node[kc];
-        if (a.arrived[Y]) break;   // its pod list changed under the caller's feet: the caller re-submits from here
+        if (a.arrived[Y]) {
+            // Earlier committed removals moved pods onto this node: GetPodsToMove now lists them after the node's own
+            // pods, in arrival order == commit order (NodeInfo.AddPod appends).  A sticky pod (PDB, drain rule) or a
+            // full ext table hands the rest of the loop back to the caller.
+            if (a.ext_cap <= 0) break;
+            uint32_t base_n = 0;
+            uint64_t bad = 0;
+            for (int j0 = 0; j0 < log_n; j0 += T) {
+                const int j = j0 + tid;
+                const bool hit = j < log_n && a.log_dest[j] == Y;
+                const int ref = hit ? a.log_ref[j] : 0;
+                const uint64_t b = cs::ballot(hit);
+                uint32_t tot, before;
+                bc.count_prefix((uint32_t)cs::popc64(b), tot, before);
+                const uint32_t pos = (uint32_t)ext_n + base_n + before + (uint32_t)cs::mbcnt(b);
+                if (hit) {
+                    if (pos < (uint32_t)a.ext_cap) { a.ext_ref[pos] = ref; a.ext_cand[pos] = kc; }
+                    if (a.pod_sticky && a.pod_sticky[ref]) bad = 1;
+                }
+                base_n += tot;
+            }
+            if (bc.sum(bad) > 0 || (uint32_t)ext_n + base_n > (uint32_t)a.ext_cap) break;
+            e_lo = ext_n; e_hi = ext_n + (int32_t)base_n; ext_n = e_hi;
+        }
         cand_done = kc + 1;
         run_lo = a.cand_run_off[kc]; run_hi = a.cand_run_off[kc + 1];
         break_on_failure = true;
@@ -239,13 +271,16 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
         if (tid == 0) { accb[Y >> 6] &= ~(1ull << (Y & 63)); scanb[Y >> 6] &= ~(1ull << (Y & 63)); }
         cs::sync();
     }
-    for (int k0 = run_lo; k0 < run_hi && !stop && !failed; k0 += 64) {
+    for (int part = 0; part < 2; ++part) {   // the caller's runs, then one run per ext pod
+    const int part_lo = part == 0 ? run_lo : e_lo, part_hi = part == 0 ? run_hi : e_hi;
+    for (int k0 = part_lo; k0 < part_hi && !stop && !failed; k0 += 64) {
+        const int run_hi = part_hi;
         const int kk = k0 + lane;
         const bool have = kk < run_hi;
-        const int32_t my_class = have ? a.run_class[kk] : 0;
-        const int32_t my_count = have ? a.run_count[kk] : 0;
-        const int32_t my_hint = have ? a.run_hint[kk] : -1;
-        const int32_t my_first = have ? a.run_first[kk] : 0;
+        const int32_t my_class = !have ? 0 : part == 0 ? a.run_class[kk] : a.pod_class[a.ext_ref[kk]];
+        const int32_t my_count = !have ? 0 : part == 0 ? a.run_count[kk] : 1;
+        const int32_t my_hint = !have ? -1 : part == 0 ? a.run_hint[kk] : -1;   // its hint is the node it sits on: the candidate
+        const int32_t my_first = !have ? 0 : part == 0 ? a.run_first[kk] : a.P + kk;
         // the class record of run kk rides along in its lane: one round trip to HBM per 64 runs, not one per run
         int64_t my_req[CASIM_KMAX_RES];
         double my_rq[CASIM_KMAX_RES];
@@ -421,21 +456,29 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
             }
         }
     }
+    }  // parts
     if (txn) {
         // every pod found a place <=> the node is removable (findPlaceFor :219-224)
         const bool ok = !failed;
         const int p_lo = a.cand_pod_off[kc], p_hi = a.cand_pod_off[kc + 1];
+        const int n_own = p_hi - p_lo, n_listed = n_own + (e_hi - e_lo);
+        // i-th listed pod of this candidate -> its slot in node_out / its flat pod index
+        auto slot_of = [&](int i) -> int { return i < n_own ? p_lo + i : a.P + e_lo + (i - n_own); };
+        auto pod_of = [&](int i) -> int { return i < n_own ? p_lo + i : a.ext_ref[e_lo + (i - n_own)]; };
         cs::sync();
         if (ok && a.persist) {
             // Commit (withForkedSnapshot :174-188): the touched nodes become the new committed state, the ghost leaves
             // the list (:230) and the destination set (planner.go:318)
-            for (int i = p_lo + tid; i < p_hi; i += T) {
-                const int m = a.node_out[i];
+            for (int i = tid; i < n_listed; i += T) {
+                const int m = a.node_out[slot_of(i)];
                 for (int r = 0; r < R; ++r) cfree[(int64_t)r * st.cap + m] = st.sfree[(int64_t)r * st.cap + m];
                 for (int w = 0; w < Wx; ++w) cexcl[(int64_t)w * st.cap + m] = st.sexcl[(int64_t)w * st.cap + m];
                 cslots[m] = st.sslots[m];
                 a.arrived[m] = 1;
+                a.log_ref[log_n + i] = pod_of(i);
+                a.log_dest[log_n + i] = m;
             }
+            log_n += n_listed;
             if (tid == 0) {
                 alive[Y >> 6] &= ~(1ull << (Y & 63));
                 uint32_t acc = 0;
@@ -444,8 +487,8 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
             n_alive--; any_dead = true;
         } else {
             // Revert: touched nodes get their committed state back, the candidate its pods and its place
-            for (int i = p_lo + tid; i < p_hi; i += T) {
-                const int m = a.node_out[i];
+            for (int i = tid; i < n_listed; i += T) {
+                const int m = a.node_out[slot_of(i)];
                 if (m < 0) continue;
                 for (int r = 0; r < R; ++r) st.sfree[(int64_t)r * st.cap + m] = cfree[(int64_t)r * st.cap + m];
                 for (int w = 0; w < Wx; ++w) st.sexcl[(int64_t)w * st.cap + m] = cexcl[(int64_t)w * st.cap + m];
@@ -469,6 +512,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
         a.out[1] = scheduled;
         a.out[2] = runs_done;
         a.out[3] = cand_done;
+        a.out[4] = ext_n;
     }
 }
 
@@ -569,8 +613,8 @@ public:
         a_.acceptable = q->node_acceptable ? up(q->node_acceptable, N) : nullptr;
         d_fbits_ = (uint64_t*)dalloc(8 * C * (size_t)S_);
         a_.fbits = d_fbits_;
-        a_.node_out = (int32_t*)dalloc(4 * P);
-        a_.out = (int32_t*)dalloc(16);
+        a_.node_out = (int32_t*)dalloc(4 * (P + (size_t)(cand && cand->ext_capacity > 0 ? cand->ext_capacity : 0)));
+        a_.out = (int32_t*)dalloc(32);
         if (K_ > 0) {
             a_.memo_classes = 0;  // breakOnFailure ends a simulation at the first miss: the memo is never consulted
             a_.n_cand = K_; a_.persist = cand->persist ? 1 : 0; a_.max_removable = cand->max_removable > 0 ? cand->max_removable : 0;
@@ -579,6 +623,12 @@ public:
             a_.cand_pod_off = up(cand->pod_offsets, (size_t)K_ + 1);
             a_.removable_out = (uint8_t*)dalloc((size_t)K_);
             a_.arrived = (uint8_t*)dalloc((size_t)cap_);
+            E_ = cand->ext_capacity > 0 ? cand->ext_capacity : 0;
+            a_.P = P_; a_.ext_cap = E_;
+            a_.pod_class = up(q->pod_class, P);
+            a_.pod_sticky = cand->pod_sticky ? up(cand->pod_sticky, P) : nullptr;
+            a_.ext_ref = (int32_t*)dalloc(4 * (size_t)E_); a_.ext_cand = (int32_t*)dalloc(4 * (size_t)E_);
+            a_.log_ref = (int32_t*)dalloc(4 * (P + (size_t)E_)); a_.log_dest = (int32_t*)dalloc(4 * (P + (size_t)E_));
             a_.committed = (char*)dalloc((size_t)cap_ * (8u * (size_t)R + 8u * (size_t)dt_.Wx + 4u));
         }
         const int alive_words = K_ > 0 ? S_ : 0;
@@ -595,7 +645,7 @@ public:
     int32_t run() {
         if (trivial_) return CASIM_OK;
         if (!ready_) return fail(CASIM_ERR_INVALID, "scheduler not initialised");
-        if (P_ > 0) bk_.launch(fill_i32_kernel, (P_ + 255) / 256, 1, 256, (size_t)0, a_.node_out, (int64_t)P_, (int32_t)-1);
+        if (P_ + E_ > 0) bk_.launch(fill_i32_kernel, (P_ + E_ + 255) / 256, 1, 256, (size_t)0, a_.node_out, (int64_t)(P_ + E_), (int32_t)-1);
         if (K_ > 0) { bk_.fill8(a_.removable_out, 2, (size_t)K_); bk_.zero(a_.arrived, (size_t)cap_); }
         if (C_ > 0) bk_.launch(sched_static_kernel, S_, C_, 64, (size_t)0, dt_, d_fbits_, S_);
         if (lds_) bk_.launch(sched_kernel<true>, 1, 1, threads_, smem_, dt_, a_);
@@ -620,21 +670,27 @@ public:
     }
 
     // removal simulation results: removable[K] (1 / 0 / 2 = not evaluated), candidates with a final answer
-    int32_t fetch_removals(uint8_t* removable_out, int32_t* node_out, int32_t* last_index_out, int32_t* n_processed_out) {
+    int32_t fetch_removals(casim_removal_results* out) {
+        if (!out) return fail(CASIM_ERR_INVALID, "null results");
+        out->n_ext = 0; out->n_processed = 0; out->last_index = last_index_;
         if (trivial_) {
-            for (int k = 0; k < K_; ++k) if (removable_out) removable_out[k] = 2;
-            for (int i = 0; i < P_; ++i) if (node_out) node_out[i] = -1;
-            if (last_index_out) *last_index_out = last_index_;
-            if (n_processed_out) *n_processed_out = 0;
+            for (int k = 0; k < K_; ++k) if (out->removable) out->removable[k] = 2;
+            for (int i = 0; i < P_; ++i) if (out->node_out) out->node_out[i] = -1;
             return CASIM_OK;
         }
-        int32_t o[4] = {0, 0, 0, 0};
-        if (node_out && P_ > 0) bk_.d2h(node_out, a_.node_out, 4 * (size_t)P_);
-        if (removable_out && K_ > 0) bk_.d2h(removable_out, a_.removable_out, (size_t)K_);
-        bk_.d2h(o, a_.out, 16);
+        int32_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        bk_.d2h(o, a_.out, 32);
+        if (out->node_out && P_ > 0) bk_.d2h(out->node_out, a_.node_out, 4 * (size_t)P_);
+        if (out->removable && K_ > 0) bk_.d2h(out->removable, a_.removable_out, (size_t)K_);
         bk_.sync();
-        if (last_index_out) *last_index_out = o[0];
-        if (n_processed_out) *n_processed_out = o[3];
+        const int ne = o[4] < E_ ? o[4] : E_;
+        if (ne > 0) {
+            if (out->ext_candidate) bk_.d2h(out->ext_candidate, a_.ext_cand, 4 * (size_t)ne);
+            if (out->ext_pod) bk_.d2h(out->ext_pod, a_.ext_ref, 4 * (size_t)ne);
+            if (out->ext_node) bk_.d2h(out->ext_node, a_.node_out + P_, 4 * (size_t)ne);
+            bk_.sync();
+        }
+        out->n_ext = ne; out->last_index = o[0]; out->n_processed = o[3];
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
     }
 
@@ -662,7 +718,7 @@ private:
 
     BK& bk_;
     DevTables dt_; SchedArgs a_;
-    int C_ = 0, N_ = 0, P_ = 0, S_ = 0, K_ = 0, threads_ = 64;
+    int C_ = 0, N_ = 0, P_ = 0, S_ = 0, K_ = 0, E_ = 0, threads_ = 64;
     int32_t cap_ = 0, n_runs_ = 0, last_index_ = 0;
     bool ready_ = false, trivial_ = false, lds_ = true;
     size_t smem_ = 0;

@@ -71,22 +71,60 @@ def make_pod_sequence(pod_class, hint_node=None, node_acceptable=None, break_on_
     return seq, (pc, hn, na)
 
 
+@dataclass
+class RemovalResult:
+    status: int                  # CASIM_OK or NG_UNSUPPORTED (delegate the whole loop)
+    removable: np.ndarray        # [K] 1 removable / 0 no place / 2 not evaluated
+    node_out: np.ndarray         # [total] destination of every listed pod in its own candidate's simulation
+    ext_candidate: np.ndarray    # [n_ext] pods listed again by a later candidate: which candidate,
+    ext_pod: np.ndarray          #         which pod (flat index),
+    ext_node: np.ndarray         #         where it went
+    last_index: int
+    n_processed: int
+
+
 def make_removal_candidates(cand_node, pod_offsets, pod_class, hint_node=None, destination=None, persist=True, max_removable=0,
-                            last_index=0):
+                            last_index=0, pod_sticky=None, ext_capacity=None):
     """casim_removal_candidates over numpy arrays; returns (struct, arrays to keep alive)."""
     cn = np.ascontiguousarray(cand_node, np.int32)
     po = np.ascontiguousarray(pod_offsets, np.int32)
     pc = np.ascontiguousarray(pod_class, np.int32)
     hn = None if hint_node is None else np.ascontiguousarray(hint_node, np.int32)
     ds = None if destination is None else np.ascontiguousarray(destination, np.uint8)
+    sk = None if pod_sticky is None else np.ascontiguousarray(pod_sticky, np.uint8)
     if po.shape[0] != cn.shape[0] + 1:
         raise ValueError("pod_offsets must have one more entry than cand_node")
+    total = int(po[-1]) if po.size else 0
+    if ext_capacity is None:
+        ext_capacity = 2 * total + 64   # a pod is listed again at most once per later candidate it lands on
     st = _abi.RemovalCandidates(n_candidates=int(cn.shape[0]), cand_node=_ptr(cn, C.c_int32) if cn.size else None,
                                 pod_offsets=_ptr(po, C.c_int32), pod_class=_ptr(pc, C.c_int32) if pc.size else None,
                                 hint_node=_ptr(hn, C.c_int32) if hn is not None and hn.size else None,
                                 destination=_ptr(ds, C.c_uint8) if ds is not None and ds.size else None,
-                                persist=int(bool(persist)), max_removable=int(max_removable), last_index=int(last_index))
-    return st, (cn, po, pc, hn, ds)
+                                pod_sticky=_ptr(sk, C.c_uint8) if sk is not None and sk.size else None,
+                                persist=int(bool(persist)), max_removable=int(max_removable), last_index=int(last_index),
+                                ext_capacity=int(ext_capacity))
+    return st, (cn, po, pc, hn, ds, sk)
+
+
+def alloc_removal_results(st: "_abi.RemovalCandidates"):
+    K = st.n_candidates
+    total = int(st.pod_offsets[K]) if K >= 0 and st.pod_offsets else 0
+    E = max(int(st.ext_capacity), 0)
+    arrs = dict(removable=np.full(max(K, 1), 2, np.uint8), node_out=np.full(max(total, 1), -1, np.int32),
+                ext_candidate=np.full(max(E, 1), -1, np.int32), ext_pod=np.full(max(E, 1), -1, np.int32),
+                ext_node=np.full(max(E, 1), -1, np.int32))
+    res = _abi.RemovalResults(removable=_ptr(arrs["removable"], C.c_uint8), node_out=_ptr(arrs["node_out"], C.c_int32),
+                              ext_candidate=_ptr(arrs["ext_candidate"], C.c_int32), ext_pod=_ptr(arrs["ext_pod"], C.c_int32),
+                              ext_node=_ptr(arrs["ext_node"], C.c_int32))
+    return res, (arrs, K, total)
+
+
+def finish_removal_results(rc, st, res, packed) -> RemovalResult:
+    arrs, K, total = packed
+    ne = int(res.n_ext)
+    return RemovalResult(rc, arrs["removable"][:K].copy(), arrs["node_out"][:total].copy(), arrs["ext_candidate"][:ne].copy(),
+                         arrs["ext_pod"][:ne].copy(), arrs["ext_node"][:ne].copy(), int(res.last_index), int(res.n_processed))
 
 
 def device_count() -> int:
@@ -154,27 +192,23 @@ class Context:
 
     def simulate_node_removals(self, classes: _abi.Pegs, nodes: _abi.Groups, cand_node, pod_offsets, pod_class, hint_node=None,
                                destination=None, persist: bool = True, max_removable: int = 0, last_index: int = 0,
-                               time_iters: int = 0):
+                               pod_sticky=None, ext_capacity: Optional[int] = None, time_iters: int = 0):
         """Planner.categorizeNodes loop around SimulateNodeRemoval on the device (casim_simulate_node_removals).
-        Returns (status, removable[K], node_out[total], last_index, n_processed); with time_iters > 0 the HIP-event
-        time in ms of one resident pass instead."""
-        rc_struct, keep = make_removal_candidates(cand_node, pod_offsets, pod_class, hint_node, destination, persist, max_removable, last_index)
+        Returns a RemovalResult; with time_iters > 0 (status, HIP-event ms of one resident pass) instead."""
+        st, keep = make_removal_candidates(cand_node, pod_offsets, pod_class, hint_node, destination, persist, max_removable, last_index,
+                                           pod_sticky, ext_capacity)
         if time_iters > 0:
             ms = C.c_float(0)
-            rc = lib.casim_time_node_removals(self._h, C.byref(classes), C.byref(nodes), C.byref(rc_struct), int(time_iters), C.byref(ms))
+            rc = lib.casim_time_node_removals(self._h, C.byref(classes), C.byref(nodes), C.byref(st), int(time_iters), C.byref(ms))
             if rc < 0:
                 check(rc, "casim_time_node_removals")
             return rc, ms.value / time_iters
-        K, total = rc_struct.n_candidates, int(keep[1][-1]) if len(keep[1]) else 0
-        removable = np.full(max(K, 1), 2, np.uint8)
-        node_out = np.full(max(total, 1), -1, np.int32)
-        li, npr = C.c_int32(0), C.c_int32(0)
-        rc = lib.casim_simulate_node_removals(self._h, C.byref(classes), C.byref(nodes), C.byref(rc_struct), _ptr(removable, C.c_uint8),
-                                              _ptr(node_out, C.c_int32), C.byref(li), C.byref(npr))
+        res, arrs = alloc_removal_results(st)
+        rc = lib.casim_simulate_node_removals(self._h, C.byref(classes), C.byref(nodes), C.byref(st), C.byref(res))
         if rc < 0:
             check(rc, "casim_simulate_node_removals")
         del keep
-        return rc, removable[:K], node_out[:total], li.value, npr.value
+        return finish_removal_results(rc, st, res, arrs)
 
 
 class Problem:

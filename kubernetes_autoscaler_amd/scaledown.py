@@ -9,8 +9,10 @@ The per-candidate Fork -> unschedule -> TrySchedulePods(breakOnFailure) -> Commi
 ONE call over all candidates (casim_simulate_node_removals -> K_sched with transactions).  What stays here is what
 the reference also keeps outside the scheduler simulation: which pods of a node have to move (drainability rules,
 PDBs), the hint map, and the snapshot objects.  When an earlier removal moved pods onto a later candidate, that
-candidate's pod list is no longer the one that was submitted; the device stops in front of it and this loop
-re-submits the rest from the updated snapshot — exactly the point where the reference calls GetPodsToMove again."""
+candidate lists them again after its own pods (the device keeps the log of committed moves); only when such a pod
+is "sticky" — the host has to re-run its drainability / PDB rules for it — does the device stop in front of that
+candidate, and this loop re-submits the rest from the updated snapshot: the point where the reference calls
+GetPodsToMove again."""
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Sequence
 
@@ -52,11 +54,14 @@ class RemovalSimulator:
     """simulator.NewRemovalSimulator(listers, clusterSnapshot, deleteOptions, drainabilityRules, persist)."""
 
     def __init__(self, ctx: Context, snapshot: List[NodeInfo], persist_successful_simulations: bool = True,
-                 pods_to_move: Callable[[NodeInfo], Optional[List[Pod]]] = default_pods_to_move, lanes=None):
+                 pods_to_move: Callable[[NodeInfo], Optional[List[Pod]]] = default_pods_to_move,
+                 is_sticky: Callable[[Pod], bool] = lambda p: False, ext_capacity: Optional[int] = None, lanes=None):
         self.ctx = ctx
         self.snapshot = snapshot            # list order == the order lastIndex refers to; mutated when persisting
         self.can_persist = persist_successful_simulations
         self.pods_to_move = pods_to_move
+        self.is_sticky = is_sticky          # pod -> True when GetPodsToMove must see it again before it moves twice (PDBs)
+        self.ext_capacity = ext_capacity    # None = engine default; 0 = re-submit at every candidate with arrivals
         self.lanes = lanes
         self.hints = Hints()
         self.last_index = 0
@@ -71,6 +76,7 @@ class RemovalSimulator:
         class_of: Dict[tuple, int] = {}
         pod_class: List[int] = []
         hint: List[int] = []
+        sticky: List[int] = []
         off = [0]
         pos = {info.node.name: i for i, info in enumerate(self.snapshot)}
         for lst in lists:
@@ -83,18 +89,20 @@ class RemovalSimulator:
                 pod_class.append(c)
                 h = self.hints.get(hint_key_from_pod(p))
                 hint.append(pos.get(h, -1) if h is not None else -1)
+                sticky.append(1 if self.is_sticky(p) else 0)
             off.append(len(pod_class))
         for info in self.snapshot:
             enc.add_group(info, pegs=[])
         enc.finalize()
         dest = np.array([1 if destinations.get(info.node.name, False) else 0 for info in self.snapshot], np.uint8)
         self.device_calls += 1
-        out = self.ctx.simulate_node_removals(enc.pegs, enc.groups, [pos[n] for n in names], off, pod_class, hint, dest,
-                                              persist=self.can_persist, max_removable=max_removable, last_index=self.last_index)
+        res = self.ctx.simulate_node_removals(enc.pegs, enc.groups, [pos[n] for n in names], off, pod_class, hint, dest,
+                                              persist=self.can_persist, max_removable=max_removable, last_index=self.last_index,
+                                              pod_sticky=sticky if any(sticky) else None, ext_capacity=self.ext_capacity)
         enc.close()
-        if out[0] == _abi.NG_UNSUPPORTED:
+        if res.status == _abi.NG_UNSUPPORTED:
             raise UnsupportedPredicate("pods to move need a predicate outside the encoded subset")
-        return out, off
+        return res, off
 
     def simulate_node_removals(self, candidates: Sequence[str], destinations: Dict[str, bool], max_removable: int = 0):
         """The categorizeNodes loop (planner.go:300-330): SimulateNodeRemoval per candidate in order, successful
@@ -107,14 +115,12 @@ class RemovalSimulator:
             if max_removable > 0 and len(removable) >= max_removable:
                 break
             by_name = {info.node.name: info for info in self.snapshot}
-            # GetPodsToMove on the CURRENT snapshot; blocked / vanished nodes never reach the device
+            # GetPodsToMove on the CURRENT snapshot; a node blocked by a pod never reaches the device
             names, lists = [], []
             for n in todo:
                 info = by_name.get(n)
-                lst = self.pods_to_move(info) if info is not None else None
                 names.append(n)
-                lists.append(lst)
-            # the device takes the longest prefix whose nodes are all simulatable
+                lists.append(self.pods_to_move(info) if info is not None else None)
             cut = next((i for i, lst in enumerate(lists) if lst is None), len(names))
             if cut == 0:
                 n = todo.pop(0)
@@ -123,32 +129,32 @@ class RemovalSimulator:
                 continue
             left = (max_removable - len(removable)) if max_removable > 0 else 0
             infos = list(self.snapshot)   # node indices of this call refer to this list
-            (status, rem, node_out, last_index, n_done), off = self._submit(names[:cut], lists[:cut], destinations, left)
-            self.last_index = last_index
-            if n_done == 0:
-                raise RuntimeError("device made no progress")  # cannot happen: a rebuilt list has no unseen arrivals
-            moves = []
-            for k in range(n_done):
-                if int(rem[k]) == 2:   # not evaluated: the removable limit was reached inside the call
+            res, off = self._submit(names[:cut], lists[:cut], destinations, left)
+            self.last_index = res.last_index
+            flat = [p for lst in lists[:cut] for p in lst]
+            again: Dict[int, list] = {}   # candidate -> [(pod, destination)] for the pods it listed again
+            for k, e, m in zip(res.ext_candidate.tolist(), res.ext_pod.tolist(), res.ext_node.tolist()):
+                again.setdefault(k, []).append((flat[e], m))
+            n_done = res.n_processed
+            for k in range(res.n_processed):
+                if int(res.removable[k]) == 2:   # not evaluated: the removable limit was reached inside the call
                     n_done = k
                     break
-                info, pods = by_name[names[k]], lists[k]
-                dests = [int(node_out[i]) for i in range(off[k], off[k + 1])]
-                for p, m in zip(pods, dests):
+                info = by_name[names[k]]
+                moved = list(zip(lists[k], (int(res.node_out[i]) for i in range(off[k], off[k + 1])))) + again.get(k, [])
+                for p, m in moved:
                     if m >= 0:  # hints.Set on every placement, reverted simulation or not (hinting_simulator.go:108,133)
                         self.hints.set(hint_key_from_pod(p), infos[m].node.name)
-                if int(rem[k]) == 1:
-                    removable.append(NodeToBeRemoved(info.node, list(pods), [p for p in info.pods if p.daemonset]))
+                if int(res.removable[k]) == 1:
+                    removable.append(NodeToBeRemoved(info.node, [p for p, _ in moved], [p for p in info.pods if p.daemonset]))
                     if self.can_persist:
-                        moves.append((info, pods, dests))
+                        # Commit: the pods now run on their destinations (arrival order), the node leaves the list
+                        for p, m in moved:
+                            infos[m].pods.append(p)
+                        self.snapshot.remove(info)
                         destinations.pop(names[k], None)   # planner.go:318 (the planner always persists)
                 else:
                     unremovable.append(UnremovableNode(info.node, NO_PLACE_TO_MOVE_PODS))
-            # Commit: the snapshot is only rewritten between device calls, so the indices above stayed valid
-            for info, pods, dests in moves:
-                for p, m in zip(pods, dests):
-                    infos[m].pods.append(p)       # the pod now runs on its destination (arrival order)
-                self.snapshot.remove(info)         # RemoveNodeInfo: later list positions shift by one
             if n_done == 0:
                 break
             todo = todo[n_done:]

@@ -426,6 +426,7 @@ def fuzz_removals(seed: int, max_nodes: int = 30) -> RemovalWorkload:
             kw["tolerations"] = [Toleration(key="dedicated", operator="Exists")]
         specs.append(kw)
     nodes = []
+    fill = rng.pick([5, 5, 12, 30])   # attempts to place a running pod per node: from nearly empty to crowded clusters
     for i in range(n_nodes):
         taints = [Taint("dedicated", "x", "NoSchedule")] if rng.chance(1, 8) else []
         node = _node(f"sd{seed}-n{i}", rng.pick([1000, 2000, 4000]), rng.pick([2, 4, 8]) * GiB, rng.pick([4, 8, 110]), {"pool": f"p{rng.below(2)}"}, taints)
@@ -435,7 +436,7 @@ def fuzz_removals(seed: int, max_nodes: int = 30) -> RemovalWorkload:
         # fill greedily with random specs that fit the node on their own terms (the snapshot is a legal cluster state)
         cpu = mem = 0
         used_ports, apps_here = set(), []
-        for _ in range(rng.below(5)):
+        for _ in range(rng.below(fill)):
             kw = specs[rng.below(n_specs)]
             rq = kw["requests"]
             if cpu + rq["cpu"] > node.allocatable["cpu"] or mem + rq["memory"] > node.allocatable["memory"] or len(info.pods) >= node.allocatable["pods"]:

@@ -1110,16 +1110,19 @@ static int snap_pos_of(const orc* o, int orig_id) {
  *   leaves the destination set (planner.go:318); otherwise Revert.  lastIndex lives in the plugin runner and is
  *   never reverted.
  * Node ids are positions at orc_snapshot_add time.  pods / hints: per candidate pod_offsets[k]..pod_offsets[k+1].
- * dynamic_lists = 1: pods that an earlier removal moved onto a later candidate are appended to that candidate's
- *   list (what GetPodsToMove sees in the committed snapshot); 0: the loop stops in front of such a candidate
- *   (*n_processed < K) — the protocol of casim_simulate_node_removals, whose caller re-submits the rest.
+ * Pods that an earlier committed removal moved onto a later candidate are appended to that candidate's list (what
+ *   GetPodsToMove sees in the committed snapshot) and reported as ext entries (candidate, pod, destination); the
+ *   loop stops in front of such a candidate (*n_processed < K) when an arrived pod is pod_sticky or the ext arrays
+ *   (ext_capacity) are full — the protocol of casim_simulate_node_removals, whose caller re-submits the rest.
  * removable_out[k]: 1 removable, 0 no place, 2 not evaluated.  node_out[i]: node the i-th listed pod was placed
  * on in ITS candidate's simulation (-1: not placed).  final_node_out[i] (may be NULL): where the pod is at the end
  * (its candidate id if it never moved for good). */
 int orc_simulate_node_removals(orc* o, int K, const int32_t* cand_node, const int32_t* pod_offsets, const int32_t* pod,
-                               const int32_t* hint, const uint8_t* destination, int persist, int max_removable,
-                               int dynamic_lists, int* last_index, uint8_t* removable_out, int32_t* node_out,
+                               const int32_t* hint, const uint8_t* destination, const uint8_t* pod_sticky, int persist,
+                               int max_removable, int ext_capacity, int* last_index, uint8_t* removable_out, int32_t* node_out,
+                               int32_t* ext_cand_out, int32_t* ext_pod_out, int32_t* ext_node_out, int* n_ext_out,
                                int32_t* final_node_out, int* n_processed) {
+    int n_ext = 0;
     const int N0 = o->snap_added;
     const int total = pod_offsets[K];
     uint8_t* dest = malloc((size_t)(N0 > 0 ? N0 : 1));
@@ -1128,6 +1131,7 @@ int orc_simulate_node_removals(orc* o, int K, const int32_t* cand_node, const in
     for (int i = 0; i < total; ++i) node_out[i] = -1;
     int32_t* where = malloc(sizeof(int32_t) * (size_t)(total > 0 ? total : 1));   /* current node (orig id) of every listed pod */
     for (int k = 0; k < K; ++k) for (int i = pod_offsets[k]; i < pod_offsets[k + 1]; ++i) where[i] = cand_node[k];
+    ivec moves, move_dest; memset(&moves, 0, sizeof moves); memset(&move_dest, 0, sizeof move_dest);   /* committed moves, in order */
     int removed = 0, k = 0;
     for (; k < K; ++k) {
         if (max_removable > 0 && removed >= max_removable) break;         /* planner.go:306-310 */
@@ -1139,10 +1143,12 @@ int orc_simulate_node_removals(orc* o, int K, const int32_t* cand_node, const in
         for (int i = pod_offsets[k]; i < pod_offsets[k + 1]; ++i) VEC_PUSH(list, i);
         int arrived = 0;
         for (int i = 0; i < total; ++i) if (where[i] == Y && !(i >= pod_offsets[k] && i < pod_offsets[k + 1])) arrived++;
-        if (arrived && !dynamic_lists) { VEC_FREE(list); break; }
         if (arrived) {
-            /* arrival order == order of the committed moves: earlier candidates first, list order inside */
-            for (int kk = 0; kk < k; ++kk) for (int i = pod_offsets[kk]; i < pod_offsets[kk + 1]; ++i) if (where[i] == Y) VEC_PUSH(list, i);
+            /* GetPodsToMove on the committed snapshot lists the arrived pods after the node's own, in arrival order
+             * (NodeInfo.AddPod appends) == order of the committed moves */
+            int sticky = 0;
+            for (int j = 0; j < moves.n; ++j) if (where[moves.v[j]] == Y && move_dest.v[j] == Y) { VEC_PUSH(list, moves.v[j]); if (pod_sticky && pod_sticky[moves.v[j]]) sticky = 1; }
+            if (sticky || n_ext + arrived > ext_capacity) { VEC_FREE(list); break; }   /* protocol: hand back to the caller */
         }
         /* Fork */
         o->undo_on = 1; o->undo.n = 0;
@@ -1167,11 +1173,17 @@ int orc_simulate_node_removals(orc* o, int K, const int32_t* cand_node, const in
         }
         const int placed = orc_try_schedule_pods(o, np, pp, hh, NULL, acc, 1, last_index, oo);
         const int ok = placed == np;
-        for (int i = 0; i < np; ++i)
-            if (list.v[i] >= pod_offsets[k] && list.v[i] < pod_offsets[k + 1]) node_out[list.v[i]] = oo[i] >= 0 ? o->snap.v[oo[i]].orig_id : -1;
+        for (int i = 0; i < np; ++i) {
+            const int d = oo[i] >= 0 ? o->snap.v[oo[i]].orig_id : -1;
+            if (list.v[i] >= pod_offsets[k] && list.v[i] < pod_offsets[k + 1]) node_out[list.v[i]] = d;
+            else { ext_cand_out[n_ext] = k; ext_pod_out[n_ext] = list.v[i]; ext_node_out[n_ext] = d; n_ext++; }
+        }
         o->undo_on = 0;
         if (ok && persist) {
-            for (int i = 0; i < np; ++i) where[list.v[i]] = o->snap.v[oo[i]].orig_id;
+            for (int i = 0; i < np; ++i) {
+                where[list.v[i]] = o->snap.v[oo[i]].orig_id;
+                VEC_PUSH(moves, list.v[i]); VEC_PUSH(move_dest, where[list.v[i]]);
+            }
             for (int i = 0; i < o->undo.n; ++i) node_free(&o->undo.v[i].copy);
             node_free(&saved_y); node_free(&o->snap.v[ypos]);
             for (int i = ypos; i + 1 < o->snap.n; ++i) o->snap.v[i] = o->snap.v[i + 1];   /* RemoveNodeInfo */
@@ -1194,6 +1206,8 @@ int orc_simulate_node_removals(orc* o, int K, const int32_t* cand_node, const in
     }
     if (final_node_out) for (int i = 0; i < total; ++i) final_node_out[i] = where[i];
     *n_processed = k;
+    *n_ext_out = n_ext;
+    VEC_FREE(moves); VEC_FREE(move_dest);
     free(dest); free(where);
     return removed;
 }

@@ -81,14 +81,13 @@ EMU_API int32_t emu_try_schedule_pods(const casim_pegs* classes, const casim_gro
 }
 
 EMU_API int32_t emu_simulate_node_removals(const casim_pegs* classes, const casim_groups* nodes, const casim_removal_candidates* cand,
-                                           int64_t lds_budget_bytes, uint8_t* removable_out, int32_t* node_out, int32_t* last_index_out,
-                                           int32_t* n_processed_out) {
+                                           int64_t lds_budget_bytes, casim_removal_results* out) {
     EmuBackend bk;
     if (lds_budget_bytes > 0) bk.lds = (size_t)lds_budget_bytes;
     casim::SchedulerT<EmuBackend> s(bk);
     int32_t rc = s.init_removals(classes, nodes, cand);
     if (rc == CASIM_OK) rc = s.run();
-    if (rc == CASIM_OK) rc = s.fetch_removals(removable_out, node_out, last_index_out, n_processed_out);
+    if (rc == CASIM_OK) rc = s.fetch_removals(out);
     if (rc < 0) g_err = s.error();
     return rc;
 }

@@ -234,6 +234,8 @@ class RemovalCase:
     persist: bool = True
     max_removable: int = 0
     last_index: int = 0
+    sticky: Optional[set] = None                   # id(pod) of pods the host must re-examine before a second move
+    ext_capacity: Optional[int] = None             # None = default (2 * pods + 64); 0 = stop at any arrival
     lanes: Sequence[str] = ("cpu", "memory")
 
     def pod_lists(self):
@@ -244,13 +246,18 @@ class RemovalCase:
             return None
         return [self.hints.get(id(p), -1) for lst in self.pod_lists() for p in lst]
 
+    def flat_sticky(self):
+        if not self.sticky:
+            return None
+        return [1 if id(p) in self.sticky else 0 for lst in self.pod_lists() for p in lst]
 
-def removal_oracle(case: RemovalCase, dynamic_lists=False):
+
+def removal_oracle(case: RemovalCase):
     s = OracleScenario(lanes=case.lanes)
     for info in case.nodes:
         s.add_existing(info)
     out = s.simulate_node_removals(case.candidates, case.pod_lists(), case.flat_hints(), case.destination, case.persist,
-                                   case.max_removable, dynamic_lists, case.last_index)
+                                   case.max_removable, case.flat_sticky(), case.ext_capacity, case.last_index)
     s.close()
     return out
 
@@ -272,27 +279,6 @@ def removal_encode(case: RemovalCase):
     return enc, np.array(pod_class, np.int32), np.array(off, np.int32)
 
 
-def emu_simulate_node_removals(classes, nodes, cand_node, pod_offsets, pod_class, hint_node=None, destination=None, persist=True,
-                               max_removable=0, last_index=0, lds_budget=0):
-    from kubernetes_autoscaler_amd.engine import make_removal_candidates
-    L = emu_lib()
-    if not hasattr(L, "_removal_ready"):
-        L.emu_simulate_node_removals.restype = C.c_int32
-        L.emu_simulate_node_removals.argtypes = [C.POINTER(_abi.Pegs), C.POINTER(_abi.Groups), C.POINTER(_abi.RemovalCandidates), C.c_int64,
-                                                 _abi.u8p, _abi.i32p, _abi.i32p, _abi.i32p]
-        L._removal_ready = True
-    st, keep = make_removal_candidates(cand_node, pod_offsets, pod_class, hint_node, destination, persist, max_removable, last_index)
-    K, total = st.n_candidates, int(keep[1][-1])
-    removable = np.full(max(K, 1), 2, np.uint8)
-    node_out = np.full(max(total, 1), -1, np.int32)
-    li, npr = C.c_int32(0), C.c_int32(0)
-    rc = L.emu_simulate_node_removals(C.byref(classes), C.byref(nodes), C.byref(st), int(lds_budget), removable.ctypes.data_as(_abi.u8p),
-                                      node_out.ctypes.data_as(_abi.i32p), C.byref(li), C.byref(npr))
-    assert rc >= 0, (rc, L.emu_last_error())
-    del keep
-    return rc, removable[:K].copy(), node_out[:total].copy(), li.value, npr.value
-
-
 class EmuContext:
     """Stands in for engine.Context in CPU tests of the host mirrors: same method, product kernels under the emulator."""
 
@@ -300,25 +286,38 @@ class EmuContext:
         self.lds_budget = lds_budget
 
     def simulate_node_removals(self, classes, nodes, cand_node, pod_offsets, pod_class, hint_node=None, destination=None,
-                               persist=True, max_removable=0, last_index=0):
-        return emu_simulate_node_removals(classes, nodes, cand_node, pod_offsets, pod_class, hint_node, destination, persist,
-                                          max_removable, last_index, self.lds_budget)
+                               persist=True, max_removable=0, last_index=0, pod_sticky=None, ext_capacity=None):
+        from kubernetes_autoscaler_amd.engine import alloc_removal_results, finish_removal_results, make_removal_candidates
+        L = emu_lib()
+        if not hasattr(L, "_removal_ready"):
+            L.emu_simulate_node_removals.restype = C.c_int32
+            L.emu_simulate_node_removals.argtypes = [C.POINTER(_abi.Pegs), C.POINTER(_abi.Groups), C.POINTER(_abi.RemovalCandidates),
+                                                     C.c_int64, C.POINTER(_abi.RemovalResults)]
+            L._removal_ready = True
+        st, keep = make_removal_candidates(cand_node, pod_offsets, pod_class, hint_node, destination, persist, max_removable, last_index,
+                                           pod_sticky, ext_capacity)
+        res, packed = alloc_removal_results(st)
+        rc = L.emu_simulate_node_removals(C.byref(classes), C.byref(nodes), C.byref(st), int(self.lds_budget), C.byref(res))
+        assert rc >= 0, (rc, L.emu_last_error())
+        del keep
+        return finish_removal_results(rc, st, res, packed)
 
 
 def removal_device(case: RemovalCase, ctx):
-    """ctx: engine.Context (MI355X) or EmuContext."""
+    """ctx: engine.Context (MI355X) or EmuContext.  Returns engine.RemovalResult."""
     enc, pod_class, off = removal_encode(case)
     out = ctx.simulate_node_removals(enc.pegs, enc.groups, case.candidates, off, pod_class, case.flat_hints(), case.destination,
-                                     persist=case.persist, max_removable=case.max_removable, last_index=case.last_index)
+                                     persist=case.persist, max_removable=case.max_removable, last_index=case.last_index,
+                                     pod_sticky=case.flat_sticky(), ext_capacity=case.ext_capacity)
     enc.close()
     return out
 
 
 def assert_removal_matches(got, want, what=""):
-    rc, rem, node_out, li, npr = got
-    w_rem, w_out, _, w_li, w_npr = want
-    assert rc == 0, f"{what}: status {rc}"
-    assert npr == w_npr, f"{what}: candidates processed got {npr} want {w_npr}"
-    assert list(rem) == list(w_rem), f"{what}: removable\n got {list(rem)}\n want {list(w_rem)}"
-    assert list(node_out) == list(w_out), f"{what}: destinations\n got {list(node_out)}\n want {list(w_out)}"
-    assert li == w_li, f"{what}: lastIndex got {li} want {w_li}"
+    assert got.status == 0, f"{what}: status {got.status}"
+    assert got.n_processed == want["n_processed"], f"{what}: candidates processed got {got.n_processed} want {want['n_processed']}"
+    assert list(got.removable) == list(want["removable"]), f"{what}: removable\n got {list(got.removable)}\n want {list(want['removable'])}"
+    assert list(got.node_out) == list(want["node_out"]), f"{what}: destinations\n got {list(got.node_out)}\n want {list(want['node_out'])}"
+    ext = list(zip(got.ext_candidate.tolist(), got.ext_pod.tolist(), got.ext_node.tolist()))
+    assert ext == want["ext"], f"{what}: pods listed again (candidate, pod, node)\n got {ext}\n want {want['ext']}"
+    assert got.last_index == want["last_index"], f"{what}: lastIndex got {got.last_index} want {want['last_index']}"

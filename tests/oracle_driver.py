@@ -69,8 +69,9 @@ def lib():
             "orc_run_filters_until_passing": (C.c_int, [P, C.c_int, C.POINTER(C.c_int)]),
             "orc_try_schedule_pods": (C.c_int, [P, C.c_int, i32p, i32p, i32p, u8p, C.c_int, C.POINTER(C.c_int), i32p]),
             "orc_snapshot_size": (C.c_int, [P]),
-            "orc_simulate_node_removals": (C.c_int, [P, C.c_int, i32p, i32p, i32p, i32p, u8p, C.c_int, C.c_int, C.c_int,
-                                                    C.POINTER(C.c_int), u8p, i32p, i32p, C.POINTER(C.c_int)]),
+            "orc_simulate_node_removals": (C.c_int, [P, C.c_int, i32p, i32p, i32p, i32p, u8p, u8p, C.c_int, C.c_int, C.c_int,
+                                                    C.POINTER(C.c_int), u8p, i32p, i32p, i32p, i32p, C.POINTER(C.c_int), i32p,
+                                                    C.POINTER(C.c_int)]),
             "orc_get_min_limit": (C.c_int64, [C.c_int64, C.c_int64]),
             "orc_sng_capacity_limit": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
             "orc_cluster_capacity_limit": (C.c_int, [C.c_int, C.c_int, C.c_int]),
@@ -259,9 +260,10 @@ class OracleScenario:
         return out[:n].copy(), li.value, ns
 
     def simulate_node_removals(self, cand_node, pod_lists, hints=None, destination=None, persist=True, max_removable=0,
-                               dynamic_lists=False, last_index=0):
+                               pod_sticky=None, ext_capacity=None, last_index=0):
         """Planner loop around SimulateNodeRemoval on the snapshot built with add_existing().  pod_lists[k] = pods to move
-        of candidate k (Pod objects).  Returns (removable[K], node_out[total], final_node[total], last_index, n_processed)."""
+        of candidate k (Pod objects).  Returns a dict: removable[K], node_out[total], ext (list of (candidate, pod, node)),
+        final[total], last_index, n_processed."""
         K = len(cand_node)
         off = np.zeros(K + 1, np.int32)
         flat = []
@@ -269,18 +271,26 @@ class OracleScenario:
             flat.extend(self.pod(p) for p in lst)
             off[k + 1] = len(flat)
         total = len(flat)
+        E = 2 * total + 64 if ext_capacity is None else int(ext_capacity)
         cn = np.ascontiguousarray(cand_node, np.int32) if K else np.zeros(1, np.int32)
         pods = np.array(flat, np.int32) if total else np.zeros(1, np.int32)
         hn = None if hints is None else np.ascontiguousarray(hints, np.int32)
         ds = None if destination is None else np.ascontiguousarray(destination, np.uint8)
+        sk = None if pod_sticky is None else np.ascontiguousarray(pod_sticky, np.uint8)
         removable = np.full(max(K, 1), 2, np.uint8)
         node_out = np.full(max(total, 1), -1, np.int32)
         final = np.full(max(total, 1), -1, np.int32)
-        li, npr = C.c_int(last_index), C.c_int(0)
+        ec, ep, en = (np.full(max(E, 1) + total + 1, -1, np.int32) for _ in range(3))
+        li, npr, ne = C.c_int(last_index), C.c_int(0), C.c_int(0)
         rc = self.L.orc_simulate_node_removals(self.h, K, cn.ctypes.data_as(i32p), off.ctypes.data_as(i32p), pods.ctypes.data_as(i32p),
                                                hn.ctypes.data_as(i32p) if hn is not None and hn.size else None,
-                                               ds.ctypes.data_as(u8p) if ds is not None and ds.size else None, int(persist),
-                                               int(max_removable), int(dynamic_lists), C.byref(li), removable.ctypes.data_as(u8p),
-                                               node_out.ctypes.data_as(i32p), final.ctypes.data_as(i32p), C.byref(npr))
+                                               ds.ctypes.data_as(u8p) if ds is not None and ds.size else None,
+                                               sk.ctypes.data_as(u8p) if sk is not None and sk.size else None, int(persist),
+                                               int(max_removable), E, C.byref(li), removable.ctypes.data_as(u8p),
+                                               node_out.ctypes.data_as(i32p), ec.ctypes.data_as(i32p), ep.ctypes.data_as(i32p),
+                                               en.ctypes.data_as(i32p), C.byref(ne), final.ctypes.data_as(i32p), C.byref(npr))
         assert rc >= 0, rc
-        return removable[:K].copy(), node_out[:total].copy(), final[:total].copy(), li.value, npr.value
+        n = ne.value
+        return dict(removable=removable[:K].copy(), node_out=node_out[:total].copy(),
+                    ext=list(zip(ec[:n].tolist(), ep[:n].tolist(), en[:n].tolist())), final=final[:total].copy(),
+                    last_index=li.value, n_processed=npr.value)

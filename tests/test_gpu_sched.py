@@ -126,3 +126,50 @@ def test_schedulable_pod_groups_matrix(ctx):
             for j, g in enumerate(groups):
                 assert bool(ok[i, j]) == s.check_predicates(t, g.pods[0])[0], (seed, name, j)
         s.close()
+
+
+# ---- scale-down removal simulation -----------------------------------------------------------------
+def test_removal_fuzz(ctx):
+    from harness import RemovalCase, assert_removal_matches, removal_device, removal_oracle
+    from kubernetes_autoscaler_amd.workloads import fuzz_removals
+    for seed in range(250):
+        w = fuzz_removals(seed)
+        case = RemovalCase(nodes=w.nodes, candidates=w.candidates, destination=w.destination, hints=w.hints, persist=w.persist,
+                           max_removable=w.max_removable, last_index=w.last_index)
+        assert_removal_matches(removal_device(case, ctx), removal_oracle(case), w.name)
+
+
+@pytest.mark.parametrize("n_nodes", [300, 2500])
+def test_removal_at_scale(ctx, n_nodes):
+    from harness import RemovalCase, assert_removal_matches, removal_device, removal_oracle
+    from kubernetes_autoscaler_amd.workloads import removal_scale
+    w = removal_scale(n_nodes, pods_per_node=10, frac_candidates=0.3, seed=11)
+    case = RemovalCase(nodes=w.nodes, candidates=w.candidates)
+    got, want = removal_device(case, ctx), removal_oracle(case)
+    assert_removal_matches(got, want, w.name)
+    assert int((got.removable == 1).sum()) > n_nodes // 20 and len(want["ext"]) > 0
+    # size-independent property: the pods of every removable node are all placed, on nodes that were not removed before
+    # their move and are not the node itself
+    off = np.cumsum([0] + [len(l) for l in case.pod_lists()])
+    for k, c in enumerate(w.candidates):
+        if got.removable[k] == 1:
+            d = got.node_out[off[k]:off[k + 1]]
+            assert (d >= 0).all() and (d != c).all()
+
+
+def test_removal_mirror_planner_loop(ctx):
+    from harness import RemovalCase, removal_oracle
+    from kubernetes_autoscaler_amd.scaledown import RemovalSimulator
+    from kubernetes_autoscaler_amd.workloads import fuzz_removals
+    for seed in range(30):
+        w = fuzz_removals(2000 + seed)
+        nodes = [NodeInfo(info.node, list(info.pods)) for info in w.nodes]
+        want = removal_oracle(RemovalCase(nodes=w.nodes, candidates=w.candidates, destination=w.destination, persist=True,
+                                          max_removable=w.max_removable, last_index=w.last_index))
+        sim = RemovalSimulator(ctx, nodes, persist_successful_simulations=True)
+        sim.last_index = w.last_index
+        dest = {info.node.name: (w.destination is None or bool(w.destination[i])) for i, info in enumerate(w.nodes)}
+        removable, unremovable, skipped = sim.simulate_node_removals([w.nodes[c].node.name for c in w.candidates], dest, w.max_removable)
+        assert [r.node.name for r in removable] == [w.nodes[c].node.name for k, c in enumerate(w.candidates) if want["removable"][k] == 1]
+        assert [u.node.name for u in unremovable] == [w.nodes[c].node.name for k, c in enumerate(w.candidates) if want["removable"][k] == 0]
+        assert sim.last_index == want["last_index"] and sim.device_calls <= 1

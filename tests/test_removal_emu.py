@@ -31,11 +31,19 @@ def test_fuzz(seed):
 def test_simple_chain():
     # three nodes of 1000m: n0 {400}, n1 {400}, n2 {300}; candidates n0, n1, n2 in that order, everything persists
     nodes = [NodeInfo(_node(f"n{i}", 1000, 10**9, 10)) for i in range(3)]
-    for i, cpu in enumerate((400, 400, 300)):
+    for i, cpu in enumerate((400, 400, 100)):
         nodes[i].pods.append(build_test_pod(f"p{i}", cpu, 1))
-    rem, node_out, final, li, npr = check(RemovalCase(nodes=nodes, candidates=[0, 1, 2]))
-    # n0's pod goes to n1 (first node after lastIndex 0); n1 then carries an arrival: the call stops in front of it
-    assert list(rem) == [1, 2, 2] and list(node_out) == [1, -1, -1] and npr == 1
+    # n0's pod goes to n1 (first node after lastIndex 0); n1 then lists it again after its own pod: both go to n2;
+    # n2 finally lists all three and has nowhere to go (its first pod already fails: the others are not tried)
+    w = check(RemovalCase(nodes=nodes, candidates=[0, 1, 2]))
+    assert list(w["removable"]) == [1, 1, 0] and list(w["node_out"]) == [1, 2, -1] and w["n_processed"] == 3
+    assert w["ext"] == [(1, 0, 2), (2, 1, -1), (2, 0, -1)] and list(w["final"]) == [2, 2, 2]
+    # ext_capacity 0: the old protocol, stop in front of n1
+    w = check(RemovalCase(nodes=nodes, candidates=[0, 1, 2], ext_capacity=0))
+    assert list(w["removable"]) == [1, 2, 2] and w["n_processed"] == 1
+    # a sticky pod hands the loop back exactly where it is listed again
+    w = check(RemovalCase(nodes=nodes, candidates=[0, 1, 2], sticky={id(nodes[0].pods[0])}))
+    assert list(w["removable"]) == [1, 2, 2] and w["n_processed"] == 1
 
 
 def test_reverted_simulation_leaves_no_trace():
@@ -44,8 +52,8 @@ def test_reverted_simulation_leaves_no_trace():
     nodes[0].pods += [build_test_pod("a", 600, 1), build_test_pod("b", 600, 1)]
     nodes[1].pods += [build_test_pod("c", 300, 1)]
     nodes[2].pods += [build_test_pod("d", 700, 1)]
-    rem, node_out, final, li, npr = check(RemovalCase(nodes=nodes, candidates=[0, 2], destination=[1, 1, 0]))
-    assert list(rem) == [0, 1] and list(node_out) == [1, -1, 1] and npr == 2
+    w = check(RemovalCase(nodes=nodes, candidates=[0, 2], destination=[1, 1, 0]))
+    assert list(w["removable"]) == [0, 1] and list(w["node_out"]) == [1, -1, 1] and w["n_processed"] == 2
 
 
 def test_list_positions_shift_after_a_removal():
@@ -59,8 +67,8 @@ def test_list_positions_shift_after_a_removal():
 
 def test_empty_nodes_are_removable():
     nodes = [NodeInfo(_node(f"n{i}", 1000, 10**9, 10)) for i in range(5)]
-    rem, node_out, final, li, npr = check(RemovalCase(nodes=nodes, candidates=[4, 0, 2, 1, 3], last_index=2))
-    assert list(rem) == [1] * 5 and npr == 5 and li == 2
+    w = check(RemovalCase(nodes=nodes, candidates=[4, 0, 2, 1, 3], last_index=2))
+    assert list(w["removable"]) == [1] * 5 and w["n_processed"] == 5 and w["last_index"] == 2
 
 
 def test_max_removable_and_not_persisting():
@@ -70,25 +78,35 @@ def test_max_removable_and_not_persisting():
             check(RemovalCase(nodes=w.nodes, candidates=w.candidates, persist=persist, max_removable=limit), f"persist={persist} limit={limit}")
 
 
+def test_ext_table_overflow_hands_back():
+    w = removal_scale(30, pods_per_node=3, frac_candidates=0.8, seed=9)
+    full = check(RemovalCase(nodes=w.nodes, candidates=w.candidates))
+    assert len(full["ext"]) > 4
+    part = check(RemovalCase(nodes=w.nodes, candidates=w.candidates, ext_capacity=3))
+    assert part["n_processed"] < full["n_processed"] and len(part["ext"]) <= 3
+
+
 def test_large_cluster_several_chunks():
     w = removal_scale(1300, pods_per_node=3, frac_candidates=0.05, seed=5)
     want = check(case_of(w), w.name, lds=(0,))
-    assert want[4] >= 1
+    assert want["n_processed"] == len(w.candidates)
 
 
-# ---- host mirror: the planner loop re-submits when a candidate received pods -----------------------------------
-@pytest.mark.parametrize("seed", range(60))
-def test_mirror_chained_calls_equal_the_reference_loop(seed):
-    """RemovalSimulator.simulate_node_removals (several device calls, GetPodsToMove re-run in between) == the oracle
-    walking the whole candidate list with arrived pods appended (what the reference's committed snapshot shows)."""
+# ---- host mirror: the planner loop, re-submitting where a sticky pod was listed again ----------------------------
+@pytest.mark.parametrize("mode", ["device-lists", "resubmit-at-arrivals", "sticky"])
+@pytest.mark.parametrize("seed", range(40))
+def test_mirror_equals_the_reference_loop(seed, mode):
+    """RemovalSimulator.simulate_node_removals — one device call, or several with GetPodsToMove re-run in between —
+    == the oracle walking the whole candidate list on the committed snapshot."""
     w = fuzz_removals(1000 + seed)
-    if not w.persist:
-        w.persist = True
     nodes = [NodeInfo(info.node, list(info.pods)) for info in w.nodes]
     case = RemovalCase(nodes=w.nodes, candidates=w.candidates, destination=w.destination, hints=None, persist=True,
                        max_removable=w.max_removable, last_index=w.last_index)
-    rem, node_out, final, li, npr = removal_oracle(case, dynamic_lists=True)
-    sim = RemovalSimulator(EmuContext(), nodes, persist_successful_simulations=True)
+    want = removal_oracle(case)
+    rem = want["removable"]
+    sticky_ids = {id(p) for i, info in enumerate(w.nodes) for j, p in enumerate(info.pods) if (i + j) % 3 == 0} if mode == "sticky" else set()
+    sim = RemovalSimulator(EmuContext(), nodes, persist_successful_simulations=True, is_sticky=lambda p: id(p) in sticky_ids,
+                           ext_capacity=0 if mode == "resubmit-at-arrivals" else None)
     sim.last_index = w.last_index
     dest = {info.node.name: (w.destination is None or bool(w.destination[i])) for i, info in enumerate(w.nodes)}
     removable, unremovable, skipped = sim.simulate_node_removals([w.nodes[c].node.name for c in w.candidates], dest, w.max_removable)
@@ -96,10 +114,20 @@ def test_mirror_chained_calls_equal_the_reference_loop(seed):
     want_unremovable = [w.nodes[c].node.name for k, c in enumerate(w.candidates) if rem[k] == 0]
     assert [r.node.name for r in removable] == want_removable
     assert [u.node.name for u in unremovable] == want_unremovable and all(u.reason == NO_PLACE_TO_MOVE_PODS for u in unremovable)
-    assert len(skipped) == len(w.candidates) - npr
-    assert sim.last_index == li
-    # where every pod that was ever listed sits at the end
+    assert len(skipped) == len(w.candidates) - want["n_processed"]
+    assert sim.last_index == want["last_index"]
+    if mode == "device-lists":
+        assert sim.device_calls <= 1
+    # where every listed pod sits at the end
     where = {id(p): info.node.name for info in nodes for p in info.pods}
     flat = [p for lst in case.pod_lists() for p in lst]
-    for p, f in zip(flat, final):
+    for p, f in zip(flat, want["final"]):
         assert where[id(p)] == w.nodes[f].node.name, (p.name, f)
+    # pods_to_reschedule of a removable node = its own pods + the pods it listed again
+    again = {}
+    for k, e, m in want["ext"]:
+        again.setdefault(k, []).append(flat[e].name)
+    lists = case.pod_lists()
+    ks = [k for k in range(len(w.candidates)) if rem[k] == 1]
+    for r, k in zip(removable, ks):
+        assert [p.name for p in r.pods_to_reschedule] == [p.name for p in lists[k]] + again.get(k, [])

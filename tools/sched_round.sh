@@ -15,3 +15,5 @@ cat $OUT/time_pending.jsonl | tee -a $OUT/summary.txt; tail -5 $OUT/time_pending
 echo "trace exit $?" | tee -a $OUT/summary.txt
 python tools/rocpd_summary.py $OUT/prof_trace 2>&1 | tee $OUT/prof_trace_summary.txt | head -30 | tee -a $OUT/summary.txt
 find "$OUT" -name "*.csv" -size +8M -delete
+timeout 900 python tools/time_removals.py > $OUT/time_removals.jsonl 2> $OUT/time_removals.err; echo "removals exit $?" | tee -a $OUT/summary.txt
+cat $OUT/time_removals.jsonl | tee -a $OUT/summary.txt; tail -5 $OUT/time_removals.err | tee -a $OUT/summary.txt
