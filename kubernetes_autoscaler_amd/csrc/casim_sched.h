@@ -26,6 +26,7 @@
 // reference consults the memo (pods without a controller are re-tried and fail again): node_out is
 // identical, the memo here (one LDS bit per class) just skips the re-scan.
 #pragma once
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -601,7 +602,9 @@ public:
         dt_.init_excl = up(g->init_excl, N * dt_.Wx);
 
         // one workgroup: 64..1024 threads, node m -> thread m % T, chunk m / T
-        threads_ = (int)(round_up64_((int64_t)N_) < 1024 ? round_up64_((int64_t)N_) : 1024);
+        int max_threads = cand ? kDefaultThreadsRemovals : kDefaultThreads;
+        if (const char* e = getenv("CASIM_SCHED_THREADS")) { const int v = atoi(e); if (v >= 64 && v <= 1024) max_threads = v / 64 * 64; }
+        threads_ = (int)(round_up64_((int64_t)N_) < max_threads ? round_up64_((int64_t)N_) : max_threads);
         cap_ = (int32_t)(((int64_t)N_ + threads_ - 1) / threads_ * threads_);
         S_ = cap_ >> 6;
         a_.N = N_; a_.C = C_; a_.n_runs = n_runs_; a_.break_on_failure = q->break_on_failure ? 1 : 0;
@@ -698,6 +701,14 @@ public:
     int runs() const { return n_runs_; }
     int threads() const { return threads_; }
     bool in_lds() const { return lds_; }
+
+    // Workgroup size cap.  Every wave runs the run's uniform instruction stream and meets the others at each
+    // collective, so more waves only pay off while a run has to look at many nodes; a piece of 256 nodes also lets
+    // a run that fits nearby stop after a quarter of the work of a 1024-node piece.  Sweep on MI355X
+    // (profiles/r01h_sched_threads_sweep.txt): 64 / 128 / 256 / 512 / 1024 threads -> 20.9 / 16.1 / 14.2 / 15.5 / 20.6 ms
+    // for 15000 nodes x 150000 pods, 41.2 / 41.6 / 42.1 / 44.9 / 53.3 ms for 3000 removals on 15000 nodes.
+    static constexpr int kDefaultThreads = 256;
+    static constexpr int kDefaultThreadsRemovals = 128;   // short runs (1-2 pods per candidate): fewer waves per barrier
 
 private:
     static int64_t round_up64_(int64_t v) { return (v + 63) & ~63ll; }
