@@ -182,10 +182,20 @@ def main():
         bytes_pack, Bp, Bn = algorithmic_bytes_pack(enc.pegs, enc.groups, nnz, info["fast_packer_slots_per_lane"] > 0)
         achieved = bytes_pack / (kms["pack_ms"] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "pack_fast_kernel<%d,%d>" % (info["fast_packer_lanes"], info["fast_packer_slots_per_lane"]) if info["fast_packer_slots_per_lane"] else "pack_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
                     "algorithmic_bytes_per_launch": bytes_pack, "bytes_per_peg_record": Bp, "bytes_per_group_record": Bn,
                     "kernel_ms": kms["pack_ms"],
                     "note": "packer is integer-ALU/latency bound (sequential per-PEG dependency), not HBM bound; see DESIGN.md"}
+        # HBM bytes per launch from the PMC passes of the same command (tools/gpu_round.sh -> tools/pmc_traffic.py):
+        # counters cannot be collected from inside the timed run, so the committed figure is used when it was taken
+        # on the same kernel and launch size
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "pack_traffic.json")))
+            if tr.get("waves_per_launch") == B and roofline["kernel"].replace(" ", "") in tr.get("kernel", "").replace(" ", ""):
+                roofline["traffic"] = tr["traffic_bytes_per_launch"]
+                roofline["traffic_source"] = "profiles/pack_traffic.json (%s: FETCH_SIZE x2 per the gfx950 rule + WRITE_SIZE, per launch)" % tr.get("run", "?")
+        except (OSError, ValueError, KeyError):
+            pass
         extra = {"kernel_ms": kms, "pipeline_ms_hip_events": total_ms, "encode_s": t_encode,
                  "sims_per_s": world * B / (dt / args.steps), "best_group": best}
         # single-simulation latency (B = 1), the north-star "< 50 ms / iteration" figure

@@ -40,8 +40,10 @@
 #endif
 
 // Waves per SIMD the register allocator of the 256-node fast packer must leave room for.  Measured on
-// MI355X (r01, C1 x 16384): natural allocation 148 VGPRs = 3 waves/SIMD -> 8.2 M sims/s; 4 waves
-// (128 VGPRs, 68 B/lane of scratch) -> 9.2 M; 5 waves (96 VGPRs, 204 B/lane) -> 4.0 M.
+// MI355X (r01, C1 x 16384): 3 waves (148 VGPRs at the time) -> 8.2 M sims/s; 4 waves -> 9.0-9.2 M; 5 waves
+// (96 VGPRs) spills ~200 B/lane -> 4.0 M.  The kernel now needs 123 VGPRs (scheduling fences in capacity_all),
+// i.e. 4 waves WITHOUT scratch: an earlier build met the bound by spilling 68 B/lane, which the PMC passes
+// showed as 2.6x the algorithmic HBM traffic (profiles/r01i_*).
 #ifndef CASIM_FAST_WAVES
 #define CASIM_FAST_WAVES 4
 #endif
@@ -175,8 +177,8 @@ struct RegStore {
     using Fresh = FreshNode<int32_t, R_>;
     int32_t fr[NPT_][R_];
     int32_t slots[NPT_];
-    int32_t pods[NPT_];
     uint32_t c[NPT_];
+    int32_t fresh_slots;  // pod slots of an empty node: pods on a node = fresh_slots - slots (no per-node counter)
 
     CS_DEVICE uint32_t capacity(int s, int, const Peg& pv, uint32_t clampk, bool selfx) const {
         uint32_t k = capacity_lanes<Lane, R_>(fr[s], slots[s], R_, pv, clampk);
@@ -219,6 +221,7 @@ struct RegStore {
                 if (selfx) k = k > 1 ? 1u : k;
             }
             c[s] = k;
+            if (NPT_ >= 4 && (s & 1) == 1) cs::sched_fence();  // interleave two slots at a time: bounds the live temporaries
         }
         return n1;
     }
@@ -226,17 +229,15 @@ struct RegStore {
 #pragma unroll
         for (int r = 0; r < R_; ++r) fr[s][r] -= (int32_t)x * pv.req[r];
         slots[s] -= (int32_t)x;
-        pods[s] += (int32_t)x;
     }
     CS_DEVICE void create(int s, int, uint32_t x, const Peg& pv, const Fresh& fn) {
 #pragma unroll
         for (int r = 0; r < R_; ++r) fr[s][r] = fn.free[r] - (int32_t)x * pv.req[r];
         slots[s] = fn.slots - (int32_t)x;
-        pods[s] = (int32_t)x;
     }
     CS_DEVICE uint32_t get_c(int s, int) const { return c[s]; }
     CS_DEVICE void set_c(int s, int, uint32_t v) { c[s] = v; }
-    CS_DEVICE int32_t npods(int s, int) const { return pods[s]; }
+    CS_DEVICE int32_t npods(int s, int) const { return fresh_slots - slots[s]; }  // only asked for created nodes
 
     // Summary pruning.  bound_free[r] / bound_slots are wave-uniform UPPER bounds of max_j free_j[r] and
     // max_j slots_j over all simulated nodes.  Placements only lower the true maxima, so a stale bound stays
@@ -694,13 +695,14 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, (NPT_ == 4 ? CASIM_FAST_WAVES : 1)) void pack_fas
     for (int s = 0; s < NPT_; ++s) {
 #pragma unroll
         for (int r = 0; r < R_; ++r) st.fr[s][r] = 0;
-        st.slots[s] = 0; st.pods[s] = 0; st.c[s] = 0;
+        st.slots[s] = 0; st.c[s] = 0;
     }
     st.reset_bounds();
     FreshNode<int32_t, R_> fn;
 #pragma unroll
     for (int r = 0; r < R_; ++r) fn.free[r] = r < t.R ? fs.fresh32[(int64_t)ng * t.R + r] : 0;
     fn.slots = t.allowed[ng] - t.init_pods[ng];
+    st.fresh_slots = fn.slots;
     fn.excl = nullptr;
     const int32_t* req32 = fs.req32;
     const int32_t* order = res.order;

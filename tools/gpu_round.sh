@@ -41,6 +41,8 @@ if [ "$MODE" = "full" ]; then
     echo "pmc $N exit $?" | tee -a "$OUT/summary.txt"
   done
   python tools/summarize_pmc.py "$OUT" 2>&1 | tee -a "$OUT/summary.txt"
+  python tools/rocpd_summary.py "$OUT"/prof_trace "$OUT"/prof_pmc_* > "$OUT/rocpd_summary.txt" 2>&1
+  python tools/pmc_traffic.py "$OUT" "$OUT/pack_traffic.json" 2>&1 | tee -a "$OUT/summary.txt"
   # keep the merged payload small: raw per-dispatch CSVs can be large
   find "$OUT" -name "*.csv" -size +8M -delete
 fi
