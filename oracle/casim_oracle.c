@@ -135,6 +135,7 @@ struct orc {
     const char* last_fail_reason; /* reason of the last failing Filter run (SchedulingError.FailingPredicateReasons) */
     /* Fork()/Revert() support for callers that commit pods to snapshot nodes: pre-images of touched nodes */
     int snap_added;     /* nodes ever added to the snapshot (source of orig_id) */
+    uint64_t shuffle;   /* != 0: ListNodeInfos() order is re-drawn for every scheduling attempt (Go map iteration) */
     int undo_on;
     struct { int n, cap; struct undo_rec { int orig_id; node copy; }* v; } undo;
 };
@@ -184,6 +185,7 @@ void orc_free(orc* o) {
     free(o);
 }
 void orc_set_taint_comparison_ops(orc* o, int enabled) { o->taint_cmp_ops = enabled; }
+void orc_set_list_shuffle(orc* o, uint64_t seed) { o->shuffle = seed; }
 
 int orc_pod(orc* o, const char* ns, const int64_t* req) {
     podspec p; memset(&p, 0, sizeof p);
@@ -667,14 +669,29 @@ int orc_last_index_at(int i, int offset, int last_index, int n) {
 
 /* RunFiltersUntilPassingNode  CA/simulator/clustersnapshot/predicate/plugin_runner.go:54-143,
  * parallelism 1.  accept_new_only mirrors Estimate's IsNodeAcceptable (binpacking_estimator.go:172-174). */
+static uint64_t splitmix64_next(uint64_t* x) {
+    uint64_t z = (*x += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
 static int run_filters_until_passing_ex(orc* o, int pod, int accept_new_only, int skip_idx, int* last_index) {
     const podspec* p = &o->pods.v[pod];
     ipa_state st; ipa_prefilter(o, p, &st);
     pts_state ts; pts_prefilter(o, p, &ts);
-    int n = o->snap.n, found = -1;
+    int n = o->snap.n, found = -1, found_pos = -1;
+    /* order-independence probe: the reference's stores enumerate nodes by Go map iteration, a fresh
+     * order for every attempt (store/basic.go:41-47, store/delta.go:143-145); lastIndex is a position in THAT list */
+    int* perm = NULL;
+    if (o->shuffle && n > 0) {
+        perm = malloc(sizeof(int) * (size_t)n);
+        for (int i = 0; i < n; ++i) perm[i] = i;
+        for (int i = n - 1; i > 0; --i) { int j = (int)(splitmix64_next(&o->shuffle) % (uint64_t)(i + 1)); int t = perm[i]; perm[i] = perm[j]; perm[j] = t; }
+    }
     for (int i = 0; i < n; ++i) {
-        int idx = orc_last_index_at(i, 1, *last_index, n);
-        if (idx < 0) break;
+        int pos = orc_last_index_at(i, 1, *last_index, n);
+        if (pos < 0) break;
+        int idx = perm ? perm[pos] : pos;
+        found_pos = pos;
         const node* nd = &o->snap.v[idx];
         if (nd->unschedulable) continue;                    /* :108-110 */
         if (accept_new_only && !nd->is_new) continue;       /* :114 */
@@ -682,7 +699,8 @@ static int run_filters_until_passing_ex(orc* o, int pod, int accept_new_only, in
         if (run_filter_plugins(o, p, nd, &st, &ts, NULL, NULL)) { found = idx; break; }
     }
     ipa_free(&st); pts_free(&ts);
-    if (found >= 0) *last_index = found;                    /* MarkMatch :138 */
+    free(perm);
+    if (found >= 0) *last_index = found_pos;                /* MarkMatch :138 (position in the list of this attempt) */
     return found;
 }
 static int run_filters_until_passing(orc* o, int pod, int accept_new_only, int* last_index) {

@@ -72,6 +72,9 @@ int orc_node_add_pod(orc* o, int node, int pod);
 /* put a copy of `node` into the cluster snapshot (insertion order is the list order) */
 int orc_snapshot_add(orc* o, int node);
 void orc_set_taint_comparison_ops(orc* o, int enabled);
+/* seed != 0: every scheduling attempt of Estimate sees the node list in a freshly drawn order, like the reference's
+ * map-backed stores — used to check that a workload's (NodeCount, Pods) does not depend on the order */
+void orc_set_list_shuffle(orc* o, uint64_t seed);
 
 /* ---- BinpackingNodeEstimator.Estimate  (CA/estimator/binpacking_estimator.go:102-161) ---- */
 typedef struct orc_estimate_result {

@@ -39,9 +39,10 @@ class Scenario:
 
 
 # ---------------------------------------------------------------------------------------------
-def run_oracle(sc: Scenario):
-    """Per group: OracleEstimate plus the list of global PEG ids it was given."""
-    s = OracleScenario(lanes=sc.lanes)
+def run_oracle(sc: Scenario, list_shuffle_seed: int = 0):
+    """Per group: OracleEstimate plus the list of global PEG ids it was given.  list_shuffle_seed != 0: every
+    scheduling attempt sees the node list in a fresh random order (Go map iteration)."""
+    s = OracleScenario(lanes=sc.lanes, list_shuffle_seed=list_shuffle_seed)
     for info in sc.existing:
         s.add_existing(info)
     out = []

@@ -63,6 +63,7 @@ def lib():
             "orc_node_add_pod": (C.c_int, [P, C.c_int, C.c_int]),
             "orc_snapshot_add": (C.c_int, [P, C.c_int]),
             "orc_set_taint_comparison_ops": (None, [P, C.c_int]),
+            "orc_set_list_shuffle": (None, [P, C.c_uint64]),
             "orc_estimate": (C.c_int, [P, C.c_int, C.c_int, i32p, i32p, C.c_int, C.c_int, C.c_int, C.POINTER(EstimateResult)]),
             "orc_check_predicates": (C.c_int, [P, C.c_int, C.c_int, cstrp, cstrp]),
             "orc_run_filters_on_snapshot_node": (C.c_int, [P, C.c_int, C.c_int, cstrp, cstrp]),
@@ -122,13 +123,15 @@ class OracleEstimate:
 class OracleScenario:
     """A cluster snapshot + pod specs + node templates inside the oracle."""
 
-    def __init__(self, lanes: Sequence[str] = ("cpu", "memory"), taint_comparison_ops: bool = False):
+    def __init__(self, lanes: Sequence[str] = ("cpu", "memory"), taint_comparison_ops: bool = False, list_shuffle_seed: int = 0):
         self.L = lib()
         self.lanes = tuple(lanes)
         self.h = self.L.orc_new(len(self.lanes))
         assert self.h
         if taint_comparison_ops:
             self.L.orc_set_taint_comparison_ops(self.h, 1)
+        if list_shuffle_seed:
+            self.L.orc_set_list_shuffle(self.h, list_shuffle_seed)
         self._pod_ids: Dict[int, int] = {}
         self._keep: List[object] = []
 
