@@ -121,11 +121,9 @@ struct BlockCtl {
         ph_red ^= 1;
         return r;
     }
-    // value of the (at most one) thread with `mine`; `fallback` when no thread has it
-    CS_DEVICE uint32_t pick(bool mine, uint32_t v, uint32_t fallback) {
+    // value of THE thread with `mine` (exactly one thread of the block has it): one barrier
+    CS_DEVICE uint32_t pick(bool mine, uint32_t v) {
         uint32_t* s = slot + ph_slot;
-        if (cs::tid() == 0) *s = fallback;
-        cs::sync();
         if (mine) *s = v;
         cs::sync();
         const uint32_t r = *s;
@@ -222,7 +220,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
             const int32_t lo = (int32_t)wpre[w], cntw = cs::popc64(alive[w]);
             if (pos >= lo && pos < lo + cntw) { mine = true; w_mine = (uint32_t)w; }
         }
-        const uint32_t w = bc.pick(mine, w_mine, 0u);
+        const uint32_t w = bc.pick(mine, w_mine);
         uint64_t b = alive[w];
         for (int32_t i = (int32_t)wpre[w]; i < pos; ++i) b &= b - 1;   // drop the live nodes in front
         return (int32_t)(w << 6) + cs::ffs64(b);
@@ -267,8 +265,8 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
             if (tid == 0) a.removable_out[kc] = 0;
             continue;
         }
-        // Fork; the candidate turns into a pod-less tainted ghost that keeps its list position (:243-265)
-        cs::sync();
+        // Fork; the candidate turns into a pod-less tainted ghost that keeps its list position (:243-265).
+        // (every path into this point ends with a barrier: nobody still reads the words rewritten here)
         if (tid == 0) { accb[Y >> 6] &= ~(1ull << (Y & 63)); scanb[Y >> 6] &= ~(1ull << (Y & 63)); }
         cs::sync();
     }
@@ -318,7 +316,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                     const bool owner = tid == hint % T;
                     uint32_t ch = 0;
                     if (owner) ch = st.capacity(0, hint, pv, 1u, false);
-                    if (bc.pick(owner, ch, 0u) > 0) {
+                    if (bc.pick(owner, ch) > 0) {
                         if (owner) { st.commit(0, hint, 1u, pv); a.node_out[first] = hint; }
                         placed = 1;
                     }
@@ -373,7 +371,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                 }
                 if (cum > 0) {
                     // MarkMatch (plugin_runner.go:138): lastIndex = node of the last pod placed so far
-                    last_index = (int32_t)bc.pick(last_mine, last_owner_val, (uint32_t)last_index);
+                    last_index = (int32_t)bc.pick(last_mine, last_owner_val);
                     placed += (int32_t)(cum < keff ? cum : keff);
                 }
                 if (cum > 0 && cum < keff) {
@@ -443,7 +441,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                             }
                             pod_base += (int32_t)(partial ? Rr : cumr);
                         }
-                        last_index = (int32_t)bc.pick(last_mine, last_owner_val, (uint32_t)last_index);
+                        last_index = (int32_t)bc.pick(last_mine, last_owner_val);
                         placed += got;
                     }
                 }
@@ -480,11 +478,8 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                 a.log_dest[log_n + i] = m;
             }
             log_n += n_listed;
-            if (tid == 0) {
-                alive[Y >> 6] &= ~(1ull << (Y & 63));
-                uint32_t acc = 0;
-                for (int w = 0; w < nw; ++w) { wpre[w] = acc; acc += (uint32_t)cs::popc64(alive[w]); }
-            }
+            if (tid == 0) alive[Y >> 6] &= ~(1ull << (Y & 63));
+            for (int w = (Y >> 6) + 1 + tid; w < nw; w += T) wpre[w] -= 1u;   // one live node less in front of these words
             n_alive--; any_dead = true;
         } else {
             // Revert: touched nodes get their committed state back, the candidate its pods and its place
