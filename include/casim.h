@@ -269,11 +269,46 @@ int32_t casim_best_option(casim_problem* p, const int32_t* kinds, int32_t n_kind
  *              explicit_self_exclusion = 1.
  * Per pod: the hinted node first (tryScheduleUsingHints :86-110: RunFiltersOnNode, no lastIndex update), else
  * the first passing node in cyclic order from lastIndex + 1 among acceptable, schedulable nodes
- * (RunFiltersUntilPassingNode, plugin_runner.go:54-143), with the SimilarPodsScheduling memo (:115-118,
- * applied to every class: a class that fit nowhere cannot fit later, state only fills up).
+ * (RunFiltersUntilPassingNode, plugin_runner.go:54-143), with the SimilarPodsScheduling memo (:115-118; see
+ * similar_key below).
  * Returns CASIM_OK, <0 on error, or CASIM_NG_UNSUPPORTED (> 0) when a class needs a predicate outside the
  * encoded subset or a group-wide (non-hostname) exclusion: the shim then runs the Go simulator.
  */
+/*
+ * Domain rules: the Filters whose verdict on a node depends on what the OTHER nodes of its topology domain hold —
+ * PodTopologySpread (V/.../podtopologyspread/filtering.go:236-366; DoNotSchedule constraints, nodeAffinityPolicy Honor,
+ * nodeTaintsPolicy Ignore) and required anti-affinity on non-hostname topology keys
+ * (V/.../interpodaffinity/filtering.go:204-432).  Built by the encoder in per-node mode
+ * (explicit_self_exclusion = 1, casim_enc_domain_rules) from the pod specs and the nodes' labels / running pods.
+ * A rule belongs to one class and one topology key and owns one counter per domain of that key:
+ *   kind 0 (spread): counter = pods matching the constraint's selector (same namespace) on ELIGIBLE nodes of the domain
+ *          (eligible = passes the class's nodeSelector / required affinity and carries every topology key of the
+ *          class's constraints); a node passes iff it carries the key and
+ *          counter[its domain] + self - min over existing domains (0 if fewer than min_domains) <= max_skew;
+ *   kind 1 (conflict): counter = pods in the domain that are anti-affine with the class through this key, either
+ *          direction; a node passes iff it lacks the key or counter[its domain] == 0.
+ * inc_*: which rules a placed pod of class c increments (on the node's domain, if the node is eligible for the rule).
+ */
+typedef struct casim_domain_rules {
+    int32_t n_keys, n_rules, n_nodes, n_classes, n_elig_rows;
+    const int32_t* node_domain;      /* [n_keys][n_nodes] domain id of the node for the key, -1 = label missing */
+    const int32_t* key_domains;      /* [n_keys] number of domains                                            */
+    const int32_t* rule_class;       /* [n_rules] rules are sorted by class                                    */
+    const int32_t* rule_key;         /* [n_rules]                                                              */
+    const int32_t* rule_kind;        /* [n_rules] 0 spread, 1 conflict                                         */
+    const int32_t* rule_max_skew;    /* [n_rules]                                                              */
+    const int32_t* rule_min_domains; /* [n_rules]                                                              */
+    const int32_t* rule_self;        /* [n_rules] 1 = a pod of the class increments its own rule               */
+    const int32_t* rule_elig_row;    /* [n_rules] row of elig_bits (kind 0) or -1 = every node carrying the key */
+    const int64_t* rule_offset;      /* [n_rules + 1] slice of count_init / domain_exists                      */
+    const int32_t* count_init;       /* counters from the pods already running                                 */
+    const uint8_t* domain_exists;    /* kind 0: an eligible node carries this domain (it counts for the minimum) */
+    const uint64_t* elig_bits;       /* [n_elig_rows][ceil(n_nodes / 64)]                                      */
+    const int32_t* class_rule_off;   /* [n_classes + 1] rules of class c: [class_rule_off[c], class_rule_off[c+1]) */
+    const int32_t* inc_off;          /* [n_classes + 1]                                                        */
+    const int32_t* inc_rule;         /* [inc_off[n_classes]]                                                   */
+} casim_domain_rules;
+
 typedef struct casim_pod_sequence {
     int32_t n_pods;                  /* P */
     const int32_t* pod_class;        /* [P] class (PEG id) of each pending pod, processing order          */
@@ -281,6 +316,14 @@ typedef struct casim_pod_sequence {
     const uint8_t* node_acceptable;  /* [N] SchedulingOptions.IsNodeAcceptable; may be NULL (= all)        */
     int32_t break_on_failure;        /* stop at the first pod that fits nowhere                            */
     int32_t last_index;              /* lastIndexOrderMapping.lastIndex on entry                           */
+    const struct casim_domain_rules* rules; /* PodTopologySpread / non-hostname anti-affinity; NULL = none  */
+    const int32_t* similar_key;      /* [P] or NULL: controller of the pod (drain.ControllerRef UID as a dense id >= 0),
+                                        -1 = none or a DaemonSet pod.  SimilarPodsScheduling (similar_pods.go:38-98)
+                                        caches "this spec of this controller found no node" for at most 10 specs per
+                                        controller.  Needed for exactness only when spread rules exist: a spread
+                                        constraint can start passing again once other domains fill up, so whether a
+                                        failed spec is re-tried matters; for every other class a node that failed once
+                                        fails again, cached or not. */
 } casim_pod_sequence;
 
 int32_t casim_try_schedule_pods(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes,
@@ -320,6 +363,8 @@ typedef struct casim_removal_candidates {
     int32_t max_removable;           /* stop after this many removable nodes (unneededNodesLimit); 0 = no limit */
     int32_t last_index;
     int32_t ext_capacity;            /* entries of the ext_* result arrays; 0 = stop at the first candidate with arrivals */
+    const struct casim_domain_rules* rules; /* the encoder's domain rules; if any exist the call returns CASIM_NG_UNSUPPORTED
+                                        (removing a node also takes its pods out of the counters: host path) */
 } casim_removal_candidates;
 
 typedef struct casim_removal_results {
@@ -410,6 +455,12 @@ int32_t casim_enc_pod_add_anti_affinity_term(casim_encoder* e, int32_t pod, cons
 int32_t casim_enc_term_add_requirement(casim_encoder* e, int32_t pod, int32_t term, const char* key,
                                        const char* op, const char* const* values, int32_t n_values);
 /* first-container requests as float64 for the fastpath chooser */
+/* DoNotSchedule topologySpreadConstraint of the pod spec (min_domains <= 0 = nil); returns its index.  Evaluated on the
+ * device only in per-node mode (explicit_self_exclusion); in template mode such a spec is flagged UNSUPPORTED. */
+int32_t casim_enc_pod_add_spread_constraint(casim_encoder* enc, int32_t pod, int32_t max_skew, const char* topology_key,
+                                            int32_t min_domains);
+int32_t casim_enc_spread_add_requirement(casim_encoder* enc, int32_t pod, int32_t constraint, const char* key, const char* op,
+                                         const char* const* values, int32_t n_values);
 int32_t casim_enc_pod_set_fastpath_requests(casim_encoder* e, int32_t pod, double cpu, double mem);
 /* Mark the spec as carrying a predicate outside the encoded subset (required pod affinity,
  * topology spread, volumes, DRA claims, multi-term node affinity, namespaceSelector...). */
@@ -434,6 +485,8 @@ int32_t casim_enc_add_existing_pod(casim_encoder* e, int32_t pod_spec, const cha
 int32_t casim_enc_finalize(casim_encoder* e);
 int32_t casim_enc_tables(const casim_encoder* e, casim_pegs* pegs_out, casim_groups* groups_out);
 /* Dictionary sizes (bits in use) for reporting: taints, label requirements, node bits, zone bits */
+/* per-node mode: the domain rules of the finalized tables (pointers owned by the encoder); n_rules == 0 when none */
+int32_t casim_enc_domain_rules(const casim_encoder* enc, casim_domain_rules* out);
 int32_t casim_enc_dict_sizes(const casim_encoder* e, int32_t sizes_out[4]);
 
 #ifdef __cplusplus

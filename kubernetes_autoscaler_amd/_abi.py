@@ -66,15 +66,24 @@ class EncoderOptions(C.Structure):
                 ("reserved", C.c_int32 * 5)]
 
 
+class DomainRules(C.Structure):
+    _fields_ = [("n_keys", C.c_int32), ("n_rules", C.c_int32), ("n_nodes", C.c_int32), ("n_classes", C.c_int32), ("n_elig_rows", C.c_int32),
+                ("node_domain", i32p), ("key_domains", i32p), ("rule_class", i32p), ("rule_key", i32p), ("rule_kind", i32p),
+                ("rule_max_skew", i32p), ("rule_min_domains", i32p), ("rule_self", i32p), ("rule_elig_row", i32p), ("rule_offset", i64p),
+                ("count_init", i32p), ("domain_exists", u8p), ("elig_bits", u64p), ("class_rule_off", i32p), ("inc_off", i32p),
+                ("inc_rule", i32p)]
+
+
 class PodSequence(C.Structure):
     _fields_ = [("n_pods", C.c_int32), ("pod_class", i32p), ("hint_node", i32p), ("node_acceptable", u8p),
-                ("break_on_failure", C.c_int32), ("last_index", C.c_int32)]
+                ("break_on_failure", C.c_int32), ("last_index", C.c_int32), ("rules", C.POINTER(DomainRules)),
+                ("similar_key", i32p)]
 
 
 class RemovalCandidates(C.Structure):
     _fields_ = [("n_candidates", C.c_int32), ("cand_node", i32p), ("pod_offsets", i32p), ("pod_class", i32p), ("hint_node", i32p),
                 ("destination", u8p), ("pod_sticky", u8p), ("persist", C.c_int32), ("max_removable", C.c_int32),
-                ("last_index", C.c_int32), ("ext_capacity", C.c_int32)]
+                ("last_index", C.c_int32), ("ext_capacity", C.c_int32), ("rules", C.POINTER(DomainRules))]
 
 
 class RemovalResults(C.Structure):
@@ -129,6 +138,9 @@ PROTOTYPES = {
     "casim_enc_pod_add_host_port": (C.c_int32, [C.c_void_p, C.c_int32, cstr, cstr, C.c_int32]),
     "casim_enc_pod_add_anti_affinity_term": (C.c_int32, [C.c_void_p, C.c_int32, cstr, cstrp, C.c_int32]),
     "casim_enc_term_add_requirement": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, cstr, cstr, cstrp, C.c_int32]),
+    "casim_enc_pod_add_spread_constraint": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, cstr, C.c_int32]),
+    "casim_enc_spread_add_requirement": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, cstr, cstr, cstrp, C.c_int32]),
+    "casim_enc_domain_rules": (C.c_int32, [C.c_void_p, C.POINTER(DomainRules)]),
     "casim_enc_pod_set_fastpath_requests": (C.c_int32, [C.c_void_p, C.c_int32, C.c_double, C.c_double]),
     "casim_enc_pod_mark_unsupported": (C.c_int32, [C.c_void_p, C.c_int32, cstr]),
     "casim_enc_add_peg": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),

@@ -38,7 +38,9 @@ struct Port { std::string ip, proto; int32_t port; bool operator<(const Port& o)
 struct Term { std::string topology_key; std::vector<std::string> namespaces; std::vector<Requirement> selector; };
 typedef std::map<std::string, std::string> Labels;
 
+struct Spread { int32_t max_skew; std::string key; int32_t min_domains; std::vector<Requirement> selector; };
 struct PodSpec {
+    std::vector<Spread> spread;   // DoNotSchedule topologySpreadConstraints
     std::string ns;
     int64_t req[CASIM_MAX_RES];
     Labels labels;
@@ -180,6 +182,14 @@ struct casim_encoder {
     std::vector<uint64_t> tol, sel, xblock, xmark, zblock, zmark, taint, label, init_excl, init_zone, zone_valid;
     std::vector<double> fp_cpu, fp_mem, cap_cpu, cap_mem;
     int dict[4] = {0, 0, 0, 0};
+    // domain rules (per-node mode)
+    struct {
+        int32_t n_keys = 0, n_rules = 0, n_rows = 0;
+        std::vector<int32_t> node_domain, key_domains, r_class, r_key, r_kind, r_skew, r_mind, r_self, r_row, count_init, class_off, inc_off, inc_rule;
+        std::vector<int64_t> r_off;
+        std::vector<uint8_t> exists;
+        std::vector<uint64_t> elig;
+    } dr;
 };
 
 extern "C" {
@@ -279,6 +289,23 @@ int32_t casim_enc_term_add_requirement(casim_encoder* e, int32_t pod, int32_t te
     if (term < 0 || (size_t)term >= e->specs[pod].anti.size()) return CASIM_ERR_INVALID;
     if (n_values < 0 || (n_values > 0 && !values)) return CASIM_ERR_INVALID;
     e->specs[pod].anti[term].selector.push_back(make_req(key, op, values, n_values)); return CASIM_OK;
+}
+int32_t casim_enc_pod_add_spread_constraint(casim_encoder* e, int32_t pod, int32_t max_skew, const char* topology_key, int32_t min_domains) {
+    POD_CHECK(e, pod);
+    if (max_skew <= 0 || !topology_key || !*topology_key) return CASIM_ERR_INVALID;
+    Spread sc; sc.max_skew = max_skew; sc.key = S(topology_key); sc.min_domains = min_domains > 0 ? min_domains : 1;  // nil => 1 (common.go:107)
+    e->specs[pod].spread.push_back(sc);
+    return (int32_t)e->specs[pod].spread.size() - 1;
+}
+int32_t casim_enc_spread_add_requirement(casim_encoder* e, int32_t pod, int32_t constraint, const char* key, const char* op,
+                                         const char* const* values, int32_t n_values) {
+    POD_CHECK(e, pod);
+    if (constraint < 0 || (size_t)constraint >= e->specs[pod].spread.size()) return CASIM_ERR_INVALID;
+    Requirement r; r.key = S(key); r.op = parse_req_op(op);
+    if (r.op == kBadOp) return CASIM_ERR_INVALID;
+    for (int i = 0; i < n_values; ++i) r.values.push_back(S(values[i]));
+    e->specs[pod].spread[(size_t)constraint].selector.push_back(r);
+    return CASIM_OK;
 }
 int32_t casim_enc_pod_set_fastpath_requests(casim_encoder* e, int32_t pod, double cpu, double mem) {
     POD_CHECK(e, pod); e->specs[pod].fp_cpu = cpu; e->specs[pod].fp_mem = mem; return CASIM_OK;
@@ -457,7 +484,8 @@ int32_t casim_enc_finalize(casim_encoder* e) {
     std::vector<std::vector<int>> z_block(G), z_mark(G);
     std::map<int, std::string> zbit_key;                  // bit -> topology key ("" = always valid)
     std::vector<int> static_zbit(G, -1);                  // per-PEG "blocked by the existing cluster" bit
-    {
+    const bool per_node = e->opt.explicit_self_exclusion != 0;   // real nodes: domains are handled by the domain rules below
+    if (!per_node) {
         auto occ = [&](int pg, const std::string& tk) {
             auto k = std::make_pair(pg, tk);
             auto it = occ_z.find(k);
@@ -481,7 +509,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
     // existing cluster pods and pods preloaded on a template: static (PEG, group) blocks through
     // non-hostname topology keys.  Sparse: only PEGs / pods that carry such terms can interact.
     std::vector<std::vector<uint32_t>> existing_block(G);   // PEG -> groups where it is blocked
-    {
+    if (!per_node) {
         auto has_zone_terms = [&](const PodSpec& p) {
             for (auto& t : p.anti) if (t.topology_key != kHostname) return true;
             return false;
@@ -519,6 +547,121 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         }
     }
     e->Wz = zbits.words();
+
+    // (4b) per-node mode: domain rules (include/casim.h, casim_domain_rules) for PodTopologySpread and for required
+    // anti-affinity on non-hostname keys.  Template mode (an Estimate): spread constraints are outside the subset.
+    e->dr = decltype(e->dr)();
+    if (!per_node) {
+        for (size_t i = 0; i < G; ++i) {
+            PodSpec& p = e->specs[(size_t)e->pegs[i].spec];
+            if (!p.spread.empty()) { p.unsupported = true; p.why = "topologySpreadConstraints"; }
+        }
+    } else {
+        auto& dr = e->dr;
+        const size_t words = (NG + 63) / 64;
+        std::map<std::string, int> key_id;
+        std::vector<std::string> keys;
+        auto key_of = [&](const std::string& k) { auto it = key_id.find(k); if (it != key_id.end()) return it->second; key_id[k] = (int)keys.size(); keys.push_back(k); return (int)keys.size() - 1; };
+        auto node_passes_affinity = [&](const PodSpec& p, const Group& g) {   // RequiredNodeAffinity.Match (nodeSelector + required term)
+            for (auto& kv : p.node_selector) { auto it = g.labels.find(kv.first); if (it == g.labels.end() || it->second != kv.second) return false; }
+            return selector_matches(p.node_affinity, g.labels);
+        };
+        auto zone_conflict = [&](const PodSpec& a, const PodSpec& b, const std::string& k) {   // either direction, through key k
+            for (auto& t : a.anti) if (t.topology_key == k && term_matches(t, b)) return true;
+            for (auto& t : b.anti) if (t.topology_key == k && term_matches(t, a)) return true;
+            return false;
+        };
+        // keys that matter: spread keys of the classes, non-hostname anti-affinity keys of classes and running pods
+        std::set<std::string> aa_keys;
+        for (size_t i = 0; i < G; ++i) for (auto& t : e->specs[(size_t)e->pegs[i].spec].anti) if (t.topology_key != kHostname) aa_keys.insert(t.topology_key);
+        std::set<int32_t> running;   // distinct specs of running pods
+        for (auto& g : e->groups) for (int32_t s2 : g.preloaded) running.insert(s2);
+        for (int32_t s2 : running) for (auto& t : e->specs[(size_t)s2].anti) if (t.topology_key != kHostname) aa_keys.insert(t.topology_key);
+        struct Rule { int cls, key, kind, skew, mind, self, row; const Spread* sc; };
+        std::vector<Rule> rules;
+        std::vector<std::vector<uint64_t>> rows;
+        for (size_t i = 0; i < G; ++i) {
+            const PodSpec& p = e->specs[(size_t)e->pegs[i].spec];
+            int row = -1;
+            if (!p.spread.empty()) {   // eligibility of a node for this class's constraints (filtering.go:262-271)
+                row = (int)rows.size(); rows.emplace_back(words, 0ull);
+                for (size_t n = 0; n < NG; ++n) {
+                    const Group& g = e->groups[n];
+                    bool ok = node_passes_affinity(p, g);
+                    for (auto& sc : p.spread) ok = ok && g.labels.count(sc.key) != 0;
+                    if (ok) rows.back()[n >> 6] |= 1ull << (n & 63);
+                }
+            }
+            for (auto& sc : p.spread) {
+                Rule r{(int)i, key_of(sc.key), 0, sc.max_skew, sc.min_domains, 0, row, &sc};
+                r.self = (!sc.selector.empty() && selector_matches(sc.selector, p.labels)) ? 1 : 0;   // an empty selector counts nothing
+                rules.push_back(r);
+            }
+            for (auto& k : aa_keys) {
+                bool any = false;
+                for (size_t j = 0; j < G && !any; ++j) any = zone_conflict(p, e->specs[(size_t)e->pegs[j].spec], k);
+                for (int32_t s2 : running) { if (any) break; any = zone_conflict(p, e->specs[(size_t)s2], k); }
+                if (!any) continue;
+                Rule r{(int)i, key_of(k), 1, 0, 0, zone_conflict(p, p, k) ? 1 : 0, -1, nullptr};
+                rules.push_back(r);
+            }
+        }
+        if (!rules.empty()) {
+            dr.n_keys = (int32_t)keys.size(); dr.n_rules = (int32_t)rules.size(); dr.n_rows = (int32_t)rows.size();
+            // domains: distinct values of each key over the nodes
+            dr.node_domain.assign(keys.size() * NG, -1); dr.key_domains.assign(keys.size(), 0);
+            for (size_t k = 0; k < keys.size(); ++k) {
+                std::map<std::string, int> val_id;
+                for (size_t n = 0; n < NG; ++n) {
+                    auto it = e->groups[n].labels.find(keys[k]);
+                    if (it == e->groups[n].labels.end()) continue;
+                    auto v = val_id.find(it->second);
+                    int id;
+                    if (v == val_id.end()) { id = (int)val_id.size(); val_id[it->second] = id; } else id = v->second;
+                    dr.node_domain[k * NG + n] = id;
+                }
+                dr.key_domains[k] = (int32_t)val_id.size();
+            }
+            dr.r_off.assign(rules.size() + 1, 0);
+            for (size_t r = 0; r < rules.size(); ++r) dr.r_off[r + 1] = dr.r_off[r] + dr.key_domains[(size_t)rules[r].key];
+            dr.count_init.assign((size_t)dr.r_off.back(), 0); dr.exists.assign((size_t)dr.r_off.back(), 0);
+            dr.class_off.assign(G + 1, 0); dr.inc_off.assign(G + 1, 0);
+            for (size_t r = 0; r < rules.size(); ++r) {
+                const Rule& R0 = rules[r];
+                const PodSpec& p = e->specs[(size_t)e->pegs[(size_t)R0.cls].spec];
+                dr.r_class.push_back(R0.cls); dr.r_key.push_back(R0.key); dr.r_kind.push_back(R0.kind); dr.r_skew.push_back(R0.skew);
+                dr.r_mind.push_back(R0.mind); dr.r_self.push_back(R0.self); dr.r_row.push_back(R0.row);
+                dr.class_off[(size_t)R0.cls + 1]++;
+                for (size_t n = 0; n < NG; ++n) {
+                    const int d = dr.node_domain[(size_t)R0.key * NG + n];
+                    if (d < 0) continue;
+                    if (R0.kind == 0 && !((rows[(size_t)R0.row][n >> 6] >> (n & 63)) & 1ull)) continue;
+                    const size_t at = (size_t)dr.r_off[r] + (size_t)d;
+                    dr.exists[at] = 1;
+                    for (int32_t s2 : e->groups[n].preloaded) {
+                        const PodSpec& q = e->specs[(size_t)s2];
+                        if (R0.kind == 0) { if (!R0.sc->selector.empty() && q.ns == p.ns && selector_matches(R0.sc->selector, q.labels)) dr.count_init[at]++; }
+                        else if (zone_conflict(p, q, keys[(size_t)R0.key])) dr.count_init[at]++;
+                    }
+                }
+            }
+            for (size_t c = 0; c < G; ++c) dr.class_off[c + 1] += dr.class_off[c];
+            // which rules a placed pod of class j feeds
+            for (size_t j = 0; j < G; ++j) {
+                const PodSpec& q = e->specs[(size_t)e->pegs[j].spec];
+                for (size_t r = 0; r < rules.size(); ++r) {
+                    const Rule& R0 = rules[r];
+                    const PodSpec& p = e->specs[(size_t)e->pegs[(size_t)R0.cls].spec];
+                    const bool feeds = R0.kind == 0 ? (!R0.sc->selector.empty() && q.ns == p.ns && selector_matches(R0.sc->selector, q.labels))
+                                                    : zone_conflict(p, q, keys[(size_t)R0.key]);
+                    if (feeds) dr.inc_rule.push_back((int32_t)r);
+                }
+                dr.inc_off[j + 1] = (int32_t)dr.inc_rule.size();
+            }
+            dr.elig.assign(rows.size() * words, 0);
+            for (size_t r = 0; r < rows.size(); ++r) for (size_t w = 0; w < words; ++w) dr.elig[r * words + w] = rows[r][w];
+        }
+    }
 
     // ---- flat PEG table ------------------------------------------------------------------
     const int Wt = e->Wt, Wl = e->Wl, Wx = e->Wx, Wz = e->Wz;
@@ -633,6 +776,21 @@ int32_t casim_enc_tables(const casim_encoder* e, casim_pegs* p, casim_groups* g)
     g->max_nodes = e->max_nodes.data(); g->existing_nodes = e->existing_nodes.data(); g->last_index = e->last_index.data();
     g->cap_cpu = e->cap_cpu.data(); g->cap_mem = e->cap_mem.data(); g->waste_cpu = e->waste_cpu.data(); g->waste_mem = e->waste_mem.data();
     if (!e->peg_off.empty()) { g->peg_offsets = e->peg_off.data(); g->peg_index = e->peg_idx.data(); }
+    return CASIM_OK;
+}
+int32_t casim_enc_domain_rules(const casim_encoder* e, casim_domain_rules* out) {
+    if (!e || !e->finalized || !out) return CASIM_ERR_INVALID;
+    memset(out, 0, sizeof *out);
+    const auto& dr = e->dr;
+    out->n_keys = dr.n_keys; out->n_rules = dr.n_rules; out->n_nodes = (int32_t)e->groups.size(); out->n_classes = (int32_t)e->pegs.size();
+    out->n_elig_rows = dr.n_rows;
+    if (dr.n_rules == 0) return CASIM_OK;
+    out->node_domain = dr.node_domain.data(); out->key_domains = dr.key_domains.data();
+    out->rule_class = dr.r_class.data(); out->rule_key = dr.r_key.data(); out->rule_kind = dr.r_kind.data();
+    out->rule_max_skew = dr.r_skew.data(); out->rule_min_domains = dr.r_mind.data(); out->rule_self = dr.r_self.data();
+    out->rule_elig_row = dr.r_row.data(); out->rule_offset = dr.r_off.data(); out->count_init = dr.count_init.data();
+    out->domain_exists = dr.exists.data(); out->elig_bits = dr.elig.data(); out->class_rule_off = dr.class_off.data();
+    out->inc_off = dr.inc_off.data(); out->inc_rule = dr.inc_rule.data();
     return CASIM_OK;
 }
 int32_t casim_enc_dict_sizes(const casim_encoder* e, int32_t sizes_out[4]) {

@@ -29,7 +29,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "casim_kernels.h"
@@ -63,7 +65,29 @@ struct SchedArgs {
     int32_t* ext_cand;            // [ext_cap] out: candidate whose simulation lists it again
     int32_t* log_ref;             // [P + ext_cap] committed moves in commit order: pod,
     int32_t* log_dest;            //               destination
+    // ---- domain rules (casim_domain_rules): PodTopologySpread, anti-affinity on non-hostname keys ----
+    int32_t n_rules;
+    const int32_t* node_domain;   // [n_keys][N]
+    const int32_t* rule_key; const int32_t* rule_kind; const int32_t* rule_max_skew; const int32_t* rule_min_domains;
+    const int32_t* rule_self; const int32_t* rule_elig_row;
+    const int64_t* rule_off;      // [n_rules + 1]
+    int32_t* rule_cnt;            // working counters (copied from count_init before every pass)
+    const uint8_t* rule_exists;
+    const uint64_t* rule_elig;    // [rows][cap / 64]
+    const int32_t* class_rule_off; const int32_t* inc_off; const int32_t* inc_rule;
+    // SimilarPodsScheduling, exact form (only consulted for classes with spread rules): per run the (controller, class)
+    // pair and the controller, -1 = pod without controller
+    const int32_t* run_pair; const int32_t* run_ctrl;
+    int32_t* pair_memo;           // [n_pairs] 1 = cached as unschedulable (zeroed before every pass)
+    int32_t* ctrl_count;          // [n_ctrl] specs cached for the controller (at most 10, similar_pods.go:52)
 };
+constexpr int kMaxRulesPerClass = 8;
+constexpr int kMaxPodsPerOwnerRef = 10;
+
+CS_GLOBAL void copy_i32_kernel(int32_t* dst, const int32_t* src, int64_t n) {
+    const int64_t i = (int64_t)cs::bid() * cs::nthreads() + cs::tid();
+    if (i < n) dst[i] = src[i];
+}
 
 CS_GLOBAL void fill_i32_kernel(int32_t* p, int64_t n, int32_t v) {
     const int64_t i = (int64_t)cs::bid() * cs::nthreads() + cs::tid();
@@ -280,6 +304,8 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
         const int32_t my_count = !have ? 0 : part == 0 ? a.run_count[kk] : 1;
         const int32_t my_hint = !have ? -1 : part == 0 ? a.run_hint[kk] : -1;   // its hint is the node it sits on: the candidate
         const int32_t my_first = !have ? 0 : part == 0 ? a.run_first[kk] : a.P + kk;
+        const int32_t my_pair = (have && part == 0 && a.run_pair) ? a.run_pair[kk] : -1;
+        const int32_t my_ctrl = (have && part == 0 && a.run_ctrl) ? a.run_ctrl[kk] : -1;
         // the class record of run kk rides along in its lane: one round trip to HBM per 64 runs, not one per run
         int64_t my_req[CASIM_KMAX_RES];
         double my_rq[CASIM_KMAX_RES];
@@ -309,24 +335,80 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
             for (int w = 0; w < Wx; ++w) selfx |= (pv.xblock[w] & pv.xmark[w]) != 0;
             const uint64_t* fb = a.fbits + (int64_t)c * (a.cap >> 6);
             int32_t placed = 0;
+            // domain rules of the class; a class that feeds one of its own counters is walked pod by pod
+            const int r_lo = a.n_rules > 0 ? a.class_rule_off[c] : 0, r_hi = a.n_rules > 0 ? a.class_rule_off[c + 1] : 0;
+            const int i_lo = a.n_rules > 0 ? a.inc_off[c] : 0, i_hi = a.n_rules > 0 ? a.inc_off[c + 1] : 0;
+            bool self_aff = false, monotone = true;   // monotone: a node that rejected the class once rejects it for good
+            for (int r = r_lo; r < r_hi; ++r) { self_aff |= a.rule_self[r] != 0; monotone &= a.rule_kind[r] != 0; }
+            const int32_t pair = (int32_t)cs::bcast_u32((uint32_t)my_pair, j), ctrl = (int32_t)cs::bcast_u32((uint32_t)my_ctrl, j);
+            int32_t minv[kMaxRulesPerClass];
+            for (int ri = 0; ri < kMaxRulesPerClass; ++ri) minv[ri] = 0;
+            // global minimum of every spread rule (minMatchNum, filtering.go:54-68): block-wide over the rule's domains
+            auto refresh_minima = [&]() {
+                for (int r = r_lo; r < r_hi; ++r) {
+                    if (a.rule_kind[r] != 0) continue;
+                    const int64_t lo = a.rule_off[r];
+                    const int32_t D = (int32_t)(a.rule_off[r + 1] - lo);
+                    uint32_t best = 0, nd = 0;   // best = INT32_MAX - min
+                    for (int32_t d = tid; d < D; d += T)
+                        if (a.rule_exists[lo + d]) {
+                            const uint32_t inv = 0x7fffffffu - (uint32_t)cs::load_relaxed_i32(a.rule_cnt + lo + d);
+                            best = inv > best ? inv : best; nd++;
+                        }
+                    const uint32_t bmax = bc.max(best);
+                    const uint64_t ndom = bc.sum(nd);
+                    minv[r - r_lo] = ndom < (uint64_t)a.rule_min_domains[r] ? 0 : (int32_t)(0x7fffffffu - bmax);
+                }
+            };
+            auto rule_ok = [&](int m) -> bool {
+                for (int r = r_lo; r < r_hi; ++r) {
+                    const int32_t d = a.node_domain[(int64_t)a.rule_key[r] * N + m];
+                    if (a.rule_kind[r] == 0) {
+                        if (d < 0) return false;   // ErrReasonNodeLabelNotMatch
+                        const int64_t skew = (int64_t)cs::load_relaxed_i32(a.rule_cnt + a.rule_off[r] + d) + a.rule_self[r] - minv[r - r_lo];
+                        if (skew > a.rule_max_skew[r]) return false;
+                    } else if (d >= 0 && cs::load_relaxed_i32(a.rule_cnt + a.rule_off[r] + d) > 0) return false;
+                }
+                return true;
+            };
+            // NodeInfo.AddPod on node m + what the new pods mean for the rules of every class
+            auto commit_pods = [&](int m, uint32_t x) {
+                st.commit(0, m, x, pv);
+                for (int ii = i_lo; ii < i_hi; ++ii) {
+                    const int r = a.inc_rule[ii];
+                    const int32_t d = a.node_domain[(int64_t)a.rule_key[r] * N + m];
+                    const int row = a.rule_elig_row[r];
+                    const bool el = row < 0 || ((a.rule_elig[(int64_t)row * (a.cap >> 6) + (m >> 6)] >> (m & 63)) & 1ull);
+                    if (d >= 0 && el) cs::atomic_add_i32(a.rule_cnt + a.rule_off[r] + d, (int32_t)x);
+                }
+            };
 
             // ---- tryScheduleUsingHints (:86-110): RunFiltersOnNode on the hinted node, no lastIndex update ----
             if (hint >= 0 && hint < N) {
                 if (((fb[hint >> 6] & accb[hint >> 6]) >> (hint & 63)) & 1ull) {
                     const bool owner = tid == hint % T;
                     uint32_t ch = 0;
-                    if (owner) ch = st.capacity(0, hint, pv, 1u, false);
+                    if (r_hi > r_lo) refresh_minima();
+                    if (owner && rule_ok(hint)) ch = st.capacity(0, hint, pv, 1u, false);
                     if (bc.pick(owner, ch) > 0) {
-                        if (owner) { st.commit(0, hint, 1u, pv); a.node_out[first] = hint; }
+                        if (owner) { commit_pods(hint, 1u); a.node_out[first] = hint; }
                         placed = 1;
+                        if (i_hi > i_lo) cs::sync();   // the counters it fed are read by the next walk
                     }
                 }
             }
 
             // ---- trySchedule (:114-135): memo, then `cnt - placed` consecutive cyclic first-fits in closed form ----
-            const uint32_t keff = (uint32_t)(cnt - placed);
-            const bool memo_hit = c < a.memo_classes && ((memo[c >> 5] >> (c & 31)) & 1u);
-            if (keff > 0 && !memo_hit) {
+            // IsSimilarUnschedulable (:114-118).  Monotone classes: one bit per class is equivalent to the reference's
+            // per-controller cache (a re-try gives the same answer); classes with spread rules: the exact cache.
+            const bool memo_hit = (monotone && c < a.memo_classes && ((memo[c >> 5] >> (c & 31)) & 1u)) ||
+                                  (pair >= 0 && cs::load_relaxed_i32(a.pair_memo + pair) != 0);
+            bool class_failed = memo_hit;
+            while (placed < cnt && !class_failed) {
+            const uint32_t keff = self_aff ? 1u : (uint32_t)(cnt - placed);
+            const int32_t placed_before = placed;
+            if (r_hi > r_lo) refresh_minima();
+            {
                 // The cyclic order starts at m0 = (lastIndex + 1) % N.  Pieces of T nodes in that order: chunk q0 from
                 // m0 on, the following chunks (wrapping), and last the part of chunk q0 below m0.
                 int32_t p0 = (int32_t)(((int64_t)last_index + 1) % n_alive);
@@ -352,14 +434,14 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                     int m; bool valid;
                     piece_node(p, m, valid);
                     uint32_t cj = 0;
-                    if (valid && (((fb[m >> 6] & scanb[m >> 6]) >> lane) & 1ull)) cj = st.capacity(0, m, pv, keff, selfx);
+                    if (valid && (((fb[m >> 6] & scanb[m >> 6]) >> lane) & 1ull) && (r_hi == r_lo || rule_ok(m))) cj = st.capacity(0, m, pv, keff, selfx);
                     const bool fit = cj > 0;
                     const uint64_t b = cs::ballot(fit);
                     uint32_t tot_p, before;
                     bc.count_prefix((uint32_t)cs::popc64(b), tot_p, before);
                     const uint32_t rank = cum + before + (uint32_t)cs::mbcnt(b);
                     const bool gets = fit && rank < keff;
-                    if (gets) { a.node_out[pod_base + (int32_t)rank] = m; st.commit(0, m, 1u, pv); }
+                    if (gets) { a.node_out[pod_base + (int32_t)rank] = m; commit_pods(m, 1u); }
                     if (valid) st.set_c(0, m, gets ? cj - 1u : 0u);
                     if (tot_p > 0) {  // every thread re-evaluates: only the owner in the LAST placing piece stays flagged
                         const uint32_t upto = cum + tot_p < keff ? cum + tot_p : keff;
@@ -435,7 +517,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                                         if (last_mine) last_owner_val = (uint32_t)rank_of(m);
                                     }
                                     const uint32_t x = (cj < Tn ? cj : Tn) + ((partial && gets) ? 1u : 0u);
-                                    if (x > 0) st.commit(0, m, x, pv);
+                                    if (x > 0) commit_pods(m, x);
                                 }
                                 cumr += tot_p;
                             }
@@ -446,10 +528,21 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                     }
                 }
             }
+            if (placed - placed_before < (int32_t)keff) class_failed = true;   // nothing changed since: the next one fails too
+            else if (i_hi > i_lo) cs::sync();                                  // counters fed by this walk are read by the next
+            }  // pods of the run
             scheduled += placed;
             if (placed < cnt) {
-                // SetUnschedulable (:127); breakOnFailure (:79-81)
-                if (c < a.memo_classes && tid == 0) memo[c >> 5] |= 1u << (c & 31);
+                // SetUnschedulable (:127, similar_pods.go:80-97: at most 10 cached specs per controller, and only when the
+                // scan actually ran); breakOnFailure (:79-81)
+                if (tid == 0) {
+                    if (monotone && c < a.memo_classes) memo[c >> 5] |= 1u << (c & 31);
+                    if (pair >= 0 && !memo_hit && cs::load_relaxed_i32(a.pair_memo + pair) == 0 &&
+                        cs::load_relaxed_i32(a.ctrl_count + ctrl) < kMaxPodsPerOwnerRef) {
+                        cs::atomic_add_i32(a.pair_memo + pair, 1);
+                        cs::atomic_add_i32(a.ctrl_count + ctrl, 1);
+                    }
+                }
                 cs::sync();
                 if (break_on_failure) { if (txn) failed = true; else stop = true; }
             }
@@ -537,7 +630,7 @@ public:
         casim_pod_sequence q; memset(&q, 0, sizeof q);
         q.n_pods = K > 0 ? rc->pod_offsets[K] : 0;
         q.pod_class = rc->pod_class; q.hint_node = rc->hint_node; q.node_acceptable = rc->destination;
-        q.break_on_failure = 1; q.last_index = rc->last_index;
+        q.break_on_failure = 1; q.last_index = rc->last_index; q.rules = rc->rules;
         return init(p, g, &q, rc);
     }
 
@@ -560,7 +653,9 @@ public:
         if (N > 0x3fffffc0ull) return fail(CASIM_ERR_INVALID, "too many nodes");
 
         // ---- runs: consecutive pods of one class without a hint; predicates outside the subset -> delegate ----
-        std::vector<int32_t> rc, rn, rh, rf, cro;
+        std::vector<int32_t> rc, rn, rh, rf, cro, rp, rk;      // class, count, hint, first pod, ..., (controller, class) pair, controller
+        std::map<std::pair<int32_t, int32_t>, int32_t> pair_id;  // (similar_key, class) -> dense id
+        std::map<int32_t, int32_t> ctrl_id;
         std::vector<uint8_t> used(C, 0);
         K_ = cand ? cand->n_candidates : 0;
         int next_cand = 0;
@@ -578,8 +673,17 @@ public:
                 for (int w = 0; w < p->w_zone; ++w)
                     if (p->zone_block[(size_t)c * p->w_zone + w] | p->zone_mark[(size_t)c * p->w_zone + w]) return CASIM_NG_UNSUPPORTED;
             }
-            if (!boundary && h < 0 && !rc.empty() && rc.back() == c && rh.back() < 0 && rn.back() < 0x7fffffff) rn.back()++;
-            else { rc.push_back(c); rn.push_back(1); rh.push_back(h); rf.push_back((int32_t)i); }
+            int32_t pr = -1, ck = -1;
+            if (q->similar_key && q->similar_key[i] >= 0) {
+                auto ci = ctrl_id.find(q->similar_key[i]);
+                if (ci == ctrl_id.end()) ci = ctrl_id.emplace(q->similar_key[i], (int32_t)ctrl_id.size()).first;
+                ck = ci->second;
+                auto pi = pair_id.find({ck, c});
+                if (pi == pair_id.end()) pi = pair_id.emplace(std::make_pair(ck, c), (int32_t)pair_id.size()).first;
+                pr = pi->second;
+            }
+            if (!boundary && h < 0 && !rc.empty() && rc.back() == c && rh.back() < 0 && rp.back() == pr && rn.back() < 0x7fffffff) rn.back()++;
+            else { rc.push_back(c); rn.push_back(1); rh.push_back(h); rf.push_back((int32_t)i); rp.push_back(pr); rk.push_back(ck); }
         }
         n_runs_ = (int32_t)rc.size();
         while (cand && (int)cro.size() <= K_) cro.push_back(n_runs_);  // candidates without pods + the end marker
@@ -608,6 +712,11 @@ public:
         a_.memo_classes = C_ < 65536 ? C_ : 65536;
         a_.run_class = up(rc.data(), rc.size()); a_.run_count = up(rn.data(), rn.size());
         a_.run_hint = up(rh.data(), rh.size()); a_.run_first = up(rf.data(), rf.size());
+        if (!pair_id.empty()) {
+            a_.run_pair = up(rp.data(), rp.size()); a_.run_ctrl = up(rk.data(), rk.size());
+            n_pairs_ = pair_id.size(); n_ctrl_ = ctrl_id.size();
+            a_.pair_memo = (int32_t*)dalloc(4 * n_pairs_); a_.ctrl_count = (int32_t*)dalloc(4 * n_ctrl_);
+        }
         a_.acceptable = q->node_acceptable ? up(q->node_acceptable, N) : nullptr;
         d_fbits_ = (uint64_t*)dalloc(8 * C * (size_t)S_);
         a_.fbits = d_fbits_;
@@ -629,6 +738,33 @@ public:
             a_.log_ref = (int32_t*)dalloc(4 * (P + (size_t)E_)); a_.log_dest = (int32_t*)dalloc(4 * (P + (size_t)E_));
             a_.committed = (char*)dalloc((size_t)cap_ * (8u * (size_t)R + 8u * (size_t)dt_.Wx + 4u));
         }
+        // ---- domain rules ----
+        const casim_domain_rules* dr = q->rules;
+        if (dr && dr->n_rules > 0) {
+            if (K_ > 0) return CASIM_NG_UNSUPPORTED;   // removing a node also removes its pods from the counters: host path
+            if (dr->n_nodes != N_ || dr->n_classes != C_) return fail(CASIM_ERR_INVALID, "domain rules were built for other tables");
+            for (int c = 0; c < C_; ++c)
+                if (dr->class_rule_off[c + 1] - dr->class_rule_off[c] > kMaxRulesPerClass) return CASIM_NG_UNSUPPORTED;
+            const size_t NR = (size_t)dr->n_rules, tot = (size_t)dr->rule_offset[NR];
+            a_.n_rules = dr->n_rules;
+            a_.node_domain = up(dr->node_domain, (size_t)dr->n_keys * N);
+            a_.rule_key = up(dr->rule_key, NR); a_.rule_kind = up(dr->rule_kind, NR); a_.rule_max_skew = up(dr->rule_max_skew, NR);
+            a_.rule_min_domains = up(dr->rule_min_domains, NR); a_.rule_self = up(dr->rule_self, NR); a_.rule_elig_row = up(dr->rule_elig_row, NR);
+            a_.rule_off = up(dr->rule_offset, NR + 1);
+            d_rule_init_ = up(dr->count_init, tot); rule_total_ = (int64_t)tot;
+            a_.rule_cnt = (int32_t*)dalloc(4 * tot);
+            a_.rule_exists = up(dr->domain_exists, tot);
+            // eligibility rows are addressed by 64-node words of the padded node range
+            if (dr->n_elig_rows > 0) {
+                const size_t w_in = (N + 63) / 64;
+                std::vector<uint64_t> rows((size_t)dr->n_elig_rows * (size_t)S_, 0ull);
+                for (int r = 0; r < dr->n_elig_rows; ++r) for (size_t w = 0; w < w_in; ++w) rows[(size_t)r * (size_t)S_ + w] = dr->elig_bits[(size_t)r * w_in + w];
+                a_.rule_elig = up(rows.data(), rows.size());
+                bk_.sync();
+            }
+            a_.class_rule_off = up(dr->class_rule_off, C + 1); a_.inc_off = up(dr->inc_off, C + 1);
+            a_.inc_rule = up(dr->inc_rule, (size_t)dr->inc_off[C]);
+        }
         const int alive_words = K_ > 0 ? S_ : 0;
         const int64_t ctrl = casim_sched_ctrl_bytes(a_.memo_classes, alive_words), bytes = casim_sched_state_bytes(R, dt_.Wx, cap_);
         lds_ = ctrl + bytes <= (int64_t)bk_.lds_budget();
@@ -645,6 +781,8 @@ public:
         if (!ready_) return fail(CASIM_ERR_INVALID, "scheduler not initialised");
         if (P_ + E_ > 0) bk_.launch(fill_i32_kernel, (P_ + E_ + 255) / 256, 1, 256, (size_t)0, a_.node_out, (int64_t)(P_ + E_), (int32_t)-1);
         if (K_ > 0) { bk_.fill8(a_.removable_out, 2, (size_t)K_); bk_.zero(a_.arrived, (size_t)cap_); }
+        if (n_pairs_ > 0) { bk_.zero(a_.pair_memo, 4 * n_pairs_); bk_.zero(a_.ctrl_count, 4 * n_ctrl_); }
+        if (rule_total_ > 0) bk_.launch(copy_i32_kernel, (int)((rule_total_ + 255) / 256), 1, 256, (size_t)0, a_.rule_cnt, d_rule_init_, rule_total_);
         if (C_ > 0) bk_.launch(sched_static_kernel, S_, C_, 64, (size_t)0, dt_, d_fbits_, S_);
         if (lds_) bk_.launch(sched_kernel<true>, 1, 1, threads_, smem_, dt_, a_);
         else bk_.launch(sched_kernel<false>, 1, 1, threads_, smem_, dt_, a_);
@@ -729,6 +867,9 @@ private:
     bool ready_ = false, trivial_ = false, lds_ = true;
     size_t smem_ = 0;
     uint64_t* d_fbits_ = nullptr;
+    const int32_t* d_rule_init_ = nullptr;
+    int64_t rule_total_ = 0;
+    size_t n_pairs_ = 0, n_ctrl_ = 0;
     std::vector<void*> allocs_;
     std::string err_;
 };

@@ -88,7 +88,13 @@ class Encoder:
                 check(lib.casim_enc_term_add_requirement(h, s, t, _b(r.key), _b(r.operator), _strs(r.values), len(r.values)))
         cpu, mem = pod.fastpath_requests()
         check(lib.casim_enc_pod_set_fastpath_requests(h, s, cpu, mem))
-        if pod.topology_spread:
+        for sc in pod.spread_constraints:   # evaluated on the device in per-node mode, flagged UNSUPPORTED by finalize otherwise
+            ci = lib.casim_enc_pod_add_spread_constraint(h, s, int(sc.max_skew), _b(sc.topology_key), int(sc.min_domains))
+            if ci < 0:
+                check(ci, "casim_enc_pod_add_spread_constraint")
+            for k, v in sc.match_labels.items():
+                check(lib.casim_enc_spread_add_requirement(h, s, ci, _b(k), b"In", _strs([v]), 1))
+        if pod.topology_spread and not pod.spread_constraints:
             check(lib.casim_enc_pod_mark_unsupported(h, s, b"topologySpreadConstraints"))
         if pod.unsupported_reason:
             check(lib.casim_enc_pod_mark_unsupported(h, s, _b(pod.unsupported_reason)))
@@ -160,6 +166,8 @@ class Encoder:
         self.pegs = _abi.Pegs()
         self.groups = _abi.Groups()
         check(lib.casim_enc_tables(self._h, C.byref(self.pegs), C.byref(self.groups)))
+        self.rules = _abi.DomainRules()
+        check(lib.casim_enc_domain_rules(self._h, C.byref(self.rules)))
         return self.pegs, self.groups
 
     def dict_sizes(self):

@@ -57,7 +57,8 @@ def finish_results(arrs, n_groups: int, nnz: int, offsets: np.ndarray) -> BatchR
     return BatchResult(offsets=offsets, **out)
 
 
-def make_pod_sequence(pod_class, hint_node=None, node_acceptable=None, break_on_failure: bool = False, last_index: int = 0):
+def make_pod_sequence(pod_class, hint_node=None, node_acceptable=None, break_on_failure: bool = False, last_index: int = 0,
+                      rules=None, similar_key=None):
     """casim_pod_sequence over numpy arrays; returns (struct, arrays to keep alive)."""
     pc = np.ascontiguousarray(pod_class, np.int32)
     hn = None if hint_node is None else np.ascontiguousarray(hint_node, np.int32)
@@ -67,8 +68,14 @@ def make_pod_sequence(pod_class, hint_node=None, node_acceptable=None, break_on_
     seq = _abi.PodSequence(n_pods=int(pc.shape[0]), pod_class=_ptr(pc, C.c_int32) if pc.size else None,
                            hint_node=_ptr(hn, C.c_int32) if hn is not None and hn.size else None,
                            node_acceptable=_ptr(na, C.c_uint8) if na is not None and na.size else None,
-                           break_on_failure=int(bool(break_on_failure)), last_index=int(last_index))
-    return seq, (pc, hn, na)
+                           break_on_failure=int(bool(break_on_failure)), last_index=int(last_index),
+                           rules=C.pointer(rules) if rules is not None and rules.n_rules > 0 else None)
+    sk = None if similar_key is None else np.ascontiguousarray(similar_key, np.int32)
+    if sk is not None and sk.size:
+        if sk.shape != pc.shape:
+            raise ValueError("similar_key must have one entry per pod")
+        seq.similar_key = _ptr(sk, C.c_int32)
+    return seq, (pc, hn, na, rules, sk)
 
 
 @dataclass
@@ -84,7 +91,7 @@ class RemovalResult:
 
 
 def make_removal_candidates(cand_node, pod_offsets, pod_class, hint_node=None, destination=None, persist=True, max_removable=0,
-                            last_index=0, pod_sticky=None, ext_capacity=None):
+                            last_index=0, pod_sticky=None, ext_capacity=None, rules=None):
     """casim_removal_candidates over numpy arrays; returns (struct, arrays to keep alive)."""
     cn = np.ascontiguousarray(cand_node, np.int32)
     po = np.ascontiguousarray(pod_offsets, np.int32)
@@ -103,8 +110,9 @@ def make_removal_candidates(cand_node, pod_offsets, pod_class, hint_node=None, d
                                 destination=_ptr(ds, C.c_uint8) if ds is not None and ds.size else None,
                                 pod_sticky=_ptr(sk, C.c_uint8) if sk is not None and sk.size else None,
                                 persist=int(bool(persist)), max_removable=int(max_removable), last_index=int(last_index),
-                                ext_capacity=int(ext_capacity))
-    return st, (cn, po, pc, hn, ds, sk)
+                                ext_capacity=int(ext_capacity),
+                                rules=C.pointer(rules) if rules is not None and rules.n_rules > 0 else None)
+    return st, (cn, po, pc, hn, ds, sk, rules)
 
 
 def alloc_removal_results(st: "_abi.RemovalCandidates"):
@@ -169,11 +177,11 @@ class Context:
 
 
     def try_schedule_pods(self, classes: _abi.Pegs, nodes: _abi.Groups, pod_class, hint_node=None, node_acceptable=None,
-                          break_on_failure: bool = False, last_index: int = 0, time_iters: int = 0):
+                          break_on_failure: bool = False, last_index: int = 0, time_iters: int = 0, rules=None, similar_key=None):
         """HintingSimulator.TrySchedulePods on the device (casim_try_schedule_pods).
         Returns (status, node_out[P], last_index, n_scheduled); status NG_UNSUPPORTED => delegate to the Go path.
         With time_iters > 0 returns the HIP-event time in ms of one resident pass instead."""
-        seq, keep = make_pod_sequence(pod_class, hint_node, node_acceptable, break_on_failure, last_index)
+        seq, keep = make_pod_sequence(pod_class, hint_node, node_acceptable, break_on_failure, last_index, rules, similar_key)
         if time_iters > 0:
             ms = C.c_float(0)
             rc = lib.casim_time_try_schedule_pods(self._h, C.byref(classes), C.byref(nodes), C.byref(seq), int(time_iters), C.byref(ms))
@@ -192,11 +200,11 @@ class Context:
 
     def simulate_node_removals(self, classes: _abi.Pegs, nodes: _abi.Groups, cand_node, pod_offsets, pod_class, hint_node=None,
                                destination=None, persist: bool = True, max_removable: int = 0, last_index: int = 0,
-                               pod_sticky=None, ext_capacity: Optional[int] = None, time_iters: int = 0):
+                               pod_sticky=None, ext_capacity: Optional[int] = None, time_iters: int = 0, rules=None):
         """Planner.categorizeNodes loop around SimulateNodeRemoval on the device (casim_simulate_node_removals).
         Returns a RemovalResult; with time_iters > 0 (status, HIP-event ms of one resident pass) instead."""
         st, keep = make_removal_candidates(cand_node, pod_offsets, pod_class, hint_node, destination, persist, max_removable, last_index,
-                                           pod_sticky, ext_capacity)
+                                           pod_sticky, ext_capacity, rules)
         if time_iters > 0:
             ms = C.c_float(0)
             rc = lib.casim_time_node_removals(self._h, C.byref(classes), C.byref(nodes), C.byref(st), int(time_iters), C.byref(ms))

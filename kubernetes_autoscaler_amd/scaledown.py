@@ -98,7 +98,8 @@ class RemovalSimulator:
         self.device_calls += 1
         res = self.ctx.simulate_node_removals(enc.pegs, enc.groups, [pos[n] for n in names], off, pod_class, hint, dest,
                                               persist=self.can_persist, max_removable=max_removable, last_index=self.last_index,
-                                              pod_sticky=sticky if any(sticky) else None, ext_capacity=self.ext_capacity)
+                                              pod_sticky=sticky if any(sticky) else None, ext_capacity=self.ext_capacity,
+                                              rules=enc.rules)
         enc.close()
         if res.status == _abi.NG_UNSUPPORTED:
             raise UnsupportedPredicate("pods to move need a predicate outside the encoded subset")

@@ -55,8 +55,8 @@ class Status:
 
 
 class UnsupportedPredicate(Exception):
-    """A pending pod needs a Filter outside the encoded subset (or a non-hostname anti-affinity): the shim
-    runs the reference HintingSimulator for this loop iteration."""
+    """A pending pod needs a Filter outside the encoded subset (required pod affinity, volumes, ...): the shim runs the
+    reference HintingSimulator for this loop iteration."""
 
 
 def encode_pending_pods(nodes: Sequence[NodeInfo], pods: Sequence[Pod], lanes=None):
@@ -101,12 +101,14 @@ class HintingSimulator:
             h = self.hints.get(hint_key_from_pod(p))
             if h is not None:
                 hint[i] = name_to_index.get(h, -1)  # hinted node left the cluster: look elsewhere (:94-97)
+        ctrl: Dict[str, int] = {}
+        similar = [(-1 if not p.controller_uid or p.daemonset else ctrl.setdefault(p.controller_uid, len(ctrl))) for p in pods]
         acceptable = None
         if is_node_acceptable is not None:
             acceptable = np.array([1 if is_node_acceptable(info) else 0 for info in nodes], np.uint8)
         status, node_out, last_index, _ = self.ctx.try_schedule_pods(
             enc.pegs, enc.groups, pod_class, hint_node=hint, node_acceptable=acceptable, break_on_failure=break_on_failure,
-            last_index=self.last_index)
+            last_index=self.last_index, rules=enc.rules, similar_key=similar)
         enc.close()
         if status == _abi.NG_UNSUPPORTED:
             raise UnsupportedPredicate("pending pods need a predicate outside the encoded subset")

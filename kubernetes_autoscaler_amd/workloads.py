@@ -487,3 +487,63 @@ def removal_scale(n_nodes: int, pods_per_node: int = 12, frac_candidates: float 
     util = sorted(range(n_nodes), key=lambda i: (sum(p.requests["cpu"] for p in nodes[i].pods), i))
     cands = util[:max(1, int(n_nodes * frac_candidates))]
     return RemovalWorkload(f"removal_{n_nodes}n", nodes, cands)
+
+
+def fuzz_pending_domains(seed: int, max_nodes: int = 40, max_pods: int = 90) -> PendingWorkload:
+    """Like fuzz_pending, with the Filters that look at a node's topology DOMAIN: PodTopologySpread constraints
+    (hostname / zone / rack keys, maxSkew 1-3, minDomains, selectors that do or do not match the pod itself, node
+    selectors that make only part of the cluster eligible) and required anti-affinity on non-hostname keys, in pending
+    AND running pods; some nodes lack a topology label."""
+    from .objects import TopologySpreadConstraint
+    rng = SplitMix64(0xD0A1A000 + seed)
+    n_nodes = 2 + rng.below(max_nodes) if not rng.chance(1, 8) else 70 + rng.below(200)
+    apps = [f"app{i}" for i in range(4)]
+    keys = [LABEL_HOSTNAME, LABEL_ZONE, "rack"]
+    n_zones, n_racks = 1 + rng.below(4), 1 + rng.below(6)
+    nodes = []
+    for i in range(n_nodes):
+        labels = {"pool": f"p{rng.below(2)}"}
+        if not rng.chance(1, 10):
+            labels[LABEL_ZONE] = f"z{rng.below(n_zones)}"
+        if not rng.chance(1, 6):
+            labels["rack"] = f"r{rng.below(n_racks)}"
+        node = _node(f"fd{seed}-n{i}", rng.pick([1000, 2000, 4000]), rng.pick([2, 8]) * GiB, rng.pick([3, 8, 110]), labels)
+        if rng.chance(1, 12):
+            node.unschedulable = True
+        info = NodeInfo(node)
+        for j in range(rng.below(3)):
+            p = Pod(name=f"run{i}-{j}", labels={"app": rng.pick(apps)}, requests={"cpu": rng.pick([0, 100, 300]), "memory": rng.pick([0, 256 * MiB])})
+            if rng.chance(1, 6):
+                p.anti_affinity = [PodAffinityTerm(rng.pick(keys[1:]), match_labels={"app": rng.pick(apps)})]
+            info.pods.append(p)
+        nodes.append(info)
+    n_specs = 1 + rng.below(5)
+    specs = []
+    for c in range(n_specs):
+        kw = dict(labels={"app": rng.pick(apps)}, requests={"cpu": rng.pick([0, 50, 100, 250, 500]), "memory": rng.pick([0, 64 * MiB, 256 * MiB])})
+        if rng.chance(1, 4):
+            kw["node_selector"] = {"pool": f"p{rng.below(2)}"}
+        if rng.chance(1, 2):
+            n_c = 1 + rng.below(2)
+            kw["spread_constraints"] = [TopologySpreadConstraint(max_skew=1 + rng.below(3), topology_key=rng.pick(keys), min_domains=rng.pick([0, 0, 1, 2, 4]),
+                                                                 match_labels=({"app": kw["labels"]["app"]} if rng.chance(2, 3) else ({"app": rng.pick(apps)} if rng.chance(3, 4) else {})))
+                                        for _ in range(n_c)]
+        if rng.chance(1, 4):
+            kw["anti_affinity"] = [PodAffinityTerm(rng.pick(keys), match_labels={"app": rng.pick(apps)})]
+        if rng.chance(1, 3):
+            kw["controller_uid"] = f"ctrl-{c}"
+        specs.append(kw)
+    n_pods = 1 + rng.below(max_pods)
+    pods, hints = [], []
+    while len(pods) < n_pods:
+        c = rng.below(n_specs)
+        for _ in range(min(rng.pick([1, 1, 2, 5, 20]), n_pods - len(pods))):
+            kw = specs[c]
+            pods.append(Pod(name=f"pend{len(pods)}", labels=dict(kw["labels"]), requests=dict(kw["requests"]),
+                            node_selector=dict(kw.get("node_selector", {})), anti_affinity=list(kw.get("anti_affinity", [])),
+                            spread_constraints=list(kw.get("spread_constraints", [])), topology_spread=bool(kw.get("spread_constraints")),
+                            controller_uid=kw.get("controller_uid", "")))
+            hints.append(rng.below(n_nodes) if rng.chance(1, 6) else -1)
+    acceptable = [0 if rng.chance(1, 6) else 1 for _ in range(n_nodes)] if rng.chance(1, 4) else None
+    return PendingWorkload(f"fuzz_pending_domains{seed}", nodes, pods, hints if rng.chance(1, 2) else None, acceptable,
+                           break_on_failure=rng.chance(1, 6), last_index=rng.below(n_nodes + 2))

@@ -168,13 +168,18 @@ class SchedCase:
     lanes: Sequence[str] = ("cpu", "memory")
 
 
+def similar_keys(pods):
+    """dense controller ids for SimilarPodsScheduling: -1 = no controller or a DaemonSet pod"""
+    keys = {}
+    return [(-1 if not p.controller_uid or p.daemonset else keys.setdefault(p.controller_uid, len(keys))) for p in pods]
+
+
 def sched_oracle(case: SchedCase):
     """(node_out, last_index, n_scheduled) from the object-level oracle; SimilarPods keyed by controller_uid."""
     s = OracleScenario(lanes=case.lanes)
     for info in case.nodes:
         s.add_existing(info)
-    keys = {}
-    sk = [(-1 if not p.controller_uid or p.daemonset else keys.setdefault(p.controller_uid, len(keys))) for p in case.pods]
+    sk = similar_keys(case.pods)
     out = s.try_schedule_pods(case.pods, case.hints, sk, case.acceptable, case.break_on_failure, case.last_index)
     s.close()
     return out
@@ -195,7 +200,8 @@ def sched_emu(case: SchedCase, lds_budget=0):
                                             _abi.i32p, _abi.i32p, _abi.i32p, _abi.i32p]
         L._sched_ready = True
     enc, pod_class = sched_encode(case)
-    seq, keep = make_pod_sequence(pod_class, case.hints, case.acceptable, case.break_on_failure, case.last_index)
+    seq, keep = make_pod_sequence(pod_class, case.hints, case.acceptable, case.break_on_failure, case.last_index, enc.rules,
+                                  similar_keys(case.pods))
     node_out = np.full(max(len(case.pods), 1), -1, np.int32)
     li, ns = C.c_int32(0), C.c_int32(0)
     info = (C.c_int32 * 2)(0, 0)
@@ -210,7 +216,8 @@ def sched_emu(case: SchedCase, lds_budget=0):
 def sched_gpu(case: SchedCase, ctx):
     enc, pod_class = sched_encode(case)
     rc, node_out, li, ns = ctx.try_schedule_pods(enc.pegs, enc.groups, pod_class, case.hints, case.acceptable,
-                                                 case.break_on_failure, case.last_index)
+                                                 case.break_on_failure, case.last_index, rules=enc.rules,
+                                                 similar_key=similar_keys(case.pods))
     enc.close()
     return rc, node_out.copy(), li, ns
 
@@ -287,7 +294,7 @@ class EmuContext:
         self.lds_budget = lds_budget
 
     def simulate_node_removals(self, classes, nodes, cand_node, pod_offsets, pod_class, hint_node=None, destination=None,
-                               persist=True, max_removable=0, last_index=0, pod_sticky=None, ext_capacity=None):
+                               persist=True, max_removable=0, last_index=0, pod_sticky=None, ext_capacity=None, rules=None):
         from kubernetes_autoscaler_amd.engine import alloc_removal_results, finish_removal_results, make_removal_candidates
         L = emu_lib()
         if not hasattr(L, "_removal_ready"):
@@ -296,7 +303,7 @@ class EmuContext:
                                                      C.c_int64, C.POINTER(_abi.RemovalResults)]
             L._removal_ready = True
         st, keep = make_removal_candidates(cand_node, pod_offsets, pod_class, hint_node, destination, persist, max_removable, last_index,
-                                           pod_sticky, ext_capacity)
+                                           pod_sticky, ext_capacity, rules)
         res, packed = alloc_removal_results(st)
         rc = L.emu_simulate_node_removals(C.byref(classes), C.byref(nodes), C.byref(st), int(self.lds_budget), C.byref(res))
         assert rc >= 0, (rc, L.emu_last_error())
@@ -309,7 +316,7 @@ def removal_device(case: RemovalCase, ctx):
     enc, pod_class, off = removal_encode(case)
     out = ctx.simulate_node_removals(enc.pegs, enc.groups, case.candidates, off, pod_class, case.flat_hints(), case.destination,
                                      persist=case.persist, max_removable=case.max_removable, last_index=case.last_index,
-                                     pod_sticky=case.flat_sticky(), ext_capacity=case.ext_capacity)
+                                     pod_sticky=case.flat_sticky(), ext_capacity=case.ext_capacity, rules=enc.rules)
     enc.close()
     return out
 

@@ -43,6 +43,15 @@ def test_fuzz(ctx):
         assert_sched_matches(sched_gpu(sc, ctx), sched_oracle(sc), w.name)
 
 
+def test_fuzz_domain_rules(ctx):
+    """PodTopologySpread + anti-affinity on non-hostname keys (domain rules) on the MI355X."""
+    from kubernetes_autoscaler_amd.workloads import fuzz_pending_domains
+    for seed in range(300):
+        w = fuzz_pending_domains(seed)
+        sc = case_of(w)
+        assert_sched_matches(sched_gpu(sc, ctx), sched_oracle(sc), w.name)
+
+
 @pytest.mark.parametrize("shape", [(1, 30, 1000), (10, 300, 1000), (100, 3000, 1000), (200, 200, 60000), (1000, 1000, 12000)],
                          ids=lambda s: f"{s[0]}n_{s[1]}s_{s[2]}p")
 def test_benchmark_filter_out_schedulable_shapes(ctx, shape):

@@ -131,3 +131,14 @@ def test_mirror_equals_the_reference_loop(seed, mode):
     ks = [k for k in range(len(w.candidates)) if rem[k] == 1]
     for r, k in zip(removable, ks):
         assert [p.name for p in r.pods_to_reschedule] == [p.name for p in lists[k]] + again.get(k, [])
+
+
+def test_domain_rules_delegate_the_removal_loop():
+    """Pods with spread constraints / zone anti-affinity among the pods to move: removing a node would also take its
+    pods out of the domain counters, which the device does not model -> the whole loop goes back to the host."""
+    from kubernetes_autoscaler_amd import _abi
+    from kubernetes_autoscaler_amd.objects import LABEL_ZONE, PodAffinityTerm
+    nodes = [NodeInfo(_node(f"n{i}", 1000, 10**9, 10, {LABEL_ZONE: f"z{i % 2}"})) for i in range(4)]
+    nodes[0].pods.append(Pod(name="z", labels={"app": "z"}, requests={"cpu": 100}, anti_affinity=[PodAffinityTerm(LABEL_ZONE, match_labels={"app": "z"})]))
+    got = removal_device(RemovalCase(nodes=nodes, candidates=[0]), EmuContext())
+    assert got.status == _abi.NG_UNSUPPORTED

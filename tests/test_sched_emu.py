@@ -89,10 +89,7 @@ def test_self_exclusion_across_runs():
 
 def test_unsupported_predicates_are_delegated():
     nodes = [NodeInfo(build_test_node("n0", 4000, 10**9))]
-    nodes[0].node.labels[LABEL_ZONE] = "z"
-    zone = Pod(name="z", labels={"app": "z"}, requests={"cpu": 1}, anti_affinity=[PodAffinityTerm(LABEL_ZONE, match_labels={"app": "z"})])
-    assert sched_emu(SchedCase(nodes=nodes, pods=[zone]))[0] == _abi.NG_UNSUPPORTED
-    spread = Pod(name="s", requests={"cpu": 1}, topology_spread=True)
+    spread = Pod(name="s", requests={"cpu": 1}, topology_spread=True)   # a constraint the shim could not describe
     assert sched_emu(SchedCase(nodes=nodes, pods=[build_test_pod("ok", 1, 1), spread]))[0] == _abi.NG_UNSUPPORTED
     # hostname anti-affinity against a node without the hostname label cannot be expressed by node bits
     named = NodeInfo(_node("named", 4000, 10**9, 100))
@@ -101,6 +98,48 @@ def test_unsupported_predicates_are_delegated():
     h.labels = {"app": "h"}
     assert sched_emu(SchedCase(nodes=[named, bare], pods=[h]))[0] == _abi.NG_UNSUPPORTED
     assert sched_emu(SchedCase(nodes=[named], pods=[h]))[0] == 0
+
+
+# ---- domain rules: PodTopologySpread and anti-affinity on non-hostname keys ---------------------------------------
+def _zoned(n, zones, cpu=4000):
+    return [NodeInfo(_node(f"n{i}", cpu, 10**9, 110, {LABEL_ZONE: f"z{i % zones}"})) for i in range(n)]
+
+
+def test_zone_anti_affinity_one_pod_per_zone():
+    nodes = _zoned(6, 3)
+    pods = [Pod(name=f"z{i}", labels={"app": "z"}, requests={"cpu": 1}, anti_affinity=[PodAffinityTerm(LABEL_ZONE, match_labels={"app": "z"})])
+            for i in range(5)]
+    node_out, li, ns = check(SchedCase(nodes=nodes, pods=pods))
+    assert ns == 3 and list(node_out) == [1, 2, 3, -1, -1]   # lastIndex 0: the walk starts at n1; one pod per zone
+
+
+def test_hostname_spread_fills_evenly():
+    from kubernetes_autoscaler_amd.objects import TopologySpreadConstraint
+    nodes = _zoned(4, 2)
+    pods = [Pod(name=f"s{i}", labels={"app": "s"}, requests={"cpu": 1}, topology_spread=True,
+                spread_constraints=[TopologySpreadConstraint(1, "kubernetes.io/hostname", 0, {"app": "s"})]) for i in range(9)]
+    node_out, li, ns = check(SchedCase(nodes=nodes, pods=pods))
+    assert ns == 9 and sorted(np.bincount(node_out, minlength=4)) == [2, 2, 2, 3]
+
+
+def test_zone_spread_with_min_domains_and_partial_eligibility():
+    from kubernetes_autoscaler_amd.objects import TopologySpreadConstraint
+    nodes = _zoned(6, 2)
+    for i, info in enumerate(nodes):
+        info.node.labels["pool"] = "a" if i < 4 else "b"
+    nodes[0].pods.append(Pod(name="r0", labels={"app": "s"}, requests={"cpu": 1}))
+    # minDomains 3 > 2 zones: the global minimum counts as 0, so every zone takes at most maxSkew pods
+    pods = [Pod(name=f"s{i}", labels={"app": "s"}, requests={"cpu": 1}, node_selector={"pool": "a"}, topology_spread=True,
+                spread_constraints=[TopologySpreadConstraint(2, LABEL_ZONE, 3, {"app": "s"})]) for i in range(8)]
+    node_out, li, ns = check(SchedCase(nodes=nodes, pods=pods))
+    assert ns == 3   # z0 already holds one matching pod on an eligible node: 1 more there, 2 in z1
+
+
+@pytest.mark.parametrize("seed", range(400))
+def test_fuzz_domain_rules(seed):
+    from kubernetes_autoscaler_amd.workloads import fuzz_pending_domains
+    w = fuzz_pending_domains(seed)
+    check(case_of(w), w.name)
 
 
 def test_empty_inputs():
