@@ -303,6 +303,9 @@ typedef struct casim_domain_rules {
     const int64_t* rule_offset;      /* [n_rules + 1] slice of count_init / domain_exists                      */
     const int32_t* count_init;       /* counters from the pods already running                                 */
     const uint8_t* domain_exists;    /* kind 0: an eligible node carries this domain (it counts for the minimum) */
+    const int32_t* domain_nodes;     /* same slices: how many eligible nodes carry the domain (a removed node leaves it) */
+    const int32_t* node_contrib;     /* [n_rules][n_nodes] what the pods running on the node add to the rule's counter
+                                        of the node's domain (the removal simulation takes them out with the node) */
     const uint64_t* elig_bits;       /* [n_elig_rows][ceil(n_nodes / 64)]                                      */
     const int32_t* class_rule_off;   /* [n_classes + 1] rules of class c: [class_rule_off[c], class_rule_off[c+1]) */
     const int32_t* inc_off;          /* [n_classes + 1]                                                        */
@@ -363,8 +366,7 @@ typedef struct casim_removal_candidates {
     int32_t max_removable;           /* stop after this many removable nodes (unneededNodesLimit); 0 = no limit */
     int32_t last_index;
     int32_t ext_capacity;            /* entries of the ext_* result arrays; 0 = stop at the first candidate with arrivals */
-    const struct casim_domain_rules* rules; /* the encoder's domain rules; if any exist the call returns CASIM_NG_UNSUPPORTED
-                                        (removing a node also takes its pods out of the counters: host path) */
+    const struct casim_domain_rules* rules; /* the encoder's domain rules (PodTopologySpread, zone anti-affinity); NULL = none */
 } casim_removal_candidates;
 
 typedef struct casim_removal_results {

@@ -70,7 +70,7 @@ class DomainRules(C.Structure):
     _fields_ = [("n_keys", C.c_int32), ("n_rules", C.c_int32), ("n_nodes", C.c_int32), ("n_classes", C.c_int32), ("n_elig_rows", C.c_int32),
                 ("node_domain", i32p), ("key_domains", i32p), ("rule_class", i32p), ("rule_key", i32p), ("rule_kind", i32p),
                 ("rule_max_skew", i32p), ("rule_min_domains", i32p), ("rule_self", i32p), ("rule_elig_row", i32p), ("rule_offset", i64p),
-                ("count_init", i32p), ("domain_exists", u8p), ("elig_bits", u64p), ("class_rule_off", i32p), ("inc_off", i32p),
+                ("count_init", i32p), ("domain_exists", u8p), ("domain_nodes", i32p), ("node_contrib", i32p), ("elig_bits", u64p), ("class_rule_off", i32p), ("inc_off", i32p),
                 ("inc_rule", i32p)]
 
 

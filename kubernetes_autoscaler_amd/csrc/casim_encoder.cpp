@@ -186,6 +186,7 @@ struct casim_encoder {
     struct {
         int32_t n_keys = 0, n_rules = 0, n_rows = 0;
         std::vector<int32_t> node_domain, key_domains, r_class, r_key, r_kind, r_skew, r_mind, r_self, r_row, count_init, class_off, inc_off, inc_rule;
+        std::vector<int32_t> dom_nodes, node_contrib;
         std::vector<int64_t> r_off;
         std::vector<uint8_t> exists;
         std::vector<uint64_t> elig;
@@ -625,6 +626,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
             dr.r_off.assign(rules.size() + 1, 0);
             for (size_t r = 0; r < rules.size(); ++r) dr.r_off[r + 1] = dr.r_off[r] + dr.key_domains[(size_t)rules[r].key];
             dr.count_init.assign((size_t)dr.r_off.back(), 0); dr.exists.assign((size_t)dr.r_off.back(), 0);
+            dr.dom_nodes.assign((size_t)dr.r_off.back(), 0); dr.node_contrib.assign(rules.size() * NG, 0);
             dr.class_off.assign(G + 1, 0); dr.inc_off.assign(G + 1, 0);
             for (size_t r = 0; r < rules.size(); ++r) {
                 const Rule& R0 = rules[r];
@@ -637,11 +639,12 @@ int32_t casim_enc_finalize(casim_encoder* e) {
                     if (d < 0) continue;
                     if (R0.kind == 0 && !((rows[(size_t)R0.row][n >> 6] >> (n & 63)) & 1ull)) continue;
                     const size_t at = (size_t)dr.r_off[r] + (size_t)d;
-                    dr.exists[at] = 1;
+                    dr.exists[at] = 1; dr.dom_nodes[at]++;
                     for (int32_t s2 : e->groups[n].preloaded) {
                         const PodSpec& q = e->specs[(size_t)s2];
-                        if (R0.kind == 0) { if (!R0.sc->selector.empty() && q.ns == p.ns && selector_matches(R0.sc->selector, q.labels)) dr.count_init[at]++; }
-                        else if (zone_conflict(p, q, keys[(size_t)R0.key])) dr.count_init[at]++;
+                        const bool feeds = R0.kind == 0 ? (!R0.sc->selector.empty() && q.ns == p.ns && selector_matches(R0.sc->selector, q.labels))
+                                                        : zone_conflict(p, q, keys[(size_t)R0.key]);
+                        if (feeds) { dr.count_init[at]++; dr.node_contrib[r * NG + n]++; }
                     }
                 }
             }
@@ -789,7 +792,8 @@ int32_t casim_enc_domain_rules(const casim_encoder* e, casim_domain_rules* out) 
     out->rule_class = dr.r_class.data(); out->rule_key = dr.r_key.data(); out->rule_kind = dr.r_kind.data();
     out->rule_max_skew = dr.r_skew.data(); out->rule_min_domains = dr.r_mind.data(); out->rule_self = dr.r_self.data();
     out->rule_elig_row = dr.r_row.data(); out->rule_offset = dr.r_off.data(); out->count_init = dr.count_init.data();
-    out->domain_exists = dr.exists.data(); out->elig_bits = dr.elig.data(); out->class_rule_off = dr.class_off.data();
+    out->domain_exists = dr.exists.data(); out->domain_nodes = dr.dom_nodes.data(); out->node_contrib = dr.node_contrib.data();
+    out->elig_bits = dr.elig.data(); out->class_rule_off = dr.class_off.data();
     out->inc_off = dr.inc_off.data(); out->inc_rule = dr.inc_rule.data();
     return CASIM_OK;
 }

@@ -72,7 +72,8 @@ struct SchedArgs {
     const int32_t* rule_self; const int32_t* rule_elig_row;
     const int64_t* rule_off;      // [n_rules + 1]
     int32_t* rule_cnt;            // working counters (copied from count_init before every pass)
-    const uint8_t* rule_exists;
+    int32_t* rule_dom_nodes;      // working copy: eligible nodes still carrying each domain (> 0 <=> the domain exists)
+    int32_t* rule_contrib;        // working copy [n_rules][N]: what the pods on a node add to each rule (transactions only)
     const uint64_t* rule_elig;    // [rows][cap / 64]
     const int32_t* class_rule_off; const int32_t* inc_off; const int32_t* inc_rule;
     // SimilarPodsScheduling, exact form (only consulted for classes with spread rules): per run the (controller, class)
@@ -292,6 +293,11 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
         // Fork; the candidate turns into a pod-less tainted ghost that keeps its list position (:243-265).
         // (every path into this point ends with a barrier: nobody still reads the words rewritten here)
         if (tid == 0) { accb[Y >> 6] &= ~(1ull << (Y & 63)); scanb[Y >> 6] &= ~(1ull << (Y & 63)); }
+        // ... pod-less: whatever its pods added to the domain counters goes with them (the ghost itself stays a domain)
+        for (int r = tid; r < a.n_rules; r += T) {
+            const int32_t d = a.node_domain[(int64_t)a.rule_key[r] * N + Y], v = cs::load_relaxed_i32(a.rule_contrib + (int64_t)r * N + Y);
+            if (d >= 0 && v != 0) cs::atomic_add_i32(a.rule_cnt + a.rule_off[r] + d, -v);
+        }
         cs::sync();
     }
     for (int part = 0; part < 2; ++part) {   // the caller's runs, then one run per ext pod
@@ -351,7 +357,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                     const int32_t D = (int32_t)(a.rule_off[r + 1] - lo);
                     uint32_t best = 0, nd = 0;   // best = INT32_MAX - min
                     for (int32_t d = tid; d < D; d += T)
-                        if (a.rule_exists[lo + d]) {
+                        if (cs::load_relaxed_i32(a.rule_dom_nodes + lo + d) > 0) {
                             const uint32_t inv = 0x7fffffffu - (uint32_t)cs::load_relaxed_i32(a.rule_cnt + lo + d);
                             best = inv > best ? inv : best; nd++;
                         }
@@ -379,7 +385,10 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                     const int32_t d = a.node_domain[(int64_t)a.rule_key[r] * N + m];
                     const int row = a.rule_elig_row[r];
                     const bool el = row < 0 || ((a.rule_elig[(int64_t)row * (a.cap >> 6) + (m >> 6)] >> (m & 63)) & 1ull);
-                    if (d >= 0 && el) cs::atomic_add_i32(a.rule_cnt + a.rule_off[r] + d, (int32_t)x);
+                    if (d >= 0 && el) {
+                        cs::atomic_add_i32(a.rule_cnt + a.rule_off[r] + d, (int32_t)x);
+                        if (txn) cs::atomic_add_i32(a.rule_contrib + (int64_t)r * N + m, (int32_t)x);
+                    }
                 }
             };
 
@@ -572,13 +581,36 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
             }
             log_n += n_listed;
             if (tid == 0) alive[Y >> 6] &= ~(1ull << (Y & 63));
+            for (int r = tid; r < a.n_rules; r += T) {   // RemoveNodeInfo: one eligible node less in its domains
+                const int32_t d = a.node_domain[(int64_t)a.rule_key[r] * N + Y];
+                const int row = a.rule_elig_row[r];
+                const bool el = row < 0 || ((a.rule_elig[(int64_t)row * (a.cap >> 6) + (Y >> 6)] >> (Y & 63)) & 1ull);
+                if (d >= 0 && el) cs::atomic_add_i32(a.rule_dom_nodes + a.rule_off[r] + d, -1);
+            }
             for (int w = (Y >> 6) + 1 + tid; w < nw; w += T) wpre[w] -= 1u;   // one live node less in front of these words
             n_alive--; any_dead = true;
         } else {
             // Revert: touched nodes get their committed state back, the candidate its pods and its place
+            for (int r = tid; r < a.n_rules; r += T) {   // the candidate gets its pods back
+                const int32_t d = a.node_domain[(int64_t)a.rule_key[r] * N + Y], v = cs::load_relaxed_i32(a.rule_contrib + (int64_t)r * N + Y);
+                if (d >= 0 && v != 0) cs::atomic_add_i32(a.rule_cnt + a.rule_off[r] + d, v);
+            }
             for (int i = tid; i < n_listed; i += T) {
                 const int m = a.node_out[slot_of(i)];
                 if (m < 0) continue;
+                if (a.n_rules > 0) {   // and the destinations lose what the reverted placements fed
+                    const int ci = a.pod_class[pod_of(i)];
+                    for (int ii = a.inc_off[ci]; ii < a.inc_off[ci + 1]; ++ii) {
+                        const int r = a.inc_rule[ii];
+                        const int32_t d = a.node_domain[(int64_t)a.rule_key[r] * N + m];
+                        const int row = a.rule_elig_row[r];
+                        const bool el = row < 0 || ((a.rule_elig[(int64_t)row * (a.cap >> 6) + (m >> 6)] >> (m & 63)) & 1ull);
+                        if (d >= 0 && el) {
+                            cs::atomic_add_i32(a.rule_cnt + a.rule_off[r] + d, -1);
+                            cs::atomic_add_i32(a.rule_contrib + (int64_t)r * N + m, -1);
+                        }
+                    }
+                }
                 for (int r = 0; r < R; ++r) st.sfree[(int64_t)r * st.cap + m] = cfree[(int64_t)r * st.cap + m];
                 for (int w = 0; w < Wx; ++w) st.sexcl[(int64_t)w * st.cap + m] = cexcl[(int64_t)w * st.cap + m];
                 st.sslots[m] = cslots[m];
@@ -741,7 +773,6 @@ public:
         // ---- domain rules ----
         const casim_domain_rules* dr = q->rules;
         if (dr && dr->n_rules > 0) {
-            if (K_ > 0) return CASIM_NG_UNSUPPORTED;   // removing a node also removes its pods from the counters: host path
             if (dr->n_nodes != N_ || dr->n_classes != C_) return fail(CASIM_ERR_INVALID, "domain rules were built for other tables");
             for (int c = 0; c < C_; ++c)
                 if (dr->class_rule_off[c + 1] - dr->class_rule_off[c] > kMaxRulesPerClass) return CASIM_NG_UNSUPPORTED;
@@ -753,7 +784,13 @@ public:
             a_.rule_off = up(dr->rule_offset, NR + 1);
             d_rule_init_ = up(dr->count_init, tot); rule_total_ = (int64_t)tot;
             a_.rule_cnt = (int32_t*)dalloc(4 * tot);
-            a_.rule_exists = up(dr->domain_exists, tot);
+            d_dom_init_ = up(dr->domain_nodes, tot);
+            a_.rule_dom_nodes = (int32_t*)dalloc(4 * tot);
+            if (K_ > 0) {
+                contrib_total_ = (int64_t)NR * (int64_t)N_;
+                d_contrib_init_ = up(dr->node_contrib, (size_t)contrib_total_);
+                a_.rule_contrib = (int32_t*)dalloc(4 * (size_t)contrib_total_);
+            }
             // eligibility rows are addressed by 64-node words of the padded node range
             if (dr->n_elig_rows > 0) {
                 const size_t w_in = (N + 63) / 64;
@@ -782,7 +819,12 @@ public:
         if (P_ + E_ > 0) bk_.launch(fill_i32_kernel, (P_ + E_ + 255) / 256, 1, 256, (size_t)0, a_.node_out, (int64_t)(P_ + E_), (int32_t)-1);
         if (K_ > 0) { bk_.fill8(a_.removable_out, 2, (size_t)K_); bk_.zero(a_.arrived, (size_t)cap_); }
         if (n_pairs_ > 0) { bk_.zero(a_.pair_memo, 4 * n_pairs_); bk_.zero(a_.ctrl_count, 4 * n_ctrl_); }
-        if (rule_total_ > 0) bk_.launch(copy_i32_kernel, (int)((rule_total_ + 255) / 256), 1, 256, (size_t)0, a_.rule_cnt, d_rule_init_, rule_total_);
+        if (rule_total_ > 0) {
+            bk_.launch(copy_i32_kernel, (int)((rule_total_ + 255) / 256), 1, 256, (size_t)0, a_.rule_cnt, d_rule_init_, rule_total_);
+            bk_.launch(copy_i32_kernel, (int)((rule_total_ + 255) / 256), 1, 256, (size_t)0, a_.rule_dom_nodes, d_dom_init_, rule_total_);
+            if (contrib_total_ > 0)
+                bk_.launch(copy_i32_kernel, (int)((contrib_total_ + 255) / 256), 1, 256, (size_t)0, a_.rule_contrib, d_contrib_init_, contrib_total_);
+        }
         if (C_ > 0) bk_.launch(sched_static_kernel, S_, C_, 64, (size_t)0, dt_, d_fbits_, S_);
         if (lds_) bk_.launch(sched_kernel<true>, 1, 1, threads_, smem_, dt_, a_);
         else bk_.launch(sched_kernel<false>, 1, 1, threads_, smem_, dt_, a_);
@@ -867,8 +909,8 @@ private:
     bool ready_ = false, trivial_ = false, lds_ = true;
     size_t smem_ = 0;
     uint64_t* d_fbits_ = nullptr;
-    const int32_t* d_rule_init_ = nullptr;
-    int64_t rule_total_ = 0;
+    const int32_t* d_rule_init_ = nullptr; const int32_t* d_dom_init_ = nullptr; const int32_t* d_contrib_init_ = nullptr;
+    int64_t rule_total_ = 0, contrib_total_ = 0;
     size_t n_pairs_ = 0, n_ctrl_ = 0;
     std::vector<void*> allocs_;
     std::string err_;

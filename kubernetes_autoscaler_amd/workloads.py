@@ -547,3 +547,54 @@ def fuzz_pending_domains(seed: int, max_nodes: int = 40, max_pods: int = 90) -> 
     acceptable = [0 if rng.chance(1, 6) else 1 for _ in range(n_nodes)] if rng.chance(1, 4) else None
     return PendingWorkload(f"fuzz_pending_domains{seed}", nodes, pods, hints if rng.chance(1, 2) else None, acceptable,
                            break_on_failure=rng.chance(1, 6), last_index=rng.below(n_nodes + 2))
+
+
+def fuzz_removals_domains(seed: int, max_nodes: int = 30) -> RemovalWorkload:
+    """fuzz_removals on a cluster with topology labels whose running pods carry spread constraints and zone-level
+    anti-affinity: removing a node takes its pods out of the domain counters, its ghost stays a domain for the
+    simulation, a committed removal drops the node from its domains."""
+    from .objects import TopologySpreadConstraint
+    rng = SplitMix64(0xD0D1000 + seed)
+    n_nodes = 2 + rng.below(max_nodes) if not rng.chance(1, 10) else 70 + rng.below(100)
+    apps = [f"app{i}" for i in range(3)]
+    keys = [LABEL_HOSTNAME, LABEL_ZONE, "rack"]
+    n_zones, n_racks = 1 + rng.below(3), 1 + rng.below(5)
+    n_specs = 1 + rng.below(5)
+    specs = []
+    for c in range(n_specs):
+        kw = dict(labels={"app": rng.pick(apps)}, requests={"cpu": rng.pick([50, 100, 250, 500]), "memory": rng.pick([64 * MiB, 256 * MiB])})
+        if rng.chance(1, 2):
+            kw["spread_constraints"] = [TopologySpreadConstraint(max_skew=1 + rng.below(3), topology_key=rng.pick(keys), min_domains=rng.pick([0, 0, 2, 3]),
+                                                                 match_labels=({"app": kw["labels"]["app"]} if rng.chance(3, 4) else {"app": rng.pick(apps)}))]
+        if rng.chance(1, 4):
+            kw["anti_affinity"] = [PodAffinityTerm(rng.pick(keys), match_labels={"app": rng.pick(apps)})]
+        if rng.chance(1, 5):
+            kw["node_selector"] = {"pool": f"p{rng.below(2)}"}
+        specs.append(kw)
+    nodes = []
+    fill = rng.pick([3, 5, 8])
+    for i in range(n_nodes):
+        labels = {"pool": f"p{rng.below(2)}"}
+        if not rng.chance(1, 12):
+            labels[LABEL_ZONE] = f"z{rng.below(n_zones)}"
+        if not rng.chance(1, 8):
+            labels["rack"] = f"r{rng.below(n_racks)}"
+        node = _node(f"sdd{seed}-n{i}", rng.pick([1000, 2000, 4000]), rng.pick([2, 4]) * GiB, rng.pick([4, 8, 110]), labels)
+        info = NodeInfo(node)
+        cpu = 0
+        for _ in range(rng.below(fill)):
+            kw = specs[rng.below(n_specs)]
+            if cpu + kw["requests"]["cpu"] > node.allocatable["cpu"] or len(info.pods) >= node.allocatable["pods"]:
+                continue
+            if "node_selector" in kw and kw["node_selector"]["pool"] != labels["pool"]:
+                continue
+            info.pods.append(Pod(name=f"r{i}-{len(info.pods)}", labels=dict(kw["labels"]), requests=dict(kw["requests"]),
+                                 anti_affinity=list(kw.get("anti_affinity", [])), node_selector=dict(kw.get("node_selector", {})),
+                                 spread_constraints=list(kw.get("spread_constraints", [])), topology_spread=bool(kw.get("spread_constraints")),
+                                 controller_uid=f"rs-{specs.index(kw)}"))
+            cpu += kw["requests"]["cpu"]
+        nodes.append(info)
+    order = rng.sample(list(range(n_nodes)), 1 + rng.below(n_nodes))
+    destination = [0 if rng.chance(1, 8) else 1 for _ in range(n_nodes)] if rng.chance(1, 3) else None
+    return RemovalWorkload(f"fuzz_removals_domains{seed}", nodes, order, destination, None, persist=not rng.chance(1, 5),
+                           max_removable=rng.pick([0, 0, 0, 2]), last_index=rng.below(n_nodes + 1))

@@ -182,3 +182,15 @@ def test_removal_mirror_planner_loop(ctx):
         assert [r.node.name for r in removable] == [w.nodes[c].node.name for k, c in enumerate(w.candidates) if want["removable"][k] == 1]
         assert [u.node.name for u in unremovable] == [w.nodes[c].node.name for k, c in enumerate(w.candidates) if want["removable"][k] == 0]
         assert sim.last_index == want["last_index"] and sim.device_calls <= 1
+
+
+def test_removal_fuzz_domain_rules(ctx):
+    """The removal loop with PodTopologySpread / zone anti-affinity among the pods: counters lose the candidate's pods
+    for the simulation, get them back on revert, lose the node's domain membership on commit."""
+    from harness import RemovalCase, assert_removal_matches, removal_device, removal_oracle
+    from kubernetes_autoscaler_amd.workloads import fuzz_removals_domains
+    for seed in range(250):
+        w = fuzz_removals_domains(seed)
+        case = RemovalCase(nodes=w.nodes, candidates=w.candidates, destination=w.destination, hints=w.hints, persist=w.persist,
+                           max_removable=w.max_removable, last_index=w.last_index)
+        assert_removal_matches(removal_device(case, ctx), removal_oracle(case), w.name)

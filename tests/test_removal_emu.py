@@ -133,12 +133,23 @@ def test_mirror_equals_the_reference_loop(seed, mode):
         assert [p.name for p in r.pods_to_reschedule] == [p.name for p in lists[k]] + again.get(k, [])
 
 
-def test_domain_rules_delegate_the_removal_loop():
-    """Pods with spread constraints / zone anti-affinity among the pods to move: removing a node would also take its
-    pods out of the domain counters, which the device does not model -> the whole loop goes back to the host."""
-    from kubernetes_autoscaler_amd import _abi
+def test_zone_anti_affinity_in_the_removal_loop():
+    """Removing n0 takes its anti-affine pod out of zone z0's counter for the simulation; it can only land in a zone
+    that holds no such pod."""
     from kubernetes_autoscaler_amd.objects import LABEL_ZONE, PodAffinityTerm
     nodes = [NodeInfo(_node(f"n{i}", 1000, 10**9, 10, {LABEL_ZONE: f"z{i % 2}"})) for i in range(4)]
-    nodes[0].pods.append(Pod(name="z", labels={"app": "z"}, requests={"cpu": 100}, anti_affinity=[PodAffinityTerm(LABEL_ZONE, match_labels={"app": "z"})]))
-    got = removal_device(RemovalCase(nodes=nodes, candidates=[0]), EmuContext())
-    assert got.status == _abi.NG_UNSUPPORTED
+
+    def z(name):
+        return Pod(name=name, labels={"app": "z"}, requests={"cpu": 100}, anti_affinity=[PodAffinityTerm(LABEL_ZONE, match_labels={"app": "z"})])
+    nodes[0].pods.append(z("a"))   # zone z0
+    nodes[1].pods.append(z("b"))   # zone z1
+    w = check(RemovalCase(nodes=nodes, candidates=[0, 1]))
+    # a: z1 is taken by b, z0 is free once n0 is a ghost -> n2; then b: z0 now holds a -> only z1 -> n3
+    assert list(w["removable"]) == [1, 1] and list(w["node_out"]) == [2, 3]
+
+
+@pytest.mark.parametrize("seed", range(300))
+def test_fuzz_domain_rules(seed):
+    from kubernetes_autoscaler_amd.workloads import fuzz_removals_domains
+    w = fuzz_removals_domains(seed)
+    check(case_of(w), w.name)
