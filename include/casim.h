@@ -293,6 +293,7 @@ typedef struct casim_domain_rules {
     int32_t n_keys, n_rules, n_nodes, n_classes, n_elig_rows;
     const int32_t* node_domain;      /* [n_keys][n_nodes] domain id of the node for the key, -1 = label missing */
     const int32_t* key_domains;      /* [n_keys] number of domains                                            */
+    const uint8_t* key_is_hostname;  /* [n_keys] the key is kubernetes.io/hostname                             */
     const int32_t* rule_class;       /* [n_rules] rules are sorted by class                                    */
     const int32_t* rule_key;         /* [n_rules]                                                              */
     const int32_t* rule_kind;        /* [n_rules] 0 spread, 1 conflict                                         */
@@ -384,6 +385,35 @@ int32_t casim_simulate_node_removals(casim_ctx* ctx, const casim_pegs* classes, 
                                      const casim_removal_candidates* cand, casim_removal_results* out);
 int32_t casim_time_node_removals(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes,
                                  const casim_removal_candidates* cand, int32_t iters, float* ms_out);
+
+/*
+ * BinpackingNodeEstimator.Estimate on the whole snapshot (CA/estimator/binpacking_estimator.go:102-342):
+ * the path for node groups whose PEGs carry domain rules (PodTopologySpread, anti-affinity on non-hostname keys), which
+ * the template-mode batch (casim_estimate_batch) flags CASIM_NG_UNSUPPORTED.  `nodes` = the n_existing nodes of the
+ * cluster snapshot, in list order, with their running pods, followed by clones of the template (one record per node the
+ * limiter may grant; hostname label = the name the estimator would give it); `classes` = the PEGs (count = pods).
+ * Encoder: per-node mode (explicit_self_exclusion = 1).  Fastpath is not modelled (a PEG with spread constraints is
+ * never fast-pathed, :411-425): callers running with fastpath on keep delegating such groups.
+ * Result as casim_results for one group; node_count also counts nodes of the cluster that took a pod in the
+ * hostname-spread retry (:212-227, trackScheduledPod :58-61).
+ */
+typedef struct casim_cluster_estimate {
+    int32_t n_existing;              /* E */
+    int32_t max_nodes;               /* limiter: 0 no limit, < 0 no node may be added */
+    int32_t last_index;
+    const struct casim_domain_rules* rules;   /* casim_enc_domain_rules; NULL = none */
+    const uint64_t* port_block;      /* [n_pegs][w_excl] casim_enc_port_block: the NodePorts part of excl_block */
+} casim_cluster_estimate;
+
+typedef struct casim_cluster_estimate_result {
+    int32_t node_count, pods_scheduled, nodes_added, limiter_nodes, last_index_out, status;
+    int64_t req_cpu_sum, req_mem_sum;
+    int32_t* order;                  /* [n_pegs] PEG processed k-th */
+    int32_t* placed;                 /* [n_pegs] pods of that PEG that were scheduled */
+} casim_cluster_estimate_result;
+
+int32_t casim_estimate_on_cluster(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes,
+                                  const casim_cluster_estimate* params, casim_cluster_estimate_result* out);
 
 /* Measurement helpers (used by bench.py): run `iters` times, bracketed by HIP events on the
  * context's stream; returns the mean per-run milliseconds of the whole pipeline and of the
@@ -489,6 +519,9 @@ int32_t casim_enc_tables(const casim_encoder* e, casim_pegs* pegs_out, casim_gro
 /* Dictionary sizes (bits in use) for reporting: taints, label requirements, node bits, zone bits */
 /* per-node mode: the domain rules of the finalized tables (pointers owned by the encoder); n_rules == 0 when none */
 int32_t casim_enc_domain_rules(const casim_encoder* enc, casim_domain_rules* out);
+/* [n_pegs][w_excl]: the bits of excl_block that come from host ports (NodePorts runs before PodTopologySpread, the
+ * hostname anti-affinity bits after it: casim_estimate_on_cluster needs to tell them apart) */
+const uint64_t* casim_enc_port_block(const casim_encoder* enc);
 int32_t casim_enc_dict_sizes(const casim_encoder* e, int32_t sizes_out[4]);
 
 #ifdef __cplusplus

@@ -68,7 +68,7 @@ class EncoderOptions(C.Structure):
 
 class DomainRules(C.Structure):
     _fields_ = [("n_keys", C.c_int32), ("n_rules", C.c_int32), ("n_nodes", C.c_int32), ("n_classes", C.c_int32), ("n_elig_rows", C.c_int32),
-                ("node_domain", i32p), ("key_domains", i32p), ("rule_class", i32p), ("rule_key", i32p), ("rule_kind", i32p),
+                ("node_domain", i32p), ("key_domains", i32p), ("key_is_hostname", u8p), ("rule_class", i32p), ("rule_key", i32p), ("rule_kind", i32p),
                 ("rule_max_skew", i32p), ("rule_min_domains", i32p), ("rule_self", i32p), ("rule_elig_row", i32p), ("rule_offset", i64p),
                 ("count_init", i32p), ("domain_exists", u8p), ("domain_nodes", i32p), ("node_contrib", i32p), ("elig_bits", u64p), ("class_rule_off", i32p), ("inc_off", i32p),
                 ("inc_rule", i32p)]
@@ -78,6 +78,17 @@ class PodSequence(C.Structure):
     _fields_ = [("n_pods", C.c_int32), ("pod_class", i32p), ("hint_node", i32p), ("node_acceptable", u8p),
                 ("break_on_failure", C.c_int32), ("last_index", C.c_int32), ("rules", C.POINTER(DomainRules)),
                 ("similar_key", i32p)]
+
+
+class ClusterEstimate(C.Structure):
+    _fields_ = [("n_existing", C.c_int32), ("max_nodes", C.c_int32), ("last_index", C.c_int32), ("rules", C.POINTER(DomainRules)),
+                ("port_block", u64p)]
+
+
+class ClusterEstimateResult(C.Structure):
+    _fields_ = [("node_count", C.c_int32), ("pods_scheduled", C.c_int32), ("nodes_added", C.c_int32), ("limiter_nodes", C.c_int32),
+                ("last_index_out", C.c_int32), ("status", C.c_int32), ("req_cpu_sum", C.c_int64), ("req_mem_sum", C.c_int64),
+                ("order", i32p), ("placed", i32p)]
 
 
 class RemovalCandidates(C.Structure):
@@ -141,6 +152,9 @@ PROTOTYPES = {
     "casim_enc_pod_add_spread_constraint": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, cstr, C.c_int32]),
     "casim_enc_spread_add_requirement": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, cstr, cstr, cstrp, C.c_int32]),
     "casim_enc_domain_rules": (C.c_int32, [C.c_void_p, C.POINTER(DomainRules)]),
+    "casim_enc_port_block": (u64p, [C.c_void_p]),
+    "casim_estimate_on_cluster": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(ClusterEstimate),
+                                              C.POINTER(ClusterEstimateResult)]),
     "casim_enc_pod_set_fastpath_requests": (C.c_int32, [C.c_void_p, C.c_int32, C.c_double, C.c_double]),
     "casim_enc_pod_mark_unsupported": (C.c_int32, [C.c_void_p, C.c_int32, cstr]),
     "casim_enc_add_peg": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),

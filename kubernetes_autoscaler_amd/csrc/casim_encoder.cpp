@@ -179,7 +179,7 @@ struct casim_encoder {
     std::vector<int64_t> req, alloc, init_req, waste_cpu, waste_mem;
     std::vector<int32_t> count, allowed, init_pods, max_nodes, existing_nodes, last_index, peg_off, peg_idx;
     std::vector<uint32_t> pflags, gflags;
-    std::vector<uint64_t> tol, sel, xblock, xmark, zblock, zmark, taint, label, init_excl, init_zone, zone_valid;
+    std::vector<uint64_t> tol, sel, xblock, xmark, zblock, zmark, taint, label, init_excl, init_zone, zone_valid, xports;
     std::vector<double> fp_cpu, fp_mem, cap_cpu, cap_mem;
     int dict[4] = {0, 0, 0, 0};
     // domain rules (per-node mode)
@@ -187,6 +187,7 @@ struct casim_encoder {
         int32_t n_keys = 0, n_rules = 0, n_rows = 0;
         std::vector<int32_t> node_domain, key_domains, r_class, r_key, r_kind, r_skew, r_mind, r_self, r_row, count_init, class_off, inc_off, inc_rule;
         std::vector<int32_t> dom_nodes, node_contrib;
+        std::vector<uint8_t> key_host;
         std::vector<int64_t> r_off;
         std::vector<uint8_t> exists;
         std::vector<uint64_t> elig;
@@ -611,6 +612,8 @@ int32_t casim_enc_finalize(casim_encoder* e) {
             dr.n_keys = (int32_t)keys.size(); dr.n_rules = (int32_t)rules.size(); dr.n_rows = (int32_t)rows.size();
             // domains: distinct values of each key over the nodes
             dr.node_domain.assign(keys.size() * NG, -1); dr.key_domains.assign(keys.size(), 0);
+            dr.key_host.assign(keys.size(), 0);
+            for (size_t k = 0; k < keys.size(); ++k) dr.key_host[k] = keys[k] == kHostname ? 1 : 0;
             for (size_t k = 0; k < keys.size(); ++k) {
                 std::map<std::string, int> val_id;
                 for (size_t n = 0; n < NG; ++n) {
@@ -670,7 +673,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
     const int Wt = e->Wt, Wl = e->Wl, Wx = e->Wx, Wz = e->Wz;
     e->req.assign(G * (size_t)R, 0); e->count.assign(G, 0); e->pflags.assign(G, 0);
     e->tol.assign(G * (size_t)Wt, 0); e->sel.assign(G * (size_t)Wl, 0);
-    e->xblock.assign(G * (size_t)Wx, 0); e->xmark.assign(G * (size_t)Wx, 0);
+    e->xblock.assign(G * (size_t)Wx, 0); e->xmark.assign(G * (size_t)Wx, 0); e->xports.assign(G * (size_t)Wx + 1, 0);
     e->zblock.assign(G * (size_t)Wz, 0); e->zmark.assign(G * (size_t)Wz, 0);
     e->fp_cpu.assign(G, 0.0); e->fp_mem.assign(G, 0.0);
     const Taint unsched{kUnschedulableTaint, "", "NoSchedule"};
@@ -694,7 +697,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
             const Port sp = sanitize(pt);
             auto own = port_bit.find(sp);
             if (own != port_bit.end()) set_bit(e->xmark, i, Wx, own->second);
-            for (auto& pb : port_bit) if (ports_conflict(sp, pb.first)) set_bit(e->xblock, i, Wx, pb.second);
+            for (auto& pb : port_bit) if (ports_conflict(sp, pb.first)) { set_bit(e->xblock, i, Wx, pb.second); set_bit(e->xports, i, Wx, pb.second); }
         }
         if (has_port) f |= CASIM_PEG_SELF_EXCL_NODE;
         if (peg_occ_bit[i] >= 0) set_bit(e->xmark, i, Wx, peg_occ_bit[i]);
@@ -788,7 +791,7 @@ int32_t casim_enc_domain_rules(const casim_encoder* e, casim_domain_rules* out) 
     out->n_keys = dr.n_keys; out->n_rules = dr.n_rules; out->n_nodes = (int32_t)e->groups.size(); out->n_classes = (int32_t)e->pegs.size();
     out->n_elig_rows = dr.n_rows;
     if (dr.n_rules == 0) return CASIM_OK;
-    out->node_domain = dr.node_domain.data(); out->key_domains = dr.key_domains.data();
+    out->node_domain = dr.node_domain.data(); out->key_domains = dr.key_domains.data(); out->key_is_hostname = dr.key_host.data();
     out->rule_class = dr.r_class.data(); out->rule_key = dr.r_key.data(); out->rule_kind = dr.r_kind.data();
     out->rule_max_skew = dr.r_skew.data(); out->rule_min_domains = dr.r_mind.data(); out->rule_self = dr.r_self.data();
     out->rule_elig_row = dr.r_row.data(); out->rule_offset = dr.r_off.data(); out->count_init = dr.count_init.data();
@@ -797,6 +800,7 @@ int32_t casim_enc_domain_rules(const casim_encoder* e, casim_domain_rules* out) 
     out->inc_off = dr.inc_off.data(); out->inc_rule = dr.inc_rule.data();
     return CASIM_OK;
 }
+const uint64_t* casim_enc_port_block(const casim_encoder* e) { return (e && e->finalized) ? e->xports.data() : nullptr; }
 int32_t casim_enc_dict_sizes(const casim_encoder* e, int32_t sizes_out[4]) {
     if (!e || !e->finalized || !sizes_out) return CASIM_ERR_INVALID;
     for (int i = 0; i < 4; ++i) sizes_out[i] = e->dict[i];

@@ -385,6 +385,20 @@ int32_t casim_try_schedule_pods(casim_ctx* ctx, const casim_pegs* classes, const
     return rc;
 }
 
+// ---- Estimate on the whole snapshot ------------------------------------------------
+int32_t casim_estimate_on_cluster(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes,
+                                  const casim_cluster_estimate* params, casim_cluster_estimate_result* out) {
+    g_err.clear();
+    if (!ctx) return set_err(CASIM_ERR_INVALID, "null context");
+    HipBackend& bk = ctx->bk; bk.bind(); bk.clear();
+    casim::ClusterEstimatorT<HipBackend> s(bk);
+    int32_t rc = s.init(classes, nodes, params);
+    if (rc == CASIM_OK) rc = s.run();
+    if (rc == CASIM_OK) rc = s.fetch(out);
+    if (rc < 0) set_err(rc, s.error());
+    return rc;
+}
+
 // ---- scale-down removal simulation ----------------------------------------------
 int32_t casim_simulate_node_removals(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes,
                                      const casim_removal_candidates* cand, casim_removal_results* out) {

@@ -367,3 +367,4 @@ private:
 }  // namespace casim
 
 #include "casim_sched.h"
+#include "casim_estimate.h"

@@ -168,6 +168,7 @@ class Encoder:
         check(lib.casim_enc_tables(self._h, C.byref(self.pegs), C.byref(self.groups)))
         self.rules = _abi.DomainRules()
         check(lib.casim_enc_domain_rules(self._h, C.byref(self.rules)))
+        self.port_block = lib.casim_enc_port_block(self._h)
         return self.pegs, self.groups
 
     def dict_sizes(self):

@@ -135,6 +135,21 @@ def finish_removal_results(rc, st, res, packed) -> RemovalResult:
                          arrs["ext_pod"][:ne].copy(), arrs["ext_node"][:ne].copy(), int(res.last_index), int(res.n_processed))
 
 
+def make_cluster_estimate(classes, n_existing, max_nodes=0, last_index=0, rules=None, port_block=None):
+    G = max(classes.n_pegs, 1)
+    arrs = dict(order=np.zeros(G, np.int32), placed=np.zeros(G, np.int32))
+    params = _abi.ClusterEstimate(n_existing=int(n_existing), max_nodes=int(max_nodes), last_index=int(last_index),
+                                  rules=C.pointer(rules) if rules is not None and rules.n_rules > 0 else None, port_block=port_block)
+    res = _abi.ClusterEstimateResult(order=_ptr(arrs["order"], C.c_int32), placed=_ptr(arrs["placed"], C.c_int32))
+    return params, res, arrs
+
+
+def finish_cluster_estimate(res, arrs, n_pegs):
+    return dict(node_count=int(res.node_count), pods_scheduled=int(res.pods_scheduled), nodes_added=int(res.nodes_added),
+                limiter_nodes=int(res.limiter_nodes), last_index_out=int(res.last_index_out), req_cpu_sum=int(res.req_cpu_sum),
+                req_mem_sum=int(res.req_mem_sum), order=arrs["order"][:n_pegs].copy(), placed=arrs["placed"][:n_pegs].copy())
+
+
 def device_count() -> int:
     return int(lib.casim_device_count())
 
@@ -197,6 +212,16 @@ class Context:
         del keep
         return rc, node_out[:seq.n_pods], li.value, ns.value
 
+
+    def estimate_on_cluster(self, classes: _abi.Pegs, nodes: _abi.Groups, n_existing: int, max_nodes: int = 0, last_index: int = 0,
+                            rules=None, port_block=None):
+        """BinpackingNodeEstimator.Estimate on the whole snapshot (casim_estimate_on_cluster): the path for node groups
+        whose PEGs carry domain rules.  Returns (status, ClusterEstimateResult fields as a dict)."""
+        params, res, arrs = make_cluster_estimate(classes, n_existing, max_nodes, last_index, rules, port_block)
+        rc = lib.casim_estimate_on_cluster(self._h, C.byref(classes), C.byref(nodes), C.byref(params), C.byref(res))
+        if rc < 0:
+            check(rc, "casim_estimate_on_cluster")
+        return rc, finish_cluster_estimate(res, arrs, classes.n_pegs)
 
     def simulate_node_removals(self, classes: _abi.Pegs, nodes: _abi.Groups, cand_node, pod_offsets, pod_class, hint_node=None,
                                destination=None, persist: bool = True, max_removable: int = 0, last_index: int = 0,

@@ -162,6 +162,37 @@ class ClusterSnapshotView:
     last_index: int = 0
 
 
+def encode_cluster_estimate(lanes, pegs: List[PodEquivalenceGroup], existing: List[NodeInfo], template: NodeInfo, max_nodes: int):
+    """Per-node tables for casim_estimate_on_cluster: the snapshot's nodes with their pods, then clones of the template
+    named like the estimator names new nodes (<template>-e-<i>, hostname label = name; addNewNodeToSnapshot
+    binpacking_estimator.go:326-342, SanitizedNodeInfo node_info_utils.go:93-137).  One clone per node the limiter may
+    grant, at most one per pod plus the one that may stay empty."""
+    import copy
+    from .objects import LABEL_HOSTNAME
+    enc = Encoder(lanes=lanes, explicit_self_exclusion=True)
+    for pg in pegs:
+        enc.add_peg(pg)
+    for info in existing:
+        enc.add_group(info, pegs=[])
+    pods_total = sum(max(len(pg.pods), 1) for pg in pegs)
+    n_clones = max_nodes if max_nodes > 0 else pods_total + 1
+    n_clones = max(1, min(n_clones, pods_total + 1))
+    for i in range(n_clones):
+        node = copy.copy(template.node)
+        node.name = f"{template.node.name}-e-{i}"
+        node.labels = dict(template.node.labels)
+        node.labels[LABEL_HOSTNAME] = node.name
+        enc.add_group(NodeInfo(node, list(template.pods)), pegs=[])
+    enc.finalize()
+    return enc
+
+
+def _fastpath_eligible(pod: Pod) -> bool:
+    """shouldUseFastPath (binpacking_estimator.go:411-425): no topology spread, no anti-affinity on a non-hostname key."""
+    from .objects import LABEL_HOSTNAME
+    return not pod.topology_spread and not pod.spread_constraints and all(t.topology_key == LABEL_HOSTNAME for t in pod.anti_affinity)
+
+
 class BinpackingNodeEstimator:
     """NewBinpackingNodeEstimator(clusterSnapshot, limiter, podOrderer, context, analyser, fastpath)
     binpacking_estimator.go:66-82 — backed by libcasim (HIP)."""
@@ -196,6 +227,12 @@ class BinpackingNodeEstimator:
                 prob.run()
                 res = prob.fetch()
             if int(res.status[0]) != 0:
+                # PEGs with domain rules (PodTopologySpread, zone anti-affinity): Estimate on the whole snapshot (K_est),
+                # unless the fastpath would pick up one of the other PEGs (not modelled there)
+                if not self.fastpath or not any(pg.pods and _fastpath_eligible(pg.pods[0]) for pg in pegs):
+                    out = self._estimate_on_cluster(pegs, node_template)
+                    if out is not None:
+                        return out
                 if self.fallback is not None:
                     return self.fallback(pegs, node_template, node_group)
                 raise NotImplementedError("a PEG needs a predicate outside the encoded subset (delegate to the Go estimator)")
@@ -208,6 +245,22 @@ class BinpackingNodeEstimator:
             return int(res.node_count[0]), pods
         finally:
             self.limiter.end_estimation()
+
+    def _estimate_on_cluster(self, pegs, node_template):
+        enc2 = encode_cluster_estimate(self.lanes, pegs, self.snapshot.existing, node_template, self.limiter.device_max_nodes())
+        try:
+            rc, out = self.engine_ctx.estimate_on_cluster(enc2.pegs, enc2.groups, len(self.snapshot.existing), self.limiter.device_max_nodes(),
+                                                          self.snapshot.last_index, enc2.rules, enc2.port_block)
+        finally:
+            enc2.close()
+        if rc != 0:
+            return None
+        pods: List[Pod] = []
+        for pg_id, n in zip(out["order"], out["placed"]):
+            pods.extend(pegs[int(pg_id)].pods[:int(n)])
+        self.snapshot.last_index = out["last_index_out"]
+        self.limiter.nodes = out["limiter_nodes"]
+        return out["node_count"], pods
 
 
 def new_estimator_builder(name: str, limiter, orderer=None, analyser=None, fastpath: bool = False, engine_ctx: Optional[Context] = None):

@@ -598,3 +598,53 @@ def fuzz_removals_domains(seed: int, max_nodes: int = 30) -> RemovalWorkload:
     destination = [0 if rng.chance(1, 8) else 1 for _ in range(n_nodes)] if rng.chance(1, 3) else None
     return RemovalWorkload(f"fuzz_removals_domains{seed}", nodes, order, destination, None, persist=not rng.chance(1, 5),
                            max_removable=rng.pick([0, 0, 0, 2]), last_index=rng.below(n_nodes + 1))
+
+
+def fuzz_estimate_domains(seed: int) -> Workload:
+    """One node group whose PEGs carry PodTopologySpread constraints (hostname / zone / rack) and zone-level
+    anti-affinity, next to a cluster whose nodes have room and topology labels of their own: exercises the
+    estimator's hostname-spread retry (binpacking_estimator.go:212-227), which may place pods on cluster nodes."""
+    from .objects import TopologySpreadConstraint
+    rng = SplitMix64(0xE57D0000 + seed)
+    apps = [f"app{i}" for i in range(3)]
+    keys = [LABEL_HOSTNAME, LABEL_HOSTNAME, LABEL_ZONE, "rack"]
+    n_zones = 1 + rng.below(3)
+    existing = []
+    for i in range(rng.below(6)):
+        labels = {}
+        if not rng.chance(1, 6):
+            labels[LABEL_ZONE] = f"z{rng.below(n_zones)}"
+        if rng.chance(1, 2):
+            labels["rack"] = f"r{rng.below(3)}"
+        info = NodeInfo(_node(f"fe{seed}-old{i}", rng.pick([200, 1000, 4000]), rng.pick([1, 4]) * GiB, rng.pick([3, 10, 110]), labels))
+        if rng.chance(1, 8):
+            del info.node.labels[LABEL_HOSTNAME]
+        for j in range(rng.below(3)):
+            p = Pod(name=f"old{i}-{j}", labels={"app": rng.pick(apps)}, requests={"cpu": rng.pick([0, 50, 100]), "memory": 64 * MiB})
+            if rng.chance(1, 5):
+                p.anti_affinity = [PodAffinityTerm(rng.pick([LABEL_ZONE, "rack"]), match_labels={"app": rng.pick(apps)})]
+            info.pods.append(p)
+        existing.append(info)
+    tlabels = {}
+    if not rng.chance(1, 8):
+        tlabels[LABEL_ZONE] = f"z{rng.below(n_zones + 1)}"
+    if rng.chance(1, 2):
+        tlabels["rack"] = f"r{rng.below(4)}"
+    tmpl = NodeInfo(_node(f"fe{seed}-tmpl", rng.pick([1000, 2000, 4000]), rng.pick([2, 8]) * GiB, rng.pick([4, 10, 110]), tlabels))
+    if rng.chance(1, 4):
+        tmpl.pods.append(Pod(name="ds", namespace="kube-system", labels={"app": rng.pick(apps)}, requests={"cpu": 100, "memory": 64 * MiB}))
+    pegs = []
+    for i in range(1 + rng.below(5)):
+        app = rng.pick(apps)
+        pod = Pod(name=f"fe{seed}-p{i}", labels={"app": app}, requests={"cpu": rng.pick([20, 100, 250, 500]), "memory": rng.pick([64 * MiB, 256 * MiB, 1 * GiB])})
+        if rng.chance(2, 3):
+            pod.spread_constraints = [TopologySpreadConstraint(max_skew=1 + rng.below(3), topology_key=rng.pick(keys), min_domains=rng.pick([0, 0, 1, 2, 3]),
+                                                               match_labels=({"app": app} if rng.chance(3, 4) else {"app": rng.pick(apps)}))
+                                      for _ in range(1 + rng.below(2))]
+            pod.topology_spread = True
+        if rng.chance(1, 5):
+            pod.anti_affinity = [PodAffinityTerm(rng.pick([LABEL_HOSTNAME, LABEL_ZONE]), match_labels={"app": rng.pick(apps)})]
+        if rng.chance(1, 6):
+            pod.host_ports = [ContainerPort(8080)]
+        pegs.append(PodEquivalenceGroup(pods=[pod] * rng.pick([1, 2, 5, 9, 14])))
+    return Workload(f"fuzz_estimate_domains{seed}", pegs, [GroupPlan(tmpl, max_nodes=rng.pick([0, 0, 2, 5, -1]), last_index=rng.below(8))], existing)

@@ -92,4 +92,16 @@ EMU_API int32_t emu_simulate_node_removals(const casim_pegs* classes, const casi
     return rc;
 }
 
+EMU_API int32_t emu_estimate_on_cluster(const casim_pegs* classes, const casim_groups* nodes, const casim_cluster_estimate* params,
+                                        int64_t lds_budget_bytes, casim_cluster_estimate_result* out) {
+    EmuBackend bk;
+    if (lds_budget_bytes > 0) bk.lds = (size_t)lds_budget_bytes;
+    casim::ClusterEstimatorT<EmuBackend> s(bk);
+    int32_t rc = s.init(classes, nodes, params);
+    if (rc == CASIM_OK) rc = s.run();
+    if (rc == CASIM_OK) rc = s.fetch(out);
+    if (rc < 0) g_err = s.error();
+    return rc;
+}
+
 }  // extern "C"

@@ -329,3 +329,52 @@ def assert_removal_matches(got, want, what=""):
     ext = list(zip(got.ext_candidate.tolist(), got.ext_pod.tolist(), got.ext_node.tolist()))
     assert ext == want["ext"], f"{what}: pods listed again (candidate, pod, node)\n got {ext}\n want {want['ext']}"
     assert got.last_index == want["last_index"], f"{what}: lastIndex got {got.last_index} want {want['last_index']}"
+
+
+# ---------------------------------------------------------------------------------------------
+# Estimate on the whole snapshot: groups whose PEGs carry domain rules
+# ---------------------------------------------------------------------------------------------
+def cluster_encode(sc: Scenario, group_index: int = 0):
+    """Per-node tables for one group of a scenario (product helper estimator.encode_cluster_estimate)."""
+    from kubernetes_autoscaler_amd.estimator import encode_cluster_estimate
+    g = sc.groups[group_index]
+    ids = list(range(len(sc.pegs))) if g.pegs is None else list(g.pegs)
+    return encode_cluster_estimate(sc.lanes, [sc.pegs[i] for i in ids], sc.existing, g.template, g.max_nodes), ids
+
+
+def cluster_estimate_emu(sc: Scenario, group_index: int = 0, lds_budget=0):
+    """K_est under the wave emulator for one group: (status, result dict, PEG ids)."""
+    from kubernetes_autoscaler_amd.engine import finish_cluster_estimate, make_cluster_estimate
+    L = emu_lib()
+    if not hasattr(L, "_cluster_ready"):
+        L.emu_estimate_on_cluster.restype = C.c_int32
+        L.emu_estimate_on_cluster.argtypes = [C.POINTER(_abi.Pegs), C.POINTER(_abi.Groups), C.POINTER(_abi.ClusterEstimate), C.c_int64,
+                                              C.POINTER(_abi.ClusterEstimateResult)]
+        L._cluster_ready = True
+    enc, ids = cluster_encode(sc, group_index)
+    g = sc.groups[group_index]
+    params, res, arrs = make_cluster_estimate(enc.pegs, len(sc.existing), g.max_nodes, g.last_index, enc.rules, enc.port_block)
+    rc = L.emu_estimate_on_cluster(C.byref(enc.pegs), C.byref(enc.groups), C.byref(params), int(lds_budget), C.byref(res))
+    assert rc >= 0, (rc, L.emu_last_error())
+    out = finish_cluster_estimate(res, arrs, enc.pegs.n_pegs)
+    enc.close()
+    return rc, out, ids
+
+
+def cluster_estimate_gpu(sc: Scenario, ctx, group_index: int = 0):
+    enc, ids = cluster_encode(sc, group_index)
+    g = sc.groups[group_index]
+    rc, out = ctx.estimate_on_cluster(enc.pegs, enc.groups, len(sc.existing), g.max_nodes, g.last_index, enc.rules, enc.port_block)
+    enc.close()
+    return rc, out, ids
+
+
+def assert_cluster_estimate_matches(got, est: OracleEstimate, oracle_ids, what=""):
+    rc, out, ids = got
+    assert rc == 0, f"{what}: status {rc}"
+    assert ids == oracle_ids, what
+    assert list(out["order"]) == list(est.order), f"{what}: PEG order got {list(out['order'])} want {list(est.order)}"
+    assert list(out["placed"]) == list(est.placed), f"{what}: placed per PEG\n got {list(out['placed'])}\n want {list(est.placed)}"
+    g = (out["node_count"], out["pods_scheduled"], out["nodes_added"], out["limiter_nodes"], out["last_index_out"], out["req_cpu_sum"], out["req_mem_sum"])
+    w = (est.node_count, est.pods_scheduled, est.nodes_added, est.limiter_nodes, est.last_index_out, est.req_cpu_sum, est.req_mem_sum)
+    assert g == w, f"{what}: (nodes, pods, added, limiter, lastIndex, cpu, mem) got {g} want {w}"

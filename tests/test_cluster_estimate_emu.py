@@ -1,0 +1,52 @@
+"""BinpackingNodeEstimator.Estimate on the whole snapshot (K_est, casim_estimate.h) under the wave
+emulator against the object-level oracle — all eight TestBinpackingEstimate rows (the three PodTopologySpread rows
+included: the hostname retry places pods on the node that is already in the cluster) and scenarios the template-mode
+packer handles too (both paths must agree with the oracle)."""
+import pytest
+
+from harness import GroupSpec, Scenario, assert_cluster_estimate_matches, cluster_estimate_emu, run_oracle
+from kubernetes_autoscaler_amd import workloads
+from test_kernels_emu_golden import GOLD, golden_scenario
+
+
+def check(sc, what="", lds=(0, 64)):
+    want = run_oracle(sc)
+    for gi in range(len(sc.groups)):
+        est, ids = want[gi]
+        for b in lds:
+            assert_cluster_estimate_matches(cluster_estimate_emu(sc, gi, lds_budget=b), est, ids, f"{what} group {gi} lds={b}")
+    return want
+
+
+@pytest.mark.parametrize("case", GOLD["cases"] + GOLD["topology_spread_cases"], ids=lambda c: c["name"])
+def test_golden_rows(case):
+    sc = golden_scenario(case)
+    want = check(sc, case["name"])
+    assert (want[0][0].node_count, want[0][0].pods_scheduled) == (case["expect_nodes"], case["expect_pods"])
+
+
+def scenario_of(w):
+    return Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing,
+                    lanes=w.lanes)
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_fuzz_same_as_template_mode(seed):
+    """the feature-mix fuzz of the packer (taints, selectors, ports, hostname and zone anti-affinity, preloaded pods,
+    every limiter sign): K_est must give the oracle's answer too"""
+    w = workloads.fuzz(4000 + seed, max_groups=2, max_pegs=8)
+    for pg in w.pegs:   # per-pod walks: keep the groups small
+        del pg.pods[12:]
+    check(scenario_of(w), w.name, lds=(0,))
+
+
+@pytest.mark.parametrize("seed", range(400))
+def test_fuzz_domain_rules(seed):
+    w = workloads.fuzz_estimate_domains(seed)
+    sc = scenario_of(w)
+    if cluster_estimate_emu(sc)[0] == 1:
+        # the only legitimate delegation here: hostname anti-affinity next to a node without a hostname label
+        assert any("kubernetes.io/hostname" not in info.node.labels for info in w.existing)
+        assert any(t.topology_key == "kubernetes.io/hostname" for pg in w.pegs for t in pg.pods[0].anti_affinity)
+        pytest.skip("delegated: hostname anti-affinity with an unnamed node")
+    check(sc, w.name)

@@ -108,16 +108,19 @@ def _est(ctx, max_nodes, fastpath=False):
     return est.BinpackingNodeEstimator(ctx, snap, limiter, est.DecreasingPodOrderer(), None, None, fastpath)
 
 
-@pytest.mark.parametrize("case", GOLD["cases"], ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", GOLD["cases"] + GOLD["topology_spread_cases"], ids=lambda c: c["name"])
 def test_binpacking_estimate_like_the_reference_test(ctx, case):
-    """TestBinpackingEstimate (binpacking_estimator_test.go:66-254) written against the mirror API."""
+    """TestBinpackingEstimate (binpacking_estimator_test.go:66-254), all eight rows, written against the mirror API: the
+    PodTopologySpread rows go through K_est (Estimate on the whole snapshot), with and without the fastpath flag."""
     from kubernetes_autoscaler_amd.objects import (NodeInfo, build_test_pod, make_node, make_pod_equivalence_group,
-                                                   with_host_port, with_labels, with_namespace)
+                                                   with_host_port, with_labels, with_max_skew, with_namespace)
     pegs = []
     for g in case["pegs"]:
         opts = [with_namespace("universe"), with_labels({"app": "estimatee"})]
         if g.get("host_port"):
             opts.append(with_host_port(g["host_port"]))
+        if g.get("max_skew"):
+            opts.append(with_max_skew(*g["max_skew"]))
         pegs.append(make_pod_equivalence_group(build_test_pod("estimatee", g["cpu"], g["mem"], *opts), g["count"]))
     node_info = NodeInfo(make_node(case["millicores"], case["memory_mib"], 10, "template", "zone-mars"))
     nodes, pods = _est(ctx, case["max_nodes"]).estimate(pegs, node_info, None)
@@ -205,3 +208,28 @@ def test_generic_packer_equals_register_packer(ctx):
         for f in ("node_count", "pods_scheduled", "nodes_added", "limiter_nodes", "last_index_out", "req_cpu_sum", "req_mem_sum", "order", "placed"):
             assert np.array_equal(getattr(a, f), getattr(b, f)), (name, f)
         assert_matches_oracle(b, run_oracle(sc), name)
+
+
+# ---- Estimate on the whole snapshot (K_est) --------------------------------------------------------
+@pytest.mark.parametrize("case", GOLD["cases"] + GOLD["topology_spread_cases"], ids=lambda c: c["name"])
+def test_cluster_estimate_golden_rows(ctx, case):
+    from harness import assert_cluster_estimate_matches, cluster_estimate_gpu
+    sc = golden_scenario(case)
+    est, ids = run_oracle(sc)[0]
+    assert (est.node_count, est.pods_scheduled) == (case["expect_nodes"], case["expect_pods"])
+    assert_cluster_estimate_matches(cluster_estimate_gpu(sc, ctx), est, ids, case["name"])
+
+
+def test_cluster_estimate_fuzz(ctx):
+    from harness import assert_cluster_estimate_matches, cluster_estimate_gpu
+    delegated = 0
+    for seed in range(300):
+        w = workloads.fuzz_estimate_domains(seed)
+        sc = scenario_of(w)
+        got = cluster_estimate_gpu(sc, ctx)
+        if got[0] == 1:
+            delegated += 1
+            continue
+        est, ids = run_oracle(sc)[0]
+        assert_cluster_estimate_matches(got, est, ids, w.name)
+    assert delegated < 40
