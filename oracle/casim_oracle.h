@@ -55,8 +55,7 @@ int orc_term_requirement(orc* o, int pod, int term, const char* key, const char*
 int orc_pod_fastpath_requests(orc* o, int pod, double cpu, double mem);
 int orc_pod_has_topology_spread(orc* o, int pod, int flag); /* only feeds shouldUseFastPath */
 /* DoNotSchedule topologySpreadConstraint (PodTopologySpread Filter, V/.../podtopologyspread/filtering.go);
- * min_domains <= 0 = nil.  The product delegates such pods (CASIM_PEG_UNSUPPORTED); the oracle evaluates them so
- * that it is pinned on TestBinpackingEstimate's topology-spread rows too. */
+ * min_domains <= 0 = nil.  (Device side: domain rules of K_sched / K_est; the template-mode packer delegates.) */
 int orc_pod_spread_constraint(orc* o, int pod, int max_skew, const char* topology_key, int min_domains);
 int orc_spread_requirement(orc* o, int pod, int constraint, const char* key, const char* op,
                            const char* const* values, int n_values);
