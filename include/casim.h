@@ -208,7 +208,11 @@ int32_t casim_problem_csr(casim_problem* p, int32_t* nnz_out, int32_t* offsets_o
  * register-resident int32 packer (0 = generic int64 packer), [1] = its lane count, [2] = 1 if the
  * generic packer keeps node state in LDS (0 = HBM slab), [3] = 1 if the schedulable subsets are
  * derived on the device, [4..7] reserved (0). */
+struct casim_cluster_estimate_result;
 int32_t casim_problem_info(casim_problem* p, int32_t info_out[8]);
+/* Replace the result of group `ng` of a batch that already ran (status becomes CASIM_NG_OK): how a group that the batch
+ * delegated and casim_estimate_on_cluster then estimated joins the expander reduce of casim_best_option. */
+int32_t casim_problem_set_group_result(casim_problem* p, int32_t ng, const struct casim_cluster_estimate_result* r);
 
 /* upload + run + fetch in one call: the form the Go Estimate() wrapper uses once per loop. */
 int32_t casim_estimate_batch(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups,

@@ -118,6 +118,7 @@ PROTOTYPES = {
     "casim_problem_fetch": (C.c_int32, [C.c_void_p, C.POINTER(Results)]),
     "casim_problem_csr": (C.c_int32, [C.c_void_p, i32p, i32p]),
     "casim_problem_info": (C.c_int32, [C.c_void_p, i32p]),
+    "casim_problem_set_group_result": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(ClusterEstimateResult)]),
     "casim_estimate_batch": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(Options), C.POINTER(Results)]),
     "casim_feasibility": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), u64p]),
     "casim_problem_dense_check": (C.c_int32, [C.c_void_p, C.c_int32, u64p, i64p, i64p]),

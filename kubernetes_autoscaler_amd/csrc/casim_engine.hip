@@ -234,6 +234,10 @@ int32_t casim_problem_info(casim_problem* p, int32_t info_out[8]) {
     info_out[2] = p->prob->pack_in_lds() ? 1 : 0; info_out[3] = p->prob->csr_on_device() ? 1 : 0;
     return CASIM_OK;
 }
+int32_t casim_problem_set_group_result(casim_problem* p, int32_t ng, const casim_cluster_estimate_result* r) {
+    PROB_ENTER(p);
+    PROB_RET(p, p->prob->set_group_result(ng, r));
+}
 int32_t casim_problem_csr(casim_problem* p, int32_t* nnz_out, int32_t* offsets_out) { PROB_ENTER(p); PROB_RET(p, p->prob->csr(nnz_out, offsets_out)); }
 
 int32_t casim_estimate_batch(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts, casim_results* out) {

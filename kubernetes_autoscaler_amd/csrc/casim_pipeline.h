@@ -284,6 +284,19 @@ public:
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
     }
 
+    // overwrite one group's result (a group estimated elsewhere joins the expander reduce)
+    int32_t set_group_result(int32_t ng, const casim_cluster_estimate_result* r) {
+        if (!ready_ || !ran_) return fail(CASIM_ERR_INVALID, "run the problem first");
+        if (!r || ng < 0 || ng >= NG_) return fail(CASIM_ERR_INVALID, "bad group index");
+        const int32_t ok = CASIM_NG_OK;
+        bk_.h2d(dr_.node_count + ng, &r->node_count, 4); bk_.h2d(dr_.pods + ng, &r->pods_scheduled, 4);
+        bk_.h2d(dr_.nodes_added + ng, &r->nodes_added, 4); bk_.h2d(dr_.limiter_nodes + ng, &r->limiter_nodes, 4);
+        bk_.h2d(dr_.last_index_out + ng, &r->last_index_out, 4); bk_.h2d(dr_.status + ng, &ok, 4);
+        bk_.h2d(dr_.cpu_sum + ng, &r->req_cpu_sum, 8); bk_.h2d(dr_.mem_sum + ng, &r->req_mem_sum, 8);
+        bk_.sync();
+        return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
+    }
+
     // bit-matrix [NG][ceil(G/64)] of the last run_feasibility()
     int32_t fetch_bits(uint64_t* out_bits) {
         if (!csr_on_device_) return fail(CASIM_ERR_INVALID, "feasibility was not computed on the device");

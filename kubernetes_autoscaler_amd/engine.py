@@ -276,6 +276,13 @@ class Problem:
         return {"fast_packer_slots_per_lane": out[0], "fast_packer_lanes": out[1], "generic_state_in_lds": bool(out[2]),
                 "csr_on_device": bool(out[3])}
 
+    def set_group_result(self, ng: int, r: dict):
+        """casim_problem_set_group_result: a group estimated by Context.estimate_on_cluster joins the expander reduce."""
+        st = _abi.ClusterEstimateResult(node_count=r["node_count"], pods_scheduled=r["pods_scheduled"], nodes_added=r["nodes_added"],
+                                        limiter_nodes=r["limiter_nodes"], last_index_out=r["last_index_out"], status=0,
+                                        req_cpu_sum=r["req_cpu_sum"], req_mem_sum=r["req_mem_sum"])
+        check(lib.casim_problem_set_group_result(self._h, int(ng), C.byref(st)), "casim_problem_set_group_result")
+
     def csr(self):
         nnz = C.c_int32(0)
         off = np.zeros(self.n_groups + 1, np.int32)

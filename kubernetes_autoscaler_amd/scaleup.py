@@ -14,7 +14,8 @@ import numpy as np
 
 from .encoder import Encoder
 from .engine import BatchResult, Context, Problem
-from .estimator import ClusterSnapshotView, EstimationContext, NodeGroup, ThresholdBasedEstimationLimiter
+from .estimator import (ClusterSnapshotView, EstimationContext, NodeGroup, ThresholdBasedEstimationLimiter, _fastpath_eligible,
+                        encode_cluster_estimate)
 from .expander import ChainStrategy, Option
 from .objects import NodeInfo, Pod, PodEquivalenceGroup
 
@@ -56,9 +57,33 @@ class ScaleUpSimulator:
                           last_index=snapshot.last_index, pegs=None)   # None: SchedulablePodGroups runs on the device
             self.limiter.end_estimation()
         enc.finalize()
+        rerun: Dict[int, dict] = {}   # groups the batch delegated and K_est estimated: index -> result
         with Problem(self.ctx, enc.pegs, enc.groups, self.fastpath) as prob:
             prob.run()
             res = prob.fetch()
+            # Groups whose PEGs carry domain rules (PodTopologySpread, zone anti-affinity) come back UNSUPPORTED from the
+            # template-mode batch: Estimate them on the whole snapshot and let them join the expander reduce.
+            can_rerun = not self.fastpath or not any(pg.pods and _fastpath_eligible(pg.pods[0]) for pg in pegs)
+            for i, ng in enumerate(node_groups):
+                if int(res.status[i]) == 0 or not can_rerun:
+                    continue
+                order, _ = res.group(i)
+                ids = sorted(int(x) for x in order)   # SchedulablePodGroups of this group (device feasibility)
+                context = EstimationContext(self.max_nodes_total, [], len(snapshot.existing))
+                self.limiter.start_estimation(pegs, ng, context)
+                maxn = self.limiter.device_max_nodes()
+                self.limiter.end_estimation()
+                enc2 = encode_cluster_estimate(self.lanes, [pegs[j] for j in ids], snapshot.existing, node_infos[ng.id()], maxn)
+                try:
+                    rc, out = self.ctx.estimate_on_cluster(enc2.pegs, enc2.groups, len(snapshot.existing), maxn, snapshot.last_index,
+                                                           enc2.rules, enc2.port_block)
+                finally:
+                    enc2.close()
+                if rc != 0:
+                    continue
+                out["peg_ids"] = ids
+                prob.set_group_result(i, out)
+                rerun[i] = out
             best_idx, n_best, best_set = self.expander.best_option_index(prob)
         total_pods = sum(len(pg.pods) for pg in pegs)
         options, schedulable, delegated = [], {}, []
@@ -66,13 +91,17 @@ class ScaleUpSimulator:
         for i, ng in enumerate(node_groups):
             order, placed = res.group(i)
             schedulable[ng.id()] = sorted(int(x) for x in order)
-            if int(res.status[i]) != 0:
+            node_count = int(res.node_count[i])
+            if i in rerun:
+                r = rerun[i]
+                order, placed, node_count = [r["peg_ids"][int(k)] for k in r["order"]], r["placed"], r["node_count"]
+            elif int(res.status[i]) != 0:
                 delegated.append(ng.id())
                 continue
             pods: List[Pod] = []
             for pg_id, n in zip(order, placed):
                 pods.extend(pegs[int(pg_id)].pods[:int(n)])
-            opt = Option(node_group=ng, node_count=int(res.node_count[i]), pods=pods)
+            opt = Option(node_group=ng, node_count=node_count, pods=pods)
             # orchestrator.go:1057-1063: drop empty options and, for all-or-nothing, partial ones
             if not pods or opt.node_count == 0:
                 continue

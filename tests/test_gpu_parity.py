@@ -167,6 +167,41 @@ def test_prepare_scale_up_batched(ctx):
     assert all(o.node_count > 0 and o.pods for o in plan.options)
 
 
+def test_prepare_scale_up_with_spread_constraints(ctx):
+    """A PEG with a hostname spread constraint makes the batch delegate every group it is schedulable on; the simulator
+    re-estimates those groups on the whole snapshot (K_est) and they take part in the expander reduce."""
+    from kubernetes_autoscaler_amd import estimator as est
+    from kubernetes_autoscaler_amd.expander import ChainStrategy
+    from kubernetes_autoscaler_amd.objects import NodeInfo, TopologySpreadConstraint, make_node
+    from kubernetes_autoscaler_amd.scaleup import ScaleUpSimulator
+    from oracle_driver import OracleScenario
+    w = workloads.config_c2(n_groups=6, n_pegs=30, pods_per_peg=6, cap=30)
+    spread_pod = w.pegs[0].pods[0]
+    spread_pod.spread_constraints = [TopologySpreadConstraint(2, "kubernetes.io/hostname", 0, dict(spread_pod.labels))]
+    spread_pod.topology_spread = True
+    existing = [NodeInfo(make_node(4000, 8000, 20, f"old{i}", "zone-x")) for i in range(3)]
+    ngs = [est.NodeGroup(f"ng{i}", max_size_=g.max_nodes, target_size_=0) for i, g in enumerate(w.groups)]
+    infos = {ng.id(): g.template for ng, g in zip(ngs, w.groups)}
+    limiter = est.ThresholdBasedEstimationLimiter([est.SngCapacityThreshold(), est.ClusterCapacityThreshold()])
+    sim = ScaleUpSimulator(ctx, limiter, ChainStrategy(["least-nodes"]), max_nodes_total=0)
+    plan = sim.prepare_scale_up(w.pegs, ngs, infos, est.ClusterSnapshotView(existing=existing))
+    assert not plan.delegated
+    # the oracle, group by group, on the PEGs that pass CheckPredicates on the template
+    want = {}
+    for ng, g in zip(ngs, w.groups):
+        s = OracleScenario()
+        for info in existing:
+            s.add_existing(info)
+        t = s.node(g.template)
+        ids = [i for i, pg in enumerate(w.pegs) if s.check_predicates(t, pg.pods[0])[0]]
+        e = s.estimate(t, [w.pegs[i] for i in ids], max_nodes=g.max_nodes, last_index=0)
+        want[ng.id()] = (e.node_count, e.pods_scheduled)
+        s.close()
+    got = {o.node_group.id(): (o.node_count, len(o.pods)) for o in plan.options}
+    assert got == {k: v for k, v in want.items() if v[0] > 0 and v[1] > 0}
+    assert plan.best is not None and plan.best.node_count == min(v[0] for v in got.values())
+
+
 def test_dense_check_matches_feasibility(ctx):
     """dense per-pod x per-node bit-matrix == fits(peg, fresh node) expanded by pod count and node repeat."""
     w = workloads.config_c2(n_groups=7, n_pegs=50, pods_per_peg=3, cap=5)
