@@ -222,7 +222,10 @@ int32_t casim_estimate_batch(casim_ctx* ctx, const casim_pegs* pegs, const casim
  * Batched CheckPredicates(exemplar, fresh template node): bit (i, g) of
  * out_bits[i * ceil(G/64) + g/64] is set iff PEG g passes every encoded Filter on an empty
  * node of group i (Appendix A `fits`).  Replaces the G x NG RunFiltersOnNode calls of
- * SchedulablePodGroups (orchestrator.go:552).  Synchronous.
+ * SchedulablePodGroups (orchestrator.go:552).  Synchronous.  For a PEG flagged CASIM_PEG_UNSUPPORTED a set bit means
+ * "not rejected by the encoded subset" (the shim runs CheckPredicates for that pair); a clear bit is final.  The same
+ * rule builds the per-group PEG lists when peg_offsets is NULL: such a PEG stays on the list of every group it may
+ * fit, which makes those groups CASIM_NG_UNSUPPORTED — it never silently drops out of an estimate.
  */
 int32_t casim_feasibility(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups,
                           uint64_t* out_bits);

@@ -86,7 +86,9 @@ CS_DEVICE uint32_t capacity_of(const int64_t* fr, int stride, int32_t slots, int
 // ------------------------------------------------------------------------------------------
 // grid = (ceil(G/256), NG), block = 256.  Thread -> one PEG; a wave's ballot is one output word.
 CS_DEVICE bool fits_fresh_node(const DevTables& t, int g, int ng) {
-    if (t.pflags[g] & CASIM_PEG_UNSUPPORTED) return false;
+    // A PEG that needs a predicate outside the encoded subset is still judged on the encoded part: failing it is final
+    // (the full Filter set only rejects more); passing it puts the PEG on the group's list, where it turns the group
+    // CASIM_NG_UNSUPPORTED (pack_unsupported) instead of silently vanishing from the estimate.
     if (!static_filters_pass(t, g, ng)) return false;
     int64_t fr[CASIM_KMAX_RES];
     for (int r = 0; r < CASIM_KMAX_RES; ++r)

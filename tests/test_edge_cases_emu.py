@@ -98,3 +98,25 @@ def test_feasibility_bits_match_check_predicates():
                 want = s.check_predicates(t, pg.exemplar())[0]
                 got = bool((int(bits[gi, pi // 64]) >> (pi % 64)) & 1)
                 assert got == want, (seed, gi, pi)
+
+
+def test_unsupported_peg_never_drops_out_of_a_device_built_list():
+    """peg_offsets == NULL (the engine derives SchedulablePodGroups): a PEG that needs a predicate outside the encoded
+    subset stays on the list of every group whose encoded Filters it passes — those groups come back
+    CASIM_NG_UNSUPPORTED — and is dropped only where the encoded part already rejects it."""
+    from kubernetes_autoscaler_amd import workloads
+    from kubernetes_autoscaler_amd.objects import TopologySpreadConstraint
+    w = workloads.config_c2(n_groups=3, n_pegs=6, pods_per_peg=3, cap=10)
+    pod = w.pegs[1].pods[0]   # schedulable on two of the three groups
+    pod.spread_constraints = [TopologySpreadConstraint(2, "kubernetes.io/hostname", 0, dict(pod.labels))]
+    pod.topology_spread = True
+    sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, None) for g in w.groups], device_csr=True)
+    res, _ = run_emu(encode(sc))
+    from oracle_driver import OracleScenario
+    s = OracleScenario()
+    passes = [s.check_predicates(s.node(g.template), pod)[0] for g in w.groups]
+    s.close()
+    assert any(passes) and not all(passes)
+    for i, ok in enumerate(passes):
+        listed = 1 in [int(x) for x in res.group(i)[0]]
+        assert listed == ok and (int(res.status[i]) == 1) == ok
