@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void dense_check_kernel(DevTables t, const int
     for (int r = 0; r < RD; ++r) req[r] = (live && r < t.R) ? t.req[(int64_t)g * t.R + r] : 0;
     const uint64_t tol = t.Wt ? t.tol[(int64_t)g * t.Wt] : 0ull, sel = t.Wl ? t.sel[(int64_t)g * t.Wl] : 0ull;
     const uint64_t xb = t.Wx ? t.xblock[(int64_t)g * t.Wx] : 0ull, zb = t.Wz ? t.zblock[(int64_t)g * t.Wz] : 0ull;
-    const uint32_t pf = live ? t.pflags[g] : CASIM_PEG_UNSUPPORTED;
+    const uint32_t pf = live ? t.pflags[g] : 0u;   // (PEGs outside the encoded subset: judged on the encoded part, like fits_fresh_node)
     const int64_t n_cb = (n_cols + 63) / 64;
     for (int cbi = 0; cbi < kDenseColBlocks; ++cbi) {
         const int64_t cb = (int64_t)blockIdx.y * kDenseColBlocks + cbi;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void dense_check_kernel(DevTables t, const int
         }
         __syncthreads();
         uint64_t bits = 0;
-        if (!(pf & CASIM_PEG_UNSUPPORTED)) {
+        if (live) {
 #pragma unroll 4
             for (int j = 0; j < 64; ++j) {
                 const DenseCol& c = cols[j];
