@@ -26,6 +26,7 @@
 // reference consults the memo (pods without a controller are re-tried and fail again): node_out is
 // identical, the memo here (one LDS bit per class) just skips the re-scan.
 #pragma once
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -79,6 +80,7 @@ struct SchedArgs {
     // SimilarPodsScheduling, exact form (only consulted for classes with spread rules): per run the (controller, class)
     // pair and the controller, -1 = pod without controller
     const int32_t* run_pair; const int32_t* run_ctrl;
+    int64_t* prof;                // [8] s_memtime ticks per phase of thread 0 (CASIM_PACK_PROF builds + CASIM_PACK_PROF_DUMP) or null
     int32_t* pair_memo;           // [n_pairs] 1 = cached as unschedulable (zeroed before every pass)
     int32_t* ctrl_count;          // [n_ctrl] specs cached for the controller (at most 10, similar_pods.go:52)
 };
@@ -166,8 +168,12 @@ inline int64_t casim_sched_state_bytes(int R, int Wx, int64_t cap) {
 }
 
 // One workgroup of T = 64..1024 threads; node m is owned by thread (m % T), chunk (m / T).
-template <bool kLds>
+// kTxn (removal transactions) and kRules (domain rules) are compile-time: the plain TrySchedulePods instantiation
+// does not carry their ~40 pointers — as one kernel, the uniform state overflowed the SGPR file and the hot loop
+// was dominated by v_writelane / v_readlane spill traffic (r01l ISA: 1800 of them).
+template <bool kLds, bool kTxn, bool kRules>
 CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) {
+    const int32_t n_rules = kRules ? a.n_rules : 0;
     using Store = MemStore<kLds>;
     const int tid = cs::tid(), lane = cs::lane(), wave = tid >> 6;
     const int T = cs::nthreads();
@@ -182,7 +188,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
     uint32_t* memo = bc.slot + 4;  // [ceil(memo_classes / 32)] class found no node
     // transactions: which nodes are still in the snapshot list, and how many live nodes precede each 64-node word
     // (lastIndex is a POSITION in the reference's node list, which shrinks when a removal is committed)
-    const bool txn = a.n_cand > 0;
+    constexpr bool txn = kTxn;
     const int nw = txn ? a.cap >> 6 : 0;
     uint64_t* alive = (uint64_t*)((char*)memo + ((4ll * ((a.memo_classes + 31) / 32) + 7) & ~7ll));  // [nw]
     uint32_t* wpre = (uint32_t*)(alive + nw);                                                           // [nw]
@@ -225,6 +231,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
     for (int i = tid; i < (a.memo_classes + 31) / 32; i += T) memo[i] = 0u;
     cs::sync();
 
+    CASIM_PROF_DECL;   // phases: 0 records / loop, 1 hint, 2 minima + origin, 3 walk (round 1), 4 lastIndex pick, 5 rounds 2.., 6 run end, 7 transactions
     int32_t last_index = a.last_index;
     int32_t scheduled = 0;
     int32_t runs_done = 0;
@@ -294,13 +301,13 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
         // (every path into this point ends with a barrier: nobody still reads the words rewritten here)
         if (tid == 0) { accb[Y >> 6] &= ~(1ull << (Y & 63)); scanb[Y >> 6] &= ~(1ull << (Y & 63)); }
         // ... pod-less: whatever its pods added to the domain counters goes with them (the ghost itself stays a domain)
-        for (int r = tid; r < a.n_rules; r += T) {
+        for (int r = tid; r < n_rules; r += T) {
             const int32_t d = a.node_domain[(int64_t)a.rule_key[r] * N + Y], v = cs::load_relaxed_i32(a.rule_contrib + (int64_t)r * N + Y);
             if (d >= 0 && v != 0) cs::atomic_add_i32(a.rule_cnt + a.rule_off[r] + d, -v);
         }
         cs::sync();
     }
-    for (int part = 0; part < 2; ++part) {   // the caller's runs, then one run per ext pod
+    for (int part = 0; part < (kTxn ? 2 : 1); ++part) {   // the caller's runs, then (removal loop) one run per ext pod
     const int part_lo = part == 0 ? run_lo : e_lo, part_hi = part == 0 ? run_hi : e_hi;
     for (int k0 = part_lo; k0 < part_hi && !stop && !failed; k0 += 64) {
         const int run_hi = part_hi;
@@ -310,8 +317,8 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
         const int32_t my_count = !have ? 0 : part == 0 ? a.run_count[kk] : 1;
         const int32_t my_hint = !have ? -1 : part == 0 ? a.run_hint[kk] : -1;   // its hint is the node it sits on: the candidate
         const int32_t my_first = !have ? 0 : part == 0 ? a.run_first[kk] : a.P + kk;
-        const int32_t my_pair = (have && part == 0 && a.run_pair) ? a.run_pair[kk] : -1;
-        const int32_t my_ctrl = (have && part == 0 && a.run_ctrl) ? a.run_ctrl[kk] : -1;
+        const int32_t my_pair = (kRules && have && part == 0 && a.run_pair) ? a.run_pair[kk] : -1;
+        const int32_t my_ctrl = (kRules && have && part == 0 && a.run_ctrl) ? a.run_ctrl[kk] : -1;
         // the class record of run kk rides along in its lane: one round trip to HBM per 64 runs, not one per run
         int64_t my_req[CASIM_KMAX_RES];
         double my_rq[CASIM_KMAX_RES];
@@ -342,8 +349,8 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
             const uint64_t* fb = a.fbits + (int64_t)c * (a.cap >> 6);
             int32_t placed = 0;
             // domain rules of the class; a class that feeds one of its own counters is walked pod by pod
-            const int r_lo = a.n_rules > 0 ? a.class_rule_off[c] : 0, r_hi = a.n_rules > 0 ? a.class_rule_off[c + 1] : 0;
-            const int i_lo = a.n_rules > 0 ? a.inc_off[c] : 0, i_hi = a.n_rules > 0 ? a.inc_off[c + 1] : 0;
+            const int r_lo = n_rules > 0 ? a.class_rule_off[c] : 0, r_hi = n_rules > 0 ? a.class_rule_off[c + 1] : 0;
+            const int i_lo = n_rules > 0 ? a.inc_off[c] : 0, i_hi = n_rules > 0 ? a.inc_off[c + 1] : 0;
             bool self_aff = false, monotone = true;   // monotone: a node that rejected the class once rejects it for good
             for (int r = r_lo; r < r_hi; ++r) { self_aff |= a.rule_self[r] != 0; monotone &= a.rule_kind[r] != 0; }
             const int32_t pair = (int32_t)cs::bcast_u32((uint32_t)my_pair, j), ctrl = (int32_t)cs::bcast_u32((uint32_t)my_ctrl, j);
@@ -392,6 +399,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                 }
             };
 
+            CASIM_PROF(0);
             // ---- tryScheduleUsingHints (:86-110): RunFiltersOnNode on the hinted node, no lastIndex update ----
             if (hint >= 0 && hint < N) {
                 if (((fb[hint >> 6] & accb[hint >> 6]) >> (hint & 63)) & 1ull) {
@@ -407,6 +415,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                 }
             }
 
+            CASIM_PROF(1);
             // ---- trySchedule (:114-135): memo, then `cnt - placed` consecutive cyclic first-fits in closed form ----
             // IsSimilarUnschedulable (:114-118).  Monotone classes: one bit per class is equivalent to the reference's
             // per-controller cache (a re-try gives the same answer); classes with spread rules: the exact cache.
@@ -439,6 +448,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                 int32_t pod_base = first + placed;
                 uint32_t last_owner_val = 0;
                 bool last_mine = false;
+                CASIM_PROF(2);
                 for (int p = 0; p < P; ++p) {
                     int m; bool valid;
                     piece_node(p, m, valid);
@@ -460,11 +470,13 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                     cum += tot_p;
                     if (cum >= keff) break;
                 }
+                CASIM_PROF(3);
                 if (cum > 0) {
                     // MarkMatch (plugin_runner.go:138): lastIndex = node of the last pod placed so far
                     last_index = (int32_t)bc.pick(last_mine, last_owner_val);
                     placed += (int32_t)(cum < keff ? cum : keff);
                 }
+                CASIM_PROF(4);
                 if (cum > 0 && cum < keff) {
                     // ---- the whole cluster was walked and pods are left: rounds 2.. over c' in closed form ----
                     const uint32_t rem = keff - cum;
@@ -537,6 +549,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                     }
                 }
             }
+            CASIM_PROF(5);
             if (placed - placed_before < (int32_t)keff) class_failed = true;   // nothing changed since: the next one fails too
             else if (i_hi > i_lo) cs::sync();                                  // counters fed by this walk are read by the next
             }  // pods of the run
@@ -558,6 +571,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
         }
     }
     }  // parts
+    CASIM_PROF(6);
     if (txn) {
         // every pod found a place <=> the node is removable (findPlaceFor :219-224)
         const bool ok = !failed;
@@ -581,7 +595,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
             }
             log_n += n_listed;
             if (tid == 0) alive[Y >> 6] &= ~(1ull << (Y & 63));
-            for (int r = tid; r < a.n_rules; r += T) {   // RemoveNodeInfo: one eligible node less in its domains
+            for (int r = tid; r < n_rules; r += T) {   // RemoveNodeInfo: one eligible node less in its domains
                 const int32_t d = a.node_domain[(int64_t)a.rule_key[r] * N + Y];
                 const int row = a.rule_elig_row[r];
                 const bool el = row < 0 || ((a.rule_elig[(int64_t)row * (a.cap >> 6) + (Y >> 6)] >> (Y & 63)) & 1ull);
@@ -591,14 +605,14 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
             n_alive--; any_dead = true;
         } else {
             // Revert: touched nodes get their committed state back, the candidate its pods and its place
-            for (int r = tid; r < a.n_rules; r += T) {   // the candidate gets its pods back
+            for (int r = tid; r < n_rules; r += T) {   // the candidate gets its pods back
                 const int32_t d = a.node_domain[(int64_t)a.rule_key[r] * N + Y], v = cs::load_relaxed_i32(a.rule_contrib + (int64_t)r * N + Y);
                 if (d >= 0 && v != 0) cs::atomic_add_i32(a.rule_cnt + a.rule_off[r] + d, v);
             }
             for (int i = tid; i < n_listed; i += T) {
                 const int m = a.node_out[slot_of(i)];
                 if (m < 0) continue;
-                if (a.n_rules > 0) {   // and the destinations lose what the reverted placements fed
+                if (n_rules > 0) {   // and the destinations lose what the reverted placements fed
                     const int ci = a.pod_class[pod_of(i)];
                     for (int ii = a.inc_off[ci]; ii < a.inc_off[ci + 1]; ++ii) {
                         const int r = a.inc_rule[ii];
@@ -627,7 +641,11 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
         if (tid == 0) a.removable_out[kc] = ok ? 1 : 0;
         cs::sync();
     }
+    CASIM_PROF(7);
     }  // transactions
+#if defined(CASIM_PACK_PROF) && !defined(CASIM_HOST_EMU)
+    if (a.prof && tid == 0) for (int i = 0; i < 8; ++i) a.prof[i] = (int64_t)prof_acc[i];
+#endif
     if (tid == 0) {
         a.out[0] = last_index;
         a.out[1] = scheduled;
@@ -752,6 +770,7 @@ public:
         a_.acceptable = q->node_acceptable ? up(q->node_acceptable, N) : nullptr;
         d_fbits_ = (uint64_t*)dalloc(8 * C * (size_t)S_);
         a_.fbits = d_fbits_;
+        if (getenv("CASIM_PACK_PROF_DUMP")) { a_.prof = (int64_t*)dalloc(64); bk_.zero(a_.prof, 64); }
         a_.node_out = (int32_t*)dalloc(4 * (P + (size_t)(cand && cand->ext_capacity > 0 ? cand->ext_capacity : 0)));
         a_.out = (int32_t*)dalloc(32);
         if (K_ > 0) {
@@ -826,8 +845,18 @@ public:
                 bk_.launch(copy_i32_kernel, (int)((contrib_total_ + 255) / 256), 1, 256, (size_t)0, a_.rule_contrib, d_contrib_init_, contrib_total_);
         }
         if (C_ > 0) bk_.launch(sched_static_kernel, S_, C_, 64, (size_t)0, dt_, d_fbits_, S_);
-        if (lds_) bk_.launch(sched_kernel<true>, 1, 1, threads_, smem_, dt_, a_);
-        else bk_.launch(sched_kernel<false>, 1, 1, threads_, smem_, dt_, a_);
+        const bool tx = K_ > 0, ru = a_.n_rules > 0;
+#define CASIM_SCHED_LAUNCH(L, X, Y) bk_.launch(sched_kernel<L, X, Y>, 1, 1, threads_, smem_, dt_, a_)
+        if (lds_) { if (tx) { if (ru) CASIM_SCHED_LAUNCH(true, true, true); else CASIM_SCHED_LAUNCH(true, true, false); }
+                    else    { if (ru) CASIM_SCHED_LAUNCH(true, false, true); else CASIM_SCHED_LAUNCH(true, false, false); } }
+        else      { if (tx) { if (ru) CASIM_SCHED_LAUNCH(false, true, true); else CASIM_SCHED_LAUNCH(false, true, false); }
+                    else    { if (ru) CASIM_SCHED_LAUNCH(false, false, true); else CASIM_SCHED_LAUNCH(false, false, false); } }
+#undef CASIM_SCHED_LAUNCH
+        if (a_.prof) {   // profiling builds: where thread 0 spent its time
+            int64_t h[8]; bk_.d2h(h, a_.prof, 64); bk_.sync();
+            fprintf(stderr, "[sched prof] ticks: records %lld hint %lld minima+origin %lld walk %lld pick %lld rounds %lld runend %lld txn %lld (runs %d)\n",
+                    (long long)h[0], (long long)h[1], (long long)h[2], (long long)h[3], (long long)h[4], (long long)h[5], (long long)h[6], (long long)h[7], n_runs_);
+        }
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
     }
 
