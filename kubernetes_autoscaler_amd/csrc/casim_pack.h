@@ -30,7 +30,7 @@
 
 // Optional phase timing (s_memtime ticks per phase, per group) for tools/prof_pack.sh builds only.
 #if defined(CASIM_PACK_PROF) && !defined(CASIM_HOST_EMU)
-#define CASIM_PROF_DECL uint64_t prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t prof_last = __builtin_amdgcn_s_memtime()
+#define CASIM_PROF_DECL uint64_t prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint64_t prof_last = __builtin_amdgcn_s_memtime()
 #define CASIM_PROF(i) do { const uint64_t _n = __builtin_amdgcn_s_memtime(); prof_acc[i] += _n - prof_last; prof_last = _n; } while (0)
 #define CASIM_PROF_STORE(p) do { if ((p) && cs::lane() == 0) for (int _i = 0; _i < 8; ++_i) (p)[(int64_t)cs::bid() * 8 + _i] = (int64_t)prof_acc[_i]; } while (0)
 #else

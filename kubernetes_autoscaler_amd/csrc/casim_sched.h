@@ -232,7 +232,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
     cs::sync();
 
     CASIM_PROF_DECL;   // phases: 0 records / loop, 1 hint, 2 minima + origin, 3 walk (round 1), 4 lastIndex pick, 5 rounds 2.., 6 run end, 7 transactions
-    int32_t last_index = a.last_index;
+    int32_t last_index = a.last_index < -1 ? -1 : a.last_index;   // (a negative origin would index out of the Go slice)
     int32_t scheduled = 0;
     int32_t runs_done = 0;
     int32_t n_alive = N;       // len(nodeInfosList)
@@ -253,10 +253,26 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
             if (pos >= lo && pos < lo + cntw) { mine = true; w_mine = (uint32_t)w; }
         }
         const uint32_t w = bc.pick(mine, w_mine);
-        uint64_t b = alive[w];
-        for (int32_t i = (int32_t)wpre[w]; i < pos; ++i) b &= b - 1;   // drop the live nodes in front
-        return (int32_t)(w << 6) + cs::ffs64(b);
+        // index of the (pos - wpre[w])-th live node of the word: binary search on popcounts
+        uint64_t x = alive[w];
+        uint32_t r = (uint32_t)(pos - (int32_t)wpre[w]);
+        int idx = 0;
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) {
+            const uint32_t cl = (uint32_t)cs::popc64(x & ((1ull << sh) - 1ull));
+            if (r >= cl) { r -= cl; x >>= sh; idx += sh; }
+        }
+        return (int32_t)(w << 6) + idx;
     };
+
+    // the loaded chunk of run records: runs [cstart, cend) of part cpart, record i in lane i - cstart
+    int cstart = 0, cend = 0, cpart = -1;
+    int32_t my_class = 0, my_count = 0, my_hint = -1, my_first = 0, my_pair = -1, my_ctrl = -1;
+    uint32_t my_flags = 0;
+    int64_t my_req[CASIM_KMAX_RES];
+    double my_rq[CASIM_KMAX_RES];
+#pragma unroll
+    for (int r = 0; r < CASIM_KMAX_RES; ++r) { my_req[r] = 0; my_rq[r] = 0.0; }
 
     const int n_tx = txn ? a.n_cand : 1;
     for (int kc = 0; kc < n_tx; ++kc) {
@@ -309,27 +325,30 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
     }
     for (int part = 0; part < (kTxn ? 2 : 1); ++part) {   // the caller's runs, then (removal loop) one run per ext pod
     const int part_lo = part == 0 ? run_lo : e_lo, part_hi = part == 0 ? run_hi : e_hi;
-    for (int k0 = part_lo; k0 < part_hi && !stop && !failed; k0 += 64) {
-        const int run_hi = part_hi;
-        const int kk = k0 + lane;
-        const bool have = kk < run_hi;
-        const int32_t my_class = !have ? 0 : part == 0 ? a.run_class[kk] : a.pod_class[a.ext_ref[kk]];
-        const int32_t my_count = !have ? 0 : part == 0 ? a.run_count[kk] : 1;
-        const int32_t my_hint = !have ? -1 : part == 0 ? a.run_hint[kk] : -1;   // its hint is the node it sits on: the candidate
-        const int32_t my_first = !have ? 0 : part == 0 ? a.run_first[kk] : a.P + kk;
-        const int32_t my_pair = (kRules && have && part == 0 && a.run_pair) ? a.run_pair[kk] : -1;
-        const int32_t my_ctrl = (kRules && have && part == 0 && a.run_ctrl) ? a.run_ctrl[kk] : -1;
-        // the class record of run kk rides along in its lane: one round trip to HBM per 64 runs, not one per run
-        int64_t my_req[CASIM_KMAX_RES];
-        double my_rq[CASIM_KMAX_RES];
+    {
+        for (int k = part_lo; k < part_hi && !stop && !failed; ++k) {
+            if (cpart != part || k < cstart || k >= cend) {
+                // 64 run records at a time, one per lane, each with its class record: one round trip to HBM per 64 runs —
+                // across candidate boundaries too (a candidate of the removal loop has one or two runs)
+                cpart = part; cstart = k;
+                const int lim = part == 0 ? a.n_runs : e_hi;
+                cend = cstart + 64 < lim ? cstart + 64 : lim;
+                const int kk = cstart + lane;
+                const bool have = kk < cend;
+                my_class = !have ? 0 : part == 0 ? a.run_class[kk] : a.pod_class[a.ext_ref[kk]];
+                my_count = !have ? 0 : part == 0 ? a.run_count[kk] : 1;
+                my_hint = !have ? -1 : part == 0 ? a.run_hint[kk] : -1;   // an ext pod's hint is the node it sits on: the candidate
+                my_first = !have ? 0 : part == 0 ? a.run_first[kk] : a.P + kk;
+                my_pair = (kRules && have && part == 0 && a.run_pair) ? a.run_pair[kk] : -1;
+                my_ctrl = (kRules && have && part == 0 && a.run_ctrl) ? a.run_ctrl[kk] : -1;
 #pragma unroll
-        for (int r = 0; r < CASIM_KMAX_RES; ++r) {
-            my_req[r] = (have && r < R) ? t.req[(int64_t)my_class * R + r] : 0;
-            my_rq[r] = my_req[r] > 0 ? 1.0 / (double)my_req[r] : 0.0;
-        }
-        const uint32_t my_flags = have ? t.pflags[my_class] : 0u;
-        const int nk = run_hi - k0 < 64 ? run_hi - k0 : 64;
-        for (int j = 0; j < nk && !stop && !failed; ++j) {
+                for (int r = 0; r < CASIM_KMAX_RES; ++r) {
+                    my_req[r] = (have && r < R) ? t.req[(int64_t)my_class * R + r] : 0;
+                    my_rq[r] = my_req[r] > 0 ? 1.0 / (double)my_req[r] : 0.0;
+                }
+                my_flags = have ? t.pflags[my_class] : 0u;
+            }
+            const int j = k - cstart;
             const int c = (int)cs::bcast_u32((uint32_t)my_class, j);
             const int32_t cnt = (int32_t)cs::bcast_u32((uint32_t)my_count, j);
             const int32_t hint = (int32_t)cs::bcast_u32((uint32_t)my_hint, j);
@@ -429,8 +448,10 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
             {
                 // The cyclic order starts at m0 = (lastIndex + 1) % N.  Pieces of T nodes in that order: chunk q0 from
                 // m0 on, the following chunks (wrapping), and last the part of chunk q0 below m0.
-                int32_t p0 = (int32_t)(((int64_t)last_index + 1) % n_alive);
-                if (p0 < 0) p0 += n_alive;
+                // (lastIndex + 1) % len(list): no division on the usual path (lastIndex is a position of the current list)
+                uint32_t u0 = (uint32_t)last_index + 1u;
+                if (u0 >= (uint32_t)n_alive) u0 %= (uint32_t)n_alive;   // rare: the list shrank, or the caller's index is stale
+                const int32_t p0 = (int32_t)u0;
                 const int32_t m0 = node_at(p0);
                 const int q0 = m0 / T;
                 const bool wrap_piece = (m0 % T) != 0;
@@ -453,11 +474,15 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                     int m; bool valid;
                     piece_node(p, m, valid);
                     uint32_t cj = 0;
-                    if (valid && (((fb[m >> 6] & scanb[m >> 6]) >> lane) & 1ull) && (r_hi == r_lo || rule_ok(m))) cj = st.capacity(0, m, pv, keff, selfx);
+                    const bool elig = valid && (((fb[m >> 6] & scanb[m >> 6]) >> lane) & 1ull);
+                    CASIM_PROF(8);    // piece setup + static word
+                    if (elig && (r_hi == r_lo || rule_ok(m))) cj = st.capacity(0, m, pv, keff, selfx);
                     const bool fit = cj > 0;
                     const uint64_t b = cs::ballot(fit);
+                    CASIM_PROF(9);    // capacity
                     uint32_t tot_p, before;
                     bc.count_prefix((uint32_t)cs::popc64(b), tot_p, before);
+                    CASIM_PROF(10);   // block prefix (barrier)
                     const uint32_t rank = cum + before + (uint32_t)cs::mbcnt(b);
                     const bool gets = fit && rank < keff;
                     if (gets) { a.node_out[pod_base + (int32_t)rank] = m; commit_pods(m, 1u); }
@@ -468,6 +493,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                         if (last_mine) last_owner_val = (uint32_t)rank_of(m);
                     }
                     cum += tot_p;
+                    CASIM_PROF(11);   // placement: node_out, commit, c'
                     if (cum >= keff) break;
                 }
                 CASIM_PROF(3);
@@ -644,7 +670,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
     CASIM_PROF(7);
     }  // transactions
 #if defined(CASIM_PACK_PROF) && !defined(CASIM_HOST_EMU)
-    if (a.prof && tid == 0) for (int i = 0; i < 8; ++i) a.prof[i] = (int64_t)prof_acc[i];
+    if (a.prof && tid == 0) for (int i = 0; i < 12; ++i) a.prof[i] = (int64_t)prof_acc[i];
 #endif
     if (tid == 0) {
         a.out[0] = last_index;
@@ -770,7 +796,7 @@ public:
         a_.acceptable = q->node_acceptable ? up(q->node_acceptable, N) : nullptr;
         d_fbits_ = (uint64_t*)dalloc(8 * C * (size_t)S_);
         a_.fbits = d_fbits_;
-        if (getenv("CASIM_PACK_PROF_DUMP")) { a_.prof = (int64_t*)dalloc(64); bk_.zero(a_.prof, 64); }
+        if (getenv("CASIM_PACK_PROF_DUMP")) { a_.prof = (int64_t*)dalloc(96); bk_.zero(a_.prof, 96); }
         a_.node_out = (int32_t*)dalloc(4 * (P + (size_t)(cand && cand->ext_capacity > 0 ? cand->ext_capacity : 0)));
         a_.out = (int32_t*)dalloc(32);
         if (K_ > 0) {
@@ -853,9 +879,10 @@ public:
                     else    { if (ru) CASIM_SCHED_LAUNCH(false, false, true); else CASIM_SCHED_LAUNCH(false, false, false); } }
 #undef CASIM_SCHED_LAUNCH
         if (a_.prof) {   // profiling builds: where thread 0 spent its time
-            int64_t h[8]; bk_.d2h(h, a_.prof, 64); bk_.sync();
-            fprintf(stderr, "[sched prof] ticks: records %lld hint %lld minima+origin %lld walk %lld pick %lld rounds %lld runend %lld txn %lld (runs %d)\n",
-                    (long long)h[0], (long long)h[1], (long long)h[2], (long long)h[3], (long long)h[4], (long long)h[5], (long long)h[6], (long long)h[7], n_runs_);
+            int64_t h[12]; bk_.d2h(h, a_.prof, 96); bk_.sync();
+            fprintf(stderr, "[sched prof] ticks: records %lld hint %lld minima+origin %lld walk-rest %lld pick %lld rounds %lld runend %lld txn %lld | piece: setup %lld capacity %lld prefix %lld place %lld (runs %d)\n",
+                    (long long)h[0], (long long)h[1], (long long)h[2], (long long)h[3], (long long)h[4], (long long)h[5], (long long)h[6], (long long)h[7],
+                    (long long)h[8], (long long)h[9], (long long)h[10], (long long)h[11], n_runs_);
         }
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
     }
