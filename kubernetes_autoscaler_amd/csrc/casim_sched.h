@@ -56,7 +56,6 @@ struct SchedArgs {
     const int32_t* cand_run_off;  // [K+1] runs of candidate k
     const int32_t* cand_pod_off;  // [K+1] pods of candidate k in node_out
     uint8_t* removable_out;       // [K] 1 removable / 0 no place (pre-filled with 2 = not evaluated)
-    uint8_t* arrived;             // [cap] node received pods of a committed removal (zeroed)
     char* committed;              // HBM: last committed sfree / sexcl / sslots (same layout as the working copy)
     // pods that a committed removal moved onto a later candidate are listed again by that candidate ("ext" pods)
     int32_t P, ext_cap;           // pods in the caller's flat list; room for ext pods (node_out has P + ext_cap entries)
@@ -161,7 +160,7 @@ struct BlockCtl {
 
 // LDS control block: collective cells, the memo bits and (transactions only) the alive words + their rank prefix
 CS_HOST_DEVICE int64_t casim_sched_ctrl_bytes(int memo_classes, int alive_words) {
-    return 2 * 16 * 8 + 2 * 16 * 4 + 16 + ((4ll * ((memo_classes + 31) / 32) + 7) & ~7ll) + 12ll * alive_words + (alive_words & 1 ? 4 : 0);
+    return 2 * 16 * 8 + 2 * 16 * 4 + 16 + ((4ll * ((memo_classes + 31) / 32) + 7) & ~7ll) + 20ll * alive_words + (alive_words & 1 ? 4 : 0);
 }
 inline int64_t casim_sched_state_bytes(int R, int Wx, int64_t cap) {
     return cap * (8ll * R + 8ll * Wx + 12ll) + 2ll * 8ll * (cap / 64);
@@ -191,7 +190,8 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
     constexpr bool txn = kTxn;
     const int nw = txn ? a.cap >> 6 : 0;
     uint64_t* alive = (uint64_t*)((char*)memo + ((4ll * ((a.memo_classes + 31) / 32) + 7) & ~7ll));  // [nw]
-    uint32_t* wpre = (uint32_t*)(alive + nw);                                                           // [nw]
+    uint64_t* arrivedb = alive + nw;                                                                    // [nw] node took pods of a committed removal
+    uint32_t* wpre = (uint32_t*)(arrivedb + nw);                                                        // [nw]
     Store st;
     st.R = R; st.Wx = Wx; st.cap = a.cap;
     char* base = kLds ? smem + casim_sched_ctrl_bytes(a.memo_classes, nw) : a.gstate;
@@ -225,7 +225,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
             for (int w = 0; w < Wx; ++w) cexcl[(int64_t)w * st.cap + m] = st.sexcl[(int64_t)w * st.cap + m];
             cslots[m] = st.sslots[m];
             const uint64_t lb = cs::ballot(live);
-            if (lane == 0) { alive[m >> 6] = lb; wpre[m >> 6] = (uint32_t)((m >> 6) << 6) < (uint32_t)N ? (uint32_t)((m >> 6) << 6) : (uint32_t)N; }
+            if (lane == 0) { arrivedb[m >> 6] = 0ull; alive[m >> 6] = lb; wpre[m >> 6] = (uint32_t)((m >> 6) << 6) < (uint32_t)N ? (uint32_t)((m >> 6) << 6) : (uint32_t)N; }
         }
     }
     for (int i = tid; i < (a.memo_classes + 31) / 32; i += T) memo[i] = 0u;
@@ -265,6 +265,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
         return (int32_t)(w << 6) + idx;
     };
 
+    int32_t my_cand = 0, my_rlo = 0, my_rhi = 0, my_plo = 0, my_phi = 0;   // candidate records kc & ~63 .. of the removal loop
     // the loaded chunk of run records: runs [cstart, cend) of part cpart, record i in lane i - cstart
     int cstart = 0, cend = 0, cpart = -1;
     int32_t my_class = 0, my_count = 0, my_hint = -1, my_first = 0, my_pair = -1, my_ctrl = -1;
@@ -281,8 +282,15 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
     if (txn) {
         // ---- SimulateNodeRemoval (cluster.go:131-172) of candidate kc, planner order (planner.go:300-330) ----
         if (a.max_removable > 0 && removed >= a.max_removable) break;
-        Y = a.cand_node[kc];
-        if (a.arrived[Y]) {
+        if ((kc & 63) == 0) {   // candidate records ride in the lanes too: 64 per round trip
+            const int kk = kc + lane;
+            const bool have = kk < a.n_cand;
+            my_cand = have ? a.cand_node[kk] : 0;
+            my_rlo = have ? a.cand_run_off[kk] : 0; my_rhi = have ? a.cand_run_off[kk + 1] : 0;
+            my_plo = have ? a.cand_pod_off[kk] : 0; my_phi = have ? a.cand_pod_off[kk + 1] : 0;
+        }
+        Y = (int)cs::bcast_u32((uint32_t)my_cand, kc & 63);
+        if ((arrivedb[Y >> 6] >> (Y & 63)) & 1ull) {
             // Earlier committed removals moved pods onto this node: GetPodsToMove now lists them after the node's own
             // pods, in arrival order == commit order (NodeInfo.AddPod appends).  A sticky pod (PDB, drain rule) or a
             // full ext table hands the rest of the loop back to the caller.
@@ -307,7 +315,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
             e_lo = ext_n; e_hi = ext_n + (int32_t)base_n; ext_n = e_hi;
         }
         cand_done = kc + 1;
-        run_lo = a.cand_run_off[kc]; run_hi = a.cand_run_off[kc + 1];
+        run_lo = (int)cs::bcast_u32((uint32_t)my_rlo, kc & 63); run_hi = (int)cs::bcast_u32((uint32_t)my_rhi, kc & 63);
         break_on_failure = true;
         if (!((alive[Y >> 6] >> (Y & 63)) & 1ull)) {   // NoNodeInfo (:139-147)
             if (tid == 0) a.removable_out[kc] = 0;
@@ -601,7 +609,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
     if (txn) {
         // every pod found a place <=> the node is removable (findPlaceFor :219-224)
         const bool ok = !failed;
-        const int p_lo = a.cand_pod_off[kc], p_hi = a.cand_pod_off[kc + 1];
+        const int p_lo = (int)cs::bcast_u32((uint32_t)my_plo, kc & 63), p_hi = (int)cs::bcast_u32((uint32_t)my_phi, kc & 63);
         const int n_own = p_hi - p_lo, n_listed = n_own + (e_hi - e_lo);
         // i-th listed pod of this candidate -> its slot in node_out / its flat pod index
         auto slot_of = [&](int i) -> int { return i < n_own ? p_lo + i : a.P + e_lo + (i - n_own); };
@@ -615,7 +623,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                 for (int r = 0; r < R; ++r) cfree[(int64_t)r * st.cap + m] = st.sfree[(int64_t)r * st.cap + m];
                 for (int w = 0; w < Wx; ++w) cexcl[(int64_t)w * st.cap + m] = st.sexcl[(int64_t)w * st.cap + m];
                 cslots[m] = st.sslots[m];
-                a.arrived[m] = 1;
+                cs::lds_or_u64(arrivedb + (m >> 6), 1ull << (m & 63));
                 a.log_ref[log_n + i] = pod_of(i);
                 a.log_dest[log_n + i] = m;
             }
@@ -806,7 +814,6 @@ public:
             a_.cand_run_off = up(cro.data(), cro.size());
             a_.cand_pod_off = up(cand->pod_offsets, (size_t)K_ + 1);
             a_.removable_out = (uint8_t*)dalloc((size_t)K_);
-            a_.arrived = (uint8_t*)dalloc((size_t)cap_);
             E_ = cand->ext_capacity > 0 ? cand->ext_capacity : 0;
             a_.P = P_; a_.ext_cap = E_;
             a_.pod_class = up(q->pod_class, P);
@@ -862,7 +869,7 @@ public:
         if (trivial_) return CASIM_OK;
         if (!ready_) return fail(CASIM_ERR_INVALID, "scheduler not initialised");
         if (P_ + E_ > 0) bk_.launch(fill_i32_kernel, (P_ + E_ + 255) / 256, 1, 256, (size_t)0, a_.node_out, (int64_t)(P_ + E_), (int32_t)-1);
-        if (K_ > 0) { bk_.fill8(a_.removable_out, 2, (size_t)K_); bk_.zero(a_.arrived, (size_t)cap_); }
+        if (K_ > 0) bk_.fill8(a_.removable_out, 2, (size_t)K_);
         if (n_pairs_ > 0) { bk_.zero(a_.pair_memo, 4 * n_pairs_); bk_.zero(a_.ctrl_count, 4 * n_ctrl_); }
         if (rule_total_ > 0) {
             bk_.launch(copy_i32_kernel, (int)((rule_total_ + 255) / 256), 1, 256, (size_t)0, a_.rule_cnt, d_rule_init_, rule_total_);
