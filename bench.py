@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--cap", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the TrySchedulePods / node-removal side measurements")
     args = ap.parse_args()
 
     import torch
@@ -230,6 +231,38 @@ def main():
                                                  "kernel_ms": ms, "algorithmic_bytes_per_launch": dbytes}
             except Exception as e:  # the probe must never take the headline number down
                 extra["roofline_dense_check"] = {"error": str(e)}
+        # the callers either side of the path, one mid-size case each: resident tables, HIP-event time
+        if not args.no_next_rows:
+            try:
+                from kubernetes_autoscaler_amd.scheduling import encode_pending_pods
+                w1 = workloads.pending_scale(5000, 50000, 64, 2)
+                e1, pc1 = encode_pending_pods(w1.nodes, w1.pods)
+                _, _, _, ns1 = ctx.try_schedule_pods(e1.pegs, e1.groups, pc1)
+                _, ms1 = ctx.try_schedule_pods(e1.pegs, e1.groups, pc1, time_iters=5)
+                e1.close()
+                extra["try_schedule_pods"] = {"workload": w1.name, "nodes": len(w1.nodes), "pending_pods": len(w1.pods), "scheduled": int(ns1),
+                                              "kernels_ms": ms1, "pods_per_s": len(w1.pods) / (ms1 * 1e-3)}
+                w2 = workloads.removal_scale(5000, pods_per_node=12, frac_candidates=0.3, seed=1)
+                e2 = kaa.Encoder(explicit_self_exclusion=True)
+                cls, pcl, off = {}, [], [0]
+                for c in w2.candidates:
+                    for p in w2.nodes[c].pods:
+                        k = p.spec_key()
+                        if k not in cls:
+                            cls[k] = e2.add_peg(kaa.PodEquivalenceGroup(pods=[p]))
+                        pcl.append(cls[k])
+                    off.append(len(pcl))
+                for info in w2.nodes:
+                    e2.add_group(info, pegs=[])
+                e2.finalize()
+                r2 = ctx.simulate_node_removals(e2.pegs, e2.groups, w2.candidates, off, pcl)
+                _, ms2 = ctx.simulate_node_removals(e2.pegs, e2.groups, w2.candidates, off, pcl, time_iters=5)
+                e2.close()
+                extra["node_removals"] = {"workload": w2.name, "nodes": len(w2.nodes), "candidates": len(w2.candidates),
+                                          "removable": int((r2.removable == 1).sum()), "kernels_ms": ms2,
+                                          "candidates_per_s": len(w2.candidates) / (ms2 * 1e-3)}
+            except Exception as e:  # must never take the headline number down
+                extra["next_rows_error"] = str(e)
         try:
             extra["copy_bandwidth_gbps"] = ctx.copy_bandwidth_gbps(1 << 30, 10)
         except Exception as e:

@@ -30,14 +30,14 @@ tail -5 "$OUT/bench.err" | tee -a "$OUT/summary.txt"
 if [ "$MODE" = "full" ]; then
   echo "== rocprofv3 kernel trace ==" | tee -a "$OUT/summary.txt"
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --truncate-kernels -d "$OLDPWD/$OUT/prof_trace" -o trace -- \
-      python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$OLDPWD/$OUT/prof_trace.log" 2>&1)
+      python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-next-rows > "$OLDPWD/$OUT/prof_trace.log" 2>&1)
   echo "trace exit $?" | tee -a "$OUT/summary.txt"
   find "$OUT/prof_trace" -name "*kernel_stats*" | head -3 | while read f; do echo "--- $f"; head -15 "$f"; done | tee -a "$OUT/summary.txt"
   for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"; do
     N=$(echo $C | tr ' ' '_' | cut -c1-24)
     echo "== rocprofv3 pmc $C ==" | tee -a "$OUT/summary.txt"
     (cd /tmp && timeout 900 rocprofv3 --pmc $C --kernel-trace -d "$OLDPWD/$OUT/prof_pmc_$N" -o pmc -- \
-        python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-dense > "$OLDPWD/$OUT/prof_pmc_$N.log" 2>&1)
+        python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-dense --no-next-rows > "$OLDPWD/$OUT/prof_pmc_$N.log" 2>&1)
     echo "pmc $N exit $?" | tee -a "$OUT/summary.txt"
   done
   python tools/summarize_pmc.py "$OUT" 2>&1 | tee -a "$OUT/summary.txt"
