@@ -110,7 +110,9 @@ int orc_run_filters_until_passing(orc* o, int pod, int* last_index);
  * Pending pods against the nodes ALREADY in the snapshot (filter-out-schedulable).
  * pod[i]          pod spec of the i-th pending pod (processing order)
  * hint[i]         snapshot index of the hinted node or -1                     (hints.go)
- * similar_key[i]  >= 0: controller-equivalence key for SimilarPodsScheduling, -1: no controller
+ * similar_key[i]  >= 0: controller-equivalence key for SimilarPodsScheduling, -1: no controller; a cached entry is a pod
+ *                 spec id, so pods with equal spec + labels must be passed with ONE id (the reference matches by
+ *                 PodSpecSemanticallyEqual + DeepEqual(labels), similar_pods.go:48-50)
  * acceptable      [snapshot size] IsNodeAcceptable per node, or NULL = every node
  * node_out[i]     snapshot index the pod was scheduled on, -1 if it stays pending
  * Pods are committed to the snapshot (the caller forks; see orc_snapshot_truncate). Returns the

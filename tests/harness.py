@@ -180,7 +180,11 @@ def sched_oracle(case: SchedCase):
     for info in case.nodes:
         s.add_existing(info)
     sk = similar_keys(case.pods)
-    out = s.try_schedule_pods(case.pods, case.hints, sk, case.acceptable, case.break_on_failure, case.last_index)
+    # the oracle's SimilarPodsScheduling entry is a pod spec id: equal specs (+ labels) must share one id, like the
+    # reference's PodSpecSemanticallyEqual / DeepEqual(labels) match (similar_pods.go:48-50)
+    canon = {}
+    pods = [canon.setdefault(p.spec_key(), p) for p in case.pods]
+    out = s.try_schedule_pods(pods, case.hints, sk, case.acceptable, case.break_on_failure, case.last_index)
     s.close()
     return out
 

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""One-off randomized stress on the MI355X with seeds the test suites do not use: every device path against the oracle.
+Usage: stress_gpu.py [first_seed] [count]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import kubernetes_autoscaler_amd as kaa  # noqa: E402
+from kubernetes_autoscaler_amd import workloads as W  # noqa: E402
+from harness import (GroupSpec, RemovalCase, Scenario, SchedCase, assert_cluster_estimate_matches, assert_matches_oracle,  # noqa: E402
+                     assert_removal_matches, assert_sched_matches, cluster_estimate_gpu, encode, removal_device, removal_oracle,
+                     run_gpu, run_oracle, sched_gpu, sched_oracle)
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 500
+ctx = kaa.Context(0)
+t0 = time.time()
+stats = {}
+
+
+def bump(k):
+    stats[k] = stats.get(k, 0) + 1
+
+
+def scen(w, **kw):
+    return Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing,
+                    lanes=w.lanes, **kw)
+
+
+for seed in range(first, first + count):
+    for gen in (W.fuzz_pending, W.fuzz_pending_domains):
+        w = gen(seed)
+        sc = SchedCase(nodes=w.nodes, pods=w.pods, hints=w.hints, acceptable=w.acceptable, break_on_failure=w.break_on_failure, last_index=w.last_index)
+        assert_sched_matches(sched_gpu(sc, ctx), sched_oracle(sc), w.name); bump(gen.__name__)
+    for gen in (W.fuzz_removals, W.fuzz_removals_domains):
+        w = gen(seed)
+        rc = RemovalCase(nodes=w.nodes, candidates=w.candidates, destination=w.destination, hints=w.hints, persist=w.persist,
+                         max_removable=w.max_removable, last_index=w.last_index)
+        assert_removal_matches(removal_device(rc, ctx), removal_oracle(rc), w.name); bump(gen.__name__)
+    w = W.fuzz_estimate_domains(seed)
+    sc = scen(w)
+    got = cluster_estimate_gpu(sc, ctx)
+    if got[0] == 0:
+        est, ids = run_oracle(sc)[0]
+        assert_cluster_estimate_matches(got, est, ids, w.name); bump("fuzz_estimate_domains")
+    else:
+        bump("fuzz_estimate_domains_delegated")
+    for fast in (False, True):
+        w = W.fuzz(seed)
+        sc = scen(w, fastpath=fast)
+        res, _ = run_gpu(encode(sc), ctx, fastpath=fast)
+        assert_matches_oracle(res, run_oracle(sc), w.name); bump(f"fuzz_packer_fast{int(fast)}")
+print("stress OK", stats, f"{time.time() - t0:.0f} s")
+ctx.close()
