@@ -194,3 +194,29 @@ def test_removal_fuzz_domain_rules(ctx):
         case = RemovalCase(nodes=w.nodes, candidates=w.candidates, destination=w.destination, hints=w.hints, persist=w.persist,
                            max_removable=w.max_removable, last_index=w.last_index)
         assert_removal_matches(removal_device(case, ctx), removal_oracle(case), w.name)
+
+
+def test_domain_rules_at_scale(ctx):
+    """2000 nodes in 3 zones, 5000 pending pods of 16 controller specs, half of them with a zone or hostname spread
+    constraint (per-pod walks, block-wide minima over 2000 hostname domains) — and the removal loop on the same cluster."""
+    from harness import RemovalCase, assert_removal_matches, removal_device, removal_oracle
+    from kubernetes_autoscaler_amd.objects import LABEL_ZONE, TopologySpreadConstraint
+    w = pending_scale(2000, 5000, n_classes=16, seed=21)
+    for p in w.pods:
+        c = int(p.labels["app"][1:])
+        if c % 4 == 0:
+            p.spread_constraints = [TopologySpreadConstraint(2, LABEL_ZONE, 0, dict(p.labels))]
+        elif c % 4 == 1:
+            p.spread_constraints = [TopologySpreadConstraint(1, "kubernetes.io/hostname", 0, dict(p.labels))]
+        p.topology_spread = bool(p.spread_constraints)
+    sc = case_of(w)
+    got, want = sched_gpu(sc, ctx), sched_oracle(sc)
+    assert want[2] > 2000
+    assert_sched_matches(got, want, w.name)
+    # removal loop: the placed spread pods now RUN on the cluster; the 200 emptiest nodes are candidates
+    for p, m in zip(w.pods, got[1]):
+        if m >= 0:
+            w.nodes[m].pods.append(p)
+    util = sorted(range(len(w.nodes)), key=lambda i: (sum(q.requests["cpu"] for q in w.nodes[i].pods), i))
+    case = RemovalCase(nodes=w.nodes, candidates=util[:200])
+    assert_removal_matches(removal_device(case, ctx), removal_oracle(case), "removals with spread pods")
