@@ -56,6 +56,7 @@ struct PegView {
     double rq[RMAX];  // 1 / req: quotient estimate of capacity_of
     const uint64_t* xblock;
     const uint64_t* xmark;
+    uint64_t xb[2], xm[2];  // first words of each, cached for the register store (up to two exclusion words)
 };
 template <class L, int RMAX>
 struct FreshNode {
@@ -124,6 +125,7 @@ struct MemStore {
     static constexpr int kNPT = 0;          // 0 = runtime slot count
     static constexpr int kRMax = CASIM_KMAX_RES;
     static constexpr bool kHasExcl = true;
+    static constexpr bool kHasZone = true;
     using Peg = PegView<int64_t, CASIM_KMAX_RES>;
     using Fresh = FreshNode<int64_t, CASIM_KMAX_RES>;
     int R, Wx, cap;
@@ -167,20 +169,30 @@ struct MemStore {
 };
 
 // ---- node store: int32 state in VGPRs (fast path) ---------------------------------------------------
-template <int R_, int NPT_>
+template <int R_, int NPT_, int WX_ = 0>
 struct RegStore {
     using Lane = int32_t;
     static constexpr int kNPT = NPT_;
     static constexpr int kRMax = R_;
-    static constexpr bool kHasExcl = false;
+    static constexpr bool kHasExcl = WX_ > 0;   // WX_ = 1 or 2 words of node-local exclusion bits (host ports, hostname anti-affinity)
+    static constexpr bool X_ = WX_ > 0;
+    static constexpr bool kHasZone = false;
     using Peg = PegView<int32_t, R_>;
     using Fresh = FreshNode<int32_t, R_>;
     int32_t fr[NPT_][R_];
+    uint64_t excl[NPT_][WX_ > 0 ? WX_ : 1];
+    CS_DEVICE bool blocked(int s, const Peg& pv) const {
+        bool b = false;
+#pragma unroll
+        for (int w = 0; w < WX_; ++w) b = b || (excl[s][w] & pv.xb[w]) != 0;
+        return b;
+    }
     int32_t slots[NPT_];
     uint32_t c[NPT_];
     int32_t fresh_slots;  // pod slots of an empty node: pods on a node = fresh_slots - slots (no per-node counter)
 
     CS_DEVICE uint32_t capacity(int s, int, const Peg& pv, uint32_t clampk, bool selfx) const {
+        if (X_ && blocked(s, pv)) return 0;   // NodePorts / hostname anti-affinity
         uint32_t k = capacity_lanes<Lane, R_>(fr[s], slots[s], R_, pv, clampk);
         if (selfx && k > 1) k = 1;
         return k;
@@ -195,6 +207,7 @@ struct RegStore {
 #pragma unroll
         for (int s = 0; s < NPT_; ++s) {
             bool fit = slots[s] > 0;
+            if (X_) fit = fit && !blocked(s, pv);
 #pragma unroll
             for (int r = 0; r < R_; ++r) fit = fit && (pv.req[r] <= 0 || fr[s][r] >= pv.req[r]);
             const uint64_t fb = cs::ballot(fit);
@@ -229,11 +242,15 @@ struct RegStore {
 #pragma unroll
         for (int r = 0; r < R_; ++r) fr[s][r] -= (int32_t)x * pv.req[r];
         slots[s] -= (int32_t)x;
+#pragma unroll
+        for (int w = 0; w < WX_; ++w) excl[s][w] |= pv.xm[w];
     }
     CS_DEVICE void create(int s, int, uint32_t x, const Peg& pv, const Fresh& fn) {
 #pragma unroll
         for (int r = 0; r < R_; ++r) fr[s][r] = fn.free[r] - (int32_t)x * pv.req[r];
         slots[s] = fn.slots - (int32_t)x;
+#pragma unroll
+        for (int w = 0; w < WX_; ++w) excl[s][w] = fn.excl[w] | (x > 0 ? pv.xm[w] : 0ull);
     }
     CS_DEVICE uint32_t get_c(int s, int) const { return c[s]; }
     CS_DEVICE void set_c(int s, int, uint32_t v) { c[s] = v; }
@@ -328,7 +345,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     const int lane = cs::lane();
     const int R = t.R;
     const int Wx = Store::kHasExcl ? t.Wx : 0;
-    const int Wz = Store::kHasExcl ? t.Wz : 0;
+    const int Wz = Store::kHasZone ? t.Wz : 0;
     const int off = t.peg_off[ng];
     const int Gn = t.peg_off[ng + 1] - off;
 
@@ -383,12 +400,16 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             const bool selfx = (pf & CASIM_PEG_SELF_EXCL_NODE) != 0;
             bool zselfx = (pf & CASIM_PEG_SELF_EXCL_ZONE) != 0;
             const bool static_ok = (pf & CASIM_KFLAG_STATIC_OK) != 0;
-            pv.xblock = nullptr; pv.xmark = nullptr;
+            pv.xblock = nullptr; pv.xmark = nullptr; pv.xb[0] = pv.xb[1] = 0; pv.xm[0] = pv.xm[1] = 0;
             const uint64_t *zblock = nullptr, *zmark = nullptr;
             if (Wx > 0 || Wz > 0) {
                 const int g = (int)cs::bcast_u32((uint32_t)my_g, j);
                 pv.xblock = t.xblock + (int64_t)g * Wx; pv.xmark = t.xmark + (int64_t)g * Wx;
                 zblock = t.zblock + (int64_t)g * Wz; zmark = t.zmark + (int64_t)g * Wz;
+                if (Store::kNPT > 0 && Wx > 0) {   // register store: the words travel in SGPRs
+                    pv.xb[0] = pv.xblock[0]; pv.xm[0] = pv.xmark[0];
+                    if (Wx > 1) { pv.xb[1] = pv.xblock[1]; pv.xm[1] = pv.xmark[1]; }
+                }
             }
             bool zblocked = false;
             for (int w = 0; w < Wz; ++w) {
@@ -682,20 +703,22 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void pack_kernel(DevTables t, DevResults res, 
 }
 
 // ---- fast kernel: int32 gcd-scaled lanes, node state in VGPRs, no exclusion masks ----------------
-// Launched only when the host proved the batch eligible (casim_pipeline.h): Wx == Wz == 0, R <= R_,
-// every scaled value < 2^31 and every group's node bound <= 64 * NPT_.
-template <int R_, int NPT_>
+// Launched only when the host proved the batch eligible (casim_pipeline.h): Wx <= 2 (WX_ exclusion words per node, two
+// VGPRs each), Wz == 0, R <= R_, every scaled value < 2^31 and every group's node bound <= 64 * NPT_.
+template <int R_, int NPT_, int WX_>
 // launch bounds (64, 1): let the register allocator take what it needs — forcing 5 waves/SIMD (<= 96
 // VGPRs) spilled ~200 B/lane to scratch and halved the throughput on MI355X (r01 measurement)
-CS_GLOBAL CS_LAUNCH_BOUNDS(64, (NPT_ == 4 ? CASIM_FAST_WAVES : 1)) void pack_fast_kernel(DevTables t, DevResults res, FastScratch fs) {
+CS_GLOBAL CS_LAUNCH_BOUNDS(64, ((NPT_ == 4 && WX_ == 0) ? CASIM_FAST_WAVES : 1)) void pack_fast_kernel(DevTables t, DevResults res, FastScratch fs) {
     if (pack_unsupported(t, res)) return;
     const int ng = cs::bid();
-    RegStore<R_, NPT_> st;
+    RegStore<R_, NPT_, WX_> st;
 #pragma unroll
     for (int s = 0; s < NPT_; ++s) {
 #pragma unroll
         for (int r = 0; r < R_; ++r) st.fr[s][r] = 0;
         st.slots[s] = 0; st.c[s] = 0;
+#pragma unroll
+        for (int w = 0; w < WX_; ++w) st.excl[s][w] = 0;
     }
     st.reset_bounds();
     FreshNode<int32_t, R_> fn;
@@ -703,7 +726,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, (NPT_ == 4 ? CASIM_FAST_WAVES : 1)) void pack_fas
     for (int r = 0; r < R_; ++r) fn.free[r] = r < t.R ? fs.fresh32[(int64_t)ng * t.R + r] : 0;
     fn.slots = t.allowed[ng] - t.init_pods[ng];
     st.fresh_slots = fn.slots;
-    fn.excl = nullptr;
+    fn.excl = WX_ > 0 ? t.init_excl + (int64_t)ng * t.Wx : nullptr;
     const int32_t* req32 = fs.req32;
     const int32_t* order = res.order;
     const int R = t.R;

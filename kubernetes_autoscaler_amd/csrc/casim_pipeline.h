@@ -134,7 +134,8 @@ public:
             int32_t maxcap = 0;
             for (size_t i = 0; i < NG; ++i) maxcap = cap[i] > maxcap ? cap[i] : maxcap;
             bool ok = o ? o->force_generic_packer == 0 : true;
-            ok = ok && dt_.Wx == 0 && dt_.Wz == 0 && R <= 4 && maxcap <= 64 * 16 && NG > 0;
+            ok = ok && dt_.Wx <= 2 && dt_.Wz == 0 && R <= 4 && maxcap <= 64 * 16 && NG > 0;
+            fast_wx_ = dt_.Wx;
             std::vector<int64_t> scale((size_t)R, 0);
             auto gcd64 = [](int64_t a, int64_t b) { if (a < 0) a = -a; if (b < 0) b = -b; while (b) { const int64_t x = a % b; a = b; b = x; } return a; };
             if (ok) {
@@ -221,15 +222,12 @@ public:
         if (NG_ == 0) return CASIM_OK;
         if (fast_npt_ > 0) {
             // register-resident int32 packer (no LDS): pick the instantiation by lanes and node bound
-            if (fast_r_ == 2) {
-                if (fast_npt_ == 1) bk_.launch(pack_fast_kernel<2, 1>, NG_, 1, 64, (size_t)0, dt_, dr_, fs_);
-                else if (fast_npt_ == 4) bk_.launch(pack_fast_kernel<2, 4>, NG_, 1, 64, (size_t)0, dt_, dr_, fs_);
-                else bk_.launch(pack_fast_kernel<2, 16>, NG_, 1, 64, (size_t)0, dt_, dr_, fs_);
-            } else {
-                if (fast_npt_ == 1) bk_.launch(pack_fast_kernel<4, 1>, NG_, 1, 64, (size_t)0, dt_, dr_, fs_);
-                else if (fast_npt_ == 4) bk_.launch(pack_fast_kernel<4, 4>, NG_, 1, 64, (size_t)0, dt_, dr_, fs_);
-                else bk_.launch(pack_fast_kernel<4, 16>, NG_, 1, 64, (size_t)0, dt_, dr_, fs_);
-            }
+#define CASIM_FAST_LAUNCH(R, N, X) bk_.launch(pack_fast_kernel<R, N, X>, NG_, 1, 64, (size_t)0, dt_, dr_, fs_)
+#define CASIM_FAST_PICK(R, X) do { if (fast_npt_ == 1) CASIM_FAST_LAUNCH(R, 1, X); else if (fast_npt_ == 4) CASIM_FAST_LAUNCH(R, 4, X); else CASIM_FAST_LAUNCH(R, 16, X); } while (0)
+            if (fast_r_ == 2) { if (fast_wx_ == 2) CASIM_FAST_PICK(2, 2); else if (fast_wx_ == 1) CASIM_FAST_PICK(2, 1); else CASIM_FAST_PICK(2, 0); }
+            else              { if (fast_wx_ == 2) CASIM_FAST_PICK(4, 2); else if (fast_wx_ == 1) CASIM_FAST_PICK(4, 1); else CASIM_FAST_PICK(4, 0); }
+#undef CASIM_FAST_PICK
+#undef CASIM_FAST_LAUNCH
             if (fs_.prof) {  // profiling builds: mean ticks per phase over the groups
                 std::vector<int64_t> h((size_t)NG_ * 8);
                 bk_.d2h(h.data(), fs_.prof, h.size() * 8); bk_.sync();
@@ -369,6 +367,7 @@ private:
     int G_ = 0, NG_ = 0, Wg_ = 0, fast_npt_ = 0, fast_r_ = 0;
     int32_t nnz_cap_ = 0;
     bool csr_on_device_ = false, pack_lds_ = true, order_lds_ = true, ready_ = false, ran_ = false;
+    int fast_wx_ = 0;
     size_t pack_smem_ = 0, order_smem_ = 0;
     uint64_t* d_bits_ = nullptr; int32_t* d_counts_ = nullptr; int32_t* d_off_ = nullptr; int32_t* d_idx_ = nullptr;
     uint8_t* d_opt_set_ = nullptr; int32_t* d_opt_out_ = nullptr; int64_t* d_opt_key_ = nullptr;
