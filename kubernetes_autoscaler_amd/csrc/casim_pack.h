@@ -126,6 +126,7 @@ struct MemStore {
     static constexpr int kRMax = CASIM_KMAX_RES;
     static constexpr bool kHasExcl = true;
     static constexpr bool kHasZone = true;
+    static constexpr int kZoneWords = 0;    // group-wide exclusion words live in LDS (per-lane copies), any number
     using Peg = PegView<int64_t, CASIM_KMAX_RES>;
     using Fresh = FreshNode<int64_t, CASIM_KMAX_RES>;
     int R, Wx, cap;
@@ -176,11 +177,13 @@ struct RegStore {
     static constexpr int kRMax = R_;
     static constexpr bool kHasExcl = WX_ > 0;   // WX_ = 1 or 2 words of node-local exclusion bits (host ports, hostname anti-affinity)
     static constexpr bool X_ = WX_ > 0;
-    static constexpr bool kHasZone = false;
+    static constexpr bool kHasZone = WX_ > 0;   // the lean instantiation (WX_ = 0) carries no exclusion state at all
+    static constexpr int kZoneWords = 2;        // group-wide exclusion words are wave-uniform: up to two, in scalar registers
     using Peg = PegView<int32_t, R_>;
     using Fresh = FreshNode<int32_t, R_>;
     int32_t fr[NPT_][R_];
     uint64_t excl[NPT_][WX_ > 0 ? WX_ : 1];
+    int wx = 0;   // words the batch really has (<= WX_)
     CS_DEVICE bool blocked(int s, const Peg& pv) const {
         bool b = false;
 #pragma unroll
@@ -250,7 +253,7 @@ struct RegStore {
         for (int r = 0; r < R_; ++r) fr[s][r] = fn.free[r] - (int32_t)x * pv.req[r];
         slots[s] = fn.slots - (int32_t)x;
 #pragma unroll
-        for (int w = 0; w < WX_; ++w) excl[s][w] = fn.excl[w] | (x > 0 ? pv.xm[w] : 0ull);
+        for (int w = 0; w < WX_; ++w) excl[s][w] = (w < wx ? fn.excl[w] : 0ull) | (x > 0 ? pv.xm[w] : 0ull);   // wx <= WX_ words exist
     }
     CS_DEVICE uint32_t get_c(int s, int) const { return c[s]; }
     CS_DEVICE void set_c(int s, int, uint32_t v) { c[s] = v; }
@@ -354,7 +357,36 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     const bool fast_last = t.fastpath && res.fast_last[ng];
     const bool group_unschedulable = (t.gflags[ng] & CASIM_NG_UNSCHEDULABLE) != 0;
     const uint64_t* zvalid = t.zone_valid + (int64_t)ng * Wz;
-    for (int w = 0; w < Wz; ++w) szone[w * 64 + lane] = t.init_zone[(int64_t)ng * Wz + w];
+    // group-wide exclusion state (anti-affinity on non-hostname keys): identical in every lane
+    constexpr int ZR = Store::kZoneWords;
+    uint64_t zreg[ZR > 0 ? ZR : 1];
+    auto zone_init = [&]() {
+        if constexpr (ZR > 0) {
+#pragma unroll
+            for (int w = 0; w < ZR; ++w) zreg[w] = w < Wz ? t.init_zone[(int64_t)ng * Wz + w] : 0ull;
+        } else {
+            for (int w = 0; w < Wz; ++w) szone[w * 64 + lane] = t.init_zone[(int64_t)ng * Wz + w];
+        }
+    };
+    auto zone_blocked = [&](const uint64_t* zb) -> bool {
+        bool b = false;
+        if constexpr (ZR > 0) {
+#pragma unroll
+            for (int w = 0; w < ZR; ++w) if (w < Wz) b |= (zreg[w] & zb[w]) != 0;
+        } else {
+            for (int w = 0; w < Wz; ++w) b |= (szone[w * 64 + lane] & zb[w]) != 0;
+        }
+        return b;
+    };
+    auto zone_mark = [&](const uint64_t* zm) {
+        if constexpr (ZR > 0) {
+#pragma unroll
+            for (int w = 0; w < ZR; ++w) if (w < Wz) zreg[w] |= zm[w] & zvalid[w];
+        } else {
+            for (int w = 0; w < Wz; ++w) szone[w * 64 + lane] |= zm[w] & zvalid[w];
+        }
+    };
+    zone_init();
 
     int32_t M = 0;                         // simulated nodes so far (estimationState.newNodeNameIndex)
     int32_t last_index = t.last_index[ng]; // lastIndexOrderMapping.lastIndex
@@ -411,11 +443,8 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     if (Wx > 1) { pv.xb[1] = pv.xblock[1]; pv.xm[1] = pv.xmark[1]; }
                 }
             }
-            bool zblocked = false;
-            for (int w = 0; w < Wz; ++w) {
-                zblocked |= (szone[w * 64 + lane] & zblock[w]) != 0;
-                zselfx |= (zblock[w] & zmark[w] & zvalid[w]) != 0;  // the PEG excludes itself group-wide
-            }
+            bool zblocked = Wz > 0 && zone_blocked(zblock);
+            for (int w = 0; w < Wz; ++w) zselfx |= (zblock[w] & zmark[w] & zvalid[w]) != 0;  // the PEG excludes itself group-wide
 
             CASIM_PROF(1);  // record broadcast + reciprocals
             int32_t placed = 0;
@@ -516,7 +545,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     on_last = cs::bcast_u32(x_mine_last, (M - 1) & 63);
                     last_index = new_last;
                     st.note_change();
-                    for (int w = 0; w < Wz; ++w) szone[w * 64 + lane] |= zmark[w] & zvalid[w];
+                    if (Wz > 0) zone_mark(zmark);
                 }
             }
 
@@ -524,8 +553,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             // ---- a3 / a4: tryToScheduleOnNewNodes (:190-269) or tryFastPath (:274-324) ----
             int32_t rem = cnt - placed;
             if (rem > 0 && more) {
-                zblocked = false;
-                for (int w = 0; w < Wz; ++w) zblocked |= (szone[w * 64 + lane] & zblock[w]) != 0;
+                zblocked = Wz > 0 && zone_blocked(zblock);
                 bool blocked = !static_ok || zblocked;
                 // capacity of a FRESH node for this PEG
                 uint32_t cfresh = 0;
@@ -630,8 +658,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         }
                     }
                 }
-                if (marked)
-                    for (int w = 0; w < Wz; ++w) szone[w * 64 + lane] |= zmark[w] & zvalid[w];
+                if (marked && Wz > 0) zone_mark(zmark);
             }
 
             CASIM_PROF(5);  // a3 / a4
@@ -703,8 +730,8 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void pack_kernel(DevTables t, DevResults res, 
 }
 
 // ---- fast kernel: int32 gcd-scaled lanes, node state in VGPRs, no exclusion masks ----------------
-// Launched only when the host proved the batch eligible (casim_pipeline.h): Wx <= 2 (WX_ exclusion words per node, two
-// VGPRs each), Wz == 0, R <= R_, every scaled value < 2^31 and every group's node bound <= 64 * NPT_.
+// Launched only when the host proved the batch eligible (casim_pipeline.h): either no exclusion state at all (WX_ = 0,
+// the bench path) or Wx <= 2 node-local words (two VGPRs each) and Wz <= 2 group-wide words (scalar) with WX_ = 2; R <= R_, every scaled value < 2^31 and every group's node bound <= 64 * NPT_.
 template <int R_, int NPT_, int WX_>
 // launch bounds (64, 1): let the register allocator take what it needs — forcing 5 waves/SIMD (<= 96
 // VGPRs) spilled ~200 B/lane to scratch and halved the throughput on MI355X (r01 measurement)
@@ -727,6 +754,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, ((NPT_ == 4 && WX_ == 0) ? CASIM_FAST_WAVES : 1))
     fn.slots = t.allowed[ng] - t.init_pods[ng];
     st.fresh_slots = fn.slots;
     fn.excl = WX_ > 0 ? t.init_excl + (int64_t)ng * t.Wx : nullptr;
+    st.wx = t.Wx < WX_ ? t.Wx : WX_;
     const int32_t* req32 = fs.req32;
     const int32_t* order = res.order;
     const int R = t.R;
