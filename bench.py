@@ -192,7 +192,8 @@ def main():
         # on the same kernel and launch size
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "pack_traffic.json")))
-            if tr.get("waves_per_launch") == B and roofline["kernel"].replace(" ", "") in tr.get("kernel", "").replace(" ", ""):
+            # same kernel family and launch size (the profile names the full instantiation, e.g. pack_fast_kernel<2, 4, 0>)
+            if tr.get("waves_per_launch") == B and roofline["kernel"].replace(" ", "").rstrip(">") in tr.get("kernel", "").replace(" ", ""):
                 roofline["traffic"] = tr["traffic_bytes_per_launch"]
                 roofline["traffic_source"] = "profiles/pack_traffic.json (%s: FETCH_SIZE x2 per the gfx950 rule + WRITE_SIZE, per launch)" % tr.get("run", "?")
         except (OSError, ValueError, KeyError):
