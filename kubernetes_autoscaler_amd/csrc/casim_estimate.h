@@ -13,6 +13,7 @@
 //   a2  tryToScheduleOnExistingNodes (:163-186): per pod, first passing CREATED node in cyclic order from lastIndex + 1
 //   a3  tryToScheduleOnNewNodes (:190-269): per pod, the newest node; when it fails on a hostname spread constraint,
 //       any other node of the snapshot (:212-227); else the exits of SURVEY N2 and a new node under the limiter
+//       (a class that has no rules, feeds no counter and does not exclude itself fills a node in one step)
 // No fastpath (a PEG with spread constraints is never fast-pathed, :411-425; callers with fastpath on delegate).
 #pragma once
 #include "casim_sched.h"
@@ -218,7 +219,41 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void estimate_kernel(DevTables t, EstArgs a)
             if (i_hi > i_lo) cs::sync();
         }
         // ---- a3: tryToScheduleOnNewNodes (:190-269) ----
-        while (placed < cnt && more) {
+        // A class without domain rules that neither feeds a counter nor excludes itself sees every node on its own: a
+        // node takes as many of its pods as fit in one step (the reference would add them one by one to the same node).
+        bool plain = r_hi == r_lo && i_hi == i_lo;
+        for (int w = 0; w < Wx; ++w) plain = plain && (pv.xblock[w] & pv.xmark[w]) == 0;
+        auto fill_node = [&](int m, uint32_t clamp) -> uint32_t {   // RunFiltersOnNode + SchedulePod, up to `clamp` times
+            const bool owner = tid == m % T;
+            uint32_t x = 0;
+            if (owner && ((fb[m >> 6] >> (m & 63)) & 1ull)) {
+                x = st.capacity(0, m, pv, clamp, false);
+                if (x > 0) st.commit(0, m, x, pv);
+            }
+            return bc.pick(owner, x);
+        };
+        while (plain && placed < cnt && more) {
+            const int last_node = M > 0 ? E + M - 1 : -1;
+            uint32_t x = 0;
+            if (last_node >= 0) {
+                x = fill_node(last_node, (uint32_t)(cnt - placed));
+                placed += (int32_t)x; total_placed += (int32_t)x; sum0 += (int64_t)x * pv.req[0]; sum1 += (int64_t)x * pv.req[1];
+                if (placed >= cnt) break;
+                // the next pod does not fit the newest node; if that node is still empty a fresh one would not help (:234-236)
+                if (x == 0 && bc.pick(tid == last_node % T, (uint32_t)st.snpods[last_node]) == 0) break;
+            }
+            if (a.max_nodes < 0 || (a.max_nodes > 0 && granted >= a.max_nodes)) { more = false; break; }
+            granted++;
+            if (E + M >= N) { more = false; break; }
+            const int fresh = E + M;
+            node_joins(fresh, +1);
+            M++;
+            cs::sync();
+            x = fill_node(fresh, (uint32_t)(cnt - placed));
+            if (x == 0) break;   // :257-263 the node stays, the PEG is abandoned
+            placed += (int32_t)x; total_placed += (int32_t)x; sum0 += (int64_t)x * pv.req[0]; sum1 += (int64_t)x * pv.req[1];
+        }
+        while (!plain && placed < cnt && more) {
             bool found = false;
             const int last_node = M > 0 ? E + M - 1 : -1;
             if (last_node >= 0) {
