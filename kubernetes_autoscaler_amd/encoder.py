@@ -88,6 +88,8 @@ class Encoder:
                 check(lib.casim_enc_term_add_requirement(h, s, t, _b(r.key), _b(r.operator), _strs(r.values), len(r.values)))
         cpu, mem = pod.fastpath_requests()
         check(lib.casim_enc_pod_set_fastpath_requests(h, s, cpu, mem))
+        if any(sc.node_taints_policy != "Ignore" for sc in pod.spread_constraints):
+            check(lib.casim_enc_pod_mark_unsupported(h, s, b"topologySpreadConstraints: nodeTaintsPolicy"))
         for sc in pod.spread_constraints:   # evaluated on the device in per-node mode, flagged UNSUPPORTED by finalize otherwise
             ci = lib.casim_enc_pod_add_spread_constraint(h, s, int(sc.max_skew), _b(sc.topology_key), int(sc.min_domains))
             if ci < 0:

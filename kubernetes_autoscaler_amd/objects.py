@@ -66,6 +66,7 @@ class TopologySpreadConstraint:
     topology_key: str
     min_domains: int = 0                   # 0 = nil (treated as 1)
     match_labels: Dict[str, str] = field(default_factory=dict)
+    node_taints_policy: str = "Ignore"     # "Honor" is outside the encoded subset (the removal ghost's taint would count)
 
 
 @dataclass
@@ -113,7 +114,7 @@ class Pod:
                 tuple((t.topology_key, tuple(sorted(t.match_labels.items())),
                        tuple((r.key, r.operator, tuple(r.values)) for r in t.match_expressions), tuple(t.namespaces))
                       for t in self.anti_affinity),
-                self.topology_spread, tuple((c.max_skew, c.topology_key, c.min_domains, tuple(sorted(c.match_labels.items())))
+                self.topology_spread, tuple((c.max_skew, c.topology_key, c.min_domains, tuple(sorted(c.match_labels.items())), c.node_taints_policy)
                                             for c in self.spread_constraints),
                 self.unsupported_reason, self.has_containers, self.spec_extra)
 

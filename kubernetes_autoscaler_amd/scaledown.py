@@ -21,12 +21,13 @@ import numpy as np
 from . import _abi
 from .encoder import Encoder
 from .engine import Context
-from .objects import NodeInfo, Pod, PodEquivalenceGroup
+from .objects import Node, NodeInfo, Pod, PodEquivalenceGroup
 from .scheduling import Hints, UnsupportedPredicate, hint_key_from_pod
 
 # simulator.UnremovableReason (cluster.go:78-103), the two this path produces
 NO_PLACE_TO_MOVE_PODS = "NoPlaceToMovePods"
 BLOCKED_BY_POD = "BlockedByPod"
+NO_NODE_INFO = "NoNodeInfo"
 
 
 @dataclass
@@ -127,6 +128,8 @@ class RemovalSimulator:
                 n = todo.pop(0)
                 if n in by_name:
                     unremovable.append(UnremovableNode(by_name[n].node, BLOCKED_BY_POD))
+                else:   # cluster.go:138-146: not in the snapshot, decided before any simulation
+                    unremovable.append(UnremovableNode(Node(name=n), NO_NODE_INFO))
                 continue
             left = (max_removable - len(removable)) if max_removable > 0 else 0
             infos = list(self.snapshot)   # node indices of this call refer to this list

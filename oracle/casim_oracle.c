@@ -86,7 +86,7 @@ typedef struct { int ip, proto, port; } hostport;
 typedef struct { int topology_key; ivec namespaces; reqvec selector; } aff_term;
 /* topologySpreadConstraint  V/.../podtopologyspread/common.go:34-41 (DoNotSchedule constraints only; nodeAffinityPolicy
  * Honor and nodeTaintsPolicy Ignore, the defaults :108-110) */
-typedef struct { int max_skew, topology_key, min_domains; reqvec selector; int selector_set; } spread_constraint;
+typedef struct { int max_skew, topology_key, min_domains; reqvec selector; int selector_set; int taints_honor; } spread_constraint;
 
 typedef struct {
     int ns;
@@ -278,6 +278,13 @@ int orc_pod_spread_constraint(orc* o, int pod, int max_skew, const char* topolog
     VEC_PUSH(o->pods.v[pod].spread, c);
     o->pods.v[pod].has_topology_spread = 1;
     return o->pods.v[pod].spread.n - 1;
+}
+/* nodeTaintsPolicy: Honor (common.go:52-56): nodes with a taint the pod does not tolerate are no domain members */
+int orc_spread_taints_policy_honor(orc* o, int pod, int constraint, int honor) {
+    PODCHK(o, pod);
+    if (constraint < 0 || constraint >= o->pods.v[pod].spread.n) return -1;
+    o->pods.v[pod].spread.v[constraint].taints_honor = honor;
+    return 0;
 }
 /* one requirement of the constraint's labelSelector (matchLabels pair == In{value}); a constraint without any
  * requirement has an EMPTY selector, which counts nothing (countPodsMatchSelector, common.go:144-147) */
@@ -589,6 +596,7 @@ static int filter_ipa(const podspec* p, const node* n, const ipa_state* s) {
  * pods (same namespace, selector) are added to the domain of its topology value — a domain exists even at count 0. */
 typedef struct { tpmap* counts; int n; } pts_state;
 static int filter_node_affinity(const orc* o, const podspec* p, const node* n);
+static int filter_taints(const orc* o, const podspec* p, const node* n);
 static void pts_prefilter(const orc* o, const podspec* p, pts_state* s) {
     s->n = p->spread.n; s->counts = NULL;
     if (s->n == 0) return;
@@ -601,6 +609,7 @@ static void pts_prefilter(const orc* o, const podspec* p, pts_state* s) {
         if (!filter_node_affinity(o, p, n)) continue;                 /* matchNodeInclusionPolicies, Honor */
         for (int c = 0; c < s->n; ++c) {
             const spread_constraint* sc = &p->spread.v[c];
+            if (sc->taints_honor && !filter_taints(o, p, n)) continue;  /* matchNodeInclusionPolicies, nodeTaintsPolicy Honor */
             int val = 0; labels_lookup(n->labels.v, n->labels.n, sc->topology_key, &val);
             int64_t count = 0;
             if (sc->selector_set)                                     /* countPodsMatchSelector common.go:143-158 */

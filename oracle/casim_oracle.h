@@ -13,7 +13,8 @@
  * TestPodSchedulesOnHintedNode, TestDetermineBestPodEquivalenceGroupToFastpath,
  * TestPodPriorityProcessor, TestThresholdBasedLimiter, TestMinLimit, TestSngCapacityThreshold,
  * TestNewClusterCapacityThreshold, TestLastIndexOrderMapping, TestRunFiltersOnNode,
- * TestRunFilterUntilPassingNode, TestDebugInfo taints, TestLeastNodes, TestLeastWaste).
+ * TestRunFilterUntilPassingNode, TestDebugInfo taints, TestLeastNodes, TestLeastWaste,
+ * TestSimulateNodeRemoval incl. its two ghost-node PodTopologySpread rows).
  * Taints / nodeSelector / anti-affinity INSIDE Estimate have no reference known-answer test
  * ("parity unpinned" for those rows); they are restated from the vendored plugin
  * sources cited below.
@@ -59,6 +60,7 @@ int orc_pod_has_topology_spread(orc* o, int pod, int flag); /* only feeds should
 int orc_pod_spread_constraint(orc* o, int pod, int max_skew, const char* topology_key, int min_domains);
 int orc_spread_requirement(orc* o, int pod, int constraint, const char* key, const char* op,
                            const char* const* values, int n_values);
+int orc_spread_taints_policy_honor(orc* o, int pod, int constraint, int honor);  /* nodeTaintsPolicy: Honor */
 
 /* ---- node objects (a template or a node of the existing cluster) ---------------------- */
 int orc_node(orc* o, const char* name, const int64_t* alloc, int allowed_pods,

@@ -138,6 +138,29 @@ def test_schedulable_pod_groups_matrix(ctx):
 
 
 # ---- scale-down removal simulation -----------------------------------------------------------------
+def test_removal_reference_table(ctx):
+    """simulator/cluster_test.go TestSimulateNodeRemoval rows (tests/golden/reference_vectors.json)."""
+    import json
+    import os
+    from harness import assert_removal_matches, removal_device, removal_oracle
+    from test_oracle_golden import golden_removal_case
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")) as f:
+        rows = json.load(f)["simulate_node_removal"]["cases"]
+    seen = 0
+    for row in rows:
+        case = golden_removal_case(row)
+        if case is None:
+            continue
+        got = removal_device(case, ctx)
+        if row.get("device_delegates"):
+            assert got.status == 1, row["name"]
+            continue
+        assert_removal_matches(got, removal_oracle(case), row["name"])
+        assert bool(got.removable[0] == 1) == row["removable"], row["name"]
+        seen += 1
+    assert seen == 6
+
+
 def test_removal_fuzz(ctx):
     from harness import RemovalCase, assert_removal_matches, removal_device, removal_oracle
     from kubernetes_autoscaler_amd.workloads import fuzz_removals

@@ -265,3 +265,43 @@ def test_pod_schedules_on_hinted_node(case):
         node_out, last_index, n_sched = sched_oracle(sc)
         assert list(node_out) == want and n_sched == len(want)
         assert last_index == 0  # hinted placements do not move lastIndex
+
+
+# ---- scale-down: RemovalSimulator.SimulateNodeRemoval ---------------------------------------------
+def golden_removal_case(case):
+    """RemovalCase of one TestSimulateNodeRemoval row (None when the candidate is not in the snapshot)."""
+    from harness import RemovalCase
+    from kubernetes_autoscaler_amd.objects import TopologySpreadConstraint
+    names = case["nodes"]
+    infos = []
+    for n in names:
+        node = build_test_node(n, 1000, 2000000)
+        if case.get("hostname_labels"):
+            node.labels = {"kubernetes.io/hostname": n}
+        infos.append(NodeInfo(node))
+    for p in case["pods"]:
+        pod = build_test_pod(p["name"], p["cpu"], p["mem"])
+        pod.labels = dict(p.get("labels", {}))
+        pod.controller_uid = p.get("controller", "")
+        if "spread" in p:
+            sp = p["spread"]
+            pod.spread_constraints = [TopologySpreadConstraint(sp["max_skew"], sp["key"], sp["min_domains"], dict(sp["match_labels"]), sp["taints_policy"])]
+            pod.topology_spread = True
+        infos[names.index(p["node"])].pods.append(pod)
+    if case["candidate"] not in names:
+        return None
+    return RemovalCase(nodes=infos, candidates=[names.index(case["candidate"])], persist=False)
+
+
+@pytest.mark.parametrize("case", GOLD["simulate_node_removal"]["cases"], ids=lambda c: c["name"])
+def test_simulate_node_removal(case):
+    from harness import removal_oracle
+    rc = golden_removal_case(case)
+    if rc is None:
+        assert case.get("no_node_info")   # NoNodeInfo: decided before any simulation (cluster.go:139-147)
+        return
+    got = removal_oracle(rc)
+    assert bool(got["removable"][0] == 1) == case["removable"]
+    if case["removable"]:
+        assert all(m >= 0 for m in got["node_out"])
+        assert [p.name for p in rc.pod_lists()[0]] == case.get("reschedule", [])

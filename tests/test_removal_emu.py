@@ -153,3 +153,48 @@ def test_fuzz_domain_rules(seed):
     from kubernetes_autoscaler_amd.workloads import fuzz_removals_domains
     w = fuzz_removals_domains(seed)
     check(case_of(w), w.name)
+
+
+# ---- the reference's own table: simulator/cluster_test.go TestSimulateNodeRemoval --------------------------------
+def _golden_rows():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")) as f:
+        return json.load(f)["simulate_node_removal"]["cases"]
+
+
+@pytest.mark.parametrize("row", _golden_rows(), ids=lambda r: r["name"])
+def test_reference_table_device(row):
+    from test_oracle_golden import golden_removal_case
+    case = golden_removal_case(row)
+    if case is None:
+        return   # NoNodeInfo is decided by the host mirror (test below)
+    if row.get("device_delegates"):
+        # nodeTaintsPolicy: Honor makes the ghost's ToBeDeleted taint a domain-membership input: outside the encoded subset
+        assert removal_device(case, EmuContext(0)).status == 1   # CASIM_NG_UNSUPPORTED
+        return
+    want = check(case, row["name"])
+    assert bool(want["removable"][0] == 1) == row["removable"]
+
+
+@pytest.mark.parametrize("row", _golden_rows(), ids=lambda r: r["name"])
+def test_reference_table_through_the_mirror(row):
+    from test_oracle_golden import golden_removal_case
+    from kubernetes_autoscaler_amd.scaledown import NO_NODE_INFO
+    from kubernetes_autoscaler_amd.scheduling import UnsupportedPredicate
+    case = golden_removal_case(row)
+    nodes = case.nodes if case is not None else []
+    sim = RemovalSimulator(EmuContext(0), list(nodes), persist_successful_simulations=False)
+    dest = {info.node.name: True for info in nodes}
+    if row.get("device_delegates"):
+        with pytest.raises(UnsupportedPredicate):
+            sim.simulate_node_removals([row["candidate"]], dest)
+        return
+    removable, unremovable, skipped = sim.simulate_node_removals([row["candidate"]], dest)
+    assert not skipped
+    if row["removable"]:
+        assert [r.node.name for r in removable] == [row["candidate"]] and not unremovable
+        assert [p.name for p in removable[0].pods_to_reschedule] == row.get("reschedule", [])
+    else:
+        assert not removable and [u.node.name for u in unremovable] == [row["candidate"]]
+        assert unremovable[0].reason == (NO_NODE_INFO if row.get("no_node_info") else NO_PLACE_TO_MOVE_PODS)
