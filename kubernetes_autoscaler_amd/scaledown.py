@@ -163,3 +163,41 @@ class RemovalSimulator:
                 break
             todo = todo[n_done:]
         return removable, unremovable, todo
+
+
+class Planner:
+    """The simulating part of planner.Planner.UpdateClusterState (planner.go:118-141): recently evicted pods are put
+    back into the snapshot (injectPods :256-270, one TrySchedulePods call on the device), then categorizeNodes
+    (:286-336) walks the eligible candidates with persisted removal simulations.  Eligibility, PDB accounting and
+    the unneeded-time bookkeeping around it stay with the caller (host policy, SURVEY §8 out of scope)."""
+
+    def __init__(self, ctx: Context, snapshot: List[NodeInfo],
+                 pods_to_move: Callable[[NodeInfo], Optional[List[Pod]]] = default_pods_to_move,
+                 is_sticky: Callable[[Pod], bool] = lambda p: False, lanes=None):
+        from .scheduling import HintingSimulator
+        self.snapshot = snapshot
+        self.rs = RemovalSimulator(ctx, snapshot, True, pods_to_move, is_sticky, lanes=lanes)
+        self.actuation_injector = HintingSimulator(ctx, lanes)
+
+    def inject_pods(self, pods: Sequence[Pod]) -> bool:
+        """injectPods: breakOnFailure, any node acceptable; what was placed stays in the snapshot.  False when not
+        every pod found a node (the reference logs a warning and goes on)."""
+        if not pods:
+            return True
+        # one lastIndex for both simulators: it belongs to the snapshot's plugin runner (plugin_runner.go:51)
+        self.actuation_injector.last_index = self.rs.last_index
+        statuses, _ = self.actuation_injector.try_schedule_pods(self.snapshot, list(pods), break_on_failure=True)
+        self.rs.last_index = self.actuation_injector.last_index
+        by_name = {info.node.name: info for info in self.snapshot}
+        for s in statuses:
+            by_name[s.node_name].pods.append(s.pod)
+        return len(statuses) == len(pods)
+
+    def update_cluster_state(self, pod_destinations: Sequence[str], eligible_candidates: Sequence[str],
+                             recent_evictions: Sequence[Pod] = (), unneeded_nodes_limit: int = 0):
+        """Returns (removable, unremovable, skipped) of the categorizeNodes loop."""
+        self.inject_pods(recent_evictions)
+        out = self.rs.simulate_node_removals(list(eligible_candidates), {n: True for n in pod_destinations}, unneeded_nodes_limit)
+        self.rs.drop_old_hints()
+        self.actuation_injector.drop_old_hints()
+        return out

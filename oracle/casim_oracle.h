@@ -14,7 +14,8 @@
  * TestPodPriorityProcessor, TestThresholdBasedLimiter, TestMinLimit, TestSngCapacityThreshold,
  * TestNewClusterCapacityThreshold, TestLastIndexOrderMapping, TestRunFiltersOnNode,
  * TestRunFilterUntilPassingNode, TestDebugInfo taints, TestLeastNodes, TestLeastWaste,
- * TestSimulateNodeRemoval incl. its two ghost-node PodTopologySpread rows).
+ * TestFilterOutSchedulable, TestSimulateNodeRemoval incl. its two ghost-node PodTopologySpread rows,
+ * the planner's TestUpdateClusterState).
  * Taints / nodeSelector / anti-affinity INSIDE Estimate have no reference known-answer test
  * ("parity unpinned" for those rows); they are restated from the vendored plugin
  * sources cited below.

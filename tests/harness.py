@@ -297,6 +297,25 @@ class EmuContext:
     def __init__(self, lds_budget=0):
         self.lds_budget = lds_budget
 
+    def try_schedule_pods(self, classes, nodes, pod_class, hint_node=None, node_acceptable=None, break_on_failure=False,
+                          last_index=0, time_iters=0, rules=None, similar_key=None):
+        from kubernetes_autoscaler_amd.engine import make_pod_sequence
+        L = emu_lib()
+        if not hasattr(L, "_sched_ready"):
+            L.emu_try_schedule_pods.restype = C.c_int32
+            L.emu_try_schedule_pods.argtypes = [C.POINTER(_abi.Pegs), C.POINTER(_abi.Groups), C.POINTER(_abi.PodSequence), C.c_int64,
+                                                _abi.i32p, _abi.i32p, _abi.i32p, _abi.i32p]
+            L._sched_ready = True
+        seq, keep = make_pod_sequence(pod_class, hint_node, node_acceptable, break_on_failure, last_index, rules, similar_key)
+        node_out = np.full(max(seq.n_pods, 1), -1, np.int32)
+        li, ns = C.c_int32(0), C.c_int32(0)
+        info = (C.c_int32 * 2)(0, 0)
+        rc = L.emu_try_schedule_pods(C.byref(classes), C.byref(nodes), C.byref(seq), int(self.lds_budget),
+                                     node_out.ctypes.data_as(_abi.i32p), C.byref(li), C.byref(ns), info)
+        assert rc >= 0, (rc, L.emu_last_error())
+        del keep
+        return rc, node_out[:seq.n_pods], li.value, ns.value
+
     def simulate_node_removals(self, classes, nodes, cand_node, pod_offsets, pod_class, hint_node=None, destination=None,
                                persist=True, max_removable=0, last_index=0, pod_sticky=None, ext_capacity=None, rules=None):
         from kubernetes_autoscaler_amd.engine import alloc_removal_results, finish_removal_results, make_removal_candidates

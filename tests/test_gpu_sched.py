@@ -84,6 +84,23 @@ def test_packing_at_scale(ctx):
         assert cpu[i] == 0 or used + cpu[i] <= info.node.allocatable["cpu"]
 
 
+def test_reference_filter_out_schedulable_table(ctx):
+    """podlistprocessor/filter_out_schedulable_test.go TestFilterOutSchedulable rows (tests/golden)."""
+    import json
+    import os
+    from harness import SchedCase, assert_sched_matches, sched_oracle
+    from test_oracle_golden import golden_filter_case
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")) as f:
+        rows = json.load(f)["filter_out_schedulable"]["cases"]
+    for row in rows:
+        nodes, cands, acceptable = golden_filter_case(row)
+        node_filter = (lambda info: False) if row.get("node_filter") == "none" else None
+        proc = FilterOutSchedulablePodListProcessor(ctx, node_filter)
+        left = proc.process(nodes, list(cands))
+        assert sorted(p.name for p in left) == sorted(row["unscheduled"]), row["name"]
+        assert sorted(proc.scheduling_simulator.hints.old) == sorted(f"default/{n}" for n in row["scheduled"]), row["name"]
+
+
 def test_host_mirror_processor_keeps_hints(ctx):
     """FilterOutSchedulablePodListProcessor.Process twice: the second loop iteration finds every pod on its hinted
     node (hints survive DropOldHints once)."""
@@ -159,6 +176,24 @@ def test_removal_reference_table(ctx):
         assert bool(got.removable[0] == 1) == row["removable"], row["name"]
         seen += 1
     assert seen == 6
+
+
+def test_reference_planner_table(ctx):
+    """core/scaledown/planner/planner_test.go TestUpdateClusterState rows through the Planner mirror: injectPods
+    (one TrySchedulePods call) then categorizeNodes (one removal call)."""
+    import json
+    import os
+    from kubernetes_autoscaler_amd.scaledown import Planner
+    from test_oracle_golden import golden_planner_case
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")) as f:
+        rows = json.load(f)["planner_update_cluster_state"]["cases"]
+    assert len(rows) == 25
+    for row in rows:
+        infos, inject = golden_planner_case(row)
+        names = [i.node.name for i in infos]
+        removable, unremovable, skipped = Planner(ctx, infos).update_cluster_state(names, row["eligible"], inject)
+        assert not skipped and [r.node.name for r in removable] == row["unneeded"], row["name"]
+        assert [u.node.name for u in unremovable] == [n for n in row["eligible"] if n not in row["unneeded"]], row["name"]
 
 
 def test_removal_fuzz(ctx):

@@ -305,3 +305,73 @@ def test_simulate_node_removal(case):
     if case["removable"]:
         assert all(m >= 0 for m in got["node_out"])
         assert [p.name for p in rc.pod_lists()[0]] == case.get("reschedule", [])
+
+
+# ---- filter-out-schedulable: filterOutSchedulableByPacking ------------------------------------------
+def golden_filter_case(row):
+    """(nodes, candidates in the order Process hands them to TrySchedulePods, acceptable) of one TestFilterOutSchedulable row."""
+    info = NodeInfo(build_test_node("node", 2000, 100))
+    for p in row["on_node"]:
+        info.pods.append(build_test_pod(p["name"], p["cpu"], p["mem"]))
+    cands = []
+    for p in row["candidates"]:
+        pod = build_test_pod(p["name"], p["cpu"], p["mem"])
+        pod.priority = p["priority"]
+        cands.append(pod)
+    cands.sort(key=lambda q: -q.priority)   # filter_out_schedulable.go:99-101 (ties keep input order, SURVEY §8c)
+    return [info], cands, ([0] if row.get("node_filter") == "none" else None)
+
+
+@pytest.mark.parametrize("row", GOLD["filter_out_schedulable"]["cases"], ids=lambda r: r["name"])
+def test_filter_out_schedulable(row):
+    from harness import SchedCase, sched_oracle
+    nodes, cands, acceptable = golden_filter_case(row)
+    if not cands:
+        return
+    node_out, _, n_sched = sched_oracle(SchedCase(nodes=nodes, pods=cands, acceptable=acceptable))
+    assert sorted(p.name for p, m in zip(cands, node_out) if m >= 0) == sorted(row["scheduled"])
+    assert sorted(p.name for p, m in zip(cands, node_out) if m < 0) == sorted(row["unscheduled"])
+    assert n_sched == len(row["scheduled"])
+
+
+# ---- scale-down planner loop: inject recently evicted pods, then categorizeNodes ---------------------------------
+def golden_planner_case(row):
+    """(snapshot nodes, pods to inject) of one TestUpdateClusterState row."""
+    from kubernetes_autoscaler_amd.objects import Taint
+    infos = []
+    for n in row["nodes"]:
+        node = build_test_node(n["name"], n["cpu"], n["mem"])
+        if n["undergoing_deletion"]:
+            node.taints.append(Taint("ToBeDeletedByClusterAutoscaler", "", "NoSchedule"))
+        infos.append(NodeInfo(node))
+    names = [n["name"] for n in row["nodes"]]
+
+    def pod_of(p):
+        pod = build_test_pod(p["name"], p["cpu"], p["mem"])
+        pod.controller_uid = p["controller"]
+        return pod
+    for p in row["pods"]:
+        infos[names.index(p["node"])].pods.append(pod_of(p))
+    return infos, [pod_of(p) for p in row["inject"]]
+
+
+@pytest.mark.parametrize("row", GOLD["planner_update_cluster_state"]["cases"], ids=lambda r: r["name"])
+def test_planner_update_cluster_state(row):
+    from oracle_driver import OracleScenario
+    from harness import similar_keys
+    infos, inject = golden_planner_case(row)
+    names = [i.node.name for i in infos]
+    s = OracleScenario(lanes=("cpu", "memory"))
+    for info in infos:
+        s.add_existing(info)
+    last_index = 0
+    if inject:   # injectPods (planner.go:256-270): committed, breakOnFailure
+        node_out, last_index, _ = s.try_schedule_pods(inject, None, similar_keys(inject), None, True, 0)
+        for p, m in zip(inject, node_out):
+            if m >= 0:
+                infos[m].pods.append(p)
+    cands = [names.index(n) for n in row["eligible"]]
+    got = s.simulate_node_removals(cands, [list(infos[c].pods) for c in cands], persist=True, last_index=last_index)
+    s.close()
+    assert got["n_processed"] == len(cands)
+    assert [names[c] for c, r in zip(cands, got["removable"]) if r == 1] == row["unneeded"]

@@ -198,3 +198,26 @@ def test_reference_table_through_the_mirror(row):
     else:
         assert not removable and [u.node.name for u in unremovable] == [row["candidate"]]
         assert unremovable[0].reason == (NO_NODE_INFO if row.get("no_node_info") else NO_PLACE_TO_MOVE_PODS)
+
+
+# ---- the reference's planner table: core/scaledown/planner/planner_test.go TestUpdateClusterState ---------------
+def _planner_rows():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")) as f:
+        return json.load(f)["planner_update_cluster_state"]["cases"]
+
+
+@pytest.mark.parametrize("lds", [0, 64])
+@pytest.mark.parametrize("row", _planner_rows(), ids=lambda r: r["name"])
+def test_reference_planner_table(row, lds):
+    from test_oracle_golden import golden_planner_case
+    from kubernetes_autoscaler_amd.scaledown import Planner
+    infos, inject = golden_planner_case(row)
+    names = [i.node.name for i in infos]
+    planner = Planner(EmuContext(lds), infos)
+    removable, unremovable, skipped = planner.update_cluster_state(names, row["eligible"], inject)
+    assert not skipped
+    assert [r.node.name for r in removable] == row["unneeded"]
+    assert [u.node.name for u in unremovable] == [n for n in row["eligible"] if n not in row["unneeded"]]
+    assert [i.node.name for i in infos] == [n for n in names if n not in row["unneeded"]]   # persisted removals left the snapshot

@@ -184,3 +184,46 @@ def test_fuzz_large_clusters():
         w = pending_scale(1100 + 400 * seed, 1500, n_classes=10, seed=40 + seed)
         w.last_index = 37 * seed * seed
         check(case_of(w), w.name, lds_budgets=(0,) if seed % 2 else (64,))
+
+
+# ---- the reference's own table: podlistprocessor/filter_out_schedulable_test.go TestFilterOutSchedulable -------------
+@pytest.mark.parametrize("row", GOLD["filter_out_schedulable"]["cases"], ids=lambda r: r["name"])
+def test_reference_filter_out_schedulable_table(row):
+    from harness import EmuContext
+    from kubernetes_autoscaler_amd.scheduling import FilterOutSchedulablePodListProcessor
+    from test_oracle_golden import golden_filter_case
+    nodes, cands, acceptable = golden_filter_case(row)
+    if cands:
+        check(SchedCase(nodes=nodes, pods=cands, acceptable=acceptable), row["name"])
+    # and through the host mirror, unsorted input like the reference test hands it over
+    node_filter = (lambda info: False) if row.get("node_filter") == "none" else None
+    proc = FilterOutSchedulablePodListProcessor(EmuContext(0), node_filter)
+    unsorted = sorted(cands, key=lambda p: [c["name"] for c in row["candidates"]].index(p.name))
+    left = proc.process(nodes, unsorted)
+    assert sorted(p.name for p in left) == sorted(row["unscheduled"])
+    assert sorted(proc.scheduling_simulator.hints.old) == sorted(f"default/{n}" for n in row["scheduled"])
+
+
+def test_reference_similar_pods_limiting_and_daemonsets():
+    """similar_pods_test.go TestSimilarPodsSchedulingLimiting / ...IgnoreDaemonSets, observed where the mirror exposes the
+    bookkeeping: 11 distinct unschedulable specs of one controller -> one overflowing controller; DaemonSet pods and
+    pods without a controller are never recorded."""
+    from harness import EmuContext
+    from kubernetes_autoscaler_amd.scheduling import HintingSimulator
+    nodes = [NodeInfo(build_test_node("n", 1000, 100000))]
+    pods = []
+    for i in range(11):
+        p = build_test_pod(f"p{i}", 3000, 200000)
+        p.controller_uid = "12345678-1234-1234-1234-123456789012"
+        p.labels = {"uniqueLabel": f"l{i}"}
+        pods.append(p)
+    statuses, overflowing = HintingSimulator(EmuContext(0)).try_schedule_pods(nodes, pods)
+    assert not statuses and overflowing == 1
+    statuses, overflowing = HintingSimulator(EmuContext(0)).try_schedule_pods(nodes, pods[:10])
+    assert not statuses and overflowing == 0
+    for p in pods:
+        p.daemonset = True
+    assert HintingSimulator(EmuContext(0)).try_schedule_pods(nodes, pods) == ([], 0)
+    for p in pods:
+        p.daemonset, p.controller_uid = False, ""
+    assert HintingSimulator(EmuContext(0)).try_schedule_pods(nodes, pods) == ([], 0)
