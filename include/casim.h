@@ -370,6 +370,8 @@ typedef struct casim_removal_candidates {
     const int32_t* hint_node;        /* [total] or NULL */
     const uint8_t* destination;      /* [N] podDestinations membership; NULL = every node */
     const uint8_t* pod_sticky;       /* [total] or NULL: 1 = may not move a second time without the host */
+    const uint8_t* cand_atomic;      /* [K] or NULL: 1 = node of an atomically scaled group (ZeroOrMaxNodeScaling): its
+                                      * removal does not count toward max_removable (planner.go:306, :321-324) */
     int32_t persist;                 /* canPersist */
     int32_t max_removable;           /* stop after this many removable nodes (unneededNodesLimit); 0 = no limit */
     int32_t last_index;

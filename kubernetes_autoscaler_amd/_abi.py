@@ -93,7 +93,7 @@ class ClusterEstimateResult(C.Structure):
 
 class RemovalCandidates(C.Structure):
     _fields_ = [("n_candidates", C.c_int32), ("cand_node", i32p), ("pod_offsets", i32p), ("pod_class", i32p), ("hint_node", i32p),
-                ("destination", u8p), ("pod_sticky", u8p), ("persist", C.c_int32), ("max_removable", C.c_int32),
+                ("destination", u8p), ("pod_sticky", u8p), ("cand_atomic", u8p), ("persist", C.c_int32), ("max_removable", C.c_int32),
                 ("last_index", C.c_int32), ("ext_capacity", C.c_int32), ("rules", C.POINTER(DomainRules))]
 
 

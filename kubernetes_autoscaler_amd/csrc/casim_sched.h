@@ -52,6 +52,7 @@ struct SchedArgs {
     char* gstate;               // HBM slab (global variant) or null
     // ---- removal simulation: n_cand > 0 turns every candidate's runs into one transaction ----
     int32_t n_cand, persist, max_removable;
+    const uint8_t* cand_atomic;   // [K] or null: removals that do not count toward max_removable
     const int32_t* cand_node;     // [K] node whose removal is simulated
     const int32_t* cand_run_off;  // [K+1] runs of candidate k
     const int32_t* cand_pod_off;  // [K+1] pods of candidate k in node_out
@@ -671,7 +672,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                 }
             }
         }
-        if (ok) removed++;
+        if (ok && !(a.cand_atomic && a.cand_atomic[kc])) removed++;   // len(removableList) - atomicScaleDownNodesCount
         if (tid == 0) a.removable_out[kc] = ok ? 1 : 0;
         cs::sync();
     }
@@ -811,6 +812,7 @@ public:
             a_.memo_classes = 0;  // breakOnFailure ends a simulation at the first miss: the memo is never consulted
             a_.n_cand = K_; a_.persist = cand->persist ? 1 : 0; a_.max_removable = cand->max_removable > 0 ? cand->max_removable : 0;
             a_.cand_node = up(cand->cand_node, (size_t)K_);
+            a_.cand_atomic = cand->cand_atomic ? up(cand->cand_atomic, (size_t)K_) : nullptr;
             a_.cand_run_off = up(cro.data(), cro.size());
             a_.cand_pod_off = up(cand->pod_offsets, (size_t)K_ + 1);
             a_.removable_out = (uint8_t*)dalloc((size_t)K_);

@@ -91,7 +91,7 @@ class RemovalResult:
 
 
 def make_removal_candidates(cand_node, pod_offsets, pod_class, hint_node=None, destination=None, persist=True, max_removable=0,
-                            last_index=0, pod_sticky=None, ext_capacity=None, rules=None):
+                            last_index=0, pod_sticky=None, ext_capacity=None, rules=None, cand_atomic=None):
     """casim_removal_candidates over numpy arrays; returns (struct, arrays to keep alive)."""
     cn = np.ascontiguousarray(cand_node, np.int32)
     po = np.ascontiguousarray(pod_offsets, np.int32)
@@ -99,6 +99,9 @@ def make_removal_candidates(cand_node, pod_offsets, pod_class, hint_node=None, d
     hn = None if hint_node is None else np.ascontiguousarray(hint_node, np.int32)
     ds = None if destination is None else np.ascontiguousarray(destination, np.uint8)
     sk = None if pod_sticky is None else np.ascontiguousarray(pod_sticky, np.uint8)
+    at = None if cand_atomic is None else np.ascontiguousarray(cand_atomic, np.uint8)
+    if at is not None and at.shape[0] != cn.shape[0]:
+        raise ValueError("cand_atomic must have one entry per candidate")
     if po.shape[0] != cn.shape[0] + 1:
         raise ValueError("pod_offsets must have one more entry than cand_node")
     total = int(po[-1]) if po.size else 0
@@ -109,10 +112,11 @@ def make_removal_candidates(cand_node, pod_offsets, pod_class, hint_node=None, d
                                 hint_node=_ptr(hn, C.c_int32) if hn is not None and hn.size else None,
                                 destination=_ptr(ds, C.c_uint8) if ds is not None and ds.size else None,
                                 pod_sticky=_ptr(sk, C.c_uint8) if sk is not None and sk.size else None,
+                                cand_atomic=_ptr(at, C.c_uint8) if at is not None and at.size else None,
                                 persist=int(bool(persist)), max_removable=int(max_removable), last_index=int(last_index),
                                 ext_capacity=int(ext_capacity),
                                 rules=C.pointer(rules) if rules is not None and rules.n_rules > 0 else None)
-    return st, (cn, po, pc, hn, ds, sk, rules)
+    return st, (cn, po, pc, hn, ds, sk, at, rules)
 
 
 def alloc_removal_results(st: "_abi.RemovalCandidates"):
@@ -225,11 +229,12 @@ class Context:
 
     def simulate_node_removals(self, classes: _abi.Pegs, nodes: _abi.Groups, cand_node, pod_offsets, pod_class, hint_node=None,
                                destination=None, persist: bool = True, max_removable: int = 0, last_index: int = 0,
-                               pod_sticky=None, ext_capacity: Optional[int] = None, time_iters: int = 0, rules=None):
+                               pod_sticky=None, ext_capacity: Optional[int] = None, time_iters: int = 0, rules=None,
+                               cand_atomic=None):
         """Planner.categorizeNodes loop around SimulateNodeRemoval on the device (casim_simulate_node_removals).
         Returns a RemovalResult; with time_iters > 0 (status, HIP-event ms of one resident pass) instead."""
         st, keep = make_removal_candidates(cand_node, pod_offsets, pod_class, hint_node, destination, persist, max_removable, last_index,
-                                           pod_sticky, ext_capacity, rules)
+                                           pod_sticky, ext_capacity, rules, cand_atomic)
         if time_iters > 0:
             ms = C.c_float(0)
             rc = lib.casim_time_node_removals(self._h, C.byref(classes), C.byref(nodes), C.byref(st), int(time_iters), C.byref(ms))

@@ -72,7 +72,8 @@ class RemovalSimulator:
         self.hints.drop_old()
 
     # ---- one device call over `names` (prefix semantics) ----------------------------------------------------
-    def _submit(self, names: Sequence[str], lists: List[List[Pod]], destinations: Dict[str, bool], max_removable: int):
+    def _submit(self, names: Sequence[str], lists: List[List[Pod]], destinations: Dict[str, bool], max_removable: int,
+                atomic: Optional[Sequence[int]] = None):
         enc = Encoder(explicit_self_exclusion=True) if self.lanes is None else Encoder(lanes=self.lanes, explicit_self_exclusion=True)
         class_of: Dict[tuple, int] = {}
         pod_class: List[int] = []
@@ -100,21 +101,25 @@ class RemovalSimulator:
         res = self.ctx.simulate_node_removals(enc.pegs, enc.groups, [pos[n] for n in names], off, pod_class, hint, dest,
                                               persist=self.can_persist, max_removable=max_removable, last_index=self.last_index,
                                               pod_sticky=sticky if any(sticky) else None, ext_capacity=self.ext_capacity,
-                                              rules=enc.rules)
+                                              rules=enc.rules, cand_atomic=atomic if atomic is not None and any(atomic) else None)
         enc.close()
         if res.status == _abi.NG_UNSUPPORTED:
             raise UnsupportedPredicate("pods to move need a predicate outside the encoded subset")
         return res, off
 
-    def simulate_node_removals(self, candidates: Sequence[str], destinations: Dict[str, bool], max_removable: int = 0):
+    def simulate_node_removals(self, candidates: Sequence[str], destinations: Dict[str, bool], max_removable: int = 0,
+                               is_atomic: Optional[Callable[[str], bool]] = None):
         """The categorizeNodes loop (planner.go:300-330): SimulateNodeRemoval per candidate in order, successful
         simulations persisted when `can_persist`, the removed node dropped from `destinations` (:318).
+        `max_removable` = unneededNodesLimit(); nodes for which `is_atomic(name)` holds (their group scales to zero or
+        max, atomicScaleDownNode :339-357) do not count toward it.
         Returns (removable: List[NodeToBeRemoved], unremovable: List[UnremovableNode], skipped: names not evaluated)."""
         removable: List[NodeToBeRemoved] = []
         unremovable: List[UnremovableNode] = []
         todo = list(candidates)
+        counted = 0   # len(removableList) - atomicScaleDownNodesCount
         while todo:
-            if max_removable > 0 and len(removable) >= max_removable:
+            if max_removable > 0 and counted >= max_removable:
                 break
             by_name = {info.node.name: info for info in self.snapshot}
             # GetPodsToMove on the CURRENT snapshot; a node blocked by a pod never reaches the device
@@ -131,9 +136,10 @@ class RemovalSimulator:
                 else:   # cluster.go:138-146: not in the snapshot, decided before any simulation
                     unremovable.append(UnremovableNode(Node(name=n), NO_NODE_INFO))
                 continue
-            left = (max_removable - len(removable)) if max_removable > 0 else 0
+            left = (max_removable - counted) if max_removable > 0 else 0
             infos = list(self.snapshot)   # node indices of this call refer to this list
-            res, off = self._submit(names[:cut], lists[:cut], destinations, left)
+            atomic = [1 if is_atomic(n) else 0 for n in names[:cut]] if is_atomic is not None else None
+            res, off = self._submit(names[:cut], lists[:cut], destinations, left, atomic)
             self.last_index = res.last_index
             flat = [p for lst in lists[:cut] for p in lst]
             again: Dict[int, list] = {}   # candidate -> [(pod, destination)] for the pods it listed again
@@ -151,6 +157,8 @@ class RemovalSimulator:
                         self.hints.set(hint_key_from_pod(p), infos[m].node.name)
                 if int(res.removable[k]) == 1:
                     removable.append(NodeToBeRemoved(info.node, [p for p, _ in moved], [p for p in info.pods if p.daemonset]))
+                    if atomic is None or not atomic[k]:
+                        counted += 1
                     if self.can_persist:
                         # Commit: the pods now run on their destinations (arrival order), the node leaves the list
                         for p, m in moved:
@@ -193,11 +201,23 @@ class Planner:
             by_name[s.node_name].pods.append(s.pod)
         return len(statuses) == len(pods)
 
+    @staticmethod
+    def unneeded_nodes_limit(previously_unneeded: int, max_scale_down_parallelism: int, scale_down_unneeded_time: float,
+                             min_update_interval: float) -> int:
+        """unneededNodesLimit (planner.go:385-400): previously unneeded + 2 N, capped by N * (U / I) + N loops' worth."""
+        n = max_scale_down_parallelism
+        limit = previously_unneeded + 2 * n
+        u = max(int(scale_down_unneeded_time * 1e9), int(min_update_interval * 1e9))   # time.Duration arithmetic (ns)
+        upper = n * int(u // int(min_update_interval * 1e9)) + n
+        return min(upper, limit)
+
     def update_cluster_state(self, pod_destinations: Sequence[str], eligible_candidates: Sequence[str],
-                             recent_evictions: Sequence[Pod] = (), unneeded_nodes_limit: int = 0):
+                             recent_evictions: Sequence[Pod] = (), unneeded_nodes_limit: int = 0,
+                             is_atomic: Optional[Callable[[str], bool]] = None):
         """Returns (removable, unremovable, skipped) of the categorizeNodes loop."""
         self.inject_pods(recent_evictions)
-        out = self.rs.simulate_node_removals(list(eligible_candidates), {n: True for n in pod_destinations}, unneeded_nodes_limit)
+        out = self.rs.simulate_node_removals(list(eligible_candidates), {n: True for n in pod_destinations}, unneeded_nodes_limit,
+                                             is_atomic)
         self.rs.drop_old_hints()
         self.actuation_injector.drop_old_hints()
         return out

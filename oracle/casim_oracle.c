@@ -1141,11 +1141,12 @@ static int snap_pos_of(const orc* o, int orig_id) {
  *   GetPodsToMove sees in the committed snapshot) and reported as ext entries (candidate, pod, destination); the
  *   loop stops in front of such a candidate (*n_processed < K) when an arrived pod is pod_sticky or the ext arrays
  *   (ext_capacity) are full — the protocol of casim_simulate_node_removals, whose caller re-submits the rest.
+ * cand_atomic[k] (may be NULL): the node belongs to an atomically scaled group; it does not count toward max_removable.
  * removable_out[k]: 1 removable, 0 no place, 2 not evaluated.  node_out[i]: node the i-th listed pod was placed
  * on in ITS candidate's simulation (-1: not placed).  final_node_out[i] (may be NULL): where the pod is at the end
  * (its candidate id if it never moved for good). */
 int orc_simulate_node_removals(orc* o, int K, const int32_t* cand_node, const int32_t* pod_offsets, const int32_t* pod,
-                               const int32_t* hint, const uint8_t* destination, const uint8_t* pod_sticky, int persist,
+                               const int32_t* hint, const uint8_t* destination, const uint8_t* pod_sticky, const uint8_t* cand_atomic, int persist,
                                int max_removable, int ext_capacity, int* last_index, uint8_t* removable_out, int32_t* node_out,
                                int32_t* ext_cand_out, int32_t* ext_pod_out, int32_t* ext_node_out, int* n_ext_out,
                                int32_t* final_node_out, int* n_processed) {
@@ -1159,9 +1160,10 @@ int orc_simulate_node_removals(orc* o, int K, const int32_t* cand_node, const in
     int32_t* where = malloc(sizeof(int32_t) * (size_t)(total > 0 ? total : 1));   /* current node (orig id) of every listed pod */
     for (int k = 0; k < K; ++k) for (int i = pod_offsets[k]; i < pod_offsets[k + 1]; ++i) where[i] = cand_node[k];
     ivec moves, move_dest; memset(&moves, 0, sizeof moves); memset(&move_dest, 0, sizeof move_dest);   /* committed moves, in order */
-    int removed = 0, k = 0;
+    int removed = 0, counted = 0, k = 0;
     for (; k < K; ++k) {
-        if (max_removable > 0 && removed >= max_removable) break;         /* planner.go:306-310 */
+        /* planner.go:306-310: len(removableList) - atomicScaleDownNodesCount >= unneededNodesLimit() */
+        if (max_removable > 0 && counted >= max_removable) break;
         const int Y = cand_node[k];
         const int ypos = snap_pos_of(o, Y);
         if (ypos < 0) { removable_out[k] = 0; continue; }                  /* NoNodeInfo :139-147 */
@@ -1217,6 +1219,7 @@ int orc_simulate_node_removals(orc* o, int K, const int32_t* cand_node, const in
             o->snap.n--;
             dest[Y] = 0;
             removed++;
+            if (!(cand_atomic && cand_atomic[k])) counted++;               /* atomicScaleDownNode :321-324 */
         } else {
             for (int i = 0; i < o->undo.n; ++i) {                          /* Revert */
                 const int pos = snap_pos_of(o, o->undo.v[i].orig_id);
@@ -1225,7 +1228,7 @@ int orc_simulate_node_removals(orc* o, int K, const int32_t* cand_node, const in
             }
             node_free(&o->snap.v[ypos]);
             o->snap.v[ypos] = saved_y;
-            if (ok) removed++;
+            if (ok) { removed++; if (!(cand_atomic && cand_atomic[k])) counted++; }
         }
         o->undo.n = 0;
         removable_out[k] = (uint8_t)(ok ? 1 : 0);

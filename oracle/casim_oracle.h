@@ -130,7 +130,7 @@ int orc_snapshot_size(const orc* o);
  * CA/core/scaledown/planner/planner.go:300-330, CA/simulator/cluster.go:131-265).  See the .c file for the
  * argument meaning.  Node ids = positions at orc_snapshot_add time.  Returns the number of removable nodes. */
 int orc_simulate_node_removals(orc* o, int n_candidates, const int32_t* cand_node, const int32_t* pod_offsets,
-                               const int32_t* pod, const int32_t* hint, const uint8_t* destination, const uint8_t* pod_sticky,
+                               const int32_t* pod, const int32_t* hint, const uint8_t* destination, const uint8_t* pod_sticky, const uint8_t* cand_atomic,
                                int persist, int max_removable, int ext_capacity, int* last_index, uint8_t* removable_out,
                                int32_t* node_out, int32_t* ext_cand_out, int32_t* ext_pod_out, int32_t* ext_node_out,
                                int* n_ext_out, int32_t* final_node_out, int* n_processed);

@@ -248,6 +248,7 @@ class RemovalCase:
     last_index: int = 0
     sticky: Optional[set] = None                   # id(pod) of pods the host must re-examine before a second move
     ext_capacity: Optional[int] = None             # None = default (2 * pods + 64); 0 = stop at any arrival
+    atomic: Optional[Sequence[int]] = None         # per candidate: node of an atomically scaled group (not counted toward the limit)
     lanes: Sequence[str] = ("cpu", "memory")
 
     def pod_lists(self):
@@ -269,7 +270,7 @@ def removal_oracle(case: RemovalCase):
     for info in case.nodes:
         s.add_existing(info)
     out = s.simulate_node_removals(case.candidates, case.pod_lists(), case.flat_hints(), case.destination, case.persist,
-                                   case.max_removable, case.flat_sticky(), case.ext_capacity, case.last_index)
+                                   case.max_removable, case.flat_sticky(), case.ext_capacity, case.last_index, case.atomic)
     s.close()
     return out
 
@@ -317,7 +318,8 @@ class EmuContext:
         return rc, node_out[:seq.n_pods], li.value, ns.value
 
     def simulate_node_removals(self, classes, nodes, cand_node, pod_offsets, pod_class, hint_node=None, destination=None,
-                               persist=True, max_removable=0, last_index=0, pod_sticky=None, ext_capacity=None, rules=None):
+                               persist=True, max_removable=0, last_index=0, pod_sticky=None, ext_capacity=None, rules=None,
+                               cand_atomic=None):
         from kubernetes_autoscaler_amd.engine import alloc_removal_results, finish_removal_results, make_removal_candidates
         L = emu_lib()
         if not hasattr(L, "_removal_ready"):
@@ -326,7 +328,7 @@ class EmuContext:
                                                      C.c_int64, C.POINTER(_abi.RemovalResults)]
             L._removal_ready = True
         st, keep = make_removal_candidates(cand_node, pod_offsets, pod_class, hint_node, destination, persist, max_removable, last_index,
-                                           pod_sticky, ext_capacity, rules)
+                                           pod_sticky, ext_capacity, rules, cand_atomic)
         res, packed = alloc_removal_results(st)
         rc = L.emu_simulate_node_removals(C.byref(classes), C.byref(nodes), C.byref(st), int(self.lds_budget), C.byref(res))
         assert rc >= 0, (rc, L.emu_last_error())
@@ -339,7 +341,8 @@ def removal_device(case: RemovalCase, ctx):
     enc, pod_class, off = removal_encode(case)
     out = ctx.simulate_node_removals(enc.pegs, enc.groups, case.candidates, off, pod_class, case.flat_hints(), case.destination,
                                      persist=case.persist, max_removable=case.max_removable, last_index=case.last_index,
-                                     pod_sticky=case.flat_sticky(), ext_capacity=case.ext_capacity, rules=enc.rules)
+                                     pod_sticky=case.flat_sticky(), ext_capacity=case.ext_capacity, rules=enc.rules,
+                                     cand_atomic=case.atomic)
     enc.close()
     return out
 

@@ -71,7 +71,7 @@ def lib():
             "orc_run_filters_until_passing": (C.c_int, [P, C.c_int, C.POINTER(C.c_int)]),
             "orc_try_schedule_pods": (C.c_int, [P, C.c_int, i32p, i32p, i32p, u8p, C.c_int, C.POINTER(C.c_int), i32p]),
             "orc_snapshot_size": (C.c_int, [P]),
-            "orc_simulate_node_removals": (C.c_int, [P, C.c_int, i32p, i32p, i32p, i32p, u8p, u8p, C.c_int, C.c_int, C.c_int,
+            "orc_simulate_node_removals": (C.c_int, [P, C.c_int, i32p, i32p, i32p, i32p, u8p, u8p, u8p, C.c_int, C.c_int, C.c_int,
                                                     C.POINTER(C.c_int), u8p, i32p, i32p, i32p, i32p, C.POINTER(C.c_int), i32p,
                                                     C.POINTER(C.c_int)]),
             "orc_get_min_limit": (C.c_int64, [C.c_int64, C.c_int64]),
@@ -266,7 +266,7 @@ class OracleScenario:
         return out[:n].copy(), li.value, ns
 
     def simulate_node_removals(self, cand_node, pod_lists, hints=None, destination=None, persist=True, max_removable=0,
-                               pod_sticky=None, ext_capacity=None, last_index=0):
+                               pod_sticky=None, ext_capacity=None, last_index=0, cand_atomic=None):
         """Planner loop around SimulateNodeRemoval on the snapshot built with add_existing().  pod_lists[k] = pods to move
         of candidate k (Pod objects).  Returns a dict: removable[K], node_out[total], ext (list of (candidate, pod, node)),
         final[total], last_index, n_processed."""
@@ -283,6 +283,7 @@ class OracleScenario:
         hn = None if hints is None else np.ascontiguousarray(hints, np.int32)
         ds = None if destination is None else np.ascontiguousarray(destination, np.uint8)
         sk = None if pod_sticky is None else np.ascontiguousarray(pod_sticky, np.uint8)
+        at = None if cand_atomic is None else np.ascontiguousarray(cand_atomic, np.uint8)
         removable = np.full(max(K, 1), 2, np.uint8)
         node_out = np.full(max(total, 1), -1, np.int32)
         final = np.full(max(total, 1), -1, np.int32)
@@ -291,7 +292,8 @@ class OracleScenario:
         rc = self.L.orc_simulate_node_removals(self.h, K, cn.ctypes.data_as(i32p), off.ctypes.data_as(i32p), pods.ctypes.data_as(i32p),
                                                hn.ctypes.data_as(i32p) if hn is not None and hn.size else None,
                                                ds.ctypes.data_as(u8p) if ds is not None and ds.size else None,
-                                               sk.ctypes.data_as(u8p) if sk is not None and sk.size else None, int(persist),
+                                               sk.ctypes.data_as(u8p) if sk is not None and sk.size else None,
+                                               at.ctypes.data_as(u8p) if at is not None and at.size else None, int(persist),
                                                int(max_removable), E, C.byref(li), removable.ctypes.data_as(u8p),
                                                node_out.ctypes.data_as(i32p), ec.ctypes.data_as(i32p), ep.ctypes.data_as(i32p),
                                                en.ctypes.data_as(i32p), C.byref(ne), final.ctypes.data_as(i32p), C.byref(npr))

@@ -196,6 +196,31 @@ def test_reference_planner_table(ctx):
         assert [u.node.name for u in unremovable] == [n for n in row["eligible"] if n not in row["unneeded"]], row["name"]
 
 
+def test_reference_unneeded_nodes_limit_table(ctx):
+    """planner_test.go TestUpdateClusterStatUnneededNodesLimit rows + random atomic flags on fuzz clusters."""
+    import json
+    import os
+    import random
+    from harness import RemovalCase, assert_removal_matches, removal_device, removal_oracle
+    from kubernetes_autoscaler_amd.scaledown import Planner
+    from kubernetes_autoscaler_amd.workloads import fuzz_removals
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")) as f:
+        rows = json.load(f)["planner_unneeded_nodes_limit"]["cases"]
+    for row in rows:
+        infos = [NodeInfo(build_test_node(f"n{i}", 1000, 10)) for i in range(row["nodes"])]
+        names = [i.node.name for i in infos]
+        limit = Planner.unneeded_nodes_limit(row["previously_unneeded"], row["max_parallelism"], row["unneeded_time_s"], row["update_interval_s"])
+        removable, unremovable, skipped = Planner(ctx, infos).update_cluster_state(names, names, (), limit, (lambda n: True) if row["atomic"] else None)
+        assert len(removable) == row["want_unneeded"] and not unremovable and skipped == names[row["want_unneeded"]:], row["name"]
+    for seed in range(40):
+        w = fuzz_removals(7000 + seed)
+        rng = random.Random(seed)
+        case = RemovalCase(nodes=w.nodes, candidates=w.candidates, destination=w.destination, hints=w.hints, persist=w.persist,
+                           max_removable=rng.randint(1, 3), last_index=w.last_index)
+        case.atomic = [1 if rng.random() < 0.4 else 0 for _ in case.candidates]
+        assert_removal_matches(removal_device(case, ctx), removal_oracle(case), w.name)
+
+
 def test_removal_fuzz(ctx):
     from harness import RemovalCase, assert_removal_matches, removal_device, removal_oracle
     from kubernetes_autoscaler_amd.workloads import fuzz_removals

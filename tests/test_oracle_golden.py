@@ -375,3 +375,19 @@ def test_planner_update_cluster_state(row):
     s.close()
     assert got["n_processed"] == len(cands)
     assert [names[c] for c, r in zip(cands, got["removable"]) if r == 1] == row["unneeded"]
+
+
+@pytest.mark.parametrize("row", GOLD["planner_unneeded_nodes_limit"]["cases"], ids=lambda r: r["name"])
+def test_planner_unneeded_nodes_limit(row):
+    from oracle_driver import OracleScenario
+    from kubernetes_autoscaler_amd.scaledown import Planner
+    n = row["nodes"]
+    limit = Planner.unneeded_nodes_limit(row["previously_unneeded"], row["max_parallelism"], row["unneeded_time_s"], row["update_interval_s"])
+    s = OracleScenario(lanes=("cpu", "memory"))
+    for i in range(n):
+        s.add_existing(NodeInfo(build_test_node(f"n{i}", 1000, 10)))
+    got = s.simulate_node_removals(list(range(n)), [[] for _ in range(n)], persist=True, max_removable=limit,
+                                   cand_atomic=[1] * n if row["atomic"] else None)
+    s.close()
+    assert int((got["removable"] == 1).sum()) == row["want_unneeded"]
+    assert got["n_processed"] == row["want_unneeded"]   # the prefix that was evaluated, the rest is skipped (:307)

@@ -221,3 +221,43 @@ def test_reference_planner_table(row, lds):
     assert [r.node.name for r in removable] == row["unneeded"]
     assert [u.node.name for u in unremovable] == [n for n in row["eligible"] if n not in row["unneeded"]]
     assert [i.node.name for i in infos] == [n for n in names if n not in row["unneeded"]]   # persisted removals left the snapshot
+
+
+def _limit_rows():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")) as f:
+        return json.load(f)["planner_unneeded_nodes_limit"]["cases"]
+
+
+@pytest.mark.parametrize("row", _limit_rows(), ids=lambda r: r["name"])
+def test_reference_unneeded_nodes_limit_table(row):
+    """planner_test.go TestUpdateClusterStatUnneededNodesLimit through the Planner mirror."""
+    from kubernetes_autoscaler_amd.objects import build_test_node
+    from kubernetes_autoscaler_amd.scaledown import Planner
+    infos = [NodeInfo(build_test_node(f"n{i}", 1000, 10)) for i in range(row["nodes"])]
+    names = [i.node.name for i in infos]
+    limit = Planner.unneeded_nodes_limit(row["previously_unneeded"], row["max_parallelism"], row["unneeded_time_s"], row["update_interval_s"])
+    removable, unremovable, skipped = Planner(EmuContext(0), infos).update_cluster_state(
+        names, names, (), limit, (lambda n: True) if row["atomic"] else None)
+    assert len(removable) == row["want_unneeded"] and not unremovable
+    assert skipped == names[row["want_unneeded"]:]
+
+
+def test_atomic_candidates_do_not_count_toward_the_limit():
+    # mixed: every third candidate is atomic; limit 4 -> the loop stops after the 4th counted removal
+    nodes = [NodeInfo(_node(f"n{i}", 1000, 10**9, 10)) for i in range(20)]
+    atomic = [1 if i % 3 == 0 else 0 for i in range(20)]
+    w = check(RemovalCase(nodes=nodes, candidates=list(range(20)), max_removable=4, atomic=atomic))
+    assert w["n_processed"] == 6 and list(w["removable"][:6]) == [1] * 6   # n0 atomic, n1, n2, n3 atomic, n4, n5
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_fuzz_atomic_candidates(seed):
+    import random
+    w = fuzz_removals(7000 + seed)
+    rng = random.Random(seed)
+    case = case_of(w)
+    case.max_removable = rng.randint(1, 3)
+    case.atomic = [1 if rng.random() < 0.4 else 0 for _ in case.candidates]
+    check(case, w.name)
