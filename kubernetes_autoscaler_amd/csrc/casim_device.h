@@ -40,6 +40,7 @@ CS_DEVICE uint32_t wave_sum_u32(uint32_t v) { return (uint32_t)casim_emu::wave_s
 CS_DEVICE uint64_t wave_sum_u64(uint64_t v) { return casim_emu::wave_sum_u64(v); }
 CS_DEVICE uint32_t wave_max_u32(uint32_t v) { return (uint32_t)casim_emu::wave_max_u64(v); }
 CS_DEVICE uint32_t bcast_u32(uint32_t v, int uniform_lane) { return (uint32_t)casim_emu::wave_xchg_u64(v, uniform_lane); }
+CS_DEVICE uint32_t uniform_u32(uint32_t v) { return v; }
 CS_DEVICE int popc64(uint64_t v) { return __builtin_popcountll(v); }
 CS_DEVICE int ffs64(uint64_t v) { return v ? __builtin_ctzll(v) : -1; }
 CS_DEVICE int fls64(uint64_t v) { return v ? 63 - __builtin_clzll(v) : -1; }
@@ -120,6 +121,8 @@ CS_DEVICE uint64_t wave_sum_u64(uint64_t v) {
 }
 // value of a wave-UNIFORM lane index: v_readlane_b32 (scalar result, no LDS crossbar)
 CS_DEVICE uint32_t bcast_u32(uint32_t v, int uniform_lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, uniform_lane); }
+// a value every lane holds identically (e.g. an LDS word read at a wave-uniform address): move it to a scalar register
+CS_DEVICE uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 CS_DEVICE int popc64(uint64_t v) { return __popcll(v); }
 CS_DEVICE int ffs64(uint64_t v) { return v ? (int)__builtin_ctzll(v) : -1; }
 CS_DEVICE int fls64(uint64_t v) { return v ? 63 - (int)__builtin_clzll(v) : -1; }

@@ -127,6 +127,7 @@ struct MemStore {
     static constexpr bool kHasExcl = true;
     static constexpr bool kHasZone = true;
     static constexpr int kZoneWords = 0;    // group-wide exclusion words live in LDS (per-lane copies), any number
+    static constexpr bool kChunkLds = false; // the 64 PEG records of a chunk stay in the lanes' registers
     using Peg = PegView<int64_t, CASIM_KMAX_RES>;
     using Fresh = FreshNode<int64_t, CASIM_KMAX_RES>;
     int R, Wx, cap;
@@ -162,6 +163,10 @@ struct MemStore {
     CS_DEVICE uint32_t get_c(int, int m) const { return (uint32_t)sctmp[m]; }
     CS_DEVICE void set_c(int, int m, uint32_t v) { sctmp[m] = (int32_t)v; }
     CS_DEVICE int32_t npods(int, int m) const { return snpods[m]; }
+    // the newest node lm (wave-uniform): every lane may ask, one lane (`mine`) writes
+    CS_DEVICE uint32_t capacity_newest(int lm, const Peg& pv, uint32_t clampk, bool selfx, bool mine) const { return mine ? capacity(0, lm, pv, clampk, selfx) : 0u; }
+    CS_DEVICE void commit_newest(int lm, uint32_t x, const Peg& pv, bool mine) { if (mine) commit(0, lm, x, pv); }
+    CS_DEVICE int32_t npods_newest(int lm, bool mine) const { return mine ? snpods[lm] : 0; }
     // summary pruning is a register-store feature
     CS_DEVICE bool may_fit(const Peg&) const { return true; }
     CS_DEVICE void tighten(int, int) {}
@@ -179,6 +184,10 @@ struct RegStore {
     static constexpr bool X_ = WX_ > 0;
     static constexpr bool kHasZone = WX_ > 0;   // the lean instantiation (WX_ = 0) carries no exclusion state at all
     static constexpr int kZoneWords = 2;        // group-wide exclusion words are wave-uniform: up to two, in scalar registers
+    // The 64 PEG records of a chunk are parked in LDS ((3 + 3 R_) words per record, kChunkBytes per wave) and read back
+    // at a wave-uniform address: nine VGPRs less than keeping them in the lanes — what the 5th / 6th wave per SIMD needs.
+    static constexpr bool kChunkLds = true;
+    static constexpr int kChunkBytes = (3 + 3 * R_) * 64 * 4;
     using Peg = PegView<int32_t, R_>;
     using Fresh = FreshNode<int32_t, R_>;
     int32_t fr[NPT_][R_];
@@ -191,7 +200,6 @@ struct RegStore {
         return b;
     }
     int32_t slots[NPT_];
-    uint32_t c[NPT_];
     int32_t fresh_slots;  // pod slots of an empty node: pods on a node = fresh_slots - slots (no per-node counter)
 
     CS_DEVICE uint32_t capacity(int s, int, const Peg& pv, uint32_t clampk, bool selfx) const {
@@ -205,7 +213,9 @@ struct RegStore {
     // the quotient chain (cvt -> f64 mul by the PEG's reciprocal -> cvt -> exact +-1 fix-up).  In the
     // steady state of a scale-up most PEGs fit nowhere or on a few nodes, so most slots stop at the mask.
     // Slots beyond M hold zeros (slots == 0): no extra guard.  Returns n1 = nodes taking >= 1 pod.
-    CS_DEVICE int32_t capacity_all(const Peg& pv, uint32_t clampk, bool selfx) {
+    // The capacities go to the caller's array: they are dead after a2, and as a member they travelled through every
+    // merge point of the PEG loop with the rest of the state.
+    CS_DEVICE int32_t capacity_all(const Peg& pv, uint32_t clampk, bool selfx, uint32_t* c) const {
         int32_t n1 = 0;
 #pragma unroll
         for (int s = 0; s < NPT_; ++s) {
@@ -255,9 +265,50 @@ struct RegStore {
 #pragma unroll
         for (int w = 0; w < WX_; ++w) excl[s][w] = (w < wx ? fn.excl[w] : 0ull) | (x > 0 ? pv.xm[w] : 0ull);   // wx <= WX_ words exist
     }
-    CS_DEVICE uint32_t get_c(int s, int) const { return c[s]; }
-    CS_DEVICE void set_c(int s, int, uint32_t v) { c[s] = v; }
+    CS_DEVICE uint32_t get_c(int, int) const { return 0; }   // (register store: pack_body keeps the capacities itself)
+    CS_DEVICE void set_c(int, int, uint32_t) {}
     CS_DEVICE int32_t npods(int s, int) const { return fresh_slots - slots[s]; }  // only asked for created nodes
+    // The newest node lm (wave-uniform index; slot lm >> 6 of lane lm & 63).  Straight-line selects over the slots
+    // instead of a branch per slot: with branches the compiler carried the whole register state through every merge
+    // point (dozens of v_mov per PEG).  Every lane evaluates its own node of that slot; the caller reads lane `mine`.
+    CS_DEVICE uint32_t capacity_newest(int lm, const Peg& pv, uint32_t clampk, bool selfx, bool) const {
+        const int ls = lm >> 6;
+        int32_t f[R_], sl = 0;
+        bool b = false;
+#pragma unroll
+        for (int r = 0; r < R_; ++r) f[r] = 0;
+#pragma unroll
+        for (int s = 0; s < NPT_; ++s) {
+            const bool h = s == ls;
+#pragma unroll
+            for (int r = 0; r < R_; ++r) f[r] = h ? fr[s][r] : f[r];
+            sl = h ? slots[s] : sl;
+            if (X_) b = h ? blocked(s, pv) : b;
+        }
+        if (X_ && b) return 0;
+        uint32_t k = capacity_lanes<Lane, R_>(f, sl, R_, pv, clampk);
+        if (selfx && k > 1) k = 1;
+        return k;
+    }
+    CS_DEVICE void commit_newest(int lm, uint32_t x, const Peg& pv, bool mine) {
+        const int ls = lm >> 6;
+#pragma unroll
+        for (int s = 0; s < NPT_; ++s) {
+            const bool h = mine && s == ls;
+#pragma unroll
+            for (int r = 0; r < R_; ++r) fr[s][r] = h ? fr[s][r] - (int32_t)x * pv.req[r] : fr[s][r];
+            slots[s] = h ? slots[s] - (int32_t)x : slots[s];
+#pragma unroll
+            for (int w = 0; w < WX_; ++w) excl[s][w] = h ? (excl[s][w] | pv.xm[w]) : excl[s][w];
+        }
+    }
+    CS_DEVICE int32_t npods_newest(int lm, bool) const {
+        const int ls = lm >> 6;
+        int32_t sl = 0;
+#pragma unroll
+        for (int s = 0; s < NPT_; ++s) sl = s == ls ? slots[s] : sl;
+        return fresh_slots - sl;
+    }
 
     // Summary pruning.  bound_free[r] / bound_slots are wave-uniform UPPER bounds of max_j free_j[r] and
     // max_j slots_j over all simulated nodes.  Placements only lower the true maxima, so a stale bound stays
@@ -341,7 +392,7 @@ struct PegChunk {
 template <class Store, class ReqLoader>
 CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, const typename Store::Fresh& fn,
                          uint64_t* szone /*[Wz][64] per-lane copies or null*/, ReqLoader load_req, const int64_t* sum_scale,
-                         int64_t* prof_out = nullptr) {
+                         int64_t* prof_out = nullptr, uint32_t* chunk = nullptr /*LDS, Store::kChunkLds only*/) {
     using L = typename Store::Lane;
     constexpr int RM = Store::kRMax;
     const int ng = cs::bid();
@@ -397,45 +448,76 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     int64_t sum0 = 0, sum1 = 0;            // sum of placed * req lane 0 / 1 (in store units)
 
     CASIM_PROF_DECL;
-    for (int k0 = 0; k0 < Gn; k0 += 64) {
-        CASIM_PROF(0);  // chunk load / store, loop overhead
-        // ---- one coalesced wave-load: PEG record k0+lane of this group, in processing order ----
-        const int kk = k0 + lane;
-        const bool have = kk < Gn;
-        const int32_t my_cnt = have ? res.s_count[off + kk] : 0;
-        const uint32_t my_flags = have ? res.s_flags[off + kk] : 0u;
-        const int32_t my_g = have ? res.order[off + kk] : 0;
-        L my_req[RM];
+    // ONE loop over the PEGs of the group: every 64th iteration loads the next chunk of records (a nested chunk / record
+    // loop made the compiler keep two copies of the node state, one per loop level, and shuffle ~70 registers per PEG).
+    int32_t my_cnt = 0, my_g = 0, my_placed = 0;
+    uint32_t my_flags = 0;
+    L my_req[RM];
+    double my_rq[RM];
 #pragma unroll
-        for (int r = 0; r < RM; ++r) my_req[r] = (have && r < R) ? load_req(off + kk, r) : (L)0;
-        // 1 / req for capacity_lanes' quotient estimate: computed by the record's own lane, i.e. 64 PEGs'
-        // worth of f64 divisions per wave instruction instead of one uniform division per PEG
-        double my_rq[RM];
+    for (int r = 0; r < RM; ++r) { my_req[r] = 0; my_rq[r] = 0.0; }
+    for (int k = 0; k < Gn; ++k) {
+        const int j = k & 63;
+        if (j == 0) {
+            CASIM_PROF(0);  // chunk load / store, loop overhead
+            if (k > 0) res.placed[off + k - 64 + lane] = my_placed;  // one coalesced wave-store per 64 PEGs (a full chunk)
+            // ---- one coalesced wave-load: PEG record k+lane of this group, in processing order ----
+            const int kk = k + lane;
+            const bool have = kk < Gn;
+            my_cnt = have ? res.s_count[off + kk] : 0;
+            my_flags = have ? res.s_flags[off + kk] : 0u;
+            my_g = have ? res.order[off + kk] : 0;
 #pragma unroll
-        for (int r = 0; r < RM; ++r) my_rq[r] = my_req[r] > 0 ? 1.0 / (double)my_req[r] : 0.0;
-        int32_t my_placed = 0;
-        const int nk = Gn - k0 < 64 ? Gn - k0 : 64;
-
-        for (int j = 0; j < nk; ++j) {
-            const int k = k0 + j;
-            const int32_t cnt = (int32_t)cs::bcast_u32((uint32_t)my_cnt, j);
-            const uint32_t pf = cs::bcast_u32(my_flags, j);
+            for (int r = 0; r < RM; ++r) my_req[r] = (have && r < R) ? load_req(off + kk, r) : (L)0;
+            // 1 / req for capacity_lanes' quotient estimate: computed by the record's own lane, i.e. 64 PEGs'
+            // worth of f64 divisions per wave instruction instead of one uniform division per PEG
+#pragma unroll
+            for (int r = 0; r < RM; ++r) my_rq[r] = my_req[r] > 0 ? 1.0 / (double)my_req[r] : 0.0;
+            my_placed = 0;
+            if constexpr (Store::kChunkLds) {
+                cs::sync();   // (one wave per block: orders the previous chunk's reads before these writes)
+                chunk[0 * 64 + lane] = (uint32_t)my_cnt; chunk[1 * 64 + lane] = my_flags; chunk[2 * 64 + lane] = (uint32_t)my_g;
+#pragma unroll
+                for (int r = 0; r < RM; ++r) {
+                    chunk[(3 + r) * 64 + lane] = (uint32_t)my_req[r];
+                    const uint64_t b = cs::double_bits(my_rq[r]);
+                    chunk[(3 + RM + 2 * r) * 64 + lane] = (uint32_t)b; chunk[(3 + RM + 2 * r + 1) * 64 + lane] = (uint32_t)(b >> 32);
+                }
+                cs::sync();
+            }
+        }
+        {
+            int32_t cnt; uint32_t pf;
             typename Store::Peg pv;
+            if constexpr (Store::kChunkLds) {
+                cnt = (int32_t)cs::uniform_u32(chunk[0 * 64 + j]);
+                pf = cs::uniform_u32(chunk[1 * 64 + j]);
 #pragma unroll
-            for (int r = 0; r < RM; ++r) {
-                if (r < R) {
-                    if constexpr (sizeof(L) == 4) pv.req[r] = (L)cs::bcast_u32((uint32_t)my_req[r], j);
-                    else pv.req[r] = (L)cs::bcast_u64((uint64_t)my_req[r], j);
-                } else pv.req[r] = 0;
-                pv.rq[r] = cs::bits_double(cs::bcast_u64(cs::double_bits(my_rq[r]), j));
+                for (int r = 0; r < RM; ++r) {
+                    pv.req[r] = r < R ? (L)cs::uniform_u32(chunk[(3 + r) * 64 + j]) : (L)0;
+                    pv.rq[r] = cs::bits_double(((uint64_t)cs::uniform_u32(chunk[(3 + RM + 2 * r + 1) * 64 + j]) << 32) | cs::uniform_u32(chunk[(3 + RM + 2 * r) * 64 + j]));
+                }
+            } else {
+                cnt = (int32_t)cs::bcast_u32((uint32_t)my_cnt, j);
+                pf = cs::bcast_u32(my_flags, j);
+#pragma unroll
+                for (int r = 0; r < RM; ++r) {
+                    if (r < R) {
+                        if constexpr (sizeof(L) == 4) pv.req[r] = (L)cs::bcast_u32((uint32_t)my_req[r], j);
+                        else pv.req[r] = (L)cs::bcast_u64((uint64_t)my_req[r], j);
+                    } else pv.req[r] = 0;
+                    pv.rq[r] = cs::bits_double(cs::bcast_u64(cs::double_bits(my_rq[r]), j));
+                }
             }
             const bool selfx = (pf & CASIM_PEG_SELF_EXCL_NODE) != 0;
-            bool zselfx = (pf & CASIM_PEG_SELF_EXCL_ZONE) != 0;
+            // (group-wide self-exclusion needs a store with zone state: the pipeline sends such batches to one)
+            bool zselfx = Store::kHasZone && (pf & CASIM_PEG_SELF_EXCL_ZONE) != 0;
             const bool static_ok = (pf & CASIM_KFLAG_STATIC_OK) != 0;
             pv.xblock = nullptr; pv.xmark = nullptr; pv.xb[0] = pv.xb[1] = 0; pv.xm[0] = pv.xm[1] = 0;
             const uint64_t *zblock = nullptr, *zmark = nullptr;
             if (Wx > 0 || Wz > 0) {
-                const int g = (int)cs::bcast_u32((uint32_t)my_g, j);
+                int g;
+                if constexpr (Store::kChunkLds) g = (int)cs::uniform_u32(chunk[2 * 64 + j]); else g = (int)cs::bcast_u32((uint32_t)my_g, j);
                 pv.xblock = t.xblock + (int64_t)g * Wx; pv.xmark = t.xmark + (int64_t)g * Wx;
                 zblock = t.zblock + (int64_t)g * Wz; zmark = t.zmark + (int64_t)g * Wz;
                 if (Store::kNPT > 0 && Wx > 0) {   // register store: the words travel in SGPRs
@@ -466,9 +548,15 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 uint64_t lane_sum = 0;
                 uint32_t lane_max = 0;
                 int32_t n1 = 0;
+                uint32_t creg[Store::kNPT > 0 ? Store::kNPT : 1];   // register store: c_j of this PEG, dead after a2
+#pragma unroll
+                for (int s = 0; s < (Store::kNPT > 0 ? Store::kNPT : 1); ++s) creg[s] = 0;
+                auto getc = [&](int s, int m) -> uint32_t {
+                    if constexpr (Store::kNPT > 0) return creg[s]; else return st.get_c(s, m);
+                };
                 if (st.may_fit(pv)) {  // summary pruning: no node can take this PEG (stale-but-safe bounds)
                     if constexpr (Store::kNPT > 0) {
-                        n1 = st.capacity_all(pv, keff, selfx);  // every slot (nodes >= M are all-zero)
+                        n1 = st.capacity_all(pv, keff, selfx, creg);  // every slot (nodes >= M are all-zero)
                     } else {
                         for_slots<Store>(S, [&](int s) {
                             const int m = s * 64 + lane;
@@ -489,7 +577,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     } else {
                         // sum and max of the capacities are only needed when the pods complete >= 1 round
                         for_slots<Store>(S, [&](int s) {
-                            const uint32_t cj = st.get_c(s, s * 64 + lane);
+                            const uint32_t cj = getc(s, s * 64 + lane);
                             lane_sum += cj;
                             lane_max = cj > lane_max ? cj : lane_max;
                         });
@@ -502,7 +590,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                                 const uint32_t mid = lo + ((hi - lo) >> 1);
                                 uint64_t ls = 0;
                                 for_slots<Store>(S, [&](int s) {
-                                    const uint32_t cj = st.get_c(s, s * 64 + lane);
+                                    const uint32_t cj = getc(s, s * 64 + lane);
                                     ls += cj < mid ? cj : mid;
                                 });
                                 const uint64_t sm = wsum(ls);
@@ -520,7 +608,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     const int32_t m0 = o > E ? o - E : 0;
                     int32_t A = 0, Tot = 0;
                     for_slots<Store>(S, [&](int s) {
-                        const uint64_t b = cs::ballot(st.get_c(s, s * 64 + lane) >= Tf);
+                        const uint64_t b = cs::ballot(getc(s, s * 64 + lane) >= Tf);
                         Tot += cs::popc64(b);
                         A += cs::popc64(b & cs::low_mask(m0 - s * 64));
                     });
@@ -529,7 +617,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     uint32_t x_mine_last = 0;
                     for_slots<Store>(S, [&](int s) {
                         const int m = s * 64 + lane;
-                        const uint32_t cj = st.get_c(s, m);
+                        const uint32_t cj = getc(s, m);
                         const bool cand = cj >= Tf;
                         const uint64_t b = cs::ballot(cand);
                         const int32_t pex = basec + cs::mbcnt(b);
@@ -611,11 +699,10 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     if (M > 0) {
                         const int lm = M - 1, owner = lm & 63;
                         uint32_t cl = 0;
-                        if (!blocked && !(selfx && on_last > 0) && lane == owner)
-                            with_slot<Store>(lm >> 6, [&](int s) { cl = st.capacity(s, lm, pv, (uint32_t)rem, selfx || zselfx); });
-                        cl = cs::bcast_u32(cl, owner);
+                        if (!blocked && !(selfx && on_last > 0))   // wave-uniform
+                            cl = cs::bcast_u32(st.capacity_newest(lm, pv, (uint32_t)rem, selfx || zselfx, lane == owner), owner);
                         if (cl > 0) {
-                            if (lane == owner) with_slot<Store>(lm >> 6, [&](int s) { st.commit(s, lm, cl, pv); });
+                            st.commit_newest(lm, cl, pv, lane == owner);
                             placed += (int32_t)cl; rem -= (int32_t)cl; marked = true;
                             st.note_change();
                             if (zselfx) blocked = true;
@@ -625,22 +712,22 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     if (!stop && M > 0) {
                         // newest node still empty and the pod does not fit it: a new one would not help (:234-236)
                         const int lm = M - 1, owner = lm & 63;
-                        uint32_t np_l = 0;
-                        if (lane == owner) with_slot<Store>(lm >> 6, [&](int s) { np_l = (uint32_t)st.npods(s, lm); });
-                        if (cs::bcast_u32(np_l, owner) == 0) stop = true;
+                        if (cs::bcast_u32((uint32_t)st.npods_newest(lm, lane == owner), owner) == 0) stop = true;
                     }
-                    while (!stop) {
+                    // (without zone state the body runs at most once: a straight line instead of a loop whose
+                    // back edge carried the whole register state)
+                    auto new_nodes = [&]() -> bool {   // false = done
                         const uint32_t cn = blocked ? 0u : cfresh;
                         if (cn == 0 || zselfx) {
-                            if (permission_left() <= 0) { more = false; break; }       // :244-246
+                            if (permission_left() <= 0) { more = false; return false; }       // :244-246
                             granted++;
                             const uint32_t x = cn < (uint32_t)rem ? cn : (uint32_t)rem;  // 0 or 1
                             create_nodes(M, 1, x, (int32_t)x);
                             M++;
-                            if (x == 0) break;                                          // :257-263 node stays, PEG abandoned
+                            if (x == 0) return false;                                   // :257-263 node stays, PEG abandoned
                             placed += (int32_t)x; rem -= (int32_t)x; marked = true;
                             blocked = true;                                             // zselfx: the group now holds one
-                            if (rem == 0) break;
+                            return Store::kHasZone && rem != 0;
                         } else {
                             // rem <= 2^31 - 1 and cn <= rem: 32-bit unsigned arithmetic is exact (an emulated
                             // 64-bit division here cost more than the whole node creation)
@@ -654,9 +741,11 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                                 M += nadd; granted += nadd; placed += pl; rem -= pl; marked = true;
                             }
                             if (need > left) more = false;
-                            break;
+                            return false;
                         }
-                    }
+                    };
+                    if constexpr (Store::kHasZone) { while (!stop && new_nodes()) {} }
+                    else { if (!stop) new_nodes(); }
                 }
                 if (marked && Wz > 0) zone_mark(zmark);
             }
@@ -667,7 +756,10 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             sum0 += (int64_t)placed * (int64_t)pv.req[0];
             sum1 += (int64_t)placed * (int64_t)pv.req[1];
         }
-        if (have) res.placed[off + kk] = my_placed;  // one coalesced wave-store per 64 PEGs
+    }
+    if (Gn > 0) {   // the last (possibly partial) chunk
+        const int kk = ((Gn - 1) & ~63) + lane;
+        if (kk < Gn) res.placed[off + kk] = my_placed;
     }
 
     CASIM_PROF(0);
@@ -743,7 +835,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, ((NPT_ == 4 && WX_ == 0) ? CASIM_FAST_WAVES : 1))
     for (int s = 0; s < NPT_; ++s) {
 #pragma unroll
         for (int r = 0; r < R_; ++r) st.fr[s][r] = 0;
-        st.slots[s] = 0; st.c[s] = 0;
+        st.slots[s] = 0;
 #pragma unroll
         for (int w = 0; w < WX_; ++w) st.excl[s][w] = 0;
     }
@@ -759,7 +851,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, ((NPT_ == 4 && WX_ == 0) ? CASIM_FAST_WAVES : 1))
     const int32_t* order = res.order;
     const int R = t.R;
     pack_body(t, res, st, fn, (uint64_t*)nullptr,
-              [=](int idx, int r) -> int32_t { return req32[(int64_t)order[idx] * R + r]; }, fs.scale, fs.prof);
+              [=](int idx, int r) -> int32_t { return req32[(int64_t)order[idx] * R + r]; }, fs.scale, fs.prof, (uint32_t*)cs::dyn_smem());
 }
 
 }  // namespace casim

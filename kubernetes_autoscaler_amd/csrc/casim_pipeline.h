@@ -135,7 +135,9 @@ public:
             for (size_t i = 0; i < NG; ++i) maxcap = cap[i] > maxcap ? cap[i] : maxcap;
             bool ok = o ? o->force_generic_packer == 0 : true;
             ok = ok && dt_.Wx <= 2 && dt_.Wz <= 2 && R <= 4 && maxcap <= 64 * 16 && NG > 0;
-            fast_wx_ = (dt_.Wx > 0 || dt_.Wz > 0) ? 2 : 0;   // lean instantiation, or the one with room for both kinds of words
+            bool zone_self = false;   // a PEG that excludes itself group-wide (anti-affinity on a non-hostname key)
+            for (size_t i = 0; i < G; ++i) zone_self = zone_self || (p->flags[i] & CASIM_PEG_SELF_EXCL_ZONE) != 0;
+            fast_wx_ = (dt_.Wx > 0 || dt_.Wz > 0 || zone_self) ? 2 : 0;   // lean instantiation, or the one with room for both kinds of words
             std::vector<int64_t> scale((size_t)R, 0);
             auto gcd64 = [](int64_t a, int64_t b) { if (a < 0) a = -a; if (b < 0) b = -b; while (b) { const int64_t x = a % b; a = b; b = x; } return a; };
             if (ok) {
@@ -222,7 +224,7 @@ public:
         if (NG_ == 0) return CASIM_OK;
         if (fast_npt_ > 0) {
             // register-resident int32 packer (no LDS): pick the instantiation by lanes and node bound
-#define CASIM_FAST_LAUNCH(R, N, X) bk_.launch(pack_fast_kernel<R, N, X>, NG_, 1, 64, (size_t)0, dt_, dr_, fs_)
+#define CASIM_FAST_LAUNCH(R, N, X) bk_.launch(pack_fast_kernel<R, N, X>, NG_, 1, 64, (size_t)RegStore<R, N, X>::kChunkBytes, dt_, dr_, fs_)
 #define CASIM_FAST_PICK(R, X) do { if (fast_npt_ == 1) CASIM_FAST_LAUNCH(R, 1, X); else if (fast_npt_ == 4) CASIM_FAST_LAUNCH(R, 4, X); else CASIM_FAST_LAUNCH(R, 16, X); } while (0)
             if (fast_r_ == 2) { if (fast_wx_ == 2) CASIM_FAST_PICK(2, 2); else CASIM_FAST_PICK(2, 0); }
             else              { if (fast_wx_ == 2) CASIM_FAST_PICK(4, 2); else CASIM_FAST_PICK(4, 0); }
