@@ -216,7 +216,41 @@ struct RegStore {
     // The capacities go to the caller's array: they are dead after a2, and as a member they travelled through every
     // merge point of the PEG loop with the rest of the state.
     CS_DEVICE int32_t capacity_all(const Peg& pv, uint32_t clampk, bool selfx, uint32_t* c) const {
+        // The common PEG asks for every lane and no request is huge: decided ONCE, so that the unrolled slots carry no
+        // per-lane branches (each wave-uniform branch costs scalar issue slots, and this kernel is bound by them as
+        // much as by the VALU: profiles/r01s_*).
+        bool simple = true;
+#pragma unroll
+        for (int r = 0; r < R_; ++r) simple = simple && pv.req[r] > 0 && pv.req[r] < (1 << 30);
         int32_t n1 = 0;
+        if (simple) {
+#pragma unroll
+            for (int s = 0; s < NPT_; ++s) {
+                bool fit = slots[s] > 0;
+                if (X_) fit = fit && !blocked(s, pv);
+#pragma unroll
+                for (int r = 0; r < R_; ++r) fit = fit && fr[s][r] >= pv.req[r];
+                const uint64_t fb = cs::ballot(fit);
+                uint32_t k = 0;
+                if (fb) {  // wave-uniform
+                    n1 += cs::popc64(fb);
+                    k = fit ? ((uint32_t)slots[s] < clampk ? (uint32_t)slots[s] : clampk) : 0u;
+#pragma unroll
+                    for (int r = 0; r < R_; ++r) {
+                        const int32_t q = pv.req[r];
+                        const uint32_t fpos = fit ? (uint32_t)fr[s][r] : 0u;
+                        uint32_t e = (uint32_t)((double)fpos * pv.rq[r]);
+                        const int32_t rem = (int32_t)(fpos - e * (uint32_t)q);   // wrapping 32-bit: it lies in (-q, 2q)
+                        e = rem < 0 ? e - 1 : (rem >= q ? e + 1 : e);
+                        k = e < k ? e : k;
+                    }
+                    if (selfx) k = k > 1 ? 1u : k;
+                }
+                c[s] = k;
+                if (NPT_ >= 4 && (s & 1) == 1) cs::sched_fence();  // interleave two slots at a time: bounds the live temporaries
+            }
+            return n1;
+        }
 #pragma unroll
         for (int s = 0; s < NPT_; ++s) {
             bool fit = slots[s] > 0;
@@ -247,7 +281,6 @@ struct RegStore {
                 if (selfx) k = k > 1 ? 1u : k;
             }
             c[s] = k;
-            if (NPT_ >= 4 && (s & 1) == 1) cs::sched_fence();  // interleave two slots at a time: bounds the live temporaries
         }
         return n1;
     }
@@ -537,7 +570,9 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             // not (plugin_runner.go:108-110); every simulated node clones the template's flag.
             const uint32_t keff = (uint32_t)(zselfx ? (cnt > 0 ? 1 : 0) : cnt);
             if (M > 0 && keff > 0 && static_ok && !zblocked && !group_unschedulable) {
-                const int S = (M + 63) >> 6;
+                // register stores of up to 4 slots walk all of them: slots past M hold zero state (c_j = 0, never a
+                // candidate, nothing committed), and a constant bound drops one scalar compare + branch per slot and pass
+                const int S = (Store::kNPT > 0 && Store::kNPT <= 4) ? Store::kNPT : (M + 63) >> 6;
                 const uint64_t cap1 = (uint64_t)keff + 1;
                 // exact wave sum of per-lane values <= cap1: one 32-bit DPP reduction when 64 * cap1 < 2^32
                 auto wsum = [&](uint64_t v) -> uint64_t {
