@@ -133,11 +133,15 @@ CS_DEVICE double bits_double(uint64_t u) { return __longlong_as_double((long lon
 
 namespace cs {
 CS_DEVICE int lane() { return tid() & 63; }
-// number of set bits of `mask` strictly below my lane (v_mbcnt on device)
+// number of set bits of `mask` strictly below my lane (v_mbcnt_lo / v_mbcnt_hi on device)
 CS_DEVICE int mbcnt(uint64_t mask) {
+#if defined(CASIM_HOST_EMU)
     int l = lane();
     uint64_t below = l == 0 ? 0ull : (~0ull >> (64 - l));
     return popc64(mask & below);
+#else
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+#endif
 }
 // exact sum of 64 uint32 lane values as a uint64: two 32-bit reductions on the 16-bit halves
 CS_DEVICE uint64_t wave_sum_u32_wide(uint32_t v) {

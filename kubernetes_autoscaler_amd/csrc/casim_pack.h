@@ -478,7 +478,6 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     bool more = true;                      // newNodesAvailable
     int32_t fakes = 0;                     // fastpath fake nodes
     int32_t total_placed = 0;
-    int64_t sum0 = 0, sum1 = 0;            // sum of placed * req lane 0 / 1 (in store units)
 
     CASIM_PROF_DECL;
     // ONE loop over the PEGs of the group: every 64th iteration loads the next chunk of records (a nested chunk / record
@@ -489,11 +488,22 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     double my_rq[RM];
 #pragma unroll
     for (int r = 0; r < RM; ++r) { my_req[r] = 0; my_rq[r] = 0.0; }
+    // results of a finished chunk: placed[] (one coalesced wave-store per 64 PEGs) and each lane's share of the
+    // sum(placed * request) totals — per lane and per chunk instead of two 64-bit scalar multiply-adds per PEG
+    int64_t acc0 = 0, acc1 = 0;
+    auto flush_chunk = [&](int kbase) {
+        if (kbase + lane < Gn) res.placed[off + kbase + lane] = my_placed;
+        L r0, r1;
+        if constexpr (Store::kChunkLds) { r0 = (L)chunk[3 * 64 + lane]; r1 = RM > 1 ? (L)chunk[4 * 64 + lane] : (L)0; }
+        else { r0 = my_req[0]; r1 = RM > 1 ? my_req[1] : (L)0; }
+        acc0 += (int64_t)my_placed * (int64_t)r0;   // lanes without a record hold my_placed == 0
+        acc1 += (int64_t)my_placed * (int64_t)r1;
+    };
     for (int k = 0; k < Gn; ++k) {
         const int j = k & 63;
         if (j == 0) {
             CASIM_PROF(0);  // chunk load / store, loop overhead
-            if (k > 0) res.placed[off + k - 64 + lane] = my_placed;  // one coalesced wave-store per 64 PEGs (a full chunk)
+            if (k > 0) flush_chunk(k - 64);
             // ---- one coalesced wave-load: PEG record k+lane of this group, in processing order ----
             const int kk = k + lane;
             const bool have = kk < Gn;
@@ -580,7 +590,6 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     return cap1 <= (1ull << 25) ? (uint64_t)cs::wave_sum_u32((uint32_t)v) : cs::wave_sum_u32_wide((uint32_t)v);
                 };
                 // pass A: capacities c_j; n1 = nodes that take at least one pod (ballots only, no reduction)
-                uint64_t lane_sum = 0;
                 uint32_t lane_max = 0;
                 int32_t n1 = 0;
                 uint32_t creg[Store::kNPT > 0 ? Store::kNPT : 1];   // register store: c_j of this PEG, dead after a2
@@ -610,42 +619,56 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         // S(1) = n1 > k: not even one full round — the k pods go to the first k fitting nodes
                         T = 0; Rr = keff; placed = (int32_t)keff;
                     } else {
-                        // sum and max of the capacities are only needed when the pods complete >= 1 round
-                        for_slots<Store>(S, [&](int s) {
-                            const uint32_t cj = getc(s, s * 64 + lane);
-                            lane_sum += cj;
-                            lane_max = cj > lane_max ? cj : lane_max;
-                        });
-                        const uint64_t tot = wsum(lane_sum);
-                        const uint32_t cmax = cs::wave_max_u32(lane_max);
-                        if (tot <= keff) { T = cmax; Rr = 0; placed = (int32_t)tot; }  // every node saturates
-                        else {
-                            uint32_t lo = 1, hi = cmax; uint64_t slo = (uint64_t)n1;  // S(lo) <= keff < S(hi)
-                            while (hi - lo > 1) {
-                                const uint32_t mid = lo + ((hi - lo) >> 1);
-                                uint64_t ls = 0;
-                                for_slots<Store>(S, [&](int s) {
-                                    const uint32_t cj = getc(s, s * 64 + lane);
-                                    ls += cj < mid ? cj : mid;
-                                });
-                                const uint64_t sm = wsum(ls);
-                                if (sm <= keff) { lo = mid; slo = sm; } else hi = mid;
+                        // sum and max of the capacities are only needed when the pods complete >= 1 round.
+                        // U = lane-sum type: c_j <= keff, so a register store of <= 16 slots with keff < 2^24 sums in
+                        // 32 bits (lane sums < 2^28, clamped wave sums < 2^31) — no 64-bit compares / adds in the lanes.
+                        auto rounds = [&](auto tag) {
+                            using U = decltype(tag);
+                            auto wsumU = [&](U v) -> U {
+                                if constexpr (sizeof(U) == 4) return cs::wave_sum_u32(v > (U)cap1 ? (U)cap1 : v);
+                                else return (U)wsum((uint64_t)v);
+                            };
+                            U lsum = 0;
+                            for_slots<Store>(S, [&](int s) {
+                                const uint32_t cj = getc(s, s * 64 + lane);
+                                lsum += cj;
+                                lane_max = cj > lane_max ? cj : lane_max;
+                            });
+                            const U tot = wsumU(lsum);
+                            const uint32_t cmax = cs::wave_max_u32(lane_max);
+                            if (tot <= (U)keff) { T = cmax; Rr = 0; placed = (int32_t)tot; }  // every node saturates
+                            else {
+                                uint32_t lo = 1, hi = cmax; U slo = (U)n1;  // S(lo) <= keff < S(hi)
+                                while (hi - lo > 1) {
+                                    const uint32_t mid = lo + ((hi - lo) >> 1);
+                                    U ls = 0;
+                                    for_slots<Store>(S, [&](int s) {
+                                        const uint32_t cj = getc(s, s * 64 + lane);
+                                        ls += cj < mid ? cj : mid;
+                                    });
+                                    const U sm = wsumU(ls);
+                                    if (sm <= (U)keff) { lo = mid; slo = sm; } else hi = mid;
+                                }
+                                T = lo; Rr = keff - (uint32_t)slo; placed = (int32_t)keff;
                             }
-                            T = lo; Rr = keff - (uint32_t)slo; placed = (int32_t)keff;
-                        }
+                        };
+                        if (Store::kNPT > 0 && Store::kNPT <= 16 && keff < (1u << 24)) rounds((uint32_t)0);
+                        else rounds((uint64_t)0);
                     }
                     CASIM_PROF(3);  // a2 reductions + bisection
                     const uint32_t Tf = Rr > 0 ? T + 1 : T;  // last round: candidates have c >= Tf
                     // rotated order starts at list position (lastIndex + 1) % n; positions < E are the
                     // pre-existing cluster nodes (never acceptable)
                     const int32_t n = E + M;
-                    const int32_t o = (int32_t)(((int64_t)last_index + 1) % n);
+                    // (lastIndex + 1 < n unless the caller's lastIndex came from a longer list: the division is the rare path)
+                    const uint32_t li1 = (uint32_t)last_index + 1u;
+                    const int32_t o = last_index < 0 ? 0 : (int32_t)(li1 < (uint32_t)n ? li1 : li1 % (uint32_t)n);   // (negative: origin 0)
                     const int32_t m0 = o > E ? o - E : 0;
                     int32_t A = 0, Tot = 0;
                     for_slots<Store>(S, [&](int s) {
-                        const uint64_t b = cs::ballot(getc(s, s * 64 + lane) >= Tf);
-                        Tot += cs::popc64(b);
-                        A += cs::popc64(b & cs::low_mask(m0 - s * 64));
+                        const bool cand = getc(s, s * 64 + lane) >= Tf;
+                        Tot += cs::popc64(cs::ballot(cand));
+                        A += cs::popc64(cs::ballot(cand && s * 64 + lane < m0));   // (a lane compare: the scalar low-mask form cost ~10 SALU per slot)
                     });
                     const int32_t target = Rr > 0 ? (int32_t)Rr - 1 : Tot - 1;
                     int32_t basec = 0, new_last = last_index;
@@ -788,14 +811,10 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             CASIM_PROF(5);  // a3 / a4
             if (lane == j) my_placed = placed;
             total_placed += placed;
-            sum0 += (int64_t)placed * (int64_t)pv.req[0];
-            sum1 += (int64_t)placed * (int64_t)pv.req[1];
         }
     }
-    if (Gn > 0) {   // the last (possibly partial) chunk
-        const int kk = ((Gn - 1) & ~63) + lane;
-        if (kk < Gn) res.placed[off + kk] = my_placed;
-    }
+    if (Gn > 0) flush_chunk((Gn - 1) & ~63);   // the last (possibly partial) chunk
+    const int64_t sum0 = (int64_t)cs::wave_sum_u64((uint64_t)acc0), sum1 = (int64_t)cs::wave_sum_u64((uint64_t)acc1);
 
     CASIM_PROF(0);
     CASIM_PROF_STORE(prof_out);
