@@ -39,11 +39,13 @@
 #define CASIM_PROF_STORE(p) (void)(p)
 #endif
 
-// Waves per SIMD the register allocator of the 256-node fast packer must leave room for.  Measured on
-// MI355X (r01, C1 x 16384): 3 waves (148 VGPRs at the time) -> 8.2 M sims/s; 4 waves -> 9.0-9.2 M; 5 waves
-// (96 VGPRs) spills ~200 B/lane -> 4.0 M.  The kernel now needs 123 VGPRs (scheduling fences in capacity_all),
-// i.e. 4 waves WITHOUT scratch: an earlier build met the bound by spilling 68 B/lane, which the PMC passes
-// showed as 2.6x the algorithmic HBM traffic (profiles/r01i_*).
+// Waves per SIMD the register allocator of the 256-node fast packer must leave room for (a lower bound for the
+// occupancy: the kernel now needs ~55 VGPRs and runs 8 waves per SIMD).  History on MI355X (C1 x 16384):
+//   r01f  nested chunk / record loops, records in lanes: 148 VGPRs natural (3 waves) 8.2 M sims/s; bounded to 128 by
+//         spilling 68 B/lane 9.2 M but 2.6x the algorithmic HBM traffic; scheduling fences -> 123 VGPRs, no scratch, 9.0 M
+//   r01s  one flat PEG loop + records parked in LDS + wave-uniform regions kept out of the CFG structurizer:
+//         the node state is no longer copied through every merge point (58 -> 49..55 VGPRs, 8 waves); with the scalar
+//         work trimmed as well (the kernel was bound by SALU issue as much as by the VALU) 13.5 M sims/s.
 #ifndef CASIM_FAST_WAVES
 #define CASIM_FAST_WAVES 4
 #endif
@@ -879,8 +881,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void pack_kernel(DevTables t, DevResults res, 
 // Launched only when the host proved the batch eligible (casim_pipeline.h): either no exclusion state at all (WX_ = 0,
 // the bench path) or Wx <= 2 node-local words (two VGPRs each) and Wz <= 2 group-wide words (scalar) with WX_ = 2; R <= R_, every scaled value < 2^31 and every group's node bound <= 64 * NPT_.
 template <int R_, int NPT_, int WX_>
-// launch bounds (64, 1): let the register allocator take what it needs — forcing 5 waves/SIMD (<= 96
-// VGPRs) spilled ~200 B/lane to scratch and halved the throughput on MI355X (r01 measurement)
+// launch bounds: a floor of CASIM_FAST_WAVES waves per SIMD for the 256-node instantiation (see the note at the top)
 CS_GLOBAL CS_LAUNCH_BOUNDS(64, ((NPT_ == 4 && WX_ == 0) ? CASIM_FAST_WAVES : 1)) void pack_fast_kernel(DevTables t, DevResults res, FastScratch fs) {
     if (pack_unsupported(t, res)) return;
     const int ng = cs::bid();
