@@ -77,7 +77,7 @@ CS_DEVICE int32_t load_relaxed_i32(const int32_t* p) { return __hip_atomic_load(
 CS_DEVICE void atomic_add_i32(int32_t* p, int32_t v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // bits set by several threads of the block in one LDS word (ds_or_b64)
 CS_DEVICE void lds_or_u64(uint64_t* p, uint64_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-CS_DEVICE uint64_t ballot(bool p) { return __ballot(p); }  // 64-bit on wave64
+CS_DEVICE uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }  // the lane mask itself (__ballot goes through an int: two more VALU ops per call)
 CS_DEVICE uint64_t readlane_u64(uint64_t v, int l) {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
     lo = (uint32_t)__shfl((int)lo, l, 64);

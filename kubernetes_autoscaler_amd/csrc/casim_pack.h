@@ -52,6 +52,9 @@
 
 namespace casim {
 
+struct CsTrue { static constexpr bool value = true; };
+struct CsFalse { static constexpr bool value = false; };
+
 template <class L, int RMAX>
 struct PegView {
     L req[RMAX];
@@ -226,31 +229,40 @@ struct RegStore {
         for (int r = 0; r < R_; ++r) simple = simple && pv.req[r] > 0 && pv.req[r] < (1 << 30);
         int32_t n1 = 0;
         if (simple) {
+            // (self-exclusion is a PEG property: two copies of the sweep instead of three selects per slot)
+            auto sweep = [&](auto sx_tag) {
+                constexpr bool kSelf = decltype(sx_tag)::value;
 #pragma unroll
-            for (int s = 0; s < NPT_; ++s) {
-                bool fit = slots[s] > 0;
-                if (X_) fit = fit && !blocked(s, pv);
+                for (int s = 0; s < NPT_; ++s) {
+                    // (bitwise &, and the wave mask as the AND of single-compare ballots: a ballot of a combined predicate
+                    // costs two extra VALU ops to re-normalise the mask)
+                    bool fit = slots[s] > 0;
+                    uint64_t fb = cs::ballot(slots[s] > 0);
+                    if (X_) { const bool nb = !blocked(s, pv); fit = fit & nb; fb &= cs::ballot(nb); }
 #pragma unroll
-                for (int r = 0; r < R_; ++r) fit = fit && fr[s][r] >= pv.req[r];
-                const uint64_t fb = cs::ballot(fit);
-                uint32_t k = 0;
-                if (fb) {  // wave-uniform
-                    n1 += cs::popc64(fb);
-                    k = fit ? ((uint32_t)slots[s] < clampk ? (uint32_t)slots[s] : clampk) : 0u;
+                    for (int r = 0; r < R_; ++r) { fit = fit & (fr[s][r] >= pv.req[r]); fb &= cs::ballot(fr[s][r] >= pv.req[r]); }
+                    uint32_t k = 0;
+                    if (fb) {  // wave-uniform
+                        n1 += cs::popc64(fb);
+                        if constexpr (kSelf) k = fit ? 1u : 0u;   // clampk >= 1, a pod slot is free and every lane fits once
+                        else {
+                            k = fit ? ((uint32_t)slots[s] < clampk ? (uint32_t)slots[s] : clampk) : 0u;
 #pragma unroll
-                    for (int r = 0; r < R_; ++r) {
-                        const int32_t q = pv.req[r];
-                        const uint32_t fpos = fit ? (uint32_t)fr[s][r] : 0u;
-                        uint32_t e = (uint32_t)((double)fpos * pv.rq[r]);
-                        const int32_t rem = (int32_t)(fpos - e * (uint32_t)q);   // wrapping 32-bit: it lies in (-q, 2q)
-                        e = rem < 0 ? e - 1 : (rem >= q ? e + 1 : e);
-                        k = e < k ? e : k;
+                            for (int r = 0; r < R_; ++r) {
+                                const int32_t q = pv.req[r];
+                                const uint32_t fpos = fit ? (uint32_t)fr[s][r] : 0u;
+                                uint32_t e = (uint32_t)((double)fpos * pv.rq[r]);
+                                const int32_t rem = (int32_t)(fpos - e * (uint32_t)q);   // wrapping 32-bit: it lies in (-q, 2q)
+                                e = e - ((uint32_t)rem >> 31) + (rem >= q ? 1u : 0u);    // exact +-1 fix-up: sign bit, carry-in
+                                k = e < k ? e : k;
+                            }
+                        }
                     }
-                    if (selfx) k = k > 1 ? 1u : k;
+                    c[s] = k;
+                    if (NPT_ >= 4 && (s & 1) == 1) cs::sched_fence();  // interleave two slots at a time: bounds the live temporaries
                 }
-                c[s] = k;
-                if (NPT_ >= 4 && (s & 1) == 1) cs::sched_fence();  // interleave two slots at a time: bounds the live temporaries
-            }
+            };
+            if (selfx) sweep(CsTrue{}); else sweep(CsFalse{});
             return n1;
         }
 #pragma unroll
@@ -668,9 +680,9 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     const int32_t m0 = o > E ? o - E : 0;
                     int32_t A = 0, Tot = 0;
                     for_slots<Store>(S, [&](int s) {
-                        const bool cand = getc(s, s * 64 + lane) >= Tf;
-                        Tot += cs::popc64(cs::ballot(cand));
-                        A += cs::popc64(cs::ballot(cand && s * 64 + lane < m0));   // (a lane compare: the scalar low-mask form cost ~10 SALU per slot)
+                        const uint64_t bc = cs::ballot(getc(s, s * 64 + lane) >= Tf);
+                        Tot += cs::popc64(bc);
+                        A += cs::popc64(bc & cs::ballot(s * 64 + lane < m0));   // (a lane compare: the scalar low-mask form cost ~10 SALU per slot)
                     });
                     const int32_t target = Rr > 0 ? (int32_t)Rr - 1 : Tot - 1;
                     int32_t basec = 0, new_last = last_index;
@@ -684,7 +696,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         const int32_t rot = m >= m0 ? pex - A : (Tot - A) + pex;
                         uint32_t x = cj < T ? cj : T;
                         if (Rr > 0 && cand && rot < (int32_t)Rr) x += 1;
-                        const uint64_t hit = cs::ballot(cand && rot == target);
+                        const uint64_t hit = b & cs::ballot(rot == target);
                         if (hit) new_last = E + s * 64 + cs::ffs64(hit);
                         if (x > 0) st.commit(s, m, x, pv);
                         if (m == M - 1) x_mine_last = x;
