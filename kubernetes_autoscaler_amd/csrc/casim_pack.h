@@ -220,7 +220,10 @@ struct RegStore {
     // Slots beyond M hold zeros (slots == 0): no extra guard.  Returns n1 = nodes taking >= 1 pod.
     // The capacities go to the caller's array: they are dead after a2, and as a member they travelled through every
     // merge point of the PEG loop with the rest of the state.
-    CS_DEVICE int32_t capacity_all(const Peg& pv, uint32_t clampk, bool selfx, uint32_t* c) const {
+    // `act`: bit s set when some node of slot s takes a pod — the later passes skip the other slots (measured on C1:
+    // 0.6 of the 4 slots per PEG).
+    CS_DEVICE int32_t capacity_all(const Peg& pv, uint32_t clampk, bool selfx, uint32_t* c, uint32_t& act) const {
+        act = 0;
         // The common PEG asks for every lane and no request is huge: decided ONCE, so that the unrolled slots carry no
         // per-lane branches (each wave-uniform branch costs scalar issue slots, and this kernel is bound by them as
         // much as by the VALU: profiles/r01s_*).
@@ -244,6 +247,7 @@ struct RegStore {
                     uint32_t k = 0;
                     if (fb) {  // wave-uniform
                         n1 += cs::popc64(fb);
+                        act |= 1u << s;
                         if constexpr (kSelf) k = fit ? 1u : 0u;   // clampk >= 1, a pod slot is free and every lane fits once
                         else {
                             k = fit ? ((uint32_t)slots[s] < clampk ? (uint32_t)slots[s] : clampk) : 0u;
@@ -275,6 +279,7 @@ struct RegStore {
             uint32_t k = 0;
             if (fb) {  // wave-uniform
                 n1 += cs::popc64(fb);
+                act |= 1u << s;
                 k = fit ? ((uint32_t)slots[s] < clampk ? (uint32_t)slots[s] : clampk) : 0u;
 #pragma unroll
                 for (int r = 0; r < R_; ++r) {
@@ -609,12 +614,14 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 uint32_t creg[Store::kNPT > 0 ? Store::kNPT : 1];   // register store: c_j of this PEG, dead after a2
 #pragma unroll
                 for (int s = 0; s < (Store::kNPT > 0 ? Store::kNPT : 1); ++s) creg[s] = 0;
+                uint32_t act = ~0u;   // slots with a non-zero capacity (register store); the memory store walks them all
+                auto live = [&](int s) -> bool { return Store::kNPT == 0 || s >= 32 || ((act >> s) & 1u) != 0; };
                 auto getc = [&](int s, int m) -> uint32_t {
                     if constexpr (Store::kNPT > 0) return creg[s]; else return st.get_c(s, m);
                 };
                 if (st.may_fit(pv)) {  // summary pruning: no node can take this PEG (stale-but-safe bounds)
                     if constexpr (Store::kNPT > 0) {
-                        n1 = st.capacity_all(pv, keff, selfx, creg);  // every slot (nodes >= M are all-zero)
+                        n1 = st.capacity_all(pv, keff, selfx, creg, act);  // every slot (nodes >= M are all-zero)
                     } else {
                         for_slots<Store>(S, [&](int s) {
                             const int m = s * 64 + lane;
@@ -644,6 +651,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                             };
                             U lsum = 0;
                             for_slots<Store>(S, [&](int s) {
+                                if (!live(s)) return;
                                 const uint32_t cj = getc(s, s * 64 + lane);
                                 lsum += cj;
                                 lane_max = cj > lane_max ? cj : lane_max;
@@ -657,6 +665,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                                     const uint32_t mid = lo + ((hi - lo) >> 1);
                                     U ls = 0;
                                     for_slots<Store>(S, [&](int s) {
+                                        if (!live(s)) return;
                                         const uint32_t cj = getc(s, s * 64 + lane);
                                         ls += cj < mid ? cj : mid;
                                     });
@@ -680,6 +689,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     const int32_t m0 = o > E ? o - E : 0;
                     int32_t A = 0, Tot = 0;
                     for_slots<Store>(S, [&](int s) {
+                        if (!live(s)) return;
                         const uint64_t bc = cs::ballot(getc(s, s * 64 + lane) >= Tf);
                         Tot += cs::popc64(bc);
                         A += cs::popc64(bc & cs::ballot(s * 64 + lane < m0));   // (a lane compare: the scalar low-mask form cost ~10 SALU per slot)
@@ -688,6 +698,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     int32_t basec = 0, new_last = last_index;
                     uint32_t x_mine_last = 0;
                     for_slots<Store>(S, [&](int s) {
+                        if (!live(s)) return;   // c_j == 0 in every lane: no candidate, nothing to commit, x on the newest node 0
                         const int m = s * 64 + lane;
                         const uint32_t cj = getc(s, m);
                         const bool cand = cj >= Tf;
