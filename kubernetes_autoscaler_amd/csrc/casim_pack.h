@@ -172,11 +172,6 @@ struct MemStore {
     CS_DEVICE uint32_t capacity_newest(int lm, const Peg& pv, uint32_t clampk, bool selfx, bool mine) const { return mine ? capacity(0, lm, pv, clampk, selfx) : 0u; }
     CS_DEVICE void commit_newest(int lm, uint32_t x, const Peg& pv, bool mine) { if (mine) commit(0, lm, x, pv); }
     CS_DEVICE int32_t npods_newest(int lm, bool mine) const { return mine ? snpods[lm] : 0; }
-    // summary pruning is a register-store feature
-    CS_DEVICE bool may_fit(const Peg&) const { return true; }
-    CS_DEVICE void tighten(int, int) {}
-    CS_DEVICE void note_create(const Fresh&) {}
-    CS_DEVICE void note_change() {}
 };
 
 // ---- node store: int32 state in VGPRs (fast path) ---------------------------------------------------
@@ -362,52 +357,10 @@ struct RegStore {
         return fresh_slots - sl;
     }
 
-    // Summary pruning.  bound_free[r] / bound_slots are wave-uniform UPPER bounds of max_j free_j[r] and
-    // max_j slots_j over all simulated nodes.  Placements only lower the true maxima, so a stale bound stays
-    // valid; a new node raises it to the fresh values.  A PEG with req[r] > bound_free[r] for some lane
-    // (or no slot anywhere) fits nowhere: its a2 sweep is skipped (it would compute c_j = 0 for every node).
-    int32_t bound_free[R_];
-    int32_t bound_slots;
-    bool dirty;
-    CS_DEVICE void reset_bounds() {
-#pragma unroll
-        for (int r = 0; r < R_; ++r) bound_free[r] = (int32_t)0x80000000;
-        bound_slots = (int32_t)0x80000000;
-        dirty = false;
-    }
-    CS_DEVICE bool may_fit(const Peg& pv) const {
-        bool ok = bound_slots >= 1;
-#pragma unroll
-        for (int r = 0; r < R_; ++r) ok = ok && !(pv.req[r] > 0 && pv.req[r] > bound_free[r]);
-        return ok;
-    }
-    CS_DEVICE void note_create(const Fresh& fn) {
-#pragma unroll
-        for (int r = 0; r < R_; ++r) bound_free[r] = fn.free[r] > bound_free[r] ? fn.free[r] : bound_free[r];
-        bound_slots = fn.slots > bound_slots ? fn.slots : bound_slots;
-        dirty = true;
-    }
-    CS_DEVICE void note_change() { dirty = true; }
-    // recompute the exact maxima (R_+1 DPP reductions); called when a sweep found nothing although the bounds passed
-    CS_DEVICE void tighten(int M, int lane) {
-        if (!dirty) return;
-        int32_t lf[R_];
-        int32_t ls = (int32_t)0x80000000;
-#pragma unroll
-        for (int r = 0; r < R_; ++r) lf[r] = (int32_t)0x80000000;
-#pragma unroll
-        for (int s = 0; s < NPT_; ++s) {
-            if (s * 64 + lane < M) {
-#pragma unroll
-                for (int r = 0; r < R_; ++r) lf[r] = fr[s][r] > lf[r] ? fr[s][r] : lf[r];
-                ls = slots[s] > ls ? slots[s] : ls;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R_; ++r) bound_free[r] = (int32_t)(cs::wave_max_u32((uint32_t)lf[r] ^ 0x80000000u) ^ 0x80000000u);
-        bound_slots = (int32_t)(cs::wave_max_u32((uint32_t)ls ^ 0x80000000u) ^ 0x80000000u);
-        dirty = false;
-    }
+    // (An earlier version kept wave-uniform upper bounds of the free resources to skip the sweep of a PEG that fits
+    // nowhere, re-tightened by R+1 wave reductions whenever a sweep came back empty.  Measured on C1 the bounds never
+    // pruned a single PEG while the re-tightening cost ~13 VALU instructions per PEG; an empty sweep is 3 compares per
+    // slot now, so the bounds are gone.)
 };
 
 // slot loops: fully unrolled for the register store (static VGPR indices), runtime for the memory store
@@ -619,19 +572,16 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 auto getc = [&](int s, int m) -> uint32_t {
                     if constexpr (Store::kNPT > 0) return creg[s]; else return st.get_c(s, m);
                 };
-                if (st.may_fit(pv)) {  // summary pruning: no node can take this PEG (stale-but-safe bounds)
-                    if constexpr (Store::kNPT > 0) {
-                        n1 = st.capacity_all(pv, keff, selfx, creg, act);  // every slot (nodes >= M are all-zero)
-                    } else {
-                        for_slots<Store>(S, [&](int s) {
-                            const int m = s * 64 + lane;
-                            uint32_t cj = 0;
-                            if (m < M) cj = st.capacity(s, m, pv, keff, selfx);
-                            st.set_c(s, m, cj);
-                            n1 += cs::popc64(cs::ballot(cj > 0));
-                        });
-                    }
-                    if (n1 == 0) st.tighten(M, lane);  // the bounds were too loose: make them exact again
+                if constexpr (Store::kNPT > 0) {
+                    n1 = st.capacity_all(pv, keff, selfx, creg, act);  // every slot (nodes >= M are all-zero)
+                } else {
+                    for_slots<Store>(S, [&](int s) {
+                        const int m = s * 64 + lane;
+                        uint32_t cj = 0;
+                        if (m < M) cj = st.capacity(s, m, pv, keff, selfx);
+                        st.set_c(s, m, cj);
+                        n1 += cs::popc64(cs::ballot(cj > 0));
+                    });
                 }
                 CASIM_PROF(2);  // a2 pass A (capacities)
                 if (n1 > 0) {
@@ -715,7 +665,6 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     });
                     on_last = cs::bcast_u32(x_mine_last, (M - 1) & 63);
                     last_index = new_last;
-                    st.note_change();
                     if (Wz > 0) zone_mark(zmark);
                 }
             }
@@ -737,7 +686,6 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 // the lane that owns node m writes its fresh state + x pods: node first+i gets
                 // min(per, pods_total - i*per) pods
                 auto create_nodes = [&](int32_t first, int32_t nadd, uint32_t per, int32_t pods_total) {
-                    st.note_create(fn);
                     const int s_lo = first >> 6, s_hi = (first + nadd - 1) >> 6;
                     for_slots<Store>(s_hi + 1, [&](int s) {
                         const int32_t m = s * 64 + lane;
@@ -787,8 +735,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         if (cl > 0) {
                             st.commit_newest(lm, cl, pv, lane == owner);
                             placed += (int32_t)cl; rem -= (int32_t)cl; marked = true;
-                            st.note_change();
-                            if (zselfx) blocked = true;
+                                    if (zselfx) blocked = true;
                         }
                     }
                     bool stop = rem == 0;
@@ -917,7 +864,6 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, ((NPT_ == 4 && WX_ == 0) ? CASIM_FAST_WAVES : 1))
 #pragma unroll
         for (int w = 0; w < WX_; ++w) st.excl[s][w] = 0;
     }
-    st.reset_bounds();
     FreshNode<int32_t, R_> fn;
 #pragma unroll
     for (int r = 0; r < R_; ++r) fn.free[r] = r < t.R ? fs.fresh32[(int64_t)ng * t.R + r] : 0;
