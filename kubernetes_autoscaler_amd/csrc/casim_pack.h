@@ -184,10 +184,10 @@ struct RegStore {
     static constexpr bool X_ = WX_ > 0;
     static constexpr bool kHasZone = WX_ > 0;   // the lean instantiation (WX_ = 0) carries no exclusion state at all
     static constexpr int kZoneWords = 2;        // group-wide exclusion words are wave-uniform: up to two, in scalar registers
-    // The 64 PEG records of a chunk are parked in LDS ((3 + 3 R_) words per record, kChunkBytes per wave) and read back
+    // The 64 PEG records of a chunk are parked in LDS ((4 + 3 R_) words per record, kChunkBytes per wave) and read back
     // at a wave-uniform address: nine VGPRs less than keeping them in the lanes — what the 5th / 6th wave per SIMD needs.
     static constexpr bool kChunkLds = true;
-    static constexpr int kChunkBytes = (3 + 3 * R_) * 64 * 4;
+    static constexpr int kChunkBytes = (4 + 3 * R_) * 64 * 4;
     using Peg = PegView<int32_t, R_>;
     using Fresh = FreshNode<int32_t, R_>;
     int32_t fr[NPT_][R_];
@@ -316,17 +316,18 @@ struct RegStore {
     CS_DEVICE void set_c(int, int, uint32_t) {}
     CS_DEVICE int32_t npods(int s, int) const { return fresh_slots - slots[s]; }  // only asked for created nodes
     // The newest node lm (wave-uniform index; slot lm >> 6 of lane lm & 63).  Straight-line selects over the slots
-    // instead of a branch per slot: with branches the compiler carried the whole register state through every merge
-    // point (dozens of v_mov per PEG).  Every lane evaluates its own node of that slot; the caller reads lane `mine`.
+    // instead of a branch per slot (with branches the compiler carried the whole register state through every merge
+    // point), and the select condition is ONE lane compare per slot (s * 64 + lane == lm): only the owner lane sees its
+    // node, the others evaluate an empty one.  The caller reads the owner lane.
     CS_DEVICE uint32_t capacity_newest(int lm, const Peg& pv, uint32_t clampk, bool selfx, bool) const {
-        const int ls = lm >> 6;
+        const int lane = cs::lane();
         int32_t f[R_], sl = 0;
         bool b = false;
 #pragma unroll
         for (int r = 0; r < R_; ++r) f[r] = 0;
 #pragma unroll
         for (int s = 0; s < NPT_; ++s) {
-            const bool h = s == ls;
+            const bool h = s * 64 + lane == lm;
 #pragma unroll
             for (int r = 0; r < R_; ++r) f[r] = h ? fr[s][r] : f[r];
             sl = h ? slots[s] : sl;
@@ -337,26 +338,25 @@ struct RegStore {
         if (selfx && k > 1) k = 1;
         return k;
     }
-    CS_DEVICE void commit_newest(int lm, uint32_t x, const Peg& pv, bool mine) {
-        const int ls = lm >> 6;
+    CS_DEVICE void commit_newest(int lm, uint32_t x, const Peg& pv, bool) {
+        const int lane = cs::lane();
 #pragma unroll
         for (int s = 0; s < NPT_; ++s) {
-            const bool h = mine && s == ls;
+            const bool h = s * 64 + lane == lm;
 #pragma unroll
-            for (int r = 0; r < R_; ++r) fr[s][r] = h ? fr[s][r] - (int32_t)x * pv.req[r] : fr[s][r];
-            slots[s] = h ? slots[s] - (int32_t)x : slots[s];
+            for (int r = 0; r < R_; ++r) fr[s][r] -= h ? (int32_t)x * pv.req[r] : 0;
+            slots[s] -= h ? (int32_t)x : 0;
 #pragma unroll
-            for (int w = 0; w < WX_; ++w) excl[s][w] = h ? (excl[s][w] | pv.xm[w]) : excl[s][w];
+            for (int w = 0; w < WX_; ++w) excl[s][w] |= h ? pv.xm[w] : 0ull;
         }
     }
     CS_DEVICE int32_t npods_newest(int lm, bool) const {
-        const int ls = lm >> 6;
+        const int lane = cs::lane();
         int32_t sl = 0;
 #pragma unroll
-        for (int s = 0; s < NPT_; ++s) sl = s == ls ? slots[s] : sl;
+        for (int s = 0; s < NPT_; ++s) sl = s * 64 + lane == lm ? slots[s] : sl;
         return fresh_slots - sl;
     }
-
     // (An earlier version kept wave-uniform upper bounds of the free resources to skip the sweep of a PEG that fits
     // nowhere, re-tightened by R+1 wave reductions whenever a sweep came back empty.  Measured on C1 the bounds never
     // pruned a single PEG while the re-tightening cost ~13 VALU instructions per PEG; an empty sweep is 3 compares per
@@ -455,7 +455,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     // ONE loop over the PEGs of the group: every 64th iteration loads the next chunk of records (a nested chunk / record
     // loop made the compiler keep two copies of the node state, one per loop level, and shuffle ~70 registers per PEG).
     int32_t my_cnt = 0, my_g = 0, my_placed = 0;
-    uint32_t my_flags = 0;
+    uint32_t my_flags = 0, my_cf = 0;   // my_cf: pods of the record's PEG that fit an EMPTY node (state-independent)
     L my_req[RM];
     double my_rq[RM];
 #pragma unroll
@@ -489,9 +489,18 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
 #pragma unroll
             for (int r = 0; r < RM; ++r) my_rq[r] = my_req[r] > 0 ? 1.0 / (double)my_req[r] : 0.0;
             my_placed = 0;
+            {   // capacity of a fresh node for the record's PEG, by the record's own lane: once per 64 PEGs instead of a
+                // wave-uniform quotient chain in every a3
+                typename Store::Peg mine;
+#pragma unroll
+                for (int r = 0; r < RM; ++r) { mine.req[r] = my_req[r]; mine.rq[r] = my_rq[r]; }
+                mine.xblock = nullptr; mine.xmark = nullptr; mine.xb[0] = mine.xb[1] = 0; mine.xm[0] = mine.xm[1] = 0;
+                my_cf = have ? capacity_lanes<L, RM>(fn.free, fn.slots, R, mine, 0x7fffffffu) : 0u;
+            }
             if constexpr (Store::kChunkLds) {
                 cs::sync();   // (one wave per block: orders the previous chunk's reads before these writes)
                 chunk[0 * 64 + lane] = (uint32_t)my_cnt; chunk[1 * 64 + lane] = my_flags; chunk[2 * 64 + lane] = (uint32_t)my_g;
+                chunk[(3 + 3 * RM) * 64 + lane] = my_cf;
 #pragma unroll
                 for (int r = 0; r < RM; ++r) {
                     chunk[(3 + r) * 64 + lane] = (uint32_t)my_req[r];
@@ -680,7 +689,11 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 {
                     bool xb = false;
                     for (int w = 0; w < Wx; ++w) xb |= (fn.excl[w] & pv.xblock[w]) != 0;
-                    if (!xb) cfresh = capacity_lanes<L, RM>(fn.free, fn.slots, R, pv, (uint32_t)rem);
+                    if (!xb) {
+                        uint32_t cf;
+                        if constexpr (Store::kChunkLds) cf = cs::uniform_u32(chunk[(3 + 3 * RM) * 64 + j]); else cf = cs::bcast_u32(my_cf, j);
+                        cfresh = cf < (uint32_t)rem ? cf : (uint32_t)rem;
+                    }
                     if ((selfx || zselfx) && cfresh > 1) cfresh = 1;
                 }
                 // the lane that owns node m writes its fresh state + x pods: node first+i gets
