@@ -318,7 +318,10 @@ public:
             if (kinds[i] == CASIM_EXPANDER_LEAST_WASTE && (!dt_.waste_cpu || !dt_.waste_mem)) return fail(CASIM_ERR_INVALID, "least-waste needs waste_cpu/waste_mem");
         }
         a.best_set = d_opt_set_; a.out = d_opt_out_; a.key_out = dev_key_out ? (int64_t*)dev_key_out : d_opt_key_;
-        bk_.launch(option_kernel, 1, 1, 256, (size_t)(8 * 256), a);
+        // one block walks all groups: with thousands of them (batched simulations) 1024 threads, not 256 — the kernel was
+        // 0.106 ms of a 1.0 ms step at NG = 16384 (profiles/r01u_rocpd_summary.txt)
+        const int opt_threads = NG_ > 1024 ? 1024 : 256;
+        bk_.launch(option_kernel, 1, 1, opt_threads, (size_t)(8 * opt_threads), a);
         if (best_ng_out || n_best_out || best_set_out || key_out) {
             int32_t o[2] = {-1, 0};
             bk_.d2h(o, d_opt_out_, 8);
