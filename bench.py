@@ -97,7 +97,69 @@ def cpu_baseline(workloads, seed_base, n_pegs, pods_per_peg, cap, budget_s=12.0,
             "sims_per_s": n / elapsed, "host_cores_available": os.cpu_count()}
 
 
+def cpu_worker(seed_base, n_sims, n_pegs, pods_per_peg, cap, budget_s):
+    """One process of the multi-core CPU leg: builds its own scenarios, waits for the start line on stdin, runs
+    orc_estimate for ~budget_s and prints {"n": simulations, "s": seconds}.  No torch / HIP in this process."""
+    from kubernetes_autoscaler_amd import workloads
+    from oracle_driver import OracleScenario
+    sims = []
+    for b in range(n_sims):
+        w = workloads.config_c1(seed_offset=seed_base + b, n_pegs=n_pegs, pods_per_peg=pods_per_peg, cap=cap)
+        s = OracleScenario()
+        sims.append((s, s.node(w.groups[0].template), w))
+    print("ready", flush=True)
+    sys.stdin.readline()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        for s, tmpl, w in sims:
+            s.estimate(tmpl, w.pegs, max_nodes=w.groups[0].max_nodes)
+            n += 1
+    print(json.dumps({"n": n, "s": time.perf_counter() - t0}), flush=True)
+
+
+def cpu_baseline_all_cores(n_pegs, pods_per_peg, cap, budget_s=4.0, max_procs=64, sims_per_proc=4):
+    """The same oracle on the host's cores at once: independent Python processes (one simulation stream each, like the
+    node-group-parallel CPU variant SURVEY §8d asks for), started together, aggregate simulations per second."""
+    import subprocess
+    procs_n = max(1, min(max_procs, (os.cpu_count() or 1)))
+    procs = []
+    try:
+        for i in range(procs_n):
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(100000 + i * sims_per_proc),
+                                           str(sims_per_proc), str(n_pegs), str(pods_per_peg), str(cap), str(budget_s)],
+                                          stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+        deadline = time.time() + 120.0
+        for p in procs:
+            line = p.stdout.readline()
+            if line.strip() != "ready" or time.time() > deadline:
+                raise RuntimeError("cpu worker did not start")
+        t0 = time.perf_counter()
+        for p in procs:
+            p.stdin.write("go\n"); p.stdin.flush()
+        total = 0
+        for p in procs:
+            total += json.loads(p.stdout.readline())["n"]
+        wall = time.perf_counter() - t0
+        for p in procs:
+            p.wait(timeout=30)
+        sims_per_s = total / wall
+        return {"value": sims_per_s * n_pegs * pods_per_peg * cap, "unit": "checks/s", "cores": procs_n, "kind": "port",
+                "sample": f"{total} C1 simulations by {procs_n} processes in {wall:.1f} s (each loops over {sims_per_proc} seeds)",
+                "sims_per_s": sims_per_s}
+    except Exception as e:  # never take the bench line down
+        for p in procs:
+            try:
+                p.kill()
+            except Exception:
+                pass
+        return {"error": str(e)}
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        a = sys.argv[2:]
+        cpu_worker(int(a[0]), int(a[1]), int(a[2]), int(a[3]), int(a[4]), float(a[5]))
+        return None
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -271,6 +333,8 @@ def main():
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(workloads, 0, args.pegs, args.pods_per_peg, args.cap)
+            if world == 1:
+                extra["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.pegs, args.pods_per_peg, args.cap)
         out = {"metric": "scale-up simulation predicate checks/s (pods x nodes)", "value": value, "unit": "checks/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
