@@ -272,7 +272,9 @@ CS_GLOBAL void order_kernel(DevTables t, DevResults res, OrderScratch os) {
         res.order[off + i] = g;
         res.s_count[off + i] = t.count[g];
         res.s_flags[off + i] = (t.pflags[g] & ~CASIM_KFLAG_STATIC_OK) | (static_filters_pass(t, g, ng) ? CASIM_KFLAG_STATIC_OK : 0u);
-        for (int r = 0; r < t.R; ++r) res.s_req[(int64_t)(off + i) * t.R + r] = t.req[(int64_t)g * t.R + r];
+        // request lanes in the form the packer of this batch reads: scaled int32 (register packer) or int64
+        if (res.s_req32) { for (int r = 0; r < t.R; ++r) res.s_req32[(int64_t)(off + i) * t.R + r] = res.req32[(int64_t)g * t.R + r]; }
+        else { for (int r = 0; r < t.R; ++r) res.s_req[(int64_t)(off + i) * t.R + r] = t.req[(int64_t)g * t.R + r]; }
     }
     if (tid == 0) res.fast_last[ng] = best >= 0 ? 1 : 0;
 }

@@ -481,7 +481,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             const bool have = kk < Gn;
             my_cnt = have ? res.s_count[off + kk] : 0;
             my_flags = have ? res.s_flags[off + kk] : 0u;
-            my_g = have ? res.order[off + kk] : 0;
+            my_g = (have && (Store::kHasExcl || Store::kHasZone)) ? res.order[off + kk] : 0;   // (only the mask tables are indexed by it)
 #pragma unroll
             for (int r = 0; r < RM; ++r) my_req[r] = (have && r < R) ? load_req(off + kk, r) : (L)0;
             // 1 / req for capacity_lanes' quotient estimate: computed by the record's own lane, i.e. 64 PEGs'
@@ -884,11 +884,10 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, ((NPT_ == 4 && WX_ == 0) ? CASIM_FAST_WAVES : 1))
     st.fresh_slots = fn.slots;
     fn.excl = WX_ > 0 ? t.init_excl + (int64_t)ng * t.Wx : nullptr;
     st.wx = t.Wx < WX_ ? t.Wx : WX_;
-    const int32_t* req32 = fs.req32;
-    const int32_t* order = res.order;
+    const int32_t* s_req32 = res.s_req32;   // processing order: coalesced, no gather through `order`
     const int R = t.R;
     pack_body(t, res, st, fn, (uint64_t*)nullptr,
-              [=](int idx, int r) -> int32_t { return req32[(int64_t)order[idx] * R + r]; }, fs.scale, fs.prof, (uint32_t*)cs::dyn_smem());
+              [=](int idx, int r) -> int32_t { return s_req32[(int64_t)idx * R + r]; }, fs.scale, fs.prof, (uint32_t*)cs::dyn_smem());
 }
 
 }  // namespace casim

@@ -195,7 +195,8 @@ public:
         dr_.order = (int32_t*)dalloc(4 * (size_t)nnz_cap_); dr_.placed = (int32_t*)dalloc(4 * (size_t)nnz_cap_);
         dr_.fast_last = (uint8_t*)dalloc(NG);
         dr_.s_count = (int32_t*)dalloc(4 * (size_t)nnz_cap_); dr_.s_flags = (uint32_t*)dalloc(4 * (size_t)nnz_cap_);
-        dr_.s_req = (int64_t*)dalloc(8 * (size_t)nnz_cap_ * (size_t)R);
+        if (fast_npt_ > 0) { dr_.s_req32 = (int32_t*)dalloc(4 * (size_t)nnz_cap_ * (size_t)R); dr_.req32 = fs_.req32; }
+        else dr_.s_req = (int64_t*)dalloc(8 * (size_t)nnz_cap_ * (size_t)R);
         d_opt_set_ = (uint8_t*)dalloc(NG);
         d_opt_out_ = (int32_t*)dalloc(16);
         d_opt_key_ = (int64_t*)dalloc(80);

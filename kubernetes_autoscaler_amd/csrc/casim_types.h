@@ -58,7 +58,10 @@ struct DevResults {
     // PEG records in processing order, written by order_kernel, streamed by pack_kernel
     int32_t* s_count;    // [nnz]
     uint32_t* s_flags;   // [nnz] CASIM_PEG_* | CASIM_KFLAG_STATIC_OK
-    int64_t* s_req;      // [nnz][R]
+    int64_t* s_req;      // [nnz][R]   (generic packer; null when the register packer runs)
+    // register packer: the gcd-scaled int32 requests in processing order (order_kernel copies them from req32)
+    int32_t* s_req32;        // [nnz][R] or null
+    const int32_t* req32;    // [G][R] source of s_req32 (FastScratch::req32)
 };
 
 // kernel-internal flag bit (not part of the ABI): the template-level Filters pass for (PEG, group)
