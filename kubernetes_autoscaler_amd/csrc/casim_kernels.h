@@ -223,15 +223,16 @@ CS_GLOBAL void order_kernel(DevTables t, DevResults res, OrderScratch os) {
     cs::sync();
     for (int k = 2; k <= npad; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < npad; i += nt) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const uint64_t ki = keys[i], kl = keys[l];
-                    const int32_t pi = pos[i], pl = pos[l];
-                    const bool gt = ki > kl || (ki == kl && pi > pl);  // (i) sorts after (l)
-                    const bool up = (i & k) == 0;
-                    if (gt == up) { keys[i] = kl; keys[l] = ki; pos[i] = pl; pos[l] = pi; }
-                }
+            // one thread per PAIR (i, i | j): every lane of every wave works in every pass (with one thread per element
+            // half of them only tested l > i, and the kernel is bound by instruction issue)
+            for (int p = tid; p < (npad >> 1); p += nt) {
+                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                const int l = i | j;
+                const uint64_t ki = keys[i], kl = keys[l];
+                const int32_t pi = pos[i], pl = pos[l];
+                const bool gt = ki > kl || (ki == kl && pi > pl);  // (i) sorts after (l)
+                const bool up = (i & k) == 0;
+                if (gt == up) { keys[i] = kl; keys[l] = ki; pos[i] = pl; pos[l] = pi; }
             }
             cs::sync();
         }

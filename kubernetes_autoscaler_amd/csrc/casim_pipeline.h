@@ -174,15 +174,18 @@ public:
         }
         // ---- order scratch geometry ----
         std::vector<int64_t> ooff(NG);
-        int64_t ototal = 0, oworst = 0;
+        int64_t ototal = 0, oworst = 0, npad_max = 1;
         for (size_t i = 0; i < NG; ++i) {
             int64_t npad = 1;
             while (npad < pegs_of_group[i]) npad <<= 1;
+            npad_max = npad > npad_max ? npad : npad_max;
             const int64_t bytes = npad * 12 + 8 + 8 * kOrderThreads;
             ooff[i] = ototal; ototal += (bytes + 255) & ~255ll;
             oworst = bytes > oworst ? bytes : oworst;
         }
         order_smem_ = (size_t)oworst;
+        // one thread per pair of the bitonic network: npad / 2 threads, 64..kOrderThreads
+        order_threads_ = (int)(npad_max / 2 < 64 ? 64 : (npad_max / 2 > kOrderThreads ? kOrderThreads : (npad_max / 2 + 63) / 64 * 64));
         order_lds_ = oworst <= (int64_t)bk_.lds_budget();
         if (!order_lds_) {
             os_.off = up(ooff.data(), NG);
@@ -217,8 +220,8 @@ public:
     }
     int32_t run_order() {
         if (NG_ == 0) return CASIM_OK;
-        if (order_lds_) bk_.launch(order_kernel<true>, NG_, 1, kOrderThreads, order_smem_, dt_, dr_, os_);
-        else bk_.launch(order_kernel<false>, NG_, 1, kOrderThreads, (size_t)0, dt_, dr_, os_);
+        if (order_lds_) bk_.launch(order_kernel<true>, NG_, 1, order_threads_, order_smem_, dt_, dr_, os_);
+        else bk_.launch(order_kernel<false>, NG_, 1, order_threads_, (size_t)0, dt_, dr_, os_);
         return CASIM_OK;
     }
     int32_t run_pack() {
@@ -375,6 +378,7 @@ private:
     bool csr_on_device_ = false, pack_lds_ = true, order_lds_ = true, ready_ = false, ran_ = false;
     int fast_wx_ = 0;
     size_t pack_smem_ = 0, order_smem_ = 0;
+    int order_threads_ = kOrderThreads;
     uint64_t* d_bits_ = nullptr; int32_t* d_counts_ = nullptr; int32_t* d_off_ = nullptr; int32_t* d_idx_ = nullptr;
     uint8_t* d_opt_set_ = nullptr; int32_t* d_opt_out_ = nullptr; int64_t* d_opt_key_ = nullptr;
     std::vector<int32_t> h_off_;
