@@ -154,13 +154,16 @@ struct MemStore {
     }
     // place x pods on node m (NodeInfo.AddPodInfo / update, types.go:361-371,439-463)
     CS_DEVICE void commit(int, int m, uint32_t x, const Peg& pv) {
-        for (int r = 0; r < R; ++r) sfree[(int64_t)r * cap + m] -= (int64_t)x * pv.req[r];
+        // (unrolled with a guard: a runtime index would put the PEG record into scratch memory)
+#pragma unroll
+        for (int r = 0; r < CASIM_KMAX_RES; ++r) if (r < R) sfree[(int64_t)r * cap + m] -= (int64_t)x * pv.req[r];
         sslots[m] -= (int32_t)x;
         snpods[m] += (int32_t)x;
         for (int w = 0; w < Wx; ++w) sexcl[(int64_t)w * cap + m] |= pv.xmark[w];
     }
     CS_DEVICE void create(int, int m, uint32_t x, const Peg& pv, const Fresh& fn) {
-        for (int r = 0; r < R; ++r) sfree[(int64_t)r * cap + m] = fn.free[r] - (int64_t)x * pv.req[r];
+#pragma unroll
+        for (int r = 0; r < CASIM_KMAX_RES; ++r) if (r < R) sfree[(int64_t)r * cap + m] = fn.free[r] - (int64_t)x * pv.req[r];
         sslots[m] = fn.slots - (int32_t)x;
         snpods[m] = (int32_t)x;
         for (int w = 0; w < Wx; ++w) sexcl[(int64_t)w * cap + m] = fn.excl[w] | (x > 0 ? pv.xmark[w] : 0ull);
