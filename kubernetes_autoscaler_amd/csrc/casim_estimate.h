@@ -39,9 +39,9 @@ struct EstArgs {
     char* gstate;
 };
 
-template <bool kLds>
+template <bool kLds, int RMAX_>
 CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void estimate_kernel(DevTables t, EstArgs a) {
-    using Store = MemStore<kLds>;
+    using Store = MemStore<kLds, RMAX_>;
     const int tid = cs::tid(), lane = cs::lane(), wave = tid >> 6;
     const int T = cs::nthreads();
     const int R = t.R, Wx = t.Wx, N = a.N, E = a.E;
@@ -101,7 +101,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void estimate_kernel(DevTables t, EstArgs a)
         const int32_t cnt = a.peg_count[k];
         typename Store::Peg pv;
 #pragma unroll
-        for (int r = 0; r < CASIM_KMAX_RES; ++r) {
+        for (int r = 0; r < RMAX_; ++r) {
             pv.req[r] = r < R ? t.req[(int64_t)c * R + r] : 0;
             pv.rq[r] = pv.req[r] > 0 ? 1.0 / (double)pv.req[r] : 0.0;
         }
@@ -149,10 +149,10 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void estimate_kernel(DevTables t, EstArgs a)
         auto filters_verdict = [&](int m) -> int {
             if (!((fb[m >> 6] >> (m & 63)) & 1ull)) return 2;
             for (int w = 0; w < Wx; ++w) if (st.sexcl[(int64_t)w * st.cap + m] & xp[w]) return 2;
-            int64_t fr[CASIM_KMAX_RES];
+            int64_t fr[RMAX_];
 #pragma unroll
-            for (int r = 0; r < CASIM_KMAX_RES; ++r) fr[r] = r < R ? st.sfree[(int64_t)r * st.cap + m] : 0;
-            if (capacity_lanes<int64_t, CASIM_KMAX_RES>(fr, st.sslots[m], R, pv, 1u) == 0) return 2;
+            for (int r = 0; r < RMAX_; ++r) fr[r] = r < R ? st.sfree[(int64_t)r * st.cap + m] : 0;
+            if (capacity_lanes<int64_t, RMAX_>(fr, st.sslots[m], R, pv, 1u) == 0) return 2;
             const int rv = rules_verdict(m);
             if (rv != 0) return rv;
             for (int w = 0; w < Wx; ++w) if (st.sexcl[(int64_t)w * st.cap + m] & pv.xblock[w]) return 2;   // hostname anti-affinity
@@ -420,8 +420,13 @@ public:
             bk_.launch(copy_i32_kernel, (int)((rule_total_ + 255) / 256), 1, 256, (size_t)0, a_.rule_dom_nodes, d_dom_init_, rule_total_);
         }
         if (C_ > 0) bk_.launch(sched_static_kernel, S_, C_, 64, (size_t)0, dt_, d_fbits_, S_);
-        if (lds_) bk_.launch(estimate_kernel<true>, 1, 1, threads_, smem_, dt_, a_);
-        else bk_.launch(estimate_kernel<false>, 1, 1, threads_, smem_, dt_, a_);
+        if (dt_.R <= 2) {
+            if (lds_) bk_.launch(estimate_kernel<true, 2>, 1, 1, threads_, smem_, dt_, a_);
+            else bk_.launch(estimate_kernel<false, 2>, 1, 1, threads_, smem_, dt_, a_);
+        } else {
+            if (lds_) bk_.launch(estimate_kernel<true, CASIM_KMAX_RES>, 1, 1, threads_, smem_, dt_, a_);
+            else bk_.launch(estimate_kernel<false, CASIM_KMAX_RES>, 1, 1, threads_, smem_, dt_, a_);
+        }
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
     }
 

@@ -21,7 +21,7 @@
 // and DPP reductions.  Two node stores share ONE algorithm body:
 //   RegStore<R, NPT>  node state in VGPRs as int32 (lanes pre-divided by their gcd on the host — exact,
 //                     see casim_pipeline.h), up to 64*NPT nodes, no exclusion bits: the fast path
-//   MemStore<kLds>    int64 state in LDS (or an HBM slab), any R / node count / exclusion masks
+//   MemStore<kLds, RMAX>  int64 state in LDS (or an HBM slab), any R / node count / exclusion masks
 // PEG records arrive in processing order (written by order_kernel): 64 records per coalesced
 // wave-load, one per lane, broadcast field by field with v_readlane.
 #pragma once
@@ -124,17 +124,19 @@ CS_DEVICE uint32_t capacity_lanes(const L* fr, int32_t slots, int R, const PegVi
 }
 
 // ---- node store: int64 state in LDS / HBM -------------------------------------------------------
-template <bool kLds>
+// RMAX_: resource lanes carried in registers (2 for the common cpu + memory batch, else CASIM_KMAX_RES): every lane costs
+// four scalar registers of PEG record (request + reciprocal), and these kernels live on the edge of the SGPR file.
+template <bool kLds, int RMAX_ = CASIM_KMAX_RES>
 struct MemStore {
     using Lane = int64_t;
     static constexpr int kNPT = 0;          // 0 = runtime slot count
-    static constexpr int kRMax = CASIM_KMAX_RES;
+    static constexpr int kRMax = RMAX_;
     static constexpr bool kHasExcl = true;
     static constexpr bool kHasZone = true;
     static constexpr int kZoneWords = 0;    // group-wide exclusion words live in LDS (per-lane copies), any number
     static constexpr bool kChunkLds = false; // the 64 PEG records of a chunk stay in the lanes' registers
-    using Peg = PegView<int64_t, CASIM_KMAX_RES>;
-    using Fresh = FreshNode<int64_t, CASIM_KMAX_RES>;
+    using Peg = PegView<int64_t, RMAX_>;
+    using Fresh = FreshNode<int64_t, RMAX_>;
     int R, Wx, cap;
     int64_t* sfree;   // [R][cap]
     uint64_t* sexcl;  // [Wx][cap]
@@ -145,10 +147,10 @@ struct MemStore {
     CS_DEVICE uint32_t capacity(int, int m, const Peg& pv, uint32_t clampk, bool selfx) const {
         for (int w = 0; w < Wx; ++w)
             if (sexcl[(int64_t)w * cap + m] & pv.xblock[w]) return 0;  // NodePorts / hostname anti-affinity
-        Lane fr[CASIM_KMAX_RES];
+        Lane fr[RMAX_];
 #pragma unroll
-        for (int r = 0; r < CASIM_KMAX_RES; ++r) fr[r] = r < R ? sfree[(int64_t)r * cap + m] : 0;
-        uint32_t k = capacity_lanes<Lane, CASIM_KMAX_RES>(fr, sslots[m], R, pv, clampk);
+        for (int r = 0; r < RMAX_; ++r) fr[r] = r < R ? sfree[(int64_t)r * cap + m] : 0;
+        uint32_t k = capacity_lanes<Lane, RMAX_>(fr, sslots[m], R, pv, clampk);
         if (selfx && k > 1) k = 1;
         return k;
     }
@@ -156,14 +158,14 @@ struct MemStore {
     CS_DEVICE void commit(int, int m, uint32_t x, const Peg& pv) {
         // (unrolled with a guard: a runtime index would put the PEG record into scratch memory)
 #pragma unroll
-        for (int r = 0; r < CASIM_KMAX_RES; ++r) if (r < R) sfree[(int64_t)r * cap + m] -= (int64_t)x * pv.req[r];
+        for (int r = 0; r < RMAX_; ++r) if (r < R) sfree[(int64_t)r * cap + m] -= (int64_t)x * pv.req[r];
         sslots[m] -= (int32_t)x;
         snpods[m] += (int32_t)x;
         for (int w = 0; w < Wx; ++w) sexcl[(int64_t)w * cap + m] |= pv.xmark[w];
     }
     CS_DEVICE void create(int, int m, uint32_t x, const Peg& pv, const Fresh& fn) {
 #pragma unroll
-        for (int r = 0; r < CASIM_KMAX_RES; ++r) if (r < R) sfree[(int64_t)r * cap + m] = fn.free[r] - (int64_t)x * pv.req[r];
+        for (int r = 0; r < RMAX_; ++r) if (r < R) sfree[(int64_t)r * cap + m] = fn.free[r] - (int64_t)x * pv.req[r];
         sslots[m] = fn.slots - (int32_t)x;
         snpods[m] = (int32_t)x;
         for (int w = 0; w < Wx; ++w) sexcl[(int64_t)w * cap + m] = fn.excl[w] | (x > 0 ? pv.xmark[w] : 0ull);
@@ -841,12 +843,12 @@ CS_DEVICE bool pack_unsupported(const DevTables& t, const DevResults& res) {
 }
 
 // ---- generic kernel: int64 state in LDS (kLds) or an HBM slab ------------------------------------
-template <bool kLds>
+template <bool kLds, int RMAX_>
 CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void pack_kernel(DevTables t, DevResults res, PackScratch ps) {
     if (pack_unsupported(t, res)) return;
     const int ng = cs::bid();
     const int R = t.R, Wx = t.Wx, Wz = t.Wz;
-    MemStore<kLds> st;
+    MemStore<kLds, RMAX_> st;
     st.R = R; st.Wx = Wx; st.cap = ps.node_cap[ng];
     char* base = kLds ? cs::dyn_smem() : ps.gstate + ps.state_off[ng];
     st.sfree = (int64_t*)base;
@@ -855,8 +857,8 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void pack_kernel(DevTables t, DevResults res, 
     st.sslots = (int32_t*)(szone + 64 * (Wz > 0 ? Wz : 1));
     st.snpods = st.sslots + st.cap;
     st.sctmp = st.snpods + st.cap;
-    FreshNode<int64_t, CASIM_KMAX_RES> fn;
-    for (int r = 0; r < CASIM_KMAX_RES; ++r) fn.free[r] = r < R ? t.alloc[(int64_t)ng * R + r] - t.init_req[(int64_t)ng * R + r] : 0;
+    FreshNode<int64_t, RMAX_> fn;
+    for (int r = 0; r < RMAX_; ++r) fn.free[r] = r < R ? t.alloc[(int64_t)ng * R + r] - t.init_req[(int64_t)ng * R + r] : 0;
     fn.slots = t.allowed[ng] - t.init_pods[ng];
     fn.excl = t.init_excl + (int64_t)ng * Wx;
     const int64_t* s_req = res.s_req;

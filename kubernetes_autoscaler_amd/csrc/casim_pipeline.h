@@ -243,8 +243,13 @@ public:
             }
             return CASIM_OK;
         }
-        if (pack_lds_) bk_.launch(pack_kernel<true>, NG_, 1, 64, pack_smem_, dt_, dr_, ps_);
-        else bk_.launch(pack_kernel<false>, NG_, 1, 64, (size_t)0, dt_, dr_, ps_);
+        if (dt_.R <= 2) {
+            if (pack_lds_) bk_.launch(pack_kernel<true, 2>, NG_, 1, 64, pack_smem_, dt_, dr_, ps_);
+            else bk_.launch(pack_kernel<false, 2>, NG_, 1, 64, (size_t)0, dt_, dr_, ps_);
+        } else {
+            if (pack_lds_) bk_.launch(pack_kernel<true, CASIM_KMAX_RES>, NG_, 1, 64, pack_smem_, dt_, dr_, ps_);
+            else bk_.launch(pack_kernel<false, CASIM_KMAX_RES>, NG_, 1, 64, (size_t)0, dt_, dr_, ps_);
+        }
         return CASIM_OK;
     }
     int32_t run() {

@@ -171,10 +171,11 @@ inline int64_t casim_sched_state_bytes(int R, int Wx, int64_t cap) {
 // kTxn (removal transactions) and kRules (domain rules) are compile-time: the plain TrySchedulePods instantiation
 // does not carry their ~40 pointers — as one kernel, the uniform state overflowed the SGPR file and the hot loop
 // was dominated by v_writelane / v_readlane spill traffic (r01l ISA: 1800 of them).
-template <bool kLds, bool kTxn, bool kRules>
+// RMAX_ = 2 for the common cpu + memory batch, else CASIM_KMAX_RES (see MemStore).
+template <bool kLds, bool kTxn, bool kRules, int RMAX_>
 CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) {
     const int32_t n_rules = kRules ? a.n_rules : 0;
-    using Store = MemStore<kLds>;
+    using Store = MemStore<kLds, RMAX_>;
     const int tid = cs::tid(), lane = cs::lane(), wave = tid >> 6;
     const int T = cs::nthreads();
     const int R = t.R, Wx = t.Wx, N = a.N;
@@ -271,10 +272,10 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
     int cstart = 0, cend = 0, cpart = -1;
     int32_t my_class = 0, my_count = 0, my_hint = -1, my_first = 0, my_pair = -1, my_ctrl = -1;
     uint32_t my_flags = 0;
-    int64_t my_req[CASIM_KMAX_RES];
-    double my_rq[CASIM_KMAX_RES];
+    int64_t my_req[RMAX_];
+    double my_rq[RMAX_];
 #pragma unroll
-    for (int r = 0; r < CASIM_KMAX_RES; ++r) { my_req[r] = 0; my_rq[r] = 0.0; }
+    for (int r = 0; r < RMAX_; ++r) { my_req[r] = 0; my_rq[r] = 0.0; }
 
     const int n_tx = txn ? a.n_cand : 1;
     for (int kc = 0; kc < n_tx; ++kc) {
@@ -351,7 +352,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                 my_pair = (kRules && have && part == 0 && a.run_pair) ? a.run_pair[kk] : -1;
                 my_ctrl = (kRules && have && part == 0 && a.run_ctrl) ? a.run_ctrl[kk] : -1;
 #pragma unroll
-                for (int r = 0; r < CASIM_KMAX_RES; ++r) {
+                for (int r = 0; r < RMAX_; ++r) {
                     my_req[r] = (have && r < R) ? t.req[(int64_t)my_class * R + r] : 0;
                     my_rq[r] = my_req[r] > 0 ? 1.0 / (double)my_req[r] : 0.0;
                 }
@@ -366,7 +367,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
             if (cnt <= 0) continue;
             typename Store::Peg pv;
 #pragma unroll
-            for (int r = 0; r < CASIM_KMAX_RES; ++r) {
+            for (int r = 0; r < RMAX_; ++r) {
                 pv.req[r] = r < R ? (int64_t)cs::bcast_u64((uint64_t)my_req[r], j) : 0;
                 pv.rq[r] = r < R ? cs::bits_double(cs::bcast_u64(cs::double_bits(my_rq[r]), j)) : 0.0;
             }
@@ -881,7 +882,8 @@ public:
         }
         if (C_ > 0) bk_.launch(sched_static_kernel, S_, C_, 64, (size_t)0, dt_, d_fbits_, S_);
         const bool tx = K_ > 0, ru = a_.n_rules > 0;
-#define CASIM_SCHED_LAUNCH(L, X, Y) bk_.launch(sched_kernel<L, X, Y>, 1, 1, threads_, smem_, dt_, a_)
+#define CASIM_SCHED_LAUNCH(L, X, Y) do { if (dt_.R <= 2) bk_.launch(sched_kernel<L, X, Y, 2>, 1, 1, threads_, smem_, dt_, a_); \
+                                         else bk_.launch(sched_kernel<L, X, Y, CASIM_KMAX_RES>, 1, 1, threads_, smem_, dt_, a_); } while (0)
         if (lds_) { if (tx) { if (ru) CASIM_SCHED_LAUNCH(true, true, true); else CASIM_SCHED_LAUNCH(true, true, false); }
                     else    { if (ru) CASIM_SCHED_LAUNCH(true, false, true); else CASIM_SCHED_LAUNCH(true, false, false); } }
         else      { if (tx) { if (ru) CASIM_SCHED_LAUNCH(false, true, true); else CASIM_SCHED_LAUNCH(false, true, false); }
