@@ -787,7 +787,9 @@ public:
         dt_.init_excl = up(g->init_excl, N * dt_.Wx);
 
         // one workgroup: 64..1024 threads, node m -> thread m % T, chunk m / T
-        int max_threads = cand ? kDefaultThreadsRemovals : kDefaultThreads;
+        // (r01w sweep: TrySchedulePods on 5000+ nodes is ~7 % faster with 512 threads — 2.31 vs 2.48 ms, 8.9 vs 9.5 ms —, the
+        // removal loop does not care)
+        int max_threads = cand ? kDefaultThreadsRemovals : (N_ >= 4096 ? 2 * kDefaultThreads : kDefaultThreads);
         if (const char* e = getenv("CASIM_SCHED_THREADS")) { const int v = atoi(e); if (v >= 64 && v <= 1024) max_threads = v / 64 * 64; }
         threads_ = (int)(round_up64_((int64_t)N_) < max_threads ? round_up64_((int64_t)N_) : max_threads);
         cap_ = (int32_t)(((int64_t)N_ + threads_ - 1) / threads_ * threads_);

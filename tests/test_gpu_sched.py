@@ -65,6 +65,13 @@ def test_benchmark_filter_out_schedulable_shapes(ctx, shape):
         assert_sched_matches((rc, node_out, li, ns), sched_oracle(sc), w.name)
 
 
+def test_packing_on_a_large_cluster(ctx):
+    """4500 nodes: the TrySchedulePods workgroup runs 512 threads from 4096 nodes on."""
+    w = pending_scale(4500, 12000, n_classes=24, seed=17)
+    sc = case_of(w)
+    assert_sched_matches(sched_gpu(sc, ctx), sched_oracle(sc), w.name)
+
+
 def test_packing_at_scale(ctx):
     """2000 heterogeneous nodes (state in LDS or HBM), 20000 pending pods that mostly fit."""
     w = pending_scale(2000, 20000, n_classes=32, seed=7)

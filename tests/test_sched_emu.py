@@ -227,3 +227,9 @@ def test_reference_similar_pods_limiting_and_daemonsets():
     for p in pods:
         p.daemonset, p.controller_uid = False, ""
     assert HintingSimulator(EmuContext(0)).try_schedule_pods(nodes, pods) == ([], 0)
+
+
+def test_large_cluster_uses_the_wide_workgroup():
+    # from 4096 nodes on the TrySchedulePods workgroup runs 512 threads (casim_sched.h init)
+    w = pending_scale(4500, 3000, n_classes=12, seed=18)
+    check(case_of(w), w.name, lds_budgets=(0,))

@@ -1,4 +1,4 @@
-for T in 64 128 256 512 1024; do
+for T in ${SWEEP_T:-64 128 256 512 1024}; do
   echo "== T=$T"
   CASIM_SCHED_THREADS=$T CASIM_ORACLE_CHECK_LIMIT=0 python tools/time_pending.py 2>/dev/null | python -c "
 import sys,json
