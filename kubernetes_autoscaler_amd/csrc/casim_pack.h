@@ -207,12 +207,6 @@ struct RegStore {
     int32_t slots[NPT_];
     int32_t fresh_slots;  // pod slots of an empty node: pods on a node = fresh_slots - slots (no per-node counter)
 
-    CS_DEVICE uint32_t capacity(int s, int, const Peg& pv, uint32_t clampk, bool selfx) const {
-        if (X_ && blocked(s, pv)) return 0;   // NodePorts / hostname anti-affinity
-        uint32_t k = capacity_lanes<Lane, R_>(fr[s], slots[s], R_, pv, clampk);
-        if (selfx && k > 1) k = 1;
-        return k;
-    }
     // Pass A for all slots.  Per slot: a cheap fit mask first (pod slot left and req <= free on every
     // requested lane: a handful of compares); only slots where SOME node fits (wave-uniform ballot) pay for
     // the quotient chain (cvt -> f64 mul by the PEG's reciprocal -> cvt -> exact +-1 fix-up).  In the
@@ -379,17 +373,6 @@ CS_DEVICE void for_slots(int S, F&& f) {
         for (int s = 0; s < S; ++s) f(s);
     }
 }
-template <class Store, class F>
-CS_DEVICE void with_slot(int ls, F&& f) {
-    if constexpr (Store::kNPT > 0) {
-#pragma unroll
-        for (int s = 0; s < Store::kNPT; ++s)
-            if (s == ls) f(s);
-    } else {
-        f(ls);
-    }
-}
-
 // PEG-record source of the 64-record chunk loaded by the wave (processing order)
 struct PegChunk {
     int32_t cnt;
