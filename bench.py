@@ -277,7 +277,7 @@ def main():
                     p2.run(); p2.fetch()
             extra["single_sim_upload_run_fetch_ms"] = (time.perf_counter() - t1) / 20 * 1e3
         # streaming form of the same predicates: dense per-pod x per-node check (HBM-facing kernel)
-        if not args.no_dense:
+        if not args.no_dense and world == 1:   # side measurements: N = 1 only
             try:
                 # bounded probe: 256 simulations' pods x (256 groups x 16 nodes) = 2.56 M x 4096 -> 1.3 GB of bits
                 rep = 16
@@ -295,7 +295,7 @@ def main():
             except Exception as e:  # the probe must never take the headline number down
                 extra["roofline_dense_check"] = {"error": str(e)}
         # the callers either side of the path, one mid-size case each: resident tables, HIP-event time
-        if not args.no_next_rows:
+        if not args.no_next_rows and world == 1:
             try:
                 from kubernetes_autoscaler_amd.scheduling import encode_pending_pods
                 w1 = workloads.pending_scale(5000, 50000, 64, 2)
@@ -331,10 +331,9 @@ def main():
         except Exception as e:
             extra["copy_bandwidth_gbps"] = str(e)
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU legs are timed at N = 1 only (other ranks would idle in the barrier)
             cpu = cpu_baseline(workloads, 0, args.pegs, args.pods_per_peg, args.cap)
-            if world == 1:
-                extra["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.pegs, args.pods_per_peg, args.cap)
+            extra["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.pegs, args.pods_per_peg, args.cap)
         out = {"metric": "scale-up simulation predicate checks/s (pods x nodes)", "value": value, "unit": "checks/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
