@@ -15,7 +15,7 @@
  * TestNewClusterCapacityThreshold, TestLastIndexOrderMapping, TestRunFiltersOnNode,
  * TestRunFilterUntilPassingNode, TestDebugInfo taints, TestLeastNodes, TestLeastWaste,
  * TestFilterOutSchedulable, TestSimulateNodeRemoval incl. its two ghost-node PodTopologySpread rows,
- * the planner's TestUpdateClusterState).
+ * the planner's TestUpdateClusterState and TestUpdateClusterStatUnneededNodesLimit, TestTopologySpreadTaintScheduling).
  * Taints / nodeSelector / anti-affinity INSIDE Estimate have no reference known-answer test
  * ("parity unpinned" for those rows); they are restated from the vendored plugin
  * sources cited below.

@@ -391,3 +391,39 @@ def test_planner_unneeded_nodes_limit(row):
     s.close()
     assert int((got["removable"] == 1).sum()) == row["want_unneeded"]
     assert got["n_processed"] == row["want_unneeded"]   # the prefix that was evaluated, the rest is skipped (:307)
+
+
+# ---- PodTopologySpread next to a tainted (to-be-deleted) node: simulator/cluster_scheduling_test.go -------------------
+def golden_taint_spread_case(row):
+    from harness import SchedCase
+    from kubernetes_autoscaler_amd.objects import Taint, TopologySpreadConstraint
+
+    def tsc():
+        return [TopologySpreadConstraint(1, "kubernetes.io/hostname", 0, {"app": "topo-app"}, row["taints_policy"])]
+    infos = []
+    for n in ("node1", "node2", "node3"):
+        node = build_test_node(n, 1000, 2000000)
+        node.labels = {"kubernetes.io/hostname": n}
+        infos.append(NodeInfo(node))
+    infos[0].node.taints.append(Taint("ToBeDeletedByClusterAutoscaler", "1", "NoSchedule"))
+    for i in (1, 2):
+        pod = build_test_pod(f"tsc-pod-node{i + 1}", 100, 100000)
+        pod.labels = {"app": "topo-app"}
+        pod.controller_uid = "rs"
+        pod.spread_constraints = tsc()
+        pod.topology_spread = True
+        infos[i].pods.append(pod)
+    repl = build_test_pod("replacement-pod", 100, 100000)
+    repl.labels = {"app": "topo-app"}
+    repl.spread_constraints = tsc()
+    repl.topology_spread = True
+    return SchedCase(nodes=infos, pods=[repl])
+
+
+@pytest.mark.parametrize("row", GOLD["topology_spread_taint_scheduling"]["cases"], ids=lambda r: r["name"])
+def test_topology_spread_taint_scheduling(row):
+    from harness import sched_oracle
+    node_out, _, n = sched_oracle(golden_taint_spread_case(row))
+    assert (n == 1) == row["schedulable"]
+    if row["schedulable"]:
+        assert node_out[0] in (1, 2)

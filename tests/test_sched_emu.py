@@ -233,3 +233,16 @@ def test_large_cluster_uses_the_wide_workgroup():
     # from 4096 nodes on the TrySchedulePods workgroup runs 512 threads (casim_sched.h init)
     w = pending_scale(4500, 3000, n_classes=12, seed=18)
     check(case_of(w), w.name, lds_budgets=(0,))
+
+
+@pytest.mark.parametrize("row", GOLD["topology_spread_taint_scheduling"]["cases"], ids=lambda r: r["name"])
+def test_reference_topology_spread_next_to_a_tainted_node(row):
+    """simulator/cluster_scheduling_test.go TestTopologySpreadTaintScheduling: the tainted, emptied node still is a spread
+    domain under the default policy (nothing fits); nodeTaintsPolicy: Honor is outside the encoded subset."""
+    from test_oracle_golden import golden_taint_spread_case
+    sc = golden_taint_spread_case(row)
+    if row.get("device_delegates"):
+        assert sched_emu(sc)[0] == _abi.NG_UNSUPPORTED
+        return
+    want = check(sc, row["name"])
+    assert (want[2] == 1) == row["schedulable"]
