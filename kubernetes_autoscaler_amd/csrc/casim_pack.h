@@ -88,8 +88,13 @@ CS_DEVICE uint32_t capacity_lanes(const L* fr, int32_t slots, int R, const PegVi
                 const bool fits = f >= q;
                 const uint32_t fpos = fits ? (uint32_t)f : 0u;
                 uint32_t e = (uint32_t)((double)fpos * pv.rq[r]);  // f < 2^31, e <= f: exact up to +-1
-                const int64_t rem = (int64_t)fpos - (int64_t)((uint64_t)e * (uint64_t)(uint32_t)q);
-                e = rem < 0 ? e - 1 : (rem >= (int64_t)q ? e + 1 : e);
+                if (q < (1 << 30)) {   // the remainder lies in (-q, 2q): wrapping 32-bit arithmetic, sign bit + carry fix-up
+                    const int32_t rem = (int32_t)(fpos - e * (uint32_t)q);
+                    e = e - ((uint32_t)rem >> 31) + (rem >= q ? 1u : 0u);
+                } else {
+                    const int64_t rem = (int64_t)fpos - (int64_t)((uint64_t)e * (uint64_t)(uint32_t)q);
+                    e = rem < 0 ? e - 1 : (rem >= (int64_t)q ? e + 1 : e);
+                }
                 c = e < c ? e : c;   // fits == false gives e == 0
             }
         }
@@ -163,6 +168,7 @@ struct MemStore {
         snpods[m] += (int32_t)x;
         for (int w = 0; w < Wx; ++w) sexcl[(int64_t)w * cap + m] |= pv.xmark[w];
     }
+    CS_DEVICE void commit_any(int, uint32_t, const Peg&) {}   // (register stores only)
     CS_DEVICE void create(int, int m, uint32_t x, const Peg& pv, const Fresh& fn) {
 #pragma unroll
         for (int r = 0; r < RMAX_; ++r) if (r < R) sfree[(int64_t)r * cap + m] = fn.free[r] - (int64_t)x * pv.req[r];
@@ -303,6 +309,14 @@ struct RegStore {
         slots[s] -= (int32_t)x;
 #pragma unroll
         for (int w = 0; w < WX_; ++w) excl[s][w] |= pv.xm[w];
+    }
+    // the same for any x >= 0 (x == 0: no change), straight-line
+    CS_DEVICE void commit_any(int s, uint32_t x, const Peg& pv) {
+#pragma unroll
+        for (int r = 0; r < R_; ++r) fr[s][r] -= (int32_t)x * pv.req[r];
+        slots[s] -= (int32_t)x;
+#pragma unroll
+        for (int w = 0; w < WX_; ++w) excl[s][w] |= x > 0 ? pv.xm[w] : 0ull;
     }
     CS_DEVICE void create(int s, int, uint32_t x, const Peg& pv, const Fresh& fn) {
 #pragma unroll
@@ -507,7 +521,8 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
 #pragma unroll
                 for (int r = 0; r < RM; ++r) {
                     pv.req[r] = r < R ? (L)cs::uniform_u32(chunk[(3 + r) * 64 + j]) : (L)0;
-                    pv.rq[r] = cs::bits_double(((uint64_t)cs::uniform_u32(chunk[(3 + RM + 2 * r + 1) * 64 + j]) << 32) | cs::uniform_u32(chunk[(3 + RM + 2 * r) * 64 + j]));
+                    // (the reciprocal only ever is a VALU operand: it stays in the vector registers the LDS read filled)
+                    pv.rq[r] = cs::bits_double(((uint64_t)chunk[(3 + RM + 2 * r + 1) * 64 + j] << 32) | chunk[(3 + RM + 2 * r) * 64 + j]);
                 }
             } else {
                 cnt = (int32_t)cs::bcast_u32((uint32_t)my_cnt, j);
@@ -656,7 +671,8 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         if (Rr > 0 && cand && rot < (int32_t)Rr) x += 1;
                         const uint64_t hit = b & cs::ballot(rot == target);
                         if (hit) new_last = E + s * 64 + cs::ffs64(hit);
-                        if (x > 0) st.commit(s, m, x, pv);
+                        if constexpr (Store::kNPT > 0) st.commit_any(s, x, pv);   // x == 0 changes nothing: no exec-mask branch
+                        else { if (x > 0) st.commit(s, m, x, pv); }
                         if (m == M - 1) x_mine_last = x;
                         basec += cs::popc64(b);
                     });
@@ -690,10 +706,11 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     const int s_lo = first >> 6, s_hi = (first + nadd - 1) >> 6;
                     for_slots<Store>(s_hi + 1, [&](int s) {
                         const int32_t m = s * 64 + lane;
-                        if (s >= s_lo && m >= first && m < first + nadd) {
-                            const int32_t i = m - first;
-                            const int64_t left = (int64_t)pods_total - (int64_t)i * per;
-                            const uint32_t x = left <= 0 ? 0u : (left < (int64_t)per ? (uint32_t)left : per);
+                        const uint32_t i = (uint32_t)(m - first);
+                        if (s >= s_lo && i < (uint32_t)nadd) {
+                            // i * per <= (nadd - 1) * per < pods_total < 2^31 for the nodes being created: 32-bit arithmetic
+                            const int32_t left = pods_total - (int32_t)(i * per);
+                            const uint32_t x = left <= 0 ? 0u : ((uint32_t)left < per ? (uint32_t)left : per);
                             st.create(s, m, x, pv, fn);
                         }
                     });
