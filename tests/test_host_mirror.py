@@ -157,3 +157,14 @@ def test_equivalence_group_ignores_daemonsets():
         p.daemonset = True
         pods.append(p)
     assert len(group_pods_by_scheduling_properties(pods)) == G["want_groups"]
+
+
+def test_bench_multi_process_cpu_leg():
+    """bench.py's cpu_baseline_all_cores: independent oracle processes started together (no GPU, no torch in the workers)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out = bench.cpu_baseline_all_cores(8, 5, 16, budget_s=0.3, max_procs=2, sims_per_proc=2)
+    assert "error" not in out, out
+    assert out["cores"] in (1, 2) and out["sims_per_s"] > 0 and out["unit"] == "checks/s"
