@@ -318,6 +318,7 @@ typedef struct casim_domain_rules {
     const int32_t* class_rule_off;   /* [n_classes + 1] rules of class c: [class_rule_off[c], class_rule_off[c+1]) */
     const int32_t* inc_off;          /* [n_classes + 1]                                                        */
     const int32_t* inc_rule;         /* [inc_off[n_classes]]                                                   */
+    int32_t n_taint_policy_rules;    /* spread rules whose eligibility row honours node taints (see casim_enc_spread_set_taints_policy) */
 } casim_domain_rules;
 
 typedef struct casim_pod_sequence {
@@ -502,6 +503,11 @@ int32_t casim_enc_pod_add_spread_constraint(casim_encoder* enc, int32_t pod, int
                                             int32_t min_domains);
 int32_t casim_enc_spread_add_requirement(casim_encoder* enc, int32_t pod, int32_t constraint, const char* key, const char* op,
                                          const char* const* values, int32_t n_values);
+/* nodeTaintsPolicy: Honor (podtopologyspread/common.go:52-56): nodes with a NoSchedule / NoExecute taint the pod does
+ * not tolerate are no members of the constraint's domains.  Default (0) = Ignore.  Evaluated by TrySchedulePods and
+ * by the estimator on the cluster; the removal loop (whose ghost node gains a taint inside a simulation) answers
+ * CASIM_NG_UNSUPPORTED for rules carrying it. */
+int32_t casim_enc_spread_set_taints_policy(casim_encoder* enc, int32_t pod, int32_t constraint, int32_t honor);
 int32_t casim_enc_pod_set_fastpath_requests(casim_encoder* e, int32_t pod, double cpu, double mem);
 /* Mark the spec as carrying a predicate outside the encoded subset (required pod affinity,
  * topology spread, volumes, DRA claims, multi-term node affinity, namespaceSelector...). */

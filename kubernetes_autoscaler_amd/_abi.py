@@ -71,7 +71,7 @@ class DomainRules(C.Structure):
                 ("node_domain", i32p), ("key_domains", i32p), ("key_is_hostname", u8p), ("rule_class", i32p), ("rule_key", i32p), ("rule_kind", i32p),
                 ("rule_max_skew", i32p), ("rule_min_domains", i32p), ("rule_self", i32p), ("rule_elig_row", i32p), ("rule_offset", i64p),
                 ("count_init", i32p), ("domain_exists", u8p), ("domain_nodes", i32p), ("node_contrib", i32p), ("elig_bits", u64p), ("class_rule_off", i32p), ("inc_off", i32p),
-                ("inc_rule", i32p)]
+                ("inc_rule", i32p), ("n_taint_policy_rules", C.c_int32)]
 
 
 class PodSequence(C.Structure):
@@ -152,6 +152,7 @@ PROTOTYPES = {
     "casim_enc_term_add_requirement": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, cstr, cstr, cstrp, C.c_int32]),
     "casim_enc_pod_add_spread_constraint": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, cstr, C.c_int32]),
     "casim_enc_spread_add_requirement": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, cstr, cstr, cstrp, C.c_int32]),
+    "casim_enc_spread_set_taints_policy": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "casim_enc_domain_rules": (C.c_int32, [C.c_void_p, C.POINTER(DomainRules)]),
     "casim_enc_port_block": (u64p, [C.c_void_p]),
     "casim_estimate_on_cluster": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(ClusterEstimate),

@@ -38,7 +38,7 @@ struct Port { std::string ip, proto; int32_t port; bool operator<(const Port& o)
 struct Term { std::string topology_key; std::vector<std::string> namespaces; std::vector<Requirement> selector; };
 typedef std::map<std::string, std::string> Labels;
 
-struct Spread { int32_t max_skew; std::string key; int32_t min_domains; std::vector<Requirement> selector; };
+struct Spread { int32_t max_skew; std::string key; int32_t min_domains; std::vector<Requirement> selector; bool taints_honor = false; };
 struct PodSpec {
     std::vector<Spread> spread;   // DoNotSchedule topologySpreadConstraints
     std::string ns;
@@ -191,6 +191,7 @@ struct casim_encoder {
         std::vector<int64_t> r_off;
         std::vector<uint8_t> exists;
         std::vector<uint64_t> elig;
+        int32_t n_taint_rules = 0;
     } dr;
 };
 
@@ -307,6 +308,12 @@ int32_t casim_enc_spread_add_requirement(casim_encoder* e, int32_t pod, int32_t 
     if (r.op == kBadOp) return CASIM_ERR_INVALID;
     for (int i = 0; i < n_values; ++i) r.values.push_back(S(values[i]));
     e->specs[pod].spread[(size_t)constraint].selector.push_back(r);
+    return CASIM_OK;
+}
+int32_t casim_enc_spread_set_taints_policy(casim_encoder* e, int32_t pod, int32_t constraint, int32_t honor) {
+    POD_CHECK(e, pod);
+    if (constraint < 0 || (size_t)constraint >= e->specs[pod].spread.size()) return CASIM_ERR_INVALID;
+    e->specs[pod].spread[(size_t)constraint].taints_honor = honor != 0;
     return CASIM_OK;
 }
 int32_t casim_enc_pod_set_fastpath_requests(casim_encoder* e, int32_t pod, double cpu, double mem) {
@@ -584,18 +591,35 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         std::vector<std::vector<uint64_t>> rows;
         for (size_t i = 0; i < G; ++i) {
             const PodSpec& p = e->specs[(size_t)e->pegs[i].spec];
-            int row = -1;
-            if (!p.spread.empty()) {   // eligibility of a node for this class's constraints (filtering.go:262-271)
+            // eligibility of a node for this class's constraints (filtering.go:262-271): every constraint key present, the
+            // pod's required node affinity matches (nodeAffinityPolicy Honor, the default), and for constraints with
+            // nodeTaintsPolicy: Honor no untolerated NoSchedule / NoExecute taint (common.go:52-56).  One row per policy.
+            int row = -1, row_honor = -1;
+            if (!p.spread.empty()) {
+                bool any_honor = false;
+                for (auto& sc : p.spread) any_honor = any_honor || sc.taints_honor;
                 row = (int)rows.size(); rows.emplace_back(words, 0ull);
+                if (any_honor) { row_honor = (int)rows.size(); rows.emplace_back(words, 0ull); }
                 for (size_t n = 0; n < NG; ++n) {
                     const Group& g = e->groups[n];
                     bool ok = node_passes_affinity(p, g);
                     for (auto& sc : p.spread) ok = ok && g.labels.count(sc.key) != 0;
-                    if (ok) rows.back()[n >> 6] |= 1ull << (n & 63);
+                    if (!ok) continue;
+                    rows[(size_t)row][n >> 6] |= 1ull << (n & 63);
+                    if (!any_honor) continue;
+                    bool tolerated = true;
+                    for (auto& tn : g.taints) {
+                        if (tn.effect != "NoSchedule" && tn.effect != "NoExecute") continue;
+                        bool tol = false;
+                        for (auto& t : p.tolerations) if (tolerates(t, tn, e->opt.enable_taint_comparison_ops != 0)) { tol = true; break; }
+                        if (!tol) { tolerated = false; break; }
+                    }
+                    if (tolerated) rows[(size_t)row_honor][n >> 6] |= 1ull << (n & 63);
                 }
             }
             for (auto& sc : p.spread) {
-                Rule r{(int)i, key_of(sc.key), 0, sc.max_skew, sc.min_domains, 0, row, &sc};
+                if (sc.taints_honor) dr.n_taint_rules++;
+                Rule r{(int)i, key_of(sc.key), 0, sc.max_skew, sc.min_domains, 0, sc.taints_honor ? row_honor : row, &sc};
                 r.self = (!sc.selector.empty() && selector_matches(sc.selector, p.labels)) ? 1 : 0;   // an empty selector counts nothing
                 rules.push_back(r);
             }
@@ -790,6 +814,7 @@ int32_t casim_enc_domain_rules(const casim_encoder* e, casim_domain_rules* out) 
     const auto& dr = e->dr;
     out->n_keys = dr.n_keys; out->n_rules = dr.n_rules; out->n_nodes = (int32_t)e->groups.size(); out->n_classes = (int32_t)e->pegs.size();
     out->n_elig_rows = dr.n_rows;
+    out->n_taint_policy_rules = dr.n_taint_rules;
     if (dr.n_rules == 0) return CASIM_OK;
     out->node_domain = dr.node_domain.data(); out->key_domains = dr.key_domains.data(); out->key_is_hostname = dr.key_host.data();
     out->rule_class = dr.r_class.data(); out->rule_key = dr.r_key.data(); out->rule_kind = dr.r_kind.data();

@@ -831,6 +831,9 @@ public:
         const casim_domain_rules* dr = q->rules;
         if (dr && dr->n_rules > 0) {
             if (dr->n_nodes != N_ || dr->n_classes != C_) return fail(CASIM_ERR_INVALID, "domain rules were built for other tables");
+            // nodeTaintsPolicy: Honor + removal simulation: the ghost node's ToBeDeleted taint would have to leave / rejoin
+            // the domains inside every transaction — not encoded, the caller runs the reference path
+            if (K_ > 0 && dr->n_taint_policy_rules > 0) return CASIM_NG_UNSUPPORTED;
             for (int c = 0; c < C_; ++c)
                 if (dr->class_rule_off[c + 1] - dr->class_rule_off[c] > kMaxRulesPerClass) return CASIM_NG_UNSUPPORTED;
             const size_t NR = (size_t)dr->n_rules, tot = (size_t)dr->rule_offset[NR];

@@ -88,14 +88,16 @@ class Encoder:
                 check(lib.casim_enc_term_add_requirement(h, s, t, _b(r.key), _b(r.operator), _strs(r.values), len(r.values)))
         cpu, mem = pod.fastpath_requests()
         check(lib.casim_enc_pod_set_fastpath_requests(h, s, cpu, mem))
-        if any(sc.node_taints_policy != "Ignore" for sc in pod.spread_constraints):
-            check(lib.casim_enc_pod_mark_unsupported(h, s, b"topologySpreadConstraints: nodeTaintsPolicy"))
         for sc in pod.spread_constraints:   # evaluated on the device in per-node mode, flagged UNSUPPORTED by finalize otherwise
             ci = lib.casim_enc_pod_add_spread_constraint(h, s, int(sc.max_skew), _b(sc.topology_key), int(sc.min_domains))
             if ci < 0:
                 check(ci, "casim_enc_pod_add_spread_constraint")
             for k, v in sc.match_labels.items():
                 check(lib.casim_enc_spread_add_requirement(h, s, ci, _b(k), b"In", _strs([v]), 1))
+            if sc.node_taints_policy == "Honor":
+                check(lib.casim_enc_spread_set_taints_policy(h, s, ci, 1))
+            elif sc.node_taints_policy != "Ignore":
+                check(lib.casim_enc_pod_mark_unsupported(h, s, b"topologySpreadConstraints: nodeTaintsPolicy"))
         if pod.topology_spread and not pod.spread_constraints:
             check(lib.casim_enc_pod_mark_unsupported(h, s, b"topologySpreadConstraints"))
         if pod.unsupported_reason:

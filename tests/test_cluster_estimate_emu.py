@@ -50,3 +50,26 @@ def test_fuzz_domain_rules(seed):
         assert any(t.topology_key == "kubernetes.io/hostname" for pg in w.pegs for t in pg.pods[0].anti_affinity)
         pytest.skip("delegated: hostname anti-affinity with an unnamed node")
     check(sc, w.name)
+
+
+@pytest.mark.parametrize("seed", range(150))
+def test_fuzz_node_taints_policy_honor(seed):
+    """K_est with tainted nodes (existing and, sometimes, the template) and nodeTaintsPolicy: Honor on some constraints."""
+    import dataclasses
+    import random
+    from kubernetes_autoscaler_amd.objects import Taint, Toleration
+    w = workloads.fuzz_estimate_domains(5000 + seed)
+    rng = random.Random(400 + seed)
+    for info in w.existing:
+        if rng.random() < 0.3:
+            info.node.taints.append(Taint("dedicated", "x", rng.choice(["NoSchedule", "NoExecute", "PreferNoSchedule"])))
+    if rng.random() < 0.25:
+        w.groups[0].template.node.taints.append(Taint("dedicated", "x", "NoSchedule"))
+    for pg in w.pegs:
+        pod = pg.pods[0]
+        pod.tolerations = rng.choice([[], [Toleration("dedicated", "Equal", "x", "")], [Toleration("", "Exists", "", "")]])
+        pod.spread_constraints = [dataclasses.replace(c, node_taints_policy=("Honor" if rng.random() < 0.6 else "Ignore")) for c in pod.spread_constraints]
+    sc = scenario_of(w)
+    if cluster_estimate_emu(sc)[0] == 1:
+        pytest.skip("delegated (hostname anti-affinity next to an unnamed node)")
+    check(sc, w.name)

@@ -185,6 +185,16 @@ def test_removal_reference_table(ctx):
     assert seen == 6
 
 
+def test_fuzz_node_taints_policy_honor(ctx):
+    """Spread constraints with nodeTaintsPolicy: Honor next to tainted nodes (eligibility rows built by the encoder)."""
+    from kubernetes_autoscaler_amd.workloads import fuzz_pending_domains
+    from test_sched_emu import honor_taints_variant
+    for seed in range(120):
+        w = honor_taints_variant(fuzz_pending_domains(3000 + seed), seed)
+        sc = case_of(w)
+        assert_sched_matches(sched_gpu(sc, ctx), sched_oracle(sc), w.name)
+
+
 def test_reference_planner_table(ctx):
     """core/scaledown/planner/planner_test.go TestUpdateClusterState rows through the Planner mirror: injectPods
     (one TrySchedulePods call) then categorizeNodes (one removal call)."""

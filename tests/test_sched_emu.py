@@ -238,11 +238,40 @@ def test_large_cluster_uses_the_wide_workgroup():
 @pytest.mark.parametrize("row", GOLD["topology_spread_taint_scheduling"]["cases"], ids=lambda r: r["name"])
 def test_reference_topology_spread_next_to_a_tainted_node(row):
     """simulator/cluster_scheduling_test.go TestTopologySpreadTaintScheduling: the tainted, emptied node still is a spread
-    domain under the default policy (nothing fits); nodeTaintsPolicy: Honor is outside the encoded subset."""
+    domain under the default policy (nothing fits); with nodeTaintsPolicy: Honor it is no domain member and node2 takes the pod."""
     from test_oracle_golden import golden_taint_spread_case
     sc = golden_taint_spread_case(row)
-    if row.get("device_delegates"):
-        assert sched_emu(sc)[0] == _abi.NG_UNSUPPORTED
-        return
     want = check(sc, row["name"])
     assert (want[2] == 1) == row["schedulable"]
+
+
+def honor_taints_variant(w, seed):
+    """fuzz_pending_domains cluster with tainted nodes; some specs tolerate them, some spread constraints carry
+    nodeTaintsPolicy: Honor (equal specs stay equal)."""
+    import dataclasses
+    import random
+    from kubernetes_autoscaler_amd.objects import Taint, Toleration
+    rng = random.Random(9000 + seed)
+    for info in w.nodes:
+        r = rng.random()
+        if r < 0.25:
+            info.node.taints.append(Taint("dedicated", "x", "NoSchedule"))
+        elif r < 0.35:
+            info.node.taints.append(Taint("maint", "y", "NoExecute"))
+        elif r < 0.45:
+            info.node.taints.append(Taint("soft", "z", "PreferNoSchedule"))   # never counts
+    plan = {}
+    for p in w.pods:
+        k = p.spec_key()
+        if k not in plan:
+            tol = rng.choice([[], [], [Toleration("dedicated", "Equal", "x", "NoSchedule")], [Toleration("", "Exists", "", "")]])
+            plan[k] = (tol, [dataclasses.replace(c, node_taints_policy=("Honor" if rng.random() < 0.6 else "Ignore")) for c in p.spread_constraints])
+        p.tolerations, p.spread_constraints = list(plan[k][0]), list(plan[k][1])
+    return w
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_fuzz_node_taints_policy_honor(seed):
+    from kubernetes_autoscaler_amd.workloads import fuzz_pending_domains
+    w = honor_taints_variant(fuzz_pending_domains(3000 + seed), seed)
+    check(case_of(w), w.name)
