@@ -508,6 +508,9 @@ int32_t casim_enc_spread_add_requirement(casim_encoder* enc, int32_t pod, int32_
  * by the estimator on the cluster; the removal loop (whose ghost node gains a taint inside a simulation) answers
  * CASIM_NG_UNSUPPORTED for rules carrying it. */
 int32_t casim_enc_spread_set_taints_policy(casim_encoder* enc, int32_t pod, int32_t constraint, int32_t honor);
+/* nodeAffinityPolicy (common.go:46-51): Honor (1, the default) = only nodes matching the pod's nodeSelector / required node
+ * affinity are members of the constraint's domains; Ignore (0) = every node carrying the constraint keys. */
+int32_t casim_enc_spread_set_affinity_policy(casim_encoder* enc, int32_t pod, int32_t constraint, int32_t honor);
 int32_t casim_enc_pod_set_fastpath_requests(casim_encoder* e, int32_t pod, double cpu, double mem);
 /* Mark the spec as carrying a predicate outside the encoded subset (required pod affinity,
  * topology spread, volumes, DRA claims, multi-term node affinity, namespaceSelector...). */

@@ -153,6 +153,7 @@ PROTOTYPES = {
     "casim_enc_pod_add_spread_constraint": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, cstr, C.c_int32]),
     "casim_enc_spread_add_requirement": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, cstr, cstr, cstrp, C.c_int32]),
     "casim_enc_spread_set_taints_policy": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "casim_enc_spread_set_affinity_policy": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "casim_enc_domain_rules": (C.c_int32, [C.c_void_p, C.POINTER(DomainRules)]),
     "casim_enc_port_block": (u64p, [C.c_void_p]),
     "casim_estimate_on_cluster": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(ClusterEstimate),

@@ -38,7 +38,7 @@ struct Port { std::string ip, proto; int32_t port; bool operator<(const Port& o)
 struct Term { std::string topology_key; std::vector<std::string> namespaces; std::vector<Requirement> selector; };
 typedef std::map<std::string, std::string> Labels;
 
-struct Spread { int32_t max_skew; std::string key; int32_t min_domains; std::vector<Requirement> selector; bool taints_honor = false; };
+struct Spread { int32_t max_skew; std::string key; int32_t min_domains; std::vector<Requirement> selector; bool taints_honor = false; bool affinity_honor = true; };
 struct PodSpec {
     std::vector<Spread> spread;   // DoNotSchedule topologySpreadConstraints
     std::string ns;
@@ -316,6 +316,12 @@ int32_t casim_enc_spread_set_taints_policy(casim_encoder* e, int32_t pod, int32_
     e->specs[pod].spread[(size_t)constraint].taints_honor = honor != 0;
     return CASIM_OK;
 }
+int32_t casim_enc_spread_set_affinity_policy(casim_encoder* e, int32_t pod, int32_t constraint, int32_t honor) {
+    POD_CHECK(e, pod);
+    if (constraint < 0 || (size_t)constraint >= e->specs[pod].spread.size()) return CASIM_ERR_INVALID;
+    e->specs[pod].spread[(size_t)constraint].affinity_honor = honor != 0;
+    return CASIM_OK;
+}
 int32_t casim_enc_pod_set_fastpath_requests(casim_encoder* e, int32_t pod, double cpu, double mem) {
     POD_CHECK(e, pod); e->specs[pod].fp_cpu = cpu; e->specs[pod].fp_mem = mem; return CASIM_OK;
 }
@@ -591,22 +597,21 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         std::vector<std::vector<uint64_t>> rows;
         for (size_t i = 0; i < G; ++i) {
             const PodSpec& p = e->specs[(size_t)e->pegs[i].spec];
-            // eligibility of a node for this class's constraints (filtering.go:262-271): every constraint key present, the
-            // pod's required node affinity matches (nodeAffinityPolicy Honor, the default), and for constraints with
-            // nodeTaintsPolicy: Honor no untolerated NoSchedule / NoExecute taint (common.go:52-56).  One row per policy.
-            int row = -1, row_honor = -1;
+            // eligibility of a node for a constraint (filtering.go:262-271, common.go:44-58): every constraint key of the
+            // class present, the pod's required node affinity matches unless the constraint says nodeAffinityPolicy: Ignore,
+            // and for nodeTaintsPolicy: Honor no untolerated NoSchedule / NoExecute taint.  One row per policy pair in use.
+            int row_of[4] = {-1, -1, -1, -1};   // [affinity honoured ? 1 : 0][taints honoured ? 2 : 0]
             if (!p.spread.empty()) {
-                bool any_honor = false;
-                for (auto& sc : p.spread) any_honor = any_honor || sc.taints_honor;
-                row = (int)rows.size(); rows.emplace_back(words, 0ull);
-                if (any_honor) { row_honor = (int)rows.size(); rows.emplace_back(words, 0ull); }
+                for (auto& sc : p.spread) {
+                    const int combo = (sc.affinity_honor ? 1 : 0) | (sc.taints_honor ? 2 : 0);
+                    if (row_of[combo] < 0) { row_of[combo] = (int)rows.size(); rows.emplace_back(words, 0ull); }
+                }
                 for (size_t n = 0; n < NG; ++n) {
                     const Group& g = e->groups[n];
-                    bool ok = node_passes_affinity(p, g);
-                    for (auto& sc : p.spread) ok = ok && g.labels.count(sc.key) != 0;
-                    if (!ok) continue;
-                    rows[(size_t)row][n >> 6] |= 1ull << (n & 63);
-                    if (!any_honor) continue;
+                    bool keys_ok = true;
+                    for (auto& sc : p.spread) keys_ok = keys_ok && g.labels.count(sc.key) != 0;
+                    if (!keys_ok) continue;
+                    const bool aff = node_passes_affinity(p, g);
                     bool tolerated = true;
                     for (auto& tn : g.taints) {
                         if (tn.effect != "NoSchedule" && tn.effect != "NoExecute") continue;
@@ -614,12 +619,17 @@ int32_t casim_enc_finalize(casim_encoder* e) {
                         for (auto& t : p.tolerations) if (tolerates(t, tn, e->opt.enable_taint_comparison_ops != 0)) { tol = true; break; }
                         if (!tol) { tolerated = false; break; }
                     }
-                    if (tolerated) rows[(size_t)row_honor][n >> 6] |= 1ull << (n & 63);
+                    for (int combo = 0; combo < 4; ++combo) {
+                        if (row_of[combo] < 0) continue;
+                        if ((combo & 1) && !aff) continue;
+                        if ((combo & 2) && !tolerated) continue;
+                        rows[(size_t)row_of[combo]][n >> 6] |= 1ull << (n & 63);
+                    }
                 }
             }
             for (auto& sc : p.spread) {
                 if (sc.taints_honor) dr.n_taint_rules++;
-                Rule r{(int)i, key_of(sc.key), 0, sc.max_skew, sc.min_domains, 0, sc.taints_honor ? row_honor : row, &sc};
+                Rule r{(int)i, key_of(sc.key), 0, sc.max_skew, sc.min_domains, 0, row_of[(sc.affinity_honor ? 1 : 0) | (sc.taints_honor ? 2 : 0)], &sc};
                 r.self = (!sc.selector.empty() && selector_matches(sc.selector, p.labels)) ? 1 : 0;   // an empty selector counts nothing
                 rules.push_back(r);
             }

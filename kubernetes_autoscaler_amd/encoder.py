@@ -98,6 +98,10 @@ class Encoder:
                 check(lib.casim_enc_spread_set_taints_policy(h, s, ci, 1))
             elif sc.node_taints_policy != "Ignore":
                 check(lib.casim_enc_pod_mark_unsupported(h, s, b"topologySpreadConstraints: nodeTaintsPolicy"))
+            if sc.node_affinity_policy == "Ignore":
+                check(lib.casim_enc_spread_set_affinity_policy(h, s, ci, 0))
+            elif sc.node_affinity_policy != "Honor":
+                check(lib.casim_enc_pod_mark_unsupported(h, s, b"topologySpreadConstraints: nodeAffinityPolicy"))
         if pod.topology_spread and not pod.spread_constraints:
             check(lib.casim_enc_pod_mark_unsupported(h, s, b"topologySpreadConstraints"))
         if pod.unsupported_reason:

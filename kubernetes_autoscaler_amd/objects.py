@@ -66,7 +66,8 @@ class TopologySpreadConstraint:
     topology_key: str
     min_domains: int = 0                   # 0 = nil (treated as 1)
     match_labels: Dict[str, str] = field(default_factory=dict)
-    node_taints_policy: str = "Ignore"     # "Honor" is outside the encoded subset (the removal ghost's taint would count)
+    node_taints_policy: str = "Ignore"     # "Honor": tainted nodes the pod does not tolerate are no domain members
+    node_affinity_policy: str = "Honor"    # "Ignore": the pod's required node affinity does not gate domain membership
 
 
 @dataclass
@@ -114,7 +115,7 @@ class Pod:
                 tuple((t.topology_key, tuple(sorted(t.match_labels.items())),
                        tuple((r.key, r.operator, tuple(r.values)) for r in t.match_expressions), tuple(t.namespaces))
                       for t in self.anti_affinity),
-                self.topology_spread, tuple((c.max_skew, c.topology_key, c.min_domains, tuple(sorted(c.match_labels.items())), c.node_taints_policy)
+                self.topology_spread, tuple((c.max_skew, c.topology_key, c.min_domains, tuple(sorted(c.match_labels.items())), c.node_taints_policy, c.node_affinity_policy)
                                             for c in self.spread_constraints),
                 self.unsupported_reason, self.has_containers, self.spec_extra)
 

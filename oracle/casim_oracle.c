@@ -86,7 +86,7 @@ typedef struct { int ip, proto, port; } hostport;
 typedef struct { int topology_key; ivec namespaces; reqvec selector; } aff_term;
 /* topologySpreadConstraint  V/.../podtopologyspread/common.go:34-41 (DoNotSchedule constraints only; nodeAffinityPolicy
  * Honor and nodeTaintsPolicy Ignore, the defaults :108-110) */
-typedef struct { int max_skew, topology_key, min_domains; reqvec selector; int selector_set; int taints_honor; } spread_constraint;
+typedef struct { int max_skew, topology_key, min_domains; reqvec selector; int selector_set; int taints_honor; int affinity_ignore; } spread_constraint;
 
 typedef struct {
     int ns;
@@ -284,6 +284,13 @@ int orc_spread_taints_policy_honor(orc* o, int pod, int constraint, int honor) {
     PODCHK(o, pod);
     if (constraint < 0 || constraint >= o->pods.v[pod].spread.n) return -1;
     o->pods.v[pod].spread.v[constraint].taints_honor = honor;
+    return 0;
+}
+/* nodeAffinityPolicy: Ignore (common.go:46-51): the pod's required node affinity / selector does not gate domain membership */
+int orc_spread_affinity_policy_ignore(orc* o, int pod, int constraint, int ignore) {
+    PODCHK(o, pod);
+    if (constraint < 0 || constraint >= o->pods.v[pod].spread.n) return -1;
+    o->pods.v[pod].spread.v[constraint].affinity_ignore = ignore;
     return 0;
 }
 /* one requirement of the constraint's labelSelector (matchLabels pair == In{value}); a constraint without any
@@ -606,10 +613,12 @@ static void pts_prefilter(const orc* o, const podspec* p, pts_state* s) {
         int all = 1;
         for (int c = 0; c < s->n; ++c) { int val; if (!labels_lookup(n->labels.v, n->labels.n, p->spread.v[c].topology_key, &val)) all = 0; }
         if (!all) continue;                                           /* nodeLabelsMatchSpreadConstraints :268 */
-        if (!filter_node_affinity(o, p, n)) continue;                 /* matchNodeInclusionPolicies, Honor */
+        const int aff_ok = filter_node_affinity(o, p, n);
         for (int c = 0; c < s->n; ++c) {
             const spread_constraint* sc = &p->spread.v[c];
-            if (sc->taints_honor && !filter_taints(o, p, n)) continue;  /* matchNodeInclusionPolicies, nodeTaintsPolicy Honor */
+            /* matchNodeInclusionPolicies common.go:44-58: nodeAffinityPolicy Honor (default), nodeTaintsPolicy Ignore (default) */
+            if (!sc->affinity_ignore && !aff_ok) continue;
+            if (sc->taints_honor && !filter_taints(o, p, n)) continue;
             int val = 0; labels_lookup(n->labels.v, n->labels.n, sc->topology_key, &val);
             int64_t count = 0;
             if (sc->selector_set)                                     /* countPodsMatchSelector common.go:143-158 */

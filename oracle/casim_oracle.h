@@ -62,6 +62,7 @@ int orc_pod_spread_constraint(orc* o, int pod, int max_skew, const char* topolog
 int orc_spread_requirement(orc* o, int pod, int constraint, const char* key, const char* op,
                            const char* const* values, int n_values);
 int orc_spread_taints_policy_honor(orc* o, int pod, int constraint, int honor);  /* nodeTaintsPolicy: Honor */
+int orc_spread_affinity_policy_ignore(orc* o, int pod, int constraint, int ignore);  /* nodeAffinityPolicy: Ignore */
 
 /* ---- node objects (a template or a node of the existing cluster) ---------------------- */
 int orc_node(orc* o, const char* name, const int64_t* alloc, int allowed_pods,

@@ -57,6 +57,7 @@ def lib():
             "orc_pod_spread_constraint": (C.c_int, [P, C.c_int, C.c_int, cstr, C.c_int]),
             "orc_spread_requirement": (C.c_int, [P, C.c_int, C.c_int, cstr, cstr, cstrp, C.c_int]),
             "orc_spread_taints_policy_honor": (C.c_int, [P, C.c_int, C.c_int, C.c_int]),
+            "orc_spread_affinity_policy_ignore": (C.c_int, [P, C.c_int, C.c_int, C.c_int]),
             "orc_node": (C.c_int, [P, cstr, i64p, C.c_int, C.c_int64, C.c_int64, C.c_int]),
             "orc_node_fastpath_capacity": (C.c_int, [P, C.c_int, C.c_double, C.c_double]),
             "orc_node_label": (C.c_int, [P, C.c_int, cstr, cstr]),
@@ -186,6 +187,8 @@ class OracleScenario:
                 L.orc_spread_requirement(h, p, c, _b(k), _b("In"), _strs([v]), 1)
             if sc.node_taints_policy == "Honor":
                 L.orc_spread_taints_policy_honor(h, p, c, 1)
+            if sc.node_affinity_policy == "Ignore":
+                L.orc_spread_affinity_policy_ignore(h, p, c, 1)
         self._pod_ids[key] = p
         return p
 

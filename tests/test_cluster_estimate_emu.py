@@ -68,7 +68,8 @@ def test_fuzz_node_taints_policy_honor(seed):
     for pg in w.pegs:
         pod = pg.pods[0]
         pod.tolerations = rng.choice([[], [Toleration("dedicated", "Equal", "x", "")], [Toleration("", "Exists", "", "")]])
-        pod.spread_constraints = [dataclasses.replace(c, node_taints_policy=("Honor" if rng.random() < 0.6 else "Ignore")) for c in pod.spread_constraints]
+        pod.spread_constraints = [dataclasses.replace(c, node_taints_policy=("Honor" if rng.random() < 0.6 else "Ignore"),
+                                                      node_affinity_policy=("Ignore" if rng.random() < 0.4 else "Honor")) for c in pod.spread_constraints]
     sc = scenario_of(w)
     if cluster_estimate_emu(sc)[0] == 1:
         pytest.skip("delegated (hostname anti-affinity next to an unnamed node)")

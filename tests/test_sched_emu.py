@@ -265,7 +265,8 @@ def honor_taints_variant(w, seed):
         k = p.spec_key()
         if k not in plan:
             tol = rng.choice([[], [], [Toleration("dedicated", "Equal", "x", "NoSchedule")], [Toleration("", "Exists", "", "")]])
-            plan[k] = (tol, [dataclasses.replace(c, node_taints_policy=("Honor" if rng.random() < 0.6 else "Ignore")) for c in p.spread_constraints])
+            plan[k] = (tol, [dataclasses.replace(c, node_taints_policy=("Honor" if rng.random() < 0.6 else "Ignore"),
+                                                 node_affinity_policy=("Ignore" if rng.random() < 0.4 else "Honor")) for c in p.spread_constraints])
         p.tolerations, p.spread_constraints = list(plan[k][0]), list(plan[k][1])
     return w
 
@@ -275,3 +276,19 @@ def test_fuzz_node_taints_policy_honor(seed):
     from kubernetes_autoscaler_amd.workloads import fuzz_pending_domains
     w = honor_taints_variant(fuzz_pending_domains(3000 + seed), seed)
     check(case_of(w), w.name)
+
+
+@pytest.mark.parametrize("policy,fits", [("Honor", True), ("Ignore", False)])
+def test_node_affinity_policy_of_a_spread_constraint(policy, fits):
+    """common.go:46-51: with nodeAffinityPolicy: Honor (default) only nodes matching the pod's nodeSelector are domain
+    members — zone z1 does not exist for the pod and z0's two pods are the global minimum; with Ignore z1 is an empty
+    domain and one more pod in z0 would skew by 3."""
+    from kubernetes_autoscaler_amd.objects import TopologySpreadConstraint
+    n0 = NodeInfo(_node("n0", 4000, 8 << 30, 110, {"pool": "a", LABEL_ZONE: "z0"}))
+    n1 = NodeInfo(_node("n1", 4000, 8 << 30, 110, {"pool": "b", LABEL_ZONE: "z1"}))
+    for i in range(2):
+        n0.pods.append(Pod(name=f"run{i}", labels={"app": "x"}, requests={"cpu": 100}))
+    pend = Pod(name="pend", labels={"app": "x"}, requests={"cpu": 100}, node_selector={"pool": "a"}, topology_spread=True,
+               spread_constraints=[TopologySpreadConstraint(1, LABEL_ZONE, 0, {"app": "x"}, "Ignore", policy)])
+    want = check(SchedCase(nodes=[n0, n1], pods=[pend]), f"nodeAffinityPolicy {policy}")
+    assert (want[2] == 1) == fits and (list(want[0]) == [0]) == fits
