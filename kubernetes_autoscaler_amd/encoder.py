@@ -92,7 +92,7 @@ class Encoder:
             ci = lib.casim_enc_pod_add_spread_constraint(h, s, int(sc.max_skew), _b(sc.topology_key), int(sc.min_domains))
             if ci < 0:
                 check(ci, "casim_enc_pod_add_spread_constraint")
-            for k, v in sc.match_labels.items():
+            for k, v in sc.effective_match_labels(pod.labels).items():
                 check(lib.casim_enc_spread_add_requirement(h, s, ci, _b(k), b"In", _strs([v]), 1))
             if sc.node_taints_policy == "Honor":
                 check(lib.casim_enc_spread_set_taints_policy(h, s, ci, 1))

@@ -11,7 +11,7 @@ Names follow the reference so that tests read like the reference's tests:
 Quantities are plain integers: cpu in millicores (Quantity.MilliValue), everything else in base
 units (Quantity.Value)."""
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Tuple
 
 MiB = 1024 * 1024
 GiB = 1024 * MiB
@@ -60,14 +60,28 @@ class PodAffinityTerm:
 
 @dataclass
 class TopologySpreadConstraint:
-    """DoNotSchedule topologySpreadConstraint.  The device path delegates pods that carry one
-    (CASIM_PEG_UNSUPPORTED); the fields exist so that the shim / tests can hand them to the checker."""
+    """DoNotSchedule topologySpreadConstraint (labelSelector in its matchLabels form; `{}` selects nothing to count,
+    common.go:145-148).  Evaluated on the device in per-node mode (TrySchedulePods, removal loop, estimator on the
+    cluster); the template-mode batch delegates PEGs that carry one."""
     max_skew: int
     topology_key: str
     min_domains: int = 0                   # 0 = nil (treated as 1)
     match_labels: Dict[str, str] = field(default_factory=dict)
     node_taints_policy: str = "Ignore"     # "Honor": tainted nodes the pod does not tolerate are no domain members
     node_affinity_policy: str = "Honor"    # "Ignore": the pod's required node affinity does not gate domain membership
+    match_label_keys: Tuple[str, ...] = ()  # matchLabelKeys: the pod's own values of these labels join the selector
+
+    def effective_match_labels(self, pod_labels: Dict[str, str]) -> Dict[str, str]:
+        """filterTopologySpreadConstraints (common.go:96-107): selector AND key == <the incoming pod's value> for every
+        matchLabelKeys entry the pod carries (mergeLabelSetWithSelector :130-143)."""
+        out = dict(self.match_labels)
+        for k in self.match_label_keys:
+            if k in pod_labels:
+                if k in out and out[k] != pod_labels[k]:
+                    out[k] = "\x01unsatisfiable"   # key == a AND key == b: nothing matches (no label value can hold a control character)
+                else:
+                    out[k] = pod_labels[k]
+        return out
 
 
 @dataclass
@@ -115,7 +129,7 @@ class Pod:
                 tuple((t.topology_key, tuple(sorted(t.match_labels.items())),
                        tuple((r.key, r.operator, tuple(r.values)) for r in t.match_expressions), tuple(t.namespaces))
                       for t in self.anti_affinity),
-                self.topology_spread, tuple((c.max_skew, c.topology_key, c.min_domains, tuple(sorted(c.match_labels.items())), c.node_taints_policy, c.node_affinity_policy)
+                self.topology_spread, tuple((c.max_skew, c.topology_key, c.min_domains, tuple(sorted(c.match_labels.items())), c.node_taints_policy, c.node_affinity_policy, tuple(c.match_label_keys))
                                             for c in self.spread_constraints),
                 self.unsupported_reason, self.has_containers, self.spec_extra)
 

@@ -183,7 +183,7 @@ class OracleScenario:
             L.orc_pod_has_topology_spread(h, p, 1)
         for sc in pod.spread_constraints:
             c = L.orc_pod_spread_constraint(h, p, int(sc.max_skew), _b(sc.topology_key), int(sc.min_domains))
-            for k, v in sc.match_labels.items():
+            for k, v in sc.effective_match_labels(pod.labels).items():
                 L.orc_spread_requirement(h, p, c, _b(k), _b("In"), _strs([v]), 1)
             if sc.node_taints_policy == "Honor":
                 L.orc_spread_taints_policy_honor(h, p, c, 1)

@@ -292,3 +292,23 @@ def test_node_affinity_policy_of_a_spread_constraint(policy, fits):
                spread_constraints=[TopologySpreadConstraint(1, LABEL_ZONE, 0, {"app": "x"}, "Ignore", policy)])
     want = check(SchedCase(nodes=[n0, n1], pods=[pend]), f"nodeAffinityPolicy {policy}")
     assert (want[2] == 1) == fits and (list(want[0]) == [0]) == fits
+
+
+def test_match_label_keys_of_a_spread_constraint():
+    """common.go:96-107: matchLabelKeys adds `key == <the incoming pod's value>` to the selector — the pods of another
+    revision (pod-template-hash) do not count.  Two zones; zone z0 holds two pods of revision A, z1 none; a pod of
+    revision B spreads only against revision-B pods: both zones are at 0 and it lands on the first node; without the keys
+    the two revision-A pods make z0 too heavy and it goes to z1."""
+    from kubernetes_autoscaler_amd.objects import TopologySpreadConstraint
+    def cluster():
+        n0 = NodeInfo(_node("n0", 4000, 8 << 30, 110, {LABEL_ZONE: "z0"}))
+        n1 = NodeInfo(_node("n1", 4000, 8 << 30, 110, {LABEL_ZONE: "z1"}))
+        for i in range(2):
+            n0.pods.append(Pod(name=f"run{i}", labels={"app": "x", "pod-template-hash": "A"}, requests={"cpu": 100}))
+        return [n0, n1]
+    def pend(keys):
+        return Pod(name="pend", labels={"app": "x", "pod-template-hash": "B"}, requests={"cpu": 100}, topology_spread=True,
+                   spread_constraints=[TopologySpreadConstraint(1, LABEL_ZONE, 0, {"app": "x"}, match_label_keys=keys)])
+    with_keys = check(SchedCase(nodes=cluster(), pods=[pend(("pod-template-hash",))], last_index=1), "matchLabelKeys")
+    without = check(SchedCase(nodes=cluster(), pods=[pend(())], last_index=1), "no matchLabelKeys")
+    assert list(with_keys[0]) == [0] and list(without[0]) == [1]
