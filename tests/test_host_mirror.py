@@ -168,3 +168,31 @@ def test_bench_multi_process_cpu_leg():
     out = bench.cpu_baseline_all_cores(8, 5, 16, budget_s=0.3, max_procs=2, sims_per_proc=2)
     assert "error" not in out, out
     assert out["cores"] in (1, 2) and out["sims_per_s"] > 0 and out["unit"] == "checks/s"
+
+
+def test_hints_drop_old_property():
+    """hints_test.go TestDropOld (testing/quick property): after DropOld the keys set since the previous DropOld survive
+    exactly one more generation."""
+    import random
+    from kubernetes_autoscaler_amd.scheduling import Hints
+    rng = random.Random(5)
+
+    def incorrect(s, want, all_keys):
+        return any(s.get(k) != k for k in want) or any(s.get(k) is not None for k in set(all_keys) - set(want))
+
+    for _ in range(200):
+        initial = [f"k{rng.randrange(40)}" for _ in range(rng.randrange(8))]
+        final = [f"k{rng.randrange(40)}" for _ in range(rng.randrange(8))]
+        all_keys = initial + final
+        s = Hints()
+        assert not incorrect(s, [], all_keys)
+        for k in initial:
+            s.set(k, k)
+        assert not incorrect(s, initial, all_keys)
+        s.drop_old()
+        assert not incorrect(s, initial, all_keys)
+        for k in final:
+            s.set(k, k)
+        assert not incorrect(s, all_keys, all_keys)
+        s.drop_old()
+        assert not incorrect(s, final, all_keys)
