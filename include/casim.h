@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CASIM_ABI_VERSION 1
+#define CASIM_ABI_VERSION 2   /* 2: casim_removal_candidates.cand_atomic, casim_domain_rules.n_taint_policy_rules */
 
 /* Resource lanes.  Lane 0 = cpu in millicores (Quantity.MilliValue), lane 1 = memory bytes,
  * lane 2 = ephemeral-storage bytes, lanes 3.. = scalar / extended resources (Quantity.Value),
