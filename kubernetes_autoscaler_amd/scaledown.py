@@ -207,8 +207,9 @@ class Planner:
         """unneededNodesLimit (planner.go:385-400): previously unneeded + 2 N, capped by N * (U / I) + N loops' worth."""
         n = max_scale_down_parallelism
         limit = previously_unneeded + 2 * n
-        u = max(int(scale_down_unneeded_time * 1e9), int(min_update_interval * 1e9))   # time.Duration arithmetic (ns)
-        upper = n * int(u // int(min_update_interval * 1e9)) + n
+        interval = max(1, round(min_update_interval * 1e9))                 # time.Duration arithmetic (integer ns)
+        u = max(round(scale_down_unneeded_time * 1e9), interval)
+        upper = n * (u // interval) + n
         return min(upper, limit)
 
     def update_cluster_state(self, pod_destinations: Sequence[str], eligible_candidates: Sequence[str],
