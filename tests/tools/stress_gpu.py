@@ -35,11 +35,21 @@ for seed in range(first, first + count):
         w = gen(seed)
         sc = SchedCase(nodes=w.nodes, pods=w.pods, hints=w.hints, acceptable=w.acceptable, break_on_failure=w.break_on_failure, last_index=w.last_index)
         assert_sched_matches(sched_gpu(sc, ctx), sched_oracle(sc), w.name); bump(gen.__name__)
+    # spread constraints with non-default node-inclusion policies next to tainted nodes (eligibility rows of the encoder)
+    from test_sched_emu import honor_taints_variant
+    w = honor_taints_variant(W.fuzz_pending_domains(seed + 7_000_000), seed)
+    sc = SchedCase(nodes=w.nodes, pods=w.pods, hints=w.hints, acceptable=w.acceptable, break_on_failure=w.break_on_failure, last_index=w.last_index)
+    assert_sched_matches(sched_gpu(sc, ctx), sched_oracle(sc), w.name); bump("fuzz_pending_policies")
     for gen in (W.fuzz_removals, W.fuzz_removals_domains):
         w = gen(seed)
         rc = RemovalCase(nodes=w.nodes, candidates=w.candidates, destination=w.destination, hints=w.hints, persist=w.persist,
                          max_removable=w.max_removable, last_index=w.last_index)
         assert_removal_matches(removal_device(rc, ctx), removal_oracle(rc), w.name); bump(gen.__name__)
+        if rc.max_removable > 0:   # candidates of atomically scaled groups do not count toward the limit
+            import random
+            rng = random.Random(seed)
+            rc.atomic = [1 if rng.random() < 0.4 else 0 for _ in rc.candidates]
+            assert_removal_matches(removal_device(rc, ctx), removal_oracle(rc), w.name + " atomic"); bump(gen.__name__ + "_atomic")
     w = W.fuzz_estimate_domains(seed)
     sc = scen(w)
     got = cluster_estimate_gpu(sc, ctx)
