@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""One-off randomized stress on the MI355X with seeds the test suites do not use: every device path against the oracle.
+"""One-off randomized stress with seeds the test suites do not use: every device path against the oracle — on the MI355X,
+or (CASIM_STRESS_EMU=1) the same product kernels under the wave emulator on the CPU.
 Usage: stress_gpu.py [first_seed] [count]"""
 import os
 import sys
@@ -10,13 +11,17 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import kubernetes_autoscaler_amd as kaa  # noqa: E402
 from kubernetes_autoscaler_amd import workloads as W  # noqa: E402
-from harness import (GroupSpec, RemovalCase, Scenario, SchedCase, assert_cluster_estimate_matches, assert_matches_oracle,  # noqa: E402
-                     assert_removal_matches, assert_sched_matches, cluster_estimate_gpu, encode, removal_device, removal_oracle,
-                     run_gpu, run_oracle, sched_gpu, sched_oracle)
+from harness import (EmuContext, GroupSpec, RemovalCase, Scenario, SchedCase, assert_cluster_estimate_matches, assert_matches_oracle,  # noqa: E402
+                     assert_removal_matches, assert_sched_matches, cluster_estimate_emu, cluster_estimate_gpu, encode, removal_device,
+                     removal_oracle, run_emu, run_gpu, run_oracle, sched_gpu, sched_oracle)
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 500
-ctx = kaa.Context(0)
+EMU = os.environ.get("CASIM_STRESS_EMU") == "1"
+ctx = EmuContext(0) if EMU else kaa.Context(0)
+if EMU:   # same call shapes as the GPU helpers
+    cluster_estimate_gpu = lambda sc, _ctx: cluster_estimate_emu(sc)          # noqa: E731
+    run_gpu = lambda enc, _ctx, fastpath=False: run_emu(enc, fastpath=fastpath)  # noqa: E731
 t0 = time.time()
 stats = {}
 
@@ -63,5 +68,6 @@ for seed in range(first, first + count):
         sc = scen(w, fastpath=fast)
         res, _ = run_gpu(encode(sc), ctx, fastpath=fast)
         assert_matches_oracle(res, run_oracle(sc), w.name); bump(f"fuzz_packer_fast{int(fast)}")
-print("stress OK", stats, f"{time.time() - t0:.0f} s")
-ctx.close()
+print("stress OK", "(emulator)" if EMU else "(MI355X)", stats, f"{time.time() - t0:.0f} s")
+if not EMU:
+    ctx.close()
