@@ -36,6 +36,8 @@ def scen(w, **kw):
 
 
 for seed in range(first, first + count):
+    if (seed - first) % 1000 == 0 and seed > first:
+        print(f"... {seed - first} seeds OK, {time.time() - t0:.0f} s", flush=True)
     for gen in (W.fuzz_pending, W.fuzz_pending_domains):
         w = gen(seed)
         sc = SchedCase(nodes=w.nodes, pods=w.pods, hints=w.hints, acceptable=w.acceptable, break_on_failure=w.break_on_failure, last_index=w.last_index)
