@@ -486,6 +486,18 @@ int32_t casim_enc_pod_add_node_selector(casim_encoder* e, int32_t pod, const cha
  * DoesNotExist/Gt/Lt; values = n_values C strings. */
 int32_t casim_enc_pod_add_node_affinity_req(casim_encoder* e, int32_t pod, const char* key,
                                             const char* op, const char* const* values, int32_t n_values);
+/* nodeSelectorTerms of requiredDuringSchedulingIgnoredDuringExecution, ORed
+ * (LazyErrorNodeSelector.Match, V/component-helpers/scheduling/corev1/nodeaffinity/nodeaffinity.go:85-107): the first call
+ * opens a term and returns its index (>= 0), the second adds one of its matchExpressions (is_field 0) or matchFields
+ * (is_field 1: key metadata.name, op In / NotIn, one value, :260-291).  The encoder folds the whole list into one
+ * per-node bit, so the kernels see it as one more label requirement.  Exclusive with casim_enc_pod_add_node_affinity_req
+ * on the same pod (CASIM_ERR_INVALID).  Template mode (an Estimate): a term that reads metadata.name or
+ * kubernetes.io/hostname marks the pod CASIM_PEG_UNSUPPORTED, because simulated nodes get fresh names
+ * (CA/simulator/node_info_utils.go:93-137). */
+int32_t casim_enc_pod_add_node_affinity_term(casim_encoder* e, int32_t pod);
+int32_t casim_enc_node_term_add_requirement(casim_encoder* e, int32_t pod, int32_t term, int32_t is_field,
+                                            const char* key, const char* op, const char* const* values,
+                                            int32_t n_values);
 /* protocol "" = TCP, ip "" = 0.0.0.0  (V/kube-scheduler/framework/types.go:633-640 sanitize) */
 int32_t casim_enc_pod_add_host_port(casim_encoder* e, int32_t pod, const char* ip, const char* protocol,
                                     int32_t port);
@@ -513,7 +525,7 @@ int32_t casim_enc_spread_set_taints_policy(casim_encoder* enc, int32_t pod, int3
 int32_t casim_enc_spread_set_affinity_policy(casim_encoder* enc, int32_t pod, int32_t constraint, int32_t honor);
 int32_t casim_enc_pod_set_fastpath_requests(casim_encoder* e, int32_t pod, double cpu, double mem);
 /* Mark the spec as carrying a predicate outside the encoded subset (required pod affinity,
- * topology spread, volumes, DRA claims, multi-term node affinity, namespaceSelector...). */
+ * topology spread, volumes, DRA claims, namespaceSelector...). */
 int32_t casim_enc_pod_mark_unsupported(casim_encoder* e, int32_t pod, const char* why);
 /* A PodEquivalenceGroup: `count` pods sharing pod spec `pod`.  Returns the PEG id. */
 int32_t casim_enc_add_peg(casim_encoder* e, int32_t pod_spec, int32_t count);

@@ -26,12 +26,15 @@ namespace {
 const char* kHostname = "kubernetes.io/hostname";
 const char* kUnschedulableTaint = "node.kubernetes.io/unschedulable";
 
-enum ReqOp { kIn, kNotIn, kExists, kDoesNotExist, kGt, kLt, kBadOp };
+enum ReqOp { kIn, kNotIn, kExists, kDoesNotExist, kGt, kLt, kBadOp, kNodeTerms };
 enum TolOp { kTolEqual, kTolExists, kTolLt, kTolGt, kTolBad };
 
 std::string S(const char* s) { return s ? std::string(s) : std::string(); }
 
-struct Requirement { std::string key; ReqOp op; std::vector<std::string> values; };
+struct NodeTerm;
+// op == kNodeTerms: a whole nodeSelectorTerms list (ORed) folded into ONE dictionary entry; key / values unused
+struct Requirement { std::string key; ReqOp op; std::vector<std::string> values; std::vector<NodeTerm> terms; };
+struct NodeTerm { std::vector<Requirement> exprs, fields; };   // v1.NodeSelectorTerm: matchExpressions AND matchFields
 struct Toleration { std::string key; TolOp op; std::string value, effect; };
 struct Taint { std::string key, value, effect; bool operator<(const Taint& o) const { return std::tie(key, value, effect) < std::tie(o.key, o.value, o.effect); } };
 struct Port { std::string ip, proto; int32_t port; bool operator<(const Port& o) const { return std::tie(ip, proto, port) < std::tie(o.ip, o.proto, o.port); } };
@@ -46,7 +49,9 @@ struct PodSpec {
     Labels labels;
     std::vector<Toleration> tolerations;
     std::vector<std::pair<std::string, std::string>> node_selector;
-    std::vector<Requirement> node_affinity;
+    std::vector<Requirement> node_affinity;   // ONE required term (casim_enc_pod_add_node_affinity_req)
+    std::vector<NodeTerm> node_terms;         // nodeSelectorTerms, ORed (casim_enc_pod_add_node_affinity_term); exclusive with the above
+    bool has_node_terms = false;
     std::vector<Port> ports;
     std::vector<Term> anti;
     double fp_cpu = 0, fp_mem = 0;
@@ -121,6 +126,39 @@ bool selector_matches(const std::vector<Requirement>& sel, const Labels& ls) {
     for (auto& r : sel) if (!requirement_matches(r, ls)) return false;
     return true;
 }
+// labels.NewRequirement rules 1, 2, 4, 5 (V/apimachinery/pkg/labels/selector.go:183-215); a requirement that does not parse
+// is a parse error of its whole term (nodeaffinity.go:210-246)
+bool requirement_parses(const Requirement& r) {
+    int64_t v;
+    switch (r.op) {
+    case kIn: case kNotIn: return !r.values.empty();
+    case kExists: case kDoesNotExist: return r.values.empty();
+    case kGt: case kLt: return r.values.size() == 1 && parse_int64(r.values[0], &v);
+    default: return false;
+    }
+}
+// LazyErrorNodeSelector.Match (nodeaffinity.go:85-107) over nodeSelectorTerm.match (:187-198): terms ORed, empty terms dropped
+// (:60-64), terms with a parse error never match, matchFields (In / NotIn with one value, :260-291) see metadata.name only and
+// are skipped for a node without a name.
+bool node_terms_match(const std::vector<NodeTerm>& terms, const Labels& ls, const std::string& node_name) {
+    for (auto& t : terms) {
+        if (t.exprs.empty() && t.fields.empty()) continue;
+        bool ok = true;
+        for (auto& r : t.exprs) ok = ok && requirement_parses(r);
+        for (auto& r : t.fields) ok = ok && (r.op == kIn || r.op == kNotIn) && r.values.size() == 1;
+        if (!ok) continue;
+        if (!t.exprs.empty() && !selector_matches(t.exprs, ls)) continue;
+        if (!t.fields.empty() && !node_name.empty()) {
+            for (auto& r : t.fields) {
+                const std::string have = r.key == "metadata.name" ? node_name : std::string();
+                ok = ok && (r.op == kIn ? have == r.values[0] : have != r.values[0]);
+            }
+            if (!ok) continue;
+        }
+        return true;
+    }
+    return false;
+}
 bool term_matches(const Term& t, const PodSpec& target) {
     bool ns_ok = false;
     for (auto& n : t.namespaces) if (n == target.ns) { ns_ok = true; break; }
@@ -155,6 +193,12 @@ bool ports_conflict(const Port& want, const Port& used) {  // CheckConflict(want
 std::string req_signature(const Requirement& r) {
     std::string s = std::to_string((int)r.op) + "\x1f" + r.key;
     for (auto& v : r.values) { s += "\x1f"; s += v; }
+    for (auto& t : r.terms) {
+        s += "\x1d";
+        for (auto& x : t.exprs) { s += "\x1e"; s += req_signature(x); }
+        s += "\x1c";
+        for (auto& x : t.fields) { s += "\x1e"; s += req_signature(x); }
+    }
     return s;
 }
 
@@ -273,7 +317,23 @@ static Requirement make_req(const char* key, const char* op, const char* const* 
 int32_t casim_enc_pod_add_node_affinity_req(casim_encoder* e, int32_t pod, const char* key, const char* op, const char* const* values, int32_t n_values) {
     POD_CHECK(e, pod);
     if (n_values < 0 || (n_values > 0 && !values)) return CASIM_ERR_INVALID;
+    if (e->specs[pod].has_node_terms) return CASIM_ERR_INVALID;   // one NodeSelector per pod: either API, not both
     e->specs[pod].node_affinity.push_back(make_req(key, op, values, n_values)); return CASIM_OK;
+}
+int32_t casim_enc_pod_add_node_affinity_term(casim_encoder* e, int32_t pod) {
+    POD_CHECK(e, pod);
+    if (!e->specs[pod].node_affinity.empty()) return CASIM_ERR_INVALID;
+    e->specs[pod].node_terms.emplace_back();
+    e->specs[pod].has_node_terms = true;
+    return (int32_t)e->specs[pod].node_terms.size() - 1;
+}
+int32_t casim_enc_node_term_add_requirement(casim_encoder* e, int32_t pod, int32_t term, int32_t is_field, const char* key, const char* op,
+                                            const char* const* values, int32_t n_values) {
+    POD_CHECK(e, pod);
+    if (term < 0 || (size_t)term >= e->specs[pod].node_terms.size()) return CASIM_ERR_INVALID;
+    if (n_values < 0 || (n_values > 0 && !values)) return CASIM_ERR_INVALID;
+    NodeTerm& t = e->specs[pod].node_terms[(size_t)term];
+    (is_field ? t.fields : t.exprs).push_back(make_req(key, op, values, n_values)); return CASIM_OK;
 }
 int32_t casim_enc_pod_add_host_port(casim_encoder* e, int32_t pod, const char* ip, const char* protocol, int32_t port) {
     POD_CHECK(e, pod); e->specs[pod].ports.push_back(Port{S(ip), S(protocol), port}); return CASIM_OK;
@@ -388,6 +448,15 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         PodSpec& p = e->specs[s];
         std::vector<Requirement> all = p.node_affinity;
         for (auto& kv : p.node_selector) { Requirement r; r.key = kv.first; r.op = kIn; r.values = {kv.second}; all.push_back(r); }
+        if (p.has_node_terms) {
+            // the ORed term list is ONE dictionary entry: a node's bit = LazyErrorNodeSelector.Match of that node, evaluated
+            // below with the node's labels and name.  Template mode: the nodes of an estimate get fresh names and hostname
+            // labels (node_info_utils.go:93-137), so a term reading either is not a template property.
+            bool per_node = false;
+            for (auto& t : p.node_terms) { if (!t.fields.empty()) per_node = true; for (auto& x : t.exprs) if (x.key == kHostname) per_node = true; }
+            if (per_node && !e->opt.explicit_self_exclusion) { p.unsupported = true; p.why = "node affinity term on metadata.name / kubernetes.io/hostname"; }
+            else { Requirement r; r.op = kNodeTerms; r.terms = p.node_terms; all.push_back(r); }
+        }
         for (auto& r : all) {
             // every simulated node gets its own hostname label (node_info_utils.go:130): not a template property
             // (per-node consumers pass real nodes: there the label is an ordinary one)
@@ -579,6 +648,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         auto key_of = [&](const std::string& k) { auto it = key_id.find(k); if (it != key_id.end()) return it->second; key_id[k] = (int)keys.size(); keys.push_back(k); return (int)keys.size() - 1; };
         auto node_passes_affinity = [&](const PodSpec& p, const Group& g) {   // RequiredNodeAffinity.Match (nodeSelector + required term)
             for (auto& kv : p.node_selector) { auto it = g.labels.find(kv.first); if (it == g.labels.end() || it->second != kv.second) return false; }
+            if (p.has_node_terms && !node_terms_match(p.node_terms, g.labels, g.name)) return false;
             return selector_matches(p.node_affinity, g.labels);
         };
         auto zone_conflict = [&](const PodSpec& a, const PodSpec& b, const std::string& k) {   // either direction, through key k
@@ -766,7 +836,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         e->cap_cpu[gi] = g.fp_cap_cpu; e->cap_mem[gi] = g.fp_cap_mem;
         e->waste_cpu[gi] = g.cap_cpu; e->waste_mem[gi] = g.cap_mem;
         for (auto& t : g.taints) { auto it = taint_id.find(t); if (it != taint_id.end()) set_bit(e->taint, gi, Wt, it->second); }
-        for (size_t l = 0; l < lreqs.size(); ++l) if (requirement_matches(lreqs[l], g.labels)) set_bit(e->label, gi, Wl, (int)l);
+        for (size_t l = 0; l < lreqs.size(); ++l) if (lreqs[l].op == kNodeTerms ? node_terms_match(lreqs[l].terms, g.labels, g.name) : requirement_matches(lreqs[l], g.labels)) set_bit(e->label, gi, Wl, (int)l);
         for (int32_t s : g.preloaded) {
             const PodSpec& p = e->specs[(size_t)s];
             for (int r = 0; r < R; ++r) e->init_req[gi * (size_t)R + (size_t)r] += p.req[r];

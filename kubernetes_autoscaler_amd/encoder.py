@@ -7,7 +7,7 @@ from typing import Dict, List, Optional, Sequence
 
 from . import _abi
 from ._ffi import check, lib
-from .objects import NodeInfo, Pod, PodEquivalenceGroup, RES_CPU, RES_EPHEMERAL, RES_MEMORY
+from .objects import NodeInfo, NodeSelectorTerm, Pod, PodEquivalenceGroup, RES_CPU, RES_EPHEMERAL, RES_MEMORY
 
 DEFAULT_LANES = (RES_CPU, RES_MEMORY)
 
@@ -78,6 +78,13 @@ class Encoder:
             check(lib.casim_enc_pod_add_node_selector(h, s, _b(k), _b(v)))
         for r in pod.node_affinity:
             check(lib.casim_enc_pod_add_node_affinity_req(h, s, _b(r.key), _b(r.operator), _strs(r.values), len(r.values)))
+        for term in (pod.node_affinity_terms or [NodeSelectorTerm()] if pod.node_affinity_terms is not None else []):
+            t = lib.casim_enc_pod_add_node_affinity_term(h, s)
+            if t < 0:
+                check(t, "casim_enc_pod_add_node_affinity_term")
+            for is_field, reqs in ((0, term.match_expressions), (1, term.match_fields)):
+                for r in reqs:
+                    check(lib.casim_enc_node_term_add_requirement(h, s, t, is_field, _b(r.key), _b(r.operator), _strs(r.values), len(r.values)))
         for p in pod.host_ports:
             check(lib.casim_enc_pod_add_host_port(h, s, _b(p.host_ip), _b(p.protocol), int(p.host_port)))
         for term in pod.anti_affinity:

@@ -92,6 +92,13 @@ class ContainerPort:
 
 
 @dataclass
+class NodeSelectorTerm:
+    """v1.NodeSelectorTerm: matchExpressions (node labels) AND matchFields (metadata.name, In / NotIn with one value)."""
+    match_expressions: List[Requirement] = field(default_factory=list)
+    match_fields: List[Requirement] = field(default_factory=list)
+
+
+@dataclass
 class Pod:
     name: str
     namespace: str = "default"
@@ -101,6 +108,8 @@ class Pod:
     tolerations: List[Toleration] = field(default_factory=list)
     node_selector: Dict[str, str] = field(default_factory=dict)
     node_affinity: List[Requirement] = field(default_factory=list)   # ONE required term, ANDed
+    # requiredDuringSchedulingIgnoredDuringExecution.nodeSelectorTerms, ORed (None = not set); exclusive with node_affinity
+    node_affinity_terms: Optional[List[NodeSelectorTerm]] = None
     host_ports: List[ContainerPort] = field(default_factory=list)
     anti_affinity: List[PodAffinityTerm] = field(default_factory=list)
     # first container's requests as AsApproximateFloat64 for the fastpath chooser; None = derive
@@ -125,6 +134,9 @@ class Pod:
                 tuple((t.key, t.operator, t.value, t.effect) for t in self.tolerations),
                 tuple(sorted(self.node_selector.items())),
                 tuple((r.key, r.operator, tuple(r.values)) for r in self.node_affinity),
+                None if self.node_affinity_terms is None else tuple(
+                    (tuple((r.key, r.operator, tuple(r.values)) for r in t.match_expressions),
+                     tuple((r.key, r.operator, tuple(r.values)) for r in t.match_fields)) for t in self.node_affinity_terms),
                 tuple((h.host_port, h.host_ip, h.protocol) for h in self.host_ports),
                 tuple((t.topology_key, tuple(sorted(t.match_labels.items())),
                        tuple((r.key, r.operator, tuple(r.values)) for r in t.match_expressions), tuple(t.namespaces))
@@ -211,6 +223,13 @@ def with_max_skew(max_skew, key, min_domains):
         if max_skew > 0:
             pod.topology_spread = True
             pod.spread_constraints = [TopologySpreadConstraint(max_skew, key, min_domains, {"app": "estimatee"})]
+    return f
+
+
+def with_node_names_affinity(*node_names):
+    """WithNodeNamesAffinity (CA/utils/test/test_utils.go:200-220): ONE term, ONE matchFields requirement
+    metadata.name In node_names."""
+    def f(pod): pod.node_affinity_terms = [NodeSelectorTerm(match_fields=[Requirement("metadata.name", "In", list(node_names))])]
     return f
 
 

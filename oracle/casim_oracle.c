@@ -83,6 +83,8 @@ typedef struct { int key, op, value, effect; } toleration;
 typedef struct { int key, op; ivec values; } requirement;
 typedef VEC(requirement) reqvec;
 typedef struct { int ip, proto, port; } hostport;
+/* v1.NodeSelectorTerm: matchExpressions (node labels) AND matchFields (metadata.name) */
+typedef struct { reqvec exprs, fields; } node_term;
 typedef struct { int topology_key; ivec namespaces; reqvec selector; } aff_term;
 /* topologySpreadConstraint  V/.../podtopologyspread/common.go:34-41 (DoNotSchedule constraints only; nodeAffinityPolicy
  * Honor and nodeTaintsPolicy Ignore, the defaults :108-110) */
@@ -96,6 +98,8 @@ typedef struct {
     VEC(kv) node_selector;
     reqvec node_affinity; /* single required term, ANDed requirements */
     int has_node_affinity;
+    VEC(node_term) node_terms; /* nodeSelectorTerms, ORed (set through orc_pod_node_affinity_term); excludes node_affinity */
+    int has_node_terms;
     VEC(hostport) ports;
     VEC(aff_term) anti_terms;
     double fp_cpu, fp_mem;
@@ -170,6 +174,8 @@ void orc_free(orc* o) {
         podspec* p = &o->pods.v[i];
         VEC_FREE(p->labels); VEC_FREE(p->tolerations); VEC_FREE(p->node_selector);
         free_reqvec(&p->node_affinity); VEC_FREE(p->ports);
+        for (int t = 0; t < p->node_terms.n; ++t) { free_reqvec(&p->node_terms.v[t].exprs); free_reqvec(&p->node_terms.v[t].fields); }
+        VEC_FREE(p->node_terms);
         for (int t = 0; t < p->anti_terms.n; ++t) { VEC_FREE(p->anti_terms.v[t].namespaces); free_reqvec(&p->anti_terms.v[t].selector); }
         VEC_FREE(p->anti_terms);
         for (int c = 0; c < p->spread.n; ++c) free_reqvec(&p->spread.v[c].selector);
@@ -239,9 +245,27 @@ static requirement make_req(orc* o, const char* key, const char* op, const char*
 }
 int orc_pod_node_affinity_req(orc* o, int pod, const char* key, const char* op, const char* const* values, int n) {
     PODCHK(o, pod);
+    if (o->pods.v[pod].has_node_terms) return -1;
     requirement r = make_req(o, key, op, values, n);
     VEC_PUSH(o->pods.v[pod].node_affinity, r);
     o->pods.v[pod].has_node_affinity = 1; return 0;
+}
+/* nodeAffinity.requiredDuringSchedulingIgnoredDuringExecution.nodeSelectorTerms[]: opens a new (empty) term */
+int orc_pod_node_affinity_term(orc* o, int pod) {
+    PODCHK(o, pod);
+    if (o->pods.v[pod].has_node_affinity) return -1; /* one NodeSelector per pod: either API, not both */
+    node_term t; memset(&t, 0, sizeof t);
+    VEC_PUSH(o->pods.v[pod].node_terms, t);
+    o->pods.v[pod].has_node_terms = 1;
+    return o->pods.v[pod].node_terms.n - 1;
+}
+int orc_pod_node_term_req(orc* o, int pod, int term, int is_field, const char* key, const char* op, const char* const* values, int n) {
+    PODCHK(o, pod);
+    if (term < 0 || term >= o->pods.v[pod].node_terms.n) return -1;
+    requirement r = make_req(o, key, op, values, n);
+    if (is_field) VEC_PUSH(o->pods.v[pod].node_terms.v[term].fields, r);
+    else VEC_PUSH(o->pods.v[pod].node_terms.v[term].exprs, r);
+    return 0;
 }
 int orc_pod_host_port(orc* o, int pod, const char* ip, const char* protocol, int port) {
     PODCHK(o, pod);
@@ -485,6 +509,44 @@ static int filter_unschedulable(const orc* o, const podspec* p, const node* n) {
     for (int j = 0; j < p->tolerations.n; ++j) if (tolerates_taint(o, &p->tolerations.v[j], &tn)) return 1;
     return 0;
 }
+/* labels.NewRequirement  V/apimachinery/pkg/labels/selector.go:183-215, rules 1, 2, 4, 5 (key / value syntax is what the
+ * API server admitted); nodeSelectorRequirementsAsSelector nodeaffinity.go:210-246: one bad requirement is a parse error of
+ * the whole term */
+static int requirement_parses(const orc* o, const requirement* r) {
+    int64_t v;
+    switch (r->op) {
+    case OP_IN: case OP_NOTIN: return r->values.n > 0;
+    case OP_EXISTS: case OP_DOESNOTEXIST: return r->values.n == 0;
+    case OP_GT: case OP_LT: return r->values.n == 1 && parse_int64(o->st.s[r->values.v[0]], &v);
+    default: return 0;
+    }
+}
+/* nodeSelectorRequirementsAsFieldSelector nodeaffinity.go:260-291: In / NotIn with exactly one value, ANDed;
+ * fields.Set.Get of a missing key is "" and extractNodeFields :155-161 only knows metadata.name */
+static int field_requirement_parses(const requirement* r) { return (r->op == OP_IN || r->op == OP_NOTIN) && r->values.n == 1; }
+static int field_requirement_matches(const orc* o, const requirement* r, const node* n) {
+    const int have = !strcmp(o->st.s[r->key], "metadata.name") ? n->name : o->id_empty;
+    return r->op == OP_IN ? have == r->values.v[0] : have != r->values.v[0];
+}
+/* LazyErrorNodeSelector.Match nodeaffinity.go:85-107 + nodeSelectorTerm.match :187-198: terms ORed, an empty term is dropped
+ * (:60-64), a term with a parse error never matches, matchFields only looked at when the node has a name */
+static int node_selector_terms_match(const orc* o, const podspec* p, const node* n) {
+    for (int t = 0; t < p->node_terms.n; ++t) {
+        const node_term* nt = &p->node_terms.v[t];
+        if (nt->exprs.n == 0 && nt->fields.n == 0) continue;
+        int ok = 1;
+        for (int i = 0; i < nt->exprs.n && ok; ++i) ok = requirement_parses(o, &nt->exprs.v[i]);
+        for (int i = 0; i < nt->fields.n && ok; ++i) ok = field_requirement_parses(&nt->fields.v[i]);
+        if (!ok) continue;
+        if (nt->exprs.n && !selector_matches(o, &nt->exprs, n->labels.v, n->labels.n)) continue;
+        if (nt->fields.n && n->name != o->id_empty) {
+            for (int i = 0; i < nt->fields.n && ok; ++i) ok = field_requirement_matches(o, &nt->fields.v[i], n);
+            if (!ok) continue;
+        }
+        return 1;
+    }
+    return 0;
+}
 /* NodeAffinity.Filter  V/.../nodeaffinity/node_affinity.go:218-240;  RequiredNodeAffinity.Match
  * V/component-helpers/scheduling/corev1/nodeaffinity/nodeaffinity.go:323-333 */
 static int filter_node_affinity(const orc* o, const podspec* p, const node* n) {
@@ -494,6 +556,7 @@ static int filter_node_affinity(const orc* o, const podspec* p, const node* n) {
         if (val != p->node_selector.v[i].value) return 0;
     }
     if (p->has_node_affinity && !selector_matches(o, &p->node_affinity, n->labels.v, n->labels.n)) return 0;
+    if (p->has_node_terms) return node_selector_terms_match(o, p, n);
     return 1;
 }
 /* HostPortInfo.CheckConflict  V/kube-scheduler/framework/types.go:602-631 */
@@ -648,6 +711,38 @@ static int filter_pts(const orc* o, const podspec* p, const node* n, const pts_s
     return 0;
 }
 
+/* NodeAffinity.PreFilter  V/.../nodeaffinity/node_affinity.go:172-210: when EVERY term carries a matchFields requirement
+ * {metadata.name In names}, only the union (over terms) of the intersections (within a term) of those name sets stays
+ * eligible.  0 = no restriction or the node is in the set, 1 = "PreFilter filtered the Node out"
+ * (CA .../predicate/plugin_runner.go:163-166 and :99-103), 2 = the set is empty: "pod affinity terms conflict" (:203).
+ * Same outcome as the Filter below (a node outside the set fails matchFields in every term); it only decides which
+ * reason the caller sees. */
+static int node_affinity_prefilter(const orc* o, const podspec* p, const node* n) {
+    if (!p->has_node_terms || p->node_terms.n == 0) return 0;
+    int any_name = 0, node_in = 0;
+    for (int t = 0; t < p->node_terms.n; ++t) {
+        const node_term* nt = &p->node_terms.v[t];
+        int restricted = 0, in_all = 1, nonempty = 1;
+        ivec inter; memset(&inter, 0, sizeof inter);
+        for (int i = 0; i < nt->fields.n; ++i) {
+            const requirement* r = &nt->fields.v[i];
+            if (strcmp(o->st.s[r->key], "metadata.name") || r->op != OP_IN) continue;
+            int has = 0;
+            for (int v = 0; v < r->values.n; ++v) if (r->values.v[v] == n->name) has = 1;
+            if (!restricted) { for (int v = 0; v < r->values.n; ++v) VEC_PUSH(inter, r->values.v[v]); }
+            else { int k = 0; for (int a = 0; a < inter.n; ++a) { int keep = 0; for (int v = 0; v < r->values.n; ++v) if (r->values.v[v] == inter.v[a]) keep = 1; if (keep) inter.v[k++] = inter.v[a]; } inter.n = k; }
+            restricted = 1; in_all = in_all && has;
+        }
+        nonempty = inter.n > 0;
+        VEC_FREE(inter);
+        if (!restricted) return 0;          /* a term without node-name affinity: every node stays eligible */
+        if (nonempty) any_name = 1;
+        if (in_all && nonempty) node_in = 1;
+    }
+    if (!any_name) return 2;
+    return node_in ? 0 : 1;
+}
+
 /* frameworkImpl.RunFilterPlugins in default profile order
  * V/kubernetes/pkg/scheduler/framework/runtime/framework.go:1093-1126,
  * V/kubernetes/pkg/scheduler/apis/config/v1/default_plugins.go:34-51: first failing Filter wins */
@@ -658,10 +753,12 @@ static int run_filter_plugins(orc* o, const podspec* p, const node* n, const ipa
     if (!reason) reason = &dummy;
     *reason = NULL;
     const char* failed = NULL;
-    if (!filter_unschedulable(o, p, n)) { failed = PL_UNSCHED; *reason = "node(s) were unschedulable"; }
+    const int pre = node_affinity_prefilter(o, p, n);   /* PreFilter results are looked at before any Filter runs */
+    if (pre) { failed = PL_AFFINITY; *reason = pre == 1 ? "PreFilter filtered the Node out" : "pod affinity terms conflict"; }
+    else if (!filter_unschedulable(o, p, n)) { failed = PL_UNSCHED; *reason = "node(s) were unschedulable"; }
     /* NodeName: pending pods have empty spec.nodeName => pass (node_name.go:79-86) */
     else if (!filter_taints(o, p, n)) { failed = PL_TAINT; *reason = "node(s) had untolerated taint(s)"; }
-    else if ((p->node_selector.n > 0 || p->has_node_affinity) && !filter_node_affinity(o, p, n)) {
+    else if ((p->node_selector.n > 0 || p->has_node_affinity || p->has_node_terms) && !filter_node_affinity(o, p, n)) {
         failed = PL_AFFINITY; *reason = "node(s) didn't match Pod's node affinity/selector";
     } else if (p->ports.n > 0 && !filter_ports(o, p, n)) {
         failed = PL_PORTS; *reason = "node(s) didn't have free ports for the requested pod ports";

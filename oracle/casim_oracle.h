@@ -50,6 +50,11 @@ int orc_pod_node_selector(orc* o, int pod, const char* key, const char* value);
 int orc_pod_node_affinity_req(orc* o, int pod, const char* key, const char* op,
                               const char* const* values, int n_values);
 int orc_pod_host_port(orc* o, int pod, const char* ip, const char* protocol, int port);
+/* nodeSelectorTerms (ORed): open a term, then add its matchExpressions (is_field 0) / matchFields (is_field 1).
+ * Exclusive with orc_pod_node_affinity_req on the same pod. */
+int orc_pod_node_affinity_term(orc* o, int pod);
+int orc_pod_node_term_req(orc* o, int pod, int term, int is_field, const char* key, const char* op,
+                          const char* const* values, int n);
 int orc_pod_anti_affinity_term(orc* o, int pod, const char* topology_key,
                                const char* const* namespaces, int n_namespaces);
 int orc_term_requirement(orc* o, int pod, int term, const char* key, const char* op,

@@ -49,6 +49,8 @@ def lib():
             "orc_pod_toleration": (C.c_int, [P, C.c_int, cstr, cstr, cstr, cstr]),
             "orc_pod_node_selector": (C.c_int, [P, C.c_int, cstr, cstr]),
             "orc_pod_node_affinity_req": (C.c_int, [P, C.c_int, cstr, cstr, cstrp, C.c_int]),
+            "orc_pod_node_affinity_term": (C.c_int, [P, C.c_int]),
+            "orc_pod_node_term_req": (C.c_int, [P, C.c_int, C.c_int, C.c_int, cstr, cstr, cstrp, C.c_int]),
             "orc_pod_host_port": (C.c_int, [P, C.c_int, cstr, cstr, C.c_int]),
             "orc_pod_anti_affinity_term": (C.c_int, [P, C.c_int, cstr, cstrp, C.c_int]),
             "orc_term_requirement": (C.c_int, [P, C.c_int, C.c_int, cstr, cstr, cstrp, C.c_int]),
@@ -170,6 +172,13 @@ class OracleScenario:
             L.orc_pod_node_selector(h, p, _b(k), _b(v))
         for r in pod.node_affinity:
             L.orc_pod_node_affinity_req(h, p, _b(r.key), _b(r.operator), _strs(r.values), len(r.values))
+        from kubernetes_autoscaler_amd.objects import NodeSelectorTerm
+        for term in (pod.node_affinity_terms or [NodeSelectorTerm()] if pod.node_affinity_terms is not None else []):
+            t = L.orc_pod_node_affinity_term(h, p)
+            assert t >= 0
+            for is_field, reqs in ((0, term.match_expressions), (1, term.match_fields)):
+                for r in reqs:
+                    assert L.orc_pod_node_term_req(h, p, t, is_field, _b(r.key), _b(r.operator), _strs(r.values), len(r.values)) == 0
         for hp in pod.host_ports:
             L.orc_pod_host_port(h, p, _b(hp.host_ip), _b(hp.protocol), int(hp.host_port))
         for term in pod.anti_affinity:

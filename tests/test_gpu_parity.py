@@ -268,3 +268,16 @@ def test_cluster_estimate_fuzz(ctx):
         est, ids = run_oracle(sc)[0]
         assert_cluster_estimate_matches(got, est, ids, w.name)
     assert delegated < 40
+
+
+def test_fuzz_node_affinity_terms_in_an_estimate(ctx):
+    """Several nodeSelectorTerms (ORed) over template labels: one more label-requirement bit per distinct term list."""
+    ran = 0
+    for seed in range(150):
+        w = workloads.fuzz(7000 + seed)
+        if workloads.add_random_node_affinity_terms(seed, [p for pg in w.pegs for p in pg.pods], [g.template for g in w.groups], allow_per_node=False):
+            sc = scenario_of(w)
+            res, _ = run_gpu(encode(sc), ctx)
+            assert_matches_oracle(res, run_oracle(sc), f"node terms {seed}")
+            ran += 1
+    assert ran > 100

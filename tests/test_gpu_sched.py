@@ -320,3 +320,42 @@ def test_domain_rules_at_scale(ctx):
     util = sorted(range(len(w.nodes)), key=lambda i: (sum(q.requests["cpu"] for q in w.nodes[i].pods), i))
     case = RemovalCase(nodes=w.nodes, candidates=util[:200])
     assert_removal_matches(removal_device(case, ctx), removal_oracle(case), "removals with spread pods")
+
+
+# ---- required node affinity: several nodeSelectorTerms (ORed) + matchFields on metadata.name ------------------------
+def test_reference_node_names_affinity_rows(ctx):
+    """TestRunFiltersOnNode's two WithNodeNamesAffinity rows (plugin_runner_test.go:121-136) through the C ABI."""
+    from kubernetes_autoscaler_amd.objects import with_node_names_affinity
+    G = GOLD["run_filters_on_node"]
+    nd = G["node"]
+    rows = [c for c in G["cases"] if "affinity" in c["name"]]
+    assert len(rows) == 2
+    for case in rows:
+        cpu, mem = G["pods"][case["test"]]
+        pod = build_test_pod(case["test"], cpu, mem, with_node_names_affinity(*G["node_names_affinity"][case["test"]]))
+        sc = SchedCase(nodes=[NodeInfo(build_test_node(nd["name"], nd["cpu"], nd["mem"]))], pods=[pod])
+        got = sched_gpu(sc, ctx)
+        assert got[0] == 0 and (got[1][0] == 0) == case["ok"]
+        assert_sched_matches(got, sched_oracle(sc), case["name"])
+
+
+def test_fuzz_node_affinity_terms(ctx):
+    """The CPU suite's term fuzz (tests/test_node_affinity_terms_emu.py) on the MI355X: TrySchedulePods with and without
+    domain rules, and the removal loop."""
+    from harness import assert_removal_matches, removal_device, removal_oracle
+    from kubernetes_autoscaler_amd.workloads import add_random_node_affinity_terms, fuzz_pending_domains, fuzz_removals
+    from test_removal_emu import case_of as removal_case_of
+    ran = 0
+    for seed in range(150):
+        for gen in (fuzz_pending, fuzz_pending_domains):
+            w = gen(seed, max_nodes=24, max_pods=60)
+            if add_random_node_affinity_terms(seed, w.pods, w.nodes):
+                sc = case_of(w)
+                assert_sched_matches(sched_gpu(sc, ctx), sched_oracle(sc), w.name)
+                ran += 1
+        w = fuzz_removals(seed)
+        if add_random_node_affinity_terms(seed, [p for info in w.nodes for p in info.pods], w.nodes):
+            case = removal_case_of(w)
+            assert_removal_matches(removal_device(case, ctx), removal_oracle(case), w.name)
+            ran += 1
+    assert ran > 300

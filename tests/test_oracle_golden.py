@@ -9,7 +9,7 @@ import pytest
 
 from kubernetes_autoscaler_amd.objects import (MiB, NodeInfo, Pod, Taint, build_test_node, build_test_pod, make_node,
                                                make_pod_equivalence_group, with_host_port, with_labels, with_max_skew,
-                                               with_namespace)
+                                               with_namespace, with_node_names_affinity)
 from oracle_driver import Limiter, OracleScenario, lib
 
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")))
@@ -150,7 +150,8 @@ def test_last_index_order_mapping():
 @pytest.mark.parametrize("case", GOLD["run_filters_on_node"]["cases"], ids=lambda c: c["name"])
 def test_run_filters_on_node(case):
     G = GOLD["run_filters_on_node"]
-    pods = {k: build_test_pod(k, v[0], v[1]) for k, v in G["pods"].items()}
+    pods = {k: build_test_pod(k, v[0], v[1], *([with_node_names_affinity(*G["node_names_affinity"][k])] if k in G["node_names_affinity"] else []))
+            for k, v in G["pods"].items()}
     s = OracleScenario()
     nd = G["node"]
     idx = s.add_existing(NodeInfo(build_test_node(nd["name"], nd["cpu"], nd["mem"]), [pods[x] for x in case["scheduled"]]))
