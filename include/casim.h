@@ -523,9 +523,23 @@ int32_t casim_enc_spread_set_taints_policy(casim_encoder* enc, int32_t pod, int3
 /* nodeAffinityPolicy (common.go:46-51): Honor (1, the default) = only nodes matching the pod's nodeSelector / required node
  * affinity are members of the constraint's domains; Ignore (0) = every node carrying the constraint keys. */
 int32_t casim_enc_spread_set_affinity_policy(casim_encoder* enc, int32_t pod, int32_t constraint, int32_t honor);
+/* namespaceSelector of a required anti-affinity term (AffinityTerm.Matches, V/kube-scheduler/framework/types.go:390-395: a
+ * pod is selected when its namespace is listed in the term OR its namespace's labels match the selector).
+ * casim_enc_add_namespace / casim_enc_namespace_add_label describe the namespace lister (name -> labels);
+ * casim_enc_term_set_namespace_selector marks the field as set on term `term` of `pod` (an empty selector selects every
+ * namespace; the pod's own namespace no longer stands in, types.go:439-447) and
+ * casim_enc_term_add_namespace_requirement adds one of its requirements (matchLabels pair == In{value}).  finalize resolves
+ * the selectors into namespace sets (interpodaffinity/plugin.go:144-157).  When a non-empty selector exists and some pod's
+ * namespace was not listed, every PEG is flagged CASIM_PEG_UNSUPPORTED (the reference treats that corner differently for
+ * arriving and resident pods, plugin.go:161-169). */
+int32_t casim_enc_add_namespace(casim_encoder* e, const char* name);
+int32_t casim_enc_namespace_add_label(casim_encoder* e, const char* name, const char* key, const char* value);
+int32_t casim_enc_term_set_namespace_selector(casim_encoder* e, int32_t pod, int32_t term);
+int32_t casim_enc_term_add_namespace_requirement(casim_encoder* e, int32_t pod, int32_t term, const char* key,
+                                                 const char* op, const char* const* values, int32_t n_values);
 int32_t casim_enc_pod_set_fastpath_requests(casim_encoder* e, int32_t pod, double cpu, double mem);
 /* Mark the spec as carrying a predicate outside the encoded subset (required pod affinity,
- * topology spread, volumes, DRA claims, namespaceSelector...). */
+ * topology spread, volumes, DRA claims...). */
 int32_t casim_enc_pod_mark_unsupported(casim_encoder* e, int32_t pod, const char* why);
 /* A PodEquivalenceGroup: `count` pods sharing pod spec `pod`.  Returns the PEG id. */
 int32_t casim_enc_add_peg(casim_encoder* e, int32_t pod_spec, int32_t count);

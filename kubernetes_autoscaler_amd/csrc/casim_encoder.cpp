@@ -38,7 +38,11 @@ struct NodeTerm { std::vector<Requirement> exprs, fields; };   // v1.NodeSelecto
 struct Toleration { std::string key; TolOp op; std::string value, effect; };
 struct Taint { std::string key, value, effect; bool operator<(const Taint& o) const { return std::tie(key, value, effect) < std::tie(o.key, o.value, o.effect); } };
 struct Port { std::string ip, proto; int32_t port; bool operator<(const Port& o) const { return std::tie(ip, proto, port) < std::tie(o.ip, o.proto, o.port); } };
-struct Term { std::string topology_key; std::vector<std::string> namespaces; std::vector<Requirement> selector; };
+// namespaceSelector: has_ns_sel = the field is set (an EMPTY selector selects every namespace, labels.Everything); finalize
+// resolves it into `namespaces` / `all_ns` the way InterPodAffinity.PreFilter does (mergeAffinityTermNamespacesIfNotEmpty,
+// V/kubernetes/pkg/scheduler/framework/plugins/interpodaffinity/plugin.go:144-157)
+struct Term { std::string topology_key; std::vector<std::string> namespaces; std::vector<Requirement> selector;
+              bool has_ns_sel = false, auto_ns = false, all_ns = false; std::vector<Requirement> ns_sel; };
 typedef std::map<std::string, std::string> Labels;
 
 struct Spread { int32_t max_skew; std::string key; int32_t min_domains; std::vector<Requirement> selector; bool taints_honor = false; bool affinity_honor = true; };
@@ -160,7 +164,7 @@ bool node_terms_match(const std::vector<NodeTerm>& terms, const Labels& ls, cons
     return false;
 }
 bool term_matches(const Term& t, const PodSpec& target) {
-    bool ns_ok = false;
+    bool ns_ok = t.all_ns;
     for (auto& n : t.namespaces) if (n == target.ns) { ns_ok = true; break; }
     return ns_ok && selector_matches(t.selector, target.labels);
 }
@@ -217,6 +221,7 @@ struct casim_encoder {
     std::vector<Group> groups;
     std::vector<Peg> pegs;
     std::vector<ExistingPod> existing;
+    std::map<std::string, Labels> namespaces;   // the namespace lister: name -> labels (only read by namespaceSelector terms)
     bool finalized = false;
     // flat tables
     int Wt = 0, Wl = 0, Wx = 0, Wz = 0;
@@ -335,6 +340,27 @@ int32_t casim_enc_node_term_add_requirement(casim_encoder* e, int32_t pod, int32
     NodeTerm& t = e->specs[pod].node_terms[(size_t)term];
     (is_field ? t.fields : t.exprs).push_back(make_req(key, op, values, n_values)); return CASIM_OK;
 }
+int32_t casim_enc_add_namespace(casim_encoder* e, const char* name) {
+    ENC_CHECK(e); e->namespaces[S(name)]; return CASIM_OK;
+}
+int32_t casim_enc_namespace_add_label(casim_encoder* e, const char* name, const char* key, const char* value) {
+    ENC_CHECK(e); e->namespaces[S(name)][S(key)] = S(value); return CASIM_OK;
+}
+int32_t casim_enc_term_set_namespace_selector(casim_encoder* e, int32_t pod, int32_t term) {
+    POD_CHECK(e, pod);
+    if (term < 0 || (size_t)term >= e->specs[pod].anti.size()) return CASIM_ERR_INVALID;
+    Term& t = e->specs[pod].anti[(size_t)term];
+    // the pod's own namespace only stands in when there are neither namespaces nor a selector (types.go:439-447)
+    if (t.auto_ns) { t.namespaces.clear(); t.auto_ns = false; }
+    t.has_ns_sel = true; return CASIM_OK;
+}
+int32_t casim_enc_term_add_namespace_requirement(casim_encoder* e, int32_t pod, int32_t term, const char* key, const char* op,
+                                                 const char* const* values, int32_t n_values) {
+    POD_CHECK(e, pod);
+    if (term < 0 || (size_t)term >= e->specs[pod].anti.size() || !e->specs[pod].anti[(size_t)term].has_ns_sel) return CASIM_ERR_INVALID;
+    if (n_values < 0 || (n_values > 0 && !values)) return CASIM_ERR_INVALID;
+    e->specs[pod].anti[(size_t)term].ns_sel.push_back(make_req(key, op, values, n_values)); return CASIM_OK;
+}
 int32_t casim_enc_pod_add_host_port(casim_encoder* e, int32_t pod, const char* ip, const char* protocol, int32_t port) {
     POD_CHECK(e, pod); e->specs[pod].ports.push_back(Port{S(ip), S(protocol), port}); return CASIM_OK;
 }
@@ -342,7 +368,7 @@ int32_t casim_enc_pod_add_anti_affinity_term(casim_encoder* e, int32_t pod, cons
     POD_CHECK(e, pod);
     if (n_namespaces < 0 || (n_namespaces > 0 && !namespaces)) return CASIM_ERR_INVALID;
     Term t; t.topology_key = S(topology_key);
-    if (n_namespaces == 0) t.namespaces.push_back(e->specs[pod].ns);  // getNamespacesFromPodAffinityTerm
+    if (n_namespaces == 0) { t.namespaces.push_back(e->specs[pod].ns); t.auto_ns = true; }  // getNamespacesFromPodAffinityTerm
     for (int i = 0; i < n_namespaces; ++i) t.namespaces.push_back(S(namespaces[i]));
     e->specs[pod].anti.push_back(t);
     return (int32_t)e->specs[pod].anti.size() - 1;
@@ -429,6 +455,27 @@ int32_t casim_enc_finalize(casim_encoder* e) {
     const bool cmp_ops = e->opt.enable_taint_comparison_ops != 0;
     for (auto& g : e->groups)
         if (g.has_pegs) for (int32_t pg : g.pegs) if (pg < 0 || (size_t)pg >= G) return CASIM_ERR_INVALID;
+
+    // ---- (0) namespaceSelector of anti-affinity terms -> explicit namespace sets ----------------------------
+    // The plugin resolves the INCOMING pod's selectors through the namespace lister (plugin.go:144-157) and evaluates the
+    // selectors of pods already on nodes against the incoming pod's namespace labels, an unlisted namespace counting as
+    // unlabelled (plugin.go:161-169).  The two only differ for a namespace the lister does not know; the conflict bits
+    // below are symmetric in who arrives first, so that corner is delegated (every PEG flagged) instead of guessed.
+    {
+        bool any_sel = false, all_known = true;
+        for (auto& p : e->specs) {
+            for (auto& t : p.anti) if (t.has_ns_sel && !t.ns_sel.empty()) any_sel = true;
+            if (!e->namespaces.count(p.ns)) all_known = false;
+        }
+        for (auto& p : e->specs)
+            for (auto& t : p.anti) {
+                if (!t.has_ns_sel) continue;
+                if (t.ns_sel.empty()) { t.all_ns = true; continue; }
+                for (auto& kv : e->namespaces) if (selector_matches(t.ns_sel, kv.second)) t.namespaces.push_back(kv.first);
+            }
+        if (any_sel && !all_known)
+            for (auto& p : e->specs) { p.unsupported = true; p.why = "namespaceSelector next to a pod whose namespace is not listed"; }
+    }
 
     // ---- dictionaries ------------------------------------------------------------------
     // (1) taints that reject scheduling (NoSchedule / NoExecute)

@@ -36,6 +36,11 @@ class Encoder:
         self._h = lib.casim_enc_create(C.byref(opts))
         if not self._h:
             raise MemoryError("casim_enc_create failed")
+        from . import objects
+        for ns, labels in objects.NAMESPACE_LISTER.items():   # the framework handle's namespace lister, as of now
+            check(lib.casim_enc_add_namespace(self._h, _b(ns)))
+            for k, v in labels.items():
+                check(lib.casim_enc_namespace_add_label(self._h, _b(ns), _b(k), _b(v)))
         self._spec_of: Dict[int, int] = {}      # id(pod object) -> spec id (PEGs repeat one pointer)
         self._keep: List[object] = []
         self.finalized = False
@@ -93,6 +98,10 @@ class Encoder:
                 check(t, "casim_enc_pod_add_anti_affinity_term")
             for r in term.requirements():
                 check(lib.casim_enc_term_add_requirement(h, s, t, _b(r.key), _b(r.operator), _strs(r.values), len(r.values)))
+            if term.namespace_selector is not None:
+                check(lib.casim_enc_term_set_namespace_selector(h, s, t))
+                for r in term.namespace_selector:
+                    check(lib.casim_enc_term_add_namespace_requirement(h, s, t, _b(r.key), _b(r.operator), _strs(r.values), len(r.values)))
         cpu, mem = pod.fastpath_requests()
         check(lib.casim_enc_pod_set_fastpath_requests(h, s, cpu, mem))
         for sc in pod.spread_constraints:   # evaluated on the device in per-node mode, flagged UNSUPPORTED by finalize otherwise

@@ -47,15 +47,40 @@ class Requirement:
 
 @dataclass
 class PodAffinityTerm:
-    """v1.PodAffinityTerm restricted to what the encoder supports (no namespaceSelector)."""
+    """v1.PodAffinityTerm.  namespace_selector: None = not set; [] = the empty selector (every namespace); it is resolved
+    against NAMESPACE_LISTER (AffinityTerm.Matches, V/kube-scheduler/framework/types.go:390-395)."""
     topology_key: str
     match_labels: Dict[str, str] = field(default_factory=dict)
     match_expressions: List[Requirement] = field(default_factory=list)
     namespaces: Sequence[str] = ()
+    namespace_selector: Optional[List[Requirement]] = None
 
     def requirements(self) -> List[Requirement]:
         reqs = [Requirement(k, "In", (v,)) for k, v in sorted(self.match_labels.items())]
         return reqs + list(self.match_expressions)
+
+
+# The namespace lister of the scheduler framework handle (an informer in the reference, CA/simulator/framework/handle.go:
+# cluster state, not an argument of the path): namespace name -> labels.  Encoder() snapshots it when it is created.
+NAMESPACE_LISTER: Dict[str, Dict[str, str]] = {}
+
+
+class namespaces:
+    """with namespaces({"team-a": {"tier": "prod"}, "default": {}}): ...  temporarily replaces NAMESPACE_LISTER."""
+
+    def __init__(self, table: Dict[str, Dict[str, str]]):
+        self.table = {k: dict(v) for k, v in table.items()}
+
+    def __enter__(self):
+        self.saved = dict(NAMESPACE_LISTER)
+        NAMESPACE_LISTER.clear()
+        NAMESPACE_LISTER.update(self.table)
+        return self
+
+    def __exit__(self, *exc):
+        NAMESPACE_LISTER.clear()
+        NAMESPACE_LISTER.update(self.saved)
+        return False
 
 
 @dataclass
@@ -139,7 +164,8 @@ class Pod:
                      tuple((r.key, r.operator, tuple(r.values)) for r in t.match_fields)) for t in self.node_affinity_terms),
                 tuple((h.host_port, h.host_ip, h.protocol) for h in self.host_ports),
                 tuple((t.topology_key, tuple(sorted(t.match_labels.items())),
-                       tuple((r.key, r.operator, tuple(r.values)) for r in t.match_expressions), tuple(t.namespaces))
+                       tuple((r.key, r.operator, tuple(r.values)) for r in t.match_expressions), tuple(t.namespaces),
+                       None if t.namespace_selector is None else tuple((r.key, r.operator, tuple(r.values)) for r in t.namespace_selector))
                       for t in self.anti_affinity),
                 self.topology_spread, tuple((c.max_skew, c.topology_key, c.min_domains, tuple(sorted(c.match_labels.items())), c.node_taints_policy, c.node_affinity_policy, tuple(c.match_label_keys))
                                             for c in self.spread_constraints),

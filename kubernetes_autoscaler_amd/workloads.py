@@ -712,3 +712,42 @@ def add_random_node_affinity_terms(seed: int, pods: Sequence[Pod], nodes: Sequen
             p.node_affinity_terms = [NodeSelectorTerm(list(t.match_expressions), list(t.match_fields)) for t in terms]
         decorated += len(group)
     return decorated
+
+
+# ---------------------------------------------------------------------------------------------
+# namespaceSelector of required anti-affinity terms
+# ---------------------------------------------------------------------------------------------
+def add_random_namespace_selectors(seed: int, pods: Sequence[Pod], hostname_only: bool = False) -> Dict[str, Dict[str, str]]:
+    """Spreads `pods` (pending and running alike; same spec -> same treatment) over four namespaces with different labels,
+    gives some anti-affinity terms a namespaceSelector (empty = every namespace, In / NotIn / Exists / DoesNotExist), drops
+    the explicit namespace list of some, and adds a selector-only term to some pods that had none.  Returns the namespace
+    table to install as the lister (objects.namespaces)."""
+    from .objects import Requirement
+    rng = SplitMix64(0x4E5AA000 + seed)
+    table = {"default": {"team": "core"}, "ns-a": {"team": "a", "tier": "prod"}, "ns-b": {"team": "b"}, "ns-c": {}}
+    names = list(table)
+    selectors = [[], [Requirement("team", "In", ["a"])], [Requirement("team", "In", ["a", "b"])], [Requirement("tier", "Exists", [])],
+                 [Requirement("team", "NotIn", ["a"])], [Requirement("team", "DoesNotExist", [])],
+                 [Requirement("team", "Exists", []), Requirement("tier", "DoesNotExist", [])]]
+    by_spec: Dict[tuple, List[Pod]] = {}
+    for p in pods:
+        by_spec.setdefault(p.spec_key(), []).append(p)
+    apps = sorted({p.labels.get("app", "") for p in pods if p.labels.get("app")}) or ["app0"]
+    for group in by_spec.values():
+        ns = rng.pick(names)
+        terms = [PodAffinityTerm(t.topology_key, dict(t.match_labels), list(t.match_expressions), tuple(t.namespaces), t.namespace_selector)
+                 for t in group[0].anti_affinity]
+        for t in terms:
+            if rng.chance(1, 2):
+                t.namespace_selector = list(rng.pick(selectors))
+                t.namespaces = tuple(rng.sample(names, rng.below(3))) if rng.chance(1, 2) else ()
+            elif rng.chance(1, 3):
+                t.namespaces = tuple(rng.sample(names, 1 + rng.below(2)))
+        if not terms and rng.chance(1, 4):
+            terms.append(PodAffinityTerm(LABEL_HOSTNAME if hostname_only or rng.chance(2, 3) else LABEL_ZONE, match_labels={"app": rng.pick(apps)},
+                                         namespace_selector=list(rng.pick(selectors))))
+        for p in group:
+            p.namespace = ns
+            p.anti_affinity = [PodAffinityTerm(t.topology_key, dict(t.match_labels), list(t.match_expressions), tuple(t.namespaces),
+                                               None if t.namespace_selector is None else list(t.namespace_selector)) for t in terms]
+    return table

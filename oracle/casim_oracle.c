@@ -85,7 +85,10 @@ typedef VEC(requirement) reqvec;
 typedef struct { int ip, proto, port; } hostport;
 /* v1.NodeSelectorTerm: matchExpressions (node labels) AND matchFields (metadata.name) */
 typedef struct { reqvec exprs, fields; } node_term;
-typedef struct { int topology_key; ivec namespaces; reqvec selector; } aff_term;
+/* has_ns_sel: the term's namespaceSelector is set (empty = labels.Everything); auto_ns: namespaces holds the pod's own
+ * namespace because neither field was given (V/kube-scheduler/framework/types.go:439-447) */
+typedef struct { int topology_key; ivec namespaces; reqvec selector; int has_ns_sel, auto_ns; reqvec ns_sel; } aff_term;
+typedef struct { int name; VEC(kv) labels; } ns_entry;
 /* topologySpreadConstraint  V/.../podtopologyspread/common.go:34-41 (DoNotSchedule constraints only; nodeAffinityPolicy
  * Honor and nodeTaintsPolicy Ignore, the defaults :108-110) */
 typedef struct { int max_skew, topology_key, min_domains; reqvec selector; int selector_set; int taints_honor; int affinity_ignore; } spread_constraint;
@@ -133,6 +136,7 @@ struct orc {
     VEC(podspec) pods;
     VEC(node) nodes;     /* node objects (templates / existing) */
     VEC(node) snap;      /* the cluster snapshot list, insertion order */
+    VEC(ns_entry) namespaces; /* the namespace lister */
     int taint_cmp_ops;
     int id_hostname, id_noschedule, id_noexecute, id_allip, id_tcp, id_empty, id_unsched_key;
     int64_t filter_runs;
@@ -176,7 +180,7 @@ void orc_free(orc* o) {
         free_reqvec(&p->node_affinity); VEC_FREE(p->ports);
         for (int t = 0; t < p->node_terms.n; ++t) { free_reqvec(&p->node_terms.v[t].exprs); free_reqvec(&p->node_terms.v[t].fields); }
         VEC_FREE(p->node_terms);
-        for (int t = 0; t < p->anti_terms.n; ++t) { VEC_FREE(p->anti_terms.v[t].namespaces); free_reqvec(&p->anti_terms.v[t].selector); }
+        for (int t = 0; t < p->anti_terms.n; ++t) { VEC_FREE(p->anti_terms.v[t].namespaces); free_reqvec(&p->anti_terms.v[t].selector); free_reqvec(&p->anti_terms.v[t].ns_sel); }
         VEC_FREE(p->anti_terms);
         for (int c = 0; c < p->spread.n; ++c) free_reqvec(&p->spread.v[c].selector);
         VEC_FREE(p->spread);
@@ -186,6 +190,8 @@ void orc_free(orc* o) {
     VEC_FREE(o->nodes);
     for (int i = 0; i < o->snap.n; ++i) node_free(&o->snap.v[i]);
     VEC_FREE(o->snap);
+    for (int i = 0; i < o->namespaces.n; ++i) VEC_FREE(o->namespaces.v[i].labels);
+    VEC_FREE(o->namespaces);
     for (int i = 0; i < o->st.n; ++i) free(o->st.s[i]);
     free(o->st.s); free(o->st.table);
     free(o);
@@ -278,10 +284,36 @@ int orc_pod_anti_affinity_term(orc* o, int pod, const char* topology_key, const 
     t.topology_key = intern(&o->st, topology_key);
     /* getNamespacesFromPodAffinityTerm  V/kubernetes/pkg/scheduler/framework/types.go (newAffinityTerm):
      * no namespaces and no namespaceSelector => the pod's own namespace */
-    if (n == 0) VEC_PUSH(t.namespaces, o->pods.v[pod].ns);
+    if (n == 0) { VEC_PUSH(t.namespaces, o->pods.v[pod].ns); t.auto_ns = 1; }
     for (int i = 0; i < n; ++i) VEC_PUSH(t.namespaces, intern(&o->st, namespaces[i]));
     VEC_PUSH(o->pods.v[pod].anti_terms, t);
     return o->pods.v[pod].anti_terms.n - 1;
+}
+static ns_entry* ns_find(const orc* o, int name) {
+    for (int i = 0; i < o->namespaces.n; ++i) if (o->namespaces.v[i].name == name) return &o->namespaces.v[i];
+    return NULL;
+}
+/* the namespace lister: a namespace and, optionally, one of its labels (key NULL = just register it) */
+int orc_namespace_label(orc* o, const char* name, const char* key, const char* value) {
+    const int id = intern(&o->st, name);
+    ns_entry* e = ns_find(o, id);
+    if (!e) { ns_entry ne; memset(&ne, 0, sizeof ne); ne.name = id; VEC_PUSH(o->namespaces, ne); e = &o->namespaces.v[o->namespaces.n - 1]; }
+    if (key) { kv l = {intern(&o->st, key), intern(&o->st, value)}; VEC_PUSH(e->labels, l); }
+    return 0;
+}
+/* the term's namespaceSelector is set (possibly empty) */
+int orc_term_namespace_selector(orc* o, int pod, int term) {
+    PODCHK(o, pod);
+    if (term < 0 || term >= o->pods.v[pod].anti_terms.n) return -1;
+    aff_term* t = &o->pods.v[pod].anti_terms.v[term];
+    if (t->auto_ns) { t->namespaces.n = 0; t->auto_ns = 0; }
+    t->has_ns_sel = 1; return 0;
+}
+int orc_term_namespace_requirement(orc* o, int pod, int term, const char* key, const char* op, const char* const* values, int n) {
+    PODCHK(o, pod);
+    if (term < 0 || term >= o->pods.v[pod].anti_terms.n || !o->pods.v[pod].anti_terms.v[term].has_ns_sel) return -1;
+    requirement r = make_req(o, key, op, values, n);
+    VEC_PUSH(o->pods.v[pod].anti_terms.v[term].ns_sel, r); return 0;
 }
 int orc_term_requirement(orc* o, int pod, int term, const char* key, const char* op, const char* const* values, int n) {
     PODCHK(o, pod);
@@ -448,10 +480,21 @@ static int selector_matches(const orc* o, const reqvec* sel, const kv* labels, i
     for (int i = 0; i < sel->n; ++i) if (!requirement_matches(o, &sel->v[i], labels, n)) return 0;
     return 1;
 }
-/* AffinityTerm.Matches  V/kube-scheduler/framework/types.go:390-395 (namespaceSelector: none => matches nothing) */
-static int term_matches_pod(const orc* o, const aff_term* t, const podspec* p) {
+/* AffinityTerm.Matches  V/kube-scheduler/framework/types.go:390-395: the pod's namespace is listed in the term OR matches
+ * its namespaceSelector.  owner_is_incoming: the term belongs to the pod being scheduled; PreFilter replaced a NON-EMPTY
+ * selector by the namespaces the lister returns for it (interpodaffinity/plugin.go:144-157, filtering.go:286-296) and
+ * passes nil labels (:253), so an unlisted namespace never matches.  Otherwise the term belongs to a pod already on a node
+ * and is evaluated against the incoming pod's namespace labels, an unlisted namespace counting as unlabelled
+ * (plugin.go:161-169, filtering.go:298,213).  An empty selector is labels.Everything in both directions. */
+static int term_matches_pod(const orc* o, const aff_term* t, const podspec* p, int owner_is_incoming) {
     int ns_ok = 0;
     for (int i = 0; i < t->namespaces.n; ++i) if (t->namespaces.v[i] == p->ns) { ns_ok = 1; break; }
+    if (!ns_ok && t->has_ns_sel) {
+        const ns_entry* e = ns_find(o, p->ns);
+        if (t->ns_sel.n == 0) ns_ok = 1;
+        else if (owner_is_incoming) ns_ok = e != NULL && selector_matches(o, &t->ns_sel, e->labels.v, e->labels.n);
+        else ns_ok = selector_matches(o, &t->ns_sel, e ? e->labels.v : NULL, e ? e->labels.n : 0);
+    }
     if (!ns_ok) return 0;
     return selector_matches(o, &t->selector, p->labels.v, p->labels.n);
 }
@@ -617,7 +660,7 @@ static void ipa_prefilter(const orc* o, const podspec* p, ipa_state* s) {
             const podspec* ep = &o->pods.v[n->pods.v[j]];
             for (int t = 0; t < ep->anti_terms.n; ++t) {
                 const aff_term* term = &ep->anti_terms.v[t];
-                if (!term_matches_pod(o, term, p)) continue;
+                if (!term_matches_pod(o, term, p, 0)) continue;
                 int val;
                 if (labels_lookup(n->labels.v, n->labels.n, term->topology_key, &val)) tpmap_add(&s->existing_anti, term->topology_key, val, 1);
             }
@@ -631,7 +674,7 @@ static void ipa_prefilter(const orc* o, const podspec* p, ipa_state* s) {
                 const podspec* ep = &o->pods.v[n->pods.v[j]];
                 for (int t = 0; t < p->anti_terms.n; ++t) {
                     const aff_term* term = &p->anti_terms.v[t];
-                    if (!term_matches_pod(o, term, ep)) continue;
+                    if (!term_matches_pod(o, term, ep, 1)) continue;
                     int val;
                     if (labels_lookup(n->labels.v, n->labels.n, term->topology_key, &val)) tpmap_add(&s->incoming_anti, term->topology_key, val, 1);
                 }

@@ -50,6 +50,11 @@ int orc_pod_node_selector(orc* o, int pod, const char* key, const char* value);
 int orc_pod_node_affinity_req(orc* o, int pod, const char* key, const char* op,
                               const char* const* values, int n_values);
 int orc_pod_host_port(orc* o, int pod, const char* ip, const char* protocol, int port);
+/* namespaceSelector of an anti-affinity term + the namespace lister it is resolved against (key NULL = register only) */
+int orc_namespace_label(orc* o, const char* name, const char* key, const char* value);
+int orc_term_namespace_selector(orc* o, int pod, int term);
+int orc_term_namespace_requirement(orc* o, int pod, int term, const char* key, const char* op,
+                                   const char* const* values, int n);
 /* nodeSelectorTerms (ORed): open a term, then add its matchExpressions (is_field 0) / matchFields (is_field 1).
  * Exclusive with orc_pod_node_affinity_req on the same pod. */
 int orc_pod_node_affinity_term(orc* o, int pod);

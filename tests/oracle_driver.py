@@ -50,6 +50,9 @@ def lib():
             "orc_pod_node_selector": (C.c_int, [P, C.c_int, cstr, cstr]),
             "orc_pod_node_affinity_req": (C.c_int, [P, C.c_int, cstr, cstr, cstrp, C.c_int]),
             "orc_pod_node_affinity_term": (C.c_int, [P, C.c_int]),
+            "orc_namespace_label": (C.c_int, [P, cstr, cstr, cstr]),
+            "orc_term_namespace_selector": (C.c_int, [P, C.c_int, C.c_int]),
+            "orc_term_namespace_requirement": (C.c_int, [P, C.c_int, C.c_int, cstr, cstr, cstrp, C.c_int]),
             "orc_pod_node_term_req": (C.c_int, [P, C.c_int, C.c_int, C.c_int, cstr, cstr, cstrp, C.c_int]),
             "orc_pod_host_port": (C.c_int, [P, C.c_int, cstr, cstr, C.c_int]),
             "orc_pod_anti_affinity_term": (C.c_int, [P, C.c_int, cstr, cstrp, C.c_int]),
@@ -138,6 +141,11 @@ class OracleScenario:
             self.L.orc_set_list_shuffle(self.h, list_shuffle_seed)
         self._pod_ids: Dict[int, int] = {}
         self._keep: List[object] = []
+        from kubernetes_autoscaler_amd import objects
+        for ns, labels in objects.NAMESPACE_LISTER.items():
+            self.L.orc_namespace_label(self.h, _b(ns), None, None)
+            for k, v in labels.items():
+                self.L.orc_namespace_label(self.h, _b(ns), _b(k), _b(v))
 
     def close(self):
         if self.h:
@@ -185,6 +193,10 @@ class OracleScenario:
             t = L.orc_pod_anti_affinity_term(h, p, _b(term.topology_key), _strs(term.namespaces), len(term.namespaces))
             for r in term.requirements():
                 L.orc_term_requirement(h, p, t, _b(r.key), _b(r.operator), _strs(r.values), len(r.values))
+            if term.namespace_selector is not None:
+                assert L.orc_term_namespace_selector(h, p, t) == 0
+                for r in term.namespace_selector:
+                    assert L.orc_term_namespace_requirement(h, p, t, _b(r.key), _b(r.operator), _strs(r.values), len(r.values)) == 0
         if pod.has_containers:
             cpu, mem = pod.fastpath_requests()
             L.orc_pod_fastpath_requests(h, p, cpu, mem)

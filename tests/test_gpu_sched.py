@@ -359,3 +359,24 @@ def test_fuzz_node_affinity_terms(ctx):
             assert_removal_matches(removal_device(case, ctx), removal_oracle(case), w.name)
             ran += 1
     assert ran > 300
+
+
+def test_fuzz_namespace_selectors(ctx):
+    """namespaceSelector of anti-affinity terms, resolved by the encoder against the namespace lister
+    (tests/test_namespace_selector_emu.py) on the MI355X: TrySchedulePods with and without domain rules, the removal loop."""
+    from harness import assert_removal_matches, removal_device, removal_oracle
+    from kubernetes_autoscaler_amd.objects import namespaces
+    from kubernetes_autoscaler_amd.workloads import add_random_namespace_selectors, fuzz_pending_domains, fuzz_removals
+    from test_removal_emu import case_of as removal_case_of
+    for seed in range(120):
+        for gen, host_only in ((fuzz_pending, True), (fuzz_pending_domains, False)):
+            w = gen(seed, max_nodes=24, max_pods=60)
+            table = add_random_namespace_selectors(seed, list(w.pods) + [p for info in w.nodes for p in info.pods], hostname_only=host_only)
+            with namespaces(table):
+                sc = case_of(w)
+                assert_sched_matches(sched_gpu(sc, ctx), sched_oracle(sc), w.name)
+        w = fuzz_removals(seed)
+        table = add_random_namespace_selectors(seed, [p for info in w.nodes for p in info.pods], hostname_only=True)
+        with namespaces(table):
+            case = removal_case_of(w)
+            assert_removal_matches(removal_device(case, ctx), removal_oracle(case), w.name)
