@@ -69,3 +69,43 @@ def test_product_package_never_touches_the_oracle():
                         assert "oracle" not in line and "emu" not in line, (path, line)
     blob = open(_ffi.LIB_PATH, "rb").read()
     assert b"orc_estimate" not in blob and b"casim_emu" not in blob
+
+
+def test_encoder_term_entry_points_reject_bad_handles_and_mixed_use():
+    """casim_enc_pod_add_node_affinity_term / casim_enc_node_term_add_requirement / casim_enc_term_set_namespace_selector /
+    casim_enc_term_add_namespace_requirement: bad indices and mixed use come back as CASIM_ERR_INVALID (host-only code)."""
+    import ctypes as C
+    from kubernetes_autoscaler_amd import _abi
+    from kubernetes_autoscaler_amd._ffi import lib
+    opts = _abi.EncoderOptions(n_res=2)
+    e = lib.casim_enc_create(C.byref(opts))
+    assert e
+    try:
+        req = (C.c_int64 * _abi.MAX_RES)(100, 0)
+        s = lib.casim_enc_add_pod_spec(e, b"default", req)
+        s2 = lib.casim_enc_add_pod_spec(e, b"default", req)
+        vals = (C.c_char_p * 1)(b"v")
+        assert lib.casim_enc_pod_add_node_affinity_term(e, 99) < 0
+        t = lib.casim_enc_pod_add_node_affinity_term(e, s)
+        assert t == 0 and lib.casim_enc_pod_add_node_affinity_term(e, s) == 1
+        assert lib.casim_enc_node_term_add_requirement(e, s, 0, 0, b"k", b"In", vals, 1) == 0
+        assert lib.casim_enc_node_term_add_requirement(e, s, 1, 1, b"metadata.name", b"In", vals, 1) == 0
+        assert lib.casim_enc_node_term_add_requirement(e, s, 2, 0, b"k", b"In", vals, 1) < 0      # no such term
+        assert lib.casim_enc_node_term_add_requirement(e, s, 0, 0, b"k", b"In", None, 1) < 0      # values missing
+        assert lib.casim_enc_node_term_add_requirement(e, s, 0, 0, b"k", b"In", vals, -1) < 0
+        assert lib.casim_enc_pod_add_node_affinity_req(e, s, b"k", b"In", vals, 1) < 0            # one NodeSelector per pod
+        assert lib.casim_enc_pod_add_node_affinity_req(e, s2, b"k", b"In", vals, 1) == 0
+        assert lib.casim_enc_pod_add_node_affinity_term(e, s2) < 0
+        # namespace selectors
+        assert lib.casim_enc_term_set_namespace_selector(e, s, 0) < 0                              # the pod has no anti-affinity term
+        a = lib.casim_enc_pod_add_anti_affinity_term(e, s, b"kubernetes.io/hostname", None, 0)
+        assert a == 0
+        assert lib.casim_enc_term_add_namespace_requirement(e, s, a, b"team", b"In", vals, 1) < 0  # selector not set yet
+        assert lib.casim_enc_term_set_namespace_selector(e, s, a) == 0
+        assert lib.casim_enc_term_add_namespace_requirement(e, s, a, b"team", b"In", vals, 1) == 0
+        assert lib.casim_enc_term_add_namespace_requirement(e, s, 7, b"team", b"In", vals, 1) < 0
+        assert lib.casim_enc_add_namespace(e, b"default") == 0
+        assert lib.casim_enc_namespace_add_label(e, b"team-a", b"team", b"a") == 0
+        assert lib.casim_enc_add_namespace(None, b"x") < 0
+    finally:
+        lib.casim_enc_destroy(e)
