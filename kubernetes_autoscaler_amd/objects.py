@@ -213,6 +213,63 @@ class PodEquivalenceGroup:
 # ---------------------------------------------------------------------------------------------
 # builders mirroring CA/utils/test/test_utils.go and the estimator tests
 # ---------------------------------------------------------------------------------------------
+@dataclass
+class Container:
+    """What resource.PodRequests reads of a v1.Container: its requests and, for init containers, restartPolicy: Always
+    (a sidecar)."""
+    requests: Dict[str, int] = field(default_factory=dict)
+    restart_always: bool = False
+
+
+def pod_requests(containers: Sequence[Container], init_containers: Sequence[Container] = (), overhead: Optional[Dict[str, int]] = None,
+                 pod_level: Optional[Dict[str, int]] = None) -> Dict[str, int]:
+    """resource.PodRequests (V/component-helpers/resource/helpers.go:151-191 over AggregateContainerRequests :198-281), which
+    podutils.PodRequests (CA/utils/pod/pod.go:88-96) and NodeResourcesFit.PreFilter (fit.go:321-347) call: the value that goes
+    into Pod.requests / the request lanes of the C ABI.
+
+        sum of the containers and of the sidecars (restartable init containers)                        :216-258
+        max with every init step: a plain init container + the sidecars started before it, a sidecar    :243-267
+            step = the sidecars so far
+        pod-level requests, when set, replace cpu / memory / hugepages-* (PodLevelResources)            :157-179
+        + overhead                                                                                      :182-185
+
+    Status-based variants (UseStatusResources: in-place resize of RUNNING containers, :205-214) do not apply to the pending
+    pods this path schedules: they have no container statuses."""
+    reqs: Dict[str, int] = {}
+
+    def add(dst, src):
+        for k, v in src.items():
+            dst[k] = dst.get(k, 0) + int(v)
+
+    def vmax(dst, src):
+        for k, v in src.items():
+            if k not in dst or int(v) > dst[k]:
+                dst[k] = int(v)
+
+    for c in containers:
+        add(reqs, c.requests)
+    sidecars: Dict[str, int] = {}
+    init_max: Dict[str, int] = {}
+    for c in init_containers:
+        if c.restart_always:
+            add(reqs, c.requests)
+            add(sidecars, c.requests)
+            step = sidecars
+        else:
+            step = {}
+            add(step, c.requests)
+            add(step, sidecars)
+        vmax(init_max, step)
+    vmax(reqs, init_max)
+    if pod_level:
+        for k, v in pod_level.items():
+            if k in (RES_CPU, RES_MEMORY) or k.startswith("hugepages-"):
+                reqs[k] = int(v)
+    if overhead:
+        add(reqs, overhead)
+    return reqs
+
+
 def build_test_pod(name: str, cpu: int, mem: int, *options) -> Pod:
     """BuildTestPod(name, cpuMilli, memBytes, opts...)  test_utils.go:38-70."""
     pod = Pod(name=name, namespace="default")

@@ -196,3 +196,24 @@ def test_hints_drop_old_property():
         assert not incorrect(s, all_keys, all_keys)
         s.drop_old()
         assert not incorrect(s, final, all_keys)
+
+
+def test_pod_requests_follows_the_sidecar_formula():
+    """resource.PodRequests (V/component-helpers/resource/helpers.go:151-281); the vendored module ships no tests, the
+    expectations are worked by hand from the formula in its comments (:233-241)."""
+    from kubernetes_autoscaler_amd.objects import Container, pod_requests
+    C = lambda cpu, mem=0, always=False: Container({"cpu": cpu, "memory": mem}, always)
+    assert pod_requests([C(100, 10), C(200, 20)]) == {"cpu": 300, "memory": 30}
+    # a plain init container only sets a floor
+    assert pod_requests([C(100, 10), C(200, 20)], [C(500, 5)]) == {"cpu": 500, "memory": 30}
+    # sidecars add to the total; a plain init container runs next to the sidecars started before it
+    got = pod_requests([C(100)], [C(50, 0, True), C(400), C(30, 0, True)])
+    assert got == {"cpu": 450, "memory": 0}            # running: 100 + 50 + 30 = 180; init step 2: 400 + 50 = 450
+    got = pod_requests([C(100)], [C(50, 0, True), C(10), C(30, 0, True)], overhead={"cpu": 7, "memory": 3})
+    assert got == {"cpu": 187, "memory": 3}            # running 180 beats every init step (50, 60, 80); + overhead
+    # pod-level requests replace cpu / memory only, overhead still on top; other resources keep the container sums
+    got = pod_requests([Container({"cpu": 100, "memory": 10, "example.com/gpu": 1})], pod_level={"cpu": 1000, "example.com/gpu": 9}, overhead={"cpu": 1})
+    assert got == {"cpu": 1001, "memory": 10, "example.com/gpu": 1}
+    assert pod_requests([]) == {}
+    # resources only some containers name
+    assert pod_requests([Container({"cpu": 1}), Container({"ephemeral-storage": 5})], [Container({"memory": 9})]) == {"cpu": 1, "ephemeral-storage": 5, "memory": 9}
