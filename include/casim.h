@@ -32,7 +32,9 @@
 extern "C" {
 #endif
 
-#define CASIM_ABI_VERSION 2   /* 2: casim_removal_candidates.cand_atomic, casim_domain_rules.n_taint_policy_rules */
+#define CASIM_ABI_VERSION 3   /* 2: casim_removal_candidates.cand_atomic, casim_domain_rules.n_taint_policy_rules
+                               * 3: casim_groups.{peg_lo,peg_hi,global_id,n_sims,sim_offsets}, casim_best_option_sims,
+                               *    casim_feasibility_reasons, casim_estimate_batch_timed, casim_mctx_*, casim_cluster_* */
 
 /* Resource lanes.  Lane 0 = cpu in millicores (Quantity.MilliValue), lane 1 = memory bytes,
  * lane 2 = ephemeral-storage bytes, lanes 3.. = scalar / extended resources (Quantity.Value),
@@ -127,6 +129,17 @@ typedef struct casim_groups {
     const int64_t* waste_mem;     /* [NG] node.Status.Capacity memory Value; may be NULL                 */
     const int32_t* peg_offsets;   /* [NG+1] CSR offsets into peg_index, or NULL = compute on device      */
     const int32_t* peg_index;     /* [peg_offsets[NG]] PEG ids, in the order they reach Estimate()       */
+    /* ---- batches of independent simulations (all optional; NULL / 0 = one simulation over all PEGs) ---------------
+     * One launch can carry many scale-up simulations (RunOnce iterations of different clusters, or what-if variants):
+     * group i only ever sees the PEGs [peg_lo[i], peg_hi[i]) — its simulation's pending pods — when the engine derives
+     * the schedulable subsets on the device (peg_offsets == NULL), and the expander reduce (casim_best_option_sims)
+     * runs per simulation over the groups [sim_offsets[s], sim_offsets[s+1]). */
+    const int32_t* peg_lo;        /* [NG] first candidate PEG of the group, or NULL = 0                    */
+    const int32_t* peg_hi;        /* [NG] one past its last candidate PEG, or NULL = G                     */
+    const int32_t* global_id;     /* [NG] id of the group inside expander keys (node groups sharded over GPUs keep their
+                                     cluster-wide index), or NULL = group_id_base + i                        */
+    int32_t n_sims;               /* S, 0 = one simulation holding every group                             */
+    const int32_t* sim_offsets;   /* [S+1] groups of simulation s, ascending, sim_offsets[0] = 0, [S] = NG  */
 } casim_groups;
 
 typedef struct casim_options {
@@ -161,6 +174,7 @@ typedef struct casim_results {
  * ==================================================================================== */
 typedef struct casim_ctx casim_ctx;
 typedef struct casim_problem casim_problem;
+struct casim_option_query;
 
 /* ABI version of the loaded library. */
 int32_t casim_abi_version(void);
@@ -218,6 +232,15 @@ int32_t casim_problem_set_group_result(casim_problem* p, int32_t ng, const struc
 int32_t casim_estimate_batch(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups,
                              const casim_options* opts, casim_results* out);
 
+/* casim_estimate_batch with the expander reduce and a phase breakdown, host clock, the stream drained after every
+ * phase (so the phases add up to slightly more than an untimed call): phase_ms_out[0] = tables to HBM (allocation +
+ * H2D), [1] = feasibility + CSR kernels, [2] = order kernel, [3] = pack kernel, [4] = expander reduce (skipped when
+ * q == NULL), [5] = results to the host (D2H), [6] = the whole call enter -> return, [7] = 0.  What bench.py and
+ * tools/casim_native report per config (wall time = enter -> return, H2D / D2H included). */
+int32_t casim_estimate_batch_timed(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups,
+                                   const casim_options* opts, casim_results* out, const struct casim_option_query* q,
+                                   double phase_ms_out[8]);
+
 /*
  * Batched CheckPredicates(exemplar, fresh template node): bit (i, g) of
  * out_bits[i * ceil(G/64) + g/64] is set iff PEG g passes every encoded Filter on an empty
@@ -227,6 +250,8 @@ int32_t casim_estimate_batch(casim_ctx* ctx, const casim_pegs* pegs, const casim
  * rule builds the per-group PEG lists when peg_offsets is NULL: such a PEG stays on the list of every group it may
  * fit, which makes those groups CASIM_NG_UNSUPPORTED — it never silently drops out of an estimate.
  */
+/* With casim_groups.peg_lo / peg_hi (a batch of simulations) row i has ceil(max_i(peg_hi - peg_lo) / 64) words and its
+ * bit k stands for PEG peg_lo[i] + k. */
 int32_t casim_feasibility(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups,
                           uint64_t* out_bits);
 
@@ -264,6 +289,34 @@ int32_t casim_problem_dense_check(casim_problem* p, int32_t col_repeat, uint64_t
 int32_t casim_best_option(casim_problem* p, const int32_t* kinds, int32_t n_kinds,
                           int32_t group_id_base, int32_t* best_ng_out, int32_t* n_best_out,
                           uint8_t* best_set_out, int64_t* key_out, void* dev_key_out);
+
+/*
+ * General form of casim_best_option: an optional validity mask and one reduce PER SIMULATION of a batch
+ * (casim_groups.sim_offsets).  valid[i] == 0 takes option i out of the competition before the first filter: how the
+ * shim applies prepareScaleUp's all-or-nothing rule (orchestrator.go:1057-1063 drops an option whose Pods are fewer than the
+ * pods it was asked to place BEFORE ExpanderStrategy.BestOption sees the list).
+ * Outputs are indexed by simulation (S = n_sims when per_sim, else 1): best_out[s] = lowest surviving group index
+ * (index inside the launch) or -1, n_best_out[s] = survivors, key_out[s][10] = the winner's key block,
+ * packed_out[s] = key block entry [0] (first filter's metric << 20 | global group id): ONE all-reduce(min) over the
+ * [S] packed keys picks every simulation's winner across GPUs when the first filter is an integer metric.
+ * dev_* are optional DEVICE pointers receiving the same data without a host round trip (RCCL operands).
+ * Synchronous unless every host out pointer is NULL.
+ */
+typedef struct casim_option_query {
+    const int32_t* kinds;       /* [n_kinds] CASIM_EXPANDER_* */
+    int32_t n_kinds;
+    int32_t group_id_base;      /* added to the group index inside keys unless casim_groups.global_id is set */
+    int32_t per_sim;            /* 1 = one reduce per simulation, 0 = one over every group */
+    const uint8_t* valid;       /* [NG] or NULL */
+    int32_t* best_out;          /* [S] or NULL */
+    int32_t* n_best_out;        /* [S] or NULL */
+    uint8_t* best_set_out;      /* [NG] or NULL */
+    int64_t* key_out;           /* [S][10] or NULL */
+    int64_t* packed_out;        /* [S] or NULL */
+    void* dev_key_out;          /* device [S][10] int64 or NULL */
+    void* dev_packed_out;       /* device [S] int64 or NULL */
+} casim_option_query;
+int32_t casim_best_option_sims(casim_problem* p, const casim_option_query* q);
 
 /*
  * HintingSimulator.TrySchedulePods (CA/simulator/scheduling/hinting_simulator.go:53-135) — the

@@ -3,7 +3,7 @@ shared library happens in _ffi.py).  Kept separate so that test harnesses that c
 structs can reuse the layouts without loading the product library."""
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_RES = 8
 
 OK = 0
@@ -46,6 +46,7 @@ class Groups(C.Structure):
         ("max_nodes", i32p), ("existing_nodes", i32p), ("last_index", i32p),
         ("cap_cpu", f64p), ("cap_mem", f64p), ("waste_cpu", i64p), ("waste_mem", i64p),
         ("peg_offsets", i32p), ("peg_index", i32p),
+        ("peg_lo", i32p), ("peg_hi", i32p), ("global_id", i32p), ("n_sims", C.c_int32), ("sim_offsets", i32p),
     ]
 
 
@@ -59,6 +60,12 @@ class Results(C.Structure):
         ("last_index_out", i32p), ("status", i32p), ("req_cpu_sum", i64p), ("req_mem_sum", i64p),
         ("order", i32p), ("placed", i32p),
     ]
+
+
+class OptionQuery(C.Structure):
+    _fields_ = [("kinds", i32p), ("n_kinds", C.c_int32), ("group_id_base", C.c_int32), ("per_sim", C.c_int32), ("valid", u8p),
+                ("best_out", i32p), ("n_best_out", i32p), ("best_set_out", u8p), ("key_out", i64p), ("packed_out", i64p),
+                ("dev_key_out", C.c_void_p), ("dev_packed_out", C.c_void_p)]
 
 
 class EncoderOptions(C.Structure):
@@ -123,6 +130,9 @@ PROTOTYPES = {
     "casim_feasibility": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), u64p]),
     "casim_problem_dense_check": (C.c_int32, [C.c_void_p, C.c_int32, u64p, i64p, i64p]),
     "casim_best_option": (C.c_int32, [C.c_void_p, i32p, C.c_int32, C.c_int32, i32p, i32p, u8p, i64p, C.c_void_p]),
+    "casim_best_option_sims": (C.c_int32, [C.c_void_p, C.POINTER(OptionQuery)]),
+    "casim_estimate_batch_timed": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(Options), C.POINTER(Results),
+                                               C.POINTER(OptionQuery), f64p]),
     "casim_problem_time": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "casim_problem_time_dense": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float), i64p, i64p]),
     "casim_try_schedule_pods": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(PodSequence), i32p, i32p, i32p]),

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -251,6 +252,38 @@ int32_t casim_estimate_batch(casim_ctx* ctx, const casim_pegs* pegs, const casim
     return rc;
 }
 
+int32_t casim_estimate_batch_timed(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts,
+                                   casim_results* out, const casim_option_query* q, double phase_ms_out[8]) {
+    using clk = std::chrono::steady_clock;
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    if (!phase_ms_out) return set_err(CASIM_ERR_INVALID, "null phase_ms_out");
+    for (int i = 0; i < 8; ++i) phase_ms_out[i] = 0.0;
+    const auto t0 = clk::now();
+    casim_problem* p = casim_problem_create(ctx, pegs, groups, opts);   // init() ends with a stream sync
+    if (!p) return g_err.empty() ? CASIM_ERR_INVALID : (casim_device_count() > 0 ? CASIM_ERR_INVALID : CASIM_ERR_NO_DEVICE);
+    HipBackend& bk = ctx->bk;
+    const auto t1 = clk::now();
+    p->prob->run_feasibility(); bk.sync();
+    const auto t2 = clk::now();
+    p->prob->run_order(); bk.sync();
+    const auto t3 = clk::now();
+    p->prob->run_pack(); bk.sync();
+    const auto t4 = clk::now();
+    int32_t rc = p->prob->run_mark();
+    if (rc == CASIM_OK && q) { rc = p->prob->best_option_query(q); bk.sync(); }
+    const auto t5 = clk::now();
+    if (rc == CASIM_OK && out) rc = p->prob->fetch(out);
+    const auto t6 = clk::now();
+    if (rc != CASIM_OK) set_err(rc, p->prob->error());
+    const std::string keep = g_err;
+    casim_problem_destroy(p);
+    g_err = keep;
+    const auto t7 = clk::now();
+    phase_ms_out[0] = ms(t0, t1); phase_ms_out[1] = ms(t1, t2); phase_ms_out[2] = ms(t2, t3); phase_ms_out[3] = ms(t3, t4);
+    phase_ms_out[4] = ms(t4, t5); phase_ms_out[5] = ms(t5, t6); phase_ms_out[6] = ms(t0, t7);
+    return rc;
+}
+
 int32_t casim_feasibility(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups, uint64_t* out_bits) {
     g_err.clear();
     if (!ctx || !groups || !out_bits) return set_err(CASIM_ERR_INVALID, "null argument");
@@ -271,6 +304,11 @@ int32_t casim_best_option(casim_problem* p, const int32_t* kinds, int32_t n_kind
                           int32_t* n_best_out, uint8_t* best_set_out, int64_t* key_out, void* dev_key_out) {
     PROB_ENTER(p);
     PROB_RET(p, p->prob->best_option(kinds, n_kinds, group_id_base, best_ng_out, n_best_out, best_set_out, key_out, dev_key_out));
+}
+
+int32_t casim_best_option_sims(casim_problem* p, const casim_option_query* q) {
+    PROB_ENTER(p);
+    PROB_RET(p, p->prob->best_option_query(q));
 }
 
 // ---- measurement -----------------------------------------------------------------------------

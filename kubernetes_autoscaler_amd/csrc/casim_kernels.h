@@ -106,13 +106,15 @@ CS_DEVICE bool fits_fresh_node(const DevTables& t, int g, int ng) {
     return true;
 }
 
+// Bit k of row ng stands for PEG peg_lo[ng] + k: a group only ever sees the PEGs of its own simulation.
 CS_GLOBAL void feas_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg]*/, int Wg) {
     const int ng = cs::bid_y();
-    const int g = cs::bid() * cs::nthreads() + cs::tid();
-    bool ok = false;
-    if (g < t.G) ok = fits_fresh_node(t, g, ng);
+    const int k = cs::bid() * cs::nthreads() + cs::tid();
+    const int lo = t.peg_lo[ng], hi = t.peg_hi[ng];
+    bool ok = false;   // (a block beyond the group's range still clears its words)
+    if (lo + k < hi) ok = fits_fresh_node(t, lo + k, ng);
     const uint64_t b = cs::ballot(ok);
-    if (cs::lane() == 0 && (g >> 6) < Wg) bits[(int64_t)ng * Wg + (g >> 6)] = b;
+    if (cs::lane() == 0 && (k >> 6) < Wg) bits[(int64_t)ng * Wg + (k >> 6)] = b;
 }
 
 // K_csr_count: nnz per group; one block (256 threads) per group.
@@ -131,20 +133,39 @@ CS_GLOBAL void csr_count_kernel(const uint64_t* CS_RESTRICT bits, int Wg, int32_
         counts[ng] = (int32_t)s;
     }
 }
-// K_csr_scan: exclusive scan of counts -> offsets[NG+1]; single block, serial chunks per thread.
+// K_csr_scan: exclusive scan of counts -> offsets[NG+1]; single block: every thread owns a contiguous chunk, the chunk sums
+// are scanned per wave (log-step lane exchange) and across waves through LDS (dyn smem: 4 B per wave).  A batch of
+// thousands of simulations has tens of thousands of groups: a one-thread scan would cost milliseconds.
 CS_GLOBAL void csr_scan_kernel(const int32_t* CS_RESTRICT counts, int NG, int32_t* CS_RESTRICT offsets) {
-    // NG is small (<= a few thousand): one thread scans; launch-latency bound either way.
-    if (cs::bid() == 0 && cs::tid() == 0) {
-        int32_t s = 0;
-        for (int i = 0; i < NG; ++i) { offsets[i] = s; s += counts[i]; }
-        offsets[NG] = s;
+    const int tid = cs::tid(), nt = cs::nthreads(), lane = cs::lane(), wave = tid >> 6, nw = (nt + 63) >> 6;
+    const int chunk = (NG + nt - 1) / nt;
+    const int a = tid * chunk < NG ? tid * chunk : NG, b = a + chunk < NG ? a + chunk : NG;
+    uint32_t mine = 0;
+    for (int i = a; i < b; ++i) mine += (uint32_t)counts[i];
+    uint32_t incl = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)cs::readlane_u64(incl, lane >= d ? lane - d : lane);
+        if (lane >= d) incl += o;
+    }
+    uint32_t* sm = (uint32_t*)cs::dyn_smem();   // [nw]
+    if (lane == 63) sm[wave] = incl;
+    cs::sync();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += sm[w];
+    int32_t s = (int32_t)(base + incl - mine);
+    for (int i = a; i < b; ++i) { offsets[i] = s; s += counts[i]; }
+    if (tid == nt - 1) {
+        uint32_t tot = 0;
+        for (int w = 0; w < nw; ++w) tot += sm[w];
+        offsets[NG] = (int32_t)tot;
     }
 }
 // K_csr_fill: PEG ids of each group in ascending order; one wave per group, 64 words per step.
 CS_GLOBAL void csr_fill_kernel(const uint64_t* CS_RESTRICT bits, int Wg, const int32_t* CS_RESTRICT offsets,
-                               int32_t* CS_RESTRICT idx) {
+                               int32_t* CS_RESTRICT idx, const int32_t* CS_RESTRICT peg_lo) {
     const int ng = cs::bid();
     const int lane = cs::lane();
+    const int lo = peg_lo[ng];
     int32_t base = offsets[ng];
     for (int w0 = 0; w0 < Wg; w0 += 64) {
         const int w = w0 + lane;
@@ -160,7 +181,7 @@ CS_GLOBAL void csr_fill_kernel(const uint64_t* CS_RESTRICT bits, int Wg, const i
         while (word) {
             const int b = cs::ffs64(word);
             word &= word - 1;
-            idx[pos++] = w * 64 + b;
+            idx[pos++] = lo + w * 64 + b;
         }
         base += (int32_t)cs::readlane_u64(incl, 63);
     }
@@ -297,9 +318,13 @@ struct OptionArgs {
     int32_t NG;
     int32_t kinds[8]; int32_t n_kinds;
     int32_t group_id_base;
+    const int32_t* global_id;  // [NG] or null = group_id_base + index
+    const int32_t* sim_off;    // [n blocks + 1] groups of each simulation (one block per simulation), or null = one block over [0, NG)
+    uint8_t* valid;            // [NG] or null: 1 = the option may compete (all-or-nothing filter, orchestrator.go:1057-1063)
     uint8_t* best_set;      // [NG] out
-    int32_t* out;           // [2]: best index (local), survivors
-    int64_t* key_out;       // [10]: key block of the winner (see option_kernel)
+    int32_t* out;           // [n blocks][2]: best index (within the launch), survivors
+    int64_t* key_out;       // [n blocks][10]: key block of the winner (see option_kernel)
+    int64_t* packed_out;    // [n blocks] or null: key_out[.][0] gathered, the operand of ONE all-reduce(min) over every simulation
 };
 
 CS_DEVICE uint64_t option_metric(const OptionArgs& a, int kind, int i) {
@@ -319,13 +344,17 @@ CS_DEVICE uint64_t option_metric(const OptionArgs& a, int kind, int i) {
 CS_GLOBAL void option_kernel(OptionArgs a) {
     const int tid = cs::tid(), nt = cs::nthreads();
     uint64_t* red = (uint64_t*)cs::dyn_smem();  // [nt]
+    // one block = one simulation: its groups are [g0, g1)
+    const int sim = cs::bid();
+    const int g0 = a.sim_off ? a.sim_off[sim] : 0, g1 = a.sim_off ? a.sim_off[sim + 1] : a.NG;
+    a.out += 2 * sim; a.key_out += 10 * sim;
     // valid options: something was scheduled on at least one node (orchestrator.go:1057-1063)
-    for (int i = tid; i < a.NG; i += nt)
-        a.best_set[i] = (a.status[i] == CASIM_NG_OK && a.node_count[i] > 0 && a.pods[i] > 0) ? 1 : 0;
+    for (int i = g0 + tid; i < g1; i += nt)
+        a.best_set[i] = (a.status[i] == CASIM_NG_OK && a.node_count[i] > 0 && a.pods[i] > 0 && (!a.valid || a.valid[i])) ? 1 : 0;
     cs::sync();
     for (int f = 0; f < a.n_kinds; ++f) {
         uint64_t mine = ~0ull;
-        for (int i = tid; i < a.NG; i += nt)
+        for (int i = g0 + tid; i < g1; i += nt)
             if (a.best_set[i]) { const uint64_t m = option_metric(a, a.kinds[f], i); mine = m < mine ? m : mine; }
         red[tid] = mine;
         cs::sync();
@@ -335,12 +364,12 @@ CS_GLOBAL void option_kernel(OptionArgs a) {
         }
         const uint64_t best = red[0];
         cs::sync();
-        for (int i = tid; i < a.NG; i += nt)
+        for (int i = g0 + tid; i < g1; i += nt)
             if (a.best_set[i] && option_metric(a, a.kinds[f], i) != best) a.best_set[i] = 0;
         cs::sync();
         // survivors
         uint32_t sv = 0;
-        for (int i = tid; i < a.NG; i += nt) sv += a.best_set[i];
+        for (int i = g0 + tid; i < g1; i += nt) sv += a.best_set[i];
         red[tid] = sv;
         cs::sync();
         for (int s = nt >> 1; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; cs::sync(); }
@@ -350,7 +379,7 @@ CS_GLOBAL void option_kernel(OptionArgs a) {
     }
     // lowest surviving index + count
     uint64_t first = ~0ull; uint32_t sv = 0;
-    for (int i = tid; i < a.NG; i += nt) if (a.best_set[i]) { if ((uint64_t)i < first) first = (uint64_t)i; sv++; }
+    for (int i = g0 + tid; i < g1; i += nt) if (a.best_set[i]) { if ((uint64_t)i < first) first = (uint64_t)i; sv++; }
     red[tid] = first;
     cs::sync();
     for (int s = nt >> 1; s > 0; s >>= 1) { if (tid < s && red[tid + s] < red[tid]) red[tid] = red[tid + s]; cs::sync(); }
@@ -373,7 +402,7 @@ CS_GLOBAL void option_kernel(OptionArgs a) {
         if (bi != ~0ull) {
             for (int f = 0; f < a.n_kinds; ++f)
                 a.key_out[1 + f] = (int64_t)(option_metric(a, a.kinds[f], (int)bi) ^ 0x8000000000000000ull);
-            const int64_t gid = (int64_t)a.group_id_base + (int64_t)bi;
+            const int64_t gid = a.global_id ? (int64_t)a.global_id[bi] : (int64_t)a.group_id_base + (int64_t)bi;
             a.key_out[9] = gid;
             if (a.n_kinds > 0) {
                 uint64_t m = option_metric(a, a.kinds[0], (int)bi);
@@ -381,6 +410,7 @@ CS_GLOBAL void option_kernel(OptionArgs a) {
                 a.key_out[0] = (int64_t)((m << 20) | (uint64_t)(gid & 0xfffff));
             } else a.key_out[0] = gid;
         }
+        if (a.packed_out) a.packed_out[sim] = a.key_out[0];
     }
 }
 

@@ -75,6 +75,19 @@ public:
         dt_.cap_cpu = g->cap_cpu ? up(g->cap_cpu, NG) : nullptr; dt_.cap_mem = g->cap_mem ? up(g->cap_mem, NG) : nullptr;
         dt_.waste_cpu = g->waste_cpu ? up(g->waste_cpu, NG) : nullptr; dt_.waste_mem = g->waste_mem ? up(g->waste_mem, NG) : nullptr;
 
+        // ---- simulations of the batch (expander reduce per simulation) ----
+        n_sims_ = 0;
+        if (g->n_sims > 0) {
+            if (!g->sim_offsets || g->sim_offsets[0] != 0 || g->sim_offsets[g->n_sims] != NG_) return fail(CASIM_ERR_INVALID, "sim_offsets must run from 0 to n_groups");
+            for (int32_t i = 0; i < g->n_sims; ++i) {
+                if (g->sim_offsets[i + 1] < g->sim_offsets[i]) return fail(CASIM_ERR_INVALID, "sim_offsets not monotone");
+                const int32_t len = g->sim_offsets[i + 1] - g->sim_offsets[i];
+                max_sim_groups_ = len > max_sim_groups_ ? len : max_sim_groups_;
+            }
+            n_sims_ = g->n_sims;
+            dt_.sim_off = up(g->sim_offsets, (size_t)n_sims_ + 1); dt_.n_sims = n_sims_;
+        }
+        dt_.global_id = g->global_id ? up(g->global_id, NG) : nullptr;
         // ---- schedulable subsets ----
         csr_on_device_ = g->peg_offsets == nullptr;
         std::vector<int64_t> pods_of_group(NG, 0);  // sum of max(count, 1) over the group's PEGs (node bound)
@@ -97,14 +110,24 @@ public:
             dt_.peg_off = up(g->peg_offsets, NG + 1);
             dt_.peg_idx = up(g->peg_index, (size_t)nnz_cap_);
         } else {
-            const int64_t cap = (int64_t)G_ * (int64_t)NG_;
-            if (cap > 0x7fffffffll) return fail(CASIM_ERR_INVALID, "G x NG too large for device-side CSR");
-            nnz_cap_ = (int32_t)cap;
-            int64_t all = 0;
-            for (size_t i = 0; i < G; ++i) { if (p->count[i] < 0) return fail(CASIM_ERR_INVALID, "negative PEG count"); all += p->count[i] > 1 ? p->count[i] : 1; }
-            for (size_t i = 0; i < NG; ++i) { pods_of_group[i] = all; pegs_of_group[i] = G_; }
-            Wg_ = (G_ + 63) / 64;
-            d_bits_ = (uint64_t*)dalloc(sizeof(uint64_t) * NG * (size_t)Wg_);
+            // candidate range of every group: its simulation's PEGs (peg_lo / peg_hi) or all of them
+            if ((g->peg_lo == nullptr) != (g->peg_hi == nullptr)) return fail(CASIM_ERR_INVALID, "peg_lo and peg_hi go together");
+            std::vector<int32_t> lo(NG, 0), hi(NG, G_);
+            std::vector<int64_t> pre(G + 1, 0);   // prefix sums of max(count, 1)
+            for (size_t i = 0; i < G; ++i) { if (p->count[i] < 0) return fail(CASIM_ERR_INVALID, "negative PEG count"); pre[i + 1] = pre[i] + (p->count[i] > 1 ? p->count[i] : 1); }
+            int64_t cap = 0; int32_t lmax = 0;
+            for (size_t i = 0; i < NG; ++i) {
+                if (g->peg_lo) { lo[i] = g->peg_lo[i]; hi[i] = g->peg_hi[i]; }
+                if (lo[i] < 0 || hi[i] < lo[i] || hi[i] > G_) return fail(CASIM_ERR_INVALID, "peg_lo / peg_hi out of range");
+                pegs_of_group[i] = hi[i] - lo[i]; pods_of_group[i] = pre[(size_t)hi[i]] - pre[(size_t)lo[i]];
+                cap += pegs_of_group[i]; lmax = pegs_of_group[i] > lmax ? pegs_of_group[i] : lmax;
+            }
+            if (cap > 0x7fffffffll) return fail(CASIM_ERR_INVALID, "sum of candidate PEG ranges too large for device-side CSR");
+            nnz_cap_ = (int32_t)cap; feas_len_ = lmax;
+            Wg_ = (lmax + 63) / 64;
+            dt_.peg_lo = up(lo.data(), NG); dt_.peg_hi = up(hi.data(), NG);
+            bk_.sync();  // lo / hi die at the end of this scope
+            d_bits_ = (uint64_t*)dalloc(sizeof(uint64_t) * NG * (size_t)(Wg_ > 0 ? Wg_ : 1));
             d_counts_ = (int32_t*)dalloc(sizeof(int32_t) * (NG + 1));
             d_off_ = (int32_t*)dalloc(sizeof(int32_t) * (NG + 1));
             d_idx_ = (int32_t*)dalloc(sizeof(int32_t) * (size_t)nnz_cap_);
@@ -203,6 +226,8 @@ public:
         d_opt_set_ = (uint8_t*)dalloc(NG);
         d_opt_out_ = (int32_t*)dalloc(16);
         d_opt_key_ = (int64_t*)dalloc(80);
+        d_opt_packed_ = (int64_t*)dalloc(8);
+        opt_cap_ = 1;
         bk_.sync();  // every staging buffer (caller tables, local vectors) may be released after init()
         if (!bk_.ok()) return fail(CASIM_ERR_HIP, bk_.error());
         ready_ = true;
@@ -212,10 +237,12 @@ public:
     // ---- launch sequence ----------------------------------------------------------------
     int32_t run_feasibility() {
         if (!csr_on_device_ || NG_ == 0) return CASIM_OK;
-        if (G_ > 0) bk_.launch(feas_kernel, (G_ + 255) / 256, NG_, 256, (size_t)0, dt_, d_bits_, Wg_);
-        bk_.launch(csr_count_kernel, NG_, 1, 256, (size_t)64, (const uint64_t*)d_bits_, Wg_, d_counts_);
-        bk_.launch(csr_scan_kernel, 1, 1, 64, (size_t)0, (const int32_t*)d_counts_, NG_, d_off_);
-        bk_.launch(csr_fill_kernel, NG_, 1, 64, (size_t)0, (const uint64_t*)d_bits_, Wg_, (const int32_t*)d_off_, d_idx_);
+        if (feas_len_ > 0) bk_.launch(feas_kernel, (feas_len_ + 255) / 256, NG_, 256, (size_t)0, dt_, d_bits_, Wg_);
+        // one wave per group counts when the rows are short (a simulation's few hundred PEGs), a whole block otherwise
+        bk_.launch(csr_count_kernel, NG_, 1, Wg_ <= 64 ? 64 : 256, (size_t)64, (const uint64_t*)d_bits_, Wg_, d_counts_);
+        const int scan_threads = NG_ <= 64 ? 64 : (NG_ <= 4096 ? 256 : 1024);
+        bk_.launch(csr_scan_kernel, 1, 1, scan_threads, (size_t)(4 * ((scan_threads + 63) / 64)), (const int32_t*)d_counts_, NG_, d_off_);
+        bk_.launch(csr_fill_kernel, NG_, 1, 64, (size_t)0, (const uint64_t*)d_bits_, Wg_, (const int32_t*)d_off_, d_idx_, dt_.peg_lo);
         return CASIM_OK;
     }
     int32_t run_order() {
@@ -258,6 +285,9 @@ public:
         ran_ = true;
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
     }
+
+    // the kernels were enqueued phase by phase (timed callers): results may be fetched
+    int32_t run_mark() { if (!ready_) return fail(CASIM_ERR_INVALID, "problem not initialised"); ran_ = true; return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error()); }
 
     int32_t csr(int32_t* nnz_out, int32_t* offsets_out) {
         if (!ready_) return fail(CASIM_ERR_INVALID, "problem not initialised");
@@ -316,34 +346,63 @@ public:
 
     int32_t best_option(const int32_t* kinds, int32_t n_kinds, int32_t group_id_base, int32_t* best_ng_out, int32_t* n_best_out,
                         uint8_t* best_set_out, int64_t* key_out, void* dev_key_out) {
+        casim_option_query q; memset(&q, 0, sizeof q);
+        q.kinds = kinds; q.n_kinds = n_kinds; q.group_id_base = group_id_base; q.best_out = best_ng_out; q.n_best_out = n_best_out;
+        q.best_set_out = best_set_out; q.key_out = key_out; q.dev_key_out = dev_key_out;
+        return best_option_query(&q);
+    }
+
+    // The expander chain over the options of the last run: one reduce over every group, or (per_sim) one per simulation
+    // of the batch — one workgroup each, every simulation's winner packed into ONE int64 so that a single
+    // all-reduce(min) over [S] keys settles all of them across GPUs.
+    int32_t best_option_query(const casim_option_query* q) {
         if (!ready_ || !ran_) return fail(CASIM_ERR_INVALID, "run the problem first");
-        if (n_kinds < 0 || n_kinds > 8 || (n_kinds > 0 && !kinds)) return fail(CASIM_ERR_INVALID, "bad expander chain");
+        if (!q) return fail(CASIM_ERR_INVALID, "null query");
+        const int32_t n_kinds = q->n_kinds;
+        if (n_kinds < 0 || n_kinds > 8 || (n_kinds > 0 && !q->kinds)) return fail(CASIM_ERR_INVALID, "bad expander chain");
+        const bool per_sim = q->per_sim != 0 && n_sims_ > 0;
+        const int S = per_sim ? n_sims_ : 1;
         OptionArgs a; memset(&a, 0, sizeof a);
         a.node_count = dr_.node_count; a.pods = dr_.pods; a.status = dr_.status; a.cpu_sum = dr_.cpu_sum; a.mem_sum = dr_.mem_sum;
-        a.waste_cpu = dt_.waste_cpu; a.waste_mem = dt_.waste_mem; a.NG = NG_; a.n_kinds = n_kinds; a.group_id_base = group_id_base;
+        a.waste_cpu = dt_.waste_cpu; a.waste_mem = dt_.waste_mem; a.NG = NG_; a.n_kinds = n_kinds; a.group_id_base = q->group_id_base;
+        a.global_id = dt_.global_id; a.sim_off = per_sim ? dt_.sim_off : nullptr;
         for (int i = 0; i < n_kinds; ++i) {
-            a.kinds[i] = kinds[i];
-            if (kinds[i] < 0 || kinds[i] > 2) return fail(CASIM_ERR_INVALID, "unknown expander kind");
-            if (kinds[i] == CASIM_EXPANDER_LEAST_WASTE && (!dt_.waste_cpu || !dt_.waste_mem)) return fail(CASIM_ERR_INVALID, "least-waste needs waste_cpu/waste_mem");
+            a.kinds[i] = q->kinds[i];
+            if (q->kinds[i] < 0 || q->kinds[i] > 2) return fail(CASIM_ERR_INVALID, "unknown expander kind");
+            if (q->kinds[i] == CASIM_EXPANDER_LEAST_WASTE && (!dt_.waste_cpu || !dt_.waste_mem)) return fail(CASIM_ERR_INVALID, "least-waste needs waste_cpu/waste_mem");
         }
-        a.best_set = d_opt_set_; a.out = d_opt_out_; a.key_out = dev_key_out ? (int64_t*)dev_key_out : d_opt_key_;
-        // one block walks all groups: with thousands of them (batched simulations) 1024 threads, not 256 — the kernel was
-        // 0.106 ms of a 1.0 ms step at NG = 16384 (profiles/r01u_rocpd_summary.txt)
-        const int opt_threads = NG_ > 1024 ? 1024 : 256;
-        bk_.launch(option_kernel, 1, 1, opt_threads, (size_t)(8 * opt_threads), a);
-        if (best_ng_out || n_best_out || best_set_out || key_out) {
-            int32_t o[2] = {-1, 0};
-            bk_.d2h(o, d_opt_out_, 8);
-            if (best_set_out) bk_.d2h(best_set_out, d_opt_set_, (size_t)NG_);
-            int64_t kk[10] = {0};
-            if (key_out) bk_.d2h(kk, a.key_out, 80);
+        if (q->valid) {
+            if (!d_opt_valid_) d_opt_valid_ = (uint8_t*)dalloc((size_t)NG_);
+            bk_.h2d(d_opt_valid_, q->valid, (size_t)NG_);
+            a.valid = d_opt_valid_;
+        }
+        if ((size_t)S > opt_cap_) {   // per-simulation result blocks (allocated on first use, kept)
+            d_opt_out_ = (int32_t*)dalloc(8 * (size_t)S); d_opt_key_ = (int64_t*)dalloc(80 * (size_t)S); d_opt_packed_ = (int64_t*)dalloc(8 * (size_t)S);
+            opt_cap_ = (size_t)S;
+        }
+        a.best_set = d_opt_set_; a.out = d_opt_out_; a.key_out = q->dev_key_out ? (int64_t*)q->dev_key_out : d_opt_key_;
+        a.packed_out = q->dev_packed_out ? (int64_t*)q->dev_packed_out : d_opt_packed_;
+        // one block walks the groups of one simulation: with thousands of them in ONE simulation (batched C1) 1024 threads —
+        // the kernel was 0.106 ms of a 1.0 ms step at NG = 16384 (profiles/r01u_rocpd_summary.txt); a simulation of a
+        // batch has tens of groups: one wave
+        const int span = per_sim ? max_sim_groups_ : NG_;
+        const int opt_threads = span > 1024 ? 1024 : (span > 64 ? 256 : 64);
+        bk_.launch(option_kernel, S, 1, opt_threads, (size_t)(8 * opt_threads), a);
+        if (q->best_out || q->n_best_out || q->best_set_out || q->key_out || q->packed_out) {
+            std::vector<int32_t> o(2 * (size_t)S);
+            bk_.d2h(o.data(), d_opt_out_, 8 * (size_t)S);
+            if (q->best_set_out) bk_.d2h(q->best_set_out, d_opt_set_, (size_t)NG_);
+            if (q->key_out) bk_.d2h(q->key_out, a.key_out, 80 * (size_t)S);
+            if (q->packed_out) bk_.d2h(q->packed_out, a.packed_out, 8 * (size_t)S);
             bk_.sync();
-            if (best_ng_out) *best_ng_out = o[0];
-            if (n_best_out) *n_best_out = o[1];
-            if (key_out) for (int i = 0; i < 10; ++i) key_out[i] = kk[i];
+            for (int i = 0; i < S; ++i) {
+                if (q->best_out) q->best_out[i] = o[2 * (size_t)i];
+                if (q->n_best_out) q->n_best_out[i] = o[2 * (size_t)i + 1];
+            }
         }
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
     }
+    int sims() const { return n_sims_; }
 
     const std::string& error() const { return err_; }
     BK& backend() { return bk_; }
@@ -385,7 +444,9 @@ private:
     size_t pack_smem_ = 0, order_smem_ = 0;
     int order_threads_ = kOrderThreads;
     uint64_t* d_bits_ = nullptr; int32_t* d_counts_ = nullptr; int32_t* d_off_ = nullptr; int32_t* d_idx_ = nullptr;
-    uint8_t* d_opt_set_ = nullptr; int32_t* d_opt_out_ = nullptr; int64_t* d_opt_key_ = nullptr;
+    uint8_t* d_opt_set_ = nullptr; int32_t* d_opt_out_ = nullptr; int64_t* d_opt_key_ = nullptr; int64_t* d_opt_packed_ = nullptr;
+    uint8_t* d_opt_valid_ = nullptr; size_t opt_cap_ = 0;
+    int n_sims_ = 0, max_sim_groups_ = 0, feas_len_ = 0;
     std::vector<int32_t> h_off_;
     std::vector<void*> allocs_;
     std::string err_;

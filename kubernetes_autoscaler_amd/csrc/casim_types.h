@@ -41,6 +41,12 @@ struct DevTables {
     // schedulable subsets (CSR), device memory
     const int32_t* peg_off;   // [NG+1]
     const int32_t* peg_idx;   // [nnz]
+    // candidate PEG range of each group (device-side CSR only): its simulation's PEGs, [0, G) without batching
+    const int32_t* peg_lo;    // [NG]
+    const int32_t* peg_hi;    // [NG]
+    const int32_t* global_id; // [NG] id of the group inside expander keys, or null = group_id_base + index
+    const int32_t* sim_off;   // [n_sims + 1] groups of each simulation, or null = one simulation
+    int32_t n_sims;
 };
 
 struct DevResults {

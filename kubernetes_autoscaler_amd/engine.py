@@ -310,6 +310,35 @@ class Problem:
                                     C.c_void_p(dev_key_ptr) if dev_key_ptr else None), "casim_best_option")
         return int(best.value), int(nbest.value), bset[:self.n_groups], key
 
+    def best_option_sims(self, kinds: Sequence[int], per_sim: bool = True, valid=None, group_id_base: int = 0,
+                         dev_packed_ptr: Optional[int] = None, fetch: bool = True, n_sims: Optional[int] = None):
+        """casim_best_option_sims: the expander chain once per simulation of the batch (or once over every group), with an
+        optional validity mask (all-or-nothing).  fetch=False only enqueues the kernel (the packed keys land in
+        dev_packed_ptr for an RCCL all-reduce).  Returns dict(best, n_best, best_set, keys, packed) when fetching."""
+        ks = (C.c_int32 * max(len(kinds), 1))(*kinds)
+        S = (n_sims if n_sims else 1) if per_sim else 1
+        q = _abi.OptionQuery(kinds=ks, n_kinds=len(kinds), group_id_base=int(group_id_base), per_sim=int(bool(per_sim)))
+        keep = [ks]
+        if valid is not None:
+            v = np.ascontiguousarray(valid, np.uint8)
+            if v.shape[0] != self.n_groups:
+                raise ValueError("valid must have one entry per group")
+            q.valid = _ptr(v, C.c_uint8); keep.append(v)
+        if dev_packed_ptr:
+            q.dev_packed_out = C.c_void_p(dev_packed_ptr)
+        out = None
+        if fetch:
+            out = dict(best=np.full(S, -1, np.int32), n_best=np.zeros(S, np.int32), best_set=np.zeros(max(self.n_groups, 1), np.uint8),
+                       keys=np.zeros((S, 10), np.int64), packed=np.zeros(S, np.int64))
+            q.best_out = _ptr(out["best"], C.c_int32); q.n_best_out = _ptr(out["n_best"], C.c_int32)
+            q.best_set_out = _ptr(out["best_set"], C.c_uint8); q.key_out = _ptr(out["keys"], C.c_int64)
+            q.packed_out = _ptr(out["packed"], C.c_int64)
+        check(lib.casim_best_option_sims(self._h, C.byref(q)), "casim_best_option_sims")
+        del keep
+        if out is not None:
+            out["best_set"] = out["best_set"][:self.n_groups]
+        return out
+
     def best_option_device(self, kinds: Sequence[int], group_id_base: int, dev_key_ptr: int):
         """Asynchronous form: only writes the 10-int64 key block into device memory (for the RCCL reduce)."""
         ks = (C.c_int32 * max(len(kinds), 1))(*kinds)
@@ -338,6 +367,34 @@ class Problem:
         nr, nc = C.c_int64(0), C.c_int64(0)
         check(lib.casim_problem_time_dense(self._h, int(col_repeat), int(iters), C.byref(ms), C.byref(nr), C.byref(nc)), "time_dense")
         return float(ms.value), int(nr.value), int(nc.value)
+
+
+def estimate_batch_timed(ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, kinds: Optional[Sequence[int]] = None, fastpath: bool = False,
+                         nnz_cap: Optional[int] = None):
+    """casim_estimate_batch_timed: one whole call (tables -> HBM -> kernels -> results) with its phase breakdown.
+    Returns (results dict of arrays, phases dict in ms, expander dict or None)."""
+    ng = groups.n_groups
+    if nnz_cap is None:
+        if groups.peg_offsets:
+            nnz_cap = int(groups.peg_offsets[ng]) if ng else 0
+        elif groups.peg_lo:
+            nnz_cap = int(sum(groups.peg_hi[i] - groups.peg_lo[i] for i in range(ng)))
+        else:
+            nnz_cap = pegs.n_pegs * ng
+    st, arrs = alloc_results(ng, nnz_cap)
+    opts = _abi.Options(fastpath=int(fastpath))
+    ph = (C.c_double * 8)()
+    q = exp = None
+    if kinds is not None:
+        ks = (C.c_int32 * max(len(kinds), 1))(*kinds)
+        S = groups.n_sims if groups.n_sims > 0 else 1
+        exp = dict(best=np.full(S, -1, np.int32), n_best=np.zeros(S, np.int32), packed=np.zeros(S, np.int64))
+        q = _abi.OptionQuery(kinds=ks, n_kinds=len(kinds), per_sim=int(groups.n_sims > 0), best_out=_ptr(exp["best"], C.c_int32),
+                             n_best_out=_ptr(exp["n_best"], C.c_int32), packed_out=_ptr(exp["packed"], C.c_int64))
+    check(lib.casim_estimate_batch_timed(ctx._h, C.byref(pegs), C.byref(groups), C.byref(opts), C.byref(st),
+                                         C.byref(q) if q is not None else None, ph), "casim_estimate_batch_timed")
+    names = ("upload_ms", "feasibility_csr_ms", "order_ms", "pack_ms", "expander_ms", "fetch_ms", "wall_ms")
+    return arrs, {k: ph[i] for i, k in enumerate(names)}, exp
 
 
 def estimate_batch(ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, fastpath: bool = False) -> BatchResult:

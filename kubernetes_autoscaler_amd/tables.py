@@ -1,0 +1,173 @@
+"""Flat table sets (casim_pegs + casim_groups) as numpy arrays: slicing, tiling and sharding of encoded batches.
+
+The encoder hands out views into its own memory; a TableSet owns copies, so a batch can be re-shaped on the host
+without touching a single pod object again: B simulations tiled from S encoded ones (bench), the node groups of every
+simulation block-partitioned over the GPUs of a node, one simulation cut out of a batch (tests)."""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+
+_PEG_COLS = {  # name -> (dtype, width field or constant per record)
+    "req": (np.int64, "n_res"), "count": (np.int32, 1), "flags": (np.uint32, 1),
+    "tol_mask": (np.uint64, "w_taint"), "sel_mask": (np.uint64, "w_label"), "excl_block": (np.uint64, "w_excl"),
+    "excl_mark": (np.uint64, "w_excl"), "zone_block": (np.uint64, "w_zone"), "zone_mark": (np.uint64, "w_zone"),
+    "fp_cpu": (np.float64, 1), "fp_mem": (np.float64, 1),
+}
+_GROUP_COLS = {
+    "alloc": (np.int64, "n_res"), "init_req": (np.int64, "n_res"), "allowed_pods": (np.int32, 1), "init_pods": (np.int32, 1),
+    "flags": (np.uint32, 1), "taint_mask": (np.uint64, "w_taint"), "label_mask": (np.uint64, "w_label"),
+    "init_excl": (np.uint64, "w_excl"), "init_zone": (np.uint64, "w_zone"), "zone_valid": (np.uint64, "w_zone"),
+    "max_nodes": (np.int32, 1), "existing_nodes": (np.int32, 1), "last_index": (np.int32, 1),
+    "cap_cpu": (np.float64, 1), "cap_mem": (np.float64, 1), "waste_cpu": (np.int64, 1), "waste_mem": (np.int64, 1),
+}
+_CT = {np.int64: C.c_int64, np.int32: C.c_int32, np.uint32: C.c_uint32, np.uint64: C.c_uint64, np.float64: C.c_double, np.uint8: C.c_uint8}
+
+
+def _view(ptr, n, width, dtype):
+    if not ptr or n * width == 0:
+        return None
+    return np.ctypeslib.as_array(ptr, shape=(n * width,)).astype(dtype, copy=True).reshape(n, width)
+
+
+@dataclass
+class TableSet:
+    dims: Dict[str, int]                      # n_res, w_taint, w_label, w_excl, w_zone
+    pegs: Dict[str, Optional[np.ndarray]]     # [G][width] per column
+    groups: Dict[str, Optional[np.ndarray]]   # [NG][width] per column
+    peg_lo: Optional[np.ndarray] = None       # [NG] candidate PEG range of each group (device-side subsets)
+    peg_hi: Optional[np.ndarray] = None
+    peg_offsets: Optional[np.ndarray] = None  # explicit per-group PEG lists (host-side subsets)
+    peg_index: Optional[np.ndarray] = None
+    global_id: Optional[np.ndarray] = None    # [NG]
+    sim_offsets: Optional[np.ndarray] = None  # [S+1]
+    _keep: List[object] = field(default_factory=list)
+
+    # ---- construction ---------------------------------------------------------------------------
+    @classmethod
+    def from_structs(cls, pegs: _abi.Pegs, groups: _abi.Groups) -> "TableSet":
+        dims = {k: int(getattr(pegs, k)) for k in ("n_res", "w_taint", "w_label", "w_excl", "w_zone")}
+        G, NG = pegs.n_pegs, groups.n_groups
+        w = lambda spec: dims[spec] if isinstance(spec, str) else spec
+        pc = {k: _view(getattr(pegs, k), G, w(wd), dt) for k, (dt, wd) in _PEG_COLS.items()}
+        gc = {k: _view(getattr(groups, k), NG, w(wd), dt) for k, (dt, wd) in _GROUP_COLS.items()}
+        ts = cls(dims, pc, gc)
+        if groups.peg_offsets:
+            ts.peg_offsets = np.ctypeslib.as_array(groups.peg_offsets, shape=(NG + 1,)).astype(np.int32, copy=True)
+            nnz = int(ts.peg_offsets[NG]) if NG else 0
+            ts.peg_index = (np.ctypeslib.as_array(groups.peg_index, shape=(nnz,)).astype(np.int32, copy=True) if nnz
+                            else np.zeros(0, np.int32))
+        if groups.peg_lo:
+            ts.peg_lo = np.ctypeslib.as_array(groups.peg_lo, shape=(NG,)).astype(np.int32, copy=True)
+            ts.peg_hi = np.ctypeslib.as_array(groups.peg_hi, shape=(NG,)).astype(np.int32, copy=True)
+        if groups.global_id:
+            ts.global_id = np.ctypeslib.as_array(groups.global_id, shape=(NG,)).astype(np.int32, copy=True)
+        if groups.n_sims > 0:
+            ts.sim_offsets = np.ctypeslib.as_array(groups.sim_offsets, shape=(groups.n_sims + 1,)).astype(np.int32, copy=True)
+        return ts
+
+    @classmethod
+    def from_encoder(cls, enc) -> "TableSet":
+        return cls.from_structs(enc.pegs, enc.groups)
+
+    @property
+    def n_pegs(self) -> int:
+        return int(self.pegs["count"].shape[0]) if self.pegs["count"] is not None else 0
+
+    @property
+    def n_groups(self) -> int:
+        return int(self.groups["max_nodes"].shape[0]) if self.groups["max_nodes"] is not None else 0
+
+    @property
+    def n_sims(self) -> int:
+        return 0 if self.sim_offsets is None else len(self.sim_offsets) - 1
+
+    # ---- re-shaping -----------------------------------------------------------------------------
+    def as_one_simulation(self) -> "TableSet":
+        """Every group sees every PEG (device-side subsets) and the whole set is one simulation."""
+        G, NG = self.n_pegs, self.n_groups
+        return TableSet(self.dims, self.pegs, self.groups, np.zeros(NG, np.int32), np.full(NG, G, np.int32), None, None,
+                        np.arange(NG, dtype=np.int32), np.array([0, NG], np.int32))
+
+    @staticmethod
+    def concat(sets: Sequence["TableSet"]) -> "TableSet":
+        """Independent simulations side by side: PEG ids and group ids are shifted, every group keeps seeing only its own
+        simulation's PEGs.  All sets must share the dictionaries (same encoder) or at least the mask widths."""
+        d = sets[0].dims
+        if any(s.dims != d for s in sets):
+            raise ValueError("table sets with different lane / mask widths cannot share one batch")
+        cat = lambda cols: None if cols[0] is None else np.concatenate(cols, axis=0)
+        pc = {k: cat([s.pegs[k] for s in sets]) for k in _PEG_COLS}
+        gc = {k: cat([s.groups[k] for s in sets]) for k in _GROUP_COLS}
+        lo, hi, gid, so = [], [], [], [0]
+        pbase = gbase = 0
+        for s in sets:
+            one = s if s.peg_lo is not None else s.as_one_simulation()
+            lo.append(one.peg_lo + pbase); hi.append(one.peg_hi + pbase)
+            gid.append((one.global_id if one.global_id is not None else np.arange(s.n_groups, dtype=np.int32)))
+            offs = one.sim_offsets if one.sim_offsets is not None else np.array([0, s.n_groups], np.int32)
+            so.extend((offs[1:] + gbase).tolist())
+            pbase += s.n_pegs; gbase += s.n_groups
+        return TableSet(d, pc, gc, np.concatenate(lo).astype(np.int32), np.concatenate(hi).astype(np.int32), None, None,
+                        np.concatenate(gid).astype(np.int32), np.array(so, np.int32))
+
+    def tile(self, times: int) -> "TableSet":
+        """The batch repeated `times` times (distinct memory, same simulations)."""
+        return TableSet.concat([self] * times) if times > 1 else self
+
+    def select_groups(self, keep: np.ndarray) -> "TableSet":
+        """The groups `keep` (ascending indices) of every simulation: how one GPU's shard of a batch is cut out.  PEG table
+        replicated, the groups keep their simulation-wide ids in expander keys."""
+        keep = np.asarray(keep, np.int64)
+        one = self if self.peg_lo is not None else self.as_one_simulation()
+        gc = {k: (None if v is None else v[keep]) for k, v in one.groups.items()}
+        so = np.searchsorted(keep, one.sim_offsets, side="left").astype(np.int32)
+        gid = one.global_id if one.global_id is not None else np.arange(one.n_groups, dtype=np.int32)
+        return TableSet(one.dims, one.pegs, gc, one.peg_lo[keep], one.peg_hi[keep], None, None, gid[keep], so)
+
+    def shard(self, rank: int, world: int, rotate: bool = True) -> "TableSet":
+        """Node groups of every simulation block-partitioned over `world` GPUs.  With `rotate` the block
+        boundaries of simulation s start at rank s % world, so that group counts which do not divide evenly (20 groups on
+        8 GPUs) still balance over a batch."""
+        one = self if self.peg_lo is not None else self.as_one_simulation()
+        keep = []
+        for s in range(one.n_sims):
+            a, b = int(one.sim_offsets[s]), int(one.sim_offsets[s + 1])
+            n = b - a
+            r = (rank + (s if rotate else 0)) % world
+            lo, hi = (n * r) // world, (n * (r + 1)) // world
+            keep.extend(range(a + lo, a + hi))
+        return one.select_groups(np.array(keep, np.int64))
+
+    # ---- ctypes ---------------------------------------------------------------------------------
+    def structs(self):
+        """(casim_pegs, casim_groups) over this set's arrays; the set must outlive every use of the structs."""
+        keep = []
+
+        def ptr(a, dt):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dt)
+            keep.append(a)
+            return a.ctypes.data_as(C.POINTER(_CT[dt]))
+        p = _abi.Pegs(n_pegs=self.n_pegs, **self.dims)
+        for k, (dt, _) in _PEG_COLS.items():
+            setattr(p, k, ptr(self.pegs[k], dt))
+        g = _abi.Groups(n_groups=self.n_groups)
+        for k, (dt, _) in _GROUP_COLS.items():
+            setattr(g, k, ptr(self.groups[k], dt))
+        if self.peg_offsets is not None:
+            g.peg_offsets = ptr(self.peg_offsets, np.int32)
+            g.peg_index = ptr(self.peg_index if self.peg_index.size else np.zeros(1, np.int32), np.int32)
+        elif self.peg_lo is not None:
+            g.peg_lo = ptr(self.peg_lo, np.int32); g.peg_hi = ptr(self.peg_hi, np.int32)
+        if self.global_id is not None:
+            g.global_id = ptr(self.global_id, np.int32)
+        if self.sim_offsets is not None:
+            g.n_sims = len(self.sim_offsets) - 1
+            g.sim_offsets = ptr(self.sim_offsets, np.int32)
+        self._keep = keep
+        return p, g

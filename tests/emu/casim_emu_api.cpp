@@ -53,6 +53,22 @@ EMU_API int32_t emu_estimate_batch(const casim_pegs* pegs, const casim_groups* g
     return rc;
 }
 
+// Same with the general expander query (validity mask, one reduce per simulation of the batch).
+EMU_API int32_t emu_estimate_batch_query(const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts,
+                                 casim_results* out, int64_t lds_budget_bytes, int32_t* nnz_out, int32_t* offsets_out,
+                                 const casim_option_query* q) {
+    EmuBackend bk;
+    if (lds_budget_bytes > 0) bk.lds = (size_t)lds_budget_bytes;
+    casim::ProblemT<EmuBackend> p(bk);
+    int32_t rc = p.init(pegs, groups, opts);
+    if (rc == CASIM_OK) rc = p.run();
+    if (rc == CASIM_OK) rc = p.fetch(out);
+    if (rc == CASIM_OK && (nnz_out || offsets_out)) rc = p.csr(nnz_out, offsets_out);
+    if (rc == CASIM_OK && q) rc = p.best_option_query(q);
+    if (rc != CASIM_OK) g_err = p.error();
+    return rc;
+}
+
 EMU_API int32_t emu_feasibility(const casim_pegs* pegs, const casim_groups* groups, uint64_t* out_bits) {
     EmuBackend bk;
     casim::ProblemT<EmuBackend> p(bk);

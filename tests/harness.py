@@ -404,3 +404,79 @@ def assert_cluster_estimate_matches(got, est: OracleEstimate, oracle_ids, what="
     g = (out["node_count"], out["pods_scheduled"], out["nodes_added"], out["limiter_nodes"], out["last_index_out"], out["req_cpu_sum"], out["req_mem_sum"])
     w = (est.node_count, est.pods_scheduled, est.nodes_added, est.limiter_nodes, est.last_index_out, est.req_cpu_sum, est.req_mem_sum)
     assert g == w, f"{what}: (nodes, pods, added, limiter, lastIndex, cpu, mem) got {g} want {w}"
+
+
+# ---------------------------------------------------------------------------------------------
+# batches of independent simulations (casim_groups.peg_lo / peg_hi / sim_offsets)
+# ---------------------------------------------------------------------------------------------
+def encode_batch(scenarios: Sequence[Scenario]):
+    """Several scenarios in ONE encoder (shared dictionaries), each group restricted to its own simulation's PEGs on the
+    device.  Returns (encoder, TableSet, [(peg base, group base)])."""
+    from kubernetes_autoscaler_amd.tables import TableSet
+    enc = Encoder(lanes=scenarios[0].lanes)
+    bases, lo, hi, so = [], [], [], [0]
+    pb = gb = 0
+    for sc in scenarios:
+        assert sc.device_csr and not sc.existing
+        for pg in sc.pegs:
+            enc.add_peg(pg)
+        for g in sc.groups:
+            enc.add_group(g.template, max_nodes=g.max_nodes, existing_nodes=0, last_index=g.last_index, pegs=None)
+            lo.append(pb); hi.append(pb + len(sc.pegs))
+        bases.append((pb, gb))
+        pb += len(sc.pegs); gb += len(sc.groups)
+        so.append(gb)
+    enc.finalize()
+    ts = TableSet.from_encoder(enc)
+    ts.peg_lo, ts.peg_hi = np.array(lo, np.int32), np.array(hi, np.int32)
+    ts.sim_offsets = np.array(so, np.int32)
+    ts.global_id = np.concatenate([np.arange(len(sc.groups), dtype=np.int32) for sc in scenarios])
+    return enc, ts, bases
+
+
+def run_emu_tables(ts, kinds=None, per_sim=True, valid=None, fastpath=False, lds_budget=0):
+    """Product kernels under the wave emulator on a TableSet.  Returns (BatchResult, expander dict or None)."""
+    L = emu_lib()
+    if not hasattr(L, "_query_bound"):
+        L.emu_estimate_batch_query.restype = C.c_int32
+        L.emu_estimate_batch_query.argtypes = [C.POINTER(_abi.Pegs), C.POINTER(_abi.Groups), C.POINTER(_abi.Options), C.POINTER(_abi.Results),
+                                               C.c_int64, _abi.i32p, _abi.i32p, C.POINTER(_abi.OptionQuery)]
+        L._query_bound = True
+    pegs, groups = ts.structs()
+    ng = groups.n_groups
+    if ts.peg_offsets is not None:
+        nnz_cap = int(ts.peg_offsets[ng])
+    elif ts.peg_lo is not None:
+        nnz_cap = int((ts.peg_hi - ts.peg_lo).sum())
+    else:
+        nnz_cap = pegs.n_pegs * ng
+    st, arrs = alloc_results(ng, nnz_cap)
+    opts = _abi.Options(fastpath=int(fastpath))
+    nnz = C.c_int32(0)
+    off = np.zeros(ng + 1, np.int32)
+    q = exp = None
+    if kinds is not None:
+        S = ts.n_sims if (per_sim and ts.n_sims) else 1
+        ks = (C.c_int32 * max(len(kinds), 1))(*kinds)
+        exp = dict(best=np.full(S, -1, np.int32), n_best=np.zeros(S, np.int32), best_set=np.zeros(max(ng, 1), np.uint8),
+                   keys=np.zeros((S, 10), np.int64), packed=np.zeros(S, np.int64))
+        q = _abi.OptionQuery(kinds=ks, n_kinds=len(kinds), per_sim=int(per_sim), best_out=exp["best"].ctypes.data_as(_abi.i32p),
+                             n_best_out=exp["n_best"].ctypes.data_as(_abi.i32p), best_set_out=exp["best_set"].ctypes.data_as(_abi.u8p),
+                             key_out=exp["keys"].ctypes.data_as(_abi.i64p), packed_out=exp["packed"].ctypes.data_as(_abi.i64p))
+        if valid is not None:
+            v = np.ascontiguousarray(valid, np.uint8)
+            q.valid = v.ctypes.data_as(_abi.u8p)
+    rc = L.emu_estimate_batch_query(C.byref(pegs), C.byref(groups), C.byref(opts), C.byref(st), int(lds_budget), C.byref(nnz),
+                                    off.ctypes.data_as(_abi.i32p), C.byref(q) if q is not None else None)
+    assert rc == 0, (rc, L.emu_last_error())
+    return finish_results(arrs, ng, int(nnz.value), off), exp
+
+
+def run_gpu_tables(ts, ctx, kinds=None, per_sim=True, valid=None, fastpath=False):
+    from kubernetes_autoscaler_amd.engine import Problem
+    pegs, groups = ts.structs()
+    with Problem(ctx, pegs, groups, fastpath) as p:
+        p.run()
+        res = p.fetch()
+        exp = p.best_option_sims(kinds, per_sim=per_sim, valid=valid, n_sims=ts.n_sims) if kinds is not None else None
+    return res, exp

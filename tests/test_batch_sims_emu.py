@@ -1,0 +1,123 @@
+"""Batches of independent simulations in one launch (casim_groups.peg_lo / peg_hi / sim_offsets, casim_best_option_sims):
+every group only sees its own simulation's PEGs, the expander chain runs once per simulation, node groups of every
+simulation can be sharded over GPUs and the per-simulation winners recombined with one min over packed keys.
+CPU: product kernels under the wave emulator vs the oracle (per simulation) and vs un-batched runs."""
+import numpy as np
+import pytest
+
+from kubernetes_autoscaler_amd import _abi, workloads
+from kubernetes_autoscaler_amd.tables import TableSet
+from harness import (GroupSpec, Scenario, assert_matches_oracle, encode, encode_batch, run_emu, run_emu_tables, run_oracle)
+
+KINDS = [[_abi.EXPANDER_LEAST_NODES], [_abi.EXPANDER_MOST_PODS, _abi.EXPANDER_LEAST_NODES],
+         [_abi.EXPANDER_LEAST_WASTE], [_abi.EXPANDER_LEAST_NODES, _abi.EXPANDER_LEAST_WASTE]]
+
+
+def _scenario(seed):
+    w = workloads.fuzz(seed, max_groups=5, max_pegs=14)
+    return Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, None) for g in w.groups], device_csr=True)
+
+
+def _shift(oracle, base):
+    return [(est, [base + i for i in ids]) for est, ids in oracle]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_batched_simulations_match_the_oracle_per_simulation(seed):
+    scs = [_scenario(1000 * seed + k) for k in range(1 + seed % 5)]
+    enc, ts, bases = encode_batch(scs)
+    res, _ = run_emu_tables(ts)
+    want = []
+    for sc, (pb, _) in zip(scs, bases):
+        want.extend(_shift(run_oracle(sc), pb))
+    assert_matches_oracle(res, want, f"batch seed {seed}")
+    enc.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("kinds", KINDS)
+def test_expander_runs_once_per_simulation(seed, kinds):
+    scs = [_scenario(500 + 97 * seed + k) for k in range(4)]
+    enc, ts, bases = encode_batch(scs)
+    res, exp = run_emu_tables(ts, kinds=kinds, per_sim=True)
+    for s, (sc, (pb, gb)) in enumerate(zip(scs, bases)):
+        e1 = encode(sc)
+        _, best1 = run_emu(e1, kinds=kinds)
+        want_best, want_n, want_set, want_key = best1
+        assert int(exp["best"][s]) == (gb + want_best if want_best >= 0 else -1), (seed, s)
+        assert int(exp["n_best"][s]) == want_n
+        assert list(exp["best_set"][gb:gb + len(sc.groups)]) == list(want_set)
+        assert list(exp["keys"][s]) == list(want_key)          # global ids are simulation-local: same key block
+        assert int(exp["packed"][s]) == int(want_key[0])
+        e1.close()
+    # one reduce over every group still available on the same batch
+    _, flat = run_emu_tables(ts, kinds=kinds, per_sim=False)
+    assert len(flat["best"]) == 1
+    enc.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_batch_recombines_with_one_min_over_packed_keys(world):
+    """Node groups of every simulation block-partitioned (rotated) over `world` shards; each shard's per-simulation packed
+    key, min over shards == the single-shard winner (integer first filter)."""
+    scs = [_scenario(7000 + k) for k in range(6)]
+    enc, ts, bases = encode_batch(scs)
+    for kinds in ([_abi.EXPANDER_LEAST_NODES], [_abi.EXPANDER_MOST_PODS]):
+        _, whole = run_emu_tables(ts, kinds=kinds)
+        packed = np.full((world, ts.n_sims), np.iinfo(np.int64).max, np.int64)
+        n_groups = 0
+        for r in range(world):
+            sh = ts.shard(r, world)
+            n_groups += sh.n_groups
+            if sh.n_groups == 0:
+                continue
+            res, exp = run_emu_tables(sh, kinds=kinds)
+            packed[r] = exp["packed"]
+        assert n_groups == ts.n_groups
+        got = packed.min(axis=0)
+        # the chain's first filter decides up to ties; ties resolve to the lowest global id in both forms
+        assert list(got) == list(whole["packed"])
+    enc.close()
+
+
+def test_validity_mask_is_applied_before_the_first_filter():
+    """all-or-nothing (orchestrator.go:1057-1063): an option that leaves pods behind never reaches the expander."""
+    scs = [_scenario(4242 + k) for k in range(3)]
+    enc, ts, bases = encode_batch(scs)
+    res, free = run_emu_tables(ts, kinds=[_abi.EXPANDER_LEAST_NODES])
+    valid = np.ones(ts.n_groups, np.uint8)
+    for s in range(ts.n_sims):
+        if free["best"][s] >= 0:
+            valid[free["best"][s]] = 0
+    _, masked = run_emu_tables(ts, kinds=[_abi.EXPANDER_LEAST_NODES], valid=valid)
+    for s in range(ts.n_sims):
+        if free["best"][s] >= 0:
+            assert masked["best"][s] != free["best"][s]
+            assert masked["best_set"][free["best"][s]] == 0
+    enc.close()
+
+
+def test_tiled_batch_repeats_its_results():
+    sc = _scenario(31337)
+    enc, ts, _ = encode_batch([sc])
+    big = ts.tile(5)
+    res, exp = run_emu_tables(big, kinds=[_abi.EXPANDER_LEAST_NODES])
+    ng = ts.n_groups
+    for k in range(1, 5):
+        assert list(res.node_count[k * ng:(k + 1) * ng]) == list(res.node_count[:ng])
+        assert list(res.pods_scheduled[k * ng:(k + 1) * ng]) == list(res.pods_scheduled[:ng])
+        assert int(exp["packed"][k]) == int(exp["packed"][0])
+    enc.close()
+
+
+def test_bad_ranges_are_rejected():
+    sc = _scenario(5)
+    enc, ts, _ = encode_batch([sc])
+    ts.peg_hi = ts.peg_hi + 1
+    from harness import emu_lib
+    import ctypes as C
+    pegs, groups = ts.structs()
+    L = emu_lib()
+    st_rc = L.emu_feasibility(C.byref(pegs), C.byref(groups), np.zeros(64, np.uint64).ctypes.data_as(_abi.u64p))
+    assert st_rc == _abi.ERR_INVALID
+    enc.close()
