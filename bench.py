@@ -1,134 +1,168 @@
 #!/usr/bin/env python3
-"""bench.py — scale-up simulation throughput on MI355X (BASELINE.json metric).
+"""bench.py — scale-up simulation throughput on MI355X (BASELINE.json metric: pods x nodes predicate checks / s).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-launches itself under torch.distributed.run)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of the hot path over one batch resident in HBM: B independent C1-shaped
-scale-up simulations per GPU (BASELINE config[1]: 10k pending pods x 256 candidate nodes, CPU+mem,
-200 PEGs x 50 pods, one node group each; distinct seeds) through
-   order kernel -> pack kernel -> expander reduce kernel [-> one RCCL collective when N > 1].
-value = predicate checks per second = N * B * (pods x node cap) / time, the metric's unit; the
-closed-form packer does not enumerate them one by one — see DESIGN.md §Measurement.
-One JSON line is printed by rank 0.  `roofline` describes the dominant kernel (pack), timed with
-HIP events inside libcasim on the launch stream; `cpu_baseline` times the CPU oracle (a C
-restatement of the reference, NOT the Go reference: no Go toolchain here) on a bounded sample of
-the same simulations, single thread."""
+Headline workload = BASELINE config[2] ("C2": 10k pending pods x 1k candidate nodes across 20 node groups with
+taints / tolerations + nodeSelector), B independent simulations per GPU resident in HBM (S distinct seeds, tiled).
+A "step" = one pass of the whole hot path over that batch:
+   feasibility (SchedulablePodGroups) -> CSR compaction -> order (DecreasingPodOrderer) -> pack (Estimate)
+   -> expander reduce per simulation [-> ONE RCCL all-reduce(min) over the per-simulation keys when N > 1].
+N > 1 (weak scaling): B * N simulations; the node groups of every simulation are block-partitioned over the N ranks
+(PEG table replicated, no data-path collective), the only exchange is the expander's min over packed keys.
+value = N-rank total of sum_NG(P_NG x Ncap_NG) per step / time, P_NG = pods of the PEGs schedulable on NG.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      the dominant kernel of the step (HIP events on the launch stream, inside libcasim), HBM bytes and — because
+                the packer is bound by instruction issue, not bandwidth — the VALU/SALU issue fraction from the PMC profile;
+  cpu_baseline  the CPU oracle (C restatement of the reference, `kind: port`; no Go toolchain in this image) on the SAME
+                C2 simulations, one thread, bounded sample; the all-cores figure next to it;
+  configs       one row per BASELINE config C0..C4: ONE simulation, enter -> return wall time of casim_estimate_batch
+                (H2D + kernels + D2H), its phases, the host encode time, the oracle on the same input, bit-exact flag;
+  c3_sharded    BASELINE config[3]: 64 node groups block-partitioned over the ranks, one all-reduce(min) per simulation."""
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "tests")):
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable copy rate
+SIMDS, CLOCK_HZ = 1024, 2.4e9
 
 
-def build_batch(workloads, Encoder, B, seed_base, n_pegs, pods_per_peg, cap):
-    """B independent C1 simulations (seeds seed_base .. seed_base+B-1) in one encoder: the PEGs go in
-    through the bulk ABI entry (same (cpu, mem) pairs as workloads.config_c1(seed))."""
-    import numpy as np
-    enc = Encoder()
-    checks = 0
-    pegs_total = 0
-    tmpl = workloads.config_c1(seed_offset=0, n_pegs=1, pods_per_peg=1, cap=cap).groups[0].template
-    counts = np.full(n_pegs, pods_per_peg, np.int32)
-    for b in range(B):
-        pairs = np.array(workloads.c1_pairs(seed_base + b, n_pegs), dtype=np.int64)
-        ids = enc.add_resource_pegs(pairs, counts)
-        enc.add_group(tmpl, max_nodes=cap, existing_nodes=0, last_index=0, pegs=list(ids))
-        checks += n_pegs * pods_per_peg * cap
-        pegs_total += n_pegs
+# ------------------------------------------------------------------------------------------------------------------
+# workloads -> tables (product encoder only; nothing here touches the oracle)
+# ------------------------------------------------------------------------------------------------------------------
+def encode_workload(w, Encoder):
+    """One simulation through the host encoder the way a shim would: every PEG, every node-group template, schedulable
+    subsets left to the device (feasibility kernel)."""
+    enc = Encoder(lanes=w.lanes)
+    for pg in w.pegs:
+        enc.add_peg(pg)
+    for info in w.existing:
+        for p in info.pods:
+            enc.add_existing_pod(p, info.node.labels)
+    for g in w.groups:
+        enc.add_group(g.template, max_nodes=g.max_nodes, existing_nodes=len(w.existing), last_index=g.last_index,
+                      pegs=list(g.pegs) if g.pegs is not None else None)
     enc.finalize()
-    return enc, checks, pegs_total
+    return enc
 
 
-def algorithmic_bytes_pack(pegs, groups, nnz, fast):
-    """sum_NG (G_NG * Bp) + NG * Bn + sum_NG (8 + 8 * G_NG), with the record sizes of the
-    packer that actually runs.  Bp = PEG record read per (group, PEG): request lanes + count + flags +
-    order entry (+ masks); Bn = node-group record; written: placed per PEG + 40 B of counters per group.
-    The register-resident packer reads gcd-scaled int32 lanes (4 B each), the generic one int64."""
-    R = pegs.n_res
+def simulation_tables(make, seeds, Encoder, TableSet):
+    """S distinct simulations of one config as one batch (each group sees only its own simulation's PEGs)."""
+    sets = []
+    for s in seeds:
+        enc = encode_workload(make(seed_offset=s), Encoder)
+        sets.append(TableSet.from_encoder(enc).as_one_simulation())
+        enc.close()
+    return TableSet.concat(sets)
+
+
+def checks_of(ts, res):
+    """sum_NG P_NG x Ncap_NG over the groups of a table set, P_NG from the schedulable subsets the device derived."""
+    import numpy as np
+    cnt = ts.pegs["count"][:, 0].astype(np.int64)
+    cap = np.maximum(ts.groups["max_nodes"][:, 0].astype(np.int64), 0)
+    pods = np.add.reduceat(np.concatenate([cnt[res.order], [0]]), res.offsets[:-1].astype(np.int64))
+    pods[res.offsets[1:] == res.offsets[:-1]] = 0
+    return int((pods * cap).sum()), int(res.offsets[-1])
+
+
+def algorithmic_bytes_pack(dims, n_groups, nnz, fast):
+    """sum_NG (G_NG * Bp) + NG * Bn + sum_NG (8 + 8 * G_NG) with the record sizes of the packer that runs.
+    Bp = PEG record read per (group, PEG): request lanes + count + flags + order entry (+ masks); Bn = node-group record;
+    written: placed per PEG + 40 B of counters per group.  The register packer reads gcd-scaled int32 lanes."""
+    R = dims["n_res"]
     lane_bytes = 4 if fast else 8
-    wsum = pegs.w_taint + pegs.w_label + 2 * pegs.w_excl + 2 * pegs.w_zone
-    Bp = lane_bytes * R + 4 + 4 + 4 + 8 * wsum
-    Bn = lane_bytes * R + 4 * 6 + 8 * (pegs.w_excl + 2 * pegs.w_zone)
-    return nnz * Bp + groups.n_groups * Bn + groups.n_groups * 40 + 4 * nnz, Bp, Bn
+    wsum = dims["w_taint"] + dims["w_label"] + 2 * dims["w_excl"] + 2 * dims["w_zone"]
+    Bp = lane_bytes * R + 4 + 4 + 4 + (0 if fast else 8 * wsum) + (8 * 2 * (dims["w_excl"] + dims["w_zone"]) if fast else 0)
+    Bn = lane_bytes * R + 4 * 6 + 8 * (dims["w_excl"] + 2 * dims["w_zone"])
+    return nnz * Bp + n_groups * Bn + n_groups * 40 + 4 * nnz, Bp, Bn
 
 
-def cpu_baseline(workloads, seed_base, n_pegs, pods_per_peg, cap, budget_s=12.0, max_sims=4096):
-    """Times orc_estimate (oracle/casim_oracle.c, single thread) on the first simulations of the
-    batch until ~budget_s of CPU work has been spent.  Scenario construction is not timed."""
+# ------------------------------------------------------------------------------------------------------------------
+# CPU legs (the oracle as the BASELINE, never as the product): only these functions import anything under oracle/
+# ------------------------------------------------------------------------------------------------------------------
+def oracle_simulation(workloads, make, seed):
+    """Builds one simulation inside the oracle; returns run(collect) -> (per-group results or None, seconds of oracle work).
+    One run = ONE native call (orc_scale_up_simulation: SchedulablePodGroups + Estimate per node group), so the CPU leg is
+    not charged for Python / ctypes overhead."""
     from oracle_driver import OracleScenario
-    sims = []
-    t_build = time.time()
-    for b in range(max_sims):
-        w = workloads.config_c1(seed_offset=seed_base + b, n_pegs=n_pegs, pods_per_peg=pods_per_peg, cap=cap)
-        s = OracleScenario()
-        sims.append((s, s.node(w.groups[0].template), w))
-        if len(sims) >= 64 and time.time() - t_build > 20.0:
-            break
-        if len(sims) >= 256:
-            break
-    checks = 0
-    elapsed = 0.0
-    n = 0
-    filter_runs = 0
-    rounds = 0
-    while elapsed < budget_s and rounds < 1000:
-        for s, tmpl, w in sims:
+    w = make(seed_offset=seed) if seed is not None else make()
+    s = OracleScenario(lanes=w.lanes)
+    for info in w.existing:
+        s.add_existing(info)
+    tmpls = [s.node(g.template) for g in w.groups]
+    if all(g.pegs is None for g in w.groups):
+        native = s.prepare_simulation(tmpls, w.pegs, [g.max_nodes for g in w.groups], [g.last_index for g in w.groups])
+
+        def run(collect=True):
             t0 = time.perf_counter()
-            r = s.estimate(tmpl, w.pegs, max_nodes=w.groups[0].max_nodes)
-            elapsed += time.perf_counter() - t0
-            checks += w.checks()
-            filter_runs += r.filter_runs
+            out, runs = native(collect)
+            return out, time.perf_counter() - t0, runs
+    else:   # explicit PEG lists per group
+        def run(collect=True):
+            t0 = time.perf_counter()
+            out = [(s.estimate(tmpl, [w.pegs[i] for i in g.pegs], max_nodes=g.max_nodes, last_index=g.last_index, node_pods_cap=0), list(g.pegs))
+                   for g, tmpl in zip(w.groups, tmpls)]
+            return out, time.perf_counter() - t0, sum(e.filter_runs for e, _ in out)
+    return w, s, run
+
+
+def cpu_baseline(workloads, make, seeds, checks_per_sim, budget_s=12.0):
+    sims = [oracle_simulation(workloads, make, sd) for sd in seeds]
+    n, elapsed, filter_runs = 0, 0.0, 0
+    while elapsed < budget_s:
+        for _, _, run in sims:
+            _, dt, runs = run(False)
+            elapsed += dt
+            filter_runs += runs
             n += 1
-        rounds += 1
-    for s, _, _ in sims:
+            if elapsed >= budget_s:
+                break
+    for _, s, _ in sims:
         s.close()
-    return {"value": checks / elapsed, "unit": "checks/s", "cores": 1, "kind": "port",
-            "sample": f"{n} C1 simulations ({len(sims)} distinct seeds x {rounds} rounds), {elapsed:.1f} s of orc_estimate, "
+    return {"value": n * checks_per_sim / elapsed, "unit": "checks/s", "cores": 1, "kind": "port",
+            "sample": f"{n} C2 simulations ({len(sims)} distinct seeds, the first of the GPU batch), {elapsed:.1f} s of oracle work "
+                      f"(orc_scale_up_simulation: CheckPredicates per PEG x group + Estimate per group, one native call per simulation), "
                       f"{filter_runs / max(n, 1):.0f} real Filter runs per simulation",
-            "sims_per_s": n / elapsed, "host_cores_available": os.cpu_count()}
+            "sims_per_s": n / elapsed, "ms_per_sim": elapsed / n * 1e3, "host_cores_available": os.cpu_count()}
 
 
-def cpu_worker(seed_base, n_sims, n_pegs, pods_per_peg, cap, budget_s):
-    """One process of the multi-core CPU leg: builds its own scenarios, waits for the start line on stdin, runs
-    orc_estimate for ~budget_s and prints {"n": simulations, "s": seconds}.  No torch / HIP in this process."""
+def cpu_worker(config, seed, budget_s):
+    """One process of the multi-core CPU leg: one simulation of `config`, waits for the start line, loops ~budget_s."""
     from kubernetes_autoscaler_amd import workloads
-    from oracle_driver import OracleScenario
-    sims = []
-    for b in range(n_sims):
-        w = workloads.config_c1(seed_offset=seed_base + b, n_pegs=n_pegs, pods_per_peg=pods_per_peg, cap=cap)
-        s = OracleScenario()
-        sims.append((s, s.node(w.groups[0].template), w))
+    _, s, run = oracle_simulation(workloads, workloads.CONFIGS[config], seed)
     print("ready", flush=True)
     sys.stdin.readline()
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < budget_s:
-        for s, tmpl, w in sims:
-            s.estimate(tmpl, w.pegs, max_nodes=w.groups[0].max_nodes)
-            n += 1
+        run(False)
+        n += 1
     print(json.dumps({"n": n, "s": time.perf_counter() - t0}), flush=True)
+    s.close()
 
 
-def cpu_baseline_all_cores(n_pegs, pods_per_peg, cap, budget_s=4.0, max_procs=64, sims_per_proc=4):
-    """The same oracle on the host's cores at once: independent Python processes (one simulation stream each, like the
-    node-group-parallel CPU variant SURVEY §8d asks for), started together, aggregate simulations per second."""
-    import subprocess
+def cpu_baseline_all_cores(config, checks_per_sim, budget_s=5.0, max_procs=128):
+    """The same oracle on every host core at once: independent processes, one simulation stream each (the node-group /
+    simulation-parallel CPU variant of SURVEY 8d), aggregate rate."""
     procs_n = max(1, min(max_procs, (os.cpu_count() or 1)))
     procs = []
     try:
         for i in range(procs_n):
-            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(100000 + i * sims_per_proc),
-                                           str(sims_per_proc), str(n_pegs), str(pods_per_peg), str(cap), str(budget_s)],
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", config, str(100000 + i), str(budget_s)],
                                           stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
-        deadline = time.time() + 120.0
+        deadline = time.time() + 180.0
         for p in procs:
             line = p.stdout.readline()
             if line.strip() != "ready" or time.time() > deadline:
@@ -136,16 +170,12 @@ def cpu_baseline_all_cores(n_pegs, pods_per_peg, cap, budget_s=4.0, max_procs=64
         t0 = time.perf_counter()
         for p in procs:
             p.stdin.write("go\n"); p.stdin.flush()
-        total = 0
-        for p in procs:
-            total += json.loads(p.stdout.readline())["n"]
+        total = sum(json.loads(p.stdout.readline())["n"] for p in procs)
         wall = time.perf_counter() - t0
         for p in procs:
             p.wait(timeout=30)
-        sims_per_s = total / wall
-        return {"value": sims_per_s * n_pegs * pods_per_peg * cap, "unit": "checks/s", "cores": procs_n, "kind": "port",
-                "sample": f"{total} C1 simulations by {procs_n} processes in {wall:.1f} s (each loops over {sims_per_proc} seeds)",
-                "sims_per_s": sims_per_s}
+        return {"value": total / wall * checks_per_sim, "unit": "checks/s", "cores": procs_n, "kind": "port",
+                "sample": f"{total} {config} simulations by {procs_n} processes in {wall:.1f} s", "sims_per_s": total / wall}
     except Exception as e:  # never take the bench line down
         for p in procs:
             try:
@@ -155,65 +185,221 @@ def cpu_baseline_all_cores(n_pegs, pods_per_peg, cap, budget_s=4.0, max_procs=64
         return {"error": str(e)}
 
 
+def config_rows(kaa, ctx, workloads, kinds, iters=20):
+    """One simulation of every BASELINE config through the whole boundary, enter -> return."""
+    import numpy as np
+    from kubernetes_autoscaler_amd.engine import estimate_batch_timed
+    from kubernetes_autoscaler_amd.tables import TableSet
+    from harness import assert_matches_oracle
+    from kubernetes_autoscaler_amd.engine import finish_results
+    rows = []
+    for name in ("C0", "C1", "C2", "C3", "C4"):
+        make = workloads.CONFIGS[name]
+        row = {"config": name}
+        try:
+            t0 = time.perf_counter()
+            w = make()
+            enc = encode_workload(w, kaa.Encoder)
+            row["encode_ms_python_mirror"] = (time.perf_counter() - t0) * 1e3
+            ts = TableSet.from_encoder(enc).as_one_simulation() if all(g.pegs is None for g in w.groups) else TableSet.from_encoder(enc)
+            if ts.sim_offsets is None:
+                ts.sim_offsets = np.array([0, ts.n_groups], np.int32)
+            pegs, groups = ts.structs()
+            row.update({"pods": w.n_pods, "pegs": len(w.pegs), "node_groups": len(w.groups),
+                        "node_cap_total": int(sum(max(g.max_nodes, 0) for g in w.groups))})
+            estimate_batch_timed(ctx, pegs, groups, kinds)          # first call: LDS opt-ins, code objects
+            ph_acc, walls = None, []
+            for _ in range(iters):
+                arrs, ph, exp = estimate_batch_timed(ctx, pegs, groups, kinds)
+                ph_acc = ph if ph_acc is None else {k: ph_acc[k] + v for k, v in ph.items()}
+            for _ in range(iters):   # the plain call a shim makes (no drain between phases) + the expander reduce
+                t1 = time.perf_counter()
+                with kaa.Problem(ctx, pegs, groups) as p:
+                    p.run()
+                    res = p.fetch()
+                    best = p.best_option_sims(kinds, per_sim=True, n_sims=1)
+                walls.append((time.perf_counter() - t1) * 1e3)
+            row["phases_ms"] = {k: v / iters for k, v in ph_acc.items()}
+            row["wall_ms"] = float(np.median(walls))
+            row["wall_ms_min"] = float(np.min(walls))
+            row["checks"], row["schedulable_peg_group_pairs"] = checks_of(ts, res)
+            row["checks_per_s_single_sim"] = row["checks"] / (row["wall_ms"] * 1e-3)
+            row["best_group"] = int(best["best"][0])
+            # the oracle on the same input (CPU, one thread) and the bit-exact comparison
+            _, s, run = oracle_simulation(workloads, make, None if name == "C0" else 0)
+            want, osec, _ = run()
+            _, osec2, _ = run(False)
+            s.close()
+            row["oracle_ms"] = min(osec, osec2) * 1e3
+            try:
+                assert_matches_oracle(res, want, name)
+                row["bit_exact"] = True
+            except AssertionError as e:
+                row["bit_exact"] = False
+                row["mismatch"] = str(e)[:200]
+            row["speedup_vs_oracle_wall"] = row["oracle_ms"] / row["wall_ms"]
+            enc.close()
+            # the same simulation through tools/casim_native: plain C++ over the C ABI, no Python between the calls —
+            # encode (all casim_enc_* calls + finalize), tables -> HBM, kernels, results -> host
+            import native_trace
+            tpath = os.path.join("/tmp", f"casim_{name}.trace")
+            native_trace.trace_estimate(w, tpath, kinds=kinds, iters=iters).close()
+            nrc, nat = native_trace.run_native(tpath)
+            keep = ("enc_calls", "encode_calls_ms", "finalize_ms", "encode_ms", "upload_ms", "feasibility_csr_ms", "order_ms", "pack_ms",
+                    "expander_ms", "fetch_ms", "timed_wall_ms", "wall_ms", "best_group", "engine_error")
+            row["native"] = {k: nat[k] for k in keep if k in nat}
+            row["native"]["exit_code"] = nrc
+            if "wall_ms" in nat and "encode_ms" in nat:
+                row["native"]["encode_plus_call_ms"] = nat["encode_ms"] + nat["wall_ms"]
+                row["native"]["same_winner_as_python_path"] = nat.get("best_group") == row["best_group"]
+        except Exception as e:  # a side table must never take the headline down
+            row["error"] = f"{type(e).__name__}: {e}"
+        rows.append(row)
+    return rows
+
+
+def c3_sharded(kaa, ctx, workloads, kinds, rank, world, dist, torch, dev_index, allreduce, iters=200):
+    """BASELINE config[3]: one C3 simulation (50k pods x 4k nodes, 64 node groups); node groups block-partitioned over
+    the ranks, PEG table replicated, ONE all-reduce(min) on the packed key.  Strong scaling: the work is fixed."""
+    import numpy as np
+    from kubernetes_autoscaler_amd.tables import TableSet
+    enc = encode_workload(workloads.config_c3(), kaa.Encoder)
+    full = TableSet.from_encoder(enc).as_one_simulation()
+    mine = full.shard(rank, world, rotate=False)
+    pegs, groups = mine.structs()
+    key = torch.full((1,), 0x7FFFFFFFFFFFFFFF, dtype=torch.int64, device=f"cuda:{dev_index}")
+    with kaa.Problem(ctx, pegs, groups) as p:
+        def it():
+            p.run()
+            p.best_option_sims(kinds, per_sim=True, fetch=False, dev_packed_ptr=key.data_ptr(), n_sims=1)
+            if world > 1:
+                allreduce(key, dist.ReduceOp.MIN)
+        for _ in range(10):
+            it()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            it()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        winner = int(key.item())
+        # the collective alone (same tensor, nothing else enqueued)
+        red_ms = None
+        if world > 1:
+            torch.cuda.synchronize(); dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(iters):
+                allreduce(key, dist.ReduceOp.MIN)
+            torch.cuda.synchronize()
+            red_ms = (time.perf_counter() - t1) / iters * 1e3
+            tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev_index}")
+            allreduce(tt, dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        res = p.fetch()
+        chk, _ = checks_of(mine, res)
+    enc.close()
+    if world > 1:
+        tc = torch.tensor([chk], dtype=torch.int64, device=f"cuda:{dev_index}")
+        allreduce(tc, dist.ReduceOp.SUM)
+        chk = int(tc.item())
+    return {"workload": "C3: 50k pods x 4k nodes, 64 node groups, resident tables", "scaling": "strong", "ranks": world,
+            "groups_on_rank0": mine.n_groups, "ms_per_simulation": dt / iters * 1e3, "checks": chk,
+            "checks_per_s": chk / (dt / iters), "winner_group": -1 if winner == 0x7FFFFFFFFFFFFFFF else winner & 0xFFFFF,
+            "winner_nodes": None if winner == 0x7FFFFFFFFFFFFFFF else winner >> 20,
+            "collective": ("rccl all_reduce(min), 1 x int64" if world > 1 else "none (1 rank)"), "all_reduce_ms": red_ms}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` without a launcher: start the ranks the way the driver would."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
-        a = sys.argv[2:]
-        cpu_worker(int(a[0]), int(a[1]), int(a[2]), int(a[3]), int(a[4]), float(a[5]))
+        cpu_worker(sys.argv[2], int(sys.argv[3]), float(sys.argv[4]))
         return None
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16384, help="independent C1 simulations per GPU per step")
-    ap.add_argument("--pegs", type=int, default=200)
-    ap.add_argument("--pods-per-peg", type=int, default=50)
-    ap.add_argument("--cap", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=600)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=4096, help="independent C2 simulations per GPU per step")
+    ap.add_argument("--seeds", type=int, default=64, help="distinct simulations the batch is tiled from")
+    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C4"], help="headline config (C2 = BASELINE config[2])")
+    ap.add_argument("--expander", default="least-nodes", choices=["least-nodes", "least-waste", "most-pods"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-config C0..C4 wall-time table")
     ap.add_argument("--no-dense", action="store_true")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the TrySchedulePods / node-removal side measurements")
+    ap.add_argument("--no-c3", action="store_true")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        relaunch_under_torchrun(args.gpus)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     import kubernetes_autoscaler_amd as kaa
     from kubernetes_autoscaler_amd import _abi, workloads
-    from kubernetes_autoscaler_amd.distributed import global_best_option
+    from kubernetes_autoscaler_amd.tables import TableSet
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: kubernetes_autoscaler_amd has no CPU path")
-    # CASIM_BENCH_SELFTEST=1: exercise the N > 1 control flow on a 1-GPU box (every rank on cuda:0, gloo
-    # for the collectives).  Numbers from this mode are meaningless; the driver never sets it.
-    selftest = os.environ.get("CASIM_BENCH_SELFTEST") == "1"
-    dev_index = 0 if selftest else local_rank
+    # CASIM_BENCH_ONE_GPU=1: every rank on cuda:0 (exercises the N > 1 path, RCCL included, on a 1-GPU box; the numbers
+    # of such a run say nothing about scaling and the JSON line says so).  The driver never sets it.
+    one_gpu = os.environ.get("CASIM_BENCH_ONE_GPU") == "1"
+    dev_index = 0 if one_gpu else local_rank
     torch.cuda.set_device(dev_index)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if selftest:
-            dist.init_process_group(backend="gloo")
-        else:
+        backend = os.environ.get("CASIM_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
 
-    B = args.batch
+    kinds = [{"least-nodes": _abi.EXPANDER_LEAST_NODES, "least-waste": _abi.EXPANDER_LEAST_WASTE, "most-pods": _abi.EXPANDER_MOST_PODS}[args.expander]]
+    make = workloads.CONFIGS[args.config]
+    B, S = args.batch, max(1, min(args.seeds, args.batch))
     t0 = time.time()
-    enc, checks_per_step, pegs_total = build_batch(workloads, kaa.Encoder, B, rank * B, args.pegs, args.pods_per_peg, args.cap)
+    seed_set = simulation_tables(make, range(S), kaa.Encoder, TableSet)       # S distinct simulations, one table set
     t_encode = time.time() - t0
+    total_sims = B * world
+    full = seed_set.tile((total_sims + S - 1) // S).head(total_sims)
+    mine = full.shard(rank, world) if world > 1 else full
+    pegs, groups = mine.structs()
+    n_sims = mine.n_sims
 
     stream = torch.cuda.current_stream().cuda_stream
     ctx = kaa.Context(dev_index, stream=stream)
-    prob = kaa.Problem(ctx, enc.pegs, enc.groups)
-    key = torch.full((10,), 0x7FFFFFFFFFFFFFFF, dtype=torch.int64, device=f"cuda:{dev_index}")
-    kinds = [_abi.EXPANDER_LEAST_NODES]
-    base = rank * B
+    t0 = time.time()
+    prob = kaa.Problem(ctx, pegs, groups)
+    t_upload = time.time() - t0
+    keys = torch.full((n_sims,), 0x7FFFFFFFFFFFFFFF, dtype=torch.int64, device=f"cuda:{dev_index}")
+
+    def allreduce(t, op):
+        """RCCL reduces device tensors in place; the gloo self-test backend goes through the host."""
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+        else:
+            h = t.cpu(); dist.all_reduce(h, op=op); t.copy_(h)
 
     def step():
         prob.run()
-        return global_best_option(prob, kinds, base, key)
+        prob.best_option_sims(kinds, per_sim=True, fetch=False, dev_packed_ptr=keys.data_ptr(), n_sims=n_sims)
+        if world > 1:
+            allreduce(keys, dist.ReduceOp.MIN)
 
     for _ in range(args.warmup):
         step()
@@ -223,133 +409,165 @@ def main():
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     for _ in range(args.steps):
-        best = step()
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t_start
+    res = prob.fetch()
+    my_checks, my_nnz = checks_of(mine, res)
+    checks_per_step = my_checks
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if selftest else f"cuda:{dev_index}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev_index}")
+        allreduce(tt, dist.ReduceOp.MAX)
         dt = float(tt.item())
+        tc = torch.tensor([my_checks], dtype=torch.int64, device=f"cuda:{dev_index}")
+        allreduce(tc, dist.ReduceOp.SUM)
+        checks_per_step = int(tc.item())
 
     out = None
+    side = {}
+    if not args.no_c3:   # every rank takes part (collective inside)
+        try:
+            side["c3_sharded"] = c3_sharded(kaa, ctx, workloads, kinds, rank, world, dist, torch, dev_index, allreduce)
+        except Exception as e:
+            side["c3_sharded"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = world * checks_per_step / (dt / args.steps)
-        # dominant kernel: per-kernel HIP-event timing on the launch stream (libcasim: casim_problem_time)
+        value = checks_per_step / (dt / args.steps)
+        winners = keys.cpu().numpy()
+        have = winners != 0x7FFFFFFFFFFFFFFF
+        # per-kernel HIP-event timing on the launch stream (libcasim: casim_problem_time)
         total_ms, kms = prob.time(iters=max(5, min(args.steps, 20)))
-        nnz, _ = prob.csr()
         info = prob.info()
-        bytes_pack, Bp, Bn = algorithmic_bytes_pack(enc.pegs, enc.groups, nnz, info["fast_packer_slots_per_lane"] > 0)
+        fast = info["fast_packer_slots_per_lane"] > 0
+        bytes_pack, Bp, Bn = algorithmic_bytes_pack(mine.dims, mine.n_groups, my_nnz, fast)
         achieved = bytes_pack / (kms["pack_ms"] * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "pack_fast_kernel<%d,%d>" % (info["fast_packer_lanes"], info["fast_packer_slots_per_lane"]) if info["fast_packer_slots_per_lane"] else "pack_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        kname = ("pack_fast_kernel<%d,%d,%d>" % (info["fast_packer_lanes"], info["fast_packer_slots_per_lane"],
+                                                  2 if (mine.dims["w_excl"] or mine.dims["w_zone"]) else 0)) if fast else "pack_kernel"
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
                     "algorithmic_bytes_per_launch": bytes_pack, "bytes_per_peg_record": Bp, "bytes_per_group_record": Bn,
-                    "kernel_ms": kms["pack_ms"],
-                    "note": "packer is integer-ALU/latency bound (sequential per-PEG dependency), not HBM bound; see DESIGN.md"}
-        # HBM bytes per launch from the PMC passes of the same command (tools/gpu_round.sh -> tools/pmc_traffic.py):
-        # counters cannot be collected from inside the timed run, so the committed figure is used when it was taken
-        # on the same kernel and launch size
+                    "kernel_ms": kms["pack_ms"], "share_of_step": kms["pack_ms"] / max(total_ms, 1e-9),
+                    "note": "the packer is bound by VALU / SALU instruction issue (sequential per-PEG dependency), not by HBM: "
+                            "see issue_roofline; DESIGN.md section 4"}
+        # PMC figures of the same command (separate rocprofv3 --pmc passes, tools/gpu_round.sh -> tools/pmc_*.py): counters
+        # cannot be collected from inside the timed run; the committed figures are used when they were taken on the same
+        # kernel instantiation and launch size
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "pack_traffic.json")))
-            # same kernel family and launch size (the profile names the full instantiation, e.g. pack_fast_kernel<2, 4, 0>)
-            if tr.get("waves_per_launch") == B and roofline["kernel"].replace(" ", "").rstrip(">") in tr.get("kernel", "").replace(" ", ""):
+            if tr.get("waves_per_launch") == mine.n_groups and kname.replace(" ", "").rstrip(">") in tr.get("kernel", "").replace(" ", ""):
                 roofline["traffic"] = tr["traffic_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/pack_traffic.json (%s: FETCH_SIZE x2 per the gfx950 rule + WRITE_SIZE, per launch)" % tr.get("run", "?")
+                roofline["traffic_source"] = "profiles/pack_traffic.json (%s)" % tr.get("run", "?")
+                if "valu_insts_per_launch" in tr:
+                    # issue roofline: one VALU / SALU wave-instruction holds its SIMD's issue port ~4 cycles (measured:
+                    # SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.0 quad-cycle); 1024 SIMDs x 2.4 GHz
+                    cyc = tr.get("cycles_per_valu", 4.0)
+                    t_issue = tr["valu_insts_per_launch"] * cyc / (SIMDS * CLOCK_HZ)
+                    roofline["issue_roofline"] = {"bound": "valu_issue", "valu_insts_per_launch": tr["valu_insts_per_launch"],
+                                                  "salu_insts_per_launch": tr.get("salu_insts_per_launch"),
+                                                  "cycles_per_valu_inst": cyc, "issue_time_ms": t_issue * 1e3,
+                                                  "frac": t_issue / (kms["pack_ms"] * 1e-3), "source": tr.get("run", "?")}
         except (OSError, ValueError, KeyError):
             pass
-        extra = {"kernel_ms": kms, "pipeline_ms_hip_events": total_ms, "encode_s": t_encode,
-                 "sims_per_s": world * B / (dt / args.steps), "best_group": best}
-        # single-simulation latency (B = 1), the north-star "< 50 ms / iteration" figure
-        enc1, checks1, _ = build_batch(workloads, kaa.Encoder, 1, 1 << 20, args.pegs, args.pods_per_peg, args.cap)
-        with kaa.Problem(ctx, enc1.pegs, enc1.groups) as p1:
-            p1.run(); torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(50):
-                p1.run()
-            torch.cuda.synchronize()
-            extra["single_sim_latency_ms"] = (time.perf_counter() - t1) / 50 * 1e3
-            t1 = time.perf_counter()
-            for _ in range(20):
-                with kaa.Problem(ctx, enc1.pegs, enc1.groups) as p2:
-                    p2.run(); p2.fetch()
-            extra["single_sim_upload_run_fetch_ms"] = (time.perf_counter() - t1) / 20 * 1e3
-        # streaming form of the same predicates: dense per-pod x per-node check (HBM-facing kernel)
-        if not args.no_dense and world == 1:   # side measurements: N = 1 only
-            try:
-                # bounded probe: 256 simulations' pods x (256 groups x 16 nodes) = 2.56 M x 4096 -> 1.3 GB of bits
-                rep = 16
-                encd, _, _ = build_batch(workloads, kaa.Encoder, 256, 1 << 21, args.pegs, args.pods_per_peg, args.cap)
-                with kaa.Problem(ctx, encd.pegs, encd.groups) as pd:
-                    ms, nr, nc = pd.time_dense(rep, iters=5)
-                R = enc.pegs.n_res
-                bp = 8 * R + 4 + 4 + 8 * 4
-                bn = 8 * 2 * R + 8 + 8 * 4
-                dbytes = nr * (bp + 4) + (nc // rep) * bn + nr * ((nc + 63) // 64) * 8
-                extra["roofline_dense_check"] = {"bound": "hbm", "kernel": "dense_check_kernel", "rows_pods": nr, "cols_nodes": nc,
-                                                 "checks_per_s": nr * nc / (ms * 1e-3), "achieved": dbytes / (ms * 1e-3) / 1e9,
-                                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": dbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                                 "kernel_ms": ms, "algorithmic_bytes_per_launch": dbytes}
-            except Exception as e:  # the probe must never take the headline number down
-                extra["roofline_dense_check"] = {"error": str(e)}
-        # the callers either side of the path, one mid-size case each: resident tables, HIP-event time
-        if not args.no_next_rows and world == 1:
-            try:
-                from kubernetes_autoscaler_amd.scheduling import encode_pending_pods
-                w1 = workloads.pending_scale(5000, 50000, 64, 2)
-                e1, pc1 = encode_pending_pods(w1.nodes, w1.pods)
-                _, _, _, ns1 = ctx.try_schedule_pods(e1.pegs, e1.groups, pc1)
-                _, ms1 = ctx.try_schedule_pods(e1.pegs, e1.groups, pc1, time_iters=5)
-                e1.close()
-                extra["try_schedule_pods"] = {"workload": w1.name, "nodes": len(w1.nodes), "pending_pods": len(w1.pods), "scheduled": int(ns1),
-                                              "kernels_ms": ms1, "pods_per_s": len(w1.pods) / (ms1 * 1e-3)}
-                w2 = workloads.removal_scale(5000, pods_per_node=12, frac_candidates=0.3, seed=1)
-                e2 = kaa.Encoder(explicit_self_exclusion=True)
-                cls, pcl, off = {}, [], [0]
-                for c in w2.candidates:
-                    for p in w2.nodes[c].pods:
-                        k = p.spec_key()
-                        if k not in cls:
-                            cls[k] = e2.add_peg(kaa.PodEquivalenceGroup(pods=[p]))
-                        pcl.append(cls[k])
-                    off.append(len(pcl))
-                for info in w2.nodes:
-                    e2.add_group(info, pegs=[])
-                e2.finalize()
-                r2 = ctx.simulate_node_removals(e2.pegs, e2.groups, w2.candidates, off, pcl)
-                _, ms2 = ctx.simulate_node_removals(e2.pegs, e2.groups, w2.candidates, off, pcl, time_iters=5)
-                e2.close()
-                extra["node_removals"] = {"workload": w2.name, "nodes": len(w2.nodes), "candidates": len(w2.candidates),
-                                          "removable": int((r2.removable == 1).sum()), "kernels_ms": ms2,
-                                          "candidates_per_s": len(w2.candidates) / (ms2 * 1e-3)}
-            except Exception as e:  # must never take the headline number down
-                extra["next_rows_error"] = str(e)
-        try:
-            extra["copy_bandwidth_gbps"] = ctx.copy_bandwidth_gbps(1 << 30, 10)
-        except Exception as e:
-            extra["copy_bandwidth_gbps"] = str(e)
+        extra = {"kernel_ms": kms, "pipeline_ms_hip_events": total_ms, "encode_s_python_mirror": t_encode, "upload_s": t_upload,
+                 "sims_per_step": total_sims, "sims_per_s": total_sims / (dt / args.steps),
+                 "timed_region_s": dt, "winners": {"simulations_with_an_option": int(have.sum()),
+                                                   "mean_nodes_of_winner": float((winners[have] >> 20).mean()) if have.any() else None}}
+        checks_per_sim = checks_per_step / total_sims
+        if world == 1:   # side measurements and CPU legs at N = 1 only (other ranks would idle in a barrier)
+            extra["copy_bandwidth_gbps"] = _try(lambda: ctx.copy_bandwidth_gbps(1 << 30, 10))
+            extra["read_stream_gbps"] = _try(lambda: {"4B_per_lane": ctx.stream_probe_gbps(1 << 30, 4, 5), "16B_per_lane": ctx.stream_probe_gbps(1 << 30, 16, 5)})
+            if not args.no_configs:
+                extra["configs"] = config_rows(kaa, ctx, workloads, kinds)
+            if not args.no_dense:
+                extra["roofline_dense_check"] = _try(lambda: dense_probe(kaa, ctx, seed_set, TableSet))
+            if not args.no_next_rows:
+                extra.update(_try(lambda: next_rows(kaa, ctx, workloads)) or {})
         cpu = None
-        if not args.no_cpu_baseline and world == 1:   # the CPU legs are timed at N = 1 only (other ranks would idle in the barrier)
-            cpu = cpu_baseline(workloads, 0, args.pegs, args.pods_per_peg, args.cap)
-            extra["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.pegs, args.pods_per_peg, args.cap)
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(workloads, make, range(min(S, 8)), checks_per_sim)
+            extra["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.config, checks_per_sim)
+        desc = {"C1": "10k pending pods x 256 candidate nodes, CPU+mem, 1 node group",
+                "C2": "10k pending pods x 1k candidate nodes across 20 node groups, taints / tolerations + nodeSelector",
+                "C4": "10k pending pods x 1k candidate nodes, 20 node groups, pod anti-affinity"}[args.config]
         out = {"metric": "scale-up simulation predicate checks/s (pods x nodes)", "value": value, "unit": "checks/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-               "config": {"workload": f"C1 x {B} simulations per GPU per step (10k pending pods x 256 candidate nodes, "
-                                      f"{args.pegs} PEGs x {args.pods_per_peg} pods, CPU+mem, 1 node group each)",
-                          "batch_per_gpu": B, "pegs_per_sim": args.pegs, "pods_per_sim": args.pegs * args.pods_per_peg,
-                          "node_cap": args.cap, "expander": "least-nodes",
-                          "reduce": "rccl all_reduce(min) on packed int64 key" if world > 1 else "device kernel only"},
+               "config": {"workload": f"{args.config} x {B} simulations per GPU per step ({desc}; {S} distinct seeds tiled), "
+                                      f"tables resident in HBM; step = feasibility + CSR + order + pack + expander reduce per simulation",
+                          "batch_per_gpu": B, "distinct_seeds": S, "checks_per_simulation": checks_per_sim,
+                          "node_groups_per_rank": mine.n_groups, "schedulable_peg_group_pairs_per_rank": my_nnz,
+                          "expander": args.expander,
+                          "partition": ("node groups of every simulation block-partitioned over the ranks (rotated), PEG table replicated"
+                                        if world > 1 else "single GPU"),
+                          "reduce": (f"{backend} all_reduce(min) on {n_sims} packed int64 keys per step" if world > 1 else "device kernel only"),
+                          "all_ranks_on_one_gpu": bool(one_gpu and world > 1)},
                "roofline": roofline, "cpu_baseline": cpu}
         out.update(extra)
+        out.update(side)
         print(json.dumps(out))
     prob.close()
     ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return out
+
+
+def _try(f):
+    try:
+        return f()
+    except Exception as e:  # side probes must never take the headline number down
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def dense_probe(kaa, ctx, seed_set, TableSet):
+    """Streaming form of the same predicates: dense per-pod x per-node check matrix (HBM-facing kernel)."""
+    ts = seed_set.tile(4)   # 4 x 64 C2 simulations' pods against (their groups x 16 nodes)
+    pegs, groups = ts.structs()
+    rep = 16
+    with kaa.Problem(ctx, pegs, groups) as pd:
+        ms, nr, nc = pd.time_dense(rep, iters=5)
+    R = ts.dims["n_res"]
+    bp = 8 * R + 4 + 4 + 8 * 4
+    bn = 8 * 2 * R + 8 + 8 * 4
+    dbytes = nr * (bp + 4) + (nc // rep) * bn + nr * ((nc + 63) // 64) * 8
+    return {"bound": "hbm", "kernel": "dense_check_kernel", "rows_pods": nr, "cols_nodes": nc, "checks_per_s": nr * nc / (ms * 1e-3),
+            "achieved": dbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": dbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "kernel_ms": ms, "algorithmic_bytes_per_launch": dbytes}
+
+
+def next_rows(kaa, ctx, workloads):
+    """The callers either side of the path, one mid-size case each: resident tables, HIP-event time."""
+    from kubernetes_autoscaler_amd.scheduling import encode_pending_pods
+    out = {}
+    w1 = workloads.pending_scale(5000, 50000, 64, 2)
+    e1, pc1 = encode_pending_pods(w1.nodes, w1.pods)
+    _, _, _, ns1 = ctx.try_schedule_pods(e1.pegs, e1.groups, pc1)
+    _, ms1 = ctx.try_schedule_pods(e1.pegs, e1.groups, pc1, time_iters=5)
+    e1.close()
+    out["try_schedule_pods"] = {"workload": w1.name, "nodes": len(w1.nodes), "pending_pods": len(w1.pods), "scheduled": int(ns1),
+                                "kernels_ms": ms1, "pods_per_s": len(w1.pods) / (ms1 * 1e-3)}
+    w2 = workloads.removal_scale(5000, pods_per_node=12, frac_candidates=0.3, seed=1)
+    e2 = kaa.Encoder(explicit_self_exclusion=True)
+    cls, pcl, off = {}, [], [0]
+    for c in w2.candidates:
+        for p in w2.nodes[c].pods:
+            k = p.spec_key()
+            if k not in cls:
+                cls[k] = e2.add_peg(kaa.PodEquivalenceGroup(pods=[p]))
+            pcl.append(cls[k])
+        off.append(len(pcl))
+    for info in w2.nodes:
+        e2.add_group(info, pegs=[])
+    e2.finalize()
+    r2 = ctx.simulate_node_removals(e2.pegs, e2.groups, w2.candidates, off, pcl)
+    _, ms2 = ctx.simulate_node_removals(e2.pegs, e2.groups, w2.candidates, off, pcl, time_iters=5)
+    e2.close()
+    out["node_removals"] = {"workload": w2.name, "nodes": len(w2.nodes), "candidates": len(w2.candidates),
+                            "removable": int((r2.removable == 1).sum()), "kernels_ms": ms2, "candidates_per_s": len(w2.candidates) / (ms2 * 1e-3)}
     return out
 
 

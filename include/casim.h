@@ -489,6 +489,10 @@ int32_t casim_problem_time_dense(casim_problem* p, int32_t col_repeat, int32_t i
 /* Device-to-device copy bandwidth probe (GB/s) used as the "achievable HBM" reference. */
 int32_t casim_copy_bandwidth(casim_ctx* ctx, int64_t bytes, int32_t iters, double* gbps_out);
 
+/* Read-only stream of `bytes` with `lane_bytes` (4 or 16) per lane and step: read bandwidth, and — under rocprofv3 --pmc
+ * FETCH_SIZE — the calibration of the counter on that access width (kernel name stream_probe_kernel<4|16>). */
+int32_t casim_stream_probe(casim_ctx* ctx, int64_t bytes, int32_t lane_bytes, int32_t iters, double* gbps_out);
+
 /* ======================================================================================
  * ENCODER  (host side, C++ inside; replaces the string work of the Filter plugins)
  * ==================================================================================== */

@@ -143,6 +143,7 @@ PROTOTYPES = {
     "casim_time_node_removals": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(RemovalCandidates), C.c_int32,
                                              C.POINTER(C.c_float)]),
     "casim_copy_bandwidth": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, f64p]),
+    "casim_stream_probe": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, f64p]),
     "casim_enc_create": (C.c_void_p, [C.POINTER(EncoderOptions)]),
     "casim_enc_destroy": (None, [C.c_void_p]),
     "casim_enc_add_group": (C.c_int32, [C.c_void_p, cstr, i64p, C.c_int32, C.c_int64, C.c_int64, C.c_int32]),

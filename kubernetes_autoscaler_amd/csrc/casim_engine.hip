@@ -151,6 +151,21 @@ __global__ void copy_probe_kernel(const uint4* __restrict__ src, uint4* __restri
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
+// Known-byte-count read streams for calibrating the profiler's FETCH_SIZE on this access width (MI355X_MICROARCH.md: the
+// x2 rule is established for 16 B / lane streams only): every lane reads W bytes per step, one value per wave is written.
+template <int W>
+__global__ __launch_bounds__(256) void stream_probe_kernel(const uint32_t* __restrict__ src, int64_t n_words, uint32_t* __restrict__ sink) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    if (W == 4) {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) acc ^= src[i];
+    } else {
+        const uint4* s4 = (const uint4*)src;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words / 4; i += stride) { const uint4 v = s4[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+    }
+    if (acc == 0x12345678u) sink[blockIdx.x] = acc;   // (never true for the zero-filled source: keeps the loads alive)
+}
+
 }  // namespace casim
 
 extern "C" {
@@ -517,6 +532,32 @@ int32_t casim_copy_bandwidth(casim_ctx* ctx, int64_t bytes, int32_t iters, doubl
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     bk.free(a); bk.free(b);
     *gbps_out = ms > 0 ? (2.0 * (double)n * 16.0 * iters) / (ms * 1e-3) / 1e9 : 0.0;
+    return bk.ok() ? CASIM_OK : set_err(CASIM_ERR_HIP, bk.msg);
+}
+
+int32_t casim_stream_probe(casim_ctx* ctx, int64_t bytes, int32_t lane_bytes, int32_t iters, double* gbps_out) {
+    g_err.clear();
+    if (!ctx || bytes < 4096 || iters <= 0 || !gbps_out || (lane_bytes != 4 && lane_bytes != 16)) return set_err(CASIM_ERR_INVALID, "bad argument");
+    HipBackend& bk = ctx->bk; bk.bind(); bk.clear();
+    const int64_t n_words = bytes / 16 * 4;
+    uint32_t* a = (uint32_t*)bk.alloc((size_t)n_words * 4); uint32_t* sink = (uint32_t*)bk.alloc(4096 * 4);
+    if (!bk.ok()) { bk.free(a); bk.free(sink); return set_err(CASIM_ERR_HIP, bk.msg); }
+    bk.zero(a, (size_t)n_words * 4);
+    hipEvent_t e0, e1;
+    bk.check(hipEventCreate(&e0), "hipEventCreate"); bk.check(hipEventCreate(&e1), "hipEventCreate");
+    auto go = [&]() {
+        if (lane_bytes == 4) bk.launch(casim::stream_probe_kernel<4>, 4096, 1, 256, (size_t)0, (const uint32_t*)a, n_words, sink);
+        else bk.launch(casim::stream_probe_kernel<16>, 4096, 1, 256, (size_t)0, (const uint32_t*)a, n_words, sink);
+    };
+    go();
+    bk.check(hipEventRecord(e0, bk.stream), "hipEventRecord");
+    for (int i = 0; i < iters; ++i) go();
+    bk.check(hipEventRecord(e1, bk.stream), "hipEventRecord");
+    bk.check(hipEventSynchronize(e1), "hipEventSynchronize");
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    bk.free(a); bk.free(sink);
+    *gbps_out = ms > 0 ? ((double)n_words * 4.0 * iters) / (ms * 1e-3) / 1e9 : 0.0;
     return bk.ok() ? CASIM_OK : set_err(CASIM_ERR_HIP, bk.msg);
 }
 

@@ -187,6 +187,11 @@ class Context:
         check(lib.casim_copy_bandwidth(self._h, nbytes, iters, C.byref(out)), "casim_copy_bandwidth")
         return out.value
 
+    def stream_probe_gbps(self, nbytes: int = 1 << 30, lane_bytes: int = 4, iters: int = 5) -> float:
+        out = C.c_double(0)
+        check(lib.casim_stream_probe(self._h, nbytes, lane_bytes, iters, C.byref(out)), "casim_stream_probe")
+        return out.value
+
     def feasibility(self, pegs: _abi.Pegs, groups: _abi.Groups) -> np.ndarray:
         """bit-matrix [NG][ceil(G/64)]: PEG g passes every encoded Filter on a fresh node of group i."""
         wg = (pegs.n_pegs + 63) // 64

@@ -118,6 +118,18 @@ class TableSet:
         """The batch repeated `times` times (distinct memory, same simulations)."""
         return TableSet.concat([self] * times) if times > 1 else self
 
+    def head(self, n_sims: int) -> "TableSet":
+        """The first n_sims simulations (their groups; the PEG table is cut after the last PEG they can see)."""
+        one = self if self.peg_lo is not None else self.as_one_simulation()
+        if n_sims >= one.n_sims:
+            return one
+        ng = int(one.sim_offsets[n_sims])
+        gp = int(one.peg_hi[:ng].max()) if ng else 0
+        pc = {k: (None if v is None else v[:gp]) for k, v in one.pegs.items()}
+        gc = {k: (None if v is None else v[:ng]) for k, v in one.groups.items()}
+        return TableSet(one.dims, pc, gc, one.peg_lo[:ng], one.peg_hi[:ng], None, None,
+                        None if one.global_id is None else one.global_id[:ng], one.sim_offsets[:n_sims + 1].copy())
+
     def select_groups(self, keep: np.ndarray) -> "TableSet":
         """The groups `keep` (ascending indices) of every simulation: how one GPU's shard of a batch is cut out.  PEG table
         replicated, the groups keep their simulation-wide ids in expander keys."""

@@ -1193,6 +1193,41 @@ int orc_check_predicates(orc* o, int template_node, int pod, const char** plugin
     return ok;
 }
 
+/* One whole scale-up simulation: the node-group loop of ScaleUpOrchestrator.ScaleUp
+ * (CA/core/scaleup/orchestrator/orchestrator.go:161-186 -> SchedulablePodGroups :535-570 -> ComputeExpansionOption
+ * :383-427 -> Estimate) restated in one call, so that the CPU baseline is not charged for per-call binding overhead:
+ * per node group i, the PEGs whose exemplar passes CheckPredicates on the fresh template (:552), in input order, go
+ * through orc_estimate.  Per-group scalars land in out[i]; order / placed of group i in order_out / placed_out at
+ * [i * n_pegs, ...) (positions index the group's own schedulable list, whose PEG ids are in sched_out at the same
+ * offset, n_sched_out[i] entries). */
+int orc_scale_up_simulation(orc* o, int n_groups, const int32_t* template_node, int n_pegs, const int32_t* peg_pod,
+                            const int32_t* peg_count, const int32_t* max_nodes, const int32_t* last_index,
+                            orc_estimate_result* out, int32_t* n_sched_out, int32_t* sched_out, int32_t* order_out,
+                            int32_t* placed_out, int64_t* filter_runs_out) {
+    int32_t* pods = malloc(sizeof(int32_t) * (size_t)(n_pegs + 1));
+    int32_t* cnts = malloc(sizeof(int32_t) * (size_t)(n_pegs + 1));
+    int64_t runs = 0;
+    int rc = 0;
+    for (int i = 0; i < n_groups && rc == 0; ++i) {
+        int32_t* ids = sched_out + (size_t)i * (size_t)n_pegs;
+        int n = 0;
+        for (int g = 0; g < n_pegs; ++g) {
+            if (peg_count[g] <= 0) continue;                       /* Exemplar() == nil */
+            o->filter_runs = 0;
+            if (orc_check_predicates(o, template_node[i], peg_pod[g], NULL, NULL) == 1) { ids[n] = g; pods[n] = peg_pod[g]; cnts[n] = peg_count[g]; n++; }
+            runs += 1;
+        }
+        n_sched_out[i] = n;
+        memset(&out[i], 0, sizeof out[i]);
+        out[i].order = order_out + (size_t)i * (size_t)n_pegs; out[i].placed = placed_out + (size_t)i * (size_t)n_pegs;
+        rc = orc_estimate(o, template_node[i], n, pods, cnts, max_nodes[i], last_index[i], 0, &out[i]);
+        runs += out[i].filter_runs;
+    }
+    free(pods); free(cnts);
+    if (filter_runs_out) *filter_runs_out = runs;
+    return rc;
+}
+
 /* ------------------------------------------------------------------------------------- */
 /* HintingSimulator.TrySchedulePods  (filter-out-schedulable)                              */
 /* ------------------------------------------------------------------------------------- */

@@ -109,6 +109,14 @@ int orc_estimate(orc* o, int template_node, int n_pegs, const int32_t* peg_pod,
                  const int32_t* peg_count, int max_nodes, int last_index, int fastpath,
                  orc_estimate_result* out);
 
+/* One whole scale-up simulation (node-group loop of ScaleUpOrchestrator.ScaleUp, orchestrator.go:161-186, :535-570,
+ * :383-427): per group the PEGs passing CheckPredicates on the fresh template, then Estimate.  Arrays of group i start at
+ * i * n_pegs in sched_out / order_out / placed_out; order / placed index the group's own schedulable list. */
+int orc_scale_up_simulation(orc* o, int n_groups, const int32_t* template_node, int n_pegs, const int32_t* peg_pod,
+                            const int32_t* peg_count, const int32_t* max_nodes, const int32_t* last_index,
+                            orc_estimate_result* out, int32_t* n_sched_out, int32_t* sched_out, int32_t* order_out,
+                            int32_t* placed_out, int64_t* filter_runs_out);
+
 /* CheckPredicates(exemplar, template) as in SchedulablePodGroups (orchestrator.go:535-570):
  * returns 1 pass / 0 fail; *plugin_out (may be NULL) receives a static plugin name. */
 int orc_check_predicates(orc* o, int template_node, int pod, const char** plugin_out,

@@ -72,6 +72,8 @@ def lib():
             "orc_set_taint_comparison_ops": (None, [P, C.c_int]),
             "orc_set_list_shuffle": (None, [P, C.c_uint64]),
             "orc_estimate": (C.c_int, [P, C.c_int, C.c_int, i32p, i32p, C.c_int, C.c_int, C.c_int, C.POINTER(EstimateResult)]),
+            "orc_scale_up_simulation": (C.c_int, [P, C.c_int, i32p, C.c_int, i32p, i32p, i32p, i32p, C.POINTER(EstimateResult), i32p, i32p,
+                                                  i32p, i32p, i64p]),
             "orc_check_predicates": (C.c_int, [P, C.c_int, C.c_int, cstrp, cstrp]),
             "orc_run_filters_on_snapshot_node": (C.c_int, [P, C.c_int, C.c_int, cstrp, cstrp]),
             "orc_run_filters_until_passing": (C.c_int, [P, C.c_int, C.POINTER(C.c_int)]),
@@ -256,6 +258,42 @@ class OracleScenario:
         return OracleEstimate(res.node_count, res.pods_scheduled, res.nodes_added, res.limiter_nodes, res.last_index_out,
                               res.req_cpu_sum, res.req_mem_sum, res.filter_runs, order[:n].copy(), placed[:n].copy(),
                               node_pods[:min(res.nodes_added, node_pods_cap)].copy())
+
+    def prepare_simulation(self, template_nodes, pegs, max_nodes, last_index):
+        """Argument block of orc_scale_up_simulation, built once; returns run() -> ([(OracleEstimate, schedulable PEG ids)], filter runs).
+        run() is ONE native call: the whole node-group loop (SchedulablePodGroups + Estimate per group)."""
+        from kubernetes_autoscaler_amd.objects import Pod
+        ng, n = len(template_nodes), len(pegs)
+        tn = np.ascontiguousarray(template_nodes, np.int32)
+        pod_ids, counts = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+        for i, g in enumerate(pegs):
+            ex = g.exemplar()
+            if ex is None:
+                ex = Pod(name="<empty>")
+                self._keep.append(ex)
+            pod_ids[i] = self.pod(ex)
+            counts[i] = len(g.pods)
+        mx, li = np.ascontiguousarray(max_nodes, np.int32), np.ascontiguousarray(last_index, np.int32)
+        res = (EstimateResult * max(ng, 1))()
+        nsched = np.zeros(max(ng, 1), np.int32)
+        sched, order, placed = (np.zeros(max(ng * n, 1), np.int32) for _ in range(3))
+        runs = C.c_int64(0)
+        p = lambda a: a.ctypes.data_as(i32p)
+
+        def run(collect=True):
+            rc = self.L.orc_scale_up_simulation(self.h, ng, p(tn), n, p(pod_ids), p(counts), p(mx), p(li), res, p(nsched), p(sched),
+                                                p(order), p(placed), C.byref(runs))
+            assert rc == 0, rc
+            if not collect:
+                return None, runs.value
+            out = []
+            for i in range(ng):
+                k, r = int(nsched[i]), res[i]
+                out.append((OracleEstimate(r.node_count, r.pods_scheduled, r.nodes_added, r.limiter_nodes, r.last_index_out, r.req_cpu_sum,
+                                           r.req_mem_sum, r.filter_runs, order[i * n:i * n + k].copy(), placed[i * n:i * n + k].copy(),
+                                           np.zeros(0, np.int32)), [int(x) for x in sched[i * n:i * n + k]]))
+            return out, runs.value
+        return run
 
     def check_predicates(self, template_node: int, pod):
         plug, reason = C.c_char_p(), C.c_char_p()

@@ -1,0 +1,101 @@
+"""tools/casim_native: the plain-C++ harness over the C ABI (no Python between the calls).  CPU: the replayed encoder
+calls produce the very tables the Python-driven encoder produced (hash over every column), and the engine half fails
+loudly without a GPU.  GPU: results of the native run == the oracle, for every entry point."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import kubernetes_autoscaler_amd as kaa
+from kubernetes_autoscaler_amd import workloads
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import native_trace as nt  # noqa: E402
+
+
+def _cases():
+    yield "C0", workloads.config_c0()
+    yield "C2-small", workloads.config_c2(n_groups=6, n_pegs=40, pods_per_peg=5, cap=8)
+    yield "C4-small", workloads.config_c4(n_groups=5, n_pegs=30, pods_per_peg=4, cap=6)
+    for seed in (1001, 2003, 77):
+        yield f"fuzz{seed}", workloads.fuzz(seed)
+
+
+@pytest.mark.parametrize("name,w", list(_cases()), ids=[n for n, _ in _cases()])
+def test_replayed_encoder_calls_build_identical_tables(tmp_path, name, w):
+    path = str(tmp_path / "t.trace")
+    enc = nt.trace_estimate(w, path)
+    rc, out = nt.run_native(path, repeat=1)
+    assert out["pegs"] == enc.pegs.n_pegs and out["groups"] == enc.groups.n_groups
+    assert out["tables_fnv"] == nt.tables_fnv(enc.pegs, enc.groups)
+    if kaa.device_count() == 0:
+        assert rc == 3 and "no HIP device" in out["engine_error"]    # no CPU fallback in the engine
+    enc.close()
+
+
+def test_pending_and_removal_traces_replay(tmp_path):
+    w = workloads.fuzz_pending(7)
+    enc, _ = nt.trace_pending(w, str(tmp_path / "p.trace"))
+    rc, out = nt.run_native(str(tmp_path / "p.trace"), repeat=1)
+    assert out["tables_fnv"] == nt.tables_fnv(enc.pegs, enc.groups)
+    enc.close()
+    r = workloads.fuzz_removals(52)
+    enc, _, _ = nt.trace_removals(r, str(tmp_path / "r.trace"))
+    rc, out = nt.run_native(str(tmp_path / "r.trace"), repeat=1)
+    assert out["tables_fnv"] == nt.tables_fnv(enc.pegs, enc.groups)
+    enc.close()
+
+
+# ---- GPU: the native path end to end against the oracle --------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,w", list(_cases()), ids=[n for n, _ in _cases()])
+def test_native_estimate_matches_the_oracle(tmp_path, name, w):
+    from harness import GroupSpec, Scenario, run_oracle
+    path, dump = str(tmp_path / "t.trace"), str(tmp_path / "t.bin")
+    nt.trace_estimate(w, path, kinds=(0,), iters=2).close()
+    rc, out = nt.run_native(path, dump=dump, repeat=1)
+    assert rc == 0, out
+    d = nt.read_dump(dump)
+    sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups],
+                  existing=w.existing, lanes=w.lanes, device_csr=True)
+    want = run_oracle(sc)
+    for i, (est, ids) in enumerate(want):
+        a, b = int(d["offsets"][i]), int(d["offsets"][i + 1])
+        if int(d["status"][i]) != 0:
+            continue   # delegated group (predicate outside the encoded subset): the oracle's answer is the Go path's
+        assert list(d["order"][a:b]) == [ids[k] for k in est.order], (name, i)
+        assert list(d["placed"][a:b]) == list(est.placed), (name, i)
+        assert (int(d["node_count"][i]), int(d["pods"][i]), int(d["nodes_added"][i]), int(d["limiter"][i]), int(d["last_index"][i])) == \
+               (est.node_count, est.pods_scheduled, est.nodes_added, est.limiter_nodes, est.last_index_out), (name, i)
+
+
+@pytest.mark.gpu
+def test_native_try_schedule_and_removals_match_the_oracle(tmp_path):
+    from harness import RemovalCase, SchedCase, removal_oracle, sched_oracle
+    for seed in (7, 19, 23):
+        w = workloads.fuzz_pending(seed)
+        path, dump = str(tmp_path / f"p{seed}.trace"), str(tmp_path / f"p{seed}.bin")
+        nt.trace_pending(w, path, iters=1)[0].close()
+        rc, out = nt.run_native(path, dump=dump, repeat=1)
+        assert rc == 0, out
+        d = nt.read_dump(dump)
+        want = sched_oracle(SchedCase(nodes=w.nodes, pods=w.pods, hints=w.hints, acceptable=w.acceptable, break_on_failure=w.break_on_failure,
+                                      last_index=w.last_index))
+        if int(d["tail"][0]) == 0:
+            assert list(d["node_out"]) == list(want[0]) and int(d["tail"][1]) == want[1] and int(d["tail"][2]) == want[2], seed
+    for seed in (52, 61):
+        r = workloads.fuzz_removals(seed)
+        path, dump = str(tmp_path / f"r{seed}.trace"), str(tmp_path / f"r{seed}.bin")
+        nt.trace_removals(r, path, iters=1)[0].close()
+        rc, out = nt.run_native(path, dump=dump, repeat=1)
+        assert rc == 0, out
+        d = nt.read_dump(dump)
+        if r.hints is not None:
+            continue   # traces carry no per-pod hints for removals yet
+        want = removal_oracle(RemovalCase(nodes=r.nodes, candidates=r.candidates, destination=r.destination, hints=r.hints, persist=r.persist,
+                                          max_removable=r.max_removable, last_index=r.last_index))
+        if int(d["tail"][0]) == 0:
+            assert list(d["removable"]) == list(want.removable), seed
+            assert list(d["node_out"]) == list(want.node_out), seed

@@ -15,13 +15,13 @@ import sys
 root, out_path = sys.argv[1], sys.argv[2]
 
 
-def per_launch(counter):
+def per_launch(counter, like="%pack%"):
     best = None
-    for db_path in glob.glob(os.path.join(root, f"prof_pmc_{counter}*", "**", "*.db"), recursive=True):
+    for db_path in glob.glob(os.path.join(root, "prof_pmc_*", "**", "*.db"), recursive=True):
         cur = sqlite3.connect(db_path).cursor()
         rows = cur.execute("select kernel_name, grid_size_x, avg(value), count(*) from counters_collection "
-                           "where counter_name = ? and kernel_name like '%pack%' group by kernel_name, grid_size_x "
-                           "order by grid_size_x desc", (counter,)).fetchall()
+                           "where counter_name = ? and kernel_name like ? group by kernel_name, grid_size_x "
+                           "order by grid_size_x desc", (counter, like)).fetchall()
         if rows:
             best = dict(kernel=rows[0][0], grid_x=int(rows[0][1]), kib=float(rows[0][2]), dispatches=int(rows[0][3]), db=os.path.relpath(db_path, root))
     return best
@@ -35,5 +35,25 @@ rec = {"kernel": f["kernel"], "waves_per_launch": f["grid_x"] // 64, "fetch_kib_
        "traffic_bytes_per_launch": f["kib"] * 1024 * 2 + w["kib"] * 1024,
        "traffic_bytes_per_launch_uncorrected": (f["kib"] + w["kib"]) * 1024,
        "dispatches_averaged": [f["dispatches"], w["dispatches"]], "source": [f["db"], w["db"]], "run": os.path.basename(os.path.normpath(root))}
+# instruction issue (the packer's actual bound): wave-instructions per launch of the same dispatch size
+for key, counter in (("valu_insts_per_launch", "SQ_INSTS_VALU"), ("salu_insts_per_launch", "SQ_INSTS_SALU"), ("waves", "SQ_WAVES"),
+                     ("active_inst_valu_quadcycles", "SQ_ACTIVE_INST_VALU"), ("wave_quadcycles", "SQ_WAVE_CYCLES"), ("busy_cycles", "SQ_BUSY_CYCLES")):
+    r = per_launch(counter)
+    if r and r["grid_x"] == f["grid_x"]:
+        rec[key] = r["kib"]
+if rec.get("valu_insts_per_launch") and rec.get("active_inst_valu_quadcycles"):
+    rec["cycles_per_valu"] = 4.0 * rec["active_inst_valu_quadcycles"] / rec["valu_insts_per_launch"]
+# calibration of the FETCH_SIZE rule on known streams (casim_stream_probe: 4 B / lane and 16 B / lane reads of 1 GiB)
+cal = {}
+for width in (4, 16):
+    r = per_launch("FETCH_SIZE", f"%stream_probe_kernel<{width}>%")
+    if r:
+        cal[f"read_{width}B_per_lane"] = {"fetch_kib_reported": r["kib"], "known_bytes": 1 << 30, "reported_over_known": r["kib"] * 1024 / float(1 << 30)}
+if cal:
+    rec["fetch_size_calibration"] = cal
+    c4 = cal.get("read_4B_per_lane")
+    if c4 and c4["reported_over_known"] > 0:
+        rec["fetch_bytes_corrected_by_4B_probe"] = f["kib"] * 1024 / c4["reported_over_known"]
+        rec["traffic_bytes_per_launch_by_4B_probe"] = rec["fetch_bytes_corrected_by_4B_probe"] + w["kib"] * 1024
 json.dump(rec, open(out_path, "w"), indent=1)
 print(json.dumps(rec))

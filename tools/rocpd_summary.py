@@ -12,9 +12,11 @@ def summarize(path):
     cur = db.cursor()
     print(f"## {path}")
     try:
+        # one row per (kernel, grid size): a batch launch and a single-simulation launch of the same kernel are different
+        # workloads and must not be averaged together
         rows = cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
-                           "max(grid_x), max(workgroup_x), max(lds_size), max(vgpr_count), max(sgpr_count), max(scratch_size) "
-                           "from kernels group by name order by sum(duration) desc").fetchall()
+                           "grid_x, max(workgroup_x), max(lds_size), max(vgpr_count), max(sgpr_count), max(scratch_size) "
+                           "from kernels group by name, grid_x order by sum(duration) desc").fetchall()
         tot = sum(r[2] for r in rows) or 1
         print("kernel,calls,total_ns,avg_ns,min_ns,max_ns,pct,grid_x,wg_x,lds,vgpr,sgpr,scratch")
         for r in rows:
@@ -28,12 +30,13 @@ def summarize(path):
             ccol = "counter_name" if "counter_name" in cols else None
             vcol = "value" if "value" in cols else ("counter_value" if "counter_value" in cols else None)
             if namecol and ccol and vcol:
-                rows = cur.execute(f"select {namecol}, {ccol}, count(*), avg({vcol}), sum({vcol}) from counters_collection "
-                                   f"group by {namecol}, {ccol} order by {namecol}, {ccol}").fetchall()
+                gcol = "grid_size_x" if "grid_size_x" in cols else "0"
+                rows = cur.execute(f"select {namecol}, {ccol}, count(*), avg({vcol}), sum({vcol}), {gcol} from counters_collection "
+                                   f"group by {namecol}, {gcol}, {ccol} order by {namecol}, {gcol}, {ccol}").fetchall()
                 if rows:
-                    print("kernel,counter,dispatches,mean_per_dispatch,sum")
+                    print("kernel,grid_x,counter,dispatches,mean_per_dispatch,sum")
                     for r in rows:
-                        print(f"{str(r[0])[:70]},{r[1]},{r[2]},{r[3]:.6g},{r[4]:.6g}")
+                        print(f"{str(r[0])[:70]},{r[5]},{r[1]},{r[2]},{r[3]:.6g},{r[4]:.6g}")
             else:
                 print("counters_collection columns:", cols)
     except sqlite3.Error as e:
