@@ -142,7 +142,7 @@ def cpu_baseline(workloads, make, seeds, checks_per_sim, budget_s=12.0):
 def cpu_worker(config, seed, budget_s):
     """One process of the multi-core CPU leg: one simulation of `config`, waits for the start line, loops ~budget_s."""
     from kubernetes_autoscaler_amd import workloads
-    _, s, run = oracle_simulation(workloads, workloads.CONFIGS[config], seed)
+    _, s, run = oracle_simulation(workloads, workloads.CONFIGS[config], None if config == "C0" else seed)
     print("ready", flush=True)
     sys.stdin.readline()
     n, t0 = 0, time.perf_counter()

@@ -6,7 +6,7 @@ import os
 import pytest
 
 from kubernetes_autoscaler_amd import estimator as est
-from kubernetes_autoscaler_amd import expander, objects
+from kubernetes_autoscaler_amd import expander, objects, workloads
 
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")))
 
@@ -165,9 +165,30 @@ def test_bench_multi_process_cpu_leg():
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
-    out = bench.cpu_baseline_all_cores(8, 5, 16, budget_s=0.3, max_procs=2, sims_per_proc=2)
+    out = bench.cpu_baseline_all_cores("C0", 1000, budget_s=0.3, max_procs=2)
     assert "error" not in out, out
     assert out["cores"] in (1, 2) and out["sims_per_s"] > 0 and out["unit"] == "checks/s"
+
+
+def test_bench_single_thread_cpu_leg_uses_the_native_loop():
+    """bench.py's cpu_baseline: orc_scale_up_simulation (one native call per simulation) == the per-call oracle path."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from harness import GroupSpec, Scenario, run_oracle
+    make = lambda seed_offset=0: workloads.config_c2(seed_offset, n_groups=6, n_pegs=40, pods_per_peg=5, cap=8)
+    w, s, run = bench.oracle_simulation(workloads, make, 3)
+    got, _, runs = run()
+    s.close()
+    want = run_oracle(Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, None) for g in w.groups], device_csr=True))
+    assert runs > 0 and len(got) == len(want)
+    for (a, ia), (b, ib) in zip(got, want):
+        assert ia == ib and list(a.order) == list(b.order) and list(a.placed) == list(b.placed)
+        assert (a.node_count, a.pods_scheduled, a.nodes_added, a.limiter_nodes, a.last_index_out) == \
+               (b.node_count, b.pods_scheduled, b.nodes_added, b.limiter_nodes, b.last_index_out)
+    out = bench.cpu_baseline(workloads, make, range(2), 1000, budget_s=0.2)
+    assert out["kind"] == "port" and out["cores"] == 1 and out["sims_per_s"] > 0
 
 
 def test_hints_drop_old_property():
