@@ -258,7 +258,7 @@ def config_rows(kaa, ctx, workloads, kinds, iters=20):
     return rows
 
 
-def c3_sharded(kaa, ctx, workloads, kinds, rank, world, dist, torch, dev_index, allreduce, iters=200):
+def c3_sharded(kaa, ctx, workloads, kinds, rank, world, dist, torch, dev_index, allreduce, collective, iters=200):
     """BASELINE config[3]: one C3 simulation (50k pods x 4k nodes, 64 node groups); node groups block-partitioned over
     the ranks, PEG table replicated, ONE all-reduce(min) on the packed key.  Strong scaling: the work is fixed."""
     import numpy as np
@@ -272,12 +272,12 @@ def c3_sharded(kaa, ctx, workloads, kinds, rank, world, dist, torch, dev_index, 
         def it():
             p.run()
             p.best_option_sims(kinds, per_sim=True, fetch=False, dev_packed_ptr=key.data_ptr(), n_sims=1)
-            if world > 1:
+            if collective:
                 allreduce(key, dist.ReduceOp.MIN)
         for _ in range(10):
             it()
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
         t0 = time.perf_counter()
         for _ in range(iters):
@@ -287,7 +287,7 @@ def c3_sharded(kaa, ctx, workloads, kinds, rank, world, dist, torch, dev_index, 
         winner = int(key.item())
         # the collective alone (same tensor, nothing else enqueued)
         red_ms = None
-        if world > 1:
+        if collective:
             torch.cuda.synchronize(); dist.barrier()
             t1 = time.perf_counter()
             for _ in range(iters):
@@ -300,7 +300,7 @@ def c3_sharded(kaa, ctx, workloads, kinds, rank, world, dist, torch, dev_index, 
         res = p.fetch()
         chk, _ = checks_of(mine, res)
     enc.close()
-    if world > 1:
+    if collective:
         tc = torch.tensor([chk], dtype=torch.int64, device=f"cuda:{dev_index}")
         allreduce(tc, dist.ReduceOp.SUM)
         chk = int(tc.item())
@@ -308,7 +308,7 @@ def c3_sharded(kaa, ctx, workloads, kinds, rank, world, dist, torch, dev_index, 
             "groups_on_rank0": mine.n_groups, "ms_per_simulation": dt / iters * 1e3, "checks": chk,
             "checks_per_s": chk / (dt / iters), "winner_group": -1 if winner == 0x7FFFFFFFFFFFFFFF else winner & 0xFFFFF,
             "winner_nodes": None if winner == 0x7FFFFFFFFFFFFFFF else winner >> 20,
-            "collective": ("rccl all_reduce(min), 1 x int64" if world > 1 else "none (1 rank)"), "all_reduce_ms": red_ms}
+            "collective": (f"all_reduce(min), 1 x int64, {world} rank(s)" if collective else "none (1 rank)"), "all_reduce_ms": red_ms}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -361,7 +361,10 @@ def main():
     dev_index = 0 if one_gpu else local_rank
     torch.cuda.set_device(dev_index)
     backend = None
-    if world > 1:
+    # CASIM_BENCH_FORCE_DIST=1 (under a launcher): build the process group and run the per-step collective even with ONE
+    # rank — how the RCCL calls are exercised on a 1-GPU box (RCCL refuses two ranks on one device).
+    collective = world > 1 or (os.environ.get("CASIM_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("CASIM_BENCH_BACKEND", "nccl")
         if backend == "nccl":
@@ -398,27 +401,27 @@ def main():
     def step():
         prob.run()
         prob.best_option_sims(kinds, per_sim=True, fetch=False, dev_packed_ptr=keys.data_ptr(), n_sims=n_sims)
-        if world > 1:
+        if collective:
             allreduce(keys, dist.ReduceOp.MIN)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if collective:
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if collective:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t_start
     res = prob.fetch()
     my_checks, my_nnz = checks_of(mine, res)
     checks_per_step = my_checks
-    if world > 1:
+    if collective:
         tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev_index}")
         allreduce(tt, dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -430,7 +433,7 @@ def main():
     side = {}
     if not args.no_c3:   # every rank takes part (collective inside)
         try:
-            side["c3_sharded"] = c3_sharded(kaa, ctx, workloads, kinds, rank, world, dist, torch, dev_index, allreduce)
+            side["c3_sharded"] = c3_sharded(kaa, ctx, workloads, kinds, rank, world, dist, torch, dev_index, allreduce, collective)
         except Exception as e:
             side["c3_sharded"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
@@ -502,7 +505,8 @@ def main():
                           "expander": args.expander,
                           "partition": ("node groups of every simulation block-partitioned over the ranks (rotated), PEG table replicated"
                                         if world > 1 else "single GPU"),
-                          "reduce": (f"{backend} all_reduce(min) on {n_sims} packed int64 keys per step" if world > 1 else "device kernel only"),
+                          "reduce": (f"{'rccl' if backend == 'nccl' else backend} all_reduce(min) on {n_sims} packed int64 keys per step, {world} rank(s)"
+                                     if collective else "device kernel only"),
                           "all_ranks_on_one_gpu": bool(one_gpu and world > 1)},
                "roofline": roofline, "cpu_baseline": cpu}
         out.update(extra)
@@ -510,7 +514,7 @@ def main():
         print(json.dumps(out))
     prob.close()
     ctx.close()
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
     return out

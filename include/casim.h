@@ -256,6 +256,36 @@ int32_t casim_feasibility(casim_ctx* ctx, const casim_pegs* pegs, const casim_gr
                           uint64_t* out_bits);
 
 /*
+ * Why a PEG does not fit a fresh node of a group: the SchedulingError of CheckPredicates for every cell of the
+ * SchedulablePodGroups matrix, i.e. what the orchestrator stores in eg.SchedulingErrors[nodeGroup.Id()]
+ * (orchestrator.go:553-567; FailingPredicateError: plugin name + reasons, CA/simulator/clustersnapshot/scheduling_error.go:40-52,
+ * filled by RunFiltersOnNode, plugin_runner.go:168-180).  One uint16 per (group, PEG): 0 = the pod fits; otherwise the low 4
+ * bits name the FIRST failing Filter plugin in the scheduler's Filter order (default_plugins.go:34-51: NodeUnschedulable,
+ * NodeName, TaintToleration, NodeAffinity, NodePorts, NodeResourcesFit, ..., PodTopologySpread, InterPodAffinity) and the upper
+ * bits carry that plugin's reasons: for NodeResourcesFit ALL of them, as fitsRequest reports them (fit.go:678-765) —
+ * CASIM_REASON_TOO_MANY_PODS and CASIM_REASON_INSUFFICIENT(lane) per lane.  The other plugins have one fixed reason string each
+ * (INTEGRATION.md lists them).  port_block = casim_enc_port_block (tells NodePorts conflicts with pods preloaded on the
+ * template from hostname anti-affinity against them; NULL = every node-local exclusion is reported as InterPodAffinity).
+ * Layout [NG][L], L = n_pegs, or max(peg_hi - peg_lo) with entry k standing for PEG peg_lo[i] + k.  Synchronous.
+ * A PEG flagged CASIM_PEG_UNSUPPORTED that passes the encoded subset gets CASIM_PLUGIN_UNKNOWN (the shim runs Go CheckPredicates).
+ */
+#define CASIM_PLUGIN_NONE 0
+#define CASIM_PLUGIN_NODE_AFFINITY_PREFILTER 1   /* "PreFilter filtered the Node out" (per-node mode only) */
+#define CASIM_PLUGIN_NODE_UNSCHEDULABLE 2        /* "node(s) were unschedulable" */
+#define CASIM_PLUGIN_TAINT_TOLERATION 3          /* "node(s) had untolerated taint(s)" */
+#define CASIM_PLUGIN_NODE_AFFINITY 4             /* "node(s) didn't match Pod's node affinity/selector" */
+#define CASIM_PLUGIN_NODE_PORTS 5                /* "node(s) didn't have free ports for the requested pod ports" */
+#define CASIM_PLUGIN_NODE_RESOURCES_FIT 6        /* "Too many pods", "Insufficient <resource>" ... */
+#define CASIM_PLUGIN_POD_TOPOLOGY_SPREAD 7
+#define CASIM_PLUGIN_INTER_POD_AFFINITY 8        /* "node(s) didn't satisfy anti-affinity rules" / "... didn't match pod affinity rules" */
+#define CASIM_PLUGIN_UNKNOWN 15                  /* outside the encoded subset: ask the Go path */
+#define CASIM_PLUGIN_MASK 0xfu
+#define CASIM_REASON_TOO_MANY_PODS 0x10u
+#define CASIM_REASON_INSUFFICIENT(lane) (0x20u << (lane))
+int32_t casim_feasibility_reasons(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups,
+                                  const uint64_t* port_block, uint16_t* out_codes);
+
+/*
  * Dense per-pod x per-node predicate matrix on resident data (the streaming form of the
  * same kernel; rows = PEG records expanded by `count`, columns = groups expanded by
  * `repeat` nodes).  Used for roofline measurement and as the device-side building block of

@@ -20,6 +20,19 @@ NGF_UNSCHEDULABLE = 0x1
 
 EXPANDER_LEAST_NODES, EXPANDER_LEAST_WASTE, EXPANDER_MOST_PODS = 0, 1, 2
 
+# casim_feasibility_reasons codes: plugin in the low 4 bits, NodeResourcesFit reasons above
+PLUGIN_MASK = 0xF
+PLUGIN_NAMES = {0: "", 1: "NodeAffinity", 2: "NodeUnschedulable", 3: "TaintToleration", 4: "NodeAffinity", 5: "NodePorts",
+                6: "NodeResourcesFit", 7: "PodTopologySpread", 8: "InterPodAffinity", 15: "<unknown>"}
+PLUGIN_REASONS = {1: "PreFilter filtered the Node out", 2: "node(s) were unschedulable", 3: "node(s) had untolerated taint(s)",
+                  4: "node(s) didn't match Pod's node affinity/selector", 5: "node(s) didn't have free ports for the requested pod ports",
+                  7: "node(s) didn't match pod topology spread constraints", 8: "node(s) didn't satisfy anti-affinity rules"}
+REASON_TOO_MANY_PODS = 0x10
+
+
+def reason_insufficient(lane: int) -> int:
+    return 0x20 << lane
+
 i32p = C.POINTER(C.c_int32)
 i64p = C.POINTER(C.c_int64)
 u32p = C.POINTER(C.c_uint32)
@@ -128,6 +141,7 @@ PROTOTYPES = {
     "casim_problem_set_group_result": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(ClusterEstimateResult)]),
     "casim_estimate_batch": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(Options), C.POINTER(Results)]),
     "casim_feasibility": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), u64p]),
+    "casim_feasibility_reasons": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), u64p, C.POINTER(C.c_uint16)]),
     "casim_problem_dense_check": (C.c_int32, [C.c_void_p, C.c_int32, u64p, i64p, i64p]),
     "casim_best_option": (C.c_int32, [C.c_void_p, i32p, C.c_int32, C.c_int32, i32p, i32p, u8p, i64p, C.c_void_p]),
     "casim_best_option_sims": (C.c_int32, [C.c_void_p, C.POINTER(OptionQuery)]),

@@ -315,6 +315,22 @@ int32_t casim_feasibility(casim_ctx* ctx, const casim_pegs* pegs, const casim_gr
     return rc;
 }
 
+int32_t casim_feasibility_reasons(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups, const uint64_t* port_block,
+                                  uint16_t* out_codes) {
+    g_err.clear();
+    if (!ctx || !groups || !out_codes) return set_err(CASIM_ERR_INVALID, "null argument");
+    casim_groups g = *groups;
+    g.peg_offsets = nullptr; g.peg_index = nullptr;
+    casim_problem* p = casim_problem_create(ctx, pegs, &g, nullptr);
+    if (!p) return CASIM_ERR_INVALID;
+    const int32_t rc = p->prob->reasons(port_block, out_codes);
+    if (rc != CASIM_OK) set_err(rc, p->prob->error());
+    const std::string keep = g_err;
+    casim_problem_destroy(p);
+    g_err = keep;
+    return rc;
+}
+
 int32_t casim_best_option(casim_problem* p, const int32_t* kinds, int32_t n_kinds, int32_t group_id_base, int32_t* best_ng_out,
                           int32_t* n_best_out, uint8_t* best_set_out, int64_t* key_out, void* dev_key_out) {
     PROB_ENTER(p);

@@ -117,6 +117,51 @@ CS_GLOBAL void feas_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg]*/,
     if (cs::lane() == 0 && (k >> 6) < Wg) bits[(int64_t)ng * Wg + (k >> 6)] = b;
 }
 
+// K_reason: the SchedulingError of every cell of the SchedulablePodGroups matrix (see casim_feasibility_reasons): first
+// failing Filter plugin in the scheduler's Filter order + the reasons of NodeResourcesFit.  Same geometry as K_feas.
+CS_DEVICE uint32_t fresh_node_verdict(const DevTables& t, const uint64_t* CS_RESTRICT port_block, int g, int ng) {
+    const uint32_t pf = t.pflags[g];
+    if ((t.gflags[ng] & CASIM_NG_UNSCHEDULABLE) && !(pf & CASIM_PEG_TOLERATES_UNSCHEDULABLE)) return CASIM_PLUGIN_NODE_UNSCHEDULABLE;
+    const uint64_t* tol = t.tol + (int64_t)g * t.Wt;
+    const uint64_t* tnt = t.taint + (int64_t)ng * t.Wt;
+    for (int w = 0; w < t.Wt; ++w) if (tnt[w] & ~tol[w]) return CASIM_PLUGIN_TAINT_TOLERATION;
+    const uint64_t* sel = t.sel + (int64_t)g * t.Wl;
+    const uint64_t* lab = t.label + (int64_t)ng * t.Wl;
+    for (int w = 0; w < t.Wl; ++w) if (sel[w] & ~lab[w]) return CASIM_PLUGIN_NODE_AFFINITY;
+    const uint64_t* xb = t.xblock + (int64_t)g * t.Wx;
+    const uint64_t* ix = t.init_excl + (int64_t)ng * t.Wx;
+    bool other_excl = false;
+    for (int w = 0; w < t.Wx; ++w) {
+        const uint64_t hit = xb[w] & ix[w];
+        if (port_block && (hit & port_block[(int64_t)g * t.Wx + w])) return CASIM_PLUGIN_NODE_PORTS;
+        other_excl = other_excl || hit != 0;
+    }
+    // NodeResourcesFit: every reason, as fitsRequest collects them (fit.go:681-765)
+    uint32_t fit = 0;
+    if (t.init_pods[ng] + 1 > t.allowed[ng]) fit |= CASIM_REASON_TOO_MANY_PODS;
+    bool all_zero = true;
+    for (int r = 0; r < t.R; ++r) all_zero = all_zero && t.req[(int64_t)g * t.R + r] == 0;
+    if (!all_zero)
+        for (int r = 0; r < t.R; ++r) {
+            const int64_t q = t.req[(int64_t)g * t.R + r];
+            if (q > 0 && q > t.alloc[(int64_t)ng * t.R + r] - t.init_req[(int64_t)ng * t.R + r]) fit |= CASIM_REASON_INSUFFICIENT(r);
+        }
+    if (fit) return CASIM_PLUGIN_NODE_RESOURCES_FIT | fit;
+    if (other_excl) return CASIM_PLUGIN_INTER_POD_AFFINITY;
+    const uint64_t* zb = t.zblock + (int64_t)g * t.Wz;
+    const uint64_t* iz = t.init_zone + (int64_t)ng * t.Wz;
+    for (int w = 0; w < t.Wz; ++w) if (zb[w] & iz[w]) return CASIM_PLUGIN_INTER_POD_AFFINITY;
+    if (pf & CASIM_PEG_UNSUPPORTED) return CASIM_PLUGIN_UNKNOWN;
+    return CASIM_PLUGIN_NONE;
+}
+CS_GLOBAL void reason_kernel(DevTables t, const uint64_t* CS_RESTRICT port_block, uint16_t* CS_RESTRICT out /*[NG][L]*/, int L) {
+    const int ng = cs::bid_y();
+    const int k = cs::bid() * cs::nthreads() + cs::tid();
+    if (k >= L) return;
+    const int lo = t.peg_lo[ng], hi = t.peg_hi[ng];
+    out[(int64_t)ng * L + k] = lo + k < hi ? (uint16_t)fresh_node_verdict(t, port_block, lo + k, ng) : (uint16_t)0;
+}
+
 // K_csr_count: nnz per group; one block (256 threads) per group.
 CS_GLOBAL void csr_count_kernel(const uint64_t* CS_RESTRICT bits, int Wg, int32_t* CS_RESTRICT counts) {
     const int ng = cs::bid();
@@ -133,32 +178,53 @@ CS_GLOBAL void csr_count_kernel(const uint64_t* CS_RESTRICT bits, int Wg, int32_
         counts[ng] = (int32_t)s;
     }
 }
-// K_csr_scan: exclusive scan of counts -> offsets[NG+1]; single block: every thread owns a contiguous chunk, the chunk sums
-// are scanned per wave (log-step lane exchange) and across waves through LDS (dyn smem: 4 B per wave).  A batch of
-// thousands of simulations has tens of thousands of groups: a one-thread scan would cost milliseconds.
-CS_GLOBAL void csr_scan_kernel(const int32_t* CS_RESTRICT counts, int NG, int32_t* CS_RESTRICT offsets) {
-    const int tid = cs::tid(), nt = cs::nthreads(), lane = cs::lane(), wave = tid >> 6, nw = (nt + 63) >> 6;
-    const int chunk = (NG + nt - 1) / nt;
-    const int a = tid * chunk < NG ? tid * chunk : NG, b = a + chunk < NG ? a + chunk : NG;
-    uint32_t mine = 0;
-    for (int i = a; i < b; ++i) mine += (uint32_t)counts[i];
+// K_csr_scan: exclusive scan of the per-group counts -> offsets[NG+1], in two launches so that a batch of thousands of
+// simulations (tens of thousands of groups) is scanned by many blocks with coalesced loads instead of one block walking
+// serial chunks (0.128 ms of a 2.3 ms step at NG = 81920, profiles/r02a_rocpd_summary.txt):
+//   csr_scan_local_kernel  block b scans its 1024 groups (one element per thread: wave scan by lane exchange + LDS across
+//                          waves), writes the block-local exclusive prefix and its block total; with rows of <= 16 words the
+//                          popcount of the row (K_csr_count) is folded in;
+//   csr_scan_fix_kernel    block b adds the totals of the blocks before it (one wave sums them) and the last block writes
+//                          offsets[NG].
+CS_DEVICE uint32_t block_exclusive_scan(uint32_t mine, uint32_t* sm /*[nw + 1]*/, uint32_t* total) {
+    const int tid = cs::tid(), lane = cs::lane(), wave = tid >> 6, nw = (cs::nthreads() + 63) >> 6;
     uint32_t incl = mine;
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t o = (uint32_t)cs::readlane_u64(incl, lane >= d ? lane - d : lane);
         if (lane >= d) incl += o;
     }
-    uint32_t* sm = (uint32_t*)cs::dyn_smem();   // [nw]
     if (lane == 63) sm[wave] = incl;
     cs::sync();
-    uint32_t base = 0;
-    for (int w = 0; w < wave; ++w) base += sm[w];
-    int32_t s = (int32_t)(base + incl - mine);
-    for (int i = a; i < b; ++i) { offsets[i] = s; s += counts[i]; }
-    if (tid == nt - 1) {
-        uint32_t tot = 0;
-        for (int w = 0; w < nw; ++w) tot += sm[w];
-        offsets[NG] = (int32_t)tot;
+    uint32_t base = 0, tot = 0;
+    for (int w = 0; w < nw; ++w) { const uint32_t v = sm[w]; if (w < wave) base += v; tot += v; }
+    *total = tot;
+    return base + incl - mine;
+}
+CS_GLOBAL void csr_scan_local_kernel(const int32_t* CS_RESTRICT counts, const uint64_t* CS_RESTRICT bits, int Wg, int NG,
+                                     int32_t* CS_RESTRICT offsets, int32_t* CS_RESTRICT block_sums, int32_t* CS_RESTRICT counts_out) {
+    const int i = cs::bid() * cs::nthreads() + cs::tid();
+    uint32_t mine = 0;
+    if (i < NG) {
+        if (bits) { for (int w = 0; w < Wg; ++w) mine += (uint32_t)cs::popc64(bits[(int64_t)i * Wg + w]); counts_out[i] = (int32_t)mine; }
+        else mine = (uint32_t)counts[i];
     }
+    uint32_t total = 0;
+    const uint32_t excl = block_exclusive_scan(mine, (uint32_t*)cs::dyn_smem(), &total);
+    if (i < NG) offsets[i] = (int32_t)excl;
+    if (cs::tid() == 0) block_sums[cs::bid()] = (int32_t)total;
+}
+CS_GLOBAL void csr_scan_fix_kernel(int NG, int32_t* CS_RESTRICT offsets, const int32_t* CS_RESTRICT block_sums, int nb) {
+    const int b = cs::bid(), tid = cs::tid(), lane = cs::lane();
+    uint32_t* sm = (uint32_t*)cs::dyn_smem();   // [1]
+    if (tid < 64) {   // wave 0: sum of the totals of the blocks in front of this one (and of all of them for the tail entry)
+        uint32_t before = 0, all = 0;
+        for (int k = lane; k < nb; k += 64) { const uint32_t v = (uint32_t)block_sums[k]; all += v; if (k < b) before += v; }
+        before = cs::wave_sum_u32(before); all = cs::wave_sum_u32(all);
+        if (lane == 0) { sm[0] = before; if (b == nb - 1) offsets[NG] = (int32_t)all; }
+    }
+    cs::sync();
+    const int i = b * cs::nthreads() + tid;
+    if (b > 0 && i < NG) offsets[i] += (int32_t)sm[0];
 }
 // K_csr_fill: PEG ids of each group in ascending order; one wave per group, 64 words per step.
 CS_GLOBAL void csr_fill_kernel(const uint64_t* CS_RESTRICT bits, int Wg, const int32_t* CS_RESTRICT offsets,
@@ -352,7 +418,11 @@ CS_GLOBAL void option_kernel(OptionArgs a) {
     for (int i = g0 + tid; i < g1; i += nt)
         a.best_set[i] = (a.status[i] == CASIM_NG_OK && a.node_count[i] > 0 && a.pods[i] > 0 && (!a.valid || a.valid[i])) ? 1 : 0;
     cs::sync();
-    for (int f = 0; f < a.n_kinds; ++f) {
+#ifndef CASIM_HOST_EMU
+#pragma unroll
+#endif
+    for (int f = 0; f < 8; ++f) {   // constant bound + unroll: kinds[f] is a kernel-argument scalar, not a scratch copy of the array
+        if (f >= a.n_kinds) break;
         uint64_t mine = ~0ull;
         for (int i = g0 + tid; i < g1; i += nt)
             if (a.best_set[i]) { const uint64_t m = option_metric(a, a.kinds[f], i); mine = m < mine ? m : mine; }
@@ -400,8 +470,11 @@ CS_GLOBAL void option_kernel(OptionArgs a) {
         const int64_t none = 0x7fffffffffffffffll;
         for (int i = 0; i < 10; ++i) a.key_out[i] = none;
         if (bi != ~0ull) {
-            for (int f = 0; f < a.n_kinds; ++f)
-                a.key_out[1 + f] = (int64_t)(option_metric(a, a.kinds[f], (int)bi) ^ 0x8000000000000000ull);
+#ifndef CASIM_HOST_EMU
+#pragma unroll
+#endif
+            for (int f = 0; f < 8; ++f)
+                if (f < a.n_kinds) a.key_out[1 + f] = (int64_t)(option_metric(a, a.kinds[f], (int)bi) ^ 0x8000000000000000ull);
             const int64_t gid = a.global_id ? (int64_t)a.global_id[bi] : (int64_t)a.group_id_base + (int64_t)bi;
             a.key_out[9] = gid;
             if (a.n_kinds > 0) {

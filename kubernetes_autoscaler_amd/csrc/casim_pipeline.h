@@ -130,6 +130,7 @@ public:
             d_bits_ = (uint64_t*)dalloc(sizeof(uint64_t) * NG * (size_t)(Wg_ > 0 ? Wg_ : 1));
             d_counts_ = (int32_t*)dalloc(sizeof(int32_t) * (NG + 1));
             d_off_ = (int32_t*)dalloc(sizeof(int32_t) * (NG + 1));
+            d_block_sums_ = (int32_t*)dalloc(sizeof(int32_t) * (NG / 64 + 2));
             d_idx_ = (int32_t*)dalloc(sizeof(int32_t) * (size_t)nnz_cap_);
             dt_.peg_off = d_off_; dt_.peg_idx = d_idx_;
         }
@@ -209,6 +210,10 @@ public:
         order_smem_ = (size_t)oworst;
         // one thread per pair of the bitonic network: npad / 2 threads, 64..kOrderThreads
         order_threads_ = (int)(npad_max / 2 < 64 ? 64 : (npad_max / 2 > kOrderThreads ? kOrderThreads : (npad_max / 2 + 63) / 64 * 64));
+        // a batch with thousands of groups fills the chip with blocks anyway: one wave per group then (the pairs of a pass are
+        // walked in a loop), so that no wave sits idle in the block barriers of a list that is far shorter than its bound
+        // (C2 batch: bound 400 PEGs -> 256 threads, actual lists ~110 -> 64 pairs; 0.49 ms of a 2.3 ms step, r02a)
+        if (NG_ >= 2048 && npad_max <= 1024) order_threads_ = 64;
         order_lds_ = oworst <= (int64_t)bk_.lds_budget();
         if (!order_lds_) {
             os_.off = up(ooff.data(), NG);
@@ -238,10 +243,14 @@ public:
     int32_t run_feasibility() {
         if (!csr_on_device_ || NG_ == 0) return CASIM_OK;
         if (feas_len_ > 0) bk_.launch(feas_kernel, (feas_len_ + 255) / 256, NG_, 256, (size_t)0, dt_, d_bits_, Wg_);
-        // one wave per group counts when the rows are short (a simulation's few hundred PEGs), a whole block otherwise
-        bk_.launch(csr_count_kernel, NG_, 1, Wg_ <= 64 ? 64 : 256, (size_t)64, (const uint64_t*)d_bits_, Wg_, d_counts_);
-        const int scan_threads = NG_ <= 64 ? 64 : (NG_ <= 4096 ? 256 : 1024);
-        bk_.launch(csr_scan_kernel, 1, 1, scan_threads, (size_t)(4 * ((scan_threads + 63) / 64)), (const int32_t*)d_counts_, NG_, d_off_);
+        // short rows (a simulation's few hundred PEGs): the row popcount is folded into the scan; long rows get a block each
+        const bool fold = Wg_ <= 16;
+        if (!fold) bk_.launch(csr_count_kernel, NG_, 1, 256, (size_t)64, (const uint64_t*)d_bits_, Wg_, d_counts_);
+        const int scan_threads = NG_ <= 64 ? 64 : (NG_ <= 256 ? 256 : 1024);
+        const int nb = (NG_ + scan_threads - 1) / scan_threads;
+        bk_.launch(csr_scan_local_kernel, nb, 1, scan_threads, (size_t)(4 * ((scan_threads + 63) / 64)), (const int32_t*)d_counts_,
+                   fold ? (const uint64_t*)d_bits_ : (const uint64_t*)nullptr, Wg_, NG_, d_off_, d_block_sums_, d_counts_);
+        bk_.launch(csr_scan_fix_kernel, nb, 1, scan_threads, (size_t)8, NG_, d_off_, (const int32_t*)d_block_sums_, nb);
         bk_.launch(csr_fill_kernel, NG_, 1, 64, (size_t)0, (const uint64_t*)d_bits_, Wg_, (const int32_t*)d_off_, d_idx_, dt_.peg_lo);
         return CASIM_OK;
     }
@@ -335,6 +344,21 @@ public:
         bk_.sync();
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
     }
+
+    // SchedulingError codes [NG][L] (L = longest candidate range): synchronous
+    int32_t reasons(const uint64_t* port_block_host, uint16_t* out_codes) {
+        if (!ready_ || !csr_on_device_) return fail(CASIM_ERR_INVALID, "reasons need device-side subsets (peg_offsets == NULL)");
+        if (!out_codes) return fail(CASIM_ERR_INVALID, "null output");
+        if (NG_ == 0 || feas_len_ == 0) return CASIM_OK;
+        const size_t n = (size_t)NG_ * (size_t)feas_len_;
+        uint16_t* d = (uint16_t*)dalloc(2 * n);
+        const uint64_t* pb = (port_block_host && dt_.Wx > 0) ? up(port_block_host, (size_t)G_ * dt_.Wx) : nullptr;
+        bk_.launch(reason_kernel, (feas_len_ + 255) / 256, NG_, 256, (size_t)0, dt_, pb, d, feas_len_);
+        bk_.d2h(out_codes, d, 2 * n);
+        bk_.sync();
+        return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
+    }
+    int feas_len() const { return feas_len_; }
 
     // bit-matrix [NG][ceil(G/64)] of the last run_feasibility()
     int32_t fetch_bits(uint64_t* out_bits) {
@@ -443,7 +467,7 @@ private:
     int fast_wx_ = 0;
     size_t pack_smem_ = 0, order_smem_ = 0;
     int order_threads_ = kOrderThreads;
-    uint64_t* d_bits_ = nullptr; int32_t* d_counts_ = nullptr; int32_t* d_off_ = nullptr; int32_t* d_idx_ = nullptr;
+    uint64_t* d_bits_ = nullptr; int32_t* d_counts_ = nullptr; int32_t* d_off_ = nullptr; int32_t* d_idx_ = nullptr; int32_t* d_block_sums_ = nullptr;
     uint8_t* d_opt_set_ = nullptr; int32_t* d_opt_out_ = nullptr; int64_t* d_opt_key_ = nullptr; int64_t* d_opt_packed_ = nullptr;
     uint8_t* d_opt_valid_ = nullptr; size_t opt_cap_ = 0;
     int n_sims_ = 0, max_sim_groups_ = 0, feas_len_ = 0;

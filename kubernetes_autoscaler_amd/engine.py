@@ -192,6 +192,16 @@ class Context:
         check(lib.casim_stream_probe(self._h, nbytes, lane_bytes, iters, C.byref(out)), "casim_stream_probe")
         return out.value
 
+    def feasibility_reasons(self, pegs: _abi.Pegs, groups: _abi.Groups, port_block=None) -> np.ndarray:
+        """casim_feasibility_reasons: uint16 [NG][L] (L = n_pegs, or the longest candidate range of a batch): 0 = fits, else
+        first failing Filter plugin (low 4 bits) + NodeResourcesFit reasons."""
+        ng = groups.n_groups
+        L = pegs.n_pegs if not groups.peg_lo else max((groups.peg_hi[i] - groups.peg_lo[i] for i in range(ng)), default=0)
+        codes = np.zeros((max(ng, 1), max(L, 1)), np.uint16)
+        check(lib.casim_feasibility_reasons(self._h, C.byref(pegs), C.byref(groups), port_block, codes.ctypes.data_as(C.POINTER(C.c_uint16))),
+              "casim_feasibility_reasons")
+        return codes[:ng, :L]
+
     def feasibility(self, pegs: _abi.Pegs, groups: _abi.Groups) -> np.ndarray:
         """bit-matrix [NG][ceil(G/64)]: PEG g passes every encoded Filter on a fresh node of group i."""
         wg = (pegs.n_pegs + 63) // 64

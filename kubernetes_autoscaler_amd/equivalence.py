@@ -7,7 +7,7 @@ Grouping is string hashing and stays on the host (the Go shim keeps calling Buil
 device is the matrix: every group's exemplar against every node-group template in ONE call
 (`Context.feasibility` -> feas_kernel), instead of G x NG CheckPredicates runs."""
 from dataclasses import dataclass, field
-from typing import Dict, List, Sequence
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
@@ -52,6 +52,61 @@ def group_pods_by_scheduling_properties(pods: Sequence[Pod]) -> List[List[Pod]]:
 def build_pod_groups(pods: Sequence[Pod]) -> List[PodGroup]:
     """BuildPodGroups (groups.go:39-49)."""
     return [PodGroup(pods=g) for g in group_pods_by_scheduling_properties(pods)]
+
+
+@dataclass
+class SchedulingError:
+    """clustersnapshot.SchedulingError of kind FailingPredicateError (CA/simulator/clustersnapshot/scheduling_error.go:29-52):
+    the Filter plugin that rejected the pod on the node and its reasons; what the orchestrator keeps per node group in
+    eg.SchedulingErrors (orchestrator.go:553-567) and NoScaleUp events print."""
+    failing_predicate_name: str
+    failing_predicate_reasons: List[str]
+    unknown: bool = False     # the pod needs a predicate outside the encoded subset: run the Go CheckPredicates for the real answer
+
+    def verbose_error(self) -> str:
+        return f"predicate {self.failing_predicate_name!r} failed: {', '.join(self.failing_predicate_reasons)}"
+
+
+def decode_scheduling_error(code: int, lanes: Sequence[str]) -> Optional[SchedulingError]:
+    """One uint16 of casim_feasibility_reasons -> SchedulingError (None = the pod fits)."""
+    from . import _abi
+    code = int(code)
+    plugin = code & _abi.PLUGIN_MASK
+    if plugin == 0:
+        return None
+    if plugin == 15:
+        return SchedulingError(_abi.PLUGIN_NAMES[15], [], unknown=True)
+    if plugin == 6:
+        reasons = ["Too many pods"] if code & _abi.REASON_TOO_MANY_PODS else []
+        for r, name in enumerate(lanes):   # fitsRequest order: pods, then cpu, memory, ephemeral-storage, scalar resources
+            if code & _abi.reason_insufficient(r):
+                reasons.append(f"Insufficient {name}")
+        return SchedulingError(_abi.PLUGIN_NAMES[6], reasons)
+    return SchedulingError(_abi.PLUGIN_NAMES[plugin], [_abi.PLUGIN_REASONS[plugin]])
+
+
+def schedulable_pod_groups_with_errors(ctx: Context, pod_groups: Sequence["PodGroup"], templates: Dict[str, NodeInfo], lanes=None):
+    """SchedulablePodGroups + the SchedulingErrors the orchestrator records for the cells that fail: returns
+    (ok [node group][pod group], errors {node group name: {pod group index: SchedulingError}})."""
+    enc = Encoder() if lanes is None else Encoder(lanes=lanes)
+    for g in pod_groups:
+        enc.add_peg(PodEquivalenceGroup(pods=g.pods))
+    names = list(templates)
+    for n in names:
+        enc.add_group(templates[n], pegs=None)
+    enc.finalize()
+    codes = ctx.feasibility_reasons(enc.pegs, enc.groups, enc.port_block)
+    lane_names = enc.lanes
+    enc.close()
+    ok = codes == 0
+    errors: Dict[str, Dict[int, SchedulingError]] = {}
+    for i, n in enumerate(names):
+        errors[n] = {j: decode_scheduling_error(codes[i, j], lane_names) for j in range(len(pod_groups)) if codes[i, j] != 0}
+    for j, g in enumerate(pod_groups):
+        g.schedulable_groups = [names[i] for i in range(len(names)) if ok[i, j]]
+        g.schedulable = bool(g.schedulable_groups)
+        g.scheduling_errors = {n: errors[n][j] for n in names if j in errors[n]}
+    return ok, errors
 
 
 def schedulable_pod_groups(ctx: Context, pod_groups: Sequence[PodGroup], templates: Dict[str, NodeInfo], lanes=None) -> np.ndarray:

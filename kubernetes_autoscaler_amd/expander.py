@@ -47,7 +47,11 @@ class ChainStrategy:
         self.names = list(names)
         self.kinds = kinds_of(names)
 
-    def best_option_index(self, problem, group_id_base: int = 0):
-        """Returns (best local group index or -1, number of equally good survivors, survivor mask)."""
-        best, n_best, best_set, _key = problem.best_option(self.kinds, group_id_base)
-        return best, n_best, best_set
+    def best_option_index(self, problem, group_id_base: int = 0, valid=None):
+        """Returns (best local group index or -1, number of equally good survivors, survivor mask).  `valid` ([NG] 0/1):
+        options the caller already dropped (empty / partial under all-or-nothing, orchestrator.go:1057-1063) never compete."""
+        if valid is None:
+            best, n_best, best_set, _key = problem.best_option(self.kinds, group_id_base)
+            return best, n_best, best_set
+        out = problem.best_option_sims(self.kinds, per_sim=False, valid=valid, group_id_base=group_id_base)
+        return int(out["best"][0]), int(out["n_best"][0]), out["best_set"]

@@ -42,7 +42,11 @@ class ScaleUpSimulator:
         self.lanes = lanes
 
     def prepare_scale_up(self, pegs: List[PodEquivalenceGroup], node_groups: List[NodeGroup], node_infos: Dict[str, NodeInfo],
-                         snapshot: ClusterSnapshotView, all_or_nothing: bool = False) -> ScaleUpPlan:
+                         snapshot: ClusterSnapshotView, all_or_nothing: bool = False,
+                         similar_node_groups: Optional[Dict[str, List[NodeGroup]]] = None) -> ScaleUpPlan:
+        """`similar_node_groups`: node group id -> its similar groups (option.SimilarNodeGroups, what the balancing processor
+        found); they feed SngCapacityThreshold through the EstimationContext exactly as orchestrator.go:409-412 does."""
+        similar_node_groups = similar_node_groups or {}
         enc = Encoder(lanes=self.lanes)
         for pg in pegs:
             enc.add_peg(pg)
@@ -51,7 +55,7 @@ class ScaleUpSimulator:
                 enc.add_existing_pod(p, info.node.labels)
         for ng in node_groups:
             # estimatorBuilder(..., NewEstimationContext(MaxNodesTotal, similarNodeGroups, currentNodeCount))  :409-412
-            context = EstimationContext(self.max_nodes_total, [], len(snapshot.existing))
+            context = EstimationContext(self.max_nodes_total, list(similar_node_groups.get(ng.id(), [])), len(snapshot.existing))
             self.limiter.start_estimation(pegs, ng, context)
             enc.add_group(node_infos[ng.id()], max_nodes=self.limiter.device_max_nodes(), existing_nodes=len(snapshot.existing),
                           last_index=snapshot.last_index, pegs=None)   # None: SchedulablePodGroups runs on the device
@@ -69,7 +73,7 @@ class ScaleUpSimulator:
                     continue
                 order, _ = res.group(i)
                 ids = sorted(int(x) for x in order)   # SchedulablePodGroups of this group (device feasibility)
-                context = EstimationContext(self.max_nodes_total, [], len(snapshot.existing))
+                context = EstimationContext(self.max_nodes_total, list(similar_node_groups.get(ng.id(), [])), len(snapshot.existing))
                 self.limiter.start_estimation(pegs, ng, context)
                 maxn = self.limiter.device_max_nodes()
                 self.limiter.end_estimation()
@@ -84,33 +88,33 @@ class ScaleUpSimulator:
                 out["peg_ids"] = ids
                 prob.set_group_result(i, out)
                 rerun[i] = out
-            best_idx, n_best, best_set = self.expander.best_option_index(prob)
-        total_pods = sum(len(pg.pods) for pg in pegs)
-        options, schedulable, delegated = [], {}, []
-        by_group: Dict[int, Option] = {}
-        for i, ng in enumerate(node_groups):
-            order, placed = res.group(i)
-            schedulable[ng.id()] = sorted(int(x) for x in order)
-            node_count = int(res.node_count[i])
-            if i in rerun:
-                r = rerun[i]
-                order, placed, node_count = [r["peg_ids"][int(k)] for k in r["order"]], r["placed"], r["node_count"]
-            elif int(res.status[i]) != 0:
-                delegated.append(ng.id())
-                continue
-            pods: List[Pod] = []
-            for pg_id, n in zip(order, placed):
-                pods.extend(pegs[int(pg_id)].pods[:int(n)])
-            opt = Option(node_group=ng, node_count=node_count, pods=pods)
-            # orchestrator.go:1057-1063: drop empty options and, for all-or-nothing, partial ones
-            if not pods or opt.node_count == 0:
-                continue
-            if all_or_nothing and len(pods) < total_pods:
-                continue
-            options.append(opt)
-            by_group[i] = opt
+            # orchestrator.go:1057-1063: empty options and, for all-or-nothing, partial ones are dropped BEFORE
+            # ExpanderStrategy.BestOption (:1079) sees the list: the mask goes to the device reduce with the chain
+            total_pods = sum(len(pg.pods) for pg in pegs)
+            options, schedulable, delegated = [], {}, []
+            by_group: Dict[int, Option] = {}
+            valid = np.zeros(len(node_groups), np.uint8)
+            for i, ng in enumerate(node_groups):
+                order, placed = res.group(i)
+                schedulable[ng.id()] = sorted(int(x) for x in order)
+                node_count = int(res.node_count[i])
+                if i in rerun:
+                    r = rerun[i]
+                    order, placed, node_count = [r["peg_ids"][int(k)] for k in r["order"]], r["placed"], r["node_count"]
+                elif int(res.status[i]) != 0:
+                    delegated.append(ng.id())
+                    continue
+                pods: List[Pod] = []
+                for pg_id, n in zip(order, placed):
+                    pods.extend(pegs[int(pg_id)].pods[:int(n)])
+                opt = Option(node_group=ng, node_count=node_count, pods=pods)
+                if not pods or opt.node_count == 0:
+                    continue
+                if all_or_nothing and len(pods) < total_pods:
+                    continue
+                options.append(opt)
+                by_group[i] = opt
+                valid[i] = 1
+            best_idx, n_best, best_set = self.expander.best_option_index(prob, valid=valid)
         best = by_group.get(best_idx) if best_idx >= 0 else None
-        if all_or_nothing and best is None and options:
-            # the device chain ran over every valid option; re-run the choice among the all-or-nothing survivors
-            best = min(options, key=lambda o: (o.node_count, node_groups.index(o.node_group)))
         return ScaleUpPlan(options, best, n_best, schedulable, res, delegated)

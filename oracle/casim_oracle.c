@@ -620,16 +620,18 @@ static int filter_ports(const orc* o, const podspec* p, const node* n) {
     return 1;
 }
 /* fitsRequest  V/.../noderesources/fit.go:678-765.  *reason gets the FIRST insufficient resource */
+static unsigned g_last_fit_mask; /* every reason of the last failing fitsRequest: bit 0 "Too many pods", bit 1 + r "Insufficient <lane r>" */
 static int filter_fit(const orc* o, const podspec* p, const node* n, const char** reason) {
     int ok = 1;
-    if (n->pods.n + 1 > n->allowed_pods) { ok = 0; if (reason && !*reason) *reason = "Too many pods"; }
+    g_last_fit_mask = 0;
+    if (n->pods.n + 1 > n->allowed_pods) { ok = 0; g_last_fit_mask |= 1u; if (reason && !*reason) *reason = "Too many pods"; }
     int all_zero = 1;
     for (int r = 0; r < o->n_res; ++r) if (p->req[r] != 0) all_zero = 0;
     if (all_zero) return ok;
     static const char* names[ORC_MAX_RES] = {"Insufficient cpu", "Insufficient memory", "Insufficient ephemeral-storage",
         "Insufficient scalar-0", "Insufficient scalar-1", "Insufficient scalar-2", "Insufficient scalar-3", "Insufficient scalar-4"};
     for (int r = 0; r < o->n_res; ++r) {
-        if (p->req[r] > 0 && p->req[r] > n->alloc[r] - n->requested[r]) { ok = 0; if (reason && !*reason) *reason = names[r]; }
+        if (p->req[r] > 0 && p->req[r] > n->alloc[r] - n->requested[r]) { ok = 0; g_last_fit_mask |= 2u << r; if (reason && !*reason) *reason = names[r]; }
     }
     return ok;
 }
@@ -882,6 +884,10 @@ int orc_run_filters_until_passing(orc* o, int pod, int* last_index) {
     PODCHK(o, pod);
     return run_filters_until_passing(o, pod, 0, last_index);
 }
+
+/* insufficientResources of the last NodeResourcesFit failure (fit.go:678-765 collects ALL of them; the Status carries one
+ * reason per entry): bit 0 "Too many pods", bit 1 + r "Insufficient <lane r>" */
+unsigned orc_last_fit_reasons(void) { return g_last_fit_mask; }
 
 /* ------------------------------------------------------------------------------------- */
 /* limiter + thresholds                                                                    */

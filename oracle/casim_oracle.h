@@ -121,6 +121,8 @@ int orc_scale_up_simulation(orc* o, int n_groups, const int32_t* template_node, 
  * returns 1 pass / 0 fail; *plugin_out (may be NULL) receives a static plugin name. */
 int orc_check_predicates(orc* o, int template_node, int pod, const char** plugin_out,
                          const char** reason_out);
+/* every reason of the last NodeResourcesFit failure: bit 0 "Too many pods", bit 1 + r "Insufficient <lane r>" */
+unsigned orc_last_fit_reasons(void);
 /* RunFiltersOnNode against snapshot node #index (plugin_runner.go:146-181) */
 int orc_run_filters_on_snapshot_node(orc* o, int index, int pod, const char** plugin_out,
                                      const char** reason_out);

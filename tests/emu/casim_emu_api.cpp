@@ -69,6 +69,17 @@ EMU_API int32_t emu_estimate_batch_query(const casim_pegs* pegs, const casim_gro
     return rc;
 }
 
+EMU_API int32_t emu_feasibility_reasons(const casim_pegs* pegs, const casim_groups* groups, const uint64_t* port_block, uint16_t* out_codes) {
+    EmuBackend bk;
+    casim::ProblemT<EmuBackend> p(bk);
+    casim_groups g = *groups;
+    g.peg_offsets = nullptr; g.peg_index = nullptr;
+    int32_t rc = p.init(pegs, &g, nullptr);
+    if (rc == CASIM_OK) rc = p.reasons(port_block, out_codes);
+    if (rc != CASIM_OK) g_err = p.error();
+    return rc;
+}
+
 EMU_API int32_t emu_feasibility(const casim_pegs* pegs, const casim_groups* groups, uint64_t* out_bits) {
     EmuBackend bk;
     casim::ProblemT<EmuBackend> p(bk);

@@ -72,6 +72,7 @@ def lib():
             "orc_set_taint_comparison_ops": (None, [P, C.c_int]),
             "orc_set_list_shuffle": (None, [P, C.c_uint64]),
             "orc_estimate": (C.c_int, [P, C.c_int, C.c_int, i32p, i32p, C.c_int, C.c_int, C.c_int, C.POINTER(EstimateResult)]),
+            "orc_last_fit_reasons": (C.c_uint, []),
             "orc_scale_up_simulation": (C.c_int, [P, C.c_int, i32p, C.c_int, i32p, i32p, i32p, i32p, C.POINTER(EstimateResult), i32p, i32p,
                                                   i32p, i32p, i64p]),
             "orc_check_predicates": (C.c_int, [P, C.c_int, C.c_int, cstrp, cstrp]),
@@ -299,6 +300,20 @@ class OracleScenario:
         plug, reason = C.c_char_p(), C.c_char_p()
         ok = self.L.orc_check_predicates(self.h, template_node, self.pod(pod), C.byref(plug), C.byref(reason))
         return bool(ok), (plug.value or b"").decode(), (reason.value or b"").decode()
+
+    def check_predicates_code(self, template_node: int, pod, lanes):
+        """CheckPredicates as the uint16 code of casim_feasibility_reasons (plugin id + NodeResourcesFit reasons)."""
+        ok, plugin, reason = self.check_predicates(template_node, pod)
+        if ok:
+            return 0
+        ids = {"NodeUnschedulable": 2, "TaintToleration": 3, "NodePorts": 5, "NodeResourcesFit": 6, "PodTopologySpread": 7, "InterPodAffinity": 8}
+        if plugin == "NodeAffinity":
+            return 1 if reason == "PreFilter filtered the Node out" else 4
+        code = ids[plugin]
+        if plugin == "NodeResourcesFit":
+            m = self.L.orc_last_fit_reasons()
+            code |= (0x10 if m & 1 else 0) | ((m >> 1) << 5)
+        return code
 
     def run_filters_on_node(self, snapshot_index: int, pod):
         plug, reason = C.c_char_p(), C.c_char_p()

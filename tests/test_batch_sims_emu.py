@@ -121,3 +121,23 @@ def test_bad_ranges_are_rejected():
     st_rc = L.emu_feasibility(C.byref(pegs), C.byref(groups), np.zeros(64, np.uint64).ctypes.data_as(_abi.u64p))
     assert st_rc == _abi.ERR_INVALID
     enc.close()
+
+
+def test_large_batch_takes_the_multi_block_scan_and_wave_per_group_order():
+    """> 2048 groups: the CSR scan runs in several 1024-thread blocks, the orderer with one wave per group."""
+    sc = _scenario(424242)
+    enc, ts, _ = encode_batch([sc, _scenario(17)])
+    ng = ts.n_groups
+    times = 2100 // ng + 1
+    big = ts.tile(times)
+    assert big.n_groups >= 2048
+    res, exp = run_emu_tables(big, kinds=[_abi.EXPANDER_LEAST_NODES])
+    base, _ = run_emu_tables(ts, kinds=[_abi.EXPANDER_LEAST_NODES])
+    nnz = int(base.offsets[-1])
+    for k in range(times):
+        assert list(res.offsets[k * ng:(k + 1) * ng + 1] - res.offsets[k * ng]) == list(base.offsets)
+        assert list(res.node_count[k * ng:(k + 1) * ng]) == list(base.node_count)
+        assert list(res.pods_scheduled[k * ng:(k + 1) * ng]) == list(base.pods_scheduled)
+        assert list(res.placed[k * nnz:(k + 1) * nnz]) == list(base.placed)
+        assert list(res.order[k * nnz:(k + 1) * nnz] - k * ts.n_pegs) == list(base.order)
+    enc.close()

@@ -25,18 +25,28 @@ if [ "$MODE" != "prof" ]; then
   tail -3 "$OUT/smoke.log" | tee -a "$S"
 
   echo "== bench (driver form, defaults) ==" | tee -a "$S"
-  /usr/bin/time -v timeout 1200 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
-  echo "bench exit $?" | tee -a "$S"
-  tail -c 6000 "$OUT/bench.json" | tee -a "$S"
-  grep -E "Elapsed|Maximum resident" "$OUT/bench.err" | tee -a "$S"
-  grep -v -E "^\s" "$OUT/bench.err" | tail -5 | tee -a "$S"
+  T0=$(date +%s.%N)
+  timeout 1200 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+  echo "bench exit $? in $(echo "$(date +%s.%N) - $T0" | bc) s" | tee -a "$S"
+  tail -c 9000 "$OUT/bench.json" | tee -a "$S"
+  tail -5 "$OUT/bench.err" | tee -a "$S"
 
-  echo "== bench --gpus 2, both ranks on cuda:0, RCCL ==" | tee -a "$S"
-  CASIM_BENCH_ONE_GPU=1 timeout 600 python bench.py --gpus 2 --steps 100 --warmup 5 --batch 1024 --no-cpu-baseline --no-configs --no-dense --no-next-rows \
-      > "$OUT/bench_2ranks_one_gpu.json" 2> "$OUT/bench_2ranks_one_gpu.err"
+  # RCCL refuses two ranks on one device ("Duplicate GPU detected"): on a 1-GPU box the N > 1 control flow (self-launch,
+  # sharded tables, per-step all-reduce of the packed keys, C3 sharded) runs over gloo with both ranks on cuda:0, and
+  # the RCCL calls themselves run in a 1-rank group (CASIM_BENCH_FORCE_DIST=1: init nccl, all-reduce every step).
+  echo "== bench --gpus 2, both ranks on cuda:0, gloo ==" | tee -a "$S"
+  CASIM_BENCH_ONE_GPU=1 CASIM_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 100 --warmup 5 --batch 1024 --no-cpu-baseline --no-configs --no-dense --no-next-rows \
+      > "$OUT/bench_2ranks_one_gpu_gloo.json" 2> "$OUT/bench_2ranks_one_gpu_gloo.err"
   echo "2-rank bench exit $?" | tee -a "$S"
-  tail -c 2500 "$OUT/bench_2ranks_one_gpu.json" | tee -a "$S"
-  tail -3 "$OUT/bench_2ranks_one_gpu.err" | tee -a "$S"
+  tail -c 2500 "$OUT/bench_2ranks_one_gpu_gloo.json" | tee -a "$S"
+  tail -3 "$OUT/bench_2ranks_one_gpu_gloo.err" | tee -a "$S"
+  echo "== bench, 1 rank, RCCL group forced ==" | tee -a "$S"
+  CASIM_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
+      bench.py --gpus 1 --steps 200 --warmup 5 --batch 1024 --no-cpu-baseline --no-configs --no-dense --no-next-rows \
+      > "$OUT/bench_1rank_rccl.json" 2> "$OUT/bench_1rank_rccl.err"
+  echo "1-rank RCCL bench exit $?" | tee -a "$S"
+  tail -c 2500 "$OUT/bench_1rank_rccl.json" | tee -a "$S"
+  tail -3 "$OUT/bench_1rank_rccl.err" | tee -a "$S"
 
   echo "== VALU issue-rate microbench ==" | tee -a "$S"
   (make -s -C tools/ubench 2>/dev/null; timeout 120 tools/ubench/valu_rates) > "$OUT/valu_rates.txt" 2>&1
