@@ -384,8 +384,13 @@ def main():
     pegs, groups = mine.structs()
     n_sims = mine.n_sims
 
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = kaa.Context(dev_index, stream=stream)
+    # ONE explicit stream for libcasim's kernels AND torch's copies / collectives: the per-step reduce reads the keys the
+    # expander kernel just wrote (torch's default stream has handle 0, which casim_ctx_create takes as "create your own":
+    # the kernels would then run unordered with torch's work and a reduce could read or overwrite keys of another step)
+    side_stream = torch.cuda.Stream(device=dev_index)
+    torch.cuda.set_stream(side_stream)
+    ctx = kaa.Context(dev_index, stream=side_stream.cuda_stream)
+    assert side_stream.cuda_stream != 0
     t0 = time.time()
     prob = kaa.Problem(ctx, pegs, groups)
     t_upload = time.time() - t0

@@ -349,6 +349,30 @@ typedef struct casim_option_query {
 int32_t casim_best_option_sims(casim_problem* p, const casim_option_query* q);
 
 /*
+ * Several devices behind ONE caller.  The scale-up loop is a single goroutine (orchestrator.go:1053) and an
+ * estimator.Estimator lives in that process, so multi-GPU has to work without one process per device: a casim_mctx owns one
+ * context (device + stream) per listed device; casim_estimate_batch_multi block-partitions the node groups of every simulation
+ * over them (rotated by simulation index; PEG table replicated, no pods x nodes data crosses devices), runs them concurrently
+ * and settles the expander's choice with ONE collective: all-reduce(min) over the per-simulation packed keys
+ * (first filter's metric << 20 | cluster-wide group id) — RCCL over xGMI when use_rccl != 0 (librccl.so is loaded at run time:
+ * ncclCommInitAll over the listed devices, ncclAllReduce(ncclMin, ncclInt64) inside one group call), a host loop otherwise.
+ * Chains whose first filter is not an integer metric (least-waste) take the per-device key blocks to the host and pick the
+ * lexicographic minimum there.  Results come back in the caller's group order; offsets_out ([NG+1], may be NULL) receives
+ * the CSR offsets of order / placed.  q->best_out[s] is the caller's index of simulation s's winner; n_best_out is 1 / 0
+ * (survivors are not counted across devices); q->dev_* are ignored.  A device named twice (tests on a 1-GPU box) is
+ * allowed without RCCL.
+ */
+typedef struct casim_mctx casim_mctx;
+casim_mctx* casim_mctx_create(const int32_t* devices, int32_t n_devices, int32_t use_rccl);
+void casim_mctx_destroy(casim_mctx* m);
+/* n devices, 1 if RCCL communicators exist, 1 if the last batch's keys were reduced by RCCL (0 = on the host), and the
+ * number of node groups each device held in the last batch ([n devices]); any pointer may be NULL. */
+int32_t casim_mctx_info(const casim_mctx* m, int32_t* n_devices_out, int32_t* uses_rccl_out, int32_t* last_reduced_by_rccl_out,
+                        int32_t* groups_per_device_out);
+int32_t casim_estimate_batch_multi(casim_mctx* m, const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts,
+                                   casim_results* out, int32_t* offsets_out, const struct casim_option_query* q);
+
+/*
  * HintingSimulator.TrySchedulePods (CA/simulator/scheduling/hinting_simulator.go:53-135) — the
  * filter-out-schedulable pass (CA/core/podlistprocessor/filter_out_schedulable.go:48-103): pending pods,
  * one by one in the caller's (priority) order, against the nodes ALREADY in the cluster snapshot.

@@ -147,6 +147,11 @@ PROTOTYPES = {
     "casim_best_option_sims": (C.c_int32, [C.c_void_p, C.POINTER(OptionQuery)]),
     "casim_estimate_batch_timed": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(Options), C.POINTER(Results),
                                                C.POINTER(OptionQuery), f64p]),
+    "casim_mctx_create": (C.c_void_p, [i32p, C.c_int32, C.c_int32]),
+    "casim_mctx_destroy": (None, [C.c_void_p]),
+    "casim_mctx_info": (C.c_int32, [C.c_void_p, i32p, i32p, i32p, i32p]),
+    "casim_estimate_batch_multi": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(Options), C.POINTER(Results), i32p,
+                                               C.POINTER(OptionQuery)]),
     "casim_problem_time": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "casim_problem_time_dense": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float), i64p, i64p]),
     "casim_try_schedule_pods": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(PodSequence), i32p, i32p, i32p]),

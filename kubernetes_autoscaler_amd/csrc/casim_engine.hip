@@ -11,7 +11,10 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include "casim_pipeline.h"
+#include "casim_multi.h"
 
 namespace {
 
@@ -61,6 +64,42 @@ typedef casim::ProblemT<HipBackend> HipProblem;
 struct casim_ctx {
     HipBackend bk;
 };
+// ---- RCCL, loaded at run time (no link-time dependency: a process that already carries an RCCL — torch ships one — keeps
+// using that copy; a plain C / Go host gets /opt/rocm/lib/librccl.so).  Only what the expander exchange needs.
+namespace {
+struct Rccl {
+    typedef void* comm_t;
+    int (*CommInitAll)(comm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int /*dtype*/, int /*op*/, comm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    void* handle = nullptr;
+    static constexpr int kInt64 = 4, kMin = 3;   // ncclInt64, ncclMin (nccl.h enums)
+    bool load(std::string& err) {
+        if (handle) return true;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* n : names) { handle = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (handle) break; }
+        if (!handle) { err = "librccl.so not found (dlopen)"; return false; }
+        CommInitAll = (decltype(CommInitAll))dlsym(handle, "ncclCommInitAll"); CommDestroy = (decltype(CommDestroy))dlsym(handle, "ncclCommDestroy");
+        AllReduce = (decltype(AllReduce))dlsym(handle, "ncclAllReduce"); GroupStart = (decltype(GroupStart))dlsym(handle, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(handle, "ncclGroupEnd"); GetErrorString = (decltype(GetErrorString))dlsym(handle, "ncclGetErrorString");
+        if (!CommInitAll || !CommDestroy || !AllReduce || !GroupStart || !GroupEnd) { err = "librccl.so misses ncclCommInitAll / ncclAllReduce"; return false; }
+        return true;
+    }
+};
+}  // namespace
+
+struct casim_mctx {
+    std::vector<casim_ctx*> ctxs;
+    Rccl rccl;
+    std::vector<Rccl::comm_t> comms;   // one per device when RCCL is in use
+    bool use_rccl = false;
+    int32_t last_reduced_by = 0;
+    std::vector<int32_t> last_groups;
+};
+
 struct casim_problem {
     casim_ctx* ctx;
     HipProblem* prob;
@@ -340,6 +379,70 @@ int32_t casim_best_option(casim_problem* p, const int32_t* kinds, int32_t n_kind
 int32_t casim_best_option_sims(casim_problem* p, const casim_option_query* q) {
     PROB_ENTER(p);
     PROB_RET(p, p->prob->best_option_query(q));
+}
+
+// ---- one process, several devices (the caller is one goroutine) -----------------------------------------
+casim_mctx* casim_mctx_create(const int32_t* devices, int32_t n_devices, int32_t use_rccl) {
+    g_err.clear();
+    if (!devices || n_devices <= 0 || n_devices > 64) { set_err(CASIM_ERR_INVALID, "bad device list"); return nullptr; }
+    casim_mctx* m = new (std::nothrow) casim_mctx();
+    if (!m) { set_err(CASIM_ERR_NOMEM, "out of memory"); return nullptr; }
+    for (int i = 0; i < n_devices; ++i) {
+        casim_ctx* c = casim_ctx_create(devices[i], nullptr);
+        if (!c) { const std::string keep = g_err; casim_mctx_destroy(m); g_err = keep; return nullptr; }
+        m->ctxs.push_back(c);
+    }
+    if (use_rccl) {
+        // RCCL wants distinct devices in one communicator; a list that names one device twice (tests on a 1-GPU box) reduces on the host
+        bool distinct = true;
+        for (int i = 0; i < n_devices; ++i) for (int j = 0; j < i; ++j) distinct = distinct && devices[i] != devices[j];
+        std::string err;
+        if (distinct && m->rccl.load(err)) {
+            m->comms.assign((size_t)n_devices, nullptr);
+            const int rc = m->rccl.CommInitAll(m->comms.data(), n_devices, devices);
+            if (rc != 0) { set_err(CASIM_ERR_HIP, std::string("ncclCommInitAll: ") + (m->rccl.GetErrorString ? m->rccl.GetErrorString(rc) : "failed")); casim_mctx_destroy(m); return nullptr; }
+            m->use_rccl = true;
+        } else if (distinct) { set_err(CASIM_ERR_HIP, err); casim_mctx_destroy(m); return nullptr; }
+    }
+    return m;
+}
+void casim_mctx_destroy(casim_mctx* m) {
+    if (!m) return;
+    for (size_t i = 0; i < m->comms.size(); ++i) if (m->comms[i]) { (void)hipSetDevice(m->ctxs[i]->bk.device); (void)m->rccl.CommDestroy(m->comms[i]); }
+    for (casim_ctx* c : m->ctxs) casim_ctx_destroy(c);
+    delete m;
+}
+int32_t casim_mctx_info(const casim_mctx* m, int32_t* n_devices_out, int32_t* uses_rccl_out, int32_t* last_reduced_by_rccl_out, int32_t* groups_per_device_out) {
+    if (!m) return CASIM_ERR_INVALID;
+    if (n_devices_out) *n_devices_out = (int32_t)m->ctxs.size();
+    if (uses_rccl_out) *uses_rccl_out = m->use_rccl ? 1 : 0;
+    if (last_reduced_by_rccl_out) *last_reduced_by_rccl_out = m->last_reduced_by;
+    if (groups_per_device_out) for (size_t d = 0; d < m->last_groups.size(); ++d) groups_per_device_out[d] = m->last_groups[d];
+    return CASIM_OK;
+}
+int32_t casim_estimate_batch_multi(casim_mctx* m, const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts,
+                                   casim_results* out, int32_t* offsets_out, const casim_option_query* q) {
+    g_err.clear();
+    if (!m) return set_err(CASIM_ERR_INVALID, "null multi-device context");
+    std::vector<HipBackend*> bks;
+    for (casim_ctx* c : m->ctxs) { c->bk.bind(); c->bk.clear(); bks.push_back(&c->bk); }
+    casim::MultiProblemT<HipBackend> mp(bks);
+    casim::MultiProblemT<HipBackend>::ReduceFn hook;
+    if (m->use_rccl) hook = [m](const std::vector<int64_t*>& keys, int S) {
+        // ONE collective over xGMI: all-reduce(min) of the per-simulation packed keys, in place, every device's own stream
+        if (m->rccl.GroupStart() != 0) return false;
+        bool ok = true;
+        for (size_t d = 0; d < keys.size(); ++d) {
+            m->ctxs[d]->bk.bind();
+            ok = ok && m->rccl.AllReduce(keys[d], keys[d], (size_t)S, Rccl::kInt64, Rccl::kMin, m->comms[d], m->ctxs[d]->bk.stream) == 0;
+        }
+        return m->rccl.GroupEnd() == 0 && ok;
+    };
+    const int32_t rc = mp.run(pegs, groups, opts, out, offsets_out, q, hook);
+    m->last_reduced_by = mp.reduced_by(); m->last_groups = mp.groups_per_device();
+    if (rc != CASIM_OK) return set_err(rc, mp.error());
+    for (casim_ctx* c : m->ctxs) if (!c->bk.ok()) return set_err(CASIM_ERR_HIP, c->bk.msg);
+    return CASIM_OK;
 }
 
 // ---- measurement -----------------------------------------------------------------------------

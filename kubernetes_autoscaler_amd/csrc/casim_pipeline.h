@@ -300,12 +300,13 @@ public:
 
     int32_t csr(int32_t* nnz_out, int32_t* offsets_out) {
         if (!ready_) return fail(CASIM_ERR_INVALID, "problem not initialised");
-        if (csr_on_device_) {
+        if (csr_on_device_ && NG_ > 0) {
             if (!ran_) return fail(CASIM_ERR_INVALID, "run the problem first");
             h_off_.resize((size_t)NG_ + 1);
             bk_.d2h(h_off_.data(), d_off_, 4 * ((size_t)NG_ + 1));
             bk_.sync();
         }
+        if (NG_ == 0) { if (nnz_out) *nnz_out = 0; if (offsets_out) offsets_out[0] = 0; return CASIM_OK; }   // an empty shard
         if (nnz_out) *nnz_out = NG_ > 0 ? h_off_[(size_t)NG_] : 0;
         if (offsets_out && NG_ >= 0) for (int i = 0; i <= NG_; ++i) offsets_out[i] = h_off_.empty() ? 0 : h_off_[(size_t)i];
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());

@@ -264,6 +264,68 @@ class Context:
         return finish_removal_results(rc, st, res, arrs)
 
 
+class MultiContext:
+    """casim_mctx: several devices behind one caller (one process, one host thread — the shape a Go estimator has).
+    estimate_batch() block-partitions the node groups of every simulation over the devices, runs them concurrently and
+    settles the expander with ONE all-reduce(min) over the per-simulation packed keys (RCCL over xGMI, or the host)."""
+
+    def __init__(self, devices: Sequence[int], use_rccl: bool = True):
+        arr = (C.c_int32 * len(devices))(*devices)
+        self._h = lib.casim_mctx_create(arr, len(devices), int(bool(use_rccl)))
+        if not self._h:
+            msg = last_error()
+            if device_count() == 0:
+                raise NoDeviceError(_abi.ERR_NO_DEVICE, msg or "no HIP device visible")
+            raise CasimError(_abi.ERR_HIP, msg)
+        self.n_devices = len(devices)
+
+    def close(self):
+        if self._h:
+            lib.casim_mctx_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def info(self):
+        n, rccl, red = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        per = (C.c_int32 * max(self.n_devices, 1))()
+        check(lib.casim_mctx_info(self._h, C.byref(n), C.byref(rccl), C.byref(red), per), "casim_mctx_info")
+        return {"devices": n.value, "rccl": bool(rccl.value), "last_reduce_by_rccl": bool(red.value), "groups_per_device": list(per)[:n.value]}
+
+    def estimate_batch(self, pegs: _abi.Pegs, groups: _abi.Groups, kinds: Optional[Sequence[int]] = None, valid=None, fastpath: bool = False,
+                       nnz_cap: Optional[int] = None):
+        """Returns (BatchResult, expander dict or None): results in the caller's group order."""
+        ng = groups.n_groups
+        if nnz_cap is None:
+            if groups.peg_offsets:
+                nnz_cap = int(groups.peg_offsets[ng]) if ng else 0
+            elif groups.peg_lo:
+                nnz_cap = int(sum(groups.peg_hi[i] - groups.peg_lo[i] for i in range(ng)))
+            else:
+                nnz_cap = pegs.n_pegs * ng
+        st, arrs = alloc_results(ng, nnz_cap)
+        opts = _abi.Options(fastpath=int(fastpath))
+        off = np.zeros(ng + 1, np.int32)
+        q = exp = None
+        keep = []
+        if kinds is not None:
+            S = groups.n_sims if groups.n_sims > 0 else 1
+            ks = (C.c_int32 * max(len(kinds), 1))(*kinds)
+            exp = dict(best=np.full(S, -1, np.int32), n_best=np.zeros(S, np.int32), packed=np.zeros(S, np.int64), keys=np.zeros((S, 10), np.int64))
+            q = _abi.OptionQuery(kinds=ks, n_kinds=len(kinds), per_sim=1, best_out=_ptr(exp["best"], C.c_int32),
+                                 n_best_out=_ptr(exp["n_best"], C.c_int32), packed_out=_ptr(exp["packed"], C.c_int64), key_out=_ptr(exp["keys"], C.c_int64))
+            if valid is not None:
+                v = np.ascontiguousarray(valid, np.uint8); keep.append(v)
+                q.valid = _ptr(v, C.c_uint8)
+        check(lib.casim_estimate_batch_multi(self._h, C.byref(pegs), C.byref(groups), C.byref(opts), C.byref(st), _ptr(off, C.c_int32),
+                                             C.byref(q) if q is not None else None), "casim_estimate_batch_multi")
+        return finish_results(arrs, ng, int(off[ng]), off), exp
+
+
 class Problem:
     """casim_problem: a batch resident in HBM; run() enqueues feasibility -> order -> pack."""
 

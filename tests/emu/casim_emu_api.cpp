@@ -8,6 +8,7 @@
 
 #include "casim_emu.h"
 #include "../../kubernetes_autoscaler_amd/csrc/casim_pipeline.h"
+#include "../../kubernetes_autoscaler_amd/csrc/casim_multi.h"
 
 namespace {
 struct EmuBackend {
@@ -19,6 +20,7 @@ struct EmuBackend {
     void zero(void* d, size_t n) { memset(d, 0, n); }
     void fill8(void* d, int v, size_t n) { memset(d, v, n); }
     void sync() {}
+    void bind() {}
     size_t lds_budget() const { return lds; }
     bool ok() const { return true; }
     const char* error() const { return ""; }
@@ -66,6 +68,28 @@ EMU_API int32_t emu_estimate_batch_query(const casim_pegs* pegs, const casim_gro
     if (rc == CASIM_OK && (nnz_out || offsets_out)) rc = p.csr(nnz_out, offsets_out);
     if (rc == CASIM_OK && q) rc = p.best_option_query(q);
     if (rc != CASIM_OK) g_err = p.error();
+    return rc;
+}
+
+// The batch over n_devices emulated devices (casim_multi.h), cross-device reduce by the host-side hook or on the host.
+EMU_API int32_t emu_estimate_batch_multi(int32_t n_devices, int32_t use_reduce_hook, const casim_pegs* pegs, const casim_groups* groups,
+                                         const casim_options* opts, casim_results* out, int32_t* offsets_out, const casim_option_query* q,
+                                         int32_t* info_out /*[1 + n_devices]: reduced by hook, groups per device*/) {
+    std::vector<EmuBackend> bks((size_t)n_devices);
+    std::vector<EmuBackend*> ptrs;
+    for (auto& b : bks) ptrs.push_back(&b);
+    casim::MultiProblemT<EmuBackend> mp(ptrs);
+    casim::MultiProblemT<EmuBackend>::ReduceFn hook = [](const std::vector<int64_t*>& keys, int S) {
+        for (int s = 0; s < S; ++s) {
+            int64_t m = keys[0][s];
+            for (size_t d = 1; d < keys.size(); ++d) m = keys[d][s] < m ? keys[d][s] : m;
+            for (size_t d = 0; d < keys.size(); ++d) keys[d][s] = m;
+        }
+        return true;
+    };
+    const int32_t rc = mp.run(pegs, groups, opts, out, offsets_out, q, use_reduce_hook ? hook : casim::MultiProblemT<EmuBackend>::ReduceFn());
+    if (rc != CASIM_OK) g_err = mp.error();
+    if (info_out) { info_out[0] = mp.reduced_by(); for (size_t d = 0; d < mp.groups_per_device().size(); ++d) info_out[1 + d] = mp.groups_per_device()[d]; }
     return rc;
 }
 

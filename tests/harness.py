@@ -480,3 +480,40 @@ def run_gpu_tables(ts, ctx, kinds=None, per_sim=True, valid=None, fastpath=False
         res = p.fetch()
         exp = p.best_option_sims(kinds, per_sim=per_sim, valid=valid, n_sims=ts.n_sims) if kinds is not None else None
     return res, exp
+
+
+def run_emu_multi(ts, n_devices, kinds=None, valid=None, use_hook=True):
+    """The batch over n emulated devices (casim_multi.h).  Returns (BatchResult, expander dict or None, info)."""
+    L = emu_lib()
+    if not hasattr(L, "_multi_bound"):
+        L.emu_estimate_batch_multi.restype = C.c_int32
+        L.emu_estimate_batch_multi.argtypes = [C.c_int32, C.c_int32, C.POINTER(_abi.Pegs), C.POINTER(_abi.Groups), C.POINTER(_abi.Options),
+                                               C.POINTER(_abi.Results), _abi.i32p, C.POINTER(_abi.OptionQuery), _abi.i32p]
+        L._multi_bound = True
+    pegs, groups = ts.structs()
+    ng = groups.n_groups
+    if ts.peg_offsets is not None:
+        nnz_cap = int(ts.peg_offsets[ng])
+    elif ts.peg_lo is not None:
+        nnz_cap = int((ts.peg_hi - ts.peg_lo).sum())
+    else:
+        nnz_cap = pegs.n_pegs * ng
+    st, arrs = alloc_results(ng, nnz_cap)
+    off = np.zeros(ng + 1, np.int32)
+    opts = _abi.Options()
+    q = exp = None
+    if kinds is not None:
+        S = ts.n_sims if ts.n_sims else 1
+        ks = (C.c_int32 * max(len(kinds), 1))(*kinds)
+        exp = dict(best=np.full(S, -1, np.int32), n_best=np.zeros(S, np.int32), keys=np.zeros((S, 10), np.int64), packed=np.zeros(S, np.int64))
+        q = _abi.OptionQuery(kinds=ks, n_kinds=len(kinds), per_sim=1, best_out=exp["best"].ctypes.data_as(_abi.i32p),
+                             n_best_out=exp["n_best"].ctypes.data_as(_abi.i32p), key_out=exp["keys"].ctypes.data_as(_abi.i64p),
+                             packed_out=exp["packed"].ctypes.data_as(_abi.i64p))
+        if valid is not None:
+            v = np.ascontiguousarray(valid, np.uint8)
+            q.valid = v.ctypes.data_as(_abi.u8p)
+    info = (C.c_int32 * (1 + n_devices))()
+    rc = L.emu_estimate_batch_multi(n_devices, int(use_hook), C.byref(pegs), C.byref(groups), C.byref(opts), C.byref(st),
+                                    off.ctypes.data_as(_abi.i32p), C.byref(q) if q is not None else None, info)
+    assert rc == 0, (rc, L.emu_last_error())
+    return finish_results(arrs, ng, int(off[ng]), off), exp, list(info)

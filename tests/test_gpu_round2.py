@@ -1,0 +1,153 @@
+"""-m gpu: the entry points added in round 2 on a real MI355X, through the C ABI, against the oracle / the single-device
+path: batches of simulations (PEG ranges, per-simulation expander, validity mask), SchedulingError codes, the multi-device
+context (one process, several contexts, RCCL or host reduce), the timed call, the all-or-nothing rule."""
+import numpy as np
+import pytest
+
+import kubernetes_autoscaler_amd as kaa
+from kubernetes_autoscaler_amd import _abi, workloads
+from kubernetes_autoscaler_amd.engine import estimate_batch_timed
+from kubernetes_autoscaler_amd.tables import TableSet
+from harness import (GroupSpec, Scenario, assert_matches_oracle, encode, encode_batch, run_emu_tables, run_gpu_tables, run_oracle)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = kaa.Context(0)
+    yield c
+    c.close()
+
+
+def _scenario(seed, groups=5):
+    w = workloads.fuzz(seed, max_groups=groups, max_pegs=14)
+    return Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, None) for g in w.groups], device_csr=True)
+
+
+def _oracle_of(scs, bases):
+    want = []
+    for sc, (pb, _) in zip(scs, bases):
+        want.extend([(est, [pb + i for i in ids]) for est, ids in run_oracle(sc)])
+    return want
+
+
+def test_batched_simulations_match_the_oracle(ctx):
+    for seed in range(40):
+        scs = [_scenario(1000 * seed + k) for k in range(1 + seed % 6)]
+        enc, ts, bases = encode_batch(scs)
+        res, exp = run_gpu_tables(ts, ctx, kinds=[_abi.EXPANDER_LEAST_NODES, _abi.EXPANDER_LEAST_WASTE])
+        assert_matches_oracle(res, _oracle_of(scs, bases), f"batch {seed}")
+        _, emu = run_emu_tables(ts, kinds=[_abi.EXPANDER_LEAST_NODES, _abi.EXPANDER_LEAST_WASTE])
+        assert list(exp["best"]) == list(emu["best"]) and list(exp["n_best"]) == list(emu["n_best"])
+        assert exp["keys"].tolist() == emu["keys"].tolist() and list(exp["packed"]) == list(emu["packed"])
+        enc.close()
+
+
+def test_large_tiled_batch_on_the_device(ctx):
+    """4096 simulations in one launch (the bench's shape, small simulations): multi-block scan, wave-per-group orderer."""
+    scs = [_scenario(31 + k, groups=4) for k in range(8)]
+    enc, ts, bases = encode_batch(scs)
+    big = ts.tile(512)
+    res, exp = run_gpu_tables(big, ctx, kinds=[_abi.EXPANDER_LEAST_NODES])
+    base, bexp = run_gpu_tables(ts, ctx, kinds=[_abi.EXPANDER_LEAST_NODES])
+    assert_matches_oracle(base, _oracle_of(scs, bases), "tile base")
+    ng, nnz = ts.n_groups, int(base.offsets[-1])
+    for k in (0, 1, 255, 511):
+        assert list(res.node_count[k * ng:(k + 1) * ng]) == list(base.node_count)
+        assert list(res.pods_scheduled[k * ng:(k + 1) * ng]) == list(base.pods_scheduled)
+        assert list(res.placed[k * nnz:(k + 1) * nnz]) == list(base.placed)
+        assert list(exp["packed"][k * ts.n_sims:(k + 1) * ts.n_sims]) == list(bexp["packed"])
+    enc.close()
+
+
+def test_reason_codes_on_the_device(ctx):
+    from test_reasons_emu import emu_reasons, oracle_codes
+    for seed in range(60):
+        w = workloads.fuzz(9000 + seed, max_groups=5, max_pegs=14)
+        sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, None) for g in w.groups], existing=w.existing,
+                      device_csr=True)
+        enc = encode(sc)
+        got = ctx.feasibility_reasons(enc.pegs, enc.groups, enc.port_block)
+        assert got.tolist() == emu_reasons(enc).tolist(), seed
+        want = oracle_codes(sc)
+        for j in range(len(w.pegs)):
+            if enc.pegs.flags[j] & _abi.PEG_UNSUPPORTED:
+                continue
+            assert list(got[:, j]) == list(want[:, j]), (seed, j)
+        enc.close()
+
+
+def test_schedulable_pod_groups_with_errors(ctx):
+    from kubernetes_autoscaler_amd.equivalence import build_pod_groups, schedulable_pod_groups_with_errors
+    from kubernetes_autoscaler_amd.objects import NodeInfo, Taint, build_test_node, build_test_pod
+    small, large = build_test_pod("small", 100, 0), build_test_pod("large", 1500, 0)
+    tainted = build_test_node("tainted", 4000, 2000000)
+    tainted.taints = [Taint("dedicated", "x", "NoSchedule")]
+    ok, errors = schedulable_pod_groups_with_errors(ctx, build_pod_groups([small, large]), {"n1000": NodeInfo(build_test_node("n1000", 1000, 2000000)),
+                                                                                             "tainted": NodeInfo(tainted)})
+    assert ok.tolist() == [[True, False], [False, False]]
+    assert errors["n1000"][1].failing_predicate_name == "NodeResourcesFit" and errors["n1000"][1].failing_predicate_reasons == ["Insufficient cpu"]
+    assert errors["tainted"][0].failing_predicate_name == "TaintToleration"
+
+
+@pytest.mark.parametrize("devices,rccl", [([0], True), ([0, 0], False), ([0, 0, 0], False)])
+def test_multi_device_context(ctx, devices, rccl):
+    with kaa.MultiContext(devices, use_rccl=rccl) as m:
+        for seed in range(12):
+            scs = [_scenario(3100 + 10 * seed + k, groups=7) for k in range(1 + seed % 4)]
+            enc, ts, bases = encode_batch(scs)
+            pegs, groups = ts.structs()
+            for kinds in ([_abi.EXPANDER_LEAST_NODES], [_abi.EXPANDER_LEAST_WASTE, _abi.EXPANDER_MOST_PODS]):
+                got, exp = m.estimate_batch(pegs, groups, kinds=kinds)
+                assert_matches_oracle(got, _oracle_of(scs, bases), f"multi {devices} seed {seed}")
+                _, one = run_gpu_tables(ts, ctx, kinds=kinds)
+                assert list(exp["best"]) == list(one["best"]) and list(exp["packed"]) == list(one["packed"])
+            info = m.info()
+            assert info["devices"] == len(devices) and sum(info["groups_per_device"]) == ts.n_groups
+            assert info["rccl"] == rccl
+            enc.close()
+        if rccl:
+            got, exp = m.estimate_batch(pegs, groups, kinds=[_abi.EXPANDER_LEAST_NODES])
+            assert m.info()["last_reduce_by_rccl"]        # ncclAllReduce(min) ran on the hardware (1-rank communicator)
+
+
+def test_timed_call_reports_phases_and_the_same_results(ctx):
+    w = workloads.config_c2(n_groups=8, n_pegs=60, pods_per_peg=6, cap=10)
+    sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, None) for g in w.groups], device_csr=True)
+    enc, ts, bases = encode_batch([sc])
+    pegs, groups = ts.structs()
+    arrs, ph, exp = estimate_batch_timed(ctx, pegs, groups, kinds=[_abi.EXPANDER_LEAST_NODES])
+    res, one = run_gpu_tables(ts, ctx, kinds=[_abi.EXPANDER_LEAST_NODES])
+    assert list(arrs["node_count"][:ts.n_groups]) == list(res.node_count) and list(arrs["pods_scheduled"][:ts.n_groups]) == list(res.pods_scheduled)
+    assert int(exp["best"][0]) == int(one["best"][0])
+    assert all(ph[k] >= 0 for k in ph) and ph["wall_ms"] >= ph["pack_ms"] > 0
+    assert_matches_oracle(res, _oracle_of([sc], bases), "timed")
+    enc.close()
+
+
+def test_all_or_nothing_drops_partial_options_before_the_expander(ctx):
+    """orchestrator.go:1057-1063 / :1079: with all-or-nothing a partial option never reaches ExpanderStrategy.BestOption."""
+    from kubernetes_autoscaler_amd import estimator as est
+    from kubernetes_autoscaler_amd import expander
+    from kubernetes_autoscaler_amd.objects import GiB, NodeInfo, Pod, PodEquivalenceGroup, build_test_node
+    from kubernetes_autoscaler_amd.scaleup import ScaleUpSimulator
+    # small nodes, capped at 2: least-waste likes it but it cannot take all pods; big nodes take everything
+    small = est.NodeGroup("small", 2, 0)
+    big = est.NodeGroup("big", 10, 0)
+    infos = {"small": NodeInfo(build_test_node("small-t", 1000, 1 * GiB)), "big": NodeInfo(build_test_node("big-t", 16000, 64 * GiB))}
+    pods = [Pod(name=f"p{i}", requests={"cpu": 500, "memory": 256 * 1024 * 1024}) for i in range(8)]
+    peg = PodEquivalenceGroup(pods=pods)
+    limiter = est.ThresholdBasedEstimationLimiter([est.SngCapacityThreshold()])
+    for chain in ([expander.LEAST_WASTE], [expander.LEAST_NODES], [expander.MOST_PODS]):
+        sim = ScaleUpSimulator(ctx, limiter, expander.ChainStrategy(chain))
+        free = sim.prepare_scale_up([peg], [small, big], infos, est.ClusterSnapshotView())
+        aon = sim.prepare_scale_up([peg], [small, big], infos, est.ClusterSnapshotView(), all_or_nothing=True)
+        assert {o.node_group.id() for o in free.options} == {"small", "big"}
+        assert [o.node_group.id() for o in aon.options] == ["big"] and aon.best.node_group.id() == "big" and aon.n_equally_good == 1
+    # similar node groups widen the SngCapacityThreshold (orchestrator.go:409-412)
+    sim = ScaleUpSimulator(ctx, limiter, expander.ChainStrategy([expander.MOST_PODS]))
+    alone = sim.prepare_scale_up([peg], [small], infos, est.ClusterSnapshotView())
+    twin = est.NodeGroup("small-b", 3, 1)
+    wider = sim.prepare_scale_up([peg], [small], infos, est.ClusterSnapshotView(), similar_node_groups={"small": [twin]})
+    assert alone.options[0].node_count == 2 and wider.options[0].node_count == 4
