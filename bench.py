@@ -493,6 +493,8 @@ def main():
                 extra["roofline_dense_check"] = _try(lambda: dense_probe(kaa, ctx, seed_set, TableSet))
             if not args.no_next_rows:
                 extra.update(_try(lambda: next_rows(kaa, ctx, workloads)) or {})
+            if not args.no_c3:
+                extra["c3_in_process_multi_device"] = _try(lambda: in_process_multi_device(kaa, workloads, kinds))
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(workloads, make, range(min(S, 8)), checks_per_sim)
@@ -522,6 +524,30 @@ def main():
     if collective:
         dist.barrier()
         dist.destroy_process_group()
+    return out
+
+
+def in_process_multi_device(kaa, workloads, kinds, iters=20):
+    """SURVEY 8e inside ONE process (the shape a Go estimator has): casim_mctx over every visible device, one C3 simulation
+    per call, enter -> return (tables -> every device, kernels, RCCL all-reduce(min) of the key, results back)."""
+    import numpy as np
+    from kubernetes_autoscaler_amd.tables import TableSet
+    n = kaa.device_count()
+    enc = encode_workload(workloads.config_c3(), kaa.Encoder)
+    ts = TableSet.from_encoder(enc).as_one_simulation()
+    pegs, groups = ts.structs()
+    out = {"workload": "C3: 50k pods x 4k nodes, 64 node groups, one call = upload + kernels + reduce + fetch", "devices": n}
+    with kaa.MultiContext(list(range(n)), use_rccl=True) as m:
+        res, exp = m.estimate_batch(pegs, groups, kinds=kinds)
+        walls = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            res, exp = m.estimate_batch(pegs, groups, kinds=kinds)
+            walls.append((time.perf_counter() - t0) * 1e3)
+        info = m.info()
+        out.update({"wall_ms": float(np.median(walls)), "winner_group": int(exp["best"][0]), "reduce": "rccl all_reduce(min)" if info["last_reduce_by_rccl"] else "host",
+                    "groups_per_device": info["groups_per_device"]})
+    enc.close()
     return out
 
 

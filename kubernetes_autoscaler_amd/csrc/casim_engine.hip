@@ -16,6 +16,11 @@
 #include "casim_pipeline.h"
 #include "casim_multi.h"
 
+namespace casim {
+// casim_pack_tu.hip: the register packer, compiled in its own translation unit (see there)
+int hip_launch_pack_fast(int lanes, int slots_per_lane, int excl_words, int n_groups, void* stream, DevTables t, DevResults res, FastScratch fs);
+}
+
 namespace {
 
 thread_local std::string g_err;
@@ -45,6 +50,9 @@ struct HipBackend {
     const char* error() const { return msg.c_str(); }
     void clear() { last = hipSuccess; msg.clear(); (void)hipGetLastError(); }  // also drop HIP's sticky last error
 
+    void launch_pack_fast(int lanes, int slots_per_lane, int excl_words, int n_groups, const DevTables& t, const DevResults& res, const FastScratch& fs) {
+        check((hipError_t)casim::hip_launch_pack_fast(lanes, slots_per_lane, excl_words, n_groups, (void*)stream, t, res, fs), "pack_fast_kernel launch");
+    }
     template <class K, class... A>
     void launch(K kernel, int gx, int gy, int block, size_t smem, A... args) {
         if (gx <= 0 || gy <= 0) return;

@@ -10,6 +10,7 @@
 //     void   sync();
 //     size_t lds_budget() const;             // dynamic LDS bytes one workgroup may ask for
 //     template <class K, class... A> void launch(K kernel, int gx, int gy, int block, size_t smem, A... args);
+//     void   launch_pack_fast(int lanes, int slots_per_lane, int excl_words, int n_groups, DevTables, DevResults, FastScratch);
 //     bool   ok() const;  const char* error() const;
 //   };
 //
@@ -29,6 +30,15 @@
 namespace casim {
 
 inline int64_t round_up64(int64_t v) { return (v + 63) & ~63ll; }
+
+// The instantiations of the register packer: lanes R in {2, 4}, node slots per lane in {1, 4, 16}, exclusion words in {0, 2}.
+#define CASIM_FAST_DISPATCH(LAUNCH, r, npt, wx)                                                                      \
+    do {                                                                                                             \
+        if ((r) == 2) { if ((wx) == 2) { if ((npt) == 1) LAUNCH(2, 1, 2); else if ((npt) == 4) LAUNCH(2, 4, 2); else LAUNCH(2, 16, 2); }          \
+                        else           { if ((npt) == 1) LAUNCH(2, 1, 0); else if ((npt) == 4) LAUNCH(2, 4, 0); else LAUNCH(2, 16, 0); } }        \
+        else          { if ((wx) == 2) { if ((npt) == 1) LAUNCH(4, 1, 2); else if ((npt) == 4) LAUNCH(4, 4, 2); else LAUNCH(4, 16, 2); }          \
+                        else           { if ((npt) == 1) LAUNCH(4, 1, 0); else if ((npt) == 4) LAUNCH(4, 4, 0); else LAUNCH(4, 16, 0); } }        \
+    } while (0)
 
 template <class BK>
 class ProblemT {
@@ -263,13 +273,9 @@ public:
     int32_t run_pack() {
         if (NG_ == 0) return CASIM_OK;
         if (fast_npt_ > 0) {
-            // register-resident int32 packer (no LDS): pick the instantiation by lanes and node bound
-#define CASIM_FAST_LAUNCH(R, N, X) bk_.launch(pack_fast_kernel<R, N, X>, NG_, 1, 64, (size_t)RegStore<R, N, X>::kChunkBytes, dt_, dr_, fs_)
-#define CASIM_FAST_PICK(R, X) do { if (fast_npt_ == 1) CASIM_FAST_LAUNCH(R, 1, X); else if (fast_npt_ == 4) CASIM_FAST_LAUNCH(R, 4, X); else CASIM_FAST_LAUNCH(R, 16, X); } while (0)
-            if (fast_r_ == 2) { if (fast_wx_ == 2) CASIM_FAST_PICK(2, 2); else CASIM_FAST_PICK(2, 0); }
-            else              { if (fast_wx_ == 2) CASIM_FAST_PICK(4, 2); else CASIM_FAST_PICK(4, 0); }
-#undef CASIM_FAST_PICK
-#undef CASIM_FAST_LAUNCH
+            // register-resident int32 packer: the instantiation (lanes, node slots per lane, exclusion words) is picked by the
+            // backend — the product compiles these kernels in their own translation unit (casim_pack_tu.hip)
+            bk_.launch_pack_fast(fast_r_, fast_npt_, fast_wx_, NG_, dt_, dr_, fs_);
             if (fs_.prof) {  // profiling builds: mean ticks per phase over the groups
                 std::vector<int64_t> h((size_t)NG_ * 8);
                 bk_.d2h(h.data(), fs_.prof, h.size() * 8); bk_.sync();

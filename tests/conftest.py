@@ -36,3 +36,6 @@ def _build_all():
     lib = os.path.join(ROOT, "kubernetes_autoscaler_amd", "libcasim.so")
     if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
         _make(os.path.join(ROOT, "kubernetes_autoscaler_amd", "csrc"))
+    native = os.path.join(ROOT, "tools", "casim_native")
+    if not os.path.exists(native) and os.path.exists(lib):
+        _make(os.path.join(ROOT, "tools"))
