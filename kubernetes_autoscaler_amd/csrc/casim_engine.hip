@@ -87,8 +87,12 @@ struct Rccl {
     static constexpr int kInt64 = 4, kMin = 3;   // ncclInt64, ncclMin (nccl.h enums)
     bool load(std::string& err) {
         if (handle) return true;
+        // 1. an RCCL the process already carries (a host that links one, torch's bundled copy): never load a second one;
+        // 2. CASIM_RCCL_PATH; 3. the system library.
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-        for (const char* n : names) { handle = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (handle) break; }
+        for (const char* n : names) { handle = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD); if (handle) break; }
+        if (!handle) { const char* env = getenv("CASIM_RCCL_PATH"); if (env && *env) handle = dlopen(env, RTLD_NOW | RTLD_LOCAL); }
+        if (!handle) for (const char* n : names) { handle = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (handle) break; }
         if (!handle) { err = "librccl.so not found (dlopen)"; return false; }
         CommInitAll = (decltype(CommInitAll))dlsym(handle, "ncclCommInitAll"); CommDestroy = (decltype(CommDestroy))dlsym(handle, "ncclCommDestroy");
         AllReduce = (decltype(AllReduce))dlsym(handle, "ncclAllReduce"); GroupStart = (decltype(GroupStart))dlsym(handle, "ncclGroupStart");

@@ -221,7 +221,6 @@ private:
     static void finish_view(GroupRows& r, const casim_pegs* p, const casim_groups* g, int S) {
         casim_groups& v = r.view; memset(&v, 0, sizeof v);
         v.n_groups = (int32_t)r.src.size();
-        auto ptr = [](auto& vec) { return vec.empty() ? nullptr : vec.data(); };
         static const int64_t z64[CASIM_KMAX_RES] = {0}; static const int32_t z32[2] = {0, 0}; static const uint32_t zu32[1] = {0}; static const uint64_t zu64[64] = {0};
         // an empty shard still needs non-null mandatory columns
         v.alloc = r.alloc.empty() ? z64 : r.alloc.data(); v.init_req = r.init_req.empty() ? z64 : r.init_req.data();
@@ -231,9 +230,10 @@ private:
         v.taint_mask = r.taint.empty() ? zu64 : r.taint.data(); v.label_mask = r.label.empty() ? zu64 : r.label.data();
         v.init_excl = r.init_excl.empty() ? zu64 : r.init_excl.data(); v.init_zone = r.init_zone.empty() ? zu64 : r.init_zone.data();
         v.zone_valid = r.zone_valid.empty() ? zu64 : r.zone_valid.data();
-        v.cap_cpu = g->cap_cpu ? ptr(r.cap_cpu) : nullptr; v.cap_mem = g->cap_mem ? ptr(r.cap_mem) : nullptr;
-        v.waste_cpu = g->waste_cpu ? ptr(r.waste_cpu) : nullptr; v.waste_mem = g->waste_mem ? ptr(r.waste_mem) : nullptr;
-        if (v.n_groups == 0) { v.cap_cpu = v.cap_mem = nullptr; v.waste_cpu = v.waste_mem = nullptr; }
+        static const double zf64[1] = {0.0};
+        v.cap_cpu = g->cap_cpu ? (r.cap_cpu.empty() ? zf64 : r.cap_cpu.data()) : nullptr; v.cap_mem = g->cap_mem ? (r.cap_mem.empty() ? zf64 : r.cap_mem.data()) : nullptr;
+        v.waste_cpu = g->waste_cpu ? (r.waste_cpu.empty() ? z64 : r.waste_cpu.data()) : nullptr;
+        v.waste_mem = g->waste_mem ? (r.waste_mem.empty() ? z64 : r.waste_mem.data()) : nullptr;
         if (g->peg_offsets) { if (r.peg_offsets.empty()) r.peg_offsets.push_back(0); v.peg_offsets = r.peg_offsets.data(); v.peg_index = r.peg_index.empty() ? z32 : r.peg_index.data(); }
         else { v.peg_lo = r.peg_lo.empty() ? z32 : r.peg_lo.data(); v.peg_hi = r.peg_hi.empty() ? z32 : r.peg_hi.data(); }
         v.global_id = r.global_id.empty() ? z32 : r.global_id.data();

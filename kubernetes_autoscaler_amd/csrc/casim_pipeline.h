@@ -400,7 +400,7 @@ public:
         for (int i = 0; i < n_kinds; ++i) {
             a.kinds[i] = q->kinds[i];
             if (q->kinds[i] < 0 || q->kinds[i] > 2) return fail(CASIM_ERR_INVALID, "unknown expander kind");
-            if (q->kinds[i] == CASIM_EXPANDER_LEAST_WASTE && (!dt_.waste_cpu || !dt_.waste_mem)) return fail(CASIM_ERR_INVALID, "least-waste needs waste_cpu/waste_mem");
+            if (q->kinds[i] == CASIM_EXPANDER_LEAST_WASTE && NG_ > 0 && (!dt_.waste_cpu || !dt_.waste_mem)) return fail(CASIM_ERR_INVALID, "least-waste needs waste_cpu/waste_mem");
         }
         if (q->valid) {
             if (!d_opt_valid_) d_opt_valid_ = (uint8_t*)dalloc((size_t)NG_);

@@ -80,4 +80,7 @@ def test_more_devices_than_groups():
     got, e2, info = run_emu_multi(ts, 8, kinds=[_abi.EXPANDER_LEAST_NODES])
     _same_results(got, one)
     assert list(e2["best"]) == list(e1["best"]) and 0 in info[1:9]
+    _, w1 = run_emu_tables(ts, kinds=[_abi.EXPANDER_LEAST_WASTE, _abi.EXPANDER_MOST_PODS])
+    _, w2, _ = run_emu_multi(ts, 8, kinds=[_abi.EXPANDER_LEAST_WASTE, _abi.EXPANDER_MOST_PODS])     # empty shards carry no capacity columns
+    assert list(w2["best"]) == list(w1["best"])
     enc.close()
