@@ -193,8 +193,15 @@ def config_rows(kaa, ctx, workloads, kinds, iters=20):
     from harness import assert_matches_oracle
     from kubernetes_autoscaler_amd.engine import finish_results
     rows = []
-    for name in ("C0", "C1", "C2", "C3", "C4"):
-        make = workloads.CONFIGS[name]
+
+    def c2_one_group(seed_offset=0):
+        """What ONE Estimate() call carries when the shim does not batch: the first node group of C2 and every PEG."""
+        w = workloads.config_c2(seed_offset)
+        w.groups = w.groups[:1]
+        w.name = "C2, one node group per call"
+        return w
+    for name in ("C0", "C1", "C2", "C3", "C4", "C2-per-call"):
+        make = workloads.CONFIGS.get(name, c2_one_group)
         row = {"config": name}
         try:
             t0 = time.perf_counter()
@@ -226,6 +233,9 @@ def config_rows(kaa, ctx, workloads, kinds, iters=20):
             row["checks_per_s_single_sim"] = row["checks"] / (row["wall_ms"] * 1e-3)
             row["best_group"] = int(best["best"][0])
             # the oracle on the same input (CPU, one thread) and the bit-exact comparison
+            if name == "C2-per-call":
+                row["note"] = ("per-call mode: one casim_estimate_batch per Estimate(), 20 of these make one C2 loop iteration; "
+                               "the batch row above is the same work in ONE call")
             _, s, run = oracle_simulation(workloads, make, None if name == "C0" else 0)
             want, osec, _ = run()
             _, osec2, _ = run(False)

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -38,8 +39,50 @@ struct HipBackend {
         if (e != hipSuccess && last == hipSuccess) { last = e; msg = std::string(what) + ": " + hipGetErrorString(e); }
     }
     void bind() { check(hipSetDevice(device), "hipSetDevice"); }
-    void* alloc(size_t b) { void* p = nullptr; check(hipMalloc(&p, b), "hipMalloc"); return p; }
-    void free(void* p) { if (p) (void)hipFree(p); }
+    // Device memory comes from a per-context pool of power-of-two blocks: a call that comes back every loop iteration
+    // (casim_estimate_batch allocates ~25 scratch / result arrays) finds its blocks in the free lists instead of paying
+    // hipMalloc / hipFree each time.  At most kPoolKeepBytes stay cached; everything is released with the context.
+    static constexpr size_t kPoolKeepBytes = (size_t)8 << 30;
+    std::map<size_t, std::vector<void*>> pool;     // block size -> free blocks
+    std::map<void*, size_t> live;                  // block -> its size
+    size_t pooled_bytes = 0;
+    static size_t block_size(size_t b) { size_t s = 256; while (s < b) s <<= 1; return s; }
+    void* alloc(size_t b) {
+        const size_t s = block_size(b);
+        auto it = pool.find(s);
+        void* p = nullptr;
+        if (it != pool.end() && !it->second.empty()) { p = it->second.back(); it->second.pop_back(); pooled_bytes -= s; }
+        else check(hipMalloc(&p, s), "hipMalloc");
+        if (p) live[p] = s;
+        return p;
+    }
+    void free(void* p) {
+        if (!p) return;
+        auto it = live.find(p);
+        if (it == live.end()) { (void)hipFree(p); return; }
+        const size_t s = it->second;
+        live.erase(it);
+        if (pooled_bytes + s <= kPoolKeepBytes) { pool[s].push_back(p); pooled_bytes += s; }
+        else (void)hipFree(p);
+    }
+    void release_pool() {
+        for (auto& kv : pool) for (void* p : kv.second) (void)hipFree(p);
+        pool.clear(); pooled_bytes = 0;
+        for (int i = 0; i < 2; ++i) { if (staging[i]) (void)hipHostFree(staging[i]); staging[i] = nullptr; staging_cap[i] = 0; }
+    }
+    // pinned host staging: 0 = uploads, 1 = fetches
+    void* staging[2] = {nullptr, nullptr}; size_t staging_cap[2] = {0, 0};
+    void* stage(int which, size_t bytes) {
+        which &= 1;
+        if (staging_cap[which] < bytes) {
+            if (staging[which]) (void)hipHostFree(staging[which]);
+            size_t cap = 1 << 16; while (cap < bytes) cap <<= 1;
+            staging[which] = nullptr; staging_cap[which] = 0;
+            check(hipHostMalloc(&staging[which], cap, hipHostMallocDefault), "hipHostMalloc");
+            if (staging[which]) staging_cap[which] = cap;
+        }
+        return staging[which];
+    }
     void h2d(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D"); }
     void d2h(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H"); }
     void zero(void* d, size_t n) { if (n) check(hipMemsetAsync(d, 0, n, stream), "hipMemsetAsync"); }
@@ -258,6 +301,8 @@ casim_ctx* casim_ctx_create(int32_t device, void* stream) {
 void casim_ctx_destroy(casim_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->bk.device);
+    if (ctx->bk.stream) (void)hipStreamSynchronize(ctx->bk.stream);
+    ctx->bk.release_pool();
     if (ctx->bk.own_stream && ctx->bk.stream) (void)hipStreamDestroy(ctx->bk.stream);
     delete ctx;
 }

@@ -7,6 +7,8 @@
 //     void   h2d(void* dst, const void* src, size_t bytes);   // async on the backend's stream
 //     void   d2h(void* dst, const void* src, size_t bytes);
 //     void   zero(void* dst, size_t bytes);
+//     void*  stage(int which, size_t bytes);  // host staging buffer (pinned on the device backend) of >= bytes, owned by the
+//                                             // backend and reused by later calls: 0 = uploads, 1 = fetches
 //     void   sync();
 //     size_t lds_budget() const;             // dynamic LDS bytes one workgroup may ask for
 //     template <class K, class... A> void launch(K kernel, int gx, int gy, int block, size_t smem, A... args);
@@ -72,6 +74,17 @@ public:
         if (dt_.fastpath && (!p->fp_cpu || !p->fp_mem || !g->cap_cpu || !g->cap_mem))
             return fail(CASIM_ERR_INVALID, "fastpath needs fp_cpu/fp_mem/cap_cpu/cap_mem");
 
+        // ---- ONE host-to-device copy for every table of the batch: the columns (and the small derived arrays below) are
+        // packed into the backend's pinned staging buffer and land in one device slab; 30+ separate pageable copies cost
+        // 0.17 ms of a 0.5 ms single-simulation call (profiles/r02d_bench.json, configs[].phases_ms.upload_ms)
+        {
+            const size_t masks = (size_t)(dt_.Wt + dt_.Wl + 2 * dt_.Wx + 2 * dt_.Wz);
+            size_t bound = G * (8 * (size_t)R + 8 + 8 * masks + 16 + 4 * (size_t)R) +
+                           NG * (16 * (size_t)R + 24 + 8 * masks + 32 + 4 + 8 + 4 + 8 + 8 + 4 * (size_t)R) + 8 * (size_t)R +
+                           4 * ((size_t)(g->n_sims > 0 ? g->n_sims : 0) + 1) + 4 * (NG + 1) + 64 * 64 + 4096;
+            if (g->peg_offsets && NG > 0 && g->peg_offsets[NG] > 0) bound += 4 * (size_t)g->peg_offsets[NG];
+            begin_uploads(bound);
+        }
         dt_.req = up(p->req, G * R); dt_.count = up(p->count, G); dt_.pflags = up(p->flags, G);
         dt_.tol = up(p->tol_mask, G * dt_.Wt); dt_.sel = up(p->sel_mask, G * dt_.Wl);
         dt_.xblock = up(p->excl_block, G * dt_.Wx); dt_.xmark = up(p->excl_mark, G * dt_.Wx);
@@ -85,6 +98,16 @@ public:
         dt_.cap_cpu = g->cap_cpu ? up(g->cap_cpu, NG) : nullptr; dt_.cap_mem = g->cap_mem ? up(g->cap_mem, NG) : nullptr;
         dt_.waste_cpu = g->waste_cpu ? up(g->waste_cpu, NG) : nullptr; dt_.waste_mem = g->waste_mem ? up(g->waste_mem, NG) : nullptr;
 
+        // ---- results slab: the per-group scalars and the CSR offsets side by side, so that ONE device-to-host copy fetches them
+        {
+            const size_t ng = NG > 0 ? NG : 1;
+            res_bytes_ = 16 * ng + 24 * ng + 4 * (ng + 1);
+            res_slab_ = (char*)dalloc(res_bytes_);
+            dr_.cpu_sum = (int64_t*)res_slab_; dr_.mem_sum = dr_.cpu_sum + ng;
+            int32_t* i32 = (int32_t*)(dr_.mem_sum + ng);
+            dr_.node_count = i32; dr_.pods = i32 + ng; dr_.nodes_added = i32 + 2 * ng; dr_.limiter_nodes = i32 + 3 * ng;
+            dr_.last_index_out = i32 + 4 * ng; dr_.status = i32 + 5 * ng; res_off_ = i32 + 6 * ng;
+        }
         // ---- simulations of the batch (expander reduce per simulation) ----
         n_sims_ = 0;
         if (g->n_sims > 0) {
@@ -135,11 +158,10 @@ public:
             if (cap > 0x7fffffffll) return fail(CASIM_ERR_INVALID, "sum of candidate PEG ranges too large for device-side CSR");
             nnz_cap_ = (int32_t)cap; feas_len_ = lmax;
             Wg_ = (lmax + 63) / 64;
-            dt_.peg_lo = up(lo.data(), NG); dt_.peg_hi = up(hi.data(), NG);
-            bk_.sync();  // lo / hi die at the end of this scope
+            dt_.peg_lo = up(lo.data(), NG); dt_.peg_hi = up(hi.data(), NG);   // (copied into the staging buffer: lo / hi may die)
             d_bits_ = (uint64_t*)dalloc(sizeof(uint64_t) * NG * (size_t)(Wg_ > 0 ? Wg_ : 1));
             d_counts_ = (int32_t*)dalloc(sizeof(int32_t) * (NG + 1));
-            d_off_ = (int32_t*)dalloc(sizeof(int32_t) * (NG + 1));
+            d_off_ = res_off_;   // inside the results slab: one copy brings the scalars and the offsets back
             d_block_sums_ = (int32_t*)dalloc(sizeof(int32_t) * (NG / 64 + 2));
             d_idx_ = (int32_t*)dalloc(sizeof(int32_t) * (size_t)nnz_cap_);
             dt_.peg_off = d_off_; dt_.peg_idx = d_idx_;
@@ -194,8 +216,7 @@ public:
                     fresh32[i * R + r] = (int32_t)((g->alloc[i * R + r] - g->init_req[i * R + r]) / scale[(size_t)r]);
                 fs_.req32 = up(req32.data(), req32.size());
                 fs_.fresh32 = up(fresh32.data(), fresh32.size());
-                fs_.scale = up(scale.data(), scale.size());
-                bk_.sync();  // the staging vectors die at the end of this scope
+                fs_.scale = up(scale.data(), scale.size());   // (all three copied into the staging buffer already)
                 if (getenv("CASIM_PACK_PROF_DUMP")) { fs_.prof = (int64_t*)dalloc(8 * 8 * NG); bk_.zero(fs_.prof, 8 * 8 * NG); }
                 fast_npt_ = maxcap <= 64 ? 1 : (maxcap <= 256 ? 4 : 16);
                 fast_r_ = R <= 2 ? 2 : 4;
@@ -230,9 +251,6 @@ public:
             os_.gbuf = (char*)dalloc((size_t)ototal);
         }
         // ---- results ----
-        dr_.node_count = (int32_t*)dalloc(4 * NG); dr_.pods = (int32_t*)dalloc(4 * NG); dr_.nodes_added = (int32_t*)dalloc(4 * NG);
-        dr_.limiter_nodes = (int32_t*)dalloc(4 * NG); dr_.last_index_out = (int32_t*)dalloc(4 * NG); dr_.status = (int32_t*)dalloc(4 * NG);
-        dr_.cpu_sum = (int64_t*)dalloc(8 * NG); dr_.mem_sum = (int64_t*)dalloc(8 * NG);
         dr_.order = (int32_t*)dalloc(4 * (size_t)nnz_cap_); dr_.placed = (int32_t*)dalloc(4 * (size_t)nnz_cap_);
         dr_.fast_last = (uint8_t*)dalloc(NG);
         dr_.s_count = (int32_t*)dalloc(4 * (size_t)nnz_cap_); dr_.s_flags = (uint32_t*)dalloc(4 * (size_t)nnz_cap_);
@@ -243,7 +261,8 @@ public:
         d_opt_key_ = (int64_t*)dalloc(80);
         d_opt_packed_ = (int64_t*)dalloc(8);
         opt_cap_ = 1;
-        bk_.sync();  // every staging buffer (caller tables, local vectors) may be released after init()
+        end_uploads();
+        bk_.sync();  // the staging buffer belongs to the backend: the next problem of this context may reuse it after init()
         if (!bk_.ok()) return fail(CASIM_ERR_HIP, bk_.error());
         ready_ = true;
         return CASIM_OK;
@@ -297,12 +316,12 @@ public:
     int32_t run() {
         if (!ready_) return fail(CASIM_ERR_INVALID, "problem not initialised");
         run_feasibility(); run_order(); run_pack();
-        ran_ = true;
+        ran_ = true; h_off_fresh_ = false;
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
     }
 
     // the kernels were enqueued phase by phase (timed callers): results may be fetched
-    int32_t run_mark() { if (!ready_) return fail(CASIM_ERR_INVALID, "problem not initialised"); ran_ = true; return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error()); }
+    int32_t run_mark() { if (!ready_) return fail(CASIM_ERR_INVALID, "problem not initialised"); ran_ = true; h_off_fresh_ = false; return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error()); }
 
     int32_t csr(int32_t* nnz_out, int32_t* offsets_out) {
         if (!ready_) return fail(CASIM_ERR_INVALID, "problem not initialised");
@@ -321,21 +340,41 @@ public:
     int32_t fetch(casim_results* out) {
         if (!ready_ || !ran_) return fail(CASIM_ERR_INVALID, "nothing to fetch: run the problem first");
         if (!out) return fail(CASIM_ERR_INVALID, "null results");
-        int32_t nnz = 0;
-        const int32_t rc = csr(&nnz, nullptr);
-        if (rc != CASIM_OK) return rc;
-        const size_t NG = (size_t)NG_;
-        if (out->node_count) bk_.d2h(out->node_count, dr_.node_count, 4 * NG);
-        if (out->pods_scheduled) bk_.d2h(out->pods_scheduled, dr_.pods, 4 * NG);
-        if (out->nodes_added) bk_.d2h(out->nodes_added, dr_.nodes_added, 4 * NG);
-        if (out->limiter_nodes) bk_.d2h(out->limiter_nodes, dr_.limiter_nodes, 4 * NG);
-        if (out->last_index_out) bk_.d2h(out->last_index_out, dr_.last_index_out, 4 * NG);
-        if (out->status) bk_.d2h(out->status, dr_.status, 4 * NG);
-        if (out->req_cpu_sum) bk_.d2h(out->req_cpu_sum, dr_.cpu_sum, 8 * NG);
-        if (out->req_mem_sum) bk_.d2h(out->req_mem_sum, dr_.mem_sum, 8 * NG);
-        if (out->order) bk_.d2h(out->order, dr_.order, 4 * (size_t)nnz);
-        if (out->placed) bk_.d2h(out->placed, dr_.placed, 4 * (size_t)nnz);
+        const size_t NG = (size_t)NG_, ng = NG > 0 ? NG : 1;
+        // copy 1: scalars + offsets (one slab); copies 2, 3: order / placed — enqueued with the first one when their bound is
+        // small or the offsets are the caller's, after it (the device-side nnz is in the slab) otherwise
+        const bool spec = !csr_on_device_ || nnz_cap_ <= 16384;
+        const size_t spec_n = !csr_on_device_ ? (size_t)(NG > 0 ? h_off_[NG] : 0) : (size_t)nnz_cap_;
+        char* st = (char*)bk_.stage(1, res_bytes_ + (spec ? 8 * spec_n : 0) + 64);
+        if (!st) return fail(CASIM_ERR_NOMEM, "no staging buffer");
+        bk_.d2h(st, res_slab_, res_bytes_);
+        int32_t* st_order = (int32_t*)(st + ((res_bytes_ + 15) & ~(size_t)15));
+        int32_t* st_placed = st_order + spec_n;
+        if (spec && spec_n > 0) {
+            if (out->order) bk_.d2h(st_order, dr_.order, 4 * spec_n);
+            if (out->placed) bk_.d2h(st_placed, dr_.placed, 4 * spec_n);
+        }
         bk_.sync();
+        const int64_t* h64 = (const int64_t*)st;
+        const int32_t* h32 = (const int32_t*)(h64 + 2 * ng);
+        if (csr_on_device_ && NG_ > 0) { h_off_.assign(h32 + 6 * ng, h32 + 6 * ng + NG + 1); h_off_fresh_ = true; }
+        const size_t nnz = NG_ > 0 ? (size_t)h_off_[NG] : 0;
+        if (out->req_cpu_sum) memcpy(out->req_cpu_sum, h64, 8 * NG);
+        if (out->req_mem_sum) memcpy(out->req_mem_sum, h64 + ng, 8 * NG);
+        if (out->node_count) memcpy(out->node_count, h32, 4 * NG);
+        if (out->pods_scheduled) memcpy(out->pods_scheduled, h32 + ng, 4 * NG);
+        if (out->nodes_added) memcpy(out->nodes_added, h32 + 2 * ng, 4 * NG);
+        if (out->limiter_nodes) memcpy(out->limiter_nodes, h32 + 3 * ng, 4 * NG);
+        if (out->last_index_out) memcpy(out->last_index_out, h32 + 4 * ng, 4 * NG);
+        if (out->status) memcpy(out->status, h32 + 5 * ng, 4 * NG);
+        if (spec) {
+            if (out->order && nnz) memcpy(out->order, st_order, 4 * nnz);
+            if (out->placed && nnz) memcpy(out->placed, st_placed, 4 * nnz);
+        } else if (nnz > 0) {   // a big batch: straight into the caller's arrays
+            if (out->order) bk_.d2h(out->order, dr_.order, 4 * nnz);
+            if (out->placed) bk_.d2h(out->placed, dr_.placed, 4 * nnz);
+            bk_.sync();
+        }
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
     }
 
@@ -447,11 +486,28 @@ public:
     static constexpr int kOrderThreads = 256;
 
 private:
+    // Uploads between begin_uploads() and end_uploads() are packed: the bytes go to the backend's staging buffer right away
+    // (the caller's array may die), the device pointer is a slice of ONE slab, and end_uploads() issues the one copy.
+    void begin_uploads(size_t bound) {
+        up_host_ = (char*)bk_.stage(0, bound);
+        up_dev_ = up_host_ ? (char*)dalloc(bound) : nullptr;
+        up_cap_ = up_dev_ ? bound : 0; up_used_ = 0;
+    }
+    void end_uploads() {
+        if (up_dev_ && up_used_ > 0) bk_.h2d(up_dev_, up_host_, up_used_);
+        up_dev_ = up_host_ = nullptr; up_cap_ = 0;
+    }
     template <class T>
     const T* up(const T* src, size_t n) {
         if (n == 0 || !src) return nullptr;
-        T* d = (T*)dalloc(sizeof(T) * n);
-        if (d) bk_.h2d(d, src, sizeof(T) * n);
+        const size_t bytes = sizeof(T) * n, at = (up_used_ + 15) & ~(size_t)15;
+        if (up_dev_ && at + bytes <= up_cap_) {
+            memcpy(up_host_ + at, src, bytes);
+            up_used_ = at + bytes;
+            return (const T*)(up_dev_ + at);
+        }
+        T* d = (T*)dalloc(bytes);   // outside a packed section (or a bound that was too small): its own copy
+        if (d) bk_.h2d(d, src, bytes);
         return d;
     }
     void* dalloc(size_t bytes) {
@@ -479,6 +535,9 @@ private:
     uint8_t* d_opt_valid_ = nullptr; size_t opt_cap_ = 0;
     int n_sims_ = 0, max_sim_groups_ = 0, feas_len_ = 0;
     std::vector<int32_t> h_off_;
+    bool h_off_fresh_ = false;
+    char* up_dev_ = nullptr; char* up_host_ = nullptr; size_t up_cap_ = 0, up_used_ = 0;
+    char* res_slab_ = nullptr; size_t res_bytes_ = 0; int32_t* res_off_ = nullptr;
     std::vector<void*> allocs_;
     std::string err_;
 };

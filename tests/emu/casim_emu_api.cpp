@@ -21,6 +21,8 @@ struct EmuBackend {
     void fill8(void* d, int v, size_t n) { memset(d, v, n); }
     void sync() {}
     void bind() {}
+    std::vector<char> staging[2];
+    void* stage(int which, size_t bytes) { if (staging[which & 1].size() < bytes) staging[which & 1].resize(bytes); return staging[which & 1].data(); }
     size_t lds_budget() const { return lds; }
     bool ok() const { return true; }
     const char* error() const { return ""; }
