@@ -145,7 +145,9 @@ typedef struct casim_groups {
 typedef struct casim_options {
     int32_t fastpath;             /* --fastpath-binpacking-enabled (flags.go:203), default 0 */
     int32_t force_generic_packer; /* 1 = never use the register-resident int32 packer (testing / A-B) */
-    int32_t reserved[6];
+    int32_t node_pods;            /* 1 = keep the pods per simulated node (casim_results.node_pods): what
+                                     estimationAnalyserFunc receives as newNodesWithPods (binpacking_estimator.go:157-159) */
+    int32_t reserved[5];
 } casim_options;
 
 /*
@@ -167,6 +169,15 @@ typedef struct casim_results {
     int64_t* req_mem_sum;     /* [NG] sum of lane-1 requests of scheduled pods            */
     int32_t* order;           /* [nnz]                                                    */
     int32_t* placed;          /* [nnz]                                                    */
+    /* optional (casim_options.node_pods = 1, else ignored; may be NULL): pods on every node the estimate added, in creation
+     * order — node j of group i is the reference's "<template>-e-<j>" (binpacking_estimator.go:326-342) and belongs to
+     * newNodesWithPods iff its count is > 0 (estimationState.trackScheduledPod :58-61).  Compact: the nodes of group i are
+     * node_pods[node_pods_offsets[i] .. node_pods_offsets[i+1]), nodes_added[i] entries; groups are cut off (and the call
+     * still succeeds) once node_pods_capacity entries are used — size it as the sum of the groups' max_nodes.  The
+     * fastpath's extrapolated nodes (tryFastPath :274-324) exist only as a count and are not listed. */
+    int32_t* node_pods;           /* [node_pods_capacity] */
+    int32_t* node_pods_offsets;   /* [NG+1] */
+    int64_t node_pods_capacity;
 } casim_results;
 
 /* ======================================================================================

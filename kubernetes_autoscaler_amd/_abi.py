@@ -64,7 +64,7 @@ class Groups(C.Structure):
 
 
 class Options(C.Structure):
-    _fields_ = [("fastpath", C.c_int32), ("force_generic_packer", C.c_int32), ("reserved", C.c_int32 * 6)]
+    _fields_ = [("fastpath", C.c_int32), ("force_generic_packer", C.c_int32), ("node_pods", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class Results(C.Structure):
@@ -72,6 +72,7 @@ class Results(C.Structure):
         ("node_count", i32p), ("pods_scheduled", i32p), ("nodes_added", i32p), ("limiter_nodes", i32p),
         ("last_index_out", i32p), ("status", i32p), ("req_cpu_sum", i64p), ("req_mem_sum", i64p),
         ("order", i32p), ("placed", i32p),
+        ("node_pods", i32p), ("node_pods_offsets", i32p), ("node_pods_capacity", C.c_int64),
     ]
 
 

@@ -814,6 +814,13 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
         const int m = s * 64 + lane;
         with_pods += cs::popc64(cs::ballot(m < M && st.npods(s, m) > 0));
     });
+    if (res.node_pods) {   // newNodesWithPods for the analyser hook: pods of every node this estimate added
+        int32_t* np = res.node_pods + res.node_pods_off[ng];
+        for_slots<Store>((M + 63) >> 6, [&](int s) {
+            const int m = s * 64 + lane;
+            if (m < M) np[m] = st.npods(s, m);
+        });
+    }
     if (lane == 0) {
         res.node_count[ng] = with_pods + fakes;
         res.pods[ng] = total_placed;

@@ -223,6 +223,12 @@ public:
             }
         }
         ps_.node_cap = up(cap.data(), NG);
+        if (o && o->node_pods) {   // pods per simulated node (estimationAnalyserFunc's newNodesWithPods)
+            np_off_.assign(NG + 1, 0);
+            for (size_t i = 0; i < NG; ++i) np_off_[i + 1] = np_off_[i] + cap[i];
+            d_node_pods_ = (int32_t*)dalloc(4 * (size_t)(np_off_[NG] > 0 ? np_off_[NG] : 1));
+            dr_.node_pods = d_node_pods_; dr_.node_pods_off = up(np_off_.data(), NG + 1);
+        }
         if (!pack_lds_) {
             ps_.state_off = up(soff.data(), NG);
             ps_.gstate = (char*)dalloc((size_t)total);
@@ -374,6 +380,22 @@ public:
             if (out->order) bk_.d2h(out->order, dr_.order, 4 * nnz);
             if (out->placed) bk_.d2h(out->placed, dr_.placed, 4 * nnz);
             bk_.sync();
+        }
+        if (d_node_pods_ && out->node_pods && out->node_pods_offsets) {
+            // padded per-group slices on the device -> compact lists (nodes_added[i] entries each) for the caller
+            std::vector<int32_t> padded((size_t)np_off_[NG] + 1);
+            bk_.d2h(padded.data(), d_node_pods_, 4 * (size_t)np_off_[NG]);
+            bk_.sync();
+            int64_t at = 0;
+            out->node_pods_offsets[0] = 0;
+            for (size_t i = 0; i < NG; ++i) {
+                int64_t n = h32[2 * ng + i];   // nodes_added
+                if (h32[5 * ng + i] != CASIM_NG_OK) n = 0;
+                if (at + n > out->node_pods_capacity) n = out->node_pods_capacity - at > 0 ? out->node_pods_capacity - at : 0;
+                if (n > 0) memcpy(out->node_pods + at, padded.data() + np_off_[i], 4 * (size_t)n);
+                at += n;
+                out->node_pods_offsets[i + 1] = (int32_t)at;
+            }
         }
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
     }
@@ -538,6 +560,7 @@ private:
     bool h_off_fresh_ = false;
     char* up_dev_ = nullptr; char* up_host_ = nullptr; size_t up_cap_ = 0, up_used_ = 0;
     char* res_slab_ = nullptr; size_t res_bytes_ = 0; int32_t* res_off_ = nullptr;
+    int32_t* d_node_pods_ = nullptr; std::vector<int64_t> np_off_;
     std::vector<void*> allocs_;
     std::string err_;
 };

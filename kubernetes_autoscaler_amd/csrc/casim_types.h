@@ -68,6 +68,9 @@ struct DevResults {
     // register packer: the gcd-scaled int32 requests in processing order (order_kernel copies them from req32)
     int32_t* s_req32;        // [nnz][R] or null
     const int32_t* req32;    // [G][R] source of s_req32 (FastScratch::req32)
+    // optional (casim_options.node_pods): pods per simulated node, group i at node_pods[node_pods_off[i] ..), node bound entries
+    int32_t* node_pods;
+    const int64_t* node_pods_off;
 };
 
 // kernel-internal flag bit (not part of the ABI): the template-level Filters pass for (PEG, group)

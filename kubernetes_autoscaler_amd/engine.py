@@ -30,13 +30,21 @@ class BatchResult:
     req_mem_sum: np.ndarray
     order: np.ndarray            # [nnz] PEG id processed k-th within its group
     placed: np.ndarray           # [nnz] pods of that PEG that were scheduled (a prefix)
+    node_pods: Optional[np.ndarray] = None          # pods per added node (Problem(..., node_pods=True)), compact
+    node_pods_offsets: Optional[np.ndarray] = None  # [NG+1]
+
+    def nodes_with_pods(self, i: int, template_name: str):
+        """newNodesWithPods of group i as the reference names them: '<template>-e-<j>' for every added node holding a pod
+        (binpacking_estimator.go:326-342, :58-61)."""
+        a, b = int(self.node_pods_offsets[i]), int(self.node_pods_offsets[i + 1])
+        return [f"{template_name}-e-{j}" for j, n in enumerate(self.node_pods[a:b]) if n > 0]
 
     def group(self, i: int):
         a, b = int(self.offsets[i]), int(self.offsets[i + 1])
         return self.order[a:b], self.placed[a:b]
 
 
-def alloc_results(n_groups: int, nnz: int):
+def alloc_results(n_groups: int, nnz: int, node_pods_capacity: int = 0):
     ng = max(n_groups, 1)
     arrs = dict(
         node_count=np.zeros(ng, np.int32), pods_scheduled=np.zeros(ng, np.int32), nodes_added=np.zeros(ng, np.int32),
@@ -49,11 +57,19 @@ def alloc_results(n_groups: int, nnz: int):
         last_index_out=_ptr(arrs["last_index_out"], C.c_int32), status=_ptr(arrs["status"], C.c_int32),
         req_cpu_sum=_ptr(arrs["req_cpu_sum"], C.c_int64), req_mem_sum=_ptr(arrs["req_mem_sum"], C.c_int64),
         order=_ptr(arrs["order"], C.c_int32), placed=_ptr(arrs["placed"], C.c_int32))
+    if node_pods_capacity > 0:
+        arrs["node_pods"] = np.zeros(node_pods_capacity, np.int32)
+        arrs["node_pods_offsets"] = np.zeros(ng + 1, np.int32)
+        st.node_pods = _ptr(arrs["node_pods"], C.c_int32); st.node_pods_offsets = _ptr(arrs["node_pods_offsets"], C.c_int32)
+        st.node_pods_capacity = node_pods_capacity
     return st, arrs
 
 
 def finish_results(arrs, n_groups: int, nnz: int, offsets: np.ndarray) -> BatchResult:
-    out = {k: (v[:nnz] if k in ("order", "placed") else v[:n_groups]) for k, v in arrs.items()}
+    out = {k: (v[:nnz] if k in ("order", "placed") else v[:n_groups]) for k, v in arrs.items() if not k.startswith("node_pods")}
+    if "node_pods" in arrs:
+        out["node_pods_offsets"] = arrs["node_pods_offsets"][:n_groups + 1]
+        out["node_pods"] = arrs["node_pods"][:int(arrs["node_pods_offsets"][n_groups])]
     return BatchResult(offsets=offsets, **out)
 
 
@@ -329,11 +345,18 @@ class MultiContext:
 class Problem:
     """casim_problem: a batch resident in HBM; run() enqueues feasibility -> order -> pack."""
 
-    def __init__(self, ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, fastpath: bool = False, force_generic_packer: bool = False):
+    def __init__(self, ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, fastpath: bool = False, force_generic_packer: bool = False,
+                 node_pods: bool = False):
         self.ctx = ctx
         self.n_groups = groups.n_groups
         self.n_pegs = pegs.n_pegs
-        opts = _abi.Options(fastpath=int(fastpath), force_generic_packer=int(force_generic_packer))
+        # room for the per-node pod counts: every group's limiter bound, or its pods when unlimited
+        self._node_pods_cap = 0
+        if node_pods:
+            total = int(sum(max(int(pegs.count[i]), 1) for i in range(pegs.n_pegs)))
+            self._node_pods_cap = int(sum((int(groups.max_nodes[i]) if groups.max_nodes[i] > 0 else (0 if groups.max_nodes[i] < 0 else total))
+                                          for i in range(groups.n_groups))) + 64
+        opts = _abi.Options(fastpath=int(fastpath), force_generic_packer=int(force_generic_packer), node_pods=int(bool(node_pods)))
         self._h = lib.casim_problem_create(ctx._h, C.byref(pegs), C.byref(groups), C.byref(opts))
         if not self._h:
             raise CasimError(_abi.ERR_INVALID, last_error())
@@ -373,7 +396,7 @@ class Problem:
 
     def fetch(self) -> BatchResult:
         nnz, off = self.csr()
-        st, arrs = alloc_results(self.n_groups, nnz)
+        st, arrs = alloc_results(self.n_groups, nnz, self._node_pods_cap)
         check(lib.casim_problem_fetch(self._h, C.byref(st)), "casim_problem_fetch")
         return finish_results(arrs, self.n_groups, nnz, off)
 

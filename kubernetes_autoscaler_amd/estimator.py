@@ -223,7 +223,7 @@ class BinpackingNodeEstimator:
             enc.add_group(node_template, max_nodes=self.limiter.device_max_nodes(), existing_nodes=len(self.snapshot.existing),
                           last_index=self.snapshot.last_index, pegs=ids)
             enc.finalize()
-            with Problem(self.engine_ctx, enc.pegs, enc.groups, self.fastpath) as prob:
+            with Problem(self.engine_ctx, enc.pegs, enc.groups, self.fastpath, node_pods=self.analyser is not None) as prob:
                 prob.run()
                 res = prob.fetch()
             if int(res.status[0]) != 0:
@@ -242,6 +242,10 @@ class BinpackingNodeEstimator:
                 pods.extend(pegs[int(pg_id)].pods[:int(n)])
             self.snapshot.last_index = int(res.last_index_out[0])   # the runner's lastIndex persists (plugin_runner.go:138)
             self.limiter.nodes = int(res.limiter_nodes[0])
+            if self.analyser is not None:
+                # estimationAnalyserFunc(clusterSnapshot, nodeGroup, newNodesWithPods)  binpacking_estimator.go:157-159: the names
+                # of the added nodes that received a pod, from the per-node pod counts the device kept
+                self.analyser(self.snapshot, node_group, {n: True for n in res.nodes_with_pods(0, node_template.node.name)})
             return int(res.node_count[0]), pods
         finally:
             self.limiter.end_estimation()

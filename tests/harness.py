@@ -434,7 +434,7 @@ def encode_batch(scenarios: Sequence[Scenario]):
     return enc, ts, bases
 
 
-def run_emu_tables(ts, kinds=None, per_sim=True, valid=None, fastpath=False, lds_budget=0):
+def run_emu_tables(ts, kinds=None, per_sim=True, valid=None, fastpath=False, lds_budget=0, node_pods_capacity=0, generic=False):
     """Product kernels under the wave emulator on a TableSet.  Returns (BatchResult, expander dict or None)."""
     L = emu_lib()
     if not hasattr(L, "_query_bound"):
@@ -450,8 +450,8 @@ def run_emu_tables(ts, kinds=None, per_sim=True, valid=None, fastpath=False, lds
         nnz_cap = int((ts.peg_hi - ts.peg_lo).sum())
     else:
         nnz_cap = pegs.n_pegs * ng
-    st, arrs = alloc_results(ng, nnz_cap)
-    opts = _abi.Options(fastpath=int(fastpath))
+    st, arrs = alloc_results(ng, nnz_cap, node_pods_capacity)
+    opts = _abi.Options(fastpath=int(fastpath), node_pods=int(node_pods_capacity > 0), force_generic_packer=int(generic))
     nnz = C.c_int32(0)
     off = np.zeros(ng + 1, np.int32)
     q = exp = None

@@ -163,3 +163,31 @@ def test_all_or_nothing_drops_partial_options_before_the_expander(ctx):
     twin = est.NodeGroup("small-b", 3, 1)
     wider = sim.prepare_scale_up([peg], [small], infos, est.ClusterSnapshotView(), similar_node_groups={"small": [twin]})
     assert alone.options[0].node_count == 2 and wider.options[0].node_count == 4
+
+
+def test_node_pods_and_the_analyser_hook(ctx):
+    """casim_results.node_pods on the device == the oracle's per-node counts; BinpackingNodeEstimator hands the analyser the
+    names of the added nodes that hold a pod (binpacking_estimator.go:157-159)."""
+    from kubernetes_autoscaler_amd import estimator as est
+    from kubernetes_autoscaler_amd.engine import Problem
+    from test_node_pods_emu import _oracle_node_pods
+    for seed in range(40):
+        w = workloads.fuzz(1000 + seed)
+        sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing)
+        enc = encode(sc)
+        for generic in (False, True):
+            with Problem(ctx, enc.pegs, enc.groups, False, generic, node_pods=True) as p:
+                p.run()
+                res = p.fetch()
+            for i, e in enumerate(_oracle_node_pods(sc)):
+                if int(res.status[i]) != 0:
+                    continue
+                a, b = int(res.node_pods_offsets[i]), int(res.node_pods_offsets[i + 1])
+                assert list(res.node_pods[a:b]) == list(e.node_pods), (seed, i, generic)
+        enc.close()
+    seen = {}
+    w = workloads.config_c0()
+    limiter = est.ThresholdBasedEstimationLimiter([est.StaticThreshold(10)])
+    e = est.BinpackingNodeEstimator(ctx, est.ClusterSnapshotView(), limiter, estimation_analyser_func=lambda snap, ng, nodes: seen.update(nodes))
+    n, pods = e.estimate(w.pegs, w.groups[0].template, est.NodeGroup("c0", 10, 0))
+    assert n == len(seen) > 0 and all(k.startswith("c0-template-e-") for k in seen)
