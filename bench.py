@@ -345,7 +345,7 @@ def main():
     ap.add_argument("--expander", default="least-nodes", choices=["least-nodes", "least-waste", "most-pods"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config C0..C4 wall-time table")
-    ap.add_argument("--no-dense", action="store_true")
+    ap.add_argument("--no-dense", action="store_true", help="(accepted for old scripts; the dense probe kernel was retired in round 2)")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the TrySchedulePods / node-removal side measurements")
     ap.add_argument("--no-c3", action="store_true")
     args = ap.parse_args()
@@ -499,8 +499,6 @@ def main():
             extra["read_stream_gbps"] = _try(lambda: {"4B_per_lane": ctx.stream_probe_gbps(1 << 30, 4, 5), "16B_per_lane": ctx.stream_probe_gbps(1 << 30, 16, 5)})
             if not args.no_configs:
                 extra["configs"] = config_rows(kaa, ctx, workloads, kinds)
-            if not args.no_dense:
-                extra["roofline_dense_check"] = _try(lambda: dense_probe(kaa, ctx, seed_set, TableSet))
             if not args.no_next_rows:
                 extra.update(_try(lambda: next_rows(kaa, ctx, workloads)) or {})
             if not args.no_c3:
@@ -566,22 +564,6 @@ def _try(f):
         return f()
     except Exception as e:  # side probes must never take the headline number down
         return {"error": f"{type(e).__name__}: {e}"}
-
-
-def dense_probe(kaa, ctx, seed_set, TableSet):
-    """Streaming form of the same predicates: dense per-pod x per-node check matrix (HBM-facing kernel)."""
-    ts = seed_set.tile(4)   # 4 x 64 C2 simulations' pods against (their groups x 16 nodes)
-    pegs, groups = ts.structs()
-    rep = 16
-    with kaa.Problem(ctx, pegs, groups) as pd:
-        ms, nr, nc = pd.time_dense(rep, iters=5)
-    R = ts.dims["n_res"]
-    bp = 8 * R + 4 + 4 + 8 * 4
-    bn = 8 * 2 * R + 8 + 8 * 4
-    dbytes = nr * (bp + 4) + (nc // rep) * bn + nr * ((nc + 63) // 64) * 8
-    return {"bound": "hbm", "kernel": "dense_check_kernel", "rows_pods": nr, "cols_nodes": nc, "checks_per_s": nr * nc / (ms * 1e-3),
-            "achieved": dbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": dbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "kernel_ms": ms, "algorithmic_bytes_per_launch": dbytes}
 
 
 def next_rows(kaa, ctx, workloads):

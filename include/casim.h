@@ -297,17 +297,6 @@ int32_t casim_feasibility_reasons(casim_ctx* ctx, const casim_pegs* pegs, const 
                                   const uint64_t* port_block, uint16_t* out_codes);
 
 /*
- * Dense per-pod x per-node predicate matrix on resident data (the streaming form of the
- * same kernel; rows = PEG records expanded by `count`, columns = groups expanded by
- * `repeat` nodes).  Used for roofline measurement and as the device-side building block of
- * filter-out-schedulable.  out_bits may be NULL (result left in HBM).
- * Layout: [ceil(n_cols/64)][n_rows] uint64 (column-block major so that the wave's stores
- * coalesce).  Asynchronous unless out_bits != NULL.
- */
-int32_t casim_problem_dense_check(casim_problem* p, int32_t col_repeat, uint64_t* out_bits,
-                                  int64_t* n_rows_out, int64_t* n_cols_out);
-
-/*
  * Expander reduce on the device results of the last run: applies the filter chain `kinds`
  * (each CASIM_EXPANDER_*) in order to the options with node_count > 0 and pods_scheduled > 0
  * (orchestrator.go:1057-1063), as chainStrategy.BestOption does (factory/chain.go:36-45).
@@ -548,9 +537,6 @@ int32_t casim_estimate_on_cluster(casim_ctx* ctx, const casim_pegs* classes, con
  * named kernel classes.  kernel_ms_out: [0]=feasibility+csr [1]=order [2]=pack (may be NULL). */
 int32_t casim_problem_time(casim_problem* p, int32_t iters, float* total_ms_out,
                            float* kernel_ms_out);
-/* Same for the dense check kernel alone. */
-int32_t casim_problem_time_dense(casim_problem* p, int32_t col_repeat, int32_t iters,
-                                 float* ms_out, int64_t* n_rows_out, int64_t* n_cols_out);
 /* Device-to-device copy bandwidth probe (GB/s) used as the "achievable HBM" reference. */
 int32_t casim_copy_bandwidth(casim_ctx* ctx, int64_t bytes, int32_t iters, double* gbps_out);
 

@@ -143,7 +143,6 @@ PROTOTYPES = {
     "casim_estimate_batch": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(Options), C.POINTER(Results)]),
     "casim_feasibility": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), u64p]),
     "casim_feasibility_reasons": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), u64p, C.POINTER(C.c_uint16)]),
-    "casim_problem_dense_check": (C.c_int32, [C.c_void_p, C.c_int32, u64p, i64p, i64p]),
     "casim_best_option": (C.c_int32, [C.c_void_p, i32p, C.c_int32, C.c_int32, i32p, i32p, u8p, i64p, C.c_void_p]),
     "casim_best_option_sims": (C.c_int32, [C.c_void_p, C.POINTER(OptionQuery)]),
     "casim_estimate_batch_timed": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(Options), C.POINTER(Results),
@@ -154,7 +153,6 @@ PROTOTYPES = {
     "casim_estimate_batch_multi": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(Options), C.POINTER(Results), i32p,
                                                C.POINTER(OptionQuery)]),
     "casim_problem_time": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
-    "casim_problem_time_dense": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float), i64p, i64p]),
     "casim_try_schedule_pods": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(PodSequence), i32p, i32p, i32p]),
     "casim_time_try_schedule_pods": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(PodSequence), C.c_int32,
                                                  C.POINTER(C.c_float)]),

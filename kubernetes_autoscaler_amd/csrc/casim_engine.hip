@@ -158,87 +158,9 @@ struct casim_mctx {
 struct casim_problem {
     casim_ctx* ctx;
     HipProblem* prob;
-    // dense-check scratch
-    uint64_t* d_dense = nullptr; size_t dense_bytes = 0;
-    int32_t* d_row_peg = nullptr; int64_t dense_rows = 0;
 };
 
-// ------------------------------------------------------------------------------------------
-// dense per-pod x per-node predicate kernel (streaming form of fits(); roofline probe and
-// building block of filter-out-schedulable)
-// ------------------------------------------------------------------------------------------
 namespace casim {
-
-// Column record staged in LDS: everything a column (= one simulated / existing node) contributes.
-struct DenseCol {
-    int64_t freepos[CASIM_KMAX_RES];  // max(free, 0): req <= freepos <=> (req == 0 || req <= free)   (fit.go:699-752)
-    uint64_t taint, label, excl, zone; // first word of each mask (dense probe supports W <= 1 per kind)
-    uint32_t flags;                    // bit0 unschedulable, bit1 no pod slot left
-    uint32_t pad;
-};
-
-// grid = (ceil(P/256), ceil(ncols/64/kColBlocksPerWG)); block = 256 threads = 256 rows (pods).
-// Each thread keeps its pod record in registers, walks 64 columns from LDS (broadcast reads) and
-// emits one uint64; the wave's 64 stores are contiguous (layout [col_block][row]).
-constexpr int kDenseColBlocks = 8;
-template <int RD>  // resource lanes actually compared (2, 4 or 8): the inner loop is RD 64-bit compares per column
-__global__ __launch_bounds__(256) void dense_check_kernel(DevTables t, const int32_t* __restrict__ row_peg, int64_t n_rows,
-                                                          int col_repeat, int64_t n_cols, uint64_t* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    DenseCol* cols = (DenseCol*)smem_raw;  // [64]
-    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool live = row < n_rows;
-    const int g = live ? row_peg[row] : 0;
-    int64_t req[RD];
-#pragma unroll
-    for (int r = 0; r < RD; ++r) req[r] = (live && r < t.R) ? t.req[(int64_t)g * t.R + r] : 0;
-    const uint64_t tol = t.Wt ? t.tol[(int64_t)g * t.Wt] : 0ull, sel = t.Wl ? t.sel[(int64_t)g * t.Wl] : 0ull;
-    const uint64_t xb = t.Wx ? t.xblock[(int64_t)g * t.Wx] : 0ull, zb = t.Wz ? t.zblock[(int64_t)g * t.Wz] : 0ull;
-    const uint32_t pf = live ? t.pflags[g] : 0u;   // (PEGs outside the encoded subset: judged on the encoded part, like fits_fresh_node)
-    const int64_t n_cb = (n_cols + 63) / 64;
-    for (int cbi = 0; cbi < kDenseColBlocks; ++cbi) {
-        const int64_t cb = (int64_t)blockIdx.y * kDenseColBlocks + cbi;
-        if (cb >= n_cb) break;
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            const int64_t col = cb * 64 + threadIdx.x;
-            DenseCol c; memset(&c, 0, sizeof c);
-            if (col < n_cols) {
-                const int ng = (int)(col / col_repeat);
-                for (int r = 0; r < CASIM_KMAX_RES; ++r) {
-                    const int64_t f = r < t.R ? t.alloc[(int64_t)ng * t.R + r] - t.init_req[(int64_t)ng * t.R + r] : 0;
-                    c.freepos[r] = f > 0 ? f : 0;
-                }
-                c.taint = t.Wt ? t.taint[(int64_t)ng * t.Wt] : 0ull; c.label = t.Wl ? t.label[(int64_t)ng * t.Wl] : 0ull;
-                c.excl = t.Wx ? t.init_excl[(int64_t)ng * t.Wx] : 0ull; c.zone = t.Wz ? t.init_zone[(int64_t)ng * t.Wz] : 0ull;
-                c.flags = ((t.gflags[ng] & CASIM_NG_UNSCHEDULABLE) ? 1u : 0u) | ((t.allowed[ng] - t.init_pods[ng] < 1) ? 2u : 0u);
-            } else c.flags = 2u;
-            cols[threadIdx.x] = c;
-        }
-        __syncthreads();
-        uint64_t bits = 0;
-        if (live) {
-#pragma unroll 4
-            for (int j = 0; j < 64; ++j) {
-                const DenseCol& c = cols[j];
-                bool ok = !(c.flags & 2u) && (!(c.flags & 1u) || (pf & CASIM_PEG_TOLERATES_UNSCHEDULABLE));
-                ok = ok && !(c.taint & ~tol) && !(sel & ~c.label) && !(xb & c.excl) && !(zb & c.zone);
-#pragma unroll
-                for (int r = 0; r < RD; ++r) ok = ok && (req[r] <= c.freepos[r]);
-                bits |= (uint64_t)ok << j;
-            }
-        }
-        if (live) out[cb * n_rows + row] = bits;
-    }
-}
-
-__global__ void expand_rows_kernel(const int32_t* __restrict__ count, int G, const int64_t* __restrict__ row_off, int32_t* __restrict__ row_peg) {
-    // one block per PEG writes its run of row -> PEG ids
-    const int g = blockIdx.x;
-    if (g >= G) return;
-    const int64_t a = row_off[g], n = count[g];
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) row_peg[a + i] = g;
-}
 
 __global__ void copy_probe_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -324,8 +246,6 @@ void casim_problem_destroy(casim_problem* p) {
     if (!p) return;
     p->ctx->bk.bind();
     (void)hipStreamSynchronize(p->ctx->bk.stream);
-    if (p->d_dense) (void)hipFree(p->d_dense);
-    if (p->d_row_peg) (void)hipFree(p->d_row_peg);
     delete p->prob;
     delete p;
 }
@@ -530,78 +450,6 @@ int32_t casim_problem_time(casim_problem* p, int32_t iters, float* total_ms_out,
     // mark as run so that fetch works after a timing loop
     const int32_t rc = p->prob->run();
     PROB_RET(p, rc != CASIM_OK ? rc : (bk.ok() ? CASIM_OK : CASIM_ERR_HIP));
-}
-
-static int32_t dense_prepare(casim_problem* p, int32_t col_repeat, int64_t* n_rows, int64_t* n_cols) {
-    HipBackend& bk = p->ctx->bk;
-    const DevTables& t = p->prob->tables();
-    if (col_repeat <= 0) return CASIM_ERR_INVALID;
-    if (t.Wt > 1 || t.Wl > 1 || t.Wx > 1 || t.Wz > 1) return CASIM_ERR_INVALID;  // dense probe: one word per mask kind
-    if (!p->d_row_peg) {
-        std::vector<int32_t> cnt((size_t)t.G);
-        bk.d2h(cnt.data(), t.count, 4 * (size_t)t.G); bk.sync();
-        std::vector<int64_t> off((size_t)t.G + 1, 0);
-        for (int i = 0; i < t.G; ++i) off[(size_t)i + 1] = off[(size_t)i] + cnt[(size_t)i];
-        p->dense_rows = off[(size_t)t.G];
-        int64_t* d_off = (int64_t*)bk.alloc(8 * ((size_t)t.G + 1));
-        bk.h2d(d_off, off.data(), 8 * ((size_t)t.G + 1));
-        p->d_row_peg = (int32_t*)bk.alloc(4 * (size_t)(p->dense_rows > 0 ? p->dense_rows : 1));
-        if (t.G > 0) bk.launch(casim::expand_rows_kernel, t.G, 1, 256, (size_t)0, t.count, t.G, (const int64_t*)d_off, p->d_row_peg);
-        bk.sync();
-        bk.free(d_off);
-    }
-    *n_rows = p->dense_rows;
-    *n_cols = (int64_t)t.NG * col_repeat;
-    const size_t need = (size_t)((*n_cols + 63) / 64) * (size_t)(*n_rows) * 8;
-    if (need > p->dense_bytes) {
-        if (p->d_dense) bk.free(p->d_dense);
-        p->d_dense = (uint64_t*)bk.alloc(need > 0 ? need : 8);
-        p->dense_bytes = need;
-    }
-    return bk.ok() ? CASIM_OK : CASIM_ERR_HIP;
-}
-static void dense_launch(casim_problem* p, int32_t col_repeat, int64_t n_rows, int64_t n_cols) {
-    HipBackend& bk = p->ctx->bk;
-    const int64_t n_cb = (n_cols + 63) / 64;
-    if (n_rows <= 0 || n_cb <= 0) return;
-    const int gx = (int)((n_rows + 255) / 256), gy = (int)((n_cb + casim::kDenseColBlocks - 1) / casim::kDenseColBlocks);
-    const DevTables& t = p->prob->tables();
-    if (t.R <= 2) bk.launch(casim::dense_check_kernel<2>, gx, gy, 256, sizeof(casim::DenseCol) * 64, t, (const int32_t*)p->d_row_peg, n_rows, (int)col_repeat, n_cols, p->d_dense);
-    else if (t.R <= 4) bk.launch(casim::dense_check_kernel<4>, gx, gy, 256, sizeof(casim::DenseCol) * 64, t, (const int32_t*)p->d_row_peg, n_rows, (int)col_repeat, n_cols, p->d_dense);
-    else bk.launch(casim::dense_check_kernel<8>, gx, gy, 256, sizeof(casim::DenseCol) * 64, t, (const int32_t*)p->d_row_peg, n_rows, (int)col_repeat, n_cols, p->d_dense);
-}
-
-int32_t casim_problem_dense_check(casim_problem* p, int32_t col_repeat, uint64_t* out_bits, int64_t* n_rows_out, int64_t* n_cols_out) {
-    PROB_ENTER(p);
-    int64_t nr = 0, nc = 0;
-    int32_t rc = dense_prepare(p, col_repeat, &nr, &nc);
-    if (rc != CASIM_OK) return set_err(rc, p->ctx->bk.ok() ? "dense check: unsupported table shape (mask wider than one word?)" : p->ctx->bk.msg);
-    dense_launch(p, col_repeat, nr, nc);
-    if (n_rows_out) *n_rows_out = nr;
-    if (n_cols_out) *n_cols_out = nc;
-    if (out_bits) { p->ctx->bk.d2h(out_bits, p->d_dense, (size_t)((nc + 63) / 64) * (size_t)nr * 8); p->ctx->bk.sync(); }
-    return p->ctx->bk.ok() ? CASIM_OK : set_err(CASIM_ERR_HIP, p->ctx->bk.msg);
-}
-int32_t casim_problem_time_dense(casim_problem* p, int32_t col_repeat, int32_t iters, float* ms_out, int64_t* n_rows_out, int64_t* n_cols_out) {
-    PROB_ENTER(p);
-    if (iters <= 0) return set_err(CASIM_ERR_INVALID, "iters must be > 0");
-    int64_t nr = 0, nc = 0;
-    int32_t rc = dense_prepare(p, col_repeat, &nr, &nc);
-    if (rc != CASIM_OK) return set_err(rc, "dense check: unsupported table shape");
-    HipBackend& bk = p->ctx->bk;
-    hipEvent_t a, b;
-    bk.check(hipEventCreate(&a), "hipEventCreate"); bk.check(hipEventCreate(&b), "hipEventCreate");
-    dense_launch(p, col_repeat, nr, nc);  // warm-up
-    bk.check(hipEventRecord(a, bk.stream), "hipEventRecord");
-    for (int i = 0; i < iters; ++i) dense_launch(p, col_repeat, nr, nc);
-    bk.check(hipEventRecord(b, bk.stream), "hipEventRecord");
-    bk.check(hipEventSynchronize(b), "hipEventSynchronize");
-    float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-    if (ms_out) *ms_out = ms / iters;
-    if (n_rows_out) *n_rows_out = nr;
-    if (n_cols_out) *n_cols_out = nc;
-    return bk.ok() ? CASIM_OK : set_err(CASIM_ERR_HIP, bk.msg);
 }
 
 // ---- filter-out-schedulable ---------------------------------------------------

@@ -451,23 +451,6 @@ class Problem:
         check(lib.casim_problem_time(self._h, int(iters), C.byref(tot), ks), "casim_problem_time")
         return float(tot.value), {"feasibility_csr_ms": ks[0], "order_ms": ks[1], "pack_ms": ks[2]}
 
-    def dense_check(self, col_repeat: int, fetch: bool = True):
-        nr, nc = C.c_int64(0), C.c_int64(0)
-        if not fetch:
-            check(lib.casim_problem_dense_check(self._h, int(col_repeat), None, C.byref(nr), C.byref(nc)), "dense_check")
-            return None, int(nr.value), int(nc.value)
-        # two calls: first learns the shape (asynchronous launch), second copies
-        check(lib.casim_problem_dense_check(self._h, int(col_repeat), None, C.byref(nr), C.byref(nc)), "dense_check")
-        bits = np.zeros(((nc.value + 63) // 64, max(nr.value, 1)), np.uint64)
-        check(lib.casim_problem_dense_check(self._h, int(col_repeat), _ptr(bits, C.c_uint64), C.byref(nr), C.byref(nc)), "dense_check")
-        return bits[:, :nr.value], int(nr.value), int(nc.value)
-
-    def time_dense(self, col_repeat: int, iters: int = 10):
-        ms = C.c_float(0)
-        nr, nc = C.c_int64(0), C.c_int64(0)
-        check(lib.casim_problem_time_dense(self._h, int(col_repeat), int(iters), C.byref(ms), C.byref(nr), C.byref(nc)), "time_dense")
-        return float(ms.value), int(nr.value), int(nc.value)
-
 
 def estimate_batch_timed(ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, kinds: Optional[Sequence[int]] = None, fastpath: bool = False,
                          nnz_cap: Optional[int] = None):

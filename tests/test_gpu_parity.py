@@ -202,30 +202,6 @@ def test_prepare_scale_up_with_spread_constraints(ctx):
     assert plan.best is not None and plan.best.node_count == min(v[0] for v in got.values())
 
 
-def test_dense_check_matches_feasibility(ctx):
-    """dense per-pod x per-node bit-matrix == fits(peg, fresh node) expanded by pod count and node repeat."""
-    w = workloads.config_c2(n_groups=7, n_pegs=50, pods_per_peg=3, cap=5)
-    sc = scenario_of(w, device_csr=True)
-    enc = encode(sc)
-    feas = ctx.feasibility(enc.pegs, enc.groups)           # [NG][ceil(G/64)]
-    rep = 3
-    with kaa.Problem(ctx, enc.pegs, enc.groups) as p:
-        bits, nr, nc = p.dense_check(rep)
-    assert (nr, nc) == (w.n_pods, len(w.groups) * rep)
-    row = 0
-    for g, pg in enumerate(w.pegs):
-        for _ in pg.pods:
-            for col in range(nc):
-                want = (int(feas[col // rep, g // 64]) >> (g % 64)) & 1
-                got = (int(bits[col // 64, row]) >> (col % 64)) & 1
-                assert got == want, (g, col)
-            row += 1
-
-
-# ---- edge cases of the boundary on the GPU ------------------------------------------------------------
-from test_edge_cases_emu import CASES as EDGE_CASES  # noqa: E402
-
-
 @pytest.mark.parametrize("name,sc", EDGE_CASES, ids=[c[0] for c in EDGE_CASES])
 def test_edge_case(ctx, name, sc):
     res, _ = run_gpu(encode(sc), ctx)
