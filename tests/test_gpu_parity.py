@@ -202,6 +202,10 @@ def test_prepare_scale_up_with_spread_constraints(ctx):
     assert plan.best is not None and plan.best.node_count == min(v[0] for v in got.values())
 
 
+# ---- edge cases of the boundary on the GPU ------------------------------------------------------------
+from test_edge_cases_emu import CASES as EDGE_CASES  # noqa: E402
+
+
 @pytest.mark.parametrize("name,sc", EDGE_CASES, ids=[c[0] for c in EDGE_CASES])
 def test_edge_case(ctx, name, sc):
     res, _ = run_gpu(encode(sc), ctx)
