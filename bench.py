@@ -574,9 +574,21 @@ def next_rows(kaa, ctx, workloads):
     e1, pc1 = encode_pending_pods(w1.nodes, w1.pods)
     _, _, _, ns1 = ctx.try_schedule_pods(e1.pegs, e1.groups, pc1)
     _, ms1 = ctx.try_schedule_pods(e1.pegs, e1.groups, pc1, time_iters=5)
-    e1.close()
+    # the same call enter -> return: every table uploaded by the call vs the node table resident (casim_cluster_*)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ctx.try_schedule_pods(e1.pegs, e1.groups, pc1)
+    call_ms = (time.perf_counter() - t0) / 5 * 1e3
+    with kaa.ResidentCluster(ctx, e1.pegs, e1.groups) as cl:
+        cl.try_schedule_pods(pc1, commit=False)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            cl.try_schedule_pods(pc1, commit=False)
+        resident_ms = (time.perf_counter() - t0) / 5 * 1e3
     out["try_schedule_pods"] = {"workload": w1.name, "nodes": len(w1.nodes), "pending_pods": len(w1.pods), "scheduled": int(ns1),
-                                "kernels_ms": ms1, "pods_per_s": len(w1.pods) / (ms1 * 1e-3)}
+                                "kernels_ms": ms1, "pods_per_s": len(w1.pods) / (ms1 * 1e-3), "call_ms_tables_uploaded": call_ms,
+                                "call_ms_resident_cluster": resident_ms}
+    e1.close()
     w2 = workloads.removal_scale(5000, pods_per_node=12, frac_candidates=0.3, seed=1)
     e2 = kaa.Encoder(explicit_self_exclusion=True)
     cls, pcl, off = {}, [], [0]

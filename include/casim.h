@@ -504,6 +504,29 @@ int32_t casim_time_node_removals(casim_ctx* ctx, const casim_pegs* classes, cons
                                  const casim_removal_candidates* cand, int32_t iters, float* ms_out);
 
 /*
+ * Resident cluster (second half): the snapshot's node table stays in HBM for a whole RunOnce iteration.
+ * The reference threads ONE ClusterSnapshot through the iteration — filter-out-schedulable adds the pods it places
+ * (SchedulePod), the scale-down planner simulates removals inside Fork / Revert (CA/simulator/clustersnapshot/store/
+ * delta.go:292-323,442-463, planner.go:286-336).  casim_cluster_create uploads the class table (every pod spec the
+ * iteration will meet: pending pods AND the pods of removal candidates, one encoder session) and the node table once;
+ *   casim_cluster_try_schedule_pods(..., commit)   forks from the committed image; commit != 0 folds the placements into it
+ *                                                  (requested += request, pod count, host-port / anti-affinity bits), 0 = Revert;
+ *   casim_cluster_simulate_node_removals           runs on the committed image and never persists (the planner's own Fork / Revert);
+ *   casim_cluster_update_nodes                     replaces the records of single nodes between calls (a delta: only those rows travel).
+ * Same results as the non-resident entry points on the equivalent tables; status conventions as there.
+ * casim_cluster_stats: out[0] full uploads (1), [1] node rows replaced by deltas, [2] commits, [3] nodes.
+ */
+typedef struct casim_cluster casim_cluster;
+casim_cluster* casim_cluster_create(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes);
+void casim_cluster_destroy(casim_cluster* c);
+int32_t casim_cluster_update_nodes(casim_cluster* c, int32_t n, const int32_t* node_index, const casim_groups* rows);
+int32_t casim_cluster_try_schedule_pods(casim_cluster* c, const casim_pod_sequence* seq, int32_t commit, int32_t* node_out,
+                                        int32_t* last_index_out, int32_t* n_scheduled_out);
+int32_t casim_cluster_simulate_node_removals(casim_cluster* c, const casim_removal_candidates* cand, casim_removal_results* out);
+int32_t casim_cluster_fetch_nodes(casim_cluster* c, int64_t* init_req_out, int32_t* init_pods_out, uint64_t* init_excl_out);
+int32_t casim_cluster_stats(const casim_cluster* c, int64_t out[4]);
+
+/*
  * BinpackingNodeEstimator.Estimate on the whole snapshot (CA/estimator/binpacking_estimator.go:102-342):
  * the path for node groups whose PEGs carry domain rules (PodTopologySpread, anti-affinity on non-hostname keys), which
  * the template-mode batch (casim_estimate_batch) flags CASIM_NG_UNSUPPORTED.  `nodes` = the n_existing nodes of the

@@ -152,6 +152,13 @@ PROTOTYPES = {
     "casim_mctx_info": (C.c_int32, [C.c_void_p, i32p, i32p, i32p, i32p]),
     "casim_estimate_batch_multi": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(Options), C.POINTER(Results), i32p,
                                                C.POINTER(OptionQuery)]),
+    "casim_cluster_create": (C.c_void_p, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups)]),
+    "casim_cluster_destroy": (None, [C.c_void_p]),
+    "casim_cluster_update_nodes": (C.c_int32, [C.c_void_p, C.c_int32, i32p, C.POINTER(Groups)]),
+    "casim_cluster_try_schedule_pods": (C.c_int32, [C.c_void_p, C.POINTER(PodSequence), C.c_int32, i32p, i32p, i32p]),
+    "casim_cluster_simulate_node_removals": (C.c_int32, [C.c_void_p, C.POINTER(RemovalCandidates), C.POINTER(RemovalResults)]),
+    "casim_cluster_fetch_nodes": (C.c_int32, [C.c_void_p, i64p, i32p, u64p]),
+    "casim_cluster_stats": (C.c_int32, [C.c_void_p, i64p]),
     "casim_problem_time": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "casim_try_schedule_pods": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(PodSequence), i32p, i32p, i32p]),
     "casim_time_try_schedule_pods": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(PodSequence), C.c_int32,

@@ -33,6 +33,8 @@ CS_DEVICE void sync() { casim_emu::block_sync(); }
 CS_DEVICE void sched_fence() {}
 CS_DEVICE int32_t load_relaxed_i32(const int32_t* p) { return *p; }
 CS_DEVICE void atomic_add_i32(int32_t* p, int32_t v) { *p += v; }  // fibers of one block never run concurrently
+CS_DEVICE void atomic_add_i64(int64_t* p, int64_t v) { *p += v; }
+CS_DEVICE void atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
 CS_DEVICE void lds_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
 CS_DEVICE uint64_t ballot(bool p) { return casim_emu::wave_ballot(p); }
 CS_DEVICE uint64_t readlane_u64(uint64_t v, int l) { return casim_emu::wave_xchg_u64(v, l); }
@@ -75,6 +77,8 @@ CS_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // device-scope relaxed load / add of a counter shared by the waves of a block (served by L2, never a stale L1 line)
 CS_DEVICE int32_t load_relaxed_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 CS_DEVICE void atomic_add_i32(int32_t* p, int32_t v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+CS_DEVICE void atomic_add_i64(int64_t* p, int64_t v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+CS_DEVICE void atomic_or_u64(uint64_t* p, uint64_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // bits set by several threads of the block in one LDS word (ds_or_b64)
 CS_DEVICE void lds_or_u64(uint64_t* p, uint64_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 CS_DEVICE uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }  // the lane mask itself (__ballot goes through an int: two more VALU ops per call)

@@ -155,6 +155,11 @@ struct casim_mctx {
     std::vector<int32_t> last_groups;
 };
 
+struct casim_cluster {
+    casim_ctx* ctx;
+    casim::ClusterT<HipBackend>* c;
+};
+
 struct casim_problem {
     casim_ctx* ctx;
     HipProblem* prob;
@@ -478,6 +483,56 @@ int32_t casim_estimate_on_cluster(casim_ctx* ctx, const casim_pegs* classes, con
     if (rc == CASIM_OK) rc = s.fetch(out);
     if (rc < 0) set_err(rc, s.error());
     return rc;
+}
+
+// ---- resident cluster (second half) ------------------------------------------------------
+casim_cluster* casim_cluster_create(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes) {
+    g_err.clear();
+    if (!ctx) { set_err(CASIM_ERR_INVALID, "null context"); return nullptr; }
+    ctx->bk.bind(); ctx->bk.clear();
+    casim_cluster* h = new (std::nothrow) casim_cluster();
+    if (!h) { set_err(CASIM_ERR_NOMEM, "out of memory"); return nullptr; }
+    h->ctx = ctx; h->c = new (std::nothrow) casim::ClusterT<HipBackend>(ctx->bk);
+    if (!h->c) { delete h; set_err(CASIM_ERR_NOMEM, "out of memory"); return nullptr; }
+    const int32_t rc = h->c->init(classes, nodes);
+    if (rc != CASIM_OK) { set_err(rc, h->c->error()); delete h->c; delete h; return nullptr; }
+    return h;
+}
+void casim_cluster_destroy(casim_cluster* h) {
+    if (!h) return;
+    h->ctx->bk.bind(); (void)hipStreamSynchronize(h->ctx->bk.stream);
+    delete h->c; delete h;
+}
+#define CLUSTER_ENTER(h) g_err.clear(); if (!(h) || !(h)->c) return set_err(CASIM_ERR_INVALID, "null cluster"); (h)->ctx->bk.bind(); (h)->ctx->bk.clear()
+int32_t casim_cluster_update_nodes(casim_cluster* h, int32_t n, const int32_t* node_index, const casim_groups* rows) {
+    CLUSTER_ENTER(h);
+    const int32_t rc = h->c->update_nodes(n, node_index, rows);
+    if (rc < 0) set_err(rc, h->c->error());
+    return rc;
+}
+int32_t casim_cluster_try_schedule_pods(casim_cluster* h, const casim_pod_sequence* seq, int32_t commit, int32_t* node_out, int32_t* last_index_out,
+                                        int32_t* n_scheduled_out) {
+    CLUSTER_ENTER(h);
+    const int32_t rc = h->c->try_schedule(seq, commit, node_out, last_index_out, n_scheduled_out);
+    if (rc < 0) set_err(rc, h->c->error());
+    return rc;
+}
+int32_t casim_cluster_simulate_node_removals(casim_cluster* h, const casim_removal_candidates* cand, casim_removal_results* out) {
+    CLUSTER_ENTER(h);
+    const int32_t rc = h->c->simulate_removals(cand, out);
+    if (rc < 0) set_err(rc, h->c->error());
+    return rc;
+}
+int32_t casim_cluster_fetch_nodes(casim_cluster* h, int64_t* init_req_out, int32_t* init_pods_out, uint64_t* init_excl_out) {
+    CLUSTER_ENTER(h);
+    const int32_t rc = h->c->fetch_nodes(init_req_out, init_pods_out, init_excl_out);
+    if (rc < 0) set_err(rc, h->c->error());
+    return rc;
+}
+int32_t casim_cluster_stats(const casim_cluster* h, int64_t out[4]) {
+    if (!h || !h->c || !out) return CASIM_ERR_INVALID;
+    h->c->stats(out);
+    return CASIM_OK;
 }
 
 // ---- scale-down removal simulation ----------------------------------------------

@@ -778,6 +778,12 @@ public:
         memset(&dt_, 0, sizeof dt_); memset(&a_, 0, sizeof a_);
         dt_.G = C_; dt_.NG = N_; dt_.R = p->n_res; dt_.Wt = p->w_taint; dt_.Wl = p->w_label; dt_.Wx = p->w_excl; dt_.Wz = 0;
         const int R = dt_.R;
+        if (resident_) {   // a resident cluster (ClusterT below): the tables are in HBM already, nothing to upload
+            dt_.req = resident_->req; dt_.pflags = resident_->pflags; dt_.tol = resident_->tol; dt_.sel = resident_->sel;
+            dt_.xblock = resident_->xblock; dt_.xmark = resident_->xmark; dt_.alloc = resident_->alloc; dt_.init_req = resident_->init_req;
+            dt_.allowed = resident_->allowed; dt_.init_pods = resident_->init_pods; dt_.gflags = resident_->gflags;
+            dt_.taint = resident_->taint; dt_.label = resident_->label; dt_.init_excl = resident_->init_excl;
+        } else {
         dt_.req = up(p->req, C * R); dt_.pflags = up(p->flags, C);
         dt_.tol = up(p->tol_mask, C * dt_.Wt); dt_.sel = up(p->sel_mask, C * dt_.Wl);
         dt_.xblock = up(p->excl_block, C * dt_.Wx); dt_.xmark = up(p->excl_mark, C * dt_.Wx);
@@ -785,6 +791,7 @@ public:
         dt_.allowed = up(g->allowed_pods, N); dt_.init_pods = up(g->init_pods, N); dt_.gflags = up(g->flags, N);
         dt_.taint = up(g->taint_mask, N * dt_.Wt); dt_.label = up(g->label_mask, N * dt_.Wl);
         dt_.init_excl = up(g->init_excl, N * dt_.Wx);
+        }
 
         // one workgroup: 64..1024 threads, node m -> thread m % T, chunk m / T
         // (r01w sweep: TrySchedulePods on 5000+ nodes is ~7 % faster with 512 threads — 2.31 vs 2.48 ms, 8.9 vs 9.5 ms —, the
@@ -945,6 +952,8 @@ public:
     }
 
     const std::string& error() const { return err_; }
+    void use_resident(const DevTables* t) { resident_ = t; }
+    const int32_t* node_out_dev() const { return trivial_ ? nullptr : a_.node_out; }
     int runs() const { return n_runs_; }
     int threads() const { return threads_; }
     bool in_lds() const { return lds_; }
@@ -976,6 +985,7 @@ private:
 
     BK& bk_;
     DevTables dt_; SchedArgs a_;
+    const DevTables* resident_ = nullptr;
     int C_ = 0, N_ = 0, P_ = 0, S_ = 0, K_ = 0, E_ = 0, threads_ = 64;
     int32_t cap_ = 0, n_runs_ = 0, last_index_ = 0;
     bool ready_ = false, trivial_ = false, lds_ = true;
@@ -986,6 +996,175 @@ private:
     size_t n_pairs_ = 0, n_ctrl_ = 0;
     std::vector<void*> allocs_;
     std::string err_;
+};
+
+
+// ---- resident cluster: the snapshot's node table stays in HBM for a whole RunOnce iteration ----------------------------
+// The reference forks / commits / reverts ONE ClusterSnapshot through a loop iteration (CA/core/static_autoscaler.go:391 ff):
+// filter-out-schedulable adds the pods it placed to the snapshot (filter_out_schedulable.go:94-103 via SchedulePod), the
+// scale-down planner then simulates removals on that state inside Fork / Revert (planner.go:286-336,
+// CA/simulator/clustersnapshot/store/delta.go:292-323,442-463).  Here the node table (one record per node: allocatable,
+// what its pods request, pod count, node-local exclusion bits, taint / label bits) is uploaded ONCE; every call forks from
+// that committed image — the kernels build their working state from it at the start of every pass, so a Revert costs
+// nothing —, and a Commit folds the call's placements into the image with one scatter kernel (commit_placements_kernel).
+// Node-level deltas between calls (a node's pods changed, a node joined) replace single records (scatter_rows_kernel).
+CS_GLOBAL void commit_placements_kernel(DevTables t, const int32_t* CS_RESTRICT node_out, const int32_t* CS_RESTRICT pod_class, int P) {
+    const int i = cs::bid() * cs::nthreads() + cs::tid();
+    if (i >= P) return;
+    const int m = node_out[i];
+    if (m < 0) return;
+    const int c = pod_class[i];
+    for (int r = 0; r < t.R; ++r) {
+        const int64_t q = t.req[(int64_t)c * t.R + r];
+        if (q) cs::atomic_add_i64((int64_t*)t.init_req + (int64_t)m * t.R + r, q);      // NodeInfo.AddPodInfo: requested += request (types.go:439-463)
+    }
+    cs::atomic_add_i32((int32_t*)t.init_pods + m, 1);
+    for (int w = 0; w < t.Wx; ++w) {
+        const uint64_t b = t.xmark[(int64_t)c * t.Wx + w];
+        if (b) cs::atomic_or_u64((uint64_t*)t.init_excl + (int64_t)m * t.Wx + w, b);    // used host ports / anti-affinity occupancy
+    }
+}
+// dst[idx[k]][0..width) = src[k][0..width) for one column (element size 4 or 8 bytes, as 4-byte words)
+CS_GLOBAL void scatter_rows_kernel(uint32_t* CS_RESTRICT dst, const uint32_t* CS_RESTRICT src, const int32_t* CS_RESTRICT idx, int n, int words_per_row) {
+    const int64_t i = (int64_t)cs::bid() * cs::nthreads() + cs::tid();
+    if (i >= (int64_t)n * words_per_row) return;
+    const int k = (int)(i / words_per_row), w = (int)(i % words_per_row);
+    dst[(int64_t)idx[k] * words_per_row + w] = src[i];
+}
+
+template <class BK>
+class ClusterT {
+public:
+    explicit ClusterT(BK& bk) : bk_(bk) {}
+    ~ClusterT() { for (void* p : allocs_) bk_.free(p); }
+    ClusterT(const ClusterT&) = delete;
+    ClusterT& operator=(const ClusterT&) = delete;
+
+    int32_t init(const casim_pegs* p, const casim_groups* g) {
+        if (!p || !g) return fail(CASIM_ERR_INVALID, "null table");
+        if (p->n_pegs < 0 || g->n_groups < 0 || p->n_res < 2 || p->n_res > CASIM_KMAX_RES) return fail(CASIM_ERR_INVALID, "bad table sizes");
+        if (p->w_taint < 0 || p->w_label < 0 || p->w_excl < 0 || p->w_zone < 0) return fail(CASIM_ERR_INVALID, "negative mask width");
+        const size_t C = (size_t)p->n_pegs, N = (size_t)g->n_groups, R = (size_t)p->n_res;
+        if (C > 0 && (!p->req || !p->flags)) return fail(CASIM_ERR_INVALID, "class table has null columns");
+        if (N > 0 && (!g->alloc || !g->init_req || !g->allowed_pods || !g->init_pods || !g->flags)) return fail(CASIM_ERR_INVALID, "node table has null columns");
+        if (C > 0 && ((p->w_taint && !p->tol_mask) || (p->w_label && !p->sel_mask) || (p->w_excl && (!p->excl_block || !p->excl_mark)) || (p->w_zone && (!p->zone_block || !p->zone_mark))))
+            return fail(CASIM_ERR_INVALID, "class mask column missing");
+        if (N > 0 && ((p->w_taint && !g->taint_mask) || (p->w_label && !g->label_mask) || (p->w_excl && !g->init_excl))) return fail(CASIM_ERR_INVALID, "node mask column missing");
+        // host copy of the class table (validation of later calls reads flags and zone words) and of the node table's shape
+        hp_ = *p; hg_ = *g;
+        keep(h_req_, p->req, C * R, hp_.req); keep(h_count_, p->count, C, hp_.count); keep(h_flags_, p->flags, C, hp_.flags);
+        keep(h_tol_, p->tol_mask, C * p->w_taint, hp_.tol_mask); keep(h_sel_, p->sel_mask, C * p->w_label, hp_.sel_mask);
+        keep(h_xb_, p->excl_block, C * p->w_excl, hp_.excl_block); keep(h_xm_, p->excl_mark, C * p->w_excl, hp_.excl_mark);
+        keep(h_zb_, p->zone_block, C * p->w_zone, hp_.zone_block); keep(h_zm_, p->zone_mark, C * p->w_zone, hp_.zone_mark);
+        hp_.fp_cpu = hp_.fp_mem = nullptr;
+        keep(h_alloc_, g->alloc, N * R, hg_.alloc); keep(h_ireq_, g->init_req, N * R, hg_.init_req); keep(h_allowed_, g->allowed_pods, N, hg_.allowed_pods);
+        keep(h_ipods_, g->init_pods, N, hg_.init_pods); keep(h_gflags_, g->flags, N, hg_.flags); keep(h_taint_, g->taint_mask, N * p->w_taint, hg_.taint_mask);
+        keep(h_label_, g->label_mask, N * p->w_label, hg_.label_mask); keep(h_iexcl_, g->init_excl, N * p->w_excl, hg_.init_excl);
+        hg_.init_zone = hg_.zone_valid = nullptr; hg_.max_nodes = hg_.existing_nodes = hg_.last_index = nullptr;
+        hg_.cap_cpu = hg_.cap_mem = nullptr; hg_.waste_cpu = hg_.waste_mem = nullptr; hg_.peg_offsets = hg_.peg_index = nullptr;
+        hg_.peg_lo = hg_.peg_hi = hg_.global_id = nullptr; hg_.n_sims = 0; hg_.sim_offsets = nullptr;
+        // device image
+        memset(&dt_, 0, sizeof dt_);
+        dt_.G = p->n_pegs; dt_.NG = g->n_groups; dt_.R = p->n_res; dt_.Wt = p->w_taint; dt_.Wl = p->w_label; dt_.Wx = p->w_excl; dt_.Wz = 0;
+        dt_.req = up(p->req, C * R); dt_.pflags = up(p->flags, C); dt_.tol = up(p->tol_mask, C * dt_.Wt); dt_.sel = up(p->sel_mask, C * dt_.Wl);
+        dt_.xblock = up(p->excl_block, C * dt_.Wx); dt_.xmark = up(p->excl_mark, C * dt_.Wx);
+        dt_.alloc = up(g->alloc, N * R); dt_.init_req = up(g->init_req, N * R); dt_.allowed = up(g->allowed_pods, N); dt_.init_pods = up(g->init_pods, N);
+        dt_.gflags = up(g->flags, N); dt_.taint = up(g->taint_mask, N * dt_.Wt); dt_.label = up(g->label_mask, N * dt_.Wl); dt_.init_excl = up(g->init_excl, N * dt_.Wx);
+        bk_.sync();
+        if (!bk_.ok()) return fail(CASIM_ERR_HIP, bk_.error());
+        ready_ = true; uploads_ = 1;
+        return CASIM_OK;
+    }
+
+    // delta: the records of n nodes are replaced (rows->n_groups == n, same lanes / mask widths); only those rows travel
+    int32_t update_nodes(int32_t n, const int32_t* idx, const casim_groups* rows) {
+        if (!ready_) return fail(CASIM_ERR_INVALID, "cluster not initialised");
+        if (n < 0 || (n > 0 && (!idx || !rows || rows->n_groups != n))) return fail(CASIM_ERR_INVALID, "bad delta");
+        if (n == 0) return CASIM_OK;
+        for (int k = 0; k < n; ++k) if (idx[k] < 0 || idx[k] >= dt_.NG) return fail(CASIM_ERR_INVALID, "node index out of range");
+        if (!rows->alloc || !rows->init_req || !rows->allowed_pods || !rows->init_pods || !rows->flags || (dt_.Wt && !rows->taint_mask) ||
+            (dt_.Wl && !rows->label_mask) || (dt_.Wx && !rows->init_excl)) return fail(CASIM_ERR_INVALID, "delta rows miss a column");
+        const size_t mark = allocs_.size();   // the staging copies of this delta are released once the kernels are done
+        const int32_t* d_idx = up(idx, (size_t)n);
+        auto col = [&](const void* dst, const void* src, int bytes_per_row) {
+            if (bytes_per_row <= 0) return;
+            const uint32_t* d_src = (const uint32_t*)up((const char*)src, (size_t)n * (size_t)bytes_per_row);
+            const int wpr = bytes_per_row / 4;
+            bk_.launch(scatter_rows_kernel, (int)(((int64_t)n * wpr + 255) / 256), 1, 256, (size_t)0, (uint32_t*)dst, d_src, d_idx, n, wpr);
+        };
+        const int R = dt_.R;
+        col(dt_.alloc, rows->alloc, 8 * R); col(dt_.init_req, rows->init_req, 8 * R); col(dt_.allowed, rows->allowed_pods, 4);
+        col(dt_.init_pods, rows->init_pods, 4); col(dt_.gflags, rows->flags, 4); col(dt_.taint, rows->taint_mask, 8 * dt_.Wt);
+        col(dt_.label, rows->label_mask, 8 * dt_.Wl); col(dt_.init_excl, rows->init_excl, 8 * dt_.Wx);
+        bk_.sync();
+        drop_temps(mark);
+        delta_rows_ += n;
+        return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
+    }
+
+    // TrySchedulePods on the committed image; commit != 0 keeps the placements (SchedulePod's AddPod on the snapshot)
+    int32_t try_schedule(const casim_pod_sequence* q, int commit, int32_t* node_out, int32_t* last_index_out, int32_t* n_scheduled_out) {
+        if (!ready_) return fail(CASIM_ERR_INVALID, "cluster not initialised");
+        SchedulerT<BK> s(bk_);
+        s.use_resident(&dt_);
+        int32_t rc = s.init(&hp_, &hg_, q);
+        if (rc == CASIM_OK) rc = s.run();
+        const size_t mark = allocs_.size();
+        if (rc == CASIM_OK && commit && q->n_pods > 0 && s.node_out_dev()) {
+            const int32_t* d_pc = up(q->pod_class, (size_t)q->n_pods);
+            bk_.launch(commit_placements_kernel, (q->n_pods + 255) / 256, 1, 256, (size_t)0, dt_, s.node_out_dev(), d_pc, (int)q->n_pods);
+            commits_++;
+        }
+        if (rc == CASIM_OK) rc = s.fetch(node_out, last_index_out, n_scheduled_out);   // (synchronises: the commit kernel is done)
+        else bk_.sync();
+        drop_temps(mark);
+        if (rc < 0) err_ = s.error();
+        return rc;
+    }
+    // the planner's removal loop on the committed image (its own Fork / Revert: nothing persists)
+    int32_t simulate_removals(const casim_removal_candidates* cand, casim_removal_results* out) {
+        if (!ready_) return fail(CASIM_ERR_INVALID, "cluster not initialised");
+        SchedulerT<BK> s(bk_);
+        s.use_resident(&dt_);
+        int32_t rc = s.init_removals(&hp_, &hg_, cand);
+        if (rc == CASIM_OK) rc = s.run();
+        if (rc == CASIM_OK) rc = s.fetch_removals(out);
+        if (rc < 0) err_ = s.error();
+        return rc;
+    }
+    // the committed image of the mutable node columns (tests, and a shim that wants to cross-check its snapshot)
+    int32_t fetch_nodes(int64_t* init_req_out, int32_t* init_pods_out, uint64_t* init_excl_out) {
+        if (!ready_) return fail(CASIM_ERR_INVALID, "cluster not initialised");
+        const size_t N = (size_t)dt_.NG;
+        if (init_req_out) bk_.d2h(init_req_out, dt_.init_req, 8 * N * (size_t)dt_.R);
+        if (init_pods_out) bk_.d2h(init_pods_out, dt_.init_pods, 4 * N);
+        if (init_excl_out && dt_.Wx) bk_.d2h(init_excl_out, dt_.init_excl, 8 * N * (size_t)dt_.Wx);
+        bk_.sync();
+        return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
+    }
+    void stats(int64_t out[4]) const { out[0] = uploads_; out[1] = delta_rows_; out[2] = commits_; out[3] = dt_.NG; }
+    const std::string& error() const { return err_; }
+
+private:
+    template <class T> void keep(std::vector<T>& v, const T* src, size_t n, const T*& field) { if (src && n) v.assign(src, src + n); else v.clear(); field = v.empty() ? nullptr : v.data(); }
+    template <class T>
+    const T* up(const T* src, size_t n) {
+        if (n == 0 || !src) return nullptr;
+        T* d = (T*)bk_.alloc(sizeof(T) * n);
+        if (d) { allocs_.push_back(d); bk_.h2d(d, src, sizeof(T) * n); }
+        return d;
+    }
+    void drop_temps(size_t mark) { while (allocs_.size() > mark) { bk_.free(allocs_.back()); allocs_.pop_back(); } }
+    int32_t fail(int32_t code, const char* msg) { err_ = msg ? msg : ""; return code; }
+    BK& bk_;
+    DevTables dt_;
+    casim_pegs hp_; casim_groups hg_;
+    std::vector<int64_t> h_req_, h_alloc_, h_ireq_; std::vector<int32_t> h_count_, h_allowed_, h_ipods_; std::vector<uint32_t> h_flags_, h_gflags_;
+    std::vector<uint64_t> h_tol_, h_sel_, h_xb_, h_xm_, h_zb_, h_zm_, h_taint_, h_label_, h_iexcl_;
+    std::vector<void*> allocs_;
+    std::string err_;
+    bool ready_ = false;
+    int64_t uploads_ = 0, delta_rows_ = 0, commits_ = 0;
 };
 
 }  // namespace casim

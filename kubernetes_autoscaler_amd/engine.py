@@ -280,6 +280,68 @@ class Context:
         return finish_removal_results(rc, st, res, arrs)
 
 
+class ResidentCluster:
+    """casim_cluster: the snapshot's node table resident in HBM for a RunOnce iteration.  try_schedule_pods(commit=True) is
+    filter-out-schedulable adding its pods to the snapshot, simulate_node_removals runs on that committed image and never
+    persists (the planner's Fork / Revert), update_nodes replaces single node records between calls."""
+
+    def __init__(self, ctx: "Context", classes: _abi.Pegs, nodes: _abi.Groups):
+        self.ctx = ctx
+        self.n_nodes, self.n_res, self.w_excl = nodes.n_groups, classes.n_res, classes.w_excl
+        self._h = lib.casim_cluster_create(ctx._h, C.byref(classes), C.byref(nodes))
+        if not self._h:
+            raise CasimError(_abi.ERR_INVALID, last_error())
+
+    def close(self):
+        if self._h:
+            lib.casim_cluster_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def try_schedule_pods(self, pod_class, hint_node=None, node_acceptable=None, break_on_failure=False, last_index=0, commit=True,
+                          rules=None, similar_key=None):
+        seq, keep = make_pod_sequence(pod_class, hint_node, node_acceptable, break_on_failure, last_index, rules, similar_key)
+        node_out = np.full(max(seq.n_pods, 1), -1, np.int32)
+        li, ns = C.c_int32(0), C.c_int32(0)
+        rc = lib.casim_cluster_try_schedule_pods(self._h, C.byref(seq), int(bool(commit)), _ptr(node_out, C.c_int32), C.byref(li), C.byref(ns))
+        if rc < 0:
+            check(rc, "casim_cluster_try_schedule_pods")
+        del keep
+        return rc, node_out[:seq.n_pods], li.value, ns.value
+
+    def simulate_node_removals(self, cand_node, pod_offsets, pod_class, hint_node=None, destination=None, persist=True, max_removable=0,
+                               last_index=0, pod_sticky=None, ext_capacity=None, rules=None, cand_atomic=None):
+        st, keep = make_removal_candidates(cand_node, pod_offsets, pod_class, hint_node, destination, persist, max_removable, last_index,
+                                           pod_sticky, ext_capacity, rules, cand_atomic)
+        res, arrs = alloc_removal_results(st)
+        rc = lib.casim_cluster_simulate_node_removals(self._h, C.byref(st), C.byref(res))
+        if rc < 0:
+            check(rc, "casim_cluster_simulate_node_removals")
+        del keep
+        return finish_removal_results(rc, st, res, arrs)
+
+    def update_nodes(self, node_index, rows: _abi.Groups):
+        idx = np.ascontiguousarray(node_index, np.int32)
+        check(lib.casim_cluster_update_nodes(self._h, int(idx.shape[0]), _ptr(idx, C.c_int32), C.byref(rows)), "casim_cluster_update_nodes")
+
+    def fetch_nodes(self):
+        req = np.zeros((max(self.n_nodes, 1), self.n_res), np.int64)
+        pods = np.zeros(max(self.n_nodes, 1), np.int32)
+        excl = np.zeros((max(self.n_nodes, 1), max(self.w_excl, 1)), np.uint64)
+        check(lib.casim_cluster_fetch_nodes(self._h, _ptr(req, C.c_int64), _ptr(pods, C.c_int32), _ptr(excl, C.c_uint64)), "casim_cluster_fetch_nodes")
+        return req[:self.n_nodes], pods[:self.n_nodes], excl[:self.n_nodes, :self.w_excl]
+
+    def stats(self):
+        out = (C.c_int64 * 4)()
+        check(lib.casim_cluster_stats(self._h, out), "casim_cluster_stats")
+        return {"full_uploads": out[0], "delta_rows": out[1], "commits": out[2], "nodes": out[3]}
+
+
 class MultiContext:
     """casim_mctx: several devices behind one caller (one process, one host thread — the shape a Go estimator has).
     estimate_batch() block-partitions the node groups of every simulation over the devices, runs them concurrently and

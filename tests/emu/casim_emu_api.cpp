@@ -100,6 +100,30 @@ EMU_API int32_t emu_estimate_batch_multi(int32_t n_devices, int32_t use_reduce_h
     return rc;
 }
 
+// ---- resident cluster under the emulator: a handle owns its backend -------------------------------------------
+struct EmuCluster { EmuBackend bk; casim::ClusterT<EmuBackend>* c = nullptr; };
+EMU_API void* emu_cluster_create(const casim_pegs* classes, const casim_groups* nodes, int64_t lds_budget_bytes) {
+    EmuCluster* h = new EmuCluster();
+    if (lds_budget_bytes > 0) h->bk.lds = (size_t)lds_budget_bytes;
+    h->c = new casim::ClusterT<EmuBackend>(h->bk);
+    if (h->c->init(classes, nodes) != CASIM_OK) { g_err = h->c->error(); delete h->c; delete h; return nullptr; }
+    return h;
+}
+EMU_API void emu_cluster_destroy(void* p) { EmuCluster* h = (EmuCluster*)p; if (h) { delete h->c; delete h; } }
+EMU_API int32_t emu_cluster_update_nodes(void* p, int32_t n, const int32_t* idx, const casim_groups* rows) {
+    EmuCluster* h = (EmuCluster*)p; const int32_t rc = h->c->update_nodes(n, idx, rows); if (rc < 0) g_err = h->c->error(); return rc;
+}
+EMU_API int32_t emu_cluster_try_schedule_pods(void* p, const casim_pod_sequence* seq, int32_t commit, int32_t* node_out, int32_t* li, int32_t* ns) {
+    EmuCluster* h = (EmuCluster*)p; const int32_t rc = h->c->try_schedule(seq, commit, node_out, li, ns); if (rc < 0) g_err = h->c->error(); return rc;
+}
+EMU_API int32_t emu_cluster_simulate_node_removals(void* p, const casim_removal_candidates* cand, casim_removal_results* out) {
+    EmuCluster* h = (EmuCluster*)p; const int32_t rc = h->c->simulate_removals(cand, out); if (rc < 0) g_err = h->c->error(); return rc;
+}
+EMU_API int32_t emu_cluster_fetch_nodes(void* p, int64_t* init_req, int32_t* init_pods, uint64_t* init_excl) {
+    EmuCluster* h = (EmuCluster*)p; return h->c->fetch_nodes(init_req, init_pods, init_excl);
+}
+EMU_API int32_t emu_cluster_stats(void* p, int64_t out[4]) { ((EmuCluster*)p)->c->stats(out); return 0; }
+
 EMU_API int32_t emu_feasibility_reasons(const casim_pegs* pegs, const casim_groups* groups, const uint64_t* port_block, uint16_t* out_codes) {
     EmuBackend bk;
     casim::ProblemT<EmuBackend> p(bk);

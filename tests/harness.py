@@ -517,3 +517,141 @@ def run_emu_multi(ts, n_devices, kinds=None, valid=None, use_hook=True):
                                     off.ctypes.data_as(_abi.i32p), C.byref(q) if q is not None else None, info)
     assert rc == 0, (rc, L.emu_last_error())
     return finish_results(arrs, ng, int(off[ng]), off), exp, list(info)
+
+
+# ---------------------------------------------------------------------------------------------
+# resident cluster (casim_cluster_*): emulator counterpart of engine.ResidentCluster
+# ---------------------------------------------------------------------------------------------
+class EmuCluster:
+    def __init__(self, classes, nodes, lds_budget=0):
+        L = self.L = emu_lib()
+        if not hasattr(L, "_cluster_bound"):
+            L.emu_cluster_create.restype = C.c_void_p
+            L.emu_cluster_create.argtypes = [C.POINTER(_abi.Pegs), C.POINTER(_abi.Groups), C.c_int64]
+            L.emu_cluster_destroy.argtypes = [C.c_void_p]
+            L.emu_cluster_update_nodes.argtypes = [C.c_void_p, C.c_int32, _abi.i32p, C.POINTER(_abi.Groups)]
+            L.emu_cluster_try_schedule_pods.argtypes = [C.c_void_p, C.POINTER(_abi.PodSequence), C.c_int32, _abi.i32p, _abi.i32p, _abi.i32p]
+            L.emu_cluster_simulate_node_removals.argtypes = [C.c_void_p, C.POINTER(_abi.RemovalCandidates), C.POINTER(_abi.RemovalResults)]
+            L.emu_cluster_fetch_nodes.argtypes = [C.c_void_p, _abi.i64p, _abi.i32p, _abi.u64p]
+            L.emu_cluster_stats.argtypes = [C.c_void_p, _abi.i64p]
+            L._cluster_bound = True
+        self.n_nodes, self.n_res, self.w_excl = nodes.n_groups, classes.n_res, classes.w_excl
+        self._h = L.emu_cluster_create(C.byref(classes), C.byref(nodes), int(lds_budget))
+        assert self._h, L.emu_last_error()
+
+    def close(self):
+        if self._h:
+            self.L.emu_cluster_destroy(self._h)
+            self._h = None
+
+    def try_schedule_pods(self, pod_class, hint_node=None, node_acceptable=None, break_on_failure=False, last_index=0, commit=True,
+                          rules=None, similar_key=None):
+        from kubernetes_autoscaler_amd.engine import make_pod_sequence
+        seq, keep = make_pod_sequence(pod_class, hint_node, node_acceptable, break_on_failure, last_index, rules, similar_key)
+        node_out = np.full(max(seq.n_pods, 1), -1, np.int32)
+        li, ns = C.c_int32(0), C.c_int32(0)
+        rc = self.L.emu_cluster_try_schedule_pods(self._h, C.byref(seq), int(bool(commit)), node_out.ctypes.data_as(_abi.i32p), C.byref(li), C.byref(ns))
+        assert rc >= 0, (rc, self.L.emu_last_error())
+        del keep
+        return rc, node_out[:seq.n_pods], li.value, ns.value
+
+    def simulate_node_removals(self, cand_node, pod_offsets, pod_class, hint_node=None, destination=None, persist=True, max_removable=0,
+                               last_index=0, pod_sticky=None, ext_capacity=None, rules=None, cand_atomic=None):
+        from kubernetes_autoscaler_amd.engine import alloc_removal_results, finish_removal_results, make_removal_candidates
+        st, keep = make_removal_candidates(cand_node, pod_offsets, pod_class, hint_node, destination, persist, max_removable, last_index,
+                                           pod_sticky, ext_capacity, rules, cand_atomic)
+        res, arrs = alloc_removal_results(st)
+        rc = self.L.emu_cluster_simulate_node_removals(self._h, C.byref(st), C.byref(res))
+        assert rc >= 0, (rc, self.L.emu_last_error())
+        del keep
+        return finish_removal_results(rc, st, res, arrs)
+
+    def update_nodes(self, node_index, rows):
+        idx = np.ascontiguousarray(node_index, np.int32)
+        rc = self.L.emu_cluster_update_nodes(self._h, int(idx.shape[0]), idx.ctypes.data_as(_abi.i32p), C.byref(rows))
+        assert rc == 0, (rc, self.L.emu_last_error())
+
+    def fetch_nodes(self):
+        req = np.zeros((max(self.n_nodes, 1), self.n_res), np.int64)
+        pods = np.zeros(max(self.n_nodes, 1), np.int32)
+        excl = np.zeros((max(self.n_nodes, 1), max(self.w_excl, 1)), np.uint64)
+        self.L.emu_cluster_fetch_nodes(self._h, req.ctypes.data_as(_abi.i64p), pods.ctypes.data_as(_abi.i32p), excl.ctypes.data_as(_abi.u64p))
+        return req[:self.n_nodes], pods[:self.n_nodes], excl[:self.n_nodes, :self.w_excl]
+
+    def stats(self):
+        out = (C.c_int64 * 4)()
+        self.L.emu_cluster_stats(self._h, out)
+        return {"full_uploads": out[0], "delta_rows": out[1], "commits": out[2], "nodes": out[3]}
+
+
+def resident_iteration(make_cluster, w, n_candidates=4):
+    """One RunOnce-shaped sequence on a resident cluster vs the oracle, which threads ONE snapshot through it the way the
+    reference does: filter-out-schedulable (committed) -> the same pods again (nothing may fit twice the same way; reverted)
+    -> the planner's removal loop over the emptiest nodes, whose pod lists include what filter-out-schedulable just placed.
+    `w` is a workloads.PendingWorkload (no domain rules).  Returns what was compared, for the caller's bookkeeping."""
+    from kubernetes_autoscaler_amd.objects import PodEquivalenceGroup as PEG
+    nodes, pods = w.nodes, w.pods
+    # ---- one encoder session for the iteration: classes = pending specs + the specs of every running pod
+    enc = Encoder(explicit_self_exclusion=True)
+    class_of = {}
+
+    def cls(p):
+        k = p.spec_key()
+        if k not in class_of:
+            class_of[k] = enc.add_peg(PEG(pods=[p]))
+        return class_of[k]
+    pod_class = np.array([cls(p) for p in pods], np.int32)
+    for info in nodes:
+        for p in info.pods:
+            cls(p)
+    for info in nodes:
+        enc.add_group(info, pegs=[])
+    enc.finalize()
+    cl = make_cluster(enc.pegs, enc.groups)
+    # ---- oracle: one snapshot for the whole sequence
+    s = OracleScenario()
+    for info in nodes:
+        s.add_existing(info)
+    canon = {}
+    opods = [canon.setdefault(p.spec_key(), p) for p in pods]
+    want1 = s.try_schedule_pods(opods, w.hints, None, w.acceptable, w.break_on_failure, w.last_index)
+    # ---- 1. filter-out-schedulable, committed
+    before = cl.fetch_nodes()
+    rc, out1, li1, ns1 = cl.try_schedule_pods(pod_class, w.hints, w.acceptable, w.break_on_failure, w.last_index, commit=True)
+    assert rc == 0
+    assert list(out1) == list(want1[0]) and li1 == want1[1] and ns1 == want1[2], "committed pass"
+    after = cl.fetch_nodes()
+    placed_on = [[] for _ in nodes]
+    for i, m in enumerate(out1):
+        if m >= 0:
+            placed_on[int(m)].append(pods[i])
+    for m, info in enumerate(nodes):   # the image holds exactly what the oracle's snapshot holds now
+        add = [0] * enc.pegs.n_res
+        for p in placed_on[m]:
+            add[0] += p.requests.get("cpu", 0); add[1] += p.requests.get("memory", 0)
+        assert list(after[0][m] - before[0][m]) == add and int(after[1][m] - before[1][m]) == len(placed_on[m]), ("image", m)
+    # ---- 2. the same pods once more, reverted: forks from the COMMITTED image (the oracle commits, so give it a throw-away copy)
+    s2 = OracleScenario()
+    for m, info in enumerate(nodes):
+        from kubernetes_autoscaler_amd.objects import NodeInfo
+        s2.add_existing(NodeInfo(info.node, list(info.pods) + placed_on[m]))
+    want2 = s2.try_schedule_pods(opods, w.hints, None, w.acceptable, w.break_on_failure, li1)
+    s2.close()
+    rc, out2, li2, ns2 = cl.try_schedule_pods(pod_class, w.hints, w.acceptable, w.break_on_failure, li1, commit=False)
+    assert list(out2) == list(want2[0]) and li2 == want2[1] and ns2 == want2[2], "reverted pass"
+    again = cl.fetch_nodes()
+    assert all((a == b).all() for a, b in zip(after, again)), "a reverted pass must not touch the image"
+    # ---- 3. removal loop on the committed image: the emptiest nodes, their pods = running + just placed (arrival order)
+    load = [len(info.pods) + len(placed_on[m]) for m, info in enumerate(nodes)]
+    cands = sorted(range(len(nodes)), key=lambda m: (load[m], m))[:n_candidates]
+    lists = [[p for p in nodes[c].pods if not p.daemonset] + placed_on[c] for c in cands]
+    want3 = s.simulate_node_removals(cands, lists, None, None, True, 0, None, None, li1, None)
+    flat = np.array([class_of[p.spec_key()] for lst in lists for p in lst], np.int32)
+    off = np.cumsum([0] + [len(x) for x in lists]).astype(np.int32)
+    got3 = cl.simulate_node_removals(cands, off, flat, last_index=li1)
+    assert_removal_matches(got3, want3, "removals on the committed image")
+    final = cl.fetch_nodes()
+    assert all((a == b).all() for a, b in zip(after, final)), "the removal loop must not touch the image"
+    st = cl.stats()
+    s.close(); cl.close(); enc.close()
+    return {"scheduled": int(ns1), "removable": int((got3.removable == 1).sum()), "stats": st}

@@ -191,3 +191,20 @@ def test_node_pods_and_the_analyser_hook(ctx):
     e = est.BinpackingNodeEstimator(ctx, est.ClusterSnapshotView(), limiter, estimation_analyser_func=lambda snap, ng, nodes: seen.update(nodes))
     n, pods = e.estimate(w.pegs, w.groups[0].template, est.NodeGroup("c0", 10, 0))
     assert n == len(seen) > 0 and all(k.startswith("c0-template-e-") for k in seen)
+
+
+def test_resident_cluster_iteration(ctx):
+    """casim_cluster_*: filter-out-schedulable committed into the resident node table, a reverted pass, the planner's removal loop
+    on the committed image — vs the oracle threading one snapshot through the same sequence."""
+    from harness import resident_iteration
+    total = 0
+    for seed in range(30):
+        w = workloads.fuzz_pending(300 + seed)
+        w.hints = None
+        out = resident_iteration(lambda classes, nodes: kaa.ResidentCluster(ctx, classes, nodes), w)
+        assert out["stats"]["full_uploads"] == 1
+        total += out["scheduled"]
+    assert total > 0
+    w = workloads.pending_scale(2000, 20000, 32, 4)      # LDS-resident state, long runs
+    out = resident_iteration(lambda classes, nodes: kaa.ResidentCluster(ctx, classes, nodes), w, n_candidates=50)
+    assert out["scheduled"] > 0

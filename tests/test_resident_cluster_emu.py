@@ -1,0 +1,81 @@
+"""casim_cluster_*: the snapshot's node table resident across the calls of one RunOnce iteration (second half).
+CPU: product kernels under the wave emulator vs the oracle, which threads ONE snapshot through the same sequence."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from kubernetes_autoscaler_amd import _abi, workloads
+from kubernetes_autoscaler_amd.encoder import Encoder
+from kubernetes_autoscaler_amd.objects import NodeInfo, PodEquivalenceGroup
+from harness import EmuCluster, resident_iteration
+from oracle_driver import OracleScenario
+
+
+@pytest.mark.parametrize("lds", [0, 4096])
+@pytest.mark.parametrize("seed", range(40))
+def test_iteration_on_a_resident_cluster_matches_one_threaded_snapshot(seed, lds):
+    w = workloads.fuzz_pending(300 + seed)
+    w.hints = None
+    out = resident_iteration(lambda classes, nodes: EmuCluster(classes, nodes, lds_budget=lds), w)
+    assert out["stats"]["full_uploads"] == 1 and out["stats"]["commits"] == (1 if len(w.pods) else 0)
+
+
+def test_node_delta_replaces_single_records():
+    """A node's pods changed between two calls: only its record travels (casim_cluster_update_nodes)."""
+    w = workloads.fuzz_pending(11, max_nodes=30, max_pods=60)
+    nodes, pods = w.nodes, w.pods
+
+    def encode(nodes_now):
+        enc = Encoder(explicit_self_exclusion=True)
+        class_of = {}
+        pc = []
+        for p in pods:
+            k = p.spec_key()
+            if k not in class_of:
+                class_of[k] = enc.add_peg(PodEquivalenceGroup(pods=[p]))
+            pc.append(class_of[k])
+        for info in nodes:           # running specs join the dictionaries in a fixed order, whatever the delta does
+            for p in info.pods:
+                k = p.spec_key()
+                if k not in class_of:
+                    class_of[k] = enc.add_peg(PodEquivalenceGroup(pods=[p]))
+        for info in nodes_now:
+            enc.add_group(info, pegs=[])
+        enc.finalize()
+        return enc, np.array(pc, np.int32)
+    enc, pc = encode(nodes)
+    cl = EmuCluster(enc.pegs, enc.groups)
+    # two nodes lose their pods (evicted since the tables were built)
+    victims = [m for m, info in enumerate(nodes) if info.pods][:2]
+    changed = [NodeInfo(info.node, [] if m in victims else list(info.pods)) for m, info in enumerate(nodes)]
+    enc2, _ = encode(changed)
+    assert enc2.pegs.w_excl == enc.pegs.w_excl and enc2.pegs.w_label == enc.pegs.w_label
+    from kubernetes_autoscaler_amd.tables import TableSet
+    rows = TableSet.from_encoder(enc2).select_groups(np.array(victims))
+    _, rg = rows.structs()
+    cl.update_nodes(victims, rg)
+    assert cl.stats()["delta_rows"] == len(victims)
+    rc, got, li, ns = cl.try_schedule_pods(pc, None, w.acceptable, w.break_on_failure, w.last_index, commit=False)
+    s = OracleScenario()
+    for info in changed:
+        s.add_existing(info)
+    canon = {}
+    want = s.try_schedule_pods([canon.setdefault(p.spec_key(), p) for p in pods], None, None, w.acceptable, w.break_on_failure, w.last_index)
+    s.close()
+    assert list(got) == list(want[0]) and li == want[1] and ns == want[2]
+    cl.close(); enc.close(); enc2.close()
+
+
+def test_bad_deltas_are_rejected():
+    w = workloads.fuzz_pending(5)
+    enc = Encoder(explicit_self_exclusion=True)
+    enc.add_peg(PodEquivalenceGroup(pods=[w.pods[0]]))
+    for info in w.nodes:
+        enc.add_group(info, pegs=[])
+    enc.finalize()
+    cl = EmuCluster(enc.pegs, enc.groups)
+    idx = np.array([len(w.nodes)], np.int32)
+    rc = cl.L.emu_cluster_update_nodes(cl._h, 1, idx.ctypes.data_as(_abi.i32p), C.byref(enc.groups))
+    assert rc == _abi.ERR_INVALID
+    cl.close(); enc.close()
