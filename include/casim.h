@@ -401,6 +401,10 @@ int32_t casim_estimate_batch_multi(casim_mctx* m, const casim_pegs* pegs, const 
  *          counter[its domain] + self - min over existing domains (0 if fewer than min_domains) <= max_skew;
  *   kind 1 (conflict): counter = pods in the domain that are anti-affine with the class through this key, either
  *          direction; a node passes iff it lacks the key or counter[its domain] == 0.
+ *   kind 2 (affinity): one rule per required pod-affinity term; counter = pods in the domain that match ALL affinity terms
+ *          of the class; a node passes iff it carries the key and counter[its domain] > 0 for every such rule — or, when
+ *          some counter is 0, iff every counter of the class's affinity rules is 0 in every domain AND rule_self (the class
+ *          matches its own terms): the "first pod of a self-affine series" exception (filtering.go:396-407).
  * inc_*: which rules a placed pod of class c increments (on the node's domain, if the node is eligible for the rule).
  */
 typedef struct casim_domain_rules {
@@ -410,7 +414,7 @@ typedef struct casim_domain_rules {
     const uint8_t* key_is_hostname;  /* [n_keys] the key is kubernetes.io/hostname                             */
     const int32_t* rule_class;       /* [n_rules] rules are sorted by class                                    */
     const int32_t* rule_key;         /* [n_rules]                                                              */
-    const int32_t* rule_kind;        /* [n_rules] 0 spread, 1 conflict                                         */
+    const int32_t* rule_kind;        /* [n_rules] 0 spread, 1 conflict, 2 affinity                             */
     const int32_t* rule_max_skew;    /* [n_rules]                                                              */
     const int32_t* rule_min_domains; /* [n_rules]                                                              */
     const int32_t* rule_self;        /* [n_rules] 1 = a pod of the class increments its own rule               */
@@ -639,6 +643,18 @@ int32_t casim_enc_pod_add_anti_affinity_term(casim_encoder* e, int32_t pod, cons
                                              const char* const* namespaces, int32_t n_namespaces);
 int32_t casim_enc_term_add_requirement(casim_encoder* e, int32_t pod, int32_t term, const char* key,
                                        const char* op, const char* const* values, int32_t n_values);
+/* REQUIRED pod affinity term (PodAffinity.RequiredDuringSchedulingIgnoredDuringExecution; V/.../interpodaffinity/
+ * filtering.go:234-272 getIncomingAffinityAntiAffinityCounts, :382-409 satisfyPodAffinity): topology key, explicit namespaces
+ * (n = 0 => the pod's own), label selector through casim_enc_aff_term_add_requirement.  A pod "matches" when it matches ALL
+ * terms of the spec; a node passes when, for every term, it carries the topology key and its domain holds a matching pod —
+ * or the pod is the first of a series with affinity to itself (no matching pod anywhere, it matches its own terms, the node
+ * carries every key).  Evaluated on the device in per-node mode (TrySchedulePods, the removal loop, Estimate on the snapshot)
+ * as domain rules of kind 2; in template mode the spec is flagged CASIM_PEG_UNSUPPORTED, which sends its node groups to
+ * casim_estimate_on_cluster.  A term with a namespaceSelector is outside the subset (casim_enc_pod_mark_unsupported). */
+int32_t casim_enc_pod_add_affinity_term(casim_encoder* e, int32_t pod, const char* topology_key,
+                                        const char* const* namespaces, int32_t n_namespaces);
+int32_t casim_enc_aff_term_add_requirement(casim_encoder* e, int32_t pod, int32_t term, const char* key,
+                                           const char* op, const char* const* values, int32_t n_values);
 /* first-container requests as float64 for the fastpath chooser */
 /* DoNotSchedule topologySpreadConstraint of the pod spec (min_domains <= 0 = nil); returns its index.  Evaluated on the
  * device only in per-node mode (explicit_self_exclusion); in template mode such a spec is flagged UNSUPPORTED. */

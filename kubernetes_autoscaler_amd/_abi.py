@@ -192,6 +192,8 @@ PROTOTYPES = {
     "casim_enc_pod_add_host_port": (C.c_int32, [C.c_void_p, C.c_int32, cstr, cstr, C.c_int32]),
     "casim_enc_pod_add_anti_affinity_term": (C.c_int32, [C.c_void_p, C.c_int32, cstr, cstrp, C.c_int32]),
     "casim_enc_term_add_requirement": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, cstr, cstr, cstrp, C.c_int32]),
+    "casim_enc_pod_add_affinity_term": (C.c_int32, [C.c_void_p, C.c_int32, cstr, cstrp, C.c_int32]),
+    "casim_enc_aff_term_add_requirement": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, cstr, cstr, cstrp, C.c_int32]),
     "casim_enc_pod_add_spread_constraint": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, cstr, C.c_int32]),
     "casim_enc_spread_add_requirement": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, cstr, cstr, cstrp, C.c_int32]),
     "casim_enc_spread_set_taints_policy": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),

@@ -58,6 +58,7 @@ struct PodSpec {
     bool has_node_terms = false;
     std::vector<Port> ports;
     std::vector<Term> anti;
+    std::vector<Term> aff;        // REQUIRED pod affinity terms (casim_enc_pod_add_affinity_term): a pod "matches" when it matches ALL
     double fp_cpu = 0, fp_mem = 0;
     bool unsupported = false;
     std::string why;
@@ -379,6 +380,21 @@ int32_t casim_enc_term_add_requirement(casim_encoder* e, int32_t pod, int32_t te
     if (n_values < 0 || (n_values > 0 && !values)) return CASIM_ERR_INVALID;
     e->specs[pod].anti[term].selector.push_back(make_req(key, op, values, n_values)); return CASIM_OK;
 }
+int32_t casim_enc_pod_add_affinity_term(casim_encoder* e, int32_t pod, const char* topology_key, const char* const* namespaces, int32_t n_namespaces) {
+    POD_CHECK(e, pod);
+    if (n_namespaces < 0 || (n_namespaces > 0 && !namespaces)) return CASIM_ERR_INVALID;
+    Term t; t.topology_key = S(topology_key);
+    if (n_namespaces == 0) { t.namespaces.push_back(e->specs[pod].ns); t.auto_ns = true; }  // getNamespacesFromPodAffinityTerm
+    for (int i = 0; i < n_namespaces; ++i) t.namespaces.push_back(S(namespaces[i]));
+    e->specs[pod].aff.push_back(t);
+    return (int32_t)e->specs[pod].aff.size() - 1;
+}
+int32_t casim_enc_aff_term_add_requirement(casim_encoder* e, int32_t pod, int32_t term, const char* key, const char* op, const char* const* values, int32_t n_values) {
+    POD_CHECK(e, pod);
+    if (term < 0 || (size_t)term >= e->specs[pod].aff.size()) return CASIM_ERR_INVALID;
+    if (n_values < 0 || (n_values > 0 && !values)) return CASIM_ERR_INVALID;
+    e->specs[pod].aff[term].selector.push_back(make_req(key, op, values, n_values)); return CASIM_OK;
+}
 int32_t casim_enc_pod_add_spread_constraint(casim_encoder* e, int32_t pod, int32_t max_skew, const char* topology_key, int32_t min_domains) {
     POD_CHECK(e, pod);
     if (max_skew <= 0 || !topology_key || !*topology_key) return CASIM_ERR_INVALID;
@@ -686,6 +702,9 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         for (size_t i = 0; i < G; ++i) {
             PodSpec& p = e->specs[(size_t)e->pegs[i].spec];
             if (!p.spread.empty()) { p.unsupported = true; p.why = "topologySpreadConstraints"; }
+            // required pod affinity looks at the pods of the node's topology domain: a property of the snapshot, not of a
+            // template — such groups are estimated on the whole snapshot (casim_estimate_on_cluster, rule kind 2 below)
+            if (!p.aff.empty()) { p.unsupported = true; p.why = "required pod affinity"; }
         }
     } else {
         auto& dr = e->dr;
@@ -709,6 +728,14 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         std::set<int32_t> running;   // distinct specs of running pods
         for (auto& g : e->groups) for (int32_t s2 : g.preloaded) running.insert(s2);
         for (int32_t s2 : running) for (auto& t : e->specs[(size_t)s2].anti) if (t.topology_key != kHostname) aa_keys.insert(t.topology_key);
+        // required pod affinity (V/.../interpodaffinity/filtering.go:234-272,382-409): an existing / placed pod counts for the
+        // class when it matches ALL of its affinity terms (podMatchesAllAffinityTerms), once per term, in the domain of its
+        // node for that term's topology key; a node passes a term when its domain holds such a pod
+        auto matches_all_aff = [&](const PodSpec& owner, const PodSpec& q) {
+            if (owner.aff.empty()) return false;
+            for (auto& t : owner.aff) if (!term_matches(t, q)) return false;
+            return true;
+        };
         struct Rule { int cls, key, kind, skew, mind, self, row; const Spread* sc; };
         std::vector<Rule> rules;
         std::vector<std::vector<uint64_t>> rows;
@@ -758,6 +785,10 @@ int32_t casim_enc_finalize(casim_encoder* e) {
                 Rule r{(int)i, key_of(k), 1, 0, 0, zone_conflict(p, p, k) ? 1 : 0, -1, nullptr};
                 rules.push_back(r);
             }
+            for (auto& t : p.aff) {   // kind 2: one rule per affinity term (its topology key), all fed by the same pods
+                Rule r{(int)i, key_of(t.topology_key), 2, 0, 0, matches_all_aff(p, p) ? 1 : 0, -1, nullptr};
+                rules.push_back(r);
+            }
         }
         if (!rules.empty()) {
             dr.n_keys = (int32_t)keys.size(); dr.n_rules = (int32_t)rules.size(); dr.n_rows = (int32_t)rows.size();
@@ -797,7 +828,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
                     for (int32_t s2 : e->groups[n].preloaded) {
                         const PodSpec& q = e->specs[(size_t)s2];
                         const bool feeds = R0.kind == 0 ? (!R0.sc->selector.empty() && q.ns == p.ns && selector_matches(R0.sc->selector, q.labels))
-                                                        : zone_conflict(p, q, keys[(size_t)R0.key]);
+                                         : R0.kind == 1 ? zone_conflict(p, q, keys[(size_t)R0.key]) : matches_all_aff(p, q);
                         if (feeds) { dr.count_init[at]++; dr.node_contrib[r * NG + n]++; }
                     }
                 }
@@ -810,7 +841,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
                     const Rule& R0 = rules[r];
                     const PodSpec& p = e->specs[(size_t)e->pegs[(size_t)R0.cls].spec];
                     const bool feeds = R0.kind == 0 ? (!R0.sc->selector.empty() && q.ns == p.ns && selector_matches(R0.sc->selector, q.labels))
-                                                    : zone_conflict(p, q, keys[(size_t)R0.key]);
+                                     : R0.kind == 1 ? zone_conflict(p, q, keys[(size_t)R0.key]) : matches_all_aff(p, q);
                     if (feeds) dr.inc_rule.push_back((int32_t)r);
                 }
                 dr.inc_off[j + 1] = (int32_t)dr.inc_rule.size();

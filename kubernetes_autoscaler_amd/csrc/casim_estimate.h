@@ -114,7 +114,19 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void estimate_kernel(DevTables t, EstArgs a)
         const int i_lo = a.n_rules > 0 ? a.inc_off[c] : 0, i_hi = a.n_rules > 0 ? a.inc_off[c + 1] : 0;
         int32_t minv[kMaxRulesPerClass];
         for (int ri = 0; ri < kMaxRulesPerClass; ++ri) minv[ri] = 0;
+        bool has_aff = false, aff_self = false, aff_first = false;
+        for (int r = r_lo; r < r_hi; ++r) if (a.rule_kind[r] == 2) { has_aff = true; aff_self = a.rule_self[r] != 0; }
         auto refresh_minima = [&]() {   // minMatchNum (filtering.go:54-68) of every spread rule of the class
+            if (has_aff) {   // len(affinityCounts) == 0 && the class matches its own terms: the first pod of the series may pass
+                uint32_t some = 0;
+                for (int r = r_lo; r < r_hi; ++r) {
+                    if (a.rule_kind[r] != 2) continue;
+                    const int64_t lo = a.rule_off[r];
+                    const int32_t D = (int32_t)(a.rule_off[r + 1] - lo);
+                    for (int32_t d = tid; d < D; d += T) if (cs::load_relaxed_i32(a.rule_cnt + lo + d) > 0) some = 1;
+                }
+                aff_first = aff_self && bc.max(some) == 0;
+            }
             for (int r = r_lo; r < r_hi; ++r) {
                 if (a.rule_kind[r] != 0) continue;
                 const int64_t lo = a.rule_off[r];
@@ -133,15 +145,19 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void estimate_kernel(DevTables t, EstArgs a)
         // PodTopologySpread + (after it) the non-hostname anti-affinity rules: 0 pass, 1 spread constraint not met
         // (ErrReasonConstraintsNotMatch), 2 anything else
         auto rules_verdict = [&](int m) -> int {
-            for (int r = r_lo; r < r_hi; ++r) {
+            bool aff_missing = false;
+            for (int r = r_lo; r < r_hi; ++r) {   // (spread rules come first in a class's list: PodTopologySpread runs before InterPodAffinity)
                 const int32_t d = a.node_domain[(int64_t)a.rule_key[r] * N + m];
                 if (a.rule_kind[r] == 0) {
                     if (d < 0) return 2;
                     const int64_t skew = (int64_t)cs::load_relaxed_i32(a.rule_cnt + a.rule_off[r] + d) + a.rule_self[r] - minv[r - r_lo];
                     if (skew > a.rule_max_skew[r]) return 1;
+                } else if (a.rule_kind[r] == 2) {
+                    if (d < 0) return 2;
+                    if (cs::load_relaxed_i32(a.rule_cnt + a.rule_off[r] + d) <= 0) aff_missing = true;
                 } else if (d >= 0 && cs::load_relaxed_i32(a.rule_cnt + a.rule_off[r] + d) > 0) return 2;
             }
-            return 0;
+            return (aff_missing && !aff_first) ? 2 : 0;
         };
         // RunFilterPlugins on node m in the default order (NodeUnschedulable / TaintToleration / NodeAffinity = static
         // bit, NodePorts, NodeResourcesFit, PodTopologySpread, InterPodAffinity): 0 pass, 1 failed on a spread

@@ -381,12 +381,29 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
             const int r_lo = n_rules > 0 ? a.class_rule_off[c] : 0, r_hi = n_rules > 0 ? a.class_rule_off[c + 1] : 0;
             const int i_lo = n_rules > 0 ? a.inc_off[c] : 0, i_hi = n_rules > 0 ? a.inc_off[c + 1] : 0;
             bool self_aff = false, monotone = true;   // monotone: a node that rejected the class once rejects it for good
-            for (int r = r_lo; r < r_hi; ++r) { self_aff |= a.rule_self[r] != 0; monotone &= a.rule_kind[r] != 0; }
+            // (affinity rules are not monotone either: a node starts passing once a matching pod lands in its domain)
+            bool has_aff = false, aff_self = false, aff_first = false;
+            for (int r = r_lo; r < r_hi; ++r) {
+                self_aff |= a.rule_self[r] != 0; monotone &= a.rule_kind[r] == 1;
+                if (a.rule_kind[r] == 2) { has_aff = true; aff_self = a.rule_self[r] != 0; }
+            }
             const int32_t pair = (int32_t)cs::bcast_u32((uint32_t)my_pair, j), ctrl = (int32_t)cs::bcast_u32((uint32_t)my_ctrl, j);
             int32_t minv[kMaxRulesPerClass];
             for (int ri = 0; ri < kMaxRulesPerClass; ++ri) minv[ri] = 0;
             // global minimum of every spread rule (minMatchNum, filtering.go:54-68): block-wide over the rule's domains
             auto refresh_minima = [&]() {
+                if (has_aff) {
+                    // len(affinityCounts) == 0 (filtering.go:402): no pod matching the class's affinity terms in any domain of
+                    // any of their keys — together with the self match it lets the first pod of the series through
+                    uint32_t some = 0;
+                    for (int r = r_lo; r < r_hi; ++r) {
+                        if (a.rule_kind[r] != 2) continue;
+                        const int64_t lo = a.rule_off[r];
+                        const int32_t D = (int32_t)(a.rule_off[r + 1] - lo);
+                        for (int32_t d = tid; d < D; d += T) if (cs::load_relaxed_i32(a.rule_cnt + lo + d) > 0) some = 1;
+                    }
+                    aff_first = aff_self && bc.max(some) == 0;
+                }
                 for (int r = r_lo; r < r_hi; ++r) {
                     if (a.rule_kind[r] != 0) continue;
                     const int64_t lo = a.rule_off[r];
@@ -403,15 +420,19 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                 }
             };
             auto rule_ok = [&](int m) -> bool {
+                bool aff_missing = false;   // some affinity term without a matching pod in the node's domain
                 for (int r = r_lo; r < r_hi; ++r) {
                     const int32_t d = a.node_domain[(int64_t)a.rule_key[r] * N + m];
                     if (a.rule_kind[r] == 0) {
                         if (d < 0) return false;   // ErrReasonNodeLabelNotMatch
                         const int64_t skew = (int64_t)cs::load_relaxed_i32(a.rule_cnt + a.rule_off[r] + d) + a.rule_self[r] - minv[r - r_lo];
                         if (skew > a.rule_max_skew[r]) return false;
+                    } else if (a.rule_kind[r] == 2) {
+                        if (d < 0) return false;   // satisfyPodAffinity: all topology labels must exist on the node
+                        if (cs::load_relaxed_i32(a.rule_cnt + a.rule_off[r] + d) <= 0) aff_missing = true;
                     } else if (d >= 0 && cs::load_relaxed_i32(a.rule_cnt + a.rule_off[r] + d) > 0) return false;
                 }
-                return true;
+                return !aff_missing || aff_first;
             };
             // NodeInfo.AddPod on node m + what the new pods mean for the rules of every class
             auto commit_pods = [&](int m, uint32_t x) {

@@ -137,6 +137,8 @@ class Pod:
     node_affinity_terms: Optional[List[NodeSelectorTerm]] = None
     host_ports: List[ContainerPort] = field(default_factory=list)
     anti_affinity: List[PodAffinityTerm] = field(default_factory=list)
+    # PodAffinity.RequiredDuringSchedulingIgnoredDuringExecution (explicit namespaces; a namespace_selector marks the spec unsupported)
+    affinity: List[PodAffinityTerm] = field(default_factory=list)
     # first container's requests as AsApproximateFloat64 for the fastpath chooser; None = derive
     fastpath_cpu: Optional[float] = None
     fastpath_mem: Optional[float] = None
@@ -167,6 +169,10 @@ class Pod:
                        tuple((r.key, r.operator, tuple(r.values)) for r in t.match_expressions), tuple(t.namespaces),
                        None if t.namespace_selector is None else tuple((r.key, r.operator, tuple(r.values)) for r in t.namespace_selector))
                       for t in self.anti_affinity),
+                tuple((t.topology_key, tuple(sorted(t.match_labels.items())),
+                       tuple((r.key, r.operator, tuple(r.values)) for r in t.match_expressions), tuple(t.namespaces),
+                       None if t.namespace_selector is None else tuple((r.key, r.operator, tuple(r.values)) for r in t.namespace_selector))
+                      for t in self.affinity),
                 self.topology_spread, tuple((c.max_skew, c.topology_key, c.min_domains, tuple(sorted(c.match_labels.items())), c.node_taints_policy, c.node_affinity_policy, tuple(c.match_label_keys))
                                             for c in self.spread_constraints),
                 self.unsupported_reason, self.has_containers, self.spec_extra)

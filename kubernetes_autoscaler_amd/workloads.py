@@ -751,3 +751,29 @@ def add_random_namespace_selectors(seed: int, pods: Sequence[Pod], hostname_only
             p.anti_affinity = [PodAffinityTerm(t.topology_key, dict(t.match_labels), list(t.match_expressions), tuple(t.namespaces),
                                                None if t.namespace_selector is None else list(t.namespace_selector)) for t in terms]
     return table
+
+
+# ---------------------------------------------------------------------------------------------
+# required pod affinity (InterPodAffinity, V/.../interpodaffinity/filtering.go:234-272,382-409)
+# ---------------------------------------------------------------------------------------------
+def add_random_pod_affinity(seed: int, pods: Sequence[Pod], frac: float = 0.5, keys: Sequence[str] = (LABEL_HOSTNAME, LABEL_ZONE, "rack"),
+                            apps: Sequence[str] = ("app0", "app1", "app2", "app3")) -> int:
+    """Decorates `pods` (same spec -> same terms, so equivalence classes survive) with 1-2 REQUIRED pod-affinity terms: towards
+    the pod's own app label (the self-affine series with its first-pod exception), towards another app (only nodes / zones
+    that already hold such a pod qualify), sometimes through a selector nobody matches.  Returns the number of decorated specs."""
+    import random
+    rng = random.Random(0xAFF1 + seed)
+    plan = {}
+    for p in pods:
+        k = p.spec_key()
+        if k not in plan:
+            terms = []
+            if rng.random() < frac:
+                for _ in range(1 if rng.random() < 0.7 else 2):
+                    own = p.labels.get("app", apps[0])
+                    r = rng.random()
+                    target = own if r < 0.5 else (rng.choice(list(apps)) if r < 0.9 else "nobody")
+                    terms.append(PodAffinityTerm(rng.choice(list(keys)), match_labels={"app": target}))
+            plan[k] = terms
+        p.affinity = list(plan[k])
+    return sum(1 for v in plan.values() if v)

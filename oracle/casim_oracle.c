@@ -105,6 +105,7 @@ typedef struct {
     int has_node_terms;
     VEC(hostport) ports;
     VEC(aff_term) anti_terms;
+    VEC(aff_term) aff_terms;   /* requiredDuringSchedulingIgnoredDuringExecution pod AFFINITY terms (explicit namespaces) */
     double fp_cpu, fp_mem;
     int fp_has_requests;
     int has_topology_spread;
@@ -182,6 +183,8 @@ void orc_free(orc* o) {
         VEC_FREE(p->node_terms);
         for (int t = 0; t < p->anti_terms.n; ++t) { VEC_FREE(p->anti_terms.v[t].namespaces); free_reqvec(&p->anti_terms.v[t].selector); free_reqvec(&p->anti_terms.v[t].ns_sel); }
         VEC_FREE(p->anti_terms);
+        for (int t = 0; t < p->aff_terms.n; ++t) { VEC_FREE(p->aff_terms.v[t].namespaces); free_reqvec(&p->aff_terms.v[t].selector); free_reqvec(&p->aff_terms.v[t].ns_sel); }
+        VEC_FREE(p->aff_terms);
         for (int c = 0; c < p->spread.n; ++c) free_reqvec(&p->spread.v[c].selector);
         VEC_FREE(p->spread);
     }
@@ -288,6 +291,22 @@ int orc_pod_anti_affinity_term(orc* o, int pod, const char* topology_key, const 
     for (int i = 0; i < n; ++i) VEC_PUSH(t.namespaces, intern(&o->st, namespaces[i]));
     VEC_PUSH(o->pods.v[pod].anti_terms, t);
     return o->pods.v[pod].anti_terms.n - 1;
+}
+/* a required pod AFFINITY term (PodAffinity.RequiredDuringSchedulingIgnoredDuringExecution); namespaces as above */
+int orc_pod_affinity_term(orc* o, int pod, const char* topology_key, const char* const* namespaces, int n) {
+    PODCHK(o, pod);
+    aff_term t; memset(&t, 0, sizeof t);
+    t.topology_key = intern(&o->st, topology_key);
+    if (n == 0) { VEC_PUSH(t.namespaces, o->pods.v[pod].ns); t.auto_ns = 1; }
+    for (int i = 0; i < n; ++i) VEC_PUSH(t.namespaces, intern(&o->st, namespaces[i]));
+    VEC_PUSH(o->pods.v[pod].aff_terms, t);
+    return o->pods.v[pod].aff_terms.n - 1;
+}
+int orc_aff_term_requirement(orc* o, int pod, int term, const char* key, const char* op, const char* const* values, int n) {
+    PODCHK(o, pod);
+    if (term < 0 || term >= o->pods.v[pod].aff_terms.n) return -1;
+    requirement r = make_req(o, key, op, values, n);
+    VEC_PUSH(o->pods.v[pod].aff_terms.v[term].selector, r); return 0;
 }
 static ns_entry* ns_find(const orc* o, int name) {
     for (int i = 0; i < o->namespaces.n; ++i) if (o->namespaces.v[i].name == name) return &o->namespaces.v[i];
@@ -648,7 +667,7 @@ static int64_t tpmap_get(const tpmap* m, int key, int value) {
     for (int i = 0; i < m->n; ++i) if (m->v[i].key == key && m->v[i].value == value) return m->v[i].count;
     return 0;
 }
-typedef struct { tpmap existing_anti; tpmap incoming_anti; int skip; } ipa_state;
+typedef struct { tpmap existing_anti; tpmap incoming_anti; tpmap incoming_aff; int skip; } ipa_state;
 
 /* InterPodAffinity.PreFilter  filtering.go:274-309 (required pod AFFINITY terms are out of
  * the encoded subset; specs carrying them are never sent down this path) */
@@ -683,14 +702,50 @@ static void ipa_prefilter(const orc* o, const podspec* p, ipa_state* s) {
             }
         }
     }
+    /* the affinity half of getIncomingAffinityAntiAffinityCounts: an existing pod counts when it matches ALL of the incoming
+     * pod's affinity terms (updateWithAffinityTerms / podMatchesAllAffinityTerms :125-133), once per term whose topology key
+     * its node carries */
+    if (p->aff_terms.n > 0) {
+        for (int i = 0; i < o->snap.n; ++i) {
+            const node* n = &o->snap.v[i];
+            for (int j = 0; j < n->pods.n; ++j) {
+                const podspec* ep = &o->pods.v[n->pods.v[j]];
+                int all = 1;
+                for (int t = 0; t < p->aff_terms.n && all; ++t) all = term_matches_pod(o, &p->aff_terms.v[t], ep, 1);
+                if (!all) continue;
+                for (int t = 0; t < p->aff_terms.n; ++t) {
+                    int val;
+                    if (labels_lookup(n->labels.v, n->labels.n, p->aff_terms.v[t].topology_key, &val)) tpmap_add(&s->incoming_aff, p->aff_terms.v[t].topology_key, val, 1);
+                }
+            }
+        }
+    }
     /* :300-305 Skip when nothing can interact */
-    s->skip = (s->existing_anti.n == 0 && p->anti_terms.n == 0);
+    s->skip = (s->existing_anti.n == 0 && p->anti_terms.n == 0 && p->aff_terms.n == 0);
 }
-static void ipa_free(ipa_state* s) { VEC_FREE(s->existing_anti); VEC_FREE(s->incoming_anti); }
+static void ipa_free(ipa_state* s) { VEC_FREE(s->existing_anti); VEC_FREE(s->incoming_anti); VEC_FREE(s->incoming_aff); }
+/* satisfyPodAffinity  filtering.go:382-409: every term's topology label on the node and a matching pod in that domain — or
+ * the pod is the first of a series with affinity to itself: no matching pod ANYWHERE (len(affinityCounts) == 0), it matches
+ * all its own terms, and the node carries every topology key */
+static int satisfy_pod_affinity(const orc* o, const podspec* p, const node* n, const ipa_state* s) {
+    int pods_exist = 1;
+    for (int t = 0; t < p->aff_terms.n; ++t) {
+        int val;
+        if (!labels_lookup(n->labels.v, n->labels.n, p->aff_terms.v[t].topology_key, &val)) return 0;
+        if (tpmap_get(&s->incoming_aff, p->aff_terms.v[t].topology_key, val) <= 0) pods_exist = 0;
+    }
+    if (!pods_exist) {
+        if (s->incoming_aff.n != 0) return 0;
+        for (int t = 0; t < p->aff_terms.n; ++t) if (!term_matches_pod(o, &p->aff_terms.v[t], p, 1)) return 0;
+        return 1;
+    }
+    return 1;
+}
 /* InterPodAffinity.Filter  filtering.go:412-432 with satisfyPodAntiAffinity :367-380 and
  * satisfyExistingPodsAntiAffinity :352-364 */
-static int filter_ipa(const podspec* p, const node* n, const ipa_state* s) {
+static int filter_ipa(const orc* o, const podspec* p, const node* n, const ipa_state* s) {
     if (s->skip) return 1;
+    if (p->aff_terms.n > 0 && !satisfy_pod_affinity(o, p, n, s)) return -1;   /* ErrReasonAffinityRulesNotMatch */
     if (s->incoming_anti.n > 0) {
         for (int t = 0; t < p->anti_terms.n; ++t) {
             int val;
@@ -811,7 +866,10 @@ static int run_filter_plugins(orc* o, const podspec* p, const node* n, const ipa
     else {
         const int pts = ts ? filter_pts(o, p, n, ts) : 0;
         if (pts) { failed = PL_PTS; *reason = pts == 1 ? REASON_PTS_CONSTRAINTS : REASON_PTS_LABEL; }
-        else if (!filter_ipa(p, n, s)) { failed = PL_IPA; *reason = "node(s) didn't satisfy anti-affinity rules"; }
+        else {
+            const int ipa = filter_ipa(o, p, n, s);
+            if (ipa <= 0) { failed = PL_IPA; *reason = ipa < 0 ? "node(s) didn't match pod affinity rules" : "node(s) didn't satisfy anti-affinity rules"; }
+        }
     }
     o->last_fail_reason = failed ? *reason : NULL;
     if (failed) { if (plugin) *plugin = failed; return 0; }

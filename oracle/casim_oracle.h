@@ -62,6 +62,10 @@ int orc_pod_node_term_req(orc* o, int pod, int term, int is_field, const char* k
                           const char* const* values, int n);
 int orc_pod_anti_affinity_term(orc* o, int pod, const char* topology_key,
                                const char* const* namespaces, int n_namespaces);
+/* required pod AFFINITY term (explicit namespaces; n = 0 => the pod's own) and one requirement of its label selector:
+ * InterPodAffinity.PreFilter / Filter, V/.../interpodaffinity/filtering.go:234-272,382-409 */
+int orc_pod_affinity_term(orc* o, int pod, const char* topology_key, const char* const* namespaces, int n_namespaces);
+int orc_aff_term_requirement(orc* o, int pod, int term, const char* key, const char* op, const char* const* values, int n_values);
 int orc_term_requirement(orc* o, int pod, int term, const char* key, const char* op,
                          const char* const* values, int n_values);
 int orc_pod_fastpath_requests(orc* o, int pod, double cpu, double mem);

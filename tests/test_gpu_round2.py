@@ -208,3 +208,53 @@ def test_resident_cluster_iteration(ctx):
     w = workloads.pending_scale(2000, 20000, 32, 4)      # LDS-resident state, long runs
     out = resident_iteration(lambda classes, nodes: kaa.ResidentCluster(ctx, classes, nodes), w, n_candidates=50)
     assert out["scheduled"] > 0
+
+
+def test_required_pod_affinity_on_the_device(ctx):
+    """a18 complete: required pod affinity as domain rules of kind 2 — TrySchedulePods, the removal loop and Estimate on the
+    snapshot on the MI355X vs the oracle (same families as tests/test_pod_affinity_emu.py)."""
+    from kubernetes_autoscaler_amd.workloads import add_random_pod_affinity
+    from harness import (RemovalCase, SchedCase, assert_cluster_estimate_matches, assert_removal_matches, assert_sched_matches,
+                         cluster_estimate_gpu, removal_device, removal_oracle, sched_gpu, sched_oracle)
+    placed = 0
+    for seed in range(120):
+        w = workloads.fuzz_pending_domains(7000 + seed)
+        add_random_pod_affinity(seed, w.pods + [p for info in w.nodes for p in info.pods], frac=0.6)
+        case = SchedCase(nodes=w.nodes, pods=w.pods, hints=w.hints, acceptable=w.acceptable, break_on_failure=w.break_on_failure, last_index=w.last_index)
+        got = sched_gpu(case, ctx)
+        assert_sched_matches(got, sched_oracle(case), w.name)
+        placed += int(got[3])
+    assert placed > 0
+    for seed in range(80):
+        w = workloads.fuzz_removals_domains(7000 + seed)
+        add_random_pod_affinity(seed, [p for info in w.nodes for p in info.pods], frac=0.5, apps=("app0", "app1", "app2"))
+        case = RemovalCase(nodes=w.nodes, candidates=w.candidates, destination=w.destination, hints=w.hints, persist=w.persist,
+                           max_removable=w.max_removable, last_index=w.last_index)
+        assert_removal_matches(removal_device(case, ctx), removal_oracle(case), w.name)
+    for seed in range(120):
+        w = workloads.fuzz_estimate_domains(7000 + seed)
+        add_random_pod_affinity(seed, [pg.pods[0] for pg in w.pegs] + [p for info in w.existing for p in info.pods] + list(w.groups[0].template.pods),
+                                frac=0.6, apps=("app0", "app1", "app2"))
+        sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing, lanes=w.lanes)
+        got = cluster_estimate_gpu(sc, ctx)
+        if got[0] == 1:
+            continue
+        est, ids = run_oracle(sc)[0]
+        assert_cluster_estimate_matches(got, est, ids, w.name)
+
+
+def test_estimator_mirror_runs_affinity_groups_on_the_snapshot(ctx):
+    """BinpackingNodeEstimator: a PEG with required pod affinity leaves the template-mode batch (CASIM_NG_UNSUPPORTED) and is
+    estimated by casim_estimate_on_cluster — same answer as the oracle's Estimate."""
+    from kubernetes_autoscaler_amd import estimator as est
+    from kubernetes_autoscaler_amd.objects import LABEL_ZONE, GiB, MiB, NodeInfo, Pod, PodAffinityTerm, PodEquivalenceGroup
+    from kubernetes_autoscaler_amd.workloads import _node
+    tmpl = NodeInfo(_node("t", 2000, 8 * GiB, 110, {LABEL_ZONE: "z0"}))
+    web = Pod(name="web", labels={"app": "web"}, requests={"cpu": 500, "memory": 256 * MiB}, affinity=[PodAffinityTerm(LABEL_ZONE, match_labels={"app": "web"})])
+    far = Pod(name="far", labels={"app": "far"}, requests={"cpu": 100, "memory": 64 * MiB}, affinity=[PodAffinityTerm(LABEL_ZONE, match_labels={"app": "absent"})])
+    pegs = [PodEquivalenceGroup([web] * 9), PodEquivalenceGroup([far] * 3)]
+    e = est.BinpackingNodeEstimator(ctx, est.ClusterSnapshotView(), est.ThresholdBasedEstimationLimiter([est.StaticThreshold(10)]))
+    n, pods = e.estimate(pegs, tmpl, est.NodeGroup("ng", 10, 0))
+    sc = Scenario(pegs=pegs, groups=[GroupSpec(tmpl, 10, 0, None)])
+    want, _ = run_oracle(sc)[0]
+    assert (n, len(pods)) == (want.node_count, want.pods_scheduled) == (3, 9)     # the zone-affine series fills 3 nodes, "far" finds no partner

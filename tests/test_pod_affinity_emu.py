@@ -1,0 +1,86 @@
+"""Required pod affinity (a18 complete): InterPodAffinity's getIncomingAffinityAntiAffinityCounts / satisfyPodAffinity
+(V/.../interpodaffinity/filtering.go:234-272,382-409) as domain rules of kind 2 in K_sched (TrySchedulePods, the removal loop)
+and K_est (Estimate on the snapshot), product kernels under the wave emulator vs the object-level oracle."""
+import pytest
+
+from kubernetes_autoscaler_amd import _abi, workloads
+from kubernetes_autoscaler_amd.objects import LABEL_HOSTNAME, LABEL_ZONE, GiB, MiB, NodeInfo, Pod, PodAffinityTerm, PodEquivalenceGroup
+from kubernetes_autoscaler_amd.workloads import _node, add_random_pod_affinity
+from harness import (EmuContext, GroupSpec, RemovalCase, Scenario, SchedCase, assert_cluster_estimate_matches, assert_removal_matches,
+                     assert_sched_matches, cluster_estimate_emu, encode, removal_device, removal_oracle, run_emu, run_oracle, sched_emu,
+                     sched_oracle)
+
+
+def sched_case(w):
+    return SchedCase(nodes=w.nodes, pods=w.pods, hints=w.hints, acceptable=w.acceptable, break_on_failure=w.break_on_failure, last_index=w.last_index)
+
+
+@pytest.mark.parametrize("seed", range(300))
+def test_try_schedule_pods_with_required_pod_affinity(seed):
+    w = workloads.fuzz_pending_domains(7000 + seed)
+    n = add_random_pod_affinity(seed, w.pods + [p for info in w.nodes for p in info.pods], frac=0.6)
+    case = sched_case(w)
+    want = sched_oracle(case)
+    for lds in (0, 4096):
+        got = sched_emu(case, lds_budget=lds)
+        assert_sched_matches(got, want, f"{w.name} lds={lds} ({n} specs with affinity)")
+
+
+@pytest.mark.parametrize("seed", range(200))
+def test_removal_loop_with_required_pod_affinity(seed):
+    w = workloads.fuzz_removals_domains(7000 + seed)
+    add_random_pod_affinity(seed, [p for info in w.nodes for p in info.pods], frac=0.5, apps=("app0", "app1", "app2"))
+    case = RemovalCase(nodes=w.nodes, candidates=w.candidates, destination=w.destination, hints=w.hints, persist=w.persist,
+                       max_removable=w.max_removable, last_index=w.last_index)
+    want = removal_oracle(case)
+    for lds in (0, 4096):
+        got = removal_device(case, EmuContext(lds))
+        assert_removal_matches(got, want, f"{w.name} lds={lds}")
+
+
+@pytest.mark.parametrize("seed", range(300))
+def test_estimate_on_the_snapshot_with_required_pod_affinity(seed):
+    w = workloads.fuzz_estimate_domains(7000 + seed)
+    add_random_pod_affinity(seed, [pg.pods[0] for pg in w.pegs] + [p for info in w.existing for p in info.pods] + list(w.groups[0].template.pods),
+                            frac=0.6, apps=("app0", "app1", "app2"))
+    sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing, lanes=w.lanes)
+    if cluster_estimate_emu(sc)[0] == 1:
+        pytest.skip("delegated (hostname anti-affinity next to an unnamed node)")
+    est, ids = run_oracle(sc)[0]
+    for lds in (0, 64):
+        assert_cluster_estimate_matches(cluster_estimate_emu(sc, 0, lds_budget=lds), est, ids, f"{w.name} lds={lds}")
+
+
+def test_template_mode_delegates_affinity_groups_to_the_snapshot_path():
+    """In a template-mode batch a PEG with required pod affinity makes its groups CASIM_NG_UNSUPPORTED (the shim re-runs them
+    through casim_estimate_on_cluster, where the rule is evaluated)."""
+    tmpl = NodeInfo(_node("t", 4000, 8 * GiB, 110, {LABEL_ZONE: "z0"}))
+    web = Pod(name="web", labels={"app": "web"}, requests={"cpu": 500, "memory": 256 * MiB},
+              affinity=[PodAffinityTerm(LABEL_ZONE, match_labels={"app": "web"})])
+    plain = Pod(name="plain", labels={"app": "x"}, requests={"cpu": 100, "memory": 64 * MiB})
+    sc = Scenario(pegs=[PodEquivalenceGroup([web] * 5), PodEquivalenceGroup([plain] * 3)], groups=[GroupSpec(tmpl, 0, 0, None), GroupSpec(tmpl, 0, 0, [1])])
+    enc = encode(sc)
+    assert enc.pegs.flags[0] & _abi.PEG_UNSUPPORTED and not (enc.pegs.flags[1] & _abi.PEG_UNSUPPORTED)
+    res, _ = run_emu(enc)
+    assert int(res.status[0]) == _abi.NG_UNSUPPORTED and int(res.status[1]) == _abi.NG_OK
+    enc.close()
+
+
+def test_self_affine_series_on_hostname_packs_one_node():
+    """The first pod passes by the exception (no matching pod anywhere, it matches its own term), the others must join it:
+    a hostname-level self-affine PEG fills ONE node and the rest stays pending — oracle and device agree."""
+    nodes = [NodeInfo(_node(f"n{i}", 1000, 4 * GiB, 110, {LABEL_ZONE: "z0"})) for i in range(3)]
+    pods = [Pod(name=f"p{i}", labels={"app": "db"}, requests={"cpu": 300, "memory": 64 * MiB}, controller_uid="db",
+                affinity=[PodAffinityTerm(LABEL_HOSTNAME, match_labels={"app": "db"})]) for i in range(5)]
+    case = SchedCase(nodes=nodes, pods=pods)
+    want = sched_oracle(case)
+    assert list(want[0]) == [1, 1, 1, -1, -1]      # (the walk starts behind lastIndex = 0)
+    assert_sched_matches(sched_emu(case), want, "self-affine hostname series")
+    # towards another app that runs on node 2 only
+    nodes[2].pods.append(Pod(name="cache", labels={"app": "cache"}, requests={"cpu": 100, "memory": 64 * MiB}))
+    pods2 = [Pod(name=f"q{i}", labels={"app": "web"}, requests={"cpu": 300, "memory": 64 * MiB}, controller_uid="web",
+                 affinity=[PodAffinityTerm(LABEL_HOSTNAME, match_labels={"app": "cache"})]) for i in range(4)]
+    case2 = SchedCase(nodes=nodes, pods=pods2)
+    want2 = sched_oracle(case2)
+    assert list(want2[0]) == [2, 2, 2, -1]
+    assert_sched_matches(sched_emu(case2), want2, "affinity to a running pod")

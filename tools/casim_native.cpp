@@ -35,7 +35,7 @@ struct Sig { int op; const char* args; };
 enum Op {
     CREATE, ADD_GROUP, GROUP_LABEL, GROUP_TAINT, GROUP_FP_CAP, GROUP_LIMITS, GROUP_PRELOADED, GROUP_SET_PEGS, ADD_POD_SPEC, POD_LABEL,
     POD_TOLERATION, POD_NODE_SELECTOR, POD_NODE_AFF_REQ, POD_NODE_AFF_TERM, NODE_TERM_REQ, POD_HOST_PORT, POD_AA_TERM, TERM_REQ,
-    POD_SPREAD, SPREAD_REQ, SPREAD_TAINTS, SPREAD_AFFINITY, ADD_NAMESPACE, NAMESPACE_LABEL, TERM_NS_SELECTOR, TERM_NS_REQ, POD_FP_REQ,
+    POD_AFF_TERM, AFF_TERM_REQ, POD_SPREAD, SPREAD_REQ, SPREAD_TAINTS, SPREAD_AFFINITY, ADD_NAMESPACE, NAMESPACE_LABEL, TERM_NS_SELECTOR, TERM_NS_REQ, POD_FP_REQ,
     POD_UNSUPPORTED, ADD_PEG, ADD_RESOURCE_PEGS, ADD_EXISTING_POD, FINALIZE
 };
 const std::map<std::string, Sig> kSigs = {
@@ -57,6 +57,8 @@ const std::map<std::string, Sig> kSigs = {
     {"casim_enc_pod_add_host_port", {POD_HOST_PORT, "issi"}},
     {"casim_enc_pod_add_anti_affinity_term", {POD_AA_TERM, "isSi"}},
     {"casim_enc_term_add_requirement", {TERM_REQ, "iissSi"}},
+    {"casim_enc_pod_add_affinity_term", {POD_AFF_TERM, "isSi"}},
+    {"casim_enc_aff_term_add_requirement", {AFF_TERM_REQ, "iissSi"}},
     {"casim_enc_pod_add_spread_constraint", {POD_SPREAD, "iisi"}},
     {"casim_enc_spread_add_requirement", {SPREAD_REQ, "iissSi"}},
     {"casim_enc_spread_set_taints_policy", {SPREAD_TAINTS, "iii"}},
@@ -171,6 +173,8 @@ int32_t replay(const std::vector<Call>& calls, size_t n_calls, casim_encoder*& e
         case POD_HOST_PORT: rc = casim_enc_pod_add_host_port(e, (int32_t)I[0], c.s(0), c.s(1), (int32_t)I[1]); break;
         case POD_AA_TERM: rc = casim_enc_pod_add_anti_affinity_term(e, (int32_t)I[0], c.s(0), c.SA[0].data(), (int32_t)I[1]); break;
         case TERM_REQ: rc = casim_enc_term_add_requirement(e, (int32_t)I[0], (int32_t)I[1], c.s(0), c.s(1), c.SA[0].data(), (int32_t)I[2]); break;
+        case POD_AFF_TERM: rc = casim_enc_pod_add_affinity_term(e, (int32_t)I[0], c.s(0), c.SA[0].data(), (int32_t)I[1]); break;
+        case AFF_TERM_REQ: rc = casim_enc_aff_term_add_requirement(e, (int32_t)I[0], (int32_t)I[1], c.s(0), c.s(1), c.SA[0].data(), (int32_t)I[2]); break;
         case POD_SPREAD: rc = casim_enc_pod_add_spread_constraint(e, (int32_t)I[0], (int32_t)I[1], c.s(0), (int32_t)I[2]); break;
         case SPREAD_REQ: rc = casim_enc_spread_add_requirement(e, (int32_t)I[0], (int32_t)I[1], c.s(0), c.s(1), c.SA[0].data(), (int32_t)I[2]); break;
         case SPREAD_TAINTS: rc = casim_enc_spread_set_taints_policy(e, (int32_t)I[0], (int32_t)I[1], (int32_t)I[2]); break;
