@@ -430,6 +430,9 @@ typedef struct casim_domain_rules {
     const int32_t* inc_off;          /* [n_classes + 1]                                                        */
     const int32_t* inc_rule;         /* [inc_off[n_classes]]                                                   */
     int32_t n_taint_policy_rules;    /* spread rules whose eligibility row honours node taints (see casim_enc_spread_set_taints_policy) */
+    const uint8_t* rule_ghost_leaves; /* [n_rules] or NULL: 1 = a removal candidate leaves this rule's domains while it is simulated —
+                                        a spread rule with nodeTaintsPolicy: Honor whose class does not tolerate the ghost's
+                                        ToBeDeletedByClusterAutoscaler:NoSchedule taint (CA/simulator/cluster.go:240-252) */
 } casim_domain_rules;
 
 typedef struct casim_pod_sequence {

@@ -92,7 +92,7 @@ class DomainRules(C.Structure):
                 ("node_domain", i32p), ("key_domains", i32p), ("key_is_hostname", u8p), ("rule_class", i32p), ("rule_key", i32p), ("rule_kind", i32p),
                 ("rule_max_skew", i32p), ("rule_min_domains", i32p), ("rule_self", i32p), ("rule_elig_row", i32p), ("rule_offset", i64p),
                 ("count_init", i32p), ("domain_exists", u8p), ("domain_nodes", i32p), ("node_contrib", i32p), ("elig_bits", u64p), ("class_rule_off", i32p), ("inc_off", i32p),
-                ("inc_rule", i32p), ("n_taint_policy_rules", C.c_int32)]
+                ("inc_rule", i32p), ("n_taint_policy_rules", C.c_int32), ("rule_ghost_leaves", u8p)]
 
 
 class PodSequence(C.Structure):

@@ -237,7 +237,7 @@ struct casim_encoder {
         int32_t n_keys = 0, n_rules = 0, n_rows = 0;
         std::vector<int32_t> node_domain, key_domains, r_class, r_key, r_kind, r_skew, r_mind, r_self, r_row, count_init, class_off, inc_off, inc_rule;
         std::vector<int32_t> dom_nodes, node_contrib;
-        std::vector<uint8_t> key_host;
+        std::vector<uint8_t> key_host, r_ghost;
         std::vector<int64_t> r_off;
         std::vector<uint8_t> exists;
         std::vector<uint64_t> elig;
@@ -736,7 +736,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
             for (auto& t : owner.aff) if (!term_matches(t, q)) return false;
             return true;
         };
-        struct Rule { int cls, key, kind, skew, mind, self, row; const Spread* sc; };
+        struct Rule { int cls, key, kind, skew, mind, self, row; const Spread* sc; int ghost = 0; };
         std::vector<Rule> rules;
         std::vector<std::vector<uint64_t>> rows;
         for (size_t i = 0; i < G; ++i) {
@@ -775,6 +775,16 @@ int32_t casim_enc_finalize(casim_encoder* e) {
                 if (sc.taints_honor) dr.n_taint_rules++;
                 Rule r{(int)i, key_of(sc.key), 0, sc.max_skew, sc.min_domains, 0, row_of[(sc.affinity_honor ? 1 : 0) | (sc.taints_honor ? 2 : 0)], &sc};
                 r.self = (!sc.selector.empty() && selector_matches(sc.selector, p.labels)) ? 1 : 0;   // an empty selector counts nothing
+                if (sc.taints_honor) {
+                    // removal simulation: the candidate turns into a ghost carrying ToBeDeletedByClusterAutoscaler:NoSchedule
+                    // (CA/simulator/cluster.go:240-252; the value is a timestamp: only an Exists toleration can match it, "0" here as in
+                    // the oracle).  With nodeTaintsPolicy: Honor such a node is no member of the constraint's domains unless the pod
+                    // tolerates the taint: the ghost LEAVES its domain for the simulation (rule_ghost_leaves).
+                    const Taint ghost{"ToBeDeletedByClusterAutoscaler", "0", "NoSchedule"};
+                    bool tol = false;
+                    for (auto& t : p.tolerations) if (tolerates(t, ghost, e->opt.enable_taint_comparison_ops != 0)) { tol = true; break; }
+                    r.ghost = tol ? 0 : 1;
+                }
                 rules.push_back(r);
             }
             for (auto& k : aa_keys) {
@@ -817,7 +827,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
                 const Rule& R0 = rules[r];
                 const PodSpec& p = e->specs[(size_t)e->pegs[(size_t)R0.cls].spec];
                 dr.r_class.push_back(R0.cls); dr.r_key.push_back(R0.key); dr.r_kind.push_back(R0.kind); dr.r_skew.push_back(R0.skew);
-                dr.r_mind.push_back(R0.mind); dr.r_self.push_back(R0.self); dr.r_row.push_back(R0.row);
+                dr.r_mind.push_back(R0.mind); dr.r_self.push_back(R0.self); dr.r_row.push_back(R0.row); dr.r_ghost.push_back((uint8_t)R0.ghost);
                 dr.class_off[(size_t)R0.cls + 1]++;
                 for (size_t n = 0; n < NG; ++n) {
                     const int d = dr.node_domain[(size_t)R0.key * NG + n];
@@ -978,6 +988,7 @@ int32_t casim_enc_domain_rules(const casim_encoder* e, casim_domain_rules* out) 
     out->rule_class = dr.r_class.data(); out->rule_key = dr.r_key.data(); out->rule_kind = dr.r_kind.data();
     out->rule_max_skew = dr.r_skew.data(); out->rule_min_domains = dr.r_mind.data(); out->rule_self = dr.r_self.data();
     out->rule_elig_row = dr.r_row.data(); out->rule_offset = dr.r_off.data(); out->count_init = dr.count_init.data();
+    out->rule_ghost_leaves = dr.r_ghost.data();
     out->domain_exists = dr.exists.data(); out->domain_nodes = dr.dom_nodes.data(); out->node_contrib = dr.node_contrib.data();
     out->elig_bits = dr.elig.data(); out->class_rule_off = dr.class_off.data();
     out->inc_off = dr.inc_off.data(); out->inc_rule = dr.inc_rule.data();

@@ -71,6 +71,7 @@ struct SchedArgs {
     const int32_t* node_domain;   // [n_keys][N]
     const int32_t* rule_key; const int32_t* rule_kind; const int32_t* rule_max_skew; const int32_t* rule_min_domains;
     const int32_t* rule_self; const int32_t* rule_elig_row;
+    const uint8_t* rule_ghost;    // [n_rules] or null: the removal candidate's ghost leaves this rule's domains (nodeTaintsPolicy: Honor)
     const int64_t* rule_off;      // [n_rules + 1]
     int32_t* rule_cnt;            // working counters (copied from count_init before every pass)
     int32_t* rule_dom_nodes;      // working copy: eligible nodes still carrying each domain (> 0 <=> the domain exists)
@@ -330,6 +331,13 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
         for (int r = tid; r < n_rules; r += T) {
             const int32_t d = a.node_domain[(int64_t)a.rule_key[r] * N + Y], v = cs::load_relaxed_i32(a.rule_contrib + (int64_t)r * N + Y);
             if (d >= 0 && v != 0) cs::atomic_add_i32(a.rule_cnt + a.rule_off[r] + d, -v);
+            // ... and tainted (ToBeDeletedByClusterAutoscaler:NoSchedule, cluster.go:240-252): for a spread rule that honours node
+            // taints and whose class does not tolerate this one, the ghost is no domain member while it is simulated
+            if (a.rule_ghost && a.rule_ghost[r] && d >= 0) {
+                const int row = a.rule_elig_row[r];
+                const bool el = row < 0 || ((a.rule_elig[(int64_t)row * (a.cap >> 6) + (Y >> 6)] >> (Y & 63)) & 1ull);
+                if (el) cs::atomic_add_i32(a.rule_dom_nodes + a.rule_off[r] + d, -1);
+            }
         }
         cs::sync();
     }
@@ -656,15 +664,20 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                 const int32_t d = a.node_domain[(int64_t)a.rule_key[r] * N + Y];
                 const int row = a.rule_elig_row[r];
                 const bool el = row < 0 || ((a.rule_elig[(int64_t)row * (a.cap >> 6) + (Y >> 6)] >> (Y & 63)) & 1ull);
-                if (d >= 0 && el) cs::atomic_add_i32(a.rule_dom_nodes + a.rule_off[r] + d, -1);
+                if (d >= 0 && el && !(a.rule_ghost && a.rule_ghost[r])) cs::atomic_add_i32(a.rule_dom_nodes + a.rule_off[r] + d, -1);   // (a ghost that left already stays out)
             }
             for (int w = (Y >> 6) + 1 + tid; w < nw; w += T) wpre[w] -= 1u;   // one live node less in front of these words
             n_alive--; any_dead = true;
         } else {
             // Revert: touched nodes get their committed state back, the candidate its pods and its place
-            for (int r = tid; r < n_rules; r += T) {   // the candidate gets its pods back
+            for (int r = tid; r < n_rules; r += T) {   // the candidate gets its pods back, and its place in the domains it left
                 const int32_t d = a.node_domain[(int64_t)a.rule_key[r] * N + Y], v = cs::load_relaxed_i32(a.rule_contrib + (int64_t)r * N + Y);
                 if (d >= 0 && v != 0) cs::atomic_add_i32(a.rule_cnt + a.rule_off[r] + d, v);
+                if (a.rule_ghost && a.rule_ghost[r] && d >= 0) {
+                    const int row = a.rule_elig_row[r];
+                    const bool el = row < 0 || ((a.rule_elig[(int64_t)row * (a.cap >> 6) + (Y >> 6)] >> (Y & 63)) & 1ull);
+                    if (el) cs::atomic_add_i32(a.rule_dom_nodes + a.rule_off[r] + d, 1);
+                }
             }
             for (int i = tid; i < n_listed; i += T) {
                 const int m = a.node_out[slot_of(i)];
@@ -859,9 +872,10 @@ public:
         const casim_domain_rules* dr = q->rules;
         if (dr && dr->n_rules > 0) {
             if (dr->n_nodes != N_ || dr->n_classes != C_) return fail(CASIM_ERR_INVALID, "domain rules were built for other tables");
-            // nodeTaintsPolicy: Honor + removal simulation: the ghost node's ToBeDeleted taint would have to leave / rejoin
-            // the domains inside every transaction — not encoded, the caller runs the reference path
-            if (K_ > 0 && dr->n_taint_policy_rules > 0) return CASIM_NG_UNSUPPORTED;
+            // nodeTaintsPolicy: Honor + removal simulation: the ghost's ToBeDeleted taint takes it out of the domains of such rules
+            // for the length of its transaction (rule_ghost_leaves, written by the encoder); tables from an encoder that does not
+            // provide the column keep being delegated
+            if (K_ > 0 && dr->n_taint_policy_rules > 0 && !dr->rule_ghost_leaves) return CASIM_NG_UNSUPPORTED;
             for (int c = 0; c < C_; ++c)
                 if (dr->class_rule_off[c + 1] - dr->class_rule_off[c] > kMaxRulesPerClass) return CASIM_NG_UNSUPPORTED;
             const size_t NR = (size_t)dr->n_rules, tot = (size_t)dr->rule_offset[NR];
@@ -870,6 +884,7 @@ public:
             a_.rule_key = up(dr->rule_key, NR); a_.rule_kind = up(dr->rule_kind, NR); a_.rule_max_skew = up(dr->rule_max_skew, NR);
             a_.rule_min_domains = up(dr->rule_min_domains, NR); a_.rule_self = up(dr->rule_self, NR); a_.rule_elig_row = up(dr->rule_elig_row, NR);
             a_.rule_off = up(dr->rule_offset, NR + 1);
+            a_.rule_ghost = (K_ > 0 && dr->rule_ghost_leaves && dr->n_taint_policy_rules > 0) ? up(dr->rule_ghost_leaves, NR) : nullptr;
             d_rule_init_ = up(dr->count_init, tot); rule_total_ = (int64_t)tot;
             a_.rule_cnt = (int32_t*)dalloc(4 * tot);
             d_dom_init_ = up(dr->domain_nodes, tot);

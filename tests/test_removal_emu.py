@@ -261,3 +261,30 @@ def test_fuzz_atomic_candidates(seed):
     case.max_removable = rng.randint(1, 3)
     case.atomic = [1 if rng.random() < 0.4 else 0 for _ in case.candidates]
     check(case, w.name)
+
+
+@pytest.mark.parametrize("seed", range(200))
+def test_fuzz_node_taints_policy_honor_in_the_removal_loop(seed):
+    """Spread constraints with nodeTaintsPolicy: Honor inside removal transactions: the candidate's ghost carries the
+    ToBeDeletedByClusterAutoscaler taint for the length of its simulation (cluster.go:240-252), so it is no member of such a rule's
+    domains unless the pod tolerates it — it leaves on Fork, rejoins on Revert, stays out on Commit."""
+    import dataclasses
+    import random
+    from kubernetes_autoscaler_amd.objects import Taint, Toleration
+    from kubernetes_autoscaler_amd.workloads import fuzz_removals_domains
+    w = fuzz_removals_domains(9000 + seed)
+    rng = random.Random(77 + seed)
+    for info in w.nodes:
+        if rng.random() < 0.2:
+            info.node.taints.append(Taint("dedicated", "x", rng.choice(["NoSchedule", "NoExecute", "PreferNoSchedule"])))
+    plan = {}
+    for info in w.nodes:
+        for p in info.pods:
+            k = p.spec_key()
+            if k not in plan:
+                tol = rng.choice([[], [], [Toleration("dedicated", "Equal", "x", "")], [Toleration("", "Exists", "", "")],
+                                  [Toleration("ToBeDeletedByClusterAutoscaler", "Exists", "", "NoSchedule")]])
+                plan[k] = (tol, [dataclasses.replace(c, node_taints_policy=("Honor" if rng.random() < 0.7 else "Ignore"),
+                                                     node_affinity_policy=("Ignore" if rng.random() < 0.3 else "Honor")) for c in p.spread_constraints])
+            p.tolerations, p.spread_constraints = list(plan[k][0]), list(plan[k][1])
+    check(case_of(w), w.name)
