@@ -117,6 +117,46 @@ CS_GLOBAL void feas_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg]*/,
     if (cs::lane() == 0 && (k >> 6) < Wg) bits[(int64_t)ng * Wg + (k >> 6)] = b;
 }
 
+// K_feas, simulation-major form for batches: grid = (ceil(L/256), n_sims).  A thread keeps ONE PEG record in registers and walks the
+// node groups of its simulation (group records are wave-uniform: scalar loads), one ballot word per group.  The group-major
+// kernel above re-read every PEG record once per group and launched 20x the blocks: 0.29 ms of a 2.0 ms step at 4096 C2
+// simulations (profiles/r02a_rocpd_summary.txt).  Requires every group of a simulation to share its PEG range and mask widths <= 1
+// word (checked by the host, which falls back to feas_kernel otherwise).
+CS_GLOBAL void feas_sim_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg]*/, int Wg) {
+    const int sim = cs::bid_y();
+    const int g0 = t.sim_off[sim], g1 = t.sim_off[sim + 1];
+    if (g1 <= g0) return;
+    const int lo = t.peg_lo[g0], hi = t.peg_hi[g0];
+    const int k = cs::bid() * cs::nthreads() + cs::tid();
+    const bool live = lo + k < hi;
+    const int g = live ? lo + k : (hi > lo ? lo : 0);
+    // the PEG record, once
+    int64_t req[CASIM_KMAX_RES];
+    bool all_zero = true;
+    for (int r = 0; r < CASIM_KMAX_RES; ++r) { req[r] = (live && r < t.R) ? t.req[(int64_t)g * t.R + r] : 0; all_zero = all_zero && req[r] == 0; }
+    const uint32_t pf = live ? t.pflags[g] : 0u;
+    const uint64_t tol = (live && t.Wt) ? t.tol[(int64_t)g * t.Wt] : 0ull, sel = (live && t.Wl) ? t.sel[(int64_t)g * t.Wl] : 0ull;
+    const uint64_t xb = (live && t.Wx) ? t.xblock[(int64_t)g * t.Wx] : 0ull, zb = (live && t.Wz) ? t.zblock[(int64_t)g * t.Wz] : 0ull;
+    for (int ng = g0; ng < g1; ++ng) {
+        // wave-uniform group record
+        bool ok = live;
+        if (t.Wt) ok = ok && (t.taint[(int64_t)ng * t.Wt] & ~tol) == 0;
+        if (t.Wl) ok = ok && (sel & ~t.label[(int64_t)ng * t.Wl]) == 0;
+        if ((t.gflags[ng] & CASIM_NG_UNSCHEDULABLE) && !(pf & CASIM_PEG_TOLERATES_UNSCHEDULABLE)) ok = false;
+        ok = ok && t.allowed[ng] - t.init_pods[ng] > 0;                     // fitsRequest: pod count first (fit.go:681-690)
+        if (!all_zero)
+            for (int r = 0; r < CASIM_KMAX_RES; ++r) {
+                if (r >= t.R) break;
+                const int64_t fr = t.alloc[(int64_t)ng * t.R + r] - t.init_req[(int64_t)ng * t.R + r];
+                ok = ok && (req[r] <= 0 || req[r] <= fr);                      // every requested lane fits once (:699-752)
+            }
+        if (t.Wx) ok = ok && (xb & t.init_excl[(int64_t)ng * t.Wx]) == 0;
+        if (t.Wz) ok = ok && (zb & t.init_zone[(int64_t)ng * t.Wz]) == 0;
+        const uint64_t b = cs::ballot(ok);
+        if (cs::lane() == 0 && (k >> 6) < Wg) bits[(int64_t)ng * Wg + (k >> 6)] = b;
+    }
+}
+
 // K_reason: the SchedulingError of every cell of the SchedulablePodGroups matrix (see casim_feasibility_reasons): first
 // failing Filter plugin in the scheduler's Filter order + the reasons of NodeResourcesFit.  Same geometry as K_feas.
 CS_DEVICE uint32_t fresh_node_verdict(const DevTables& t, const uint64_t* CS_RESTRICT port_block, int g, int ng) {
@@ -359,7 +399,8 @@ CS_GLOBAL void order_kernel(DevTables t, DevResults res, OrderScratch os) {
         const int g = t.peg_idx[off + pos[src]];
         res.order[off + i] = g;
         res.s_count[off + i] = t.count[g];
-        res.s_flags[off + i] = (t.pflags[g] & ~CASIM_KFLAG_STATIC_OK) | (static_filters_pass(t, g, ng) ? CASIM_KFLAG_STATIC_OK : 0u);
+        // (lists derived by the feasibility kernel only hold PEGs that passed these Filters already)
+        res.s_flags[off + i] = (t.pflags[g] & ~CASIM_KFLAG_STATIC_OK) | ((t.lists_from_feas || static_filters_pass(t, g, ng)) ? CASIM_KFLAG_STATIC_OK : 0u);
         // request lanes in the form the packer of this batch reads: scaled int32 (register packer) or int64
         if (res.s_req32) { for (int r = 0; r < t.R; ++r) res.s_req32[(int64_t)(off + i) * t.R + r] = res.req32[(int64_t)g * t.R + r]; }
         else { for (int r = 0; r < t.R; ++r) res.s_req[(int64_t)(off + i) * t.R + r] = t.req[(int64_t)g * t.R + r]; }

@@ -123,6 +123,7 @@ public:
         dt_.global_id = g->global_id ? up(g->global_id, NG) : nullptr;
         // ---- schedulable subsets ----
         csr_on_device_ = g->peg_offsets == nullptr;
+        dt_.lists_from_feas = csr_on_device_ ? 1 : 0;
         std::vector<int64_t> pods_of_group(NG, 0);  // sum of max(count, 1) over the group's PEGs (node bound)
         std::vector<int32_t> pegs_of_group(NG, 0);
         if (!csr_on_device_) {
@@ -157,6 +158,11 @@ public:
             }
             if (cap > 0x7fffffffll) return fail(CASIM_ERR_INVALID, "sum of candidate PEG ranges too large for device-side CSR");
             nnz_cap_ = (int32_t)cap; feas_len_ = lmax;
+            // simulation-major feasibility kernel: every group of a simulation shares its PEG range, one word per mask kind
+            feas_by_sim_ = n_sims_ > 0 && dt_.Wt <= 1 && dt_.Wl <= 1 && dt_.Wx <= 1 && dt_.Wz <= 1;
+            for (int32_t si = 0; si < n_sims_ && feas_by_sim_; ++si)
+                for (int32_t i = g->sim_offsets[si] + 1; i < g->sim_offsets[si + 1]; ++i)
+                    if (lo[(size_t)i] != lo[(size_t)g->sim_offsets[si]] || hi[(size_t)i] != hi[(size_t)g->sim_offsets[si]]) { feas_by_sim_ = false; break; }
             Wg_ = (lmax + 63) / 64;
             dt_.peg_lo = up(lo.data(), NG); dt_.peg_hi = up(hi.data(), NG);   // (copied into the staging buffer: lo / hi may die)
             d_bits_ = (uint64_t*)dalloc(sizeof(uint64_t) * NG * (size_t)(Wg_ > 0 ? Wg_ : 1));
@@ -277,7 +283,10 @@ public:
     // ---- launch sequence ----------------------------------------------------------------
     int32_t run_feasibility() {
         if (!csr_on_device_ || NG_ == 0) return CASIM_OK;
-        if (feas_len_ > 0) bk_.launch(feas_kernel, (feas_len_ + 255) / 256, NG_, 256, (size_t)0, dt_, d_bits_, Wg_);
+        if (feas_len_ > 0) {
+            if (feas_by_sim_) bk_.launch(feas_sim_kernel, (feas_len_ + 255) / 256, n_sims_, 256, (size_t)0, dt_, d_bits_, Wg_);
+            else bk_.launch(feas_kernel, (feas_len_ + 255) / 256, NG_, 256, (size_t)0, dt_, d_bits_, Wg_);
+        }
         // short rows (a simulation's few hundred PEGs): the row popcount is folded into the scan; long rows get a block each
         const bool fold = Wg_ <= 16;
         if (!fold) bk_.launch(csr_count_kernel, NG_, 1, 256, (size_t)64, (const uint64_t*)d_bits_, Wg_, d_counts_);
@@ -556,6 +565,7 @@ private:
     uint8_t* d_opt_set_ = nullptr; int32_t* d_opt_out_ = nullptr; int64_t* d_opt_key_ = nullptr; int64_t* d_opt_packed_ = nullptr;
     uint8_t* d_opt_valid_ = nullptr; size_t opt_cap_ = 0;
     int n_sims_ = 0, max_sim_groups_ = 0, feas_len_ = 0;
+    bool feas_by_sim_ = false;
     std::vector<int32_t> h_off_;
     bool h_off_fresh_ = false;
     char* up_dev_ = nullptr; char* up_host_ = nullptr; size_t up_cap_ = 0, up_used_ = 0;

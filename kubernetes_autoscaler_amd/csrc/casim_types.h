@@ -47,6 +47,7 @@ struct DevTables {
     const int32_t* global_id; // [NG] id of the group inside expander keys, or null = group_id_base + index
     const int32_t* sim_off;   // [n_sims + 1] groups of each simulation, or null = one simulation
     int32_t n_sims;
+    int32_t lists_from_feas;  // 1 = the per-group PEG lists come from the feasibility kernel: every listed PEG passed the template-level Filters
 };
 
 struct DevResults {
