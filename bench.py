@@ -486,7 +486,12 @@ def main():
                     roofline["issue_roofline"] = {"bound": "valu_issue", "valu_insts_per_launch": tr["valu_insts_per_launch"],
                                                   "salu_insts_per_launch": tr.get("salu_insts_per_launch"),
                                                   "cycles_per_valu_inst": cyc, "issue_time_ms": t_issue * 1e3,
-                                                  "frac": t_issue / (kms["pack_ms"] * 1e-3), "source": tr.get("run", "?")}
+                                                  "frac": t_issue / (kms["pack_ms"] * 1e-3), "clock_ghz_assumed": CLOCK_HZ / 1e9,
+                                                  "source": tr.get("run", "?")}
+                    if tr.get("effective_clock_ghz"):   # the chip clocks to its power budget: the same fraction at the measured clock
+                        ec = tr["effective_clock_ghz"]
+                        roofline["issue_roofline"]["effective_clock_ghz"] = ec
+                        roofline["issue_roofline"]["frac_at_effective_clock"] = tr["valu_insts_per_launch"] * cyc / (SIMDS * ec * 1e9) / (kms["pack_ms"] * 1e-3)
         except (OSError, ValueError, KeyError):
             pass
         extra = {"kernel_ms": kms, "pipeline_ms_hip_events": total_ms, "encode_s_python_mirror": t_encode, "upload_s": t_upload,

@@ -122,7 +122,10 @@ CS_GLOBAL void feas_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg]*/,
 // kernel above re-read every PEG record once per group and launched 20x the blocks: 0.29 ms of a 2.0 ms step at 4096 C2
 // simulations (profiles/r02a_rocpd_summary.txt).  Requires every group of a simulation to share its PEG range and mask widths <= 1
 // word (checked by the host, which falls back to feas_kernel otherwise).
-CS_GLOBAL void feas_sim_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg]*/, int Wg) {
+// req32 / fresh32 (optional): the gcd-scaled int32 lanes of the register packer (exact: the gcd divides every value of a lane),
+// two 32-bit compares per cell instead of 64-bit subtract + compare chains.
+CS_GLOBAL void feas_sim_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg]*/, int Wg, const int32_t* CS_RESTRICT req32,
+                               const int32_t* CS_RESTRICT fresh32) {
     const int sim = cs::bid_y();
     const int g0 = t.sim_off[sim], g1 = t.sim_off[sim + 1];
     if (g1 <= g0) return;
@@ -132,8 +135,13 @@ CS_GLOBAL void feas_sim_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg
     const int g = live ? lo + k : (hi > lo ? lo : 0);
     // the PEG record, once
     int64_t req[CASIM_KMAX_RES];
+    int32_t rq32[4] = {0, 0, 0, 0};
     bool all_zero = true;
-    for (int r = 0; r < CASIM_KMAX_RES; ++r) { req[r] = (live && r < t.R) ? t.req[(int64_t)g * t.R + r] : 0; all_zero = all_zero && req[r] == 0; }
+    const bool narrow = req32 != nullptr && t.R <= 4;
+    for (int r = 0; r < CASIM_KMAX_RES; ++r) {
+        if (narrow) { if (r < 4) { rq32[r] = (live && r < t.R) ? req32[(int64_t)g * t.R + r] : 0; all_zero = all_zero && rq32[r] == 0; } req[r] = 0; }
+        else { req[r] = (live && r < t.R) ? t.req[(int64_t)g * t.R + r] : 0; all_zero = all_zero && req[r] == 0; }
+    }
     const uint32_t pf = live ? t.pflags[g] : 0u;
     const uint64_t tol = (live && t.Wt) ? t.tol[(int64_t)g * t.Wt] : 0ull, sel = (live && t.Wl) ? t.sel[(int64_t)g * t.Wl] : 0ull;
     const uint64_t xb = (live && t.Wx) ? t.xblock[(int64_t)g * t.Wx] : 0ull, zb = (live && t.Wz) ? t.zblock[(int64_t)g * t.Wz] : 0ull;
@@ -144,12 +152,20 @@ CS_GLOBAL void feas_sim_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg
         if (t.Wl) ok = ok && (sel & ~t.label[(int64_t)ng * t.Wl]) == 0;
         if ((t.gflags[ng] & CASIM_NG_UNSCHEDULABLE) && !(pf & CASIM_PEG_TOLERATES_UNSCHEDULABLE)) ok = false;
         ok = ok && t.allowed[ng] - t.init_pods[ng] > 0;                     // fitsRequest: pod count first (fit.go:681-690)
-        if (!all_zero)
-            for (int r = 0; r < CASIM_KMAX_RES; ++r) {
-                if (r >= t.R) break;
-                const int64_t fr = t.alloc[(int64_t)ng * t.R + r] - t.init_req[(int64_t)ng * t.R + r];
-                ok = ok && (req[r] <= 0 || req[r] <= fr);                      // every requested lane fits once (:699-752)
+        if (!all_zero) {
+            if (narrow) {
+                for (int r = 0; r < 4; ++r) {
+                    if (r >= t.R) break;
+                    ok = ok && (rq32[r] <= 0 || rq32[r] <= fresh32[(int64_t)ng * t.R + r]);
+                }
+            } else {
+                for (int r = 0; r < CASIM_KMAX_RES; ++r) {
+                    if (r >= t.R) break;
+                    const int64_t fr = t.alloc[(int64_t)ng * t.R + r] - t.init_req[(int64_t)ng * t.R + r];
+                    ok = ok && (req[r] <= 0 || req[r] <= fr);                  // every requested lane fits once (:699-752)
+                }
             }
+        }
         if (t.Wx) ok = ok && (xb & t.init_excl[(int64_t)ng * t.Wx]) == 0;
         if (t.Wz) ok = ok && (zb & t.init_zone[(int64_t)ng * t.Wz]) == 0;
         const uint64_t b = cs::ballot(ok);

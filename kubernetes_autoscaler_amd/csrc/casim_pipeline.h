@@ -284,7 +284,8 @@ public:
     int32_t run_feasibility() {
         if (!csr_on_device_ || NG_ == 0) return CASIM_OK;
         if (feas_len_ > 0) {
-            if (feas_by_sim_) bk_.launch(feas_sim_kernel, (feas_len_ + 255) / 256, n_sims_, 256, (size_t)0, dt_, d_bits_, Wg_);
+            if (feas_by_sim_) bk_.launch(feas_sim_kernel, (feas_len_ + 255) / 256, n_sims_, 256, (size_t)0, dt_, d_bits_, Wg_,
+                                         fast_npt_ > 0 ? fs_.req32 : (const int32_t*)nullptr, fast_npt_ > 0 ? fs_.fresh32 : (const int32_t*)nullptr);
             else bk_.launch(feas_kernel, (feas_len_ + 255) / 256, NG_, 256, (size_t)0, dt_, d_bits_, Wg_);
         }
         // short rows (a simulation's few hundred PEGs): the row popcount is folded into the scan; long rows get a block each

@@ -43,6 +43,19 @@ for key, counter in (("valu_insts_per_launch", "SQ_INSTS_VALU"), ("salu_insts_pe
         rec[key] = r["kib"]
 if rec.get("valu_insts_per_launch") and rec.get("active_inst_valu_quadcycles"):
     rec["cycles_per_valu"] = 4.0 * rec["active_inst_valu_quadcycles"] / rec["valu_insts_per_launch"]
+# effective shader clock during the kernel: GRBM_GUI_ACTIVE cycles of the dispatch / its duration (same pass, same dispatches)
+g = per_launch("GRBM_GUI_ACTIVE")
+if g and g["grid_x"] == f["grid_x"]:
+    for db_path in glob.glob(os.path.join(root, "prof_pmc_SQ*", "**", "*.db"), recursive=True):
+        try:
+            cur = sqlite3.connect(db_path).cursor()
+            row = cur.execute("select avg(duration) from kernels where name like '%pack%' and grid_x = ?", (g["grid_x"],)).fetchone()
+            if row and row[0]:
+                rec["gui_active_cycles_per_launch"] = g["kib"]
+                rec["kernel_ns_in_the_counter_pass"] = float(row[0])
+                rec["effective_clock_ghz"] = g["kib"] / float(row[0])
+        except sqlite3.Error:
+            pass
 # calibration of the FETCH_SIZE rule on known streams (casim_stream_probe: 4 B / lane and 16 B / lane reads of 1 GiB)
 cal = {}
 for width in (4, 16):
