@@ -488,7 +488,10 @@ typedef struct casim_removal_candidates {
     const uint8_t* cand_atomic;      /* [K] or NULL: 1 = node of an atomically scaled group (ZeroOrMaxNodeScaling): its
                                       * removal does not count toward max_removable (planner.go:306, :321-324) */
     int32_t persist;                 /* canPersist */
-    int32_t max_removable;           /* stop after this many removable nodes (unneededNodesLimit); 0 = no limit */
+    int32_t max_removable;           /* stop after this many removable nodes (what is LEFT of unneededNodesLimit);
+                                      * <= 0 = no limit.  A limit that is already used up (planner.go:303 breaks before
+                                      * the first candidate, also when unneededNodesLimit() is 0) is the caller's early
+                                      * return: there is nothing to simulate, so no call is made */
     int32_t last_index;
     int32_t ext_capacity;            /* entries of the ext_* result arrays; 0 = stop at the first candidate with arrivals */
     const struct casim_domain_rules* rules; /* the encoder's domain rules (PodTopologySpread, zone anti-affinity); NULL = none */

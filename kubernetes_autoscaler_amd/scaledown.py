@@ -107,11 +107,12 @@ class RemovalSimulator:
             raise UnsupportedPredicate("pods to move need a predicate outside the encoded subset")
         return res, off
 
-    def simulate_node_removals(self, candidates: Sequence[str], destinations: Dict[str, bool], max_removable: int = 0,
-                               is_atomic: Optional[Callable[[str], bool]] = None):
+    def simulate_node_removals(self, candidates: Sequence[str], destinations: Dict[str, bool],
+                               max_removable: Optional[int] = None, is_atomic: Optional[Callable[[str], bool]] = None):
         """The categorizeNodes loop (planner.go:300-330): SimulateNodeRemoval per candidate in order, successful
         simulations persisted when `can_persist`, the removed node dropped from `destinations` (:318).
-        `max_removable` = unneededNodesLimit(); nodes for which `is_atomic(name)` holds (their group scales to zero or
+        `max_removable` = unneededNodesLimit(), None for no limit; 0 is a real limit and stops the loop before the
+        first candidate (planner.go:303 compares `>=`).  Nodes for which `is_atomic(name)` holds (their group scales to zero or
         max, atomicScaleDownNode :339-357) do not count toward it.
         Returns (removable: List[NodeToBeRemoved], unremovable: List[UnremovableNode], skipped: names not evaluated)."""
         removable: List[NodeToBeRemoved] = []
@@ -119,7 +120,7 @@ class RemovalSimulator:
         todo = list(candidates)
         counted = 0   # len(removableList) - atomicScaleDownNodesCount
         while todo:
-            if max_removable > 0 and counted >= max_removable:
+            if max_removable is not None and counted >= max_removable:
                 break
             by_name = {info.node.name: info for info in self.snapshot}
             # GetPodsToMove on the CURRENT snapshot; a node blocked by a pod never reaches the device
@@ -136,7 +137,8 @@ class RemovalSimulator:
                 else:   # cluster.go:138-146: not in the snapshot, decided before any simulation
                     unremovable.append(UnremovableNode(Node(name=n), NO_NODE_INFO))
                 continue
-            left = (max_removable - counted) if max_removable > 0 else 0
+            # the ABI field counts what is LEFT and keeps 0 for "no limit": a limited call always has left >= 1 here
+            left = (max_removable - counted) if max_removable is not None else 0
             infos = list(self.snapshot)   # node indices of this call refer to this list
             atomic = [1 if is_atomic(n) else 0 for n in names[:cut]] if is_atomic is not None else None
             res, off = self._submit(names[:cut], lists[:cut], destinations, left, atomic)
@@ -213,7 +215,7 @@ class Planner:
         return min(upper, limit)
 
     def update_cluster_state(self, pod_destinations: Sequence[str], eligible_candidates: Sequence[str],
-                             recent_evictions: Sequence[Pod] = (), unneeded_nodes_limit: int = 0,
+                             recent_evictions: Sequence[Pod] = (), unneeded_nodes_limit: Optional[int] = None,
                              is_atomic: Optional[Callable[[str], bool]] = None):
         """Returns (removable, unremovable, skipped) of the categorizeNodes loop."""
         self.inject_pods(recent_evictions)

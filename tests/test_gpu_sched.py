@@ -278,7 +278,7 @@ def test_removal_mirror_planner_loop(ctx):
         sim = RemovalSimulator(ctx, nodes, persist_successful_simulations=True)
         sim.last_index = w.last_index
         dest = {info.node.name: (w.destination is None or bool(w.destination[i])) for i, info in enumerate(w.nodes)}
-        removable, unremovable, skipped = sim.simulate_node_removals([w.nodes[c].node.name for c in w.candidates], dest, w.max_removable)
+        removable, unremovable, skipped = sim.simulate_node_removals([w.nodes[c].node.name for c in w.candidates], dest, w.max_removable or None)   # the fuzz rows keep the ABI's 0 = no limit
         assert [r.node.name for r in removable] == [w.nodes[c].node.name for k, c in enumerate(w.candidates) if want["removable"][k] == 1]
         assert [u.node.name for u in unremovable] == [w.nodes[c].node.name for k, c in enumerate(w.candidates) if want["removable"][k] == 0]
         assert sim.last_index == want["last_index"] and sim.device_calls <= 1

@@ -109,7 +109,7 @@ def test_mirror_equals_the_reference_loop(seed, mode):
                            ext_capacity=0 if mode == "resubmit-at-arrivals" else None)
     sim.last_index = w.last_index
     dest = {info.node.name: (w.destination is None or bool(w.destination[i])) for i, info in enumerate(w.nodes)}
-    removable, unremovable, skipped = sim.simulate_node_removals([w.nodes[c].node.name for c in w.candidates], dest, w.max_removable)
+    removable, unremovable, skipped = sim.simulate_node_removals([w.nodes[c].node.name for c in w.candidates], dest, w.max_removable or None)   # the fuzz rows keep the ABI's 0 = no limit
     want_removable = [w.nodes[c].node.name for k, c in enumerate(w.candidates) if rem[k] == 1]
     want_unremovable = [w.nodes[c].node.name for k, c in enumerate(w.candidates) if rem[k] == 0]
     assert [r.node.name for r in removable] == want_removable
@@ -242,6 +242,19 @@ def test_reference_unneeded_nodes_limit_table(row):
         names, names, (), limit, (lambda n: True) if row["atomic"] else None)
     assert len(removable) == row["want_unneeded"] and not unremovable
     assert skipped == names[row["want_unneeded"]:]
+
+
+def test_a_limit_of_zero_skips_every_candidate():
+    """planner.go:303: `len(removableList)-atomic >= unneededNodesLimit` holds before the first candidate when the limit
+    is 0 (no parallelism, nothing previously unneeded); None is the mirror's spelling of "no limit"."""
+    from kubernetes_autoscaler_amd.objects import build_test_node
+    from kubernetes_autoscaler_amd.scaledown import Planner
+    assert Planner.unneeded_nodes_limit(0, 0, 600.0, 10.0) == 0
+    for limit, want in ((0, 0), (None, 5), (2, 2)):
+        infos = [NodeInfo(build_test_node(f"n{i}", 1000, 10)) for i in range(5)]
+        names = [i.node.name for i in infos]
+        removable, unremovable, skipped = Planner(EmuContext(0), infos).update_cluster_state(names, names, (), limit)
+        assert len(removable) == want and not unremovable and skipped == names[want:]
 
 
 def test_atomic_candidates_do_not_count_toward_the_limit():
