@@ -43,6 +43,10 @@ CS_DEVICE uint64_t wave_sum_u64(uint64_t v) { return casim_emu::wave_sum_u64(v);
 CS_DEVICE uint32_t wave_max_u32(uint32_t v) { return (uint32_t)casim_emu::wave_max_u64(v); }
 CS_DEVICE uint32_t bcast_u32(uint32_t v, int uniform_lane) { return (uint32_t)casim_emu::wave_xchg_u64(v, uniform_lane); }
 CS_DEVICE uint32_t uniform_u32(uint32_t v) { return v; }
+template <int N> struct Words { uint32_t w[N]; };
+template <int N> CS_DEVICE Words<N> const_load(const uint32_t* p) { Words<N> r; memcpy(r.w, p, 4 * N); return r; }
+CS_DEVICE bool lane_pred(uint64_t mask) { return ((mask >> (casim_emu::cur().tid & 63)) & 1ull) != 0; }
+CS_DEVICE void write_lane_u32(uint32_t& v, uint32_t uniform_value, int uniform_lane) { if ((casim_emu::cur().tid & 63) == uniform_lane) v = uniform_value; }
 CS_DEVICE int popc64(uint64_t v) { return __builtin_popcountll(v); }
 CS_DEVICE int ffs64(uint64_t v) { return v ? __builtin_ctzll(v) : -1; }
 CS_DEVICE int fls64(uint64_t v) { return v ? 63 - __builtin_clzll(v) : -1; }
@@ -127,6 +131,28 @@ CS_DEVICE uint64_t wave_sum_u64(uint64_t v) {
 CS_DEVICE uint32_t bcast_u32(uint32_t v, int uniform_lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, uniform_lane); }
 // a value every lane holds identically (e.g. an LDS word read at a wave-uniform address): move it to a scalar register
 CS_DEVICE uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// N (8 or 16) consecutive dwords at a wave-UNIFORM address, written by an EARLIER kernel: ONE scalar load (s_load_dwordxN
+// through the constant cache) straight into scalar registers — no VALU, no LDS, and it can be issued a loop iteration
+// ahead.  The data must not be written by the kernel that reads it this way (constant address space semantics).
+template <int N> struct Words { uint32_t w[N]; };
+template <int N> CS_DEVICE Words<N> const_load(const uint32_t* p) {
+    Words<N> r;
+    if constexpr (N == 1) r.w[0] = *(const __attribute__((address_space(4))) uint32_t*)p;
+    else {
+        typedef uint32_t vec_t __attribute__((ext_vector_type(N)));
+        const vec_t v = *(const __attribute__((address_space(4))) vec_t*)p;
+#pragma unroll
+        for (int i = 0; i < N; ++i) r.w[i] = v[i];
+    }
+    return r;
+}
+// my lane's bit of a wave-uniform lane mask as a predicate: the mask register pair IS the condition (no VALU)
+CS_DEVICE bool lane_pred(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+// v[uniform_lane] = uniform_value: one v_writelane_b32 instead of lane-compare + select + move
+CS_DEVICE void write_lane_u32(uint32_t& v, uint32_t uniform_value, int uniform_lane) {
+    // (one scalar register per VALU instruction on gfx9: the lane select travels in M0)
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(uniform_value), "s"(uniform_lane) : "m0");
+}
 CS_DEVICE int popc64(uint64_t v) { return __popcll(v); }
 CS_DEVICE int ffs64(uint64_t v) { return v ? (int)__builtin_ctzll(v) : -1; }
 CS_DEVICE int fls64(uint64_t v) { return v ? 63 - (int)__builtin_clzll(v) : -1; }

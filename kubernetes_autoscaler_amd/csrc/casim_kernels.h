@@ -341,6 +341,8 @@ CS_DEVICE int32_t fastpath_saved(const DevTables& t, int g, int ng) {
     return nodes > 0 ? n - n / nodes : 0;
 }
 
+struct alignas(16) RecQuad { uint32_t a, b, c, d; };
+template <int N> struct IntTag { static constexpr int value = N; };
 // One block (256 threads) per group.  Bitonic sort of (key, position) pairs in LDS, or in an
 // HBM scratch slab when the group's PEG list does not fit (kLds == false).
 template <bool kLds>
@@ -414,12 +416,46 @@ CS_GLOBAL void order_kernel(DevTables t, DevResults res, OrderScratch os) {
         // (PEG, group): evaluate them once here and hand them over as one flag bit.
         const int g = t.peg_idx[off + pos[src]];
         res.order[off + i] = g;
-        res.s_count[off + i] = t.count[g];
         // (lists derived by the feasibility kernel only hold PEGs that passed these Filters already)
-        res.s_flags[off + i] = (t.pflags[g] & ~CASIM_KFLAG_STATIC_OK) | ((t.lists_from_feas || static_filters_pass(t, g, ng)) ? CASIM_KFLAG_STATIC_OK : 0u);
-        // request lanes in the form the packer of this batch reads: scaled int32 (register packer) or int64
-        if (res.s_req32) { for (int r = 0; r < t.R; ++r) res.s_req32[(int64_t)(off + i) * t.R + r] = res.req32[(int64_t)g * t.R + r]; }
-        else { for (int r = 0; r < t.R; ++r) res.s_req[(int64_t)(off + i) * t.R + r] = t.req[(int64_t)g * t.R + r]; }
+        const uint32_t flags = (t.pflags[g] & ~CASIM_KFLAG_STATIC_OK) | ((t.lists_from_feas || static_filters_pass(t, g, ng)) ? CASIM_KFLAG_STATIC_OK : 0u);
+        if (res.rec) {
+            // register packer: one record (casim_types.h) = everything the packer needs to know about the PEG, computed HERE
+            // by the record's own thread — the scaled requests, their reciprocals (the packer's quotient estimate) and how
+            // many pods of the PEG fit an EMPTY node of this group (fitsRequest on the template, fit.go:681-765)
+            auto emit = [&](auto rl_tag) {   // (RL as a constant: the record is built in registers, not in a scratch array)
+                constexpr int RL = decltype(rl_tag)::value, DW = RL == 2 ? 8 : 16;
+                uint32_t w[DW];
+#pragma unroll
+                for (int k = 0; k < DW; ++k) w[k] = 0;
+                const int32_t slots = t.allowed[ng] - t.init_pods[ng];
+                uint32_t cf = slots > 0 ? (uint32_t)slots : 0u;
+                bool simple = true;
+#pragma unroll
+                for (int r = 0; r < RL; ++r) {
+                    const int32_t q = r < t.R ? res.req32[(int64_t)g * t.R + r] : 0;
+                    simple = simple && q > 0 && q < (1 << 30);
+                    w[2 + r] = (uint32_t)q;
+                    const uint64_t rq = cs::double_bits(q > 0 ? 1.0 / (double)q : 0.0);
+                    w[2 + RL + 2 * r] = (uint32_t)rq; w[2 + RL + 2 * r + 1] = (uint32_t)(rq >> 32);
+                    if (q > 0) {
+                        const int32_t f = res.fresh32[(int64_t)ng * t.R + r];
+                        const uint32_t e = f >= q ? (uint32_t)f / (uint32_t)q : 0u;
+                        cf = e < cf ? e : cf;
+                    }
+                }
+                w[0] = (uint32_t)t.count[g];
+                w[1] = (flags & (CASIM_REC_FLAG_MASK & ~(CASIM_REC_SIMPLE | CASIM_REC_A2_OK))) | (cf << CASIM_REC_FRESH_SHIFT) | (simple ? CASIM_REC_SIMPLE : 0u) |
+                       (((flags & CASIM_KFLAG_STATIC_OK) && t.count[g] > 0) ? CASIM_REC_A2_OK : 0u);
+                RecQuad* out = (RecQuad*)(res.rec + (int64_t)(off + i) * DW);   // 16-byte stores (records are 32 / 64 bytes)
+#pragma unroll
+                for (int k = 0; k < DW / 4; ++k) out[k] = RecQuad{w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]};
+            };
+            if (res.rec_dw == 8) emit(IntTag<2>{}); else emit(IntTag<4>{});
+        } else {
+            res.s_count[off + i] = t.count[g];
+            res.s_flags[off + i] = flags;
+            for (int r = 0; r < t.R; ++r) res.s_req[(int64_t)(off + i) * t.R + r] = t.req[(int64_t)g * t.R + r];
+        }
     }
     if (tid == 0) res.fast_last[ng] = best >= 0 ? 1 : 0;
 }

@@ -22,8 +22,11 @@
 //   RegStore<R, NPT>  node state in VGPRs as int32 (lanes pre-divided by their gcd on the host — exact,
 //                     see casim_pipeline.h), up to 64*NPT nodes, no exclusion bits: the fast path
 //   MemStore<kLds, RMAX>  int64 state in LDS (or an HBM slab), any R / node count / exclusion masks
-// PEG records arrive in processing order (written by order_kernel): 64 records per coalesced
-// wave-load, one per lane, broadcast field by field with v_readlane.
+// PEG records arrive in processing order (written by order_kernel).  Memory store: 64 records per coalesced
+// wave-load, one per lane, broadcast field by field with v_readlane.  Register store: ONE scalar load per PEG
+// (s_load_dwordx8 / x16 of the 32- or 64-byte record of casim_types.h, issued one PEG ahead) puts every field
+// straight into scalar registers: no VALU, no LDS (the record fetch was 31 % of the kernel's cycles as LDS reads +
+// v_readfirstlane, profiles/r02m_pack_phase_profile.txt).
 #pragma once
 #include "casim_device.h"
 #include "casim_types.h"
@@ -139,7 +142,7 @@ struct MemStore {
     static constexpr bool kHasExcl = true;
     static constexpr bool kHasZone = true;
     static constexpr int kZoneWords = 0;    // group-wide exclusion words live in LDS (per-lane copies), any number
-    static constexpr bool kChunkLds = false; // the 64 PEG records of a chunk stay in the lanes' registers
+    static constexpr int kRecDw = 0;        // PEG records: three arrays, 64 records per wave-load, fields broadcast by v_readlane
     using Peg = PegView<int64_t, RMAX_>;
     using Fresh = FreshNode<int64_t, RMAX_>;
     int R, Wx, cap;
@@ -195,10 +198,7 @@ struct RegStore {
     static constexpr bool X_ = WX_ > 0;
     static constexpr bool kHasZone = WX_ > 0;   // the lean instantiation (WX_ = 0) carries no exclusion state at all
     static constexpr int kZoneWords = 2;        // group-wide exclusion words are wave-uniform: up to two, in scalar registers
-    // The 64 PEG records of a chunk are parked in LDS ((4 + 3 R_) words per record, kChunkBytes per wave) and read back
-    // at a wave-uniform address: nine VGPRs less than keeping them in the lanes — what the 5th / 6th wave per SIMD needs.
-    static constexpr bool kChunkLds = true;
-    static constexpr int kChunkBytes = (4 + 3 * R_) * 64 * 4;
+    static constexpr int kRecDw = R_ <= 2 ? 8 : 16;   // PEG records: one scalar load of kRecDw dwords per PEG (casim_types.h)
     using Peg = PegView<int32_t, R_>;
     using Fresh = FreshNode<int32_t, R_>;
     int32_t fr[NPT_][R_];
@@ -222,14 +222,11 @@ struct RegStore {
     // merge point of the PEG loop with the rest of the state.
     // `act`: bit s set when some node of slot s takes a pod — the later passes skip the other slots (measured on C1:
     // 0.6 of the 4 slots per PEG).
-    CS_DEVICE int32_t capacity_all(const Peg& pv, uint32_t clampk, bool selfx, uint32_t* c, uint32_t& act) const {
+    CS_DEVICE int32_t capacity_all(const Peg& pv, uint32_t clampk, bool selfx, bool simple, uint32_t* c, uint32_t& act) const {
         act = 0;
-        // The common PEG asks for every lane and no request is huge: decided ONCE, so that the unrolled slots carry no
-        // per-lane branches (each wave-uniform branch costs scalar issue slots, and this kernel is bound by them as
-        // much as by the VALU: profiles/r01s_*).
-        bool simple = true;
-#pragma unroll
-        for (int r = 0; r < R_; ++r) simple = simple && pv.req[r] > 0 && pv.req[r] < (1 << 30);
+        // `simple`: the common PEG asks for every lane and no request is huge (CASIM_REC_SIMPLE, decided once by order_kernel),
+        // so that the unrolled slots carry no per-lane branches (each wave-uniform branch costs scalar issue slots, and this
+        // kernel is bound by them more than by the VALU: profiles/r01s_*, r02n_*).
         int32_t n1 = 0;
         if (simple) {
             // (self-exclusion is a PEG property: two copies of the sweep instead of three selects per slot)
@@ -237,29 +234,32 @@ struct RegStore {
                 constexpr bool kSelf = decltype(sx_tag)::value;
 #pragma unroll
                 for (int s = 0; s < NPT_; ++s) {
-                    // (bitwise &, and the wave mask as the AND of single-compare ballots: a ballot of a combined predicate
-                    // costs two extra VALU ops to re-normalise the mask)
-                    bool fit = slots[s] > 0;
+                    // the wave mask of "fits" as the AND of single-compare masks (each v_cmp writes its mask register pair);
+                    // inside the branch the mask IS the lane predicate again (cs::lane_pred) — carried across the branch as
+                    // a bool it was materialised in a VGPR and compared back (6 VALU per slot)
                     uint64_t fb = cs::ballot(slots[s] > 0);
-                    if (X_) { const bool nb = !blocked(s, pv); fit = fit & nb; fb &= cs::ballot(nb); }
+                    if (X_) fb &= cs::ballot(!blocked(s, pv));
 #pragma unroll
-                    for (int r = 0; r < R_; ++r) { fit = fit & (fr[s][r] >= pv.req[r]); fb &= cs::ballot(fr[s][r] >= pv.req[r]); }
+                    for (int r = 0; r < R_; ++r) fb &= cs::ballot(fr[s][r] >= pv.req[r]);
                     uint32_t k = 0;
                     if (fb) {  // wave-uniform
                         n1 += cs::popc64(fb);
                         act |= 1u << s;
+                        const bool fit = cs::lane_pred(fb);
                         if constexpr (kSelf) k = fit ? 1u : 0u;   // clampk >= 1, a pod slot is free and every lane fits once
                         else {
-                            k = fit ? ((uint32_t)slots[s] < clampk ? (uint32_t)slots[s] : clampk) : 0u;
+                            // (lanes that do not fit compute garbage and are masked at the end: no select per operand)
+                            k = (uint32_t)slots[s] < clampk ? (uint32_t)slots[s] : clampk;
 #pragma unroll
                             for (int r = 0; r < R_; ++r) {
                                 const int32_t q = pv.req[r];
-                                const uint32_t fpos = fit ? (uint32_t)fr[s][r] : 0u;
+                                const uint32_t fpos = (uint32_t)fr[s][r];
                                 uint32_t e = (uint32_t)((double)fpos * pv.rq[r]);
                                 const int32_t rem = (int32_t)(fpos - e * (uint32_t)q);   // wrapping 32-bit: it lies in (-q, 2q)
                                 e = e - ((uint32_t)rem >> 31) + (rem >= q ? 1u : 0u);    // exact +-1 fix-up: sign bit, carry-in
                                 k = e < k ? e : k;
                             }
+                            k = fit ? k : 0u;
                         }
                     }
                     c[s] = k;
@@ -399,9 +399,11 @@ struct PegChunk {
 template <class Store, class ReqLoader>
 CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, const typename Store::Fresh& fn,
                          uint64_t* szone /*[Wz][64] per-lane copies or null*/, ReqLoader load_req, const int64_t* sum_scale,
-                         int64_t* prof_out = nullptr, uint32_t* chunk = nullptr /*LDS, Store::kChunkLds only*/) {
+                         int64_t* prof_out = nullptr) {
     using L = typename Store::Lane;
     constexpr int RM = Store::kRMax;
+    constexpr int DW = Store::kRecDw;
+    constexpr bool kRecScalar = DW > 0;
     const int ng = cs::bid();
     const int lane = cs::lane();
     const int R = t.R;
@@ -449,27 +451,50 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     int32_t M = 0;                         // simulated nodes so far (estimationState.newNodeNameIndex)
     int32_t last_index = t.last_index[ng]; // lastIndexOrderMapping.lastIndex
     int32_t granted = 0;                   // limiter.nodes
-    bool more = true;                      // newNodesAvailable
+    // newNodesAvailable, as an all-ones / zero word: wave-uniform flags that live across PEGs are kept as integers and
+    // tested with integer arithmetic — as bools the compiler carries them as 64-bit lane masks (s_cselect_b64 / s_and_b64 /
+    // s_andn2 with exec / s_cbranch_vcc: 5-6 scalar instructions per test instead of 2-3, in a kernel bound by scalar issue)
+    int32_t more_mask = -1;
     int32_t fakes = 0;                     // fastpath fake nodes
     int32_t total_placed = 0;
 
     CASIM_PROF_DECL;
-    // ONE loop over the PEGs of the group: every 64th iteration loads the next chunk of records (a nested chunk / record
-    // loop made the compiler keep two copies of the node state, one per loop level, and shuffle ~70 registers per PEG).
+    // ONE loop over the PEGs of the group (a nested chunk / record loop made the compiler keep two copies of the node state,
+    // one per loop level, and shuffle ~70 registers per PEG).  Memory store: every 64th iteration loads the next chunk of
+    // records into the lanes.  Register store: record k + 1 is fetched by a scalar load while PEG k is simulated.
     int32_t my_cnt = 0, my_g = 0, my_placed = 0;
     uint32_t my_flags = 0, my_cf = 0;   // my_cf: pods of the record's PEG that fit an EMPTY node (state-independent)
     L my_req[RM];
     double my_rq[RM];
 #pragma unroll
     for (int r = 0; r < RM; ++r) { my_req[r] = 0; my_rq[r] = 0.0; }
+    const uint32_t* recp = nullptr;          // this group's records (register store)
+    const uint32_t* rp = nullptr;            // record of the current PEG
+    cs::Words<(DW > 0 ? DW : 1)> cur;
+    cur.w[0] = 0;
+    int32_t g_cur = 0;                       // the PEG's index into the mask tables (stores with exclusion state only)
+    constexpr bool kNeedG = Store::kHasExcl || Store::kHasZone;
+    // a2 is worth entering when the record says so (CASIM_REC_A2_OK) AND the group has simulated nodes AND its template is
+    // schedulable: the last two as a mask that is zero until the first node exists
+    const uint32_t a2_bit = group_unschedulable ? 0u : CASIM_REC_A2_OK;
+    uint32_t a2_gate = 0;
+    if constexpr (kRecScalar) {
+        recp = res.rec + (int64_t)off * DW; rp = recp;
+        // (the record array ends with one spare record: the load of record k + 1 needs no bound)
+        cur = cs::const_load<DW>(rp);
+        if (kNeedG) g_cur = (int32_t)cs::const_load<1>((const uint32_t*)res.order + off).w[0];
+    }
     // results of a finished chunk: placed[] (one coalesced wave-store per 64 PEGs) and each lane's share of the
     // sum(placed * request) totals — per lane and per chunk instead of two 64-bit scalar multiply-adds per PEG
     int64_t acc0 = 0, acc1 = 0;
     auto flush_chunk = [&](int kbase) {
-        if (kbase + lane < Gn) res.placed[off + kbase + lane] = my_placed;
+        const bool have = kbase + lane < Gn;
+        if (have) res.placed[off + kbase + lane] = my_placed;
         L r0, r1;
-        if constexpr (Store::kChunkLds) { r0 = (L)chunk[3 * 64 + lane]; r1 = RM > 1 ? (L)chunk[4 * 64 + lane] : (L)0; }
-        else { r0 = my_req[0]; r1 = RM > 1 ? my_req[1] : (L)0; }
+        if constexpr (kRecScalar) {   // the lane's own record, straight from memory (once per 64 PEGs)
+            r0 = have ? (L)recp[(int64_t)(kbase + lane) * DW + 2] : (L)0;
+            r1 = (have && RM > 1) ? (L)recp[(int64_t)(kbase + lane) * DW + 3] : (L)0;
+        } else { r0 = my_req[0]; r1 = RM > 1 ? my_req[1] : (L)0; }
         acc0 += (int64_t)my_placed * (int64_t)r0;   // lanes without a record hold my_placed == 0
         acc1 += (int64_t)my_placed * (int64_t)r1;
     };
@@ -478,20 +503,21 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
         if (j == 0) {
             CASIM_PROF(0);  // chunk load / store, loop overhead
             if (k > 0) flush_chunk(k - 64);
-            // ---- one coalesced wave-load: PEG record k+lane of this group, in processing order ----
-            const int kk = k + lane;
-            const bool have = kk < Gn;
-            my_cnt = have ? res.s_count[off + kk] : 0;
-            my_flags = have ? res.s_flags[off + kk] : 0u;
-            my_g = (have && (Store::kHasExcl || Store::kHasZone)) ? res.order[off + kk] : 0;   // (only the mask tables are indexed by it)
-#pragma unroll
-            for (int r = 0; r < RM; ++r) my_req[r] = (have && r < R) ? load_req(off + kk, r) : (L)0;
-            // 1 / req for capacity_lanes' quotient estimate: computed by the record's own lane, i.e. 64 PEGs'
-            // worth of f64 divisions per wave instruction instead of one uniform division per PEG
-#pragma unroll
-            for (int r = 0; r < RM; ++r) my_rq[r] = my_req[r] > 0 ? 1.0 / (double)my_req[r] : 0.0;
             my_placed = 0;
-            {   // capacity of a fresh node for the record's PEG, by the record's own lane: once per 64 PEGs instead of a
+            if constexpr (!kRecScalar) {
+                // ---- one coalesced wave-load: PEG record k+lane of this group, in processing order ----
+                const int kk = k + lane;
+                const bool have = kk < Gn;
+                my_cnt = have ? res.s_count[off + kk] : 0;
+                my_flags = have ? res.s_flags[off + kk] : 0u;
+                my_g = (have && kNeedG) ? res.order[off + kk] : 0;   // (only the mask tables are indexed by it)
+#pragma unroll
+                for (int r = 0; r < RM; ++r) my_req[r] = (have && r < R) ? load_req(off + kk, r) : (L)0;
+                // 1 / req for capacity_lanes' quotient estimate: computed by the record's own lane, i.e. 64 PEGs'
+                // worth of f64 divisions per wave instruction instead of one uniform division per PEG
+#pragma unroll
+                for (int r = 0; r < RM; ++r) my_rq[r] = my_req[r] > 0 ? 1.0 / (double)my_req[r] : 0.0;
+                // capacity of a fresh node for the record's PEG, by the record's own lane: once per 64 PEGs instead of a
                 // wave-uniform quotient chain in every a3
                 typename Store::Peg mine;
 #pragma unroll
@@ -499,30 +525,18 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 mine.xblock = nullptr; mine.xmark = nullptr; mine.xb[0] = mine.xb[1] = 0; mine.xm[0] = mine.xm[1] = 0;
                 my_cf = have ? capacity_lanes<L, RM>(fn.free, fn.slots, R, mine, 0x7fffffffu) : 0u;
             }
-            if constexpr (Store::kChunkLds) {
-                cs::sync();   // (one wave per block: orders the previous chunk's reads before these writes)
-                chunk[0 * 64 + lane] = (uint32_t)my_cnt; chunk[1 * 64 + lane] = my_flags; chunk[2 * 64 + lane] = (uint32_t)my_g;
-                chunk[(3 + 3 * RM) * 64 + lane] = my_cf;
-#pragma unroll
-                for (int r = 0; r < RM; ++r) {
-                    chunk[(3 + r) * 64 + lane] = (uint32_t)my_req[r];
-                    const uint64_t b = cs::double_bits(my_rq[r]);
-                    chunk[(3 + RM + 2 * r) * 64 + lane] = (uint32_t)b; chunk[(3 + RM + 2 * r + 1) * 64 + lane] = (uint32_t)(b >> 32);
-                }
-                cs::sync();
-            }
         }
         {
-            int32_t cnt; uint32_t pf;
+            int32_t cnt; uint32_t pf, cf_rec = 0;
             typename Store::Peg pv;
-            if constexpr (Store::kChunkLds) {
-                cnt = (int32_t)cs::uniform_u32(chunk[0 * 64 + j]);
-                pf = cs::uniform_u32(chunk[1 * 64 + j]);
+            if constexpr (kRecScalar) {
+                cnt = (int32_t)cur.w[0];
+                pf = cur.w[1];
+                cf_rec = (cur.w[1] >> CASIM_REC_FRESH_SHIFT) & CASIM_REC_FRESH_MAX;
 #pragma unroll
                 for (int r = 0; r < RM; ++r) {
-                    pv.req[r] = r < R ? (L)cs::uniform_u32(chunk[(3 + r) * 64 + j]) : (L)0;
-                    // (the reciprocal only ever is a VALU operand: it stays in the vector registers the LDS read filled)
-                    pv.rq[r] = cs::bits_double(((uint64_t)chunk[(3 + RM + 2 * r + 1) * 64 + j] << 32) | chunk[(3 + RM + 2 * r) * 64 + j]);
+                    pv.req[r] = (L)cur.w[2 + r];   // (lanes past R hold a zero request and a zero reciprocal)
+                    pv.rq[r] = cs::bits_double(((uint64_t)cur.w[2 + RM + 2 * r + 1] << 32) | cur.w[2 + RM + 2 * r]);
                 }
             } else {
                 cnt = (int32_t)cs::bcast_u32((uint32_t)my_cnt, j);
@@ -544,7 +558,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             const uint64_t *zblock = nullptr, *zmark = nullptr;
             if (Wx > 0 || Wz > 0) {
                 int g;
-                if constexpr (Store::kChunkLds) g = (int)cs::uniform_u32(chunk[2 * 64 + j]); else g = (int)cs::bcast_u32((uint32_t)my_g, j);
+                if constexpr (kRecScalar) g = g_cur; else g = (int)cs::bcast_u32((uint32_t)my_g, j);
                 pv.xblock = t.xblock + (int64_t)g * Wx; pv.xmark = t.xmark + (int64_t)g * Wx;
                 zblock = t.zblock + (int64_t)g * Wz; zmark = t.zmark + (int64_t)g * Wz;
                 if (Store::kNPT > 0 && Wx > 0) {   // register store: the words travel in SGPRs
@@ -563,7 +577,10 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             // RunFiltersUntilPassingNode skips Spec.Unschedulable nodes before any Filter runs, tolerated or
             // not (plugin_runner.go:108-110); every simulated node clones the template's flag.
             const uint32_t keff = (uint32_t)(zselfx ? (cnt > 0 ? 1 : 0) : cnt);
-            if (M > 0 && keff > 0 && static_ok && !zblocked && !group_unschedulable) {
+            bool a2_go;
+            if constexpr (kRecScalar) a2_go = (pf & a2_gate) != 0;
+            else a2_go = M > 0 && keff > 0 && static_ok && !group_unschedulable;
+            if (a2_go && !zblocked) {
                 // register stores of up to 4 slots walk all of them: slots past M hold zero state (c_j = 0, never a
                 // candidate, nothing committed), and a constant bound drops one scalar compare + branch per slot and pass
                 const int S = (Store::kNPT > 0 && Store::kNPT <= 4) ? Store::kNPT : (M + 63) >> 6;
@@ -585,7 +602,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     if constexpr (Store::kNPT > 0) return creg[s]; else return st.get_c(s, m);
                 };
                 if constexpr (Store::kNPT > 0) {
-                    n1 = st.capacity_all(pv, keff, selfx, creg, act);  // every slot (nodes >= M are all-zero)
+                    n1 = st.capacity_all(pv, keff, selfx, (pf & CASIM_REC_SIMPLE) != 0, creg, act);  // every slot (nodes >= M are all-zero)
                 } else {
                     for_slots<Store>(S, [&](int s) {
                         const int m = s * 64 + lane;
@@ -685,7 +702,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             CASIM_PROF(4);  // a2 passes B + C (rotated rank, commit)
             // ---- a3 / a4: tryToScheduleOnNewNodes (:190-269) or tryFastPath (:274-324) ----
             int32_t rem = cnt - placed;
-            if (rem > 0 && more) {
+            if ((rem & more_mask) > 0) {   // pods left && newNodesAvailable
                 zblocked = Wz > 0 && zone_blocked(zblock);
                 bool blocked = !static_ok || zblocked;
                 // capacity of a FRESH node for this PEG
@@ -695,7 +712,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     for (int w = 0; w < Wx; ++w) xb |= (fn.excl[w] & pv.xblock[w]) != 0;
                     if (!xb) {
                         uint32_t cf;
-                        if constexpr (Store::kChunkLds) cf = cs::uniform_u32(chunk[(3 + 3 * RM) * 64 + j]); else cf = cs::bcast_u32(my_cf, j);
+                        if constexpr (kRecScalar) cf = cf_rec; else cf = cs::bcast_u32(my_cf, j);
                         cfresh = cf < (uint32_t)rem ? cf : (uint32_t)rem;
                     }
                     if ((selfx || zselfx) && cfresh > 1) cfresh = 1;
@@ -724,7 +741,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
 
                 if (fast_last && k == Gn - 1) {
                     // tryFastPath: one simulated node, the rest by arithmetic
-                    if (permission_left() <= 0) more = false;
+                    if (permission_left() <= 0) more_mask = 0;
                     else {
                         granted++;
                         const uint32_t per = blocked ? 0u : (cfresh < (uint32_t)rem ? cfresh : (uint32_t)rem);
@@ -740,7 +757,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                             const int64_t fp = (int64_t)nf * per;
                             placed += (int32_t)(nf == want ? (int64_t)rem - per : fp);
                             fakes += nf; granted += nf;
-                            if (nf < want) more = false;
+                            if (nf < want) more_mask = 0;
                         }
                     }
                 } else {
@@ -767,7 +784,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     auto new_nodes = [&]() -> bool {   // false = done
                         const uint32_t cn = blocked ? 0u : cfresh;
                         if (cn == 0 || zselfx) {
-                            if (permission_left() <= 0) { more = false; return false; }       // :244-246
+                            if (permission_left() <= 0) { more_mask = 0; return false; }       // :244-246
                             granted++;
                             const uint32_t x = cn < (uint32_t)rem ? cn : (uint32_t)rem;  // 0 or 1
                             create_nodes(M, 1, x, (int32_t)x);
@@ -788,7 +805,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                                 create_nodes(M, nadd, cn, pl);
                                 M += nadd; granted += nadd; placed += pl; rem -= pl; marked = true;
                             }
-                            if (need > left) more = false;
+                            if (need > left) more_mask = 0;
                             return false;
                         }
                     };
@@ -796,11 +813,18 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     else { if (!stop) new_nodes(); }
                 }
                 if (marked && Wz > 0) zone_mark(zmark);
+                a2_gate = M > 0 ? a2_bit : 0u;
             }
 
             CASIM_PROF(5);  // a3 / a4
-            if (lane == j) my_placed = placed;
+            if constexpr (kRecScalar) { uint32_t mp = (uint32_t)my_placed; cs::write_lane_u32(mp, (uint32_t)placed, j); my_placed = (int32_t)mp; }
+            else { if (lane == j) my_placed = placed; }
             total_placed += placed;
+        }
+        if constexpr (kRecScalar) {   // record k + 1 into the registers record k just left (in flight across the loop edge)
+            rp += DW;
+            cur = cs::const_load<DW>(rp);
+            if (kNeedG) g_cur = (int32_t)cs::const_load<1>((const uint32_t*)res.order + off + k + 1).w[0];
         }
     }
     if (Gn > 0) flush_chunk((Gn - 1) & ~63);   // the last (possibly partial) chunk
@@ -834,11 +858,12 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
 }
 
 // a group carrying a PEG outside the encoded predicate subset is delegated (status only)
+template <int DW /* dwords of a PEG record, 0 = the three-array form */>
 CS_DEVICE bool pack_unsupported(const DevTables& t, const DevResults& res) {
     const int ng = cs::bid(), lane = cs::lane();
     const int off = t.peg_off[ng], Gn = t.peg_off[ng + 1] - off;
     bool bad = false;
-    for (int i = lane; i < Gn; i += 64) bad |= (res.s_flags[off + i] & CASIM_PEG_UNSUPPORTED) != 0;
+    for (int i = lane; i < Gn; i += 64) bad |= ((DW > 0 ? res.rec[(int64_t)(off + i) * DW + 1] : res.s_flags[off + i]) & CASIM_PEG_UNSUPPORTED) != 0;
     if (!cs::ballot(bad)) return false;
     for (int i = lane; i < Gn; i += 64) res.placed[off + i] = 0;
     if (lane == 0) {
@@ -852,7 +877,7 @@ CS_DEVICE bool pack_unsupported(const DevTables& t, const DevResults& res) {
 // ---- generic kernel: int64 state in LDS (kLds) or an HBM slab ------------------------------------
 template <bool kLds, int RMAX_>
 CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void pack_kernel(DevTables t, DevResults res, PackScratch ps) {
-    if (pack_unsupported(t, res)) return;
+    if (pack_unsupported<0>(t, res)) return;
     const int ng = cs::bid();
     const int R = t.R, Wx = t.Wx, Wz = t.Wz;
     MemStore<kLds, RMAX_> st;
@@ -878,7 +903,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void pack_kernel(DevTables t, DevResults res, 
 template <int R_, int NPT_, int WX_>
 // launch bounds: a floor of CASIM_FAST_WAVES waves per SIMD for the 256-node instantiation (see the note at the top)
 CS_GLOBAL CS_LAUNCH_BOUNDS(64, ((NPT_ == 4 && WX_ == 0) ? CASIM_FAST_WAVES : 1)) void pack_fast_kernel(DevTables t, DevResults res, FastScratch fs) {
-    if (pack_unsupported(t, res)) return;
+    if (pack_unsupported<RegStore<R_, NPT_, WX_>::kRecDw>(t, res)) return;
     const int ng = cs::bid();
     RegStore<R_, NPT_, WX_> st;
 #pragma unroll
@@ -896,10 +921,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, ((NPT_ == 4 && WX_ == 0) ? CASIM_FAST_WAVES : 1))
     st.fresh_slots = fn.slots;
     fn.excl = WX_ > 0 ? t.init_excl + (int64_t)ng * t.Wx : nullptr;
     st.wx = t.Wx < WX_ ? t.Wx : WX_;
-    const int32_t* s_req32 = res.s_req32;   // processing order: coalesced, no gather through `order`
-    const int R = t.R;
-    pack_body(t, res, st, fn, (uint64_t*)nullptr,
-              [=](int idx, int r) -> int32_t { return s_req32[(int64_t)idx * R + r]; }, fs.scale, fs.prof, (uint32_t*)cs::dyn_smem());
+    pack_body(t, res, st, fn, (uint64_t*)nullptr, [](int, int) -> int32_t { return 0; } /* (requests come with the records) */, fs.scale, fs.prof);
 }
 
 }  // namespace casim

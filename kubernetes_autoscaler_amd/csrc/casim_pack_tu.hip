@@ -17,7 +17,7 @@ namespace casim {
 // returns the HIP error of the launch (hipSuccess = 0)
 int hip_launch_pack_fast(int lanes, int slots_per_lane, int excl_words, int n_groups, void* stream, DevTables t, DevResults res, FastScratch fs) {
     if (n_groups <= 0) return 0;
-#define CASIM_TU_LAUNCH(R, N, X) pack_fast_kernel<R, N, X><<<dim3((unsigned)n_groups, 1, 1), dim3(64, 1, 1), (size_t)RegStore<R, N, X>::kChunkBytes, (hipStream_t)stream>>>(t, res, fs)
+#define CASIM_TU_LAUNCH(R, N, X) pack_fast_kernel<R, N, X><<<dim3((unsigned)n_groups, 1, 1), dim3(64, 1, 1), (size_t)0, (hipStream_t)stream>>>(t, res, fs)
 #define CASIM_TU_PICK(R, X) do { if (slots_per_lane == 1) CASIM_TU_LAUNCH(R, 1, X); else if (slots_per_lane == 4) CASIM_TU_LAUNCH(R, 4, X); else CASIM_TU_LAUNCH(R, 16, X); } while (0)
     if (lanes == 2) { if (excl_words == 2) CASIM_TU_PICK(2, 2); else CASIM_TU_PICK(2, 0); }
     else            { if (excl_words == 2) CASIM_TU_PICK(4, 2); else CASIM_TU_PICK(4, 0); }

@@ -197,6 +197,8 @@ public:
             for (size_t i = 0; i < NG; ++i) maxcap = cap[i] > maxcap ? cap[i] : maxcap;
             bool ok = o ? o->force_generic_packer == 0 : true;
             ok = ok && dt_.Wx <= 2 && dt_.Wz <= 2 && R <= 4 && maxcap <= 64 * 16 && NG > 0;
+            // (the PEG record carries the pods that fit an empty node in 23 bits: casim_types.h)
+            for (size_t i = 0; i < NG && ok; ++i) ok = (int64_t)g->allowed_pods[i] - (int64_t)g->init_pods[i] <= CASIM_REC_FRESH_MAX;
             bool zone_self = false;   // a PEG that excludes itself group-wide (anti-affinity on a non-hostname key)
             for (size_t i = 0; i < G; ++i) zone_self = zone_self || (p->flags[i] & CASIM_PEG_SELF_EXCL_ZONE) != 0;
             fast_wx_ = (dt_.Wx > 0 || dt_.Wz > 0 || zone_self) ? 2 : 0;   // lean instantiation, or the one with room for both kinds of words
@@ -263,11 +265,16 @@ public:
             os_.gbuf = (char*)dalloc((size_t)ototal);
         }
         // ---- results ----
-        dr_.order = (int32_t*)dalloc(4 * (size_t)nnz_cap_); dr_.placed = (int32_t*)dalloc(4 * (size_t)nnz_cap_);
+        dr_.order = (int32_t*)dalloc(4 * ((size_t)nnz_cap_ + 1)); dr_.placed = (int32_t*)dalloc(4 * (size_t)nnz_cap_);
         dr_.fast_last = (uint8_t*)dalloc(NG);
-        dr_.s_count = (int32_t*)dalloc(4 * (size_t)nnz_cap_); dr_.s_flags = (uint32_t*)dalloc(4 * (size_t)nnz_cap_);
-        if (fast_npt_ > 0) { dr_.s_req32 = (int32_t*)dalloc(4 * (size_t)nnz_cap_ * (size_t)R); dr_.req32 = fs_.req32; }
-        else dr_.s_req = (int64_t*)dalloc(8 * (size_t)nnz_cap_ * (size_t)R);
+        if (fast_npt_ > 0) {   // register packer: one record per PEG (casim_types.h) instead of the three arrays
+            dr_.rec_dw = fast_r_ == 2 ? 8 : 16;
+            dr_.rec = (uint32_t*)dalloc(4 * ((size_t)nnz_cap_ + 1) * (size_t)dr_.rec_dw);   // + one spare record: the packer loads record k + 1 unconditionally
+            dr_.req32 = fs_.req32; dr_.fresh32 = fs_.fresh32;
+        } else {
+            dr_.s_count = (int32_t*)dalloc(4 * (size_t)nnz_cap_); dr_.s_flags = (uint32_t*)dalloc(4 * (size_t)nnz_cap_);
+            dr_.s_req = (int64_t*)dalloc(8 * (size_t)nnz_cap_ * (size_t)R);
+        }
         d_opt_set_ = (uint8_t*)dalloc(NG);
         d_opt_out_ = (int32_t*)dalloc(16);
         d_opt_key_ = (int64_t*)dalloc(80);

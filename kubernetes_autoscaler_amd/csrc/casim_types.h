@@ -66,9 +66,12 @@ struct DevResults {
     int32_t* s_count;    // [nnz]
     uint32_t* s_flags;   // [nnz] CASIM_PEG_* | CASIM_KFLAG_STATIC_OK
     int64_t* s_req;      // [nnz][R]   (generic packer; null when the register packer runs)
-    // register packer: the gcd-scaled int32 requests in processing order (order_kernel copies them from req32)
-    int32_t* s_req32;        // [nnz][R] or null
-    const int32_t* req32;    // [G][R] source of s_req32 (FastScratch::req32)
+    // register packer: ONE record per PEG in processing order instead of the three arrays above (see casim_peg_record
+    // below): order_kernel writes it, the packer reads it with one scalar load per PEG
+    uint32_t* rec;           // [nnz][rec_dw] or null
+    int32_t rec_dw;          // 8 (R <= 2) or 16 (R <= 4)
+    const int32_t* req32;    // [G][R]  gcd-scaled requests (FastScratch::req32)
+    const int32_t* fresh32;  // [NG][R] gcd-scaled free resources of an empty node (FastScratch::fresh32)
     // optional (casim_options.node_pods): pods per simulated node, group i at node_pods[node_pods_off[i] ..), node bound entries
     int32_t* node_pods;
     const int64_t* node_pods_off;
@@ -76,6 +79,18 @@ struct DevResults {
 
 // kernel-internal flag bit (not part of the ABI): the template-level Filters pass for (PEG, group)
 #define CASIM_KFLAG_STATIC_OK 0x80000000u
+
+// PEG record of the register packer (dwords; RL = 2 or 4 request lanes, record = 8 or 16 dwords):
+//   [0] pods of the PEG
+//   [1] CASIM_PEG_* flags (bits 0-6) | CASIM_REC_SIMPLE | pods of this PEG that fit an EMPTY node << 8 | CASIM_REC_A2_OK | CASIM_KFLAG_STATIC_OK
+//   [2 .. 2+RL) gcd-scaled requests   [2+RL .. 2+3RL) their reciprocals as IEEE doubles (lo, hi), 0.0 for a zero request
+// The fresh-node capacity is < 2^22 by eligibility (casim_pipeline.h: pod slots of an empty node).  Everything the packer
+// would otherwise derive per PEG with scalar compares is a bit here (the kernel is bound by SCALAR issue, r02n PMC):
+#define CASIM_REC_SIMPLE 0x80u            /* every request lane of the record is in (0, 2^30): the branch-free quotient sweep applies */
+#define CASIM_REC_A2_OK 0x40000000u       /* template-level Filters pass AND the PEG has pods: existing simulated nodes are worth a visit */
+#define CASIM_REC_FRESH_SHIFT 8
+#define CASIM_REC_FRESH_MAX 0x3fffff
+#define CASIM_REC_FLAG_MASK 0xc00000ffu
 
 // Per-group scratch geometry of the packer: simulated-node state lives in LDS when every
 // group of the launch fits, else in an HBM scratch slab.

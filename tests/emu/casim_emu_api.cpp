@@ -31,7 +31,7 @@ struct EmuBackend {
         casim_emu::launch(gx, gy, block, smem, [&]() { kernel(args...); });
     }
     void launch_pack_fast(int lanes, int slots_per_lane, int excl_words, int n_groups, const DevTables& t, const DevResults& res, const FastScratch& fs) {
-#define CASIM_EMU_FAST(R, N, X) launch(casim::pack_fast_kernel<R, N, X>, n_groups, 1, 64, (size_t)casim::RegStore<R, N, X>::kChunkBytes, t, res, fs)
+#define CASIM_EMU_FAST(R, N, X) launch(casim::pack_fast_kernel<R, N, X>, n_groups, 1, 64, (size_t)0, t, res, fs)
         CASIM_FAST_DISPATCH(CASIM_EMU_FAST, lanes, slots_per_lane, excl_words);
 #undef CASIM_EMU_FAST
     }

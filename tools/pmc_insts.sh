@@ -11,7 +11,7 @@ for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAV
          "SQ_WAVES SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_SALU SQ_INSTS_VMEM_WR"; do
   i=$((i+1))
   (cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace -d "$OUT/pmc_$i" -o pmc -- \
-      python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-dense --no-next-rows > "$OUT/pmc_$i.log" 2>&1)
+      python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-next-rows --no-c3 > "$OUT/pmc_$i.log" 2>&1)
   echo "pass $i exit $?"
 done
 python tools/rocpd_summary.py "$OUT"/pmc_* 2>&1 | grep -E "pack_fast|^kernel," > "$OUT/pmc_insts.txt"
