@@ -46,6 +46,9 @@ CS_DEVICE uint32_t uniform_u32(uint32_t v) { return v; }
 template <int N> struct Words { uint32_t w[N]; };
 template <int N> CS_DEVICE Words<N> const_load(const uint32_t* p) { Words<N> r; memcpy(r.w, p, 4 * N); return r; }
 CS_DEVICE bool lane_pred(uint64_t mask) { return ((mask >> (casim_emu::cur().tid & 63)) & 1ull) != 0; }
+CS_DEVICE void keep_scalar(uint32_t&) {}
+CS_DEVICE int32_t opaque_i32(int32_t v) { return v; }
+CS_DEVICE bool flag_set(uint32_t word, uint32_t bit) { return (word & bit) != 0; }
 CS_DEVICE void write_lane_u32(uint32_t& v, uint32_t uniform_value, int uniform_lane) { if ((casim_emu::cur().tid & 63) == uniform_lane) v = uniform_value; }
 CS_DEVICE int popc64(uint64_t v) { return __builtin_popcountll(v); }
 CS_DEVICE int ffs64(uint64_t v) { return v ? __builtin_ctzll(v) : -1; }
@@ -148,6 +151,15 @@ template <int N> CS_DEVICE Words<N> const_load(const uint32_t* p) {
 }
 // my lane's bit of a wave-uniform lane mask as a predicate: the mask register pair IS the condition (no VALU)
 CS_DEVICE bool lane_pred(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+// pin a wave-uniform value that lives across loop iterations to a scalar register (the register allocator otherwise may
+// give the loop-carried copy a VGPR, and every test of it becomes VALU work)
+CS_DEVICE void keep_scalar(uint32_t& v) { v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v); asm volatile("" : "+s"(v)); }
+// a copy of a lane value the optimiser cannot see through (no instruction): keeps it from merging two computations
+CS_DEVICE int32_t opaque_i32(int32_t v) { asm volatile("" : "+v"(v)); return v; }
+// test of one bit of a wave-UNIFORM word, meant to sit directly in an `if`: the word goes through an opaque scalar copy so
+// that every test is its own s_bitcmp + s_cbranch_scc.  A flag tested in several places as one bool is kept by the
+// compiler as a 64-bit lane mask (s_cselect_b64, then s_and_b64 with exec + s_cbranch_vcc at every use).
+CS_DEVICE bool flag_set(uint32_t word, uint32_t bit) { asm volatile("" : "+s"(word)); return (word & bit) != 0; }
 // v[uniform_lane] = uniform_value: one v_writelane_b32 instead of lane-compare + select + move
 CS_DEVICE void write_lane_u32(uint32_t& v, uint32_t uniform_value, int uniform_lane) {
     // (one scalar register per VALU instruction on gfx9: the lane select travels in M0)

@@ -353,6 +353,12 @@ CS_GLOBAL void order_kernel(DevTables t, DevResults res, OrderScratch os) {
     const int tid = cs::tid(), nt = cs::nthreads();
     int npad = 1;
     while (npad < Gn) npad <<= 1;
+#if defined(CASIM_PACK_PROF) && !defined(CASIM_HOST_EMU)
+    uint64_t oprof[4] = {0, 0, 0, 0}; uint64_t oprof_last = __builtin_amdgcn_s_memtime();
+#define CASIM_OPROF(i) do { const uint64_t _n = __builtin_amdgcn_s_memtime(); oprof[i] += _n - oprof_last; oprof_last = _n; } while (0)
+#else
+#define CASIM_OPROF(i)
+#endif
     char* base = kLds ? cs::dyn_smem() : os.gbuf + os.off[ng];
     uint64_t* keys = (uint64_t*)base;           // [npad]
     int32_t* pos = (int32_t*)(keys + npad);     // [npad]
@@ -366,6 +372,7 @@ CS_GLOBAL void order_kernel(DevTables t, DevResults res, OrderScratch os) {
         }
     }
     cs::sync();
+    CASIM_OPROF(0);   // scores
     for (int k = 2; k <= npad; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             // one thread per PAIR (i, i | j): every lane of every wave works in every pass (with one thread per element
@@ -382,6 +389,7 @@ CS_GLOBAL void order_kernel(DevTables t, DevResults res, OrderScratch os) {
             cs::sync();
         }
     }
+    CASIM_OPROF(1);   // sort
     // fastpath: the eligible PEG with the largest simulationsSaved, last one on ties, goes last
     int best = -1;
     if (t.fastpath && Gn > 0) {
@@ -458,6 +466,10 @@ CS_GLOBAL void order_kernel(DevTables t, DevResults res, OrderScratch os) {
         }
     }
     if (tid == 0) res.fast_last[ng] = best >= 0 ? 1 : 0;
+    CASIM_OPROF(2);   // records
+#if defined(CASIM_PACK_PROF) && !defined(CASIM_HOST_EMU)
+    if (os.prof && tid == 0) for (int i = 0; i < 4; ++i) os.prof[(int64_t)ng * 4 + i] = (int64_t)oprof[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

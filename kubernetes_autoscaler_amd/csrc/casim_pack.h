@@ -213,93 +213,88 @@ struct RegStore {
     int32_t slots[NPT_];
     int32_t fresh_slots;  // pod slots of an empty node: pods on a node = fresh_slots - slots (no per-node counter)
 
-    // Pass A for all slots.  Per slot: a cheap fit mask first (pod slot left and req <= free on every
-    // requested lane: a handful of compares); only slots where SOME node fits (wave-uniform ballot) pay for
-    // the quotient chain (cvt -> f64 mul by the PEG's reciprocal -> cvt -> exact +-1 fix-up).  In the
-    // steady state of a scale-up most PEGs fit nowhere or on a few nodes, so most slots stop at the mask.
-    // Slots beyond M hold zeros (slots == 0): no extra guard.  Returns n1 = nodes taking >= 1 pod.
+    // `simple`: the common PEG asks for every lane and no request is huge (CASIM_REC_SIMPLE, decided once by order_kernel),
+    // so that the slot code carries no per-lane branches (each wave-uniform branch costs scalar issue slots, and this
+    // kernel is bound by them more than by the VALU: profiles/r01s_*, r02n_*).
+    //
+    // fit_mask: the wave mask of "a pod of the PEG fits node (s, lane)" as the AND of single-compare masks (each v_cmp
+    // writes its mask register pair).  ONLY this mask crosses the wave-uniform branches of a2: inside them it IS the lane
+    // predicate again (cs::lane_pred).  A bool carried across such a branch is materialised in a VGPR and compared back
+    // (6 VALU per slot), and so is a compare that two branches share.
+    CS_DEVICE uint64_t fit_mask(int s, const Peg& pv, uint32_t pf /* record flags */) const {
+        uint64_t fb;
+        if (cs::flag_set(pf, CASIM_REC_SIMPLE)) {
+            fb = cs::ballot(slots[s] > 0);
+            if (X_) fb &= cs::ballot(!blocked(s, pv));
+#pragma unroll
+            for (int r = 0; r < R_; ++r) fb &= cs::ballot(fr[s][r] >= pv.req[r]);
+        } else {
+            // (the slot count through an opaque copy: otherwise the compiler shares the compare with the branch above and
+            // carries its result across as a 0 / 1 VGPR — two VALU more on the common path)
+            fb = cs::ballot(cs::opaque_i32(slots[s]) > 0);
+            if (X_) fb &= cs::ballot(!blocked(s, pv));
+#pragma unroll
+            for (int r = 0; r < R_; ++r) if (pv.req[r] > 0) fb &= cs::ballot(fr[s][r] >= pv.req[r]);   // wave-uniform test
+        }
+        return fb;
+    }
+    // c_j of slot s for a non-empty fit mask: cheap compares decided who fits, only now the quotient chain
+    // (cvt -> f64 mul by the PEG's reciprocal -> cvt -> exact +-1 fix-up) runs.  In the steady state of a scale-up most PEGs
+    // fit nowhere or on a few nodes, so most slots stop at the mask.
+    CS_DEVICE uint32_t capacity_slot(int s, const Peg& pv, uint32_t clampk, uint32_t pf, uint64_t fb) const {
+        const bool fit = cs::lane_pred(fb);
+        if (cs::flag_set(pf, CASIM_PEG_SELF_EXCL_NODE)) return fit ? 1u : 0u;   // clampk >= 1, a pod slot is free and every requested lane fits once
+        uint32_t k = (uint32_t)slots[s] < clampk ? (uint32_t)slots[s] : clampk;
+        if (cs::flag_set(pf, CASIM_REC_SIMPLE)) {
+            // (lanes that do not fit compute garbage and are masked at the end: no select per operand)
+#pragma unroll
+            for (int r = 0; r < R_; ++r) {
+                const int32_t q = pv.req[r];
+                const uint32_t fpos = (uint32_t)fr[s][r];
+                uint32_t e = (uint32_t)((double)fpos * pv.rq[r]);
+                const int32_t rem = (int32_t)(fpos - e * (uint32_t)q);   // wrapping 32-bit: it lies in (-q, 2q)
+                e = e - ((uint32_t)rem >> 31) + (rem >= q ? 1u : 0u);    // exact +-1 fix-up: sign bit, carry-in
+                k = e < k ? e : k;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R_; ++r) {
+                const int32_t q = pv.req[r];
+                if (q > 0) {  // wave-uniform
+                    const uint32_t fpos = fit ? (uint32_t)fr[s][r] : 0u;
+                    uint32_t e = (uint32_t)((double)fpos * pv.rq[r]);
+                    if (q < (1 << 30)) {  // remainder in wrapping 32-bit arithmetic: it lies in (-q, 2q)
+                        const int32_t rem = (int32_t)(fpos - e * (uint32_t)q);
+                        e = rem < 0 ? e - 1 : (rem >= q ? e + 1 : e);
+                    } else {
+                        const int64_t rem = (int64_t)fpos - (int64_t)((uint64_t)e * (uint64_t)(uint32_t)q);
+                        e = rem < 0 ? e - 1 : (rem >= (int64_t)q ? e + 1 : e);
+                    }
+                    k = e < k ? e : k;
+                }
+            }
+        }
+        return fit ? k : 0u;
+    }
+    // Pass A for all slots.  Slots beyond M hold zeros (slots == 0): no extra guard.  Returns n1 = nodes taking >= 1 pod.
     // The capacities go to the caller's array: they are dead after a2, and as a member they travelled through every
     // merge point of the PEG loop with the rest of the state.
     // `act`: bit s set when some node of slot s takes a pod — the later passes skip the other slots (measured on C1:
     // 0.6 of the 4 slots per PEG).
-    CS_DEVICE int32_t capacity_all(const Peg& pv, uint32_t clampk, bool selfx, bool simple, uint32_t* c, uint32_t& act) const {
+    CS_DEVICE int32_t capacity_all(const Peg& pv, uint32_t clampk, uint32_t pf, uint32_t* c, uint32_t& act) const {
         act = 0;
-        // `simple`: the common PEG asks for every lane and no request is huge (CASIM_REC_SIMPLE, decided once by order_kernel),
-        // so that the unrolled slots carry no per-lane branches (each wave-uniform branch costs scalar issue slots, and this
-        // kernel is bound by them more than by the VALU: profiles/r01s_*, r02n_*).
         int32_t n1 = 0;
-        if (simple) {
-            // (self-exclusion is a PEG property: two copies of the sweep instead of three selects per slot)
-            auto sweep = [&](auto sx_tag) {
-                constexpr bool kSelf = decltype(sx_tag)::value;
-#pragma unroll
-                for (int s = 0; s < NPT_; ++s) {
-                    // the wave mask of "fits" as the AND of single-compare masks (each v_cmp writes its mask register pair);
-                    // inside the branch the mask IS the lane predicate again (cs::lane_pred) — carried across the branch as
-                    // a bool it was materialised in a VGPR and compared back (6 VALU per slot)
-                    uint64_t fb = cs::ballot(slots[s] > 0);
-                    if (X_) fb &= cs::ballot(!blocked(s, pv));
-#pragma unroll
-                    for (int r = 0; r < R_; ++r) fb &= cs::ballot(fr[s][r] >= pv.req[r]);
-                    uint32_t k = 0;
-                    if (fb) {  // wave-uniform
-                        n1 += cs::popc64(fb);
-                        act |= 1u << s;
-                        const bool fit = cs::lane_pred(fb);
-                        if constexpr (kSelf) k = fit ? 1u : 0u;   // clampk >= 1, a pod slot is free and every lane fits once
-                        else {
-                            // (lanes that do not fit compute garbage and are masked at the end: no select per operand)
-                            k = (uint32_t)slots[s] < clampk ? (uint32_t)slots[s] : clampk;
-#pragma unroll
-                            for (int r = 0; r < R_; ++r) {
-                                const int32_t q = pv.req[r];
-                                const uint32_t fpos = (uint32_t)fr[s][r];
-                                uint32_t e = (uint32_t)((double)fpos * pv.rq[r]);
-                                const int32_t rem = (int32_t)(fpos - e * (uint32_t)q);   // wrapping 32-bit: it lies in (-q, 2q)
-                                e = e - ((uint32_t)rem >> 31) + (rem >= q ? 1u : 0u);    // exact +-1 fix-up: sign bit, carry-in
-                                k = e < k ? e : k;
-                            }
-                            k = fit ? k : 0u;
-                        }
-                    }
-                    c[s] = k;
-                    if (NPT_ >= 4 && (s & 1) == 1) cs::sched_fence();  // interleave two slots at a time: bounds the live temporaries
-                }
-            };
-            if (selfx) sweep(CsTrue{}); else sweep(CsFalse{});
-            return n1;
-        }
 #pragma unroll
         for (int s = 0; s < NPT_; ++s) {
-            bool fit = slots[s] > 0;
-            if (X_) fit = fit && !blocked(s, pv);
-#pragma unroll
-            for (int r = 0; r < R_; ++r) fit = fit && (pv.req[r] <= 0 || fr[s][r] >= pv.req[r]);
-            const uint64_t fb = cs::ballot(fit);
+            const uint64_t fb = fit_mask(s, pv, pf);
             uint32_t k = 0;
             if (fb) {  // wave-uniform
                 n1 += cs::popc64(fb);
                 act |= 1u << s;
-                k = fit ? ((uint32_t)slots[s] < clampk ? (uint32_t)slots[s] : clampk) : 0u;
-#pragma unroll
-                for (int r = 0; r < R_; ++r) {
-                    const int32_t q = pv.req[r];
-                    if (q > 0) {  // wave-uniform
-                        const uint32_t fpos = fit ? (uint32_t)fr[s][r] : 0u;
-                        uint32_t e = (uint32_t)((double)fpos * pv.rq[r]);
-                        if (q < (1 << 30)) {  // remainder in wrapping 32-bit arithmetic: it lies in (-q, 2q)
-                            const int32_t rem = (int32_t)(fpos - e * (uint32_t)q);
-                            e = rem < 0 ? e - 1 : (rem >= q ? e + 1 : e);
-                        } else {
-                            const int64_t rem = (int64_t)fpos - (int64_t)((uint64_t)e * (uint64_t)(uint32_t)q);
-                            e = rem < 0 ? e - 1 : (rem >= (int64_t)q ? e + 1 : e);
-                        }
-                        k = e < k ? e : k;
-                    }
-                }
-                if (selfx) k = k > 1 ? 1u : k;
+                k = capacity_slot(s, pv, clampk, pf, fb);
             }
             c[s] = k;
+            if (NPT_ >= 4 && (s & 1) == 1) cs::sched_fence();  // interleave two slots at a time: bounds the live temporaries
         }
         return n1;
     }
@@ -409,13 +404,16 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     const int R = t.R;
     const int Wx = Store::kHasExcl ? t.Wx : 0;
     const int Wz = Store::kHasZone ? t.Wz : 0;
-    const int off = t.peg_off[ng];
-    const int Gn = t.peg_off[ng + 1] - off;
+    // (per-group scalars: written by the host or by earlier kernels, read through the scalar cache into scalar registers —
+    // as vector loads they lived in VGPRs and every use of them was a VALU instruction)
+    auto gload = [&](const void* base, int64_t i) -> int32_t { return (int32_t)cs::const_load<1>((const uint32_t*)base + i).w[0]; };
+    const int off = gload(t.peg_off, ng);
+    const int Gn = gload(t.peg_off, ng + 1) - off;
 
-    const int32_t maxn = t.max_nodes[ng];
-    const int32_t E = t.existing[ng];
+    const int32_t maxn = gload(t.max_nodes, ng);
+    const int32_t E = gload(t.existing, ng);
     const bool fast_last = t.fastpath && res.fast_last[ng];
-    const bool group_unschedulable = (t.gflags[ng] & CASIM_NG_UNSCHEDULABLE) != 0;
+    const bool group_unschedulable = ((uint32_t)gload(t.gflags, ng) & CASIM_NG_UNSCHEDULABLE) != 0;
     const uint64_t* zvalid = t.zone_valid + (int64_t)ng * Wz;
     // group-wide exclusion state (anti-affinity on non-hostname keys): identical in every lane
     constexpr int ZR = Store::kZoneWords;
@@ -449,7 +447,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     zone_init();
 
     int32_t M = 0;                         // simulated nodes so far (estimationState.newNodeNameIndex)
-    int32_t last_index = t.last_index[ng]; // lastIndexOrderMapping.lastIndex
+    int32_t last_index = gload(t.last_index, ng); // lastIndexOrderMapping.lastIndex
     int32_t granted = 0;                   // limiter.nodes
     // newNodesAvailable, as an all-ones / zero word: wave-uniform flags that live across PEGs are kept as integers and
     // tested with integer arithmetic — as bools the compiler carries them as 64-bit lane masks (s_cselect_b64 / s_and_b64 /
@@ -578,7 +576,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             // not (plugin_runner.go:108-110); every simulated node clones the template's flag.
             const uint32_t keff = (uint32_t)(zselfx ? (cnt > 0 ? 1 : 0) : cnt);
             bool a2_go;
-            if constexpr (kRecScalar) a2_go = (pf & a2_gate) != 0;
+            if constexpr (kRecScalar) { cs::keep_scalar(a2_gate); a2_go = (pf & a2_gate) != 0; }
             else a2_go = M > 0 && keff > 0 && static_ok && !group_unschedulable;
             if (a2_go && !zblocked) {
                 // register stores of up to 4 slots walk all of them: slots past M hold zero state (c_j = 0, never a
@@ -601,19 +599,10 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 auto getc = [&](int s, int m) -> uint32_t {
                     if constexpr (Store::kNPT > 0) return creg[s]; else return st.get_c(s, m);
                 };
-                if constexpr (Store::kNPT > 0) {
-                    n1 = st.capacity_all(pv, keff, selfx, (pf & CASIM_REC_SIMPLE) != 0, creg, act);  // every slot (nodes >= M are all-zero)
-                } else {
-                    for_slots<Store>(S, [&](int s) {
-                        const int m = s * 64 + lane;
-                        uint32_t cj = 0;
-                        if (m < M) cj = st.capacity(s, m, pv, keff, selfx);
-                        st.set_c(s, m, cj);
-                        n1 += cs::popc64(cs::ballot(cj > 0));
-                    });
-                }
-                CASIM_PROF(2);  // a2 pass A (capacities)
-                if (n1 > 0) {
+                // everything after pass A, for n1 > 0 nodes that take a pod (a continuation: the one-slot register store runs
+                // it inside the "somebody fits" branch of its only slot instead of re-testing a count after the merge)
+                auto a2_rest = [&](const int32_t n1) {
+                    CASIM_PROF(2);  // a2 pass A (capacities)
                     uint32_t T, Rr;
                     if ((uint32_t)n1 > keff) {
                         // S(1) = n1 > k: not even one full round — the k pods go to the first k fitting nodes
@@ -696,6 +685,26 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     on_last = cs::bcast_u32(x_mine_last, (M - 1) & 63);
                     last_index = new_last;
                     if (Wz > 0) zone_mark(zmark);
+                };
+                if constexpr (Store::kNPT == 1) {
+                    const uint64_t fb = st.fit_mask(0, pv, pf);
+                    if (fb) {  // wave-uniform
+                        act = 1u;
+                        creg[0] = st.capacity_slot(0, pv, keff, pf, fb);
+                        a2_rest(cs::popc64(fb));
+                    }
+                } else if constexpr (Store::kNPT > 0) {
+                    n1 = st.capacity_all(pv, keff, pf, creg, act);  // every slot (nodes >= M are all-zero)
+                    if (n1 > 0) a2_rest(n1);
+                } else {
+                    for_slots<Store>(S, [&](int s) {
+                        const int m = s * 64 + lane;
+                        uint32_t cj = 0;
+                        if (m < M) cj = st.capacity(s, m, pv, keff, selfx);
+                        st.set_c(s, m, cj);
+                        n1 += cs::popc64(cs::ballot(cj > 0));
+                    });
+                    if (n1 > 0) a2_rest(n1);
                 }
             }
 
@@ -813,7 +822,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     else { if (!stop) new_nodes(); }
                 }
                 if (marked && Wz > 0) zone_mark(zmark);
-                a2_gate = M > 0 ? a2_bit : 0u;
+                if constexpr (kRecScalar) { a2_gate = M > 0 ? a2_bit : 0u; cs::keep_scalar(a2_gate); }
             }
 
             CASIM_PROF(5);  // a3 / a4
@@ -826,6 +835,13 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             cur = cs::const_load<DW>(rp);
             if (kNeedG) g_cur = (int32_t)cs::const_load<1>((const uint32_t*)res.order + off + k + 1).w[0];
         }
+    }
+    if constexpr (kRecScalar) {
+        // (the loop's scalars leave it as scalars: with a vector use behind the loop the compiler kept VGPR copies of them
+        // and refreshed the copies in every iteration)
+        uint32_t a = (uint32_t)M, b = (uint32_t)granted, c = (uint32_t)last_index, d = (uint32_t)total_placed, e = (uint32_t)fakes;
+        cs::keep_scalar(a); cs::keep_scalar(b); cs::keep_scalar(c); cs::keep_scalar(d); cs::keep_scalar(e);
+        M = (int32_t)a; granted = (int32_t)b; last_index = (int32_t)c; total_placed = (int32_t)d; fakes = (int32_t)e;
     }
     if (Gn > 0) flush_chunk((Gn - 1) & ~63);   // the last (possibly partial) chunk
     const int64_t sum0 = (int64_t)cs::wave_sum_u64((uint64_t)acc0), sum1 = (int64_t)cs::wave_sum_u64((uint64_t)acc1);

@@ -308,8 +308,16 @@ public:
     }
     int32_t run_order() {
         if (NG_ == 0) return CASIM_OK;
+        if (getenv("CASIM_PACK_PROF_DUMP") && !os_.prof) { os_.prof = (int64_t*)dalloc(8 * 4 * (size_t)NG_); bk_.zero(os_.prof, 8 * 4 * (size_t)NG_); }
         if (order_lds_) bk_.launch(order_kernel<true>, NG_, 1, order_threads_, order_smem_, dt_, dr_, os_);
         else bk_.launch(order_kernel<false>, NG_, 1, order_threads_, (size_t)0, dt_, dr_, os_);
+        if (os_.prof) {  // profiling builds: mean ticks per phase over the groups
+            std::vector<int64_t> h((size_t)NG_ * 4);
+            bk_.d2h(h.data(), os_.prof, h.size() * 8); bk_.sync();
+            double m[4] = {0};
+            for (int i = 0; i < NG_; ++i) for (int j = 0; j < 4; ++j) m[j] += (double)h[(size_t)i * 4 + j] / NG_;
+            fprintf(stderr, "[order prof] ticks/group: scores %.0f sort %.0f records %.0f (threads %d)\n", m[0], m[1], m[2], order_threads_);
+        }
         return CASIM_OK;
     }
     int32_t run_pack() {
@@ -562,7 +570,7 @@ private:
     int32_t fail(int32_t code, const char* msg) { err_ = msg ? msg : ""; return code; }
 
     BK& bk_;
-    DevTables dt_; DevResults dr_; PackScratch ps_; OrderScratch os_; FastScratch fs_ = {nullptr, nullptr, nullptr, nullptr};
+    DevTables dt_; DevResults dr_; PackScratch ps_; OrderScratch os_ = {nullptr, nullptr, nullptr}; FastScratch fs_ = {nullptr, nullptr, nullptr, nullptr};
     int G_ = 0, NG_ = 0, Wg_ = 0, fast_npt_ = 0, fast_r_ = 0;
     int32_t nnz_cap_ = 0;
     bool csr_on_device_ = false, pack_lds_ = true, order_lds_ = true, ready_ = false, ran_ = false;

@@ -112,6 +112,7 @@ struct FastScratch {
 struct OrderScratch {
     const int64_t* off;  // [NG] byte offset into gbuf (global variant)
     char* gbuf;
+    int64_t* prof;       // [NG][4] phase ticks (CASIM_PACK_PROF builds) or null
 };
 
 // bytes of packer state per simulated node (8-byte fields first)
