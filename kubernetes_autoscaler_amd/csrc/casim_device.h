@@ -162,7 +162,10 @@ CS_DEVICE int32_t opaque_i32(int32_t v) { asm volatile("" : "+v"(v)); return v; 
 CS_DEVICE bool flag_set(uint32_t word, uint32_t bit) { asm volatile("" : "+s"(word)); return (word & bit) != 0; }
 // v[uniform_lane] = uniform_value: one v_writelane_b32 instead of lane-compare + select + move
 CS_DEVICE void write_lane_u32(uint32_t& v, uint32_t uniform_value, int uniform_lane) {
-    // (one scalar register per VALU instruction on gfx9: the lane select travels in M0)
+    // (one scalar register per VALU instruction on gfx9: the lane select travels in M0; readfirstlane is a no-op for values
+    // the compiler already holds in scalar registers and makes the operands legal when it does not)
+    uniform_value = (uint32_t)__builtin_amdgcn_readfirstlane((int)uniform_value);
+    uniform_lane = __builtin_amdgcn_readfirstlane(uniform_lane);
     asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(uniform_value), "s"(uniform_lane) : "m0");
 }
 CS_DEVICE int popc64(uint64_t v) { return __popcll(v); }

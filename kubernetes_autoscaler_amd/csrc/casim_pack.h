@@ -496,7 +496,12 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
         acc0 += (int64_t)my_placed * (int64_t)r0;   // lanes without a record hold my_placed == 0
         acc1 += (int64_t)my_placed * (int64_t)r1;
     };
-    for (int k = 0; k < Gn; ++k) {
+    // One PEG.  kDry = the limiter has run dry (newNodesAvailable == false): a3 / a4 can never be entered again, and a PEG that
+    // fits no simulated node leaves no trace at all (placed 0, my_placed already 0, lastIndex kept) — in C2 that is 60 % of
+    // all steps (profiles/r02s_packer_notes.txt), so the register store runs them in a loop of their own without the a3
+    // code and its tests.
+    auto peg_step = [&](const int k, auto dry_tag) __attribute__((always_inline)) {
+        constexpr bool kDry = decltype(dry_tag)::value;
         const int j = k & 63;
         if (j == 0) {
             CASIM_PROF(0);  // chunk load / store, loop overhead
@@ -576,7 +581,10 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             // not (plugin_runner.go:108-110); every simulated node clones the template's flag.
             const uint32_t keff = (uint32_t)(zselfx ? (cnt > 0 ? 1 : 0) : cnt);
             bool a2_go;
-            if constexpr (kRecScalar) { cs::keep_scalar(a2_gate); a2_go = (pf & a2_gate) != 0; }
+            if constexpr (kRecScalar) {
+                if constexpr (!kDry) cs::keep_scalar(a2_gate);   // (kDry: nothing changes it any more, it stays in its scalar register)
+                a2_go = (pf & a2_gate) != 0;
+            }
             else a2_go = M > 0 && keff > 0 && static_ok && !group_unschedulable;
             if (a2_go && !zblocked) {
                 // register stores of up to 4 slots walk all of them: slots past M hold zero state (c_j = 0, never a
@@ -682,9 +690,13 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         if (m == M - 1) x_mine_last = x;
                         basec += cs::popc64(b);
                     });
-                    on_last = cs::bcast_u32(x_mine_last, (M - 1) & 63);
+                    if constexpr (!kDry) on_last = cs::bcast_u32(x_mine_last, (M - 1) & 63);   // (only a3 asks)
                     last_index = new_last;
                     if (Wz > 0) zone_mark(zmark);
+                    if constexpr (kDry) {   // placed > 0 here; the tail of the step does not run
+                        uint32_t mp = (uint32_t)my_placed; cs::write_lane_u32(mp, (uint32_t)placed, j); my_placed = (int32_t)mp;
+                        total_placed += placed;
+                    }
                 };
                 if constexpr (Store::kNPT == 1) {
                     const uint64_t fb = st.fit_mask(0, pv, pf);
@@ -711,7 +723,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             CASIM_PROF(4);  // a2 passes B + C (rotated rank, commit)
             // ---- a3 / a4: tryToScheduleOnNewNodes (:190-269) or tryFastPath (:274-324) ----
             int32_t rem = cnt - placed;
-            if ((rem & more_mask) > 0) {   // pods left && newNodesAvailable
+            if (!kDry && (rem & more_mask) > 0) {   // pods left && newNodesAvailable
                 zblocked = Wz > 0 && zone_blocked(zblock);
                 bool blocked = !static_ok || zblocked;
                 // capacity of a FRESH node for this PEG
@@ -826,14 +838,25 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             }
 
             CASIM_PROF(5);  // a3 / a4
-            if constexpr (kRecScalar) { uint32_t mp = (uint32_t)my_placed; cs::write_lane_u32(mp, (uint32_t)placed, j); my_placed = (int32_t)mp; }
-            else { if (lane == j) my_placed = placed; }
-            total_placed += placed;
+            if constexpr (!kDry) {   // (kDry: a2 recorded what it placed, nothing else can place)
+                if constexpr (kRecScalar) { uint32_t mp = (uint32_t)my_placed; cs::write_lane_u32(mp, (uint32_t)placed, j); my_placed = (int32_t)mp; }
+                else { if (lane == j) my_placed = placed; }
+                total_placed += placed;
+            }
         }
         if constexpr (kRecScalar) {   // record k + 1 into the registers record k just left (in flight across the loop edge)
             rp += DW;
             cur = cs::const_load<DW>(rp);
             if (kNeedG) g_cur = (int32_t)cs::const_load<1>((const uint32_t*)res.order + off + k + 1).w[0];
+        }
+    };
+    {
+        int k = 0;
+        if constexpr (kRecScalar) {
+            for (; k < Gn && more_mask != 0; ++k) peg_step(k, CsFalse{});
+            for (; k < Gn; ++k) peg_step(k, CsTrue{});
+        } else {
+            for (; k < Gn; ++k) peg_step(k, CsFalse{});
         }
     }
     if constexpr (kRecScalar) {
