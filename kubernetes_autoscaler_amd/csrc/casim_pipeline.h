@@ -242,27 +242,42 @@ public:
             ps_.gstate = (char*)dalloc((size_t)total);
         }
         // ---- order scratch geometry ----
-        std::vector<int64_t> ooff(NG);
-        int64_t ototal = 0, oworst = 0, npad_max = 1;
+        int64_t npad_max = 1;
+        std::vector<int64_t> npad_of(NG);
         for (size_t i = 0; i < NG; ++i) {
             int64_t npad = 1;
             while (npad < pegs_of_group[i]) npad <<= 1;
+            npad_of[i] = npad;
             npad_max = npad > npad_max ? npad : npad_max;
-            const int64_t bytes = npad * 12 + 8 + 8 * kOrderThreads;
-            ooff[i] = ototal; ototal += (bytes + 255) & ~255ll;
-            oworst = bytes > oworst ? bytes : oworst;
         }
-        order_smem_ = (size_t)oworst;
         // one thread per pair of the bitonic network: npad / 2 threads, 64..kOrderThreads
         order_threads_ = (int)(npad_max / 2 < 64 ? 64 : (npad_max / 2 > kOrderThreads ? kOrderThreads : (npad_max / 2 + 63) / 64 * 64));
-        // a batch with thousands of groups fills the chip with blocks anyway: one wave per group then (the pairs of a pass are
-        // walked in a loop), so that no wave sits idle in the block barriers of a list that is far shorter than its bound
-        // (C2 batch: bound 400 PEGs -> 256 threads, actual lists ~110 -> 64 pairs; 0.49 ms of a 2.3 ms step, r02a)
-        if (NG_ >= 2048 && npad_max <= 1024) order_threads_ = 64;
+        // a batch with thousands of groups fills the chip with blocks anyway: one wave per group then, so that no wave sits idle
+        // in the block barriers of a list that is far shorter than its bound (C2 batch: bound 400 PEGs -> 256 threads, actual
+        // lists ~110 -> 64 pairs; 0.49 ms of a 2.3 ms step, r02a).  The kernel is latency-bound (dependent gathers, LDS round
+        // trips), so its LDS is sized for the lists the one-wave networks take (<= 256 PEGs: 3.5 KB, 8 waves per SIMD) and
+        // the few longer lists of such a launch sort in an HBM slab; sized for the BOUND (400 -> 512 entries + the
+        // reduction array of 256 threads = 8.2 KB) the launch ran at 4-5 waves per SIMD.
+        const bool batch = NG_ >= 2048 && npad_max <= 1024;
+        if (batch) order_threads_ = 64;
+        const int64_t lds_cap = batch && npad_max > 256 ? 256 : 0;
+        std::vector<int64_t> ooff(NG, 0);
+        int64_t ototal = 0, oworst = 0;
+        bool any_slab = false;
+        for (size_t i = 0; i < NG; ++i) {
+            // (a one-wave block sorts lists of <= 256 PEGs in a network of 64 / 128 / 256 entries: never less than 64)
+            const int64_t entries = order_threads_ == 64 && npad_of[i] < 64 ? 64 : npad_of[i];
+            const int64_t bytes = entries * 12 + 8 + 8 * order_threads_;
+            if (lds_cap == 0 || npad_of[i] > lds_cap) { ooff[i] = ototal; ototal += (bytes + 255) & ~255ll; any_slab = any_slab || lds_cap > 0; }
+            const int64_t in_lds = lds_cap > 0 && npad_of[i] > lds_cap ? lds_cap * 12 + 8 + 8 * order_threads_ : bytes;
+            oworst = in_lds > oworst ? in_lds : oworst;
+        }
+        order_smem_ = (size_t)oworst;
         order_lds_ = oworst <= (int64_t)bk_.lds_budget();
-        if (!order_lds_) {
+        os_.lds_list_cap = (int32_t)lds_cap;
+        if (!order_lds_ || any_slab) {
             os_.off = up(ooff.data(), NG);
-            os_.gbuf = (char*)dalloc((size_t)ototal);
+            os_.gbuf = (char*)dalloc((size_t)(ototal > 0 ? ototal : 256));
         }
         // ---- results ----
         dr_.order = (int32_t*)dalloc(4 * ((size_t)nnz_cap_ + 1)); dr_.placed = (int32_t*)dalloc(4 * (size_t)nnz_cap_);

@@ -113,6 +113,7 @@ struct OrderScratch {
     const int64_t* off;  // [NG] byte offset into gbuf (global variant)
     char* gbuf;
     int64_t* prof;       // [NG][4] phase ticks (CASIM_PACK_PROF builds) or null
+    int32_t lds_list_cap; // > 0: the launch's LDS holds lists up to this length, longer ones use gbuf (LDS variant only)
 };
 
 // bytes of packer state per simulated node (8-byte fields first)
