@@ -365,10 +365,14 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
     char* base = kLds ? cs::dyn_smem() : os.gbuf + os.off[ng];
     uint64_t* keys = (uint64_t*)base;           // [npad]
     int32_t* pos = (int32_t*)(keys + npad);     // [npad]
+    int32_t* gid = pos + npad;                  // [npad] PEG id of list position i (read back after the sort: one dependent
+                                                //        global gather less on the way to the records)
 #pragma unroll
     for (int i = tid; i < npad; i += nt) {
         if (i < Gn) {
-            keys[i] = desc_key(peg_score(t, t.peg_idx[off + i], ng));
+            const int g = t.peg_idx[off + i];
+            gid[i] = g;
+            keys[i] = desc_key(peg_score(t, g, ng));
             pos[i] = i;
         } else {
             keys[i] = ~0ull;
@@ -413,12 +417,12 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
     // fastpath: the eligible PEG with the largest simulationsSaved, last one on ties, goes last
     int best = -1;
     if (t.fastpath && Gn > 0) {
-        int64_t* red = (int64_t*)(pos + npad + (npad & 1));  // [nt] 8-byte aligned
+        int64_t* red = (int64_t*)(gid + npad);  // [nt] 8-byte aligned (16 bytes per entry behind an 8-byte aligned base)
         int64_t mine = -1;
 #pragma unroll
         for (int i = tid; i < (NPAD > 0 ? NPAD : Gn); i += nt) {
             if (NPAD > 0 && i >= Gn) continue;
-            const int32_t sv = fastpath_saved(t, t.peg_idx[off + pos[i]], ng);
+            const int32_t sv = fastpath_saved(t, gid[pos[i]], ng);
             if (sv >= 0) {
                 const int64_t v = ((int64_t)sv << 32) | (uint32_t)i;
                 mine = v > mine ? v : mine;
@@ -446,7 +450,7 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
         // group's records with coalesced loads, 64 records per wave-load, and never chases indices.
         // The template-level Filters (taints, nodeSelector / affinity, unschedulable) are constant per
         // (PEG, group): evaluate them once here and hand them over as one flag bit.
-        const int g = t.peg_idx[off + pos[src]];
+        const int g = gid[pos[src]];
         res.order[off + i] = g;
         // (lists derived by the feasibility kernel only hold PEGs that passed these Filters already)
         const uint32_t flags = (t.pflags[g] & ~CASIM_KFLAG_STATIC_OK) | ((t.lists_from_feas || static_filters_pass(t, g, ng)) ? CASIM_KFLAG_STATIC_OK : 0u);

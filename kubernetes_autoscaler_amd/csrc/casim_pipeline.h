@@ -267,9 +267,9 @@ public:
         for (size_t i = 0; i < NG; ++i) {
             // (a one-wave block sorts lists of <= 256 PEGs in a network of 64 / 128 / 256 entries: never less than 64)
             const int64_t entries = order_threads_ == 64 && npad_of[i] < 64 ? 64 : npad_of[i];
-            const int64_t bytes = entries * 12 + 8 + 8 * order_threads_;
+            const int64_t bytes = entries * 16 + 8 + 8 * order_threads_;   // keys, positions, PEG ids + the fastpath reduction
             if (lds_cap == 0 || npad_of[i] > lds_cap) { ooff[i] = ototal; ototal += (bytes + 255) & ~255ll; any_slab = any_slab || lds_cap > 0; }
-            const int64_t in_lds = lds_cap > 0 && npad_of[i] > lds_cap ? lds_cap * 12 + 8 + 8 * order_threads_ : bytes;
+            const int64_t in_lds = lds_cap > 0 && npad_of[i] > lds_cap ? lds_cap * 16 + 8 + 8 * order_threads_ : bytes;
             oworst = in_lds > oworst ? in_lds : oworst;
         }
         order_smem_ = (size_t)oworst;
