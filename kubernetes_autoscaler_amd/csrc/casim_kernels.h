@@ -124,6 +124,9 @@ CS_GLOBAL void feas_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg]*/,
 // word (checked by the host, which falls back to feas_kernel otherwise).
 // req32 / fresh32 (optional): the gcd-scaled int32 lanes of the register packer (exact: the gcd divides every value of a lane),
 // two 32-bit compares per cell instead of 64-bit subtract + compare chains.
+// The group records of the simulation are staged in LDS first (dynamic LDS: 128 bytes per group of the largest simulation): one
+// coalesced load phase per block, then every group costs a few LDS broadcast reads — as global loads behind the `bits` store
+// of the previous group each field was its own dependent round trip (0.146 ms at 4096 x 20 groups, three times the issue time).
 CS_GLOBAL void feas_sim_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg]*/, int Wg, const int32_t* CS_RESTRICT req32,
                                const int32_t* CS_RESTRICT fresh32) {
     const int sim = cs::bid_y();
@@ -133,11 +136,34 @@ CS_GLOBAL void feas_sim_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg
     const int k = cs::bid() * cs::nthreads() + cs::tid();
     const bool live = lo + k < hi;
     const int g = live ? lo + k : (hi > lo ? lo : 0);
+    const bool narrow = req32 != nullptr && t.R <= 4;
+    // ---- stage: record i = 16 x uint64: [0] taint [1] label [2] node-local exclusion [3] group-wide exclusion
+    //      [4] flags | free pod slots << 32   [5..6] scaled free lanes (int32 pairs, narrow)   [8..15] free lanes (int64, wide)
+    uint64_t* grec = (uint64_t*)cs::dyn_smem();
+    for (int i = cs::tid(); i < (g1 - g0) * 16; i += cs::nthreads()) {
+        const int ng = g0 + (i >> 4), f = i & 15;
+        uint64_t v = 0;
+        if (f == 0) v = t.Wt ? t.taint[(int64_t)ng * t.Wt] : 0ull;
+        else if (f == 1) v = t.Wl ? t.label[(int64_t)ng * t.Wl] : ~0ull;
+        else if (f == 2) v = t.Wx ? t.init_excl[(int64_t)ng * t.Wx] : 0ull;
+        else if (f == 3) v = t.Wz ? t.init_zone[(int64_t)ng * t.Wz] : 0ull;
+        else if (f == 4) v = (uint64_t)t.gflags[ng] | ((uint64_t)(uint32_t)(t.allowed[ng] - t.init_pods[ng]) << 32);
+        else if (f == 5 || f == 6) {
+            if (narrow) {
+                const int r = (f - 5) * 2;
+                const uint32_t a = r < t.R ? (uint32_t)fresh32[(int64_t)ng * t.R + r] : 0u, b2 = r + 1 < t.R ? (uint32_t)fresh32[(int64_t)ng * t.R + r + 1] : 0u;
+                v = (uint64_t)a | ((uint64_t)b2 << 32);
+            }
+        } else if (f >= 8) {
+            const int r = f - 8;
+            if (!narrow && r < t.R) v = (uint64_t)(t.alloc[(int64_t)ng * t.R + r] - t.init_req[(int64_t)ng * t.R + r]);
+        }
+        grec[i] = v;
+    }
     // the PEG record, once
     int64_t req[CASIM_KMAX_RES];
     int32_t rq32[4] = {0, 0, 0, 0};
     bool all_zero = true;
-    const bool narrow = req32 != nullptr && t.R <= 4;
     for (int r = 0; r < CASIM_KMAX_RES; ++r) {
         if (narrow) { if (r < 4) { rq32[r] = (live && r < t.R) ? req32[(int64_t)g * t.R + r] : 0; all_zero = all_zero && rq32[r] == 0; } req[r] = 0; }
         else { req[r] = (live && r < t.R) ? t.req[(int64_t)g * t.R + r] : 0; all_zero = all_zero && req[r] == 0; }
@@ -145,29 +171,29 @@ CS_GLOBAL void feas_sim_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg
     const uint32_t pf = live ? t.pflags[g] : 0u;
     const uint64_t tol = (live && t.Wt) ? t.tol[(int64_t)g * t.Wt] : 0ull, sel = (live && t.Wl) ? t.sel[(int64_t)g * t.Wl] : 0ull;
     const uint64_t xb = (live && t.Wx) ? t.xblock[(int64_t)g * t.Wx] : 0ull, zb = (live && t.Wz) ? t.zblock[(int64_t)g * t.Wz] : 0ull;
+    cs::sync();
     for (int ng = g0; ng < g1; ++ng) {
-        // wave-uniform group record
-        bool ok = live;
-        if (t.Wt) ok = ok && (t.taint[(int64_t)ng * t.Wt] & ~tol) == 0;
-        if (t.Wl) ok = ok && (sel & ~t.label[(int64_t)ng * t.Wl]) == 0;
-        if ((t.gflags[ng] & CASIM_NG_UNSCHEDULABLE) && !(pf & CASIM_PEG_TOLERATES_UNSCHEDULABLE)) ok = false;
-        ok = ok && t.allowed[ng] - t.init_pods[ng] > 0;                     // fitsRequest: pod count first (fit.go:681-690)
+        const uint64_t* gr = grec + (int64_t)(ng - g0) * 16;   // wave-uniform address: LDS broadcast reads
+        const uint64_t fl = gr[4];
+        bool ok = live && (gr[0] & ~tol) == 0 && (sel & ~gr[1]) == 0;
+        if (((uint32_t)fl & CASIM_NG_UNSCHEDULABLE) && !(pf & CASIM_PEG_TOLERATES_UNSCHEDULABLE)) ok = false;
+        ok = ok && (int32_t)(fl >> 32) > 0;                                      // fitsRequest: pod count first (fit.go:681-690)
         if (!all_zero) {
             if (narrow) {
+                const uint64_t f01 = gr[5], f23 = gr[6];
+                const int32_t fr[4] = {(int32_t)(uint32_t)f01, (int32_t)(f01 >> 32), (int32_t)(uint32_t)f23, (int32_t)(f23 >> 32)};
                 for (int r = 0; r < 4; ++r) {
                     if (r >= t.R) break;
-                    ok = ok && (rq32[r] <= 0 || rq32[r] <= fresh32[(int64_t)ng * t.R + r]);
+                    ok = ok && (rq32[r] <= 0 || rq32[r] <= fr[r]);
                 }
             } else {
                 for (int r = 0; r < CASIM_KMAX_RES; ++r) {
                     if (r >= t.R) break;
-                    const int64_t fr = t.alloc[(int64_t)ng * t.R + r] - t.init_req[(int64_t)ng * t.R + r];
-                    ok = ok && (req[r] <= 0 || req[r] <= fr);                  // every requested lane fits once (:699-752)
+                    ok = ok && (req[r] <= 0 || req[r] <= (int64_t)gr[8 + r]);      // every requested lane fits once (:699-752)
                 }
             }
         }
-        if (t.Wx) ok = ok && (xb & t.init_excl[(int64_t)ng * t.Wx]) == 0;
-        if (t.Wz) ok = ok && (zb & t.init_zone[(int64_t)ng * t.Wz]) == 0;
+        ok = ok && (xb & gr[2]) == 0 && (zb & gr[3]) == 0;
         const uint64_t b = cs::ballot(ok);
         if (cs::lane() == 0 && (k >> 6) < Wg) bits[(int64_t)ng * Wg + (k >> 6)] = b;
     }

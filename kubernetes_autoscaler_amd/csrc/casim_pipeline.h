@@ -159,7 +159,8 @@ public:
             if (cap > 0x7fffffffll) return fail(CASIM_ERR_INVALID, "sum of candidate PEG ranges too large for device-side CSR");
             nnz_cap_ = (int32_t)cap; feas_len_ = lmax;
             // simulation-major feasibility kernel: every group of a simulation shares its PEG range, one word per mask kind
-            feas_by_sim_ = n_sims_ > 0 && dt_.Wt <= 1 && dt_.Wl <= 1 && dt_.Wx <= 1 && dt_.Wz <= 1;
+            feas_by_sim_ = n_sims_ > 0 && dt_.Wt <= 1 && dt_.Wl <= 1 && dt_.Wx <= 1 && dt_.Wz <= 1 &&
+                           (size_t)128 * (size_t)max_sim_groups_ <= 48 * 1024;   // (the kernel stages a simulation's group records in LDS)
             for (int32_t si = 0; si < n_sims_ && feas_by_sim_; ++si)
                 for (int32_t i = g->sim_offsets[si] + 1; i < g->sim_offsets[si + 1]; ++i)
                     if (lo[(size_t)i] != lo[(size_t)g->sim_offsets[si]] || hi[(size_t)i] != hi[(size_t)g->sim_offsets[si]]) { feas_by_sim_ = false; break; }
@@ -306,7 +307,7 @@ public:
     int32_t run_feasibility() {
         if (!csr_on_device_ || NG_ == 0) return CASIM_OK;
         if (feas_len_ > 0) {
-            if (feas_by_sim_) bk_.launch(feas_sim_kernel, (feas_len_ + 255) / 256, n_sims_, 256, (size_t)0, dt_, d_bits_, Wg_,
+            if (feas_by_sim_) bk_.launch(feas_sim_kernel, (feas_len_ + 255) / 256, n_sims_, 256, (size_t)128 * (size_t)max_sim_groups_, dt_, d_bits_, Wg_,
                                          fast_npt_ > 0 ? fs_.req32 : (const int32_t*)nullptr, fast_npt_ > 0 ? fs_.fresh32 : (const int32_t*)nullptr);
             else bk_.launch(feas_kernel, (feas_len_ + 255) / 256, NG_, 256, (size_t)0, dt_, d_bits_, Wg_);
         }
