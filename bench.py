@@ -80,13 +80,19 @@ def checks_of(ts, res):
 
 def algorithmic_bytes_pack(dims, n_groups, nnz, fast):
     """sum_NG (G_NG * Bp) + NG * Bn + sum_NG (8 + 8 * G_NG) with the record sizes of the packer that runs.
-    Bp = PEG record read per (group, PEG): request lanes + count + flags + order entry (+ masks); Bn = node-group record;
-    written: placed per PEG + 40 B of counters per group.  The register packer reads gcd-scaled int32 lanes."""
+    Bp = PEG record read per (group, PEG); Bn = node-group record; written: placed per PEG + 40 B of counters per group.
+    Register packer: ONE record of 32 B (<= 2 lanes) or 64 B (<= 4 lanes) per PEG — count, flags + fresh-node capacity, the
+    gcd-scaled int32 requests and their reciprocals (csrc/casim_types.h) — plus the order entry when mask tables are indexed.
+    Generic packer: int64 request lanes + count + flags + order entry + mask words."""
     R = dims["n_res"]
-    lane_bytes = 4 if fast else 8
     wsum = dims["w_taint"] + dims["w_label"] + 2 * dims["w_excl"] + 2 * dims["w_zone"]
-    Bp = lane_bytes * R + 4 + 4 + 4 + (0 if fast else 8 * wsum) + (8 * 2 * (dims["w_excl"] + dims["w_zone"]) if fast else 0)
-    Bn = lane_bytes * R + 4 * 6 + 8 * (dims["w_excl"] + 2 * dims["w_zone"])
+    masks = dims["w_excl"] + dims["w_zone"]
+    if fast:
+        Bp = (32 if R <= 2 else 64) + (4 + 8 * 2 * masks if masks else 0)
+        Bn = 4 * R + 4 * 6 + 8 * (dims["w_excl"] + 2 * dims["w_zone"])
+    else:
+        Bp = 8 * R + 4 + 4 + 4 + 8 * wsum
+        Bn = 8 * R + 4 * 6 + 8 * (dims["w_excl"] + 2 * dims["w_zone"])
     return nnz * Bp + n_groups * Bn + n_groups * 40 + 4 * nnz, Bp, Bn
 
 
@@ -468,7 +474,7 @@ def main():
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
                     "algorithmic_bytes_per_launch": bytes_pack, "bytes_per_peg_record": Bp, "bytes_per_group_record": Bn,
                     "kernel_ms": kms["pack_ms"], "share_of_step": kms["pack_ms"] / max(total_ms, 1e-9),
-                    "note": "the packer is bound by VALU / SALU instruction issue (sequential per-PEG dependency), not by HBM: "
+                    "note": "the packer is bound by scalar / vector instruction ISSUE (sequential per-PEG dependency), not by HBM: "
                             "see issue_roofline; DESIGN.md section 4"}
         # PMC figures of the same command (separate rocprofv3 --pmc passes, tools/gpu_round.sh -> tools/pmc_*.py): counters
         # cannot be collected from inside the timed run; the committed figures are used when they were taken on the same
@@ -482,16 +488,19 @@ def main():
                     # issue roofline: one VALU / SALU wave-instruction holds its SIMD's issue port ~4 cycles (measured:
                     # SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.0 quad-cycle); 1024 SIMDs x 2.4 GHz
                     cyc = tr.get("cycles_per_valu", 4.0)
-                    t_issue = tr["valu_insts_per_launch"] * cyc / (SIMDS * CLOCK_HZ)
-                    roofline["issue_roofline"] = {"bound": "valu_issue", "valu_insts_per_launch": tr["valu_insts_per_launch"],
-                                                  "salu_insts_per_launch": tr.get("salu_insts_per_launch"),
-                                                  "cycles_per_valu_inst": cyc, "issue_time_ms": t_issue * 1e3,
+                    # a SIMD issues at most one VALU and one scalar instruction per ~4 cycles (different waves): the port with
+                    # more instructions bounds the kernel
+                    valu, salu = tr["valu_insts_per_launch"], tr.get("salu_insts_per_launch") or 0
+                    port = "salu_issue" if salu > valu else "valu_issue"
+                    t_issue = max(valu, salu) * cyc / (SIMDS * CLOCK_HZ)
+                    roofline["issue_roofline"] = {"bound": port, "valu_insts_per_launch": valu, "salu_insts_per_launch": salu,
+                                                  "cycles_per_inst": cyc, "issue_time_ms": t_issue * 1e3,
                                                   "frac": t_issue / (kms["pack_ms"] * 1e-3), "clock_ghz_assumed": CLOCK_HZ / 1e9,
                                                   "source": tr.get("run", "?")}
                     if tr.get("effective_clock_ghz"):   # the chip clocks to its power budget: the same fraction at the measured clock
                         ec = tr["effective_clock_ghz"]
                         roofline["issue_roofline"]["effective_clock_ghz"] = ec
-                        roofline["issue_roofline"]["frac_at_effective_clock"] = tr["valu_insts_per_launch"] * cyc / (SIMDS * ec * 1e9) / (kms["pack_ms"] * 1e-3)
+                        roofline["issue_roofline"]["frac_at_effective_clock"] = max(valu, salu) * cyc / (SIMDS * ec * 1e9) / (kms["pack_ms"] * 1e-3)
         except (OSError, ValueError, KeyError):
             pass
         extra = {"kernel_ms": kms, "pipeline_ms_hip_events": total_ms, "encode_s_python_mirror": t_encode, "upload_s": t_upload,

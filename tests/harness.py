@@ -655,3 +655,20 @@ def resident_iteration(make_cluster, w, n_candidates=4):
     st = cl.stats()
     s.close(); cl.close(); enc.close()
     return {"scheduled": int(ns1), "removable": int((got3.removable == 1).sum()), "stats": st}
+
+
+def mixed_list_simulations():
+    """Four simulations whose PEG lists are 40, 300, 700 and 120 long (three node groups each, limits 4 / 7 / none): lists
+    beyond the orderer's one-wave networks, several record chunks per group in the packer, most PEGs behind a dry limiter."""
+    from kubernetes_autoscaler_amd.objects import GiB, MiB, Node, NodeInfo, Pod, PodEquivalenceGroup
+
+    def tmpl(cpu, mem, pods=110):
+        cap = {"cpu": cpu, "memory": mem, "pods": pods}
+        return NodeInfo(Node(name=f"t{cpu}", labels={}, allocatable=dict(cap), capacity=dict(cap)))
+
+    def sim(n_pegs, salt):
+        pegs = [PodEquivalenceGroup(pods=[Pod(name="p", requests={"cpu": 50 + ((i * 131 + salt) % 1500), "memory": (1 + (i * 7 + salt) % 40) * 100 * MiB})] * (1 + (i + salt) % 5))
+                for i in range(n_pegs)]
+        return Scenario(pegs=pegs, groups=[GroupSpec(tmpl(4000, 16 * GiB), 4), GroupSpec(tmpl(16000, 64 * GiB), 7), GroupSpec(tmpl(2000, 4 * GiB), 0)],
+                        device_csr=True)
+    return [sim(40, 1), sim(300, 2), sim(700, 3), sim(120, 4)]

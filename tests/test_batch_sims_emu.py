@@ -34,6 +34,20 @@ def test_batched_simulations_match_the_oracle_per_simulation(seed):
     enc.close()
 
 
+def test_lists_of_very_different_lengths_in_one_batch():
+    """40 / 300 / 700 / 120 PEGs per simulation: several record chunks per group in the packer, most PEGs behind a dry
+    limiter, lists beyond the orderer's one-wave networks (the GPU test tiles this batch to 3072 groups)."""
+    from harness import mixed_list_simulations
+    scs = mixed_list_simulations()
+    enc, ts, bases = encode_batch(scs)
+    res, _ = run_emu_tables(ts)
+    want = []
+    for sc, (pb, _) in zip(scs, bases):
+        want.extend(_shift(run_oracle(sc), pb))
+    assert_matches_oracle(res, want, "mixed list lengths")
+    enc.close()
+
+
 @pytest.mark.parametrize("seed", range(8))
 @pytest.mark.parametrize("kinds", KINDS)
 def test_expander_runs_once_per_simulation(seed, kinds):

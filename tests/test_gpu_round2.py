@@ -61,6 +61,28 @@ def test_large_tiled_batch_on_the_device(ctx):
     enc.close()
 
 
+def test_batch_with_lists_beyond_the_one_wave_networks(ctx):
+    """A batch (>= 2048 groups: one wave per group in the orderer, LDS sized for lists of <= 256 PEGs) whose simulations
+    mix short lists with lists of 300 and 700 PEGs: the long ones sort in the HBM slab of the same launch; the packer
+    walks them through several record chunks, most of it behind a dry limiter."""
+    from harness import mixed_list_simulations
+    scs = mixed_list_simulations()
+    enc, ts, bases = encode_batch(scs)
+    want = _oracle_of(scs, bases)
+    base, _ = run_gpu_tables(ts, ctx)
+    assert_matches_oracle(base, want, "mixed lists, small launch")
+    big = ts.tile(256)   # 3072 groups
+    res, _ = run_gpu_tables(big, ctx)
+    ng, nnz = ts.n_groups, int(base.offsets[-1])
+    for k in (0, 1, 128, 255):
+        assert list(res.node_count[k * ng:(k + 1) * ng]) == list(base.node_count)
+        assert list(res.pods_scheduled[k * ng:(k + 1) * ng]) == list(base.pods_scheduled)
+        assert list(res.last_index_out[k * ng:(k + 1) * ng]) == list(base.last_index_out)
+        assert list(res.placed[k * nnz:(k + 1) * nnz]) == list(base.placed)
+        assert [o - k * ts.n_pegs for o in res.order[k * nnz:(k + 1) * nnz]] == list(base.order)
+    enc.close()
+
+
 def test_reason_codes_on_the_device(ctx):
     from test_reasons_emu import emu_reasons, oracle_codes
     for seed in range(60):
