@@ -482,19 +482,24 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
         cur = cs::const_load<DW>(rp);
         if (kNeedG) g_cur = (int32_t)cs::const_load<1>((const uint32_t*)res.order + off).w[0];
     }
-    // results of a finished chunk: placed[] (one coalesced wave-store per 64 PEGs) and each lane's share of the
-    // sum(placed * request) totals — per lane and per chunk instead of two 64-bit scalar multiply-adds per PEG
+    // results of a finished chunk: placed[] (one coalesced wave-store per 64 PEGs); memory store: also each lane's share of
+    // the sum(placed * request) totals, per lane and per chunk instead of two 64-bit scalar multiply-adds per PEG
     int64_t acc0 = 0, acc1 = 0;
     auto flush_chunk = [&](int kbase) {
-        const bool have = kbase + lane < Gn;
-        if (have) res.placed[off + kbase + lane] = my_placed;
-        L r0, r1;
-        if constexpr (kRecScalar) {   // the lane's own record, straight from memory (once per 64 PEGs)
-            r0 = have ? (L)recp[(int64_t)(kbase + lane) * DW + 2] : (L)0;
-            r1 = (have && RM > 1) ? (L)recp[(int64_t)(kbase + lane) * DW + 3] : (L)0;
-        } else { r0 = my_req[0]; r1 = RM > 1 ? my_req[1] : (L)0; }
-        acc0 += (int64_t)my_placed * (int64_t)r0;   // lanes without a record hold my_placed == 0
-        acc1 += (int64_t)my_placed * (int64_t)r1;
+        if (kbase + lane < Gn) res.placed[off + kbase + lane] = my_placed;
+        if constexpr (!kRecScalar) {
+            acc0 += (int64_t)my_placed * (int64_t)my_req[0];   // lanes without a record hold my_placed == 0
+            acc1 += (int64_t)my_placed * (int64_t)(RM > 1 ? my_req[1] : (L)0);
+        }
+    };
+    // register store: the totals grow where a PEG records what it placed — every lane the same product, on the VALU (the
+    // scalar unit is the busy one, and as scalar 64-bit multiply-adds these are eight instructions).  Reading the lane's own
+    // record back at the chunk flush instead touched every record line a second time, 64 PEGs after the scalar load had
+    // dropped it from the caches: the kernel's HBM read traffic was twice its algorithmic bytes (profiles/r03c).
+    auto add_totals = [&](int32_t placed, int32_t q0, int32_t q1) {
+        const int32_t pv_ = cs::opaque_i32(placed);   // (a VGPR copy: keeps the arithmetic off the scalar unit)
+        acc0 += (int64_t)pv_ * (int64_t)q0;
+        acc1 += (int64_t)pv_ * (int64_t)q1;
     };
     // One PEG.  kDry = the limiter has run dry (newNodesAvailable == false): a3 / a4 can never be entered again, and a PEG that
     // fits no simulated node leaves no trace at all (placed 0, my_placed already 0, lastIndex kept) — in C2 that is 60 % of
@@ -696,6 +701,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     if constexpr (kDry) {   // placed > 0 here; the tail of the step does not run
                         uint32_t mp = (uint32_t)my_placed; cs::write_lane_u32(mp, (uint32_t)placed, j); my_placed = (int32_t)mp;
                         total_placed += placed;
+                        add_totals(placed, (int32_t)pv.req[0], RM > 1 ? (int32_t)pv.req[1] : 0);
                     }
                 };
                 if constexpr (Store::kNPT == 1) {
@@ -839,8 +845,10 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
 
             CASIM_PROF(5);  // a3 / a4
             if constexpr (!kDry) {   // (kDry: a2 recorded what it placed, nothing else can place)
-                if constexpr (kRecScalar) { uint32_t mp = (uint32_t)my_placed; cs::write_lane_u32(mp, (uint32_t)placed, j); my_placed = (int32_t)mp; }
-                else { if (lane == j) my_placed = placed; }
+                if constexpr (kRecScalar) {
+                    uint32_t mp = (uint32_t)my_placed; cs::write_lane_u32(mp, (uint32_t)placed, j); my_placed = (int32_t)mp;
+                    add_totals(placed, (int32_t)pv.req[0], RM > 1 ? (int32_t)pv.req[1] : 0);
+                } else { if (lane == j) my_placed = placed; }
                 total_placed += placed;
             }
         }
@@ -867,7 +875,9 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
         M = (int32_t)a; granted = (int32_t)b; last_index = (int32_t)c; total_placed = (int32_t)d; fakes = (int32_t)e;
     }
     if (Gn > 0) flush_chunk((Gn - 1) & ~63);   // the last (possibly partial) chunk
-    const int64_t sum0 = (int64_t)cs::wave_sum_u64((uint64_t)acc0), sum1 = (int64_t)cs::wave_sum_u64((uint64_t)acc1);
+    int64_t sum0, sum1;
+    if constexpr (kRecScalar) { sum0 = (int64_t)cs::bcast_u64((uint64_t)acc0, 0); sum1 = (int64_t)cs::bcast_u64((uint64_t)acc1, 0); }   // (every lane holds the total)
+    else { sum0 = (int64_t)cs::wave_sum_u64((uint64_t)acc0); sum1 = (int64_t)cs::wave_sum_u64((uint64_t)acc1); }
 
     CASIM_PROF(0);
     CASIM_PROF_STORE(prof_out);
