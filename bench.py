@@ -347,6 +347,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4096, help="independent C2 simulations per GPU per step")
     ap.add_argument("--seeds", type=int, default=64, help="distinct simulations the batch is tiled from")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="the batch of a GPU runs as this many sub-batches on HIP streams of their own (one casim context each): the "
+                         "latency-bound feasibility / order kernels of one sub-batch overlap the issue-bound packer of another")
     ap.add_argument("--config", default="C2", choices=["C1", "C2", "C4"], help="headline config (C2 = BASELINE config[2])")
     ap.add_argument("--expander", default="least-nodes", choices=["least-nodes", "least-waste", "most-pods"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -397,20 +400,27 @@ def main():
     total_sims = B * world
     full = seed_set.tile((total_sims + S - 1) // S).head(total_sims)
     mine = full.shard(rank, world) if world > 1 else full
-    pegs, groups = mine.structs()
     n_sims = mine.n_sims
+    K = max(1, min(args.streams, n_sims))
+    cuts = [(n_sims * i) // K for i in range(K + 1)]
+    parts = [mine.sim_slice(cuts[i], cuts[i + 1]) for i in range(K)] if K > 1 else [mine]
 
-    # ONE explicit stream for libcasim's kernels AND torch's copies / collectives: the per-step reduce reads the keys the
-    # expander kernel just wrote (torch's default stream has handle 0, which casim_ctx_create takes as "create your own":
-    # the kernels would then run unordered with torch's work and a reduce could read or overwrite keys of another step)
-    side_stream = torch.cuda.Stream(device=dev_index)
+    # Explicit streams for libcasim's kernels AND torch's copies / collectives (torch's default stream has handle 0, which
+    # casim_ctx_create takes as "create your own": the kernels would then run unordered with torch's work).  Stream 0 of the
+    # list is also torch's current stream: the per-step reduce runs there after waiting for the other streams, and they wait
+    # for it before the next step overwrites the keys.
+    streams = [torch.cuda.Stream(device=dev_index) for _ in range(K)]
+    side_stream = streams[0]
     torch.cuda.set_stream(side_stream)
-    ctx = kaa.Context(dev_index, stream=side_stream.cuda_stream)
-    assert side_stream.cuda_stream != 0
+    assert all(st.cuda_stream != 0 for st in streams)
+    ctxs = [kaa.Context(dev_index, stream=st.cuda_stream) for st in streams]
+    ctx = ctxs[0]
     t0 = time.time()
-    prob = kaa.Problem(ctx, pegs, groups)
+    probs = [kaa.Problem(c, *part.structs()) for c, part in zip(ctxs, parts)]
+    prob = probs[0]
     t_upload = time.time() - t0
     keys = torch.full((n_sims,), 0x7FFFFFFFFFFFFFFF, dtype=torch.int64, device=f"cuda:{dev_index}")
+    key_ptr = [keys.data_ptr() + 8 * cuts[i] for i in range(K)]
 
     def allreduce(t, op):
         """RCCL reduces device tensors in place; the gloo self-test backend goes through the host."""
@@ -420,10 +430,15 @@ def main():
             h = t.cpu(); dist.all_reduce(h, op=op); t.copy_(h)
 
     def step():
-        prob.run()
-        prob.best_option_sims(kinds, per_sim=True, fetch=False, dev_packed_ptr=keys.data_ptr(), n_sims=n_sims)
+        for i in range(K):
+            probs[i].run()
+            probs[i].best_option_sims(kinds, per_sim=True, fetch=False, dev_packed_ptr=key_ptr[i], n_sims=parts[i].n_sims)
         if collective:
+            for st in streams[1:]:
+                side_stream.wait_stream(st)
             allreduce(keys, dist.ReduceOp.MIN)
+            for st in streams[1:]:
+                st.wait_stream(side_stream)
 
     for _ in range(args.warmup):
         step()
@@ -439,8 +454,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t_start
-    res = prob.fetch()
-    my_checks, my_nnz = checks_of(mine, res)
+    my_checks = my_nnz = 0
+    for p_, part in zip(probs, parts):
+        c_, z_ = checks_of(part, p_.fetch())
+        my_checks += c_; my_nnz += z_
+    part0_nnz = checks_of(parts[0], probs[0].fetch())[1]
     checks_per_step = my_checks
     if collective:
         tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev_index}")
@@ -466,7 +484,8 @@ def main():
         total_ms, kms = prob.time(iters=max(5, min(args.steps, 20)))
         info = prob.info()
         fast = info["fast_packer_slots_per_lane"] > 0
-        bytes_pack, Bp, Bn = algorithmic_bytes_pack(mine.dims, mine.n_groups, my_nnz, fast)
+        # (one launch = one sub-batch: bytes, duration and the PMC figures below are all per launch of sub-batch 0)
+        bytes_pack, Bp, Bn = algorithmic_bytes_pack(parts[0].dims, parts[0].n_groups, part0_nnz, fast)
         achieved = bytes_pack / (kms["pack_ms"] * 1e-3) / 1e9
         kname = ("pack_fast_kernel<%d,%d,%d>" % (info["fast_packer_lanes"], info["fast_packer_slots_per_lane"],
                                                   2 if (mine.dims["w_excl"] or mine.dims["w_zone"]) else 0)) if fast else "pack_kernel"
@@ -474,6 +493,7 @@ def main():
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
                     "algorithmic_bytes_per_launch": bytes_pack, "bytes_per_peg_record": Bp, "bytes_per_group_record": Bn,
                     "kernel_ms": kms["pack_ms"], "share_of_step": kms["pack_ms"] / max(total_ms, 1e-9),
+                    "launch": f"sub-batch 0 of {K}: {parts[0].n_sims} simulations, {parts[0].n_groups} node groups (one wave each), timed alone on its stream",
                     "note": "the packer is bound by scalar / vector instruction ISSUE (sequential per-PEG dependency), not by HBM: "
                             "see issue_roofline; DESIGN.md section 4"}
         # PMC figures of the same command (separate rocprofv3 --pmc passes, tools/gpu_round.sh -> tools/pmc_*.py): counters
@@ -481,7 +501,7 @@ def main():
         # kernel instantiation and launch size
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "pack_traffic.json")))
-            if tr.get("waves_per_launch") == mine.n_groups and kname.replace(" ", "").rstrip(">") in tr.get("kernel", "").replace(" ", ""):
+            if tr.get("waves_per_launch") == parts[0].n_groups and kname.replace(" ", "").rstrip(">") in tr.get("kernel", "").replace(" ", ""):
                 roofline["traffic"] = tr["traffic_bytes_per_launch"]
                 roofline["traffic_source"] = "profiles/pack_traffic.json (%s)" % tr.get("run", "?")
                 if "valu_insts_per_launch" in tr:
@@ -503,7 +523,9 @@ def main():
                         roofline["issue_roofline"]["frac_at_effective_clock"] = max(valu, salu) * cyc / (SIMDS * ec * 1e9) / (kms["pack_ms"] * 1e-3)
         except (OSError, ValueError, KeyError):
             pass
-        extra = {"kernel_ms": kms, "pipeline_ms_hip_events": total_ms, "encode_s_python_mirror": t_encode, "upload_s": t_upload,
+        extra = {"kernel_ms": kms, "pipeline_ms_hip_events": total_ms,
+                 "kernel_ms_note": f"HIP events around each kernel of sub-batch 0 ({parts[0].n_sims} of the {n_sims} simulations) running alone; "
+                                   f"in the timed step the {K} sub-batches overlap on their streams", "encode_s_python_mirror": t_encode, "upload_s": t_upload,
                  "sims_per_step": total_sims, "sims_per_s": total_sims / (dt / args.steps),
                  "timed_region_s": dt, "winners": {"simulations_with_an_option": int(have.sum()),
                                                    "mean_nodes_of_winner": float((winners[have] >> 20).mean()) if have.any() else None}}
@@ -528,8 +550,10 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
                "config": {"workload": f"{args.config} x {B} simulations per GPU per step ({desc}; {S} distinct seeds tiled), "
-                                      f"tables resident in HBM; step = feasibility + CSR + order + pack + expander reduce per simulation",
+                                      f"tables resident in HBM; step = feasibility + CSR + order + pack + expander reduce per simulation, "
+                                      f"the batch as {K} sub-batches on {K} HIP streams",
                           "batch_per_gpu": B, "distinct_seeds": S, "checks_per_simulation": checks_per_sim,
+                          "streams": K, "simulations_per_stream": [p_.n_sims for p_ in parts],
                           "node_groups_per_rank": mine.n_groups, "schedulable_peg_group_pairs_per_rank": my_nnz,
                           "expander": args.expander,
                           "partition": ("node groups of every simulation block-partitioned over the ranks (rotated), PEG table replicated"
@@ -541,8 +565,10 @@ def main():
         out.update(extra)
         out.update(side)
         print(json.dumps(out))
-    prob.close()
-    ctx.close()
+    for p_ in probs:
+        p_.close()
+    for c_ in ctxs:
+        c_.close()
     if collective:
         dist.barrier()
         dist.destroy_process_group()

@@ -130,6 +130,19 @@ class TableSet:
         return TableSet(one.dims, pc, gc, one.peg_lo[:ng], one.peg_hi[:ng], None, None,
                         None if one.global_id is None else one.global_id[:ng], one.sim_offsets[:n_sims + 1].copy())
 
+    def sim_slice(self, a: int, b: int) -> "TableSet":
+        """Simulations [a, b) as a table set of their own (their groups and the PEG rows they can see, re-based to 0): how a
+        batch is cut into sub-batches that run on different HIP streams of one device."""
+        one = self if self.peg_lo is not None else self.as_one_simulation()
+        a, b = max(0, a), min(b, one.n_sims)
+        g0, g1 = int(one.sim_offsets[a]), int(one.sim_offsets[b])
+        p0 = int(one.peg_lo[g0:g1].min()) if g1 > g0 else 0
+        p1 = int(one.peg_hi[g0:g1].max()) if g1 > g0 else 0
+        pc = {k: (None if v is None else v[p0:p1]) for k, v in one.pegs.items()}
+        gc = {k: (None if v is None else v[g0:g1]) for k, v in one.groups.items()}
+        return TableSet(one.dims, pc, gc, one.peg_lo[g0:g1] - p0, one.peg_hi[g0:g1] - p0, None, None,
+                        None if one.global_id is None else one.global_id[g0:g1], (one.sim_offsets[a:b + 1] - g0).astype(np.int32))
+
     def select_groups(self, keep: np.ndarray) -> "TableSet":
         """The groups `keep` (ascending indices) of every simulation: how one GPU's shard of a batch is cut out.  PEG table
         replicated, the groups keep their simulation-wide ids in expander keys."""

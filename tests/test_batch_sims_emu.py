@@ -34,6 +34,26 @@ def test_batched_simulations_match_the_oracle_per_simulation(seed):
     enc.close()
 
 
+def test_slices_of_a_batch_are_batches_of_their_own():
+    """TableSet.sim_slice: what bench.py hands to its HIP streams.  Every slice gives exactly its simulations' part of
+    the whole batch's results."""
+    scs = [_scenario(500 + k) for k in range(7)]
+    enc, ts, bases = encode_batch(scs)
+    whole, wexp = run_emu_tables(ts, kinds=[_abi.EXPANDER_LEAST_NODES])
+    for a, b in ((0, 3), (3, 4), (4, 7), (0, 7), (6, 7)):
+        part = ts.sim_slice(a, b)
+        res, exp = run_emu_tables(part, kinds=[_abi.EXPANDER_LEAST_NODES])
+        g0, g1 = int(ts.sim_offsets[a]), int(ts.sim_offsets[b])
+        assert list(res.node_count) == list(whole.node_count[g0:g1]) and list(res.pods_scheduled) == list(whole.pods_scheduled[g0:g1])
+        assert list(res.last_index_out) == list(whole.last_index_out[g0:g1])
+        z0, z1 = int(whole.offsets[g0]), int(whole.offsets[g1])
+        assert list(res.placed) [:z1 - z0] == list(whole.placed[z0:z1])
+        p0 = int(ts.peg_lo[g0])
+        assert [o + p0 for o in res.order[:z1 - z0]] == list(whole.order[z0:z1])
+        assert list(exp["packed"]) == list(wexp["packed"][a:b])   # (keys carry simulation-wide group ids)
+    enc.close()
+
+
 def test_lists_of_very_different_lengths_in_one_batch():
     """40 / 300 / 700 / 120 PEGs per simulation: several record chunks per group in the packer, most PEGs behind a dry
     limiter, lists beyond the orderer's one-wave networks (the GPU test tiles this batch to 3072 groups)."""
