@@ -343,7 +343,7 @@ def main():
         return None
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=600)
+    ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4096, help="independent C2 simulations per GPU per step")
     ap.add_argument("--seeds", type=int, default=64, help="distinct simulations the batch is tiled from")
@@ -480,11 +480,21 @@ def main():
         value = checks_per_step / (dt / args.steps)
         winners = keys.cpu().numpy()
         have = winners != 0x7FFFFFFFFFFFFFFF
-        # per-kernel HIP-event timing on the launch stream (libcasim: casim_problem_time)
-        total_ms, kms = prob.time(iters=max(5, min(args.steps, 20)))
+        # per-kernel HIP-event timing on the launch stream (libcasim: casim_problem_time), twice: in the regime of the timed
+        # region — the other streams keep running their sub-batches while sub-batch 0 is timed, which is what a kernel trace
+        # of this command sees — and with the device to itself (what the serialising PMC passes see)
+        n_time = max(5, min(args.steps, 20))
+        if K > 1:
+            for _ in range(n_time + 6):
+                for i in range(1, K):
+                    probs[i].run()
+                    probs[i].best_option_sims(kinds, per_sim=True, fetch=False, dev_packed_ptr=key_ptr[i], n_sims=parts[i].n_sims)
+        total_ms, kms = prob.time(iters=n_time)
+        torch.cuda.synchronize()
+        alone_ms, kms_alone = prob.time(iters=n_time) if K > 1 else (total_ms, kms)
         info = prob.info()
         fast = info["fast_packer_slots_per_lane"] > 0
-        # (one launch = one sub-batch: bytes, duration and the PMC figures below are all per launch of sub-batch 0)
+        # (one launch = one sub-batch: bytes, durations and the PMC figures below are all per launch of sub-batch 0)
         bytes_pack, Bp, Bn = algorithmic_bytes_pack(parts[0].dims, parts[0].n_groups, part0_nnz, fast)
         achieved = bytes_pack / (kms["pack_ms"] * 1e-3) / 1e9
         kname = ("pack_fast_kernel<%d,%d,%d>" % (info["fast_packer_lanes"], info["fast_packer_slots_per_lane"],
@@ -493,9 +503,13 @@ def main():
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
                     "algorithmic_bytes_per_launch": bytes_pack, "bytes_per_peg_record": Bp, "bytes_per_group_record": Bn,
                     "kernel_ms": kms["pack_ms"], "share_of_step": kms["pack_ms"] / max(total_ms, 1e-9),
-                    "launch": f"sub-batch 0 of {K}: {parts[0].n_sims} simulations, {parts[0].n_groups} node groups (one wave each), timed alone on its stream",
+                    "launch": f"sub-batch 0 of {K}: {parts[0].n_sims} simulations, {parts[0].n_groups} node groups (one wave each); "
+                              f"kernel_ms = its average duration while the other {K - 1} stream(s) run their sub-batches (the timed region's regime)",
+                    "device_to_itself": {"kernel_ms": kms_alone["pack_ms"], "achieved": bytes_pack / (kms_alone["pack_ms"] * 1e-3) / 1e9,
+                                         "frac": bytes_pack / (kms_alone["pack_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                         "kernel_ms_all": kms_alone, "pipeline_ms": alone_ms},
                     "note": "the packer is bound by scalar / vector instruction ISSUE (sequential per-PEG dependency), not by HBM: "
-                            "see issue_roofline; DESIGN.md section 4"}
+                            "see issue_roofline (counters and duration of the launch with the device to itself); DESIGN.md section 4"}
         # PMC figures of the same command (separate rocprofv3 --pmc passes, tools/gpu_round.sh -> tools/pmc_*.py): counters
         # cannot be collected from inside the timed run; the committed figures are used when they were taken on the same
         # kernel instantiation and launch size
@@ -515,17 +529,17 @@ def main():
                     t_issue = max(valu, salu) * cyc / (SIMDS * CLOCK_HZ)
                     roofline["issue_roofline"] = {"bound": port, "valu_insts_per_launch": valu, "salu_insts_per_launch": salu,
                                                   "cycles_per_inst": cyc, "issue_time_ms": t_issue * 1e3,
-                                                  "frac": t_issue / (kms["pack_ms"] * 1e-3), "clock_ghz_assumed": CLOCK_HZ / 1e9,
+                                                  "frac": t_issue / (kms_alone["pack_ms"] * 1e-3), "clock_ghz_assumed": CLOCK_HZ / 1e9,
                                                   "source": tr.get("run", "?")}
                     if tr.get("effective_clock_ghz"):   # the chip clocks to its power budget: the same fraction at the measured clock
                         ec = tr["effective_clock_ghz"]
                         roofline["issue_roofline"]["effective_clock_ghz"] = ec
-                        roofline["issue_roofline"]["frac_at_effective_clock"] = max(valu, salu) * cyc / (SIMDS * ec * 1e9) / (kms["pack_ms"] * 1e-3)
+                        roofline["issue_roofline"]["frac_at_effective_clock"] = max(valu, salu) * cyc / (SIMDS * ec * 1e9) / (kms_alone["pack_ms"] * 1e-3)
         except (OSError, ValueError, KeyError):
             pass
         extra = {"kernel_ms": kms, "pipeline_ms_hip_events": total_ms,
-                 "kernel_ms_note": f"HIP events around each kernel of sub-batch 0 ({parts[0].n_sims} of the {n_sims} simulations) running alone; "
-                                   f"in the timed step the {K} sub-batches overlap on their streams", "encode_s_python_mirror": t_encode, "upload_s": t_upload,
+                 "kernel_ms_note": f"HIP events around each kernel of sub-batch 0 ({parts[0].n_sims} of the {n_sims} simulations) while the other "
+                                   f"{K - 1} stream(s) run theirs; roofline.device_to_itself has the same launch alone", "encode_s_python_mirror": t_encode, "upload_s": t_upload,
                  "sims_per_step": total_sims, "sims_per_s": total_sims / (dt / args.steps),
                  "timed_region_s": dt, "winners": {"simulations_with_an_option": int(have.sum()),
                                                    "mean_nodes_of_winner": float((winners[have] >> 20).mean()) if have.any() else None}}

@@ -49,6 +49,7 @@ CS_DEVICE bool lane_pred(uint64_t mask) { return ((mask >> (casim_emu::cur().tid
 CS_DEVICE void keep_scalar(uint32_t&) {}
 CS_DEVICE int32_t opaque_i32(int32_t v) { return v; }
 CS_DEVICE bool flag_set(uint32_t word, uint32_t bit) { return (word & bit) != 0; }
+CS_DEVICE uint32_t uniform_div_u32(uint32_t a, uint32_t b) { return a / b; }
 CS_DEVICE void write_lane_u32(uint32_t& v, uint32_t uniform_value, int uniform_lane) { if ((casim_emu::cur().tid & 63) == uniform_lane) v = uniform_value; }
 CS_DEVICE int popc64(uint64_t v) { return __builtin_popcountll(v); }
 CS_DEVICE int ffs64(uint64_t v) { return v ? __builtin_ctzll(v) : -1; }
@@ -160,6 +161,17 @@ CS_DEVICE int32_t opaque_i32(int32_t v) { asm volatile("" : "+v"(v)); return v; 
 // that every test is its own s_bitcmp + s_cbranch_scc.  A flag tested in several places as one bool is kept by the
 // compiler as a 64-bit lane mask (s_cselect_b64, then s_and_b64 with exec + s_cbranch_vcc at every use).
 CS_DEVICE bool flag_set(uint32_t word, uint32_t bit) { asm volatile("" : "+s"(word)); return (word & bit) != 0; }
+// a / b for wave-UNIFORM 32-bit values (b > 0) on the VECTOR unit: f64 reciprocal estimate + exact +-1 fix-up (the operands are
+// below 2^32, the estimate is within one of the quotient), ~10 VALU.  The compiler's expansion of a uniform division is ~17
+// scalar instructions around a v_rcp_f32 — and the scalar unit is the packer's bottleneck.
+CS_DEVICE uint32_t uniform_div_u32(uint32_t a, uint32_t b) {
+    uint32_t va = a, vb = b;
+    asm volatile("" : "+v"(va), "+v"(vb));   // vector copies: keeps the arithmetic below off the scalar unit
+    uint32_t q = (uint32_t)((double)va * __builtin_amdgcn_rcp((double)vb));
+    const uint64_t wide = (uint64_t)q * vb;   // (b may exceed 2^31: the fix-up compares the 64-bit product)
+    q = wide > va ? q - 1 : ((uint64_t)va - wide >= vb ? q + 1 : q);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+}
 // v[uniform_lane] = uniform_value: one v_writelane_b32 instead of lane-compare + select + move
 CS_DEVICE void write_lane_u32(uint32_t& v, uint32_t uniform_value, int uniform_lane) {
     // (one scalar register per VALU instruction on gfx9: the lane select travels in M0; readfirstlane is a no-op for values

@@ -413,6 +413,9 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     const int32_t maxn = gload(t.max_nodes, ng);
     const int32_t E = gload(t.existing, ng);
     const bool fast_last = t.fastpath && res.fast_last[ng];
+    // the limiter as one number: 0 = grants nothing (max_nodes < 0), INT32_MAX = no limit (max_nodes == 0)
+    const int32_t grant_bound = maxn < 0 ? 0 : (maxn == 0 ? 0x7fffffff : maxn);
+    const int32_t fast_k = fast_last ? Gn - 1 : -1;   // the PEG that takes tryFastPath, if any
     const bool group_unschedulable = ((uint32_t)gload(t.gflags, ng) & CASIM_NG_UNSCHEDULABLE) != 0;
     const uint64_t* zvalid = t.zone_valid + (int64_t)ng * Wz;
     // group-wide exclusion state (anti-affinity on non-hostname keys): identical in every lane
@@ -759,14 +762,11 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         }
                     });
                 };
-                auto permission_left = [&]() -> int64_t {  // nodes the limiter would still grant
-                    if (maxn < 0) return 0;
-                    if (maxn == 0) return 0x7fffffffll;
-                    return maxn > granted ? (int64_t)(maxn - granted) : 0;
-                };
+                // nodes the limiter would still grant (granted never passes the bound: one subtraction)
+                auto permission_left = [&]() -> int64_t { return (int64_t)(grant_bound - granted); };
                 bool marked = false;
 
-                if (fast_last && k == Gn - 1) {
+                if (k == fast_k) {
                     // tryFastPath: one simulated node, the rest by arithmetic
                     if (permission_left() <= 0) more_mask = 0;
                     else {
@@ -777,7 +777,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         if (per > 0) {
                             marked = true;
                             placed += (int32_t)per;
-                            const int32_t size = (int32_t)(((uint32_t)rem + per - 1u) / per);  // scaleUpSize
+                            const int32_t size = (int32_t)cs::uniform_div_u32((uint32_t)rem + per - 1u, per);  // scaleUpSize
                             const int64_t left = permission_left();
                             const int32_t want = size - 1;
                             const int32_t nf = want < left ? want : (int32_t)left;
@@ -823,7 +823,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         } else {
                             // rem <= 2^31 - 1 and cn <= rem: 32-bit unsigned arithmetic is exact (an emulated
                             // 64-bit division here cost more than the whole node creation)
-                            const int64_t need = (int64_t)(((uint32_t)rem + cn - 1u) / cn);
+                            const int64_t need = (int64_t)cs::uniform_div_u32((uint32_t)rem + cn - 1u, cn);
                             const int64_t left = permission_left();
                             const int32_t nadd = (int32_t)(need < left ? need : left);
                             const int64_t fit = (int64_t)nadd * cn;

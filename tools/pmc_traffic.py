@@ -53,7 +53,9 @@ if g and g["grid_x"] == f["grid_x"]:
             if row and row[0]:
                 rec["gui_active_cycles_per_launch"] = g["kib"]
                 rec["kernel_ns_in_the_counter_pass"] = float(row[0])
-                rec["effective_clock_ghz"] = g["kib"] / float(row[0])
+                # the counter comes back summed over the 8 XCDs of the device (19.4 "GHz" otherwise)
+                rec["gui_active_xcds"] = 8
+                rec["effective_clock_ghz"] = g["kib"] / 8.0 / float(row[0])
         except sqlite3.Error:
             pass
 # calibration of the FETCH_SIZE rule on known streams (casim_stream_probe: 4 B / lane and 16 B / lane reads of 1 GiB)
