@@ -50,6 +50,7 @@ CS_DEVICE void keep_scalar(uint32_t&) {}
 CS_DEVICE int32_t opaque_i32(int32_t v) { return v; }
 CS_DEVICE bool flag_set(uint32_t word, uint32_t bit) { return (word & bit) != 0; }
 CS_DEVICE uint32_t uniform_div_u32(uint32_t a, uint32_t b) { return a / b; }
+CS_DEVICE uint32_t scalar_min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 CS_DEVICE void write_lane_u32(uint32_t& v, uint32_t uniform_value, int uniform_lane) { if ((casim_emu::cur().tid & 63) == uniform_lane) v = uniform_value; }
 CS_DEVICE int popc64(uint64_t v) { return __builtin_popcountll(v); }
 CS_DEVICE int ffs64(uint64_t v) { return v ? __builtin_ctzll(v) : -1; }
@@ -171,6 +172,14 @@ CS_DEVICE uint32_t uniform_div_u32(uint32_t a, uint32_t b) {
     const uint64_t wide = (uint64_t)q * vb;   // (b may exceed 2^31: the fix-up compares the 64-bit product)
     q = wide > va ? q - 1 : ((uint64_t)va - wide >= vb ? q + 1 : q);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+}
+// min of two wave-uniform values as ONE s_min_u32 (min(x, 1) written in C++ becomes "x != 0" as a lane mask, a v_cndmask and a
+// v_readfirstlane)
+CS_DEVICE uint32_t scalar_min_u32(uint32_t a, uint32_t b) {
+    a = (uint32_t)__builtin_amdgcn_readfirstlane((int)a); b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);   // (no-ops for scalar operands)
+    uint32_t r;
+    asm volatile("s_min_u32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc");
+    return r;
 }
 // v[uniform_lane] = uniform_value: one v_writelane_b32 instead of lane-compare + select + move
 CS_DEVICE void write_lane_u32(uint32_t& v, uint32_t uniform_value, int uniform_lane) {

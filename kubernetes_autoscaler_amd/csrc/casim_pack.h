@@ -415,7 +415,8 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     const bool fast_last = t.fastpath && res.fast_last[ng];
     // the limiter as one number: 0 = grants nothing (max_nodes < 0), INT32_MAX = no limit (max_nodes == 0)
     const int32_t grant_bound = maxn < 0 ? 0 : (maxn == 0 ? 0x7fffffff : maxn);
-    const int32_t fast_k = fast_last ? Gn - 1 : -1;   // the PEG that takes tryFastPath, if any
+    int32_t fast_k = fast_last ? Gn - 1 : -1;   // the PEG that takes tryFastPath, if any (pinned: one compare per PEG, not flag AND compare)
+    { uint32_t fk = (uint32_t)fast_k; cs::keep_scalar(fk); fast_k = (int32_t)fk; }
     const bool group_unschedulable = ((uint32_t)gload(t.gflags, ng) & CASIM_NG_UNSCHEDULABLE) != 0;
     const uint64_t* zvalid = t.zone_valid + (int64_t)ng * Wz;
     // group-wide exclusion state (anti-affinity on non-hostname keys): identical in every lane
@@ -734,7 +735,10 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             int32_t rem = cnt - placed;
             if (!kDry && (rem & more_mask) > 0) {   // pods left && newNodesAvailable
                 zblocked = Wz > 0 && zone_blocked(zblock);
-                bool blocked = !static_ok || zblocked;
+                // "no node of this group takes the PEG": the template-level Filters fail (CASIM_KFLAG_STATIC_OK clear — tested as a bit
+                // where it is needed: a wave-uniform bool costs scalar mask instructions) or the group-wide exclusion state blocks it
+                uint32_t zone_stop = zblocked ? 1u : 0u;
+                auto blocked = [&]() -> bool { return !cs::flag_set(pf, CASIM_KFLAG_STATIC_OK) || (Store::kHasZone && zone_stop != 0); };
                 // capacity of a FRESH node for this PEG
                 uint32_t cfresh = 0;
                 {
@@ -745,7 +749,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         if constexpr (kRecScalar) cf = cf_rec; else cf = cs::bcast_u32(my_cf, j);
                         cfresh = cf < (uint32_t)rem ? cf : (uint32_t)rem;
                     }
-                    if ((selfx || zselfx) && cfresh > 1) cfresh = 1;
+                    if (cs::flag_set(pf, CASIM_PEG_SELF_EXCL_NODE) || zselfx) cfresh = cs::scalar_min_u32(cfresh, 1u);
                 }
                 // the lane that owns node m writes its fresh state + x pods: node first+i gets
                 // min(per, pods_total - i*per) pods
@@ -771,7 +775,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     if (permission_left() <= 0) more_mask = 0;
                     else {
                         granted++;
-                        const uint32_t per = blocked ? 0u : (cfresh < (uint32_t)rem ? cfresh : (uint32_t)rem);
+                        const uint32_t per = blocked() ? 0u : (cfresh < (uint32_t)rem ? cfresh : (uint32_t)rem);
                         create_nodes(M, 1, per, (int32_t)per);
                         M++;
                         if (per > 0) {
@@ -792,12 +796,12 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     if (M > 0) {
                         const int lm = M - 1, owner = lm & 63;
                         uint32_t cl = 0;
-                        if (!blocked && !(selfx && on_last > 0))   // wave-uniform
+                        if (!blocked() && !(selfx && on_last > 0))   // wave-uniform
                             cl = cs::bcast_u32(st.capacity_newest(lm, pv, (uint32_t)rem, selfx || zselfx, lane == owner), owner);
                         if (cl > 0) {
                             st.commit_newest(lm, cl, pv, lane == owner);
                             placed += (int32_t)cl; rem -= (int32_t)cl; marked = true;
-                                    if (zselfx) blocked = true;
+                            if (zselfx) zone_stop = 1u;
                         }
                     }
                     bool stop = rem == 0;
@@ -809,7 +813,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     // (without zone state the body runs at most once: a straight line instead of a loop whose
                     // back edge carried the whole register state)
                     auto new_nodes = [&]() -> bool {   // false = done
-                        const uint32_t cn = blocked ? 0u : cfresh;
+                        const uint32_t cn = blocked() ? 0u : cfresh;
                         if (cn == 0 || zselfx) {
                             if (permission_left() <= 0) { more_mask = 0; return false; }       // :244-246
                             granted++;
@@ -818,7 +822,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                             M++;
                             if (x == 0) return false;                                   // :257-263 node stays, PEG abandoned
                             placed += (int32_t)x; rem -= (int32_t)x; marked = true;
-                            blocked = true;                                             // zselfx: the group now holds one
+                            zone_stop = 1u;                                             // zselfx: the group now holds one
                             return Store::kHasZone && rem != 0;
                         } else {
                             // rem <= 2^31 - 1 and cn <= rem: 32-bit unsigned arithmetic is exact (an emulated
