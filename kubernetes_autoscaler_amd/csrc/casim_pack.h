@@ -792,8 +792,12 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         }
                     }
                 } else {
-                    // next-fit on the newest node (:198-209)
-                    if (M > 0) {
+                    // next-fit on the newest node (:198-209).  When a2 ran for this PEG it walked EVERY simulated node, the newest
+                    // included, with the same predicate, and left pods over: the newest node is full for this PEG (register store
+                    // without group-wide state: a2 ran iff the gate bit was set)
+                    bool newest_may_fit = M > 0;
+                    if constexpr (kRecScalar && !Store::kHasZone) newest_may_fit = M > 0 && (pf & a2_gate) == 0;
+                    if (newest_may_fit) {
                         const int lm = M - 1, owner = lm & 63;
                         uint32_t cl = 0;
                         if (!blocked() && !(selfx && on_last > 0))   // wave-uniform
