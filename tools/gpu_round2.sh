@@ -54,7 +54,7 @@ if [ "$MODE" != "prof" ]; then
 fi
 
 if [ "$MODE" != "quick" ]; then
-  BARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-configs --no-next-rows --no-c3"
+  BARGS="--steps 300 --warmup 5 --no-cpu-baseline --no-configs --no-next-rows --no-c3"   # (the timed region dominates the trace: its kernels overlap across streams)
   echo "== rocprofv3 kernel trace ==" | tee -a "$S"
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --truncate-kernels -d "$OLDPWD/$OUT/prof_trace" -o trace -- \
       python "$OLDPWD/bench.py" $BARGS > "$OLDPWD/$OUT/prof_trace.log" 2>&1)
