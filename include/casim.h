@@ -570,6 +570,13 @@ int32_t casim_estimate_on_cluster(casim_ctx* ctx, const casim_pegs* classes, con
  * named kernel classes.  kernel_ms_out: [0]=feasibility+csr [1]=order [2]=pack (may be NULL). */
 int32_t casim_problem_time(casim_problem* p, int32_t iters, float* total_ms_out,
                            float* kernel_ms_out);
+/* The same measurement WITHOUT stopping the stream: casim_problem_run_marked is casim_problem_run with HIP events recorded
+ * around the three kernel classes (nothing waits; up to 64 marked runs are kept, older ones are overwritten);
+ * casim_problem_marked_ms waits for the stream and returns the mean milliseconds over the marked runs (and forgets
+ * them).  For kernels that overlap with work of other streams — sub-batches of one batch on several contexts — this is
+ * what a kernel trace of the same loop sees. */
+int32_t casim_problem_run_marked(casim_problem* p);
+int32_t casim_problem_marked_ms(casim_problem* p, float* total_ms_out, float* kernel_ms_out /*[3]*/, int32_t* n_runs_out);
 /* Device-to-device copy bandwidth probe (GB/s) used as the "achievable HBM" reference. */
 int32_t casim_copy_bandwidth(casim_ctx* ctx, int64_t bytes, int32_t iters, double* gbps_out);
 

@@ -160,6 +160,8 @@ PROTOTYPES = {
     "casim_cluster_fetch_nodes": (C.c_int32, [C.c_void_p, i64p, i32p, u64p]),
     "casim_cluster_stats": (C.c_int32, [C.c_void_p, i64p]),
     "casim_problem_time": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "casim_problem_run_marked": (C.c_int32, [C.c_void_p]),
+    "casim_problem_marked_ms": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "casim_try_schedule_pods": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(PodSequence), i32p, i32p, i32p]),
     "casim_time_try_schedule_pods": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(PodSequence), C.c_int32,
                                                  C.POINTER(C.c_float)]),

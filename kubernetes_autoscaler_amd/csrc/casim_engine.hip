@@ -163,6 +163,8 @@ struct casim_cluster {
 struct casim_problem {
     casim_ctx* ctx;
     HipProblem* prob;
+    std::vector<hipEvent_t> marks;   // casim_problem_run_marked: 4 events per kept run (created on first use)
+    int32_t n_marked = 0;
 };
 
 namespace casim {
@@ -251,6 +253,7 @@ void casim_problem_destroy(casim_problem* p) {
     if (!p) return;
     p->ctx->bk.bind();
     (void)hipStreamSynchronize(p->ctx->bk.stream);
+    for (hipEvent_t e : p->marks) (void)hipEventDestroy(e);
     delete p->prob;
     delete p;
 }
@@ -455,6 +458,47 @@ int32_t casim_problem_time(casim_problem* p, int32_t iters, float* total_ms_out,
     // mark as run so that fetch works after a timing loop
     const int32_t rc = p->prob->run();
     PROB_RET(p, rc != CASIM_OK ? rc : (bk.ok() ? CASIM_OK : CASIM_ERR_HIP));
+}
+
+static const int kMarkedRuns = 64;
+int32_t casim_problem_run_marked(casim_problem* p) {
+    PROB_ENTER(p);
+    HipBackend& bk = p->ctx->bk;
+    if (p->marks.empty()) {
+        p->marks.resize((size_t)kMarkedRuns * 4);
+        for (auto& e : p->marks) bk.check(hipEventCreate(&e), "hipEventCreate");
+    }
+    hipEvent_t* ev = p->marks.data() + (size_t)(p->n_marked % kMarkedRuns) * 4;
+    bk.check(hipEventRecord(ev[0], bk.stream), "hipEventRecord");
+    p->prob->run_feasibility();
+    bk.check(hipEventRecord(ev[1], bk.stream), "hipEventRecord");
+    p->prob->run_order();
+    bk.check(hipEventRecord(ev[2], bk.stream), "hipEventRecord");
+    p->prob->run_pack();
+    bk.check(hipEventRecord(ev[3], bk.stream), "hipEventRecord");
+    p->prob->run_mark();
+    p->n_marked++;
+    PROB_RET(p, bk.ok() ? CASIM_OK : CASIM_ERR_HIP);
+}
+
+int32_t casim_problem_marked_ms(casim_problem* p, float* total_ms_out, float* kernel_ms_out, int32_t* n_runs_out) {
+    PROB_ENTER(p);
+    HipBackend& bk = p->ctx->bk;
+    bk.sync();
+    const int n = p->n_marked < kMarkedRuns ? p->n_marked : kMarkedRuns;
+    double tot = 0, k[3] = {0, 0, 0};
+    for (int i = 0; i < n; ++i) {
+        hipEvent_t* ev = p->marks.data() + (size_t)i * 4;
+        float a = 0, b = 0, c = 0, d = 0;
+        (void)hipEventElapsedTime(&a, ev[0], ev[3]); (void)hipEventElapsedTime(&b, ev[0], ev[1]);
+        (void)hipEventElapsedTime(&c, ev[1], ev[2]); (void)hipEventElapsedTime(&d, ev[2], ev[3]);
+        tot += a; k[0] += b; k[1] += c; k[2] += d;
+    }
+    if (total_ms_out) *total_ms_out = n ? (float)(tot / n) : 0.f;
+    if (kernel_ms_out) for (int i = 0; i < 3; ++i) kernel_ms_out[i] = n ? (float)(k[i] / n) : 0.f;
+    if (n_runs_out) *n_runs_out = n;
+    p->n_marked = 0;
+    PROB_RET(p, bk.ok() ? CASIM_OK : CASIM_ERR_HIP);
 }
 
 // ---- filter-out-schedulable ---------------------------------------------------

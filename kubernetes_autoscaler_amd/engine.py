@@ -507,6 +507,17 @@ class Problem:
         check(lib.casim_best_option(self._h, ks, len(kinds), int(group_id_base), None, None, None, None,
                                     C.c_void_p(dev_key_ptr)), "casim_best_option")
 
+    def run_marked(self):
+        """run() with HIP events recorded around the kernel classes; nothing waits (see marked_ms)."""
+        check(lib.casim_problem_run_marked(self._h), "casim_problem_run_marked")
+
+    def marked_ms(self):
+        """Mean (total ms, per-kernel-class ms, runs) over the run_marked() calls since the last collection."""
+        tot, n = C.c_float(0), C.c_int32(0)
+        ks = (C.c_float * 3)()
+        check(lib.casim_problem_marked_ms(self._h, C.byref(tot), ks, C.byref(n)), "casim_problem_marked_ms")
+        return float(tot.value), {"feasibility_csr_ms": ks[0], "order_ms": ks[1], "pack_ms": ks[2]}, int(n.value)
+
     def time(self, iters: int = 10):
         tot = C.c_float(0)
         ks = (C.c_float * 3)()
