@@ -524,8 +524,11 @@ def main():
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "pack_traffic.json")))
             if tr.get("waves_per_launch") == parts[0].n_groups and kname.replace(" ", "").rstrip(">") in tr.get("kernel", "").replace(" ", ""):
-                roofline["traffic"] = tr["traffic_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/pack_traffic.json (%s)" % tr.get("run", "?")
+                # FETCH_SIZE corrected by the probe of the kernel's own access path when the PMC pass carried one (the register
+                # packer reads its records with scalar loads: stream_probe_scalar_kernel), else by the x2 rule of wide vector streams
+                roofline["traffic"] = tr.get("traffic_bytes_per_launch_by_scalar_probe", tr["traffic_bytes_per_launch"])
+                roofline["traffic_source"] = "profiles/pack_traffic.json (%s%s)" % (tr.get("run", "?"), ", FETCH_SIZE calibrated on 32-byte scalar loads"
+                                                                                   if "traffic_bytes_per_launch_by_scalar_probe" in tr else "")
                 if "valu_insts_per_launch" in tr:
                     # issue roofline: one VALU / SALU wave-instruction holds its SIMD's issue port ~4 cycles (measured:
                     # SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.0 quad-cycle); 1024 SIMDs x 2.4 GHz
@@ -555,7 +558,8 @@ def main():
         checks_per_sim = checks_per_step / total_sims
         if world == 1:   # side measurements and CPU legs at N = 1 only (other ranks would idle in a barrier)
             extra["copy_bandwidth_gbps"] = _try(lambda: ctx.copy_bandwidth_gbps(1 << 30, 10))
-            extra["read_stream_gbps"] = _try(lambda: {"4B_per_lane": ctx.stream_probe_gbps(1 << 30, 4, 5), "16B_per_lane": ctx.stream_probe_gbps(1 << 30, 16, 5)})
+            extra["read_stream_gbps"] = _try(lambda: {"4B_per_lane": ctx.stream_probe_gbps(1 << 30, 4, 5), "16B_per_lane": ctx.stream_probe_gbps(1 << 30, 16, 5),
+                                                             "32B_scalar_load_per_wave": ctx.stream_probe_gbps(1 << 30, 0, 5)})
             if not args.no_configs:
                 extra["configs"] = config_rows(kaa, ctx, workloads, kinds)
             if not args.no_next_rows:

@@ -581,7 +581,9 @@ int32_t casim_problem_marked_ms(casim_problem* p, float* total_ms_out, float* ke
 int32_t casim_copy_bandwidth(casim_ctx* ctx, int64_t bytes, int32_t iters, double* gbps_out);
 
 /* Read-only stream of `bytes` with `lane_bytes` (4 or 16) per lane and step: read bandwidth, and — under rocprofv3 --pmc
- * FETCH_SIZE — the calibration of the counter on that access width (kernel name stream_probe_kernel<4|16>). */
+ * FETCH_SIZE — the calibration of the counter on that access width (kernel name stream_probe_kernel<4|16>).
+ * lane_bytes == 0: the scalar form — every wave walks its own region with one 32-byte scalar load per step (kernel
+ * stream_probe_scalar_kernel), the register packer's record fetch. */
 int32_t casim_stream_probe(casim_ctx* ctx, int64_t bytes, int32_t lane_bytes, int32_t iters, double* gbps_out);
 
 /* ======================================================================================

@@ -189,6 +189,18 @@ __global__ __launch_bounds__(256) void stream_probe_kernel(const uint32_t* __res
     if (acc == 0x12345678u) sink[blockIdx.x] = acc;   // (never true for the zero-filled source: keeps the loads alive)
 }
 
+// The same for SCALAR loads (the register packer's record fetch): every wave walks its own contiguous region with one
+// s_load_dwordx8 (32 B) per step through the constant cache — the access pattern of pack_fast_kernel's PEG records.
+__global__ __launch_bounds__(64) void stream_probe_scalar_kernel(const uint32_t* __restrict__ src, int64_t words_per_wave, uint32_t* __restrict__ sink) {
+    const uint32_t* p = src + (int64_t)blockIdx.x * words_per_wave;
+    uint32_t acc = 0;
+    for (int64_t i = 0; i < words_per_wave; i += 8) {
+        const cs::Words<8> w = cs::const_load<8>(p + i);
+        acc ^= w.w[0] ^ w.w[1] ^ w.w[2] ^ w.w[3] ^ w.w[4] ^ w.w[5] ^ w.w[6] ^ w.w[7];
+    }
+    if (acc == 0x12345678u) sink[blockIdx.x & 4095] = acc;
+}
+
 }  // namespace casim
 
 extern "C" {
@@ -660,16 +672,18 @@ int32_t casim_copy_bandwidth(casim_ctx* ctx, int64_t bytes, int32_t iters, doubl
 
 int32_t casim_stream_probe(casim_ctx* ctx, int64_t bytes, int32_t lane_bytes, int32_t iters, double* gbps_out) {
     g_err.clear();
-    if (!ctx || bytes < 4096 || iters <= 0 || !gbps_out || (lane_bytes != 4 && lane_bytes != 16)) return set_err(CASIM_ERR_INVALID, "bad argument");
+    if (!ctx || bytes < 4096 || iters <= 0 || !gbps_out || (lane_bytes != 4 && lane_bytes != 16 && lane_bytes != 0)) return set_err(CASIM_ERR_INVALID, "bad argument");
     HipBackend& bk = ctx->bk; bk.bind(); bk.clear();
-    const int64_t n_words = bytes / 16 * 4;
+    const int n_waves = 65536;   // scalar form: one wave per block, 65536 regions
+    const int64_t n_words = lane_bytes == 0 ? bytes / 4 / n_waves / 8 * 8 * n_waves : bytes / 16 * 4;
     uint32_t* a = (uint32_t*)bk.alloc((size_t)n_words * 4); uint32_t* sink = (uint32_t*)bk.alloc(4096 * 4);
     if (!bk.ok()) { bk.free(a); bk.free(sink); return set_err(CASIM_ERR_HIP, bk.msg); }
     bk.zero(a, (size_t)n_words * 4);
     hipEvent_t e0, e1;
     bk.check(hipEventCreate(&e0), "hipEventCreate"); bk.check(hipEventCreate(&e1), "hipEventCreate");
     auto go = [&]() {
-        if (lane_bytes == 4) bk.launch(casim::stream_probe_kernel<4>, 4096, 1, 256, (size_t)0, (const uint32_t*)a, n_words, sink);
+        if (lane_bytes == 0) bk.launch(casim::stream_probe_scalar_kernel, n_waves, 1, 64, (size_t)0, (const uint32_t*)a, n_words / n_waves, sink);
+        else if (lane_bytes == 4) bk.launch(casim::stream_probe_kernel<4>, 4096, 1, 256, (size_t)0, (const uint32_t*)a, n_words, sink);
         else bk.launch(casim::stream_probe_kernel<16>, 4096, 1, 256, (size_t)0, (const uint32_t*)a, n_words, sink);
     };
     go();

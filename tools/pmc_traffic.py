@@ -64,11 +64,19 @@ for width in (4, 16):
     r = per_launch("FETCH_SIZE", f"%stream_probe_kernel<{width}>%")
     if r:
         cal[f"read_{width}B_per_lane"] = {"fetch_kib_reported": r["kib"], "known_bytes": 1 << 30, "reported_over_known": r["kib"] * 1024 / float(1 << 30)}
+r = per_launch("FETCH_SIZE", "%stream_probe_scalar_kernel%")
+if r:   # (the probe reads 65536 regions of whole 32-byte records: 1 GiB exactly for a 1 GiB request)
+    cal["read_32B_scalar_loads"] = {"fetch_kib_reported": r["kib"], "known_bytes": 1 << 30, "reported_over_known": r["kib"] * 1024 / float(1 << 30)}
 if cal:
     rec["fetch_size_calibration"] = cal
     c4 = cal.get("read_4B_per_lane")
     if c4 and c4["reported_over_known"] > 0:
         rec["fetch_bytes_corrected_by_4B_probe"] = f["kib"] * 1024 / c4["reported_over_known"]
         rec["traffic_bytes_per_launch_by_4B_probe"] = rec["fetch_bytes_corrected_by_4B_probe"] + w["kib"] * 1024
+    cs_ = cal.get("read_32B_scalar_loads")
+    if cs_ and cs_["reported_over_known"] > 0 and "pack_fast" in rec.get("kernel", ""):
+        # the register packer fetches its records with scalar loads: the counter is corrected by the probe of THAT access path
+        rec["fetch_bytes_corrected_by_scalar_probe"] = f["kib"] * 1024 / cs_["reported_over_known"]
+        rec["traffic_bytes_per_launch_by_scalar_probe"] = rec["fetch_bytes_corrected_by_scalar_probe"] + w["kib"] * 1024
 json.dump(rec, open(out_path, "w"), indent=1)
 print(json.dumps(rec))
