@@ -223,7 +223,7 @@ struct RegStore {
     // (6 VALU per slot), and so is a compare that two branches share.
     CS_DEVICE uint64_t fit_mask(int s, const Peg& pv, uint32_t pf /* record flags */) const {
         uint64_t fb;
-        if (cs::flag_set(pf, CASIM_REC_SIMPLE)) {
+        if ((pf & CASIM_REC_SIMPLE) != 0) {   // (plain here, opaque in capacity_slot: two separate bit tests, no shared lane-mask bool)
             fb = cs::ballot(slots[s] > 0);
             if (X_) fb &= cs::ballot(!blocked(s, pv));
 #pragma unroll
@@ -512,7 +512,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     auto peg_step = [&](const int k, auto dry_tag) __attribute__((always_inline)) {
         constexpr bool kDry = decltype(dry_tag)::value;
         const int j = k & 63;
-        if (j == 0) {
+        if (!kDry && j == 0) {   // (the dry loop below walks chunk by chunk and does this itself)
             CASIM_PROF(0);  // chunk load / store, loop overhead
             if (k > 0) flush_chunk(k - 64);
             my_placed = 0;
@@ -591,8 +591,8 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             const uint32_t keff = (uint32_t)(zselfx ? (cnt > 0 ? 1 : 0) : cnt);
             bool a2_go;
             if constexpr (kRecScalar) {
-                if constexpr (!kDry) cs::keep_scalar(a2_gate);   // (kDry: nothing changes it any more, it stays in its scalar register)
-                a2_go = (pf & a2_gate) != 0;
+                if constexpr (!kDry) { cs::keep_scalar(a2_gate); a2_go = (pf & a2_gate) != 0; }
+                else a2_go = (pf & CASIM_REC_A2_OK) != 0;   // (the dry loop only runs with the gate open: one bit test)
             }
             else a2_go = M > 0 && keff > 0 && static_ok && !group_unschedulable;
             if (a2_go && !zblocked) {
@@ -870,7 +870,21 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
         int k = 0;
         if constexpr (kRecScalar) {
             for (; k < Gn && more_mask != 0; ++k) peg_step(k, CsFalse{});
-            for (; k < Gn; ++k) peg_step(k, CsTrue{});
+            // behind a dry limiter: nothing at all can happen without a node that takes pods (no a3, a2 gated off) — else chunk by
+            // chunk, so that the steps themselves carry no chunk test
+            if (a2_gate != 0) {
+                while (k < Gn) {
+                    if ((k & 63) == 0) { if (k > 0) flush_chunk(k - 64); my_placed = 0; }
+                    const int kend = (k | 63) + 1 < Gn ? (k | 63) + 1 : Gn;
+                    for (; k < kend; ++k) peg_step(k, CsTrue{});
+                }
+            } else {
+                // the chunks still have to be flushed (placed[] of the PEGs before the limiter ran dry), nothing else
+                while (k < Gn) {
+                    if ((k & 63) == 0) { if (k > 0) flush_chunk(k - 64); my_placed = 0; }
+                    k = (k | 63) + 1;
+                }
+            }
         } else {
             for (; k < Gn; ++k) peg_step(k, CsFalse{});
         }
