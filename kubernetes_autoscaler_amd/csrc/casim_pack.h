@@ -24,9 +24,16 @@
 //   MemStore<kLds, RMAX>  int64 state in LDS (or an HBM slab), any R / node count / exclusion masks
 // PEG records arrive in processing order (written by order_kernel).  Memory store: 64 records per coalesced
 // wave-load, one per lane, broadcast field by field with v_readlane.  Register store: ONE scalar load per PEG
-// (s_load_dwordx8 / x16 of the 32- or 64-byte record of casim_types.h, issued one PEG ahead) puts every field
-// straight into scalar registers: no VALU, no LDS (the record fetch was 31 % of the kernel's cycles as LDS reads +
+// (s_load_dwordx8 / x16 of the 32- or 64-byte record of casim_types.h, issued when the previous PEG is done) puts every
+// field straight into scalar registers: no VALU, no LDS (the record fetch was 31 % of the kernel's cycles as LDS reads +
 // v_readfirstlane, profiles/r02m_pack_phase_profile.txt).
+//
+// The register packer is bound by SCALAR instruction issue (profiles/r02n .. r03*: a SIMD issues one scalar and one vector
+// instruction per ~4 cycles, and a PEG step carried more scalar than vector instructions).  What follows from that, and
+// shapes the code below: wave-uniform flags are integers / record bits tested where they are needed (a C++ bool that
+// lives across branches becomes a 64-bit lane mask and costs 5-6 scalar instructions per test), only lane MASKS cross
+// wave-uniform branches, uniform divisions run on the vector unit, and the PEGs behind a dry limiter — most of a
+// scale-up — run in a loop of their own that contains no a3 / a4 code.
 #pragma once
 #include "casim_device.h"
 #include "casim_types.h"
