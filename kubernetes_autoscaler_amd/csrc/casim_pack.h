@@ -802,9 +802,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     // next-fit on the newest node (:198-209).  When a2 ran for this PEG it walked EVERY simulated node, the newest
                     // included, with the same predicate, and left pods over: the newest node is full for this PEG (register store
                     // without group-wide state: a2 ran iff the gate bit was set)
-                    bool newest_may_fit = M > 0;
-                    if constexpr (kRecScalar && !Store::kHasZone) newest_may_fit = M > 0 && (pf & a2_gate) == 0;
-                    if (newest_may_fit) {
+                    auto ask_newest = [&]() {
                         const int lm = M - 1, owner = lm & 63;
                         uint32_t cl = 0;
                         if (!blocked() && !(selfx && on_last > 0))   // wave-uniform
@@ -814,13 +812,15 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                             placed += (int32_t)cl; rem -= (int32_t)cl; marked = true;
                             if (zselfx) zone_stop = 1u;
                         }
-                    }
-                    bool stop = rem == 0;
-                    if (!stop && M > 0) {
-                        // newest node still empty and the pod does not fit it: a new one would not help (:234-236)
+                    };
+                    // (nested ifs: each is one scalar compare + branch; as one combined bool the tests became lane masks)
+                    if constexpr (kRecScalar && !Store::kHasZone) { if ((pf & a2_gate) == 0) { if (M > 0) ask_newest(); } }
+                    else { if (M > 0) ask_newest(); }
+                    // newest node still empty and the pod does not fit it: a new one would not help (:234-236)
+                    auto newest_pods = [&]() -> uint32_t {
                         const int lm = M - 1, owner = lm & 63;
-                        if (cs::bcast_u32((uint32_t)st.npods_newest(lm, lane == owner), owner) == 0) stop = true;
-                    }
+                        return cs::bcast_u32((uint32_t)st.npods_newest(lm, lane == owner), owner);
+                    };
                     // (without zone state the body runs at most once: a straight line instead of a loop whose
                     // back edge carried the whole register state)
                     auto new_nodes = [&]() -> bool {   // false = done
@@ -851,8 +851,17 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                             return false;
                         }
                     };
-                    if constexpr (Store::kHasZone) { while (!stop && new_nodes()) {} }
-                    else { if (!stop) new_nodes(); }
+                    if constexpr (Store::kHasZone) {
+                        bool stop = rem == 0;
+                        if (!stop && M > 0 && newest_pods() == 0) stop = true;
+                        while (!stop && new_nodes()) {}
+                    } else {
+                        if (rem != 0) {
+                            uint32_t np = 1u;   // (no node yet: nothing to compare)
+                            if (M > 0) np = newest_pods();
+                            if (np != 0) new_nodes();
+                        }
+                    }
                 }
                 if (marked && Wz > 0) zone_mark(zmark);
                 if constexpr (kRecScalar) { a2_gate = M > 0 ? a2_bit : 0u; cs::keep_scalar(a2_gate); }

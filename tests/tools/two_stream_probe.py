@@ -42,6 +42,6 @@ def run(n_parts):
     return dt * 1e3, w
 
 
-for n in (1, 2, 4, 8, 16):
+for n in (1, 2, 3, 4, 5, 6, 8):
     ms, w = run(n)
     print(f"{n} stream(s): {ms:.4f} ms per step of {B} simulations  (key checksum {w[0]})")
