@@ -54,7 +54,9 @@ def test_fuzz_batches(ctx):
     """Every fuzz family of the CPU suite, on the GPU (one problem per seed)."""
     for base, n, kw, fast, dcsr in ((0, 60, dict(rich=False), False, False), (1000, 150, {}, False, False),
                                     (2000, 40, {}, True, False), (3000, 40, {}, False, True),
-                                    (5000, 60, dict(max_groups=3, max_pegs=48), False, False)):
+                                    (5000, 60, dict(max_groups=3, max_pegs=48), False, False),
+                                    (7000, 40, dict(max_groups=3, max_pegs=260, rich=False), False, False),   # long lists: the dry-limiter loop
+                                    (7000, 40, dict(max_groups=3, max_pegs=260), False, False)):              # ... with exclusion state
         for seed in range(n):
             sc = scenario_of(workloads.fuzz(base + seed, **kw), fastpath=fast, device_csr=dcsr)
             res, _ = run_gpu(encode(sc), ctx, fastpath=fast)

@@ -27,6 +27,16 @@ def test_fuzz_rich(seed):
     assert_matches_oracle(res, run_oracle(sc), f"seed {seed}")
 
 
+@pytest.mark.parametrize("rich", [False, True], ids=["plain", "rich"])
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_long_lists(seed, rich):
+    """Up to 260 PEGs per group (several 64-record chunks), limits of 1 / 3 / 7 nodes common: the register packer's loop behind
+    a dry limiter across chunk boundaries, with (rich) and without exclusion state."""
+    sc = scenario_of(workloads.fuzz(7000 + seed, max_groups=3, max_pegs=260, rich=rich))
+    res, _ = run_emu(encode(sc))
+    assert_matches_oracle(res, run_oracle(sc), f"seed {seed}")
+
+
 @pytest.mark.parametrize("seed", range(40))
 def test_fuzz_fastpath(seed):
     sc = scenario_of(workloads.fuzz(2000 + seed), fastpath=True)
