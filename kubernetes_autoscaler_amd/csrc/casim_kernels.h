@@ -259,14 +259,14 @@ CS_GLOBAL void csr_count_kernel(const uint64_t* CS_RESTRICT bits, int Wg, int32_
         counts[ng] = (int32_t)s;
     }
 }
-// K_csr_scan: exclusive scan of the per-group counts -> offsets[NG+1], in two launches so that a batch of thousands of
+// K_csr_scan: exclusive scan of the per-group counts -> offsets[NG+1], in two steps so that a batch of thousands of
 // simulations (tens of thousands of groups) is scanned by many blocks with coalesced loads instead of one block walking
 // serial chunks (0.128 ms of a 2.3 ms step at NG = 81920, profiles/r02a_rocpd_summary.txt):
 //   csr_scan_local_kernel  block b scans its 1024 groups (one element per thread: wave scan by lane exchange + LDS across
 //                          waves), writes the block-local exclusive prefix and its block total; with rows of <= 16 words the
 //                          popcount of the row (K_csr_count) is folded in;
-//   csr_scan_fix_kernel    block b adds the totals of the blocks before it (one wave sums them) and the last block writes
-//                          offsets[NG].
+//   csr_fill_kernel        (below) adds the totals of the blocks in front of a group's block while it fills the group's list and
+//                          writes the final offsets (a fix-up launch of its own until the end of round 2).
 CS_DEVICE uint32_t block_exclusive_scan(uint32_t mine, uint32_t* sm /*[nw + 1]*/, uint32_t* total) {
     const int tid = cs::tid(), lane = cs::lane(), wave = tid >> 6, nw = (cs::nthreads() + 63) >> 6;
     uint32_t incl = mine;
@@ -294,26 +294,26 @@ CS_GLOBAL void csr_scan_local_kernel(const int32_t* CS_RESTRICT counts, const ui
     if (i < NG) offsets[i] = (int32_t)excl;
     if (cs::tid() == 0) block_sums[cs::bid()] = (int32_t)total;
 }
-CS_GLOBAL void csr_scan_fix_kernel(int NG, int32_t* CS_RESTRICT offsets, const int32_t* CS_RESTRICT block_sums, int nb) {
-    const int b = cs::bid(), tid = cs::tid(), lane = cs::lane();
-    uint32_t* sm = (uint32_t*)cs::dyn_smem();   // [1]
-    if (tid < 64) {   // wave 0: sum of the totals of the blocks in front of this one (and of all of them for the tail entry)
-        uint32_t before = 0, all = 0;
-        for (int k = lane; k < nb; k += 64) { const uint32_t v = (uint32_t)block_sums[k]; all += v; if (k < b) before += v; }
-        before = cs::wave_sum_u32(before); all = cs::wave_sum_u32(all);
-        if (lane == 0) { sm[0] = before; if (b == nb - 1) offsets[NG] = (int32_t)all; }
-    }
-    cs::sync();
-    const int i = b * cs::nthreads() + tid;
-    if (b > 0 && i < NG) offsets[i] += (int32_t)sm[0];
-}
 // K_csr_fill: PEG ids of each group in ascending order; one wave per group, 64 words per step.
-CS_GLOBAL void csr_fill_kernel(const uint64_t* CS_RESTRICT bits, int Wg, const int32_t* CS_RESTRICT offsets,
-                               int32_t* CS_RESTRICT idx, const int32_t* CS_RESTRICT peg_lo) {
+// local_offsets (optional): the block-local exclusive offsets of csr_scan_local_kernel together with its block totals — the wave
+// adds the totals of the blocks in front of its own (a handful of values) and writes the FINAL offset of its group (the last
+// group also the grand total): the separate fix-up launch of the scan is folded into this kernel (one launch less in every
+// stream's chain of a batch step; the chain's length is the step's).
+CS_GLOBAL void csr_fill_kernel(const uint64_t* CS_RESTRICT bits, int Wg, int32_t* CS_RESTRICT offsets,
+                               int32_t* CS_RESTRICT idx, const int32_t* CS_RESTRICT peg_lo,
+                               const int32_t* CS_RESTRICT local_offsets, const int32_t* CS_RESTRICT block_sums, int scan_threads, int NG,
+                               const int32_t* CS_RESTRICT counts) {
     const int ng = cs::bid();
     const int lane = cs::lane();
     const int lo = peg_lo[ng];
-    int32_t base = offsets[ng];
+    int32_t base;
+    if (local_offsets) {
+        const int b = ng / scan_threads;
+        uint32_t before = 0;
+        for (int k = lane; k < b; k += 64) before += (uint32_t)block_sums[k];
+        base = local_offsets[ng] + (int32_t)cs::wave_sum_u32(before);
+        if (lane == 0) { offsets[ng] = base; if (ng == NG - 1) offsets[NG] = base + counts[ng]; }
+    } else base = offsets[ng];
     for (int w0 = 0; w0 < Wg; w0 += 64) {
         const int w = w0 + lane;
         uint64_t word = w < Wg ? bits[(int64_t)ng * Wg + w] : 0ull;

@@ -170,6 +170,7 @@ public:
             d_counts_ = (int32_t*)dalloc(sizeof(int32_t) * (NG + 1));
             d_off_ = res_off_;   // inside the results slab: one copy brings the scalars and the offsets back
             d_block_sums_ = (int32_t*)dalloc(sizeof(int32_t) * (NG / 64 + 2));
+            d_off_local_ = (int32_t*)dalloc(sizeof(int32_t) * (NG + 1));
             d_idx_ = (int32_t*)dalloc(sizeof(int32_t) * (size_t)nnz_cap_);
             dt_.peg_off = d_off_; dt_.peg_idx = d_idx_;
         }
@@ -316,10 +317,12 @@ public:
         if (!fold) bk_.launch(csr_count_kernel, NG_, 1, 256, (size_t)64, (const uint64_t*)d_bits_, Wg_, d_counts_);
         const int scan_threads = NG_ <= 64 ? 64 : (NG_ <= 256 ? 256 : 1024);
         const int nb = (NG_ + scan_threads - 1) / scan_threads;
+        // block-local offsets + block totals, then the fill kernel adds the totals in front of a group's block itself and writes the
+        // final offsets (no separate fix-up launch)
         bk_.launch(csr_scan_local_kernel, nb, 1, scan_threads, (size_t)(4 * ((scan_threads + 63) / 64)), (const int32_t*)d_counts_,
-                   fold ? (const uint64_t*)d_bits_ : (const uint64_t*)nullptr, Wg_, NG_, d_off_, d_block_sums_, d_counts_);
-        bk_.launch(csr_scan_fix_kernel, nb, 1, scan_threads, (size_t)8, NG_, d_off_, (const int32_t*)d_block_sums_, nb);
-        bk_.launch(csr_fill_kernel, NG_, 1, 64, (size_t)0, (const uint64_t*)d_bits_, Wg_, (const int32_t*)d_off_, d_idx_, dt_.peg_lo);
+                   fold ? (const uint64_t*)d_bits_ : (const uint64_t*)nullptr, Wg_, NG_, d_off_local_, d_block_sums_, d_counts_);
+        bk_.launch(csr_fill_kernel, NG_, 1, 64, (size_t)0, (const uint64_t*)d_bits_, Wg_, d_off_, d_idx_, dt_.peg_lo,
+                   (const int32_t*)d_off_local_, (const int32_t*)d_block_sums_, scan_threads, NG_, (const int32_t*)d_counts_);
         return CASIM_OK;
     }
     int32_t run_order() {
@@ -593,7 +596,7 @@ private:
     int fast_wx_ = 0;
     size_t pack_smem_ = 0, order_smem_ = 0;
     int order_threads_ = kOrderThreads;
-    uint64_t* d_bits_ = nullptr; int32_t* d_counts_ = nullptr; int32_t* d_off_ = nullptr; int32_t* d_idx_ = nullptr; int32_t* d_block_sums_ = nullptr;
+    uint64_t* d_bits_ = nullptr; int32_t* d_counts_ = nullptr; int32_t* d_off_ = nullptr; int32_t* d_idx_ = nullptr; int32_t* d_block_sums_ = nullptr; int32_t* d_off_local_ = nullptr;
     uint8_t* d_opt_set_ = nullptr; int32_t* d_opt_out_ = nullptr; int64_t* d_opt_key_ = nullptr; int64_t* d_opt_packed_ = nullptr;
     uint8_t* d_opt_valid_ = nullptr; size_t opt_cap_ = 0;
     int n_sims_ = 0, max_sim_groups_ = 0, feas_len_ = 0;
