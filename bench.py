@@ -575,7 +575,10 @@ def main():
                 "C4": "10k pending pods x 1k candidate nodes, 20 node groups, pod anti-affinity"}[args.config]
         out = {"metric": "scale-up simulation predicate checks/s (pods x nodes)", "value": value, "unit": "checks/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               # the arithmetic type of the kernels that ran: the register packer and the batch feasibility kernel compute on int32 lanes
+               # (every resource lane divided by the gcd of its values on the host: exact), the generic packer on the boundary's int64
+               "dtype": "int32" if fast else "int64", "data": "synthetic",
                "config": {"workload": f"{args.config} x {B} simulations per GPU per step ({desc}; {S} distinct seeds tiled), "
                                       f"tables resident in HBM; step = feasibility + CSR + order + pack + expander reduce per simulation, "
                                       f"the batch as {K} sub-batches on {K} HIP streams",
