@@ -50,12 +50,13 @@
 #endif
 
 // Waves per SIMD the register allocator of the 256-node fast packer must leave room for (a lower bound for the
-// occupancy: the kernel now needs ~55 VGPRs and runs 8 waves per SIMD).  History on MI355X (C1 x 16384):
+// occupancy: the kernel needs 36 VGPRs by now and runs 7-8 waves per SIMD).  History on MI355X (C1 x 16384):
 //   r01f  nested chunk / record loops, records in lanes: 148 VGPRs natural (3 waves) 8.2 M sims/s; bounded to 128 by
 //         spilling 68 B/lane 9.2 M but 2.6x the algorithmic HBM traffic; scheduling fences -> 123 VGPRs, no scratch, 9.0 M
 //   r01s  one flat PEG loop + records parked in LDS + wave-uniform regions kept out of the CFG structurizer:
 //         the node state is no longer copied through every merge point (58 -> 49..55 VGPRs, 8 waves); with the scalar
 //         work trimmed as well (the kernel was bound by SALU issue as much as by the VALU) 13.5 M sims/s.
+//   r02m+ records by scalar load instead of the LDS parking, scalar-issue economy throughout (see the head of this file).
 #ifndef CASIM_FAST_WAVES
 #define CASIM_FAST_WAVES 4
 #endif
@@ -389,13 +390,6 @@ CS_DEVICE void for_slots(int S, F&& f) {
         for (int s = 0; s < S; ++s) f(s);
     }
 }
-// PEG-record source of the 64-record chunk loaded by the wave (processing order)
-struct PegChunk {
-    int32_t cnt;
-    uint32_t flags;
-    int32_t g;
-};
-
 // The algorithm body, shared by every store.
 //   ReqLoader(kk, r) -> request lane r of sorted record kk (int64 original or int32 gcd-scaled)
 template <class Store, class ReqLoader>
@@ -470,7 +464,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     CASIM_PROF_DECL;
     // ONE loop over the PEGs of the group (a nested chunk / record loop made the compiler keep two copies of the node state,
     // one per loop level, and shuffle ~70 registers per PEG).  Memory store: every 64th iteration loads the next chunk of
-    // records into the lanes.  Register store: record k + 1 is fetched by a scalar load while PEG k is simulated.
+    // records into the lanes.  Register store: record k + 1 is fetched by a scalar load at the end of PEG k.
     int32_t my_cnt = 0, my_g = 0, my_placed = 0;
     uint32_t my_flags = 0, my_cf = 0;   // my_cf: pods of the record's PEG that fit an EMPTY node (state-independent)
     L my_req[RM];
