@@ -619,9 +619,29 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 };
                 // everything after pass A, for n1 > 0 nodes that take a pod (a continuation: the one-slot register store runs
                 // it inside the "somebody fits" branch of its only slot instead of re-testing a count after the merge)
+                // rotated order starts at list position (lastIndex + 1) % n; positions < E are the pre-existing cluster nodes (never
+                // acceptable): first simulated node of the rotated order
+                auto rotation_origin = [&]() -> int32_t {
+                    const int32_t n = E + M;
+                    // (lastIndex + 1 < n unless the caller's lastIndex came from a longer list: the division is the rare path)
+                    const uint32_t li1 = (uint32_t)last_index + 1u;
+                    const int32_t o = last_index < 0 ? 0 : (int32_t)(li1 < (uint32_t)n ? li1 : li1 % (uint32_t)n);   // (negative: origin 0)
+                    return o > E ? o - E : 0;
+                };
+                auto a2_finish = [&](const int32_t new_last, const uint32_t x_mine_last) {
+                    if constexpr (!kDry) on_last = cs::bcast_u32(x_mine_last, (M - 1) & 63);   // (only a3 asks)
+                    last_index = new_last;
+                    if (Wz > 0) zone_mark(zmark);
+                    if constexpr (kDry) {   // placed > 0 here; the tail of the step does not run
+                        uint32_t mp = (uint32_t)my_placed; cs::write_lane_u32(mp, (uint32_t)placed, j); my_placed = (int32_t)mp;
+                        total_placed += placed;
+                        add_totals(placed, (int32_t)pv.req[0], RM > 1 ? (int32_t)pv.req[1] : 0);
+                    }
+                };
                 auto a2_rest = [&](const int32_t n1) {
                     CASIM_PROF(2);  // a2 pass A (capacities)
                     uint32_t T, Rr;
+                    bool done = false;
                     if ((uint32_t)n1 > keff) {
                         // S(1) = n1 > k: not even one full round — the k pods go to the first k fitting nodes
                         T = 0; Rr = keff; placed = (int32_t)keff;
@@ -644,8 +664,32 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                             });
                             const U tot = wsumU(lsum);
                             const uint32_t cmax = cs::wave_max_u32(lane_max);
-                            if (tot <= (U)keff) { T = cmax; Rr = 0; placed = (int32_t)tot; }  // every node saturates
-                            else {
+                            if (tot <= (U)keff) {   // every fitting node saturates (28 % of the C2 steps, 2.6 nodes on average)
+                                T = cmax; Rr = 0; placed = (int32_t)tot;
+                                if constexpr (Store::kNPT > 0) {
+                                    // Each node takes its whole capacity, and the last pod of the round-robin lands on the LAST node, in
+                                    // rotated order, among those with the largest capacity (they alone are still served in round cmax):
+                                    // one lane mask per slot and find-last-bit, no ranks, no second reduction.
+                                    const int32_t m0 = rotation_origin();
+                                    int32_t last_lo = -1, last_all = -1;   // largest node index below the origin / overall with c == cmax
+                                    uint32_t x_mine_last = 0;
+                                    for_slots<Store>(S, [&](int s) {
+                                        if (!live(s)) return;
+                                        const int m = s * 64 + lane;
+                                        const uint32_t cj = getc(s, m);
+                                        const uint64_t b = cs::ballot(cj == cmax);
+                                        if (b) {
+                                            last_all = s * 64 + cs::fls64(b);
+                                            const uint64_t bl = b & cs::ballot(m < m0);
+                                            if (bl) last_lo = s * 64 + cs::fls64(bl);
+                                        }
+                                        st.commit_any(s, cj, pv);
+                                        if (m == M - 1) x_mine_last = cj;
+                                    });
+                                    a2_finish(E + (last_lo >= 0 ? last_lo : last_all), x_mine_last);
+                                    done = true;
+                                }
+                            } else {
                                 uint32_t lo = 1, hi = cmax; U slo = (U)n1;  // S(lo) <= keff < S(hi)
                                 while (hi - lo > 1) {
                                     const uint32_t mid = lo + ((hi - lo) >> 1);
@@ -665,14 +709,9 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         else rounds((uint64_t)0);
                     }
                     CASIM_PROF(3);  // a2 reductions + bisection
+                    if (done) return;
                     const uint32_t Tf = Rr > 0 ? T + 1 : T;  // last round: candidates have c >= Tf
-                    // rotated order starts at list position (lastIndex + 1) % n; positions < E are the
-                    // pre-existing cluster nodes (never acceptable)
-                    const int32_t n = E + M;
-                    // (lastIndex + 1 < n unless the caller's lastIndex came from a longer list: the division is the rare path)
-                    const uint32_t li1 = (uint32_t)last_index + 1u;
-                    const int32_t o = last_index < 0 ? 0 : (int32_t)(li1 < (uint32_t)n ? li1 : li1 % (uint32_t)n);   // (negative: origin 0)
-                    const int32_t m0 = o > E ? o - E : 0;
+                    const int32_t m0 = rotation_origin();
                     int32_t A = 0, Tot = 0;
                     for_slots<Store>(S, [&](int s) {
                         if (!live(s)) return;
@@ -700,14 +739,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         if (m == M - 1) x_mine_last = x;
                         basec += cs::popc64(b);
                     });
-                    if constexpr (!kDry) on_last = cs::bcast_u32(x_mine_last, (M - 1) & 63);   // (only a3 asks)
-                    last_index = new_last;
-                    if (Wz > 0) zone_mark(zmark);
-                    if constexpr (kDry) {   // placed > 0 here; the tail of the step does not run
-                        uint32_t mp = (uint32_t)my_placed; cs::write_lane_u32(mp, (uint32_t)placed, j); my_placed = (int32_t)mp;
-                        total_placed += placed;
-                        add_totals(placed, (int32_t)pv.req[0], RM > 1 ? (int32_t)pv.req[1] : 0);
-                    }
+                    a2_finish(new_last, x_mine_last);
                 };
                 if constexpr (Store::kNPT == 1) {
                     const uint64_t fb = st.fit_mask(0, pv, pf);
