@@ -402,8 +402,6 @@ def main():
     mine = full.shard(rank, world) if world > 1 else full
     n_sims = mine.n_sims
     K = max(1, min(args.streams, n_sims))
-    cuts = [(n_sims * i) // K for i in range(K + 1)]
-    parts = [mine.sim_slice(cuts[i], cuts[i + 1]) for i in range(K)] if K > 1 else [mine]
 
     # Explicit streams for libcasim's kernels AND torch's copies / collectives (torch's default stream has handle 0, which
     # casim_ctx_create takes as "create your own": the kernels would then run unordered with torch's work).  Stream 0 of the
@@ -413,11 +411,11 @@ def main():
     side_stream = streams[0]
     torch.cuda.set_stream(side_stream)
     assert all(st.cuda_stream != 0 for st in streams)
-    ctxs = [kaa.Context(dev_index, stream=st.cuda_stream) for st in streams]
-    ctx = ctxs[0]
     t0 = time.time()
-    probs = [kaa.Problem(c, *part.structs()) for c, part in zip(ctxs, parts)]
-    prob = probs[0]
+    # the batch as K sub-batches (cut by simulation), each a casim_problem on a context / stream of its own
+    batch = kaa.StreamedBatch(dev_index, mine, n_streams=K, streams=[st.cuda_stream for st in streams])
+    parts, probs, ctxs, cuts = batch.parts, batch.probs, batch.ctxs, batch.cuts
+    ctx, prob = ctxs[0], probs[0]
     t_upload = time.time() - t0
     keys = torch.full((n_sims,), 0x7FFFFFFFFFFFFFFF, dtype=torch.int64, device=f"cuda:{dev_index}")
     key_ptr = [keys.data_ptr() + 8 * cuts[i] for i in range(K)]
@@ -430,9 +428,8 @@ def main():
             h = t.cpu(); dist.all_reduce(h, op=op); t.copy_(h)
 
     def step():
-        for i in range(K):
-            probs[i].run()
-            probs[i].best_option_sims(kinds, per_sim=True, fetch=False, dev_packed_ptr=key_ptr[i], n_sims=parts[i].n_sims)
+        batch.run()
+        batch.best_option_sims(kinds, dev_packed_ptr=keys.data_ptr(), fetch=False)
         if collective:
             for st in streams[1:]:
                 side_stream.wait_stream(st)
@@ -595,10 +592,7 @@ def main():
         out.update(extra)
         out.update(side)
         print(json.dumps(out))
-    for p_ in probs:
-        p_.close()
-    for c_ in ctxs:
-        c_.close()
+    batch.close()
     if collective:
         dist.barrier()
         dist.destroy_process_group()
