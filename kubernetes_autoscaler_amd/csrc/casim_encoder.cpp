@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <deque>
 #include <map>
 #include <set>
 #include <string>
@@ -218,8 +219,8 @@ inline void set_bit(std::vector<uint64_t>& m, size_t row, int W, int bit) { m[ro
 
 struct casim_encoder {
     casim_encoder_options opt;
-    std::vector<PodSpec> specs;
-    std::vector<Group> groups;
+    std::deque<PodSpec> specs;   // (a deque: at cluster scale there is one spec per running pod, and growing a vector moved every one of them ~2.5 times)
+    std::deque<Group> groups;    // (same: one record per node in the per-node entry points)
     std::vector<Peg> pegs;
     std::vector<ExistingPod> existing;
     std::map<std::string, Labels> namespaces;   // the namespace lister: name -> labels (only read by namespaceSelector terms)
@@ -303,7 +304,7 @@ int32_t casim_enc_add_pod_spec(casim_encoder* e, const char* namespace_, const i
     PodSpec p;
     p.ns = S(namespace_);
     for (int r = 0; r < CASIM_MAX_RES; ++r) p.req[r] = r < e->opt.n_res ? req[r] : 0;
-    e->specs.push_back(p);
+    e->specs.push_back(std::move(p));
     return (int32_t)e->specs.size() - 1;
 }
 int32_t casim_enc_pod_add_label(casim_encoder* e, int32_t pod, const char* key, const char* value) {
@@ -593,8 +594,13 @@ int32_t casim_enc_finalize(casim_encoder* e) {
                 peg_blockers[j].push_back(peg_occ_bit[i]);
             }
         }
-        std::set<int32_t> pre_specs;  // distinct specs preloaded on some template
-        for (auto& g : e->groups) for (int32_t s : g.preloaded) pre_specs.insert(s);
+        // distinct specs preloaded on some template, ascending (a flag per spec: at cluster scale every running pod has its own)
+        std::vector<int32_t> pre_specs;
+        {
+            std::vector<uint8_t> seen(NS, 0);
+            for (auto& g : e->groups) for (int32_t s : g.preloaded) seen[(size_t)s] = 1;
+            for (size_t s = 0; s < NS; ++s) if (seen[s]) pre_specs.push_back((int32_t)s);
+        }
         for (int32_t s : pre_specs) {
             bool s_has_terms = false;
             for (auto& t : e->specs[(size_t)s].anti) if (t.topology_key == kHostname) s_has_terms = true;
@@ -725,8 +731,12 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         // keys that matter: spread keys of the classes, non-hostname anti-affinity keys of classes and running pods
         std::set<std::string> aa_keys;
         for (size_t i = 0; i < G; ++i) for (auto& t : e->specs[(size_t)e->pegs[i].spec].anti) if (t.topology_key != kHostname) aa_keys.insert(t.topology_key);
-        std::set<int32_t> running;   // distinct specs of running pods
-        for (auto& g : e->groups) for (int32_t s2 : g.preloaded) running.insert(s2);
+        std::vector<int32_t> running;   // distinct specs of running pods, ascending
+        {
+            std::vector<uint8_t> seen(NS, 0);
+            for (auto& g : e->groups) for (int32_t s2 : g.preloaded) seen[(size_t)s2] = 1;
+            for (size_t s2 = 0; s2 < NS; ++s2) if (seen[s2]) running.push_back((int32_t)s2);
+        }
         for (int32_t s2 : running) for (auto& t : e->specs[(size_t)s2].anti) if (t.topology_key != kHostname) aa_keys.insert(t.topology_key);
         // required pod affinity (V/.../interpodaffinity/filtering.go:234-272,382-409): an existing / placed pod counts for the
         // class when it matches ALL of its affinity terms (podMatchesAllAffinityTerms), once per term, in the domain of its
