@@ -44,7 +44,26 @@ struct Port { std::string ip, proto; int32_t port; bool operator<(const Port& o)
 // V/kubernetes/pkg/scheduler/framework/plugins/interpodaffinity/plugin.go:144-157)
 struct Term { std::string topology_key; std::vector<std::string> namespaces; std::vector<Requirement> selector;
               bool has_ns_sel = false, auto_ns = false, all_ns = false; std::vector<Requirement> ns_sel; };
-typedef std::map<std::string, std::string> Labels;
+// A label set: a handful of (key, value) pairs kept sorted by key in one vector — the subset of std::map the encoder uses
+// (operator[], find, count, end).  One record per pod at cluster scale: a tree node per label was a third of the encode calls' time.
+struct Labels {
+    typedef std::pair<std::string, std::string> Item;
+    typedef std::vector<Item>::const_iterator const_iterator;
+    std::vector<Item> v;
+    const_iterator begin() const { return v.begin(); }
+    const_iterator end() const { return v.end(); }
+    const_iterator find(const std::string& k) const {
+        for (auto it = v.begin(); it != v.end(); ++it) if (it->first == k) return it;   // (linear: label sets are tiny)
+        return v.end();
+    }
+    size_t count(const std::string& k) const { return find(k) != v.end() ? 1 : 0; }
+    std::string& operator[](const std::string& k) {
+        auto it = v.begin();
+        while (it != v.end() && it->first < k) ++it;
+        if (it == v.end() || it->first != k) it = v.insert(it, Item(k, std::string()));
+        return it->second;
+    }
+};
 
 struct Spread { int32_t max_skew; std::string key; int32_t min_domains; std::vector<Requirement> selector; bool taints_honor = false; bool affinity_honor = true; };
 struct PodSpec {
