@@ -206,7 +206,10 @@ def config_rows(kaa, ctx, workloads, kinds, iters=20):
         w.groups = w.groups[:1]
         w.name = "C2, one node group per call"
         return w
-    for name in ("C0", "C1", "C2", "C3", "C4", "C2-per-call"):
+    # R1 / R2 = the reference's own benchmark regimes for this path: BenchmarkRunOnceScaleUp — 10 000
+    # singleton PEGs -> one 200-node group (core/bench/benchmark_runonce_test.go:395-418,493-503) — and
+    # BenchmarkBinpackingEstimate — 2595 nodes / 51 000 pods (estimator/binpacking_estimator_test.go:256-303)
+    for name in ("C0", "C1", "C2", "C3", "C4", "C2-per-call", "R1", "R2"):
         make = workloads.CONFIGS.get(name, c2_one_group)
         row = {"config": name}
         try:
@@ -242,7 +245,13 @@ def config_rows(kaa, ctx, workloads, kinds, iters=20):
             if name == "C2-per-call":
                 row["note"] = ("per-call mode: one casim_estimate_batch per Estimate(), 20 of these make one C2 loop iteration; "
                                "the batch row above is the same work in ONE call")
-            _, s, run = oracle_simulation(workloads, make, None if name == "C0" else 0)
+            if name in ("R1", "R2"):
+                # one group, G dependent PEG steps in ONE wave: what a step costs when nothing runs beside it
+                row["pegs_in_the_one_group"] = len(w.pegs)
+                row["pack_us_per_peg_step"] = row["phases_ms"]["pack_ms"] * 1e3 / max(len(w.pegs), 1)
+                row["expected_by_the_reference"] = {"R1": "target size 200 (verifyTargetSize)", "R2": "2595 nodes, 51000 pods"}[name]
+                row["got"] = [int(res.node_count[0]), int(res.pods_scheduled[0])]
+            _, s, run = oracle_simulation(workloads, make, None if name in ("C0", "R1", "R2") else 0)
             want, osec, _ = run()
             _, osec2, _ = run(False)
             s.close()

@@ -63,12 +63,39 @@ def test_fuzz_batches(ctx):
             assert_matches_oracle(res, run_oracle(sc), f"fuzz {base + seed}")
 
 
-@pytest.mark.parametrize("name", ["C0", "C1", "C2", "C3", "C4"])
+@pytest.mark.parametrize("name", ["C0", "C1", "C2", "C3", "C4", "R1", "R2"])
 def test_baseline_configs_full_size(ctx, name):
+    """BASELINE configs C0-C4 and the reference's own benchmark regimes: R1 = BenchmarkRunOnceScaleUp (10 000 singleton PEGs ->
+    200 nodes, core/bench/benchmark_runonce_test.go:395-418,493-503), R2 = BenchmarkBinpackingEstimate (2595 nodes / 51 000 pods,
+    estimator/binpacking_estimator_test.go:256-303)."""
     w = workloads.CONFIGS[name]()
-    sc = scenario_of(w, device_csr=name in ("C2", "C3", "C4"))
+    sc = scenario_of(w, device_csr=name in ("C2", "C3", "C4", "R1"))
     res, _ = run_gpu(encode(sc), ctx)
-    assert_matches_oracle(res, run_oracle(sc), name)
+    oracle = run_oracle(sc)
+    assert_matches_oracle(res, oracle, name)
+    if name == "R1":
+        assert (int(res.node_count[0]), int(res.pods_scheduled[0])) == (200, 10000)
+    if name == "R2":
+        assert (int(res.node_count[0]), int(res.pods_scheduled[0])) == (2595, 51000)
+
+
+@pytest.mark.parametrize("n_pegs,cap,seed,generic", [(2000, 64, 0, False), (2049, 200, 1, False), (5000, 256, 2, False), (5000, 1000, 3, True),
+                                                     (8191, 300, 4, True), (12000, 700, 5, False), (20000, 1024, 6, False),
+                                                     (20000, 5000, 7, False), (16385, 40, 8, False), (3000, 3000, 9, False)])
+def test_thousands_of_pegs_in_one_group(ctx, n_pegs, cap, seed, generic):
+    """2 000 - 20 000 PEGs in ONE group (the HBM-slab sort of order_kernel, list bound > 1024; SURVEY N7: singleton PEGs are the
+    reference's own benchmark regime), every node store."""
+    sc = scenario_of(workloads.config_many_pegs(seed, n_pegs, cap))
+    res, _ = run_gpu(encode(sc), ctx, generic=generic)
+    assert_matches_oracle(res, run_oracle(sc), f"many {n_pegs} cap {cap}")
+
+
+def test_r1_with_the_int64_packer_and_smaller_scale_ups(ctx):
+    for nodes, generic in ((200, True), (1, False), (7, False), (60, False), (60, True)):
+        sc = scenario_of(workloads.config_r1(nodes, max_ng_size=10000 if nodes == 200 else 1000))
+        res, _ = run_gpu(encode(sc), ctx, generic=generic)
+        assert int(res.node_count[0]) == nodes
+        assert_matches_oracle(res, run_oracle(sc), f"R1 {nodes}")
 
 
 def test_batched_simulations_are_independent(ctx):
