@@ -329,7 +329,24 @@ def c3_sharded(kaa, ctx, workloads, kinds, rank, world, dist, torch, dev_index, 
         tc = torch.tensor([chk], dtype=torch.int64, device=f"cuda:{dev_index}")
         allreduce(tc, dist.ReduceOp.SUM)
         chk = int(tc.item())
-    return {"workload": "C3: 50k pods x 4k nodes, 64 node groups, resident tables", "scaling": "strong", "ranks": world,
+    # what does NOT shrink when the groups are spread over more GPUs: the expander reduce + the collective, and the chain of the
+    # longest group (one wave walks its PEGs one after the other) — measured here as the reduce share and the kernel share
+    with kaa.Problem(ctx, pegs, groups) as p2:
+        p2.run()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(iters):
+            p2.best_option_sims(kinds, per_sim=True, fetch=False, dev_packed_ptr=key.data_ptr(), n_sims=1)
+            if collective:
+                allreduce(key, dist.ReduceOp.MIN)
+        torch.cuda.synchronize()
+        reduce_ms = (time.perf_counter() - t1) / iters * 1e3
+        _, kms = p2.time(iters=10)
+    serial = {"reduce_ms_per_simulation": reduce_ms, "kernels_ms_per_simulation": sum(kms.values()), "kernel_ms": kms,
+              "reduce_share_of_iteration": reduce_ms / (dt / iters * 1e3),
+              "note": "one simulation = 64 waves of dependent PEG steps: already concurrent on ONE GPU, so N GPUs shorten only the "
+                      "feasibility / order launches; expected strong-scaling ceiling ~1.0-1.2x (DESIGN.md section 6)"}
+    return {"workload": "C3: 50k pods x 4k nodes, 64 node groups, resident tables", "scaling": "strong", "ranks": world, "serial_fraction": serial,
             "groups_on_rank0": mine.n_groups, "ms_per_simulation": dt / iters * 1e3, "checks": chk,
             "checks_per_s": chk / (dt / iters), "winner_group": -1 if winner == 0x7FFFFFFFFFFFFFFF else winner & 0xFFFFF,
             "winner_nodes": None if winner == 0x7FFFFFFFFFFFFFFF else winner >> 20,
@@ -412,22 +429,19 @@ def main():
     n_sims = mine.n_sims
     K = max(1, min(args.streams, n_sims))
 
-    # Explicit streams for libcasim's kernels AND torch's copies / collectives (torch's default stream has handle 0, which
-    # casim_ctx_create takes as "create your own": the kernels would then run unordered with torch's work).  Stream 0 of the
-    # list is also torch's current stream: the per-step reduce runs there after waiting for the other streams, and they wait
-    # for it before the next step overwrites the keys.
-    streams = [torch.cuda.Stream(device=dev_index) for _ in range(K)]
-    side_stream = streams[0]
+    # ONE casim context on an explicit torch stream (torch's default stream has handle 0, which casim_ctx_create takes as "create
+    # your own": the kernels would then run unordered with torch's work).  The sub-batching lives inside libcasim
+    # (casim_options.n_streams): the context's internal streams fork from this stream at every run and join into it when the
+    # expander writes the keys to a device pointer — the per-step RCCL all-reduce runs on it.
+    side_stream = torch.cuda.Stream(device=dev_index)
     torch.cuda.set_stream(side_stream)
-    assert all(st.cuda_stream != 0 for st in streams)
+    assert side_stream.cuda_stream != 0
     t0 = time.time()
-    # the batch as K sub-batches (cut by simulation), each a casim_problem on a context / stream of its own
-    batch = kaa.StreamedBatch(dev_index, mine, n_streams=K, streams=[st.cuda_stream for st in streams])
-    parts, probs, ctxs, cuts = batch.parts, batch.probs, batch.ctxs, batch.cuts
-    ctx, prob = ctxs[0], probs[0]
+    batch = kaa.StreamedBatch(dev_index, mine, n_streams=K, stream=side_stream.cuda_stream)
+    ctx, prob = batch.ctx, batch.prob
+    K = batch.parts
     t_upload = time.time() - t0
     keys = torch.full((n_sims,), 0x7FFFFFFFFFFFFFFF, dtype=torch.int64, device=f"cuda:{dev_index}")
-    key_ptr = [keys.data_ptr() + 8 * cuts[i] for i in range(K)]
 
     def allreduce(t, op):
         """RCCL reduces device tensors in place; the gloo self-test backend goes through the host."""
@@ -436,35 +450,40 @@ def main():
         else:
             h = t.cpu(); dist.all_reduce(h, op=op); t.copy_(h)
 
-    def step():
-        batch.run()
-        batch.best_option_sims(kinds, dev_packed_ptr=keys.data_ptr(), fetch=False)
+    def make_step(b):
         if collective:
-            for st in streams[1:]:
-                side_stream.wait_stream(st)
-            allreduce(keys, dist.ReduceOp.MIN)
-            for st in streams[1:]:
-                st.wait_stream(side_stream)
+            def step():
+                b.run()
+                b.best_option_sims(kinds, dev_packed_ptr=keys.data_ptr(), fetch=False)   # joins the internal streams into side_stream
+                allreduce(keys, dist.ReduceOp.MIN)                                       # ... where the collective runs; the next run() forks after it
+        else:
+            def step():
+                b.run()
+                b.best_option_sims(kinds, fetch=False)   # keys stay in the problem's own buffers: nothing on the context's stream, steps overlap
+        return step
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if collective:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if collective:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t_start
-    my_checks = my_nnz = 0
-    for p_, part in zip(probs, parts):
-        c_, z_ = checks_of(part, p_.fetch())
-        my_checks += c_; my_nnz += z_
-    part0_nnz = checks_of(parts[0], probs[0].fetch())[1]
+    def timed(step, steps, warmup):
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        if collective:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        if collective:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t_start
+
+    dt = timed(make_step(batch), args.steps, args.warmup)
+    res_all = prob.fetch()
+    my_checks, my_nnz = checks_of(batch.tables, res_all)
+    part0_groups = int(batch.tables.sim_offsets[(n_sims * 1) // K]) if K > 1 else mine.n_groups
+    part0_nnz = int(res_all.offsets[part0_groups])
+    final = prob.best_option_sims(kinds, per_sim=True, n_sims=n_sims)    # (host fetch: the winners of the last step)
     checks_per_step = my_checks
     if collective:
         tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev_index}")
@@ -473,6 +492,15 @@ def main():
         tc = torch.tensor([my_checks], dtype=torch.int64, device=f"cuda:{dev_index}")
         allreduce(tc, dist.ReduceOp.SUM)
         checks_per_step = int(tc.item())
+    # the collective of a step alone (same tensor, nothing else enqueued): what the step pays that does not shrink with N
+    all_reduce_ms = None
+    if collective:
+        torch.cuda.synchronize(); dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(50):
+            allreduce(keys, dist.ReduceOp.MIN)
+        torch.cuda.synchronize()
+        all_reduce_ms = (time.perf_counter() - t1) / 50 * 1e3
 
     out = None
     side = {}
@@ -484,22 +512,16 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = checks_per_step / (dt / args.steps)
-        winners = keys.cpu().numpy()
+        winners = keys.cpu().numpy() if collective else final["packed"]
         have = winners != 0x7FFFFFFFFFFFFFFF
-        # per-kernel HIP-event timing on the launch stream (libcasim: casim_problem_time), twice: in the regime of the timed
-        # region — the other streams keep running their sub-batches while sub-batch 0 is timed, which is what a kernel trace
-        # of this command sees — and with the device to itself (what the serialising PMC passes see)
+        # per-kernel HIP-event timing on the launch stream (libcasim), twice: in the regime of the timed region — the other
+        # internal streams keep running their parts while part 0 is timed (casim_problem_run_marked), which is what a kernel
+        # trace of this command sees — and with the device to itself (casim_problem_time: what the serialising PMC passes see)
         n_time = max(5, min(args.steps, 20))
         if K > 1:
-            # the timed region once more, for 48 steps, with events recorded (not waited for) around the kernels of sub-batch 0:
-            # its kernels share the device with whatever the other streams are running, exactly as in the timed steps and as
-            # in a kernel trace of this command
             for _ in range(48):
                 prob.run_marked()
-                prob.best_option_sims(kinds, per_sim=True, fetch=False, dev_packed_ptr=key_ptr[0], n_sims=parts[0].n_sims)
-                for i in range(1, K):
-                    probs[i].run()
-                    probs[i].best_option_sims(kinds, per_sim=True, fetch=False, dev_packed_ptr=key_ptr[i], n_sims=parts[i].n_sims)
+                prob.best_option_sims(kinds, per_sim=True, fetch=False, n_sims=n_sims)
             total_ms, kms, _n = prob.marked_ms()
             torch.cuda.synchronize()
             alone_ms, kms_alone = prob.time(iters=n_time)
@@ -509,7 +531,7 @@ def main():
         info = prob.info()
         fast = info["fast_packer_slots_per_lane"] > 0
         # (one launch = one sub-batch: bytes, durations and the PMC figures below are all per launch of sub-batch 0)
-        bytes_pack, Bp, Bn = algorithmic_bytes_pack(parts[0].dims, parts[0].n_groups, part0_nnz, fast)
+        bytes_pack, Bp, Bn = algorithmic_bytes_pack(mine.dims, part0_groups, part0_nnz, fast)
         achieved = bytes_pack / (kms["pack_ms"] * 1e-3) / 1e9
         kname = ("pack_fast_kernel<%d,%d,%d>" % (info["fast_packer_lanes"], info["fast_packer_slots_per_lane"],
                                                   2 if (mine.dims["w_excl"] or mine.dims["w_zone"]) else 0)) if fast else "pack_kernel"
@@ -517,7 +539,7 @@ def main():
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
                     "algorithmic_bytes_per_launch": bytes_pack, "bytes_per_peg_record": Bp, "bytes_per_group_record": Bn,
                     "kernel_ms": kms["pack_ms"], "share_of_step": kms["pack_ms"] / max(total_ms, 1e-9),
-                    "launch": f"sub-batch 0 of {K}: {parts[0].n_sims} simulations, {parts[0].n_groups} node groups (one wave each); "
+                    "launch": f"sub-batch 0 of {K}: {(n_sims * 1) // K if K > 1 else n_sims} simulations, {part0_groups} node groups (one wave each); "
                               f"kernel_ms = its average duration over 48 more steps of the timed loop (events recorded, not waited for): the kernels of the {K} streams time-share the device",
                     "device_to_itself": {"kernel_ms": kms_alone["pack_ms"], "achieved": bytes_pack / (kms_alone["pack_ms"] * 1e-3) / 1e9,
                                          "frac": bytes_pack / (kms_alone["pack_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
@@ -529,7 +551,7 @@ def main():
         # kernel instantiation and launch size
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "pack_traffic.json")))
-            if tr.get("waves_per_launch") == parts[0].n_groups and kname.replace(" ", "").rstrip(">") in tr.get("kernel", "").replace(" ", ""):
+            if tr.get("waves_per_launch") == part0_groups and kname.replace(" ", "").rstrip(">") in tr.get("kernel", "").replace(" ", ""):
                 # FETCH_SIZE corrected by the probe of the kernel's own access path when the PMC pass carried one (the register
                 # packer reads its records with scalar loads: stream_probe_scalar_kernel), else by the x2 rule of wide vector streams
                 roofline["traffic"] = tr.get("traffic_bytes_per_launch_by_scalar_probe", tr["traffic_bytes_per_launch"])
@@ -555,13 +577,25 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         extra = {"kernel_ms": kms, "pipeline_ms_hip_events": total_ms,
-                 "kernel_ms_note": f"HIP events around each kernel class of sub-batch 0 ({parts[0].n_sims} of the {n_sims} simulations) in the timed loop's "
+                 "kernel_ms_note": f"HIP events around each kernel class of sub-batch 0 ({(n_sims * 1) // K if K > 1 else n_sims} of the {n_sims} simulations) in the timed loop's "
                                    f"own regime ({K} streams time-sharing the device: per stream the durations add up to the step); "
                                    f"roofline.device_to_itself has the same launches alone", "encode_s_python_mirror": t_encode, "upload_s": t_upload,
                  "sims_per_step": total_sims, "sims_per_s": total_sims / (dt / args.steps),
                  "timed_region_s": dt, "winners": {"simulations_with_an_option": int(have.sum()),
                                                    "mean_nodes_of_winner": float((winners[have] >> 20).mean()) if have.any() else None}}
         checks_per_sim = checks_per_step / total_sims
+        # ---- the headline three ways, same batch, same context -------------------------------------------
+        rows = {"resident": {"what": "tables resident in HBM, results stay on the device (the `value` of this line)", "dtype": "int32" if fast else "int64",
+                             "ms_per_step": ms_per_step, "checks_per_s": value, "sims_per_s": total_sims / (dt / args.steps), "steps": args.steps,
+                             "one_casim_ctx": True, "streams_inside_libcasim": K}}
+        if world == 1:
+            rows["enter_return"] = _try(lambda: enter_return_row(kaa, ctx, batch.tables, kinds, K, checks_per_step, max(3, min(args.steps, 10)), res_all, final))
+            rows["int64"] = _try(lambda: int64_row(kaa, dev_index, batch.tables, kinds, K, checks_per_step, max(5, min(args.steps, 50)), res_all, final, torch))
+        extra["headline_rows"] = rows
+        extra["multi_gpu"] = {"rccl_world_size": world if (collective and backend == "nccl") else (0 if not collective else None),
+                              "collective_backend": backend if collective else None, "all_reduce_ms": all_reduce_ms,
+                              "all_reduce_operand": f"{n_sims} packed int64 keys per step" if collective else None,
+                              "all_reduce_share_of_step": (all_reduce_ms / ms_per_step) if all_reduce_ms else None}
         if world == 1:   # side measurements and CPU legs at N = 1 only (other ranks would idle in a barrier)
             extra["copy_bandwidth_gbps"] = _try(lambda: ctx.copy_bandwidth_gbps(1 << 30, 10))
             extra["read_stream_gbps"] = _try(lambda: {"4B_per_lane": ctx.stream_probe_gbps(1 << 30, 4, 5), "16B_per_lane": ctx.stream_probe_gbps(1 << 30, 16, 5),
@@ -589,7 +623,8 @@ def main():
                                       f"tables resident in HBM; step = feasibility + CSR + order + pack + expander reduce per simulation, "
                                       f"the batch as {K} sub-batches on {K} HIP streams",
                           "batch_per_gpu": B, "distinct_seeds": S, "checks_per_simulation": checks_per_sim,
-                          "streams": K, "simulations_per_stream": [p_.n_sims for p_ in parts],
+                          "streams": K, "streams_where": "inside libcasim (casim_options.n_streams): ONE casim_ctx, one casim_problem",
+                          "simulations_per_stream": [(n_sims * (i + 1)) // K - (n_sims * i) // K for i in range(K)],
                           "node_groups_per_rank": mine.n_groups, "schedulable_peg_group_pairs_per_rank": my_nnz,
                           "expander": args.expander,
                           "partition": ("node groups of every simulation block-partitioned over the ranks (rotated), PEG table replicated"
@@ -606,6 +641,66 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return out
+
+
+def _same_results(a, b):
+    """bit-equality of two BatchResults + expander answers (resident vs enter -> return vs int64)"""
+    import numpy as np
+    ra, ea = a; rb, eb = b
+    nnz = int(ra.offsets[-1])
+    ok = all(np.array_equal(getattr(ra, f), getattr(rb, f)) for f in ("offsets", "node_count", "pods_scheduled", "nodes_added", "limiter_nodes",
+                                                                      "last_index_out", "status", "req_cpu_sum", "req_mem_sum"))
+    ok = ok and np.array_equal(ra.order[:nnz], rb.order[:nnz]) and np.array_equal(ra.placed[:nnz], rb.placed[:nnz])
+    return bool(ok and np.array_equal(ea["best"], eb["best"]) and np.array_equal(ea["packed"], eb["packed"]))
+
+
+def enter_return_row(kaa, ctx, tables, kinds, K, checks_per_step, steps, res_resident, exp_resident):
+    """SURVEY 8d's wall time: casim_estimate_batch_query enter -> return — fresh tables packed into pinned memory and copied to
+    HBM, kernels, expander reduce, scalars + order + placed copied back, EVERY step; the parts of the batch run end to end on
+    the context's internal streams (upload of one part under the kernels of another)."""
+    from kubernetes_autoscaler_amd.engine import BatchCall
+    pegs, groups = tables.structs()
+    call = BatchCall(ctx, pegs, groups, kinds=kinds, n_streams=K)
+    call.call_raw()                       # first call: lanes, pools, pinned buffers
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        call.call_raw()
+    dt = (time.perf_counter() - t0) / steps
+    one = BatchCall(ctx, pegs, groups, kinds=kinds, n_streams=0)
+    one.call_raw()
+    t0 = time.perf_counter()
+    for _ in range(max(1, steps // 2)):
+        one.call_raw()
+    dt1 = (time.perf_counter() - t0) / max(1, steps // 2)
+    res, exp = call.call()
+    bytes_in = sum(v.nbytes for v in tables.pegs.values() if v is not None) + sum(v.nbytes for v in tables.groups.values() if v is not None)
+    nnz = int(res.offsets[-1])
+    return {"what": "casim_estimate_batch_query enter -> return every step: H2D of fresh tables from pinned staging + kernels + expander + D2H of "
+                    "scalars / order / placed, parts overlapped on the internal streams", "dtype": "int32",
+            "ms_per_step": dt * 1e3, "checks_per_s": checks_per_step / dt, "sims_per_s": tables.n_sims / dt, "steps": steps,
+            "ms_per_step_one_stream": dt1 * 1e3, "table_bytes_in": bytes_in, "result_bytes_out": 8 * nnz + 48 * tables.n_groups,
+            "pcie_inclusive": True, "bit_equal_to_resident": _same_results((res, exp), (res_resident, exp_resident))}
+
+
+def int64_row(kaa, dev_index, tables, kinds, K, checks_per_step, steps, res_resident, exp_resident, torch):
+    """The resident step with casim_options.force_generic_packer: int64 lanes end to end (the boundary's own type), node state in
+    LDS — what a batch pays when the exact gcd narrowing to int32 does not apply."""
+    with kaa.StreamedBatch(dev_index, tables, n_streams=K, force_generic_packer=True) as b:
+        for _ in range(3):
+            b.run(); b.best_option_sims(kinds, fetch=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            b.run(); b.best_option_sims(kinds, fetch=False)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res = b.fetch()
+        exp = b.best_option_sims(kinds)
+        info = b.prob.info()
+    return {"what": "resident step, force_generic_packer (int64 MemStore packer)", "dtype": "int64", "ms_per_step": dt * 1e3,
+            "checks_per_s": checks_per_step / dt, "sims_per_s": tables.n_sims / dt, "steps": steps,
+            "register_packer": info["fast_packer_slots_per_lane"] > 0,
+            "bit_equal_to_resident": _same_results((res, exp), (res_resident, exp_resident))}
 
 
 def in_process_multi_device(kaa, workloads, kinds, iters=20):

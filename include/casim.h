@@ -32,9 +32,11 @@
 extern "C" {
 #endif
 
-#define CASIM_ABI_VERSION 3   /* 2: casim_removal_candidates.cand_atomic, casim_domain_rules.n_taint_policy_rules
+#define CASIM_ABI_VERSION 4   /* 2: casim_removal_candidates.cand_atomic, casim_domain_rules.n_taint_policy_rules
                                * 3: casim_groups.{peg_lo,peg_hi,global_id,n_sims,sim_offsets}, casim_best_option_sims,
-                               *    casim_feasibility_reasons, casim_estimate_batch_timed, casim_mctx_*, casim_cluster_* */
+                               *    casim_feasibility_reasons, casim_estimate_batch_timed, casim_mctx_*, casim_cluster_*
+                               * 4: casim_options.n_streams (sub-batches on internal HIP streams), casim_enc_group_pods,
+                               *    casim_selfcheck */
 
 /* Resource lanes.  Lane 0 = cpu in millicores (Quantity.MilliValue), lane 1 = memory bytes,
  * lane 2 = ephemeral-storage bytes, lanes 3.. = scalar / extended resources (Quantity.Value),
@@ -147,7 +149,17 @@ typedef struct casim_options {
     int32_t force_generic_packer; /* 1 = never use the register-resident int32 packer (testing / A-B) */
     int32_t node_pods;            /* 1 = keep the pods per simulated node (casim_results.node_pods): what
                                      estimationAnalyserFunc receives as newNodesWithPods (binpacking_estimator.go:157-159) */
-    int32_t reserved[5];
+    int32_t n_streams;            /* > 1: a batch of simulations (casim_groups.n_sims >= 2, subsets derived on the device from
+                                     peg_lo / peg_hi) is cut by simulation into up to n_streams sub-batches that run on HIP streams
+                                     of their own INSIDE the context (own memory pool and pinned staging each): the memory-latency-
+                                     bound feasibility / order kernels of one part overlap the issue-bound packer of another, and in
+                                     casim_estimate_batch the upload of one part overlaps the kernels and result copies of others.
+                                     Results are identical to n_streams <= 1.  Ordering towards the context's stream:
+                                     casim_problem_run forks from it (every internal stream waits for what it holds);
+                                     casim_best_option_sims with dev_* outputs joins into it (work enqueued there afterwards sees
+                                     the keys); host outputs / casim_problem_fetch synchronise.  Batches that cannot be cut (one
+                                     simulation, explicit peg_offsets, node_pods) run as one part; casim_problem_info [4] tells. */
+    int32_t reserved[4];
 } casim_options;
 
 /*
@@ -232,7 +244,7 @@ int32_t casim_problem_csr(casim_problem* p, int32_t* nnz_out, int32_t* offsets_o
 /* How the resident batch will be executed (for reports): info_out[0] = node slots per lane of the
  * register-resident int32 packer (0 = generic int64 packer), [1] = its lane count, [2] = 1 if the
  * generic packer keeps node state in LDS (0 = HBM slab), [3] = 1 if the schedulable subsets are
- * derived on the device, [4..7] reserved (0). */
+ * derived on the device, [4] = parts the batch runs as on internal streams (1 = not cut), [5..7] reserved (0). */
 struct casim_cluster_estimate_result;
 int32_t casim_problem_info(casim_problem* p, int32_t info_out[8]);
 /* Replace the result of group `ng` of a batch that already ran (status becomes CASIM_NG_OK): how a group that the batch
@@ -242,6 +254,13 @@ int32_t casim_problem_set_group_result(casim_problem* p, int32_t ng, const struc
 /* upload + run + fetch in one call: the form the Go Estimate() wrapper uses once per loop. */
 int32_t casim_estimate_batch(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups,
                              const casim_options* opts, casim_results* out);
+
+/* casim_estimate_batch + the CSR offsets of order / placed + the expander reduce, enter -> return in ONE call: what a prefetching
+ * shim calls once per scale-up loop and what SURVEY 8d defines the wall time on (H2D and D2H included).
+ * offsets_out ([NG+1]) and q may be NULL.  With opts->n_streams > 1 the parts of the batch run end to end on their own streams:
+ * the upload of one overlaps the kernels of another and the result copies of a third; a q then has to be per_sim. */
+int32_t casim_estimate_batch_query(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts,
+                                   casim_results* out, int32_t* offsets_out, const struct casim_option_query* q);
 
 /* casim_estimate_batch with the expander reduce and a phase breakdown, host clock, the stream drained after every
  * phase (so the phases add up to slightly more than an untimed call): phase_ms_out[0] = tables to HBM (allocation +

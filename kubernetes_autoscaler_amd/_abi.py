@@ -3,7 +3,7 @@ shared library happens in _ffi.py).  Kept separate so that test harnesses that c
 structs can reuse the layouts without loading the product library."""
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_RES = 8
 
 OK = 0
@@ -64,7 +64,7 @@ class Groups(C.Structure):
 
 
 class Options(C.Structure):
-    _fields_ = [("fastpath", C.c_int32), ("force_generic_packer", C.c_int32), ("node_pods", C.c_int32), ("reserved", C.c_int32 * 5)]
+    _fields_ = [("fastpath", C.c_int32), ("force_generic_packer", C.c_int32), ("node_pods", C.c_int32), ("n_streams", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class Results(C.Structure):
@@ -145,6 +145,8 @@ PROTOTYPES = {
     "casim_feasibility_reasons": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), u64p, C.POINTER(C.c_uint16)]),
     "casim_best_option": (C.c_int32, [C.c_void_p, i32p, C.c_int32, C.c_int32, i32p, i32p, u8p, i64p, C.c_void_p]),
     "casim_best_option_sims": (C.c_int32, [C.c_void_p, C.POINTER(OptionQuery)]),
+    "casim_estimate_batch_query": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(Options), C.POINTER(Results), i32p,
+                                               C.POINTER(OptionQuery)]),
     "casim_estimate_batch_timed": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(Options), C.POINTER(Results),
                                                C.POINTER(OptionQuery), f64p]),
     "casim_mctx_create": (C.c_void_p, [i32p, C.c_int32, C.c_int32]),

@@ -16,6 +16,7 @@
 
 #include "casim_pipeline.h"
 #include "casim_multi.h"
+#include "casim_streams.h"
 
 namespace casim {
 // casim_pack_tu.hip: the register packer, compiled in its own translation unit (see there)
@@ -69,6 +70,7 @@ struct HipBackend {
         for (auto& kv : pool) for (void* p : kv.second) (void)hipFree(p);
         pool.clear(); pooled_bytes = 0;
         for (int i = 0; i < 2; ++i) { if (staging[i]) (void)hipHostFree(staging[i]); staging[i] = nullptr; staging_cap[i] = 0; }
+        if (mark_ev) { (void)hipEventDestroy(mark_ev); mark_ev = nullptr; }
     }
     // pinned host staging: 0 = uploads, 1 = fetches
     void* staging[2] = {nullptr, nullptr}; size_t staging_cap[2] = {0, 0};
@@ -88,6 +90,14 @@ struct HipBackend {
     void zero(void* d, size_t n) { if (n) check(hipMemsetAsync(d, 0, n, stream), "hipMemsetAsync"); }
     void fill8(void* d, int v, size_t n) { if (n) check(hipMemsetAsync(d, v, n, stream), "hipMemsetAsync"); }
     void sync() { check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
+    // fork / join between the streams of one context (casim_streams.h): mark() records an event on the own stream,
+    // wait_mark(o) makes the own stream wait for o's last mark
+    hipEvent_t mark_ev = nullptr;
+    void mark() {
+        if (!mark_ev) check(hipEventCreateWithFlags(&mark_ev, hipEventDisableTiming), "hipEventCreate");
+        if (mark_ev) check(hipEventRecord(mark_ev, stream), "hipEventRecord");
+    }
+    void wait_mark(HipBackend& o) { if (o.mark_ev) check(hipStreamWaitEvent(stream, o.mark_ev, 0), "hipStreamWaitEvent"); }
     size_t lds_budget() const { return lds; }
     bool ok() const { return last == hipSuccess; }
     const char* error() const { return msg.c_str(); }
@@ -109,11 +119,27 @@ struct HipBackend {
 };
 
 typedef casim::ProblemT<HipBackend> HipProblem;
+typedef casim::StreamedProblemT<HipBackend> HipStreamed;
 
 }  // namespace
 
 struct casim_ctx {
     HipBackend bk;
+    // lanes: backends on the SAME device with a stream, a memory pool and pinned staging buffers of their own — the parts of a
+    // streamed batch (casim_options.n_streams) run on them; created on first use, kept for the life of the context
+    std::vector<HipBackend*> lanes;
+    std::vector<HipBackend*> get_lanes(int k) {
+        while ((int)lanes.size() < k) {
+            HipBackend* l = new (std::nothrow) HipBackend();
+            if (!l) break;
+            l->device = bk.device; l->lds = bk.lds; l->own_stream = true;
+            l->bind();
+            l->check(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking), "hipStreamCreate");
+            if (!l->ok()) { delete l; break; }
+            lanes.push_back(l);
+        }
+        return std::vector<HipBackend*>(lanes.begin(), lanes.begin() + ((int)lanes.size() < k ? (int)lanes.size() : k));
+    }
 };
 // ---- RCCL, loaded at run time (no link-time dependency: a process that already carries an RCCL — torch ships one — keeps
 // using that copy; a plain C / Go host gets /opt/rocm/lib/librccl.so).  Only what the expander exchange needs.
@@ -162,9 +188,12 @@ struct casim_cluster {
 
 struct casim_problem {
     casim_ctx* ctx;
-    HipProblem* prob;
+    HipProblem* prob;                // the batch as ONE part on the context's stream, or
+    HipStreamed* sp = nullptr;       // ... cut into parts on the context's lanes (casim_options.n_streams); prob = part 0 then
     std::vector<hipEvent_t> marks;   // casim_problem_run_marked: 4 events per kept run (created on first use)
     int32_t n_marked = 0;
+    HipBackend& bk0() { return sp ? sp->lane(0) : ctx->bk; }   // where part 0's kernels run (timing helpers)
+    const std::string& error() const { return sp && !sp->error().empty() ? sp->error() : prob->error(); }
 };
 
 namespace casim {
@@ -243,9 +272,24 @@ void casim_ctx_destroy(casim_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->bk.device);
     if (ctx->bk.stream) (void)hipStreamSynchronize(ctx->bk.stream);
+    for (HipBackend* l : ctx->lanes) {
+        if (l->stream) (void)hipStreamSynchronize(l->stream);
+        l->release_pool();
+        if (l->stream) (void)hipStreamDestroy(l->stream);
+        delete l;
+    }
+    ctx->lanes.clear();
     ctx->bk.release_pool();
     if (ctx->bk.own_stream && ctx->bk.stream) (void)hipStreamDestroy(ctx->bk.stream);
     delete ctx;
+}
+
+static bool wants_streams(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts, std::vector<HipBackend*>* lanes) {
+    if (!HipStreamed::eligible(pegs, groups, opts)) return false;
+    int k = opts->n_streams > 16 ? 16 : opts->n_streams;
+    if (k > groups->n_sims) k = groups->n_sims;
+    *lanes = ctx->get_lanes(k);
+    return lanes->size() >= 2;
 }
 
 casim_problem* casim_problem_create(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts) {
@@ -255,6 +299,16 @@ casim_problem* casim_problem_create(casim_ctx* ctx, const casim_pegs* pegs, cons
     casim_problem* p = new (std::nothrow) casim_problem();
     if (!p) { set_err(CASIM_ERR_NOMEM, "out of memory"); return nullptr; }
     p->ctx = ctx;
+    std::vector<HipBackend*> lanes;
+    if (wants_streams(ctx, pegs, groups, opts, &lanes)) {
+        for (HipBackend* l : lanes) l->clear();
+        p->sp = new (std::nothrow) HipStreamed(ctx->bk, lanes);
+        if (!p->sp) { delete p; set_err(CASIM_ERR_NOMEM, "out of memory"); return nullptr; }
+        const int32_t rc = p->sp->init(pegs, groups, opts, /*threads=*/true);
+        if (rc != CASIM_OK) { set_err(rc, p->sp->error()); delete p->sp; delete p; return nullptr; }
+        p->prob = p->sp->part(0).prob.get();
+        return p;
+    }
     p->prob = new (std::nothrow) HipProblem(ctx->bk);
     if (!p->prob) { delete p; set_err(CASIM_ERR_NOMEM, "out of memory"); return nullptr; }
     const int32_t rc = p->prob->init(pegs, groups, opts);
@@ -265,8 +319,9 @@ void casim_problem_destroy(casim_problem* p) {
     if (!p) return;
     p->ctx->bk.bind();
     (void)hipStreamSynchronize(p->ctx->bk.stream);
+    if (p->sp) p->sp->sync_all();
     for (hipEvent_t e : p->marks) (void)hipEventDestroy(e);
-    delete p->prob;
+    if (p->sp) delete p->sp; else delete p->prob;
     delete p;
 }
 
@@ -274,29 +329,97 @@ void casim_problem_destroy(casim_problem* p) {
     g_err.clear();                                                               \
     if (!(p) || !(p)->prob) return set_err(CASIM_ERR_INVALID, "null problem");   \
     (p)->ctx->bk.bind(); (p)->ctx->bk.clear()
-#define PROB_RET(p, rc) do { const int32_t _rc = (rc); if (_rc != CASIM_OK) set_err(_rc, (p)->prob->error()); return _rc; } while (0)
+#define PROB_RET(p, rc) do { const int32_t _rc = (rc); if (_rc != CASIM_OK) set_err(_rc, (p)->error()); return _rc; } while (0)
+static void clear_lanes(casim_problem* p) { if (p->sp) for (size_t i = 0; i < p->sp->n_parts(); ++i) p->sp->lane(i).clear(); }
+static int32_t lanes_ok(casim_problem* p) {
+    if (p->sp) for (size_t i = 0; i < p->sp->n_parts(); ++i) if (!p->sp->lane(i).ok()) return set_err(CASIM_ERR_HIP, p->sp->lane(i).msg);
+    return CASIM_OK;
+}
 
-int32_t casim_problem_run(casim_problem* p) { PROB_ENTER(p); PROB_RET(p, p->prob->run()); }
-int32_t casim_problem_fetch(casim_problem* p, casim_results* out) { PROB_ENTER(p); PROB_RET(p, p->prob->fetch(out)); }
+int32_t casim_problem_run(casim_problem* p) {
+    PROB_ENTER(p);
+    if (p->sp) { clear_lanes(p); const int32_t rc = p->sp->run(); if (rc != CASIM_OK) return set_err(rc, p->sp->error()); return lanes_ok(p); }
+    PROB_RET(p, p->prob->run());
+}
+int32_t casim_problem_fetch(casim_problem* p, casim_results* out) {
+    PROB_ENTER(p);
+    if (p->sp) { clear_lanes(p); const int32_t rc = p->sp->fetch(out, /*threads=*/p->sp->groups() >= 4096); if (rc != CASIM_OK) return set_err(rc, p->sp->error()); return lanes_ok(p); }
+    PROB_RET(p, p->prob->fetch(out));
+}
 int32_t casim_problem_info(casim_problem* p, int32_t info_out[8]) {
     g_err.clear();
     if (!p || !p->prob || !info_out) return set_err(CASIM_ERR_INVALID, "null argument");
     for (int i = 0; i < 8; ++i) info_out[i] = 0;
     info_out[0] = p->prob->fast_npt(); info_out[1] = p->prob->fast_lanes();
     info_out[2] = p->prob->pack_in_lds() ? 1 : 0; info_out[3] = p->prob->csr_on_device() ? 1 : 0;
+    info_out[4] = p->sp ? (int32_t)p->sp->n_parts() : 1;
     return CASIM_OK;
 }
 int32_t casim_problem_set_group_result(casim_problem* p, int32_t ng, const casim_cluster_estimate_result* r) {
     PROB_ENTER(p);
+    if (p->sp) { const int32_t rc = p->sp->set_group_result(ng, r); if (rc != CASIM_OK) return set_err(rc, p->sp->error()); return CASIM_OK; }
     PROB_RET(p, p->prob->set_group_result(ng, r));
 }
-int32_t casim_problem_csr(casim_problem* p, int32_t* nnz_out, int32_t* offsets_out) { PROB_ENTER(p); PROB_RET(p, p->prob->csr(nnz_out, offsets_out)); }
+int32_t casim_problem_csr(casim_problem* p, int32_t* nnz_out, int32_t* offsets_out) {
+    PROB_ENTER(p);
+    if (p->sp) { const int32_t rc = p->sp->csr(nnz_out, offsets_out); if (rc != CASIM_OK) return set_err(rc, p->sp->error()); return lanes_ok(p); }
+    PROB_RET(p, p->prob->csr(nnz_out, offsets_out));
+}
+
+// enter -> return of a streamed batch: every part is uploaded, run, reduced and fetched on its own lane
+static int32_t estimate_streamed(casim_ctx* ctx, std::vector<HipBackend*>& lanes, const casim_pegs* pegs, const casim_groups* groups,
+                                 const casim_options* opts, casim_results* out, const casim_option_query* q) {
+    ctx->bk.bind(); ctx->bk.clear();
+    for (HipBackend* l : lanes) l->clear();
+    HipStreamed sp(ctx->bk, lanes);
+    const int32_t rc = sp.estimate(pegs, groups, opts, out, q, /*threads=*/true);
+    sp.sync_all();
+    if (rc != CASIM_OK) return set_err(rc, sp.error());
+    for (HipBackend* l : lanes) if (!l->ok()) return set_err(CASIM_ERR_HIP, l->msg);
+    return CASIM_OK;
+}
 
 int32_t casim_estimate_batch(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts, casim_results* out) {
+    g_err.clear();
+    if (!ctx) return set_err(CASIM_ERR_INVALID, "null context");
+    {
+        std::vector<HipBackend*> lanes;
+        if (wants_streams(ctx, pegs, groups, opts, &lanes)) return estimate_streamed(ctx, lanes, pegs, groups, opts, out, nullptr);
+    }
     casim_problem* p = casim_problem_create(ctx, pegs, groups, opts);
     if (!p) return g_err.empty() ? CASIM_ERR_INVALID : (casim_device_count() > 0 ? CASIM_ERR_INVALID : CASIM_ERR_NO_DEVICE);
     int32_t rc = casim_problem_run(p);
     if (rc == CASIM_OK) rc = casim_problem_fetch(p, out);
+    const std::string keep = g_err;
+    casim_problem_destroy(p);
+    g_err = keep;
+    return rc;
+}
+
+int32_t casim_estimate_batch_query(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts,
+                                   casim_results* out, int32_t* offsets_out, const casim_option_query* q) {
+    g_err.clear();
+    if (!ctx) return set_err(CASIM_ERR_INVALID, "null context");
+    {
+        std::vector<HipBackend*> lanes;
+        if (wants_streams(ctx, pegs, groups, opts, &lanes)) {
+            ctx->bk.bind(); ctx->bk.clear();
+            for (HipBackend* l : lanes) l->clear();
+            HipStreamed sp(ctx->bk, lanes);
+            int32_t rc = sp.estimate(pegs, groups, opts, out, q, /*threads=*/true);
+            if (rc == CASIM_OK && offsets_out) rc = sp.csr(nullptr, offsets_out);
+            sp.sync_all();
+            if (rc != CASIM_OK) return set_err(rc, sp.error());
+            for (HipBackend* l : lanes) if (!l->ok()) return set_err(CASIM_ERR_HIP, l->msg);
+            return CASIM_OK;
+        }
+    }
+    casim_problem* p = casim_problem_create(ctx, pegs, groups, opts);
+    if (!p) return g_err.empty() ? CASIM_ERR_INVALID : (casim_device_count() > 0 ? CASIM_ERR_INVALID : CASIM_ERR_NO_DEVICE);
+    int32_t rc = casim_problem_run(p);
+    if (rc == CASIM_OK && q) rc = casim_best_option_sims(p, q);
+    if (rc == CASIM_OK && out) rc = casim_problem_fetch(p, out);
+    if (rc == CASIM_OK && offsets_out) rc = casim_problem_csr(p, nullptr, offsets_out);
     const std::string keep = g_err;
     casim_problem_destroy(p);
     g_err = keep;
@@ -310,7 +433,10 @@ int32_t casim_estimate_batch_timed(casim_ctx* ctx, const casim_pegs* pegs, const
     if (!phase_ms_out) return set_err(CASIM_ERR_INVALID, "null phase_ms_out");
     for (int i = 0; i < 8; ++i) phase_ms_out[i] = 0.0;
     const auto t0 = clk::now();
-    casim_problem* p = casim_problem_create(ctx, pegs, groups, opts);   // init() ends with a stream sync
+    casim_options one; memset(&one, 0, sizeof one);
+    if (opts) one = *opts;
+    one.n_streams = 0;   // (phase by phase on ONE stream: the streamed form has no phases to drain between)
+    casim_problem* p = casim_problem_create(ctx, pegs, groups, &one);   // init() ends with a stream sync
     if (!p) return g_err.empty() ? CASIM_ERR_INVALID : (casim_device_count() > 0 ? CASIM_ERR_INVALID : CASIM_ERR_NO_DEVICE);
     HipBackend& bk = ctx->bk;
     const auto t1 = clk::now();
@@ -370,11 +496,13 @@ int32_t casim_feasibility_reasons(casim_ctx* ctx, const casim_pegs* pegs, const 
 int32_t casim_best_option(casim_problem* p, const int32_t* kinds, int32_t n_kinds, int32_t group_id_base, int32_t* best_ng_out,
                           int32_t* n_best_out, uint8_t* best_set_out, int64_t* key_out, void* dev_key_out) {
     PROB_ENTER(p);
+    if (p->sp) return set_err(CASIM_ERR_INVALID, "a streamed batch reduces per simulation: use casim_best_option_sims with per_sim = 1");
     PROB_RET(p, p->prob->best_option(kinds, n_kinds, group_id_base, best_ng_out, n_best_out, best_set_out, key_out, dev_key_out));
 }
 
 int32_t casim_best_option_sims(casim_problem* p, const casim_option_query* q) {
     PROB_ENTER(p);
+    if (p->sp) { clear_lanes(p); const int32_t rc = p->sp->best_option_query(q); if (rc != CASIM_OK) return set_err(rc, p->sp->error()); return lanes_ok(p); }
     PROB_RET(p, p->prob->best_option_query(q));
 }
 
@@ -443,10 +571,12 @@ int32_t casim_estimate_batch_multi(casim_mctx* m, const casim_pegs* pegs, const 
 }
 
 // ---- measurement -----------------------------------------------------------------------------
+// (a streamed batch: part 0 on its lane — one launch of each kernel class with the device to itself)
 int32_t casim_problem_time(casim_problem* p, int32_t iters, float* total_ms_out, float* kernel_ms_out) {
     PROB_ENTER(p);
     if (iters <= 0) return set_err(CASIM_ERR_INVALID, "iters must be > 0");
-    HipBackend& bk = p->ctx->bk;
+    HipBackend& bk = p->bk0();
+    if (p->sp) { p->sp->sync_all(); bk.clear(); }
     hipEvent_t ev[4];
     for (auto& e : ev) bk.check(hipEventCreate(&e), "hipEventCreate");
     double tot = 0, kf = 0, ko = 0, kp = 0;
@@ -468,14 +598,16 @@ int32_t casim_problem_time(casim_problem* p, int32_t iters, float* total_ms_out,
     if (total_ms_out) *total_ms_out = (float)(tot / iters);
     if (kernel_ms_out) { kernel_ms_out[0] = (float)(kf / iters); kernel_ms_out[1] = (float)(ko / iters); kernel_ms_out[2] = (float)(kp / iters); }
     // mark as run so that fetch works after a timing loop
-    const int32_t rc = p->prob->run();
+    const int32_t rc = p->sp ? p->sp->run() : p->prob->run();
     PROB_RET(p, rc != CASIM_OK ? rc : (bk.ok() ? CASIM_OK : CASIM_ERR_HIP));
 }
 
 static const int kMarkedRuns = 64;
+// (a streamed batch: the events go around the kernels of part 0 while the other parts run beside it, as in an unmarked run)
 int32_t casim_problem_run_marked(casim_problem* p) {
     PROB_ENTER(p);
-    HipBackend& bk = p->ctx->bk;
+    HipBackend& bk = p->bk0();
+    if (p->sp) { clear_lanes(p); p->sp->fork(); }
     if (p->marks.empty()) {
         p->marks.resize((size_t)kMarkedRuns * 4);
         for (auto& e : p->marks) bk.check(hipEventCreate(&e), "hipEventCreate");
@@ -489,13 +621,18 @@ int32_t casim_problem_run_marked(casim_problem* p) {
     p->prob->run_pack();
     bk.check(hipEventRecord(ev[3], bk.stream), "hipEventRecord");
     p->prob->run_mark();
+    if (p->sp) {
+        for (size_t i = 1; i < p->sp->n_parts(); ++i) { const int32_t rc = p->sp->part(i).prob->run(); if (rc != CASIM_OK) return set_err(rc, p->sp->part(i).prob->error()); }
+        p->sp->set_ran();
+    }
     p->n_marked++;
+    if (p->sp) return lanes_ok(p);
     PROB_RET(p, bk.ok() ? CASIM_OK : CASIM_ERR_HIP);
 }
 
 int32_t casim_problem_marked_ms(casim_problem* p, float* total_ms_out, float* kernel_ms_out, int32_t* n_runs_out) {
     PROB_ENTER(p);
-    HipBackend& bk = p->ctx->bk;
+    HipBackend& bk = p->bk0();
     bk.sync();
     const int n = p->n_marked < kMarkedRuns ? p->n_marked : kMarkedRuns;
     double tot = 0, k[3] = {0, 0, 0};

@@ -44,6 +44,15 @@ public:
         const int D = (int)bks_.size(), NG = g->n_groups, R = p->n_res;
         if (D <= 0) return fail(CASIM_ERR_INVALID, "no device");
         if (NG < 0 || R < 2 || R > CASIM_KMAX_RES) return fail(CASIM_ERR_INVALID, "bad table sizes");
+        if (o && o->node_pods) return fail(CASIM_ERR_INVALID, "casim_options.node_pods is not available on the multi-device path (per-node pod lists are not scattered across devices)");
+        // the id a group carries inside expander keys: the caller's global_id, else group_id_base + its index in the caller's
+        // table (include/casim.h) — the shards always carry explicit ids, so the rule is applied HERE (with a
+        // non-zero base the shards used to carry the bare index and the winner lookup below never matched)
+        const int64_t id_base = q ? (int64_t)q->group_id_base : 0;
+        for (int i = 0; i < NG; ++i) {
+            const int64_t gid = g->global_id ? (int64_t)g->global_id[i] : id_base + i;
+            if (gid < 0 || gid >= (1ll << 20)) return fail(CASIM_ERR_INVALID, "group id inside expander keys must be in [0, 2^20)");
+        }
         // ---- simulations + owner of every group -------------------------------------------------------
         std::vector<int32_t> so;
         if (g->n_sims > 0) {
@@ -65,12 +74,17 @@ public:
         std::vector<GroupRows> rows((size_t)D);
         for (int d = 0; d < D; ++d) rows[(size_t)d].sim_off.push_back(0);
         for (int s = 0; s < S; ++s) {
-            for (int i = so[(size_t)s]; i < so[(size_t)s + 1]; ++i) gather(rows[(size_t)owner[(size_t)i]], p, g, i);
+            for (int i = so[(size_t)s]; i < so[(size_t)s + 1]; ++i) gather(rows[(size_t)owner[(size_t)i]], p, g, i, (int32_t)id_base);
             for (int d = 0; d < D; ++d) rows[(size_t)d].sim_off.push_back((int32_t)rows[(size_t)d].src.size());
         }
         // ---- upload + launch everywhere, then wait -------------------------------------------------------
         std::vector<std::unique_ptr<ProblemT<BK>>> probs;
         std::vector<int64_t*> dev_keys((size_t)D, nullptr);
+        // every exit (errors included) leaves no device busy and returns the key blocks to their pools
+        struct Guard {
+            std::vector<BK*>& bks; std::vector<int64_t*>& keys;
+            ~Guard() { for (size_t d = 0; d < bks.size(); ++d) { bks[d]->bind(); bks[d]->sync(); if (keys[d]) { bks[d]->free(keys[d]); keys[d] = nullptr; } } }
+        } guard{bks_, dev_keys};
         for (int d = 0; d < D; ++d) {
             GroupRows& gr = rows[(size_t)d];
             finish_view(gr, p, g, S);
@@ -110,6 +124,13 @@ public:
                 bks_[0]->bind();
                 bks_[0]->d2h(packed.data(), dev_keys[0], 8 * (size_t)S); bks_[0]->sync();
                 for (int s = 0; s < S; ++s) win_gid[(size_t)s] = packed[(size_t)s] == 0x7fffffffffffffffll ? -1 : (packed[(size_t)s] & 0xfffff);
+                if (q->key_out)   // the collective carries the packed key only: [0] packed, [1] the (single, integer) filter's metric, [9] the id
+                    for (int s = 0; s < S; ++s) {
+                        int64_t* kb = q->key_out + 10 * (size_t)s;
+                        const bool none = win_gid[(size_t)s] < 0;
+                        for (int f = 0; f < 10; ++f) kb[f] = 0x7fffffffffffffffll;
+                        if (!none) { kb[0] = packed[(size_t)s]; kb[1] = (int64_t)((uint64_t)(packed[(size_t)s] >> 20) ^ 0x8000000000000000ull); kb[9] = win_gid[(size_t)s]; }
+                    }
                 reduced_by_ = 1;
             } else {
                 for (int d = 0; d < D; ++d) { bks_[(size_t)d]->bind(); bks_[(size_t)d]->sync(); }
@@ -139,7 +160,7 @@ public:
                 for (int s = 0; s < S; ++s) {
                     int32_t idx = -1;
                     for (int i = so[(size_t)s]; i < so[(size_t)s + 1] && idx < 0; ++i) {
-                        const int64_t gid = g->global_id ? g->global_id[i] : (int64_t)q->group_id_base + i;
+                        const int64_t gid = g->global_id ? g->global_id[i] : id_base + i;
                         if (win_gid[(size_t)s] >= 0 && (gid & 0xfffff) == (win_gid[(size_t)s] & 0xfffff)) idx = i;
                     }
                     if (q->best_out) q->best_out[s] = idx;
@@ -190,7 +211,6 @@ public:
             }
             if (offsets_out) memcpy(offsets_out, goff.data(), 4 * ((size_t)NG + 1));
         }
-        for (int d = 0; d < D; ++d) { bks_[(size_t)d]->bind(); bks_[(size_t)d]->sync(); if (dev_keys[(size_t)d]) bks_[(size_t)d]->free(dev_keys[(size_t)d]); }
         groups_per_device_.clear();
         for (int d = 0; d < D; ++d) groups_per_device_.push_back((int32_t)rows[(size_t)d].src.size());
         return CASIM_OK;
@@ -201,7 +221,7 @@ public:
 
 private:
     template <class T> static void row(std::vector<T>& dst, const T* src, int i, int w) { if (src && w > 0) dst.insert(dst.end(), src + (int64_t)i * w, src + (int64_t)(i + 1) * w); }
-    static void gather(GroupRows& r, const casim_pegs* p, const casim_groups* g, int i) {
+    static void gather(GroupRows& r, const casim_pegs* p, const casim_groups* g, int i, int32_t id_base) {
         const int R = p->n_res;
         row(r.alloc, g->alloc, i, R); row(r.init_req, g->init_req, i, R); row(r.allowed, g->allowed_pods, i, 1); row(r.init_pods, g->init_pods, i, 1);
         row(r.flags, g->flags, i, 1); row(r.taint, g->taint_mask, i, p->w_taint); row(r.label, g->label_mask, i, p->w_label);
@@ -215,7 +235,7 @@ private:
         } else {
             r.peg_lo.push_back(g->peg_lo ? g->peg_lo[i] : 0); r.peg_hi.push_back(g->peg_hi ? g->peg_hi[i] : p->n_pegs);
         }
-        r.global_id.push_back(g->global_id ? g->global_id[i] : i);
+        r.global_id.push_back(g->global_id ? g->global_id[i] : id_base + i);
         r.src.push_back(i);
     }
     static void finish_view(GroupRows& r, const casim_pegs* p, const casim_groups* g, int S) {

@@ -1,0 +1,259 @@
+// casim_streams.h — a batch of independent simulations as sub-batches on HIP streams of their own, INSIDE one casim_problem
+// (casim_options.n_streams; VERDICT r2 next #2: the overlap used to live in Python, kubernetes_autoscaler_amd/streams.py).
+//
+// Why: the feasibility / ordering kernels of the scale-up path wait on memory, the packer on instruction issue; run back to
+// back on one stream they leave each other's resource idle and every launch ends in a tail.  Cut by simulation, each part a
+// ProblemT on a "lane" of the context (a backend with its own stream, memory pool and pinned staging buffers on the SAME
+// device), the parts overlap (1.41 -> 1.06 ms per 4096 C2 simulations).
+//
+// Ordering contract towards the caller (who only knows the context's stream):
+//   run()                fork: every lane waits for what the context's stream holds at that moment, then the parts are enqueued;
+//   best_option_query()  with DEVICE outputs: join — the context's stream waits for every lane, so that work the caller enqueues
+//                        there (an RCCL all-reduce on the keys) sees them; with host outputs the call synchronises the lanes;
+//   fetch() / csr()      synchronise the lanes.
+// A caller that leaves the context's stream alone between steps (resident tables, keys read at the end) gets steps that
+// overlap each other as well: the forks then wait for nothing.
+//
+// The parts see VIEWS of the caller's tables (pointer offsets, no copies) — only peg_lo / peg_hi / sim_offsets are re-based
+// into small arrays — and write their results straight into the caller's arrays at the part's offsets; PEG ids of `order`
+// are shifted back to the numbering of the whole batch on the host.  Results are identical to the unstreamed call
+// (tests/test_streams_emu.py, tests/test_gpu_round3.py).
+//
+// Backend concept additions:  void mark();  void wait_mark(BK& other);  (record an event on the own stream / make the own
+// stream wait for the other's last mark; no-ops for the synchronous emulator backend).
+#pragma once
+#include <memory>
+#include <thread>
+
+#include "casim_pipeline.h"
+
+namespace casim {
+
+template <class BK>
+class StreamedProblemT {
+public:
+    StreamedProblemT(BK& primary, std::vector<BK*> lanes) : primary_(primary), lanes_(std::move(lanes)) {}
+
+    // a batch is cut when it holds at least two simulations, the schedulable subsets are derived on the device from per-group
+    // candidate ranges, and the per-node pod lists are not asked for (their compaction runs over the whole batch)
+    static bool eligible(const casim_pegs* p, const casim_groups* g, const casim_options* o) {
+        return p && g && o && o->n_streams > 1 && g->n_sims >= 2 && g->sim_offsets && !g->peg_offsets && g->peg_lo && g->peg_hi && !o->node_pods &&
+               g->n_groups > 0;
+    }
+
+    struct Part {
+        int s0 = 0, s1 = 0, g0 = 0, g1 = 0, p0 = 0, p1 = 0;
+        casim_pegs pv; casim_groups gv;
+        std::vector<int32_t> lo, hi, so;
+        std::unique_ptr<ProblemT<BK>> prob;
+        int32_t rc = CASIM_OK;
+    };
+
+    // cut + upload.  `threads`: every part is prepared (table packing into its lane's pinned buffer, H2D) by a thread of its own
+    int32_t init(const casim_pegs* p, const casim_groups* g, const casim_options* o, bool threads) {
+        if (!eligible(p, g, o)) return fail(CASIM_ERR_INVALID, "batch cannot be cut into streamed parts");
+        const int S = g->n_sims;
+        if (g->sim_offsets[0] != 0 || g->sim_offsets[S] != g->n_groups) return fail(CASIM_ERR_INVALID, "sim_offsets must run from 0 to n_groups");
+        for (int s = 0; s < S; ++s) if (g->sim_offsets[s + 1] < g->sim_offsets[s]) return fail(CASIM_ERR_INVALID, "sim_offsets not monotone");
+        for (int i = 0; i < g->n_groups; ++i)
+            if (g->peg_lo[i] < 0 || g->peg_hi[i] < g->peg_lo[i] || g->peg_hi[i] > p->n_pegs) return fail(CASIM_ERR_INVALID, "peg_lo / peg_hi out of range");
+        int K = (int)lanes_.size();
+        if (K > o->n_streams) K = o->n_streams;
+        if (K > S) K = S;
+        if (K < 1) return fail(CASIM_ERR_INVALID, "no lane");
+        opts_ = *o; opts_.n_streams = 0;
+        n_groups_ = g->n_groups; n_sims_ = S; has_gid_ = g->global_id != nullptr;
+        parts_.clear(); parts_.resize((size_t)K);
+        for (int i = 0; i < K; ++i) cut(parts_[(size_t)i], p, g, (int)((int64_t)S * i / K), (int)((int64_t)S * (i + 1) / K));
+        auto work = [&](int i) {
+            Part& pt = parts_[(size_t)i];
+            lanes_[(size_t)i]->bind();
+            pt.prob.reset(new ProblemT<BK>(*lanes_[(size_t)i]));
+            pt.rc = pt.prob->init(&pt.pv, &pt.gv, &opts_);
+        };
+        each(work, threads);
+        for (auto& pt : parts_) if (pt.rc != CASIM_OK) return fail(pt.rc, pt.prob->error().c_str());
+        ready_ = true;
+        return CASIM_OK;
+    }
+
+    int32_t run() {
+        if (!ready_) return fail(CASIM_ERR_INVALID, "problem not initialised");
+        primary_.bind(); primary_.mark();
+        for (size_t i = 0; i < parts_.size(); ++i) {
+            lanes_[i]->wait_mark(primary_);
+            const int32_t rc = parts_[i].prob->run();
+            if (rc != CASIM_OK) return fail(rc, parts_[i].prob->error().c_str());
+        }
+        ran_ = true;
+        return CASIM_OK;
+    }
+    // fork only (timed callers enqueue the phases of a part themselves)
+    void fork() { primary_.bind(); primary_.mark(); for (size_t i = 0; i < parts_.size(); ++i) lanes_[i]->wait_mark(primary_); }
+    void join() { for (size_t i = 0; i < parts_.size(); ++i) { lanes_[i]->mark(); primary_.wait_mark(*lanes_[i]); } }
+    void sync_all() { for (size_t i = 0; i < parts_.size(); ++i) lanes_[i]->sync(); }
+    void set_ran() { ran_ = true; }
+
+    // whole-batch CSR offsets of order / placed
+    int32_t csr(int32_t* nnz_out, int32_t* offsets_out) {
+        if (!ready_ || !ran_) return fail(CASIM_ERR_INVALID, "run the problem first");
+        int32_t base = 0;
+        std::vector<int32_t> loc;
+        if (offsets_out) offsets_out[0] = 0;
+        for (auto& pt : parts_) {
+            const int n = pt.g1 - pt.g0;
+            loc.assign((size_t)n + 1, 0);
+            int32_t nnz = 0;
+            const int32_t rc = pt.prob->csr(&nnz, loc.data());
+            if (rc != CASIM_OK) return fail(rc, pt.prob->error().c_str());
+            if (offsets_out) for (int k = 1; k <= n; ++k) offsets_out[pt.g0 + k] = base + loc[(size_t)k];
+            base += nnz;
+        }
+        if (nnz_out) *nnz_out = base;
+        return CASIM_OK;
+    }
+
+    int32_t fetch(casim_results* out, bool threads) {
+        if (!ready_ || !ran_) return fail(CASIM_ERR_INVALID, "nothing to fetch: run the problem first");
+        if (!out) return fail(CASIM_ERR_INVALID, "null results");
+        // the parts' shares of order / placed: their nnz (device-side CSR) first
+        std::vector<int32_t> base(parts_.size() + 1, 0);
+        for (size_t i = 0; i < parts_.size(); ++i) {
+            int32_t nnz = 0;
+            const int32_t rc = parts_[i].prob->csr(&nnz, nullptr);
+            if (rc != CASIM_OK) return fail(rc, parts_[i].prob->error().c_str());
+            base[i + 1] = base[i] + nnz;
+        }
+        auto work = [&](int i) {
+            Part& pt = parts_[(size_t)i];
+            lanes_[(size_t)i]->bind();
+            casim_results r; memset(&r, 0, sizeof r);
+            auto at = [&](auto* ptr, int64_t off) { return ptr ? ptr + off : ptr; };
+            r.node_count = at(out->node_count, pt.g0); r.pods_scheduled = at(out->pods_scheduled, pt.g0); r.nodes_added = at(out->nodes_added, pt.g0);
+            r.limiter_nodes = at(out->limiter_nodes, pt.g0); r.last_index_out = at(out->last_index_out, pt.g0); r.status = at(out->status, pt.g0);
+            r.req_cpu_sum = at(out->req_cpu_sum, pt.g0); r.req_mem_sum = at(out->req_mem_sum, pt.g0);
+            r.order = at(out->order, base[(size_t)i]); r.placed = at(out->placed, base[(size_t)i]);
+            pt.rc = pt.prob->fetch(&r);
+            if (pt.rc == CASIM_OK && r.order && pt.p0 != 0) {   // PEG ids back in the numbering of the whole batch
+                const int32_t n = base[(size_t)i + 1] - base[(size_t)i], add = pt.p0;
+                for (int32_t k = 0; k < n; ++k) r.order[k] += add;
+            }
+        };
+        each(work, threads);
+        for (auto& pt : parts_) if (pt.rc != CASIM_OK) return fail(pt.rc, pt.prob->error().c_str());
+        return CASIM_OK;
+    }
+
+    // The expander chain, one reduce per simulation; every part fills its slice of the caller's outputs.
+    int32_t best_option_query(const casim_option_query* q) {
+        if (!ready_ || !ran_) return fail(CASIM_ERR_INVALID, "run the problem first");
+        if (!q) return fail(CASIM_ERR_INVALID, "null query");
+        if (!q->per_sim) return fail(CASIM_ERR_INVALID, "a streamed batch reduces per simulation (per_sim = 1)");
+        for (size_t i = 0; i < parts_.size(); ++i) {
+            const int32_t rc = part_query(i, q);
+            if (rc != CASIM_OK) return rc;
+        }
+        if (q->dev_key_out || q->dev_packed_out) join();
+        return CASIM_OK;
+    }
+    int32_t part_query(size_t i, const casim_option_query* q) {
+        Part& pt = parts_[i];
+        lanes_[i]->bind();
+        casim_option_query lq = *q;
+        lq.per_sim = 1;
+        lq.group_id_base = q->group_id_base + (has_gid_ ? 0 : pt.g0);
+        if (q->valid) lq.valid = q->valid + pt.g0;
+        if (q->best_out) lq.best_out = q->best_out + pt.s0;
+        if (q->n_best_out) lq.n_best_out = q->n_best_out + pt.s0;
+        if (q->best_set_out) lq.best_set_out = q->best_set_out + pt.g0;
+        if (q->key_out) lq.key_out = q->key_out + 10 * (int64_t)pt.s0;
+        if (q->packed_out) lq.packed_out = q->packed_out + pt.s0;
+        if (q->dev_key_out) lq.dev_key_out = (char*)q->dev_key_out + 80 * (int64_t)pt.s0;
+        if (q->dev_packed_out) lq.dev_packed_out = (char*)q->dev_packed_out + 8 * (int64_t)pt.s0;
+        const int32_t rc = pt.prob->best_option_query(&lq);
+        if (rc != CASIM_OK) return fail(rc, pt.prob->error().c_str());
+        if (q->best_out) for (int s = pt.s0; s < pt.s1; ++s) if (q->best_out[s] >= 0) q->best_out[s] += pt.g0;   // index inside the whole batch
+        return CASIM_OK;
+    }
+
+    // enter -> return in one go: every part is uploaded, run, reduced and fetched by its own worker, so that the upload of one
+    // part overlaps the kernels of another and the result copies of a third (wall = enter -> return)
+    int32_t estimate(const casim_pegs* p, const casim_groups* g, const casim_options* o, casim_results* out, const casim_option_query* q, bool threads) {
+        int32_t rc = init(p, g, o, threads);
+        if (rc != CASIM_OK) return rc;
+        rc = run();
+        if (rc == CASIM_OK && q) rc = best_option_query(q);
+        if (rc == CASIM_OK && out) rc = fetch(out, threads);
+        return rc;
+    }
+
+    int32_t set_group_result(int32_t ng, const casim_cluster_estimate_result* r) {
+        for (auto& pt : parts_) if (ng >= pt.g0 && ng < pt.g1) {
+            const int32_t rc = pt.prob->set_group_result(ng - pt.g0, r);
+            return rc == CASIM_OK ? rc : fail(rc, pt.prob->error().c_str());
+        }
+        return fail(CASIM_ERR_INVALID, "bad group index");
+    }
+
+    size_t n_parts() const { return parts_.size(); }
+    Part& part(size_t i) { return parts_[i]; }
+    BK& lane(size_t i) { return *lanes_[i]; }
+    int groups() const { return n_groups_; }
+    int sims() const { return n_sims_; }
+    const std::string& error() const { return err_; }
+
+private:
+    template <class T> static const T* off(const T* p, int64_t n) { return p ? p + n : p; }
+    void cut(Part& pt, const casim_pegs* p, const casim_groups* g, int s0, int s1) {
+        pt.s0 = s0; pt.s1 = s1; pt.g0 = g->sim_offsets[s0]; pt.g1 = g->sim_offsets[s1];
+        int lo = p->n_pegs, hi = 0;
+        for (int i = pt.g0; i < pt.g1; ++i) { lo = g->peg_lo[i] < lo ? g->peg_lo[i] : lo; hi = g->peg_hi[i] > hi ? g->peg_hi[i] : hi; }
+        if (hi < lo) { lo = 0; hi = 0; }
+        pt.p0 = lo; pt.p1 = hi;
+        const int R = p->n_res;
+        casim_pegs& v = pt.pv; v = *p;
+        v.n_pegs = hi - lo;
+        v.req = off(p->req, (int64_t)lo * R); v.count = off(p->count, lo); v.flags = off(p->flags, lo);
+        v.tol_mask = off(p->tol_mask, (int64_t)lo * p->w_taint); v.sel_mask = off(p->sel_mask, (int64_t)lo * p->w_label);
+        v.excl_block = off(p->excl_block, (int64_t)lo * p->w_excl); v.excl_mark = off(p->excl_mark, (int64_t)lo * p->w_excl);
+        v.zone_block = off(p->zone_block, (int64_t)lo * p->w_zone); v.zone_mark = off(p->zone_mark, (int64_t)lo * p->w_zone);
+        v.fp_cpu = off(p->fp_cpu, lo); v.fp_mem = off(p->fp_mem, lo);
+        casim_groups& w = pt.gv; w = *g;
+        const int64_t a = pt.g0;
+        w.n_groups = pt.g1 - pt.g0;
+        w.alloc = off(g->alloc, a * R); w.init_req = off(g->init_req, a * R); w.allowed_pods = off(g->allowed_pods, a); w.init_pods = off(g->init_pods, a);
+        w.flags = off(g->flags, a); w.taint_mask = off(g->taint_mask, a * p->w_taint); w.label_mask = off(g->label_mask, a * p->w_label);
+        w.init_excl = off(g->init_excl, a * p->w_excl); w.init_zone = off(g->init_zone, a * p->w_zone); w.zone_valid = off(g->zone_valid, a * p->w_zone);
+        w.max_nodes = off(g->max_nodes, a); w.existing_nodes = off(g->existing_nodes, a); w.last_index = off(g->last_index, a);
+        w.cap_cpu = off(g->cap_cpu, a); w.cap_mem = off(g->cap_mem, a); w.waste_cpu = off(g->waste_cpu, a); w.waste_mem = off(g->waste_mem, a);
+        w.global_id = off(g->global_id, a);
+        w.peg_offsets = nullptr; w.peg_index = nullptr;
+        pt.lo.resize((size_t)w.n_groups); pt.hi.resize((size_t)w.n_groups);
+        for (int i = 0; i < w.n_groups; ++i) { pt.lo[(size_t)i] = g->peg_lo[pt.g0 + i] - lo; pt.hi[(size_t)i] = g->peg_hi[pt.g0 + i] - lo; }
+        pt.so.resize((size_t)(s1 - s0) + 1);
+        for (int s = s0; s <= s1; ++s) pt.so[(size_t)(s - s0)] = g->sim_offsets[s] - pt.g0;
+        static const int32_t z32[1] = {0};
+        w.peg_lo = w.n_groups ? pt.lo.data() : z32; w.peg_hi = w.n_groups ? pt.hi.data() : z32;
+        w.n_sims = s1 - s0; w.sim_offsets = pt.so.data();
+    }
+    template <class F>
+    void each(F&& f, bool threads) {
+        const int K = (int)parts_.size();
+        if (!threads || K == 1) { for (int i = 0; i < K; ++i) f(i); return; }
+        std::vector<std::thread> th;
+        for (int i = 1; i < K; ++i) th.emplace_back([&f, i]() { f(i); });
+        f(0);
+        for (auto& t : th) t.join();
+    }
+    int32_t fail(int32_t code, const char* msg) { err_ = msg ? msg : ""; return code; }
+
+    BK& primary_;
+    std::vector<BK*> lanes_;
+    std::vector<Part> parts_;
+    casim_options opts_;
+    int n_groups_ = 0, n_sims_ = 0;
+    bool has_gid_ = false, ready_ = false, ran_ = false;
+    std::string err_;
+};
+
+}  // namespace casim

@@ -408,7 +408,9 @@ class Problem:
     """casim_problem: a batch resident in HBM; run() enqueues feasibility -> order -> pack."""
 
     def __init__(self, ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, fastpath: bool = False, force_generic_packer: bool = False,
-                 node_pods: bool = False):
+                 node_pods: bool = False, n_streams: int = 0):
+        """n_streams > 1: a batch of simulations runs as up to n_streams sub-batches on internal HIP streams of the context
+        (casim_options.n_streams); results are identical, info()["parts"] tells whether the batch was cut."""
         self.ctx = ctx
         self.n_groups = groups.n_groups
         self.n_pegs = pegs.n_pegs
@@ -418,7 +420,8 @@ class Problem:
             total = int(sum(max(int(pegs.count[i]), 1) for i in range(pegs.n_pegs)))
             self._node_pods_cap = int(sum((int(groups.max_nodes[i]) if groups.max_nodes[i] > 0 else (0 if groups.max_nodes[i] < 0 else total))
                                           for i in range(groups.n_groups))) + 64
-        opts = _abi.Options(fastpath=int(fastpath), force_generic_packer=int(force_generic_packer), node_pods=int(bool(node_pods)))
+        opts = _abi.Options(fastpath=int(fastpath), force_generic_packer=int(force_generic_packer), node_pods=int(bool(node_pods)),
+                            n_streams=int(n_streams))
         self._h = lib.casim_problem_create(ctx._h, C.byref(pegs), C.byref(groups), C.byref(opts))
         if not self._h:
             raise CasimError(_abi.ERR_INVALID, last_error())
@@ -441,7 +444,7 @@ class Problem:
         out = (C.c_int32 * 8)()
         check(lib.casim_problem_info(self._h, out), "casim_problem_info")
         return {"fast_packer_slots_per_lane": out[0], "fast_packer_lanes": out[1], "generic_state_in_lds": bool(out[2]),
-                "csr_on_device": bool(out[3])}
+                "csr_on_device": bool(out[3]), "parts": int(out[4])}
 
     def set_group_result(self, ng: int, r: dict):
         """casim_problem_set_group_result: a group estimated by Context.estimate_on_cluster joins the expander reduce."""
@@ -551,6 +554,46 @@ def estimate_batch_timed(ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, kin
                                          C.byref(q) if q is not None else None, ph), "casim_estimate_batch_timed")
     names = ("upload_ms", "feasibility_csr_ms", "order_ms", "pack_ms", "expander_ms", "fetch_ms", "wall_ms")
     return arrs, {k: ph[i] for i, k in enumerate(names)}, exp
+
+
+def _nnz_cap(pegs, groups):
+    ng = groups.n_groups
+    if groups.peg_offsets:
+        return int(groups.peg_offsets[ng]) if ng else 0
+    if groups.peg_lo:
+        lo = np.ctypeslib.as_array(groups.peg_lo, shape=(ng,)); hi = np.ctypeslib.as_array(groups.peg_hi, shape=(ng,))
+        return int((hi.astype(np.int64) - lo).sum())
+    return pegs.n_pegs * ng
+
+
+class BatchCall:
+    """casim_estimate_batch_query with its buffers kept between calls: upload + kernels + expander reduce per simulation + fetch,
+    enter -> return in ONE call of the C ABI (SURVEY 8d's wall time).  n_streams > 1: the parts of the batch run end to end on
+    the context's internal streams.  call() returns (BatchResult, expander dict or None)."""
+
+    def __init__(self, ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, kinds: Optional[Sequence[int]] = None, fastpath: bool = False,
+                 force_generic_packer: bool = False, n_streams: int = 0):
+        self.ctx, self.pegs, self.groups = ctx, pegs, groups
+        ng = groups.n_groups
+        self.st, self.arrs = alloc_results(ng, _nnz_cap(pegs, groups))
+        self.opts = _abi.Options(fastpath=int(fastpath), force_generic_packer=int(force_generic_packer), n_streams=int(n_streams))
+        self.off = np.zeros(ng + 1, np.int32)
+        self.q = self.exp = None
+        if kinds is not None:
+            S = groups.n_sims if groups.n_sims > 0 else 1
+            self._ks = (C.c_int32 * max(len(kinds), 1))(*kinds)
+            self.exp = dict(best=np.full(S, -1, np.int32), n_best=np.zeros(S, np.int32), packed=np.zeros(S, np.int64))
+            self.q = _abi.OptionQuery(kinds=self._ks, n_kinds=len(kinds), per_sim=int(groups.n_sims > 0), best_out=_ptr(self.exp["best"], C.c_int32),
+                                      n_best_out=_ptr(self.exp["n_best"], C.c_int32), packed_out=_ptr(self.exp["packed"], C.c_int64))
+
+    def call_raw(self):
+        check(lib.casim_estimate_batch_query(self.ctx._h, C.byref(self.pegs), C.byref(self.groups), C.byref(self.opts), C.byref(self.st),
+                                             _ptr(self.off, C.c_int32), C.byref(self.q) if self.q is not None else None), "casim_estimate_batch_query")
+
+    def call(self):
+        self.call_raw()
+        ng = self.groups.n_groups
+        return finish_results(self.arrs, ng, int(self.off[ng]), self.off.copy()), self.exp
 
 
 def estimate_batch(ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, fastpath: bool = False) -> BatchResult:

@@ -9,6 +9,7 @@
 #include "casim_emu.h"
 #include "../../kubernetes_autoscaler_amd/csrc/casim_pipeline.h"
 #include "../../kubernetes_autoscaler_amd/csrc/casim_multi.h"
+#include "../../kubernetes_autoscaler_amd/csrc/casim_streams.h"
 
 namespace {
 struct EmuBackend {
@@ -21,6 +22,8 @@ struct EmuBackend {
     void fill8(void* d, int v, size_t n) { memset(d, v, n); }
     void sync() {}
     void bind() {}
+    void mark() {}
+    void wait_mark(EmuBackend&) {}
     std::vector<char> staging[2];
     void* stage(int which, size_t bytes) { if (staging[which & 1].size() < bytes) staging[which & 1].resize(bytes); return staging[which & 1].data(); }
     size_t lds_budget() const { return lds; }
@@ -75,6 +78,27 @@ EMU_API int32_t emu_estimate_batch_query(const casim_pegs* pegs, const casim_gro
     if (rc == CASIM_OK && (nnz_out || offsets_out)) rc = p.csr(nnz_out, offsets_out);
     if (rc == CASIM_OK && q) rc = p.best_option_query(q);
     if (rc != CASIM_OK) g_err = p.error();
+    return rc;
+}
+
+// The batch cut into sub-batches on the lanes of one context (casim_streams.h; the emulator runs the parts one after the other):
+// how casim_options.n_streams cuts the tables and puts the results back together.  parts_out: how many parts ran (1 = not cut).
+EMU_API int32_t emu_estimate_batch_streams(const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts, casim_results* out,
+                                           int32_t* nnz_out, int32_t* offsets_out, const casim_option_query* q, int32_t* parts_out) {
+    typedef casim::StreamedProblemT<EmuBackend> SP;
+    EmuBackend primary;
+    if (!SP::eligible(pegs, groups, opts)) {
+        if (parts_out) *parts_out = 1;
+        return emu_estimate_batch_query(pegs, groups, opts, out, 0, nnz_out, offsets_out, q);
+    }
+    std::vector<EmuBackend> bks((size_t)opts->n_streams);
+    std::vector<EmuBackend*> lanes;
+    for (auto& b : bks) lanes.push_back(&b);
+    SP sp(primary, lanes);
+    int32_t rc = sp.estimate(pegs, groups, opts, out, q, /*threads=*/false);
+    if (rc == CASIM_OK && (nnz_out || offsets_out)) rc = sp.csr(nnz_out, offsets_out);
+    if (rc != CASIM_OK) g_err = sp.error();
+    if (parts_out) *parts_out = (int32_t)sp.n_parts();
     return rc;
 }
 

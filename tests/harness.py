@@ -472,17 +472,51 @@ def run_emu_tables(ts, kinds=None, per_sim=True, valid=None, fastpath=False, lds
     return finish_results(arrs, ng, int(nnz.value), off), exp
 
 
-def run_gpu_tables(ts, ctx, kinds=None, per_sim=True, valid=None, fastpath=False):
+def run_emu_streams(ts, n_streams, kinds=None, valid=None, generic=False, group_id_base=0):
+    """The batch cut into sub-batches the way casim_options.n_streams does it (csrc/casim_streams.h), parts run by the emulator one
+    after the other.  Returns (BatchResult, expander dict or None, parts)."""
+    L = emu_lib()
+    if not hasattr(L, "_streams_bound"):
+        L.emu_estimate_batch_streams.restype = C.c_int32
+        L.emu_estimate_batch_streams.argtypes = [C.POINTER(_abi.Pegs), C.POINTER(_abi.Groups), C.POINTER(_abi.Options), C.POINTER(_abi.Results),
+                                                 _abi.i32p, _abi.i32p, C.POINTER(_abi.OptionQuery), _abi.i32p]
+        L._streams_bound = True
+    pegs, groups = ts.structs()
+    ng = groups.n_groups
+    nnz_cap = int((ts.peg_hi - ts.peg_lo).sum()) if ts.peg_lo is not None else (int(ts.peg_offsets[ng]) if ts.peg_offsets is not None else pegs.n_pegs * ng)
+    st, arrs = alloc_results(ng, nnz_cap)
+    opts = _abi.Options(force_generic_packer=int(generic), n_streams=int(n_streams))
+    nnz, parts = C.c_int32(0), C.c_int32(0)
+    off = np.zeros(ng + 1, np.int32)
+    q = exp = None
+    if kinds is not None:
+        S = ts.n_sims if ts.n_sims else 1
+        ks = (C.c_int32 * max(len(kinds), 1))(*kinds)
+        exp = dict(best=np.full(S, -1, np.int32), n_best=np.zeros(S, np.int32), best_set=np.zeros(max(ng, 1), np.uint8),
+                   keys=np.zeros((S, 10), np.int64), packed=np.zeros(S, np.int64))
+        q = _abi.OptionQuery(kinds=ks, n_kinds=len(kinds), per_sim=1, group_id_base=int(group_id_base), best_out=exp["best"].ctypes.data_as(_abi.i32p),
+                             n_best_out=exp["n_best"].ctypes.data_as(_abi.i32p), best_set_out=exp["best_set"].ctypes.data_as(_abi.u8p),
+                             key_out=exp["keys"].ctypes.data_as(_abi.i64p), packed_out=exp["packed"].ctypes.data_as(_abi.i64p))
+        if valid is not None:
+            v = np.ascontiguousarray(valid, np.uint8)
+            q.valid = v.ctypes.data_as(_abi.u8p)
+    rc = L.emu_estimate_batch_streams(C.byref(pegs), C.byref(groups), C.byref(opts), C.byref(st), C.byref(nnz), off.ctypes.data_as(_abi.i32p),
+                                      C.byref(q) if q is not None else None, C.byref(parts))
+    assert rc == 0, (rc, L.emu_last_error())
+    return finish_results(arrs, ng, int(nnz.value), off), exp, int(parts.value)
+
+
+def run_gpu_tables(ts, ctx, kinds=None, per_sim=True, valid=None, fastpath=False, n_streams=0, generic=False):
     from kubernetes_autoscaler_amd.engine import Problem
     pegs, groups = ts.structs()
-    with Problem(ctx, pegs, groups, fastpath) as p:
+    with Problem(ctx, pegs, groups, fastpath, generic, n_streams=n_streams) as p:
         p.run()
         res = p.fetch()
         exp = p.best_option_sims(kinds, per_sim=per_sim, valid=valid, n_sims=ts.n_sims) if kinds is not None else None
     return res, exp
 
 
-def run_emu_multi(ts, n_devices, kinds=None, valid=None, use_hook=True):
+def run_emu_multi(ts, n_devices, kinds=None, valid=None, use_hook=True, group_id_base=0, expect_rc=0):
     """The batch over n emulated devices (casim_multi.h).  Returns (BatchResult, expander dict or None, info)."""
     L = emu_lib()
     if not hasattr(L, "_multi_bound"):
@@ -506,7 +540,7 @@ def run_emu_multi(ts, n_devices, kinds=None, valid=None, use_hook=True):
         S = ts.n_sims if ts.n_sims else 1
         ks = (C.c_int32 * max(len(kinds), 1))(*kinds)
         exp = dict(best=np.full(S, -1, np.int32), n_best=np.zeros(S, np.int32), keys=np.zeros((S, 10), np.int64), packed=np.zeros(S, np.int64))
-        q = _abi.OptionQuery(kinds=ks, n_kinds=len(kinds), per_sim=1, best_out=exp["best"].ctypes.data_as(_abi.i32p),
+        q = _abi.OptionQuery(kinds=ks, n_kinds=len(kinds), per_sim=1, group_id_base=int(group_id_base), best_out=exp["best"].ctypes.data_as(_abi.i32p),
                              n_best_out=exp["n_best"].ctypes.data_as(_abi.i32p), key_out=exp["keys"].ctypes.data_as(_abi.i64p),
                              packed_out=exp["packed"].ctypes.data_as(_abi.i64p))
         if valid is not None:
@@ -515,7 +549,9 @@ def run_emu_multi(ts, n_devices, kinds=None, valid=None, use_hook=True):
     info = (C.c_int32 * (1 + n_devices))()
     rc = L.emu_estimate_batch_multi(n_devices, int(use_hook), C.byref(pegs), C.byref(groups), C.byref(opts), C.byref(st),
                                     off.ctypes.data_as(_abi.i32p), C.byref(q) if q is not None else None, info)
-    assert rc == 0, (rc, L.emu_last_error())
+    assert rc == expect_rc, (rc, L.emu_last_error())
+    if rc != 0:
+        return None, None, list(info)
     return finish_results(arrs, ng, int(off[ng]), off), exp, list(info)
 
 

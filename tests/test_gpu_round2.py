@@ -84,8 +84,8 @@ def test_batch_with_lists_beyond_the_one_wave_networks(ctx):
 
 
 def test_streamed_batch_equals_one_problem():
-    """kaa.StreamedBatch: the simulations of a batch spread over 1 / 3 / 4 contexts (streams) of the device give the results
-    of ONE problem — group arrays, CSR offsets, PEG ids in the whole batch's numbering, per-simulation expander winners and
+    """casim_options.n_streams: the simulations of a batch spread over 1 / 3 / 4 / 16 internal streams of ONE context give the results
+    of ONE unstreamed problem — group arrays, CSR offsets, PEG ids in the whole batch's numbering, per-simulation expander winners and
     the packed keys written into slices of one device tensor (tests/tools/streamed_batch_check.py, its own process: torch
     first, so that the tensor and libcasim share one HIP runtime)."""
     import json
@@ -97,7 +97,7 @@ def test_streamed_batch_equals_one_problem():
                        text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-    assert out["streams_checked"] == [1, 3, 4] and out["simulations"] == 11
+    assert out["streams_checked"] == [1, 3, 4, 16] and out["simulations"] == 11
 
 
 def test_reason_codes_on_the_device(ctx):

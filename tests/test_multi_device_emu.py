@@ -84,3 +84,30 @@ def test_more_devices_than_groups():
     _, w2, _ = run_emu_multi(ts, 8, kinds=[_abi.EXPANDER_LEAST_WASTE, _abi.EXPANDER_MOST_PODS])     # empty shards carry no capacity columns
     assert list(w2["best"]) == list(w1["best"])
     enc.close()
+
+
+@pytest.mark.parametrize("use_hook", [True, False])
+@pytest.mark.parametrize("base", [0, 100, 70000])
+def test_group_id_base_without_global_ids(base, use_hook):
+    """casim_groups.global_id == NULL and q->group_id_base != 0: the keys carry base + the caller's index on every
+    device, and the winner lookup finds it again (it used to answer "no option" for every simulation)."""
+    scs = [_scenario(6400 + k, groups=6) for k in range(4)]
+    enc, ts, _ = encode_batch(scs)
+    ts.global_id = None
+    kinds = [_abi.EXPANDER_LEAST_NODES]
+    _, one = run_emu_tables(ts, kinds=kinds)
+    _, exp, _ = run_emu_multi(ts, 3, kinds=kinds, use_hook=use_hook, group_id_base=base)
+    assert list(exp["best"]) == list(one["best"]) and any(b >= 0 for b in exp["best"])
+    for s_, b in enumerate(exp["best"]):
+        if b >= 0:
+            assert int(exp["packed"][s_]) & 0xFFFFF == base + b
+            assert int(exp["keys"][s_][9]) == base + b and int(exp["keys"][s_][0]) == int(exp["packed"][s_])
+    enc.close()
+
+
+def test_group_ids_beyond_the_key_field_are_rejected():
+    scs = [_scenario(6500, groups=3)]
+    enc, ts, _ = encode_batch(scs)
+    ts.global_id = None
+    run_emu_multi(ts, 2, kinds=[_abi.EXPANDER_LEAST_NODES], group_id_base=(1 << 20) - 1, expect_rc=_abi.ERR_INVALID)
+    enc.close()
