@@ -97,6 +97,7 @@ struct HipBackend {
         if (!mark_ev) check(hipEventCreateWithFlags(&mark_ev, hipEventDisableTiming), "hipEventCreate");
         if (mark_ev) check(hipEventRecord(mark_ev, stream), "hipEventRecord");
     }
+    bool idle() { const hipError_t e = hipStreamQuery(stream); if (e == hipErrorNotReady) return false; check(e, "hipStreamQuery"); return true; }
     void wait_mark(HipBackend& o) { if (o.mark_ev) check(hipStreamWaitEvent(stream, o.mark_ev, 0), "hipStreamWaitEvent"); }
     size_t lds_budget() const { return lds; }
     bool ok() const { return last == hipSuccess; }

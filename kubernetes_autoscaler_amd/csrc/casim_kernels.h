@@ -512,7 +512,8 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
                 for (int k = 0; k < DW / 4; ++k) out[k] = RecQuad{w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]};
             };
             if (res.rec_dw == 8) emit(IntTag<2>{}); else emit(IntTag<4>{});
-        } else {
+        }
+        if (res.s_count) {   // the generic packer's three arrays (also next to the records when it stands by for retries)
             res.s_count[off + i] = t.count[g];
             res.s_flags[off + i] = flags;
             for (int r = 0; r < t.R; ++r) res.s_req[(int64_t)(off + i) * t.R + r] = t.req[(int64_t)g * t.R + r];

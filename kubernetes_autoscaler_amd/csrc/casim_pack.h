@@ -460,6 +460,10 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     int32_t more_mask = -1;
     int32_t fakes = 0;                     // fastpath fake nodes
     int32_t total_placed = 0;
+    // register store of 16 slots per lane only: the group may ask for more than its 1024 node slots (its BOUND — limiter cap or
+    // pods — exceeds them; most such groups never get there: BenchmarkRunOnceScaleUp is bound by 10 000 and creates 200).  The
+    // step that would create node 1025 stops node creation and marks the group for the generic packer's retry launch.
+    uint32_t overflow = 0;
 
     CASIM_PROF_DECL;
     // ONE loop over the PEGs of the group (a nested chunk / record loop made the compiler keep two copies of the node state,
@@ -787,6 +791,9 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 // the lane that owns node m writes its fresh state + x pods: node first+i gets
                 // min(per, pods_total - i*per) pods
                 auto create_nodes = [&](int32_t first, int32_t nadd, uint32_t per, int32_t pods_total) {
+                    if constexpr (Store::kNPT == 16) {
+                        if (first + nadd > 64 * 16) { overflow = 1u; more_mask = 0; return; }   // (whatever the callers book after this is discarded)
+                    }
                     const int s_lo = first >> 6, s_hi = (first + nadd - 1) >> 6;
                     for_slots<Store>(s_hi + 1, [&](int s) {
                         const int32_t m = s * 64 + lane;
@@ -964,7 +971,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
         res.nodes_added[ng] = M;
         res.limiter_nodes[ng] = granted;
         res.last_index_out[ng] = last_index;
-        res.status[ng] = CASIM_NG_OK;
+        res.status[ng] = overflow ? CASIM_NG_RETRY_INTERNAL : CASIM_NG_OK;
         res.cpu_sum[ng] = sum0 * (sum_scale ? sum_scale[0] : 1);
         res.mem_sum[ng] = sum1 * (sum_scale ? sum_scale[1] : 1);
     }
@@ -990,6 +997,7 @@ CS_DEVICE bool pack_unsupported(const DevTables& t, const DevResults& res) {
 // ---- generic kernel: int64 state in LDS (kLds) or an HBM slab ------------------------------------
 template <bool kLds, int RMAX_>
 CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void pack_kernel(DevTables t, DevResults res, PackScratch ps) {
+    if (ps.retry_only && res.status[cs::bid()] != CASIM_NG_RETRY_INTERNAL) return;   // (standing by behind the register packer)
     if (pack_unsupported<0>(t, res)) return;
     const int ng = cs::bid();
     const int R = t.R, Wx = t.Wx, Wz = t.Wz;

@@ -198,7 +198,11 @@ public:
             int32_t maxcap = 0;
             for (size_t i = 0; i < NG; ++i) maxcap = cap[i] > maxcap ? cap[i] : maxcap;
             bool ok = o ? o->force_generic_packer == 0 : true;
-            ok = ok && dt_.Wx <= 2 && dt_.Wz <= 2 && R <= 4 && maxcap <= 64 * 16 && NG > 0;
+            // groups whose node BOUND exceeds the 1024 register slots still start in the register packer: the bound (limiter cap or
+            // pods) is rarely reached — BenchmarkRunOnceScaleUp: bound 10 000, 200 nodes created — and a group that does run out
+            // is packed again by the generic packer's retry launch (pack_kernel, PackScratch::retry_only)
+            fast_retry_ = maxcap > 64 * 16;
+            ok = ok && dt_.Wx <= 2 && dt_.Wz <= 2 && R <= 4 && NG > 0;
             // (the PEG record carries the pods that fit an empty node in 23 bits: casim_types.h)
             for (size_t i = 0; i < NG && ok; ++i) ok = (int64_t)g->allowed_pods[i] - (int64_t)g->init_pods[i] <= CASIM_REC_FRESH_MAX;
             bool zone_self = false;   // a PEG that excludes itself group-wide (anti-affinity on a non-hostname key)
@@ -231,6 +235,7 @@ public:
                 fast_npt_ = maxcap <= 64 ? 1 : (maxcap <= 256 ? 4 : 16);
                 fast_r_ = R <= 2 ? 2 : 4;
             }
+            if (fast_npt_ == 0) fast_retry_ = false;
         }
         ps_.node_cap = up(cap.data(), NG);
         if (o && o->node_pods) {   // pods per simulated node (estimationAnalyserFunc's newNodesWithPods)
@@ -288,7 +293,8 @@ public:
             dr_.rec_dw = fast_r_ == 2 ? 8 : 16;
             dr_.rec = (uint32_t*)dalloc(4 * ((size_t)nnz_cap_ + 1) * (size_t)dr_.rec_dw);   // + one spare record: the packer loads record k + 1 unconditionally
             dr_.req32 = fs_.req32; dr_.fresh32 = fs_.fresh32;
-        } else {
+        }
+        if (fast_npt_ == 0 || fast_retry_) {
             dr_.s_count = (int32_t*)dalloc(4 * (size_t)nnz_cap_); dr_.s_flags = (uint32_t*)dalloc(4 * (size_t)nnz_cap_);
             dr_.s_req = (int64_t*)dalloc(8 * (size_t)nnz_cap_ * (size_t)R);
         }
@@ -352,8 +358,9 @@ public:
                 for (int i = 0; i < NG_; ++i) for (int j = 0; j < 8; ++j) m[j] += (double)h[(size_t)i * 8 + j] / NG_;
                 fprintf(stderr, "[pack prof] ticks/group: loop %.0f bcast %.0f passA %.0f reduce %.0f passBC %.0f a3 %.0f\n", m[0], m[1], m[2], m[3], m[4], m[5]);
             }
-            return CASIM_OK;
+            if (!fast_retry_) return CASIM_OK;
         }
+        ps_.retry_only = fast_npt_ > 0 ? 1 : 0;
         if (dt_.R <= 2) {
             if (pack_lds_) bk_.launch(pack_kernel<true, 2>, NG_, 1, 64, pack_smem_, dt_, dr_, ps_);
             else bk_.launch(pack_kernel<false, 2>, NG_, 1, 64, (size_t)0, dt_, dr_, ps_);
@@ -594,6 +601,7 @@ private:
     int32_t nnz_cap_ = 0;
     bool csr_on_device_ = false, pack_lds_ = true, order_lds_ = true, ready_ = false, ran_ = false;
     int fast_wx_ = 0;
+    bool fast_retry_ = false;
     size_t pack_smem_ = 0, order_smem_ = 0;
     int order_threads_ = kOrderThreads;
     uint64_t* d_bits_ = nullptr; int32_t* d_counts_ = nullptr; int32_t* d_off_ = nullptr; int32_t* d_idx_ = nullptr; int32_t* d_block_sums_ = nullptr; int32_t* d_off_local_ = nullptr;

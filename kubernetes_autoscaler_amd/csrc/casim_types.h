@@ -98,7 +98,11 @@ struct PackScratch {
     const int32_t* node_cap;   // [NG] node slots reserved for the group (multiple of 64)
     const int64_t* state_off;  // [NG] byte offset into gstate (global variant)
     char* gstate;              // HBM slab (global variant) or null
+    int32_t retry_only;        // 1 = only the groups the register packer gave up on (status CASIM_NG_RETRY_INTERNAL) are packed
 };
+// kernel-internal status (never leaves the library): the register packer ran out of node slots (> 1024 simulated nodes) — the
+// generic packer's retry launch, enqueued right behind it, packs the group
+#define CASIM_NG_RETRY_INTERNAL 0x7f
 
 // Inputs of the register-resident fast packer: every resource lane divided by the gcd of all its
 // values (requests, allocatable, preloaded requests) — exact, and small enough for int32.

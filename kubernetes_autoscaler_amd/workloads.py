@@ -252,6 +252,17 @@ def config_many_pegs(seed_offset: int = 0, n_pegs: int = 5000, cap: int = 200, m
     return Workload(f"MANY{n_pegs}", pegs, [GroupPlan(tmpl, max_nodes=cap)])
 
 
+def config_retry_mix() -> Workload:
+    """Node BOUNDS beyond the register packer's 1024 slots in one launch: a roomy template (tens of nodes) and a tiny one
+    (> 1024 nodes), unlimited and limited — the tiny ones are packed again by the generic packer's retry launch."""
+    pegs = [_peg(f"p{i}", 100 + 10 * (i % 7), 128 * MiB * (1 + i % 3), 40 + 13 * (i % 5)) for i in range(60)]
+    groups = [GroupPlan(NodeInfo(_node("roomy", 64000, 256 * GiB, 110)), max_nodes=0),
+              GroupPlan(NodeInfo(_node("tiny", 300, 1 * GiB, 110)), max_nodes=0),
+              GroupPlan(NodeInfo(_node("tiny-capped", 300, 1 * GiB, 110)), max_nodes=1500),
+              GroupPlan(NodeInfo(_node("roomy-capped", 64000, 256 * GiB, 110)), max_nodes=3000, last_index=2)]
+    return Workload("retry", pegs, groups)
+
+
 CONFIGS = {"C0": config_c0, "C1": config_c1, "C2": config_c2, "C3": config_c3, "C4": config_c4, "R1": config_r1, "R2": config_r2}
 
 

@@ -23,6 +23,7 @@ struct EmuBackend {
     void sync() {}
     void bind() {}
     void mark() {}
+    bool idle() { return true; }
     void wait_mark(EmuBackend&) {}
     std::vector<char> staging[2];
     void* stage(int which, size_t bytes) { if (staging[which & 1].size() < bytes) staging[which & 1].resize(bytes); return staging[which & 1].data(); }

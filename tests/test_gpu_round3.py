@@ -91,3 +91,19 @@ def test_streamed_problem_many_resident_steps_and_validity_mask(ctx):
     assert_matches_oracle(res, want, "streamed fuzz batch")
     assert list(exp["best"]) == list(bexp["best"]) and exp["keys"].tolist() == bexp["keys"].tolist() and list(exp["best_set"]) == list(bexp["best_set"])
     enc.close()
+
+
+def test_register_packer_beyond_its_node_slots_with_generic_retry(ctx):
+    """node bounds > 1024: register packer first, generic retry launch for the groups that really overflow (same launch)"""
+    w = workloads.config_retry_mix()
+    for device_csr in (False, True):
+        sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], device_csr=device_csr)
+        enc = encode(sc)
+        with kaa.Problem(ctx, enc.pegs, enc.groups) as p:
+            assert p.info()["fast_packer_slots_per_lane"] == 16
+            p.run(); res = p.fetch()
+            p.run(); again = p.fetch()            # resident re-run: the retry marks are rewritten every pass
+        oracle = run_oracle(sc)
+        assert oracle[0][0].nodes_added < 1024 < oracle[1][0].nodes_added
+        assert_matches_oracle(res, oracle, f"retry csr={device_csr}")
+        assert_matches_oracle(again, oracle, f"retry again csr={device_csr}")

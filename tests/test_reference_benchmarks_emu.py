@@ -77,3 +77,16 @@ def test_fuzz_thousands_of_pegs_device_csr_two_groups():
 def test_distinct_scores_fails_loudly_when_the_draw_space_is_exhausted():
     with pytest.raises(ValueError, match="distinct scores"):
         workloads.config_c1(n_pegs=30000)
+
+
+def test_register_packer_with_node_bounds_beyond_its_slots_and_the_generic_retry():
+    """Node BOUNDS above the register packer's 1024 slots no longer send a batch to the int64 packer: the groups start in the
+    register packer, and only those that really create a 1025th node are packed again by the generic packer's retry launch.
+    One launch with both kinds: a roomy template (tens of nodes) and a tiny one (> 1024 nodes), unlimited and limited."""
+    w = workloads.config_retry_mix()
+    for device_csr in (False, True):
+        sc = scenario_of(w, device_csr)
+        oracle = run_oracle(sc)
+        assert oracle[0][0].nodes_added < 1024 < oracle[1][0].nodes_added and oracle[2][0].nodes_added == 1500
+        res, _ = run_emu(encode(sc))
+        assert_matches_oracle(res, oracle, f"retry csr={device_csr}")

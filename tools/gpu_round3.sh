@@ -13,7 +13,7 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 S="$OUT/summary.txt"
 echo "== device ==" | tee "$S"
 (rocminfo | grep -E "Marketing Name|gfx9" | head -4; nproc; free -g | head -2) 2>&1 | tee -a "$S"
-has() { case "$MODE" in $1) return 0;; esac; return 1; }
+has() { [[ "|$1|" == *"|$MODE|"* ]]; }
 
 if has "tests|quick|full"; then
   echo "== pytest -m gpu ==" | tee -a "$S"
