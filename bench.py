@@ -775,7 +775,19 @@ def next_rows(kaa, ctx, workloads):
     e2.close()
     out["node_removals"] = {"workload": w2.name, "nodes": len(w2.nodes), "candidates": len(w2.candidates),
                             "removable": int((r2.removable == 1).sum()), "kernels_ms": ms2, "candidates_per_s": len(w2.candidates) / (ms2 * 1e-3)}
+    out["group_pods"] = group_pods_row()
     return out
+
+
+def group_pods_row():
+    """SURVEY 8 f2, first half: equivalence.BuildPodGroups behind the C ABI (casim_enc_group_pods) at 150 000 pending pods, host only,
+    through tools/casim_group_bench (plain C++ over include/casim.h)."""
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "casim_group_bench")
+    if not os.path.exists(exe):
+        return {"error": "tools/casim_group_bench not built"}
+    r = subprocess.run([exe, "150000", "1500", "3", "5"], capture_output=True, text=True, timeout=300)
+    rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    return {"reference": "CA/core/scaleup/equivalence/groups.go:39-104", "rows": rows} if rows else {"error": r.stderr[-300:]}
 
 
 if __name__ == "__main__":

@@ -731,6 +731,24 @@ int32_t casim_enc_add_peg(casim_encoder* e, int32_t pod_spec, int32_t count);
 int32_t casim_enc_add_resource_pegs(casim_encoder* e, const char* namespace_, int32_t n, const int64_t* req,
                                     const int32_t* count, int32_t* ids_out);
 
+/* f2 — pod equivalence groups: equivalence.BuildPodGroups / groupPodsBySchedulingProperties / match
+ * (CA/core/scaleup/equivalence/groups.go:39-104) over n_pods pending pods IN LIST ORDER.  pod_spec[i] = the spec record of pod i
+ * (pods the shim knows to be identical may share one record; different records are compared by content: namespace, requests,
+ * labels (reflect.DeepEqual on the label map), every scheduling field registered through casim_enc_pod_*, and the `extra` digest
+ * the shim sets with casim_enc_pod_set_spec_extra for the sanitized PodSpec fields the encoder does not model — what
+ * utils.PodSpecSemanticallyEqual compares, CA/utils/utils.go:63-119).  controller_uid[i] = drain.ControllerRef(pod).UID, NULL or ""
+ * when the pod has no controller; daemonset[i] != 0 for pod_utils.IsDaemonSetPod (NULL = none).  Both kinds are singletons; a
+ * controller keeps at most 10 joinable groups, a further distinct spec opens a group nobody can join (groups.go:58,81-90).
+ * group_out[i] = group id in creation order (the reference's ids are map keys: "Group ID is meaningless"); *n_groups_out = count.
+ * Callable before or after finalize. */
+int32_t casim_enc_pod_set_spec_extra(casim_encoder* e, int32_t pod, const char* digest);
+int32_t casim_enc_group_pods(casim_encoder* e, int32_t n_pods, const int32_t* pod_spec, const char* const* controller_uid,
+                             const uint8_t* daemonset, int32_t* group_out, int32_t* n_groups_out);
+/* One PEG per group of casim_enc_group_pods, in group order: exemplar = the group's first pod (PodEquivalenceGroup.Exemplar,
+ * CA/estimator/estimator.go:42-51), count = its size.  peg_ids_out (may be NULL) [n_groups].  Returns the first PEG id or <0. */
+int32_t casim_enc_add_grouped_pegs(casim_encoder* e, int32_t n_pods, const int32_t* pod_spec, const int32_t* group, int32_t n_groups,
+                                   int32_t* peg_ids_out);
+
 /* Pods already running in the cluster that may interact with anti-affinity on non-hostname
  * topology keys: (pod spec, label set of the node it runs on given as a group-like label
  * list).  v0 accepts them only to detect interactions; see DESIGN.md. */

@@ -210,6 +210,9 @@ PROTOTYPES = {
     "casim_enc_pod_mark_unsupported": (C.c_int32, [C.c_void_p, C.c_int32, cstr]),
     "casim_enc_add_peg": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
     "casim_enc_add_resource_pegs": (C.c_int32, [C.c_void_p, cstr, C.c_int32, i64p, i32p, i32p]),
+    "casim_enc_pod_set_spec_extra": (C.c_int32, [C.c_void_p, C.c_int32, cstr]),
+    "casim_enc_group_pods": (C.c_int32, [C.c_void_p, C.c_int32, i32p, cstrp, u8p, i32p, i32p]),
+    "casim_enc_add_grouped_pegs": (C.c_int32, [C.c_void_p, C.c_int32, i32p, i32p, C.c_int32, i32p]),
     "casim_enc_add_existing_pod": (C.c_int32, [C.c_void_p, C.c_int32, cstrp, cstrp, C.c_int32]),
     "casim_enc_finalize": (C.c_int32, [C.c_void_p]),
     "casim_enc_tables": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups)]),

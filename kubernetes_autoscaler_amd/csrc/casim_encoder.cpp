@@ -13,10 +13,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <deque>
 #include <map>
 #include <set>
 #include <string>
+#include <string_view>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -82,6 +85,7 @@ struct PodSpec {
     double fp_cpu = 0, fp_mem = 0;
     bool unsupported = false;
     std::string why;
+    std::string extra;            // casim_enc_pod_set_spec_extra: digest of the sanitized PodSpec fields the encoder does not model (grouping only)
 };
 struct Group {
     std::string name;
@@ -1028,6 +1032,127 @@ int32_t casim_enc_dict_sizes(const casim_encoder* e, int32_t sizes_out[4]) {
     if (!e || !e->finalized || !sizes_out) return CASIM_ERR_INVALID;
     for (int i = 0; i < 4; ++i) sizes_out[i] = e->dict[i];
     return CASIM_OK;
+}
+
+}  // extern "C"
+
+// ---- f2: pod equivalence groups -------------------------------------------------------------------------------------------------
+// BuildPodGroups / groupPodsBySchedulingProperties / match  (CA/core/scaleup/equivalence/groups.go:39-104).  match() compares a pod
+// with the representant of each of its controller's groups: reflect.DeepEqual(labels) && PodSpecSemanticallyEqual(spec)
+// (CA/utils/utils.go:63-119: projected volumes, hostname and env dropped, apiequality.Semantic: quantities by value, nil == empty).
+// Here a spec is everything the shim told the encoder about it plus `extra`; two specs match when their canonical byte strings are
+// equal.  The string is built once per distinct spec id and interned, so match() is one integer compare.
+namespace {
+void put(std::string& o, const std::string& s) { uint32_t n = (uint32_t)s.size(); o.append((const char*)&n, 4); o.append(s); }
+void put_i(std::string& o, int64_t v) { o.append((const char*)&v, 8); }
+void put_reqs(std::string& o, const std::vector<Requirement>& rs);
+void put_node_terms(std::string& o, const std::vector<NodeTerm>& ts) {
+    put_i(o, (int64_t)ts.size());
+    for (auto& t : ts) { put_reqs(o, t.exprs); put_reqs(o, t.fields); }
+}
+void put_reqs(std::string& o, const std::vector<Requirement>& rs) {
+    put_i(o, (int64_t)rs.size());
+    for (auto& r : rs) {
+        put(o, r.key); put_i(o, r.op); put_i(o, (int64_t)r.values.size());
+        for (auto& v : r.values) put(o, v);
+        put_node_terms(o, r.terms);
+    }
+}
+void put_terms(std::string& o, const std::vector<Term>& ts) {
+    put_i(o, (int64_t)ts.size());
+    for (auto& t : ts) {
+        put(o, t.topology_key); put_i(o, (int64_t)t.namespaces.size());
+        for (auto& n : t.namespaces) put(o, n);
+        put_reqs(o, t.selector); put_i(o, t.has_ns_sel); put_reqs(o, t.ns_sel);
+    }
+}
+std::string canonical_spec(const PodSpec& p, int R) {
+    std::string o;
+    o.reserve(256);
+    put(o, p.ns);
+    for (int r = 0; r < R; ++r) put_i(o, p.req[r]);
+    put_i(o, (int64_t)p.labels.v.size());
+    for (auto& kv : p.labels.v) { put(o, kv.first); put(o, kv.second); }     // (sorted by key: a Go map has no order)
+    put_i(o, (int64_t)p.tolerations.size());
+    for (auto& t : p.tolerations) { put(o, t.key); put_i(o, t.op); put(o, t.value); put(o, t.effect); }
+    std::vector<std::pair<std::string, std::string>> ns = p.node_selector;   // map[string]string
+    std::sort(ns.begin(), ns.end());
+    put_i(o, (int64_t)ns.size());
+    for (auto& kv : ns) { put(o, kv.first); put(o, kv.second); }
+    put_reqs(o, p.node_affinity); put_i(o, p.has_node_terms); put_node_terms(o, p.node_terms);
+    put_i(o, (int64_t)p.ports.size());
+    for (auto& h : p.ports) { put(o, h.ip); put(o, h.proto); put_i(o, h.port); }
+    put_terms(o, p.anti); put_terms(o, p.aff);
+    put_i(o, (int64_t)p.spread.size());
+    for (auto& c : p.spread) { put_i(o, c.max_skew); put(o, c.key); put_i(o, c.min_domains); put_reqs(o, c.selector); put_i(o, c.taints_honor); put_i(o, c.affinity_honor); }
+    put_i(o, p.unsupported); put(o, p.why); put(o, p.extra);
+    int64_t f[2]; memcpy(f, &p.fp_cpu, 8); memcpy(f + 1, &p.fp_mem, 8); put_i(o, f[0]); put_i(o, f[1]);
+    return o;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t casim_enc_pod_set_spec_extra(casim_encoder* e, int32_t pod, const char* digest) {
+    POD_CHECK(e, pod); e->specs[pod].extra = S(digest); return CASIM_OK;
+}
+
+int32_t casim_enc_group_pods(casim_encoder* e, int32_t n_pods, const int32_t* pod_spec, const char* const* controller_uid,
+                             const uint8_t* daemonset, int32_t* group_out, int32_t* n_groups_out) {
+    if (!e || n_pods < 0 || (n_pods > 0 && (!pod_spec || !group_out))) return CASIM_ERR_INVALID;
+    const size_t NS = e->specs.size();
+    for (int32_t i = 0; i < n_pods; ++i) if (pod_spec[i] < 0 || (size_t)pod_spec[i] >= NS) return CASIM_ERR_INVALID;
+    // canonical id of a spec, built the first time a controller has to compare it
+    std::vector<int32_t> canon(NS, -1);
+    std::unordered_map<std::string, int32_t> interned;
+    auto canon_of = [&](int32_t s) {
+        if (canon[s] < 0) canon[s] = interned.emplace(canonical_spec(e->specs[s], e->opt.n_res), (int32_t)interned.size()).first->second;
+        return canon[s];
+    };
+    struct Eg { int32_t id, spec, canon; };                 // equivalenceGroup{id, representant}
+    struct Ctl { int32_t n = 0; Eg eg[10]; };               // maxEquivalenceGroupsByController (groups.go:58)
+    std::unordered_map<std::string_view, Ctl> by_controller;
+    by_controller.reserve(1024);
+    int32_t next = 0;
+    for (int32_t i = 0; i < n_pods; ++i) {
+        const char* uid = controller_uid ? controller_uid[i] : nullptr;
+        if (!uid || !uid[0] || (daemonset && daemonset[i])) { group_out[i] = next++; continue; }   // groups.go:69-74
+        Ctl& c = by_controller[std::string_view(uid)];
+        const int32_t s = pod_spec[i];
+        int32_t hit = -1;
+        for (int32_t k = 0; k < c.n && hit < 0; ++k) if (c.eg[k].spec == s) hit = c.eg[k].id;       // same spec record: equal by construction
+        if (hit < 0 && c.n > 0) {
+            const int32_t cs = canon_of(s);
+            for (int32_t k = 0; k < c.n && hit < 0; ++k) {
+                if (c.eg[k].canon < 0) c.eg[k].canon = canon_of(c.eg[k].spec);
+                if (c.eg[k].canon == cs) hit = c.eg[k].id;
+            }
+        }
+        if (hit >= 0) { group_out[i] = hit; continue; }
+        if (c.n < 10) c.eg[c.n++] = Eg{next, s, canon[s]};   // beyond 10 the pod still opens a group, nobody can join it (groups.go:81-90)
+        group_out[i] = next++;
+    }
+    if (n_groups_out) *n_groups_out = next;
+    return CASIM_OK;
+}
+
+int32_t casim_enc_add_grouped_pegs(casim_encoder* e, int32_t n_pods, const int32_t* pod_spec, const int32_t* group, int32_t n_groups,
+                                   int32_t* peg_ids_out) {
+    ENC_CHECK(e);
+    if (n_pods < 0 || n_groups < 0 || (n_pods > 0 && (!pod_spec || !group))) return CASIM_ERR_INVALID;
+    std::vector<int32_t> first(n_groups, -1), count(n_groups, 0);
+    for (int32_t i = 0; i < n_pods; ++i) {
+        if (group[i] < 0 || group[i] >= n_groups || pod_spec[i] < 0 || (size_t)pod_spec[i] >= e->specs.size()) return CASIM_ERR_INVALID;
+        if (first[group[i]] < 0) first[group[i]] = pod_spec[i];   // the exemplar: Pods[0] (PodEquivalenceGroup.Exemplar)
+        ++count[group[i]];
+    }
+    const int32_t base = (int32_t)e->pegs.size();
+    for (int32_t g = 0; g < n_groups; ++g) {
+        if (first[g] < 0) return CASIM_ERR_INVALID;
+        e->pegs.push_back(Peg{first[g], count[g]});
+        if (peg_ids_out) peg_ids_out[g] = base + g;
+    }
+    return base;
 }
 
 }  // extern "C"

@@ -133,6 +133,10 @@ class Encoder:
             check(lib.casim_enc_pod_mark_unsupported(h, s, _b(pod.unsupported_reason)))
         if unknown:
             check(lib.casim_enc_pod_mark_unsupported(h, s, _b("resource not in lanes: " + ",".join(unknown))))
+        # grouping only: the fields PodSpecSemanticallyEqual compares that the encoder has no call for
+        extra = repr((pod.spec_extra, pod.has_containers, pod.topology_spread, tuple(tuple(c.match_label_keys) for c in pod.spread_constraints),
+                      tuple(tuple(sorted(c.match_labels.items())) for c in pod.spread_constraints)))
+        check(lib.casim_enc_pod_set_spec_extra(h, s, _b(extra)))
         self._spec_of[key] = s
         return s
 
@@ -147,6 +151,44 @@ class Encoder:
             check(g, "casim_enc_add_peg")
         self.n_pegs += 1
         return g
+
+    def group_pods(self, pods: Sequence[Pod], share_specs: bool = False):
+        """equivalence.BuildPodGroups behind the C ABI (casim_enc_group_pods, CA/core/scaleup/equivalence/groups.go:39-104):
+        returns (group id per pod, number of groups).  Every pod OBJECT gets a spec record of its own unless share_specs (then pods
+        with equal Pod.spec_key() share one, the way a shim that interns specs would call it): the native side compares content."""
+        import numpy as np
+        n = len(pods)
+        if share_specs:
+            seen: Dict[object, int] = {}
+            spec = np.empty(n, np.int32)
+            for i, p in enumerate(pods):
+                k = p.spec_key()
+                if k not in seen:
+                    seen[k] = self.add_pod_spec(p)
+                spec[i] = seen[k]
+        else:
+            spec = np.array([self.add_pod_spec(p) for p in pods], np.int32)
+        uids = (C.c_char_p * max(n, 1))(*[_b(p.controller_uid) if p.controller_uid else None for p in pods])
+        ds = np.array([1 if p.daemonset else 0 for p in pods], np.uint8)
+        out = np.empty(n, np.int32)
+        ng = C.c_int32(0)
+        check(lib.casim_enc_group_pods(self._h, n, spec.ctypes.data_as(_abi.i32p), uids, ds.ctypes.data_as(_abi.u8p),
+                                       out.ctypes.data_as(_abi.i32p), C.byref(ng)), "casim_enc_group_pods")
+        self._last_group_specs = spec
+        return out, int(ng.value)
+
+    def add_grouped_pegs(self, pods: Sequence[Pod], group, n_groups: int):
+        """One PEG per equivalence group (exemplar = first pod, count = size): casim_enc_add_grouped_pegs."""
+        import numpy as np
+        spec = np.array([self.add_pod_spec(p) for p in pods], np.int32)
+        group = np.ascontiguousarray(group, np.int32)
+        ids = np.empty(n_groups, np.int32)
+        first = lib.casim_enc_add_grouped_pegs(self._h, len(pods), spec.ctypes.data_as(_abi.i32p), group.ctypes.data_as(_abi.i32p), n_groups,
+                                               ids.ctypes.data_as(_abi.i32p))
+        if first < 0:
+            check(first, "casim_enc_add_grouped_pegs")
+        self.n_pegs += n_groups
+        return ids
 
     def add_resource_pegs(self, requests, counts, namespace: str = "default"):
         """Bulk form (casim_enc_add_resource_pegs): `requests` is an [n][R] integer array of lanes,

@@ -3,8 +3,8 @@
     BuildPodGroups / groupPodsBySchedulingProperties   CA/core/scaleup/equivalence/groups.go:39-104
     SchedulablePodGroups (the PEG x node-group matrix)   CA/core/scaleup/orchestrator/orchestrator.go:535-570
 
-Grouping is string hashing and stays on the host (the Go shim keeps calling BuildPodGroups); what moves to the
-device is the matrix: every group's exemplar against every node-group template in ONE call
+Grouping is string hashing and stays on the host: `casim_enc_group_pods` in libcasim's encoder (group_pods_native); the
+Python restatement below is the checker for it.  What moves to the device is the matrix: every group's exemplar against every node-group template in ONE call
 (`Context.feasibility` -> feas_kernel), instead of G x NG CheckPredicates runs."""
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
@@ -49,9 +49,22 @@ def group_pods_by_scheduling_properties(pods: Sequence[Pod]) -> List[List[Pod]]:
     return groups
 
 
-def build_pod_groups(pods: Sequence[Pod]) -> List[PodGroup]:
-    """BuildPodGroups (groups.go:39-49)."""
-    return [PodGroup(pods=g) for g in group_pods_by_scheduling_properties(pods)]
+def group_pods_native(pods: Sequence[Pod], share_specs: bool = False) -> List[List[Pod]]:
+    """The same grouping through libcasim (casim_enc_group_pods): what a shim calls instead of BuildPodGroups."""
+    enc = Encoder()
+    try:
+        gid, n = enc.group_pods(pods, share_specs=share_specs)
+    finally:
+        enc.close()
+    groups: List[List[Pod]] = [[] for _ in range(n)]
+    for p, g in zip(pods, gid):
+        groups[int(g)].append(p)
+    return groups
+
+
+def build_pod_groups(pods: Sequence[Pod], native: bool = True) -> List[PodGroup]:
+    """BuildPodGroups (groups.go:39-49); native = through the C ABI (the product path), else the Python restatement above (test scaffolding)."""
+    return [PodGroup(pods=g) for g in (group_pods_native(pods) if native else group_pods_by_scheduling_properties(pods))]
 
 
 @dataclass
