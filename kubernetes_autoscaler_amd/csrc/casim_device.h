@@ -48,6 +48,7 @@ template <int N> CS_DEVICE Words<N> const_load(const uint32_t* p) { Words<N> r; 
 CS_DEVICE bool lane_pred(uint64_t mask) { return ((mask >> (casim_emu::cur().tid & 63)) & 1ull) != 0; }
 CS_DEVICE void keep_scalar(uint32_t&) {}
 CS_DEVICE int32_t opaque_i32(int32_t v) { return v; }
+CS_DEVICE void consume_u32(uint32_t) {}
 CS_DEVICE bool flag_set(uint32_t word, uint32_t bit) { return (word & bit) != 0; }
 CS_DEVICE uint32_t uniform_div_u32(uint32_t a, uint32_t b) { return a / b; }
 CS_DEVICE uint32_t scalar_min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
@@ -158,6 +159,8 @@ CS_DEVICE bool lane_pred(uint64_t mask) { return __builtin_amdgcn_inverse_ballot
 CS_DEVICE void keep_scalar(uint32_t& v) { v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v); asm volatile("" : "+s"(v)); }
 // a copy of a lane value the optimiser cannot see through (no instruction): keeps it from merging two computations
 CS_DEVICE int32_t opaque_i32(int32_t v) { asm volatile("" : "+v"(v)); return v; }
+// a use of a lane value that emits nothing: keeps a load alive (and its destination register reserved) until here
+CS_DEVICE void consume_u32(uint32_t v) { asm volatile("" : : "v"(v)); }
 // test of one bit of a wave-UNIFORM word, meant to sit directly in an `if`: the word goes through an opaque scalar copy so
 // that every test is its own s_bitcmp + s_cbranch_scc.  A flag tested in several places as one bool is kept by the
 // compiler as a 64-bit lane mask (s_cselect_b64, then s_and_b64 with exec + s_cbranch_vcc at every use).

@@ -289,11 +289,14 @@ struct RegStore {
     // merge point of the PEG loop with the rest of the state.
     // `act`: bit s set when some node of slot s takes a pod — the later passes skip the other slots (measured on C1:
     // 0.6 of the 4 slots per PEG).
-    CS_DEVICE int32_t capacity_all(const Peg& pv, uint32_t clampk, uint32_t pf, uint32_t* c, uint32_t& act) const {
+    // S = slots in use ((M + 63) >> 6): the 16-slot store skips the empty ones with one scalar compare each (a group whose BOUND is
+    // 1024 nodes usually creates far fewer: BenchmarkRunOnceScaleUp 200) — stores of <= 4 slots walk them all (constant bound).
+    CS_DEVICE int32_t capacity_all(const Peg& pv, uint32_t clampk, uint32_t pf, uint32_t* c, uint32_t& act, int S) const {
         act = 0;
         int32_t n1 = 0;
 #pragma unroll
         for (int s = 0; s < NPT_; ++s) {
+            if (NPT_ > 4 && s >= S) { c[s] = 0; continue; }   // wave-uniform
             const uint64_t fb = fit_mask(s, pv, pf);
             uint32_t k = 0;
             if (fb) {  // wave-uniform
@@ -479,6 +482,18 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     const uint32_t* rp = nullptr;            // record of the current PEG
     cs::Words<(DW > 0 ? DW : 1)> cur;
     cur.w[0] = 0;
+    // Register store: one dword of every record of the NEXT chunk is touched by a vector load at each chunk boundary (64 lanes x
+    // record stride = the chunk's 2 / 4 KB, 16 / 32 cache lines in flight together) and consumed a chunk later, i.e. never waited
+    // for: the scalar loads of the PEG steps then find their lines in this XCD's L2 instead of paying the memory latency line by
+    // line — a lone wave (one Estimate per call, BenchmarkRunOnceScaleUp's 10 000 dependent steps) is bound by exactly that latency.
+    uint32_t rec_touch = 0;
+    auto touch_chunk = [&](int kbase) {
+        if constexpr (kRecScalar) {
+            cs::consume_u32(rec_touch);
+            const int kk = kbase + lane;
+            rec_touch = kk < Gn ? recp[(int64_t)kk * DW] : 0u;
+        }
+    };
     int32_t g_cur = 0;                       // the PEG's index into the mask tables (stores with exclusion state only)
     constexpr bool kNeedG = Store::kHasExcl || Store::kHasZone;
     // a2 is worth entering when the record says so (CASIM_REC_A2_OK) AND the group has simulated nodes AND its template is
@@ -487,6 +502,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     uint32_t a2_gate = 0;
     if constexpr (kRecScalar) {
         recp = res.rec + (int64_t)off * DW; rp = recp;
+        touch_chunk(0);
         // (the record array ends with one spare record: the load of record k + 1 needs no bound)
         cur = cs::const_load<DW>(rp);
         if (kNeedG) g_cur = (int32_t)cs::const_load<1>((const uint32_t*)res.order + off).w[0];
@@ -521,6 +537,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             CASIM_PROF(0);  // chunk load / store, loop overhead
             if (k > 0) flush_chunk(k - 64);
             my_placed = 0;
+            touch_chunk(k + 64);
             if constexpr (!kRecScalar) {
                 // ---- one coalesced wave-load: PEG record k+lane of this group, in processing order ----
                 const int kk = k + lane;
@@ -753,7 +770,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         a2_rest(cs::popc64(fb));
                     }
                 } else if constexpr (Store::kNPT > 0) {
-                    n1 = st.capacity_all(pv, keff, pf, creg, act);  // every slot (nodes >= M are all-zero)
+                    n1 = st.capacity_all(pv, keff, pf, creg, act, S);  // (<= 4 slots: every slot, nodes >= M are all-zero)
                     if (n1 > 0) a2_rest(n1);
                 } else {
                     for_slots<Store>(S, [&](int s) {
@@ -923,7 +940,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             // chunk, so that the steps themselves carry no chunk test
             if (a2_gate != 0) {
                 while (k < Gn) {
-                    if ((k & 63) == 0) { if (k > 0) flush_chunk(k - 64); my_placed = 0; }
+                    if ((k & 63) == 0) { if (k > 0) flush_chunk(k - 64); my_placed = 0; touch_chunk(k + 64); }
                     const int kend = (k | 63) + 1 < Gn ? (k | 63) + 1 : Gn;
                     for (; k < kend; ++k) peg_step(k, CsTrue{});
                 }
@@ -945,6 +962,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
         cs::keep_scalar(a); cs::keep_scalar(b); cs::keep_scalar(c); cs::keep_scalar(d); cs::keep_scalar(e);
         M = (int32_t)a; granted = (int32_t)b; last_index = (int32_t)c; total_placed = (int32_t)d; fakes = (int32_t)e;
     }
+    if constexpr (kRecScalar) cs::consume_u32(rec_touch);
     if (Gn > 0) flush_chunk((Gn - 1) & ~63);   // the last (possibly partial) chunk
     int64_t sum0, sum1;
     if constexpr (kRecScalar) { sum0 = (int64_t)cs::bcast_u64((uint64_t)acc0, 0); sum1 = (int64_t)cs::bcast_u64((uint64_t)acc1, 0); }   // (every lane holds the total)
