@@ -623,7 +623,7 @@ def main():
                                       f"tables resident in HBM; step = feasibility + CSR + order + pack + expander reduce per simulation, "
                                       f"the batch as {K} sub-batches on {K} HIP streams",
                           "batch_per_gpu": B, "distinct_seeds": S, "checks_per_simulation": checks_per_sim,
-                          "streams": K, "streams_where": "inside libcasim (casim_options.n_streams): ONE casim_ctx, one casim_problem",
+                          "streams": K, "forks_from_the_context_stream": info.get("forks"), "streams_parked_by_the_lane_probe": info.get("parked_streams"), "streams_where": "inside libcasim (casim_options.n_streams): ONE casim_ctx, one casim_problem",
                           "simulations_per_stream": [(n_sims * (i + 1)) // K - (n_sims * i) // K for i in range(K)],
                           "node_groups_per_rank": mine.n_groups, "schedulable_peg_group_pairs_per_rank": my_nnz,
                           "expander": args.expander,

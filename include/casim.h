@@ -244,7 +244,9 @@ int32_t casim_problem_csr(casim_problem* p, int32_t* nnz_out, int32_t* offsets_o
 /* How the resident batch will be executed (for reports): info_out[0] = node slots per lane of the
  * register-resident int32 packer (0 = generic int64 packer), [1] = its lane count, [2] = 1 if the
  * generic packer keeps node state in LDS (0 = HBM slab), [3] = 1 if the schedulable subsets are
- * derived on the device, [4] = parts the batch runs as on internal streams (1 = not cut), [5..7] reserved (0). */
+ * derived on the device, [4] = parts the batch runs as on internal streams (1 = not cut), [5] = how many runs so far had to fork
+ * from the context's stream (it held pending work: see casim_options.n_streams), [6] = streams the context parked because
+ * they shared a hardware queue with a lane it already had (the runtime maps streams onto GPU_MAX_HW_QUEUES queues), [7] reserved (0). */
 struct casim_cluster_estimate_result;
 int32_t casim_problem_info(casim_problem* p, int32_t info_out[8]);
 /* Replace the result of group `ng` of a batch that already ran (status becomes CASIM_NG_OK): how a group that the batch

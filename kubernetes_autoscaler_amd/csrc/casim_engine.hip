@@ -124,21 +124,68 @@ typedef casim::StreamedProblemT<HipBackend> HipStreamed;
 
 }  // namespace
 
+// The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and reads the variable once, at its
+// first API call.  A streamed batch (casim_options.n_streams) wants a queue per lane next to the caller's own streams: unless the
+// process has set the variable, libcasim asks for 8 when it is loaded.  No effect when the runtime is already initialised — the
+// lane probe of casim_ctx::get_lanes then makes the best of the queues there are ("streams and hardware queues").
+__attribute__((constructor)) static void casim_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
+namespace casim {
+// one wave that spins for `ticks` of the constant-rate wall clock (100 MHz): the lane-concurrency probe of casim_ctx::get_lanes
+__global__ __launch_bounds__(64) void lane_probe_kernel(uint64_t ticks) {
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+}  // namespace casim
+
 struct casim_ctx {
     HipBackend bk;
     // lanes: backends on the SAME device with a stream, a memory pool and pinned staging buffers of their own — the parts of a
     // streamed batch (casim_options.n_streams) run on them; created on first use, kept for the life of the context
     std::vector<HipBackend*> lanes;
+    // Streams are not hardware queues: the HIP runtime multiplexes them onto a few HSA queues (GPU_MAX_HW_QUEUES, 4 by default), and two
+    // streams that share one run back to back.  Measured on the MI355X (profiles/r04e_stream_queue_probe.txt): four lanes created in
+    // a row gave the resident loop NOTHING (1.21 ms per 4096 C2 simulations, the one-stream figure), three gave 1.07, four on
+    // distinct queues 1.05.  So every candidate lane proves that it runs CONCURRENTLY with the lanes already taken — a spin kernel of
+    // ~150 us on each of them at once must take the time of one — and a stream that does not is parked (kept until the context goes:
+    // destroying it would hand the same queue to the next candidate).  CASIM_LANE_PROBE=0 takes the streams as they come.
+    std::vector<hipStream_t> parked;
+    bool lanes_capped = false;       // the runtime has no further queue to offer: later calls stop asking
+    double spin_solo_ms = 0;
+    uint64_t spin_ticks = 15000;     // of the 100 MHz wall clock
+    double spin_ms(const std::vector<hipStream_t>& on) {
+        for (hipStream_t st : on) (void)hipStreamSynchronize(st);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (hipStream_t st : on) hipLaunchKernelGGL(casim::lane_probe_kernel, dim3(1), dim3(64), 0, st, spin_ticks);
+        for (hipStream_t st : on) (void)hipStreamSynchronize(st);
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    bool runs_beside_the_lanes(hipStream_t cand) {
+        static const bool probe = !(getenv("CASIM_LANE_PROBE") && atoi(getenv("CASIM_LANE_PROBE")) == 0);
+        if (!probe || lanes.empty()) return true;
+        if (spin_solo_ms == 0) { (void)spin_ms({cand}); const double a = spin_ms({cand}), b = spin_ms({cand}); spin_solo_ms = a < b ? a : b; }
+        std::vector<hipStream_t> all;
+        for (HipBackend* l : lanes) all.push_back(l->stream);
+        all.push_back(cand);
+        const double a = spin_ms(all), b = spin_ms(all);
+        return (a < b ? a : b) < 1.6 * spin_solo_ms;
+    }
     std::vector<HipBackend*> get_lanes(int k) {
-        while ((int)lanes.size() < k) {
+        bk.bind();
+        int tries = 0;
+        while ((int)lanes.size() < k && !lanes_capped) {
             HipBackend* l = new (std::nothrow) HipBackend();
             if (!l) break;
             l->device = bk.device; l->lds = bk.lds; l->own_stream = true;
             l->bind();
             l->check(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking), "hipStreamCreate");
             if (!l->ok()) { delete l; break; }
-            lanes.push_back(l);
+            if (runs_beside_the_lanes(l->stream)) { lanes.push_back(l); continue; }
+            parked.push_back(l->stream);
+            delete l;
+            if (++tries >= 12) lanes_capped = true;
         }
+        (void)hipGetLastError();
         return std::vector<HipBackend*>(lanes.begin(), lanes.begin() + ((int)lanes.size() < k ? (int)lanes.size() : k));
     }
 };
@@ -280,6 +327,8 @@ void casim_ctx_destroy(casim_ctx* ctx) {
         delete l;
     }
     ctx->lanes.clear();
+    for (hipStream_t st : ctx->parked) (void)hipStreamDestroy(st);
+    ctx->parked.clear();
     ctx->bk.release_pool();
     if (ctx->bk.own_stream && ctx->bk.stream) (void)hipStreamDestroy(ctx->bk.stream);
     delete ctx;
@@ -354,6 +403,8 @@ int32_t casim_problem_info(casim_problem* p, int32_t info_out[8]) {
     info_out[0] = p->prob->fast_npt(); info_out[1] = p->prob->fast_lanes();
     info_out[2] = p->prob->pack_in_lds() ? 1 : 0; info_out[3] = p->prob->csr_on_device() ? 1 : 0;
     info_out[4] = p->sp ? (int32_t)p->sp->n_parts() : 1;
+    info_out[5] = p->sp ? (int32_t)(p->sp->forks() & 0x7fffffff) : 0;   // forks from the context's stream so far (diagnostic)
+    info_out[6] = p->ctx ? (int32_t)p->ctx->parked.size() : 0;
     return CASIM_OK;
 }
 int32_t casim_problem_set_group_result(casim_problem* p, int32_t ng, const casim_cluster_estimate_result* r) {

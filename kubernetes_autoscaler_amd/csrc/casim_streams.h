@@ -82,7 +82,9 @@ public:
         // fork — unless the context's stream holds nothing (a stream query, no device work): an event wait in front of every
         // step cost the resident loop 15 % (1.22 vs 1.06 ms per 4096 C2 simulations, profiles/r03a_*)
         primary_.bind();
-        const bool need_fork = !primary_.idle();
+        static const int fork_mode = getenv("CASIM_FORK_MODE") ? atoi(getenv("CASIM_FORK_MODE")) : 1;   // (experiments: 0 never, 1 when busy, 2 always)
+        const bool need_fork = fork_mode == 2 || (fork_mode == 1 && !primary_.idle());
+        n_forks_ += need_fork ? 1 : 0;
         if (need_fork) primary_.mark();
         for (size_t i = 0; i < parts_.size(); ++i) {
             if (need_fork) lanes_[i]->wait_mark(primary_);
@@ -204,6 +206,7 @@ public:
     BK& lane(size_t i) { return *lanes_[i]; }
     int groups() const { return n_groups_; }
     int sims() const { return n_sims_; }
+    int64_t forks() const { return n_forks_; }
     const std::string& error() const { return err_; }
 
 private:
@@ -257,6 +260,7 @@ private:
     casim_options opts_;
     int n_groups_ = 0, n_sims_ = 0;
     bool has_gid_ = false, ready_ = false, ran_ = false;
+    int64_t n_forks_ = 0;
     std::string err_;
 };
 
