@@ -545,6 +545,11 @@ int32_t casim_time_node_removals(casim_ctx* ctx, const casim_pegs* classes, cons
  *   casim_cluster_simulate_node_removals           runs on the committed image and never persists (the planner's own Fork / Revert);
  *   casim_cluster_update_nodes                     replaces the records of single nodes between calls (a delta: only those rows travel).
  * Same results as the non-resident entry points on the equivalent tables; status conventions as there.
+ * Domain rules (casim_pod_sequence.rules, casim_removal_candidates.rules) after a commit: the caller keeps passing the rules its
+ * encoder built from the snapshot BEFORE the commits; the cluster adds the pods it committed since (class, node remembered per
+ * pod) to count_init / node_contrib itself, with the kernels' increment rule, so that spread / zone anti-affinity / pod-affinity
+ * counters see them the way the reference's one ClusterSnapshot does.  casim_cluster_update_nodes makes it forget the pods it
+ * committed to the replaced nodes: their new records, and counters derived with them, describe those nodes from then on.
  * casim_cluster_stats: out[0] full uploads (1), [1] node rows replaced by deltas, [2] commits, [3] nodes.
  */
 typedef struct casim_cluster casim_cluster;

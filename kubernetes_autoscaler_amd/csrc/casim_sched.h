@@ -1135,39 +1135,66 @@ public:
         bk_.sync();
         drop_temps(mark);
         delta_rows_ += n;
+        if (!committed_.empty()) {   // the new records (and the caller's rule counters) describe these nodes from now on
+            std::vector<uint8_t> gone((size_t)dt_.NG, 0);
+            for (int k = 0; k < n; ++k) gone[(size_t)idx[k]] = 1;
+            size_t w = 0;
+            for (size_t i = 0; i < committed_.size(); ++i) if (!gone[(size_t)committed_[i].node]) committed_[w++] = committed_[i];
+            committed_.resize(w);
+        }
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
     }
 
     // TrySchedulePods on the committed image; commit != 0 keeps the placements (SchedulePod's AddPod on the snapshot)
     int32_t try_schedule(const casim_pod_sequence* q, int commit, int32_t* node_out, int32_t* last_index_out, int32_t* n_scheduled_out) {
         if (!ready_) return fail(CASIM_ERR_INVALID, "cluster not initialised");
+        if (!q) return fail(CASIM_ERR_INVALID, "null pod sequence");
+        PatchedRules pr;
+        casim_pod_sequence qq = *q;
+        int32_t rc = with_committed(q->rules, pr);
+        if (rc != CASIM_OK) return rc;
+        qq.rules = pr.rules;
         SchedulerT<BK> s(bk_);
         s.use_resident(&dt_);
-        int32_t rc = s.init(&hp_, &hg_, q);
+        rc = s.init(&hp_, &hg_, &qq);
         if (rc == CASIM_OK) rc = s.run();
         const size_t mark = allocs_.size();
-        if (rc == CASIM_OK && commit && q->n_pods > 0 && s.node_out_dev()) {
+        const bool folds = rc == CASIM_OK && commit && q->n_pods > 0 && s.node_out_dev();
+        if (folds) {
             const int32_t* d_pc = up(q->pod_class, (size_t)q->n_pods);
             bk_.launch(commit_placements_kernel, (q->n_pods + 255) / 256, 1, 256, (size_t)0, dt_, s.node_out_dev(), d_pc, (int)q->n_pods);
             commits_++;
         }
+        std::vector<int32_t> own;
+        if (folds && !node_out) { own.resize((size_t)q->n_pods); node_out = own.data(); }   // (the placements are remembered below)
         if (rc == CASIM_OK) rc = s.fetch(node_out, last_index_out, n_scheduled_out);   // (synchronises: the commit kernel is done)
         else bk_.sync();
         drop_temps(mark);
         if (rc < 0) err_ = s.error();
+        // what the committed pods mean for the domain rules of LATER calls: the caller's count_init / node_contrib come from the
+        // encoder, which saw the snapshot before this commit (with_committed adds them back in)
+        if (folds && rc == CASIM_OK)
+            for (int32_t i = 0; i < q->n_pods; ++i) if (node_out[i] >= 0) committed_.push_back({q->pod_class[i], node_out[i]});
         return rc;
     }
     // the planner's removal loop on the committed image (its own Fork / Revert: nothing persists)
     int32_t simulate_removals(const casim_removal_candidates* cand, casim_removal_results* out) {
         if (!ready_) return fail(CASIM_ERR_INVALID, "cluster not initialised");
+        if (!cand) return fail(CASIM_ERR_INVALID, "null candidates");
+        PatchedRules pr;
+        casim_removal_candidates cc = *cand;
+        int32_t rc = with_committed(cand->rules, pr);
+        if (rc != CASIM_OK) return rc;
+        cc.rules = pr.rules;
         SchedulerT<BK> s(bk_);
         s.use_resident(&dt_);
-        int32_t rc = s.init_removals(&hp_, &hg_, cand);
+        rc = s.init_removals(&hp_, &hg_, &cc);
         if (rc == CASIM_OK) rc = s.run();
         if (rc == CASIM_OK) rc = s.fetch_removals(out);
         if (rc < 0) err_ = s.error();
         return rc;
     }
+    int64_t committed_pods() const { return (int64_t)committed_.size(); }
     // the committed image of the mutable node columns (tests, and a shim that wants to cross-check its snapshot)
     int32_t fetch_nodes(int64_t* init_req_out, int32_t* init_pods_out, uint64_t* init_excl_out) {
         if (!ready_) return fail(CASIM_ERR_INVALID, "cluster not initialised");
@@ -1192,6 +1219,50 @@ private:
     }
     void drop_temps(size_t mark) { while (allocs_.size() > mark) { bk_.free(allocs_.back()); allocs_.pop_back(); } }
     int32_t fail(int32_t code, const char* msg) { err_ = msg ? msg : ""; return code; }
+    // Domain rules after commits.  The image in HBM carries what a committed pod does to its node (requests, pod count, exclusion
+    // bits); what it does to the OTHER nodes of its topology domains — PodTopologySpread counts, zone anti-affinity, required pod
+    // affinity — lives in the rules' counters, and those arrive per call from an encoder that read the snapshot BEFORE the commits
+    // (the reference's one ClusterSnapshot sees the pods AddPod placed: CA/simulator/clustersnapshot/store/delta.go:292-323).  So
+    // the cluster remembers (class, node) of every committed pod and, in front of every later call that brings rules, adds
+    // them to the caller's count_init / node_contrib with the kernels' own rule (casim_sched.h, commit_pods: the node carries the
+    // rule's key and is eligible for the rule).  A node whose record is replaced (update_nodes) forgets its pods: the new record and
+    // the caller's counters already describe it.
+    struct PatchedRules {
+        casim_domain_rules copy;
+        std::vector<int32_t> count, contrib;
+        const casim_domain_rules* rules = nullptr;
+    };
+    int32_t with_committed(const casim_domain_rules* in, PatchedRules& pr) {
+        pr.rules = in;
+        if (!in || in->n_rules <= 0 || committed_.empty()) return CASIM_OK;
+        if (in->n_nodes != dt_.NG) return fail(CASIM_ERR_INVALID, "domain rules describe another node table");
+        if (!in->rule_offset || !in->rule_key || !in->rule_elig_row || !in->node_domain || !in->inc_off || !in->count_init)
+            return fail(CASIM_ERR_INVALID, "domain rules miss a column");
+        const int64_t N = in->n_nodes, total = in->rule_offset[in->n_rules];
+        pr.count.assign(in->count_init, in->count_init + total);
+        if (in->node_contrib) pr.contrib.assign(in->node_contrib, in->node_contrib + (int64_t)in->n_rules * N);
+        const int64_t wpr = (N + 63) / 64;
+        for (const Placed& pl : committed_) {
+            if (pl.cls < 0 || pl.cls >= in->n_classes) continue;   // (a class the rules do not know increments nothing)
+            for (int32_t ii = in->inc_off[pl.cls]; ii < in->inc_off[pl.cls + 1]; ++ii) {
+                const int32_t r = in->inc_rule[ii];
+                const int32_t d = in->node_domain[(int64_t)in->rule_key[r] * N + pl.node];
+                const int32_t row = in->rule_elig_row[r];
+                const bool el = row < 0 || ((in->elig_bits[(int64_t)row * wpr + (pl.node >> 6)] >> (pl.node & 63)) & 1ull);
+                if (d >= 0 && el) {
+                    pr.count[(size_t)(in->rule_offset[r] + d)] += 1;
+                    if (!pr.contrib.empty()) pr.contrib[(size_t)((int64_t)r * N + pl.node)] += 1;
+                }
+            }
+        }
+        pr.copy = *in;
+        pr.copy.count_init = pr.count.data();
+        if (!pr.contrib.empty()) pr.copy.node_contrib = pr.contrib.data();
+        pr.rules = &pr.copy;
+        return CASIM_OK;
+    }
+    struct Placed { int32_t cls, node; };
+    std::vector<Placed> committed_;
     BK& bk_;
     DevTables dt_;
     casim_pegs hp_; casim_groups hg_;

@@ -620,11 +620,13 @@ class EmuCluster:
         return {"full_uploads": out[0], "delta_rows": out[1], "commits": out[2], "nodes": out[3]}
 
 
-def resident_iteration(make_cluster, w, n_candidates=4):
+def resident_iteration(make_cluster, w, n_candidates=4, with_rules=False):
     """One RunOnce-shaped sequence on a resident cluster vs the oracle, which threads ONE snapshot through it the way the
     reference does: filter-out-schedulable (committed) -> the same pods again (nothing may fit twice the same way; reverted)
     -> the planner's removal loop over the emptiest nodes, whose pod lists include what filter-out-schedulable just placed.
-    `w` is a workloads.PendingWorkload (no domain rules).  Returns what was compared, for the caller's bookkeeping."""
+    `w` is a workloads.PendingWorkload; with_rules: every call carries the encoder's domain rules (PodTopologySpread, zone
+    anti-affinity, pod affinity) — counters from BEFORE the commit, which the cluster has to bring up to date itself.
+    Returns what was compared, for the caller's bookkeeping."""
     from kubernetes_autoscaler_amd.objects import PodEquivalenceGroup as PEG
     nodes, pods = w.nodes, w.pods
     # ---- one encoder session for the iteration: classes = pending specs + the specs of every running pod
@@ -644,16 +646,18 @@ def resident_iteration(make_cluster, w, n_candidates=4):
         enc.add_group(info, pegs=[])
     enc.finalize()
     cl = make_cluster(enc.pegs, enc.groups)
+    rules = enc.rules if with_rules else None
+    sk = similar_keys(pods) if with_rules else None
     # ---- oracle: one snapshot for the whole sequence
     s = OracleScenario()
     for info in nodes:
         s.add_existing(info)
     canon = {}
     opods = [canon.setdefault(p.spec_key(), p) for p in pods]
-    want1 = s.try_schedule_pods(opods, w.hints, None, w.acceptable, w.break_on_failure, w.last_index)
+    want1 = s.try_schedule_pods(opods, w.hints, sk, w.acceptable, w.break_on_failure, w.last_index)
     # ---- 1. filter-out-schedulable, committed
     before = cl.fetch_nodes()
-    rc, out1, li1, ns1 = cl.try_schedule_pods(pod_class, w.hints, w.acceptable, w.break_on_failure, w.last_index, commit=True)
+    rc, out1, li1, ns1 = cl.try_schedule_pods(pod_class, w.hints, w.acceptable, w.break_on_failure, w.last_index, commit=True, rules=rules, similar_key=sk)
     assert rc == 0
     assert list(out1) == list(want1[0]) and li1 == want1[1] and ns1 == want1[2], "committed pass"
     after = cl.fetch_nodes()
@@ -671,9 +675,9 @@ def resident_iteration(make_cluster, w, n_candidates=4):
     for m, info in enumerate(nodes):
         from kubernetes_autoscaler_amd.objects import NodeInfo
         s2.add_existing(NodeInfo(info.node, list(info.pods) + placed_on[m]))
-    want2 = s2.try_schedule_pods(opods, w.hints, None, w.acceptable, w.break_on_failure, li1)
+    want2 = s2.try_schedule_pods(opods, w.hints, sk, w.acceptable, w.break_on_failure, li1)
     s2.close()
-    rc, out2, li2, ns2 = cl.try_schedule_pods(pod_class, w.hints, w.acceptable, w.break_on_failure, li1, commit=False)
+    rc, out2, li2, ns2 = cl.try_schedule_pods(pod_class, w.hints, w.acceptable, w.break_on_failure, li1, commit=False, rules=rules, similar_key=sk)
     assert list(out2) == list(want2[0]) and li2 == want2[1] and ns2 == want2[2], "reverted pass"
     again = cl.fetch_nodes()
     assert all((a == b).all() for a, b in zip(after, again)), "a reverted pass must not touch the image"
@@ -684,7 +688,7 @@ def resident_iteration(make_cluster, w, n_candidates=4):
     want3 = s.simulate_node_removals(cands, lists, None, None, True, 0, None, None, li1, None)
     flat = np.array([class_of[p.spec_key()] for lst in lists for p in lst], np.int32)
     off = np.cumsum([0] + [len(x) for x in lists]).astype(np.int32)
-    got3 = cl.simulate_node_removals(cands, off, flat, last_index=li1)
+    got3 = cl.simulate_node_removals(cands, off, flat, last_index=li1, rules=rules)
     assert_removal_matches(got3, want3, "removals on the committed image")
     final = cl.fetch_nodes()
     assert all((a == b).all() for a, b in zip(after, final)), "the removal loop must not touch the image"

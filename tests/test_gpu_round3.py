@@ -107,3 +107,16 @@ def test_register_packer_beyond_its_node_slots_with_generic_retry(ctx):
         assert oracle[0][0].nodes_added < 1024 < oracle[1][0].nodes_added
         assert_matches_oracle(res, oracle, f"retry csr={device_csr}")
         assert_matches_oracle(again, oracle, f"retry again csr={device_csr}")
+
+
+def test_resident_cluster_iteration_with_domain_rules(ctx):
+    """commits on the resident cluster feed the PodTopologySpread / zone anti-affinity / pod-affinity counters of the
+    later calls of the iteration (reverted pass, removal loop) — vs the oracle threading one snapshot through the sequence."""
+    from harness import resident_iteration
+    total = 0
+    for seed in range(30):
+        w = workloads.fuzz_pending_domains(8300 + seed)
+        w.hints = None
+        out = resident_iteration(lambda classes, nodes: kaa.ResidentCluster(ctx, classes, nodes), w, with_rules=True)
+        total += out["scheduled"]
+    assert total > 0

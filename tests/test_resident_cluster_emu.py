@@ -79,3 +79,51 @@ def test_bad_deltas_are_rejected():
     rc = cl.L.emu_cluster_update_nodes(cl._h, 1, idx.ctypes.data_as(_abi.i32p), C.byref(enc.groups))
     assert rc == _abi.ERR_INVALID
     cl.close(); enc.close()
+
+
+def _split_case(w):
+    from harness import similar_keys
+    from kubernetes_autoscaler_amd.scheduling import encode_pending_pods
+    enc, pc = encode_pending_pods(w.nodes, w.pods)
+    half = len(w.pods) // 2
+    parts = [slice(0, half), slice(half, len(w.pods))]
+    canon = {}
+    opods = [canon.setdefault(p.spec_key(), p) for p in w.pods]
+    return enc, pc, parts, opods, similar_keys
+
+
+@pytest.mark.parametrize("lds", [0, 4096])
+@pytest.mark.parametrize("seed", range(60))
+def test_committed_pods_count_in_the_domain_rules_of_later_calls(seed, lds):
+    """PodTopologySpread / zone anti-affinity / pod-affinity counters come per call from an encoder that saw the snapshot
+    BEFORE the commits; the cluster adds what it committed since.  The oracle threads ONE snapshot through both passes."""
+    w = workloads.fuzz_pending_domains(8100 + seed)
+    if len(w.pods) < 2:
+        pytest.skip("needs two pods")
+    enc, pc, (a, b), opods, similar_keys = _split_case(w)
+    s = OracleScenario()
+    for info in w.nodes:
+        s.add_existing(info)
+    hints = lambda sl: None if w.hints is None else list(w.hints[sl])
+    want1 = s.try_schedule_pods(opods[a], hints(a), similar_keys(w.pods[a]), w.acceptable, w.break_on_failure, w.last_index)
+    want2 = s.try_schedule_pods(opods[b], hints(b), similar_keys(w.pods[b]), w.acceptable, w.break_on_failure, want1[1])
+    s.close()
+    cl = EmuCluster(enc.pegs, enc.groups, lds_budget=lds)
+    rc, out1, li1, ns1 = cl.try_schedule_pods(pc[a], hints(a), w.acceptable, w.break_on_failure, w.last_index, commit=True, rules=enc.rules,
+                                              similar_key=similar_keys(w.pods[a]))
+    assert rc == 0 and list(out1) == list(want1[0]) and li1 == want1[1] and ns1 == want1[2], "committed pass"
+    for _ in range(2):   # (uncommitted: twice the same answer)
+        rc, out2, li2, ns2 = cl.try_schedule_pods(pc[b], hints(b), w.acceptable, w.break_on_failure, li1, commit=False, rules=enc.rules,
+                                                  similar_key=similar_keys(w.pods[b]))
+        assert rc == 0 and list(out2) == list(want2[0]) and li2 == want2[1] and ns2 == want2[2], "second pass on the committed image"
+    cl.close(); enc.close()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_iteration_with_domain_rules_on_a_resident_cluster(seed):
+    """The whole RunOnce-shaped sequence (committed pass, reverted pass, removal loop) with spread / zone anti-affinity / pod
+    affinity rules whose counters predate the commit."""
+    w = workloads.fuzz_pending_domains(8300 + seed)
+    w.hints = None
+    out = resident_iteration(lambda classes, nodes: EmuCluster(classes, nodes), w, with_rules=True)
+    assert out["stats"]["full_uploads"] == 1
