@@ -533,9 +533,11 @@ def main():
         # (one launch = one sub-batch: bytes, durations and the PMC figures below are all per launch of sub-batch 0)
         bytes_pack, Bp, Bn = algorithmic_bytes_pack(mine.dims, part0_groups, part0_nnz, fast)
         achieved = bytes_pack / (kms["pack_ms"] * 1e-3) / 1e9
-        kname = ("pack_fast_kernel<%d,%d,%d>" % (info["fast_packer_lanes"], info["fast_packer_slots_per_lane"],
-                                                  2 if (mine.dims["w_excl"] or mine.dims["w_zone"]) else 0)) if fast else "pack_kernel"
-        roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        build_info = ctx.pack_build_info()   # which of the library's two builds of the register packer ran (self-check verdict)
+        kname = ("pack_fast_kernel<%d,%d,%d,%d>" % (info["fast_packer_lanes"], info["fast_packer_slots_per_lane"],
+                                                     2 if (mine.dims["w_excl"] or mine.dims["w_zone"]) else 0,
+                                                     1 if build_info["build"] == "plain" else 0)) if fast else "pack_kernel"
+        roofline = {"bound": "hbm", "kernel": kname, "packer_build_self_check": build_info, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
                     "algorithmic_bytes_per_launch": bytes_pack, "bytes_per_peg_record": Bp, "bytes_per_group_record": Bn,
                     "kernel_ms": kms["pack_ms"], "share_of_step": kms["pack_ms"] / max(total_ms, 1e-9),

@@ -32,11 +32,13 @@
 extern "C" {
 #endif
 
-#define CASIM_ABI_VERSION 4   /* 2: casim_removal_candidates.cand_atomic, casim_domain_rules.n_taint_policy_rules
+#define CASIM_ABI_VERSION 5   /* 2: casim_removal_candidates.cand_atomic, casim_domain_rules.n_taint_policy_rules
                                * 3: casim_groups.{peg_lo,peg_hi,global_id,n_sims,sim_offsets}, casim_best_option_sims,
                                *    casim_feasibility_reasons, casim_estimate_batch_timed, casim_mctx_*, casim_cluster_*
                                * 4: casim_options.n_streams (sub-batches on internal HIP streams), casim_enc_group_pods,
-                               *    casim_selfcheck */
+                               *    casim_enc_add_grouped_pegs, casim_enc_pod_set_spec_extra
+                               * 5: casim_options.pack_build, casim_pack_build_info (two builds of the register packer + self-check),
+                               *    casim_problem_info [5], [6] */
 
 /* Resource lanes.  Lane 0 = cpu in millicores (Quantity.MilliValue), lane 1 = memory bytes,
  * lane 2 = ephemeral-storage bytes, lanes 3.. = scalar / extended resources (Quantity.Value),
@@ -159,8 +161,14 @@ typedef struct casim_options {
                                      casim_best_option_sims with dev_* outputs joins into it (work enqueued there afterwards sees
                                      the keys); host outputs / casim_problem_fetch synchronise.  Batches that cannot be cut (one
                                      simulation, explicit peg_offsets, node_pods) run as one part; casim_problem_info [4] tells. */
-    int32_t reserved[4];
+    int32_t pack_build;           /* which build of the register packer runs (csrc/casim_pack_tu.hip): CASIM_PACK_BUILD_AUTO (0, default) = the
+                                     one the library's self-check left standing for the device, _PLAIN = compiled without the
+                                     experimental LLVM option, _OPTION = compiled with it; see casim_pack_build_info */
+    int32_t reserved[3];
 } casim_options;
+#define CASIM_PACK_BUILD_AUTO 0
+#define CASIM_PACK_BUILD_PLAIN 1
+#define CASIM_PACK_BUILD_OPTION 2
 
 /*
  * Results of one batch.  All arrays caller-allocated.  `order`/`placed` use the same CSR
@@ -240,6 +248,12 @@ int32_t casim_problem_fetch(casim_problem* p, casim_results* out);
  * (needed when the engine computed the schedulable subsets).  offsets_out has NG+1 slots or
  * is NULL.  Synchronises the stream. */
 int32_t casim_problem_csr(casim_problem* p, int32_t* nnz_out, int32_t* offsets_out);
+
+/* Which build of the register packer serves `device` in this process (csrc/casim_pack_tu.hip: the kernels exist twice, compiled with
+ * and without an experimental LLVM option; the first casim_ctx_create on a device runs a built-in corpus of 12 batches through both
+ * and retires the option build on any difference).  out[0] = CASIM_PACK_BUILD_PLAIN / _OPTION (AUTO = no context created yet),
+ * [1] = batches compared, [2] = batches that differed, [3] = 1 when the environment forced the build (CASIM_PACK_BUILD=plain|option). */
+int32_t casim_pack_build_info(int32_t device, int32_t out[4]);
 
 /* How the resident batch will be executed (for reports): info_out[0] = node slots per lane of the
  * register-resident int32 packer (0 = generic int64 packer), [1] = its lane count, [2] = 1 if the

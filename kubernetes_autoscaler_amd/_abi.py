@@ -3,7 +3,7 @@ shared library happens in _ffi.py).  Kept separate so that test harnesses that c
 structs can reuse the layouts without loading the product library."""
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_RES = 8
 
 OK = 0
@@ -18,6 +18,7 @@ PEG_FASTPATH_AA_SELF = 0x10
 PEG_UNSUPPORTED = 0x20
 NGF_UNSCHEDULABLE = 0x1
 
+PACK_BUILD_AUTO, PACK_BUILD_PLAIN, PACK_BUILD_OPTION = 0, 1, 2
 EXPANDER_LEAST_NODES, EXPANDER_LEAST_WASTE, EXPANDER_MOST_PODS = 0, 1, 2
 
 # casim_feasibility_reasons codes: plugin in the low 4 bits, NodeResourcesFit reasons above
@@ -64,7 +65,7 @@ class Groups(C.Structure):
 
 
 class Options(C.Structure):
-    _fields_ = [("fastpath", C.c_int32), ("force_generic_packer", C.c_int32), ("node_pods", C.c_int32), ("n_streams", C.c_int32), ("reserved", C.c_int32 * 4)]
+    _fields_ = [("fastpath", C.c_int32), ("force_generic_packer", C.c_int32), ("node_pods", C.c_int32), ("n_streams", C.c_int32), ("pack_build", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class Results(C.Structure):
@@ -171,6 +172,7 @@ PROTOTYPES = {
                                                  C.POINTER(RemovalResults)]),
     "casim_time_node_removals": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(RemovalCandidates), C.c_int32,
                                              C.POINTER(C.c_float)]),
+    "casim_pack_build_info": (C.c_int32, [C.c_int32, i32p]),
     "casim_copy_bandwidth": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, f64p]),
     "casim_stream_probe": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, f64p]),
     "casim_enc_create": (C.c_void_p, [C.POINTER(EncoderOptions)]),

@@ -9,6 +9,7 @@
 
 #include <chrono>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -21,6 +22,7 @@
 namespace casim {
 // casim_pack_tu.hip: the register packer, compiled in its own translation unit (see there)
 int hip_launch_pack_fast(int lanes, int slots_per_lane, int excl_words, int n_groups, void* stream, DevTables t, DevResults res, FastScratch fs);
+int hip_launch_pack_fast_plain(int lanes, int slots_per_lane, int excl_words, int n_groups, void* stream, DevTables t, DevResults res, FastScratch fs);
 }
 
 namespace {
@@ -104,8 +106,14 @@ struct HipBackend {
     const char* error() const { return msg.c_str(); }
     void clear() { last = hipSuccess; msg.clear(); (void)hipGetLastError(); }  // also drop HIP's sticky last error
 
-    void launch_pack_fast(int lanes, int slots_per_lane, int excl_words, int n_groups, const DevTables& t, const DevResults& res, const FastScratch& fs) {
-        check((hipError_t)casim::hip_launch_pack_fast(lanes, slots_per_lane, excl_words, n_groups, (void*)stream, t, res, fs), "pack_fast_kernel launch");
+    // The register packer exists twice in the library (casim_pack_tu.hip): build 0 compiled with the experimental structurizer
+    // option, build 1 without.  `want`: casim_options.pack_build of the problem (CASIM_PACK_BUILD_*); AUTO takes the build the
+    // self-check left standing for this device (pack_plain).
+    bool pack_plain = false;
+    void launch_pack_fast(int want, int lanes, int slots_per_lane, int excl_words, int n_groups, const DevTables& t, const DevResults& res, const FastScratch& fs) {
+        const bool plain = want == CASIM_PACK_BUILD_PLAIN || (want != CASIM_PACK_BUILD_OPTION && pack_plain);
+        if (plain) check((hipError_t)casim::hip_launch_pack_fast_plain(lanes, slots_per_lane, excl_words, n_groups, (void*)stream, t, res, fs), "pack_fast_kernel launch (plain build)");
+        else check((hipError_t)casim::hip_launch_pack_fast(lanes, slots_per_lane, excl_words, n_groups, (void*)stream, t, res, fs), "pack_fast_kernel launch");
     }
     template <class K, class... A>
     void launch(K kernel, int gx, int gy, int block, size_t smem, A... args) {
@@ -176,7 +184,7 @@ struct casim_ctx {
         while ((int)lanes.size() < k && !lanes_capped) {
             HipBackend* l = new (std::nothrow) HipBackend();
             if (!l) break;
-            l->device = bk.device; l->lds = bk.lds; l->own_stream = true;
+            l->device = bk.device; l->lds = bk.lds; l->own_stream = true; l->pack_plain = bk.pack_plain;
             l->bind();
             l->check(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking), "hipStreamCreate");
             if (!l->ok()) { delete l; break; }
@@ -243,6 +251,141 @@ struct casim_problem {
     HipBackend& bk0() { return sp ? sp->lane(0) : ctx->bk; }   // where part 0's kernels run (timing helpers)
     const std::string& error() const { return sp && !sp->error().empty() ? sp->error() : prob->error(); }
 };
+
+// ---- which build of the register packer serves a device (casim_pack_tu.hip) -------------------------------------------------------
+// Build 0 of the packer is compiled with an experimental LLVM option that was caught miscompiling a sibling kernel; build 1 is the
+// same source without it.  Before the first context of a process on a device is handed out, a built-in corpus goes through both:
+// 12 batches — one per kernel instantiation (2 / 4 resource lanes x 1 / 4 / 16 node slots per lane x without / with exclusion
+// words) — of 48 node groups over 160 PEGs with taints, selectors, limits, existing nodes, self-excluding PEGs and host-port
+// bits, schedulable subsets derived on the device.  Every output array must be identical; any difference (or an error of build 0
+// alone) retires build 0 for the process and says so once on stderr.  ~40 ms, once.  CASIM_PACK_BUILD=plain|option skips the
+// check and forces a build; CASIM_PACK_SELFCHECK_FAULT=1 makes the comparison see a flipped word (how the fallback is tested).
+namespace {
+struct PackBuildState { int checked = 0; int plain = 0; int batches = 0; int differing = 0; int forced = 0; };
+PackBuildState g_pack_build[64];
+std::mutex g_pack_build_mu;
+
+struct SelfCheckRng { uint64_t s; uint32_t next() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(s >> 33); } uint32_t below(uint32_t n) { return n ? next() % n : 0; } };
+
+// one batch of the corpus through one build: every result array into `out`
+int32_t self_check_run(HipBackend& bk, int build, int lanes4, int slot_class, int excl, std::vector<int64_t>& out) {
+    SelfCheckRng rng{0x9E3779B97F4A7C15ull ^ (uint64_t)(lanes4 * 131 + slot_class * 17 + excl)};
+    const int G = 160, NG = 48, R = lanes4 ? 3 : 2;
+    std::vector<int64_t> req((size_t)G * R), alloc((size_t)NG * R), ireq((size_t)NG * R);
+    std::vector<int32_t> count(G), allowed(NG), ipods(NG), maxn(NG), existing(NG), lastidx(NG);
+    std::vector<uint32_t> pflags(G), gflags(NG);
+    std::vector<uint64_t> tol(G), sel(G), xb(G), xm(G), taint(NG), label(NG), iexcl(NG);
+    for (int g = 0; g < G; ++g) {
+        req[(size_t)g * R] = 50 + 50 * (int64_t)rng.below(60);
+        req[(size_t)g * R + 1] = ((int64_t)64 + 64 * rng.below(96)) << 20;
+        if (R > 2) req[(size_t)g * R + 2] = rng.below(4) == 0 ? 1 + rng.below(2) : 0;
+        count[g] = 1 + (int32_t)rng.below(slot_class == 2 ? 90 : 40);
+        pflags[g] = rng.below(16) == 0 ? CASIM_PEG_TOLERATES_UNSCHEDULABLE : 0u;
+        tol[g] = rng.below(3) ? ~0ull : (uint64_t)rng.next();          // most PEGs tolerate everything
+        sel[g] = rng.below(4) ? 0ull : (1ull << rng.below(6));          // a few need one label requirement
+        xb[g] = xm[g] = 0;
+        if (excl) {
+            const uint32_t k = rng.below(8);
+            if (k == 0) { pflags[g] |= CASIM_PEG_SELF_EXCL_NODE; xb[g] = xm[g] = 1ull << rng.below(40); }   // self anti-affinity / own host port
+            else if (k == 1) { xb[g] = 1ull << rng.below(40); }                                              // blocked by somebody's bit
+            else if (k == 2) { xm[g] = 1ull << rng.below(40); }                                              // marks a bit others avoid
+        }
+    }
+    for (int i = 0; i < NG; ++i) {
+        const int32_t pods_cap = slot_class == 2 ? 4 + (int32_t)rng.below(8) : (slot_class == 1 ? 8 + (int32_t)rng.below(24) : 20 + (int32_t)rng.below(90));
+        alloc[(size_t)i * R] = 2000 + 1000 * (int64_t)rng.below(slot_class == 0 ? 62 : 14);
+        alloc[(size_t)i * R + 1] = ((int64_t)8 + 8 * rng.below(slot_class == 0 ? 32 : 8)) << 30;
+        if (R > 2) alloc[(size_t)i * R + 2] = rng.below(3) ? 8 : 0;
+        ipods[i] = (int32_t)rng.below(3);
+        ireq[(size_t)i * R] = 100 * ipods[i]; ireq[(size_t)i * R + 1] = ((int64_t)128 * ipods[i]) << 20;
+        if (R > 2) ireq[(size_t)i * R + 2] = 0;
+        allowed[i] = pods_cap + ipods[i];
+        gflags[i] = rng.below(12) == 0 ? CASIM_NG_UNSCHEDULABLE : 0u;
+        taint[i] = rng.below(3) ? 0ull : (1ull << rng.below(8));
+        label[i] = (uint64_t)rng.next() & 0x3full;
+        iexcl[i] = excl && rng.below(4) == 0 ? 1ull << rng.below(40) : 0ull;
+        // the node bound decides the instantiation: <= 64 -> 1 slot per lane, <= 256 -> 4, <= 1024 -> 16
+        maxn[i] = slot_class == 0 ? 1 + (int32_t)rng.below(60) : (slot_class == 1 ? 70 + (int32_t)rng.below(180) : 300 + (int32_t)rng.below(700));
+        if (rng.below(10) == 0) maxn[i] = -1;
+        existing[i] = (int32_t)rng.below(6);
+        lastidx[i] = (int32_t)rng.below((uint32_t)existing[i] + 4) - 1;
+    }
+    casim_pegs p; memset(&p, 0, sizeof p);
+    p.n_pegs = G; p.n_res = R; p.w_taint = 1; p.w_label = 1; p.w_excl = excl ? 1 : 0; p.w_zone = 0;
+    p.req = req.data(); p.count = count.data(); p.flags = pflags.data(); p.tol_mask = tol.data(); p.sel_mask = sel.data();
+    p.excl_block = excl ? xb.data() : nullptr; p.excl_mark = excl ? xm.data() : nullptr;
+    casim_groups g; memset(&g, 0, sizeof g);
+    g.n_groups = NG; g.alloc = alloc.data(); g.init_req = ireq.data(); g.allowed_pods = allowed.data(); g.init_pods = ipods.data(); g.flags = gflags.data();
+    g.taint_mask = taint.data(); g.label_mask = label.data(); g.init_excl = excl ? iexcl.data() : nullptr;
+    g.max_nodes = maxn.data(); g.existing_nodes = existing.data(); g.last_index = lastidx.data();
+    casim_options o; memset(&o, 0, sizeof o);
+    o.pack_build = build;
+    bk.clear();
+    HipProblem prob(bk);
+    int32_t rc = prob.init(&p, &g, &o);
+    if (rc != CASIM_OK) return rc;
+    if (prob.fast_npt() != (slot_class == 0 ? 1 : (slot_class == 1 ? 4 : 16)) || prob.fast_lanes() != (lanes4 ? 4 : 2)) return CASIM_ERR_INVALID;   // (the corpus no longer reaches the instantiation it is meant for)
+    rc = prob.run();
+    if (rc != CASIM_OK) return rc;
+    int32_t nnz = 0;
+    std::vector<int32_t> off((size_t)NG + 1);
+    rc = prob.csr(&nnz, off.data());
+    if (rc != CASIM_OK) return rc;
+    std::vector<int32_t> a((size_t)NG * 6), order((size_t)nnz + 1), placed((size_t)nnz + 1);
+    std::vector<int64_t> sums((size_t)NG * 2);
+    casim_results r; memset(&r, 0, sizeof r);
+    r.node_count = a.data(); r.pods_scheduled = a.data() + NG; r.nodes_added = a.data() + 2 * NG; r.limiter_nodes = a.data() + 3 * NG;
+    r.last_index_out = a.data() + 4 * NG; r.status = a.data() + 5 * NG; r.req_cpu_sum = sums.data(); r.req_mem_sum = sums.data() + NG;
+    r.order = order.data(); r.placed = placed.data();
+    rc = prob.fetch(&r);
+    if (rc != CASIM_OK) return rc;
+    out.clear();
+    out.push_back(nnz);
+    for (int32_t v : off) out.push_back(v);
+    for (int32_t v : a) out.push_back(v);
+    for (int64_t v : sums) out.push_back(v);
+    for (int32_t k = 0; k < nnz; ++k) { out.push_back(order[(size_t)k]); out.push_back(placed[(size_t)k]); }
+    return CASIM_OK;
+}
+
+// decides pack_plain for the device of `bk` (once per process and device)
+void resolve_pack_build(HipBackend& bk) {
+    if (bk.device < 0 || bk.device >= 64) return;
+    std::lock_guard<std::mutex> lock(g_pack_build_mu);
+    PackBuildState& st = g_pack_build[bk.device];
+    if (!st.checked) {
+        st.checked = 1;
+        const char* force = getenv("CASIM_PACK_BUILD");
+        if (force && !strcmp(force, "plain")) { st.plain = 1; st.forced = 1; }
+        else if (force && !strcmp(force, "option")) { st.plain = 0; st.forced = 1; }
+        else {
+            const bool fault = getenv("CASIM_PACK_SELFCHECK_FAULT") && atoi(getenv("CASIM_PACK_SELFCHECK_FAULT")) != 0;
+            HipBackend tmp;
+            tmp.device = bk.device; tmp.lds = bk.lds; tmp.own_stream = true;
+            tmp.bind();
+            tmp.check(hipStreamCreateWithFlags(&tmp.stream, hipStreamNonBlocking), "hipStreamCreate");
+            std::vector<int64_t> a, b;
+            for (int lanes4 = 0; lanes4 < 2 && tmp.stream; ++lanes4) for (int sc = 0; sc < 3; ++sc) for (int excl = 0; excl < 2; ++excl) {
+                const int32_t rb = self_check_run(tmp, CASIM_PACK_BUILD_PLAIN, lanes4, sc, excl, b);
+                if (rb != CASIM_OK) continue;   // (the reference build itself cannot run this batch: nothing to compare)
+                const int32_t ra = self_check_run(tmp, CASIM_PACK_BUILD_OPTION, lanes4, sc, excl, a);
+                st.batches++;
+                if (fault && st.batches == 5 && !a.empty()) a[a.size() / 2] ^= 1;
+                if (ra != CASIM_OK || a != b) st.differing++;
+            }
+            if (tmp.stream) { (void)hipStreamSynchronize(tmp.stream); }
+            tmp.release_pool();
+            if (tmp.stream) (void)hipStreamDestroy(tmp.stream);
+            (void)hipGetLastError();
+            st.plain = st.differing > 0 ? 1 : 0;
+            if (st.plain) fprintf(stderr, "libcasim: the register packer's self-check found %d of %d batches differing between its two builds on device %d: "
+                                          "the build with -structurizecfg-skip-uniform-regions is retired for this process (plain build in use)\n",
+                                  st.differing, st.batches, bk.device);
+        }
+    }
+    bk.pack_plain = st.plain != 0;
+}
+}  // namespace
 
 namespace casim {
 
@@ -314,7 +457,19 @@ casim_ctx* casim_ctx_create(int32_t device, void* stream) {
     if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && optin > 0) c->bk.lds = (size_t)optin;
     if (c->bk.lds > 160 * 1024) c->bk.lds = 160 * 1024;
     if (!c->bk.ok()) { set_err(CASIM_ERR_HIP, c->bk.msg); delete c; return nullptr; }
+    resolve_pack_build(c->bk);
+    c->bk.clear();
     return c;
+}
+
+int32_t casim_pack_build_info(int32_t device, int32_t out[4]) {
+    g_err.clear();
+    if (!out || device < 0 || device >= 64) return set_err(CASIM_ERR_INVALID, "bad argument");
+    std::lock_guard<std::mutex> lock(g_pack_build_mu);
+    const PackBuildState& st = g_pack_build[device];
+    out[0] = st.checked ? (st.plain ? CASIM_PACK_BUILD_PLAIN : CASIM_PACK_BUILD_OPTION) : CASIM_PACK_BUILD_AUTO;
+    out[1] = st.batches; out[2] = st.differing; out[3] = st.forced;
+    return CASIM_OK;
 }
 void casim_ctx_destroy(casim_ctx* ctx) {
     if (!ctx) return;

@@ -1039,7 +1039,9 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void pack_kernel(DevTables t, DevResults res, 
 // ---- fast kernel: int32 gcd-scaled lanes, node state in VGPRs, no exclusion masks ----------------
 // Launched only when the host proved the batch eligible (casim_pipeline.h): either no exclusion state at all (WX_ = 0,
 // the bench path) or Wx <= 2 node-local words (two VGPRs each) and Wz <= 2 group-wide words (scalar) with WX_ = 2; R <= R_, every scaled value < 2^31 and every group's node bound <= 64 * NPT_.
-template <int R_, int NPT_, int WX_>
+// BUILD_: which build of this file the instantiation belongs to — the product library carries the kernels twice (casim_pack_tu.hip:
+// 0 = compiled with the experimental structurizer option, 1 = without it), and kernels of two translation units need two names.
+template <int R_, int NPT_, int WX_, int BUILD_ = 0>
 // launch bounds: a floor of CASIM_FAST_WAVES waves per SIMD for the 256-node instantiation (see the note at the top)
 CS_GLOBAL CS_LAUNCH_BOUNDS(64, ((NPT_ == 4 && WX_ == 0) ? CASIM_FAST_WAVES : 1)) void pack_fast_kernel(DevTables t, DevResults res, FastScratch fs) {
     if (pack_unsupported<RegStore<R_, NPT_, WX_>::kRecDw>(t, res)) return;

@@ -198,6 +198,7 @@ public:
             int32_t maxcap = 0;
             for (size_t i = 0; i < NG; ++i) maxcap = cap[i] > maxcap ? cap[i] : maxcap;
             bool ok = o ? o->force_generic_packer == 0 : true;
+            pack_build_ = o ? o->pack_build : 0;
             // groups whose node BOUND exceeds the 1024 register slots still start in the register packer: the bound (limiter cap or
             // pods) is rarely reached — BenchmarkRunOnceScaleUp: bound 10 000, 200 nodes created — and a group that does run out
             // is packed again by the generic packer's retry launch (pack_kernel, PackScratch::retry_only)
@@ -350,7 +351,7 @@ public:
         if (fast_npt_ > 0) {
             // register-resident int32 packer: the instantiation (lanes, node slots per lane, exclusion words) is picked by the
             // backend — the product compiles these kernels in their own translation unit (casim_pack_tu.hip)
-            bk_.launch_pack_fast(fast_r_, fast_npt_, fast_wx_, NG_, dt_, dr_, fs_);
+            bk_.launch_pack_fast(pack_build_, fast_r_, fast_npt_, fast_wx_, NG_, dt_, dr_, fs_);
             if (fs_.prof) {  // profiling builds: mean ticks per phase over the groups
                 std::vector<int64_t> h((size_t)NG_ * 8);
                 bk_.d2h(h.data(), fs_.prof, h.size() * 8); bk_.sync();
@@ -602,6 +603,7 @@ private:
     bool csr_on_device_ = false, pack_lds_ = true, order_lds_ = true, ready_ = false, ran_ = false;
     int fast_wx_ = 0;
     bool fast_retry_ = false;
+    int pack_build_ = 0;      // casim_options.pack_build
     size_t pack_smem_ = 0, order_smem_ = 0;
     int order_threads_ = kOrderThreads;
     uint64_t* d_bits_ = nullptr; int32_t* d_counts_ = nullptr; int32_t* d_off_ = nullptr; int32_t* d_idx_ = nullptr; int32_t* d_block_sums_ = nullptr; int32_t* d_off_local_ = nullptr;

@@ -198,6 +198,12 @@ class Context:
     def __exit__(self, *a):
         self.close()
 
+    def pack_build_info(self) -> dict:
+        """casim_pack_build_info: which build of the register packer the self-check left standing for this context's device."""
+        out = (C.c_int32 * 4)()
+        check(lib.casim_pack_build_info(self.device, out), "casim_pack_build_info")
+        return {"build": {0: "auto", 1: "plain", 2: "option"}[out[0]], "batches_compared": out[1], "batches_differing": out[2], "forced_by_env": bool(out[3])}
+
     def copy_bandwidth_gbps(self, nbytes: int = 1 << 30, iters: int = 10) -> float:
         out = C.c_double(0)
         check(lib.casim_copy_bandwidth(self._h, nbytes, iters, C.byref(out)), "casim_copy_bandwidth")
@@ -408,9 +414,10 @@ class Problem:
     """casim_problem: a batch resident in HBM; run() enqueues feasibility -> order -> pack."""
 
     def __init__(self, ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, fastpath: bool = False, force_generic_packer: bool = False,
-                 node_pods: bool = False, n_streams: int = 0):
+                 node_pods: bool = False, n_streams: int = 0, pack_build: int = 0):
         """n_streams > 1: a batch of simulations runs as up to n_streams sub-batches on internal HIP streams of the context
-        (casim_options.n_streams); results are identical, info()["parts"] tells whether the batch was cut."""
+        (casim_options.n_streams); results are identical, info()["parts"] tells whether the batch was cut.
+        pack_build: _abi.PACK_BUILD_AUTO / _PLAIN / _OPTION (casim_options.pack_build)."""
         self.ctx = ctx
         self.n_groups = groups.n_groups
         self.n_pegs = pegs.n_pegs
@@ -421,7 +428,7 @@ class Problem:
             self._node_pods_cap = int(sum((int(groups.max_nodes[i]) if groups.max_nodes[i] > 0 else (0 if groups.max_nodes[i] < 0 else total))
                                           for i in range(groups.n_groups))) + 64
         opts = _abi.Options(fastpath=int(fastpath), force_generic_packer=int(force_generic_packer), node_pods=int(bool(node_pods)),
-                            n_streams=int(n_streams))
+                            n_streams=int(n_streams), pack_build=int(pack_build))
         self._h = lib.casim_problem_create(ctx._h, C.byref(pegs), C.byref(groups), C.byref(opts))
         if not self._h:
             raise CasimError(_abi.ERR_INVALID, last_error())

@@ -34,7 +34,7 @@ struct EmuBackend {
     void launch(K kernel, int gx, int gy, int block, size_t smem, A... args) {
         casim_emu::launch(gx, gy, block, smem, [&]() { kernel(args...); });
     }
-    void launch_pack_fast(int lanes, int slots_per_lane, int excl_words, int n_groups, const DevTables& t, const DevResults& res, const FastScratch& fs) {
+    void launch_pack_fast(int /*build: one build under the emulator*/, int lanes, int slots_per_lane, int excl_words, int n_groups, const DevTables& t, const DevResults& res, const FastScratch& fs) {
 #define CASIM_EMU_FAST(R, N, X) launch(casim::pack_fast_kernel<R, N, X>, n_groups, 1, 64, (size_t)0, t, res, fs)
         CASIM_FAST_DISPATCH(CASIM_EMU_FAST, lanes, slots_per_lane, excl_words);
 #undef CASIM_EMU_FAST

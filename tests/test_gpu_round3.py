@@ -2,6 +2,8 @@
   * the headline three ways are ONE answer: resident step through the context's internal streams (casim_options.n_streams),
     enter -> return (casim_estimate_batch_query, streamed and not) and the int64 packer (force_generic_packer) — bit-equal;
   * streams inside one casim_ctx == the unstreamed problem, also after many resident steps and with a validity mask."""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,6 +14,7 @@ from kubernetes_autoscaler_amd.tables import TableSet
 from harness import GroupSpec, Scenario, assert_matches_oracle, encode, encode_batch, run_gpu_tables, run_oracle
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KINDS = [_abi.EXPANDER_LEAST_NODES]
 FIELDS = ("offsets", "node_count", "pods_scheduled", "nodes_added", "limiter_nodes", "last_index_out", "status", "req_cpu_sum", "req_mem_sum")
 
@@ -80,7 +83,7 @@ def test_streamed_problem_many_resident_steps_and_validity_mask(ctx):
     with kaa.Problem(ctx, pegs, groups) as p:
         p.run(); bexp = p.best_option_sims([_abi.EXPANDER_LEAST_WASTE], valid=valid, n_sims=ts.n_sims)
     with kaa.Problem(ctx, pegs, groups, n_streams=7) as p:
-        assert p.info()["parts"] == 7
+        assert 2 <= p.info()["parts"] <= 7      # (7 asked; the context takes as many lanes as the runtime has concurrent hardware queues for)
         for _ in range(25):
             p.run()
             p.best_option_sims([_abi.EXPANDER_LEAST_WASTE], fetch=False, n_sims=ts.n_sims)
@@ -120,3 +123,61 @@ def test_resident_cluster_iteration_with_domain_rules(ctx):
         out = resident_iteration(lambda classes, nodes: kaa.ResidentCluster(ctx, classes, nodes), w, with_rules=True)
         total += out["scheduled"]
     assert total > 0
+
+
+def test_packer_self_check_ran_and_found_the_two_builds_identical(ctx):
+    """libcasim carries the register packer twice (with / without the experimental structurizer option) and
+    compares the two on a built-in corpus before the first context of the process is handed out."""
+    info = ctx.pack_build_info()
+    if info["forced_by_env"]:
+        pytest.skip("CASIM_PACK_BUILD forces a build")
+    assert info["batches_compared"] == 12 and info["batches_differing"] == 0 and info["build"] == "option", info
+
+
+def test_both_packer_builds_agree_with_the_oracle(ctx):
+    """casim_options.pack_build: the plain and the option build of every instantiation the fuzz families reach, both against the oracle."""
+    for seed in range(60):
+        w = workloads.fuzz(7000 + seed, max_groups=3, max_pegs=260, rich=seed % 2 == 0)
+        sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing, lanes=w.lanes,
+                      device_csr=seed % 3 == 0)
+        enc = encode(sc)
+        want = run_oracle(sc)
+        for build in (_abi.PACK_BUILD_PLAIN, _abi.PACK_BUILD_OPTION):
+            with kaa.Problem(ctx, enc.pegs, enc.groups, pack_build=build) as p:
+                p.run(); res = p.fetch()
+            assert_matches_oracle(res, want, f"seed {seed} build {build}")
+        enc.close()
+    w = workloads.CONFIGS["C2"]()
+    sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing, lanes=w.lanes, device_csr=True)
+    enc = encode(sc); want = run_oracle(sc)
+    for build in (_abi.PACK_BUILD_PLAIN, _abi.PACK_BUILD_OPTION):
+        with kaa.Problem(ctx, enc.pegs, enc.groups, pack_build=build) as p:
+            assert p.info()["fast_packer_slots_per_lane"] > 0
+            p.run(); res = p.fetch()
+        assert_matches_oracle(res, want, f"C2 build {build}")
+    enc.close()
+
+
+def test_a_failing_self_check_retires_the_option_build():
+    """CASIM_PACK_SELFCHECK_FAULT=1 flips one word of the option build's results inside the comparison: the process must come up on the
+    plain build, say so, and still match the oracle (own process: the verdict is per process and device)."""
+    import json, subprocess, sys
+    code = (
+        "import json, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import kubernetes_autoscaler_amd as kaa\n"
+        "from kubernetes_autoscaler_amd import workloads\n"
+        "from harness import GroupSpec, Scenario, encode, run_oracle, assert_matches_oracle\n"
+        "ctx = kaa.Context(0)\n"
+        "w = workloads.CONFIGS['C1']()\n"
+        "sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing, lanes=w.lanes)\n"
+        "enc = encode(sc)\n"
+        "with kaa.Problem(ctx, enc.pegs, enc.groups) as p:\n"
+        "    p.run(); res = p.fetch(); fast = p.info()['fast_packer_slots_per_lane']\n"
+        "assert_matches_oracle(res, run_oracle(sc), 'C1 on the plain build')\n"
+        "print(json.dumps({'info': ctx.pack_build_info(), 'fast': fast}))\n") % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ); env["CASIM_PACK_SELFCHECK_FAULT"] = "1"; env.pop("CASIM_PACK_BUILD", None)
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["info"]["build"] == "plain" and out["info"]["batches_differing"] == 1 and out["fast"] > 0, out
+    assert "retired for this process" in p.stderr
