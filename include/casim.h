@@ -38,7 +38,7 @@ extern "C" {
                                * 4: casim_options.n_streams (sub-batches on internal HIP streams), casim_enc_group_pods,
                                *    casim_enc_add_grouped_pegs, casim_enc_pod_set_spec_extra
                                * 5: casim_options.pack_build, casim_pack_build_info (two builds of the register packer + self-check),
-                               *    casim_problem_info [5], [6] */
+                               *    casim_problem_info [5], [6], casim_prefetch_* */
 
 /* Resource lanes.  Lane 0 = cpu in millicores (Quantity.MilliValue), lane 1 = memory bytes,
  * lane 2 = ephemeral-storage bytes, lanes 3.. = scalar / extended resources (Quantity.Value),
@@ -787,6 +787,45 @@ int32_t casim_enc_domain_rules(const casim_encoder* enc, casim_domain_rules* out
  * hostname anti-affinity bits after it: casim_estimate_on_cluster needs to tell them apart) */
 const uint64_t* casim_enc_port_block(const casim_encoder* enc);
 int32_t casim_enc_dict_sizes(const casim_encoder* e, int32_t sizes_out[4]);
+
+/* ======================================================================================
+ * PREFETCH CACHE of the estimator shim (host code, csrc/casim_prefetch.cpp)
+ * ======================================================================================
+ * The estimator.Estimator interface hands the estimator ONE node group per call (CA/estimator/estimator.go:53-56;
+ * ComputeExpansionOption, CA/core/scaleup/orchestrator/orchestrator.go:383-427).  The shim's NodeGroupListProcessor wrapper sees
+ * every candidate group, every template and the pending pods BEFORE that loop (orchestrator.go:121-123): it runs ONE batch over
+ * all of them (casim_prefetch_fill) and each Estimate() is a casim_prefetch_lookup.  A lookup hits only when the call asks exactly
+ * the question the batch answered: same group key, same PEG list AS A SET (keys are the caller's 64-bit identities: exemplar
+ * pod pointer, group id hash + template generation; the orchestrator's list order comes out of a Go map and only breaks score
+ * ties), same max_nodes (the limiter's answer after StartEstimation), same E and lastIndex.  Everything else returns CASIM_PREFETCH_MISS with the reason and the shim takes the per-call path (one
+ * casim_estimate_batch with one group record): the cache is an accelerator, never the source of truth.
+ * A hit may carry status CASIM_NG_UNSUPPORTED: the batch delegated that group (casim_estimate_on_cluster or the Go estimator).
+ */
+typedef struct casim_prefetch casim_prefetch;
+typedef struct casim_prefetch_result {
+    int32_t node_count, pods_scheduled, nodes_added, limiter_nodes, last_index_out, status;   /* as casim_results, one group */
+    int64_t req_cpu_sum, req_mem_sum;
+    int32_t n_pegs;        /* entries written to order_out / placed_out (= the PEG list's length) */
+    int32_t miss_reason;   /* CASIM_PREFETCH_MISS_* when the call returned CASIM_PREFETCH_MISS */
+} casim_prefetch_result;
+#define CASIM_PREFETCH_MISS 64          /* return value of casim_prefetch_lookup (> 0: not an error) */
+#define CASIM_PREFETCH_MISS_GROUP 1     /* the batch did not hold this node group (processor not installed, group added since) */
+#define CASIM_PREFETCH_MISS_PEGS 2      /* the PEG list differs from the group's schedulable subset of the batch */
+#define CASIM_PREFETCH_MISS_LIMITS 3    /* max_nodes / existing_nodes / last_index differ from what the batch ran with */
+casim_prefetch* casim_prefetch_create(casim_ctx* ctx);
+void casim_prefetch_destroy(casim_prefetch* p);
+void casim_prefetch_clear(casim_prefetch* p);   /* a new loop iteration: forget the previous batch */
+const char* casim_prefetch_error(const casim_prefetch* p);
+/* One batch over every PEG (peg_key[G]) and every group (group_key[NG]); groups->peg_offsets == NULL lets the device derive the
+ * schedulable subsets (SchedulablePodGroups), an explicit CSR keeps the caller's lists.  Replaces the cache's content. */
+int32_t casim_prefetch_fill(casim_prefetch* p, const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts,
+                            const uint64_t* group_key, const uint64_t* peg_key);
+/* order_out[k] = position IN THE CALLER'S LIST of the PEG processed k-th, placed_out[k] = how many of its pods were scheduled
+ * (Estimate()'s []*Pod = concat_k list[order_out[k]].Pods[0:placed_out[k]]); both [n_pegs], may be NULL. */
+int32_t casim_prefetch_lookup(casim_prefetch* p, uint64_t group_key, const uint64_t* peg_keys, int32_t n_pegs, int32_t max_nodes,
+                              int32_t existing_nodes, int32_t last_index, casim_prefetch_result* out, int32_t* order_out, int32_t* placed_out);
+/* out[0] fills, [1] groups cached in total, [2] hits, [3] misses: unknown group, [4] misses: PEG list, [5] misses: limits */
+int32_t casim_prefetch_stats(const casim_prefetch* p, int64_t out[8]);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,199 @@
+package gpubinpacking
+
+/*
+#include <stdlib.h>
+#include "casim.h"
+*/
+import "C"
+
+import (
+	apiv1 "k8s.io/api/core/v1"
+	metav1 "k8s.io/apimachinery/pkg/apis/meta/v1"
+	"k8s.io/autoscaler/cluster-autoscaler/estimator"
+	"k8s.io/autoscaler/cluster-autoscaler/simulator/framework"
+	podutils "k8s.io/autoscaler/cluster-autoscaler/utils/pod"
+	schedutil "k8s.io/kubernetes/pkg/scheduler/util"
+)
+
+// session is one casim_encoder: pod specs and node templates in, flat tables out (casim_enc_tables).
+type session struct {
+	enc  *C.casim_encoder
+	strs cstrings
+	spec map[*apiv1.Pod]C.int32_t // exemplar pod -> pod-spec id of this session
+}
+
+func newSession() *session {
+	var o C.casim_encoder_options
+	o.n_res = 3 // cpu (milli), memory (bytes), ephemeral storage (bytes); extended resources are appended by the caller
+	return &session{enc: C.casim_enc_create(&o), spec: map[*apiv1.Pod]C.int32_t{}}
+}
+
+func (s *session) close() {
+	if s.enc != nil {
+		C.casim_enc_destroy(s.enc)
+		s.enc = nil
+	}
+	s.strs.free()
+}
+
+func (s *session) selector(sel *metav1.LabelSelector, add func(key, op *C.char, vals **C.char, n C.int32_t)) {
+	if sel == nil {
+		return
+	}
+	for k, v := range sel.MatchLabels {
+		add(s.strs.s(k), s.strs.s("In"), s.strs.arr([]string{v}), 1)
+	}
+	for _, r := range sel.MatchExpressions {
+		add(s.strs.s(r.Key), s.strs.s(string(r.Operator)), s.strs.arr(r.Values), C.int32_t(len(r.Values)))
+	}
+}
+
+// pod encodes what the Filter plugins read from the exemplar pod: NodeResourcesFit.PreFilter (computePodResourceRequest,
+// vendor/k8s.io/kubernetes/pkg/scheduler/framework/plugins/noderesources/fit.go:321-331), TaintToleration, NodeAffinity /
+// nodeSelector, NodePorts, InterPodAffinity, PodTopologySpread (SURVEY 8b "inputs the shim must extract").
+func (s *session) pod(pod *apiv1.Pod) C.int32_t {
+	if id, ok := s.spec[pod]; ok {
+		return id
+	}
+	e, c := s.enc, &s.strs
+	req := podutils.PodRequests(pod) // cluster-autoscaler/utils/pod/pod.go:88
+	lanes := [C.CASIM_MAX_RES]C.int64_t{C.int64_t(req.Cpu().MilliValue()), C.int64_t(req.Memory().Value()), C.int64_t(req.StorageEphemeral().Value())}
+	id := C.casim_enc_add_pod_spec(e, c.s(pod.Namespace), &lanes[0])
+	s.spec[pod] = id
+	for k, v := range pod.Labels {
+		C.casim_enc_pod_add_label(e, id, c.s(k), c.s(v))
+	}
+	for _, t := range pod.Spec.Tolerations {
+		C.casim_enc_pod_add_toleration(e, id, c.s(t.Key), c.s(string(t.Operator)), c.s(t.Value), c.s(string(t.Effect)))
+	}
+	for k, v := range pod.Spec.NodeSelector {
+		C.casim_enc_pod_add_node_selector(e, id, c.s(k), c.s(v))
+	}
+	for _, p := range schedutil.GetHostPorts(pod) {
+		C.casim_enc_pod_add_host_port(e, id, c.s(p.HostIP), c.s(string(p.Protocol)), C.int32_t(p.HostPort))
+	}
+	if a := pod.Spec.Affinity; a != nil {
+		if a.PodAffinity != nil {
+			for _, term := range a.PodAffinity.RequiredDuringSchedulingIgnoredDuringExecution {
+				t := C.casim_enc_pod_add_affinity_term(e, id, c.s(term.TopologyKey), c.arr(term.Namespaces), C.int32_t(len(term.Namespaces)))
+				if term.NamespaceSelector != nil { // affinity terms with a namespaceSelector are outside the encoded subset
+					C.casim_enc_pod_mark_unsupported(e, id, c.s("pod affinity with a namespaceSelector"))
+				}
+				s.selector(term.LabelSelector, func(k, op *C.char, v **C.char, n C.int32_t) { C.casim_enc_aff_term_add_requirement(e, id, t, k, op, v, n) })
+			}
+		}
+		if a.PodAntiAffinity != nil {
+			for _, term := range a.PodAntiAffinity.RequiredDuringSchedulingIgnoredDuringExecution {
+				t := C.casim_enc_pod_add_anti_affinity_term(e, id, c.s(term.TopologyKey), c.arr(term.Namespaces), C.int32_t(len(term.Namespaces)))
+				if term.NamespaceSelector != nil { // resolved by casim_enc_finalize against the namespaces fed with casim_enc_add_namespace
+					C.casim_enc_term_set_namespace_selector(e, id, t)
+					s.selector(term.NamespaceSelector, func(k, op *C.char, v **C.char, n C.int32_t) {
+						C.casim_enc_term_add_namespace_requirement(e, id, t, k, op, v, n)
+					})
+				}
+				s.selector(term.LabelSelector, func(k, op *C.char, v **C.char, n C.int32_t) { C.casim_enc_term_add_requirement(e, id, t, k, op, v, n) })
+			}
+		}
+		if na := a.NodeAffinity; na != nil && na.RequiredDuringSchedulingIgnoredDuringExecution != nil {
+			terms := na.RequiredDuringSchedulingIgnoredDuringExecution.NodeSelectorTerms
+			if len(terms) == 0 { // a selector without terms matches nothing
+				C.casim_enc_pod_add_node_affinity_term(e, id)
+			}
+			for _, term := range terms {
+				t := C.casim_enc_pod_add_node_affinity_term(e, id)
+				for _, r := range term.MatchExpressions {
+					C.casim_enc_node_term_add_requirement(e, id, t, 0, c.s(r.Key), c.s(string(r.Operator)), c.arr(r.Values), C.int32_t(len(r.Values)))
+				}
+				for _, r := range term.MatchFields {
+					C.casim_enc_node_term_add_requirement(e, id, t, 1, c.s(r.Key), c.s(string(r.Operator)), c.arr(r.Values), C.int32_t(len(r.Values)))
+				}
+			}
+		}
+	}
+	for _, tc := range pod.Spec.TopologySpreadConstraints {
+		if tc.WhenUnsatisfiable != apiv1.DoNotSchedule { // ScheduleAnyway only scores
+			continue
+		}
+		minDomains := C.int32_t(0)
+		if tc.MinDomains != nil {
+			minDomains = C.int32_t(*tc.MinDomains)
+		}
+		ci := C.casim_enc_pod_add_spread_constraint(e, id, C.int32_t(tc.MaxSkew), c.s(tc.TopologyKey), minDomains)
+		if tc.NodeTaintsPolicy != nil && *tc.NodeTaintsPolicy == apiv1.NodeInclusionPolicyHonor {
+			C.casim_enc_spread_set_taints_policy(e, id, ci, 1)
+		}
+		if tc.NodeAffinityPolicy != nil && *tc.NodeAffinityPolicy == apiv1.NodeInclusionPolicyIgnore {
+			C.casim_enc_spread_set_affinity_policy(e, id, ci, 0)
+		}
+		s.selector(tc.LabelSelector, func(k, op *C.char, v **C.char, n C.int32_t) { C.casim_enc_spread_add_requirement(e, id, ci, k, op, v, n) })
+		for _, k := range tc.MatchLabelKeys { // the pod's own values join the selector (podtopologyspread/common.go:96-107)
+			if v, ok := pod.Labels[k]; ok && tc.LabelSelector != nil {
+				C.casim_enc_spread_add_requirement(e, id, ci, c.s(k), c.s("In"), c.arr([]string{v}), 1)
+			}
+		}
+	}
+	if hasVolumesOrClaims(pod) {
+		C.casim_enc_pod_mark_unsupported(e, id, c.s("volumes / DRA"))
+	}
+	if len(pod.Spec.Containers) > 0 { // the fastpath chooser reads the FIRST container (binpacking_estimator.go:451-458)
+		r := pod.Spec.Containers[0].Resources.Requests
+		C.casim_enc_pod_set_fastpath_requests(e, id, C.double(r.Cpu().AsApproximateFloat64()), C.double(r.Memory().AsApproximateFloat64()))
+	}
+	return id
+}
+
+func hasVolumesOrClaims(pod *apiv1.Pod) bool {
+	for _, v := range pod.Spec.Volumes {
+		if v.PersistentVolumeClaim != nil || v.Ephemeral != nil || v.CSI != nil {
+			return true
+		}
+	}
+	return len(pod.Spec.ResourceClaims) > 0
+}
+
+// peg adds one PodEquivalenceGroup: exemplar + size.
+func (s *session) peg(g estimator.PodEquivalenceGroup) C.int32_t {
+	return C.casim_enc_add_peg(s.enc, s.pod(g.Exemplar()), C.int32_t(len(g.Pods)))
+}
+
+// group adds one node group: the template the estimator clones for every simulated node (SanitizedNodeInfo,
+// cluster-autoscaler/simulator/node_info_utils.go:93-137) with the DaemonSet pods preloaded on it, the limiter's answer,
+// the snapshot's node count E and the runner's lastIndex.  pegs == nil: SchedulablePodGroups is derived on the device.
+func (s *session) group(tmpl *framework.NodeInfo, maxNodes, existing, lastIndex int, pegs []C.int32_t) C.int32_t {
+	node, c := tmpl.Node(), &s.strs
+	al := node.Status.Allocatable
+	lanes := [C.CASIM_MAX_RES]C.int64_t{C.int64_t(al.Cpu().MilliValue()), C.int64_t(al.Memory().Value()), C.int64_t(al.StorageEphemeral().Value())}
+	unsched := C.int32_t(0)
+	if node.Spec.Unschedulable {
+		unsched = 1
+	}
+	g := C.casim_enc_add_group(s.enc, c.s(node.Name), &lanes[0], C.int32_t(al.Pods().Value()),
+		C.int64_t(node.Status.Capacity.Cpu().MilliValue()), C.int64_t(node.Status.Capacity.Memory().Value()), unsched)
+	for k, v := range node.Labels {
+		C.casim_enc_group_add_label(s.enc, g, c.s(k), c.s(v))
+	}
+	for _, t := range node.Spec.Taints {
+		C.casim_enc_group_add_taint(s.enc, g, c.s(t.Key), c.s(t.Value), c.s(string(t.Effect)))
+	}
+	C.casim_enc_group_set_fastpath_capacity(s.enc, g, C.double(node.Status.Capacity.Cpu().AsApproximateFloat64()), C.double(node.Status.Capacity.Memory().AsApproximateFloat64()))
+	C.casim_enc_group_set_limits(s.enc, g, C.int32_t(maxNodes), C.int32_t(existing), C.int32_t(lastIndex))
+	for _, pi := range tmpl.Pods() {
+		C.casim_enc_group_add_preloaded_pod(s.enc, g, s.pod(pi.Pod))
+	}
+	if pegs != nil {
+		var p *C.int32_t
+		if len(pegs) > 0 {
+			p = &pegs[0]
+		}
+		C.casim_enc_group_set_pegs(s.enc, g, p, C.int32_t(len(pegs)))
+	}
+	return g
+}
+
+func (s *session) tables() (pegs C.casim_pegs, groups C.casim_groups, err error) {
+	if err = rcErr(C.casim_enc_finalize(s.enc), "casim_enc_finalize"); err != nil {
+		return
+	}
+	err = rcErr(C.casim_enc_tables(s.enc, &pegs, &groups), "casim_enc_tables")
+	return
+}

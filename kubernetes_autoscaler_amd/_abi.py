@@ -64,6 +64,16 @@ class Groups(C.Structure):
     ]
 
 
+class PrefetchResult(C.Structure):
+    _fields_ = [("node_count", C.c_int32), ("pods_scheduled", C.c_int32), ("nodes_added", C.c_int32), ("limiter_nodes", C.c_int32),
+                ("last_index_out", C.c_int32), ("status", C.c_int32), ("req_cpu_sum", C.c_int64), ("req_mem_sum", C.c_int64),
+                ("n_pegs", C.c_int32), ("miss_reason", C.c_int32)]
+
+
+PREFETCH_MISS = 64
+PREFETCH_MISS_GROUP, PREFETCH_MISS_PEGS, PREFETCH_MISS_LIMITS = 1, 2, 3
+
+
 class Options(C.Structure):
     _fields_ = [("fastpath", C.c_int32), ("force_generic_packer", C.c_int32), ("node_pods", C.c_int32), ("n_streams", C.c_int32), ("pack_build", C.c_int32), ("reserved", C.c_int32 * 3)]
 
@@ -173,6 +183,13 @@ PROTOTYPES = {
     "casim_time_node_removals": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(RemovalCandidates), C.c_int32,
                                              C.POINTER(C.c_float)]),
     "casim_pack_build_info": (C.c_int32, [C.c_int32, i32p]),
+    "casim_prefetch_create": (C.c_void_p, [C.c_void_p]),
+    "casim_prefetch_destroy": (None, [C.c_void_p]),
+    "casim_prefetch_clear": (None, [C.c_void_p]),
+    "casim_prefetch_error": (C.c_char_p, [C.c_void_p]),
+    "casim_prefetch_fill": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(Options), u64p, u64p]),
+    "casim_prefetch_lookup": (C.c_int32, [C.c_void_p, C.c_uint64, u64p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(PrefetchResult), i32p, i32p]),
+    "casim_prefetch_stats": (C.c_int32, [C.c_void_p, i64p]),
     "casim_copy_bandwidth": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, f64p]),
     "casim_stream_probe": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, f64p]),
     "casim_enc_create": (C.c_void_p, [C.POINTER(EncoderOptions)]),

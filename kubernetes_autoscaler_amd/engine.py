@@ -607,3 +607,57 @@ def estimate_batch(ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, fastpath:
     with Problem(ctx, pegs, groups, fastpath) as p:
         p.run()
         return p.fetch()
+
+
+class PrefetchCache:
+    """casim_prefetch_*: one batch over every candidate node group (fill), one lookup per Estimate()."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self._h = lib.casim_prefetch_create(ctx._h)
+        if not self._h:
+            raise CasimError(_abi.ERR_INVALID, "casim_prefetch_create failed")
+
+    def close(self):
+        if self._h:
+            lib.casim_prefetch_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def clear(self):
+        lib.casim_prefetch_clear(self._h)
+
+    def fill(self, pegs: _abi.Pegs, groups: _abi.Groups, group_keys, peg_keys, fastpath: bool = False):
+        gk = np.ascontiguousarray(group_keys, np.uint64); pk = np.ascontiguousarray(peg_keys, np.uint64)
+        if gk.shape[0] != groups.n_groups or pk.shape[0] != pegs.n_pegs:
+            raise ValueError("one key per group and per PEG")
+        opts = _abi.Options(fastpath=int(fastpath))
+        rc = lib.casim_prefetch_fill(self._h, C.byref(pegs), C.byref(groups), C.byref(opts), gk.ctypes.data_as(_abi.u64p), pk.ctypes.data_as(_abi.u64p))
+        if rc != 0:
+            raise CasimError(rc, (lib.casim_prefetch_error(self._h) or b"").decode())
+
+    def lookup(self, group_key: int, peg_keys, max_nodes: int, existing_nodes: int, last_index: int):
+        """(hit, dict): hit -> node_count, pods_scheduled, ..., order (positions in the caller's PEG list), placed; miss -> {'miss_reason'}."""
+        pk = np.ascontiguousarray(peg_keys, np.uint64)
+        n = int(pk.shape[0])
+        r = _abi.PrefetchResult()
+        order = np.zeros(max(n, 1), np.int32); placed = np.zeros(max(n, 1), np.int32)
+        rc = lib.casim_prefetch_lookup(self._h, C.c_uint64(int(group_key)), pk.ctypes.data_as(_abi.u64p), n, int(max_nodes), int(existing_nodes), int(last_index),
+                                       C.byref(r), order.ctypes.data_as(_abi.i32p), placed.ctypes.data_as(_abi.i32p))
+        if rc == _abi.PREFETCH_MISS:
+            return False, {"miss_reason": int(r.miss_reason)}
+        if rc != 0:
+            raise CasimError(rc, "casim_prefetch_lookup")
+        out = {f: int(getattr(r, f)) for f, _ in _abi.PrefetchResult._fields_}
+        out["order"] = order[:n].copy(); out["placed"] = placed[:n].copy()
+        return True, out
+
+    def stats(self):
+        out = (C.c_int64 * 8)()
+        lib.casim_prefetch_stats(self._h, out)
+        return {"fills": out[0], "groups_cached": out[1], "hits": out[2], "miss_group": out[3], "miss_pegs": out[4], "miss_limits": out[5]}

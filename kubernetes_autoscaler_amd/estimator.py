@@ -200,7 +200,8 @@ class BinpackingNodeEstimator:
     def __init__(self, engine_ctx: Context, cluster_snapshot: ClusterSnapshotView, limiter: ThresholdBasedEstimationLimiter,
                  pod_orderer: Optional[DecreasingPodOrderer] = None, context: Optional[EstimationContext] = None,
                  estimation_analyser_func: Optional[Callable] = None, fastpath_binpacking_enabled: bool = False,
-                 lanes: Sequence[str] = ("cpu", "memory"), fallback: Optional[Callable] = None):
+                 lanes: Sequence[str] = ("cpu", "memory"), fallback: Optional[Callable] = None, prefetch: Optional["PrefetchShared"] = None):
+        self.prefetch = prefetch   # filled by PrefetchNodeGroupListProcessor.process before the orchestrator's loops
         self.engine_ctx = engine_ctx
         self.snapshot = cluster_snapshot
         self.limiter = limiter
@@ -215,6 +216,15 @@ class BinpackingNodeEstimator:
         """Estimate  binpacking_estimator.go:102-161: (node count, pods that fit, in placement order)."""
         self.limiter.start_estimation(pegs, node_group, self.context)
         try:
+            if self.prefetch is not None and self.analyser is None:   # (the analyser wants the pods per node: per-call path)
+                hit = self.prefetch.lookup(pegs, node_template, node_group, self.limiter.device_max_nodes(), len(self.snapshot.existing))
+                if hit is not None and hit["status"] == 0:
+                    pods = []
+                    for k, n in zip(hit["order"], hit["placed"]):
+                        pods.extend(pegs[int(k)].pods[:int(n)])
+                    self.limiter.nodes = hit["limiter_nodes"]
+                    return hit["node_count"], pods
+                # miss (another PEG subset, another limiter answer, unknown group) or a delegated group: the per-call path below
             enc = Encoder(lanes=self.lanes)
             ids = [enc.add_peg(pg) for pg in pegs]
             for info in self.snapshot.existing:
@@ -267,7 +277,80 @@ class BinpackingNodeEstimator:
         return out["node_count"], pods
 
 
-def new_estimator_builder(name: str, limiter, orderer=None, analyser=None, fastpath: bool = False, engine_ctx: Optional[Context] = None):
+class PrefetchShared:
+    """What the shim's NodeGroupListProcessor wrapper and its estimators share (gpubinpacking.shared in integration/go): the
+    prefetch cache and the identities the keys are made of.  Keys: a PEG is its exemplar pod object (the orchestrator passes the
+    same *PodEquivalenceGroup values to every Estimate of a loop), a node group is (Id(), identity of its template NodeInfo).
+    Every group of a batch is estimated from the lastIndex the snapshot's runner has when the batch is filled — the estimators
+    of a prefetched loop do not thread lastIndex from one group into the next (the per-call path does)."""
+
+    def __init__(self, engine_ctx: Context, limiter: "ThresholdBasedEstimationLimiter", max_nodes_total: int = 0, fastpath: bool = False,
+                 lanes: Sequence[str] = ("cpu", "memory")):
+        from .engine import PrefetchCache
+        self.ctx, self.limiter, self.max_nodes_total, self.fastpath, self.lanes = engine_ctx, limiter, max_nodes_total, fastpath, lanes
+        self.cache = PrefetchCache(engine_ctx)
+        self.loop_last_index = 0
+
+    def close(self):
+        self.cache.close()
+
+    @staticmethod
+    def peg_key(pg: PodEquivalenceGroup) -> int:
+        return id(pg.pods[0]) & 0xFFFFFFFFFFFFFFFF
+
+    @staticmethod
+    def group_key(node_group, template: NodeInfo) -> int:
+        return hash((node_group.id(), id(template))) & 0xFFFFFFFFFFFFFFFF
+
+    def fill(self, pegs: List[PodEquivalenceGroup], node_groups, node_infos, snapshot: ClusterSnapshotView, similar_node_groups=None):
+        """ONE casim_estimate_batch over every PEG and every candidate group; SchedulablePodGroups on the device."""
+        similar_node_groups = similar_node_groups or {}
+        self.loop_last_index = snapshot.last_index
+        enc = Encoder(lanes=self.lanes)
+        for pg in pegs:
+            enc.add_peg(pg)
+        for info in snapshot.existing:
+            for p in info.pods:
+                enc.add_existing_pod(p, info.node.labels)
+        gkeys = []
+        for ng in node_groups:
+            context = EstimationContext(self.max_nodes_total, list(similar_node_groups.get(ng.id(), [])), len(snapshot.existing))
+            self.limiter.start_estimation(pegs, ng, context)   # the reference's own limiter decides max_nodes (threshold_based_limiter.go:34-43)
+            enc.add_group(node_infos[ng.id()], max_nodes=self.limiter.device_max_nodes(), existing_nodes=len(snapshot.existing),
+                          last_index=snapshot.last_index, pegs=None)
+            self.limiter.end_estimation()
+            gkeys.append(self.group_key(ng, node_infos[ng.id()]))
+        enc.finalize()
+        try:
+            self.cache.fill(enc.pegs, enc.groups, gkeys, [self.peg_key(pg) for pg in pegs], self.fastpath)
+        finally:
+            enc.close()
+
+    def lookup(self, pegs, node_template, node_group, max_nodes: int, existing_nodes: int):
+        hit, out = self.cache.lookup(self.group_key(node_group, node_template), [self.peg_key(pg) for pg in pegs], max_nodes, existing_nodes,
+                                     self.loop_last_index)
+        return out if hit else None
+
+
+class PrefetchNodeGroupListProcessor:
+    """gpubinpacking.WrapNodeGroupListProcessor: processors.NodeGroupListProcessor.Process sees every candidate node group, every
+    template NodeInfo and the pending pods before ScaleUp's two loops run (CA/core/scaleup/orchestrator/orchestrator.go:121-123);
+    the wrapper lets the inner processor answer, then fills the shared cache with one batch."""
+
+    def __init__(self, inner, shared: PrefetchShared, build_pod_groups: Callable):
+        self.inner, self.shared, self.build_pod_groups = inner, shared, build_pod_groups
+        self.pegs: List[PodEquivalenceGroup] = []
+
+    def process(self, snapshot: ClusterSnapshotView, node_groups, node_infos, unschedulable_pods):
+        if self.inner is not None:
+            node_groups, node_infos = self.inner.process(snapshot, node_groups, node_infos, unschedulable_pods)
+        self.pegs = self.build_pod_groups(unschedulable_pods)   # equivalence.BuildPodGroups: the groups the orchestrator will pass on
+        self.shared.fill(self.pegs, node_groups, node_infos, snapshot)
+        return node_groups, node_infos
+
+
+def new_estimator_builder(name: str, limiter, orderer=None, analyser=None, fastpath: bool = False, engine_ctx: Optional[Context] = None,
+                          prefetch: Optional[PrefetchShared] = None):
     """NewEstimatorBuilder  estimator.go:62-77: returns func(clusterSnapshot, context) Estimator."""
     if name != GPU_BINPACKING_ESTIMATOR_NAME:
         raise ValueError(f"unknown estimator: {name} (this package provides only {GPU_BINPACKING_ESTIMATOR_NAME})")
@@ -275,5 +358,5 @@ def new_estimator_builder(name: str, limiter, orderer=None, analyser=None, fastp
         engine_ctx = Context(0)
 
     def builder(cluster_snapshot: ClusterSnapshotView, context: EstimationContext):
-        return BinpackingNodeEstimator(engine_ctx, cluster_snapshot, limiter, orderer, context, analyser, fastpath)
+        return BinpackingNodeEstimator(engine_ctx, cluster_snapshot, limiter, orderer, context, analyser, fastpath, prefetch=prefetch)
     return builder

@@ -99,3 +99,19 @@ def test_native_try_schedule_and_removals_match_the_oracle(tmp_path):
         if int(d["tail"][0]) == 0:
             assert list(d["removable"]) == list(want.removable), seed
             assert list(d["node_out"]) == list(want.node_out), seed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["C2", "C4", "C1"])
+def test_native_replay_of_the_estimator_shim_call_sequence(tmp_path, name):
+    """both modes of INTEGRATION 1a in plain C++ over the C ABI (tools/casim_native --shim) — prefetch fill, one
+    lookup per group that must equal the per-call answer, a reordered list (hit, positions in the caller's order) and every miss path
+    (another PEG subset, a PEG twice, limiter, lastIndex, unknown group, cleared cache)."""
+    w = workloads.CONFIGS[name]()
+    path = str(tmp_path / "t.trace")
+    nt.trace_estimate(w, path, kinds=(0,), iters=1).close()
+    rc, out = nt.run_native(path, repeat=1, shim=True)
+    assert rc == 0, out
+    s = out["shim"]
+    assert s["groups"] == len(w.groups) and s["hits"] == s["hits_equal_to_per_call"] == len(w.groups) and s["miss_paths_checked"] == 1 and s["failed_checks"] == 0, s
+    assert s["stats"][0] == 1 and s["stats"][2] == len(w.groups) + 2 and s["stats"][3] == 2 and s["stats"][4] == 2 and s["stats"][5] == 2, s

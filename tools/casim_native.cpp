@@ -227,15 +227,157 @@ void dump_i32(FILE* f, const char* tag, const std::vector<int32_t>& a) {
 }
 template <class T> double median(std::vector<T> v) { if (v.empty()) return 0; std::sort(v.begin(), v.end()); return (double)v[v.size() / 2]; }
 
+
+// ---- the estimator shim's call sequence, replayed in plain C++ ----------------------------------------------------
+// What integration/go/gpubinpacking/{prefetch,estimator}.go do over cgo, call for call: the NodeGroupListProcessor wrapper fills ONE
+// batch (casim_prefetch_fill); then, group by group in the orchestrator's order, Estimate() = casim_prefetch_lookup with the PEG list
+// the orchestrator passes (SchedulablePodGroups' result), and on a miss the per-call path (one casim_estimate_batch with one group
+// record and that list).  Checked here: every hit equals the per-call answer field by field, and each miss path reports its reason.
+struct OneGroup { int32_t v[6]; int64_t sums[2]; std::vector<int32_t> order, placed; };
+casim_groups group_view(const casim_pegs& p, const casim_groups& g, int i) {
+    casim_groups w = g;
+    const int64_t R = p.n_res;
+    auto at = [&](auto* ptr, int64_t off) { return ptr ? ptr + off : ptr; };
+    w.n_groups = 1;
+    w.alloc = at(g.alloc, i * R); w.init_req = at(g.init_req, i * R); w.allowed_pods = at(g.allowed_pods, i); w.init_pods = at(g.init_pods, i); w.flags = at(g.flags, i);
+    w.taint_mask = at(g.taint_mask, (int64_t)i * p.w_taint); w.label_mask = at(g.label_mask, (int64_t)i * p.w_label); w.init_excl = at(g.init_excl, (int64_t)i * p.w_excl);
+    w.init_zone = at(g.init_zone, (int64_t)i * p.w_zone); w.zone_valid = at(g.zone_valid, (int64_t)i * p.w_zone);
+    w.max_nodes = at(g.max_nodes, i); w.existing_nodes = at(g.existing_nodes, i); w.last_index = at(g.last_index, i);
+    w.cap_cpu = at(g.cap_cpu, i); w.cap_mem = at(g.cap_mem, i); w.waste_cpu = at(g.waste_cpu, i); w.waste_mem = at(g.waste_mem, i);
+    w.peg_lo = w.peg_hi = w.global_id = nullptr; w.n_sims = 0; w.sim_offsets = nullptr;
+    return w;
+}
+// per-call mode: ONE Estimate() = one casim_estimate_batch with one group record and the caller's PEG list; order as positions in that list
+int32_t per_call(casim_ctx* ctx, const casim_pegs& p, const casim_groups& g, int i, const std::vector<int32_t>& list, int32_t max_nodes, const casim_options& opt, OneGroup& out) {
+    casim_groups w = group_view(p, g, i);
+    const int32_t off[2] = {0, (int32_t)list.size()};
+    const int32_t mn[1] = {max_nodes};
+    w.peg_offsets = off; w.peg_index = list.data(); w.max_nodes = mn;
+    const size_t n = list.size();
+    out.order.assign(n + 1, 0); out.placed.assign(n + 1, 0);
+    casim_results r; memset(&r, 0, sizeof r);
+    r.node_count = &out.v[0]; r.pods_scheduled = &out.v[1]; r.nodes_added = &out.v[2]; r.limiter_nodes = &out.v[3]; r.last_index_out = &out.v[4]; r.status = &out.v[5];
+    r.req_cpu_sum = &out.sums[0]; r.req_mem_sum = &out.sums[1]; r.order = out.order.data(); r.placed = out.placed.data();
+    const int32_t rc = casim_estimate_batch(ctx, &p, &w, &opt, &r);
+    out.order.resize(n); out.placed.resize(n);
+    std::vector<int32_t> pos((size_t)p.n_pegs, -1);
+    for (size_t k = 0; k < n; ++k) pos[(size_t)list[k]] = (int32_t)k;
+    for (size_t k = 0; k < n; ++k) out.order[k] = pos[(size_t)out.order[k]];
+    return rc;
+}
+// returns the number of failed checks; prints one JSON member
+int shim_replay(casim_ctx* ctx, const casim_pegs& pegs, const casim_groups& groups, int fastpath) {
+    const int NG = groups.n_groups, G = pegs.n_pegs;
+    casim_options opt; memset(&opt, 0, sizeof opt); opt.fastpath = fastpath;
+    int bad = 0;
+    auto fail = [&](const char* what, int i) { if (bad < 8) fprintf(stderr, "casim_native --shim: %s (group %d)\n", what, i); ++bad; };
+    // the orchestrator's SchedulablePodGroups lists (here: the device's own subsets, ascending PEG id = the order of the caller's list)
+    std::vector<std::vector<int32_t>> lists((size_t)NG);
+    {
+        casim_problem* pr = casim_problem_create(ctx, &pegs, &groups, &opt);
+        if (!pr) { printf(", \"shim\": {\"error\": \"%s\"}", casim_last_error()); return 1; }
+        casim_problem_run(pr);
+        int32_t nnz = 0; std::vector<int32_t> off((size_t)NG + 1);
+        casim_problem_csr(pr, &nnz, off.data());
+        std::vector<int32_t> a((size_t)NG * 6 + 1), order((size_t)nnz + 1), placed((size_t)nnz + 1); std::vector<int64_t> sums((size_t)NG * 2 + 1);
+        casim_results r; memset(&r, 0, sizeof r);
+        r.node_count = a.data(); r.pods_scheduled = a.data() + NG; r.nodes_added = a.data() + 2 * NG; r.limiter_nodes = a.data() + 3 * NG; r.last_index_out = a.data() + 4 * NG;
+        r.status = a.data() + 5 * NG; r.req_cpu_sum = sums.data(); r.req_mem_sum = sums.data() + NG; r.order = order.data(); r.placed = placed.data();
+        casim_problem_fetch(pr, &r);
+        casim_problem_destroy(pr);
+        for (int i = 0; i < NG; ++i) {
+            lists[(size_t)i].assign(order.begin() + off[(size_t)i], order.begin() + off[(size_t)i + 1]);
+            if (groups.peg_offsets) lists[(size_t)i].assign(groups.peg_index + groups.peg_offsets[i], groups.peg_index + groups.peg_offsets[i + 1]);
+            else std::sort(lists[(size_t)i].begin(), lists[(size_t)i].end());
+        }
+    }
+    // keys: opaque 64-bit identities (the Go side hashes the exemplar pod pointer / the group id + template generation)
+    std::vector<uint64_t> gkey((size_t)NG), pkey((size_t)G);
+    for (int i = 0; i < NG; ++i) gkey[(size_t)i] = 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
+    for (int g = 0; g < G; ++g) pkey[(size_t)g] = 0xC2B2AE3D27D4EB4Full * (uint64_t)(g + 1);
+    auto keys_of = [&](const std::vector<int32_t>& l) { std::vector<uint64_t> k(l.size()); for (size_t j = 0; j < l.size(); ++j) k[j] = pkey[(size_t)l[j]]; return k; };
+    casim_prefetch* pf = casim_prefetch_create(ctx);
+    const auto tf = clk::now();
+    int32_t rc = casim_prefetch_fill(pf, &pegs, &groups, &opt, gkey.data(), pkey.data());   // ---- NodeGroupListProcessor.Process
+    const double fill_ms = ms_since(tf);
+    if (rc != 0) { printf(", \"shim\": {\"error\": \"fill %d %s\"}", rc, casim_prefetch_error(pf)); casim_prefetch_destroy(pf); return 1; }
+    int hits = 0, equal = 0; double lookup_ms = 0, percall_ms = 0;
+    for (int i = 0; i < NG; ++i) {                                                         // ---- ComputeExpansionOption, group by group
+        const std::vector<int32_t>& l = lists[(size_t)i];
+        std::vector<uint64_t> k = keys_of(l);
+        std::vector<int32_t> order(l.size() + 1), placed(l.size() + 1);
+        casim_prefetch_result r;
+        const auto t0 = clk::now();
+        rc = casim_prefetch_lookup(pf, gkey[(size_t)i], k.data(), (int32_t)k.size(), groups.max_nodes[i], groups.existing_nodes[i], groups.last_index[i], &r, order.data(), placed.data());
+        lookup_ms += ms_since(t0);
+        if (rc != CASIM_OK) { fail("expected a hit", i); continue; }
+        ++hits;
+        OneGroup pc;
+        const auto t1 = clk::now();
+        if (per_call(ctx, pegs, groups, i, l, groups.max_nodes[i], opt, pc) != 0) { fail("per-call estimate failed", i); continue; }
+        percall_ms += ms_since(t1);
+        order.resize(l.size()); placed.resize(l.size());
+        const bool same = r.node_count == pc.v[0] && r.pods_scheduled == pc.v[1] && r.nodes_added == pc.v[2] && r.limiter_nodes == pc.v[3] && r.last_index_out == pc.v[4] &&
+                          r.status == pc.v[5] && r.req_cpu_sum == pc.sums[0] && r.req_mem_sum == pc.sums[1] && (r.status != 0 || (order == pc.order && placed == pc.placed));
+        if (same) ++equal; else fail("hit differs from the per-call answer", i);
+    }
+    // ---- the miss paths, on the first group with at least two schedulable PEGs
+    int miss_checked = 0;
+    for (int i = 0; i < NG && miss_checked == 0; ++i) {
+        const std::vector<int32_t>& l = lists[(size_t)i];
+        if (l.size() < 2) continue;
+        miss_checked = 1;
+        casim_prefetch_result r; OneGroup pc;
+        std::vector<int32_t> sub(l.begin(), l.end() - 1);                                  // the orchestrator passed another subset
+        std::vector<uint64_t> k = keys_of(sub);
+        rc = casim_prefetch_lookup(pf, gkey[(size_t)i], k.data(), (int32_t)k.size(), groups.max_nodes[i], groups.existing_nodes[i], groups.last_index[i], &r, nullptr, nullptr);
+        if (rc != CASIM_PREFETCH_MISS || r.miss_reason != CASIM_PREFETCH_MISS_PEGS) fail("another PEG list must miss", i);
+        if (per_call(ctx, pegs, groups, i, sub, groups.max_nodes[i], opt, pc) != 0) fail("per-call after a PEG-list miss", i);
+        {   // the same set in another order (the orchestrator's list comes out of a Go map): a hit, positions follow the caller's list
+            std::vector<int32_t> swapped(l); std::swap(swapped[0], swapped[l.size() - 1]);
+            k = keys_of(swapped);
+            std::vector<int32_t> o1(l.size()), o2(l.size());
+            rc = casim_prefetch_lookup(pf, gkey[(size_t)i], k.data(), (int32_t)k.size(), groups.max_nodes[i], groups.existing_nodes[i], groups.last_index[i], &r, o2.data(), nullptr);
+            std::vector<uint64_t> k1 = keys_of(l);
+            const int32_t rc1 = casim_prefetch_lookup(pf, gkey[(size_t)i], k1.data(), (int32_t)k1.size(), groups.max_nodes[i], groups.existing_nodes[i], groups.last_index[i], &r, o1.data(), nullptr);
+            bool ok = rc == CASIM_OK && rc1 == CASIM_OK;
+            for (size_t j = 0; j < l.size() && ok; ++j) ok = swapped[(size_t)o2[j]] == l[(size_t)o1[j]];
+            if (!ok) fail("a reordered PEG list must hit with positions in the caller's order", i);
+        }
+        std::vector<uint64_t> dup = keys_of(l); dup[0] = dup[1];                             // not a set: one PEG twice
+        rc = casim_prefetch_lookup(pf, gkey[(size_t)i], dup.data(), (int32_t)dup.size(), groups.max_nodes[i], groups.existing_nodes[i], groups.last_index[i], &r, nullptr, nullptr);
+        if (rc != CASIM_PREFETCH_MISS || r.miss_reason != CASIM_PREFETCH_MISS_PEGS) fail("a list with a PEG twice must miss", i);
+        k = keys_of(l);
+        const int32_t other = groups.max_nodes[i] > 1 ? groups.max_nodes[i] - 1 : groups.max_nodes[i] + 1;   // the limiter answered differently
+        rc = casim_prefetch_lookup(pf, gkey[(size_t)i], k.data(), (int32_t)k.size(), other, groups.existing_nodes[i], groups.last_index[i], &r, nullptr, nullptr);
+        if (rc != CASIM_PREFETCH_MISS || r.miss_reason != CASIM_PREFETCH_MISS_LIMITS) fail("another max_nodes must miss", i);
+        if (per_call(ctx, pegs, groups, i, l, other, opt, pc) != 0) fail("per-call after a limits miss", i);
+        rc = casim_prefetch_lookup(pf, gkey[(size_t)i], k.data(), (int32_t)k.size(), groups.max_nodes[i], groups.existing_nodes[i], groups.last_index[i] + 1, &r, nullptr, nullptr);
+        if (rc != CASIM_PREFETCH_MISS || r.miss_reason != CASIM_PREFETCH_MISS_LIMITS) fail("another lastIndex must miss", i);
+        rc = casim_prefetch_lookup(pf, 0xDEADBEEFull, k.data(), (int32_t)k.size(), groups.max_nodes[i], groups.existing_nodes[i], groups.last_index[i], &r, nullptr, nullptr);
+        if (rc != CASIM_PREFETCH_MISS || r.miss_reason != CASIM_PREFETCH_MISS_GROUP) fail("an unknown group must miss", i);
+        casim_prefetch_clear(pf);                                                          // the next loop iteration
+        rc = casim_prefetch_lookup(pf, gkey[(size_t)i], k.data(), (int32_t)k.size(), groups.max_nodes[i], groups.existing_nodes[i], groups.last_index[i], &r, nullptr, nullptr);
+        if (rc != CASIM_PREFETCH_MISS || r.miss_reason != CASIM_PREFETCH_MISS_GROUP) fail("a cleared cache must miss", i);
+    }
+    int64_t st[8]; casim_prefetch_stats(pf, st);
+    casim_prefetch_destroy(pf);
+    printf(", \"shim\": {\"groups\": %d, \"hits\": %d, \"hits_equal_to_per_call\": %d, \"miss_paths_checked\": %d, \"failed_checks\": %d, \"fill_ms\": %.4f, "
+           "\"lookups_ms\": %.4f, \"per_call_ms_total\": %.4f, \"stats\": [%lld, %lld, %lld, %lld, %lld, %lld]}",
+           NG, hits, equal, miss_checked, bad, fill_ms, lookup_ms, percall_ms, (long long)st[0], (long long)st[1], (long long)st[2], (long long)st[3], (long long)st[4], (long long)st[5]);
+    return bad;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: casim_native TRACE [--device N] [--dump FILE] [--repeat K]\n"); return 2; }
-    int device = 0, repeat = 3; const char* dump = nullptr;
+    if (argc < 2) { fprintf(stderr, "usage: casim_native TRACE [--device N] [--dump FILE] [--repeat K] [--shim]\n"); return 2; }
+    int device = 0, repeat = 3; const char* dump = nullptr; bool shim = false;
     for (int i = 2; i < argc; ++i) {
         if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--dump") && i + 1 < argc) dump = argv[++i];
         else if (!strcmp(argv[i], "--repeat") && i + 1 < argc) repeat = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--shim")) shim = true;
     }
     std::vector<Call> calls; Directive dir; std::string err;
     const auto tp = clk::now();
@@ -315,6 +457,7 @@ int main(int argc, char** argv) {
                 dump_i32(df, "limiter", lim); dump_i32(df, "last_index", li); dump_i32(df, "status", st); dump_i32(df, "order", order); dump_i32(df, "placed", placed);
                 dump_i32(df, "best", std::vector<int32_t>{best, nbest});
             }
+            if (shim && shim_replay(ctx, pegs, groups, fastpath) != 0) exit_code = 5;
         } else if (dir.name == "try_schedule") {
             const int iters = (int)c.one();
             casim_pod_sequence seq; memset(&seq, 0, sizeof seq);

@@ -96,9 +96,9 @@ def trace_removals(w, path, iters=5):
     return enc, off, pcl
 
 
-def run_native(trace_path, dump=None, repeat=3, device=0, timeout=600):
-    """Runs casim_native; returns (exit code, parsed JSON)."""
-    cmd = [build(), trace_path, "--repeat", str(repeat), "--device", str(device)] + (["--dump", dump] if dump else [])
+def run_native(trace_path, dump=None, repeat=3, device=0, timeout=600, shim=False):
+    """Runs casim_native; returns (exit code, parsed JSON).  shim: also replay the estimator shim's call sequence (--shim)."""
+    cmd = [build(), trace_path, "--repeat", str(repeat), "--device", str(device)] + (["--dump", dump] if dump else []) + (["--shim"] if shim else [])
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
     line = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else "{}"
     try:
