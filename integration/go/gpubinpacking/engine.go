@@ -9,8 +9,8 @@ replayed call for call in plain C++ by tools/casim_native --shim (tests/test_nat
 which run against the oracle on the MI355X.
 
 Files: engine.go (context, errors), encode.go (pods / templates -> casim_enc_* calls), estimator.go (Estimate: prefetch
-lookup, per-call path, fallback), prefetch.go (NodeGroupListProcessor wrapper, the shared cache), estimator_go.patch (the
-one case added to estimator.NewEstimatorBuilder).
+lookup, per-call path, fallback), prefetch.go (NodeGroupListProcessor wrapper, the shared cache), builder.go (the
+EstimatorBuilder and the limiter wrapper), autoscaler_go.patch (core/autoscaler.go picks the builder by --estimator).
 */
 package gpubinpacking
 

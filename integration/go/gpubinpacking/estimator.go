@@ -16,10 +16,10 @@ import (
 	"k8s.io/autoscaler/cluster-autoscaler/simulator/framework"
 )
 
-// DeviceLimiter is what the shim needs from the reference's limiter beyond estimator.EstimationLimiter: the node limit
-// StartEstimation computed (thresholdBasedEstimationLimiter.maxNodes, threshold_based_limiter.go:34-43) — one accessor added to
-// that type by estimator_go.patch.  The duration limit stays on the host (checked between calls; the device runs with the
-// node limit only).
+// DeviceLimiter is what the shim needs from the limiter beyond estimator.EstimationLimiter: the node limit StartEstimation
+// computed (thresholdBasedEstimationLimiter.maxNodes is private, threshold_based_limiter.go:27-43; builder.go's deviceLimiter folds
+// the public thresholds with the reference's rule).  The duration limit stays on the host (checked between calls; the device
+// runs with the node limit only).
 type DeviceLimiter interface {
 	estimator.EstimationLimiter
 	MaxNodes() int // <0 forbid, 0 unlimited, >0 cap: casim_groups.max_nodes verbatim
@@ -35,7 +35,7 @@ type gpuEstimator struct {
 	fallback estimator.Estimator // the reference's BinpackingNodeEstimator: groups outside the encoded predicate subset
 }
 
-// New is what the case added to estimator.NewEstimatorBuilder returns (estimator_go.patch).
+// New is what NewEstimatorBuilder (builder.go) returns for every (snapshot, context) pair.
 func New(engine *Engine, snapshot clustersnapshot.ClusterSnapshot, limiter DeviceLimiter, context estimator.EstimationContext,
 	fastpath bool, shared *Shared, fallback estimator.Estimator) estimator.Estimator {
 	if engine == nil {

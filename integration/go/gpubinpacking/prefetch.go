@@ -13,6 +13,7 @@ import (
 	apiv1 "k8s.io/api/core/v1"
 	"k8s.io/autoscaler/cluster-autoscaler/cloudprovider"
 	ca_context "k8s.io/autoscaler/cluster-autoscaler/context"
+	coreoptions "k8s.io/autoscaler/cluster-autoscaler/core/options"
 	"k8s.io/autoscaler/cluster-autoscaler/core/scaleup/equivalence"
 	"k8s.io/autoscaler/cluster-autoscaler/estimator"
 	"k8s.io/autoscaler/cluster-autoscaler/processors/nodegroups"
@@ -31,9 +32,27 @@ type Shared struct {
 	loopLastIndex int // ... when the batch of the current loop was filled: every group of the batch starts from it
 }
 
-// NewShared is created once, next to the Engine.
-func NewShared(engine *Engine, limiter DeviceLimiter, maxNodesTotal int, fastpath bool) *Shared {
-	return &Shared{engine: engine, cache: C.casim_prefetch_create(engine.ctx), limiter: limiter, maxNodesTotal: maxNodesTotal, fastpath: fastpath}
+// EstimatorName is the --estimator value that selects this package (autoscaler_go.patch).
+const EstimatorName = "gpu-binpacking"
+
+// NewShared is created once, next to the Engine; NewEstimatorBuilder hands it the limiter.
+func NewShared(engine *Engine, maxNodesTotal int, fastpath bool) *Shared {
+	return &Shared{engine: engine, cache: C.casim_prefetch_create(engine.ctx), maxNodesTotal: maxNodesTotal, fastpath: fastpath}
+}
+
+// SimilarNodeGroups returns what ComputeSimilarNodeGroups would find for a group (orchestrator.go:395): the configured
+// NodeGroupSetProcessor when BalanceSimilarNodeGroups is on, else nothing.
+func SimilarNodeGroups(opts *coreoptions.AutoscalerOptions) func(*ca_context.AutoscalingContext, cloudprovider.NodeGroup, map[string]*framework.NodeInfo) []cloudprovider.NodeGroup {
+	return func(ctx *ca_context.AutoscalingContext, ng cloudprovider.NodeGroup, infos map[string]*framework.NodeInfo) []cloudprovider.NodeGroup {
+		if !opts.BalanceSimilarNodeGroups || opts.Processors.NodeGroupSetProcessor == nil {
+			return nil
+		}
+		similar, err := opts.Processors.NodeGroupSetProcessor.FindSimilarNodeGroups(ctx, ng, infos)
+		if err != nil {
+			return nil
+		}
+		return similar
+	}
 }
 
 // Close releases the cache.
@@ -56,7 +75,7 @@ func groupKey(ng cloudprovider.NodeGroup, tmpl *framework.NodeInfo) C.uint64_t {
 func (s *Shared) fill(autoscalingCtx *ca_context.AutoscalingContext, pegs []estimator.PodEquivalenceGroup, ngs []cloudprovider.NodeGroup,
 	infos map[string]*framework.NodeInfo, similar func(cloudprovider.NodeGroup) []cloudprovider.NodeGroup) error {
 	C.casim_prefetch_clear(s.cache)
-	if len(pegs) == 0 || len(ngs) == 0 {
+	if len(pegs) == 0 || len(ngs) == 0 || s.limiter == nil {
 		return nil
 	}
 	sess := newSession()
