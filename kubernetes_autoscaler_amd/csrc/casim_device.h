@@ -45,6 +45,9 @@ CS_DEVICE uint32_t bcast_u32(uint32_t v, int uniform_lane) { return (uint32_t)ca
 CS_DEVICE uint32_t uniform_u32(uint32_t v) { return v; }
 template <int N> struct Words { uint32_t w[N]; };
 template <int N> CS_DEVICE Words<N> const_load(const uint32_t* p) { Words<N> r; memcpy(r.w, p, 4 * N); return r; }
+struct RecBase { const char* p; };
+CS_DEVICE RecBase rec_base(const uint32_t* p) { return RecBase{(const char*)p}; }
+template <int N> CS_DEVICE Words<N> rec_load(const RecBase& b, uint32_t byte_off) { Words<N> r; memcpy(r.w, b.p + byte_off, 4 * N); return r; }
 CS_DEVICE bool lane_pred(uint64_t mask) { return ((mask >> (casim_emu::cur().tid & 63)) & 1ull) != 0; }
 CS_DEVICE void keep_scalar(uint32_t&) {}
 CS_DEVICE int32_t opaque_i32(int32_t v) { return v; }
@@ -150,6 +153,38 @@ template <int N> CS_DEVICE Words<N> const_load(const uint32_t* p) {
 #pragma unroll
         for (int i = 0; i < N; ++i) r.w[i] = v[i];
     }
+    return r;
+}
+// The same through a BUFFER resource and a 32-bit byte offset: s_buffer_load_dwordxN sdst, s[rsrc:rsrc+3], s_off.  A loop that
+// walks records then carries ONE 32-bit scalar (offset += record size; compare with the end offset) instead of a 64-bit
+// pointer plus a counter: s_add_u32 / s_addc_u32 / s_add_i32 / s_cmp / copy of the pointer pair became s_add_i32 / s_cmp — three
+// scalar instructions less per PEG step in a kernel bound by scalar issue (the compiler widens a 32-bit offset added to a
+// pointer back into 64-bit arithmetic, measured; the intrinsic keeps the offset operand as it is and still tracks lgkmcnt).
+typedef int rsrc_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x8_t __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x16_t __attribute__((ext_vector_type(16)));
+extern "C" __device__ u32x8_t casim_llvm_s_buffer_load_v8(rsrc_t, uint32_t, uint32_t) __asm("llvm.amdgcn.s.buffer.load.v8i32");
+extern "C" __device__ u32x16_t casim_llvm_s_buffer_load_v16(rsrc_t, uint32_t, uint32_t) __asm("llvm.amdgcn.s.buffer.load.v16i32");
+struct RecBase { rsrc_t r; };
+// raw buffer over [p, p + 4 GiB): stride 0, num_records 0xffffffff (bytes), gfx9 untyped 32-bit data format (word 3 = 0x00020000)
+CS_DEVICE RecBase rec_base(const uint32_t* p) {
+    const uint64_t a = (uint64_t)p;
+    RecBase b;
+    b.r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a); b.r[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)); b.r[2] = -1; b.r[3] = 0x00020000;
+    return b;
+}
+template <int N> CS_DEVICE Words<N> rec_load(const RecBase& b, uint32_t byte_off) {
+    static_assert(N == 8 || N == 16, "records are 8 or 16 dwords");
+    Words<N> r;
+    if constexpr (N == 8) { const u32x8_t v = casim_llvm_s_buffer_load_v8(b.r, byte_off, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.w[i] = v[i]; }
+    else { const u32x16_t v = casim_llvm_s_buffer_load_v16(b.r, byte_off, 0);
+        // (the 64-byte record uses 14 of its 16 dwords; the optimiser trims a load to the elements somebody reads and the backend cannot
+        // select the resulting <14 x i32>: the two spare words are "read" by an empty statement)
+        asm volatile("" : : "s"(v[14]), "s"(v[15]));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) r.w[i] = v[i]; }
     return r;
 }
 // my lane's bit of a wave-uniform lane mask as a predicate: the mask register pair IS the condition (no VALU)

@@ -505,8 +505,9 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
                     }
                 }
                 w[0] = (uint32_t)t.count[g];
+                const bool a2_ok = (flags & CASIM_KFLAG_STATIC_OK) && t.count[g] > 0;
                 w[1] = (flags & (CASIM_REC_FLAG_MASK & ~(CASIM_REC_SIMPLE | CASIM_REC_A2_OK))) | (cf << CASIM_REC_FRESH_SHIFT) | (simple ? CASIM_REC_SIMPLE : 0u) |
-                       (((flags & CASIM_KFLAG_STATIC_OK) && t.count[g] > 0) ? CASIM_REC_A2_OK : 0u);
+                       (a2_ok ? CASIM_REC_A2_OK : 0u) | ((a2_ok && simple) ? CASIM_REC_A2_SIMPLE : 0u);
                 RecQuad* out = (RecQuad*)(res.rec + (int64_t)(off + i) * DW);   // 16-byte stores (records are 32 / 64 bytes)
 #pragma unroll
                 for (int k = 0; k < DW / 4; ++k) out[k] = RecQuad{w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]};

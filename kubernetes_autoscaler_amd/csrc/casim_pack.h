@@ -479,7 +479,14 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
 #pragma unroll
     for (int r = 0; r < RM; ++r) { my_req[r] = 0; my_rq[r] = 0.0; }
     const uint32_t* recp = nullptr;          // this group's records (register store)
-    const uint32_t* rp = nullptr;            // record of the current PEG
+    // The record walk carries ONE 32-bit scalar: the byte offset of the current record inside the group's record array (a buffer
+    // resource, cs::rec_load).  The PEG index k = roff >> kRecShift is derived where a step needs it (placements, chunk edges);
+    // the common step — a PEG that fits nowhere — only adds the record size and compares with the end offset.
+    constexpr uint32_t kRecBytes = 4u * (uint32_t)(DW > 0 ? DW : 1);
+    constexpr int kRecShift = DW == 16 ? 6 : 5;
+    cs::RecBase rbase;
+    uint32_t roff = 0;
+    const uint32_t rend = (uint32_t)Gn * kRecBytes;
     cs::Words<(DW > 0 ? DW : 1)> cur;
     cur.w[0] = 0;
     // Register store: one dword of every record of the NEXT chunk is touched by a vector load at each chunk boundary (64 lanes x
@@ -501,10 +508,11 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     const uint32_t a2_bit = group_unschedulable ? 0u : CASIM_REC_A2_OK;
     uint32_t a2_gate = 0;
     if constexpr (kRecScalar) {
-        recp = res.rec + (int64_t)off * DW; rp = recp;
+        recp = res.rec + (int64_t)off * DW;
+        rbase = cs::rec_base(recp);
         touch_chunk(0);
         // (the record array ends with one spare record: the load of record k + 1 needs no bound)
-        cur = cs::const_load<DW>(rp);
+        cur = cs::rec_load<DW>(rbase, 0u);
         if (kNeedG) g_cur = (int32_t)cs::const_load<1>((const uint32_t*)res.order + off).w[0];
     }
     // results of a finished chunk: placed[] (one coalesced wave-store per 64 PEGs); memory store: also each lane's share of
@@ -530,8 +538,10 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     // fits no simulated node leaves no trace at all (placed 0, my_placed already 0, lastIndex kept) — in C2 that is 60 % of
     // all steps (profiles/r02s_packer_notes.txt), so the register store runs them in a loop of their own without the a3
     // code and its tests.
-    auto peg_step = [&](const int k, auto dry_tag) __attribute__((always_inline)) {
+    auto peg_step = [&](const int k_arg, auto dry_tag) __attribute__((always_inline)) {
         constexpr bool kDry = decltype(dry_tag)::value;
+        int k;
+        if constexpr (kRecScalar) k = (int)(roff >> kRecShift); else k = k_arg;   // (scalar records: only the steps that place pods read it)
         const int j = k & 63;
         if (!kDry && j == 0) {   // (the dry loop below walks chunk by chunk and does this itself)
             CASIM_PROF(0);  // chunk load / store, loop overhead
@@ -612,8 +622,17 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             // not (plugin_runner.go:108-110); every simulated node clones the template's flag.
             const uint32_t keff = (uint32_t)(zselfx ? (cnt > 0 ? 1 : 0) : cnt);
             bool a2_go;
+            uint64_t fb_first = 0;   // one-slot register store behind a dry limiter: the fit mask IS the gate
             if constexpr (kRecScalar) {
                 if constexpr (!kDry) { cs::keep_scalar(a2_gate); a2_go = (pf & a2_gate) != 0; }
+                else if constexpr (Store::kNPT == 1) {
+                    // (the dry loop only runs with the gate open.)  The common PEG — template Filters pass, pods > 0, every lane asked for
+                    // and small: CASIM_REC_A2_SIMPLE — goes from ONE bit test straight to its three compares; the others test A2_OK
+                    // and take the general mask.  A PEG that fits nowhere is done after the mask: 11 scalar + 3 vector instructions.
+                    if ((pf & CASIM_REC_A2_SIMPLE) != 0) fb_first = st.fit_mask(0, pv, CASIM_REC_SIMPLE);
+                    else if ((pf & CASIM_REC_A2_OK) != 0) fb_first = st.fit_mask(0, pv, 0u);
+                    a2_go = fb_first != 0;
+                }
                 else a2_go = (pf & CASIM_REC_A2_OK) != 0;   // (the dry loop only runs with the gate open: one bit test)
             }
             else a2_go = M > 0 && keff > 0 && static_ok && !group_unschedulable;
@@ -763,7 +782,8 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     a2_finish(new_last, x_mine_last);
                 };
                 if constexpr (Store::kNPT == 1) {
-                    const uint64_t fb = st.fit_mask(0, pv, pf);
+                    uint64_t fb;
+                    if constexpr (kRecScalar && kDry) fb = fb_first; else fb = st.fit_mask(0, pv, pf);
                     if (fb) {  // wave-uniform
                         act = 1u;
                         creg[0] = st.capacity_slot(0, pv, keff, pf, fb);
@@ -927,32 +947,43 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             }
         }
         if constexpr (kRecScalar) {   // record k + 1 into the registers record k just left (in flight across the loop edge)
-            rp += DW;
-            cur = cs::const_load<DW>(rp);
+            roff += kRecBytes;
+            cur = cs::rec_load<DW>(rbase, roff);
             if (kNeedG) g_cur = (int32_t)cs::const_load<1>((const uint32_t*)res.order + off + k + 1).w[0];
         }
     };
     {
-        int k = 0;
         if constexpr (kRecScalar) {
-            for (; k < Gn && more_mask != 0; ++k) peg_step(k, CsFalse{});
+            // (scalar tests and branches: `roff < rend && more_mask != 0` as one condition became lane-mask arithmetic, 11 scalar
+            // instructions of loop overhead per step)
+            if (roff < rend) {
+                for (;;) {
+                    peg_step(0, CsFalse{});
+                    if (roff >= rend) break;
+                    uint32_t mm = (uint32_t)more_mask; cs::keep_scalar(mm); more_mask = (int32_t)mm;
+                    if (mm == 0) break;
+                }
+            }
             // behind a dry limiter: nothing at all can happen without a node that takes pods (no a3, a2 gated off) — else chunk by
             // chunk, so that the steps themselves carry no chunk test
+            constexpr uint32_t kChunkBytes = 64u * kRecBytes;
             if (a2_gate != 0) {
-                while (k < Gn) {
-                    if ((k & 63) == 0) { if (k > 0) flush_chunk(k - 64); my_placed = 0; touch_chunk(k + 64); }
-                    const int kend = (k | 63) + 1 < Gn ? (k | 63) + 1 : Gn;
-                    for (; k < kend; ++k) peg_step(k, CsTrue{});
+                while (roff < rend) {
+                    if ((roff & (kChunkBytes - 1u)) == 0) { const int k = (int)(roff >> kRecShift); if (k > 0) flush_chunk(k - 64); my_placed = 0; touch_chunk(k + 64); }
+                    const uint32_t cnext = (roff | (kChunkBytes - 1u)) + 1u;
+                    const uint32_t cend = cnext < rend ? cnext : rend;
+                    do peg_step(0, CsTrue{}); while (roff < cend);
                 }
             } else {
                 // the chunks still have to be flushed (placed[] of the PEGs before the limiter ran dry), nothing else
+                int k = (int)(roff >> kRecShift);
                 while (k < Gn) {
                     if ((k & 63) == 0) { if (k > 0) flush_chunk(k - 64); my_placed = 0; }
                     k = (k | 63) + 1;
                 }
             }
         } else {
-            for (; k < Gn; ++k) peg_step(k, CsFalse{});
+            for (int k = 0; k < Gn; ++k) peg_step(k, CsFalse{});
         }
     }
     if constexpr (kRecScalar) {

@@ -204,7 +204,7 @@ public:
             // is packed again by the generic packer's retry launch (pack_kernel, PackScratch::retry_only)
             fast_retry_ = maxcap > 64 * 16;
             ok = ok && dt_.Wx <= 2 && dt_.Wz <= 2 && R <= 4 && NG > 0;
-            // (the PEG record carries the pods that fit an empty node in 23 bits: casim_types.h)
+            // (the PEG record carries the pods that fit an empty node in 21 bits: casim_types.h)
             for (size_t i = 0; i < NG && ok; ++i) ok = (int64_t)g->allowed_pods[i] - (int64_t)g->init_pods[i] <= CASIM_REC_FRESH_MAX;
             bool zone_self = false;   // a PEG that excludes itself group-wide (anti-affinity on a non-hostname key)
             for (size_t i = 0; i < G; ++i) zone_self = zone_self || (p->flags[i] & CASIM_PEG_SELF_EXCL_ZONE) != 0;

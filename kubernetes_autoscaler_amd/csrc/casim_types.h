@@ -82,14 +82,15 @@ struct DevResults {
 
 // PEG record of the register packer (dwords; RL = 2 or 4 request lanes, record = 8 or 16 dwords):
 //   [0] pods of the PEG
-//   [1] CASIM_PEG_* flags (bits 0-6) | CASIM_REC_SIMPLE | pods of this PEG that fit an EMPTY node << 8 | CASIM_REC_A2_OK | CASIM_KFLAG_STATIC_OK
+//   [1] CASIM_PEG_* flags (bits 0-6) | CASIM_REC_SIMPLE | pods of this PEG that fit an EMPTY node << 8 | CASIM_REC_A2_SIMPLE | CASIM_REC_A2_OK | CASIM_KFLAG_STATIC_OK
 //   [2 .. 2+RL) gcd-scaled requests   [2+RL .. 2+3RL) their reciprocals as IEEE doubles (lo, hi), 0.0 for a zero request
-// The fresh-node capacity is < 2^22 by eligibility (casim_pipeline.h: pod slots of an empty node).  Everything the packer
+// The fresh-node capacity is < 2^21 by eligibility (casim_pipeline.h: pod slots of an empty node).  Everything the packer
 // would otherwise derive per PEG with scalar compares is a bit here (the kernel is bound by SCALAR issue, r02n PMC):
 #define CASIM_REC_SIMPLE 0x80u            /* every request lane of the record is in (0, 2^30): the branch-free quotient sweep applies */
 #define CASIM_REC_A2_OK 0x40000000u       /* template-level Filters pass AND the PEG has pods: existing simulated nodes are worth a visit */
+#define CASIM_REC_A2_SIMPLE 0x20000000u   /* A2_OK and SIMPLE in one bit: the test at the head of a PEG step behind a dry limiter */
 #define CASIM_REC_FRESH_SHIFT 8
-#define CASIM_REC_FRESH_MAX 0x3fffff
+#define CASIM_REC_FRESH_MAX 0x1fffff
 #define CASIM_REC_FLAG_MASK 0xc00000ffu
 
 // Per-group scratch geometry of the packer: simulated-node state lives in LDS when every
