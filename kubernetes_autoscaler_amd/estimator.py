@@ -255,7 +255,14 @@ class BinpackingNodeEstimator:
             if self.analyser is not None:
                 # estimationAnalyserFunc(clusterSnapshot, nodeGroup, newNodesWithPods)  binpacking_estimator.go:157-159: the names
                 # of the added nodes that received a pod, from the per-node pod counts the device kept
-                self.analyser(self.snapshot, node_group, {n: True for n in res.nodes_with_pods(0, node_template.node.name)})
+                names = res.nodes_with_pods(0, node_template.node.name)
+                # tryFastPath books the extrapolated nodes as "<lastNodeName>-fake-<j>", j = 1 .. (binpacking_estimator.go:311-321): the
+                # device returns them as a count only (node_count - listed nodes), the names are rebuilt here
+                fakes = int(res.node_count[0]) - len(names)
+                if self.fastpath and fakes > 0 and int(res.nodes_added[0]) > 0:
+                    last = f"{node_template.node.name}-e-{int(res.nodes_added[0]) - 1}"
+                    names = names + [f"{last}-fake-{j}" for j in range(1, fakes + 1)]
+                self.analyser(self.snapshot, node_group, {n: True for n in names})
             return int(res.node_count[0]), pods
         finally:
             self.limiter.end_estimation()

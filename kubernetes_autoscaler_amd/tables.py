@@ -87,7 +87,12 @@ class TableSet:
 
     # ---- re-shaping -----------------------------------------------------------------------------
     def as_one_simulation(self) -> "TableSet":
-        """Every group sees every PEG (device-side subsets) and the whole set is one simulation."""
+        """Every group sees every PEG (device-side subsets) and the whole set is one simulation.  A table set that carries explicit
+        SchedulablePodGroups lists (peg_offsets / peg_index) cannot be re-shaped this way: the lists would silently be replaced
+        by "every group sees every PEG" and the estimates would change."""
+        if self.peg_offsets is not None:
+            raise ValueError("this table set carries explicit per-group PEG lists (peg_offsets): head / sim_slice / shard / StreamedBatch "
+                             "work on device-derived subsets only")
         G, NG = self.n_pegs, self.n_groups
         return TableSet(self.dims, self.pegs, self.groups, np.zeros(NG, np.int32), np.full(NG, G, np.int32), None, None,
                         np.arange(NG, dtype=np.int32), np.array([0, NG], np.int32))

@@ -230,6 +230,15 @@ def test_node_pods_and_the_analyser_hook(ctx):
     e = est.BinpackingNodeEstimator(ctx, est.ClusterSnapshotView(), limiter, estimation_analyser_func=lambda snap, ng, nodes: seen.update(nodes))
     n, pods = e.estimate(w.pegs, w.groups[0].template, est.NodeGroup("c0", 10, 0))
     assert n == len(seen) > 0 and all(k.startswith("c0-template-e-") for k in seen)
+    # fastpath: the extrapolated nodes reach the analyser as "<lastNodeName>-fake-<j>" (binpacking_estimator.go:311-321), so that
+    # len(newNodesWithPods) == the returned node count as in the reference
+    seen.clear()
+    e = est.BinpackingNodeEstimator(ctx, est.ClusterSnapshotView(), limiter, estimation_analyser_func=lambda snap, ng, nodes: seen.update(nodes),
+                                    fastpath_binpacking_enabled=True)
+    n, pods = e.estimate(w.pegs, w.groups[0].template, est.NodeGroup("c0", 10, 0))
+    assert n == len(seen) > 1, (n, seen)
+    fake = sorted(k for k in seen if "-fake-" in k)
+    assert fake and all(k.startswith("c0-template-e-0-fake-") for k in fake) and len(fake) == n - 1, seen
 
 
 def test_resident_cluster_iteration(ctx):
