@@ -778,6 +778,7 @@ def next_rows(kaa, ctx, workloads):
     out["node_removals"] = {"workload": w2.name, "nodes": len(w2.nodes), "candidates": len(w2.candidates),
                             "removable": int((r2.removable == 1).sum()), "kernels_ms": ms2, "candidates_per_s": len(w2.candidates) / (ms2 * 1e-3)}
     out["group_pods"] = group_pods_row()
+    out["incremental_encode"] = incremental_encode_row()
     return out
 
 
@@ -790,6 +791,17 @@ def group_pods_row():
     r = subprocess.run([exe, "150000", "1500", "3", "5"], capture_output=True, text=True, timeout=300)
     rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     return {"reference": "CA/core/scaleup/equivalence/groups.go:39-104", "rows": rows} if rows else {"error": r.stderr[-300:]}
+
+
+def incremental_encode_row():
+    """second-iteration encode of a 15 000-node / 150 000-pod cluster with 1 % of the nodes changed (casim_enc_begin_update /
+    _group_reset / _refinalize) next to the full encode of the same cluster, host only, through tools/casim_incr_bench (plain C++)."""
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "casim_incr_bench")
+    if not os.path.exists(exe):
+        return {"error": "tools/casim_incr_bench not built"}
+    r = subprocess.run([exe, "15000", "10", "128", "1", "3"], capture_output=True, text=True, timeout=600)
+    rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    return {"reference": "CA/simulator/clustersnapshot/store/delta.go:235-246,292-323 (the snapshot's O(1) fork + in-place AddPod)", "rows": rows} if rows else {"error": r.stderr[-300:]}
 
 
 if __name__ == "__main__":

@@ -38,7 +38,7 @@ extern "C" {
                                * 4: casim_options.n_streams (sub-batches on internal HIP streams), casim_enc_group_pods,
                                *    casim_enc_add_grouped_pegs, casim_enc_pod_set_spec_extra
                                * 5: casim_options.pack_build, casim_pack_build_info (two builds of the register packer + self-check),
-                               *    casim_problem_info [5], [6], casim_prefetch_* */
+                               *    casim_problem_info [5], [6], casim_prefetch_*, casim_enc_begin_update / _group_reset / _refinalize / _group_rows */
 
 /* Resource lanes.  Lane 0 = cpu in millicores (Quantity.MilliValue), lane 1 = memory bytes,
  * lane 2 = ephemeral-storage bytes, lanes 3.. = scalar / extended resources (Quantity.Value),
@@ -775,6 +775,34 @@ int32_t casim_enc_add_grouped_pegs(casim_encoder* e, int32_t n_pods, const int32
  * list).  v0 accepts them only to detect interactions; see DESIGN.md. */
 int32_t casim_enc_add_existing_pod(casim_encoder* e, int32_t pod_spec, const char* const* node_label_keys,
                                    const char* const* node_label_values, int32_t n_labels);
+
+/* ---- incremental re-encode (per-node mode: explicit_self_exclusion = 1) ------------------------------------------------
+ * The reference forks its snapshot in O(1) and adds pods in place (CA/simulator/clustersnapshot/store/delta.go:235-246,292-323);
+ * re-walking 15 000 nodes / 150 000 pods through the encoder costs tens of milliseconds per loop iteration.  Between two iterations
+ * most nodes are unchanged, so a FINALIZED encoder can be kept and updated:
+ *   casim_enc_begin_update(e);
+ *   for every node whose pods / labels / taints changed:
+ *       casim_enc_group_reset(e, node, alloc, ...);                     // forgets its labels, taints and running pods
+ *       casim_enc_group_add_label / _add_taint / _add_preloaded_pod ... // describe it again (new pod specs: casim_enc_add_pod_spec + casim_enc_pod_*)
+ *   casim_enc_set_peg_count(e, class, n) for classes whose number of pending pods changed;
+ *   rc = casim_enc_refinalize(e, changed, cap, &n_changed);
+ * CASIM_OK: only those rows of the node table and their share of the domain-rule counters were recomputed, against the
+ * dictionaries of the last full finalize; the table pointers of casim_enc_tables / casim_enc_domain_rules stay valid and show the
+ * new state; casim_enc_group_rows packs the changed rows for casim_cluster_update_nodes.
+ * CASIM_ENC_NEEDS_FULL (> 0): the update would change a dictionary — a new NoSchedule / NoExecute taint, a label value that opens a
+ * new topology domain of a rule key, a running spec that needs a node bit or a rule nobody has yet (ports, (anti-)affinity,
+ * spread constraints of its own, or a class's anti-affinity term matching it), a node without a hostname label next to hostname
+ * bits, nodes or classes added — the session stays open and casim_enc_finalize rebuilds everything from the objects the encoder
+ * holds (nothing has to be described again).  Results after an update are identical to a full finalize of the same objects
+ * (tests/test_incremental_encode.py compares every column). */
+#define CASIM_ENC_NEEDS_FULL 65
+int32_t casim_enc_begin_update(casim_encoder* e);
+int32_t casim_enc_group_reset(casim_encoder* e, int32_t group, const int64_t* alloc, int32_t allowed_pods, int64_t capacity_cpu_milli,
+                              int64_t capacity_mem_bytes, int32_t unschedulable);
+int32_t casim_enc_set_peg_count(casim_encoder* e, int32_t peg, int32_t count);
+int32_t casim_enc_refinalize(casim_encoder* e, int32_t* changed_out, int32_t capacity, int32_t* n_changed_out);
+/* n rows of the node table as a compact casim_groups (pointers owned by the encoder, valid until the next call) */
+int32_t casim_enc_group_rows(casim_encoder* e, const int32_t* groups, int32_t n, casim_groups* rows_out);
 
 /* Build the dictionaries and the flat tables.  After finalize the views below stay valid
  * until the encoder is destroyed. */

@@ -70,6 +70,7 @@ class PrefetchResult(C.Structure):
                 ("n_pegs", C.c_int32), ("miss_reason", C.c_int32)]
 
 
+ENC_NEEDS_FULL = 65
 PREFETCH_MISS = 64
 PREFETCH_MISS_GROUP, PREFETCH_MISS_PEGS, PREFETCH_MISS_LIMITS = 1, 2, 3
 
@@ -234,6 +235,11 @@ PROTOTYPES = {
     "casim_enc_add_grouped_pegs": (C.c_int32, [C.c_void_p, C.c_int32, i32p, i32p, C.c_int32, i32p]),
     "casim_enc_add_existing_pod": (C.c_int32, [C.c_void_p, C.c_int32, cstrp, cstrp, C.c_int32]),
     "casim_enc_finalize": (C.c_int32, [C.c_void_p]),
+    "casim_enc_begin_update": (C.c_int32, [C.c_void_p]),
+    "casim_enc_group_reset": (C.c_int32, [C.c_void_p, C.c_int32, i64p, C.c_int32, C.c_int64, C.c_int64, C.c_int32]),
+    "casim_enc_set_peg_count": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
+    "casim_enc_refinalize": (C.c_int32, [C.c_void_p, i32p, C.c_int32, i32p]),
+    "casim_enc_group_rows": (C.c_int32, [C.c_void_p, i32p, C.c_int32, C.POINTER(Groups)]),
     "casim_enc_tables": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups)]),
     "casim_enc_dict_sizes": (C.c_int32, [C.c_void_p, i32p]),
 }

@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
 #include <deque>
 #include <map>
 #include <set>
@@ -267,6 +268,30 @@ struct casim_encoder {
         std::vector<uint64_t> elig;
         int32_t n_taint_rules = 0;
     } dr;
+    // ---- what an incremental re-encode needs from the last full finalize (casim_enc_refinalize, per-node mode) ----
+    struct FinalRule { int cls, key, kind, row; const Spread* sc; };
+    struct {
+        bool valid = false;
+        size_t n_specs = 0, NG = 0, G = 0;
+        std::map<Taint, int> taint_id;
+        std::vector<Requirement> lreqs;
+        std::map<Port, int> port_bit;
+        std::map<int32_t, int> pre_occ_bit;
+        std::vector<uint8_t> running;                         // [specs] preloaded on some node at the last full finalize (or proved inert since)
+        std::vector<size_t> with_terms;                       // PEGs whose spec carries hostname anti-affinity terms
+        std::vector<std::string> keys;                        // topology keys of the domain rules
+        std::vector<std::map<std::string, int>> val_id;       // per key: label value -> domain id
+        std::vector<FinalRule> rules;
+        std::vector<std::array<int, 4>> class_rows;           // per class: eligibility row per (affinity honoured, taints honoured) combination, -1 = none
+        std::vector<uint8_t> dirty;                           // [groups] reset since the last (re)finalize
+        std::vector<int32_t> dirty_list;
+    } fs;
+    bool updating = false;
+    std::vector<int64_t> rows_alloc, rows_init_req, rows_waste_cpu, rows_waste_mem;   // casim_enc_group_rows: compact copies
+    std::vector<int32_t> rows_allowed, rows_init_pods, rows_max_nodes, rows_existing, rows_last_index;
+    std::vector<uint32_t> rows_gflags;
+    std::vector<uint64_t> rows_taint, rows_label, rows_init_excl;
+    std::vector<double> rows_cap_cpu, rows_cap_mem;
 };
 
 extern "C" {
@@ -279,9 +304,13 @@ casim_encoder* casim_enc_create(const casim_encoder_options* opts) {
 }
 void casim_enc_destroy(casim_encoder* e) { delete e; }
 
+// After finalize the encoder is read-only — except inside an update session (casim_enc_begin_update .. casim_enc_refinalize), where
+// NEW pod specs may be described and the groups that were reset (casim_enc_group_reset) refilled.  Everything else stays frozen:
+// the specs of the last finalize feed dictionaries that an update does not rebuild.
+#define ENC_OPEN(e) if (!(e) || ((e)->finalized && !(e)->updating)) return CASIM_ERR_INVALID
 #define ENC_CHECK(e) if (!(e) || (e)->finalized) return CASIM_ERR_INVALID
-#define POD_CHECK(e, p) ENC_CHECK(e); if ((p) < 0 || (size_t)(p) >= (e)->specs.size()) return CASIM_ERR_INVALID
-#define GRP_CHECK(e, g) ENC_CHECK(e); if ((g) < 0 || (size_t)(g) >= (e)->groups.size()) return CASIM_ERR_INVALID
+#define POD_CHECK(e, p) ENC_OPEN(e); if ((p) < 0 || (size_t)(p) >= (e)->specs.size() || ((e)->updating && (size_t)(p) < (e)->fs.n_specs)) return CASIM_ERR_INVALID
+#define GRP_CHECK(e, g) ENC_OPEN(e); if ((g) < 0 || (size_t)(g) >= (e)->groups.size() || ((e)->updating && !(e)->fs.dirty[(size_t)(g)])) return CASIM_ERR_INVALID
 
 int32_t casim_enc_add_group(casim_encoder* e, const char* template_name, const int64_t* alloc, int32_t allowed_pods,
                             int64_t capacity_cpu_milli, int64_t capacity_mem_bytes, int32_t unschedulable) {
@@ -312,7 +341,9 @@ int32_t casim_enc_group_set_limits(casim_encoder* e, int32_t group, int32_t max_
     return CASIM_OK;
 }
 int32_t casim_enc_group_add_preloaded_pod(casim_encoder* e, int32_t group, int32_t pod_spec) {
-    GRP_CHECK(e, group); POD_CHECK(e, pod_spec); e->groups[group].preloaded.push_back(pod_spec); return CASIM_OK;
+    GRP_CHECK(e, group);
+    if (pod_spec < 0 || (size_t)pod_spec >= e->specs.size()) return CASIM_ERR_INVALID;
+    e->groups[group].preloaded.push_back(pod_spec); return CASIM_OK;
 }
 int32_t casim_enc_group_set_pegs(casim_encoder* e, int32_t group, const int32_t* pegs, int32_t n) {
     GRP_CHECK(e, group);
@@ -322,7 +353,7 @@ int32_t casim_enc_group_set_pegs(casim_encoder* e, int32_t group, const int32_t*
     return CASIM_OK;
 }
 int32_t casim_enc_add_pod_spec(casim_encoder* e, const char* namespace_, const int64_t* req) {
-    ENC_CHECK(e);
+    ENC_OPEN(e);
     if (!req) return CASIM_ERR_INVALID;
     PodSpec p;
     p.ns = S(namespace_);
@@ -489,7 +520,8 @@ int32_t casim_enc_add_existing_pod(casim_encoder* e, int32_t pod_spec, const cha
 }
 
 int32_t casim_enc_finalize(casim_encoder* e) {
-    ENC_CHECK(e);
+    ENC_OPEN(e);   // (also the full fallback of an update session: casim_enc_refinalize said CASIM_ENC_NEEDS_FULL)
+    e->fs.valid = false;
     const int R = e->opt.n_res;
     const size_t G = e->pegs.size(), NG = e->groups.size(), NS = e->specs.size();
     const bool cmp_ops = e->opt.enable_taint_comparison_ops != 0;
@@ -596,6 +628,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         std::vector<size_t> with_terms;  // PEGs whose spec has hostname terms
         for (size_t i = 0; i < G; ++i)
             for (auto& t : e->specs[(size_t)e->pegs[i].spec].anti) if (t.topology_key == kHostname) { with_terms.push_back(i); break; }
+        e->fs.with_terms = with_terms;
         for (size_t i : with_terms) {
             const PodSpec& a = e->specs[(size_t)e->pegs[i].spec];
             for (size_t j = 0; j < G; ++j) {
@@ -623,6 +656,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
             std::vector<uint8_t> seen(NS, 0);
             for (auto& g : e->groups) for (int32_t s : g.preloaded) seen[(size_t)s] = 1;
             for (size_t s = 0; s < NS; ++s) if (seen[s]) pre_specs.push_back((int32_t)s);
+            e->fs.running = seen;
         }
         for (int32_t s : pre_specs) {
             bool s_has_terms = false;
@@ -727,6 +761,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
     // (4b) per-node mode: domain rules (include/casim.h, casim_domain_rules) for PodTopologySpread and for required
     // anti-affinity on non-hostname keys.  Template mode (an Estimate): spread constraints are outside the subset.
     e->dr = decltype(e->dr)();
+    e->fs.keys.clear(); e->fs.val_id.clear(); e->fs.rules.clear(); e->fs.class_rows.assign(G, std::array<int, 4>{{-1, -1, -1, -1}});
     if (!per_node) {
         for (size_t i = 0; i < G; ++i) {
             PodSpec& p = e->specs[(size_t)e->pegs[i].spec];
@@ -804,6 +839,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
                     }
                 }
             }
+            e->fs.class_rows[i] = std::array<int, 4>{{row_of[0], row_of[1], row_of[2], row_of[3]}};
             for (auto& sc : p.spread) {
                 if (sc.taints_honor) dr.n_taint_rules++;
                 Rule r{(int)i, key_of(sc.key), 0, sc.max_skew, sc.min_domains, 0, row_of[(sc.affinity_honor ? 1 : 0) | (sc.taints_honor ? 2 : 0)], &sc};
@@ -839,6 +875,8 @@ int32_t casim_enc_finalize(casim_encoder* e) {
             dr.node_domain.assign(keys.size() * NG, -1); dr.key_domains.assign(keys.size(), 0);
             dr.key_host.assign(keys.size(), 0);
             for (size_t k = 0; k < keys.size(); ++k) dr.key_host[k] = keys[k] == kHostname ? 1 : 0;
+            e->fs.keys = keys;
+            for (auto& R1 : rules) e->fs.rules.push_back(casim_encoder::FinalRule{R1.cls, R1.key, R1.kind, R1.row, R1.sc});
             for (size_t k = 0; k < keys.size(); ++k) {
                 std::map<std::string, int> val_id;
                 for (size_t n = 0; n < NG; ++n) {
@@ -850,6 +888,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
                     dr.node_domain[k * NG + n] = id;
                 }
                 dr.key_domains[k] = (int32_t)val_id.size();
+                e->fs.val_id.push_back(val_id);
             }
             dr.r_off.assign(rules.size() + 1, 0);
             for (size_t r = 0; r < rules.size(); ++r) dr.r_off[r + 1] = dr.r_off[r] + dr.key_domains[(size_t)rules[r].key];
@@ -987,9 +1026,228 @@ int32_t casim_enc_finalize(casim_encoder* e) {
     }
     e->dict[0] = (int)taint_id.size(); e->dict[1] = (int)lreqs.size(); e->dict[2] = xbits.n; e->dict[3] = zbits.n;
     e->finalized = true;
+    // what casim_enc_refinalize works from
+    e->fs.taint_id = taint_id; e->fs.lreqs = lreqs; e->fs.port_bit = port_bit; e->fs.pre_occ_bit = pre_occ_bit;
+    e->fs.n_specs = NS; e->fs.NG = NG; e->fs.G = G;
+    e->fs.dirty.assign(NG, 0); e->fs.dirty_list.clear();
+    e->fs.valid = true; e->updating = false;
     return CASIM_OK;
 }
 
+}  // extern "C"
+
+// ---- incremental re-encode (per-node mode) --------------------------------------------------------------------------------------
+// The reference forks its snapshot in O(1) and adds pods in place (CA/simulator/clustersnapshot/store/delta.go:235-246,292-323); a
+// full encode of 15 000 nodes / 150 000 pods costs tens of milliseconds per loop iteration (profiles/r02i_native_scale.jsonl).
+// Between two iterations most nodes are unchanged: an update session re-describes ONLY the changed nodes (their labels, taints
+// and running pods) and casim_enc_refinalize recomputes those rows of the node table and their share of the domain-rule
+// counters against the dictionaries of the last full finalize.  Whatever would change a dictionary — a new rejecting taint, a
+// label value that opens a new topology domain, a running spec that needs a node bit or a rule nobody has yet, a node without a
+// hostname label, nodes added or removed, new classes — answers CASIM_ENC_NEEDS_FULL, and the caller runs casim_enc_finalize on the
+// same encoder (every object it described is still there).
+namespace {
+bool node_passes_affinity_of(const PodSpec& p, const Group& g) {   // RequiredNodeAffinity.Match (nodeSelector + required term)
+    for (auto& kv : p.node_selector) { auto it = g.labels.find(kv.first); if (it == g.labels.end() || it->second != kv.second) return false; }
+    if (p.has_node_terms && !node_terms_match(p.node_terms, g.labels, g.name)) return false;
+    return selector_matches(p.node_affinity, g.labels);
+}
+bool zone_conflict_of(const PodSpec& a, const PodSpec& b, const std::string& k) {
+    for (auto& t : a.anti) if (t.topology_key == k && term_matches(t, b)) return true;
+    for (auto& t : b.anti) if (t.topology_key == k && term_matches(t, a)) return true;
+    return false;
+}
+bool matches_all_aff_of(const PodSpec& owner, const PodSpec& q) {
+    if (owner.aff.empty()) return false;
+    for (auto& t : owner.aff) if (!term_matches(t, q)) return false;
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t casim_enc_begin_update(casim_encoder* e) {
+    if (!e || !e->finalized || !e->fs.valid || e->updating) return CASIM_ERR_INVALID;
+    if (!e->opt.explicit_self_exclusion) return CASIM_ERR_INVALID;   // per-node tables only (template tables are a few dozen rows)
+    e->updating = true;
+    return CASIM_OK;
+}
+int32_t casim_enc_group_reset(casim_encoder* e, int32_t group, const int64_t* alloc, int32_t allowed_pods, int64_t capacity_cpu_milli,
+                              int64_t capacity_mem_bytes, int32_t unschedulable) {
+    if (!e || !e->updating || group < 0 || (size_t)group >= e->groups.size() || !alloc) return CASIM_ERR_INVALID;
+    Group& g = e->groups[(size_t)group];
+    if (!e->fs.dirty[(size_t)group]) {
+        // the node leaves the domain rules with everything it contributed (its row and counters are rebuilt by refinalize)
+        auto& dr = e->dr;
+        const size_t NG = e->fs.NG, words = (NG + 63) / 64, n = (size_t)group;
+        for (size_t r = 0; r < e->fs.rules.size(); ++r) {
+            const auto& R0 = e->fs.rules[r];
+            const int d = dr.node_domain[(size_t)R0.key * NG + n];
+            if (d < 0) continue;
+            if (R0.kind == 0 && !((dr.elig[(size_t)R0.row * words + (n >> 6)] >> (n & 63)) & 1ull)) continue;
+            const size_t at = (size_t)dr.r_off[r] + (size_t)d;
+            dr.dom_nodes[at]--; dr.exists[at] = dr.dom_nodes[at] > 0 ? 1 : 0;
+            dr.count_init[at] -= dr.node_contrib[r * NG + n];
+            dr.node_contrib[r * NG + n] = 0;
+        }
+        for (size_t row = 0; row < (size_t)dr.n_rows; ++row) dr.elig[row * words + (n >> 6)] &= ~(1ull << (n & 63));
+        e->fs.dirty[(size_t)group] = 1; e->fs.dirty_list.push_back(group);
+    }
+    for (int r = 0; r < CASIM_MAX_RES; ++r) g.alloc[r] = r < e->opt.n_res ? alloc[r] : 0;
+    g.allowed = allowed_pods; g.cap_cpu = capacity_cpu_milli; g.cap_mem = capacity_mem_bytes; g.unschedulable = unschedulable != 0;
+    g.fp_cap_cpu = (double)capacity_cpu_milli * 1e-3; g.fp_cap_mem = (double)capacity_mem_bytes;
+    g.labels = Labels(); g.taints.clear(); g.preloaded.clear();
+    return CASIM_OK;
+}
+int32_t casim_enc_set_peg_count(casim_encoder* e, int32_t peg, int32_t count) {
+    if (!e || !e->updating || peg < 0 || (size_t)peg >= e->pegs.size() || count < 0) return CASIM_ERR_INVALID;
+    e->pegs[(size_t)peg].count = count;
+    e->count[(size_t)peg] = count;
+    return CASIM_OK;
+}
+
+int32_t casim_enc_refinalize(casim_encoder* e, int32_t* changed_out, int32_t capacity, int32_t* n_changed_out) {
+    if (!e || !e->updating) return CASIM_ERR_INVALID;
+    auto& fs = e->fs; auto& dr = e->dr;
+    const size_t NG = fs.NG, G = fs.G, R = (size_t)e->opt.n_res, words = (NG + 63) / 64;
+    const int Wt = e->Wt, Wl = e->Wl, Wx = e->Wx;
+    const bool cmp_ops = e->opt.enable_taint_comparison_ops != 0;
+    if (e->groups.size() != NG || e->pegs.size() != G) return CASIM_ENC_NEEDS_FULL;   // nodes or classes were added
+    // ---- 1. nothing may touch a dictionary ----
+    bool hostname_bits = !fs.port_bit.empty() || !fs.pre_occ_bit.empty() || !fs.with_terms.empty();
+    if (fs.running.size() < e->specs.size()) fs.running.resize(e->specs.size(), 0);
+    for (int32_t gi : fs.dirty_list) {
+        const Group& g = e->groups[(size_t)gi];
+        for (auto& t : g.taints) if ((t.effect == "NoSchedule" || t.effect == "NoExecute") && !fs.taint_id.count(t)) return CASIM_ENC_NEEDS_FULL;
+        if (hostname_bits && !g.labels.count(kHostname)) return CASIM_ENC_NEEDS_FULL;
+        for (size_t k = 0; k < fs.keys.size(); ++k) {
+            auto it = g.labels.find(fs.keys[k]);
+            if (it != g.labels.end() && !fs.val_id[k].count(it->second)) return CASIM_ENC_NEEDS_FULL;   // a new topology domain
+        }
+        for (int32_t s2 : g.preloaded) {
+            if (fs.running[(size_t)s2]) continue;
+            const PodSpec& q = e->specs[(size_t)s2];
+            // a spec no node ran at the last finalize: fine as long as it needs no node bit and no rule that does not exist yet
+            for (auto& pt : q.ports) if (pt.port > 0 && !fs.port_bit.count(sanitize(pt))) return CASIM_ENC_NEEDS_FULL;
+            if (!q.anti.empty() || !q.aff.empty() || !q.spread.empty()) return CASIM_ENC_NEEDS_FULL;
+            for (size_t i : fs.with_terms)
+                for (auto& t : e->specs[(size_t)e->pegs[i].spec].anti) if (t.topology_key == kHostname && term_matches(t, q)) return CASIM_ENC_NEEDS_FULL;
+            for (size_t i = 0; i < G; ++i)
+                for (auto& t : e->specs[(size_t)e->pegs[i].spec].anti) {
+                    if (t.topology_key == kHostname || !term_matches(t, q)) continue;
+                    bool have = false;
+                    for (auto& R0 : fs.rules) if (R0.kind == 1 && (size_t)R0.cls == i && fs.keys[(size_t)R0.key] == t.topology_key) have = true;
+                    if (!have) return CASIM_ENC_NEEDS_FULL;
+                }
+            fs.running[(size_t)s2] = 1;
+        }
+    }
+    // ---- 2. rows of the node table ----
+    for (int32_t gsel : fs.dirty_list) {
+        const size_t gi = (size_t)gsel;
+        const Group& g = e->groups[gi];
+        for (size_t r = 0; r < R; ++r) { e->alloc[gi * R + r] = g.alloc[r]; e->init_req[gi * R + r] = 0; }
+        e->allowed[gi] = g.allowed; e->init_pods[gi] = 0;
+        e->gflags[gi] = g.unschedulable ? CASIM_NG_UNSCHEDULABLE : 0;
+        e->max_nodes[gi] = g.max_nodes; e->existing_nodes[gi] = g.existing; e->last_index[gi] = g.last_index;
+        e->cap_cpu[gi] = g.fp_cap_cpu; e->cap_mem[gi] = g.fp_cap_mem; e->waste_cpu[gi] = g.cap_cpu; e->waste_mem[gi] = g.cap_mem;
+        for (int w = 0; w < Wt; ++w) e->taint[gi * (size_t)Wt + (size_t)w] = 0;
+        for (int w = 0; w < Wl; ++w) e->label[gi * (size_t)Wl + (size_t)w] = 0;
+        for (int w = 0; w < Wx; ++w) e->init_excl[gi * (size_t)Wx + (size_t)w] = 0;
+        for (auto& t : g.taints) { auto it = fs.taint_id.find(t); if (it != fs.taint_id.end()) set_bit(e->taint, gi, Wt, it->second); }
+        for (size_t l = 0; l < fs.lreqs.size(); ++l)
+            if (fs.lreqs[l].op == kNodeTerms ? node_terms_match(fs.lreqs[l].terms, g.labels, g.name) : requirement_matches(fs.lreqs[l], g.labels)) set_bit(e->label, gi, Wl, (int)l);
+        for (int32_t s2 : g.preloaded) {
+            const PodSpec& p = e->specs[(size_t)s2];
+            for (size_t r = 0; r < R; ++r) e->init_req[gi * R + r] += p.req[r];
+            e->init_pods[gi] += 1;
+            for (auto& pt : p.ports) {
+                if (pt.port <= 0) continue;
+                auto it = fs.port_bit.find(sanitize(pt));
+                if (it != fs.port_bit.end()) set_bit(e->init_excl, gi, Wx, it->second);
+            }
+            auto ob = fs.pre_occ_bit.find(s2);
+            if (ob != fs.pre_occ_bit.end()) set_bit(e->init_excl, gi, Wx, ob->second);
+        }
+        // ---- 3. the node's place in the domain rules ----
+        if (!fs.rules.empty()) {
+            for (size_t k = 0; k < fs.keys.size(); ++k) {
+                auto it = g.labels.find(fs.keys[k]);
+                dr.node_domain[k * NG + gi] = it == g.labels.end() ? -1 : fs.val_id[k].at(it->second);
+            }
+            for (size_t i = 0; i < G; ++i) {   // eligibility rows of the classes with spread constraints
+                const PodSpec& p = e->specs[(size_t)e->pegs[i].spec];
+                if (p.spread.empty()) continue;
+                bool keys_ok = true;
+                for (auto& sc : p.spread) keys_ok = keys_ok && g.labels.count(sc.key) != 0;
+                if (!keys_ok) continue;
+                const bool aff = node_passes_affinity_of(p, g);
+                bool tolerated = true;
+                for (auto& tn : g.taints) {
+                    if (tn.effect != "NoSchedule" && tn.effect != "NoExecute") continue;
+                    bool tol = false;
+                    for (auto& t : p.tolerations) if (tolerates(t, tn, cmp_ops)) { tol = true; break; }
+                    if (!tol) { tolerated = false; break; }
+                }
+                for (int combo = 0; combo < 4; ++combo) {
+                    const int row = fs.class_rows[i][(size_t)combo];
+                    if (row < 0) continue;
+                    if ((combo & 1) && !aff) continue;
+                    if ((combo & 2) && !tolerated) continue;
+                    dr.elig[(size_t)row * words + (gi >> 6)] |= 1ull << (gi & 63);
+                }
+            }
+            for (size_t r = 0; r < fs.rules.size(); ++r) {
+                const auto& R0 = fs.rules[r];
+                const PodSpec& p = e->specs[(size_t)e->pegs[(size_t)R0.cls].spec];
+                const int d = dr.node_domain[(size_t)R0.key * NG + gi];
+                if (d < 0) continue;
+                if (R0.kind == 0 && !((dr.elig[(size_t)R0.row * words + (gi >> 6)] >> (gi & 63)) & 1ull)) continue;
+                const size_t at = (size_t)dr.r_off[r] + (size_t)d;
+                dr.exists[at] = 1; dr.dom_nodes[at]++;
+                for (int32_t s2 : g.preloaded) {
+                    const PodSpec& q = e->specs[(size_t)s2];
+                    const bool feeds = R0.kind == 0 ? (!R0.sc->selector.empty() && q.ns == p.ns && selector_matches(R0.sc->selector, q.labels))
+                                     : R0.kind == 1 ? zone_conflict_of(p, q, fs.keys[(size_t)R0.key]) : matches_all_aff_of(p, q);
+                    if (feeds) { dr.count_init[at]++; dr.node_contrib[r * NG + gi]++; }
+                }
+            }
+        }
+    }
+    const int32_t n = (int32_t)fs.dirty_list.size();
+    if (n_changed_out) *n_changed_out = n;
+    if (changed_out) for (int32_t k = 0; k < n && k < capacity; ++k) changed_out[k] = fs.dirty_list[(size_t)k];
+    for (int32_t gi : fs.dirty_list) fs.dirty[(size_t)gi] = 0;
+    fs.dirty_list.clear();
+    fs.n_specs = e->specs.size();
+    e->updating = false;
+    return CASIM_OK;
+}
+
+// compact copies of n rows of the node table (what casim_cluster_update_nodes takes); valid until the next call / destroy
+int32_t casim_enc_group_rows(casim_encoder* e, const int32_t* groups, int32_t n, casim_groups* out) {
+    if (!e || !e->finalized || !out || n < 0 || (n > 0 && !groups)) return CASIM_ERR_INVALID;
+    const size_t R = (size_t)e->opt.n_res, Wt = (size_t)e->Wt, Wl = (size_t)e->Wl, Wx = (size_t)e->Wx, N = (size_t)n;
+    for (int32_t k = 0; k < n; ++k) if (groups[k] < 0 || (size_t)groups[k] >= e->groups.size()) return CASIM_ERR_INVALID;
+    auto pick = [&](auto& dst, const auto& src, size_t width) {
+        dst.resize(N * width + 1);
+        for (size_t k = 0; k < N; ++k) for (size_t w = 0; w < width; ++w) dst[k * width + w] = src[(size_t)groups[k] * width + w];
+    };
+    pick(e->rows_alloc, e->alloc, R); pick(e->rows_init_req, e->init_req, R); pick(e->rows_allowed, e->allowed, 1); pick(e->rows_init_pods, e->init_pods, 1);
+    pick(e->rows_gflags, e->gflags, 1); pick(e->rows_taint, e->taint, Wt); pick(e->rows_label, e->label, Wl); pick(e->rows_init_excl, e->init_excl, Wx);
+    pick(e->rows_max_nodes, e->max_nodes, 1); pick(e->rows_existing, e->existing_nodes, 1); pick(e->rows_last_index, e->last_index, 1);
+    pick(e->rows_cap_cpu, e->cap_cpu, 1); pick(e->rows_cap_mem, e->cap_mem, 1); pick(e->rows_waste_cpu, e->waste_cpu, 1); pick(e->rows_waste_mem, e->waste_mem, 1);
+    memset(out, 0, sizeof *out);
+    out->n_groups = n;
+    out->alloc = e->rows_alloc.data(); out->init_req = e->rows_init_req.data(); out->allowed_pods = e->rows_allowed.data(); out->init_pods = e->rows_init_pods.data();
+    out->flags = e->rows_gflags.data(); out->taint_mask = e->rows_taint.data(); out->label_mask = e->rows_label.data(); out->init_excl = e->rows_init_excl.data();
+    out->max_nodes = e->rows_max_nodes.data(); out->existing_nodes = e->rows_existing.data(); out->last_index = e->rows_last_index.data();
+    out->cap_cpu = e->rows_cap_cpu.data(); out->cap_mem = e->rows_cap_mem.data(); out->waste_cpu = e->rows_waste_cpu.data(); out->waste_mem = e->rows_waste_mem.data();
+    return CASIM_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
 int32_t casim_enc_tables(const casim_encoder* e, casim_pegs* p, casim_groups* g) {
     if (!e || !e->finalized || !p || !g) return CASIM_ERR_INVALID;
     memset(p, 0, sizeof *p); memset(g, 0, sizeof *g);

@@ -246,6 +246,47 @@ class Encoder:
         self.port_block = lib.casim_enc_port_block(self._h)
         return self.pegs, self.groups
 
+    # ---- incremental re-encode (per-node mode; casim.h "incremental re-encode") ----------------------
+    def begin_update(self):
+        check(lib.casim_enc_begin_update(self._h), "casim_enc_begin_update")
+
+    def reset_group(self, g: int, template: NodeInfo):
+        """Describe node `g` again: casim_enc_group_reset + the same calls add_group makes for its labels, taints and running pods."""
+        node = template.node
+        check(lib.casim_enc_group_reset(self._h, int(g), self._lane_vector(node.allocatable), node.allowed_pods(), int(node.capacity.get(RES_CPU, 0)),
+                                        int(node.capacity.get(RES_MEMORY, 0)), int(node.unschedulable)), "casim_enc_group_reset")
+        for k, v in node.labels.items():
+            check(lib.casim_enc_group_add_label(self._h, g, _b(k), _b(v)))
+        for t in node.taints:
+            check(lib.casim_enc_group_add_taint(self._h, g, _b(t.key), _b(t.value), _b(t.effect)))
+        for p in template.pods:
+            check(lib.casim_enc_group_add_preloaded_pod(self._h, g, self.add_pod_spec(p)))
+
+    def set_peg_count(self, peg: int, count: int):
+        check(lib.casim_enc_set_peg_count(self._h, int(peg), int(count)), "casim_enc_set_peg_count")
+
+    def refinalize(self):
+        """(True, changed node indices) after an incremental update, (False, None) when the update needs a full finalize — which
+        this method then runs on the same encoder."""
+        import numpy as np
+        cap = max(self.n_groups, 1)
+        changed = np.zeros(cap, np.int32)
+        n = C.c_int32(0)
+        rc = lib.casim_enc_refinalize(self._h, changed.ctypes.data_as(_abi.i32p), cap, C.byref(n))
+        if rc == _abi.ENC_NEEDS_FULL:
+            self.finalized = False
+            self.finalize()
+            return False, None
+        check(rc, "casim_enc_refinalize")
+        return True, changed[:n.value].copy()
+
+    def group_rows(self, groups) -> _abi.Groups:
+        import numpy as np
+        idx = np.ascontiguousarray(groups, np.int32)
+        rows = _abi.Groups()
+        check(lib.casim_enc_group_rows(self._h, idx.ctypes.data_as(_abi.i32p), int(idx.shape[0]), C.byref(rows)), "casim_enc_group_rows")
+        return rows
+
     def dict_sizes(self):
         out = (C.c_int32 * 4)()
         check(lib.casim_enc_dict_sizes(self._h, out))

@@ -90,7 +90,7 @@ class TableSet:
         """Every group sees every PEG (device-side subsets) and the whole set is one simulation.  A table set that carries explicit
         SchedulablePodGroups lists (peg_offsets / peg_index) cannot be re-shaped this way: the lists would silently be replaced
         by "every group sees every PEG" and the estimates would change."""
-        if self.peg_offsets is not None:
+        if self.peg_offsets is not None and int(self.peg_offsets[-1]) > 0:   # (all-empty lists: the per-node tables of casim_try_schedule_pods, nothing to lose)
             raise ValueError("this table set carries explicit per-group PEG lists (peg_offsets): head / sim_slice / shard / StreamedBatch "
                              "work on device-derived subsets only")
         G, NG = self.n_pegs, self.n_groups

@@ -127,3 +127,49 @@ def test_iteration_with_domain_rules_on_a_resident_cluster(seed):
     w.hints = None
     out = resident_iteration(lambda classes, nodes: EmuCluster(classes, nodes), w, with_rules=True)
     assert out["stats"]["full_uploads"] == 1
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_incremental_encode_feeds_the_node_delta(seed):
+    """The whole second-iteration path: an update session on the iteration's encoder re-describes the nodes that changed
+    (casim_enc_group_reset ... casim_enc_refinalize), casim_enc_group_rows packs exactly those rows, casim_cluster_update_nodes
+    ships them — and the next TrySchedulePods on the resident cluster equals the oracle on the changed snapshot."""
+    w = workloads.fuzz_pending(600 + seed, max_nodes=30, max_pods=60)
+    nodes, pods = w.nodes, w.pods
+    enc = Encoder(explicit_self_exclusion=True)
+    class_of, pc = {}, []
+    for p in pods:
+        k = p.spec_key()
+        if k not in class_of:
+            class_of[k] = enc.add_peg(PodEquivalenceGroup(pods=[p]))
+        pc.append(class_of[k])
+    for info in nodes:
+        for p in info.pods:
+            k = p.spec_key()
+            if k not in class_of:
+                class_of[k] = enc.add_peg(PodEquivalenceGroup(pods=[p]))
+    for info in nodes:
+        enc.add_group(info, pegs=[])
+    enc.finalize()
+    pc = np.array(pc, np.int32)
+    cl = EmuCluster(enc.pegs, enc.groups)
+    victims = [m for m, info in enumerate(nodes) if info.pods][:3]
+    if not victims:
+        pytest.skip("no node runs a pod")
+    changed = [NodeInfo(info.node, list(info.pods)[1:] if m in victims else list(info.pods)) for m, info in enumerate(nodes)]   # one pod left each
+    enc.begin_update()
+    for m in victims:
+        enc.reset_group(m, changed[m])
+    ok, idx = enc.refinalize()
+    assert ok and sorted(int(x) for x in idx) == victims
+    cl.update_nodes(idx, enc.group_rows(idx))
+    assert cl.stats()["delta_rows"] == len(victims)
+    rc, got, li, ns = cl.try_schedule_pods(pc, None, w.acceptable, w.break_on_failure, w.last_index, commit=False)
+    s = OracleScenario()
+    for info in changed:
+        s.add_existing(info)
+    canon = {}
+    want = s.try_schedule_pods([canon.setdefault(p.spec_key(), p) for p in pods], None, None, w.acceptable, w.break_on_failure, w.last_index)
+    s.close()
+    assert list(got) == list(want[0]) and li == want[1] and ns == want[2]
+    cl.close(); enc.close()

@@ -71,7 +71,9 @@ if has "prof|full"; then
   for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"; do
     N=$(echo $C | tr ' ' '_' | cut -c1-24)
     echo "== rocprofv3 pmc $C ==" | tee -a "$S"
-    (cd /tmp && timeout 900 rocprofv3 --pmc $C --kernel-trace -d "$OLDPWD/$OUT/prof_pmc_$N" -o pmc -- \
+    # (counter passes serialise the kernels: the lane probe of casim_ctx would find no two streams running side by side and leave the
+    # batch uncut — CASIM_LANE_PROBE=0 keeps the launch geometry of the timed run, 4 sub-batches of 20480 waves)
+    (cd /tmp && CASIM_LANE_PROBE=0 timeout 900 rocprofv3 --pmc $C --kernel-trace -d "$OLDPWD/$OUT/prof_pmc_$N" -o pmc -- \
         python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-next-rows --no-c3 > "$OLDPWD/$OUT/prof_pmc_$N.log" 2>&1)
     echo "pmc $N exit $?" | tee -a "$S"
   done
