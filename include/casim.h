@@ -164,7 +164,14 @@ typedef struct casim_options {
     int32_t pack_build;           /* which build of the register packer runs (csrc/casim_pack_tu.hip): CASIM_PACK_BUILD_AUTO (0, default) = the
                                      one the library's self-check left standing for the device, _PLAIN = compiled without the
                                      experimental LLVM option, _OPTION = compiled with it; see casim_pack_build_info */
-    int32_t reserved[3];
+    int32_t no_singleton_merge;   /* 1 = keep every PEG row as it is.  Default (0): adjacent rows that are identical in every column, hold ONE pod
+                                     each and carry no exclusion state — controller-less pods, one PodEquivalenceGroup each
+                                     (equivalence/groups.go:69-73; BenchmarkRunOnceScaleUp: 10 000 of them) — are estimated as one row of k
+                                     pods with the one rule in which the two differ (lastIndex, csrc/casim_pipeline.h SingletonRuns) and
+                                     written out member by member again: results are identical, 10 000 dependent PEG steps become one.
+                                     Not applied with fastpath, to batches of simulations, or when opts is NULL.  (PEG flag bit 0x40 is
+                                     reserved for this and must be zero in casim_pegs.flags.) */
+    int32_t reserved[2];
 } casim_options;
 #define CASIM_PACK_BUILD_AUTO 0
 #define CASIM_PACK_BUILD_PLAIN 1

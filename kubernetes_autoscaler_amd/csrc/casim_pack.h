@@ -915,6 +915,15 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                             const int32_t pl = (int32_t)(fit < rem ? fit : rem);
                             if (nadd > 0) {
                                 create_nodes(M, nadd, cn, pl);
+                                // A run of k identical singleton PEGs merged into this row (CASIM_KFLAG_SINGLETON_RUN, casim_pipeline.h): each
+                                // of them runs tryToScheduleOnExistingNodes first, so every pod after the first on a new node got there
+                                // through a match that moved lastIndex to that node (plugin_runner.go:138) — the last new node holding >= 2
+                                // pods.  (A template that is unschedulable never matches there: its pods arrive by name, as a PEG's do.)
+                                if (cs::flag_set(pf, CASIM_KFLAG_SINGLETON_RUN) && !group_unschedulable && cn >= 2u) {
+                                    const int32_t on_last_new = pl - (nadd - 1) * (int32_t)cn;
+                                    if (on_last_new >= 2) last_index = E + M + nadd - 1;
+                                    else if (nadd >= 2) last_index = E + M + nadd - 2;
+                                }
                                 M += nadd; granted += nadd; placed += pl; rem -= pl; marked = true;
                             }
                             if (need > left) more_mask = 0;

@@ -42,6 +42,120 @@ inline int64_t round_up64(int64_t v) { return (v + 63) & ~63ll; }
                         else           { if ((npt) == 1) LAUNCH(4, 1, 0); else if ((npt) == 4) LAUNCH(4, 4, 0); else LAUNCH(4, 16, 0); } }        \
     } while (0)
 
+
+// ---- runs of identical singleton PEGs (host) ------------------------------------------------------------------------------------
+// Pods without a controller are one PodEquivalenceGroup each (CA/core/scaleup/equivalence/groups.go:69-73): the
+// reference's own BenchmarkRunOnceScaleUp hands Estimate 10 000 singleton PEGs of one and the same pod
+// (CA/core/bench/benchmark_runonce_test.go:395-418), i.e. 10 000 dependent PEG steps of one lone wave (14.5 ms on the MI355X against
+// 7.4 ms of the C restatement on one CPU core, profiles/r05a_bench.json).  Adjacent rows of the PEG table that are identical in every
+// column the device reads, hold one pod each and carry no exclusion state are merged on the host into ONE row of k pods before the
+// upload: they have equal scores, the orderer keeps equal scores in input order, so they are adjacent in processing order too, and
+// scheduling k identical pods one by one is what a PEG of k pods does — tryToScheduleOnExistingNodes is pod by pod anyway
+// (binpacking_estimator.go:163-186), and in tryToScheduleOnNewNodes (:190-269) the two differ in ONE observable: a later singleton
+// reaches the node its predecessor opened through tryToScheduleOnExistingNodes, whose match moves lastIndex to that node
+// (plugin_runner.go:138), where a PEG of k pods fills it with SchedulePod on the node's name and leaves lastIndex alone.  The
+// row is flagged CASIM_KFLAG_SINGLETON_RUN and the packer applies that rule; the results are expanded again on the way out
+// (placed = 1 for the first `placed` members, 0 for the rest: identical pods tried in order, the ones that find no room are the
+// last).  Off with the fastpath (its chooser reads PEG sizes), with batches of simulations (the scan would sit in every
+// enter -> return call of a million-PEG batch) and for callers that pass no options (the feasibility entry points index by PEG).
+struct SingletonRuns {
+    bool active = false;
+    std::vector<int32_t> first, len;   // [Gm] first original id and length of merged row m
+    casim_pegs p; casim_groups g;      // the merged tables (views into the vectors below)
+    std::vector<int64_t> req; std::vector<int32_t> count; std::vector<uint32_t> flags;
+    std::vector<uint64_t> tol, sel, xb, xm, zb, zm; std::vector<double> fpc, fpm;
+    std::vector<int32_t> lo, hi, off, idx;
+
+    bool build(const casim_pegs* P, const casim_groups* Gp, const casim_options* o) {
+        active = false;
+        if (!o || o->fastpath || o->no_singleton_merge || Gp->n_sims > 1) return false;
+        const int G = P->n_pegs, NG = Gp->n_groups, R = P->n_res;
+        if (G < 2 || !P->count || !P->flags || !P->req) return false;
+        bool any = false;
+        for (int i = 1; i < G && !any; ++i) any = P->count[i] == 1 && P->count[i - 1] == 1;
+        if (!any) return false;
+        const int Wt = P->w_taint, Wl = P->w_label, Wx = P->w_excl, Wz = P->w_zone;
+        auto zero = [](const uint64_t* m, int64_t at, int w) { for (int k = 0; k < w; ++k) if (m && m[at + k]) return false; return true; };
+        auto plain = [&](int i) {
+            return P->count[i] == 1 && (P->flags[i] & (CASIM_PEG_SELF_EXCL_NODE | CASIM_PEG_SELF_EXCL_ZONE | CASIM_PEG_UNSUPPORTED | CASIM_KFLAG_SINGLETON_RUN)) == 0 &&
+                   zero(P->excl_block, (int64_t)i * Wx, Wx) && zero(P->excl_mark, (int64_t)i * Wx, Wx) && zero(P->zone_block, (int64_t)i * Wz, Wz) && zero(P->zone_mark, (int64_t)i * Wz, Wz);
+        };
+        auto same = [&](int a, int b) {
+            if (P->flags[a] != P->flags[b]) return false;
+            for (int r = 0; r < R; ++r) if (P->req[(int64_t)a * R + r] != P->req[(int64_t)b * R + r]) return false;
+            for (int k = 0; k < Wt; ++k) if (P->tol_mask[(int64_t)a * Wt + k] != P->tol_mask[(int64_t)b * Wt + k]) return false;
+            for (int k = 0; k < Wl; ++k) if (P->sel_mask[(int64_t)a * Wl + k] != P->sel_mask[(int64_t)b * Wl + k]) return false;
+            if (P->fp_cpu && P->fp_cpu[a] != P->fp_cpu[b]) return false;
+            if (P->fp_mem && P->fp_mem[a] != P->fp_mem[b]) return false;
+            return true;
+        };
+        // a run may not cross the edge of any group's candidate range or of a consecutive stretch of an explicit list
+        std::vector<uint8_t> cut((size_t)G + 2, 0);
+        if (Gp->peg_offsets && Gp->peg_index) {
+            for (int i = 0; i < NG; ++i) {
+                const int32_t a = Gp->peg_offsets[i], b = Gp->peg_offsets[i + 1];
+                for (int32_t k = a; k < b; ++k) {
+                    const int32_t id = Gp->peg_index[k];
+                    if (id < 0 || id >= G) return false;   // (init reports it)
+                    if (k == a || Gp->peg_index[k - 1] + 1 != id) { cut[(size_t)id] = 1; if (k > a) cut[(size_t)Gp->peg_index[k - 1] + 1] = 1; }
+                    if (k == b - 1) cut[(size_t)id + 1] = 1;
+                }
+            }
+        } else if (Gp->peg_lo && Gp->peg_hi) {
+            for (int i = 0; i < NG; ++i) {
+                if (Gp->peg_lo[i] < 0 || Gp->peg_hi[i] > G || Gp->peg_hi[i] < Gp->peg_lo[i]) return false;
+                cut[(size_t)Gp->peg_lo[i]] = 1; cut[(size_t)Gp->peg_hi[i]] = 1;
+            }
+        }
+        std::vector<int32_t> new_of((size_t)G + 1, 0);
+        first.clear(); len.clear();
+        bool prev_plain = false;
+        for (int i = 0; i < G; ++i) {
+            const bool pl = plain(i);
+            if (i > 0 && pl && prev_plain && !cut[(size_t)i] && same(i, i - 1)) len.back()++;
+            else { first.push_back(i); len.push_back(1); }
+            new_of[(size_t)i] = (int32_t)first.size() - 1;
+            prev_plain = pl;
+        }
+        const int Gm = (int)first.size();
+        new_of[(size_t)G] = Gm;
+        if (Gm == G) return false;
+        // ---- merged PEG table ----
+        auto rows = [&](auto& dst, const auto* src, int w) { dst.clear(); if (!src || w == 0) return; dst.resize((size_t)Gm * (size_t)w); for (int m = 0; m < Gm; ++m) for (int k = 0; k < w; ++k) dst[(size_t)m * w + k] = src[(int64_t)first[(size_t)m] * w + k]; };
+        rows(req, P->req, R); rows(count, P->count, 1); rows(flags, P->flags, 1); rows(tol, P->tol_mask, Wt); rows(sel, P->sel_mask, Wl);
+        rows(xb, P->excl_block, Wx); rows(xm, P->excl_mark, Wx); rows(zb, P->zone_block, Wz); rows(zm, P->zone_mark, Wz); rows(fpc, P->fp_cpu, 1); rows(fpm, P->fp_mem, 1);
+        for (int m = 0; m < Gm; ++m) if (len[(size_t)m] > 1) { count[(size_t)m] = len[(size_t)m]; flags[(size_t)m] |= CASIM_KFLAG_SINGLETON_RUN; }
+        p = *P; p.n_pegs = Gm;
+        p.req = req.data(); p.count = count.data(); p.flags = flags.data();
+        p.tol_mask = tol.empty() ? nullptr : tol.data(); p.sel_mask = sel.empty() ? nullptr : sel.data();
+        p.excl_block = xb.empty() ? nullptr : xb.data(); p.excl_mark = xm.empty() ? nullptr : xm.data();
+        p.zone_block = zb.empty() ? nullptr : zb.data(); p.zone_mark = zm.empty() ? nullptr : zm.data();
+        p.fp_cpu = fpc.empty() ? nullptr : fpc.data(); p.fp_mem = fpm.empty() ? nullptr : fpm.data();
+        // ---- the groups' views of it ----
+        g = *Gp;
+        if (Gp->peg_offsets && Gp->peg_index) {
+            off.assign(1, 0); idx.clear();
+            for (int i = 0; i < NG; ++i) {
+                for (int32_t k = Gp->peg_offsets[i]; k < Gp->peg_offsets[i + 1]; ++k) {
+                    const int32_t m = new_of[(size_t)Gp->peg_index[k]];
+                    if (Gp->peg_index[k] == first[(size_t)m]) idx.push_back(m);   // (the cuts made every listed run whole: its head stands for it)
+                }
+                off.push_back((int32_t)idx.size());
+            }
+            if (idx.empty()) idx.push_back(0);
+            g.peg_offsets = off.data(); g.peg_index = idx.data();
+        } else if (Gp->peg_lo && Gp->peg_hi) {
+            lo.resize((size_t)NG); hi.resize((size_t)NG);
+            for (int i = 0; i < NG; ++i) { lo[(size_t)i] = new_of[(size_t)Gp->peg_lo[i]]; hi[(size_t)i] = new_of[(size_t)Gp->peg_hi[i]]; }
+            g.peg_lo = lo.data(); g.peg_hi = hi.data();
+        }
+        active = true;
+        return true;
+    }
+    // entries of merged lists -> entries of the caller's lists
+    int64_t expanded(const int32_t* ids, int64_t n) const { int64_t t = 0; for (int64_t k = 0; k < n; ++k) t += len[(size_t)ids[k]]; return t; }
+};
+
 template <class BK>
 class ProblemT {
 public:
@@ -56,6 +170,7 @@ public:
         if (p->n_pegs < 0 || g->n_groups < 0) return fail(CASIM_ERR_INVALID, "negative size");
         if (p->n_res < 2 || p->n_res > CASIM_KMAX_RES) return fail(CASIM_ERR_INVALID, "n_res must be in [2, 8]");
         if (p->w_taint < 0 || p->w_label < 0 || p->w_excl < 0 || p->w_zone < 0) return fail(CASIM_ERR_INVALID, "negative mask width");
+        if (runs_.build(p, g, o)) { p = &runs_.p; g = &runs_.g; }   // adjacent identical singleton PEGs become one row (SingletonRuns)
         G_ = p->n_pegs; NG_ = g->n_groups;
         memset(&dt_, 0, sizeof dt_); memset(&dr_, 0, sizeof dr_); memset(&ps_, 0, sizeof ps_); memset(&os_, 0, sizeof os_);
         dt_.G = G_; dt_.R = p->n_res; dt_.Wt = p->w_taint; dt_.Wl = p->w_label; dt_.Wx = p->w_excl; dt_.Wz = p->w_zone;
@@ -390,14 +505,59 @@ public:
             bk_.sync();
         }
         if (NG_ == 0) { if (nnz_out) *nnz_out = 0; if (offsets_out) offsets_out[0] = 0; return CASIM_OK; }   // an empty shard
-        if (nnz_out) *nnz_out = NG_ > 0 ? h_off_[(size_t)NG_] : 0;
-        if (offsets_out && NG_ >= 0) for (int i = 0; i <= NG_; ++i) offsets_out[i] = h_off_.empty() ? 0 : h_off_[(size_t)i];
+        const std::vector<int32_t>* offs = &h_off_;
+        if (runs_.active) {   // the caller counts entries of ITS lists: a merged row stands for `len` of them
+            const int32_t rc = expand_offsets();
+            if (rc != CASIM_OK) return rc;
+            offs = &h_off_exp_;
+        }
+        if (nnz_out) *nnz_out = NG_ > 0 ? (*offs)[(size_t)NG_] : 0;
+        if (offsets_out && NG_ >= 0) for (int i = 0; i <= NG_; ++i) offsets_out[i] = offs->empty() ? 0 : (*offs)[(size_t)i];
+        return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
+    }
+    // merged lists -> offsets in the caller's numbering (h_off_ must be current)
+    int32_t expand_offsets() {
+        const size_t NG = (size_t)NG_, nnz = NG > 0 ? (size_t)h_off_[NG] : 0;
+        h_idx_m_.resize(nnz + 1);
+        if (nnz > 0) {
+            if (csr_on_device_) { bk_.d2h(h_idx_m_.data(), d_idx_, 4 * nnz); bk_.sync(); }
+            else memcpy(h_idx_m_.data(), runs_.g.peg_index, 4 * nnz);
+        }
+        h_off_exp_.assign(NG + 1, 0);
+        for (size_t i = 0; i < NG; ++i) {
+            const int64_t t = (int64_t)h_off_exp_[i] + runs_.expanded(h_idx_m_.data() + h_off_[i], (int64_t)h_off_[i + 1] - h_off_[i]);
+            if (t > 0x7fffffffll) return fail(CASIM_ERR_INVALID, "expanded PEG lists too long");
+            h_off_exp_[i + 1] = (int32_t)t;
+        }
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
     }
 
     int32_t fetch(casim_results* out) {
         if (!ready_ || !ran_) return fail(CASIM_ERR_INVALID, "nothing to fetch: run the problem first");
         if (!out) return fail(CASIM_ERR_INVALID, "null results");
+        if (runs_.active && (out->order || out->placed)) {
+            // merged rows on the device, the caller's rows in its arrays: fetch into host copies, then write every run out member by
+            // member — identical pods tried in order, so the first `placed` of them were scheduled
+            casim_results m = *out;
+            int32_t rc = csr(nullptr, nullptr);                       // h_off_ (merged), h_idx_m_, h_off_exp_
+            if (rc != CASIM_OK) return rc;
+            const size_t NG = (size_t)NG_, nnz_m = NG > 0 ? (size_t)h_off_[NG] : 0;
+            std::vector<int32_t> order_m(nnz_m + 1), placed_m(nnz_m + 1);
+            m.order = order_m.data(); m.placed = placed_m.data();
+            runs_.active = false;                                     // (the plain path below, on the merged numbering)
+            rc = fetch(&m);
+            runs_.active = true;
+            if (rc != CASIM_OK) return rc;
+            for (size_t i = 0; i < NG; ++i) {
+                int64_t at = h_off_exp_[i];
+                for (int32_t k = h_off_[i]; k < h_off_[i + 1]; ++k) {
+                    const int32_t row = order_m[(size_t)k], n = runs_.len[(size_t)row], f = runs_.first[(size_t)row], pl = placed_m[(size_t)k];
+                    if (n == 1) { if (out->order) out->order[at] = f; if (out->placed) out->placed[at] = pl; ++at; continue; }
+                    for (int32_t j = 0; j < n; ++j, ++at) { if (out->order) out->order[at] = f + j; if (out->placed) out->placed[at] = j < pl ? 1 : 0; }
+                }
+            }
+            return CASIM_OK;
+        }
         const size_t NG = (size_t)NG_, ng = NG > 0 ? NG : 1;
         // copy 1: scalars + offsets (one slab); copies 2, 3: order / placed — enqueued with the first one when their bound is
         // small or the offsets are the caller's, after it (the device-side nnz is in the slab) otherwise
@@ -603,6 +763,8 @@ private:
     bool csr_on_device_ = false, pack_lds_ = true, order_lds_ = true, ready_ = false, ran_ = false;
     int fast_wx_ = 0;
     bool fast_retry_ = false;
+    SingletonRuns runs_;
+    std::vector<int32_t> h_off_exp_, h_idx_m_;
     int pack_build_ = 0;      // casim_options.pack_build
     size_t pack_smem_ = 0, order_smem_ = 0;
     int order_threads_ = kOrderThreads;

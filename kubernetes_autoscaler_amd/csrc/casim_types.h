@@ -79,6 +79,11 @@ struct DevResults {
 
 // kernel-internal flag bit (not part of the ABI): the template-level Filters pass for (PEG, group)
 #define CASIM_KFLAG_STATIC_OK 0x80000000u
+// kernel-internal PEG flag (never set by a caller): this table row stands for a RUN of adjacent, identical, controller-less pods — k
+// singleton PodEquivalenceGroups that the host merged into one row of k pods (casim_pipeline.h, SingletonRuns).  The packer
+// places them with the closed forms of one PEG and applies the one rule in which k singleton PEGs differ from a PEG of k pods:
+// every pod after the first on a NEW node reaches it through tryToScheduleOnExistingNodes, which moves lastIndex there.
+#define CASIM_KFLAG_SINGLETON_RUN 0x40u
 
 // PEG record of the register packer (dwords; RL = 2 or 4 request lanes, record = 8 or 16 dwords):
 //   [0] pods of the PEG

@@ -338,6 +338,44 @@ def fuzz(seed: int, max_groups: int = 4, max_pegs: int = 12, rich: bool = True) 
     return Workload(f"fuzz{seed}", pegs, groups, existing)
 
 
+def fuzz_singleton_runs(seed: int, max_groups: int = 3) -> Workload:
+    """Runs of ADJACENT identical controller-less pods — one PodEquivalenceGroup each (equivalence/groups.go:69-73; the shape
+    of BenchmarkRunOnceScaleUp) — between ordinary PEGs, against templates with limits of every sign, existing nodes, entry
+    lastIndex values, an unschedulable template now and then: what casim_pipeline.h merges into one row per run (SingletonRuns).
+    The oracle estimates every singleton on its own."""
+    rng = SplitMix64(0x51A61E00 + seed)
+    groups = []
+    for gi in range(1 + rng.below(max_groups)):
+        node = _node(f"sr{seed}-ng{gi}", rng.pick([1000, 2000, 4000, 8000]), rng.pick([2, 4, 8, 32]) * GiB, rng.pick([2, 3, 5, 10, 110]),
+                     {LABEL_ZONE: f"zone-{rng.below(2)}", "pool": f"p{rng.below(2)}"},
+                     [Taint("dedicated", "x", "NoSchedule")] if rng.chance(1, 6) else [])
+        if rng.chance(1, 10):
+            node.unschedulable = True
+        groups.append(GroupPlan(NodeInfo(node, []), max_nodes=rng.pick([0, 0, 2, 5, 9, 40, -1]), last_index=rng.below(7)))
+    pegs = []
+    shapes = [(rng.pick([100, 250, 500, 1000]), rng.pick([128 * MiB, 512 * MiB, 1 * GiB, 2 * GiB])) for _ in range(3)]
+    n = 0
+    for _ in range(2 + rng.below(6)):
+        kind = rng.below(4)
+        if kind <= 1:                       # a run of identical singletons
+            cpu, mem = rng.pick(shapes)
+            kw = {}
+            if rng.chance(1, 4):
+                kw["tolerations"] = [Toleration(key="dedicated", operator="Exists")]
+            if rng.chance(1, 5):
+                kw["node_selector"] = {"pool": f"p{rng.below(2)}"}
+            for _k in range(rng.pick([1, 2, 3, 5, 9, 17, 40])):
+                pegs.append(_peg(f"sr{seed}-s{n}", cpu, mem, 1, labels={"app": "solo"}, **{k: (list(v) if isinstance(v, list) else dict(v)) for k, v in kw.items()})); n += 1
+        elif kind == 2:                     # an ordinary PEG in between
+            pegs.append(_peg(f"sr{seed}-p{n}", rng.pick([100, 300, 700]), rng.pick([256 * MiB, 1 * GiB]), rng.pick([2, 4, 11, 30]), labels={"app": f"c{n}"})); n += 1
+        else:                               # singletons that differ (no run), one with a host port (never merged)
+            for _k in range(1 + rng.below(3)):
+                kw = {"host_ports": [ContainerPort(8080)]} if rng.chance(1, 3) else {}
+                pegs.append(_peg(f"sr{seed}-d{n}", rng.pick([150, 350, 550]), rng.pick([128 * MiB, 384 * MiB]), 1, labels={"app": f"d{n}"}, **kw)); n += 1
+    existing = [NodeInfo(_node(f"sr{seed}-old{i}", 1000, 1 * GiB, 10, {LABEL_ZONE: "zone-0"})) for i in range(rng.below(4))]
+    return Workload(f"singleton_runs{seed}", pegs, groups, existing)
+
+
 # ---------------------------------------------------------------------------------------------
 # filter-out-schedulable workloads (SURVEY §8 f1): pending pods against the nodes already in the cluster
 # ---------------------------------------------------------------------------------------------

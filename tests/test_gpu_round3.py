@@ -181,3 +181,28 @@ def test_a_failing_self_check_retires_the_option_build():
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["info"]["build"] == "plain" and out["info"]["batches_differing"] == 1 and out["fast"] > 0, out
     assert "retired for this process" in p.stderr
+
+
+def test_runs_of_identical_singleton_pegs_on_the_device(ctx):
+    """SingletonRuns (csrc/casim_pipeline.h): adjacent identical controller-less pods estimated as one row — equal to the oracle, which
+    estimates every singleton PEG on its own, and to the unmerged run; BenchmarkRunOnceScaleUp's 10 000 singletons at full size."""
+    from kubernetes_autoscaler_amd.engine import Problem
+    for seed in range(80):
+        w = workloads.fuzz_singleton_runs(seed)
+        for dcsr in (False, True):
+            sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing, lanes=w.lanes, device_csr=dcsr)
+            enc = encode(sc); want = run_oracle(sc)
+            for generic in (False, True):
+                with Problem(ctx, enc.pegs, enc.groups, force_generic_packer=generic) as p:
+                    p.run(); res = p.fetch()
+                assert_matches_oracle(res, want, f"singleton runs {seed} csr={dcsr} generic={generic}")
+            enc.close()
+    w = workloads.CONFIGS["R1"]()
+    sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing, lanes=w.lanes, device_csr=True)
+    enc = encode(sc); want = run_oracle(sc)
+    with Problem(ctx, enc.pegs, enc.groups) as p:
+        p.run(); res = p.fetch()
+        tot, kms = p.time(iters=5)
+    assert_matches_oracle(res, want, "R1, 10 000 singleton PEGs as one row")
+    assert int(res.nodes_added[0]) == 200 and tot < 2.0, (tot, kms)     # (14.5 ms as 10 000 dependent steps)
+    enc.close()
