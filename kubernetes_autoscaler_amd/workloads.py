@@ -342,7 +342,7 @@ def fuzz_singleton_runs(seed: int, max_groups: int = 3) -> Workload:
     """Runs of ADJACENT identical controller-less pods — one PodEquivalenceGroup each (equivalence/groups.go:69-73; the shape
     of BenchmarkRunOnceScaleUp) — between ordinary PEGs, against templates with limits of every sign, existing nodes, entry
     lastIndex values, an unschedulable template now and then: what casim_pipeline.h merges into one row per run (SingletonRuns).
-    The oracle estimates every singleton on its own."""
+    The CPU checker of the tests estimates every singleton on its own."""
     rng = SplitMix64(0x51A61E00 + seed)
     groups = []
     for gi in range(1 + rng.below(max_groups)):
