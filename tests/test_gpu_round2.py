@@ -231,14 +231,20 @@ def test_node_pods_and_the_analyser_hook(ctx):
     n, pods = e.estimate(w.pegs, w.groups[0].template, est.NodeGroup("c0", 10, 0))
     assert n == len(seen) > 0 and all(k.startswith("c0-template-e-") for k in seen)
     # fastpath: the extrapolated nodes reach the analyser as "<lastNodeName>-fake-<j>" (binpacking_estimator.go:311-321), so that
-    # len(newNodesWithPods) == the returned node count as in the reference
+    # len(newNodesWithPods) == the returned node count as in the reference.  One PEG of many identical pods: tryFastPath
+    # simulates ONE node and books the rest by arithmetic.
+    import copy
+    from kubernetes_autoscaler_amd.objects import PodEquivalenceGroup
     seen.clear()
+    pod = w.pegs[0].pods[0]
+    one = [PodEquivalenceGroup(pods=[copy.copy(pod) for _ in range(60)])]
+    limiter = est.ThresholdBasedEstimationLimiter([est.StaticThreshold(100)])
     e = est.BinpackingNodeEstimator(ctx, est.ClusterSnapshotView(), limiter, estimation_analyser_func=lambda snap, ng, nodes: seen.update(nodes),
                                     fastpath_binpacking_enabled=True)
-    n, pods = e.estimate(w.pegs, w.groups[0].template, est.NodeGroup("c0", 10, 0))
-    assert n == len(seen) > 1, (n, seen)
+    n, pods = e.estimate(one, w.groups[0].template, est.NodeGroup("c0", 100, 0))
+    assert n == len(seen) > 1 and len(pods) == 60, (n, seen)
     fake = sorted(k for k in seen if "-fake-" in k)
-    assert fake and all(k.startswith("c0-template-e-0-fake-") for k in fake) and len(fake) == n - 1, seen
+    assert len(fake) == n - 1 and all(k.startswith("c0-template-e-0-fake-") for k in fake), seen
 
 
 def test_resident_cluster_iteration(ctx):
