@@ -71,10 +71,11 @@ if has "prof|full"; then
   for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"; do
     N=$(echo $C | tr ' ' '_' | cut -c1-24)
     echo "== rocprofv3 pmc $C ==" | tee -a "$S"
-    # (counter passes serialise the kernels: the lane probe of casim_ctx would find no two streams running side by side and leave the
-    # batch uncut — CASIM_LANE_PROBE=0 keeps the launch geometry of the timed run, 4 sub-batches of 20480 waves)
-    (cd /tmp && CASIM_LANE_PROBE=0 timeout 900 rocprofv3 --pmc $C --kernel-trace -d "$OLDPWD/$OUT/prof_pmc_$N" -o pmc -- \
-        python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-next-rows --no-c3 > "$OLDPWD/$OUT/prof_pmc_$N.log" 2>&1)
+    # (counters are device-global, sampled around a dispatch: kernels of other streams that overlap it pollute them.  The counter passes
+    # therefore run ONE sub-batch of the timed loop as the whole batch on one stream — 1024 simulations = the same 20480-wave launches,
+    # device to themselves)
+    (cd /tmp && timeout 900 rocprofv3 --pmc $C --kernel-trace -d "$OLDPWD/$OUT/prof_pmc_$N" -o pmc -- \
+        python "$OLDPWD/bench.py" --steps 3 --warmup 1 --batch 1024 --streams 1 --no-cpu-baseline --no-configs --no-next-rows --no-c3 > "$OLDPWD/$OUT/prof_pmc_$N.log" 2>&1)
     echo "pmc $N exit $?" | tee -a "$S"
   done
   python tools/rocpd_summary.py "$OUT"/prof_trace "$OUT"/prof_pmc_* > "$OUT/rocpd_summary.txt" 2>&1
