@@ -450,12 +450,29 @@ def main():
         else:
             h = t.cpu(); dist.all_reduce(h, op=op); t.copy_(h)
 
+    # N > 1: the step's collective runs on a stream of its own, and ONLY that stream waits for the keys (casim_option_query.join_stream): the
+    # context's stream stays idle, so the next run does not fork from it and the sub-batches keep running ahead of each other exactly as at
+    # N = 1 — with the default join every internal stream waited for all the others' previous step, the four chains ran in lock-step (all in
+    # the feasibility phase, then all in the packer) and the step took 1.45 ms instead of 1.03 (1-rank RCCL group, profiles/r05j_*).
+    # The steps are independent batches; keys are double-buffered and the host waits for the all-reduce of two steps ago before a buffer is
+    # written again.
+    comm_stream = torch.cuda.Stream(device=dev_index) if collective else None
+    keys2 = [keys, torch.full_like(keys, 0x7FFFFFFFFFFFFFFF)] if collective else [keys]
+    reduced = [None, None]
+    step_no = [0]
+
     def make_step(b):
         if collective:
             def step():
+                i = step_no[0] & 1
+                step_no[0] += 1
+                if reduced[i] is not None:
+                    reduced[i].synchronize()                                                 # host: this buffer's previous all-reduce (two steps ago) is done
                 b.run()
-                b.best_option_sims(kinds, dev_packed_ptr=keys.data_ptr(), fetch=False)   # joins the internal streams into side_stream
-                allreduce(keys, dist.ReduceOp.MIN)                                       # ... where the collective runs; the next run() forks after it
+                b.best_option_sims(kinds, dev_packed_ptr=keys2[i].data_ptr(), fetch=False, join_stream=comm_stream.cuda_stream)
+                with torch.cuda.stream(comm_stream):
+                    allreduce(keys2[i], dist.ReduceOp.MIN)
+                    reduced[i] = torch.cuda.Event(); reduced[i].record(comm_stream)
         else:
             def step():
                 b.run()
@@ -512,7 +529,7 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = checks_per_step / (dt / args.steps)
-        winners = keys.cpu().numpy() if collective else final["packed"]
+        winners = keys2[(step_no[0] - 1) & 1].cpu().numpy() if collective else final["packed"]   # (the last step's reduced keys)
         have = winners != 0x7FFFFFFFFFFFFFFF
         # per-kernel HIP-event timing on the launch stream (libcasim), twice: in the regime of the timed region — the other
         # internal streams keep running their parts while part 0 is timed (casim_problem_run_marked), which is what a kernel

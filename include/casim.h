@@ -38,7 +38,7 @@ extern "C" {
                                * 4: casim_options.n_streams (sub-batches on internal HIP streams), casim_enc_group_pods,
                                *    casim_enc_add_grouped_pegs, casim_enc_pod_set_spec_extra
                                * 5: casim_options.pack_build, casim_pack_build_info (two builds of the register packer + self-check),
-                               *    casim_problem_info [5], [6], casim_prefetch_*, casim_enc_begin_update / _group_reset / _refinalize / _group_rows */
+                               *    casim_problem_info [5], [6], casim_option_query.join_stream, casim_prefetch_*, casim_enc_begin_update / _group_reset / _refinalize / _group_rows */
 
 /* Resource lanes.  Lane 0 = cpu in millicores (Quantity.MilliValue), lane 1 = memory bytes,
  * lane 2 = ephemeral-storage bytes, lanes 3.. = scalar / extended resources (Quantity.Value),
@@ -387,6 +387,13 @@ typedef struct casim_option_query {
     int64_t* packed_out;        /* [S] or NULL */
     void* dev_key_out;          /* device [S][10] int64 or NULL */
     void* dev_packed_out;       /* device [S] int64 or NULL */
+    void* join_stream;          /* hipStream_t or NULL.  With dev_* outputs the keys are ordered against a stream: by default the CONTEXT's
+                                   stream waits for them (a collective enqueued there sees them) — and, being busy, makes the next
+                                   casim_problem_run fork from it: every internal stream then waits for all the others' previous step.  A
+                                   caller whose steps are independent passes the stream its collective runs on instead: only THAT stream
+                                   waits, the context's stream stays idle and the sub-batches keep running ahead of each other (the
+                                   caller then owns the reuse of its key buffers: bench.py keeps two and waits on the host for the
+                                   all-reduce of two steps ago). */
 } casim_option_query;
 int32_t casim_best_option_sims(casim_problem* p, const casim_option_query* q);
 

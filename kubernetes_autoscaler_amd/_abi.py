@@ -91,7 +91,7 @@ class Results(C.Structure):
 class OptionQuery(C.Structure):
     _fields_ = [("kinds", i32p), ("n_kinds", C.c_int32), ("group_id_base", C.c_int32), ("per_sim", C.c_int32), ("valid", u8p),
                 ("best_out", i32p), ("n_best_out", i32p), ("best_set_out", u8p), ("key_out", i64p), ("packed_out", i64p),
-                ("dev_key_out", C.c_void_p), ("dev_packed_out", C.c_void_p)]
+                ("dev_key_out", C.c_void_p), ("dev_packed_out", C.c_void_p), ("join_stream", C.c_void_p)]
 
 
 class EncoderOptions(C.Structure):

@@ -101,6 +101,7 @@ struct HipBackend {
     }
     bool idle() { const hipError_t e = hipStreamQuery(stream); if (e == hipErrorNotReady) return false; check(e, "hipStreamQuery"); return true; }
     void wait_mark(HipBackend& o) { if (o.mark_ev) check(hipStreamWaitEvent(stream, o.mark_ev, 0), "hipStreamWaitEvent"); }
+    void make_wait(void* raw_stream) { if (mark_ev) check(hipStreamWaitEvent((hipStream_t)raw_stream, mark_ev, 0), "hipStreamWaitEvent"); }
     size_t lds_budget() const { return lds; }
     bool ok() const { return last == hipSuccess; }
     const char* error() const { return msg.c_str(); }
@@ -710,7 +711,11 @@ int32_t casim_best_option(casim_problem* p, const int32_t* kinds, int32_t n_kind
 int32_t casim_best_option_sims(casim_problem* p, const casim_option_query* q) {
     PROB_ENTER(p);
     if (p->sp) { clear_lanes(p); const int32_t rc = p->sp->best_option_query(q); if (rc != CASIM_OK) return set_err(rc, p->sp->error()); return lanes_ok(p); }
-    PROB_RET(p, p->prob->best_option_query(q));
+    const int32_t rc = p->prob->best_option_query(q);
+    if (rc == CASIM_OK && q && q->join_stream && (q->dev_key_out || q->dev_packed_out) && q->join_stream != (void*)p->ctx->bk.stream) {
+        p->ctx->bk.mark(); p->ctx->bk.make_wait(q->join_stream);   // an uncut batch ran on the context's stream: the caller's stream waits for it
+    }
+    PROB_RET(p, rc);
 }
 
 // ---- one process, several devices (the caller is one goroutine) -----------------------------------------

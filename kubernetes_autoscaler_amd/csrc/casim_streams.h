@@ -19,8 +19,9 @@
 // are shifted back to the numbering of the whole batch on the host.  Results are identical to the unstreamed call
 // (tests/test_streams_emu.py, tests/test_gpu_round3.py).
 //
-// Backend concept additions:  void mark();  void wait_mark(BK& other);  bool idle();  (record an event on the own stream / make
-// the own stream wait for the other's last mark / nothing is pending on the own stream; trivial for the synchronous emulator).
+// Backend concept additions:  void mark();  void wait_mark(BK& other);  bool idle();  void make_wait(void* raw_stream);  (record an
+// event on the own stream / make the own stream wait for the other's last mark / nothing is pending on the own stream / make a stream of
+// the CALLER's wait for the own last mark; trivial for the synchronous emulator).
 #pragma once
 #include <memory>
 #include <thread>
@@ -159,7 +160,10 @@ public:
             const int32_t rc = part_query(i, q);
             if (rc != CASIM_OK) return rc;
         }
-        if (q->dev_key_out || q->dev_packed_out) join();
+        if (q->dev_key_out || q->dev_packed_out) {
+            if (q->join_stream) { for (size_t i = 0; i < parts_.size(); ++i) { lanes_[i]->mark(); lanes_[i]->make_wait(q->join_stream); } }   // the caller's stream waits, not ours
+            else join();
+        }
         return CASIM_OK;
     }
     int32_t part_query(size_t i, const casim_option_query* q) {

@@ -483,10 +483,11 @@ class Problem:
         return int(best.value), int(nbest.value), bset[:self.n_groups], key
 
     def best_option_sims(self, kinds: Sequence[int], per_sim: bool = True, valid=None, group_id_base: int = 0,
-                         dev_packed_ptr: Optional[int] = None, fetch: bool = True, n_sims: Optional[int] = None):
+                         dev_packed_ptr: Optional[int] = None, fetch: bool = True, n_sims: Optional[int] = None, join_stream: Optional[int] = None):
         """casim_best_option_sims: the expander chain once per simulation of the batch (or once over every group), with an
         optional validity mask (all-or-nothing).  fetch=False only enqueues the kernel (the packed keys land in
-        dev_packed_ptr for an RCCL all-reduce).  Returns dict(best, n_best, best_set, keys, packed) when fetching."""
+        dev_packed_ptr for an RCCL all-reduce; join_stream = raw handle of the stream that shall wait for them instead of the
+        context's stream: casim_option_query.join_stream).  Returns dict(best, n_best, best_set, keys, packed) when fetching."""
         ks = (C.c_int32 * max(len(kinds), 1))(*kinds)
         S = (n_sims if n_sims else 1) if per_sim else 1
         q = _abi.OptionQuery(kinds=ks, n_kinds=len(kinds), group_id_base=int(group_id_base), per_sim=int(bool(per_sim)))
@@ -498,6 +499,8 @@ class Problem:
             q.valid = _ptr(v, C.c_uint8); keep.append(v)
         if dev_packed_ptr:
             q.dev_packed_out = C.c_void_p(dev_packed_ptr)
+        if join_stream:
+            q.join_stream = C.c_void_p(join_stream)
         out = None
         if fetch:
             out = dict(best=np.full(S, -1, np.int32), n_best=np.zeros(S, np.int32), best_set=np.zeros(max(self.n_groups, 1), np.uint8),

@@ -33,8 +33,8 @@ class StreamedBatch:
     def run(self):
         self.prob.run()
 
-    def best_option_sims(self, kinds: Sequence[int], dev_packed_ptr: Optional[int] = None, fetch: bool = True):
-        return self.prob.best_option_sims(kinds, per_sim=True, fetch=fetch, dev_packed_ptr=dev_packed_ptr, n_sims=self.n_sims)
+    def best_option_sims(self, kinds: Sequence[int], dev_packed_ptr: Optional[int] = None, fetch: bool = True, join_stream: Optional[int] = None):
+        return self.prob.best_option_sims(kinds, per_sim=True, fetch=fetch, dev_packed_ptr=dev_packed_ptr, n_sims=self.n_sims, join_stream=join_stream)
 
     def fetch(self) -> BatchResult:
         return self.prob.fetch()

@@ -25,6 +25,7 @@ struct EmuBackend {
     void mark() {}
     bool idle() { return true; }
     void wait_mark(EmuBackend&) {}
+    void make_wait(void*) {}
     std::vector<char> staging[2];
     void* stage(int which, size_t bytes) { if (staging[which & 1].size() < bytes) staging[which & 1].resize(bytes); return staging[which & 1].data(); }
     size_t lds_budget() const { return lds; }
