@@ -39,7 +39,7 @@ def test_struct_layouts_match_the_header():
     # sizes computed by hand from include/casim.h (LP64): ints first, then pointers
     assert ctypes.sizeof(_abi.Pegs) == 6 * 4 + 11 * 8
     assert ctypes.sizeof(_abi.Groups) == 8 + 19 * 8 + 3 * 8 + 8 + 8
-    assert ctypes.sizeof(_abi.OptionQuery) == 8 + 4 * 4 + 8 * 8
+    assert ctypes.sizeof(_abi.OptionQuery) == 8 + 4 * 4 + 9 * 8      # (+ join_stream, ABI 5)
     assert ctypes.sizeof(_abi.Results) == 10 * 8 + 3 * 8
     assert ctypes.sizeof(_abi.Options) == 32 and ctypes.sizeof(_abi.EncoderOptions) == 32
 
