@@ -111,3 +111,17 @@ def test_group_ids_beyond_the_key_field_are_rejected():
     ts.global_id = None
     run_emu_multi(ts, 2, kinds=[_abi.EXPANDER_LEAST_NODES], group_id_base=(1 << 20) - 1, expect_rc=_abi.ERR_INVALID)
     enc.close()
+
+
+@pytest.mark.parametrize("n_devices", [1, 2, 3])
+@pytest.mark.parametrize("seed", range(12))
+def test_singleton_runs_across_devices(seed, n_devices):
+    """SingletonRuns (casim_pipeline.h) under the multi-device path: every device merges the runs of its own view and writes them out
+    member by member; one simulation (merging is off for batches of simulations), groups block-partitioned over the devices."""
+    w = workloads.fuzz_singleton_runs(300 + seed, max_groups=5)
+    sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, None) for g in w.groups], existing=w.existing, lanes=w.lanes, device_csr=True)
+    enc = encode(sc)
+    ts = TableSet.from_encoder(enc).as_one_simulation()
+    got, _, info = run_emu_multi(ts, n_devices)
+    assert_matches_oracle(got, run_oracle(sc), f"singleton runs over {n_devices} devices, seed {seed}")
+    enc.close()
