@@ -273,6 +273,11 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
     int cstart = 0, cend = 0, cpart = -1;
     int32_t my_class = 0, my_count = 0, my_hint = -1, my_first = 0, my_pair = -1, my_ctrl = -1;
     uint32_t my_flags = 0;
+    // per-class facts of the chunk's runs, fetched with the run records (one lane per run): the class's self-exclusion verdict and its
+    // slices of the rule tables.  As per-run loads behind the class id they were three dependent HBM round trips in front of every
+    // run — a third of the removal loop's time, whose runs are one or two pods long (profiles/r05d_sched_phase_profile.txt)
+    uint32_t my_selfx = 0;
+    int32_t my_klo = 0, my_khi = 0, my_ilo = 0, my_ihi = 0;   // (rules of the class: [klo, khi); increments: [ilo, ihi))
     int64_t my_req[RMAX_];
     double my_rq[RMAX_];
 #pragma unroll
@@ -365,6 +370,10 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
                     my_rq[r] = my_req[r] > 0 ? 1.0 / (double)my_req[r] : 0.0;
                 }
                 my_flags = have ? t.pflags[my_class] : 0u;
+                my_selfx = (my_flags & CASIM_PEG_SELF_EXCL_NODE) != 0 ? 1u : 0u;
+                if (have) for (int w = 0; w < Wx; ++w) my_selfx |= (t.xblock[(int64_t)my_class * Wx + w] & t.xmark[(int64_t)my_class * Wx + w]) != 0 ? 1u : 0u;
+                my_klo = (have && n_rules > 0) ? a.class_rule_off[my_class] : 0; my_khi = (have && n_rules > 0) ? a.class_rule_off[my_class + 1] : 0;
+                my_ilo = (have && n_rules > 0) ? a.inc_off[my_class] : 0; my_ihi = (have && n_rules > 0) ? a.inc_off[my_class + 1] : 0;
             }
             const int j = k - cstart;
             const int c = (int)cs::bcast_u32((uint32_t)my_class, j);
@@ -381,13 +390,12 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) 
             }
             pv.xblock = t.xblock + (int64_t)c * Wx;
             pv.xmark = t.xmark + (int64_t)c * Wx;
-            bool selfx = (cs::bcast_u32(my_flags, j) & CASIM_PEG_SELF_EXCL_NODE) != 0;
-            for (int w = 0; w < Wx; ++w) selfx |= (pv.xblock[w] & pv.xmark[w]) != 0;
+            const bool selfx = cs::bcast_u32(my_selfx, j) != 0;
             const uint64_t* fb = a.fbits + (int64_t)c * (a.cap >> 6);
             int32_t placed = 0;
             // domain rules of the class; a class that feeds one of its own counters is walked pod by pod
-            const int r_lo = n_rules > 0 ? a.class_rule_off[c] : 0, r_hi = n_rules > 0 ? a.class_rule_off[c + 1] : 0;
-            const int i_lo = n_rules > 0 ? a.inc_off[c] : 0, i_hi = n_rules > 0 ? a.inc_off[c + 1] : 0;
+            const int r_lo = (int)cs::bcast_u32((uint32_t)my_klo, j), r_hi = (int)cs::bcast_u32((uint32_t)my_khi, j);
+            const int i_lo = (int)cs::bcast_u32((uint32_t)my_ilo, j), i_hi = (int)cs::bcast_u32((uint32_t)my_ihi, j);
             bool self_aff = false, monotone = true;   // monotone: a node that rejected the class once rejects it for good
             // (affinity rules are not monotone either: a node starts passing once a matching pod lands in its domain)
             bool has_aff = false, aff_self = false, aff_first = false;
