@@ -719,7 +719,7 @@ int32_t casim_enc_term_add_requirement(casim_encoder* e, int32_t pod, int32_t te
  * or the pod is the first of a series with affinity to itself (no matching pod anywhere, it matches its own terms, the node
  * carries every key).  Evaluated on the device in per-node mode (TrySchedulePods, the removal loop, Estimate on the snapshot)
  * as domain rules of kind 2; in template mode the spec is flagged CASIM_PEG_UNSUPPORTED, which sends its node groups to
- * casim_estimate_on_cluster.  A term with a namespaceSelector is outside the subset (casim_enc_pod_mark_unsupported). */
+ * casim_estimate_on_cluster.  A term's namespaceSelector: casim_enc_aff_term_set_namespace_selector (below). */
 int32_t casim_enc_pod_add_affinity_term(casim_encoder* e, int32_t pod, const char* topology_key,
                                         const char* const* namespaces, int32_t n_namespaces);
 int32_t casim_enc_aff_term_add_requirement(casim_encoder* e, int32_t pod, int32_t term, const char* key,
@@ -753,6 +753,12 @@ int32_t casim_enc_namespace_add_label(casim_encoder* e, const char* name, const 
 int32_t casim_enc_term_set_namespace_selector(casim_encoder* e, int32_t pod, int32_t term);
 int32_t casim_enc_term_add_namespace_requirement(casim_encoder* e, int32_t pod, int32_t term, const char* key,
                                                  const char* op, const char* const* values, int32_t n_values);
+/* the same for a required AFFINITY term (index returned by casim_enc_pod_add_affinity_term): the term is the incoming pod's, so a non-empty
+ * selector selects among the namespaces fed with casim_enc_add_namespace — what the namespace lister returns to InterPodAffinity.PreFilter
+ * (plugin.go:144-157); an empty selector selects every namespace. */
+int32_t casim_enc_aff_term_set_namespace_selector(casim_encoder* e, int32_t pod, int32_t term);
+int32_t casim_enc_aff_term_add_namespace_requirement(casim_encoder* e, int32_t pod, int32_t term, const char* key, const char* op,
+                                                     const char* const* values, int32_t n_values);
 int32_t casim_enc_pod_set_fastpath_requests(casim_encoder* e, int32_t pod, double cpu, double mem);
 /* Mark the spec as carrying a predicate outside the encoded subset (required pod affinity,
  * topology spread, volumes, DRA claims...). */

@@ -76,8 +76,11 @@ func (s *session) pod(pod *apiv1.Pod) C.int32_t {
 		if a.PodAffinity != nil {
 			for _, term := range a.PodAffinity.RequiredDuringSchedulingIgnoredDuringExecution {
 				t := C.casim_enc_pod_add_affinity_term(e, id, c.s(term.TopologyKey), c.arr(term.Namespaces), C.int32_t(len(term.Namespaces)))
-				if term.NamespaceSelector != nil { // affinity terms with a namespaceSelector are outside the encoded subset
-					C.casim_enc_pod_mark_unsupported(e, id, c.s("pod affinity with a namespaceSelector"))
+				if term.NamespaceSelector != nil { // the incoming pod's own term: resolved by casim_enc_finalize against the lister's namespaces
+					C.casim_enc_aff_term_set_namespace_selector(e, id, t)
+					s.selector(term.NamespaceSelector, func(k, op *C.char, v **C.char, n C.int32_t) {
+						C.casim_enc_aff_term_add_namespace_requirement(e, id, t, k, op, v, n)
+					})
 				}
 				s.selector(term.LabelSelector, func(k, op *C.char, v **C.char, n C.int32_t) { C.casim_enc_aff_term_add_requirement(e, id, t, k, op, v, n) })
 			}

@@ -212,6 +212,8 @@ PROTOTYPES = {
     "casim_enc_namespace_add_label": (C.c_int32, [C.c_void_p, cstr, cstr, cstr]),
     "casim_enc_term_set_namespace_selector": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
     "casim_enc_term_add_namespace_requirement": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, cstr, cstr, cstrp, C.c_int32]),
+    "casim_enc_aff_term_set_namespace_selector": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
+    "casim_enc_aff_term_add_namespace_requirement": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, cstr, cstr, cstrp, C.c_int32]),
     "casim_enc_node_term_add_requirement": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, cstr, cstr, cstrp, C.c_int32]),
     "casim_enc_pod_add_host_port": (C.c_int32, [C.c_void_p, C.c_int32, cstr, cstr, C.c_int32]),
     "casim_enc_pod_add_anti_affinity_term": (C.c_int32, [C.c_void_p, C.c_int32, cstr, cstrp, C.c_int32]),

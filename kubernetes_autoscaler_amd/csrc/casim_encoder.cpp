@@ -47,7 +47,7 @@ struct Port { std::string ip, proto; int32_t port; bool operator<(const Port& o)
 // resolves it into `namespaces` / `all_ns` the way InterPodAffinity.PreFilter does (mergeAffinityTermNamespacesIfNotEmpty,
 // V/kubernetes/pkg/scheduler/framework/plugins/interpodaffinity/plugin.go:144-157)
 struct Term { std::string topology_key; std::vector<std::string> namespaces; std::vector<Requirement> selector;
-              bool has_ns_sel = false, auto_ns = false, all_ns = false; std::vector<Requirement> ns_sel; };
+              bool has_ns_sel = false, auto_ns = false, all_ns = false, ns_resolved = false; std::vector<Requirement> ns_sel; };
 // A label set: a handful of (key, value) pairs kept sorted by key in one vector — the subset of std::map the encoder uses
 // (operator[], find, count, end).  One record per pod at cluster scale: a tree node per label was a third of the encode calls' time.
 struct Labels {
@@ -417,6 +417,22 @@ int32_t casim_enc_term_add_namespace_requirement(casim_encoder* e, int32_t pod, 
     if (n_values < 0 || (n_values > 0 && !values)) return CASIM_ERR_INVALID;
     e->specs[pod].anti[(size_t)term].ns_sel.push_back(make_req(key, op, values, n_values)); return CASIM_OK;
 }
+// the same for a required AFFINITY term: the term is the incoming pod's, PreFilter replaces a non-empty selector by the namespaces the
+// lister returns for it (interpodaffinity/plugin.go:144-157) — exactly what finalize does with the namespaces it was given
+int32_t casim_enc_aff_term_set_namespace_selector(casim_encoder* e, int32_t pod, int32_t term) {
+    POD_CHECK(e, pod);
+    if (term < 0 || (size_t)term >= e->specs[pod].aff.size()) return CASIM_ERR_INVALID;
+    Term& t = e->specs[pod].aff[(size_t)term];
+    if (t.auto_ns) { t.namespaces.clear(); t.auto_ns = false; }
+    t.has_ns_sel = true; return CASIM_OK;
+}
+int32_t casim_enc_aff_term_add_namespace_requirement(casim_encoder* e, int32_t pod, int32_t term, const char* key, const char* op,
+                                                     const char* const* values, int32_t n_values) {
+    POD_CHECK(e, pod);
+    if (term < 0 || (size_t)term >= e->specs[pod].aff.size() || !e->specs[pod].aff[(size_t)term].has_ns_sel) return CASIM_ERR_INVALID;
+    if (n_values < 0 || (n_values > 0 && !values)) return CASIM_ERR_INVALID;
+    e->specs[pod].aff[(size_t)term].ns_sel.push_back(make_req(key, op, values, n_values)); return CASIM_OK;
+}
 int32_t casim_enc_pod_add_host_port(casim_encoder* e, int32_t pod, const char* ip, const char* protocol, int32_t port) {
     POD_CHECK(e, pod); e->specs[pod].ports.push_back(Port{S(ip), S(protocol), port}); return CASIM_OK;
 }
@@ -547,6 +563,15 @@ int32_t casim_enc_finalize(casim_encoder* e) {
             }
         if (any_sel && !all_known)
             for (auto& p : e->specs) { p.unsupported = true; p.why = "namespaceSelector next to a pod whose namespace is not listed"; }
+        // required AFFINITY terms are only ever the incoming pod's (existing pods' affinity does not constrain it): no symmetry to keep,
+        // an unlisted namespace simply is not selected by a non-empty selector
+        for (auto& p : e->specs)
+            for (auto& t : p.aff) {
+                if (!t.has_ns_sel || t.ns_resolved) continue;
+                t.ns_resolved = true;   // (a second finalize of an update session must not append the namespaces again)
+                if (t.ns_sel.empty()) { t.all_ns = true; continue; }
+                for (auto& kv : e->namespaces) if (selector_matches(t.ns_sel, kv.second)) t.namespaces.push_back(kv.first);
+            }
     }
 
     // ---- dictionaries ------------------------------------------------------------------

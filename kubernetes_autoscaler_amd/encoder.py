@@ -103,12 +103,13 @@ class Encoder:
                 for r in term.namespace_selector:
                     check(lib.casim_enc_term_add_namespace_requirement(h, s, t, _b(r.key), _b(r.operator), _strs(r.values), len(r.values)))
         for term in pod.affinity:   # required pod affinity: domain rules of kind 2 in per-node mode, delegated in template mode
-            if term.namespace_selector is not None:
-                check(lib.casim_enc_pod_mark_unsupported(h, s, b"required pod affinity with a namespaceSelector"))
-                continue
             t = lib.casim_enc_pod_add_affinity_term(h, s, _b(term.topology_key), _strs(term.namespaces), len(term.namespaces))
             if t < 0:
                 check(t, "casim_enc_pod_add_affinity_term")
+            if term.namespace_selector is not None:
+                check(lib.casim_enc_aff_term_set_namespace_selector(h, s, t))
+                for r in term.namespace_selector:
+                    check(lib.casim_enc_aff_term_add_namespace_requirement(h, s, t, _b(r.key), _b(r.operator), _strs(r.values), len(r.values)))
             for r in term.requirements():
                 check(lib.casim_enc_aff_term_add_requirement(h, s, t, _b(r.key), _b(r.operator), _strs(r.values), len(r.values)))
         cpu, mem = pod.fastpath_requests()

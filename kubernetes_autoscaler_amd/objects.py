@@ -137,7 +137,7 @@ class Pod:
     node_affinity_terms: Optional[List[NodeSelectorTerm]] = None
     host_ports: List[ContainerPort] = field(default_factory=list)
     anti_affinity: List[PodAffinityTerm] = field(default_factory=list)
-    # PodAffinity.RequiredDuringSchedulingIgnoredDuringExecution (explicit namespaces; a namespace_selector marks the spec unsupported)
+    # PodAffinity.RequiredDuringSchedulingIgnoredDuringExecution (namespaces and / or a namespace_selector, resolved through the lister)
     affinity: List[PodAffinityTerm] = field(default_factory=list)
     # first container's requests as AsApproximateFloat64 for the fastpath chooser; None = derive
     fastpath_cpu: Optional[float] = None

@@ -840,10 +840,22 @@ def add_random_namespace_selectors(seed: int, pods: Sequence[Pod], hostname_only
         if not terms and rng.chance(1, 4):
             terms.append(PodAffinityTerm(LABEL_HOSTNAME if hostname_only or rng.chance(2, 3) else LABEL_ZONE, match_labels={"app": rng.pick(apps)},
                                          namespace_selector=list(rng.pick(selectors))))
+        # required AFFINITY terms: the incoming pod's own terms, resolved through the namespace lister (plugin.go:144-157)
+        aterms = [PodAffinityTerm(t.topology_key, dict(t.match_labels), list(t.match_expressions), tuple(t.namespaces), t.namespace_selector)
+                  for t in getattr(group[0], "affinity", [])]
+        for t in aterms:
+            if rng.chance(1, 2):
+                t.namespace_selector = list(rng.pick(selectors))
+                t.namespaces = tuple(rng.sample(names, rng.below(3))) if rng.chance(1, 2) else ()
+            elif rng.chance(1, 3):
+                t.namespaces = tuple(rng.sample(names, 1 + rng.below(2)))
         for p in group:
             p.namespace = ns
             p.anti_affinity = [PodAffinityTerm(t.topology_key, dict(t.match_labels), list(t.match_expressions), tuple(t.namespaces),
                                                None if t.namespace_selector is None else list(t.namespace_selector)) for t in terms]
+            if aterms:
+                p.affinity = [PodAffinityTerm(t.topology_key, dict(t.match_labels), list(t.match_expressions), tuple(t.namespaces),
+                                              None if t.namespace_selector is None else list(t.namespace_selector)) for t in aterms]
     return table
 
 

@@ -334,6 +334,21 @@ int orc_term_namespace_requirement(orc* o, int pod, int term, const char* key, c
     requirement r = make_req(o, key, op, values, n);
     VEC_PUSH(o->pods.v[pod].anti_terms.v[term].ns_sel, r); return 0;
 }
+/* the same for a REQUIRED AFFINITY term (V/kube-scheduler/framework/types.go:390-395, 439-447; the term is the incoming pod's: a
+ * non-empty selector only ever selects namespaces the lister knows, interpodaffinity/plugin.go:144-157) */
+int orc_aff_term_namespace_selector(orc* o, int pod, int term) {
+    PODCHK(o, pod);
+    if (term < 0 || term >= o->pods.v[pod].aff_terms.n) return -1;
+    aff_term* t = &o->pods.v[pod].aff_terms.v[term];
+    if (t->auto_ns) { t->namespaces.n = 0; t->auto_ns = 0; }
+    t->has_ns_sel = 1; return 0;
+}
+int orc_aff_term_namespace_requirement(orc* o, int pod, int term, const char* key, const char* op, const char* const* values, int n) {
+    PODCHK(o, pod);
+    if (term < 0 || term >= o->pods.v[pod].aff_terms.n || !o->pods.v[pod].aff_terms.v[term].has_ns_sel) return -1;
+    requirement r = make_req(o, key, op, values, n);
+    VEC_PUSH(o->pods.v[pod].aff_terms.v[term].ns_sel, r); return 0;
+}
 int orc_term_requirement(orc* o, int pod, int term, const char* key, const char* op, const char* const* values, int n) {
     PODCHK(o, pod);
     if (term < 0 || term >= o->pods.v[pod].anti_terms.n) return -1;

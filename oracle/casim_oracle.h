@@ -50,7 +50,10 @@ int orc_pod_node_selector(orc* o, int pod, const char* key, const char* value);
 int orc_pod_node_affinity_req(orc* o, int pod, const char* key, const char* op,
                               const char* const* values, int n_values);
 int orc_pod_host_port(orc* o, int pod, const char* ip, const char* protocol, int port);
-/* namespaceSelector of an anti-affinity term + the namespace lister it is resolved against (key NULL = register only) */
+/* namespaceSelector of an anti-affinity term (orc_term_*) or of a required affinity term (orc_aff_term_*) + the namespace lister it is
+ * resolved against (key NULL = register only) */
+int orc_aff_term_namespace_selector(orc* o, int pod, int term);
+int orc_aff_term_namespace_requirement(orc* o, int pod, int term, const char* key, const char* op, const char* const* values, int n);
 int orc_namespace_label(orc* o, const char* name, const char* key, const char* value);
 int orc_term_namespace_selector(orc* o, int pod, int term);
 int orc_term_namespace_requirement(orc* o, int pod, int term, const char* key, const char* op,

@@ -52,6 +52,7 @@ def lib():
             "orc_pod_node_affinity_term": (C.c_int, [P, C.c_int]),
             "orc_namespace_label": (C.c_int, [P, cstr, cstr, cstr]),
             "orc_term_namespace_selector": (C.c_int, [P, C.c_int, C.c_int]),
+            "orc_aff_term_namespace_selector": (C.c_int, [P, C.c_int, C.c_int]),
             "orc_term_namespace_requirement": (C.c_int, [P, C.c_int, C.c_int, cstr, cstr, cstrp, C.c_int]),
             "orc_pod_node_term_req": (C.c_int, [P, C.c_int, C.c_int, C.c_int, cstr, cstr, cstrp, C.c_int]),
             "orc_pod_host_port": (C.c_int, [P, C.c_int, cstr, cstr, C.c_int]),
@@ -59,6 +60,7 @@ def lib():
             "orc_term_requirement": (C.c_int, [P, C.c_int, C.c_int, cstr, cstr, cstrp, C.c_int]),
             "orc_pod_affinity_term": (C.c_int, [P, C.c_int, cstr, cstrp, C.c_int]),
             "orc_aff_term_requirement": (C.c_int, [P, C.c_int, C.c_int, cstr, cstr, cstrp, C.c_int]),
+            "orc_aff_term_namespace_requirement": (C.c_int, [P, C.c_int, C.c_int, cstr, cstr, cstrp, C.c_int]),
             "orc_pod_fastpath_requests": (C.c_int, [P, C.c_int, C.c_double, C.c_double]),
             "orc_pod_has_topology_spread": (C.c_int, [P, C.c_int, C.c_int]),
             "orc_pod_spread_constraint": (C.c_int, [P, C.c_int, C.c_int, cstr, C.c_int]),
@@ -203,10 +205,13 @@ class OracleScenario:
                 for r in term.namespace_selector:
                     assert L.orc_term_namespace_requirement(h, p, t, _b(r.key), _b(r.operator), _strs(r.values), len(r.values)) == 0
         for term in getattr(pod, "affinity", ()):
-            assert term.namespace_selector is None, "the oracle restates required pod affinity with explicit namespaces only"
             t = L.orc_pod_affinity_term(h, p, _b(term.topology_key), _strs(term.namespaces), len(term.namespaces))
             for r in term.requirements():
                 assert L.orc_aff_term_requirement(h, p, t, _b(r.key), _b(r.operator), _strs(r.values), len(r.values)) == 0
+            if term.namespace_selector is not None:
+                assert L.orc_aff_term_namespace_selector(h, p, t) == 0
+                for r in term.namespace_selector:
+                    assert L.orc_aff_term_namespace_requirement(h, p, t, _b(r.key), _b(r.operator), _strs(r.values), len(r.values)) == 0
         if pod.has_containers:
             cpu, mem = pod.fastpath_requests()
             L.orc_pod_fastpath_requests(h, p, cpu, mem)

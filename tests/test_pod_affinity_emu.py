@@ -84,3 +84,53 @@ def test_self_affine_series_on_hostname_packs_one_node():
     want2 = sched_oracle(case2)
     assert list(want2[0]) == [2, 2, 2, -1]
     assert_sched_matches(sched_emu(case2), want2, "affinity to a running pod")
+
+
+# ---- namespaceSelector on required AFFINITY terms (VERDICT r2 missing #4, second half) -----------------------------------------
+# The term is the incoming pod's: a non-empty selector selects among the namespaces the lister knows (plugin.go:144-157), an empty
+# one selects every namespace; the encoder resolves it at finalize from casim_enc_add_namespace / _namespace_add_label.
+@pytest.mark.parametrize("seed", range(200))
+def test_try_schedule_pods_with_affinity_namespace_selectors(seed):
+    from kubernetes_autoscaler_amd.objects import namespaces
+    w = workloads.fuzz_pending_domains(7600 + seed)
+    everybody = w.pods + [p for info in w.nodes for p in info.pods]
+    add_random_pod_affinity(seed, everybody, frac=0.6)
+    table = workloads.add_random_namespace_selectors(seed, everybody)
+    n_sel = sum(1 for p in everybody for t in p.affinity if t.namespace_selector is not None)
+    with namespaces(table):
+        case = sched_case(w)
+        want = sched_oracle(case)
+        got = sched_emu(case)
+        assert got[0] == 0, f"affinity terms with a namespaceSelector must not be delegated any more (status {got[0]})"
+        assert_sched_matches(got, want, f"{w.name} ({n_sel} affinity terms with a namespaceSelector)")
+
+
+@pytest.mark.parametrize("seed", range(150))
+def test_estimate_on_the_snapshot_with_affinity_namespace_selectors(seed):
+    from kubernetes_autoscaler_amd.objects import namespaces
+    w = workloads.fuzz_estimate_domains(7600 + seed)
+    everybody = [pg.pods[0] for pg in w.pegs] + [p for info in w.existing for p in info.pods] + list(w.groups[0].template.pods)
+    add_random_pod_affinity(seed, everybody, frac=0.6, apps=("app0", "app1", "app2"))
+    # (the PEGs' other pods are copies of the exemplar: same namespace and terms)
+    table = workloads.add_random_namespace_selectors(seed, [p for pg in w.pegs for p in pg.pods] + [p for info in w.existing for p in info.pods] + list(w.groups[0].template.pods))
+    with namespaces(table):
+        sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing, lanes=w.lanes)
+        if cluster_estimate_emu(sc)[0] == 1:
+            pytest.skip("delegated (hostname anti-affinity next to an unnamed node, or a namespaceSelector next to an unlisted namespace)")
+        est, ids = run_oracle(sc)[0]
+        assert_cluster_estimate_matches(cluster_estimate_emu(sc, 0), est, ids, w.name)
+
+
+def test_an_affinity_selector_only_sees_listed_namespaces():
+    """team=a selects ns-a; a partner in an UNLISTED namespace with the same labels is not selected (the lister does not know it)"""
+    from kubernetes_autoscaler_amd.objects import Requirement, namespaces
+    nodes = [NodeInfo(_node(f"n{i}", 2000, 4 * GiB, 110, {LABEL_ZONE: f"z{i}"})) for i in range(3)]
+    nodes[1].pods.append(Pod(name="partner-listed", namespace="ns-a", labels={"app": "db"}, requests={"cpu": 100, "memory": 64 * MiB}))
+    nodes[2].pods.append(Pod(name="partner-unlisted", namespace="ns-ghost", labels={"app": "db"}, requests={"cpu": 100, "memory": 64 * MiB}))
+    web = [Pod(name=f"web{i}", namespace="default", labels={"app": "web"}, requests={"cpu": 300, "memory": 64 * MiB}, controller_uid="web",
+               affinity=[PodAffinityTerm(LABEL_ZONE, match_labels={"app": "db"}, namespace_selector=[Requirement("team", "In", ["a"])])]) for i in range(3)]
+    with namespaces({"default": {"team": "core"}, "ns-a": {"team": "a"}}):
+        case = SchedCase(nodes=nodes, pods=web)
+        want = sched_oracle(case)
+        assert list(want[0]) == [1, 1, 1]                     # only the zone of the listed partner qualifies
+        assert_sched_matches(sched_emu(case), want, "affinity namespaceSelector, listed namespaces only")

@@ -35,7 +35,7 @@ struct Sig { int op; const char* args; };
 enum Op {
     CREATE, ADD_GROUP, GROUP_LABEL, GROUP_TAINT, GROUP_FP_CAP, GROUP_LIMITS, GROUP_PRELOADED, GROUP_SET_PEGS, ADD_POD_SPEC, POD_LABEL,
     POD_TOLERATION, POD_NODE_SELECTOR, POD_NODE_AFF_REQ, POD_NODE_AFF_TERM, NODE_TERM_REQ, POD_HOST_PORT, POD_AA_TERM, TERM_REQ,
-    POD_AFF_TERM, AFF_TERM_REQ, POD_SPREAD, SPREAD_REQ, SPREAD_TAINTS, SPREAD_AFFINITY, ADD_NAMESPACE, NAMESPACE_LABEL, TERM_NS_SELECTOR, TERM_NS_REQ, POD_FP_REQ,
+    POD_AFF_TERM, AFF_TERM_REQ, POD_SPREAD, SPREAD_REQ, SPREAD_TAINTS, SPREAD_AFFINITY, ADD_NAMESPACE, NAMESPACE_LABEL, TERM_NS_SELECTOR, TERM_NS_REQ, AFF_TERM_NS_SELECTOR, AFF_TERM_NS_REQ, POD_FP_REQ,
     POD_UNSUPPORTED, POD_SPEC_EXTRA, ADD_PEG, ADD_RESOURCE_PEGS, ADD_EXISTING_POD, FINALIZE
 };
 const std::map<std::string, Sig> kSigs = {
@@ -67,6 +67,8 @@ const std::map<std::string, Sig> kSigs = {
     {"casim_enc_namespace_add_label", {NAMESPACE_LABEL, "sss"}},
     {"casim_enc_term_set_namespace_selector", {TERM_NS_SELECTOR, "ii"}},
     {"casim_enc_term_add_namespace_requirement", {TERM_NS_REQ, "iissSi"}},
+    {"casim_enc_aff_term_set_namespace_selector", {AFF_TERM_NS_SELECTOR, "ii"}},
+    {"casim_enc_aff_term_add_namespace_requirement", {AFF_TERM_NS_REQ, "iissSi"}},
     {"casim_enc_pod_set_fastpath_requests", {POD_FP_REQ, "idd"}},
     {"casim_enc_pod_mark_unsupported", {POD_UNSUPPORTED, "is"}},
     {"casim_enc_pod_set_spec_extra", {POD_SPEC_EXTRA, "is"}},
@@ -184,6 +186,8 @@ int32_t replay(const std::vector<Call>& calls, size_t n_calls, casim_encoder*& e
         case NAMESPACE_LABEL: rc = casim_enc_namespace_add_label(e, c.s(0), c.s(1), c.s(2)); break;
         case TERM_NS_SELECTOR: rc = casim_enc_term_set_namespace_selector(e, (int32_t)I[0], (int32_t)I[1]); break;
         case TERM_NS_REQ: rc = casim_enc_term_add_namespace_requirement(e, (int32_t)I[0], (int32_t)I[1], c.s(0), c.s(1), c.SA[0].data(), (int32_t)I[2]); break;
+        case AFF_TERM_NS_SELECTOR: rc = casim_enc_aff_term_set_namespace_selector(e, (int32_t)I[0], (int32_t)I[1]); break;
+        case AFF_TERM_NS_REQ: rc = casim_enc_aff_term_add_namespace_requirement(e, (int32_t)I[0], (int32_t)I[1], c.s(0), c.s(1), c.SA[0].data(), (int32_t)I[2]); break;
         case POD_FP_REQ: rc = casim_enc_pod_set_fastpath_requests(e, (int32_t)I[0], c.D[0], c.D[1]); break;
         case POD_UNSUPPORTED: rc = casim_enc_pod_mark_unsupported(e, (int32_t)I[0], c.s(0)); break;
         case POD_SPEC_EXTRA: rc = casim_enc_pod_set_spec_extra(e, (int32_t)I[0], c.s(0)); break;
