@@ -24,6 +24,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -167,6 +168,10 @@ public:
     // ---- upload -----------------------------------------------------------------------
     int32_t init(const casim_pegs* p, const casim_groups* g, const casim_options* o) {
         if (!p || !g) return fail(CASIM_ERR_INVALID, "null table");
+        static const bool timing = getenv("CASIM_INIT_TIMING") != nullptr;
+        struct Stage { bool on; const char* what; std::chrono::steady_clock::time_point t0;
+                       void mark(const char* next) { if (!on) return; const auto t1 = std::chrono::steady_clock::now();
+                           fprintf(stderr, "[init] %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count()); what = next; t0 = t1; } } stage{timing, "runs + checks", std::chrono::steady_clock::now()};
         if (p->n_pegs < 0 || g->n_groups < 0) return fail(CASIM_ERR_INVALID, "negative size");
         if (p->n_res < 2 || p->n_res > CASIM_KMAX_RES) return fail(CASIM_ERR_INVALID, "n_res must be in [2, 8]");
         if (p->w_taint < 0 || p->w_label < 0 || p->w_excl < 0 || p->w_zone < 0) return fail(CASIM_ERR_INVALID, "negative mask width");
@@ -200,6 +205,7 @@ public:
             if (g->peg_offsets && NG > 0 && g->peg_offsets[NG] > 0) bound += 4 * (size_t)g->peg_offsets[NG];
             begin_uploads(bound);
         }
+        stage.mark("table columns -> staging");
         dt_.req = up(p->req, G * R); dt_.count = up(p->count, G); dt_.pflags = up(p->flags, G);
         dt_.tol = up(p->tol_mask, G * dt_.Wt); dt_.sel = up(p->sel_mask, G * dt_.Wl);
         dt_.xblock = up(p->excl_block, G * dt_.Wx); dt_.xmark = up(p->excl_mark, G * dt_.Wx);
@@ -213,6 +219,7 @@ public:
         dt_.cap_cpu = g->cap_cpu ? up(g->cap_cpu, NG) : nullptr; dt_.cap_mem = g->cap_mem ? up(g->cap_mem, NG) : nullptr;
         dt_.waste_cpu = g->waste_cpu ? up(g->waste_cpu, NG) : nullptr; dt_.waste_mem = g->waste_mem ? up(g->waste_mem, NG) : nullptr;
 
+        stage.mark("slabs, ranges, csr buffers");
         // ---- results slab: the per-group scalars and the CSR offsets side by side, so that ONE device-to-host copy fetches them
         {
             const size_t ng = NG > 0 ? NG : 1;
@@ -290,6 +297,7 @@ public:
             dt_.peg_off = d_off_; dt_.peg_idx = d_idx_;
         }
 
+        stage.mark("packer geometry");
         // ---- packer state geometry ----
         std::vector<int32_t> cap(NG);
         std::vector<int64_t> soff(NG);
@@ -308,6 +316,7 @@ public:
         pack_lds_ = worst <= (int64_t)bk_.lds_budget();
         // ---- fast packer eligibility: no exclusion masks, <= 4 lanes, <= 1024 nodes per group and every
         // lane value representable as int32 after dividing the lane by the gcd of all its values ----
+        stage.mark("gcd scaling + int32 tables");
         fast_npt_ = 0;
         {
             int32_t maxcap = 0;
@@ -326,24 +335,47 @@ public:
             fast_wx_ = (dt_.Wx > 0 || dt_.Wz > 0 || zone_self) ? 2 : 0;   // lean instantiation, or the one with room for both kinds of words
             std::vector<int64_t> scale((size_t)R, 0);
             auto gcd64 = [](int64_t a, int64_t b) { if (a < 0) a = -a; if (b < 0) b = -b; while (b) { const int64_t x = a % b; a = b; b = x; } return a; };
+            // (a million-PEG batch walks these loops in every enter -> return call: 5.3 of 11.8 ms as three passes of 64-bit divisions,
+            // profiles/r05p_init_stages.txt.  One modulo per value while the gcd settles — it is almost always final after a few rows —
+            // no division in the range check, and the exact quotient by a multiply with the modular inverse of the gcd's odd part)
+            auto fold = [&](int r, int64_t v) {
+                int64_t& sc = scale[(size_t)r];
+                if (sc == 1 || v == 0) return;
+                if (sc == 0) { sc = v < 0 ? -v : v; return; }
+                // (byte-granular lanes settle on a power of two — MiB multiples — : a mask; milli-cpu lanes fit 32 bits: the short division)
+                int64_t m;
+                if ((sc & (sc - 1)) == 0) m = v & (sc - 1);
+                else if (v >= 0 && v <= 0xffffffffll && sc <= 0xffffffffll) m = (int64_t)((uint32_t)v % (uint32_t)sc);
+                else m = v % sc;
+                if (m != 0) sc = gcd64(sc, m < 0 ? -m : m);
+            };
             if (ok) {
-                for (size_t i = 0; i < G; ++i) for (int r = 0; r < R; ++r) scale[(size_t)r] = gcd64(scale[(size_t)r], p->req[i * R + r]);
-                for (size_t i = 0; i < NG; ++i) for (int r = 0; r < R; ++r) {
-                    scale[(size_t)r] = gcd64(scale[(size_t)r], g->alloc[i * R + r]);
-                    scale[(size_t)r] = gcd64(scale[(size_t)r], g->init_req[i * R + r]);
-                }
+                for (size_t i = 0; i < G; ++i) for (int r = 0; r < R; ++r) fold(r, p->req[i * R + r]);
+                for (size_t i = 0; i < NG; ++i) for (int r = 0; r < R; ++r) { fold(r, g->alloc[i * R + r]); fold(r, g->init_req[i * R + r]); }
                 for (int r = 0; r < R; ++r) if (scale[(size_t)r] == 0) scale[(size_t)r] = 1;
-                const int64_t lim = 0x7fffffffll;
-                auto fits32 = [&](int64_t v, int r) { const int64_t s = v / scale[(size_t)r]; return s <= lim && s >= -lim; };
+                // |v / scale| <= 2^31 - 1  <=>  |v| <= (2^31 - 1) * scale   (the product saturates: a scale beyond 2^32 admits every int64)
+                std::vector<int64_t> vmax((size_t)R);
+                for (int r = 0; r < R; ++r) vmax[(size_t)r] = scale[(size_t)r] > (0x7fffffffffffffffll / 0x7fffffffll) ? 0x7fffffffffffffffll : 0x7fffffffll * scale[(size_t)r];
+                auto fits32 = [&](int64_t v, int r) { return v <= vmax[(size_t)r] && v >= -vmax[(size_t)r]; };
                 for (size_t i = 0; i < G && ok; ++i) for (int r = 0; r < R; ++r) ok = ok && p->req[i * R + r] >= 0 && fits32(p->req[i * R + r], r);
                 for (size_t i = 0; i < NG && ok; ++i) for (int r = 0; r < R; ++r)
                     ok = ok && fits32(g->alloc[i * R + r], r) && fits32(g->init_req[i * R + r], r) && fits32(g->alloc[i * R + r] - g->init_req[i * R + r], r);
             }
             if (ok) {
+                // exact division by scale = 2^tz * odd: shift, then multiply by the inverse of `odd` modulo 2^64 (Newton: 5 steps)
+                std::vector<uint64_t> inv((size_t)R); std::vector<int> tz((size_t)R);
+                for (int r = 0; r < R; ++r) {
+                    uint64_t sc = (uint64_t)scale[(size_t)r]; int z = 0;
+                    while ((sc & 1ull) == 0) { sc >>= 1; ++z; }
+                    uint64_t x = sc;                       // 3 correct bits
+                    for (int it = 0; it < 5; ++it) x *= 2ull - sc * x;
+                    inv[(size_t)r] = x; tz[(size_t)r] = z;
+                }
+                auto quot = [&](int64_t v, int r) -> int32_t { return (int32_t)(int64_t)((uint64_t)(v >> tz[(size_t)r]) * inv[(size_t)r]); };   // (v is a multiple of scale: the arithmetic shift is exact)
                 std::vector<int32_t> req32(G * (size_t)R), fresh32(NG * (size_t)R);
-                for (size_t i = 0; i < G; ++i) for (int r = 0; r < R; ++r) req32[i * R + r] = (int32_t)(p->req[i * R + r] / scale[(size_t)r]);
+                for (size_t i = 0; i < G; ++i) for (int r = 0; r < R; ++r) req32[i * R + r] = quot(p->req[i * R + r], r);
                 for (size_t i = 0; i < NG; ++i) for (int r = 0; r < R; ++r)
-                    fresh32[i * R + r] = (int32_t)((g->alloc[i * R + r] - g->init_req[i * R + r]) / scale[(size_t)r]);
+                    fresh32[i * R + r] = quot(g->alloc[i * R + r] - g->init_req[i * R + r], r);
                 fs_.req32 = up(req32.data(), req32.size());
                 fs_.fresh32 = up(fresh32.data(), fresh32.size());
                 fs_.scale = up(scale.data(), scale.size());   // (all three copied into the staging buffer already)
@@ -364,6 +396,7 @@ public:
             ps_.state_off = up(soff.data(), NG);
             ps_.gstate = (char*)dalloc((size_t)total);
         }
+        stage.mark("order geometry + result arrays");
         // ---- order scratch geometry ----
         int64_t npad_max = 1;
         std::vector<int64_t> npad_of(NG);
@@ -419,8 +452,10 @@ public:
         d_opt_key_ = (int64_t*)dalloc(80);
         d_opt_packed_ = (int64_t*)dalloc(8);
         opt_cap_ = 1;
+        stage.mark("H2D copy + sync");
         end_uploads();
         bk_.sync();  // the staging buffer belongs to the backend: the next problem of this context may reuse it after init()
+        stage.mark("done");
         if (!bk_.ok()) return fail(CASIM_ERR_HIP, bk_.error());
         ready_ = true;
         return CASIM_OK;
