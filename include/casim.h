@@ -718,8 +718,11 @@ int32_t casim_enc_term_add_requirement(casim_encoder* e, int32_t pod, int32_t te
  * terms of the spec; a node passes when, for every term, it carries the topology key and its domain holds a matching pod —
  * or the pod is the first of a series with affinity to itself (no matching pod anywhere, it matches its own terms, the node
  * carries every key).  Evaluated on the device in per-node mode (TrySchedulePods, the removal loop, Estimate on the snapshot)
- * as domain rules of kind 2; in template mode the spec is flagged CASIM_PEG_UNSUPPORTED, which sends its node groups to
- * casim_estimate_on_cluster.  A term's namespaceSelector: casim_enc_aff_term_set_namespace_selector (below). */
+ * as domain rules of kind 2.  Template mode (an Estimate): when every term's key is a non-hostname key and no PEG of the batch can
+ * become a partner (nobody matches all terms, the PEG itself included), the verdict of every (PEG, group) pair is fixed by the
+ * existing cluster (casim_enc_add_existing_pod) and the template's preloaded pods — satisfied: the term is a no-op, else the PEG
+ * never fits the group — and the group stays in the template-mode packer; otherwise (hostname keys, partners inside the batch,
+ * a self-affine series) the spec is flagged CASIM_PEG_UNSUPPORTED, which sends its node groups to casim_estimate_on_cluster.  A term's namespaceSelector: casim_enc_aff_term_set_namespace_selector (below). */
 int32_t casim_enc_pod_add_affinity_term(casim_encoder* e, int32_t pod, const char* topology_key,
                                         const char* const* namespaces, int32_t n_namespaces);
 int32_t casim_enc_aff_term_add_requirement(casim_encoder* e, int32_t pod, int32_t term, const char* key,

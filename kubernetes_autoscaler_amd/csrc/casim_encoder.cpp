@@ -781,6 +781,51 @@ int32_t casim_enc_finalize(casim_encoder* e) {
             if (!existing_block[i].empty()) { static_zbit[i] = zbits.next(); zbit_key[static_zbit[i]] = ""; z_block[i].push_back(static_zbit[i]); }
         }
     }
+    // (4a) template mode: required pod affinity whose verdict is STATIC.  satisfyPodAffinity (interpodaffinity/filtering.go:382-409)
+    // asks, per term, for a pod matching ALL terms of the incoming pod in the node's domain of the term's key; counts only grow
+    // during an Estimate.  When every term's key is a non-hostname key — all nodes of a group share the template's domains — and
+    // NO PEG of the batch can become such a partner (nobody matches all terms, the PEG itself included: no "first pod of a
+    // self-affine series" either), the verdict of a (PEG, group) pair is fixed by the existing cluster and the template's
+    // preloaded pods: satisfied -> the affinity is a no-op, else the PEG never fits the group — the static (PEG, group) block the
+    // anti-affinity against existing pods already uses.  "Near the cache that runs in zone a" is this case.  Anything else
+    // (hostname keys, partners inside the batch) stays with the snapshot path (casim_estimate_on_cluster).
+    std::vector<uint8_t> aff_static(G, 0);
+    if (!per_node) {
+        auto matches_all = [&](const PodSpec& owner, const PodSpec& q) {
+            for (auto& t : owner.aff) if (!term_matches(t, q)) return false;
+            return true;
+        };
+        for (size_t i = 0; i < G; ++i) {
+            const PodSpec& a = e->specs[(size_t)e->pegs[i].spec];
+            if (a.aff.empty()) continue;
+            bool host = false, partner = false;
+            for (auto& t : a.aff) host = host || t.topology_key == kHostname;
+            if (host) continue;
+            for (size_t j = 0; j < G && !partner; ++j) partner = matches_all(a, e->specs[(size_t)e->pegs[j].spec]);
+            if (partner) continue;
+            std::vector<uint32_t> never;
+            for (size_t gi = 0; gi < NG; ++gi) {
+                const Group& g = e->groups[gi];
+                bool sat = true;
+                for (auto& t : a.aff) {
+                    auto a1 = g.labels.find(t.topology_key);
+                    if (a1 == g.labels.end()) { sat = false; break; }   // all topology labels must exist on the node
+                    bool found = false;
+                    for (auto& x : e->existing) {
+                        if (found) break;
+                        auto b1 = x.node_labels.find(t.topology_key);
+                        if (b1 != x.node_labels.end() && b1->second == a1->second && matches_all(a, e->specs[(size_t)x.spec])) found = true;
+                    }
+                    for (int32_t s2 : g.preloaded) if (!found && matches_all(a, e->specs[(size_t)s2])) found = true;
+                    if (!found) { sat = false; break; }
+                }
+                if (!sat) never.push_back((uint32_t)gi);
+            }
+            aff_static[i] = 1;
+            for (uint32_t gi : never) if (std::find(existing_block[i].begin(), existing_block[i].end(), gi) == existing_block[i].end()) existing_block[i].push_back(gi);
+            if (!existing_block[i].empty() && static_zbit[i] < 0) { static_zbit[i] = zbits.next(); zbit_key[static_zbit[i]] = ""; z_block[i].push_back(static_zbit[i]); }
+        }
+    }
     e->Wz = zbits.words();
 
     // (4b) per-node mode: domain rules (include/casim.h, casim_domain_rules) for PodTopologySpread and for required
@@ -793,7 +838,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
             if (!p.spread.empty()) { p.unsupported = true; p.why = "topologySpreadConstraints"; }
             // required pod affinity looks at the pods of the node's topology domain: a property of the snapshot, not of a
             // template — such groups are estimated on the whole snapshot (casim_estimate_on_cluster, rule kind 2 below)
-            if (!p.aff.empty()) { p.unsupported = true; p.why = "required pod affinity"; }
+            if (!p.aff.empty() && !aff_static[i]) { p.unsupported = true; p.why = "required pod affinity"; }   // ((4a) took the static ones)
         }
     } else {
         auto& dr = e->dr;

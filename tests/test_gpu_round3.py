@@ -224,3 +224,24 @@ def test_affinity_terms_with_namespace_selectors_on_the_device(ctx):
             case = SchedCase(nodes=w.nodes, pods=w.pods, hints=w.hints, acceptable=w.acceptable, break_on_failure=w.break_on_failure, last_index=w.last_index)
             assert_sched_matches(sched_gpu(case, ctx), sched_oracle(case), w.name)
     assert seen > 100
+
+
+def test_static_pod_affinity_in_template_mode_on_the_device(ctx):
+    """required pod affinity whose verdict is fixed by the existing cluster (non-hostname keys, no partner inside the batch) stays in
+    casim_estimate_batch: both packers vs the oracle"""
+    from test_pod_affinity_emu import _static_affinity_workload
+    from kubernetes_autoscaler_amd.engine import Problem
+    checked = 0
+    for seed in range(100):
+        w, n_aff = _static_affinity_workload(seed)
+        sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing, lanes=w.lanes, device_csr=seed % 2 == 0)
+        enc = encode(sc)
+        for generic in (False, True):
+            with Problem(ctx, enc.pegs, enc.groups, force_generic_packer=generic) as p:
+                p.run(); res = p.fetch()
+            if any(int(s) != 0 for s in res.status):
+                continue
+            assert_matches_oracle(res, run_oracle(sc), f"static affinity {seed} generic={generic}")
+            checked += 1
+        enc.close()
+    assert checked > 120

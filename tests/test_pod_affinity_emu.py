@@ -134,3 +134,69 @@ def test_an_affinity_selector_only_sees_listed_namespaces():
         want = sched_oracle(case)
         assert list(want[0]) == [1, 1, 1]                     # only the zone of the listed partner qualifies
         assert_sched_matches(sched_emu(case), want, "affinity namespaceSelector, listed namespaces only")
+
+
+# ---- required pod affinity in TEMPLATE mode when the verdict is static (VERDICT r2 missing #4, first half: the common shape) ----------------
+# Non-hostname keys and no possible partner inside the batch: every (PEG, group) verdict is fixed by the existing cluster and the
+# template's preloaded pods, and the group runs in the template-mode packer (casim_estimate_batch) instead of the snapshot path.
+def _static_affinity_workload(seed):
+    from kubernetes_autoscaler_amd.workloads import SplitMix64
+    rng = SplitMix64(0xAFF17000 + seed)
+    w = workloads.fuzz(9300 + seed, max_groups=5, max_pegs=10, rich=seed % 2 == 0)
+    zones = ["zone-0", "zone-1", "zone-9"]
+    # partners live in the existing cluster only: cache / db pods on some existing nodes (their zone is their node's), and sometimes a
+    # DaemonSet-like cache pod preloaded on a template
+    for k, info in enumerate(w.existing):
+        for _ in range(rng.below(3)):
+            info.pods.append(Pod(name=f"part-{seed}-{k}", namespace=rng.pick(["default", "infra"]), labels={"app": rng.pick(["cache", "db"])},
+                                 requests={"cpu": 50, "memory": 64 * MiB}))
+    if rng.chance(1, 3) and w.groups:
+        w.groups[rng.below(len(w.groups))].template.pods.append(Pod(name=f"ds-cache-{seed}", namespace="default", labels={"app": "cache"},
+                                                                    requests={"cpu": 50, "memory": 32 * MiB}))
+    n = 0
+    for pg in w.pegs:
+        if rng.chance(1, 2):
+            terms = [PodAffinityTerm(LABEL_ZONE, match_labels={"app": rng.pick(["cache", "db"])},
+                                     namespaces=tuple(rng.sample(["default", "infra"], 1 + rng.below(2))) if rng.chance(1, 2) else ())]
+            if rng.chance(1, 4):
+                terms.append(PodAffinityTerm("pool", match_labels={"app": terms[0].match_labels["app"]}))   # a key most templates lack
+            for p in pg.pods:
+                p.affinity = [PodAffinityTerm(t.topology_key, dict(t.match_labels), list(t.match_expressions), tuple(t.namespaces), None) for t in terms]
+            n += 1
+    return w, n
+
+
+@pytest.mark.parametrize("device_csr", [False, True])
+@pytest.mark.parametrize("seed", range(150))
+def test_template_mode_packs_groups_whose_affinity_verdict_is_static(seed, device_csr):
+    w, n_aff = _static_affinity_workload(seed)
+    sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing, lanes=w.lanes,
+                  device_csr=device_csr)
+    enc = encode(sc)
+    assert not any(enc.pegs.flags[i] & _abi.PEG_UNSUPPORTED for i in range(enc.pegs.n_pegs) if w.pegs[i].pods and w.pegs[i].pods[0].affinity and
+                   not any(t.topology_key == LABEL_HOSTNAME for t in w.pegs[i].pods[0].affinity)), "static affinity must not be delegated"
+    for generic in (False, True):
+        res, _ = run_emu(enc, generic=generic)
+        if any(int(s) != 0 for s in res.status):
+            pytest.skip("another predicate of the fuzz family is outside the template subset")
+        from harness import assert_matches_oracle
+        assert_matches_oracle(res, run_oracle(sc), f"static affinity seed {seed} ({n_aff} PEGs) generic={generic}")
+    enc.close()
+
+
+def test_static_affinity_changes_the_answer():
+    """near the cache in zone-0: the zone-0 template takes the pods, the zone-1 template none — without the term both would"""
+    cache = Pod(name="cache", labels={"app": "cache"}, requests={"cpu": 100, "memory": 64 * MiB})
+    old = NodeInfo(_node("old", 1000, 2 * GiB, 10, {LABEL_ZONE: "zone-0"}), [cache])
+    t0 = NodeInfo(_node("t0", 4000, 8 * GiB, 110, {LABEL_ZONE: "zone-0"}))
+    t1 = NodeInfo(_node("t1", 4000, 8 * GiB, 110, {LABEL_ZONE: "zone-1"}))
+    web = [Pod(name=f"web{i}", labels={"app": "web"}, requests={"cpu": 500, "memory": 256 * MiB},
+               affinity=[PodAffinityTerm(LABEL_ZONE, match_labels={"app": "cache"})]) for i in range(9)]
+    sc = Scenario(pegs=[PodEquivalenceGroup(web)], groups=[GroupSpec(t0, 0, 0, None), GroupSpec(t1, 0, 0, None)], existing=[old], device_csr=True)
+    enc = encode(sc)
+    assert not (enc.pegs.flags[0] & _abi.PEG_UNSUPPORTED)
+    res, _ = run_emu(enc)
+    assert [int(x) for x in res.status] == [0, 0] and [int(x) for x in res.pods_scheduled] == [9, 0] and int(res.node_count[0]) == 2
+    from harness import assert_matches_oracle
+    assert_matches_oracle(res, run_oracle(sc), "near the cache")
+    enc.close()
