@@ -1,4 +1,5 @@
-for T in ${SWEEP_T:-64 128 256 512 1024}; do
+# K_sched workgroup sizes on the f1 / f4 timing tools: SWEEP_T="64 128 256 512"
+for T in ${SWEEP_T:-64 128 256 512}; do
   echo "== T=$T"
   CASIM_SCHED_THREADS=$T CASIM_ORACLE_CHECK_LIMIT=0 python tests/tools/time_pending.py 2>/dev/null | python -c "
 import sys,json
