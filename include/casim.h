@@ -32,13 +32,14 @@
 extern "C" {
 #endif
 
-#define CASIM_ABI_VERSION 5   /* 2: casim_removal_candidates.cand_atomic, casim_domain_rules.n_taint_policy_rules
+#define CASIM_ABI_VERSION 6   /* 2: casim_removal_candidates.cand_atomic, casim_domain_rules.n_taint_policy_rules
                                * 3: casim_groups.{peg_lo,peg_hi,global_id,n_sims,sim_offsets}, casim_best_option_sims,
                                *    casim_feasibility_reasons, casim_estimate_batch_timed, casim_mctx_*, casim_cluster_*
                                * 4: casim_options.n_streams (sub-batches on internal HIP streams), casim_enc_group_pods,
                                *    casim_enc_add_grouped_pegs, casim_enc_pod_set_spec_extra
                                * 5: casim_options.pack_build, casim_pack_build_info (two builds of the register packer + self-check),
-                               *    casim_problem_info [5], [6], casim_option_query.join_stream, casim_prefetch_*, casim_enc_begin_update / _group_reset / _refinalize / _group_rows */
+                               *    casim_problem_info [5], [6], casim_option_query.join_stream, casim_prefetch_*, casim_enc_begin_update / _group_reset / _refinalize / _group_rows
+                               * 6: casim_pegs.zone_polarity (group bits of NEED polarity: required pod affinity towards a partner of the batch) */
 
 /* Resource lanes.  Lane 0 = cpu in millicores (Quantity.MilliValue), lane 1 = memory bytes,
  * lane 2 = ephemeral-storage bytes, lanes 3.. = scalar / extended resources (Quantity.Value),
@@ -103,6 +104,10 @@ typedef struct casim_pegs {
     const uint64_t* zone_mark;  /* [G][w_zone] group bits this PEG sets once placed in the group */
     const double* fp_cpu;     /* [G] first container cpu request, AsApproximateFloat64 (binpacking_estimator.go:451-455); may be NULL if fastpath unused */
     const double* fp_mem;     /* [G] first container memory request, AsApproximateFloat64 (:456-458) */
+    const uint64_t* zone_polarity; /* [w_zone] or NULL (= all zero): group bits of NEED polarity.  A PEG whose zone_block holds such a
+                                 bit is forbidden in the group while the bit is CLEAR (required pod affinity on a non-hostname key:
+                                 "a pod matching all my terms sits in this domain" — interpodaffinity/filtering.go:382-409), a
+                                 plain bit forbids it while SET (anti-affinity).  Marks set bits of either kind. (ABI 6) */
 } casim_pegs;
 
 /*

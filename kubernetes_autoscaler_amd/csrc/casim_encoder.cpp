@@ -254,7 +254,7 @@ struct casim_encoder {
     std::vector<int64_t> req, alloc, init_req, waste_cpu, waste_mem;
     std::vector<int32_t> count, allowed, init_pods, max_nodes, existing_nodes, last_index, peg_off, peg_idx;
     std::vector<uint32_t> pflags, gflags;
-    std::vector<uint64_t> tol, sel, xblock, xmark, zblock, zmark, taint, label, init_excl, init_zone, zone_valid, xports;
+    std::vector<uint64_t> tol, sel, xblock, xmark, zblock, zmark, zpol, taint, label, init_excl, init_zone, zone_valid, xports;
     std::vector<double> fp_cpu, fp_mem, cap_cpu, cap_mem;
     int dict[4] = {0, 0, 0, 0};
     // domain rules (per-node mode)
@@ -781,15 +781,27 @@ int32_t casim_enc_finalize(casim_encoder* e) {
             if (!existing_block[i].empty()) { static_zbit[i] = zbits.next(); zbit_key[static_zbit[i]] = ""; z_block[i].push_back(static_zbit[i]); }
         }
     }
-    // (4a) template mode: required pod affinity whose verdict is STATIC.  satisfyPodAffinity (interpodaffinity/filtering.go:382-409)
-    // asks, per term, for a pod matching ALL terms of the incoming pod in the node's domain of the term's key; counts only grow
-    // during an Estimate.  When every term's key is a non-hostname key — all nodes of a group share the template's domains — and
-    // NO PEG of the batch can become such a partner (nobody matches all terms, the PEG itself included: no "first pod of a
-    // self-affine series" either), the verdict of a (PEG, group) pair is fixed by the existing cluster and the template's
-    // preloaded pods: satisfied -> the affinity is a no-op, else the PEG never fits the group — the static (PEG, group) block the
-    // anti-affinity against existing pods already uses.  "Near the cache that runs in zone a" is this case.  Anything else
-    // (hostname keys, partners inside the batch) stays with the snapshot path (casim_estimate_on_cluster).
+    // (4a) template mode: required pod affinity.  satisfyPodAffinity (interpodaffinity/filtering.go:382-409) asks, per term, for a
+    // pod matching ALL terms of the incoming pod in the node's domain of the term's key — or, when no such pod exists ANYWHERE and the
+    // pod matches its own terms, lets the first pod of the series through (:396-407).  Counts only grow while an Estimate runs, and all
+    // nodes of a group share the template's non-hostname domains, so for a (PEG, group) pair:
+    //   * a term key the template lacks                                            -> the PEG never fits the group: the static
+    //     (PEG, group) block the anti-affinity against existing pods already uses;
+    //   * every term satisfied by the existing cluster / the template's preloaded pods (which sit on every clone: they share ALL
+    //     its domains, the hostname included)                                      -> the affinity is a no-op for the whole Estimate;
+    //   * the first-pod exception holds at snapshot time, every key a non-hostname key -> a no-op as well: whoever places the first
+    //     matching pod (the PEG itself or a partner of the batch) satisfies every later one;
+    //   * neither, non-hostname keys: the PEG waits for a PARTNER OF THE BATCH (a PEG matching all of its terms) to place a pod in
+    //     the group — a group bit of NEED polarity (casim_pegs.zone_polarity): the PEG is forbidden while it is clear, every
+    //     partner marks it, it starts set in the groups of the two cases above.  (SchedulablePodGroups never lists such a PEG: its
+    //     sample pod fails on a fresh template node — K_feas says the same through the same bit; a caller's own list may.)
+    //     Without a partner in the batch: never;
+    //   * a hostname term that is not satisfied by the template's preloaded pods   -> the partner has to sit on the SAME node (and
+    //     a series that got in by the exception has to join its first pod's node): DYNAMIC per node, estimated on the snapshot
+    //     (casim_estimate_on_cluster) — unless nobody in the batch can be the partner and no exception holds: never.
     std::vector<uint8_t> aff_static(G, 0);
+    std::vector<int> need_bits;   // group bits of NEED polarity
+    std::vector<std::pair<uint32_t, int>> zone_preset;   // (group, bit): set from the start
     if (!per_node) {
         auto matches_all = [&](const PodSpec& owner, const PodSpec& q) {
             for (auto& t : owner.aff) if (!term_matches(t, q)) return false;
@@ -798,32 +810,59 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         for (size_t i = 0; i < G; ++i) {
             const PodSpec& a = e->specs[(size_t)e->pegs[i].spec];
             if (a.aff.empty()) continue;
-            bool host = false, partner = false;
+            bool host = false;
             for (auto& t : a.aff) host = host || t.topology_key == kHostname;
-            if (host) continue;
-            for (size_t j = 0; j < G && !partner; ++j) partner = matches_all(a, e->specs[(size_t)e->pegs[j].spec]);
-            if (partner) continue;
-            std::vector<uint32_t> never;
+            const bool self = matches_all(a, a);
+            std::vector<size_t> partners;   // PEGs of the batch whose pods match all terms
+            for (size_t j = 0; j < G; ++j) if (matches_all(a, e->specs[(size_t)e->pegs[j].spec])) partners.push_back(j);
+            // len(affinityCounts) == 0 as far as the existing cluster goes: a matching pod on a node that carries one of the keys
+            bool anywhere_cluster = false;
+            for (auto& x : e->existing) {
+                if (anywhere_cluster) break;
+                if (!matches_all(a, e->specs[(size_t)x.spec])) continue;
+                for (auto& t : a.aff) if (x.node_labels.count(t.topology_key)) { anywhere_cluster = true; break; }
+            }
+            std::vector<uint32_t> never, waits;
+            bool dynamic = false;
             for (size_t gi = 0; gi < NG; ++gi) {
                 const Group& g = e->groups[gi];
+                bool keys = true;
+                for (auto& t : a.aff) keys = keys && (t.topology_key == kHostname || g.labels.count(t.topology_key) != 0);   // (clones always carry their own hostname)
+                if (!keys) { never.push_back((uint32_t)gi); continue; }
+                bool pre = false;
+                for (int32_t s2 : g.preloaded) if (!pre && matches_all(a, e->specs[(size_t)s2])) pre = true;
                 bool sat = true;
                 for (auto& t : a.aff) {
-                    auto a1 = g.labels.find(t.topology_key);
-                    if (a1 == g.labels.end()) { sat = false; break; }   // all topology labels must exist on the node
-                    bool found = false;
-                    for (auto& x : e->existing) {
-                        if (found) break;
-                        auto b1 = x.node_labels.find(t.topology_key);
-                        if (b1 != x.node_labels.end() && b1->second == a1->second && matches_all(a, e->specs[(size_t)x.spec])) found = true;
+                    bool found = pre;
+                    if (!found && t.topology_key != kHostname) {   // (an existing node never shares a hostname with a new one)
+                        auto a1 = g.labels.find(t.topology_key);
+                        for (auto& x : e->existing) {
+                            if (found) break;
+                            auto b1 = x.node_labels.find(t.topology_key);
+                            if (b1 != x.node_labels.end() && b1->second == a1->second && matches_all(a, e->specs[(size_t)x.spec])) found = true;
+                        }
                     }
-                    for (int32_t s2 : g.preloaded) if (!found && matches_all(a, e->specs[(size_t)s2])) found = true;
                     if (!found) { sat = false; break; }
                 }
-                if (!sat) never.push_back((uint32_t)gi);
+                if (sat) continue;                                         // no-op for the whole Estimate
+                const bool exception = self && !anywhere_cluster && !pre;
+                if (host) { if (exception || !partners.empty()) dynamic = true; else never.push_back((uint32_t)gi); continue; }
+                if (exception) continue;                                    // no-op: the first pod passes, the rest finds it
+                if (partners.empty()) never.push_back((uint32_t)gi); else waits.push_back((uint32_t)gi);
             }
+            if (dynamic) continue;   // (flagged below: estimated on the snapshot)
             aff_static[i] = 1;
             for (uint32_t gi : never) if (std::find(existing_block[i].begin(), existing_block[i].end(), gi) == existing_block[i].end()) existing_block[i].push_back(gi);
             if (!existing_block[i].empty() && static_zbit[i] < 0) { static_zbit[i] = zbits.next(); zbit_key[static_zbit[i]] = ""; z_block[i].push_back(static_zbit[i]); }
+            if (!waits.empty()) {
+                const int b = zbits.next();
+                zbit_key[b] = ""; need_bits.push_back(b);
+                z_block[i].push_back(b);
+                for (size_t j : partners) z_mark[j].push_back(b);
+                std::vector<uint8_t> w8(NG, 0);
+                for (uint32_t gi : waits) w8[gi] = 1;
+                for (size_t gi = 0; gi < NG; ++gi) if (!w8[gi]) zone_preset.emplace_back((uint32_t)gi, b);
+            }
         }
     }
     e->Wz = zbits.words();
@@ -1085,6 +1124,9 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         any_explicit = any_explicit || g.has_pegs;
     }
     for (size_t i = 0; i < G; ++i) for (uint32_t gi : existing_block[i]) set_bit(e->init_zone, gi, Wz, static_zbit[i]);
+    for (auto& pr : zone_preset) set_bit(e->init_zone, pr.first, Wz, pr.second);
+    e->zpol.assign((size_t)Wz, 0ull);
+    for (int b : need_bits) e->zpol[(size_t)(b >> 6)] |= 1ull << (b & 63);
     e->peg_off.clear(); e->peg_idx.clear();
     if (any_explicit) {
         e->peg_off.push_back(0);
@@ -1327,6 +1369,7 @@ int32_t casim_enc_tables(const casim_encoder* e, casim_pegs* p, casim_groups* g)
     p->tol_mask = e->tol.data(); p->sel_mask = e->sel.data();
     p->excl_block = e->xblock.data(); p->excl_mark = e->xmark.data();
     p->zone_block = e->zblock.data(); p->zone_mark = e->zmark.data();
+    p->zone_polarity = e->zpol.empty() ? nullptr : e->zpol.data();
     p->fp_cpu = e->fp_cpu.data(); p->fp_mem = e->fp_mem.data();
     g->n_groups = (int32_t)e->groups.size();
     g->alloc = e->alloc.data(); g->init_req = e->init_req.data(); g->allowed_pods = e->allowed.data(); g->init_pods = e->init_pods.data();

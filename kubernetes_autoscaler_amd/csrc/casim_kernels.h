@@ -102,7 +102,7 @@ CS_DEVICE bool fits_fresh_node(const DevTables& t, int g, int ng) {
     const uint64_t* zb = t.zblock + (int64_t)g * t.Wz;
     const uint64_t* iz = t.init_zone + (int64_t)ng * t.Wz;
     for (int w = 0; w < t.Wz; ++w)
-        if (zb[w] & iz[w]) return false;
+        if (zb[w] & (iz[w] ^ t.zpol[w])) return false;   // (a NEED bit forbids while clear)
     return true;
 }
 
@@ -146,7 +146,7 @@ CS_GLOBAL void feas_sim_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg
         if (f == 0) v = t.Wt ? t.taint[(int64_t)ng * t.Wt] : 0ull;
         else if (f == 1) v = t.Wl ? t.label[(int64_t)ng * t.Wl] : ~0ull;
         else if (f == 2) v = t.Wx ? t.init_excl[(int64_t)ng * t.Wx] : 0ull;
-        else if (f == 3) v = t.Wz ? t.init_zone[(int64_t)ng * t.Wz] : 0ull;
+        else if (f == 3) v = t.Wz ? (t.init_zone[(int64_t)ng * t.Wz] ^ t.zpol[0]) : 0ull;   // (NEED bits inverted once: the cell test stays one AND)
         else if (f == 4) v = (uint64_t)t.gflags[ng] | ((uint64_t)(uint32_t)(t.allowed[ng] - t.init_pods[ng]) << 32);
         else if (f == 5 || f == 6) {
             if (narrow) {
@@ -231,7 +231,7 @@ CS_DEVICE uint32_t fresh_node_verdict(const DevTables& t, const uint64_t* CS_RES
     if (other_excl) return CASIM_PLUGIN_INTER_POD_AFFINITY;
     const uint64_t* zb = t.zblock + (int64_t)g * t.Wz;
     const uint64_t* iz = t.init_zone + (int64_t)ng * t.Wz;
-    for (int w = 0; w < t.Wz; ++w) if (zb[w] & iz[w]) return CASIM_PLUGIN_INTER_POD_AFFINITY;
+    for (int w = 0; w < t.Wz; ++w) if (zb[w] & (iz[w] ^ t.zpol[w])) return CASIM_PLUGIN_INTER_POD_AFFINITY;
     if (pf & CASIM_PEG_UNSUPPORTED) return CASIM_PLUGIN_UNKNOWN;
     return CASIM_PLUGIN_NONE;
 }

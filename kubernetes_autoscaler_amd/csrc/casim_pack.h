@@ -438,9 +438,9 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
         bool b = false;
         if constexpr (ZR > 0) {
 #pragma unroll
-            for (int w = 0; w < ZR; ++w) if (w < Wz) b |= (zreg[w] & zb[w]) != 0;
+            for (int w = 0; w < ZR; ++w) if (w < Wz) b |= ((zreg[w] ^ t.zpol[w]) & zb[w]) != 0;   // (a NEED bit forbids while clear)
         } else {
-            for (int w = 0; w < Wz; ++w) b |= (szone[w * 64 + lane] & zb[w]) != 0;
+            for (int w = 0; w < Wz; ++w) b |= ((szone[w * 64 + lane] ^ t.zpol[w]) & zb[w]) != 0;
         }
         return b;
     };
@@ -611,7 +611,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 }
             }
             bool zblocked = Wz > 0 && zone_blocked(zblock);
-            for (int w = 0; w < Wz; ++w) zselfx |= (zblock[w] & zmark[w] & zvalid[w]) != 0;  // the PEG excludes itself group-wide
+            for (int w = 0; w < Wz; ++w) zselfx |= (zblock[w] & zmark[w] & zvalid[w] & ~t.zpol[w]) != 0;  // the PEG excludes itself group-wide (a NEED bit it sets itself is the opposite)
 
             CASIM_PROF(1);  // record broadcast + reciprocals
             int32_t placed = 0;

@@ -201,7 +201,7 @@ public:
             const size_t masks = (size_t)(dt_.Wt + dt_.Wl + 2 * dt_.Wx + 2 * dt_.Wz);
             size_t bound = G * (8 * (size_t)R + 8 + 8 * masks + 16 + 4 * (size_t)R) +
                            NG * (16 * (size_t)R + 24 + 8 * masks + 32 + 4 + 8 + 4 + 8 + 8 + 4 * (size_t)R) + 8 * (size_t)R +
-                           4 * ((size_t)(g->n_sims > 0 ? g->n_sims : 0) + 1) + 4 * (NG + 1) + 64 * 64 + 4096;
+                           4 * ((size_t)(g->n_sims > 0 ? g->n_sims : 0) + 1) + 4 * (NG + 1) + 8 * (size_t)dt_.Wz + 64 * 64 + 4096;
             if (g->peg_offsets && NG > 0 && g->peg_offsets[NG] > 0) bound += 4 * (size_t)g->peg_offsets[NG];
             begin_uploads(bound);
         }
@@ -210,6 +210,9 @@ public:
         dt_.tol = up(p->tol_mask, G * dt_.Wt); dt_.sel = up(p->sel_mask, G * dt_.Wl);
         dt_.xblock = up(p->excl_block, G * dt_.Wx); dt_.xmark = up(p->excl_mark, G * dt_.Wx);
         dt_.zblock = up(p->zone_block, G * dt_.Wz); dt_.zmark = up(p->zone_mark, G * dt_.Wz);
+        zpol_host_.assign((size_t)dt_.Wz, 0ull);   // (the kernels always read Wz polarity words: zeros when the caller passed none)
+        if (p->zone_polarity) for (int w = 0; w < dt_.Wz; ++w) zpol_host_[(size_t)w] = p->zone_polarity[w];
+        dt_.zpol = up(zpol_host_.data(), (size_t)dt_.Wz);
         dt_.fp_cpu = p->fp_cpu ? up(p->fp_cpu, G) : nullptr; dt_.fp_mem = p->fp_mem ? up(p->fp_mem, G) : nullptr;
         dt_.alloc = up(g->alloc, NG * R); dt_.init_req = up(g->init_req, NG * R);
         dt_.allowed = up(g->allowed_pods, NG); dt_.init_pods = up(g->init_pods, NG); dt_.gflags = up(g->flags, NG);
@@ -811,6 +814,7 @@ private:
     std::vector<int32_t> h_off_;
     bool h_off_fresh_ = false;
     char* up_dev_ = nullptr; char* up_host_ = nullptr; size_t up_cap_ = 0, up_used_ = 0;
+    std::vector<uint64_t> zpol_host_;
     char* res_slab_ = nullptr; size_t res_bytes_ = 0; int32_t* res_off_ = nullptr;
     int32_t* d_node_pods_ = nullptr; std::vector<int64_t> np_off_;
     std::vector<void*> allocs_;

@@ -245,3 +245,26 @@ def test_static_pod_affinity_in_template_mode_on_the_device(ctx):
             checked += 1
         enc.close()
     assert checked > 120
+
+
+def test_pod_affinity_towards_partners_of_the_batch_on_the_device(ctx):
+    """zone-level required pod affinity whose partner is another PEG of the batch (or the PEG itself): group bits of NEED polarity
+    (casim_pegs.zone_polarity) in K_feas and in both packers, the caller's lists and device-derived lists, vs the oracle"""
+    from test_pod_affinity_emu import _batch_affinity_workload
+    from kubernetes_autoscaler_amd.engine import Problem
+    from kubernetes_autoscaler_amd.objects import LABEL_ZONE
+    checked = with_need = 0
+    for seed in range(160):
+        w, n_aff = _batch_affinity_workload(seed, keys=(LABEL_ZONE, LABEL_ZONE, "pool-0", "pool"))
+        sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing, lanes=w.lanes, device_csr=seed % 2 == 0)
+        enc = encode(sc)
+        need = bool(enc.pegs.zone_polarity) and enc.pegs.w_zone > 0 and any(int(enc.pegs.zone_polarity[k]) for k in range(enc.pegs.w_zone))
+        for generic in (False, True):
+            with Problem(ctx, enc.pegs, enc.groups, force_generic_packer=generic) as p:
+                p.run(); res = p.fetch()
+            if any(int(s) != 0 for s in res.status):
+                continue
+            assert_matches_oracle(res, run_oracle(sc), f"batch affinity {seed} generic={generic}")
+            checked += 1; with_need += 1 if need else 0
+        enc.close()
+    assert checked > 200 and with_need > 40

@@ -51,19 +51,25 @@ def test_estimate_on_the_snapshot_with_required_pod_affinity(seed):
         assert_cluster_estimate_matches(cluster_estimate_emu(sc, 0, lds_budget=lds), est, ids, f"{w.name} lds={lds}")
 
 
-def test_template_mode_delegates_affinity_groups_to_the_snapshot_path():
-    """In a template-mode batch a PEG with required pod affinity makes its groups CASIM_NG_UNSUPPORTED (the shim re-runs them
-    through casim_estimate_on_cluster, where the rule is evaluated)."""
+def test_template_mode_delegates_only_the_dynamic_affinity_case():
+    """In a template-mode batch the only affinity verdict that changes while the Estimate runs is the self-affine series on a
+    HOSTNAME key that got in by the first-pod exception (the rest of the series has to join the first pod's node): that PEG makes
+    its groups CASIM_NG_UNSUPPORTED (the shim re-runs them through casim_estimate_on_cluster).  The same series on a zone key is a
+    no-op for the whole Estimate — every clone shares the template's zone — and stays in the batch."""
     tmpl = NodeInfo(_node("t", 4000, 8 * GiB, 110, {LABEL_ZONE: "z0"}))
-    web = Pod(name="web", labels={"app": "web"}, requests={"cpu": 500, "memory": 256 * MiB},
-              affinity=[PodAffinityTerm(LABEL_ZONE, match_labels={"app": "web"})])
     plain = Pod(name="plain", labels={"app": "x"}, requests={"cpu": 100, "memory": 64 * MiB})
-    sc = Scenario(pegs=[PodEquivalenceGroup([web] * 5), PodEquivalenceGroup([plain] * 3)], groups=[GroupSpec(tmpl, 0, 0, None), GroupSpec(tmpl, 0, 0, [1])])
-    enc = encode(sc)
-    assert enc.pegs.flags[0] & _abi.PEG_UNSUPPORTED and not (enc.pegs.flags[1] & _abi.PEG_UNSUPPORTED)
-    res, _ = run_emu(enc)
-    assert int(res.status[0]) == _abi.NG_UNSUPPORTED and int(res.status[1]) == _abi.NG_OK
-    enc.close()
+    for key, delegated in ((LABEL_HOSTNAME, True), (LABEL_ZONE, False)):
+        web = Pod(name="web", labels={"app": "web"}, requests={"cpu": 500, "memory": 256 * MiB}, affinity=[PodAffinityTerm(key, match_labels={"app": "web"})])
+        sc = Scenario(pegs=[PodEquivalenceGroup([web] * 5), PodEquivalenceGroup([plain] * 3)], groups=[GroupSpec(tmpl, 0, 0, None), GroupSpec(tmpl, 0, 0, [1])])
+        enc = encode(sc)
+        assert bool(enc.pegs.flags[0] & _abi.PEG_UNSUPPORTED) == delegated and not (enc.pegs.flags[1] & _abi.PEG_UNSUPPORTED)
+        res, _ = run_emu(enc)
+        assert int(res.status[0]) == (_abi.NG_UNSUPPORTED if delegated else _abi.NG_OK) and int(res.status[1]) == _abi.NG_OK
+        if not delegated:
+            from harness import assert_matches_oracle
+            assert_matches_oracle(res, run_oracle(sc), "self-affine series on the zone key")
+            assert int(res.pods_scheduled[0]) == 8
+        enc.close()
 
 
 def test_self_affine_series_on_hostname_packs_one_node():
@@ -199,4 +205,83 @@ def test_static_affinity_changes_the_answer():
     assert [int(x) for x in res.status] == [0, 0] and [int(x) for x in res.pods_scheduled] == [9, 0] and int(res.node_count[0]) == 2
     from harness import assert_matches_oracle
     assert_matches_oracle(res, run_oracle(sc), "near the cache")
+    enc.close()
+
+
+# Partners INSIDE the batch, self-affine series and hostname keys: an Estimate only sees the PEGs whose sample pod passes on a fresh
+# template node at snapshot time, and counts only grow, so every verdict but one (the hostname series that got in by the first-pod
+# exception) is fixed per (PEG, group) — encoder block (4a).
+def _batch_affinity_workload(seed, keys=(LABEL_HOSTNAME, LABEL_ZONE, LABEL_ZONE, "pool")):
+    from kubernetes_autoscaler_amd.workloads import SplitMix64
+    rng = SplitMix64(0xAFF18000 + seed)
+    w = workloads.fuzz(9700 + seed, max_groups=5, max_pegs=10, rich=seed % 2 == 0)
+    apps = ["app0", "app1", "app2"]
+    for pg in w.pegs:   # the batch's own pods carry the labels the terms select
+        a = rng.pick(apps)
+        for p in pg.pods:
+            p.labels = dict(p.labels, app=a)
+    for k, info in enumerate(w.existing):
+        for _ in range(rng.below(2)):
+            info.pods.append(Pod(name=f"part-{seed}-{k}", labels={"app": rng.pick(apps)}, requests={"cpu": 50, "memory": 64 * MiB}))
+    if rng.chance(1, 3) and w.groups:
+        w.groups[rng.below(len(w.groups))].template.pods.append(Pod(name=f"ds-{seed}", labels={"app": rng.pick(apps)}, requests={"cpu": 50, "memory": 32 * MiB}))
+    n = add_random_pod_affinity(seed, [p for pg in w.pegs for p in pg.pods], frac=0.6, keys=keys, apps=apps)
+    return w, n
+
+
+def _dynamic(pg):
+    """what may be left to the snapshot path: a hostname term (the partner has to sit on the SAME node; whether a verdict really is
+    dynamic depends on the cluster and the batch — the encoder decides, this is the necessary condition)"""
+    p = pg.pods[0]
+    return bool(p.affinity) and any(t.topology_key == LABEL_HOSTNAME for t in p.affinity)
+
+
+@pytest.mark.parametrize("seed", range(300))
+def test_template_mode_with_partners_inside_the_batch(seed):
+    w, n_aff = _batch_affinity_workload(seed)
+    sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing, lanes=w.lanes)
+    enc = encode(sc)
+    for i, pg in enumerate(w.pegs):
+        if pg.pods and pg.pods[0].affinity and not _dynamic(pg) and (enc.pegs.flags[i] & _abi.PEG_UNSUPPORTED):
+            other = [p for p in pg.pods[:1] if p.spread_constraints or p.unsupported_reason]
+            assert other, f"PEG {i}: an affinity verdict that is static was delegated"
+    oracle = run_oracle(sc)
+    compared = 0
+    for generic in (False, True):
+        res, _ = run_emu(enc, generic=generic)
+        for gi, (est, ids) in enumerate(oracle):
+            if int(res.status[gi]) != 0:
+                continue   # (a delegated PEG on the group's list)
+            order, placed = res.group(gi)
+            tag = f"batch affinity seed {seed} group {gi} generic={generic}"
+            assert list(order) == [ids[k] for k in est.order], f"{tag}: PEG order"
+            assert list(placed) == list(est.placed), f"{tag}: placed per PEG\n got {list(placed)}\n want {list(est.placed)}"
+            assert (int(res.node_count[gi]), int(res.pods_scheduled[gi]), int(res.nodes_added[gi]), int(res.last_index_out[gi])) == \
+                (est.node_count, est.pods_scheduled, est.nodes_added, est.last_index_out), tag
+            compared += 1
+    enc.close()
+    if not compared:
+        pytest.skip("every group holds a delegated PEG")
+
+
+@pytest.mark.parametrize("device_csr", [False, True])
+@pytest.mark.parametrize("seed", range(300))
+def test_template_mode_zone_affinity_never_delegates(seed, device_csr):
+    """Non-hostname keys only: every verdict is static or a group bit of NEED polarity (the PEG waits for a partner of the batch),
+    nothing goes to the snapshot path.  device_csr: the lists come from K_feas, which reads the same bits — SchedulablePodGroups
+    drops a PEG whose partner is not there yet; with the caller's lists (every group sees every PEG) the PEG waits its turn."""
+    w, n_aff = _batch_affinity_workload(seed, keys=(LABEL_ZONE, LABEL_ZONE, "pool-0", "pool"))
+    sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing, lanes=w.lanes,
+                  device_csr=device_csr)
+    enc = encode(sc)
+    for i, pg in enumerate(w.pegs):
+        if pg.pods and pg.pods[0].affinity and (enc.pegs.flags[i] & _abi.PEG_UNSUPPORTED):
+            assert pg.pods[0].spread_constraints or pg.pods[0].unsupported_reason, f"PEG {i}: zone-level affinity was delegated"
+    oracle = run_oracle(sc)
+    from harness import assert_matches_oracle
+    for generic in (False, True):
+        res, _ = run_emu(enc, generic=generic)
+        if any(int(x) != 0 for x in res.status):
+            pytest.skip("another predicate of the fuzz family is outside the template subset")
+        assert_matches_oracle(res, oracle, f"zone affinity seed {seed} ({n_aff} PEGs) generic={generic} device_csr={device_csr}")
     enc.close()
