@@ -26,11 +26,40 @@
 
 #include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "casim_kernels.h"
 
 namespace casim {
+
+// Host-side loops over the table columns of a million-PEG batch (the gcd pass, the int32 tables, the copy into pinned staging) are
+// cut over a few threads: an enter -> return call of the headline batch spent 2.1 ms of every part's 4.4 ms of init in them
+// (profiles/r05p_init_stages.txt).  f(lo, hi, t) for thread t of at most kHostLoopThreads; short loops run inline.
+// CASIM_HOST_THREADS = 1 switches it off.
+constexpr int kHostLoopThreads = 4;
+inline int host_loop_threads() {
+    const char* e = getenv("CASIM_HOST_THREADS");
+    const int v = e ? atoi(e) : kHostLoopThreads;
+    return v < 1 ? 1 : (v > kHostLoopThreads ? kHostLoopThreads : v);
+}
+template <class F>
+inline void par_for(size_t n, size_t min_per_thread, F f) {
+    int T = host_loop_threads();
+    if (const char* e = getenv("CASIM_HOST_GRAIN")) { const long v = atol(e); if (v > 0) min_per_thread = (size_t)v; }   // (tests: threads on small tables)
+    if (min_per_thread > 0 && n / min_per_thread < (size_t)T) T = (int)(n / min_per_thread);
+    if (T <= 1) { f((size_t)0, n, 0); return; }
+    std::thread th[kHostLoopThreads];
+    for (int t = 1; t < T; ++t) th[t] = std::thread([&f, n, T, t] { f(n * (size_t)t / (size_t)T, n * (size_t)(t + 1) / (size_t)T, t); });
+    f((size_t)0, n / (size_t)T, 0);
+    for (int t = 1; t < T; ++t) th[t].join();
+}
+inline void par_memcpy(void* dst, const void* src, size_t bytes) {
+    // (threads are spawned per call: below ~16 MB the spawn costs more than it saves — 6 MB columns of a 1024-simulation part copied
+    // slower on 4 threads, 0.9 -> 1.3 ms per part; the 26 MB columns of an unsplit 4096-simulation batch copy twice as fast)
+    if (bytes < (16u << 20)) { memcpy(dst, src, bytes); return; }
+    par_for(bytes, (size_t)4 << 20, [dst, src](size_t lo, size_t hi, int) { memcpy((char*)dst + lo, (const char*)src + lo, hi - lo); });
+}
 
 inline int64_t round_up64(int64_t v) { return (v + 63) & ~63ll; }
 
@@ -341,8 +370,7 @@ public:
             // (a million-PEG batch walks these loops in every enter -> return call: 5.3 of 11.8 ms as three passes of 64-bit divisions,
             // profiles/r05p_init_stages.txt.  One modulo per value while the gcd settles — it is almost always final after a few rows —
             // no division in the range check, and the exact quotient by a multiply with the modular inverse of the gcd's odd part)
-            auto fold = [&](int r, int64_t v) {
-                int64_t& sc = scale[(size_t)r];
+            auto fold = [&](int64_t& sc, int64_t v) {
                 if (sc == 1 || v == 0) return;
                 if (sc == 0) { sc = v < 0 ? -v : v; return; }
                 // (byte-granular lanes settle on a power of two — MiB multiples — : a mask; milli-cpu lanes fit 32 bits: the short division)
@@ -353,16 +381,44 @@ public:
                 if (m != 0) sc = gcd64(sc, m < 0 ? -m : m);
             };
             if (ok) {
-                for (size_t i = 0; i < G; ++i) for (int r = 0; r < R; ++r) fold(r, p->req[i * R + r]);
-                for (size_t i = 0; i < NG; ++i) for (int r = 0; r < R; ++r) { fold(r, g->alloc[i * R + r]); fold(r, g->init_req[i * R + r]); }
-                for (int r = 0; r < R; ++r) if (scale[(size_t)r] == 0) scale[(size_t)r] = 1;
+                // one pass over the columns, cut over the host threads: per lane the gcd, the largest magnitude (of a request, an
+                // allocatable, a preloaded amount, a fresh node's free amount) and "some request is negative"
+                struct Part { int64_t sc[CASIM_MAX_RES], amax[CASIM_MAX_RES]; bool neg; };
+                Part parts[kHostLoopThreads];
+                for (auto& pt : parts) { for (int r = 0; r < CASIM_MAX_RES; ++r) pt.sc[r] = pt.amax[r] = 0; pt.neg = false; }
+                auto mag = [](int64_t v) -> int64_t { return v < 0 ? (v == INT64_MIN ? INT64_MAX : -v) : v; };
+                par_for(G, 65536, [&](size_t lo, size_t hi, int t) {
+                    Part& pt = parts[t];
+                    for (size_t i = lo; i < hi; ++i) for (int r = 0; r < R; ++r) {
+                        const int64_t v = p->req[i * R + r];
+                        fold(pt.sc[r], v); pt.neg = pt.neg || v < 0; if (mag(v) > pt.amax[r]) pt.amax[r] = mag(v);
+                    }
+                });
+                Part grp; for (int r = 0; r < CASIM_MAX_RES; ++r) grp.sc[r] = grp.amax[r] = 0; grp.neg = false;
+                for (size_t i = 0; i < NG; ++i) for (int r = 0; r < R; ++r) {
+                    const int64_t a = g->alloc[i * R + r], b = g->init_req[i * R + r];
+                    fold(grp.sc[r], a); fold(grp.sc[r], b);
+                    if (a == INT64_MIN || b == INT64_MIN) grp.neg = true;   // (no int32 image either way)
+                    int64_t d; const bool ovf = __builtin_sub_overflow(a, b, &d);
+                    const int64_t m3 = ovf ? INT64_MAX : mag(d), m2 = mag(a) > mag(b) ? mag(a) : mag(b);
+                    const int64_t mm = m3 > m2 ? m3 : m2;
+                    if (mm > grp.amax[r]) grp.amax[r] = mm;
+                }
+                bool neg = false;
+                std::vector<int64_t> amax((size_t)R, 0);
+                for (int r = 0; r < R; ++r) {
+                    int64_t sc = grp.sc[r], am = grp.amax[r];
+                    for (auto& pt : parts) { if (pt.sc[r] != 0) sc = sc == 0 ? pt.sc[r] : gcd64(sc, pt.sc[r]); if (pt.amax[r] > am) am = pt.amax[r]; }
+                    scale[(size_t)r] = sc == 0 ? 1 : sc; amax[(size_t)r] = am;
+                }
+                neg = grp.neg;
+                for (auto& pt : parts) neg = neg || pt.neg;
                 // |v / scale| <= 2^31 - 1  <=>  |v| <= (2^31 - 1) * scale   (the product saturates: a scale beyond 2^32 admits every int64)
-                std::vector<int64_t> vmax((size_t)R);
-                for (int r = 0; r < R; ++r) vmax[(size_t)r] = scale[(size_t)r] > (0x7fffffffffffffffll / 0x7fffffffll) ? 0x7fffffffffffffffll : 0x7fffffffll * scale[(size_t)r];
-                auto fits32 = [&](int64_t v, int r) { return v <= vmax[(size_t)r] && v >= -vmax[(size_t)r]; };
-                for (size_t i = 0; i < G && ok; ++i) for (int r = 0; r < R; ++r) ok = ok && p->req[i * R + r] >= 0 && fits32(p->req[i * R + r], r);
-                for (size_t i = 0; i < NG && ok; ++i) for (int r = 0; r < R; ++r)
-                    ok = ok && fits32(g->alloc[i * R + r], r) && fits32(g->init_req[i * R + r], r) && fits32(g->alloc[i * R + r] - g->init_req[i * R + r], r);
+                for (int r = 0; r < R; ++r) {
+                    const int64_t vmax = scale[(size_t)r] > (0x7fffffffffffffffll / 0x7fffffffll) ? 0x7fffffffffffffffll : 0x7fffffffll * scale[(size_t)r];
+                    ok = ok && amax[(size_t)r] <= vmax;
+                }
+                ok = ok && !neg;
             }
             if (ok) {
                 // exact division by scale = 2^tz * odd: shift, then multiply by the inverse of `odd` modulo 2^64 (Newton: 5 steps)
@@ -375,11 +431,15 @@ public:
                     inv[(size_t)r] = x; tz[(size_t)r] = z;
                 }
                 auto quot = [&](int64_t v, int r) -> int32_t { return (int32_t)(int64_t)((uint64_t)(v >> tz[(size_t)r]) * inv[(size_t)r]); };   // (v is a multiple of scale: the arithmetic shift is exact)
-                std::vector<int32_t> req32(G * (size_t)R), fresh32(NG * (size_t)R);
-                for (size_t i = 0; i < G; ++i) for (int r = 0; r < R; ++r) req32[i * R + r] = quot(p->req[i * R + r], r);
+                // (the big table is written straight into the staging buffer)
+                std::vector<int32_t> req32_own, fresh32(NG * (size_t)R);
+                const int32_t* req32_dev = nullptr;
+                int32_t* req32 = up_reserve<int32_t>(G * (size_t)R, &req32_dev);
+                if (!req32) { req32_own.resize(G * (size_t)R); req32 = req32_own.data(); }
+                par_for(G, 65536, [&](size_t lo, size_t hi, int) { for (size_t i = lo; i < hi; ++i) for (int r = 0; r < R; ++r) req32[i * R + r] = quot(p->req[i * R + r], r); });
                 for (size_t i = 0; i < NG; ++i) for (int r = 0; r < R; ++r)
                     fresh32[i * R + r] = quot(g->alloc[i * R + r] - g->init_req[i * R + r], r);
-                fs_.req32 = up(req32.data(), req32.size());
+                fs_.req32 = req32_dev ? req32_dev : up(req32_own.data(), req32_own.size());
                 fs_.fresh32 = up(fresh32.data(), fresh32.size());
                 fs_.scale = up(scale.data(), scale.size());   // (all three copied into the staging buffer already)
                 if (getenv("CASIM_PACK_PROF_DUMP")) { fs_.prof = (int64_t*)dalloc(8 * 8 * NG); bk_.zero(fs_.prof, 8 * 8 * NG); }
@@ -774,13 +834,23 @@ private:
         if (n == 0 || !src) return nullptr;
         const size_t bytes = sizeof(T) * n, at = (up_used_ + 15) & ~(size_t)15;
         if (up_dev_ && at + bytes <= up_cap_) {
-            memcpy(up_host_ + at, src, bytes);
+            par_memcpy(up_host_ + at, src, bytes);
             up_used_ = at + bytes;
             return (const T*)(up_dev_ + at);
         }
         T* d = (T*)dalloc(bytes);   // outside a packed section (or a bound that was too small): its own copy
         if (d) bk_.h2d(d, src, bytes);
         return d;
+    }
+    // room for n values inside the packed section, to be written in place (host pointer) instead of built in a vector and copied;
+    // null when there is no packed section or no room (the caller falls back on up())
+    template <class T>
+    T* up_reserve(size_t n, const T** dev_out) {
+        const size_t bytes = sizeof(T) * n, at = (up_used_ + 15) & ~(size_t)15;
+        if (n == 0 || !up_dev_ || at + bytes > up_cap_) return nullptr;
+        up_used_ = at + bytes;
+        *dev_out = (const T*)(up_dev_ + at);
+        return (T*)(up_host_ + at);
     }
     void* dalloc(size_t bytes) {
         if (bytes == 0) bytes = 8;

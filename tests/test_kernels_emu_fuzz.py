@@ -105,3 +105,16 @@ def test_fuzz_fast_packer_shapes(seed):
                   existing=[], lanes=lanes)
     res, _ = run_emu(encode(sc))
     assert_matches_oracle(res, run_oracle(sc), f"seed {seed}")
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_host_loops_cut_over_threads(seed, monkeypatch):
+    """The gcd pass / int32 tables / staging copies of ProblemT::init run on up to four host threads for million-PEG batches;
+    CASIM_HOST_GRAIN makes them do so on fuzz-sized tables: same results (lanes with every kind of gcd: the shapes family)."""
+    monkeypatch.setenv("CASIM_HOST_GRAIN", "3")
+    if seed < 30:
+        test_fuzz_fast_packer_shapes(seed)
+    else:
+        sc = scenario_of(workloads.fuzz(1000 + seed))
+        res, _ = run_emu(encode(sc))
+        assert_matches_oracle(res, run_oracle(sc), f"seed {seed}")
