@@ -38,6 +38,7 @@ CS_DEVICE void atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
 CS_DEVICE void lds_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
 CS_DEVICE uint64_t ballot(bool p) { return casim_emu::wave_ballot(p); }
 CS_DEVICE uint64_t readlane_u64(uint64_t v, int l) { return casim_emu::wave_xchg_u64(v, l); }
+CS_DEVICE uint32_t shfl_u32(uint32_t v, int l) { return (uint32_t)casim_emu::wave_xchg_u64(v, l); }
 CS_DEVICE uint32_t wave_sum_u32(uint32_t v) { return (uint32_t)casim_emu::wave_sum_u64(v); }
 CS_DEVICE uint64_t wave_sum_u64(uint64_t v) { return casim_emu::wave_sum_u64(v); }
 CS_DEVICE uint32_t wave_max_u32(uint32_t v) { return (uint32_t)casim_emu::wave_max_u64(v); }
@@ -101,6 +102,8 @@ CS_DEVICE uint64_t readlane_u64(uint64_t v, int l) {
     hi = (uint32_t)__shfl((int)hi, l, 64);
     return ((uint64_t)hi << 32) | lo;
 }
+// value of lane l (per-lane source): ds_bpermute_b32 — the LDS crossbar, no LDS memory
+CS_DEVICE uint32_t shfl_u32(uint32_t v, int l) { return (uint32_t)__shfl((int)v, l, 64); }
 // Wave64 reductions on the VALU with DPP (data-parallel primitives): 6 dependent VALU ops instead of
 // 6 ds_bpermute round trips through the LDS crossbar (each ~100 cycles of latency on the packer's
 // critical path — r01a profile).  Pattern: butterfly inside each row of 16 lanes (quad_perm, row_ror),

@@ -392,6 +392,57 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
     int32_t* pos = (int32_t*)(keys + npad);     // [npad]
     int32_t* gid = pos + npad;                  // [npad] PEG id of list position i (read back after the sort: one dependent
                                                 //        global gather less on the way to the records)
+    if constexpr (NPAD > 0) {
+        // ONE wave, the list in REGISTERS: element i = tid + 64 * q lives in slot q of lane tid.  A compare-exchange with distance
+        // j < 64 fetches the partner from lane tid ^ j through the LDS crossbar (ds_bpermute: three dwords per element, no LDS
+        // memory, no barrier), with j >= 64 it swaps two slots of the same lane.  As (key, position) arrays in LDS every stage was
+        // four reads, a compare, four predicated writes and a barrier — ~70 instructions for two elements per lane, 28 stages for
+        // 128 entries: 60 % of this kernel, which is bound by instruction issue (profiles/r05d_sched_phase_profile.txt, [order prof]).
+        constexpr int QN = NPAD / 64;
+        uint64_t ek[QN];
+        int32_t ep[QN];
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+            const int i = tid + 64 * q;
+            if (i < Gn) {
+                const int g = t.peg_idx[off + i];
+                gid[i] = g;
+                ek[q] = desc_key(peg_score(t, g, ng));
+                ep[q] = i;
+            } else { ek[q] = ~0ull; ep[q] = 0x7fffffff; }
+        }
+        CASIM_OPROF(0);   // scores
+#pragma unroll
+        for (int k = 2; k <= NPAD; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                if (j >= 64) {
+                    const int dq = j >> 6;
+#pragma unroll
+                    for (int q = 0; q < QN; ++q) {
+                        if (q & dq) continue;
+                        const bool up = ((64 * q) & k) == 0;   // (k > j >= 64: a constant of the slot)
+                        const bool gt = ek[q] > ek[q | dq] || (ek[q] == ek[q | dq] && ep[q] > ep[q | dq]);
+                        if (gt == up) { const uint64_t tk = ek[q]; ek[q] = ek[q | dq]; ek[q | dq] = tk; const int32_t tp = ep[q]; ep[q] = ep[q | dq]; ep[q | dq] = tp; }
+                    }
+                } else {
+                    const bool low = (tid & j) == 0;   // I am the lower index of my pair
+#pragma unroll
+                    for (int q = 0; q < QN; ++q) {
+                        const bool up = ((tid + 64 * q) & k) == 0;
+                        const uint64_t pk = cs::readlane_u64(ek[q], tid ^ j);
+                        const int32_t pp = (int32_t)cs::shfl_u32((uint32_t)ep[q], tid ^ j);
+                        const bool gt = ek[q] > pk || (ek[q] == pk && ep[q] > pp);   // mine sorts after the partner
+                        // the lower index keeps the smaller of the two when the run ascends, the larger when it descends
+                        if (gt == (low == up)) { ek[q] = pk; ep[q] = pp; }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < QN; ++q) pos[tid + 64 * q] = ep[q];
+        cs::sync();
+    } else {
 #pragma unroll
     for (int i = tid; i < npad; i += nt) {
         if (i < Gn) {
@@ -417,20 +468,6 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
         const bool up = (i & k) == 0;
         if (gt == up) { keys[i] = kl; keys[l] = ki; pos[i] = pl; pos[l] = pi; }
     };
-    if constexpr (NPAD > 0) {
-#pragma unroll
-        for (int k = 2; k <= NPAD; k <<= 1) {
-#pragma unroll
-            for (int j = k >> 1; j > 0; j >>= 1) {
-#pragma unroll
-                for (int q = 0; q < (NPAD / 2 + 63) / 64; ++q) {
-                    const int p = tid + 64 * q;
-                    if (NPAD >= 128 || p < NPAD / 2) exchange(p, k, j);
-                }
-                cs::sync();
-            }
-        }
-    } else {
         for (int k = 2; k <= npad; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
                 for (int p = tid; p < (npad >> 1); p += nt) exchange(p, k, j);

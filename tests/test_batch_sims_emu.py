@@ -175,3 +175,36 @@ def test_large_batch_takes_the_multi_block_scan_and_wave_per_group_order():
         assert list(res.placed[k * nnz:(k + 1) * nnz]) == list(base.placed)
         assert list(res.order[k * nnz:(k + 1) * nnz] - k * ts.n_pegs) == list(base.order)
     enc.close()
+
+
+@pytest.mark.parametrize("n_pegs", [20, 100, 220])
+def test_one_wave_orderer_networks_of_64_128_256_entries(n_pegs):
+    """Launches of >= 2048 groups sort every list of <= 256 PEGs in ONE wave, in registers (order_group<NPAD>: 64 / 128 / 256
+    entries = 1 / 2 / 4 slots per lane, partners through the LDS crossbar): scores with many ties (same requests, different
+    counts) so that the position tie-break is exercised in every stage; 2 simulations tiled to 2100 groups vs the oracle."""
+    from kubernetes_autoscaler_amd.objects import NodeInfo, Pod, PodEquivalenceGroup
+    from kubernetes_autoscaler_amd.workloads import _node, SplitMix64
+    rng = SplitMix64(0x0DE7 + n_pegs)
+    scs = []
+    for s in range(2):
+        pegs = []
+        for i in range(n_pegs):
+            req = {"cpu": 50 * (1 + rng.below(6)), "memory": (64 << 20) * (1 + rng.below(4))}   # 24 distinct scores: ties everywhere
+            pegs.append(PodEquivalenceGroup(pods=[Pod(name=f"s{s}p{i}", requests=req)] * (1 + rng.below(3))))
+        groups = [GroupSpec(NodeInfo(_node(f"t{s}-{k}", 1000 * (2 + k), (2 + 2 * k) << 30, 30, {})), max_nodes=3 + k, last_index=0, pegs=None) for k in range(3)]
+        scs.append(Scenario(pegs=pegs, groups=groups, device_csr=True))
+    enc, ts, bases = encode_batch(scs)
+    want = []
+    for sc, (pb, _) in zip(scs, bases):
+        want.extend(_shift(run_oracle(sc), pb))
+    times = 350   # 2 simulations x 3 groups x 350 = 2100 groups >= 2048: the batch geometry (one wave per group)
+    big = ts.tile(times)
+    res, _ = run_emu_tables(big)
+    G, NG = ts.n_pegs, ts.n_groups
+    for t in (0, 1, times // 2, times - 1):
+        for gi, (est, ids) in enumerate(want):
+            g = t * NG + gi
+            order, placed = res.group(g)
+            assert [int(o) - t * G for o in order] == [ids[k] for k in est.order], f"copy {t} group {gi}: PEG order"
+            assert list(placed) == list(est.placed) and int(res.node_count[g]) == est.node_count
+    enc.close()
