@@ -15,16 +15,54 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <deque>
 #include <map>
 #include <set>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <unordered_map>
 #include <utility>
 #include <vector>
 
 #include "../../include/casim.h"
+
+// Loops of casim_enc_finalize that touch every node / every running pod's spec record run on up to four threads (like the host loops of
+// the engine, casim_pipeline.h par_for): f(lo, hi, t) over [0, n) cut into T slices.  CASIM_HOST_THREADS = 1 switches it off,
+// CASIM_HOST_GRAIN sets the smallest slice worth a thread (tests: threads on small inputs).
+namespace {
+inline int enc_threads(size_t n, size_t grain) {
+    int T = 4;
+    if (const char* ev = getenv("CASIM_HOST_THREADS")) { const int v = atoi(ev); T = v < 1 ? 1 : (v > 4 ? 4 : v); }
+    if (const char* ev = getenv("CASIM_HOST_GRAIN")) { const long v = atol(ev); if (v > 0) grain = (size_t)v; }
+    if (grain > 0 && n / grain < (size_t)T) T = (int)(n / grain);
+    return T < 1 ? 1 : T;
+}
+template <class F>
+inline void enc_par_for(size_t n, int T, F f) {
+    if (T <= 1) { f((size_t)0, n, 0); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back([&f, n, T, t] { f(n * (size_t)t / (size_t)T, n * (size_t)(t + 1) / (size_t)T, t); });
+    f((size_t)0, n / (size_t)T, 0);
+    for (auto& x : th) x.join();
+}
+}  // namespace
+
+// CASIM_ENC_TIMING=1: casim_enc_finalize prints the milliseconds of its stages to stderr (tools/casim_incr_bench)
+namespace {
+struct EncStageTimer {
+    bool on; std::chrono::steady_clock::time_point t0; std::string line;
+    EncStageTimer() : on(getenv("CASIM_ENC_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char* what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        char b[96]; snprintf(b, sizeof b, " %s %.2f", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        line += b; t0 = t1;
+    }
+    ~EncStageTimer() { if (on) fprintf(stderr, "[enc finalize ms]%s\n", line.c_str()); }
+};
+}  // namespace
 
 namespace {
 
@@ -243,6 +281,8 @@ inline void set_bit(std::vector<uint64_t>& m, size_t row, int W, int bit) { m[ro
 
 struct casim_encoder {
     casim_encoder_options opt;
+    std::vector<int32_t> term_specs;   // specs with (anti-)affinity terms, in the order they got their first one (finalize looks at these only: at cluster scale the
+                                       // other 150 000 spec records stay cold)
     std::deque<PodSpec> specs;   // (a deque: at cluster scale there is one spec per running pod, and growing a vector moved every one of them ~2.5 times)
     std::deque<Group> groups;    // (same: one record per node in the per-node entry points)
     std::vector<Peg> pegs;
@@ -442,6 +482,7 @@ int32_t casim_enc_pod_add_anti_affinity_term(casim_encoder* e, int32_t pod, cons
     Term t; t.topology_key = S(topology_key);
     if (n_namespaces == 0) { t.namespaces.push_back(e->specs[pod].ns); t.auto_ns = true; }  // getNamespacesFromPodAffinityTerm
     for (int i = 0; i < n_namespaces; ++i) t.namespaces.push_back(S(namespaces[i]));
+    if (e->specs[pod].anti.empty() && e->specs[pod].aff.empty()) e->term_specs.push_back(pod);
     e->specs[pod].anti.push_back(t);
     return (int32_t)e->specs[pod].anti.size() - 1;
 }
@@ -457,6 +498,7 @@ int32_t casim_enc_pod_add_affinity_term(casim_encoder* e, int32_t pod, const cha
     Term t; t.topology_key = S(topology_key);
     if (n_namespaces == 0) { t.namespaces.push_back(e->specs[pod].ns); t.auto_ns = true; }  // getNamespacesFromPodAffinityTerm
     for (int i = 0; i < n_namespaces; ++i) t.namespaces.push_back(S(namespaces[i]));
+    if (e->specs[pod].anti.empty() && e->specs[pod].aff.empty()) e->term_specs.push_back(pod);
     e->specs[pod].aff.push_back(t);
     return (int32_t)e->specs[pod].aff.size() - 1;
 }
@@ -538,6 +580,7 @@ int32_t casim_enc_add_existing_pod(casim_encoder* e, int32_t pod_spec, const cha
 int32_t casim_enc_finalize(casim_encoder* e) {
     ENC_OPEN(e);   // (also the full fallback of an update session: casim_enc_refinalize said CASIM_ENC_NEEDS_FULL)
     e->fs.valid = false;
+    EncStageTimer stage;
     const int R = e->opt.n_res;
     const size_t G = e->pegs.size(), NG = e->groups.size(), NS = e->specs.size();
     const bool cmp_ops = e->opt.enable_taint_comparison_ops != 0;
@@ -550,30 +593,35 @@ int32_t casim_enc_finalize(casim_encoder* e) {
     // unlabelled (plugin.go:161-169).  The two only differ for a namespace the lister does not know; the conflict bits
     // below are symmetric in who arrives first, so that corner is delegated (every PEG flagged) instead of guessed.
     {
-        bool any_sel = false, all_known = true;
-        for (auto& p : e->specs) {
-            for (auto& t : p.anti) if (t.has_ns_sel && !t.ns_sel.empty()) any_sel = true;
-            if (!e->namespaces.count(p.ns)) all_known = false;
-        }
-        for (auto& p : e->specs)
-            for (auto& t : p.anti) {
-                if (!t.has_ns_sel) continue;
-                if (t.ns_sel.empty()) { t.all_ns = true; continue; }
-                for (auto& kv : e->namespaces) if (selector_matches(t.ns_sel, kv.second)) t.namespaces.push_back(kv.first);
-            }
-        if (any_sel && !all_known)
-            for (auto& p : e->specs) { p.unsupported = true; p.why = "namespaceSelector next to a pod whose namespace is not listed"; }
-        // required AFFINITY terms are only ever the incoming pod's (existing pods' affinity does not constrain it): no symmetry to keep,
-        // an unlisted namespace simply is not selected by a non-empty selector
-        for (auto& p : e->specs)
-            for (auto& t : p.aff) {
+        // (only specs with terms are visited — e->term_specs; "every namespace listed" is only asked when a selector exists)
+        bool any_sel = false;
+        for (int32_t sp : e->term_specs)
+            for (auto& t : e->specs[(size_t)sp].anti) if (t.has_ns_sel && !t.ns_sel.empty()) any_sel = true;
+        for (int32_t sp : e->term_specs)
+            for (auto& t : e->specs[(size_t)sp].anti) {
                 if (!t.has_ns_sel || t.ns_resolved) continue;
                 t.ns_resolved = true;   // (a second finalize of an update session must not append the namespaces again)
                 if (t.ns_sel.empty()) { t.all_ns = true; continue; }
                 for (auto& kv : e->namespaces) if (selector_matches(t.ns_sel, kv.second)) t.namespaces.push_back(kv.first);
             }
+        if (any_sel) {
+            bool all_known = true;
+            for (auto& p : e->specs) if (!e->namespaces.count(p.ns)) { all_known = false; break; }
+            if (!all_known)
+                for (auto& p : e->specs) { p.unsupported = true; p.why = "namespaceSelector next to a pod whose namespace is not listed"; }
+        }
+        // required AFFINITY terms are only ever the incoming pod's (existing pods' affinity does not constrain it): no symmetry to keep,
+        // an unlisted namespace simply is not selected by a non-empty selector
+        for (int32_t sp : e->term_specs)
+            for (auto& t : e->specs[(size_t)sp].aff) {
+                if (!t.has_ns_sel || t.ns_resolved) continue;
+                t.ns_resolved = true;
+                if (t.ns_sel.empty()) { t.all_ns = true; continue; }
+                for (auto& kv : e->namespaces) if (selector_matches(t.ns_sel, kv.second)) t.namespaces.push_back(kv.first);
+            }
     }
 
+    stage.mark("namespaces");
     // ---- dictionaries ------------------------------------------------------------------
     // (1) taints that reject scheduling (NoSchedule / NoExecute)
     std::map<Taint, int> taint_id;
@@ -581,6 +629,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         for (auto& t : g.taints)
             if ((t.effect == "NoSchedule" || t.effect == "NoExecute") && !taint_id.count(t)) { const int id = (int)taint_id.size(); taint_id[t] = id; }
     e->Wt = ((int)taint_id.size() + 63) / 64;
+    stage.mark("taints");
     // (2) label requirements used by some PEG spec (nodeSelector pair == In{value})
     std::map<std::string, int> lreq_id;
     std::vector<Requirement> lreqs;
@@ -614,6 +663,102 @@ int32_t casim_enc_finalize(casim_encoder* e) {
     }
     e->Wl = ((int)lreqs.size() + 63) / 64;
 
+    stage.mark("label_reqs");
+    // ---- content classes of the running pods ----------------------------------------------------
+    // At cluster scale a shim without a spec cache hands over one spec record per RUNNING pod (150 000 records of ~1 500 shapes).  What
+    // finalize asks of a running pod — does a PEG's term / a rule's selector match it, does it hold a host port, does it carry terms
+    // of its own — looks at its namespace, labels, anti-affinity terms and host ports only.  So the distinct running specs are put
+    // into classes of equal (namespace, labels) once (hash, then equality against the class representative: exact); a spec with
+    // anti-affinity terms or host ports is a class of its own ("special").  The one pass that touches every (cold) spec record runs on up to
+    // four threads, each interning its slice; the slices' classes are merged in spec order, so class ids do not depend on the threads.
+    struct RunningClasses {
+        std::vector<uint8_t> seen;        // [specs] preloaded on some group
+        std::vector<int32_t> specs;       // distinct running specs, ascending
+        std::vector<int32_t> cls;         // [specs] class of a running spec, -1 otherwise
+        std::vector<int32_t> rep;         // [classes] representative spec (the first of the class in spec order)
+        std::vector<uint8_t> is_special;  // [classes] carries anti-affinity terms or host ports: a class of its own
+        std::vector<int32_t> special;     // the special classes, ascending
+    } rc;
+    {
+        rc.seen.assign(NS, 0);
+        for (auto& g : e->groups) for (int32_t s : g.preloaded) rc.seen[(size_t)s] = 1;
+        for (size_t s = 0; s < NS; ++s) if (rc.seen[s]) rc.specs.push_back((int32_t)s);
+        rc.cls.assign(NS, -1);
+        const size_t n = rc.specs.size();
+        const int T = enc_threads(n, 8192);
+        struct Local { std::vector<int32_t> rep; std::vector<uint64_t> hash; std::vector<int32_t> cls; };   // cls: per spec of the slice
+        std::vector<Local> loc((size_t)T);
+        // (eight bytes per multiply; the length goes in, so "ab" + "c" != "a" + "bc")
+        auto mix = [](uint64_t h, const std::string& x) {
+            const char* d = x.data();
+            size_t len = x.size();
+            h = (h ^ (uint64_t)len) * 0x9E3779B97F4A7C15ull;
+            while (len >= 8) { uint64_t w; memcpy(&w, d, 8); h = (h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; d += 8; len -= 8; }
+            if (len) { uint64_t w = 0; memcpy(&w, d, len); h = (h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
+            return h;
+        };
+        auto same = [&](const PodSpec& a, const PodSpec& b) { return a.ns == b.ns && a.labels.v == b.labels.v; };
+        auto work = [&](int t) {
+            Local& L = loc[(size_t)t];
+            const size_t lo = n * (size_t)t / (size_t)T, hi = n * (size_t)(t + 1) / (size_t)T;
+            std::vector<int32_t> table(4096, 0);
+            size_t filled = 0;
+            L.cls.resize(hi - lo);
+            for (size_t k = lo; k < hi; ++k) {
+                // (the records are cold and each is two dependent misses — the record, then its label block: fetched 48 / 24 specs ahead)
+                if (k + 48 < hi) { const PodSpec& f = e->specs[(size_t)rc.specs[k + 48]]; __builtin_prefetch(&f.ns); __builtin_prefetch(&f.labels); __builtin_prefetch(&f.anti); }
+                if (k + 24 < hi) { const PodSpec& f = e->specs[(size_t)rc.specs[k + 24]]; if (!f.labels.v.empty()) __builtin_prefetch(f.labels.v.data()); }
+                const PodSpec& q = e->specs[(size_t)rc.specs[k]];
+                if (!q.anti.empty() || !q.ports.empty()) { L.cls[k - lo] = (int32_t)L.rep.size(); L.rep.push_back(rc.specs[k]); L.hash.push_back(0); continue; }
+                uint64_t h = mix(1469598103934665603ull, q.ns);
+                for (auto& kv : q.labels.v) { h = mix(h, kv.first); h = mix(h, kv.second); }
+                h |= 1ull;   // (0 marks the special ones)
+                // open addressing on the hash (a slot = local class + 1): the few thousand shapes of a slice stay in L1 / L2
+                size_t at = (size_t)(h >> 17) & (table.size() - 1);
+                int32_t c = -1;
+                for (;;) {
+                    const int32_t x = table[at] - 1;
+                    if (x < 0) break;
+                    if (L.hash[(size_t)x] == h && same(e->specs[(size_t)L.rep[(size_t)x]], q)) { c = x; break; }
+                    at = (at + 1) & (table.size() - 1);
+                }
+                if (c < 0) {
+                    c = (int32_t)L.rep.size(); L.rep.push_back(rc.specs[k]); L.hash.push_back(h); table[at] = c + 1;
+                    if (++filled * 2 > table.size()) {   // keep it at most half full
+                        std::vector<int32_t> bigger(table.size() * 2, 0);
+                        for (size_t x = 0; x < L.rep.size(); ++x) {
+                            if (L.hash[x] == 0) continue;
+                            size_t b = (size_t)(L.hash[x] >> 17) & (bigger.size() - 1);
+                            while (bigger[b]) b = (b + 1) & (bigger.size() - 1);
+                            bigger[b] = (int32_t)x + 1;
+                        }
+                        table.swap(bigger);
+                    }
+                }
+                L.cls[k - lo] = c;
+            }
+        };
+        enc_par_for(n, T, [&](size_t, size_t, int t) { work(t); });   // (work(t) takes the same slice bounds)
+        // merge: slices in order, local classes in order of first appearance == ascending representative
+        std::unordered_map<uint64_t, std::vector<int32_t>> by_hash;
+        for (int t = 0; t < T; ++t) {
+            Local& L = loc[(size_t)t];
+            std::vector<int32_t> global(L.rep.size(), -1);
+            for (size_t x = 0; x < L.rep.size(); ++x) {
+                const PodSpec& q = e->specs[(size_t)L.rep[x]];
+                int32_t c = -1;
+                if (L.hash[x] != 0) {
+                    auto& cands = by_hash[L.hash[x]];
+                    for (int32_t y : cands) if (same(e->specs[(size_t)rc.rep[(size_t)y]], q)) { c = y; break; }
+                    if (c < 0) { c = (int32_t)rc.rep.size(); rc.rep.push_back(L.rep[x]); rc.is_special.push_back(0); cands.push_back(c); }
+                } else { c = (int32_t)rc.rep.size(); rc.rep.push_back(L.rep[x]); rc.is_special.push_back(1); rc.special.push_back(c); }
+                global[x] = c;
+            }
+            const size_t lo = n * (size_t)t / (size_t)T;
+            for (size_t k = 0; k < L.cls.size(); ++k) rc.cls[(size_t)rc.specs[lo + k]] = global[(size_t)L.cls[k]];
+        }
+    }
+    stage.mark("running_classes");
     // (3) node-local exclusion bits: host ports and hostname anti-affinity across DIFFERENT units.
     // Units: every PEG, plus every spec preloaded on some template.
     BitAlloc xbits;
@@ -624,9 +769,10 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         std::map<Port, std::set<int>> users;            // port -> units using it (unit = PEG id, or -1-spec for preloaded)
         for (size_t i = 0; i < G; ++i)
             for (auto& p : e->specs[(size_t)e->pegs[i].spec].ports) if (p.port > 0) users[sanitize(p)].insert((int)i);
-        for (auto& g : e->groups)
-            for (int32_t s : g.preloaded)
-                for (auto& p : e->specs[(size_t)s].ports) if (p.port > 0) users[sanitize(p)].insert(-1 - s);
+        for (int32_t c : rc.special) {   // (running pods with host ports are content classes of their own)
+            const int32_t s = rc.rep[(size_t)c];
+            for (auto& p : e->specs[(size_t)s].ports) if (p.port > 0) users[sanitize(p)].insert(-1 - s);
+        }
         // a used port needs a bit when some OTHER unit wants a conflicting port
         for (auto& a : users) {
             bool shared = false;
@@ -676,25 +822,31 @@ int32_t casim_enc_finalize(casim_encoder* e) {
             }
         }
         // distinct specs preloaded on some template, ascending (a flag per spec: at cluster scale every running pod has its own)
-        std::vector<int32_t> pre_specs;
-        {
-            std::vector<uint8_t> seen(NS, 0);
-            for (auto& g : e->groups) for (int32_t s : g.preloaded) seen[(size_t)s] = 1;
-            for (size_t s = 0; s < NS; ++s) if (seen[s]) pre_specs.push_back((int32_t)s);
-            e->fs.running = seen;
-        }
+        const std::vector<int32_t>& pre_specs = rc.specs;
+        e->fs.running = rc.seen;
+        // A running pod without terms of its own conflicts with a PEG only through the PEG's terms, which look at its namespace and
+        // labels: one verdict per (content class, PEG with terms), not one per running pod (1.2 M term evaluations over 150 000 cold
+        // spec records were 35 ms of a full finalize).  Every conflicting SPEC still gets its own bit, in ascending spec order.
+        std::vector<int8_t> verdict(with_terms.empty() ? 0 : rc.rep.size() * with_terms.size(), (int8_t)-1);
         for (int32_t s : pre_specs) {
-            bool s_has_terms = false;
-            for (auto& t : e->specs[(size_t)s].anti) if (t.topology_key == kHostname) s_has_terms = true;
-            auto visit = [&](size_t i) {
-                if (host_conflict(e->specs[(size_t)s], e->specs[(size_t)e->pegs[i].spec])) {
-                    if (!pre_occ_bit.count(s)) pre_occ_bit[s] = xbits.next();
-                    peg_blockers[i].push_back(pre_occ_bit[s]);
-                }
+            const int32_t c = rc.cls[(size_t)s];
+            auto hit = [&](size_t i) {
+                if (!pre_occ_bit.count(s)) pre_occ_bit[s] = xbits.next();
+                peg_blockers[i].push_back(pre_occ_bit[s]);
             };
-            // only a pod that carries hostname terms can conflict with a term-less one
-            if (s_has_terms) for (size_t i = 0; i < G; ++i) visit(i);
-            else for (size_t i : with_terms) visit(i);
+            if (rc.is_special[(size_t)c]) {   // (s is the class: it may carry hostname terms — then it can conflict with a term-less PEG)
+                bool s_has_terms = false;
+                for (auto& t : e->specs[(size_t)s].anti) if (t.topology_key == kHostname) s_has_terms = true;
+                auto visit = [&](size_t i) { if (host_conflict(e->specs[(size_t)s], e->specs[(size_t)e->pegs[i].spec])) hit(i); };
+                if (s_has_terms) for (size_t i = 0; i < G; ++i) visit(i);
+                else for (size_t i : with_terms) visit(i);
+                continue;
+            }
+            for (size_t w = 0; w < with_terms.size(); ++w) {
+                int8_t& v = verdict[(size_t)c * with_terms.size() + w];
+                if (v < 0) v = host_conflict(e->specs[(size_t)rc.rep[(size_t)c]], e->specs[(size_t)e->pegs[with_terms[w]].spec]) ? 1 : 0;
+                if (v) hit(with_terms[w]);
+            }
         }
     }
     e->Wx = xbits.words();
@@ -712,6 +864,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
                 }
     }
 
+    stage.mark("node_bits");
     // (4) group-wide exclusion bits: anti-affinity on non-hostname topology keys.  All nodes of a group
     // clone one template, so a domain == the whole group when the template carries the key.
     BitAlloc zbits;
@@ -781,6 +934,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
             if (!existing_block[i].empty()) { static_zbit[i] = zbits.next(); zbit_key[static_zbit[i]] = ""; z_block[i].push_back(static_zbit[i]); }
         }
     }
+    stage.mark("zone_bits");
     // (4a) template mode: required pod affinity.  satisfyPodAffinity (interpodaffinity/filtering.go:382-409) asks, per term, for a
     // pod matching ALL terms of the incoming pod in the node's domain of the term's key — or, when no such pod exists ANYWHERE and the
     // pod matches its own terms, lets the first pod of the series through (:396-407).  Counts only grow while an Estimate runs, and all
@@ -867,6 +1021,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
     }
     e->Wz = zbits.words();
 
+    stage.mark("affinity_static");
     // (4b) per-node mode: domain rules (include/casim.h, casim_domain_rules) for PodTopologySpread and for required
     // anti-affinity on non-hostname keys.  Template mode (an Estimate): spread constraints are outside the subset.
     e->dr = decltype(e->dr)();
@@ -898,13 +1053,8 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         // keys that matter: spread keys of the classes, non-hostname anti-affinity keys of classes and running pods
         std::set<std::string> aa_keys;
         for (size_t i = 0; i < G; ++i) for (auto& t : e->specs[(size_t)e->pegs[i].spec].anti) if (t.topology_key != kHostname) aa_keys.insert(t.topology_key);
-        std::vector<int32_t> running;   // distinct specs of running pods, ascending
-        {
-            std::vector<uint8_t> seen(NS, 0);
-            for (auto& g : e->groups) for (int32_t s2 : g.preloaded) seen[(size_t)s2] = 1;
-            for (size_t s2 = 0; s2 < NS; ++s2) if (seen[s2]) running.push_back((int32_t)s2);
-        }
-        for (int32_t s2 : running) for (auto& t : e->specs[(size_t)s2].anti) if (t.topology_key != kHostname) aa_keys.insert(t.topology_key);
+        // (running pods through their content classes: only a class of its own can carry terms)
+        for (int32_t c : rc.special) for (auto& t : e->specs[(size_t)rc.rep[(size_t)c]].anti) if (t.topology_key != kHostname) aa_keys.insert(t.topology_key);
         // required pod affinity (V/.../interpodaffinity/filtering.go:234-272,382-409): an existing / placed pod counts for the
         // class when it matches ALL of its affinity terms (podMatchesAllAffinityTerms), once per term, in the domain of its
         // node for that term's topology key; a node passes a term when its domain holds such a pod
@@ -916,6 +1066,8 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         struct Rule { int cls, key, kind, skew, mind, self, row; const Spread* sc; int ghost = 0; };
         std::vector<Rule> rules;
         std::vector<std::vector<uint64_t>> rows;
+        struct SpreadClass { size_t cls; int row_of[4]; };
+        std::vector<SpreadClass> spread_classes;   // their eligibility rows are filled after the loop, nodes in parallel
         for (size_t i = 0; i < G; ++i) {
             const PodSpec& p = e->specs[(size_t)e->pegs[i].spec];
             // eligibility of a node for a constraint (filtering.go:262-271, common.go:44-58): every constraint key of the
@@ -927,26 +1079,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
                     const int combo = (sc.affinity_honor ? 1 : 0) | (sc.taints_honor ? 2 : 0);
                     if (row_of[combo] < 0) { row_of[combo] = (int)rows.size(); rows.emplace_back(words, 0ull); }
                 }
-                for (size_t n = 0; n < NG; ++n) {
-                    const Group& g = e->groups[n];
-                    bool keys_ok = true;
-                    for (auto& sc : p.spread) keys_ok = keys_ok && g.labels.count(sc.key) != 0;
-                    if (!keys_ok) continue;
-                    const bool aff = node_passes_affinity(p, g);
-                    bool tolerated = true;
-                    for (auto& tn : g.taints) {
-                        if (tn.effect != "NoSchedule" && tn.effect != "NoExecute") continue;
-                        bool tol = false;
-                        for (auto& t : p.tolerations) if (tolerates(t, tn, e->opt.enable_taint_comparison_ops != 0)) { tol = true; break; }
-                        if (!tol) { tolerated = false; break; }
-                    }
-                    for (int combo = 0; combo < 4; ++combo) {
-                        if (row_of[combo] < 0) continue;
-                        if ((combo & 1) && !aff) continue;
-                        if ((combo & 2) && !tolerated) continue;
-                        rows[(size_t)row_of[combo]][n >> 6] |= 1ull << (n & 63);
-                    }
-                }
+                spread_classes.push_back(SpreadClass{i, {row_of[0], row_of[1], row_of[2], row_of[3]}});
             }
             e->fs.class_rows[i] = std::array<int, 4>{{row_of[0], row_of[1], row_of[2], row_of[3]}};
             for (auto& sc : p.spread) {
@@ -968,7 +1101,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
             for (auto& k : aa_keys) {
                 bool any = false;
                 for (size_t j = 0; j < G && !any; ++j) any = zone_conflict(p, e->specs[(size_t)e->pegs[j].spec], k);
-                for (int32_t s2 : running) { if (any) break; any = zone_conflict(p, e->specs[(size_t)s2], k); }
+                for (int32_t s2 : rc.rep) { if (any) break; any = zone_conflict(p, e->specs[(size_t)s2], k); }   // (one pod per content class)
                 if (!any) continue;
                 Rule r{(int)i, key_of(k), 1, 0, 0, zone_conflict(p, p, k) ? 1 : 0, -1, nullptr};
                 rules.push_back(r);
@@ -978,6 +1111,34 @@ int32_t casim_enc_finalize(casim_encoder* e) {
                 rules.push_back(r);
             }
         }
+        // the rows: node ranges on 64-node word boundaries (no two threads share a word), every class with constraints per node
+        enc_par_for(words, enc_threads(NG, 2048) > 1 ? enc_threads(NG, 2048) : 1, [&](size_t wlo, size_t whi, int) {
+            for (size_t n = wlo * 64; n < whi * 64 && n < NG; ++n) {
+                const Group& g = e->groups[n];
+                for (auto& sc0 : spread_classes) {
+                    const PodSpec& p = e->specs[(size_t)e->pegs[sc0.cls].spec];
+                    const int* row_of = sc0.row_of;
+                    bool keys_ok = true;
+                    for (auto& sc : p.spread) keys_ok = keys_ok && g.labels.count(sc.key) != 0;
+                    if (!keys_ok) continue;
+                    const bool aff = node_passes_affinity(p, g);
+                    bool tolerated = true;
+                    for (auto& tn : g.taints) {
+                        if (tn.effect != "NoSchedule" && tn.effect != "NoExecute") continue;
+                        bool tol = false;
+                        for (auto& t : p.tolerations) if (tolerates(t, tn, e->opt.enable_taint_comparison_ops != 0)) { tol = true; break; }
+                        if (!tol) { tolerated = false; break; }
+                    }
+                    for (int combo = 0; combo < 4; ++combo) {
+                        if (row_of[combo] < 0) continue;
+                        if ((combo & 1) && !aff) continue;
+                        if ((combo & 2) && !tolerated) continue;
+                        rows[(size_t)row_of[combo]][n >> 6] |= 1ull << (n & 63);
+                    }
+                }
+            }
+        });
+        stage.mark("dr_rules_rows");
         if (!rules.empty()) {
             dr.n_keys = (int32_t)keys.size(); dr.n_rules = (int32_t)rules.size(); dr.n_rows = (int32_t)rows.size();
             // domains: distinct values of each key over the nodes
@@ -1004,26 +1165,48 @@ int32_t casim_enc_finalize(casim_encoder* e) {
             dr.count_init.assign((size_t)dr.r_off.back(), 0); dr.exists.assign((size_t)dr.r_off.back(), 0);
             dr.dom_nodes.assign((size_t)dr.r_off.back(), 0); dr.node_contrib.assign(rules.size() * NG, 0);
             dr.class_off.assign(G + 1, 0); dr.inc_off.assign(G + 1, 0);
+        stage.mark("dr_domains");
+            // "does a running pod feed this rule" looks at the pod's namespace, labels and anti-affinity terms only: every (rule, content
+            // class) pair is evaluated once, and a node's pods are walked ONCE, each adding to the rules its class feeds — instead of one
+            // string-keyed selector evaluation per (rule, node, running pod) triple (4.8 M of them were 120 of the 185 ms of a full
+            // finalize at 15 000 nodes / 150 000 running pods / 32 rules).
+            const std::vector<int32_t>& spec_class = rc.cls;
+            const std::vector<int32_t>& class_rep = rc.rep;
+            std::vector<std::vector<int32_t>> class_feeds(class_rep.size());   // rules a running pod of the class feeds, ascending
             for (size_t r = 0; r < rules.size(); ++r) {
                 const Rule& R0 = rules[r];
                 const PodSpec& p = e->specs[(size_t)e->pegs[(size_t)R0.cls].spec];
                 dr.r_class.push_back(R0.cls); dr.r_key.push_back(R0.key); dr.r_kind.push_back(R0.kind); dr.r_skew.push_back(R0.skew);
                 dr.r_mind.push_back(R0.mind); dr.r_self.push_back(R0.self); dr.r_row.push_back(R0.row); dr.r_ghost.push_back((uint8_t)R0.ghost);
                 dr.class_off[(size_t)R0.cls + 1]++;
+                for (size_t c = 0; c < class_rep.size(); ++c) {
+                    const PodSpec& q = e->specs[(size_t)class_rep[c]];
+                    const bool feeds = R0.kind == 0 ? (!R0.sc->selector.empty() && q.ns == p.ns && selector_matches(R0.sc->selector, q.labels))
+                                     : R0.kind == 1 ? zone_conflict(p, q, keys[(size_t)R0.key]) : matches_all_aff(p, q);
+                    if (feeds) class_feeds[c].push_back((int32_t)r);
+                }
+                // the nodes of the rule's domains (a spread rule: the eligible ones)
+                const int32_t* nd = &dr.node_domain[(size_t)R0.key * NG];
+                const uint64_t* row = R0.kind == 0 ? rows[(size_t)R0.row].data() : nullptr;
                 for (size_t n = 0; n < NG; ++n) {
-                    const int d = dr.node_domain[(size_t)R0.key * NG + n];
-                    if (d < 0) continue;
-                    if (R0.kind == 0 && !((rows[(size_t)R0.row][n >> 6] >> (n & 63)) & 1ull)) continue;
-                    const size_t at = (size_t)dr.r_off[r] + (size_t)d;
+                    if (nd[n] < 0) continue;
+                    if (row && !((row[n >> 6] >> (n & 63)) & 1ull)) continue;
+                    const size_t at = (size_t)dr.r_off[r] + (size_t)nd[n];
                     dr.exists[at] = 1; dr.dom_nodes[at]++;
-                    for (int32_t s2 : e->groups[n].preloaded) {
-                        const PodSpec& q = e->specs[(size_t)s2];
-                        const bool feeds = R0.kind == 0 ? (!R0.sc->selector.empty() && q.ns == p.ns && selector_matches(R0.sc->selector, q.labels))
-                                         : R0.kind == 1 ? zone_conflict(p, q, keys[(size_t)R0.key]) : matches_all_aff(p, q);
-                        if (feeds) { dr.count_init[at]++; dr.node_contrib[r * NG + n]++; }
+                }
+            }
+            for (size_t n = 0; n < NG; ++n) {
+                for (int32_t s2 : e->groups[n].preloaded) {
+                    for (int32_t r : class_feeds[(size_t)spec_class[(size_t)s2]]) {
+                        const Rule& R0 = rules[(size_t)r];
+                        const int d = dr.node_domain[(size_t)R0.key * NG + n];
+                        if (d < 0) continue;
+                        if (R0.kind == 0 && !((rows[(size_t)R0.row][n >> 6] >> (n & 63)) & 1ull)) continue;
+                        dr.count_init[(size_t)dr.r_off[(size_t)r] + (size_t)d]++; dr.node_contrib[(size_t)r * NG + n]++;
                     }
                 }
             }
+        stage.mark("dr_counters");
             for (size_t c = 0; c < G; ++c) dr.class_off[c + 1] += dr.class_off[c];
             // which rules a placed pod of class j feeds
             for (size_t j = 0; j < G; ++j) {
@@ -1042,6 +1225,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         }
     }
 
+    stage.mark("domain_rules");
     // ---- flat PEG table ------------------------------------------------------------------
     const int Wt = e->Wt, Wl = e->Wl, Wx = e->Wx, Wz = e->Wz;
     e->req.assign(G * (size_t)R, 0); e->count.assign(G, 0); e->pflags.assign(G, 0);
@@ -1088,6 +1272,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         e->fp_cpu[i] = p.fp_cpu; e->fp_mem[i] = p.fp_mem;
     }
 
+    stage.mark("peg_table");
     // ---- flat group table ------------------------------------------------------------------
     e->alloc.assign(NG * (size_t)R, 0); e->init_req.assign(NG * (size_t)R, 0);
     e->allowed.assign(NG, 0); e->init_pods.assign(NG, 0); e->gflags.assign(NG, 0);
@@ -1138,6 +1323,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
     }
     e->dict[0] = (int)taint_id.size(); e->dict[1] = (int)lreqs.size(); e->dict[2] = xbits.n; e->dict[3] = zbits.n;
     e->finalized = true;
+    stage.mark("group_table");
     // what casim_enc_refinalize works from
     e->fs.taint_id = taint_id; e->fs.lreqs = lreqs; e->fs.port_bit = port_bit; e->fs.pre_occ_bit = pre_occ_bit;
     e->fs.n_specs = NS; e->fs.NG = NG; e->fs.G = G;

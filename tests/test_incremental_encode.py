@@ -131,3 +131,42 @@ def test_updates_that_touch_a_dictionary_ask_for_a_full_finalize():
     assert lib.casim_enc_group_reset(enc._h, 0, enc._lane_vector(info.node.allocatable), 10, 0, 0, 0) == _abi.ERR_INVALID
     assert lib.casim_enc_group_add_label(enc._h, 0, b"a", b"b") == _abi.ERR_INVALID
     enc.close()
+
+
+def _encode_per_pod_records(nodes, pods, copies):
+    """like _encode, but every running pod is described through a spec record of its OWN (a deep copy: the binding caches by object
+    identity) when `copies` is set — what a shim without a spec cache hands over at cluster scale"""
+    enc = Encoder(explicit_self_exclusion=True)
+    for p in pods:
+        enc.add_peg(PodEquivalenceGroup(pods=[p]))
+    for info in nodes:
+        running = [copy.deepcopy(q) for q in info.pods] if copies else list(info.pods)
+        enc.add_group(NodeInfo(info.node, running), pegs=[])
+    enc.finalize()
+    return enc
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_content_classes_of_running_pods_threads_and_record_sharing(seed, monkeypatch):
+    """casim_enc_finalize puts the running pods' spec records into content classes (namespace + labels; terms / host ports: a class of
+    its own) on up to four threads and evaluates selectors once per class.  The tables must not depend on the number of threads, and
+    the domain-rule columns must not depend on whether equal running pods share one spec record or bring one each."""
+    w = workloads.fuzz_pending_domains(9300 + seed) if seed % 4 else workloads.fuzz_pending(9300 + seed)
+    monkeypatch.setenv("CASIM_HOST_THREADS", "1")
+    one = _encode_per_pod_records(w.nodes, w.pods, copies=True)
+    want = _columns(one)
+    monkeypatch.setenv("CASIM_HOST_THREADS", "4"); monkeypatch.setenv("CASIM_HOST_GRAIN", "1")
+    four = _encode_per_pod_records(w.nodes, w.pods, copies=True)
+    got = _columns(four)
+    assert got.keys() == want.keys()
+    for k in want:
+        assert got[k] == want[k], ("threads", k)
+    monkeypatch.delenv("CASIM_HOST_GRAIN")
+    shared = _encode_per_pod_records(w.nodes, w.pods, copies=False)
+    sh = _columns(shared)
+    for k in ("node_domain", "count_init", "domain_exists", "domain_nodes", "node_contrib", "elig", "rule_offset", "inc_rule", "alloc", "init_req",
+              "init_pods", "flags", "taint", "label"):
+        if k in want or k in sh:
+            assert sh.get(k) == want.get(k), ("shared records", k)
+    for enc in (one, four, shared):
+        enc.close()
