@@ -176,7 +176,10 @@ typedef struct casim_options {
                                      written out member by member again: results are identical, 10 000 dependent PEG steps become one.
                                      Not applied with fastpath, to batches of simulations, or when opts is NULL.  (PEG flag bit 0x40 is
                                      reserved for this and must be zero in casim_pegs.flags.) */
-    int32_t reserved[2];
+    int32_t no_front_kernel;      /* 1 = a call of <= 1024 groups runs feasibility, list offsets, lists and PEG order as the four separate launches
+                                     a batch uses instead of the one fused launch (csrc/casim_kernels.h front_kernel; testing / A-B).  Results
+                                     are identical.  (Took one of the two reserved words of ABI 6: zero keeps its meaning.) */
+    int32_t reserved[1];
 } casim_options;
 #define CASIM_PACK_BUILD_AUTO 0
 #define CASIM_PACK_BUILD_PLAIN 1
@@ -272,7 +275,8 @@ int32_t casim_pack_build_info(int32_t device, int32_t out[4]);
  * generic packer keeps node state in LDS (0 = HBM slab), [3] = 1 if the schedulable subsets are
  * derived on the device, [4] = parts the batch runs as on internal streams (1 = not cut), [5] = how many runs so far had to fork
  * from the context's stream (it held pending work: see casim_options.n_streams), [6] = streams the context parked because
- * they shared a hardware queue with a lane it already had (the runtime maps streams onto GPU_MAX_HW_QUEUES queues), [7] reserved (0). */
+ * they shared a hardware queue with a lane it already had (the runtime maps streams onto GPU_MAX_HW_QUEUES queues), [7] = 1 when feasibility,
+ * list offsets, lists and PEG order run as ONE launch (front_kernel: calls of <= 1024 groups; casim_options.no_front_kernel). */
 struct casim_cluster_estimate_result;
 int32_t casim_problem_info(casim_problem* p, int32_t info_out[8]);
 /* Replace the result of group `ng` of a batch that already ran (status becomes CASIM_NG_OK): how a group that the batch

@@ -33,6 +33,10 @@ CS_DEVICE void sync() { casim_emu::block_sync(); }
 CS_DEVICE void sched_fence() {}
 CS_DEVICE int32_t load_relaxed_i32(const int32_t* p) { return *p; }
 CS_DEVICE void atomic_add_i32(int32_t* p, int32_t v) { *p += v; }  // fibers of one block never run concurrently
+// a word one block publishes for the blocks behind it (front_kernel): the emulator runs the blocks of a launch one after the other in
+// ascending order, so a block only ever waits for words that are already there
+CS_DEVICE void publish_u64(uint64_t* p, uint64_t v) { *p = v; }
+CS_DEVICE uint64_t poll_u64(const uint64_t* p) { return *p; }
 CS_DEVICE void atomic_add_i64(int64_t* p, int64_t v) { *p += v; }
 CS_DEVICE void atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
 CS_DEVICE void lds_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
@@ -91,6 +95,10 @@ CS_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // device-scope relaxed load / add of a counter shared by the waves of a block (served by L2, never a stale L1 line)
 CS_DEVICE int32_t load_relaxed_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 CS_DEVICE void atomic_add_i32(int32_t* p, int32_t v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a word one block publishes for the blocks behind it (front_kernel): device-scope release / acquire — the eight XCDs have an L2 each,
+// a plain store would sit in the writer's
+CS_DEVICE void publish_u64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+CS_DEVICE uint64_t poll_u64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
 CS_DEVICE void atomic_add_i64(int64_t* p, int64_t v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 CS_DEVICE void atomic_or_u64(uint64_t* p, uint64_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // bits set by several threads of the block in one LDS word (ds_or_b64)

@@ -87,6 +87,7 @@ struct HipBackend {
         }
         return staging[which];
     }
+    void* stage_if_fits(int which, size_t bytes) { which &= 1; return staging_cap[which] >= bytes ? staging[which] : nullptr; }   // (never re-allocates)
     void h2d(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D"); }
     void d2h(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H"); }
     void zero(void* d, size_t n) { if (n) check(hipMemsetAsync(d, 0, n, stream), "hipMemsetAsync"); }
@@ -498,7 +499,13 @@ static bool wants_streams(casim_ctx* ctx, const casim_pegs* pegs, const casim_gr
     return lanes->size() >= 2;
 }
 
+static casim_problem* problem_create(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts, bool one_shot);
 casim_problem* casim_problem_create(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts) {
+    return problem_create(ctx, pegs, groups, opts, /*one_shot=*/false);
+}
+// one_shot: the caller runs, fetches and destroys the problem before the context sees anything else (casim_estimate_batch*): the
+// upload is not waited for on its own (ProblemT::init)
+static casim_problem* problem_create(casim_ctx* ctx, const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts, bool one_shot) {
     g_err.clear();
     if (!ctx) { set_err(CASIM_ERR_INVALID, "null context"); return nullptr; }
     ctx->bk.bind(); ctx->bk.clear();
@@ -517,6 +524,7 @@ casim_problem* casim_problem_create(casim_ctx* ctx, const casim_pegs* pegs, cons
     }
     p->prob = new (std::nothrow) HipProblem(ctx->bk);
     if (!p->prob) { delete p; set_err(CASIM_ERR_NOMEM, "out of memory"); return nullptr; }
+    p->prob->set_one_shot(one_shot);
     const int32_t rc = p->prob->init(pegs, groups, opts);
     if (rc != CASIM_OK) { set_err(rc, p->prob->error()); delete p->prob; delete p; return nullptr; }
     return p;
@@ -561,6 +569,7 @@ int32_t casim_problem_info(casim_problem* p, int32_t info_out[8]) {
     info_out[4] = p->sp ? (int32_t)p->sp->n_parts() : 1;
     info_out[5] = p->sp ? (int32_t)(p->sp->forks() & 0x7fffffff) : 0;   // forks from the context's stream so far (diagnostic)
     info_out[6] = p->ctx ? (int32_t)p->ctx->parked.size() : 0;
+    info_out[7] = p->prob->uses_front() ? 1 : 0;
     return CASIM_OK;
 }
 int32_t casim_problem_set_group_result(casim_problem* p, int32_t ng, const casim_cluster_estimate_result* r) {
@@ -594,7 +603,7 @@ int32_t casim_estimate_batch(casim_ctx* ctx, const casim_pegs* pegs, const casim
         std::vector<HipBackend*> lanes;
         if (wants_streams(ctx, pegs, groups, opts, &lanes)) return estimate_streamed(ctx, lanes, pegs, groups, opts, out, nullptr);
     }
-    casim_problem* p = casim_problem_create(ctx, pegs, groups, opts);
+    casim_problem* p = problem_create(ctx, pegs, groups, opts, /*one_shot=*/true);
     if (!p) return g_err.empty() ? CASIM_ERR_INVALID : (casim_device_count() > 0 ? CASIM_ERR_INVALID : CASIM_ERR_NO_DEVICE);
     int32_t rc = casim_problem_run(p);
     if (rc == CASIM_OK) rc = casim_problem_fetch(p, out);
@@ -622,11 +631,18 @@ int32_t casim_estimate_batch_query(casim_ctx* ctx, const casim_pegs* pegs, const
             return CASIM_OK;
         }
     }
-    casim_problem* p = casim_problem_create(ctx, pegs, groups, opts);
+    casim_problem* p = problem_create(ctx, pegs, groups, opts, /*one_shot=*/true);
     if (!p) return g_err.empty() ? CASIM_ERR_INVALID : (casim_device_count() > 0 ? CASIM_ERR_INVALID : CASIM_ERR_NO_DEVICE);
     int32_t rc = casim_problem_run(p);
-    if (rc == CASIM_OK && q) rc = casim_best_option_sims(p, q);
+    // one wait for the device serves the expander's answer, the results and the offsets: the query's copies stay in flight until the
+    // fetch has waited (a single simulation spent a third of its call in three separate round trips)
+    const bool one_wait = q && out && !p->sp && !(q->join_stream && (q->dev_key_out || q->dev_packed_out));
+    if (rc == CASIM_OK && q) {
+        if (one_wait) { rc = p->prob->best_option_query(q, /*defer_sync=*/true); if (rc != CASIM_OK) set_err(rc, p->prob->error()); }
+        else rc = casim_best_option_sims(p, q);
+    }
     if (rc == CASIM_OK && out) rc = casim_problem_fetch(p, out);
+    if (one_wait) { const int32_t rc2 = p->prob->best_option_finish(/*synced=*/rc == CASIM_OK); if (rc == CASIM_OK && rc2 != CASIM_OK) rc = set_err(rc2, p->prob->error()); }
     if (rc == CASIM_OK && offsets_out) rc = casim_problem_csr(p, nullptr, offsets_out);
     const std::string keep = g_err;
     casim_problem_destroy(p);

@@ -564,10 +564,7 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
 #endif
 }
 template <bool kLds>
-CS_GLOBAL void order_kernel(DevTables t, DevResults res, OrderScratch os) {
-    const int ng = cs::bid();
-    const int off = t.peg_off[ng];
-    const int Gn = t.peg_off[ng + 1] - off;
+CS_DEVICE void order_dispatch(const DevTables& t, const DevResults& res, const OrderScratch& os, const int ng, const int off, const int Gn) {
     if (kLds && cs::nthreads() == 64 && Gn <= 256) {   // one wave per group (batches of simulations): straight-line networks
         if (Gn <= 64) order_group<kLds, 64>(t, res, os, ng, off, Gn);
         else if (Gn <= 128) order_group<kLds, 128>(t, res, os, ng, off, Gn);
@@ -577,6 +574,77 @@ CS_GLOBAL void order_kernel(DevTables t, DevResults res, OrderScratch os) {
         // hangs on); the few longer lists of the launch sort in the HBM scratch slab
         order_group<false, 0>(t, res, os, ng, off, Gn);
     } else order_group<kLds, 0>(t, res, os, ng, off, Gn);
+}
+template <bool kLds>
+CS_GLOBAL void order_kernel(DevTables t, DevResults res, OrderScratch os) {
+    const int ng = cs::bid();
+    const int off = t.peg_off[ng];
+    order_dispatch<kLds>(t, res, os, ng, off, t.peg_off[ng + 1] - off);
+}
+
+// ------------------------------------------------------------------------------------------
+// K_front: feasibility row + list offsets + list + PEG order of ONE group per block, in ONE launch
+// ------------------------------------------------------------------------------------------
+// A single Estimate call (one simulation, tens of groups, hundreds of PEGs) is bound by the launches in its chain, not by work: feas,
+// scan, fill and order were four dependent launches of a few microseconds each.  Here block ng does all four for its group.  The one
+// thing a group needs from the others — the number of list entries in front of its own — travels through `ticket`: every block
+// publishes (epoch << 32 | count) with a device-scope release store as soon as its row is done, then waits for the words of the blocks
+// in front of it to carry this launch's epoch (the run counter of the problem: a second run on the same tables does not read the first's).  Workgroups of a launch are dispatched in ascending order, so everything a resident block waits for is resident
+// or finished (the assumption every single-pass chained scan makes); nobody waits for a block behind it.  `ticket` starts as zeros
+// (the host keeps it inside the upload slab), epochs start at 1.  The batch geometry keeps its separate kernels: tens of thousands of groups
+// would serialise on the tickets (a last-block scan inside feas_sim_kernel cost 1.05 -> 2.77 ms per step, profiles/r02s_packer_notes.txt).
+// LDS (dynamic, shared with order_group which takes it over afterwards): [Wg] ballot words, then [waves + 1] counters.
+template <bool kLds>
+CS_GLOBAL void front_kernel(DevTables t, DevResults res, OrderScratch os, uint64_t* CS_RESTRICT bits /*[NG][Wg]*/, int Wg,
+                            int32_t* offsets /*[NG + 1] == t.peg_off*/, int32_t* idx /*[nnz bound] == t.peg_idx*/,
+                            uint64_t* ticket /*[NG]*/, uint32_t epoch, int NG) {
+    const int ng = cs::bid(), tid = cs::tid(), lane = cs::lane(), wave = tid >> 6, nw = (cs::nthreads() + 63) >> 6;
+    const int lo = t.peg_lo[ng], hi = t.peg_hi[ng];
+    uint64_t* words = (uint64_t*)cs::dyn_smem();
+    uint32_t* cnt = (uint32_t*)(words + Wg);   // [nw] per-wave counts, [nw] the entries in front of this group
+    // 1. the row (feas_kernel): wave w takes words w, w + nw, ..
+    uint32_t mine = 0;
+    for (int w = wave; w < Wg; w += nw) {
+        const int k = w * 64 + lane;
+        bool ok = false;
+        if (lo + k < hi) ok = fits_fresh_node(t, lo + k, ng);
+        const uint64_t b = cs::ballot(ok);
+        if (lane == 0) { bits[(int64_t)ng * Wg + w] = b; words[w] = b; }
+        mine += (uint32_t)cs::popc64(b);
+    }
+    if (lane == 0) cnt[wave] = mine;
+    cs::sync();
+    uint32_t total = 0;
+    for (int w = 0; w < nw; ++w) total += cnt[w];
+    // 2. publish the count, 3. collect the counts in front (wave 0; a lane per predecessor)
+    if (wave == 0) {
+        if (lane == 0) cs::publish_u64(ticket + ng, ((uint64_t)epoch << 32) | total);
+        uint32_t before = 0;
+        for (int j = lane; j < ng; j += 64) {
+            uint64_t v;
+            do v = cs::poll_u64(ticket + j); while ((uint32_t)(v >> 32) != epoch);
+            before += (uint32_t)v;
+        }
+        before = cs::wave_sum_u32(before);
+        if (lane == 0) {
+            cnt[nw] = before;
+            offsets[ng] = (int32_t)before;
+            if (ng == NG - 1) offsets[NG] = (int32_t)(before + total);
+        }
+    }
+    cs::sync();
+    const int32_t base = (int32_t)cnt[nw];
+    // 4. the list (csr_fill_kernel): PEG ids ascending — a lane per bit, its place = set bits in the words in front + in the lanes below
+    for (int w = wave; w < Wg; w += nw) {
+        uint32_t front = 0;
+        for (int j = lane; j < w; j += 64) front += (uint32_t)cs::popc64(words[j]);
+        front = cs::wave_sum_u32(front);
+        const uint64_t b = words[w];
+        if ((b >> lane) & 1ull) idx[base + (int32_t)front + cs::mbcnt(b)] = lo + w * 64 + lane;
+    }
+    cs::sync();   // the list is read back by other waves of the block (and the LDS changes hands)
+    // 5. the order (order_kernel)
+    order_dispatch<kLds>(t, res, os, ng, base, (int)total);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -230,7 +230,8 @@ public:
             const size_t masks = (size_t)(dt_.Wt + dt_.Wl + 2 * dt_.Wx + 2 * dt_.Wz);
             size_t bound = G * (8 * (size_t)R + 8 + 8 * masks + 16 + 4 * (size_t)R) +
                            NG * (16 * (size_t)R + 24 + 8 * masks + 32 + 4 + 8 + 4 + 8 + 8 + 4 * (size_t)R) + 8 * (size_t)R +
-                           4 * ((size_t)(g->n_sims > 0 ? g->n_sims : 0) + 1) + 4 * (NG + 1) + 8 * (size_t)dt_.Wz + 64 * 64 + 4096;
+                           4 * ((size_t)(g->n_sims > 0 ? g->n_sims : 0) + 1) + 4 * (NG + 1) + 8 * (size_t)dt_.Wz + 64 * 64 + 4096 +
+                           (NG <= kFrontMaxGroups ? 8 * NG + 16 : 0);   // (front_kernel's tickets)
             if (g->peg_offsets && NG > 0 && g->peg_offsets[NG] > 0) bound += 4 * (size_t)g->peg_offsets[NG];
             begin_uploads(bound);
         }
@@ -256,6 +257,10 @@ public:
         {
             const size_t ng = NG > 0 ? NG : 1;
             res_bytes_ = 16 * ng + 24 * ng + 4 * (ng + 1);
+            // behind them the answer of ONE expander reduce (winner + count, packed key, key block, surviving set): a call that asks for
+            // both gets both with the same copy (best_option_query(q, defer_sync))
+            opt_off_ = (res_bytes_ + 7) & ~(size_t)7;
+            res_bytes_ = opt_off_ + 16 + 8 + 80 + ((ng + 7) & ~(size_t)7);
             res_slab_ = (char*)dalloc(res_bytes_);
             dr_.cpu_sum = (int64_t*)res_slab_; dr_.mem_sum = dr_.cpu_sum + ng;
             int32_t* i32 = (int32_t*)(dr_.mem_sum + ng);
@@ -327,6 +332,13 @@ public:
             d_off_local_ = (int32_t*)dalloc(sizeof(int32_t) * (NG + 1));
             d_idx_ = (int32_t*)dalloc(sizeof(int32_t) * (size_t)nnz_cap_);
             dt_.peg_off = d_off_; dt_.peg_idx = d_idx_;
+            // a single call's chain in one launch (front_kernel): a few hundred groups at most — the blocks wait for each other's counts
+            front_ = NG > 0 && NG <= kFrontMaxGroups && feas_len_ > 0 && Wg_ <= 512 && !(o && o->no_front_kernel) && !getenv("CASIM_NO_FRONT");
+            if (front_) {
+                const uint64_t* dev = nullptr;
+                uint64_t* h = up_reserve<uint64_t>(NG, &dev);
+                if (h) { memset(h, 0, 8 * NG); d_ticket_ = (uint64_t*)dev; } else front_ = false;
+            }
         }
 
         stage.mark("packer geometry");
@@ -510,14 +522,15 @@ public:
             dr_.s_count = (int32_t*)dalloc(4 * (size_t)nnz_cap_); dr_.s_flags = (uint32_t*)dalloc(4 * (size_t)nnz_cap_);
             dr_.s_req = (int64_t*)dalloc(8 * (size_t)nnz_cap_ * (size_t)R);
         }
-        d_opt_set_ = (uint8_t*)dalloc(NG);
-        d_opt_out_ = (int32_t*)dalloc(16);
-        d_opt_key_ = (int64_t*)dalloc(80);
-        d_opt_packed_ = (int64_t*)dalloc(8);
+        d_opt_out_ = (int32_t*)(res_slab_ + opt_off_); d_opt_packed_ = (int64_t*)(res_slab_ + opt_off_ + 16);
+        d_opt_key_ = (int64_t*)(res_slab_ + opt_off_ + 24); d_opt_set_ = (uint8_t*)(res_slab_ + opt_off_ + 104);
         opt_cap_ = 1;
         stage.mark("H2D copy + sync");
         end_uploads();
-        bk_.sync();  // the staging buffer belongs to the backend: the next problem of this context may reuse it after init()
+        // the staging buffer belongs to the backend: the next problem of this context may reuse it after init() — unless the caller
+        // runs and fetches THIS problem before anything else touches the context (one call = one problem: casim_estimate_batch); the
+        // copy then drains with the kernels behind it and a single call waits for the device once instead of twice
+        if (!one_shot_) bk_.sync();
         stage.mark("done");
         if (!bk_.ok()) return fail(CASIM_ERR_HIP, bk_.error());
         ready_ = true;
@@ -527,6 +540,17 @@ public:
     // ---- launch sequence ----------------------------------------------------------------
     int32_t run_feasibility() {
         if (!csr_on_device_ || NG_ == 0) return CASIM_OK;
+        front_ran_ = false;
+        if (front_) {
+            const int nw = (order_threads_ + 63) / 64;
+            const size_t own = 8 * (size_t)Wg_ + 4 * ((size_t)nw + 1) + 8;
+            const size_t smem = order_lds_ && order_smem_ > own ? order_smem_ : own;
+            ++front_epoch_;
+            if (order_lds_) bk_.launch(front_kernel<true>, NG_, 1, order_threads_, smem, dt_, dr_, os_, d_bits_, Wg_, d_off_, d_idx_, d_ticket_, front_epoch_, NG_);
+            else bk_.launch(front_kernel<false>, NG_, 1, order_threads_, smem, dt_, dr_, os_, d_bits_, Wg_, d_off_, d_idx_, d_ticket_, front_epoch_, NG_);
+            front_ran_ = true;
+            return CASIM_OK;
+        }
         if (feas_len_ > 0) {
             if (feas_by_sim_) bk_.launch(feas_sim_kernel, (feas_len_ + 255) / 256, n_sims_, 256, (size_t)128 * (size_t)max_sim_groups_, dt_, d_bits_, Wg_,
                                          fast_npt_ > 0 ? fs_.req32 : (const int32_t*)nullptr, fast_npt_ > 0 ? fs_.fresh32 : (const int32_t*)nullptr);
@@ -546,7 +570,7 @@ public:
         return CASIM_OK;
     }
     int32_t run_order() {
-        if (NG_ == 0) return CASIM_OK;
+        if (NG_ == 0 || front_ran_) return CASIM_OK;   // (front_kernel ordered the lists it made)
         if (getenv("CASIM_PACK_PROF_DUMP") && !os_.prof) { os_.prof = (int64_t*)dalloc(8 * 4 * (size_t)NG_); bk_.zero(os_.prof, 8 * 4 * (size_t)NG_); }
         if (order_lds_) bk_.launch(order_kernel<true>, NG_, 1, order_threads_, order_smem_, dt_, dr_, os_);
         else bk_.launch(order_kernel<false>, NG_, 1, order_threads_, (size_t)0, dt_, dr_, os_);
@@ -598,9 +622,12 @@ public:
         if (!ready_) return fail(CASIM_ERR_INVALID, "problem not initialised");
         if (csr_on_device_ && NG_ > 0) {
             if (!ran_) return fail(CASIM_ERR_INVALID, "run the problem first");
-            h_off_.resize((size_t)NG_ + 1);
-            bk_.d2h(h_off_.data(), d_off_, 4 * ((size_t)NG_ + 1));
-            bk_.sync();
+            if (!h_off_fresh_) {   // (fetch() brings the offsets along with the scalars: no second round trip behind it)
+                h_off_.resize((size_t)NG_ + 1);
+                bk_.d2h(h_off_.data(), d_off_, 4 * ((size_t)NG_ + 1));
+                bk_.sync();
+                h_off_fresh_ = true;
+            }
         }
         if (NG_ == 0) { if (nnz_out) *nnz_out = 0; if (offsets_out) offsets_out[0] = 0; return CASIM_OK; }   // an empty shard
         const std::vector<int32_t>* offs = &h_off_;
@@ -664,6 +691,7 @@ public:
         char* st = (char*)bk_.stage(1, res_bytes_ + (spec ? 8 * spec_n : 0) + 64);
         if (!st) return fail(CASIM_ERR_NOMEM, "no staging buffer");
         bk_.d2h(st, res_slab_, res_bytes_);
+        last_fetch_ = st;
         int32_t* st_order = (int32_t*)(st + ((res_bytes_ + 15) & ~(size_t)15));
         int32_t* st_placed = st_order + spec_n;
         if (spec && spec_n > 0) {
@@ -757,7 +785,7 @@ public:
     // The expander chain over the options of the last run: one reduce over every group, or (per_sim) one per simulation
     // of the batch — one workgroup each, every simulation's winner packed into ONE int64 so that a single
     // all-reduce(min) over [S] keys settles all of them across GPUs.
-    int32_t best_option_query(const casim_option_query* q) {
+    int32_t best_option_query(const casim_option_query* q, bool defer_sync = false) {
         if (!ready_ || !ran_) return fail(CASIM_ERR_INVALID, "run the problem first");
         if (!q) return fail(CASIM_ERR_INVALID, "null query");
         const int32_t n_kinds = q->n_kinds;
@@ -791,17 +819,67 @@ public:
         const int opt_threads = span > 1024 ? 1024 : (span > 64 ? 256 : 64);
         bk_.launch(option_kernel, S, 1, opt_threads, (size_t)(8 * opt_threads), a);
         if (q->best_out || q->n_best_out || q->best_set_out || q->key_out || q->packed_out) {
-            std::vector<int32_t> o(2 * (size_t)S);
-            bk_.d2h(o.data(), d_opt_out_, 8 * (size_t)S);
+            // deferred: the answers land in the (pinned) upload staging buffer — a copy into the caller's pageable arrays would wait for
+            // the stream by itself — and move to the caller's arrays once the fetch has waited; the upload that used the buffer is
+            // ahead of these copies on the same stream
+            const size_t b_out = 8 * (size_t)S, b_set = q->best_set_out ? ((size_t)NG_ + 7) & ~(size_t)7 : 0, b_key = q->key_out ? 80 * (size_t)S : 0,
+                         b_pk = q->packed_out ? 8 * (size_t)S : 0;
+            if (defer_sync && S == 1 && opt_cap_ == 1 && !q->dev_key_out && !q->dev_packed_out) {
+                // the one-simulation answer sits inside the results slab: the fetch that follows brings it along, no copy of its own
+                opt_pending_q_ = q; opt_pending_s_ = 1; opt_stage_ = nullptr; opt_in_slab_ = true;
+                return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
+            }
+            char* st = defer_sync ? (char*)bk_.stage_if_fits(0, b_out + b_set + b_key + b_pk) : nullptr;
+            if (st) {
+                bk_.d2h(st, d_opt_out_, b_out);
+                if (q->best_set_out) bk_.d2h(st + b_out, d_opt_set_, (size_t)NG_);
+                if (q->key_out) bk_.d2h(st + b_out + b_set, a.key_out, b_key);
+                if (q->packed_out) bk_.d2h(st + b_out + b_set + b_key, a.packed_out, b_pk);
+                opt_pending_q_ = q; opt_pending_s_ = S; opt_stage_ = st;
+                return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
+            }
+            opt_host_.resize(2 * (size_t)S);
+            bk_.d2h(opt_host_.data(), d_opt_out_, b_out);
             if (q->best_set_out) bk_.d2h(q->best_set_out, d_opt_set_, (size_t)NG_);
-            if (q->key_out) bk_.d2h(q->key_out, a.key_out, 80 * (size_t)S);
-            if (q->packed_out) bk_.d2h(q->packed_out, a.packed_out, 8 * (size_t)S);
+            if (q->key_out) bk_.d2h(q->key_out, a.key_out, b_key);
+            if (q->packed_out) bk_.d2h(q->packed_out, a.packed_out, b_pk);
             bk_.sync();
             for (int i = 0; i < S; ++i) {
-                if (q->best_out) q->best_out[i] = o[2 * (size_t)i];
-                if (q->n_best_out) q->n_best_out[i] = o[2 * (size_t)i + 1];
+                if (q->best_out) q->best_out[i] = opt_host_[2 * (size_t)i];
+                if (q->n_best_out) q->n_best_out[i] = opt_host_[2 * (size_t)i + 1];
             }
         }
+        return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
+    }
+    // the host side of a query whose copies were left in flight (best_option_query(q, defer_sync = true)); synced = the stream has been
+    // waited for since
+    int32_t best_option_finish(bool synced) {
+        const casim_option_query* q = opt_pending_q_;
+        if (!q) return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
+        if (opt_in_slab_) {
+            opt_in_slab_ = false; opt_pending_q_ = nullptr;
+            if (!synced || !last_fetch_) return fail(CASIM_ERR_INVALID, "expander answer deferred without a fetch");
+            const char* b = last_fetch_ + opt_off_;
+            const int32_t* o = (const int32_t*)b;
+            if (q->best_out) q->best_out[0] = o[0];
+            if (q->n_best_out) q->n_best_out[0] = o[1];
+            if (q->packed_out) memcpy(q->packed_out, b + 16, 8);
+            if (q->key_out) memcpy(q->key_out, b + 24, 80);
+            if (q->best_set_out) memcpy(q->best_set_out, b + 104, (size_t)NG_);
+            return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
+        }
+        if (!synced) bk_.sync();
+        const size_t S = (size_t)opt_pending_s_;
+        const size_t b_out = 8 * S, b_set = q->best_set_out ? ((size_t)NG_ + 7) & ~(size_t)7 : 0, b_key = q->key_out ? 80 * S : 0;
+        const int32_t* o = (const int32_t*)opt_stage_;
+        for (size_t i = 0; i < S; ++i) {
+            if (q->best_out) q->best_out[i] = o[2 * i];
+            if (q->n_best_out) q->n_best_out[i] = o[2 * i + 1];
+        }
+        if (q->best_set_out) memcpy(q->best_set_out, opt_stage_ + b_out, (size_t)NG_);
+        if (q->key_out) memcpy(q->key_out, opt_stage_ + b_out + b_set, b_key);
+        if (q->packed_out) memcpy(q->packed_out, opt_stage_ + b_out + b_set + b_key, 8 * S);
+        opt_pending_q_ = nullptr; opt_stage_ = nullptr;
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
     }
     int sims() const { return n_sims_; }
@@ -812,6 +890,8 @@ public:
     int groups() const { return NG_; }
     int pegs() const { return G_; }
     bool csr_on_device() const { return csr_on_device_; }
+    void set_one_shot(bool v) { one_shot_ = v; }   // before init(): see the end of init()
+    bool uses_front() const { return front_; }
     bool pack_in_lds() const { return pack_lds_; }
     int fast_npt() const { return fast_npt_; }
     int fast_lanes() const { return fast_npt_ > 0 ? fast_r_ : 0; }   // > 0: the register-resident packer handles this batch
@@ -881,6 +961,12 @@ private:
     uint8_t* d_opt_valid_ = nullptr; size_t opt_cap_ = 0;
     int n_sims_ = 0, max_sim_groups_ = 0, feas_len_ = 0;
     bool feas_by_sim_ = false;
+    bool one_shot_ = false;
+    std::vector<int32_t> opt_host_; const casim_option_query* opt_pending_q_ = nullptr; int opt_pending_s_ = 0; const char* opt_stage_ = nullptr;
+    bool opt_in_slab_ = false; size_t opt_off_ = 0; const char* last_fetch_ = nullptr;   // (the staged copy of the results slab of the last fetch())
+    bool front_ = false, front_ran_ = false;   // feas + offsets + lists + order in ONE launch (front_kernel)
+    uint64_t* d_ticket_ = nullptr; uint32_t front_epoch_ = 0;
+    static constexpr size_t kFrontMaxGroups = 1024;
     std::vector<int32_t> h_off_;
     bool h_off_fresh_ = false;
     char* up_dev_ = nullptr; char* up_host_ = nullptr; size_t up_cap_ = 0, up_used_ = 0;

@@ -414,10 +414,11 @@ class Problem:
     """casim_problem: a batch resident in HBM; run() enqueues feasibility -> order -> pack."""
 
     def __init__(self, ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, fastpath: bool = False, force_generic_packer: bool = False,
-                 node_pods: bool = False, n_streams: int = 0, pack_build: int = 0):
+                 node_pods: bool = False, n_streams: int = 0, pack_build: int = 0, no_front_kernel: bool = False):
         """n_streams > 1: a batch of simulations runs as up to n_streams sub-batches on internal HIP streams of the context
         (casim_options.n_streams); results are identical, info()["parts"] tells whether the batch was cut.
-        pack_build: _abi.PACK_BUILD_AUTO / _PLAIN / _OPTION (casim_options.pack_build)."""
+        pack_build: _abi.PACK_BUILD_AUTO / _PLAIN / _OPTION (casim_options.pack_build).
+        no_front_kernel: the four separate launches of a batch instead of the fused one (casim_options.no_front_kernel; info()["front_kernel"])."""
         self.ctx = ctx
         self.n_groups = groups.n_groups
         self.n_pegs = pegs.n_pegs
@@ -428,7 +429,7 @@ class Problem:
             self._node_pods_cap = int(sum((int(groups.max_nodes[i]) if groups.max_nodes[i] > 0 else (0 if groups.max_nodes[i] < 0 else total))
                                           for i in range(groups.n_groups))) + 64
         opts = _abi.Options(fastpath=int(fastpath), force_generic_packer=int(force_generic_packer), node_pods=int(bool(node_pods)),
-                            n_streams=int(n_streams), pack_build=int(pack_build))
+                            n_streams=int(n_streams), pack_build=int(pack_build), no_front_kernel=int(bool(no_front_kernel)))
         self._h = lib.casim_problem_create(ctx._h, C.byref(pegs), C.byref(groups), C.byref(opts))
         if not self._h:
             raise CasimError(_abi.ERR_INVALID, last_error())
@@ -451,7 +452,7 @@ class Problem:
         out = (C.c_int32 * 8)()
         check(lib.casim_problem_info(self._h, out), "casim_problem_info")
         return {"fast_packer_slots_per_lane": out[0], "fast_packer_lanes": out[1], "generic_state_in_lds": bool(out[2]),
-                "csr_on_device": bool(out[3]), "parts": int(out[4]), "forks": int(out[5]), "parked_streams": int(out[6])}
+                "csr_on_device": bool(out[3]), "parts": int(out[4]), "forks": int(out[5]), "parked_streams": int(out[6]), "front_kernel": bool(out[7])}
 
     def set_group_result(self, ng: int, r: dict):
         """casim_problem_set_group_result: a group estimated by Context.estimate_on_cluster joins the expander reduce."""

@@ -27,6 +27,7 @@ struct EmuBackend {
     void wait_mark(EmuBackend&) {}
     void make_wait(void*) {}
     std::vector<char> staging[2];
+    void* stage_if_fits(int which, size_t bytes) { return staging[which & 1].size() >= bytes ? staging[which & 1].data() : nullptr; }
     void* stage(int which, size_t bytes) { if (staging[which & 1].size() < bytes) staging[which & 1].resize(bytes); return staging[which & 1].data(); }
     size_t lds_budget() const { return lds; }
     bool ok() const { return true; }
@@ -47,6 +48,7 @@ thread_local std::string g_err;
 #define EMU_API __attribute__((visibility("default")))
 extern "C" {
 
+static int32_t g_last_front = 0;
 EMU_API const char* emu_last_error() { return g_err.c_str(); }
 
 // lds_budget_bytes <= 0 keeps the default (160 KiB); a tiny value forces the HBM-scratch variants.
@@ -64,6 +66,7 @@ EMU_API int32_t emu_estimate_batch(const casim_pegs* pegs, const casim_groups* g
     if (rc == CASIM_OK && n_kinds >= 0 && best_out)
         rc = p.best_option(kinds, n_kinds, group_id_base, &best_out[0], &best_out[1], best_set_out, key_out, nullptr);
     if (rc != CASIM_OK) g_err = p.error();
+    g_last_front = p.uses_front() ? 1 : 0;
     return rc;
 }
 
@@ -80,8 +83,11 @@ EMU_API int32_t emu_estimate_batch_query(const casim_pegs* pegs, const casim_gro
     if (rc == CASIM_OK && (nnz_out || offsets_out)) rc = p.csr(nnz_out, offsets_out);
     if (rc == CASIM_OK && q) rc = p.best_option_query(q);
     if (rc != CASIM_OK) g_err = p.error();
+    g_last_front = p.uses_front() ? 1 : 0;
     return rc;
 }
+// 1 when the last emu_estimate_batch_query ran feasibility / offsets / lists / order as ONE launch (front_kernel)
+EMU_API int32_t emu_last_front() { return g_last_front; }
 
 // The batch cut into sub-batches on the lanes of one context (casim_streams.h; the emulator runs the parts one after the other):
 // how casim_options.n_streams cuts the tables and puts the results back together.  parts_out: how many parts ran (1 = not cut).

@@ -92,7 +92,7 @@ def emu_lib():
     return _emu
 
 
-def run_emu(enc: Encoder, fastpath=False, lds_budget=0, kinds=None, group_id_base=0, generic=False):
+def run_emu(enc: Encoder, fastpath=False, lds_budget=0, kinds=None, group_id_base=0, generic=False, front=True):
     """Product kernels under the wave emulator.  Returns (BatchResult, best) where best is
     None or (best_index, n_best, best_set, key)."""
     L = emu_lib()
@@ -100,7 +100,7 @@ def run_emu(enc: Encoder, fastpath=False, lds_budget=0, kinds=None, group_id_bas
     ng, G = groups.n_groups, pegs.n_pegs
     nnz_cap = G * ng if not groups.peg_offsets else groups.peg_offsets[ng]
     st, arrs = alloc_results(ng, nnz_cap)
-    opts = _abi.Options(fastpath=int(fastpath), force_generic_packer=int(generic))
+    opts = _abi.Options(fastpath=int(fastpath), force_generic_packer=int(generic), no_front_kernel=int(not front))
     nnz = C.c_int32(0)
     off = np.zeros(ng + 1, np.int32)
     best = (C.c_int32 * 2)(-1, 0)
@@ -434,7 +434,7 @@ def encode_batch(scenarios: Sequence[Scenario]):
     return enc, ts, bases
 
 
-def run_emu_tables(ts, kinds=None, per_sim=True, valid=None, fastpath=False, lds_budget=0, node_pods_capacity=0, generic=False):
+def run_emu_tables(ts, kinds=None, per_sim=True, valid=None, fastpath=False, lds_budget=0, node_pods_capacity=0, generic=False, front=True):
     """Product kernels under the wave emulator on a TableSet.  Returns (BatchResult, expander dict or None)."""
     L = emu_lib()
     if not hasattr(L, "_query_bound"):
@@ -451,7 +451,7 @@ def run_emu_tables(ts, kinds=None, per_sim=True, valid=None, fastpath=False, lds
     else:
         nnz_cap = pegs.n_pegs * ng
     st, arrs = alloc_results(ng, nnz_cap, node_pods_capacity)
-    opts = _abi.Options(fastpath=int(fastpath), node_pods=int(node_pods_capacity > 0), force_generic_packer=int(generic))
+    opts = _abi.Options(fastpath=int(fastpath), node_pods=int(node_pods_capacity > 0), force_generic_packer=int(generic), no_front_kernel=int(not front))
     nnz = C.c_int32(0)
     off = np.zeros(ng + 1, np.int32)
     q = exp = None

@@ -268,3 +268,91 @@ def test_pod_affinity_towards_partners_of_the_batch_on_the_device(ctx):
             checked += 1; with_need += 1 if need else 0
         enc.close()
     assert checked > 200 and with_need > 40
+
+
+def test_front_kernel_equals_the_separate_launches_and_the_oracle(ctx):
+    """A call of <= 1024 groups runs feasibility, list offsets, lists and PEG order as ONE launch (front_kernel: the blocks hand each
+    other their counts through device-scope release / acquire words — across XCDs on the real chip).  Same bits as the four
+    separate launches (casim_options.no_front_kernel) and as the oracle: feature-mix fuzz, long rows, 200 groups with empty rows,
+    three runs of one resident problem (the epoch of the tickets), the baseline configs C0-C2."""
+    from kubernetes_autoscaler_amd.engine import Problem
+    from kubernetes_autoscaler_amd.objects import NodeInfo, Pod, PodEquivalenceGroup
+    from kubernetes_autoscaler_amd.workloads import _node, SplitMix64
+
+    def both(sc, fastpath=False, generic=False, runs=1):
+        enc = encode(sc)
+        out = []
+        for no_front in (False, True):
+            with Problem(ctx, enc.pegs, enc.groups, fastpath, generic, no_front_kernel=no_front) as p:
+                assert p.info()["front_kernel"] == (not no_front)
+                for _ in range(runs):
+                    p.run()
+                out.append(p.fetch())
+        _same(out[0], out[1], "front vs separate")
+        enc.close()
+        return out[0]
+
+    def scenario(w, fastpath=False):
+        return Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups],
+                        existing=w.existing, lanes=w.lanes, fastpath=fastpath, device_csr=True)
+
+    for seed in range(60):
+        fast = seed % 3 == 1
+        sc = scenario(workloads.fuzz(3000 + seed), fastpath=fast)
+        assert_matches_oracle(both(sc, fastpath=fast, generic=seed % 3 == 2, runs=1 + 2 * (seed % 5 == 0)), run_oracle(sc), f"fuzz {seed}")
+    for seed in range(12):
+        sc = scenario(workloads.fuzz(7000 + seed, max_groups=3, max_pegs=260, rich=seed % 2 == 0))
+        assert_matches_oracle(both(sc), run_oracle(sc), f"long rows {seed}")
+    rng = SplitMix64(0xF207)
+    pegs = [PodEquivalenceGroup(pods=[Pod(name=f"p{i}", requests={"cpu": 100 * (1 + rng.below(8)), "memory": (128 << 20) * (1 + rng.below(6))},
+                                          node_selector=({"pool": f"p{rng.below(5)}"} if rng.chance(2, 3) else {}))] * (1 + rng.below(5))) for i in range(150)]
+    groups = [GroupSpec(NodeInfo(_node(f"g{k}", 50 if k % 9 == 4 else 1000 * (1 + rng.below(8)), (1 + rng.below(16)) << 30, 30,
+                                       {"pool": f"p{rng.below(7)}"} if rng.chance(3, 4) else {})), max_nodes=rng.pick([0, 2, 5, 20]), last_index=0, pegs=None)
+              for k in range(200)]
+    sc = Scenario(pegs=pegs, groups=groups, device_csr=True)
+    assert_matches_oracle(both(sc, runs=3), run_oracle(sc), "200 groups")
+    for cfg in (workloads.config_c0, workloads.config_c1, workloads.config_c2):
+        w = cfg()
+        sc = scenario(w)
+        assert_matches_oracle(both(sc), run_oracle(sc), w.name)
+
+
+def test_one_call_with_expander_waits_for_the_device_once(ctx):
+    """casim_estimate_batch_query on a single simulation: the upload is not waited for on its own, the expander's answer travels inside
+    the results slab and the offsets come with the fetch — ONE wait per call.  Winner, survivor set, key block, packed key, results and
+    offsets equal the resident problem's (casim_problem_* with a wait per step) and the oracle's, call after call on one context."""
+    import ctypes as C
+    from kubernetes_autoscaler_amd.engine import Problem, alloc_results, finish_results, _ptr
+    from kubernetes_autoscaler_amd._ffi import lib
+
+    def scenario(w):
+        return Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups],
+                        existing=w.existing, lanes=w.lanes, device_csr=True)
+
+    chains = ([_abi.EXPANDER_LEAST_NODES], [_abi.EXPANDER_MOST_PODS, _abi.EXPANDER_LEAST_NODES], [_abi.EXPANDER_LEAST_NODES, _abi.EXPANDER_MOST_PODS])
+    for seed in range(45):
+        w = workloads.fuzz(3000 + seed) if seed % 3 else workloads.fuzz(5000 + seed, max_groups=4, max_pegs=48)
+        sc = scenario(w)
+        enc = encode(sc)
+        kinds = chains[seed % 3]
+        with Problem(ctx, enc.pegs, enc.groups) as p:
+            p.run()
+            want = p.fetch()
+            wb = p.best_option_sims(kinds, per_sim=False)
+        ng = enc.groups.n_groups
+        st, arrs = alloc_results(ng, ng * enc.pegs.n_pegs)
+        off = np.zeros(ng + 1, np.int32)
+        ks = (C.c_int32 * len(kinds))(*kinds)
+        got = dict(best=np.full(1, -1, np.int32), n_best=np.zeros(1, np.int32), best_set=np.full(max(ng, 1), 7, np.uint8), keys=np.zeros((1, 10), np.int64),
+                   packed=np.zeros(1, np.int64))
+        q = _abi.OptionQuery(kinds=ks, n_kinds=len(kinds), best_out=_ptr(got["best"], C.c_int32), n_best_out=_ptr(got["n_best"], C.c_int32),
+                             best_set_out=_ptr(got["best_set"], C.c_uint8), key_out=_ptr(got["keys"], C.c_int64), packed_out=_ptr(got["packed"], C.c_int64))
+        opts = _abi.Options()
+        for rep in range(2):   # (the second call reuses the pooled blocks and staging of the first)
+            assert lib.casim_estimate_batch_query(ctx._h, C.byref(enc.pegs), C.byref(enc.groups), C.byref(opts), C.byref(st), _ptr(off, C.c_int32), C.byref(q)) == 0
+            res = finish_results(arrs, ng, int(off[ng]), off.copy())
+            _same(res, want, f"seed {seed} call {rep}")
+            assert int(got["best"][0]) == int(wb["best"][0]) and int(got["n_best"][0]) == int(wb["n_best"][0]), seed
+            assert np.array_equal(got["best_set"][:ng], wb["best_set"][:ng]) and np.array_equal(got["keys"], wb["keys"]) and np.array_equal(got["packed"], wb["packed"]), seed
+        assert_matches_oracle(res, run_oracle(sc), f"seed {seed}")
+        enc.close()
