@@ -63,24 +63,22 @@ int32_t casim_prefetch_fill(casim_prefetch* p, const casim_pegs* pegs, const cas
     p->by_group.clear();
     const int NG = groups->n_groups, G = pegs->n_pegs;
     if (NG <= 0) return CASIM_OK;
-    casim_problem* prob = casim_problem_create(p->ctx, pegs, groups, opts);
-    if (!prob) { p->err = casim_last_error(); return casim_device_count() > 0 ? CASIM_ERR_INVALID : CASIM_ERR_NO_DEVICE; }
-    int32_t rc = casim_problem_run(prob);
-    int32_t nnz = 0;
+    // one call, one wait for the device (casim_estimate_batch_query keeps the upload, the kernels, the results and the offsets on one
+    // round trip): the arrays are sized for the bound of the lists — explicit offsets, the candidate ranges, or every PEG for every group
+    int64_t cap = 0;
+    if (groups->peg_offsets) cap = groups->peg_offsets[NG];
+    else if (groups->peg_lo && groups->peg_hi) for (int i = 0; i < NG; ++i) cap += (int64_t)groups->peg_hi[i] - groups->peg_lo[i];
+    else cap = (int64_t)NG * G;
+    if (cap < 0 || cap > 0x7fffffffll) { p->err = "PEG lists too long"; return CASIM_ERR_INVALID; }
     std::vector<int32_t> off((size_t)NG + 1, 0);
-    if (rc == CASIM_OK) rc = casim_problem_csr(prob, &nnz, off.data());
-    std::vector<int32_t> a((size_t)NG * 6), order((size_t)nnz + 1), placed((size_t)nnz + 1);
+    std::vector<int32_t> a((size_t)NG * 6), order((size_t)cap + 1), placed((size_t)cap + 1);
     std::vector<int64_t> sums((size_t)NG * 2);
-    if (rc == CASIM_OK) {
-        casim_results r; memset(&r, 0, sizeof r);
-        r.node_count = a.data(); r.pods_scheduled = a.data() + NG; r.nodes_added = a.data() + 2 * (size_t)NG; r.limiter_nodes = a.data() + 3 * (size_t)NG;
-        r.last_index_out = a.data() + 4 * (size_t)NG; r.status = a.data() + 5 * (size_t)NG; r.req_cpu_sum = sums.data(); r.req_mem_sum = sums.data() + NG;
-        r.order = order.data(); r.placed = placed.data();
-        rc = casim_problem_fetch(prob, &r);
-    }
-    if (rc != CASIM_OK) p->err = casim_last_error();
-    casim_problem_destroy(prob);
-    if (rc != CASIM_OK) return rc;
+    casim_results r; memset(&r, 0, sizeof r);
+    r.node_count = a.data(); r.pods_scheduled = a.data() + NG; r.nodes_added = a.data() + 2 * (size_t)NG; r.limiter_nodes = a.data() + 3 * (size_t)NG;
+    r.last_index_out = a.data() + 4 * (size_t)NG; r.status = a.data() + 5 * (size_t)NG; r.req_cpu_sum = sums.data(); r.req_mem_sum = sums.data() + NG;
+    r.order = order.data(); r.placed = placed.data();
+    const int32_t rc = casim_estimate_batch_query(p->ctx, pegs, groups, opts, &r, off.data(), nullptr);
+    if (rc != CASIM_OK) { p->err = casim_last_error(); return rc == CASIM_ERR_NO_DEVICE || casim_device_count() > 0 ? rc : CASIM_ERR_NO_DEVICE; }
     std::vector<int32_t> ids, pos((size_t)G, -1);
     for (int i = 0; i < NG; ++i) {
         Entry e;
