@@ -820,6 +820,24 @@ public:
         memset(&dt_, 0, sizeof dt_); memset(&a_, 0, sizeof a_);
         dt_.G = C_; dt_.NG = N_; dt_.R = p->n_res; dt_.Wt = p->w_taint; dt_.Wl = p->w_label; dt_.Wx = p->w_excl; dt_.Wz = 0;
         const int R = dt_.R;
+        // ---- ONE host-to-device copy for everything this call uploads (class / node tables unless resident, run tables, candidate and
+        // pod columns, domain rules): the columns are packed into the backend's pinned staging buffer and land in one device slab, as
+        // ProblemT does it — three dozen separate copies out of pageable memory were 0.2-0.3 ms of a 2.5 ms TrySchedulePods call
+        // (profiles/r07e_bench.json: call 2.50 ms, kernels 2.21).  A column that does not fit the bound falls back on its own copy.
+        {
+            const size_t masks = (size_t)(dt_.Wt + dt_.Wl + dt_.Wx);
+            size_t bound = 64 * 64 + 4096;
+            if (!resident_) bound += C * (8 * (size_t)R + 8 + 8 * (masks + (size_t)dt_.Wx)) + N * (16 * (size_t)R + 16 + 8 * masks);
+            bound += 4 * (rc.size() + rn.size() + rh.size() + rf.size() + rp.size() + rk.size() + cro.size()) + N;
+            if (cand) bound += 16 * ((size_t)K_ + 1) + 8 * P;
+            if (q->rules && q->rules->n_rules > 0 && q->rules->rule_offset) {
+                const casim_domain_rules* r0 = q->rules;
+                const size_t NR = (size_t)r0->n_rules, tot = (size_t)r0->rule_offset[NR];
+                bound += 4 * (size_t)r0->n_keys * N + 64 * (NR + 1) + 8 * tot + (cand ? 4 * NR * N : 0) + 8 * (size_t)r0->n_elig_rows * ((N + 1023) / 64 + 16) +
+                         8 * (C + 1) + 4 * (size_t)(r0->inc_off ? r0->inc_off[C] : 0);
+            }
+            begin_uploads(bound);
+        }
         if (resident_) {   // a resident cluster (ClusterT below): the tables are in HBM already, nothing to upload
             dt_.req = resident_->req; dt_.pflags = resident_->pflags; dt_.tol = resident_->tol; dt_.sel = resident_->sel;
             dt_.xblock = resident_->xblock; dt_.xmark = resident_->xmark; dt_.alloc = resident_->alloc; dt_.init_req = resident_->init_req;
@@ -908,7 +926,7 @@ public:
                 std::vector<uint64_t> rows((size_t)dr->n_elig_rows * (size_t)S_, 0ull);
                 for (int r = 0; r < dr->n_elig_rows; ++r) for (size_t w = 0; w < w_in; ++w) rows[(size_t)r * (size_t)S_ + w] = dr->elig_bits[(size_t)r * w_in + w];
                 a_.rule_elig = up(rows.data(), rows.size());
-                bk_.sync();
+                if (direct_uploads_ > 0) bk_.sync();   // (`rows` is a local; a packed upload has copied it already)
             }
             a_.class_rule_off = up(dr->class_rule_off, C + 1); a_.inc_off = up(dr->inc_off, C + 1);
             a_.inc_rule = up(dr->inc_rule, (size_t)dr->inc_off[C]);
@@ -918,7 +936,10 @@ public:
         lds_ = ctrl + bytes <= (int64_t)bk_.lds_budget();
         smem_ = (size_t)(lds_ ? ctrl + bytes : ctrl);
         if (!lds_) a_.gstate = (char*)dalloc((size_t)bytes);
-        bk_.sync();  // the run tables above are locals: the uploads must have left them
+        end_uploads();
+        // the run tables above are locals: uploads that went out on their own must have left them.  Packed ones were copied into the
+        // staging buffer when up() returned; nothing else uses that buffer before this call's results have been waited for
+        if (direct_uploads_ > 0) bk_.sync();
         if (!bk_.ok()) return fail(CASIM_ERR_HIP, bk_.error());
         ready_ = true;
         return CASIM_OK;
@@ -961,10 +982,17 @@ public:
             if (n_scheduled_out) *n_scheduled_out = 0;
             return CASIM_OK;
         }
-        int32_t o[4] = {0, 0, 0, 0};
-        if (node_out) bk_.d2h(node_out, a_.node_out, 4 * (size_t)P_);
+        // through the pinned fetch staging buffer: a copy into the caller's pageable array waits for the stream by itself and moves at a
+        // fraction of the link's rate
+        const size_t nb = node_out ? 4 * (size_t)P_ : 0;
+        char* st = (char*)bk_.stage(1, 64 + nb);
+        int32_t o4[4] = {0, 0, 0, 0};
+        int32_t* o = st ? (int32_t*)st : o4;
+        if (st) { if (nb) bk_.d2h(st + 64, a_.node_out, nb); }
+        else if (nb) bk_.d2h(node_out, a_.node_out, nb);
         bk_.d2h(o, a_.out, 16);
         bk_.sync();
+        if (st && nb) memcpy(node_out, st + 64, nb);
         if (last_index_out) *last_index_out = o[0];
         if (n_scheduled_out) *n_scheduled_out = o[1];
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
@@ -979,17 +1007,30 @@ public:
             for (int i = 0; i < P_; ++i) if (out->node_out) out->node_out[i] = -1;
             return CASIM_OK;
         }
-        int32_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // everything in ONE round trip through the pinned fetch staging buffer (the ext tables up to their capacity: how many entries
+        // are valid comes with the same copies)
+        const size_t nb = out->node_out && P_ > 0 ? 4 * (size_t)P_ : 0, rb = out->removable && K_ > 0 ? ((size_t)K_ + 15) & ~(size_t)15 : 0;
+        const size_t eb = 4 * (size_t)E_;
+        char* st = (char*)bk_.stage(1, 64 + nb + rb + 3 * eb + 64);
+        if (!st) return fail(CASIM_ERR_NOMEM, "no staging buffer");
+        int32_t* o = (int32_t*)st;
+        char* s_node = st + 64; char* s_rem = s_node + nb; char* s_ec = s_rem + rb; char* s_ep = s_ec + eb; char* s_en = s_ep + eb;
         bk_.d2h(o, a_.out, 32);
-        if (out->node_out && P_ > 0) bk_.d2h(out->node_out, a_.node_out, 4 * (size_t)P_);
-        if (out->removable && K_ > 0) bk_.d2h(out->removable, a_.removable_out, (size_t)K_);
+        if (nb) bk_.d2h(s_node, a_.node_out, nb);
+        if (rb) bk_.d2h(s_rem, a_.removable_out, (size_t)K_);
+        if (E_ > 0) {
+            if (out->ext_candidate) bk_.d2h(s_ec, a_.ext_cand, eb);
+            if (out->ext_pod) bk_.d2h(s_ep, a_.ext_ref, eb);
+            if (out->ext_node) bk_.d2h(s_en, a_.node_out + P_, eb);
+        }
         bk_.sync();
+        if (nb) memcpy(out->node_out, s_node, nb);
+        if (rb) memcpy(out->removable, s_rem, (size_t)K_);
         const int ne = o[4] < E_ ? o[4] : E_;
         if (ne > 0) {
-            if (out->ext_candidate) bk_.d2h(out->ext_candidate, a_.ext_cand, 4 * (size_t)ne);
-            if (out->ext_pod) bk_.d2h(out->ext_pod, a_.ext_ref, 4 * (size_t)ne);
-            if (out->ext_node) bk_.d2h(out->ext_node, a_.node_out + P_, 4 * (size_t)ne);
-            bk_.sync();
+            if (out->ext_candidate) memcpy(out->ext_candidate, s_ec, 4 * (size_t)ne);
+            if (out->ext_pod) memcpy(out->ext_pod, s_ep, 4 * (size_t)ne);
+            if (out->ext_node) memcpy(out->ext_node, s_en, 4 * (size_t)ne);
         }
         out->n_ext = ne; out->last_index = o[0]; out->n_processed = o[3];
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
@@ -1012,11 +1053,26 @@ public:
 
 private:
     static int64_t round_up64_(int64_t v) { return (v + 63) & ~63ll; }
+    void begin_uploads(size_t bound) {
+        up_host_ = (char*)bk_.stage(0, bound);
+        up_dev_ = up_host_ ? (char*)dalloc(bound) : nullptr;
+        up_cap_ = up_dev_ ? bound : 0; up_used_ = 0; direct_uploads_ = 0;
+    }
+    void end_uploads() {
+        if (up_dev_ && up_used_ > 0) bk_.h2d(up_dev_, up_host_, up_used_);
+        up_dev_ = up_host_ = nullptr; up_cap_ = 0;
+    }
     template <class T>
     const T* up(const T* src, size_t n) {
         if (n == 0 || !src) return nullptr;
-        T* d = (T*)dalloc(sizeof(T) * n);
-        if (d) bk_.h2d(d, src, sizeof(T) * n);
+        const size_t bytes = sizeof(T) * n, at = (up_used_ + 15) & ~(size_t)15;
+        if (up_dev_ && at + bytes <= up_cap_) {
+            memcpy(up_host_ + at, src, bytes);
+            up_used_ = at + bytes;
+            return (const T*)(up_dev_ + at);
+        }
+        T* d = (T*)dalloc(bytes);   // outside a packed section (or a bound that was too small): its own copy
+        if (d) { bk_.h2d(d, src, bytes); ++direct_uploads_; }
         return d;
     }
     void* dalloc(size_t bytes) {
@@ -1028,6 +1084,7 @@ private:
     int32_t fail(int32_t code, const char* msg) { err_ = msg ? msg : ""; return code; }
 
     BK& bk_;
+    char* up_host_ = nullptr; char* up_dev_ = nullptr; size_t up_cap_ = 0, up_used_ = 0; int direct_uploads_ = 0;   // packed uploads (begin_uploads / up / end_uploads)
     DevTables dt_; SchedArgs a_;
     const DevTables* resident_ = nullptr;
     int C_ = 0, N_ = 0, P_ = 0, S_ = 0, K_ = 0, E_ = 0, threads_ = 64;
