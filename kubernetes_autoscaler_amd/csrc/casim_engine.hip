@@ -690,7 +690,7 @@ int32_t casim_feasibility(casim_ctx* ctx, const casim_pegs* pegs, const casim_gr
     if (!ctx || !groups || !out_bits) return set_err(CASIM_ERR_INVALID, "null argument");
     casim_groups g = *groups;
     g.peg_offsets = nullptr; g.peg_index = nullptr;
-    casim_problem* p = casim_problem_create(ctx, pegs, &g, nullptr);
+    casim_problem* p = problem_create(ctx, pegs, &g, nullptr, /*one_shot=*/true);
     if (!p) return CASIM_ERR_INVALID;
     int32_t rc = p->prob->run_feasibility();
     if (rc == CASIM_OK) rc = p->prob->fetch_bits(out_bits);
@@ -707,7 +707,7 @@ int32_t casim_feasibility_reasons(casim_ctx* ctx, const casim_pegs* pegs, const 
     if (!ctx || !groups || !out_codes) return set_err(CASIM_ERR_INVALID, "null argument");
     casim_groups g = *groups;
     g.peg_offsets = nullptr; g.peg_index = nullptr;
-    casim_problem* p = casim_problem_create(ctx, pegs, &g, nullptr);
+    casim_problem* p = problem_create(ctx, pegs, &g, nullptr, /*one_shot=*/true);
     if (!p) return CASIM_ERR_INVALID;
     const int32_t rc = p->prob->reasons(port_block, out_codes);
     if (rc != CASIM_OK) set_err(rc, p->prob->error());
