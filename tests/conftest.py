@@ -9,8 +9,35 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _cpu_tier_in_parallel(config):
+    """`python -m pytest tests -m "not gpu"` (the CPU tier: ~9 000 oracle / emulator / host-logic cases, 25 minutes on one core) restarts
+    itself under pytest-xdist with up to 8 workers when nobody chose a worker count: ~3.5 minutes.  Only that invocation: the GPU tier
+    must stay one process (its tests time kernels and probe hardware queues).  CASIM_PYTEST_SERIAL=1 keeps the plain run."""
+    if os.environ.get("CASIM_PYTEST_SERIAL") or os.environ.get("_CASIM_PYTEST_REEXEC") or hasattr(config, "workerinput"):
+        return
+    opt = config.option
+    if getattr(opt, "numprocesses", None) or (getattr(opt, "markexpr", "") or "").strip() != "not gpu":
+        return
+    if getattr(opt, "collectonly", False) or getattr(opt, "usepdb", False) or len(config.invocation_params.args) == 0:
+        return
+    try:
+        import xdist  # noqa: F401
+    except ImportError:
+        return
+    n = min(8, os.cpu_count() or 1)
+    if n < 2:
+        return
+    capman = config.pluginmanager.getplugin("capturemanager")
+    if capman is not None:
+        capman.stop_global_capturing()   # (fd-level capture has replaced stdout / stderr: give them back before the new image starts)
+    os.environ["_CASIM_PYTEST_REEXEC"] = "1"
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, [sys.executable, "-m", "pytest", *[str(a) for a in config.invocation_params.args], "-n", str(n)])
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _cpu_tier_in_parallel(config)
     # test modules import kubernetes_autoscaler_amd (which refuses to load without libcasim.so) while they are collected:
     # a fresh checkout has no built artefacts (*.so is git-ignored), so build before collection.  One process at a time
     # (pytest-xdist configures every worker).
