@@ -10,7 +10,7 @@
 //   K_sched_static  grid (ceil(N/64), C): one wave = 64 nodes x one pod class; the state-independent
 //                   Filters (TaintToleration, NodeAffinity / nodeSelector, NodeUnschedulable) as one
 //                   ballot word per (class, 64 nodes).  Fully parallel, streams the mask tables once.
-//   K_sched         ONE workgroup of T = 64..1024 threads (the pass is one sequential process); node m is owned by
+//   K_sched         ONE workgroup of T = 64..512 threads (the pass is one sequential process); node m is owned by
 //                   thread m % T, chunk m / T, its state (free resources, free pod slots, node-local exclusion
 //                   bits) lives in LDS, or in an HBM slab when the cluster outgrows 160 KB.  The host folds
 //                   consecutive pods of one class without hints into a run (class, k).  A run walks the nodes in
@@ -168,13 +168,15 @@ inline int64_t casim_sched_state_bytes(int R, int Wx, int64_t cap) {
     return cap * (8ll * R + 8ll * Wx + 12ll) + 2ll * 8ll * (cap / 64);
 }
 
-// One workgroup of T = 64..1024 threads; node m is owned by thread (m % T), chunk (m / T).
+// One workgroup of T = 64..512 threads; node m is owned by thread (m % T), chunk (m / T).
 // kTxn (removal transactions) and kRules (domain rules) are compile-time: the plain TrySchedulePods instantiation
 // does not carry their ~40 pointers — as one kernel, the uniform state overflowed the SGPR file and the hot loop
 // was dominated by v_writelane / v_readlane spill traffic (r01l ISA: 1800 of them).
 // RMAX_ = 2 for the common cpu + memory batch, else CASIM_KMAX_RES (see MemStore).
 template <bool kLds, bool kTxn, bool kRules, int RMAX_>
-CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void sched_kernel(DevTables t, SchedArgs a) {
+// (launch bound 512: two waves per SIMD at most, so a wave may hold 256 vector registers — the instantiations with up to 8 resource
+// lanes needed 128 + 40-52 spilled ones and ran with 80-132 bytes of scratch per lane under a bound of 1024, which no sweep ever favoured)
+CS_GLOBAL CS_LAUNCH_BOUNDS(512, 1) void sched_kernel(DevTables t, SchedArgs a) {
     const int32_t n_rules = kRules ? a.n_rules : 0;
     using Store = MemStore<kLds, RMAX_>;
     const int tid = cs::tid(), lane = cs::lane(), wave = tid >> 6;
@@ -853,11 +855,11 @@ public:
         dt_.init_excl = up(g->init_excl, N * dt_.Wx);
         }
 
-        // one workgroup: 64..1024 threads, node m -> thread m % T, chunk m / T
+        // one workgroup: 64..512 threads, node m -> thread m % T, chunk m / T
         // (r01w sweep: TrySchedulePods on 5000+ nodes is ~7 % faster with 512 threads — 2.31 vs 2.48 ms, 8.9 vs 9.5 ms —, the
         // removal loop does not care)
         int max_threads = cand ? kDefaultThreadsRemovals : (N_ >= 4096 ? 2 * kDefaultThreads : kDefaultThreads);
-        if (const char* e = getenv("CASIM_SCHED_THREADS")) { const int v = atoi(e); if (v >= 64 && v <= 1024) max_threads = v / 64 * 64; }
+        if (const char* e = getenv("CASIM_SCHED_THREADS")) { const int v = atoi(e); if (v >= 64) max_threads = (v > 512 ? 512 : v) / 64 * 64; }   // (the kernel's launch bound)
         threads_ = (int)(round_up64_((int64_t)N_) < max_threads ? round_up64_((int64_t)N_) : max_threads);
         cap_ = (int32_t)(((int64_t)N_ + threads_ - 1) / threads_ * threads_);
         S_ = cap_ >> 6;

@@ -380,3 +380,25 @@ def test_fuzz_namespace_selectors(ctx):
         with namespaces(table):
             case = removal_case_of(w)
             assert_removal_matches(removal_device(case, ctx), removal_oracle(case), w.name)
+
+
+def test_extended_resource_lanes_on_the_device(ctx):
+    """More than two resource lanes select the `<.., 8>` instantiations of sched_kernel (148-160 vector registers, no scratch since the
+    launch bound of 512): TrySchedulePods with and without domain rules and the removal loop, 4 and 8 lanes, against the oracle."""
+    from harness import RemovalCase, assert_removal_matches, removal_device, removal_oracle
+    from kubernetes_autoscaler_amd.workloads import fuzz_pending_domains, fuzz_removals
+    from test_sched_lanes_emu import LANES4, LANES8, with_extra_resources
+    for seed in range(80):
+        lanes = LANES8 if seed % 2 else LANES4
+        w = fuzz_pending(seed) if seed % 4 < 2 else fuzz_pending_domains(seed)
+        nodes, pods = with_extra_resources(w.nodes, w.pods, lanes, seed)
+        case = SchedCase(nodes=nodes, pods=pods, hints=w.hints, acceptable=w.acceptable, break_on_failure=w.break_on_failure, last_index=w.last_index,
+                         lanes=lanes)
+        assert_sched_matches(sched_gpu(case, ctx), sched_oracle(case), f"{w.name} {len(lanes)} lanes")
+    for seed in range(50):
+        lanes = LANES8 if seed % 2 else LANES4
+        w = fuzz_removals(seed)
+        nodes, _ = with_extra_resources(w.nodes, [], lanes, seed)
+        case = RemovalCase(nodes=nodes, candidates=w.candidates, destination=w.destination, hints=w.hints, persist=w.persist, max_removable=w.max_removable,
+                           last_index=w.last_index, lanes=lanes)
+        assert_removal_matches(removal_device(case, ctx), removal_oracle(case), f"{w.name} {len(lanes)} lanes")
