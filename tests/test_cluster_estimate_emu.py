@@ -74,3 +74,28 @@ def test_fuzz_node_taints_policy_honor(seed):
     if cluster_estimate_emu(sc)[0] == 1:
         pytest.skip("delegated (hostname anti-affinity next to an unnamed node)")
     check(sc, w.name)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_fuzz_domain_rules_with_extended_resources(seed):
+    """more than two resource lanes: the `<.., 8>` instantiation of estimate_kernel (4 lanes on even seeds, 8 on odd ones); the template,
+    the existing nodes and most PEGs get amounts on the extra lanes, sometimes the binding ones"""
+    import copy
+    from kubernetes_autoscaler_amd.workloads import SplitMix64
+    lanes = ("cpu", "memory", "ephemeral-storage", "example.com/gpu") + (("example.com/fpga", "hugepages-2Mi", "example.com/nic", "example.com/license") if seed % 2 else ())
+    w = copy.deepcopy(workloads.fuzz_estimate_domains(2000 + seed))
+    rng = SplitMix64(0xE57A + seed)
+    for info in [g.template for g in w.groups] + list(w.existing):
+        for lane in lanes[2:]:
+            v = rng.pick([0, 1, 2, 4, 8])
+            info.node.allocatable[lane] = v
+            info.node.capacity[lane] = v
+    for pg in w.pegs:
+        if pg.pods:
+            extra = {lane: rng.pick([1, 1, 2]) for lane in lanes[2:] if rng.chance(1, 3)}
+            for p in {id(p): p for p in pg.pods}.values():
+                p.requests.update(extra)
+    sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing, lanes=lanes)
+    if cluster_estimate_emu(sc)[0] == 1:
+        pytest.skip("delegated: hostname anti-affinity with an unnamed node")
+    check(sc, f"{w.name} {len(lanes)} lanes")
