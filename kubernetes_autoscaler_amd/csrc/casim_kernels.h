@@ -589,19 +589,20 @@ CS_GLOBAL void order_kernel(DevTables t, DevResults res, OrderScratch os) {
 // scan, fill and order were four dependent launches of a few microseconds each.  Here block ng does all four for its group.  The one
 // thing a group needs from the others — the number of list entries in front of its own — travels through `ticket`: every block
 // publishes (epoch << 32 | count) with a device-scope release store as soon as its row is done, then waits for the words of the blocks
-// in front of it to carry this launch's epoch (the run counter of the problem: a second run on the same tables does not read the first's).  Workgroups of a launch are dispatched in ascending order, so everything a resident block waits for is resident
+// in front of it to carry this launch's epoch (the run counter of the problem: a second run on the same tables does not read the first's)
+// — for a bounded number of polls; what has not arrived by then it counts itself (see step 3 below), so no block waits without bound.  Workgroups of a launch are dispatched in ascending order, so everything a resident block waits for is resident
 // or finished (the assumption every single-pass chained scan makes); nobody waits for a block behind it.  `ticket` starts as zeros
 // (the host keeps it inside the upload slab), epochs start at 1.  The batch geometry keeps its separate kernels: tens of thousands of groups
 // would serialise on the tickets (a last-block scan inside feas_sim_kernel cost 1.05 -> 2.77 ms per step, profiles/r02s_packer_notes.txt).
-// LDS (dynamic, shared with order_group which takes it over afterwards): [Wg] ballot words, then [waves + 1] counters.
+// LDS (dynamic, shared with order_group which takes it over afterwards): [Wg] ballot words, then [2 waves + 3] counters.
 template <bool kLds>
 CS_GLOBAL void front_kernel(DevTables t, DevResults res, OrderScratch os, uint64_t* CS_RESTRICT bits /*[NG][Wg]*/, int Wg,
                             int32_t* offsets /*[NG + 1] == t.peg_off*/, int32_t* idx /*[nnz bound] == t.peg_idx*/,
-                            uint64_t* ticket /*[NG]*/, uint32_t epoch, int NG) {
+                            uint64_t* ticket /*[NG]*/, uint32_t epoch, int NG, uint32_t spin_limit) {
     const int ng = cs::bid(), tid = cs::tid(), lane = cs::lane(), wave = tid >> 6, nw = (cs::nthreads() + 63) >> 6;
     const int lo = t.peg_lo[ng], hi = t.peg_hi[ng];
     uint64_t* words = (uint64_t*)cs::dyn_smem();
-    uint32_t* cnt = (uint32_t*)(words + Wg);   // [nw] per-wave counts, [nw] the entries in front of this group
+    uint32_t* cnt = (uint32_t*)(words + Wg);   // [0, nw) per-wave counts, [nw] the entries in front of this group, [nw + 1, nw + 3) tickets missing, [nw + 3, 2 nw + 3) recount
     // 1. the row (feas_kernel): wave w takes words w, w + nw, ..
     uint32_t mine = 0;
     for (int w = wave; w < Wg; w += nw) {
@@ -616,17 +617,52 @@ CS_GLOBAL void front_kernel(DevTables t, DevResults res, OrderScratch os, uint64
     cs::sync();
     uint32_t total = 0;
     for (int w = 0; w < nw; ++w) total += cnt[w];
-    // 2. publish the count, 3. collect the counts in front (wave 0; a lane per predecessor)
-    if (wave == 0) {
-        if (lane == 0) cs::publish_u64(ticket + ng, ((uint64_t)epoch << 32) | total);
-        uint32_t before = 0;
-        for (int j = lane; j < ng; j += 64) {
-            uint64_t v;
-            do v = cs::poll_u64(ticket + j); while ((uint32_t)(v >> 32) != epoch);
-            before += (uint32_t)v;
+    // 2. publish the count, 3. collect the counts in front: wave 0 polls a lane per predecessor, at most `spin_limit` times each.  A
+    // ticket that has not arrived by then is NOT waited for any longer: the whole block counts that group's row itself (the same
+    // predicate, the same count its owner will publish).  So no block ever holds its slot waiting for another one without bound —
+    // several front kernels of different streams sharing a saturated chip cannot starve each other's lowest blocks into a circular
+    // wait — and in the usual case (every block resident within microseconds) nothing is counted twice.
+    if (wave == 0 && lane == 0) { cs::publish_u64(ticket + ng, ((uint64_t)epoch << 32) | total); cnt[nw] = 0; }
+    uint32_t before = 0;   // (wave 0: per-lane partial sums of the tickets that arrived)
+    for (int j0 = 0; j0 < ng; j0 += 64) {
+        if (wave == 0) {
+            const int j = j0 + lane;
+            bool have = j >= ng;
+            if (!have) {
+                uint64_t v = 0;
+                for (uint32_t spin = 0; spin < spin_limit; ++spin) {
+                    v = cs::poll_u64(ticket + j);
+                    if ((uint32_t)(v >> 32) == epoch) { have = true; break; }
+                }
+                if (have) before += (uint32_t)v;
+            }
+            const uint64_t missing = cs::ballot(!have);
+            if (lane == 0) { cnt[nw + 1] = (uint32_t)missing; cnt[nw + 2] = (uint32_t)(missing >> 32); }
         }
+        cs::sync();
+        uint64_t missing = (uint64_t)cnt[nw + 1] | ((uint64_t)cnt[nw + 2] << 32);   // (the same for every thread of the block)
+        while (missing) {
+            const int jm = j0 + cs::ffs64(missing);
+            missing &= missing - 1;
+            const int lo_j = t.peg_lo[jm], hi_j = t.peg_hi[jm];
+            uint32_t c = 0;
+            for (int w = wave; w * 64 < hi_j - lo_j; w += nw) {
+                const int k = w * 64 + lane;
+                bool ok = false;
+                if (lo_j + k < hi_j) ok = fits_fresh_node(t, lo_j + k, jm);
+                c += (uint32_t)cs::popc64(cs::ballot(ok));
+            }
+            if (lane == 0) cnt[nw + 3 + wave] = c;
+            cs::sync();
+            if (tid == 0) { uint32_t sum = 0; for (int w = 0; w < nw; ++w) sum += cnt[nw + 3 + w]; cnt[nw] += sum; }
+            cs::sync();
+        }
+        cs::sync();   // (cnt[nw + 1 ..] is rewritten by the next chunk of predecessors)
+    }
+    if (wave == 0) {
         before = cs::wave_sum_u32(before);
         if (lane == 0) {
+            before += cnt[nw];
             cnt[nw] = before;
             offsets[ng] = (int32_t)before;
             if (ng == NG - 1) offsets[NG] = (int32_t)(before + total);

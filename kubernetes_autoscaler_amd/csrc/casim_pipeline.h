@@ -543,11 +543,15 @@ public:
         front_ran_ = false;
         if (front_) {
             const int nw = (order_threads_ + 63) / 64;
-            const size_t own = 8 * (size_t)Wg_ + 4 * ((size_t)nw + 1) + 8;
+            const size_t own = 8 * (size_t)Wg_ + 4 * (2 * (size_t)nw + 3) + 8;
+            // polls per ticket before a block counts a missing predecessor's row itself (front_kernel); CASIM_FRONT_SPIN=0: never wait,
+            // always count (tests)
+            uint32_t spin = 256;
+            if (const char* e = getenv("CASIM_FRONT_SPIN")) { const long v = atol(e); spin = v < 0 ? 0u : (uint32_t)v; }
             const size_t smem = order_lds_ && order_smem_ > own ? order_smem_ : own;
             ++front_epoch_;
-            if (order_lds_) bk_.launch(front_kernel<true>, NG_, 1, order_threads_, smem, dt_, dr_, os_, d_bits_, Wg_, d_off_, d_idx_, d_ticket_, front_epoch_, NG_);
-            else bk_.launch(front_kernel<false>, NG_, 1, order_threads_, smem, dt_, dr_, os_, d_bits_, Wg_, d_off_, d_idx_, d_ticket_, front_epoch_, NG_);
+            if (order_lds_) bk_.launch(front_kernel<true>, NG_, 1, order_threads_, smem, dt_, dr_, os_, d_bits_, Wg_, d_off_, d_idx_, d_ticket_, front_epoch_, NG_, spin);
+            else bk_.launch(front_kernel<false>, NG_, 1, order_threads_, smem, dt_, dr_, os_, d_bits_, Wg_, d_off_, d_idx_, d_ticket_, front_epoch_, NG_, spin);
             front_ran_ = true;
             return CASIM_OK;
         }

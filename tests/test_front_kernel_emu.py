@@ -112,3 +112,30 @@ def test_feasibility_bits_are_still_written():
     for g in range(len(sc.groups)):
         assert int(off[g + 1] - off[g]) == int(sum(bin(int(x)).count("1") for x in np.atleast_1d(bits[g])))
     enc.close()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_blocks_that_do_not_wait_count_the_rows_in_front_themselves(seed, monkeypatch):
+    """CASIM_FRONT_SPIN=0: no ticket is ever waited for — every block recounts the rows of all the groups in front of it (the path a
+    block takes on the device when a predecessor has not published within the poll limit: nobody waits without bound)."""
+    monkeypatch.setenv("CASIM_FRONT_SPIN", "0")
+    fast = seed % 3 == 1
+    sc = _scenario(workloads.fuzz(3000 + seed) if seed % 2 else workloads.fuzz(7000 + seed, max_groups=4, max_pegs=200), fastpath=fast)
+    fused, _, _ = _both(encode(sc), fastpath=fast)
+    assert_matches_oracle(fused, run_oracle(sc), f"seed {seed}")
+
+
+def test_recount_with_many_groups(monkeypatch):
+    """80 groups, rows of up to 3 words, every block recounting everything in front of it (two chunks of 64 predecessors)"""
+    from kubernetes_autoscaler_amd.workloads import _node, SplitMix64
+    monkeypatch.setenv("CASIM_FRONT_SPIN", "0")
+    rng = SplitMix64(0xF208)
+    pegs = [PodEquivalenceGroup(pods=[Pod(name=f"p{i}", requests={"cpu": 100 * (1 + rng.below(8)), "memory": (128 << 20) * (1 + rng.below(6))},
+                                          node_selector=({"pool": f"p{rng.below(4)}"} if rng.chance(2, 3) else {}))] * (1 + rng.below(4))) for i in range(150)]
+    groups = [GroupSpec(NodeInfo(_node(f"g{k}", 50 if k % 7 == 3 else 1000 * (1 + rng.below(8)), (1 + rng.below(16)) << 30, 30,
+                                       {"pool": f"p{rng.below(5)}"} if rng.chance(3, 4) else {})), max_nodes=rng.pick([0, 2, 5]), last_index=0, pegs=None) for k in range(80)]
+    sc = Scenario(pegs=pegs, groups=groups, device_csr=True)
+    enc = encode(sc)
+    fused, _, _ = _both(enc)
+    assert_matches_oracle(fused, run_oracle(sc), "80 groups, recount")
+    enc.close()

@@ -315,6 +315,19 @@ def test_front_kernel_equals_the_separate_launches_and_the_oracle(ctx):
         w = cfg()
         sc = scenario(w)
         assert_matches_oracle(both(sc), run_oracle(sc), w.name)
+    # blocks that do not wait: with a poll limit of 0 every block counts the rows in front of it itself (what a block does on a
+    # saturated chip when a predecessor has not published in time)
+    os.environ["CASIM_FRONT_SPIN"] = "0"
+    try:
+        assert_matches_oracle(both(Scenario(pegs=pegs, groups=groups[:90], device_csr=True), runs=2), run_oracle(Scenario(pegs=pegs, groups=groups[:90], device_csr=True)),
+                              "90 groups, recount")
+        for seed in range(30):
+            sc = scenario(workloads.fuzz(3000 + seed))
+            assert_matches_oracle(both(sc), run_oracle(sc), f"recount fuzz {seed}")
+        w = workloads.config_c2()
+        assert_matches_oracle(both(scenario(w)), run_oracle(scenario(w)), "C2 recount")
+    finally:
+        del os.environ["CASIM_FRONT_SPIN"]
 
 
 def test_one_call_with_expander_waits_for_the_device_once(ctx):
