@@ -261,6 +261,20 @@ public:
             // both gets both with the same copy (best_option_query(q, defer_sync))
             opt_off_ = (res_bytes_ + 7) & ~(size_t)7;
             res_bytes_ = opt_off_ + 16 + 8 + 80 + ((ng + 7) & ~(size_t)7);
+            // and, when the lists are short (a single simulation), the PEG order and the pods placed per PEG: the fetch of a call is
+            // ONE copy instead of three (each copy is a launch of its own on this runtime)
+            {
+                int64_t cap = 0;
+                if (g->peg_offsets) cap = NG > 0 ? g->peg_offsets[NG] : 0;
+                else if (g->peg_lo && g->peg_hi) { for (size_t i = 0; i < NG; ++i) cap += (int64_t)g->peg_hi[i] - g->peg_lo[i]; }
+                else cap = (int64_t)NG * G_;
+                ord_in_slab_ = cap >= 0 && cap <= 16384;
+                if (ord_in_slab_) {
+                    ord_off_ = (res_bytes_ + 15) & ~(size_t)15;
+                    ord_cap_ = (size_t)cap;
+                    res_bytes_ = ord_off_ + 4 * (ord_cap_ + 1) + 4 * ord_cap_;
+                }
+            }
             res_slab_ = (char*)dalloc(res_bytes_);
             dr_.cpu_sum = (int64_t*)res_slab_; dr_.mem_sum = dr_.cpu_sum + ng;
             int32_t* i32 = (int32_t*)(dr_.mem_sum + ng);
@@ -511,7 +525,8 @@ public:
             os_.gbuf = (char*)dalloc((size_t)(ototal > 0 ? ototal : 256));
         }
         // ---- results ----
-        dr_.order = (int32_t*)dalloc(4 * ((size_t)nnz_cap_ + 1)); dr_.placed = (int32_t*)dalloc(4 * (size_t)nnz_cap_);
+        if (ord_in_slab_ && (size_t)nnz_cap_ <= ord_cap_) { dr_.order = (int32_t*)(res_slab_ + ord_off_); dr_.placed = dr_.order + ord_cap_ + 1; }
+        else { ord_in_slab_ = false; dr_.order = (int32_t*)dalloc(4 * ((size_t)nnz_cap_ + 1)); dr_.placed = (int32_t*)dalloc(4 * (size_t)nnz_cap_); }
         dr_.fast_last = (uint8_t*)dalloc(NG);
         if (fast_npt_ > 0) {   // register packer: one record per PEG (casim_types.h) instead of the three arrays
             dr_.rec_dw = fast_r_ == 2 ? 8 : 16;
@@ -698,7 +713,8 @@ public:
         last_fetch_ = st;
         int32_t* st_order = (int32_t*)(st + ((res_bytes_ + 15) & ~(size_t)15));
         int32_t* st_placed = st_order + spec_n;
-        if (spec && spec_n > 0) {
+        if (ord_in_slab_) { st_order = (int32_t*)(st + ord_off_); st_placed = st_order + ord_cap_ + 1; }   // (they came with the slab)
+        else if (spec && spec_n > 0) {
             if (out->order) bk_.d2h(st_order, dr_.order, 4 * spec_n);
             if (out->placed) bk_.d2h(st_placed, dr_.placed, 4 * spec_n);
         }
@@ -966,6 +982,7 @@ private:
     int n_sims_ = 0, max_sim_groups_ = 0, feas_len_ = 0;
     bool feas_by_sim_ = false;
     bool one_shot_ = false;
+    bool ord_in_slab_ = false; size_t ord_off_ = 0, ord_cap_ = 0;   // order / placed inside the results slab (short lists)
     std::vector<int32_t> opt_host_; const casim_option_query* opt_pending_q_ = nullptr; int opt_pending_s_ = 0; const char* opt_stage_ = nullptr;
     bool opt_in_slab_ = false; size_t opt_off_ = 0; const char* last_fetch_ = nullptr;   // (the staged copy of the results slab of the last fetch())
     bool front_ = false, front_ran_ = false;   // feas + offsets + lists + order in ONE launch (front_kernel)
