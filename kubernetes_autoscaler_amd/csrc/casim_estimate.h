@@ -368,6 +368,19 @@ public:
 
         memset(&dt_, 0, sizeof dt_); memset(&a_, 0, sizeof a_);
         dt_.G = C_; dt_.NG = N_; dt_.R = R; dt_.Wt = p->w_taint; dt_.Wl = p->w_label; dt_.Wx = p->w_excl; dt_.Wz = 0;
+        // ONE host-to-device copy for every table of the call (packed into the backend's pinned staging buffer, as SchedulerT and
+        // ProblemT do it); a column beyond the bound falls back on a copy of its own
+        {
+            const size_t masks = (size_t)(dt_.Wt + dt_.Wl + dt_.Wx);
+            size_t bound = 64 * 64 + 4096 + C * (8 * (size_t)R + 24 + 8 * (masks + 2 * (size_t)dt_.Wx)) + N * (16 * (size_t)R + 16 + 8 * masks);
+            if (ce->rules && ce->rules->n_rules > 0 && ce->rules->rule_offset) {
+                const casim_domain_rules* r0 = ce->rules;
+                const size_t NR = (size_t)r0->n_rules, tot = (size_t)r0->rule_offset[NR];
+                bound += 4 * (size_t)r0->n_keys * N + 64 * (NR + 1) + 8 * tot + 4 * NR * N + 8 * (size_t)r0->n_elig_rows * ((N + 1023) / 64 + 16) + 8 * (C + 1) +
+                         4 * (size_t)(r0->inc_off ? r0->inc_off[C] : 0);
+            }
+            begin_uploads(bound);
+        }
         dt_.req = up(p->req, C * R); dt_.pflags = up(p->flags, C);
         dt_.tol = up(p->tol_mask, C * dt_.Wt); dt_.sel = up(p->sel_mask, C * dt_.Wl);
         dt_.xblock = up(p->excl_block, C * dt_.Wx); dt_.xmark = up(p->excl_mark, C * dt_.Wx);
@@ -408,7 +421,7 @@ public:
                 std::vector<uint64_t> rows((size_t)dr->n_elig_rows * (size_t)S_, 0ull);
                 for (int r = 0; r < dr->n_elig_rows; ++r) for (size_t w = 0; w < w_in; ++w) rows[(size_t)r * (size_t)S_ + w] = dr->elig_bits[(size_t)r * w_in + w];
                 a_.rule_elig = up(rows.data(), rows.size());
-                bk_.sync();
+                if (direct_uploads_ > 0) bk_.sync();   // (`rows` is a local; a packed upload has copied it already)
             }
             a_.class_rule_off = up(dr->class_rule_off, C + 1); a_.inc_off = up(dr->inc_off, C + 1);
             a_.inc_rule = up(dr->inc_rule, (size_t)dr->inc_off[C]);
@@ -423,7 +436,8 @@ public:
         lds_ = ctrl + bytes <= (int64_t)bk_.lds_budget();
         smem_ = (size_t)(lds_ ? ctrl + bytes : ctrl);
         if (!lds_) a_.gstate = (char*)dalloc((size_t)bytes);
-        bk_.sync();
+        end_uploads();
+        if (direct_uploads_ > 0) bk_.sync();   // (locals uploaded on their own must have left; packed ones were copied when up() returned)
         if (!bk_.ok()) return fail(CASIM_ERR_HIP, bk_.error());
         ready_ = true;
         return CASIM_OK;
@@ -448,11 +462,14 @@ public:
 
     int32_t fetch(casim_cluster_estimate_result* out) {
         if (!ready_ || !out) return fail(CASIM_ERR_INVALID, "nothing to fetch");
-        int32_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int64_t sums[2] = {0, 0};
-        std::vector<int32_t> placed((size_t)C_ > 0 ? (size_t)C_ : 1);
-        bk_.d2h(o, a_.out, 32); bk_.d2h(sums, a_.sums, 16);
-        if (C_ > 0) bk_.d2h(placed.data(), a_.placed, 4 * (size_t)C_);
+        // one round trip through the pinned fetch staging buffer
+        char* st = (char*)bk_.stage(1, 64 + 4 * (size_t)(C_ > 0 ? C_ : 1));
+        if (!st) return fail(CASIM_ERR_NOMEM, "no staging buffer");
+        const int32_t* o = (const int32_t*)st;
+        const int64_t* sums = (const int64_t*)(st + 32);
+        const int32_t* placed = (const int32_t*)(st + 64);
+        bk_.d2h(st, a_.out, 32); bk_.d2h(st + 32, a_.sums, 16);
+        if (C_ > 0) bk_.d2h(st + 64, a_.placed, 4 * (size_t)C_);
         bk_.sync();
         out->node_count = o[0]; out->pods_scheduled = o[1]; out->nodes_added = o[2]; out->limiter_nodes = o[3]; out->last_index_out = o[4];
         out->status = CASIM_NG_OK; out->req_cpu_sum = sums[0]; out->req_mem_sum = sums[1];
@@ -467,11 +484,26 @@ public:
     bool in_lds() const { return lds_; }
 
 private:
+    void begin_uploads(size_t bound) {
+        up_host_ = (char*)bk_.stage(0, bound);
+        up_dev_ = up_host_ ? (char*)dalloc(bound) : nullptr;
+        up_cap_ = up_dev_ ? bound : 0; up_used_ = 0; direct_uploads_ = 0;
+    }
+    void end_uploads() {
+        if (up_dev_ && up_used_ > 0) bk_.h2d(up_dev_, up_host_, up_used_);
+        up_dev_ = up_host_ = nullptr; up_cap_ = 0;
+    }
     template <class T>
     const T* up(const T* src, size_t n) {
         if (n == 0 || !src) return nullptr;
-        T* d = (T*)dalloc(sizeof(T) * n);
-        if (d) bk_.h2d(d, src, sizeof(T) * n);
+        const size_t bytes = sizeof(T) * n, at = (up_used_ + 15) & ~(size_t)15;
+        if (up_dev_ && at + bytes <= up_cap_) {
+            memcpy(up_host_ + at, src, bytes);
+            up_used_ = at + bytes;
+            return (const T*)(up_dev_ + at);
+        }
+        T* d = (T*)dalloc(bytes);
+        if (d) { bk_.h2d(d, src, bytes); ++direct_uploads_; }
         return d;
     }
     void* dalloc(size_t bytes) {
@@ -483,6 +515,7 @@ private:
     int32_t fail(int32_t code, const char* msg) { err_ = msg ? msg : ""; return code; }
 
     BK& bk_;
+    char* up_host_ = nullptr; char* up_dev_ = nullptr; size_t up_cap_ = 0, up_used_ = 0; int direct_uploads_ = 0;   // packed uploads
     DevTables dt_; EstArgs a_;
     int C_ = 0, N_ = 0, E_ = 0, S_ = 0, threads_ = 64;
     int32_t cap_ = 0;
