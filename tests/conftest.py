@@ -20,9 +20,7 @@ def _cpu_tier_in_parallel(config):
         return
     if getattr(opt, "collectonly", False) or getattr(opt, "usepdb", False) or len(config.invocation_params.args) == 0:
         return
-    try:
-        import xdist  # noqa: F401
-    except ImportError:
+    if not config.pluginmanager.hasplugin("xdist"):   # (not installed, or switched off with -p no:xdist)
         return
     n = min(8, os.cpu_count() or 1)
     if n < 2:
