@@ -70,6 +70,19 @@ for seed in range(first, first + count):
         sc = scen(w, fastpath=fast)
         res, _ = run_gpu(encode(sc), ctx, fastpath=fast)
         assert_matches_oracle(res, run_oracle(sc), w.name); bump(f"fuzz_packer_fast{int(fast)}")
+    # lists derived on the device: one launch for feasibility + offsets + lists + order (front_kernel), long rows on odd seeds
+    w = W.fuzz(seed + 3_000_000, max_groups=6, max_pegs=150 if seed % 2 else 24)
+    sc = scen(w, device_csr=True)
+    res, _ = run_gpu(encode(sc), ctx)
+    assert_matches_oracle(res, run_oracle(sc), w.name); bump("fuzz_packer_device_lists")
+    # more than two resource lanes in K_sched (every fourth seed)
+    if seed % 4 == 0:
+        from test_sched_lanes_emu import LANES4, LANES8, with_extra_resources
+        lanes = LANES8 if seed % 8 == 0 else LANES4
+        w = W.fuzz_pending(seed + 5_000_000)
+        nodes, pods = with_extra_resources(w.nodes, w.pods, lanes, seed)
+        sc = SchedCase(nodes=nodes, pods=pods, hints=w.hints, acceptable=w.acceptable, break_on_failure=w.break_on_failure, last_index=w.last_index, lanes=lanes)
+        assert_sched_matches(sched_gpu(sc, ctx), sched_oracle(sc), w.name + " lanes"); bump("fuzz_pending_lanes")
 print("stress OK", "(emulator)" if EMU else "(MI355X)", stats, f"{time.time() - t0:.0f} s")
 if not EMU:
     ctx.close()
