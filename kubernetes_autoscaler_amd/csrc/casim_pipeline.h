@@ -233,6 +233,7 @@ public:
                            4 * ((size_t)(g->n_sims > 0 ? g->n_sims : 0) + 1) + 4 * (NG + 1) + 8 * (size_t)dt_.Wz + 64 * 64 + 4096 +
                            (NG <= kFrontMaxGroups ? 8 * NG + 16 : 0);   // (front_kernel's tickets)
             if (g->peg_offsets && NG > 0 && g->peg_offsets[NG] > 0) bound += 4 * (size_t)g->peg_offsets[NG];
+            if (getenv("CASIM_TEST_SMALL_UPLOAD_BOUND")) bound = 512;   // (tests: most columns take the fallback copy of their own; the tickets of front_kernel then do not fit and the separate launches run)
             begin_uploads(bound);
         }
         stage.mark("table columns -> staging");

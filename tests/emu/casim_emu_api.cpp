@@ -77,11 +77,16 @@ EMU_API int32_t emu_estimate_batch_query(const casim_pegs* pegs, const casim_gro
     EmuBackend bk;
     if (lds_budget_bytes > 0) bk.lds = (size_t)lds_budget_bytes;
     casim::ProblemT<EmuBackend> p(bk);
+    // the sequence of casim_estimate_batch_query (csrc/casim_engine.hip): one-shot problem, the expander's answer left in flight until
+    // the fetch has waited, offsets from the fetch
+    p.set_one_shot(true);
     int32_t rc = p.init(pegs, groups, opts);
     if (rc == CASIM_OK) rc = p.run();
+    const bool one_wait = q && out;
+    if (rc == CASIM_OK && q) rc = p.best_option_query(q, /*defer_sync=*/one_wait);
     if (rc == CASIM_OK) rc = p.fetch(out);
+    if (one_wait) { const int32_t rc2 = p.best_option_finish(/*synced=*/rc == CASIM_OK); if (rc == CASIM_OK) rc = rc2; }
     if (rc == CASIM_OK && (nnz_out || offsets_out)) rc = p.csr(nnz_out, offsets_out);
-    if (rc == CASIM_OK && q) rc = p.best_option_query(q);
     if (rc != CASIM_OK) g_err = p.error();
     g_last_front = p.uses_front() ? 1 : 0;
     return rc;

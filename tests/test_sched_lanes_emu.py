@@ -65,3 +65,30 @@ def test_removal_loop_with_extended_resources(seed, lanes):
     want = removal_oracle(case)
     for lds in (0, 64):
         assert_removal_matches(removal_device(case, EmuContext(lds)), want, f"{w.name} {len(lanes)} lanes lds={lds}")
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_uploads_that_do_not_fit_the_packed_slab(seed, monkeypatch):
+    """CASIM_TEST_SMALL_UPLOAD_BOUND: the bound of the packed upload is 512 bytes, so most columns of a call take the fallback copy of
+    their own (and the call waits for them before its locals die): same results — TrySchedulePods, the removal loop, K_est, Estimate."""
+    from harness import GroupSpec, Scenario, assert_cluster_estimate_matches, assert_matches_oracle, cluster_estimate_emu, encode, run_emu, run_oracle
+    from kubernetes_autoscaler_amd import workloads
+    monkeypatch.setenv("CASIM_TEST_SMALL_UPLOAD_BOUND", "1")
+    w = fuzz_pending_domains(40 + seed)
+    case = SchedCase(nodes=w.nodes, pods=w.pods, hints=w.hints, acceptable=w.acceptable, break_on_failure=w.break_on_failure, last_index=w.last_index)
+    assert_sched_matches(sched_emu(case), sched_oracle(case), w.name)
+    w = fuzz_removals(40 + seed)
+    rc = RemovalCase(nodes=w.nodes, candidates=w.candidates, destination=w.destination, hints=w.hints, persist=w.persist, max_removable=w.max_removable,
+                     last_index=w.last_index)
+    assert_removal_matches(removal_device(rc, EmuContext(0)), removal_oracle(rc), w.name)
+    w = workloads.fuzz_estimate_domains(40 + seed)
+    sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing, lanes=w.lanes)
+    got = cluster_estimate_emu(sc)
+    if got[0] == 0:
+        est, ids = run_oracle(sc)[0]
+        assert_cluster_estimate_matches(got, est, ids, w.name)
+    w = workloads.fuzz(3000 + seed)
+    sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing, lanes=w.lanes,
+                  device_csr=True)
+    res, _ = run_emu(encode(sc))
+    assert_matches_oracle(res, run_oracle(sc), w.name)
