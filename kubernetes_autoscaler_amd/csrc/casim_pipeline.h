@@ -924,11 +924,26 @@ private:
     void begin_uploads(size_t bound) {
         up_host_ = (char*)bk_.stage(0, bound);
         up_dev_ = up_host_ ? (char*)dalloc(bound) : nullptr;
-        up_cap_ = up_dev_ ? bound : 0; up_used_ = 0;
+        up_cap_ = up_dev_ ? bound : 0; up_used_ = 0; up_flushed_ = 0; up_reserved_ = false;
     }
     void end_uploads() {
-        if (up_dev_ && up_used_ > 0) bk_.h2d(up_dev_, up_host_, up_used_);
+        if (up_dev_ && up_used_ > up_flushed_) bk_.h2d(up_dev_ + up_flushed_, up_host_ + up_flushed_, up_used_ - up_flushed_);
         up_dev_ = up_host_ = nullptr; up_cap_ = 0;
+    }
+    // A big batch does not wait for its last column before the first one travels: every kUploadChunk bytes of staged columns go out
+    // as a copy of their own (same slab, same stream), so the link works while the host stages the next columns and runs the gcd
+    // pass.  Only columns that are final when up() returns: once somebody has RESERVED room to write in place later (up_reserve), the
+    // rest goes out with end_uploads().  A single simulation stays one copy.
+    static constexpr size_t kUploadChunk = (size_t)4 << 20;
+    static size_t upload_chunk() {   // (CASIM_TEST_UPLOAD_CHUNK: tests send small tables in many pieces)
+        const char* e = getenv("CASIM_TEST_UPLOAD_CHUNK");
+        const long v = e ? atol(e) : 0;
+        return v > 0 ? (size_t)v : kUploadChunk;
+    }
+    void flush_uploads_early() {
+        if (up_reserved_ || !up_dev_ || up_used_ - up_flushed_ < upload_chunk()) return;
+        bk_.h2d(up_dev_ + up_flushed_, up_host_ + up_flushed_, up_used_ - up_flushed_);
+        up_flushed_ = up_used_;
     }
     template <class T>
     const T* up(const T* src, size_t n) {
@@ -937,6 +952,7 @@ private:
         if (up_dev_ && at + bytes <= up_cap_) {
             par_memcpy(up_host_ + at, src, bytes);
             up_used_ = at + bytes;
+            flush_uploads_early();
             return (const T*)(up_dev_ + at);
         }
         T* d = (T*)dalloc(bytes);   // outside a packed section (or a bound that was too small): its own copy
@@ -949,6 +965,7 @@ private:
     T* up_reserve(size_t n, const T** dev_out) {
         const size_t bytes = sizeof(T) * n, at = (up_used_ + 15) & ~(size_t)15;
         if (n == 0 || !up_dev_ || at + bytes > up_cap_) return nullptr;
+        up_reserved_ = true;
         up_used_ = at + bytes;
         *dev_out = (const T*)(up_dev_ + at);
         return (T*)(up_host_ + at);
@@ -991,7 +1008,7 @@ private:
     static constexpr size_t kFrontMaxGroups = 1024;
     std::vector<int32_t> h_off_;
     bool h_off_fresh_ = false;
-    char* up_dev_ = nullptr; char* up_host_ = nullptr; size_t up_cap_ = 0, up_used_ = 0;
+    char* up_dev_ = nullptr; char* up_host_ = nullptr; size_t up_cap_ = 0, up_used_ = 0; size_t up_flushed_ = 0; bool up_reserved_ = false;
     std::vector<uint64_t> zpol_host_;
     char* res_slab_ = nullptr; size_t res_bytes_ = 0; int32_t* res_off_ = nullptr;
     int32_t* d_node_pods_ = nullptr; std::vector<int64_t> np_off_;

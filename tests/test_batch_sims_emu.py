@@ -208,3 +208,21 @@ def test_one_wave_orderer_networks_of_64_128_256_entries(n_pegs):
             assert [int(o) - t * G for o in order] == [ids[k] for k in est.order], f"copy {t} group {gi}: PEG order"
             assert list(placed) == list(est.placed) and int(res.node_count[g]) == est.node_count
     enc.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_tables_uploaded_in_pieces(seed, monkeypatch):
+    """A big batch sends its staged columns in pieces of 4 MB while the host stages the rest (ProblemT::flush_uploads_early);
+    CASIM_TEST_UPLOAD_CHUNK=48 makes a few hundred bytes of tables travel in a dozen pieces: same results."""
+    scs = [_scenario(4000 * seed + k) for k in range(2 + seed % 3)]
+    enc, ts, bases = encode_batch(scs)
+    base, _ = run_emu_tables(ts, kinds=[0])
+    monkeypatch.setenv("CASIM_TEST_UPLOAD_CHUNK", "48")
+    res, _ = run_emu_tables(ts, kinds=[0])
+    for f in ("node_count", "pods_scheduled", "nodes_added", "limiter_nodes", "last_index_out", "order", "placed", "offsets"):
+        assert np.array_equal(np.asarray(getattr(res, f)), np.asarray(getattr(base, f))), f
+    want = []
+    for sc, (pb, _) in zip(scs, bases):
+        want.extend(_shift(run_oracle(sc), pb))
+    assert_matches_oracle(res, want, f"pieces seed {seed}")
+    enc.close()
