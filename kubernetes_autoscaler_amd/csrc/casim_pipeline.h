@@ -711,7 +711,6 @@ public:
         char* st = (char*)bk_.stage(1, res_bytes_ + (spec ? 8 * spec_n : 0) + 64);
         if (!st) return fail(CASIM_ERR_NOMEM, "no staging buffer");
         bk_.d2h(st, res_slab_, res_bytes_);
-        last_fetch_ = st;
         int32_t* st_order = (int32_t*)(st + ((res_bytes_ + 15) & ~(size_t)15));
         int32_t* st_placed = st_order + spec_n;
         if (ord_in_slab_) { st_order = (int32_t*)(st + ord_off_); st_placed = st_order + ord_cap_ + 1; }   // (they came with the slab)
@@ -720,6 +719,7 @@ public:
             if (out->placed) bk_.d2h(st_placed, dr_.placed, 4 * spec_n);
         }
         bk_.sync();
+        if (opt_in_slab_) opt_keep_.assign(st + opt_off_, st + opt_off_ + 104 + ((ng + 7) & ~(size_t)7));   // (the expander's answer came along: best_option_finish)
         const int64_t* h64 = (const int64_t*)st;
         const int32_t* h32 = (const int32_t*)(h64 + 2 * ng);
         if (csr_on_device_ && NG_ > 0) { h_off_.assign(h32 + 6 * ng, h32 + 6 * ng + NG + 1); h_off_fresh_ = true; }
@@ -735,7 +735,9 @@ public:
         if (spec) {
             if (out->order && nnz) memcpy(out->order, st_order, 4 * nnz);
             if (out->placed && nnz) memcpy(out->placed, st_placed, 4 * nnz);
-        } else if (nnz > 0) {   // a big batch: straight into the caller's arrays
+        }
+        if (!spec && nnz > 0) {   // a big batch: straight into the caller's arrays (through the pinned staging buffer in two pieces it was
+                                  // no faster: 6.4-6.5 ms against 6.2-6.3 per headline call, r07n)
             if (out->order) bk_.d2h(out->order, dr_.order, 4 * nnz);
             if (out->placed) bk_.d2h(out->placed, dr_.placed, 4 * nnz);
             bk_.sync();
@@ -847,7 +849,7 @@ public:
                          b_pk = q->packed_out ? 8 * (size_t)S : 0;
             if (defer_sync && S == 1 && opt_cap_ == 1 && !q->dev_key_out && !q->dev_packed_out) {
                 // the one-simulation answer sits inside the results slab: the fetch that follows brings it along, no copy of its own
-                opt_pending_q_ = q; opt_pending_s_ = 1; opt_stage_ = nullptr; opt_in_slab_ = true;
+                opt_pending_q_ = q; opt_pending_s_ = 1; opt_stage_ = nullptr; opt_in_slab_ = true; opt_keep_.clear();
                 return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
             }
             char* st = defer_sync ? (char*)bk_.stage_if_fits(0, b_out + b_set + b_key + b_pk) : nullptr;
@@ -879,8 +881,8 @@ public:
         if (!q) return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
         if (opt_in_slab_) {
             opt_in_slab_ = false; opt_pending_q_ = nullptr;
-            if (!synced || !last_fetch_) return fail(CASIM_ERR_INVALID, "expander answer deferred without a fetch");
-            const char* b = last_fetch_ + opt_off_;
+            if (!synced || opt_keep_.empty()) return fail(CASIM_ERR_INVALID, "expander answer deferred without a fetch");
+            const char* b = opt_keep_.data();
             const int32_t* o = (const int32_t*)b;
             if (q->best_out) q->best_out[0] = o[0];
             if (q->n_best_out) q->n_best_out[0] = o[1];
@@ -1002,7 +1004,7 @@ private:
     bool one_shot_ = false;
     bool ord_in_slab_ = false; size_t ord_off_ = 0, ord_cap_ = 0;   // order / placed inside the results slab (short lists)
     std::vector<int32_t> opt_host_; const casim_option_query* opt_pending_q_ = nullptr; int opt_pending_s_ = 0; const char* opt_stage_ = nullptr;
-    bool opt_in_slab_ = false; size_t opt_off_ = 0; const char* last_fetch_ = nullptr;   // (the staged copy of the results slab of the last fetch())
+    bool opt_in_slab_ = false; size_t opt_off_ = 0; std::vector<char> opt_keep_;   // (the expander's answer as the last fetch() brought it)
     bool front_ = false, front_ran_ = false;   // feas + offsets + lists + order in ONE launch (front_kernel)
     uint64_t* d_ticket_ = nullptr; uint32_t front_epoch_ = 0;
     static constexpr size_t kFrontMaxGroups = 1024;

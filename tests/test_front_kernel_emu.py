@@ -139,3 +139,23 @@ def test_recount_with_many_groups(monkeypatch):
     fused, _, _ = _both(enc)
     assert_matches_oracle(fused, run_oracle(sc), "80 groups, recount")
     enc.close()
+
+
+def test_one_call_with_long_lists_and_the_expander():
+    """lists beyond 16 384 entries (order / placed outside the results slab, fetched through the staging buffer in two pieces) next to an
+    expander answer that rides in the slab: 6 groups x 3 000 PEGs in ONE call"""
+    from kubernetes_autoscaler_amd.workloads import _node, SplitMix64
+    rng = SplitMix64(0xF209)
+    pegs = [PodEquivalenceGroup(pods=[Pod(name=f"p{i}", requests={"cpu": 10 * (1 + rng.below(300)), "memory": (16 << 20) * (1 + rng.below(200))})] * (1 + rng.below(3)))
+            for i in range(3000)]
+    groups = [GroupSpec(NodeInfo(_node(f"g{k}", 4000 * (1 + k), (8 + 8 * k) << 30, 110, {})), max_nodes=rng.pick([5, 20, 60]), last_index=0, pegs=None) for k in range(6)]
+    sc = Scenario(pegs=pegs, groups=groups, device_csr=True)
+    enc, ts, bases = encode_batch([sc])
+    res, exp = run_emu_tables(ts, kinds=[0, 1], per_sim=False)
+    want = run_oracle(sc)
+    assert_matches_oracle(res, want, "6 x 3000")
+    assert int(np.asarray(res.offsets)[-1]) > 16384
+    nodes = [int(x) for x in res.node_count]
+    best = int(exp["best"][0])
+    assert best >= 0 and nodes[best] == min(n for n in nodes if n > 0)
+    enc.close()
