@@ -1280,8 +1280,12 @@ int32_t casim_enc_finalize(casim_encoder* e) {
     e->init_excl.assign(NG * (size_t)Wx, 0); e->init_zone.assign(NG * (size_t)Wz, 0); e->zone_valid.assign(NG * (size_t)Wz, 0);
     e->max_nodes.assign(NG, 0); e->existing_nodes.assign(NG, 0); e->last_index.assign(NG, 0);
     e->cap_cpu.assign(NG, 0.0); e->cap_mem.assign(NG, 0.0); e->waste_cpu.assign(NG, 0); e->waste_mem.assign(NG, 0);
+    // (a row per node, nothing shared between rows: node ranges on up to four threads — at cluster scale the loop reads the requests of
+    // every running pod's cold spec record)
+    uint8_t explicit_in_slice[4] = {0, 0, 0, 0};
+    enc_par_for(NG, enc_threads(NG, 2048), [&](size_t g_lo, size_t g_hi, int slice) {
     bool any_explicit = false;
-    for (size_t gi = 0; gi < NG; ++gi) {
+    for (size_t gi = g_lo; gi < g_hi; ++gi) {
         const Group& g = e->groups[gi];
         for (int r = 0; r < R; ++r) e->alloc[gi * (size_t)R + (size_t)r] = g.alloc[r];
         e->allowed[gi] = g.allowed;
@@ -1308,6 +1312,9 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         }
         any_explicit = any_explicit || g.has_pegs;
     }
+    explicit_in_slice[slice & 3] = any_explicit ? 1 : 0;
+    });
+    const bool any_explicit = explicit_in_slice[0] || explicit_in_slice[1] || explicit_in_slice[2] || explicit_in_slice[3];
     for (size_t i = 0; i < G; ++i) for (uint32_t gi : existing_block[i]) set_bit(e->init_zone, gi, Wz, static_zbit[i]);
     for (auto& pr : zone_preset) set_bit(e->init_zone, pr.first, Wz, pr.second);
     e->zpol.assign((size_t)Wz, 0ull);
