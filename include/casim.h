@@ -39,7 +39,9 @@ extern "C" {
                                *    casim_enc_add_grouped_pegs, casim_enc_pod_set_spec_extra
                                * 5: casim_options.pack_build, casim_pack_build_info (two builds of the register packer + self-check),
                                *    casim_problem_info [5], [6], casim_option_query.join_stream, casim_prefetch_*, casim_enc_begin_update / _group_reset / _refinalize / _group_rows
-                               * 6: casim_pegs.zone_polarity (group bits of NEED polarity: required pod affinity towards a partner of the batch) */
+                               * 6: casim_pegs.zone_polarity (group bits of NEED polarity: required pod affinity towards a partner of the batch);
+                               *    later, without a new number (layouts unchanged, zero keeps its meaning): casim_options.no_front_kernel in one of
+                               *    the two reserved words, casim_problem_info [7] */
 
 /* Resource lanes.  Lane 0 = cpu in millicores (Quantity.MilliValue), lane 1 = memory bytes,
  * lane 2 = ephemeral-storage bytes, lanes 3.. = scalar / extended resources (Quantity.Value),
