@@ -685,6 +685,15 @@ int32_t casim_enc_group_set_limits(casim_encoder* e, int32_t group, int32_t max_
 /* A pod preloaded on the template (DaemonSet pod): `pod` is a pod spec id from
  * casim_enc_add_pod_spec. */
 int32_t casim_enc_group_add_preloaded_pod(casim_encoder* e, int32_t group, int32_t pod_spec);
+/* Many plain running pods in ONE call (per-node mode at cluster scale: 150 000 running pods are 600 000 calls and, from cgo, a C
+ * string per label otherwise).  Pod i: namespace strings[ns[i]], requests req[i * n_res ..], labels
+ * (strings[label_key[k]], strings[label_val[k]]) for k in [label_off[i], label_off[i + 1]), running on node group[i] (>= 0: added as
+ * casim_enc_group_add_preloaded_pod does; -1: only the spec is created).  Pods with tolerations, selectors, host ports or
+ * (anti-)affinity terms get those through the calls above on the returned ids.  Returns the spec id of pod 0 (the ids are
+ * consecutive), or a negative CASIM_ERR_*; nothing is added on an error.  Not inside an update session. */
+int32_t casim_enc_add_running_pods(casim_encoder* e, int32_t n_pods, const int32_t* group, const int32_t* ns, const int64_t* req,
+                                   const int32_t* label_off, const int32_t* label_key, const int32_t* label_val,
+                                   const char* const* strings, int32_t n_strings);
 /* Restrict the group to an explicit PEG list (order = order the PEGs reach Estimate).  If never
  * called for any group, the engine derives the schedulable subsets on the device. */
 int32_t casim_enc_group_set_pegs(casim_encoder* e, int32_t group, const int32_t* pegs, int32_t n);

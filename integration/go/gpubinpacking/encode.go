@@ -200,3 +200,70 @@ func (s *session) tables() (pegs C.casim_pegs, groups C.casim_groups, err error)
 	err = rcErr(C.casim_enc_tables(s.enc, &pegs, &groups), "casim_enc_tables")
 	return
 }
+
+// runningPods hands the running pods of many nodes to the encoder in ONE cgo crossing (casim_enc_add_running_pods; per-node
+// consumers — filter-out-schedulable, the removal simulation — describe 10^5 running pods per loop).  Pods that only carry a
+// namespace, labels and requests go into flat arrays with an interned string table (no C string per label); a pod with
+// tolerations, selectors, host ports or (anti-)affinity terms ends the batch collected so far and takes the per-pod calls, so
+// that spec ids follow the order of the pods.  groups[i] is the encoder's group id of nodes[i].
+func (s *session) runningPods(nodes []*framework.NodeInfo, groups []C.int32_t) {
+	var grp, ns, off, lk, lv []C.int32_t
+	var req []C.int64_t
+	off = append(off, 0)
+	strIdx := map[string]C.int32_t{}
+	var strs []*C.char
+	sid := func(x string) C.int32_t {
+		if i, ok := strIdx[x]; ok {
+			return i
+		}
+		i := C.int32_t(len(strs))
+		strIdx[x] = i
+		strs = append(strs, s.strs.s(x))
+		return i
+	}
+	flush := func() {
+		if len(grp) == 0 {
+			return
+		}
+		var pk, pv *C.int32_t
+		if len(lk) > 0 {
+			pk, pv = &lk[0], &lv[0]
+		}
+		C.casim_enc_add_running_pods(s.enc, C.int32_t(len(grp)), &grp[0], &ns[0], &req[0], &off[0], pk, pv, &strs[0], C.int32_t(len(strs)))
+		grp, ns, req, lk, lv, off = grp[:0], ns[:0], req[:0], lk[:0], lv[:0], append(off[:0], 0)
+	}
+	plain := func(p *apiv1.Pod) bool {
+		sp := &p.Spec
+		if len(sp.Tolerations) > 0 || len(sp.NodeSelector) > 0 || sp.Affinity != nil || len(sp.TopologySpreadConstraints) > 0 || hasVolumesOrClaims(p) {
+			return false
+		}
+		for i := range sp.Containers {
+			for _, cp := range sp.Containers[i].Ports {
+				if cp.HostPort > 0 {
+					return false
+				}
+			}
+		}
+		return true
+	}
+	for i, ni := range nodes {
+		for _, pi := range ni.Pods() {
+			p := pi.Pod
+			if _, seen := s.spec[p]; seen || !plain(p) {
+				flush()
+				C.casim_enc_group_add_preloaded_pod(s.enc, groups[i], s.pod(p))
+				continue
+			}
+			r := podutils.PodRequests(p)
+			grp = append(grp, groups[i])
+			ns = append(ns, sid(p.Namespace))
+			req = append(req, C.int64_t(r.Cpu().MilliValue()), C.int64_t(r.Memory().Value()), C.int64_t(r.StorageEphemeral().Value()))
+			for k, v := range p.Labels { // (any order: the encoder keeps a pod's labels sorted by key)
+				lk = append(lk, sid(k))
+				lv = append(lv, sid(v))
+			}
+			off = append(off, C.int32_t(len(lk)))
+		}
+	}
+	flush()
+}

@@ -202,6 +202,8 @@ PROTOTYPES = {
     "casim_enc_group_set_fastpath_capacity": (C.c_int32, [C.c_void_p, C.c_int32, C.c_double, C.c_double]),
     "casim_enc_group_set_limits": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "casim_enc_group_add_preloaded_pod": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
+    "casim_enc_add_running_pods": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_char_p), C.c_int32]),
     "casim_enc_group_set_pegs": (C.c_int32, [C.c_void_p, C.c_int32, i32p, C.c_int32]),
     "casim_enc_add_pod_spec": (C.c_int32, [C.c_void_p, cstr, i64p]),
     "casim_enc_pod_add_label": (C.c_int32, [C.c_void_p, C.c_int32, cstr, cstr]),

@@ -385,6 +385,37 @@ int32_t casim_enc_group_add_preloaded_pod(casim_encoder* e, int32_t group, int32
     if (pod_spec < 0 || (size_t)pod_spec >= e->specs.size()) return CASIM_ERR_INVALID;
     e->groups[group].preloaded.push_back(pod_spec); return CASIM_OK;
 }
+int32_t casim_enc_add_running_pods(casim_encoder* e, int32_t n_pods, const int32_t* group, const int32_t* ns, const int64_t* req,
+                                   const int32_t* label_off, const int32_t* label_key, const int32_t* label_val,
+                                   const char* const* strings, int32_t n_strings) {
+    ENC_OPEN(e);
+    if (e->updating || n_pods < 0 || n_strings < 0) return CASIM_ERR_INVALID;
+    if (n_pods == 0) return (int32_t)e->specs.size();
+    if (!ns || !req || !label_off || !strings || (label_off[n_pods] > 0 && (!label_key || !label_val))) return CASIM_ERR_INVALID;
+    // validate everything first: nothing is added on an error
+    if (label_off[0] != 0) return CASIM_ERR_INVALID;
+    const int32_t NGr = (int32_t)e->groups.size();
+    for (int32_t i = 0; i < n_pods; ++i) {
+        if (ns[i] < 0 || ns[i] >= n_strings || label_off[i + 1] < label_off[i]) return CASIM_ERR_INVALID;
+        if (group && (group[i] < -1 || group[i] >= NGr)) return CASIM_ERR_INVALID;
+    }
+    for (int32_t k = 0; k < label_off[n_pods]; ++k)
+        if (label_key[k] < 0 || label_key[k] >= n_strings || label_val[k] < 0 || label_val[k] >= n_strings) return CASIM_ERR_INVALID;
+    std::vector<std::string> strs((size_t)n_strings);
+    for (int32_t k = 0; k < n_strings; ++k) strs[(size_t)k] = S(strings[k]);
+    const int32_t first = (int32_t)e->specs.size();
+    const int R = e->opt.n_res;
+    for (int32_t i = 0; i < n_pods; ++i) {
+        e->specs.emplace_back();
+        PodSpec& p = e->specs.back();
+        p.ns = strs[(size_t)ns[i]];
+        for (int r = 0; r < CASIM_MAX_RES; ++r) p.req[r] = r < R ? req[(size_t)i * (size_t)R + (size_t)r] : 0;
+        p.labels.v.reserve((size_t)(label_off[i + 1] - label_off[i]));
+        for (int32_t k = label_off[i]; k < label_off[i + 1]; ++k) p.labels[strs[(size_t)label_key[k]]] = strs[(size_t)label_val[k]];
+        if (group && group[i] >= 0) e->groups[(size_t)group[i]].preloaded.push_back(first + i);
+    }
+    return first;
+}
 int32_t casim_enc_group_set_pegs(casim_encoder* e, int32_t group, const int32_t* pegs, int32_t n) {
     GRP_CHECK(e, group);
     if (n < 0 || (n > 0 && !pegs)) return CASIM_ERR_INVALID;

@@ -3,6 +3,7 @@
 It walks pod / node-template objects exactly the way the cgo shim of INTEGRATION.md does and
 returns flat tables (ctypes views owned by the C++ encoder)."""
 import ctypes as C
+import dataclasses
 from typing import Dict, List, Optional, Sequence
 
 from . import _abi
@@ -230,6 +231,57 @@ class Encoder:
             check(lib.casim_enc_group_set_pegs(self._h, g, arr, len(pegs)))
         self.n_groups += 1
         return g
+
+    def add_running_pods(self, pods_of_group: Sequence[Sequence[Pod]], groups: Optional[Sequence[int]] = None):
+        """casim_enc_add_running_pods: the running pods of many nodes in ONE call (plain pods: namespace, requests, labels; anything with
+        tolerations / selectors / ports / terms goes through add_pod_spec + casim_enc_group_add_preloaded_pod as before).
+        pods_of_group[k] = pods running on group groups[k] (default: group k).  Returns the spec ids, one list per group."""
+        strings, index = [], {}
+
+        def sid(x: str) -> int:
+            if x not in index:
+                index[x] = len(strings); strings.append(x)
+            return index[x]
+
+        out = [[] for _ in pods_of_group]
+        gidx, ns, req, off, lk, lv, plain = [], [], [], [0], [], [], []
+
+        def flush():
+            # (spec ids follow the order of the pods: a pod that needs the per-pod calls ends the batch collected so far)
+            if not plain:
+                return
+            arr = lambda t, v: (t * max(len(v), 1))(*v)   # noqa: E731
+            cs = (C.c_char_p * max(len(strings), 1))(*[_b(x) for x in strings])
+            first = lib.casim_enc_add_running_pods(self._h, len(plain), arr(C.c_int32, gidx), arr(C.c_int32, ns), arr(C.c_int64, [int(x) for x in req]),
+                                                   arr(C.c_int32, off), arr(C.c_int32, lk), arr(C.c_int32, lv), cs, len(strings))
+            if first < 0:
+                check(first, "casim_enc_add_running_pods")
+            for i, (k, p) in enumerate(plain):
+                self._spec_of[id(p)] = first + i
+                out[k].append(first + i)
+            del gidx[:], ns[:], req[:], lk[:], lv[:], plain[:]
+            off[:] = [0]
+
+        for k, pods in enumerate(pods_of_group):
+            g = k if groups is None else int(groups[k])
+            for p in pods:
+                # plain = nothing but namespace, labels and requests on known lanes differs from a default Pod
+                bare = dataclasses.replace(p, name="", uid="", controller_uid="", daemonset=False, priority=0)
+                is_plain = bare == Pod(name="", namespace=p.namespace, labels=p.labels, requests=p.requests) and \
+                    not [r for r, v in p.requests.items() if r not in self.lanes and v]
+                if not is_plain or id(p) in self._spec_of:
+                    flush()
+                    s = self.add_pod_spec(p)
+                    check(lib.casim_enc_group_add_preloaded_pod(self._h, g, s))
+                    out[k].append(s)
+                    continue
+                self._keep.append(p)
+                gidx.append(g); ns.append(sid(p.namespace)); req.extend(self._lane_vector(p.requests)[:len(self.lanes)])
+                for a, b in p.labels.items():
+                    lk.append(sid(a)); lv.append(sid(b))
+                off.append(len(lk)); plain.append((k, p))
+        flush()
+        return out
 
     def add_existing_pod(self, pod: Pod, node_labels: Dict[str, str]):
         ks, vs = list(node_labels.keys()), list(node_labels.values())

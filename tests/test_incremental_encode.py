@@ -170,3 +170,34 @@ def test_content_classes_of_running_pods_threads_and_record_sharing(seed, monkey
             assert sh.get(k) == want.get(k), ("shared records", k)
     for enc in (one, four, shared):
         enc.close()
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_bulk_running_pods_give_the_same_tables(seed):
+    """casim_enc_add_running_pods (the running pods of every node in ONE call; pods with tolerations / ports / terms still one by one)
+    against the per-pod calls: every column of the node table and of the domain rules identical; bad indices add nothing."""
+    import ctypes as C
+    from kubernetes_autoscaler_amd._ffi import lib
+    w = workloads.fuzz_pending_domains(9500 + seed) if seed % 3 else workloads.fuzz_pending(9500 + seed)
+    one = _encode_per_pod_records(w.nodes, w.pods, copies=True)
+    want = _columns(one)
+    enc = Encoder(explicit_self_exclusion=True)
+    for p in w.pods:
+        enc.add_peg(PodEquivalenceGroup(pods=[p]))
+    for info in w.nodes:
+        enc.add_group(NodeInfo(info.node, []), pegs=[])
+    before = lib.casim_enc_add_running_pods(enc._h, 0, None, None, None, None, None, None, None, 0)   # (0 pods: the next spec id)
+    bad = (C.c_int32 * 1)(len(w.nodes) + 5)
+    zero = (C.c_int32 * 2)(0, 0)
+    strs = (C.c_char_p * 1)(b"default")
+    req = (C.c_int64 * 8)(*([1] * 8))
+    assert lib.casim_enc_add_running_pods(enc._h, 1, bad, zero, req, zero, None, None, strs, 1) < 0            # group out of range
+    assert lib.casim_enc_add_running_pods(enc._h, 0, None, None, None, None, None, None, None, 0) == before  # nothing was added
+    ids = enc.add_running_pods([[copy.deepcopy(q) for q in info.pods] for info in w.nodes])
+    assert [len(x) for x in ids] == [len(info.pods) for info in w.nodes]
+    enc.finalize()
+    got = _columns(enc)
+    assert got.keys() == want.keys()
+    for k in want:
+        assert got[k] == want[k], k
+    one.close(); enc.close()

@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
     const int rep = argc > 5 ? atoi(argv[5]) : 5;
     casim_encoder_options o = {}; o.n_res = 2; o.explicit_self_exclusion = 1;
     const int64_t alloc[CASIM_MAX_RES] = {16000, (int64_t)64 << 30};
-    std::vector<double> t_calls, t_fin, t_upd_calls, t_refin, t_rows;
+    std::vector<double> t_calls, t_fin, t_upd_calls, t_refin, t_rows, t_bulk_calls, t_bulk_fin;
     int32_t n_changed = 0, rc_inc = 0, rules = 0;
     for (int r = 0; r < rep; ++r) {
         rng_state = 2463534242u;
@@ -94,12 +94,55 @@ int main(int argc, char** argv) {
         const double t6 = now_ms();
         t_calls.push_back(t1 - t0); t_fin.push_back(t2 - t1); t_upd_calls.push_back(t4 - t3); t_refin.push_back(t5 - t4); t_rows.push_back(t6 - t5);
         casim_enc_destroy(e);
+        // ---- the same cluster with the running pods handed over in ONE call (casim_enc_add_running_pods): what a shim that keeps its pods in
+        // flat arrays pays; the string table holds every distinct namespace / label key / label value once ----
+        {
+            rng_state = 2463534242u;
+            casim_encoder* b = casim_enc_create(&o);
+            const double u0 = now_ms();
+            for (int c = 0; c < C; ++c) {
+                int64_t req[CASIM_MAX_RES] = {250 + 250 * (c % 8), (int64_t)(512 + 256 * (c % 5)) << 20};
+                const int32_t s = casim_enc_add_pod_spec(b, "default", req);
+                const std::string app = "pending-" + std::to_string(c);
+                casim_enc_pod_add_label(b, s, "app", app.c_str());
+                casim_enc_pod_add_toleration(b, s, "dedicated", "Equal", (c % 7) ? "batch" : "infra", "NoSchedule");
+                if (c % 3 == 0) casim_enc_pod_add_node_selector(b, s, "pool", (c % 2) ? "general" : "highmem");
+                if (c % 4 == 0) { const int32_t ci = casim_enc_pod_add_spread_constraint(b, s, 1 + c % 3, "topology.kubernetes.io/zone", 0);
+                                  const char* v[1] = {app.c_str()}; casim_enc_spread_add_requirement(b, s, ci, "app", "In", v, 1); }
+                if (c % 16 == 1) { const int32_t t = casim_enc_pod_add_anti_affinity_term(b, s, "kubernetes.io/hostname", nullptr, 0);
+                                   const char* v[1] = {app.c_str()}; casim_enc_term_add_requirement(b, s, t, "app", "In", v, 1); }
+                casim_enc_add_peg(b, s, 1 + (int32_t)(rnd() % 40));
+            }
+            // string table: "default", "app", "tier", "backend", "frontend", app-0 .. app-1499
+            std::vector<std::string> tab = {"default", "app", "tier", "backend", "frontend"};
+            for (int k = 0; k < 1500; ++k) tab.push_back("app-" + std::to_string(k));
+            std::vector<const char*> strs; for (auto& x : tab) strs.push_back(x.c_str());
+            std::vector<int32_t> grp, nsx, loff = {0}, lk, lv; std::vector<int64_t> rq;
+            for (int n = 0; n < N; ++n) {
+                const int32_t g = casim_enc_add_group(b, "", alloc, 110, 16000, (int64_t)64 << 30, 0);
+                for (int k = 0; k < P; ++k) {
+                    const int ctl = (int)(rnd() % 1500);
+                    grp.push_back(g); nsx.push_back(0);
+                    rq.push_back(100 + 50 * (ctl % 5)); rq.push_back((int64_t)(128 + 64 * (ctl % 4)) << 20);
+                    lk.push_back(1); lv.push_back(5 + ctl); lk.push_back(2); lv.push_back((ctl % 3) ? 3 : 4);
+                    loff.push_back((int32_t)lk.size());
+                }
+                describe_node(b, g, n, {});
+            }
+            const int32_t first = casim_enc_add_running_pods(b, (int32_t)grp.size(), grp.data(), nsx.data(), rq.data(), loff.data(), lk.data(), lv.data(), strs.data(), (int32_t)strs.size());
+            const double u1 = now_ms();
+            if (first < 0 || casim_enc_finalize(b) != CASIM_OK) { fprintf(stderr, "bulk encode failed\n"); return 1; }
+            const double u2 = now_ms();
+            t_bulk_calls.push_back(u1 - u0); t_bulk_fin.push_back(u2 - u1);
+            casim_enc_destroy(b);
+        }
     }
     auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
     printf("{\"what\": \"incremental re-encode, per-node mode\", \"nodes\": %d, \"running_pods\": %d, \"classes\": %d, \"domain_rules\": %d, \"churn_percent\": %.2f, "
            "\"full\": {\"encoder_calls_ms\": %.3f, \"finalize_ms\": %.3f, \"encode_ms\": %.3f}, "
+           "\"full_with_bulk_running_pods\": {\"encoder_calls_ms\": %.3f, \"finalize_ms\": %.3f, \"encode_ms\": %.3f}, "
            "\"incremental\": {\"status\": %d, \"nodes_re_described\": %d, \"encoder_calls_ms\": %.3f, \"refinalize_ms\": %.3f, \"group_rows_ms\": %.3f, \"encode_ms\": %.3f}}\n",
-           N, N * P, C, rules, churn, med(t_calls), med(t_fin), med(t_calls) + med(t_fin), rc_inc, n_changed, med(t_upd_calls), med(t_refin), med(t_rows),
+           N, N * P, C, rules, churn, med(t_calls), med(t_fin), med(t_calls) + med(t_fin), med(t_bulk_calls), med(t_bulk_fin), med(t_bulk_calls) + med(t_bulk_fin), rc_inc, n_changed, med(t_upd_calls), med(t_refin), med(t_rows),
            med(t_upd_calls) + med(t_refin) + med(t_rows));
     return 0;
 }
