@@ -206,7 +206,7 @@ func (s *session) tables() (pegs C.casim_pegs, groups C.casim_groups, err error)
 // namespace, labels and requests go into flat arrays with an interned string table (no C string per label); a pod with
 // tolerations, selectors, host ports or (anti-)affinity terms ends the batch collected so far and takes the per-pod calls, so
 // that spec ids follow the order of the pods.  groups[i] is the encoder's group id of nodes[i].
-func (s *session) runningPods(nodes []*framework.NodeInfo, groups []C.int32_t) {
+func (s *session) runningPods(nodes []*framework.NodeInfo, groups []C.int32_t) error {
 	var grp, ns, off, lk, lv []C.int32_t
 	var req []C.int64_t
 	off = append(off, 0)
@@ -221,6 +221,7 @@ func (s *session) runningPods(nodes []*framework.NodeInfo, groups []C.int32_t) {
 		strs = append(strs, s.strs.s(x))
 		return i
 	}
+	var firstErr error
 	flush := func() {
 		if len(grp) == 0 {
 			return
@@ -229,7 +230,11 @@ func (s *session) runningPods(nodes []*framework.NodeInfo, groups []C.int32_t) {
 		if len(lk) > 0 {
 			pk, pv = &lk[0], &lv[0]
 		}
-		C.casim_enc_add_running_pods(s.enc, C.int32_t(len(grp)), &grp[0], &ns[0], &req[0], &off[0], pk, pv, &strs[0], C.int32_t(len(strs)))
+		// the call adds NOTHING on a bad index (casim.h): a dropped batch would leave nodes emptier than they are, so the
+		// first error ends the session — the caller falls back to the Go path for this loop
+		if rc := C.casim_enc_add_running_pods(s.enc, C.int32_t(len(grp)), &grp[0], &ns[0], &req[0], &off[0], pk, pv, &strs[0], C.int32_t(len(strs))); rc < 0 && firstErr == nil {
+			firstErr = rcErr(rc, "casim_enc_add_running_pods")
+		}
 		grp, ns, req, lk, lv, off = grp[:0], ns[:0], req[:0], lk[:0], lv[:0], append(off[:0], 0)
 	}
 	plain := func(p *apiv1.Pod) bool {
@@ -266,4 +271,5 @@ func (s *session) runningPods(nodes []*framework.NodeInfo, groups []C.int32_t) {
 		}
 	}
 	flush()
+	return firstErr
 }

@@ -7,11 +7,13 @@ package gpubinpacking
 import "C"
 
 import (
-	"unsafe"
+	"strconv"
+	"sync"
 
 	apiv1 "k8s.io/api/core/v1"
 	"k8s.io/autoscaler/cluster-autoscaler/cloudprovider"
 	"k8s.io/autoscaler/cluster-autoscaler/estimator"
+	"k8s.io/autoscaler/cluster-autoscaler/metrics"
 	"k8s.io/autoscaler/cluster-autoscaler/simulator/clustersnapshot"
 	"k8s.io/autoscaler/cluster-autoscaler/simulator/framework"
 )
@@ -32,7 +34,28 @@ type gpuEstimator struct {
 	context  estimator.EstimationContext
 	fastpath bool
 	shared   *Shared             // nil = per-call mode only
+	runner   *runnerState        // lastIndex of THIS snapshot's plugin runner, as the shim threads it (never nil)
 	fallback estimator.Estimator // the reference's BinpackingNodeEstimator: groups outside the encoded predicate subset
+}
+
+// runnerState is the one piece of SchedulerPluginRunner state an Estimate reads and writes: lastIndexOrderMapping.lastIndex
+// (cluster-autoscaler/simulator/clustersnapshot/scheduling_opts.go:39-63).  In the reference the runner lives inside the snapshot
+// (predicate/predicate_snapshot.go:64) and its lastIndex survives every Estimate of every loop (plugin_runner.go:33-36,138); the
+// orchestrator builds a fresh estimator per node group (orchestrator.go:409-413), so the shim keeps one runnerState per snapshot
+// OUTSIDE the estimators — in prefetch mode and in per-call mode alike (the analyser path has no Shared).
+type runnerState struct {
+	mu        sync.Mutex
+	lastIndex int
+}
+
+var runnerStates sync.Map // clustersnapshot.ClusterSnapshot -> *runnerState
+
+func runnerOf(snapshot clustersnapshot.ClusterSnapshot) *runnerState {
+	if st, ok := runnerStates.Load(snapshot); ok {
+		return st.(*runnerState)
+	}
+	st, _ := runnerStates.LoadOrStore(snapshot, &runnerState{})
+	return st.(*runnerState)
 }
 
 // New is what NewEstimatorBuilder (builder.go) returns for every (snapshot, context) pair.
@@ -41,13 +64,39 @@ func New(engine *Engine, snapshot clustersnapshot.ClusterSnapshot, limiter Devic
 	if engine == nil {
 		return fallback
 	}
-	return &gpuEstimator{engine: engine, snapshot: snapshot, limiter: limiter, context: context, fastpath: fastpath, shared: shared, fallback: fallback}
+	return &gpuEstimator{engine: engine, snapshot: snapshot, limiter: limiter, context: context, fastpath: fastpath, shared: shared,
+		runner: runnerOf(snapshot), fallback: fallback}
+}
+
+// observeHeterogeneity restates estimator.observeBinpackingHeterogeneity (binpacking_estimator.go:371-396; unexported there, and
+// package estimator does not change) on top of the exported metric (metrics/legacy_functions.go:245).
+func observeHeterogeneity(pegs []estimator.PodEquivalenceGroup, tmpl *framework.NodeInfo) {
+	var instanceType, cpuCount string
+	if node := tmpl.Node(); node != nil {
+		if node.Labels != nil {
+			instanceType = node.Labels[apiv1.LabelInstanceTypeStable]
+		}
+		cpuCount = node.Status.Capacity.Cpu().String()
+	}
+	namespaces := map[string]bool{}
+	for i := range pegs {
+		if e := pegs[i].Exemplar(); e != nil {
+			namespaces[e.Namespace] = true
+		}
+	}
+	bucket := "11+" // (quantized: metric cardinality)
+	if len(namespaces) <= 5 {
+		bucket = strconv.Itoa(len(namespaces))
+	} else if len(namespaces) <= 10 {
+		bucket = "6-10"
+	}
+	metrics.ObserveBinpackingHeterogeneity(instanceType, cpuCount, bucket, len(pegs))
 }
 
 // Estimate implements estimator.Estimator (estimator.go:53-56) with the semantics of BinpackingNodeEstimator.Estimate
 // (binpacking_estimator.go:102-161): node count, and the pods that fit in placement order.
 func (g *gpuEstimator) Estimate(pegs []estimator.PodEquivalenceGroup, tmpl *framework.NodeInfo, ng cloudprovider.NodeGroup) (int, []*apiv1.Pod) {
-	observeBinpackingHeterogeneity(pegs, tmpl) // the metric stays on the Go side (binpacking_estimator.go:107)
+	observeHeterogeneity(pegs, tmpl) // the metric stays on the Go side (binpacking_estimator.go:107)
 	g.limiter.StartEstimation(pegs, ng, g.context)
 	defer g.limiter.EndEstimation()
 	maxNodes := g.limiter.MaxNodes()
@@ -57,6 +106,8 @@ func (g *gpuEstimator) Estimate(pegs []estimator.PodEquivalenceGroup, tmpl *fram
 	if g.shared != nil {
 		if r, order, placed, ok := g.shared.lookup(ng, tmpl, pegs, maxNodes, existing); ok {
 			if r.status == C.CASIM_NG_OK {
+				// (a hit leaves the runner's lastIndex where the batch found it: every group of a batch starts from the same
+				// loopLastIndex, INTEGRATION.md 1a; the per-call path below is the one that threads it from Estimate to Estimate)
 				return int(r.node_count), prefixPods(pegs, order, placed)
 			}
 			return g.fallback.Estimate(pegs, tmpl, ng) // the batch delegated this group (CASIM_NG_UNSUPPORTED)
@@ -119,17 +170,15 @@ func nodeCount(s clustersnapshot.ClusterSnapshot) int {
 }
 
 // lastIndex / setLastIndex: the shim never runs the snapshot's SchedulerPluginRunner for simulated pods, so it keeps the
-// runner's lastIndex (scheduling_opts.go:39-63) itself, per snapshot, shared by the estimators of a loop.
+// runner's lastIndex (scheduling_opts.go:39-63) itself, per snapshot (runnerState), shared by every estimator built on that
+// snapshot — with or without a prefetch cache.
 func (g *gpuEstimator) lastIndex() int {
-	if g.shared != nil {
-		return g.shared.lastIndex
-	}
-	return 0
+	g.runner.mu.Lock()
+	defer g.runner.mu.Unlock()
+	return g.runner.lastIndex
 }
 func (g *gpuEstimator) setLastIndex(v int) {
-	if g.shared != nil {
-		g.shared.lastIndex = v
-	}
+	g.runner.mu.Lock()
+	g.runner.lastIndex = v
+	g.runner.mu.Unlock()
 }
-
-var _ = unsafe.Pointer(nil)

@@ -28,8 +28,7 @@ type Shared struct {
 	limiter       DeviceLimiter
 	maxNodesTotal int
 	fastpath      bool
-	lastIndex     int // lastIndexOrderMapping.lastIndex of the snapshot's runner, as the shim threads it
-	loopLastIndex int // ... when the batch of the current loop was filled: every group of the batch starts from it
+	loopLastIndex int // the snapshot runner's lastIndex (estimator.go: runnerState) when the batch of the current loop was filled: every group of the batch starts from it
 }
 
 // EstimatorName is the --estimator value that selects this package (autoscaler_go.patch).
@@ -86,7 +85,10 @@ func (s *Shared) fill(autoscalingCtx *ca_context.AutoscalingContext, pegs []esti
 		pkeys[i] = pegKey(p)
 	}
 	existing := nodeCount(autoscalingCtx.ClusterSnapshot)
-	s.loopLastIndex = s.lastIndex
+	rs := runnerOf(autoscalingCtx.ClusterSnapshot)
+	rs.mu.Lock()
+	s.loopLastIndex = rs.lastIndex
+	rs.mu.Unlock()
 	gkeys := make([]C.uint64_t, 0, len(ngs))
 	for _, ng := range ngs {
 		tmpl, ok := infos[ng.Id()]
@@ -99,6 +101,9 @@ func (s *Shared) fill(autoscalingCtx *ca_context.AutoscalingContext, pegs []esti
 		sess.group(tmpl, s.limiter.MaxNodes(), existing, s.loopLastIndex, nil)
 		s.limiter.EndEstimation()
 		gkeys = append(gkeys, groupKey(ng, tmpl))
+	}
+	if len(gkeys) == 0 { // no candidate group came with a template: nothing to prefetch (and no &gkeys[0] to take)
+		return nil
 	}
 	pt, gt, err := sess.tables()
 	if err != nil {
