@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CASIM_ABI_VERSION 6   /* 2: casim_removal_candidates.cand_atomic, casim_domain_rules.n_taint_policy_rules
+#define CASIM_ABI_VERSION 7   /* 2: casim_removal_candidates.cand_atomic, casim_domain_rules.n_taint_policy_rules
                                * 3: casim_groups.{peg_lo,peg_hi,global_id,n_sims,sim_offsets}, casim_best_option_sims,
                                *    casim_feasibility_reasons, casim_estimate_batch_timed, casim_mctx_*, casim_cluster_*
                                * 4: casim_options.n_streams (sub-batches on internal HIP streams), casim_enc_group_pods,
@@ -41,7 +41,8 @@ extern "C" {
                                *    casim_problem_info [5], [6], casim_option_query.join_stream, casim_prefetch_*, casim_enc_begin_update / _group_reset / _refinalize / _group_rows
                                * 6: casim_pegs.zone_polarity (group bits of NEED polarity: required pod affinity towards a partner of the batch);
                                *    later, without a new number (layouts unchanged, zero keeps its meaning): casim_options.no_front_kernel in one of
-                               *    the two reserved words, casim_problem_info [7] */
+                               *    the two reserved words, casim_problem_info [7]
+                               * 7: casim_cluster_forget_commits */
 
 /* Resource lanes.  Lane 0 = cpu in millicores (Quantity.MilliValue), lane 1 = memory bytes,
  * lane 2 = ephemeral-storage bytes, lanes 3.. = scalar / extended resources (Quantity.Value),
@@ -74,6 +75,7 @@ extern "C" {
                                           (all nodes of a group clone one template)   */
 #define CASIM_PEG_FASTPATH_OK 0x8u     /* shouldUseFastPath  CA/estimator/binpacking_estimator.go:411 */
 #define CASIM_PEG_FASTPATH_AA_SELF 0x10u /* numNodesByAntiAffinity = len(pods)  :444-450      */
+#define CASIM_PEG_FLAG_MASK 0x3fu      /* the caller's bits; every other bit of casim_pegs.flags is reserved and must be zero (CASIM_ERR_INVALID) */
 #define CASIM_PEG_UNSUPPORTED 0x20u    /* needs fallback (affinity, topology spread, DRA, ...)   */
 
 /* ---- group flags (casim_groups.flags) ---------------------------------------------------- */
@@ -589,6 +591,10 @@ int32_t casim_time_node_removals(casim_ctx* ctx, const casim_pegs* classes, cons
  * pod) to count_init / node_contrib itself, with the kernels' increment rule, so that spread / zone anti-affinity / pod-affinity
  * counters see them the way the reference's one ClusterSnapshot does.  casim_cluster_update_nodes makes it forget the pods it
  * committed to the replaced nodes: their new records, and counters derived with them, describe those nodes from then on.
+ * casim_cluster_forget_commits: for a caller whose NEXT rules were built from a snapshot that already holds the committed pods
+ * (a shim that rebuilds its domain rules from a fresh snapshot every loop and keeps the resident cluster): the cluster stops
+ * adding the pods committed so far to count_init / node_contrib — without it they would be counted twice, silently.  The image
+ * itself (requests, pod counts, exclusion bits) is untouched; pods committed afterwards are remembered again.
  * casim_cluster_stats: out[0] full uploads (1), [1] node rows replaced by deltas, [2] commits, [3] nodes.
  */
 typedef struct casim_cluster casim_cluster;
@@ -600,6 +606,7 @@ int32_t casim_cluster_try_schedule_pods(casim_cluster* c, const casim_pod_sequen
 int32_t casim_cluster_simulate_node_removals(casim_cluster* c, const casim_removal_candidates* cand, casim_removal_results* out);
 int32_t casim_cluster_fetch_nodes(casim_cluster* c, int64_t* init_req_out, int32_t* init_pods_out, uint64_t* init_excl_out);
 int32_t casim_cluster_stats(const casim_cluster* c, int64_t out[4]);
+int32_t casim_cluster_forget_commits(casim_cluster* c);
 
 /*
  * BinpackingNodeEstimator.Estimate on the whole snapshot (CA/estimator/binpacking_estimator.go:102-342):
@@ -837,7 +844,9 @@ int32_t casim_enc_add_existing_pod(casim_encoder* e, int32_t pod_spec, const cha
  * spread constraints of its own, or a class's anti-affinity term matching it), a node without a hostname label next to hostname
  * bits, nodes or classes added — the session stays open and casim_enc_finalize rebuilds everything from the objects the encoder
  * holds (nothing has to be described again).  Results after an update are identical to a full finalize of the same objects
- * (tests/test_incremental_encode.py compares every column). */
+ * (tests/test_incremental_encode.py compares every column).
+ * casim_enc_refinalize with changed_out != NULL and capacity < the number of changed nodes: CASIM_ERR_INVALID, nothing recomputed, the
+ * session stays open and *n_changed_out holds the capacity needed (a truncated list would leave the device image stale). */
 #define CASIM_ENC_NEEDS_FULL 65
 int32_t casim_enc_begin_update(casim_encoder* e);
 int32_t casim_enc_group_reset(casim_encoder* e, int32_t group, const int64_t* alloc, int32_t allowed_pods, int64_t capacity_cpu_milli,

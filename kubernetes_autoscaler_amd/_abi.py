@@ -3,7 +3,7 @@ shared library happens in _ffi.py).  Kept separate so that test harnesses that c
 structs can reuse the layouts without loading the product library."""
 import ctypes as C
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_RES = 8
 
 OK = 0
@@ -174,6 +174,7 @@ PROTOTYPES = {
     "casim_cluster_simulate_node_removals": (C.c_int32, [C.c_void_p, C.POINTER(RemovalCandidates), C.POINTER(RemovalResults)]),
     "casim_cluster_fetch_nodes": (C.c_int32, [C.c_void_p, i64p, i32p, u64p]),
     "casim_cluster_stats": (C.c_int32, [C.c_void_p, i64p]),
+    "casim_cluster_forget_commits": (C.c_int32, [C.c_void_p]),
     "casim_problem_time": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "casim_problem_run_marked": (C.c_int32, [C.c_void_p]),
     "casim_problem_marked_ms": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),

@@ -1448,6 +1448,13 @@ int32_t casim_enc_refinalize(casim_encoder* e, int32_t* changed_out, int32_t cap
     const int Wt = e->Wt, Wl = e->Wl, Wx = e->Wx;
     const bool cmp_ops = e->opt.enable_taint_comparison_ops != 0;
     if (e->groups.size() != NG || e->pegs.size() != G) return CASIM_ENC_NEEDS_FULL;   // nodes or classes were added
+    // the changed-node list must fit the caller's array BEFORE anything is recomputed: a truncated list would leave rows the caller
+    // never ships to casim_cluster_update_nodes (a stale device image) with no way to get them back — the session stays open,
+    // n_changed_out says what is needed
+    if (changed_out && (capacity < 0 || (size_t)capacity < fs.dirty_list.size())) {
+        if (n_changed_out) *n_changed_out = (int32_t)fs.dirty_list.size();
+        return CASIM_ERR_INVALID;
+    }
     // ---- 1. nothing may touch a dictionary ----
     bool hostname_bits = !fs.port_bit.empty() || !fs.pre_occ_bit.empty() || !fs.with_terms.empty();
     if (fs.running.size() < e->specs.size()) fs.running.resize(e->specs.size(), 0);
@@ -1742,8 +1749,8 @@ int32_t casim_enc_add_grouped_pegs(casim_encoder* e, int32_t n_pods, const int32
         ++count[group[i]];
     }
     const int32_t base = (int32_t)e->pegs.size();
+    for (int32_t g = 0; g < n_groups; ++g) if (first[g] < 0) return CASIM_ERR_INVALID;   // (an empty group: nothing is added at all)
     for (int32_t g = 0; g < n_groups; ++g) {
-        if (first[g] < 0) return CASIM_ERR_INVALID;
         e->pegs.push_back(Peg{first[g], count[g]});
         if (peg_ids_out) peg_ids_out[g] = base + g;
     }

@@ -955,6 +955,12 @@ int32_t casim_cluster_stats(const casim_cluster* h, int64_t out[4]) {
     h->c->stats(out);
     return CASIM_OK;
 }
+int32_t casim_cluster_forget_commits(casim_cluster* h) {
+    g_err.clear();
+    if (!h || !h->c) return set_err(CASIM_ERR_INVALID, "null cluster");
+    h->c->forget_commits();
+    return CASIM_OK;
+}
 
 // ---- scale-down removal simulation ----------------------------------------------
 int32_t casim_simulate_node_removals(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes,

@@ -204,6 +204,13 @@ public:
         if (p->n_pegs < 0 || g->n_groups < 0) return fail(CASIM_ERR_INVALID, "negative size");
         if (p->n_res < 2 || p->n_res > CASIM_KMAX_RES) return fail(CASIM_ERR_INVALID, "n_res must be in [2, 8]");
         if (p->w_taint < 0 || p->w_label < 0 || p->w_excl < 0 || p->w_zone < 0) return fail(CASIM_ERR_INVALID, "negative mask width");
+        // the caller's flag words carry CASIM_PEG_* only: the bits above them are the library's own (CASIM_KFLAG_SINGLETON_RUN changes the
+        // lastIndex rule of the packer, CASIM_REC_* / CASIM_KFLAG_STATIC_OK are record bits) — a caller that sets one is refused, not obeyed
+        if (p->n_pegs > 0 && p->flags) {
+            uint32_t acc = 0;
+            for (int32_t i = 0; i < p->n_pegs; ++i) acc |= p->flags[i];
+            if (acc & ~(uint32_t)CASIM_PEG_FLAG_MASK) return fail(CASIM_ERR_INVALID, "PEG flags: a reserved bit is set (only CASIM_PEG_* bits 0-5 belong to the caller)");
+        }
         if (runs_.build(p, g, o)) { p = &runs_.p; g = &runs_.g; }   // adjacent identical singleton PEGs become one row (SingletonRuns)
         G_ = p->n_pegs; NG_ = g->n_groups;
         memset(&dt_, 0, sizeof dt_); memset(&dr_, 0, sizeof dr_); memset(&ps_, 0, sizeof ps_); memset(&os_, 0, sizeof os_);

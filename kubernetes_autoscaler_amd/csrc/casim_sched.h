@@ -31,6 +31,7 @@
 #include <string.h>
 
 #include <map>
+#include <unordered_map>
 #include <string>
 #include <utility>
 #include <vector>
@@ -1206,9 +1207,9 @@ public:
         if (!committed_.empty()) {   // the new records (and the caller's rule counters) describe these nodes from now on
             std::vector<uint8_t> gone((size_t)dt_.NG, 0);
             for (int k = 0; k < n; ++k) gone[(size_t)idx[k]] = 1;
-            size_t w = 0;
-            for (size_t i = 0; i < committed_.size(); ++i) if (!gone[(size_t)committed_[i].node]) committed_[w++] = committed_[i];
-            committed_.resize(w);
+            for (auto it = committed_.begin(); it != committed_.end();) {
+                if (gone[(size_t)(uint32_t)(it->first & 0xffffffffull)]) { committed_total_ -= it->second; it = committed_.erase(it); } else ++it;
+            }
         }
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
     }
@@ -1242,7 +1243,7 @@ public:
         // what the committed pods mean for the domain rules of LATER calls: the caller's count_init / node_contrib come from the
         // encoder, which saw the snapshot before this commit (with_committed adds them back in)
         if (folds && rc == CASIM_OK)
-            for (int32_t i = 0; i < q->n_pods; ++i) if (node_out[i] >= 0) committed_.push_back({q->pod_class[i], node_out[i]});
+            for (int32_t i = 0; i < q->n_pods; ++i) if (node_out[i] >= 0) { committed_[((uint64_t)(uint32_t)q->pod_class[i] << 32) | (uint32_t)node_out[i]] += 1; committed_total_++; }
         return rc;
     }
     // the planner's removal loop on the committed image (its own Fork / Revert: nothing persists)
@@ -1262,7 +1263,11 @@ public:
         if (rc < 0) err_ = s.error();
         return rc;
     }
-    int64_t committed_pods() const { return (int64_t)committed_.size(); }
+    int64_t committed_pods() const { return committed_total_; }
+    // The caller's NEXT rules already contain every pod committed so far (its encoder re-read the snapshot after the commits —
+    // a shim that rebuilds its domain rules from a fresh snapshot each loop but keeps the resident cluster): nothing is added to
+    // count_init / node_contrib for them any more.  Commits made after this call are remembered again.
+    void forget_commits() { committed_.clear(); committed_total_ = 0; }
     // the committed image of the mutable node columns (tests, and a shim that wants to cross-check its snapshot)
     int32_t fetch_nodes(int64_t* init_req_out, int32_t* init_pods_out, uint64_t* init_excl_out) {
         if (!ready_) return fail(CASIM_ERR_INVALID, "cluster not initialised");
@@ -1306,20 +1311,27 @@ private:
         if (in->n_nodes != dt_.NG) return fail(CASIM_ERR_INVALID, "domain rules describe another node table");
         if (!in->rule_offset || !in->rule_key || !in->rule_elig_row || !in->node_domain || !in->inc_off || !in->count_init)
             return fail(CASIM_ERR_INVALID, "domain rules miss a column");
+        if (in->n_classes > 0 && in->inc_off[in->n_classes] > 0 && !in->inc_rule) return fail(CASIM_ERR_INVALID, "domain rules: inc_off lists rules but inc_rule is null");
+        for (int32_t r = 0; r < in->n_rules; ++r)
+            if (in->rule_elig_row[r] >= 0 && !in->elig_bits) return fail(CASIM_ERR_INVALID, "domain rules: a rule names an eligibility row but elig_bits is null");
         const int64_t N = in->n_nodes, total = in->rule_offset[in->n_rules];
         pr.count.assign(in->count_init, in->count_init + total);
         if (in->node_contrib) pr.contrib.assign(in->node_contrib, in->node_contrib + (int64_t)in->n_rules * N);
         const int64_t wpr = (N + 63) / 64;
-        for (const Placed& pl : committed_) {
-            if (pl.cls < 0 || pl.cls >= in->n_classes) continue;   // (a class the rules do not know increments nothing)
-            for (int32_t ii = in->inc_off[pl.cls]; ii < in->inc_off[pl.cls + 1]; ++ii) {
+        // one entry per (class, node) with the number of pods committed there: the cost of a call is O(distinct pairs x rules of the
+        // class), however many pods the iteration has committed
+        for (const auto& kv : committed_) {
+            const int32_t cls = (int32_t)(kv.first >> 32), node = (int32_t)(uint32_t)(kv.first & 0xffffffffull), k = kv.second;
+            if (cls < 0 || cls >= in->n_classes || node >= N) continue;   // (a class the rules do not know increments nothing)
+            for (int32_t ii = in->inc_off[cls]; ii < in->inc_off[cls + 1]; ++ii) {
                 const int32_t r = in->inc_rule[ii];
-                const int32_t d = in->node_domain[(int64_t)in->rule_key[r] * N + pl.node];
+                if (r < 0 || r >= in->n_rules) return fail(CASIM_ERR_INVALID, "domain rules: inc_rule out of range");
+                const int32_t d = in->node_domain[(int64_t)in->rule_key[r] * N + node];
                 const int32_t row = in->rule_elig_row[r];
-                const bool el = row < 0 || ((in->elig_bits[(int64_t)row * wpr + (pl.node >> 6)] >> (pl.node & 63)) & 1ull);
+                const bool el = row < 0 || ((in->elig_bits[(int64_t)row * wpr + (node >> 6)] >> (node & 63)) & 1ull);
                 if (d >= 0 && el) {
-                    pr.count[(size_t)(in->rule_offset[r] + d)] += 1;
-                    if (!pr.contrib.empty()) pr.contrib[(size_t)((int64_t)r * N + pl.node)] += 1;
+                    pr.count[(size_t)(in->rule_offset[r] + d)] += k;
+                    if (!pr.contrib.empty()) pr.contrib[(size_t)((int64_t)r * N + node)] += k;
                 }
             }
         }
@@ -1329,8 +1341,8 @@ private:
         pr.rules = &pr.copy;
         return CASIM_OK;
     }
-    struct Placed { int32_t cls, node; };
-    std::vector<Placed> committed_;
+    std::unordered_map<uint64_t, int32_t> committed_;   // (class << 32 | node) -> pods committed there since the node's record was last replaced
+    int64_t committed_total_ = 0;
     BK& bk_;
     DevTables dt_;
     casim_pegs hp_; casim_groups hg_;

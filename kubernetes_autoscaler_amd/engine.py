@@ -342,6 +342,10 @@ class ResidentCluster:
         check(lib.casim_cluster_fetch_nodes(self._h, _ptr(req, C.c_int64), _ptr(pods, C.c_int32), _ptr(excl, C.c_uint64)), "casim_cluster_fetch_nodes")
         return req[:self.n_nodes], pods[:self.n_nodes], excl[:self.n_nodes, :self.w_excl]
 
+    def forget_commits(self):
+        """the caller's next rules come from a snapshot that already holds the committed pods (casim.h)"""
+        check(lib.casim_cluster_forget_commits(self._h), "casim_cluster_forget_commits")
+
     def stats(self):
         out = (C.c_int64 * 4)()
         check(lib.casim_cluster_stats(self._h, out), "casim_cluster_stats")

@@ -160,6 +160,7 @@ EMU_API int32_t emu_cluster_fetch_nodes(void* p, int64_t* init_req, int32_t* ini
     EmuCluster* h = (EmuCluster*)p; return h->c->fetch_nodes(init_req, init_pods, init_excl);
 }
 EMU_API int32_t emu_cluster_stats(void* p, int64_t out[4]) { ((EmuCluster*)p)->c->stats(out); return 0; }
+EMU_API int32_t emu_cluster_forget_commits(void* p) { ((EmuCluster*)p)->c->forget_commits(); return 0; }
 
 EMU_API int32_t emu_feasibility_reasons(const casim_pegs* pegs, const casim_groups* groups, const uint64_t* port_block, uint16_t* out_codes) {
     EmuBackend bk;

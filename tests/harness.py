@@ -570,6 +570,7 @@ class EmuCluster:
             L.emu_cluster_simulate_node_removals.argtypes = [C.c_void_p, C.POINTER(_abi.RemovalCandidates), C.POINTER(_abi.RemovalResults)]
             L.emu_cluster_fetch_nodes.argtypes = [C.c_void_p, _abi.i64p, _abi.i32p, _abi.u64p]
             L.emu_cluster_stats.argtypes = [C.c_void_p, _abi.i64p]
+            L.emu_cluster_forget_commits.argtypes = [C.c_void_p]
             L._cluster_bound = True
         self.n_nodes, self.n_res, self.w_excl = nodes.n_groups, classes.n_res, classes.w_excl
         self._h = L.emu_cluster_create(C.byref(classes), C.byref(nodes), int(lds_budget))
@@ -613,6 +614,9 @@ class EmuCluster:
         excl = np.zeros((max(self.n_nodes, 1), max(self.w_excl, 1)), np.uint64)
         self.L.emu_cluster_fetch_nodes(self._h, req.ctypes.data_as(_abi.i64p), pods.ctypes.data_as(_abi.i32p), excl.ctypes.data_as(_abi.u64p))
         return req[:self.n_nodes], pods[:self.n_nodes], excl[:self.n_nodes, :self.w_excl]
+
+    def forget_commits(self):
+        assert self.L.emu_cluster_forget_commits(self._h) == 0
 
     def stats(self):
         out = (C.c_int64 * 4)()

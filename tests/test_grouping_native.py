@@ -152,6 +152,25 @@ def test_grouped_pegs_feed_the_encoder():
     a.close(); b.close()
 
 
+def test_an_empty_group_adds_no_peg_at_all():
+    """casim_enc_add_grouped_pegs used to push the PEGs in front of the first empty group before it noticed"""
+    from kubernetes_autoscaler_amd import _abi
+    from kubernetes_autoscaler_amd._ffi import lib
+    import ctypes as C
+    rng = random.Random(9)
+    pods = [_random_pod(rng, i) for i in range(6)]
+    e = Encoder()
+    spec = np.array([e.add_pod_spec(p) for p in pods], np.int32)
+    gid = np.array([0, 0, 1, 3, 3, 3], np.int32)   # group 2 is empty
+    ids = np.full(4, -7, np.int32)
+    assert lib.casim_enc_add_grouped_pegs(e._h, 6, spec.ctypes.data_as(_abi.i32p), gid.ctypes.data_as(_abi.i32p), 4, ids.ctypes.data_as(_abi.i32p)) == _abi.ERR_INVALID
+    assert list(ids) == [-7] * 4
+    gid2 = np.array([0, 0, 1, 2, 2, 2], np.int32)
+    assert lib.casim_enc_add_grouped_pegs(e._h, 6, spec.ctypes.data_as(_abi.i32p), gid2.ctypes.data_as(_abi.i32p), 3, ids.ctypes.data_as(_abi.i32p)) == 0   # first id 0: nothing was left behind
+    assert list(ids[:3]) == [0, 1, 2]
+    e.close()
+
+
 def test_invalid_arguments_are_refused():
     from kubernetes_autoscaler_amd import _abi
     from kubernetes_autoscaler_amd._ffi import lib

@@ -112,6 +112,34 @@ def test_incremental_update_equals_a_full_finalize(seed):
     a.close(); b.close()
 
 
+def test_a_changed_list_that_does_not_fit_is_refused_before_anything_is_recomputed():
+    """with capacity < changed nodes the list used to be truncated and the dirty set cleared — rows the caller could never ship
+    to casim_cluster_update_nodes.  Now: CASIM_ERR_INVALID, the needed capacity in n_changed_out, the session still open; the retry with
+    room gives the tables of a full finalize."""
+    import random
+    from kubernetes_autoscaler_amd._ffi import lib
+    w = workloads.fuzz_pending(9007)
+    a, b = _encode(w.nodes, w.pods), _encode(w.nodes, w.pods)
+    new_nodes, changed = _churn(w.nodes, random.Random(3))
+    assert len(changed) >= 2
+    for enc in (a, b):
+        enc.begin_update()
+        for m in changed:
+            enc.reset_group(m, new_nodes[m])
+    small = np.zeros(1, np.int32)
+    n = C.c_int32(0)
+    assert lib.casim_enc_refinalize(a._h, small.ctypes.data_as(_abi.i32p), 1, C.byref(n)) == _abi.ERR_INVALID
+    assert n.value == len(changed)
+    ok, idx = a.refinalize()                                        # the session is still open: same call with room
+    assert lib.casim_enc_finalize(b._h) == 0
+    got, want = _columns(a), _columns(b)
+    for k in want:
+        assert got[k] == want[k], k
+    if ok:
+        assert sorted(int(x) for x in idx) == changed
+    a.close(); b.close()
+
+
 def test_updates_that_touch_a_dictionary_ask_for_a_full_finalize():
     w = workloads.fuzz_pending_domains(9100)
     enc = _encode(w.nodes, w.pods)

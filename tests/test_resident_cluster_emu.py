@@ -119,6 +119,83 @@ def test_committed_pods_count_in_the_domain_rules_of_later_calls(seed, lds):
     cl.close(); enc.close()
 
 
+def _second_pass_with_fresh_rules(w, forget):
+    """first half committed with the encoder's rules; then the caller RE-ENCODES the snapshot (the committed pods are running pods of
+    their nodes now, same class ids) and passes those rules for the second half — with or without telling the cluster"""
+    enc, pc, (a, b), opods, similar_keys = _split_case(w)
+    s = OracleScenario()
+    for info in w.nodes:
+        s.add_existing(info)
+    hints = lambda sl: None if w.hints is None else list(w.hints[sl])
+    want1 = s.try_schedule_pods(opods[a], hints(a), similar_keys(w.pods[a]), w.acceptable, w.break_on_failure, w.last_index)
+    want2 = s.try_schedule_pods(opods[b], hints(b), similar_keys(w.pods[b]), w.acceptable, w.break_on_failure, want1[1])
+    s.close()
+    cl = EmuCluster(enc.pegs, enc.groups)
+    rc, out1, li1, ns1 = cl.try_schedule_pods(pc[a], hints(a), w.acceptable, w.break_on_failure, w.last_index, commit=True, rules=enc.rules,
+                                              similar_key=similar_keys(w.pods[a]))
+    assert rc == 0 and list(out1) == list(want1[0])
+    placed_on = [[] for _ in w.nodes]
+    for i, m in enumerate(out1):
+        if m >= 0:
+            placed_on[int(m)].append(w.pods[a][i])
+    from kubernetes_autoscaler_amd.scheduling import encode_pending_pods
+    enc2, pc2 = encode_pending_pods([NodeInfo(info.node, list(info.pods) + placed_on[m]) for m, info in enumerate(w.nodes)], w.pods)
+    same_shape = (list(pc2) == list(pc) and enc2.pegs.n_pegs == enc.pegs.n_pegs and enc2.pegs.w_excl == enc.pegs.w_excl and
+                  enc2.pegs.w_label == enc.pegs.w_label and enc2.pegs.w_taint == enc.pegs.w_taint and enc2.pegs.w_zone == enc.pegs.w_zone)
+    got = None
+    if same_shape and enc2.rules is not None:
+        if forget:
+            cl.forget_commits()
+        rc, out2, li2, ns2 = cl.try_schedule_pods(pc[b], hints(b), w.acceptable, w.break_on_failure, li1, commit=False, rules=enc2.rules,
+                                                  similar_key=similar_keys(w.pods[b]))
+        got = (rc, list(out2), li2, ns2)
+    cl.close(); enc.close(); enc2.close()
+    return got, (0, list(want2[0]), want2[1], want2[2]), int(ns1)
+
+
+def test_rules_from_a_fresh_snapshot_need_forget_commits():
+    """a shim that rebuilds its domain rules from a fresh snapshot every loop already has the committed pods in them as running
+    pods; casim_cluster_forget_commits says so.  With it the second pass equals the oracle's one threaded snapshot in every case; without it
+    the committed pods are counted twice and some cases differ (which is what makes the call necessary, not cosmetic)."""
+    compared = double_counted = 0
+    for seed in range(60):
+        w = workloads.fuzz_pending_domains(8100 + seed)
+        if len(w.pods) < 2:
+            continue
+        got, want, committed = _second_pass_with_fresh_rules(w, forget=True)
+        if got is None or committed == 0:
+            continue
+        compared += 1
+        assert got == want, f"seed {seed}"
+        got_twice, _, _ = _second_pass_with_fresh_rules(w, forget=False)
+        double_counted += got_twice != want
+    assert compared >= 20 and double_counted >= 1, (compared, double_counted)
+
+
+def test_commit_bookkeeping_is_per_class_and_node_and_null_columns_are_rejected():
+    """committed pods are kept as (class, node) -> count (the cost of a later call does not grow with the pods committed), and rules whose
+    inc_rule / elig_bits columns are missing although they are referenced are an error, not a crash"""
+    w = workloads.fuzz_pending_domains(8107)
+    enc, pc, (a, b), opods, similar_keys = _split_case(w)
+    cl = EmuCluster(enc.pegs, enc.groups)
+    rc, out1, li1, ns1 = cl.try_schedule_pods(pc[a], None, w.acceptable, w.break_on_failure, w.last_index, commit=True, rules=enc.rules,
+                                              similar_key=similar_keys(w.pods[a]))
+    assert rc == 0
+    if ns1 > 0 and enc.rules is not None and enc.rules.n_rules > 0:
+        from kubernetes_autoscaler_amd.engine import make_pod_sequence
+        broken = type(enc.rules)()
+        C.memmove(C.byref(broken), C.byref(enc.rules), C.sizeof(broken))
+        broken.inc_rule = None
+        seq, keep = make_pod_sequence(pc[b], None, w.acceptable, w.break_on_failure, li1, broken, similar_keys(w.pods[b]))
+        node_out = np.full(max(seq.n_pods, 1), -1, np.int32)
+        li, ns = C.c_int32(0), C.c_int32(0)
+        rc = cl.L.emu_cluster_try_schedule_pods(cl._h, C.byref(seq), 0, node_out.ctypes.data_as(_abi.i32p), C.byref(li), C.byref(ns))
+        n_inc = enc.rules.inc_off[enc.rules.n_classes] if enc.rules.n_classes > 0 else 0
+        assert rc == (_abi.ERR_INVALID if n_inc > 0 else 0)
+        del keep
+    cl.close(); enc.close()
+
+
 @pytest.mark.parametrize("seed", range(40))
 def test_iteration_with_domain_rules_on_a_resident_cluster(seed):
     """The whole RunOnce-shaped sequence (committed pass, reverted pass, removal loop) with spread / zone anti-affinity / pod
