@@ -169,7 +169,11 @@ typedef struct casim_options {
                                      casim_problem_run forks from it (every internal stream waits for what it holds);
                                      casim_best_option_sims with dev_* outputs joins into it (work enqueued there afterwards sees
                                      the keys); host outputs / casim_problem_fetch synchronise.  Batches that cannot be cut (one
-                                     simulation, explicit peg_offsets, node_pods) run as one part; casim_problem_info [4] tells. */
+                                     simulation, explicit peg_offsets, node_pods) run as one part; casim_problem_info [4] tells.
+                                     PROCESS-WIDE SIDE EFFECT of loading the library: its constructor calls
+                                     setenv("GPU_MAX_HW_QUEUES", "8", overwrite = 0) so that the internal streams get hardware queues of
+                                     their own; CASIM_KEEP_ENV=1 (or setting the variable yourself) before the library loads keeps the
+                                     process environment untouched — the context then uses the queues there are (fewer parts). */
     int32_t pack_build;           /* which build of the register packer runs (csrc/casim_pack_tu.hip): CASIM_PACK_BUILD_AUTO (0, default) = the
                                      one the library's self-check left standing for the device, _PLAIN = compiled without the
                                      experimental LLVM option, _OPTION = compiled with it; see casim_pack_build_info */

@@ -348,9 +348,12 @@ class OracleScenario:
         acc = None if acceptable is None else np.ascontiguousarray(acceptable, np.uint8)
         out = np.full(max(n, 1), -1, np.int32)
         li = C.c_int(last_index)
+        import time
+        t0 = time.perf_counter()
         ns = self.L.orc_try_schedule_pods(self.h, n, ids.ctypes.data_as(i32p), hn.ctypes.data_as(i32p), sk.ctypes.data_as(i32p),
                                           acc.ctypes.data_as(u8p) if acc is not None else None, int(break_on_failure), C.byref(li),
                                           out.ctypes.data_as(i32p))
+        self.last_native_s = time.perf_counter() - t0   # (the native call alone: what bench.py's oracle_ms reports)
         assert ns >= 0, ns
         return out[:n].copy(), li.value, ns
 
@@ -378,6 +381,8 @@ class OracleScenario:
         final = np.full(max(total, 1), -1, np.int32)
         ec, ep, en = (np.full(max(E, 1) + total + 1, -1, np.int32) for _ in range(3))
         li, npr, ne = C.c_int(last_index), C.c_int(0), C.c_int(0)
+        import time
+        t0 = time.perf_counter()
         rc = self.L.orc_simulate_node_removals(self.h, K, cn.ctypes.data_as(i32p), off.ctypes.data_as(i32p), pods.ctypes.data_as(i32p),
                                                hn.ctypes.data_as(i32p) if hn is not None and hn.size else None,
                                                ds.ctypes.data_as(u8p) if ds is not None and ds.size else None,
@@ -386,6 +391,7 @@ class OracleScenario:
                                                int(max_removable), E, C.byref(li), removable.ctypes.data_as(u8p),
                                                node_out.ctypes.data_as(i32p), ec.ctypes.data_as(i32p), ep.ctypes.data_as(i32p),
                                                en.ctypes.data_as(i32p), C.byref(ne), final.ctypes.data_as(i32p), C.byref(npr))
+        self.last_native_s = time.perf_counter() - t0
         assert rc >= 0, rc
         n = ne.value
         return dict(removable=removable[:K].copy(), node_out=node_out[:total].copy(),

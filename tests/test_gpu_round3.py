@@ -131,7 +131,25 @@ def test_packer_self_check_ran_and_found_the_two_builds_identical(ctx):
     info = ctx.pack_build_info()
     if info["forced_by_env"]:
         pytest.skip("CASIM_PACK_BUILD forces a build")
-    assert info["batches_compared"] == 12 and info["batches_differing"] == 0 and info["build"] == "option", info
+    # 16 case families x 12 instantiations (zone words alone on an instantiation without exclusion words is not run: 6 fewer)
+    assert info["batches_compared"] == 186 and info["batches_differing"] == 0 and info["build"] == "option", info
+
+
+def test_packer_self_check_corpus_runs_everything_it_generates_in_time():
+    """every batch of the grown corpus (fastpath, singleton runs, zone words with NEED polarity, caller lists, PEGs
+    outside the simple shape; alone and combined) must be RUNNABLE by the plain build — a batch it refuses is not compared — and the whole
+    check has to stay a start-up cost nobody notices (own process: the verdict is per process)."""
+    import re, subprocess, sys
+    code = "import sys; sys.path.insert(0, %r)\nimport kubernetes_autoscaler_amd as kaa\nctx = kaa.Context(0)\nprint(ctx.pack_build_info())\n" % ROOT
+    env = dict(os.environ); env["CASIM_PACK_SELFCHECK_VERBOSE"] = "1"; env.pop("CASIM_PACK_BUILD", None)
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    m = re.search(r"packer self-check: (\d+) batches compared, (\d+) differing, (\d+) not runnable, ([0-9.]+) ms", p.stderr)
+    assert m, p.stderr[-2000:]
+    compared, differing, skipped, ms = int(m.group(1)), int(m.group(2)), int(m.group(3)), float(m.group(4))
+    print(f"self-check: {compared} batches, {ms:.1f} ms")
+    assert compared == 186 and differing == 0 and skipped == 0
+    assert ms < 400.0   # (includes the first launches of 24 kernel instantiations: code-object loading, not compute)
 
 
 def test_both_packer_builds_agree_with_the_oracle(ctx):
