@@ -118,3 +118,95 @@ class ScaleUpSimulator:
             best_idx, n_best, best_set = self.expander.best_option_index(prob, valid=valid)
         best = by_group.get(best_idx) if best_idx >= 0 else None
         return ScaleUpPlan(options, best, n_best, schedulable, res, delegated)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The host rules of ScaleUpOrchestrator.ScaleUp around the simulation (orchestrator.go:86-196, 380-437, 1043-1180): what turns the
+# per-group answers of SchedulablePodGroups + Estimate into the expander's option list, the final size change and the three pod
+# sets of status.ScaleUpStatus.  Pure host logic over results — the device (or the oracle, in tests) supplies `estimates`.
+# ---------------------------------------------------------------------------------------------------------------------
+@dataclass
+class GroupEstimate:
+    """One node group after the two loops of prepareScaleUp (:1049-1068)."""
+    node_group: NodeGroup
+    schedulable: List[int]        # PEG indices whose sample pod passed CheckPredicates on the template (SchedulablePodGroups :535-570)
+    node_count: int               # Estimate's first result
+    pods: List[Pod]               # ... and its second: the pods that fit, in placement order
+
+
+@dataclass
+class ScaleUpDecision:
+    scale_up: bool
+    options: List[Option]                  # what ExpanderStrategy.BestOption receives (:1079)
+    best: Optional[Option]
+    final_group: Optional[str]
+    final_size_change: int
+    pods_triggered_scale_up: List[Pod]
+    pods_remain_unschedulable: List[Pod]
+    pods_await_evaluation: List[Pod]
+    reason: str = ""
+
+
+def decide_scale_up(pegs: List[PodEquivalenceGroup], estimates: List[GroupEstimate], n_existing_nodes: int, *, all_or_nothing: bool = False,
+                    zero_or_max_node_scaling: bool = False, max_nodes_total: int = 0, stop_binpacking=None, choose=None) -> ScaleUpDecision:
+    """`choose(options) -> Option | None`: the expander (default: the first option, what a test's mock strategy picks when it is given
+    nothing).  `stop_binpacking(options) -> bool`: processors.BinpackingLimiter.StopBinpacking, asked after every group (:1065)."""
+    n_pods = sum(len(pg.pods) for pg in pegs)
+    schedulable_somewhere = [False] * len(pegs)
+    failing_on: Dict[str, set] = {}                    # group id -> PEGs whose sample pod failed there (eg.SchedulingErrors)
+    for ge in estimates:                               # first loop (:1049-1051): every group, whatever the second loop does
+        ok = set(ge.schedulable)
+        for i in ok:
+            schedulable_somewhere[i] = True
+        failing_on[ge.node_group.id()] = {i for i in range(len(pegs)) if i not in ok}
+    options: List[Option] = []
+    for ge in estimates:                               # second loop (:1053-1068)
+        node_count, pods = (ge.node_count, list(ge.pods)) if ge.schedulable else (0, [])
+        if zero_or_max_node_scaling:                   # ComputeExpansionOption :421-434
+            if all_or_nothing and node_count > ge.node_group.max_size():
+                node_count, pods = 0, []
+            if node_count > 0:
+                node_count = ge.node_group.max_size()
+        if pods and node_count > 0 and not (all_or_nothing and len(pods) < n_pods):
+            options.append(Option(node_group=ge.node_group, node_count=node_count, pods=pods))
+        if stop_binpacking is not None and stop_binpacking(options):
+            break
+
+    def remaining(all_unschedulable=False):            # GetRemainingPods :803-819 / markAllGroupsAsUnschedulable
+        return [p for i, pg in enumerate(pegs) if all_unschedulable or not schedulable_somewhere[i] for p in pg.pods]
+
+    def none(reason, all_unschedulable=False):
+        return ScaleUpDecision(False, options, None, None, 0, [], remaining(all_unschedulable), [], reason)
+    if not options:
+        return none("no expansion options")
+    best = choose(options) if choose is not None else options[0]
+    if best is None or best.node_count <= 0:
+        return none("expander filtered out all options", True)
+    new_nodes = best.node_count
+    if max_nodes_total > 0 and n_existing_nodes + new_nodes > max_nodes_total:   # GetCappedNewNodeCount
+        new_nodes = max_nodes_total - n_existing_nodes
+        if new_nodes < 1:
+            return none("max node total count reached", True)
+    if new_nodes < best.node_count and all_or_nothing:
+        return none("all-or-nothing", True)            # abortAllOrNothing :895-903, :1120
+    capacity = best.node_group.max_size() - best.node_group.target_size()      # the one-group form of balanceScaleUps' capacity check (:1160-1169)
+    if capacity < new_nodes:
+        if all_or_nothing:
+            return none("all-or-nothing", True)
+        new_nodes = capacity
+    if new_nodes <= 0:
+        return none("node group at its max size", True)
+    bad = failing_on.get(best.node_group.id(), set())
+    awaiting = [p for i, pg in enumerate(pegs) if schedulable_somewhere[i] and i in bad for p in pg.pods]   # GetPodsAwaitingEvaluation :998-1009
+    return ScaleUpDecision(True, options, best, best.node_group.id(), new_nodes, list(best.pods), remaining(), awaiting)
+
+
+def estimates_from_results(pegs: List[PodEquivalenceGroup], node_groups: List[NodeGroup], per_group) -> List[GroupEstimate]:
+    """`per_group[i]` = (PEG ids in processing order, pods placed per entry, node count) of group i — a BatchResult row or an oracle estimate."""
+    out = []
+    for ng, (order, placed, node_count) in zip(node_groups, per_group):
+        pods: List[Pod] = []
+        for pg_id, n in zip(order, placed):
+            pods.extend(pegs[int(pg_id)].pods[:int(n)])
+        out.append(GroupEstimate(ng, sorted(int(x) for x in order), int(node_count), pods))
+    return out

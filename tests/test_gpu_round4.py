@@ -1,0 +1,59 @@
+"""-m gpu: round 4 on a real MI355X through the C ABI.
+  * the reference's orchestrator rows (tests/golden/reference_vectors.json: orchestrator_scale_up) through the product kernels: the chain
+    SchedulablePodGroups -> Estimate per node group -> expander input -> status sets, both packers;
+  * casim_cluster_forget_commits on the device;
+  * (further down) what round 4 adds to the batch path."""
+import os
+
+import numpy as np
+import pytest
+
+import kubernetes_autoscaler_amd as kaa
+from kubernetes_autoscaler_amd import _abi, workloads
+from harness import assert_matches_oracle, encode, run_gpu, run_oracle
+from orchestrator_rows import ROWS, Row, per_group_of_batch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = kaa.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("generic", [False, True], ids=["register-packer", "int64-packer"])
+def test_reference_orchestrator_rows_on_the_device(ctx, generic):
+    for row in ROWS:
+        r = Row(row)
+        sc = r.scenario()
+        enc = encode(sc)
+        res, _ = run_gpu(enc, ctx, generic=generic)
+        enc.close()
+        assert_matches_oracle(res, run_oracle(sc), row["name"])
+        r.check(r.decide(per_group_of_batch(res)), "MI355X:")
+
+
+def test_rules_from_a_fresh_snapshot_need_forget_commits_on_the_device(ctx):
+    """the emulator test of tests/test_resident_cluster_emu.py on the MI355X: second pass with rules re-encoded from the committed snapshot"""
+    from test_resident_cluster_emu import _second_pass_with_fresh_rules
+    import harness
+    saved = harness.EmuCluster
+    import test_resident_cluster_emu as mod
+    mod.EmuCluster = lambda classes, nodes, lds_budget=0: kaa.ResidentCluster(ctx, classes, nodes)
+    try:
+        compared = 0
+        for seed in range(30):
+            w = workloads.fuzz_pending_domains(8100 + seed)
+            if len(w.pods) < 2:
+                continue
+            got, want, committed = _second_pass_with_fresh_rules(w, forget=True)
+            if got is None or committed == 0:
+                continue
+            compared += 1
+            assert got == want, f"seed {seed}"
+        assert compared >= 10
+    finally:
+        mod.EmuCluster = saved
