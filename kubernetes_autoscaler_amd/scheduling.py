@@ -47,6 +47,37 @@ class Hints:
         self.current = {}
 
 
+class SimilarPodsScheduling:
+    """similar_pods.go:38-107: per controller UID the specs already found unschedulable (at most 10: beyond that the controller
+    "overflows" and nothing more is cached for it).  Match = DeepEqual(labels) AND PodSpecSemanticallyEqual (utils/utils.go:64-75),
+    which ignores projected volumes and the per-pod fields the sanitizer drops — exactly what Pod.spec_key() compares: labels,
+    namespace and every scheduling-relevant spec field of the model, `spec_extra` standing for the spec fields the model does not
+    carry (a non-projected volume changes it, a projected one does not).  DaemonSet pods are never cached (:84-86), pods without a
+    controller neither cached nor found (:66-69, :84)."""
+
+    def __init__(self):
+        self.items: Dict[str, List[tuple]] = {}
+        self.overflowing_controllers = set()
+
+    def is_similar_unschedulable(self, pod: Pod) -> bool:
+        if not pod.controller_uid:
+            return False
+        key = pod.spec_key()
+        return any(k == key for k in self.items.get(pod.controller_uid, ()))
+
+    def set_unschedulable(self, pod: Pod):
+        if not pod.controller_uid or pod.daemonset:
+            return
+        pm = self.items.setdefault(pod.controller_uid, [])
+        if len(pm) >= MAX_PODS_PER_OWNER_REF:
+            self.overflowing_controllers.add(pod.controller_uid)
+            return
+        pm.append(pod.spec_key())
+
+    def overflowing_controller_count(self) -> int:
+        return len(self.overflowing_controllers)
+
+
 @dataclass
 class Status:
     """scheduling.Status: a pod and the node it can be moved to."""
@@ -114,8 +145,7 @@ class HintingSimulator:
             raise UnsupportedPredicate("pending pods need a predicate outside the encoded subset")
         self.last_index = last_index
         statuses: List[Status] = []
-        items: Dict[str, List[int]] = {}
-        overflowing = set()
+        similar_pods = SimilarPodsScheduling()   # (the device decided every pod; this replays the reference's bookkeeping for the metric)
         for i, p in enumerate(pods):
             m = int(node_out[i])
             if m >= 0:
@@ -123,17 +153,12 @@ class HintingSimulator:
                 self.hints.set(hint_key_from_pod(p), name)
                 statuses.append(Status(p, name))
                 continue
-            # replay of the SimilarPodsScheduling bookkeeping (IsSimilarUnschedulable / SetUnschedulable)
-            if p.controller_uid:
-                seen = items.setdefault(p.controller_uid, [])
-                if int(pod_class[i]) not in seen and not p.daemonset:
-                    if len(seen) >= MAX_PODS_PER_OWNER_REF:
-                        overflowing.add(p.controller_uid)
-                    else:
-                        seen.append(int(pod_class[i]))
+            # trySchedule (hinting_simulator.go:112-135): a pod whose like already failed is not tried again, the others are recorded
+            if not similar_pods.is_similar_unschedulable(p):
+                similar_pods.set_unschedulable(p)
             if break_on_failure:
                 break
-        return statuses, len(overflowing)
+        return statuses, similar_pods.overflowing_controller_count()
 
     def drop_old_hints(self):
         self.hints.drop_old()

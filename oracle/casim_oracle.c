@@ -957,6 +957,32 @@ int orc_run_filters_until_passing(orc* o, int pod, int* last_index) {
     PODCHK(o, pod);
     return run_filters_until_passing(o, pod, 0, last_index);
 }
+/* RunFiltersUntilPassingNode (plugin_runner.go:54-143) under an ARBITRARY NodeOrderMapping, given as data: At(i) = order[i] for
+ * i < n_order, -1 beyond (a mapping may end the walk early: checkNode :93-97 cancels).  `acceptable` (may be NULL) is
+ * SchedulingOptions.IsNodeAcceptable per snapshot index; visited_out receives the nodes IsNodeAcceptable was asked about, in order
+ * (:108-116: after the Unschedulable short-circuit).  The earliest step that passes wins (:126-133 keeps the smallest i whatever the
+ * goroutines' timing).  No production caller passes a NodeOrdering (the estimator and TrySchedulePods use the runner's lastIndex
+ * mapping); the function exists so that the reference's three tests of the mapping contract (plugin_runner_test.go:296-446) pin the
+ * oracle's loop. */
+int orc_run_filters_until_passing_ordered(orc* o, int pod, const int* order, int n_order, const unsigned char* acceptable,
+                                          int* visited_out, int* n_visited_out) {
+    PODCHK(o, pod);
+    const podspec* p = &o->pods.v[pod];
+    ipa_state st; ipa_prefilter(o, p, &st);
+    pts_state ts; pts_prefilter(o, p, &ts);
+    int n = o->snap.n, found = -1, nv = 0;
+    for (int i = 0; i < n; ++i) {                           /* ParallelizeUntil over len(nodeInfosList) steps */
+        const int idx = i < n_order ? order[i] : -1;        /* nodeOrdering.At(i) */
+        if (idx < 0 || idx >= n) break;                     /* :94-97 */
+        const node* nd = &o->snap.v[idx];
+        if (nd->unschedulable) continue;                    /* :108-110 */
+        if (acceptable) { if (visited_out) visited_out[nv] = idx; nv++; if (!acceptable[idx]) continue; }   /* :114-116 */
+        if (run_filter_plugins(o, p, nd, &st, &ts, NULL, NULL)) { found = idx; break; }
+    }
+    ipa_free(&st); pts_free(&ts);
+    if (n_visited_out) *n_visited_out = nv;
+    return found;
+}
 
 /* insufficientResources of the last NodeResourcesFit failure (fit.go:678-765 collects ALL of them; the Status carries one
  * reason per entry): bit 0 "Too many pods", bit 1 + r "Insufficient <lane r>" */

@@ -136,6 +136,9 @@ int orc_run_filters_on_snapshot_node(orc* o, int index, int pod, const char** pl
 /* RunFiltersUntilPassingNode over the whole snapshot, every node acceptable
  * (plugin_runner.go:54-143); returns the matched list index or -1; updates *last_index. */
 int orc_run_filters_until_passing(orc* o, int pod, int* last_index);
+/* the same loop under an arbitrary NodeOrderMapping given as data (plugin_runner_test.go:296-446); returns the snapshot index found or -1 */
+int orc_run_filters_until_passing_ordered(orc* o, int pod, const int* order, int n_order, const unsigned char* acceptable,
+                                          int* visited_out, int* n_visited_out);
 
 /* ---- HintingSimulator.TrySchedulePods  (CA/simulator/scheduling/hinting_simulator.go:53-135) ----
  * Pending pods against the nodes ALREADY in the snapshot (filter-out-schedulable).

@@ -82,6 +82,7 @@ def lib():
             "orc_check_predicates": (C.c_int, [P, C.c_int, C.c_int, cstrp, cstrp]),
             "orc_run_filters_on_snapshot_node": (C.c_int, [P, C.c_int, C.c_int, cstrp, cstrp]),
             "orc_run_filters_until_passing": (C.c_int, [P, C.c_int, C.POINTER(C.c_int)]),
+            "orc_run_filters_until_passing_ordered": (C.c_int, [P, C.c_int, i32p, C.c_int, u8p, i32p, C.POINTER(C.c_int)]),
             "orc_try_schedule_pods": (C.c_int, [P, C.c_int, i32p, i32p, i32p, u8p, C.c_int, C.POINTER(C.c_int), i32p]),
             "orc_snapshot_size": (C.c_int, [P]),
             "orc_simulate_node_removals": (C.c_int, [P, C.c_int, i32p, i32p, i32p, i32p, u8p, u8p, u8p, C.c_int, C.c_int, C.c_int,
@@ -336,6 +337,17 @@ class OracleScenario:
         li = C.c_int(last_index)
         idx = self.L.orc_run_filters_until_passing(self.h, self.pod(pod), C.byref(li))
         return idx, li.value
+
+    def run_filters_until_passing_ordered(self, pod, order, acceptable):
+        """RunFiltersUntilPassingNode under a NodeOrderMapping given as the list of snapshot indices it yields (shorter than the
+        snapshot = the mapping answers -1 from there on); acceptable[idx] = IsNodeAcceptable.  Returns (index found or -1, visited)."""
+        order = np.ascontiguousarray(order, np.int32)
+        acc = np.ascontiguousarray(acceptable, np.uint8)
+        visited = np.full(max(len(acc), 1), -1, np.int32)
+        nv = C.c_int(0)
+        idx = self.L.orc_run_filters_until_passing_ordered(self.h, self.pod(pod), order.ctypes.data_as(i32p), len(order), acc.ctypes.data_as(u8p),
+                                                           visited.ctypes.data_as(i32p), C.byref(nv))
+        return idx, [int(x) for x in visited[:nv.value]]
 
     def try_schedule_pods(self, pods, hints=None, similar_keys=None, acceptable=None, break_on_failure: bool = False,
                           last_index: int = 0):

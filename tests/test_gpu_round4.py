@@ -39,9 +39,8 @@ def test_reference_orchestrator_rows_on_the_device(ctx, generic):
 def test_rules_from_a_fresh_snapshot_need_forget_commits_on_the_device(ctx):
     """the emulator test of tests/test_resident_cluster_emu.py on the MI355X: second pass with rules re-encoded from the committed snapshot"""
     from test_resident_cluster_emu import _second_pass_with_fresh_rules
-    import harness
-    saved = harness.EmuCluster
     import test_resident_cluster_emu as mod
+    saved = mod.EmuCluster
     mod.EmuCluster = lambda classes, nodes, lds_budget=0: kaa.ResidentCluster(ctx, classes, nodes)
     try:
         compared = 0

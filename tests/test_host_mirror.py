@@ -238,3 +238,33 @@ def test_pod_requests_follows_the_sidecar_formula():
     assert pod_requests([]) == {}
     # resources only some containers name
     assert pod_requests([Container({"cpu": 1}), Container({"ephemeral-storage": 5})], [Container({"memory": 9})]) == {"cpu": 1, "ephemeral-storage": 5, "memory": 9}
+
+
+def test_similar_pods_scheduling_like_the_reference_tests():
+    """simulator/scheduling/similar_pods_test.go:32-150 on the mirror's memo (scheduling.SimilarPodsScheduling)."""
+    import json, os
+    from kubernetes_autoscaler_amd.objects import Pod
+    from kubernetes_autoscaler_amd.scheduling import SimilarPodsScheduling
+    G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))["similar_pods_scheduling"]
+
+    def build(p, labels=None):
+        vol = p.get("volume", "")
+        return Pod(name=p["name"], requests={"cpu": p["cpu"], "memory": p["mem"]}, controller_uid=p["controller"], daemonset=bool(p.get("daemonset")),
+                   labels=dict(labels or {}), spec_extra="" if vol in ("", "projected") else vol)
+    for case in G["cases"]:
+        memo = SimilarPodsScheduling()
+        if "generate" in case:
+            g = case["generate"]
+            pods = [build({"name": f"p{i}", "cpu": g["cpu"], "mem": g["mem"], "controller": g["controller"]}, {g["unique_label"]: f"l{i}"}) for i in range(g["count"])]
+            assert not any(memo.is_similar_unschedulable(p) for p in pods)
+            for p in pods:
+                memo.set_unschedulable(p)
+            assert [memo.is_similar_unschedulable(p) for p in pods] == [True] * (g["count"] - 1) + [False], case["name"]
+        else:
+            pods = {k: build(v) for k, v in case["pods"].items()}
+            for op in case["ops"]:
+                if op[0] == "set":
+                    memo.set_unschedulable(pods[op[1]])
+                else:
+                    assert memo.is_similar_unschedulable(pods[op[1]]) == op[2], (case["name"], op)
+        assert memo.overflowing_controller_count() == case["overflowing"], case["name"]

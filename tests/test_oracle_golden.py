@@ -428,3 +428,21 @@ def test_topology_spread_taint_scheduling(row):
     assert (n == 1) == row["schedulable"]
     if row["schedulable"]:
         assert node_out[0] in (1, 2)
+
+
+@pytest.mark.parametrize("case", GOLD["node_order_mapping_contract"]["cases"], ids=lambda c: c["name"])
+def test_node_order_mapping_contract(case):
+    """plugin_runner_test.go:296-446: visit order = the mapping's order, a mapping that answers -1 ends the walk, the earliest passing
+    step wins (the reference's goroutines may finish in any order; its `i < earliestMatch` keeps the smallest step)."""
+    G = GOLD["node_order_mapping_contract"]
+    s = OracleScenario()
+    index = {}
+    for name in case["nodes"]:
+        index[name] = s.add_existing(NodeInfo(build_test_node(name, 1000, 2000000)))
+    acc = [1 if name in case["acceptable"] else 0 for name in case["nodes"]]
+    idx, visited = s.run_filters_until_passing_ordered(build_test_pod("p100", *G["pod"]), [index[n] for n in case["order"]], acc)
+    names = {v: k for k, v in index.items()}
+    assert (names[idx] if idx >= 0 else None) == case["expect_node"]
+    if "expect_visited" in case:
+        assert [names[v] for v in visited] == case["expect_visited"]
+    s.close()

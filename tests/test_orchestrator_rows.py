@@ -39,3 +39,44 @@ def test_product_kernels_reproduce_the_reference_row_under_the_emulator(row, gen
     enc.close()
     assert all(int(s) == 0 for s in res.status)
     r.check(r.decide(per_group_of_batch(res)), "emulator:")
+
+
+def _sanitized_template():
+    import json, os
+    from kubernetes_autoscaler_amd.objects import Node, NodeInfo, Pod, Taint
+    G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))["sanitized_node_info"]
+    t = G["template"]
+    cap = {"cpu": t["cpu"], "memory": t["mem"], "pods": t["pods_capacity"]}
+    node = Node(name=t["name"], labels=dict(t["labels"]), taints=[Taint(*x) for x in t["taints"]], allocatable=dict(cap), capacity=dict(cap))
+    return G, NodeInfo(node, [Pod(name=n, requests={"cpu": c, "memory": m}) for n, c, m in t["pods"]])
+
+
+@pytest.mark.parametrize("device", ["oracle", "emulator-register", "emulator-int64"])
+def test_a_simulated_node_inherits_what_the_reference_says_it_inherits(device):
+    """simulator/node_info_utils_test.go:395-428 (TestSanitizedNodeInfo) as seen through Estimate (row a8): every node the estimate adds
+    carries ALL the template's taints (nothing is sanitized a second time — not even ToBeDeleted), its labels, and the template's pods
+    (their requests and their pod slots)."""
+    from harness import GroupSpec, Scenario
+    from kubernetes_autoscaler_amd.objects import Pod, PodEquivalenceGroup, Toleration
+    G, tmpl = _sanitized_template()
+    exp = G["expect"]
+    everything = [Toleration(operator="Exists")]
+    two_of_three = [Toleration(key="startup-taint", operator="Exists"), Toleration(key="a", operator="Equal", value="b")]
+    free = 1000 - exp["requested_cpu"]
+    pegs = [PodEquivalenceGroup(pods=[Pod(name="untolerating", requests={"cpu": 10, "memory": 0})] * 3),
+            PodEquivalenceGroup(pods=[Pod(name="misses-the-to-be-deleted-taint", requests={"cpu": 10, "memory": 0}, tolerations=two_of_three)] * 3),
+            PodEquivalenceGroup(pods=[Pod(name="exactly-what-is-left", requests={"cpu": free, "memory": 0}, tolerations=everything)] * 2),
+            PodEquivalenceGroup(pods=[Pod(name="one-milli-too-much", requests={"cpu": free + 1, "memory": 0}, tolerations=everything)] * 2),
+            PodEquivalenceGroup(pods=[Pod(name="slots-only", requests={"cpu": 0, "memory": 0}, tolerations=everything)] * 200)]
+    want = {0: (0, 0), 1: (0, 0), 2: (2, 2), 3: (0, 0), 4: (-(-200 // (100 - exp["pod_count"])), 200)}   # PEG -> (nodes, pods): 98 free slots per node
+    for k, (nodes, pods) in want.items():
+        sc = Scenario(pegs=[pegs[k]], groups=[GroupSpec(tmpl, 0, 0, [0])], existing=[])
+        if device == "oracle":
+            est, _ = run_oracle(sc)[0]
+            got = (est.node_count, est.pods_scheduled)
+        else:
+            enc = encode(sc)
+            res, _ = run_emu(enc, generic=device.endswith("int64"))
+            enc.close()
+            got = (int(res.node_count[0]), int(res.pods_scheduled[0]))
+        assert got == (nodes, pods), (pegs[k].pods[0].name, got)
