@@ -649,6 +649,8 @@ def main():
                              "one_casim_ctx": True, "streams_inside_libcasim": K}}
         if world == 1:
             rows["enter_return"] = _try(lambda: enter_return_row(kaa, ctx, batch.tables, kinds, K, checks_per_step, max(3, min(args.steps, 10)), res_all, final))
+            rows["enter_return_every_list"] = _try(lambda: enter_return_row(kaa, ctx, batch.tables, kinds, K, checks_per_step, max(3, min(args.steps, 10)), res_all, final,
+                                                                            winners_only=False))
             rows["int64"] = _try(lambda: int64_row(kaa, dev_index, batch.tables, kinds, K, checks_per_step, max(5, min(args.steps, 50)), res_all, final, torch))
         extra["headline_rows"] = rows
         # the §8(d) wall-clock form of the same metric at top level (VERDICT r3 next #1b): `value` is the resident regime the bench
@@ -658,7 +660,8 @@ def main():
         extra["ms_per_step_wall"] = er.get("ms_per_step")
         extra["sims_per_s_wall"] = er.get("sims_per_s")
         extra["value_regimes"] = {"value": "resident: tables in HBM, results stay on the device (bench contract)",
-                                  "value_wall": "SURVEY 8(d): host-side enter -> return of casim_estimate_batch_query every step, H2D + kernels + expander + D2H (PCIe inclusive)"}
+                                  "value_wall": "SURVEY 8(d): host-side enter -> return of casim_estimate_batch_query every step, H2D + kernels + expander + D2H (PCIe inclusive); "
+                                                "results = every group's scalars + the winners' PEG lists (SURVEY 8e; headline_rows.enter_return_every_list ships all lists)"}
         if not args.no_verify:
             extra["headline_check"] = _try(lambda: verify_headline(workloads, make, S, batch.tables, res_all))
             extra["headline_bit_exact"] = bool((extra["headline_check"] or {}).get("headline_bit_exact", False))
@@ -725,12 +728,48 @@ def _same_results(a, b):
     return bool(ok and np.array_equal(ea["best"], eb["best"]) and np.array_equal(ea["packed"], eb["packed"]))
 
 
-def enter_return_row(kaa, ctx, tables, kinds, K, checks_per_step, steps, res_resident, exp_resident):
+def _same_winners(a, b):
+    """a = (BatchResult, exp) of a winners_only call, b = the full answer: scalars, offsets, expander answer equal, and the compact lists are
+    the winners' slices of the full lists"""
+    import numpy as np
+    ra, ea = a; rb, eb = b
+    ok = all(np.array_equal(getattr(ra, f), getattr(rb, f)) for f in ("offsets", "node_count", "pods_scheduled", "nodes_added", "limiter_nodes",
+                                                                      "last_index_out", "status", "req_cpu_sum", "req_mem_sum"))
+    ok = ok and np.array_equal(ea["best"], eb["best"]) and np.array_equal(ea["packed"], eb["packed"])
+    if not ok:
+        return False
+    w = ra.winner_offsets
+    best = np.asarray(ea["best"], np.int64)
+    has = np.nonzero(best >= 0)[0]
+    # gather the winners' slices of the full lists in one go
+    starts = rb.offsets[best[has]].astype(np.int64); lens = (rb.offsets[best[has] + 1] - rb.offsets[best[has]]).astype(np.int64)
+    idx = np.repeat(starts - np.concatenate([[0], np.cumsum(lens)[:-1]]), lens) + np.arange(int(lens.sum()))
+    n = int(w[-1])
+    return bool(n == int(lens.sum()) and np.array_equal(ra.order[:n], rb.order[idx]) and np.array_equal(ra.placed[:n], rb.placed[idx]))
+
+
+def enter_return_row(kaa, ctx, tables, kinds, K, checks_per_step, steps, res_resident, exp_resident, winners_only=True):
     """SURVEY 8d's wall time: casim_estimate_batch_query enter -> return — fresh tables packed into pinned memory and copied to
-    HBM, kernels, expander reduce, scalars + order + placed copied back, EVERY step; the parts of the batch run end to end on
-    the context's internal streams (upload of one part under the kernels of another)."""
+    HBM, kernels, expander reduce, results copied back, EVERY step; the parts of the batch run end to end on the context's internal
+    streams (upload of one part under the kernels of another).  winners_only: the per-group scalars and offsets of every
+    group, PEG order / pods placed of the winning group of every simulation only (compacted on the device); False = every list, what
+    a shim that serves all Estimate() calls from the batch fetches."""
     from kubernetes_autoscaler_amd.engine import BatchCall
     pegs, groups = tables.structs()
+    if winners_only:
+        call = BatchCall(ctx, pegs, groups, kinds=kinds, n_streams=K, winners_only=True)
+        call.call_raw()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            call.call_raw()
+        dt = (time.perf_counter() - t0) / steps
+        res, exp = call.call()
+        bytes_in = sum(v.nbytes for v in tables.pegs.values() if v is not None) + sum(v.nbytes for v in tables.groups.values() if v is not None)
+        return {"what": "casim_estimate_batch_query enter -> return every step, casim_options.winners_only: H2D of fresh tables from pinned staging + kernels + "
+                        "expander + winners' lists compacted on the device + D2H of every group's scalars / offsets and the winners' order / placed", "dtype": "int32",
+                "ms_per_step": dt * 1e3, "checks_per_s": checks_per_step / dt, "sims_per_s": tables.n_sims / dt, "steps": steps,
+                "table_bytes_in": bytes_in, "result_bytes_out": 8 * int(res.winner_offsets[-1]) + 52 * tables.n_groups + 16 * tables.n_sims,
+                "pcie_inclusive": True, "bit_equal_to_resident": _same_winners((res, exp), (res_resident, exp_resident))}
     call = BatchCall(ctx, pegs, groups, kinds=kinds, n_streams=K)
     call.call_raw()                       # first call: lanes, pools, pinned buffers
     t0 = time.perf_counter()

@@ -42,7 +42,7 @@ extern "C" {
                                * 6: casim_pegs.zone_polarity (group bits of NEED polarity: required pod affinity towards a partner of the batch);
                                *    later, without a new number (layouts unchanged, zero keeps its meaning): casim_options.no_front_kernel in one of
                                *    the two reserved words, casim_problem_info [7]
-                               * 7: casim_cluster_forget_commits */
+                               * 7: casim_cluster_forget_commits, casim_options.winners_only (the last reserved word) */
 
 /* Resource lanes.  Lane 0 = cpu in millicores (Quantity.MilliValue), lane 1 = memory bytes,
  * lane 2 = ephemeral-storage bytes, lanes 3.. = scalar / extended resources (Quantity.Value),
@@ -187,7 +187,14 @@ typedef struct casim_options {
     int32_t no_front_kernel;      /* 1 = a call of <= 1024 groups runs feasibility, list offsets, lists and PEG order as the four separate launches
                                      a batch uses instead of the one fused launch (csrc/casim_kernels.h front_kernel; testing / A-B).  Results
                                      are identical.  (Took one of the two reserved words of ABI 6: zero keeps its meaning.) */
-    int32_t reserved[1];
+    int32_t winners_only;         /* 1 = casim_estimate_batch_query with an expander query (q->best_out set) returns the PEG order / pods placed of the
+                                     WINNING group of every simulation only ("per-PEG placed[] arrays only travel for the winning NG"):
+                                     out->order / out->placed then hold, simulation after simulation, the list of group best_out[s] (nothing for a
+                                     simulation without an option) — list s starts at sum over s' < s of (offsets_out[best_out[s'] + 1] -
+                                     offsets_out[best_out[s']]) and PEG ids are the batch's own — compacted ON THE DEVICE, so the copy back is a few
+                                     MB instead of 8 bytes per (group, PEG) pair; the per-group scalars and offsets_out stay complete.  A caller
+                                     that serves every group's Estimate() from the batch (the prefetch cache of the Go shim) keeps 0.  Implies
+                                     no_singleton_merge.  (Took the last reserved word of ABI 6: zero keeps its meaning.) */
 } casim_options;
 #define CASIM_PACK_BUILD_AUTO 0
 #define CASIM_PACK_BUILD_PLAIN 1
@@ -857,7 +864,10 @@ int32_t casim_enc_group_reset(casim_encoder* e, int32_t group, const int64_t* al
                               int64_t capacity_mem_bytes, int32_t unschedulable);
 int32_t casim_enc_set_peg_count(casim_encoder* e, int32_t peg, int32_t count);
 int32_t casim_enc_refinalize(casim_encoder* e, int32_t* changed_out, int32_t capacity, int32_t* n_changed_out);
-/* n rows of the node table as a compact casim_groups (pointers owned by the encoder, valid until the next call) */
+/* n rows of the node table as a compact casim_groups (pointers owned by the encoder, valid until the next call).  Besides node deltas
+ * (casim_cluster_update_nodes) this is the PER-CALL mode of an estimator shim: the tables of a scale-up loop are encoded ONCE (every PEG,
+ * every candidate group), and one Estimate() = this call with n = 1 + the caller's own peg_offsets / peg_index / max_nodes /
+ * existing_nodes / last_index written into the returned struct + casim_estimate_batch: no encoder work per Estimate() at all. */
 int32_t casim_enc_group_rows(casim_encoder* e, const int32_t* groups, int32_t n, casim_groups* rows_out);
 
 /* Build the dictionaries and the flat tables.  After finalize the views below stay valid

@@ -7,6 +7,7 @@ package gpubinpacking
 import "C"
 
 import (
+	"runtime"
 	"strconv"
 	"sync"
 
@@ -114,6 +115,17 @@ func (g *gpuEstimator) Estimate(pegs []estimator.PodEquivalenceGroup, tmpl *fram
 		}
 	}
 
+	// ---- per-call mode, first choice: the loop's tables are still there (a lookup missed: other PEG list, other limits) — no encoding ----
+	if g.shared != nil {
+		if n, order, placed, li, st, ok := g.shared.estimateOnLoopTables(ng, tmpl, pegs, maxNodes, existing, g.lastIndex(), g.fastpath); ok {
+			if st != C.CASIM_NG_OK {
+				return g.fallback.Estimate(pegs, tmpl, ng)
+			}
+			g.setLastIndex(li)
+			return n, prefixPods(pegs, order, placed)
+		}
+	}
+
 	// ---- per-call mode: ONE casim_estimate_batch with one group record and the PEGs the orchestrator passed ----
 	s := newSession()
 	defer s.close()
@@ -127,12 +139,20 @@ func (g *gpuEstimator) Estimate(pegs []estimator.PodEquivalenceGroup, tmpl *fram
 		return g.fallback.Estimate(pegs, tmpl, ng)
 	}
 	n := len(pegs)
-	var nodeCount, podsScheduled, nodesAdded, limiterNodes, lastIndexOut, status C.int32_t
-	var cpu, mem C.int64_t
+	scal := make([]C.int32_t, 6) // node_count, pods_scheduled, nodes_added, limiter_nodes, last_index_out, status
+	sums := make([]C.int64_t, 2)
 	order := make([]C.int32_t, n+1)
 	placed := make([]C.int32_t, n+1)
-	res := C.casim_results{node_count: &nodeCount, pods_scheduled: &podsScheduled, nodes_added: &nodesAdded, limiter_nodes: &limiterNodes,
-		last_index_out: &lastIndexOut, status: &status, req_cpu_sum: &cpu, req_mem_sum: &mem, order: &order[0], placed: &placed[0]}
+	// a C struct that carries pointers into Go memory: every one of them pinned for the duration of the call (cgo pointer rules)
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	pin.Pin(&scal[0])
+	pin.Pin(&sums[0])
+	pin.Pin(&order[0])
+	pin.Pin(&placed[0])
+	res := C.casim_results{node_count: &scal[0], pods_scheduled: &scal[1], nodes_added: &scal[2], limiter_nodes: &scal[3],
+		last_index_out: &scal[4], status: &scal[5], req_cpu_sum: &sums[0], req_mem_sum: &sums[1], order: &order[0], placed: &placed[0]}
+	nodeCount, lastIndexOut, status := &scal[0], &scal[4], &scal[5]
 	var opts C.casim_options
 	if g.fastpath {
 		opts.fastpath = 1
@@ -140,11 +160,11 @@ func (g *gpuEstimator) Estimate(pegs []estimator.PodEquivalenceGroup, tmpl *fram
 	g.engine.mu.Lock()
 	rc := C.casim_estimate_batch(g.engine.ctx, &pt, &gt, &opts, &res)
 	g.engine.mu.Unlock()
-	if rc != C.CASIM_OK || status != C.CASIM_NG_OK {
+	if rc != C.CASIM_OK || *status != C.CASIM_NG_OK {
 		return g.fallback.Estimate(pegs, tmpl, ng) // fail closed: error, or a predicate outside the encoded subset
 	}
-	g.setLastIndex(int(lastIndexOut)) // the runner's lastIndex persists across Estimates (plugin_runner.go:33-36,138)
-	return int(nodeCount), prefixPods(pegs, order[:n], placed[:n])
+	g.setLastIndex(int(*lastIndexOut)) // the runner's lastIndex persists across Estimates (plugin_runner.go:33-36,138)
+	return int(*nodeCount), prefixPods(pegs, order[:n], placed[:n])
 }
 
 // prefixPods rebuilds Estimate()'s []*Pod: PEG order[k] was processed k-th and placed[k] of its pods were scheduled — always

@@ -8,6 +8,7 @@ import "C"
 
 import (
 	"hash/fnv"
+	"runtime"
 	"unsafe"
 
 	apiv1 "k8s.io/api/core/v1"
@@ -28,6 +29,12 @@ type Shared struct {
 	limiter       DeviceLimiter
 	maxNodesTotal int
 	fastpath      bool
+	// the tables of the current loop (every PEG, every candidate group), kept until the next fill: a lookup that misses is served from
+	// THEM — one casim_enc_group_rows + one casim_estimate_batch, no encoder work per Estimate() (estimator.go: estimateOnLoopTables)
+	sess     *session
+	pegs     C.casim_pegs
+	pegID    map[*apiv1.Pod]C.int32_t // exemplar pod -> PEG id of the loop's tables
+	groupRow map[C.uint64_t]C.int32_t // groupKey -> row of the loop's group table
 	loopLastIndex int // the snapshot runner's lastIndex (estimator.go: runnerState) when the batch of the current loop was filled: every group of the batch starts from it
 }
 
@@ -54,8 +61,19 @@ func SimilarNodeGroups(opts *coreoptions.AutoscalerOptions) func(*ca_context.Aut
 	}
 }
 
-// Close releases the cache.
-func (s *Shared) Close() { C.casim_prefetch_destroy(s.cache) }
+// Close releases the cache and the loop's tables.
+func (s *Shared) Close() {
+	s.dropLoopTables()
+	C.casim_prefetch_destroy(s.cache)
+}
+
+func (s *Shared) dropLoopTables() {
+	if s.sess != nil {
+		s.sess.close()
+		s.sess = nil
+	}
+	s.pegID, s.groupRow = nil, nil
+}
 
 // Keys are opaque to libcasim.  A PEG is its exemplar pod (the orchestrator builds the groups once per loop and passes the same
 // *apiv1.Pod values to SchedulablePodGroups and to every Estimate); a node group is its Id() plus the identity of the template
@@ -74,14 +92,21 @@ func groupKey(ng cloudprovider.NodeGroup, tmpl *framework.NodeInfo) C.uint64_t {
 func (s *Shared) fill(autoscalingCtx *ca_context.AutoscalingContext, pegs []estimator.PodEquivalenceGroup, ngs []cloudprovider.NodeGroup,
 	infos map[string]*framework.NodeInfo, similar func(cloudprovider.NodeGroup) []cloudprovider.NodeGroup) error {
 	C.casim_prefetch_clear(s.cache)
+	s.dropLoopTables()
 	if len(pegs) == 0 || len(ngs) == 0 || s.limiter == nil {
 		return nil
 	}
 	sess := newSession()
-	defer sess.close()
+	keep := false
+	defer func() {
+		if !keep {
+			sess.close()
+		}
+	}()
 	pkeys := make([]C.uint64_t, len(pegs))
+	pegID := make(map[*apiv1.Pod]C.int32_t, len(pegs))
 	for i, p := range pegs {
-		sess.peg(p)
+		pegID[p.Exemplar()] = sess.peg(p)
 		pkeys[i] = pegKey(p)
 	}
 	existing := nodeCount(autoscalingCtx.ClusterSnapshot)
@@ -90,6 +115,7 @@ func (s *Shared) fill(autoscalingCtx *ca_context.AutoscalingContext, pegs []esti
 	s.loopLastIndex = rs.lastIndex
 	rs.mu.Unlock()
 	gkeys := make([]C.uint64_t, 0, len(ngs))
+	groupRow := make(map[C.uint64_t]C.int32_t, len(ngs))
 	for _, ng := range ngs {
 		tmpl, ok := infos[ng.Id()]
 		if !ok {
@@ -98,9 +124,10 @@ func (s *Shared) fill(autoscalingCtx *ca_context.AutoscalingContext, pegs []esti
 		// estimatorBuilder(snapshot, NewEstimationContext(MaxNodesTotal, SimilarNodeGroups, currentNodeCount)) — orchestrator.go:409-412
 		ectx := estimator.NewEstimationContext(s.maxNodesTotal, similar(ng), existing)
 		s.limiter.StartEstimation(pegs, ng, ectx)
-		sess.group(tmpl, s.limiter.MaxNodes(), existing, s.loopLastIndex, nil)
+		row := sess.group(tmpl, s.limiter.MaxNodes(), existing, s.loopLastIndex, nil)
 		s.limiter.EndEstimation()
 		gkeys = append(gkeys, groupKey(ng, tmpl))
+		groupRow[groupKey(ng, tmpl)] = row
 	}
 	if len(gkeys) == 0 { // no candidate group came with a template: nothing to prefetch (and no &gkeys[0] to take)
 		return nil
@@ -115,7 +142,79 @@ func (s *Shared) fill(autoscalingCtx *ca_context.AutoscalingContext, pegs []esti
 	}
 	s.engine.mu.Lock()
 	defer s.engine.mu.Unlock()
-	return rcErr(C.casim_prefetch_fill(s.cache, &pt, &gt, &opts, &gkeys[0], &pkeys[0]), "casim_prefetch_fill")
+	if err := rcErr(C.casim_prefetch_fill(s.cache, &pt, &gt, &opts, &gkeys[0], &pkeys[0]), "casim_prefetch_fill"); err != nil {
+		return err
+	}
+	keep = true // the encoder stays: its tables serve the per-call path of this loop
+	s.sess, s.pegs, s.pegID, s.groupRow = sess, pt, pegID, groupRow
+	return nil
+}
+
+// estimateOnLoopTables is the per-call path WITHOUT encoding: the group's row of the loop's tables (casim_enc_group_rows, n = 1), the
+// PEG list the orchestrator passed as ids of the loop's PEG table, this call's limiter answer / E / lastIndex, one casim_estimate_batch.
+// ok == false: the loop's tables do not know this group or one of the PEGs (the caller encodes the call by itself).
+func (s *Shared) estimateOnLoopTables(ng cloudprovider.NodeGroup, tmpl *framework.NodeInfo, pegs []estimator.PodEquivalenceGroup,
+	maxNodes, existing, lastIndex int, fastpath bool) (nodeCount int, order, placed []C.int32_t, lastIndexOut int, status C.int32_t, ok bool) {
+	if s.sess == nil {
+		return
+	}
+	row, found := s.groupRow[groupKey(ng, tmpl)]
+	if !found {
+		return
+	}
+	n := len(pegs)
+	ids := make([]C.int32_t, n+1)
+	for i := range pegs {
+		id, known := s.pegID[pegs[i].Exemplar()]
+		if !known || int(s.pegCount(id)) != len(pegs[i].Pods) {
+			return
+		}
+		ids[i] = id
+	}
+	var rows C.casim_groups
+	s.engine.mu.Lock()
+	defer s.engine.mu.Unlock()
+	if C.casim_enc_group_rows(s.sess.enc, &row, 1, &rows) != C.CASIM_OK {
+		return
+	}
+	// Go memory referenced from C structs is pinned for the call (cgo pointer rules)
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	off := []C.int32_t{0, C.int32_t(n)}
+	lim := []C.int32_t{C.int32_t(maxNodes), C.int32_t(existing), C.int32_t(lastIndex)}
+	scal := make([]C.int32_t, 6)
+	sums := make([]C.int64_t, 2)
+	order = make([]C.int32_t, n+1)
+	placed = make([]C.int32_t, n+1)
+	for _, p := range []*C.int32_t{&off[0], &ids[0], &lim[0], &scal[0], &order[0], &placed[0]} {
+		pin.Pin(p)
+	}
+	pin.Pin(&sums[0])
+	rows.peg_offsets, rows.peg_index = &off[0], &ids[0]
+	rows.max_nodes, rows.existing_nodes, rows.last_index = &lim[0], &lim[1], &lim[2]
+	res := C.casim_results{node_count: &scal[0], pods_scheduled: &scal[1], nodes_added: &scal[2], limiter_nodes: &scal[3], last_index_out: &scal[4],
+		status: &scal[5], req_cpu_sum: &sums[0], req_mem_sum: &sums[1], order: &order[0], placed: &placed[0]}
+	var opts C.casim_options
+	if fastpath {
+		opts.fastpath = 1
+	}
+	if C.casim_estimate_batch(s.engine.ctx, &s.pegs, &rows, &opts, &res) != C.CASIM_OK {
+		return
+	}
+	// order holds ids of the loop's PEG table: back to positions in the caller's list
+	pos := make(map[C.int32_t]C.int32_t, n)
+	for i := 0; i < n; i++ {
+		pos[ids[i]] = C.int32_t(i)
+	}
+	for k := 0; k < n; k++ {
+		order[k] = pos[order[k]]
+	}
+	return int(scal[0]), order[:n], placed[:n], int(scal[4]), scal[5], true
+}
+
+// pegCount reads the pod count of PEG id from the loop's tables (a hit needs the same pods, not only the same exemplar).
+func (s *Shared) pegCount(id C.int32_t) C.int32_t {
+	return *(*C.int32_t)(unsafe.Add(unsafe.Pointer(s.pegs.count), uintptr(id)*unsafe.Sizeof(C.int32_t(0))))
 }
 
 // lookup: a hit only when the call asks exactly the question the batch answered (group, PEG set, limiter answer, E, lastIndex).

@@ -77,7 +77,7 @@ PREFETCH_MISS_GROUP, PREFETCH_MISS_PEGS, PREFETCH_MISS_LIMITS = 1, 2, 3
 
 
 class Options(C.Structure):
-    _fields_ = [("fastpath", C.c_int32), ("force_generic_packer", C.c_int32), ("node_pods", C.c_int32), ("n_streams", C.c_int32), ("pack_build", C.c_int32), ("no_singleton_merge", C.c_int32), ("no_front_kernel", C.c_int32), ("reserved", C.c_int32 * 1)]
+    _fields_ = [("fastpath", C.c_int32), ("force_generic_packer", C.c_int32), ("node_pods", C.c_int32), ("n_streams", C.c_int32), ("pack_build", C.c_int32), ("no_singleton_merge", C.c_int32), ("no_front_kernel", C.c_int32), ("winners_only", C.c_int32)]
 
 
 class Results(C.Structure):

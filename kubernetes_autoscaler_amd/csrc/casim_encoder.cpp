@@ -330,7 +330,7 @@ struct casim_encoder {
     std::vector<int64_t> rows_alloc, rows_init_req, rows_waste_cpu, rows_waste_mem;   // casim_enc_group_rows: compact copies
     std::vector<int32_t> rows_allowed, rows_init_pods, rows_max_nodes, rows_existing, rows_last_index;
     std::vector<uint32_t> rows_gflags;
-    std::vector<uint64_t> rows_taint, rows_label, rows_init_excl;
+    std::vector<uint64_t> rows_taint, rows_label, rows_init_excl, rows_init_zone, rows_zone_valid;
     std::vector<double> rows_cap_cpu, rows_cap_mem;
 };
 
@@ -1569,7 +1569,7 @@ int32_t casim_enc_refinalize(casim_encoder* e, int32_t* changed_out, int32_t cap
 // compact copies of n rows of the node table (what casim_cluster_update_nodes takes); valid until the next call / destroy
 int32_t casim_enc_group_rows(casim_encoder* e, const int32_t* groups, int32_t n, casim_groups* out) {
     if (!e || !e->finalized || !out || n < 0 || (n > 0 && !groups)) return CASIM_ERR_INVALID;
-    const size_t R = (size_t)e->opt.n_res, Wt = (size_t)e->Wt, Wl = (size_t)e->Wl, Wx = (size_t)e->Wx, N = (size_t)n;
+    const size_t R = (size_t)e->opt.n_res, Wt = (size_t)e->Wt, Wl = (size_t)e->Wl, Wx = (size_t)e->Wx, Wz = e->init_zone.size() / (e->groups.empty() ? 1 : e->groups.size()), N = (size_t)n;
     for (int32_t k = 0; k < n; ++k) if (groups[k] < 0 || (size_t)groups[k] >= e->groups.size()) return CASIM_ERR_INVALID;
     auto pick = [&](auto& dst, const auto& src, size_t width) {
         dst.resize(N * width + 1);
@@ -1577,12 +1577,14 @@ int32_t casim_enc_group_rows(casim_encoder* e, const int32_t* groups, int32_t n,
     };
     pick(e->rows_alloc, e->alloc, R); pick(e->rows_init_req, e->init_req, R); pick(e->rows_allowed, e->allowed, 1); pick(e->rows_init_pods, e->init_pods, 1);
     pick(e->rows_gflags, e->gflags, 1); pick(e->rows_taint, e->taint, Wt); pick(e->rows_label, e->label, Wl); pick(e->rows_init_excl, e->init_excl, Wx);
+    pick(e->rows_init_zone, e->init_zone, Wz); pick(e->rows_zone_valid, e->zone_valid, Wz);   // (template mode: group-wide exclusion words of the rows)
     pick(e->rows_max_nodes, e->max_nodes, 1); pick(e->rows_existing, e->existing_nodes, 1); pick(e->rows_last_index, e->last_index, 1);
     pick(e->rows_cap_cpu, e->cap_cpu, 1); pick(e->rows_cap_mem, e->cap_mem, 1); pick(e->rows_waste_cpu, e->waste_cpu, 1); pick(e->rows_waste_mem, e->waste_mem, 1);
     memset(out, 0, sizeof *out);
     out->n_groups = n;
     out->alloc = e->rows_alloc.data(); out->init_req = e->rows_init_req.data(); out->allowed_pods = e->rows_allowed.data(); out->init_pods = e->rows_init_pods.data();
     out->flags = e->rows_gflags.data(); out->taint_mask = e->rows_taint.data(); out->label_mask = e->rows_label.data(); out->init_excl = e->rows_init_excl.data();
+    out->init_zone = e->rows_init_zone.data(); out->zone_valid = e->rows_zone_valid.data();
     out->max_nodes = e->rows_max_nodes.data(); out->existing_nodes = e->rows_existing.data(); out->last_index = e->rows_last_index.data();
     out->cap_cpu = e->rows_cap_cpu.data(); out->cap_mem = e->rows_cap_mem.data(); out->waste_cpu = e->rows_waste_cpu.data(); out->waste_mem = e->rows_waste_mem.data();
     return CASIM_OK;

@@ -98,7 +98,7 @@ struct SingletonRuns {
 
     bool build(const casim_pegs* P, const casim_groups* Gp, const casim_options* o) {
         active = false;
-        if (!o || o->fastpath || o->no_singleton_merge || Gp->n_sims > 1) return false;
+        if (!o || o->fastpath || o->no_singleton_merge || o->winners_only || Gp->n_sims > 1) return false;
         const int G = P->n_pegs, NG = Gp->n_groups, R = P->n_res;
         if (G < 2 || !P->count || !P->flags || !P->req) return false;
         bool any = false;
@@ -216,6 +216,7 @@ public:
         memset(&dt_, 0, sizeof dt_); memset(&dr_, 0, sizeof dr_); memset(&ps_, 0, sizeof ps_); memset(&os_, 0, sizeof os_);
         dt_.G = G_; dt_.R = p->n_res; dt_.Wt = p->w_taint; dt_.Wl = p->w_label; dt_.Wx = p->w_excl; dt_.Wz = p->w_zone;
         dt_.NG = NG_; dt_.fastpath = o ? o->fastpath : 0;
+        winners_only_ = o && o->winners_only != 0; winners_ready_ = false;
         const int R = dt_.R;
         const size_t G = (size_t)G_, NG = (size_t)NG_;
         if (G > 0 && (!p->req || !p->count || !p->flags)) return fail(CASIM_ERR_INVALID, "PEG table has null columns");
@@ -276,7 +277,7 @@ public:
                 if (g->peg_offsets) cap = NG > 0 ? g->peg_offsets[NG] : 0;
                 else if (g->peg_lo && g->peg_hi) { for (size_t i = 0; i < NG; ++i) cap += (int64_t)g->peg_hi[i] - g->peg_lo[i]; }
                 else cap = (int64_t)NG * G_;
-                ord_in_slab_ = cap >= 0 && cap <= 16384;
+                ord_in_slab_ = cap >= 0 && cap <= 16384 && !winners_only_;   // (winners only: the compacted lists are a copy of their own)
                 if (ord_in_slab_) {
                     ord_off_ = (res_bytes_ + 15) & ~(size_t)15;
                     ord_cap_ = (size_t)cap;
@@ -711,13 +712,17 @@ public:
             return CASIM_OK;
         }
         const size_t NG = (size_t)NG_, ng = NG > 0 ? NG : 1;
+        const bool winners = winners_only_ && (out->order || out->placed);
+        if (winners && !winners_ready_) return fail(CASIM_ERR_INVALID, "winners_only: run the expander query (per simulation, best_out set) before the fetch");
         // copy 1: scalars + offsets (one slab); copies 2, 3: order / placed — enqueued with the first one when their bound is
         // small or the offsets are the caller's, after it (the device-side nnz is in the slab) otherwise
-        const bool spec = !csr_on_device_ || nnz_cap_ <= 16384;
+        const bool spec = (!csr_on_device_ || nnz_cap_ <= 16384) && !winners;
         const size_t spec_n = !csr_on_device_ ? (size_t)(NG > 0 ? h_off_[NG] : 0) : (size_t)nnz_cap_;
         char* st = (char*)bk_.stage(1, res_bytes_ + (spec ? 8 * spec_n : 0) + 64);
         if (!st) return fail(CASIM_ERR_NOMEM, "no staging buffer");
         bk_.d2h(st, res_slab_, res_bytes_);
+        int32_t wtotal = 0;
+        if (winners) bk_.d2h(&wtotal, d_woff_ + winners_s_, 4);
         int32_t* st_order = (int32_t*)(st + ((res_bytes_ + 15) & ~(size_t)15));
         int32_t* st_placed = st_order + spec_n;
         if (ord_in_slab_) { st_order = (int32_t*)(st + ord_off_); st_placed = st_order + ord_cap_ + 1; }   // (they came with the slab)
@@ -743,7 +748,14 @@ public:
             if (out->order && nnz) memcpy(out->order, st_order, 4 * nnz);
             if (out->placed && nnz) memcpy(out->placed, st_placed, 4 * nnz);
         }
-        if (!spec && nnz > 0) {   // a big batch: straight into the caller's arrays (through the pinned staging buffer in two pieces it was
+        if (winners) {            // the compacted lists of the simulations' winning groups: sum(len(winner)) entries
+            if (wtotal > 0) {
+                if (out->order) bk_.d2h(out->order, d_worder_, 4 * (size_t)wtotal);
+                if (out->placed) bk_.d2h(out->placed, d_wplaced_, 4 * (size_t)wtotal);
+                bk_.sync();
+            }
+            winners_total_ = wtotal;
+        } else if (!spec && nnz > 0) {   // a big batch: straight into the caller's arrays (through the pinned staging buffer in two pieces it was
                                   // no faster: 6.4-6.5 ms against 6.2-6.3 per headline call, r07n)
             if (out->order) bk_.d2h(out->order, dr_.order, 4 * nnz);
             if (out->placed) bk_.d2h(out->placed, dr_.placed, 4 * nnz);
@@ -848,6 +860,16 @@ public:
         const int span = per_sim ? max_sim_groups_ : NG_;
         const int opt_threads = span > 1024 ? 1024 : (span > 64 ? 256 : 64);
         bk_.launch(option_kernel, S, 1, opt_threads, (size_t)(8 * opt_threads), a);
+        if (winners_only_) {
+            // the winners' lists, compacted on the device right behind the reduce: what fetch() copies back (casim_options.winners_only)
+            if (!d_woff_ || (size_t)S > woff_cap_) { d_woff_ = (int32_t*)dalloc(4 * ((size_t)S + 1)); woff_cap_ = (size_t)S; }
+            if (!d_worder_) { d_worder_ = (int32_t*)dalloc(4 * ((size_t)nnz_cap_ + 1)); d_wplaced_ = (int32_t*)dalloc(4 * ((size_t)nnz_cap_ + 1)); }
+            const int wt = S > 256 ? 1024 : 256;
+            bk_.launch(winner_offsets_kernel, 1, 1, wt, (size_t)(4 * ((wt + 63) / 64 + 2)), (const int32_t*)d_opt_out_, (const int32_t*)dt_.peg_off, S, d_woff_);
+            bk_.launch(gather_winners_kernel, S, 1, 64, (size_t)0, (const int32_t*)d_opt_out_, (const int32_t*)dt_.peg_off, (const int32_t*)d_woff_,
+                       (const int32_t*)dr_.order, (const int32_t*)dr_.placed, d_worder_, d_wplaced_);
+            winners_ready_ = true; winners_s_ = S;
+        }
         if (q->best_out || q->n_best_out || q->best_set_out || q->key_out || q->packed_out) {
             // deferred: the answers land in the (pinned) upload staging buffer — a copy into the caller's pageable arrays would wait for
             // the stream by itself — and move to the caller's arrays once the fetch has waited; the upload that used the buffer is
@@ -913,6 +935,17 @@ public:
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
     }
     int sims() const { return n_sims_; }
+    bool winners_only() const { return winners_only_; }
+    // entries of the compacted winners' lists (after the expander query; waits for the device): a streamed batch needs every part's
+    // share before it knows where the next part's lists start in the caller's arrays
+    int32_t winners_total(int32_t* n_out) {
+        if (!winners_only_ || !winners_ready_) return fail(CASIM_ERR_INVALID, "winners_only: no expander query ran");
+        int32_t t = 0;
+        bk_.d2h(&t, d_woff_ + winners_s_, 4);
+        bk_.sync();
+        *n_out = t;
+        return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
+    }
 
     const std::string& error() const { return err_; }
     BK& backend() { return bk_; }
@@ -1012,6 +1045,8 @@ private:
     bool ord_in_slab_ = false; size_t ord_off_ = 0, ord_cap_ = 0;   // order / placed inside the results slab (short lists)
     std::vector<int32_t> opt_host_; const casim_option_query* opt_pending_q_ = nullptr; int opt_pending_s_ = 0; const char* opt_stage_ = nullptr;
     bool opt_in_slab_ = false; size_t opt_off_ = 0; std::vector<char> opt_keep_;   // (the expander's answer as the last fetch() brought it)
+    bool winners_only_ = false, winners_ready_ = false; int winners_s_ = 0; int32_t winners_total_ = 0;   // casim_options.winners_only
+    int32_t* d_woff_ = nullptr; int32_t* d_worder_ = nullptr; int32_t* d_wplaced_ = nullptr; size_t woff_cap_ = 0;
     bool front_ = false, front_ran_ = false;   // feas + offsets + lists + order in ONE launch (front_kernel)
     uint64_t* d_ticket_ = nullptr; uint32_t front_epoch_ = 0;
     static constexpr size_t kFrontMaxGroups = 1024;

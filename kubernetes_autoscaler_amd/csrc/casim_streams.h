@@ -125,9 +125,10 @@ public:
         if (!out) return fail(CASIM_ERR_INVALID, "null results");
         // the parts' shares of order / placed: their nnz (device-side CSR) first
         std::vector<int32_t> base(parts_.size() + 1, 0);
+        const bool winners = opts_.winners_only != 0 && (out->order || out->placed);   // the parts' compacted winners' lists, back to back
         for (size_t i = 0; i < parts_.size(); ++i) {
             int32_t nnz = 0;
-            const int32_t rc = parts_[i].prob->csr(&nnz, nullptr);
+            const int32_t rc = winners ? parts_[i].prob->winners_total(&nnz) : parts_[i].prob->csr(&nnz, nullptr);
             if (rc != CASIM_OK) return fail(rc, parts_[i].prob->error().c_str());
             base[i + 1] = base[i] + nnz;
         }

@@ -32,6 +32,7 @@ class BatchResult:
     placed: np.ndarray           # [nnz] pods of that PEG that were scheduled (a prefix)
     node_pods: Optional[np.ndarray] = None          # pods per added node (Problem(..., node_pods=True)), compact
     node_pods_offsets: Optional[np.ndarray] = None  # [NG+1]
+    winner_offsets: Optional[np.ndarray] = None     # winners_only calls: order / placed hold the winners' lists only, list s at [w[s], w[s+1])
 
     def nodes_with_pods(self, i: int, template_name: str):
         """newNodesWithPods of group i as the reference names them: '<template>-e-<j>' for every added node holding a pod
@@ -587,11 +588,16 @@ class BatchCall:
     the context's internal streams.  call() returns (BatchResult, expander dict or None)."""
 
     def __init__(self, ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, kinds: Optional[Sequence[int]] = None, fastpath: bool = False,
-                 force_generic_packer: bool = False, n_streams: int = 0):
+                 force_generic_packer: bool = False, n_streams: int = 0, winners_only: bool = False):
+        """winners_only (casim_options.winners_only): order / placed come back for the winning group of every simulation only —
+        call() then returns a BatchResult whose `order` / `placed` are those compact lists and whose `winner_offsets` [S + 1] says where
+        simulation s's list sits (see winners_view)."""
         self.ctx, self.pegs, self.groups = ctx, pegs, groups
         ng = groups.n_groups
+        self.winners_only = bool(winners_only)
         self.st, self.arrs = alloc_results(ng, _nnz_cap(pegs, groups))
-        self.opts = _abi.Options(fastpath=int(fastpath), force_generic_packer=int(force_generic_packer), n_streams=int(n_streams))
+        self.opts = _abi.Options(fastpath=int(fastpath), force_generic_packer=int(force_generic_packer), n_streams=int(n_streams),
+                                 winners_only=int(self.winners_only))
         self.off = np.zeros(ng + 1, np.int32)
         self.q = self.exp = None
         if kinds is not None:
@@ -608,7 +614,20 @@ class BatchCall:
     def call(self):
         self.call_raw()
         ng = self.groups.n_groups
-        return finish_results(self.arrs, ng, int(self.off[ng]), self.off.copy()), self.exp
+        res = finish_results(self.arrs, ng, int(self.off[ng]), self.off.copy())
+        if self.winners_only:
+            res.winner_offsets = winner_offsets(self.off, self.exp["best"])
+        return res, self.exp
+
+
+def winner_offsets(offsets, best) -> np.ndarray:
+    """casim_options.winners_only: where simulation s's winning list sits inside the compact order / placed arrays — [S + 1] prefix sums of
+    the winners' list lengths (0 for a simulation without an option), from the batch's full CSR offsets and the expander's best_out."""
+    best = np.asarray(best, np.int64)
+    off = np.asarray(offsets, np.int64)
+    has = best >= 0
+    lens = np.where(has, off[np.where(has, best, 0) + 1] - off[np.where(has, best, 0)], 0)
+    return np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
 
 
 def estimate_batch(ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, fastpath: bool = False) -> BatchResult:

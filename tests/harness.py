@@ -434,7 +434,8 @@ def encode_batch(scenarios: Sequence[Scenario]):
     return enc, ts, bases
 
 
-def run_emu_tables(ts, kinds=None, per_sim=True, valid=None, fastpath=False, lds_budget=0, node_pods_capacity=0, generic=False, front=True):
+def run_emu_tables(ts, kinds=None, per_sim=True, valid=None, fastpath=False, lds_budget=0, node_pods_capacity=0, generic=False, front=True,
+                   winners_only=False):
     """Product kernels under the wave emulator on a TableSet.  Returns (BatchResult, expander dict or None)."""
     L = emu_lib()
     if not hasattr(L, "_query_bound"):
@@ -451,7 +452,8 @@ def run_emu_tables(ts, kinds=None, per_sim=True, valid=None, fastpath=False, lds
     else:
         nnz_cap = pegs.n_pegs * ng
     st, arrs = alloc_results(ng, nnz_cap, node_pods_capacity)
-    opts = _abi.Options(fastpath=int(fastpath), node_pods=int(node_pods_capacity > 0), force_generic_packer=int(generic), no_front_kernel=int(not front))
+    opts = _abi.Options(fastpath=int(fastpath), node_pods=int(node_pods_capacity > 0), force_generic_packer=int(generic), no_front_kernel=int(not front),
+                        winners_only=int(winners_only))
     nnz = C.c_int32(0)
     off = np.zeros(ng + 1, np.int32)
     q = exp = None
@@ -472,7 +474,7 @@ def run_emu_tables(ts, kinds=None, per_sim=True, valid=None, fastpath=False, lds
     return finish_results(arrs, ng, int(nnz.value), off), exp
 
 
-def run_emu_streams(ts, n_streams, kinds=None, valid=None, generic=False, group_id_base=0):
+def run_emu_streams(ts, n_streams, kinds=None, valid=None, generic=False, group_id_base=0, winners_only=False):
     """The batch cut into sub-batches the way casim_options.n_streams does it (csrc/casim_streams.h), parts run by the emulator one
     after the other.  Returns (BatchResult, expander dict or None, parts)."""
     L = emu_lib()
@@ -485,7 +487,7 @@ def run_emu_streams(ts, n_streams, kinds=None, valid=None, generic=False, group_
     ng = groups.n_groups
     nnz_cap = int((ts.peg_hi - ts.peg_lo).sum()) if ts.peg_lo is not None else (int(ts.peg_offsets[ng]) if ts.peg_offsets is not None else pegs.n_pegs * ng)
     st, arrs = alloc_results(ng, nnz_cap)
-    opts = _abi.Options(force_generic_packer=int(generic), n_streams=int(n_streams))
+    opts = _abi.Options(force_generic_packer=int(generic), n_streams=int(n_streams), winners_only=int(winners_only))
     nnz, parts = C.c_int32(0), C.c_int32(0)
     off = np.zeros(ng + 1, np.int32)
     q = exp = None

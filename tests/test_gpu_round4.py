@@ -56,3 +56,28 @@ def test_rules_from_a_fresh_snapshot_need_forget_commits_on_the_device(ctx):
         assert compared >= 10
     finally:
         mod.EmuCluster = saved
+
+
+def test_winners_only_on_the_device(ctx):
+    """casim_options.winners_only through casim_estimate_batch_query on the MI355X: one part and streamed parts against the full answer
+    (the emulator form is tests/test_winners_only_emu.py); a C2 batch like the bench's enter_return row."""
+    from bench import _same_winners, simulation_tables
+    from kubernetes_autoscaler_amd.engine import BatchCall
+    from kubernetes_autoscaler_amd.tables import TableSet
+    from test_winners_only_emu import _batch, _check
+    KINDS = [_abi.EXPANDER_LEAST_NODES]
+    enc, ts, _ = _batch(37)
+    pegs, groups = ts.structs()
+    full, fexp = BatchCall(ctx, pegs, groups, kinds=KINDS).call()
+    for k in (0, 3):
+        call = BatchCall(ctx, pegs, groups, kinds=KINDS, n_streams=k, winners_only=True)
+        for _ in range(2):
+            got, gexp = call.call()
+        assert _check(full, fexp, got, gexp, f"n_streams {k}") > 0
+    enc.close()
+    c2 = simulation_tables(workloads.config_c2, range(4), kaa.Encoder, TableSet).tile(24)     # 96 simulations
+    pegs, groups = c2.structs()
+    full = BatchCall(ctx, pegs, groups, kinds=KINDS, n_streams=4).call()
+    win = BatchCall(ctx, pegs, groups, kinds=KINDS, n_streams=4, winners_only=True).call()
+    assert _same_winners(win, full)
+    assert int(win[0].winner_offsets[-1]) * 8 < int(full[0].offsets[-1])      # (an eighth of the lists at most: 20 groups per simulation)
