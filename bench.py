@@ -236,6 +236,7 @@ def config_rows(kaa, ctx, workloads, kinds, iters=20):
     from harness import assert_matches_oracle
     from kubernetes_autoscaler_amd.engine import finish_results
     rows = []
+    loop_tables = {}   # filled by row C2 (native --shim replay), reported by row C2-per-call
 
     def c2_one_group(seed_offset=0):
         """What ONE Estimate() call carries when the shim does not batch: the first node group of C2 and every PEG."""
@@ -306,7 +307,15 @@ def config_rows(kaa, ctx, workloads, kinds, iters=20):
             import native_trace
             tpath = os.path.join("/tmp", f"casim_{name}.trace")
             native_trace.trace_estimate(w, tpath, kinds=kinds, iters=iters).close()
-            nrc, nat = native_trace.run_native(tpath)
+            nrc, nat = native_trace.run_native(tpath, shim=(name == "C2"))
+            if name == "C2" and isinstance(nat.get("shim"), dict):
+                # per-call mode of the shim on the LOOP's tables: the loop is encoded once (this row's encode_ms, every PEG
+                # and every group), an Estimate() that misses the prefetch cache is casim_enc_group_rows + casim_estimate_batch — no encoder work
+                sh = nat["shim"]
+                loop_tables["per_call_on_loop_tables_ms"] = sh.get("per_call_on_loop_tables_ms")
+                loop_tables["loop_encode_ms"] = nat.get("encode_ms")
+                loop_tables["groups"] = sh.get("groups")
+                loop_tables["failed_checks"] = sh.get("failed_checks")
             keep = ("enc_calls", "encode_calls_ms", "finalize_ms", "encode_ms", "upload_ms", "feasibility_csr_ms", "order_ms", "pack_ms",
                     "expander_ms", "fetch_ms", "timed_wall_ms", "wall_ms", "best_group", "engine_error")
             row["native"] = {k: nat[k] for k in keep if k in nat}
@@ -314,6 +323,14 @@ def config_rows(kaa, ctx, workloads, kinds, iters=20):
             if "wall_ms" in nat and "encode_ms" in nat:
                 row["native"]["encode_plus_call_ms"] = nat["encode_ms"] + nat["wall_ms"]
                 row["native"]["same_winner_as_python_path"] = nat.get("best_group") == row["best_group"]
+            if name == "C2-per-call" and loop_tables.get("per_call_on_loop_tables_ms"):
+                # what ONE Estimate() of a C2 loop costs in per-call mode now: the call on the loop's tables + its share of the loop's one encode
+                lt = loop_tables
+                per = lt["per_call_on_loop_tables_ms"] + (lt["loop_encode_ms"] or 0.0) / max(lt["groups"] or 1, 1)
+                row["native"]["on_loop_tables"] = dict(lt, encode_share_plus_call_ms=per, speedup_vs_oracle=row["oracle_ms"] / per,
+                                                       what="casim_enc_group_rows + casim_estimate_batch on the tables the loop encoded once (row C2's encode_ms / 20 groups): "
+                                                            "how the Go shim serves an Estimate() that misses the prefetch cache (integration/go/gpubinpacking/prefetch.go estimateOnLoopTables); "
+                                                            "encode_plus_call_ms above is a call that encodes its 400 PEGs itself (no loop tables: the analyser path)")
         except Exception as e:  # a side table must never take the headline down
             row["error"] = f"{type(e).__name__}: {e}"
         rows.append(row)

@@ -253,8 +253,16 @@ casim_groups group_view(const casim_pegs& p, const casim_groups& g, int i) {
     return w;
 }
 // per-call mode: ONE Estimate() = one casim_estimate_batch with one group record and the caller's PEG list; order as positions in that list
-int32_t per_call(casim_ctx* ctx, const casim_pegs& p, const casim_groups& g, int i, const std::vector<int32_t>& list, int32_t max_nodes, const casim_options& opt, OneGroup& out) {
+// (enc != NULL: the group's row through casim_enc_group_rows, the call the Go shim makes — estimateOnLoopTables in
+// integration/go/gpubinpacking/prefetch.go; NULL: pointer offsets into the caller's own tables)
+int32_t per_call(casim_ctx* ctx, const casim_pegs& p, const casim_groups& g, int i, const std::vector<int32_t>& list, int32_t max_nodes, const casim_options& opt, OneGroup& out,
+                 casim_encoder* enc = nullptr) {
     casim_groups w = group_view(p, g, i);
+    if (enc) {
+        const int32_t row = i;
+        memset(&w, 0, sizeof w);
+        if (casim_enc_group_rows(enc, &row, 1, &w) != CASIM_OK) return CASIM_ERR_INVALID;
+    }
     const int32_t off[2] = {0, (int32_t)list.size()};
     const int32_t mn[1] = {max_nodes};
     w.peg_offsets = off; w.peg_index = list.data(); w.max_nodes = mn;
@@ -271,7 +279,7 @@ int32_t per_call(casim_ctx* ctx, const casim_pegs& p, const casim_groups& g, int
     return rc;
 }
 // returns the number of failed checks; prints one JSON member
-int shim_replay(casim_ctx* ctx, const casim_pegs& pegs, const casim_groups& groups, int fastpath) {
+int shim_replay(casim_ctx* ctx, const casim_pegs& pegs, const casim_groups& groups, int fastpath, casim_encoder* enc) {
     const int NG = groups.n_groups, G = pegs.n_pegs;
     casim_options opt; memset(&opt, 0, sizeof opt); opt.fastpath = fastpath;
     int bad = 0;
@@ -306,7 +314,7 @@ int shim_replay(casim_ctx* ctx, const casim_pegs& pegs, const casim_groups& grou
     int32_t rc = casim_prefetch_fill(pf, &pegs, &groups, &opt, gkey.data(), pkey.data());   // ---- NodeGroupListProcessor.Process
     const double fill_ms = ms_since(tf);
     if (rc != 0) { printf(", \"shim\": {\"error\": \"fill %d %s\"}", rc, casim_prefetch_error(pf)); casim_prefetch_destroy(pf); return 1; }
-    int hits = 0, equal = 0; double lookup_ms = 0, percall_ms = 0;
+    int hits = 0, equal = 0, rows_calls = 0; double lookup_ms = 0, percall_ms = 0, rows_ms = 0;
     for (int i = 0; i < NG; ++i) {                                                         // ---- ComputeExpansionOption, group by group
         const std::vector<int32_t>& l = lists[(size_t)i];
         std::vector<uint64_t> k = keys_of(l);
@@ -321,6 +329,16 @@ int shim_replay(casim_ctx* ctx, const casim_pegs& pegs, const casim_groups& grou
         const auto t1 = clk::now();
         if (per_call(ctx, pegs, groups, i, l, groups.max_nodes[i], opt, pc) != 0) { fail("per-call estimate failed", i); continue; }
         percall_ms += ms_since(t1);
+        {   // the same Estimate() the way the Go shim serves a miss: row through casim_enc_group_rows, no encoding (3 calls, the median)
+            OneGroup pr; std::vector<double> t;
+            for (int rep = 0; rep < 3; ++rep) {
+                const auto t2 = clk::now();
+                if (per_call(ctx, pegs, groups, i, l, groups.max_nodes[i], opt, pr, enc) != 0) { fail("per-call through casim_enc_group_rows failed", i); break; }
+                t.push_back(ms_since(t2));
+            }
+            if (!t.empty()) { rows_ms += median(t); ++rows_calls; }
+            if (pr.order != pc.order || pr.placed != pc.placed || memcmp(pr.v, pc.v, sizeof pc.v) != 0) fail("per-call through casim_enc_group_rows differs", i);
+        }
         order.resize(l.size()); placed.resize(l.size());
         const bool same = r.node_count == pc.v[0] && r.pods_scheduled == pc.v[1] && r.nodes_added == pc.v[2] && r.limiter_nodes == pc.v[3] && r.last_index_out == pc.v[4] &&
                           r.status == pc.v[5] && r.req_cpu_sum == pc.sums[0] && r.req_mem_sum == pc.sums[1] && (r.status != 0 || (order == pc.order && placed == pc.placed));
@@ -368,8 +386,8 @@ int shim_replay(casim_ctx* ctx, const casim_pegs& pegs, const casim_groups& grou
     int64_t st[8]; casim_prefetch_stats(pf, st);
     casim_prefetch_destroy(pf);
     printf(", \"shim\": {\"groups\": %d, \"hits\": %d, \"hits_equal_to_per_call\": %d, \"miss_paths_checked\": %d, \"failed_checks\": %d, \"fill_ms\": %.4f, "
-           "\"lookups_ms\": %.4f, \"per_call_ms_total\": %.4f, \"stats\": [%lld, %lld, %lld, %lld, %lld, %lld]}",
-           NG, hits, equal, miss_checked, bad, fill_ms, lookup_ms, percall_ms, (long long)st[0], (long long)st[1], (long long)st[2], (long long)st[3], (long long)st[4], (long long)st[5]);
+           "\"lookups_ms\": %.4f, \"per_call_ms_total\": %.4f, \"per_call_on_loop_tables_ms\": %.4f, \"stats\": [%lld, %lld, %lld, %lld, %lld, %lld]}",
+           NG, hits, equal, miss_checked, bad, fill_ms, lookup_ms, percall_ms, rows_calls ? rows_ms / rows_calls : 0.0, (long long)st[0], (long long)st[1], (long long)st[2], (long long)st[3], (long long)st[4], (long long)st[5]);
     return bad;
 }
 
@@ -462,7 +480,7 @@ int main(int argc, char** argv) {
                 dump_i32(df, "limiter", lim); dump_i32(df, "last_index", li); dump_i32(df, "status", st); dump_i32(df, "order", order); dump_i32(df, "placed", placed);
                 dump_i32(df, "best", std::vector<int32_t>{best, nbest});
             }
-            if (shim && shim_replay(ctx, pegs, groups, fastpath) != 0) exit_code = 5;
+            if (shim && shim_replay(ctx, pegs, groups, fastpath, enc) != 0) exit_code = 5;
         } else if (dir.name == "try_schedule") {
             const int iters = (int)c.one();
             casim_pod_sequence seq; memset(&seq, 0, sizeof seq);
