@@ -804,6 +804,76 @@ CS_GLOBAL void option_kernel(OptionArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// K_gcd / K_scale: the exact int32 image of the request table, on the device
+// ------------------------------------------------------------------------------------------
+// The register packer computes on int32 lanes: every resource lane divided by the gcd of all its values (exact).  For a batch of a
+// million PEGs the host pass over the request table — one modulo per value while the gcd settles, then the quotients — was the longest
+// stage of an enter -> return call (2.1 of ~4.5 ms per part, profiles/r05p_init_stages.txt) and its result, 8 more bytes per PEG, travelled
+// over the link as well.  The int64 table is on the device anyway: gcd_reduce_kernel folds it to one partial per block (gcd, largest
+// magnitude, "some value is negative" per lane; the host folds the few hundred partials together with the group table and decides),
+// scale_requests_kernel writes the quotients.  Same arithmetic as the host pass (casim_pipeline.h), same results by test.
+struct GcdPartial { uint64_t sc[4]; uint64_t amax[4]; uint64_t neg; };
+CS_DEVICE uint64_t gcd_u64(uint64_t a, uint64_t b) { while (b) { const uint64_t x = a % b; a = b; b = x; } return a; }
+CS_DEVICE uint64_t gcd_fold(uint64_t sc, uint64_t a /* |value| */) {
+    if (sc == 1 || a == 0) return sc;
+    if (sc == 0) return a;
+    uint64_t m;
+    if ((sc & (sc - 1)) == 0) m = a & (sc - 1);                                                // byte-granular lanes settle on a power of two
+    else if (a <= 0xffffffffull && sc <= 0xffffffffull) m = (uint64_t)((uint32_t)a % (uint32_t)sc);   // milli-cpu lanes: the short division
+    else m = a % sc;
+    return m ? gcd_u64(sc, m) : sc;
+}
+CS_GLOBAL void gcd_reduce_kernel(const int64_t* CS_RESTRICT req /*[G][R]*/, int64_t G, int R, GcdPartial* CS_RESTRICT out /*[nblocks]*/) {
+    uint64_t sc[4] = {0, 0, 0, 0}, amax[4] = {0, 0, 0, 0};
+    bool neg = false;
+    const int64_t stride = (int64_t)cs::nblocks() * cs::nthreads();
+    for (int64_t i = (int64_t)cs::bid() * cs::nthreads() + cs::tid(); i < G; i += stride) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r >= R) break;
+            const int64_t v = req[i * R + r];
+            neg = neg || v < 0;
+            const uint64_t a = v < 0 ? (v == INT64_MIN ? (uint64_t)INT64_MAX : (uint64_t)(-v)) : (uint64_t)v;
+            sc[r] = gcd_fold(sc[r], a);
+            amax[r] = a > amax[r] ? a : amax[r];
+        }
+    }
+    // wave: butterfly over the lanes (a partner's gcd is folded like a value), block: one partial per wave through LDS
+    const int lane = cs::lane(), wave = cs::tid() >> 6, nw = (cs::nthreads() + 63) >> 6;
+    for (int d = 32; d > 0; d >>= 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint64_t os = cs::readlane_u64(sc[r], lane ^ d), oa = cs::readlane_u64(amax[r], lane ^ d);
+            sc[r] = gcd_fold(sc[r], os);
+            amax[r] = oa > amax[r] ? oa : amax[r];
+        }
+    }
+    const bool wneg = cs::ballot(neg) != 0;
+    uint64_t* sm = (uint64_t*)cs::dyn_smem();   // [nw][9]
+    if (lane == 0) { for (int r = 0; r < 4; ++r) { sm[wave * 9 + r] = sc[r]; sm[wave * 9 + 4 + r] = amax[r]; } sm[wave * 9 + 8] = wneg ? 1 : 0; }
+    cs::sync();
+    if (cs::tid() == 0) {
+        GcdPartial p;
+        for (int r = 0; r < 4; ++r) { p.sc[r] = 0; p.amax[r] = 0; }
+        p.neg = 0;
+        for (int w = 0; w < nw; ++w) {
+            for (int r = 0; r < 4; ++r) { p.sc[r] = gcd_fold(p.sc[r], sm[w * 9 + r]); p.amax[r] = sm[w * 9 + 4 + r] > p.amax[r] ? sm[w * 9 + 4 + r] : p.amax[r]; }
+            p.neg |= sm[w * 9 + 8];
+        }
+        out[cs::bid()] = p;
+    }
+}
+// exact division by scale = 2^tz * odd: arithmetic shift, then multiply by the inverse of `odd` modulo 2^64 (every value is a multiple)
+struct ScaleParams { uint64_t inv[4]; int32_t tz[4]; };
+CS_GLOBAL void scale_requests_kernel(const int64_t* CS_RESTRICT req, int64_t n /* G * R */, int R, ScaleParams sp, int32_t* CS_RESTRICT out) {
+    const int64_t stride = (int64_t)cs::nblocks() * cs::nthreads();
+    for (int64_t i = (int64_t)cs::bid() * cs::nthreads() + cs::tid(); i < n; i += stride) {
+        const int r = (int)(i % R);
+        out[i] = (int32_t)(int64_t)((uint64_t)(req[i] >> sp.tz[r]) * sp.inv[r]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // K_winners: the lists of the winning groups only (casim_options.winners_only)
 // ------------------------------------------------------------------------------------------
 // After the expander's reduce: best[s][0] = winning group of simulation s (index inside the launch, -1 = no option).  One block scans the

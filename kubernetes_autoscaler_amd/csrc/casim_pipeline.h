@@ -415,6 +415,11 @@ public:
                 else m = v % sc;
                 if (m != 0) sc = gcd64(sc, m < 0 ? -m : m);
             };
+            // (device form of the pass over the request table: tables of >= kDevGcdMin values whose staged columns may go out now — nothing
+            // reserved for later writes — and whose lanes fit the kernel's four; CASIM_DEV_GCD_MIN: tests run it on small tables)
+            const char* dgm = getenv("CASIM_DEV_GCD_MIN");
+            const long dev_gcd_min = dgm ? atol(dgm) : (long)kDevGcdMin;
+            const bool dev_gcd = ok && R <= 4 && (long)(G * (size_t)R) >= dev_gcd_min && dt_.req != nullptr && !up_reserved_;
             if (ok) {
                 // one pass over the columns, cut over the host threads: per lane the gcd, the largest magnitude (of a request, an
                 // allocatable, a preloaded amount, a fresh node's free amount) and "some request is negative"
@@ -422,13 +427,34 @@ public:
                 Part parts[kHostLoopThreads];
                 for (auto& pt : parts) { for (int r = 0; r < CASIM_MAX_RES; ++r) pt.sc[r] = pt.amax[r] = 0; pt.neg = false; }
                 auto mag = [](int64_t v) -> int64_t { return v < 0 ? (v == INT64_MIN ? INT64_MAX : -v) : v; };
-                par_for(G, 65536, [&](size_t lo, size_t hi, int t) {
+                if (!dev_gcd) par_for(G, 65536, [&](size_t lo, size_t hi, int t) {
                     Part& pt = parts[t];
                     for (size_t i = lo; i < hi; ++i) for (int r = 0; r < R; ++r) {
                         const int64_t v = p->req[i * R + r];
                         fold(pt.sc[r], v); pt.neg = pt.neg || v < 0; if (mag(v) > pt.amax[r]) pt.amax[r] = mag(v);
                     }
                 });
+                // big tables: the fold over the request table runs on the DEVICE, where the table is anyway (gcd_reduce_kernel: one partial per
+                // block; the quotients by scale_requests_kernel further down) — the host pass above was skipped
+                if (dev_gcd) {
+                    flush_uploads_all();
+                    const int nb = (int)(G / 2048 < 1 ? 1 : (G / 2048 > 1024 ? 1024 : G / 2048));
+                    GcdPartial* d_part = (GcdPartial*)dalloc(sizeof(GcdPartial) * (size_t)nb);
+                    GcdPartial* h_part = (GcdPartial*)bk_.stage(1, sizeof(GcdPartial) * (size_t)nb);
+                    if (!d_part || !h_part) return fail(CASIM_ERR_NOMEM, "no room for the gcd partials");
+                    bk_.launch(gcd_reduce_kernel, nb, 1, 256, (size_t)(8 * 9 * 4), (const int64_t*)dt_.req, (int64_t)G, R, d_part);
+                    bk_.d2h(h_part, d_part, sizeof(GcdPartial) * (size_t)nb);
+                    bk_.sync();
+                    if (!bk_.ok()) return fail(CASIM_ERR_HIP, bk_.error());
+                    Part& pt = parts[0];
+                    for (int b = 0; b < nb; ++b) {
+                        for (int r = 0; r < R; ++r) {
+                            if (h_part[b].sc[r] != 0) pt.sc[r] = pt.sc[r] == 0 ? (int64_t)h_part[b].sc[r] : gcd64(pt.sc[r], (int64_t)h_part[b].sc[r]);
+                            if ((int64_t)h_part[b].amax[r] > pt.amax[r]) pt.amax[r] = (int64_t)h_part[b].amax[r];
+                        }
+                        pt.neg = pt.neg || h_part[b].neg != 0;
+                    }
+                }
                 Part grp; for (int r = 0; r < CASIM_MAX_RES; ++r) grp.sc[r] = grp.amax[r] = 0; grp.neg = false;
                 for (size_t i = 0; i < NG; ++i) for (int r = 0; r < R; ++r) {
                     const int64_t a = g->alloc[i * R + r], b = g->init_req[i * R + r];
@@ -469,9 +495,20 @@ public:
                 // (the big table is written straight into the staging buffer)
                 std::vector<int32_t> req32_own, fresh32(NG * (size_t)R);
                 const int32_t* req32_dev = nullptr;
-                int32_t* req32 = up_reserve<int32_t>(G * (size_t)R, &req32_dev);
-                if (!req32) { req32_own.resize(G * (size_t)R); req32 = req32_own.data(); }
-                par_for(G, 65536, [&](size_t lo, size_t hi, int) { for (size_t i = lo; i < hi; ++i) for (int r = 0; r < R; ++r) req32[i * R + r] = quot(p->req[i * R + r], r); });
+                if (dev_gcd) {   // the quotients on the device, from the int64 table that is there already: 8 bytes per PEG less over the link
+                    int32_t* d32 = (int32_t*)dalloc(4 * G * (size_t)R);
+                    if (!d32) return fail(CASIM_ERR_NOMEM, "no room for the int32 request table");
+                    ScaleParams sp; memset(&sp, 0, sizeof sp);
+                    for (int r = 0; r < R; ++r) { sp.inv[r] = inv[(size_t)r]; sp.tz[r] = tz[(size_t)r]; }
+                    const int64_t nv = (int64_t)(G * (size_t)R);
+                    const int nb = (int)(nv / 1024 < 1 ? 1 : (nv / 1024 > 2048 ? 2048 : nv / 1024));
+                    bk_.launch(scale_requests_kernel, nb, 1, 256, (size_t)0, (const int64_t*)dt_.req, nv, R, sp, d32);
+                    req32_dev = d32;
+                } else {
+                    int32_t* req32 = up_reserve<int32_t>(G * (size_t)R, &req32_dev);
+                    if (!req32) { req32_own.resize(G * (size_t)R); req32 = req32_own.data(); }
+                    par_for(G, 65536, [&](size_t lo, size_t hi, int) { for (size_t i = lo; i < hi; ++i) for (int r = 0; r < R; ++r) req32[i * R + r] = quot(p->req[i * R + r], r); });
+                }
                 for (size_t i = 0; i < NG; ++i) for (int r = 0; r < R; ++r)
                     fresh32[i * R + r] = quot(g->alloc[i * R + r] - g->init_req[i * R + r], r);
                 fs_.req32 = req32_dev ? req32_dev : up(req32_own.data(), req32_own.size());
@@ -982,6 +1019,11 @@ private:
         const long v = e ? atol(e) : 0;
         return v > 0 ? (size_t)v : kUploadChunk;
     }
+    void flush_uploads_all() {   // everything staged so far goes out now (a kernel is about to read it)
+        if (up_reserved_ || !up_dev_ || up_used_ <= up_flushed_) return;
+        bk_.h2d(up_dev_ + up_flushed_, up_host_ + up_flushed_, up_used_ - up_flushed_);
+        up_flushed_ = up_used_;
+    }
     void flush_uploads_early() {
         if (up_reserved_ || !up_dev_ || up_used_ - up_flushed_ < upload_chunk()) return;
         bk_.h2d(up_dev_ + up_flushed_, up_host_ + up_flushed_, up_used_ - up_flushed_);
@@ -1050,6 +1092,7 @@ private:
     bool front_ = false, front_ran_ = false;   // feas + offsets + lists + order in ONE launch (front_kernel)
     uint64_t* d_ticket_ = nullptr; uint32_t front_epoch_ = 0;
     static constexpr size_t kFrontMaxGroups = 1024;
+    static constexpr size_t kDevGcdMin = (size_t)1 << 17;   // request values from which the gcd / int32 pass runs on the device
     std::vector<int32_t> h_off_;
     bool h_off_fresh_ = false;
     char* up_dev_ = nullptr; char* up_host_ = nullptr; size_t up_cap_ = 0, up_used_ = 0; size_t up_flushed_ = 0; bool up_reserved_ = false;

@@ -2,6 +2,7 @@
 Covers taints/tolerations, nodeSelector, host ports (shared / wildcard), hostname and zone
 anti-affinity (self and cross), preloaded DaemonSet pods, every limiter sign, lastIndex / existing
 nodes, zero requests, ties in the orderer score, fastpath, device-side feasibility + CSR."""
+import numpy as np
 import pytest
 
 from harness import GroupSpec, Scenario, assert_matches_oracle, encode, run_emu, run_oracle
@@ -118,3 +119,33 @@ def test_host_loops_cut_over_threads(seed, monkeypatch):
         sc = scenario_of(workloads.fuzz(1000 + seed))
         res, _ = run_emu(encode(sc))
         assert_matches_oracle(res, run_oracle(sc), f"seed {seed}")
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_gcd_and_int32_tables_on_the_device(seed, monkeypatch):
+    """Round 4: for big request tables the gcd fold and the int32 quotients run on the DEVICE (gcd_reduce_kernel / scale_requests_kernel,
+    casim_kernels.h: the host pass was the longest stage of an enter -> return call); CASIM_DEV_GCD_MIN=1 sends fuzz-sized tables down
+    that path: same results as the oracle — lanes with every kind of gcd (the shapes family), lanes that do not narrow at all (generic
+    packer), 3- and 4-lane tables."""
+    monkeypatch.setenv("CASIM_DEV_GCD_MIN", "1")
+    if seed < 30:
+        test_fuzz_fast_packer_shapes(seed)
+    else:
+        sc = scenario_of(workloads.fuzz(1000 + seed))
+        res, _ = run_emu(encode(sc))
+        assert_matches_oracle(res, run_oracle(sc), f"seed {seed}")
+
+
+def test_device_gcd_gives_the_tables_of_the_host_pass(monkeypatch):
+    """the same batch of simulations through both forms of the pass: every result array identical, and the register packer is chosen
+    either way (the verdict on the gcd-scaled ranges is the same)"""
+    import kubernetes_autoscaler_amd as kaa
+    from kubernetes_autoscaler_amd.tables import TableSet
+    from harness import run_emu_tables
+    import bench
+    ts = bench.simulation_tables(workloads.config_c2, range(2), kaa.Encoder, TableSet)
+    a, _ = run_emu_tables(ts)
+    monkeypatch.setenv("CASIM_DEV_GCD_MIN", "1")
+    b, _ = run_emu_tables(ts)
+    for f in ("offsets", "node_count", "pods_scheduled", "nodes_added", "limiter_nodes", "last_index_out", "status", "req_cpu_sum", "req_mem_sum", "order", "placed"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
