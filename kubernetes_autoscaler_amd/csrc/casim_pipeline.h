@@ -25,6 +25,8 @@
 #include <string.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -186,6 +188,18 @@ struct SingletonRuns {
     int64_t expanded(const int32_t* ids, int64_t n) const { int64_t t = 0; for (int64_t k = 0; k < n; ++k) t += len[(size_t)ids[k]]; return t; }
 };
 
+// The parts of a streamed batch upload IN TURN (casim_streams.h).  Four parts that stage and copy at the same time share the link
+// equally, so every part's tables arrive at the same late moment and the kernels of all of them start together: upload phase, then
+// kernel phase, nothing overlapped (4.2 ms per headline call).  With a turn, part 0's bytes travel first (while it is still staging:
+// the early chunks), its kernels run under part 1's copy, and so on: the last part is ready when the link has moved everything
+// once, and only ITS kernels are left.  Staging (the host memcpy into pinned memory) stays parallel: it needs no turn.
+struct UploadGate {
+    std::mutex mu; std::condition_variable cv; int turn = 0;
+    bool my_turn(int i) { std::lock_guard<std::mutex> l(mu); return turn >= i; }
+    void wait_turn(int i) { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return turn >= i; }); }
+    void pass(int i) { { std::lock_guard<std::mutex> l(mu); if (turn == i) turn = i + 1; } cv.notify_all(); }
+};
+
 template <class BK>
 class ProblemT {
 public:
@@ -201,6 +215,7 @@ public:
         struct Stage { bool on; const char* what; std::chrono::steady_clock::time_point t0;
                        void mark(const char* next) { if (!on) return; const auto t1 = std::chrono::steady_clock::now();
                            fprintf(stderr, "[init] %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count()); what = next; t0 = t1; } } stage{timing, "runs + checks", std::chrono::steady_clock::now()};
+        struct GatePass { ProblemT* self; ~GatePass() { self->pass_gate(); } } gate_pass{this};   // (whatever way init() ends, the next part gets its turn)
         if (p->n_pegs < 0 || g->n_groups < 0) return fail(CASIM_ERR_INVALID, "negative size");
         if (p->n_res < 2 || p->n_res > CASIM_KMAX_RES) return fail(CASIM_ERR_INVALID, "n_res must be in [2, 8]");
         if (p->w_taint < 0 || p->w_label < 0 || p->w_excl < 0 || p->w_zone < 0) return fail(CASIM_ERR_INVALID, "negative mask width");
@@ -252,13 +267,14 @@ public:
         zpol_host_.assign((size_t)dt_.Wz, 0ull);   // (the kernels always read Wz polarity words: zeros when the caller passed none)
         if (p->zone_polarity) for (int w = 0; w < dt_.Wz; ++w) zpol_host_[(size_t)w] = p->zone_polarity[w];
         dt_.zpol = up(zpol_host_.data(), (size_t)dt_.Wz);
-        dt_.fp_cpu = p->fp_cpu ? up(p->fp_cpu, G) : nullptr; dt_.fp_mem = p->fp_mem ? up(p->fp_mem, G) : nullptr;
+        // (the fastpath chooser's columns only travel when the fastpath is on: 16 bytes per PEG, a quarter of a C2 batch's upload)
+        dt_.fp_cpu = (dt_.fastpath && p->fp_cpu) ? up(p->fp_cpu, G) : nullptr; dt_.fp_mem = (dt_.fastpath && p->fp_mem) ? up(p->fp_mem, G) : nullptr;
         dt_.alloc = up(g->alloc, NG * R); dt_.init_req = up(g->init_req, NG * R);
         dt_.allowed = up(g->allowed_pods, NG); dt_.init_pods = up(g->init_pods, NG); dt_.gflags = up(g->flags, NG);
         dt_.taint = up(g->taint_mask, NG * dt_.Wt); dt_.label = up(g->label_mask, NG * dt_.Wl);
         dt_.init_excl = up(g->init_excl, NG * dt_.Wx); dt_.init_zone = up(g->init_zone, NG * dt_.Wz); dt_.zone_valid = up(g->zone_valid, NG * dt_.Wz);
         dt_.max_nodes = up(g->max_nodes, NG); dt_.existing = up(g->existing_nodes, NG); dt_.last_index = up(g->last_index, NG);
-        dt_.cap_cpu = g->cap_cpu ? up(g->cap_cpu, NG) : nullptr; dt_.cap_mem = g->cap_mem ? up(g->cap_mem, NG) : nullptr;
+        dt_.cap_cpu = (dt_.fastpath && g->cap_cpu) ? up(g->cap_cpu, NG) : nullptr; dt_.cap_mem = (dt_.fastpath && g->cap_mem) ? up(g->cap_mem, NG) : nullptr;
         dt_.waste_cpu = g->waste_cpu ? up(g->waste_cpu, NG) : nullptr; dt_.waste_mem = g->waste_mem ? up(g->waste_mem, NG) : nullptr;
 
         stage.mark("slabs, ranges, csr buffers");
@@ -445,6 +461,7 @@ public:
                     bk_.launch(gcd_reduce_kernel, nb, 1, 256, (size_t)(8 * 9 * 4), (const int64_t*)dt_.req, (int64_t)G, R, d_part);
                     bk_.d2h(h_part, d_part, sizeof(GcdPartial) * (size_t)nb);
                     bk_.sync();
+                    pass_gate();   // the bulk of this part's tables is on the device: the next part's turn on the link
                     if (!bk_.ok()) return fail(CASIM_ERR_HIP, bk_.error());
                     Part& pt = parts[0];
                     for (int b = 0; b < nb; ++b) {
@@ -592,6 +609,7 @@ public:
         // runs and fetches THIS problem before anything else touches the context (one call = one problem: casim_estimate_batch); the
         // copy then drains with the kernels behind it and a single call waits for the device once instead of twice
         if (!one_shot_) bk_.sync();
+        pass_gate();
         stage.mark("done");
         if (!bk_.ok()) return fail(CASIM_ERR_HIP, bk_.error());
         ready_ = true;
@@ -991,6 +1009,8 @@ public:
     int pegs() const { return G_; }
     bool csr_on_device() const { return csr_on_device_; }
     void set_one_shot(bool v) { one_shot_ = v; }   // before init(): see the end of init()
+    void set_upload_gate(UploadGate* g, int index) { gate_ = g; gate_idx_ = index; gate_passed_ = false; }   // before init(): parts of a streamed batch
+    void pass_gate() { if (gate_ && !gate_passed_) { gate_passed_ = true; gate_->pass(gate_idx_); } }
     bool uses_front() const { return front_; }
     bool pack_in_lds() const { return pack_lds_; }
     int fast_npt() const { return fast_npt_; }
@@ -1006,6 +1026,7 @@ private:
         up_cap_ = up_dev_ ? bound : 0; up_used_ = 0; up_flushed_ = 0; up_reserved_ = false;
     }
     void end_uploads() {
+        if (gate_ && !gate_passed_) gate_->wait_turn(gate_idx_);
         if (up_dev_ && up_used_ > up_flushed_) bk_.h2d(up_dev_ + up_flushed_, up_host_ + up_flushed_, up_used_ - up_flushed_);
         up_dev_ = up_host_ = nullptr; up_cap_ = 0;
     }
@@ -1020,12 +1041,14 @@ private:
         return v > 0 ? (size_t)v : kUploadChunk;
     }
     void flush_uploads_all() {   // everything staged so far goes out now (a kernel is about to read it)
+        if (gate_ && !gate_passed_) gate_->wait_turn(gate_idx_);
         if (up_reserved_ || !up_dev_ || up_used_ <= up_flushed_) return;
         bk_.h2d(up_dev_ + up_flushed_, up_host_ + up_flushed_, up_used_ - up_flushed_);
         up_flushed_ = up_used_;
     }
     void flush_uploads_early() {
         if (up_reserved_ || !up_dev_ || up_used_ - up_flushed_ < upload_chunk()) return;
+        if (gate_ && !gate_passed_ && !gate_->my_turn(gate_idx_)) return;   // (not this part's turn on the link yet: keep staging)
         bk_.h2d(up_dev_ + up_flushed_, up_host_ + up_flushed_, up_used_ - up_flushed_);
         up_flushed_ = up_used_;
     }
@@ -1084,6 +1107,7 @@ private:
     int n_sims_ = 0, max_sim_groups_ = 0, feas_len_ = 0;
     bool feas_by_sim_ = false;
     bool one_shot_ = false;
+    UploadGate* gate_ = nullptr; int gate_idx_ = 0; bool gate_passed_ = false;
     bool ord_in_slab_ = false; size_t ord_off_ = 0, ord_cap_ = 0;   // order / placed inside the results slab (short lists)
     std::vector<int32_t> opt_host_; const casim_option_query* opt_pending_q_ = nullptr; int opt_pending_s_ = 0; const char* opt_stage_ = nullptr;
     bool opt_in_slab_ = false; size_t opt_off_ = 0; std::vector<char> opt_keep_;   // (the expander's answer as the last fetch() brought it)

@@ -66,11 +66,22 @@ public:
         n_groups_ = g->n_groups; n_sims_ = S; has_gid_ = g->global_id != nullptr;
         parts_.clear(); parts_.resize((size_t)K);
         for (int i = 0; i < K; ++i) cut(parts_[(size_t)i], p, g, (int)((int64_t)S * i / K), (int)((int64_t)S * (i + 1) / K));
+        UploadGate gate;   // the parts take the link in turn (casim_pipeline.h: UploadGate); CASIM_UPLOAD_GATE=0: all at once, as until round 4
+        static const bool use_gate = !(getenv("CASIM_UPLOAD_GATE") && atoi(getenv("CASIM_UPLOAD_GATE")) == 0);
         auto work = [&](int i) {
             Part& pt = parts_[(size_t)i];
             lanes_[(size_t)i]->bind();
             pt.prob.reset(new ProblemT<BK>(*lanes_[(size_t)i]));
+            if (use_gate) pt.prob->set_upload_gate(&gate, i);
+            pt.prob->set_one_shot(pipeline_q_ != nullptr || pipeline_);
             pt.rc = pt.prob->init(&pt.pv, &pt.gv, &opts_);
+            // enter -> return in one call (estimate()): the part's kernels and its expander reduce are enqueued by the part's own worker
+            // as soon as ITS tables are up — under the uploads of the parts behind it in the turn order
+            if (pipeline_ && pt.rc == CASIM_OK) {
+                if (pipeline_fork_) lanes_[(size_t)i]->wait_mark(primary_);
+                pt.rc = pt.prob->run();
+                if (pt.rc == CASIM_OK && pipeline_q_) pt.rc = part_query((size_t)i, pipeline_q_);
+            }
         };
         each(work, threads);
         for (auto& pt : parts_) if (pt.rc != CASIM_OK) return fail(pt.rc, pt.prob->error().c_str());
@@ -159,7 +170,7 @@ public:
         if (!q->per_sim) return fail(CASIM_ERR_INVALID, "a streamed batch reduces per simulation (per_sim = 1)");
         for (size_t i = 0; i < parts_.size(); ++i) {
             const int32_t rc = part_query(i, q);
-            if (rc != CASIM_OK) return rc;
+            if (rc != CASIM_OK) return fail(rc, parts_[i].prob->error().c_str());
         }
         if (q->dev_key_out || q->dev_packed_out) {
             if (q->join_stream) { for (size_t i = 0; i < parts_.size(); ++i) { lanes_[i]->mark(); lanes_[i]->make_wait(q->join_stream); } }   // the caller's stream waits, not ours
@@ -182,7 +193,7 @@ public:
         if (q->dev_key_out) lq.dev_key_out = (char*)q->dev_key_out + 80 * (int64_t)pt.s0;
         if (q->dev_packed_out) lq.dev_packed_out = (char*)q->dev_packed_out + 8 * (int64_t)pt.s0;
         const int32_t rc = pt.prob->best_option_query(&lq);
-        if (rc != CASIM_OK) return fail(rc, pt.prob->error().c_str());
+        if (rc != CASIM_OK) return rc;   // (the caller reads the part's message: several parts may be in here at once)
         if (q->best_out) for (int s = pt.s0; s < pt.s1; ++s) if (q->best_out[s] >= 0) q->best_out[s] += pt.g0;   // index inside the whole batch
         return CASIM_OK;
     }
@@ -190,11 +201,21 @@ public:
     // enter -> return in one go: every part is uploaded, run, reduced and fetched by its own worker, so that the upload of one
     // part overlaps the kernels of another and the result copies of a third (wall = enter -> return)
     int32_t estimate(const casim_pegs* p, const casim_groups* g, const casim_options* o, casim_results* out, const casim_option_query* q, bool threads) {
-        int32_t rc = init(p, g, o, threads);
+        if (q && !q->per_sim) return fail(CASIM_ERR_INVALID, "a streamed batch reduces per simulation (per_sim = 1)");
+        // fork once, up front: every lane waits for what the context's stream holds NOW (nothing, for a caller that leaves it alone)
+        primary_.bind();
+        pipeline_fork_ = !primary_.idle();
+        if (pipeline_fork_) { primary_.mark(); ++n_forks_; }
+        pipeline_ = true; pipeline_q_ = q;
+        int32_t rc = init(p, g, o, threads);   // upload, run and reduce every part, part by part (see init)
+        pipeline_ = false; pipeline_q_ = nullptr;
         if (rc != CASIM_OK) return rc;
-        rc = run();
-        if (rc == CASIM_OK && q) rc = best_option_query(q);
-        if (rc == CASIM_OK && out) rc = fetch(out, threads);
+        ran_ = true;
+        if (q && (q->dev_key_out || q->dev_packed_out)) {
+            if (q->join_stream) { for (size_t i = 0; i < parts_.size(); ++i) { lanes_[i]->mark(); lanes_[i]->make_wait(q->join_stream); } }
+            else join();
+        }
+        if (out) rc = fetch(out, threads);
         return rc;
     }
 
@@ -265,6 +286,7 @@ private:
     casim_options opts_;
     int n_groups_ = 0, n_sims_ = 0;
     bool has_gid_ = false, ready_ = false, ran_ = false;
+    bool pipeline_ = false, pipeline_fork_ = false; const casim_option_query* pipeline_q_ = nullptr;   // estimate(): parts run from their init workers
     int64_t n_forks_ = 0;
     std::string err_;
 };
