@@ -30,6 +30,8 @@ CS_DEVICE int nblocks() { return casim_emu::cur().nblocks; }
 CS_DEVICE int bid_y() { return casim_emu::cur().bidy; }
 CS_DEVICE char* dyn_smem() { return casim_emu::dyn_smem(); }
 CS_DEVICE void sync() { casim_emu::block_sync(); }
+// the lanes of ONE wave rendezvous (LDS written by some lanes, read by others of the same wave): a ballot is the emulator's wave-level meeting point
+CS_DEVICE void wave_sync() { (void)casim_emu::wave_ballot(true); }
 CS_DEVICE void sched_fence() {}
 CS_DEVICE int32_t load_relaxed_i32(const int32_t* p) { return *p; }
 CS_DEVICE void atomic_add_i32(int32_t* p, int32_t v) { *p += v; }  // fibers of one block never run concurrently
@@ -90,6 +92,10 @@ CS_DEVICE char* dyn_smem() {
     return casim_smem;
 }
 CS_DEVICE void sync() { __syncthreads(); }
+// LDS written by some lanes of a wave, read by other lanes of the SAME wave (waves of a block working on different groups: no s_barrier,
+// which would need the same trip count in every wave): the wave's own LDS operations complete in order — wait for them, and keep the
+// compiler from moving accesses across
+CS_DEVICE void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 // instruction-scheduling fence: the machine scheduler may not move anything across (bounds live ranges of unrolled slot code)
 CS_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // device-scope relaxed load / add of a counter shared by the waves of a block (served by L2, never a stale L1 line)

@@ -375,10 +375,16 @@ template <int N> struct IntTag { static constexpr int value = N; };
 // the sorting network is straight-line code with constant masks and strides — no inner pair loop, no loop control, half
 // the address arithmetic (sort phase 18.9 k -> 13.0 k cycles per group, profiles/r02v).
 // NPAD == 0: any block size / list length (the loops are runtime loops).
-template <bool kLds, int NPAD>
-CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const OrderScratch& os, const int ng, const int off, const int Gn) {
-    const int tid = cs::tid();
-    const int nt = NPAD > 0 ? 64 : cs::nthreads();
+// kWave: ONE WAVE of a larger block orders the group on its own (front_sim_kernel: the waves of a simulation's block take its groups in
+// turn) — lane instead of thread index, wave_sync instead of the block barrier, `smem` = the wave's own LDS scratch laid out as
+// pos[NPAD] | gid[NPAD] | red[64], with gid ALREADY holding the list (PEG ids in ascending order); NPAD > 0 only.
+// smem != null without kWave: the block's scratch starts there instead of at the dynamic LDS base.
+template <bool kLds, int NPAD, bool kWave = false>
+CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const OrderScratch& os, const int ng, const int off, const int Gn, char* smem = nullptr) {
+    static_assert(!kWave || NPAD > 0, "a single wave sorts in its registers");
+    const int tid = kWave ? cs::lane() : cs::tid();
+    const int nt = (NPAD > 0 || kWave) ? 64 : cs::nthreads();
+    auto barrier = [&]() { if constexpr (kWave) cs::wave_sync(); else cs::sync(); };
     int npad = NPAD > 0 ? NPAD : 1;
     if (NPAD == 0) while (npad < Gn) npad <<= 1;
 #if defined(CASIM_PACK_PROF) && !defined(CASIM_HOST_EMU)
@@ -387,9 +393,9 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
 #else
 #define CASIM_OPROF(i)
 #endif
-    char* base = kLds ? cs::dyn_smem() : os.gbuf + os.off[ng];
+    char* base = smem ? smem : (kLds ? cs::dyn_smem() : os.gbuf + os.off[ng]);
     uint64_t* keys = (uint64_t*)base;           // [npad]
-    int32_t* pos = (int32_t*)(keys + npad);     // [npad]
+    int32_t* pos = kWave ? (int32_t*)base : (int32_t*)(keys + npad);     // [npad]  (kWave: no key array, the keys live in registers)
     int32_t* gid = pos + npad;                  // [npad] PEG id of list position i (read back after the sort: one dependent
                                                 //        global gather less on the way to the records)
     if constexpr (NPAD > 0) {
@@ -405,8 +411,9 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
         for (int q = 0; q < QN; ++q) {
             const int i = tid + 64 * q;
             if (i < Gn) {
-                const int g = t.peg_idx[off + i];
-                gid[i] = g;
+                int g;
+                if constexpr (kWave) g = gid[i];   // (the caller built the list in the wave's scratch)
+                else { g = t.peg_idx[off + i]; gid[i] = g; }
                 ek[q] = desc_key(peg_score(t, g, ng));
                 ep[q] = i;
             } else { ek[q] = ~0ull; ep[q] = 0x7fffffff; }
@@ -441,7 +448,7 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
         }
 #pragma unroll
         for (int q = 0; q < QN; ++q) pos[tid + 64 * q] = ep[q];
-        cs::sync();
+        barrier();
     } else {
 #pragma unroll
     for (int i = tid; i < npad; i += nt) {
@@ -491,14 +498,14 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
             }
         }
         red[tid] = mine;
-        cs::sync();
+        barrier();
         for (int s = nt >> 1; s > 0; s >>= 1) {
             if (tid < s) { const int64_t o = red[tid + s]; if (o > red[tid]) red[tid] = o; }
-            cs::sync();
+            barrier();
         }
         const int64_t top = red[0];
         if (top >= 0) best = (int)(uint32_t)(top & 0xffffffffll);
-        cs::sync();
+        barrier();
     }
 #pragma unroll
     for (int i = tid; i < (NPAD > 0 ? NPAD : Gn); i += nt) {
@@ -681,6 +688,162 @@ CS_GLOBAL void front_kernel(DevTables t, DevResults res, OrderScratch os, uint64
     cs::sync();   // the list is read back by other waves of the block (and the LDS changes hands)
     // 5. the order (order_kernel)
     order_dispatch<kLds>(t, res, os, ng, base, (int)total);
+}
+
+// ------------------------------------------------------------------------------------------
+// K_front_sim: feasibility rows + lists + PEG order of every group of ONE SIMULATION per block, fixed-stride lists
+// ------------------------------------------------------------------------------------------
+// The batch geometry of round 3 ran four launches per sub-batch in front of the packer — feas_sim_kernel, csr_scan_local_kernel,
+// csr_fill_kernel, order_kernel: 682 scalar + 1337 vector instructions per group, none of them sequential — because
+// a group's list position depended on the counts of every group in front of it.  With FIXED-STRIDE lists it does not: group ng owns the
+// region [peg_off[ng], peg_off[ng] + (peg_hi - peg_lo)) of order / placed / records (peg_off is static: the host's prefix sum of the
+// candidate range lengths, the bound every one of those arrays was sized for anyway) and its length travels apart (peg_cnt).  So ONE
+// block per simulation does everything: (A) every thread keeps one PEG in registers and walks the simulation's group records staged in
+// LDS (feas_sim_kernel's loop), the ballot words stay in LDS; (B) the waves take the groups in turn — list from the words (a lane per
+// bit), the register sorting network of order_group, the records — with no block barrier: each wave works in its own LDS scratch;
+// (C) the rare list beyond the one-wave networks (> 256 PEGs) is ordered by the whole block afterwards.  No bit matrix round trip, no
+// scan, no fill, no dependent launches.  Compaction for callers that fetch every list happens at fetch time (compact_lists_kernel).
+// LDS: [hdr: cnt per group][grec 16 x u64 per group][words Wg per group][per wave: pos | gid | red], phase C reuses everything behind hdr.
+CS_HOST_DEVICE size_t front_sim_wave_scratch() { return (size_t)(256 * 8 + 64 * 8); }
+template <bool kLds>
+CS_GLOBAL void front_sim_kernel(DevTables t, DevResults res, OrderScratch os, uint64_t* CS_RESTRICT bits /*[NG][Wg] or null*/, int Wg,
+                                const int32_t* CS_RESTRICT req32, const int32_t* CS_RESTRICT fresh32, int32_t* CS_RESTRICT cnt_out /*[NG] == t.peg_cnt*/,
+                                int32_t* CS_RESTRICT idx /*[nnz bound], lists beyond 256 entries only*/, int max_groups) {
+    const int sim = cs::bid();
+    const int g0 = t.sim_off[sim], g1 = t.sim_off[sim + 1];
+    const int ngroups = g1 - g0;
+    if (ngroups <= 0) return;
+    const int lo = t.peg_lo[g0], hi = t.peg_hi[g0];
+    const int tid = cs::tid(), lane = cs::lane(), wave = tid >> 6, nw = (cs::nthreads() + 63) >> 6;
+    const int k = tid;
+    const bool live = lo + k < hi;
+    const int g = live ? lo + k : (hi > lo ? lo : 0);
+    const bool narrow = req32 != nullptr && t.R <= 4;
+    char* smem = cs::dyn_smem();
+    int32_t* cnt_lds = (int32_t*)smem;                                         // [max_groups]
+    uint64_t* grec = (uint64_t*)(smem + (((size_t)max_groups * 4 + 15) & ~(size_t)15));   // [ngroups][16]
+    uint64_t* words = grec + (size_t)max_groups * 16;                          // [ngroups][Wg]
+    char* scratch0 = (char*)(words + (size_t)max_groups * Wg);
+    // ---- A. stage the group records (feas_sim_kernel's layout), then the rows
+    for (int i = tid; i < ngroups * 16; i += cs::nthreads()) {
+        const int ng = g0 + (i >> 4), f = i & 15;
+        uint64_t v = 0;
+        if (f == 0) v = t.Wt ? t.taint[(int64_t)ng * t.Wt] : 0ull;
+        else if (f == 1) v = t.Wl ? t.label[(int64_t)ng * t.Wl] : ~0ull;
+        else if (f == 2) v = t.Wx ? t.init_excl[(int64_t)ng * t.Wx] : 0ull;
+        else if (f == 3) v = t.Wz ? (t.init_zone[(int64_t)ng * t.Wz] ^ t.zpol[0]) : 0ull;
+        else if (f == 4) v = (uint64_t)t.gflags[ng] | ((uint64_t)(uint32_t)(t.allowed[ng] - t.init_pods[ng]) << 32);
+        else if (f == 5 || f == 6) {
+            if (narrow) {
+                const int r = (f - 5) * 2;
+                const uint32_t a = r < t.R ? (uint32_t)fresh32[(int64_t)ng * t.R + r] : 0u, b2 = r + 1 < t.R ? (uint32_t)fresh32[(int64_t)ng * t.R + r + 1] : 0u;
+                v = (uint64_t)a | ((uint64_t)b2 << 32);
+            }
+        } else if (f >= 8) {
+            const int r = f - 8;
+            if (!narrow && r < t.R) v = (uint64_t)(t.alloc[(int64_t)ng * t.R + r] - t.init_req[(int64_t)ng * t.R + r]);
+        }
+        grec[i] = v;
+    }
+    int64_t req[CASIM_KMAX_RES];
+    int32_t rq32[4] = {0, 0, 0, 0};
+    for (int r = 0; r < CASIM_KMAX_RES; ++r) {
+        if (narrow) { if (r < 4) rq32[r] = (live && r < t.R) ? req32[(int64_t)g * t.R + r] : 0; req[r] = 0; }
+        else req[r] = (live && r < t.R) ? t.req[(int64_t)g * t.R + r] : 0;
+    }
+    const uint32_t pf = live ? t.pflags[g] : 0u;
+    const uint64_t tol = (live && t.Wt) ? t.tol[(int64_t)g * t.Wt] : 0ull, sel = (live && t.Wl) ? t.sel[(int64_t)g * t.Wl] : 0ull;
+    const uint64_t xb = (live && t.Wx) ? t.xblock[(int64_t)g * t.Wx] : 0ull, zb = (live && t.Wz) ? t.zblock[(int64_t)g * t.Wz] : 0ull;
+    cs::sync();
+    const bool tolerates_unsched = (pf & CASIM_PEG_TOLERATES_UNSCHEDULABLE) != 0;
+    for (int gl = 0; gl < ngroups; ++gl) {
+        const uint64_t* gr = grec + (int64_t)gl * 16;
+        const uint64_t fl = gr[4];
+        bool ok = live & ((gr[0] & ~tol) == 0) & ((sel & ~gr[1]) == 0) & ((xb & gr[2]) == 0) & ((zb & gr[3]) == 0);
+        ok = ok & (tolerates_unsched | (((uint32_t)fl & CASIM_NG_UNSCHEDULABLE) == 0));
+        ok = ok & ((int32_t)(fl >> 32) > 0);
+        if (narrow) {
+            const uint64_t f01 = gr[5], f23 = gr[6];
+            bool fit = (rq32[0] <= 0) | (rq32[0] <= (int32_t)(uint32_t)f01);
+            fit = fit & ((rq32[1] <= 0) | (rq32[1] <= (int32_t)(f01 >> 32)));
+            fit = fit & ((rq32[2] <= 0) | (rq32[2] <= (int32_t)(uint32_t)f23));
+            fit = fit & ((rq32[3] <= 0) | (rq32[3] <= (int32_t)(f23 >> 32)));
+            ok = ok & fit;
+        } else {
+            bool fit = true;
+#pragma unroll
+            for (int r = 0; r < CASIM_KMAX_RES; ++r) fit = fit & ((req[r] <= 0) | (req[r] <= (int64_t)gr[8 + r]));
+            ok = ok & fit;
+        }
+        const uint64_t b = cs::ballot(ok);
+        if (lane == 0 && wave < Wg) { words[(int64_t)gl * Wg + wave] = b; if (bits) bits[(int64_t)(g0 + gl) * Wg + wave] = b; }
+    }
+    cs::sync();
+    // ---- B. the waves take the groups in turn: list, order, records — no block barrier in here
+    char* my = scratch0 + (size_t)wave * front_sim_wave_scratch();
+    int32_t* my_gid = (int32_t*)my + 256;   // (order_group<.., NPAD, true>: pos[NPAD] | gid[NPAD]; NPAD <= 256 -> gid of the 256-layout is the furthest)
+    for (int gl = wave; gl < ngroups; gl += nw) {
+        const int ng = g0 + gl;
+        const int base = t.peg_off[ng];
+        int total = 0;
+        for (int w = 0; w < Wg; ++w) total += cs::popc64(words[(int64_t)gl * Wg + w]);
+        if (lane == 0) { cnt_lds[gl] = total; cnt_out[ng] = total; }
+        if (total > 256) {   // (ordered by the whole block in phase C: its list goes to global memory)
+            int run = 0;
+            for (int w = 0; w < Wg; ++w) {
+                const uint64_t b = words[(int64_t)gl * Wg + w];
+                if ((b >> lane) & 1ull) idx[base + run + cs::mbcnt(b)] = lo + w * 64 + lane;
+                run += cs::popc64(b);
+            }
+            continue;
+        }
+        // the layout order_group expects depends on its NPAD: gid sits right behind pos[NPAD]
+        const int npad = total <= 64 ? 64 : (total <= 128 ? 128 : 256);
+        int32_t* gid = (int32_t*)my + npad;
+        int run = 0;
+        for (int w = 0; w < Wg; ++w) {
+            const uint64_t b = words[(int64_t)gl * Wg + w];
+            if ((b >> lane) & 1ull) gid[run + cs::mbcnt(b)] = lo + w * 64 + lane;
+            run += cs::popc64(b);
+        }
+        cs::wave_sync();
+        if (npad == 64) order_group<true, 64, true>(t, res, os, ng, base, total, my);
+        else if (npad == 128) order_group<true, 128, true>(t, res, os, ng, base, total, my);
+        else order_group<true, 256, true>(t, res, os, ng, base, total, my);
+        cs::wave_sync();   // (the scratch changes hands: the wave's next group)
+    }
+    (void)my_gid;
+    cs::sync();
+    // ---- C. lists beyond the one-wave networks: the whole block, one after the other (block-uniform loop: cnt_lds is the same for everybody)
+    for (int gl = 0; gl < ngroups; ++gl) {
+        const int total = cnt_lds[gl];
+        if (total <= 256) continue;
+        order_group<kLds, 0>(t, res, os, g0 + gl, t.peg_off[g0 + gl], total, kLds ? (char*)grec : nullptr);
+        cs::sync();
+    }
+}
+
+// K_compact: fixed-stride lists -> the compact CSR a caller fetches (casim_problem_fetch of every list; never in the resident loop)
+CS_GLOBAL void count_offsets_kernel(const int32_t* CS_RESTRICT cnt /*[NG]*/, int NG, int32_t* CS_RESTRICT coff /*[NG + 1]*/) {
+    uint32_t* sm = (uint32_t*)cs::dyn_smem();
+    uint32_t carry = 0;
+    for (int s0 = 0; s0 < NG; s0 += cs::nthreads()) {
+        const int s = s0 + cs::tid();
+        const uint32_t mine = s < NG ? (uint32_t)cnt[s] : 0u;
+        uint32_t total = 0;
+        const uint32_t excl = block_exclusive_scan(mine, sm, &total);
+        if (s < NG) coff[s] = (int32_t)(carry + excl);
+        carry += total;
+        cs::sync();
+    }
+    if (cs::tid() == 0) coff[NG] = (int32_t)carry;
+}
+CS_GLOBAL void compact_lists_kernel(const int32_t* CS_RESTRICT off, const int32_t* CS_RESTRICT cnt, const int32_t* CS_RESTRICT coff,
+                                    const int32_t* CS_RESTRICT order, const int32_t* CS_RESTRICT placed, int32_t* CS_RESTRICT corder,
+                                    int32_t* CS_RESTRICT cplaced) {
+    const int ng = cs::bid();
+    const int a = off[ng], n = cnt[ng], c = coff[ng];
+    for (int i = cs::tid(); i < n; i += cs::nthreads()) { corder[c + i] = order[a + i]; cplaced[c + i] = placed[a + i]; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -879,15 +1042,15 @@ CS_GLOBAL void scale_requests_kernel(const int64_t* CS_RESTRICT req, int64_t n /
 // After the expander's reduce: best[s][0] = winning group of simulation s (index inside the launch, -1 = no option).  One block scans the
 // winners' list lengths into woff[S + 1]; one wave per simulation then copies order / placed of the winner to woff[s].  What leaves the
 // device afterwards is sum(len(winner)) entries instead of every (group, PEG) pair — 3.6 MB instead of 69 MB for 4096 C2 simulations.
-CS_GLOBAL void winner_offsets_kernel(const int32_t* CS_RESTRICT best /*[S][2]*/, const int32_t* CS_RESTRICT off /*[NG + 1]*/, int S,
-                                     int32_t* CS_RESTRICT woff /*[S + 1]*/) {
+CS_GLOBAL void winner_offsets_kernel(const int32_t* CS_RESTRICT best /*[S][2]*/, const int32_t* CS_RESTRICT off /*[NG + 1]*/, const int32_t* CS_RESTRICT cnt /*[NG] or null*/,
+                                     int S, int32_t* CS_RESTRICT woff /*[S + 1]*/) {
     uint32_t* sm = (uint32_t*)cs::dyn_smem();   // [nw + 1] of the scan + [1] carry
     const int nw = (cs::nthreads() + 63) >> 6;
     uint32_t carry = 0;
     for (int s0 = 0; s0 < S; s0 += cs::nthreads()) {
         const int s = s0 + cs::tid();
         uint32_t mine = 0;
-        if (s < S) { const int b = best[2 * s]; if (b >= 0) mine = (uint32_t)(off[b + 1] - off[b]); }
+        if (s < S) { const int b = best[2 * s]; if (b >= 0) mine = (uint32_t)(cnt ? cnt[b] : off[b + 1] - off[b]); }
         uint32_t total = 0;
         const uint32_t excl = block_exclusive_scan(mine, sm, &total);
         if (s < S) woff[s] = (int32_t)(carry + excl);
@@ -897,13 +1060,13 @@ CS_GLOBAL void winner_offsets_kernel(const int32_t* CS_RESTRICT best /*[S][2]*/,
     if (cs::tid() == 0) woff[S] = (int32_t)carry;
     (void)nw;
 }
-CS_GLOBAL void gather_winners_kernel(const int32_t* CS_RESTRICT best, const int32_t* CS_RESTRICT off, const int32_t* CS_RESTRICT woff,
+CS_GLOBAL void gather_winners_kernel(const int32_t* CS_RESTRICT best, const int32_t* CS_RESTRICT off, const int32_t* CS_RESTRICT cnt, const int32_t* CS_RESTRICT woff,
                                      const int32_t* CS_RESTRICT order, const int32_t* CS_RESTRICT placed, int32_t* CS_RESTRICT worder,
                                      int32_t* CS_RESTRICT wplaced) {
     const int s = cs::bid();
     const int b = best[2 * s];
     if (b < 0) return;
-    const int a = off[b], n = off[b + 1] - a, w = woff[s];
+    const int a = off[b], n = cnt ? cnt[b] : off[b + 1] - a, w = woff[s];
     for (int i = cs::tid(); i < n; i += cs::nthreads()) { worder[w + i] = order[a + i]; wplaced[w + i] = placed[a + i]; }
 }
 

@@ -412,7 +412,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     // as vector loads they lived in VGPRs and every use of them was a VALU instruction)
     auto gload = [&](const void* base, int64_t i) -> int32_t { return (int32_t)cs::const_load<1>((const uint32_t*)base + i).w[0]; };
     const int off = gload(t.peg_off, ng);
-    const int Gn = gload(t.peg_off, ng + 1) - off;
+    const int Gn = t.peg_cnt ? gload(t.peg_cnt, ng) : gload(t.peg_off, ng + 1) - off;   // (fixed-stride lists carry their length apart)
 
     const int32_t maxn = gload(t.max_nodes, ng);
     const int32_t E = gload(t.existing, ng);
@@ -1039,7 +1039,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
 template <int DW /* dwords of a PEG record, 0 = the three-array form */>
 CS_DEVICE bool pack_unsupported(const DevTables& t, const DevResults& res) {
     const int ng = cs::bid(), lane = cs::lane();
-    const int off = t.peg_off[ng], Gn = t.peg_off[ng + 1] - off;
+    const int off = t.peg_off[ng], Gn = t.peg_cnt ? t.peg_cnt[ng] : t.peg_off[ng + 1] - off;
     bool bad = false;
     for (int i = lane; i < Gn; i += 64) bad |= ((DW > 0 ? res.rec[(int64_t)(off + i) * DW + 1] : res.s_flags[off + i]) & CASIM_PEG_UNSUPPORTED) != 0;
     if (!cs::ballot(bad)) return false;

@@ -372,11 +372,29 @@ public:
             d_idx_ = (int32_t*)dalloc(sizeof(int32_t) * (size_t)nnz_cap_);
             dt_.peg_off = d_off_; dt_.peg_idx = d_idx_;
             // a single call's chain in one launch (front_kernel): a few hundred groups at most — the blocks wait for each other's counts
-            front_ = NG > 0 && NG <= kFrontMaxGroups && feas_len_ > 0 && Wg_ <= 512 && !(o && o->no_front_kernel) && !getenv("CASIM_NO_FRONT");
+            // (a batch of >= 2 simulations takes front_sim_kernel further down: no tickets at all)
+            const bool want_strided = feas_by_sim_ && n_sims_ >= 2 && feas_len_ > 0 && feas_len_ <= 1024 && !(o && o->no_front_kernel) && !getenv("CASIM_NO_STRIDED");
+            front_ = !want_strided && NG > 0 && NG <= kFrontMaxGroups && feas_len_ > 0 && Wg_ <= 512 && !(o && o->no_front_kernel) && !getenv("CASIM_NO_FRONT");
             if (front_) {
                 const uint64_t* dev = nullptr;
                 uint64_t* h = up_reserve<uint64_t>(NG, &dev);
                 if (h) { memset(h, 0, 8 * NG); d_ticket_ = (uint64_t*)dev; } else front_ = false;
+            }
+            // batches: fixed-stride lists and ONE launch in front of the packer (front_sim_kernel) — group i owns [soff[i], soff[i] + (hi - lo))
+            // of order / placed / records, the bound those arrays are sized for; its length is written to the slab's offset area (peg_cnt)
+            strided_ = want_strided;
+            if (strided_) {
+                h_off_static_.assign(NG + 1, 0);
+                for (size_t i = 0; i < NG; ++i) h_off_static_[i + 1] = h_off_static_[i] + pegs_of_group[i];
+                dt_.peg_off = up(h_off_static_.data(), NG + 1);
+                dt_.peg_cnt = res_off_;
+                const size_t hdr = ((size_t)max_sim_groups_ * 4 + 15) & ~(size_t)15;
+                const int nwv = Wg_;
+                const size_t phase_ab = (size_t)max_sim_groups_ * 16 * 8 + (size_t)max_sim_groups_ * (size_t)Wg_ * 8 + (size_t)nwv * front_sim_wave_scratch();
+                int64_t npad = 1; while (npad < lmax) npad <<= 1;
+                const size_t phase_c = lmax > 256 ? (size_t)npad * 16 + 8 + 8 * (size_t)(64 * nwv) : 0;
+                front_sim_smem_ = hdr + (phase_ab > phase_c ? phase_ab : phase_c) + 64;
+                if (front_sim_smem_ > bk_.lds_budget()) { strided_ = false; dt_.peg_off = d_off_; dt_.peg_cnt = nullptr; }
             }
         }
 
@@ -634,6 +652,12 @@ public:
             front_ran_ = true;
             return CASIM_OK;
         }
+        if (strided_) {
+            bk_.launch(front_sim_kernel<true>, n_sims_, 1, 64 * Wg_, front_sim_smem_, dt_, dr_, os_, d_bits_, Wg_,
+                       fast_npt_ > 0 ? fs_.req32 : (const int32_t*)nullptr, fast_npt_ > 0 ? fs_.fresh32 : (const int32_t*)nullptr, res_off_, d_idx_, max_sim_groups_);
+            front_ran_ = true;
+            return CASIM_OK;
+        }
         if (feas_len_ > 0) {
             if (feas_by_sim_) bk_.launch(feas_sim_kernel, (feas_len_ + 255) / 256, n_sims_, 256, (size_t)128 * (size_t)max_sim_groups_, dt_, d_bits_, Wg_,
                                          fast_npt_ > 0 ? fs_.req32 : (const int32_t*)nullptr, fast_npt_ > 0 ? fs_.fresh32 : (const int32_t*)nullptr);
@@ -709,6 +733,7 @@ public:
                 h_off_.resize((size_t)NG_ + 1);
                 bk_.d2h(h_off_.data(), d_off_, 4 * ((size_t)NG_ + 1));
                 bk_.sync();
+                if (strided_) counts_to_offsets();
                 h_off_fresh_ = true;
             }
         }
@@ -722,6 +747,12 @@ public:
         if (nnz_out) *nnz_out = NG_ > 0 ? (*offs)[(size_t)NG_] : 0;
         if (offsets_out && NG_ >= 0) for (int i = 0; i <= NG_; ++i) offsets_out[i] = offs->empty() ? 0 : (*offs)[(size_t)i];
         return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
+    }
+    // fixed-stride lists: h_off_ holds the groups' list LENGTHS as the device wrote them -> the compact CSR offsets the caller indexes with
+    void counts_to_offsets() {
+        int32_t run = 0;
+        for (int i = 0; i < NG_; ++i) { const int32_t c = h_off_[(size_t)i]; h_off_[(size_t)i] = run; run += c; }
+        h_off_[(size_t)NG_] = run;
     }
     // merged lists -> offsets in the caller's numbering (h_off_ must be current)
     int32_t expand_offsets() {
@@ -771,7 +802,14 @@ public:
         if (winners && !winners_ready_) return fail(CASIM_ERR_INVALID, "winners_only: run the expander query (per simulation, best_out set) before the fetch");
         // copy 1: scalars + offsets (one slab); copies 2, 3: order / placed — enqueued with the first one when their bound is
         // small or the offsets are the caller's, after it (the device-side nnz is in the slab) otherwise
-        const bool spec = (!csr_on_device_ || nnz_cap_ <= 16384) && !winners;
+        const bool spec = (!csr_on_device_ || nnz_cap_ <= 16384) && !winners && !strided_;
+        const bool compact = strided_ && !winners && (out->order || out->placed);
+        if (compact) {   // fixed-stride lists -> compact CSR on the device, behind everything else on the stream (never in the resident loop)
+            if (!d_coff_) { d_coff_ = (int32_t*)dalloc(4 * ((size_t)NG_ + 1)); d_corder_ = (int32_t*)dalloc(4 * ((size_t)nnz_cap_ + 1)); d_cplaced_ = (int32_t*)dalloc(4 * ((size_t)nnz_cap_ + 1)); }
+            bk_.launch(count_offsets_kernel, 1, 1, 1024, (size_t)(4 * (1024 / 64 + 2)), (const int32_t*)dt_.peg_cnt, NG_, d_coff_);
+            bk_.launch(compact_lists_kernel, NG_, 1, 64, (size_t)0, (const int32_t*)dt_.peg_off, (const int32_t*)dt_.peg_cnt, (const int32_t*)d_coff_,
+                       (const int32_t*)dr_.order, (const int32_t*)dr_.placed, d_corder_, d_cplaced_);
+        }
         const size_t spec_n = !csr_on_device_ ? (size_t)(NG > 0 ? h_off_[NG] : 0) : (size_t)nnz_cap_;
         char* st = (char*)bk_.stage(1, res_bytes_ + (spec ? 8 * spec_n : 0) + 64);
         if (!st) return fail(CASIM_ERR_NOMEM, "no staging buffer");
@@ -789,7 +827,7 @@ public:
         if (opt_in_slab_) opt_keep_.assign(st + opt_off_, st + opt_off_ + 104 + ((ng + 7) & ~(size_t)7));   // (the expander's answer came along: best_option_finish)
         const int64_t* h64 = (const int64_t*)st;
         const int32_t* h32 = (const int32_t*)(h64 + 2 * ng);
-        if (csr_on_device_ && NG_ > 0) { h_off_.assign(h32 + 6 * ng, h32 + 6 * ng + NG + 1); h_off_fresh_ = true; }
+        if (csr_on_device_ && NG_ > 0) { h_off_.assign(h32 + 6 * ng, h32 + 6 * ng + NG + 1); if (strided_) counts_to_offsets(); h_off_fresh_ = true; }
         const size_t nnz = NG_ > 0 ? (size_t)h_off_[NG] : 0;
         if (out->req_cpu_sum) memcpy(out->req_cpu_sum, h64, 8 * NG);
         if (out->req_mem_sum) memcpy(out->req_mem_sum, h64 + ng, 8 * NG);
@@ -810,6 +848,12 @@ public:
                 bk_.sync();
             }
             winners_total_ = wtotal;
+        } else if (compact) {
+            if (nnz > 0) {
+                if (out->order) bk_.d2h(out->order, d_corder_, 4 * nnz);
+                if (out->placed) bk_.d2h(out->placed, d_cplaced_, 4 * nnz);
+                bk_.sync();
+            }
         } else if (!spec && nnz > 0) {   // a big batch: straight into the caller's arrays (through the pinned staging buffer in two pieces it was
                                   // no faster: 6.4-6.5 ms against 6.2-6.3 per headline call, r07n)
             if (out->order) bk_.d2h(out->order, dr_.order, 4 * nnz);
@@ -920,8 +964,8 @@ public:
             if (!d_woff_ || (size_t)S > woff_cap_) { d_woff_ = (int32_t*)dalloc(4 * ((size_t)S + 1)); woff_cap_ = (size_t)S; }
             if (!d_worder_) { d_worder_ = (int32_t*)dalloc(4 * ((size_t)nnz_cap_ + 1)); d_wplaced_ = (int32_t*)dalloc(4 * ((size_t)nnz_cap_ + 1)); }
             const int wt = S > 256 ? 1024 : 256;
-            bk_.launch(winner_offsets_kernel, 1, 1, wt, (size_t)(4 * ((wt + 63) / 64 + 2)), (const int32_t*)d_opt_out_, (const int32_t*)dt_.peg_off, S, d_woff_);
-            bk_.launch(gather_winners_kernel, S, 1, 64, (size_t)0, (const int32_t*)d_opt_out_, (const int32_t*)dt_.peg_off, (const int32_t*)d_woff_,
+            bk_.launch(winner_offsets_kernel, 1, 1, wt, (size_t)(4 * ((wt + 63) / 64 + 2)), (const int32_t*)d_opt_out_, (const int32_t*)dt_.peg_off, (const int32_t*)dt_.peg_cnt, S, d_woff_);
+            bk_.launch(gather_winners_kernel, S, 1, 64, (size_t)0, (const int32_t*)d_opt_out_, (const int32_t*)dt_.peg_off, (const int32_t*)dt_.peg_cnt, (const int32_t*)d_woff_,
                        (const int32_t*)dr_.order, (const int32_t*)dr_.placed, d_worder_, d_wplaced_);
             winners_ready_ = true; winners_s_ = S;
         }
@@ -1012,6 +1056,7 @@ public:
     void set_upload_gate(UploadGate* g, int index) { gate_ = g; gate_idx_ = index; gate_passed_ = false; }   // before init(): parts of a streamed batch
     void pass_gate() { if (gate_ && !gate_passed_) { gate_passed_ = true; gate_->pass(gate_idx_); } }
     bool uses_front() const { return front_; }
+    bool uses_strided_lists() const { return strided_; }
     bool pack_in_lds() const { return pack_lds_; }
     int fast_npt() const { return fast_npt_; }
     int fast_lanes() const { return fast_npt_ > 0 ? fast_r_ : 0; }   // > 0: the register-resident packer handles this batch
@@ -1114,6 +1159,8 @@ private:
     bool winners_only_ = false, winners_ready_ = false; int winners_s_ = 0; int32_t winners_total_ = 0;   // casim_options.winners_only
     int32_t* d_woff_ = nullptr; int32_t* d_worder_ = nullptr; int32_t* d_wplaced_ = nullptr; size_t woff_cap_ = 0;
     bool front_ = false, front_ran_ = false;   // feas + offsets + lists + order in ONE launch (front_kernel)
+    bool strided_ = false; size_t front_sim_smem_ = 0; std::vector<int32_t> h_off_static_;   // batches: fixed-stride lists, front_sim_kernel
+    int32_t* d_coff_ = nullptr; int32_t* d_corder_ = nullptr; int32_t* d_cplaced_ = nullptr;   // ... compacted at fetch time
     uint64_t* d_ticket_ = nullptr; uint32_t front_epoch_ = 0;
     static constexpr size_t kFrontMaxGroups = 1024;
     static constexpr size_t kDevGcdMin = (size_t)1 << 17;   // request values from which the gcd / int32 pass runs on the device

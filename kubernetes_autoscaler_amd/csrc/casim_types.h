@@ -49,6 +49,9 @@ struct DevTables {
     const int32_t* sim_off;   // [n_sims + 1] groups of each simulation, or null = one simulation
     int32_t n_sims;
     int32_t lists_from_feas;  // 1 = the per-group PEG lists come from the feasibility kernel: every listed PEG passed the template-level Filters
+    // fixed-stride lists (batches, front_sim_kernel): peg_off is STATIC — group ng owns the region [peg_off[ng], peg_off[ng] + (peg_hi - peg_lo)) of
+    // order / placed / the record array — and its list length is peg_cnt[ng]; null = compact CSR, length = peg_off[ng + 1] - peg_off[ng]
+    const int32_t* peg_cnt;   // [NG] or null
 };
 
 struct DevResults {

@@ -66,7 +66,7 @@ EMU_API int32_t emu_estimate_batch(const casim_pegs* pegs, const casim_groups* g
     if (rc == CASIM_OK && n_kinds >= 0 && best_out)
         rc = p.best_option(kinds, n_kinds, group_id_base, &best_out[0], &best_out[1], best_set_out, key_out, nullptr);
     if (rc != CASIM_OK) g_err = p.error();
-    g_last_front = p.uses_front() ? 1 : 0;
+    g_last_front = p.uses_front() ? 1 : (p.uses_strided_lists() ? 2 : 0);
     return rc;
 }
 
@@ -88,10 +88,10 @@ EMU_API int32_t emu_estimate_batch_query(const casim_pegs* pegs, const casim_gro
     if (one_wait) { const int32_t rc2 = p.best_option_finish(/*synced=*/rc == CASIM_OK); if (rc == CASIM_OK) rc = rc2; }
     if (rc == CASIM_OK && (nnz_out || offsets_out)) rc = p.csr(nnz_out, offsets_out);
     if (rc != CASIM_OK) g_err = p.error();
-    g_last_front = p.uses_front() ? 1 : 0;
+    g_last_front = p.uses_front() ? 1 : (p.uses_strided_lists() ? 2 : 0);
     return rc;
 }
-// 1 when the last emu_estimate_batch_query ran feasibility / offsets / lists / order as ONE launch (front_kernel)
+// 1 when the last emu_estimate_batch_query ran feasibility / offsets / lists / order as ONE launch (front_kernel), 2: front_sim_kernel with fixed-stride lists
 EMU_API int32_t emu_last_front() { return g_last_front; }
 
 // The batch cut into sub-batches on the lanes of one context (casim_streams.h; the emulator runs the parts one after the other):
