@@ -823,6 +823,47 @@ CS_GLOBAL void front_sim_kernel(DevTables t, DevResults res, OrderScratch os, ui
     }
 }
 
+// The same lists with the parallelism of order_kernel (one wave per GROUP, NG blocks): feas_sim_kernel writes the bit matrix as before, this
+// kernel reads its group's row (a few words), builds the list in LDS and orders it — the scan and fill launches are gone, the wave count of
+// the ordering step is not (front_sim_kernel's 7-wave blocks, three groups per wave one after the other, overlapped WORSE with the packers
+// of the other streams: 1.13 ms per step against 1.03, profiles/r08f_*).
+template <bool kLds>
+CS_GLOBAL void order_strided_kernel(DevTables t, DevResults res, OrderScratch os, const uint64_t* CS_RESTRICT bits /*[NG][Wg]*/, int Wg,
+                                    int32_t* CS_RESTRICT cnt_out /*[NG] == t.peg_cnt*/, int32_t* CS_RESTRICT idx) {
+    const int ng = cs::bid(), lane = cs::lane();
+    const int base = t.peg_off[ng], lo = t.peg_lo[ng];
+    const uint64_t* row = bits + (int64_t)ng * Wg;
+    int total = 0;
+    for (int w = 0; w < Wg; ++w) total += cs::popc64(row[w]);
+    if (cs::tid() == 0) cnt_out[ng] = total;
+    char* smem = cs::dyn_smem();
+    if (cs::nthreads() == 64 && total <= 256) {
+        const int npad = total <= 64 ? 64 : (total <= 128 ? 128 : 256);
+        int32_t* gid = (int32_t*)smem + npad;
+        int run = 0;
+        for (int w = 0; w < Wg; ++w) {
+            const uint64_t b = row[w];
+            if ((b >> lane) & 1ull) gid[run + cs::mbcnt(b)] = lo + w * 64 + lane;
+            run += cs::popc64(b);
+        }
+        cs::wave_sync();
+        if (npad == 64) order_group<true, 64, true>(t, res, os, ng, base, total, smem);
+        else if (npad == 128) order_group<true, 128, true>(t, res, os, ng, base, total, smem);
+        else order_group<true, 256, true>(t, res, os, ng, base, total, smem);
+        return;
+    }
+    // a long list (or a block of several waves): through global memory and the general network
+    for (int w = cs::tid() >> 6; w < Wg; w += (cs::nthreads() + 63) >> 6) {
+        int run = 0;
+        for (int j = 0; j < w; ++j) run += cs::popc64(row[j]);
+        const uint64_t b = row[w];
+        if ((b >> lane) & 1ull) idx[base + run + cs::mbcnt(b)] = lo + w * 64 + lane;
+    }
+    cs::sync();
+    if (kLds && os.lds_list_cap > 0 && total > os.lds_list_cap) order_group<false, 0>(t, res, os, ng, base, total);
+    else order_group<kLds, 0>(t, res, os, ng, base, total);
+}
+
 // K_compact: fixed-stride lists -> the compact CSR a caller fetches (casim_problem_fetch of every list; never in the resident loop)
 CS_GLOBAL void count_offsets_kernel(const int32_t* CS_RESTRICT cnt /*[NG]*/, int NG, int32_t* CS_RESTRICT coff /*[NG + 1]*/) {
     uint32_t* sm = (uint32_t*)cs::dyn_smem();

@@ -383,6 +383,7 @@ public:
             // batches: fixed-stride lists and ONE launch in front of the packer (front_sim_kernel) — group i owns [soff[i], soff[i] + (hi - lo))
             // of order / placed / records, the bound those arrays are sized for; its length is written to the slab's offset area (peg_cnt)
             strided_ = want_strided;
+            strided_one_launch_ = getenv("CASIM_FRONT_SIM") != nullptr && atoi(getenv("CASIM_FRONT_SIM")) != 0;   // (the one-launch form: measured slower in the loop)
             if (strided_) {
                 h_off_static_.assign(NG + 1, 0);
                 for (size_t i = 0; i < NG; ++i) h_off_static_[i + 1] = h_off_static_[i] + pegs_of_group[i];
@@ -394,7 +395,7 @@ public:
                 int64_t npad = 1; while (npad < lmax) npad <<= 1;
                 const size_t phase_c = lmax > 256 ? (size_t)npad * 16 + 8 + 8 * (size_t)(64 * nwv) : 0;
                 front_sim_smem_ = hdr + (phase_ab > phase_c ? phase_ab : phase_c) + 64;
-                if (front_sim_smem_ > bk_.lds_budget()) { strided_ = false; dt_.peg_off = d_off_; dt_.peg_cnt = nullptr; }
+                if (strided_one_launch_ && front_sim_smem_ > bk_.lds_budget()) strided_one_launch_ = false;
             }
         }
 
@@ -652,10 +653,15 @@ public:
             front_ran_ = true;
             return CASIM_OK;
         }
-        if (strided_) {
+        if (strided_ && strided_one_launch_) {
             bk_.launch(front_sim_kernel<true>, n_sims_, 1, 64 * Wg_, front_sim_smem_, dt_, dr_, os_, d_bits_, Wg_,
                        fast_npt_ > 0 ? fs_.req32 : (const int32_t*)nullptr, fast_npt_ > 0 ? fs_.fresh32 : (const int32_t*)nullptr, res_off_, d_idx_, max_sim_groups_);
             front_ran_ = true;
+            return CASIM_OK;
+        }
+        if (strided_) {   // rows by feas_sim_kernel; run_order() builds and orders the lists (order_strided_kernel): no scan, no fill
+            bk_.launch(feas_sim_kernel, (feas_len_ + 255) / 256, n_sims_, 256, (size_t)128 * (size_t)max_sim_groups_, dt_, d_bits_, Wg_,
+                       fast_npt_ > 0 ? fs_.req32 : (const int32_t*)nullptr, fast_npt_ > 0 ? fs_.fresh32 : (const int32_t*)nullptr);
             return CASIM_OK;
         }
         if (feas_len_ > 0) {
@@ -679,7 +685,12 @@ public:
     int32_t run_order() {
         if (NG_ == 0 || front_ran_) return CASIM_OK;   // (front_kernel ordered the lists it made)
         if (getenv("CASIM_PACK_PROF_DUMP") && !os_.prof) { os_.prof = (int64_t*)dalloc(8 * 4 * (size_t)NG_); bk_.zero(os_.prof, 8 * 4 * (size_t)NG_); }
-        if (order_lds_) bk_.launch(order_kernel<true>, NG_, 1, order_threads_, order_smem_, dt_, dr_, os_);
+        if (strided_) {
+            const size_t smem = order_smem_ > front_sim_wave_scratch() ? order_smem_ : front_sim_wave_scratch();
+            if (order_lds_) bk_.launch(order_strided_kernel<true>, NG_, 1, order_threads_, smem, dt_, dr_, os_, (const uint64_t*)d_bits_, Wg_, res_off_, d_idx_);
+            else bk_.launch(order_strided_kernel<false>, NG_, 1, order_threads_, front_sim_wave_scratch(), dt_, dr_, os_, (const uint64_t*)d_bits_, Wg_, res_off_, d_idx_);
+        }
+        else if (order_lds_) bk_.launch(order_kernel<true>, NG_, 1, order_threads_, order_smem_, dt_, dr_, os_);
         else bk_.launch(order_kernel<false>, NG_, 1, order_threads_, (size_t)0, dt_, dr_, os_);
         if (os_.prof) {  // profiling builds: mean ticks per phase over the groups
             std::vector<int64_t> h((size_t)NG_ * 4);
@@ -1159,7 +1170,7 @@ private:
     bool winners_only_ = false, winners_ready_ = false; int winners_s_ = 0; int32_t winners_total_ = 0;   // casim_options.winners_only
     int32_t* d_woff_ = nullptr; int32_t* d_worder_ = nullptr; int32_t* d_wplaced_ = nullptr; size_t woff_cap_ = 0;
     bool front_ = false, front_ran_ = false;   // feas + offsets + lists + order in ONE launch (front_kernel)
-    bool strided_ = false; size_t front_sim_smem_ = 0; std::vector<int32_t> h_off_static_;   // batches: fixed-stride lists, front_sim_kernel
+    bool strided_ = false, strided_one_launch_ = false; size_t front_sim_smem_ = 0; std::vector<int32_t> h_off_static_;   // batches: fixed-stride lists, front_sim_kernel
     int32_t* d_coff_ = nullptr; int32_t* d_corder_ = nullptr; int32_t* d_cplaced_ = nullptr;   // ... compacted at fetch time
     uint64_t* d_ticket_ = nullptr; uint32_t front_epoch_ = 0;
     static constexpr size_t kFrontMaxGroups = 1024;
