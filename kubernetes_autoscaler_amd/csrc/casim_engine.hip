@@ -30,6 +30,10 @@ namespace {
 thread_local std::string g_err;
 int32_t set_err(int32_t code, const std::string& m) { g_err = m; return code; }
 
+// which build of the register packer an AUTO launch of instantiation (lanes, slots per lane, exclusion words) takes on `device`: runs
+// the self-check of THAT instantiation on first use (resolve below)
+bool casim_pack_use_plain(int device, size_t lds, int lanes, int slots_per_lane, int excl_words);
+
 struct HipBackend {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -111,9 +115,10 @@ struct HipBackend {
     // The register packer exists twice in the library (casim_pack_tu.hip): build 0 compiled with the experimental structurizer
     // option, build 1 without.  `want`: casim_options.pack_build of the problem (CASIM_PACK_BUILD_*); AUTO takes the build the
     // self-check left standing for this device (pack_plain).
-    bool pack_plain = false;
+    bool pack_plain = false;   // (CASIM_PACK_BUILD=plain / a failed check: the process-wide verdict, copied when the context is created)
     void launch_pack_fast(int want, int lanes, int slots_per_lane, int excl_words, int n_groups, const DevTables& t, const DevResults& res, const FastScratch& fs) {
-        const bool plain = want == CASIM_PACK_BUILD_PLAIN || (want != CASIM_PACK_BUILD_OPTION && pack_plain);
+        // AUTO: the instantiation about to run has been through the self-check, or goes through it now (once per process, device and instantiation)
+        const bool plain = want == CASIM_PACK_BUILD_PLAIN || (want != CASIM_PACK_BUILD_OPTION && (pack_plain || casim_pack_use_plain(device, lds, lanes, slots_per_lane, excl_words)));
         if (plain) check((hipError_t)casim::hip_launch_pack_fast_plain(lanes, slots_per_lane, excl_words, n_groups, (void*)stream, t, res, fs), "pack_fast_kernel launch (plain build)");
         else check((hipError_t)casim::hip_launch_pack_fast(lanes, slots_per_lane, excl_words, n_groups, (void*)stream, t, res, fs), "pack_fast_kernel launch");
     }
@@ -278,7 +283,7 @@ struct casim_problem {
 // alone) retires build 0 for the process and says so once on stderr.  ~40 ms, once.  CASIM_PACK_BUILD=plain|option skips the
 // check and forces a build; CASIM_PACK_SELFCHECK_FAULT=1 makes the comparison see a flipped word (how the fallback is tested).
 namespace {
-struct PackBuildState { int checked = 0; int plain = 0; int batches = 0; int differing = 0; int forced = 0; int skipped = 0; double ms = 0; };
+struct PackBuildState { int checked = 0; int plain = 0; int batches = 0; int differing = 0; int forced = 0; int skipped = 0; double ms = 0; uint32_t checked_mask = 0; };
 PackBuildState g_pack_build[64];
 std::mutex g_pack_build_mu;
 
@@ -430,7 +435,46 @@ int32_t self_check_run(HipBackend& bk, int build, int lanes4, int slot_class, in
 struct SelfCheckCase { int variant; uint32_t seed; };
 const SelfCheckCase kSelfCheckCases[] = {{0, 0}, {1, 1}, {2, 2}, {4, 3}, {8, 4}, {16, 5}, {3, 6}, {6, 7}, {12, 8}, {24, 9}, {17, 10}, {10, 11}, {20, 12}, {30, 13}, {31, 14}, {0, 15}};
 
-// decides pack_plain for the device of `bk` (once per process and device)
+// The check of ONE instantiation (lanes4, slot class, exclusion words) on `device`: its 16 case families through both builds.
+// Caller holds g_pack_build_mu.
+void self_check_instantiation(PackBuildState& st, int device, size_t lds, int lanes4, int sc, int excl) {
+    const bool fault = getenv("CASIM_PACK_SELFCHECK_FAULT") && atoi(getenv("CASIM_PACK_SELFCHECK_FAULT")) != 0;
+    HipBackend tmp;
+    tmp.device = device; tmp.lds = lds; tmp.own_stream = true;
+    tmp.bind();
+    tmp.check(hipStreamCreateWithFlags(&tmp.stream, hipStreamNonBlocking), "hipStreamCreate");
+    std::vector<int64_t> a, b;
+    const auto t0 = std::chrono::steady_clock::now();
+    int n_cases = (int)(sizeof kSelfCheckCases / sizeof kSelfCheckCases[0]);
+    if (const char* e = getenv("CASIM_PACK_SELFCHECK_CASES")) { const int v = atoi(e); if (v >= 1 && v < n_cases) n_cases = v; }   // (1 = the one batch per instantiation of round 3)
+    for (int ci = 0; ci < n_cases && tmp.stream; ++ci) {
+        const SelfCheckCase& cse = kSelfCheckCases[ci];
+        if (cse.variant == 4 && !excl) continue;   // (zone words alone need an instantiation that carries them: nothing new to run)
+        const int32_t rb = self_check_run(tmp, CASIM_PACK_BUILD_PLAIN, lanes4, sc, excl, cse.variant, cse.seed, b);
+        if (rb != CASIM_OK) { st.skipped++; continue; }   // (the reference build itself cannot run this batch: nothing to compare)
+        const int32_t ra = self_check_run(tmp, CASIM_PACK_BUILD_OPTION, lanes4, sc, excl, cse.variant, cse.seed, a);
+        st.batches++;
+        if (fault && st.batches == 5 && !a.empty()) a[a.size() / 2] ^= 1;
+        if (ra != CASIM_OK || a != b) st.differing++;
+    }
+    if (tmp.stream) { (void)hipStreamSynchronize(tmp.stream); }
+    tmp.release_pool();
+    if (tmp.stream) (void)hipStreamDestroy(tmp.stream);
+    (void)hipGetLastError();
+    st.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    st.checked_mask |= 1u << (lanes4 * 6 + sc * 2 + excl);
+    if (st.differing > 0 && !st.plain) {
+        st.plain = 1;
+        fprintf(stderr, "libcasim: the register packer's self-check found %d of %d batches differing between its two builds on device %d: "
+                        "the build with -structurizecfg-skip-uniform-regions is retired for this process (plain build in use)\n",
+                st.differing, st.batches, device);
+    }
+    if (getenv("CASIM_PACK_SELFCHECK_VERBOSE")) fprintf(stderr, "libcasim: packer self-check: %d batches compared, %d differing, %d not runnable, %.1f ms\n", st.batches, st.differing, st.skipped, st.ms);
+}
+
+// The verdict for the device of `bk` when a context is created: a forced build (CASIM_PACK_BUILD), or — CASIM_PACK_SELFCHECK=eager — every
+// instantiation checked up front (192 - 6 batches, ~150 ms).  Default: LAZY — nothing here; an instantiation is checked right before its first
+// AUTO launch (casim_pack_use_plain: 16 batches, ~13 ms, paid by the first problem that needs it), so that start-up costs what the process uses.
 void resolve_pack_build(HipBackend& bk) {
     if (bk.device < 0 || bk.device >= 64) return;
     std::lock_guard<std::mutex> lock(g_pack_build_mu);
@@ -440,40 +484,23 @@ void resolve_pack_build(HipBackend& bk) {
         const char* force = getenv("CASIM_PACK_BUILD");
         if (force && !strcmp(force, "plain")) { st.plain = 1; st.forced = 1; }
         else if (force && !strcmp(force, "option")) { st.plain = 0; st.forced = 1; }
-        else {
-            const bool fault = getenv("CASIM_PACK_SELFCHECK_FAULT") && atoi(getenv("CASIM_PACK_SELFCHECK_FAULT")) != 0;
-            HipBackend tmp;
-            tmp.device = bk.device; tmp.lds = bk.lds; tmp.own_stream = true;
-            tmp.bind();
-            tmp.check(hipStreamCreateWithFlags(&tmp.stream, hipStreamNonBlocking), "hipStreamCreate");
-            std::vector<int64_t> a, b;
-            const auto t0 = std::chrono::steady_clock::now();
-            int n_cases = (int)(sizeof kSelfCheckCases / sizeof kSelfCheckCases[0]);
-            if (const char* e = getenv("CASIM_PACK_SELFCHECK_CASES")) { const int v = atoi(e); if (v >= 1 && v < n_cases) n_cases = v; }   // (1 = the 12 batches of round 3)
-            for (int ci = 0; ci < n_cases && tmp.stream; ++ci)
-            for (int lanes4 = 0; lanes4 < 2; ++lanes4) for (int sc = 0; sc < 3; ++sc) for (int excl = 0; excl < 2; ++excl) {
-                const SelfCheckCase& cse = kSelfCheckCases[ci];
-                if ((cse.variant & 4) && !excl && cse.variant == 4) continue;   // (zone words need an instantiation that carries them: nothing new to run)
-                const int32_t rb = self_check_run(tmp, CASIM_PACK_BUILD_PLAIN, lanes4, sc, excl, cse.variant, cse.seed, b);
-                if (rb != CASIM_OK) { st.skipped++; continue; }   // (the reference build itself cannot run this batch: nothing to compare)
-                const int32_t ra = self_check_run(tmp, CASIM_PACK_BUILD_OPTION, lanes4, sc, excl, cse.variant, cse.seed, a);
-                st.batches++;
-                if (fault && st.batches == 5 && !a.empty()) a[a.size() / 2] ^= 1;
-                if (ra != CASIM_OK || a != b) st.differing++;
-            }
-            st.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            if (getenv("CASIM_PACK_SELFCHECK_VERBOSE")) fprintf(stderr, "libcasim: packer self-check: %d batches compared, %d differing, %d not runnable, %.1f ms\n", st.batches, st.differing, st.skipped, st.ms);
-            if (tmp.stream) { (void)hipStreamSynchronize(tmp.stream); }
-            tmp.release_pool();
-            if (tmp.stream) (void)hipStreamDestroy(tmp.stream);
-            (void)hipGetLastError();
-            st.plain = st.differing > 0 ? 1 : 0;
-            if (st.plain) fprintf(stderr, "libcasim: the register packer's self-check found %d of %d batches differing between its two builds on device %d: "
-                                          "the build with -structurizecfg-skip-uniform-regions is retired for this process (plain build in use)\n",
-                                  st.differing, st.batches, bk.device);
+        else if (const char* mode = getenv("CASIM_PACK_SELFCHECK")) {
+            if (!strcmp(mode, "eager"))
+                for (int lanes4 = 0; lanes4 < 2; ++lanes4) for (int sc = 0; sc < 3; ++sc) for (int excl = 0; excl < 2; ++excl) self_check_instantiation(st, bk.device, bk.lds, lanes4, sc, excl);
         }
     }
     bk.pack_plain = st.plain != 0;
+}
+
+bool casim_pack_use_plain(int device, size_t lds, int lanes, int slots_per_lane, int excl_words) {
+    if (device < 0 || device >= 64) return false;
+    const int lanes4 = lanes > 2 ? 1 : 0, sc = slots_per_lane <= 1 ? 0 : (slots_per_lane <= 4 ? 1 : 2), excl = excl_words > 0 ? 1 : 0;
+    const uint32_t bit = 1u << (lanes4 * 6 + sc * 2 + excl);
+    std::lock_guard<std::mutex> lock(g_pack_build_mu);
+    PackBuildState& st = g_pack_build[device];
+    if (st.forced || st.plain) return st.plain != 0;
+    if (!(st.checked_mask & bit)) self_check_instantiation(st, device, lds, lanes4, sc, excl);
+    return st.plain != 0;
 }
 }  // namespace
 

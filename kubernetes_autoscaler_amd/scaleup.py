@@ -123,7 +123,7 @@ class ScaleUpSimulator:
 # ---------------------------------------------------------------------------------------------------------------------
 # The host rules of ScaleUpOrchestrator.ScaleUp around the simulation (orchestrator.go:86-196, 380-437, 1043-1180): what turns the
 # per-group answers of SchedulablePodGroups + Estimate into the expander's option list, the final size change and the three pod
-# sets of status.ScaleUpStatus.  Pure host logic over results — the device (or the oracle, in tests) supplies `estimates`.
+# sets of status.ScaleUpStatus.  Pure host logic over results — `estimates` come from the device (tests also feed it the CPU checker's answers).
 # ---------------------------------------------------------------------------------------------------------------------
 @dataclass
 class GroupEstimate:
@@ -202,7 +202,7 @@ def decide_scale_up(pegs: List[PodEquivalenceGroup], estimates: List[GroupEstima
 
 
 def estimates_from_results(pegs: List[PodEquivalenceGroup], node_groups: List[NodeGroup], per_group) -> List[GroupEstimate]:
-    """`per_group[i]` = (PEG ids in processing order, pods placed per entry, node count) of group i — a BatchResult row or an oracle estimate."""
+    """`per_group[i]` = (PEG ids in processing order, pods placed per entry, node count) of group i (a BatchResult row, or the same three things from any other estimator)."""
     out = []
     for ng, (order, placed, node_count) in zip(node_groups, per_group):
         pods: List[Pod] = []

@@ -79,14 +79,25 @@ def test_many_groups_wait_for_more_than_one_wave_of_tickets():
     enc.close()
 
 
-def test_a_few_simulations_in_one_call_take_the_fused_launch_too():
-    """a TableSet of 6 simulations (peg_lo / peg_hi per simulation, 18 groups): below the batch geometry, one launch"""
+def test_a_few_simulations_in_one_call_take_the_fused_launch_too(monkeypatch):
+    """a TableSet of 6 simulations (peg_lo / peg_hi per simulation, 18 groups): below the batch geometry, one launch.  (Since round 4 a batch of
+    >= 2 simulations prefers fixed-stride lists — emu_last_front() == 2, the same comparison below — and takes the ticket kernel only when those
+    are switched off.)"""
     scs = [Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, None) for g in w.groups], existing=[], lanes=w.lanes,
                     device_csr=True) for w in (workloads.fuzz(5100 + i, max_groups=3, max_pegs=40, rich=False) for i in range(6))]
     enc, ts, bases = encode_batch(scs)
     L = emu_lib()
+    strided, estr = run_emu_tables(ts, kinds=[0])
+    assert L.emu_last_front() == 2
+    monkeypatch.setenv("CASIM_NO_STRIDED", "1")
     fused, ef = run_emu_tables(ts, kinds=[0])
     assert L.emu_last_front() == 1
+    for f in FIELDS:
+        a, b = getattr(fused, f, None), getattr(strided, f, None)
+        if a is not None or b is not None:
+            assert np.array_equal(np.asarray(a), np.asarray(b)), ("fixed-stride lists", f)
+    for k in ("best", "n_best", "best_set", "keys", "packed"):
+        assert np.array_equal(ef[k], estr[k]), k
     split, es = run_emu_tables(ts, kinds=[0], front=False)
     assert L.emu_last_front() == 0
     for f in FIELDS:

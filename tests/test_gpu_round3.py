@@ -131,8 +131,11 @@ def test_packer_self_check_ran_and_found_the_two_builds_identical(ctx):
     info = ctx.pack_build_info()
     if info["forced_by_env"]:
         pytest.skip("CASIM_PACK_BUILD forces a build")
-    # 16 case families x 12 instantiations (zone words alone on an instantiation without exclusion words is not run: 6 fewer)
-    assert info["batches_compared"] == 186 and info["batches_differing"] == 0 and info["build"] == "option", info
+    # lazy since round 4: every instantiation this process has launched so far went through its 16 (15 without exclusion words) case families
+    with kaa.Problem(ctx, *_c2_batch(1, 2).structs()) as p:
+        p.run(); p.fetch()
+    info = ctx.pack_build_info()
+    assert info["batches_compared"] >= 15 and info["batches_differing"] == 0 and info["build"] == "option", info
 
 
 def test_packer_self_check_corpus_runs_everything_it_generates_in_time():
@@ -141,15 +144,34 @@ def test_packer_self_check_corpus_runs_everything_it_generates_in_time():
     check has to stay a start-up cost nobody notices (own process: the verdict is per process)."""
     import re, subprocess, sys
     code = "import sys; sys.path.insert(0, %r)\nimport kubernetes_autoscaler_amd as kaa\nctx = kaa.Context(0)\nprint(ctx.pack_build_info())\n" % ROOT
-    env = dict(os.environ); env["CASIM_PACK_SELFCHECK_VERBOSE"] = "1"; env.pop("CASIM_PACK_BUILD", None)
+    env = dict(os.environ); env["CASIM_PACK_SELFCHECK_VERBOSE"] = "1"; env["CASIM_PACK_SELFCHECK"] = "eager"; env.pop("CASIM_PACK_BUILD", None)
     p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
-    m = re.search(r"packer self-check: (\d+) batches compared, (\d+) differing, (\d+) not runnable, ([0-9.]+) ms", p.stderr)
-    assert m, p.stderr[-2000:]
-    compared, differing, skipped, ms = int(m.group(1)), int(m.group(2)), int(m.group(3)), float(m.group(4))
-    print(f"self-check: {compared} batches, {ms:.1f} ms")
+    ms_ = re.findall(r"packer self-check: (\d+) batches compared, (\d+) differing, (\d+) not runnable, ([0-9.]+) ms", p.stderr)
+    assert len(ms_) == 12, p.stderr[-2000:]     # (one line per instantiation, cumulative figures)
+    compared, differing, skipped, ms = int(ms_[-1][0]), int(ms_[-1][1]), int(ms_[-1][2]), float(ms_[-1][3])
+    print(f"self-check, eager: {compared} batches, {ms:.1f} ms")
     assert compared == 186 and differing == 0 and skipped == 0
-    assert ms < 400.0   # (includes the first launches of 24 kernel instantiations: code-object loading, not compute)
+    assert ms < 600.0   # (includes the first launches of 24 kernel instantiations: code-object loading, not compute)
+
+
+def test_packer_self_check_is_lazy_and_cheap_at_start_up():
+    """the default: a context costs nothing; the first problem that needs an instantiation checks THAT one (15-16 batches, both builds) — a
+    process that runs C2 batches pays for one instantiation, not for twelve (VERDICT r3 next #10: < 50 ms at start-up)"""
+    import re, subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\nimport kubernetes_autoscaler_amd as kaa\nfrom kubernetes_autoscaler_amd import workloads\n"
+            "from harness import GroupSpec, Scenario, encode\nctx = kaa.Context(0)\nprint('before', ctx.pack_build_info())\n"
+            "w = workloads.CONFIGS['C2']()\nsc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing, lanes=w.lanes, device_csr=True)\n"
+            "enc = encode(sc)\nfor _ in range(2):\n    with kaa.Problem(ctx, enc.pegs, enc.groups) as p:\n        p.run(); p.fetch()\nprint('after', ctx.pack_build_info())\n") % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ); env["CASIM_PACK_SELFCHECK_VERBOSE"] = "1"; env.pop("CASIM_PACK_BUILD", None); env.pop("CASIM_PACK_SELFCHECK", None)
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "'batches_compared': 0" in p.stdout.split("after")[0]          # nothing ran when the context came up
+    ms_ = re.findall(r"packer self-check: (\d+) batches compared, (\d+) differing, (\d+) not runnable, ([0-9.]+) ms", p.stderr)
+    assert len(ms_) == 1, p.stderr[-2000:]                                  # ONE instantiation, checked once (the second problem found it done)
+    compared, differing, skipped, ms = int(ms_[0][0]), int(ms_[0][1]), int(ms_[0][2]), float(ms_[0][3])
+    print(f"self-check, lazy: {compared} batches, {ms:.1f} ms")
+    assert compared == 15 and differing == 0 and skipped == 0 and ms < 50.0
 
 
 def test_both_packer_builds_agree_with_the_oracle(ctx):
