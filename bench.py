@@ -775,16 +775,20 @@ def enter_return_row(kaa, ctx, tables, kinds, K, checks_per_step, steps, res_res
     pegs, groups = tables.structs()
     if winners_only:
         call = BatchCall(ctx, pegs, groups, kinds=kinds, n_streams=K, winners_only=True)
-        call.call_raw()
-        t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(3):                # first calls: lanes' pools and pinned buffers grow to this call's sizes
             call.call_raw()
-        dt = (time.perf_counter() - t0) / steps
+        seq = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            call.call_raw()
+            seq.append(time.perf_counter() - t0)
+        dt = sum(seq) / steps
         res, exp = call.call()
         bytes_in = sum(v.nbytes for v in tables.pegs.values() if v is not None) + sum(v.nbytes for v in tables.groups.values() if v is not None)
         return {"what": "casim_estimate_batch_query enter -> return every step, casim_options.winners_only: H2D of fresh tables from pinned staging + kernels + "
                         "expander + winners' lists compacted on the device + D2H of every group's scalars / offsets and the winners' order / placed", "dtype": "int32",
                 "ms_per_step": dt * 1e3, "checks_per_s": checks_per_step / dt, "sims_per_s": tables.n_sims / dt, "steps": steps,
+                "ms_per_call_sequence": [round(x * 1e3, 3) for x in seq],
                 "table_bytes_in": bytes_in, "result_bytes_out": 8 * int(res.winner_offsets[-1]) + 52 * tables.n_groups + 16 * tables.n_sims,
                 "pcie_inclusive": True, "bit_equal_to_resident": _same_winners((res, exp), (res_resident, exp_resident))}
     call = BatchCall(ctx, pegs, groups, kinds=kinds, n_streams=K)

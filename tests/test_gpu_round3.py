@@ -132,7 +132,9 @@ def test_packer_self_check_ran_and_found_the_two_builds_identical(ctx):
     if info["forced_by_env"]:
         pytest.skip("CASIM_PACK_BUILD forces a build")
     # lazy since round 4: every instantiation this process has launched so far went through its 16 (15 without exclusion words) case families
-    with kaa.Problem(ctx, *_c2_batch(1, 2).structs()) as p:
+    ts = _c2_batch(1, 2)                 # (kept alive: the structs point into its arrays)
+    pegs, groups = ts.structs()
+    with kaa.Problem(ctx, pegs, groups) as p:
         p.run(); p.fetch()
     info = ctx.pack_build_info()
     assert info["batches_compared"] >= 15 and info["batches_differing"] == 0 and info["build"] == "option", info
