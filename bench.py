@@ -668,7 +668,8 @@ def main():
             rows["enter_return"] = _try(lambda: enter_return_row(kaa, ctx, batch.tables, kinds, K, checks_per_step, max(3, min(args.steps, 10)), res_all, final))
             rows["enter_return_every_list"] = _try(lambda: enter_return_row(kaa, ctx, batch.tables, kinds, K, checks_per_step, max(3, min(args.steps, 10)), res_all, final,
                                                                             winners_only=False))
-            rows["int64"] = _try(lambda: int64_row(kaa, dev_index, batch.tables, kinds, K, checks_per_step, max(5, min(args.steps, 50)), res_all, final, torch))
+            rows["int64"] = _try(lambda: int64_row(kaa, dev_index, batch.tables, kinds, K, checks_per_step, max(5, min(args.steps, 50)), res_all, final, torch, packer=2))
+            rows["int64_lds_store"] = _try(lambda: int64_row(kaa, dev_index, batch.tables, kinds, K, checks_per_step, max(5, min(args.steps, 50)), res_all, final, torch, packer=1))
         extra["headline_rows"] = rows
         # the §8(d) wall-clock form of the same metric at top level (VERDICT r3 next #1b): `value` is the resident regime the bench
         # contract asks for (inputs in HBM when the timed region starts); value_wall is casim_estimate_batch_query enter -> return
@@ -813,10 +814,12 @@ def enter_return_row(kaa, ctx, tables, kinds, K, checks_per_step, steps, res_res
             "pcie_inclusive": True, "bit_equal_to_resident": _same_results((res, exp), (res_resident, exp_resident))}
 
 
-def int64_row(kaa, dev_index, tables, kinds, K, checks_per_step, steps, res_resident, exp_resident, torch):
-    """The resident step with casim_options.force_generic_packer: int64 lanes end to end (the boundary's own type), node state in
-    LDS — what a batch pays when the exact gcd narrowing to int32 does not apply."""
-    with kaa.StreamedBatch(dev_index, tables, n_streams=K, force_generic_packer=True) as b:
+def int64_row(kaa, dev_index, tables, kinds, K, checks_per_step, steps, res_resident, exp_resident, torch, packer=1):
+    """The resident step on int64 lanes end to end (the boundary's own type) — what a batch pays when the exact gcd narrowing to int32
+    does not apply.  packer = 2 (casim_options.force_generic_packer == 2): the register store on two int64 lanes (round 4: what such a
+    batch takes by itself); packer = 1: the LDS store's generic packer (more than two lanes, negative requests; every such batch until
+    round 4)."""
+    with kaa.StreamedBatch(dev_index, tables, n_streams=K, force_generic_packer=packer) as b:
         for _ in range(3):
             b.run(); b.best_option_sims(kinds, fetch=False)
         torch.cuda.synchronize()
@@ -828,7 +831,8 @@ def int64_row(kaa, dev_index, tables, kinds, K, checks_per_step, steps, res_resi
         res = b.fetch()
         exp = b.best_option_sims(kinds)
         info = b.prob.info()
-    return {"what": "resident step, force_generic_packer (int64 MemStore packer)", "dtype": "int64", "ms_per_step": dt * 1e3,
+    return {"what": "resident step, int64 lanes: " + ("register store on two int64 lanes (pack_fast64_kernel)" if packer == 2 else "force_generic_packer (int64 MemStore packer, node state in LDS)"),
+            "dtype": "int64", "ms_per_step": dt * 1e3, "packer_lanes": info["fast_packer_lanes"],
             "checks_per_s": checks_per_step / dt, "sims_per_s": tables.n_sims / dt, "steps": steps,
             "register_packer": info["fast_packer_slots_per_lane"] > 0,
             "bit_equal_to_resident": _same_results((res, exp), (res_resident, exp_resident))}

@@ -157,7 +157,9 @@ typedef struct casim_groups {
 
 typedef struct casim_options {
     int32_t fastpath;             /* --fastpath-binpacking-enabled (flags.go:203), default 0 */
-    int32_t force_generic_packer; /* 1 = never use the register-resident int32 packer (testing / A-B) */
+    int32_t force_generic_packer; /* 0 = the library picks: the register-resident packer on gcd-scaled int32 lanes, on two int64 lanes when a
+                                     lane does not narrow (R <= 2, no negative request, amounts < 2^62), else the LDS store's generic one;
+                                     1 = never a register-resident packer; 2 = skip the int32 narrowing (int64 lanes when eligible) — testing / A-B */
     int32_t node_pods;            /* 1 = keep the pods per simulated node (casim_results.node_pods): what
                                      estimationAnalyserFunc receives as newNodesWithPods (binpacking_estimator.go:157-159) */
     int32_t n_streams;            /* > 1: a batch of simulations (casim_groups.n_sims >= 2, subsets derived on the device from
@@ -286,7 +288,8 @@ int32_t casim_problem_csr(casim_problem* p, int32_t* nnz_out, int32_t* offsets_o
 int32_t casim_pack_build_info(int32_t device, int32_t out[4]);
 
 /* How the resident batch will be executed (for reports): info_out[0] = node slots per lane of the
- * register-resident int32 packer (0 = generic int64 packer), [1] = its lane count, [2] = 1 if the
+ * register-resident packer (0 = generic int64 packer, node state in LDS / HBM), [1] = its lanes (2 / 4: gcd-scaled int32 lanes; 8: two int64
+ * lanes, the batch did not narrow), [2] = 1 if the
  * generic packer keeps node state in LDS (0 = HBM slab), [3] = 1 if the schedulable subsets are
  * derived on the device, [4] = parts the batch runs as on internal streams (1 = not cut), [5] = how many runs so far had to fork
  * from the context's stream (it held pending work: see casim_options.n_streams), [6] = streams the context parked because

@@ -301,7 +301,7 @@ struct SelfCheckRng { uint64_t s; uint32_t next() { s = s * 6364136223846793005u
 int32_t self_check_run(HipBackend& bk, int build, int lanes4, int slot_class, int excl, int variant, uint32_t seed, std::vector<int64_t>& out) {
     SelfCheckRng rng{0x9E3779B97F4A7C15ull ^ (uint64_t)(lanes4 * 131 + slot_class * 17 + excl) ^ ((uint64_t)seed << 20) ^ ((uint64_t)variant << 40)};
     const bool v_fast = (variant & 1) != 0, v_runs = (variant & 2) != 0, v_zone = excl && (variant & 4) != 0, v_lists = (variant & 8) != 0, v_odd = (variant & 16) != 0;
-    const int G = 160, NG = 48, R = lanes4 ? 3 : 2;
+    const int G = 160, NG = 48, R = lanes4 == 1 ? 3 : 2;   // lanes4: 0 = two int32 lanes, 1 = four, 2 = two int64 lanes (the same tables as 0, not narrowed)
     std::vector<int64_t> req((size_t)G * R), alloc((size_t)NG * R), ireq((size_t)NG * R);
     std::vector<int32_t> count(G), allowed(NG), ipods(NG), maxn(NG), existing(NG), lastidx(NG);
     std::vector<uint32_t> pflags(G), gflags(NG);
@@ -402,11 +402,12 @@ int32_t self_check_run(HipBackend& bk, int build, int lanes4, int slot_class, in
     g.max_nodes = maxn.data(); g.existing_nodes = existing.data(); g.last_index = lastidx.data();
     casim_options o; memset(&o, 0, sizeof o);
     o.pack_build = build; o.fastpath = v_fast ? 1 : 0;
+    if (lanes4 == 2) o.force_generic_packer = 2;
     bk.clear();
     HipProblem prob(bk);
     int32_t rc = prob.init(&p, &g, &o);
     if (rc != CASIM_OK) return rc;
-    if (prob.fast_npt() != (slot_class == 0 ? 1 : (slot_class == 1 ? 4 : 16)) || prob.fast_lanes() != (lanes4 ? 4 : 2)) return CASIM_ERR_INVALID;   // (the corpus no longer reaches the instantiation it is meant for)
+    if (prob.fast_npt() != (slot_class == 0 ? 1 : (slot_class == 1 ? 4 : 16)) || prob.fast_lanes() != (lanes4 == 2 ? 8 : (lanes4 ? 4 : 2))) return CASIM_ERR_INVALID;   // (the corpus no longer reaches the instantiation it is meant for)
     rc = prob.run();
     if (rc != CASIM_OK) return rc;
     int32_t nnz = 0;
@@ -430,8 +431,8 @@ int32_t self_check_run(HipBackend& bk, int build, int lanes4, int slot_class, in
     return CASIM_OK;
 }
 
-// The corpus: every instantiation (2 / 4 lanes x 1 / 4 / 16 slots x without / with exclusion words) x 16 batches — the 12 plain batches the
-// check started with, then every feature bit alone, in pairs, and all together, each on data of its own.  192 batches, 384 runs.
+// The corpus: every instantiation (2 / 4 int32 lanes or 2 int64 lanes x 1 / 4 / 16 slots x without / with exclusion words) x 16 batches — the 12 plain batches the
+// check started with, then every feature bit alone, in pairs, and all together, each on data of its own.  288 batches, 576 runs.
 struct SelfCheckCase { int variant; uint32_t seed; };
 const SelfCheckCase kSelfCheckCases[] = {{0, 0}, {1, 1}, {2, 2}, {4, 3}, {8, 4}, {16, 5}, {3, 6}, {6, 7}, {12, 8}, {24, 9}, {17, 10}, {10, 11}, {20, 12}, {30, 13}, {31, 14}, {0, 15}};
 
@@ -473,7 +474,7 @@ void self_check_instantiation(PackBuildState& st, int device, size_t lds, int la
 }
 
 // The verdict for the device of `bk` when a context is created: a forced build (CASIM_PACK_BUILD), or — CASIM_PACK_SELFCHECK=eager — every
-// instantiation checked up front (192 - 6 batches, ~150 ms).  Default: LAZY — nothing here; an instantiation is checked right before its first
+// instantiation checked up front (288 - 9 batches, ~270 ms).  Default: LAZY — nothing here; an instantiation is checked right before its first
 // AUTO launch (casim_pack_use_plain: 16 batches, ~13 ms, paid by the first problem that needs it), so that start-up costs what the process uses.
 void resolve_pack_build(HipBackend& bk) {
     if (bk.device < 0 || bk.device >= 64) return;
@@ -486,7 +487,7 @@ void resolve_pack_build(HipBackend& bk) {
         else if (force && !strcmp(force, "option")) { st.plain = 0; st.forced = 1; }
         else if (const char* mode = getenv("CASIM_PACK_SELFCHECK")) {
             if (!strcmp(mode, "eager"))
-                for (int lanes4 = 0; lanes4 < 2; ++lanes4) for (int sc = 0; sc < 3; ++sc) for (int excl = 0; excl < 2; ++excl) self_check_instantiation(st, bk.device, bk.lds, lanes4, sc, excl);
+                for (int lanes4 = 0; lanes4 < 3; ++lanes4) for (int sc = 0; sc < 3; ++sc) for (int excl = 0; excl < 2; ++excl) self_check_instantiation(st, bk.device, bk.lds, lanes4, sc, excl);
         }
     }
     bk.pack_plain = st.plain != 0;
@@ -494,7 +495,7 @@ void resolve_pack_build(HipBackend& bk) {
 
 bool casim_pack_use_plain(int device, size_t lds, int lanes, int slots_per_lane, int excl_words) {
     if (device < 0 || device >= 64) return false;
-    const int lanes4 = lanes > 2 ? 1 : 0, sc = slots_per_lane <= 1 ? 0 : (slots_per_lane <= 4 ? 1 : 2), excl = excl_words > 0 ? 1 : 0;
+    const int lanes4 = lanes == 8 ? 2 : (lanes > 2 ? 1 : 0), sc = slots_per_lane <= 1 ? 0 : (slots_per_lane <= 4 ? 1 : 2), excl = excl_words > 0 ? 1 : 0;
     const uint32_t bit = 1u << (lanes4 * 6 + sc * 2 + excl);
     std::lock_guard<std::mutex> lock(g_pack_build_mu);
     PackBuildState& st = g_pack_build[device];

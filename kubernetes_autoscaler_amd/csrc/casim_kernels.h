@@ -556,7 +556,36 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
 #pragma unroll
                 for (int k = 0; k < DW / 4; ++k) out[k] = RecQuad{w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]};
             };
-            if (res.rec_dw == 8) emit(IntTag<2>{}); else emit(IntTag<4>{});
+            // int64 register store: the two requests as they came (no gcd scaling), 64-bit quotient for the empty node's capacity
+            auto emit64 = [&]() {
+                uint32_t w[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) w[k] = 0;
+                const int32_t slots = t.allowed[ng] - t.init_pods[ng];
+                uint32_t cf = slots > 0 ? (uint32_t)slots : 0u;
+                bool simple = true;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int64_t q = r < t.R ? t.req[(int64_t)g * t.R + r] : 0;
+                    simple = simple && q > 0;
+                    w[2 + 2 * r] = (uint32_t)(uint64_t)q; w[2 + 2 * r + 1] = (uint32_t)((uint64_t)q >> 32);
+                    const uint64_t rq = cs::double_bits(q > 0 ? 1.0 / (double)q : 0.0);
+                    w[6 + 2 * r] = (uint32_t)rq; w[6 + 2 * r + 1] = (uint32_t)(rq >> 32);
+                    if (q > 0) {
+                        const int64_t f = t.alloc[(int64_t)ng * t.R + r] - t.init_req[(int64_t)ng * t.R + r];
+                        const uint64_t e = f >= q ? (uint64_t)f / (uint64_t)q : 0ull;
+                        cf = e < (uint64_t)cf ? (uint32_t)e : cf;
+                    }
+                }
+                w[0] = (uint32_t)t.count[g];
+                const bool a2_ok = (flags & CASIM_KFLAG_STATIC_OK) && t.count[g] > 0;
+                w[1] = (flags & (CASIM_REC_FLAG_MASK & ~(CASIM_REC_SIMPLE | CASIM_REC_A2_OK))) | (cf << CASIM_REC_FRESH_SHIFT) | (simple ? CASIM_REC_SIMPLE : 0u) |
+                       (a2_ok ? CASIM_REC_A2_OK : 0u) | ((a2_ok && simple) ? CASIM_REC_A2_SIMPLE : 0u);
+                RecQuad* out = (RecQuad*)(res.rec + (int64_t)(off + i) * 16);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) out[k] = RecQuad{w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]};
+            };
+            if (res.rec_i64) emit64(); else if (res.rec_dw == 8) emit(IntTag<2>{}); else emit(IntTag<4>{});
         }
         if (res.s_count) {   // the generic packer's three arrays (also next to the records when it stands by for retries)
             res.s_count[off + i] = t.count[g];

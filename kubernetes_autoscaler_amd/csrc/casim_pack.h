@@ -197,19 +197,25 @@ struct MemStore {
 };
 
 // ---- node store: int32 state in VGPRs (fast path) ---------------------------------------------------
-template <int R_, int NPT_, int WX_ = 0>
+// L_ = int64_t (round 4, R_ == 2 only): the SAME store on the boundary's own type, for batches whose lanes do not narrow to 32 bits
+// (byte-granular, co-prime memory requests beyond 2^31 after the gcd) — register pairs instead of registers, 64-byte records carrying the
+// int64 requests, quotients by the same f64 estimate + exact fix-up (exact below 2^53, a real division above).  Until round 4 such a
+// batch fell back on the LDS store's generic packer, 3.4 x slower on the headline batch.
+template <int R_, int NPT_, int WX_ = 0, class L_ = int32_t>
 struct RegStore {
-    using Lane = int32_t;
+    using Lane = L_;
+    static constexpr bool k64 = sizeof(L_) == 8;
+    static_assert(!k64 || R_ == 2, "the int64 register store keeps two lanes (64-byte records)");
     static constexpr int kNPT = NPT_;
     static constexpr int kRMax = R_;
     static constexpr bool kHasExcl = WX_ > 0;   // WX_ = 1 or 2 words of node-local exclusion bits (host ports, hostname anti-affinity)
     static constexpr bool X_ = WX_ > 0;
     static constexpr bool kHasZone = WX_ > 0;   // the lean instantiation (WX_ = 0) carries no exclusion state at all
     static constexpr int kZoneWords = 2;        // group-wide exclusion words are wave-uniform: up to two, in scalar registers
-    static constexpr int kRecDw = R_ <= 2 ? 8 : 16;   // PEG records: one scalar load of kRecDw dwords per PEG (casim_types.h)
-    using Peg = PegView<int32_t, R_>;
-    using Fresh = FreshNode<int32_t, R_>;
-    int32_t fr[NPT_][R_];
+    static constexpr int kRecDw = (k64 || R_ > 2) ? 16 : 8;   // PEG records: one scalar load of kRecDw dwords per PEG (casim_types.h)
+    using Peg = PegView<L_, R_>;
+    using Fresh = FreshNode<L_, R_>;
+    L_ fr[NPT_][R_];
     uint64_t excl[NPT_][WX_ > 0 ? WX_ : 1];
     int wx = 0;   // words the batch really has (<= WX_)
     CS_DEVICE bool blocked(int s, const Peg& pv) const {
@@ -253,6 +259,29 @@ struct RegStore {
         const bool fit = cs::lane_pred(fb);
         if (cs::flag_set(pf, CASIM_PEG_SELF_EXCL_NODE)) return fit ? 1u : 0u;   // clampk >= 1, a pod slot is free and every requested lane fits once
         uint32_t k = (uint32_t)slots[s] < clampk ? (uint32_t)slots[s] : clampk;
+        if constexpr (k64) {
+            // int64 lanes: the quotient estimate in f64 is exact up to +-1 while the free amount is below 2^53 and the quotient below 2^31
+            // (an estimate beyond that is clamped: the pod-slot bound k is smaller anyway); larger amounts take the real division
+#pragma unroll
+            for (int r = 0; r < R_; ++r) {
+                const int64_t q = pv.req[r];
+                if (q > 0) {   // wave-uniform
+                    const int64_t f = fit ? fr[s][r] : 0;
+                    uint32_t e;
+                    if (f < (1ll << 53)) {
+                        const double ed = (double)f * pv.rq[r];
+                        e = ed >= 2147483648.0 ? 0x7fffffffu : (uint32_t)ed;
+                        const int64_t rem = f - (int64_t)((uint64_t)e * (uint64_t)q);
+                        if (e != 0x7fffffffu) e = rem < 0 ? e - 1 : (rem >= q ? e + 1 : e);
+                    } else {
+                        const uint64_t d = (uint64_t)f / (uint64_t)q;
+                        e = d > 0x7fffffffull ? 0x7fffffffu : (uint32_t)d;
+                    }
+                    k = e < k ? e : k;
+                }
+            }
+            return fit ? k : 0u;
+        }
         if (cs::flag_set(pf, CASIM_REC_SIMPLE)) {
             // (lanes that do not fit compute garbage and are masked at the end: no select per operand)
 #pragma unroll
@@ -311,7 +340,7 @@ struct RegStore {
     }
     CS_DEVICE void commit(int s, int, uint32_t x, const Peg& pv) {
 #pragma unroll
-        for (int r = 0; r < R_; ++r) fr[s][r] -= (int32_t)x * pv.req[r];
+        for (int r = 0; r < R_; ++r) fr[s][r] -= (L_)x * pv.req[r];
         slots[s] -= (int32_t)x;
 #pragma unroll
         for (int w = 0; w < WX_; ++w) excl[s][w] |= pv.xm[w];
@@ -319,14 +348,14 @@ struct RegStore {
     // the same for any x >= 0 (x == 0: no change), straight-line
     CS_DEVICE void commit_any(int s, uint32_t x, const Peg& pv) {
 #pragma unroll
-        for (int r = 0; r < R_; ++r) fr[s][r] -= (int32_t)x * pv.req[r];
+        for (int r = 0; r < R_; ++r) fr[s][r] -= (L_)x * pv.req[r];
         slots[s] -= (int32_t)x;
 #pragma unroll
         for (int w = 0; w < WX_; ++w) excl[s][w] |= x > 0 ? pv.xm[w] : 0ull;
     }
     CS_DEVICE void create(int s, int, uint32_t x, const Peg& pv, const Fresh& fn) {
 #pragma unroll
-        for (int r = 0; r < R_; ++r) fr[s][r] = fn.free[r] - (int32_t)x * pv.req[r];
+        for (int r = 0; r < R_; ++r) fr[s][r] = fn.free[r] - (L_)x * pv.req[r];
         slots[s] = fn.slots - (int32_t)x;
 #pragma unroll
         for (int w = 0; w < WX_; ++w) excl[s][w] = (w < wx ? fn.excl[w] : 0ull) | (x > 0 ? pv.xm[w] : 0ull);   // wx <= WX_ words exist
@@ -340,7 +369,7 @@ struct RegStore {
     // node, the others evaluate an empty one.  The caller reads the owner lane.
     CS_DEVICE uint32_t capacity_newest(int lm, const Peg& pv, uint32_t clampk, bool selfx, bool) const {
         const int lane = cs::lane();
-        int32_t f[R_], sl = 0;
+        L_ f[R_]; int32_t sl = 0;
         bool b = false;
 #pragma unroll
         for (int r = 0; r < R_; ++r) f[r] = 0;
@@ -363,7 +392,7 @@ struct RegStore {
         for (int s = 0; s < NPT_; ++s) {
             const bool h = s * 64 + lane == lm;
 #pragma unroll
-            for (int r = 0; r < R_; ++r) fr[s][r] -= h ? (int32_t)x * pv.req[r] : 0;
+            for (int r = 0; r < R_; ++r) fr[s][r] -= h ? (L_)x * pv.req[r] : (L_)0;
             slots[s] -= h ? (int32_t)x : 0;
 #pragma unroll
             for (int w = 0; w < WX_; ++w) excl[s][w] |= h ? pv.xm[w] : 0ull;
@@ -529,7 +558,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     // scalar unit is the busy one, and as scalar 64-bit multiply-adds these are eight instructions).  Reading the lane's own
     // record back at the chunk flush instead touched every record line a second time, 64 PEGs after the scalar load had
     // dropped it from the caches: the kernel's HBM read traffic was twice its algorithmic bytes (profiles/r03c).
-    auto add_totals = [&](int32_t placed, int32_t q0, int32_t q1) {
+    auto add_totals = [&](int32_t placed, L q0, L q1) {
         const int32_t pv_ = cs::opaque_i32(placed);   // (a VGPR copy: keeps the arithmetic off the scalar unit)
         acc0 += (int64_t)pv_ * (int64_t)q0;
         acc1 += (int64_t)pv_ * (int64_t)q1;
@@ -577,10 +606,18 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 cnt = (int32_t)cur.w[0];
                 pf = cur.w[1];
                 cf_rec = (cur.w[1] >> CASIM_REC_FRESH_SHIFT) & CASIM_REC_FRESH_MAX;
+                if constexpr (sizeof(L) == 8) {   // 64-byte record of the int64 register store: [2..5] two int64 requests, [6..9] their reciprocals
 #pragma unroll
-                for (int r = 0; r < RM; ++r) {
-                    pv.req[r] = (L)cur.w[2 + r];   // (lanes past R hold a zero request and a zero reciprocal)
-                    pv.rq[r] = cs::bits_double(((uint64_t)cur.w[2 + RM + 2 * r + 1] << 32) | cur.w[2 + RM + 2 * r]);
+                    for (int r = 0; r < RM; ++r) {
+                        pv.req[r] = (L)(((uint64_t)cur.w[2 + 2 * r + 1] << 32) | cur.w[2 + 2 * r]);
+                        pv.rq[r] = cs::bits_double(((uint64_t)cur.w[2 + 2 * RM + 2 * r + 1] << 32) | cur.w[2 + 2 * RM + 2 * r]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < RM; ++r) {
+                        pv.req[r] = (L)cur.w[2 + r];   // (lanes past R hold a zero request and a zero reciprocal)
+                        pv.rq[r] = cs::bits_double(((uint64_t)cur.w[2 + RM + 2 * r + 1] << 32) | cur.w[2 + RM + 2 * r]);
+                    }
                 }
             } else {
                 cnt = (int32_t)cs::bcast_u32((uint32_t)my_cnt, j);
@@ -675,7 +712,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     if constexpr (kDry) {   // placed > 0 here; the tail of the step does not run
                         uint32_t mp = (uint32_t)my_placed; cs::write_lane_u32(mp, (uint32_t)placed, j); my_placed = (int32_t)mp;
                         total_placed += placed;
-                        add_totals(placed, (int32_t)pv.req[0], RM > 1 ? (int32_t)pv.req[1] : 0);
+                        add_totals(placed, pv.req[0], RM > 1 ? pv.req[1] : (L)0);
                     }
                 };
                 auto a2_rest = [&](const int32_t n1) {
@@ -950,7 +987,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             if constexpr (!kDry) {   // (kDry: a2 recorded what it placed, nothing else can place)
                 if constexpr (kRecScalar) {
                     uint32_t mp = (uint32_t)my_placed; cs::write_lane_u32(mp, (uint32_t)placed, j); my_placed = (int32_t)mp;
-                    add_totals(placed, (int32_t)pv.req[0], RM > 1 ? (int32_t)pv.req[1] : 0);
+                    add_totals(placed, pv.req[0], RM > 1 ? pv.req[1] : (L)0);
                 } else { if (lane == j) my_placed = placed; }
                 total_placed += placed;
             }
@@ -1103,6 +1140,29 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, ((NPT_ == 4 && WX_ == 0) ? CASIM_FAST_WAVES : 1))
     fn.excl = WX_ > 0 ? t.init_excl + (int64_t)ng * t.Wx : nullptr;
     st.wx = t.Wx < WX_ ? t.Wx : WX_;
     pack_body(t, res, st, fn, (uint64_t*)nullptr, [](int, int) -> int32_t { return 0; } /* (requests come with the records) */, fs.scale, fs.prof);
+}
+
+// ---- the same on int64 lanes (two of them): no gcd narrowing, requests and free amounts as the boundary carries them -----------------
+template <int NPT_, int WX_, int BUILD_ = 0>
+CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void pack_fast64_kernel(DevTables t, DevResults res, FastScratch fs) {
+    if (pack_unsupported<16>(t, res)) return;
+    const int ng = cs::bid();
+    RegStore<2, NPT_, WX_, int64_t> st;
+#pragma unroll
+    for (int s = 0; s < NPT_; ++s) {
+        st.fr[s][0] = 0; st.fr[s][1] = 0;
+        st.slots[s] = 0;
+#pragma unroll
+        for (int w = 0; w < WX_; ++w) st.excl[s][w] = 0;
+    }
+    FreshNode<int64_t, 2> fn;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) fn.free[r] = r < t.R ? t.alloc[(int64_t)ng * t.R + r] - t.init_req[(int64_t)ng * t.R + r] : 0;
+    fn.slots = t.allowed[ng] - t.init_pods[ng];
+    st.fresh_slots = fn.slots;
+    fn.excl = WX_ > 0 ? t.init_excl + (int64_t)ng * t.Wx : nullptr;
+    st.wx = t.Wx < WX_ ? t.Wx : WX_;
+    pack_body(t, res, st, fn, (uint64_t*)nullptr, [](int, int) -> int64_t { return 0; } /* (requests come with the records) */, (const int64_t*)nullptr, fs.prof);
 }
 
 }  // namespace casim

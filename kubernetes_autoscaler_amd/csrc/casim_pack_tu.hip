@@ -30,7 +30,14 @@ int hip_launch_pack_fast_plain(int lanes, int slots_per_lane, int excl_words, in
     if (n_groups <= 0) return 0;
 #define CASIM_TU_LAUNCH(R, N, X) pack_fast_kernel<R, N, X, CASIM_PACK_BUILD><<<dim3((unsigned)n_groups, 1, 1), dim3(64, 1, 1), (size_t)0, (hipStream_t)stream>>>(t, res, fs)
 #define CASIM_TU_PICK(R, X) do { if (slots_per_lane == 1) CASIM_TU_LAUNCH(R, 1, X); else if (slots_per_lane == 4) CASIM_TU_LAUNCH(R, 4, X); else CASIM_TU_LAUNCH(R, 16, X); } while (0)
-    if (lanes == 2) { if (excl_words == 2) CASIM_TU_PICK(2, 2); else CASIM_TU_PICK(2, 0); }
+    if (lanes == 8) {   // two int64 lanes (pack_fast64_kernel)
+#define CASIM_TU_LAUNCH64(N, X) pack_fast64_kernel<N, X, CASIM_PACK_BUILD><<<dim3((unsigned)n_groups, 1, 1), dim3(64, 1, 1), (size_t)0, (hipStream_t)stream>>>(t, res, fs)
+#define CASIM_TU_PICK64(X) do { if (slots_per_lane == 1) CASIM_TU_LAUNCH64(1, X); else if (slots_per_lane == 4) CASIM_TU_LAUNCH64(4, X); else CASIM_TU_LAUNCH64(16, X); } while (0)
+        if (excl_words == 2) CASIM_TU_PICK64(2); else CASIM_TU_PICK64(0);
+#undef CASIM_TU_PICK64
+#undef CASIM_TU_LAUNCH64
+    }
+    else if (lanes == 2) { if (excl_words == 2) CASIM_TU_PICK(2, 2); else CASIM_TU_PICK(2, 0); }
     else            { if (excl_words == 2) CASIM_TU_PICK(4, 2); else CASIM_TU_PICK(4, 0); }
 #undef CASIM_TU_PICK
 #undef CASIM_TU_LAUNCH

@@ -65,10 +65,13 @@ inline void par_memcpy(void* dst, const void* src, size_t bytes) {
 
 inline int64_t round_up64(int64_t v) { return (v + 63) & ~63ll; }
 
-// The instantiations of the register packer: lanes R in {2, 4}, node slots per lane in {1, 4, 16}, exclusion words in {0, 2}.
+// The instantiations of the register packer: lanes R in {2, 4} (int32) or 8 (= two int64 lanes), node slots per lane in {1, 4, 16},
+// exclusion words in {0, 2}.
 #define CASIM_FAST_DISPATCH(LAUNCH, r, npt, wx)                                                                      \
     do {                                                                                                             \
-        if ((r) == 2) { if ((wx) == 2) { if ((npt) == 1) LAUNCH(2, 1, 2); else if ((npt) == 4) LAUNCH(2, 4, 2); else LAUNCH(2, 16, 2); }          \
+        if ((r) == 8) { if ((wx) == 2) { if ((npt) == 1) LAUNCH(8, 1, 2); else if ((npt) == 4) LAUNCH(8, 4, 2); else LAUNCH(8, 16, 2); }          \
+                        else           { if ((npt) == 1) LAUNCH(8, 1, 0); else if ((npt) == 4) LAUNCH(8, 4, 0); else LAUNCH(8, 16, 0); } }        \
+        else if ((r) == 2) { if ((wx) == 2) { if ((npt) == 1) LAUNCH(2, 1, 2); else if ((npt) == 4) LAUNCH(2, 4, 2); else LAUNCH(2, 16, 2); }          \
                         else           { if ((npt) == 1) LAUNCH(2, 1, 0); else if ((npt) == 4) LAUNCH(2, 4, 0); else LAUNCH(2, 16, 0); } }        \
         else          { if ((wx) == 2) { if ((npt) == 1) LAUNCH(4, 1, 2); else if ((npt) == 4) LAUNCH(4, 4, 2); else LAUNCH(4, 16, 2); }          \
                         else           { if ((npt) == 1) LAUNCH(4, 1, 0); else if ((npt) == 4) LAUNCH(4, 4, 0); else LAUNCH(4, 16, 0); } }        \
@@ -423,7 +426,10 @@ public:
         {
             int32_t maxcap = 0;
             for (size_t i = 0; i < NG; ++i) maxcap = cap[i] > maxcap ? cap[i] : maxcap;
-            bool ok = o ? o->force_generic_packer == 0 : true;
+            bool ok = o ? o->force_generic_packer != 1 : true;
+            // force_generic_packer == 2 (tests, the bench's int64 row): skip the int32 narrowing, take the int64 register store when it applies
+            const bool want_i64 = o && o->force_generic_packer == 2;
+            fast_i64_ = false;
             pack_build_ = o ? o->pack_build : 0;
             // groups whose node BOUND exceeds the 1024 register slots still start in the register packer: the bound (limiter cap or
             // pods) is rarely reached — BenchmarkRunOnceScaleUp: bound 10 000, 200 nodes created — and a group that does run out
@@ -454,7 +460,7 @@ public:
             // reserved for later writes — and whose lanes fit the kernel's four; CASIM_DEV_GCD_MIN: tests run it on small tables)
             const char* dgm = getenv("CASIM_DEV_GCD_MIN");
             const long dev_gcd_min = dgm ? atol(dgm) : (long)kDevGcdMin;
-            const bool dev_gcd = ok && R <= 4 && (long)(G * (size_t)R) >= dev_gcd_min && dt_.req != nullptr && !up_reserved_;
+            const bool dev_gcd = ok && !want_i64 && R <= 4 && (long)(G * (size_t)R) >= dev_gcd_min && dt_.req != nullptr && !up_reserved_;
             if (ok) {
                 // one pass over the columns, cut over the host threads: per lane the gcd, the largest magnitude (of a request, an
                 // allocatable, a preloaded amount, a fresh node's free amount) and "some request is negative"
@@ -511,13 +517,24 @@ public:
                 neg = grp.neg;
                 for (auto& pt : parts) neg = neg || pt.neg;
                 // |v / scale| <= 2^31 - 1  <=>  |v| <= (2^31 - 1) * scale   (the product saturates: a scale beyond 2^32 admits every int64)
+                bool fits32 = true, fits62 = true;
                 for (int r = 0; r < R; ++r) {
                     const int64_t vmax = scale[(size_t)r] > (0x7fffffffffffffffll / 0x7fffffffll) ? 0x7fffffffffffffffll : 0x7fffffffll * scale[(size_t)r];
-                    ok = ok && amax[(size_t)r] <= vmax;
+                    fits32 = fits32 && amax[(size_t)r] <= vmax;
+                    fits62 = fits62 && amax[(size_t)r] < (1ll << 62);
                 }
-                ok = ok && !neg;
+                // lanes that do not narrow (byte-granular co-prime amounts beyond 2^31 after the gcd): the same register store on int64 lanes,
+                // two of them (RegStore<2, NPT, WX, int64_t>) — requests as they came, no scaling.  More lanes, negative requests or amounts
+                // beyond 2^62: the LDS store's generic packer.
+                fast_i64_ = !neg && R <= 2 && fits62 && (want_i64 || !fits32);
+                ok = ok && !neg && (fits32 || fast_i64_);
             }
-            if (ok) {
+            if (ok && fast_i64_) {
+                fs_.req32 = nullptr; fs_.fresh32 = nullptr; fs_.scale = nullptr;
+                if (getenv("CASIM_PACK_PROF_DUMP")) { fs_.prof = (int64_t*)dalloc(8 * 8 * NG); bk_.zero(fs_.prof, 8 * 8 * NG); }
+                fast_npt_ = maxcap <= 64 ? 1 : (maxcap <= 256 ? 4 : 16);
+                fast_r_ = 2;
+            } else if (ok) {
                 // exact division by scale = 2^tz * odd: shift, then multiply by the inverse of `odd` modulo 2^64 (Newton: 5 steps)
                 std::vector<uint64_t> inv((size_t)R); std::vector<int> tz((size_t)R);
                 for (int r = 0; r < R; ++r) {
@@ -611,7 +628,8 @@ public:
         else { ord_in_slab_ = false; dr_.order = (int32_t*)dalloc(4 * ((size_t)nnz_cap_ + 1)); dr_.placed = (int32_t*)dalloc(4 * (size_t)nnz_cap_); }
         dr_.fast_last = (uint8_t*)dalloc(NG);
         if (fast_npt_ > 0) {   // register packer: one record per PEG (casim_types.h) instead of the three arrays
-            dr_.rec_dw = fast_r_ == 2 ? 8 : 16;
+            dr_.rec_dw = (fast_r_ == 2 && !fast_i64_) ? 8 : 16;
+            dr_.rec_i64 = fast_i64_ ? 1 : 0;
             dr_.rec = (uint32_t*)dalloc(4 * ((size_t)nnz_cap_ + 1) * (size_t)dr_.rec_dw);   // + one spare record: the packer loads record k + 1 unconditionally
             dr_.req32 = fs_.req32; dr_.fresh32 = fs_.fresh32;
         }
@@ -706,7 +724,7 @@ public:
         if (fast_npt_ > 0) {
             // register-resident int32 packer: the instantiation (lanes, node slots per lane, exclusion words) is picked by the
             // backend — the product compiles these kernels in their own translation unit (casim_pack_tu.hip)
-            bk_.launch_pack_fast(pack_build_, fast_r_, fast_npt_, fast_wx_, NG_, dt_, dr_, fs_);
+            bk_.launch_pack_fast(pack_build_, fast_i64_ ? 8 : fast_r_, fast_npt_, fast_wx_, NG_, dt_, dr_, fs_);
             if (fs_.prof) {  // profiling builds: mean ticks per phase over the groups
                 std::vector<int64_t> h((size_t)NG_ * 8);
                 bk_.d2h(h.data(), fs_.prof, h.size() * 8); bk_.sync();
@@ -1070,7 +1088,7 @@ public:
     bool uses_strided_lists() const { return strided_; }
     bool pack_in_lds() const { return pack_lds_; }
     int fast_npt() const { return fast_npt_; }
-    int fast_lanes() const { return fast_npt_ > 0 ? fast_r_ : 0; }   // > 0: the register-resident packer handles this batch
+    int fast_lanes() const { return fast_npt_ > 0 ? (fast_i64_ ? 8 : fast_r_) : 0; }   // > 0: the register-resident packer handles this batch (2 / 4 int32 lanes; 8 = two int64 lanes)
     static constexpr int kOrderThreads = 256;
 
 private:
@@ -1151,6 +1169,7 @@ private:
     int32_t nnz_cap_ = 0;
     bool csr_on_device_ = false, pack_lds_ = true, order_lds_ = true, ready_ = false, ran_ = false;
     int fast_wx_ = 0;
+    bool fast_i64_ = false;   // the register store on int64 lanes (lanes that do not narrow to 32 bits, R <= 2)
     bool fast_retry_ = false;
     SingletonRuns runs_;
     std::vector<int32_t> h_off_exp_, h_idx_m_;

@@ -73,7 +73,8 @@ struct DevResults {
     // register packer: ONE record per PEG in processing order instead of the three arrays above (see casim_peg_record
     // below): order_kernel writes it, the packer reads it with one scalar load per PEG
     uint32_t* rec;           // [nnz][rec_dw] or null
-    int32_t rec_dw;          // 8 (R <= 2) or 16 (R <= 4)
+    int32_t rec_dw;          // 8 (R <= 2) or 16 (R <= 4, or the int64 record)
+    int32_t rec_i64;         // 1: 16-dword records of the int64 register store (two int64 requests as they came, no gcd scaling; req32 / fresh32 null)
     const int32_t* req32;    // [G][R]  gcd-scaled requests (FastScratch::req32)
     const int32_t* fresh32;  // [NG][R] gcd-scaled free resources of an empty node (FastScratch::fresh32)
     // optional (casim_options.node_pods): pods per simulated node, group i at node_pods[node_pods_off[i] ..), node bound entries
@@ -93,6 +94,8 @@ struct DevResults {
 //   [0] pods of the PEG
 //   [1] CASIM_PEG_* flags (bits 0-6) | CASIM_REC_SIMPLE | pods of this PEG that fit an EMPTY node << 8 | CASIM_REC_A2_SIMPLE | CASIM_REC_A2_OK | CASIM_KFLAG_STATIC_OK
 //   [2 .. 2+RL) gcd-scaled requests   [2+RL .. 2+3RL) their reciprocals as IEEE doubles (lo, hi), 0.0 for a zero request
+// int64 register store (DevResults::rec_i64, 16 dwords): [0], [1] the same; [2..5] two int64 requests (lo, hi) as the boundary carries them;
+//   [6..9] their reciprocals; [10..15] zero.  CASIM_REC_SIMPLE there means only "both lanes are requested" (no magnitude condition).
 // The fresh-node capacity is < 2^21 by eligibility (casim_pipeline.h: pod slots of an empty node).  Everything the packer
 // would otherwise derive per PEG with scalar compares is a bit here (the kernel is bound by SCALAR issue, r02n PMC):
 #define CASIM_REC_SIMPLE 0x80u            /* every request lane of the record is in (0, 2^30): the branch-free quotient sweep applies */

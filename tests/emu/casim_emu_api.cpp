@@ -37,7 +37,8 @@ struct EmuBackend {
         casim_emu::launch(gx, gy, block, smem, [&]() { kernel(args...); });
     }
     void launch_pack_fast(int /*build: one build under the emulator*/, int lanes, int slots_per_lane, int excl_words, int n_groups, const DevTables& t, const DevResults& res, const FastScratch& fs) {
-#define CASIM_EMU_FAST(R, N, X) launch(casim::pack_fast_kernel<R, N, X>, n_groups, 1, 64, (size_t)0, t, res, fs)
+#define CASIM_EMU_FAST(R, N, X) do { if constexpr ((R) == 8) launch(casim::pack_fast64_kernel<N, X>, n_groups, 1, 64, (size_t)0, t, res, fs); \
+                                     else launch(casim::pack_fast_kernel<((R) == 8 ? 2 : (R)), N, X>, n_groups, 1, 64, (size_t)0, t, res, fs); } while (0)
         CASIM_FAST_DISPATCH(CASIM_EMU_FAST, lanes, slots_per_lane, excl_words);
 #undef CASIM_EMU_FAST
     }
@@ -48,7 +49,7 @@ thread_local std::string g_err;
 #define EMU_API __attribute__((visibility("default")))
 extern "C" {
 
-static int32_t g_last_front = 0;
+static int32_t g_last_front = 0, g_last_lanes = 0;
 EMU_API const char* emu_last_error() { return g_err.c_str(); }
 
 // lds_budget_bytes <= 0 keeps the default (160 KiB); a tiny value forces the HBM-scratch variants.
@@ -67,6 +68,7 @@ EMU_API int32_t emu_estimate_batch(const casim_pegs* pegs, const casim_groups* g
         rc = p.best_option(kinds, n_kinds, group_id_base, &best_out[0], &best_out[1], best_set_out, key_out, nullptr);
     if (rc != CASIM_OK) g_err = p.error();
     g_last_front = p.uses_front() ? 1 : (p.uses_strided_lists() ? 2 : 0);
+    g_last_lanes = p.fast_lanes() * 100 + p.fast_npt();
     return rc;
 }
 
@@ -89,10 +91,13 @@ EMU_API int32_t emu_estimate_batch_query(const casim_pegs* pegs, const casim_gro
     if (rc == CASIM_OK && (nnz_out || offsets_out)) rc = p.csr(nnz_out, offsets_out);
     if (rc != CASIM_OK) g_err = p.error();
     g_last_front = p.uses_front() ? 1 : (p.uses_strided_lists() ? 2 : 0);
+    g_last_lanes = p.fast_lanes() * 100 + p.fast_npt();
     return rc;
 }
 // 1 when the last emu_estimate_batch_query ran feasibility / offsets / lists / order as ONE launch (front_kernel), 2: front_sim_kernel with fixed-stride lists
 EMU_API int32_t emu_last_front() { return g_last_front; }
+// packer of the last emu_estimate_batch(_query): lanes * 100 + node slots per lane (lanes 2 / 4: int32 register store, 8: two int64 lanes, 0: LDS store)
+EMU_API int32_t emu_last_packer() { return g_last_lanes; }
 
 // The batch cut into sub-batches on the lanes of one context (casim_streams.h; the emulator runs the parts one after the other):
 // how casim_options.n_streams cuts the tables and puts the results back together.  parts_out: how many parts ran (1 = not cut).

@@ -150,11 +150,11 @@ def test_packer_self_check_corpus_runs_everything_it_generates_in_time():
     p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     ms_ = re.findall(r"packer self-check: (\d+) batches compared, (\d+) differing, (\d+) not runnable, ([0-9.]+) ms", p.stderr)
-    assert len(ms_) == 12, p.stderr[-2000:]     # (one line per instantiation, cumulative figures)
+    assert len(ms_) == 18, p.stderr[-2000:]     # (one line per instantiation — 2 / 4 int32 lanes, 2 int64 lanes — cumulative figures)
     compared, differing, skipped, ms = int(ms_[-1][0]), int(ms_[-1][1]), int(ms_[-1][2]), float(ms_[-1][3])
     print(f"self-check, eager: {compared} batches, {ms:.1f} ms")
-    assert compared == 186 and differing == 0 and skipped == 0
-    assert ms < 600.0   # (includes the first launches of 24 kernel instantiations: code-object loading, not compute)
+    assert compared == 279 and differing == 0 and skipped == 0
+    assert ms < 900.0   # (includes the first launches of 36 kernel instantiations: code-object loading, not compute)
 
 
 def test_packer_self_check_is_lazy_and_cheap_at_start_up():

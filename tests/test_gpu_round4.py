@@ -81,3 +81,38 @@ def test_winners_only_on_the_device(ctx):
     win = BatchCall(ctx, pegs, groups, kinds=KINDS, n_streams=4, winners_only=True).call()
     assert _same_winners(win, full)
     assert int(win[0].winner_offsets[-1]) * 8 < int(full[0].offsets[-1])      # (an eighth of the lists at most: 20 groups per simulation)
+
+
+def test_int64_register_packer_on_the_device(ctx):
+    """pack_fast64_kernel through the C ABI (the emulator form is tests/test_pack_i64_emu.py): forced on fuzz scenarios against the oracle,
+    selected by itself for byte-granular co-prime amounts (problem_info [1] == 8), amounts beyond 2^53, and the headline batch bit-equal to
+    the int32 store, resident and streamed."""
+    from harness import GroupSpec, Scenario, run_gpu_tables
+    from test_gpu_round3 import KINDS, _c2_batch, _same
+    from test_pack_i64_emu import shape_scenario
+    import test_kernels_emu_fuzz as F
+    from kubernetes_autoscaler_amd.engine import Problem
+    on64 = 0
+    for seed in range(40):
+        sc = F.scenario_of(workloads.fuzz(seed, rich=seed % 3 == 0))
+        enc = encode(sc)
+        with Problem(ctx, enc.pegs, enc.groups, False, 2) as p:
+            on64 += p.info()["fast_packer_lanes"] == 8
+            p.run(); res = p.fetch()
+        enc.close()
+        assert_matches_oracle(res, run_oracle(sc), f"forced int64 store, seed {seed}")
+    assert on64 >= 20
+    for seed in range(30):
+        sc = shape_scenario(seed, 1 << 20, 1024) if seed % 3 else shape_scenario(seed, 1 << 40, 1 << 9)
+        enc = encode(sc)
+        with Problem(ctx, enc.pegs, enc.groups) as p:
+            assert p.info()["fast_packer_lanes"] == 8, seed
+            p.run(); res = p.fetch()
+        enc.close()
+        assert_matches_oracle(res, run_oracle(sc), f"wide lanes, seed {seed}")
+    ts = _c2_batch(6, 16)
+    base, bexp = run_gpu_tables(ts, ctx, kinds=KINDS)
+    for k in (0, 4):
+        res, exp = run_gpu_tables(ts, ctx, kinds=KINDS, n_streams=k, generic=2)
+        _same(res, base, f"int64 register store, n_streams {k}")
+        assert list(exp["best"]) == list(bexp["best"]) and list(exp["packed"]) == list(bexp["packed"])

@@ -33,7 +33,7 @@ def main():
         for seed in range(cnt):
             sc = scen(workloads.fuzz(base + seed, **kw), fast, dcsr)
             enc = encode(sc)
-            for generic in (False, True):
+            for generic in (False, True, 2):     # register store on int32 lanes, LDS store, register store on int64 lanes
                 res, _ = run_gpu(enc, ctx, fastpath=fast, generic=generic)
                 feed(res)
             enc.close()
