@@ -10,5 +10,4 @@ from . import _abi  # noqa: F401
 from ._ffi import CasimError, NoDeviceError, LIB_PATH  # noqa: F401
 from .objects import *  # noqa: F401,F403
 from .encoder import Encoder  # noqa: F401
-from .engine import BatchResult, Context, MultiContext, PrefetchCache, Problem, ResidentCluster, device_count, estimate_batch  # noqa: F401
-from .streams import StreamedBatch  # noqa: F401
+from .engine import BatchResult, Context, MultiContext, PrefetchCache, Problem, ResidentCluster, StreamedBatch, device_count, estimate_batch  # noqa: F401

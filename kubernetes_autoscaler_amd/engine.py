@@ -688,3 +688,36 @@ class PrefetchCache:
         out = (C.c_int64 * 8)()
         lib.casim_prefetch_stats(self._h, out)
         return {"fills": out[0], "groups_cached": out[1], "hits": out[2], "miss_group": out[3], "miss_pegs": out[4], "miss_limits": out[5]}
+
+
+class StreamedBatch:
+    """One casim context on `device` (on `stream`, a raw hipStream_t handle, when given) and one streamed casim_problem: a TableSet of
+    independent simulations whose parts run on the context's internal streams (casim_options.n_streams, csrc/casim_streams.h)."""
+
+    def __init__(self, device: int, tables, n_streams: int = 4, stream: Optional[int] = None, **problem_kw):
+        self.tables = tables if tables.peg_lo is not None else tables.as_one_simulation()
+        self.n_sims = self.tables.n_sims
+        self.ctx = Context(device, stream=stream)
+        self._structs = self.tables.structs()
+        self.prob = Problem(self.ctx, *self._structs, n_streams=n_streams, **problem_kw)
+        self.parts = self.prob.info()["parts"]
+
+    def close(self):
+        if self.prob is not None:
+            self.prob.close(); self.ctx.close()
+            self.prob = self.ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def run(self):
+        self.prob.run()
+
+    def best_option_sims(self, kinds: Sequence[int], dev_packed_ptr: Optional[int] = None, fetch: bool = True, join_stream: Optional[int] = None):
+        return self.prob.best_option_sims(kinds, per_sim=True, fetch=fetch, dev_packed_ptr=dev_packed_ptr, n_sims=self.n_sims, join_stream=join_stream)
+
+    def fetch(self) -> BatchResult:
+        return self.prob.fetch()
