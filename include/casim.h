@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CASIM_ABI_VERSION 7   /* 2: casim_removal_candidates.cand_atomic, casim_domain_rules.n_taint_policy_rules
+#define CASIM_ABI_VERSION 8   /* 2: casim_removal_candidates.cand_atomic, casim_domain_rules.n_taint_policy_rules
                                * 3: casim_groups.{peg_lo,peg_hi,global_id,n_sims,sim_offsets}, casim_best_option_sims,
                                *    casim_feasibility_reasons, casim_estimate_batch_timed, casim_mctx_*, casim_cluster_*
                                * 4: casim_options.n_streams (sub-batches on internal HIP streams), casim_enc_group_pods,
@@ -42,7 +42,8 @@ extern "C" {
                                * 6: casim_pegs.zone_polarity (group bits of NEED polarity: required pod affinity towards a partner of the batch);
                                *    later, without a new number (layouts unchanged, zero keeps its meaning): casim_options.no_front_kernel in one of
                                *    the two reserved words, casim_problem_info [7]
-                               * 7: casim_cluster_forget_commits, casim_options.winners_only (the last reserved word) */
+                               * 7: casim_cluster_forget_commits, casim_options.winners_only (the last reserved word)
+                               * 8: casim_pegs.excl_polarity (node bits of NEED polarity: hostname-level required pod affinity inside casim_estimate_batch) */
 
 /* Resource lanes.  Lane 0 = cpu in millicores (Quantity.MilliValue), lane 1 = memory bytes,
  * lane 2 = ephemeral-storage bytes, lanes 3.. = scalar / extended resources (Quantity.Value),
@@ -112,6 +113,12 @@ typedef struct casim_pegs {
                                  bit is forbidden in the group while the bit is CLEAR (required pod affinity on a non-hostname key:
                                  "a pod matching all my terms sits in this domain" — interpodaffinity/filtering.go:382-409), a
                                  plain bit forbids it while SET (anti-affinity).  Marks set bits of either kind. (ABI 6) */
+    const uint64_t* excl_polarity; /* [w_excl] or NULL (= all zero): NODE bits of NEED polarity (ABI 8) — required pod affinity on
+                                 kubernetes.io/hostname: a PEG whose excl_block holds such a bit fits a node only while the bit is SET there
+                                 ("a pod matching all my terms sits on this node"); every partner marks it.  A PEG that both needs and marks
+                                 such a bit is a self-affine SERIES: while no simulated node of the group carries the bit (and the template's
+                                 own pods do not), its first pod passes without it (the first-pod exception, filtering.go:396-407) and the
+                                 rest of the PEG then has to join that pod's node. */
 } casim_pegs;
 
 /*

@@ -3,7 +3,7 @@ shared library happens in _ffi.py).  Kept separate so that test harnesses that c
 structs can reuse the layouts without loading the product library."""
 import ctypes as C
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_RES = 8
 
 OK = 0
@@ -49,7 +49,7 @@ class Pegs(C.Structure):
         ("req", i64p), ("count", i32p), ("flags", u32p),
         ("tol_mask", u64p), ("sel_mask", u64p), ("excl_block", u64p), ("excl_mark", u64p),
         ("zone_block", u64p), ("zone_mark", u64p), ("fp_cpu", f64p), ("fp_mem", f64p),
-        ("zone_polarity", u64p),
+        ("zone_polarity", u64p), ("excl_polarity", u64p),
     ]
 
 

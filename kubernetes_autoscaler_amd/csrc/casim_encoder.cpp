@@ -294,7 +294,7 @@ struct casim_encoder {
     std::vector<int64_t> req, alloc, init_req, waste_cpu, waste_mem;
     std::vector<int32_t> count, allowed, init_pods, max_nodes, existing_nodes, last_index, peg_off, peg_idx;
     std::vector<uint32_t> pflags, gflags;
-    std::vector<uint64_t> tol, sel, xblock, xmark, zblock, zmark, zpol, taint, label, init_excl, init_zone, zone_valid, xports;
+    std::vector<uint64_t> tol, sel, xblock, xmark, zblock, zmark, zpol, xpol, taint, label, init_excl, init_zone, zone_valid, xports;
     std::vector<double> fp_cpu, fp_mem, cap_cpu, cap_mem;
     int dict[4] = {0, 0, 0, 0};
     // domain rules (per-node mode)
@@ -981,10 +981,17 @@ int32_t casim_enc_finalize(casim_encoder* e) {
     //     partner marks it, it starts set in the groups of the two cases above.  (SchedulablePodGroups never lists such a PEG: its
     //     sample pod fails on a fresh template node — K_feas says the same through the same bit; a caller's own list may.)
     //     Without a partner in the batch: never;
-    //   * a hostname term that is not satisfied by the template's preloaded pods   -> the partner has to sit on the SAME node (and
-    //     a series that got in by the exception has to join its first pod's node): DYNAMIC per node, estimated on the snapshot
-    //     (casim_estimate_on_cluster) — unless nobody in the batch can be the partner and no exception holds: never.
+    //   * a hostname term that is not satisfied by the template's preloaded pods   -> the partner has to sit on the SAME node: a NODE
+    //     bit of NEED polarity (casim_pegs.excl_polarity, ABI 8) — the PEG fits a node only while the bit is set there, every partner of
+    //     the batch marks it, fresh nodes of a group whose template carries a partner start with it.  When the PEG matches its own terms
+    //     and no matching pod exists in the cluster it marks the bit ITSELF: the packer then lets its first pod in by the exception while
+    //     no node of the estimate carries the bit and makes the rest of the PEG join that pod's node (casim_pack.h, the series).
+    //     Nobody in the batch who could be the partner and no exception: never.  (Round 3 sent this case to casim_estimate_on_cluster.)
     std::vector<uint8_t> aff_static(G, 0);
+    std::vector<int> host_need_bit(G, -1);               // node bit of NEED polarity that blocks PEG i
+    std::vector<std::vector<int>> host_marks(G);         // node bits of NEED polarity PEG j sets (it is a partner of their owners)
+    std::vector<std::pair<uint32_t, int>> excl_preset;   // (group, bit): every fresh node of the group carries it
+    std::vector<int> xneed_bits;
     std::vector<int> need_bits;   // group bits of NEED polarity
     std::vector<std::pair<uint32_t, int>> zone_preset;   // (group, bit): set from the start
     if (!per_node) {
@@ -1007,8 +1014,9 @@ int32_t casim_enc_finalize(casim_encoder* e) {
                 if (!matches_all(a, e->specs[(size_t)x.spec])) continue;
                 for (auto& t : a.aff) if (x.node_labels.count(t.topology_key)) { anywhere_cluster = true; break; }
             }
-            std::vector<uint32_t> never, waits;
-            bool dynamic = false;
+            std::vector<uint32_t> never, waits, sat_groups;
+            bool dynamic = false, other_partner = false;
+            for (size_t j : partners) other_partner = other_partner || j != i;
             for (size_t gi = 0; gi < NG; ++gi) {
                 const Group& g = e->groups[gi];
                 bool keys = true;
@@ -1029,13 +1037,20 @@ int32_t casim_enc_finalize(casim_encoder* e) {
                     }
                     if (!found) { sat = false; break; }
                 }
-                if (sat) continue;                                         // no-op for the whole Estimate
+                if (sat) { sat_groups.push_back((uint32_t)gi); continue; }  // no-op for the whole Estimate
                 const bool exception = self && !anywhere_cluster && !pre;
-                if (host) { if (exception || !partners.empty()) dynamic = true; else never.push_back((uint32_t)gi); continue; }
+                // (a PEG that is its own only partner cannot start a series without the exception: nobody ever sets its bit)
+                if (host) { if (exception || other_partner) dynamic = true; else never.push_back((uint32_t)gi); continue; }
                 if (exception) continue;                                    // no-op: the first pod passes, the rest finds it
                 if (partners.empty()) never.push_back((uint32_t)gi); else waits.push_back((uint32_t)gi);
             }
-            if (dynamic) continue;   // (flagged below: estimated on the snapshot)
+            if (dynamic) {
+                const int b = xbits.next();
+                host_need_bit[i] = b; xneed_bits.push_back(b);
+                const bool starts_itself = self && !anywhere_cluster;   // the first-pod exception can hold: the PEG marks its own bit
+                for (size_t j : partners) if (j != i || starts_itself) host_marks[j].push_back(b);
+                for (uint32_t gi : sat_groups) excl_preset.emplace_back(gi, b);
+            }
             aff_static[i] = 1;
             for (uint32_t gi : never) if (std::find(existing_block[i].begin(), existing_block[i].end(), gi) == existing_block[i].end()) existing_block[i].push_back(gi);
             if (!existing_block[i].empty() && static_zbit[i] < 0) { static_zbit[i] = zbits.next(); zbit_key[static_zbit[i]] = ""; z_block[i].push_back(static_zbit[i]); }
@@ -1051,6 +1066,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         }
     }
     e->Wz = zbits.words();
+    e->Wx = xbits.words();   // ((4a) may have added node bits of NEED polarity)
 
     stage.mark("affinity_static");
     // (4b) per-node mode: domain rules (include/casim.h, casim_domain_rules) for PodTopologySpread and for required
@@ -1290,6 +1306,8 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         if (has_port) f |= CASIM_PEG_SELF_EXCL_NODE;
         if (peg_occ_bit[i] >= 0) set_bit(e->xmark, i, Wx, peg_occ_bit[i]);
         for (int b : peg_blockers[i]) set_bit(e->xblock, i, Wx, b);
+        if (host_need_bit[i] >= 0) set_bit(e->xblock, i, Wx, host_need_bit[i]);
+        for (int b : host_marks[i]) set_bit(e->xmark, i, Wx, b);
         for (int b : z_block[i]) set_bit(e->zblock, i, Wz, b);
         for (int b : z_mark[i]) set_bit(e->zmark, i, Wz, b);
         // fastpath eligibility: no topology spread (unsupported anyway) and no non-hostname anti-affinity
@@ -1348,6 +1366,9 @@ int32_t casim_enc_finalize(casim_encoder* e) {
     const bool any_explicit = explicit_in_slice[0] || explicit_in_slice[1] || explicit_in_slice[2] || explicit_in_slice[3];
     for (size_t i = 0; i < G; ++i) for (uint32_t gi : existing_block[i]) set_bit(e->init_zone, gi, Wz, static_zbit[i]);
     for (auto& pr : zone_preset) set_bit(e->init_zone, pr.first, Wz, pr.second);
+    for (auto& pr : excl_preset) set_bit(e->init_excl, pr.first, Wx, pr.second);
+    e->xpol.assign((size_t)Wx, 0ull);
+    for (int b : xneed_bits) e->xpol[(size_t)(b >> 6)] |= 1ull << (b & 63);
     e->zpol.assign((size_t)Wz, 0ull);
     for (int b : need_bits) e->zpol[(size_t)(b >> 6)] |= 1ull << (b & 63);
     e->peg_off.clear(); e->peg_idx.clear();
@@ -1603,6 +1624,7 @@ int32_t casim_enc_tables(const casim_encoder* e, casim_pegs* p, casim_groups* g)
     p->excl_block = e->xblock.data(); p->excl_mark = e->xmark.data();
     p->zone_block = e->zblock.data(); p->zone_mark = e->zmark.data();
     p->zone_polarity = e->zpol.empty() ? nullptr : e->zpol.data();
+    p->excl_polarity = e->xpol.empty() ? nullptr : e->xpol.data();
     p->fp_cpu = e->fp_cpu.data(); p->fp_mem = e->fp_mem.data();
     g->n_groups = (int32_t)e->groups.size();
     g->alloc = e->alloc.data(); g->init_req = e->init_req.data(); g->allowed_pods = e->allowed.data(); g->init_pods = e->init_pods.data();

@@ -97,8 +97,13 @@ CS_DEVICE bool fits_fresh_node(const DevTables& t, int g, int ng) {
     if (capacity_of(fr, 1, slots, t.R, t.req + (int64_t)g * t.R, 1u) == 0) return false;
     const uint64_t* xb = t.xblock + (int64_t)g * t.Wx;
     const uint64_t* ix = t.init_excl + (int64_t)ng * t.Wx;
-    for (int w = 0; w < t.Wx; ++w)
-        if (xb[w] & ix[w]) return false;
+    for (int w = 0; w < t.Wx; ++w) {
+        // (NEED bits, casim_pegs.excl_polarity: forbidden while clear — except the ones the PEG marks itself: at snapshot time its first pod
+        // passes by the first-pod exception, the encoder only builds such a series when no partner exists anywhere)
+        const uint64_t pol = t.xpol ? t.xpol[w] : 0ull;
+        const uint64_t b = xb[w] & ~(t.xmark[(int64_t)g * t.Wx + w] & pol);
+        if ((b & ix[w]) != (b & pol)) return false;
+    }
     const uint64_t* zb = t.zblock + (int64_t)g * t.Wz;
     const uint64_t* iz = t.init_zone + (int64_t)ng * t.Wz;
     for (int w = 0; w < t.Wz; ++w)
@@ -145,7 +150,7 @@ CS_GLOBAL void feas_sim_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg
         uint64_t v = 0;
         if (f == 0) v = t.Wt ? t.taint[(int64_t)ng * t.Wt] : 0ull;
         else if (f == 1) v = t.Wl ? t.label[(int64_t)ng * t.Wl] : ~0ull;
-        else if (f == 2) v = t.Wx ? t.init_excl[(int64_t)ng * t.Wx] : 0ull;
+        else if (f == 2) v = t.Wx ? (t.init_excl[(int64_t)ng * t.Wx] ^ (t.xpol ? t.xpol[0] : 0ull)) : 0ull;   // (NEED bits inverted once, like the group-wide word)
         else if (f == 3) v = t.Wz ? (t.init_zone[(int64_t)ng * t.Wz] ^ t.zpol[0]) : 0ull;   // (NEED bits inverted once: the cell test stays one AND)
         else if (f == 4) v = (uint64_t)t.gflags[ng] | ((uint64_t)(uint32_t)(t.allowed[ng] - t.init_pods[ng]) << 32);
         else if (f == 5 || f == 6) {
@@ -169,7 +174,8 @@ CS_GLOBAL void feas_sim_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg
     }
     const uint32_t pf = live ? t.pflags[g] : 0u;
     const uint64_t tol = (live && t.Wt) ? t.tol[(int64_t)g * t.Wt] : 0ull, sel = (live && t.Wl) ? t.sel[(int64_t)g * t.Wl] : 0ull;
-    const uint64_t xb = (live && t.Wx) ? t.xblock[(int64_t)g * t.Wx] : 0ull, zb = (live && t.Wz) ? t.zblock[(int64_t)g * t.Wz] : 0ull;
+    // (a NEED bit the PEG marks itself does not count on a fresh node: fits_fresh_node)
+    const uint64_t xb = (live && t.Wx) ? (t.xblock[(int64_t)g * t.Wx] & ~(t.xmark[(int64_t)g * t.Wx] & (t.xpol ? t.xpol[0] : 0ull))) : 0ull, zb = (live && t.Wz) ? t.zblock[(int64_t)g * t.Wz] : 0ull;
     cs::sync();
     // (branch-free: every test is evaluated and the verdicts are ANDed as lane masks — written with && the compiler built an
     // exec-mask region per test, ~85 scalar instructions per group, 12 % of all scalar instructions of a batch step)
@@ -213,7 +219,9 @@ CS_DEVICE uint32_t fresh_node_verdict(const DevTables& t, const uint64_t* CS_RES
     const uint64_t* ix = t.init_excl + (int64_t)ng * t.Wx;
     bool other_excl = false;
     for (int w = 0; w < t.Wx; ++w) {
-        const uint64_t hit = xb[w] & ix[w];
+        const uint64_t pol = t.xpol ? t.xpol[w] : 0ull;
+        const uint64_t b = xb[w] & ~(t.xmark[(int64_t)g * t.Wx + w] & pol);
+        const uint64_t hit = (b & ix[w]) ^ (b & pol);   // a plain bit that is set, a NEED bit (required pod affinity on the hostname) that is clear
         if (port_block && (hit & port_block[(int64_t)g * t.Wx + w])) return CASIM_PLUGIN_NODE_PORTS;
         other_excl = other_excl || hit != 0;
     }
@@ -759,7 +767,7 @@ CS_GLOBAL void front_sim_kernel(DevTables t, DevResults res, OrderScratch os, ui
         uint64_t v = 0;
         if (f == 0) v = t.Wt ? t.taint[(int64_t)ng * t.Wt] : 0ull;
         else if (f == 1) v = t.Wl ? t.label[(int64_t)ng * t.Wl] : ~0ull;
-        else if (f == 2) v = t.Wx ? t.init_excl[(int64_t)ng * t.Wx] : 0ull;
+        else if (f == 2) v = t.Wx ? (t.init_excl[(int64_t)ng * t.Wx] ^ (t.xpol ? t.xpol[0] : 0ull)) : 0ull;   // (NEED bits inverted once, like the group-wide word)
         else if (f == 3) v = t.Wz ? (t.init_zone[(int64_t)ng * t.Wz] ^ t.zpol[0]) : 0ull;
         else if (f == 4) v = (uint64_t)t.gflags[ng] | ((uint64_t)(uint32_t)(t.allowed[ng] - t.init_pods[ng]) << 32);
         else if (f == 5 || f == 6) {
@@ -782,7 +790,8 @@ CS_GLOBAL void front_sim_kernel(DevTables t, DevResults res, OrderScratch os, ui
     }
     const uint32_t pf = live ? t.pflags[g] : 0u;
     const uint64_t tol = (live && t.Wt) ? t.tol[(int64_t)g * t.Wt] : 0ull, sel = (live && t.Wl) ? t.sel[(int64_t)g * t.Wl] : 0ull;
-    const uint64_t xb = (live && t.Wx) ? t.xblock[(int64_t)g * t.Wx] : 0ull, zb = (live && t.Wz) ? t.zblock[(int64_t)g * t.Wz] : 0ull;
+    // (a NEED bit the PEG marks itself does not count on a fresh node: fits_fresh_node)
+    const uint64_t xb = (live && t.Wx) ? (t.xblock[(int64_t)g * t.Wx] & ~(t.xmark[(int64_t)g * t.Wx] & (t.xpol ? t.xpol[0] : 0ull))) : 0ull, zb = (live && t.Wz) ? t.zblock[(int64_t)g * t.Wz] : 0ull;
     cs::sync();
     const bool tolerates_unsched = (pf & CASIM_PEG_TOLERATES_UNSCHEDULABLE) != 0;
     for (int gl = 0; gl < ngroups; ++gl) {

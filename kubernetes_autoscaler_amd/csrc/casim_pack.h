@@ -73,6 +73,18 @@ struct PegView {
     const uint64_t* xblock;
     const uint64_t* xmark;
     uint64_t xb[2], xm[2];  // first words of each, cached for the register store (up to two exclusion words)
+    // node bits of NEED polarity (casim_pegs.excl_polarity: hostname-level required pod affinity): a node is blocked when
+    // (state & block) != need, need = block & polarity — a plain bit forbids while set, a NEED bit while clear.  `waive`: the first pod of a
+    // self-affine series enters by the first-pod exception, the NEED bits it marks itself do not count (block & mark & polarity dropped).
+    uint64_t xp[2] = {0, 0};          // need words of xb (register store)
+    const uint64_t* xpol = nullptr;   // [Wx] polarity words or null (memory store: need computed per word)
+    bool waive = false;
+    CS_DEVICE uint64_t block_word(int w) const {
+        uint64_t b = xblock[w];
+        if (xpol && waive) b &= ~(xmark[w] & xpol[w]);
+        return b;
+    }
+    CS_DEVICE uint64_t need_word(int w) const { return xpol ? (block_word(w) & xpol[w]) : 0ull; }
 };
 template <class L, int RMAX>
 struct FreshNode {
@@ -162,7 +174,7 @@ struct MemStore {
 
     CS_DEVICE uint32_t capacity(int, int m, const Peg& pv, uint32_t clampk, bool selfx) const {
         for (int w = 0; w < Wx; ++w)
-            if (sexcl[(int64_t)w * cap + m] & pv.xblock[w]) return 0;  // NodePorts / hostname anti-affinity
+            if ((sexcl[(int64_t)w * cap + m] & pv.block_word(w)) != pv.need_word(w)) return 0;  // NodePorts / hostname anti-affinity / a missing partner (NEED bits)
         Lane fr[RMAX_];
 #pragma unroll
         for (int r = 0; r < RMAX_; ++r) fr[r] = r < R ? sfree[(int64_t)r * cap + m] : 0;
@@ -180,6 +192,14 @@ struct MemStore {
         for (int w = 0; w < Wx; ++w) sexcl[(int64_t)w * cap + m] |= pv.xmark[w];
     }
     CS_DEVICE void commit_any(int, uint32_t, const Peg&) {}   // (register stores only)
+    // some simulated node m < M carries one of the PEG's own NEED bits (block & mark & polarity): a partner of the series is placed already
+    CS_DEVICE bool any_node_has_own_need(const Peg& pv, int M) const {
+        bool any = false;
+        const int lane = cs::lane();
+        for (int m = lane; m < M; m += 64)
+            for (int w = 0; w < Wx; ++w) any = any || (sexcl[(int64_t)w * cap + m] & pv.xblock[w] & pv.xmark[w] & pv.xpol[w]) != 0;
+        return cs::ballot(any) != 0;
+    }
     CS_DEVICE void create(int, int m, uint32_t x, const Peg& pv, const Fresh& fn) {
 #pragma unroll
         for (int r = 0; r < RMAX_; ++r) if (r < R) sfree[(int64_t)r * cap + m] = fn.free[r] - (int64_t)x * pv.req[r];
@@ -221,8 +241,17 @@ struct RegStore {
     CS_DEVICE bool blocked(int s, const Peg& pv) const {
         bool b = false;
 #pragma unroll
-        for (int w = 0; w < WX_; ++w) b = b || (excl[s][w] & pv.xb[w]) != 0;
+        for (int w = 0; w < WX_; ++w) b = b || (excl[s][w] & pv.xb[w]) != pv.xp[w];   // (NEED bits: blocked while clear)
         return b;
+    }
+    // some simulated node carries one of the PEG's own NEED bits (slots past M hold zeros)
+    CS_DEVICE bool any_node_has_own_need(const Peg& pv, int) const {
+        bool any = false;
+#pragma unroll
+        for (int s = 0; s < NPT_; ++s)
+#pragma unroll
+            for (int w = 0; w < WX_; ++w) any = any || (w < wx && (excl[s][w] & pv.xblock[w] & pv.xmark[w] & pv.xpol[w]) != 0);
+        return cs::ballot(any) != 0;
     }
     int32_t slots[NPT_];
     int32_t fresh_slots;  // pod slots of an empty node: pods on a node = fresh_slots - slots (no per-node counter)
@@ -492,6 +521,9 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     int32_t more_mask = -1;
     int32_t fakes = 0;                     // fastpath fake nodes
     int32_t total_placed = 0;
+    // self-affine hostname series (casim_pegs.excl_polarity): 1 = the record is being walked a second time (see peg_step)
+    int series_phase = 0;
+    bool series_skip_a2 = false, series_repeat = false;
     // register store of 16 slots per lane only: the group may ask for more than its 1024 node slots (its BOUND — limiter cap or
     // pods — exceeds them; most such groups never get there: BenchmarkRunOnceScaleUp is bound by 10 000 and creates 200).  The
     // step that would create node 1025 stops node creation and marks the group for the generic packer's retry launch.
@@ -602,6 +634,8 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
         {
             int32_t cnt; uint32_t pf, cf_rec = 0;
             typename Store::Peg pv;
+            int32_t series_carry = 0, series_cnt = 0;   // pods of the record placed by pass 0 / pods of the whole record
+            bool series_first = false;                  // this is pass 0 of a series
             if constexpr (kRecScalar) {
                 cnt = (int32_t)cur.w[0];
                 pf = cur.w[1];
@@ -642,9 +676,29 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 if constexpr (kRecScalar) g = g_cur; else g = (int)cs::bcast_u32((uint32_t)my_g, j);
                 pv.xblock = t.xblock + (int64_t)g * Wx; pv.xmark = t.xmark + (int64_t)g * Wx;
                 zblock = t.zblock + (int64_t)g * Wz; zmark = t.zmark + (int64_t)g * Wz;
+                if constexpr (Store::kHasExcl) {
+                    if (Wx > 0) {
+                        pv.xpol = t.xpol;
+                        // A PEG that needs a NEED bit it marks itself: a self-affine series on the hostname key (casim_pegs.excl_polarity).
+                        // While no simulated node carries the bit and a fresh node would not either, NO matching pod exists anywhere (the
+                        // encoder only builds the series when the cluster holds none): the first pod passes without it (filtering.go:396-407)
+                        // — every pod of the PEG would, one by one, but the moment one is placed the rest has to join ITS node.  So the
+                        // record is walked twice: pass 0 places ONE pod with the bits waived, pass 1 the other cnt - 1 with the bits in force.
+                        uint64_t own = 0;
+                        for (int w = 0; w < Wx; ++w) own |= pv.xblock[w] & pv.xmark[w] & t.xpol[w];
+                        if (own != 0) {   // wave-uniform, rare
+                            if (series_phase == 1) { series_carry = 1; cnt -= 1; }
+                            else {
+                                bool partner = st.any_node_has_own_need(pv, M);
+                                for (int w = 0; w < Wx; ++w) partner = partner || (fn.excl[w] & pv.xblock[w] & pv.xmark[w] & t.xpol[w]) != 0;
+                                if (!partner) { series_first = true; series_cnt = cnt; cnt = cnt > 0 ? 1 : 0; pv.waive = true; }
+                            }
+                        }
+                    }
+                }
                 if (Store::kNPT > 0 && Wx > 0) {   // register store: the words travel in SGPRs
-                    pv.xb[0] = pv.xblock[0]; pv.xm[0] = pv.xmark[0];
-                    if (Wx > 1) { pv.xb[1] = pv.xblock[1]; pv.xm[1] = pv.xmark[1]; }
+                    pv.xb[0] = pv.block_word(0); pv.xm[0] = pv.xmark[0]; pv.xp[0] = pv.need_word(0);
+                    if (Wx > 1) { pv.xb[1] = pv.block_word(1); pv.xm[1] = pv.xmark[1]; pv.xp[1] = pv.need_word(1); }
                 }
             }
             bool zblocked = Wz > 0 && zone_blocked(zblock);
@@ -673,6 +727,15 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 else a2_go = (pf & CASIM_REC_A2_OK) != 0;   // (the dry loop only runs with the gate open: one bit test)
             }
             else a2_go = M > 0 && keff > 0 && static_ok && !group_unschedulable;
+            if constexpr (Store::kHasExcl) {
+                // (pass 1 of a series whose first pod opened a NEW node: the reference tried the existing nodes for every pod of the PEG before it
+                // added that node — tryToScheduleOnExistingNodes runs first, binpacking_estimator.go:136-141 — so the rest reaches it by name, the
+                // next-fit on the newest node below, and lastIndex stays where it was)
+                if (series_phase == 1 && series_skip_a2) a2_go = false;
+                // (a series that also excludes itself per node — a host port: the only node with the bit holds its first pod, which is not
+                // remembered by a node bit: nothing more fits anywhere, a3 below still opens the node the reference opens in vain)
+                if (series_phase == 1 && selfx) { a2_go = false; on_last = 1u; }
+            }
             if (a2_go && !zblocked) {
                 // register stores of up to 4 slots walk all of them: slots past M hold zero state (c_j = 0, never a
                 // candidate, nothing committed), and a constant bound drops one scalar compare + branch per slot and pass
@@ -710,7 +773,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     last_index = new_last;
                     if (Wz > 0) zone_mark(zmark);
                     if constexpr (kDry) {   // placed > 0 here; the tail of the step does not run
-                        uint32_t mp = (uint32_t)my_placed; cs::write_lane_u32(mp, (uint32_t)placed, j); my_placed = (int32_t)mp;
+                        uint32_t mp = (uint32_t)my_placed; cs::write_lane_u32(mp, (uint32_t)(placed + series_carry), j); my_placed = (int32_t)mp;
                         total_placed += placed;
                         add_totals(placed, pv.req[0], RM > 1 ? pv.req[1] : (L)0);
                     }
@@ -842,8 +905,14 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             }
 
             CASIM_PROF(4);  // a2 passes B + C (rotated rank, commit)
+            const int32_t placed_a2 = placed;
             // ---- a3 / a4: tryToScheduleOnNewNodes (:190-269) or tryFastPath (:274-324) ----
             int32_t rem = cnt - placed;
+            if constexpr (Store::kHasExcl && !kDry) {
+                // tryFastPath of a series whose first pod fitted no simulated node (then none of its pods did): the one node it simulates takes
+                // the first pod by the exception and every later one finds it there — the whole PEG behaves like one without the bits
+                if (series_first && placed == 0 && k == fast_k) { series_first = false; cnt = series_cnt; rem = cnt; }
+            }
             if (!kDry && (rem & more_mask) > 0) {   // pods left && newNodesAvailable
                 zblocked = Wz > 0 && zone_blocked(zblock);
                 // "no node of this group takes the PEG": the template-level Filters fail (CASIM_KFLAG_STATIC_OK clear — tested as a bit
@@ -854,7 +923,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 uint32_t cfresh = 0;
                 {
                     bool xb = false;
-                    for (int w = 0; w < Wx; ++w) xb |= (fn.excl[w] & pv.xblock[w]) != 0;
+                    for (int w = 0; w < Wx; ++w) xb |= (fn.excl[w] & pv.block_word(w)) != pv.need_word(w);   // (a NEED bit the template's own pods do not set: no partner on a fresh node)
                     if (!xb) {
                         uint32_t cf;
                         if constexpr (kRecScalar) cf = cf_rec; else cf = cs::bcast_u32(my_cf, j);
@@ -986,16 +1055,24 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             CASIM_PROF(5);  // a3 / a4
             if constexpr (!kDry) {   // (kDry: a2 recorded what it placed, nothing else can place)
                 if constexpr (kRecScalar) {
-                    uint32_t mp = (uint32_t)my_placed; cs::write_lane_u32(mp, (uint32_t)placed, j); my_placed = (int32_t)mp;
+                    uint32_t mp = (uint32_t)my_placed; cs::write_lane_u32(mp, (uint32_t)(placed + series_carry), j); my_placed = (int32_t)mp;
                     add_totals(placed, pv.req[0], RM > 1 ? pv.req[1] : (L)0);
-                } else { if (lane == j) my_placed = placed; }
+                } else { if (lane == j) my_placed = placed + series_carry; }
                 total_placed += placed;
+            }
+            if constexpr (Store::kHasExcl) {
+                // pass 0 of a series placed its pod and the record holds more: the same record again, NEED bits in force
+                series_repeat = series_first && placed == 1 && series_cnt > 1;
+                series_skip_a2 = placed_a2 == 0;
+                series_phase = series_repeat ? 1 : 0;
             }
         }
         if constexpr (kRecScalar) {   // record k + 1 into the registers record k just left (in flight across the loop edge)
-            roff += kRecBytes;
-            cur = cs::rec_load<DW>(rbase, roff);
-            if (kNeedG) g_cur = (int32_t)cs::const_load<1>((const uint32_t*)res.order + off + k + 1).w[0];
+            if (!(Store::kHasExcl && series_repeat)) {
+                roff += kRecBytes;
+                cur = cs::rec_load<DW>(rbase, roff);
+                if (kNeedG) g_cur = (int32_t)cs::const_load<1>((const uint32_t*)res.order + off + k + 1).w[0];
+            }
         }
     };
     {
@@ -1029,7 +1106,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 }
             }
         } else {
-            for (int k = 0; k < Gn; ++k) peg_step(k, CsFalse{});
+            for (int k = 0; k < Gn;) { peg_step(k, CsFalse{}); if (!series_repeat) ++k; }
         }
     }
     if constexpr (kRecScalar) {

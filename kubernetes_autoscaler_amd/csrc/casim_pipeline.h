@@ -270,6 +270,9 @@ public:
         zpol_host_.assign((size_t)dt_.Wz, 0ull);   // (the kernels always read Wz polarity words: zeros when the caller passed none)
         if (p->zone_polarity) for (int w = 0; w < dt_.Wz; ++w) zpol_host_[(size_t)w] = p->zone_polarity[w];
         dt_.zpol = up(zpol_host_.data(), (size_t)dt_.Wz);
+        xpol_host_.assign((size_t)dt_.Wx, 0ull);
+        if (p->excl_polarity) for (int w = 0; w < dt_.Wx; ++w) xpol_host_[(size_t)w] = p->excl_polarity[w];
+        dt_.xpol = up(xpol_host_.data(), (size_t)dt_.Wx);
         // (the fastpath chooser's columns only travel when the fastpath is on: 16 bytes per PEG, a quarter of a C2 batch's upload)
         dt_.fp_cpu = (dt_.fastpath && p->fp_cpu) ? up(p->fp_cpu, G) : nullptr; dt_.fp_mem = (dt_.fastpath && p->fp_mem) ? up(p->fp_mem, G) : nullptr;
         dt_.alloc = up(g->alloc, NG * R); dt_.init_req = up(g->init_req, NG * R);
@@ -1197,7 +1200,7 @@ private:
     std::vector<int32_t> h_off_;
     bool h_off_fresh_ = false;
     char* up_dev_ = nullptr; char* up_host_ = nullptr; size_t up_cap_ = 0, up_used_ = 0; size_t up_flushed_ = 0; bool up_reserved_ = false;
-    std::vector<uint64_t> zpol_host_;
+    std::vector<uint64_t> zpol_host_, xpol_host_;
     char* res_slab_ = nullptr; size_t res_bytes_ = 0; int32_t* res_off_ = nullptr;
     int32_t* d_node_pods_ = nullptr; std::vector<int64_t> np_off_;
     std::vector<void*> allocs_;

@@ -19,6 +19,7 @@ struct DevTables {
     const uint64_t* zblock;  // [G][Wz]
     const uint64_t* zmark;   // [G][Wz]
     const uint64_t* zpol;    // [Wz] group bits of NEED polarity (casim_pegs.zone_polarity; all zero when the caller passed none)
+    const uint64_t* xpol;    // [Wx] node bits of NEED polarity (casim_pegs.excl_polarity; all zero when the caller passed none; null outside the template-mode pipeline)
     const double* fp_cpu;    // [G] or null
     const double* fp_mem;    // [G] or null
     // node-group table

@@ -45,6 +45,7 @@ class TableSet:
     global_id: Optional[np.ndarray] = None    # [NG]
     sim_offsets: Optional[np.ndarray] = None  # [S+1]
     zone_polarity: Optional[np.ndarray] = None  # [w_zone] group bits of NEED polarity (casim_pegs.zone_polarity), one row per batch
+    excl_polarity: Optional[np.ndarray] = None  # [w_excl] node bits of NEED polarity (casim_pegs.excl_polarity), one row per batch
     _keep: List[object] = field(default_factory=list)
 
     # ---- construction ---------------------------------------------------------------------------
@@ -58,6 +59,8 @@ class TableSet:
         ts = cls(dims, pc, gc)
         if pegs.zone_polarity and dims["w_zone"] > 0:
             ts.zone_polarity = np.ctypeslib.as_array(pegs.zone_polarity, shape=(dims["w_zone"],)).astype(np.uint64, copy=True)
+        if pegs.excl_polarity and dims["w_excl"] > 0:
+            ts.excl_polarity = np.ctypeslib.as_array(pegs.excl_polarity, shape=(dims["w_excl"],)).astype(np.uint64, copy=True)
         if groups.peg_offsets:
             ts.peg_offsets = np.ctypeslib.as_array(groups.peg_offsets, shape=(NG + 1,)).astype(np.int32, copy=True)
             nnz = int(ts.peg_offsets[NG]) if NG else 0
@@ -98,7 +101,7 @@ class TableSet:
                              "work on device-derived subsets only")
         G, NG = self.n_pegs, self.n_groups
         return TableSet(self.dims, self.pegs, self.groups, np.zeros(NG, np.int32), np.full(NG, G, np.int32), None, None,
-                        np.arange(NG, dtype=np.int32), np.array([0, NG], np.int32), zone_polarity=self.zone_polarity)
+                        np.arange(NG, dtype=np.int32), np.array([0, NG], np.int32), zone_polarity=self.zone_polarity, excl_polarity=self.excl_polarity)
 
     @staticmethod
     def concat(sets: Sequence["TableSet"]) -> "TableSet":
@@ -122,8 +125,11 @@ class TableSet:
         pols = [s.zone_polarity for s in sets if s.zone_polarity is not None]   # (one dictionary, one polarity row)
         if any(not np.array_equal(pz, pols[0]) for pz in pols) or (pols and len(pols) != len(sets)):
             raise ValueError("table sets with different zone polarity rows cannot share one batch")
+        xpols = [s.excl_polarity for s in sets if s.excl_polarity is not None]
+        if any(not np.array_equal(px, xpols[0]) for px in xpols) or (xpols and len(xpols) != len(sets)):
+            raise ValueError("table sets with different node polarity rows cannot share one batch")
         return TableSet(d, pc, gc, np.concatenate(lo).astype(np.int32), np.concatenate(hi).astype(np.int32), None, None,
-                        np.concatenate(gid).astype(np.int32), np.array(so, np.int32), zone_polarity=pols[0] if pols else None)
+                        np.concatenate(gid).astype(np.int32), np.array(so, np.int32), zone_polarity=pols[0] if pols else None, excl_polarity=xpols[0] if xpols else None)
 
     def tile(self, times: int) -> "TableSet":
         """The batch repeated `times` times (distinct memory, same simulations)."""
@@ -139,7 +145,7 @@ class TableSet:
         pc = {k: (None if v is None else v[:gp]) for k, v in one.pegs.items()}
         gc = {k: (None if v is None else v[:ng]) for k, v in one.groups.items()}
         return TableSet(one.dims, pc, gc, one.peg_lo[:ng], one.peg_hi[:ng], None, None,
-                        None if one.global_id is None else one.global_id[:ng], one.sim_offsets[:n_sims + 1].copy(), zone_polarity=one.zone_polarity)
+                        None if one.global_id is None else one.global_id[:ng], one.sim_offsets[:n_sims + 1].copy(), zone_polarity=one.zone_polarity, excl_polarity=one.excl_polarity)
 
     def sim_slice(self, a: int, b: int) -> "TableSet":
         """Simulations [a, b) as a table set of their own (their groups and the PEG rows they can see, re-based to 0): how a
@@ -153,7 +159,7 @@ class TableSet:
         gc = {k: (None if v is None else v[g0:g1]) for k, v in one.groups.items()}
         return TableSet(one.dims, pc, gc, one.peg_lo[g0:g1] - p0, one.peg_hi[g0:g1] - p0, None, None,
                         None if one.global_id is None else one.global_id[g0:g1], (one.sim_offsets[a:b + 1] - g0).astype(np.int32),
-                        zone_polarity=one.zone_polarity)
+                        zone_polarity=one.zone_polarity, excl_polarity=one.excl_polarity)
 
     def select_groups(self, keep: np.ndarray) -> "TableSet":
         """The groups `keep` (ascending indices) of every simulation: how one GPU's shard of a batch is cut out.  PEG table
@@ -163,7 +169,7 @@ class TableSet:
         gc = {k: (None if v is None else v[keep]) for k, v in one.groups.items()}
         so = np.searchsorted(keep, one.sim_offsets, side="left").astype(np.int32)
         gid = one.global_id if one.global_id is not None else np.arange(one.n_groups, dtype=np.int32)
-        return TableSet(one.dims, one.pegs, gc, one.peg_lo[keep], one.peg_hi[keep], None, None, gid[keep], so, zone_polarity=one.zone_polarity)
+        return TableSet(one.dims, one.pegs, gc, one.peg_lo[keep], one.peg_hi[keep], None, None, gid[keep], so, zone_polarity=one.zone_polarity, excl_polarity=one.excl_polarity)
 
     def shard(self, rank: int, world: int, rotate: bool = True) -> "TableSet":
         """Node groups of every simulation block-partitioned over `world` GPUs.  With `rotate` the block
@@ -195,6 +201,8 @@ class TableSet:
             setattr(p, k, ptr(self.pegs[k], dt))
         if self.zone_polarity is not None:
             p.zone_polarity = ptr(self.zone_polarity, np.uint64)
+        if self.excl_polarity is not None:
+            p.excl_polarity = ptr(self.excl_polarity, np.uint64)
         g = _abi.Groups(n_groups=self.n_groups)
         for k, (dt, _) in _GROUP_COLS.items():
             setattr(g, k, ptr(self.groups[k], dt))
