@@ -298,9 +298,11 @@ struct SelfCheckRng { uint64_t s; uint32_t next() { s = s * 6364136223846793005u
 //      partly invalid keys (instantiations with exclusion words only)
 //   8  the caller's own PEG lists (template-level Filters then run inside the orderer) instead of device-derived ones
 //  16  PEGs outside the simple shape: a zero request lane, a request >= 2^30 after gcd scaling (4-lane instantiations)
+//  32  node bits of NEED polarity (hostname-level pod affinity, ABI 8): PEGs that wait for a partner on the node, partners, self-affine series
+//      that enter by the first-pod exception (the record walked twice), templates that carry the partner (instantiations with exclusion words only)
 int32_t self_check_run(HipBackend& bk, int build, int lanes4, int slot_class, int excl, int variant, uint32_t seed, std::vector<int64_t>& out) {
     SelfCheckRng rng{0x9E3779B97F4A7C15ull ^ (uint64_t)(lanes4 * 131 + slot_class * 17 + excl) ^ ((uint64_t)seed << 20) ^ ((uint64_t)variant << 40)};
-    const bool v_fast = (variant & 1) != 0, v_runs = (variant & 2) != 0, v_zone = excl && (variant & 4) != 0, v_lists = (variant & 8) != 0, v_odd = (variant & 16) != 0;
+    const bool v_fast = (variant & 1) != 0, v_runs = (variant & 2) != 0, v_zone = excl && (variant & 4) != 0, v_lists = (variant & 8) != 0, v_odd = (variant & 16) != 0, v_need = excl && (variant & 32) != 0;
     const int G = 160, NG = 48, R = lanes4 == 1 ? 3 : 2;   // lanes4: 0 = two int32 lanes, 1 = four, 2 = two int64 lanes (the same tables as 0, not narrowed)
     std::vector<int64_t> req((size_t)G * R), alloc((size_t)NG * R), ireq((size_t)NG * R);
     std::vector<int32_t> count(G), allowed(NG), ipods(NG), maxn(NG), existing(NG), lastidx(NG);
@@ -308,6 +310,7 @@ int32_t self_check_run(HipBackend& bk, int build, int lanes4, int slot_class, in
     std::vector<uint64_t> tol(G), sel(G), xb(G), xm(G), zb(G, 0), zm(G, 0), taint(NG), label(NG), iexcl(NG), izone(NG, 0), zvalid(NG, ~0ull);
     std::vector<double> fpc(G), fpm(G), capc(NG), capm(NG);
     const uint64_t zpol = 0x00ff0000ull;   // bits 16-23 of the zone word have NEED polarity
+    const uint64_t xpol = 0xffull << 40;   // bits 40-47 of the node word have NEED polarity (the plain bits above use 0-39)
     for (int g = 0; g < G; ++g) {
         req[(size_t)g * R] = 50 + 50 * (int64_t)rng.below(60);
         req[(size_t)g * R + 1] = ((int64_t)64 + 64 * rng.below(96)) << 20;
@@ -322,6 +325,13 @@ int32_t self_check_run(HipBackend& bk, int build, int lanes4, int slot_class, in
             if (k == 0) { pflags[g] |= CASIM_PEG_SELF_EXCL_NODE; xb[g] = xm[g] = 1ull << rng.below(40); }   // self anti-affinity / own host port
             else if (k == 1) { xb[g] = 1ull << rng.below(40); }                                              // blocked by somebody's bit
             else if (k == 2) { xm[g] = 1ull << rng.below(40); }                                              // marks a bit others avoid
+        }
+        if (v_need) {
+            const uint32_t k = rng.below(8);
+            const uint64_t bit = 1ull << (40 + rng.below(8));
+            if (k == 0) { xb[g] |= bit; xm[g] |= bit; }   // a series: needs the bit it marks itself
+            else if (k == 1) xb[g] |= bit;                  // waits for a partner on the node
+            else if (k == 2 || k == 3) xm[g] |= bit;        // a partner
         }
         if (v_zone) {
             const uint32_t k = rng.below(10);
@@ -365,6 +375,7 @@ int32_t self_check_run(HipBackend& bk, int build, int lanes4, int slot_class, in
         taint[i] = rng.below(3) ? 0ull : (1ull << rng.below(8));
         label[i] = (uint64_t)rng.next() & 0x3full;
         iexcl[i] = excl && rng.below(4) == 0 ? 1ull << rng.below(40) : 0ull;
+        if (v_need && rng.below(5) == 0) iexcl[i] |= 1ull << (40 + rng.below(8));   // the template's own pods are the partner
         if (v_zone) {
             izone[i] = (rng.below(4) == 0 ? 1ull << rng.below(16) : 0ull) | (rng.below(4) == 0 ? 1ull << (16 + rng.below(8)) : 0ull);   // pods of the existing cluster: a conflict, a partner
             zvalid[i] = rng.below(5) == 0 ? ~(0x0f0full) : ~0ull;                                                                     // a template without some of the keys
@@ -391,6 +402,7 @@ int32_t self_check_run(HipBackend& bk, int build, int lanes4, int slot_class, in
     p.n_pegs = G; p.n_res = R; p.w_taint = 1; p.w_label = 1; p.w_excl = excl ? 1 : 0; p.w_zone = v_zone ? 1 : 0;
     p.req = req.data(); p.count = count.data(); p.flags = pflags.data(); p.tol_mask = tol.data(); p.sel_mask = sel.data();
     p.excl_block = excl ? xb.data() : nullptr; p.excl_mark = excl ? xm.data() : nullptr;
+    if (v_need) p.excl_polarity = &xpol;
     if (v_zone) { p.zone_block = zb.data(); p.zone_mark = zm.data(); p.zone_polarity = &zpol; }
     if (v_fast) { p.fp_cpu = fpc.data(); p.fp_mem = fpm.data(); }
     casim_groups g; memset(&g, 0, sizeof g);
@@ -431,12 +443,12 @@ int32_t self_check_run(HipBackend& bk, int build, int lanes4, int slot_class, in
     return CASIM_OK;
 }
 
-// The corpus: every instantiation (2 / 4 int32 lanes or 2 int64 lanes x 1 / 4 / 16 slots x without / with exclusion words) x 16 batches — the 12 plain batches the
-// check started with, then every feature bit alone, in pairs, and all together, each on data of its own.  288 batches, 576 runs.
+// The corpus: every instantiation (2 / 4 int32 lanes or 2 int64 lanes x 1 / 4 / 16 slots x without / with exclusion words) x 18 batches — the 12 plain batches the
+// check started with, then every feature bit alone, in pairs, and all together, each on data of its own.  324 batches, 648 runs.
 struct SelfCheckCase { int variant; uint32_t seed; };
-const SelfCheckCase kSelfCheckCases[] = {{0, 0}, {1, 1}, {2, 2}, {4, 3}, {8, 4}, {16, 5}, {3, 6}, {6, 7}, {12, 8}, {24, 9}, {17, 10}, {10, 11}, {20, 12}, {30, 13}, {31, 14}, {0, 15}};
+const SelfCheckCase kSelfCheckCases[] = {{0, 0}, {1, 1}, {2, 2}, {4, 3}, {8, 4}, {16, 5}, {3, 6}, {6, 7}, {12, 8}, {24, 9}, {17, 10}, {10, 11}, {20, 12}, {30, 13}, {31, 14}, {0, 15}, {32, 16}, {44, 17}};
 
-// The check of ONE instantiation (lanes4, slot class, exclusion words) on `device`: its 16 case families through both builds.
+// The check of ONE instantiation (lanes4, slot class, exclusion words) on `device`: its 18 case families through both builds.
 // Caller holds g_pack_build_mu.
 void self_check_instantiation(PackBuildState& st, int device, size_t lds, int lanes4, int sc, int excl) {
     const bool fault = getenv("CASIM_PACK_SELFCHECK_FAULT") && atoi(getenv("CASIM_PACK_SELFCHECK_FAULT")) != 0;
@@ -450,7 +462,7 @@ void self_check_instantiation(PackBuildState& st, int device, size_t lds, int la
     if (const char* e = getenv("CASIM_PACK_SELFCHECK_CASES")) { const int v = atoi(e); if (v >= 1 && v < n_cases) n_cases = v; }   // (1 = the one batch per instantiation of round 3)
     for (int ci = 0; ci < n_cases && tmp.stream; ++ci) {
         const SelfCheckCase& cse = kSelfCheckCases[ci];
-        if (cse.variant == 4 && !excl) continue;   // (zone words alone need an instantiation that carries them: nothing new to run)
+        if (!excl && (cse.variant == 4 || cse.variant == 32)) continue;   // (zone words / node NEED bits alone need an instantiation that carries them: nothing new to run)
         const int32_t rb = self_check_run(tmp, CASIM_PACK_BUILD_PLAIN, lanes4, sc, excl, cse.variant, cse.seed, b);
         if (rb != CASIM_OK) { st.skipped++; continue; }   // (the reference build itself cannot run this batch: nothing to compare)
         const int32_t ra = self_check_run(tmp, CASIM_PACK_BUILD_OPTION, lanes4, sc, excl, cse.variant, cse.seed, a);
@@ -474,8 +486,8 @@ void self_check_instantiation(PackBuildState& st, int device, size_t lds, int la
 }
 
 // The verdict for the device of `bk` when a context is created: a forced build (CASIM_PACK_BUILD), or — CASIM_PACK_SELFCHECK=eager — every
-// instantiation checked up front (288 - 9 batches, ~270 ms).  Default: LAZY — nothing here; an instantiation is checked right before its first
-// AUTO launch (casim_pack_use_plain: 16 batches, ~13 ms, paid by the first problem that needs it), so that start-up costs what the process uses.
+// instantiation checked up front (324 - 18 batches, ~300 ms).  Default: LAZY — nothing here; an instantiation is checked right before its first
+// AUTO launch (casim_pack_use_plain: 16-18 batches, ~15 ms, paid by the first problem that needs it), so that start-up costs what the process uses.
 void resolve_pack_build(HipBackend& bk) {
     if (bk.device < 0 || bk.device >= 64) return;
     std::lock_guard<std::mutex> lock(g_pack_build_mu);

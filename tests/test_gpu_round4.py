@@ -116,3 +116,48 @@ def test_int64_register_packer_on_the_device(ctx):
         res, exp = run_gpu_tables(ts, ctx, kinds=KINDS, n_streams=k, generic=2)
         _same(res, base, f"int64 register store, n_streams {k}")
         assert list(exp["best"]) == list(bexp["best"]) and list(exp["packed"]) == list(bexp["packed"])
+
+
+def test_hostname_pod_affinity_in_the_template_packers_on_the_device(ctx):
+    """VERDICT r3 missing #3 on the MI355X: hostname-level required pod affinity as node bits of NEED polarity (casim_pegs.excl_polarity, ABI 8)
+    — partners of the batch, self-affine series walked twice — in K_feas and in all three packers, both list modes, with and without
+    tryFastPath, vs the oracle (the emulator form: tests/test_pod_affinity_emu.py::test_template_mode_hostname_affinity_never_delegates);
+    then a batch of such simulations through the stream parts."""
+    from harness import GroupSpec, Scenario, encode_batch, run_gpu_tables
+    from test_pod_affinity_emu import _batch_affinity_workload
+    from kubernetes_autoscaler_amd.engine import Problem
+    from kubernetes_autoscaler_amd.objects import LABEL_HOSTNAME, LABEL_ZONE
+    checked = with_need = 0
+    for seed in range(240):
+        w, n_aff = _batch_affinity_workload(20000 + seed, keys=(LABEL_HOSTNAME, LABEL_HOSTNAME, LABEL_HOSTNAME, LABEL_ZONE))
+        fast = seed % 4 == 3
+        sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing, lanes=w.lanes,
+                      device_csr=seed % 2 == 0, fastpath=fast)
+        enc = encode(sc)
+        need = bool(enc.pegs.excl_polarity) and enc.pegs.w_excl > 0 and any(int(enc.pegs.excl_polarity[k]) for k in range(enc.pegs.w_excl))
+        want = run_oracle(sc)
+        for generic in (0, 1, 2):
+            with Problem(ctx, enc.pegs, enc.groups, fast, generic) as p:
+                p.run(); res = p.fetch()
+            if any(int(s) != 0 for s in res.status):
+                continue
+            assert_matches_oracle(res, want, f"hostname affinity {seed} generic={generic} fastpath={fast}")
+            checked += 1; with_need += 1 if need else 0
+        enc.close()
+    assert checked > 600 and with_need > 300
+    # simulations side by side (one polarity row per batch: one encoder), stream parts against one part
+    scs = []
+    for k in range(12):
+        w, _ = _batch_affinity_workload(20500 + k, keys=(LABEL_HOSTNAME, LABEL_HOSTNAME, LABEL_ZONE))
+        scs.append(Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, None) for g in w.groups], existing=[], lanes=w.lanes, device_csr=True))
+    enc, ts, bases = encode_batch(scs)
+    want = []
+    for sc, (pb, _) in zip(scs, bases):
+        want.extend([(est, [pb + i for i in ids]) for est, ids in run_oracle(sc)])
+    one, _ = run_gpu_tables(ts, ctx)
+    if not any(int(s) != 0 for s in one.status):
+        assert_matches_oracle(one, want, "hostname affinity, batch of simulations")
+    cut, _ = run_gpu_tables(ts, ctx, n_streams=3)
+    for f in ("node_count", "pods_scheduled", "nodes_added", "last_index_out", "status", "order", "placed"):
+        assert np.array_equal(getattr(one, f), getattr(cut, f)), f
+    enc.close()

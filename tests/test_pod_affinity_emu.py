@@ -341,3 +341,27 @@ def test_template_mode_hostname_affinity_never_delegates(seed, device_csr):
             pytest.skip("another predicate of the fuzz family is outside the template subset")
         assert_matches_oracle(res, oracle, f"hostname affinity seed {seed} ({n_aff} PEGs) generic={generic} device_csr={device_csr} fastpath={fast}")
     enc.close()
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_hostname_affinity_in_batches_of_simulations(seed):
+    """simulations side by side in one table set (one encoder, one polarity row; TableSet carries casim_pegs.excl_polarity through its
+    views), fixed-stride lists, stream parts: against the oracle's simulation of each scenario"""
+    from harness import assert_matches_oracle, encode_batch, run_emu_streams, run_emu_tables
+    import numpy as np
+    scs = []
+    for k in range(2 + seed % 5):
+        w, _ = _batch_affinity_workload(21000 + 13 * seed + k, keys=(LABEL_HOSTNAME, LABEL_HOSTNAME, LABEL_ZONE))
+        scs.append(Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, None) for g in w.groups], existing=[], lanes=w.lanes, device_csr=True))
+    enc, ts, bases = encode_batch(scs)
+    want = []
+    for sc, (pb, _) in zip(scs, bases):
+        want.extend([(est, [pb + i for i in ids]) for est, ids in run_oracle(sc)])
+    one, _ = run_emu_tables(ts)
+    if any(int(s) != 0 for s in one.status):
+        pytest.skip("another predicate of the fuzz family is outside the template subset")
+    assert_matches_oracle(one, want, f"hostname affinity, {len(scs)} simulations")
+    cut, _, parts = run_emu_streams(ts, 3)
+    for f in ("node_count", "pods_scheduled", "nodes_added", "last_index_out", "status", "order", "placed"):
+        assert np.array_equal(getattr(one, f), getattr(cut, f)), f
+    enc.close()
