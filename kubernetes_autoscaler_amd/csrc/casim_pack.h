@@ -768,8 +768,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     const int32_t o = last_index < 0 ? 0 : (int32_t)(li1 < (uint32_t)n ? li1 : li1 % (uint32_t)n);   // (negative: origin 0)
                     return o > E ? o - E : 0;
                 };
-                auto a2_finish = [&](const int32_t new_last, const uint32_t x_mine_last) {
-                    if constexpr (!kDry) on_last = cs::bcast_u32(x_mine_last, (M - 1) & 63);   // (only a3 asks)
+                auto a2_finish_core = [&](const int32_t new_last) {
                     last_index = new_last;
                     if (Wz > 0) zone_mark(zmark);
                     if constexpr (kDry) {   // placed > 0 here; the tail of the step does not run
@@ -778,8 +777,44 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         add_totals(placed, pv.req[0], RM > 1 ? pv.req[1] : (L)0);
                     }
                 };
-                auto a2_rest = [&](const int32_t n1) {
+                auto a2_finish = [&](const int32_t new_last, const uint32_t x_mine_last) {
+                    if constexpr (!kDry) on_last = cs::bcast_u32(x_mine_last, (M - 1) & 63);   // (only a3 asks)
+                    a2_finish_core(new_last);
+                };
+                auto a2_rest = [&](const int32_t n1, const uint64_t fb1 = 0) {
                     CASIM_PROF(2);  // a2 pass A (capacities)
+                    if constexpr (Store::kNPT == 1) {
+                        // ONE node takes the PEG (57 % of the placing steps of a C2 batch, 2.6 fitting nodes on average over the rest): its capacity
+                        // is clamped to the pods of the PEG, so it saturates (tot = cmax = c <= keff), the node is the last one served and
+                        // nothing needs a wave reduction — the lane index from the fit mask, the capacity by one v_readlane.
+                        if (n1 == 1) {
+                            const int l1 = cs::ffs64(fb1);
+                            const uint32_t c1 = cs::bcast_u32(creg[0], l1);
+                            placed = (int32_t)c1;
+                            st.commit_any(0, creg[0], pv);   // (c == 0 in every other lane: no change there)
+                            if constexpr (!kDry) on_last = l1 == ((M - 1) & 63) ? c1 : 0u;
+                            a2_finish_core(E + l1);
+                            CASIM_PROF(3);
+                            return;
+                        }
+                        // TWO nodes that both saturate (15 % of the placing steps): capacities by two v_readlane, the last node served is the
+                        // one with the larger capacity — equal capacities: the later one in rotated order
+                        if (n1 == 2) {
+                            const int la = cs::ffs64(fb1), lb = cs::fls64(fb1);
+                            const uint32_t ca = cs::bcast_u32(creg[0], la), cb = cs::bcast_u32(creg[0], lb);
+                            if (ca + cb <= keff) {   // (both <= keff < 2^31: no wrap)
+                                placed = (int32_t)(ca + cb);
+                                st.commit_any(0, creg[0], pv);
+                                int last;
+                                if (ca != cb) last = ca > cb ? la : lb;
+                                else { const int32_t m0 = rotation_origin(); last = lb < m0 ? lb : (la < m0 ? la : lb); }
+                                if constexpr (!kDry) { const int lm = (M - 1) & 63; on_last = la == lm ? ca : (lb == lm ? cb : 0u); }
+                                a2_finish_core(E + last);
+                                CASIM_PROF(3);
+                                return;
+                            }
+                        }
+                    }
                     uint32_t T, Rr;
                     bool done = false;
                     if ((uint32_t)n1 > keff) {
@@ -802,8 +837,12 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                                 lsum += cj;
                                 lane_max = cj > lane_max ? cj : lane_max;
                             });
-                            const U tot = wsumU(lsum);
-                            const uint32_t cmax = cs::wave_max_u32(lane_max);
+                            U tot; uint32_t cmax;
+                            if constexpr (sizeof(U) == 4) {   // sum and max in one interleaved pass (the chains fill each other's DPP wait states)
+                                uint32_t t32;
+                                cs::wave_sum_max_u32(lsum > (U)cap1 ? (U)cap1 : lsum, lane_max, t32, cmax);
+                                tot = (U)t32;
+                            } else { tot = wsumU(lsum); cmax = cs::wave_max_u32(lane_max); }
                             if (tot <= (U)keff) {   // every fitting node saturates (28 % of the C2 steps, 2.6 nodes on average)
                                 T = cmax; Rr = 0; placed = (int32_t)tot;
                                 if constexpr (Store::kNPT > 0) {
@@ -887,7 +926,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     if (fb) {  // wave-uniform
                         act = 1u;
                         creg[0] = st.capacity_slot(0, pv, keff, pf, fb);
-                        a2_rest(cs::popc64(fb));
+                        a2_rest(cs::popc64(fb), fb);
                     }
                 } else if constexpr (Store::kNPT > 0) {
                     n1 = st.capacity_all(pv, keff, pf, creg, act, S);  // (<= 4 slots: every slot, nodes >= M are all-zero)
