@@ -668,6 +668,12 @@ def main():
             rows["enter_return"] = _try(lambda: enter_return_row(kaa, ctx, batch.tables, kinds, K, checks_per_step, max(3, min(args.steps, 10)), res_all, final))
             rows["enter_return_every_list"] = _try(lambda: enter_return_row(kaa, ctx, batch.tables, kinds, K, checks_per_step, max(3, min(args.steps, 10)), res_all, final,
                                                                             winners_only=False))
+            # the caller's tables in page-locked memory (casim_host_alloc): no staging memcpy on the host, the columns travel from where they lie
+            def _pinned_row():
+                r = enter_return_row(kaa, ctx, batch.tables.pinned(), kinds, K, checks_per_step, max(3, min(args.steps, 10)), res_all, final)
+                r["what"] = "enter_return with the caller's tables in page-locked host memory (casim_host_alloc): columns of >= 1 MiB are copied to the device where they lie"
+                return r
+            rows["enter_return_pinned_tables"] = _try(_pinned_row)
             rows["int64"] = _try(lambda: int64_row(kaa, dev_index, batch.tables, kinds, K, checks_per_step, max(5, min(args.steps, 50)), res_all, final, torch, packer=2))
             rows["int64_lds_store"] = _try(lambda: int64_row(kaa, dev_index, batch.tables, kinds, K, checks_per_step, max(5, min(args.steps, 50)), res_all, final, torch, packer=1))
         extra["headline_rows"] = rows
@@ -778,32 +784,44 @@ def enter_return_row(kaa, ctx, tables, kinds, K, checks_per_step, steps, res_res
         call = BatchCall(ctx, pegs, groups, kinds=kinds, n_streams=K, winners_only=True)
         for _ in range(3):                # first calls: lanes' pools and pinned buffers grow to this call's sizes
             call.call_raw()
+        # (the interpreter's cyclic GC is parked for the timed calls: this process holds millions of workload objects, and a full collection
+        # in the middle of a call showed up as one 10-16 ms call in ten — the harness's pause, not the library's)
+        import gc
+        gc.collect(); gc.disable()
         seq = []
-        for _ in range(steps):
-            t0 = time.perf_counter()
-            call.call_raw()
-            seq.append(time.perf_counter() - t0)
+        try:
+            for _ in range(steps):
+                t0 = time.perf_counter()
+                call.call_raw()
+                seq.append(time.perf_counter() - t0)
+        finally:
+            gc.enable()
         dt = sum(seq) / steps
         res, exp = call.call()
         bytes_in = sum(v.nbytes for v in tables.pegs.values() if v is not None) + sum(v.nbytes for v in tables.groups.values() if v is not None)
         return {"what": "casim_estimate_batch_query enter -> return every step, casim_options.winners_only: H2D of fresh tables from pinned staging + kernels + "
                         "expander + winners' lists compacted on the device + D2H of every group's scalars / offsets and the winners' order / placed", "dtype": "int32",
                 "ms_per_step": dt * 1e3, "checks_per_s": checks_per_step / dt, "sims_per_s": tables.n_sims / dt, "steps": steps,
-                "ms_per_call_sequence": [round(x * 1e3, 3) for x in seq],
+                "ms_per_call_sequence": [round(x * 1e3, 3) for x in seq], "ms_per_step_median": sorted(seq)[len(seq) // 2] * 1e3,
                 "table_bytes_in": bytes_in, "result_bytes_out": 8 * int(res.winner_offsets[-1]) + 52 * tables.n_groups + 16 * tables.n_sims,
                 "pcie_inclusive": True, "bit_equal_to_resident": _same_winners((res, exp), (res_resident, exp_resident))}
+    import gc
     call = BatchCall(ctx, pegs, groups, kinds=kinds, n_streams=K)
     call.call_raw()                       # first call: lanes, pools, pinned buffers
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        call.call_raw()
-    dt = (time.perf_counter() - t0) / steps
-    one = BatchCall(ctx, pegs, groups, kinds=kinds, n_streams=0)
-    one.call_raw()
-    t0 = time.perf_counter()
-    for _ in range(max(1, steps // 2)):
+    gc.collect(); gc.disable()
+    try:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            call.call_raw()
+        dt = (time.perf_counter() - t0) / steps
+        one = BatchCall(ctx, pegs, groups, kinds=kinds, n_streams=0)
         one.call_raw()
-    dt1 = (time.perf_counter() - t0) / max(1, steps // 2)
+        t0 = time.perf_counter()
+        for _ in range(max(1, steps // 2)):
+            one.call_raw()
+        dt1 = (time.perf_counter() - t0) / max(1, steps // 2)
+    finally:
+        gc.enable()
     res, exp = call.call()
     bytes_in = sum(v.nbytes for v in tables.pegs.values() if v is not None) + sum(v.nbytes for v in tables.groups.values() if v is not None)
     nnz = int(res.offsets[-1])

@@ -263,6 +263,13 @@ casim_ctx* casim_ctx_create(int32_t device, void* stream);
 void casim_ctx_destroy(casim_ctx* ctx);
 /* Number of HIP devices visible (0 when none / no driver). */
 int32_t casim_device_count(void);
+/* Page-locked host memory for table columns (hipHostMalloc): a column of >= 1 MiB that lives in page-locked memory — from here, from
+ * hipHostRegister, from a pinned torch tensor — is copied to the device straight from the caller's array instead of through the library's
+ * staging buffer (the host-side memcpy of a 4096-simulation call is ~1 ms per part of its 3.8 ms).  The library finds out by itself
+ * (hipPointerGetAttributes); pageable columns work as before.  The arrays must stay untouched until the call that uploads them returns
+ * (it does not return before the copies have finished).  NULL on failure. */
+void* casim_host_alloc(size_t bytes);
+void casim_host_free(void* p);
 
 /*
  * Upload one batch (PEG table + node-group table) to HBM and size the device scratch.

@@ -146,6 +146,8 @@ PROTOTYPES = {
     "casim_ctx_create": (C.c_void_p, [C.c_int32, C.c_void_p]),
     "casim_ctx_destroy": (None, [C.c_void_p]),
     "casim_device_count": (C.c_int32, []),
+    "casim_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "casim_host_free": (None, [C.c_void_p]),
     "casim_problem_create": (C.c_void_p, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(Options)]),
     "casim_problem_destroy": (None, [C.c_void_p]),
     "casim_problem_run": (C.c_int32, [C.c_void_p]),

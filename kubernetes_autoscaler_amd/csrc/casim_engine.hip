@@ -93,6 +93,12 @@ struct HipBackend {
     }
     void* stage_if_fits(int which, size_t bytes) { which &= 1; return staging_cap[which] >= bytes ? staging[which] : nullptr; }   // (never re-allocates)
     void h2d(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D"); }
+    // the caller's array is page-locked (casim_host_alloc, hipHostRegister, a pinned torch tensor): the DMA engine can read it where it lies
+    bool pinned(const void* p) const {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // (plain pageable memory: "invalid value", and sticky)
+        return a.type == hipMemoryTypeHost;
+    }
     void d2h(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H"); }
     void zero(void* d, size_t n) { if (n) check(hipMemsetAsync(d, 0, n, stream), "hipMemsetAsync"); }
     void fill8(void* d, int v, size_t n) { if (n) check(hipMemsetAsync(d, v, n, stream), "hipMemsetAsync"); }
@@ -556,6 +562,12 @@ __global__ __launch_bounds__(64) void stream_probe_scalar_kernel(const uint32_t*
 extern "C" {
 
 int32_t casim_abi_version(void) { return CASIM_ABI_VERSION; }
+void* casim_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void casim_host_free(void* p) { if (p) (void)hipHostFree(p); }
 const char* casim_last_error(void) { return g_err.c_str(); }
 
 int32_t casim_device_count(void) {

@@ -1112,6 +1112,7 @@ private:
     // pass.  Only columns that are final when up() returns: once somebody has RESERVED room to write in place later (up_reserve), the
     // rest goes out with end_uploads().  A single simulation stays one copy.
     static constexpr size_t kUploadChunk = (size_t)4 << 20;
+    static constexpr size_t kDirectUploadMin = (size_t)1 << 20;   // columns below this are cheaper to stage than to ask about (hipPointerGetAttributes)
     static size_t upload_chunk() {   // (CASIM_TEST_UPLOAD_CHUNK: tests send small tables in many pieces)
         const char* e = getenv("CASIM_TEST_UPLOAD_CHUNK");
         const long v = e ? atol(e) : 0;
@@ -1134,6 +1135,15 @@ private:
         if (n == 0 || !src) return nullptr;
         const size_t bytes = sizeof(T) * n, at = (up_used_ + 15) & ~(size_t)15;
         if (up_dev_ && at + bytes <= up_cap_) {
+            // a big column in page-locked memory travels from where it lies: what is staged in front of it goes out first (the staged range
+            // must not cover the column's slice of the slab: its bytes in the staging buffer are garbage), then the column itself
+            if (bytes >= kDirectUploadMin && !up_reserved_ && bk_.pinned(src)) {
+                if (up_used_ > up_flushed_) bk_.h2d(up_dev_ + up_flushed_, up_host_ + up_flushed_, up_used_ - up_flushed_);
+                bk_.h2d(up_dev_ + at, src, bytes);
+                up_used_ = up_flushed_ = at + bytes;
+                ++direct_uploads_;
+                return (const T*)(up_dev_ + at);
+            }
             par_memcpy(up_host_ + at, src, bytes);
             up_used_ = at + bytes;
             flush_uploads_early();
@@ -1200,6 +1210,7 @@ private:
     std::vector<int32_t> h_off_;
     bool h_off_fresh_ = false;
     char* up_dev_ = nullptr; char* up_host_ = nullptr; size_t up_cap_ = 0, up_used_ = 0; size_t up_flushed_ = 0; bool up_reserved_ = false;
+    int direct_uploads_ = 0;   // columns copied straight from the caller's page-locked arrays
     std::vector<uint64_t> zpol_host_, xpol_host_;
     char* res_slab_ = nullptr; size_t res_bytes_ = 0; int32_t* res_off_ = nullptr;
     int32_t* d_node_pods_ = nullptr; std::vector<int64_t> np_off_;

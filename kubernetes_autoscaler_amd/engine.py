@@ -175,6 +175,32 @@ def device_count() -> int:
     return int(lib.casim_device_count())
 
 
+class _HostBlock:
+    """One casim_host_alloc block, freed with the last array that views it."""
+
+    def __init__(self, nbytes: int):
+        self.ptr = lib.casim_host_alloc(max(int(nbytes), 8))
+        if not self.ptr:
+            raise CasimError("casim_host_alloc failed")
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib.casim_host_free(self.ptr)
+            self.ptr = None
+
+
+def pinned_copy(a: np.ndarray) -> np.ndarray:
+    """A copy of `a` in page-locked host memory (casim_host_alloc): a table column that lives there is copied to the device where it lies
+    — the library skips its staging memcpy for columns of >= 1 MiB (include/casim.h)."""
+    a = np.ascontiguousarray(a)
+    blk = _HostBlock(a.nbytes)
+    buf = (C.c_uint8 * max(a.nbytes, 8)).from_address(blk.ptr)
+    buf._casim_block = blk          # (numpy keeps `buf` as the array's base: the block lives as long as a view of it does)
+    out = np.frombuffer(buf, dtype=np.uint8, count=a.nbytes).view(a.dtype).reshape(a.shape)
+    out[...] = a
+    return out
+
+
 class Context:
     """casim_ctx: one HIP device + one stream.  `stream` may be a raw hipStream_t (int), e.g.
     torch.cuda.current_stream().cuda_stream, so that torch events bracket the kernels."""

@@ -135,6 +135,15 @@ class TableSet:
         """The batch repeated `times` times (distinct memory, same simulations)."""
         return TableSet.concat([self] * times) if times > 1 else self
 
+    def pinned(self) -> "TableSet":
+        """The same tables with every column in page-locked host memory (engine.pinned_copy): enter -> return calls then upload them
+        without the library's staging copy."""
+        from .engine import pinned_copy
+        pc = {k: (None if v is None else pinned_copy(v)) for k, v in self.pegs.items()}
+        gc = {k: (None if v is None else pinned_copy(v)) for k, v in self.groups.items()}
+        return TableSet(self.dims, pc, gc, self.peg_lo, self.peg_hi, self.peg_offsets, self.peg_index, self.global_id, self.sim_offsets,
+                        zone_polarity=self.zone_polarity, excl_polarity=self.excl_polarity)
+
     def head(self, n_sims: int) -> "TableSet":
         """The first n_sims simulations (their groups; the PEG table is cut after the last PEG they can see)."""
         one = self if self.peg_lo is not None else self.as_one_simulation()

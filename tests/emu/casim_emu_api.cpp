@@ -30,6 +30,7 @@ struct EmuBackend {
     void* stage_if_fits(int which, size_t bytes) { return staging[which & 1].size() >= bytes ? staging[which & 1].data() : nullptr; }
     void* stage(int which, size_t bytes) { if (staging[which & 1].size() < bytes) staging[which & 1].resize(bytes); return staging[which & 1].data(); }
     size_t lds_budget() const { return lds; }
+    bool pinned(const void*) const { return false; }
     bool ok() const { return true; }
     const char* error() const { return ""; }
     template <class K, class... A>

@@ -161,3 +161,25 @@ def test_hostname_pod_affinity_in_the_template_packers_on_the_device(ctx):
     for f in ("node_count", "pods_scheduled", "nodes_added", "last_index_out", "status", "order", "placed"):
         assert np.array_equal(getattr(one, f), getattr(cut, f)), f
     enc.close()
+
+
+def test_tables_in_page_locked_memory_upload_without_staging(ctx):
+    """casim_host_alloc (include/casim.h): columns of >= 1 MiB in page-locked memory are copied to the device where they lie; results are the
+    ones of the staged upload — a C2 batch big enough for its request / mask columns to pass the threshold, one part and stream parts,
+    resident problem and enter -> return."""
+    from bench import simulation_tables
+    from kubernetes_autoscaler_amd.engine import BatchCall, Problem
+    from kubernetes_autoscaler_amd.tables import TableSet
+    KINDS = [_abi.EXPANDER_LEAST_NODES]
+    ts = simulation_tables(workloads.config_c2, range(4), kaa.Encoder, TableSet).tile(64)     # 256 simulations, ~100 k PEGs: req column 1.6 MB
+    pin = ts.pinned()
+    assert max(v.nbytes for v in pin.pegs.values() if v is not None) >= (1 << 20)
+    for k in (0, 4):
+        a = BatchCall(ctx, *ts.structs(), kinds=KINDS, n_streams=k).call()
+        b = BatchCall(ctx, *pin.structs(), kinds=KINDS, n_streams=k).call()
+        for f in ("node_count", "pods_scheduled", "nodes_added", "last_index_out", "status", "offsets", "order", "placed"):
+            assert np.array_equal(getattr(a[0], f), getattr(b[0], f)), (k, f)
+        assert list(a[1]["packed"]) == list(b[1]["packed"])
+    with Problem(ctx, *pin.structs(), n_streams=4) as p:
+        p.run(); res = p.fetch()
+    assert np.array_equal(res.placed, a[0].placed) and np.array_equal(res.node_count, a[0].node_count)
