@@ -58,10 +58,12 @@ CS_DEVICE RecBase rec_base(const uint32_t* p) { return RecBase{(const char*)p}; 
 template <int N> CS_DEVICE Words<N> rec_load(const RecBase& b, uint32_t byte_off) { Words<N> r; memcpy(r.w, b.p + byte_off, 4 * N); return r; }
 CS_DEVICE bool lane_pred(uint64_t mask) { return ((mask >> (casim_emu::cur().tid & 63)) & 1ull) != 0; }
 CS_DEVICE void keep_scalar(uint32_t&) {}
+CS_DEVICE void keep_apart() {}
 CS_DEVICE int32_t opaque_i32(int32_t v) { return v; }
 CS_DEVICE void consume_u32(uint32_t) {}
 CS_DEVICE bool flag_set(uint32_t word, uint32_t bit) { return (word & bit) != 0; }
 CS_DEVICE uint32_t uniform_div_u32(uint32_t a, uint32_t b) { return a / b; }
+CS_DEVICE uint32_t uniform_div_u32_small(uint32_t a, uint32_t b) { return a / b; }
 CS_DEVICE uint32_t scalar_min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 CS_DEVICE void write_lane_u32(uint32_t& v, uint32_t uniform_value, int uniform_lane) { if ((casim_emu::cur().tid & 63) == uniform_lane) v = uniform_value; }
 CS_DEVICE int popc64(uint64_t v) { return __builtin_popcountll(v); }
@@ -231,6 +233,9 @@ CS_DEVICE void consume_u32(uint32_t v) { asm volatile("" : : "v"(v)); }
 // test of one bit of a wave-UNIFORM word, meant to sit directly in an `if`: the word goes through an opaque scalar copy so
 // that every test is its own s_bitcmp + s_cbranch_scc.  A flag tested in several places as one bool is kept by the
 // compiler as a 64-bit lane mask (s_cselect_b64, then s_and_b64 with exec + s_cbranch_vcc at every use).
+// an empty side effect: a branch that contains it is not folded into its neighbours' conditions (SimplifyCFG merges side-effect-free
+// nested tests into one lane-mask expression: s_cselect_b64 + s_or_b64 + s_andn2_b64 + s_cbranch_vcc per merged test)
+CS_DEVICE void keep_apart() { asm volatile(""); }
 CS_DEVICE bool flag_set(uint32_t word, uint32_t bit) { asm volatile("" : "+s"(word)); return (word & bit) != 0; }
 // a / b for wave-UNIFORM 32-bit values (b > 0) on the VECTOR unit: f64 reciprocal estimate + exact +-1 fix-up (the operands are
 // below 2^32, the estimate is within one of the quotient), ~10 VALU.  The compiler's expansion of a uniform division is ~17
@@ -241,6 +246,17 @@ CS_DEVICE uint32_t uniform_div_u32(uint32_t a, uint32_t b) {
     uint32_t q = (uint32_t)((double)va * __builtin_amdgcn_rcp((double)vb));
     const uint64_t wide = (uint64_t)q * vb;   // (b may exceed 2^31: the fix-up compares the 64-bit product)
     q = wide > va ? q - 1 : ((uint64_t)va - wide >= vb ? q + 1 : q);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+}
+// the same for a divisor below 2^30 (the packer's: pods that fit an empty node, < 2^21 by eligibility): the remainder of the estimate lies
+// in (-b, 2b), so it is exact in WRAPPING 32-bit arithmetic and the fix-up is sign bit + one compare — straight-line code; the general
+// form above compares 64-bit products under two exec-mask regions (18 instructions, 4 of them scalar)
+CS_DEVICE uint32_t uniform_div_u32_small(uint32_t a, uint32_t b) {
+    uint32_t va = a, vb = b;
+    asm volatile("" : "+v"(va), "+v"(vb));
+    uint32_t q = (uint32_t)((double)va * __builtin_amdgcn_rcp((double)vb));
+    const int32_t rem = (int32_t)(va - q * vb);
+    q = q - ((uint32_t)rem >> 31) + (rem >= (int32_t)vb ? 1u : 0u);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
 }
 // min of two wave-uniform values as ONE s_min_u32 (min(x, 1) written in C++ becomes "x != 0" as a lane mask, a v_cndmask and a

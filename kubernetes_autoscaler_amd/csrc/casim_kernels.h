@@ -557,7 +557,10 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
                     }
                 }
                 w[0] = (uint32_t)t.count[g];
-                const bool a2_ok = (flags & CASIM_KFLAG_STATIC_OK) && t.count[g] > 0;
+                if (!(flags & CASIM_KFLAG_STATIC_OK)) cf = 0u;   // the template-level Filters fail: no pod of the PEG fits an empty node of this group (the packer's a3 reads only this)
+                // (RunFiltersUntilPassingNode skips Spec.Unschedulable nodes before any Filter runs, plugin_runner.go:108-110: in such a group the
+                // simulated nodes are never worth a visit — decided here, the packer tests ONE constant bit)
+                const bool a2_ok = (flags & CASIM_KFLAG_STATIC_OK) && t.count[g] > 0 && !(t.gflags[ng] & CASIM_NG_UNSCHEDULABLE);
                 w[1] = (flags & (CASIM_REC_FLAG_MASK & ~(CASIM_REC_SIMPLE | CASIM_REC_A2_OK))) | (cf << CASIM_REC_FRESH_SHIFT) | (simple ? CASIM_REC_SIMPLE : 0u) |
                        (a2_ok ? CASIM_REC_A2_OK : 0u) | ((a2_ok && simple) ? CASIM_REC_A2_SIMPLE : 0u);
                 RecQuad* out = (RecQuad*)(res.rec + (int64_t)(off + i) * DW);   // 16-byte stores (records are 32 / 64 bytes)
@@ -586,7 +589,10 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
                     }
                 }
                 w[0] = (uint32_t)t.count[g];
-                const bool a2_ok = (flags & CASIM_KFLAG_STATIC_OK) && t.count[g] > 0;
+                if (!(flags & CASIM_KFLAG_STATIC_OK)) cf = 0u;   // the template-level Filters fail: no pod of the PEG fits an empty node of this group (the packer's a3 reads only this)
+                // (RunFiltersUntilPassingNode skips Spec.Unschedulable nodes before any Filter runs, plugin_runner.go:108-110: in such a group the
+                // simulated nodes are never worth a visit — decided here, the packer tests ONE constant bit)
+                const bool a2_ok = (flags & CASIM_KFLAG_STATIC_OK) && t.count[g] > 0 && !(t.gflags[ng] & CASIM_NG_UNSCHEDULABLE);
                 w[1] = (flags & (CASIM_REC_FLAG_MASK & ~(CASIM_REC_SIMPLE | CASIM_REC_A2_OK))) | (cf << CASIM_REC_FRESH_SHIFT) | (simple ? CASIM_REC_SIMPLE : 0u) |
                        (a2_ok ? CASIM_REC_A2_OK : 0u) | ((a2_ok && simple) ? CASIM_REC_A2_SIMPLE : 0u);
                 RecQuad* out = (RecQuad*)(res.rec + (int64_t)(off + i) * 16);

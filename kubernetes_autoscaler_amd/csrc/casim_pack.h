@@ -566,8 +566,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     constexpr bool kNeedG = Store::kHasExcl || Store::kHasZone;
     // a2 is worth entering when the record says so (CASIM_REC_A2_OK) AND the group has simulated nodes AND its template is
     // schedulable: the last two as a mask that is zero until the first node exists
-    const uint32_t a2_bit = group_unschedulable ? 0u : CASIM_REC_A2_OK;
-    uint32_t a2_gate = 0;
+    // (the records of an unschedulable template carry no CASIM_REC_A2_OK: order_group)
     if constexpr (kRecScalar) {
         recp = res.rec + (int64_t)off * DW;
         rbase = cs::rec_base(recp);
@@ -715,7 +714,13 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             bool a2_go;
             uint64_t fb_first = 0;   // one-slot register store behind a dry limiter: the fit mask IS the gate
             if constexpr (kRecScalar) {
-                if constexpr (!kDry) { cs::keep_scalar(a2_gate); a2_go = (pf & a2_gate) != 0; }
+                if constexpr (!kDry) {
+                    // (two scalar tests, each its own compare + branch.  As ONE bit test against a gate word that a3 rewrote — round 3 — the gate
+                    // travelled through a VGPR phi and the verdict, reused by a3, became a lane mask: 8 scalar instructions at the head of every step)
+                    uint32_t m0 = (uint32_t)M; cs::keep_scalar(m0);
+                    a2_go = false;
+                    if ((int32_t)m0 > 0) a2_go = cs::flag_set(pf, CASIM_REC_A2_OK);
+                }
                 else if constexpr (Store::kNPT == 1) {
                     // (the dry loop only runs with the gate open.)  The common PEG — template Filters pass, pods > 0, every lane asked for
                     // and small: CASIM_REC_A2_SIMPLE — goes from ONE bit test straight to its three compares; the others test A2_OK
@@ -980,7 +985,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     for_slots<Store>(s_hi + 1, [&](int s) {
                         const int32_t m = s * 64 + lane;
                         const uint32_t i = (uint32_t)(m - first);
-                        if (s >= s_lo && i < (uint32_t)nadd) {
+                        if ((Store::kNPT == 1 || s >= s_lo) && i < (uint32_t)nadd) {   // (one slot: the node bound is <= 64, first is in it)
                             // i * per <= (nadd - 1) * per < pods_total < 2^31 for the nodes being created: 32-bit arithmetic
                             const int32_t left = pods_total - (int32_t)(i * per);
                             const uint32_t x = left <= 0 ? 0u : ((uint32_t)left < per ? (uint32_t)left : per);
@@ -1029,8 +1034,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         }
                     };
                     // (nested ifs: each is one scalar compare + branch; as one combined bool the tests became lane masks)
-                    if constexpr (kRecScalar && !Store::kHasZone) { if ((pf & a2_gate) == 0) { if (M > 0) ask_newest(); } }
-                    else { if (M > 0) ask_newest(); }
+                    if constexpr (!(kRecScalar && !Store::kHasZone)) { if (M > 0) ask_newest(); }
                     // newest node still empty and the pod does not fit it: a new one would not help (:234-236)
                     auto newest_pods = [&]() -> uint32_t {
                         const int lm = M - 1, owner = lm & 63;
@@ -1039,7 +1043,10 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     // (without zone state the body runs at most once: a straight line instead of a loop whose
                     // back edge carried the whole register state)
                     auto new_nodes = [&]() -> bool {   // false = done
-                        const uint32_t cn = blocked() ? 0u : cfresh;
+                        // (records of a store without group-wide state carry 0 pods per empty node when the template-level Filters fail:
+                        // order_group — "blocked" is cfresh == 0 there, one test instead of a flag test merged into a lane mask)
+                        uint32_t cn;
+                        if constexpr (kRecScalar && !Store::kHasZone) cn = cfresh; else cn = blocked() ? 0u : cfresh;
                         if (cn == 0 || zselfx) {
                             if (permission_left() <= 0) { more_mask = 0; return false; }       // :244-246
                             granted++;
@@ -1053,22 +1060,25 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         } else {
                             // rem <= 2^31 - 1 and cn <= rem: 32-bit unsigned arithmetic is exact (an emulated
                             // 64-bit division here cost more than the whole node creation)
-                            const int64_t need = (int64_t)cs::uniform_div_u32((uint32_t)rem + cn - 1u, cn);
-                            const int64_t left = permission_left();
-                            const int32_t nadd = (int32_t)(need < left ? need : left);
-                            const int64_t fit = (int64_t)nadd * cn;
-                            const int32_t pl = (int32_t)(fit < rem ? fit : rem);
+                            // (records carry the pods that fit an empty node in 21 bits: the short form of the division)
+                            // need = ceil(rem / cn) <= rem < 2^31, 0 <= left < 2^31, nadd * cn <= need * cn < rem + cn < 2^32: everything in 32 bits
+                            // (as int64 the two minima became VECTOR 64-bit compares of scalar values — there is no scalar s_cmp_lt_i64)
+                            const int32_t need = (int32_t)(kRecScalar ? cs::uniform_div_u32_small((uint32_t)rem + cn - 1u, cn) : cs::uniform_div_u32((uint32_t)rem + cn - 1u, cn));
+                            const int32_t left = grant_bound - granted;
+                            const int32_t nadd = need < left ? need : left;
+                            const uint32_t fit = (uint32_t)nadd * cn;
+                            const int32_t pl = fit < (uint32_t)rem ? (int32_t)fit : rem;
                             if (nadd > 0) {
                                 create_nodes(M, nadd, cn, pl);
                                 // A run of k identical singleton PEGs merged into this row (CASIM_KFLAG_SINGLETON_RUN, casim_pipeline.h): each
                                 // of them runs tryToScheduleOnExistingNodes first, so every pod after the first on a new node got there
                                 // through a match that moved lastIndex to that node (plugin_runner.go:138) — the last new node holding >= 2
                                 // pods.  (A template that is unschedulable never matches there: its pods arrive by name, as a PEG's do.)
-                                if (cs::flag_set(pf, CASIM_KFLAG_SINGLETON_RUN) && !group_unschedulable && cn >= 2u) {
+                                if (cs::flag_set(pf, CASIM_KFLAG_SINGLETON_RUN)) { cs::keep_apart(); if (!group_unschedulable && cn >= 2u) {   // (the rare flag first, as a branch of its own)
                                     const int32_t on_last_new = pl - (nadd - 1) * (int32_t)cn;
                                     if (on_last_new >= 2) last_index = E + M + nadd - 1;
                                     else if (nadd >= 2) last_index = E + M + nadd - 2;
-                                }
+                                } }
                                 M += nadd; granted += nadd; placed += pl; rem -= pl; marked = true;
                             }
                             if (need > left) more_mask = 0;
@@ -1079,6 +1089,13 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         bool stop = rem == 0;
                         if (!stop && M > 0 && newest_pods() == 0) stop = true;
                         while (!stop && new_nodes()) {}
+                    } else if constexpr (kRecScalar) {
+                        // ONE test of "a node exists" for both questions (as two tests of M the compiler kept the verdict as a pair of lane masks)
+                        uint32_t m1 = (uint32_t)M; cs::keep_scalar(m1);
+                        if ((int32_t)m1 > 0) {
+                            if (!cs::flag_set(pf, CASIM_REC_A2_OK)) ask_newest();     // a2 did not run for this PEG
+                            if (rem != 0) { if (newest_pods() != 0) new_nodes(); }
+                        } else { if (rem != 0) new_nodes(); }   // (no node yet: nothing to compare)
                     } else {
                         if (rem != 0) {
                             uint32_t np = 1u;   // (no node yet: nothing to compare)
@@ -1088,7 +1105,6 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     }
                 }
                 if (marked && Wz > 0) zone_mark(zmark);
-                if constexpr (kRecScalar) { a2_gate = M > 0 ? a2_bit : 0u; cs::keep_scalar(a2_gate); }
             }
 
             CASIM_PROF(5);  // a3 / a4
@@ -1129,7 +1145,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             // behind a dry limiter: nothing at all can happen without a node that takes pods (no a3, a2 gated off) — else chunk by
             // chunk, so that the steps themselves carry no chunk test
             constexpr uint32_t kChunkBytes = 64u * kRecBytes;
-            if (a2_gate != 0) {
+            if (M > 0 && !group_unschedulable) {   // (a2 can run: a node exists and the template is schedulable)
                 while (roff < rend) {
                     if ((roff & (kChunkBytes - 1u)) == 0) { const int k = (int)(roff >> kRecShift); if (k > 0) flush_chunk(k - 64); my_placed = 0; touch_chunk(k + 64); }
                     const uint32_t cnext = (roff | (kChunkBytes - 1u)) + 1u;
