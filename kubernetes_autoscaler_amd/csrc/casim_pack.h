@@ -789,10 +789,12 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 auto a2_rest = [&](const int32_t n1, const uint64_t fb1 = 0) {
                     CASIM_PROF(2);  // a2 pass A (capacities)
                     if constexpr (Store::kNPT == 1) {
+                        // (the count as a 32-bit scalar: as the 64-bit popcount it came from, "n1 == 1" was a VECTOR compare of a scalar pair)
+                        uint32_t n1s = (uint32_t)n1; cs::keep_scalar(n1s);
                         // ONE node takes the PEG (57 % of the placing steps of a C2 batch, 2.6 fitting nodes on average over the rest): its capacity
                         // is clamped to the pods of the PEG, so it saturates (tot = cmax = c <= keff), the node is the last one served and
                         // nothing needs a wave reduction — the lane index from the fit mask, the capacity by one v_readlane.
-                        if (n1 == 1) {
+                        if (n1s == 1u) {
                             const int l1 = cs::ffs64(fb1);
                             const uint32_t c1 = cs::bcast_u32(creg[0], l1);
                             placed = (int32_t)c1;
@@ -804,7 +806,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         }
                         // TWO nodes that both saturate (15 % of the placing steps): capacities by two v_readlane, the last node served is the
                         // one with the larger capacity — equal capacities: the later one in rotated order
-                        if (n1 == 2) {
+                        if (n1s == 2u) {
                             const int la = cs::ffs64(fb1), lb = cs::fls64(fb1);
                             const uint32_t ca = cs::bcast_u32(creg[0], la), cb = cs::bcast_u32(creg[0], lb);
                             if (ca + cb <= keff) {   // (both <= keff < 2^31: no wrap)
@@ -1022,10 +1024,12 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     // next-fit on the newest node (:198-209).  When a2 ran for this PEG it walked EVERY simulated node, the newest
                     // included, with the same predicate, and left pods over: the newest node is full for this PEG (register store
                     // without group-wide state: a2 ran iff the gate bit was set)
-                    auto ask_newest = [&]() {
+                    // a2_may_have_run: CsFalse where the caller knows a2 did not run for this PEG (then it put nothing on the newest node: on_last is
+                    // dead in that instantiation and the packer stops computing it)
+                    auto ask_newest = [&](auto a2_may_have_run) {
                         const int lm = M - 1, owner = lm & 63;
                         uint32_t cl = 0;
-                        if (!blocked() && !(selfx && on_last > 0))   // wave-uniform
+                        if (!blocked() && !(decltype(a2_may_have_run)::value && selfx && on_last > 0))   // wave-uniform
                             cl = cs::bcast_u32(st.capacity_newest(lm, pv, (uint32_t)rem, selfx || zselfx, lane == owner), owner);
                         if (cl > 0) {
                             st.commit_newest(lm, cl, pv, lane == owner);
@@ -1034,7 +1038,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         }
                     };
                     // (nested ifs: each is one scalar compare + branch; as one combined bool the tests became lane masks)
-                    if constexpr (!(kRecScalar && !Store::kHasZone)) { if (M > 0) ask_newest(); }
+                    if constexpr (!(kRecScalar && !Store::kHasZone)) { if (M > 0) ask_newest(CsTrue{}); }
                     // newest node still empty and the pod does not fit it: a new one would not help (:234-236)
                     auto newest_pods = [&]() -> uint32_t {
                         const int lm = M - 1, owner = lm & 63;
@@ -1093,7 +1097,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         // ONE test of "a node exists" for both questions (as two tests of M the compiler kept the verdict as a pair of lane masks)
                         uint32_t m1 = (uint32_t)M; cs::keep_scalar(m1);
                         if ((int32_t)m1 > 0) {
-                            if (!cs::flag_set(pf, CASIM_REC_A2_OK)) ask_newest();     // a2 did not run for this PEG
+                            if (!cs::flag_set(pf, CASIM_REC_A2_OK)) ask_newest(CsFalse{});     // a2 did not run for this PEG
                             if (rem != 0) { if (newest_pods() != 0) new_nodes(); }
                         } else { if (rem != 0) new_nodes(); }   // (no node yet: nothing to compare)
                     } else {
