@@ -59,6 +59,7 @@ template <int N> CS_DEVICE Words<N> rec_load(const RecBase& b, uint32_t byte_off
 CS_DEVICE bool lane_pred(uint64_t mask) { return ((mask >> (casim_emu::cur().tid & 63)) & 1ull) != 0; }
 CS_DEVICE void keep_scalar(uint32_t&) {}
 CS_DEVICE void keep_apart() {}
+CS_DEVICE double estimate_rcp_f64(double x) { return 1.0 / x; }
 CS_DEVICE int32_t opaque_i32(int32_t v) { return v; }
 CS_DEVICE void consume_u32(uint32_t) {}
 CS_DEVICE bool flag_set(uint32_t word, uint32_t bit) { return (word & bit) != 0; }
@@ -247,6 +248,13 @@ CS_DEVICE uint32_t uniform_div_u32(uint32_t a, uint32_t b) {
     const uint64_t wide = (uint64_t)q * vb;   // (b may exceed 2^31: the fix-up compares the 64-bit product)
     q = wide > va ? q - 1 : ((uint64_t)va - wide >= vb ? q + 1 : q);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+}
+// 1 / x as a quotient ESTIMATE (relative error ~2^-50: v_rcp_f64 + one Newton step, 3 instructions) — for the +-1 fix-up forms of
+// capacity_of / the packer, whose proof asks for 2^-51.  An IEEE division is ~15 instructions (v_div_scale x 2, v_rcp, 5 FMAs,
+// v_div_fmas, v_div_fixup) and nothing downstream needs the correctly rounded reciprocal.  The emulator divides.
+CS_DEVICE double estimate_rcp_f64(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
 }
 // the same for a divisor below 2^30 (the packer's: pods that fit an empty node, < 2^21 by eligibility): the remainder of the estimate lies
 // in (-b, 2b), so it is exact in WRAPPING 32-bit arithmetic and the fix-up is sign bit + one compare — straight-line code; the general

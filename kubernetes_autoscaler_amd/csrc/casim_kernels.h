@@ -548,11 +548,20 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
                     const int32_t q = r < t.R ? res.req32[(int64_t)g * t.R + r] : 0;
                     simple = simple && q > 0 && q < (1 << 30);
                     w[2 + r] = (uint32_t)q;
-                    const uint64_t rq = cs::double_bits(q > 0 ? 1.0 / (double)q : 0.0);
+                    // (the reciprocal is only ever a quotient estimate with an exact +-1 fix-up behind it: no IEEE division — 4 of them per lane
+                    // pass were ~60 of this kernel's ~800 vector instructions — and the empty node's capacity by the same estimate instead of
+                    // the compiler's 32-bit division sequence)
+                    const double rqd = q > 0 ? cs::estimate_rcp_f64((double)q) : 0.0;
+                    const uint64_t rq = cs::double_bits(rqd);
                     w[2 + RL + 2 * r] = (uint32_t)rq; w[2 + RL + 2 * r + 1] = (uint32_t)(rq >> 32);
                     if (q > 0) {
                         const int32_t f = res.fresh32[(int64_t)ng * t.R + r];
-                        const uint32_t e = f >= q ? (uint32_t)f / (uint32_t)q : 0u;
+                        uint32_t e = 0u;
+                        if (f >= q) {
+                            e = (uint32_t)((double)(uint32_t)f * rqd);
+                            const int64_t rem = (int64_t)f - (int64_t)((uint64_t)e * (uint64_t)(uint32_t)q);   // (q may be >= 2^30: 64-bit remainder)
+                            e = rem < 0 ? e - 1u : (rem >= (int64_t)q ? e + 1u : e);
+                        }
                         cf = e < cf ? e : cf;
                     }
                 }
@@ -580,7 +589,7 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
                     const int64_t q = r < t.R ? t.req[(int64_t)g * t.R + r] : 0;
                     simple = simple && q > 0;
                     w[2 + 2 * r] = (uint32_t)(uint64_t)q; w[2 + 2 * r + 1] = (uint32_t)((uint64_t)q >> 32);
-                    const uint64_t rq = cs::double_bits(q > 0 ? 1.0 / (double)q : 0.0);
+                    const uint64_t rq = cs::double_bits(q > 0 ? cs::estimate_rcp_f64((double)q) : 0.0);
                     w[6 + 2 * r] = (uint32_t)rq; w[6 + 2 * r + 1] = (uint32_t)(rq >> 32);
                     if (q > 0) {
                         const int64_t f = t.alloc[(int64_t)ng * t.R + r] - t.init_req[(int64_t)ng * t.R + r];
