@@ -21,7 +21,7 @@ EMU = os.environ.get("CASIM_STRESS_EMU") == "1"
 ctx = EmuContext(0) if EMU else kaa.Context(0)
 if EMU:   # same call shapes as the GPU helpers
     cluster_estimate_gpu = lambda sc, _ctx: cluster_estimate_emu(sc)          # noqa: E731
-    run_gpu = lambda enc, _ctx, fastpath=False: run_emu(enc, fastpath=fastpath)  # noqa: E731
+    run_gpu = lambda enc, _ctx, fastpath=False, generic=False: run_emu(enc, fastpath=fastpath, generic=generic)  # noqa: E731
 t0 = time.time()
 stats = {}
 
@@ -75,6 +75,32 @@ for seed in range(first, first + count):
     sc = scen(w, device_csr=True)
     res, _ = run_gpu(encode(sc), ctx)
     assert_matches_oracle(res, run_oracle(sc), w.name); bump("fuzz_packer_device_lists")
+    # round 4: the register store on int64 lanes (forced on the same scenario; wide lanes that select it by themselves) and the LDS store
+    enc = encode(sc)
+    want = run_oracle(sc)
+    for generic in (2, 1):
+        if EMU:
+            res, _ = run_emu(enc, generic=generic)
+        else:
+            from harness import run_gpu as _run_gpu
+            res, _ = _run_gpu(enc, ctx, generic=generic)
+        assert_matches_oracle(res, want, w.name + f" generic={generic}"); bump(f"fuzz_packer_generic{generic}")
+    enc.close()
+    from test_pack_i64_emu import shape_scenario
+    sc = shape_scenario(seed, 1 << 20, 1024) if seed % 5 else shape_scenario(seed, 1 << 40, 1 << 9)
+    res, _ = run_gpu(encode(sc), ctx)
+    assert_matches_oracle(res, run_oracle(sc), f"wide lanes {seed}"); bump("wide_lanes_int64_store")
+    # round 4: hostname-level required pod affinity inside the template packers (node bits of NEED polarity, the series walked twice)
+    from test_pod_affinity_emu import _batch_affinity_workload
+    from kubernetes_autoscaler_amd.objects import LABEL_HOSTNAME, LABEL_ZONE
+    w, _n = _batch_affinity_workload(1_000_000 + seed, keys=(LABEL_HOSTNAME, LABEL_HOSTNAME, LABEL_HOSTNAME, LABEL_ZONE))
+    fast = seed % 4 == 3
+    sc = scen(w, device_csr=seed % 2 == 0, fastpath=fast)
+    res, _ = run_gpu(encode(sc), ctx, fastpath=fast)
+    if not any(int(x) != 0 for x in res.status):
+        assert_matches_oracle(res, run_oracle(sc), f"hostname affinity {seed}"); bump("hostname_affinity")
+    else:
+        bump("hostname_affinity_other_predicate_delegated")
     # more than two resource lanes in K_sched (every fourth seed)
     if seed % 4 == 0:
         from test_sched_lanes_emu import LANES4, LANES8, with_extra_resources
