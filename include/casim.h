@@ -296,8 +296,9 @@ int32_t casim_problem_fetch(casim_problem* p, casim_results* out);
 int32_t casim_problem_csr(casim_problem* p, int32_t* nnz_out, int32_t* offsets_out);
 
 /* Which build of the register packer serves `device` in this process (csrc/casim_pack_tu.hip: the kernels exist twice, compiled with
- * and without an experimental LLVM option; the first casim_ctx_create on a device runs a built-in corpus of 12 batches through both
- * and retires the option build on any difference).  out[0] = CASIM_PACK_BUILD_PLAIN / _OPTION (AUTO = no context created yet),
+ * and without an experimental LLVM option; right before the first AUTO launch of an instantiation — lanes x node slots x exclusion words — on a
+ * device the library runs that instantiation's 16-18 corpus batches through both builds, ~15 ms, and retires the option build for the process on
+ * any difference; CASIM_PACK_SELFCHECK=eager checks all 18 instantiations, 306 batches, when the first context is created).  out[0] = CASIM_PACK_BUILD_PLAIN / _OPTION (AUTO = no context created yet),
  * [1] = batches compared, [2] = batches that differed, [3] = 1 when the environment forced the build (CASIM_PACK_BUILD=plain|option). */
 int32_t casim_pack_build_info(int32_t device, int32_t out[4]);
 
