@@ -219,6 +219,7 @@ uint64_t tables_hash(const casim_pegs& p, const casim_groups& g) {
     col(p.req, G * R * 8); col(p.count, G * 4); col(p.flags, G * 4); col(p.tol_mask, G * p.w_taint * 8); col(p.sel_mask, G * p.w_label * 8);
     col(p.excl_block, G * p.w_excl * 8); col(p.excl_mark, G * p.w_excl * 8); col(p.zone_block, G * p.w_zone * 8); col(p.zone_mark, G * p.w_zone * 8);
     col(p.zone_polarity, (size_t)p.w_zone * 8);
+    col(p.excl_polarity, (size_t)p.w_excl * 8);
     col(g.alloc, NG * R * 8); col(g.init_req, NG * R * 8); col(g.allowed_pods, NG * 4); col(g.init_pods, NG * 4); col(g.flags, NG * 4);
     col(g.taint_mask, NG * p.w_taint * 8); col(g.label_mask, NG * p.w_label * 8); col(g.init_excl, NG * p.w_excl * 8);
     col(g.init_zone, NG * p.w_zone * 8); col(g.zone_valid, NG * p.w_zone * 8); col(g.max_nodes, NG * 4); col(g.existing_nodes, NG * 4); col(g.last_index, NG * 4);

@@ -24,7 +24,7 @@ def tables_fnv(pegs, groups) -> str:
     G, NG, R = pegs.n_pegs, groups.n_groups, pegs.n_res
     cols = [(pegs.req, G * R, np.int64), (pegs.count, G, np.int32), (pegs.flags, G, np.uint32), (pegs.tol_mask, G * pegs.w_taint, np.uint64),
             (pegs.sel_mask, G * pegs.w_label, np.uint64), (pegs.excl_block, G * pegs.w_excl, np.uint64), (pegs.excl_mark, G * pegs.w_excl, np.uint64),
-            (pegs.zone_block, G * pegs.w_zone, np.uint64), (pegs.zone_mark, G * pegs.w_zone, np.uint64), (pegs.zone_polarity, pegs.w_zone, np.uint64),
+            (pegs.zone_block, G * pegs.w_zone, np.uint64), (pegs.zone_mark, G * pegs.w_zone, np.uint64), (pegs.zone_polarity, pegs.w_zone, np.uint64), (pegs.excl_polarity, pegs.w_excl, np.uint64),
             (groups.alloc, NG * R, np.int64), (groups.init_req, NG * R, np.int64), (groups.allowed_pods, NG, np.int32), (groups.init_pods, NG, np.int32),
             (groups.flags, NG, np.uint32), (groups.taint_mask, NG * pegs.w_taint, np.uint64), (groups.label_mask, NG * pegs.w_label, np.uint64),
             (groups.init_excl, NG * pegs.w_excl, np.uint64), (groups.init_zone, NG * pegs.w_zone, np.uint64), (groups.zone_valid, NG * pegs.w_zone, np.uint64),
