@@ -674,6 +674,14 @@ def main():
                 r["what"] = "enter_return with the caller's tables in page-locked host memory (casim_host_alloc): columns of >= 1 MiB are copied to the device where they lie"
                 return r
             rows["enter_return_pinned_tables"] = _try(_pinned_row)
+            # the Go-compat form (every list comes back) with tables AND result lists page-locked: the prefetch fill of a shim that allocates
+            # its flat arrays through casim_host_alloc
+            def _pinned_all_row():
+                r = enter_return_row(kaa, ctx, batch.tables.pinned(), kinds, K, checks_per_step, max(3, min(args.steps, 10)), res_all, final, winners_only=False,
+                                     pinned_results=True)
+                r["what"] = "enter_return_every_list with the caller's tables and its order / placed arrays in page-locked host memory (casim_host_alloc)"
+                return r
+            rows["enter_return_every_list_pinned"] = _try(_pinned_all_row)
             rows["int64"] = _try(lambda: int64_row(kaa, dev_index, batch.tables, kinds, K, checks_per_step, max(5, min(args.steps, 50)), res_all, final, torch, packer=2))
             rows["int64_lds_store"] = _try(lambda: int64_row(kaa, dev_index, batch.tables, kinds, K, checks_per_step, max(5, min(args.steps, 50)), res_all, final, torch, packer=1))
         extra["headline_rows"] = rows
@@ -772,7 +780,7 @@ def _same_winners(a, b):
     return bool(n == int(lens.sum()) and np.array_equal(ra.order[:n], rb.order[idx]) and np.array_equal(ra.placed[:n], rb.placed[idx]))
 
 
-def enter_return_row(kaa, ctx, tables, kinds, K, checks_per_step, steps, res_resident, exp_resident, winners_only=True):
+def enter_return_row(kaa, ctx, tables, kinds, K, checks_per_step, steps, res_resident, exp_resident, winners_only=True, pinned_results=False):
     """SURVEY 8d's wall time: casim_estimate_batch_query enter -> return — fresh tables packed into pinned memory and copied to
     HBM, kernels, expander reduce, results copied back, EVERY step; the parts of the batch run end to end on the context's internal
     streams (upload of one part under the kernels of another).  winners_only: the per-group scalars and offsets of every
@@ -806,7 +814,7 @@ def enter_return_row(kaa, ctx, tables, kinds, K, checks_per_step, steps, res_res
                 "table_bytes_in": bytes_in, "result_bytes_out": 8 * int(res.winner_offsets[-1]) + 52 * tables.n_groups + 16 * tables.n_sims,
                 "pcie_inclusive": True, "bit_equal_to_resident": _same_winners((res, exp), (res_resident, exp_resident))}
     import gc
-    call = BatchCall(ctx, pegs, groups, kinds=kinds, n_streams=K)
+    call = BatchCall(ctx, pegs, groups, kinds=kinds, n_streams=K, pinned_results=pinned_results)
     call.call_raw()                       # first call: lanes, pools, pinned buffers
     gc.collect(); gc.disable()
     try:

@@ -932,12 +932,14 @@ CS_GLOBAL void count_offsets_kernel(const int32_t* CS_RESTRICT cnt /*[NG]*/, int
     }
     if (cs::tid() == 0) coff[NG] = (int32_t)carry;
 }
+// id_add: a part of a cut batch numbers its PEGs from 0; the caller sees the whole batch's numbering (casim_streams.h) — added here, where the
+// ids pass through registers anyway, instead of by a host loop over millions of fetched entries
 CS_GLOBAL void compact_lists_kernel(const int32_t* CS_RESTRICT off, const int32_t* CS_RESTRICT cnt, const int32_t* CS_RESTRICT coff,
                                     const int32_t* CS_RESTRICT order, const int32_t* CS_RESTRICT placed, int32_t* CS_RESTRICT corder,
-                                    int32_t* CS_RESTRICT cplaced) {
+                                    int32_t* CS_RESTRICT cplaced, int32_t id_add) {
     const int ng = cs::bid();
     const int a = off[ng], n = cnt[ng], c = coff[ng];
-    for (int i = cs::tid(); i < n; i += cs::nthreads()) { corder[c + i] = order[a + i]; cplaced[c + i] = placed[a + i]; }
+    for (int i = cs::tid(); i < n; i += cs::nthreads()) { corder[c + i] = order[a + i] + id_add; cplaced[c + i] = placed[a + i]; }
 }
 
 // ------------------------------------------------------------------------------------------

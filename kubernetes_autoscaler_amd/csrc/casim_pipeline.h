@@ -840,8 +840,9 @@ public:
             if (!d_coff_) { d_coff_ = (int32_t*)dalloc(4 * ((size_t)NG_ + 1)); d_corder_ = (int32_t*)dalloc(4 * ((size_t)nnz_cap_ + 1)); d_cplaced_ = (int32_t*)dalloc(4 * ((size_t)nnz_cap_ + 1)); }
             bk_.launch(count_offsets_kernel, 1, 1, 1024, (size_t)(4 * (1024 / 64 + 2)), (const int32_t*)dt_.peg_cnt, NG_, d_coff_);
             bk_.launch(compact_lists_kernel, NG_, 1, 64, (size_t)0, (const int32_t*)dt_.peg_off, (const int32_t*)dt_.peg_cnt, (const int32_t*)d_coff_,
-                       (const int32_t*)dr_.order, (const int32_t*)dr_.placed, d_corder_, d_cplaced_);
+                       (const int32_t*)dr_.order, (const int32_t*)dr_.placed, d_corder_, d_cplaced_, order_id_base_);
         }
+        fetch_rebased_ = compact;
         const size_t spec_n = !csr_on_device_ ? (size_t)(NG > 0 ? h_off_[NG] : 0) : (size_t)nnz_cap_;
         char* st = (char*)bk_.stage(1, res_bytes_ + (spec ? 8 * spec_n : 0) + 64);
         if (!st) return fail(CASIM_ERR_NOMEM, "no staging buffer");
@@ -1085,6 +1086,10 @@ public:
     int pegs() const { return G_; }
     bool csr_on_device() const { return csr_on_device_; }
     void set_one_shot(bool v) { one_shot_ = v; }   // before init(): see the end of init()
+    // a part of a cut batch: what its PEG ids lack to be the whole batch's (casim_streams.h); fetch adds it on the device where it compacts
+    // the lists anyway and says so (last_fetch_rebased), the other fetch paths leave it to the caller
+    void set_order_id_base(int32_t b) { order_id_base_ = b; }
+    bool last_fetch_rebased() const { return fetch_rebased_; }
     void set_upload_gate(UploadGate* g, int index) { gate_ = g; gate_idx_ = index; gate_passed_ = false; }   // before init(): parts of a streamed batch
     void pass_gate() { if (gate_ && !gate_passed_) { gate_passed_ = true; gate_->pass(gate_idx_); } }
     bool uses_front() const { return front_; }
@@ -1211,6 +1216,7 @@ private:
     bool h_off_fresh_ = false;
     char* up_dev_ = nullptr; char* up_host_ = nullptr; size_t up_cap_ = 0, up_used_ = 0; size_t up_flushed_ = 0; bool up_reserved_ = false;
     int direct_uploads_ = 0;   // columns copied straight from the caller's page-locked arrays
+    int32_t order_id_base_ = 0; bool fetch_rebased_ = false;
     std::vector<uint64_t> zpol_host_, xpol_host_;
     char* res_slab_ = nullptr; size_t res_bytes_ = 0; int32_t* res_off_ = nullptr;
     int32_t* d_node_pods_ = nullptr; std::vector<int64_t> np_off_;

@@ -45,13 +45,16 @@ class BatchResult:
         return self.order[a:b], self.placed[a:b]
 
 
-def alloc_results(n_groups: int, nnz: int, node_pods_capacity: int = 0):
+def alloc_results(n_groups: int, nnz: int, node_pods_capacity: int = 0, pinned_lists: bool = False):
+    """pinned_lists: `order` / `placed` in page-locked memory (casim_host_alloc) — the D2H copy of a big batch then goes straight into
+    them at link speed instead of through the runtime's bounce buffers."""
     ng = max(n_groups, 1)
+    big = (lambda n: pinned_copy(np.zeros(n, np.int32))) if pinned_lists else (lambda n: np.zeros(n, np.int32))
     arrs = dict(
         node_count=np.zeros(ng, np.int32), pods_scheduled=np.zeros(ng, np.int32), nodes_added=np.zeros(ng, np.int32),
         limiter_nodes=np.zeros(ng, np.int32), last_index_out=np.zeros(ng, np.int32), status=np.zeros(ng, np.int32),
         req_cpu_sum=np.zeros(ng, np.int64), req_mem_sum=np.zeros(ng, np.int64),
-        order=np.zeros(max(nnz, 1), np.int32), placed=np.zeros(max(nnz, 1), np.int32))
+        order=big(max(nnz, 1)), placed=big(max(nnz, 1)))
     st = _abi.Results(
         node_count=_ptr(arrs["node_count"], C.c_int32), pods_scheduled=_ptr(arrs["pods_scheduled"], C.c_int32),
         nodes_added=_ptr(arrs["nodes_added"], C.c_int32), limiter_nodes=_ptr(arrs["limiter_nodes"], C.c_int32),
@@ -614,14 +617,14 @@ class BatchCall:
     the context's internal streams.  call() returns (BatchResult, expander dict or None)."""
 
     def __init__(self, ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, kinds: Optional[Sequence[int]] = None, fastpath: bool = False,
-                 force_generic_packer: bool = False, n_streams: int = 0, winners_only: bool = False):
+                 force_generic_packer: bool = False, n_streams: int = 0, winners_only: bool = False, pinned_results: bool = False):
         """winners_only (casim_options.winners_only): order / placed come back for the winning group of every simulation only —
         call() then returns a BatchResult whose `order` / `placed` are those compact lists and whose `winner_offsets` [S + 1] says where
         simulation s's list sits (see winners_view)."""
         self.ctx, self.pegs, self.groups = ctx, pegs, groups
         ng = groups.n_groups
         self.winners_only = bool(winners_only)
-        self.st, self.arrs = alloc_results(ng, _nnz_cap(pegs, groups))
+        self.st, self.arrs = alloc_results(ng, _nnz_cap(pegs, groups), pinned_lists=pinned_results)
         self.opts = _abi.Options(fastpath=int(fastpath), force_generic_packer=int(force_generic_packer), n_streams=int(n_streams),
                                  winners_only=int(self.winners_only))
         self.off = np.zeros(ng + 1, np.int32)
