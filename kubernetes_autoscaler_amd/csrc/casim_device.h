@@ -60,6 +60,7 @@ CS_DEVICE bool lane_pred(uint64_t mask) { return ((mask >> (casim_emu::cur().tid
 CS_DEVICE void keep_scalar(uint32_t&) {}
 CS_DEVICE void keep_apart() {}
 CS_DEVICE double estimate_rcp_f64(double x) { return 1.0 / x; }
+template <class T> CS_DEVICE const T& kernarg_view(const T& param, size_t) { return param; }
 CS_DEVICE int32_t opaque_i32(int32_t v) { return v; }
 CS_DEVICE void consume_u32(uint32_t) {}
 CS_DEVICE bool flag_set(uint32_t word, uint32_t bit) { return (word & bit) != 0; }
@@ -248,6 +249,20 @@ CS_DEVICE uint32_t uniform_div_u32(uint32_t a, uint32_t b) {
     const uint64_t wide = (uint64_t)q * vb;   // (b may exceed 2^31: the fix-up compares the 64-bit product)
     q = wide > va ? q - 1 : ((uint64_t)va - wide >= vb ? q + 1 : q);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+}
+// A kernel's by-value struct parameter, read again from the KERNARG SEGMENT (scalar loads through the constant cache) instead of from the
+// scalar registers the prologue loaded it into.  Why: DevTables + DevResults are ~70 pointers; a kernel that needs a third of them at its
+// END (order_group's record emission) keeps them live across everything in front of it, and the register allocator parks what does not
+// fit in the lanes of a VGPR — order_strided_kernel re-read 28 parked pointers with 2 500 static v_readlane_b32, a quarter of its
+// straight-line vector instructions.  A fresh view (the pointer is laundered, so nothing is shared with earlier loads) gives every use a
+// short-lived s_load.  `byte_offset` = the parameter's offset in the explicit kernel arguments (declaration order, natural alignment).
+template <class T> CS_DEVICE const T& kernarg_view(const T&, size_t byte_offset) {
+    const uint64_t a = (uint64_t)(const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    // (through readfirstlane: inside a loop the compiler takes for divergent a plain "+s" copy of the pointer is an illegal VGPR -> SGPR move)
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    const __attribute__((address_space(4))) char* p = (const __attribute__((address_space(4))) char*)(((uint64_t)hi << 32) | lo);
+    return *(const T*)(const char*)(p + byte_offset);
 }
 // 1 / x as a quotient ESTIMATE (relative error ~2^-50: v_rcp_f64 + one Newton step, 3 instructions) — for the +-1 fix-up forms of
 // capacity_of / the packer, whose proof asks for 2^-51.  An IEEE division is ~15 instructions (v_div_scale x 2, v_rcp, 5 FMAs,

@@ -515,6 +515,10 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
         if (top >= 0) best = (int)(uint32_t)(top & 0xffffffffll);
         barrier();
     }
+    // (the tables and result arrays through a fresh view of the kernel arguments: see cs::kernarg_view — every kernel that calls order_group
+    // declares (DevTables, DevResults, ...) first)
+    const DevTables& te_ = cs::kernarg_view(t, 0);
+    const DevResults& re_ = cs::kernarg_view(res, (sizeof(DevTables) + 7) & ~(size_t)7);
 #pragma unroll
     for (int i = tid; i < (NPAD > 0 ? NPAD : Gn); i += nt) {
         if (NPAD > 0 && i >= Gn) continue;
@@ -528,10 +532,10 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
         // The template-level Filters (taints, nodeSelector / affinity, unschedulable) are constant per
         // (PEG, group): evaluate them once here and hand them over as one flag bit.
         const int g = gid[pos[src]];
-        res.order[off + i] = g;
+        re_.order[off + i] = g;
         // (lists derived by the feasibility kernel only hold PEGs that passed these Filters already)
-        const uint32_t flags = (t.pflags[g] & ~CASIM_KFLAG_STATIC_OK) | ((t.lists_from_feas || static_filters_pass(t, g, ng)) ? CASIM_KFLAG_STATIC_OK : 0u);
-        if (res.rec) {
+        const uint32_t flags = (te_.pflags[g] & ~CASIM_KFLAG_STATIC_OK) | ((te_.lists_from_feas || static_filters_pass(te_, g, ng)) ? CASIM_KFLAG_STATIC_OK : 0u);
+        if (re_.rec) {
             // register packer: one record (casim_types.h) = everything the packer needs to know about the PEG, computed HERE
             // by the record's own thread — the scaled requests, their reciprocals (the packer's quotient estimate) and how
             // many pods of the PEG fit an EMPTY node of this group (fitsRequest on the template, fit.go:681-765)
@@ -540,12 +544,12 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
                 uint32_t w[DW];
 #pragma unroll
                 for (int k = 0; k < DW; ++k) w[k] = 0;
-                const int32_t slots = t.allowed[ng] - t.init_pods[ng];
+                const int32_t slots = te_.allowed[ng] - te_.init_pods[ng];
                 uint32_t cf = slots > 0 ? (uint32_t)slots : 0u;
                 bool simple = true;
 #pragma unroll
                 for (int r = 0; r < RL; ++r) {
-                    const int32_t q = r < t.R ? res.req32[(int64_t)g * t.R + r] : 0;
+                    const int32_t q = r < te_.R ? re_.req32[(int64_t)g * te_.R + r] : 0;
                     simple = simple && q > 0 && q < (1 << 30);
                     w[2 + r] = (uint32_t)q;
                     // (the reciprocal is only ever a quotient estimate with an exact +-1 fix-up behind it: no IEEE division — 4 of them per lane
@@ -555,7 +559,7 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
                     const uint64_t rq = cs::double_bits(rqd);
                     w[2 + RL + 2 * r] = (uint32_t)rq; w[2 + RL + 2 * r + 1] = (uint32_t)(rq >> 32);
                     if (q > 0) {
-                        const int32_t f = res.fresh32[(int64_t)ng * t.R + r];
+                        const int32_t f = re_.fresh32[(int64_t)ng * te_.R + r];
                         uint32_t e = 0u;
                         if (f >= q) {
                             e = (uint32_t)((double)(uint32_t)f * rqd);
@@ -565,14 +569,14 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
                         cf = e < cf ? e : cf;
                     }
                 }
-                w[0] = (uint32_t)t.count[g];
+                w[0] = (uint32_t)te_.count[g];
                 if (!(flags & CASIM_KFLAG_STATIC_OK)) cf = 0u;   // the template-level Filters fail: no pod of the PEG fits an empty node of this group (the packer's a3 reads only this)
                 // (RunFiltersUntilPassingNode skips Spec.Unschedulable nodes before any Filter runs, plugin_runner.go:108-110: in such a group the
                 // simulated nodes are never worth a visit — decided here, the packer tests ONE constant bit)
-                const bool a2_ok = (flags & CASIM_KFLAG_STATIC_OK) && t.count[g] > 0 && !(t.gflags[ng] & CASIM_NG_UNSCHEDULABLE);
+                const bool a2_ok = (flags & CASIM_KFLAG_STATIC_OK) && te_.count[g] > 0 && !(te_.gflags[ng] & CASIM_NG_UNSCHEDULABLE);
                 w[1] = (flags & (CASIM_REC_FLAG_MASK & ~(CASIM_REC_SIMPLE | CASIM_REC_A2_OK))) | (cf << CASIM_REC_FRESH_SHIFT) | (simple ? CASIM_REC_SIMPLE : 0u) |
                        (a2_ok ? CASIM_REC_A2_OK : 0u) | ((a2_ok && simple) ? CASIM_REC_A2_SIMPLE : 0u);
-                RecQuad* out = (RecQuad*)(res.rec + (int64_t)(off + i) * DW);   // 16-byte stores (records are 32 / 64 bytes)
+                RecQuad* out = (RecQuad*)(re_.rec + (int64_t)(off + i) * DW);   // 16-byte stores (records are 32 / 64 bytes)
 #pragma unroll
                 for (int k = 0; k < DW / 4; ++k) out[k] = RecQuad{w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]};
             };
@@ -581,39 +585,39 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
                 uint32_t w[16];
 #pragma unroll
                 for (int k = 0; k < 16; ++k) w[k] = 0;
-                const int32_t slots = t.allowed[ng] - t.init_pods[ng];
+                const int32_t slots = te_.allowed[ng] - te_.init_pods[ng];
                 uint32_t cf = slots > 0 ? (uint32_t)slots : 0u;
                 bool simple = true;
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
-                    const int64_t q = r < t.R ? t.req[(int64_t)g * t.R + r] : 0;
+                    const int64_t q = r < te_.R ? te_.req[(int64_t)g * te_.R + r] : 0;
                     simple = simple && q > 0;
                     w[2 + 2 * r] = (uint32_t)(uint64_t)q; w[2 + 2 * r + 1] = (uint32_t)((uint64_t)q >> 32);
                     const uint64_t rq = cs::double_bits(q > 0 ? cs::estimate_rcp_f64((double)q) : 0.0);
                     w[6 + 2 * r] = (uint32_t)rq; w[6 + 2 * r + 1] = (uint32_t)(rq >> 32);
                     if (q > 0) {
-                        const int64_t f = t.alloc[(int64_t)ng * t.R + r] - t.init_req[(int64_t)ng * t.R + r];
+                        const int64_t f = te_.alloc[(int64_t)ng * te_.R + r] - te_.init_req[(int64_t)ng * te_.R + r];
                         const uint64_t e = f >= q ? (uint64_t)f / (uint64_t)q : 0ull;
                         cf = e < (uint64_t)cf ? (uint32_t)e : cf;
                     }
                 }
-                w[0] = (uint32_t)t.count[g];
+                w[0] = (uint32_t)te_.count[g];
                 if (!(flags & CASIM_KFLAG_STATIC_OK)) cf = 0u;   // the template-level Filters fail: no pod of the PEG fits an empty node of this group (the packer's a3 reads only this)
                 // (RunFiltersUntilPassingNode skips Spec.Unschedulable nodes before any Filter runs, plugin_runner.go:108-110: in such a group the
                 // simulated nodes are never worth a visit — decided here, the packer tests ONE constant bit)
-                const bool a2_ok = (flags & CASIM_KFLAG_STATIC_OK) && t.count[g] > 0 && !(t.gflags[ng] & CASIM_NG_UNSCHEDULABLE);
+                const bool a2_ok = (flags & CASIM_KFLAG_STATIC_OK) && te_.count[g] > 0 && !(te_.gflags[ng] & CASIM_NG_UNSCHEDULABLE);
                 w[1] = (flags & (CASIM_REC_FLAG_MASK & ~(CASIM_REC_SIMPLE | CASIM_REC_A2_OK))) | (cf << CASIM_REC_FRESH_SHIFT) | (simple ? CASIM_REC_SIMPLE : 0u) |
                        (a2_ok ? CASIM_REC_A2_OK : 0u) | ((a2_ok && simple) ? CASIM_REC_A2_SIMPLE : 0u);
-                RecQuad* out = (RecQuad*)(res.rec + (int64_t)(off + i) * 16);
+                RecQuad* out = (RecQuad*)(re_.rec + (int64_t)(off + i) * 16);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) out[k] = RecQuad{w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]};
             };
-            if (res.rec_i64) emit64(); else if (res.rec_dw == 8) emit(IntTag<2>{}); else emit(IntTag<4>{});
+            if (re_.rec_i64) emit64(); else if (re_.rec_dw == 8) emit(IntTag<2>{}); else emit(IntTag<4>{});
         }
-        if (res.s_count) {   // the generic packer's three arrays (also next to the records when it stands by for retries)
-            res.s_count[off + i] = t.count[g];
-            res.s_flags[off + i] = flags;
-            for (int r = 0; r < t.R; ++r) res.s_req[(int64_t)(off + i) * t.R + r] = t.req[(int64_t)g * t.R + r];
+        if (re_.s_count) {   // the generic packer's three arrays (also next to the records when it stands by for retries)
+            re_.s_count[off + i] = te_.count[g];
+            re_.s_flags[off + i] = flags;
+            for (int r = 0; r < te_.R; ++r) re_.s_req[(int64_t)(off + i) * te_.R + r] = te_.req[(int64_t)g * te_.R + r];
         }
     }
     if (tid == 0) res.fast_last[ng] = best >= 0 ? 1 : 0;

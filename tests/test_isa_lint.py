@@ -68,3 +68,25 @@ def test_no_packer_instantiation_spills(packer_asm):
     """every instantiation (int32 2 / 4 lanes, int64 lanes x 1 / 4 / 16 slots x without / with exclusion words): no scratch"""
     sizes = re.findall(r"\.private_segment_fixed_size:\s+(\d+)", packer_asm)
     assert len(sizes) >= 18 and all(int(x) == 0 for x in sizes), sizes
+
+
+def test_order_kernel_parks_no_pointers_in_vgpr_lanes(tmp_path):
+    """order_strided_kernel keeps ~70 table / result pointers in its arguments and needs a third of them at its END (the record emission):
+    carried across the sorting network they did not fit the scalar register file, the allocator parked 28 of them in the lanes of a VGPR
+    and the kernel re-read them with 2 500 static v_readlane_b32 — a quarter of its straight-line vector instructions.  The emission now
+    reads the arguments through cs::kernarg_view (fresh scalar loads from the kernarg segment): no parked registers."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    src = tmp_path / "order_tu.hip"
+    src.write_text('#include <hip/hip_runtime.h>\n#include "%s"\n#include "%s"\n'
+                   'template __global__ void casim::order_strided_kernel<true>(DevTables, DevResults, OrderScratch, const uint64_t*, int, int32_t*, int32_t*);\n'
+                   % (os.path.join(ROOT, "include", "casim.h"), os.path.join(ROOT, "kubernetes_autoscaler_amd", "csrc", "casim_kernels.h")))
+    out = tmp_path / "order_tu.s"
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "--cuda-device-only", "-S", "-o", str(out), str(src)],
+                   check=True, timeout=600, stderr=subprocess.DEVNULL)
+    k = _kernel_text(open(out).read(), "_ZN5casim20order_strided_kernel")
+    ops = [l.strip().split()[0] for l in k if l.startswith("\t") and not l.strip().startswith((";", "."))]
+    parked_reads = sum(1 for l in k if re.search(r"\tv_readlane_b32 s\d+, v\d+, \d+$", l))     # constant lane: a parked scalar coming back
+    assert ops.count("v_writelane_b32") == 0 and parked_reads == 0, (ops.count("v_writelane_b32"), parked_reads)
+    assert sum(1 for o in ops if o.startswith("v_")) <= 8600     # 7 839 (10 588 with the parked pointers)
+    assert not any(o.startswith("scratch_") for o in ops)
