@@ -132,6 +132,9 @@ CS_GLOBAL void feas_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg]*/,
 // The group records of the simulation are staged in LDS first (dynamic LDS: 128 bytes per group of the largest simulation): one
 // coalesced load phase per block, then every group costs a few LDS broadcast reads — as global loads behind the `bits` store
 // of the previous group each field was its own dependent round trip (0.146 ms at 4096 x 20 groups, three times the issue time).
+// kLean: the batch carries no exclusion words of either kind and at most two (narrowed) resource lanes — the headline's shape: the cell loses
+// its two mask tests and the compares of lanes 2 and 3 (12 of ~41 vector instructions per group and wave)
+template <bool kLean>
 CS_GLOBAL void feas_sim_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg]*/, int Wg, const int32_t* CS_RESTRICT req32,
                                const int32_t* CS_RESTRICT fresh32) {
     const int sim = cs::bid_y();
@@ -183,15 +186,18 @@ CS_GLOBAL void feas_sim_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg
     for (int ng = g0; ng < g1; ++ng) {
         const uint64_t* gr = grec + (int64_t)(ng - g0) * 16;   // wave-uniform address: LDS broadcast reads
         const uint64_t fl = gr[4];
-        bool ok = live & ((gr[0] & ~tol) == 0) & ((sel & ~gr[1]) == 0) & ((xb & gr[2]) == 0) & ((zb & gr[3]) == 0);
+        bool ok = live & ((gr[0] & ~tol) == 0) & ((sel & ~gr[1]) == 0);
+        if constexpr (!kLean) ok = ok & ((xb & gr[2]) == 0) & ((zb & gr[3]) == 0);
         ok = ok & (tolerates_unsched | (((uint32_t)fl & CASIM_NG_UNSCHEDULABLE) == 0));
         ok = ok & ((int32_t)(fl >> 32) > 0);                                      // fitsRequest: pod count first (fit.go:681-690)
         if (narrow) {   // wave-uniform; lanes past R carry a zero request, which passes
             const uint64_t f01 = gr[5], f23 = gr[6];
             bool fit = (rq32[0] <= 0) | (rq32[0] <= (int32_t)(uint32_t)f01);
             fit = fit & ((rq32[1] <= 0) | (rq32[1] <= (int32_t)(f01 >> 32)));
-            fit = fit & ((rq32[2] <= 0) | (rq32[2] <= (int32_t)(uint32_t)f23));
-            fit = fit & ((rq32[3] <= 0) | (rq32[3] <= (int32_t)(f23 >> 32)));
+            if constexpr (!kLean) {
+                fit = fit & ((rq32[2] <= 0) | (rq32[2] <= (int32_t)(uint32_t)f23));
+                fit = fit & ((rq32[3] <= 0) | (rq32[3] <= (int32_t)(f23 >> 32)));
+            }
             ok = ok & fit;   // (a pod without requests, whose lane tests the reference skips, :699, passes every one of them)
         } else {
             bool fit = true;

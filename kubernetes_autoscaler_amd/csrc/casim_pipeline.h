@@ -681,12 +681,12 @@ public:
             return CASIM_OK;
         }
         if (strided_) {   // rows by feas_sim_kernel; run_order() builds and orders the lists (order_strided_kernel): no scan, no fill
-            bk_.launch(feas_sim_kernel, (feas_len_ + 255) / 256, n_sims_, 256, (size_t)128 * (size_t)max_sim_groups_, dt_, d_bits_, Wg_,
+            launch_feas_sim((feas_len_ + 255) / 256, n_sims_, 256, (size_t)128 * (size_t)max_sim_groups_, dt_, d_bits_, Wg_,
                        fast_npt_ > 0 ? fs_.req32 : (const int32_t*)nullptr, fast_npt_ > 0 ? fs_.fresh32 : (const int32_t*)nullptr);
             return CASIM_OK;
         }
         if (feas_len_ > 0) {
-            if (feas_by_sim_) bk_.launch(feas_sim_kernel, (feas_len_ + 255) / 256, n_sims_, 256, (size_t)128 * (size_t)max_sim_groups_, dt_, d_bits_, Wg_,
+            if (feas_by_sim_) launch_feas_sim((feas_len_ + 255) / 256, n_sims_, 256, (size_t)128 * (size_t)max_sim_groups_, dt_, d_bits_, Wg_,
                                          fast_npt_ > 0 ? fs_.req32 : (const int32_t*)nullptr, fast_npt_ > 0 ? fs_.fresh32 : (const int32_t*)nullptr);
             else bk_.launch(feas_kernel, (feas_len_ + 255) / 256, NG_, 256, (size_t)0, dt_, d_bits_, Wg_);
         }
@@ -1100,6 +1100,12 @@ public:
     static constexpr int kOrderThreads = 256;
 
 private:
+    // the lean instantiation for batches without exclusion words whose (at most two) lanes are narrowed to int32: the headline's shape
+    void launch_feas_sim(int gx, int gy, int block, size_t smem, const DevTables& t, uint64_t* bits, int wg, const int32_t* req32, const int32_t* fresh32) {
+        const bool lean = t.Wx == 0 && t.Wz == 0 && t.R <= 2 && req32 != nullptr;
+        if (lean) bk_.launch(feas_sim_kernel<true>, gx, gy, block, smem, t, bits, wg, req32, fresh32);
+        else bk_.launch(feas_sim_kernel<false>, gx, gy, block, smem, t, bits, wg, req32, fresh32);
+    }
     // Uploads between begin_uploads() and end_uploads() are packed: the bytes go to the backend's staging buffer right away
     // (the caller's array may die), the device pointer is a slice of ONE slab, and end_uploads() issues the one copy.
     void begin_uploads(size_t bound) {
