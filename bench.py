@@ -790,8 +790,8 @@ def enter_return_row(kaa, ctx, tables, kinds, K, checks_per_step, steps, res_res
     pegs, groups = tables.structs()
     if winners_only:
         call = BatchCall(ctx, pegs, groups, kinds=kinds, n_streams=K, winners_only=True)
-        for _ in range(3):                # first calls: lanes' pools and pinned buffers grow to this call's sizes
-            call.call_raw()
+        for _ in range(8):                # first calls: lanes' pools and pinned buffers grow to this call's sizes (a 15 ms call still showed up
+            call.call_raw()               # among the first seven after three warm-up calls: tests/tools/enter_return_outliers.py)
         # (the interpreter's cyclic GC is parked for the timed calls: this process holds millions of workload objects, and a full collection
         # in the middle of a call showed up as one 10-16 ms call in ten — the harness's pause, not the library's)
         import gc

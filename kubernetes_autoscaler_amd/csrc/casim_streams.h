@@ -66,8 +66,11 @@ public:
         n_groups_ = g->n_groups; n_sims_ = S; has_gid_ = g->global_id != nullptr;
         parts_.clear(); parts_.resize((size_t)K);
         for (int i = 0; i < K; ++i) cut(parts_[(size_t)i], p, g, (int)((int64_t)S * i / K), (int)((int64_t)S * (i + 1) / K));
-        UploadGate gate;   // the parts take the link in turn (casim_pipeline.h: UploadGate); CASIM_UPLOAD_GATE=0: all at once, as until round 4
-        static const bool use_gate = !(getenv("CASIM_UPLOAD_GATE") && atoi(getenv("CASIM_UPLOAD_GATE")) == 0);
+        // CASIM_UPLOAD_GATE=1: the parts take the link in turn (casim_pipeline.h: UploadGate).  Built in round 4 and measured neutral then (3.54 vs
+        // 3.56 ms per headline call); with the direct uploads and the shorter kernels of the end of the round the uploads all at once are 9 %
+        // faster (3.27-3.37 against 3.60-3.66 ms, three alternating processes of 100 calls each, profiles/r09h_upload_gate_ab.txt): off by default
+        UploadGate gate;
+        static const bool use_gate = getenv("CASIM_UPLOAD_GATE") && atoi(getenv("CASIM_UPLOAD_GATE")) != 0;
         auto work = [&](int i) {
             Part& pt = parts_[(size_t)i];
             lanes_[(size_t)i]->bind();
