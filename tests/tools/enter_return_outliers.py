@@ -9,7 +9,7 @@ from kubernetes_autoscaler_amd.tables import TableSet
 full = bench.simulation_tables(workloads.CONFIGS["C2"], range(64), kaa.Encoder, TableSet).tile(64).head(4096)
 ctx = kaa.Context(0)
 gc.collect(); gc.disable()
-call = BatchCall(ctx, *full.structs(), kinds=[_abi.EXPANDER_LEAST_NODES], n_streams=4, winners_only=True)
+call = BatchCall(ctx, *full.structs(), kinds=[_abi.EXPANDER_LEAST_NODES], n_streams=int(sys.argv[1]) if len(sys.argv) > 1 else 4, winners_only=True)
 for _ in range(10): call.call_raw()
 seq = []
 for i in range(100):
