@@ -30,6 +30,10 @@ import subprocess
 import sys
 import time
 
+# One hardware queue per internal stream of a streamed batch: the HOST's setting, made here — before anything
+# initialises the HIP runtime — because libcasim no longer edits the process environment by itself.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
@@ -458,6 +462,8 @@ def compact_line(out, side_file=SIDE_FILE):
     if isinstance(out.get("roofline_feasibility"), dict):
         line["roofline_feasibility"] = _pick(out["roofline_feasibility"], ("bound", "kernel", "kernel_ms", "algorithmic_bytes_per_launch", "traffic", "achieved",
                                                                           "peak", "unit", "frac", "workload", "kernel_ms_in_loop", "bit_exact"))
+    if isinstance(out.get("roofline_feasibility_c3"), dict):
+        line["roofline_feasibility_c3"] = _pick(out["roofline_feasibility_c3"], ("kernel", "kernel_ms", "algorithmic_bytes_per_launch", "traffic", "achieved", "frac", "bit_exact"))
     cpu = out.get("cpu_baseline")
     line["cpu_baseline"] = _pick(cpu, ("value", "unit", "cores", "kind", "label", "sample", "sims_per_s")) if isinstance(cpu, dict) else None
     allc = out.get("cpu_baseline_all_cores")
@@ -531,6 +537,7 @@ def main():
     ap.add_argument("--no-dense", action="store_true", help="(accepted for old scripts; the dense probe kernel was retired in round 2)")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the TrySchedulePods / node-removal side measurements")
     ap.add_argument("--no-c3", action="store_true")
+    ap.add_argument("--no-feasibility-row", action="store_true", help="skip the batched feasibility launches of roofline_feasibility")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -808,6 +815,13 @@ def main():
                 extra.update(_try(lambda: next_rows(kaa, ctx, workloads)) or {})
             if not args.no_c3:
                 extra["c3_in_process_multi_device"] = _try(lambda: in_process_multi_device(kaa, workloads, kinds))
+            if not args.no_feasibility_row:
+                # the HBM roofline on the kernel that can carry it: the batched feasibility launch, C2 and C3 shapes
+                torch.cuda.synchronize()
+                extra["roofline_feasibility"] = _try(lambda: feasibility_roofline(kaa, ctx, workloads, TableSet, "C2", 16384, 64, verify=not args.no_verify))
+                extra["roofline_feasibility_c3"] = _try(lambda: feasibility_roofline(kaa, ctx, workloads, TableSet, "C3", 1024, 8, verify=not args.no_verify))
+                if isinstance(extra.get("roofline_feasibility"), dict):
+                    extra["roofline_feasibility"]["kernel_ms_in_loop"] = kms.get("feasibility_csr_ms")
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(workloads, make, range(min(S, 8)), checks_per_sim)
@@ -845,6 +859,57 @@ def main():
     if out is not None:
         emit(out)   # the contract line is the last thing this process writes to stdout
     return out
+
+
+def feasibility_bytes(ts, lean):
+    """Algorithmic bytes of ONE feas_stream_kernel launch over the table set (P x Bp + N x Bn + ceil(P x N / 8) with the record
+    sizes of the kernel that runs): per PEG the columns a cell needs as the kernel reads them — 4 B per narrowed
+    request lane, 4 B flags, one 8-byte word per mask kind; per group its 64-byte record; per (group, 64 PEGs) one 8-byte ballot word."""
+    d = ts.dims
+    lanes = min(d["n_res"], 2 if lean else 4)
+    Bp = 4 * lanes + 4 + 8 * (1 if d["w_taint"] else 0) + 8 * (1 if d["w_label"] else 0) + (0 if lean else 16 * (1 if d["w_excl"] else 0) + 8 * (1 if d["w_zone"] else 0))
+    Bn = 64
+    import numpy as np
+    words = (np.asarray(ts.peg_hi, np.int64) - np.asarray(ts.peg_lo, np.int64) + 63) // 64
+    out = int(words.sum()) * 8
+    return ts.n_pegs * Bp + ts.n_groups * Bn + out, Bp, Bn, out
+
+
+def feasibility_roofline(kaa, ctx, workloads, TableSet, config, n_sims, n_seeds, iters=50, verify=True):
+    """The HBM-roofline row BASELINE.md section 4 asks for, on the kernel that can carry it (VERDICT r4 missing #5): the SchedulablePodGroups
+    matrix of a BATCHED launch — `n_sims` simulations of `config` (n_seeds distinct ones, tiled), one launch of feas_stream_kernel — timed
+    alone (casim_problem_time_feasibility: `iters` launches back to back between two HIP events), algorithmic bytes per launch from the
+    tables, and the whole problem's results checked against the oracle (every group of every tile)."""
+    make = workloads.CONFIGS[config]
+    ts = simulation_tables(make, range(n_seeds), kaa.Encoder, TableSet).tile((n_sims + n_seeds - 1) // n_seeds).head(n_sims)
+    pegs, groups = ts.structs()
+    with kaa.Problem(ctx, pegs, groups) as prob:
+        ms, info = prob.time_feasibility(iters)
+        row = {"bound": "hbm", "workload": f"{config} x {n_sims} simulations in ONE launch ({ts.n_pegs} PEGs, {ts.n_groups} node groups; {n_seeds} distinct seeds tiled)",
+               "kernel": ("feas_stream_kernel<%s, %s>" % ("lean" if info["lean"] else "full", "mask31" if info["mask31"] else "mask64")) if info["stream"] else "feas_sim_kernel",
+               "kernel_ms": ms, "workgroups": info["workgroups"], "launches_timed": iters, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None}
+        b, Bp, Bn, out = feasibility_bytes(ts, info["lean"])
+        row.update({"algorithmic_bytes_per_launch": b, "bytes_per_peg": Bp, "bytes_per_group_record": Bn, "bytes_written": out,
+                    "achieved": b / (ms * 1e-3) / 1e9, "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "cells_per_launch": int(((ts.peg_hi - ts.peg_lo).astype("int64")).sum()),
+                    "bytes_note": "per PEG the columns the cell needs as the kernel reads them (narrowed int32 request lanes, flags, one word per mask kind), "
+                                  "per group its 64-byte record, one bit per cell; the int64 boundary tables (16 B of requests per PEG instead of 8) are narrowed once per problem at init"})
+        if verify:
+            prob.run()
+            res = prob.fetch()
+            chk = verify_headline(workloads, make, n_seeds, ts, res)
+            row["bit_exact"] = bool(chk["headline_bit_exact"]); row["groups_compared"] = chk["groups_compared"]
+    try:   # counters of the same kernel and launch size, when a PMC pass has been committed (tools/feas_traffic.py)
+        tr = json.load(open(os.path.join(ROOT, "profiles", "feas_traffic.json")))
+        for r in tr.get("rows", []):
+            if r.get("workgroups") == row["workgroups"] and r.get("kernel_tag") == row["kernel"]:
+                row["traffic"] = r.get("traffic_bytes_per_launch"); row["traffic_source"] = "profiles/feas_traffic.json (%s)" % tr.get("run", "?")
+                for k in ("valu_insts_per_launch", "salu_insts_per_launch", "kernel_ms_rocprof"):
+                    if k in r:
+                        row[k] = r[k]
+    except (OSError, ValueError, KeyError):
+        pass
+    return row
 
 
 def _same_results(a, b):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CASIM_ABI_VERSION 8   /* 2: casim_removal_candidates.cand_atomic, casim_domain_rules.n_taint_policy_rules
+#define CASIM_ABI_VERSION 9   /* 2: casim_removal_candidates.cand_atomic, casim_domain_rules.n_taint_policy_rules
                                * 3: casim_groups.{peg_lo,peg_hi,global_id,n_sims,sim_offsets}, casim_best_option_sims,
                                *    casim_feasibility_reasons, casim_estimate_batch_timed, casim_mctx_*, casim_cluster_*
                                * 4: casim_options.n_streams (sub-batches on internal HIP streams), casim_enc_group_pods,
@@ -60,6 +60,9 @@ extern "C" {
 #define CASIM_ERR_NO_DEVICE (-3)    /* no gfx950 device visible: the engine NEVER falls   */
                                     /* back to a CPU path                                  */
 #define CASIM_ERR_NOMEM (-4)
+#define CASIM_ERR_NO_LANE (-5)      /* casim_enc_lane: every resource lane (CASIM_MAX_RES) is taken   */
+#define CASIM_ENC_DELEGATED 1       /* casim_enc_pod_set_request / casim_enc_group_set_allocatable: no lane left for the name — the pod spec
+                                       was marked CASIM_PEG_UNSUPPORTED (the allocatable entry dropped); not an error                  */
 /* per node-group status written to casim_results.status                                  */
 #define CASIM_NG_OK 0
 #define CASIM_NG_UNSUPPORTED 1      /* a PEG of this group needs a predicate outside the   */
@@ -179,10 +182,11 @@ typedef struct casim_options {
                                      casim_best_option_sims with dev_* outputs joins into it (work enqueued there afterwards sees
                                      the keys); host outputs / casim_problem_fetch synchronise.  Batches that cannot be cut (one
                                      simulation, explicit peg_offsets, node_pods) run as one part; casim_problem_info [4] tells.
-                                     PROCESS-WIDE SIDE EFFECT of loading the library: its constructor calls
-                                     setenv("GPU_MAX_HW_QUEUES", "8", overwrite = 0) so that the internal streams get hardware queues of
-                                     their own; CASIM_KEEP_ENV=1 (or setting the variable yourself) before the library loads keeps the
-                                     process environment untouched — the context then uses the queues there are (fewer parts). */
+                                     The internal streams want hardware queues of their own: export GPU_MAX_HW_QUEUES=8 in the host's
+                                     environment before the process makes its first HIP call.  The library
+                                     does NOT edit the process environment by itself; CASIM_SET_HW_QUEUES=1 opts in to its load-time
+                                     constructor doing setenv("GPU_MAX_HW_QUEUES", "8", overwrite = 0).  Without either the context
+                                     uses the queues there are (fewer concurrent parts; casim_problem_info [4], [6]). */
     int32_t pack_build;           /* which build of the register packer runs (csrc/casim_pack_tu.hip): CASIM_PACK_BUILD_AUTO (0, default) = the
                                      one the library's self-check left standing for the device, _PLAIN = compiled without the
                                      experimental LLVM option, _OPTION = compiled with it; see casim_pack_build_info */
@@ -204,6 +208,18 @@ typedef struct casim_options {
                                      MB instead of 8 bytes per (group, PEG) pair; the per-group scalars and offsets_out stay complete.  A caller
                                      that serves every group's Estimate() from the batch (the prefetch cache of the Go shim) keeps 0.  Implies
                                      no_singleton_merge.  (Took the last reserved word of ABI 6: zero keeps its meaning.) */
+    int32_t chain_last_index;     /* ABI 9.  1 = the groups of ONE simulation are estimated AS IF one after the other, in table order, each starting from
+                                     the lastIndex its predecessor left: group i of a simulation runs with last_index_out of group i - 1 (the first
+                                     group with casim_groups.last_index of its own; the column's other entries are ignored).  This is what the
+                                     reference does when the orchestrator calls Estimate() group after group on one snapshot: lastIndex lives in
+                                     the snapshot's plugin runner (CA/simulator/clustersnapshot/predicate/plugin_runner.go:138,
+                                     predicate_snapshot.go:64) and is never reverted.  A group that comes back CASIM_NG_UNSUPPORTED hands its input
+                                     on unchanged.  Default 0: every group starts from its own last_index entry (independent Estimate() calls).
+                                     Simulations stay independent of each other, so batches keep their parallelism; inside a simulation the
+                                     library runs the packer to a fixed point (at most groups-per-simulation passes, each re-estimating only
+                                     the groups whose input changed) — results are exactly those of the sequential loop.  The whole simulation
+                                     has to live in the problem (not with node groups sharded over devices: CASIM_ERR_INVALID). */
+    int32_t reserved[3];          /* zero */
 } casim_options;
 #define CASIM_PACK_BUILD_AUTO 0
 #define CASIM_PACK_BUILD_PLAIN 1
@@ -671,6 +687,11 @@ int32_t casim_estimate_on_cluster(casim_ctx* ctx, const casim_pegs* classes, con
  * named kernel classes.  kernel_ms_out: [0]=feasibility+csr [1]=order [2]=pack (may be NULL). */
 int32_t casim_problem_time(casim_problem* p, int32_t iters, float* total_ms_out,
                            float* kernel_ms_out);
+/* The feasibility launch (SchedulablePodGroups matrix) of the problem alone: `iters` launches back to back between two HIP events on the
+ * launch stream, average per launch.  info_out (may be NULL): [0] 1 = the streaming kernel of round 5 (csrc/casim_kernels.h
+ * feas_stream_kernel; batches of simulations on narrowed int32 lanes), [1] its lean instantiation, [2] its mask31 instantiation,
+ * [3] workgroups per launch.  What bench.py's roofline_feasibility row is measured with. */
+int32_t casim_problem_time_feasibility(casim_problem* p, int32_t iters, float* ms_per_launch_out, int32_t info_out[4]);
 /* The same measurement WITHOUT stopping the stream: casim_problem_run_marked is casim_problem_run with HIP events recorded
  * around the three kernel classes (nothing waits; up to 64 marked runs are kept, older ones are overwritten);
  * casim_problem_marked_ms waits for the stream and returns the mean milliseconds over the marked runs (and forgets
@@ -737,6 +758,32 @@ int32_t casim_enc_group_set_pegs(casim_encoder* e, int32_t group, const int32_t*
 /* ---- pod specs and PEGs -------------------------------------------------------------- */
 /* A pod spec = the scheduling-relevant part of one exemplar pod.  Returns its id. */
 int32_t casim_enc_add_pod_spec(casim_encoder* e, const char* namespace_, const int64_t* req);
+/* ---- resources BY NAME (ABI 9) --------------------------------------------------------------------------------------------
+ * The reference keeps cpu / memory / ephemeral-storage in fields of their own and EVERYTHING else by name in
+ * Resource.ScalarResources (V/kubernetes/pkg/scheduler/framework/types.go:989-998); fitsRequest walks the pod's map
+ * (V/.../noderesources/fit.go:731-763: zero quantities skipped, the rest compared with Allocatable[name] - Requested[name]) and
+ * AddPodInfo accumulates name by name (types.go:444-448).  Lane numbers are an encoding detail that stays BEHIND the ABI: a binding
+ * hands over every entry of the pod's request list and of node.Status.Allocatable under its Kubernetes name and cannot drop or
+ * mis-order a lane.  The positional arrays of casim_enc_add_pod_spec / casim_enc_add_group cover lanes [0, casim_encoder_options.n_res)
+ * and stay what they were; named values are written on top of them.
+ *
+ * casim_enc_lane: "cpu" -> 0 (value in millicores), "memory" -> 1, "ephemeral-storage" -> 2 (bytes), any other name -> its lane,
+ *   assigned in first-use order from max(3, n_res) on (Quantity.Value units); CASIM_ERR_NO_LANE when all CASIM_MAX_RES lanes are
+ *   taken or the name is new after casim_enc_finalize (update sessions re-encode rows of fixed width); "pods" / NULL / "" ->
+ *   CASIM_ERR_INVALID.  The caller decides WHICH names count — the scheduler's own rule is schedutil.IsScalarResourceName
+ *   (extended resources, hugepages-*, attachable-volumes-*, prefixed native names: types.go Resource.Add) — the encoder takes every
+ *   name it is given.
+ * casim_enc_pod_set_request: the pod's request for the name (>= 0).  CASIM_OK, or CASIM_ENC_DELEGATED (1) when no lane is left and
+ *   value != 0: the pod spec is marked CASIM_PEG_UNSUPPORTED, so every group that lists it comes back CASIM_NG_UNSUPPORTED and the
+ *   shim runs the reference path — a request is NEVER silently ignored.
+ * casim_enc_group_set_allocatable: the template's Allocatable[name] ("pods" sets allowed_pods).  CASIM_ENC_DELEGATED when no lane
+ *   is left (harmless: every pod that asks for the name is delegated).
+ * casim_enc_lane_count: lanes the tables carry (casim_pegs.n_res after finalize); casim_enc_lane_name: the name of a lane or NULL. */
+int32_t casim_enc_lane(casim_encoder* e, const char* resource_name);
+int32_t casim_enc_pod_set_request(casim_encoder* e, int32_t pod, const char* resource_name, int64_t value);
+int32_t casim_enc_group_set_allocatable(casim_encoder* e, int32_t group, const char* resource_name, int64_t value);
+int32_t casim_enc_lane_count(const casim_encoder* e);
+const char* casim_enc_lane_name(const casim_encoder* e, int32_t lane);
 int32_t casim_enc_pod_add_label(casim_encoder* e, int32_t pod, const char* key, const char* value);
 /* op: "", "Equal", "Exists", "Lt", "Gt";  effect: "", "NoSchedule", "NoExecute", "PreferNoSchedule" */
 int32_t casim_enc_pod_add_toleration(casim_encoder* e, int32_t pod, const char* key, const char* op,

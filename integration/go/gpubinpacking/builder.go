@@ -45,20 +45,38 @@ func (l *deviceLimiter) StartEstimation(pegs []estimator.PodEquivalenceGroup, ng
 
 func (l *deviceLimiter) MaxNodes() int { return l.maxNodes }
 
+// BuilderOptions: what a host may set besides the reference's own arguments.
+type BuilderOptions struct {
+	Routing             Routing  // which per-call Estimates go to the device (estimator.go); zero value = DefaultRouting
+	AnalyserOnReference bool     // an EstimationAnalyserFunc that reads the PODS of simulated nodes: every Estimate runs the reference estimator
+	Runners             *Runners // nil = a registry of its own
+}
+
 // NewEstimatorBuilder is what core/autoscaler.go assigns to AutoscalerOptions.EstimatorBuilder when --estimator=gpu-binpacking
 // (autoscaler_go.patch): the same arguments estimator.NewEstimatorBuilder takes, with the thresholds instead of the limiter built
 // from them.  engine == nil (no MI355X, ABI mismatch): every estimator it builds IS the reference's BinpackingNodeEstimator.
 func NewEstimatorBuilder(engine *Engine, shared *Shared, thresholds []estimator.Threshold, orderer estimator.EstimationPodOrderer,
-	analyser estimator.EstimationAnalyserFunc, fastpath bool) estimator.EstimatorBuilder {
+	analyser estimator.EstimationAnalyserFunc, fastpath bool, bo BuilderOptions) estimator.EstimatorBuilder {
 	limiter := newDeviceLimiter(thresholds)
+	runners := bo.Runners
+	if runners == nil {
+		runners = NewRunners()
+	}
+	routing := bo.Routing
+	if routing == (Routing{}) {
+		routing = DefaultRouting
+	}
 	if shared != nil {
 		shared.limiter = limiter
+		shared.runners = runners
 	}
 	return func(snapshot clustersnapshot.ClusterSnapshot, ctx estimator.EstimationContext) estimator.Estimator {
 		fallback := estimator.NewBinpackingNodeEstimator(snapshot, limiter, orderer, ctx, analyser, fastpath)
-		if analyser != nil { // estimationAnalyserFunc wants newNodesWithPods: served by the per-call path with casim_options.node_pods
-			return New(engine, snapshot, limiter, ctx, fastpath, nil, fallback)
+		if analyser != nil && bo.AnalyserOnReference {
+			return fallback
 		}
-		return New(engine, snapshot, limiter, ctx, fastpath, shared, fallback)
+		// with an analyser the estimator takes the per-call path with casim_options.node_pods and calls it (estimator.go: analyse); the
+		// fallback it falls back to calls it by itself
+		return New(engine, snapshot, limiter, ctx, fastpath, shared, runners, analyser, routing, fallback)
 	}
 }

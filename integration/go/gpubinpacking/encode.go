@@ -24,8 +24,35 @@ type session struct {
 
 func newSession() *session {
 	var o C.casim_encoder_options
-	o.n_res = 3 // cpu (milli), memory (bytes), ephemeral storage (bytes); extended resources are appended by the caller
+	// three POSITIONAL lanes — cpu (milli), memory (bytes), ephemeral storage (bytes): the three fields framework.Resource keeps apart
+	// (vendor/k8s.io/kubernetes/pkg/scheduler/framework/types.go:989-998).  Everything else the scheduler counts lives in
+	// Resource.ScalarResources BY NAME and crosses the ABI by name (scalars below; casim_enc_pod_set_request /
+	// casim_enc_group_set_allocatable, ABI 9): the encoder owns the lane numbers, this file cannot drop or mis-order one.
+	o.n_res = 3
 	return &session{enc: C.casim_enc_create(&o), spec: map[*apiv1.Pod]C.int32_t{}}
+}
+
+// scalars walks a ResourceList the way framework.Resource.Add does (types.go:1026-1048): cpu / memory / ephemeral-storage / pods have
+// fields of their own, every other name counts iff schedutil.IsScalarResourceName says so (extended resources, hugepages-*,
+// attachable-volumes-*, prefixed native names) and is then compared name by name in fitsRequest (noderesources/fit.go:731-763).
+// NodeResourcesFit runs here with the default scheduler profile, as in the reference's framework handle: no ignored extended
+// resources or resource groups, no DRA-backed extended resources (those pods are delegated: hasVolumesOrClaims).
+func scalars(rl apiv1.ResourceList, visit func(name apiv1.ResourceName, value int64)) {
+	for name, q := range rl {
+		switch name {
+		case apiv1.ResourceCPU, apiv1.ResourceMemory, apiv1.ResourceEphemeralStorage, apiv1.ResourcePods:
+			continue
+		}
+		if schedutil.IsScalarResourceName(name) {
+			visit(name, q.Value())
+		}
+	}
+}
+
+func hasScalars(rl apiv1.ResourceList) bool {
+	found := false
+	scalars(rl, func(apiv1.ResourceName, int64) { found = true })
+	return found
 }
 
 func (s *session) close() {
@@ -60,6 +87,11 @@ func (s *session) pod(pod *apiv1.Pod) C.int32_t {
 	lanes := [C.CASIM_MAX_RES]C.int64_t{C.int64_t(req.Cpu().MilliValue()), C.int64_t(req.Memory().Value()), C.int64_t(req.StorageEphemeral().Value())}
 	id := C.casim_enc_add_pod_spec(e, c.s(pod.Namespace), &lanes[0])
 	s.spec[pod] = id
+	// ScalarResources by name.  CASIM_ENC_DELEGATED (every lane taken): the encoder has marked the pod CASIM_PEG_UNSUPPORTED, its groups
+	// come back CASIM_NG_UNSUPPORTED and Estimate() runs the reference path — a request is never silently ignored.
+	scalars(req, func(name apiv1.ResourceName, v int64) {
+		C.casim_enc_pod_set_request(e, id, c.s(string(name)), C.int64_t(v))
+	})
 	for k, v := range pod.Labels {
 		C.casim_enc_pod_add_label(e, id, c.s(k), c.s(v))
 	}
@@ -172,6 +204,10 @@ func (s *session) group(tmpl *framework.NodeInfo, maxNodes, existing, lastIndex 
 	}
 	g := C.casim_enc_add_group(s.enc, c.s(node.Name), &lanes[0], C.int32_t(al.Pods().Value()),
 		C.int64_t(node.Status.Capacity.Cpu().MilliValue()), C.int64_t(node.Status.Capacity.Memory().Value()), unsched)
+	// Allocatable.ScalarResources by name (NodeInfo.SetNode -> NewResource(node.Status.Allocatable), types.go:1003-1011)
+	scalars(al, func(name apiv1.ResourceName, v int64) {
+		C.casim_enc_group_set_allocatable(s.enc, g, c.s(string(name)), C.int64_t(v))
+	})
 	for k, v := range node.Labels {
 		C.casim_enc_group_add_label(s.enc, g, c.s(k), c.s(v))
 	}
@@ -254,12 +290,13 @@ func (s *session) runningPods(nodes []*framework.NodeInfo, groups []C.int32_t) e
 	for i, ni := range nodes {
 		for _, pi := range ni.Pods() {
 			p := pi.Pod
-			if _, seen := s.spec[p]; seen || !plain(p) {
+			r := podutils.PodRequests(p)
+			// (the flat arrays carry the three positional lanes: a pod with scalar / extended requests takes the per-pod calls, which name them)
+			if _, seen := s.spec[p]; seen || !plain(p) || hasScalars(r) {
 				flush()
 				C.casim_enc_group_add_preloaded_pod(s.enc, groups[i], s.pod(p))
 				continue
 			}
-			r := podutils.PodRequests(p)
 			grp = append(grp, groups[i])
 			ns = append(ns, sid(p.Namespace))
 			req = append(req, C.int64_t(r.Cpu().MilliValue()), C.int64_t(r.Memory().Value()), C.int64_t(r.StorageEphemeral().Value()))

@@ -35,7 +35,13 @@ type Shared struct {
 	pegs     C.casim_pegs
 	pegID    map[*apiv1.Pod]C.int32_t // exemplar pod -> PEG id of the loop's tables
 	groupRow map[C.uint64_t]C.int32_t // groupKey -> row of the loop's group table
-	loopLastIndex int // the snapshot runner's lastIndex (estimator.go: runnerState) when the batch of the current loop was filled: every group of the batch starts from it
+	loopLastIndex int // the snapshot runner's lastIndex (estimator.go: runnerState) when the batch of the current loop was filled: the FIRST group of the batch starts from it
+	runners       *Runners // the builder's registry (builder.go sets it)
+	// Unchained = the round-4 protocol: every group of the batch starts from loopLastIndex and hits never move the runner.  Default (false): the
+	// batch hands lastIndex from group to group (casim_options.chain_last_index), the way the orchestrator's loop does on one snapshot
+	// (plugin_runner.go:138); over BASELINE configs C1-C4 and 400 fuzz scenarios the two differ in the (node count, pods) of 6 of 2381 groups
+	// (profiles/r10_chain_rate.json) — rarely, but the chained batch is the reference's answer.
+	Unchained bool
 }
 
 // EstimatorName is the --estimator value that selects this package (autoscaler_go.patch).
@@ -110,7 +116,10 @@ func (s *Shared) fill(autoscalingCtx *ca_context.AutoscalingContext, pegs []esti
 		pkeys[i] = pegKey(p)
 	}
 	existing := nodeCount(autoscalingCtx.ClusterSnapshot)
-	rs := runnerOf(autoscalingCtx.ClusterSnapshot)
+	if s.runners == nil {
+		s.runners = NewRunners()
+	}
+	rs := s.runners.of(autoscalingCtx.ClusterSnapshot)
 	rs.mu.Lock()
 	s.loopLastIndex = rs.lastIndex
 	rs.mu.Unlock()
@@ -139,6 +148,9 @@ func (s *Shared) fill(autoscalingCtx *ca_context.AutoscalingContext, pegs []esti
 	var opts C.casim_options
 	if s.fastpath {
 		opts.fastpath = 1
+	}
+	if !s.Unchained {
+		opts.chain_last_index = 1 // groups in the order the orchestrator will call Estimate(): the order of `ngs`
 	}
 	s.engine.mu.Lock()
 	defer s.engine.mu.Unlock()
@@ -218,8 +230,14 @@ func (s *Shared) pegCount(id C.int32_t) C.int32_t {
 }
 
 // lookup: a hit only when the call asks exactly the question the batch answered (group, PEG set, limiter answer, E, lastIndex).
-func (s *Shared) lookup(ng cloudprovider.NodeGroup, tmpl *framework.NodeInfo, pegs []estimator.PodEquivalenceGroup, maxNodes, existing int) (
+// runnerLastIndex = the snapshot runner's lastIndex at the time of THIS Estimate(): the chained batch answered group i for the lastIndex
+// group i - 1 left behind, so the call hits iff the runner stands there (the calls so far arrived in the batch's order).
+func (s *Shared) lookup(ng cloudprovider.NodeGroup, tmpl *framework.NodeInfo, pegs []estimator.PodEquivalenceGroup, maxNodes, existing, runnerLastIndex int) (
 	r C.casim_prefetch_result, order, placed []C.int32_t, ok bool) {
+	li := runnerLastIndex
+	if s.Unchained {
+		li = s.loopLastIndex
+	}
 	n := len(pegs)
 	keys := make([]C.uint64_t, n+1)
 	for i, p := range pegs {
@@ -228,7 +246,7 @@ func (s *Shared) lookup(ng cloudprovider.NodeGroup, tmpl *framework.NodeInfo, pe
 	order = make([]C.int32_t, n+1)
 	placed = make([]C.int32_t, n+1)
 	rc := C.casim_prefetch_lookup(s.cache, groupKey(ng, tmpl), &keys[0], C.int32_t(n), C.int32_t(maxNodes), C.int32_t(existing),
-		C.int32_t(s.loopLastIndex), &r, &order[0], &placed[0])
+		C.int32_t(li), &r, &order[0], &placed[0])
 	return r, order[:n], placed[:n], rc == C.CASIM_OK
 }
 

@@ -3,11 +3,12 @@ shared library happens in _ffi.py).  Kept separate so that test harnesses that c
 structs can reuse the layouts without loading the product library."""
 import ctypes as C
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_RES = 8
 
 OK = 0
-ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_NOMEM = -1, -2, -3, -4
+ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_NOMEM, ERR_NO_LANE = -1, -2, -3, -4, -5
+ENC_DELEGATED = 1
 NG_OK, NG_UNSUPPORTED = 0, 1
 
 PEG_TOLERATES_UNSCHEDULABLE = 0x1
@@ -77,7 +78,7 @@ PREFETCH_MISS_GROUP, PREFETCH_MISS_PEGS, PREFETCH_MISS_LIMITS = 1, 2, 3
 
 
 class Options(C.Structure):
-    _fields_ = [("fastpath", C.c_int32), ("force_generic_packer", C.c_int32), ("node_pods", C.c_int32), ("n_streams", C.c_int32), ("pack_build", C.c_int32), ("no_singleton_merge", C.c_int32), ("no_front_kernel", C.c_int32), ("winners_only", C.c_int32)]
+    _fields_ = [("fastpath", C.c_int32), ("force_generic_packer", C.c_int32), ("node_pods", C.c_int32), ("n_streams", C.c_int32), ("pack_build", C.c_int32), ("no_singleton_merge", C.c_int32), ("no_front_kernel", C.c_int32), ("winners_only", C.c_int32), ("chain_last_index", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class Results(C.Structure):
@@ -178,6 +179,7 @@ PROTOTYPES = {
     "casim_cluster_stats": (C.c_int32, [C.c_void_p, i64p]),
     "casim_cluster_forget_commits": (C.c_int32, [C.c_void_p]),
     "casim_problem_time": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "casim_problem_time_feasibility": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), i32p]),
     "casim_problem_run_marked": (C.c_int32, [C.c_void_p]),
     "casim_problem_marked_ms": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "casim_try_schedule_pods": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(PodSequence), i32p, i32p, i32p]),
@@ -209,6 +211,11 @@ PROTOTYPES = {
                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_char_p), C.c_int32]),
     "casim_enc_group_set_pegs": (C.c_int32, [C.c_void_p, C.c_int32, i32p, C.c_int32]),
     "casim_enc_add_pod_spec": (C.c_int32, [C.c_void_p, cstr, i64p]),
+    "casim_enc_lane": (C.c_int32, [C.c_void_p, cstr]),
+    "casim_enc_pod_set_request": (C.c_int32, [C.c_void_p, C.c_int32, cstr, C.c_int64]),
+    "casim_enc_group_set_allocatable": (C.c_int32, [C.c_void_p, C.c_int32, cstr, C.c_int64]),
+    "casim_enc_lane_count": (C.c_int32, [C.c_void_p]),
+    "casim_enc_lane_name": (C.c_char_p, [C.c_void_p, C.c_int32]),
     "casim_enc_pod_add_label": (C.c_int32, [C.c_void_p, C.c_int32, cstr, cstr]),
     "casim_enc_pod_add_toleration": (C.c_int32, [C.c_void_p, C.c_int32, cstr, cstr, cstr, cstr]),
     "casim_enc_pod_add_node_selector": (C.c_int32, [C.c_void_p, C.c_int32, cstr, cstr]),

@@ -56,6 +56,7 @@ template <int N> CS_DEVICE Words<N> const_load(const uint32_t* p) { Words<N> r; 
 struct RecBase { const char* p; };
 CS_DEVICE RecBase rec_base(const uint32_t* p) { return RecBase{(const char*)p}; }
 template <int N> CS_DEVICE Words<N> rec_load(const RecBase& b, uint32_t byte_off) { Words<N> r; memcpy(r.w, b.p + byte_off, 4 * N); return r; }
+template <int N> CS_DEVICE Words<N> rec_load_all(const RecBase& b, uint32_t byte_off) { return rec_load<N>(b, byte_off); }
 CS_DEVICE bool lane_pred(uint64_t mask) { return ((mask >> (casim_emu::cur().tid & 63)) & 1ull) != 0; }
 CS_DEVICE void keep_scalar(uint32_t&) {}
 CS_DEVICE void keep_apart() {}
@@ -68,6 +69,11 @@ CS_DEVICE uint32_t uniform_div_u32(uint32_t a, uint32_t b) { return a / b; }
 CS_DEVICE uint32_t uniform_div_u32_small(uint32_t a, uint32_t b) { return a / b; }
 CS_DEVICE uint32_t scalar_min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 CS_DEVICE void write_lane_u32(uint32_t& v, uint32_t uniform_value, int uniform_lane) { if ((casim_emu::cur().tid & 63) == uniform_lane) v = uniform_value; }
+CS_DEVICE uint32_t and_or_u32(uint32_t uniform_a, uint32_t b, uint32_t c) { return (uniform_a & b) | c; }
+CS_DEVICE int uniform_i32(int v) { return v; }
+CS_DEVICE void write_lane2_u32(uint32_t& lo, uint32_t& hi, uint64_t uniform_value, uint32_t uniform_lane_times_64) {
+    if ((uint32_t)(casim_emu::cur().tid & 63) == (uniform_lane_times_64 >> 6)) { lo = (uint32_t)uniform_value; hi = (uint32_t)(uniform_value >> 32); }
+}
 CS_DEVICE int popc64(uint64_t v) { return __builtin_popcountll(v); }
 CS_DEVICE int ffs64(uint64_t v) { return v ? __builtin_ctzll(v) : -1; }
 CS_DEVICE int fls64(uint64_t v) { return v ? 63 - __builtin_clzll(v) : -1; }
@@ -223,6 +229,22 @@ template <int N> CS_DEVICE Words<N> rec_load(const RecBase& b, uint32_t byte_off
         for (int i = 0; i < 16; ++i) r.w[i] = v[i]; }
     return r;
 }
+// the same for a caller that reads only SOME words of the record: every element is "read" by an empty statement, so the optimiser cannot
+// trim the load to a vector width the backend has no s_buffer_load for (<6 x i32>, <14 x i32>: "Cannot select")
+template <int N> CS_DEVICE Words<N> rec_load_all(const RecBase& b, uint32_t byte_off) {
+    static_assert(N == 8 || N == 16, "records are 8 or 16 dwords");
+    Words<N> r;
+    if constexpr (N == 8) { const u32x8_t v = casim_llvm_s_buffer_load_v8(b.r, byte_off, 0);
+        asm volatile("" : : "s"(v[0]), "s"(v[1]), "s"(v[2]), "s"(v[3]), "s"(v[4]), "s"(v[5]), "s"(v[6]), "s"(v[7]));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.w[i] = v[i]; }
+    else { const u32x16_t v = casim_llvm_s_buffer_load_v16(b.r, byte_off, 0);
+        asm volatile("" : : "s"(v[0]), "s"(v[1]), "s"(v[2]), "s"(v[3]), "s"(v[4]), "s"(v[5]), "s"(v[6]), "s"(v[7]));
+        asm volatile("" : : "s"(v[8]), "s"(v[9]), "s"(v[10]), "s"(v[11]), "s"(v[12]), "s"(v[13]), "s"(v[14]), "s"(v[15]));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) r.w[i] = v[i]; }
+    return r;
+}
 // my lane's bit of a wave-uniform lane mask as a predicate: the mask register pair IS the condition (no VALU)
 CS_DEVICE bool lane_pred(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
 // pin a wave-uniform value that lives across loop iterations to a scalar register (the register allocator otherwise may
@@ -242,10 +264,12 @@ CS_DEVICE bool flag_set(uint32_t word, uint32_t bit) { asm volatile("" : "+s"(wo
 // a / b for wave-UNIFORM 32-bit values (b > 0) on the VECTOR unit: f64 reciprocal estimate + exact +-1 fix-up (the operands are
 // below 2^32, the estimate is within one of the quotient), ~10 VALU.  The compiler's expansion of a uniform division is ~17
 // scalar instructions around a v_rcp_f32 — and the scalar unit is the packer's bottleneck.
+CS_DEVICE double estimate_rcp_f64(double x);
 CS_DEVICE uint32_t uniform_div_u32(uint32_t a, uint32_t b) {
     uint32_t va = a, vb = b;
     asm volatile("" : "+v"(va), "+v"(vb));   // vector copies: keeps the arithmetic below off the scalar unit
-    uint32_t q = (uint32_t)((double)va * __builtin_amdgcn_rcp((double)vb));
+    // (rcp + one Newton step: the raw v_rcp_f64 is only good to ~2^-24 relative, and the +-1 fix-up needs quotient x error < 1 — ADVICE r4)
+    uint32_t q = (uint32_t)((double)va * estimate_rcp_f64((double)vb));
     const uint64_t wide = (uint64_t)q * vb;   // (b may exceed 2^31: the fix-up compares the 64-bit product)
     q = wide > va ? q - 1 : ((uint64_t)va - wide >= vb ? q + 1 : q);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
@@ -273,11 +297,14 @@ CS_DEVICE double estimate_rcp_f64(double x) {
 }
 // the same for a divisor below 2^30 (the packer's: pods that fit an empty node, < 2^21 by eligibility): the remainder of the estimate lies
 // in (-b, 2b), so it is exact in WRAPPING 32-bit arithmetic and the fix-up is sign bit + one compare — straight-line code; the general
-// form above compares 64-bit products under two exec-mask regions (18 instructions, 4 of them scalar)
+// form above compares 64-bit products under two exec-mask regions (18 instructions, 4 of them scalar).
+// The estimate is within one of the quotient for EVERY a < 2^32 because the reciprocal carries a Newton step (relative error ~2^-50:
+// quotient x error < 2^-18); the raw v_rcp_f64 (~2^-24) would be off by more than one from a / b >= 2^24 on — cn = 1 next to a PEG of 2^24
+// pods, ADVICE r4 — and the emulator, which divides, could not have told.
 CS_DEVICE uint32_t uniform_div_u32_small(uint32_t a, uint32_t b) {
     uint32_t va = a, vb = b;
     asm volatile("" : "+v"(va), "+v"(vb));
-    uint32_t q = (uint32_t)((double)va * __builtin_amdgcn_rcp((double)vb));
+    uint32_t q = (uint32_t)((double)va * estimate_rcp_f64((double)vb));
     const int32_t rem = (int32_t)(va - q * vb);
     q = q - ((uint32_t)rem >> 31) + (rem >= (int32_t)vb ? 1u : 0u);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
@@ -298,6 +325,24 @@ CS_DEVICE void write_lane_u32(uint32_t& v, uint32_t uniform_value, int uniform_l
     uniform_lane = __builtin_amdgcn_readfirstlane(uniform_lane);
     asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(uniform_value), "s"(uniform_lane) : "m0");
 }
+// (wave-uniform a & lane b) | lane c as ONE v_and_or_b32 — the accumulation step of feas_stream_kernel's static-Filter word.  Left to itself the
+// compiler balances an OR of k AND terms into k v_and + (k - 1) / 2 v_or3 (a tree: more instruction-level parallelism, which a wave that
+// issues one instruction per ~4 cycles cannot use) instead of the chain of k fused instructions
+CS_DEVICE uint32_t and_or_u32(uint32_t uniform_a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    uniform_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)uniform_a);   // (a no-op for a value the compiler holds in a scalar register)
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "s"(uniform_a), "v"(b), "v"(c));
+    return r;
+}
+// both halves of a wave-uniform 64-bit word into lane (byte offset >> 6) of two VGPRs: the lane select is derived from the record walk's byte
+// offset by the one scalar instruction that loads M0, and both v_writelane share it
+CS_DEVICE void write_lane2_u32(uint32_t& lo, uint32_t& hi, uint64_t uniform_value, uint32_t uniform_lane_times_64) {
+    const uint32_t vl = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)uniform_value), vh = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uniform_value >> 32));
+    uniform_lane_times_64 = (uint32_t)__builtin_amdgcn_readfirstlane((int)uniform_lane_times_64);
+    asm volatile("s_lshr_b32 m0, %4, 6\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(lo), "+v"(hi) : "s"(vl), "s"(vh), "s"(uniform_lane_times_64) : "m0");
+}
+// a wave-uniform int the compiler cannot prove uniform (a global load indexed by the block id): to a scalar register
+CS_DEVICE int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 CS_DEVICE int popc64(uint64_t v) { return __popcll(v); }
 CS_DEVICE int ffs64(uint64_t v) { return v ? (int)__builtin_ctzll(v) : -1; }
 CS_DEVICE int fls64(uint64_t v) { return v ? 63 - (int)__builtin_clzll(v) : -1; }

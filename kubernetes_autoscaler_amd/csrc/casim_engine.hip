@@ -122,9 +122,26 @@ struct HipBackend {
     // option, build 1 without.  `want`: casim_options.pack_build of the problem (CASIM_PACK_BUILD_*); AUTO takes the build the
     // self-check left standing for this device (pack_plain).
     bool pack_plain = false;   // (CASIM_PACK_BUILD=plain / a failed check: the process-wide verdict, copied when the context is created)
+    // Verdicts this backend already holds, one bit per instantiation (pack_bit): the hot path reads them without the process-wide lock.
+    // prepare_pack_fast() — called from ProblemT::init, where the instantiation is known and no kernel of the problem is in flight yet —
+    // runs the instantiation's self-check on first use (it used to run inside the first launch, ~15 ms of streams, pool frees and
+    // 32-36 simulations in the middle of an enter -> return call, under a mutex every pack launch of the process took).
+    uint32_t pack_known_mask = 0, pack_plain_mask = 0;
+    static uint32_t pack_bit(int lanes, int slots_per_lane, int excl_words) {
+        const int lanes4 = lanes == 8 ? 2 : (lanes > 2 ? 1 : 0), sc = slots_per_lane <= 1 ? 0 : (slots_per_lane <= 4 ? 1 : 2), excl = excl_words > 0 ? 1 : 0;
+        return 1u << (lanes4 * 6 + sc * 2 + excl);
+    }
+    void prepare_pack_fast(int want, int lanes, int slots_per_lane, int excl_words) {
+        if (want == CASIM_PACK_BUILD_PLAIN || want == CASIM_PACK_BUILD_OPTION || pack_plain) return;
+        const uint32_t bit = pack_bit(lanes, slots_per_lane, excl_words);
+        if (pack_known_mask & bit) return;
+        if (casim_pack_use_plain(device, lds, lanes, slots_per_lane, excl_words)) { pack_plain = true; pack_plain_mask |= bit; }
+        pack_known_mask |= bit;
+    }
     void launch_pack_fast(int want, int lanes, int slots_per_lane, int excl_words, int n_groups, const DevTables& t, const DevResults& res, const FastScratch& fs) {
-        // AUTO: the instantiation about to run has been through the self-check, or goes through it now (once per process, device and instantiation)
-        const bool plain = want == CASIM_PACK_BUILD_PLAIN || (want != CASIM_PACK_BUILD_OPTION && (pack_plain || casim_pack_use_plain(device, lds, lanes, slots_per_lane, excl_words)));
+        // AUTO: the instantiation about to run has been through the self-check (prepare_pack_fast at init; here only for a caller that skipped it)
+        prepare_pack_fast(want, lanes, slots_per_lane, excl_words);
+        const bool plain = want == CASIM_PACK_BUILD_PLAIN || (want != CASIM_PACK_BUILD_OPTION && pack_plain);
         if (plain) check((hipError_t)casim::hip_launch_pack_fast_plain(lanes, slots_per_lane, excl_words, n_groups, (void*)stream, t, res, fs), "pack_fast_kernel launch (plain build)");
         else check((hipError_t)casim::hip_launch_pack_fast(lanes, slots_per_lane, excl_words, n_groups, (void*)stream, t, res, fs), "pack_fast_kernel launch");
     }
@@ -146,14 +163,15 @@ typedef casim::StreamedProblemT<HipBackend> HipStreamed;
 }  // namespace
 
 // The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and reads the variable once, at its
-// first API call.  A streamed batch (casim_options.n_streams) wants a queue per lane next to the caller's own streams: unless the
-// process has set the variable, libcasim asks for 8 when it is loaded.  This is a PROCESS-WIDE environment change made by a library
-// constructor (documented in include/casim.h at casim_options.n_streams and in INTEGRATION.md section 4): a host that wants its
-// environment left alone sets CASIM_KEEP_ENV=1 (or the variable itself) before libcasim loads.  No effect when the runtime is already
-// initialised — the lane probe of casim_ctx::get_lanes then makes the best of the queues there are.
+// first API call.  A streamed batch (casim_options.n_streams) wants a queue per lane next to the caller's own streams, i.e.
+// GPU_MAX_HW_QUEUES=8 in the process environment BEFORE the first HIP call.  That is the HOST's decision: a
+// library loaded into the autoscaler process does not edit its environment by default.  The host exports the variable itself
+// (one line in the deployment, or os.Setenv in main before the shim is used) — or opts IN to the library
+// doing it at load time with CASIM_SET_HW_QUEUES=1 (never overrides a value the process already set).  Without either the lane
+// probe of casim_ctx::get_lanes makes the best of the queues there are (typically 3 concurrent lanes instead of 4).
 __attribute__((constructor)) static void casim_default_hw_queues() {
-    const char* keep = getenv("CASIM_KEEP_ENV");
-    if (keep && atoi(keep) != 0) return;
+    const char* want = getenv("CASIM_SET_HW_QUEUES");
+    if (!want || atoi(want) == 0) return;
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
 }
 
@@ -609,7 +627,8 @@ int32_t casim_pack_build_info(int32_t device, int32_t out[4]) {
     if (!out || device < 0 || device >= 64) return set_err(CASIM_ERR_INVALID, "bad argument");
     std::lock_guard<std::mutex> lock(g_pack_build_mu);
     const PackBuildState& st = g_pack_build[device];
-    out[0] = st.checked ? (st.plain ? CASIM_PACK_BUILD_PLAIN : CASIM_PACK_BUILD_OPTION) : CASIM_PACK_BUILD_AUTO;
+    // (_OPTION only once an instantiation has been through the comparison — or the build is forced; until then: AUTO = "unchecked")
+    out[0] = st.plain ? CASIM_PACK_BUILD_PLAIN : ((st.forced || st.checked_mask) ? CASIM_PACK_BUILD_OPTION : CASIM_PACK_BUILD_AUTO);
     out[1] = st.batches; out[2] = st.differing; out[3] = st.forced;
     return CASIM_OK;
 }
@@ -918,6 +937,8 @@ int32_t casim_estimate_batch_multi(casim_mctx* m, const casim_pegs* pegs, const 
                                    casim_results* out, int32_t* offsets_out, const casim_option_query* q) {
     g_err.clear();
     if (!m) return set_err(CASIM_ERR_INVALID, "null multi-device context");
+    if (opts && opts->chain_last_index && m->ctxs.size() > 1)
+        return set_err(CASIM_ERR_INVALID, "chain_last_index needs every group of a simulation in one problem: not with node groups sharded over devices");
     std::vector<HipBackend*> bks;
     for (casim_ctx* c : m->ctxs) { c->bk.bind(); c->bk.clear(); bks.push_back(&c->bk); }
     casim::MultiProblemT<HipBackend> mp(bks);
@@ -969,6 +990,29 @@ int32_t casim_problem_time(casim_problem* p, int32_t iters, float* total_ms_out,
     // mark as run so that fetch works after a timing loop
     const int32_t rc = p->sp ? p->sp->run() : p->prob->run();
     PROB_RET(p, rc != CASIM_OK ? rc : (bk.ok() ? CASIM_OK : CASIM_ERR_HIP));
+}
+
+// The feasibility launch of a problem alone, `iters` times back to back between two HIP events on the launch stream: the average includes
+// the gap between two launches (conservative for a roofline fraction).  info_out (may be NULL): [0] 1 = feas_stream_kernel (round 5),
+// 0 = another form, [1] 1 = its lean instantiation, [2] 1 = its mask31 instantiation, [3] workgroups of the launch.
+int32_t casim_problem_time_feasibility(casim_problem* p, int32_t iters, float* ms_per_launch_out, int32_t info_out[4]) {
+    PROB_ENTER(p);
+    if (iters <= 0 || !ms_per_launch_out) return set_err(CASIM_ERR_INVALID, "iters must be > 0");
+    HipBackend& bk = p->bk0();
+    if (p->sp) { p->sp->sync_all(); bk.clear(); }
+    hipEvent_t ev[2];
+    for (auto& e : ev) bk.check(hipEventCreate(&e), "hipEventCreate");
+    p->prob->run_feasibility();   // (warm: code object, caches)
+    bk.check(hipEventRecord(ev[0], bk.stream), "hipEventRecord");
+    for (int i = 0; i < iters; ++i) p->prob->run_feasibility();
+    bk.check(hipEventRecord(ev[1], bk.stream), "hipEventRecord");
+    bk.check(hipEventSynchronize(ev[1]), "hipEventSynchronize");
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    *ms_per_launch_out = ms / (float)iters;
+    if (info_out) p->prob->feasibility_info(info_out);
+    PROB_RET(p, bk.ok() ? CASIM_OK : CASIM_ERR_HIP);
 }
 
 static const int kMarkedRuns = 64;

@@ -210,6 +210,148 @@ CS_GLOBAL void feas_sim_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// K_feas, round 5: the streaming form (feas_stream_kernel) — the kernel BASELINE.md section 4 prices against the HBM roofline
+// ------------------------------------------------------------------------------------------
+// Same cells, same output rows as feas_sim_kernel (narrowed int32 lanes, one word per mask kind, every group of a simulation on one PEG
+// range), rebuilt around what that kernel spent its time on: ~29 vector instructions + 4 LDS reads per (wave, group) — the group record
+// came out of LDS field by field into VGPRs, every test was its own 64-bit compare, the ballot word went through two v_mov and a
+// lane-0 store.  Here
+//   * the group record is ONE 32-byte (lean) / 64-byte scalar load into SGPRs (s_load_dwordx8 / x16 through the scalar cache: no LDS, no
+//     barrier, no staging phase) of a record built once per problem (feas_group_records_kernel, at init): taint word, INVERTED label
+//     word, free lanes, flags — with the wave-uniform gates folded INTO the data: a group without a free pod slot gets f0 = INT32_MIN
+//     (every lane fails the lane-0 compare: "pod count first", fit.go:681-690), the unschedulable bit is one more AND-OR term;
+//   * the PEG side is pre-inverted once per lane: ~tol, "does not tolerate unschedulable", requests with rq <= 0 replaced by
+//     INT32_MIN + 1 (a lane nobody asks for passes every free amount, fit.go:699, and still fails the INT32_MIN gate);
+//   * all static Filters of a cell are ONE accumulated word: x = (taint & ~tol) | (sel & ~label) | (unsched & ~tolerates) [| excl | zone],
+//     built from v_and_or_b32, tested by ONE compare; the requests by one 32-bit compare per lane; the three lane masks meet on the
+//     SCALAR unit (s_and_b64);
+//   * the 64 ballot words of up to 64 groups are parked in the lanes of two VGPRs (v_writelane, lane j = group j) and leave with ONE
+//     store instruction per 64 groups.
+// Lean cell: 8 (narrow dictionaries: the masks' upper halves are zero, kMask32) or 10 vector instructions per (wave, group) instead of
+// ~29 + 4 LDS; the scalar side ~6 + one s_load.  grid = ONE dimension, XCD-aware: workgroup ids are dealt round-robin to the 8 XCDs, so
+// the blocks of a simulation take ids that agree mod 8 — its group records are fetched into ONE XCD's L2, not up to eight.
+// Algorithmic bytes: per PEG the columns the cell needs as this kernel reads them — 4 R (narrowed requests) + 4
+// (flags) + 8 (tolerations) + 8 (selector) [+ 8 + 8 exclusion words] — per group its 32 / 64-byte record, per cell one bit.
+#define CASIM_FEAS_REC_DW 16
+// record (dwords): [0,1] taint  [2,3] ~label (bit 31 of [2]: see kMask31)  [4] f0 | INT32_MIN gate  [5] f1  [6] unschedulable (0 / 1)  [7] 0
+//                  [8,9] node-local exclusion ^ NEED polarity  [10,11] group-wide exclusion ^ NEED polarity  [12] f2  [13] f3  [14,15] 0
+// mask31 != 0: every taint / label-requirement bit of the batch lies below bit 31 (mask_hi_or_kernel), so bit 31 of the label word is free
+// and carries the NodeUnschedulable test as one more "label requirement": set in ~label for an unschedulable template, set in the PEG's
+// selector word (by the kernel, per lane) when the PEG does not tolerate node.kubernetes.io/unschedulable.
+CS_GLOBAL void feas_group_records_kernel(DevTables t, const int32_t* CS_RESTRICT fresh32, uint32_t* CS_RESTRICT rec /*[NG + 2][16]*/, int mask31) {
+    const int ng = cs::bid() * cs::nthreads() + cs::tid();
+    if (ng > t.NG + 1) return;
+    uint32_t* r = rec + (int64_t)ng * CASIM_FEAS_REC_DW;
+    if (ng >= t.NG) {   // the two spare records behind the last group: the kernel loads up to two records ahead of the one it works on
+        for (int k = 0; k < CASIM_FEAS_REC_DW; ++k) r[k] = 0;
+        return;
+    }
+    const uint64_t taint = t.Wt ? t.taint[(int64_t)ng * t.Wt] : 0ull, nlabel = t.Wl ? ~t.label[(int64_t)ng * t.Wl] : 0ull;
+    const uint64_t ex = t.Wx ? (t.init_excl[(int64_t)ng * t.Wx] ^ (t.xpol ? t.xpol[0] : 0ull)) : 0ull;
+    const uint64_t zn = t.Wz ? (t.init_zone[(int64_t)ng * t.Wz] ^ t.zpol[0]) : 0ull;
+    int32_t f[4];
+    for (int k = 0; k < 4; ++k) f[k] = k < t.R ? fresh32[(int64_t)ng * t.R + k] : 0x7fffffff;
+    if (t.allowed[ng] - t.init_pods[ng] <= 0) f[0] = (int32_t)0x80000000;
+    const uint32_t unsched = (t.gflags[ng] & CASIM_NG_UNSCHEDULABLE) ? 1u : 0u;
+    r[0] = (uint32_t)taint; r[1] = (uint32_t)(taint >> 32);
+    r[2] = mask31 ? (((uint32_t)nlabel & 0x7fffffffu) | (unsched << 31)) : (uint32_t)nlabel; r[3] = (uint32_t)(nlabel >> 32);
+    r[4] = (uint32_t)f[0]; r[5] = (uint32_t)f[1]; r[6] = unsched; r[7] = 0;
+    r[8] = (uint32_t)ex; r[9] = (uint32_t)(ex >> 32); r[10] = (uint32_t)zn; r[11] = (uint32_t)(zn >> 32);
+    r[12] = (uint32_t)f[2]; r[13] = (uint32_t)f[3]; r[14] = 0; r[15] = 0;
+}
+
+// OR of the bits 31.. of two word arrays (the groups' taint words, the PEGs' selector words): zero = every taint / label-requirement bit
+// the cells can ever see in `x` sits below bit 31, and feas_stream_kernel<.., kMask31> may drop the upper-half terms and use bit 31 itself.
+// (The other two operands do not matter: a zero taint bit kills its term whatever ~tol holds, a zero selector bit whatever ~label holds.)
+CS_GLOBAL void mask_hi_or_kernel(const uint64_t* CS_RESTRICT a, int64_t na, const uint64_t* CS_RESTRICT b, int64_t nb, uint64_t* CS_RESTRICT out) {
+    const int64_t stride = (int64_t)cs::nblocks() * cs::nthreads();
+    uint64_t acc = 0;
+    for (int64_t i = (int64_t)cs::bid() * cs::nthreads() + cs::tid(); i < na; i += stride) acc |= a[i] >> 31;
+    for (int64_t i = (int64_t)cs::bid() * cs::nthreads() + cs::tid(); i < nb; i += stride) acc |= b[i] >> 31;
+    if (acc) cs::atomic_or_u64(out, acc);
+}
+
+// kLean: no exclusion words, at most two request lanes (one 32-byte record load per group).  kMask31: the batch's dictionaries stay below
+// bit 31 and the group records were built for it (feas_group_records_kernel(mask31 = 1)): 7 vector instructions per (wave, group) —
+// v_and, v_and_or, v_cmp_eq, 2 x v_cmp_ge, 2 x v_writelane — else 10.
+template <bool kLean, bool kMask31>
+CS_GLOBAL CS_LAUNCH_BOUNDS(256, 1) void feas_stream_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg]*/, int Wg, const int32_t* CS_RESTRICT req32,
+                                                          const uint32_t* CS_RESTRICT grec /*[NG + 2][16]*/, int gx /* blocks per simulation */, int n_sims) {
+    // workgroup id -> (simulation, block of the simulation): ids that agree mod 8 run on one XCD
+    const int id = cs::bid();
+    const int chunk = id / (8 * gx), within = id - chunk * (8 * gx);
+    const int sim = chunk * 8 + (within & 7), bx = within >> 3;
+    if (sim >= n_sims) return;
+    const int g0 = cs::uniform_i32(t.sim_off[sim]), g1 = cs::uniform_i32(t.sim_off[sim + 1]);
+    if (g1 <= g0) return;
+    const int lo = cs::uniform_i32(t.peg_lo[g0]), hi = cs::uniform_i32(t.peg_hi[g0]);
+    const int k = bx * cs::nthreads() + cs::tid();
+    const int word = cs::uniform_i32(k >> 6);
+    if (word >= Wg) return;                       // (wave-uniform: a wave past the row's last word has nothing to write)
+    const bool live = lo + k < hi;
+    const int g = live ? lo + k : (hi > lo ? lo : 0);
+    const int R = t.R;
+    constexpr int RD = kLean ? 8 : 16;
+    // ---- the PEG, once: pre-inverted so that a cell is AND-OR terms and signed compares
+    int32_t rq[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int32_t v = (r < R && r < (kLean ? 2 : 4)) ? req32[(int64_t)g * R + r] : 0;
+        rq[r] = v > 0 ? v : (int32_t)0x80000001;
+    }
+    const uint32_t pf = t.pflags[g];
+    const uint64_t tol = t.Wt ? t.tol[(int64_t)g * t.Wt] : 0ull, sel = t.Wl ? t.sel[(int64_t)g * t.Wl] : 0ull;
+    const uint32_t no_unsched = (pf & CASIM_PEG_TOLERATES_UNSCHEDULABLE) ? 0u : 1u;
+    const uint32_t ntol_lo = ~(uint32_t)tol, ntol_hi = ~(uint32_t)(tol >> 32), sel_hi = (uint32_t)(sel >> 32);
+    const uint32_t sel_lo = kMask31 ? ((uint32_t)sel | (no_unsched << 31)) : (uint32_t)sel;
+    uint32_t xb_lo = 0, xb_hi = 0, zb_lo = 0, zb_hi = 0;
+    if constexpr (!kLean) {
+        // (a NEED bit the PEG marks itself does not count on a fresh node: fits_fresh_node)
+        const uint64_t xb = t.Wx ? (t.xblock[(int64_t)g * t.Wx] & ~(t.xmark[(int64_t)g * t.Wx] & (t.xpol ? t.xpol[0] : 0ull))) : 0ull;
+        const uint64_t zb = t.Wz ? t.zblock[(int64_t)g * t.Wz] : 0ull;
+        xb_lo = (uint32_t)xb; xb_hi = (uint32_t)(xb >> 32); zb_lo = (uint32_t)zb; zb_hi = (uint32_t)(zb >> 32);
+    }
+    const uint64_t live_mask = cs::ballot(live);
+    uint32_t out_lo = 0, out_hi = 0;              // lane j: the ballot word of group base + j
+    uint64_t* const row0 = bits + (int64_t)g0 * Wg + word;
+    const int lane = cs::lane();
+    // the record walk carries ONE 32-bit scalar (cs::rec_load: s_buffer_load_dwordxN with a byte offset): it addresses the record, its
+    // upper bits are the lane the ballot word is parked in, and it ends the loop
+    const cs::RecBase rb = cs::rec_base(grec + (int64_t)g0 * CASIM_FEAS_REC_DW);
+    auto cell = [&](const cs::Words<RD>& q) -> uint64_t {
+        uint32_t x = q.w[0] & ntol_lo;
+        if constexpr (!kMask31) x = cs::and_or_u32(q.w[1], ntol_hi, x);
+        x = cs::and_or_u32(q.w[2], sel_lo, x);
+        if constexpr (!kMask31) { x = cs::and_or_u32(q.w[3], sel_hi, x); x = cs::and_or_u32(q.w[6], no_unsched, x); }
+        if constexpr (kLean) {
+            return cs::ballot(x == 0) & cs::ballot(rq[0] <= (int32_t)q.w[4]) & cs::ballot(rq[1] <= (int32_t)q.w[5]);
+        } else {
+            x = cs::and_or_u32(q.w[8], xb_lo, x); x = cs::and_or_u32(q.w[9], xb_hi, x);
+            x = cs::and_or_u32(q.w[10], zb_lo, x); x = cs::and_or_u32(q.w[11], zb_hi, x);
+            return cs::ballot(x == 0) & cs::ballot(rq[0] <= (int32_t)q.w[4]) & cs::ballot(rq[1] <= (int32_t)q.w[5]) &
+                   cs::ballot(rq[2] <= (int32_t)q.w[12]) & cs::ballot(rq[3] <= (int32_t)q.w[13]);
+        }
+    };
+    constexpr uint32_t kRecBytes = 4u * CASIM_FEAS_REC_DW;
+    for (int base = g0; base < g1; base += 64) {
+        const uint32_t n = cs::scalar_min_u32((uint32_t)(g1 - base), 64u);
+        const uint32_t first = (uint32_t)(base - g0) * kRecBytes, end = n * kRecBytes;
+        // two records per step, each loaded a step ahead of its use; `off` counts bytes inside this round of 64 groups.  An odd count runs one
+        // record over (the next simulation's first, or one of the TWO spare records the array ends with): its word lands in a lane >= n,
+        // which is not stored; the look-ahead reaches one record further still
+        cs::Words<RD> a = cs::rec_load_all<RD>(rb, first);
+        for (uint32_t off = 0; off < end; off += 2 * kRecBytes) {
+            const cs::Words<RD> b = cs::rec_load_all<RD>(rb, first + off + kRecBytes);
+            cs::write_lane2_u32(out_lo, out_hi, cell(a), off);
+            a = cs::rec_load_all<RD>(rb, first + off + 2 * kRecBytes);
+            cs::write_lane2_u32(out_lo, out_hi, cell(b), off + kRecBytes);
+        }
+        // one store instruction for up to 64 rows; lanes past the row's end of the simulation drop out (dead PEGs: masked here, once)
+        if (lane < (int)n) row0[(int64_t)(base - g0 + lane) * Wg] = (((uint64_t)out_hi << 32) | out_lo) & live_mask;
+    }
+}
+
 // K_reason: the SchedulingError of every cell of the SchedulablePodGroups matrix (see casim_feasibility_reasons): first
 // failing Filter plugin in the scheduler's Filter order + the reasons of NodeResourcesFit.  Same geometry as K_feas.
 CS_DEVICE uint32_t fresh_node_verdict(const DevTables& t, const uint64_t* CS_RESTRICT port_block, int g, int ng) {
@@ -525,6 +667,19 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
     // declares (DevTables, DevResults, ...) first)
     const DevTables& te_ = cs::kernarg_view(t, 0);
     const DevResults& re_ = cs::kernarg_view(res, (sizeof(DevTables) + 7) & ~(size_t)7);
+    // RULE for every kernel that calls order_group: its first two explicit arguments are (DevTables, DevResults), passed on UNMODIFIED —
+    // the views above re-read them at byte offsets 0 and sizeof(DevTables) rounded up.  Nothing in the language enforces it, so
+    // the A/B library of tests/ab is built with -DCASIM_CHECK_KERNARGS: every group then compares the views with the parameters it was
+    // handed and traps on a difference (tests/test_gpu_ab_structurizer.py runs the whole corpus through that build on the MI355X).
+#if defined(CASIM_CHECK_KERNARGS) && !defined(CASIM_HOST_EMU)
+    {
+        static_assert(sizeof(DevTables) % 4 == 0 && sizeof(DevResults) % 4 == 0, "compared word by word");
+        bool same = true;
+        for (size_t i = 0; i < sizeof(DevTables) / 4; ++i) same = same && ((const uint32_t*)&te_)[i] == ((const uint32_t*)&t)[i];
+        for (size_t i = 0; i < sizeof(DevResults) / 4; ++i) same = same && ((const uint32_t*)&re_)[i] == ((const uint32_t*)&res)[i];
+        if (!same) __builtin_trap();
+    }
+#endif
 #pragma unroll
     for (int i = tid; i < (NPAD > 0 ? NPAD : Gn); i += nt) {
         if (NPAD > 0 && i >= Gn) continue;
@@ -1174,6 +1329,32 @@ CS_GLOBAL void gather_winners_kernel(const int32_t* CS_RESTRICT best, const int3
     if (b < 0) return;
     const int a = off[b], n = cnt ? cnt[b] : off[b + 1] - a, w = woff[s];
     for (int i = cs::tid(); i < n; i += cs::nthreads()) { worder[w + i] = order[a + i]; wplaced[w + i] = placed[a + i]; }
+}
+
+// casim_options.chain_last_index: the groups of a simulation as ONE sequence of Estimate() calls on one snapshot — lastIndex lives in the
+// snapshot's plugin runner and survives every Estimate (CA/simulator/clustersnapshot/predicate/plugin_runner.go:138: MarkMatch;
+// predicate_snapshot.go:64; the Fork / Revert around an estimate does not touch it), so group i starts where group i - 1 ended.
+// The packer keeps its parallelism (one wave per group) and iterates to the sequential loop's fixed point instead: after every pass a
+// thread per simulation compares each group's INPUT with its predecessor's current OUTPUT, rewrites the input where they differ and marks
+// the group for the next pass.  After pass p the first p + 1 groups of every simulation are final (induction over the chain), and a pass
+// without marks proves the whole chain consistent — i.e. equal to the sequential loop; the host enqueues (groups per simulation - 1)
+// fix-up passes, the bound.  A wave of an unmarked group leaves at its first instruction (pack_unsupported).
+CS_GLOBAL void chain_fix_kernel(DevTables t, DevResults res, int32_t* CS_RESTRICT last_index_rw /* = t.last_index */, int32_t* CS_RESTRICT redo /*[NG]*/,
+                                int32_t* CS_RESTRICT marks /*[1], += groups marked*/) {
+    const int sim = cs::bid() * cs::nthreads() + cs::tid();
+    const int n_sims = t.sim_off ? t.n_sims : 1;
+    if (sim >= n_sims) return;
+    const int g0 = t.sim_off ? t.sim_off[sim] : 0, g1 = t.sim_off ? t.sim_off[sim + 1] : t.NG;
+    int n = 0;
+    for (int i = g0; i < g1; ++i) {
+        int r = 0;
+        if (i > g0) {
+            const int32_t want = res.last_index_out[i - 1];
+            if (last_index_rw[i] != want) { last_index_rw[i] = want; r = 1; ++n; }
+        }
+        redo[i] = r;
+    }
+    if (n && marks) cs::atomic_add_i32(marks, n);
 }
 
 }  // namespace casim

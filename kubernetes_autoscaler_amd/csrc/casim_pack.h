@@ -1212,6 +1212,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
 template <int DW /* dwords of a PEG record, 0 = the three-array form */>
 CS_DEVICE bool pack_unsupported(const DevTables& t, const DevResults& res) {
     const int ng = cs::bid(), lane = cs::lane();
+    if (t.chain_redo && !t.chain_redo[ng]) return true;   // (a fix-up pass of casim_options.chain_last_index: this group's input did not change)
     const int off = t.peg_off[ng], Gn = t.peg_cnt ? t.peg_cnt[ng] : t.peg_off[ng + 1] - off;
     bool bad = false;
     for (int i = lane; i < Gn; i += 64) bad |= ((DW > 0 ? res.rec[(int64_t)(off + i) * DW + 1] : res.s_flags[off + i]) & CASIM_PEG_UNSUPPORTED) != 0;

@@ -13,6 +13,7 @@
 //     size_t lds_budget() const;             // dynamic LDS bytes one workgroup may ask for
 //     template <class K, class... A> void launch(K kernel, int gx, int gy, int block, size_t smem, A... args);
 //     void   launch_pack_fast(int lanes, int slots_per_lane, int excl_words, int n_groups, DevTables, DevResults, FastScratch);
+//     void   prepare_pack_fast(int build, int lanes, int slots_per_lane, int excl_words);   (before the first launch of an instantiation: init)
 //     bool   ok() const;  const char* error() const;
 //   };
 //
@@ -218,7 +219,10 @@ public:
         struct Stage { bool on; const char* what; std::chrono::steady_clock::time_point t0;
                        void mark(const char* next) { if (!on) return; const auto t1 = std::chrono::steady_clock::now();
                            fprintf(stderr, "[init] %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count()); what = next; t0 = t1; } } stage{timing, "runs + checks", std::chrono::steady_clock::now()};
-        struct GatePass { ProblemT* self; ~GatePass() { self->pass_gate(); } } gate_pass{this};   // (whatever way init() ends, the next part gets its turn)
+        // whatever way init() ends, the next part gets its turn — and a FAILED init does not return while a copy out of the caller's own
+        // page-locked columns is still in flight (casim.h: "does not return before the copies have finished"; the caller may reuse its
+        // tables right after the error return — ADVICE r4)
+        struct GatePass { ProblemT* self; ~GatePass() { if (!self->ready_ && self->direct_uploads_ > 0) self->bk_.sync(); self->pass_gate(); } } gate_pass{this};
         if (p->n_pegs < 0 || g->n_groups < 0) return fail(CASIM_ERR_INVALID, "negative size");
         if (p->n_res < 2 || p->n_res > CASIM_KMAX_RES) return fail(CASIM_ERR_INVALID, "n_res must be in [2, 8]");
         if (p->w_taint < 0 || p->w_label < 0 || p->w_excl < 0 || p->w_zone < 0) return fail(CASIM_ERR_INVALID, "negative mask width");
@@ -325,6 +329,16 @@ public:
             dt_.sim_off = up(g->sim_offsets, (size_t)n_sims_ + 1); dt_.n_sims = n_sims_;
         }
         dt_.global_id = g->global_id ? up(g->global_id, NG) : nullptr;
+        // casim_options.chain_last_index: lastIndex handed from group to group inside a simulation (run_pack: fixed-point passes)
+        chain_ = o && o->chain_last_index != 0 && NG > 1;
+        chain_passes_ = chain_ ? (n_sims_ > 0 ? max_sim_groups_ : NG_) - 1 : 0;
+        if (chain_passes_ <= 0) chain_ = false;
+        d_chain_redo_ = nullptr; d_chain_marks_ = nullptr;
+        if (chain_) {
+            d_chain_redo_ = (int32_t*)dalloc(4 * NG);
+            d_chain_marks_ = (int32_t*)dalloc(4 * ((size_t)chain_passes_ + 1));
+            bk_.zero(d_chain_marks_, 4 * ((size_t)chain_passes_ + 1));
+        }
         // ---- schedulable subsets ----
         csr_on_device_ = g->peg_offsets == nullptr;
         dt_.lists_from_feas = csr_on_device_ ? 1 : 0;
@@ -575,6 +589,7 @@ public:
                 fast_r_ = R <= 2 ? 2 : 4;
             }
             if (fast_npt_ == 0) fast_retry_ = false;
+            else bk_.prepare_pack_fast(pack_build_, fast_i64_ ? 8 : fast_r_, fast_npt_, fast_wx_);   // (the instantiation's self-check, first use only: here, not inside the first launch)
         }
         ps_.node_cap = up(cap.data(), NG);
         if (o && o->node_pods) {   // pods per simulated node (estimationAnalyserFunc's newNodesWithPods)
@@ -645,10 +660,38 @@ public:
         opt_cap_ = 1;
         stage.mark("H2D copy + sync");
         end_uploads();
+        // the streaming feasibility kernel's group records (feas_group_records_kernel): once per problem, behind the uploads on the same stream
+        d_feas_rec_ = nullptr;
+        {
+            const bool off = getenv("CASIM_NO_FEAS_STREAM") != nullptr;   // A/B switch: the LDS-staged feas_sim_kernel of round 4
+            if (!off && feas_by_sim_ && csr_on_device_ && fast_npt_ > 0 && !fast_i64_ && fs_.fresh32 && NG_ > 0 && dt_.R <= 4) {
+                d_feas_rec_ = (uint32_t*)dalloc(((size_t)NG_ + 2) * CASIM_FEAS_REC_DW * 4);
+                // narrow dictionaries (every taint / label-requirement bit below bit 31): decided on the device, read back behind the sync a
+                // resident problem's init ends with anyway — the records are then built a second time in their mask31 form (once per
+                // problem); a one-shot call does not wait here and runs the general instantiation
+                feas_mask31_ = false; h_mask_hi_ = ~0ull;
+                if (d_feas_rec_) bk_.launch(feas_group_records_kernel, (NG_ + 257) / 256, 1, 256, (size_t)0, dt_, fs_.fresh32, d_feas_rec_, 0);
+                if (d_feas_rec_ && !one_shot_) {
+                    uint64_t* flag = (uint64_t*)dalloc(8);
+                    if (flag) {
+                        bk_.zero(flag, 8);
+                        const int64_t na = (int64_t)NG_ * dt_.Wt, nb = (int64_t)G_ * dt_.Wl;
+                        const int64_t most = na > nb ? na : nb;
+                        const int blocks = (int)(most / 2048 > 1024 ? 1024 : (most / 2048 < 1 ? 1 : most / 2048));
+                        bk_.launch(mask_hi_or_kernel, blocks, 1, 256, (size_t)0, dt_.taint, na, dt_.sel, nb, flag);
+                        bk_.d2h(&h_mask_hi_, flag, 8);
+                    }
+                }
+            }
+        }
         // the staging buffer belongs to the backend: the next problem of this context may reuse it after init() — unless the caller
         // runs and fetches THIS problem before anything else touches the context (one call = one problem: casim_estimate_batch); the
         // copy then drains with the kernels behind it and a single call waits for the device once instead of twice
-        if (!one_shot_) bk_.sync();
+        if (!one_shot_) {
+            bk_.sync();
+            feas_mask31_ = d_feas_rec_ != nullptr && h_mask_hi_ == 0;
+            if (feas_mask31_) bk_.launch(feas_group_records_kernel, (NG_ + 257) / 256, 1, 256, (size_t)0, dt_, fs_.fresh32, d_feas_rec_, 1);
+        }
         pass_gate();
         stage.mark("done");
         if (!bk_.ok()) return fail(CASIM_ERR_HIP, bk_.error());
@@ -724,6 +767,29 @@ public:
     }
     int32_t run_pack() {
         if (NG_ == 0) return CASIM_OK;
+        if (chain_) bk_.zero(d_chain_marks_, 4 * ((size_t)chain_passes_ + 1));
+        run_pack_pass(dt_);
+        if (chain_) {
+            // casim_options.chain_last_index (chain_fix_kernel): fix-up passes to the sequential loop's fixed point.  Nothing is waited for:
+            // the bound — groups per simulation - 1 passes — is enqueued, a pass without marked groups is a row of waves that leave at once.
+            // (the caller's last_index column sits in the upload slab: device memory of this problem, rewritten in place)
+            DevTables dc = dt_;
+            dc.chain_redo = d_chain_redo_;
+            const int n_sims = n_sims_ > 0 ? n_sims_ : 1;
+            for (int pass = 0; pass < chain_passes_; ++pass) {
+                bk_.launch(chain_fix_kernel, (n_sims + 255) / 256, 1, 256, (size_t)0, dt_, dr_, (int32_t*)dt_.last_index, d_chain_redo_, d_chain_marks_ + pass);
+                run_pack_pass(dc);
+            }
+        }
+        return CASIM_OK;
+    }
+    // marked groups per fix-up pass of the last run (chain mode; tests and the bench's chain row): waits for the device
+    std::vector<int32_t> chain_marks() {
+        std::vector<int32_t> h((size_t)(chain_ ? chain_passes_ : 0));
+        if (!h.empty()) { bk_.d2h(h.data(), d_chain_marks_, 4 * h.size()); bk_.sync(); }
+        return h;
+    }
+    int32_t run_pack_pass(const DevTables& dt_) {   // (one launch set of the packer over the groups `dt_` lets through)
         if (fast_npt_ > 0) {
             // register-resident int32 packer: the instantiation (lanes, node slots per lane, exclusion words) is picked by the
             // backend — the product compiles these kernels in their own translation unit (casim_pack_tu.hip)
@@ -1092,6 +1158,12 @@ public:
     bool last_fetch_rebased() const { return fetch_rebased_; }
     void set_upload_gate(UploadGate* g, int index) { gate_ = g; gate_idx_ = index; gate_passed_ = false; }   // before init(): parts of a streamed batch
     void pass_gate() { if (gate_ && !gate_passed_) { gate_passed_ = true; gate_->pass(gate_idx_); } }
+    // [0] the streaming feasibility kernel serves this problem, [1] lean, [2] mask31, [3] its workgroups
+    void feasibility_info(int32_t out[4]) const {
+        const bool stream = d_feas_rec_ != nullptr && fast_npt_ > 0 && (strided_ || feas_by_sim_) && !front_ && !(strided_ && strided_one_launch_);
+        out[0] = stream ? 1 : 0; out[1] = stream && dt_.Wx == 0 && dt_.Wz == 0 && dt_.R <= 2; out[2] = stream && feas_mask31_;
+        out[3] = stream ? ((n_sims_ + 7) / 8) * 8 * ((feas_len_ + 255) / 256) : 0;
+    }
     bool uses_front() const { return front_; }
     bool uses_strided_lists() const { return strided_; }
     bool pack_in_lds() const { return pack_lds_; }
@@ -1103,6 +1175,15 @@ private:
     // the lean instantiation for batches without exclusion words whose (at most two) lanes are narrowed to int32: the headline's shape
     void launch_feas_sim(int gx, int gy, int block, size_t smem, const DevTables& t, uint64_t* bits, int wg, const int32_t* req32, const int32_t* fresh32) {
         const bool lean = t.Wx == 0 && t.Wz == 0 && t.R <= 2 && req32 != nullptr;
+        if (d_feas_rec_ && req32 != nullptr) {   // the streaming form (round 5): group records in scalar registers, XCD-aware 1-D grid
+            const int n_sims = gy, blocks = ((n_sims + 7) / 8) * 8 * gx;
+            if (getenv("CASIM_FEAS_TRACE")) fprintf(stderr, "[feas] feas_stream_kernel<%s, %s> %d blocks x %d, %d simulations\n", lean ? "lean" : "full", feas_mask31_ ? "mask31" : "mask64", blocks, block, n_sims);
+            if (lean) { if (feas_mask31_) bk_.launch(feas_stream_kernel<true, true>, blocks, 1, block, (size_t)0, t, bits, wg, req32, (const uint32_t*)d_feas_rec_, gx, n_sims);
+                        else bk_.launch(feas_stream_kernel<true, false>, blocks, 1, block, (size_t)0, t, bits, wg, req32, (const uint32_t*)d_feas_rec_, gx, n_sims); }
+            else { if (feas_mask31_) bk_.launch(feas_stream_kernel<false, true>, blocks, 1, block, (size_t)0, t, bits, wg, req32, (const uint32_t*)d_feas_rec_, gx, n_sims);
+                   else bk_.launch(feas_stream_kernel<false, false>, blocks, 1, block, (size_t)0, t, bits, wg, req32, (const uint32_t*)d_feas_rec_, gx, n_sims); }
+            return;
+        }
         if (lean) bk_.launch(feas_sim_kernel<true>, gx, gy, block, smem, t, bits, wg, req32, fresh32);
         else bk_.launch(feas_sim_kernel<false>, gx, gy, block, smem, t, bits, wg, req32, fresh32);
     }
@@ -1204,6 +1285,9 @@ private:
     uint8_t* d_opt_set_ = nullptr; int32_t* d_opt_out_ = nullptr; int64_t* d_opt_key_ = nullptr; int64_t* d_opt_packed_ = nullptr;
     uint8_t* d_opt_valid_ = nullptr; size_t opt_cap_ = 0;
     int n_sims_ = 0, max_sim_groups_ = 0, feas_len_ = 0;
+    uint64_t h_mask_hi_ = ~0ull;
+    uint32_t* d_feas_rec_ = nullptr; bool feas_mask31_ = false;   // feas_stream_kernel: [NG][16] group records; every taint / label-requirement bit in the words' lower halves
+    bool chain_ = false; int chain_passes_ = 0; int32_t* d_chain_redo_ = nullptr; int32_t* d_chain_marks_ = nullptr;   // casim_options.chain_last_index
     bool feas_by_sim_ = false;
     bool one_shot_ = false;
     UploadGate* gate_ = nullptr; int gate_idx_ = 0; bool gate_passed_ = false;

@@ -12,7 +12,8 @@
 //     out of a Go map (equivalence.groupPodsBySchedulingProperties, CA/core/scaleup/equivalence/groups.go:62-104: `range` over
 //     map[equivalenceGroupId]) — its order is random per loop, and the estimator sorts the PEGs by score before it uses them
 //     (DecreasingPodOrderer); input order only breaks score ties, which the reference therefore breaks at random itself,
-//   * the limiter's answer (max_nodes after StartEstimation), the snapshot's node count E and lastIndex —
+//   * the limiter's answer (max_nodes after StartEstimation), the snapshot's node count E and lastIndex (with casim_options.chain_last_index:
+//     the lastIndex the group's predecessor in the batch left behind — the runner's value when the calls arrive in the batch's order) —
 // and everything else is a miss with its reason, answered by the per-call path (one casim_estimate_batch with one group).
 // Keys are opaque to this file: the Go side hashes what it has (pointer of the exemplar pod, group id string).
 #include <stdint.h>
@@ -85,6 +86,14 @@ int32_t casim_prefetch_fill(casim_prefetch* p, const casim_pegs* pegs, const cas
         e.max_nodes = groups->max_nodes ? groups->max_nodes[i] : 0;
         e.existing = groups->existing_nodes ? groups->existing_nodes[i] : 0;
         e.last_index = groups->last_index ? groups->last_index[i] : 0;
+        // casim_options.chain_last_index: group i ran with the lastIndex its predecessor (of the same simulation) left — THAT is the question the
+        // batch answered for it, and what a lookup has to come with (the shim passes the runner's current lastIndex: a hit then proves that the
+        // Estimate() calls so far arrived in the batch's order, and the shim moves the runner on to this group's last_index_out)
+        if (opts && opts->chain_last_index && i > 0) {
+            bool first_of_sim = false;
+            if (groups->n_sims > 0 && groups->sim_offsets) for (int32_t s2 = 0; s2 < groups->n_sims && !first_of_sim; ++s2) first_of_sim = groups->sim_offsets[s2] == i;
+            if (!first_of_sim) e.last_index = a[4 * (size_t)NG + (size_t)i - 1];
+        }
         const int32_t lo = off[(size_t)i], n = off[(size_t)i + 1] - lo;
         // Estimate() receives the schedulable PEGs in the order of the caller's list: explicit lists keep theirs, device-derived
         // subsets come in table order (ascending PEG id)

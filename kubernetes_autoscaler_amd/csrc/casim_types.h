@@ -53,6 +53,9 @@ struct DevTables {
     // fixed-stride lists (batches, front_sim_kernel): peg_off is STATIC — group ng owns the region [peg_off[ng], peg_off[ng] + (peg_hi - peg_lo)) of
     // order / placed / the record array — and its list length is peg_cnt[ng]; null = compact CSR, length = peg_off[ng + 1] - peg_off[ng]
     const int32_t* peg_cnt;   // [NG] or null
+    // casim_options.chain_last_index: null in the first packer pass; in the fix-up passes chain_redo[ng] != 0 marks the groups whose input
+    // lastIndex changed (chain_fix_kernel) — every other group's wave leaves at once
+    const int32_t* chain_redo;// [NG] or null
 };
 
 struct DevResults {

@@ -28,7 +28,14 @@ class Encoder:
     """One encoder instance == one scale-up loop's worth of PEGs and node groups."""
 
     def __init__(self, lanes: Sequence[str] = DEFAULT_LANES, enable_taint_comparison_ops: bool = False,
-                 explicit_self_exclusion: bool = False):
+                 explicit_self_exclusion: bool = False, named_lanes: bool = False):
+        """named_lanes: the call sequence of the Go shim (integration/go/gpubinpacking/encode.go) — three positional lanes (cpu, memory,
+        ephemeral-storage) and EVERY other resource of a pod's requests / a node's allocatable handed over by name
+        (casim_enc_pod_set_request / casim_enc_group_set_allocatable, ABI 9): lane numbers stay behind the ABI; a name that finds no
+        lane delegates the pod instead of dropping the request.  `lanes` is ignored then (self.lanes is read back after finalize)."""
+        self.named_lanes = bool(named_lanes)
+        if self.named_lanes:
+            lanes = (RES_CPU, RES_MEMORY, RES_EPHEMERAL)
         if len(lanes) < 2 or len(lanes) > _abi.MAX_RES or lanes[0] != RES_CPU or lanes[1] != RES_MEMORY:
             raise ValueError("lanes must start with ('cpu', 'memory') and have 2..8 entries")
         self.lanes = tuple(lanes)
@@ -72,10 +79,16 @@ class Encoder:
             return self._spec_of[key]
         self._keep.append(pod)
         h = self._h
-        unknown = [r for r, v in pod.requests.items() if r not in self.lanes and v]
+        unknown = [r for r, v in pod.requests.items() if r not in self.lanes and v] if not self.named_lanes else []
         s = lib.casim_enc_add_pod_spec(h, _b(pod.namespace), self._lane_vector(pod.requests))
         if s < 0:
             check(s, "casim_enc_add_pod_spec")
+        if self.named_lanes:   # ScalarResources by name (fit.go:731-763); CASIM_ENC_DELEGATED (1) = no lane left, the pod is marked unsupported
+            for name, v in pod.requests.items():
+                if name not in (RES_CPU, RES_MEMORY, RES_EPHEMERAL):
+                    rc = lib.casim_enc_pod_set_request(h, s, _b(name), int(v))
+                    if rc < 0:
+                        check(rc, "casim_enc_pod_set_request")
         for k, v in pod.labels.items():
             check(lib.casim_enc_pod_add_label(h, s, _b(k), _b(v)))
         for t in pod.tolerations:
@@ -219,6 +232,12 @@ class Encoder:
                                     int(node.unschedulable))
         if g < 0:
             check(g, "casim_enc_add_group")
+        if self.named_lanes:
+            for name, v in node.allocatable.items():
+                if name not in (RES_CPU, RES_MEMORY, RES_EPHEMERAL, "pods"):
+                    rc = lib.casim_enc_group_set_allocatable(self._h, g, _b(name), int(v))
+                    if rc < 0:
+                        check(rc, "casim_enc_group_set_allocatable")
         for k, v in node.labels.items():
             check(lib.casim_enc_group_add_label(self._h, g, _b(k), _b(v)))
         for t in node.taints:
@@ -291,6 +310,8 @@ class Encoder:
     def finalize(self):
         check(lib.casim_enc_finalize(self._h), "casim_enc_finalize")
         self.finalized = True
+        if self.named_lanes:   # which resource each lane of the tables stands for
+            self.lanes = tuple((lib.casim_enc_lane_name(self._h, i) or b"").decode() for i in range(lib.casim_enc_lane_count(self._h)))
         self.pegs = _abi.Pegs()
         self.groups = _abi.Groups()
         check(lib.casim_enc_tables(self._h, C.byref(self.pegs), C.byref(self.groups)))
@@ -308,6 +329,12 @@ class Encoder:
         node = template.node
         check(lib.casim_enc_group_reset(self._h, int(g), self._lane_vector(node.allocatable), node.allowed_pods(), int(node.capacity.get(RES_CPU, 0)),
                                         int(node.capacity.get(RES_MEMORY, 0)), int(node.unschedulable)), "casim_enc_group_reset")
+        if self.named_lanes:
+            for name, v in node.allocatable.items():
+                if name not in (RES_CPU, RES_MEMORY, RES_EPHEMERAL, "pods"):
+                    rc = lib.casim_enc_group_set_allocatable(self._h, int(g), _b(name), int(v))
+                    if rc < 0:
+                        check(rc, "casim_enc_group_set_allocatable")
         for k, v in node.labels.items():
             check(lib.casim_enc_group_add_label(self._h, g, _b(k), _b(v)))
         for t in node.taints:

@@ -448,11 +448,13 @@ class Problem:
     """casim_problem: a batch resident in HBM; run() enqueues feasibility -> order -> pack."""
 
     def __init__(self, ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, fastpath: bool = False, force_generic_packer: bool = False,
-                 node_pods: bool = False, n_streams: int = 0, pack_build: int = 0, no_front_kernel: bool = False):
+                 node_pods: bool = False, n_streams: int = 0, pack_build: int = 0, no_front_kernel: bool = False, chain_last_index: bool = False):
         """n_streams > 1: a batch of simulations runs as up to n_streams sub-batches on internal HIP streams of the context
         (casim_options.n_streams); results are identical, info()["parts"] tells whether the batch was cut.
         pack_build: _abi.PACK_BUILD_AUTO / _PLAIN / _OPTION (casim_options.pack_build).
-        no_front_kernel: the four separate launches of a batch instead of the fused one (casim_options.no_front_kernel; info()["front_kernel"])."""
+        no_front_kernel: the four separate launches of a batch instead of the fused one (casim_options.no_front_kernel; info()["front_kernel"]).
+        chain_last_index: the groups of one simulation as successive Estimate() calls on one snapshot — lastIndex handed from group to group
+        (casim_options.chain_last_index, plugin_runner.go:138)."""
         self.ctx = ctx
         self.n_groups = groups.n_groups
         self.n_pegs = pegs.n_pegs
@@ -463,7 +465,8 @@ class Problem:
             self._node_pods_cap = int(sum((int(groups.max_nodes[i]) if groups.max_nodes[i] > 0 else (0 if groups.max_nodes[i] < 0 else total))
                                           for i in range(groups.n_groups))) + 64
         opts = _abi.Options(fastpath=int(fastpath), force_generic_packer=int(force_generic_packer), node_pods=int(bool(node_pods)),
-                            n_streams=int(n_streams), pack_build=int(pack_build), no_front_kernel=int(bool(no_front_kernel)))
+                            n_streams=int(n_streams), pack_build=int(pack_build), no_front_kernel=int(bool(no_front_kernel)),
+                            chain_last_index=int(bool(chain_last_index)))
         self._h = lib.casim_problem_create(ctx._h, C.byref(pegs), C.byref(groups), C.byref(opts))
         if not self._h:
             raise CasimError(_abi.ERR_INVALID, last_error())
@@ -573,6 +576,14 @@ class Problem:
         return float(tot.value), {"feasibility_csr_ms": ks[0], "order_ms": ks[1], "pack_ms": ks[2]}
 
 
+    def time_feasibility(self, iters: int = 50):
+        """casim_problem_time_feasibility: (ms per feasibility launch, {"stream", "lean", "mask31", "workgroups"})"""
+        ms = C.c_float(0)
+        info = (C.c_int32 * 4)()
+        check(lib.casim_problem_time_feasibility(self._h, int(iters), C.byref(ms), info), "casim_problem_time_feasibility")
+        return float(ms.value), {"stream": bool(info[0]), "lean": bool(info[1]), "mask31": bool(info[2]), "workgroups": int(info[3])}
+
+
 def estimate_batch_timed(ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, kinds: Optional[Sequence[int]] = None, fastpath: bool = False,
                          nnz_cap: Optional[int] = None):
     """casim_estimate_batch_timed: one whole call (tables -> HBM -> kernels -> results) with its phase breakdown.
@@ -617,7 +628,8 @@ class BatchCall:
     the context's internal streams.  call() returns (BatchResult, expander dict or None)."""
 
     def __init__(self, ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, kinds: Optional[Sequence[int]] = None, fastpath: bool = False,
-                 force_generic_packer: bool = False, n_streams: int = 0, winners_only: bool = False, pinned_results: bool = False):
+                 force_generic_packer: bool = False, n_streams: int = 0, winners_only: bool = False, pinned_results: bool = False,
+                 chain_last_index: bool = False):
         """winners_only (casim_options.winners_only): order / placed come back for the winning group of every simulation only —
         call() then returns a BatchResult whose `order` / `placed` are those compact lists and whose `winner_offsets` [S + 1] says where
         simulation s's list sits (see winners_view)."""
@@ -626,7 +638,7 @@ class BatchCall:
         self.winners_only = bool(winners_only)
         self.st, self.arrs = alloc_results(ng, _nnz_cap(pegs, groups), pinned_lists=pinned_results)
         self.opts = _abi.Options(fastpath=int(fastpath), force_generic_packer=int(force_generic_packer), n_streams=int(n_streams),
-                                 winners_only=int(self.winners_only))
+                                 winners_only=int(self.winners_only), chain_last_index=int(bool(chain_last_index)))
         self.off = np.zeros(ng + 1, np.int32)
         self.q = self.exp = None
         if kinds is not None:
@@ -688,11 +700,11 @@ class PrefetchCache:
     def clear(self):
         lib.casim_prefetch_clear(self._h)
 
-    def fill(self, pegs: _abi.Pegs, groups: _abi.Groups, group_keys, peg_keys, fastpath: bool = False):
+    def fill(self, pegs: _abi.Pegs, groups: _abi.Groups, group_keys, peg_keys, fastpath: bool = False, chain_last_index: bool = False):
         gk = np.ascontiguousarray(group_keys, np.uint64); pk = np.ascontiguousarray(peg_keys, np.uint64)
         if gk.shape[0] != groups.n_groups or pk.shape[0] != pegs.n_pegs:
             raise ValueError("one key per group and per PEG")
-        opts = _abi.Options(fastpath=int(fastpath))
+        opts = _abi.Options(fastpath=int(fastpath), chain_last_index=int(bool(chain_last_index)))
         rc = lib.casim_prefetch_fill(self._h, C.byref(pegs), C.byref(groups), C.byref(opts), gk.ctypes.data_as(_abi.u64p), pk.ctypes.data_as(_abi.u64p))
         if rc != 0:
             raise CasimError(rc, (lib.casim_prefetch_error(self._h) or b"").decode())

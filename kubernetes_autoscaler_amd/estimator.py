@@ -217,12 +217,15 @@ class BinpackingNodeEstimator:
         self.limiter.start_estimation(pegs, node_group, self.context)
         try:
             if self.prefetch is not None and self.analyser is None:   # (the analyser wants the pods per node: per-call path)
-                hit = self.prefetch.lookup(pegs, node_template, node_group, self.limiter.device_max_nodes(), len(self.snapshot.existing))
+                hit = self.prefetch.lookup(pegs, node_template, node_group, self.limiter.device_max_nodes(), len(self.snapshot.existing),
+                                           runner_last_index=self.snapshot.last_index)
                 if hit is not None and hit["status"] == 0:
                     pods = []
                     for k, n in zip(hit["order"], hit["placed"]):
                         pods.extend(pegs[int(k)].pods[:int(n)])
                     self.limiter.nodes = hit["limiter_nodes"]
+                    if self.prefetch.chain:   # the runner moves on exactly as if this Estimate had run here (plugin_runner.go:138)
+                        self.snapshot.last_index = hit["last_index_out"]
                     return hit["node_count"], pods
                 # miss (another PEG subset, another limiter answer, unknown group) or a delegated group: the per-call path below
             enc = Encoder(lanes=self.lanes)
@@ -292,8 +295,14 @@ class PrefetchShared:
     of a prefetched loop do not thread lastIndex from one group into the next (the per-call path does)."""
 
     def __init__(self, engine_ctx: Context, limiter: "ThresholdBasedEstimationLimiter", max_nodes_total: int = 0, fastpath: bool = False,
-                 lanes: Sequence[str] = ("cpu", "memory")):
+                 lanes: Sequence[str] = ("cpu", "memory"), chain_last_index: bool = True):
+        """chain_last_index (default since round 5, casim_options.chain_last_index): the batch estimates the groups in the order the processor
+        handed them over, each from the lastIndex its predecessor left — what the orchestrator's loop does on one snapshot
+        (plugin_runner.go:138).  A lookup then comes with the runner's CURRENT lastIndex: it hits only while the Estimate() calls arrive in
+        the batch's order, and a hit moves the runner on (BinpackingNodeEstimator.estimate).  False: every group from the loop's lastIndex
+        (rounds 3-4; hits never moved the runner)."""
         from .engine import PrefetchCache
+        self.chain = bool(chain_last_index)
         self.ctx, self.limiter, self.max_nodes_total, self.fastpath, self.lanes = engine_ctx, limiter, max_nodes_total, fastpath, lanes
         self.cache = PrefetchCache(engine_ctx)
         self.loop_last_index = 0
@@ -329,13 +338,14 @@ class PrefetchShared:
             gkeys.append(self.group_key(ng, node_infos[ng.id()]))
         enc.finalize()
         try:
-            self.cache.fill(enc.pegs, enc.groups, gkeys, [self.peg_key(pg) for pg in pegs], self.fastpath)
+            self.cache.fill(enc.pegs, enc.groups, gkeys, [self.peg_key(pg) for pg in pegs], self.fastpath, chain_last_index=self.chain)
         finally:
             enc.close()
 
-    def lookup(self, pegs, node_template, node_group, max_nodes: int, existing_nodes: int):
-        hit, out = self.cache.lookup(self.group_key(node_group, node_template), [self.peg_key(pg) for pg in pegs], max_nodes, existing_nodes,
-                                     self.loop_last_index)
+    def lookup(self, pegs, node_template, node_group, max_nodes: int, existing_nodes: int, runner_last_index: Optional[int] = None):
+        """runner_last_index: the snapshot runner's lastIndex at the time of THIS Estimate() (chain mode); None = the loop's (unchained mode)"""
+        li = self.loop_last_index if (runner_last_index is None or not self.chain) else runner_last_index
+        hit, out = self.cache.lookup(self.group_key(node_group, node_template), [self.peg_key(pg) for pg in pegs], max_nodes, existing_nodes, li)
         return out if hit else None
 
 

@@ -10,7 +10,8 @@ import ctypes as C
 
 from . import _abi
 
-_SKIP = {"casim_enc_destroy", "casim_enc_tables", "casim_enc_domain_rules", "casim_enc_port_block", "casim_enc_dict_sizes"}
+_SKIP = {"casim_enc_destroy", "casim_enc_tables", "casim_enc_domain_rules", "casim_enc_port_block", "casim_enc_dict_sizes",
+         "casim_enc_lane_count", "casim_enc_lane_name"}   # (read-only)
 # integer array arguments: function -> {arg index: length spec}; 'R' = encoder lanes (MAX_RES slots are passed, R are read),
 # ('arg', i) = value of argument i, ('mul', i, 'R') = argument i times R, None = output / unused
 _ARRAYS = {

@@ -1305,10 +1305,15 @@ int orc_check_predicates(orc* o, int template_node, int pod, const char** plugin
  * through orc_estimate.  Per-group scalars land in out[i]; order / placed of group i in order_out / placed_out at
  * [i * n_pegs, ...) (positions index the group's own schedulable list, whose PEG ids are in sched_out at the same
  * offset, n_sched_out[i] entries). */
-int orc_scale_up_simulation(orc* o, int n_groups, const int32_t* template_node, int n_pegs, const int32_t* peg_pod,
+/* chain != 0: the loop as the orchestrator really runs it on ONE snapshot — the plugin runner's lastIndex (plugin_runner.go:138 MarkMatch on
+ * the runner's defaultNodeOrdering; the runner belongs to the snapshot, predicate_snapshot.go:64) is never reverted by the Fork / Revert around an
+ * Estimate, so group i starts from the lastIndex group i - 1 left behind; last_index[0] is the loop's starting value, the other entries are
+ * ignored.  chain == 0: every Estimate starts from its own last_index entry (independent calls). */
+static int scale_up_simulation(orc* o, int chain, int n_groups, const int32_t* template_node, int n_pegs, const int32_t* peg_pod,
                             const int32_t* peg_count, const int32_t* max_nodes, const int32_t* last_index,
                             orc_estimate_result* out, int32_t* n_sched_out, int32_t* sched_out, int32_t* order_out,
                             int32_t* placed_out, int64_t* filter_runs_out) {
+    int32_t carried = n_groups > 0 ? last_index[0] : 0;
     int32_t* pods = malloc(sizeof(int32_t) * (size_t)(n_pegs + 1));
     int32_t* cnts = malloc(sizeof(int32_t) * (size_t)(n_pegs + 1));
     int64_t runs = 0;
@@ -1325,12 +1330,27 @@ int orc_scale_up_simulation(orc* o, int n_groups, const int32_t* template_node, 
         n_sched_out[i] = n;
         memset(&out[i], 0, sizeof out[i]);
         out[i].order = order_out + (size_t)i * (size_t)n_pegs; out[i].placed = placed_out + (size_t)i * (size_t)n_pegs;
-        rc = orc_estimate(o, template_node[i], n, pods, cnts, max_nodes[i], last_index[i], 0, &out[i]);
+        rc = orc_estimate(o, template_node[i], n, pods, cnts, max_nodes[i], chain ? carried : last_index[i], 0, &out[i]);
+        carried = out[i].last_index_out;
         runs += out[i].filter_runs;
     }
     free(pods); free(cnts);
     if (filter_runs_out) *filter_runs_out = runs;
     return rc;
+}
+int orc_scale_up_simulation(orc* o, int n_groups, const int32_t* template_node, int n_pegs, const int32_t* peg_pod,
+                            const int32_t* peg_count, const int32_t* max_nodes, const int32_t* last_index,
+                            orc_estimate_result* out, int32_t* n_sched_out, int32_t* sched_out, int32_t* order_out,
+                            int32_t* placed_out, int64_t* filter_runs_out) {
+    return scale_up_simulation(o, 0, n_groups, template_node, n_pegs, peg_pod, peg_count, max_nodes, last_index, out, n_sched_out, sched_out, order_out,
+                               placed_out, filter_runs_out);
+}
+int orc_scale_up_simulation_chained(orc* o, int n_groups, const int32_t* template_node, int n_pegs, const int32_t* peg_pod,
+                                    const int32_t* peg_count, const int32_t* max_nodes, const int32_t* last_index,
+                                    orc_estimate_result* out, int32_t* n_sched_out, int32_t* sched_out, int32_t* order_out,
+                                    int32_t* placed_out, int64_t* filter_runs_out) {
+    return scale_up_simulation(o, 1, n_groups, template_node, n_pegs, peg_pod, peg_count, max_nodes, last_index, out, n_sched_out, sched_out, order_out,
+                               placed_out, filter_runs_out);
 }
 
 /* ------------------------------------------------------------------------------------- */

@@ -123,6 +123,11 @@ int orc_scale_up_simulation(orc* o, int n_groups, const int32_t* template_node, 
                             const int32_t* peg_count, const int32_t* max_nodes, const int32_t* last_index,
                             orc_estimate_result* out, int32_t* n_sched_out, int32_t* sched_out, int32_t* order_out,
                             int32_t* placed_out, int64_t* filter_runs_out);
+/* the same loop with lastIndex carried from group to group (the plugin runner's state survives every Estimate: plugin_runner.go:138) */
+int orc_scale_up_simulation_chained(orc* o, int n_groups, const int32_t* template_node, int n_pegs, const int32_t* peg_pod,
+                            const int32_t* peg_count, const int32_t* max_nodes, const int32_t* last_index,
+                            orc_estimate_result* out, int32_t* n_sched_out, int32_t* sched_out, int32_t* order_out,
+                            int32_t* placed_out, int64_t* filter_runs_out);
 
 /* CheckPredicates(exemplar, template) as in SchedulablePodGroups (orchestrator.go:535-570):
  * returns 1 pass / 0 fail; *plugin_out (may be NULL) receives a static plugin name. */

@@ -4,6 +4,9 @@ import sys
 
 import pytest
 
+# the host's setting for a streamed batch's internal streams (one hardware queue each); libcasim does not edit the environment by itself
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

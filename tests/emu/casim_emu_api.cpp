@@ -37,6 +37,7 @@ struct EmuBackend {
     void launch(K kernel, int gx, int gy, int block, size_t smem, A... args) {
         casim_emu::launch(gx, gy, block, smem, [&]() { kernel(args...); });
     }
+    void prepare_pack_fast(int, int, int, int) {}
     void launch_pack_fast(int /*build: one build under the emulator*/, int lanes, int slots_per_lane, int excl_words, int n_groups, const DevTables& t, const DevResults& res, const FastScratch& fs) {
 #define CASIM_EMU_FAST(R, N, X) do { if constexpr ((R) == 8) launch(casim::pack_fast64_kernel<N, X>, n_groups, 1, 64, (size_t)0, t, res, fs); \
                                      else launch(casim::pack_fast_kernel<((R) == 8 ? 2 : (R)), N, X>, n_groups, 1, 64, (size_t)0, t, res, fs); } while (0)
@@ -82,7 +83,9 @@ EMU_API int32_t emu_estimate_batch_query(const casim_pegs* pegs, const casim_gro
     casim::ProblemT<EmuBackend> p(bk);
     // the sequence of casim_estimate_batch_query (csrc/casim_engine.hip): one-shot problem, the expander's answer left in flight until
     // the fetch has waited, offsets from the fetch
-    p.set_one_shot(true);
+    // (CASIM_EMU_RESIDENT=1: the resident form instead — casim_problem_create + run: init ends with a wait, which is where a problem learns
+    // facts about its tables from the device, e.g. feas_stream_kernel's narrow-dictionary instantiation)
+    p.set_one_shot(getenv("CASIM_EMU_RESIDENT") == nullptr);
     int32_t rc = p.init(pegs, groups, opts);
     if (rc == CASIM_OK) rc = p.run();
     const bool one_wait = q && out;

@@ -39,28 +39,33 @@ class Scenario:
 
 
 # ---------------------------------------------------------------------------------------------
-def run_oracle(sc: Scenario, list_shuffle_seed: int = 0):
+def run_oracle(sc: Scenario, list_shuffle_seed: int = 0, chain: bool = False):
     """Per group: OracleEstimate plus the list of global PEG ids it was given.  list_shuffle_seed != 0: every
-    scheduling attempt sees the node list in a fresh random order (Go map iteration)."""
+    scheduling attempt sees the node list in a fresh random order (Go map iteration).
+    chain: lastIndex carried from one group's Estimate to the next (one snapshot, one plugin runner: plugin_runner.go:138)."""
     s = OracleScenario(lanes=sc.lanes, list_shuffle_seed=list_shuffle_seed)
     for info in sc.existing:
         s.add_existing(info)
     out = []
+    carried = None
     for g in sc.groups:
         tmpl = s.node(g.template)
         if g.pegs is None and sc.device_csr:
             ids = [i for i, pg in enumerate(sc.pegs) if pg.exemplar() is not None and s.check_predicates(tmpl, pg.exemplar())[0]]
         else:
             ids = list(range(len(sc.pegs))) if g.pegs is None else list(g.pegs)
-        est = s.estimate(tmpl, [sc.pegs[i] for i in ids], max_nodes=g.max_nodes, last_index=g.last_index, fastpath=sc.fastpath,
-                         node_pods_cap=0)
+        est = s.estimate(tmpl, [sc.pegs[i] for i in ids], max_nodes=g.max_nodes, last_index=g.last_index if (carried is None or not chain) else carried,
+                         fastpath=sc.fastpath, node_pods_cap=0)
+        carried = est.last_index_out
         out.append((est, ids))
     s.close()
     return out
 
 
-def encode(sc: Scenario) -> Encoder:
-    enc = Encoder(lanes=sc.lanes)
+def encode(sc: Scenario, named_lanes: bool = False) -> Encoder:
+    """named_lanes: the Go shim's call sequence — three positional lanes, every other resource by NAME (casim_enc_pod_set_request /
+    casim_enc_group_set_allocatable, ABI 9)"""
+    enc = Encoder(lanes=sc.lanes, named_lanes=named_lanes)
     for pg in sc.pegs:
         enc.add_peg(pg)
     for info in sc.existing:
@@ -92,7 +97,7 @@ def emu_lib():
     return _emu
 
 
-def run_emu(enc: Encoder, fastpath=False, lds_budget=0, kinds=None, group_id_base=0, generic=False, front=True):
+def run_emu(enc: Encoder, fastpath=False, lds_budget=0, kinds=None, group_id_base=0, generic=False, front=True, chain=False):
     """Product kernels under the wave emulator.  Returns (BatchResult, best) where best is
     None or (best_index, n_best, best_set, key)."""
     L = emu_lib()
@@ -100,7 +105,7 @@ def run_emu(enc: Encoder, fastpath=False, lds_budget=0, kinds=None, group_id_bas
     ng, G = groups.n_groups, pegs.n_pegs
     nnz_cap = G * ng if not groups.peg_offsets else groups.peg_offsets[ng]
     st, arrs = alloc_results(ng, nnz_cap)
-    opts = _abi.Options(fastpath=int(fastpath), force_generic_packer=int(generic), no_front_kernel=int(not front))
+    opts = _abi.Options(fastpath=int(fastpath), force_generic_packer=int(generic), no_front_kernel=int(not front), chain_last_index=int(chain))
     nnz = C.c_int32(0)
     off = np.zeros(ng + 1, np.int32)
     best = (C.c_int32 * 2)(-1, 0)
@@ -124,9 +129,9 @@ def run_emu_feasibility(enc: Encoder) -> np.ndarray:
     return bits[:enc.groups.n_groups, :wg]
 
 
-def run_gpu(enc: Encoder, ctx, fastpath=False, kinds=None, group_id_base=0, generic=False):
+def run_gpu(enc: Encoder, ctx, fastpath=False, kinds=None, group_id_base=0, generic=False, chain=False):
     from kubernetes_autoscaler_amd.engine import Problem
-    with Problem(ctx, enc.pegs, enc.groups, fastpath, generic) as p:
+    with Problem(ctx, enc.pegs, enc.groups, fastpath, generic, chain_last_index=chain) as p:
         p.run()
         res = p.fetch()
         best = p.best_option(kinds, group_id_base) if kinds is not None else None
@@ -435,7 +440,7 @@ def encode_batch(scenarios: Sequence[Scenario]):
 
 
 def run_emu_tables(ts, kinds=None, per_sim=True, valid=None, fastpath=False, lds_budget=0, node_pods_capacity=0, generic=False, front=True,
-                   winners_only=False):
+                   winners_only=False, chain=False):
     """Product kernels under the wave emulator on a TableSet.  Returns (BatchResult, expander dict or None)."""
     L = emu_lib()
     if not hasattr(L, "_query_bound"):
@@ -453,7 +458,7 @@ def run_emu_tables(ts, kinds=None, per_sim=True, valid=None, fastpath=False, lds
         nnz_cap = pegs.n_pegs * ng
     st, arrs = alloc_results(ng, nnz_cap, node_pods_capacity)
     opts = _abi.Options(fastpath=int(fastpath), node_pods=int(node_pods_capacity > 0), force_generic_packer=int(generic), no_front_kernel=int(not front),
-                        winners_only=int(winners_only))
+                        winners_only=int(winners_only), chain_last_index=int(chain))
     nnz = C.c_int32(0)
     off = np.zeros(ng + 1, np.int32)
     q = exp = None
@@ -474,7 +479,7 @@ def run_emu_tables(ts, kinds=None, per_sim=True, valid=None, fastpath=False, lds
     return finish_results(arrs, ng, int(nnz.value), off), exp
 
 
-def run_emu_streams(ts, n_streams, kinds=None, valid=None, generic=False, group_id_base=0, winners_only=False):
+def run_emu_streams(ts, n_streams, kinds=None, valid=None, generic=False, group_id_base=0, winners_only=False, chain=False):
     """The batch cut into sub-batches the way casim_options.n_streams does it (csrc/casim_streams.h), parts run by the emulator one
     after the other.  Returns (BatchResult, expander dict or None, parts)."""
     L = emu_lib()
@@ -487,7 +492,7 @@ def run_emu_streams(ts, n_streams, kinds=None, valid=None, generic=False, group_
     ng = groups.n_groups
     nnz_cap = int((ts.peg_hi - ts.peg_lo).sum()) if ts.peg_lo is not None else (int(ts.peg_offsets[ng]) if ts.peg_offsets is not None else pegs.n_pegs * ng)
     st, arrs = alloc_results(ng, nnz_cap)
-    opts = _abi.Options(force_generic_packer=int(generic), n_streams=int(n_streams), winners_only=int(winners_only))
+    opts = _abi.Options(force_generic_packer=int(generic), n_streams=int(n_streams), winners_only=int(winners_only), chain_last_index=int(chain))
     nnz, parts = C.c_int32(0), C.c_int32(0)
     off = np.zeros(ng + 1, np.int32)
     q = exp = None
@@ -508,10 +513,10 @@ def run_emu_streams(ts, n_streams, kinds=None, valid=None, generic=False, group_
     return finish_results(arrs, ng, int(nnz.value), off), exp, int(parts.value)
 
 
-def run_gpu_tables(ts, ctx, kinds=None, per_sim=True, valid=None, fastpath=False, n_streams=0, generic=False):
+def run_gpu_tables(ts, ctx, kinds=None, per_sim=True, valid=None, fastpath=False, n_streams=0, generic=False, chain=False):
     from kubernetes_autoscaler_amd.engine import Problem
     pegs, groups = ts.structs()
-    with Problem(ctx, pegs, groups, fastpath, generic, n_streams=n_streams) as p:
+    with Problem(ctx, pegs, groups, fastpath, generic, n_streams=n_streams, chain_last_index=chain) as p:
         p.run()
         res = p.fetch()
         exp = p.best_option_sims(kinds, per_sim=per_sim, valid=valid, n_sims=ts.n_sims) if kinds is not None else None

@@ -79,6 +79,8 @@ def lib():
             "orc_last_fit_reasons": (C.c_uint, []),
             "orc_scale_up_simulation": (C.c_int, [P, C.c_int, i32p, C.c_int, i32p, i32p, i32p, i32p, C.POINTER(EstimateResult), i32p, i32p,
                                                   i32p, i32p, i64p]),
+            "orc_scale_up_simulation_chained": (C.c_int, [P, C.c_int, i32p, C.c_int, i32p, i32p, i32p, i32p, C.POINTER(EstimateResult), i32p, i32p,
+                                                          i32p, i32p, i64p]),
             "orc_check_predicates": (C.c_int, [P, C.c_int, C.c_int, cstrp, cstrp]),
             "orc_run_filters_on_snapshot_node": (C.c_int, [P, C.c_int, C.c_int, cstrp, cstrp]),
             "orc_run_filters_until_passing": (C.c_int, [P, C.c_int, C.POINTER(C.c_int)]),
@@ -273,7 +275,7 @@ class OracleScenario:
                               res.req_cpu_sum, res.req_mem_sum, res.filter_runs, order[:n].copy(), placed[:n].copy(),
                               node_pods[:min(res.nodes_added, node_pods_cap)].copy())
 
-    def prepare_simulation(self, template_nodes, pegs, max_nodes, last_index):
+    def prepare_simulation(self, template_nodes, pegs, max_nodes, last_index, chain=False):
         """Argument block of orc_scale_up_simulation, built once; returns run() -> ([(OracleEstimate, schedulable PEG ids)], filter runs).
         run() is ONE native call: the whole node-group loop (SchedulablePodGroups + Estimate per group)."""
         from kubernetes_autoscaler_amd.objects import Pod
@@ -295,7 +297,7 @@ class OracleScenario:
         p = lambda a: a.ctypes.data_as(i32p)
 
         def run(collect=True):
-            rc = self.L.orc_scale_up_simulation(self.h, ng, p(tn), n, p(pod_ids), p(counts), p(mx), p(li), res, p(nsched), p(sched),
+            rc = (self.L.orc_scale_up_simulation_chained if chain else self.L.orc_scale_up_simulation)(self.h, ng, p(tn), n, p(pod_ids), p(counts), p(mx), p(li), res, p(nsched), p(sched),
                                                 p(order), p(placed), C.byref(runs))
             assert rc == 0, rc
             if not collect:

@@ -41,7 +41,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_abi.Groups) == 8 + 19 * 8 + 3 * 8 + 8 + 8
     assert ctypes.sizeof(_abi.OptionQuery) == 8 + 4 * 4 + 9 * 8      # (+ join_stream, ABI 5)
     assert ctypes.sizeof(_abi.Results) == 10 * 8 + 3 * 8
-    assert ctypes.sizeof(_abi.Options) == 32 and ctypes.sizeof(_abi.EncoderOptions) == 32
+    assert ctypes.sizeof(_abi.Options) == 48 and ctypes.sizeof(_abi.EncoderOptions) == 32   # (+ chain_last_index + 3 reserved words, ABI 9)
 
 
 @pytest.mark.skipif(kaa.device_count() > 0, reason="a GPU is visible")

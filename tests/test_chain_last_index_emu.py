@@ -1,0 +1,79 @@
+"""casim_options.chain_last_index (ABI 9): the groups of one simulation as SUCCESSIVE Estimate() calls on one snapshot — the plugin runner's
+lastIndex (CA/simulator/clustersnapshot/predicate/plugin_runner.go:138, the runner lives in the snapshot: predicate_snapshot.go:64) survives
+every Estimate, so group i starts where group i - 1 stopped.  The engine keeps one wave per group and iterates the packer to the sequential
+loop's fixed point (chain_fix_kernel + re-estimates of the groups whose input changed); the oracle runs the loop as written
+(run_oracle(chain=True), orc_scale_up_simulation_chained).  CPU: product kernels under the wave emulator."""
+import numpy as np
+import pytest
+
+from kubernetes_autoscaler_amd import workloads
+from harness import GroupSpec, Scenario, assert_matches_oracle, encode, encode_batch, run_emu, run_emu_streams, run_emu_tables, run_oracle
+
+
+def _scenario(seed, device_csr, max_groups=7, max_pegs=14, existing=True):
+    w = workloads.fuzz(seed, max_groups=max_groups, max_pegs=max_pegs)
+    return Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, None if device_csr else g.pegs) for g in w.groups],
+                    existing=w.existing if existing else [], lanes=w.lanes, device_csr=device_csr)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_chained_groups_match_the_sequential_loop(seed):
+    sc = _scenario(31000 + seed, device_csr=seed % 2 == 0)
+    want = run_oracle(sc, chain=True)
+    for generic in (False, True):
+        enc = encode(sc)
+        res, _ = run_emu(enc, chain=True, generic=generic)
+        assert_matches_oracle(res, want, f"seed {seed} generic={generic}")
+        enc.close()
+
+
+def test_the_chain_changes_results_somewhere_and_the_unchained_run_differs_there():
+    """the option is not a no-op: over the corpus some group's lastIndex input differs from its own table entry, and with it node counts or
+    placements of some group (what INTEGRATION.md quotes as the prefetch mode's divergence rate comes from tests/tools/chain_rate.py)"""
+    differing_inputs = differing_results = 0
+    for seed in range(40):
+        sc = _scenario(31000 + seed, device_csr=True)
+        a, b = run_oracle(sc, chain=False), run_oracle(sc, chain=True)
+        for (ea, _), (eb, _) in zip(a, b):
+            differing_inputs += ea.last_index_out != eb.last_index_out
+            differing_results += (ea.node_count, ea.pods_scheduled, list(ea.placed)) != (eb.node_count, eb.pods_scheduled, list(eb.placed))
+    assert differing_inputs > 0, "the corpus never exercises a carried lastIndex"
+    print(f"chained vs unchained over 40 scenarios: {differing_inputs} groups end on another lastIndex, {differing_results} differ in (nodes, pods, placed)")
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_chains_stay_inside_their_simulation_in_a_batch(seed):
+    """batches: every simulation is its own chain (its first group starts from its own last_index), also when the batch is cut into streamed parts"""
+    scs = [_scenario(32000 + 100 * seed + k, device_csr=True, max_groups=6, existing=False) for k in range(2 + seed % 4)]
+    enc, ts, bases = encode_batch(scs)
+    want = []
+    for sc, (pb, _) in zip(scs, bases):
+        want.extend([(est, [pb + i for i in ids]) for est, ids in run_oracle(sc, chain=True)])
+    res, _ = run_emu_tables(ts, chain=True)
+    assert_matches_oracle(res, want, f"batch {seed}")
+    res, _ = run_emu_tables(ts, chain=True, generic=True)
+    assert_matches_oracle(res, want, f"batch {seed} (generic packer)")
+    res, _, parts = run_emu_streams(ts, 3, chain=True)
+    assert_matches_oracle(res, want, f"batch {seed} ({parts} streamed parts)")
+    enc.close()
+
+
+def test_a_single_group_and_an_unchained_run_are_untouched():
+    sc = _scenario(31007, device_csr=True, max_groups=1)
+    enc = encode(sc)
+    a, _ = run_emu(enc, chain=True)
+    b, _ = run_emu(enc, chain=False)
+    assert list(a.last_index_out) == list(b.last_index_out) and list(a.node_count) == list(b.node_count)
+    assert_matches_oracle(a, run_oracle(sc), "one group")
+    enc.close()
+
+
+def test_c2_as_one_chained_simulation():
+    """BASELINE config[2] at full size: 20 node groups, one chain"""
+    w = workloads.config_c2()
+    sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing, lanes=w.lanes,
+                  device_csr=True)
+    enc = encode(sc)
+    res, _ = run_emu(enc, chain=True)
+    assert_matches_oracle(res, run_oracle(sc, chain=True), "C2 chained")
+    enc.close()

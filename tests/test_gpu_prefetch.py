@@ -21,14 +21,17 @@ def ctx():
     c.close()
 
 
-def _oracle_per_group(w, last_index=0):
-    """SchedulablePodGroups + Estimate, group by group, every group from the same entry lastIndex."""
+def _oracle_per_group(w, last_index=0, chain=False):
+    """SchedulablePodGroups + Estimate, group by group, every group from the same entry lastIndex — or (chain) from the lastIndex its
+    predecessor left, as the orchestrator's loop runs them on one snapshot (plugin_runner.go:138)."""
     out = []
     for g in w.groups:
         s = OracleScenario(lanes=w.lanes)
         t = s.node(g.template)
         ids = [i for i, pg in enumerate(w.pegs) if s.check_predicates(t, pg.pods[0])[0]]
         e = s.estimate(t, [w.pegs[i] for i in ids], max_nodes=g.max_nodes, last_index=last_index)
+        if chain:
+            last_index = e.last_index_out
         out.append((ids, e))
         s.close()
     return out
@@ -50,12 +53,13 @@ def test_prefetch_mode_answers_every_estimate_of_the_loop_from_one_batch(ctx):
     snapshot = est.ClusterSnapshotView()
     proc.process(snapshot, ngs, infos, pods)
     builder = est.new_estimator_builder(est.GPU_BINPACKING_ESTIMATOR_NAME, limiter, engine_ctx=ctx, prefetch=shared)
-    want = _oracle_per_group(w)
+    want = _oracle_per_group(w, chain=True)   # (the batch chains lastIndex through the groups since round 5: casim_options.chain_last_index)
     for ng, g, (ids, e) in zip(ngs, w.groups, want):
         # the orchestrator's loop: SchedulablePodGroups filtered the PEGs, a fresh estimator per group, ONE Estimate
         estimator = builder(snapshot, est.EstimationContext(0, [], 0))
         n, got_pods = estimator.estimate([w.pegs[i] for i in ids], infos[ng.id()], ng)
         assert (n, len(got_pods)) == (e.node_count, e.pods_scheduled), ng.id()
+        assert snapshot.last_index == e.last_index_out                      # a hit moves the runner on, like the Estimate it stands for
     st = shared.cache.stats()
     assert st["fills"] == 1 and st["groups_cached"] == len(ngs) and st["hits"] == len(ngs) and st["miss_pegs"] == st["miss_limits"] == st["miss_group"] == 0
     shared.close()
@@ -64,7 +68,7 @@ def test_prefetch_mode_answers_every_estimate_of_the_loop_from_one_batch(ctx):
 def test_cache_misses_take_the_per_call_path_and_stay_exact(ctx):
     w = workloads.config_c2(n_groups=6, n_pegs=60, pods_per_peg=8, cap=15)
     ngs, infos, limiter = _setup(w)
-    shared = est.PrefetchShared(ctx, limiter)
+    shared = est.PrefetchShared(ctx, limiter, chain_last_index=False)   # (the key protocol of the unchained batch: every group from the loop's lastIndex)
     snapshot = est.ClusterSnapshotView()
     shared.fill(w.pegs, ngs[:5], infos, snapshot)            # group 5 is not part of the batch
     builder = est.new_estimator_builder(est.GPU_BINPACKING_ESTIMATOR_NAME, limiter, engine_ctx=ctx, prefetch=shared)
@@ -100,7 +104,7 @@ def test_lookup_returns_positions_in_the_callers_list(ctx):
     """order_out indexes the list Estimate() received, whatever ids the PEGs had in the batch"""
     w = workloads.config_c2(n_groups=4, n_pegs=40, pods_per_peg=5, cap=10)
     ngs, infos, limiter = _setup(w)
-    shared = est.PrefetchShared(ctx, limiter)
+    shared = est.PrefetchShared(ctx, limiter, chain_last_index=False)
     snapshot = est.ClusterSnapshotView()
     shared.fill(w.pegs, ngs, infos, snapshot)
     for ng, g, (ids, e) in zip(ngs, w.groups, _oracle_per_group(w)):
@@ -108,4 +112,40 @@ def test_lookup_returns_positions_in_the_callers_list(ctx):
         assert hit is not None and hit["n_pegs"] == len(ids)
         assert sorted(int(k) for k in hit["order"]) == list(range(len(ids)))
         assert [int(k) for k in hit["order"]] == [int(k) for k in e.order] and [int(x) for x in hit["placed"]] == [int(x) for x in e.placed]
+    shared.close()
+
+
+def test_a_chained_batch_hits_only_while_the_calls_arrive_in_its_order(ctx):
+    """casim_options.chain_last_index in the prefetch cache: group i was estimated from the lastIndex group i - 1 left, so its entry answers
+    an Estimate() that comes with exactly that lastIndex.  In order: every call hits and equals the sequential oracle loop.  Out of order
+    (the orchestrator skipped a group): the call comes with another lastIndex — a miss on the limits unless the two happen to agree — and
+    whichever path answers, the result is what the reference computes for that call with the runner's real lastIndex."""
+    w = workloads.config_c2(n_groups=8, n_pegs=70, pods_per_peg=9, cap=18)
+    ngs, infos, limiter = _setup(w)
+    want = _oracle_per_group(w, chain=True)
+    assert len({e.last_index_out for _, e in want}) > 1            # (the chain hands different values on)
+    shared = est.PrefetchShared(ctx, limiter)
+    snapshot = est.ClusterSnapshotView()
+    shared.fill(w.pegs, ngs, infos, snapshot)
+    builder = est.new_estimator_builder(est.GPU_BINPACKING_ESTIMATOR_NAME, limiter, engine_ctx=ctx, prefetch=shared)
+    for ng, (ids, e) in zip(ngs, want):
+        n, got = builder(snapshot, est.EstimationContext(0, [], 0)).estimate([w.pegs[i] for i in ids], infos[ng.id()], ng)
+        assert (n, len(got), snapshot.last_index) == (e.node_count, e.pods_scheduled, e.last_index_out), ng.id()
+    st = shared.cache.stats()
+    assert st["hits"] == len(ngs) and st["miss_limits"] == 0, st
+    # a lookup that comes with a lastIndex the batch did not use for the group misses on the limits
+    ids = want[3][0]
+    assert shared.lookup([w.pegs[i] for i in ids], infos[ngs[3].id()], ngs[3], w.groups[3].max_nodes, 0, runner_last_index=want[2][1].last_index_out + 1) is None
+    assert shared.cache.stats()["miss_limits"] == 1
+    # the same loop with groups 1 and 4 skipped: every call still equals the oracle's Estimate from the runner's real lastIndex
+    snapshot = est.ClusterSnapshotView()
+    shared.fill(w.pegs, ngs, infos, snapshot)
+    li = 0
+    for k in (0, 2, 3, 5, 6, 7):
+        ids = want[k][0]
+        s = OracleScenario(lanes=w.lanes); t = s.node(w.groups[k].template)
+        e = s.estimate(t, [w.pegs[i] for i in ids], max_nodes=w.groups[k].max_nodes, last_index=li); s.close()
+        n, got = builder(snapshot, est.EstimationContext(0, [], 0)).estimate([w.pegs[i] for i in ids], infos[ngs[k].id()], ngs[k])
+        assert (n, len(got), snapshot.last_index) == (e.node_count, e.pods_scheduled, e.last_index_out), k
+        li = e.last_index_out
     shared.close()

@@ -36,7 +36,7 @@ enum Op {
     CREATE, ADD_GROUP, GROUP_LABEL, GROUP_TAINT, GROUP_FP_CAP, GROUP_LIMITS, GROUP_PRELOADED, GROUP_SET_PEGS, ADD_POD_SPEC, POD_LABEL,
     POD_TOLERATION, POD_NODE_SELECTOR, POD_NODE_AFF_REQ, POD_NODE_AFF_TERM, NODE_TERM_REQ, POD_HOST_PORT, POD_AA_TERM, TERM_REQ,
     POD_AFF_TERM, AFF_TERM_REQ, POD_SPREAD, SPREAD_REQ, SPREAD_TAINTS, SPREAD_AFFINITY, ADD_NAMESPACE, NAMESPACE_LABEL, TERM_NS_SELECTOR, TERM_NS_REQ, AFF_TERM_NS_SELECTOR, AFF_TERM_NS_REQ, POD_FP_REQ,
-    POD_UNSUPPORTED, POD_SPEC_EXTRA, ADD_PEG, ADD_RESOURCE_PEGS, ADD_EXISTING_POD, FINALIZE
+    POD_UNSUPPORTED, POD_SPEC_EXTRA, ADD_PEG, ADD_RESOURCE_PEGS, ADD_EXISTING_POD, FINALIZE, ENC_LANE, POD_SET_REQUEST, GROUP_SET_ALLOCATABLE, LANE_COUNT, LANE_NAME
 };
 const std::map<std::string, Sig> kSigs = {
     {"casim_enc_create", {CREATE, "iii"}},
@@ -76,6 +76,11 @@ const std::map<std::string, Sig> kSigs = {
     {"casim_enc_add_resource_pegs", {ADD_RESOURCE_PEGS, "siAaa"}},
     {"casim_enc_add_existing_pod", {ADD_EXISTING_POD, "iSSi"}},
     {"casim_enc_finalize", {FINALIZE, ""}},
+    {"casim_enc_lane", {ENC_LANE, "s"}},
+    {"casim_enc_pod_set_request", {POD_SET_REQUEST, "isl"}},
+    {"casim_enc_group_set_allocatable", {GROUP_SET_ALLOCATABLE, "isl"}},
+    {"casim_enc_lane_count", {LANE_COUNT, ""}},
+    {"casim_enc_lane_name", {LANE_NAME, "i"}},
 };
 
 struct Call {
@@ -195,6 +200,12 @@ int32_t replay(const std::vector<Call>& calls, size_t n_calls, casim_encoder*& e
         case ADD_RESOURCE_PEGS: rc = casim_enc_add_resource_pegs(e, c.s(0), (int32_t)I[0], c.A64[0].data(), c.A32[0].data(), nullptr); break;
         case ADD_EXISTING_POD: rc = casim_enc_add_existing_pod(e, (int32_t)I[0], c.SA[0].data(), c.SA[1].data(), (int32_t)I[1]); break;
         case FINALIZE: rc = casim_enc_finalize(e); break;
+        // resources by name (ABI 9): CASIM_ENC_DELEGATED (1) is an answer, not an error; a lane lookup that finds none is the caller's to handle
+        case ENC_LANE: (void)casim_enc_lane(e, c.s(0)); rc = 0; break;
+        case POD_SET_REQUEST: rc = casim_enc_pod_set_request(e, (int32_t)I[0], c.s(0), I[1]); break;
+        case GROUP_SET_ALLOCATABLE: rc = casim_enc_group_set_allocatable(e, (int32_t)I[0], c.s(0), I[1]); break;
+        case LANE_COUNT: (void)casim_enc_lane_count(e); rc = 0; break;
+        case LANE_NAME: (void)casim_enc_lane_name(e, (int32_t)I[0]); rc = 0; break;
         default: rc = -1;
         }
         if (rc < 0) { fprintf(stderr, "casim_native: encoder call (op %d) failed with %d: %s\n", c.op, rc, casim_last_error()); return rc; }
