@@ -1,0 +1,200 @@
+"""-m gpu: round 5 on a real MI355X through the C ABI.
+  * casim_options.chain_last_index: the groups of a simulation as successive Estimate() calls (lastIndex handed on, plugin_runner.go:138) —
+    the packer's fixed-point passes against the oracle's sequential loop, both packers, batches, streamed parts;
+  * resources by name (ABI 9): the reference's GPU-pool orchestrator rows through the call sequence of the Go binding;
+  * feas_stream_kernel: every instantiation against the oracle and against the LDS-staged kernel it replaces;
+  * the a3 quotient with a divisor of one next to a very large PEG."""
+import os
+
+import numpy as np
+import pytest
+
+import kubernetes_autoscaler_amd as kaa
+from kubernetes_autoscaler_amd import _abi, workloads
+from kubernetes_autoscaler_amd.objects import Node, NodeInfo, Pod, PodEquivalenceGroup
+from harness import (GroupSpec, Scenario, assert_matches_oracle, encode, encode_batch, run_gpu, run_gpu_tables, run_oracle)
+from orchestrator_rows import Row, per_group_of_batch
+
+pytestmark = pytest.mark.gpu
+GiB = 1 << 30
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = kaa.Context(0)
+    yield c
+    c.close()
+
+
+def _scenario(seed, device_csr, max_groups=7, max_pegs=14, existing=True):
+    w = workloads.fuzz(seed, max_groups=max_groups, max_pegs=max_pegs)
+    return Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, None if device_csr else g.pegs) for g in w.groups],
+                    existing=w.existing if existing else [], lanes=w.lanes, device_csr=device_csr)
+
+
+# ---- chain_last_index ---------------------------------------------------------------------------------------------------------------
+def test_chained_groups_match_the_sequential_loop_on_the_device(ctx):
+    changed = 0
+    for seed in range(120):
+        sc = _scenario(31000 + seed, device_csr=seed % 2 == 0)
+        want = run_oracle(sc, chain=True)
+        changed += any(a.last_index_out != b.last_index_out for (a, _), (b, _) in zip(want, run_oracle(sc)))
+        for generic in (False, True):
+            enc = encode(sc)
+            res, _ = run_gpu(enc, ctx, chain=True, generic=generic)
+            enc.close()
+            assert_matches_oracle(res, want, f"seed {seed} generic={generic}")
+    assert changed > 10     # (the corpus exercises the chain)
+
+
+def test_chained_batches_and_streamed_parts_on_the_device(ctx):
+    for seed in range(12):
+        scs = [_scenario(32000 + 100 * seed + k, device_csr=True, max_groups=6, existing=False) for k in range(2 + seed % 5)]
+        enc, ts, bases = encode_batch(scs)
+        want = []
+        for sc, (pb, _) in zip(scs, bases):
+            want.extend([(est, [pb + i for i in ids]) for est, ids in run_oracle(sc, chain=True)])
+        for kw in ({}, {"generic": True}, {"n_streams": 3}):
+            res, _ = run_gpu_tables(ts, ctx, chain=True, **kw)
+            assert_matches_oracle(res, want, f"batch {seed} {kw}")
+        enc.close()
+
+
+def test_c2_and_c4_as_one_chained_simulation_on_the_device(ctx):
+    for name in ("C2", "C4", "C3"):
+        w = workloads.CONFIGS[name]()
+        sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing, lanes=w.lanes,
+                      device_csr=True)
+        enc = encode(sc)
+        res, _ = run_gpu(enc, ctx, chain=True)
+        enc.close()
+        assert_matches_oracle(res, run_oracle(sc, chain=True), f"{name} chained")
+
+
+# ---- resources by name ------------------------------------------------------------------------------------------------------------------
+def test_gpu_pool_rows_through_the_named_resource_calls_on_the_device(ctx):
+    from test_named_lanes import GPU_ROWS
+    assert len(GPU_ROWS) == 3
+    for row in GPU_ROWS:
+        for generic in (False, True):
+            r = Row(row)
+            sc = r.scenario()
+            enc = encode(sc, named_lanes=True)
+            assert enc.lanes == ("cpu", "memory", "ephemeral-storage", "nvidia.com/gpu")
+            res, _ = run_gpu(enc, ctx, generic=generic)
+            enc.close()
+            assert_matches_oracle(res, run_oracle(sc), row["name"])
+            r.check(r.decide(per_group_of_batch(res)), "MI355X, named lanes:")
+
+
+def test_hugepages_and_a_name_without_a_lane_on_the_device(ctx):
+    from test_named_lanes import _tmpl
+    huge = "hugepages-2Mi"
+    pods = [Pod(name="hp", requests={"cpu": 100, "memory": 64 << 20, huge: 1 * GiB})] * 3
+    sc = Scenario(pegs=[PodEquivalenceGroup(pods=pods)], groups=[GroupSpec(_tmpl("with-hugepages", {huge: 2 * GiB}), 0, 0, None), GroupSpec(_tmpl("without"), 0, 0, None)],
+                  existing=[], lanes=("cpu", "memory", huge), device_csr=True)
+    enc = encode(sc, named_lanes=True)
+    res, _ = run_gpu(enc, ctx)
+    enc.close()
+    assert_matches_oracle(res, run_oracle(sc), "hugepages")
+    assert (int(res.node_count[0]), int(res.pods_scheduled[0]), int(res.pods_scheduled[1])) == (2, 3, 0)
+    # six names: the pod that asks for the sixth is delegated, never estimated without its request
+    rq = {"cpu": 100, "memory": 1 << 28}
+    names = [f"example.com/dev{i}" for i in range(6)]
+    pegs = [PodEquivalenceGroup(pods=[Pod(name="five", requests={**rq, **{n: 1 for n in names[:5]}})] * 2),
+            PodEquivalenceGroup(pods=[Pod(name="sixth", requests={**rq, names[5]: 1})] * 2)]
+    sc = Scenario(pegs=pegs, groups=[GroupSpec(_tmpl("t", {n: 4 for n in names}), 0, 0, None)], existing=[], lanes=("cpu", "memory"), device_csr=True)
+    enc = encode(sc, named_lanes=True)
+    assert int(enc.pegs.flags[1]) & _abi.PEG_UNSUPPORTED and not int(enc.pegs.flags[0]) & _abi.PEG_UNSUPPORTED
+    res, _ = run_gpu(enc, ctx)
+    enc.close()
+    assert int(res.status[0]) == _abi.NG_UNSUPPORTED
+
+
+# ---- feas_stream_kernel ------------------------------------------------------------------------------------------------------------------
+def _both(ts, ctx, **kw):
+    os.environ.pop("CASIM_NO_FEAS_STREAM", None)
+    new, _ = run_gpu_tables(ts, ctx, **kw)
+    os.environ["CASIM_NO_FEAS_STREAM"] = "1"
+    try:
+        old, _ = run_gpu_tables(ts, ctx, **kw)
+    finally:
+        os.environ.pop("CASIM_NO_FEAS_STREAM", None)
+    for f in ("node_count", "pods_scheduled", "nodes_added", "limiter_nodes", "last_index_out", "status", "offsets", "order", "placed"):
+        assert np.array_equal(getattr(new, f), getattr(old, f)), f
+    return new
+
+
+def test_streaming_feasibility_kernel_on_the_device(ctx):
+    """the emulator corpus of tests/test_feas_stream_emu.py on the MI355X (resident problems: the mask31 instantiations; the one-shot calls of
+    the other GPU tests run the general ones)"""
+    from test_feas_stream_emu import _sc, _want
+    for seed in range(24):
+        scs = [_sc(52000 + 97 * seed + k, max_groups=6, max_pegs=90 if seed % 3 == 0 else 14, rich=seed % 2 == 0) for k in range(2 + seed % 5)]
+        enc, ts, bases = encode_batch(scs)
+        res = _both(ts, ctx)
+        assert_matches_oracle(res, _want(scs, bases), f"seed {seed}")
+        enc.close()
+
+
+def test_the_headline_batch_takes_the_streaming_kernel_and_stays_exact(ctx):
+    """C2 x 256 simulations as the bench builds them: the problem reports feas_stream_kernel<lean, mask31>, its feasibility launch can be
+    timed alone, and every group equals the oracle (bench.verify_headline) — with streams and without"""
+    import bench
+    from kubernetes_autoscaler_amd.tables import TableSet
+    seeds = 4
+    ts = bench.simulation_tables(workloads.config_c2, range(seeds), kaa.Encoder, TableSet).tile(64)
+    pegs, groups = ts.structs()
+    for n_streams in (0, 4):
+        with kaa.Problem(ctx, pegs, groups, n_streams=n_streams) as prob:
+            ms, info = prob.time_feasibility(10)
+            assert info["stream"] and info["lean"] and info["mask31"] and ms > 0, info
+            prob.run()
+            res = prob.fetch()
+        chk = bench.verify_headline(workloads, workloads.config_c2, seeds, ts, res)
+        assert chk["headline_bit_exact"] and chk["groups_compared"] == ts.n_groups, chk
+    row = bench.feasibility_roofline(kaa, ctx, workloads, TableSet, "C2", 512, 4, iters=10)
+    assert row["bit_exact"] and row["kernel"] == "feas_stream_kernel<lean, mask31>" and 0 < row["frac"] < 1.0, row
+    print("roofline_feasibility (C2 x 512, a small launch):", {k: row[k] for k in ("kernel_ms", "achieved", "frac", "algorithmic_bytes_per_launch")})
+
+
+def test_gates_dictionaries_and_long_simulations_on_the_device(ctx):
+    import test_feas_stream_emu as m
+    from kubernetes_autoscaler_amd.objects import Taint, Toleration
+    # more than 64 groups per simulation, rows that end inside a word
+    rng = np.random.default_rng(7)
+    pegs = [PodEquivalenceGroup(pods=[Pod(name=f"p{i}", requests={"cpu": int(rng.choice([100, 500, 2000, 9000])), "memory": int(rng.choice([1, 4, 40])) << 28})] * int(rng.integers(1, 4)))
+            for i in range(130)]
+    groups = [GroupSpec(m._tmpl(f"g{i}", cpu=int(rng.choice([1000, 4000, 16000])), mem=int(rng.choice([2, 16, 64])) * GiB), 3, 0, None) for i in range(70)]
+    scs = [Scenario(pegs=pegs, groups=groups, device_csr=True), Scenario(pegs=pegs[:130], groups=groups[:3], device_csr=True)]
+    enc, ts, bases = encode_batch(scs)
+    assert_matches_oracle(_both(ts, ctx), m._want(scs, bases), "70 groups")
+    enc.close()
+    # dictionaries beyond bit 31
+    gs = [GroupSpec(m._tmpl(f"t{i}", taints=[Taint(f"k{i}", "v", "NoSchedule")], labels={f"l{i}": "x"}), 0, 0, None) for i in range(40)]
+    ps = [PodEquivalenceGroup(pods=[Pod(name=f"p{i}", requests={"cpu": 100, "memory": 1 << 28}, node_selector={f"l{i}": "x"},
+                                        tolerations=[Toleration(key=f"k{i}", operator="Exists")])] * 2) for i in range(40)]
+    scs = [Scenario(pegs=ps, groups=gs, device_csr=True), Scenario(pegs=ps[5:], groups=gs[3:], device_csr=True)]
+    enc, ts, bases = encode_batch(scs)
+    want = m._want(scs, bases)
+    assert_matches_oracle(_both(ts, ctx), want, "40 keys")
+    assert [ids for _, ids in want[:40]] == [[i] for i in range(40)]
+    enc.close()
+
+
+# ---- ADVICE r4 ---------------------------------------------------------------------------------------------------------------------------
+def test_a3_quotient_with_a_divisor_of_one_and_a_very_large_peg(ctx):
+    """need = ceil(rem / cn) with cn = 1 (one pod per node) and rem up to 2^25: the raw v_rcp_f64 estimate (~2^-24 relative) is off by more
+    than the +-1 the fix-up repairs from quotients of 2^24 on; with the Newton step it is exact.  The limiter caps what is created, so the
+    oracle finishes quickly; nodes_added / limiter grants / pods must agree."""
+    for count, cap in ((1 << 25, 900), ((1 << 24) + 12345, 64), ((1 << 25) - 1, 1)):
+        cap_d = {"cpu": 1000, "memory": 4 * GiB, "pods": 110}
+        tmpl = NodeInfo(Node(name="one-pod-per-node", labels={}, allocatable=dict(cap_d), capacity=dict(cap_d)), [])
+        big = PodEquivalenceGroup(pods=[Pod(name="big", requests={"cpu": 600, "memory": 1 * GiB})])   # (one object; the count travels as a number below)
+        sc = Scenario(pegs=[big], groups=[GroupSpec(tmpl, cap, 0, None)], existing=[], device_csr=True)
+        enc = encode(sc)
+        # the PEG's pod count, written where the encoder put it (2^25 pod objects are not needed to say "2^25")
+        np.ctypeslib.as_array(enc.pegs.count, shape=(1,))[0] = count
+        res, _ = run_gpu(enc, ctx)
+        enc.close()
+        assert (int(res.status[0]), int(res.node_count[0]), int(res.pods_scheduled[0]), int(res.nodes_added[0])) == (0, cap, cap, cap), (count, cap, res.node_count, res.pods_scheduled)
