@@ -339,7 +339,10 @@ CS_DEVICE uint32_t and_or_u32(uint32_t uniform_a, uint32_t b, uint32_t c) {
 CS_DEVICE void write_lane2_u32(uint32_t& lo, uint32_t& hi, uint64_t uniform_value, uint32_t uniform_lane_times_64) {
     const uint32_t vl = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)uniform_value), vh = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uniform_value >> 32));
     uniform_lane_times_64 = (uint32_t)__builtin_amdgcn_readfirstlane((int)uniform_lane_times_64);
-    asm volatile("s_lshr_b32 m0, %4, 6\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(lo), "+v"(hi) : "s"(vl), "s"(vh), "s"(uniform_lane_times_64) : "m0");
+    // (s_lshr_b32 writes SCC: without the clobber the compiler kept a loop's s_cmp result in SCC ACROSS this statement and the loop of
+    // feas_stream_kernel left after its first trip — groups 2.. of every simulation came back empty on the MI355X, the emulator could not see it;
+    // tests/tools/writelane_probe.hip is the micro-probe that found it)
+    asm volatile("s_lshr_b32 m0, %4, 6\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(lo), "+v"(hi) : "s"(vl), "s"(vh), "s"(uniform_lane_times_64) : "m0", "scc");
 }
 // a wave-uniform int the compiler cannot prove uniform (a global load indexed by the block id): to a scalar register
 CS_DEVICE int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -27,15 +27,15 @@ if has tests; then
 fi
 if has bench; then
   echo "== bench, the driver's command line ==" | tee -a "$S"
-  T0=$(date +%s.%N)
+  T0=$SECONDS
   timeout 1500 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver.out" 2> "$OUT/bench_driver.err"
-  echo "bench exit $? in $(echo "$(date +%s.%N) - $T0" | bc) s; stdout lines: $(wc -l < "$OUT/bench_driver.out"), last line bytes: $(tail -1 "$OUT/bench_driver.out" | wc -c)" | tee -a "$S"
+  echo "bench exit $? in $((SECONDS - T0)) s; stdout lines: $(wc -l < "$OUT/bench_driver.out"), last line bytes: $(tail -1 "$OUT/bench_driver.out" | wc -c)" | tee -a "$S"
   tail -1 "$OUT/bench_driver.out" | tee -a "$S"
   cp bench_side.json "$OUT/bench_driver_side.json" 2>/dev/null
   echo "== bench, defaults ==" | tee -a "$S"
-  T0=$(date +%s.%N)
+  T0=$SECONDS
   timeout 1500 python3 bench.py > "$OUT/bench.out" 2> "$OUT/bench.err"
-  echo "bench exit $? in $(echo "$(date +%s.%N) - $T0" | bc) s" | tee -a "$S"
+  echo "bench exit $? in $((SECONDS - T0)) s" | tee -a "$S"
   tail -1 "$OUT/bench.out" | tee -a "$S"
   cp bench_side.json "$OUT/bench_side.json" 2>/dev/null
   tail -3 "$OUT/bench.err" | cut -c1-400 | tee -a "$S"
