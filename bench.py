@@ -886,7 +886,8 @@ def feasibility_roofline(kaa, ctx, workloads, TableSet, config, n_sims, n_seeds,
     with kaa.Problem(ctx, pegs, groups) as prob:
         ms, info = prob.time_feasibility(iters)
         row = {"bound": "hbm", "workload": f"{config} x {n_sims} simulations in ONE launch ({ts.n_pegs} PEGs, {ts.n_groups} node groups; {n_seeds} distinct seeds tiled)",
-               "kernel": ("feas_stream_kernel<%s, %s>" % ("lean" if info["lean"] else "full", "mask31" if info["mask31"] else "mask64")) if info["stream"] else "feas_sim_kernel",
+               "kernel": ("feas_stream_kernel<%s, %s, %s>" % ("lean" if info["lean"] else "full", "lo" if info["narrow_masks"] else "hi", "bit" if info["unsched_on_spare_bit"] else "term"))
+                         if info["stream"] else "feas_sim_kernel",
                "kernel_ms": ms, "workgroups": info["workgroups"], "launches_timed": iters, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None}
         b, Bp, Bn, out = feasibility_bytes(ts, info["lean"])
         row.update({"algorithmic_bytes_per_launch": b, "bytes_per_peg": Bp, "bytes_per_group_record": Bn, "bytes_written": out,

@@ -689,7 +689,7 @@ int32_t casim_problem_time(casim_problem* p, int32_t iters, float* total_ms_out,
                            float* kernel_ms_out);
 /* The feasibility launch (SchedulablePodGroups matrix) of the problem alone: `iters` launches back to back between two HIP events on the
  * launch stream, average per launch.  info_out (may be NULL): [0] 1 = the streaming kernel of round 5 (csrc/casim_kernels.h
- * feas_stream_kernel; batches of simulations on narrowed int32 lanes), [1] its lean instantiation, [2] its mask31 instantiation,
+ * feas_stream_kernel; batches of simulations on narrowed int32 lanes), [1] its lean instantiation, [2] bit 0: no upper-half terms, bit 1: NodeUnschedulable rides on a spare mask bit,
  * [3] workgroups per launch.  What bench.py's roofline_feasibility row is measured with. */
 int32_t casim_problem_time_feasibility(casim_problem* p, int32_t iters, float* ms_per_launch_out, int32_t info_out[4]);
 /* The same measurement WITHOUT stopping the stream: casim_problem_run_marked is casim_problem_run with HIP events recorded

@@ -53,6 +53,8 @@ CS_DEVICE uint32_t bcast_u32(uint32_t v, int uniform_lane) { return (uint32_t)ca
 CS_DEVICE uint32_t uniform_u32(uint32_t v) { return v; }
 template <int N> struct Words { uint32_t w[N]; };
 template <int N> CS_DEVICE Words<N> const_load(const uint32_t* p) { Words<N> r; memcpy(r.w, p, 4 * N); return r; }
+CS_DEVICE Words<4> load4(const uint32_t* p) { Words<4> r; memcpy(r.w, p, 16); return r; }
+CS_DEVICE void store4(uint32_t* p, const Words<4>& v) { memcpy(p, v.w, 16); }
 struct RecBase { const char* p; };
 CS_DEVICE RecBase rec_base(const uint32_t* p) { return RecBase{(const char*)p}; }
 template <int N> CS_DEVICE Words<N> rec_load(const RecBase& b, uint32_t byte_off) { Words<N> r; memcpy(r.w, b.p + byte_off, 4 * N); return r; }
@@ -71,8 +73,9 @@ CS_DEVICE uint32_t scalar_min_u32(uint32_t a, uint32_t b) { return a < b ? a : b
 CS_DEVICE void write_lane_u32(uint32_t& v, uint32_t uniform_value, int uniform_lane) { if ((casim_emu::cur().tid & 63) == uniform_lane) v = uniform_value; }
 CS_DEVICE uint32_t and_or_u32(uint32_t uniform_a, uint32_t b, uint32_t c) { return (uniform_a & b) | c; }
 CS_DEVICE int uniform_i32(int v) { return v; }
-CS_DEVICE void write_lane2_u32(uint32_t& lo, uint32_t& hi, uint64_t uniform_value, uint32_t uniform_lane_times_64) {
-    if ((uint32_t)(casim_emu::cur().tid & 63) == (uniform_lane_times_64 >> 6)) { lo = (uint32_t)uniform_value; hi = (uint32_t)(uniform_value >> 32); }
+CS_DEVICE uint32_t and_or_vvv(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | c; }
+CS_DEVICE void write_lane2_u32(uint32_t& lo, uint32_t& hi, uint64_t uniform_value, uint32_t uniform_lane) {
+    if ((uint32_t)(casim_emu::cur().tid & 63) == uniform_lane) { lo = (uint32_t)uniform_value; hi = (uint32_t)(uniform_value >> 32); }
 }
 CS_DEVICE int popc64(uint64_t v) { return __builtin_popcountll(v); }
 CS_DEVICE int ffs64(uint64_t v) { return v ? __builtin_ctzll(v) : -1; }
@@ -196,6 +199,18 @@ template <int N> CS_DEVICE Words<N> const_load(const uint32_t* p) {
         for (int i = 0; i < N; ++i) r.w[i] = v[i];
     }
     return r;
+}
+// 16 bytes at a 16-byte-aligned address as ONE access (global_load_dwordx4 / ds_read_b128 / ds_write_b128, whichever memory p points into)
+CS_DEVICE Words<4> load4(const uint32_t* p) {
+    typedef uint32_t vec4_t __attribute__((ext_vector_type(4)));
+    const vec4_t v = *(const vec4_t*)p;
+    Words<4> r; r.w[0] = v[0]; r.w[1] = v[1]; r.w[2] = v[2]; r.w[3] = v[3];
+    return r;
+}
+CS_DEVICE void store4(uint32_t* p, const Words<4>& q) {
+    typedef uint32_t vec4_t __attribute__((ext_vector_type(4)));
+    vec4_t v; v[0] = q.w[0]; v[1] = q.w[1]; v[2] = q.w[2]; v[3] = q.w[3];
+    *(vec4_t*)p = v;
 }
 // The same through a BUFFER resource and a 32-bit byte offset: s_buffer_load_dwordxN sdst, s[rsrc:rsrc+3], s_off.  A loop that
 // walks records then carries ONE 32-bit scalar (offset += record size; compare with the end offset) instead of a 64-bit
@@ -334,15 +349,21 @@ CS_DEVICE uint32_t and_or_u32(uint32_t uniform_a, uint32_t b, uint32_t c) {
     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "s"(uniform_a), "v"(b), "v"(c));
     return r;
 }
-// both halves of a wave-uniform 64-bit word into lane (byte offset >> 6) of two VGPRs: the lane select is derived from the record walk's byte
-// offset by the one scalar instruction that loads M0, and both v_writelane share it
-CS_DEVICE void write_lane2_u32(uint32_t& lo, uint32_t& hi, uint64_t uniform_value, uint32_t uniform_lane_times_64) {
+// both halves of a wave-uniform 64-bit word into one lane of two VGPRs: ONE scalar instruction loads M0, both v_writelane share it.
+// (A first version derived the lane from a byte offset with s_lshr_b32 m0, x, 6 and did not declare that s_lshr writes SCC: the compiler
+// kept a loop's s_cmp result in SCC ACROSS the statement and the group loop of feas_stream_kernel left after its first trip — groups 2.. of
+// every simulation came back empty on the MI355X, and the emulator could not see it.  tests/tools/writelane_probe.hip is the micro-probe
+// that found it; s_mov_b32 leaves SCC alone.)
+CS_DEVICE void write_lane2_u32(uint32_t& lo, uint32_t& hi, uint64_t uniform_value, uint32_t uniform_lane) {
     const uint32_t vl = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)uniform_value), vh = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uniform_value >> 32));
-    uniform_lane_times_64 = (uint32_t)__builtin_amdgcn_readfirstlane((int)uniform_lane_times_64);
-    // (s_lshr_b32 writes SCC: without the clobber the compiler kept a loop's s_cmp result in SCC ACROSS this statement and the loop of
-    // feas_stream_kernel left after its first trip — groups 2.. of every simulation came back empty on the MI355X, the emulator could not see it;
-    // tests/tools/writelane_probe.hip is the micro-probe that found it)
-    asm volatile("s_lshr_b32 m0, %4, 6\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(lo), "+v"(hi) : "s"(vl), "s"(vh), "s"(uniform_lane_times_64) : "m0", "scc");
+    uniform_lane = (uint32_t)__builtin_amdgcn_readfirstlane((int)uniform_lane);
+    asm volatile("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(lo), "+v"(hi) : "s"(vl), "s"(vh), "s"(uniform_lane) : "m0");
+}
+// (lane a & lane b) | lane c as ONE v_and_or_b32: see and_or_u32
+CS_DEVICE uint32_t and_or_vvv(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 // a wave-uniform int the compiler cannot prove uniform (a global load indexed by the block id): to a scalar register
 CS_DEVICE int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -994,7 +994,7 @@ int32_t casim_problem_time(casim_problem* p, int32_t iters, float* total_ms_out,
 
 // The feasibility launch of a problem alone, `iters` times back to back between two HIP events on the launch stream: the average includes
 // the gap between two launches (conservative for a roofline fraction).  info_out (may be NULL): [0] 1 = feas_stream_kernel (round 5),
-// 0 = another form, [1] 1 = its lean instantiation, [2] 1 = its mask31 instantiation, [3] workgroups of the launch.
+// 0 = another form, [1] 1 = its lean instantiation, [2] bit 0: no upper-half terms, bit 1: NodeUnschedulable on a spare mask bit, [3] workgroups of the launch.
 int32_t casim_problem_time_feasibility(casim_problem* p, int32_t iters, float* ms_per_launch_out, int32_t info_out[4]) {
     PROB_ENTER(p);
     if (iters <= 0 || !ms_per_launch_out) return set_err(CASIM_ERR_INVALID, "iters must be > 0");

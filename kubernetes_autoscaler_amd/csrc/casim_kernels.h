@@ -214,70 +214,71 @@ CS_GLOBAL void feas_sim_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg
 // K_feas, round 5: the streaming form (feas_stream_kernel) — the kernel BASELINE.md section 4 prices against the HBM roofline
 // ------------------------------------------------------------------------------------------
 // Same cells, same output rows as feas_sim_kernel (narrowed int32 lanes, one word per mask kind, every group of a simulation on one PEG
-// range), rebuilt around what that kernel spent its time on: ~29 vector instructions + 4 LDS reads per (wave, group) — the group record
-// came out of LDS field by field into VGPRs, every test was its own 64-bit compare, the ballot word went through two v_mov and a
-// lane-0 store.  Here
-//   * the group record is ONE 32-byte (lean) / 64-byte scalar load into SGPRs (s_load_dwordx8 / x16 through the scalar cache: no LDS, no
-//     barrier, no staging phase) of a record built once per problem (feas_group_records_kernel, at init): taint word, INVERTED label
-//     word, free lanes, flags — with the wave-uniform gates folded INTO the data: a group without a free pod slot gets f0 = INT32_MIN
-//     (every lane fails the lane-0 compare: "pod count first", fit.go:681-690), the unschedulable bit is one more AND-OR term;
-//   * the PEG side is pre-inverted once per lane: ~tol, "does not tolerate unschedulable", requests with rq <= 0 replaced by
-//     INT32_MIN + 1 (a lane nobody asks for passes every free amount, fit.go:699, and still fails the INT32_MIN gate);
-//   * all static Filters of a cell are ONE accumulated word: x = (taint & ~tol) | (sel & ~label) | (unsched & ~tolerates) [| excl | zone],
-//     built from v_and_or_b32, tested by ONE compare; the requests by one 32-bit compare per lane; the three lane masks meet on the
-//     SCALAR unit (s_and_b64);
-//   * the 64 ballot words of up to 64 groups are parked in the lanes of two VGPRs (v_writelane, lane j = group j) and leave with ONE
-//     store instruction per 64 groups.
-// Lean cell: 8 (narrow dictionaries: the masks' upper halves are zero, kMask32) or 10 vector instructions per (wave, group) instead of
-// ~29 + 4 LDS; the scalar side ~6 + one s_load.  grid = ONE dimension, XCD-aware: workgroup ids are dealt round-robin to the 8 XCDs, so
-// the blocks of a simulation take ids that agree mod 8 — its group records are fetched into ONE XCD's L2, not up to eight.
+// range), rebuilt around what that kernel spent its time on: ~29 vector instructions + 4 LDS reads per (wave, group) — every field of the
+// group record its own LDS read, every test its own 64-bit compare, the ballot word through two v_mov and a lane-0 store.  Here
+//   * the group record is built ONCE per problem (feas_group_records_kernel, at init) with the wave-uniform gates folded INTO the data: a
+//     group without a free pod slot gets f0 = INT32_MIN (every lane fails the lane-0 compare: "pod count first", fit.go:681-690), the label
+//     word is stored inverted, and the NodeUnschedulable test rides on a SPARE BIT of the taint or label word when the batch's dictionaries
+//     leave one (group side: "template is unschedulable", PEG side: "does not tolerate it") — else it is one more AND-OR term;
+//   * a block copies its simulation's records into LDS with the SAME burst of loads that fetches its PEG columns: after one wait the group
+//     loop touches no memory but LDS (a first version walked the records with scalar loads two ahead: every record a dependent miss of its
+//     own, waves parked 80 % of their 4.5 us lives — profiles/r10c_feas_rocpd_summary.txt — and half the issue slots empty);
+//   * the PEG side is pre-inverted once per lane: ~tol, requests with rq <= 0 replaced by INT32_MIN + 1 (a lane nobody asks for passes every
+//     free amount, fit.go:699, and still fails the INT32_MIN gate);
+//   * all static Filters of a cell are ONE accumulated word, x = (taint & ~tol) | (sel & ~label) [| upper halves | exclusion words], built
+//     from v_and_or_b32 and tested by ONE compare; the requests by one 32-bit compare per lane; the lane masks meet on the SCALAR unit;
+//   * the ballot words of up to 64 groups are parked in the lanes of two VGPRs (v_writelane, lane j = group j) and leave with ONE store
+//     instruction per 64 groups.
+// Lean cell, dictionaries in the lower halves, a spare bit for NodeUnschedulable (BASELINE config C2): ONE ds_read_b128 and 7 vector
+// instructions per (wave, group) — v_and, v_and_or, v_cmp_eq, 2 x v_cmp_ge, 2 x v_writelane; 10 with every term.  grid = ONE dimension,
+// XCD-aware: workgroup ids are dealt round-robin to the 8 XCDs, so the blocks of a simulation take ids that agree mod 8 — its group
+// records are fetched into ONE XCD's L2.
 // Algorithmic bytes: per PEG the columns the cell needs as this kernel reads them — 4 R (narrowed requests) + 4
-// (flags) + 8 (tolerations) + 8 (selector) [+ 8 + 8 exclusion words] — per group its 32 / 64-byte record, per cell one bit.
+// (flags) + 8 (tolerations) + 8 (selector) [+ 8 + 8 exclusion words] — per group its 64-byte record, per cell one bit.
 #define CASIM_FEAS_REC_DW 16
-// record (dwords): [0,1] taint  [2,3] ~label (bit 31 of [2]: see kMask31)  [4] f0 | INT32_MIN gate  [5] f1  [6] unschedulable (0 / 1)  [7] 0
+// record (dwords): [0] taint lo  [1] ~label lo  [2] f0 | INT32_MIN gate  [3] f1      (all a lean cell with narrow dictionaries reads)
+//                  [4] taint hi  [5] ~label hi  [6] unschedulable (0 / 1)  [7] 0
 //                  [8,9] node-local exclusion ^ NEED polarity  [10,11] group-wide exclusion ^ NEED polarity  [12] f2  [13] f3  [14,15] 0
-// mask31 != 0: every taint / label-requirement bit of the batch lies below bit 31 (mask_hi_or_kernel), so bit 31 of the label word is free
-// and carries the NodeUnschedulable test as one more "label requirement": set in ~label for an unschedulable template, set in the PEG's
-// selector word (by the kernel, per lane) when the PEG does not tolerate node.kubernetes.io/unschedulable.
-CS_GLOBAL void feas_group_records_kernel(DevTables t, const int32_t* CS_RESTRICT fresh32, uint32_t* CS_RESTRICT rec /*[NG + 2][16]*/, int mask31) {
+// us_word: 0 = the NodeUnschedulable bit rides in the taint word, 1 = in the label word, at bit us_bit; -1 = nowhere ([6] is its own term)
+CS_GLOBAL void feas_group_records_kernel(DevTables t, const int32_t* CS_RESTRICT fresh32, uint32_t* CS_RESTRICT rec /*[NG][16]*/, int us_word, int us_bit) {
     const int ng = cs::bid() * cs::nthreads() + cs::tid();
-    if (ng > t.NG + 1) return;
+    if (ng >= t.NG) return;
     uint32_t* r = rec + (int64_t)ng * CASIM_FEAS_REC_DW;
-    if (ng >= t.NG) {   // the two spare records behind the last group: the kernel loads up to two records ahead of the one it works on
-        for (int k = 0; k < CASIM_FEAS_REC_DW; ++k) r[k] = 0;
-        return;
-    }
-    const uint64_t taint = t.Wt ? t.taint[(int64_t)ng * t.Wt] : 0ull, nlabel = t.Wl ? ~t.label[(int64_t)ng * t.Wl] : 0ull;
+    uint64_t taint = t.Wt ? t.taint[(int64_t)ng * t.Wt] : 0ull, nlabel = t.Wl ? ~t.label[(int64_t)ng * t.Wl] : 0ull;
     const uint64_t ex = t.Wx ? (t.init_excl[(int64_t)ng * t.Wx] ^ (t.xpol ? t.xpol[0] : 0ull)) : 0ull;
     const uint64_t zn = t.Wz ? (t.init_zone[(int64_t)ng * t.Wz] ^ t.zpol[0]) : 0ull;
     int32_t f[4];
     for (int k = 0; k < 4; ++k) f[k] = k < t.R ? fresh32[(int64_t)ng * t.R + k] : 0x7fffffff;
     if (t.allowed[ng] - t.init_pods[ng] <= 0) f[0] = (int32_t)0x80000000;
-    const uint32_t unsched = (t.gflags[ng] & CASIM_NG_UNSCHEDULABLE) ? 1u : 0u;
-    r[0] = (uint32_t)taint; r[1] = (uint32_t)(taint >> 32);
-    r[2] = mask31 ? (((uint32_t)nlabel & 0x7fffffffu) | (unsched << 31)) : (uint32_t)nlabel; r[3] = (uint32_t)(nlabel >> 32);
-    r[4] = (uint32_t)f[0]; r[5] = (uint32_t)f[1]; r[6] = unsched; r[7] = 0;
+    const uint64_t unsched = (t.gflags[ng] & CASIM_NG_UNSCHEDULABLE) ? 1ull : 0ull;
+    if (us_word == 0) taint = (taint & ~(1ull << us_bit)) | (unsched << us_bit);
+    if (us_word == 1) nlabel = (nlabel & ~(1ull << us_bit)) | (unsched << us_bit);
+    r[0] = (uint32_t)taint; r[1] = (uint32_t)nlabel; r[2] = (uint32_t)f[0]; r[3] = (uint32_t)f[1];
+    r[4] = (uint32_t)(taint >> 32); r[5] = (uint32_t)(nlabel >> 32); r[6] = (uint32_t)unsched; r[7] = 0;
     r[8] = (uint32_t)ex; r[9] = (uint32_t)(ex >> 32); r[10] = (uint32_t)zn; r[11] = (uint32_t)(zn >> 32);
     r[12] = (uint32_t)f[2]; r[13] = (uint32_t)f[3]; r[14] = 0; r[15] = 0;
 }
 
-// OR of the bits 31.. of two word arrays (the groups' taint words, the PEGs' selector words): zero = every taint / label-requirement bit
-// the cells can ever see in `x` sits below bit 31, and feas_stream_kernel<.., kMask31> may drop the upper-half terms and use bit 31 itself.
+// OR of two word arrays (the groups' taint words, the PEGs' selector words) -> out[0], out[1]: which bits of the cells' `x` can ever be set.
 // (The other two operands do not matter: a zero taint bit kills its term whatever ~tol holds, a zero selector bit whatever ~label holds.)
-CS_GLOBAL void mask_hi_or_kernel(const uint64_t* CS_RESTRICT a, int64_t na, const uint64_t* CS_RESTRICT b, int64_t nb, uint64_t* CS_RESTRICT out) {
+// The host reads them behind the wait a resident problem's init ends with: upper halves unused -> the kHi terms go; a bit nobody uses ->
+// NodeUnschedulable rides there.
+CS_GLOBAL void mask_or_kernel(const uint64_t* CS_RESTRICT a, int64_t na, const uint64_t* CS_RESTRICT b, int64_t nb, uint64_t* CS_RESTRICT out /*[2]*/) {
     const int64_t stride = (int64_t)cs::nblocks() * cs::nthreads();
-    uint64_t acc = 0;
-    for (int64_t i = (int64_t)cs::bid() * cs::nthreads() + cs::tid(); i < na; i += stride) acc |= a[i] >> 31;
-    for (int64_t i = (int64_t)cs::bid() * cs::nthreads() + cs::tid(); i < nb; i += stride) acc |= b[i] >> 31;
-    if (acc) cs::atomic_or_u64(out, acc);
+    uint64_t acc_a = 0, acc_b = 0;
+    for (int64_t i = (int64_t)cs::bid() * cs::nthreads() + cs::tid(); i < na; i += stride) acc_a |= a[i];
+    for (int64_t i = (int64_t)cs::bid() * cs::nthreads() + cs::tid(); i < nb; i += stride) acc_b |= b[i];
+    if (acc_a) cs::atomic_or_u64(out, acc_a);
+    if (acc_b) cs::atomic_or_u64(out + 1, acc_b);
 }
 
-// kLean: no exclusion words, at most two request lanes (one 32-byte record load per group).  kMask31: the batch's dictionaries stay below
-// bit 31 and the group records were built for it (feas_group_records_kernel(mask31 = 1)): 7 vector instructions per (wave, group) —
-// v_and, v_and_or, v_cmp_eq, 2 x v_cmp_ge, 2 x v_writelane — else 10.
-template <bool kLean, bool kMask31>
+// kLean: no exclusion words, at most two request lanes.  kHi: some taint / label-requirement bit lies in an upper half.  kUnschedTerm:
+// NodeUnschedulable as a term of its own (no spare bit, or nobody looked: one-shot calls) — else the records carry it at (us_word, us_bit).
+// Dynamic LDS: (groups of the largest simulation, rounded up to 4) x 64 bytes.
+template <bool kLean, bool kHi, bool kUnschedTerm>
 CS_GLOBAL CS_LAUNCH_BOUNDS(256, 1) void feas_stream_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg]*/, int Wg, const int32_t* CS_RESTRICT req32,
-                                                          const uint32_t* CS_RESTRICT grec /*[NG + 2][16]*/, int gx /* blocks per simulation */, int n_sims) {
+                                                          const uint32_t* CS_RESTRICT grec /*[NG][16]*/, int gx /* blocks per simulation */, int n_sims,
+                                                          int us_word, int us_bit) {
     // workgroup id -> (simulation, block of the simulation): ids that agree mod 8 run on one XCD
     const int id = cs::bid();
     const int chunk = id / (8 * gx), within = id - chunk * (8 * gx);
@@ -288,64 +289,88 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(256, 1) void feas_stream_kernel(DevTables t, uint64_t
     const int lo = cs::uniform_i32(t.peg_lo[g0]), hi = cs::uniform_i32(t.peg_hi[g0]);
     const int k = bx * cs::nthreads() + cs::tid();
     const int word = cs::uniform_i32(k >> 6);
-    if (word >= Wg) return;                       // (wave-uniform: a wave past the row's last word has nothing to write)
     const bool live = lo + k < hi;
     const int g = live ? lo + k : (hi > lo ? lo : 0);
     const int R = t.R;
-    constexpr int RD = kLean ? 8 : 16;
-    // ---- the PEG, once: pre-inverted so that a cell is AND-OR terms and signed compares
+    // ---- the PEG, once: pre-inverted so that a cell is AND-OR terms and signed compares (these loads and the record copy below are in flight together)
     int32_t rq[4];
+    if (R == 2) {   // (the usual shape: one 8-byte load)
+        rq[0] = req32[(int64_t)g * 2]; rq[1] = req32[(int64_t)g * 2 + 1]; rq[2] = 0; rq[3] = 0;
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int32_t v = (r < R && r < (kLean ? 2 : 4)) ? req32[(int64_t)g * R + r] : 0;
-        rq[r] = v > 0 ? v : (int32_t)0x80000001;
+        for (int r = 0; r < 4; ++r) rq[r] = (r < R && r < (kLean ? 2 : 4)) ? req32[(int64_t)g * R + r] : 0;
     }
     const uint32_t pf = t.pflags[g];
     const uint64_t tol = t.Wt ? t.tol[(int64_t)g * t.Wt] : 0ull, sel = t.Wl ? t.sel[(int64_t)g * t.Wl] : 0ull;
-    const uint32_t no_unsched = (pf & CASIM_PEG_TOLERATES_UNSCHEDULABLE) ? 0u : 1u;
-    const uint32_t ntol_lo = ~(uint32_t)tol, ntol_hi = ~(uint32_t)(tol >> 32), sel_hi = (uint32_t)(sel >> 32);
-    const uint32_t sel_lo = kMask31 ? ((uint32_t)sel | (no_unsched << 31)) : (uint32_t)sel;
-    uint32_t xb_lo = 0, xb_hi = 0, zb_lo = 0, zb_hi = 0;
+    uint64_t xb = 0, zb = 0;
     if constexpr (!kLean) {
         // (a NEED bit the PEG marks itself does not count on a fresh node: fits_fresh_node)
-        const uint64_t xb = t.Wx ? (t.xblock[(int64_t)g * t.Wx] & ~(t.xmark[(int64_t)g * t.Wx] & (t.xpol ? t.xpol[0] : 0ull))) : 0ull;
-        const uint64_t zb = t.Wz ? t.zblock[(int64_t)g * t.Wz] : 0ull;
-        xb_lo = (uint32_t)xb; xb_hi = (uint32_t)(xb >> 32); zb_lo = (uint32_t)zb; zb_hi = (uint32_t)(zb >> 32);
+        xb = t.Wx ? (t.xblock[(int64_t)g * t.Wx] & ~(t.xmark[(int64_t)g * t.Wx] & (t.xpol ? t.xpol[0] : 0ull))) : 0ull;
+        zb = t.Wz ? t.zblock[(int64_t)g * t.Wz] : 0ull;
     }
+    // ---- the simulation's group records -> LDS (16-byte pieces; the lean cell reads the first 32 bytes of a record, all 64 are copied: one layout)
+    uint32_t* lrec = (uint32_t*)cs::dyn_smem();
+    {
+        const int n4 = (g1 - g0) * 4;
+        const uint32_t* src = grec + (int64_t)g0 * CASIM_FEAS_REC_DW;
+        for (int i = cs::tid(); i < n4; i += cs::nthreads()) {
+            const cs::Words<4> q = cs::load4(src + (int64_t)i * 4);
+            cs::store4(lrec + (int64_t)i * 4, q);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rq[r] = rq[r] > 0 ? rq[r] : (int32_t)0x80000001;
+    const uint32_t no_unsched = (pf & CASIM_PEG_TOLERATES_UNSCHEDULABLE) ? 0u : 1u;
+    uint64_t ntol = ~tol, sel2 = sel;
+    if constexpr (!kUnschedTerm) {
+        // the PEG's side of the NodeUnschedulable bit: set = "does not tolerate" (ANDed with the group's "is unschedulable")
+        const uint64_t b = (uint64_t)no_unsched << us_bit;
+        if (us_word == 0) ntol = (ntol & ~(1ull << us_bit)) | b; else sel2 = (sel2 & ~(1ull << us_bit)) | b;
+    }
+    const uint32_t ntol_lo = (uint32_t)ntol, ntol_hi = (uint32_t)(ntol >> 32), sel_lo = (uint32_t)sel2, sel_hi = (uint32_t)(sel2 >> 32);
+    const uint32_t xb_lo = (uint32_t)xb, xb_hi = (uint32_t)(xb >> 32), zb_lo = (uint32_t)zb, zb_hi = (uint32_t)(zb >> 32);
+    cs::sync();
+    if (word >= Wg) return;                       // (wave-uniform, behind the barrier: a wave past the row's last word has nothing to write)
     const uint64_t live_mask = cs::ballot(live);
     uint32_t out_lo = 0, out_hi = 0;              // lane j: the ballot word of group base + j
     uint64_t* const row0 = bits + (int64_t)g0 * Wg + word;
     const int lane = cs::lane();
-    // the record walk carries ONE 32-bit scalar (cs::rec_load: s_buffer_load_dwordxN with a byte offset): it addresses the record, its
-    // upper bits are the lane the ballot word is parked in, and it ends the loop
-    const cs::RecBase rb = cs::rec_base(grec + (int64_t)g0 * CASIM_FEAS_REC_DW);
-    auto cell = [&](const cs::Words<RD>& q) -> uint64_t {
-        uint32_t x = q.w[0] & ntol_lo;
-        if constexpr (!kMask31) x = cs::and_or_u32(q.w[1], ntol_hi, x);
-        x = cs::and_or_u32(q.w[2], sel_lo, x);
-        if constexpr (!kMask31) { x = cs::and_or_u32(q.w[3], sel_hi, x); x = cs::and_or_u32(q.w[6], no_unsched, x); }
+    // one cell row: the group's record out of LDS (a wave-uniform address: broadcast reads), the static word, the compares
+    struct Rec { cs::Words<4> a, b, c, d; };
+    auto fetch = [&](const uint32_t* q) -> Rec {
+        Rec r;
+        r.a = cs::load4(q);
+        if constexpr (kHi || kUnschedTerm) r.b = cs::load4(q + 4);
+        if constexpr (!kLean) { r.c = cs::load4(q + 8); r.d = cs::load4(q + 12); }
+        return r;
+    };
+    auto cell = [&](const Rec& r) -> uint64_t {
+        uint32_t x = r.a.w[0] & ntol_lo;
+        x = cs::and_or_vvv(r.a.w[1], sel_lo, x);
+        if constexpr (kHi) { x = cs::and_or_vvv(r.b.w[0], ntol_hi, x); x = cs::and_or_vvv(r.b.w[1], sel_hi, x); }
+        if constexpr (kUnschedTerm) x = cs::and_or_vvv(r.b.w[2], no_unsched, x);
         if constexpr (kLean) {
-            return cs::ballot(x == 0) & cs::ballot(rq[0] <= (int32_t)q.w[4]) & cs::ballot(rq[1] <= (int32_t)q.w[5]);
+            return cs::ballot(x == 0) & cs::ballot(rq[0] <= (int32_t)r.a.w[2]) & cs::ballot(rq[1] <= (int32_t)r.a.w[3]);
         } else {
-            x = cs::and_or_u32(q.w[8], xb_lo, x); x = cs::and_or_u32(q.w[9], xb_hi, x);
-            x = cs::and_or_u32(q.w[10], zb_lo, x); x = cs::and_or_u32(q.w[11], zb_hi, x);
-            return cs::ballot(x == 0) & cs::ballot(rq[0] <= (int32_t)q.w[4]) & cs::ballot(rq[1] <= (int32_t)q.w[5]) &
-                   cs::ballot(rq[2] <= (int32_t)q.w[12]) & cs::ballot(rq[3] <= (int32_t)q.w[13]);
+            x = cs::and_or_vvv(r.c.w[0], xb_lo, x); x = cs::and_or_vvv(r.c.w[1], xb_hi, x); x = cs::and_or_vvv(r.c.w[2], zb_lo, x); x = cs::and_or_vvv(r.c.w[3], zb_hi, x);
+            return cs::ballot(x == 0) & cs::ballot(rq[0] <= (int32_t)r.a.w[2]) & cs::ballot(rq[1] <= (int32_t)r.a.w[3]) &
+                   cs::ballot(rq[2] <= (int32_t)r.d.w[0]) & cs::ballot(rq[3] <= (int32_t)r.d.w[1]);
         }
     };
-    constexpr uint32_t kRecBytes = 4u * CASIM_FEAS_REC_DW;
     for (int base = g0; base < g1; base += 64) {
         const uint32_t n = cs::scalar_min_u32((uint32_t)(g1 - base), 64u);
-        const uint32_t first = (uint32_t)(base - g0) * kRecBytes, end = n * kRecBytes;
-        // two records per step, each loaded a step ahead of its use; `off` counts bytes inside this round of 64 groups.  An odd count runs one
-        // record over (the next simulation's first, or one of the TWO spare records the array ends with): its word lands in a lane >= n,
-        // which is not stored; the look-ahead reaches one record further still
-        cs::Words<RD> a = cs::rec_load_all<RD>(rb, first);
-        for (uint32_t off = 0; off < end; off += 2 * kRecBytes) {
-            const cs::Words<RD> b = cs::rec_load_all<RD>(rb, first + off + kRecBytes);
-            cs::write_lane2_u32(out_lo, out_hi, cell(a), off);
-            a = cs::rec_load_all<RD>(rb, first + off + 2 * kRecBytes);
-            cs::write_lane2_u32(out_lo, out_hi, cell(b), off + kRecBytes);
+        const uint32_t* q = lrec + (int64_t)(base - g0) * CASIM_FEAS_REC_DW;
+        // four groups per step (immediate LDS offsets), each record read a group ahead of its use.  A count that is no multiple of four
+        // runs up to three records over and the look-ahead one more — inside the LDS allocation, which is rounded up to four records plus
+        // four; the words of the extra cells land in lanes >= n, which are not stored
+        Rec cur = fetch(q);
+        for (uint32_t j = 0; j < n; j += 4) {
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const Rec nxt = fetch(q + (int64_t)(j + u + 1) * CASIM_FEAS_REC_DW);
+                cs::write_lane2_u32(out_lo, out_hi, cell(cur), j + u);
+                cur = nxt;
+            }
         }
         // one store instruction for up to 64 rows; lanes past the row's end of the simulation drop out (dead PEGs: masked here, once)
         if (lane < (int)n) row0[(int64_t)(base - g0 + lane) * Wg] = (((uint64_t)out_hi << 32) | out_lo) & live_mask;

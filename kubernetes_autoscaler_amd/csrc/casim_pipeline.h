@@ -665,21 +665,23 @@ public:
         {
             const bool off = getenv("CASIM_NO_FEAS_STREAM") != nullptr;   // A/B switch: the LDS-staged feas_sim_kernel of round 4
             if (!off && feas_by_sim_ && csr_on_device_ && fast_npt_ > 0 && !fast_i64_ && fs_.fresh32 && NG_ > 0 && dt_.R <= 4) {
-                d_feas_rec_ = (uint32_t*)dalloc(((size_t)NG_ + 2) * CASIM_FEAS_REC_DW * 4);
-                // narrow dictionaries (every taint / label-requirement bit below bit 31): decided on the device, read back behind the sync a
-                // resident problem's init ends with anyway — the records are then built a second time in their mask31 form (once per
-                // problem); a one-shot call does not wait here and runs the general instantiation
-                feas_mask31_ = false; h_mask_hi_ = ~0ull;
-                if (d_feas_rec_) bk_.launch(feas_group_records_kernel, (NG_ + 257) / 256, 1, 256, (size_t)0, dt_, fs_.fresh32, d_feas_rec_, 0);
+                d_feas_rec_ = (uint32_t*)dalloc((size_t)NG_ * CASIM_FEAS_REC_DW * 4);
+                // which bits of the taint / selector words the batch uses at all: decided on the device (mask_or_kernel), read back behind
+                // the wait a resident problem's init ends with anyway — unused upper halves drop the kHi terms, an unused bit carries
+                // NodeUnschedulable (the records are then built a second time, once per problem); a one-shot call does not wait here and
+                // runs the general instantiation
+                feas_hi_ = true; feas_us_word_ = -1; feas_us_bit_ = 0; h_mask_used_[0] = h_mask_used_[1] = ~0ull;
+                feas_smem_ = (size_t)(((max_sim_groups_ + 3) & ~3) + 4) * CASIM_FEAS_REC_DW * 4;   // (rounded up to four records, plus four: see the kernel's look-ahead)
+                if (d_feas_rec_) bk_.launch(feas_group_records_kernel, (NG_ + 255) / 256, 1, 256, (size_t)0, dt_, fs_.fresh32, d_feas_rec_, -1, 0);
                 if (d_feas_rec_ && !one_shot_) {
-                    uint64_t* flag = (uint64_t*)dalloc(8);
+                    uint64_t* flag = (uint64_t*)dalloc(16);
                     if (flag) {
-                        bk_.zero(flag, 8);
+                        bk_.zero(flag, 16);
                         const int64_t na = (int64_t)NG_ * dt_.Wt, nb = (int64_t)G_ * dt_.Wl;
                         const int64_t most = na > nb ? na : nb;
                         const int blocks = (int)(most / 2048 > 1024 ? 1024 : (most / 2048 < 1 ? 1 : most / 2048));
-                        bk_.launch(mask_hi_or_kernel, blocks, 1, 256, (size_t)0, dt_.taint, na, dt_.sel, nb, flag);
-                        bk_.d2h(&h_mask_hi_, flag, 8);
+                        bk_.launch(mask_or_kernel, blocks, 1, 256, (size_t)0, dt_.taint, na, dt_.sel, nb, flag);
+                        bk_.d2h(h_mask_used_, flag, 16);
                     }
                 }
             }
@@ -689,8 +691,15 @@ public:
         // copy then drains with the kernels behind it and a single call waits for the device once instead of twice
         if (!one_shot_) {
             bk_.sync();
-            feas_mask31_ = d_feas_rec_ != nullptr && h_mask_hi_ == 0;
-            if (feas_mask31_) bk_.launch(feas_group_records_kernel, (NG_ + 257) / 256, 1, 256, (size_t)0, dt_, fs_.fresh32, d_feas_rec_, 1);
+            if (d_feas_rec_ && (h_mask_used_[0] & h_mask_used_[1]) != ~0ull) {
+                const uint64_t ut = h_mask_used_[0], us = h_mask_used_[1];
+                feas_hi_ = ((ut | us) >> 32) != 0;
+                const int top = feas_hi_ ? 64 : 32;
+                feas_us_word_ = -1;
+                for (int b = 0; b < top && feas_us_word_ < 0; ++b) if (!((ut >> b) & 1)) { feas_us_word_ = 0; feas_us_bit_ = b; }
+                for (int b = 0; b < top && feas_us_word_ < 0; ++b) if (!((us >> b) & 1)) { feas_us_word_ = 1; feas_us_bit_ = b; }
+                if (feas_us_word_ >= 0) bk_.launch(feas_group_records_kernel, (NG_ + 255) / 256, 1, 256, (size_t)0, dt_, fs_.fresh32, d_feas_rec_, feas_us_word_, feas_us_bit_);
+            }
         }
         pass_gate();
         stage.mark("done");
@@ -1161,7 +1170,7 @@ public:
     // [0] the streaming feasibility kernel serves this problem, [1] lean, [2] mask31, [3] its workgroups
     void feasibility_info(int32_t out[4]) const {
         const bool stream = d_feas_rec_ != nullptr && fast_npt_ > 0 && (strided_ || feas_by_sim_) && !front_ && !(strided_ && strided_one_launch_);
-        out[0] = stream ? 1 : 0; out[1] = stream && dt_.Wx == 0 && dt_.Wz == 0 && dt_.R <= 2; out[2] = stream && feas_mask31_;
+        out[0] = stream ? 1 : 0; out[1] = stream && dt_.Wx == 0 && dt_.Wz == 0 && dt_.R <= 2; out[2] = stream ? ((feas_hi_ ? 0 : 1) | (feas_us_word_ >= 0 ? 2 : 0)) : 0;
         out[3] = stream ? ((n_sims_ + 7) / 8) * 8 * ((feas_len_ + 255) / 256) : 0;
     }
     bool uses_front() const { return front_; }
@@ -1175,13 +1184,18 @@ private:
     // the lean instantiation for batches without exclusion words whose (at most two) lanes are narrowed to int32: the headline's shape
     void launch_feas_sim(int gx, int gy, int block, size_t smem, const DevTables& t, uint64_t* bits, int wg, const int32_t* req32, const int32_t* fresh32) {
         const bool lean = t.Wx == 0 && t.Wz == 0 && t.R <= 2 && req32 != nullptr;
-        if (d_feas_rec_ && req32 != nullptr) {   // the streaming form (round 5): group records in scalar registers, XCD-aware 1-D grid
+        if (d_feas_rec_ && req32 != nullptr) {   // the streaming form (round 5): group records through LDS, one accumulated word per cell, XCD-aware 1-D grid
             const int n_sims = gy, blocks = ((n_sims + 7) / 8) * 8 * gx;
-            if (getenv("CASIM_FEAS_TRACE")) fprintf(stderr, "[feas] feas_stream_kernel<%s, %s> %d blocks x %d, %d simulations\n", lean ? "lean" : "full", feas_mask31_ ? "mask31" : "mask64", blocks, block, n_sims);
-            if (lean) { if (feas_mask31_) bk_.launch(feas_stream_kernel<true, true>, blocks, 1, block, (size_t)0, t, bits, wg, req32, (const uint32_t*)d_feas_rec_, gx, n_sims);
-                        else bk_.launch(feas_stream_kernel<true, false>, blocks, 1, block, (size_t)0, t, bits, wg, req32, (const uint32_t*)d_feas_rec_, gx, n_sims); }
-            else { if (feas_mask31_) bk_.launch(feas_stream_kernel<false, true>, blocks, 1, block, (size_t)0, t, bits, wg, req32, (const uint32_t*)d_feas_rec_, gx, n_sims);
-                   else bk_.launch(feas_stream_kernel<false, false>, blocks, 1, block, (size_t)0, t, bits, wg, req32, (const uint32_t*)d_feas_rec_, gx, n_sims); }
+            const bool term = feas_us_word_ < 0;
+            if (getenv("CASIM_FEAS_TRACE")) fprintf(stderr, "[feas] feas_stream_kernel<%s, %s, %s> %d blocks x %d, %d simulations\n", lean ? "lean" : "full", feas_hi_ ? "hi" : "lo",
+                                                    term ? "term" : "bit", blocks, block, n_sims);
+            const uint32_t* rec = (const uint32_t*)d_feas_rec_;
+#define CASIM_FEAS_LAUNCH(L, H, T) bk_.launch(feas_stream_kernel<L, H, T>, blocks, 1, block, feas_smem_, t, bits, wg, req32, rec, gx, n_sims, feas_us_word_, feas_us_bit_)
+            if (lean) { if (feas_hi_) { if (term) CASIM_FEAS_LAUNCH(true, true, true); else CASIM_FEAS_LAUNCH(true, true, false); }
+                        else { if (term) CASIM_FEAS_LAUNCH(true, false, true); else CASIM_FEAS_LAUNCH(true, false, false); } }
+            else { if (feas_hi_) { if (term) CASIM_FEAS_LAUNCH(false, true, true); else CASIM_FEAS_LAUNCH(false, true, false); }
+                   else { if (term) CASIM_FEAS_LAUNCH(false, false, true); else CASIM_FEAS_LAUNCH(false, false, false); } }
+#undef CASIM_FEAS_LAUNCH
             return;
         }
         if (lean) bk_.launch(feas_sim_kernel<true>, gx, gy, block, smem, t, bits, wg, req32, fresh32);
@@ -1285,8 +1299,10 @@ private:
     uint8_t* d_opt_set_ = nullptr; int32_t* d_opt_out_ = nullptr; int64_t* d_opt_key_ = nullptr; int64_t* d_opt_packed_ = nullptr;
     uint8_t* d_opt_valid_ = nullptr; size_t opt_cap_ = 0;
     int n_sims_ = 0, max_sim_groups_ = 0, feas_len_ = 0;
-    uint64_t h_mask_hi_ = ~0ull;
-    uint32_t* d_feas_rec_ = nullptr; bool feas_mask31_ = false;   // feas_stream_kernel: [NG][16] group records; every taint / label-requirement bit in the words' lower halves
+    // feas_stream_kernel: [NG][16] group records; bits the batch's taint / selector words use at all (mask_or_kernel); upper halves in use;
+    // where the NodeUnschedulable bit rides (-1: a term of its own); dynamic LDS of the launch
+    uint64_t h_mask_used_[2] = {~0ull, ~0ull};
+    uint32_t* d_feas_rec_ = nullptr; bool feas_hi_ = true; int feas_us_word_ = -1, feas_us_bit_ = 0; size_t feas_smem_ = 0;
     bool chain_ = false; int chain_passes_ = 0; int32_t* d_chain_redo_ = nullptr; int32_t* d_chain_marks_ = nullptr;   // casim_options.chain_last_index
     bool feas_by_sim_ = false;
     bool one_shot_ = false;

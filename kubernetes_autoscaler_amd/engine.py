@@ -577,11 +577,12 @@ class Problem:
 
 
     def time_feasibility(self, iters: int = 50):
-        """casim_problem_time_feasibility: (ms per feasibility launch, {"stream", "lean", "mask31", "workgroups"})"""
+        """casim_problem_time_feasibility: (ms per feasibility launch, {"stream", "lean", "narrow_masks", "unsched_on_spare_bit", "workgroups"})"""
         ms = C.c_float(0)
         info = (C.c_int32 * 4)()
         check(lib.casim_problem_time_feasibility(self._h, int(iters), C.byref(ms), info), "casim_problem_time_feasibility")
-        return float(ms.value), {"stream": bool(info[0]), "lean": bool(info[1]), "mask31": bool(info[2]), "workgroups": int(info[3])}
+        return float(ms.value), {"stream": bool(info[0]), "lean": bool(info[1]), "narrow_masks": bool(info[2] & 1), "unsched_on_spare_bit": bool(info[2] & 2),
+                                 "workgroups": int(info[3])}
 
 
 def estimate_batch_timed(ctx: Context, pegs: _abi.Pegs, groups: _abi.Groups, kinds: Optional[Sequence[int]] = None, fastpath: bool = False,

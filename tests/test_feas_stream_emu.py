@@ -17,8 +17,8 @@ GiB = 1 << 30
 
 
 def _run_both(ts, capfd, resident=True, **kw):
-    """resident: the casim_problem_create form (init waits for the device and learns whether the dictionaries are narrow: the mask31
-    instantiations); else the one-shot call of casim_estimate_batch_query (general instantiations only)"""
+    """resident: the casim_problem_create form (init waits for the device and learns which mask bits the batch uses: the instantiations
+    without upper-half terms / with NodeUnschedulable on a spare bit); else the one-shot call of casim_estimate_batch_query (general one)"""
     os.environ["CASIM_FEAS_TRACE"] = "1"
     os.environ.pop("CASIM_NO_FEAS_STREAM", None)
     if resident:
@@ -95,8 +95,8 @@ def test_the_gates_folded_into_the_group_record(capfd):
 
 
 def test_dictionaries_beyond_31_entries_use_the_upper_mask_halves(capfd):
-    """40 distinct taints and 40 selector pairs: bits 32-39 of the words decide cells — the mask31 instantiation must NOT be chosen, and a
-    batch whose dictionaries stay below 31 takes it"""
+    """40 distinct taints and 40 selector pairs: bits 32-39 of the words decide cells — the instantiation without upper-half terms must NOT be
+    chosen, and a batch whose dictionaries stay in the lower halves takes it; both find a spare bit for NodeUnschedulable"""
     def batch(n_keys):
         groups = [GroupSpec(_tmpl(f"t{i}", taints=[Taint(f"k{i}", "v", "NoSchedule")], labels={f"l{i}": "x"}), 0, 0, None) for i in range(n_keys)]
         pegs = []
@@ -104,11 +104,11 @@ def test_dictionaries_beyond_31_entries_use_the_upper_mask_halves(capfd):
             pegs.append(PodEquivalenceGroup(pods=[Pod(name=f"p{i}", requests={"cpu": 100, "memory": 1 << 28}, node_selector={f"l{i}": "x"},
                                                       tolerations=[Toleration(key=f"k{i}", operator="Exists")])] * 2))
         return [Scenario(pegs=pegs, groups=groups, device_csr=True), Scenario(pegs=pegs[5:], groups=groups[3:], device_csr=True)]
-    for n_keys, tag in ((40, "mask64"), (12, "mask31")):
+    for n_keys, tag in ((40, "hi, bit>"), (12, "lo, bit>")):
         scs = batch(n_keys)
         enc, ts, bases = encode_batch(scs)
         res, trace = _run_both(ts, capfd)
-        assert f"feas_stream_kernel<lean, {tag}>" in trace, trace[-300:]
+        assert f"feas_stream_kernel<lean, {tag}" in trace, trace[-300:]
         want = _want(scs, bases)
         assert_matches_oracle(res, want, tag)
         assert [ids for _, ids in want[:n_keys]] == [[i] for i in range(n_keys)]      # PEG i fits template i only (its taint, its label)
@@ -128,3 +128,26 @@ def test_more_than_64_groups_and_rows_that_end_inside_a_word(capfd):
     assert "feas_stream_kernel<" in trace
     assert_matches_oracle(res, _want(scs, bases), "70 groups")
     enc.close()
+
+
+def test_no_spare_bit_and_an_unschedulable_template(capfd):
+    """64 taints AND 64 label requirements in use: no spare bit anywhere — NodeUnschedulable stays a term of its own (<.., hi, term>), and with
+    one bit free it rides there; an unschedulable template among the groups makes the bit matter"""
+    from kubernetes_autoscaler_amd.objects import Taint, Toleration
+    tol_unsched = Toleration(key="node.kubernetes.io/unschedulable", operator="Exists", effect="NoSchedule")
+    for n_keys, tag in ((64, "hi, term>"), (63, "hi, bit>")):
+        groups = [GroupSpec(_tmpl(f"t{i}", taints=[Taint(f"k{i}", "v", "NoSchedule")], labels={f"l{i}": "x"}, unschedulable=i % 5 == 0), 0, 0, None) for i in range(n_keys)]
+        pegs = [PodEquivalenceGroup(pods=[Pod(name=f"p{i}", requests={"cpu": 100, "memory": 1 << 28}, node_selector={f"l{i}": "x"},
+                                              tolerations=[Toleration(key=f"k{i}", operator="Exists")] + ([tol_unsched] if i % 10 == 0 else []))] * 2) for i in range(n_keys)]
+        scs = [Scenario(pegs=pegs, groups=groups, device_csr=True), Scenario(pegs=pegs[7:], groups=groups[2:], device_csr=True)]
+        enc, ts, bases = encode_batch(scs)
+        if enc.pegs.w_taint > 1 or enc.pegs.w_label > 1:
+            enc.close()
+            pytest.skip("the encoder spent a second mask word")
+        res, trace = _run_both(ts, capfd)
+        assert f"feas_stream_kernel<lean, {tag}" in trace, trace[-300:]
+        want = _want(scs, bases)
+        assert_matches_oracle(res, want, tag)
+        # PEG i fits template i only — and not even that one when the template is cordoned and the PEG does not tolerate it
+        assert [ids for _, ids in want[:n_keys]] == [[i] if (i % 5 != 0 or i % 10 == 0) else [] for i in range(n_keys)]
+        enc.close()

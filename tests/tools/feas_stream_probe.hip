@@ -14,7 +14,7 @@ template <class T> T* up(const std::vector<T>& v) { T* d = nullptr; if (hipMallo
 int run_variant(int kVar, const DevTables& t, uint64_t* d_bits, int Wg, const int32_t* d_req32, const uint32_t* d_rec, int gx, int n_sims, size_t words, const std::vector<uint64_t>& want, const char* what) {
     (void)hipMemset(d_bits, 0xff, words * 8);
     const int blocks = ((n_sims + 7) / 8) * 8 * gx;
-    hipLaunchKernelGGL((feas_stream_kernel<true, false>), dim3(blocks), dim3(256), 0, 0, t, d_bits, Wg, d_req32, d_rec, gx, n_sims);
+    hipLaunchKernelGGL((feas_stream_kernel<true, true, true>), dim3(blocks), dim3(256), (size_t)(((7 + 3) & ~3) + 4) * 64, 0, t, d_bits, Wg, d_req32, d_rec, gx, n_sims, -1, 0);
     CK(hipDeviceSynchronize());
     std::vector<uint64_t> got(words);
     CK(hipMemcpy(got.data(), d_bits, words * 8, hipMemcpyDeviceToHost));
@@ -45,7 +45,7 @@ int main() {
     const int32_t* d_req32 = up(req32); const int32_t* d_fresh32 = up(fresh32);
     uint32_t* d_rec = nullptr; CK(hipMalloc(&d_rec, (size_t)(NG + 2) * 64));
     uint64_t* d_bits = nullptr; const size_t words = (size_t)NG * Wg; CK(hipMalloc(&d_bits, words * 8));
-    hipLaunchKernelGGL(feas_group_records_kernel, dim3((NG + 257) / 256), dim3(256), 0, 0, t, d_fresh32, d_rec, 0);
+    hipLaunchKernelGGL(feas_group_records_kernel, dim3((NG + 255) / 256), dim3(256), 0, 0, t, d_fresh32, d_rec, -1, 0);
     CK(hipDeviceSynchronize());
     std::vector<uint32_t> rec((size_t)(NG + 2) * 16);
     CK(hipMemcpy(rec.data(), d_rec, rec.size() * 4, hipMemcpyDeviceToHost));
@@ -54,8 +54,8 @@ int main() {
         const uint32_t* r = rec.data() + (size_t)i * 16;
         const uint64_t nl = ~label[i];
         const int32_t f0 = allowed[i] - init_pods[i] <= 0 ? (int32_t)0x80000000 : fresh32[i * R];
-        const bool ok = r[0] == (uint32_t)taint[i] && r[1] == (uint32_t)(taint[i] >> 32) && r[2] == (uint32_t)nl && r[3] == (uint32_t)(nl >> 32) && (int32_t)r[4] == f0 &&
-                        (int32_t)r[5] == fresh32[i * R + 1] && r[6] == ((gflags[i] & CASIM_NG_UNSCHEDULABLE) ? 1u : 0u);
+        const bool ok = r[0] == (uint32_t)taint[i] && r[4] == (uint32_t)(taint[i] >> 32) && r[1] == (uint32_t)nl && r[5] == (uint32_t)(nl >> 32) && (int32_t)r[2] == f0 &&
+                        (int32_t)r[3] == fresh32[i * R + 1] && r[6] == ((gflags[i] & CASIM_NG_UNSCHEDULABLE) ? 1u : 0u);
         if (!ok && rec_bad++ < 4) printf("record %d wrong: %08x %08x %08x %08x %08x %08x %08x\n", i, r[0], r[1], r[2], r[3], r[4], r[5], r[6]);
     }
     printf("group records: %d of %d wrong\n", rec_bad, NG);
@@ -68,7 +68,7 @@ int main() {
     }
     const int gx = (pegs_per_sim + 255) / 256;
     int bad = 0;
-    bad += run_variant(0, t, d_bits, Wg, d_req32, d_rec, gx, n_sims, words, want, "feas_stream_kernel<lean, mask64>");
+    bad += run_variant(0, t, d_bits, Wg, d_req32, d_rec, gx, n_sims, words, want, "feas_stream_kernel<lean, hi, term>");
     printf(bad ? "PROBE: product variant WRONG\n" : "PROBE: product variant ok\n");
     return 0;
 }

@@ -9,9 +9,9 @@ __global__ void k_m0_mov(unsigned* out, unsigned base, int n) {   // s_mov_b32 m
     for (int j = 0; j < n; ++j) cs::write_lane_u32(v, base + (unsigned)j, j);
     out[threadIdx.x] = v;
 }
-__global__ void k_m0_lshr(unsigned* out, unsigned base, int n) {  // s_lshr_b32 m0, 64 j, 6 ; two v_writelane  (cs::write_lane2_u32)
+__global__ void k_m0_lshr(unsigned* out, unsigned base, int n) {  // cs::write_lane2_u32 (round 5): one M0 load, two v_writelane
     unsigned lo = 0, hi = 0;
-    for (int j = 0; j < n; ++j) cs::write_lane2_u32(lo, hi, ((unsigned long long)(base + 5000u + (unsigned)j) << 32) | (base + (unsigned)j), (unsigned)j * 64u);
+    for (int j = 0; j < n; ++j) cs::write_lane2_u32(lo, hi, ((unsigned long long)(base + 5000u + (unsigned)j) << 32) | (base + (unsigned)j), (unsigned)j);
     out[threadIdx.x] = lo; out[64 + threadIdx.x] = hi;
 }
 __global__ void k_m0_two_values(unsigned* out, unsigned base, int n) {  // two DIFFERENT uniform values written with one M0 — but each from a VALU-independent SGPR
@@ -43,7 +43,7 @@ int main() {
     if (hipMalloc(&d, sizeof h) != hipSuccess) { printf("no device\n"); return 1; }
     for (int n : {1, 2, 3, 5, 20, 64}) {
         hipLaunchKernelGGL(k_m0_mov, dim3(1), dim3(64), 0, 0, d, 1000u, n); (void)hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost); check("s_mov m0 + v_writelane (round-4 helper)", h, 1000u, n);
-        hipLaunchKernelGGL(k_m0_lshr, dim3(1), dim3(64), 0, 0, d, 2000u, n); (void)hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost); check("s_lshr m0 + 2 x v_writelane: low words", h, 2000u, n); check("                            high words", h + 64, 7000u, n);
+        hipLaunchKernelGGL(k_m0_lshr, dim3(1), dim3(64), 0, 0, d, 2000u, n); (void)hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost); check("write_lane2_u32: low words", h, 2000u, n); check("                            high words", h + 64, 7000u, n);
         hipLaunchKernelGGL(k_m0_two_values, dim3(1), dim3(64), 0, 0, d, 3000u, n); (void)hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost); check("s_mov m0 + nops + 2 x v_writelane: low", h, 3000u, n); check("                             high", h + 64, 8000u, n);
         hipLaunchKernelGGL(k_const, dim3(1), dim3(64), 0, 0, d, 4000u, n); (void)hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost); check("inline-constant lane select", h, 4000u, n);
     }

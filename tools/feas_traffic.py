@@ -46,12 +46,15 @@ def durations(like):
 
 
 def tag_of(name):
+    """the tag bench.py builds from casim_problem_time_feasibility's info: feas_stream_kernel<lean|full, lo|hi, bit|term>"""
     s = name.replace(" ", "")
     i = s.find("feas_stream_kernel<")
     if i < 0:
         return name
     args = s[i + len("feas_stream_kernel<"):].split(">")[0].split(",")
-    return "feas_stream_kernel<%s, %s>" % ("lean" if args[0] == "true" else "full", "mask31" if args[1] == "true" else "mask64")
+    if len(args) < 3:
+        return name
+    return "feas_stream_kernel<%s, %s, %s>" % ("lean" if args[0] == "true" else "full", "hi" if args[1] == "true" else "lo", "term" if args[2] == "true" else "bit")
 
 
 fetch, write = rows_of("FETCH_SIZE", "%feas_stream_kernel%"), rows_of("WRITE_SIZE", "%feas_stream_kernel%")
