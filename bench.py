@@ -475,6 +475,10 @@ def compact_line(out, side_file=SIDE_FILE):
     i64 = rows.get("int64") if isinstance(rows, dict) else None
     if isinstance(i64, dict) and "checks_per_s" in i64:
         line["value_int64"], line["ms_per_step_int64"] = i64["checks_per_s"], i64.get("ms_per_step")
+    for name in ("c1_resident", "c3_resident", "c4_resident"):
+        r = rows.get(name) if isinstance(rows, dict) else None
+        if isinstance(r, dict) and "checks_per_s" in r:
+            line.setdefault("other_configs", {})[name] = _pick(r, ("ms_per_step", "checks_per_s", "sims_per_s", "bit_exact"))
     mg = out.get("multi_gpu")
     if isinstance(mg, dict) and mg.get("all_reduce_ms") is not None:
         line["multi_gpu"] = _pick(mg, ("rccl_world_size", "collective_backend", "all_reduce_ms", "all_reduce_share_of_step"))
@@ -815,6 +819,13 @@ def main():
                 extra.update(_try(lambda: next_rows(kaa, ctx, workloads)) or {})
             if not args.no_c3:
                 extra["c3_in_process_multi_device"] = _try(lambda: in_process_multi_device(kaa, workloads, kinds))
+            if not args.no_configs:
+                extra["per_call_crossover"] = _try(lambda: per_call_crossover(kaa, ctx, workloads))
+                # the other BASELINE configs that fit one GPU as verified batched throughput rows (C2 is the headline itself)
+                torch.cuda.synchronize()
+                extra["headline_rows"]["c4_resident"] = _try(lambda: batched_config_row(kaa, torch, dev_index, workloads, TableSet, "C4", 2048, 32, kinds, K, verify=not args.no_verify))
+                extra["headline_rows"]["c3_resident"] = _try(lambda: batched_config_row(kaa, torch, dev_index, workloads, TableSet, "C3", 512, 8, kinds, K, verify=not args.no_verify))
+                extra["headline_rows"]["c1_resident"] = _try(lambda: batched_config_row(kaa, torch, dev_index, workloads, TableSet, "C1", 4096, 32, kinds, K, verify=not args.no_verify))
             if not args.no_feasibility_row:
                 # the HBM roofline on the kernel that can carry it: the batched feasibility launch, C2 and C3 shapes
                 torch.cuda.synchronize()
@@ -859,6 +870,84 @@ def main():
     if out is not None:
         emit(out)   # the contract line is the last thing this process writes to stdout
     return out
+
+
+def batched_config_row(kaa, torch, dev_index, workloads, TableSet, config, n_sims, n_seeds, kinds, K, steps=50, verify=True):
+    """a verified THROUGHPUT figure for the other BASELINE configs that fit one GPU — `n_sims` simulations of `config`
+    resident in HBM as one streamed casim_problem (the headline's regime: `steps` steps of run + expander reduce, nothing fetched), the
+    kernels of sub-batch 0 timed with the device to itself, and every group of the last step compared with the oracle."""
+    make = workloads.CONFIGS[config]
+    ts = simulation_tables(make, range(n_seeds), kaa.Encoder, TableSet).tile((n_sims + n_seeds - 1) // n_seeds).head(n_sims)
+    stream = torch.cuda.Stream(device=dev_index)
+    b = kaa.StreamedBatch(dev_index, ts, n_streams=K, stream=stream.cuda_stream)
+    try:
+        for _ in range(5):
+            b.run(); b.best_option_sims(kinds, fetch=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            b.run(); b.best_option_sims(kinds, fetch=False)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res = b.prob.fetch()
+        checks, nnz = checks_of(b.tables, res)
+        alone_ms, kms = b.prob.time(iters=5)
+        info = b.prob.info()
+        row = {"what": f"{config} x {n_sims} simulations per step, resident ({n_seeds} distinct seeds tiled), {b.parts} sub-batches on {b.parts} streams", "ms_per_step": dt * 1e3,
+               "checks_per_s": checks / dt, "sims_per_s": n_sims / dt, "checks_per_simulation": checks / n_sims, "node_groups": int(ts.n_groups), "pegs": int(ts.n_pegs),
+               "schedulable_pairs": nnz, "kernel_ms_sub_batch_0_alone": kms, "packer": {"lanes": info["fast_packer_lanes"], "slots_per_lane": info["fast_packer_slots_per_lane"]},
+               "dtype": "int32" if info["fast_packer_slots_per_lane"] > 0 and info["fast_packer_lanes"] != 8 else "int64", "steps": steps}
+        if verify:
+            chk = verify_headline(workloads, make, n_seeds, b.tables, res)
+            row["bit_exact"] = bool(chk["headline_bit_exact"]); row["groups_compared"] = chk["groups_compared"]; row["verify_s"] = chk["verify_s"]
+        return row
+    finally:
+        b.close()
+
+
+def per_call_crossover(kaa, ctx, workloads, iters=60):
+    """where does ONE Estimate() per call stop paying on the device?  C1-shaped single-group calls (CPU + memory, PEGs of
+    10 pods, the caller's own PEG list: what the shim's per-call path sends) over a sweep of (pods, node cap); per point the enter -> return
+    wall time of casim_estimate_batch_query (median of `iters` calls, tables already encoded: the shim's per-call path reuses the loop's
+    tables) next to the oracle's Estimate of the same call (one native call, best of a few).  `work` = pods x node bound is the quantity
+    gpubinpacking.Routing compares with MinDeviceWork; `crossover_work` = the smallest work from which on the device wins at every larger
+    point of the sweep."""
+    from kubernetes_autoscaler_amd.engine import BatchCall
+    from harness import GroupSpec, Scenario, encode
+    from oracle_driver import OracleScenario
+    rows = []
+    for pods, cap in ((50, 5), (100, 10), (200, 10), (200, 40), (500, 20), (500, 100), (1000, 30), (1000, 100), (2000, 50), (2000, 256), (5000, 100), (10000, 256)):
+        w = workloads.config_c1(n_pegs=max(1, pods // 10), pods_per_peg=10, cap=cap)
+        sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, list(range(len(w.pegs)))) for g in w.groups], existing=w.existing,
+                      lanes=w.lanes, device_csr=False)
+        enc = encode(sc)
+        bc = BatchCall(ctx, enc.pegs, enc.groups)
+        for _ in range(10):
+            bc.call_raw()
+        ts = []
+        for _ in range(iters):
+            t0 = time.perf_counter(); bc.call_raw(); ts.append(time.perf_counter() - t0)
+        ts.sort()
+        o = OracleScenario(lanes=w.lanes)
+        tmpl = o.node(w.groups[0].template)
+        native = o.prepare_simulation([tmpl], w.pegs, [w.groups[0].max_nodes], [0])
+        best = 1e9
+        for _ in range(5):
+            t0 = time.perf_counter(); native(False); best = min(best, time.perf_counter() - t0)
+        o.close(); enc.close()
+        n_pods = sum(len(pg.pods) for pg in w.pegs)
+        rows.append({"pods": n_pods, "node_cap": cap, "work": n_pods * min(cap, n_pods), "device_call_us": ts[len(ts) // 2] * 1e6, "oracle_us": best * 1e6,
+                     "device_over_oracle": ts[len(ts) // 2] / best})
+    rows.sort(key=lambda r: r["work"])
+    cross = None
+    for i, r in enumerate(rows):
+        if all(x["device_over_oracle"] < 1.0 for x in rows[i:]):
+            cross = r["work"]
+            break
+    return {"what": "one Estimate() per call, C1-shaped (one group, PEGs of 10 pods, the caller's PEG list), device enter -> return vs the oracle's native Estimate (one EPYC core, "
+                    "a C restatement: the Go reference is slower, i.e. its crossover lies lower)",
+            "rows": rows, "crossover_work": cross, "shim_default_min_device_work": 60000,
+            "note": "gpubinpacking.Routing (integration/go/gpubinpacking/estimator.go) hands calls with pods x node bound below MinDeviceWork to the reference estimator"}
 
 
 def feasibility_bytes(ts, lean):

@@ -198,3 +198,15 @@ def test_a3_quotient_with_a_divisor_of_one_and_a_very_large_peg(ctx):
         res, _ = run_gpu(enc, ctx)
         enc.close()
         assert (int(res.status[0]), int(res.node_count[0]), int(res.pods_scheduled[0]), int(res.nodes_added[0])) == (0, cap, cap, cap), (count, cap, res.node_count, res.pods_scheduled)
+
+
+# ---- the snapshot's SchedulePod rows (predicate_snapshot_test.go:400-511) -------------------------------------------------------------------
+def test_snapshot_schedule_pod_rows_on_the_device(ctx):
+    from harness import SchedCase, assert_sched_matches, sched_gpu, sched_oracle
+    from test_snapshot_schedule_pod import CASES, build
+    for case in CASES:
+        nodes, pod, acceptable, want = build(case)
+        sc = SchedCase(nodes=nodes, pods=[pod], acceptable=acceptable)
+        got = sched_gpu(sc, ctx)
+        assert_sched_matches(got, sched_oracle(sc), case["name"])
+        assert int(got[1][0]) == want, case["name"]
