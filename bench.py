@@ -39,6 +39,7 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+SHIM_MIN_DEVICE_WORK = 150000   # gpubinpacking.DefaultRouting.MinDeviceWork (integration/go/gpubinpacking/estimator.go)
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable copy rate
 SIMDS, CLOCK_HZ = 1024, 2.4e9
 
@@ -306,6 +307,17 @@ def config_rows(kaa, ctx, workloads, kinds, iters=20):
                 row["bit_exact"] = False
                 row["mismatch"] = str(e)[:200]
             row["speedup_vs_oracle_wall"] = row["oracle_ms"] / row["wall_ms"]
+            # which path the Go shim takes for this call (gpubinpacking.Routing: per-call Estimates with pods x node bound below MinDeviceWork
+            # go to the reference estimator; batches from the prefetch fill always go to the device) and the ratio ON THAT PATH
+            if len(w.groups) == 1:
+                bound = w.groups[0].max_nodes if w.groups[0].max_nodes > 0 else w.n_pods
+                work = w.n_pods * min(bound, w.n_pods)
+                row["shim_route"] = {"work_pods_x_node_bound": int(work), "min_device_work": SHIM_MIN_DEVICE_WORK,
+                                     "path": "reference estimator" if work < SHIM_MIN_DEVICE_WORK else "device"}
+                row["speedup_on_the_path_the_shim_takes"] = 1.0 if work < SHIM_MIN_DEVICE_WORK else row["speedup_vs_oracle_wall"]
+            else:
+                row["shim_route"] = {"path": "device (one batch per loop: the prefetch fill)"}
+                row["speedup_on_the_path_the_shim_takes"] = row["speedup_vs_oracle_wall"]
             enc.close()
             # the same simulation through tools/casim_native: plain C++ over the C ABI, no Python between the calls —
             # encode (all casim_enc_* calls + finalize), tables -> HBM, kernels, results -> host
@@ -946,7 +958,7 @@ def per_call_crossover(kaa, ctx, workloads, iters=60):
             break
     return {"what": "one Estimate() per call, C1-shaped (one group, PEGs of 10 pods, the caller's PEG list), device enter -> return vs the oracle's native Estimate (one EPYC core, "
                     "a C restatement: the Go reference is slower, i.e. its crossover lies lower)",
-            "rows": rows, "crossover_work": cross, "shim_default_min_device_work": 60000,
+            "rows": rows, "crossover_work": cross, "shim_default_min_device_work": SHIM_MIN_DEVICE_WORK,
             "note": "gpubinpacking.Routing (integration/go/gpubinpacking/estimator.go) hands calls with pods x node bound below MinDeviceWork to the reference estimator"}
 
 

@@ -47,15 +47,17 @@ type gpuEstimator struct {
 // one upload, two launches, one copy back and one wait — 30-150 us on an MI355X whatever the size — while the reference's loop costs
 // one Filter run per (pod, simulated node) pair it visits.  MinDeviceWork is the crossover in those units: pods of the call x node
 // bound of the call (the limiter's cap, or the pod count when unlimited).  Below it gpuEstimator.Estimate hands the call to the
-// reference estimator.  The default comes from the sweep bench.py prints as `per_call_crossover` (one C-restatement core against the
-// device, enter -> return; the Go reference is slower than the C restatement, so the default errs towards the device); 0 disables
-// routing.  Hits of the prefetch cache cost no device work and are always taken.
+// reference estimator.  The default comes from the sweep bench.py prints as `per_call_crossover` (profiles/r10e_bench_side.json: plain
+// CPU + memory calls cross at 50 000 - 100 000 against one core running the C restatement; a call with selectors and taints — one group
+// of config C2, work 125 000 — still loses 0.76x there, hence 150 000.  The Go reference is slower than the C restatement, so calls just
+// below the threshold give up tens of microseconds at most); 0 disables routing.  Hits of the prefetch cache cost no device work and are
+// always taken.
 type Routing struct {
 	MinDeviceWork int64
 }
 
 // DefaultRouting: see INTEGRATION.md section 1c for the sweep behind the number.
-var DefaultRouting = Routing{MinDeviceWork: 60000}
+var DefaultRouting = Routing{MinDeviceWork: 150000}
 
 func (r Routing) cpuIsCheaper(pegs []estimator.PodEquivalenceGroup, maxNodes int) bool {
 	if r.MinDeviceWork <= 0 {

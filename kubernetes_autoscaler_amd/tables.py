@@ -109,7 +109,8 @@ class TableSet:
         simulation's PEGs.  All sets must share the dictionaries (same encoder) or at least the mask widths."""
         d = sets[0].dims
         if any(s.dims != d for s in sets):
-            raise ValueError("table sets with different lane / mask widths cannot share one batch")
+            sets = TableSet._widened(sets)
+            d = sets[0].dims
         cat = lambda cols: None if cols[0] is None else np.concatenate(cols, axis=0)
         pc = {k: cat([s.pegs[k] for s in sets]) for k in _PEG_COLS}
         gc = {k: cat([s.groups[k] for s in sets]) for k in _GROUP_COLS}
@@ -130,6 +131,36 @@ class TableSet:
             raise ValueError("table sets with different node polarity rows cannot share one batch")
         return TableSet(d, pc, gc, np.concatenate(lo).astype(np.int32), np.concatenate(hi).astype(np.int32), None, None,
                         np.concatenate(gid).astype(np.int32), np.array(so, np.int32), zone_polarity=pols[0] if pols else None, excl_polarity=xpols[0] if xpols else None)
+
+    @staticmethod
+    def _widened(sets: Sequence["TableSet"]) -> List["TableSet"]:
+        """Simulations encoded by encoders of their OWN (one dictionary each: C4's pairwise exclusion bits differ from seed to seed) side by
+        side: every mask column padded with zero words to the widest set's width.  Exact — a simulation's groups only ever meet their own
+        simulation's PEGs, so the bit numbering never crosses a simulation, and a zero word neither blocks nor marks anything.  Only for sets
+        without NEED polarity rows (one row serves the whole batch) and with equal resource lanes."""
+        if any(s.dims["n_res"] != sets[0].dims["n_res"] for s in sets):
+            raise ValueError("table sets with different resource lanes cannot share one batch")
+        for s in sets:
+            if (s.zone_polarity is not None and s.zone_polarity.any()) or (s.excl_polarity is not None and s.excl_polarity.any()):
+                raise ValueError("table sets with different mask widths AND polarity rows cannot share one batch")
+        dims = dict(sets[0].dims)
+        for k in ("w_taint", "w_label", "w_excl", "w_zone"):
+            dims[k] = max(s.dims[k] for s in sets)
+
+        def pad(col, n, spec, dtype):
+            w = dims[spec] if isinstance(spec, str) else spec
+            if col is None:
+                return np.zeros((n, w), dtype) if isinstance(spec, str) and w > 0 else None
+            return col if col.shape[1] == w else np.concatenate([col, np.zeros((col.shape[0], w - col.shape[1]), col.dtype)], axis=1)
+        out = []
+        for s in sets:
+            pc = {k: pad(s.pegs[k], s.n_pegs, wd, dt) for k, (dt, wd) in _PEG_COLS.items()}
+            gc = {k: pad(s.groups[k], s.n_groups, wd, dt) for k, (dt, wd) in _GROUP_COLS.items()}
+            # (optional scalar columns must be all there or all absent)
+            out.append(TableSet(dims, pc, gc, s.peg_lo, s.peg_hi, s.peg_offsets, s.peg_index, s.global_id, s.sim_offsets,
+                                zone_polarity=np.zeros(dims["w_zone"], np.uint64) if dims["w_zone"] else None,
+                                excl_polarity=np.zeros(dims["w_excl"], np.uint64) if dims["w_excl"] else None))
+        return out
 
     def tile(self, times: int) -> "TableSet":
         """The batch repeated `times` times (distinct memory, same simulations)."""

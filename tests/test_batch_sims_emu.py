@@ -226,3 +226,28 @@ def test_tables_uploaded_in_pieces(seed, monkeypatch):
         want.extend(_shift(run_oracle(sc), pb))
     assert_matches_oracle(res, want, f"pieces seed {seed}")
     enc.close()
+
+
+def test_simulations_with_dictionaries_of_their_own_widen_to_one_batch():
+    """TableSet.concat of sets whose mask widths differ (every simulation encoded by an encoder of its own: taints only in one, pairwise
+    anti-affinity bits only in another): the columns are padded with zero words and every group still equals the oracle's estimate of its
+    own simulation — what bench.py's batched C4 row relies on (seeds whose exclusion dictionaries differ in size)"""
+    import bench
+    import kubernetes_autoscaler_amd as kaa
+    makes = [lambda seed_offset=0: workloads.config_c2(seed_offset, n_groups=4, n_pegs=30, pods_per_peg=4, cap=6),
+             lambda seed_offset=0: workloads.config_c4(seed_offset, n_groups=5, n_pegs=40, pods_per_peg=4, cap=8),
+             lambda seed_offset=0: workloads.config_c1(seed_offset, n_pegs=20, pods_per_peg=5, cap=12)]
+    sets = [bench.simulation_tables(m, range(2), kaa.Encoder, TableSet) for m in makes]
+    assert len({tuple(sorted(s.dims.items())) for s in sets}) > 1          # the widths really differ
+    ts = TableSet.concat(sets)
+    assert ts.n_sims == 6 and ts.dims["w_taint"] == max(s.dims["w_taint"] for s in sets) and ts.dims["w_excl"] == max(s.dims["w_excl"] for s in sets)
+    res, _ = run_emu_tables(ts)
+    g = 0
+    for m, s in zip(makes, sets):
+        part = ts.sim_slice(g, g + 2)
+        r, _ = run_emu_tables(part)
+        chk = bench.verify_headline(workloads, m, 2, part, r)
+        assert chk["headline_bit_exact"], chk
+        g0, g1 = int(ts.sim_offsets[g]), int(ts.sim_offsets[g + 2])
+        assert list(res.node_count[g0:g1]) == list(r.node_count) and list(res.pods_scheduled[g0:g1]) == list(r.pods_scheduled)
+        g += 2
