@@ -114,4 +114,8 @@ def test_native_replay_of_the_estimator_shim_call_sequence(tmp_path, name):
     assert rc == 0, out
     s = out["shim"]
     assert s["groups"] == len(w.groups) and s["hits"] == s["hits_equal_to_per_call"] == len(w.groups) and s["miss_paths_checked"] == 1 and s["failed_checks"] == 0, s
-    assert s["stats"][0] == 1 and s["stats"][2] == len(w.groups) + 2 and s["stats"][3] == 2 and s["stats"][4] == 2 and s["stats"][5] == 2, s
+    # round 5: a second fill with casim_options.chain_last_index — every Estimate() of the loop, in the batch's order, hits with the runner's
+    # lastIndex as of the call and equals the per-call answer from that value (integration/go/gpubinpacking/{prefetch,estimator}.go)
+    c = out["shim_chained"]
+    assert c["hits"] == c["hits_equal_to_per_call"] == len(w.groups), c
+    assert s["stats"][0] == 2 and s["stats"][2] == 2 * len(w.groups) + 2 and s["stats"][3] == 2 and s["stats"][4] == 2 and s["stats"][5] == 2, s

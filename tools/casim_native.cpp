@@ -268,7 +268,7 @@ casim_groups group_view(const casim_pegs& p, const casim_groups& g, int i) {
 // (enc != NULL: the group's row through casim_enc_group_rows, the call the Go shim makes — estimateOnLoopTables in
 // integration/go/gpubinpacking/prefetch.go; NULL: pointer offsets into the caller's own tables)
 int32_t per_call(casim_ctx* ctx, const casim_pegs& p, const casim_groups& g, int i, const std::vector<int32_t>& list, int32_t max_nodes, const casim_options& opt, OneGroup& out,
-                 casim_encoder* enc = nullptr) {
+                 casim_encoder* enc = nullptr, const int32_t* last_index = nullptr /* the runner's lastIndex for this call, or the table's entry */) {
     casim_groups w = group_view(p, g, i);
     if (enc) {
         const int32_t row = i;
@@ -278,6 +278,7 @@ int32_t per_call(casim_ctx* ctx, const casim_pegs& p, const casim_groups& g, int
     const int32_t off[2] = {0, (int32_t)list.size()};
     const int32_t mn[1] = {max_nodes};
     w.peg_offsets = off; w.peg_index = list.data(); w.max_nodes = mn;
+    if (last_index) w.last_index = last_index;
     const size_t n = list.size();
     out.order.assign(n + 1, 0); out.placed.assign(n + 1, 0);
     casim_results r; memset(&r, 0, sizeof r);
@@ -395,8 +396,34 @@ int shim_replay(casim_ctx* ctx, const casim_pegs& pegs, const casim_groups& grou
         rc = casim_prefetch_lookup(pf, gkey[(size_t)i], k.data(), (int32_t)k.size(), groups.max_nodes[i], groups.existing_nodes[i], groups.last_index[i], &r, nullptr, nullptr);
         if (rc != CASIM_PREFETCH_MISS || r.miss_reason != CASIM_PREFETCH_MISS_GROUP) fail("a cleared cache must miss", i);
     }
+    // ---- the CHAINED loop (round 5: prefetch.go fills with casim_options.chain_last_index; estimator.go looks up with the runner's lastIndex as of
+    // the call and moves it on at every hit): in the batch's order every call hits and equals the per-call Estimate from the runner's value
+    int chain_hits = 0, chain_equal = 0;
+    {
+        casim_options copt = opt; copt.chain_last_index = 1;
+        rc = casim_prefetch_fill(pf, &pegs, &groups, &copt, gkey.data(), pkey.data());
+        if (rc != 0) fail("chained fill", 0);
+        int32_t runner = NG > 0 && groups.last_index ? groups.last_index[0] : 0;
+        for (int i = 0; i < NG && rc == 0; ++i) {
+            const std::vector<int32_t>& l = lists[(size_t)i];
+            std::vector<uint64_t> k = keys_of(l);
+            std::vector<int32_t> order(l.size() + 1), placed(l.size() + 1);
+            casim_prefetch_result r;
+            const int32_t lr = casim_prefetch_lookup(pf, gkey[(size_t)i], k.data(), (int32_t)k.size(), groups.max_nodes[i], groups.existing_nodes[i], runner, &r, order.data(), placed.data());
+            if (lr != CASIM_OK) { fail("chained batch: expected a hit with the runner's lastIndex", i); break; }
+            ++chain_hits;
+            OneGroup pc;
+            if (per_call(ctx, pegs, groups, i, l, groups.max_nodes[i], opt, pc, enc, &runner) != 0) { fail("per-call estimate (chained)", i); break; }
+            order.resize(l.size()); placed.resize(l.size());
+            const bool same = r.node_count == pc.v[0] && r.pods_scheduled == pc.v[1] && r.nodes_added == pc.v[2] && r.limiter_nodes == pc.v[3] && r.last_index_out == pc.v[4] &&
+                              r.status == pc.v[5] && (r.status != 0 || (order == pc.order && placed == pc.placed));
+            if (same) ++chain_equal; else fail("chained hit differs from the per-call answer with the runner's lastIndex", i);
+            if (r.status == 0) runner = r.last_index_out;     // (a delegated group hands its input on: the reference path would move the real runner)
+        }
+    }
     int64_t st[8]; casim_prefetch_stats(pf, st);
     casim_prefetch_destroy(pf);
+    printf(", \"shim_chained\": {\"hits\": %d, \"hits_equal_to_per_call\": %d}", chain_hits, chain_equal);
     printf(", \"shim\": {\"groups\": %d, \"hits\": %d, \"hits_equal_to_per_call\": %d, \"miss_paths_checked\": %d, \"failed_checks\": %d, \"fill_ms\": %.4f, "
            "\"lookups_ms\": %.4f, \"per_call_ms_total\": %.4f, \"per_call_on_loop_tables_ms\": %.4f, \"stats\": [%lld, %lld, %lld, %lld, %lld, %lld]}",
            NG, hits, equal, miss_checked, bad, fill_ms, lookup_ms, percall_ms, rows_calls ? rows_ms / rows_calls : 0.0, (long long)st[0], (long long)st[1], (long long)st[2], (long long)st[3], (long long)st[4], (long long)st[5]);
