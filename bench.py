@@ -194,12 +194,23 @@ def cpu_worker(config, seed, budget_s):
     _, s, run = oracle_simulation(workloads, workloads.CONFIGS[config], None if config == "C0" else seed)
     print("ready", flush=True)
     sys.stdin.readline()
+    spins = _alu_spin(0.25)   # (all workers at once: do the cores the processes were given really run in parallel?)
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < budget_s:
         run(False)
         n += 1
-    print(json.dumps({"n": n, "s": time.perf_counter() - t0}), flush=True)
+    print(json.dumps({"n": n, "s": time.perf_counter() - t0, "spins": spins}), flush=True)
     s.close()
+
+
+def _alu_spin(seconds):
+    """iterations of a register-only loop in `seconds`: a worker's share of a core, whatever the memory system does"""
+    n, x, t_end = 0, 1, time.perf_counter() + seconds
+    while time.perf_counter() < t_end:
+        for _ in range(2000):
+            x = (x * 1103515245 + 12345) & 0x7fffffff
+        n += 1
+    return n
 
 
 def cpu_baseline_all_cores(config, checks_per_sim, budget_s=5.0, max_procs=128):
@@ -216,15 +227,29 @@ def cpu_baseline_all_cores(config, checks_per_sim, budget_s=5.0, max_procs=128):
             line = p.stdout.readline()
             if line.strip() != "ready" or time.time() > deadline:
                 raise RuntimeError("cpu worker did not start")
+        alone = _alu_spin(0.25)   # one process with the machine to itself
         t0 = time.perf_counter()
         for p in procs:
             p.stdin.write("go\n"); p.stdin.flush()
-        total = sum(json.loads(p.stdout.readline())["n"] for p in procs)
+        answers = [json.loads(p.stdout.readline()) for p in procs]
+        total = sum(a["n"] for a in answers)
         wall = time.perf_counter() - t0
         for p in procs:
             p.wait(timeout=30)
+        # why N processes are not N times one: the register-only spin every worker runs first tells whether the cores are
+        # really there (cgroup quota, affinity mask, SMT siblings); what is missing beyond that is the memory system under pointer-chasing
+        quota = None
+        try:
+            quota = open("/sys/fs/cgroup/cpu.max").read().strip()
+        except OSError:
+            pass
+        alu_scaling = sum(a.get("spins", 0) for a in answers) / max(alone, 1)
         return {"value": total / wall * checks_per_sim, "unit": "checks/s", "cores": procs_n, "kind": "port", "label": "C restatement, not the Go reference",
-                "sample": f"{total} {config} simulations by {procs_n} processes in {wall:.1f} s", "sims_per_s": total / wall}
+                "sample": f"{total} {config} simulations by {procs_n} processes in {wall:.1f} s", "sims_per_s": total / wall,
+                "scaling_evidence": {"register_only_spin_aggregate_over_one_process": alu_scaling, "cgroup_cpu_max": quota,
+                                     "affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, "os_cpu_count": os.cpu_count(),
+                                     "reading": "spin scaling ~ processes: the cores are there and the oracle's shortfall is its memory traffic (per-pod node lists, "
+                                                "pointer chasing); spin scaling well below: quota / affinity / SMT"}}
     except Exception as e:  # never take the bench line down
         for p in procs:
             try:
