@@ -203,6 +203,15 @@ def cpu_worker(config, seed, budget_s):
     s.close()
 
 
+def _cgroup_cpus():
+    """CPUs the cgroup grants (cpu.max quota / period), None when unlimited or unreadable"""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        return None
+
+
 def _alu_spin(seconds):
     """iterations of a register-only loop in `seconds`: a worker's share of a core, whatever the memory system does"""
     n, x, t_end = 0, 1, time.perf_counter() + seconds
@@ -217,6 +226,9 @@ def cpu_baseline_all_cores(config, checks_per_sim, budget_s=5.0, max_procs=128):
     """The same oracle on every host core at once: independent processes, one simulation stream each (the node-group /
     simulation-parallel CPU variant of SURVEY 8d), aggregate rate."""
     procs_n = max(1, min(max_procs, (os.cpu_count() or 1)))
+    granted = _cgroup_cpus()
+    if granted:   # (r10f: the GPU box reports 256 CPUs and grants 16 of them, cpu.max = "1600000 100000": more processes than that only take turns)
+        procs_n = max(1, min(procs_n, int(granted + 0.999)))
     procs = []
     try:
         for i in range(procs_n):
@@ -248,8 +260,9 @@ def cpu_baseline_all_cores(config, checks_per_sim, budget_s=5.0, max_procs=128):
                 "sample": f"{total} {config} simulations by {procs_n} processes in {wall:.1f} s", "sims_per_s": total / wall,
                 "scaling_evidence": {"register_only_spin_aggregate_over_one_process": alu_scaling, "cgroup_cpu_max": quota,
                                      "affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, "os_cpu_count": os.cpu_count(),
-                                     "reading": "spin scaling ~ processes: the cores are there and the oracle's shortfall is its memory traffic (per-pod node lists, "
-                                                "pointer chasing); spin scaling well below: quota / affinity / SMT"}}
+                                     "cgroup_cpus_granted": granted,
+                                     "reading": "processes = min(128, os.cpu_count(), the cgroup's CPUs); spin scaling ~ processes: the cores are there and what the "
+                                                "oracle lacks beyond it is its memory traffic; spin scaling well below: quota / affinity / SMT"}}
     except Exception as e:  # never take the bench line down
         for p in procs:
             try:
