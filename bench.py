@@ -1274,7 +1274,20 @@ def next_rows(kaa, ctx, workloads):
         e2.add_group(info, pegs=[])
     e2.finalize()
     r2 = ctx.simulate_node_removals(e2.pegs, e2.groups, w2.candidates, off, pcl)
+    kern2 = ctx.last_removals_info()
     _, ms2 = ctx.simulate_node_removals(e2.pegs, e2.groups, w2.candidates, off, pcl, time_iters=5)
+    # A/B: the same call through K_sched's general transaction loop (CASIM_NO_LEAN_REMOVALS is read when the call is prepared)
+    prev = os.environ.get("CASIM_NO_LEAN_REMOVALS")
+    os.environ["CASIM_NO_LEAN_REMOVALS"] = "1"
+    try:
+        r2b = ctx.simulate_node_removals(e2.pegs, e2.groups, w2.candidates, off, pcl)
+        _, ms2b = ctx.simulate_node_removals(e2.pegs, e2.groups, w2.candidates, off, pcl, time_iters=5)
+    finally:
+        if prev is None:
+            del os.environ["CASIM_NO_LEAN_REMOVALS"]
+        else:
+            os.environ["CASIM_NO_LEAN_REMOVALS"] = prev
+    same2 = bool(np.array_equal(r2.removable, r2b.removable) and np.array_equal(r2.node_out, r2b.node_out) and int(r2.last_index) == int(r2b.last_index))
     e2.close()
     s = OracleScenario()
     for info in w2.nodes:
@@ -1289,7 +1302,10 @@ def next_rows(kaa, ctx, workloads):
     exact2 = bool(np.array_equal(np.asarray(r2.removable), want2["removable"]) and np.array_equal(np.asarray(r2.node_out), want2["node_out"]) and
                   int(r2.last_index) == want2["last_index"] and int(r2.n_processed) == want2["n_processed"])
     out["node_removals"] = {"workload": w2.name, "nodes": len(w2.nodes), "candidates": len(w2.candidates),
-                            "removable": int((r2.removable == 1).sum()), "kernels_ms": ms2, "candidates_per_s": len(w2.candidates) / (ms2 * 1e-3),
+                            "removable": int((r2.removable == 1).sum()), "pods_moved": len(pcl),
+                            "kernel": "removals_lean_kernel (one wave over per-class fit masks)" if kern2["lean"] else "sched_kernel (K_sched's transaction loop)",
+                            "kernels_ms": ms2, "candidates_per_s": len(w2.candidates) / (ms2 * 1e-3),
+                            "kernels_ms_k_sched": ms2b, "same_results_as_k_sched": same2,
                             "oracle_ms": oracle2_ms, "bit_exact": exact2, "speedup_vs_oracle_kernels": oracle2_ms / ms2,
                             "cpu_baseline": {"kind": "port", "cores": 1, "what": "orc_simulate_node_removals, the native call alone"},
                             "issue_roofline": sched_issue_roofline("node_removals", ms2)}

@@ -619,6 +619,11 @@ int32_t casim_simulate_node_removals(casim_ctx* ctx, const casim_pegs* classes, 
                                      const casim_removal_candidates* cand, casim_removal_results* out);
 int32_t casim_time_node_removals(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes,
                                  const casim_removal_candidates* cand, int32_t iters, float* ms_out);
+/* Which kernel the calling thread's last removal simulation (either entry point, the resident cluster's too) ran as: info_out[0] 1 = the one-wave
+ * kernel over per-class fit masks (removals_lean_kernel: clusters without domain rules and node-local exclusion words, <= 64 pod classes,
+ * <= 4 resource lanes, node state within the LDS budget), 0 = K_sched's general transaction loop; [1] threads of the workgroup; [2] 1 = node
+ * state in LDS; [3] runs of the call.  Results are identical either way; CASIM_NO_LEAN_REMOVALS=1 in the environment keeps K_sched (A/B). */
+int32_t casim_last_removals_info(int32_t info_out[4]);
 
 /*
  * Resident cluster (second half): the snapshot's node table stays in HBM for a whole RunOnce iteration.

@@ -189,6 +189,7 @@ PROTOTYPES = {
                                                  C.POINTER(RemovalResults)]),
     "casim_time_node_removals": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(RemovalCandidates), C.c_int32,
                                              C.POINTER(C.c_float)]),
+    "casim_last_removals_info": (C.c_int32, [i32p]),
     "casim_pack_build_info": (C.c_int32, [C.c_int32, i32p]),
     "casim_prefetch_create": (C.c_void_p, [C.c_void_p]),
     "casim_prefetch_destroy": (None, [C.c_void_p]),

@@ -32,6 +32,7 @@ CS_DEVICE char* dyn_smem() { return casim_emu::dyn_smem(); }
 CS_DEVICE void sync() { casim_emu::block_sync(); }
 // the lanes of ONE wave rendezvous (LDS written by some lanes, read by others of the same wave): a ballot is the emulator's wave-level meeting point
 CS_DEVICE void wave_sync() { (void)casim_emu::wave_ballot(true); }
+CS_DEVICE void lds_order() { (void)casim_emu::wave_ballot(true); }   // (lanes are fibers here: the rendezvous IS the order)
 CS_DEVICE void sched_fence() {}
 CS_DEVICE int32_t load_relaxed_i32(const int32_t* p) { return *p; }
 CS_DEVICE void atomic_add_i32(int32_t* p, int32_t v) { *p += v; }  // fibers of one block never run concurrently
@@ -110,6 +111,9 @@ CS_DEVICE void sync() { __syncthreads(); }
 // which would need the same trip count in every wave): the wave's own LDS operations complete in order — wait for them, and keep the
 // compiler from moving accesses across
 CS_DEVICE void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+// LDS written by one lane of a ONE-WAVE block and read by the others later in program order (or the other way round): the wave's LDS
+// operations execute in the order they were issued, so nothing has to be waited for — only the compiler may not move accesses across
+CS_DEVICE void lds_order() { __builtin_amdgcn_wave_barrier(); }
 // instruction-scheduling fence: the machine scheduler may not move anything across (bounds live ranges of unrolled slot code)
 CS_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // device-scope relaxed load / add of a counter shared by the waves of a block (served by L2, never a stale L1 line)

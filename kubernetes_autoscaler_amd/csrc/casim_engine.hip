@@ -1160,6 +1160,12 @@ int32_t casim_simulate_node_removals(casim_ctx* ctx, const casim_pegs* classes, 
     if (rc < 0) set_err(rc, s.error());
     return rc;
 }
+int32_t casim_last_removals_info(int32_t info_out[4]) {
+    if (!info_out) return CASIM_ERR_INVALID;
+    const int32_t* li = casim::last_removals_info();
+    for (int i = 0; i < 4; ++i) info_out[i] = li[i];
+    return CASIM_OK;
+}
 int32_t casim_time_node_removals(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes,
                                  const casim_removal_candidates* cand, int32_t iters, float* ms_out) {
     g_err.clear();

@@ -737,7 +737,315 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(512, 1) void sched_kernel(DevTables t, SchedArgs a) {
 }
 
 
+// ---- K_removals: the removal loop as ONE wave over per-class fit masks (round 5) ------------------------------------
+//
+// The removal loop (SimulateNodeRemoval per candidate, planner order; cluster.go:131-260) is a chain: lastIndex is a POSITION in a node list that
+// shrinks with every committed removal and it is never reverted (plugin_runner.go:138), so candidate k starts where candidate k - 1 stopped
+// (DESIGN.md 17e).  What can shrink is the cost of a link of that chain.  sched_kernel above pays ~950 instructions and five or six drains per
+// candidate for the generality of its walk (blocks of T nodes, capacities of every node of a piece, block-wide prefix sums, closed-form rounds).
+// A removal candidate moves one or two pods, each to the first node after lastIndex that takes it.  So, for clusters without domain rules and
+// node-local exclusion words:
+//
+//   fit[c][w]   one bit per (class, node): the static Filters pass AND one more pod of the class fits the node NOW (fitsRequest on the node's
+//               current free amounts and pod slots).  Kept exact incrementally: a placement on node m can only clear bit m (lane c = class c
+//               re-evaluates the node against its own request: one compare per lane), a revert recomputes bit m from the static word.
+//   successor   "first passing node at or after position p" = first set bit of fit[c] & scan in cyclic order: the 64 lanes look at 64 words at
+//               once, ballot + two find-first-set; no capacities, no prefix sums, no barrier — the block IS one wave.
+//
+// Node state (free amounts, pod slots) stays int64 in LDS, the placements of the running transaction sit in an LDS ring (revert / commit read them
+// back without waiting for stores).  Everything else — ghost, list positions after removals, pods listed again by a later candidate ("ext"), sticky
+// pods, atomic groups, max_removable, hints, persist on / off — follows sched_kernel<.., kTxn = true, ..> statement by statement; results are
+// identical (tests/test_removal_lean_emu.py runs every removal case through both kernels).  Not eligible (host side, SchedulerT::init): domain
+// rules, exclusion words, more than 64 classes, more than 4 lanes, state beyond the LDS budget -> sched_kernel as before.
+constexpr int kLeanTxnCap = 256;   // placements of one transaction kept in LDS; longer ones read node_out back (after a real wait)
+CS_HOST_DEVICE int64_t casim_lean_removal_bytes(int R, int C, int64_t cap) {
+    const int64_t S = cap >> 6;
+    return 8 * (int64_t)C * S + 4 * 8 * S + 4 * ((S + 1) & ~1ll) + 4 * kLeanTxnCap + 8 * (int64_t)R * cap + 4 * cap;
+}
+
+// grid (S, C), block 64: static word AND "one pod of the class fits the node as the snapshot stands"
+CS_GLOBAL void lean_fit0_kernel(DevTables t, const uint64_t* CS_RESTRICT fbits, uint64_t* CS_RESTRICT fit0, int S) {
+    const int c = cs::bid_y(), w = cs::bid(), lane = cs::lane();
+    const int m = w * 64 + lane;
+    bool ok = false;
+    if (m < t.NG && ((fbits[(int64_t)c * S + w] >> lane) & 1ull)) {
+        ok = t.allowed[m] - t.init_pods[m] > 0;
+        for (int r = 0; r < t.R; ++r) {
+            const int64_t q = t.req[(int64_t)c * t.R + r];
+            if (q > 0 && t.alloc[(int64_t)m * t.R + r] - t.init_req[(int64_t)m * t.R + r] < q) ok = false;
+        }
+    }
+    const uint64_t b = cs::ballot(ok);
+    if (lane == 0) fit0[(int64_t)c * S + w] = b;
+}
+
+template <int RMAX_>
+CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedArgs a, const uint64_t* CS_RESTRICT fit0) {
+    const int lane = cs::lane();
+    const int R = t.R, N = a.N, cap = a.cap, S = cap >> 6, C = a.C;
+    char* smem = cs::dyn_smem();
+    uint64_t* fit = (uint64_t*)smem;                 // [C][S]
+    uint64_t* accb = fit + (int64_t)C * S;           // [S] acceptable (the hinted node's test)
+    uint64_t* scanb = accb + S;                      // [S] acceptable && !Spec.Unschedulable (the scan's)
+    uint64_t* alive = scanb + S;                     // [S] node still in the snapshot's list
+    uint64_t* arrived = alive + S;                   // [S] node took pods of a committed removal
+    uint32_t* wpre = (uint32_t*)(arrived + S);       // [S] live nodes in front of the word
+    int32_t* txn_node = (int32_t*)(wpre + ((S + 1) & ~1));   // [kLeanTxnCap] destination of the i-th listed pod of the running transaction
+    int64_t* sfree = (int64_t*)(txn_node + kLeanTxnCap);     // [R][cap]
+    int32_t* sslots = (int32_t*)(sfree + (int64_t)R * cap);  // [cap]
+
+    // ---- prologue: node state = what the running pods of each node hold ----
+    for (int m = lane; m < cap; m += 64) {
+        const bool live = m < N;
+        for (int r = 0; r < R; ++r) sfree[(int64_t)r * cap + m] = live ? t.alloc[(int64_t)m * R + r] - t.init_req[(int64_t)m * R + r] : 0;
+        sslots[m] = live ? t.allowed[m] - t.init_pods[m] : 0;
+        const bool acc = live && (a.acceptable == nullptr || a.acceptable[m] != 0);
+        const uint64_t ab = cs::ballot(acc);
+        const uint64_t sb = cs::ballot(acc && !(t.gflags[live ? m : 0] & CASIM_NG_UNSCHEDULABLE));
+        const uint64_t lb = cs::ballot(live);
+        if (lane == 0) {
+            const int w = m >> 6;
+            accb[w] = ab; scanb[w] = sb; alive[w] = lb; arrived[w] = 0ull;
+            wpre[w] = (uint32_t)(w << 6) < (uint32_t)N ? (uint32_t)(w << 6) : (uint32_t)N;
+        }
+    }
+    for (int i = lane; i < C * S; i += 64) fit[i] = fit0[i];
+    // lane c holds class c's request: a node is re-evaluated against every class in one step
+    int64_t my_q[RMAX_];
+#pragma unroll
+    for (int r = 0; r < RMAX_; ++r) my_q[r] = (lane < C && r < R) ? t.req[(int64_t)lane * R + r] : 0;
+    cs::sync();
+
+    int32_t last_index = a.last_index < -1 ? -1 : a.last_index;
+    int32_t scheduled = 0, runs_done = 0, n_alive = N, removed = 0, cand_done = 0, log_n = 0, ext_n = 0;
+    bool any_dead = false;
+
+    auto rank_of = [&](int m) -> int32_t {
+        if (!any_dead) return m;
+        return (int32_t)wpre[m >> 6] + cs::popc64(alive[m >> 6] & cs::low_mask(m & 63));
+    };
+    auto node_at = [&](int32_t pos) -> int32_t {
+        if (!any_dead) return pos;
+        int wsel = 0;
+        for (int base = 0; base < S; base += 64) {
+            const int w = base + lane;
+            bool mine = false;
+            if (w < S) { const int32_t lo = (int32_t)wpre[w], cntw = cs::popc64(alive[w]); mine = pos >= lo && pos < lo + cntw; }
+            const uint64_t b = cs::ballot(mine);
+            if (b != 0ull) { wsel = base + cs::ffs64(b); break; }
+        }
+        uint64_t x = alive[wsel];
+        uint32_t r = (uint32_t)(pos - (int32_t)wpre[wsel]);
+        int idx = 0;
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) {
+            const uint32_t cl = (uint32_t)cs::popc64(x & ((1ull << sh) - 1ull));
+            if (r >= cl) { r -= cl; x >>= sh; idx += sh; }
+        }
+        return (int32_t)(wsel << 6) + idx;
+    };
+    // first node at or after m0 in cyclic order that passes for class c (RunFiltersUntilPassingNode, plugin_runner.go:54-143), or -1
+    auto first_fit = [&](int c, int m0) -> int32_t {
+        const uint64_t* row = fit + (int64_t)c * S;
+        const int w0 = m0 >> 6, b0 = m0 & 63;
+        for (int base = w0 & ~63; base < S; base += 64) {
+            const int w = base + lane;
+            uint64_t x = (w < S && w >= w0) ? (row[w] & scanb[w]) : 0ull;
+            if (w == w0) x &= ~cs::low_mask(b0);
+            const uint64_t b = cs::ballot(x != 0ull);
+            if (b != 0ull) { const int j = cs::ffs64(b); return (int32_t)((base + j) << 6) + cs::ffs64(cs::bcast_u64(x, j)); }
+        }
+        for (int base = 0; base <= w0; base += 64) {
+            const int w = base + lane;
+            uint64_t x = w <= w0 ? (row[w] & scanb[w]) : 0ull;
+            if (w == w0) x &= cs::low_mask(b0);
+            const uint64_t b = cs::ballot(x != 0ull);
+            if (b != 0ull) { const int j = cs::ffs64(b); return (int32_t)((base + j) << 6) + cs::ffs64(cs::bcast_u64(x, j)); }
+        }
+        return -1;
+    };
+    // NodeInfo.AddPod of one pod of class c on node m (dir = +1) or its revert (dir = -1); every class's bit of the node follows
+    auto move_pod = [&](int c, int m, int dir) {
+        int64_t f[RMAX_];
+#pragma unroll
+        for (int r = 0; r < RMAX_; ++r) {
+            const int64_t q = r < R ? (int64_t)cs::bcast_u64((uint64_t)my_q[r], c) : 0;
+            f[r] = r < R ? sfree[(int64_t)r * cap + m] - (dir > 0 ? q : -q) : 0;
+        }
+        const int32_t sl = sslots[m] - dir;
+        cs::lds_order();   // (everybody has read the node before its record changes)
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < RMAX_; ++r) if (r < R) sfree[(int64_t)r * cap + m] = f[r];
+            sslots[m] = sl;
+        }
+        bool fits = sl > 0;
+#pragma unroll
+        for (int r = 0; r < RMAX_; ++r) if (r < R && my_q[r] > 0 && f[r] < my_q[r]) fits = false;
+        if (lane < C) {
+            uint64_t* word = fit + (int64_t)lane * S + (m >> 6);
+            const uint64_t bit = 1ull << (m & 63);
+            if (dir > 0) { if (!fits) *word &= ~bit; }   // (a fuller node never starts to fit)
+            else {
+                const bool stat = (a.fbits[(int64_t)lane * S + (m >> 6)] >> (m & 63)) & 1ull;
+                *word = (fits && stat) ? (*word | bit) : (*word & ~bit);
+            }
+        }
+        cs::lds_order();   // (the masks are read by all lanes in the next search)
+    };
+
+    int32_t my_cand = 0, my_rlo = 0, my_rhi = 0, my_plo = 0, my_phi = 0;   // candidate records kc & ~63 .., one per lane
+    int cstart = 0, cend = 0, cpart = -1;                                   // run records [cstart, cend) of part cpart, one per lane
+    int32_t my_class = 0, my_count = 0, my_hint = -1, my_first = 0;
+
+    for (int kc = 0; kc < a.n_cand; ++kc) {
+        // ---- SimulateNodeRemoval (cluster.go:131-172) of candidate kc, planner order (planner.go:300-330) ----
+        if (a.max_removable > 0 && removed >= a.max_removable) break;
+        if ((kc & 63) == 0) {
+            const int kk = kc + lane;
+            const bool have = kk < a.n_cand;
+            my_cand = have ? a.cand_node[kk] : 0;
+            my_rlo = have ? a.cand_run_off[kk] : 0; my_rhi = have ? a.cand_run_off[kk + 1] : 0;
+            my_plo = have ? a.cand_pod_off[kk] : 0; my_phi = have ? a.cand_pod_off[kk + 1] : 0;
+        }
+        const int Y = (int)cs::bcast_u32((uint32_t)my_cand, kc & 63);
+        int e_lo = 0, e_hi = 0;
+        if ((arrived[Y >> 6] >> (Y & 63)) & 1ull) {
+            // pods that earlier committed removals moved onto this node are listed after its own, in commit order (see sched_kernel)
+            if (a.ext_cap <= 0) break;
+            cs::sync();   // (the log entries were written by other lanes)
+            uint32_t base_n = 0;
+            bool bad = false;
+            for (int j0 = 0; j0 < log_n; j0 += 64) {
+                const int j = j0 + lane;
+                const bool hit = j < log_n && a.log_dest[j] == Y;
+                const int ref = hit ? a.log_ref[j] : 0;
+                const uint64_t b = cs::ballot(hit);
+                const uint32_t pos = (uint32_t)ext_n + base_n + (uint32_t)cs::mbcnt(b);
+                if (hit) {
+                    if (pos < (uint32_t)a.ext_cap) { a.ext_ref[pos] = ref; a.ext_cand[pos] = kc; }
+                    if (a.pod_sticky && a.pod_sticky[ref]) bad = true;
+                }
+                base_n += (uint32_t)cs::popc64(b);
+            }
+            if (cs::ballot(bad) != 0ull || (uint32_t)ext_n + base_n > (uint32_t)a.ext_cap) break;
+            e_lo = ext_n; e_hi = ext_n + (int32_t)base_n; ext_n = e_hi;
+            cs::sync();   // (ext_ref is read back by the run records of part 1)
+        }
+        cand_done = kc + 1;
+        const int run_lo = (int)cs::bcast_u32((uint32_t)my_rlo, kc & 63), run_hi = (int)cs::bcast_u32((uint32_t)my_rhi, kc & 63);
+        const int p_lo = (int)cs::bcast_u32((uint32_t)my_plo, kc & 63), p_hi = (int)cs::bcast_u32((uint32_t)my_phi, kc & 63);
+        if (!((alive[Y >> 6] >> (Y & 63)) & 1ull)) {   // NoNodeInfo (:139-147)
+            if (lane == 0) a.removable_out[kc] = 0;
+            continue;
+        }
+        const int n_own = p_hi - p_lo, n_listed = n_own + (e_hi - e_lo);
+        auto slot_of = [&](int i) -> int { return i < n_own ? p_lo + i : a.P + e_lo + (i - n_own); };
+        auto pod_of = [&](int i) -> int { return i < n_own ? p_lo + i : a.ext_ref[e_lo + (i - n_own)]; };
+        // Fork; the candidate turns into a pod-less tainted ghost that keeps its list position (:243-265)
+        cs::lds_order();
+        if (lane == 0) { accb[Y >> 6] &= ~(1ull << (Y & 63)); scanb[Y >> 6] &= ~(1ull << (Y & 63)); }
+        for (int i = lane; i < n_listed && i < kLeanTxnCap; i += 64) txn_node[i] = -1;
+        cs::lds_order();
+
+        bool failed = false;
+        for (int part = 0; part < 2; ++part) {   // the candidate's own pods, then one run per ext pod
+            const int part_lo = part == 0 ? run_lo : e_lo, part_hi = part == 0 ? run_hi : e_hi;
+            for (int k = part_lo; k < part_hi && !failed; ++k) {
+                if (cpart != part || k < cstart || k >= cend) {
+                    cpart = part; cstart = k;
+                    const int lim = part == 0 ? a.n_runs : e_hi;
+                    cend = cstart + 64 < lim ? cstart + 64 : lim;
+                    const int kk = cstart + lane;
+                    const bool have = kk < cend;
+                    my_class = !have ? 0 : part == 0 ? a.run_class[kk] : a.pod_class[a.ext_ref[kk]];
+                    my_count = !have ? 0 : part == 0 ? a.run_count[kk] : 1;
+                    my_hint = !have ? -1 : part == 0 ? a.run_hint[kk] : -1;
+                    my_first = !have ? 0 : part == 0 ? a.run_first[kk] : a.P + kk;
+                }
+                const int j = k - cstart;
+                const int c = (int)cs::bcast_u32((uint32_t)my_class, j);
+                const int32_t cnt = (int32_t)cs::bcast_u32((uint32_t)my_count, j);
+                const int32_t hint = (int32_t)cs::bcast_u32((uint32_t)my_hint, j);
+                const int32_t first = (int32_t)cs::bcast_u32((uint32_t)my_first, j);
+                runs_done++;
+                for (int32_t i = 0; i < cnt && !failed; ++i) {
+                    const int slot = first + i;
+                    const int ti = part == 0 ? slot - p_lo : n_own + (k - e_lo);
+                    int32_t m = -1;
+                    // tryScheduleUsingHints (:86-110): RunFiltersOnNode on the hinted node, no lastIndex update
+                    if (hint >= 0 && hint < N && (((fit[(int64_t)c * S + (hint >> 6)] & accb[hint >> 6]) >> (hint & 63)) & 1ull)) m = hint;
+                    else {
+                        uint32_t u0 = (uint32_t)last_index + 1u;
+                        if (u0 >= (uint32_t)n_alive) u0 %= (uint32_t)n_alive;
+                        m = first_fit(c, node_at((int32_t)u0));
+                        if (m >= 0) last_index = rank_of(m);   // MarkMatch (plugin_runner.go:138)
+                    }
+                    if (m < 0) { failed = true; break; }      // breakOnFailure (:79-81)
+                    if (lane == 0) { a.node_out[slot] = m; if (ti < kLeanTxnCap) txn_node[ti] = m; }
+                    move_pod(c, m, +1);
+                    scheduled++;
+                }
+            }
+        }
+        // ---- every pod found a place <=> the node is removable (findPlaceFor :219-224) ----
+        const bool ok = !failed;
+        if (n_listed > kLeanTxnCap) cs::sync();   // (the tail of the placements comes back from node_out)
+        auto placed_at = [&](int i) -> int32_t { return i < kLeanTxnCap ? txn_node[i] : a.node_out[slot_of(i)]; };
+        if (ok && a.persist) {
+            // Commit (withForkedSnapshot :174-188): the ghost leaves the list (:230) and the destination set (planner.go:318)
+            for (int i = lane; i < n_listed; i += 64) {
+                const int m = placed_at(i);
+                cs::lds_or_u64(arrived + (m >> 6), 1ull << (m & 63));
+                a.log_ref[log_n + i] = pod_of(i);
+                a.log_dest[log_n + i] = m;
+            }
+            log_n += n_listed;
+            cs::lds_order();
+            if (lane == 0) alive[Y >> 6] &= ~(1ull << (Y & 63));
+            for (int w = (Y >> 6) + 1 + lane; w < S; w += 64) wpre[w] -= 1u;
+            n_alive--; any_dead = true;
+        } else {
+            // Revert: every destination gets its pod's amounts back, the candidate its place among the destinations
+            for (int i0 = 0; i0 < n_listed; i0 += 64) {
+                const int ii = i0 + lane;
+                const int32_t mi = ii < n_listed ? placed_at(ii) : -1;
+                const int32_t ci = (ii < n_listed && mi >= 0) ? a.pod_class[pod_of(ii)] : 0;
+                const int lim = n_listed - i0 < 64 ? n_listed - i0 : 64;
+                for (int u = 0; u < lim; ++u) {
+                    const int32_t m = (int32_t)cs::bcast_u32((uint32_t)mi, u);
+                    if (m < 0) continue;
+                    move_pod((int)cs::bcast_u32((uint32_t)ci, u), m, -1);
+                }
+            }
+            cs::lds_order();
+            if (lane == 0) {
+                const bool acc = a.acceptable == nullptr || a.acceptable[Y] != 0;
+                if (acc) {
+                    accb[Y >> 6] |= 1ull << (Y & 63);
+                    if (!(t.gflags[Y] & CASIM_NG_UNSCHEDULABLE)) scanb[Y >> 6] |= 1ull << (Y & 63);
+                }
+            }
+        }
+        cs::lds_order();
+        if (ok && !(a.cand_atomic && a.cand_atomic[kc])) removed++;   // len(removableList) - atomicScaleDownNodesCount
+        if (lane == 0) a.removable_out[kc] = ok ? 1 : 0;
+    }
+    if (lane == 0) {
+        a.out[0] = last_index;
+        a.out[1] = scheduled;
+        a.out[2] = runs_done;
+        a.out[3] = cand_done;
+        a.out[4] = ext_n;
+    }
+}
+
+
 // ---- host side: one TrySchedulePods call ------------------------------------------------------------
+// which kernel the calling thread's last removal simulation ran as (casim_last_removals_info): [0] 1 = removals_lean_kernel, [1] threads of the
+// block, [2] node state in LDS, [3] runs
+inline int32_t* last_removals_info() { static thread_local int32_t info[4] = {0, 0, 0, 0}; return info; }
+
 template <class BK>
 class SchedulerT {
 public:
@@ -862,6 +1170,17 @@ public:
         // removal loop does not care)
         int max_threads = cand ? kDefaultThreadsRemovals : (N_ >= 4096 ? 2 * kDefaultThreads : kDefaultThreads);
         if (const char* e = getenv("CASIM_SCHED_THREADS")) { const int v = atoi(e); if (v >= 64) max_threads = (v > 512 ? 512 : v) / 64 * 64; }   // (the kernel's launch bound)
+        // the removal loop as one wave over per-class fit masks (removals_lean_kernel): no domain rules, no node-local exclusion state, a lane
+        // per class, the node state in LDS.  CASIM_NO_LEAN_REMOVALS=1: sched_kernel as before (A/B, tests run both)
+        lean_ = false;
+        if (cand && K_ > 0 && !(q->rules && q->rules->n_rules > 0) && dt_.Wx == 0 && C_ <= 64 && R <= 4 &&
+            !(getenv("CASIM_NO_LEAN_REMOVALS") && atoi(getenv("CASIM_NO_LEAN_REMOVALS")) != 0)) {
+            bool plain = true;
+            for (size_t c = 0; c < C; ++c) if (used[c] && (p->flags[c] & CASIM_PEG_SELF_EXCL_NODE)) plain = false;
+            lean_smem_ = (size_t)casim_lean_removal_bytes(R, C_, round_up64_((int64_t)N_));
+            lean_ = plain && lean_smem_ <= bk_.lds_budget();
+        }
+        if (lean_) max_threads = 64;   // (cap_ = the node count rounded up to whole words)
         threads_ = (int)(round_up64_((int64_t)N_) < max_threads ? round_up64_((int64_t)N_) : max_threads);
         cap_ = (int32_t)(((int64_t)N_ + threads_ - 1) / threads_ * threads_);
         S_ = cap_ >> 6;
@@ -879,6 +1198,7 @@ public:
         a_.acceptable = q->node_acceptable ? up(q->node_acceptable, N) : nullptr;
         d_fbits_ = (uint64_t*)dalloc(8 * C * (size_t)S_);
         a_.fbits = d_fbits_;
+        if (lean_) d_fit0_ = (uint64_t*)dalloc(8 * C * (size_t)S_);
         if (getenv("CASIM_PACK_PROF_DUMP")) { a_.prof = (int64_t*)dalloc(96); bk_.zero(a_.prof, 96); }
         a_.node_out = (int32_t*)dalloc(4 * (P + (size_t)(cand && cand->ext_capacity > 0 ? cand->ext_capacity : 0)));
         a_.out = (int32_t*)dalloc(32);
@@ -962,6 +1282,13 @@ public:
                 bk_.launch(copy_i32_kernel, (int)((contrib_total_ + 255) / 256), 1, 256, (size_t)0, a_.rule_contrib, d_contrib_init_, contrib_total_);
         }
         if (C_ > 0) bk_.launch(sched_static_kernel, S_, C_, 64, (size_t)0, dt_, d_fbits_, S_);
+        if (K_ > 0) { int32_t* li = last_removals_info(); li[0] = lean_ ? 1 : 0; li[1] = lean_ ? 64 : threads_; li[2] = (lean_ || lds_) ? 1 : 0; li[3] = n_runs_; }
+        if (lean_) {
+            bk_.launch(lean_fit0_kernel, S_, C_, 64, (size_t)0, dt_, (const uint64_t*)d_fbits_, d_fit0_, S_);
+            if (dt_.R <= 2) bk_.launch(removals_lean_kernel<2>, 1, 1, 64, lean_smem_, dt_, a_, (const uint64_t*)d_fit0_);
+            else bk_.launch(removals_lean_kernel<4>, 1, 1, 64, lean_smem_, dt_, a_, (const uint64_t*)d_fit0_);
+            return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
+        }
         const bool tx = K_ > 0, ru = a_.n_rules > 0;
 #define CASIM_SCHED_LAUNCH(L, X, Y) do { if (dt_.R <= 2) bk_.launch(sched_kernel<L, X, Y, 2>, 1, 1, threads_, smem_, dt_, a_); \
                                          else bk_.launch(sched_kernel<L, X, Y, CASIM_KMAX_RES>, 1, 1, threads_, smem_, dt_, a_); } while (0)
@@ -1046,6 +1373,7 @@ public:
     int runs() const { return n_runs_; }
     int threads() const { return threads_; }
     bool in_lds() const { return lds_; }
+    bool lean() const { return lean_; }   // the removal loop runs as removals_lean_kernel
 
     // Workgroup size cap.  Every wave runs the run's uniform instruction stream and meets the others at each
     // collective, so more waves only pay off while a run has to look at many nodes; a piece of 256 nodes also lets
@@ -1093,9 +1421,9 @@ private:
     const DevTables* resident_ = nullptr;
     int C_ = 0, N_ = 0, P_ = 0, S_ = 0, K_ = 0, E_ = 0, threads_ = 64;
     int32_t cap_ = 0, n_runs_ = 0, last_index_ = 0;
-    bool ready_ = false, trivial_ = false, lds_ = true;
-    size_t smem_ = 0;
-    uint64_t* d_fbits_ = nullptr;
+    bool ready_ = false, trivial_ = false, lds_ = true, lean_ = false;
+    size_t smem_ = 0, lean_smem_ = 0;
+    uint64_t* d_fbits_ = nullptr; uint64_t* d_fit0_ = nullptr;
     const int32_t* d_rule_init_ = nullptr; const int32_t* d_dom_init_ = nullptr; const int32_t* d_contrib_init_ = nullptr;
     int64_t rule_total_ = 0, contrib_total_ = 0;
     size_t n_pairs_ = 0, n_ctrl_ = 0;

@@ -294,6 +294,14 @@ class Context:
             check(rc, "casim_estimate_on_cluster")
         return rc, finish_cluster_estimate(res, arrs, classes.n_pegs)
 
+    @staticmethod
+    def last_removals_info():
+        """casim_last_removals_info: which kernel this thread's last removal simulation ran as — {"lean": the one-wave kernel over per-class
+        fit masks, "threads", "state_in_lds", "runs"}"""
+        info = (C.c_int32 * 4)()
+        check(lib.casim_last_removals_info(info), "casim_last_removals_info")
+        return {"lean": bool(info[0]), "threads": int(info[1]), "state_in_lds": bool(info[2]), "runs": int(info[3])}
+
     def simulate_node_removals(self, classes: _abi.Pegs, nodes: _abi.Groups, cand_node, pod_offsets, pod_class, hint_node=None,
                                destination=None, persist: bool = True, max_removable: int = 0, last_index: int = 0,
                                pod_sticky=None, ext_capacity: Optional[int] = None, time_iters: int = 0, rules=None,

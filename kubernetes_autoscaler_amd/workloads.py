@@ -566,6 +566,67 @@ def fuzz_removals(seed: int, max_nodes: int = 30) -> RemovalWorkload:
                            max_removable=rng.pick([0, 0, 0, 1, 3]), last_index=rng.below(n_nodes + 1))
 
 
+def fuzz_removals_plain(seed: int, max_nodes: int = 40) -> RemovalWorkload:
+    """fuzz_removals without host ports / anti-affinity (the shape the one-wave removal kernel takes, csrc/casim_sched.h removals_lean_kernel):
+    resources, pod slots, node selectors, taints / tolerations, unschedulable nodes — crowded clusters so that simulations fail and are
+    reverted, up to 40 pod specs, candidates that are destinations too (pods listed again), hints (some stale), a destination subset, now
+    and then a cluster of more than 64 mask words' worth of nodes and a candidate with more pods than the kernel's LDS ring of placements."""
+    rng = SplitMix64(0x1EA2000 + seed)
+    big = rng.chance(1, 25)
+    n_nodes = (4100 + rng.below(300)) if big else (2 + rng.below(max_nodes) if not rng.chance(1, 8) else 70 + rng.below(200))
+    n_specs = 1 + rng.below(40 if rng.chance(1, 4) else 6)
+    specs = []
+    for c in range(n_specs):
+        kw = dict(labels={"app": f"a{c % 5}"}, requests={"cpu": rng.pick([0, 50, 100, 250, 500, 1000]), "memory": rng.pick([0, 64 * MiB, 256 * MiB, 1 * GiB])})
+        if rng.chance(1, 5):
+            kw["node_selector"] = {"pool": f"p{rng.below(2)}"}
+        if rng.chance(1, 5):
+            kw["tolerations"] = [Toleration(key="dedicated", operator="Exists")]
+        specs.append(kw)
+    many = (not big) and rng.chance(1, 12)   # one node with hundreds of tiny pods
+    fill = rng.pick([3, 5, 12, 30, 60])
+    nodes = []
+    for i in range(n_nodes):
+        taints = [Taint("dedicated", "x", "NoSchedule")] if rng.chance(1, 8) else []
+        node = _node(f"lr{seed}-n{i}", rng.pick([1000, 2000, 4000]), rng.pick([2, 4, 8]) * GiB, rng.pick([4, 8, 110]), {"pool": f"p{rng.below(2)}"}, taints)
+        if many and i == 1:
+            node = _node(f"lr{seed}-n{i}", 64000, 256 * GiB, 600, {"pool": "p0"})
+        if rng.chance(1, 15):
+            node.unschedulable = True
+        info = NodeInfo(node)
+        cpu = mem = 0
+        for _ in range(rng.below((3 if big else fill) + 1) if not (many and i == 1) else 300 + rng.below(100)):
+            kw = specs[rng.below(n_specs)] if not (many and i == 1) else specs[0]
+            rq = kw["requests"] if not (many and i == 1) else {"cpu": 10, "memory": 8 * MiB}
+            if cpu + rq["cpu"] > node.allocatable["cpu"] or mem + rq["memory"] > node.allocatable["memory"] or len(info.pods) >= node.allocatable["pods"]:
+                continue
+            if "node_selector" in kw and kw["node_selector"]["pool"] != node.labels["pool"]:
+                continue
+            if taints and "tolerations" not in kw:
+                continue
+            info.pods.append(Pod(name=f"r{i}-{len(info.pods)}", labels=dict(kw["labels"]), requests=dict(rq), node_selector=dict(kw.get("node_selector", {})),
+                                 tolerations=list(kw.get("tolerations", [])), controller_uid=f"rs-{specs.index(kw)}"))
+            cpu += rq["cpu"]; mem += rq["memory"]
+        if rng.chance(1, 6):
+            info.pods.append(Pod(name=f"ds{i}", namespace="kube-system", labels={"app": "ds"}, requests={"cpu": 50, "memory": 32 * MiB}, daemonset=True))
+        nodes.append(info)
+    if big:
+        order = rng.sample(list(range(n_nodes)), 20 + rng.below(60))
+    else:
+        order = rng.sample(list(range(n_nodes)), 1 + rng.below(n_nodes))
+        if many and 1 not in order:
+            order.insert(rng.below(len(order) + 1), 1)
+    destination = [0 if rng.chance(1, 8) else 1 for _ in range(n_nodes)] if rng.chance(1, 3) else None
+    hints = {}
+    if rng.chance(1, 2):
+        for c in order:
+            for p in nodes[c].pods:
+                if not p.daemonset and rng.chance(1, 4):
+                    hints[id(p)] = rng.below(n_nodes + 2)   # (now and then a node that is not there any more)
+    return RemovalWorkload(f"fuzz_removals_plain{seed}", nodes, order, destination, hints or None, persist=not rng.chance(1, 5),
+                           max_removable=rng.pick([0, 0, 0, 1, 3]), last_index=rng.below(n_nodes + 1))
+
+
 def removal_scale(n_nodes: int, pods_per_node: int = 12, frac_candidates: float = 0.3, seed: int = 1) -> RemovalWorkload:
     """An under-used cluster: every node ~35 % full with controller pods; the emptiest nodes are candidates
     (utilization order, like the planner's eligibility + sorting processors)."""

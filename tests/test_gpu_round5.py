@@ -210,3 +210,41 @@ def test_snapshot_schedule_pod_rows_on_the_device(ctx):
         got = sched_gpu(sc, ctx)
         assert_sched_matches(got, sched_oracle(sc), case["name"])
         assert int(got[1][0]) == want, case["name"]
+
+
+# ---- the removal loop as one wave over per-class fit masks (removals_lean_kernel) ---------------------------------------------------------
+def test_lean_removal_kernel_and_k_sched_agree_with_the_oracle_on_the_device(ctx, monkeypatch):
+    from harness import RemovalCase, assert_removal_matches, removal_device, removal_oracle
+    from kubernetes_autoscaler_amd.workloads import fuzz_removals, fuzz_removals_plain, removal_scale
+    lean = 0
+    cases = [fuzz_removals_plain(s) for s in range(90)] + [fuzz_removals(s) for s in range(30)] + [removal_scale(700, pods_per_node=12, frac_candidates=0.3, seed=2)]
+    for w in cases:
+        case = RemovalCase(nodes=w.nodes, candidates=w.candidates, destination=w.destination, hints=w.hints, persist=w.persist,
+                           max_removable=w.max_removable, last_index=w.last_index)
+        want = removal_oracle(case)
+        monkeypatch.delenv("CASIM_NO_LEAN_REMOVALS", raising=False)
+        assert_removal_matches(removal_device(case, ctx), want, f"{w.name} lean")
+        lean += int(kaa.Context.last_removals_info()["lean"])
+        monkeypatch.setenv("CASIM_NO_LEAN_REMOVALS", "1")
+        assert_removal_matches(removal_device(case, ctx), want, f"{w.name} K_sched")
+        assert not kaa.Context.last_removals_info()["lean"]
+    monkeypatch.delenv("CASIM_NO_LEAN_REMOVALS", raising=False)
+    assert lean >= 100, lean
+
+
+def test_lean_removal_kernel_long_transactions_and_wide_clusters_on_the_device(ctx, monkeypatch):
+    from harness import RemovalCase, assert_removal_matches, removal_device, removal_oracle
+    from kubernetes_autoscaler_amd.workloads import fuzz_removals_plain
+    monkeypatch.delenv("CASIM_NO_LEAN_REMOVALS", raising=False)
+    seen_big = seen_long = 0
+    for seed in range(400):
+        w = fuzz_removals_plain(seed)
+        big, long_ = len(w.nodes) > 4096, any(len(w.nodes[c].pods) > 256 for c in w.candidates)
+        if not (big or long_):
+            continue
+        case = RemovalCase(nodes=w.nodes, candidates=w.candidates, destination=w.destination, hints=w.hints, persist=w.persist,
+                           max_removable=w.max_removable, last_index=w.last_index)
+        assert_removal_matches(removal_device(case, ctx), removal_oracle(case), w.name)
+        assert kaa.Context.last_removals_info()["lean"]
+        seen_big += big; seen_long += long_
+    assert seen_big >= 5 and seen_long >= 10

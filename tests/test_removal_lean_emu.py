@@ -1,0 +1,128 @@
+"""The removal loop as ONE wave over per-class fit masks (csrc/casim_sched.h removals_lean_kernel, round 5) under the wave emulator:
+every case through the lean kernel AND through K_sched's general transaction loop (CASIM_NO_LEAN_REMOVALS=1), both against the oracle —
+removable flag per candidate, destination of every pod, the pods listed again (ext), lastIndex, candidates decided.
+The shapes the lean kernel takes: no domain rules, no node-local exclusion words, <= 64 classes, <= 4 lanes, state within the LDS budget;
+everything else keeps K_sched (checked here too: the info word says which kernel ran)."""
+import ctypes as C
+
+import pytest
+
+from harness import EmuContext, RemovalCase, assert_removal_matches, emu_lib, removal_device, removal_oracle
+from kubernetes_autoscaler_amd.objects import NodeInfo, Pod, build_test_pod
+from kubernetes_autoscaler_amd.workloads import GiB, MiB, _node, fuzz_removals, fuzz_removals_plain, removal_scale
+
+
+def last_kernel():
+    info = (C.c_int32 * 4)()
+    emu_lib().emu_last_removals_info(info)
+    return list(info)
+
+
+def both(case, what="", monkeypatch=None, expect_lean=True):
+    want = removal_oracle(case)
+    monkeypatch.delenv("CASIM_NO_LEAN_REMOVALS", raising=False)
+    got = removal_device(case, EmuContext(0))
+    lean = last_kernel()[0]
+    assert_removal_matches(got, want, f"{what} lean kernel")
+    monkeypatch.setenv("CASIM_NO_LEAN_REMOVALS", "1")
+    got = removal_device(case, EmuContext(0))
+    assert last_kernel()[0] == 0
+    assert_removal_matches(got, want, f"{what} K_sched")
+    monkeypatch.delenv("CASIM_NO_LEAN_REMOVALS", raising=False)
+    if expect_lean is not None and want["n_processed"] + len(want["removable"]) > 0:
+        assert lean == (1 if expect_lean else 0), f"{what}: kernel {lean}"
+    return want, lean
+
+
+def case_of(w, **kw) -> RemovalCase:
+    return RemovalCase(nodes=w.nodes, candidates=w.candidates, destination=w.destination, hints=w.hints, persist=w.persist,
+                       max_removable=w.max_removable, last_index=w.last_index, **kw)
+
+
+@pytest.mark.parametrize("seed", range(400))
+def test_fuzz_plain_clusters(seed, monkeypatch):
+    w = fuzz_removals_plain(seed)
+    both(case_of(w), w.name, monkeypatch)
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_fuzz_plain_with_sticky_atomic_and_small_ext_tables(seed, monkeypatch):
+    w = fuzz_removals_plain(5000 + seed, max_nodes=25)
+    import random
+    rnd = random.Random(seed)
+    pods = [p for c in w.candidates for p in w.nodes[c].pods if not p.daemonset]
+    sticky = {id(p) for p in pods if rnd.random() < 0.1} if seed % 3 == 0 else None
+    atomic = [1 if rnd.random() < 0.3 else 0 for _ in w.candidates] if seed % 2 == 0 else None
+    ext = rnd.choice([None, None, 0, 1, 3, 10])
+    both(case_of(w, sticky=sticky, atomic=atomic, ext_capacity=ext), w.name, monkeypatch)
+
+
+@pytest.mark.parametrize("seed", range(150))
+def test_general_fuzz_takes_the_kernel_its_shape_allows(seed, monkeypatch):
+    """fuzz_removals: a third of the seeds carry host ports / hostname anti-affinity (exclusion words): K_sched; the rest: the lean kernel"""
+    w = fuzz_removals(seed)
+    both(case_of(w), w.name, monkeypatch, expect_lean=None)
+
+
+def test_share_of_the_general_fuzz_on_the_lean_kernel(monkeypatch):
+    monkeypatch.delenv("CASIM_NO_LEAN_REMOVALS", raising=False)
+    n = 0
+    for seed in range(60):
+        removal_device(case_of(fuzz_removals(seed)), EmuContext(0))
+        n += last_kernel()[0]
+    assert 20 <= n < 60, n
+
+
+def test_three_and_four_resource_lanes(monkeypatch):
+    lanes = ("cpu", "memory", "ephemeral-storage", "example.com/gpu")
+    for seed in range(12):
+        nodes = []
+        for i in range(12):
+            node = _node(f"n{i}", 4000, 8 * GiB, 20)
+            node.allocatable["ephemeral-storage"] = node.capacity["ephemeral-storage"] = 100 * GiB
+            node.allocatable["example.com/gpu"] = node.capacity["example.com/gpu"] = (i + seed) % 3
+            info = NodeInfo(node)
+            for j in range((i * 7 + seed) % 4):
+                rq = {"cpu": 500, "memory": 1 * GiB, "ephemeral-storage": (10 + 20 * ((i + j) % 3)) * GiB}
+                if seed % 2 and node.allocatable["example.com/gpu"] > j and (i + j + seed) % 2:   # (only when the lane is there)
+                    rq["example.com/gpu"] = 1
+                info.pods.append(Pod(name=f"p{i}-{j}", labels={"app": "x"}, requests=rq, controller_uid=f"rs{j}"))
+            nodes.append(info)
+        order = [(3 * k + seed) % 12 for k in range(8)]
+        order = list(dict.fromkeys(order))
+        both(RemovalCase(nodes=nodes, candidates=order, lanes=lanes[:3 + seed % 2], last_index=seed % 13), f"lanes seed {seed}", monkeypatch)
+
+
+def test_more_than_sixty_four_classes_keep_k_sched(monkeypatch):
+    nodes = [NodeInfo(_node(f"n{i}", 64000, 256 * GiB, 200)) for i in range(6)]
+    for i in range(3):
+        for j in range(30):
+            nodes[i].pods.append(build_test_pod(f"p{i}-{j}", 10 + i * 30 + j, 1))   # 90 distinct requests
+    both(RemovalCase(nodes=nodes, candidates=[0, 1, 2]), "90 classes", monkeypatch, expect_lean=False)
+
+
+def test_a_transaction_longer_than_the_lds_ring(monkeypatch):
+    """one candidate with 300 + pods: placements beyond the ring come back from node_out; committed, then listed again by the next candidate;
+    and the same loop without persistence (every transaction reverted pod by pod)"""
+    nodes = [NodeInfo(_node(f"n{i}", 64000, 256 * GiB, 800)) for i in range(4)]
+    for j in range(310):
+        nodes[0].pods.append(build_test_pod(f"a{j}", 10 + (j % 3), 1))
+    for j in range(5):
+        nodes[1].pods.append(build_test_pod(f"b{j}", 100, 1))
+    for persist in (True, False):
+        w, _ = both(RemovalCase(nodes=nodes, candidates=[0, 1, 2], persist=persist), f"long transaction persist={persist}", monkeypatch)
+        assert list(w["removable"]) == [1, 1, 1]
+    # a failing long transaction: the last pod finds no node, 300 + placements are taken back
+    small = [NodeInfo(_node(f"n{i}", 3200, 256 * GiB, 800)) for i in range(3)]
+    for j in range(310):
+        small[0].pods.append(build_test_pod(f"a{j}", 10, 1))
+    small[0].pods.append(build_test_pod("big", 3000, 1))
+    small[1].pods.append(build_test_pod("c", 1000, 1))
+    w, _ = both(RemovalCase(nodes=small, candidates=[0, 1]), "long transaction reverted", monkeypatch)
+    assert list(w["removable"]) == [0, 1]
+
+
+def test_bench_shape_small(monkeypatch):
+    w = removal_scale(300, pods_per_node=12, frac_candidates=0.3, seed=4)
+    want, lean = both(case_of(w), w.name, monkeypatch)
+    assert lean == 1 and want["n_processed"] == len(w.candidates)

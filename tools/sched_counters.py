@@ -14,8 +14,8 @@ rec = {}
 for db_path in sorted(glob.glob(os.path.join(root, "pmc_*", "**", "*.db"), recursive=True)):
     cur = sqlite3.connect(db_path).cursor()
     try:
-        kern = cur.execute("select name, grid_x, workgroup_x, avg(duration), count(*) from kernels where name like '%sched_kernel%' group by name, grid_x").fetchall()
-        cnt = cur.execute("select kernel_name, grid_size_x, counter_name, avg(value) from counters_collection where kernel_name like '%sched_kernel%' "
+        kern = cur.execute("select name, grid_x, workgroup_x, avg(duration), count(*) from kernels where name like '%sched_kernel%' or name like '%removals_lean_kernel%' group by name, grid_x").fetchall()
+        cnt = cur.execute("select kernel_name, grid_size_x, counter_name, avg(value) from counters_collection where kernel_name like '%sched_kernel%' or kernel_name like '%removals_lean_kernel%' "
                           "group by kernel_name, grid_size_x, counter_name").fetchall()
     except sqlite3.Error as e:
         print("skip", db_path, e)
@@ -23,12 +23,12 @@ for db_path in sorted(glob.glob(os.path.join(root, "pmc_*", "**", "*.db"), recur
     for name, gx, wx, dur, n in kern:
         # template arguments <kLds, kRemoval, ...>: the second one tells the removal loop from the TrySchedulePods pass
         args = name[name.index("<") + 1:name.index(">")].replace(" ", "").split(",") if "<" in name else []
-        row = "node_removals" if len(args) > 1 and args[1] in ("true", "1") else "try_schedule_pods"
+        row = "node_removals" if ("removals_lean" in name or (len(args) > 1 and args[1] in ("true", "1"))) else "try_schedule_pods"
         r = rec.setdefault(row, {"kernel": name[:120], "workgroup_threads": int(wx), "grid_x": int(gx), "counters": {}, "kernel_ns_in_counter_passes": []})
         r["kernel_ns_in_counter_passes"].append(float(dur))
     for name, gx, counter, val in cnt:
         args = name[name.index("<") + 1:name.index(">")].replace(" ", "").split(",") if "<" in name else []
-        row = "node_removals" if len(args) > 1 and args[1] in ("true", "1") else "try_schedule_pods"
+        row = "node_removals" if ("removals_lean" in name or (len(args) > 1 and args[1] in ("true", "1"))) else "try_schedule_pods"
         if row in rec:
             rec[row]["counters"][counter] = float(val)
 for row, r in rec.items():

@@ -16,6 +16,6 @@ for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAV
   echo "pass $i exit $?"
 done
 python tools/sched_counters.py "$OUT" "$OUT/sched_counters.json"
-python tools/rocpd_summary.py "$OUT"/pmc_* 2>&1 | grep -E "sched_kernel|sched_static|^kernel," > "$OUT/sched_counters.txt"
+python tools/rocpd_summary.py "$OUT"/pmc_* 2>&1 | grep -E "sched_kernel|sched_static|removals_lean|lean_fit0|^kernel," > "$OUT/sched_counters.txt"
 find "$OUT" -name "*.csv" -size +4M -delete
 find "$OUT" -name "*.db" -size +16M -delete
