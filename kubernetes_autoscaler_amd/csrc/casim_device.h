@@ -43,6 +43,8 @@ CS_DEVICE uint64_t poll_u64(const uint64_t* p) { return *p; }
 CS_DEVICE void atomic_add_i64(int64_t* p, int64_t v) { *p += v; }
 CS_DEVICE void atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
 CS_DEVICE void lds_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
+CS_DEVICE void lds_and_u64(uint64_t* p, uint64_t v) { *p &= v; }
+CS_DEVICE void lds_sub_u32(uint32_t* p, uint32_t v) { *p -= v; }
 CS_DEVICE uint64_t ballot(bool p) { return casim_emu::wave_ballot(p); }
 CS_DEVICE uint64_t readlane_u64(uint64_t v, int l) { return casim_emu::wave_xchg_u64(v, l); }
 CS_DEVICE uint32_t shfl_u32(uint32_t v, int l) { return (uint32_t)casim_emu::wave_xchg_u64(v, l); }
@@ -127,6 +129,9 @@ CS_DEVICE void atomic_add_i64(int64_t* p, int64_t v) { (void)__hip_atomic_fetch_
 CS_DEVICE void atomic_or_u64(uint64_t* p, uint64_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // bits set by several threads of the block in one LDS word (ds_or_b64)
 CS_DEVICE void lds_or_u64(uint64_t* p, uint64_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// the same without a value coming back (ds_and_b64 / ds_sub_u32: nothing to wait for)
+CS_DEVICE void lds_and_u64(uint64_t* p, uint64_t v) { (void)__hip_atomic_fetch_and(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+CS_DEVICE void lds_sub_u32(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_sub(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 CS_DEVICE uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }  // the lane mask itself (__ballot goes through an int: two more VALU ops per call)
 CS_DEVICE uint64_t readlane_u64(uint64_t v, int l) {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);

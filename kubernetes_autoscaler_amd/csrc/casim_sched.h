@@ -757,10 +757,11 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(512, 1) void sched_kernel(DevTables t, SchedArgs a) {
 // pods, atomic groups, max_removable, hints, persist on / off — follows sched_kernel<.., kTxn = true, ..> statement by statement; results are
 // identical (tests/test_removal_lean_emu.py runs every removal case through both kernels).  Not eligible (host side, SchedulerT::init): domain
 // rules, exclusion words, more than 64 classes, more than 4 lanes, state beyond the LDS budget -> sched_kernel as before.
-constexpr int kLeanTxnCap = 256;   // placements of one transaction kept in LDS; longer ones read node_out back (after a real wait)
-CS_HOST_DEVICE int64_t casim_lean_removal_bytes(int R, int C, int64_t cap) {
+constexpr int kLeanTxnCap = 256;   // pods of one transaction (destination, pod, class) kept in LDS; longer ones fall back on HBM (after a real wait)
+// log_cap: committed moves the call can make (pods + ext capacity), rounded up to 256
+CS_HOST_DEVICE int64_t casim_lean_removal_bytes(int R, int C, int64_t cap, int64_t log_cap) {
     const int64_t S = cap >> 6;
-    return 8 * (int64_t)C * S + 4 * 8 * S + 4 * ((S + 1) & ~1ll) + 4 * kLeanTxnCap + 8 * (int64_t)R * cap + 4 * cap;
+    return 8 * (int64_t)C * S + 4 * 8 * S + 4 * ((S + 1) & ~1ll) + 3 * 4 * kLeanTxnCap + 8 * (int64_t)R * cap + 4 * cap + ((5 * log_cap + 7) & ~7ll);
 }
 
 // grid (S, C), block 64: static word AND "one pod of the class fits the node as the snapshot stands"
@@ -780,7 +781,7 @@ CS_GLOBAL void lean_fit0_kernel(DevTables t, const uint64_t* CS_RESTRICT fbits, 
 }
 
 template <int RMAX_>
-CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedArgs a, const uint64_t* CS_RESTRICT fit0) {
+CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedArgs a, const uint64_t* CS_RESTRICT fit0, int log_cap) {
     const int lane = cs::lane();
     const int R = t.R, N = a.N, cap = a.cap, S = cap >> 6, C = a.C;
     char* smem = cs::dyn_smem();
@@ -790,9 +791,15 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
     uint64_t* alive = scanb + S;                     // [S] node still in the snapshot's list
     uint64_t* arrived = alive + S;                   // [S] node took pods of a committed removal
     uint32_t* wpre = (uint32_t*)(arrived + S);       // [S] live nodes in front of the word
-    int32_t* txn_node = (int32_t*)(wpre + ((S + 1) & ~1));   // [kLeanTxnCap] destination of the i-th listed pod of the running transaction
-    int64_t* sfree = (int64_t*)(txn_node + kLeanTxnCap);     // [R][cap]
+    int32_t* txn_node = (int32_t*)(wpre + ((S + 1) & ~1));   // [kLeanTxnCap] the running transaction: destination of its i-th listed pod,
+    int32_t* txn_ref = txn_node + kLeanTxnCap;               //               the pod's flat index,
+    int32_t* txn_cls = txn_ref + kLeanTxnCap;                //               its class
+    int64_t* sfree = (int64_t*)(txn_cls + kLeanTxnCap);      // [R][cap]
     int32_t* sslots = (int32_t*)(sfree + (int64_t)R * cap);  // [cap]
+    // committed moves in commit order (what a later candidate that received pods lists again): destination, pod, class
+    uint16_t* llog_dest = (uint16_t*)(sslots + cap);          // [log_cap] (8-byte aligned: cap is a multiple of 64)
+    uint16_t* llog_ref = llog_dest + log_cap;                 // [log_cap]
+    uint8_t* llog_cls = (uint8_t*)(llog_ref + log_cap);       // [log_cap]
 
     // ---- prologue: node state = what the running pods of each node hold ----
     for (int m = lane; m < cap; m += 64) {
@@ -818,61 +825,61 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
 
     int32_t last_index = a.last_index < -1 ? -1 : a.last_index;
     int32_t scheduled = 0, runs_done = 0, n_alive = N, removed = 0, cand_done = 0, log_n = 0, ext_n = 0;
-    bool any_dead = false;
 
-    auto rank_of = [&](int m) -> int32_t {
-        if (!any_dead) return m;
-        return (int32_t)wpre[m >> 6] + cs::popc64(alive[m >> 6] & cs::low_mask(m & 63));
-    };
-    auto node_at = [&](int32_t pos) -> int32_t {
-        if (!any_dead) return pos;
-        int wsel = 0;
-        for (int base = 0; base < S; base += 64) {
-            const int w = base + lane;
-            bool mine = false;
-            if (w < S) { const int32_t lo = (int32_t)wpre[w], cntw = cs::popc64(alive[w]); mine = pos >= lo && pos < lo + cntw; }
-            const uint64_t b = cs::ballot(mine);
-            if (b != 0ull) { wsel = base + cs::ffs64(b); break; }
-        }
-        uint64_t x = alive[wsel];
-        uint32_t r = (uint32_t)(pos - (int32_t)wpre[wsel]);
-        int idx = 0;
-#pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) {
-            const uint32_t cl = (uint32_t)cs::popc64(x & ((1ull << sh) - 1ull));
-            if (r >= cl) { r -= cl; x >>= sh; idx += sh; }
-        }
-        return (int32_t)(wsel << 6) + idx;
-    };
-    // first node at or after m0 in cyclic order that passes for class c (RunFiltersUntilPassingNode, plugin_runner.go:54-143), or -1
-    auto first_fit = [&](int c, int m0) -> int32_t {
+    // First node at or behind list POSITION u0, in cyclic order, that passes for class c (RunFiltersUntilPassingNode, plugin_runner.go:54-143);
+    // its own position comes back in pos_out (MarkMatch :138), -1 = no node passes.  Positions count the nodes still in the list: lane w
+    // holds word w's live bits and how many live nodes precede it, so "position >= u0" is all of a word, none of it, or — in the one word
+    // that holds position u0 — the bits from the u0-th live node on.  One round trip to LDS per 64 words; everything else in registers.
+    auto find = [&](int c, uint32_t u0, int32_t& pos_out) -> int32_t {
         const uint64_t* row = fit + (int64_t)c * S;
-        const int w0 = m0 >> 6, b0 = m0 & 63;
-        for (int base = w0 & ~63; base < S; base += 64) {
-            const int w = base + lane;
-            uint64_t x = (w < S && w >= w0) ? (row[w] & scanb[w]) : 0ull;
-            if (w == w0) x &= ~cs::low_mask(b0);
-            const uint64_t b = cs::ballot(x != 0ull);
-            if (b != 0ull) { const int j = cs::ffs64(b); return (int32_t)((base + j) << 6) + cs::ffs64(cs::bcast_u64(x, j)); }
-        }
-        for (int base = 0; base <= w0; base += 64) {
-            const int w = base + lane;
-            uint64_t x = w <= w0 ? (row[w] & scanb[w]) : 0ull;
-            if (w == w0) x &= cs::low_mask(b0);
-            const uint64_t b = cs::ballot(x != 0ull);
-            if (b != 0ull) { const int j = cs::ffs64(b); return (int32_t)((base + j) << 6) + cs::ffs64(cs::bcast_u64(x, j)); }
+        for (int pass = 0; pass < 2; ++pass) {   // at or behind u0, then (wrapped) in front of it
+            for (int base = pass == 0 ? (int)((u0 >> 6) & ~63u) : 0; base < S; base += 64) {   // (a node's position never exceeds its index)
+                // (every lane loads — lanes past the last word re-read it and drop what they got: four loads in flight, ONE wait; as guarded
+                // loads each sat in a branch of its own behind the previous one's wait)
+                const int w = base + lane;
+                const bool in = w < S;
+                const int wc = in ? w : S - 1;
+                uint64_t al = alive[wc], x = row[wc] & scanb[wc];
+                uint32_t lo = wpre[wc];
+                if (!in) { al = 0ull; x = 0ull; lo = 0xffffffffu; }
+                const uint32_t hi = lo + (uint32_t)cs::popc64(al);
+                const bool bound = in && lo < u0 && hi > u0;   // the word that holds position u0
+                uint64_t keep = pass == 0 ? ((in && lo >= u0) ? ~0ull : 0ull) : ((in && hi <= u0) ? ~0ull : 0ull);
+                const uint64_t bb = cs::ballot(bound);
+                if (bb != 0ull) {
+                    const int jb = cs::ffs64(bb);
+                    const uint64_t xa = cs::bcast_u64(al, jb);
+                    const uint32_t r = u0 - cs::bcast_u32(lo, jb);
+                    // the live node with exactly r live nodes below it
+                    const int bit = cs::ffs64(cs::ballot(((xa >> lane) & 1ull) && (uint32_t)cs::mbcnt(xa) == r));
+                    if (lane == jb) keep = pass == 0 ? ~cs::low_mask(bit) : cs::low_mask(bit);
+                }
+                const uint64_t y = x & keep;
+                const uint64_t b = cs::ballot(y != 0ull);
+                if (b != 0ull) {
+                    const int j = cs::ffs64(b);
+                    const int bit = cs::ffs64(cs::bcast_u64(y, j));
+                    pos_out = (int32_t)cs::bcast_u32(lo, j) + cs::popc64(cs::bcast_u64(al, j) & cs::low_mask(bit));
+                    return (int32_t)((base + j) << 6) + bit;
+                }
+                if (pass == 1 && bb != 0ull) break;   // (nothing in front of u0 lies behind its word)
+            }
         }
         return -1;
     };
     // NodeInfo.AddPod of one pod of class c on node m (dir = +1) or its revert (dir = -1); every class's bit of the node follows
     auto move_pod = [&](int c, int m, int dir) {
+        // (all lanes' reads go out together, lanes past R re-read lane 0 and are never looked at: my_q is zero there.  Guarded by r < R
+        // each read sat behind the previous one's wait)
         int64_t f[RMAX_];
 #pragma unroll
-        for (int r = 0; r < RMAX_; ++r) {
-            const int64_t q = r < R ? (int64_t)cs::bcast_u64((uint64_t)my_q[r], c) : 0;
-            f[r] = r < R ? sfree[(int64_t)r * cap + m] - (dir > 0 ? q : -q) : 0;
-        }
+        for (int r = 0; r < RMAX_; ++r) f[r] = sfree[(int64_t)(r < R ? r : 0) * cap + m];
         const int32_t sl = sslots[m] - dir;
+#pragma unroll
+        for (int r = 0; r < RMAX_; ++r) {
+            const int64_t q = (int64_t)cs::bcast_u64((uint64_t)my_q[r], c);
+            f[r] -= dir > 0 ? q : -q;
+        }
         cs::lds_order();   // (everybody has read the node before its record changes)
         if (lane == 0) {
 #pragma unroll
@@ -885,17 +892,17 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
         if (lane < C) {
             uint64_t* word = fit + (int64_t)lane * S + (m >> 6);
             const uint64_t bit = 1ull << (m & 63);
-            if (dir > 0) { if (!fits) *word &= ~bit; }   // (a fuller node never starts to fit)
+            if (dir > 0) { if (!fits) cs::lds_and_u64(word, ~bit); }   // (a fuller node never starts to fit)
             else {
                 const bool stat = (a.fbits[(int64_t)lane * S + (m >> 6)] >> (m & 63)) & 1ull;
-                *word = (fits && stat) ? (*word | bit) : (*word & ~bit);
+                if (fits && stat) cs::lds_or_u64(word, bit); else cs::lds_and_u64(word, ~bit);
             }
         }
         cs::lds_order();   // (the masks are read by all lanes in the next search)
     };
 
     int32_t my_cand = 0, my_rlo = 0, my_rhi = 0, my_plo = 0, my_phi = 0;   // candidate records kc & ~63 .., one per lane
-    int cstart = 0, cend = 0, cpart = -1;                                   // run records [cstart, cend) of part cpart, one per lane
+    int cstart = 0, cend = 0;                                               // run records [cstart, cend), one per lane
     int32_t my_class = 0, my_count = 0, my_hint = -1, my_first = 0;
 
     for (int kc = 0; kc < a.n_cand; ++kc) {
@@ -909,121 +916,141 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
             my_plo = have ? a.cand_pod_off[kk] : 0; my_phi = have ? a.cand_pod_off[kk + 1] : 0;
         }
         const int Y = (int)cs::bcast_u32((uint32_t)my_cand, kc & 63);
+        const int p_lo = (int)cs::bcast_u32((uint32_t)my_plo, kc & 63), p_hi = (int)cs::bcast_u32((uint32_t)my_phi, kc & 63);
+        const int n_own = p_hi - p_lo;
+        const uint64_t ybit = 1ull << (Y & 63);
+        const bool has_arrivals = (arrived[Y >> 6] & ybit) != 0ull, is_alive = (alive[Y >> 6] & ybit) != 0ull;
         int e_lo = 0, e_hi = 0;
-        if ((arrived[Y >> 6] >> (Y & 63)) & 1ull) {
-            // pods that earlier committed removals moved onto this node are listed after its own, in commit order (see sched_kernel)
+        if (has_arrivals) {
+            // Pods that earlier committed removals moved onto this node are listed after its own, in commit order (see sched_kernel): the
+            // log, four entries per lane and step; a step without a hit costs one compare round.  Each hit goes to the ext tables and, with
+            // its class, into the transaction's ring right behind the node's own pods.
             if (a.ext_cap <= 0) break;
-            cs::sync();   // (the log entries were written by other lanes)
-            uint32_t base_n = 0;
+            uint32_t found = 0;
             bool bad = false;
-            for (int j0 = 0; j0 < log_n; j0 += 64) {
-                const int j = j0 + lane;
-                const bool hit = j < log_n && a.log_dest[j] == Y;
-                const int ref = hit ? a.log_ref[j] : 0;
-                const uint64_t b = cs::ballot(hit);
-                const uint32_t pos = (uint32_t)ext_n + base_n + (uint32_t)cs::mbcnt(b);
-                if (hit) {
+            for (int j0 = 0; j0 < log_n; j0 += 256) {
+                const int jj = j0 + lane * 4;
+                const uint64_t d4 = *(const uint64_t*)(llog_dest + jj);
+                bool h[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) h[k] = jj + k < log_n && (int)((d4 >> (16 * k)) & 0xffffull) == Y;
+                if (cs::ballot(h[0] || h[1] || h[2] || h[3]) == 0ull) continue;
+                uint32_t before = 0, total = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const uint64_t bk = cs::ballot(h[k]); before += (uint32_t)cs::mbcnt(bk); total += (uint32_t)cs::popc64(bk); }
+                uint32_t idx = found + before;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (!h[k]) continue;
+                    const int ref = (int)llog_ref[jj + k], cls = (int)llog_cls[jj + k];
+                    const uint32_t pos = (uint32_t)ext_n + idx;
                     if (pos < (uint32_t)a.ext_cap) { a.ext_ref[pos] = ref; a.ext_cand[pos] = kc; }
+                    if ((uint32_t)n_own + idx < (uint32_t)kLeanTxnCap) { txn_ref[n_own + idx] = ref; txn_cls[n_own + idx] = cls; }
                     if (a.pod_sticky && a.pod_sticky[ref]) bad = true;
+                    idx++;
                 }
-                base_n += (uint32_t)cs::popc64(b);
+                found += total;
             }
-            if (cs::ballot(bad) != 0ull || (uint32_t)ext_n + base_n > (uint32_t)a.ext_cap) break;
-            e_lo = ext_n; e_hi = ext_n + (int32_t)base_n; ext_n = e_hi;
-            cs::sync();   // (ext_ref is read back by the run records of part 1)
+            if (cs::ballot(bad) != 0ull || (uint32_t)ext_n + found > (uint32_t)a.ext_cap) break;
+            e_lo = ext_n; e_hi = ext_n + (int32_t)found; ext_n = e_hi;
         }
         cand_done = kc + 1;
-        const int run_lo = (int)cs::bcast_u32((uint32_t)my_rlo, kc & 63), run_hi = (int)cs::bcast_u32((uint32_t)my_rhi, kc & 63);
-        const int p_lo = (int)cs::bcast_u32((uint32_t)my_plo, kc & 63), p_hi = (int)cs::bcast_u32((uint32_t)my_phi, kc & 63);
-        if (!((alive[Y >> 6] >> (Y & 63)) & 1ull)) {   // NoNodeInfo (:139-147)
+        if (!is_alive) {   // NoNodeInfo (:139-147)
             if (lane == 0) a.removable_out[kc] = 0;
             continue;
         }
-        const int n_own = p_hi - p_lo, n_listed = n_own + (e_hi - e_lo);
+        const int run_lo = (int)cs::bcast_u32((uint32_t)my_rlo, kc & 63), run_hi = (int)cs::bcast_u32((uint32_t)my_rhi, kc & 63);
+        const int n_listed = n_own + (e_hi - e_lo);
+        if (n_listed > kLeanTxnCap) cs::sync();   // (the tail of this transaction goes through HBM: ext_ref, node_out)
         auto slot_of = [&](int i) -> int { return i < n_own ? p_lo + i : a.P + e_lo + (i - n_own); };
-        auto pod_of = [&](int i) -> int { return i < n_own ? p_lo + i : a.ext_ref[e_lo + (i - n_own)]; };
         // Fork; the candidate turns into a pod-less tainted ghost that keeps its list position (:243-265)
-        cs::lds_order();
-        if (lane == 0) { accb[Y >> 6] &= ~(1ull << (Y & 63)); scanb[Y >> 6] &= ~(1ull << (Y & 63)); }
-        for (int i = lane; i < n_listed && i < kLeanTxnCap; i += 64) txn_node[i] = -1;
+        if (lane == 0) { cs::lds_and_u64(accb + (Y >> 6), ~ybit); cs::lds_and_u64(scanb + (Y >> 6), ~ybit); }
         cs::lds_order();
 
         bool failed = false;
-        for (int part = 0; part < 2; ++part) {   // the candidate's own pods, then one run per ext pod
-            const int part_lo = part == 0 ? run_lo : e_lo, part_hi = part == 0 ? run_hi : e_hi;
-            for (int k = part_lo; k < part_hi && !failed; ++k) {
-                if (cpart != part || k < cstart || k >= cend) {
-                    cpart = part; cstart = k;
-                    const int lim = part == 0 ? a.n_runs : e_hi;
-                    cend = cstart + 64 < lim ? cstart + 64 : lim;
-                    const int kk = cstart + lane;
-                    const bool have = kk < cend;
-                    my_class = !have ? 0 : part == 0 ? a.run_class[kk] : a.pod_class[a.ext_ref[kk]];
-                    my_count = !have ? 0 : part == 0 ? a.run_count[kk] : 1;
-                    my_hint = !have ? -1 : part == 0 ? a.run_hint[kk] : -1;
-                    my_first = !have ? 0 : part == 0 ? a.run_first[kk] : a.P + kk;
-                }
-                const int j = k - cstart;
-                const int c = (int)cs::bcast_u32((uint32_t)my_class, j);
-                const int32_t cnt = (int32_t)cs::bcast_u32((uint32_t)my_count, j);
-                const int32_t hint = (int32_t)cs::bcast_u32((uint32_t)my_hint, j);
-                const int32_t first = (int32_t)cs::bcast_u32((uint32_t)my_first, j);
+        int n_done = 0;   // listed pods placed so far (they are tried in listing order; the first miss ends the transaction)
+        // one pod of class c (hinted or not), the n_done-th listed pod of the transaction: tryScheduleUsingHints, then trySchedule (:86-135)
+        auto schedule_pod = [&](int c, int32_t hint, int slot, int ref) {
+            int32_t m = -1;
+            if (hint >= 0 && hint < N && (((fit[(int64_t)c * S + (hint >> 6)] & accb[hint >> 6]) >> (hint & 63)) & 1ull)) m = hint;   // (no lastIndex update)
+            else {
+                uint32_t u0 = (uint32_t)last_index + 1u;
+                if (u0 >= (uint32_t)n_alive) u0 %= (uint32_t)n_alive;
+                int32_t pos = 0;
+                m = find(c, u0, pos);
+                if (m >= 0) last_index = pos;   // MarkMatch (plugin_runner.go:138)
+            }
+            if (m < 0) { failed = true; return; }      // breakOnFailure (:79-81)
+            if (lane == 0) {
+                a.node_out[slot] = m;
+                if (n_done < kLeanTxnCap) { txn_node[n_done] = m; txn_ref[n_done] = ref; txn_cls[n_done] = c; }
+            }
+            move_pod(c, m, +1);
+            scheduled++; n_done++;
+        };
+        // ---- the candidate's own pods: runs of one class ----
+        for (int k = run_lo; k < run_hi && !failed; ++k) {
+            if (k < cstart || k >= cend) {
+                cstart = k;
+                cend = cstart + 64 < a.n_runs ? cstart + 64 : a.n_runs;
+                const int kk = cstart + lane;
+                const bool have = kk < cend;
+                my_class = have ? a.run_class[kk] : 0; my_count = have ? a.run_count[kk] : 0;
+                my_hint = have ? a.run_hint[kk] : -1; my_first = have ? a.run_first[kk] : 0;
+            }
+            const int j = k - cstart;
+            const int c = (int)cs::bcast_u32((uint32_t)my_class, j);
+            const int32_t cnt = (int32_t)cs::bcast_u32((uint32_t)my_count, j);
+            const int32_t hint = (int32_t)cs::bcast_u32((uint32_t)my_hint, j);
+            const int32_t first = (int32_t)cs::bcast_u32((uint32_t)my_first, j);
+            runs_done++;
+            for (int32_t i = 0; i < cnt && !failed; ++i) schedule_pod(c, hint, first + i, first + i);
+        }
+        // ---- then the pods that arrived, in the order they were listed ----
+        for (int e0 = e_lo; e0 < e_hi && !failed; e0 += 64) {
+            const int ee = e0 + lane, ti = n_own + (ee - e_lo);
+            int32_t my_r = 0, my_c = 0;
+            if (ee < e_hi) {
+                my_r = ti < kLeanTxnCap ? txn_ref[ti] : a.ext_ref[ee];
+                my_c = ti < kLeanTxnCap ? txn_cls[ti] : a.pod_class[my_r];
+            }
+            const int lim = e_hi - e0 < 64 ? e_hi - e0 : 64;
+            for (int u = 0; u < lim && !failed; ++u) {
                 runs_done++;
-                for (int32_t i = 0; i < cnt && !failed; ++i) {
-                    const int slot = first + i;
-                    const int ti = part == 0 ? slot - p_lo : n_own + (k - e_lo);
-                    int32_t m = -1;
-                    // tryScheduleUsingHints (:86-110): RunFiltersOnNode on the hinted node, no lastIndex update
-                    if (hint >= 0 && hint < N && (((fit[(int64_t)c * S + (hint >> 6)] & accb[hint >> 6]) >> (hint & 63)) & 1ull)) m = hint;
-                    else {
-                        uint32_t u0 = (uint32_t)last_index + 1u;
-                        if (u0 >= (uint32_t)n_alive) u0 %= (uint32_t)n_alive;
-                        m = first_fit(c, node_at((int32_t)u0));
-                        if (m >= 0) last_index = rank_of(m);   // MarkMatch (plugin_runner.go:138)
-                    }
-                    if (m < 0) { failed = true; break; }      // breakOnFailure (:79-81)
-                    if (lane == 0) { a.node_out[slot] = m; if (ti < kLeanTxnCap) txn_node[ti] = m; }
-                    move_pod(c, m, +1);
-                    scheduled++;
-                }
+                schedule_pod((int)cs::bcast_u32((uint32_t)my_c, u), -1, a.P + e0 + u, (int)cs::bcast_u32((uint32_t)my_r, u));
             }
         }
         // ---- every pod found a place <=> the node is removable (findPlaceFor :219-224) ----
         const bool ok = !failed;
-        if (n_listed > kLeanTxnCap) cs::sync();   // (the tail of the placements comes back from node_out)
+        if (n_listed > kLeanTxnCap) cs::sync();
         auto placed_at = [&](int i) -> int32_t { return i < kLeanTxnCap ? txn_node[i] : a.node_out[slot_of(i)]; };
+        auto ref_at = [&](int i) -> int32_t { return i < n_own ? p_lo + i : (i < kLeanTxnCap ? txn_ref[i] : a.ext_ref[e_lo + (i - n_own)]); };
+        auto class_at = [&](int i) -> int32_t { return i < kLeanTxnCap ? txn_cls[i] : a.pod_class[ref_at(i)]; };
         if (ok && a.persist) {
             // Commit (withForkedSnapshot :174-188): the ghost leaves the list (:230) and the destination set (planner.go:318)
             for (int i = lane; i < n_listed; i += 64) {
                 const int m = placed_at(i);
                 cs::lds_or_u64(arrived + (m >> 6), 1ull << (m & 63));
-                a.log_ref[log_n + i] = pod_of(i);
-                a.log_dest[log_n + i] = m;
+                llog_dest[log_n + i] = (uint16_t)m; llog_ref[log_n + i] = (uint16_t)ref_at(i); llog_cls[log_n + i] = (uint8_t)class_at(i);
             }
             log_n += n_listed;
-            cs::lds_order();
-            if (lane == 0) alive[Y >> 6] &= ~(1ull << (Y & 63));
-            for (int w = (Y >> 6) + 1 + lane; w < S; w += 64) wpre[w] -= 1u;
-            n_alive--; any_dead = true;
+            if (lane == 0) cs::lds_and_u64(alive + (Y >> 6), ~ybit);
+            for (int w = (Y >> 6) + 1 + lane; w < S; w += 64) cs::lds_sub_u32(wpre + w, 1u);
+            n_alive--;
         } else {
             // Revert: every destination gets its pod's amounts back, the candidate its place among the destinations
-            for (int i0 = 0; i0 < n_listed; i0 += 64) {
+            for (int i0 = 0; i0 < n_done; i0 += 64) {
                 const int ii = i0 + lane;
-                const int32_t mi = ii < n_listed ? placed_at(ii) : -1;
-                const int32_t ci = (ii < n_listed && mi >= 0) ? a.pod_class[pod_of(ii)] : 0;
-                const int lim = n_listed - i0 < 64 ? n_listed - i0 : 64;
-                for (int u = 0; u < lim; ++u) {
-                    const int32_t m = (int32_t)cs::bcast_u32((uint32_t)mi, u);
-                    if (m < 0) continue;
-                    move_pod((int)cs::bcast_u32((uint32_t)ci, u), m, -1);
-                }
+                const int32_t mi = ii < n_done ? placed_at(ii) : -1;
+                const int32_t ci = ii < n_done ? class_at(ii) : 0;
+                const int lim = n_done - i0 < 64 ? n_done - i0 : 64;
+                for (int u = 0; u < lim; ++u) move_pod((int)cs::bcast_u32((uint32_t)ci, u), (int32_t)cs::bcast_u32((uint32_t)mi, u), -1);
             }
-            cs::lds_order();
             if (lane == 0) {
                 const bool acc = a.acceptable == nullptr || a.acceptable[Y] != 0;
                 if (acc) {
-                    accb[Y >> 6] |= 1ull << (Y & 63);
-                    if (!(t.gflags[Y] & CASIM_NG_UNSCHEDULABLE)) scanb[Y >> 6] |= 1ull << (Y & 63);
+                    cs::lds_or_u64(accb + (Y >> 6), ybit);
+                    if (!(t.gflags[Y] & CASIM_NG_UNSCHEDULABLE)) cs::lds_or_u64(scanb + (Y >> 6), ybit);
                 }
             }
         }
@@ -1177,8 +1204,10 @@ public:
             !(getenv("CASIM_NO_LEAN_REMOVALS") && atoi(getenv("CASIM_NO_LEAN_REMOVALS")) != 0)) {
             bool plain = true;
             for (size_t c = 0; c < C; ++c) if (used[c] && (p->flags[c] & CASIM_PEG_SELF_EXCL_NODE)) plain = false;
-            lean_smem_ = (size_t)casim_lean_removal_bytes(R, C_, round_up64_((int64_t)N_));
-            lean_ = plain && lean_smem_ <= bk_.lds_budget();
+            // (the log of committed moves sits in LDS as 16-bit node and pod indices)
+            lean_log_cap_ = (int32_t)(((int64_t)P_ + (cand->ext_capacity > 0 ? cand->ext_capacity : 0) + 255) & ~255ll);
+            lean_smem_ = (size_t)casim_lean_removal_bytes(R, C_, round_up64_((int64_t)N_), lean_log_cap_);
+            lean_ = plain && N_ <= 65536 && P_ <= 65536 && lean_smem_ <= bk_.lds_budget();
         }
         if (lean_) max_threads = 64;   // (cap_ = the node count rounded up to whole words)
         threads_ = (int)(round_up64_((int64_t)N_) < max_threads ? round_up64_((int64_t)N_) : max_threads);
@@ -1285,8 +1314,8 @@ public:
         if (K_ > 0) { int32_t* li = last_removals_info(); li[0] = lean_ ? 1 : 0; li[1] = lean_ ? 64 : threads_; li[2] = (lean_ || lds_) ? 1 : 0; li[3] = n_runs_; }
         if (lean_) {
             bk_.launch(lean_fit0_kernel, S_, C_, 64, (size_t)0, dt_, (const uint64_t*)d_fbits_, d_fit0_, S_);
-            if (dt_.R <= 2) bk_.launch(removals_lean_kernel<2>, 1, 1, 64, lean_smem_, dt_, a_, (const uint64_t*)d_fit0_);
-            else bk_.launch(removals_lean_kernel<4>, 1, 1, 64, lean_smem_, dt_, a_, (const uint64_t*)d_fit0_);
+            if (dt_.R <= 2) bk_.launch(removals_lean_kernel<2>, 1, 1, 64, lean_smem_, dt_, a_, (const uint64_t*)d_fit0_, lean_log_cap_);
+            else bk_.launch(removals_lean_kernel<4>, 1, 1, 64, lean_smem_, dt_, a_, (const uint64_t*)d_fit0_, lean_log_cap_);
             return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
         }
         const bool tx = K_ > 0, ru = a_.n_rules > 0;
@@ -1422,7 +1451,7 @@ private:
     int C_ = 0, N_ = 0, P_ = 0, S_ = 0, K_ = 0, E_ = 0, threads_ = 64;
     int32_t cap_ = 0, n_runs_ = 0, last_index_ = 0;
     bool ready_ = false, trivial_ = false, lds_ = true, lean_ = false;
-    size_t smem_ = 0, lean_smem_ = 0;
+    size_t smem_ = 0, lean_smem_ = 0; int32_t lean_log_cap_ = 0;
     uint64_t* d_fbits_ = nullptr; uint64_t* d_fit0_ = nullptr;
     const int32_t* d_rule_init_ = nullptr; const int32_t* d_dom_init_ = nullptr; const int32_t* d_contrib_init_ = nullptr;
     int64_t rule_total_ = 0, contrib_total_ = 0;
