@@ -519,7 +519,9 @@ def compact_line(out, side_file=SIDE_FILE):
     allc = out.get("cpu_baseline_all_cores")
     if isinstance(allc, dict) and "value" in allc:
         line["cpu_baseline_all_cores"] = _pick(allc, ("value", "cores", "sims_per_s"))
-    for k in ("sims_per_s", "timed_region_s", "value_wall", "ms_per_step_wall", "value_wall_every_list", "ms_per_step_wall_every_list", "headline_bit_exact"):
+    for k in ("sims_per_s", "timed_region_s", "value_wall", "ms_per_step_wall", "table_bytes_in", "value_wall_req32", "ms_per_step_wall_req32", "table_bytes_in_req32",
+              "wall_req32_bit_equal", "value_wall_shared_pegs", "ms_per_step_wall_shared_pegs",
+              "table_bytes_in_shared_pegs", "wall_shared_pegs_bit_equal", "value_wall_every_list", "ms_per_step_wall_every_list", "headline_bit_exact"):
         if k in out:
             line[k] = out[k]
     i64 = rows.get("int64") if isinstance(rows, dict) else None
@@ -836,6 +838,23 @@ def main():
                 r["what"] = "enter_return_every_list with the caller's tables and its order / placed arrays in page-locked host memory (casim_host_alloc)"
                 return r
             rows["enter_return_every_list_pinned"] = _try(_pinned_all_row)
+            # PEG tables shipped once per DISTINCT simulation, a node-group table per simulation (TableSet.tile_groups: what a sweep of limiter /
+            # template variants over the same pending pods hands over) — the same 4096 simulations, the same answers
+            # the requests as 32-bit multiples of a per-lane unit (casim_pegs.req32 / req_unit, ABI 10: milli-cpu, MiB — what a Go shim holds anyway)
+            def _req32_row():
+                r = enter_return_row(kaa, ctx, batch.tables, kinds, K, checks_per_step, max(3, min(args.steps, 10)), res_all, final, narrow=True)
+                r["what"] = ("enter_return with the requests handed over as casim_pegs.req32 + req_unit (req = NULL): 8 bytes per PEG less on the link, no gcd "
+                             "pass (a device round trip in the middle of every part's upload), the int64 table rebuilt on the device")
+                return r
+            rows["enter_return_req32"] = _try(_req32_row)
+            def _shared_row():
+                shared = seed_set.tile_groups((total_sims + S - 1) // S).head(total_sims)
+                r = enter_return_row(kaa, ctx, shared, kinds, K, checks_per_step, max(3, min(args.steps, 10)), res_all, final, order_mod=seed_set.n_pegs, narrow=True)
+                r["what"] = (f"enter_return_req32 with the PEG tables of the {S} distinct simulations shipped ONCE and a node-group table per simulation (casim_groups.peg_lo / "
+                             "peg_hi of the tiles point into the same PEG rows): what a sweep of limiter / template variants over the same pending pods hands over")
+                r["peg_rows_shipped"] = shared.n_pegs
+                return r
+            rows["enter_return_shared_pegs"] = _try(_shared_row)
             rows["int64"] = _try(lambda: int64_row(kaa, dev_index, batch.tables, kinds, K, checks_per_step, max(5, min(args.steps, 50)), res_all, final, torch, packer=2))
             rows["int64_lds_store"] = _try(lambda: int64_row(kaa, dev_index, batch.tables, kinds, K, checks_per_step, max(5, min(args.steps, 50)), res_all, final, torch, packer=1))
         extra["headline_rows"] = rows
@@ -846,6 +865,17 @@ def main():
         extra["ms_per_step_wall"] = er.get("ms_per_step")
         extra["sims_per_s_wall"] = er.get("sims_per_s")
         # (the winners-only regime is not what a shim's prefetch fill needs — the every-list form next to it, top level)
+        extra["table_bytes_in"] = er.get("table_bytes_in")
+        rq = rows.get("enter_return_req32") or {}
+        extra["value_wall_req32"] = rq.get("checks_per_s")
+        extra["ms_per_step_wall_req32"] = rq.get("ms_per_step")
+        extra["table_bytes_in_req32"] = rq.get("table_bytes_in")
+        extra["wall_req32_bit_equal"] = rq.get("bit_equal_to_resident")
+        sh = rows.get("enter_return_shared_pegs") or {}
+        extra["value_wall_shared_pegs"] = sh.get("checks_per_s")
+        extra["ms_per_step_wall_shared_pegs"] = sh.get("ms_per_step")
+        extra["table_bytes_in_shared_pegs"] = sh.get("table_bytes_in")
+        extra["wall_shared_pegs_bit_equal"] = sh.get("bit_equal_to_resident")
         el = rows.get("enter_return_every_list") or {}
         extra["value_wall_every_list"] = el.get("checks_per_s")
         extra["ms_per_step_wall_every_list"] = el.get("ms_per_step")
@@ -1063,9 +1093,10 @@ def _same_results(a, b):
     return bool(ok and np.array_equal(ea["best"], eb["best"]) and np.array_equal(ea["packed"], eb["packed"]))
 
 
-def _same_winners(a, b):
+def _same_winners(a, b, order_mod=None):
     """a = (BatchResult, exp) of a winners_only call, b = the full answer: scalars, offsets, expander answer equal, and the compact lists are
-    the winners' slices of the full lists"""
+    the winners' slices of the full lists.  order_mod: a's PEG ids are those of a shared PEG table of that many rows (TableSet.tile_groups), b's
+    the tiled batch's (the same rows, shifted by a multiple of it per tile)"""
     import numpy as np
     ra, ea = a; rb, eb = b
     ok = all(np.array_equal(getattr(ra, f), getattr(rb, f)) for f in ("offsets", "node_count", "pods_scheduled", "nodes_added", "limiter_nodes",
@@ -1080,17 +1111,35 @@ def _same_winners(a, b):
     starts = rb.offsets[best[has]].astype(np.int64); lens = (rb.offsets[best[has] + 1] - rb.offsets[best[has]]).astype(np.int64)
     idx = np.repeat(starts - np.concatenate([[0], np.cumsum(lens)[:-1]]), lens) + np.arange(int(lens.sum()))
     n = int(w[-1])
-    return bool(n == int(lens.sum()) and np.array_equal(ra.order[:n], rb.order[idx]) and np.array_equal(ra.placed[:n], rb.placed[idx]))
+    want_order = rb.order[idx] if order_mod is None else rb.order[idx] % order_mod
+    return bool(n == int(lens.sum()) and np.array_equal(ra.order[:n], want_order) and np.array_equal(ra.placed[:n], rb.placed[idx]))
 
 
-def enter_return_row(kaa, ctx, tables, kinds, K, checks_per_step, steps, res_resident, exp_resident, winners_only=True, pinned_results=False):
+def link_table_bytes(tables, narrow=False, fastpath=False):
+    """bytes of the caller's columns that cross the link in one call: every column the library ships (the fastpath chooser's four only with the
+    fastpath; with casim_pegs.req32 the 4-byte requests + the units instead of the int64 table)"""
+    n = 0
+    for k, v in tables.pegs.items():
+        if v is None or (k in ("fp_cpu", "fp_mem") and not fastpath):
+            continue
+        n += v.nbytes // 2 + 8 * v.shape[1] if (k == "req" and narrow) else v.nbytes
+    for k, v in tables.groups.items():
+        if v is None or (k in ("cap_cpu", "cap_mem") and not fastpath):
+            continue
+        n += v.nbytes
+    for a in (tables.peg_lo, tables.peg_hi, tables.global_id, tables.sim_offsets):
+        n += 0 if a is None else a.nbytes
+    return int(n)
+
+
+def enter_return_row(kaa, ctx, tables, kinds, K, checks_per_step, steps, res_resident, exp_resident, winners_only=True, pinned_results=False, order_mod=None, narrow=False):
     """SURVEY 8d's wall time: casim_estimate_batch_query enter -> return — fresh tables packed into pinned memory and copied to
     HBM, kernels, expander reduce, results copied back, EVERY step; the parts of the batch run end to end on the context's internal
     streams (upload of one part under the kernels of another).  winners_only: the per-group scalars and offsets of every
     group, PEG order / pods placed of the winning group of every simulation only (compacted on the device); False = every list, what
     a shim that serves all Estimate() calls from the batch fetches."""
     from kubernetes_autoscaler_amd.engine import BatchCall
-    pegs, groups = tables.structs()
+    pegs, groups = tables.structs(narrow_requests=narrow)
     if winners_only:
         call = BatchCall(ctx, pegs, groups, kinds=kinds, n_streams=K, winners_only=True)
         for _ in range(8):                # first calls: lanes' pools and pinned buffers grow to this call's sizes (a 15 ms call still showed up
@@ -1109,13 +1158,13 @@ def enter_return_row(kaa, ctx, tables, kinds, K, checks_per_step, steps, res_res
             gc.enable()
         dt = sum(seq) / steps
         res, exp = call.call()
-        bytes_in = sum(v.nbytes for v in tables.pegs.values() if v is not None) + sum(v.nbytes for v in tables.groups.values() if v is not None)
+        bytes_in = link_table_bytes(tables, narrow)
         return {"what": "casim_estimate_batch_query enter -> return every step, casim_options.winners_only: H2D of fresh tables from pinned staging + kernels + "
                         "expander + winners' lists compacted on the device + D2H of every group's scalars / offsets and the winners' order / placed", "dtype": "int32",
                 "ms_per_step": dt * 1e3, "checks_per_s": checks_per_step / dt, "sims_per_s": tables.n_sims / dt, "steps": steps,
                 "ms_per_call_sequence": [round(x * 1e3, 3) for x in seq], "ms_per_step_median": sorted(seq)[len(seq) // 2] * 1e3,
                 "table_bytes_in": bytes_in, "result_bytes_out": 8 * int(res.winner_offsets[-1]) + 52 * tables.n_groups + 16 * tables.n_sims,
-                "pcie_inclusive": True, "bit_equal_to_resident": _same_winners((res, exp), (res_resident, exp_resident))}
+                "pcie_inclusive": True, "bit_equal_to_resident": _same_winners((res, exp), (res_resident, exp_resident), order_mod)}
     import gc
     call = BatchCall(ctx, pegs, groups, kinds=kinds, n_streams=K, pinned_results=pinned_results)
     call.call_raw()                       # first call: lanes, pools, pinned buffers
@@ -1134,7 +1183,7 @@ def enter_return_row(kaa, ctx, tables, kinds, K, checks_per_step, steps, res_res
     finally:
         gc.enable()
     res, exp = call.call()
-    bytes_in = sum(v.nbytes for v in tables.pegs.values() if v is not None) + sum(v.nbytes for v in tables.groups.values() if v is not None)
+    bytes_in = link_table_bytes(tables, narrow)
     nnz = int(res.offsets[-1])
     return {"what": "casim_estimate_batch_query enter -> return every step: H2D of fresh tables from pinned staging + kernels + expander + D2H of "
                     "scalars / order / placed, parts overlapped on the internal streams", "dtype": "int32",

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CASIM_ABI_VERSION 9   /* 2: casim_removal_candidates.cand_atomic, casim_domain_rules.n_taint_policy_rules
+#define CASIM_ABI_VERSION 10  /* 2: casim_removal_candidates.cand_atomic, casim_domain_rules.n_taint_policy_rules
                                * 3: casim_groups.{peg_lo,peg_hi,global_id,n_sims,sim_offsets}, casim_best_option_sims,
                                *    casim_feasibility_reasons, casim_estimate_batch_timed, casim_mctx_*, casim_cluster_*
                                * 4: casim_options.n_streams (sub-batches on internal HIP streams), casim_enc_group_pods,
@@ -43,7 +43,10 @@ extern "C" {
                                *    later, without a new number (layouts unchanged, zero keeps its meaning): casim_options.no_front_kernel in one of
                                *    the two reserved words, casim_problem_info [7]
                                * 7: casim_cluster_forget_commits, casim_options.winners_only (the last reserved word)
-                               * 8: casim_pegs.excl_polarity (node bits of NEED polarity: hostname-level required pod affinity inside casim_estimate_batch) */
+                               * 8: casim_pegs.excl_polarity (node bits of NEED polarity: hostname-level required pod affinity inside casim_estimate_batch)
+                               * 9: casim_enc_lane / _pod_set_request / _group_set_allocatable / _lane_count / _lane_name (resources by name),
+                               *    casim_options.chain_last_index (+ 3 reserved words), casim_problem_time_feasibility
+                               * 10: casim_pegs.req32 / req_unit (requests narrowed by the caller), casim_last_removals_info */
 
 /* Resource lanes.  Lane 0 = cpu in millicores (Quantity.MilliValue), lane 1 = memory bytes,
  * lane 2 = ephemeral-storage bytes, lanes 3.. = scalar / extended resources (Quantity.Value),
@@ -122,6 +125,13 @@ typedef struct casim_pegs {
                                  such a bit is a self-affine SERIES: while no simulated node of the group carries the bit (and the template's
                                  own pods do not), its first pod passes without it (the first-pod exception, filtering.go:396-407) and the
                                  rest of the PEG then has to join that pod's node. */
+    const int32_t* req32;     /* ABI 10.  [G][R] or NULL: the requests as 32-bit multiples of a per-lane unit the CALLER knows — request of PEG g in
+                                 lane r = req32[g * R + r] * req_unit[r] (milli-cpu, MiB-granular memory: what a Go shim holds anyway).  When set, `req`
+                                 may be NULL: half the request bytes cross the link and the library's own gcd pass over the table (a device round trip in
+                                 the middle of a big call's upload) is not needed.  Exact: the int64 table the kernels read is rebuilt on the device
+                                 as req32 * req_unit.  Honoured by the Estimate batch path (casim_estimate_batch / _query / _multi,
+                                 casim_problem_create); K_sched's and the resident cluster's entry points need `req` (CASIM_ERR_INVALID without). */
+    const int64_t* req_unit;  /* [R], every entry > 0; read only with req32 */
 } casim_pegs;
 
 /*

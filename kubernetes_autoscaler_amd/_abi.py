@@ -3,7 +3,7 @@ shared library happens in _ffi.py).  Kept separate so that test harnesses that c
 structs can reuse the layouts without loading the product library."""
 import ctypes as C
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_RES = 8
 
 OK = 0
@@ -51,6 +51,7 @@ class Pegs(C.Structure):
         ("tol_mask", u64p), ("sel_mask", u64p), ("excl_block", u64p), ("excl_mark", u64p),
         ("zone_block", u64p), ("zone_mark", u64p), ("fp_cpu", f64p), ("fp_mem", f64p),
         ("zone_polarity", u64p), ("excl_polarity", u64p),
+        ("req32", i32p), ("req_unit", i64p),   # ABI 10: requests narrowed by the caller (req may then be NULL)
     ]
 
 

@@ -1322,6 +1322,20 @@ CS_GLOBAL void scale_requests_kernel(const int64_t* CS_RESTRICT req, int64_t n /
     }
 }
 
+// casim_pegs.req32 / req_unit (ABI 10): the caller shipped 32-bit multiples of a per-lane unit.  The int64 table every kernel reads is rebuilt here
+// (exact: a product), and — only when the node-group columns force a finer scale than the caller's unit — the packer's int32 table as
+// req32 * (unit / scale), which the host checked to fit
+struct UnitParams { int64_t unit[CASIM_KMAX_RES]; int32_t factor[CASIM_KMAX_RES]; };
+CS_GLOBAL void expand_requests_kernel(const int32_t* CS_RESTRICT req32, int64_t n /* G * R */, int R, UnitParams up, int64_t* CS_RESTRICT out64, int32_t* CS_RESTRICT out32 /* or null */) {
+    const int64_t stride = (int64_t)cs::nblocks() * cs::nthreads();
+    for (int64_t i = (int64_t)cs::bid() * cs::nthreads() + cs::tid(); i < n; i += stride) {
+        const int r = (int)(i % R);
+        const int32_t v = req32[i];
+        out64[i] = (int64_t)v * up.unit[r];
+        if (out32) out32[i] = v * up.factor[r];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // K_winners: the lists of the winning groups only (casim_options.winners_only)
 // ------------------------------------------------------------------------------------------

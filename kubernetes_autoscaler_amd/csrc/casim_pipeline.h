@@ -161,7 +161,7 @@ struct SingletonRuns {
         rows(req, P->req, R); rows(count, P->count, 1); rows(flags, P->flags, 1); rows(tol, P->tol_mask, Wt); rows(sel, P->sel_mask, Wl);
         rows(xb, P->excl_block, Wx); rows(xm, P->excl_mark, Wx); rows(zb, P->zone_block, Wz); rows(zm, P->zone_mark, Wz); rows(fpc, P->fp_cpu, 1); rows(fpm, P->fp_mem, 1);
         for (int m = 0; m < Gm; ++m) if (len[(size_t)m] > 1) { count[(size_t)m] = len[(size_t)m]; flags[(size_t)m] |= CASIM_KFLAG_SINGLETON_RUN; }
-        p = *P; p.n_pegs = Gm;
+        p = *P; p.n_pegs = Gm; p.req32 = nullptr; p.req_unit = nullptr;   // (the merged rows carry the int64 requests)
         p.req = req.data(); p.count = count.data(); p.flags = flags.data();
         p.tol_mask = tol.empty() ? nullptr : tol.data(); p.sel_mask = sel.empty() ? nullptr : sel.data();
         p.excl_block = xb.empty() ? nullptr : xb.data(); p.excl_mark = xm.empty() ? nullptr : xm.data();
@@ -241,7 +241,10 @@ public:
         winners_only_ = o && o->winners_only != 0; winners_ready_ = false;
         const int R = dt_.R;
         const size_t G = (size_t)G_, NG = (size_t)NG_;
-        if (G > 0 && (!p->req || !p->count || !p->flags)) return fail(CASIM_ERR_INVALID, "PEG table has null columns");
+        // casim_pegs.req32 + req_unit (ABI 10): the requests came narrowed by the caller; the int64 table is rebuilt on the device
+        const bool narrow_in = G > 0 && p->req32 != nullptr && p->req_unit != nullptr;
+        if (G > 0 && ((!p->req && !narrow_in) || !p->count || !p->flags)) return fail(CASIM_ERR_INVALID, "PEG table has null columns");
+        if (narrow_in) for (int r = 0; r < R; ++r) if (p->req_unit[r] <= 0) return fail(CASIM_ERR_INVALID, "req_unit must be positive");
         if (NG > 0 && (!g->alloc || !g->init_req || !g->allowed_pods || !g->init_pods || !g->flags || !g->max_nodes ||
                        !g->existing_nodes || !g->last_index))
             return fail(CASIM_ERR_INVALID, "group table has null columns");
@@ -267,7 +270,14 @@ public:
             begin_uploads(bound);
         }
         stage.mark("table columns -> staging");
-        dt_.req = up(p->req, G * R); dt_.count = up(p->count, G); dt_.pflags = up(p->flags, G);
+        const int32_t* d_req32_in = nullptr; int64_t* d_req64 = nullptr; int32_t* d_req32_scaled = nullptr;
+        if (narrow_in) {
+            d_req32_in = up(p->req32, G * R);
+            d_req64 = (int64_t*)dalloc(8 * G * (size_t)R);
+            if (!d_req32_in || !d_req64) return fail(CASIM_ERR_NOMEM, "no room for the request table");
+            dt_.req = d_req64;
+        } else dt_.req = up(p->req, G * R);
+        dt_.count = up(p->count, G); dt_.pflags = up(p->flags, G);
         dt_.tol = up(p->tol_mask, G * dt_.Wt); dt_.sel = up(p->sel_mask, G * dt_.Wl);
         dt_.xblock = up(p->excl_block, G * dt_.Wx); dt_.xmark = up(p->excl_mark, G * dt_.Wx);
         dt_.zblock = up(p->zone_block, G * dt_.Wz); dt_.zmark = up(p->zone_mark, G * dt_.Wz);
@@ -459,6 +469,7 @@ public:
             for (size_t i = 0; i < G; ++i) zone_self = zone_self || (p->flags[i] & CASIM_PEG_SELF_EXCL_ZONE) != 0;
             fast_wx_ = (dt_.Wx > 0 || dt_.Wz > 0 || zone_self) ? 2 : 0;   // lean instantiation, or the one with room for both kinds of words
             std::vector<int64_t> scale((size_t)R, 0);
+            std::vector<char> lane_has_request((size_t)R, 0);   // (narrow_in: a lane without a single request has no unit to honour)
             auto gcd64 = [](int64_t a, int64_t b) { if (a < 0) a = -a; if (b < 0) b = -b; while (b) { const int64_t x = a % b; a = b; b = x; } return a; };
             // (a million-PEG batch walks these loops in every enter -> return call: 5.3 of 11.8 ms as three passes of 64-bit divisions,
             // profiles/r05p_init_stages.txt.  One modulo per value while the gcd settles — it is almost always final after a few rows —
@@ -477,7 +488,7 @@ public:
             // reserved for later writes — and whose lanes fit the kernel's four; CASIM_DEV_GCD_MIN: tests run it on small tables)
             const char* dgm = getenv("CASIM_DEV_GCD_MIN");
             const long dev_gcd_min = dgm ? atol(dgm) : (long)kDevGcdMin;
-            const bool dev_gcd = ok && !want_i64 && R <= 4 && (long)(G * (size_t)R) >= dev_gcd_min && dt_.req != nullptr && !up_reserved_;
+            const bool dev_gcd = ok && !narrow_in && !want_i64 && R <= 4 && (long)(G * (size_t)R) >= dev_gcd_min && dt_.req != nullptr && !up_reserved_;
             if (ok) {
                 // one pass over the columns, cut over the host threads: per lane the gcd, the largest magnitude (of a request, an
                 // allocatable, a preloaded amount, a fresh node's free amount) and "some request is negative"
@@ -485,7 +496,36 @@ public:
                 Part parts[kHostLoopThreads];
                 for (auto& pt : parts) { for (int r = 0; r < CASIM_MAX_RES; ++r) pt.sc[r] = pt.amax[r] = 0; pt.neg = false; }
                 auto mag = [](int64_t v) -> int64_t { return v < 0 ? (v == INT64_MIN ? INT64_MAX : -v) : v; };
-                if (!dev_gcd) par_for(G, 65536, [&](size_t lo, size_t hi, int t) {
+                // (requests narrowed by the caller: the unit is a common divisor by definition — one pass of compares for sign and magnitude)
+                if (narrow_in) par_for(G, 262144, [&](size_t lo, size_t hi, int t) {   // (a part of 1024 C2 simulations: one thread, no spawn)
+                    // (smallest and largest value per lane: compares only — a division per value made this pass three times the device
+                    // gcd pass it replaces, profiles/r11h)
+                    int32_t vmin[CASIM_MAX_RES], vmax[CASIM_MAX_RES];
+                    for (int r = 0; r < R; ++r) { vmin[r] = 0; vmax[r] = 0; }
+                    if (R == 2) {
+                        int32_t a0 = 0, b0 = 0, a1 = 0, b1 = 0;
+                        const int32_t* q = p->req32 + lo * 2;
+                        for (size_t i = 0, n = hi - lo; i < n; ++i) {
+                            const int32_t x = q[2 * i], y = q[2 * i + 1];
+                            a0 = x < a0 ? x : a0; b0 = x > b0 ? x : b0; a1 = y < a1 ? y : a1; b1 = y > b1 ? y : b1;
+                        }
+                        vmin[0] = a0; vmax[0] = b0; vmin[1] = a1; vmax[1] = b1;
+                    } else {
+                        for (size_t i = lo; i < hi; ++i) for (int r = 0; r < R; ++r) {
+                            const int32_t v = p->req32[i * R + r];
+                            vmin[r] = v < vmin[r] ? v : vmin[r]; vmax[r] = v > vmax[r] ? v : vmax[r];
+                        }
+                    }
+                    Part& pt = parts[t];
+                    for (int r = 0; r < R; ++r) {
+                        if (vmin[r] == 0 && vmax[r] == 0) continue;
+                        const int64_t u = p->req_unit[r], a = -(int64_t)vmin[r] > (int64_t)vmax[r] ? -(int64_t)vmin[r] : (int64_t)vmax[r];
+                        pt.sc[r] = u; pt.neg = pt.neg || vmin[r] < 0;
+                        const int64_t m = a > INT64_MAX / u ? INT64_MAX : a * u;
+                        if (m > pt.amax[r]) pt.amax[r] = m;
+                    }
+                });
+                else if (!dev_gcd) par_for(G, 65536, [&](size_t lo, size_t hi, int t) {
                     Part& pt = parts[t];
                     for (size_t i = lo; i < hi; ++i) for (int r = 0; r < R; ++r) {
                         const int64_t v = p->req[i * R + r];
@@ -528,7 +568,7 @@ public:
                 std::vector<int64_t> amax((size_t)R, 0);
                 for (int r = 0; r < R; ++r) {
                     int64_t sc = grp.sc[r], am = grp.amax[r];
-                    for (auto& pt : parts) { if (pt.sc[r] != 0) sc = sc == 0 ? pt.sc[r] : gcd64(sc, pt.sc[r]); if (pt.amax[r] > am) am = pt.amax[r]; }
+                    for (auto& pt : parts) { if (pt.sc[r] != 0) { sc = sc == 0 ? pt.sc[r] : gcd64(sc, pt.sc[r]); lane_has_request[(size_t)r] = 1; } if (pt.amax[r] > am) am = pt.amax[r]; }
                     scale[(size_t)r] = sc == 0 ? 1 : sc; amax[(size_t)r] = am;
                 }
                 neg = grp.neg;
@@ -565,6 +605,21 @@ public:
                 // (the big table is written straight into the staging buffer)
                 std::vector<int32_t> req32_own, fresh32(NG * (size_t)R);
                 const int32_t* req32_dev = nullptr;
+                if (narrow_in) {
+                    // the caller's table IS the packer's when no node-group amount forces a finer scale than its unit (a lane without a single
+                    // request keeps whatever is there: zeros); else req32 * (unit / scale), by the kernel that rebuilds the int64 table
+                    bool same = true;
+                    for (int r = 0; r < R; ++r) {
+                        narrow_factor_[r] = lane_has_request[(size_t)r] ? (int32_t)(p->req_unit[r] / scale[(size_t)r]) : 1;
+                        same = same && narrow_factor_[r] == 1;
+                    }
+                    if (same) req32_dev = d_req32_in;
+                    else {
+                        d_req32_scaled = (int32_t*)dalloc(4 * G * (size_t)R);
+                        if (!d_req32_scaled) return fail(CASIM_ERR_NOMEM, "no room for the int32 request table");
+                        req32_dev = d_req32_scaled;
+                    }
+                } else
                 if (dev_gcd) {   // the quotients on the device, from the int64 table that is there already: 8 bytes per PEG less over the link
                     int32_t* d32 = (int32_t*)dalloc(4 * G * (size_t)R);
                     if (!d32) return fail(CASIM_ERR_NOMEM, "no room for the int32 request table");
@@ -660,6 +715,13 @@ public:
         opt_cap_ = 1;
         stage.mark("H2D copy + sync");
         end_uploads();
+        if (narrow_in) {   // behind the uploads on the same stream, in front of every kernel that reads a request
+            UnitParams upar; memset(&upar, 0, sizeof upar);
+            for (int r = 0; r < R && r < CASIM_KMAX_RES; ++r) { upar.unit[r] = p->req_unit[r]; upar.factor[r] = d_req32_scaled ? narrow_factor_[r] : 1; }
+            const int64_t nv = (int64_t)(G * (size_t)R);
+            const int nb = (int)(nv / 1024 < 1 ? 1 : (nv / 1024 > 2048 ? 2048 : nv / 1024));
+            bk_.launch(expand_requests_kernel, nb, 1, 256, (size_t)0, d_req32_in, nv, R, upar, d_req64, d_req32_scaled);
+        }
         // the streaming feasibility kernel's group records (feas_group_records_kernel): once per problem, behind the uploads on the same stream
         d_feas_rec_ = nullptr;
         {
@@ -1288,6 +1350,7 @@ private:
     int32_t nnz_cap_ = 0;
     bool csr_on_device_ = false, pack_lds_ = true, order_lds_ = true, ready_ = false, ran_ = false;
     int fast_wx_ = 0;
+    int32_t narrow_factor_[CASIM_KMAX_RES] = {1, 1, 1, 1, 1, 1, 1, 1};   // casim_pegs.req_unit / the packer's scale, per lane
     bool fast_i64_ = false;   // the register store on int64 lanes (lanes that do not narrow to 32 bits, R <= 2)
     bool fast_retry_ = false;
     SingletonRuns runs_;

@@ -255,7 +255,7 @@ private:
         const int R = p->n_res;
         casim_pegs& v = pt.pv; v = *p;
         v.n_pegs = hi - lo;
-        v.req = off(p->req, (int64_t)lo * R); v.count = off(p->count, lo); v.flags = off(p->flags, lo);
+        v.req = off(p->req, (int64_t)lo * R); v.req32 = off(p->req32, (int64_t)lo * R); v.count = off(p->count, lo); v.flags = off(p->flags, lo);
         v.tol_mask = off(p->tol_mask, (int64_t)lo * p->w_taint); v.sel_mask = off(p->sel_mask, (int64_t)lo * p->w_label);
         v.excl_block = off(p->excl_block, (int64_t)lo * p->w_excl); v.excl_mark = off(p->excl_mark, (int64_t)lo * p->w_excl);
         v.zone_block = off(p->zone_block, (int64_t)lo * p->w_zone); v.zone_mark = off(p->zone_mark, (int64_t)lo * p->w_zone);

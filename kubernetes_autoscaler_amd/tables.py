@@ -166,6 +166,20 @@ class TableSet:
         """The batch repeated `times` times (distinct memory, same simulations)."""
         return TableSet.concat([self] * times) if times > 1 else self
 
+    def tile_groups(self, times: int) -> "TableSet":
+        """`times` copies of every simulation's node-group table over ONE copy of the PEG tables: the simulations of copy k see the same PEG rows
+        as those of copy 0 (casim_groups.peg_lo / peg_hi point into the shared rows).  What a caller that sweeps limiter / template variants
+        over the same pending pods hands over: the pods travel once.  PEG ids in the results are the shared table's."""
+        if times <= 1:
+            return self
+        one = self if self.peg_lo is not None else self.as_one_simulation()
+        gc = {k: (None if v is None else np.concatenate([v] * times, axis=0)) for k, v in one.groups.items()}
+        ng = one.n_groups
+        so = np.concatenate([[0]] + [one.sim_offsets[1:] + k * ng for k in range(times)]).astype(np.int32)
+        gid = one.global_id if one.global_id is not None else np.arange(ng, dtype=np.int32)
+        return TableSet(one.dims, one.pegs, gc, np.concatenate([one.peg_lo] * times).astype(np.int32), np.concatenate([one.peg_hi] * times).astype(np.int32),
+                        None, None, np.concatenate([gid] * times).astype(np.int32), so, zone_polarity=one.zone_polarity, excl_polarity=one.excl_polarity)
+
     def pinned(self) -> "TableSet":
         """The same tables with every column in page-locked host memory (engine.pinned_copy): enter -> return calls then upload them
         without the library's staging copy."""
@@ -226,8 +240,26 @@ class TableSet:
         return one.select_groups(np.array(keep, np.int64))
 
     # ---- ctypes ---------------------------------------------------------------------------------
-    def structs(self):
-        """(casim_pegs, casim_groups) over this set's arrays; the set must outlive every use of the structs."""
+    def narrowed_requests(self):
+        """(req32 [G][R] int32, req_unit [R] int64): the request table as 32-bit multiples of a per-lane unit (the lane's gcd) — what a caller
+        that knows its units (milli-cpu, MiB) holds in the first place (casim_pegs.req32 / req_unit, ABI 10).  ValueError when a lane does not fit."""
+        req = self.pegs["req"]
+        R = self.dims["n_res"]
+        unit = np.ones(R, np.int64)
+        out = np.zeros(req.shape, np.int32)
+        for r in range(R):
+            col = req[:, r]
+            g = int(np.gcd.reduce(np.abs(col))) if col.size else 0
+            unit[r] = g if g > 0 else 1
+            q = col // unit[r]
+            if q.size and (q.max() > 0x7fffffff or q.min() < -0x7fffffff):
+                raise ValueError(f"lane {r} does not narrow to 32 bits")
+            out[:, r] = q
+        return out, unit
+
+    def structs(self, narrow_requests: bool = False):
+        """(casim_pegs, casim_groups) over this set's arrays; the set must outlive every use of the structs.
+        narrow_requests: hand the requests over as casim_pegs.req32 + req_unit (req = NULL): half the request bytes for the link."""
         keep = []
 
         def ptr(a, dt):
@@ -239,6 +271,10 @@ class TableSet:
         p = _abi.Pegs(n_pegs=self.n_pegs, **self.dims)
         for k, (dt, _) in _PEG_COLS.items():
             setattr(p, k, ptr(self.pegs[k], dt))
+        if narrow_requests:
+            r32, unit = self.narrowed_requests()
+            p.req = None
+            p.req32 = ptr(r32, np.int32); p.req_unit = ptr(unit, np.int64)
         if self.zone_polarity is not None:
             p.zone_polarity = ptr(self.zone_polarity, np.uint64)
         if self.excl_polarity is not None:

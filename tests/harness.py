@@ -440,7 +440,7 @@ def encode_batch(scenarios: Sequence[Scenario]):
 
 
 def run_emu_tables(ts, kinds=None, per_sim=True, valid=None, fastpath=False, lds_budget=0, node_pods_capacity=0, generic=False, front=True,
-                   winners_only=False, chain=False):
+                   winners_only=False, chain=False, narrow_requests=False):
     """Product kernels under the wave emulator on a TableSet.  Returns (BatchResult, expander dict or None)."""
     L = emu_lib()
     if not hasattr(L, "_query_bound"):
@@ -448,7 +448,7 @@ def run_emu_tables(ts, kinds=None, per_sim=True, valid=None, fastpath=False, lds
         L.emu_estimate_batch_query.argtypes = [C.POINTER(_abi.Pegs), C.POINTER(_abi.Groups), C.POINTER(_abi.Options), C.POINTER(_abi.Results),
                                                C.c_int64, _abi.i32p, _abi.i32p, C.POINTER(_abi.OptionQuery)]
         L._query_bound = True
-    pegs, groups = ts.structs()
+    pegs, groups = ts.structs(narrow_requests=narrow_requests)
     ng = groups.n_groups
     if ts.peg_offsets is not None:
         nnz_cap = int(ts.peg_offsets[ng])
@@ -479,7 +479,7 @@ def run_emu_tables(ts, kinds=None, per_sim=True, valid=None, fastpath=False, lds
     return finish_results(arrs, ng, int(nnz.value), off), exp
 
 
-def run_emu_streams(ts, n_streams, kinds=None, valid=None, generic=False, group_id_base=0, winners_only=False, chain=False):
+def run_emu_streams(ts, n_streams, kinds=None, valid=None, generic=False, group_id_base=0, winners_only=False, chain=False, narrow_requests=False):
     """The batch cut into sub-batches the way casim_options.n_streams does it (csrc/casim_streams.h), parts run by the emulator one
     after the other.  Returns (BatchResult, expander dict or None, parts)."""
     L = emu_lib()
@@ -488,7 +488,7 @@ def run_emu_streams(ts, n_streams, kinds=None, valid=None, generic=False, group_
         L.emu_estimate_batch_streams.argtypes = [C.POINTER(_abi.Pegs), C.POINTER(_abi.Groups), C.POINTER(_abi.Options), C.POINTER(_abi.Results),
                                                  _abi.i32p, _abi.i32p, C.POINTER(_abi.OptionQuery), _abi.i32p]
         L._streams_bound = True
-    pegs, groups = ts.structs()
+    pegs, groups = ts.structs(narrow_requests=narrow_requests)
     ng = groups.n_groups
     nnz_cap = int((ts.peg_hi - ts.peg_lo).sum()) if ts.peg_lo is not None else (int(ts.peg_offsets[ng]) if ts.peg_offsets is not None else pegs.n_pegs * ng)
     st, arrs = alloc_results(ng, nnz_cap)
@@ -513,9 +513,9 @@ def run_emu_streams(ts, n_streams, kinds=None, valid=None, generic=False, group_
     return finish_results(arrs, ng, int(nnz.value), off), exp, int(parts.value)
 
 
-def run_gpu_tables(ts, ctx, kinds=None, per_sim=True, valid=None, fastpath=False, n_streams=0, generic=False, chain=False):
+def run_gpu_tables(ts, ctx, kinds=None, per_sim=True, valid=None, fastpath=False, n_streams=0, generic=False, chain=False, narrow_requests=False):
     from kubernetes_autoscaler_amd.engine import Problem
-    pegs, groups = ts.structs()
+    pegs, groups = ts.structs(narrow_requests=narrow_requests)
     with Problem(ctx, pegs, groups, fastpath, generic, n_streams=n_streams, chain_last_index=chain) as p:
         p.run()
         res = p.fetch()

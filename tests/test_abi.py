@@ -37,7 +37,7 @@ def test_library_is_built_for_gfx950_only():
 
 def test_struct_layouts_match_the_header():
     # sizes computed by hand from include/casim.h (LP64): ints first, then pointers
-    assert ctypes.sizeof(_abi.Pegs) == 6 * 4 + 13 * 8                  # (+ zone_polarity, ABI 6; + excl_polarity, ABI 8)
+    assert ctypes.sizeof(_abi.Pegs) == 6 * 4 + 15 * 8                  # (+ zone_polarity, ABI 6; + excl_polarity, ABI 8; + req32, req_unit, ABI 10)
     assert ctypes.sizeof(_abi.Groups) == 8 + 19 * 8 + 3 * 8 + 8 + 8
     assert ctypes.sizeof(_abi.OptionQuery) == 8 + 4 * 4 + 9 * 8      # (+ join_stream, ABI 5)
     assert ctypes.sizeof(_abi.Results) == 10 * 8 + 3 * 8

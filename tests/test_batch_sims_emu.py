@@ -251,3 +251,30 @@ def test_simulations_with_dictionaries_of_their_own_widen_to_one_batch():
         g0, g1 = int(ts.sim_offsets[g]), int(ts.sim_offsets[g + 2])
         assert list(res.node_count[g0:g1]) == list(r.node_count) and list(res.pods_scheduled[g0:g1]) == list(r.pods_scheduled)
         g += 2
+
+
+def test_simulations_that_share_their_peg_rows():
+    """TableSet.tile_groups: the simulations of every copy point (casim_groups.peg_lo / peg_hi) into ONE copy of the PEG tables — a sweep of limiter /
+    template variants over the same pending pods ships the pods once.  Same answers as the batch that carries a copy per simulation, PEG ids in the
+    lists are the shared table's; cut into streamed parts as well (every part uploads the rows its simulations can see)."""
+    from harness import run_emu_streams
+    scs = [_scenario(700 + k) for k in range(5)]
+    enc, ts, _ = encode_batch(scs)
+    big, shared = ts.tile(3), ts.tile_groups(3)
+    assert shared.n_pegs == ts.n_pegs and shared.n_groups == big.n_groups and shared.n_sims == big.n_sims
+    for kinds in ([_abi.EXPANDER_LEAST_NODES], [_abi.EXPANDER_LEAST_WASTE]):
+        a, ea = run_emu_tables(big, kinds=kinds)
+        b, eb = run_emu_tables(shared, kinds=kinds)
+        for f in ("node_count", "pods_scheduled", "nodes_added", "last_index_out", "status", "placed", "offsets"):
+            assert list(getattr(a, f)) == list(getattr(b, f)), f
+        assert [o % ts.n_pegs for o in a.order] == list(b.order) and list(ea["packed"]) == list(eb["packed"]) and list(ea["best"]) == list(eb["best"])
+    for wo in (False, True):
+        a, ea, pa = run_emu_streams(big, 3, kinds=[_abi.EXPANDER_LEAST_NODES], winners_only=wo)
+        b, eb, pb = run_emu_streams(shared, 3, kinds=[_abi.EXPANDER_LEAST_NODES], winners_only=wo)
+        assert pa == pb == 3 and list(a.node_count) == list(b.node_count) and list(a.placed) == list(b.placed)
+        assert [o % ts.n_pegs for o in a.order] == list(b.order) and list(ea["packed"]) == list(eb["packed"])
+    # a head of it is a batch of its own
+    h = shared.head(7)
+    c, _ = run_emu_tables(h, kinds=None)
+    assert list(c.node_count) == list(b.node_count[:h.n_groups])
+    enc.close()

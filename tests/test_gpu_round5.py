@@ -248,3 +248,51 @@ def test_lean_removal_kernel_long_transactions_and_wide_clusters_on_the_device(c
         assert kaa.Context.last_removals_info()["lean"]
         seen_big += big; seen_long += long_
     assert seen_big >= 5 and seen_long >= 10
+
+
+# ---- casim_pegs.req32 / req_unit (ABI 10) and simulations that share their PEG rows ------------------------------------------------------------
+def test_narrowed_requests_and_shared_peg_rows_on_the_device(ctx):
+    """the batch with int64 requests == the batch with req32 + req_unit (req NULL) == the batch whose simulations point into ONE copy of the PEG
+    tables (TableSet.tile_groups), resident and cut into streamed parts; sizes beyond the device gcd pass's threshold included"""
+    fields = ("offsets", "node_count", "pods_scheduled", "nodes_added", "limiter_nodes", "last_index_out", "status", "req_cpu_sum", "req_mem_sum", "placed")
+    for seed, tiles in ((0, 1), (1, 3), (2, 40)):
+        scs = [_scenario(52000 + 10 * seed + k, device_csr=True, existing=False) for k in range(4)]
+        if len({sc.lanes for sc in scs}) > 1:
+            scs = [scs[0]] * 4
+        enc, ts, _ = encode_batch(scs)
+        big, shared = ts.tile(tiles), ts.tile_groups(tiles)
+        kinds = [_abi.EXPANDER_LEAST_WASTE]
+        for streams in (0, 3):
+            wide, ew = run_gpu_tables(big, ctx, kinds=kinds, n_streams=streams)
+            narrow, en = run_gpu_tables(big, ctx, kinds=kinds, n_streams=streams, narrow_requests=True)
+            sh, es = run_gpu_tables(shared, ctx, kinds=kinds, n_streams=streams, narrow_requests=True)
+            for f in fields:
+                assert np.array_equal(getattr(wide, f), getattr(narrow, f)), (seed, streams, f)
+                assert np.array_equal(getattr(wide, f), getattr(sh, f)), (seed, streams, f, "shared")
+            assert np.array_equal(wide.order, narrow.order) and np.array_equal(np.asarray(wide.order) % ts.n_pegs, sh.order)
+            assert np.array_equal(ew["packed"], en["packed"]) and np.array_equal(ew["packed"], es["packed"])
+        enc.close()
+
+
+def test_narrowed_requests_on_the_headline_shape(ctx):
+    """C2 simulations (the bench's batch, a small one): req32 input through the device's own narrowing-free path against the int64 input that takes the
+    device gcd pass (>= 2^17 request values)"""
+    from kubernetes_autoscaler_amd.tables import TableSet
+    sets = []
+    for s in range(4):
+        w = workloads.config_c2(seed_offset=s)
+        enc = kaa.Encoder(lanes=w.lanes)
+        for pg in w.pegs:
+            enc.add_peg(pg)
+        for g in w.groups:
+            enc.add_group(g.template, max_nodes=g.max_nodes, existing_nodes=0, last_index=g.last_index, pegs=None)
+        enc.finalize()
+        sets.append(TableSet.from_encoder(enc).as_one_simulation())
+        enc.close()
+    ts = TableSet.concat(sets).tile(48)      # 192 simulations x 400 PEGs x 2 lanes = 153 600 values
+    kinds = [_abi.EXPANDER_LEAST_NODES]
+    wide, ew = run_gpu_tables(ts, ctx, kinds=kinds, n_streams=4)
+    narrow, en = run_gpu_tables(ts, ctx, kinds=kinds, n_streams=4, narrow_requests=True)
+    for f in ("node_count", "pods_scheduled", "last_index_out", "placed", "order", "req_cpu_sum", "req_mem_sum"):
+        assert np.array_equal(getattr(wide, f), getattr(narrow, f)), f
+    assert np.array_equal(ew["packed"], en["packed"])
