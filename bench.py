@@ -1261,10 +1261,15 @@ def sched_issue_roofline(row, kernels_ms):
         cyc = rec.get("cycles_per_valu", 4.14)
         port = "salu_issue" if salu > valu else "valu_issue"
         t_issue = max(valu, salu) / simds * cyc / CLOCK_HZ
+        if waves == 1:   # ONE wave issues one instruction at a time, whatever its port: every instruction counts
+            port = "single_wave_issue"
+            t_issue = (valu + salu + c.get("SQ_INSTS_LDS", 0.0) + c.get("SQ_INSTS_VMEM_RD", 0.0) + c.get("SQ_INSTS_VMEM_WR", 0.0)) * cyc / CLOCK_HZ
         return {"bound": port, "valu_insts": valu, "salu_insts": salu, "waves": waves, "simds_in_use": simds, "cycles_per_inst": cyc,
                 "issue_time_ms": t_issue * 1e3, "frac": t_issue / (kernels_ms * 1e-3), "frac_of_device": t_issue * simds / SIMDS / (kernels_ms * 1e-3),
                 "wait_share_of_wave_cycles": (c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]) if c.get("SQ_WAIT_INST_ANY") and c.get("SQ_WAVE_CYCLES") else None,
-                "scope": "one workgroup on one CU (the pass is sequential by definition: every pod sees the placements before it)",
+                "wait_any_share_of_wave_cycles": (c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]) if c.get("SQ_WAIT_ANY") and c.get("SQ_WAVE_CYCLES") else None,
+                "scope": ("one wave (the chain of candidates is sequential: lastIndex is a list position that every commit shifts, DESIGN 17e)" if waves == 1 else
+                          "one workgroup on one CU (the pass is sequential by definition: every pod sees the placements before it)"),
                 "source": f"profiles/sched_counters.json ({rec.get('run', '?')}), kernel {rec['kernel'][:60]}"}
     except (OSError, ValueError, KeyError, ZeroDivisionError) as e:
         return {"error": f"no committed counters for this row: {type(e).__name__}: {e}"}
