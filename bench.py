@@ -585,7 +585,7 @@ def main():
     ap.add_argument("--streams", type=int, default=4,
                     help="the batch of a GPU runs as this many sub-batches on HIP streams of their own (one casim context each): the "
                          "latency-bound feasibility / order kernels of one sub-batch overlap the issue-bound packer of another")
-    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C4"], help="headline config (C2 = BASELINE config[2])")
+    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C3", "C4"], help="headline config (C2 = BASELINE config[2])")
     ap.add_argument("--expander", default="least-nodes", choices=["least-nodes", "least-waste", "most-pods"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison of the timed batch (headline_bit_exact)")

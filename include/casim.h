@@ -334,8 +334,10 @@ int32_t casim_pack_build_info(int32_t device, int32_t out[4]);
  * generic packer keeps node state in LDS (0 = HBM slab), [3] = 1 if the schedulable subsets are
  * derived on the device, [4] = parts the batch runs as on internal streams (1 = not cut), [5] = how many runs so far had to fork
  * from the context's stream (it held pending work: see casim_options.n_streams), [6] = streams the context parked because
- * they shared a hardware queue with a lane it already had (the runtime maps streams onto GPU_MAX_HW_QUEUES queues), [7] = 1 when feasibility,
- * list offsets, lists and PEG order run as ONE launch (front_kernel: calls of <= 1024 groups; casim_options.no_front_kernel). */
+ * they shared a hardware queue with a lane it already had (the runtime maps streams onto GPU_MAX_HW_QUEUES queues), [7] bit 0 = feasibility,
+ * list offsets, lists and PEG order run as ONE launch (front_kernel: calls of <= 1024 groups; casim_options.no_front_kernel), bit 1 = the
+ * orderer ranks a simulation's PEGs once per (cpu, memory) allocatable pair and every group takes its list from that ranking (batches with long
+ * candidate ranges whose pairs serve several groups: rank_shapes_kernel / order_ranked_kernel; CASIM_RANK_ONCE=0 / 1 forces it off / on). */
 struct casim_cluster_estimate_result;
 int32_t casim_problem_info(casim_problem* p, int32_t info_out[8]);
 /* Replace the result of group `ng` of a batch that already ran (status becomes CASIM_NG_OK): how a group that the batch

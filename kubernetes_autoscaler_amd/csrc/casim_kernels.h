@@ -560,9 +560,12 @@ template <int N> struct IntTag { static constexpr int value = N; };
 // turn) — lane instead of thread index, wave_sync instead of the block barrier, `smem` = the wave's own LDS scratch laid out as
 // pos[NPAD] | gid[NPAD] | red[64], with gid ALREADY holding the list (PEG ids in ascending order); NPAD > 0 only.
 // smem != null without kWave: the block's scratch starts there instead of at the dynamic LDS base.
-template <bool kLds, int NPAD, bool kWave = false>
+// kSorted (with kWave, NPAD == 0): `smem` holds gid[Gn] = the group's PEGs ALREADY in processing order (order_ranked_kernel: ranked once per
+// allocatable pair, compacted against the group's feasibility row) — no scores, no sort, the records only; never with the fastpath.
+template <bool kLds, int NPAD, bool kWave = false, bool kSorted = false>
 CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const OrderScratch& os, const int ng, const int off, const int Gn, char* smem = nullptr) {
-    static_assert(!kWave || NPAD > 0, "a single wave sorts in its registers");
+    static_assert(!kWave || NPAD > 0 || kSorted, "a single wave sorts in its registers");
+    static_assert(!kSorted || (kWave && NPAD == 0), "a sorted list is handed over by ONE wave");
     const int tid = kWave ? cs::lane() : cs::tid();
     const int nt = (NPAD > 0 || kWave) ? 64 : cs::nthreads();
     auto barrier = [&]() { if constexpr (kWave) cs::wave_sync(); else cs::sync(); };
@@ -577,9 +580,11 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
     char* base = smem ? smem : (kLds ? cs::dyn_smem() : os.gbuf + os.off[ng]);
     uint64_t* keys = (uint64_t*)base;           // [npad]
     int32_t* pos = kWave ? (int32_t*)base : (int32_t*)(keys + npad);     // [npad]  (kWave: no key array, the keys live in registers)
-    int32_t* gid = pos + npad;                  // [npad] PEG id of list position i (read back after the sort: one dependent
-                                                //        global gather less on the way to the records)
-    if constexpr (NPAD > 0) {
+    int32_t* gid = kSorted ? (int32_t*)base : pos + npad;   // [npad] PEG id of list position i (read back after the sort: one dependent
+                                                            //        global gather less on the way to the records)
+    if constexpr (kSorted) {
+        // (nothing to do: the list came in processing order)
+    } else if constexpr (NPAD > 0) {
         // ONE wave, the list in REGISTERS: element i = tid + 64 * q lives in slot q of lane tid.  A compare-exchange with distance
         // j < 64 fetches the partner from lane tid ^ j through the LDS crossbar (ds_bpermute: three dwords per element, no LDS
         // memory, no barrier), with j >= 64 it swaps two slots of the same lane.  As (key, position) arrays in LDS every stage was
@@ -666,7 +671,7 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
     CASIM_OPROF(1);   // sort
     // fastpath: the eligible PEG with the largest simulationsSaved, last one on ties, goes last
     int best = -1;
-    if (t.fastpath && Gn > 0) {
+    if (!kSorted && t.fastpath && Gn > 0) {
         int64_t* red = (int64_t*)(gid + npad);  // [nt] 8-byte aligned (16 bytes per entry behind an 8-byte aligned base)
         int64_t mine = -1;
 #pragma unroll
@@ -717,7 +722,7 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
         // group's records with coalesced loads, 64 records per wave-load, and never chases indices.
         // The template-level Filters (taints, nodeSelector / affinity, unschedulable) are constant per
         // (PEG, group): evaluate them once here and hand them over as one flag bit.
-        const int g = gid[pos[src]];
+        const int g = kSorted ? gid[src] : gid[pos[src]];
         re_.order[off + i] = g;
         // (lists derived by the feasibility kernel only hold PEGs that passed these Filters already)
         const uint32_t flags = (te_.pflags[g] & ~CASIM_KFLAG_STATIC_OK) | ((te_.lists_from_feas || static_filters_pass(te_, g, ng)) ? CASIM_KFLAG_STATIC_OK : 0u);
@@ -1105,6 +1110,72 @@ CS_GLOBAL void order_strided_kernel(DevTables t, DevResults res, OrderScratch os
     cs::sync();
     if (kLds && os.lds_list_cap > 0 && total > os.lds_list_cap) order_group<false, 0>(t, res, os, ng, base, total);
     else order_group<kLds, 0>(t, res, os, ng, base, total);
+}
+
+// ---- rank once per (simulation, allocatable pair) (VERDICT r4 next #5b) ----------------------------------------------------------------------
+// The orderer's score depends on the PEG and on the template's (cpu, memory) allocatable only (decreasing_pod_orderer.go:76-81): the 64 node
+// groups of a C3 simulation are 5 such pairs.  order_strided_kernel sorts every group's list (~250 of the simulation's 1000 PEGs: a 256-key
+// register network per group, the general LDS network beyond that) — 59 % of the batched C3 step's kernel time (profiles/r11l).  Instead:
+//   rank_shapes_kernel   one block per (simulation, pair): ALL PEGs of the simulation by (score descending, id ascending) — the canonical tie
+//                        rule: lists are built in ascending id order — -> ranks[pair][k]
+//   order_ranked_kernel  one wave per group: walks its pair's ranks 64 at a time, keeps the PEGs whose bit is set in the group's feasibility
+//                        row (ballot + mbcnt: the order survives) and emits the records (order_group<.., kSorted>)
+// A subsequence of a sorted sequence is sorted: the lists are exactly those of the per-group sort.  The host turns it on when the candidate
+// ranges are long and a pair serves several groups (csrc/casim_pipeline.h: rank_once_; CASIM_RANK_ONCE=0 / 1 forces it off / on); for the
+// headline's 20 groups x ~110 PEGs it loses (five 512-key sorts against twenty 128-key networks).
+CS_GLOBAL void rank_shapes_kernel(DevTables t, const int32_t* CS_RESTRICT pair_rep /*[n_pairs] one group of the pair*/, int32_t* CS_RESTRICT ranks /*[n_pairs][stride]*/, int stride) {
+    const int pair = cs::bid(), tid = cs::tid(), nt = cs::nthreads();
+    const int ng = pair_rep[pair];
+    const int lo = t.peg_lo[ng], n = t.peg_hi[ng] - lo;
+    int npad = 64;
+    while (npad < n) npad <<= 1;
+    uint64_t* keys = (uint64_t*)cs::dyn_smem();   // [npad]
+    int32_t* pos = (int32_t*)(keys + npad);       // [npad]
+    for (int i = tid; i < npad; i += nt) {
+        if (i < n) { keys[i] = desc_key(peg_score(t, lo + i, ng)); pos[i] = i; }
+        else { keys[i] = ~0ull; pos[i] = 0x7fffffff; }
+    }
+    cs::sync();
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int p = tid; p < (npad >> 1); p += nt) {   // one thread per pair (i, i | j), as in order_group
+                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                const int l = i | j;
+                const uint64_t ki = keys[i], kl = keys[l];
+                const int32_t pi = pos[i], pl = pos[l];
+                const bool gt = ki > kl || (ki == kl && pi > pl);
+                const bool up = (i & k) == 0;
+                if (gt == up) { keys[i] = kl; keys[l] = ki; pos[i] = pl; pos[l] = pi; }
+            }
+            cs::sync();
+        }
+    }
+    for (int i = tid; i < n; i += nt) ranks[(int64_t)pair * stride + i] = lo + pos[i];
+}
+// LDS: [Wg rounded up to even] row words, then gid[stride]
+CS_GLOBAL void order_ranked_kernel(DevTables t, DevResults res, OrderScratch os, const uint64_t* CS_RESTRICT bits /*[NG][Wg]*/, int Wg, int32_t* CS_RESTRICT cnt_out /*[NG] == t.peg_cnt*/,
+                                   const int32_t* CS_RESTRICT pair_of_group /*[NG]*/, const int32_t* CS_RESTRICT ranks, int stride) {
+    const int ng = cs::bid(), lane = cs::lane();
+    const int base = t.peg_off[ng], lo = t.peg_lo[ng], n = t.peg_hi[ng] - lo;
+    char* smem = cs::dyn_smem();
+    uint64_t* rowl = (uint64_t*)smem;
+    int32_t* gid = (int32_t*)(rowl + ((Wg + 1) & ~1));
+    for (int w = lane; w < Wg; w += 64) rowl[w] = bits[(int64_t)ng * Wg + w];
+    cs::wave_sync();
+    const int32_t* rk = ranks + (int64_t)pair_of_group[ng] * stride;
+    int run = 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int k = c0 + lane;
+        const int p = k < n ? rk[k] : lo;
+        const int rel = p - lo;
+        const bool keep = k < n && ((rowl[rel >> 6] >> (rel & 63)) & 1ull);
+        const uint64_t b = cs::ballot(keep);
+        if (keep) gid[run + cs::mbcnt(b)] = p;
+        run += cs::popc64(b);
+    }
+    if (lane == 0) cnt_out[ng] = run;
+    cs::wave_sync();
+    order_group<true, 0, true, true>(t, res, os, ng, base, run, (char*)gid);
 }
 
 // K_compact: fixed-stride lists -> the compact CSR a caller fetches (casim_problem_fetch of every list; never in the resident loop)

@@ -414,6 +414,38 @@ public:
             // of order / placed / records, the bound those arrays are sized for; its length is written to the slab's offset area (peg_cnt)
             strided_ = want_strided;
             strided_one_launch_ = getenv("CASIM_FRONT_SIM") != nullptr && atoi(getenv("CASIM_FRONT_SIM")) != 0;   // (the one-launch form: measured slower in the loop)
+            // rank once per (simulation, allocatable pair) instead of a sort per group (casim_kernels.h rank_shapes_kernel): when the candidate
+            // ranges are long and a pair serves several groups — C3: 64 groups, 5 pairs, 1000 PEGs.  CASIM_RANK_ONCE=0 / 1: never / whenever possible
+            rank_once_ = false;
+            if (strided_ && !dt_.fastpath && R >= 2) {
+                const char* e = getenv("CASIM_RANK_ONCE");
+                const int mode = e ? atoi(e) : -1;
+                if (mode != 0) {
+                    std::vector<int32_t> pair_of(NG), rep;
+                    bool few = true;
+                    for (int32_t si = 0; si < n_sims_ && few; ++si) {
+                        const size_t first_pair = rep.size();
+                        for (int32_t i = g->sim_offsets[si]; i < g->sim_offsets[si + 1]; ++i) {
+                            const int64_t a0 = g->alloc[(size_t)i * R], a1 = g->alloc[(size_t)i * R + 1];
+                            size_t k = first_pair;
+                            for (; k < rep.size(); ++k) if (g->alloc[(size_t)rep[k] * R] == a0 && g->alloc[(size_t)rep[k] * R + 1] == a1) break;
+                            if (k == rep.size()) { rep.push_back(i); if (rep.size() - first_pair > 32) { few = false; break; } }
+                            pair_of[(size_t)i] = (int32_t)k;
+                        }
+                    }
+                    const bool pays = lmax >= 512 && NG >= 3 * rep.size();
+                    if (few && !rep.empty() && (mode > 0 || pays)) {
+                        rank_once_ = true;
+                        n_pairs_ = (int32_t)rep.size();
+                        rank_stride_ = (int32_t)round_up64(lmax);
+                        int64_t npad = 64; while (npad < lmax) npad <<= 1;
+                        rank_smem_ = (size_t)npad * 12;
+                        d_pair_of_ = up(pair_of.data(), NG); d_pair_rep_ = up(rep.data(), rep.size());
+                        d_ranks_ = (int32_t*)dalloc(4 * (size_t)n_pairs_ * (size_t)rank_stride_);
+                        if (!d_pair_of_ || !d_pair_rep_ || !d_ranks_ || rank_smem_ > bk_.lds_budget()) rank_once_ = false;
+                    }
+                }
+            }
             if (strided_) {
                 h_off_static_.assign(NG + 1, 0);
                 for (size_t i = 0; i < NG; ++i) h_off_static_[i + 1] = h_off_static_[i] + pegs_of_group[i];
@@ -820,7 +852,11 @@ public:
     int32_t run_order() {
         if (NG_ == 0 || front_ran_) return CASIM_OK;   // (front_kernel ordered the lists it made)
         if (getenv("CASIM_PACK_PROF_DUMP") && !os_.prof) { os_.prof = (int64_t*)dalloc(8 * 4 * (size_t)NG_); bk_.zero(os_.prof, 8 * 4 * (size_t)NG_); }
-        if (strided_) {
+        if (strided_ && rank_once_) {
+            bk_.launch(rank_shapes_kernel, (int)n_pairs_, 1, 256, rank_smem_, dt_, d_pair_rep_, d_ranks_, (int)rank_stride_);
+            bk_.launch(order_ranked_kernel, NG_, 1, 64, (size_t)(8 * ((Wg_ + 1) & ~1) + 4 * (size_t)rank_stride_), dt_, dr_, os_, (const uint64_t*)d_bits_, Wg_, res_off_,
+                       d_pair_of_, (const int32_t*)d_ranks_, (int)rank_stride_);
+        } else if (strided_) {
             const size_t smem = order_smem_ > front_sim_wave_scratch() ? order_smem_ : front_sim_wave_scratch();
             if (order_lds_) bk_.launch(order_strided_kernel<true>, NG_, 1, order_threads_, smem, dt_, dr_, os_, (const uint64_t*)d_bits_, Wg_, res_off_, d_idx_);
             else bk_.launch(order_strided_kernel<false>, NG_, 1, order_threads_, front_sim_wave_scratch(), dt_, dr_, os_, (const uint64_t*)d_bits_, Wg_, res_off_, d_idx_);
@@ -1237,6 +1273,7 @@ public:
     }
     bool uses_front() const { return front_; }
     bool uses_strided_lists() const { return strided_; }
+    bool uses_rank_once() const { return strided_ && rank_once_ && !strided_one_launch_; }
     bool pack_in_lds() const { return pack_lds_; }
     int fast_npt() const { return fast_npt_; }
     int fast_lanes() const { return fast_npt_ > 0 ? (fast_i64_ ? 8 : fast_r_) : 0; }   // > 0: the register-resident packer handles this batch (2 / 4 int32 lanes; 8 = two int64 lanes)
@@ -1376,6 +1413,8 @@ private:
     bool winners_only_ = false, winners_ready_ = false; int winners_s_ = 0; int32_t winners_total_ = 0;   // casim_options.winners_only
     int32_t* d_woff_ = nullptr; int32_t* d_worder_ = nullptr; int32_t* d_wplaced_ = nullptr; size_t woff_cap_ = 0;
     bool front_ = false, front_ran_ = false;   // feas + offsets + lists + order in ONE launch (front_kernel)
+    bool rank_once_ = false; int32_t n_pairs_ = 0, rank_stride_ = 0; size_t rank_smem_ = 0;   // the orderer's ranks per (simulation, allocatable pair)
+    const int32_t* d_pair_of_ = nullptr; const int32_t* d_pair_rep_ = nullptr; int32_t* d_ranks_ = nullptr;
     bool strided_ = false, strided_one_launch_ = false; size_t front_sim_smem_ = 0; std::vector<int32_t> h_off_static_;   // batches: fixed-stride lists, front_sim_kernel
     int32_t* d_coff_ = nullptr; int32_t* d_corder_ = nullptr; int32_t* d_cplaced_ = nullptr;   // ... compacted at fetch time
     uint64_t* d_ticket_ = nullptr; uint32_t front_epoch_ = 0;

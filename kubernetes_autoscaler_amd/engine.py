@@ -497,7 +497,7 @@ class Problem:
         out = (C.c_int32 * 8)()
         check(lib.casim_problem_info(self._h, out), "casim_problem_info")
         return {"fast_packer_slots_per_lane": out[0], "fast_packer_lanes": out[1], "generic_state_in_lds": bool(out[2]),
-                "csr_on_device": bool(out[3]), "parts": int(out[4]), "forks": int(out[5]), "parked_streams": int(out[6]), "front_kernel": bool(out[7])}
+                "csr_on_device": bool(out[3]), "parts": int(out[4]), "forks": int(out[5]), "parked_streams": int(out[6]), "front_kernel": bool(out[7] & 1), "ranked_orderer": bool(out[7] & 2)}
 
     def set_group_result(self, ng: int, r: dict):
         """casim_problem_set_group_result: a group estimated by Context.estimate_on_cluster joins the expander reduce."""

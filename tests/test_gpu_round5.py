@@ -296,3 +296,53 @@ def test_narrowed_requests_on_the_headline_shape(ctx):
     for f in ("node_count", "pods_scheduled", "last_index_out", "placed", "order", "req_cpu_sum", "req_mem_sum"):
         assert np.array_equal(getattr(wide, f), getattr(narrow, f)), f
     assert np.array_equal(ew["packed"], en["packed"])
+
+
+# ---- the orderer's ranks once per (simulation, allocatable pair) ---------------------------------------------------------------------------------
+def test_ranked_orderer_equals_the_per_group_sort_on_the_device(ctx, monkeypatch):
+    from kubernetes_autoscaler_amd.engine import Problem
+    from kubernetes_autoscaler_amd.tables import TableSet
+    fields = ("offsets", "node_count", "pods_scheduled", "nodes_added", "limiter_nodes", "last_index_out", "status", "req_cpu_sum", "req_mem_sum", "order", "placed")
+    # (a) fuzz batches, the path forced on
+    for seed in range(12):
+        scs = [_scenario(56000 + 10 * seed + k, device_csr=True, existing=False) for k in range(2 + seed % 3)]
+        if len({sc.lanes for sc in scs}) > 1:
+            scs = [scs[0], scs[0]]
+        enc, ts, bases = encode_batch(scs)
+        monkeypatch.setenv("CASIM_RANK_ONCE", "0")
+        a, ea = run_gpu_tables(ts.tile(3), ctx, kinds=[_abi.EXPANDER_LEAST_WASTE], n_streams=seed % 3)
+        monkeypatch.setenv("CASIM_RANK_ONCE", "1")
+        b, eb = run_gpu_tables(ts.tile(3), ctx, kinds=[_abi.EXPANDER_LEAST_WASTE], n_streams=seed % 3)
+        for f in fields:
+            assert np.array_equal(getattr(a, f), getattr(b, f)), (seed, f)
+        assert np.array_equal(ea["packed"], eb["packed"])
+        enc.close()
+    # (b) C3-shaped: the automatic rule takes it (info says so), results equal the forced-off run and the oracle's for one simulation
+    monkeypatch.delenv("CASIM_RANK_ONCE", raising=False)
+    sets, ws = [], []
+    for s in range(3):
+        w = workloads.config_c3(seed_offset=s)
+        enc = kaa.Encoder(lanes=w.lanes)
+        for pg in w.pegs:
+            enc.add_peg(pg)
+        for g in w.groups:
+            enc.add_group(g.template, max_nodes=g.max_nodes, existing_nodes=0, last_index=g.last_index, pegs=None)
+        enc.finalize()
+        sets.append(TableSet.from_encoder(enc).as_one_simulation())
+        enc.close(); ws.append(w)
+    ts = TableSet.concat(sets).tile(4)
+    pegs, groups = ts.structs()
+    with Problem(ctx, pegs, groups, False, False, n_streams=0) as p:
+        assert p.info()["ranked_orderer"]
+        p.run(); auto = p.fetch()
+    monkeypatch.setenv("CASIM_RANK_ONCE", "0")
+    with Problem(ctx, pegs, groups, False, False, n_streams=0) as p:
+        assert not p.info()["ranked_orderer"]
+        p.run(); off = p.fetch()
+    monkeypatch.delenv("CASIM_RANK_ONCE")
+    for f in fields:
+        assert np.array_equal(getattr(auto, f), getattr(off, f)), f
+    sc = Scenario(pegs=ws[0].pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, None) for g in ws[0].groups], device_csr=True, lanes=ws[0].lanes)
+    want = run_oracle(sc)
+    ng = len(ws[0].groups)
+    assert [int(x) for x in auto.node_count[:ng]] == [e.node_count for e, _ in want] and [int(x) for x in auto.pods_scheduled[:ng]] == [e.pods_scheduled for e, _ in want]
