@@ -977,9 +977,24 @@ def batched_config_row(kaa, torch, dev_index, workloads, TableSet, config, n_sim
                "checks_per_s": checks / dt, "sims_per_s": n_sims / dt, "checks_per_simulation": checks / n_sims, "node_groups": int(ts.n_groups), "pegs": int(ts.n_pegs),
                "schedulable_pairs": nnz, "kernel_ms_sub_batch_0_alone": kms, "packer": {"lanes": info["fast_packer_lanes"], "slots_per_lane": info["fast_packer_slots_per_lane"]},
                "dtype": "int32" if info["fast_packer_slots_per_lane"] > 0 and info["fast_packer_lanes"] != 8 else "int64", "steps": steps}
+        row["ranked_orderer"] = bool(info.get("ranked_orderer"))
         if verify:
             chk = verify_headline(workloads, make, n_seeds, b.tables, res)
             row["bit_exact"] = bool(chk["headline_bit_exact"]); row["groups_compared"] = chk["groups_compared"]; row["verify_s"] = chk["verify_s"]
+        # rocprofv3 of the same step (tools/config_prof.sh -> tools/config_counters.py -> profiles/config_counters.json, committed): the step's kernels
+        # inside the 4-stream loop, and the dominant one's duration and instruction counters with the device to itself
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "config_counters.json"))).get(config)
+            if prof:
+                d = prof.get("dominant") or {}
+                row["rocprof"] = {"run": prof.get("run"), "step_kernels_in_loop": prof.get("step_kernels_in_loop", [])[:4], "dominant": d}
+                if d.get("valu_insts") and d.get("salu_insts") and d.get("kernel_us_alone"):
+                    port = max(d["valu_insts"], d["salu_insts"])
+                    cyc = d.get("cycles_per_valu") or 4.14
+                    row["rocprof"]["issue_roofline"] = {"bound": "salu_issue" if d["salu_insts"] > d["valu_insts"] else "valu_issue",
+                                                        "frac": port * cyc / (SIMDS * CLOCK_HZ) / (d["kernel_us_alone"] * 1e-6)}
+        except (OSError, ValueError, KeyError):
+            pass
         return row
     finally:
         b.close()
