@@ -519,8 +519,8 @@ def compact_line(out, side_file=SIDE_FILE):
     allc = out.get("cpu_baseline_all_cores")
     if isinstance(allc, dict) and "value" in allc:
         line["cpu_baseline_all_cores"] = _pick(allc, ("value", "cores", "sims_per_s"))
-    for k in ("sims_per_s", "timed_region_s", "value_wall", "ms_per_step_wall", "table_bytes_in", "value_wall_req32", "ms_per_step_wall_req32", "table_bytes_in_req32",
-              "wall_req32_bit_equal", "value_wall_shared_pegs", "ms_per_step_wall_shared_pegs",
+    for k in ("sims_per_s", "timed_region_s", "value_wall", "ms_per_step_wall", "ms_per_step_wall_median", "table_bytes_in", "value_wall_req32", "ms_per_step_wall_req32",
+              "ms_per_step_wall_req32_median", "table_bytes_in_req32", "wall_req32_bit_equal", "value_wall_shared_pegs", "ms_per_step_wall_shared_pegs", "ms_per_step_wall_shared_pegs_median",
               "table_bytes_in_shared_pegs", "wall_shared_pegs_bit_equal", "value_wall_every_list", "ms_per_step_wall_every_list", "headline_bit_exact"):
         if k in out:
             line[k] = out[k]
@@ -866,14 +866,17 @@ def main():
         extra["sims_per_s_wall"] = er.get("sims_per_s")
         # (the winners-only regime is not what a shim's prefetch fill needs — the every-list form next to it, top level)
         extra["table_bytes_in"] = er.get("table_bytes_in")
+        extra["ms_per_step_wall_median"] = er.get("ms_per_step_median")   # (ten calls: one host hiccup of 6-10 ms moves the mean by 10-20 %)
         rq = rows.get("enter_return_req32") or {}
         extra["value_wall_req32"] = rq.get("checks_per_s")
         extra["ms_per_step_wall_req32"] = rq.get("ms_per_step")
+        extra["ms_per_step_wall_req32_median"] = rq.get("ms_per_step_median")
         extra["table_bytes_in_req32"] = rq.get("table_bytes_in")
         extra["wall_req32_bit_equal"] = rq.get("bit_equal_to_resident")
         sh = rows.get("enter_return_shared_pegs") or {}
         extra["value_wall_shared_pegs"] = sh.get("checks_per_s")
         extra["ms_per_step_wall_shared_pegs"] = sh.get("ms_per_step")
+        extra["ms_per_step_wall_shared_pegs_median"] = sh.get("ms_per_step_median")
         extra["table_bytes_in_shared_pegs"] = sh.get("table_bytes_in")
         extra["wall_shared_pegs_bit_equal"] = sh.get("bit_equal_to_resident")
         el = rows.get("enter_return_every_list") or {}
