@@ -1123,14 +1123,38 @@ CS_GLOBAL void order_strided_kernel(DevTables t, DevResults res, OrderScratch os
 // A subsequence of a sorted sequence is sorted: the lists are exactly those of the per-group sort.  The host turns it on when the candidate
 // ranges are long and a pair serves several groups (csrc/casim_pipeline.h: rank_once_; CASIM_RANK_ONCE=0 / 1 forces it off / on); for the
 // headline's 20 groups x ~110 PEGs it loses (five 512-key sorts against twenty 128-key networks).
-CS_GLOBAL void rank_shapes_kernel(DevTables t, const int32_t* CS_RESTRICT pair_rep /*[n_pairs] one group of the pair*/, int32_t* CS_RESTRICT ranks /*[n_pairs][stride]*/, int stride) {
-    const int pair = cs::bid(), tid = cs::tid(), nt = cs::nthreads();
+// `list` names the pairs this launch ranks.  pair_base == null: every listed pair sorts.  Else (second launch, the pairs whose allocatable is
+// PROPORTIONAL to their simulation's base pair: k x (cpu, memory) — instance families): the scores are the base pair's times a constant, so the
+// base ranking almost always is this pair's too; the block CHECKS that (adjacent entries of the base ranking in (score descending, id
+// ascending) order under ITS scores: one pass) and points pair_src at the base ranking, or sorts when the check fails (rounding made a tie).
+CS_GLOBAL void rank_shapes_kernel(DevTables t, const int32_t* CS_RESTRICT list, const int32_t* CS_RESTRICT pair_rep /*[n_pairs] one group of the pair*/,
+                                  const int32_t* CS_RESTRICT pair_base /*[n_pairs] or null*/, int32_t* CS_RESTRICT pair_src /*[n_pairs] whose ranking the pair's groups read*/,
+                                  int32_t* CS_RESTRICT ranks /*[n_pairs][stride]*/, int stride) {
+    const int pair = list[cs::bid()], tid = cs::tid(), nt = cs::nthreads();
     const int ng = pair_rep[pair];
     const int lo = t.peg_lo[ng], n = t.peg_hi[ng] - lo;
     int npad = 64;
     while (npad < n) npad <<= 1;
     uint64_t* keys = (uint64_t*)cs::dyn_smem();   // [npad]
     int32_t* pos = (int32_t*)(keys + npad);       // [npad]
+    if (pair_base) {
+        const int32_t* rb = ranks + (int64_t)pair_base[pair] * stride;
+        bool bad = false;
+        for (int i = tid; i + 1 < n; i += nt) {
+            const int a = rb[i], b = rb[i + 1];
+            const uint64_t ka = desc_key(peg_score(t, a, ng)), kb = desc_key(peg_score(t, b, ng));
+            bad = bad || ka > kb || (ka == kb && a > b);
+        }
+        uint32_t* flag = (uint32_t*)keys;   // [waves of the block]
+        const uint64_t bb = cs::ballot(bad);
+        if (cs::lane() == 0) flag[tid >> 6] = bb != 0ull ? 1u : 0u;
+        cs::sync();
+        bool any = false;
+        for (int w = 0; w < (nt + 63) / 64; ++w) any = any || flag[w] != 0u;
+        cs::sync();   // (the words are the sort's key array in a moment)
+        if (!any) { if (tid == 0) pair_src[pair] = pair_base[pair]; return; }
+    }
+    if (tid == 0) pair_src[pair] = pair;
     for (int i = tid; i < npad; i += nt) {
         if (i < n) { keys[i] = desc_key(peg_score(t, lo + i, ng)); pos[i] = i; }
         else { keys[i] = ~0ull; pos[i] = 0x7fffffff; }
@@ -1154,7 +1178,7 @@ CS_GLOBAL void rank_shapes_kernel(DevTables t, const int32_t* CS_RESTRICT pair_r
 }
 // LDS: [Wg rounded up to even] row words, then gid[stride]
 CS_GLOBAL void order_ranked_kernel(DevTables t, DevResults res, OrderScratch os, const uint64_t* CS_RESTRICT bits /*[NG][Wg]*/, int Wg, int32_t* CS_RESTRICT cnt_out /*[NG] == t.peg_cnt*/,
-                                   const int32_t* CS_RESTRICT pair_of_group /*[NG]*/, const int32_t* CS_RESTRICT ranks, int stride) {
+                                   const int32_t* CS_RESTRICT pair_of_group /*[NG]*/, const int32_t* CS_RESTRICT pair_src /*[n_pairs]*/, const int32_t* CS_RESTRICT ranks, int stride) {
     const int ng = cs::bid(), lane = cs::lane();
     const int base = t.peg_off[ng], lo = t.peg_lo[ng], n = t.peg_hi[ng] - lo;
     char* smem = cs::dyn_smem();
@@ -1162,7 +1186,7 @@ CS_GLOBAL void order_ranked_kernel(DevTables t, DevResults res, OrderScratch os,
     int32_t* gid = (int32_t*)(rowl + ((Wg + 1) & ~1));
     for (int w = lane; w < Wg; w += 64) rowl[w] = bits[(int64_t)ng * Wg + w];
     cs::wave_sync();
-    const int32_t* rk = ranks + (int64_t)pair_of_group[ng] * stride;
+    const int32_t* rk = ranks + (int64_t)pair_src[pair_of_group[ng]] * stride;
     int run = 0;
     for (int c0 = 0; c0 < n; c0 += 64) {
         const int k = c0 + lane;

@@ -433,16 +433,48 @@ public:
                             pair_of[(size_t)i] = (int32_t)k;
                         }
                     }
+                    // pairs proportional to their simulation's first one (k x (cpu, memory): instance families) share ITS ranking whenever a linear
+                    // check on the device passes (rank_shapes_kernel, second launch): one sort per simulation instead of one per pair
+                    std::vector<int32_t> base_of(rep.size()), sorted_list, checked_list;
+                    bool all_prop = few && !rep.empty();
+                    if (few) {
+                        size_t pi = 0;
+                        for (int32_t si = 0; si < n_sims_; ++si) {
+                            if (g->sim_offsets[si + 1] == g->sim_offsets[si]) continue;
+                            const size_t first = pi;
+                            while (pi < rep.size() && rep[pi] < g->sim_offsets[si + 1]) {
+                                const __int128 a0 = g->alloc[(size_t)rep[first] * R], a1 = g->alloc[(size_t)rep[first] * R + 1];
+                                const __int128 b0 = g->alloc[(size_t)rep[pi] * R], b1 = g->alloc[(size_t)rep[pi] * R + 1];
+                                // (off by default: one sort per simulation plus checks is less WORK than a sort per pair, but the sorts of all pairs run side by
+                                // side in one launch while the checks wait for the base pairs' launch — C3 x 512: 0.69 ms per step shared, 0.66 every pair
+                                // sorting, profiles/r12d; CASIM_RANK_SHARE=1 turns it on)
+                                const bool share = getenv("CASIM_RANK_SHARE") && atoi(getenv("CASIM_RANK_SHARE")) != 0;
+                                const bool prop = pi == first || (share && a0 > 0 && a1 > 0 && b0 > 0 && b1 > 0 && a0 * b1 == a1 * b0);
+                                base_of[pi] = (int32_t)(prop ? first : pi);
+                                if (pi == first || !prop) sorted_list.push_back((int32_t)pi); else checked_list.push_back((int32_t)pi);
+                                all_prop = all_prop && prop;
+                                ++pi;
+                            }
+                        }
+                    }
+                    // (the headline's shape — 20 groups, 5 proportional pairs, ~110 of 400 PEGs per list — gains nothing even with ONE sort per simulation:
+                    // 0.869 ms per step against 0.865 with the per-group register networks, profiles/r12c; the rule stays with long ranges)
+                    (void)all_prop;
                     const bool pays = lmax >= 512 && NG >= 3 * rep.size();
                     if (few && !rep.empty() && (mode > 0 || pays)) {
                         rank_once_ = true;
                         n_pairs_ = (int32_t)rep.size();
+                        n_sorted_pairs_ = (int32_t)sorted_list.size(); n_checked_pairs_ = (int32_t)checked_list.size();
+                        d_pair_base_ = up(base_of.data(), base_of.size());
+                        d_sorted_list_ = up(sorted_list.data(), sorted_list.size());
+                        d_checked_list_ = checked_list.empty() ? nullptr : up(checked_list.data(), checked_list.size());
+                        d_pair_src_ = (int32_t*)dalloc(4 * rep.size());
                         rank_stride_ = (int32_t)round_up64(lmax);
                         int64_t npad = 64; while (npad < lmax) npad <<= 1;
                         rank_smem_ = (size_t)npad * 12;
                         d_pair_of_ = up(pair_of.data(), NG); d_pair_rep_ = up(rep.data(), rep.size());
                         d_ranks_ = (int32_t*)dalloc(4 * (size_t)n_pairs_ * (size_t)rank_stride_);
-                        if (!d_pair_of_ || !d_pair_rep_ || !d_ranks_ || rank_smem_ > bk_.lds_budget()) rank_once_ = false;
+                        if (!d_pair_of_ || !d_pair_rep_ || !d_ranks_ || !d_pair_base_ || !d_sorted_list_ || !d_pair_src_ || rank_smem_ > bk_.lds_budget()) rank_once_ = false;
                     }
                 }
             }
@@ -853,9 +885,11 @@ public:
         if (NG_ == 0 || front_ran_) return CASIM_OK;   // (front_kernel ordered the lists it made)
         if (getenv("CASIM_PACK_PROF_DUMP") && !os_.prof) { os_.prof = (int64_t*)dalloc(8 * 4 * (size_t)NG_); bk_.zero(os_.prof, 8 * 4 * (size_t)NG_); }
         if (strided_ && rank_once_) {
-            bk_.launch(rank_shapes_kernel, (int)n_pairs_, 1, 256, rank_smem_, dt_, d_pair_rep_, d_ranks_, (int)rank_stride_);
+            bk_.launch(rank_shapes_kernel, (int)n_sorted_pairs_, 1, 256, rank_smem_, dt_, d_sorted_list_, d_pair_rep_, (const int32_t*)nullptr, d_pair_src_, d_ranks_, (int)rank_stride_);
+            if (n_checked_pairs_ > 0)
+                bk_.launch(rank_shapes_kernel, (int)n_checked_pairs_, 1, 256, rank_smem_, dt_, d_checked_list_, d_pair_rep_, d_pair_base_, d_pair_src_, d_ranks_, (int)rank_stride_);
             bk_.launch(order_ranked_kernel, NG_, 1, 64, (size_t)(8 * ((Wg_ + 1) & ~1) + 4 * (size_t)rank_stride_), dt_, dr_, os_, (const uint64_t*)d_bits_, Wg_, res_off_,
-                       d_pair_of_, (const int32_t*)d_ranks_, (int)rank_stride_);
+                       d_pair_of_, (const int32_t*)d_pair_src_, (const int32_t*)d_ranks_, (int)rank_stride_);
         } else if (strided_) {
             const size_t smem = order_smem_ > front_sim_wave_scratch() ? order_smem_ : front_sim_wave_scratch();
             if (order_lds_) bk_.launch(order_strided_kernel<true>, NG_, 1, order_threads_, smem, dt_, dr_, os_, (const uint64_t*)d_bits_, Wg_, res_off_, d_idx_);
@@ -1415,6 +1449,8 @@ private:
     bool front_ = false, front_ran_ = false;   // feas + offsets + lists + order in ONE launch (front_kernel)
     bool rank_once_ = false; int32_t n_pairs_ = 0, rank_stride_ = 0; size_t rank_smem_ = 0;   // the orderer's ranks per (simulation, allocatable pair)
     const int32_t* d_pair_of_ = nullptr; const int32_t* d_pair_rep_ = nullptr; int32_t* d_ranks_ = nullptr;
+    int32_t n_sorted_pairs_ = 0, n_checked_pairs_ = 0;   // pairs that sort / pairs proportional to their simulation's base pair (check, sort only on failure)
+    const int32_t* d_pair_base_ = nullptr; const int32_t* d_sorted_list_ = nullptr; const int32_t* d_checked_list_ = nullptr; int32_t* d_pair_src_ = nullptr;
     bool strided_ = false, strided_one_launch_ = false; size_t front_sim_smem_ = 0; std::vector<int32_t> h_off_static_;   // batches: fixed-stride lists, front_sim_kernel
     int32_t* d_coff_ = nullptr; int32_t* d_corder_ = nullptr; int32_t* d_cplaced_ = nullptr;   // ... compacted at fetch time
     uint64_t* d_ticket_ = nullptr; uint32_t front_epoch_ = 0;

@@ -12,14 +12,15 @@ from kubernetes_autoscaler_amd import _abi, workloads
 from kubernetes_autoscaler_amd.tables import TableSet
 kinds = [_abi.EXPANDER_LEAST_NODES]
 rows = []
-for cfg, n_sims, n_seeds, modes in (("C3", 512, 8, (None, "0")), ("C2", 4096, 64, (None, "1"))):
+for cfg, n_sims, n_seeds, modes in (("C3", 512, 8, (None, "0")), ("C3", 512, 8, (None, "share1")), ("C2", 4096, 64, (None, "1"))):
     ts = bench.simulation_tables(workloads.CONFIGS[cfg], range(n_seeds), kaa.Encoder, TableSet).tile((n_sims + n_seeds - 1) // n_seeds).head(n_sims)
     row = {"config": cfg, "sims": n_sims}
     keep = {}
     for mode in modes:
-        if mode is None:
-            os.environ.pop("CASIM_RANK_ONCE", None)
-        else:
+        os.environ.pop("CASIM_RANK_ONCE", None); os.environ.pop("CASIM_RANK_SHARE", None)
+        if mode == "share1":
+            os.environ["CASIM_RANK_SHARE"] = "1"
+        elif mode is not None:
             os.environ["CASIM_RANK_ONCE"] = mode
         stream = torch.cuda.Stream(device=0)
         b = kaa.StreamedBatch(0, ts, n_streams=4, stream=stream.cuda_stream)
@@ -32,12 +33,12 @@ for cfg, n_sims, n_seeds, modes in (("C3", 512, 8, (None, "0")), ("C2", 4096, 64
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 100
         res = b.fetch()
-        name = "default" if mode is None else f"CASIM_RANK_ONCE={mode}"
+        name = "default" if mode is None else ("CASIM_RANK_SHARE=1" if mode == "share1" else f"CASIM_RANK_ONCE={mode}")
         row[name] = {"ms_per_step": dt * 1e3, "ranked_orderer": bool(b.prob.info()["ranked_orderer"])}
         keep[name] = res
         b.close()
     a, c = list(keep.values())
     row["same_results"] = bool(all(np.array_equal(getattr(a, f), getattr(c, f)) for f in ("node_count", "pods_scheduled", "last_index_out", "order", "placed", "offsets")))
     rows.append(row)
-os.environ.pop("CASIM_RANK_ONCE", None)
+os.environ.pop("CASIM_RANK_ONCE", None); os.environ.pop("CASIM_RANK_SHARE", None)
 print(json.dumps(rows))
