@@ -109,6 +109,41 @@ for seed in range(first, first + count):
         nodes, pods = with_extra_resources(w.nodes, w.pods, lanes, seed)
         sc = SchedCase(nodes=nodes, pods=pods, hints=w.hints, acceptable=w.acceptable, break_on_failure=w.break_on_failure, last_index=w.last_index, lanes=lanes)
         assert_sched_matches(sched_gpu(sc, ctx), sched_oracle(sc), w.name + " lanes"); bump("fuzz_pending_lanes")
+    # round 5: the removal loop as one wave over per-class fit masks AND through K_sched (plain clusters: the shape the lean kernel takes)
+    w = W.fuzz_removals_plain(seed)
+    rc = RemovalCase(nodes=w.nodes, candidates=w.candidates, destination=w.destination, hints=w.hints, persist=w.persist,
+                     max_removable=w.max_removable, last_index=w.last_index)
+    want = removal_oracle(rc)
+    os.environ.pop("CASIM_NO_LEAN_REMOVALS", None)
+    assert_removal_matches(removal_device(rc, ctx), want, w.name + " lean"); bump("fuzz_removals_plain_lean")
+    os.environ["CASIM_NO_LEAN_REMOVALS"] = "1"
+    assert_removal_matches(removal_device(rc, ctx), want, w.name + " K_sched"); bump("fuzz_removals_plain_k_sched")
+    os.environ.pop("CASIM_NO_LEAN_REMOVALS", None)
+    # round 5: batches — chained groups, the ranked orderer forced on, requests narrowed by the caller, PEG rows shared between the tiles
+    if seed % 2 == 0:
+        from harness import encode_batch, run_emu_tables, run_gpu_tables
+        import numpy as np
+        scs = [Scenario(pegs=x.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, None) for g in x.groups], device_csr=True, lanes=x.lanes)
+               for x in (W.fuzz(seed * 7 + k, max_groups=6, max_pegs=14) for k in range(2 + seed % 3))]
+        if len({sc.lanes for sc in scs}) > 1:
+            scs = [scs[0], scs[0]]
+        enc, ts, bases = encode_batch(scs)
+        chain = seed % 4 == 0
+        want = []
+        for sc, (pb, _) in zip(scs, bases):
+            want.extend([(est, [pb + i for i in ids]) for est, ids in run_oracle(sc, chain=chain)])
+        run_t = (lambda t, **kw: run_emu_tables(t, kinds=None, chain=chain, **kw)[0]) if EMU else (lambda t, **kw: run_gpu_tables(t, ctx, kinds=None, chain=chain, **kw)[0])
+        os.environ["CASIM_RANK_ONCE"] = "1"
+        os.environ["CASIM_RANK_SHARE"] = str(seed % 3 == 0 and 1 or 0)
+        res = run_t(ts, narrow_requests=True)
+        os.environ.pop("CASIM_RANK_ONCE", None); os.environ.pop("CASIM_RANK_SHARE", None)
+        assert_matches_oracle(res, want, f"batch ranked + req32 {seed}"); bump("batch_ranked_req32")
+        sh = run_t(ts.tile_groups(2))
+        ng = ts.n_groups
+        assert list(sh.node_count[:ng]) == list(res.node_count) and list(sh.node_count[ng:]) == list(res.node_count) and \
+            list(sh.order[:len(res.order)]) == list(res.order), f"shared PEG rows {seed}"
+        bump("batch_shared_peg_rows")
+        enc.close()
 print("stress OK", "(emulator)" if EMU else "(MI355X)", stats, f"{time.time() - t0:.0f} s")
 if not EMU:
     ctx.close()
