@@ -127,7 +127,7 @@ typedef struct casim_pegs {
                                  rest of the PEG then has to join that pod's node. */
     const int32_t* req32;     /* ABI 10.  [G][R] or NULL: the requests as 32-bit multiples of a per-lane unit the CALLER knows — request of PEG g in
                                  lane r = req32[g * R + r] * req_unit[r] (milli-cpu, MiB-granular memory: what a Go shim holds anyway).  When set, `req`
-                                 may be NULL: half the request bytes cross the link and the library's own gcd pass over the table (a device round trip in
+                                 may be NULL (when both are set they must describe the same requests; the batch path reads req32): half the request bytes cross the link and the library's own gcd pass over the table (a device round trip in
                                  the middle of a big call's upload) is not needed.  Exact: the int64 table the kernels read is rebuilt on the device
                                  as req32 * req_unit.  Honoured by the Estimate batch path (casim_estimate_batch / _query / _multi,
                                  casim_problem_create); K_sched's and the resident cluster's entry points need `req` (CASIM_ERR_INVALID without). */
