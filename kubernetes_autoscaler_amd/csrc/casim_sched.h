@@ -82,6 +82,9 @@ struct SchedArgs {
     // SimilarPodsScheduling, exact form (only consulted for classes with spread rules): per run the (controller, class)
     // pair and the controller, -1 = pod without controller
     const int32_t* run_pair; const int32_t* run_ctrl;
+    // removals_lean_kernel: the candidate and run columns above interleaved (16 bytes per record: one load per lane, one pointer each)
+    const int32_t* lean_cand;     // [K + 1][4] node, first run, first pod, atomic (entry K: the end markers)
+    const int32_t* lean_run;      // [n_runs][4] class, count, hint, first pod
     int64_t* prof;                // [8] s_memtime ticks per phase of thread 0 (CASIM_PACK_PROF builds + CASIM_PACK_PROF_DUMP) or null
     int32_t* pair_memo;           // [n_pairs] 1 = cached as unschedulable (zeroed before every pass)
     int32_t* ctrl_count;          // [n_ctrl] specs cached for the controller (at most 10, similar_pods.go:52)
@@ -783,7 +786,8 @@ CS_GLOBAL void lean_fit0_kernel(DevTables t, const uint64_t* CS_RESTRICT fbits, 
 template <int RMAX_>
 CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedArgs a, const uint64_t* CS_RESTRICT fit0, int log_cap) {
     const int lane = cs::lane();
-    const int R = t.R, N = a.N, cap = a.cap, S = cap >> 6, C = a.C;
+    const int R = RMAX_ == 2 ? 2 : t.R;   // (n_res >= 2 always: the two-lane instantiation knows its lane count, every `r < R` folds away)
+    const int N = a.N, cap = a.cap, S = cap >> 6, C = a.C;
     char* smem = cs::dyn_smem();
     uint64_t* fit = (uint64_t*)smem;                 // [C][S]
     uint64_t* accb = fit + (int64_t)C * S;           // [S] acceptable (the hinted node's test)
@@ -901,7 +905,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
         cs::lds_order();   // (the masks are read by all lanes in the next search)
     };
 
-    int32_t my_cand = 0, my_rlo = 0, my_rhi = 0, my_plo = 0, my_phi = 0;   // candidate records kc & ~63 .., one per lane
+    int32_t my_cand = 0, my_rlo = 0, my_rhi = 0, my_plo = 0, my_phi = 0, my_atomic = 0;   // candidate records kc & ~63 .., one per lane
     int cstart = 0, cend = 0;                                               // run records [cstart, cend), one per lane
     int32_t my_class = 0, my_count = 0, my_hint = -1, my_first = 0;
 
@@ -909,11 +913,10 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
         // ---- SimulateNodeRemoval (cluster.go:131-172) of candidate kc, planner order (planner.go:300-330) ----
         if (a.max_removable > 0 && removed >= a.max_removable) break;
         if ((kc & 63) == 0) {
-            const int kk = kc + lane;
-            const bool have = kk < a.n_cand;
-            my_cand = have ? a.cand_node[kk] : 0;
-            my_rlo = have ? a.cand_run_off[kk] : 0; my_rhi = have ? a.cand_run_off[kk + 1] : 0;
-            my_plo = have ? a.cand_pod_off[kk] : 0; my_phi = have ? a.cand_pod_off[kk + 1] : 0;
+            const int kk = kc + lane < a.n_cand ? kc + lane : a.n_cand - 1;   // (every lane loads: lanes past the end re-read the last record)
+            const cs::Words<4> r0 = cs::load4((const uint32_t*)a.lean_cand + 4 * (int64_t)kk), r1 = cs::load4((const uint32_t*)a.lean_cand + 4 * (int64_t)(kk + 1));
+            my_cand = (int32_t)r0.w[0]; my_rlo = (int32_t)r0.w[1]; my_plo = (int32_t)r0.w[2]; my_atomic = (int32_t)r0.w[3];
+            my_rhi = (int32_t)r1.w[1]; my_phi = (int32_t)r1.w[2];
         }
         const int Y = (int)cs::bcast_u32((uint32_t)my_cand, kc & 63);
         const int p_lo = (int)cs::bcast_u32((uint32_t)my_plo, kc & 63), p_hi = (int)cs::bcast_u32((uint32_t)my_phi, kc & 63);
@@ -993,10 +996,9 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
             if (k < cstart || k >= cend) {
                 cstart = k;
                 cend = cstart + 64 < a.n_runs ? cstart + 64 : a.n_runs;
-                const int kk = cstart + lane;
-                const bool have = kk < cend;
-                my_class = have ? a.run_class[kk] : 0; my_count = have ? a.run_count[kk] : 0;
-                my_hint = have ? a.run_hint[kk] : -1; my_first = have ? a.run_first[kk] : 0;
+                const int kk = cstart + lane < cend ? cstart + lane : cend - 1;
+                const cs::Words<4> rr = cs::load4((const uint32_t*)a.lean_run + 4 * (int64_t)kk);
+                my_class = (int32_t)rr.w[0]; my_count = (int32_t)rr.w[1]; my_hint = (int32_t)rr.w[2]; my_first = (int32_t)rr.w[3];
             }
             const int j = k - cstart;
             const int c = (int)cs::bcast_u32((uint32_t)my_class, j);
@@ -1055,7 +1057,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
             }
         }
         cs::lds_order();
-        if (ok && !(a.cand_atomic && a.cand_atomic[kc])) removed++;   // len(removableList) - atomicScaleDownNodesCount
+        if (ok && cs::bcast_u32((uint32_t)my_atomic, kc & 63) == 0u) removed++;   // len(removableList) - atomicScaleDownNodesCount
         if (lane == 0) a.removable_out[kc] = ok ? 1 : 0;
     }
     if (lane == 0) {
@@ -1120,6 +1122,7 @@ public:
 
         // ---- runs: consecutive pods of one class without a hint; predicates outside the subset -> delegate ----
         std::vector<int32_t> rc, rn, rh, rf, cro, rp, rk;      // class, count, hint, first pod, ..., (controller, class) pair, controller
+        std::vector<int32_t> lc, lr;                           // the lean removal kernel's interleaved candidate / run records (live until the uploads have left)
         std::map<std::pair<int32_t, int32_t>, int32_t> pair_id;  // (similar_key, class) -> dense id
         std::map<int32_t, int32_t> ctrl_id;
         std::vector<uint8_t> used(C, 0);
@@ -1167,7 +1170,7 @@ public:
             size_t bound = 64 * 64 + 4096;
             if (!resident_) bound += C * (8 * (size_t)R + 8 + 8 * (masks + (size_t)dt_.Wx)) + N * (16 * (size_t)R + 16 + 8 * masks);
             bound += 4 * (rc.size() + rn.size() + rh.size() + rf.size() + rp.size() + rk.size() + cro.size()) + N;
-            if (cand) bound += 16 * ((size_t)K_ + 1) + 8 * P;
+            if (cand) bound += 16 * ((size_t)K_ + 1) + 8 * P + 16 * ((size_t)K_ + 2) + 16 * (rc.size() + 2);
             if (q->rules && q->rules->n_rules > 0 && q->rules->rule_offset) {
                 const casim_domain_rules* r0 = q->rules;
                 const size_t NR = (size_t)r0->n_rules, tot = (size_t)r0->rule_offset[NR];
@@ -1234,6 +1237,18 @@ public:
         if (K_ > 0) {
             a_.memo_classes = 0;  // breakOnFailure ends a simulation at the first miss: the memo is never consulted
             a_.n_cand = K_; a_.persist = cand->persist ? 1 : 0; a_.max_removable = cand->max_removable > 0 ? cand->max_removable : 0;
+            if (lean_) {   // the kernel's candidate / run records (SchedArgs::lean_cand, lean_run)
+                lc.assign(4 * ((size_t)K_ + 1), 0); lr.assign(4 * (rc.size() > 0 ? rc.size() : 1), 0);
+                for (int k = 0; k <= K_; ++k) {
+                    lc[4 * (size_t)k + 0] = k < K_ ? cand->cand_node[k] : 0;
+                    lc[4 * (size_t)k + 1] = cro[(size_t)k];
+                    lc[4 * (size_t)k + 2] = cand->pod_offsets[k];
+                    lc[4 * (size_t)k + 3] = (k < K_ && cand->cand_atomic && cand->cand_atomic[k]) ? 1 : 0;
+                }
+                for (size_t i = 0; i < rc.size(); ++i) { lr[4 * i] = rc[i]; lr[4 * i + 1] = rn[i]; lr[4 * i + 2] = rh[i]; lr[4 * i + 3] = rf[i]; }
+                a_.lean_cand = up(lc.data(), lc.size()); a_.lean_run = up(lr.data(), lr.size());
+                if (!a_.lean_cand || !a_.lean_run) lean_ = false;
+            }
             a_.cand_node = up(cand->cand_node, (size_t)K_);
             a_.cand_atomic = cand->cand_atomic ? up(cand->cand_atomic, (size_t)K_) : nullptr;
             a_.cand_run_off = up(cro.data(), cro.size());
