@@ -612,7 +612,9 @@ typedef struct casim_removal_candidates {
                                       * the first candidate, also when unneededNodesLimit() is 0) is the caller's early
                                       * return: there is nothing to simulate, so no call is made */
     int32_t last_index;
-    int32_t ext_capacity;            /* entries of the ext_* result arrays; 0 = stop at the first candidate with arrivals */
+    int32_t ext_capacity;            /* entries of the ext_* result arrays; 0 = stop at the first candidate with arrivals.  (The one-wave removal kernel —
+                                      * casim_last_removals_info — keeps a log of `pods + ext_capacity` committed moves in LDS: a capacity far beyond what the
+                                      * loop can list pushes a big call to the general loop for nothing.) */
     const struct casim_domain_rules* rules; /* the encoder's domain rules (PodTopologySpread, zone anti-affinity); NULL = none */
 } casim_removal_candidates;
 
