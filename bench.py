@@ -375,6 +375,12 @@ def config_rows(kaa, ctx, workloads, kinds, iters=20):
                     "expander_ms", "fetch_ms", "timed_wall_ms", "wall_ms", "best_group", "engine_error")
             row["native"] = {k: nat[k] for k in keep if k in nat}
             row["native"]["exit_code"] = nrc
+            # the row's encode figures are the shim's sequence since ABI 11 (the PEGs through casim_enc_add_pods); the same workload pod by pod beside it
+            try:
+                pbp = native_trace.encode_only(w, tpath + ".pod_by_pod", bulk=False)
+                row["native"]["encode_pod_by_pod"] = dict(pbp, same_tables=pbp.get("tables_fnv") == nat.get("tables_fnv"))
+            except Exception as e:
+                row["native"]["encode_pod_by_pod"] = {"error": f"{type(e).__name__}: {e}"}
             if "wall_ms" in nat and "encode_ms" in nat:
                 row["native"]["encode_plus_call_ms"] = nat["encode_ms"] + nat["wall_ms"]
                 row["native"]["same_winner_as_python_path"] = nat.get("best_group") == row["best_group"]

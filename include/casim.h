@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CASIM_ABI_VERSION 10  /* 2: casim_removal_candidates.cand_atomic, casim_domain_rules.n_taint_policy_rules
+#define CASIM_ABI_VERSION 11  /* 2: casim_removal_candidates.cand_atomic, casim_domain_rules.n_taint_policy_rules
                                * 3: casim_groups.{peg_lo,peg_hi,global_id,n_sims,sim_offsets}, casim_best_option_sims,
                                *    casim_feasibility_reasons, casim_estimate_batch_timed, casim_mctx_*, casim_cluster_*
                                * 4: casim_options.n_streams (sub-batches on internal HIP streams), casim_enc_group_pods,
@@ -46,7 +46,9 @@ extern "C" {
                                * 8: casim_pegs.excl_polarity (node bits of NEED polarity: hostname-level required pod affinity inside casim_estimate_batch)
                                * 9: casim_enc_lane / _pod_set_request / _group_set_allocatable / _lane_count / _lane_name (resources by name),
                                *    casim_options.chain_last_index (+ 3 reserved words), casim_problem_time_feasibility
-                               * 10: casim_pegs.req32 / req_unit (requests narrowed by the caller), casim_last_removals_info */
+                               * 10: casim_pegs.req32 / req_unit (requests narrowed by the caller), casim_last_removals_info
+                               * 11: casim_pod_columns / casim_enc_add_pods (the pods of a loop — namespace, requests, labels, tolerations, nodeSelector,
+                               *     PEG sizes — in ONE crossing over an interned string table) */
 
 /* Resource lanes.  Lane 0 = cpu in millicores (Quantity.MilliValue), lane 1 = memory bytes,
  * lane 2 = ephemeral-storage bytes, lanes 3.. = scalar / extended resources (Quantity.Value),
@@ -896,6 +898,40 @@ int32_t casim_enc_add_peg(casim_encoder* e, int32_t pod_spec, int32_t count);
  * PEG ids.  Returns the id of the first PEG added or <0. */
 int32_t casim_enc_add_resource_pegs(casim_encoder* e, const char* namespace_, int32_t n, const int64_t* req,
                                     const int32_t* count, int32_t* ids_out);
+
+/* Bulk form for pods in general (ABI 11): what nearly every pending pod carries — namespace, requests, labels, tolerations, nodeSelector,
+ * the first container's requests — for n_pods pods in ONE call, strings by index into a table the caller interned (clusters repeat a few
+ * dozen keys and values over thousands of pods; from cgo that is one C string per DISTINCT string instead of one per use).  C2 of the bench
+ * (400 PEGs, 20 node groups) is 3 875 casim_enc_* calls pod by pod and 280 with this one; the encoder also sees equal tolerations as
+ * equal indices without hashing them.  Pod i becomes spec record first + i (the return value is `first`; ids are consecutive) exactly as
+ * casim_enc_add_pod_spec + casim_enc_pod_add_label / _add_toleration / _add_node_selector / _set_fastpath_requests in that order
+ * would have built it; peg_count[i] >= 0 also makes it the exemplar of a PEG of that size (casim_enc_add_peg; PEG ids are consecutive
+ * in pod order, peg_ids_out[i] = the id or -1).  Everything rarer — host ports, (anti-)affinity terms, node-affinity terms, spread
+ * constraints, requests by name, unsupported marks, the spec digest — goes through the per-pod calls on the returned ids afterwards.
+ * A string index of -1 is NULL / "".  Offsets: [n_pods + 1], starting at 0, non-decreasing; a NULL offset column = no pod has any.
+ * Nothing is added on an error (CASIM_ERR_INVALID: an index out of range, offsets that do not rise, a PEG size below -1).  Not after
+ * casim_enc_finalize. */
+typedef struct casim_pod_columns {
+    int32_t n_pods, n_strings;
+    const char* const* strings;     /* [n_strings] NUL-terminated, distinct or not                                          */
+    const int32_t* ns;              /* [n_pods] namespace                                                                   */
+    const int64_t* req;             /* [n_pods][n_res] positional lanes (casim_encoder_options.n_res)                       */
+    const double* fastpath_req;     /* [n_pods][2] Containers[0] cpu, memory as float64 (binpacking_estimator.go:451-458);
+                                       NULL = derived from lanes 0 / 1 as casim_enc_add_resource_pegs does                   */
+    const int32_t* peg_count;       /* [n_pods] or NULL: >= 0 = exemplar of a PEG of that many pods, -1 = spec record only   */
+    const int32_t* label_off;       /* [n_pods + 1] or NULL                                                                 */
+    const int32_t* label_key;       /* labels of pod i: k in [label_off[i], label_off[i + 1])                               */
+    const int32_t* label_val;
+    const int32_t* tol_off;         /* [n_pods + 1] or NULL; tolerations in the pod's order                                 */
+    const int32_t* tol_key;
+    const int32_t* tol_op;          /* "Exists" / "Equal" / "" / "Lt" / "Gt" as casim_enc_pod_add_toleration takes them      */
+    const int32_t* tol_value;
+    const int32_t* tol_effect;
+    const int32_t* sel_off;         /* [n_pods + 1] or NULL; nodeSelector pairs                                             */
+    const int32_t* sel_key;
+    const int32_t* sel_val;
+} casim_pod_columns;
+int32_t casim_enc_add_pods(casim_encoder* e, const casim_pod_columns* pods, int32_t* peg_ids_out);
 
 /* f2 — pod equivalence groups: equivalence.BuildPodGroups / groupPodsBySchedulingProperties / match
  * (CA/core/scaleup/equivalence/groups.go:39-104) over n_pods pending pods IN LIST ORDER.  pod_spec[i] = the spec record of pod i

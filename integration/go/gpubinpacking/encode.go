@@ -7,6 +7,8 @@ package gpubinpacking
 import "C"
 
 import (
+	"runtime"
+
 	apiv1 "k8s.io/api/core/v1"
 	metav1 "k8s.io/apimachinery/pkg/apis/meta/v1"
 	"k8s.io/autoscaler/cluster-autoscaler/estimator"
@@ -101,6 +103,19 @@ func (s *session) pod(pod *apiv1.Pod) C.int32_t {
 	for k, v := range pod.Spec.NodeSelector {
 		C.casim_enc_pod_add_node_selector(e, id, c.s(k), c.s(v))
 	}
+	if len(pod.Spec.Containers) > 0 { // the fastpath chooser reads the FIRST container (binpacking_estimator.go:451-458)
+		r := pod.Spec.Containers[0].Resources.Requests
+		C.casim_enc_pod_set_fastpath_requests(e, id, C.double(r.Cpu().AsApproximateFloat64()), C.double(r.Memory().AsApproximateFloat64()))
+	}
+	s.podRest(pod, id)
+	return id
+}
+
+// podRest: the fields casim_enc_add_pods (ABI 11) has no column for — host ports, pod (anti-)affinity, node-affinity terms, spread
+// constraints, volumes / claims — on spec record id, after its namespace, requests, labels, tolerations and nodeSelector are in
+// (pod by pod: pod() above; in one crossing: pegs() below).
+func (s *session) podRest(pod *apiv1.Pod, id C.int32_t) {
+	e, c := s.enc, &s.strs
 	for _, p := range schedutil.GetHostPorts(pod) {
 		C.casim_enc_pod_add_host_port(e, id, c.s(p.HostIP), c.s(string(p.Protocol)), C.int32_t(p.HostPort))
 	}
@@ -170,11 +185,6 @@ func (s *session) pod(pod *apiv1.Pod) C.int32_t {
 	if hasVolumesOrClaims(pod) {
 		C.casim_enc_pod_mark_unsupported(e, id, c.s("volumes / DRA"))
 	}
-	if len(pod.Spec.Containers) > 0 { // the fastpath chooser reads the FIRST container (binpacking_estimator.go:451-458)
-		r := pod.Spec.Containers[0].Resources.Requests
-		C.casim_enc_pod_set_fastpath_requests(e, id, C.double(r.Cpu().AsApproximateFloat64()), C.double(r.Memory().AsApproximateFloat64()))
-	}
-	return id
 }
 
 func hasVolumesOrClaims(pod *apiv1.Pod) bool {
@@ -189,6 +199,120 @@ func hasVolumesOrClaims(pod *apiv1.Pod) bool {
 // peg adds one PodEquivalenceGroup: exemplar + size.
 func (s *session) peg(g estimator.PodEquivalenceGroup) C.int32_t {
 	return C.casim_enc_add_peg(s.enc, s.pod(g.Exemplar()), C.int32_t(len(g.Pods)))
+}
+
+// pegs adds the PodEquivalenceGroups of a loop in list order and returns their PEG ids.  What nearly every exemplar carries — namespace,
+// the three positional requests, labels, tolerations, nodeSelector, the first container's requests — crosses the ABI ONCE
+// (casim_enc_add_pods, ABI 11) as index columns over a string table interned here: one C string per DISTINCT key / value instead of one
+// per use, 1 cgo crossing instead of ~9 per exemplar (C2 of the bench: 3 875 casim_enc_* calls pod by pod, 280 this way).  The encoder
+// builds the same records as pod() + peg() would (tests/test_bulk_pods.py compares the tables); requests by name and the rarer
+// fields follow per pod on the returned ids (scalars, podRest), in list order, so lanes are handed out as before.  An exemplar
+// that already has a record in this session ends the run and takes peg().
+func (s *session) pegs(groups []estimator.PodEquivalenceGroup) ([]C.int32_t, error) {
+	ids := make([]C.int32_t, len(groups))
+	var run []int
+	inRun := map[*apiv1.Pod]bool{}
+	var firstErr error
+	flush := func() {
+		if len(run) == 0 {
+			return
+		}
+		n := len(run)
+		strIdx := map[string]C.int32_t{}
+		var strs []*C.char
+		sid := func(x string) C.int32_t {
+			if i, ok := strIdx[x]; ok {
+				return i
+			}
+			i := C.int32_t(len(strs))
+			strIdx[x] = i
+			strs = append(strs, s.strs.s(x))
+			return i
+		}
+		ns, cnt, out := make([]C.int32_t, n), make([]C.int32_t, n), make([]C.int32_t, n)
+		req := make([]C.int64_t, 0, 3*n)
+		fp := make([]C.double, 0, 2*n)
+		loff, toff, soff := make([]C.int32_t, 1, n+1), make([]C.int32_t, 1, n+1), make([]C.int32_t, 1, n+1)
+		var lk, lv, tk, to, tv, te, sk, sv []C.int32_t
+		for i, gi := range run {
+			pod := groups[gi].Exemplar()
+			r := podutils.PodRequests(pod) // cluster-autoscaler/utils/pod/pod.go:88
+			ns[i], cnt[i] = sid(pod.Namespace), C.int32_t(len(groups[gi].Pods))
+			req = append(req, C.int64_t(r.Cpu().MilliValue()), C.int64_t(r.Memory().Value()), C.int64_t(r.StorageEphemeral().Value()))
+			fc, fm := 0.0, 0.0
+			if len(pod.Spec.Containers) > 0 { // the fastpath chooser reads the FIRST container (binpacking_estimator.go:451-458)
+				cr := pod.Spec.Containers[0].Resources.Requests
+				fc, fm = cr.Cpu().AsApproximateFloat64(), cr.Memory().AsApproximateFloat64()
+			}
+			fp = append(fp, C.double(fc), C.double(fm))
+			for k, v := range pod.Labels {
+				lk, lv = append(lk, sid(k)), append(lv, sid(v))
+			}
+			loff = append(loff, C.int32_t(len(lk)))
+			for _, t := range pod.Spec.Tolerations {
+				tk, to = append(tk, sid(t.Key)), append(to, sid(string(t.Operator)))
+				tv, te = append(tv, sid(t.Value)), append(te, sid(string(t.Effect)))
+			}
+			toff = append(toff, C.int32_t(len(tk)))
+			for k, v := range pod.Spec.NodeSelector {
+				sk, sv = append(sk, sid(k)), append(sv, sid(v))
+			}
+			soff = append(soff, C.int32_t(len(sk)))
+		}
+		// the struct carries pointers into Go memory: every column is pinned for the call (cgo pointer rules)
+		var pin runtime.Pinner
+		defer pin.Unpin()
+		col := func(v []C.int32_t) *C.int32_t {
+			if len(v) == 0 {
+				return nil
+			}
+			pin.Pin(&v[0])
+			return &v[0]
+		}
+		var pc C.casim_pod_columns
+		pc.n_pods, pc.n_strings = C.int32_t(n), C.int32_t(len(strs))
+		pin.Pin(&strs[0])
+		pc.strings = &strs[0]
+		pin.Pin(&req[0])
+		pin.Pin(&fp[0])
+		pc.ns, pc.req, pc.fastpath_req, pc.peg_count = col(ns), &req[0], &fp[0], col(cnt)
+		pc.label_off, pc.label_key, pc.label_val = col(loff), col(lk), col(lv)
+		pc.tol_off, pc.tol_key, pc.tol_op, pc.tol_value, pc.tol_effect = col(toff), col(tk), col(to), col(tv), col(te)
+		pc.sel_off, pc.sel_key, pc.sel_val = col(soff), col(sk), col(sv)
+		first := C.casim_enc_add_pods(s.enc, &pc, &out[0])
+		if first < 0 { // nothing was added (casim.h): the caller falls back to the reference path for this loop
+			if firstErr == nil {
+				firstErr = rcErr(first, "casim_enc_add_pods")
+			}
+		} else {
+			for i, gi := range run {
+				pod, id := groups[gi].Exemplar(), first+C.int32_t(i)
+				s.spec[pod] = id
+				// ScalarResources by name, in list order (CASIM_ENC_DELEGATED marks the pod: see pod())
+				scalars(podutils.PodRequests(pod), func(name apiv1.ResourceName, v int64) {
+					C.casim_enc_pod_set_request(s.enc, id, s.strs.s(string(name)), C.int64_t(v))
+				})
+				s.podRest(pod, id)
+				ids[gi] = out[i]
+			}
+		}
+		run = run[:0]
+		for k := range inRun {
+			delete(inRun, k)
+		}
+	}
+	for gi, g := range groups {
+		pod := g.Exemplar()
+		if _, seen := s.spec[pod]; seen || inRun[pod] {
+			flush()
+			ids[gi] = s.peg(g)
+			continue
+		}
+		run = append(run, gi)
+		inRun[pod] = true
+	}
+	flush()
+	return ids, firstErr
 }
 
 // group adds one node group: the template the estimator clones for every simulated node (SanitizedNodeInfo,

@@ -224,9 +224,9 @@ func (g *gpuEstimator) Estimate(pegs []estimator.PodEquivalenceGroup, tmpl *fram
 	// ---- per-call mode: ONE casim_estimate_batch with one group record and the PEGs the orchestrator passed ----
 	s := newSession()
 	defer s.close()
-	ids := make([]C.int32_t, len(pegs))
-	for i, p := range pegs {
-		ids[i] = s.peg(p)
+	ids, err := s.pegs(pegs) // (one crossing for the exemplars: casim_enc_add_pods)
+	if err != nil {
+		return g.fallback.Estimate(pegs, tmpl, ng)
 	}
 	s.group(tmpl, maxNodes, existing, g.lastIndex(), ids)
 	pt, gt, err := s.tables()

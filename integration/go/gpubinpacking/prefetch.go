@@ -111,8 +111,12 @@ func (s *Shared) fill(autoscalingCtx *ca_context.AutoscalingContext, pegs []esti
 	}()
 	pkeys := make([]C.uint64_t, len(pegs))
 	pegID := make(map[*apiv1.Pod]C.int32_t, len(pegs))
+	ids, err := sess.pegs(pegs) // (one crossing for the exemplars: casim_enc_add_pods)
+	if err != nil {
+		return err
+	}
 	for i, p := range pegs {
-		pegID[p.Exemplar()] = sess.peg(p)
+		pegID[p.Exemplar()] = ids[i]
 		pkeys[i] = pegKey(p)
 	}
 	existing := nodeCount(autoscalingCtx.ClusterSnapshot)

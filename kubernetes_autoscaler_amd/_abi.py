@@ -3,7 +3,7 @@ shared library happens in _ffi.py).  Kept separate so that test harnesses that c
 structs can reuse the layouts without loading the product library."""
 import ctypes as C
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_RES = 8
 
 OK = 0
@@ -141,6 +141,15 @@ class RemovalResults(C.Structure):
 cstr = C.c_char_p
 cstrp = C.POINTER(C.c_char_p)
 
+
+class PodColumns(C.Structure):
+    """casim_pod_columns (ABI 11): the pods of a loop for casim_enc_add_pods, strings by index into `strings`."""
+    _fields_ = [("n_pods", C.c_int32), ("n_strings", C.c_int32), ("strings", cstrp), ("ns", i32p), ("req", i64p), ("fastpath_req", f64p),
+                ("peg_count", i32p), ("label_off", i32p), ("label_key", i32p), ("label_val", i32p),
+                ("tol_off", i32p), ("tol_key", i32p), ("tol_op", i32p), ("tol_value", i32p), ("tol_effect", i32p),
+                ("sel_off", i32p), ("sel_key", i32p), ("sel_val", i32p)]
+
+
 # name -> (restype, argtypes): every symbol include/casim.h declares
 PROTOTYPES = {
     "casim_abi_version": (C.c_int32, []),
@@ -247,6 +256,7 @@ PROTOTYPES = {
     "casim_enc_pod_mark_unsupported": (C.c_int32, [C.c_void_p, C.c_int32, cstr]),
     "casim_enc_add_peg": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
     "casim_enc_add_resource_pegs": (C.c_int32, [C.c_void_p, cstr, C.c_int32, i64p, i32p, i32p]),
+    "casim_enc_add_pods": (C.c_int32, [C.c_void_p, C.POINTER(PodColumns), i32p]),
     "casim_enc_pod_set_spec_extra": (C.c_int32, [C.c_void_p, C.c_int32, cstr]),
     "casim_enc_group_pods": (C.c_int32, [C.c_void_p, C.c_int32, i32p, cstrp, u8p, i32p, i32p]),
     "casim_enc_add_grouped_pegs": (C.c_int32, [C.c_void_p, C.c_int32, i32p, i32p, C.c_int32, i32p]),

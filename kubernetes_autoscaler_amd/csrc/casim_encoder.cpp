@@ -113,7 +113,7 @@ struct PodSpec {
     std::string ns;
     int64_t req[CASIM_MAX_RES];
     Labels labels;
-    std::vector<Toleration> tolerations;
+    std::vector<int32_t> tolerations;   // ids into casim_encoder::tol_dict (tolerations are interned when they arrive: casim_enc_pod_add_toleration)
     std::vector<std::pair<std::string, std::string>> node_selector;
     std::vector<Requirement> node_affinity;   // ONE required term (casim_enc_pod_add_node_affinity_req)
     std::vector<NodeTerm> node_terms;         // nodeSelectorTerms, ORed (casim_enc_pod_add_node_affinity_term); exclusive with the above
@@ -291,6 +291,25 @@ struct casim_encoder {
         int n = lane_names.empty() ? opt.n_res : first_named() + (int)lane_names.size();
         if (touch_ephemeral && n < 3) n = 3;
         return n > opt.n_res ? n : opt.n_res;
+    }
+    // Distinct tolerations (key, operator, value, effect), in order of arrival; pod specs hold ids.  Clusters repeat a handful of tolerations
+    // over thousands of pods: a hit stores four bytes instead of three strings, and finalize asks "does it tolerate taint T" once per
+    // distinct toleration instead of once per pod (peg_table stage: C3 1.33 -> 0.2 ms).
+    std::vector<Toleration> tol_dict;
+    std::unordered_map<std::string, int32_t> tol_id;
+    std::string tol_sig;   // scratch
+    int32_t intern_toleration(const char* key, TolOp op, const char* value, const char* effect) {
+        const char* k = key ? key : ""; const char* v = value ? value : ""; const char* f = effect ? effect : "";
+        const uint32_t lens[2] = {(uint32_t)strlen(k), (uint32_t)strlen(v)};   // (lengths in: no separator a string could contain)
+        tol_sig.assign(1, (char)('0' + (int)op));
+        tol_sig.append((const char*)lens, sizeof lens);
+        tol_sig.append(k, lens[0]); tol_sig.append(v, lens[1]); tol_sig.append(f);
+        auto it = tol_id.find(tol_sig);
+        if (it != tol_id.end()) return it->second;
+        const int32_t id = (int32_t)tol_dict.size();
+        tol_dict.push_back(Toleration{std::string(k), op, std::string(v), std::string(f)});
+        tol_id.emplace(tol_sig, id);
+        return id;
     }
     std::vector<int32_t> term_specs;   // specs with (anti-)affinity terms, in the order they got their first one (finalize looks at these only: at cluster scale the
                                        // other 150 000 spec records stay cold)
@@ -507,7 +526,7 @@ int32_t casim_enc_pod_add_label(casim_encoder* e, int32_t pod, const char* key, 
     POD_CHECK(e, pod); e->specs[pod].labels[S(key)] = S(value); return CASIM_OK;
 }
 int32_t casim_enc_pod_add_toleration(casim_encoder* e, int32_t pod, const char* key, const char* op, const char* value, const char* effect) {
-    POD_CHECK(e, pod); e->specs[pod].tolerations.push_back(Toleration{S(key), parse_tol_op(op), S(value), S(effect)}); return CASIM_OK;
+    POD_CHECK(e, pod); e->specs[pod].tolerations.push_back(e->intern_toleration(key, parse_tol_op(op), value, effect)); return CASIM_OK;
 }
 int32_t casim_enc_pod_add_node_selector(casim_encoder* e, int32_t pod, const char* key, const char* value) {
     POD_CHECK(e, pod); e->specs[pod].node_selector.push_back({S(key), S(value)}); return CASIM_OK;
@@ -670,6 +689,76 @@ int32_t casim_enc_add_resource_pegs(casim_encoder* e, const char* namespace_, in
     }
     return first;
 }
+// ABI 11: the pods of a loop in one crossing (casim.h: casim_pod_columns).  Record for record what the per-pod calls build, in their order:
+// add_pod_spec, labels, tolerations, nodeSelector pairs, fastpath requests, add_peg.
+int32_t casim_enc_add_pods(casim_encoder* e, const casim_pod_columns* c, int32_t* peg_ids_out) {
+    ENC_CHECK(e);
+    if (!c || c->n_pods < 0 || c->n_strings < 0 || (c->n_strings > 0 && !c->strings)) return CASIM_ERR_INVALID;
+    const int32_t n = c->n_pods, NSTR = c->n_strings;
+    if (n == 0) return (int32_t)e->specs.size();
+    if (!c->ns || !c->req) return CASIM_ERR_INVALID;
+    // ---- validate everything first: nothing is added on an error
+    auto str_ok = [&](int32_t k, bool may_be_null) { return (k >= 0 && k < NSTR) || (may_be_null && k == -1); };
+    auto offsets_ok = [&](const int32_t* off) {
+        if (!off) return true;
+        if (off[0] != 0) return false;
+        for (int32_t i = 0; i < n; ++i) if (off[i + 1] < off[i]) return false;
+        return true;
+    };
+    if (!offsets_ok(c->label_off) || !offsets_ok(c->tol_off) || !offsets_ok(c->sel_off)) return CASIM_ERR_INVALID;
+    for (int32_t i = 0; i < n; ++i) {
+        if (!str_ok(c->ns[i], true)) return CASIM_ERR_INVALID;
+        if (c->peg_count && c->peg_count[i] < -1) return CASIM_ERR_INVALID;
+    }
+    const int32_t NL = c->label_off ? c->label_off[n] : 0, NT = c->tol_off ? c->tol_off[n] : 0, NSEL = c->sel_off ? c->sel_off[n] : 0;
+    if ((NL > 0 && (!c->label_key || !c->label_val)) || (NT > 0 && (!c->tol_key || !c->tol_op || !c->tol_value || !c->tol_effect)) ||
+        (NSEL > 0 && (!c->sel_key || !c->sel_val))) return CASIM_ERR_INVALID;
+    for (int32_t k = 0; k < NL; ++k) if (!str_ok(c->label_key[k], true) || !str_ok(c->label_val[k], true)) return CASIM_ERR_INVALID;
+    for (int32_t k = 0; k < NT; ++k)
+        if (!str_ok(c->tol_key[k], true) || !str_ok(c->tol_op[k], true) || !str_ok(c->tol_value[k], true) || !str_ok(c->tol_effect[k], true)) return CASIM_ERR_INVALID;
+    for (int32_t k = 0; k < NSEL; ++k) if (!str_ok(c->sel_key[k], true) || !str_ok(c->sel_val[k], true)) return CASIM_ERR_INVALID;
+    // ---- the string table once; slot NSTR is the empty string every -1 reads
+    std::vector<std::string> strs((size_t)NSTR + 1);
+    for (int32_t k = 0; k < NSTR; ++k) strs[(size_t)k] = S(c->strings[k]);
+    auto str = [&](int32_t k) -> const std::string& { return strs[(size_t)(k < 0 ? NSTR : k)]; };
+    // tolerations: equal index quadruples are equal tolerations — found again without building a signature (a miss goes through the
+    // encoder-wide dictionary, where the same toleration may already sit under other indices or from the per-pod calls)
+    struct Quad { int32_t k, o, v, f; bool operator==(const Quad& x) const { return k == x.k && o == x.o && v == x.v && f == x.f; } };
+    struct QuadHash { size_t operator()(const Quad& q) const {
+        uint64_t h = ((uint64_t)(uint32_t)q.k << 32 | (uint32_t)q.v) * 0x9E3779B97F4A7C15ull;
+        h ^= ((uint64_t)(uint32_t)q.o << 32 | (uint32_t)q.f) * 0xC2B2AE3D27D4EB4Full; return (size_t)(h ^ (h >> 29)); } };
+    std::unordered_map<Quad, int32_t, QuadHash> tol_of_quad;
+    const int32_t first = (int32_t)e->specs.size();
+    const int R = e->opt.n_res;
+    for (int32_t i = 0; i < n; ++i) {
+        e->specs.emplace_back();
+        PodSpec& p = e->specs.back();
+        p.ns = str(c->ns[i]);
+        for (int r = 0; r < CASIM_MAX_RES; ++r) p.req[r] = r < R ? c->req[(size_t)i * (size_t)R + (size_t)r] : 0;
+        if (c->label_off) {
+            p.labels.v.reserve((size_t)(c->label_off[i + 1] - c->label_off[i]));
+            for (int32_t k = c->label_off[i]; k < c->label_off[i + 1]; ++k) p.labels[str(c->label_key[k])] = str(c->label_val[k]);
+        }
+        if (c->tol_off) {
+            p.tolerations.reserve((size_t)(c->tol_off[i + 1] - c->tol_off[i]));
+            for (int32_t k = c->tol_off[i]; k < c->tol_off[i + 1]; ++k) {
+                const Quad q{c->tol_key[k], c->tol_op[k], c->tol_value[k], c->tol_effect[k]};
+                auto it = tol_of_quad.find(q);
+                if (it == tol_of_quad.end())
+                    it = tol_of_quad.emplace(q, e->intern_toleration(str(q.k).c_str(), parse_tol_op(q.o < 0 ? nullptr : str(q.o).c_str()), str(q.v).c_str(), str(q.f).c_str())).first;
+                p.tolerations.push_back(it->second);
+            }
+        }
+        if (c->sel_off)
+            for (int32_t k = c->sel_off[i]; k < c->sel_off[i + 1]; ++k) p.node_selector.push_back({str(c->sel_key[k]), str(c->sel_val[k])});
+        if (c->fastpath_req) { p.fp_cpu = c->fastpath_req[2 * (size_t)i]; p.fp_mem = c->fastpath_req[2 * (size_t)i + 1]; }
+        else { p.fp_cpu = (double)p.req[0] * 1e-3; p.fp_mem = (double)p.req[1]; }
+        int32_t peg = -1;
+        if (c->peg_count && c->peg_count[i] >= 0) { peg = (int32_t)e->pegs.size(); e->pegs.push_back(Peg{first + i, c->peg_count[i]}); }
+        if (peg_ids_out) peg_ids_out[i] = peg;
+    }
+    return first;
+}
 int32_t casim_enc_add_existing_pod(casim_encoder* e, int32_t pod_spec, const char* const* keys, const char* const* values, int32_t n) {
     POD_CHECK(e, pod_spec);
     if (n < 0 || (n > 0 && (!keys || !values))) return CASIM_ERR_INVALID;
@@ -733,16 +822,31 @@ int32_t casim_enc_finalize(casim_encoder* e) {
     e->Wt = ((int)taint_id.size() + 63) / 64;
     stage.mark("taints");
     // (2) label requirements used by some PEG spec (nodeSelector pair == In{value})
-    std::map<std::string, int> lreq_id;
+    std::unordered_map<std::string, int> lreq_id;   // (ids are handed out in order of discovery; the map only finds them again)
     std::vector<Requirement> lreqs;
     std::vector<std::vector<int>> spec_lreqs(NS);
     std::vector<bool> spec_used(NS, false);
     for (auto& pg : e->pegs) spec_used[(size_t)pg.spec] = true;
+    std::string lreq_sig;
     for (size_t s = 0; s < NS; ++s) {
         if (!spec_used[s]) continue;
         PodSpec& p = e->specs[s];
-        std::vector<Requirement> all = p.node_affinity;
-        for (auto& kv : p.node_selector) { Requirement r; r.key = kv.first; r.op = kIn; r.values = {kv.second}; all.push_back(r); }
+        // the spec's requirements in the order nodeAffinity's one term, nodeSelector pairs, the ORed term list; `make` builds the
+        // dictionary entry only when the signature is new (a nodeSelector pair is In{value}: its signature is written without one)
+        auto visit = [&](const std::string& key, const std::string& sig, auto make) {
+            // every simulated node gets its own hostname label (node_info_utils.go:130): not a template property
+            // (per-node consumers pass real nodes: there the label is an ordinary one)
+            if (key == kHostname && !e->opt.explicit_self_exclusion) { p.unsupported = true; p.why = "node selector on kubernetes.io/hostname"; return; }
+            auto it = lreq_id.find(sig);
+            int id;
+            if (it == lreq_id.end()) { id = (int)lreqs.size(); lreq_id.emplace(sig, id); lreqs.push_back(make()); } else id = it->second;
+            spec_lreqs[s].push_back(id);
+        };
+        for (auto& r : p.node_affinity) visit(r.key, req_signature(r), [&] { return r; });
+        for (auto& kv : p.node_selector) {
+            lreq_sig.assign(1, (char)('0' + (int)kIn)); lreq_sig.push_back('\x1f'); lreq_sig.append(kv.first); lreq_sig.push_back('\x1f'); lreq_sig.append(kv.second);
+            visit(kv.first, lreq_sig, [&] { Requirement r; r.key = kv.first; r.op = kIn; r.values = {kv.second}; return r; });
+        }
         if (p.has_node_terms) {
             // the ORed term list is ONE dictionary entry: a node's bit = LazyErrorNodeSelector.Match of that node, evaluated
             // below with the node's labels and name.  Template mode: the nodes of an estimate get fresh names and hostname
@@ -750,17 +854,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
             bool per_node = false;
             for (auto& t : p.node_terms) { if (!t.fields.empty()) per_node = true; for (auto& x : t.exprs) if (x.key == kHostname) per_node = true; }
             if (per_node && !e->opt.explicit_self_exclusion) { p.unsupported = true; p.why = "node affinity term on metadata.name / kubernetes.io/hostname"; }
-            else { Requirement r; r.op = kNodeTerms; r.terms = p.node_terms; all.push_back(r); }
-        }
-        for (auto& r : all) {
-            // every simulated node gets its own hostname label (node_info_utils.go:130): not a template property
-            // (per-node consumers pass real nodes: there the label is an ordinary one)
-            if (r.key == kHostname && !e->opt.explicit_self_exclusion) { p.unsupported = true; p.why = "node selector on kubernetes.io/hostname"; continue; }
-            const std::string sig = req_signature(r);
-            auto it = lreq_id.find(sig);
-            int id;
-            if (it == lreq_id.end()) { id = (int)lreqs.size(); lreq_id[sig] = id; lreqs.push_back(r); } else id = it->second;
-            spec_lreqs[s].push_back(id);
+            else { Requirement r; r.op = kNodeTerms; r.terms = p.node_terms; visit(r.key, req_signature(r), [&] { return r; }); }
         }
     }
     e->Wl = ((int)lreqs.size() + 63) / 64;
@@ -902,9 +996,39 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         for (size_t i = 0; i < G; ++i)
             for (auto& t : e->specs[(size_t)e->pegs[i].spec].anti) if (t.topology_key == kHostname) { with_terms.push_back(i); break; }
         e->fs.with_terms = with_terms;
+        // Which PEGs can a term match at all?  A selector with an In requirement (matchLabels is one) only matches pods that CARRY one of
+        // its (key, value) pairs, so the candidates of such a term come from an index pair -> PEGs (ascending) instead of a walk over every
+        // PEG (C4: 200 PEGs with terms x 400 PEGs x a string compare = 1.7 of finalize's 2.2 ms).  A term without an In requirement keeps
+        // the full walk.  Candidates are visited in ascending PEG order, as before: the bits are handed out in order of discovery.
+        std::unordered_map<std::string, std::vector<int32_t>> pegs_of_pair;
+        std::string pair_sig;
+        auto pair_key = [&](const std::string& k, const std::string& v) -> const std::string& {
+            const uint32_t len = (uint32_t)k.size();
+            pair_sig.assign((const char*)&len, sizeof len); pair_sig.append(k); pair_sig.append(v);
+            return pair_sig;
+        };
+        if (!with_terms.empty())
+            for (size_t j = 0; j < G; ++j)
+                for (auto& kv : e->specs[(size_t)e->pegs[j].spec].labels) pegs_of_pair[pair_key(kv.first, kv.second)].push_back((int32_t)j);
+        std::vector<int32_t> cand;
         for (size_t i : with_terms) {
             const PodSpec& a = e->specs[(size_t)e->pegs[i].spec];
-            for (size_t j = 0; j < G; ++j) {
+            bool indexed = true;
+            cand.clear();
+            for (auto& t : a.anti) {
+                if (t.topology_key != kHostname) continue;
+                const Requirement* in = nullptr;
+                for (auto& r : t.selector) if (r.op == kIn) { in = &r; break; }
+                if (!in) { indexed = false; break; }
+                for (auto& v : in->values) {
+                    auto it = pegs_of_pair.find(pair_key(in->key, v));
+                    if (it != pegs_of_pair.end()) cand.insert(cand.end(), it->second.begin(), it->second.end());
+                }
+            }
+            if (indexed) { std::sort(cand.begin(), cand.end()); cand.erase(std::unique(cand.begin(), cand.end()), cand.end()); }
+            const size_t n_visit = indexed ? cand.size() : G;
+            for (size_t q = 0; q < n_visit; ++q) {
+                const size_t j = indexed ? (size_t)cand[q] : q;
                 const PodSpec& b = e->specs[(size_t)e->pegs[j].spec];
                 bool hit = false;
                 for (auto& t : a.anti) if (t.topology_key == kHostname && term_matches(t, b)) { hit = true; break; }
@@ -1211,7 +1335,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
                     // tolerates the taint: the ghost LEAVES its domain for the simulation (rule_ghost_leaves).
                     const Taint ghost{"ToBeDeletedByClusterAutoscaler", "0", "NoSchedule"};
                     bool tol = false;
-                    for (auto& t : p.tolerations) if (tolerates(t, ghost, e->opt.enable_taint_comparison_ops != 0)) { tol = true; break; }
+                    for (int32_t ti : p.tolerations) if (tolerates(e->tol_dict[(size_t)ti], ghost, e->opt.enable_taint_comparison_ops != 0)) { tol = true; break; }
                     r.ghost = tol ? 0 : 1;
                 }
                 rules.push_back(r);
@@ -1244,7 +1368,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
                     for (auto& tn : g.taints) {
                         if (tn.effect != "NoSchedule" && tn.effect != "NoExecute") continue;
                         bool tol = false;
-                        for (auto& t : p.tolerations) if (tolerates(t, tn, e->opt.enable_taint_comparison_ops != 0)) { tol = true; break; }
+                        for (int32_t ti : p.tolerations) if (tolerates(e->tol_dict[(size_t)ti], tn, e->opt.enable_taint_comparison_ops != 0)) { tol = true; break; }
                         if (!tol) { tolerated = false; break; }
                     }
                     for (int combo = 0; combo < 4; ++combo) {
@@ -1352,16 +1476,31 @@ int32_t casim_enc_finalize(casim_encoder* e) {
     e->zblock.assign(G * (size_t)Wz, 0); e->zmark.assign(G * (size_t)Wz, 0);
     e->fp_cpu.assign(G, 0.0); e->fp_mem.assign(G, 0.0);
     const Taint unsched{kUnschedulableTaint, "", "NoSchedule"};
+    // A PEG tolerates a taint when ONE of its tolerations does (v1helper.TolerationsTolerateTaint): its row is the OR of what each
+    // toleration tolerates.  PEG lists are mostly distinct, single tolerations are not (a few keys x operators x effects; interned when
+    // they arrive), so the verdicts are worked out once per distinct toleration a PEG uses — [Wt words, then one word for the
+    // unschedulable taint] — and ORed per PEG.
+    const size_t TW = (size_t)Wt + 1;
+    std::vector<uint64_t> tol_rows(e->tol_dict.size() * TW, 0);
+    std::vector<uint8_t> tol_row_done(e->tol_dict.size(), 0);
+    auto toleration_row = [&](int32_t ti) -> size_t {
+        const size_t at = (size_t)ti * TW;
+        if (tol_row_done[(size_t)ti]) return at;
+        tol_row_done[(size_t)ti] = 1;
+        const Toleration& t = e->tol_dict[(size_t)ti];
+        for (auto& kv : taint_id) if (tolerates(t, kv.first, cmp_ops)) tol_rows[at + (size_t)(kv.second >> 6)] |= 1ull << (kv.second & 63);
+        if (tolerates(t, unsched, cmp_ops)) tol_rows[at + (size_t)Wt] = 1;
+        return at;
+    };
     for (size_t i = 0; i < G; ++i) {
         const PodSpec& p = e->specs[(size_t)e->pegs[i].spec];
         for (int r = 0; r < R; ++r) e->req[i * (size_t)R + (size_t)r] = p.req[r];
         e->count[i] = e->pegs[i].count;
         uint32_t f = pflags[i];
-        for (auto& t : p.tolerations) if (tolerates(t, unsched, cmp_ops)) { f |= CASIM_PEG_TOLERATES_UNSCHEDULABLE; break; }
-        for (auto& kv : taint_id) {
-            bool ok = false;
-            for (auto& t : p.tolerations) if (tolerates(t, kv.first, cmp_ops)) { ok = true; break; }
-            if (ok) set_bit(e->tol, i, Wt, kv.second);
+        for (int32_t ti : p.tolerations) {
+            const size_t at = toleration_row(ti);
+            for (int w = 0; w < Wt; ++w) e->tol[i * (size_t)Wt + (size_t)w] |= tol_rows[at + (size_t)w];
+            if (tol_rows[at + (size_t)Wt]) f |= CASIM_PEG_TOLERATES_UNSCHEDULABLE;
         }
         for (int id : spec_lreqs[(size_t)e->pegs[i].spec]) set_bit(e->sel, i, Wl, id);
         // ports: any host port conflicts with a second copy of the same pod
@@ -1620,7 +1759,7 @@ int32_t casim_enc_refinalize(casim_encoder* e, int32_t* changed_out, int32_t cap
                 for (auto& tn : g.taints) {
                     if (tn.effect != "NoSchedule" && tn.effect != "NoExecute") continue;
                     bool tol = false;
-                    for (auto& t : p.tolerations) if (tolerates(t, tn, cmp_ops)) { tol = true; break; }
+                    for (int32_t ti : p.tolerations) if (tolerates(e->tol_dict[(size_t)ti], tn, cmp_ops)) { tol = true; break; }
                     if (!tol) { tolerated = false; break; }
                 }
                 for (int combo = 0; combo < 4; ++combo) {
@@ -1771,7 +1910,7 @@ std::string canonical_spec(const PodSpec& p, int R) {
     put_i(o, (int64_t)p.labels.v.size());
     for (auto& kv : p.labels.v) { put(o, kv.first); put(o, kv.second); }     // (sorted by key: a Go map has no order)
     put_i(o, (int64_t)p.tolerations.size());
-    for (auto& t : p.tolerations) { put(o, t.key); put_i(o, t.op); put(o, t.value); put(o, t.effect); }
+    for (int32_t ti : p.tolerations) put_i(o, ti);   // (interned: equal ids == equal (key, operator, value, effect))
     std::vector<std::pair<std::string, std::string>> ns = p.node_selector;   // map[string]string
     std::sort(ns.begin(), ns.end());
     put_i(o, (int64_t)ns.size());

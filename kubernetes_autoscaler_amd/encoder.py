@@ -4,7 +4,7 @@ It walks pod / node-template objects exactly the way the cgo shim of INTEGRATION
 returns flat tables (ctypes views owned by the C++ encoder)."""
 import ctypes as C
 import dataclasses
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Tuple
 
 from . import _abi
 from ._ffi import check, lib
@@ -79,22 +79,36 @@ class Encoder:
             return self._spec_of[key]
         self._keep.append(pod)
         h = self._h
-        unknown = [r for r, v in pod.requests.items() if r not in self.lanes and v] if not self.named_lanes else []
         s = lib.casim_enc_add_pod_spec(h, _b(pod.namespace), self._lane_vector(pod.requests))
         if s < 0:
             check(s, "casim_enc_add_pod_spec")
-        if self.named_lanes:   # ScalarResources by name (fit.go:731-763); CASIM_ENC_DELEGATED (1) = no lane left, the pod is marked unsupported
-            for name, v in pod.requests.items():
-                if name not in (RES_CPU, RES_MEMORY, RES_EPHEMERAL):
-                    rc = lib.casim_enc_pod_set_request(h, s, _b(name), int(v))
-                    if rc < 0:
-                        check(rc, "casim_enc_pod_set_request")
+        self._named_requests(pod, s)
         for k, v in pod.labels.items():
             check(lib.casim_enc_pod_add_label(h, s, _b(k), _b(v)))
         for t in pod.tolerations:
             check(lib.casim_enc_pod_add_toleration(h, s, _b(t.key), _b(t.operator), _b(t.value), _b(t.effect)))
         for k, v in pod.node_selector.items():
             check(lib.casim_enc_pod_add_node_selector(h, s, _b(k), _b(v)))
+        cpu, mem = pod.fastpath_requests()
+        check(lib.casim_enc_pod_set_fastpath_requests(h, s, cpu, mem))
+        self._pod_rest(pod, s)
+        self._spec_of[key] = s
+        return s
+
+    def _named_requests(self, pod: Pod, s: int):
+        if self.named_lanes:   # ScalarResources by name (fit.go:731-763); CASIM_ENC_DELEGATED (1) = no lane left, the pod is marked unsupported
+            for name, v in pod.requests.items():
+                if name not in (RES_CPU, RES_MEMORY, RES_EPHEMERAL):
+                    rc = lib.casim_enc_pod_set_request(self._h, s, _b(name), int(v))
+                    if rc < 0:
+                        check(rc, "casim_enc_pod_set_request")
+
+    def _pod_rest(self, pod: Pod, s: int, digest: bool = True):
+        """What casim_enc_add_pods (ABI 11) has no column for: node affinity, host ports, (anti-)affinity terms, spread constraints, marks, the
+        grouping digest — per-pod calls on spec record `s`, after its namespace / requests / labels / tolerations / nodeSelector / fastpath
+        requests are in (pod by pod: add_pod_spec; in bulk: add_pegs)."""
+        h = self._h
+        unknown = [r for r, v in pod.requests.items() if r not in self.lanes and v] if not self.named_lanes else []
         for r in pod.node_affinity:
             check(lib.casim_enc_pod_add_node_affinity_req(h, s, _b(r.key), _b(r.operator), _strs(r.values), len(r.values)))
         for term in (pod.node_affinity_terms or [NodeSelectorTerm()] if pod.node_affinity_terms is not None else []):
@@ -126,8 +140,6 @@ class Encoder:
                     check(lib.casim_enc_aff_term_add_namespace_requirement(h, s, t, _b(r.key), _b(r.operator), _strs(r.values), len(r.values)))
             for r in term.requirements():
                 check(lib.casim_enc_aff_term_add_requirement(h, s, t, _b(r.key), _b(r.operator), _strs(r.values), len(r.values)))
-        cpu, mem = pod.fastpath_requests()
-        check(lib.casim_enc_pod_set_fastpath_requests(h, s, cpu, mem))
         for sc in pod.spread_constraints:   # evaluated on the device in per-node mode, flagged UNSUPPORTED by finalize otherwise
             ci = lib.casim_enc_pod_add_spread_constraint(h, s, int(sc.max_skew), _b(sc.topology_key), int(sc.min_domains))
             if ci < 0:
@@ -148,12 +160,91 @@ class Encoder:
             check(lib.casim_enc_pod_mark_unsupported(h, s, _b(pod.unsupported_reason)))
         if unknown:
             check(lib.casim_enc_pod_mark_unsupported(h, s, _b("resource not in lanes: " + ",".join(unknown))))
+        if not digest:
+            return
         # grouping only: the fields PodSpecSemanticallyEqual compares that the encoder has no call for
         extra = repr((pod.spec_extra, pod.has_containers, pod.topology_spread, tuple(tuple(c.match_label_keys) for c in pod.spread_constraints),
                       tuple(tuple(sorted(c.match_labels.items())) for c in pod.spread_constraints)))
         check(lib.casim_enc_pod_set_spec_extra(h, s, _b(extra)))
-        self._spec_of[key] = s
-        return s
+
+    def add_pegs(self, pegs: Sequence[PodEquivalenceGroup], digests: bool = True) -> List[int]:
+        """The PEGs of a loop through casim_enc_add_pods (ABI 11): ONE crossing for every exemplar's namespace, requests, labels, tolerations,
+        nodeSelector and fastpath requests, strings by index into an interned table; the rarer fields follow pod by pod (_pod_rest).  Builds the
+        same records, PEG ids and tables as add_peg called in a loop (tests/test_bulk_pods.py); what integration/go/gpubinpacking/encode.go
+        (session.pegs) does.  An exemplar that already has a spec record (two PEGs, one pod object) ends the run and takes add_peg.
+        digests=False leaves out casim_enc_pod_set_spec_extra (read by casim_enc_group_pods only: the Go shim's Estimate path never sets it — its PEGs
+        arrive grouped); keep the default when the same pod objects may go through group_pods later."""
+        import numpy as np
+        out: List[int] = []
+        run: List[Tuple[PodEquivalenceGroup, Pod]] = []
+        in_run = set()
+
+        def flush():
+            if not run:
+                return
+            strs: Dict[str, int] = {}
+            table: List[bytes] = []
+
+            def sid(x) -> int:
+                if x is None:
+                    return -1
+                i = strs.get(x)
+                if i is None:
+                    i = strs[x] = len(table)
+                    table.append(_b(x))
+                return i
+            n = len(run)
+            R = len(self.lanes)
+            ns = np.empty(n, np.int32); req = np.zeros((n, R), np.int64); fp = np.empty((n, 2), np.float64); cnt = np.empty(n, np.int32)
+            loff, lk, lv = [0], [], []
+            toff, tk, to, tv, te = [0], [], [], [], []
+            soff, sk, sv = [0], [], []
+            for i, (pg, ex) in enumerate(run):
+                ns[i] = sid(ex.namespace)
+                for r, name in enumerate(self.lanes):
+                    req[i, r] = int(ex.requests.get(name, 0))
+                fp[i] = ex.fastpath_requests()
+                cnt[i] = len(pg.pods)
+                for k, v in ex.labels.items():
+                    lk.append(sid(k)); lv.append(sid(v))
+                loff.append(len(lk))
+                for t in ex.tolerations:
+                    tk.append(sid(t.key)); to.append(sid(t.operator)); tv.append(sid(t.value)); te.append(sid(t.effect))
+                toff.append(len(tk))
+                for k, v in ex.node_selector.items():
+                    sk.append(sid(k)); sv.append(sid(v))
+                soff.append(len(sk))
+            cols = [np.asarray(a, np.int32) for a in (loff, lk, lv, toff, tk, to, tv, te, soff, sk, sv)]
+            keep = [ns, req, fp, cnt] + cols
+            ptr = lambda a: a.ctypes.data_as(_abi.i32p)   # noqa: E731
+            pc = _abi.PodColumns(n_pods=n, n_strings=len(table), strings=(C.c_char_p * max(len(table), 1))(*table), ns=ptr(ns),
+                                 req=req.ctypes.data_as(_abi.i64p), fastpath_req=fp.ctypes.data_as(_abi.f64p), peg_count=ptr(cnt),
+                                 label_off=ptr(cols[0]), label_key=ptr(cols[1]), label_val=ptr(cols[2]),
+                                 tol_off=ptr(cols[3]), tol_key=ptr(cols[4]), tol_op=ptr(cols[5]), tol_value=ptr(cols[6]), tol_effect=ptr(cols[7]),
+                                 sel_off=ptr(cols[8]), sel_key=ptr(cols[9]), sel_val=ptr(cols[10]))
+            peg_ids = np.empty(n, np.int32)
+            first = lib.casim_enc_add_pods(self._h, C.byref(pc), ptr(peg_ids))
+            if first < 0:
+                check(first, "casim_enc_add_pods")
+            del keep
+            for i, (pg, ex) in enumerate(run):
+                self._keep.append(ex)
+                self._named_requests(ex, first + i)
+                self._pod_rest(ex, first + i, digest=digests)
+                self._spec_of[id(ex)] = first + i
+                out.append(int(peg_ids[i]))
+            self.n_pegs += n
+            run.clear(); in_run.clear()
+
+        for pg in pegs:
+            ex = pg.exemplar()
+            if ex is None or id(ex) in self._spec_of or id(ex) in in_run:
+                flush()
+                out.append(self.add_peg(pg))
+                continue
+            run.append((pg, ex)); in_run.add(id(ex))
+        flush()
+        return out
 
     def add_peg(self, peg: PodEquivalenceGroup) -> int:
         ex = peg.exemplar()

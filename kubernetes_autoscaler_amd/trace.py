@@ -50,6 +50,9 @@ class CallTrace:
             self.n_res = int(o.n_res)
             self.lines.append("\t".join([name, str(o.n_res), str(o.enable_taint_comparison_ops), str(o.explicit_self_exclusion)]))
             return
+        if name == "casim_enc_add_pods":
+            self.lines.append("\t".join([name] + self._pod_columns(args[1]._obj if hasattr(args[1], "_obj") else args[1].contents)))
+            return
         argtypes = _abi.PROTOTYPES[name][1]
         arrays = _ARRAYS.get(name, {})
         toks = [name]
@@ -85,6 +88,25 @@ class CallTrace:
             else:
                 raise ValueError(f"{name}: cannot serialise argument {i} of type {t}")
         self.lines.append("\t".join(toks))
+
+
+    def _pod_columns(self, pc):
+        """casim_pod_columns as tokens: n_pods, the string table, then every column as (count, items...) — 0 items = a NULL column."""
+        n = int(pc.n_pods)
+
+        def arr(ptr, count, fmt=lambda x: str(int(x))):
+            if not ptr or count <= 0:
+                return ["0"]
+            return [str(count)] + [fmt(ptr[k]) for k in range(count)]
+        toks = [str(n), str(int(pc.n_strings))] + [_esc(pc.strings[k]) for k in range(int(pc.n_strings))]
+        toks += arr(pc.ns, n) + arr(pc.req, n * self.n_res) + arr(pc.fastpath_req, 2 * n, lambda x: repr(float(x))) + arr(pc.peg_count, n)
+        for off, cols in ((pc.label_off, (pc.label_key, pc.label_val)), (pc.tol_off, (pc.tol_key, pc.tol_op, pc.tol_value, pc.tol_effect)),
+                          (pc.sel_off, (pc.sel_key, pc.sel_val))):
+            total = int(off[n]) if off and n > 0 else 0
+            toks += arr(off, n + 1 if off else 0)
+            for c in cols:
+                toks += arr(c, total)
+        return toks
 
 
 class _RecordingLib:

@@ -30,13 +30,13 @@ using clk = std::chrono::steady_clock;
 double ms_since(clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); }
 
 // argument kinds of one trace line: i = int32, l = int64, d = double, s = string (may be NULL), S = string array,
-// A = int64 array, a = int32 array (arrays: count followed by the items)
+// A = int64 array, a = int32 array, D = double array (arrays: count followed by the items)
 struct Sig { int op; const char* args; };
 enum Op {
     CREATE, ADD_GROUP, GROUP_LABEL, GROUP_TAINT, GROUP_FP_CAP, GROUP_LIMITS, GROUP_PRELOADED, GROUP_SET_PEGS, ADD_POD_SPEC, POD_LABEL,
     POD_TOLERATION, POD_NODE_SELECTOR, POD_NODE_AFF_REQ, POD_NODE_AFF_TERM, NODE_TERM_REQ, POD_HOST_PORT, POD_AA_TERM, TERM_REQ,
     POD_AFF_TERM, AFF_TERM_REQ, POD_SPREAD, SPREAD_REQ, SPREAD_TAINTS, SPREAD_AFFINITY, ADD_NAMESPACE, NAMESPACE_LABEL, TERM_NS_SELECTOR, TERM_NS_REQ, AFF_TERM_NS_SELECTOR, AFF_TERM_NS_REQ, POD_FP_REQ,
-    POD_UNSUPPORTED, POD_SPEC_EXTRA, ADD_PEG, ADD_RESOURCE_PEGS, ADD_EXISTING_POD, FINALIZE, ENC_LANE, POD_SET_REQUEST, GROUP_SET_ALLOCATABLE, LANE_COUNT, LANE_NAME
+    POD_UNSUPPORTED, POD_SPEC_EXTRA, ADD_PEG, ADD_RESOURCE_PEGS, ADD_EXISTING_POD, FINALIZE, ENC_LANE, POD_SET_REQUEST, GROUP_SET_ALLOCATABLE, LANE_COUNT, LANE_NAME, ADD_PODS
 };
 const std::map<std::string, Sig> kSigs = {
     {"casim_enc_create", {CREATE, "iii"}},
@@ -81,6 +81,8 @@ const std::map<std::string, Sig> kSigs = {
     {"casim_enc_group_set_allocatable", {GROUP_SET_ALLOCATABLE, "isl"}},
     {"casim_enc_lane_count", {LANE_COUNT, ""}},
     {"casim_enc_lane_name", {LANE_NAME, "i"}},
+    // casim_pod_columns (ABI 11): n_pods, strings, ns, req, fastpath_req, peg_count, label_off / key / val, tol_off / key / op / value / effect, sel_off / key / val
+    {"casim_enc_add_pods", {ADD_PODS, "iSaADaaaaaaaaaaaa"}},
 };
 
 struct Call {
@@ -93,6 +95,7 @@ struct Call {
     std::vector<std::vector<const char*>> SA;
     std::vector<std::vector<int64_t>> A64;
     std::vector<std::vector<int32_t>> A32;
+    std::vector<std::vector<double>> AD;
     const char* s(size_t k) const { return S_null[k] ? nullptr : S[k].c_str(); }
 };
 
@@ -140,6 +143,7 @@ bool parse_trace(const char* path, std::vector<Call>& calls, Directive& dir, std
                 const size_t n = (size_t)strtoll(t[k++].c_str(), nullptr, 10);
                 if (!need(n)) return false;
                 if (*a == 'S') { c.SA_store.emplace_back(); for (size_t j = 0; j < n; ++j) c.SA_store.back().push_back(unesc(t[k++])); }
+                else if (*a == 'D') { c.AD.emplace_back(); for (size_t j = 0; j < n; ++j) c.AD.back().push_back(strtod(t[k++].c_str(), nullptr)); }
                 else if (*a == 'A') { c.A64.emplace_back(); for (size_t j = 0; j < n; ++j) c.A64.back().push_back(strtoll(t[k++].c_str(), nullptr, 10)); }
                 else { c.A32.emplace_back(); for (size_t j = 0; j < n; ++j) c.A32.back().push_back((int32_t)strtoll(t[k++].c_str(), nullptr, 10)); }
             }
@@ -206,6 +210,16 @@ int32_t replay(const std::vector<Call>& calls, size_t n_calls, casim_encoder*& e
         case GROUP_SET_ALLOCATABLE: rc = casim_enc_group_set_allocatable(e, (int32_t)I[0], c.s(0), I[1]); break;
         case LANE_COUNT: (void)casim_enc_lane_count(e); rc = 0; break;
         case LANE_NAME: (void)casim_enc_lane_name(e, (int32_t)I[0]); rc = 0; break;
+        case ADD_PODS: {
+            casim_pod_columns pc; memset(&pc, 0, sizeof pc);
+            auto col = [&](size_t k) -> const int32_t* { return c.A32[k].empty() ? nullptr : c.A32[k].data(); };
+            pc.n_pods = (int32_t)I[0]; pc.n_strings = (int32_t)c.SA_store[0].size(); pc.strings = c.SA[0].data();
+            pc.ns = col(0); pc.req = c.A64[0].data(); pc.fastpath_req = c.AD[0].empty() ? nullptr : c.AD[0].data(); pc.peg_count = col(1);
+            pc.label_off = col(2); pc.label_key = col(3); pc.label_val = col(4);
+            pc.tol_off = col(5); pc.tol_key = col(6); pc.tol_op = col(7); pc.tol_value = col(8); pc.tol_effect = col(9);
+            pc.sel_off = col(10); pc.sel_key = col(11); pc.sel_val = col(12);
+            rc = casim_enc_add_pods(e, &pc, nullptr); break;
+        }
         default: rc = -1;
         }
         if (rc < 0) { fprintf(stderr, "casim_native: encoder call (op %d) failed with %d: %s\n", c.op, rc, casim_last_error()); return rc; }

@@ -41,14 +41,18 @@ def tables_fnv(pegs, groups) -> str:
     return f"{h:016x}"
 
 
-def trace_estimate(w, path, kinds=(0,), iters=20, device_subsets=True):
-    """One scale-up simulation (a workloads.Workload) -> trace file.  Returns the finalized encoder (caller closes)."""
+def trace_estimate(w, path, kinds=(0,), iters=20, device_subsets=True, bulk=True):
+    """One scale-up simulation (a workloads.Workload) -> trace file.  Returns the finalized encoder (caller closes).
+    bulk: the PEGs through casim_enc_add_pods (ABI 11, what integration/go/gpubinpacking does: Encoder.add_pegs); False: pod by pod."""
     from kubernetes_autoscaler_amd import trace as tr
     from kubernetes_autoscaler_amd.encoder import Encoder
     with tr.recording() as t:
         enc = Encoder(lanes=w.lanes)
-        for pg in w.pegs:
-            enc.add_peg(pg)
+        if bulk:
+            enc.add_pegs(w.pegs, digests=False)   # (the shim's sequence: the grouping digest is read by casim_enc_group_pods only)
+        else:
+            for pg in w.pegs:
+                enc.add_peg(pg)
         for info in w.existing:
             for p in info.pods:
                 enc.add_existing_pod(p, info.node.labels)
@@ -106,6 +110,19 @@ def run_native(trace_path, dump=None, repeat=3, device=0, timeout=600, shim=Fals
     except ValueError:
         out = {"raw": p.stdout[-500:], "stderr": p.stderr[-500:]}
     return p.returncode, out
+
+
+def encode_only(w, path, bulk, repeat=9):
+    """The encoder half alone through casim_native (no engine directive: nothing touches a device): median native milliseconds of the
+    casim_enc_* calls and of finalize, the number of calls, the tables' hash — bulk (casim_enc_add_pods) or pod by pod."""
+    trace_estimate(w, path, bulk=bulk).close()
+    with open(path) as f:
+        lines = [ln for ln in f.read().splitlines() if ln and not ln.startswith("@")]
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    rc, out = run_native(path, repeat=repeat)
+    keep = ("enc_calls", "encode_calls_ms", "finalize_ms", "encode_ms", "tables_fnv")
+    return dict({k: out[k] for k in keep if k in out}, exit_code=rc)
 
 
 def read_dump(path):
