@@ -1299,6 +1299,64 @@ def sched_issue_roofline(row, kernels_ms):
         return {"error": f"no committed counters for this row: {type(e).__name__}: {e}"}
 
 
+def removal_row(kaa, ctx, OracleScenario, w2, counters_row, ext_capacity=None):
+    """One scale-down removal workload on the device — the kernel the library picks, then K_sched's general loop forced — and through
+    the oracle's native call: kernel times, the A/B, bit-exactness in every field.  counters_row: name of the profiles/sched_counters.json row or None."""
+    import numpy as np
+    e2 = kaa.Encoder(explicit_self_exclusion=True)
+    cls, pcl, off = {}, [], [0]
+    for c in w2.candidates:
+        for p in w2.nodes[c].pods:
+            k = p.spec_key()
+            if k not in cls:
+                cls[k] = e2.add_peg(kaa.PodEquivalenceGroup(pods=[p]))
+            pcl.append(cls[k])
+        off.append(len(pcl))
+    for info in w2.nodes:
+        e2.add_group(info, pegs=[])
+    e2.finalize()
+    kw = {} if ext_capacity is None else {"ext_capacity": ext_capacity}
+    r2 = ctx.simulate_node_removals(e2.pegs, e2.groups, w2.candidates, off, pcl, **kw)
+    kern2 = ctx.last_removals_info()
+    _, ms2 = ctx.simulate_node_removals(e2.pegs, e2.groups, w2.candidates, off, pcl, time_iters=5, **kw)
+    # A/B: the same call through K_sched's general transaction loop (CASIM_NO_LEAN_REMOVALS is read when the call is prepared)
+    prev = os.environ.get("CASIM_NO_LEAN_REMOVALS")
+    os.environ["CASIM_NO_LEAN_REMOVALS"] = "1"
+    try:
+        r2b = ctx.simulate_node_removals(e2.pegs, e2.groups, w2.candidates, off, pcl, **kw)
+        _, ms2b = ctx.simulate_node_removals(e2.pegs, e2.groups, w2.candidates, off, pcl, time_iters=5, **kw)
+    finally:
+        if prev is None:
+            del os.environ["CASIM_NO_LEAN_REMOVALS"]
+        else:
+            os.environ["CASIM_NO_LEAN_REMOVALS"] = prev
+    same2 = bool(np.array_equal(r2.removable, r2b.removable) and np.array_equal(r2.node_out, r2b.node_out) and int(r2.last_index) == int(r2b.last_index))
+    e2.close()
+    s = OracleScenario()
+    for info in w2.nodes:
+        s.add_existing(info)
+    lists = [list(w2.nodes[c].pods) for c in w2.candidates]
+    for lst in lists:
+        for p in lst:
+            s.pod(p)
+    want2 = s.simulate_node_removals(w2.candidates, lists, None, None, True, 0, None, ext_capacity, 0, None)
+    oracle2_ms = s.last_native_s * 1e3
+    s.close()
+    ext_same = [tuple(x) for x in zip(r2.ext_candidate.tolist(), r2.ext_pod.tolist(), r2.ext_node.tolist())] == [tuple(x) for x in want2["ext"]]
+    exact2 = bool(np.array_equal(np.asarray(r2.removable), want2["removable"]) and np.array_equal(np.asarray(r2.node_out), want2["node_out"]) and
+                  int(r2.last_index) == want2["last_index"] and int(r2.n_processed) == want2["n_processed"] and ext_same)
+    row = {"workload": w2.name, "nodes": len(w2.nodes), "candidates": len(w2.candidates),
+           "removable": int((r2.removable == 1).sum()), "pods_moved": len(pcl), "pods_listed_again": len(want2["ext"]),
+           "kernel": "removals_lean_kernel (one wave over per-class fit masks)" if kern2["lean"] else "sched_kernel (K_sched's transaction loop)",
+           "kernels_ms": ms2, "candidates_per_s": len(w2.candidates) / (ms2 * 1e-3),
+           "kernels_ms_k_sched": ms2b, "same_results_as_k_sched": same2,
+           "oracle_ms": oracle2_ms, "bit_exact": exact2, "speedup_vs_oracle_kernels": oracle2_ms / ms2,
+           "cpu_baseline": {"kind": "port", "cores": 1, "what": "orc_simulate_node_removals, the native call alone"}}
+    if counters_row:
+        row["issue_roofline"] = sched_issue_roofline(counters_row, ms2)
+    return row
+
+
 def next_rows(kaa, ctx, workloads):
     """The callers either side of the path, one mid-size case each: resident tables, HIP-event time; the oracle on the
     same input beside it (one host core, the native call alone), bit-exact flag, issue roofline of K_sched."""
@@ -1338,55 +1396,16 @@ def next_rows(kaa, ctx, workloads):
                                 "speedup_vs_oracle_call": oracle1_ms / call_ms, "cpu_baseline": {"kind": "port", "cores": 1, "what": "orc_try_schedule_pods, the native call alone"},
                                 "issue_roofline": sched_issue_roofline("try_schedule_pods", ms1)}
     e1.close()
-    w2 = workloads.removal_scale(5000, pods_per_node=12, frac_candidates=0.3, seed=1)
-    e2 = kaa.Encoder(explicit_self_exclusion=True)
-    cls, pcl, off = {}, [], [0]
-    for c in w2.candidates:
-        for p in w2.nodes[c].pods:
-            k = p.spec_key()
-            if k not in cls:
-                cls[k] = e2.add_peg(kaa.PodEquivalenceGroup(pods=[p]))
-            pcl.append(cls[k])
-        off.append(len(pcl))
-    for info in w2.nodes:
-        e2.add_group(info, pegs=[])
-    e2.finalize()
-    r2 = ctx.simulate_node_removals(e2.pegs, e2.groups, w2.candidates, off, pcl)
-    kern2 = ctx.last_removals_info()
-    _, ms2 = ctx.simulate_node_removals(e2.pegs, e2.groups, w2.candidates, off, pcl, time_iters=5)
-    # A/B: the same call through K_sched's general transaction loop (CASIM_NO_LEAN_REMOVALS is read when the call is prepared)
-    prev = os.environ.get("CASIM_NO_LEAN_REMOVALS")
-    os.environ["CASIM_NO_LEAN_REMOVALS"] = "1"
+    out["node_removals"] = removal_row(kaa, ctx, OracleScenario, workloads.removal_scale(5000, pods_per_node=12, frac_candidates=0.3, seed=1), "node_removals")
+    # R3 = the reference's own benchmark of this loop: BenchmarkRunOnceScaleDown (core/bench/benchmark_runonce_test.go:505-521), 400 nodes at 40 %,
+    # every node a candidate, verifyToBeDeleted(240) — tests/golden/reference_vectors.json: benchmark_runonce_scale_down
     try:
-        r2b = ctx.simulate_node_removals(e2.pegs, e2.groups, w2.candidates, off, pcl)
-        _, ms2b = ctx.simulate_node_removals(e2.pegs, e2.groups, w2.candidates, off, pcl, time_iters=5)
-    finally:
-        if prev is None:
-            del os.environ["CASIM_NO_LEAN_REMOVALS"]
-        else:
-            os.environ["CASIM_NO_LEAN_REMOVALS"] = prev
-    same2 = bool(np.array_equal(r2.removable, r2b.removable) and np.array_equal(r2.node_out, r2b.node_out) and int(r2.last_index) == int(r2b.last_index))
-    e2.close()
-    s = OracleScenario()
-    for info in w2.nodes:
-        s.add_existing(info)
-    lists = [list(w2.nodes[c].pods) for c in w2.candidates]
-    for lst in lists:
-        for p in lst:
-            s.pod(p)
-    want2 = s.simulate_node_removals(w2.candidates, lists, None, None, True, 0, None, None, 0, None)
-    oracle2_ms = s.last_native_s * 1e3
-    s.close()
-    exact2 = bool(np.array_equal(np.asarray(r2.removable), want2["removable"]) and np.array_equal(np.asarray(r2.node_out), want2["node_out"]) and
-                  int(r2.last_index) == want2["last_index"] and int(r2.n_processed) == want2["n_processed"])
-    out["node_removals"] = {"workload": w2.name, "nodes": len(w2.nodes), "candidates": len(w2.candidates),
-                            "removable": int((r2.removable == 1).sum()), "pods_moved": len(pcl),
-                            "kernel": "removals_lean_kernel (one wave over per-class fit masks)" if kern2["lean"] else "sched_kernel (K_sched's transaction loop)",
-                            "kernels_ms": ms2, "candidates_per_s": len(w2.candidates) / (ms2 * 1e-3),
-                            "kernels_ms_k_sched": ms2b, "same_results_as_k_sched": same2,
-                            "oracle_ms": oracle2_ms, "bit_exact": exact2, "speedup_vs_oracle_kernels": oracle2_ms / ms2,
-                            "cpu_baseline": {"kind": "port", "cores": 1, "what": "orc_simulate_node_removals, the native call alone"},
-                            "issue_roofline": sched_issue_roofline("node_removals", ms2)}
+        r3 = removal_row(kaa, ctx, OracleScenario, workloads.runonce_scale_down(400), None, ext_capacity=64 * 1024)
+        r3["reference_answer"] = {"to_be_deleted": 240, "matches": r3["removable"] == 240,
+                                  "source": "BenchmarkRunOnceScaleDown: verifyToBeDeleted(240), core/bench/benchmark_runonce_test.go:505-521"}
+        out["node_removals_runonce_scale_down"] = r3
+    except Exception as e:  # a side table must never take the headline down
+        out["node_removals_runonce_scale_down"] = {"error": f"{type(e).__name__}: {e}"}
     out["group_pods"] = group_pods_row()
     out["incremental_encode"] = incremental_encode_row()
     return out

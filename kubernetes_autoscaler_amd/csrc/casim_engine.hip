@@ -1175,6 +1175,7 @@ int32_t casim_time_node_removals(casim_ctx* ctx, const casim_pegs* classes, cons
     int32_t rc = s.init_removals(classes, nodes, cand);
     if (rc != CASIM_OK) { if (rc < 0) set_err(rc, s.error()); return rc; }
     rc = s.run();
+    if (rc == CASIM_OK) rc = s.confirm_kernel();   // (a one-wave kernel whose LDS log is smaller than the worst case may have given up: time what answers)
     hipEvent_t e0, e1;
     bk.check(hipEventCreate(&e0), "hipEventCreate"); bk.check(hipEventCreate(&e1), "hipEventCreate");
     bk.check(hipEventRecord(e0, bk.stream), "hipEventRecord");

@@ -1029,6 +1029,9 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
         auto ref_at = [&](int i) -> int32_t { return i < n_own ? p_lo + i : (i < kLeanTxnCap ? txn_ref[i] : a.ext_ref[e_lo + (i - n_own)]); };
         auto class_at = [&](int i) -> int32_t { return i < kLeanTxnCap ? txn_cls[i] : a.pod_class[ref_at(i)]; };
         if (ok && a.persist) {
+            // The log was sized to what LDS holds when the worst case (every pod of the call and every ext slot committed) does not fit: a
+            // commit that would run past it ends the kernel with out[5] = 1 and the host runs the call again through K_sched (fetch_removals).
+            if (log_n + n_listed > log_cap) { if (lane == 0) a.out[5] = 1; return; }
             // Commit (withForkedSnapshot :174-188): the ghost leaves the list (:230) and the destination set (planner.go:318)
             for (int i = lane; i < n_listed; i += 64) {
                 const int m = placed_at(i);
@@ -1066,6 +1069,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
         a.out[2] = runs_done;
         a.out[3] = cand_done;
         a.out[4] = ext_n;
+        a.out[5] = 0;
     }
 }
 
@@ -1210,7 +1214,29 @@ public:
             // (the log of committed moves sits in LDS as 16-bit node and pod indices)
             lean_log_cap_ = (int32_t)(((int64_t)P_ + (cand->ext_capacity > 0 ? cand->ext_capacity : 0) + 255) & ~255ll);
             lean_smem_ = (size_t)casim_lean_removal_bytes(R, C_, round_up64_((int64_t)N_), lean_log_cap_);
+            // The worst case — every pod of the call and every ext slot a committed move — rarely happens: a removal that fails commits
+            // nothing, and ext_capacity is a bound the caller picks generously.  When it does not fit, the log gets what LDS has left (at least a
+            // quarter of the worst case, or the attempt is not worth a launch); the kernel gives up at the commit that would overflow it and
+            // fetch_removals / confirm_kernel run the call again through K_sched.  Results are those of whichever kernel finished.
+            lean_optimistic_ = false;
+            if (const char* ev = getenv("CASIM_LEAN_LOG_CAP")) {   // tests: a log of this many entries, so that the give-up path runs on small cases
+                const int v = atoi(ev) & ~255;
+                if (v >= 256 && v < lean_log_cap_) {
+                    lean_log_cap_ = v; lean_optimistic_ = true;
+                    lean_smem_ = (size_t)casim_lean_removal_bytes(R, C_, round_up64_((int64_t)N_), lean_log_cap_);
+                }
+            }
+            if (lean_smem_ > bk_.lds_budget() && !(getenv("CASIM_NO_OPTIMISTIC_LOG") && atoi(getenv("CASIM_NO_OPTIMISTIC_LOG")) != 0)) {
+                const int64_t fixed = casim_lean_removal_bytes(R, C_, round_up64_((int64_t)N_), 0);
+                const int64_t room = (((int64_t)bk_.lds_budget() - fixed - 8) / 5) & ~255ll;
+                if (room >= 256 && room * 4 >= lean_log_cap_) {
+                    lean_log_cap_ = (int32_t)room;
+                    lean_smem_ = (size_t)casim_lean_removal_bytes(R, C_, round_up64_((int64_t)N_), lean_log_cap_);
+                    lean_optimistic_ = true;
+                }
+            }
             lean_ = plain && N_ <= 65536 && P_ <= 65536 && lean_smem_ <= bk_.lds_budget();
+            if (!lean_) lean_optimistic_ = false;
         }
         if (lean_) max_threads = 64;   // (cap_ = the node count rounded up to whole words)
         threads_ = (int)(round_up64_((int64_t)N_) < max_threads ? round_up64_((int64_t)N_) : max_threads);
@@ -1399,6 +1425,11 @@ public:
             if (out->ext_node) bk_.d2h(s_en, a_.node_out + P_, eb);
         }
         bk_.sync();
+        if (lean_ && lean_optimistic_ && bk_.ok() && o[5] == 1) {   // the log overflowed: the general loop answers (run() re-initialises every output)
+            lean_ = false; lean_optimistic_ = false; lean_gave_up_ = true;
+            const int32_t rc = run();
+            return rc == CASIM_OK ? fetch_removals(out) : rc;
+        }
         if (nb) memcpy(out->node_out, s_node, nb);
         if (rb) memcpy(out->removable, s_rem, (size_t)K_);
         const int ne = o[4] < E_ ? o[4] : E_;
@@ -1418,6 +1449,18 @@ public:
     int threads() const { return threads_; }
     bool in_lds() const { return lds_; }
     bool lean() const { return lean_; }   // the removal loop runs as removals_lean_kernel
+    bool lean_gave_up() const { return lean_gave_up_; }
+    // After a first run(): did the one-wave kernel with a log smaller than the worst case finish?  If not, later run()s take K_sched (callers that
+    // run() repeatedly without fetching: the timing entry points).  Synchronises only when there is something to ask.
+    int32_t confirm_kernel() {
+        if (trivial_ || !lean_ || !lean_optimistic_) return CASIM_OK;
+        int32_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        bk_.d2h(o, a_.out, 32); bk_.sync();
+        if (!bk_.ok()) return fail(CASIM_ERR_HIP, bk_.error());
+        if (o[5] == 1) { lean_ = false; lean_gave_up_ = true; }
+        lean_optimistic_ = false;
+        return CASIM_OK;
+    }
 
     // Workgroup size cap.  Every wave runs the run's uniform instruction stream and meets the others at each
     // collective, so more waves only pay off while a run has to look at many nodes; a piece of 256 nodes also lets
@@ -1467,6 +1510,8 @@ private:
     int32_t cap_ = 0, n_runs_ = 0, last_index_ = 0;
     bool ready_ = false, trivial_ = false, lds_ = true, lean_ = false;
     size_t smem_ = 0, lean_smem_ = 0; int32_t lean_log_cap_ = 0;
+    bool lean_gave_up_ = false;
+    bool lean_optimistic_ = false;   // the LDS log is smaller than the call's worst case: the kernel may give up (out[5]), K_sched then runs
     uint64_t* d_fbits_ = nullptr; uint64_t* d_fit0_ = nullptr;
     const int32_t* d_rule_init_ = nullptr; const int32_t* d_dom_init_ = nullptr; const int32_t* d_contrib_init_ = nullptr;
     int64_t rule_total_ = 0, contrib_total_ = 0;

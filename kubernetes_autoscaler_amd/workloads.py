@@ -644,6 +644,18 @@ def removal_scale(n_nodes: int, pods_per_node: int = 12, frac_candidates: float 
     return RemovalWorkload(f"removal_{n_nodes}n", nodes, cands)
 
 
+def runonce_scale_down(n_nodes: int = 400, pods_per_node: int = 40) -> RemovalWorkload:
+    """R3 = the reference's own benchmark of the scale-down path, BenchmarkRunOnceScaleDown (CA/core/bench/benchmark_runonce_test.go:505-521) on
+    setupScaleDown60Percent(400) (:424-452): `n_nodes` nodes BuildTestNode(.., 10000, 10000) with 100 pod slots, pods_per_node pods of 1 % of a
+    node each (pod i on node i % n_nodes, safe-to-evict, no controller), every node under the utilisation threshold and therefore a candidate, in
+    list order, simulations persisted (the planner's NewRemovalSimulator(.., true)).  The benchmark's verify step holds the answer:
+    verifyToBeDeleted(240) (:473-491) — 60 % of the nodes go, the other 160 end up exactly full."""
+    nodes = [NodeInfo(_node(f"ng1-node-{i}", 10000, 10000, 100)) for i in range(n_nodes)]
+    for j in range(n_nodes * pods_per_node):
+        nodes[j % n_nodes].pods.append(Pod(name=f"pod-{j}", requests={"cpu": 100, "memory": 100}))
+    return RemovalWorkload(f"runonce_scale_down_{n_nodes}n", nodes, list(range(n_nodes)))
+
+
 def fuzz_pending_domains(seed: int, max_nodes: int = 40, max_pods: int = 90) -> PendingWorkload:
     """Like fuzz_pending, with the Filters that look at a node's topology DOMAIN: PodTopologySpread constraints
     (hostname / zone / rack keys, maxSkew 1-3, minDomains, selectors that do or do not match the pod itself, node

@@ -232,6 +232,28 @@ def test_lean_removal_kernel_and_k_sched_agree_with_the_oracle_on_the_device(ctx
     assert lean >= 100, lean
 
 
+def test_the_reference_scale_down_benchmark_on_the_device(ctx, monkeypatch):
+    """BenchmarkRunOnceScaleDown at full size (core/bench/benchmark_runonce_test.go:505-521: 400 nodes at 40 %, verifyToBeDeleted(240)): both
+    removal kernels == the oracle in every field, and the reference's own number comes out."""
+    import json, os
+    from harness import RemovalCase, assert_removal_matches, removal_device, removal_oracle
+    from kubernetes_autoscaler_amd.workloads import runonce_scale_down
+    b = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")))["benchmark_runonce_scale_down"]
+    w = runonce_scale_down(b["nodes"], b["pods_per_node"])
+    case = RemovalCase(nodes=w.nodes, candidates=w.candidates, ext_capacity=40 * b["nodes"] * b["pods_per_node"])
+    want = removal_oracle(case)
+    assert sum(1 for r in want["removable"] if r == 1) == b["expect_to_be_deleted"]
+    for force_k_sched in (False, True):
+        if force_k_sched:
+            monkeypatch.setenv("CASIM_NO_LEAN_REMOVALS", "1")
+        else:
+            monkeypatch.delenv("CASIM_NO_LEAN_REMOVALS", raising=False)
+        got = removal_device(case, ctx)
+        assert_removal_matches(got, want, f"{w.name} {'K_sched' if force_k_sched else 'default kernel'}")
+        assert int((got.removable == 1).sum()) == b["expect_to_be_deleted"]
+    monkeypatch.delenv("CASIM_NO_LEAN_REMOVALS", raising=False)
+
+
 def test_lean_removal_kernel_long_transactions_and_wide_clusters_on_the_device(ctx, monkeypatch):
     from harness import RemovalCase, assert_removal_matches, removal_device, removal_oracle
     from kubernetes_autoscaler_amd.workloads import fuzz_removals_plain

@@ -308,6 +308,23 @@ def test_simulate_node_removal(case):
         assert [p.name for p in rc.pod_lists()[0]] == case.get("reschedule", [])
 
 
+def test_benchmark_runonce_scale_down():
+    """BenchmarkRunOnceScaleDown (core/bench/benchmark_runonce_test.go:505-521): 400 nodes at 40 % — verifyToBeDeleted(240).  The one answer the
+    reference holds for the PERSISTED removal loop at benchmark size: every node a candidate, pods that arrived from earlier removals listed again."""
+    from harness import RemovalCase, removal_oracle
+    from kubernetes_autoscaler_amd.workloads import runonce_scale_down
+    b = GOLD["benchmark_runonce_scale_down"]
+    w = runonce_scale_down(b["nodes"], b["pods_per_node"])
+    assert all(n.node.allocatable == {"cpu": b["node_cpu"], "memory": b["node_mem"], "pods": b["node_pods"]} for n in w.nodes)
+    assert all(p.requests == {"cpu": b["pod_cpu"], "memory": b["pod_mem"]} for n in w.nodes for p in n.pods)
+    got = removal_oracle(RemovalCase(nodes=w.nodes, candidates=w.candidates, ext_capacity=40 * b["nodes"] * b["pods_per_node"]))
+    assert got["n_processed"] == b["nodes"]
+    assert sum(1 for r in got["removable"] if r == 1) == b["expect_to_be_deleted"]
+    # (why 240 whatever the order: a node can go while the others have room for all 16 000 pods, i.e. while more than 160 nodes are left)
+    left = b["nodes"] - b["expect_to_be_deleted"]
+    assert left * b["node_pods"] == b["nodes"] * b["pods_per_node"]
+
+
 # ---- filter-out-schedulable (SURVEY §8 f1): filterOutSchedulableByPacking ------------------------------------------
 def golden_filter_case(row):
     """(nodes, candidates in the order Process hands them to TrySchedulePods, acceptable) of one TestFilterOutSchedulable row."""

@@ -9,7 +9,7 @@ import pytest
 
 from harness import EmuContext, RemovalCase, assert_removal_matches, emu_lib, removal_device, removal_oracle
 from kubernetes_autoscaler_amd.objects import NodeInfo, Pod, build_test_pod
-from kubernetes_autoscaler_amd.workloads import GiB, MiB, _node, fuzz_removals, fuzz_removals_plain, removal_scale
+from kubernetes_autoscaler_amd.workloads import GiB, MiB, _node, fuzz_removals, fuzz_removals_plain, removal_scale, runonce_scale_down
 
 
 def last_kernel():
@@ -126,3 +126,35 @@ def test_bench_shape_small(monkeypatch):
     w = removal_scale(300, pods_per_node=12, frac_candidates=0.3, seed=4)
     want, lean = both(case_of(w), w.name, monkeypatch)
     assert lean == 1 and want["n_processed"] == len(w.candidates)
+
+
+def test_the_reference_scale_down_benchmark_shape_small(monkeypatch):
+    """BenchmarkRunOnceScaleDown's cluster at 50 nodes (benchmark_runonce_test.go:424-452): 60 % of the nodes go, as at its 400 (golden vector
+    benchmark_runonce_scale_down; tests/test_gpu_round5.py runs the full size on the device) — through both removal kernels.  Every candidate
+    after the first lists pods that arrived from earlier removals: 40-pod transactions plus the ext path, all night."""
+    w = runonce_scale_down(50)
+    want, _ = both(case_of(w, ext_capacity=50 * 40 * 40), w.name, monkeypatch, expect_lean=None)
+    assert want["n_processed"] == 50 and sum(1 for r in want["removable"] if r == 1) == 30 and len(want["ext"]) > 1000
+
+
+def test_a_log_smaller_than_the_worst_case_gives_up_and_k_sched_answers(monkeypatch):
+    """The one-wave kernel's LDS log is sized to what fits when `pods + ext_capacity` does not (casim_sched.h: lean_optimistic_): the kernel ends
+    at the commit that would overflow it, the host runs the call again through K_sched — same results as the oracle either way.  CASIM_LEAN_LOG_CAP
+    makes the log 256 entries, so that both outcomes occur on small cases."""
+    monkeypatch.delenv("CASIM_NO_LEAN_REMOVALS", raising=False)
+    monkeypatch.setenv("CASIM_LEAN_LOG_CAP", "256")
+    finished = gave_up = 0
+    cases = [case_of(fuzz_removals_plain(s)) for s in range(0, 400, 7)] + [case_of(runonce_scale_down(n), ext_capacity=4000) for n in (5, 10, 20, 40)]
+    for case in cases:
+        want = removal_oracle(case)
+        got = removal_device(case, EmuContext(0))
+        assert_removal_matches(got, want, "small log")
+        moves = sum(len(lst) for lst, r in zip(case.pod_lists(), want["removable"]) if r == 1) + sum(1 for c, _, _ in want["ext"] if want["removable"][c] == 1)
+        lean = last_kernel()[0]
+        if case.persist and moves > 256:
+            assert lean == 0, moves        # it cannot have finished
+        if lean:
+            finished += 1
+        elif moves > 256:
+            gave_up += 1
+    assert finished >= 20 and gave_up >= 3, (finished, gave_up)
