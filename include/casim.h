@@ -616,10 +616,9 @@ typedef struct casim_removal_candidates {
     int32_t last_index;
     int32_t ext_capacity;            /* entries of the ext_* result arrays; 0 = stop at the first candidate with arrivals.  (The one-wave removal kernel —
                                       * casim_last_removals_info — keeps its log of committed moves in LDS.  The worst case is `pods + ext_capacity`
-                                      * entries; when that does not fit, the log gets what LDS has left — if that is at least a quarter of the worst
-                                      * case — and a call that really commits more moves than it holds is run again through the general loop: same
-                                      * results, the first attempt's time lost.  A capacity far beyond what the loop can list can still push a big call
-                                      * to the general loop for nothing.) */
+                                      * entries; when that does not fit, the log gets what LDS has left — if that holds at least half of the call's
+                                      * pods; moves onto nodes that were removed since are squeezed out when it fills up — and a call that still
+                                      * outgrows it is run again through the general loop: same results, the first attempt's time lost.) */
     const struct casim_domain_rules* rules; /* the encoder's domain rules (PodTopologySpread, zone anti-affinity); NULL = none */
 } casim_removal_candidates;
 

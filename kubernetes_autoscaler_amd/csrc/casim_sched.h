@@ -85,6 +85,7 @@ struct SchedArgs {
     // removals_lean_kernel: the candidate and run columns above interleaved (16 bytes per record: one load per lane, one pointer each)
     const int32_t* lean_cand;     // [K + 1][4] node, first run, first pod, atomic (entry K: the end markers)
     const int32_t* lean_run;      // [n_runs][4] class, count, hint, first pod
+    int32_t lean_bulk_min;        // runs of at least this many unhinted pods of one class are placed a word of nodes at a time (schedule_run)
     int64_t* prof;                // [8] s_memtime ticks per phase of thread 0 (CASIM_PACK_PROF builds + CASIM_PACK_PROF_DUMP) or null
     int32_t* pair_memo;           // [n_pairs] 1 = cached as unschedulable (zeroed before every pass)
     int32_t* ctrl_count;          // [n_ctrl] specs cached for the controller (at most 10, similar_pods.go:52)
@@ -783,7 +784,10 @@ CS_GLOBAL void lean_fit0_kernel(DevTables t, const uint64_t* CS_RESTRICT fbits, 
     if (lane == 0) fit0[(int64_t)c * S + w] = b;
 }
 
-template <int RMAX_>
+// BULK_: runs of unhinted pods of one class are placed a word of nodes at a time (schedule_run).  The host picks the instantiation by the call's own
+// runs (lean_bulk_): a call of short runs keeps the pod-by-pod kernel as it was — the second code path costs it registers (3.55 -> 4.09 ms on the
+// bench's 5000-node row when both lived in one kernel).
+template <int RMAX_, bool BULK_>
 CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedArgs a, const uint64_t* CS_RESTRICT fit0, int log_cap) {
     const int lane = cs::lane();
     const int R = RMAX_ == 2 ? 2 : t.R;   // (n_res >= 2 always: the two-lane instantiation knows its lane count, every `r < R` folds away)
@@ -905,6 +909,26 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
         cs::lds_order();   // (the masks are read by all lanes in the next search)
     };
 
+    // Entries of the log whose destination has left the list are dead: a node that goes takes every pod it had received along (they were listed
+    // again and their moves logged anew).  Squeezing them out keeps the order of the rest — what a later listing walks.  Done when the log is
+    // full, and as soon as the dead outnumber the living: every candidate that received pods walks the whole log.
+    int32_t dead_n = 0;
+    auto squeeze_log = [&]() {
+        int32_t keep_n = 0;
+        for (int j0 = 0; j0 < log_n; j0 += 64) {
+            const int jj = j0 + lane;
+            const bool in = jj < log_n;
+            const uint32_t d = in ? llog_dest[jj] : 0u, rf = in ? llog_ref[jj] : 0u, cl = in ? llog_cls[jj] : 0u;
+            const bool live = in && ((alive[d >> 6] >> (d & 63)) & 1ull) != 0ull;
+            const uint64_t kb = cs::ballot(live);
+            cs::lds_order();   // (every lane holds its entry before any slot is overwritten: slots only move down)
+            if (live) { const int o = keep_n + cs::mbcnt(kb); llog_dest[o] = (uint16_t)d; llog_ref[o] = (uint16_t)rf; llog_cls[o] = (uint8_t)cl; }
+            keep_n += cs::popc64(kb);
+            cs::lds_order();
+        }
+        log_n = keep_n; dead_n = 0;
+    };
+
     int32_t my_cand = 0, my_rlo = 0, my_rhi = 0, my_plo = 0, my_phi = 0, my_atomic = 0;   // candidate records kc & ~63 .., one per lane
     int cstart = 0, cend = 0;                                               // run records [cstart, cend), one per lane
     int32_t my_class = 0, my_count = 0, my_hint = -1, my_first = 0;
@@ -929,6 +953,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
             // log, four entries per lane and step; a step without a hit costs one compare round.  Each hit goes to the ext tables and, with
             // its class, into the transaction's ring right behind the node's own pods.
             if (a.ext_cap <= 0) break;
+            if (BULK_ && log_n >= 2048 && 2 * dead_n > log_n) squeeze_log();
             uint32_t found = 0;
             bool bad = false;
             for (int j0 = 0; j0 < log_n; j0 += 256) {
@@ -991,6 +1016,94 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
             move_pod(c, m, +1);
             scheduled++; n_done++;
         };
+        // `cnt` unhinted pods of class c in a row (a node's replicas of one controller; BenchmarkRunOnceScaleDown moves nothing else): pod by pod each
+        // of them is a search + a node update, two LDS round trips.  But the search of pod i + 1 starts behind the node pod i took (MarkMatch), and a
+        // placement only changes the bits of ITS node: until the walk comes round to where it started, the nodes the pods take are simply the class's
+        // passing nodes in cyclic list order from lastIndex + 1, one pod each.  So a run is placed a WORD of nodes at a time: the passing nodes of the
+        // word (lanes = its nodes) take the next pods in lane order (rank = mbcnt), their records are updated side by side and every class's bit
+        // of those nodes follows (one ballot per class).  Coming round (more pods than passing nodes) starts the next walk with the masks as they
+        // are then — exactly where the pod-by-pod loop would be.  ref_base < 0: arrived pods (their refs and classes sit in the ring already).
+        auto schedule_run = [&](int c, int32_t cnt, int slot_base, int ref_base) {
+            if (!BULK_) return;
+            const uint64_t* row = fit + (int64_t)c * S;
+            int64_t q[RMAX_];
+#pragma unroll
+            for (int r = 0; r < RMAX_; ++r) q[r] = (int64_t)cs::bcast_u64((uint64_t)my_q[r], c);
+            int32_t left = cnt, done = 0;
+            while (left > 0) {
+                uint32_t u0 = (uint32_t)last_index + 1u;
+                if (u0 >= (uint32_t)n_alive) u0 %= (uint32_t)n_alive;
+                const int32_t left_before = left;
+                for (int pass = 0; pass < 2 && left > 0; ++pass) {   // at or behind u0, then (wrapped) in front of it: as in find()
+                    for (int base = pass == 0 ? (int)((u0 >> 6) & ~63u) : 0; base < S && left > 0; base += 64) {
+                        const int w0 = base + lane;
+                        const bool in = w0 < S;
+                        const int wc = in ? w0 : S - 1;
+                        uint64_t al = alive[wc], x = row[wc] & scanb[wc];
+                        uint32_t lo = wpre[wc];
+                        if (!in) { al = 0ull; x = 0ull; lo = 0xffffffffu; }
+                        const uint32_t hi = lo + (uint32_t)cs::popc64(al);
+                        const bool bound = in && lo < u0 && hi > u0;
+                        uint64_t keep = pass == 0 ? ((in && lo >= u0) ? ~0ull : 0ull) : ((in && hi <= u0) ? ~0ull : 0ull);
+                        const uint64_t bb = cs::ballot(bound);
+                        if (bb != 0ull) {
+                            const int jb = cs::ffs64(bb);
+                            const uint64_t xa = cs::bcast_u64(al, jb);
+                            const uint32_t rr = u0 - cs::bcast_u32(lo, jb);
+                            const int bit = cs::ffs64(cs::ballot(((xa >> lane) & 1ull) && (uint32_t)cs::mbcnt(xa) == rr));
+                            if (lane == jb) keep = pass == 0 ? ~cs::low_mask(bit) : cs::low_mask(bit);
+                        }
+                        const uint64_t y = x & keep;
+                        uint64_t b = cs::ballot(y != 0ull);
+                        while (b != 0ull && left > 0) {   // the words of this block that hold passing nodes, in list order
+                            const int j = cs::ffs64(b);
+                            b &= b - 1ull;
+                            const uint64_t yw = cs::bcast_u64(y, j);
+                            const int w = base + j;
+                            const int m = (w << 6) + lane;                       // lanes = the word's nodes
+                            const int rank = cs::mbcnt(yw);
+                            const int avail = cs::popc64(yw);
+                            const int take = avail < left ? avail : left;
+                            const bool sel = ((yw >> lane) & 1ull) != 0ull && rank < take;
+                            if (sel) {
+                                const int i = done + rank, ti = n_done + rank;
+                                a.node_out[slot_base + i] = m;
+                                if (ti < kLeanTxnCap) {
+                                    txn_node[ti] = m;
+                                    if (ref_base >= 0) { txn_ref[ti] = ref_base + i; txn_cls[ti] = c; }
+                                }
+                            }
+                            int64_t f[RMAX_];
+#pragma unroll
+                            for (int r = 0; r < RMAX_; ++r) f[r] = sfree[(int64_t)(r < R ? r : 0) * cap + m] - (sel ? q[r] : 0);
+                            const int32_t sl = sslots[m] - (sel ? 1 : 0);
+                            if (sel) {
+#pragma unroll
+                                for (int r = 0; r < RMAX_; ++r) if (r < R) sfree[(int64_t)r * cap + m] = f[r];
+                                sslots[m] = sl;
+                            }
+                            for (int cc = 0; cc < C; ++cc) {   // a fuller node never starts to fit: bits only fall
+                                bool fits = sl > 0;
+#pragma unroll
+                                for (int r = 0; r < RMAX_; ++r) {
+                                    const int64_t qq = (int64_t)cs::bcast_u64((uint64_t)my_q[r], cc);
+                                    if (r < R && qq > 0 && f[r] < qq) fits = false;
+                                }
+                                const uint64_t nb = cs::ballot(sel && !fits);
+                                if (nb != 0ull && lane == 0) cs::lds_and_u64(fit + (int64_t)cc * S + w, ~nb);
+                            }
+                            // MarkMatch of the run's last pod so far: the position of the highest node taken
+                            const int bit_last = cs::fls64(cs::ballot(sel));
+                            last_index = (int32_t)cs::bcast_u32(lo, j) + cs::popc64(cs::bcast_u64(al, j) & cs::low_mask(bit_last));
+                            left -= take; done += take; n_done += take; scheduled += take;
+                            cs::lds_order();
+                        }
+                        if (pass == 1 && bb != 0ull) break;
+                    }
+                }
+                if (left == left_before) { failed = true; return; }   // nothing passes any more: breakOnFailure (:79-81)
+            }
+        };
         // ---- the candidate's own pods: runs of one class ----
         for (int k = run_lo; k < run_hi && !failed; ++k) {
             if (k < cstart || k >= cend) {
@@ -1006,7 +1119,8 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
             const int32_t hint = (int32_t)cs::bcast_u32((uint32_t)my_hint, j);
             const int32_t first = (int32_t)cs::bcast_u32((uint32_t)my_first, j);
             runs_done++;
-            for (int32_t i = 0; i < cnt && !failed; ++i) schedule_pod(c, hint, first + i, first + i);
+            if (BULK_ && hint < 0 && cnt >= a.lean_bulk_min) schedule_run(c, cnt, first, first);
+            else for (int32_t i = 0; i < cnt && !failed; ++i) schedule_pod(c, hint, first + i, first + i);
         }
         // ---- then the pods that arrived, in the order they were listed ----
         for (int e0 = e_lo; e0 < e_hi && !failed; e0 += 64) {
@@ -1017,9 +1131,23 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
                 my_c = ti < kLeanTxnCap ? txn_cls[ti] : a.pod_class[my_r];
             }
             const int lim = e_hi - e0 < 64 ? e_hi - e0 : 64;
-            for (int u = 0; u < lim && !failed; ++u) {
-                runs_done++;
-                schedule_pod((int)cs::bcast_u32((uint32_t)my_c, u), -1, a.P + e0 + u, (int)cs::bcast_u32((uint32_t)my_r, u));
+            if (!BULK_) {
+                for (int u = 0; u < lim && !failed; ++u) {
+                    runs_done++;
+                    schedule_pod((int)cs::bcast_u32((uint32_t)my_c, u), -1, a.P + e0 + u, (int)cs::bcast_u32((uint32_t)my_r, u));
+                }
+                continue;
+            }
+            for (int u = 0; u < lim && !failed;) {
+                // arrived pods of one class in a row are a run like any other
+                const int c = (int)cs::bcast_u32((uint32_t)my_c, u);
+                const uint64_t same = cs::ballot(ee < e_hi && my_c == c) >> u;   // bit 0 = lane u
+                int len = cs::ffs64(~same);
+                if (len < 0 || len > lim - u) len = lim - u;
+                runs_done += len;
+                if (len >= a.lean_bulk_min) schedule_run(c, len, a.P + e0 + u, -1);
+                else for (int i = 0; i < len && !failed; ++i) schedule_pod(c, -1, a.P + e0 + u + i, (int)cs::bcast_u32((uint32_t)my_r, u + i));
+                u += len;
             }
         }
         // ---- every pod found a place <=> the node is removable (findPlaceFor :219-224) ----
@@ -1031,7 +1159,10 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
         if (ok && a.persist) {
             // The log was sized to what LDS holds when the worst case (every pod of the call and every ext slot committed) does not fit: a
             // commit that would run past it ends the kernel with out[5] = 1 and the host runs the call again through K_sched (fetch_removals).
-            if (log_n + n_listed > log_cap) { if (lane == 0) a.out[5] = 1; return; }
+            if (log_n + n_listed > log_cap) {
+                squeeze_log();
+                if (log_n + n_listed > log_cap) { if (lane == 0) a.out[5] = 1; return; }
+            }
             // Commit (withForkedSnapshot :174-188): the ghost leaves the list (:230) and the destination set (planner.go:318)
             for (int i = lane; i < n_listed; i += 64) {
                 const int m = placed_at(i);
@@ -1039,6 +1170,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
                 llog_dest[log_n + i] = (uint16_t)m; llog_ref[log_n + i] = (uint16_t)ref_at(i); llog_cls[log_n + i] = (uint8_t)class_at(i);
             }
             log_n += n_listed;
+            dead_n += e_hi - e_lo;   // (what this node had received leaves with it)
             if (lane == 0) cs::lds_and_u64(alive + (Y >> 6), ~ybit);
             for (int w = (Y >> 6) + 1 + lane; w < S; w += 64) cs::lds_sub_u32(wpre + w, 1u);
             n_alive--;
@@ -1215,8 +1347,8 @@ public:
             lean_log_cap_ = (int32_t)(((int64_t)P_ + (cand->ext_capacity > 0 ? cand->ext_capacity : 0) + 255) & ~255ll);
             lean_smem_ = (size_t)casim_lean_removal_bytes(R, C_, round_up64_((int64_t)N_), lean_log_cap_);
             // The worst case — every pod of the call and every ext slot a committed move — rarely happens: a removal that fails commits
-            // nothing, and ext_capacity is a bound the caller picks generously.  When it does not fit, the log gets what LDS has left (at least a
-            // quarter of the worst case, or the attempt is not worth a launch); the kernel gives up at the commit that would overflow it and
+            // nothing, and ext_capacity is a bound the caller picks generously.  When it does not fit, the log gets what LDS has left (room for at
+            // least half of the call's pods, or the attempt is not worth a launch); the kernel gives up at the commit that would overflow it and
             // fetch_removals / confirm_kernel run the call again through K_sched.  Results are those of whichever kernel finished.
             lean_optimistic_ = false;
             if (const char* ev = getenv("CASIM_LEAN_LOG_CAP")) {   // tests: a log of this many entries, so that the give-up path runs on small cases
@@ -1229,7 +1361,8 @@ public:
             if (lean_smem_ > bk_.lds_budget() && !(getenv("CASIM_NO_OPTIMISTIC_LOG") && atoi(getenv("CASIM_NO_OPTIMISTIC_LOG")) != 0)) {
                 const int64_t fixed = casim_lean_removal_bytes(R, C_, round_up64_((int64_t)N_), 0);
                 const int64_t room = (((int64_t)bk_.lds_budget() - fixed - 8) / 5) & ~255ll;
-                if (room >= 256 && room * 4 >= lean_log_cap_) {
+                // (entries whose destination was removed since are squeezed out when the log fills up: what stays is at most one entry per pod)
+                if (room >= 256 && room * 2 >= (int64_t)P_) {
                     lean_log_cap_ = (int32_t)room;
                     lean_smem_ = (size_t)casim_lean_removal_bytes(R, C_, round_up64_((int64_t)N_), lean_log_cap_);
                     lean_optimistic_ = true;
@@ -1263,6 +1396,12 @@ public:
         if (K_ > 0) {
             a_.memo_classes = 0;  // breakOnFailure ends a simulation at the first miss: the memo is never consulted
             a_.n_cand = K_; a_.persist = cand->persist ? 1 : 0; a_.max_removable = cand->max_removable > 0 ? cand->max_removable : 0;
+            a_.lean_bulk_min = 4;   // CASIM_LEAN_BULK_MIN: 0 = pod by pod always (A/B, tests run both)
+            if (const char* ev = getenv("CASIM_LEAN_BULK_MIN")) { const int v = atoi(ev); a_.lean_bulk_min = v <= 0 ? 0x7fffffff : (v < 2 ? 2 : v); }
+            // which instantiation: the one that places runs a word of nodes at a time when the call has such runs of its own (pods that
+            // arrive later travel in the runs they left in)
+            lean_bulk_ = false;
+            for (size_t i = 0; i < rn.size(); ++i) if (rh[i] < 0 && rn[i] >= a_.lean_bulk_min) { lean_bulk_ = true; break; }
             if (lean_) {   // the kernel's candidate / run records (SchedArgs::lean_cand, lean_run)
                 lc.assign(4 * ((size_t)K_ + 1), 0); lr.assign(4 * (rc.size() > 0 ? rc.size() : 1), 0);
                 for (int k = 0; k <= K_; ++k) {
@@ -1355,8 +1494,13 @@ public:
         if (K_ > 0) { int32_t* li = last_removals_info(); li[0] = lean_ ? 1 : 0; li[1] = lean_ ? 64 : threads_; li[2] = (lean_ || lds_) ? 1 : 0; li[3] = n_runs_; }
         if (lean_) {
             bk_.launch(lean_fit0_kernel, S_, C_, 64, (size_t)0, dt_, (const uint64_t*)d_fbits_, d_fit0_, S_);
-            if (dt_.R <= 2) bk_.launch(removals_lean_kernel<2>, 1, 1, 64, lean_smem_, dt_, a_, (const uint64_t*)d_fit0_, lean_log_cap_);
-            else bk_.launch(removals_lean_kernel<4>, 1, 1, 64, lean_smem_, dt_, a_, (const uint64_t*)d_fit0_, lean_log_cap_);
+            if (lean_bulk_) {
+                if (dt_.R <= 2) bk_.launch(removals_lean_kernel<2, true>, 1, 1, 64, lean_smem_, dt_, a_, (const uint64_t*)d_fit0_, lean_log_cap_);
+                else bk_.launch(removals_lean_kernel<4, true>, 1, 1, 64, lean_smem_, dt_, a_, (const uint64_t*)d_fit0_, lean_log_cap_);
+            } else {
+                if (dt_.R <= 2) bk_.launch(removals_lean_kernel<2, false>, 1, 1, 64, lean_smem_, dt_, a_, (const uint64_t*)d_fit0_, lean_log_cap_);
+                else bk_.launch(removals_lean_kernel<4, false>, 1, 1, 64, lean_smem_, dt_, a_, (const uint64_t*)d_fit0_, lean_log_cap_);
+            }
             return bk_.ok() ? CASIM_OK : fail(CASIM_ERR_HIP, bk_.error());
         }
         const bool tx = K_ > 0, ru = a_.n_rules > 0;
@@ -1510,7 +1654,7 @@ private:
     int32_t cap_ = 0, n_runs_ = 0, last_index_ = 0;
     bool ready_ = false, trivial_ = false, lds_ = true, lean_ = false;
     size_t smem_ = 0, lean_smem_ = 0; int32_t lean_log_cap_ = 0;
-    bool lean_gave_up_ = false;
+    bool lean_gave_up_ = false, lean_bulk_ = false;
     bool lean_optimistic_ = false;   // the LDS log is smaller than the call's worst case: the kernel may give up (out[5]), K_sched then runs
     uint64_t* d_fbits_ = nullptr; uint64_t* d_fit0_ = nullptr;
     const int32_t* d_rule_init_ = nullptr; const int32_t* d_dom_init_ = nullptr; const int32_t* d_contrib_init_ = nullptr;

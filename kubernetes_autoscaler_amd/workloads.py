@@ -644,6 +644,66 @@ def removal_scale(n_nodes: int, pods_per_node: int = 12, frac_candidates: float 
     return RemovalWorkload(f"removal_{n_nodes}n", nodes, cands)
 
 
+def fuzz_removals_runs(seed: int) -> RemovalWorkload:
+    """Plain clusters whose nodes run REPLICAS: a few pod specs, each node a handful of runs of 1-50 identical pods (what BenchmarkRunOnceScaleDown
+    is made of, and what the one-wave removal kernel places a word of nodes at a time: csrc/casim_sched.h schedule_run).  Tight and loose clusters
+    (runs that come round the node list, runs that fail half way and are reverted), pod-slot limits that bite before the resources do, node
+    selectors / taints that thin the passing nodes out, clusters of several mask words, every node a candidate now and then (pods that arrived are
+    listed again — in runs of their own), some hints, a destination subset, any lastIndex."""
+    rng = SplitMix64(0x2B0B5000 + seed)
+    big = rng.chance(1, 30)                    # more than 64 mask words: the walk crosses blocks of words
+    n_nodes = (4100 + rng.below(200)) if big else rng.pick([3, 6, 12, 30, 64, 65, 100, 200]) + rng.below(5)
+    n_specs = 1 + rng.below(rng.pick([1, 2, 4, 6]))
+    specs = []
+    for c in range(n_specs):
+        kw = dict(labels={"app": f"a{c}"}, requests={"cpu": rng.pick([0, 10, 50, 100, 250]), "memory": rng.pick([0, 16 * MiB, 64 * MiB, 256 * MiB])})
+        if rng.chance(1, 6):
+            kw["node_selector"] = {"pool": f"p{rng.below(2)}"}
+        if rng.chance(1, 6):
+            kw["tolerations"] = [Toleration(key="dedicated", operator="Exists")]
+        specs.append(kw)
+    load = rng.pick([0.2, 0.4, 0.6, 0.8])      # how full the nodes start: 0.8 leaves room for few removals
+    slots = rng.pick([20, 60, 110])
+    nodes = []
+    for i in range(n_nodes):
+        taints = [Taint("dedicated", "x", "NoSchedule")] if rng.chance(1, 10) else []
+        cpu_cap, mem_cap = rng.pick([2000, 4000, 8000]), rng.pick([4, 8, 16]) * GiB
+        node = _node(f"rr{seed}-n{i}", cpu_cap, mem_cap, slots, {"pool": f"p{rng.below(2)}"}, taints)
+        if rng.chance(1, 20):
+            node.unschedulable = True
+        info = NodeInfo(node)
+        cpu = mem = 0
+        for _ in range(1 + rng.below(4)):
+            kw = specs[rng.below(n_specs)]
+            if "node_selector" in kw and kw["node_selector"]["pool"] != node.labels["pool"]:
+                continue
+            if taints and "tolerations" not in kw:
+                continue
+            rq = kw["requests"]
+            for _ in range(1 + rng.below(rng.pick([3, 10, 50]))):
+                if cpu + rq["cpu"] > load * cpu_cap or mem + rq["memory"] > load * mem_cap or len(info.pods) >= load * slots:
+                    break
+                info.pods.append(Pod(name=f"r{i}-{len(info.pods)}", labels=dict(kw["labels"]), requests=dict(rq), node_selector=dict(kw.get("node_selector", {})),
+                                     tolerations=list(kw.get("tolerations", [])), controller_uid=f"rs-{specs.index(kw)}"))
+                cpu += rq["cpu"]; mem += rq["memory"]
+        nodes.append(info)
+    if big:
+        order = rng.sample(list(range(n_nodes)), 20 + rng.below(40))
+    else:
+        order = list(range(n_nodes)) if rng.chance(1, 3) else rng.sample(list(range(n_nodes)), 1 + rng.below(n_nodes))
+    destination = [0 if rng.chance(1, 8) else 1 for _ in range(n_nodes)] if rng.chance(1, 4) else None
+    if big and rng.chance(1, 2):               # few destinations: runs come round a long list
+        destination = [1 if rng.chance(1, 40) else 0 for _ in range(n_nodes)]
+    hints = {}
+    if rng.chance(1, 4):
+        for c in order:
+            for p in nodes[c].pods:
+                if rng.chance(1, 10):
+                    hints[id(p)] = rng.below(n_nodes + 1)
+    return RemovalWorkload(f"fuzz_removals_runs{seed}", nodes, order, destination, hints or None, persist=not rng.chance(1, 6),
+                           max_removable=rng.pick([0, 0, 0, 2, 5]), last_index=rng.below(n_nodes + 1))
+
+
 def runonce_scale_down(n_nodes: int = 400, pods_per_node: int = 40) -> RemovalWorkload:
     """R3 = the reference's own benchmark of the scale-down path, BenchmarkRunOnceScaleDown (CA/core/bench/benchmark_runonce_test.go:505-521) on
     setupScaleDown60Percent(400) (:424-452): `n_nodes` nodes BuildTestNode(.., 10000, 10000) with 100 pod slots, pods_per_node pods of 1 % of a

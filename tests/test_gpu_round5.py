@@ -232,6 +232,59 @@ def test_lean_removal_kernel_and_k_sched_agree_with_the_oracle_on_the_device(ctx
     assert lean >= 100, lean
 
 
+def test_runs_of_replicas_a_word_of_nodes_at_a_time_on_the_device(ctx, monkeypatch):
+    """runs of identical pods (workloads.fuzz_removals_runs: replicas, tight and loose clusters, runs that come round the list or fail half way,
+    pods listed again, clusters of > 64 mask words): the one-wave kernel placing a word of nodes at a time (schedule_run), the same kernel pod by
+    pod (CASIM_LEAN_BULK_MIN=0) and K_sched — each against the oracle in every field"""
+    from harness import RemovalCase, assert_removal_matches, removal_device, removal_oracle
+    from kubernetes_autoscaler_amd.workloads import fuzz_removals_runs
+    lean = 0
+    for seed in range(160):
+        w = fuzz_removals_runs(seed)
+        case = RemovalCase(nodes=w.nodes, candidates=w.candidates, destination=w.destination, hints=w.hints, persist=w.persist,
+                           max_removable=w.max_removable, last_index=w.last_index, ext_capacity=4 * sum(len(n.pods) for n in w.nodes) + 64)
+        want = removal_oracle(case)
+        for name, env in (("a word at a time", {}), ("pod by pod", {"CASIM_LEAN_BULK_MIN": "0"}), ("K_sched", {"CASIM_NO_LEAN_REMOVALS": "1"})):
+            for k in ("CASIM_LEAN_BULK_MIN", "CASIM_NO_LEAN_REMOVALS"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            assert_removal_matches(removal_device(case, ctx), want, f"{w.name} {name}")
+            if not env:
+                lean += int(kaa.Context.last_removals_info()["lean"])
+    for k in ("CASIM_LEAN_BULK_MIN", "CASIM_NO_LEAN_REMOVALS"):
+        monkeypatch.delenv(k, raising=False)
+    assert lean >= 120, lean
+
+
+def test_a_removal_log_smaller_than_the_worst_case_on_the_device(ctx, monkeypatch):
+    """the one-wave kernel with a 256-entry log (CASIM_LEAN_LOG_CAP): it finishes (squeezing dead entries out when the log fills up) or gives up
+    at the commit that does not fit and K_sched answers — the oracle's results either way (tests/test_removal_lean_emu.py: the same under the emulator)"""
+    from harness import RemovalCase, assert_removal_matches, removal_device, removal_oracle
+    from kubernetes_autoscaler_amd.workloads import fuzz_removals_plain, fuzz_removals_runs
+    monkeypatch.delenv("CASIM_NO_LEAN_REMOVALS", raising=False)
+    finished = squeezed = gave_up = 0
+    from kubernetes_autoscaler_amd.workloads import runonce_scale_down
+    for w in ([fuzz_removals_plain(s) for s in range(0, 400, 9)] + [fuzz_removals_runs(s) for s in range(80)] +
+              [runonce_scale_down(n, ppn) for n, ppn in ((20, 6), (30, 5), (40, 4), (25, 8), (60, 3))]):
+        case = RemovalCase(nodes=w.nodes, candidates=w.candidates, destination=w.destination, hints=w.hints, persist=w.persist,
+                           max_removable=w.max_removable, last_index=w.last_index, ext_capacity=4 * sum(len(n.pods) for n in w.nodes) + 64)
+        want = removal_oracle(case)
+        monkeypatch.delenv("CASIM_LEAN_LOG_CAP", raising=False)
+        assert_removal_matches(removal_device(case, ctx), want, f"{w.name}")
+        eligible = bool(kaa.Context.last_removals_info()["lean"])
+        monkeypatch.setenv("CASIM_LEAN_LOG_CAP", "256")
+        assert_removal_matches(removal_device(case, ctx), want, f"{w.name} small log")
+        ran_lean = bool(kaa.Context.last_removals_info()["lean"])
+        assert not (ran_lean and not eligible)
+        moves = sum(len(lst) for lst, r in zip(case.pod_lists(), want["removable"]) if r == 1) + sum(1 for c, _, _ in want["ext"] if want["removable"][c] == 1)
+        finished += int(ran_lean)
+        squeezed += int(ran_lean and case.persist and moves > 256)
+        gave_up += int(eligible and not ran_lean)
+    monkeypatch.delenv("CASIM_LEAN_LOG_CAP", raising=False)
+    assert finished >= 20 and squeezed >= 2 and gave_up >= 5, (finished, squeezed, gave_up)
+
+
 def test_the_reference_scale_down_benchmark_on_the_device(ctx, monkeypatch):
     """BenchmarkRunOnceScaleDown at full size (core/bench/benchmark_runonce_test.go:505-521: 400 nodes at 40 %, verifyToBeDeleted(240)): both
     removal kernels == the oracle in every field, and the reference's own number comes out."""

@@ -9,7 +9,7 @@ import pytest
 
 from harness import EmuContext, RemovalCase, assert_removal_matches, emu_lib, removal_device, removal_oracle
 from kubernetes_autoscaler_amd.objects import NodeInfo, Pod, build_test_pod
-from kubernetes_autoscaler_amd.workloads import GiB, MiB, _node, fuzz_removals, fuzz_removals_plain, removal_scale, runonce_scale_down
+from kubernetes_autoscaler_amd.workloads import GiB, MiB, _node, fuzz_removals, fuzz_removals_plain, fuzz_removals_runs, removal_scale, runonce_scale_down
 
 
 def last_kernel():
@@ -132,29 +132,67 @@ def test_the_reference_scale_down_benchmark_shape_small(monkeypatch):
     """BenchmarkRunOnceScaleDown's cluster at 50 nodes (benchmark_runonce_test.go:424-452): 60 % of the nodes go, as at its 400 (golden vector
     benchmark_runonce_scale_down; tests/test_gpu_round5.py runs the full size on the device) — through both removal kernels.  Every candidate
     after the first lists pods that arrived from earlier removals: 40-pod transactions plus the ext path, all night."""
-    w = runonce_scale_down(50)
-    want, _ = both(case_of(w, ext_capacity=50 * 40 * 40), w.name, monkeypatch, expect_lean=None)
-    assert want["n_processed"] == 50 and sum(1 for r in want["removable"] if r == 1) == 30 and len(want["ext"]) > 1000
+    for n in (50, 110):   # (at 110 nodes the log passes 2 048 entries with most of them dead: squeezed before it is full)
+        w = runonce_scale_down(n)
+        want, lean = both(case_of(w, ext_capacity=n * 40 * 40), w.name, monkeypatch, expect_lean=None)
+        assert lean == 1 and want["n_processed"] == n and sum(1 for r in want["removable"] if r == 1) == n * 6 // 10 and len(want["ext"]) > 1000
 
 
 def test_a_log_smaller_than_the_worst_case_gives_up_and_k_sched_answers(monkeypatch):
-    """The one-wave kernel's LDS log is sized to what fits when `pods + ext_capacity` does not (casim_sched.h: lean_optimistic_): the kernel ends
-    at the commit that would overflow it, the host runs the call again through K_sched — same results as the oracle either way.  CASIM_LEAN_LOG_CAP
-    makes the log 256 entries, so that both outcomes occur on small cases."""
+    """The one-wave kernel's LDS log is sized to what fits when `pods + ext_capacity` does not (casim_sched.h: lean_optimistic_): when it fills up,
+    moves onto nodes that were removed since are squeezed out; a commit that still does not fit ends the kernel and the host runs the call again
+    through K_sched — the oracle's results either way.  CASIM_LEAN_LOG_CAP makes the log 256 entries, so that all three outcomes (fits, fits after
+    squeezing, gives up) occur on small cases."""
     monkeypatch.delenv("CASIM_NO_LEAN_REMOVALS", raising=False)
-    monkeypatch.setenv("CASIM_LEAN_LOG_CAP", "256")
-    finished = gave_up = 0
+    finished = squeezed = gave_up = 0
     cases = [case_of(fuzz_removals_plain(s)) for s in range(0, 400, 7)] + [case_of(runonce_scale_down(n), ext_capacity=4000) for n in (5, 10, 20, 40)]
+    cases += [case_of(w, ext_capacity=4 * sum(len(n.pods) for n in w.nodes) + 64) for w in (fuzz_removals_runs(s) for s in range(0, 240, 5)) if len(w.nodes) < 1000]
+    # (every node a candidate, few pods each: many more moves than live entries — pods travel from node to node as the cluster empties)
+    cases += [case_of(runonce_scale_down(n, ppn), ext_capacity=4000) for n, ppn in ((20, 6), (30, 5), (40, 4), (25, 8), (60, 3))]
     for case in cases:
         want = removal_oracle(case)
+        monkeypatch.delenv("CASIM_LEAN_LOG_CAP", raising=False)
+        removal_device(case, EmuContext(0))
+        eligible = last_kernel()[0] == 1
+        monkeypatch.setenv("CASIM_LEAN_LOG_CAP", "256")
         got = removal_device(case, EmuContext(0))
         assert_removal_matches(got, want, "small log")
+        lean = last_kernel()[0] == 1
+        assert not (lean and not eligible)
         moves = sum(len(lst) for lst, r in zip(case.pod_lists(), want["removable"]) if r == 1) + sum(1 for c, _, _ in want["ext"] if want["removable"][c] == 1)
-        lean = last_kernel()[0]
-        if case.persist and moves > 256:
-            assert lean == 0, moves        # it cannot have finished
-        if lean:
-            finished += 1
-        elif moves > 256:
-            gave_up += 1
-    assert finished >= 20 and gave_up >= 3, (finished, gave_up)
+        finished += int(lean)
+        squeezed += int(lean and case.persist and moves > 256)      # more committed moves than entries: it finished because dead ones went
+        gave_up += int(eligible and not lean)
+    monkeypatch.delenv("CASIM_LEAN_LOG_CAP", raising=False)
+    assert finished >= 20 and squeezed >= 2 and gave_up >= 3, (finished, squeezed, gave_up)
+
+
+@pytest.mark.parametrize("seed", range(240))
+def test_fuzz_runs_of_replicas(seed, monkeypatch):
+    """runs of identical pods: the one-wave kernel a word of nodes at a time (schedule_run), the same kernel pod by pod (CASIM_LEAN_BULK_MIN=0)
+    and K_sched, all three against the oracle in every field"""
+    w = fuzz_removals_runs(seed)
+    case = case_of(w, ext_capacity=4 * sum(len(n.pods) for n in w.nodes) + 64)
+    monkeypatch.delenv("CASIM_LEAN_BULK_MIN", raising=False)
+    want, lean = both(case, w.name, monkeypatch, expect_lean=None)
+    monkeypatch.setenv("CASIM_LEAN_BULK_MIN", "0")
+    got = removal_device(case, EmuContext(0))
+    assert_removal_matches(got, want, f"{w.name} lean kernel, pod by pod")
+    assert last_kernel()[0] == lean
+
+
+def test_the_run_fuzz_reaches_what_it_is_for():
+    """long runs, runs that come round the list, failed (reverted) transactions, pods listed again — and most cases on the one-wave kernel"""
+    longest = failed = again = 0
+    for seed in range(240):
+        w = fuzz_removals_runs(seed)
+        case = case_of(w, ext_capacity=4 * sum(len(n.pods) for n in w.nodes) + 64)
+        want = removal_oracle(case)
+        failed += sum(1 for r in want["removable"] if r == 0)
+        again += len(want["ext"])
+        for lst in case.pod_lists():
+            run = 1
+            for a, b in zip(lst, lst[1:]):
+                run = run + 1 if a.spec_key() == b.spec_key() else 1
+                longest = max(longest, run)
+    assert longest >= 40 and failed >= 300 and again >= 3000, (longest, failed, again)
