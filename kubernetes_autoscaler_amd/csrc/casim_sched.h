@@ -761,6 +761,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(512, 1) void sched_kernel(DevTables t, SchedArgs a) {
 // pods, atomic groups, max_removable, hints, persist on / off — follows sched_kernel<.., kTxn = true, ..> statement by statement; results are
 // identical (tests/test_removal_lean_emu.py runs every removal case through both kernels).  Not eligible (host side, SchedulerT::init): domain
 // rules, exclusion words, more than 64 classes, more than 4 lanes, state beyond the LDS budget -> sched_kernel as before.
+constexpr int kLeanLogBuckets = 8;   // removals_lean_kernel<., true>: the log of committed moves in this many parts, by destination & 7
 constexpr int kLeanTxnCap = 256;   // pods of one transaction (destination, pod, class) kept in LDS; longer ones fall back on HBM (after a real wait)
 // log_cap: committed moves the call can make (pods + ext capacity), rounded up to 256
 CS_HOST_DEVICE int64_t casim_lean_removal_bytes(int R, int C, int64_t cap, int64_t log_cap) {
@@ -808,6 +809,12 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
     uint16_t* llog_dest = (uint16_t*)(sslots + cap);          // [log_cap] (8-byte aligned: cap is a multiple of 64)
     uint16_t* llog_ref = llog_dest + log_cap;                 // [log_cap]
     uint8_t* llog_cls = (uint8_t*)(llog_ref + log_cap);       // [log_cap]
+    // BULK_: the log in kLeanLogBuckets parts of log_cap / kLeanLogBuckets entries, an entry in the part of its destination & 7 — a candidate that
+    // received pods walks ONE part (what it is after sits there in commit order); with 40-100 pods per candidate and every node a candidate
+    // (BenchmarkRunOnceScaleDown) the walk of one undivided log was most of a candidate's time.  Lane b holds part b's fill.
+    constexpr int B = BULK_ ? kLeanLogBuckets : 1;
+    const int cap_b = log_cap / B;
+    int32_t my_log_n = 0;
 
     // ---- prologue: node state = what the running pods of each node hold ----
     for (int m = lane; m < cap; m += 64) {
@@ -910,23 +917,27 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
     };
 
     // Entries of the log whose destination has left the list are dead: a node that goes takes every pod it had received along (they were listed
-    // again and their moves logged anew).  Squeezing them out keeps the order of the rest — what a later listing walks.  Done when the log is
-    // full, and as soon as the dead outnumber the living: every candidate that received pods walks the whole log.
-    int32_t dead_n = 0;
+    // again and their moves logged anew).  Squeezing them out keeps the order of the rest — what a later listing walks.  Done when a commit
+    // does not fit.
+    auto part_n = [&](int b) -> int32_t { return B == 1 ? log_n : (int32_t)cs::bcast_u32((uint32_t)my_log_n, b); };
     auto squeeze_log = [&]() {
-        int32_t keep_n = 0;
-        for (int j0 = 0; j0 < log_n; j0 += 64) {
-            const int jj = j0 + lane;
-            const bool in = jj < log_n;
-            const uint32_t d = in ? llog_dest[jj] : 0u, rf = in ? llog_ref[jj] : 0u, cl = in ? llog_cls[jj] : 0u;
-            const bool live = in && ((alive[d >> 6] >> (d & 63)) & 1ull) != 0ull;
-            const uint64_t kb = cs::ballot(live);
-            cs::lds_order();   // (every lane holds its entry before any slot is overwritten: slots only move down)
-            if (live) { const int o = keep_n + cs::mbcnt(kb); llog_dest[o] = (uint16_t)d; llog_ref[o] = (uint16_t)rf; llog_cls[o] = (uint8_t)cl; }
-            keep_n += cs::popc64(kb);
-            cs::lds_order();
+        for (int b = 0; b < B; ++b) {
+            const int32_t nb = part_n(b);
+            uint16_t* ld = llog_dest + b * cap_b; uint16_t* lr = llog_ref + b * cap_b; uint8_t* lc = llog_cls + b * cap_b;
+            int32_t keep_n = 0;
+            for (int j0 = 0; j0 < nb; j0 += 64) {
+                const int jj = j0 + lane;
+                const bool in = jj < nb;
+                const uint32_t d = in ? ld[jj] : 0u, rf = in ? lr[jj] : 0u, cl = in ? lc[jj] : 0u;
+                const bool live = in && ((alive[d >> 6] >> (d & 63)) & 1ull) != 0ull;
+                const uint64_t kb = cs::ballot(live);
+                cs::lds_order();   // (every lane holds its entry before any slot is overwritten: slots only move down)
+                if (live) { const int o = keep_n + cs::mbcnt(kb); ld[o] = (uint16_t)d; lr[o] = (uint16_t)rf; lc[o] = (uint8_t)cl; }
+                keep_n += cs::popc64(kb);
+                cs::lds_order();
+            }
+            if (B == 1) log_n = keep_n; else if (lane == b) my_log_n = keep_n;
         }
-        log_n = keep_n; dead_n = 0;
     };
 
     int32_t my_cand = 0, my_rlo = 0, my_rhi = 0, my_plo = 0, my_phi = 0, my_atomic = 0;   // candidate records kc & ~63 .., one per lane
@@ -953,15 +964,17 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
             // log, four entries per lane and step; a step without a hit costs one compare round.  Each hit goes to the ext tables and, with
             // its class, into the transaction's ring right behind the node's own pods.
             if (a.ext_cap <= 0) break;
-            if (BULK_ && log_n >= 2048 && 2 * dead_n > log_n) squeeze_log();
+            const int lb = B == 1 ? 0 : (Y & (B - 1));
+            const int32_t ln = part_n(lb);
+            const uint16_t* ld = llog_dest + lb * cap_b; const uint16_t* lr = llog_ref + lb * cap_b; const uint8_t* lc = llog_cls + lb * cap_b;
             uint32_t found = 0;
             bool bad = false;
-            for (int j0 = 0; j0 < log_n; j0 += 256) {
+            for (int j0 = 0; j0 < ln; j0 += 256) {
                 const int jj = j0 + lane * 4;
-                const uint64_t d4 = *(const uint64_t*)(llog_dest + jj);
+                const uint64_t d4 = *(const uint64_t*)(ld + jj);
                 bool h[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) h[k] = jj + k < log_n && (int)((d4 >> (16 * k)) & 0xffffull) == Y;
+                for (int k = 0; k < 4; ++k) h[k] = jj + k < ln && (int)((d4 >> (16 * k)) & 0xffffull) == Y;
                 if (cs::ballot(h[0] || h[1] || h[2] || h[3]) == 0ull) continue;
                 uint32_t before = 0, total = 0;
 #pragma unroll
@@ -970,7 +983,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (!h[k]) continue;
-                    const int ref = (int)llog_ref[jj + k], cls = (int)llog_cls[jj + k];
+                    const int ref = (int)lr[jj + k], cls = (int)lc[jj + k];
                     const uint32_t pos = (uint32_t)ext_n + idx;
                     if (pos < (uint32_t)a.ext_cap) { a.ext_ref[pos] = ref; a.ext_cand[pos] = kc; }
                     if ((uint32_t)n_own + idx < (uint32_t)kLeanTxnCap) { txn_ref[n_own + idx] = ref; txn_cls[n_own + idx] = cls; }
@@ -1159,18 +1172,47 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
         if (ok && a.persist) {
             // The log was sized to what LDS holds when the worst case (every pod of the call and every ext slot committed) does not fit: a
             // commit that would run past it ends the kernel with out[5] = 1 and the host runs the call again through K_sched (fetch_removals).
-            if (log_n + n_listed > log_cap) {
-                squeeze_log();
-                if (log_n + n_listed > log_cap) { if (lane == 0) a.out[5] = 1; return; }
+            if (B == 1) {
+                if (log_n + n_listed > log_cap) {
+                    squeeze_log();
+                    if (log_n + n_listed > log_cap) { if (lane == 0) a.out[5] = 1; return; }
+                }
+                // Commit (withForkedSnapshot :174-188): the ghost leaves the list (:230) and the destination set (planner.go:318)
+                for (int i = lane; i < n_listed; i += 64) {
+                    const int m = placed_at(i);
+                    cs::lds_or_u64(arrived + (m >> 6), 1ull << (m & 63));
+                    llog_dest[log_n + i] = (uint16_t)m; llog_ref[log_n + i] = (uint16_t)ref_at(i); llog_cls[log_n + i] = (uint8_t)class_at(i);
+                }
+                log_n += n_listed;
+            } else {
+                // what each part of the log is about to receive (lane b counts part b), then — room permitting — the entries, part by part in
+                // listing order
+                int32_t my_add = 0;
+                for (int i0 = 0; i0 < n_listed; i0 += 64) {
+                    const bool v = i0 + lane < n_listed;
+                    const int m = v ? placed_at(i0 + lane) : 0;
+                    for (int b = 0; b < B; ++b) { const uint64_t mb = cs::ballot(v && (m & (B - 1)) == b); if (lane == b) my_add += cs::popc64(mb); }
+                }
+                if (cs::ballot(lane < B && my_log_n + my_add > cap_b) != 0ull) {
+                    squeeze_log();
+                    if (cs::ballot(lane < B && my_log_n + my_add > cap_b) != 0ull) { if (lane == 0) a.out[5] = 1; return; }
+                }
+                for (int i0 = 0; i0 < n_listed; i0 += 64) {
+                    const int i = i0 + lane;
+                    const bool v = i < n_listed;
+                    const int m = v ? placed_at(i) : 0;
+                    const int32_t rf = v ? ref_at(i) : 0, cl = v ? class_at(i) : 0;
+                    if (v) cs::lds_or_u64(arrived + (m >> 6), 1ull << (m & 63));
+                    for (int b = 0; b < B; ++b) {
+                        const bool mine = v && (m & (B - 1)) == b;
+                        const uint64_t mb = cs::ballot(mine);
+                        if (mb == 0ull) continue;
+                        const int32_t at = (int32_t)cs::bcast_u32((uint32_t)my_log_n, b);
+                        if (mine) { const int o = b * cap_b + at + cs::mbcnt(mb); llog_dest[o] = (uint16_t)m; llog_ref[o] = (uint16_t)rf; llog_cls[o] = (uint8_t)cl; }
+                        if (lane == b) my_log_n += cs::popc64(mb);
+                    }
+                }
             }
-            // Commit (withForkedSnapshot :174-188): the ghost leaves the list (:230) and the destination set (planner.go:318)
-            for (int i = lane; i < n_listed; i += 64) {
-                const int m = placed_at(i);
-                cs::lds_or_u64(arrived + (m >> 6), 1ull << (m & 63));
-                llog_dest[log_n + i] = (uint16_t)m; llog_ref[log_n + i] = (uint16_t)ref_at(i); llog_cls[log_n + i] = (uint8_t)class_at(i);
-            }
-            log_n += n_listed;
-            dead_n += e_hi - e_lo;   // (what this node had received leaves with it)
             if (lane == 0) cs::lds_and_u64(alive + (Y >> 6), ~ybit);
             for (int w = (Y >> 6) + 1 + lane; w < S; w += 64) cs::lds_sub_u32(wpre + w, 1u);
             n_alive--;
@@ -1344,28 +1386,47 @@ public:
             bool plain = true;
             for (size_t c = 0; c < C; ++c) if (used[c] && (p->flags[c] & CASIM_PEG_SELF_EXCL_NODE)) plain = false;
             // (the log of committed moves sits in LDS as 16-bit node and pod indices)
-            lean_log_cap_ = (int32_t)(((int64_t)P_ + (cand->ext_capacity > 0 ? cand->ext_capacity : 0) + 255) & ~255ll);
-            lean_smem_ = (size_t)casim_lean_removal_bytes(R, C_, round_up64_((int64_t)N_), lean_log_cap_);
-            // The worst case — every pod of the call and every ext slot a committed move — rarely happens: a removal that fails commits
-            // nothing, and ext_capacity is a bound the caller picks generously.  When it does not fit, the log gets what LDS has left (room for at
-            // least half of the call's pods, or the attempt is not worth a launch); the kernel gives up at the commit that would overflow it and
-            // fetch_removals / confirm_kernel run the call again through K_sched.  Results are those of whichever kernel finished.
+            const int64_t worst = ((int64_t)P_ + (cand->ext_capacity > 0 ? cand->ext_capacity : 0) + 255) & ~255ll;
+            const int64_t capN = round_up64_((int64_t)N_);
+            const int64_t fixed = casim_lean_removal_bytes(R, C_, capN, 0);
+            const int64_t room = (((int64_t)bk_.lds_budget() - fixed - 8) / 5) & ~255ll;   // entries LDS has left for the log
+            const int forced_cap = getenv("CASIM_LEAN_LOG_CAP") ? atoi(getenv("CASIM_LEAN_LOG_CAP")) : 0;   // tests: a small log, so that squeezing and giving up happen on small cases
+            // which instantiation: the one that places runs a word of nodes at a time when the call has such runs of its own (pods that
+            // arrive later travel in the runs they left in).  CASIM_LEAN_BULK_MIN: 0 = pod by pod always (A/B, tests run both)
+            lean_bulk_min_ = 4;
+            if (const char* ev = getenv("CASIM_LEAN_BULK_MIN")) { const int v = atoi(ev); lean_bulk_min_ = v <= 0 ? 0x7fffffff : (v < 2 ? 2 : v); }
+            lean_bulk_ = false;
+            const bool no_optimism = getenv("CASIM_NO_OPTIMISTIC_LOG") && atoi(getenv("CASIM_NO_OPTIMISTIC_LOG")) != 0;
+            if (!no_optimism) for (size_t i = 0; i < rn.size(); ++i) if (rh[i] < 0 && rn[i] >= lean_bulk_min_) { lean_bulk_ = true; break; }
             lean_optimistic_ = false;
-            if (const char* ev = getenv("CASIM_LEAN_LOG_CAP")) {   // tests: a log of this many entries, so that the give-up path runs on small cases
-                const int v = atoi(ev) & ~255;
-                if (v >= 256 && v < lean_log_cap_) {
-                    lean_log_cap_ = v; lean_optimistic_ = true;
-                    lean_smem_ = (size_t)casim_lean_removal_bytes(R, C_, round_up64_((int64_t)N_), lean_log_cap_);
-                }
+            if (lean_bulk_) {
+                // its log comes in kLeanLogBuckets parts (by destination): each part gets an equal share of what LDS has left, never more than
+                // the worst case.  A part can fill up before the whole would have: this instantiation may always give up (K_sched then answers).
+                int64_t part = worst < room / kLeanLogBuckets ? worst : (room / kLeanLogBuckets) & ~255ll;
+                if (forced_cap >= 64 && forced_cap / kLeanLogBuckets < part) part = forced_cap / kLeanLogBuckets < 64 ? 64 : (forced_cap / kLeanLogBuckets) & ~63ll;
+                if (part >= 64 && (part * kLeanLogBuckets * 2 >= (int64_t)P_ || forced_cap >= 64)) {
+                    lean_log_cap_ = (int32_t)(part * kLeanLogBuckets); lean_optimistic_ = true;
+                    lean_smem_ = (size_t)casim_lean_removal_bytes(R, C_, capN, lean_log_cap_);
+                } else lean_bulk_ = false;
             }
-            if (lean_smem_ > bk_.lds_budget() && !(getenv("CASIM_NO_OPTIMISTIC_LOG") && atoi(getenv("CASIM_NO_OPTIMISTIC_LOG")) != 0)) {
-                const int64_t fixed = casim_lean_removal_bytes(R, C_, round_up64_((int64_t)N_), 0);
-                const int64_t room = (((int64_t)bk_.lds_budget() - fixed - 8) / 5) & ~255ll;
-                // (entries whose destination was removed since are squeezed out when the log fills up: what stays is at most one entry per pod)
-                if (room >= 256 && room * 2 >= (int64_t)P_) {
-                    lean_log_cap_ = (int32_t)room;
-                    lean_smem_ = (size_t)casim_lean_removal_bytes(R, C_, round_up64_((int64_t)N_), lean_log_cap_);
-                    lean_optimistic_ = true;
+            if (!lean_bulk_) {
+                lean_log_cap_ = (int32_t)worst;
+                lean_smem_ = (size_t)casim_lean_removal_bytes(R, C_, capN, lean_log_cap_);
+                // The worst case — every pod of the call and every ext slot a committed move — rarely happens: a removal that fails commits
+                // nothing, and ext_capacity is a bound the caller picks generously.  When it does not fit, the log gets what LDS has left (room for at
+                // least half of the call's pods, or the attempt is not worth a launch; moves onto nodes that were removed since are squeezed out
+                // when it fills up); the kernel gives up at the commit that still does not fit and fetch_removals / confirm_kernel run the call
+                // again through K_sched.  Results are those of whichever kernel finished.
+                if (forced_cap >= 256 && (forced_cap & ~255) < lean_log_cap_) {
+                    lean_log_cap_ = forced_cap & ~255; lean_optimistic_ = true;
+                    lean_smem_ = (size_t)casim_lean_removal_bytes(R, C_, capN, lean_log_cap_);
+                }
+                if (lean_smem_ > bk_.lds_budget() && !no_optimism) {
+                    if (room >= 256 && room * 2 >= (int64_t)P_) {
+                        lean_log_cap_ = (int32_t)room;
+                        lean_smem_ = (size_t)casim_lean_removal_bytes(R, C_, capN, lean_log_cap_);
+                        lean_optimistic_ = true;
+                    }
                 }
             }
             lean_ = plain && N_ <= 65536 && P_ <= 65536 && lean_smem_ <= bk_.lds_budget();
@@ -1396,12 +1457,8 @@ public:
         if (K_ > 0) {
             a_.memo_classes = 0;  // breakOnFailure ends a simulation at the first miss: the memo is never consulted
             a_.n_cand = K_; a_.persist = cand->persist ? 1 : 0; a_.max_removable = cand->max_removable > 0 ? cand->max_removable : 0;
-            a_.lean_bulk_min = 4;   // CASIM_LEAN_BULK_MIN: 0 = pod by pod always (A/B, tests run both)
-            if (const char* ev = getenv("CASIM_LEAN_BULK_MIN")) { const int v = atoi(ev); a_.lean_bulk_min = v <= 0 ? 0x7fffffff : (v < 2 ? 2 : v); }
-            // which instantiation: the one that places runs a word of nodes at a time when the call has such runs of its own (pods that
-            // arrive later travel in the runs they left in)
-            lean_bulk_ = false;
-            for (size_t i = 0; i < rn.size(); ++i) if (rh[i] < 0 && rn[i] >= a_.lean_bulk_min) { lean_bulk_ = true; break; }
+            a_.lean_bulk_min = lean_bulk_min_;
+
             if (lean_) {   // the kernel's candidate / run records (SchedArgs::lean_cand, lean_run)
                 lc.assign(4 * ((size_t)K_ + 1), 0); lr.assign(4 * (rc.size() > 0 ? rc.size() : 1), 0);
                 for (int k = 0; k <= K_; ++k) {
@@ -1655,6 +1712,7 @@ private:
     bool ready_ = false, trivial_ = false, lds_ = true, lean_ = false;
     size_t smem_ = 0, lean_smem_ = 0; int32_t lean_log_cap_ = 0;
     bool lean_gave_up_ = false, lean_bulk_ = false;
+    int32_t lean_bulk_min_ = 4;
     bool lean_optimistic_ = false;   // the LDS log is smaller than the call's worst case: the kernel may give up (out[5]), K_sched then runs
     uint64_t* d_fbits_ = nullptr; uint64_t* d_fit0_ = nullptr;
     const int32_t* d_rule_init_ = nullptr; const int32_t* d_dom_init_ = nullptr; const int32_t* d_contrib_init_ = nullptr;
