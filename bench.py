@@ -1299,6 +1299,49 @@ def sched_issue_roofline(row, kernels_ms):
         return {"error": f"no committed counters for this row: {type(e).__name__}: {e}"}
 
 
+def run_filters_row(kaa, ctx, OracleScenario):
+    import numpy as np
+    from kubernetes_autoscaler_amd.objects import NodeInfo, build_test_node, build_test_pod, with_labels, with_pod_hostname_anti_affinity
+    from kubernetes_autoscaler_amd.scheduling import encode_pending_pods
+    pod = build_test_pod("p", 100, 1000, with_pod_hostname_anti_affinity({"app": "p"}), with_labels({"app": "p"}))
+    nodes = []
+    for i in range(5000):
+        info = NodeInfo(build_test_node(f"n-{i}", 10, 1000))
+        info.pods.extend(build_test_pod(f"p-{i}-{j}", 1, 1, with_labels({"app": "p"})) for j in range(10))
+        nodes.append(info)
+    nodes.append(NodeInfo(build_test_node("n-5000", 1000, 1000)))
+    enc, pc = encode_pending_pods(nodes, [pod])
+    rc, node_out, li, ns = ctx.try_schedule_pods(enc.pegs, enc.groups, pc)
+    _, ms = ctx.try_schedule_pods(enc.pegs, enc.groups, pc, time_iters=20)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ctx.try_schedule_pods(enc.pegs, enc.groups, pc)
+    call_ms = (time.perf_counter() - t0) / 5 * 1e3
+    with kaa.ResidentCluster(ctx, enc.pegs, enc.groups) as cl:
+        cl.try_schedule_pods(pc, commit=False)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            cl.try_schedule_pods(pc, commit=False)
+        resident_ms = (time.perf_counter() - t0) / 20 * 1e3
+    enc.close()
+    s = OracleScenario()
+    for info in nodes:
+        s.add_existing(info)
+    s.pod(pod)
+    want = s.try_schedule_pods([pod], None, None, None, False, 0)
+    oracle_ms = s.last_native_s * 1e3
+    for _ in range(4):
+        s.try_schedule_pods([pod], None, None, None, False, 0)
+        oracle_ms = min(oracle_ms, s.last_native_s * 1e3)
+    s.close()
+    exact = bool(rc == 0 and np.array_equal(np.asarray(node_out), want[0]) and int(li) == want[1] and int(ns) == want[2])
+    return {"workload": "BenchmarkRunFiltersUntilPassingNode: 1 pod x 5001 label-less nodes (50 000 running pods), hostname anti-affinity term",
+            "status": int(rc), "passing_node": int(node_out[0]), "reference_answer": {"passing_node": 5000, "matches": int(node_out[0]) == 5000,
+                                                                                    "source": "plugin_runner_test.go:524-583: \"Last node is the only one that can fit the pod\""},
+            "kernels_ms": ms, "call_ms_tables_uploaded": call_ms, "call_ms_resident_cluster": resident_ms, "oracle_ms": oracle_ms, "bit_exact": exact,
+            "cpu_baseline": {"kind": "port", "cores": 1, "what": "orc_try_schedule_pods, the native call alone (best of 5)"}}
+
+
 def removal_row(kaa, ctx, OracleScenario, w2, counters_row, ext_capacity=None):
     """One scale-down removal workload on the device — the kernel the library picks, then K_sched's general loop forced — and through
     the oracle's native call: kernel times, the A/B, bit-exactness in every field.  counters_row: name of the profiles/sched_counters.json row or None."""
@@ -1406,6 +1449,14 @@ def next_rows(kaa, ctx, workloads):
         out["node_removals_runonce_scale_down"] = r3
     except Exception as e:  # a side table must never take the headline down
         out["node_removals_runonce_scale_down"] = {"error": f"{type(e).__name__}: {e}"}
+    # R4 = BenchmarkRunFiltersUntilPassingNode (simulator/clustersnapshot/predicate/plugin_runner_test.go:524-583): ONE pod with a hostname
+    # anti-affinity term against 5 001 nodes built by BuildTestNode (no labels: the term is inert), one node with room — a single
+    # RunFiltersUntilPassingNode, the smallest unit of the path.  Device: one K_sched launch on the resident node table; a call that uploads its
+    # tables first is dominated by the upload (the shim would not send ONE pod: Routing)
+    try:
+        out["run_filters_until_passing_node"] = run_filters_row(kaa, ctx, OracleScenario)
+    except Exception as e:  # a side table must never take the headline down
+        out["run_filters_until_passing_node"] = {"error": f"{type(e).__name__}: {e}"}
     out["group_pods"] = group_pods_row()
     out["incremental_encode"] = incremental_encode_row()
     return out

@@ -348,6 +348,7 @@ struct casim_encoder {
         std::map<Port, int> port_bit;
         std::map<int32_t, int> pre_occ_bit;
         std::vector<uint8_t> running;                         // [specs] preloaded on some node at the last full finalize (or proved inert since)
+        bool hostname_inert = false;                          // hostname anti-affinity terms exist and no node carried kubernetes.io/hostname: no node bits for them
         std::vector<size_t> with_terms;                       // PEGs whose spec carries hostname anti-affinity terms
         std::vector<std::string> keys;                        // topology keys of the domain rules
         std::vector<std::map<std::string, int>> val_id;       // per key: label value -> domain id
@@ -991,10 +992,21 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         for (auto& t : b.anti) if (t.topology_key == kHostname && term_matches(t, a)) return true;
         return false;
     };
+    // Per-node mode with NO node carrying kubernetes.io/hostname (the reference's BuildTestNode never sets it: BenchmarkRunFiltersUntilPassingNode's
+    // 5 001 nodes, most of its unit tests): a required anti-affinity term counts and blocks through the topology PAIRS of the nodes' labels
+    // (V/kubernetes/pkg/scheduler/framework/plugins/interpodaffinity/filtering.go: updateWithAntiAffinityTerms skips a node without the key,
+    // satisfyExistingPodsAntiAffinity walks the node's labels, satisfyPodAntiAffinity asks for the term's key on the node) — without the label on
+    // any node the hostname terms are inert as a whole, and no node bit is needed for them.  Some nodes with, some without: delegated (below).
+    bool hostname_inert = e->opt.explicit_self_exclusion && NG > 0;
+    if (hostname_inert) for (auto& g : e->groups) if (g.labels.count(kHostname)) { hostname_inert = false; break; }
+    bool any_hostname_terms = false;
     {
         std::vector<size_t> with_terms;  // PEGs whose spec has hostname terms
         for (size_t i = 0; i < G; ++i)
             for (auto& t : e->specs[(size_t)e->pegs[i].spec].anti) if (t.topology_key == kHostname) { with_terms.push_back(i); break; }
+        for (int32_t c : rc.special) for (auto& t : e->specs[(size_t)rc.rep[(size_t)c]].anti) if (t.topology_key == kHostname) any_hostname_terms = true;
+        if (!with_terms.empty()) any_hostname_terms = true;
+        if (hostname_inert) with_terms.clear();
         e->fs.with_terms = with_terms;
         // Which PEGs can a term match at all?  A selector with an In requirement (matchLabels is one) only matches pods that CARRY one of
         // its (key, value) pairs, so the candidates of such a term come from an index pair -> PEGs (ascending) instead of a walk over every
@@ -1055,6 +1067,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
         // spec records were 35 ms of a full finalize).  Every conflicting SPEC still gets its own bit, in ascending spec order.
         std::vector<int8_t> verdict(with_terms.empty() ? 0 : rc.rep.size() * with_terms.size(), (int8_t)-1);
         for (int32_t s : pre_specs) {
+            if (hostname_inert) break;   // (what follows finds hostname conflicts between running pods and PEGs)
             const int32_t c = rc.cls[(size_t)s];
             auto hit = [&](size_t i) {
                 if (!pre_occ_bit.count(s)) pre_occ_bit[s] = xbits.next();
@@ -1594,6 +1607,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
     e->finalized = true;
     stage.mark("group_table");
     // what casim_enc_refinalize works from
+    e->fs.hostname_inert = hostname_inert && any_hostname_terms;
     e->fs.taint_id = taint_id; e->fs.lreqs = lreqs; e->fs.port_bit = port_bit; e->fs.pre_occ_bit = pre_occ_bit;
     e->fs.n_specs = NS; e->fs.NG = NG; e->fs.G = G;
     e->fs.dirty.assign(NG, 0); e->fs.dirty_list.clear();
@@ -1693,6 +1707,7 @@ int32_t casim_enc_refinalize(casim_encoder* e, int32_t* changed_out, int32_t cap
         const Group& g = e->groups[(size_t)gi];
         for (auto& t : g.taints) if ((t.effect == "NoSchedule" || t.effect == "NoExecute") && !fs.taint_id.count(t)) return CASIM_ENC_NEEDS_FULL;
         if (hostname_bits && !g.labels.count(kHostname)) return CASIM_ENC_NEEDS_FULL;
+        if (fs.hostname_inert && g.labels.count(kHostname)) return CASIM_ENC_NEEDS_FULL;   // (the first node with the label: the terms start to count)
         for (size_t k = 0; k < fs.keys.size(); ++k) {
             auto it = g.labels.find(fs.keys[k]);
             if (it != g.labels.end() && !fs.val_id[k].count(it->second)) return CASIM_ENC_NEEDS_FULL;   // a new topology domain

@@ -285,6 +285,27 @@ def test_a_removal_log_smaller_than_the_worst_case_on_the_device(ctx, monkeypatc
     assert finished >= 20 and squeezed >= 2 and gave_up >= 5, (finished, squeezed, gave_up)
 
 
+def test_clusters_without_the_hostname_label_on_the_device(ctx):
+    """BenchmarkRunFiltersUntilPassingNode (plugin_runner_test.go:524-583: 5 001 nodes built by BuildTestNode — no labels —, a pod with a hostname
+    anti-affinity term, one node with room) and fuzz clusters with the label taken off every node: the terms are inert (no node carries the
+    topology key), nothing is delegated, every field equals the oracle's (tests/test_hostname_inert.py: the same under the emulator)"""
+    from harness import RemovalCase, SchedCase, assert_removal_matches, assert_sched_matches, removal_device, removal_oracle, sched_gpu, sched_oracle
+    from test_hostname_inert import _strip, benchmark_cluster
+    from kubernetes_autoscaler_amd import workloads as W
+    case, b = benchmark_cluster()
+    got = sched_gpu(case, ctx)
+    assert_sched_matches(got, sched_oracle(case), "BenchmarkRunFiltersUntilPassingNode")
+    assert list(got[1]) == [b["expect_node_index"]]
+    for seed in range(200, 260):
+        w = W.fuzz_pending(seed)
+        sc = SchedCase(nodes=_strip(w.nodes), pods=w.pods, hints=w.hints, acceptable=w.acceptable, break_on_failure=w.break_on_failure, last_index=w.last_index)
+        assert_sched_matches(sched_gpu(sc, ctx), sched_oracle(sc), w.name)
+        r = W.fuzz_removals(seed)
+        rc = RemovalCase(nodes=_strip(r.nodes), candidates=r.candidates, destination=r.destination, hints=r.hints, persist=r.persist,
+                         max_removable=r.max_removable, last_index=r.last_index)
+        assert_removal_matches(removal_device(rc, ctx), removal_oracle(rc), r.name)
+
+
 def test_the_reference_scale_down_benchmark_on_the_device(ctx, monkeypatch):
     """BenchmarkRunOnceScaleDown at full size (core/bench/benchmark_runonce_test.go:505-521: 400 nodes at 40 %, verifyToBeDeleted(240)): both
     removal kernels == the oracle in every field, and the reference's own number comes out."""

@@ -325,6 +325,16 @@ def test_benchmark_runonce_scale_down():
     assert left * b["node_pods"] == b["nodes"] * b["pods_per_node"]
 
 
+def test_benchmark_run_filters_until_passing_node():
+    """BenchmarkRunFiltersUntilPassingNode (plugin_runner_test.go:524-583): 5 001 label-less nodes, a pod with a hostname anti-affinity term, one
+    node with room — "Last node is the only one that can fit the pod" (tests/test_hostname_inert.py runs the device path on it)."""
+    from harness import sched_oracle
+    from test_hostname_inert import benchmark_cluster
+    case, b = benchmark_cluster()
+    node_out, last_index, scheduled = sched_oracle(case)
+    assert list(node_out) == [b["expect_node_index"]] and scheduled == 1 and last_index == b["expect_node_index"]   # MarkMatch (plugin_runner.go:138)
+
+
 # ---- filter-out-schedulable (SURVEY §8 f1): filterOutSchedulableByPacking ------------------------------------------
 def golden_filter_case(row):
     """(nodes, candidates in the order Process hands them to TrySchedulePods, acceptable) of one TestFilterOutSchedulable row."""
