@@ -1,9 +1,13 @@
 #!/bin/bash
 # Instruction / wait counters of the removal loop's two kernels on bench.py's node_removals workload (5000 nodes, 1500 candidates): separate
 # rocprofv3 --pmc passes (kernel trace only) of tests/tools/removal_ab.py -> gpurun_out/<tag>/removal_counters.json.
-# Usage on the GPU box: bash tools/removal_counters.sh <tag>
+# Usage on the GPU box: bash tools/removal_counters.sh <tag> [runonce]     runonce: the passes run tests/tools/time_runonce_scale_down.py 400 instead
+# (R3 = BenchmarkRunOnceScaleDown: removals_lean_kernel<2, true> — runs a word of nodes at a time, the log in eight parts — next to K_sched)
 set -u
 TAG=${1:-removal_counters}
+WHAT=${2:-ab}
+CMD="tests/tools/removal_ab.py 5000 2"
+if [ "$WHAT" = "runonce" ]; then CMD="tests/tools/time_runonce_scale_down.py 400"; fi
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -13,7 +17,7 @@ for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAV
          "SQ_WAVES SQ_INST_CYCLES_SALU SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SMEM SQ_INSTS_FLAT SQ_ACTIVE_INST_FLAT"; do
   i=$((i+1))
   (cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace -d "$OUT/pmc_$i" -o pmc -- \
-      python "$OLDPWD/tests/tools/removal_ab.py" 5000 2 > "$OUT/pmc_$i.log" 2>&1)
+      python "$OLDPWD/"$CMD > "$OUT/pmc_$i.log" 2>&1)
   echo "pass $i exit $?"
 done
 python - "$OUT" <<'PY'
