@@ -47,8 +47,16 @@ def real_options(case):
     return out
 
 
+def _emu(enc, kinds):
+    return run_emu(enc, kinds=kinds)
+
+
 @pytest.mark.parametrize("case", GOLD["cases"], ids=lambda c: c["name"])
 def test_chain_strategy_rows(case):
+    check_row(case, _emu)
+
+
+def check_row(case, run):
     opts, letters = case["options"], (list(case["filters"]) + [case["fallback"]])[:2]
     contains = lambda s: (lambda i, left: s in opts[i])   # noqa: E731
     assert chain(opts, [contains(s) for s in case["filters"]], contains(case["fallback"])) == case["expect"]
@@ -73,7 +81,7 @@ def test_chain_strategy_rows(case):
     pegs = [PodEquivalenceGroup([Pod(name=f"o{i}", requests={"cpu": 500, "memory": 1})] * p) for i, (_, p) in enumerate(counts)]
     groups = [GroupSpec(NodeInfo(build_test_node(f"g{i}", 1000, 1000)), 10, 0, [i]) for i in range(len(opts))]
     enc = encode(Scenario(pegs=pegs, groups=groups))
-    res, best = run_emu(enc, kinds=kinds)
+    res, best = run(enc, kinds)
     assert [int(x) for x in res.node_count] == [n for n, _ in counts] and [int(x) for x in res.pods_scheduled] == [p for _, p in counts]
     assert best[0] == case["expect"], (case["name"], best)
     enc.close()

@@ -285,6 +285,14 @@ def test_a_removal_log_smaller_than_the_worst_case_on_the_device(ctx, monkeypatc
     assert finished >= 20 and squeezed >= 2 and gave_up >= 5, (finished, squeezed, gave_up)
 
 
+def test_chain_strategy_rows_on_the_device(ctx):
+    """TestChainStrategy_BestOption (expander/factory/chain_test.go:57-134) through packer + option_kernel on the MI355X (tests/test_chain_strategy_rows.py)"""
+    from harness import run_gpu
+    from test_chain_strategy_rows import GOLD, check_row
+    for case in GOLD["cases"]:
+        check_row(case, lambda enc, kinds: run_gpu(enc, ctx, kinds=kinds))
+
+
 def test_clusters_without_the_hostname_label_on_the_device(ctx):
     """BenchmarkRunFiltersUntilPassingNode (plugin_runner_test.go:524-583: 5 001 nodes built by BuildTestNode — no labels —, a pod with a hostname
     anti-affinity term, one node with room) and fuzz clusters with the label taken off every node: the terms are inert (no node carries the
