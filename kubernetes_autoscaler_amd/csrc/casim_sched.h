@@ -31,6 +31,7 @@
 #include <string.h>
 
 #include <map>
+#include <type_traits>
 #include <unordered_map>
 #include <string>
 #include <utility>
@@ -85,6 +86,9 @@ struct SchedArgs {
     // removals_lean_kernel: the candidate and run columns above interleaved (16 bytes per record: one load per lane, one pointer each)
     const int32_t* lean_cand;     // [K + 1][4] node, first run, first pod, atomic (entry K: the end markers)
     const int32_t* lean_run;      // [n_runs][4] class, count, hint, first pod
+    uint16_t* glog_dest;          // removals_lean_kernel<., true, true>: the log of committed moves in HBM (kLeanLogBuckets parts of log_cap / kLeanLogBuckets
+    uint32_t* glog_ref;           // entries each): destination, pod (32 bits: calls of more than 65 536 pods), class
+    uint8_t* glog_cls;
     int32_t lean_bulk_min;        // runs of at least this many unhinted pods of one class are placed a word of nodes at a time (schedule_run)
     int64_t* prof;                // [8] s_memtime ticks per phase of thread 0 (CASIM_PACK_PROF builds + CASIM_PACK_PROF_DUMP) or null
     int32_t* pair_memo;           // [n_pairs] 1 = cached as unschedulable (zeroed before every pass)
@@ -788,7 +792,10 @@ CS_GLOBAL void lean_fit0_kernel(DevTables t, const uint64_t* CS_RESTRICT fbits, 
 // BULK_: runs of unhinted pods of one class are placed a word of nodes at a time (schedule_run).  The host picks the instantiation by the call's own
 // runs (lean_bulk_): a call of short runs keeps the pod-by-pod kernel as it was — the second code path costs it registers (3.55 -> 4.09 ms on the
 // bench's 5000-node row when both lived in one kernel).
-template <int RMAX_, bool BULK_>
+// GLOG_ (with BULK_): the log lives in HBM instead of LDS — calls whose live moves outgrow what LDS has left next to the node state, or with more
+// than 65 536 pods (32-bit pod indices there).  Same walk, same squeeze; the wave orders its own global traffic with a workgroup fence where the
+// LDS form has a wave barrier.  Sized for the worst case in every part: it never gives up.
+template <int RMAX_, bool BULK_, bool GLOG_ = false>
 CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedArgs a, const uint64_t* CS_RESTRICT fit0, int log_cap) {
     const int lane = cs::lane();
     const int R = RMAX_ == 2 ? 2 : t.R;   // (n_res >= 2 always: the two-lane instantiation knows its lane count, every `r < R` folds away)
@@ -806,9 +813,11 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
     int64_t* sfree = (int64_t*)(txn_cls + kLeanTxnCap);      // [R][cap]
     int32_t* sslots = (int32_t*)(sfree + (int64_t)R * cap);  // [cap]
     // committed moves in commit order (what a later candidate that received pods lists again): destination, pod, class
-    uint16_t* llog_dest = (uint16_t*)(sslots + cap);          // [log_cap] (8-byte aligned: cap is a multiple of 64)
-    uint16_t* llog_ref = llog_dest + log_cap;                 // [log_cap]
-    uint8_t* llog_cls = (uint8_t*)(llog_ref + log_cap);       // [log_cap]
+    typedef typename std::conditional<GLOG_, uint32_t, uint16_t>::type ref_t;
+    uint16_t* llog_dest = GLOG_ ? a.glog_dest : (uint16_t*)(sslots + cap);                       // [log_cap] (8-byte aligned: cap is a multiple of 64)
+    ref_t* llog_ref = GLOG_ ? (ref_t*)a.glog_ref : (ref_t*)((uint16_t*)(sslots + cap) + log_cap);   // [log_cap]
+    uint8_t* llog_cls = GLOG_ ? a.glog_cls : (uint8_t*)((uint16_t*)(sslots + cap) + 2 * (int64_t)log_cap);   // [log_cap]
+    auto log_order = [&]() { if (GLOG_) cs::wave_sync(); else cs::lds_order(); };   // lanes read what other lanes wrote to the log
     // BULK_: the log in kLeanLogBuckets parts of log_cap / kLeanLogBuckets entries, an entry in the part of its destination & 7 — a candidate that
     // received pods walks ONE part (what it is after sits there in commit order); with 40-100 pods per candidate and every node a candidate
     // (BenchmarkRunOnceScaleDown) the walk of one undivided log was most of a candidate's time.  Lane b holds part b's fill.
@@ -923,7 +932,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
     auto squeeze_log = [&]() {
         for (int b = 0; b < B; ++b) {
             const int32_t nb = part_n(b);
-            uint16_t* ld = llog_dest + b * cap_b; uint16_t* lr = llog_ref + b * cap_b; uint8_t* lc = llog_cls + b * cap_b;
+            uint16_t* ld = llog_dest + (int64_t)b * cap_b; ref_t* lr = llog_ref + (int64_t)b * cap_b; uint8_t* lc = llog_cls + (int64_t)b * cap_b;
             int32_t keep_n = 0;
             for (int j0 = 0; j0 < nb; j0 += 64) {
                 const int jj = j0 + lane;
@@ -931,10 +940,10 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
                 const uint32_t d = in ? ld[jj] : 0u, rf = in ? lr[jj] : 0u, cl = in ? lc[jj] : 0u;
                 const bool live = in && ((alive[d >> 6] >> (d & 63)) & 1ull) != 0ull;
                 const uint64_t kb = cs::ballot(live);
-                cs::lds_order();   // (every lane holds its entry before any slot is overwritten: slots only move down)
-                if (live) { const int o = keep_n + cs::mbcnt(kb); ld[o] = (uint16_t)d; lr[o] = (uint16_t)rf; lc[o] = (uint8_t)cl; }
+                log_order();   // (every lane holds its entry before any slot is overwritten: slots only move down)
+                if (live) { const int o = keep_n + cs::mbcnt(kb); ld[o] = (uint16_t)d; lr[o] = (ref_t)rf; lc[o] = (uint8_t)cl; }
                 keep_n += cs::popc64(kb);
-                cs::lds_order();
+                log_order();
             }
             if (B == 1) log_n = keep_n; else if (lane == b) my_log_n = keep_n;
         }
@@ -966,7 +975,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
             if (a.ext_cap <= 0) break;
             const int lb = B == 1 ? 0 : (Y & (B - 1));
             const int32_t ln = part_n(lb);
-            const uint16_t* ld = llog_dest + lb * cap_b; const uint16_t* lr = llog_ref + lb * cap_b; const uint8_t* lc = llog_cls + lb * cap_b;
+            const uint16_t* ld = llog_dest + (int64_t)lb * cap_b; const ref_t* lr = llog_ref + (int64_t)lb * cap_b; const uint8_t* lc = llog_cls + (int64_t)lb * cap_b;
             uint32_t found = 0;
             bool bad = false;
             for (int j0 = 0; j0 < ln; j0 += 256) {
@@ -1181,7 +1190,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
                 for (int i = lane; i < n_listed; i += 64) {
                     const int m = placed_at(i);
                     cs::lds_or_u64(arrived + (m >> 6), 1ull << (m & 63));
-                    llog_dest[log_n + i] = (uint16_t)m; llog_ref[log_n + i] = (uint16_t)ref_at(i); llog_cls[log_n + i] = (uint8_t)class_at(i);
+                    llog_dest[log_n + i] = (uint16_t)m; llog_ref[log_n + i] = (ref_t)ref_at(i); llog_cls[log_n + i] = (uint8_t)class_at(i);
                 }
                 log_n += n_listed;
             } else {
@@ -1208,7 +1217,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
                         const uint64_t mb = cs::ballot(mine);
                         if (mb == 0ull) continue;
                         const int32_t at = (int32_t)cs::bcast_u32((uint32_t)my_log_n, b);
-                        if (mine) { const int o = b * cap_b + at + cs::mbcnt(mb); llog_dest[o] = (uint16_t)m; llog_ref[o] = (uint16_t)rf; llog_cls[o] = (uint8_t)cl; }
+                        if (mine) { const int64_t o = (int64_t)b * cap_b + at + cs::mbcnt(mb); llog_dest[o] = (uint16_t)m; llog_ref[o] = (ref_t)rf; llog_cls[o] = (uint8_t)cl; }
                         if (lane == b) my_log_n += cs::popc64(mb);
                     }
                 }
@@ -1234,6 +1243,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
             }
         }
         cs::lds_order();
+        if (GLOG_) cs::wave_sync();   // (the entries just logged are in HBM: the next candidate's listing reads them through other lanes)
         if (ok && cs::bcast_u32((uint32_t)my_atomic, kc & 63) == 0u) removed++;   // len(removableList) - atomicScaleDownNodesCount
         if (lane == 0) a.removable_out[kc] = ok ? 1 : 0;
     }
@@ -1387,6 +1397,7 @@ public:
             for (size_t c = 0; c < C; ++c) if (used[c] && (p->flags[c] & CASIM_PEG_SELF_EXCL_NODE)) plain = false;
             // (the log of committed moves sits in LDS as 16-bit node and pod indices)
             const int64_t worst = ((int64_t)P_ + (cand->ext_capacity > 0 ? cand->ext_capacity : 0) + 255) & ~255ll;
+            const int64_t E0_worst_ = cand->ext_capacity > 0 ? cand->ext_capacity : 0;
             const int64_t capN = round_up64_((int64_t)N_);
             const int64_t fixed = casim_lean_removal_bytes(R, C_, capN, 0);
             const int64_t room = (((int64_t)bk_.lds_budget() - fixed - 8) / 5) & ~255ll;   // entries LDS has left for the log
@@ -1429,8 +1440,22 @@ public:
                     }
                 }
             }
-            lean_ = plain && N_ <= 65536 && P_ <= 65536 && lean_smem_ <= bk_.lds_budget();
-            if (!lean_) lean_optimistic_ = false;
+            // The log in HBM (removals_lean_kernel<., true, true>): when the node state fits LDS but the log does not — not even the optimistic one —
+            // or the call lists more than 65 536 pods.  Every part is sized for the worst case (it never gives up); 7 bytes per entry.
+            lean_glog_ = false;
+            {
+                const bool force = getenv("CASIM_LEAN_HBM_LOG") && atoi(getenv("CASIM_LEAN_HBM_LOG")) != 0;   // tests: every eligible call
+                const bool off = getenv("CASIM_LEAN_HBM_LOG") && atoi(getenv("CASIM_LEAN_HBM_LOG")) == 0;
+                const bool lds_log_ok = P_ <= 65536 && lean_smem_ <= bk_.lds_budget();
+                const int64_t glog_bytes = 7 * worst * kLeanLogBuckets;
+                if (!off && (force || !lds_log_ok) && fixed <= (int64_t)bk_.lds_budget() && glog_bytes <= (256ll << 20) && (int64_t)P_ + E0_worst_ <= 0x7fffffffll) {
+                    lean_glog_ = true; lean_bulk_ = true; lean_optimistic_ = false;
+                    lean_log_cap_ = (int32_t)(worst * kLeanLogBuckets);
+                    lean_smem_ = (size_t)fixed;
+                }
+            }
+            lean_ = plain && N_ <= 65536 && (lean_glog_ || P_ <= 65536) && lean_smem_ <= bk_.lds_budget();
+            if (!lean_) { lean_optimistic_ = false; lean_glog_ = false; }
         }
         if (lean_) max_threads = 64;   // (cap_ = the node count rounded up to whole words)
         threads_ = (int)(round_up64_((int64_t)N_) < max_threads ? round_up64_((int64_t)N_) : max_threads);
@@ -1451,6 +1476,10 @@ public:
         d_fbits_ = (uint64_t*)dalloc(8 * C * (size_t)S_);
         a_.fbits = d_fbits_;
         if (lean_) d_fit0_ = (uint64_t*)dalloc(8 * C * (size_t)S_);
+        if (lean_ && lean_glog_) {
+            a_.glog_dest = (uint16_t*)dalloc(2 * (size_t)lean_log_cap_); a_.glog_ref = (uint32_t*)dalloc(4 * (size_t)lean_log_cap_); a_.glog_cls = (uint8_t*)dalloc((size_t)lean_log_cap_);
+            if (!a_.glog_dest || !a_.glog_ref || !a_.glog_cls) { lean_ = false; lean_glog_ = false; }
+        }
         if (getenv("CASIM_PACK_PROF_DUMP")) { a_.prof = (int64_t*)dalloc(96); bk_.zero(a_.prof, 96); }
         a_.node_out = (int32_t*)dalloc(4 * (P + (size_t)(cand && cand->ext_capacity > 0 ? cand->ext_capacity : 0)));
         a_.out = (int32_t*)dalloc(32);
@@ -1551,7 +1580,10 @@ public:
         if (K_ > 0) { int32_t* li = last_removals_info(); li[0] = lean_ ? 1 : 0; li[1] = lean_ ? 64 : threads_; li[2] = (lean_ || lds_) ? 1 : 0; li[3] = n_runs_; }
         if (lean_) {
             bk_.launch(lean_fit0_kernel, S_, C_, 64, (size_t)0, dt_, (const uint64_t*)d_fbits_, d_fit0_, S_);
-            if (lean_bulk_) {
+            if (lean_glog_) {
+                if (dt_.R <= 2) bk_.launch(removals_lean_kernel<2, true, true>, 1, 1, 64, lean_smem_, dt_, a_, (const uint64_t*)d_fit0_, lean_log_cap_);
+                else bk_.launch(removals_lean_kernel<4, true, true>, 1, 1, 64, lean_smem_, dt_, a_, (const uint64_t*)d_fit0_, lean_log_cap_);
+            } else if (lean_bulk_) {
                 if (dt_.R <= 2) bk_.launch(removals_lean_kernel<2, true>, 1, 1, 64, lean_smem_, dt_, a_, (const uint64_t*)d_fit0_, lean_log_cap_);
                 else bk_.launch(removals_lean_kernel<4, true>, 1, 1, 64, lean_smem_, dt_, a_, (const uint64_t*)d_fit0_, lean_log_cap_);
             } else {
@@ -1711,7 +1743,7 @@ private:
     int32_t cap_ = 0, n_runs_ = 0, last_index_ = 0;
     bool ready_ = false, trivial_ = false, lds_ = true, lean_ = false;
     size_t smem_ = 0, lean_smem_ = 0; int32_t lean_log_cap_ = 0;
-    bool lean_gave_up_ = false, lean_bulk_ = false;
+    bool lean_gave_up_ = false, lean_bulk_ = false, lean_glog_ = false;
     int32_t lean_bulk_min_ = 4;
     bool lean_optimistic_ = false;   // the LDS log is smaller than the call's worst case: the kernel may give up (out[5]), K_sched then runs
     uint64_t* d_fbits_ = nullptr; uint64_t* d_fit0_ = nullptr;

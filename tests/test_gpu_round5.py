@@ -314,6 +314,30 @@ def test_clusters_without_the_hostname_label_on_the_device(ctx):
         assert_removal_matches(removal_device(rc, ctx), removal_oracle(rc), r.name)
 
 
+def test_the_removal_log_in_hbm_on_the_device(ctx, monkeypatch):
+    """removals_lean_kernel<., true, true> (the log of committed moves in HBM, 32-bit pod indices): forced on the run fuzz and the plain fuzz
+    (CASIM_LEAN_HBM_LOG=1), picked by itself for BenchmarkRunOnceScaleDown's cluster at 1 650 nodes (66 000 pods) — the oracle's results in every field"""
+    from harness import RemovalCase, assert_removal_matches, removal_device, removal_oracle
+    from kubernetes_autoscaler_amd.workloads import fuzz_removals_plain, fuzz_removals_runs, runonce_scale_down
+    monkeypatch.delenv("CASIM_NO_LEAN_REMOVALS", raising=False)
+    monkeypatch.setenv("CASIM_LEAN_HBM_LOG", "1")
+    ran = 0
+    for w in [fuzz_removals_runs(s) for s in range(120)] + [fuzz_removals_plain(s) for s in range(0, 400, 5)]:
+        case = RemovalCase(nodes=w.nodes, candidates=w.candidates, destination=w.destination, hints=w.hints, persist=w.persist,
+                           max_removable=w.max_removable, last_index=w.last_index, ext_capacity=4 * sum(len(n.pods) for n in w.nodes) + 64)
+        assert_removal_matches(removal_device(case, ctx), removal_oracle(case), f"{w.name} log in HBM")
+        ran += int(kaa.Context.last_removals_info()["lean"])
+    assert ran >= 150, ran
+    monkeypatch.delenv("CASIM_LEAN_HBM_LOG", raising=False)
+    w = runonce_scale_down(1650)
+    case = RemovalCase(nodes=w.nodes, candidates=w.candidates, ext_capacity=70000)
+    want = removal_oracle(case)
+    got = removal_device(case, ctx)
+    assert kaa.Context.last_removals_info()["lean"]
+    assert_removal_matches(got, want, w.name)
+    assert int((got.removable == 1).sum()) == 990
+
+
 def test_the_reference_scale_down_benchmark_on_the_device(ctx, monkeypatch):
     """BenchmarkRunOnceScaleDown at full size (core/bench/benchmark_runonce_test.go:505-521: 400 nodes at 40 %, verifyToBeDeleted(240)): both
     removal kernels == the oracle in every field, and the reference's own number comes out."""

@@ -196,3 +196,32 @@ def test_the_run_fuzz_reaches_what_it_is_for():
                 run = run + 1 if a.spec_key() == b.spec_key() else 1
                 longest = max(longest, run)
     assert longest >= 40 and failed >= 300 and again >= 3000, (longest, failed, again)
+
+
+@pytest.mark.parametrize("base", range(0, 240, 40))
+def test_the_log_in_hbm(base, monkeypatch):
+    """removals_lean_kernel<., true, true>: the log of committed moves in HBM (calls whose live moves outgrow LDS or that list more than 65 536 pods).
+    CASIM_LEAN_HBM_LOG=1 sends every eligible call through it: the run fuzz and the plain fuzz against the oracle in every field."""
+    monkeypatch.delenv("CASIM_NO_LEAN_REMOVALS", raising=False)
+    monkeypatch.setenv("CASIM_LEAN_HBM_LOG", "1")
+    ran = 0
+    for seed in range(base, base + 40):
+        for w in (fuzz_removals_runs(seed), fuzz_removals_plain(seed)):
+            case = case_of(w, ext_capacity=4 * sum(len(n.pods) for n in w.nodes) + 64)
+            assert_removal_matches(removal_device(case, EmuContext(0)), removal_oracle(case), f"{w.name} log in HBM")
+            ran += last_kernel()[0]
+    assert ran >= 60, ran
+
+
+def test_more_pods_than_sixteen_bits(monkeypatch):
+    """BenchmarkRunOnceScaleDown's cluster at 1 650 nodes: 66 000 pods to move — beyond the 16-bit pod indices of the LDS log; the HBM log (32-bit)
+    is picked by itself and the one-wave kernel answers: 60 % of the nodes go"""
+    monkeypatch.delenv("CASIM_NO_LEAN_REMOVALS", raising=False)
+    monkeypatch.delenv("CASIM_LEAN_HBM_LOG", raising=False)
+    w = runonce_scale_down(1650)
+    case = case_of(w, ext_capacity=70000)
+    want = removal_oracle(case)
+    got = removal_device(case, EmuContext(0))
+    assert last_kernel()[0] == 1
+    assert_removal_matches(got, want, w.name)
+    assert sum(1 for r in want["removable"] if r == 1) == 990

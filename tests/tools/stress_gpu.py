@@ -124,12 +124,12 @@ for seed in range(first, first + count):
     rc = RemovalCase(nodes=w.nodes, candidates=w.candidates, destination=w.destination, hints=w.hints, persist=w.persist,
                      max_removable=w.max_removable, last_index=w.last_index, ext_capacity=4 * sum(len(n.pods) for n in w.nodes) + 64)
     want = removal_oracle(rc)
-    for tag, env in (("word_at_a_time", {}), ("pod_by_pod", {"CASIM_LEAN_BULK_MIN": "0"}), ("k_sched", {"CASIM_NO_LEAN_REMOVALS": "1"})):
-        for k in ("CASIM_LEAN_BULK_MIN", "CASIM_NO_LEAN_REMOVALS"):
+    for tag, env in (("word_at_a_time", {}), ("pod_by_pod", {"CASIM_LEAN_BULK_MIN": "0"}), ("k_sched", {"CASIM_NO_LEAN_REMOVALS": "1"}), ("log_in_hbm", {"CASIM_LEAN_HBM_LOG": "1"})):
+        for k in ("CASIM_LEAN_BULK_MIN", "CASIM_NO_LEAN_REMOVALS", "CASIM_LEAN_HBM_LOG"):
             os.environ.pop(k, None)
         os.environ.update(env)
         assert_removal_matches(removal_device(rc, ctx), want, w.name + " " + tag); bump("fuzz_removals_runs_" + tag)
-    for k in ("CASIM_LEAN_BULK_MIN", "CASIM_NO_LEAN_REMOVALS"):
+    for k in ("CASIM_LEAN_BULK_MIN", "CASIM_NO_LEAN_REMOVALS", "CASIM_LEAN_HBM_LOG"):
         os.environ.pop(k, None)
     # round 5: batches — chained groups, the ranked orderer forced on, requests narrowed by the caller, PEG rows shared between the tiles
     if seed % 2 == 0:

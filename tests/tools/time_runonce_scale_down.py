@@ -35,8 +35,9 @@ for n in [int(x) for x in sys.argv[1:]] or [400, 1000]:
     row = {"nodes": n, "candidates": n, "pods": int(len(pc)), "pods_listed_again": len(want["ext"]), "removable_oracle": int(sum(1 for r in want["removable"] if r == 1)),
            "reference_answer": int(0.6 * n), "oracle_ms": s.last_native_s * 1e3, "ext_capacity": ext_cap}
     s.close()
-    for name, env in (("default", {}), ("no_optimistic_log", {"CASIM_NO_OPTIMISTIC_LOG": "1"}), ("k_sched", {"CASIM_NO_LEAN_REMOVALS": "1"})):
-        for k in ("CASIM_NO_OPTIMISTIC_LOG", "CASIM_NO_LEAN_REMOVALS"):
+    for name, env in (("default", {}), ("log_in_hbm", {"CASIM_LEAN_HBM_LOG": "1"}), ("no_optimistic_log", {"CASIM_NO_OPTIMISTIC_LOG": "1", "CASIM_LEAN_HBM_LOG": "0"}),
+                      ("k_sched", {"CASIM_NO_LEAN_REMOVALS": "1"})):
+        for k in ("CASIM_NO_OPTIMISTIC_LOG", "CASIM_NO_LEAN_REMOVALS", "CASIM_LEAN_HBM_LOG"):
             os.environ.pop(k, None)
         os.environ.update(env)
         r = ctx.simulate_node_removals(enc.pegs, enc.groups, case.candidates, off, pc, ext_capacity=ext_cap)
@@ -47,7 +48,7 @@ for n in [int(x) for x in sys.argv[1:]] or [400, 1000]:
                      int(r.last_index) == want["last_index"] and int(r.n_processed) == want["n_processed"] and ext == [tuple(x) for x in want["ext"]])
         row[name] = {"kernels_ms": ms, "ran_lean": bool(info["lean"]), "removable": int((r.removable == 1).sum()), "bit_exact": exact,
                      "us_per_candidate": ms * 1e3 / n, "speedup_vs_oracle": row["oracle_ms"] / ms}
-    for k in ("CASIM_NO_OPTIMISTIC_LOG", "CASIM_NO_LEAN_REMOVALS"):
+    for k in ("CASIM_NO_OPTIMISTIC_LOG", "CASIM_NO_LEAN_REMOVALS", "CASIM_LEAN_HBM_LOG"):
         os.environ.pop(k, None)
     rows.append(row)
     enc.close()
