@@ -1448,7 +1448,9 @@ public:
                 const bool off = getenv("CASIM_LEAN_HBM_LOG") && atoi(getenv("CASIM_LEAN_HBM_LOG")) == 0;
                 const bool lds_log_ok = P_ <= 65536 && lean_smem_ <= bk_.lds_budget();
                 const int64_t glog_bytes = 7 * worst * kLeanLogBuckets;
-                if (!off && (force || !lds_log_ok) && fixed <= (int64_t)bk_.lds_budget() && glog_bytes <= (256ll << 20) && (int64_t)P_ + E0_worst_ <= 0x7fffffffll) {
+                glog_possible_ = !off && fixed <= (int64_t)bk_.lds_budget() && glog_bytes <= (256ll << 20) && (int64_t)P_ + E0_worst_ <= 0x7fffffffll;
+                glog_worst_ = worst; glog_fixed_ = fixed;
+                if (glog_possible_ && (force || !lds_log_ok)) {
                     lean_glog_ = true; lean_bulk_ = true; lean_optimistic_ = false;
                     lean_log_cap_ = (int32_t)(worst * kLeanLogBuckets);
                     lean_smem_ = (size_t)fixed;
@@ -1476,10 +1478,7 @@ public:
         d_fbits_ = (uint64_t*)dalloc(8 * C * (size_t)S_);
         a_.fbits = d_fbits_;
         if (lean_) d_fit0_ = (uint64_t*)dalloc(8 * C * (size_t)S_);
-        if (lean_ && lean_glog_) {
-            a_.glog_dest = (uint16_t*)dalloc(2 * (size_t)lean_log_cap_); a_.glog_ref = (uint32_t*)dalloc(4 * (size_t)lean_log_cap_); a_.glog_cls = (uint8_t*)dalloc((size_t)lean_log_cap_);
-            if (!a_.glog_dest || !a_.glog_ref || !a_.glog_cls) { lean_ = false; lean_glog_ = false; }
-        }
+        if (lean_ && lean_glog_ && !alloc_glog_()) { lean_ = false; lean_glog_ = false; }
         if (getenv("CASIM_PACK_PROF_DUMP")) { a_.prof = (int64_t*)dalloc(96); bk_.zero(a_.prof, 96); }
         a_.node_out = (int32_t*)dalloc(4 * (P + (size_t)(cand && cand->ext_capacity > 0 ? cand->ext_capacity : 0)));
         a_.out = (int32_t*)dalloc(32);
@@ -1658,8 +1657,9 @@ public:
             if (out->ext_node) bk_.d2h(s_en, a_.node_out + P_, eb);
         }
         bk_.sync();
-        if (lean_ && lean_optimistic_ && bk_.ok() && o[5] == 1) {   // the log overflowed: the general loop answers (run() re-initialises every output)
-            lean_ = false; lean_optimistic_ = false; lean_gave_up_ = true;
+        if (lean_ && lean_optimistic_ && bk_.ok() && o[5] == 1) {   // the LDS log overflowed: the same kernel with its log in HBM answers, or the general loop (run() re-initialises every output)
+            lean_optimistic_ = false; lean_gave_up_ = true;
+            if (!switch_to_glog_()) lean_ = false;
             const int32_t rc = run();
             return rc == CASIM_OK ? fetch_removals(out) : rc;
         }
@@ -1690,8 +1690,8 @@ public:
         int32_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         bk_.d2h(o, a_.out, 32); bk_.sync();
         if (!bk_.ok()) return fail(CASIM_ERR_HIP, bk_.error());
-        if (o[5] == 1) { lean_ = false; lean_gave_up_ = true; }
         lean_optimistic_ = false;
+        if (o[5] == 1) { lean_gave_up_ = true; if (!switch_to_glog_()) lean_ = false; }
         return CASIM_OK;
     }
 
@@ -1743,7 +1743,21 @@ private:
     int32_t cap_ = 0, n_runs_ = 0, last_index_ = 0;
     bool ready_ = false, trivial_ = false, lds_ = true, lean_ = false;
     size_t smem_ = 0, lean_smem_ = 0; int32_t lean_log_cap_ = 0;
-    bool lean_gave_up_ = false, lean_bulk_ = false, lean_glog_ = false;
+    bool lean_gave_up_ = false, lean_bulk_ = false, lean_glog_ = false, glog_possible_ = false;
+    int64_t glog_worst_ = 0, glog_fixed_ = 0;
+    bool alloc_glog_() {
+        a_.glog_dest = (uint16_t*)dalloc(2 * (size_t)lean_log_cap_); a_.glog_ref = (uint32_t*)dalloc(4 * (size_t)lean_log_cap_); a_.glog_cls = (uint8_t*)dalloc((size_t)lean_log_cap_);
+        return a_.glog_dest && a_.glog_ref && a_.glog_cls;
+    }
+    // the LDS log gave up: the third instantiation (log in HBM, every part sized for the worst case) when it is possible at all
+    bool switch_to_glog_() {
+        if (!glog_possible_) return false;
+        lean_log_cap_ = (int32_t)(glog_worst_ * kLeanLogBuckets);
+        lean_smem_ = (size_t)glog_fixed_;
+        if (!alloc_glog_()) return false;
+        lean_glog_ = true; lean_bulk_ = true;
+        return true;
+    }
     int32_t lean_bulk_min_ = 4;
     bool lean_optimistic_ = false;   // the LDS log is smaller than the call's worst case: the kernel may give up (out[5]), K_sched then runs
     uint64_t* d_fbits_ = nullptr; uint64_t* d_fit0_ = nullptr;

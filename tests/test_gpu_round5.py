@@ -263,6 +263,7 @@ def test_a_removal_log_smaller_than_the_worst_case_on_the_device(ctx, monkeypatc
     from harness import RemovalCase, assert_removal_matches, removal_device, removal_oracle
     from kubernetes_autoscaler_amd.workloads import fuzz_removals_plain, fuzz_removals_runs
     monkeypatch.delenv("CASIM_NO_LEAN_REMOVALS", raising=False)
+    monkeypatch.setenv("CASIM_LEAN_HBM_LOG", "0")    # (the fall-back to K_sched; with the HBM log allowed the one-wave kernel would answer again)
     finished = squeezed = gave_up = 0
     from kubernetes_autoscaler_amd.workloads import runonce_scale_down
     for w in ([fuzz_removals_plain(s) for s in range(0, 400, 9)] + [fuzz_removals_runs(s) for s in range(80)] +
@@ -282,7 +283,15 @@ def test_a_removal_log_smaller_than_the_worst_case_on_the_device(ctx, monkeypatc
         squeezed += int(ran_lean and case.persist and moves > 256)
         gave_up += int(eligible and not ran_lean)
     monkeypatch.delenv("CASIM_LEAN_LOG_CAP", raising=False)
+    monkeypatch.delenv("CASIM_LEAN_HBM_LOG", raising=False)
     assert finished >= 20 and squeezed >= 2 and gave_up >= 5, (finished, squeezed, gave_up)
+    # default policy: an LDS log that gives up hands over to the log in HBM — still the one-wave kernel, still the oracle's results
+    monkeypatch.setenv("CASIM_LEAN_LOG_CAP", "256")
+    for w in [runonce_scale_down(n, ppn) for n, ppn in ((20, 40), (40, 20), (30, 30))]:
+        case = RemovalCase(nodes=w.nodes, candidates=w.candidates, ext_capacity=4000)
+        assert_removal_matches(removal_device(case, ctx), removal_oracle(case), f"{w.name} LDS log, then HBM log")
+        assert kaa.Context.last_removals_info()["lean"]
+    monkeypatch.delenv("CASIM_LEAN_LOG_CAP", raising=False)
 
 
 def test_chain_strategy_rows_on_the_device(ctx):

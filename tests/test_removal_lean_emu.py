@@ -144,6 +144,7 @@ def test_a_log_smaller_than_the_worst_case_gives_up_and_k_sched_answers(monkeypa
     through K_sched — the oracle's results either way.  CASIM_LEAN_LOG_CAP makes the log 256 entries, so that all three outcomes (fits, fits after
     squeezing, gives up) occur on small cases."""
     monkeypatch.delenv("CASIM_NO_LEAN_REMOVALS", raising=False)
+    monkeypatch.setenv("CASIM_LEAN_HBM_LOG", "0")    # (the fall-back to K_sched is what this test is after; test_an_lds_log_that_gives_up_... has the other one)
     finished = squeezed = gave_up = 0
     cases = [case_of(fuzz_removals_plain(s)) for s in range(0, 400, 7)] + [case_of(runonce_scale_down(n), ext_capacity=4000) for n in (5, 10, 20, 40)]
     cases += [case_of(w, ext_capacity=4 * sum(len(n.pods) for n in w.nodes) + 64) for w in (fuzz_removals_runs(s) for s in range(0, 240, 5)) if len(w.nodes) < 1000]
@@ -225,3 +226,32 @@ def test_more_pods_than_sixteen_bits(monkeypatch):
     assert last_kernel()[0] == 1
     assert_removal_matches(got, want, w.name)
     assert sum(1 for r in want["removable"] if r == 1) == 990
+
+
+def test_an_lds_log_that_gives_up_hands_over_to_the_log_in_hbm(monkeypatch):
+    """default policy: the LDS log first; when it gives up, the same one-wave kernel runs again with its log in HBM (K_sched only where that is not
+    possible) — the oracle's results, and the kernel that answered is the one-wave kernel"""
+    monkeypatch.delenv("CASIM_NO_LEAN_REMOVALS", raising=False)
+    monkeypatch.delenv("CASIM_LEAN_HBM_LOG", raising=False)
+    handed_over = 0
+    cases = [case_of(runonce_scale_down(n, ppn), ext_capacity=4000) for n, ppn in ((20, 40), (40, 20), (30, 30))]
+    cases += [case_of(w, ext_capacity=4 * sum(len(n.pods) for n in w.nodes) + 64) for w in (fuzz_removals_runs(s) for s in range(0, 240, 6)) if len(w.nodes) < 1000]
+    for case in cases:
+        want = removal_oracle(case)
+        monkeypatch.setenv("CASIM_LEAN_LOG_CAP", "256")
+        monkeypatch.setenv("CASIM_LEAN_HBM_LOG", "0")
+        removal_device(case, EmuContext(0))
+        gives_up = last_kernel()[0] == 0
+        monkeypatch.delenv("CASIM_LEAN_HBM_LOG", raising=False)
+        got = removal_device(case, EmuContext(0))
+        assert_removal_matches(got, want, "LDS log, then HBM log")
+        monkeypatch.delenv("CASIM_LEAN_LOG_CAP", raising=False)
+        removal_device(case, EmuContext(0))
+        eligible = last_kernel()[0] == 1
+        if eligible and gives_up:
+            monkeypatch.setenv("CASIM_LEAN_LOG_CAP", "256")
+            removal_device(case, EmuContext(0))
+            assert last_kernel()[0] == 1      # (with the small LDS log AND the HBM log allowed: still the one-wave kernel)
+            monkeypatch.delenv("CASIM_LEAN_LOG_CAP", raising=False)
+            handed_over += 1
+    assert handed_over >= 3, handed_over
