@@ -618,7 +618,8 @@ typedef struct casim_removal_candidates {
                                       * casim_last_removals_info — keeps its log of committed moves in LDS.  The worst case is `pods + ext_capacity`
                                       * entries; when that does not fit, the log gets what LDS has left — if that holds at least half of the call's
                                       * pods; moves onto nodes that were removed since are squeezed out when it fills up — and a call that still
-                                      * outgrows it is run again through the general loop: same results, the first attempt's time lost.) */
+                                      * outgrows it is run again with the log in HBM (or, where that is not possible, through the general loop): same
+                                      * results, the first attempt's time lost.  Calls that list more than 65 536 pods keep the log in HBM from the start.) */
     const struct casim_domain_rules* rules; /* the encoder's domain rules (PodTopologySpread, zone anti-affinity); NULL = none */
 } casim_removal_candidates;
 
