@@ -1397,15 +1397,16 @@ def removal_row(kaa, ctx, OracleScenario, w2, counters_row, ext_capacity=None):
            "cpu_baseline": {"kind": "port", "cores": 1, "what": "orc_simulate_node_removals, the native call alone"}}
     if counters_row:
         row["issue_roofline"] = sched_issue_roofline(counters_row, ms2)
-    # the same call through tools/casim_native (plain C++ over the C ABI): encode of the whole snapshot (one spec record per running pod, pod by pod:
-    # a shim at cluster scale hands them over with casim_enc_add_running_pods), then casim_simulate_node_removals enter -> return with its tables uploaded
+    # the same call through tools/casim_native (plain C++ over the C ABI): encode of the whole snapshot the way the Go shim hands it over (one spec record
+    # per running pod; the plain ones in ONE casim_enc_add_running_pods over an interned string table: encode.go runningPods), then
+    # casim_simulate_node_removals enter -> return with its tables uploaded
     try:
         import native_trace
         tpath = os.path.join("/tmp", f"casim_{w2.name}.trace")
-        native_trace.trace_removals(w2, tpath, iters=5)[0].close()
+        native_trace.trace_removals(w2, tpath, iters=5, bulk=True)[0].close()
         nrc, nat = native_trace.run_native(tpath)
-        row["native"] = dict({k: nat[k] for k in ("enc_calls", "encode_ms", "wall_ms", "kernels_ms", "removable", "n_ext", "engine_error") if k in nat}, exit_code=nrc,
-                             what="encode_ms: every casim_enc_* call + finalize; wall_ms: casim_simulate_node_removals enter -> return (tables uploaded by the call, ext_capacity 2 * pods + 64)")
+        row["native"] = dict({k: nat[k] for k in ("enc_calls", "encode_calls_ms", "finalize_ms", "encode_ms", "wall_ms", "kernels_ms", "removable", "n_ext", "engine_error") if k in nat}, exit_code=nrc,
+                             what="encode_ms: every casim_enc_* call (running pods through casim_enc_add_running_pods) + finalize; wall_ms: casim_simulate_node_removals enter -> return (tables uploaded by the call, ext_capacity 2 * pods + 64)")
     except Exception as e:
         row["native"] = {"error": f"{type(e).__name__}: {e}"}
     return row

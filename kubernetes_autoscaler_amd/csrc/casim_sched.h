@@ -1180,7 +1180,8 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void removals_lean_kernel(DevTables t, SchedAr
         auto class_at = [&](int i) -> int32_t { return i < kLeanTxnCap ? txn_cls[i] : a.pod_class[ref_at(i)]; };
         if (ok && a.persist) {
             // The log was sized to what LDS holds when the worst case (every pod of the call and every ext slot committed) does not fit: a
-            // commit that would run past it ends the kernel with out[5] = 1 and the host runs the call again through K_sched (fetch_removals).
+            // commit that would run past it — also after squeezing — ends the kernel with out[5] = 1 and the host runs the call again
+            // (fetch_removals: with the log in HBM, or through K_sched).
             if (B == 1) {
                 if (log_n + n_listed > log_cap) {
                     squeeze_log();
@@ -1412,7 +1413,8 @@ public:
             lean_optimistic_ = false;
             if (lean_bulk_) {
                 // its log comes in kLeanLogBuckets parts (by destination): each part gets an equal share of what LDS has left, never more than
-                // the worst case.  A part can fill up before the whole would have: this instantiation may always give up (K_sched then answers).
+                // the worst case.  A part can fill up before the whole would have: this instantiation may always give up (the same kernel with its
+                // log in HBM then answers — switch_to_glog_ — or, where that is not possible, K_sched).
                 int64_t part = worst < room / kLeanLogBuckets ? worst : (room / kLeanLogBuckets) & ~255ll;
                 if (forced_cap >= 64 && forced_cap / kLeanLogBuckets < part) part = forced_cap / kLeanLogBuckets < 64 ? 64 : (forced_cap / kLeanLogBuckets) & ~63ll;
                 if (part >= 64 && (part * kLeanLogBuckets * 2 >= (int64_t)P_ || forced_cap >= 64)) {
@@ -1427,7 +1429,7 @@ public:
                 // nothing, and ext_capacity is a bound the caller picks generously.  When it does not fit, the log gets what LDS has left (room for at
                 // least half of the call's pods, or the attempt is not worth a launch; moves onto nodes that were removed since are squeezed out
                 // when it fills up); the kernel gives up at the commit that still does not fit and fetch_removals / confirm_kernel run the call
-                // again through K_sched.  Results are those of whichever kernel finished.
+                // again with the log in HBM (switch_to_glog_) or through K_sched.  Results are those of whichever kernel finished.
                 if (forced_cap >= 256 && (forced_cap & ~255) < lean_log_cap_) {
                     lean_log_cap_ = forced_cap & ~255; lean_optimistic_ = true;
                     lean_smem_ = (size_t)casim_lean_removal_bytes(R, C_, capN, lean_log_cap_);

@@ -50,6 +50,17 @@ class CallTrace:
             self.n_res = int(o.n_res)
             self.lines.append("\t".join([name, str(o.n_res), str(o.enable_taint_comparison_ops), str(o.explicit_self_exclusion)]))
             return
+        if name == "casim_enc_add_running_pods":
+            # (e, n_pods, group[n], ns[n], req[n][R], label_off[n + 1], label_key[L], label_val[L], strings[S], S)
+            n, S = int(args[1]), int(args[9])
+            L = int(args[5][n]) if n > 0 else 0
+
+            def ints(a, count):
+                return [str(count)] + [str(int(a[k])) for k in range(count)]
+            toks = [name, str(n)] + ints(args[2], n) + ints(args[3], n) + ints(args[4], n * self.n_res) + ints(args[5], n + 1) + ints(args[6], L) + ints(args[7], L)
+            toks += [str(S)] + [_esc(args[8][k]) for k in range(S)]
+            self.lines.append("\t".join(toks))
+            return
         if name == "casim_enc_add_pods":
             self.lines.append("\t".join([name] + self._pod_columns(args[1]._obj if hasattr(args[1], "_obj") else args[1].contents)))
             return

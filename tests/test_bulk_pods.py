@@ -186,3 +186,24 @@ def test_the_go_shim_adds_the_pegs_of_a_loop_in_one_crossing():
     assert "s.podRest(pod, id)" in pod and "casim_enc_pod_add_host_port" not in pod
     assert "err := s.pegs(pegs)" in open(os.path.join(shim, "estimator.go")).read()
     assert "err := sess.pegs(pegs)" in open(os.path.join(shim, "prefetch.go")).read()
+
+
+@pytest.mark.parametrize("make", [lambda: workloads.removal_scale(300, pods_per_node=12, frac_candidates=0.3, seed=4), lambda: workloads.runonce_scale_down(40),
+                                  lambda: workloads.fuzz_removals(3), lambda: workloads.fuzz_removals_plain(5), lambda: workloads.fuzz_removals_domains(7)],
+                         ids=["removal_scale", "runonce_scale_down", "fuzz_removals", "fuzz_removals_plain", "fuzz_removals_domains"])
+def test_running_pods_in_one_crossing_trace_and_replay(make, tmp_path):
+    """casim_enc_add_running_pods (what the Go shim's runningPods uses for a snapshot's plain pods) recorded and replayed by tools/casim_native: the
+    same tables as the per-pod calls, from the Python mirror and from the plain-C++ replay, in a fraction of the crossings"""
+    if not os.path.exists(nt.NATIVE):
+        nt.build()
+    w = make()
+    out = {}
+    for bulk in (False, True):
+        path = str(tmp_path / f"r{int(bulk)}.trace")
+        enc, _, _ = nt.trace_removals(w, path, iters=1, bulk=bulk)
+        h = (nt.tables_fnv(enc.pegs, enc.groups), rules_hash(enc))
+        enc.close()
+        _, nat = nt.run_native(path, repeat=1)
+        out[bulk] = (h, nat["tables_fnv"], nat["enc_calls"])
+    assert out[False][0] == out[True][0] and out[False][1] == out[True][1] == out[True][0][0]
+    assert out[True][2] <= out[False][2]

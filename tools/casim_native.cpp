@@ -36,7 +36,7 @@ enum Op {
     CREATE, ADD_GROUP, GROUP_LABEL, GROUP_TAINT, GROUP_FP_CAP, GROUP_LIMITS, GROUP_PRELOADED, GROUP_SET_PEGS, ADD_POD_SPEC, POD_LABEL,
     POD_TOLERATION, POD_NODE_SELECTOR, POD_NODE_AFF_REQ, POD_NODE_AFF_TERM, NODE_TERM_REQ, POD_HOST_PORT, POD_AA_TERM, TERM_REQ,
     POD_AFF_TERM, AFF_TERM_REQ, POD_SPREAD, SPREAD_REQ, SPREAD_TAINTS, SPREAD_AFFINITY, ADD_NAMESPACE, NAMESPACE_LABEL, TERM_NS_SELECTOR, TERM_NS_REQ, AFF_TERM_NS_SELECTOR, AFF_TERM_NS_REQ, POD_FP_REQ,
-    POD_UNSUPPORTED, POD_SPEC_EXTRA, ADD_PEG, ADD_RESOURCE_PEGS, ADD_EXISTING_POD, FINALIZE, ENC_LANE, POD_SET_REQUEST, GROUP_SET_ALLOCATABLE, LANE_COUNT, LANE_NAME, ADD_PODS
+    POD_UNSUPPORTED, POD_SPEC_EXTRA, ADD_PEG, ADD_RESOURCE_PEGS, ADD_EXISTING_POD, FINALIZE, ENC_LANE, POD_SET_REQUEST, GROUP_SET_ALLOCATABLE, LANE_COUNT, LANE_NAME, ADD_PODS, ADD_RUNNING_PODS
 };
 const std::map<std::string, Sig> kSigs = {
     {"casim_enc_create", {CREATE, "iii"}},
@@ -83,6 +83,8 @@ const std::map<std::string, Sig> kSigs = {
     {"casim_enc_lane_name", {LANE_NAME, "i"}},
     // casim_pod_columns (ABI 11): n_pods, strings, ns, req, fastpath_req, peg_count, label_off / key / val, tol_off / key / op / value / effect, sel_off / key / val
     {"casim_enc_add_pods", {ADD_PODS, "iSaADaaaaaaaaaaaa"}},
+    // n_pods, group, ns, req, label_off, label_key, label_val, strings
+    {"casim_enc_add_running_pods", {ADD_RUNNING_PODS, "iaaAaaaS"}},
 };
 
 struct Call {
@@ -210,6 +212,11 @@ int32_t replay(const std::vector<Call>& calls, size_t n_calls, casim_encoder*& e
         case GROUP_SET_ALLOCATABLE: rc = casim_enc_group_set_allocatable(e, (int32_t)I[0], c.s(0), I[1]); break;
         case LANE_COUNT: (void)casim_enc_lane_count(e); rc = 0; break;
         case LANE_NAME: (void)casim_enc_lane_name(e, (int32_t)I[0]); rc = 0; break;
+        case ADD_RUNNING_PODS: {
+            auto col = [&](size_t k) -> const int32_t* { return c.A32[k].empty() ? nullptr : c.A32[k].data(); };
+            const int32_t first = casim_enc_add_running_pods(e, (int32_t)I[0], col(0), col(1), c.A64[0].data(), col(2), col(3), col(4), c.SA[0].data(), (int32_t)c.SA_store[0].size());
+            rc = first < 0 ? first : 0; break;
+        }
         case ADD_PODS: {
             casim_pod_columns pc; memset(&pc, 0, sizeof pc);
             auto col = [&](size_t k) -> const int32_t* { return c.A32[k].empty() ? nullptr : c.A32[k].data(); };

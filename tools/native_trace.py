@@ -77,10 +77,13 @@ def trace_pending(w, path, iters=5):
     return enc, pod_class
 
 
-def trace_removals(w, path, iters=5):
-    """Scale-down removal simulation (workloads.RemovalWorkload) -> trace file."""
+def trace_removals(w, path, iters=5, bulk=False):
+    """Scale-down removal simulation (workloads.RemovalWorkload) -> trace file.  bulk: the running pods of all nodes through
+    casim_enc_add_running_pods (what integration/go/gpubinpacking/encode.go runningPods does: plain pods in ONE crossing over an interned string
+    table, the others pod by pod); False: every running pod through the per-pod calls."""
     import kubernetes_autoscaler_amd as kaa
     from kubernetes_autoscaler_amd import trace as tr
+    from kubernetes_autoscaler_amd.objects import NodeInfo
     with tr.recording() as t:
         enc = kaa.Encoder(explicit_self_exclusion=True)
         cls, pcl, off = {}, [], [0]
@@ -91,8 +94,13 @@ def trace_removals(w, path, iters=5):
                     cls[k] = enc.add_peg(kaa.PodEquivalenceGroup(pods=[p]))
                 pcl.append(cls[k])
             off.append(len(pcl))
-        for info in w.nodes:
-            enc.add_group(info, pegs=[])
+        if bulk:
+            for info in w.nodes:
+                enc.add_group(NodeInfo(info.node, []), pegs=[])
+            enc.add_running_pods([info.pods for info in w.nodes])
+        else:
+            for info in w.nodes:
+                enc.add_group(info, pegs=[])
         enc.finalize()
     tr.add_removals(t, w.candidates, off, pcl, destination=w.destination, persist=w.persist, max_removable=w.max_removable,
                     last_index=w.last_index, iters=iters)
