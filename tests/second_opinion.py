@@ -184,3 +184,33 @@ def fits_fresh_template(pod: Pod, template: NodeInfo) -> bool:
         return False
     return (taints_allow(pod, node.taints) and node_affinity_allows(pod, node) and ports_allow(pod, template.pods) and
             anti_affinity_allows(pod, node, template.pods) and resources_allow(pod, template))
+
+
+# ---- per-node mode: a pod against the nodes of a SNAPSHOT (RunFiltersOnNode; filter-out-schedulable, the removal loop) ------------------------------
+# PodAffinityTerm doc (V/api/core/v1/types.go): "This pod should be co-located (affinity) or not co-located (anti-affinity) with the pods matching the
+# labelSelector in the specified namespaces, where co-located is defined as running on a node whose value of the label with key topologyKey matches
+# that of any node on which any of the selected pods is running.  Empty topologyKey is not allowed."  A node WITHOUT the key has no value to match:
+# it is co-located with nothing under that key — BuildTestNode clusters carry no kubernetes.io/hostname at all.
+def co_located(topology_key: str, a, b) -> bool:
+    return topology_key in a.labels and topology_key in b.labels and a.labels[topology_key] == b.labels[topology_key]
+
+
+def fits_existing_node(pod: Pod, index: int, cluster) -> bool:
+    """does `pod` pass the Filter plugins on node `index` of the snapshot `cluster` (a list of NodeInfo, every node with the pods running on it)?
+    Anti-affinity looks at every pod of the snapshot: the incoming pod's terms against pods co-located with the node, the running pods' terms
+    against the incoming pod (symmetry: "the pod will not be scheduled onto the node" holds for existing pods' required anti-affinity too)."""
+    info = cluster[index]
+    node = info.node
+    if node.unschedulable and not any(tolerates(t, UNSCHEDULABLE_TAINT[0], "", UNSCHEDULABLE_TAINT[1]) for t in pod.tolerations):
+        return False
+    if not (taints_allow(pod, node.taints) and node_affinity_allows(pod, node) and ports_allow(pod, info.pods) and resources_allow(pod, info)):
+        return False
+    for other_info in cluster:
+        for other in other_info.pods:
+            for term in pod.anti_affinity:
+                if co_located(term.topology_key, node, other_info.node) and _term_selects(term, pod, other):
+                    return False
+            for term in other.anti_affinity:
+                if co_located(term.topology_key, node, other_info.node) and _term_selects(term, other, pod):
+                    return False
+    return True

@@ -164,3 +164,52 @@ def test_host_ports_and_anti_affinity_against_the_template_pods(block):
             pegs.append(PodEquivalenceGroup(pods=[pod] * 2))
         sc = Scenario(pegs=pegs, groups=groups, existing=[], device_csr=True)
         _check(sc, f"ports / anti-affinity {block}/{case}")
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_snapshot_nodes_with_and_without_the_hostname_label(block):
+    """Per-node mode (RunFiltersOnNode on the nodes of a snapshot): the independent evaluator against the oracle AND against the product's
+    feasibility matrix (encoder + feas kernel under the emulator), cell by cell — on fuzz_pending clusters as generated (every node named), with
+    kubernetes.io/hostname taken off every node (hostname anti-affinity inert: DESIGN 17e-3, nothing delegated) and taken off every other node
+    (classes with hostname terms are delegated by the encoder: those are compared evaluator vs oracle only)."""
+    import copy
+    from harness import SchedCase, run_emu_feasibility, sched_encode
+    from kubernetes_autoscaler_amd import _abi
+    from kubernetes_autoscaler_amd.objects import LABEL_HOSTNAME, NodeInfo
+    from oracle_driver import OracleScenario
+    from kubernetes_autoscaler_amd import workloads as W
+    cells = device_cells = delegated = 0
+    for seed in range(40 * block, 40 * block + 40):
+        for mode in ("named", "stripped", "mixed"):
+            w = W.fuzz_pending(seed)
+            nodes = [NodeInfo(copy.deepcopy(n.node), list(n.pods)) for n in w.nodes]
+            for i, n in enumerate(nodes):
+                if mode == "stripped" or (mode == "mixed" and i % 2 == 0):
+                    n.node.labels.pop(LABEL_HOSTNAME, None)
+            canon = {}
+            for p in w.pods:
+                canon.setdefault(p.spec_key(), p)
+            classes = list(canon.values())
+            orc = OracleScenario()
+            for info in nodes:
+                orc.add_existing(info)
+            enc, pc = sched_encode(SchedCase(nodes=nodes, pods=classes))
+            bits = run_emu_feasibility(enc)
+            for ci, p in enumerate(classes):
+                c = int(pc[ci])
+                unsupported = bool(enc.pegs.flags[c] & _abi.PEG_UNSUPPORTED)
+                if mode != "mixed":
+                    assert not unsupported, (seed, mode, p.name)
+                delegated += int(unsupported)
+                for ni in range(len(nodes)):
+                    want = so.fits_existing_node(p, ni, nodes)
+                    ok, plug, _ = orc.run_filters_on_node(ni, p)
+                    assert ok == want, (seed, mode, p.name, nodes[ni].node.name, "oracle", plug)
+                    cells += 1
+                    if not unsupported:
+                        got = bool((int(bits[ni][c >> 6]) >> (c & 63)) & 1)
+                        assert got == want, (seed, mode, p.name, nodes[ni].node.name, "device")
+                        device_cells += 1
+            enc.close()
+            orc.close()
+    assert cells >= 5000 and device_cells >= 4000 and delegated >= 1, (cells, device_cells, delegated)
