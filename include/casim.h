@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CASIM_ABI_VERSION 11  /* 2: casim_removal_candidates.cand_atomic, casim_domain_rules.n_taint_policy_rules
+#define CASIM_ABI_VERSION 12  /* 2: casim_removal_candidates.cand_atomic, casim_domain_rules.n_taint_policy_rules
                                * 3: casim_groups.{peg_lo,peg_hi,global_id,n_sims,sim_offsets}, casim_best_option_sims,
                                *    casim_feasibility_reasons, casim_estimate_batch_timed, casim_mctx_*, casim_cluster_*
                                * 4: casim_options.n_streams (sub-batches on internal HIP streams), casim_enc_group_pods,
@@ -48,7 +48,10 @@ extern "C" {
                                *    casim_options.chain_last_index (+ 3 reserved words), casim_problem_time_feasibility
                                * 10: casim_pegs.req32 / req_unit (requests narrowed by the caller), casim_last_removals_info
                                * 11: casim_pod_columns / casim_enc_add_pods (the pods of a loop — namespace, requests, labels, tolerations, nodeSelector,
-                               *     PEG sizes — in ONE crossing over an interned string table) */
+                               *     PEG sizes — in ONE crossing over an interned string table)
+                               * 12: casim_enc_group_set_allocatable opens no lane and casim_enc_pod_set_request opens none for a request of zero (a
+                               *     column no pod reads is not a column: real nodes' hugepages-*: 0 / attachable-volumes-* widen no table);
+                               *     casim_last_chain_info (long chains stop at their fixed point) */
 
 /* Resource lanes.  Lane 0 = cpu in millicores (Quantity.MilliValue), lane 1 = memory bytes,
  * lane 2 = ephemeral-storage bytes, lanes 3.. = scalar / extended resources (Quantity.Value),
@@ -229,7 +232,10 @@ typedef struct casim_options {
                                      on unchanged.  Default 0: every group starts from its own last_index entry (independent Estimate() calls).
                                      Simulations stay independent of each other, so batches keep their parallelism; inside a simulation the
                                      library runs the packer to a fixed point (at most groups-per-simulation passes, each re-estimating only
-                                     the groups whose input changed) — results are exactly those of the sequential loop.  The whole simulation
+                                     the groups whose input changed) — results are exactly those of the sequential loop.  Chains of up to 24
+                                     passes (batches of simulations) are enqueued whole, nothing is waited for; longer ones (ONE simulation with a
+                                     group per node group: the Go shim's prefetch) go out in growing blocks and stop at the first block whose last
+                                     pass marked nothing (casim_last_chain_info; CASIM_CHAIN_ASYNC_MAX moves the limit).  The whole simulation
                                      has to live in the problem (not with node groups sharded over devices: CASIM_ERR_INVALID). */
     int32_t reserved[3];          /* zero */
 } casim_options;
@@ -643,6 +649,10 @@ int32_t casim_time_node_removals(casim_ctx* ctx, const casim_pegs* classes, cons
  * <= 4 resource lanes, node state within the LDS budget), 0 = K_sched's general transaction loop; [1] threads of the workgroup; [2] 1 = node
  * state in LDS; [3] runs of the call.  Results are identical either way; CASIM_NO_LEAN_REMOVALS=1 in the environment keeps K_sched (A/B). */
 int32_t casim_last_removals_info(int32_t info_out[4]);
+/* The calling thread's last run with casim_options.chain_last_index: info_out[0] = passes the fixed point is bounded by (groups per
+ * simulation - 1), [1] = passes enqueued, [2] = times the host read the marks of a pass back (one wait each; 0 for a chain enqueued
+ * whole), [3] = 1 when the chain was short enough to be enqueued whole. */
+int32_t casim_last_chain_info(int32_t info_out[4]);
 
 /*
  * Resident cluster (second half): the snapshot's node table stays in HBM for a whole RunOnce iteration.
@@ -797,11 +807,17 @@ int32_t casim_enc_add_pod_spec(casim_encoder* e, const char* namespace_, const i
  *   CASIM_ERR_INVALID.  The caller decides WHICH names count — the scheduler's own rule is schedutil.IsScalarResourceName
  *   (extended resources, hugepages-*, attachable-volumes-*, prefixed native names: types.go Resource.Add) — the encoder takes every
  *   name it is given.
- * casim_enc_pod_set_request: the pod's request for the name (>= 0).  CASIM_OK, or CASIM_ENC_DELEGATED (1) when no lane is left and
+ * casim_enc_pod_set_request: the pod's request for the name (>= 0).  A NON-ZERO request opens the name's lane; a request of zero opens
+ *   none (fitsRequest skips zero quantities, fit.go:733).  CASIM_OK, or CASIM_ENC_DELEGATED (1) when no lane is left and
  *   value != 0: the pod spec is marked CASIM_PEG_UNSUPPORTED, so every group that lists it comes back CASIM_NG_UNSUPPORTED and the
- *   shim runs the reference path — a request is NEVER silently ignored.
- * casim_enc_group_set_allocatable: the template's Allocatable[name] ("pods" sets allowed_pods).  CASIM_ENC_DELEGATED when no lane
- *   is left (harmless: every pod that asks for the name is delegated).
+ *   shim runs the reference path — a request is NEVER silently ignored.  A NEGATIVE return (CASIM_ERR_INVALID: negative value, bad
+ *   id) means the request was NOT recorded: the caller must fail closed (casim_enc_pod_mark_unsupported, or give the call up).
+ * casim_enc_group_set_allocatable: the template's Allocatable[name] ("pods" sets allowed_pods).  Allocatable NEVER opens a lane: a
+ *   column no pod reads is not a column (real nodes list hugepages-1Gi: 0, hugepages-2Mi: 0, attachable-volumes-*; one lane per
+ *   listed name used to push every table past the four lanes the register packer takes).  A name without a lane is kept aside and
+ *   written into its lane by casim_enc_finalize if some pod's request has opened one by then — pods and groups may arrive in any
+ *   order.  After finalize (update sessions: fixed table width) a name without a lane answers CASIM_ENC_DELEGATED (harmless: every
+ *   pod that asks for the name is delegated).
  * casim_enc_lane_count: lanes the tables carry (casim_pegs.n_res after finalize); casim_enc_lane_name: the name of a lane or NULL. */
 int32_t casim_enc_lane(casim_encoder* e, const char* resource_name);
 int32_t casim_enc_pod_set_request(casim_encoder* e, int32_t pod, const char* resource_name, int64_t value);

@@ -22,6 +22,7 @@ type session struct {
 	enc  *C.casim_encoder
 	strs cstrings
 	spec map[*apiv1.Pod]C.int32_t // exemplar pod -> pod-spec id of this session
+	err  error                    // first value the encoder refused to record for a NODE (group): tables() returns it and the call falls back to the reference path
 }
 
 func newSession() *session {
@@ -48,6 +49,16 @@ func scalars(rl apiv1.ResourceList, visit func(name apiv1.ResourceName, value in
 		if schedutil.IsScalarResourceName(name) {
 			visit(name, q.Value())
 		}
+	}
+}
+
+// request hands one named request of pod-spec id to the encoder and fails CLOSED: CASIM_ENC_DELEGATED (1: every lane taken) has already
+// marked the pod CASIM_PEG_UNSUPPORTED; a NEGATIVE return (CASIM_ERR_INVALID: e.g. a negative Quantity.Value) means the request was NOT
+// recorded, so the pod is marked here — its groups come back CASIM_NG_UNSUPPORTED and Estimate() runs the reference path.  A request is
+// never silently ignored (ADVICE r5).
+func (s *session) request(id C.int32_t, name apiv1.ResourceName, v int64) {
+	if rc := C.casim_enc_pod_set_request(s.enc, id, s.strs.s(string(name)), C.int64_t(v)); rc < 0 {
+		C.casim_enc_pod_mark_unsupported(s.enc, id, s.strs.s("request "+string(name)+" refused by the encoder"))
 	}
 }
 
@@ -91,9 +102,7 @@ func (s *session) pod(pod *apiv1.Pod) C.int32_t {
 	s.spec[pod] = id
 	// ScalarResources by name.  CASIM_ENC_DELEGATED (every lane taken): the encoder has marked the pod CASIM_PEG_UNSUPPORTED, its groups
 	// come back CASIM_NG_UNSUPPORTED and Estimate() runs the reference path — a request is never silently ignored.
-	scalars(req, func(name apiv1.ResourceName, v int64) {
-		C.casim_enc_pod_set_request(e, id, c.s(string(name)), C.int64_t(v))
-	})
+	scalars(req, func(name apiv1.ResourceName, v int64) { s.request(id, name, v) })
 	for k, v := range pod.Labels {
 		C.casim_enc_pod_add_label(e, id, c.s(k), c.s(v))
 	}
@@ -289,9 +298,7 @@ func (s *session) pegs(groups []estimator.PodEquivalenceGroup) ([]C.int32_t, err
 				pod, id := groups[gi].Exemplar(), first+C.int32_t(i)
 				s.spec[pod] = id
 				// ScalarResources by name, in list order (CASIM_ENC_DELEGATED marks the pod: see pod())
-				scalars(podutils.PodRequests(pod), func(name apiv1.ResourceName, v int64) {
-					C.casim_enc_pod_set_request(s.enc, id, s.strs.s(string(name)), C.int64_t(v))
-				})
+				scalars(podutils.PodRequests(pod), func(name apiv1.ResourceName, v int64) { s.request(id, name, v) })
 				s.podRest(pod, id)
 				ids[gi] = out[i]
 			}
@@ -329,8 +336,12 @@ func (s *session) group(tmpl *framework.NodeInfo, maxNodes, existing, lastIndex 
 	g := C.casim_enc_add_group(s.enc, c.s(node.Name), &lanes[0], C.int32_t(al.Pods().Value()),
 		C.int64_t(node.Status.Capacity.Cpu().MilliValue()), C.int64_t(node.Status.Capacity.Memory().Value()), unsched)
 	// Allocatable.ScalarResources by name (NodeInfo.SetNode -> NewResource(node.Status.Allocatable), types.go:1003-1011)
+	// (the encoder opens a lane for a name only when some pod asks for a non-zero amount of it: hugepages-*: 0 and attachable-volumes-* of
+	// real nodes widen no table; a negative return means the value was NOT recorded — the session fails closed)
 	scalars(al, func(name apiv1.ResourceName, v int64) {
-		C.casim_enc_group_set_allocatable(s.enc, g, c.s(string(name)), C.int64_t(v))
+		if rc := C.casim_enc_group_set_allocatable(s.enc, g, c.s(string(name)), C.int64_t(v)); rc < 0 && s.err == nil {
+			s.err = rcErr(rc, "casim_enc_group_set_allocatable("+string(name)+")")
+		}
 	})
 	for k, v := range node.Labels {
 		C.casim_enc_group_add_label(s.enc, g, c.s(k), c.s(v))
@@ -354,6 +365,9 @@ func (s *session) group(tmpl *framework.NodeInfo, maxNodes, existing, lastIndex 
 }
 
 func (s *session) tables() (pegs C.casim_pegs, groups C.casim_groups, err error) {
+	if err = s.err; err != nil {
+		return
+	}
 	if err = rcErr(C.casim_enc_finalize(s.enc), "casim_enc_finalize"); err != nil {
 		return
 	}

@@ -54,13 +54,17 @@ type gpuEstimator struct {
 // always taken.
 type Routing struct {
 	MinDeviceWork int64
+	// Unsynced lets calls take the reference path even when the snapshot does not expose its runner's lastIndex (RunnerIndex): the
+	// reference Estimate then moves a lastIndex the device never sees and vice versa — node counts and placements of later groups can
+	// differ from a run that stayed on one side (6 of 2381 groups in profiles/r10_chain_rate.json).  Off by default.
+	Unsynced bool
 }
 
 // DefaultRouting: see INTEGRATION.md section 1c for the sweep behind the number.
 var DefaultRouting = Routing{MinDeviceWork: 150000}
 
-func (r Routing) cpuIsCheaper(pegs []estimator.PodEquivalenceGroup, maxNodes int) bool {
-	if r.MinDeviceWork <= 0 {
+func (r Routing) cpuIsCheaper(pegs []estimator.PodEquivalenceGroup, maxNodes int, synced bool) bool {
+	if r.MinDeviceWork <= 0 || (!synced && !r.Unsynced) {
 		return false
 	}
 	pods := int64(0)
@@ -77,15 +81,53 @@ func (r Routing) cpuIsCheaper(pegs []estimator.PodEquivalenceGroup, maxNodes int
 	return pods*bound < r.MinDeviceWork
 }
 
+// RunnerIndex is what a snapshot offers when its plugin runner's lastIndex can be read and written from outside: the accessors
+// autoscaler_go.patch adds to predicate.PredicateSnapshot (three one-line methods over lastIndexOrderMapping.lastIndex,
+// cluster-autoscaler/simulator/clustersnapshot/scheduling_opts.go:39-63).  With them the snapshot's runner is the ONE source of truth:
+// the shim reads lastIndex from it before every device call or cache lookup and writes last_index_out back after, so Estimates that run
+// the reference's loop (routed small calls, groups outside the encoded subset) and every other user of the runner between two scale-up
+// loops (HintingSimulator.TrySchedulePods in filter-out-schedulable, the scale-down planner's simulations) move the same number the
+// device starts from (ADVICE r5: a private copy next to a runner that moves on its own is stale after the first mixed loop).
+type RunnerIndex interface {
+	RunnerLastIndex() int
+	SetRunnerLastIndex(int)
+}
+
 // runnerState is the one piece of SchedulerPluginRunner state an Estimate reads and writes: lastIndexOrderMapping.lastIndex
 // (cluster-autoscaler/simulator/clustersnapshot/scheduling_opts.go:39-63).  In the reference the runner lives inside the snapshot
 // (predicate/predicate_snapshot.go:64) and its lastIndex survives every Estimate of every loop (plugin_runner.go:33-36,138); the
-// orchestrator builds a fresh estimator per node group (orchestrator.go:409-413), so the shim keeps one runnerState per snapshot
-// OUTSIDE the estimators — in prefetch mode and in per-call mode alike.
+// orchestrator builds a fresh estimator per node group (orchestrator.go:409-413), so the state is kept per snapshot OUTSIDE the
+// estimators — in prefetch mode and in per-call mode alike.  `real` != nil (the snapshot implements RunnerIndex): every read and write
+// goes to the snapshot's runner.  `real` == nil (a snapshot without the accessors): the shim threads a PRIVATE copy that only its own
+// device calls move — exact as long as every Estimate of the process goes to the device; Routing is then off by default and a group the
+// reference path had to take (CASIM_NG_UNSUPPORTED) leaves the copy where the device left it (INTEGRATION.md 1c).
 type runnerState struct {
 	mu        sync.Mutex
 	lastIndex int
+	real      RunnerIndex
 }
+
+func (r *runnerState) get() int {
+	r.mu.Lock()
+	defer r.mu.Unlock()
+	if r.real != nil {
+		return r.real.RunnerLastIndex()
+	}
+	return r.lastIndex
+}
+
+func (r *runnerState) set(v int) {
+	r.mu.Lock()
+	defer r.mu.Unlock()
+	if r.real != nil {
+		r.real.SetRunnerLastIndex(v)
+		return
+	}
+	r.lastIndex = v
+}
+
+// synced: the snapshot's own runner is read and written (mixing device and reference Estimates is exact).
+func (r *runnerState) synced() bool { return r.real != nil }
 
 // Runners holds the runnerStates of ONE EstimatorBuilder (NewEstimatorBuilder creates it; Shared points at the same one).  The
 // autoscaler has one long-lived ClusterSnapshot, so the registry normally holds one entry; it is bounded all the same — round 4 kept a
@@ -123,6 +165,9 @@ func (r *Runners) of(snapshot clustersnapshot.ClusterSnapshot) *runnerState {
 		r.order = r.order[1:]
 	}
 	st = &runnerState{}
+	if real, ok := snapshot.(RunnerIndex); ok {
+		st.real = real
+	}
 	r.state[snapshot] = st
 	r.order = append(r.order, snapshot)
 	return st
@@ -206,7 +251,7 @@ func (g *gpuEstimator) Estimate(pegs []estimator.PodEquivalenceGroup, tmpl *fram
 	}
 
 	// ---- small calls: the reference's loop is cheaper than a trip to the device (Routing) ----
-	if g.routing.cpuIsCheaper(pegs, maxNodes) {
+	if g.routing.cpuIsCheaper(pegs, maxNodes, g.runner.synced()) {
 		return g.fallback.Estimate(pegs, tmpl, ng)
 	}
 
@@ -337,16 +382,9 @@ func nodeCount(s clustersnapshot.ClusterSnapshot) int {
 	return len(infos)
 }
 
-// lastIndex / setLastIndex: the shim never runs the snapshot's SchedulerPluginRunner for simulated pods, so it keeps the
-// runner's lastIndex (scheduling_opts.go:39-63) itself, per snapshot (runnerState), shared by every estimator built on that
-// snapshot — with or without a prefetch cache.
-func (g *gpuEstimator) lastIndex() int {
-	g.runner.mu.Lock()
-	defer g.runner.mu.Unlock()
-	return g.runner.lastIndex
-}
-func (g *gpuEstimator) setLastIndex(v int) {
-	g.runner.mu.Lock()
-	g.runner.lastIndex = v
-	g.runner.mu.Unlock()
-}
+// lastIndex / setLastIndex: the shim never runs the snapshot's SchedulerPluginRunner for simulated pods; it reads the runner's
+// lastIndex (scheduling_opts.go:39-63) before a device call and writes last_index_out back after it (runnerState: the snapshot's own
+// runner when it implements RunnerIndex, else a private copy per snapshot), shared by every estimator built on that snapshot — with
+// or without a prefetch cache.
+func (g *gpuEstimator) lastIndex() int     { return g.runner.get() }
+func (g *gpuEstimator) setLastIndex(v int) { g.runner.set(v) }

@@ -35,7 +35,7 @@ type Shared struct {
 	pegs     C.casim_pegs
 	pegID    map[*apiv1.Pod]C.int32_t // exemplar pod -> PEG id of the loop's tables
 	groupRow map[C.uint64_t]C.int32_t // groupKey -> row of the loop's group table
-	loopLastIndex int // the snapshot runner's lastIndex (estimator.go: runnerState) when the batch of the current loop was filled: the FIRST group of the batch starts from it
+	loopLastIndex int // the snapshot runner's lastIndex (estimator.go: runnerState.get) when the batch of the current loop was filled: the FIRST group of the batch starts from it
 	runners       *Runners // the builder's registry (builder.go sets it)
 	// Unchained = the round-4 protocol: every group of the batch starts from loopLastIndex and hits never move the runner.  Default (false): the
 	// batch hands lastIndex from group to group (casim_options.chain_last_index), the way the orchestrator's loop does on one snapshot
@@ -123,10 +123,7 @@ func (s *Shared) fill(autoscalingCtx *ca_context.AutoscalingContext, pegs []esti
 	if s.runners == nil {
 		s.runners = NewRunners()
 	}
-	rs := s.runners.of(autoscalingCtx.ClusterSnapshot)
-	rs.mu.Lock()
-	s.loopLastIndex = rs.lastIndex
-	rs.mu.Unlock()
+	s.loopLastIndex = s.runners.of(autoscalingCtx.ClusterSnapshot).get() // (the snapshot's own runner when it implements RunnerIndex)
 	gkeys := make([]C.uint64_t, 0, len(ngs))
 	groupRow := make(map[C.uint64_t]C.int32_t, len(ngs))
 	for _, ng := range ngs {

@@ -3,7 +3,7 @@ shared library happens in _ffi.py).  Kept separate so that test harnesses that c
 structs can reuse the layouts without loading the product library."""
 import ctypes as C
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 MAX_RES = 8
 
 OK = 0
@@ -200,6 +200,7 @@ PROTOTYPES = {
     "casim_time_node_removals": (C.c_int32, [C.c_void_p, C.POINTER(Pegs), C.POINTER(Groups), C.POINTER(RemovalCandidates), C.c_int32,
                                              C.POINTER(C.c_float)]),
     "casim_last_removals_info": (C.c_int32, [i32p]),
+    "casim_last_chain_info": (C.c_int32, [i32p]),
     "casim_pack_build_info": (C.c_int32, [C.c_int32, i32p]),
     "casim_prefetch_create": (C.c_void_p, [C.c_void_p]),
     "casim_prefetch_destroy": (None, [C.c_void_p]),

@@ -129,6 +129,10 @@ struct PodSpec {
 struct Group {
     std::string name;
     int64_t alloc[CASIM_MAX_RES];
+    // Allocatable[name] handed over (casim_enc_group_set_allocatable) while no pod had asked for the name yet: kept aside, written into the
+    // name's lane by finalize IF a request has opened one by then.  Allocatable never opens a lane (real nodes list hugepages-1Gi: 0,
+    // hugepages-2Mi: 0, attachable-volumes-*: columns no pending pod reads, which used to widen every table past the register packer's four lanes)
+    std::vector<std::pair<std::string, int64_t>> named_alloc;
     int32_t allowed = 0;
     int64_t cap_cpu = 0, cap_mem = 0;
     double fp_cap_cpu = 0, fp_cap_mem = 0;
@@ -490,13 +494,16 @@ int32_t casim_enc_lane(casim_encoder* e, const char* resource_name) {
 int32_t casim_enc_pod_set_request(casim_encoder* e, int32_t pod, const char* resource_name, int64_t value) {
     POD_CHECK(e, pod);
     if (!resource_name || !*resource_name || value < 0) return CASIM_ERR_INVALID;
-    const int lane = casim_enc_lane(e, resource_name);
-    if (lane == CASIM_ERR_INVALID) return CASIM_ERR_INVALID;
+    const std::string name = S(resource_name);
+    if (name == "pods") return CASIM_ERR_INVALID;
+    // a request of ZERO opens no lane: fitsRequest skips zero quantities (fit.go:733) and adding zero to a node's sums changes nothing
+    // (types.go:444-448) — the name only matters once some pod asks for a non-zero amount
+    const int lane = lane_of(e, name, /*may_add=*/!e->finalized && value != 0);
     PodSpec& p = e->specs[pod];
-    if (lane < 0) {   // every lane is taken: the pod leaves the encoded subset (fail closed), unless it asks for nothing (fit.go:733 skips zero quantities)
+    if (lane < 0) {   // every lane is taken: the pod leaves the encoded subset (fail closed), unless it asks for nothing
         if (value == 0) return CASIM_OK;
         p.unsupported = true;
-        if (p.why.empty()) p.why = "resource " + S(resource_name) + ": no lane left (CASIM_MAX_RES)";
+        if (p.why.empty()) p.why = "resource " + name + ": no lane left (CASIM_MAX_RES)";
         return CASIM_ENC_DELEGATED;
     }
     p.req[lane] = value;
@@ -506,13 +513,29 @@ int32_t casim_enc_pod_set_request(casim_encoder* e, int32_t pod, const char* res
 int32_t casim_enc_group_set_allocatable(casim_encoder* e, int32_t group, const char* resource_name, int64_t value) {
     GRP_CHECK(e, group);
     if (!resource_name || !*resource_name) return CASIM_ERR_INVALID;
-    if (S(resource_name) == "pods") { e->groups[group].allowed = (int32_t)value; return CASIM_OK; }
-    const int lane = casim_enc_lane(e, resource_name);
-    if (lane == CASIM_ERR_INVALID) return CASIM_ERR_INVALID;
-    if (lane < 0) return CASIM_ENC_DELEGATED;   // (no lane left: every pod that ASKS for the name is delegated by casim_enc_pod_set_request, so the column is not missed)
-    e->groups[group].alloc[lane] = value;
-    if (lane == CASIM_RES_EPHEMERAL && e->opt.n_res < 3 && value != 0) e->touch_ephemeral = true;
+    const std::string name = S(resource_name);
+    Group& g = e->groups[group];
+    if (name == "pods") { g.allowed = (int32_t)value; return CASIM_OK; }
+    // Allocatable never opens a lane: only a pod's non-zero request does (a column no pod reads is not a column).  A name without a lane
+    // is kept aside until finalize, by when every pod of the loop has been seen — the order of pods and groups does not matter.
+    const int lane = lane_of(e, name, /*may_add=*/false);
+    for (auto it = g.named_alloc.begin(); it != g.named_alloc.end(); ++it) if (it->first == name) { g.named_alloc.erase(it); break; }
+    if (lane >= 0) { g.alloc[lane] = value; return CASIM_OK; }
+    if (e->finalized) return CASIM_ENC_DELEGATED;   // (fixed table width: the name has no column, and every pod that asks for it is delegated by casim_enc_pod_set_request)
+    g.named_alloc.emplace_back(name, value);
     return CASIM_OK;
+}
+// finalize: names a request has opened a lane for since the group was described
+static void resolve_named_allocatable(casim_encoder* e) {
+    for (auto& g : e->groups) {
+        if (g.named_alloc.empty()) continue;
+        size_t keep = 0;
+        for (auto& nv : g.named_alloc) {
+            const int lane = lane_of(e, nv.first, /*may_add=*/false);
+            if (lane >= 0) g.alloc[lane] = nv.second; else g.named_alloc[keep++] = nv;
+        }
+        g.named_alloc.resize(keep);
+    }
 }
 int32_t casim_enc_lane_count(const casim_encoder* e) { return e ? (e->finalized ? e->out_res : e->lanes_now()) : CASIM_ERR_INVALID; }
 const char* casim_enc_lane_name(const casim_encoder* e, int32_t lane) {
@@ -773,6 +796,7 @@ int32_t casim_enc_finalize(casim_encoder* e) {
     ENC_OPEN(e);   // (also the full fallback of an update session: casim_enc_refinalize said CASIM_ENC_NEEDS_FULL)
     e->fs.valid = false;
     EncStageTimer stage;
+    resolve_named_allocatable(e);
     const int R = e->out_res = e->lanes_now();   // (positional lanes + the named ones: casim_enc_lane)
     const size_t G = e->pegs.size(), NG = e->groups.size(), NS = e->specs.size();
     const bool cmp_ops = e->opt.enable_taint_comparison_ops != 0;
@@ -1676,7 +1700,7 @@ int32_t casim_enc_group_reset(casim_encoder* e, int32_t group, const int64_t* al
     for (int r = 0; r < CASIM_MAX_RES; ++r) g.alloc[r] = r < e->opt.n_res ? alloc[r] : 0;
     g.allowed = allowed_pods; g.cap_cpu = capacity_cpu_milli; g.cap_mem = capacity_mem_bytes; g.unschedulable = unschedulable != 0;
     g.fp_cap_cpu = (double)capacity_cpu_milli * 1e-3; g.fp_cap_mem = (double)capacity_mem_bytes;
-    g.labels = Labels(); g.taints.clear(); g.preloaded.clear();
+    g.labels = Labels(); g.taints.clear(); g.preloaded.clear(); g.named_alloc.clear();
     return CASIM_OK;
 }
 int32_t casim_enc_set_peg_count(casim_encoder* e, int32_t peg, int32_t count) {

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <map>
 #include <mutex>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -224,6 +225,19 @@ struct casim_ctx {
         }
         return false;
     }
+    // Once per process: a caller asked for more concurrent lanes than the runtime's hardware queues carry.  Until round 5 the library
+    // set GPU_MAX_HW_QUEUES=8 by itself at load time (opt-out CASIM_KEEP_ENV); it no longer touches the environment, so a host that
+    // relied on the old default now runs ~3 lanes instead of 4 — say so instead of being slower in silence (CASIM_QUIET=1 mutes).
+    void note_parked_lanes(int asked) {
+        static std::atomic<bool> said{false};
+        if (said.exchange(true) || (getenv("CASIM_QUIET") && atoi(getenv("CASIM_QUIET")) != 0)) return;
+        const char* q = getenv("GPU_MAX_HW_QUEUES");
+        fprintf(stderr, "libcasim: %d of the %d stream lanes asked for run concurrently (%zu streams shared a hardware queue with a lane and were parked); "
+                        "GPU_MAX_HW_QUEUES=%s.  Export GPU_MAX_HW_QUEUES=8 before the process's first HIP call, or CASIM_SET_HW_QUEUES=1 to let libcasim "
+                        "set it when it is loaded (the library stopped editing the environment by default: INTEGRATION.md section 4; CASIM_KEEP_ENV "
+                        "is gone).  CASIM_QUIET=1 silences this note.\n",
+                (int)lanes.size(), asked, parked.size(), q ? q : "(unset: the runtime's default, 4)");
+    }
     std::vector<HipBackend*> get_lanes(int k) {
         bk.bind();
         int tries = 0;
@@ -240,6 +254,7 @@ struct casim_ctx {
             if (++tries >= 12) lanes_capped = true;
         }
         (void)hipGetLastError();
+        if ((int)lanes.size() < k && !parked.empty()) note_parked_lanes(k);
         return std::vector<HipBackend*>(lanes.begin(), lanes.begin() + ((int)lanes.size() < k ? (int)lanes.size() : k));
     }
 };
@@ -1164,6 +1179,12 @@ int32_t casim_last_removals_info(int32_t info_out[4]) {
     if (!info_out) return CASIM_ERR_INVALID;
     const int32_t* li = casim::last_removals_info();
     for (int i = 0; i < 4; ++i) info_out[i] = li[i];
+    return CASIM_OK;
+}
+int32_t casim_last_chain_info(int32_t info_out[4]) {
+    if (!info_out) return CASIM_ERR_INVALID;
+    const int32_t* ci = casim::last_chain_info();
+    for (int i = 0; i < 4; ++i) info_out[i] = ci[i];
     return CASIM_OK;
 }
 int32_t casim_time_node_removals(casim_ctx* ctx, const casim_pegs* classes, const casim_groups* nodes,

@@ -204,6 +204,10 @@ struct UploadGate {
     void pass(int i) { { std::lock_guard<std::mutex> l(mu); if (turn == i) turn = i + 1; } cv.notify_all(); }
 };
 
+// the calling thread's last chained run (casim_last_chain_info): [0] passes the fixed point is bounded by (groups per simulation - 1),
+// [1] passes enqueued, [2] times the host looked at the marks (a wait each), [3] 1 = short chain, enqueued whole
+inline int32_t* last_chain_info() { static thread_local int32_t info[4] = {0, 0, 0, 0}; return info; }
+
 template <class BK>
 class ProblemT {
 public:
@@ -911,22 +915,41 @@ public:
         if (chain_) bk_.zero(d_chain_marks_, 4 * ((size_t)chain_passes_ + 1));
         run_pack_pass(dt_);
         if (chain_) {
-            // casim_options.chain_last_index (chain_fix_kernel): fix-up passes to the sequential loop's fixed point.  Nothing is waited for:
-            // the bound — groups per simulation - 1 passes — is enqueued, a pass without marked groups is a row of waves that leave at once.
+            // casim_options.chain_last_index (chain_fix_kernel): fix-up passes to the sequential loop's fixed point.
             // (the caller's last_index column sits in the upload slab: device memory of this problem, rewritten in place)
+            // SHORT chains — batches of simulations, a few tens of groups each — are enqueued whole and nothing is waited for: the bound is
+            // groups per simulation - 1 passes, a pass without marked groups is a row of waves that leave at once.  LONG chains (the Go
+            // shim's prefetch: ONE simulation with a group per node group, a few hundred passes of near-empty launches) stop at the
+            // fixed point: passes go out in growing blocks and after each block the marks of its LAST pass come back (4 bytes, one wait) —
+            // a pass that marked nothing re-estimated nothing, so every later pass would find the same tables and mark nothing either.
             DevTables dc = dt_;
             dc.chain_redo = d_chain_redo_;
             const int n_sims = n_sims_ > 0 ? n_sims_ : 1;
-            for (int pass = 0; pass < chain_passes_; ++pass) {
-                bk_.launch(chain_fix_kernel, (n_sims + 255) / 256, 1, 256, (size_t)0, dt_, dr_, (int32_t*)dt_.last_index, d_chain_redo_, d_chain_marks_ + pass);
-                run_pack_pass(dc);
+            const char* async_env = getenv("CASIM_CHAIN_ASYNC_MAX");
+            const int async_max = async_env ? atoi(async_env) : 24;
+            const bool whole = chain_passes_ <= async_max;
+            int pass = 0, block = 4, checks = 0;
+            while (pass < chain_passes_) {
+                const int end = whole ? chain_passes_ : (pass + block < chain_passes_ ? pass + block : chain_passes_);
+                for (; pass < end; ++pass) {
+                    bk_.launch(chain_fix_kernel, (n_sims + 255) / 256, 1, 256, (size_t)0, dt_, dr_, (int32_t*)dt_.last_index, d_chain_redo_, d_chain_marks_ + pass);
+                    run_pack_pass(dc);
+                }
+                if (pass >= chain_passes_) break;
+                int32_t marked = 0;
+                bk_.d2h(&marked, d_chain_marks_ + (pass - 1), 4); bk_.sync(); ++checks;
+                if (marked == 0) break;
+                if (block < 32) block *= 2;
             }
+            chain_passes_run_ = pass;
+            int32_t* ci = last_chain_info();
+            ci[0] = chain_passes_; ci[1] = pass; ci[2] = checks; ci[3] = whole ? 1 : 0;
         }
         return CASIM_OK;
     }
     // marked groups per fix-up pass of the last run (chain mode; tests and the bench's chain row): waits for the device
     std::vector<int32_t> chain_marks() {
-        std::vector<int32_t> h((size_t)(chain_ ? chain_passes_ : 0));
+        std::vector<int32_t> h((size_t)(chain_ ? chain_passes_ : 0));   // (passes an early stop never enqueued read zero: the marks were cleared)
         if (!h.empty()) { bk_.d2h(h.data(), d_chain_marks_, 4 * h.size()); bk_.sync(); }
         return h;
     }
@@ -1437,7 +1460,7 @@ private:
     // where the NodeUnschedulable bit rides (-1: a term of its own); dynamic LDS of the launch
     uint64_t h_mask_used_[2] = {~0ull, ~0ull};
     uint32_t* d_feas_rec_ = nullptr; bool feas_hi_ = true; int feas_us_word_ = -1, feas_us_bit_ = 0; size_t feas_smem_ = 0;
-    bool chain_ = false; int chain_passes_ = 0; int32_t* d_chain_redo_ = nullptr; int32_t* d_chain_marks_ = nullptr;   // casim_options.chain_last_index
+    bool chain_ = false; int chain_passes_ = 0; int chain_passes_run_ = 0; int32_t* d_chain_redo_ = nullptr; int32_t* d_chain_marks_ = nullptr;   // casim_options.chain_last_index
     bool feas_by_sim_ = false;
     bool one_shot_ = false;
     UploadGate* gate_ = nullptr; int gate_idx_ = 0; bool gate_passed_ = false;

@@ -302,6 +302,14 @@ class Context:
         check(lib.casim_last_removals_info(info), "casim_last_removals_info")
         return {"lean": bool(info[0]), "threads": int(info[1]), "state_in_lds": bool(info[2]), "runs": int(info[3])}
 
+    @staticmethod
+    def last_chain_info():
+        """casim_last_chain_info: this thread's last run with chain_last_index — {"bound": passes the fixed point is bounded by, "passes":
+        passes enqueued, "checks": times the host read a pass's marks back, "whole": the chain was enqueued whole}"""
+        info = (C.c_int32 * 4)()
+        check(lib.casim_last_chain_info(info), "casim_last_chain_info")
+        return {"bound": int(info[0]), "passes": int(info[1]), "checks": int(info[2]), "whole": bool(info[3])}
+
     def simulate_node_removals(self, classes: _abi.Pegs, nodes: _abi.Groups, cand_node, pod_offsets, pod_class, hint_node=None,
                                destination=None, persist: bool = True, max_removable: int = 0, last_index: int = 0,
                                pod_sticky=None, ext_capacity: Optional[int] = None, time_iters: int = 0, rules=None,

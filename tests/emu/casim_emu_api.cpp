@@ -227,6 +227,12 @@ EMU_API int32_t emu_last_removals_info(int32_t info_out[4]) {
     return 0;
 }
 
+EMU_API int32_t emu_last_chain_info(int32_t info_out[4]) {
+    const int32_t* ci = casim::last_chain_info();
+    for (int i = 0; i < 4; ++i) info_out[i] = ci[i];
+    return 0;
+}
+
 EMU_API int32_t emu_estimate_on_cluster(const casim_pegs* classes, const casim_groups* nodes, const casim_cluster_estimate* params,
                                         int64_t lds_budget_bytes, casim_cluster_estimate_result* out) {
     EmuBackend bk;

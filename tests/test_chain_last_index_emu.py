@@ -77,3 +77,47 @@ def test_c2_as_one_chained_simulation():
     res, _ = run_emu(enc, chain=True)
     assert_matches_oracle(res, run_oracle(sc, chain=True), "C2 chained")
     enc.close()
+
+
+def _chain_info():
+    import ctypes as C
+    from harness import emu_lib
+    info = (C.c_int32 * 4)()
+    emu_lib().emu_last_chain_info(info)
+    return {"bound": int(info[0]), "passes": int(info[1]), "checks": int(info[2]), "whole": bool(info[3])}
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_long_chains_stop_at_their_fixed_point(seed, monkeypatch):
+    """the Go shim's prefetch is ONE simulation with a group per node group — a few hundred groups mean a few hundred fix-up
+    passes enqueued, nearly all of them empty launches.  Chains longer than CASIM_CHAIN_ASYNC_MAX passes (24) go out in growing blocks and
+    stop at the first block whose last pass marked nothing; here the limit is 0, so every fuzz chain takes that path: same results as the
+    sequential loop, fewer passes than the bound wherever the chain converges early"""
+    monkeypatch.setenv("CASIM_CHAIN_ASYNC_MAX", "0")
+    sc = _scenario(31500 + seed, device_csr=seed % 2 == 0, max_groups=12)
+    want = run_oracle(sc, chain=True)
+    for generic in (False, True):
+        enc = encode(sc)
+        res, _ = run_emu(enc, chain=True, generic=generic)
+        assert_matches_oracle(res, want, f"seed {seed} generic={generic}")
+        info = _chain_info()
+        if len(sc.groups) > 1:
+            assert info["bound"] == len(sc.groups) - 1 and not info["whole"] and 1 <= info["passes"] <= info["bound"]
+            assert info["checks"] >= (1 if info["passes"] < info["bound"] else 0)
+        enc.close()
+
+
+def test_a_chain_of_many_groups_needs_a_few_passes():
+    """sixty node groups in one simulation (bound: 59 passes, over the limit of 24 without any override): the blocks stop long before the bound,
+    results are the sequential loop's"""
+    w = workloads.fuzz(31901, max_groups=7, max_pegs=10)
+    groups = [GroupSpec(g.template, g.max_nodes, g.last_index, None) for g in w.groups]
+    groups = [groups[i % len(groups)] for i in range(60)]
+    sc = Scenario(pegs=w.pegs, groups=groups, existing=w.existing, lanes=w.lanes, device_csr=True)
+    enc = encode(sc)
+    res, _ = run_emu(enc, chain=True)
+    assert_matches_oracle(res, run_oracle(sc, chain=True), "60 groups chained")
+    info = _chain_info()
+    assert info["bound"] == 59 and not info["whole"] and info["passes"] < 59 and info["checks"] >= 1, info
+    print(f"60-group chain: {info}")
+    enc.close()

@@ -88,7 +88,7 @@ def test_a_name_without_a_lane_delegates_the_pod():
     g = lib.casim_enc_add_group(h, b"tmpl", alloc, 110, 4000, 16 << 30, 0)
     for n in names[:5]:
         assert lib.casim_enc_group_set_allocatable(h, g, n.encode(), 8) == _abi.OK
-    assert lib.casim_enc_group_set_allocatable(h, g, names[5].encode(), 8) == _abi.ENC_DELEGATED
+    assert lib.casim_enc_group_set_allocatable(h, g, names[5].encode(), 8) == _abi.OK   # (kept aside: no pod request opened a lane for it)
     assert lib.casim_enc_group_set_allocatable(h, g, b"pods", 17) == _abi.OK
     assert lib.casim_enc_lane(h, b"pods") == _abi.ERR_INVALID and lib.casim_enc_lane(h, b"") == _abi.ERR_INVALID
     assert lib.casim_enc_group_set_limits(h, g, 0, 0, 0) == _abi.OK
@@ -126,15 +126,12 @@ def test_named_lanes_give_the_tables_of_positional_lanes(seed):
         extra = {n: int(rng.integers(1, 9)) for n in ext if rng.integers(0, 3) > 0}
         extra["ephemeral-storage"] = int(rng.integers(8, 64)) << 30
         groups.append(GroupSpec(_tmpl(f"t{gi}", extra), int(rng.choice([0, 3, 20])), 0, None))
-    # first-use order of the names = order of first appearance over pods (PEG order), then templates: the encoder's rule
+    # the encoder's rule: a name gets a lane when a pod asks for a NON-ZERO amount of it, in order of first such request (PEG order);
+    # a request of zero and a template's Allocatable open none (a column no pod reads is not a column)
     seen = []
     for pg in pegs:
-        for n in pg.pods[0].requests:
-            if n in ext and n not in seen:
-                seen.append(n)
-    for g in groups:
-        for n in g.template.node.allocatable:
-            if n in ext and n not in seen:
+        for n, v in pg.pods[0].requests.items():
+            if n in ext and v > 0 and n not in seen:
                 seen.append(n)
     lanes = ("cpu", "memory", "ephemeral-storage", *seen)
     sc = Scenario(pegs=pegs, groups=groups, existing=[], lanes=lanes, device_csr=True)
@@ -168,4 +165,58 @@ def test_the_named_calls_replay_natively(tmp_path):
     rc, out = nt.run_native(path, repeat=1)
     assert out["pegs"] == enc.pegs.n_pegs and out["groups"] == enc.groups.n_groups
     assert out["tables_fnv"] == nt.tables_fnv(enc.pegs, enc.groups)     # the C++ replay built the very tables, extended-resource lane included
+    enc.close()
+
+
+def test_allocatable_nobody_asks_for_opens_no_lane():
+    """real nodes list hugepages-1Gi: 0, hugepages-2Mi: 0 and attachable-volumes-*; encode.go hands every
+    IsScalarResourceName entry of Allocatable over.  A lane per listed name made the tables five or more lanes wide — past the four the
+    register packer, feas_stream_kernel and the lean removal kernel take.  Allocatable opens no lane, a request of zero opens none
+    (fit.go:733 skips zero quantities); only a pod's non-zero request does, and then the group's value is found whatever the order of the calls."""
+    node_extras = {"hugepages-1Gi": 0, "hugepages-2Mi": 0, "attachable-volumes-aws-ebs": 25, "example.com/fpga": 2}
+    enc = Encoder(named_lanes=True)
+    h = enc._h
+    vec = (C.c_int64 * _abi.MAX_RES)(100, 1 << 20, 0)
+    alloc = (C.c_int64 * _abi.MAX_RES)(4000, 16 << 30, 100 << 30)
+    g0 = lib.casim_enc_add_group(h, b"before-the-pods", alloc, 110, 4000, 16 << 30, 0)
+    for n, v in node_extras.items():
+        assert lib.casim_enc_group_set_allocatable(h, g0, n.encode(), v) == _abi.OK
+    assert lib.casim_enc_lane_count(h) == 3
+    a = lib.casim_enc_add_pod_spec(h, b"default", vec)
+    assert lib.casim_enc_pod_set_request(h, a, b"hugepages-2Mi", 0) == _abi.OK      # PodRequests lists the name with a zero quantity
+    assert lib.casim_enc_lane_count(h) == 3
+    b = lib.casim_enc_add_pod_spec(h, b"default", vec)
+    assert lib.casim_enc_pod_set_request(h, b, b"example.com/fpga", 1) == _abi.OK   # the one name a pod needs
+    assert lib.casim_enc_lane_count(h) == 4
+    g1 = lib.casim_enc_add_group(h, b"after-the-pods", alloc, 110, 4000, 16 << 30, 0)
+    for n, v in node_extras.items():
+        assert lib.casim_enc_group_set_allocatable(h, g1, n.encode(), v + (1 if n == "example.com/fpga" else 0)) == _abi.OK
+    g2 = lib.casim_enc_add_group(h, b"without-the-device", alloc, 110, 4000, 16 << 30, 0)
+    for spec in (a, b):
+        assert lib.casim_enc_add_peg(h, spec, 5) >= 0
+    for g in (g0, g1, g2):
+        assert lib.casim_enc_group_set_limits(h, g, 0, 0, 0) == _abi.OK
+    pegs, groups = enc.finalize()
+    assert pegs.n_res == 4 and enc.lanes == ("cpu", "memory", "ephemeral-storage", "example.com/fpga")
+    al = np.ctypeslib.as_array(groups.alloc, shape=(3, 4))
+    assert list(al[:, 3]) == [2, 3, 0]
+    req = np.ctypeslib.as_array(pegs.req, shape=(2, 4))
+    assert list(req[:, 3]) == [0, 1]
+    res, _ = run_emu(enc)
+    assert all(int(s) == 0 for s in res.status)
+    # 5 plain pods fit one node everywhere; 5 fpga pods need ceil(5 / 2) = 3 and ceil(5 / 3) = 2 nodes more, and none fit a node without the device
+    assert [int(x) for x in res.pods_scheduled] == [10, 10, 5]
+    assert [int(x) for x in res.node_count] == [3, 2, 1]
+    enc.close()
+
+
+def test_an_invalid_request_is_reported_not_recorded():
+    """a negative quantity answers CASIM_ERR_INVALID and the request is NOT recorded — the binding must fail closed on rc < 0
+    (encode.go marks the pod unsupported; tests/test_go_shim_symbols.py pins that)"""
+    enc = Encoder(named_lanes=True)
+    h = enc._h
+    a = lib.casim_enc_add_pod_spec(h, b"default", (C.c_int64 * _abi.MAX_RES)(100, 1 << 20, 0))
+    assert lib.casim_enc_pod_set_request(h, a, b"example.com/dev", -1) == _abi.ERR_INVALID
+    assert lib.casim_enc_pod_set_request(h, a, b"pods", 1) == _abi.ERR_INVALID
+    assert lib.casim_enc_lane_count(h) == 3
     enc.close()

@@ -156,6 +156,10 @@ def scan_go_package(d=SHIM):
             out["defs"].add(m.group(1))
         for m in re.finditer(r"^(?:type|var|const) ([A-Za-z_]\w*)\b", src, re.M):
             out["defs"].add(m.group(1))
+        # methods declared by an interface type of the package (`Name(args) result` lines inside `type X interface { ... }`)
+        for m in re.finditer(r"^type [A-Za-z_]\w* interface \{\n(.*?)^\}", src, re.M | re.S):
+            for mm in re.finditer(r"^\s+([A-Za-z_]\w*)\(", m.group(1), re.M):
+                out["defs"].add(mm.group(1))
         # names that hold function values inside function bodies: `name := func`, `name = func`, parameters `name func(`
         loc = set(re.findall(r"\b([A-Za-z_]\w*)\s*:?=\s*func\b", src)) | set(re.findall(r"\b([A-Za-z_]\w*)\s+func\(", src))
         out["locals"][fn] = loc
