@@ -51,7 +51,7 @@ extern "C" {
                                *     PEG sizes — in ONE crossing over an interned string table)
                                * 12: casim_enc_group_set_allocatable opens no lane and casim_enc_pod_set_request opens none for a request of zero (a
                                *     column no pod reads is not a column: real nodes' hugepages-*: 0 / attachable-volumes-* widen no table);
-                               *     casim_last_chain_info (long chains stop at their fixed point) */
+                               *     casim_last_chain_info (long chains stop at their fixed point); CASIM_PREFETCH_MISS_LAST_INDEX */
 
 /* Resource lanes.  Lane 0 = cpu in millicores (Quantity.MilliValue), lane 1 = memory bytes,
  * lane 2 = ephemeral-storage bytes, lanes 3.. = scalar / extended resources (Quantity.Value),
@@ -1044,7 +1044,10 @@ typedef struct casim_prefetch_result {
 #define CASIM_PREFETCH_MISS 64          /* return value of casim_prefetch_lookup (> 0: not an error) */
 #define CASIM_PREFETCH_MISS_GROUP 1     /* the batch did not hold this node group (processor not installed, group added since) */
 #define CASIM_PREFETCH_MISS_PEGS 2      /* the PEG list differs from the group's schedulable subset of the batch */
-#define CASIM_PREFETCH_MISS_LIMITS 3    /* max_nodes / existing_nodes / last_index differ from what the batch ran with */
+#define CASIM_PREFETCH_MISS_LIMITS 3    /* max_nodes / existing_nodes differ from what the batch ran with */
+#define CASIM_PREFETCH_MISS_LAST_INDEX 4 /* ABI 12: ONLY last_index differs — a chained batch (casim_options.chain_last_index) whose order the calls left (a
+                                          * group ran elsewhere or was skipped): the caller may fill the cache again with the REST of the loop's groups,
+                                          * chained from the runner's lastIndex of now (the Go shim's rechain), instead of one per-call trip per group */
 casim_prefetch* casim_prefetch_create(casim_ctx* ctx);
 void casim_prefetch_destroy(casim_prefetch* p);
 void casim_prefetch_clear(casim_prefetch* p);   /* a new loop iteration: forget the previous batch */
@@ -1057,7 +1060,8 @@ int32_t casim_prefetch_fill(casim_prefetch* p, const casim_pegs* pegs, const cas
  * (Estimate()'s []*Pod = concat_k list[order_out[k]].Pods[0:placed_out[k]]); both [n_pegs], may be NULL. */
 int32_t casim_prefetch_lookup(casim_prefetch* p, uint64_t group_key, const uint64_t* peg_keys, int32_t n_pegs, int32_t max_nodes,
                               int32_t existing_nodes, int32_t last_index, casim_prefetch_result* out, int32_t* order_out, int32_t* placed_out);
-/* out[0] fills, [1] groups cached in total, [2] hits, [3] misses: unknown group, [4] misses: PEG list, [5] misses: limits */
+/* out[0] fills, [1] groups cached in total, [2] hits, [3] misses: unknown group, [4] misses: PEG list, [5] misses: limits or lastIndex,
+ * [6] of those: lastIndex alone (CASIM_PREFETCH_MISS_LAST_INDEX) */
 int32_t casim_prefetch_stats(const casim_prefetch* p, int64_t out[8]);
 
 #ifdef __cplusplus

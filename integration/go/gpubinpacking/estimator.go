@@ -239,14 +239,20 @@ func (g *gpuEstimator) Estimate(pegs []estimator.PodEquivalenceGroup, tmpl *fram
 		// with the runner's lastIndex as of NOW — it hits while the Estimate() calls arrive in the batch's order (the orchestrator walks the
 		// list the processor saw) and misses on the limits when a group was skipped or estimated elsewhere in between; a hit moves the
 		// runner on exactly as the Estimate it stands for would have (plugin_runner.go:138).
-		if r, order, placed, ok := g.shared.lookup(ng, tmpl, pegs, maxNodes, existing, g.lastIndex()); ok {
+		r, order, placed, ok := g.shared.lookup(ng, tmpl, pegs, maxNodes, existing, g.lastIndex())
+		if !ok && r.miss_reason == C.CASIM_PREFETCH_MISS_LAST_INDEX && g.shared.rechain(ng, tmpl, g.lastIndex()) {
+			// the chain was left (an earlier group ran on the reference path or was skipped): the rest of the loop was estimated again as one
+			// chained batch from the runner's lastIndex of now (prefetch.go: rechain) — this lookup and the following ones hit again
+			r, order, placed, ok = g.shared.lookup(ng, tmpl, pegs, maxNodes, existing, g.lastIndex())
+		}
+		if ok {
 			if r.status == C.CASIM_NG_OK {
 				if !g.shared.Unchained {
 					g.setLastIndex(int(r.last_index_out))
 				}
 				return int(r.node_count), prefixPods(pegs, order, placed)
 			}
-			return g.fallback.Estimate(pegs, tmpl, ng) // the batch delegated this group (CASIM_NG_UNSUPPORTED); the reference path moves the real runner
+			return g.fallback.Estimate(pegs, tmpl, ng) // the batch delegated this group (CASIM_NG_UNSUPPORTED); the reference path moves the snapshot's runner (read back by the next lastIndex())
 		}
 	}
 

@@ -35,6 +35,12 @@ type Shared struct {
 	pegs     C.casim_pegs
 	pegID    map[*apiv1.Pod]C.int32_t // exemplar pod -> PEG id of the loop's tables
 	groupRow map[C.uint64_t]C.int32_t // groupKey -> row of the loop's group table
+	// the batch of the loop in its order (= the order of Estimate() calls the chain assumes): rows of the loop's group table, their keys, the
+	// PEG keys — what a re-chain needs (rechain below); rechains counts them per loop
+	batchRows []C.int32_t
+	batchKeys []C.uint64_t
+	pegKeys   []C.uint64_t
+	rechains  int
 	loopLastIndex int // the snapshot runner's lastIndex (estimator.go: runnerState.get) when the batch of the current loop was filled: the FIRST group of the batch starts from it
 	runners       *Runners // the builder's registry (builder.go sets it)
 	// Unchained = the round-4 protocol: every group of the batch starts from loopLastIndex and hits never move the runner.  Default (false): the
@@ -79,6 +85,7 @@ func (s *Shared) dropLoopTables() {
 		s.sess = nil
 	}
 	s.pegID, s.groupRow = nil, nil
+	s.batchRows, s.batchKeys, s.pegKeys, s.rechains = nil, nil, nil, 0
 }
 
 // Keys are opaque to libcasim.  A PEG is its exemplar pod (the orchestrator builds the groups once per loop and passes the same
@@ -125,6 +132,7 @@ func (s *Shared) fill(autoscalingCtx *ca_context.AutoscalingContext, pegs []esti
 	}
 	s.loopLastIndex = s.runners.of(autoscalingCtx.ClusterSnapshot).get() // (the snapshot's own runner when it implements RunnerIndex)
 	gkeys := make([]C.uint64_t, 0, len(ngs))
+	rows := make([]C.int32_t, 0, len(ngs))
 	groupRow := make(map[C.uint64_t]C.int32_t, len(ngs))
 	for _, ng := range ngs {
 		tmpl, ok := infos[ng.Id()]
@@ -137,6 +145,7 @@ func (s *Shared) fill(autoscalingCtx *ca_context.AutoscalingContext, pegs []esti
 		row := sess.group(tmpl, s.limiter.MaxNodes(), existing, s.loopLastIndex, nil)
 		s.limiter.EndEstimation()
 		gkeys = append(gkeys, groupKey(ng, tmpl))
+		rows = append(rows, row)
 		groupRow[groupKey(ng, tmpl)] = row
 	}
 	if len(gkeys) == 0 { // no candidate group came with a template: nothing to prefetch (and no &gkeys[0] to take)
@@ -160,7 +169,58 @@ func (s *Shared) fill(autoscalingCtx *ca_context.AutoscalingContext, pegs []esti
 	}
 	keep = true // the encoder stays: its tables serve the per-call path of this loop
 	s.sess, s.pegs, s.pegID, s.groupRow = sess, pt, pegID, groupRow
+	s.batchRows, s.batchKeys, s.pegKeys, s.rechains = rows, gkeys, pkeys, 0
 	return nil
+}
+
+// maxRechains bounds the batches one loop may spend on re-chaining (each is one device call over the REST of the loop's groups).
+const maxRechains = 4
+
+// rechain: a chained batch answers group i for the lastIndex group i - 1 left.  When the chain is LEFT — a group ran on the reference path
+// (CASIM_NG_UNSUPPORTED, a routed small call) or was skipped, so the runner stands elsewhere — every later lookup of the loop misses on
+// lastIndex alone (CASIM_PREFETCH_MISS_LAST_INDEX) and would take one per-call device trip each (ADVICE r5).  Instead the REST of the
+// batch, from the group that missed on, is estimated again as ONE chained batch that starts from the runner's lastIndex of now: the rows
+// of the loop's group table (casim_enc_group_rows, no encoding), their limits as the fill computed them, the first group's last_index
+// overridden.  The cache then holds the rest of the loop; groups answered before are gone (a second Estimate for one of them misses on
+// the group and takes the per-call path on the loop's tables).  false: nothing to re-chain (unknown group, last group of the batch, the
+// budget of this loop is spent, an error) — the caller continues with the per-call path.
+func (s *Shared) rechain(ng cloudprovider.NodeGroup, tmpl *framework.NodeInfo, lastIndex int) bool {
+	if s.sess == nil || s.Unchained || s.rechains >= maxRechains {
+		return false
+	}
+	key := groupKey(ng, tmpl)
+	from := -1
+	for i, k := range s.batchKeys {
+		if k == key {
+			from = i
+			break
+		}
+	}
+	if from < 0 || len(s.batchKeys)-from < 2 {
+		return false
+	}
+	s.rechains++
+	n := len(s.batchKeys) - from
+	var rows C.casim_groups
+	s.engine.mu.Lock()
+	defer s.engine.mu.Unlock()
+	if C.casim_enc_group_rows(s.sess.enc, &s.batchRows[from], C.int32_t(n), &rows) != C.CASIM_OK {
+		return false
+	}
+	li := make([]C.int32_t, n) // (the chain reads the FIRST group's entry; the others are ignored, casim.h casim_options.chain_last_index)
+	for i := range li {
+		li[i] = C.int32_t(lastIndex)
+	}
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	pin.Pin(&li[0])
+	rows.last_index = &li[0]
+	var opts C.casim_options
+	if s.fastpath {
+		opts.fastpath = 1
+	}
+	opts.chain_last_index = 1
+	return C.casim_prefetch_fill(s.cache, &s.pegs, &rows, &opts, &s.batchKeys[from], &s.pegKeys[0]) == C.CASIM_OK
 }
 
 // estimateOnLoopTables is the per-call path WITHOUT encoding: the group's row of the loop's tables (casim_enc_group_rows, n = 1), the

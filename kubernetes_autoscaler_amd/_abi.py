@@ -75,7 +75,7 @@ class PrefetchResult(C.Structure):
 
 ENC_NEEDS_FULL = 65
 PREFETCH_MISS = 64
-PREFETCH_MISS_GROUP, PREFETCH_MISS_PEGS, PREFETCH_MISS_LIMITS = 1, 2, 3
+PREFETCH_MISS_GROUP, PREFETCH_MISS_PEGS, PREFETCH_MISS_LIMITS, PREFETCH_MISS_LAST_INDEX = 1, 2, 3, 4
 
 
 class Options(C.Structure):

@@ -135,8 +135,9 @@ int32_t casim_prefetch_lookup(casim_prefetch* p, uint64_t group_key, const uint6
         }
     }
     if (!same) { out->miss_reason = CASIM_PREFETCH_MISS_PEGS; p->stats[4]++; return CASIM_PREFETCH_MISS; }
-    if (max_nodes != e.max_nodes || existing_nodes != e.existing || last_index != e.last_index) {
-        out->miss_reason = CASIM_PREFETCH_MISS_LIMITS; p->stats[5]++; return CASIM_PREFETCH_MISS;
+    if (max_nodes != e.max_nodes || existing_nodes != e.existing) { out->miss_reason = CASIM_PREFETCH_MISS_LIMITS; p->stats[5]++; return CASIM_PREFETCH_MISS; }
+    if (last_index != e.last_index) {   // the limiter's answers agree: the call only comes with another lastIndex (a chained batch whose order was left)
+        out->miss_reason = CASIM_PREFETCH_MISS_LAST_INDEX; p->stats[5]++; p->stats[6]++; return CASIM_PREFETCH_MISS;
     }
     *out = e.r;
     if (order_out) for (int32_t k = 0; k < n_pegs; ++k) order_out[k] = to_caller[(size_t)e.order[(size_t)k]];

@@ -745,7 +745,8 @@ class PrefetchCache:
     def stats(self):
         out = (C.c_int64 * 8)()
         lib.casim_prefetch_stats(self._h, out)
-        return {"fills": out[0], "groups_cached": out[1], "hits": out[2], "miss_group": out[3], "miss_pegs": out[4], "miss_limits": out[5]}
+        return {"fills": out[0], "groups_cached": out[1], "hits": out[2], "miss_group": out[3], "miss_pegs": out[4], "miss_limits": out[5],
+                "miss_last_index": out[6]}
 
 
 class StreamedBatch:

@@ -12,6 +12,7 @@ import time
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional, Sequence, Tuple
 
+from . import _abi
 from .encoder import Encoder
 from .engine import Context, Problem
 from .objects import NodeInfo, Pod, PodEquivalenceGroup
@@ -219,6 +220,12 @@ class BinpackingNodeEstimator:
             if self.prefetch is not None and self.analyser is None:   # (the analyser wants the pods per node: per-call path)
                 hit = self.prefetch.lookup(pegs, node_template, node_group, self.limiter.device_max_nodes(), len(self.snapshot.existing),
                                            runner_last_index=self.snapshot.last_index)
+                if hit is None and self.prefetch.last_miss == _abi.PREFETCH_MISS_LAST_INDEX and \
+                        self.prefetch.rechain(node_group, node_template, self.snapshot.last_index):
+                    # the chain was left (an earlier group ran elsewhere or was skipped): the rest of the loop as one chained batch from the
+                    # runner's lastIndex of now (gpubinpacking/prefetch.go: rechain) — this lookup and the following ones hit again
+                    hit = self.prefetch.lookup(pegs, node_template, node_group, self.limiter.device_max_nodes(), len(self.snapshot.existing),
+                                               runner_last_index=self.snapshot.last_index)
                 if hit is not None and hit["status"] == 0:
                     pods = []
                     for k, n in zip(hit["order"], hit["placed"]):
@@ -306,8 +313,19 @@ class PrefetchShared:
         self.ctx, self.limiter, self.max_nodes_total, self.fastpath, self.lanes = engine_ctx, limiter, max_nodes_total, fastpath, lanes
         self.cache = PrefetchCache(engine_ctx)
         self.loop_last_index = 0
+        self.enc = None          # the loop's tables stay until the next fill (the Go shim keeps its session: Shared.sess): rechain reads them
+        self.batch_keys, self.peg_keys, self.rechains, self.last_miss = [], [], 0, 0
+
+    MAX_RECHAINS = 4             # batches one loop may spend on re-chaining (gpubinpacking/prefetch.go: maxRechains)
+
+    def _drop_loop_tables(self):
+        if self.enc is not None:
+            self.enc.close()
+            self.enc = None
+        self.batch_keys, self.peg_keys, self.rechains = [], [], 0
 
     def close(self):
+        self._drop_loop_tables()
         self.cache.close()
 
     @staticmethod
@@ -321,6 +339,7 @@ class PrefetchShared:
     def fill(self, pegs: List[PodEquivalenceGroup], node_groups, node_infos, snapshot: ClusterSnapshotView, similar_node_groups=None):
         """ONE casim_estimate_batch over every PEG and every candidate group; SchedulablePodGroups on the device."""
         similar_node_groups = similar_node_groups or {}
+        self._drop_loop_tables()
         self.loop_last_index = snapshot.last_index
         enc = Encoder(lanes=self.lanes)
         for pg in pegs:
@@ -337,15 +356,38 @@ class PrefetchShared:
             self.limiter.end_estimation()
             gkeys.append(self.group_key(ng, node_infos[ng.id()]))
         enc.finalize()
+        pkeys = [self.peg_key(pg) for pg in pegs]
         try:
-            self.cache.fill(enc.pegs, enc.groups, gkeys, [self.peg_key(pg) for pg in pegs], self.fastpath, chain_last_index=self.chain)
-        finally:
+            self.cache.fill(enc.pegs, enc.groups, gkeys, pkeys, self.fastpath, chain_last_index=self.chain)
+        except Exception:
             enc.close()
+            raise
+        self.enc, self.batch_keys, self.peg_keys = enc, gkeys, pkeys
+
+    def rechain(self, node_group, node_template, last_index: int) -> bool:
+        """gpubinpacking/prefetch.go rechain: the REST of the loop's batch, from this group on, estimated again as one chained batch that starts
+        from `last_index` (rows of the loop's group table through casim_enc_group_rows, the first group's last_index overridden).  False:
+        nothing to re-chain (unchained mode, unknown group, the batch's last group, this loop's budget spent)."""
+        import numpy as np
+        key = self.group_key(node_group, node_template)
+        if not self.chain or self.enc is None or self.rechains >= self.MAX_RECHAINS or key not in self.batch_keys:
+            return False
+        pos = self.batch_keys.index(key)
+        n = len(self.batch_keys) - pos
+        if n < 2:
+            return False
+        self.rechains += 1
+        rows = self.enc.group_rows(range(pos, pos + n))
+        li = np.full(n, int(last_index), np.int32)   # (the chain reads the FIRST group's entry)
+        rows.last_index = li.ctypes.data_as(_abi.i32p)
+        self.cache.fill(self.enc.pegs, rows, self.batch_keys[pos:], self.peg_keys, self.fastpath, chain_last_index=True)
+        return True
 
     def lookup(self, pegs, node_template, node_group, max_nodes: int, existing_nodes: int, runner_last_index: Optional[int] = None):
         """runner_last_index: the snapshot runner's lastIndex at the time of THIS Estimate() (chain mode); None = the loop's (unchained mode)"""
         li = self.loop_last_index if (runner_last_index is None or not self.chain) else runner_last_index
         hit, out = self.cache.lookup(self.group_key(node_group, node_template), [self.peg_key(pg) for pg in pegs], max_nodes, existing_nodes, li)
+        self.last_miss = 0 if hit else int(out["miss_reason"])
         return out if hit else None
 
 

@@ -166,7 +166,7 @@ def test_the_go_shim_adds_the_pegs_of_a_loop_in_one_crossing():
     body = src[i:src.index("\n}\n", i)]
     assert "C.casim_enc_add_pods(s.enc, &pc, &out[0])" in body and "var pc C.casim_pod_columns" in body
     assert "runtime.Pinner" in body and "pin.Unpin()" in body and body.count("pin.Pin(") >= 4
-    assert "scalars(podutils.PodRequests(pod), func(" in body and "C.casim_enc_pod_set_request(s.enc, id, s.strs.s(string(name)), C.int64_t(v))" in body
+    assert "scalars(podutils.PodRequests(pod), func(name apiv1.ResourceName, v int64) { s.request(id, name, v) })" in body   # (request: no return code dropped)
     assert "s.podRest(pod, id)" in body and "ids[gi] = s.peg(g)" in body
     for column in ("ns", "req", "fastpath_req", "peg_count", "label_off", "label_key", "label_val", "tol_off", "tol_key", "tol_op", "tol_value",
                    "tol_effect", "sel_off", "sel_key", "sel_val", "strings", "n_pods", "n_strings"):

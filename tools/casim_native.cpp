@@ -410,7 +410,7 @@ int shim_replay(casim_ctx* ctx, const casim_pegs& pegs, const casim_groups& grou
         if (rc != CASIM_PREFETCH_MISS || r.miss_reason != CASIM_PREFETCH_MISS_LIMITS) fail("another max_nodes must miss", i);
         if (per_call(ctx, pegs, groups, i, l, other, opt, pc) != 0) fail("per-call after a limits miss", i);
         rc = casim_prefetch_lookup(pf, gkey[(size_t)i], k.data(), (int32_t)k.size(), groups.max_nodes[i], groups.existing_nodes[i], groups.last_index[i] + 1, &r, nullptr, nullptr);
-        if (rc != CASIM_PREFETCH_MISS || r.miss_reason != CASIM_PREFETCH_MISS_LIMITS) fail("another lastIndex must miss", i);
+        if (rc != CASIM_PREFETCH_MISS || r.miss_reason != CASIM_PREFETCH_MISS_LAST_INDEX) fail("another lastIndex must miss (on lastIndex alone)", i);
         rc = casim_prefetch_lookup(pf, 0xDEADBEEFull, k.data(), (int32_t)k.size(), groups.max_nodes[i], groups.existing_nodes[i], groups.last_index[i], &r, nullptr, nullptr);
         if (rc != CASIM_PREFETCH_MISS || r.miss_reason != CASIM_PREFETCH_MISS_GROUP) fail("an unknown group must miss", i);
         casim_prefetch_clear(pf);                                                          // the next loop iteration
@@ -442,9 +442,65 @@ int shim_replay(casim_ctx* ctx, const casim_pegs& pegs, const casim_groups& grou
             if (r.status == 0) runner = r.last_index_out;     // (a delegated group hands its input on: the reference path would move the real runner)
         }
     }
+    // ---- the chain LEFT and re-chained (round 6: prefetch.go rechain).  Group `mid - 1` runs on the reference path and moves the runner somewhere the
+    // batch did not expect: the lookup of group `mid` misses on lastIndex ALONE; the rest of the loop — rows mid .. NG - 1 of the loop's group table
+    // through casim_enc_group_rows, the first one's last_index overridden — is filled again as one chained batch from the runner's value, and every
+    // call from `mid` on hits and equals the per-call Estimate from the runner's lastIndex
+    int rechain_hits = 0, rechain_equal = 0, rechain_groups = 0;
+    if (enc && NG >= 3) {
+        casim_options copt = opt; copt.chain_last_index = 1;
+        rc = casim_prefetch_fill(pf, &pegs, &groups, &copt, gkey.data(), pkey.data());
+        if (rc != 0) fail("chained fill before the re-chain", 0);
+        const int mid = NG / 2;
+        casim_prefetch_result r;
+        // the calls before `mid` arrive in order and hit; then the runner ends one node further than the batch assumed
+        int32_t runner = groups.last_index ? groups.last_index[0] : 0;
+        for (int i = 0; i < mid; ++i) {
+            std::vector<uint64_t> k = keys_of(lists[(size_t)i]);
+            if (casim_prefetch_lookup(pf, gkey[(size_t)i], k.data(), (int32_t)k.size(), groups.max_nodes[i], groups.existing_nodes[i], runner, &r, nullptr, nullptr) != CASIM_OK) { fail("chained batch before the re-chain: expected a hit", i); break; }
+            if (r.status == 0) runner = r.last_index_out;
+        }
+        runner += 1;
+        {
+            std::vector<uint64_t> k = keys_of(lists[(size_t)mid]);
+            const int32_t lr = casim_prefetch_lookup(pf, gkey[(size_t)mid], k.data(), (int32_t)k.size(), groups.max_nodes[mid], groups.existing_nodes[mid], runner, &r, nullptr, nullptr);
+            if (lr != CASIM_PREFETCH_MISS || r.miss_reason != CASIM_PREFETCH_MISS_LAST_INDEX) fail("a left chain must miss on lastIndex alone", mid);
+        }
+        const int n = NG - mid;
+        std::vector<int32_t> rows((size_t)n), li((size_t)n, runner);
+        for (int i = 0; i < n; ++i) rows[(size_t)i] = mid + i;
+        casim_groups rest; memset(&rest, 0, sizeof rest);
+        if (casim_enc_group_rows(enc, rows.data(), n, &rest) != CASIM_OK) fail("casim_enc_group_rows of the rest of the loop", mid);
+        else {
+            rest.last_index = li.data();
+            rc = casim_prefetch_fill(pf, &pegs, &rest, &copt, gkey.data() + mid, pkey.data());
+            if (rc != 0) fail("re-chained fill", mid);
+            for (int i = mid; i < NG && rc == 0; ++i) {
+                const std::vector<int32_t>& l = lists[(size_t)i];
+                std::vector<uint64_t> k = keys_of(l);
+                std::vector<int32_t> order(l.size() + 1), placed(l.size() + 1);
+                const int32_t lr = casim_prefetch_lookup(pf, gkey[(size_t)i], k.data(), (int32_t)k.size(), groups.max_nodes[i], groups.existing_nodes[i], runner, &r, order.data(), placed.data());
+                ++rechain_groups;
+                if (lr != CASIM_OK) { fail("re-chained batch: expected a hit with the runner's lastIndex", i); break; }
+                ++rechain_hits;
+                OneGroup pc;
+                if (per_call(ctx, pegs, groups, i, l, groups.max_nodes[i], opt, pc, enc, &runner) != 0) { fail("per-call estimate (re-chained)", i); break; }
+                order.resize(l.size()); placed.resize(l.size());
+                const bool same = r.node_count == pc.v[0] && r.pods_scheduled == pc.v[1] && r.nodes_added == pc.v[2] && r.limiter_nodes == pc.v[3] && r.last_index_out == pc.v[4] &&
+                                  r.status == pc.v[5] && (r.status != 0 || (order == pc.order && placed == pc.placed));
+                if (same) ++rechain_equal; else fail("re-chained hit differs from the per-call answer with the runner's lastIndex", i);
+                if (r.status == 0) runner = r.last_index_out;
+            }
+            // a group answered before the re-chain is gone from the cache
+            std::vector<uint64_t> k0 = keys_of(lists[0]);
+            const int32_t lr = casim_prefetch_lookup(pf, gkey[0], k0.data(), (int32_t)k0.size(), groups.max_nodes[0], groups.existing_nodes[0], groups.last_index ? groups.last_index[0] : 0, &r, nullptr, nullptr);
+            if (lr != CASIM_PREFETCH_MISS || r.miss_reason != CASIM_PREFETCH_MISS_GROUP) fail("a group before the re-chained rest must miss on the group", 0);
+        }
+    }
     int64_t st[8]; casim_prefetch_stats(pf, st);
     casim_prefetch_destroy(pf);
     printf(", \"shim_chained\": {\"hits\": %d, \"hits_equal_to_per_call\": %d}", chain_hits, chain_equal);
+    printf(", \"shim_rechained\": {\"groups\": %d, \"hits\": %d, \"hits_equal_to_per_call\": %d}", rechain_groups, rechain_hits, rechain_equal);
     printf(", \"shim\": {\"groups\": %d, \"hits\": %d, \"hits_equal_to_per_call\": %d, \"miss_paths_checked\": %d, \"failed_checks\": %d, \"fill_ms\": %.4f, "
            "\"lookups_ms\": %.4f, \"per_call_ms_total\": %.4f, \"per_call_on_loop_tables_ms\": %.4f, \"stats\": [%lld, %lld, %lld, %lld, %lld, %lld]}",
            NG, hits, equal, miss_checked, bad, fill_ms, lookup_ms, percall_ms, rows_calls ? rows_ms / rows_calls : 0.0, (long long)st[0], (long long)st[1], (long long)st[2], (long long)st[3], (long long)st[4], (long long)st[5]);
