@@ -910,6 +910,7 @@ def main():
                 extra["c3_in_process_multi_device"] = _try(lambda: in_process_multi_device(kaa, workloads, kinds))
             if not args.no_configs:
                 extra["per_call_crossover"] = _try(lambda: per_call_crossover(kaa, ctx, workloads))
+                extra["chained_loop"] = _try(lambda: chained_loop_row(kaa, ctx, workloads))
                 # the other BASELINE configs that fit one GPU as verified batched throughput rows (C2 is the headline itself)
                 torch.cuda.synchronize()
                 extra["headline_rows"]["c4_resident"] = _try(lambda: batched_config_row(kaa, torch, dev_index, workloads, TableSet, "C4", 2048, 32, kinds, K, verify=not args.no_verify))
@@ -1052,6 +1053,52 @@ def per_call_crossover(kaa, ctx, workloads, iters=60):
                     "a C restatement: the Go reference is slower, i.e. its crossover lies lower)",
             "rows": rows, "crossover_work": cross, "shim_default_min_device_work": SHIM_MIN_DEVICE_WORK,
             "note": "gpubinpacking.Routing (integration/go/gpubinpacking/estimator.go) hands calls with pods x node bound below MinDeviceWork to the reference estimator"}
+
+
+def chained_loop_row(kaa, ctx, workloads, replicas=16, iters=12):
+    """the Go shim's prefetch is ONE simulation with a group per node group, chained (casim_options.chain_last_index) — a
+    cluster with a few hundred node groups used to enqueue a few hundred fix-up passes, nearly all of them empty launches.  Config C2's 20
+    groups `replicas` times over (320 node groups, 400 PEGs, one chain): enter -> return of casim_estimate_batch_query with the chain stopped
+    at its fixed point (default) against the whole bound enqueued (CASIM_CHAIN_ASYNC_MAX raised), identical results, and against the
+    oracle's chained loop on one core."""
+    import numpy as np
+    from kubernetes_autoscaler_amd.engine import BatchCall
+    from harness import GroupSpec, Scenario, encode, run_oracle, assert_matches_oracle
+    w = workloads.config_c2()
+    base = [GroupSpec(g.template, g.max_nodes, g.last_index, None) for g in w.groups]
+    sc = Scenario(pegs=w.pegs, groups=base * replicas, existing=w.existing, lanes=w.lanes, device_csr=True)
+    enc = encode(sc)
+    out = {"workload": f"C2's {len(base)} node groups x {replicas} = {len(base) * replicas} groups in ONE chained simulation, {len(w.pegs)} PEGs (the Go shim's prefetch fill)"}
+    results = {}
+    for label, env in (("stop_at_fixed_point", None), ("whole_bound_enqueued", "1000000")):
+        if env is None:
+            os.environ.pop("CASIM_CHAIN_ASYNC_MAX", None)
+        else:
+            os.environ["CASIM_CHAIN_ASYNC_MAX"] = env
+        bc = BatchCall(ctx, enc.pegs, enc.groups, chain_last_index=True)
+        for _ in range(3):
+            bc.call_raw()
+        ts = []
+        for _ in range(iters):
+            t0 = time.perf_counter(); bc.call_raw(); ts.append(time.perf_counter() - t0)
+        ts.sort()
+        res, _ = bc.call()
+        results[label] = res
+        out[label] = {"call_ms": ts[len(ts) // 2] * 1e3, "chain": kaa.Context.last_chain_info()}
+    os.environ.pop("CASIM_CHAIN_ASYNC_MAX", None)
+    a, b = results["stop_at_fixed_point"], results["whole_bound_enqueued"]
+    out["identical_results"] = bool(all(np.array_equal(getattr(a, f), getattr(b, f)) for f in ("node_count", "pods_scheduled", "nodes_added", "last_index_out", "status", "order", "placed")))
+    t0 = time.perf_counter()
+    want = run_oracle(sc, chain=True)
+    out["oracle_ms"] = (time.perf_counter() - t0) * 1e3
+    try:
+        assert_matches_oracle(a, want, "chained loop")
+        out["bit_exact"] = True
+    except AssertionError as e:
+        out["bit_exact"] = False
+        out["first_difference"] = str(e)[:200]
+    enc.close()
+    return out
 
 
 def feasibility_bytes(ts, lean):

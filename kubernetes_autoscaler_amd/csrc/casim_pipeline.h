@@ -391,7 +391,20 @@ public:
             if (cap > 0x7fffffffll) return fail(CASIM_ERR_INVALID, "sum of candidate PEG ranges too large for device-side CSR");
             nnz_cap_ = (int32_t)cap; feas_len_ = lmax;
             // simulation-major feasibility kernel: every group of a simulation shares its PEG range, one word per mask kind
-            feas_by_sim_ = n_sims_ > 0 && dt_.Wt <= 1 && dt_.Wl <= 1 && dt_.Wx <= 1 && dt_.Wz <= 1 &&
+            // Exclusion words of a FRESH node only speak through what the template already holds: (block & init_excl) != (block & polarity)
+            // (fits_fresh_node).  A batch whose templates carry no marked pods and whose dictionaries have no NEED bits — pod anti-affinity
+            // between PENDING pods only: BASELINE config C4, 240 hostname bits = 4 words — has a vacuous exclusion term: its cells are decided
+            // by requests, taints and selectors alone, and the simulation-major kernels (one word per mask kind) run it with Wx = 0.
+            // (round 6: the batched C4 row took the dense feas_kernel + scan + fill + order_kernel instead, 35 % of its step)
+            excl_vacuous_ = false;
+            if (n_sims_ > 0 && dt_.Wx > 1 && g->init_excl && !getenv("CASIM_NO_VACUOUS_EXCL")) {
+                bool any = false;
+                for (int w = 0; w < dt_.Wx && !any; ++w) any = xpol_host_[(size_t)w] != 0;
+                const size_t nw = NG * (size_t)dt_.Wx;
+                for (size_t i = 0; i < nw && !any; ++i) any = g->init_excl[i] != 0;
+                excl_vacuous_ = !any;
+            }
+            feas_by_sim_ = n_sims_ > 0 && dt_.Wt <= 1 && dt_.Wl <= 1 && (dt_.Wx <= 1 || excl_vacuous_) && dt_.Wz <= 1 &&
                            (size_t)128 * (size_t)max_sim_groups_ <= 48 * 1024;   // (the kernel stages a simulation's group records in LDS)
             for (int32_t si = 0; si < n_sims_ && feas_by_sim_; ++si)
                 for (int32_t i = g->sim_offsets[si] + 1; i < g->sim_offsets[si + 1]; ++i)
@@ -417,7 +430,7 @@ public:
             // batches: fixed-stride lists and ONE launch in front of the packer (front_sim_kernel) — group i owns [soff[i], soff[i] + (hi - lo))
             // of order / placed / records, the bound those arrays are sized for; its length is written to the slab's offset area (peg_cnt)
             strided_ = want_strided;
-            strided_one_launch_ = getenv("CASIM_FRONT_SIM") != nullptr && atoi(getenv("CASIM_FRONT_SIM")) != 0;   // (the one-launch form: measured slower in the loop)
+            strided_one_launch_ = getenv("CASIM_FRONT_SIM") != nullptr && atoi(getenv("CASIM_FRONT_SIM")) != 0 && !excl_vacuous_;   // (the one-launch form: measured slower in the loop)
             // rank once per (simulation, allocatable pair) instead of a sort per group (casim_kernels.h rank_shapes_kernel): when the candidate
             // ranges are long and a pair serves several groups — C3: 64 groups, 5 pairs, 1000 PEGs.  CASIM_RANK_ONCE=0 / 1: never / whenever possible
             rank_once_ = false;
@@ -802,7 +815,7 @@ public:
                 // runs the general instantiation
                 feas_hi_ = true; feas_us_word_ = -1; feas_us_bit_ = 0; h_mask_used_[0] = h_mask_used_[1] = ~0ull;
                 feas_smem_ = (size_t)(((max_sim_groups_ + 3) & ~3) + 4) * CASIM_FEAS_REC_DW * 4;   // (rounded up to four records, plus four: see the kernel's look-ahead)
-                if (d_feas_rec_) bk_.launch(feas_group_records_kernel, (NG_ + 255) / 256, 1, 256, (size_t)0, dt_, fs_.fresh32, d_feas_rec_, -1, 0);
+                if (d_feas_rec_) bk_.launch(feas_group_records_kernel, (NG_ + 255) / 256, 1, 256, (size_t)0, feas_tables(), fs_.fresh32, d_feas_rec_, -1, 0);
                 if (d_feas_rec_ && !one_shot_) {
                     uint64_t* flag = (uint64_t*)dalloc(16);
                     if (flag) {
@@ -828,7 +841,7 @@ public:
                 feas_us_word_ = -1;
                 for (int b = 0; b < top && feas_us_word_ < 0; ++b) if (!((ut >> b) & 1)) { feas_us_word_ = 0; feas_us_bit_ = b; }
                 for (int b = 0; b < top && feas_us_word_ < 0; ++b) if (!((us >> b) & 1)) { feas_us_word_ = 1; feas_us_bit_ = b; }
-                if (feas_us_word_ >= 0) bk_.launch(feas_group_records_kernel, (NG_ + 255) / 256, 1, 256, (size_t)0, dt_, fs_.fresh32, d_feas_rec_, feas_us_word_, feas_us_bit_);
+                if (feas_us_word_ >= 0) bk_.launch(feas_group_records_kernel, (NG_ + 255) / 256, 1, 256, (size_t)0, feas_tables(), fs_.fresh32, d_feas_rec_, feas_us_word_, feas_us_bit_);
             }
         }
         pass_gate();
@@ -863,12 +876,12 @@ public:
             return CASIM_OK;
         }
         if (strided_) {   // rows by feas_sim_kernel; run_order() builds and orders the lists (order_strided_kernel): no scan, no fill
-            launch_feas_sim((feas_len_ + 255) / 256, n_sims_, 256, (size_t)128 * (size_t)max_sim_groups_, dt_, d_bits_, Wg_,
+            launch_feas_sim((feas_len_ + 255) / 256, n_sims_, 256, (size_t)128 * (size_t)max_sim_groups_, feas_tables(), d_bits_, Wg_,
                        fast_npt_ > 0 ? fs_.req32 : (const int32_t*)nullptr, fast_npt_ > 0 ? fs_.fresh32 : (const int32_t*)nullptr);
             return CASIM_OK;
         }
         if (feas_len_ > 0) {
-            if (feas_by_sim_) launch_feas_sim((feas_len_ + 255) / 256, n_sims_, 256, (size_t)128 * (size_t)max_sim_groups_, dt_, d_bits_, Wg_,
+            if (feas_by_sim_) launch_feas_sim((feas_len_ + 255) / 256, n_sims_, 256, (size_t)128 * (size_t)max_sim_groups_, feas_tables(), d_bits_, Wg_,
                                          fast_npt_ > 0 ? fs_.req32 : (const int32_t*)nullptr, fast_npt_ > 0 ? fs_.fresh32 : (const int32_t*)nullptr);
             else bk_.launch(feas_kernel, (feas_len_ + 255) / 256, NG_, 256, (size_t)0, dt_, d_bits_, Wg_);
         }
@@ -1462,6 +1475,8 @@ private:
     uint32_t* d_feas_rec_ = nullptr; bool feas_hi_ = true; int feas_us_word_ = -1, feas_us_bit_ = 0; size_t feas_smem_ = 0;
     bool chain_ = false; int chain_passes_ = 0; int chain_passes_run_ = 0; int32_t* d_chain_redo_ = nullptr; int32_t* d_chain_marks_ = nullptr;   // casim_options.chain_last_index
     bool feas_by_sim_ = false;
+    bool excl_vacuous_ = false;   // Wx > 1, but no template holds a marked pod and no bit has NEED polarity: the simulation-major feasibility kernels run with Wx = 0
+    DevTables feas_tables() const { DevTables t = dt_; if (excl_vacuous_) t.Wx = 0; return t; }
     bool one_shot_ = false;
     UploadGate* gate_ = nullptr; int gate_idx_ = 0; bool gate_passed_ = false;
     bool ord_in_slab_ = false; size_t ord_off_ = 0, ord_cap_ = 0;   // order / placed inside the results slab (short lists)

@@ -278,3 +278,48 @@ def test_simulations_that_share_their_peg_rows():
     c, _ = run_emu_tables(h, kinds=None)
     assert list(c.node_count) == list(b.node_count[:h.n_groups])
     enc.close()
+
+
+def _c4_batch(n_seeds, spoil=False):
+    """C4-shaped simulations whose hostname anti-affinity bits need TWO exclusion words (400 PEGs, 60 % with a term).  spoil: one template of
+    the second simulation carries a DaemonSet pod that matches a term — its init_excl word is no longer zero."""
+    import copy
+    import bench
+    import kubernetes_autoscaler_amd as kaa
+    from kubernetes_autoscaler_amd.objects import Pod
+
+    def make(seed_offset=0):
+        w = workloads.config_c4(seed_offset, n_groups=4, n_pegs=400, pods_per_peg=2, cap=6)
+        if spoil and seed_offset == 1:
+            w = copy.deepcopy(w)
+            victim = next(pg.pods[0] for pg in w.pegs if pg.pods[0].anti_affinity)
+            w.groups[2].template.pods.append(Pod(name="ds", requests={"cpu": 10, "memory": 1 << 20}, labels=dict(victim.labels)))
+        return w
+    return make, bench.simulation_tables(make, range(n_seeds), kaa.Encoder, TableSet)
+
+
+@pytest.mark.parametrize("spoil", [False, True], ids=["vacuous", "a-template-holds-a-marked-pod"])
+def test_exclusion_words_that_say_nothing_about_a_fresh_node_take_the_simulation_major_path(spoil, monkeypatch):
+    """round 6: exclusion words speak about a FRESH node only through what the template already holds ((block & init_excl) != (block & polarity),
+    fits_fresh_node).  Pod anti-affinity between PENDING pods alone — BASELINE config C4 — leaves every init_excl word zero: the batch's cells
+    are decided by requests, taints and selectors, and the simulation-major kernels (feas_sim / feas_stream + strided lists, one word per mask
+    kind) take it although the dictionary is two words wide (the batched C4 row spent 35 % of its step in the dense feas_kernel + scan + fill
+    before).  One marked pod on one template and the batch is back on the general path.  Either way: the oracle's answers, and the same
+    answers as with the shortcut switched off."""
+    import bench
+    from harness import emu_lib
+    make, ts = _c4_batch(3, spoil)
+    assert ts.dims["w_excl"] == 2, ts.dims
+    res, _ = run_emu_tables(ts)
+    path = emu_lib().emu_last_front()
+    assert (path == 2) == (not spoil), path           # 2 = strided lists (simulation-major feasibility); 0 / 1 = dense kernel + CSR, or the fused front kernel of small calls
+    chk = bench.verify_headline(workloads, make, 3, ts, res)
+    assert chk["headline_bit_exact"], chk
+    monkeypatch.setenv("CASIM_NO_VACUOUS_EXCL", "1")
+    ref, _ = run_emu_tables(ts)
+    assert emu_lib().emu_last_front() != 2
+    for f in ("node_count", "pods_scheduled", "nodes_added", "last_index_out", "status", "order", "placed", "offsets"):
+        assert list(getattr(res, f)) == list(getattr(ref, f)), f
+    res64, _ = run_emu_tables(ts, generic=True)
+    for f in ("node_count", "pods_scheduled", "order", "placed"):
+        assert list(getattr(res64, f)) == list(getattr(ref, f)), f

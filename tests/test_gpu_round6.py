@@ -1,0 +1,143 @@
+"""-m gpu: what round 6 added, through the C ABI on the MI355X.
+  * a chained prefetch batch whose order was LEFT is re-chained: the rest of the loop as one chained batch from the runner's lastIndex
+    (CASIM_PREFETCH_MISS_LAST_INDEX; integration/go/gpubinpacking/prefetch.go rechain, mirrored by estimator.PrefetchShared.rechain);
+  * long chains stop at their fixed point (casim_last_chain_info);
+  * Allocatable opens no lane, a request of zero opens none (ABI 12): a node that lists hugepages-*: 0 and attachable-volumes-* keeps the
+    tables inside the register packer's four lanes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import kubernetes_autoscaler_amd as kaa
+from kubernetes_autoscaler_amd import _abi, workloads
+from kubernetes_autoscaler_amd import estimator as est
+from kubernetes_autoscaler_amd._ffi import lib
+from kubernetes_autoscaler_amd.engine import Problem
+from kubernetes_autoscaler_amd.objects import Node, NodeInfo, Pod, PodEquivalenceGroup
+from harness import GroupSpec, Scenario, assert_matches_oracle, encode, run_gpu, run_oracle
+from oracle_driver import OracleScenario
+from test_gpu_prefetch import _oracle_per_group, _setup
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = kaa.Context(0)
+    yield c
+    c.close()
+
+
+def _oracle_estimate(w, k, ids, last_index):
+    s = OracleScenario(lanes=w.lanes)
+    t = s.node(w.groups[k].template)
+    e = s.estimate(t, [w.pegs[i] for i in ids], max_nodes=w.groups[k].max_nodes, last_index=last_index)
+    s.close()
+    return e
+
+
+def test_a_left_chain_is_rechained_from_the_runners_last_index(ctx):
+    """group 2 of an eight-group loop runs on the reference path (here: the oracle stands in for it) and leaves the runner one node further
+    than the batch assumed.  Group 3 misses on lastIndex ALONE, the shim re-chains groups 3..7 as one batch from the runner's value, and
+    every call from there on HITS — each answer equal to the oracle's Estimate from the runner's real lastIndex.  Device trips: the fill +
+    ONE re-chain instead of the fill + five per-call estimates."""
+    w = workloads.config_c2(n_groups=8, n_pegs=70, pods_per_peg=9, cap=18)
+    ngs, infos, limiter = _setup(w)
+    want = _oracle_per_group(w, chain=True)
+    shared = est.PrefetchShared(ctx, limiter)
+    snapshot = est.ClusterSnapshotView()
+    shared.fill(w.pegs, ngs, infos, snapshot)
+    builder = est.new_estimator_builder(est.GPU_BINPACKING_ESTIMATOR_NAME, limiter, engine_ctx=ctx, prefetch=shared)
+    li = 0
+    for k in range(8):
+        ids = want[k][0]
+        if k == 2:     # "the reference path": the runner moves without the shim (and ends somewhere the chain did not expect)
+            e = _oracle_estimate(w, k, ids, li)
+            li = snapshot.last_index = e.last_index_out + 1
+            continue
+        e = _oracle_estimate(w, k, ids, li)
+        n, got = builder(snapshot, est.EstimationContext(0, [], 0)).estimate([w.pegs[i] for i in ids], infos[ngs[k].id()], ngs[k])
+        assert (n, len(got), snapshot.last_index) == (e.node_count, e.pods_scheduled, e.last_index_out), k
+        li = e.last_index_out
+    st = shared.cache.stats()
+    assert shared.rechains == 1 and st["fills"] == 2, (shared.rechains, st)
+    assert st["miss_last_index"] == 1 and st["miss_limits"] == 1 and st["hits"] == 7, st       # groups 0, 1 + 3..7 hit; one miss triggered the re-chain
+    # a group answered before the re-chain is gone from the cache (a second Estimate for it takes the per-call path)
+    assert shared.lookup([w.pegs[i] for i in want[0][0]], infos[ngs[0].id()], ngs[0], w.groups[0].max_nodes, 0, runner_last_index=0) is None
+    assert shared.last_miss == _abi.PREFETCH_MISS_GROUP
+    shared.close()
+
+
+def test_the_rechain_budget_bounds_the_batches_of_a_loop(ctx):
+    """every other group leaves the chain: after MAX_RECHAINS re-chains the per-call path answers — still the oracle's Estimate for the runner's lastIndex"""
+    w = workloads.config_c2(n_groups=14, n_pegs=40, pods_per_peg=8, cap=12)
+    ngs, infos, limiter = _setup(w)
+    want = _oracle_per_group(w, chain=True)
+    shared = est.PrefetchShared(ctx, limiter)
+    snapshot = est.ClusterSnapshotView()
+    shared.fill(w.pegs, ngs, infos, snapshot)
+    builder = est.new_estimator_builder(est.GPU_BINPACKING_ESTIMATOR_NAME, limiter, engine_ctx=ctx, prefetch=shared)
+    li = 0
+    for k in range(14):
+        ids = want[k][0]
+        e = _oracle_estimate(w, k, ids, li)
+        if k % 2 == 1:
+            li = snapshot.last_index = e.last_index_out + 1
+            continue
+        n, got = builder(snapshot, est.EstimationContext(0, [], 0)).estimate([w.pegs[i] for i in ids], infos[ngs[k].id()], ngs[k])
+        assert (n, len(got), snapshot.last_index) == (e.node_count, e.pods_scheduled, e.last_index_out), k
+        li = e.last_index_out
+    assert shared.rechains == est.PrefetchShared.MAX_RECHAINS
+    shared.close()
+
+
+def test_long_chains_stop_at_their_fixed_point_on_the_device(ctx):
+    """one simulation with 96 node groups (bound: 95 fix-up passes): the blocks stop long before the bound, the results are the sequential loop's;
+    a 20-group chain is enqueued whole (no wait inside the run)"""
+    w = workloads.fuzz(31901, max_groups=7, max_pegs=10)
+    base = [GroupSpec(g.template, g.max_nodes, g.last_index, None) for g in w.groups]
+    sc = Scenario(pegs=w.pegs, groups=[base[i % len(base)] for i in range(96)], existing=w.existing, lanes=w.lanes, device_csr=True)
+    enc = encode(sc)
+    res, _ = run_gpu(enc, ctx, chain=True)
+    assert_matches_oracle(res, run_oracle(sc, chain=True), "96 groups chained")
+    info = kaa.Context.last_chain_info()
+    assert info["bound"] == 95 and not info["whole"] and info["passes"] < 48 and info["checks"] >= 1, info
+    enc.close()
+    w = workloads.config_c2()
+    sc = Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, g.pegs) for g in w.groups], existing=w.existing, lanes=w.lanes, device_csr=True)
+    enc = encode(sc)
+    res, _ = run_gpu(enc, ctx, chain=True)
+    assert_matches_oracle(res, run_oracle(sc, chain=True), "C2 chained")
+    info = kaa.Context.last_chain_info()
+    assert info == {"bound": 19, "passes": 19, "checks": 0, "whole": True}, info
+    enc.close()
+
+
+def test_real_node_allocatables_keep_the_register_packer(ctx):
+    """a GPU-pool scale-up described the way encode.go describes real objects: nodes list hugepages-1Gi: 0, hugepages-2Mi: 0,
+    attachable-volumes-aws-ebs: 25 next to nvidia.com/gpu, pods list hugepages-2Mi: 0.  Four lanes (cpu, memory, ephemeral-storage, gpu):
+    the register packer takes the batch (casim_problem_info[0] > 0) and the results are the oracle's."""
+    GiB = 1 << 30
+    extras = {"hugepages-1Gi": 0, "hugepages-2Mi": 0, "attachable-volumes-aws-ebs": 25}
+
+    def tmpl(name, gpus):
+        cap = {"cpu": 16000, "memory": 64 * GiB, "ephemeral-storage": 200 * GiB, "pods": 110, **extras}
+        if gpus:
+            cap["nvidia.com/gpu"] = gpus
+        return NodeInfo(Node(name=name, labels={}, allocatable=dict(cap), capacity=dict(cap)), [])
+
+    pegs = [PodEquivalenceGroup(pods=[Pod(name="train", requests={"cpu": 2000, "memory": 8 * GiB, "nvidia.com/gpu": 1, "hugepages-2Mi": 0})] * 21),
+            PodEquivalenceGroup(pods=[Pod(name="web", requests={"cpu": 500, "memory": 1 * GiB, "hugepages-2Mi": 0})] * 40)]
+    groups = [GroupSpec(tmpl("gpu-8", 8), 0, 0, None), GroupSpec(tmpl("gpu-4", 4), 0, 0, None), GroupSpec(tmpl("cpu-only", 0), 0, 0, None)]
+    sc = Scenario(pegs=pegs, groups=groups, existing=[], lanes=("cpu", "memory", "ephemeral-storage", "nvidia.com/gpu"), device_csr=True)
+    enc = encode(sc, named_lanes=True)
+    assert enc.lanes == ("cpu", "memory", "ephemeral-storage", "nvidia.com/gpu"), enc.lanes
+    with Problem(ctx, enc.pegs, enc.groups, False) as prob:
+        info = (C.c_int32 * 8)()
+        assert lib.casim_problem_info(prob._h, info) == 0
+        assert info[0] > 0, list(info)          # node slots per lane of the register packer (0 = the generic int64 packer)
+    res, _ = run_gpu(enc, ctx)
+    assert_matches_oracle(res, run_oracle(sc), "gpu pool with real allocatables")
+    print("gpu pool:", [int(x) for x in res.node_count], [int(x) for x in res.pods_scheduled])
+    enc.close()
