@@ -78,6 +78,7 @@ struct HipBackend {
         pool.clear(); pooled_bytes = 0;
         for (int i = 0; i < 2; ++i) { if (staging[i]) (void)hipHostFree(staging[i]); staging[i] = nullptr; staging_cap[i] = 0; }
         if (mark_ev) { (void)hipEventDestroy(mark_ev); mark_ev = nullptr; }
+        if (turn_ev) { (void)hipEventDestroy(turn_ev); turn_ev = nullptr; }
     }
     // pinned host staging: 0 = uploads, 1 = fetches
     void* staging[2] = {nullptr, nullptr}; size_t staging_cap[2] = {0, 0};
@@ -94,6 +95,25 @@ struct HipBackend {
     }
     void* stage_if_fits(int which, size_t bytes) { which &= 1; return staging_cap[which] >= bytes ? staging[which] : nullptr; }   // (never re-allocates)
     void h2d(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D"); }
+    // Big table uploads of a streamed call.  Copies that four lanes issue on four streams share the link, so every part's tables arrive at the
+    // same late moment and no kernel runs under an upload (profiles/r14d_enter_return_trace.txt: 60 MB in 1.2 ms, THEN 1.1 ms of kernels).  The
+    // parts therefore take the link IN TURN, on the device's own clock: part i's first big copy waits for the event part i - 1 recorded behind
+    // its last one (wait_turn_event / record_turn_event; the host only makes sure the record is issued before the wait: UploadGate in issue
+    // order).  Part 0's tables arrive first, at the full rate of the link, and its kernels run under the uploads of the parts behind it.
+    // (A stream of its own for all uploads was tried first: the runtime served it with an SDMA engine at ~31 GB/s where the lanes' own
+    // streams copy with blit kernels at ~55 — profiles/r14f_upload_stream_trace.txt — and every cell of the matrix got slower.)
+    hipEvent_t turn_ev = nullptr;
+    // OFF by default (CASIM_UPLOAD_FIFO=1 turns it on): measured neutral to slower in every cell of tables x requests x parts
+    // (profiles/r14i_enter_return_matrix.txt) — a part behind the turn event finds its later small copies waiting on the host until its
+    // stream has drained, and calls with small tables (PEG rows shared between simulations) only lose the stagger
+    bool bulk_ready() const { static const bool on = getenv("CASIM_UPLOAD_FIFO") && atoi(getenv("CASIM_UPLOAD_FIFO")) != 0; return on; }
+    void h2d_bulk(void* d, const void* s, size_t n) { h2d(d, s, n); }
+    void bulk_fence() {}
+    void record_turn_event() {
+        if (!turn_ev) check(hipEventCreateWithFlags(&turn_ev, hipEventDisableTiming), "hipEventCreate");
+        if (turn_ev) check(hipEventRecord(turn_ev, stream), "hipEventRecord");
+    }
+    void wait_turn_event(HipBackend& prev) { if (prev.turn_ev) check(hipStreamWaitEvent(stream, prev.turn_ev, 0), "hipStreamWaitEvent"); }
     // the caller's array is page-locked (casim_host_alloc, hipHostRegister, a pinned torch tensor): the DMA engine can read it where it lies
     bool pinned(const void* p) const {
         hipPointerAttribute_t a;

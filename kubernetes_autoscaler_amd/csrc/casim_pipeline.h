@@ -7,6 +7,8 @@
 //     void   h2d(void* dst, const void* src, size_t bytes);   // async on the backend's stream
 //     void   d2h(void* dst, const void* src, size_t bytes);
 //     void   zero(void* dst, size_t bytes);
+//     void   h2d_bulk(void* d, const void* s, size_t n); void bulk_fence();   // big table uploads: may travel on a queue the lanes of a context share
+//                                             // (FIFO: the parts of a streamed call arrive in turn order); bulk_fence() makes the own stream wait for them
 //     void*  stage(int which, size_t bytes);  // host staging buffer (pinned on the device backend) of >= bytes, owned by the
 //                                             // backend and reused by later calls: 0 = uploads, 1 = fetches
 //     void   sync();
@@ -25,8 +27,14 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <pthread.h>
+
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -36,9 +44,90 @@
 
 namespace casim {
 
+// ---- host threads ---------------------------------------------------------------------------------------------------------------------
+// A process-wide pool of worker threads, created on first use and never torn down (the threads sleep on a condition variable; the OS takes
+// them with the process).  Until round 6 every parallel host loop and every part of a streamed call started threads of its own: ~150 us
+// before the four parts of a headline call were running, and per-call spawns made threading the 6 MB columns of a part a loss (0.9 ->
+// 1.3 ms), so each part staged its 18 MB on ONE thread — 0.9 of the 3.3 ms of an enter -> return call (profiles/r14c_enter_return_timeline.txt).
+// run(n, f) executes f(0) .. f(n - 1), the caller working along with the pool, and returns when all are done.  Tasks are handed out in
+// index order and a caller never waits for a task nobody has started (it takes them itself), so nested calls — a part's worker that cuts
+// a copy over the pool — and tasks that wait for LOWER-numbered tasks of their own job (the parts' turn order) cannot deadlock.
+// CASIM_POOL_THREADS (default 12, 0 = none: every run() is the caller's own loop).
+class HostPool {
+public:
+    static HostPool& get() {
+        static std::atomic<HostPool*> inst{nullptr};
+        HostPool* p = inst.load(std::memory_order_acquire);
+        if (!p) {
+            static std::mutex mk;
+            std::lock_guard<std::mutex> l(mk);
+            p = inst.load(std::memory_order_relaxed);
+            if (!p) {
+                p = new HostPool();
+                inst.store(p, std::memory_order_release);
+                // a forked child has none of the threads and maybe a locked mutex: it gets a fresh pool (the old one is left where it is)
+                static std::atomic<HostPool*>* slot = &inst;
+                pthread_atfork(nullptr, nullptr, [] { slot->store(nullptr, std::memory_order_release); });
+            }
+        }
+        return *p;
+    }
+    int workers() const { return (int)n_workers_; }
+    template <class F>
+    void run(int n, F&& f) {
+        if (n <= 0) return;
+        if (n == 1 || n_workers_ == 0) { for (int i = 0; i < n; ++i) f(i); return; }
+        auto job = std::make_shared<Job>();
+        job->n = n; job->fn = [&f](int i) { f(i); };
+        { std::lock_guard<std::mutex> l(mu_); jobs_.push_back(job); }
+        cv_.notify_all();
+        work_on(*job);
+        // (the tasks still running belong to other threads: wait for them — the function object lives on this stack)
+        std::unique_lock<std::mutex> l(job->mu);
+        job->cv.wait(l, [&] { return job->done.load(std::memory_order_acquire) >= n; });
+    }
+private:
+    struct Job { std::function<void(int)> fn; int n = 0; std::atomic<int> next{0}, done{0}; std::mutex mu; std::condition_variable cv; };
+    static void work_on(Job& j) {
+        for (;;) {
+            const int i = j.next.fetch_add(1, std::memory_order_acq_rel);
+            if (i >= j.n) return;
+            j.fn(i);
+            if (j.done.fetch_add(1, std::memory_order_acq_rel) + 1 >= j.n) { std::lock_guard<std::mutex> l(j.mu); j.cv.notify_all(); }
+        }
+    }
+    HostPool() {
+        const char* e = getenv("CASIM_POOL_THREADS");
+        long n = e ? atol(e) : 12;
+        const long hw = (long)std::thread::hardware_concurrency();
+        if (hw > 0 && n > hw - 1) n = hw - 1;
+        if (n < 0) n = 0;
+        if (n > 64) n = 64;
+        n_workers_ = (size_t)n;
+        for (long t = 0; t < n; ++t) std::thread([this] { loop(); }).detach();
+    }
+    void loop() {
+        for (;;) {
+            std::shared_ptr<Job> job;
+            {
+                std::unique_lock<std::mutex> l(mu_);
+                for (;;) {
+                    while (!jobs_.empty() && jobs_.front()->next.load(std::memory_order_acquire) >= jobs_.front()->n) jobs_.pop_front();   // handed out completely
+                    // (a job further back may still have tasks while the front one has none left to give: take the first that has)
+                    for (auto& j : jobs_) if (j->next.load(std::memory_order_acquire) < j->n) { job = j; break; }
+                    if (job) break;
+                    cv_.wait(l);
+                }
+            }
+            work_on(*job);
+        }
+    }
+    std::mutex mu_; std::condition_variable cv_; std::deque<std::shared_ptr<Job>> jobs_; size_t n_workers_ = 0;
+};
+
 // Host-side loops over the table columns of a million-PEG batch (the gcd pass, the int32 tables, the copy into pinned staging) are
-// cut over a few threads: an enter -> return call of the headline batch spent 2.1 ms of every part's 4.4 ms of init in them
-// (profiles/r05p_init_stages.txt).  f(lo, hi, t) for thread t of at most kHostLoopThreads; short loops run inline.
+// cut over a few threads of the pool: an enter -> return call of the headline batch spent 2.1 ms of every part's 4.4 ms of init in them
+// (profiles/r05p_init_stages.txt).  f(lo, hi, t) for slice t of at most kHostLoopThreads; short loops run inline.
 // CASIM_HOST_THREADS = 1 switches it off.
 constexpr int kHostLoopThreads = 4;
 inline int host_loop_threads() {
@@ -52,16 +141,13 @@ inline void par_for(size_t n, size_t min_per_thread, F f) {
     if (const char* e = getenv("CASIM_HOST_GRAIN")) { const long v = atol(e); if (v > 0) min_per_thread = (size_t)v; }   // (tests: threads on small tables)
     if (min_per_thread > 0 && n / min_per_thread < (size_t)T) T = (int)(n / min_per_thread);
     if (T <= 1) { f((size_t)0, n, 0); return; }
-    std::thread th[kHostLoopThreads];
-    for (int t = 1; t < T; ++t) th[t] = std::thread([&f, n, T, t] { f(n * (size_t)t / (size_t)T, n * (size_t)(t + 1) / (size_t)T, t); });
-    f((size_t)0, n / (size_t)T, 0);
-    for (int t = 1; t < T; ++t) th[t].join();
+    HostPool::get().run(T, [&f, n, T](int t) { f(n * (size_t)t / (size_t)T, n * (size_t)(t + 1) / (size_t)T, t); });
 }
 inline void par_memcpy(void* dst, const void* src, size_t bytes) {
-    // (threads are spawned per call: below ~16 MB the spawn costs more than it saves — 6 MB columns of a 1024-simulation part copied
-    // slower on 4 threads, 0.9 -> 1.3 ms per part; the 26 MB columns of an unsplit 4096-simulation batch copy twice as fast)
-    if (bytes < (16u << 20)) { memcpy(dst, src, bytes); return; }
-    par_for(bytes, (size_t)4 << 20, [dst, src](size_t lo, size_t hi, int) { memcpy((char*)dst + lo, (const char*)src + lo, hi - lo); });
+    // (slices of >= 1 MiB on the pool's threads: no spawn per call any more — the 6 MB columns of a 1024-simulation part, which copied SLOWER
+    // on four freshly started threads, 0.9 -> 1.3 ms per part, are worth cutting now)
+    if (bytes < (2u << 20)) { memcpy(dst, src, bytes); return; }
+    par_for(bytes, (size_t)1 << 20, [dst, src](size_t lo, size_t hi, int) { memcpy((char*)dst + lo, (const char*)src + lo, hi - lo); });
 }
 
 inline int64_t round_up64(int64_t v) { return (v + 63) & ~63ll; }
@@ -301,6 +387,16 @@ public:
         dt_.cap_cpu = (dt_.fastpath && g->cap_cpu) ? up(g->cap_cpu, NG) : nullptr; dt_.cap_mem = (dt_.fastpath && g->cap_mem) ? up(g->cap_mem, NG) : nullptr;
         dt_.waste_cpu = g->waste_cpu ? up(g->waste_cpu, NG) : nullptr; dt_.waste_mem = g->waste_mem ? up(g->waste_mem, NG) : nullptr;
 
+        // the parts of a streamed call share the upload queue: this part's table columns enter it NOW, behind the columns of the parts in front
+        // of it, and the next part's follow — nobody holds the turn while it computes its geometry (what is staged later is small and travels
+        // on the part's own stream, where nothing is queued in front of it)
+        if (gate_issue_order_ && gate_ && !gate_passed_) {
+            stage.mark("wait for the turn");
+            gate_->wait_turn(gate_idx_);
+            stage.mark("issue the table columns");
+            if (up_dev_ && !up_reserved_) issue_uploads();
+            pass_gate();
+        }
         stage.mark("slabs, ranges, csr buffers");
         // ---- results slab: the per-group scalars and the CSR offsets side by side, so that ONE device-to-host copy fetches them
         {
@@ -617,6 +713,7 @@ public:
                 // block; the quotients by scale_requests_kernel further down) — the host pass above was skipped
                 if (dev_gcd) {
                     flush_uploads_all();
+                    if (gate_issue_order_) pass_gate();   // the bulk of this part's tables is IN the queue: the next part's line up behind them
                     const int nb = (int)(G / 2048 < 1 ? 1 : (G / 2048 > 1024 ? 1024 : G / 2048));
                     GcdPartial* d_part = (GcdPartial*)dalloc(sizeof(GcdPartial) * (size_t)nb);
                     GcdPartial* h_part = (GcdPartial*)bk_.stage(1, sizeof(GcdPartial) * (size_t)nb);
@@ -1333,8 +1430,19 @@ public:
     // the lists anyway and says so (last_fetch_rebased), the other fetch paths leave it to the caller
     void set_order_id_base(int32_t b) { order_id_base_ = b; }
     bool last_fetch_rebased() const { return fetch_rebased_; }
-    void set_upload_gate(UploadGate* g, int index) { gate_ = g; gate_idx_ = index; gate_passed_ = false; }   // before init(): parts of a streamed batch
-    void pass_gate() { if (gate_ && !gate_passed_) { gate_passed_ = true; gate_->pass(gate_idx_); } }
+    // before init(): parts of a streamed batch.  issue_order: the parts' big uploads share ONE queue (the backend's bulk path), so a part hands the
+    // turn on as soon as its tables are IN the queue — no wait for the device in between
+    // `prev`: the backend of the part in front (null for part 0): this part's first big copy waits, on the device, for the event that part recorded
+    // behind its last one
+    void set_upload_gate(UploadGate* g, int index, bool issue_order = false, BK* prev = nullptr) {
+        gate_ = g; gate_idx_ = index; gate_passed_ = false; gate_issue_order_ = issue_order; turn_prev_ = prev; turn_waited_ = false;
+    }
+    void pass_gate() {
+        if (gate_ && !gate_passed_) {
+            if (gate_issue_order_) bk_.record_turn_event();   // (behind this part's last big copy; the next part's first one waits for it on the device)
+            gate_passed_ = true; gate_->pass(gate_idx_);
+        }
+    }
     // [0] the streaming feasibility kernel serves this problem, [1] lean, [2] mask31, [3] its workgroups
     void feasibility_info(int32_t out[4]) const {
         const bool stream = d_feas_rec_ != nullptr && fast_npt_ > 0 && (strided_ || feas_by_sim_) && !front_ && !(strided_ && strided_one_launch_);
@@ -1376,10 +1484,32 @@ private:
         up_host_ = (char*)bk_.stage(0, bound);
         up_dev_ = up_host_ ? (char*)dalloc(bound) : nullptr;
         up_cap_ = up_dev_ ? bound : 0; up_used_ = 0; up_flushed_ = 0; up_reserved_ = false;
+        up_segs_.clear(); up_seg_bytes_ = 0;
+    }
+    // What is ready to travel and has not been handed to the backend yet: `up_segs_` (in slab order: staged ranges and page-locked columns
+    // of the caller that go out from where they lie) followed by the staged range [up_flushed_, up_used_).  The parts of a streamed call take
+    // the link in turn (set_upload_gate, issue order): the first copy of a part waits on the device for the event the part in front of it
+    // recorded behind its last big copy.  (h2d_bulk / bulk_fence: the backend's hook for big pieces — the same stream on the device backend.)
+    static constexpr size_t kBulkMin = (size_t)1 << 20;
+    void issue_uploads() {
+        if (gate_issue_order_ && !gate_passed_ && turn_prev_ && !turn_waited_) { bk_.wait_turn_event(*turn_prev_); turn_waited_ = true; }
+        const size_t tail = up_used_ > up_flushed_ ? up_used_ - up_flushed_ : 0;
+        const bool bulk = up_seg_bytes_ + tail >= kBulkMin;
+        for (const UpSeg& sg : up_segs_) {
+            const void* src = sg.src ? sg.src : (const void*)(up_host_ + sg.at);
+            if (bulk) bk_.h2d_bulk(up_dev_ + sg.at, src, sg.bytes); else bk_.h2d(up_dev_ + sg.at, src, sg.bytes);
+        }
+        up_segs_.clear(); up_seg_bytes_ = 0;
+        if (tail > 0) {
+            if (bulk) bk_.h2d_bulk(up_dev_ + up_flushed_, up_host_ + up_flushed_, tail); else bk_.h2d(up_dev_ + up_flushed_, up_host_ + up_flushed_, tail);
+            up_flushed_ = up_used_;
+        }
     }
     void end_uploads() {
         if (gate_ && !gate_passed_) gate_->wait_turn(gate_idx_);
-        if (up_dev_ && up_used_ > up_flushed_) bk_.h2d(up_dev_ + up_flushed_, up_host_ + up_flushed_, up_used_ - up_flushed_);
+        if (up_dev_) issue_uploads();
+        bk_.bulk_fence();
+        if (gate_issue_order_) pass_gate();   // (everything of this part is in the queue: the next part's tables line up behind it)
         up_dev_ = up_host_ = nullptr; up_cap_ = 0;
     }
     // A big batch does not wait for its last column before the first one travels: every kUploadChunk bytes of staged columns go out
@@ -1388,6 +1518,11 @@ private:
     // rest goes out with end_uploads().  A single simulation stays one copy.
     static constexpr size_t kUploadChunk = (size_t)4 << 20;
     static constexpr size_t kDirectUploadMin = (size_t)1 << 20;   // columns below this are cheaper to stage than to ask about (hipPointerGetAttributes)
+    static size_t direct_upload_min() {   // (CASIM_TEST_DIRECT_MIN: tests send small page-locked columns from where they lie)
+        const char* e = getenv("CASIM_TEST_DIRECT_MIN");
+        const long v = e ? atol(e) : 0;
+        return v > 0 ? (size_t)v : kDirectUploadMin;
+    }
     static size_t upload_chunk() {   // (CASIM_TEST_UPLOAD_CHUNK: tests send small tables in many pieces)
         const char* e = getenv("CASIM_TEST_UPLOAD_CHUNK");
         const long v = e ? atol(e) : 0;
@@ -1395,28 +1530,29 @@ private:
     }
     void flush_uploads_all() {   // everything staged so far goes out now (a kernel is about to read it)
         if (gate_ && !gate_passed_) gate_->wait_turn(gate_idx_);
-        if (up_reserved_ || !up_dev_ || up_used_ <= up_flushed_) return;
-        bk_.h2d(up_dev_ + up_flushed_, up_host_ + up_flushed_, up_used_ - up_flushed_);
-        up_flushed_ = up_used_;
+        if (up_reserved_ || !up_dev_) { bk_.bulk_fence(); return; }
+        issue_uploads();
+        bk_.bulk_fence();
     }
     void flush_uploads_early() {
-        if (up_reserved_ || !up_dev_ || up_used_ - up_flushed_ < upload_chunk()) return;
+        if (up_reserved_ || !up_dev_ || up_seg_bytes_ + (up_used_ - up_flushed_) < upload_chunk()) return;
         if (gate_ && !gate_passed_ && !gate_->my_turn(gate_idx_)) return;   // (not this part's turn on the link yet: keep staging)
-        bk_.h2d(up_dev_ + up_flushed_, up_host_ + up_flushed_, up_used_ - up_flushed_);
-        up_flushed_ = up_used_;
+        issue_uploads();
     }
     template <class T>
     const T* up(const T* src, size_t n) {
         if (n == 0 || !src) return nullptr;
         const size_t bytes = sizeof(T) * n, at = (up_used_ + 15) & ~(size_t)15;
         if (up_dev_ && at + bytes <= up_cap_) {
-            // a big column in page-locked memory travels from where it lies: what is staged in front of it goes out first (the staged range
-            // must not cover the column's slice of the slab: its bytes in the staging buffer are garbage), then the column itself
-            if (bytes >= kDirectUploadMin && !up_reserved_ && bk_.pinned(src)) {
-                if (up_used_ > up_flushed_) bk_.h2d(up_dev_ + up_flushed_, up_host_ + up_flushed_, up_used_ - up_flushed_);
-                bk_.h2d(up_dev_ + at, src, bytes);
+            // a big column in page-locked memory travels from where it lies: what is staged in front of it is listed first (the staged range
+            // must not cover the column's slice of the slab: its bytes in the staging buffer are garbage), then the column itself — both go
+            // out at the next flush that finds the link free for this part (a streamed call's parts take it in turn)
+            if (bytes >= direct_upload_min() && !up_reserved_ && bk_.pinned(src)) {
+                if (up_used_ > up_flushed_) { up_segs_.push_back({up_flushed_, nullptr, up_used_ - up_flushed_}); up_seg_bytes_ += up_used_ - up_flushed_; }
+                up_segs_.push_back({at, (const void*)src, bytes}); up_seg_bytes_ += bytes;
                 up_used_ = up_flushed_ = at + bytes;
                 ++direct_uploads_;
+                flush_uploads_early();
                 return (const T*)(up_dev_ + at);
             }
             par_memcpy(up_host_ + at, src, bytes);
@@ -1478,7 +1614,8 @@ private:
     bool excl_vacuous_ = false;   // Wx > 1, but no template holds a marked pod and no bit has NEED polarity: the simulation-major feasibility kernels run with Wx = 0
     DevTables feas_tables() const { DevTables t = dt_; if (excl_vacuous_) t.Wx = 0; return t; }
     bool one_shot_ = false;
-    UploadGate* gate_ = nullptr; int gate_idx_ = 0; bool gate_passed_ = false;
+    UploadGate* gate_ = nullptr; int gate_idx_ = 0; bool gate_passed_ = false, gate_issue_order_ = false;
+    BK* turn_prev_ = nullptr; bool turn_waited_ = false;
     bool ord_in_slab_ = false; size_t ord_off_ = 0, ord_cap_ = 0;   // order / placed inside the results slab (short lists)
     std::vector<int32_t> opt_host_; const casim_option_query* opt_pending_q_ = nullptr; int opt_pending_s_ = 0; const char* opt_stage_ = nullptr;
     bool opt_in_slab_ = false; size_t opt_off_ = 0; std::vector<char> opt_keep_;   // (the expander's answer as the last fetch() brought it)
@@ -1497,6 +1634,8 @@ private:
     std::vector<int32_t> h_off_;
     bool h_off_fresh_ = false;
     char* up_dev_ = nullptr; char* up_host_ = nullptr; size_t up_cap_ = 0, up_used_ = 0; size_t up_flushed_ = 0; bool up_reserved_ = false;
+    struct UpSeg { size_t at; const void* src /* null: staged bytes of up_host_ */; size_t bytes; };
+    std::vector<UpSeg> up_segs_; size_t up_seg_bytes_ = 0;   // listed for upload, not handed to the backend yet (issue_uploads)
     int direct_uploads_ = 0;   // columns copied straight from the caller's page-locked arrays
     int32_t order_id_base_ = 0; bool fetch_rebased_ = false;
     std::vector<uint64_t> zpol_host_, xpol_host_;

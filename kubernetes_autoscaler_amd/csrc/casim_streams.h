@@ -30,6 +30,23 @@
 
 namespace casim {
 
+// CASIM_CALL_TIMELINE=1: where the wall time of an enter -> return call goes — every worker stamps its milestones (microseconds since the call
+// entered estimate()), printed to stderr when the call returns.  Diagnostics only (tests/tools/enter_return_timeline.py).
+struct CallTimeline {
+    bool on = false;
+    std::chrono::steady_clock::time_point t0;
+    std::mutex mu;
+    std::vector<std::string> lines;
+    void start() { static const bool env = getenv("CASIM_CALL_TIMELINE") && atoi(getenv("CASIM_CALL_TIMELINE")) != 0; on = env; if (on) { t0 = std::chrono::steady_clock::now(); lines.clear(); } }
+    void stamp(int part, const char* what) {
+        if (!on) return;
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        char buf[160]; snprintf(buf, sizeof buf, "[timeline] part %d %-34s %9.1f us", part, what, us);
+        std::lock_guard<std::mutex> l(mu); lines.emplace_back(buf);
+    }
+    void dump() { if (!on) return; for (auto& l : lines) fprintf(stderr, "%s\n", l.c_str()); fprintf(stderr, "[timeline] --\n"); }
+};
+
 template <class BK>
 class StreamedProblemT {
 public:
@@ -66,27 +83,62 @@ public:
         n_groups_ = g->n_groups; n_sims_ = S; has_gid_ = g->global_id != nullptr;
         parts_.clear(); parts_.resize((size_t)K);
         for (int i = 0; i < K; ++i) cut(parts_[(size_t)i], p, g, (int)((int64_t)S * i / K), (int)((int64_t)S * (i + 1) / K));
-        // CASIM_UPLOAD_GATE=1: the parts take the link in turn (casim_pipeline.h: UploadGate).  Built in round 4 and measured neutral then (3.54 vs
-        // 3.56 ms per headline call); with the direct uploads and the shorter kernels of the end of the round the uploads all at once are 9 %
-        // faster (3.27-3.37 against 3.60-3.66 ms, three alternating processes of 100 calls each, profiles/r09h_upload_gate_ab.txt): off by default
+        // The parts take the link IN TURN (round 6): part i's big uploads wait — on the device, by an event — for the last big upload of part
+        // i - 1, and the host only keeps the ISSUE order (UploadGate in issue order: part i enqueues its first copy when part i - 1 has
+        // enqueued its last one and recorded the event; nobody waits for the device).  Part 0's tables arrive first at the full rate of the
+        // link and its kernels run under the uploads behind it; with the copies of four streams sharing the link every part's tables
+        // arrive at the same late moment.  Taking turns by WAITING for each part's copies on the host (round 4's gate, CASIM_UPLOAD_GATE=1
+        // with CASIM_UPLOAD_FIFO=0) measured neutral to 9 % slower (profiles/r09h_upload_gate_ab.txt).  CASIM_UPLOAD_GATE=0 / 1 forces the gate.
         UploadGate gate;
-        static const bool use_gate = getenv("CASIM_UPLOAD_GATE") && atoi(getenv("CASIM_UPLOAD_GATE")) != 0;
+        const bool fifo = pipeline_ && K > 1 && lanes_[0]->bulk_ready();
+        const int gate_env = getenv("CASIM_UPLOAD_GATE") ? atoi(getenv("CASIM_UPLOAD_GATE")) : -1;
+        const bool use_gate = gate_env >= 0 ? gate_env != 0 : fifo;
         auto work = [&](int i) {
             Part& pt = parts_[(size_t)i];
+            tl_.stamp(i, "worker starts");
             lanes_[(size_t)i]->bind();
             pt.prob.reset(new ProblemT<BK>(*lanes_[(size_t)i]));
-            if (use_gate) pt.prob->set_upload_gate(&gate, i);
+            if (use_gate) pt.prob->set_upload_gate(&gate, i, /*issue_order=*/fifo, fifo && i > 0 ? lanes_[(size_t)i - 1] : nullptr);
             pt.prob->set_one_shot(pipeline_q_ != nullptr || pipeline_);
             pt.prob->set_order_id_base(pt.p0);
             pt.rc = pt.prob->init(&pt.pv, &pt.gv, &opts_);
+            tl_.stamp(i, "init returned (tables enqueued)");
             // enter -> return in one call (estimate()): the part's kernels and its expander reduce are enqueued by the part's own worker
             // as soon as ITS tables are up — under the uploads of the parts behind it in the turn order
             if (pipeline_ && pt.rc == CASIM_OK) {
                 if (pipeline_fork_) lanes_[(size_t)i]->wait_mark(primary_);
                 pt.rc = pt.prob->run();
+                tl_.stamp(i, "kernels enqueued");
                 if (pt.rc == CASIM_OK && pipeline_q_) pt.rc = part_query((size_t)i, pipeline_q_);
+                tl_.stamp(i, "expander reduce returned");
+            }
+            // ... and fetched by it as well: a part's results travel while the parts behind it still compute.  The lists of part i start where
+            // the lists of parts 0 .. i - 1 end, so every worker publishes its total as soon as it knows it and waits for its predecessors'
+            // (a joined fetch — totals part by part, then a second round of workers — left a tail of ~0.6 ms of small copies and waits behind
+            // the last kernel of a headline call: profiles/r14d_enter_return_trace.txt)
+            if (pipeline_ && pipeline_out_) {
+                int32_t nnz = 0;
+                if (pt.rc == CASIM_OK) {
+                    const bool winners = opts_.winners_only != 0 && (pipeline_out_->order || pipeline_out_->placed);
+                    pt.rc = winners ? pt.prob->winners_total(&nnz) : pt.prob->csr(&nnz, nullptr);
+                }
+                int64_t base = 0;
+                {
+                    std::unique_lock<std::mutex> l(tot_mu_);
+                    totals_[(size_t)i] = pt.rc == CASIM_OK ? nnz : 0; total_known_[(size_t)i] = 1;   // (a failed part still reports: nobody waits for ever)
+                    tot_cv_.notify_all();
+                    tot_cv_.wait(l, [&] { for (int k = 0; k < i; ++k) if (!total_known_[(size_t)k]) return false; return true; });
+                    for (int k = 0; k < i; ++k) base += totals_[(size_t)k];
+                }
+                tl_.stamp(i, "fetch starts");
+                if (pt.rc == CASIM_OK) {
+                    if (base + nnz > 0x7fffffffll) pt.rc = CASIM_ERR_INVALID;
+                    else fetch_part(i, pipeline_out_, (int32_t)base, (int32_t)(base + nnz));
+                }
+                tl_.stamp(i, "fetch done");
             }
         };
+        if (pipeline_ && pipeline_out_) { totals_.assign((size_t)K, 0); total_known_.assign((size_t)K, 0); }
         each(work, threads);
         for (auto& pt : parts_) if (pt.rc != CASIM_OK) return fail(pt.rc, pt.prob->error().c_str());
         ready_ = true;
@@ -147,7 +199,8 @@ public:
             if (rc != CASIM_OK) return fail(rc, parts_[i].prob->error().c_str());
             base[i + 1] = base[i] + nnz;
         }
-        auto work = [&](int i) { fetch_part(i, out, base[(size_t)i], base[(size_t)i + 1]); };
+        tl_.stamp(-1, "list totals known");
+        auto work = [&](int i) { tl_.stamp(i, "fetch starts"); fetch_part(i, out, base[(size_t)i], base[(size_t)i + 1]); tl_.stamp(i, "fetch done"); };
         each(work, threads);
         for (auto& pt : parts_) if (pt.rc != CASIM_OK) return fail(pt.rc, pt.prob->error().c_str());
         return CASIM_OK;
@@ -210,21 +263,28 @@ public:
     int32_t estimate(const casim_pegs* p, const casim_groups* g, const casim_options* o, casim_results* out, const casim_option_query* q, bool threads) {
         if (q && !q->per_sim) return fail(CASIM_ERR_INVALID, "a streamed batch reduces per simulation (per_sim = 1)");
         // fork once, up front: every lane waits for what the context's stream holds NOW (nothing, for a caller that leaves it alone)
+        tl_.start();
         primary_.bind();
         pipeline_fork_ = !primary_.idle();
         if (pipeline_fork_) { primary_.mark(); ++n_forks_; }
-        pipeline_ = true; pipeline_q_ = q;
-        int32_t rc = init(p, g, o, threads);   // upload, run and reduce every part, part by part (see init)
-        pipeline_ = false; pipeline_q_ = nullptr;
+        // (device outputs of the expander join into the caller's stream below: those calls fetch after the join, the old way)
+        const bool fetch_in_workers = out != nullptr && !(q && (q->dev_key_out || q->dev_packed_out)) && !getenv("CASIM_JOINED_FETCH");
+        pipeline_ = true; pipeline_q_ = q; pipeline_out_ = fetch_in_workers ? out : nullptr;
+        int32_t rc = init(p, g, o, threads);   // upload, run, reduce and fetch every part, part by part (see init)
+        pipeline_ = false; pipeline_q_ = nullptr; pipeline_out_ = nullptr;
         if (rc != CASIM_OK) return rc;
         ran_ = true;
+        if (fetch_in_workers) { tl_.stamp(-1, "parts joined (fetched by their workers)"); tl_.dump(); return CASIM_OK; }
         if (q && (q->dev_key_out || q->dev_packed_out)) {
             if (q->join_stream) { for (size_t i = 0; i < parts_.size(); ++i) { lanes_[i]->mark(); lanes_[i]->make_wait(q->join_stream); } }
             else join();
         }
         // (measured, round 4: fetching every part from its upload worker as soon as the parts in front of it have reported their list lengths —
         // D2H under the uploads of the parts behind — changes nothing: 5.3-5.7 ms either way for the every-list form of the headline call)
+        tl_.stamp(-1, "parts joined");
         if (out) rc = fetch(out, threads);
+        tl_.stamp(-1, "fetch returned");
+        tl_.dump();
         return rc;
     }
 
@@ -278,14 +338,13 @@ private:
         w.peg_lo = w.n_groups ? pt.lo.data() : z32; w.peg_hi = w.n_groups ? pt.hi.data() : z32;
         w.n_sims = s1 - s0; w.sim_offsets = pt.so.data();
     }
+    // the parts' workers: tasks of the process-wide pool (casim_pipeline.h: HostPool), handed out in part order — a worker that waits for the
+    // part in front of it (upload turn, list base) waits for a task that is running
     template <class F>
     void each(F&& f, bool threads) {
         const int K = (int)parts_.size();
         if (!threads || K == 1) { for (int i = 0; i < K; ++i) f(i); return; }
-        std::vector<std::thread> th;
-        for (int i = 1; i < K; ++i) th.emplace_back([&f, i]() { f(i); });
-        f(0);
-        for (auto& t : th) t.join();
+        HostPool::get().run(K, f);
     }
     int32_t fail(int32_t code, const char* msg) { err_ = msg ? msg : ""; return code; }
 
@@ -296,9 +355,12 @@ private:
     int n_groups_ = 0, n_sims_ = 0;
     bool has_gid_ = false, ready_ = false, ran_ = false;
     bool pipeline_ = false, pipeline_fork_ = false; const casim_option_query* pipeline_q_ = nullptr;   // estimate(): parts run from their init workers
+    casim_results* pipeline_out_ = nullptr;                                                              // ... and are fetched by them
+    std::mutex tot_mu_; std::condition_variable tot_cv_; std::vector<int32_t> totals_; std::vector<char> total_known_;   // list totals, part by part
 
     int64_t n_forks_ = 0;
     std::string err_;
+    CallTimeline tl_;
 };
 
 }  // namespace casim

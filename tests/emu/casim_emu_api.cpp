@@ -17,6 +17,15 @@ struct EmuBackend {
     void* alloc(size_t b) { return calloc(1, b); }
     void free(void* p) { ::free(p); }
     void h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
+    void h2d_bulk(void* d, const void* s, size_t n) { memcpy(d, s, n); ++bulk_copies; }
+    void bulk_fence() {}
+    void record_turn_event() { ++turn_records; }
+    void wait_turn_event(EmuBackend& prev) { if (prev.turn_records > 0) ++turn_waits; }
+    int turn_records = 0, turn_waits = 0;
+    int bulk_copies = 0;
+    // CASIM_EMU_FIFO=1: the parts of a streamed call take the link in turn, in issue order (what the device backend does when the context's lanes
+    // share an upload stream); CASIM_EMU_PINNED=1: every column counts as page-locked (the direct-upload path of ProblemT::up)
+    bool bulk_ready() const { const char* e = getenv("CASIM_EMU_FIFO"); return e && atoi(e) != 0; }
     void d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     void zero(void* d, size_t n) { memset(d, 0, n); }
     void fill8(void* d, int v, size_t n) { memset(d, v, n); }
@@ -30,7 +39,7 @@ struct EmuBackend {
     void* stage_if_fits(int which, size_t bytes) { return staging[which & 1].size() >= bytes ? staging[which & 1].data() : nullptr; }
     void* stage(int which, size_t bytes) { if (staging[which & 1].size() < bytes) staging[which & 1].resize(bytes); return staging[which & 1].data(); }
     size_t lds_budget() const { return lds; }
-    bool pinned(const void*) const { return false; }
+    bool pinned(const void*) const { const char* e = getenv("CASIM_EMU_PINNED"); return e && atoi(e) != 0; }
     bool ok() const { return true; }
     const char* error() const { return ""; }
     template <class K, class... A>
@@ -96,6 +105,19 @@ EMU_API int32_t emu_estimate_batch_query(const casim_pegs* pegs, const casim_gro
     if (rc != CASIM_OK) g_err = p.error();
     g_last_front = p.uses_front() ? 1 : (p.uses_strided_lists() ? 2 : 0);
     g_last_lanes = p.fast_lanes() * 100 + p.fast_npt();
+    return rc;
+}
+// ProblemT::init alone, `iters` times (host-side cost of an enter -> return call's table preparation: CASIM_INIT_TIMING=1 prints the stages;
+// the few small kernels init launches run under the emulator, the stage that holds them says so)
+EMU_API int32_t emu_init_only(const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts, int32_t iters) {
+    int32_t rc = CASIM_OK;
+    for (int32_t i = 0; i < iters && rc == CASIM_OK; ++i) {
+        EmuBackend bk;
+        casim::ProblemT<EmuBackend> p(bk);
+        p.set_one_shot(true);
+        rc = p.init(pegs, groups, opts);
+        if (rc != CASIM_OK) g_err = p.error();
+    }
     return rc;
 }
 // 1 when the last emu_estimate_batch_query ran feasibility / offsets / lists / order as ONE launch (front_kernel), 2: front_sim_kernel with fixed-stride lists

@@ -78,3 +78,35 @@ def test_simulations_of_very_different_sizes_and_empty_ones():
         _same(res, whole, f"mixed k {k}")
         assert list(exp["packed"]) == list(wexp["packed"])
     enc.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_parts_that_take_the_link_in_turn_and_columns_sent_from_where_they_lie(seed, monkeypatch):
+    """round 6: the parts of an enter -> return call upload IN TURN when the lanes share an upload queue (UploadGate in issue order: a part's
+    tables enter the queue when the part in front has put all of its own in), page-locked columns are LISTED and go out at the next flush
+    that finds the link free for the part (they used to be copied the moment ProblemT::up saw them), and every part is fetched by its own
+    worker (list bases handed from part to part).  The emulated backend plays a shared queue (CASIM_EMU_FIFO), calls every column
+    page-locked (CASIM_EMU_PINNED) and the test knobs make the small tables travel in many pieces: same results as the uncut batch —
+    int64 and caller-narrowed requests, winners only, chained."""
+    for k, v in (("CASIM_EMU_FIFO", "1"), ("CASIM_EMU_PINNED", "1"), ("CASIM_TEST_UPLOAD_CHUNK", "512"), ("CASIM_TEST_DIRECT_MIN", "256")):
+        monkeypatch.setenv(k, v)
+    n = 3 + seed % 5
+    scs = [_scenario(5200 + 17 * seed + i, rich=(seed % 2 == 1)) for i in range(n)]
+    enc, ts, _ = encode_batch(scs)
+    kinds = KINDS[seed % len(KINDS)]
+    for narrow in (False, True):
+        whole, wexp = run_emu_tables(ts, kinds=kinds, narrow_requests=narrow)
+        for k in (2, 4):
+            res, exp, parts = run_emu_streams(ts, k, kinds=kinds, narrow_requests=narrow)
+            assert parts == min(k, n)
+            _same(res, whole, f"seed {seed} k {k} narrow {narrow}")
+            assert list(exp["best"]) == list(wexp["best"]) and list(exp["packed"]) == list(wexp["packed"])
+    wo, woexp = run_emu_tables(ts, kinds=kinds, winners_only=True)
+    res, exp, _ = run_emu_streams(ts, 3, kinds=kinds, winners_only=True)
+    assert list(res.node_count) == list(wo.node_count) and list(exp["best"]) == list(woexp["best"])
+    nw = int(sum(int(wo.offsets[b + 1] - wo.offsets[b]) for b in woexp["best"] if b >= 0))
+    assert list(res.order[:nw]) == list(wo.order[:nw]) and list(res.placed[:nw]) == list(wo.placed[:nw])
+    ch, _ = run_emu_tables(ts, chain=True)
+    res, _, _ = run_emu_streams(ts, 3, chain=True)
+    _same(res, ch, f"seed {seed} chained")
+    enc.close()
