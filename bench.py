@@ -1103,7 +1103,7 @@ def chained_loop_row(kaa, ctx, workloads, replicas=16, iters=12):
 
 def feasibility_bytes(ts, lean):
     """Algorithmic bytes of ONE feas_stream_kernel launch over the table set (P x Bp + N x Bn + ceil(P x N / 8) with the record
-    sizes of the kernel that runs, DESIGN.md section 17): per PEG the columns a cell needs as the kernel reads them — 4 B per narrowed
+    sizes of the kernel that runs, DESIGN.md section 5): per PEG the columns a cell needs as the kernel reads them — 4 B per narrowed
     request lane, 4 B flags, one 8-byte word per mask kind; per group its 64-byte record; per (group, 64 PEGs) one 8-byte ballot word."""
     d = ts.dims
     lanes = min(d["n_res"], 2 if lean else 4)

@@ -233,7 +233,7 @@ CS_GLOBAL void feas_sim_kernel(DevTables t, uint64_t* CS_RESTRICT bits /*[NG][Wg
 // instructions per (wave, group) — v_and, v_and_or, v_cmp_eq, 2 x v_cmp_ge, 2 x v_writelane; 10 with every term.  grid = ONE dimension,
 // XCD-aware: workgroup ids are dealt round-robin to the 8 XCDs, so the blocks of a simulation take ids that agree mod 8 — its group
 // records are fetched into ONE XCD's L2.
-// Algorithmic bytes: per PEG the columns the cell needs as this kernel reads them — 4 R (narrowed requests) + 4
+// Algorithmic bytes (history: docs/HISTORY.md 17a): per PEG the columns the cell needs as this kernel reads them — 4 R (narrowed requests) + 4
 // (flags) + 8 (tolerations) + 8 (selector) [+ 8 + 8 exclusion words] — per group its 64-byte record, per cell one bit.
 #define CASIM_FEAS_REC_DW 16
 // record (dwords): [0] taint lo  [1] ~label lo  [2] f0 | INT32_MIN gate  [3] f1      (all a lean cell with narrow dictionaries reads)
