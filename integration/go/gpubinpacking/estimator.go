@@ -97,21 +97,21 @@ type RunnerIndex interface {
 // (cluster-autoscaler/simulator/clustersnapshot/scheduling_opts.go:39-63).  In the reference the runner lives inside the snapshot
 // (predicate/predicate_snapshot.go:64) and its lastIndex survives every Estimate of every loop (plugin_runner.go:33-36,138); the
 // orchestrator builds a fresh estimator per node group (orchestrator.go:409-413), so the state is kept per snapshot OUTSIDE the
-// estimators — in prefetch mode and in per-call mode alike.  `real` != nil (the snapshot implements RunnerIndex): every read and write
-// goes to the snapshot's runner.  `real` == nil (a snapshot without the accessors): the shim threads a PRIVATE copy that only its own
+// estimators — in prefetch mode and in per-call mode alike.  `snap` != nil (the snapshot implements RunnerIndex): every read and write
+// goes to the snapshot's runner.  `snap` == nil (a snapshot without the accessors): the shim threads a PRIVATE copy that only its own
 // device calls move — exact as long as every Estimate of the process goes to the device; Routing is then off by default and a group the
 // reference path had to take (CASIM_NG_UNSUPPORTED) leaves the copy where the device left it (INTEGRATION.md 1c).
 type runnerState struct {
 	mu        sync.Mutex
 	lastIndex int
-	real      RunnerIndex
+	snap      RunnerIndex // the snapshot's own runner, when it can be reached
 }
 
 func (r *runnerState) get() int {
 	r.mu.Lock()
 	defer r.mu.Unlock()
-	if r.real != nil {
-		return r.real.RunnerLastIndex()
+	if r.snap != nil {
+		return r.snap.RunnerLastIndex()
 	}
 	return r.lastIndex
 }
@@ -119,15 +119,15 @@ func (r *runnerState) get() int {
 func (r *runnerState) set(v int) {
 	r.mu.Lock()
 	defer r.mu.Unlock()
-	if r.real != nil {
-		r.real.SetRunnerLastIndex(v)
+	if r.snap != nil {
+		r.snap.SetRunnerLastIndex(v)
 		return
 	}
 	r.lastIndex = v
 }
 
 // synced: the snapshot's own runner is read and written (mixing device and reference Estimates is exact).
-func (r *runnerState) synced() bool { return r.real != nil }
+func (r *runnerState) synced() bool { return r.snap != nil }
 
 // Runners holds the runnerStates of ONE EstimatorBuilder (NewEstimatorBuilder creates it; Shared points at the same one).  The
 // autoscaler has one long-lived ClusterSnapshot, so the registry normally holds one entry; it is bounded all the same — round 4 kept a
@@ -165,8 +165,8 @@ func (r *Runners) of(snapshot clustersnapshot.ClusterSnapshot) *runnerState {
 		r.order = r.order[1:]
 	}
 	st = &runnerState{}
-	if real, ok := snapshot.(RunnerIndex); ok {
-		st.real = real
+	if ri, ok := snapshot.(RunnerIndex); ok {
+		st.snap = ri
 	}
 	r.state[snapshot] = st
 	r.order = append(r.order, snapshot)

@@ -107,6 +107,39 @@ EMU_API int32_t emu_estimate_batch_query(const casim_pegs* pegs, const casim_gro
     g_last_lanes = p.fast_lanes() * 100 + p.fast_npt();
     return rc;
 }
+// The host pool (casim_pipeline.h: HostPool) under the patterns the library uses it in, `rounds` times from `callers` threads at once: tasks that wait for
+// the task in front of them (the parts' turn order), each cutting a loop over the pool from inside (a part that stages its tables).  Returns 0, or
+// the number of wrong sums; a deadlock shows as the test's timeout.
+EMU_API int32_t emu_pool_selftest(int32_t rounds, int32_t callers, int32_t tasks) {
+    std::atomic<int> bad{0};
+    auto one_caller = [&](int c) {
+        std::vector<int64_t> data((size_t)1 << 16);
+        for (size_t i = 0; i < data.size(); ++i) data[i] = (int64_t)(i % 97) + c;
+        int64_t want = 0;
+        for (int64_t v : data) want += v;
+        for (int r = 0; r < rounds; ++r) {
+            std::vector<std::atomic<int>> turn((size_t)tasks);
+            for (auto& t : turn) t.store(0);
+            std::vector<int64_t> sums((size_t)tasks, 0);
+            casim::HostPool::get().run(tasks, [&](int i) {
+                if (i > 0) while (turn[(size_t)i - 1].load(std::memory_order_acquire) == 0) std::this_thread::yield();   // the part in front passes its turn
+                int64_t parts[casim::kHostLoopThreads] = {0, 0, 0, 0};
+                casim::par_for(data.size(), 1024, [&](size_t lo, size_t hi, int t) { int64_t a = 0; for (size_t k = lo; k < hi; ++k) a += data[k]; parts[t] += a; });
+                turn[(size_t)i].store(1, std::memory_order_release);
+                casim::par_for(data.size(), 4096, [&](size_t lo, size_t hi, int t) { int64_t a = 0; for (size_t k = lo; k < hi; ++k) a += data[k]; parts[t] += a; });
+                sums[(size_t)i] = parts[0] + parts[1] + parts[2] + parts[3];
+            });
+            for (int i = 0; i < tasks; ++i) if (sums[(size_t)i] != 2 * want) bad.fetch_add(1);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int c = 1; c < callers; ++c) th.emplace_back(one_caller, c);
+    one_caller(0);
+    for (auto& t : th) t.join();
+    return bad.load() + (casim::HostPool::get().workers() < 0 ? 1 : 0);
+}
+EMU_API int32_t emu_pool_workers() { return casim::HostPool::get().workers(); }
+
 // ProblemT::init alone, `iters` times (host-side cost of an enter -> return call's table preparation: CASIM_INIT_TIMING=1 prints the stages;
 // the few small kernels init launches run under the emulator, the stage that holds them says so)
 EMU_API int32_t emu_init_only(const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts, int32_t iters) {
