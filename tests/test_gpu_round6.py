@@ -141,3 +141,23 @@ def test_real_node_allocatables_keep_the_register_packer(ctx):
     assert_matches_oracle(res, run_oracle(sc), "gpu pool with real allocatables")
     print("gpu pool:", [int(x) for x in res.node_count], [int(x) for x in res.pods_scheduled])
     enc.close()
+
+
+@pytest.mark.parametrize("switches", [{}, {"CASIM_UPLOAD_FIFO": "1"}, {"CASIM_JOINED_FETCH": "1"}, {"CASIM_POOL_THREADS": "0"},
+                                      {"CASIM_UPLOAD_FIFO": "1", "CASIM_POOL_THREADS": "1"}],
+                         ids=["defaults", "uploads-in-turn", "joined-fetch", "no-pool", "in-turn-one-worker"])
+def test_enter_return_of_streamed_batches_under_every_switch(switches):
+    """round 6: the parts of a streamed enter -> return call are tasks of the host pool, each fetched by its own worker (list bases handed
+    from part to part), page-locked columns are listed and sent at the next flush, and — as an option — the parts take the link in turn by an
+    event chain.  tests/tools/enter_return_check.py compares 16 cells (tables pageable / page-locked x requests int64 / req32 x 2 / 4 parts x every
+    list / winners only, three calls each) with the unstreamed problem and the oracle, in a process of its own per setting of the switches."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8", **switches)
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "enter_return_check.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    assert info["cells"] == 16, info
