@@ -107,8 +107,6 @@ struct HipBackend {
     // (profiles/r14i_enter_return_matrix.txt) — a part behind the turn event finds its later small copies waiting on the host until its
     // stream has drained, and calls with small tables (PEG rows shared between simulations) only lose the stagger
     bool bulk_ready() const { static const bool on = getenv("CASIM_UPLOAD_FIFO") && atoi(getenv("CASIM_UPLOAD_FIFO")) != 0; return on; }
-    void h2d_bulk(void* d, const void* s, size_t n) { h2d(d, s, n); }
-    void bulk_fence() {}
     void record_turn_event() {
         if (!turn_ev) check(hipEventCreateWithFlags(&turn_ev, hipEventDisableTiming), "hipEventCreate");
         if (turn_ev) check(hipEventRecord(turn_ev, stream), "hipEventRecord");

@@ -7,8 +7,7 @@
 //     void   h2d(void* dst, const void* src, size_t bytes);   // async on the backend's stream
 //     void   d2h(void* dst, const void* src, size_t bytes);
 //     void   zero(void* dst, size_t bytes);
-//     void   h2d_bulk(void* d, const void* s, size_t n); void bulk_fence();   // big table uploads: may travel on a queue the lanes of a context share
-//                                             // (FIFO: the parts of a streamed call arrive in turn order); bulk_fence() makes the own stream wait for them
+//     void   record_turn_event(); void wait_turn_event(BK& prev); bool bulk_ready();   // the parts of a streamed call taking the link in turn (casim_streams.h)
 //     void*  stage(int which, size_t bytes);  // host staging buffer (pinned on the device backend) of >= bytes, owned by the
 //                                             // backend and reused by later calls: 0 = uploads, 1 = fetches
 //     void   sync();
@@ -1487,29 +1486,19 @@ private:
         up_segs_.clear(); up_seg_bytes_ = 0;
     }
     // What is ready to travel and has not been handed to the backend yet: `up_segs_` (in slab order: staged ranges and page-locked columns
-    // of the caller that go out from where they lie) followed by the staged range [up_flushed_, up_used_).  The parts of a streamed call take
-    // the link in turn (set_upload_gate, issue order): the first copy of a part waits on the device for the event the part in front of it
-    // recorded behind its last big copy.  (h2d_bulk / bulk_fence: the backend's hook for big pieces — the same stream on the device backend.)
-    static constexpr size_t kBulkMin = (size_t)1 << 20;
+    // of the caller that go out from where they lie) followed by the staged range [up_flushed_, up_used_).  When the parts of a streamed
+    // call take the link in turn (set_upload_gate, issue order) the first copy of a part waits, on the device, for the event the part in
+    // front of it recorded behind its last big copy.
     void issue_uploads() {
         if (gate_issue_order_ && !gate_passed_ && turn_prev_ && !turn_waited_) { bk_.wait_turn_event(*turn_prev_); turn_waited_ = true; }
-        const size_t tail = up_used_ > up_flushed_ ? up_used_ - up_flushed_ : 0;
-        const bool bulk = up_seg_bytes_ + tail >= kBulkMin;
-        for (const UpSeg& sg : up_segs_) {
-            const void* src = sg.src ? sg.src : (const void*)(up_host_ + sg.at);
-            if (bulk) bk_.h2d_bulk(up_dev_ + sg.at, src, sg.bytes); else bk_.h2d(up_dev_ + sg.at, src, sg.bytes);
-        }
+        for (const UpSeg& sg : up_segs_) bk_.h2d(up_dev_ + sg.at, sg.src ? sg.src : (const void*)(up_host_ + sg.at), sg.bytes);
         up_segs_.clear(); up_seg_bytes_ = 0;
-        if (tail > 0) {
-            if (bulk) bk_.h2d_bulk(up_dev_ + up_flushed_, up_host_ + up_flushed_, tail); else bk_.h2d(up_dev_ + up_flushed_, up_host_ + up_flushed_, tail);
-            up_flushed_ = up_used_;
-        }
+        if (up_used_ > up_flushed_) { bk_.h2d(up_dev_ + up_flushed_, up_host_ + up_flushed_, up_used_ - up_flushed_); up_flushed_ = up_used_; }
     }
     void end_uploads() {
         if (gate_ && !gate_passed_) gate_->wait_turn(gate_idx_);
         if (up_dev_) issue_uploads();
-        bk_.bulk_fence();
-        if (gate_issue_order_) pass_gate();   // (everything of this part is in the queue: the next part's tables line up behind it)
+        if (gate_issue_order_) pass_gate();   // (everything of this part is in its queue: the next part's tables wait for the event behind it)
         up_dev_ = up_host_ = nullptr; up_cap_ = 0;
     }
     // A big batch does not wait for its last column before the first one travels: every kUploadChunk bytes of staged columns go out
@@ -1530,9 +1519,8 @@ private:
     }
     void flush_uploads_all() {   // everything staged so far goes out now (a kernel is about to read it)
         if (gate_ && !gate_passed_) gate_->wait_turn(gate_idx_);
-        if (up_reserved_ || !up_dev_) { bk_.bulk_fence(); return; }
+        if (up_reserved_ || !up_dev_) return;
         issue_uploads();
-        bk_.bulk_fence();
     }
     void flush_uploads_early() {
         if (up_reserved_ || !up_dev_ || up_seg_bytes_ + (up_used_ - up_flushed_) < upload_chunk()) return;

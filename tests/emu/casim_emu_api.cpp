@@ -17,14 +17,11 @@ struct EmuBackend {
     void* alloc(size_t b) { return calloc(1, b); }
     void free(void* p) { ::free(p); }
     void h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
-    void h2d_bulk(void* d, const void* s, size_t n) { memcpy(d, s, n); ++bulk_copies; }
-    void bulk_fence() {}
     void record_turn_event() { ++turn_records; }
     void wait_turn_event(EmuBackend& prev) { if (prev.turn_records > 0) ++turn_waits; }
     int turn_records = 0, turn_waits = 0;
-    int bulk_copies = 0;
-    // CASIM_EMU_FIFO=1: the parts of a streamed call take the link in turn, in issue order (what the device backend does when the context's lanes
-    // share an upload stream); CASIM_EMU_PINNED=1: every column counts as page-locked (the direct-upload path of ProblemT::up)
+    // CASIM_EMU_FIFO=1: the parts of a streamed call take the link in turn, in issue order (the device backend's CASIM_UPLOAD_FIFO=1: an event
+    // chain on the lanes' streams); CASIM_EMU_PINNED=1: every column counts as page-locked (the direct-upload path of ProblemT::up)
     bool bulk_ready() const { const char* e = getenv("CASIM_EMU_FIFO"); return e && atoi(e) != 0; }
     void d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     void zero(void* d, size_t n) { memset(d, 0, n); }
