@@ -106,7 +106,7 @@ struct HipBackend {
     // OFF by default (CASIM_UPLOAD_FIFO=1 turns it on): measured neutral to slower in every cell of tables x requests x parts
     // (profiles/r14i_enter_return_matrix.txt) — a part behind the turn event finds its later small copies waiting on the host until its
     // stream has drained, and calls with small tables (PEG rows shared between simulations) only lose the stagger
-    bool bulk_ready() const { static const bool on = getenv("CASIM_UPLOAD_FIFO") && atoi(getenv("CASIM_UPLOAD_FIFO")) != 0; return on; }
+    bool turns_enabled() const { static const bool on = getenv("CASIM_UPLOAD_FIFO") && atoi(getenv("CASIM_UPLOAD_FIFO")) != 0; return on; }
     void record_turn_event() {
         if (!turn_ev) check(hipEventCreateWithFlags(&turn_ev, hipEventDisableTiming), "hipEventCreate");
         if (turn_ev) check(hipEventRecord(turn_ev, stream), "hipEventRecord");

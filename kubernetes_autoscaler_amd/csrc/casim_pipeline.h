@@ -7,7 +7,7 @@
 //     void   h2d(void* dst, const void* src, size_t bytes);   // async on the backend's stream
 //     void   d2h(void* dst, const void* src, size_t bytes);
 //     void   zero(void* dst, size_t bytes);
-//     void   record_turn_event(); void wait_turn_event(BK& prev); bool bulk_ready();   // the parts of a streamed call taking the link in turn (casim_streams.h)
+//     void   record_turn_event(); void wait_turn_event(BK& prev); bool turns_enabled();   // the parts of a streamed call taking the link in turn (casim_streams.h)
 //     void*  stage(int which, size_t bytes);  // host staging buffer (pinned on the device backend) of >= bytes, owned by the
 //                                             // backend and reused by later calls: 0 = uploads, 1 = fetches
 //     void   sync();
@@ -386,9 +386,9 @@ public:
         dt_.cap_cpu = (dt_.fastpath && g->cap_cpu) ? up(g->cap_cpu, NG) : nullptr; dt_.cap_mem = (dt_.fastpath && g->cap_mem) ? up(g->cap_mem, NG) : nullptr;
         dt_.waste_cpu = g->waste_cpu ? up(g->waste_cpu, NG) : nullptr; dt_.waste_mem = g->waste_mem ? up(g->waste_mem, NG) : nullptr;
 
-        // the parts of a streamed call share the upload queue: this part's table columns enter it NOW, behind the columns of the parts in front
-        // of it, and the next part's follow — nobody holds the turn while it computes its geometry (what is staged later is small and travels
-        // on the part's own stream, where nothing is queued in front of it)
+        // the parts of a streamed call take the link in turn (CASIM_UPLOAD_FIFO=1): this part's table columns are enqueued NOW, behind the event
+        // of the part in front of it, and the next part's follow — nobody holds the turn while it computes its geometry (what is staged later
+        // is small and not ordered)
         if (gate_issue_order_ && gate_ && !gate_passed_) {
             stage.mark("wait for the turn");
             gate_->wait_turn(gate_idx_);
@@ -712,7 +712,7 @@ public:
                 // block; the quotients by scale_requests_kernel further down) — the host pass above was skipped
                 if (dev_gcd) {
                     flush_uploads_all();
-                    if (gate_issue_order_) pass_gate();   // the bulk of this part's tables is IN the queue: the next part's line up behind them
+                    if (gate_issue_order_) pass_gate();   // the bulk of this part's tables is enqueued: the next part's wait for the event behind them
                     const int nb = (int)(G / 2048 < 1 ? 1 : (G / 2048 > 1024 ? 1024 : G / 2048));
                     GcdPartial* d_part = (GcdPartial*)dalloc(sizeof(GcdPartial) * (size_t)nb);
                     GcdPartial* h_part = (GcdPartial*)bk_.stage(1, sizeof(GcdPartial) * (size_t)nb);
@@ -1429,7 +1429,7 @@ public:
     // the lists anyway and says so (last_fetch_rebased), the other fetch paths leave it to the caller
     void set_order_id_base(int32_t b) { order_id_base_ = b; }
     bool last_fetch_rebased() const { return fetch_rebased_; }
-    // before init(): parts of a streamed batch.  issue_order: the parts' big uploads share ONE queue (the backend's bulk path), so a part hands the
+    // before init(): parts of a streamed batch.  issue_order: the parts' big uploads are ordered on the device by an event chain, so a part hands the
     // turn on as soon as its tables are IN the queue — no wait for the device in between
     // `prev`: the backend of the part in front (null for part 0): this part's first big copy waits, on the device, for the event that part recorded
     // behind its last one

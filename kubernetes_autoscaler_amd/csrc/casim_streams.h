@@ -90,7 +90,7 @@ public:
         // arrive at the same late moment.  Taking turns by WAITING for each part's copies on the host (round 4's gate, CASIM_UPLOAD_GATE=1
         // with CASIM_UPLOAD_FIFO=0) measured neutral to 9 % slower (profiles/r09h_upload_gate_ab.txt).  CASIM_UPLOAD_GATE=0 / 1 forces the gate.
         UploadGate gate;
-        const bool fifo = pipeline_ && K > 1 && lanes_[0]->bulk_ready();
+        const bool fifo = pipeline_ && K > 1 && lanes_[0]->turns_enabled();
         const int gate_env = getenv("CASIM_UPLOAD_GATE") ? atoi(getenv("CASIM_UPLOAD_GATE")) : -1;
         const bool use_gate = gate_env >= 0 ? gate_env != 0 : fifo;
         auto work = [&](int i) {

@@ -22,7 +22,7 @@ struct EmuBackend {
     int turn_records = 0, turn_waits = 0;
     // CASIM_EMU_FIFO=1: the parts of a streamed call take the link in turn, in issue order (the device backend's CASIM_UPLOAD_FIFO=1: an event
     // chain on the lanes' streams); CASIM_EMU_PINNED=1: every column counts as page-locked (the direct-upload path of ProblemT::up)
-    bool bulk_ready() const { const char* e = getenv("CASIM_EMU_FIFO"); return e && atoi(e) != 0; }
+    bool turns_enabled() const { const char* e = getenv("CASIM_EMU_FIFO"); return e && atoi(e) != 0; }
     void d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     void zero(void* d, size_t n) { memset(d, 0, n); }
     void fill8(void* d, int v, size_t n) { memset(d, v, n); }

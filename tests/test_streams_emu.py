@@ -82,10 +82,10 @@ def test_simulations_of_very_different_sizes_and_empty_ones():
 
 @pytest.mark.parametrize("seed", range(8))
 def test_parts_that_take_the_link_in_turn_and_columns_sent_from_where_they_lie(seed, monkeypatch):
-    """round 6: the parts of an enter -> return call upload IN TURN when the lanes share an upload queue (UploadGate in issue order: a part's
-    tables enter the queue when the part in front has put all of its own in), page-locked columns are LISTED and go out at the next flush
+    """round 6: the parts of an enter -> return call can upload IN TURN (CASIM_UPLOAD_FIFO=1: UploadGate in issue order + an event chain on the
+    device — a part's tables are enqueued when the part in front has enqueued all of its own), page-locked columns are LISTED and go out at the next flush
     that finds the link free for the part (they used to be copied the moment ProblemT::up saw them), and every part is fetched by its own
-    worker (list bases handed from part to part).  The emulated backend plays a shared queue (CASIM_EMU_FIFO), calls every column
+    worker (list bases handed from part to part).  The emulated backend plays the turn order (CASIM_EMU_FIFO), calls every column
     page-locked (CASIM_EMU_PINNED) and the test knobs make the small tables travel in many pieces: same results as the uncut batch —
     int64 and caller-narrowed requests, winners only, chained."""
     for k, v in (("CASIM_EMU_FIFO", "1"), ("CASIM_EMU_PINNED", "1"), ("CASIM_TEST_UPLOAD_CHUNK", "512"), ("CASIM_TEST_DIRECT_MIN", "256")):
