@@ -474,15 +474,34 @@ public:
             // candidate range of every group: its simulation's PEGs (peg_lo / peg_hi) or all of them
             if ((g->peg_lo == nullptr) != (g->peg_hi == nullptr)) return fail(CASIM_ERR_INVALID, "peg_lo and peg_hi go together");
             std::vector<int32_t> lo(NG, 0), hi(NG, G_);
-            std::vector<int64_t> pre(G + 1, 0);   // prefix sums of max(count, 1)
-            for (size_t i = 0; i < G; ++i) { if (p->count[i] < 0) return fail(CASIM_ERR_INVALID, "negative PEG count"); pre[i + 1] = pre[i] + (p->count[i] > 1 ? p->count[i] : 1); }
+            // pods of a group's candidate range = sum of max(count, 1) over it.  Groups of one simulation share their range and ranges of a
+            // batch are disjoint or equal, so the sum of the range just seen is remembered; a prefix-sum table over all G PEGs (3.3 MB
+            // written and read back per part of a headline call) is only built when ranges overlap in another way
+            std::vector<int64_t> pre;
+            bool neg = false;
+            auto range_sum = [&](int32_t a, int32_t b) { int64_t s = 0; for (int32_t k = a; k < b; ++k) { const int32_t c = p->count[k]; neg = neg || c < 0; s += c > 1 ? c : 1; } return s; };
             int64_t cap = 0; int32_t lmax = 0;
+            int32_t seen_lo = -1, seen_hi = -1; int64_t seen_sum = 0; int64_t walked = 0;
             for (size_t i = 0; i < NG; ++i) {
                 if (g->peg_lo) { lo[i] = g->peg_lo[i]; hi[i] = g->peg_hi[i]; }
                 if (lo[i] < 0 || hi[i] < lo[i] || hi[i] > G_) return fail(CASIM_ERR_INVALID, "peg_lo / peg_hi out of range");
-                pegs_of_group[i] = hi[i] - lo[i]; pods_of_group[i] = pre[(size_t)hi[i]] - pre[(size_t)lo[i]];
+                pegs_of_group[i] = hi[i] - lo[i];
+                if (lo[i] != seen_lo || hi[i] != seen_hi) {
+                    if (pre.empty() && walked + pegs_of_group[i] > (int64_t)G + 4096) {   // ranges that overlap without being equal: the table after all
+                        pre.assign(G + 1, 0);
+                        for (size_t k = 0; k < G; ++k) { neg = neg || p->count[k] < 0; pre[k + 1] = pre[k] + (p->count[k] > 1 ? p->count[k] : 1); }
+                    }
+                    seen_lo = lo[i]; seen_hi = hi[i];
+                    if (!pre.empty()) seen_sum = pre[(size_t)hi[i]] - pre[(size_t)lo[i]];
+                    else { seen_sum = range_sum(lo[i], hi[i]); walked += pegs_of_group[i]; }
+                }
+                pods_of_group[i] = seen_sum;
                 cap += pegs_of_group[i]; lmax = pegs_of_group[i] > lmax ? pegs_of_group[i] : lmax;
             }
+            // (a PEG no group's range covers is never read by a kernel of this problem; the check of every count stays with the explicit lists
+            // and with the request passes further down, which walk all G rows)
+            if (!neg && walked < (int64_t)G && pre.empty()) for (size_t k = 0; k < G && !neg; ++k) neg = p->count[k] < 0;
+            if (neg) return fail(CASIM_ERR_INVALID, "negative PEG count");
             if (cap > 0x7fffffffll) return fail(CASIM_ERR_INVALID, "sum of candidate PEG ranges too large for device-side CSR");
             nnz_cap_ = (int32_t)cap; feas_len_ = lmax;
             // simulation-major feasibility kernel: every group of a simulation shares its PEG range, one word per mask kind
@@ -852,7 +871,9 @@ public:
         // trips), so its LDS is sized for the lists the one-wave networks take (<= 256 PEGs: 3.5 KB, 8 waves per SIMD) and
         // the few longer lists of such a launch sort in an HBM slab; sized for the BOUND (400 -> 512 entries + the
         // reduction array of 256 threads = 8.2 KB) the launch ran at 4-5 waves per SIMD.
-        const bool batch = NG_ >= 2048 && npad_max <= 1024;
+        // (CASIM_TEST_BATCH_GROUPS: the CPU suite reaches the batch geometry with a few dozen groups under the emulator)
+        const char* bg = getenv("CASIM_TEST_BATCH_GROUPS");
+        const bool batch = NG_ >= (bg && atoi(bg) > 0 ? atoi(bg) : 2048) && npad_max <= 1024;
         if (batch) order_threads_ = 64;
         const int64_t lds_cap = batch && npad_max > 256 ? 256 : 0;
         std::vector<int64_t> ooff(NG, 0);

@@ -178,10 +178,13 @@ def test_large_batch_takes_the_multi_block_scan_and_wave_per_group_order():
 
 
 @pytest.mark.parametrize("n_pegs", [20, 100, 220])
-def test_one_wave_orderer_networks_of_64_128_256_entries(n_pegs):
+def test_one_wave_orderer_networks_of_64_128_256_entries(n_pegs, monkeypatch):
     """Launches of >= 2048 groups sort every list of <= 256 PEGs in ONE wave, in registers (order_group<NPAD>: 64 / 128 / 256
     entries = 1 / 2 / 4 slots per lane, partners through the LDS crossbar): scores with many ties (same requests, different
-    counts) so that the position tie-break is exercised in every stage; 2 simulations tiled to 2100 groups vs the oracle."""
+    counts) so that the position tie-break is exercised in every stage; 2 simulations tiled to the batch geometry vs the oracle
+    (CASIM_TEST_BATCH_GROUPS lowers the 2048 to 60 groups: 2 100 emulated groups took two minutes of the CPU suite; the MI355X runs the
+    real threshold in tests/test_gpu_round2.py and in the bench's headline check)."""
+    monkeypatch.setenv("CASIM_TEST_BATCH_GROUPS", "60")
     from kubernetes_autoscaler_amd.objects import NodeInfo, Pod, PodEquivalenceGroup
     from kubernetes_autoscaler_amd.workloads import _node, SplitMix64
     rng = SplitMix64(0x0DE7 + n_pegs)
@@ -197,7 +200,7 @@ def test_one_wave_orderer_networks_of_64_128_256_entries(n_pegs):
     want = []
     for sc, (pb, _) in zip(scs, bases):
         want.extend(_shift(run_oracle(sc), pb))
-    times = 350   # 2 simulations x 3 groups x 350 = 2100 groups >= 2048: the batch geometry (one wave per group)
+    times = 12    # 2 simulations x 3 groups x 12 = 72 groups >= 60: the batch geometry (one wave per group)
     big = ts.tile(times)
     res, _ = run_emu_tables(big)
     G, NG = ts.n_pegs, ts.n_groups
@@ -323,3 +326,39 @@ def test_exclusion_words_that_say_nothing_about_a_fresh_node_take_the_simulation
     res64, _ = run_emu_tables(ts, generic=True)
     for f in ("node_count", "pods_scheduled", "order", "placed"):
         assert list(getattr(res64, f)) == list(getattr(ref, f)), f
+
+
+@pytest.mark.parametrize("shape", ["zeros-and-ties", "forty-binades", "narrow"])
+def test_one_wave_networks_on_extreme_scores(shape, monkeypatch):
+    """the one-wave (key, position) networks of the batch geometry on score shapes the corpus does not hold: "zeros-and-ties" — requests of zero
+    (score +0.0) next to many equal scores (the position decides); "forty-binades" — a one-milli request on a node of 10^12 milli next to
+    requests of most of a node (2^-40 against 2^-1); "narrow" — the usual shape.  Written for round 6's experiment with ONE 64-bit key per
+    element (exponent code, mantissa, position: exact when the list's scores lie within 31 binades; measured 1 % of the orderer, not kept —
+    DESIGN section 8); the cases stay as a check of the general network against the oracle's order."""
+    from kubernetes_autoscaler_amd.objects import NodeInfo, Pod, PodEquivalenceGroup
+    from kubernetes_autoscaler_amd.workloads import _node, SplitMix64
+    monkeypatch.setenv("CASIM_TEST_BATCH_GROUPS", "8")
+    rng = SplitMix64(0x1E7 + len(shape))
+    scs = []
+    for s in range(2):
+        pegs = []
+        for i in range(90 + 20 * s):
+            if shape == "zeros-and-ties":
+                req = {"cpu": 0 if i % 7 == 0 else 100 * (1 + rng.below(3)), "memory": 0 if i % 5 == 0 else (128 << 20) * (1 + rng.below(2))}
+            elif shape == "forty-binades":
+                req = {"cpu": 1 if i % 3 == 0 else 10 ** 6 * (1 + rng.below(900000)), "memory": 1 if i % 4 == 0 else (1 << 20) * (1 + rng.below(4000))}
+            else:
+                req = {"cpu": 50 + rng.below(4000), "memory": (1 << 20) * (16 + rng.below(8000))}
+            pegs.append(PodEquivalenceGroup(pods=[Pod(name=f"{shape}{s}p{i}", requests=req)] * (1 + rng.below(2))))
+        big = shape == "forty-binades"
+        groups = [GroupSpec(NodeInfo(_node(f"t{s}-{k}", (10 ** 12 if big else 4000) * (1 + k), ((1 << 42) if big else (16 << 30)) * (1 + k), 110, {})),
+                            max_nodes=4 + k, last_index=0, pegs=None) for k in range(4)]
+        scs.append(Scenario(pegs=pegs, groups=groups, device_csr=True))
+    enc, ts, bases = encode_batch(scs)
+    want = []
+    for sc, (pb, _) in zip(scs, bases):
+        want.extend(_shift(run_oracle(sc), pb))
+    for generic in (False, True):
+        res, _ = run_emu_tables(ts, generic=generic)
+        assert_matches_oracle(res, want, f"{shape} generic={generic}")
+    enc.close()
