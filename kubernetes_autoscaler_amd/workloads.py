@@ -338,6 +338,49 @@ def fuzz(seed: int, max_groups: int = 4, max_pegs: int = 12, rich: bool = True) 
     return Workload(f"fuzz{seed}", pegs, groups, existing)
 
 
+def fuzz_lean(seed: int, max_groups: int = 5, max_pegs: int = 16) -> Workload:
+    """Small estimates of the shape the wide packer takes (csrc/casim_pack_wide.h: an estimate per lane): cpu + memory requests (zero ones
+    among them), taints / tolerations / selectors, DaemonSet pods on the template, unschedulable templates next to pods that tolerate
+    everything, pod limits of 1 / 3 / 10 / 110, limiter values of every sign — and nothing that needs exclusion words, no PEG of more
+    than 255 pods, no group whose node bound exceeds 64."""
+    rng = SplitMix64(0x1EA70000 + seed)
+    n_groups = 1 + rng.below(max_groups)
+    n_pegs = 1 + rng.below(max_pegs)
+    counts = [rng.pick([1, 1, 1, 2, 3, 7, 20, 25, 64, 130, 255]) for _ in range(n_pegs)]
+    few = sum(max(c, 1) for c in counts) <= 64
+    groups = []
+    for gi in range(n_groups):
+        cpu = rng.pick([1000, 2000, 4000, 8000, 16000])
+        mem = rng.pick([1, 2, 8, 64]) * GiB
+        labels = {LABEL_ZONE: f"zone-{rng.below(2)}"} if rng.chance(3, 4) else {}
+        for k in rng.sample(LABEL_KEYS[:4], rng.below(4)):
+            labels[k] = f"v{rng.below(2)}"
+        taints = [Taint(k, f"t{rng.below(2)}", rng.pick(["NoSchedule", "NoExecute", "PreferNoSchedule"])) for k in rng.sample(TAINT_KEYS[:3], rng.below(3))]
+        node = _node(f"ln{seed}-ng{gi}", cpu, mem, rng.pick([1, 3, 10, 110]), labels, taints)
+        if rng.chance(1, 8):
+            node.unschedulable = True
+        pre = []
+        if rng.chance(1, 3):
+            pre.append(Pod(name=f"ds{gi}", namespace="kube-system", labels={"app": "ds"}, requests={"cpu": rng.pick([100, 900]), "memory": 64 * MiB}))
+        limits = [1, 2, 3, 7, 19, 40, 50, 64, -1] + ([0, 0] if few else [])
+        groups.append(GroupPlan(NodeInfo(node, pre), max_nodes=rng.pick(limits), last_index=rng.pick([0, 1, 2, 5, 9, 70])))
+    pegs = []
+    for i in range(n_pegs):
+        cpu = rng.pick([0, 50, 100, 250, 500, 1000, 1500, 3000])
+        mem = rng.pick([0, 64 * MiB, 256 * MiB, 1 * GiB, 3 * GiB])
+        kw = {}
+        if rng.chance(1, 2):
+            kw["tolerations"] = [Toleration(key=k, operator=rng.pick(["Exists", "Equal", ""]), value=f"t{rng.below(2)}",
+                                            effect=rng.pick(["", "NoSchedule", "NoExecute"])) for k in rng.sample(TAINT_KEYS[:3], 1 + rng.below(3))]
+            if rng.chance(1, 3):
+                kw["tolerations"].append(Toleration(operator="Exists"))  # tolerates everything, node.kubernetes.io/unschedulable included
+        if rng.chance(1, 4):
+            kw["node_selector"] = {k: f"v{rng.below(2)}" for k in rng.sample(LABEL_KEYS[:4], 1)}
+        pegs.append(_peg(f"ln{seed}-peg{i}", cpu, mem, counts[i], labels={"app": f"app{i}"}, **kw))
+    existing = [NodeInfo(_node(f"ln{seed}-old{i}", 1000, 1 * GiB, 10, {LABEL_ZONE: f"zone-{rng.below(2)}"})) for i in range(rng.below(4))]
+    return Workload(f"lean{seed}", pegs, groups, existing)
+
+
 def fuzz_singleton_runs(seed: int, max_groups: int = 3) -> Workload:
     """Runs of ADJACENT identical controller-less pods — one PodEquivalenceGroup each (equivalence/groups.go:69-73; the shape
     of BenchmarkRunOnceScaleUp) — between ordinary PEGs, against templates with limits of every sign, existing nodes, entry

@@ -422,11 +422,12 @@ def encode_batch(scenarios: Sequence[Scenario]):
     bases, lo, hi, so = [], [], [], [0]
     pb = gb = 0
     for sc in scenarios:
-        assert sc.device_csr and not sc.existing
+        # (nodes already in the cluster only shift list positions here — the rotation origin of a2 — : their pods, if any, would be shared by the batch)
+        assert sc.device_csr and not any(info.pods for info in sc.existing)
         for pg in sc.pegs:
             enc.add_peg(pg)
         for g in sc.groups:
-            enc.add_group(g.template, max_nodes=g.max_nodes, existing_nodes=0, last_index=g.last_index, pegs=None)
+            enc.add_group(g.template, max_nodes=g.max_nodes, existing_nodes=len(sc.existing), last_index=g.last_index, pegs=None)
             lo.append(pb); hi.append(pb + len(sc.pegs))
         bases.append((pb, gb))
         pb += len(sc.pegs); gb += len(sc.groups)
