@@ -762,7 +762,7 @@ int32_t casim_problem_info(casim_problem* p, int32_t info_out[8]) {
     info_out[4] = p->sp ? (int32_t)p->sp->n_parts() : 1;
     info_out[5] = p->sp ? (int32_t)(p->sp->forks() & 0x7fffffff) : 0;   // forks from the context's stream so far (diagnostic)
     info_out[6] = p->ctx ? (int32_t)p->ctx->parked.size() : 0;
-    info_out[7] = (p->prob->uses_front() ? 1 : 0) | (p->prob->uses_rank_once() ? 2 : 0) | (p->prob->wide_packer() ? 4 : 0);
+    info_out[7] = (p->prob->uses_front() ? 1 : 0) | (p->prob->uses_rank_once() ? 2 : 0);
     return CASIM_OK;
 }
 int32_t casim_problem_set_group_result(casim_problem* p, int32_t ng, const casim_cluster_estimate_result* r) {

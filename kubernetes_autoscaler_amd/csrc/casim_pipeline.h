@@ -40,7 +40,6 @@
 #include <vector>
 
 #include "casim_kernels.h"
-#include "casim_pack_wide.h"
 
 namespace casim {
 
@@ -454,7 +453,6 @@ public:
         dt_.lists_from_feas = csr_on_device_ ? 1 : 0;
         std::vector<int64_t> pods_of_group(NG, 0);  // sum of max(count, 1) over the group's PEGs (node bound)
         std::vector<int32_t> pegs_of_group(NG, 0);
-        int32_t count_max = 0;   // largest PEG any group lists (the wide packer walks the pods of a PEG one by one)
         if (!csr_on_device_) {
             if (NG > 0 && g->peg_offsets[0] != 0) return fail(CASIM_ERR_INVALID, "peg_offsets[0] != 0");
             nnz_cap_ = NG > 0 ? g->peg_offsets[NG] : 0;
@@ -467,7 +465,6 @@ public:
                     if (pg < 0 || pg >= G_) return fail(CASIM_ERR_INVALID, "peg_index out of range");
                     if (p->count[pg] < 0) return fail(CASIM_ERR_INVALID, "negative PEG count");
                     pods_of_group[i] += p->count[pg] > 1 ? p->count[pg] : 1;
-                    count_max = p->count[pg] > count_max ? p->count[pg] : count_max;
                 }
             }
             h_off_.assign(g->peg_offsets, g->peg_offsets + NG + 1);
@@ -482,7 +479,7 @@ public:
             // written and read back per part of a headline call) is only built when ranges overlap in another way
             std::vector<int64_t> pre;
             bool neg = false;
-            auto range_sum = [&](int32_t a, int32_t b) { int64_t s = 0; for (int32_t k = a; k < b; ++k) { const int32_t c = p->count[k]; neg = neg || c < 0; s += c > 1 ? c : 1; count_max = c > count_max ? c : count_max; } return s; };
+            auto range_sum = [&](int32_t a, int32_t b) { int64_t s = 0; for (int32_t k = a; k < b; ++k) { const int32_t c = p->count[k]; neg = neg || c < 0; s += c > 1 ? c : 1; } return s; };
             int64_t cap = 0; int32_t lmax = 0;
             int32_t seen_lo = -1, seen_hi = -1; int64_t seen_sum = 0; int64_t walked = 0;
             for (size_t i = 0; i < NG; ++i) {
@@ -492,7 +489,7 @@ public:
                 if (lo[i] != seen_lo || hi[i] != seen_hi) {
                     if (pre.empty() && walked + pegs_of_group[i] > (int64_t)G + 4096) {   // ranges that overlap without being equal: the table after all
                         pre.assign(G + 1, 0);
-                        for (size_t k = 0; k < G; ++k) { neg = neg || p->count[k] < 0; pre[k + 1] = pre[k] + (p->count[k] > 1 ? p->count[k] : 1); count_max = p->count[k] > count_max ? p->count[k] : count_max; }
+                        for (size_t k = 0; k < G; ++k) { neg = neg || p->count[k] < 0; pre[k + 1] = pre[k] + (p->count[k] > 1 ? p->count[k] : 1); }
                     }
                     seen_lo = lo[i]; seen_hi = hi[i];
                     if (!pre.empty()) seen_sum = pre[(size_t)hi[i]] - pre[(size_t)lo[i]];
@@ -632,11 +629,9 @@ public:
         std::vector<int32_t> cap(NG);
         std::vector<int64_t> soff(NG);
         int64_t total = 0, worst = 0;
-        int64_t bound_max = 1;   // largest node bound of a group before rounding (the wide packer's LDS slots per estimate)
         for (size_t i = 0; i < NG; ++i) {
             int64_t n = g->max_nodes[i] > 0 ? (int64_t)g->max_nodes[i] : (g->max_nodes[i] < 0 ? 0 : pods_of_group[i]);
             if (g->max_nodes[i] > 0 && pods_of_group[i] < n) n = pods_of_group[i];  // never more nodes than pods (+ empty ones)
-            bound_max = n > bound_max ? n : bound_max;
             n = round_up64(n > 0 ? n : 1);  // both terms bound the nodes ever added (limiter grants / one node per pod)
             if (n > 0x3fffffffll) return fail(CASIM_ERR_INVALID, "node bound too large");
             cap[i] = (int32_t)n;
@@ -846,22 +841,6 @@ public:
             }
             if (fast_npt_ == 0) fast_retry_ = false;
             else bk_.prepare_pack_fast(pack_build_, fast_i64_ ? 8 : fast_r_, fast_npt_, fast_wx_);   // (the instantiation's self-check, first use only: here, not inside the first launch)
-            // the wide packer (casim_pack_wide.h: an estimate per LANE) takes the batches of many small estimates that the lean register
-            // packer would: narrowed lanes, no exclusion state, <= 64 nodes and short PEGs.  CASIM_WIDE_MIN_GROUPS: groups from which a
-            // launch fills enough waves to pay (tests reach the kernel with a few dozen); CASIM_NO_WIDE: A/B switch
-            wide_ = false;
-            {
-                const char* wm = getenv("CASIM_WIDE_MIN_GROUPS");
-                const long wide_min = wm ? atol(wm) : (long)kWideMinGroups;
-                wide_ = fast_npt_ == 1 && !fast_i64_ && fast_wx_ == 0 && fast_r_ == 2 && R <= 2 && n_sims_ >= 2 && (long)NG >= wide_min &&
-                        count_max <= kWideMaxCount && bound_max <= kWideMaxNodes && !(o && o->node_pods) && !getenv("CASIM_NO_WIDE") &&
-                        casim_wide_smem((int32_t)bound_max) <= bk_.lds_budget();
-                if (getenv("CASIM_WIDE_DEBUG")) fprintf(stderr, "[wide] %d: npt %d i64 %d wx %d r %d R %d sims %d NG %zu cmax %d bound %lld\n", (int)wide_, fast_npt_, (int)fast_i64_, fast_wx_, fast_r_, (int)R, (int)n_sims_, NG, (int)count_max, (long long)bound_max);
-                if (wide_) {
-                    ws_.fresh32 = fs_.fresh32; ws_.scale = fs_.scale; ws_.perm = nullptr;
-                    ws_.cap = (int32_t)bound_max; ws_.n_slots = (int32_t)NG;
-                }
-            }
         }
         ps_.node_cap = up(cap.data(), NG);
         if (o && o->node_pods) {   // pods per simulated node (estimationAnalyserFunc's newNodesWithPods)
@@ -1105,10 +1084,6 @@ public:
         return h;
     }
     int32_t run_pack_pass(const DevTables& dt_) {   // (one launch set of the packer over the groups `dt_` lets through)
-        if (wide_ && !dt_.chain_redo) {   // an estimate per lane (casim_pack_wide.h); the fix-up passes of a chain re-estimate a few groups: a wave each
-            bk_.launch(pack_wide_kernel, (NG_ + 63) / 64, 1, 64, casim_wide_smem(ws_.cap), dt_, dr_, ws_);
-            return CASIM_OK;
-        }
         if (fast_npt_ > 0) {
             // register-resident int32 packer: the instantiation (lanes, node slots per lane, exclusion words) is picked by the
             // backend — the product compiles these kernels in their own translation unit (casim_pack_tu.hip)
@@ -1499,7 +1474,6 @@ public:
     bool uses_rank_once() const { return strided_ && rank_once_ && !strided_one_launch_; }
     bool pack_in_lds() const { return pack_lds_; }
     int fast_npt() const { return fast_npt_; }
-    bool wide_packer() const { return wide_; }
     int fast_lanes() const { return fast_npt_ > 0 ? (fast_i64_ ? 8 : fast_r_) : 0; }   // > 0: the register-resident packer handles this batch (2 / 4 int32 lanes; 8 = two int64 lanes)
     static constexpr int kOrderThreads = 256;
 
@@ -1625,8 +1599,6 @@ private:
     BK& bk_;
     DevTables dt_; DevResults dr_; PackScratch ps_; OrderScratch os_ = {nullptr, nullptr, nullptr}; FastScratch fs_ = {nullptr, nullptr, nullptr, nullptr};
     int G_ = 0, NG_ = 0, Wg_ = 0, fast_npt_ = 0, fast_r_ = 0;
-    bool wide_ = false;      // the packer of this problem is pack_wide_kernel (an estimate per lane)
-    WideScratch ws_{};
     int32_t nnz_cap_ = 0;
     bool csr_on_device_ = false, pack_lds_ = true, order_lds_ = true, ready_ = false, ran_ = false;
     int fast_wx_ = 0;
@@ -1667,7 +1639,6 @@ private:
     int32_t* d_coff_ = nullptr; int32_t* d_corder_ = nullptr; int32_t* d_cplaced_ = nullptr;   // ... compacted at fetch time
     uint64_t* d_ticket_ = nullptr; uint32_t front_epoch_ = 0;
     static constexpr size_t kFrontMaxGroups = 1024;
-    static constexpr size_t kWideMinGroups = 4096;          // groups from which the wide packer's launch fills 64 waves
     static constexpr size_t kDevGcdMin = (size_t)1 << 17;   // request values from which the gcd / int32 pass runs on the device
     std::vector<int32_t> h_off_;
     bool h_off_fresh_ = false;

@@ -339,7 +339,7 @@ def fuzz(seed: int, max_groups: int = 4, max_pegs: int = 12, rich: bool = True) 
 
 
 def fuzz_lean(seed: int, max_groups: int = 5, max_pegs: int = 16) -> Workload:
-    """Small estimates of the shape the wide packer takes (csrc/casim_pack_wide.h: an estimate per lane): cpu + memory requests (zero ones
+    """Small estimates of the shape the lean register packer takes in a batch (pack_fast_kernel<2, 1, 0>): cpu + memory requests (zero ones
     among them), taints / tolerations / selectors, DaemonSet pods on the template, unschedulable templates next to pods that tolerate
     everything, pod limits of 1 / 3 / 10 / 110, limiter values of every sign — and nothing that needs exclusion words, no PEG of more
     than 255 pods, no group whose node bound exceeds 64."""

@@ -57,7 +57,7 @@ thread_local std::string g_err;
 #define EMU_API __attribute__((visibility("default")))
 extern "C" {
 
-static int32_t g_last_front = 0, g_last_lanes = 0, g_last_wide = 0;
+static int32_t g_last_front = 0, g_last_lanes = 0;
 EMU_API const char* emu_last_error() { return g_err.c_str(); }
 
 // lds_budget_bytes <= 0 keeps the default (160 KiB); a tiny value forces the HBM-scratch variants.
@@ -77,7 +77,6 @@ EMU_API int32_t emu_estimate_batch(const casim_pegs* pegs, const casim_groups* g
     if (rc != CASIM_OK) g_err = p.error();
     g_last_front = p.uses_front() ? 1 : (p.uses_strided_lists() ? 2 : 0);
     g_last_lanes = p.fast_lanes() * 100 + p.fast_npt();
-    g_last_wide = p.wide_packer() ? 1 : 0;
     return rc;
 }
 
@@ -103,7 +102,6 @@ EMU_API int32_t emu_estimate_batch_query(const casim_pegs* pegs, const casim_gro
     if (rc != CASIM_OK) g_err = p.error();
     g_last_front = p.uses_front() ? 1 : (p.uses_strided_lists() ? 2 : 0);
     g_last_lanes = p.fast_lanes() * 100 + p.fast_npt();
-    g_last_wide = p.wide_packer() ? 1 : 0;
     return rc;
 }
 // The host pool (casim_pipeline.h: HostPool) under the patterns the library uses it in, `rounds` times from `callers` threads at once: tasks that wait for
@@ -156,8 +154,6 @@ EMU_API int32_t emu_init_only(const casim_pegs* pegs, const casim_groups* groups
 EMU_API int32_t emu_last_front() { return g_last_front; }
 // packer of the last emu_estimate_batch(_query): lanes * 100 + node slots per lane (lanes 2 / 4: int32 register store, 8: two int64 lanes, 0: LDS store)
 EMU_API int32_t emu_last_packer() { return g_last_lanes; }
-// 1 = the last batch call's packer was pack_wide_kernel (an estimate per lane: casim_pack_wide.h)
-EMU_API int32_t emu_last_wide() { return g_last_wide; }
 
 // The batch cut into sub-batches on the lanes of one context (casim_streams.h; the emulator runs the parts one after the other):
 // how casim_options.n_streams cuts the tables and puts the results back together.  parts_out: how many parts ran (1 = not cut).

@@ -161,3 +161,29 @@ def test_enter_return_of_streamed_batches_under_every_switch(switches):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     info = json.loads(out.stdout.strip().splitlines()[-1])
     assert info["cells"] == 16, info
+
+
+@pytest.mark.parametrize("fastpath", [False, True])
+def test_batches_of_small_estimates_on_the_device(ctx, fastpath):
+    """workloads.fuzz_lean (tests/test_lean_batches_emu.py): nodes already in the cluster, unschedulable templates next to pods that tolerate
+    everything, every limiter sign, PEGs of 1 .. 255 pods — 40 batches of 2 - 6 simulations each, unchained and chained, one of them tiled to
+    3 000 groups (the batch geometry of the headline: one-wave orderer, simulation-major feasibility, four lanes)."""
+    from harness import encode_batch, run_gpu_tables
+    from test_lean_batches_emu import _want, lean_batch
+    for seed in range(40):
+        scs = lean_batch(2000 + seed + (500 if fastpath else 0), fastpath)
+        enc, ts, bases = encode_batch(scs)
+        res, _ = run_gpu_tables(ts, ctx, fastpath=fastpath)
+        assert_matches_oracle(res, _want(scs, bases), f"lean batch {seed} fastpath {fastpath}")
+        if not fastpath:
+            res, _ = run_gpu_tables(ts, ctx, chain=True)
+            assert_matches_oracle(res, _want(scs, bases, chain=True), f"lean batch {seed}, chained")
+        if seed == 0:
+            n_groups = int(ts.sim_offsets[-1])
+            tiles = 3000 // n_groups + 1
+            big = ts.tile(tiles)
+            res, _ = run_gpu_tables(big, ctx, fastpath=fastpath, n_streams=4)
+            small, _ = run_gpu_tables(ts, ctx, fastpath=fastpath)
+            for name in ("node_count", "pods_scheduled", "nodes_added", "limiter_nodes", "last_index_out"):
+                assert list(getattr(res, name)) == list(getattr(small, name)) * tiles, name
+        enc.close()
