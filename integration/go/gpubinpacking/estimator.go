@@ -298,7 +298,7 @@ func (g *gpuEstimator) Estimate(pegs []estimator.PodEquivalenceGroup, tmpl *fram
 	pin.Pin(&placed[0])
 	res := C.casim_results{node_count: &scal[0], pods_scheduled: &scal[1], nodes_added: &scal[2], limiter_nodes: &scal[3],
 		last_index_out: &scal[4], status: &scal[5], req_cpu_sum: &sums[0], req_mem_sum: &sums[1], order: &order[0], placed: &placed[0]}
-	nodeCount, nodesAdded, lastIndexOut, status := &scal[0], &scal[2], &scal[4], &scal[5]
+	nodeCountOut, nodesAdded, lastIndexOut, status := &scal[0], &scal[2], &scal[4], &scal[5]
 	var opts C.casim_options
 	if g.fastpath {
 		opts.fastpath = 1
@@ -306,7 +306,7 @@ func (g *gpuEstimator) Estimate(pegs []estimator.PodEquivalenceGroup, tmpl *fram
 	// estimationAnalyserFunc wants newNodesWithPods (binpacking_estimator.go:157-159): the device keeps the pods per simulated node
 	// (casim_options.node_pods); room for the limiter's cap, or for one node per pod when the limiter sets none
 	var nodePods []C.int32_t
-	nodePodsOff := make([]C.int64_t, 2)
+	nodePodsOff := make([]C.int32_t, 2) // casim_results.node_pods_offsets is int32_t* ([NG + 1])
 	if g.analyser != nil {
 		room := maxNodes
 		if room <= 0 {
@@ -329,9 +329,9 @@ func (g *gpuEstimator) Estimate(pegs []estimator.PodEquivalenceGroup, tmpl *fram
 	}
 	g.setLastIndex(int(*lastIndexOut)) // the runner's lastIndex persists across Estimates (plugin_runner.go:33-36,138)
 	if g.analyser != nil {
-		g.analyse(ng, tmpl, nodePods[:int(nodePodsOff[1]-nodePodsOff[0])], int(*nodeCount), int(*nodesAdded))
+		g.analyse(ng, tmpl, nodePods[:int(nodePodsOff[1]-nodePodsOff[0])], int(*nodeCountOut), int(*nodesAdded))
 	}
-	return int(*nodeCount), prefixPods(pegs, order[:n], placed[:n])
+	return int(*nodeCountOut), prefixPods(pegs, order[:n], placed[:n])
 }
 
 // analyse calls estimationAnalyserFunc(clusterSnapshot, nodeGroup, newNodesWithPods) the way Estimate does at its end
