@@ -4,17 +4,81 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <ucontext.h>
-
 #include <vector>
+
+// Fiber switch.  glibc's swapcontext saves and restores the signal mask — one rt_sigprocmask system call per switch, and a kernel under
+// the emulator switches at every ballot / reduction / barrier of every lane: a third of the CPU suite's time was spent in the kernel.
+// x86-64: the callee-saved registers, the stack pointer and the two floating-point control words, ~20 instructions in user space.
+// Anything else (or -DCASIM_EMU_UCONTEXT): ucontext as before.
+#if defined(__x86_64__) && !defined(CASIM_EMU_UCONTEXT)
+#define CASIM_EMU_ASM_SWITCH 1
+extern "C" void casim_emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .globl casim_emu_switch
+    .hidden casim_emu_switch
+    .type casim_emu_switch,@function
+casim_emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    subq $8, %rsp
+    stmxcsr (%rsp)
+    fnstcw 4(%rsp)
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    ldmxcsr (%rsp)
+    fldcw 4(%rsp)
+    addq $8, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size casim_emu_switch, .-casim_emu_switch
+)");
+#else
+#include <ucontext.h>
+#endif
 
 namespace casim_emu {
 namespace {
 
 constexpr size_t kStack = 256 * 1024;
 
+#ifdef CASIM_EMU_ASM_SWITCH
+struct Context { void* sp = nullptr; };
+inline void switch_to(Context& from, Context& to) { casim_emu_switch(&from.sp, to.sp); }
+// a fresh stack whose first switch_to "returns" into entry() (which never returns): the frame casim_emu_switch pops, top down —
+// a null return address for entry (keeps its stack pointer at 8 mod 16, as after a call), entry, rbp, rbx, r12-r15, the control words
+inline void make_context(Context& c, char* stack, size_t size, void (*entry)()) {
+    uintptr_t top = ((uintptr_t)stack + size) & ~(uintptr_t)15;
+    uint64_t* f = (uint64_t*)top;
+    f[-1] = 0;
+    f[-2] = (uint64_t)(uintptr_t)entry;
+    for (int i = 3; i <= 8; ++i) f[-i] = 0;
+    f[-9] = 0x1F80ull | (0x037Full << 32);   // MXCSR, x87 control word: the defaults
+    c.sp = (void*)(f - 9);
+}
+#else
+struct Context { ucontext_t uc; };
+inline void switch_to(Context& from, Context& to) { swapcontext(&from.uc, &to.uc); }
+inline void make_context(Context& c, char* stack, size_t size, void (*entry)()) {
+    getcontext(&c.uc);
+    c.uc.uc_stack.ss_sp = stack;
+    c.uc.uc_stack.ss_size = size;
+    c.uc.uc_link = nullptr;
+    makecontext(&c.uc, entry, 0);
+}
+#endif
+
 struct Fiber {
-    ucontext_t uc;
+    Context uc;
     FiberCtx ctx;
     char* stack = nullptr;
     bool done = false;
@@ -37,7 +101,7 @@ struct Block {
     uint64_t gen = 0;
     int live = 0;
     uint64_t events = 0;  // bumped by every completed collective / finished fiber (deadlock detection)
-    ucontext_t sched;
+    Context sched;
     const std::function<void()>* body = nullptr;
     std::vector<char> smem;
 };
@@ -47,7 +111,7 @@ Block* g_blk = nullptr;
 void yield_fiber() {
     Block& b = *g_blk;
     Fiber& f = b.fibers[b.cur];
-    swapcontext(&f.uc, &b.sched);
+    switch_to(f.uc, b.sched);
 }
 
 void trampoline() {
@@ -56,7 +120,7 @@ void trampoline() {
     b.fibers[b.cur].done = true;
     b.live--;
     b.events++;
-    swapcontext(&b.fibers[b.cur].uc, &b.sched);
+    switch_to(b.fibers[b.cur].uc, b.sched);
 }
 
 WaveState& my_wave() { return g_blk->waves[g_blk->fibers[g_blk->cur].ctx.tid >> 6]; }
@@ -173,11 +237,7 @@ void launch(int gx, int gy, int block, size_t smem, const std::function<void()>&
                 Fiber& f = blk.fibers[(size_t)i];
                 f.ctx = FiberCtx{i, bx, by, block, gx};
                 f.done = false;
-                getcontext(&f.uc);
-                f.uc.uc_stack.ss_sp = f.stack;
-                f.uc.uc_stack.ss_size = kStack;
-                f.uc.uc_link = nullptr;
-                makecontext(&f.uc, (void (*)())trampoline, 0);
+                make_context(f.uc, f.stack, kStack, trampoline);
             }
             long spins = 0;
             while (blk.live > 0) {
@@ -186,7 +246,7 @@ void launch(int gx, int gy, int block, size_t smem, const std::function<void()>&
                     if (blk.fibers[(size_t)i].done) continue;
                     blk.cur = i;
                     const uint64_t ev_before = blk.events;
-                    swapcontext(&blk.sched, &blk.fibers[(size_t)i].uc);
+                    switch_to(blk.sched, blk.fibers[(size_t)i].uc);
                     progressed |= blk.events != ev_before;
                 }
                 // a block whose threads wait forever (divergent collective) would spin here
