@@ -730,7 +730,7 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
             // register packer: one record (casim_types.h) = everything the packer needs to know about the PEG, computed HERE
             // by the record's own thread — the scaled requests, their reciprocals (the packer's quotient estimate) and how
             // many pods of the PEG fit an EMPTY node of this group (fitsRequest on the template, fit.go:681-765)
-            auto emit = [&](auto rl_tag) {   // (RL as a constant: the record is built in registers, not in a scratch array)
+            auto emit = [&](auto rl_tag, auto xw_tag) {   // (RL as a constant: the record is built in registers, not in a scratch array)
                 constexpr int RL = decltype(rl_tag)::value, DW = RL == 2 ? 8 : 16;
                 uint32_t w[DW];
 #pragma unroll
@@ -767,9 +767,17 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
                 const bool a2_ok = (flags & CASIM_KFLAG_STATIC_OK) && te_.count[g] > 0 && !(te_.gflags[ng] & CASIM_NG_UNSCHEDULABLE);
                 w[1] = (flags & (CASIM_REC_FLAG_MASK & ~(CASIM_REC_SIMPLE | CASIM_REC_A2_OK))) | (cf << CASIM_REC_FRESH_SHIFT) | (simple ? CASIM_REC_SIMPLE : 0u) |
                        (a2_ok ? CASIM_REC_A2_OK : 0u) | ((a2_ok && simple) ? CASIM_REC_A2_SIMPLE : 0u);
-                RecQuad* out = (RecQuad*)(re_.rec + (int64_t)(off + i) * DW);   // 16-byte stores (records are 32 / 64 bytes)
+                constexpr int DWOUT = decltype(xw_tag)::value ? 16 : DW;
+                RecQuad* out = (RecQuad*)(re_.rec + (int64_t)(off + i) * DWOUT);   // 16-byte stores (records are 32 / 64 bytes)
 #pragma unroll
                 for (int k = 0; k < DW / 4; ++k) out[k] = RecQuad{w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]};
+                if constexpr (decltype(xw_tag)::value) {   // DevResults::rec_xw: the PEG's node-local exclusion words ride with the record (casim_types.h)
+                    uint64_t xb[2] = {0, 0}, xm[2] = {0, 0};
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) if (q < te_.Wx) { xb[q] = te_.xblock[(int64_t)g * te_.Wx + q]; xm[q] = te_.xmark[(int64_t)g * te_.Wx + q]; }
+                    out[2] = RecQuad{(uint32_t)xb[0], (uint32_t)(xb[0] >> 32), (uint32_t)xb[1], (uint32_t)(xb[1] >> 32)};
+                    out[3] = RecQuad{(uint32_t)xm[0], (uint32_t)(xm[0] >> 32), (uint32_t)xm[1], (uint32_t)(xm[1] >> 32)};
+                }
             };
             // int64 register store: the two requests as they came (no gcd scaling), 64-bit quotient for the empty node's capacity
             auto emit64 = [&]() {
@@ -803,7 +811,7 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
 #pragma unroll
                 for (int k = 0; k < 4; ++k) out[k] = RecQuad{w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]};
             };
-            if (re_.rec_i64) emit64(); else if (re_.rec_dw == 8) emit(IntTag<2>{}); else emit(IntTag<4>{});
+            if (re_.rec_i64) emit64(); else if (re_.rec_dw == 8) emit(IntTag<2>{}, IntTag<0>{}); else if (re_.rec_xw) emit(IntTag<2>{}, IntTag<1>{}); else emit(IntTag<4>{}, IntTag<0>{});
         }
         if (re_.s_count) {   // the generic packer's three arrays (also next to the records when it stands by for retries)
             re_.s_count[off + i] = te_.count[g];

@@ -66,7 +66,10 @@ namespace casim {
 struct CsTrue { static constexpr bool value = true; };
 struct CsFalse { static constexpr bool value = false; };
 
-template <class L, int RMAX>
+// kVal: the PEG's exclusion words (and their polarity words) are VALUES of the view — the register stores, whose words live in scalar
+// registers (a view that points at local copies keeps them in scratch memory: the optimiser does not see through a pointer stored in a
+// struct) — instead of pointers into the mask tables (the memory store: any number of words)
+template <class L, int RMAX, bool kVal = false>
 struct PegView {
     L req[RMAX];
     double rq[RMAX];  // 1 / req: quotient estimate of capacity_of
@@ -79,26 +82,33 @@ struct PegView {
     uint64_t xp[2] = {0, 0};          // need words of xb (register store)
     const uint64_t* xpol = nullptr;   // [Wx] polarity words or null (memory store: need computed per word)
     bool waive = false;
+    uint64_t vb[2] = {0, 0}, vm[2] = {0, 0}, vp[2] = {0, 0};   // kVal: block / mark / polarity words
+    CS_DEVICE uint64_t bw(int w) const { if constexpr (kVal) return vb[w]; else return xblock[w]; }
+    CS_DEVICE uint64_t mw(int w) const { if constexpr (kVal) return vm[w]; else return xmark[w]; }
+    CS_DEVICE uint64_t pw(int w) const { if constexpr (kVal) return vp[w]; else return xpol[w]; }
+    CS_DEVICE bool has_pol() const { if constexpr (kVal) return true; else return xpol != nullptr; }
     CS_DEVICE uint64_t block_word(int w) const {
-        uint64_t b = xblock[w];
-        if (xpol && waive) b &= ~(xmark[w] & xpol[w]);
+        uint64_t b = bw(w);
+        if (has_pol() && waive) b &= ~(mw(w) & pw(w));
         return b;
     }
-    CS_DEVICE uint64_t need_word(int w) const { return xpol ? (block_word(w) & xpol[w]) : 0ull; }
+    CS_DEVICE uint64_t need_word(int w) const { return has_pol() ? (block_word(w) & pw(w)) : 0ull; }
 };
-template <class L, int RMAX>
+template <class L, int RMAX, bool kVal = false>
 struct FreshNode {
     L free[RMAX];  // alloc - requested by pods preloaded on the template
     int32_t slots;           // allowed pods - preloaded pods
     const uint64_t* excl;    // node bits already set on a fresh node
+    uint64_t ve[2] = {0, 0}; // kVal: the same as values (filled by pack_body)
+    CS_DEVICE uint64_t ex(int w) const { if constexpr (kVal) return ve[w]; else return excl[w]; }
 };
 
 // How many pods with request `req` fit into (free, slots), clamped to `clampk`
 // (fitsRequest, fit.go:681-765: pod count first, then every lane with req > 0 needs req <= free).
 // Quotients use one f64 multiply by the PEG's precomputed reciprocal + an exact +-1 fix-up (see
 // capacity_of in casim_kernels.h for the error bound); int64 lanes above 2^53 fall back to a division.
-template <class L, int RMAX>
-CS_DEVICE uint32_t capacity_lanes(const L* fr, int32_t slots, int R, const PegView<L, RMAX>& pv, uint32_t clampk) {
+template <class L, int RMAX, class PV /* a PegView<L, RMAX, .> */>
+CS_DEVICE uint32_t capacity_lanes(const L* fr, int32_t slots, int R, const PV& pv, uint32_t clampk) {
     if constexpr (sizeof(L) == 4) {
         // int32 lanes: straight-line code (selects, no lane-divergent branch) so that the slots of one
         // sweep interleave; the only branches are on the wave-uniform request.
@@ -163,6 +173,7 @@ struct MemStore {
     static constexpr bool kHasZone = true;
     static constexpr int kZoneWords = 0;    // group-wide exclusion words live in LDS (per-lane copies), any number
     static constexpr int kRecDw = 0;        // PEG records: three arrays, 64 records per wave-load, fields broadcast by v_readlane
+    static constexpr bool kRecWords = false;
     using Peg = PegView<int64_t, RMAX_>;
     using Fresh = FreshNode<int64_t, RMAX_>;
     int R, Wx, cap;
@@ -189,7 +200,7 @@ struct MemStore {
         for (int r = 0; r < RMAX_; ++r) if (r < R) sfree[(int64_t)r * cap + m] -= (int64_t)x * pv.req[r];
         sslots[m] -= (int32_t)x;
         snpods[m] += (int32_t)x;
-        for (int w = 0; w < Wx; ++w) sexcl[(int64_t)w * cap + m] |= pv.xmark[w];
+        for (int w = 0; w < Wx; ++w) sexcl[(int64_t)w * cap + m] |= pv.mw(w);
     }
     CS_DEVICE void commit_any(int, uint32_t, const Peg&) {}   // (register stores only)
     // some simulated node m < M carries one of the PEG's own NEED bits (block & mark & polarity): a partner of the series is placed already
@@ -197,7 +208,7 @@ struct MemStore {
         bool any = false;
         const int lane = cs::lane();
         for (int m = lane; m < M; m += 64)
-            for (int w = 0; w < Wx; ++w) any = any || (sexcl[(int64_t)w * cap + m] & pv.xblock[w] & pv.xmark[w] & pv.xpol[w]) != 0;
+            for (int w = 0; w < Wx; ++w) any = any || (sexcl[(int64_t)w * cap + m] & pv.bw(w) & pv.mw(w) & pv.pw(w)) != 0;
         return cs::ballot(any) != 0;
     }
     CS_DEVICE void create(int, int m, uint32_t x, const Peg& pv, const Fresh& fn) {
@@ -205,7 +216,7 @@ struct MemStore {
         for (int r = 0; r < RMAX_; ++r) if (r < R) sfree[(int64_t)r * cap + m] = fn.free[r] - (int64_t)x * pv.req[r];
         sslots[m] = fn.slots - (int32_t)x;
         snpods[m] = (int32_t)x;
-        for (int w = 0; w < Wx; ++w) sexcl[(int64_t)w * cap + m] = fn.excl[w] | (x > 0 ? pv.xmark[w] : 0ull);
+        for (int w = 0; w < Wx; ++w) sexcl[(int64_t)w * cap + m] = fn.ex(w) | (x > 0 ? pv.mw(w) : 0ull);
     }
     CS_DEVICE uint32_t get_c(int, int m) const { return (uint32_t)sctmp[m]; }
     CS_DEVICE void set_c(int, int m, uint32_t v) { sctmp[m] = (int32_t)v; }
@@ -232,9 +243,10 @@ struct RegStore {
     static constexpr bool X_ = WX_ > 0;
     static constexpr bool kHasZone = WX_ > 0;   // the lean instantiation (WX_ = 0) carries no exclusion state at all
     static constexpr int kZoneWords = 2;        // group-wide exclusion words are wave-uniform: up to two, in scalar registers
-    static constexpr int kRecDw = (k64 || R_ > 2) ? 16 : 8;   // PEG records: one scalar load of kRecDw dwords per PEG (casim_types.h)
-    using Peg = PegView<L_, R_>;
-    using Fresh = FreshNode<L_, R_>;
+    static constexpr bool kRecWords = !k64 && R_ == 2 && WX_ > 0;   // the PEG's node-local exclusion words ride with its record (DevResults::rec_xw)
+    static constexpr int kRecDw = (k64 || R_ > 2 || kRecWords) ? 16 : 8;   // PEG records: one scalar load of kRecDw dwords per PEG (casim_types.h)
+    using Peg = PegView<L_, R_, (WX_ > 0)>;
+    using Fresh = FreshNode<L_, R_, (WX_ > 0)>;
     L_ fr[NPT_][R_];
     uint64_t excl[NPT_][WX_ > 0 ? WX_ : 1];
     int wx = 0;   // words the batch really has (<= WX_)
@@ -250,7 +262,7 @@ struct RegStore {
 #pragma unroll
         for (int s = 0; s < NPT_; ++s)
 #pragma unroll
-            for (int w = 0; w < WX_; ++w) any = any || (w < wx && (excl[s][w] & pv.xblock[w] & pv.xmark[w] & pv.xpol[w]) != 0);
+            for (int w = 0; w < WX_; ++w) any = any || (w < wx && (excl[s][w] & pv.bw(w) & pv.mw(w) & pv.pw(w)) != 0);
         return cs::ballot(any) != 0;
     }
     int32_t slots[NPT_];
@@ -387,7 +399,7 @@ struct RegStore {
         for (int r = 0; r < R_; ++r) fr[s][r] = fn.free[r] - (L_)x * pv.req[r];
         slots[s] = fn.slots - (int32_t)x;
 #pragma unroll
-        for (int w = 0; w < WX_; ++w) excl[s][w] = (w < wx ? fn.excl[w] : 0ull) | (x > 0 ? pv.xm[w] : 0ull);   // wx <= WX_ words exist
+        for (int w = 0; w < WX_; ++w) excl[s][w] = (w < wx ? fn.ex(w) : 0ull) | (x > 0 ? pv.xm[w] : 0ull);   // wx <= WX_ words exist
     }
     CS_DEVICE uint32_t get_c(int, int) const { return 0; }   // (register store: pack_body keeps the capacities itself)
     CS_DEVICE void set_c(int, int, uint32_t) {}
@@ -451,10 +463,22 @@ CS_DEVICE void for_slots(int S, F&& f) {
         for (int s = 0; s < S; ++s) f(s);
     }
 }
+// loops over the (<= 2) exclusion words of a register store with constant indices (the words live in scalar registers: a runtime index
+// would send them through memory), over any number of words for the memory store
+template <bool kTwoStatic, class F>
+CS_DEVICE void for_words(int n, F&& f) {
+    if constexpr (kTwoStatic) { if (0 < n) f(0); if (1 < n) f(1); }
+    else { for (int w = 0; w < n; ++w) f(w); }
+}
+// one 64-bit word at a wave-uniform address, written before the kernel started: a scalar load
+CS_DEVICE uint64_t uniform_word(const uint64_t* p) {
+    const cs::Words<2> v = cs::const_load<2>((const uint32_t*)p);
+    return ((uint64_t)v.w[1] << 32) | v.w[0];
+}
 // The algorithm body, shared by every store.
 //   ReqLoader(kk, r) -> request lane r of sorted record kk (int64 original or int32 gcd-scaled)
 template <class Store, class ReqLoader>
-CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, const typename Store::Fresh& fn,
+CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, const typename Store::Fresh& fn_in,
                          uint64_t* szone /*[Wz][64] per-lane copies or null*/, ReqLoader load_req, const int64_t* sum_scale,
                          int64_t* prof_out = nullptr) {
     using L = typename Store::Lane;
@@ -480,7 +504,22 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     int32_t fast_k = fast_last ? Gn - 1 : -1;   // the PEG that takes tryFastPath, if any (pinned: one compare per PEG, not flag AND compare)
     { uint32_t fk = (uint32_t)fast_k; cs::keep_scalar(fk); fast_k = (int32_t)fk; }
     const bool group_unschedulable = ((uint32_t)gload(t.gflags, ng) & CASIM_NG_UNSCHEDULABLE) != 0;
-    const uint64_t* zvalid = t.zone_valid + (int64_t)ng * Wz;
+    const uint64_t* zvalid_p = t.zone_valid + (int64_t)ng * Wz;
+    // Register store with exclusion state: <= 2 node-local and <= 2 group-wide words, ALL of them wave-uniform.  What is constant for the
+    // group — polarity words, the bits a fresh node starts with, the valid group bits — is fetched ONCE, by scalar loads, into scalar
+    // registers, and travels as VALUES (PegView / FreshNode kVal; the accessors below).  (Read through the table pointers where they were
+    // needed, the compiler issued a VECTOR load of the same address in every lane and waited for it, several times per PEG step: 87 % of
+    // the anti-affinity packer's time on BASELINE config C4, profiles/r15c_pack_phase_profile_c4.txt.)
+    constexpr bool kRegX = Store::kNPT > 0 && Store::kHasExcl;
+    uint64_t c_xpol[2] = {0, 0}, c_zpol[2] = {0, 0}, c_zvalid[2] = {0, 0};
+    typename Store::Fresh fn = fn_in;
+    if constexpr (kRegX) {
+        for_words<true>(Wx, [&](int w) { c_xpol[w] = uniform_word(t.xpol + w); fn.ve[w] = uniform_word(fn_in.excl + w); });
+        for_words<true>(Wz, [&](int w) { c_zpol[w] = uniform_word(t.zpol + w); c_zvalid[w] = uniform_word(zvalid_p + w); });
+    }
+    auto zpol = [&](int w) -> uint64_t { if constexpr (kRegX) return c_zpol[w]; else return t.zpol[w]; };
+    auto zvalid = [&](int w) -> uint64_t { if constexpr (kRegX) return c_zvalid[w]; else return zvalid_p[w]; };
+    auto xpolw = [&](int w) -> uint64_t { if constexpr (kRegX) return c_xpol[w]; else return t.xpol[w]; };
     // group-wide exclusion state (anti-affinity on non-hostname keys): identical in every lane
     constexpr int ZR = Store::kZoneWords;
     uint64_t zreg[ZR > 0 ? ZR : 1];
@@ -492,22 +531,22 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             for (int w = 0; w < Wz; ++w) szone[w * 64 + lane] = t.init_zone[(int64_t)ng * Wz + w];
         }
     };
-    auto zone_blocked = [&](const uint64_t* zb) -> bool {
+    auto zone_blocked = [&](auto zb /* w -> block word */) -> bool {
         bool b = false;
         if constexpr (ZR > 0) {
 #pragma unroll
-            for (int w = 0; w < ZR; ++w) if (w < Wz) b |= ((zreg[w] ^ t.zpol[w]) & zb[w]) != 0;   // (a NEED bit forbids while clear)
+            for (int w = 0; w < ZR; ++w) if (w < Wz) b |= ((zreg[w] ^ zpol(w)) & zb(w)) != 0;   // (a NEED bit forbids while clear)
         } else {
-            for (int w = 0; w < Wz; ++w) b |= ((szone[w * 64 + lane] ^ t.zpol[w]) & zb[w]) != 0;
+            for (int w = 0; w < Wz; ++w) b |= ((szone[w * 64 + lane] ^ zpol(w)) & zb(w)) != 0;
         }
         return b;
     };
-    auto zone_mark = [&](const uint64_t* zm) {
+    auto zone_mark = [&](auto zm /* w -> mark word */) {
         if constexpr (ZR > 0) {
 #pragma unroll
-            for (int w = 0; w < ZR; ++w) if (w < Wz) zreg[w] |= zm[w] & zvalid[w];
+            for (int w = 0; w < ZR; ++w) if (w < Wz) zreg[w] |= zm(w) & zvalid(w);
         } else {
-            for (int w = 0; w < Wz; ++w) szone[w * 64 + lane] |= zm[w] & zvalid[w];
+            for (int w = 0; w < Wz; ++w) szone[w * 64 + lane] |= zm(w) & zvalid(w);
         }
     };
     zone_init();
@@ -669,12 +708,26 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
             bool zselfx = Store::kHasZone && (pf & CASIM_PEG_SELF_EXCL_ZONE) != 0;
             const bool static_ok = (pf & CASIM_KFLAG_STATIC_OK) != 0;
             pv.xblock = nullptr; pv.xmark = nullptr; pv.xb[0] = pv.xb[1] = 0; pv.xm[0] = pv.xm[1] = 0;
-            const uint64_t *zblock = nullptr, *zmark = nullptr;
+            const uint64_t *zblock_p = nullptr, *zmark_p = nullptr;
+            uint64_t c_zb[2] = {0, 0}, c_zm[2] = {0, 0};   // register store: the PEG's group-wide words, in scalar registers
+            auto zblock = [&](int w) -> uint64_t { if constexpr (kRegX) return c_zb[w]; else return zblock_p[w]; };
+            auto zmark = [&](int w) -> uint64_t { if constexpr (kRegX) return c_zm[w]; else return zmark_p[w]; };
             if (Wx > 0 || Wz > 0) {
                 int g;
                 if constexpr (kRecScalar) g = g_cur; else g = (int)cs::bcast_u32((uint32_t)my_g, j);
-                pv.xblock = t.xblock + (int64_t)g * Wx; pv.xmark = t.xmark + (int64_t)g * Wx;
-                zblock = t.zblock + (int64_t)g * Wz; zmark = t.zmark + (int64_t)g * Wz;
+                if constexpr (kRegX) {
+                    if constexpr (Store::kRecWords) {   // (they came with the record: casim_types.h, DevResults::rec_xw)
+                        pv.vb[0] = ((uint64_t)cur.w[9] << 32) | cur.w[8];   pv.vb[1] = ((uint64_t)cur.w[11] << 32) | cur.w[10];
+                        pv.vm[0] = ((uint64_t)cur.w[13] << 32) | cur.w[12]; pv.vm[1] = ((uint64_t)cur.w[15] << 32) | cur.w[14];
+                    } else {
+                        for_words<true>(Wx, [&](int w) { pv.vb[w] = uniform_word(t.xblock + (int64_t)g * Wx + w); pv.vm[w] = uniform_word(t.xmark + (int64_t)g * Wx + w); });
+                    }
+                    pv.vp[0] = c_xpol[0]; pv.vp[1] = c_xpol[1];
+                    for_words<true>(Wz, [&](int w) { c_zb[w] = uniform_word(t.zblock + (int64_t)g * Wz + w); c_zm[w] = uniform_word(t.zmark + (int64_t)g * Wz + w); });
+                } else {
+                    pv.xblock = t.xblock + (int64_t)g * Wx; pv.xmark = t.xmark + (int64_t)g * Wx;
+                    zblock_p = t.zblock + (int64_t)g * Wz; zmark_p = t.zmark + (int64_t)g * Wz;
+                }
                 if constexpr (Store::kHasExcl) {
                     if (Wx > 0) {
                         pv.xpol = t.xpol;
@@ -684,24 +737,24 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         // — every pod of the PEG would, one by one, but the moment one is placed the rest has to join ITS node.  So the
                         // record is walked twice: pass 0 places ONE pod with the bits waived, pass 1 the other cnt - 1 with the bits in force.
                         uint64_t own = 0;
-                        for (int w = 0; w < Wx; ++w) own |= pv.xblock[w] & pv.xmark[w] & t.xpol[w];
+                        for_words<kRegX>(Wx, [&](int w) { own |= pv.bw(w) & pv.mw(w) & xpolw(w); });
                         if (own != 0) {   // wave-uniform, rare
                             if (series_phase == 1) { series_carry = 1; cnt -= 1; }
                             else {
                                 bool partner = st.any_node_has_own_need(pv, M);
-                                for (int w = 0; w < Wx; ++w) partner = partner || (fn.excl[w] & pv.xblock[w] & pv.xmark[w] & t.xpol[w]) != 0;
+                                for_words<kRegX>(Wx, [&](int w) { partner = partner || (fn.ex(w) & pv.bw(w) & pv.mw(w) & xpolw(w)) != 0; });
                                 if (!partner) { series_first = true; series_cnt = cnt; cnt = cnt > 0 ? 1 : 0; pv.waive = true; }
                             }
                         }
                     }
                 }
                 if (Store::kNPT > 0 && Wx > 0) {   // register store: the words travel in SGPRs
-                    pv.xb[0] = pv.block_word(0); pv.xm[0] = pv.xmark[0]; pv.xp[0] = pv.need_word(0);
-                    if (Wx > 1) { pv.xb[1] = pv.block_word(1); pv.xm[1] = pv.xmark[1]; pv.xp[1] = pv.need_word(1); }
+                    pv.xb[0] = pv.block_word(0); pv.xm[0] = pv.mw(0); pv.xp[0] = pv.need_word(0);
+                    if (Wx > 1) { pv.xb[1] = pv.block_word(1); pv.xm[1] = pv.mw(1); pv.xp[1] = pv.need_word(1); }
                 }
             }
             bool zblocked = Wz > 0 && zone_blocked(zblock);
-            for (int w = 0; w < Wz; ++w) zselfx |= (zblock[w] & zmark[w] & zvalid[w] & ~t.zpol[w]) != 0;  // the PEG excludes itself group-wide (a NEED bit it sets itself is the opposite)
+            for_words<kRegX>(Wz, [&](int w) { zselfx |= (zblock(w) & zmark(w) & zvalid(w) & ~zpol(w)) != 0; });  // the PEG excludes itself group-wide (a NEED bit it sets itself is the opposite)
 
             CASIM_PROF(1);  // record broadcast + reciprocals
             int32_t placed = 0;
@@ -969,7 +1022,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 uint32_t cfresh = 0;
                 {
                     bool xb = false;
-                    for (int w = 0; w < Wx; ++w) xb |= (fn.excl[w] & pv.block_word(w)) != pv.need_word(w);   // (a NEED bit the template's own pods do not set: no partner on a fresh node)
+                    for_words<kRegX>(Wx, [&](int w) { xb |= (fn.ex(w) & pv.block_word(w)) != pv.need_word(w); });   // (a NEED bit the template's own pods do not set: no partner on a fresh node)
                     if (!xb) {
                         uint32_t cf;
                         if constexpr (kRecScalar) cf = cf_rec; else cf = cs::bcast_u32(my_cf, j);
@@ -1269,7 +1322,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, ((NPT_ == 4 && WX_ == 0) ? CASIM_FAST_WAVES : 1))
 #pragma unroll
         for (int w = 0; w < WX_; ++w) st.excl[s][w] = 0;
     }
-    FreshNode<int32_t, R_> fn;
+    typename RegStore<R_, NPT_, WX_>::Fresh fn;
 #pragma unroll
     for (int r = 0; r < R_; ++r) fn.free[r] = r < t.R ? fs.fresh32[(int64_t)ng * t.R + r] : 0;
     fn.slots = t.allowed[ng] - t.init_pods[ng];
@@ -1292,7 +1345,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(64, 1) void pack_fast64_kernel(DevTables t, DevResult
 #pragma unroll
         for (int w = 0; w < WX_; ++w) st.excl[s][w] = 0;
     }
-    FreshNode<int64_t, 2> fn;
+    typename RegStore<2, NPT_, WX_, int64_t>::Fresh fn;
 #pragma unroll
     for (int r = 0; r < 2; ++r) fn.free[r] = r < t.R ? t.alloc[(int64_t)ng * t.R + r] - t.init_req[(int64_t)ng * t.R + r] : 0;
     fn.slots = t.allowed[ng] - t.init_pods[ng];

@@ -899,7 +899,9 @@ public:
         else { ord_in_slab_ = false; dr_.order = (int32_t*)dalloc(4 * ((size_t)nnz_cap_ + 1)); dr_.placed = (int32_t*)dalloc(4 * (size_t)nnz_cap_); }
         dr_.fast_last = (uint8_t*)dalloc(NG);
         if (fast_npt_ > 0) {   // register packer: one record per PEG (casim_types.h) instead of the three arrays
-            dr_.rec_dw = (fast_r_ == 2 && !fast_i64_) ? 8 : 16;
+            // two int32 lanes next to exclusion words: the words ride with the record (DevResults::rec_xw — RegStore<2, ., 2>::kRecWords expects them)
+            dr_.rec_xw = (fast_r_ == 2 && !fast_i64_ && fast_wx_ > 0) ? 1 : 0;
+            dr_.rec_dw = (fast_r_ == 2 && !fast_i64_ && !dr_.rec_xw) ? 8 : 16;
             dr_.rec_i64 = fast_i64_ ? 1 : 0;
             dr_.rec = (uint32_t*)dalloc(4 * ((size_t)nnz_cap_ + 1) * (size_t)dr_.rec_dw);   // + one spare record: the packer loads record k + 1 unconditionally
             dr_.req32 = fs_.req32; dr_.fresh32 = fs_.fresh32;

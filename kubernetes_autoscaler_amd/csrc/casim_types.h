@@ -79,6 +79,7 @@ struct DevResults {
     uint32_t* rec;           // [nnz][rec_dw] or null
     int32_t rec_dw;          // 8 (R <= 2) or 16 (R <= 4, or the int64 record)
     int32_t rec_i64;         // 1: 16-dword records of the int64 register store (two int64 requests as they came, no gcd scaling; req32 / fresh32 null)
+    int32_t rec_xw;          // 1: 16-dword records = the 8-dword record of two int32 lanes + the PEG's node-local exclusion words (see below)
     const int32_t* req32;    // [G][R]  gcd-scaled requests (FastScratch::req32)
     const int32_t* fresh32;  // [NG][R] gcd-scaled free resources of an empty node (FastScratch::fresh32)
     // optional (casim_options.node_pods): pods per simulated node, group i at node_pods[node_pods_off[i] ..), node bound entries
@@ -100,6 +101,10 @@ struct DevResults {
 //   [2 .. 2+RL) gcd-scaled requests   [2+RL .. 2+3RL) their reciprocals as IEEE doubles (lo, hi), 0.0 for a zero request
 // int64 register store (DevResults::rec_i64, 16 dwords): [0], [1] the same; [2..5] two int64 requests (lo, hi) as the boundary carries them;
 //   [6..9] their reciprocals; [10..15] zero.  CASIM_REC_SIMPLE there means only "both lanes are requested" (no magnitude condition).
+// Two int32 lanes WITH exclusion words (DevResults::rec_xw, round 6; 16 dwords): [0..7] as the 8-dword record; [8..11] xblock[0], xblock[1]
+//   (lo, hi each), [12..15] xmark[0], xmark[1] — the PEG's row of casim_pegs.excl_block / excl_mark, zero past Wx.  Until then the packer
+//   fetched these words from the mask tables at the head of every PEG step, behind the record: dependent loads nobody had issued ahead — 87 % of
+//   the anti-affinity packer's time on BASELINE config C4 (profiles/r15c_pack_phase_profile_c4.txt).  In the record they arrive with it, a step ahead.
 // The fresh-node capacity is < 2^21 by eligibility (casim_pipeline.h: pod slots of an empty node).  Everything the packer
 // would otherwise derive per PEG with scalar compares is a bit here (the kernel is bound by SCALAR issue, r02n PMC):
 #define CASIM_REC_SIMPLE 0x80u            /* every request lane of the record is in (0, 2^30): the branch-free quotient sweep applies */

@@ -88,7 +88,7 @@ def test_order_kernel_parks_no_pointers_in_vgpr_lanes(tmp_path):
     ops = [l.strip().split()[0] for l in k if l.startswith("\t") and not l.strip().startswith((";", "."))]
     parked_reads = sum(1 for l in k if re.search(r"\tv_readlane_b32 s\d+, v\d+, \d+$", l))     # constant lane: a parked scalar coming back
     assert ops.count("v_writelane_b32") == 0 and parked_reads == 0, (ops.count("v_writelane_b32"), parked_reads)
-    assert sum(1 for o in ops if o.startswith("v_")) <= 8600     # 7 839 (10 588 with the parked pointers)
+    assert sum(1 for o in ops if o.startswith("v_")) <= 9300     # 8 652 static (7 839 before the record form that carries exclusion words was compiled in; 10 588 with the parked pointers)
     assert not any(o.startswith("scratch_") for o in ops)
 
 
