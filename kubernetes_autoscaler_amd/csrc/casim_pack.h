@@ -520,6 +520,9 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     auto zpol = [&](int w) -> uint64_t { if constexpr (kRegX) return c_zpol[w]; else return t.zpol[w]; };
     auto zvalid = [&](int w) -> uint64_t { if constexpr (kRegX) return c_zvalid[w]; else return zvalid_p[w]; };
     auto xpolw = [&](int w) -> uint64_t { if constexpr (kRegX) return c_xpol[w]; else return t.xpol[w]; };
+    // (register store: words past the batch's Wx / Wz are zeros that change no verdict — the word logic below runs over both words without
+    // asking, each `w < Wx` was a scalar compare + branch + the register moves of its merge point in every PEG step)
+    const int WxL = kRegX ? 2 : Wx;
     // group-wide exclusion state (anti-affinity on non-hostname keys): identical in every lane
     constexpr int ZR = Store::kZoneWords;
     uint64_t zreg[ZR > 0 ? ZR : 1];
@@ -723,7 +726,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         for_words<true>(Wx, [&](int w) { pv.vb[w] = uniform_word(t.xblock + (int64_t)g * Wx + w); pv.vm[w] = uniform_word(t.xmark + (int64_t)g * Wx + w); });
                     }
                     pv.vp[0] = c_xpol[0]; pv.vp[1] = c_xpol[1];
-                    for_words<true>(Wz, [&](int w) { c_zb[w] = uniform_word(t.zblock + (int64_t)g * Wz + w); c_zm[w] = uniform_word(t.zmark + (int64_t)g * Wz + w); });
+                    if (Wz > 0) for_words<true>(Wz, [&](int w) { c_zb[w] = uniform_word(t.zblock + (int64_t)g * Wz + w); c_zm[w] = uniform_word(t.zmark + (int64_t)g * Wz + w); });
                 } else {
                     pv.xblock = t.xblock + (int64_t)g * Wx; pv.xmark = t.xmark + (int64_t)g * Wx;
                     zblock_p = t.zblock + (int64_t)g * Wz; zmark_p = t.zmark + (int64_t)g * Wz;
@@ -737,12 +740,12 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                         // — every pod of the PEG would, one by one, but the moment one is placed the rest has to join ITS node.  So the
                         // record is walked twice: pass 0 places ONE pod with the bits waived, pass 1 the other cnt - 1 with the bits in force.
                         uint64_t own = 0;
-                        for_words<kRegX>(Wx, [&](int w) { own |= pv.bw(w) & pv.mw(w) & xpolw(w); });
+                        for_words<kRegX>(WxL, [&](int w) { own |= pv.bw(w) & pv.mw(w) & xpolw(w); });
                         if (own != 0) {   // wave-uniform, rare
                             if (series_phase == 1) { series_carry = 1; cnt -= 1; }
                             else {
                                 bool partner = st.any_node_has_own_need(pv, M);
-                                for_words<kRegX>(Wx, [&](int w) { partner = partner || (fn.ex(w) & pv.bw(w) & pv.mw(w) & xpolw(w)) != 0; });
+                                for_words<kRegX>(WxL, [&](int w) { partner = partner || (fn.ex(w) & pv.bw(w) & pv.mw(w) & xpolw(w)) != 0; });
                                 if (!partner) { series_first = true; series_cnt = cnt; cnt = cnt > 0 ? 1 : 0; pv.waive = true; }
                             }
                         }
@@ -750,11 +753,11 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 }
                 if (Store::kNPT > 0 && Wx > 0) {   // register store: the words travel in SGPRs
                     pv.xb[0] = pv.block_word(0); pv.xm[0] = pv.mw(0); pv.xp[0] = pv.need_word(0);
-                    if (Wx > 1) { pv.xb[1] = pv.block_word(1); pv.xm[1] = pv.mw(1); pv.xp[1] = pv.need_word(1); }
+                    if (kRegX || Wx > 1) { pv.xb[1] = pv.block_word(1); pv.xm[1] = pv.mw(1); pv.xp[1] = pv.need_word(1); }
                 }
             }
             bool zblocked = Wz > 0 && zone_blocked(zblock);
-            for_words<kRegX>(Wz, [&](int w) { zselfx |= (zblock(w) & zmark(w) & zvalid(w) & ~zpol(w)) != 0; });  // the PEG excludes itself group-wide (a NEED bit it sets itself is the opposite)
+            if (!kRegX || Wz > 0) for_words<kRegX>(kRegX ? 2 : Wz, [&](int w) { zselfx |= (zblock(w) & zmark(w) & zvalid(w) & ~zpol(w)) != 0; });  // the PEG excludes itself group-wide (a NEED bit it sets itself is the opposite)
 
             CASIM_PROF(1);  // record broadcast + reciprocals
             int32_t placed = 0;
@@ -1022,7 +1025,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 uint32_t cfresh = 0;
                 {
                     bool xb = false;
-                    for_words<kRegX>(Wx, [&](int w) { xb |= (fn.ex(w) & pv.block_word(w)) != pv.need_word(w); });   // (a NEED bit the template's own pods do not set: no partner on a fresh node)
+                    for_words<kRegX>(WxL, [&](int w) { xb |= (fn.ex(w) & pv.block_word(w)) != pv.need_word(w); });   // (a NEED bit the template's own pods do not set: no partner on a fresh node)
                     if (!xb) {
                         uint32_t cf;
                         if constexpr (kRecScalar) cf = cf_rec; else cf = cs::bcast_u32(my_cf, j);
