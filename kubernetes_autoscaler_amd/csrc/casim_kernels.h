@@ -765,16 +765,21 @@ CS_DEVICE void order_group(const DevTables& t, const DevResults& res, const Orde
                 // (RunFiltersUntilPassingNode skips Spec.Unschedulable nodes before any Filter runs, plugin_runner.go:108-110: in such a group the
                 // simulated nodes are never worth a visit — decided here, the packer tests ONE constant bit)
                 const bool a2_ok = (flags & CASIM_KFLAG_STATIC_OK) && te_.count[g] > 0 && !(te_.gflags[ng] & CASIM_NG_UNSCHEDULABLE);
+                // (a record that carries exclusion words: CASIM_REC_A2_SIMPLE also says "and every one of them is zero" — the packer's dry loop then
+                // decides such a PEG by the lean store's three compares, before any word logic: casim_pack.h, `idle`)
+                uint64_t xb[2] = {0, 0}, xm[2] = {0, 0};
+                if constexpr (decltype(xw_tag)::value) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) if (q < te_.Wx) { xb[q] = te_.xblock[(int64_t)g * te_.Wx + q]; xm[q] = te_.xmark[(int64_t)g * te_.Wx + q]; }
+                }
+                const bool wordless = (xb[0] | xb[1] | xm[0] | xm[1]) == 0ull;
                 w[1] = (flags & (CASIM_REC_FLAG_MASK & ~(CASIM_REC_SIMPLE | CASIM_REC_A2_OK))) | (cf << CASIM_REC_FRESH_SHIFT) | (simple ? CASIM_REC_SIMPLE : 0u) |
-                       (a2_ok ? CASIM_REC_A2_OK : 0u) | ((a2_ok && simple) ? CASIM_REC_A2_SIMPLE : 0u);
+                       (a2_ok ? CASIM_REC_A2_OK : 0u) | ((a2_ok && simple && wordless) ? CASIM_REC_A2_SIMPLE : 0u);
                 constexpr int DWOUT = decltype(xw_tag)::value ? 16 : DW;
                 RecQuad* out = (RecQuad*)(re_.rec + (int64_t)(off + i) * DWOUT);   // 16-byte stores (records are 32 / 64 bytes)
 #pragma unroll
                 for (int k = 0; k < DW / 4; ++k) out[k] = RecQuad{w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]};
                 if constexpr (decltype(xw_tag)::value) {   // DevResults::rec_xw: the PEG's node-local exclusion words ride with the record (casim_types.h)
-                    uint64_t xb[2] = {0, 0}, xm[2] = {0, 0};
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) if (q < te_.Wx) { xb[q] = te_.xblock[(int64_t)g * te_.Wx + q]; xm[q] = te_.xmark[(int64_t)g * te_.Wx + q]; }
                     out[2] = RecQuad{(uint32_t)xb[0], (uint32_t)(xb[0] >> 32), (uint32_t)xb[1], (uint32_t)(xb[1] >> 32)};
                     out[3] = RecQuad{(uint32_t)xm[0], (uint32_t)(xm[0] >> 32), (uint32_t)xm[1], (uint32_t)(xm[1] >> 32)};
                 }

@@ -203,6 +203,7 @@ struct MemStore {
         for (int w = 0; w < Wx; ++w) sexcl[(int64_t)w * cap + m] |= pv.mw(w);
     }
     CS_DEVICE void commit_any(int, uint32_t, const Peg&) {}   // (register stores only)
+    CS_DEVICE uint64_t fit_mask_lean(int, const Peg&) const { return ~0ull; }   // (register stores only)
     // some simulated node m < M carries one of the PEG's own NEED bits (block & mark & polarity): a partner of the series is placed already
     CS_DEVICE bool any_node_has_own_need(const Peg& pv, int M) const {
         bool any = false;
@@ -291,6 +292,13 @@ struct RegStore {
 #pragma unroll
             for (int r = 0; r < R_; ++r) if (pv.req[r] > 0) fb &= cs::ballot(fr[s][r] >= pv.req[r]);   // wave-uniform test
         }
+        return fb;
+    }
+    // the same for a PEG without exclusion words whose requests are all positive (an `idle` step of pack_body): slots and requests only
+    CS_DEVICE uint64_t fit_mask_lean(int s, const Peg& pv) const {
+        uint64_t fb = cs::ballot(slots[s] > 0);
+#pragma unroll
+        for (int r = 0; r < R_; ++r) fb &= cs::ballot(fr[s][r] >= pv.req[r]);
         return fb;
     }
     // c_j of slot s for a non-empty fit mask: cheap compares decided who fits, only now the quotient chain
@@ -706,6 +714,14 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                     pv.rq[r] = cs::bits_double(cs::bcast_u64(cs::double_bits(my_rq[r]), j));
                 }
             }
+            // Behind a dry limiter, a PEG WITHOUT exclusion words (a record that carries them says so in CASIM_REC_A2_SIMPLE: order_group) in a
+            // batch without group-wide words either fits a node by requests and pod slots alone or leaves no trace at all: the lean store's
+            // three compares, before any of the word logic below (BASELINE C4: ~70 % of all steps; it cost them ~60 scalar instructions each)
+            bool idle = false;
+            if constexpr (kDry && Store::kRecWords && Store::kNPT == 1) {
+                if ((pf & CASIM_REC_A2_SIMPLE) != 0 && Wz == 0) idle = st.fit_mask_lean(0, pv) == 0ull;
+            }
+            if (!idle) {
             const bool selfx = (pf & CASIM_PEG_SELF_EXCL_NODE) != 0;
             // (group-wide self-exclusion needs a store with zone state: the pipeline sends such batches to one)
             bool zselfx = Store::kHasZone && (pf & CASIM_PEG_SELF_EXCL_ZONE) != 0;
@@ -1181,6 +1197,7 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
                 series_skip_a2 = placed_a2 == 0;
                 series_phase = series_repeat ? 1 : 0;
             }
+            }   // (!idle)
         }
         if constexpr (kRecScalar) {   // record k + 1 into the registers record k just left (in flight across the loop edge)
             if (!(Store::kHasExcl && series_repeat)) {
