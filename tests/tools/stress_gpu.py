@@ -156,6 +156,23 @@ for seed in range(first, first + count):
             list(sh.order[:len(res.order)]) == list(res.order), f"shared PEG rows {seed}"
         bump("batch_shared_peg_rows")
         enc.close()
+    # round 6, second session: batches of small estimates on the lean register packer (existing nodes, unschedulable templates, every limiter sign)
+    # and C4-shaped batches behind a dry limiter (the anti-affinity packer's record words and its idle steps)
+    if seed % 2 == 1:
+        from harness import encode_batch, run_emu_tables, run_gpu_tables
+        from test_lean_batches_emu import _want, lean_batch
+        fast = seed % 4 == 3
+        scs = lean_batch(3_000_000 + seed, fast)
+        enc, ts, bases = encode_batch(scs)
+        res = run_emu_tables(ts, fastpath=fast)[0] if EMU else run_gpu_tables(ts, ctx, fastpath=fast)[0]
+        assert_matches_oracle(res, _want(scs, bases), f"lean batch {seed}"); bump("lean_batches")
+        enc.close()
+        scs = [Scenario(pegs=x.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, None) for g in x.groups], device_csr=True, lanes=x.lanes)
+               for x in (W.config_c4(4_000_000 + seed * 3 + k, n_groups=3, n_pegs=24 + seed % 40, pods_per_peg=1 + seed % 5, cap=2 + seed % 7) for k in range(2))]
+        enc, ts, bases = encode_batch(scs)
+        res = run_emu_tables(ts)[0] if EMU else run_gpu_tables(ts, ctx)[0]
+        assert_matches_oracle(res, _want(scs, bases), f"C4-shaped batch {seed}"); bump("c4_shaped_batches")
+        enc.close()
 print("stress OK", "(emulator)" if EMU else "(MI355X)", stats, f"{time.time() - t0:.0f} s")
 if not EMU:
     ctx.close()
