@@ -65,3 +65,21 @@ def test_the_workloads_reach_what_they_are_for():
         seen["refuses"] += any(g.max_nodes < 0 for g in w.groups)
         seen["big_peg"] += any(len(pg.pods) == 255 for pg in w.pegs)
     assert all(v >= 5 for v in seen.values()), seen
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_c4_shaped_batches_behind_a_dry_limiter(seed):
+    """The anti-affinity register packer (pack_fast_kernel<2, 1, 2>): its records carry the PEG's exclusion words (DevResults::rec_xw) and,
+    behind a dry limiter, a PEG WITHOUT words is decided by the lean store's three compares before any word logic (casim_pack.h: `idle`).
+    BASELINE config C4 in small: half of the PEGs self-anti-affine on the hostname, a tenth anti-affine to another PEG's label, limits of 2 .. 8
+    nodes — most steps run behind the dry limiter, PEGs with and without words alternate."""
+    scs = []
+    for k in range(2):
+        w = workloads.config_c4(4_100_000 + seed * 3 + k, n_groups=3, n_pegs=24 + (seed * 7) % 40, pods_per_peg=1 + seed % 5, cap=2 + seed % 7)
+        scs.append(Scenario(pegs=w.pegs, groups=[GroupSpec(g.template, g.max_nodes, g.last_index, None) for g in w.groups], device_csr=True))
+    enc, ts, bases = encode_batch(scs)
+    assert ts.dims["w_excl"] in (1, 2), ts.dims
+    res, _ = run_emu_tables(ts)
+    assert emu_lib().emu_last_packer() == 201
+    assert_matches_oracle(res, _want(scs, bases), f"C4-shaped batch {seed}")
+    enc.close()
