@@ -405,6 +405,9 @@ CS_DEVICE uint64_t wave_sum_u32_wide(uint32_t v) {
 CS_DEVICE uint64_t bcast_u64(uint64_t v, int uniform_lane) {
     return ((uint64_t)bcast_u32((uint32_t)(v >> 32), uniform_lane) << 32) | bcast_u32((uint32_t)v, uniform_lane);
 }
+// acc + k * q as two's-complement arithmetic: the request totals of an Estimate wrap past INT64_MAX (tables nobody runs, but the
+// oracle's totals wrap the same way and signed overflow itself is undefined: tests/tools/sanitize_cpu.sh found these sums)
+CS_DEVICE int64_t wrap_madd_i64(int64_t acc, int64_t k, int64_t q) { return (int64_t)((uint64_t)acc + (uint64_t)k * (uint64_t)q); }
 // bits [0, n) set; n may be <= 0 or >= 64
 CS_DEVICE uint64_t low_mask(int n) { return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1)); }
 }  // namespace cs

@@ -62,6 +62,10 @@ struct HipBackend {
         if (it != pool.end() && !it->second.empty()) { p = it->second.back(); it->second.pop_back(); pooled_bytes -= s; }
         else check(hipMalloc(&p, s), "hipMalloc");
         if (p) live[p] = s;
+        // CASIM_POISON_ALLOC=1 (tests): every block starts as 0xA5 bytes — fresh HBM pages tend to be zero and a pooled block holds the last
+        // call's similar data, so a kernel that reads what nobody wrote can go unnoticed; poisoned, it computes something else than the oracle
+        static const bool poison = getenv("CASIM_POISON_ALLOC") && atoi(getenv("CASIM_POISON_ALLOC")) != 0;
+        if (p && poison) { check(hipMemsetAsync(p, 0xA5, s, stream), "hipMemsetAsync (poison)"); check(hipStreamSynchronize(stream), "hipStreamSynchronize (poison)"); }   // (done before any stream uses the block)
         return p;
     }
     void free(void* p) {

@@ -225,7 +225,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void estimate_kernel(DevTables t, EstArgs a)
             if (owner) { v = (uint32_t)filters_verdict(m); if (v == 0) commit(m); }
             return (int)bc.pick(owner, v);
         };
-        auto account = [&]() { total_placed++; sum0 += pv.req[0]; sum1 += pv.req[1]; };
+        auto account = [&]() { total_placed++; sum0 = cs::wrap_madd_i64(sum0, 1, pv.req[0]); sum1 = cs::wrap_madd_i64(sum1, 1, pv.req[1]); };
 
         int32_t placed = 0;
         // ---- a2: tryToScheduleOnExistingNodes (:163-186): created nodes only; the first miss ends it ----
@@ -253,7 +253,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void estimate_kernel(DevTables t, EstArgs a)
             uint32_t x = 0;
             if (last_node >= 0) {
                 x = fill_node(last_node, (uint32_t)(cnt - placed));
-                placed += (int32_t)x; total_placed += (int32_t)x; sum0 += (int64_t)x * pv.req[0]; sum1 += (int64_t)x * pv.req[1];
+                placed += (int32_t)x; total_placed += (int32_t)x; sum0 = cs::wrap_madd_i64(sum0, (int64_t)x, pv.req[0]); sum1 = cs::wrap_madd_i64(sum1, (int64_t)x, pv.req[1]);
                 if (placed >= cnt) break;
                 // the next pod does not fit the newest node; if that node is still empty a fresh one would not help (:234-236)
                 if (x == 0 && bc.pick(tid == last_node % T, (uint32_t)st.snpods[last_node]) == 0) break;
@@ -267,7 +267,7 @@ CS_GLOBAL CS_LAUNCH_BOUNDS(1024, 1) void estimate_kernel(DevTables t, EstArgs a)
             cs::sync();
             x = fill_node(fresh, (uint32_t)(cnt - placed));
             if (x == 0) break;   // :257-263 the node stays, the PEG is abandoned
-            placed += (int32_t)x; total_placed += (int32_t)x; sum0 += (int64_t)x * pv.req[0]; sum1 += (int64_t)x * pv.req[1];
+            placed += (int32_t)x; total_placed += (int32_t)x; sum0 = cs::wrap_madd_i64(sum0, (int64_t)x, pv.req[0]); sum1 = cs::wrap_madd_i64(sum1, (int64_t)x, pv.req[1]);
         }
         while (!plain && placed < cnt && more) {
             bool found = false;

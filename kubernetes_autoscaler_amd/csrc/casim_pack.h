@@ -631,8 +631,8 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     auto flush_chunk = [&](int kbase) {
         if (kbase + lane < Gn) res.placed[off + kbase + lane] = my_placed;
         if constexpr (!kRecScalar) {
-            acc0 += (int64_t)my_placed * (int64_t)my_req[0];   // lanes without a record hold my_placed == 0
-            acc1 += (int64_t)my_placed * (int64_t)(RM > 1 ? my_req[1] : (L)0);
+            acc0 = cs::wrap_madd_i64(acc0, my_placed, (int64_t)my_req[0]);   // lanes without a record hold my_placed == 0
+            acc1 = cs::wrap_madd_i64(acc1, my_placed, (int64_t)(RM > 1 ? my_req[1] : (L)0));
         }
     };
     // register store: the totals grow where a PEG records what it placed — every lane the same product, on the VALU (the
@@ -641,8 +641,8 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
     // dropped it from the caches: the kernel's HBM read traffic was twice its algorithmic bytes (profiles/r03c).
     auto add_totals = [&](int32_t placed, L q0, L q1) {
         const int32_t pv_ = cs::opaque_i32(placed);   // (a VGPR copy: keeps the arithmetic off the scalar unit)
-        acc0 += (int64_t)pv_ * (int64_t)q0;
-        acc1 += (int64_t)pv_ * (int64_t)q1;
+        acc0 = cs::wrap_madd_i64(acc0, pv_, (int64_t)q0);
+        acc1 = cs::wrap_madd_i64(acc1, pv_, (int64_t)q1);
     };
     // One PEG.  kDry = the limiter has run dry (newNodesAvailable == false): a3 / a4 can never be entered again, and a PEG that
     // fits no simulated node leaves no trace at all (placed 0, my_placed already 0, lastIndex kept) — in C2 that is 60 % of
@@ -1276,8 +1276,8 @@ CS_DEVICE void pack_body(const DevTables& t, const DevResults& res, Store& st, c
         res.limiter_nodes[ng] = granted;
         res.last_index_out[ng] = last_index;
         res.status[ng] = overflow ? CASIM_NG_RETRY_INTERNAL : CASIM_NG_OK;
-        res.cpu_sum[ng] = sum0 * (sum_scale ? sum_scale[0] : 1);
-        res.mem_sum[ng] = sum1 * (sum_scale ? sum_scale[1] : 1);
+        res.cpu_sum[ng] = cs::wrap_madd_i64(0, sum0, sum_scale ? sum_scale[0] : 1);
+        res.mem_sum[ng] = cs::wrap_madd_i64(0, sum1, sum_scale ? sum_scale[1] : 1);
     }
 }
 

@@ -1086,6 +1086,10 @@ typedef struct {
     int64_t cpu_sum, mem_sum;
 } est_state;
 
+/* The request totals of an Estimate are two's-complement sums (tables whose requests add up past INT64_MAX wrap, here and in the
+ * kernels alike; signed overflow itself is undefined in C: found by tests/tools/sanitize_cpu.sh). */
+static int64_t wrap_madd(int64_t acc, int64_t k, int64_t q) { return (int64_t)((uint64_t)acc + (uint64_t)k * (uint64_t)q); }
+
 /* labelSelectorMatches(term.LabelSelector, exemplar.Labels) && key == hostname
  * binpacking_estimator.go:444-450 */
 static int peg_aa_self_hostname(const orc* o, const podspec* p) {
@@ -1128,8 +1132,8 @@ static void commit(est_state* s, int pod, int node_idx) {
     node_add_pod(o, &o->snap.v[node_idx], pod);
     o->snap.v[node_idx].new_pods++;
     s->scheduled++;
-    s->cpu_sum += o->pods.v[pod].req[0];
-    s->mem_sum += o->pods.v[pod].req[1];
+    s->cpu_sum = wrap_madd(s->cpu_sum, 1, o->pods.v[pod].req[0]);
+    s->mem_sum = wrap_madd(s->mem_sum, 1, o->pods.v[pod].req[1]);
 }
 
 /* tryToScheduleOnExistingNodes :163-186; returns index of first unscheduled pod */
@@ -1193,8 +1197,8 @@ static int try_fast_path(est_state* s, int pod, int count, int* placed) {
         /* trackScheduledPod(pods[i+k], fakeNodeName): counted, not simulated */
         s->fake_nodes++;
         s->scheduled += k; *placed += k;
-        s->cpu_sum += (int64_t)k * o->pods.v[pod].req[0];
-        s->mem_sum += (int64_t)k * o->pods.v[pod].req[1];
+        s->cpu_sum = wrap_madd(s->cpu_sum, k, o->pods.v[pod].req[0]);
+        s->mem_sum = wrap_madd(s->mem_sum, k, o->pods.v[pod].req[1]);
         i += k;
     }
     return 1;
@@ -1467,6 +1471,7 @@ int orc_simulate_node_removals(orc* o, int K, const int32_t* cand_node, const in
     for (int k = 0; k < K; ++k) removable_out[k] = 2;
     for (int i = 0; i < total; ++i) node_out[i] = -1;
     int32_t* where = malloc(sizeof(int32_t) * (size_t)(total > 0 ? total : 1));   /* current node (orig id) of every listed pod */
+    for (int i = 0; i < total; ++i) where[i] = -1;   /* (offsets that do not start at 0 leave no entry unset) */
     for (int k = 0; k < K; ++k) for (int i = pod_offsets[k]; i < pod_offsets[k + 1]; ++i) where[i] = cand_node[k];
     ivec moves, move_dest; memset(&moves, 0, sizeof moves); memset(&move_dest, 0, sizeof move_dest);   /* committed moves, in order */
     int removed = 0, counted = 0, k = 0;

@@ -46,6 +46,17 @@ casim_emu_switch:
 #include <ucontext.h>
 #endif
 
+// ThreadSanitizer (tests/tools/sanitize_cpu.sh, pass 3) has to be told about every switch of stacks: it keeps a shadow stack per fiber
+#if defined(__SANITIZE_THREAD__)
+#define CASIM_EMU_TSAN 1
+extern "C" {
+void* __tsan_get_current_fiber(void);
+void* __tsan_create_fiber(unsigned flags);
+void __tsan_destroy_fiber(void* fiber);
+void __tsan_switch_to_fiber(void* fiber, unsigned flags);
+}
+#endif
+
 namespace casim_emu {
 namespace {
 
@@ -82,6 +93,9 @@ struct Fiber {
     FiberCtx ctx;
     char* stack = nullptr;
     bool done = false;
+#ifdef CASIM_EMU_TSAN
+    void* tsan = nullptr;
+#endif
 };
 
 struct WaveState {
@@ -102,16 +116,28 @@ struct Block {
     int live = 0;
     uint64_t events = 0;  // bumped by every completed collective / finished fiber (deadlock detection)
     Context sched;
+#ifdef CASIM_EMU_TSAN
+    void* tsan_sched = nullptr;
+#endif
     const std::function<void()>* body = nullptr;
     std::vector<char> smem;
 };
 
-Block* g_blk = nullptr;
+// The block a thread is running: one per THREAD — the parts of a streamed call launch their kernels from the host pool's workers
+// (CASIM_EMU_THREADS=1: casim_streams.h with threads on, as the product runs it on the device).
+thread_local Block* g_blk = nullptr;
+
+inline void to_sched(Block& b, Fiber& f) {
+#ifdef CASIM_EMU_TSAN
+    __tsan_switch_to_fiber(b.tsan_sched, 0);
+#endif
+    switch_to(f.uc, b.sched);
+}
 
 void yield_fiber() {
     Block& b = *g_blk;
     Fiber& f = b.fibers[b.cur];
-    switch_to(f.uc, b.sched);
+    to_sched(b, f);
 }
 
 void trampoline() {
@@ -120,7 +146,7 @@ void trampoline() {
     b.fibers[b.cur].done = true;
     b.live--;
     b.events++;
-    switch_to(b.fibers[b.cur].uc, b.sched);
+    to_sched(b, b.fibers[b.cur]);
 }
 
 WaveState& my_wave() { return g_blk->waves[g_blk->fibers[g_blk->cur].ctx.tid >> 6]; }
@@ -223,6 +249,9 @@ void launch(int gx, int gy, int block, size_t smem, const std::function<void()>&
     for (int i = 0; i < block; ++i) blk.fibers[(size_t)i].stack = (char*)malloc(kStack);
     Block* prev = g_blk;
     g_blk = &blk;
+#ifdef CASIM_EMU_TSAN
+    blk.tsan_sched = __tsan_get_current_fiber();
+#endif
     for (int by = 0; by < gy; ++by) {
         for (int bx = 0; bx < gx; ++bx) {
             blk.arrived = 0; blk.gen = 0; blk.live = block;
@@ -238,6 +267,10 @@ void launch(int gx, int gy, int block, size_t smem, const std::function<void()>&
                 f.ctx = FiberCtx{i, bx, by, block, gx};
                 f.done = false;
                 make_context(f.uc, f.stack, kStack, trampoline);
+#ifdef CASIM_EMU_TSAN
+                if (f.tsan) __tsan_destroy_fiber(f.tsan);
+                f.tsan = __tsan_create_fiber(0);
+#endif
             }
             long spins = 0;
             while (blk.live > 0) {
@@ -246,6 +279,9 @@ void launch(int gx, int gy, int block, size_t smem, const std::function<void()>&
                     if (blk.fibers[(size_t)i].done) continue;
                     blk.cur = i;
                     const uint64_t ev_before = blk.events;
+#ifdef CASIM_EMU_TSAN
+                    __tsan_switch_to_fiber(blk.fibers[(size_t)i].tsan, 0);
+#endif
                     switch_to(blk.sched, blk.fibers[(size_t)i].uc);
                     progressed |= blk.events != ev_before;
                 }
@@ -259,6 +295,9 @@ void launch(int gx, int gy, int block, size_t smem, const std::function<void()>&
         }
     }
     g_blk = prev;
+#ifdef CASIM_EMU_TSAN
+    for (int i = 0; i < block; ++i) if (blk.fibers[(size_t)i].tsan) __tsan_destroy_fiber(blk.fibers[(size_t)i].tsan);
+#endif
     for (int i = 0; i < block; ++i) free(blk.fibers[(size_t)i].stack);
 }
 

@@ -14,7 +14,11 @@
 namespace {
 struct EmuBackend {
     size_t lds = 160 * 1024;
-    void* alloc(size_t b) { return calloc(1, b); }
+    // Device memory is NOT zero when a kernel first sees it (the product's backend hands out blocks of its pool again, with whatever the last
+    // call left in them): 0xA5 bytes here, as in the emulated LDS, so that a kernel that reads what nobody wrote computes something else
+    // than the oracle.  CASIM_EMU_ZERO_ALLOC=1: zeroed blocks (to tell such a read from other differences).
+    static bool zero_alloc() { static const bool z = getenv("CASIM_EMU_ZERO_ALLOC") && atoi(getenv("CASIM_EMU_ZERO_ALLOC")) != 0; return z; }
+    void* alloc(size_t b) { void* p = malloc(b ? b : 1); if (p && b) memset(p, zero_alloc() ? 0 : 0xA5, b); return p; }
     void free(void* p) { ::free(p); }
     void h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     void record_turn_event() { ++turn_records; }
@@ -155,7 +159,7 @@ EMU_API int32_t emu_last_front() { return g_last_front; }
 // packer of the last emu_estimate_batch(_query): lanes * 100 + node slots per lane (lanes 2 / 4: int32 register store, 8: two int64 lanes, 0: LDS store)
 EMU_API int32_t emu_last_packer() { return g_last_lanes; }
 
-// The batch cut into sub-batches on the lanes of one context (casim_streams.h; the emulator runs the parts one after the other):
+// The batch cut into sub-batches on the lanes of one context (casim_streams.h; the emulator runs the parts one after the other by default):
 // how casim_options.n_streams cuts the tables and puts the results back together.  parts_out: how many parts ran (1 = not cut).
 EMU_API int32_t emu_estimate_batch_streams(const casim_pegs* pegs, const casim_groups* groups, const casim_options* opts, casim_results* out,
                                            int32_t* nnz_out, int32_t* offsets_out, const casim_option_query* q, int32_t* parts_out) {
@@ -169,7 +173,10 @@ EMU_API int32_t emu_estimate_batch_streams(const casim_pegs* pegs, const casim_g
     std::vector<EmuBackend*> lanes;
     for (auto& b : bks) lanes.push_back(&b);
     SP sp(primary, lanes);
-    int32_t rc = sp.estimate(pegs, groups, opts, out, q, /*threads=*/false);
+    // CASIM_EMU_THREADS=1: the parts run as tasks of the host pool, as on the device (upload turns, list bases handed from part to part, every
+    // part fetched by its own worker) — the emulator keeps its running block per thread; default: one part after the other
+    const char* thr = getenv("CASIM_EMU_THREADS");
+    int32_t rc = sp.estimate(pegs, groups, opts, out, q, /*threads=*/thr && atoi(thr) != 0);
     if (rc == CASIM_OK && (nnz_out || offsets_out)) rc = sp.csr(nnz_out, offsets_out);
     if (rc != CASIM_OK) g_err = sp.error();
     if (parts_out) *parts_out = (int32_t)sp.n_parts();

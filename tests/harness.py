@@ -17,7 +17,7 @@ from kubernetes_autoscaler_amd.objects import Node, NodeInfo, PodEquivalenceGrou
 from oracle_driver import OracleEstimate, OracleScenario
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EMU_LIB = os.path.join(ROOT, "tests", "emu", "libcasim_emu.so")
+EMU_LIB = os.environ.get("CASIM_EMU_LIB") or os.path.join(ROOT, "tests", "emu", "libcasim_emu.so")   # override: sanitizer builds (tests/tools/sanitize_cpu.sh)
 
 
 @dataclass

@@ -8,7 +8,7 @@ from typing import Dict, List, Sequence
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "oracle", "libcasim_oracle.so")
+LIB = os.environ.get("CASIM_ORACLE_LIB") or os.path.join(ROOT, "oracle", "libcasim_oracle.so")   # override: sanitizer builds (tests/tools/sanitize_cpu.sh)
 MAX_RES = 8
 
 i32p = C.POINTER(C.c_int32)

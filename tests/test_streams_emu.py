@@ -1,7 +1,10 @@
 """casim_options.n_streams (csrc/casim_streams.h): a batch of simulations cut by simulation into sub-batches that the product runs on
 internal HIP streams of ONE context.  Here the cutting (table views, re-based candidate ranges and simulation offsets), the
 per-part expander queries and the merge of the results (group arrays, CSR offsets, PEG ids back in the whole batch's numbering)
-run under the emulator, parts one after the other: results must equal the uncut batch, for every cut."""
+run under the emulator: results must equal the uncut batch, for every cut — with the parts one after the other and with the parts as tasks
+of the host pool (CASIM_EMU_THREADS=1: casim_streams.h with `threads` on, the way the product runs a streamed call on the device — upload
+turns, list bases handed from part to part under a mutex, every part fetched by its own worker; the emulator keeps its running block per
+thread).  tests/tools/sanitize_cpu.sh runs this module under ThreadSanitizer."""
 import numpy as np
 import pytest
 
@@ -9,6 +12,14 @@ from kubernetes_autoscaler_amd import _abi, workloads
 from harness import GroupSpec, Scenario, encode_batch, run_emu_streams, run_emu_tables
 
 KINDS = [[_abi.EXPANDER_LEAST_NODES], [_abi.EXPANDER_LEAST_WASTE], [_abi.EXPANDER_MOST_PODS, _abi.EXPANDER_LEAST_NODES]]
+
+
+@pytest.fixture(autouse=True, params=["parts-in-turn", "parts-on-the-pool"])
+def parts_mode(request, monkeypatch):
+    monkeypatch.setenv("CASIM_EMU_THREADS", "1" if request.param == "parts-on-the-pool" else "0")
+    return request.param
+
+
 FIELDS = ("node_count", "pods_scheduled", "nodes_added", "limiter_nodes", "last_index_out", "status", "req_cpu_sum", "req_mem_sum", "offsets")
 
 
