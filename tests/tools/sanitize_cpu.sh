@@ -8,23 +8,28 @@
 #   pass 2  libcasim.so itself with the HOST side instrumented (hipcc -fsanitize=address,undefined: clang ignores the option for gfx950 and
 #           says so; the encoder, the C ABI's argument checks, the prefetch cache and the host pool are host code) — CASIM_LIB_PATH, clang's
 #           runtime preloaded; the tests that drive the encoder and the ABI
-#   pass 3  the host pool's self-test under gcc -fsanitize=thread (tasks in index order, nested loops, several callers)
+#   pass 3  gcc -fsanitize=thread: the host pool's self-test (tasks in index order, nested loops, several callers) and tests/test_streams_emu.py
+#           with the parts of a streamed call as tasks of the pool (CASIM_EMU_THREADS=1: upload turns, list bases under a mutex, fetch workers)
 #
 # AddressSanitizer / ThreadSanitizer reports go to $OUT/{asan,asan_host,tsan}.<pid> (one file per process that had something to say; an
 # AddressSanitizer report also ends its process, i.e. fails the run); UndefinedBehaviorSanitizer writes "runtime error" lines to stderr, so the
 # passes run with -s (no capture: pytest-xdist workers inherit stderr) into $OUT/pass{1,2}.log.  The script ends with the counts.
-# usage: tests/tools/sanitize_cpu.sh [out_dir]      (about 25 minutes on 8 cores, most of it the two instrumented builds)
+# usage: [PASSES="1 2 3"] tests/tools/sanitize_cpu.sh [out_dir]      (about 25 minutes on 8 cores for all three)
+# Do not rebuild tests/emu or oracle while a pass runs: the passes load whatever library is there.
 set -u
 ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
 OUT="${1:-/tmp/casim_sanitize}"
-B="$ROOT/build/asan"; T="$ROOT/build/tsan"
+B="$OUT/build_asan"; T="$OUT/build_tsan"   # (outside the repo: nothing of this travels to the GPU box)
 mkdir -p "$OUT" "$B/obj" "$T"
 GCC_ASAN="$(gcc -print-file-name=libasan.so)"; GCC_TSAN="$(gcc -print-file-name=libtsan.so)"
 CLANG_ASAN="$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)"
 EMU_SRC="casim_emu.cpp casim_emu_api.cpp"
 EMU_FLAGS="-O1 -g -fPIC -fvisibility=hidden -Wl,-Bsymbolic -std=c++17 -ffp-contract=off -I. -I../../include -fno-omit-frame-pointer -shared"
 cd "$ROOT"
+PASSES="${PASSES:-1 2 3}"
+has() { [[ " $PASSES " == *" $1 "* ]]; }
 
+if has 1; then
 echo "== build: emulator + oracle, gcc address + undefined =="
 (cd tests/emu && g++ $EMU_FLAGS -fsanitize=address,undefined -o "$B/libcasim_emu.so" $EMU_SRC) || exit 1
 (cd oracle && gcc -O1 -g -fPIC -std=c11 -D_GNU_SOURCE -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -shared -o "$B/libcasim_oracle.so" casim_oracle.c -lm) || exit 1
@@ -33,7 +38,9 @@ CASIM_EMU_LIB="$B/libcasim_emu.so" CASIM_ORACLE_LIB="$B/libcasim_oracle.so" LD_P
   ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:log_path=$OUT/asan" UBSAN_OPTIONS="print_stacktrace=0:halt_on_error=0" \
   python -m pytest tests -q -s -m "not gpu" -n 7 -p no:cacheprovider > "$OUT/pass1.log" 2>&1
 tail -1 "$OUT/pass1.log"
+fi
 
+if has 2; then
 echo "== build: libcasim.so, host side address + undefined (hipcc) =="
 make -s -C kubernetes_autoscaler_amd/csrc OUT="$B/libcasim.so" OBJDIR="$B/obj" \
   EXTRA="-fsanitize=address,undefined -fno-omit-frame-pointer -shared-libsan -g -Wno-option-ignored -Wno-inline-asm" > "$OUT/build_libcasim.txt" 2>&1 || { tail -5 "$OUT/build_libcasim.txt"; exit 1; }
@@ -42,7 +49,9 @@ CASIM_LIB_PATH="$B/libcasim.so" LD_PRELOAD="$CLANG_ASAN" \
   ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:log_path=$OUT/asan_host" UBSAN_OPTIONS="print_stacktrace=0:halt_on_error=0" \
   python -m pytest tests -q -s -m "not gpu" -n 7 -p no:cacheprovider > "$OUT/pass2.log" 2>&1
 tail -1 "$OUT/pass2.log"
+fi
 
+if has 3; then
 echo "== build: emulator, gcc thread =="
 (cd tests/emu && g++ $EMU_FLAGS -fsanitize=thread -o "$T/libcasim_emu.so" $EMU_SRC) || exit 1
 echo "== pass 3: host pool self-test =="
@@ -50,10 +59,17 @@ for w in 0 1 2 7 32; do
   CASIM_POOL_THREADS=$w CASIM_EMU_LIB="$T/libcasim_emu.so" LD_PRELOAD="$GCC_TSAN" TSAN_OPTIONS="log_path=$OUT/tsan:halt_on_error=0" \
     python -c "import ctypes as C, os; L = C.CDLL(os.environ['CASIM_EMU_LIB']); L.emu_pool_selftest.argtypes = [C.c_int32] * 3; r = L.emu_pool_selftest(20, 3, 8); print('workers', L.emu_pool_workers(), 'self-test', r)"
 done 2>&1 | tee "$OUT/pass3.txt"
+echo "== pass 3: the streamed call with its parts on the pool's workers, host loops cut over the pool from 16 elements up =="
+# (the cases with parts as pool tasks; the emulator tells ThreadSanitizer about its fiber switches.  test_simulations_of_very_different_sizes...
+#  launches blocks of 1 024 fibers by the thousand, a ThreadSanitizer thread state each: left out, it takes an hour)
+CASIM_HOST_GRAIN=16 CASIM_EMU_LIB="$T/libcasim_emu.so" LD_PRELOAD="$GCC_TSAN" TSAN_OPTIONS="log_path=$OUT/tsan:halt_on_error=0:report_signal_unsafe=0" \
+  python -m pytest tests/test_streams_emu.py -q -n 7 -p no:cacheprovider \
+  -k "parts-on-the-pool and (streamed_parts or validity or cannot_be_cut or take_the_link)" 2>&1 | tail -1 | tee -a "$OUT/pass3.txt"
+fi
 
 echo "== reports =="
 n=$(ls "$OUT"/asan.* "$OUT"/asan_host.* "$OUT"/tsan.* 2>/dev/null | wc -l)
 echo "AddressSanitizer / ThreadSanitizer report files: $n"
-echo "UndefinedBehaviorSanitizer lines: pass 1 $(grep -c 'runtime error' "$OUT/pass1.log"), pass 2 $(grep -c 'runtime error' "$OUT/pass2.log")"
-grep -h -o "[a-z_]*\.[a-z]*:[0-9]*:[0-9]*: runtime error: [a-z ]*" "$OUT/pass1.log" "$OUT/pass2.log" | sort | uniq -c | sort -rn | head -20
+echo "UndefinedBehaviorSanitizer lines: pass 1 $(grep -c 'runtime error' "$OUT/pass1.log" 2>/dev/null), pass 2 $(grep -c 'runtime error' "$OUT/pass2.log" 2>/dev/null)"
+grep -h -o "[a-z_]*\.[a-z]*:[0-9]*:[0-9]*: runtime error: [a-z ]*" "$OUT/pass1.log" "$OUT/pass2.log" 2>/dev/null | sort | uniq -c | sort -rn | head -20
 grep -h "ERROR: AddressSanitizer\|WARNING: ThreadSanitizer" "$OUT"/asan.* "$OUT"/asan_host.* "$OUT"/tsan.* 2>/dev/null | sed 's/^==[0-9]*==//' | sort | uniq -c | sort -rn | head -20
