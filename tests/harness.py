@@ -481,8 +481,29 @@ def run_emu_tables(ts, kinds=None, per_sim=True, valid=None, fastpath=False, lds
 
 
 def run_emu_streams(ts, n_streams, kinds=None, valid=None, generic=False, group_id_base=0, winners_only=False, chain=False, narrow_requests=False):
-    """The batch cut into sub-batches the way casim_options.n_streams does it (csrc/casim_streams.h), parts run by the emulator one
-    after the other.  Returns (BatchResult, expander dict or None, parts)."""
+    """The batch cut into sub-batches the way casim_options.n_streams does it (csrc/casim_streams.h).  Returns (BatchResult, expander
+    dict or None, parts).  The emulator runs the parts one after the other, or — CASIM_EMU_THREADS=1 — as tasks of the host pool, the way
+    the product runs them on the device; a caller that did not choose gets BOTH, compared array by array."""
+    args = (ts, n_streams, kinds, valid, generic, group_id_base, winners_only, chain, narrow_requests)
+    if os.environ.get("CASIM_EMU_THREADS") is not None:
+        return _run_emu_streams(*args)
+    first = _run_emu_streams(*args)
+    os.environ["CASIM_EMU_THREADS"] = "1"
+    try:
+        second = _run_emu_streams(*args)
+    finally:
+        del os.environ["CASIM_EMU_THREADS"]
+    (ra, ea, pa), (rb, eb, pb) = first, second
+    assert pa == pb, ("parts", pa, pb)
+    for f in ("node_count", "pods_scheduled", "nodes_added", "limiter_nodes", "last_index_out", "status", "req_cpu_sum", "req_mem_sum", "offsets", "order", "placed"):
+        assert np.array_equal(np.asarray(getattr(ra, f)), np.asarray(getattr(rb, f))), ("parts on the pool differ from parts in turn", f)
+    if ea is not None:
+        for k in ea:
+            assert np.array_equal(ea[k], eb[k]), ("parts on the pool differ from parts in turn", k)
+    return first
+
+
+def _run_emu_streams(ts, n_streams, kinds, valid, generic, group_id_base, winners_only, chain, narrow_requests):
     L = emu_lib()
     if not hasattr(L, "_streams_bound"):
         L.emu_estimate_batch_streams.restype = C.c_int32
