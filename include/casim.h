@@ -149,8 +149,8 @@ typedef struct casim_groups {
     int32_t n_groups;             /* NG */
     const int64_t* alloc;         /* [NG][R] node.Status.Allocatable per lane (types.go:527-537 SetNode)  */
     const int64_t* init_req;      /* [NG][R] requested by pods preloaded on the template (DaemonSets; node_info_utils.go:111-118) */
-    const int32_t* allowed_pods;  /* [NG] Allocatable.AllowedPodNumber                                   */
-    const int32_t* init_pods;     /* [NG] pods preloaded on the template                                 */
+    const int32_t* allowed_pods;  /* [NG] Allocatable.AllowedPodNumber, in [0, 2^30]                     */
+    const int32_t* init_pods;     /* [NG] pods preloaded on the template, in [0, 2^30]                   */
     const uint32_t* flags;        /* [NG] CASIM_NG_*                                                     */
     const uint64_t* taint_mask;   /* [NG][w_taint] NoSchedule/NoExecute taints of the template (helper/taint.go:23-27) */
     const uint64_t* label_mask;   /* [NG][w_label] label requirements the template satisfies            */
@@ -159,8 +159,8 @@ typedef struct casim_groups {
     const uint64_t* zone_valid;   /* [NG][w_zone] group bits whose topology key exists on the template: only these
                                      are ever marked (a term on a key the node lacks never matches, filtering.go:155-163) */
     const int32_t* max_nodes;     /* [NG] limiter result after getMinLimit: <0 forbid, 0 unlimited, >0 cap (threshold_based_limiter.go:34-69) */
-    const int32_t* existing_nodes;/* [NG] E: nodes already in the snapshot; they occupy list positions 0..E-1 */
-    const int32_t* last_index;    /* [NG] lastIndexOrderMapping.lastIndex on entry (scheduling_opts.go:39-63) */
+    const int32_t* existing_nodes;/* [NG] 0 <= E < 2^30: nodes already in the snapshot; they occupy list positions 0..E-1; else CASIM_ERR_INVALID */
+    const int32_t* last_index;    /* [NG] in [0, 2^30): lastIndexOrderMapping.lastIndex on entry (scheduling_opts.go:39-63); else CASIM_ERR_INVALID */
     const double* cap_cpu;        /* [NG] node.Status.Capacity cpu  AsApproximateFloat64 (fastpath chooser); may be NULL */
     const double* cap_mem;        /* [NG] node.Status.Capacity mem  AsApproximateFloat64; may be NULL    */
     const int64_t* waste_cpu;     /* [NG] node.Status.Capacity cpu MilliValue (least-waste, waste.go:85-90); may be NULL */

@@ -213,6 +213,9 @@ struct SingletonRuns {
         // a run may not cross the edge of any group's candidate range or of a consecutive stretch of an explicit list
         std::vector<uint8_t> cut((size_t)G + 2, 0);
         if (Gp->peg_offsets && Gp->peg_index) {
+            // (offsets that do not run from 0 upwards would walk this scan out of the caller's list: init reports them)
+            if (NG > 0 && Gp->peg_offsets[0] != 0) return false;
+            for (int i = 0; i < NG; ++i) if (Gp->peg_offsets[i + 1] < Gp->peg_offsets[i]) return false;
             for (int i = 0; i < NG; ++i) {
                 const int32_t a = Gp->peg_offsets[i], b = Gp->peg_offsets[i + 1];
                 for (int32_t k = a; k < b; ++k) {
@@ -337,6 +340,17 @@ public:
         if (NG > 0 && (!g->alloc || !g->init_req || !g->allowed_pods || !g->init_pods || !g->flags || !g->max_nodes ||
                        !g->existing_nodes || !g->last_index))
             return fail(CASIM_ERR_INVALID, "group table has null columns");
+        // existing_nodes is a LENGTH (the snapshot's nodes in front of the simulated ones: with the added nodes the modulus of the cyclic
+        // search, scheduling_opts.go:54-59) and last_index a list position: a negative one is a caller's bug, and a modulus of zero or less
+        // is not something to hand a kernel
+        // Both stay below 2^30, like the bound on the nodes an Estimate can add: E + added nodes and lastIndex + 1 are 32-bit sums in the kernels.
+        // Pod counts of a template are counts: negative ones (or an allowed number past 2^30) only make `allowed - init` overflow.
+        for (size_t i = 0; i < NG; ++i) {
+            if (g->existing_nodes[i] < 0 || g->last_index[i] < 0) return fail(CASIM_ERR_INVALID, "negative existing_nodes / last_index");
+            if (g->existing_nodes[i] > 0x3fffffff || g->last_index[i] > 0x3fffffff) return fail(CASIM_ERR_INVALID, "existing_nodes / last_index too large");
+            if (g->init_pods[i] < 0 || g->allowed_pods[i] < 0 || g->init_pods[i] > 0x3fffffff || g->allowed_pods[i] > 0x3fffffff)
+                return fail(CASIM_ERR_INVALID, "allowed_pods / init_pods out of range");
+        }
         if (G > 0 && ((dt_.Wt && !p->tol_mask) || (dt_.Wl && !p->sel_mask) || (dt_.Wx && (!p->excl_block || !p->excl_mark)) ||
                       (dt_.Wz && (!p->zone_block || !p->zone_mark))))
             return fail(CASIM_ERR_INVALID, "PEG mask column missing");
@@ -456,9 +470,11 @@ public:
         if (!csr_on_device_) {
             if (NG > 0 && g->peg_offsets[0] != 0) return fail(CASIM_ERR_INVALID, "peg_offsets[0] != 0");
             nnz_cap_ = NG > 0 ? g->peg_offsets[NG] : 0;
+            // (the whole offsets column first: peg_index is peg_offsets[NG] entries long, and an offset in the middle that lies past it
+            // would walk the scan below out of the caller's list before the next group's offset gave it away)
+            for (size_t i = 0; i < NG; ++i) if (g->peg_offsets[i + 1] < g->peg_offsets[i]) return fail(CASIM_ERR_INVALID, "peg_offsets not monotone");
             for (size_t i = 0; i < NG; ++i) {
                 const int32_t a = g->peg_offsets[i], b = g->peg_offsets[i + 1];
-                if (b < a) return fail(CASIM_ERR_INVALID, "peg_offsets not monotone");
                 pegs_of_group[i] = b - a;
                 for (int32_t k = a; k < b; ++k) {
                     const int32_t pg = g->peg_index[k];
