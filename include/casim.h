@@ -160,7 +160,7 @@ typedef struct casim_groups {
                                      are ever marked (a term on a key the node lacks never matches, filtering.go:155-163) */
     const int32_t* max_nodes;     /* [NG] limiter result after getMinLimit: <0 forbid, 0 unlimited, >0 cap (threshold_based_limiter.go:34-69) */
     const int32_t* existing_nodes;/* [NG] 0 <= E < 2^30: nodes already in the snapshot; they occupy list positions 0..E-1; else CASIM_ERR_INVALID */
-    const int32_t* last_index;    /* [NG] in [0, 2^30): lastIndexOrderMapping.lastIndex on entry (scheduling_opts.go:39-63); else CASIM_ERR_INVALID */
+    const int32_t* last_index;    /* [NG] in [-1, 2^30): lastIndexOrderMapping.lastIndex on entry (scheduling_opts.go:39-63; -1 = start at position 0); else CASIM_ERR_INVALID */
     const double* cap_cpu;        /* [NG] node.Status.Capacity cpu  AsApproximateFloat64 (fastpath chooser); may be NULL */
     const double* cap_mem;        /* [NG] node.Status.Capacity mem  AsApproximateFloat64; may be NULL    */
     const int64_t* waste_cpu;     /* [NG] node.Status.Capacity cpu MilliValue (least-waste, waste.go:85-90); may be NULL */

@@ -341,12 +341,14 @@ public:
                        !g->existing_nodes || !g->last_index))
             return fail(CASIM_ERR_INVALID, "group table has null columns");
         // existing_nodes is a LENGTH (the snapshot's nodes in front of the simulated ones: with the added nodes the modulus of the cyclic
-        // search, scheduling_opts.go:54-59) and last_index a list position: a negative one is a caller's bug, and a modulus of zero or less
-        // is not something to hand a kernel
+        // search, scheduling_opts.go:54-59) and last_index a list position: a negative length or a position below -1 is a caller's bug, and a
+        // modulus of zero or less is not something to hand a kernel
         // Both stay below 2^30, like the bound on the nodes an Estimate can add: E + added nodes and lastIndex + 1 are 32-bit sums in the kernels.
         // Pod counts of a template are counts: negative ones (or an allowed number past 2^30) only make `allowed - init` overflow.
         for (size_t i = 0; i < NG; ++i) {
-            if (g->existing_nodes[i] < 0 || g->last_index[i] < 0) return fail(CASIM_ERR_INVALID, "negative existing_nodes / last_index");
+            // (last_index = -1 is "start at list position 0": lastIndex + 1 is the first position tried; the reference never holds it, the packer's
+            // self-check corpus and older callers do)
+            if (g->existing_nodes[i] < 0 || g->last_index[i] < -1) return fail(CASIM_ERR_INVALID, "negative existing_nodes / last_index");
             if (g->existing_nodes[i] > 0x3fffffff || g->last_index[i] > 0x3fffffff) return fail(CASIM_ERR_INVALID, "existing_nodes / last_index too large");
             if (g->init_pods[i] < 0 || g->allowed_pods[i] < 0 || g->init_pods[i] > 0x3fffffff || g->allowed_pods[i] > 0x3fffffff)
                 return fail(CASIM_ERR_INVALID, "allowed_pods / init_pods out of range");

@@ -135,3 +135,87 @@ def test_dimensions_that_lie():
         opts = _abi.Options()
         assert L.emu_estimate_batch_query(C.byref(pegs), C.byref(g2), C.byref(opts), C.byref(st), 0, C.byref(nnz), off.ctypes.data_as(_abi.i32p), None) != 0
     enc.close()
+
+
+# ---- the callers either side of the path: casim_try_schedule_pods, casim_simulate_node_removals -------------------------------------
+def _sched_lib():
+    L = emu_lib()
+    L.emu_try_schedule_pods.restype = C.c_int32
+    L.emu_try_schedule_pods.argtypes = [C.POINTER(_abi.Pegs), C.POINTER(_abi.Groups), C.POINTER(_abi.PodSequence), C.c_int64, _abi.i32p, _abi.i32p, _abi.i32p, _abi.i32p]
+    L.emu_simulate_node_removals.restype = C.c_int32
+    L.emu_simulate_node_removals.argtypes = [C.POINTER(_abi.Pegs), C.POINTER(_abi.Groups), C.POINTER(_abi.RemovalCandidates), C.c_int64, C.POINTER(_abi.RemovalResults)]
+    return L
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_one_lying_entry_in_a_pod_sequence(seed):
+    from harness import SchedCase, sched_encode, similar_keys
+    from kubernetes_autoscaler_amd.engine import make_pod_sequence
+    gen = workloads.fuzz_pending_domains if seed % 2 else workloads.fuzz_pending
+    w = gen(95000 + seed)
+    case = SchedCase(nodes=w.nodes, pods=w.pods, hints=w.hints, acceptable=w.acceptable, break_on_failure=w.break_on_failure, last_index=w.last_index)
+    enc, pod_class = sched_encode(case)
+    L = _sched_lib()
+    rng = np.random.default_rng(seed)
+    n_nodes, n_classes, P = enc.groups.n_groups, enc.pegs.n_pegs, len(case.pods)
+
+    def run(pc, hints, last_index):
+        seq, keep = make_pod_sequence(pc, hints, case.acceptable, case.break_on_failure, 0, enc.rules, similar_keys(case.pods))
+        seq.last_index = int(last_index)
+        out = np.full(max(P, 1), -1, np.int32)
+        li, ns = C.c_int32(0), C.c_int32(0)
+        return L.emu_try_schedule_pods(C.byref(enc.pegs), C.byref(enc.groups), C.byref(seq), 0, out.ctypes.data_as(_abi.i32p), C.byref(li), C.byref(ns), None)
+    hints = None if case.hints is None else np.asarray(case.hints, np.int32)
+    assert run(pod_class, hints, case.last_index) >= 0
+    lies = EXTREMES + (n_nodes, n_nodes + 1, n_classes, n_classes + 1)
+    for _ in range(10):
+        if P:
+            pc = np.array(pod_class, np.int32); pc[int(rng.integers(0, P))] = int(rng.choice(lies))
+            assert isinstance(run(pc, hints, case.last_index), int)
+            if hints is not None:
+                h = hints.copy(); h[int(rng.integers(0, P))] = int(rng.choice(lies))
+                assert isinstance(run(pod_class, h, case.last_index), int)
+        assert isinstance(run(pod_class, hints, int(rng.choice(lies))), int)
+    enc.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_one_lying_entry_in_a_removal_loop(seed):
+    from harness import RemovalCase, removal_encode
+    from kubernetes_autoscaler_amd.engine import alloc_removal_results, make_removal_candidates
+    gen = workloads.fuzz_removals_domains if seed % 2 else workloads.fuzz_removals
+    r = gen(96000 + seed)
+    case = RemovalCase(nodes=r.nodes, candidates=r.candidates, destination=r.destination, hints=r.hints, persist=r.persist, max_removable=r.max_removable,
+                       last_index=r.last_index)
+    enc, pod_class, off = removal_encode(case)
+    L = _sched_lib()
+    rng = np.random.default_rng(seed)
+    n_nodes, n_classes, K, total = enc.groups.n_groups, enc.pegs.n_pegs, len(case.candidates), len(pod_class)
+    hints = case.flat_hints()
+
+    def run(cands, offsets, classes, h, last_index=case.last_index, max_removable=case.max_removable, ext_capacity=None):
+        st, keep = make_removal_candidates(cands, offsets, classes, h, case.destination, case.persist, 0, 0, case.flat_sticky(), ext_capacity, enc.rules)
+        st.last_index = int(last_index); st.max_removable = int(max_removable)
+        # the result arrays follow the HONEST sizes: a lying scalar must not make the library write past them either
+        honest, _ = make_removal_candidates(case.candidates, off, pod_class, hints, case.destination, case.persist, 0, 0, case.flat_sticky(),
+                                            max(int(st.ext_capacity), 0) if int(st.ext_capacity) < 10 ** 6 else None, enc.rules)
+        res, packed = alloc_removal_results(honest)
+        return L.emu_simulate_node_removals(C.byref(enc.pegs), C.byref(enc.groups), C.byref(st), 0, C.byref(res))
+    assert run(case.candidates, off, pod_class, hints) >= 0
+    lies = EXTREMES + (n_nodes, n_nodes + 1, n_classes, n_classes + 1, total, total + 1)
+    for _ in range(8):
+        if K:
+            c = np.array(case.candidates, np.int32); c[int(rng.integers(0, K))] = int(rng.choice(lies))
+            assert isinstance(run(c, off, pod_class, hints), int)
+            o = np.array(off, np.int32); o[int(rng.integers(0, K))] = int(rng.choice(lies))     # (not the last one: the lists are pod_offsets[K] long by definition)
+            assert isinstance(run(case.candidates, o, pod_class, hints), int)
+        if total:
+            pc = np.array(pod_class, np.int32); pc[int(rng.integers(0, total))] = int(rng.choice(lies))
+            assert isinstance(run(case.candidates, off, pc, hints), int)
+            if hints is not None:
+                h = np.array(hints, np.int32); h[int(rng.integers(0, total))] = int(rng.choice(lies))
+                assert isinstance(run(case.candidates, off, pod_class, h), int)
+        assert isinstance(run(case.candidates, off, pod_class, hints, last_index=int(rng.choice(lies))), int)
+        assert isinstance(run(case.candidates, off, pod_class, hints, max_removable=int(rng.choice(lies))), int)
+        assert isinstance(run(case.candidates, off, pod_class, hints, ext_capacity=int(rng.choice((-1, 0, 1, 2)))), int)
+    enc.close()
