@@ -15,7 +15,7 @@
 # AddressSanitizer / ThreadSanitizer reports go to $OUT/{asan,asan_host,tsan}.<pid> (one file per process that had something to say; an
 # AddressSanitizer report also ends its process, i.e. fails the run); UndefinedBehaviorSanitizer writes "runtime error" lines to stderr, so the
 # passes run with -s (no capture: pytest-xdist workers inherit stderr) into $OUT/pass{1,2}.log.  The script ends with the counts.
-# usage: [PASSES="1 2 3 4"] tests/tools/sanitize_cpu.sh [out_dir]      (about 30 minutes on 8 cores for all four)
+# usage: [PASSES="1 2 3 4"] tests/tools/sanitize_cpu.sh [out_dir]      (34 minutes on 8 cores for all four: profiles/r16d_sanitize_cpu.txt)
 # Do not rebuild tests/emu or oracle while a pass runs: the passes load whatever library is there.
 set -u
 ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
